@@ -1,0 +1,1375 @@
+/* TEST INFRASTRUCTURE -- CPU oracle, not part of the shipped product.
+ * See boom_oracle.h for scope, usage rules and parity status ("PINNED").
+ * All file:line citations are relative to the BOOM reference tree. */
+#define _GNU_SOURCE
+#include "boom_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BO_NEG_INF (-INFINITY)
+
+/* ====================================================================== */
+/*                                   RNG                                  */
+/* ====================================================================== */
+
+/* std::mt19937_64 (Matsumoto & Nishimura 2000; ISO C++ [rand.predef]). */
+void bo_rng_seed_mt(bo_rng *r, uint64_t seed) {
+  memset(r, 0, sizeof(*r));
+  r->kind = BO_RNG_MT;
+  r->mt[0] = seed;
+  for (int i = 1; i < 312; ++i) {
+    r->mt[i] =
+        6364136223846793005ULL * (r->mt[i - 1] ^ (r->mt[i - 1] >> 62)) + (uint64_t)i;
+  }
+  r->mti = 312;
+}
+
+static uint64_t mt_next(bo_rng *r) {
+  const uint64_t UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL;
+  const uint64_t MATRIX_A = 0xB5026F5AA96619E9ULL;
+  if (r->mti >= 312) {
+    uint64_t *mt = r->mt;
+    int i;
+    for (i = 0; i < 312 - 156; ++i) {
+      uint64_t x = (mt[i] & UM) | (mt[i + 1] & LM);
+      mt[i] = mt[i + 156] ^ (x >> 1) ^ ((x & 1ULL) ? MATRIX_A : 0ULL);
+    }
+    for (; i < 311; ++i) {
+      uint64_t x = (mt[i] & UM) | (mt[i + 1] & LM);
+      mt[i] = mt[i + (156 - 312)] ^ (x >> 1) ^ ((x & 1ULL) ? MATRIX_A : 0ULL);
+    }
+    uint64_t x = (mt[311] & UM) | (mt[0] & LM);
+    mt[311] = mt[155] ^ (x >> 1) ^ ((x & 1ULL) ? MATRIX_A : 0ULL);
+    r->mti = 0;
+  }
+  uint64_t x = r->mt[r->mti++];
+  x ^= (x >> 29) & 0x5555555555555555ULL;
+  x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+  x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+  x ^= (x >> 43);
+  return x;
+}
+
+/* Philox4x32-10, Salmon, Moraes, Dror & Shaw, "Parallel random numbers: as
+ * easy as 1, 2, 3", SC'11. */
+void bo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
+                      uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int round = 0; round < 10; ++round) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void bo_rng_seed_philox(bo_rng *r, uint64_t seed, uint32_t chain,
+                        uint32_t stream, uint64_t pos) {
+  memset(r, 0, sizeof(*r));
+  r->kind = BO_RNG_PHILOX;
+  r->seed = seed;
+  r->chain = chain;
+  r->stream = stream;
+  r->pos = pos;
+}
+
+/* RNG::operator(), distributions/rng.hpp:45.  For the MT engine this is
+ * libstdc++'s uniform_real_distribution<double>(0,1) = generate_canonical<
+ * double,53>(mt19937_64): one 64-bit draw, converted to double (round to
+ * nearest), divided by 2^64, and clamped below 1. */
+double bo_unif(bo_rng *r) {
+  if (r->kind == BO_RNG_MT) {
+    uint64_t x = mt_next(r);
+    double u = (double)x / 18446744073709551616.0;
+    if (u >= 1.0) u = nextafter(1.0, 0.0);
+    return u;
+  } else {
+    uint64_t block = r->pos >> 1;
+    uint32_t ctr[4] = {(uint32_t)block, (uint32_t)(block >> 32), r->chain,
+                       r->stream};
+    uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
+    uint32_t o[4];
+    bo_philox4x32_10(ctr, key, o);
+    int h = (int)(r->pos & 1);
+    uint64_t x = (uint64_t)o[2 * h] | ((uint64_t)o[2 * h + 1] << 32);
+    r->pos++;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+  }
+}
+
+/* seed_rng, distributions/rng.cpp:39-47: llround(u * 2^64) (the reference
+ * multiplies by double(UINT64_MAX) == 2^64), retried while <= 2.  llround
+ * overflows for u >= 0.5; on x86-64 that yields INT64_MIN, i.e. 2^63 once
+ * converted to the unsigned seed type -- restated explicitly so the oracle
+ * does not depend on undefined behaviour. */
+uint64_t bo_seed_rng(bo_rng *r) {
+  uint64_t ans = 0;
+  while (ans <= 2) {
+    double u = bo_runif(r, 0, 1) * 18446744073709551616.0;
+    if (u >= 9223372036854775808.0) {
+      ans = 0x8000000000000000ULL;
+    } else {
+      ans = (uint64_t)llround(u);
+    }
+  }
+  return ans;
+}
+
+/* Rmath::runif_mt, Bmath/runif.cpp:45-52 (no draw when a == b). */
+double bo_runif(bo_rng *r, double a, double b) {
+  if (a == b) return a;
+  return a + (b - a) * bo_unif(r);
+}
+
+/* random_int_mt, distributions/random_int.cpp:26-29 */
+int bo_random_int(bo_rng *r, int lo, int hi) {
+  double tmp = bo_runif(r, (double)lo, (double)(hi + 1));
+  return (int)floor(tmp);
+}
+
+/* shuffle, cpputil/shuffle.hpp:36-46 (in place; persistent vector) */
+void bo_shuffle(bo_rng *r, int *v, int n) {
+  if (n <= 0) return;
+  for (int i = n - 1; i > 0; --i) {
+    int other = bo_random_int(r, 0, i);
+    int tmp = v[i];
+    v[i] = v[other];
+    v[other] = tmp;
+  }
+}
+
+/* norm_rand, KINDERMAN_RAMAGE branch, Bmath/snorm.cpp:137-141, 287-340 */
+#define KR_A 2.216035867166471
+#define KR_C1 0.398942280401433
+#define KR_C2 0.180025191068563
+static double kr_g(double x) {
+  return KR_C1 * exp(-x * x / 2.0) - KR_C2 * (KR_A - x);
+}
+double bo_norm_rand(bo_rng *r) {
+  double u1, u2, u3, tt;
+  u1 = bo_unif(r);
+  if (u1 < 0.884070402298758) {
+    u2 = bo_unif(r);
+    return KR_A * (1.131131635444180 * u1 + u2 - 1);
+  }
+  if (u1 >= 0.973310954173898) { /* tail */
+    for (;;) {
+      u2 = bo_unif(r);
+      u3 = bo_unif(r);
+      tt = (KR_A * KR_A - 2 * log(u3));
+      if (u2 * u2 < (KR_A * KR_A) / tt)
+        return (u1 < 0.986655477086949) ? sqrt(tt) : -sqrt(tt);
+    }
+  }
+  if (u1 >= 0.958720824790463) { /* region 3 */
+    for (;;) {
+      u2 = bo_unif(r);
+      u3 = bo_unif(r);
+      tt = KR_A - 0.630834801921960 * fmin(u2, u3);
+      if (fmax(u2, u3) <= 0.755591531667601) return (u2 < u3) ? tt : -tt;
+      if (0.034240503750111 * fabs(u2 - u3) <= kr_g(tt))
+        return (u2 < u3) ? tt : -tt;
+    }
+  }
+  if (u1 >= 0.911312780288703) { /* region 2 */
+    for (;;) {
+      u2 = bo_unif(r);
+      u3 = bo_unif(r);
+      tt = 0.479727404222441 + 1.105473661022070 * fmin(u2, u3);
+      if (fmax(u2, u3) <= 0.872834976671790) return (u2 < u3) ? tt : -tt;
+      if (0.049264496373128 * fabs(u2 - u3) <= kr_g(tt))
+        return (u2 < u3) ? tt : -tt;
+    }
+  }
+  for (;;) { /* region 1 */
+    u2 = bo_unif(r);
+    u3 = bo_unif(r);
+    tt = 0.479727404222441 - 0.595507138015940 * fmin(u2, u3);
+    if (tt < 0.) continue;
+    if (fmax(u2, u3) <= 0.805577924423817) return (u2 < u3) ? tt : -tt;
+    if (0.053377549506886 * fabs(u2 - u3) <= kr_g(tt))
+      return (u2 < u3) ? tt : -tt;
+  }
+}
+
+/* rnorm_mt, Bmath/rnorm.cpp:55-67 (no draw when sigma == 0) */
+double bo_rnorm(bo_rng *r, double mu, double sigma) {
+  if (sigma == 0.) return mu;
+  return mu + sigma * bo_norm_rand(r);
+}
+
+/* exp_rand, Bmath/sexp.cpp:58-104 */
+double bo_exp_rand(bo_rng *r) {
+  static const double q[] = {
+      0.6931471805599453, 0.9333736875190459, 0.9888777961838675,
+      0.9984959252914960, 0.9998292811061389, 0.9999833164100727,
+      0.9999985691438767, 0.9999998906925558, 0.9999999924734159,
+      0.9999999995283275, 0.9999999999728814, 0.9999999999985598,
+      0.9999999999999289, 0.9999999999999968, 0.9999999999999999,
+      1.0000000000000000};
+  double a = 0., u, ustar, umin;
+  int i;
+  u = bo_unif(r);
+  while (u <= 0.0 || u >= 1.0) u = bo_unif(r);
+  for (;;) {
+    u += u;
+    if (u > 1.0) break;
+    a += q[0];
+  }
+  u -= 1.;
+  if (u <= q[0]) return a + u;
+  i = 0;
+  ustar = bo_unif(r);
+  umin = ustar;
+  do {
+    ustar = bo_unif(r);
+    if (ustar < umin) umin = ustar;
+    i++;
+  } while (u > q[i]);
+  return a + umin * q[0];
+}
+
+/* Rmath::rgamma_mt(rng, a, scale), Bmath/rgamma.cpp:80-259, reached through
+ * BOOM::rgamma_mt(rng, a, b) = Rmath::rgamma_mt(rng, a, 1/b)
+ * (distributions/Rmath_dist.cpp:72-74). */
+static double rgamma_scale(bo_rng *rng, double a, double scale, int *status) {
+  const double sqrt32 = 5.656854;
+  const double exp_m1 = 0.36787944117144232159;
+  const double q1 = 0.04166669, q2 = 0.02083148, q3 = 0.00801191,
+               q4 = 0.00144121, q5 = -7.388e-5, q6 = 2.4511e-4, q7 = 2.424e-4;
+  const double a1 = 0.3333333, a2 = -0.250003, a3 = 0.2000062,
+               a4 = -0.1662921, a5 = 0.1423657, a6 = -0.1367177,
+               a7 = 0.1233795;
+  double s, s2, d, q0, b, si, c;
+  double e, p, q, r, t, u, v, w, x, ret_val;
+
+  if (a < .3) {
+    /* rloggamma_small_alpha branch: not on the hot path (shape = DF/2 with
+     * DF >= n >= 2); not restated. */
+    *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+    return NAN;
+  } else if (a < 1.) { /* GS */
+    e = 1.0 + exp_m1 * a;
+    for (;;) {
+      p = e * bo_unif(rng);
+      if (p >= 1.0) {
+        x = -log((e - p) / a);
+        if (bo_exp_rand(rng) >= (1.0 - a) * log(x)) break;
+      } else {
+        x = exp(log(p) / a);
+        if (bo_exp_rand(rng) >= x) break;
+      }
+    }
+    if (x > 0) return scale * x;
+    return rgamma_scale(rng, a, scale, status);
+  }
+  /* GD, a >= 1 */
+  s2 = a - 0.5;
+  s = sqrt(s2);
+  d = sqrt32 - s * 12.0;
+  t = bo_norm_rand(rng);
+  x = s + 0.5 * t;
+  ret_val = x * x;
+  if (t >= 0.0) return scale * ret_val;
+  u = bo_unif(rng);
+  if (d * u <= t * t * t) return scale * ret_val;
+  r = 1.0 / a;
+  q0 = ((((((q7 * r + q6) * r + q5) * r + q4) * r + q3) * r + q2) * r + q1) * r;
+  if (a <= 3.686) {
+    b = 0.463 + s + 0.178 * s2;
+    si = 1.235;
+    c = 0.195 / s - 0.079 + 0.16 * s;
+  } else if (a <= 13.022) {
+    b = 1.654 + 0.0076 * s2;
+    si = 1.68 / s + 0.275;
+    c = 0.062 / s + 0.024;
+  } else {
+    b = 1.77;
+    si = 0.75;
+    c = 0.1515 / s;
+  }
+  if (x > 0.0) {
+    v = t / (s + s);
+    if (fabs(v) <= 0.25)
+      q = q0 + 0.5 * t * t *
+                   ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v +
+                    a1) * v;
+    else
+      q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log1p(v);
+    if (log(1.0 - u) <= q) return scale * ret_val;
+  }
+  for (;;) {
+    e = bo_exp_rand(rng);
+    u = bo_unif(rng);
+    u = u + u - 1.0;
+    if (u < 0.0)
+      t = b - si * e;
+    else
+      t = b + si * e;
+    if (t >= -0.71874483771719) {
+      v = t / (s + s);
+      if (fabs(v) <= 0.25)
+        q = q0 + 0.5 * t * t *
+                     ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v +
+                      a1) * v;
+      else
+        q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+      if (q > 0.0) {
+        w = expm1(q);
+        if (c * fabs(u) <= w * exp(e - 0.5 * t * t)) break;
+      }
+    }
+  }
+  x = s + 0.5 * t;
+  return scale * x * x;
+}
+
+double bo_rgamma(bo_rng *r, double a, double b, int *status) {
+  return rgamma_scale(r, a, 1.0 / b, status);
+}
+
+/* rtrun_gamma_mt, distributions/trun_gamma.cpp:73-106.  Only the rejection
+ * branch (cut < mode) is restated; the adaptive-rejection and slice branches
+ * set *status. */
+double bo_rtrun_gamma(bo_rng *r, double a, double b, double cut, int *status) {
+  double mode = (a - 1) / b;
+  double x = cut;
+  if (cut < mode) {
+    do {
+      x = bo_rgamma(r, a, b, status);
+      if (*status) return NAN;
+    } while (x < cut);
+    return x;
+  }
+  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  return NAN;
+}
+
+/* rmulti_mt_impl, distributions/rmulti.cpp:41-78 (probsum by plain sum; the
+ * reference switches to an abs-norm for n > 35, equal for non-negative prob) */
+int bo_rmulti(bo_rng *r, const double *prob, int n, int *status) {
+  double probsum = 0;
+  for (int i = 0; i < n; ++i) probsum += prob[i];
+  if (!isfinite(probsum) || probsum <= 0) {
+    *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+    return 0;
+  }
+  double tmp = bo_runif(r, 0, probsum);
+  double psum = 0;
+  for (int i = 0; i < n; ++i) {
+    psum += prob[i];
+    if (tmp <= psum) return i;
+  }
+  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  return 0;
+}
+
+/* ====================================================================== */
+/*                                 LinAlg                                 */
+/* ====================================================================== */
+#define IDX(i, j, n) ((size_t)(j) * (size_t)(n) + (size_t)(i))
+
+/* Cholesky::decompose -> Eigen::LLT (LinAlg/Cholesky.cpp:33-58; the unblocked
+ * left-looking kernel, Eigen/src/Cholesky/LLT.h:313-335).  Reads the lower
+ * triangle of A; L is full storage with the strict upper triangle zeroed.
+ * A non-positive pivot means "not positive definite" (the LDLT fallback in the
+ * reference leaves pos_def_ false, so callers see the same thing). */
+int bo_chol(int n, const double *A, double *L) {
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) L[IDX(i, j, n)] = (i >= j) ? A[IDX(i, j, n)] : 0.0;
+  for (int k = 0; k < n; ++k) {
+    double x = L[IDX(k, k, n)];
+    for (int j = 0; j < k; ++j) x -= L[IDX(k, j, n)] * L[IDX(k, j, n)];
+    if (!(x > 0.0)) return 0;
+    x = sqrt(x);
+    L[IDX(k, k, n)] = x;
+    for (int i = k + 1; i < n; ++i) {
+      double s = L[IDX(i, k, n)];
+      for (int j = 0; j < k; ++j) s -= L[IDX(i, j, n)] * L[IDX(k, j, n)];
+      L[IDX(i, k, n)] = s / x;
+    }
+  }
+  return 1;
+}
+
+/* SpdMatrix::logdet(bool&), LinAlg/SpdMatrix.cpp:261-299 */
+double bo_spd_logdet(int n, const double *A, int *ok) {
+  *ok = 1;
+  if (n == 0) return BO_NEG_INF;
+  if (n == 1) {
+    if (A[0] <= 0) {
+      *ok = 0;
+      return BO_NEG_INF;
+    }
+    return log(A[0]);
+  }
+  if (n == 2) {
+    double det = A[0] * A[3] - A[2] * A[2];
+    if (det <= 0) {
+      *ok = 0;
+      return BO_NEG_INF;
+    }
+    return log(det);
+  }
+  double *L = (double *)malloc(sizeof(double) * (size_t)n * n);
+  if (!bo_chol(n, A, L)) {
+    free(L);
+    *ok = 0;
+    return BO_NEG_INF;
+  }
+  double ans = 0.0;
+  for (int i = 0; i < n; ++i) ans += log(L[IDX(i, i, n)]);
+  ans *= 2;
+  free(L);
+  return ans;
+}
+
+static void lsolve_inplace(int n, const double *L, double *x) {
+  for (int i = 0; i < n; ++i) {
+    double s = x[i];
+    for (int j = 0; j < i; ++j) s -= L[IDX(i, j, n)] * x[j];
+    x[i] = s / L[IDX(i, i, n)];
+  }
+}
+static void ltsolve_inplace(int n, const double *L, double *x) {
+  for (int i = n - 1; i >= 0; --i) {
+    double s = x[i];
+    for (int j = i + 1; j < n; ++j) s -= L[IDX(j, i, n)] * x[j];
+    x[i] = s / L[IDX(i, i, n)];
+  }
+}
+
+/* SpdMatrix::solve(Vector, bool&), LinAlg/SpdMatrix.cpp:330-341 */
+int bo_spd_solve(int n, const double *A, const double *rhs, double *x) {
+  double *L = (double *)malloc(sizeof(double) * (size_t)n * n);
+  if (!bo_chol(n, A, L)) {
+    free(L);
+    for (int i = 0; i < n; ++i) x[i] = BO_NEG_INF;
+    return 0;
+  }
+  memcpy(x, rhs, sizeof(double) * n);
+  lsolve_inplace(n, L, x);
+  ltsolve_inplace(n, L, x);
+  free(L);
+  return 1;
+}
+
+/* SpdMatrix::Mdist(x), LinAlg/SpdMatrix.cpp:363-378 */
+double bo_spd_mdist(int n, const double *A, const double *x) {
+  double ans = 0;
+  for (int j = 0; j < n; ++j) {
+    ans += x[j] * x[j] * A[IDX(j, j, n)];
+    for (int i = j + 1; i < n; ++i) ans += 2 * x[j] * x[i] * A[IDX(i, j, n)];
+  }
+  return ans;
+}
+
+/* NeRegSuf(X, y), Models/Glm/RegressionModel.cpp:309-328 */
+void bo_neregsuf(int n, int p, const double *X, const double *y, double *xtx,
+                 double *xty, double *yty, double *sumy, double *xsum) {
+  double q = 0, sy = 0;
+  for (int i = 0; i < n; ++i) {
+    q += y[i] * y[i];
+    sy += y[i];
+  }
+  *yty = q;
+  *sumy = sy;
+  for (int j = 0; j < p; ++j) {
+    const double *xj = X + (size_t)j * n;
+    double s = 0, t = 0;
+    for (int i = 0; i < n; ++i) {
+      s += xj[i];
+      t += xj[i] * y[i];
+    }
+    xsum[j] = s;
+    xty[j] = t;
+    for (int k = 0; k <= j; ++k) {
+      const double *xk = X + (size_t)k * n;
+      double d = 0;
+      for (int i = 0; i < n; ++i) d += xj[i] * xk[i];
+      xtx[IDX(j, k, p)] = d;
+      xtx[IDX(k, j, p)] = d;
+    }
+  }
+}
+
+/* ====================================================================== */
+/*                                  SSVS                                  */
+/* ====================================================================== */
+struct bo_ssvs {
+  int p;
+  /* sufficient statistics (NeRegSuf, RegressionModel.hpp:156-231) */
+  double *xtx, *xty, yty, n, sumy, *xsum;
+  /* priors */
+  double *b, *ominv;     /* slab: MvnGivenScalarSigma (b, Omega^{-1}) */
+  double prior_df, prior_ss; /* 2*alpha, 2*beta of the ChisqModel */
+  double *pi, *logpi, *logcpi;
+  int64_t max_model_size;
+  double sigma_max;
+  double swap_threshold;
+  int max_nflips, draw_beta, draw_sigma;
+  /* state */
+  uint8_t *gamma;
+  double *beta, sigsq;
+  int *indx; /* persistent permutation, BregVsSampler.hpp:219 */
+  bo_rng rng;
+  /* mutable workspace members (BregVsSampler.hpp:238-240) */
+  int k;          /* size of posterior_mean_ / V */
+  double *pm;     /* posterior_mean_ */
+  double *V;      /* unscaled_posterior_precision_ (k x k) */
+  double DF, SS;
+  int failure_count;
+  /* CorrelationMap (CorrelationMap.cpp:41-59) */
+  int cm_filled;
+  int *cm_start; /* p+1 */
+  int *cm_idx;
+  double *cm_cor;
+  /* scratch */
+  int *g;
+  double *w1, *w2, *w3, *M1, *M2;
+  double min_margin;
+};
+
+static void *xcalloc(size_t n, size_t sz) {
+  void *p = calloc(n ? n : 1, sz);
+  if (!p) abort();
+  return p;
+}
+
+bo_ssvs *bo_ssvs_create(int p, const double *xtx, const double *xty,
+                        double yty, double n, double sumy, const double *xsum,
+                        const double *prior_mean, const double *ominv,
+                        double prior_df, double sigma_guess, const double *pi) {
+  bo_ssvs *s = (bo_ssvs *)xcalloc(1, sizeof(bo_ssvs));
+  size_t pp = (size_t)p * p;
+  s->p = p;
+  s->xtx = (double *)xcalloc(pp, sizeof(double));
+  s->xty = (double *)xcalloc(p, sizeof(double));
+  s->xsum = (double *)xcalloc(p, sizeof(double));
+  s->b = (double *)xcalloc(p, sizeof(double));
+  s->ominv = (double *)xcalloc(pp, sizeof(double));
+  s->pi = (double *)xcalloc(p, sizeof(double));
+  s->logpi = (double *)xcalloc(p, sizeof(double));
+  s->logcpi = (double *)xcalloc(p, sizeof(double));
+  memcpy(s->xtx, xtx, pp * sizeof(double));
+  memcpy(s->xty, xty, p * sizeof(double));
+  memcpy(s->xsum, xsum, p * sizeof(double));
+  memcpy(s->b, prior_mean, p * sizeof(double));
+  memcpy(s->ominv, ominv, pp * sizeof(double));
+  memcpy(s->pi, pi, p * sizeof(double));
+  s->yty = yty;
+  s->n = n;
+  s->sumy = sumy;
+  /* ChisqModel(df, sigma): alpha = df/2, beta = df*sigma^2/2
+   * (ChisqModel.cpp:56-57); prior_df = 2 alpha, prior_ss = 2 beta
+   * (BregVsSampler.cpp:211-214). */
+  double alpha = prior_df / 2.0;
+  double beta = prior_df * sigma_guess * sigma_guess / 2.0;
+  s->prior_df = 2 * alpha;
+  s->prior_ss = 2 * beta;
+  /* VariableSelectionPrior::ensure_log_probabilities,
+   * VariableSelectionPrior.cpp:310-317 */
+  for (int j = 0; j < p; ++j) {
+    s->logpi[j] = log(pi[j]);
+    s->logcpi[j] = log(1 - pi[j]);
+  }
+  s->max_model_size = -1;
+  s->sigma_max = INFINITY;
+  s->swap_threshold = 0.8; /* CorrelationMap.hpp:37 */
+  s->max_nflips = p;
+  s->draw_beta = 1;
+  s->draw_sigma = 1;
+  s->gamma = (uint8_t *)xcalloc(p, 1);
+  s->beta = (double *)xcalloc(p, sizeof(double));
+  s->sigsq = 1.0;
+  s->indx = (int *)xcalloc(p, sizeof(int));
+  for (int j = 0; j < p; ++j) s->indx[j] = j;
+  s->pm = (double *)xcalloc(p, sizeof(double));
+  s->V = (double *)xcalloc(pp, sizeof(double));
+  s->DF = BO_NEG_INF;
+  s->SS = BO_NEG_INF;
+  s->g = (int *)xcalloc(p, sizeof(int));
+  s->w1 = (double *)xcalloc(p, sizeof(double));
+  s->w2 = (double *)xcalloc(p, sizeof(double));
+  s->w3 = (double *)xcalloc(p, sizeof(double));
+  s->M1 = (double *)xcalloc(pp, sizeof(double));
+  s->M2 = (double *)xcalloc(pp, sizeof(double));
+  s->min_margin = INFINITY;
+  bo_rng_seed_philox(&s->rng, 0, 0, 0, 0);
+  return s;
+}
+
+void bo_ssvs_destroy(bo_ssvs *s) {
+  if (!s) return;
+  free(s->xtx); free(s->xty); free(s->xsum); free(s->b); free(s->ominv);
+  free(s->pi); free(s->logpi); free(s->logcpi); free(s->gamma); free(s->beta);
+  free(s->indx); free(s->pm); free(s->V); free(s->cm_start); free(s->cm_idx);
+  free(s->cm_cor); free(s->g); free(s->w1); free(s->w2); free(s->w3);
+  free(s->M1); free(s->M2);
+  free(s);
+}
+
+void bo_ssvs_set_options(bo_ssvs *s, int64_t max_model_size,
+                         double sigma_upper_limit, double swap_threshold,
+                         int max_flips, int draw_beta, int draw_sigma) {
+  s->max_model_size = max_model_size;
+  s->sigma_max = sigma_upper_limit;
+  if (swap_threshold != s->swap_threshold) s->cm_filled = 0;
+  s->swap_threshold = swap_threshold;
+  s->max_nflips = max_flips < 0 ? s->p : max_flips;
+  s->draw_beta = draw_beta;
+  s->draw_sigma = draw_sigma;
+}
+
+void bo_ssvs_set_state(bo_ssvs *s, const uint8_t *gamma, const double *beta,
+                       double sigsq) {
+  memcpy(s->gamma, gamma, s->p);
+  if (beta) memcpy(s->beta, beta, sizeof(double) * s->p);
+  s->sigsq = sigsq;
+}
+void bo_ssvs_get_state(const bo_ssvs *s, uint8_t *gamma, double *beta,
+                       double *sigsq) {
+  if (gamma) memcpy(gamma, s->gamma, s->p);
+  if (beta) memcpy(beta, s->beta, sizeof(double) * s->p);
+  if (sigsq) *sigsq = s->sigsq;
+}
+void bo_ssvs_get_perm(const bo_ssvs *s, int *perm) {
+  memcpy(perm, s->indx, sizeof(int) * s->p);
+}
+bo_rng *bo_ssvs_rng(bo_ssvs *s) { return &s->rng; }
+double bo_ssvs_min_margin(const bo_ssvs *s) { return s->min_margin; }
+
+void bo_ssvs_set_suf(bo_ssvs *s, const double *xty, double yty, double n,
+                     double sumy, const double *xsum) {
+  memcpy(s->xty, xty, sizeof(double) * s->p);
+  memcpy(s->xsum, xsum, sizeof(double) * s->p);
+  s->yty = yty;
+  s->n = n;
+  s->sumy = sumy;
+}
+
+/* VariableSelectionPrior::logp, VariableSelectionPrior.cpp:271-285 */
+static double spike_logp(const bo_ssvs *s, const uint8_t *g, int nvars) {
+  if (s->max_model_size >= 0 && nvars > s->max_model_size) return BO_NEG_INF;
+  double ans = 0;
+  for (int i = 0; i < s->p; ++i) {
+    ans += g[i] ? s->logpi[i] : s->logcpi[i];
+    if (!isfinite(ans)) return BO_NEG_INF;
+  }
+  return ans;
+}
+
+static int gather_index(const bo_ssvs *s, const uint8_t *g, int *idx) {
+  int k = 0;
+  for (int j = 0; j < s->p; ++j)
+    if (g[j]) idx[k++] = j;
+  return k;
+}
+
+/* Selector::select(SpdMatrix), LinAlg/Selector.cpp:411-426 */
+static void select_spd(const double *A, int p, const int *idx, int k,
+                       double *out) {
+  for (int c = 0; c < k; ++c)
+    for (int r = 0; r < k; ++r) out[IDX(r, c, k)] = A[IDX(idx[r], idx[c], p)];
+}
+
+/* BregVsSampler::set_reg_post_params, BregVsSampler.cpp:395-484.
+ * Returns ldoi (or -inf when V is not positive definite); *status is set on
+ * the error exits that throw in the reference. */
+static double set_reg_post_params(bo_ssvs *s, const uint8_t *g, int do_ldoi,
+                                  int *status) {
+  int *idx = s->g;
+  int k = gather_index(s, g, idx);
+  if (k == 0) return 0;
+  double *prior_mean = s->w1;
+  double *xty = s->w2;
+  double *A = s->M1; /* unscaled prior precision, selected */
+  double *S = s->M2; /* xtx, selected */
+  for (int i = 0; i < k; ++i) prior_mean[i] = s->b[idx[i]];
+  select_spd(s->ominv, s->p, idx, k, A);
+  int ok = 1;
+  double ldoi = do_ldoi ? bo_spd_logdet(k, A, &ok) : 0.0;
+  select_spd(s->xtx, s->p, idx, k, S);
+  for (int i = 0; i < k; ++i) xty[i] = s->xty[idx[i]];
+  s->k = k;
+  for (size_t i = 0; i < (size_t)k * k; ++i) s->V[i] = A[i] + S[i];
+  /* posterior_mean_ = A * prior_mean + xty */
+  double *rhs = s->w3;
+  for (int i = 0; i < k; ++i) {
+    double acc = 0;
+    for (int j = 0; j < k; ++j) acc += A[IDX(i, j, k)] * prior_mean[j];
+    rhs[i] = acc + xty[i];
+  }
+  int pd = bo_spd_solve(k, s->V, rhs, s->pm);
+  if (!pd) {
+    for (int i = 0; i < k; ++i) s->pm[i] = 0;
+    return BO_NEG_INF;
+  }
+  s->DF = s->n + s->prior_df;
+  s->SS = s->prior_ss;
+  if (!isfinite(s->SS)) {
+    *status = BO_ERR_NEGATIVE_SS;
+    return ldoi;
+  }
+  double dot = 0;
+  for (int i = 0; i < k; ++i) dot += s->pm[i] * xty[i];
+  double likelihood_ss = s->yty - 2 * dot + bo_spd_mdist(k, S, s->pm);
+  s->SS += likelihood_ss;
+  if (!isfinite(s->SS)) {
+    *status = BO_ERR_NEGATIVE_SS;
+    return ldoi;
+  }
+  double *diff = s->w3;
+  for (int i = 0; i < k; ++i) diff[i] = s->pm[i] - prior_mean[i];
+  double prior_mismatch_ss = bo_spd_mdist(k, A, diff);
+  s->SS += prior_mismatch_ss;
+  if (s->SS < 0 || !isfinite(s->SS)) {
+    *status = BO_ERR_NEGATIVE_SS;
+  }
+  return ldoi;
+}
+
+/* BregVsSampler::log_model_prob, BregVsSampler.cpp:216-239 */
+static double log_model_prob(bo_ssvs *s, const uint8_t *g, int *status) {
+  int nvars = 0;
+  for (int j = 0; j < s->p; ++j) nvars += g[j] ? 1 : 0;
+  if (nvars == 0) {
+    double ss = s->yty + s->prior_ss;
+    double df = s->n + s->prior_df;
+    return spike_logp(s, g, 0) - (.5 * df - 1) * log(ss);
+  }
+  double ans = spike_logp(s, g, nvars);
+  if (ans == BO_NEG_INF) return ans;
+  double ldoi = set_reg_post_params(s, g, 1, status);
+  if (*status) return BO_NEG_INF;
+  if (ldoi <= BO_NEG_INF) return BO_NEG_INF;
+  int ok = 1;
+  ans += .5 * (ldoi - bo_spd_logdet(s->k, s->V, &ok));
+  ans -= (.5 * s->DF - 1) * log(s->SS);
+  return ans;
+}
+
+double bo_ssvs_log_model_prob(bo_ssvs *s, const uint8_t *gamma, int *status) {
+  *status = 0;
+  return log_model_prob(s, gamma, status);
+}
+
+/* BregVsSampler::mcmc_one_flip, BregVsSampler.cpp:241-250 */
+static double mcmc_one_flip(bo_ssvs *s, uint8_t *g, int which, double logp_old,
+                            int *status) {
+  g[which] = !g[which];
+  double logp_new = log_model_prob(s, g, status);
+  if (*status) return logp_old;
+  double u = bo_runif(&s->rng, 0, 1);
+  double lu = log(u), delta = logp_new - logp_old;
+  double margin = fabs(lu - delta);
+  if (margin < s->min_margin) s->min_margin = margin;
+  if (lu > delta) {
+    g[which] = !g[which];
+    return logp_old;
+  }
+  return logp_new;
+}
+
+/* CorrelationMap::fill, CorrelationMap.cpp:41-59, on RegSuf::centered_xtx
+ * (RegressionModel.cpp:53-57). */
+static void correlation_map_fill(bo_ssvs *s) {
+  int p = s->p;
+  free(s->cm_start); free(s->cm_idx); free(s->cm_cor);
+  s->cm_start = (int *)xcalloc(p + 1, sizeof(int));
+  double *sd = (double *)xcalloc(p, sizeof(double));
+  double n = s->n;
+  #define COV(i, j) ((s->xtx[IDX(i, j, p)] + (-n) * (s->xsum[i] / n) * (s->xsum[j] / n)) / (n - 1))
+  for (int i = 0; i < p; ++i) {
+    double v = COV(i, i);
+    sd[i] = sqrt(v);
+    if (!(sd[i] > 0.0)) sd[i] = 1.0;
+  }
+  int count = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    count = 0;
+    for (int i = 0; i < p; ++i) {
+      if (pass == 1) s->cm_start[i] = count;
+      for (int j = 0; j < p; ++j) {
+        if (j == i) continue;
+        double c = fabs(COV(i, j) / (sd[i] * sd[j]));
+        if (c >= s->swap_threshold) {
+          if (pass == 1) {
+            s->cm_idx[count] = j;
+            s->cm_cor[count] = c;
+          }
+          ++count;
+        }
+      }
+    }
+    if (pass == 0) {
+      s->cm_idx = (int *)xcalloc(count, sizeof(int));
+      s->cm_cor = (double *)xcalloc(count, sizeof(double));
+    }
+  }
+  s->cm_start[p] = count;
+  #undef COV
+  free(sd);
+  s->cm_filled = 1;
+}
+
+/* BregVsSampler::attempt_swap, BregVsSampler.cpp:277-310, with
+ * CorrelationMap::propose_swap / proposal_weight (CorrelationMap.cpp:61-115)
+ * and Selector::random_included_position (LinAlg/Selector.cpp:297-304). */
+static void attempt_swap(bo_ssvs *s, int *status) {
+  if (s->swap_threshold >= 1.0) return;
+  if (!s->cm_filled) correlation_map_fill(s);
+  int p = s->p;
+  uint8_t *included = (uint8_t *)malloc(p);
+  memcpy(included, s->gamma, p);
+  int nvars = 0;
+  for (int j = 0; j < p; ++j) nvars += included[j];
+  if (nvars == 0 || nvars == p) {
+    free(included);
+    return;
+  }
+  int pos = bo_random_int(&s->rng, 0, nvars - 1);
+  int index = -1;
+  for (int j = 0, c = 0; j < p; ++j) {
+    if (included[j]) {
+      if (c == pos) { index = j; break; }
+      ++c;
+    }
+  }
+  /* propose_swap */
+  int lo = s->cm_start[index], hi = s->cm_start[index + 1];
+  if (lo == hi) { free(included); return; }
+  int ncand = 0;
+  int *swaps = (int *)malloc(sizeof(int) * (hi - lo));
+  double *weights = (double *)malloc(sizeof(double) * (hi - lo));
+  double total = 0;
+  for (int i = lo; i < hi; ++i) {
+    if (!included[s->cm_idx[i]]) {
+      swaps[ncand] = s->cm_idx[i];
+      weights[ncand] = s->cm_cor[i];
+      total += weights[ncand];
+      ++ncand;
+    }
+  }
+  if (total == 0) { free(swaps); free(weights); free(included); return; }
+  for (int i = 0; i < ncand; ++i) weights[i] /= total;
+  int which = bo_rmulti(&s->rng, weights, ncand, status);
+  double forward_w = weights[which];
+  int candidate = swaps[which];
+  free(swaps); free(weights);
+  if (*status) { free(included); return; }
+
+  double original_logp = log_model_prob(s, included, status);
+  included[index] = 0;
+  included[candidate] = 1;
+  /* reverse weight: proposal_weight(included, candidate, index), i.e. the
+   * table of `candidate`, looking for `index` among its excluded correlates */
+  double reverse_w;
+  {
+    int l2 = s->cm_start[candidate], h2 = s->cm_start[candidate + 1];
+    double ans = BO_NEG_INF, tot = 0;
+    for (int i = l2; i < h2; ++i) {
+      if (!included[s->cm_idx[i]]) {
+        if (s->cm_idx[i] == index) ans = s->cm_cor[i];
+        tot += s->cm_cor[i];
+      }
+    }
+    reverse_w = (tot == 0) ? 0 : ans / tot;
+  }
+  double log_num = log_model_prob(s, included, status) - log(forward_w);
+  double log_den = original_logp - log(reverse_w);
+  double logu = log(bo_runif(&s->rng, 0, 1));
+  if (logu < log_num - log_den) memcpy(s->gamma, included, p);
+  free(included);
+}
+
+/* BregVsSampler::draw_model_indicators, BregVsSampler.cpp:353-378 */
+static void draw_model_indicators(bo_ssvs *s, int *status) {
+  int p = s->p;
+  uint8_t *g = (uint8_t *)malloc(p);
+  memcpy(g, s->gamma, p);
+  bo_shuffle(&s->rng, s->indx, p);
+  double logp = log_model_prob(s, g, status);
+  if (!*status && !isfinite(logp)) {
+    /* VariableSelectionPrior::make_valid, VariableSelectionPrior.cpp:287-300 */
+    for (int i = 0; i < p; ++i) {
+      if (s->pi[i] <= 0.0 && g[i]) g[i] = 0;
+      if (s->pi[i] >= 1.0 && !g[i]) g[i] = 1;
+    }
+    logp = log_model_prob(s, g, status);
+  }
+  if (!*status && !isfinite(logp)) *status = BO_ERR_ILLEGAL_START;
+  if (*status) { free(g); return; }
+  int n = s->max_nflips < p ? s->max_nflips : p;
+  for (int i = 0; i < n && !*status; ++i) {
+    logp = mcmc_one_flip(s, g, s->indx[i], logp, status);
+  }
+  memcpy(s->gamma, g, p);
+  free(g);
+  if (*status) return;
+  attempt_swap(s, status);
+}
+
+/* GenericGaussianVarianceSampler::draw,
+ * Models/PosteriorSamplers/GenericGaussianVarianceSampler.cpp:44-63 */
+static double variance_draw(bo_rng *rng, double prior_df, double prior_ss,
+                            double sigma_max, double data_df, double data_ss,
+                            int *status) {
+  double DF = data_df + prior_df;
+  double SS = data_ss + prior_ss;
+  if (sigma_max == 0.0) return 0.0;
+  if (sigma_max == INFINITY) return 1.0 / bo_rgamma(rng, DF / 2, SS / 2, status);
+  return 1.0 / bo_rtrun_gamma(rng, DF / 2, SS / 2,
+                              1.0 / (sigma_max * sigma_max), status);
+}
+
+static int ssvs_draw(bo_ssvs *s);
+
+/* BregVsSampler::draw_sigma, BregVsSampler.cpp:313-324 */
+static void draw_sigma(bo_ssvs *s, int nvars, int *status) {
+  double df, ss;
+  if (nvars == 0) {
+    ss = s->yty;
+    df = s->n;
+  } else {
+    df = s->DF - s->prior_df;
+    ss = s->SS - s->prior_ss;
+  }
+  s->sigsq = variance_draw(&s->rng, s->prior_df, s->prior_ss, s->sigma_max, df,
+                           ss, status);
+}
+
+/* BregVsSampler::draw_beta, BregVsSampler.cpp:326-351, with
+ * rmvn_precision_upper_cholesky_mt (distributions/mvn.cpp:114-122) */
+static void draw_beta(bo_ssvs *s, int nvars, int *status) {
+  if (nvars == 0) return;
+  int k = s->k;
+  double *P = s->M1, *L = s->M2;
+  for (size_t i = 0; i < (size_t)k * k; ++i) P[i] = s->V[i] / s->sigsq;
+  if (bo_chol(k, P, L)) {
+    double *z = s->w1;
+    for (int i = 0; i < k; ++i) z[i] = bo_rnorm(&s->rng, 0, 1);
+    ltsolve_inplace(k, L, z); /* Usolve_inplace(L^T, z) */
+    for (int i = 0; i < k; ++i) s->pm[i] = z[i] + s->pm[i];
+    /* set_included_coefficients */
+    memset(s->beta, 0, sizeof(double) * s->p);
+    for (int j = 0, c = 0; j < s->p; ++j)
+      if (s->gamma[j]) s->beta[j] = s->pm[c++];
+    s->failure_count = 0;
+  } else {
+    if (++s->failure_count > 10) {
+      *status = BO_ERR_NOT_PD;
+      return;
+    }
+    *status = ssvs_draw(s);
+  }
+}
+
+/* BregVsSampler::draw, BregVsSampler.cpp:252-261 */
+static int ssvs_draw(bo_ssvs *s) {
+  int status = 0;
+  if (s->max_nflips > 0) draw_model_indicators(s, &status);
+  if (status) return status;
+  int nvars = 0;
+  for (int j = 0; j < s->p; ++j) nvars += s->gamma[j];
+  if (s->draw_beta || s->draw_sigma) {
+    set_reg_post_params(s, s->gamma, 0, &status);
+    if (status) return status;
+  }
+  if (s->draw_sigma) draw_sigma(s, nvars, &status);
+  if (status) return status;
+  if (s->draw_beta) draw_beta(s, nvars, &status);
+  return status;
+}
+
+int bo_ssvs_draw(bo_ssvs *s) { return ssvs_draw(s); }
+
+/* ---- convenience-ctor prior assembly ---------------------------------- */
+/* BregVsSampler ctor #1, BregVsSampler.cpp:37-44, 48-85 */
+void bo_breg_prior_ctor1(int p, const double *xtx, double yty, double n,
+                         double sumy, double prior_nobs, double expected_rsq,
+                         double expected_model_size,
+                         int first_term_is_intercept, double *b, double *ominv,
+                         double *pi, double *prior_df, double *sigma_guess) {
+  double ybar = sumy / n;
+  /* RegSuf::SST = yty - n * ybar^2 (RegressionModel.cpp) */
+  double sst = yty - n * ybar * ybar;
+  double sample_variance = sst / (n - 1);
+  *sigma_guess = sqrt(sample_variance * (1 - expected_rsq));
+  *prior_df = prior_nobs;
+  for (int j = 0; j < p; ++j) b[j] = 0.0;
+  if (first_term_is_intercept) b[0] = ybar;
+  for (size_t i = 0; i < (size_t)p * p; ++i) ominv[i] = xtx[i] * (prior_nobs / n);
+  double prob = expected_model_size / p;
+  if (prob > 1) prob = 1.0;
+  for (int j = 0; j < p; ++j) pi[j] = prob;
+  if (first_term_is_intercept) pi[0] = 1.0;
+}
+
+/* BregVsSampler ctor #2, BregVsSampler.cpp:87-142 */
+void bo_breg_prior_ctor2(int p, const double *xtx, double n, double sumy,
+                         double prior_sigma_nobs, double prior_sigma_guess,
+                         double prior_beta_nobs, double diagonal_shrinkage,
+                         double prior_inclusion_probability,
+                         int force_intercept, double *b, double *ominv,
+                         double *pi, double *prior_df, double *sigma_guess) {
+  *prior_df = prior_sigma_nobs;
+  *sigma_guess = prior_sigma_guess;
+  for (int j = 0; j < p; ++j) b[j] = 0.0;
+  b[0] = sumy / n;
+  for (size_t i = 0; i < (size_t)p * p; ++i)
+    ominv[i] = xtx[i] * (prior_beta_nobs / n);
+  double alpha = diagonal_shrinkage;
+  if (alpha < 1.0) {
+    for (int j = 0; j < p; ++j) {
+      double d = ominv[IDX(j, j, p)];
+      ominv[IDX(j, j, p)] = d + d * (alpha / (1 - alpha));
+    }
+    for (size_t i = 0; i < (size_t)p * p; ++i) ominv[i] *= (1 - alpha);
+  } else {
+    for (int j = 0; j < p; ++j)
+      for (int i = 0; i < p; ++i)
+        if (i != j) ominv[IDX(i, j, p)] = 0.0;
+  }
+  for (int j = 0; j < p; ++j) pi[j] = prior_inclusion_probability;
+  if (force_intercept) pi[0] = 1.0;
+}
+
+/* ---- many chains (cpu_baseline leg) ------------------------------------ */
+typedef struct {
+  int p;
+  const double *xtx, *xty, *xsum, *prior_mean, *ominv, *pi;
+  double yty, n, sumy, prior_df, sigma_guess;
+  int64_t max_model_size;
+  double sigma_upper_limit, swap_threshold;
+  int max_flips;
+  uint64_t seed;
+  int chain_lo, chain_hi, nsweeps;
+  uint8_t *gamma;
+  double *beta, *sigsq;
+  int status;
+} chain_job;
+
+static void *chain_worker(void *arg) {
+  chain_job *j = (chain_job *)arg;
+  for (int c = j->chain_lo; c < j->chain_hi; ++c) {
+    bo_ssvs *s = bo_ssvs_create(j->p, j->xtx, j->xty, j->yty, j->n, j->sumy,
+                                j->xsum, j->prior_mean, j->ominv, j->prior_df,
+                                j->sigma_guess, j->pi);
+    bo_ssvs_set_options(s, j->max_model_size, j->sigma_upper_limit,
+                        j->swap_threshold, j->max_flips, 1, 1);
+    bo_ssvs_set_state(s, j->gamma + (size_t)c * j->p, j->beta + (size_t)c * j->p,
+                      j->sigsq[c]);
+    bo_rng_seed_philox(&s->rng, j->seed, (uint32_t)c, 0, 0);
+    for (int i = 0; i < j->nsweeps; ++i) {
+      int st = ssvs_draw(s);
+      if (st) { j->status = st; break; }
+    }
+    bo_ssvs_get_state(s, j->gamma + (size_t)c * j->p, j->beta + (size_t)c * j->p,
+                      &j->sigsq[c]);
+    bo_ssvs_destroy(s);
+  }
+  return NULL;
+}
+
+int bo_ssvs_run_chains(int p, const double *xtx, const double *xty, double yty,
+                       double n, double sumy, const double *xsum,
+                       const double *prior_mean, const double *ominv,
+                       double prior_df, double sigma_guess, const double *pi,
+                       int64_t max_model_size, double sigma_upper_limit,
+                       double swap_threshold, int max_flips, uint64_t seed,
+                       int chains, int nsweeps, int nthreads, uint8_t *gamma,
+                       double *beta, double *sigsq) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > chains) nthreads = chains;
+  pthread_t *th = (pthread_t *)xcalloc(nthreads, sizeof(pthread_t));
+  chain_job *jobs = (chain_job *)xcalloc(nthreads, sizeof(chain_job));
+  for (int t = 0; t < nthreads; ++t) {
+    chain_job *j = &jobs[t];
+    j->p = p; j->xtx = xtx; j->xty = xty; j->xsum = xsum;
+    j->prior_mean = prior_mean; j->ominv = ominv; j->pi = pi;
+    j->yty = yty; j->n = n; j->sumy = sumy; j->prior_df = prior_df;
+    j->sigma_guess = sigma_guess; j->max_model_size = max_model_size;
+    j->sigma_upper_limit = sigma_upper_limit; j->swap_threshold = swap_threshold;
+    j->max_flips = max_flips; j->seed = seed; j->nsweeps = nsweeps;
+    j->chain_lo = (int)((int64_t)chains * t / nthreads);
+    j->chain_hi = (int)((int64_t)chains * (t + 1) / nthreads);
+    j->gamma = gamma; j->beta = beta; j->sigsq = sigsq;
+    pthread_create(&th[t], NULL, chain_worker, j);
+  }
+  int status = 0;
+  for (int t = 0; t < nthreads; ++t) {
+    pthread_join(th[t], NULL);
+    if (jobs[t].status) status = jobs[t].status;
+  }
+  free(th);
+  free(jobs);
+  return status;
+}
+
+/* ====================================================================== */
+/*                               state space                              */
+/* ====================================================================== */
+struct bo_ss {
+  int T, p;
+  double *y, *X; /* X: T x p column-major */
+  uint8_t *observed;
+  bo_ssvs *reg;
+  /* local level */
+  double level_sigsq, level_prior_df, level_prior_ss, level_sigma_max;
+  double a0, P0;
+  double level_n, level_sumsq; /* ZeroMeanGaussianModel suf */
+  bo_rng level_rng, state_rng;
+  int latent_initialized;
+  double *state;
+  /* filter nodes: v, F, K, r for the data filter and the simulation filter */
+  double *v, *F, *K, *r, *vs, *Fs, *Ks, *rs;
+};
+
+bo_ss *bo_ss_create(int T, int p, const double *y, const double *X,
+                    const uint8_t *observed, const double *prior_mean,
+                    const double *ominv, double prior_df, double sigma_guess,
+                    const double *pi, double level_df,
+                    double level_sigma_guess, double level_sigma_upper_limit,
+                    double initial_state_mean, double initial_state_variance,
+                    double initial_level_sigma) {
+  bo_ss *m = (bo_ss *)xcalloc(1, sizeof(bo_ss));
+  m->T = T;
+  m->p = p;
+  m->y = (double *)xcalloc(T, sizeof(double));
+  m->X = (double *)xcalloc((size_t)T * p, sizeof(double));
+  m->observed = (uint8_t *)xcalloc(T, 1);
+  memcpy(m->y, y, sizeof(double) * T);
+  memcpy(m->X, X, sizeof(double) * (size_t)T * p);
+  for (int t = 0; t < T; ++t) m->observed[t] = observed ? observed[t] : 1;
+  /* The ctor adds every RegressionData to the regression model, whose
+   * NeRegSuf::Update accumulates xtx, xty, ... and then fixes xtx
+   * (StateSpaceRegressionModel.cpp:100-125, :160-165;
+   * RegressionModel.cpp:381-404).  Missing points do not update the
+   * sufficient statistics (Models/Policies/SufstatDataPolicy.hpp:166-167),
+   * so the fixed xtx is over observed rows only. */
+  double *xtx = (double *)xcalloc((size_t)p * p, sizeof(double));
+  double *xty = (double *)xcalloc(p, sizeof(double));
+  double *xsum = (double *)xcalloc(p, sizeof(double));
+  double yty = 0, sumy = 0, nobs0 = 0;
+  for (int t = 0; t < T; ++t) {
+    if (!m->observed[t]) continue;
+    nobs0 += 1;
+    for (int j = 0; j < p; ++j) {
+      double xj = X[IDX(t, j, T)];
+      xty[j] += xj * y[t];
+      xsum[j] += xj;
+      for (int i = 0; i < p; ++i) xtx[IDX(i, j, p)] += X[IDX(t, i, T)] * xj;
+    }
+    yty += y[t] * y[t];
+    sumy += y[t];
+  }
+  m->reg = bo_ssvs_create(p, xtx, xty, yty, nobs0, sumy, xsum, prior_mean,
+                          ominv, prior_df, sigma_guess, pi);
+  free(xtx); free(xty); free(xsum);
+  m->level_sigsq = initial_level_sigma * initial_level_sigma;
+  m->level_prior_df = 2 * (level_df / 2.0);
+  m->level_prior_ss = 2 * (level_df * level_sigma_guess * level_sigma_guess / 2.0);
+  m->level_sigma_max = level_sigma_upper_limit;
+  m->a0 = initial_state_mean;
+  m->P0 = initial_state_variance;
+  m->state = (double *)xcalloc(T, sizeof(double));
+  m->v = (double *)xcalloc(T, sizeof(double));
+  m->F = (double *)xcalloc(T, sizeof(double));
+  m->K = (double *)xcalloc(T, sizeof(double));
+  m->r = (double *)xcalloc(T, sizeof(double));
+  m->vs = (double *)xcalloc(T, sizeof(double));
+  m->Fs = (double *)xcalloc(T, sizeof(double));
+  m->Ks = (double *)xcalloc(T, sizeof(double));
+  m->rs = (double *)xcalloc(T, sizeof(double));
+  bo_rng_seed_philox(&m->level_rng, 0, 0, 1, 0);
+  bo_rng_seed_philox(&m->state_rng, 0, 0, 2, 0);
+  return m;
+}
+
+void bo_ss_destroy(bo_ss *m) {
+  if (!m) return;
+  bo_ssvs_destroy(m->reg);
+  free(m->y); free(m->X); free(m->observed); free(m->state);
+  free(m->v); free(m->F); free(m->K); free(m->r);
+  free(m->vs); free(m->Fs); free(m->Ks); free(m->rs);
+  free(m);
+}
+
+bo_ssvs *bo_ss_regression(bo_ss *m) { return m->reg; }
+bo_rng *bo_ss_level_rng(bo_ss *m) { return &m->level_rng; }
+bo_rng *bo_ss_state_rng(bo_ss *m) { return &m->state_rng; }
+void bo_ss_set_level_sigsq(bo_ss *m, double sigsq) { m->level_sigsq = sigsq; }
+double bo_ss_level_sigsq(const bo_ss *m) { return m->level_sigsq; }
+const double *bo_ss_state(const bo_ss *m) { return m->state; }
+void bo_ss_level_suf(const bo_ss *m, double *n, double *sumsq) {
+  *n = m->level_n;
+  *sumsq = m->level_sumsq;
+}
+
+/* ScalarMarginalDistribution::update, ScalarKalmanFilter.cpp:41-83,
+ * specialised to state dimension 1 with Z = 1, T = 1 (IdentityMatrix),
+ * RQR = sigma^2_level (LocalLevelStateModel.cpp:32-91).  (a, P) enter as the
+ * one-step-ahead moments and leave as the next ones. */
+static int marginal_update(double y, int missing, double H, double rqr,
+                           double *a, double *P, double *v, double *F,
+                           double *K) {
+  double PZ = *P;
+  *F = PZ + H;
+  if (*F <= 0) return BO_ERR_FORECAST_VARIANCE;
+  double TPZ = PZ;
+  if (!missing) {
+    *K = TPZ / *F;
+    double mu = *a;
+    *v = y - mu;
+  } else {
+    *K = 0.0;
+    *v = 0;
+  }
+  if (!missing) {
+    *a = *a + *K * *v;
+  }
+  if (!missing) {
+    *P = *P + (-1.0) * TPZ * *K;
+  }
+  *P = *P + rqr;
+  return 0;
+}
+
+/* observation_variance(t), StateSpaceRegressionModel.cpp:167-177 */
+static double observation_variance(const bo_ss *m, int t) {
+  int n = m->observed[t] ? 1 : 0;
+  if (n == 0) ++n;
+  return m->reg->sigsq / n;
+}
+
+/* fast_disturbance_smooth, ScalarKalmanFilter.cpp:168-196.  Returns the
+ * initial scaled state error r_{-1}. */
+static double disturbance_smooth(int T, const double *v, const double *F,
+                                 const double *K, double *rout) {
+  double r = 0.0;
+  for (int t = T - 1; t >= 0; --t) {
+    double coefficient = (v[t] / F[t]) - K[t] * r;
+    double rt_1 = r; /* T^T r with T = 1 */
+    rt_1 += coefficient; /* Z = 1 */
+    rout[t] = r;
+    r = rt_1;
+  }
+  return r;
+}
+
+/* Base::impute_state, StateSpaceModelBase.cpp:278-291 = clear_client_data
+ * (:248-254) + simulate_forward (:771-790) + propagate_disturbances (:858-891)
+ */
+int bo_ss_impute_state(bo_ss *m, bo_rng *rng) {
+  int T = m->T, p = m->p;
+  bo_ssvs *reg = m->reg;
+  /* clear_client_data: NeRegSuf::clear keeps xtx (RegressionModel.cpp:372-379),
+   * state-model suf cleared */
+  double *xty = (double *)xcalloc(p, sizeof(double));
+  double *xsum = (double *)xcalloc(p, sizeof(double));
+  double yty = 0, nobs = 0, sumy = 0;
+  m->level_n = 0;
+  m->level_sumsq = 0;
+
+  /* simulate_forward: filter.update() over the adjusted observations
+   * (ScalarKalmanFilter.cpp:132-161; adjusted_observation
+   * StateSpaceRegressionModel.cpp:65-77,179-181: y_t - x_t . Beta) */
+  double a = m->a0, P = m->P0;
+  int status = 0;
+  for (int t = 0; t < T && !status; ++t) {
+    int missing = !m->observed[t];
+    double ystar = BO_NEG_INF;
+    if (!missing) {
+      double pred = 0;
+      int nvars = 0;
+      for (int j = 0; j < p; ++j) nvars += reg->gamma[j];
+      if (nvars > 0)
+        for (int j = 0; j < p; ++j) pred += m->X[IDX(t, j, T)] * reg->beta[j];
+      ystar = (m->y[t] - pred) / 1;
+    }
+    status = marginal_update(ystar, missing, observation_variance(m, t),
+                             m->level_sigsq, &a, &P, &m->v[t], &m->F[t],
+                             &m->K[t]);
+  }
+  /* forward simulation + simulation filter (StateSpaceModelBase.cpp:771-790,
+   * :430-443, :849-852; LocalLevelStateModel.cpp:62-69) */
+  double as = m->a0, Ps = m->P0;
+  double level_sigma = sqrt(m->level_sigsq);
+  for (int t = 0; t < T && !status; ++t) {
+    if (t == 0) {
+      m->state[0] = bo_rnorm(rng, m->a0, sqrt(m->P0));
+    } else {
+      m->state[t] = m->state[t - 1] + bo_rnorm(rng, 0, level_sigma);
+    }
+    double H = observation_variance(m, t);
+    double ysim = bo_rnorm(rng, m->state[t], sqrt(H));
+    status = marginal_update(ysim, !m->observed[t], H, m->level_sigsq, &as, &Ps,
+                             &m->vs[t], &m->Fs[t], &m->Ks[t]);
+  }
+  if (status) { free(xty); free(xsum); return status; }
+
+  /* propagate_disturbances, StateSpaceModelBase.cpp:858-891 */
+  double r0 = disturbance_smooth(T, m->v, m->F, m->K, m->r);
+  double r0s = disturbance_smooth(T, m->vs, m->Fs, m->Ks, m->rs);
+  double mean_sim = m->a0 + m->P0 * r0s;
+  double mean_obs = m->a0 + m->P0 * r0;
+  for (int t = 0; t < T; ++t) {
+    if (t > 0) {
+      mean_sim = mean_sim + m->level_sigsq * m->rs[t - 1];
+      mean_obs = mean_obs + m->level_sigsq * m->r[t - 1];
+    }
+    m->state[t] += mean_obs - mean_sim;
+    /* observe_state (LocalLevelStateModel.cpp:52-58; GaussianSuf::update_raw) */
+    if (t > 0) {
+      double diff = m->state[t] - m->state[t - 1];
+      m->level_n += 1;
+      m->level_sumsq += diff * diff;
+    }
+    /* observe_data_given_state, StateSpaceRegressionModel.cpp:188-200 +
+     * NeRegSuf::add_mixture_data, RegressionModel.cpp:356-370 */
+    if (m->observed[t]) {
+      double resid = m->y[t] - m->state[t];
+      for (int j = 0; j < p; ++j) {
+        double xj = m->X[IDX(t, j, T)];
+        xty[j] += xj * (resid * 1.0);
+        xsum[j] += xj * 1.0;
+      }
+      yty += resid * resid * 1.0;
+      nobs += 1.0;
+      sumy += resid * 1.0;
+    }
+  }
+  bo_ssvs_set_suf(reg, xty, yty, nobs, sumy, xsum);
+  free(xty);
+  free(xsum);
+  return 0;
+}
+
+/* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64 */
+int bo_ss_draw(bo_ss *m) {
+  int status = 0;
+  if (!m->latent_initialized) {
+    status = bo_ss_impute_state(m, &m->state_rng);
+    if (status) return status;
+    m->latent_initialized = 1;
+  }
+  status = ssvs_draw(m->reg);
+  if (status) return status;
+  /* ZeroMeanGaussianConjSampler::draw, ZeroMeanGaussianConjSampler.cpp:57-60 */
+  m->level_sigsq = variance_draw(&m->level_rng, m->level_prior_df,
+                                 m->level_prior_ss, m->level_sigma_max,
+                                 m->level_n, m->level_sumsq, &status);
+  if (status) return status;
+  return bo_ss_impute_state(m, &m->state_rng);
+}

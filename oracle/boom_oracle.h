@@ -1,0 +1,181 @@
+/* TEST INFRASTRUCTURE -- CPU oracle, not part of the shipped product.
+ *
+ * Clean-room C restatement of the BOOM hot path: the
+ * BregVsSampler SSVS Gibbs sweep and the scalar Kalman filter / Durbin-Koopman
+ * simulation smoother behind StateSpacePosteriorSampler, written against flat
+ * arrays with the same control flow and RNG consumption order as the
+ * reference.  Every function cites the reference file:line it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker.  Nothing under boom_amd/ links,
+ * imports or calls it.
+ *
+ * Parity status: PINNED.  With the MT19937-64 uniform source the restatement
+ * reproduces the compiled, unmodified reference (oracle/_ref/libboomref.so)
+ * on the same seeds: inclusion indicators identical, continuous draws to
+ * <= 1e-9 relative (Eigen's vectorised reductions round differently from the
+ * plain loops here).  The fixtures in tests/golden/ were produced by that
+ * reference build (tests/golden/make_golden.py) and are re-checked on every
+ * test run, including on the GPU box where the reference itself is absent.
+ */
+#ifndef BOOM_ORACLE_H
+#define BOOM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ RNG */
+/* Uniform source with BOOM::RNG semantics (distributions/rng.hpp:27-54): one
+ * double in [0,1) per call.  Two interchangeable engines:
+ *   BO_RNG_MT      std::mt19937_64 + libstdc++ uniform_real_distribution, the
+ *                  reference's own engine -- used to pin this file against it.
+ *   BO_RNG_PHILOX  Philox4x32-10 (Salmon et al., SC'11) counter stream, the
+ *                  engine of the HIP kernels: uniform number i of stream
+ *                  (seed, chain, stream) comes from block i>>1, 64-bit half
+ *                  i&1, u = (x >> 11) * 2^-53.
+ */
+enum { BO_RNG_MT = 0, BO_RNG_PHILOX = 1 };
+
+typedef struct bo_rng {
+  int kind;
+  /* mt19937_64 */
+  uint64_t mt[312];
+  int mti;
+  /* philox */
+  uint64_t seed;
+  uint32_t chain;
+  uint32_t stream;
+  uint64_t pos; /* index of the next uniform */
+} bo_rng;
+
+void bo_rng_seed_mt(bo_rng *r, uint64_t seed);
+void bo_rng_seed_philox(bo_rng *r, uint64_t seed, uint32_t chain,
+                        uint32_t stream, uint64_t pos);
+double bo_unif(bo_rng *r);
+/* BOOM::seed_rng, distributions/rng.cpp:39-47 */
+uint64_t bo_seed_rng(bo_rng *r);
+void bo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
+                      uint32_t out[4]);
+
+double bo_runif(bo_rng *r, double a, double b);
+int bo_random_int(bo_rng *r, int lo, int hi);
+void bo_shuffle(bo_rng *r, int *v, int n);
+double bo_norm_rand(bo_rng *r);
+double bo_rnorm(bo_rng *r, double mu, double sigma);
+double bo_exp_rand(bo_rng *r);
+/* BOOM::rgamma_mt(rng, a, b): shape a, RATE b.  *status != 0 on a branch the
+ * oracle does not restate (a < 0.3). */
+double bo_rgamma(bo_rng *r, double a, double b, int *status);
+double bo_rtrun_gamma(bo_rng *r, double a, double b, double cut, int *status);
+int bo_rmulti(bo_rng *r, const double *prob, int n, int *status);
+
+/* ---------------------------------------------------------------- LinAlg */
+/* All matrices column-major, full storage (LinAlg/Matrix.hpp:429). */
+int bo_chol(int n, const double *A, double *L);      /* 1 = positive definite */
+double bo_spd_logdet(int n, const double *A, int *ok);
+int bo_spd_solve(int n, const double *A, const double *rhs, double *x);
+double bo_spd_mdist(int n, const double *A, const double *x);
+
+/* NeRegSuf(X, y), Models/Glm/RegressionModel.cpp:309-328 */
+void bo_neregsuf(int n, int p, const double *X, const double *y, double *xtx,
+                 double *xty, double *yty, double *sumy, double *xsum);
+
+/* ------------------------------------------------------------------ SSVS */
+enum {
+  BO_OK = 0,
+  BO_ERR_NOT_PD = 1,        /* draw_beta failed > 10 times */
+  BO_ERR_NEGATIVE_SS = 2,   /* set_reg_post_params: SS < 0 or non-finite */
+  BO_ERR_ILLEGAL_START = 3, /* draw_model_indicators: no legal configuration */
+  BO_ERR_UNSUPPORTED_RNG_BRANCH = 4,
+  BO_ERR_FORECAST_VARIANCE = 5
+};
+
+typedef struct bo_ssvs bo_ssvs;
+
+/* Sufficient statistics + raw priors (BregVsSampler ctor #5 semantics,
+ * BregVsSampler.cpp:180-194).  prior_df / sigma_guess parameterise
+ * ChisqModel(df, sigma_guess) (ChisqModel.cpp:56-57). */
+bo_ssvs *bo_ssvs_create(int p, const double *xtx, const double *xty,
+                        double yty, double n, double sumy, const double *xsum,
+                        const double *prior_mean, const double *ominv,
+                        double prior_df, double sigma_guess, const double *pi);
+void bo_ssvs_destroy(bo_ssvs *s);
+void bo_ssvs_set_options(bo_ssvs *s, int64_t max_model_size,
+                         double sigma_upper_limit, double swap_threshold,
+                         int max_flips, int draw_beta, int draw_sigma);
+void bo_ssvs_set_state(bo_ssvs *s, const uint8_t *gamma, const double *beta,
+                       double sigsq);
+void bo_ssvs_get_state(const bo_ssvs *s, uint8_t *gamma, double *beta,
+                       double *sigsq);
+void bo_ssvs_get_perm(const bo_ssvs *s, int *perm);
+bo_rng *bo_ssvs_rng(bo_ssvs *s);
+/* BregVsSampler::log_model_prob, BregVsSampler.cpp:216-239 */
+double bo_ssvs_log_model_prob(bo_ssvs *s, const uint8_t *gamma, int *status);
+/* BregVsSampler::draw, BregVsSampler.cpp:252-261.  Returns BO_OK or an error. */
+int bo_ssvs_draw(bo_ssvs *s);
+/* smallest |log(u) - (logp_new - logp_old)| seen over all flips so far */
+double bo_ssvs_min_margin(const bo_ssvs *s);
+/* replace the sufficient statistics that change under the state-space model */
+void bo_ssvs_set_suf(bo_ssvs *s, const double *xty, double yty, double n,
+                     double sumy, const double *xsum);
+
+/* Convenience-ctor prior assembly (BregVsSampler.cpp:48-85 and :87-142).
+ * Outputs b (p), ominv (p*p), pi (p), prior_df, sigma_guess. */
+void bo_breg_prior_ctor1(int p, const double *xtx, double yty, double n,
+                         double sumy, double prior_nobs, double expected_rsq,
+                         double expected_model_size,
+                         int first_term_is_intercept, double *b, double *ominv,
+                         double *pi, double *prior_df, double *sigma_guess);
+void bo_breg_prior_ctor2(int p, const double *xtx, double n, double sumy,
+                         double prior_sigma_nobs, double prior_sigma_guess,
+                         double prior_beta_nobs, double diagonal_shrinkage,
+                         double prior_inclusion_probability,
+                         int force_intercept, double *b, double *ominv,
+                         double *pi, double *prior_df, double *sigma_guess);
+
+/* Many independent chains (the engine's semantics): chain c uses the Philox
+ * stream (seed, c, stream 0).  Runs nsweeps sweeps of every chain with
+ * nthreads OpenMP-free pthreads (cpu_baseline leg); outputs the final state of
+ * every chain.  gamma: chains x p, beta: chains x p, sigsq: chains. */
+int bo_ssvs_run_chains(int p, const double *xtx, const double *xty, double yty,
+                       double n, double sumy, const double *xsum,
+                       const double *prior_mean, const double *ominv,
+                       double prior_df, double sigma_guess, const double *pi,
+                       int64_t max_model_size, double sigma_upper_limit,
+                       double swap_threshold, int max_flips, uint64_t seed,
+                       int chains, int nsweeps, int nthreads, uint8_t *gamma,
+                       double *beta, double *sigsq);
+
+/* ---------------------------------------------------------- state space */
+typedef struct bo_ss bo_ss;
+
+/* StateSpaceRegressionModel(y, X, observed) + one LocalLevelStateModel
+ * (StateSpaceRegressionModel.cpp:100-125, LocalLevelStateModel.cpp:32-91).
+ * X is T x p column-major; observed may be NULL (all observed). */
+bo_ss *bo_ss_create(int T, int p, const double *y, const double *X,
+                    const uint8_t *observed, const double *prior_mean,
+                    const double *ominv, double prior_df, double sigma_guess,
+                    const double *pi, double level_df,
+                    double level_sigma_guess, double level_sigma_upper_limit,
+                    double initial_state_mean, double initial_state_variance,
+                    double initial_level_sigma);
+void bo_ss_destroy(bo_ss *m);
+bo_ssvs *bo_ss_regression(bo_ss *m);
+bo_rng *bo_ss_level_rng(bo_ss *m);
+bo_rng *bo_ss_state_rng(bo_ss *m);
+void bo_ss_set_level_sigsq(bo_ss *m, double sigsq);
+double bo_ss_level_sigsq(const bo_ss *m);
+const double *bo_ss_state(const bo_ss *m);
+void bo_ss_level_suf(const bo_ss *m, double *n, double *sumsq);
+/* Base::impute_state, StateSpaceModelBase.cpp:278-291 */
+int bo_ss_impute_state(bo_ss *m, bo_rng *rng);
+/* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64 */
+int bo_ss_draw(bo_ss *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

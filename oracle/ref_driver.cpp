@@ -1,0 +1,460 @@
+// TEST INFRASTRUCTURE -- not part of the shipped product.
+//
+// C-ABI driver around the *unmodified* BOOM reference at /root/reference.  It
+// is compiled only in the build container (see oracle/Makefile) into
+// oracle/_ref/libboomref.so and is used for two things:
+//   1. to pin the clean-room restatement in oracle/boom_oracle.c (same seeds,
+//      std::mt19937_64 stream => same draws), and
+//   2. to generate the golden fixtures under tests/golden/ (see
+//      tests/golden/make_golden.py).
+// This file is our own code: it only *calls* the reference's public classes.
+// It never ships to the GPU box in source form that is needed at run time;
+// nothing in boom_amd/ links it.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "LinAlg/Cholesky.hpp"
+#include "LinAlg/Matrix.hpp"
+#include "LinAlg/Selector.hpp"
+#include "LinAlg/SpdMatrix.hpp"
+#include "LinAlg/Vector.hpp"
+#include "Models/ChisqModel.hpp"
+#include "Models/Glm/PosteriorSamplers/BregVsSampler.hpp"
+#include "Models/Glm/RegressionModel.hpp"
+#include "Models/Glm/VariableSelectionPrior.hpp"
+#include "Models/MvnGivenScalarSigma.hpp"
+#include "Models/PosteriorSamplers/ZeroMeanGaussianConjSampler.hpp"
+#include "Models/StateSpace/PosteriorSamplers/StateSpacePosteriorSampler.hpp"
+#include "Models/StateSpace/StateModels/LocalLevelStateModel.hpp"
+#include "Models/StateSpace/StateSpaceRegressionModel.hpp"
+#include "cpputil/shuffle.hpp"
+#include "distributions.hpp"
+#include "distributions/rng.hpp"
+#include "distributions/trun_gamma.hpp"
+
+using namespace BOOM;
+
+static std::string g_err;
+
+#define REF_TRY try {
+#define REF_CATCH                                  \
+  }                                                \
+  catch (std::exception & e) {                     \
+    g_err = e.what();                              \
+    return 1;                                      \
+  }                                                \
+  catch (...) {                                    \
+    g_err = "unknown exception";                   \
+    return 2;                                      \
+  }                                                \
+  return 0;
+
+static Matrix make_matrix(int nr, int nc, const double *colmajor) {
+  Matrix m(nr, nc);
+  std::memcpy(m.data(), colmajor, sizeof(double) * nr * nc);
+  return m;
+}
+static SpdMatrix make_spd(int n, const double *colmajor) {
+  SpdMatrix m(n);
+  std::memcpy(m.data(), colmajor, sizeof(double) * n * n);
+  return m;
+}
+static Vector make_vector(int n, const double *x) {
+  Vector v(n);
+  std::memcpy(v.data(), x, sizeof(double) * n);
+  return v;
+}
+
+extern "C" {
+
+const char *ref_last_error() { return g_err.c_str(); }
+
+// ---------------------------------------------------------------- RNG KATs
+int ref_rng_uniform(uint64_t seed, int n, double *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = rng();
+  REF_CATCH
+}
+
+int ref_seed_rng(uint64_t seed, int n, uint64_t *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = seed_rng(rng);
+  REF_CATCH
+}
+
+int ref_rng_norm(uint64_t seed, int n, double *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = rnorm_mt(rng, 0, 1);
+  REF_CATCH
+}
+
+int ref_rng_exp(uint64_t seed, int n, double *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = rexp_mt(rng, 1.0);
+  REF_CATCH
+}
+
+// BOOM::rgamma_mt(rng, a, b) with b a *rate*.
+int ref_rng_gamma(uint64_t seed, double a, double b, int n, double *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = rgamma_mt(rng, a, b);
+  REF_CATCH
+}
+
+int ref_rng_trun_gamma(uint64_t seed, double a, double b, double cut, int n,
+                       double *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = rtrun_gamma_mt(rng, a, b, cut);
+  REF_CATCH
+}
+
+int ref_rng_random_int(uint64_t seed, int lo, int hi, int n, int *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = random_int_mt(rng, lo, hi);
+  REF_CATCH
+}
+
+// A persistent index vector shuffled nrep times in place (as BregVsSampler's
+// `indx` member is); out is nrep x p.
+int ref_rng_shuffle(uint64_t seed, int p, int nrep, int *out) {
+  REF_TRY
+  RNG rng(seed);
+  std::vector<int> v(p);
+  for (int i = 0; i < p; ++i) v[i] = i;
+  for (int r = 0; r < nrep; ++r) {
+    shuffle(v, rng);
+    for (int i = 0; i < p; ++i) out[r * p + i] = v[i];
+  }
+  REF_CATCH
+}
+
+int ref_rng_rmulti(uint64_t seed, int k, const double *prob, int n, int *out) {
+  REF_TRY
+  RNG rng(seed);
+  Vector pr = make_vector(k, prob);
+  for (int i = 0; i < n; ++i) out[i] = rmulti_mt(rng, pr);
+  REF_CATCH
+}
+
+// ---------------------------------------------------------- LinAlg KATs
+int ref_spd_logdet(int n, const double *A, double *out, int *ok) {
+  REF_TRY
+  SpdMatrix S = make_spd(n, A);
+  bool good = true;
+  *out = S.logdet(good);
+  *ok = good;
+  REF_CATCH
+}
+
+int ref_spd_chol(int n, const double *A, double *L, int *ok) {
+  REF_TRY
+  SpdMatrix S = make_spd(n, A);
+  bool good = true;
+  Matrix l = S.chol(good);
+  *ok = good;
+  if (good) std::memcpy(L, l.data(), sizeof(double) * n * n);
+  REF_CATCH
+}
+
+int ref_spd_solve(int n, const double *A, const double *rhs, double *out,
+                  int *ok) {
+  REF_TRY
+  SpdMatrix S = make_spd(n, A);
+  bool good = true;
+  Vector ans = S.solve(make_vector(n, rhs), good);
+  *ok = good;
+  std::memcpy(out, ans.data(), sizeof(double) * n);
+  REF_CATCH
+}
+
+int ref_spd_mdist(int n, const double *A, const double *x, double *out) {
+  REF_TRY
+  SpdMatrix S = make_spd(n, A);
+  *out = S.Mdist(make_vector(n, x));
+  REF_CATCH
+}
+
+// ------------------------------------------------------- sufficient stats
+int ref_neregsuf(int n, int p, const double *X, const double *y, double *xtx,
+                 double *xty, double *yty, double *ybar, double *xbar) {
+  REF_TRY
+  Matrix Xm = make_matrix(n, p, X);
+  Vector yv = make_vector(n, y);
+  NeRegSuf suf(Xm, yv);
+  SpdMatrix S = suf.xtx();
+  std::memcpy(xtx, S.data(), sizeof(double) * p * p);
+  Vector s = suf.xty();
+  std::memcpy(xty, s.data(), sizeof(double) * p);
+  *yty = suf.yty();
+  *ybar = suf.ybar();
+  Vector xb = suf.xbar();
+  std::memcpy(xbar, xb.data(), sizeof(double) * p);
+  REF_CATCH
+}
+
+// ------------------------------------------------------------- SSVS runs
+struct RefSsvsOptions {
+  int64_t max_model_size;    // < 0: no limit
+  double sigma_upper_limit;  // +inf: none
+  double swap_threshold;     // >= 1 disables the swap move
+  int max_flips;             // < 0: p
+  int draw_beta;             // NOTE reference bug: allow_* sets the flag false
+  int draw_sigma;
+};
+
+static void record(const RegressionModel &model, int p, int sweep,
+                   uint8_t *out_gamma, double *out_beta, double *out_sigsq) {
+  const Selector &inc(model.coef().inc());
+  const Vector &beta(model.Beta());
+  for (int j = 0; j < p; ++j) {
+    out_gamma[(size_t)sweep * p + j] = inc[j] ? 1 : 0;
+    out_beta[(size_t)sweep * p + j] = beta[j];
+  }
+  out_sigsq[sweep] = model.sigsq();
+}
+
+static void apply_options(BregVsSampler &sampler, const Ptr<VariableSelectionPrior> &spike,
+                          const RefSsvsOptions *opt) {
+  if (opt->max_model_size >= 0) spike->set_max_model_size(opt->max_model_size);
+  if (std::isfinite(opt->sigma_upper_limit)) {
+    sampler.set_sigma_upper_limit(opt->sigma_upper_limit);
+  }
+  sampler.set_correlation_swap_threshold(opt->swap_threshold);
+  if (opt->max_flips >= 0) sampler.limit_model_selection(opt->max_flips);
+  if (!opt->draw_beta) sampler.suppress_beta_draw();
+  if (!opt->draw_sigma) sampler.suppress_sigma_draw();
+}
+
+// Raw-prior run (ctor #5: model objects).  Data are given either as (X, y)
+// [X != NULL] or as sufficient statistics.  GlobalRng is seeded with `seed`
+// and the sampler takes its private seed from it, exactly as the R / Python
+// wrappers do (spike_slab_wrapper.cc:201-254).
+int ref_ssvs_run(int n, int p, const double *X, const double *y,
+                 const double *xtx, const double *xty, double yty, double ybar,
+                 const double *xbar, const double *prior_mean,
+                 const double *ominv, double prior_df, double sigma_guess,
+                 const double *pi, const RefSsvsOptions *opt, uint64_t seed,
+                 const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                 double *out_beta, double *out_sigsq) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  Ptr<RegressionModel> model;
+  if (X) {
+    model = new RegressionModel(make_matrix(n, p, X), make_vector(n, y), false);
+  } else {
+    NEW(NeRegSuf, suf)(make_spd(p, xtx), make_vector(p, xty), yty, (double)n,
+                       ybar, make_vector(p, xbar));
+    model = new RegressionModel(Ptr<RegSuf>(suf));
+  }
+  NEW(MvnGivenScalarSigma, slab)(make_vector(p, prior_mean), make_spd(p, ominv),
+                                 model->Sigsq_prm());
+  NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  NEW(BregVsSampler, sampler)(model.get(), slab, siginv_prior, spike);
+  apply_options(*sampler, spike, opt);
+  model->set_method(sampler);
+  model->coef().drop_all();
+  for (int j = 0; j < p; ++j) {
+    if (init_gamma[j]) model->coef().add(j);
+  }
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    record(*model, p, i, out_gamma, out_beta, out_sigsq);
+  }
+  REF_CATCH
+}
+
+// Convenience-ctor run:
+//   which == 1: (model, prior_nobs=a0, expected_rsq=a1, expected_model_size=a2,
+//                first_term_is_intercept=flag)            BregVsSampler.cpp:48-85
+//   which == 2: (model, prior_sigma_nobs=a0, prior_sigma_guess=a1,
+//                prior_beta_nobs=a2, diagonal_shrinkage=a3,
+//                prior_inclusion_probability=a4, force_intercept=flag)  :87-142
+int ref_ssvs_run_ctor(int which, int n, int p, const double *X, const double *y,
+                      double a0, double a1, double a2, double a3, double a4,
+                      int flag, const RefSsvsOptions *opt, uint64_t seed,
+                      const uint8_t *init_gamma, int nsweeps,
+                      uint8_t *out_gamma, double *out_beta, double *out_sigsq) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  NEW(RegressionModel, model)(make_matrix(n, p, X), make_vector(n, y), false);
+  Ptr<BregVsSampler> sampler;
+  if (which == 1) {
+    sampler = new BregVsSampler(model.get(), a0, a1, a2, flag != 0);
+  } else {
+    sampler = new BregVsSampler(model.get(), a0, a1, a2, a3, a4, flag != 0);
+  }
+  RefSsvsOptions o = *opt;
+  o.max_model_size = -1;
+  if (std::isfinite(o.sigma_upper_limit)) {
+    sampler->set_sigma_upper_limit(o.sigma_upper_limit);
+  }
+  sampler->set_correlation_swap_threshold(o.swap_threshold);
+  if (o.max_flips >= 0) sampler->limit_model_selection(o.max_flips);
+  model->set_method(sampler);
+  model->coef().drop_all();
+  for (int j = 0; j < p; ++j) {
+    if (init_gamma[j]) model->coef().add(j);
+  }
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    record(*model, p, i, out_gamma, out_beta, out_sigsq);
+  }
+  REF_CATCH
+}
+
+// log_model_prob of an arbitrary inclusion vector (pins a5/a6 directly).
+int ref_ssvs_log_model_prob(int n, int p, const double *xtx, const double *xty,
+                            double yty, double ybar, const double *xbar,
+                            const double *prior_mean, const double *ominv,
+                            double prior_df, double sigma_guess,
+                            const double *pi, int64_t max_model_size,
+                            int ngamma, const uint8_t *gammas, double *out) {
+  REF_TRY
+  GlobalRng::rng.seed(1);
+  NEW(NeRegSuf, suf)(make_spd(p, xtx), make_vector(p, xty), yty, (double)n,
+                     ybar, make_vector(p, xbar));
+  NEW(RegressionModel, model)(Ptr<RegSuf>(suf));
+  NEW(MvnGivenScalarSigma, slab)(make_vector(p, prior_mean), make_spd(p, ominv),
+                                 model->Sigsq_prm());
+  NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
+  NEW(BregVsSampler, sampler)(model.get(), slab, siginv_prior, spike);
+  for (int g = 0; g < ngamma; ++g) {
+    Selector inc(p, false);
+    for (int j = 0; j < p; ++j) {
+      if (gammas[(size_t)g * p + j]) inc.add(j);
+    }
+    out[g] = sampler->log_model_prob(inc);
+  }
+  REF_CATCH
+}
+
+// ------------------------------------------------------ state-space runs
+// bsts "local level + regression" (SURVEY 3.3): StateSpaceRegressionModel with
+// one LocalLevelStateModel, BregVsSampler on the observation model,
+// ZeroMeanGaussianConjSampler on the level variance, StateSpacePosteriorSampler
+// on top.  Samplers are constructed in that order (each takes its private seed
+// from GlobalRng at construction, PosteriorSampler.cpp:34-35).
+struct RefSsOptions {
+  double level_df;
+  double level_sigma_guess;
+  double level_sigma_upper_limit;  // +inf: none
+  double initial_state_mean;
+  double initial_state_variance;
+  double initial_level_sigma;
+};
+
+int ref_ss_run(int T, int p, const double *y, const double *X,
+               const uint8_t *observed, const double *prior_mean,
+               const double *ominv, double prior_df, double sigma_guess,
+               const double *pi, const RefSsvsOptions *opt,
+               const RefSsOptions *ss, uint64_t seed, const uint8_t *init_gamma,
+               int nsweeps, uint8_t *out_gamma, double *out_beta,
+               double *out_sigsq, double *out_level_sigsq, double *out_state) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  std::vector<bool> obs;
+  if (observed) {
+    obs.resize(T);
+    for (int t = 0; t < T; ++t) obs[t] = observed[t] != 0;
+  }
+  NEW(StateSpaceRegressionModel, model)(make_vector(T, y), make_matrix(T, p, X),
+                                        obs);
+  RegressionModel *reg = model->observation_model();
+  NEW(MvnGivenScalarSigma, slab)(make_vector(p, prior_mean), make_spd(p, ominv),
+                                 reg->Sigsq_prm());
+  NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  NEW(BregVsSampler, reg_sampler)(reg, slab, siginv_prior, spike);
+  apply_options(*reg_sampler, spike, opt);
+  reg->set_method(reg_sampler);
+  reg->coef().drop_all();
+  for (int j = 0; j < p; ++j) {
+    if (init_gamma[j]) reg->coef().add(j);
+  }
+
+  NEW(LocalLevelStateModel, level)(ss->initial_level_sigma);
+  NEW(ZeroMeanGaussianConjSampler, level_sampler)(level.get(), ss->level_df,
+                                                 ss->level_sigma_guess);
+  if (std::isfinite(ss->level_sigma_upper_limit)) {
+    level_sampler->set_sigma_upper_limit(ss->level_sigma_upper_limit);
+  }
+  level->set_method(level_sampler);
+  level->set_initial_state_mean(ss->initial_state_mean);
+  level->set_initial_state_variance(ss->initial_state_variance);
+  model->add_state(level);
+
+  NEW(StateSpacePosteriorSampler, sampler)(model.get());
+  model->set_method(sampler);
+
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    record(*reg, p, i, out_gamma, out_beta, out_sigsq);
+    out_level_sigsq[i] = level->sigsq();
+    const Matrix &state(model->state());
+    for (int t = 0; t < T; ++t) out_state[(size_t)i * T + t] = state(0, t);
+  }
+  REF_CATCH
+}
+
+// One isolated impute_state() with fixed parameters: pins a14-a18 (filter,
+// simulation, disturbance smoother, mean correction, sufficient statistics)
+// without any parameter draw in between.  Outputs the drawn state and the
+// regression / level sufficient statistics left behind.
+int ref_ss_impute_state(int T, int p, const double *y, const double *X,
+                        const uint8_t *observed, const double *beta,
+                        const uint8_t *gamma, double sigsq_obs,
+                        double sigsq_level, double a0, double P0,
+                        uint64_t seed, double *out_state, double *out_xty,
+                        double *out_yty, double *out_n, double *out_level_sumsq,
+                        double *out_level_n) {
+  REF_TRY
+  std::vector<bool> obs;
+  if (observed) {
+    obs.resize(T);
+    for (int t = 0; t < T; ++t) obs[t] = observed[t] != 0;
+  }
+  NEW(StateSpaceRegressionModel, model)(make_vector(T, y), make_matrix(T, p, X),
+                                        obs);
+  RegressionModel *reg = model->observation_model();
+  reg->coef().drop_all();
+  Vector b(p, 0.0);
+  for (int j = 0; j < p; ++j) {
+    if (gamma[j]) {
+      reg->coef().add(j);
+      b[j] = beta[j];
+    }
+  }
+  reg->coef().set_Beta(b);
+  reg->set_sigsq(sigsq_obs);
+  NEW(LocalLevelStateModel, level)(std::sqrt(sigsq_level));
+  level->set_initial_state_mean(a0);
+  level->set_initial_state_variance(P0);
+  model->add_state(level);
+  RNG rng(seed);
+  model->impute_state(rng);
+  const Matrix &state(model->state());
+  for (int t = 0; t < T; ++t) out_state[t] = state(0, t);
+  Vector xty = reg->suf()->xty();
+  std::memcpy(out_xty, xty.data(), sizeof(double) * p);
+  *out_yty = reg->suf()->yty();
+  *out_n = reg->suf()->n();
+  *out_level_sumsq = level->suf()->sumsq();
+  *out_level_n = level->suf()->n();
+  REF_CATCH
+}
+
+}  // extern "C"

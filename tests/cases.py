@@ -1,0 +1,89 @@
+"""Seeded synthetic inputs shared by the golden generator and the parity tests.
+
+Every case is a pure function of its arguments (numpy PCG64 with an explicit
+seed), so fixtures, oracle runs and GPU runs all see identical inputs.
+"""
+import numpy as np
+
+
+def regression_data(n, p, nsignal, seed, intercept=True, noise_sd=1.0,
+                    collinear=None):
+    """X[:,0]=1 (if intercept), rest iid N(0,1); beta_true alternating
+    +-{1,2,3} on the first nsignal columns."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((n, p))
+    if intercept:
+        X[:, 0] = 1.0
+    if collinear:
+        # columns listed in `collinear` become noisy copies of the first one
+        base = collinear[0]
+        for j in collinear[1:]:
+            X[:, j] = X[:, base] + 0.05 * rng.standard_normal(n)
+    beta = np.zeros(p)
+    mags = [1.0, 2.0, 3.0]
+    for j in range(nsignal):
+        beta[j] = mags[j % 3] * (1 if j % 2 == 0 else -1)
+    y = X @ beta + noise_sd * rng.standard_normal(n)
+    return X, y, beta
+
+
+def suf_from_xy(X, y):
+    n = X.shape[0]
+    return dict(xtx=X.T @ X, xty=X.T @ y, yty=float(y @ y), n=float(n),
+                sumy=float(y.sum()), xsum=X.sum(axis=0))
+
+
+def spike_slab_prior(suf, expected_model_size, kappa=0.01,
+                     diagonal_shrinkage=0.5, prior_df=0.01, expected_r2=0.5,
+                     force_intercept=True, prior_mean=None):
+    """The R SpikeSlabPrior defaults (spike.slab.prior.R:143-155) in raw form:
+    b = (ybar, 0...), Omega^{-1} = kappa*((1-w) XtX/n + w diag(XtX/n)),
+    ChisqModel(df, sqrt(1-r2)*sd(y)), pi_j = ems/p (pi_0 = 1 if forced)."""
+    p = len(suf["xty"])
+    n = suf["n"]
+    ybar = suf["sumy"] / n
+    xtxn = suf["xtx"] / n
+    w = diagonal_shrinkage
+    ominv = kappa * ((1 - w) * xtxn + w * np.diag(np.diag(xtxn)))
+    b = np.zeros(p)
+    b[0] = ybar
+    if prior_mean is not None:
+        b = np.asarray(prior_mean, dtype=float)
+    sdy = np.sqrt((suf["yty"] - n * ybar * ybar) / (n - 1))
+    pi = np.full(p, min(1.0, expected_model_size / p))
+    if force_intercept:
+        pi[0] = 1.0
+    return dict(b=b, ominv=ominv, df=prior_df,
+                sigma_guess=float(np.sqrt(1 - expected_r2) * sdy), pi=pi)
+
+
+def state_space_data(T, p, nsignal, seed, level_sd=0.5, obs_sd=0.2,
+                     missing_frac=0.0):
+    """Local level + regression: no intercept column."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((T, p))
+    beta = np.zeros(p)
+    for j in range(nsignal):
+        beta[j] = 3.0 * (j + 1)
+    level = np.cumsum(level_sd * rng.standard_normal(T))
+    y = level + X @ beta + obs_sd * rng.standard_normal(T)
+    observed = None
+    if missing_frac > 0:
+        observed = (rng.random(T) >= missing_frac).astype(np.uint8)
+        observed[0] = 1
+    return X, y, beta, observed
+
+
+def bsts_priors(X, y, expected_model_size):
+    """bsts R defaults (bsts.R:426-457, add.local.level.R:181-190)."""
+    T, p = X.shape
+    suf = suf_from_xy(X, y)
+    sdy = float(np.std(y, ddof=1))
+    prior = spike_slab_prior(suf, expected_model_size, force_intercept=False,
+                             prior_mean=np.zeros(p))
+    prior["sigma_guess"] = float(np.sqrt(0.5) * sdy)
+    ss = dict(level_df=0.01, level_sigma_guess=0.01 * sdy,
+              level_sigma_upper_limit=sdy, initial_state_mean=float(y[0]),
+              initial_state_variance=sdy * sdy, initial_level_sigma=1.0)
+    sigma_upper = 1.2 * sdy
+    return prior, ss, sigma_upper

@@ -1,0 +1,666 @@
+"""ctypes bindings for the two CHECKERS (test infrastructure only):
+
+* ``Oracle``  -- oracle/libboomoracle.so, our clean-room C restatement
+* ``Ref``     -- oracle/_ref/libboomref.so, the unmodified BOOM reference
+                 (exists only where it was built: the build container, or the
+                 GPU box via the prebuilt .so that travels with the snapshot)
+
+Nothing under boom_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libboomoracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libboomref.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_u8_p = C.POINTER(C.c_uint8)
+c_int_p = C.POINTER(C.c_int)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _u8(a):
+    return None if a is None else a.ctypes.data_as(c_u8_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def fcol(a):
+    """column-major flat copy of a 2-d array"""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).T).ravel()
+
+
+def build_oracle():
+    src = os.path.join(ORACLE_DIR, "boom_oracle.c")
+    if (not os.path.exists(ORACLE_SO)
+            or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"],
+                              stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+class BoRng(C.Structure):
+    _fields_ = [("kind", C.c_int), ("mt", C.c_uint64 * 312), ("mti", C.c_int),
+                ("seed", C.c_uint64), ("chain", C.c_uint32),
+                ("stream", C.c_uint32), ("pos", C.c_uint64)]
+
+
+class RefSsvsOptions(C.Structure):
+    _fields_ = [("max_model_size", C.c_int64), ("sigma_upper_limit", C.c_double),
+                ("swap_threshold", C.c_double), ("max_flips", C.c_int),
+                ("draw_beta", C.c_int), ("draw_sigma", C.c_int)]
+
+
+class RefSsOptions(C.Structure):
+    _fields_ = [("level_df", C.c_double), ("level_sigma_guess", C.c_double),
+                ("level_sigma_upper_limit", C.c_double),
+                ("initial_state_mean", C.c_double),
+                ("initial_state_variance", C.c_double),
+                ("initial_level_sigma", C.c_double)]
+
+
+def ssvs_options(max_model_size=-1, sigma_upper_limit=float("inf"),
+                 swap_threshold=0.8, max_flips=-1, draw_beta=1, draw_sigma=1):
+    return dict(max_model_size=int(max_model_size),
+                sigma_upper_limit=float(sigma_upper_limit),
+                swap_threshold=float(swap_threshold), max_flips=int(max_flips),
+                draw_beta=int(draw_beta), draw_sigma=int(draw_sigma))
+
+
+# ---------------------------------------------------------------------------
+class Oracle:
+    def __init__(self):
+        self.lib = L = C.CDLL(build_oracle())
+        L.bo_unif.restype = C.c_double
+        L.bo_norm_rand.restype = C.c_double
+        L.bo_exp_rand.restype = C.c_double
+        L.bo_rgamma.restype = C.c_double
+        L.bo_rgamma.argtypes = [C.c_void_p, C.c_double, C.c_double, c_int_p]
+        L.bo_rtrun_gamma.restype = C.c_double
+        L.bo_rtrun_gamma.argtypes = [C.c_void_p, C.c_double, C.c_double,
+                                     C.c_double, c_int_p]
+        L.bo_seed_rng.restype = C.c_uint64
+        L.bo_rng_seed_mt.argtypes = [C.c_void_p, C.c_uint64]
+        L.bo_rng_seed_philox.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32,
+                                         C.c_uint32, C.c_uint64]
+        L.bo_spd_logdet.restype = C.c_double
+        L.bo_spd_mdist.restype = C.c_double
+        L.bo_ssvs_create.restype = C.c_void_p
+        L.bo_ssvs_create.argtypes = [C.c_int, c_double_p, c_double_p, C.c_double,
+                                     C.c_double, C.c_double, c_double_p,
+                                     c_double_p, c_double_p, C.c_double,
+                                     C.c_double, c_double_p]
+        L.bo_ssvs_destroy.argtypes = [C.c_void_p]
+        L.bo_ssvs_set_options.argtypes = [C.c_void_p, C.c_int64, C.c_double,
+                                          C.c_double, C.c_int, C.c_int, C.c_int]
+        L.bo_ssvs_set_state.argtypes = [C.c_void_p, c_u8_p, c_double_p,
+                                        C.c_double]
+        L.bo_ssvs_get_state.argtypes = [C.c_void_p, c_u8_p, c_double_p,
+                                        c_double_p]
+        L.bo_ssvs_get_perm.argtypes = [C.c_void_p, c_int_p]
+        L.bo_ssvs_rng.restype = C.c_void_p
+        L.bo_ssvs_rng.argtypes = [C.c_void_p]
+        L.bo_ssvs_draw.argtypes = [C.c_void_p]
+        L.bo_ssvs_min_margin.restype = C.c_double
+        L.bo_ssvs_min_margin.argtypes = [C.c_void_p]
+        L.bo_ssvs_log_model_prob.restype = C.c_double
+        L.bo_ssvs_log_model_prob.argtypes = [C.c_void_p, c_u8_p, c_int_p]
+        L.bo_ssvs_run_chains.argtypes = [
+            C.c_int, c_double_p, c_double_p, C.c_double, C.c_double, C.c_double,
+            c_double_p, c_double_p, c_double_p, C.c_double, C.c_double,
+            c_double_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_uint64,
+            C.c_int, C.c_int, C.c_int, c_u8_p, c_double_p, c_double_p]
+        L.bo_ss_create.restype = C.c_void_p
+        L.bo_ss_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p,
+                                   c_u8_p, c_double_p, c_double_p, C.c_double,
+                                   C.c_double, c_double_p, C.c_double,
+                                   C.c_double, C.c_double, C.c_double,
+                                   C.c_double, C.c_double]
+        L.bo_ss_destroy.argtypes = [C.c_void_p]
+        L.bo_ss_regression.restype = C.c_void_p
+        L.bo_ss_regression.argtypes = [C.c_void_p]
+        L.bo_ss_level_rng.restype = C.c_void_p
+        L.bo_ss_level_rng.argtypes = [C.c_void_p]
+        L.bo_ss_state_rng.restype = C.c_void_p
+        L.bo_ss_state_rng.argtypes = [C.c_void_p]
+        L.bo_ss_set_level_sigsq.argtypes = [C.c_void_p, C.c_double]
+        L.bo_ss_level_sigsq.restype = C.c_double
+        L.bo_ss_level_sigsq.argtypes = [C.c_void_p]
+        L.bo_ss_state.restype = c_double_p
+        L.bo_ss_state.argtypes = [C.c_void_p]
+        L.bo_ss_level_suf.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.bo_ss_impute_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.bo_ss_draw.argtypes = [C.c_void_p]
+
+    # -- RNG -----------------------------------------------------------------
+    def rng_mt(self, seed):
+        r = BoRng()
+        self.lib.bo_rng_seed_mt(C.byref(r), int(seed))
+        return r
+
+    def rng_philox(self, seed, chain=0, stream=0, pos=0):
+        r = BoRng()
+        self.lib.bo_rng_seed_philox(C.byref(r), int(seed), chain, stream, pos)
+        return r
+
+    def uniforms(self, rng, n):
+        return np.array([self.lib.bo_unif(C.byref(rng)) for _ in range(n)])
+
+    def norms(self, rng, n):
+        return np.array([self.lib.bo_norm_rand(C.byref(rng)) for _ in range(n)])
+
+    def exps(self, rng, n):
+        return np.array([self.lib.bo_exp_rand(C.byref(rng)) for _ in range(n)])
+
+    def gammas(self, rng, a, b, n):
+        st = C.c_int(0)
+        out = np.array([self.lib.bo_rgamma(C.byref(rng), a, b, C.byref(st))
+                        for _ in range(n)])
+        assert st.value == 0
+        return out
+
+    def trun_gammas(self, rng, a, b, cut, n):
+        st = C.c_int(0)
+        out = np.array([self.lib.bo_rtrun_gamma(C.byref(rng), a, b, cut,
+                                                C.byref(st)) for _ in range(n)])
+        assert st.value == 0
+        return out
+
+    def seed_rngs(self, rng, n):
+        return np.array([self.lib.bo_seed_rng(C.byref(rng)) for _ in range(n)],
+                        dtype=np.uint64)
+
+    def random_ints(self, rng, lo, hi, n):
+        return np.array([self.lib.bo_random_int(C.byref(rng), lo, hi)
+                         for _ in range(n)], dtype=np.int32)
+
+    def shuffles(self, rng, p, nrep):
+        v = np.arange(p, dtype=np.int32)
+        out = np.zeros((nrep, p), dtype=np.int32)
+        for r in range(nrep):
+            self.lib.bo_shuffle(C.byref(rng), _ip(v), p)
+            out[r] = v
+        return out
+
+    def rmultis(self, rng, prob, n):
+        prob = f64(prob)
+        st = C.c_int(0)
+        return np.array([self.lib.bo_rmulti(C.byref(rng), _dp(prob), len(prob),
+                                            C.byref(st)) for _ in range(n)],
+                        dtype=np.int32)
+
+    # -- LinAlg ----------------------------------------------------------------
+    def chol(self, A):
+        n = A.shape[0]
+        a = fcol(A)
+        L = np.zeros(n * n)
+        ok = self.lib.bo_chol(n, _dp(a), _dp(L))
+        return L.reshape(n, n).T.copy(), bool(ok)
+
+    def logdet(self, A):
+        n = A.shape[0]
+        a = fcol(A)
+        ok = C.c_int(0)
+        v = self.lib.bo_spd_logdet(n, _dp(a), C.byref(ok))
+        return v, bool(ok.value)
+
+    def solve(self, A, rhs):
+        n = A.shape[0]
+        a = fcol(A)
+        rhs = f64(rhs)
+        x = np.zeros(n)
+        ok = self.lib.bo_spd_solve(n, _dp(a), _dp(rhs), _dp(x))
+        return x, bool(ok)
+
+    def mdist(self, A, x):
+        a = fcol(A)
+        x = f64(x)
+        return self.lib.bo_spd_mdist(A.shape[0], _dp(a), _dp(x))
+
+    def neregsuf(self, X, y):
+        n, p = X.shape
+        xc = fcol(X)
+        y = f64(y)
+        xtx = np.zeros(p * p)
+        xty = np.zeros(p)
+        yty = C.c_double()
+        sumy = C.c_double()
+        xsum = np.zeros(p)
+        self.lib.bo_neregsuf(n, p, _dp(xc), _dp(y), _dp(xtx), _dp(xty),
+                             C.byref(yty), C.byref(sumy), _dp(xsum))
+        return dict(xtx=xtx.reshape(p, p).T.copy(), xty=xty, yty=yty.value,
+                    n=float(n), sumy=sumy.value, xsum=xsum)
+
+    # -- SSVS --------------------------------------------------------------------
+    def ssvs_create(self, suf, prior):
+        p = len(suf["xty"])
+        h = self.lib.bo_ssvs_create(
+            p, _dp(fcol(suf["xtx"])), _dp(f64(suf["xty"])), suf["yty"],
+            suf["n"], suf["sumy"], _dp(f64(suf["xsum"])), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), prior["df"], prior["sigma_guess"],
+            _dp(f64(prior["pi"])))
+        return h
+
+    def ssvs_run(self, suf, prior, opts, rng_setup, init_gamma, nsweeps,
+                 init_beta=None, init_sigsq=1.0, want_margin=False):
+        """rng_setup: ('mt', global_seed) -> sampler seeded by seed_rng(global)
+        as the reference wrappers do; or ('philox', seed, chain)."""
+        p = len(suf["xty"])
+        h = self.ssvs_create(suf, prior)
+        self.lib.bo_ssvs_set_options(h, opts["max_model_size"],
+                                     opts["sigma_upper_limit"],
+                                     opts["swap_threshold"], opts["max_flips"],
+                                     opts["draw_beta"], opts["draw_sigma"])
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        b0 = f64(init_beta) if init_beta is not None else np.zeros(p)
+        self.lib.bo_ssvs_set_state(h, _u8(g0), _dp(b0), float(init_sigsq))
+        rp = self.lib.bo_ssvs_rng(h)
+        if rng_setup[0] == "mt":
+            glob = self.rng_mt(rng_setup[1])
+            seed = self.lib.bo_seed_rng(C.byref(glob))
+            self.lib.bo_rng_seed_mt(rp, seed)
+        else:
+            self.lib.bo_rng_seed_philox(rp, int(rng_setup[1]), int(rng_setup[2]),
+                                        0, 0)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        s = C.c_double()
+        status = 0
+        for i in range(nsweeps):
+            status = self.lib.bo_ssvs_draw(h)
+            if status:
+                break
+            self.lib.bo_ssvs_get_state(h, _u8(g), _dp(b), C.byref(s))
+            gam[i] = g
+            beta[i] = b
+            sig[i] = s.value
+        margin = self.lib.bo_ssvs_min_margin(h)
+        self.lib.bo_ssvs_destroy(h)
+        out = dict(gamma=gam, beta=beta, sigsq=sig, status=status)
+        if want_margin:
+            out["min_margin"] = margin
+        return out
+
+    def log_model_prob(self, suf, prior, gammas, max_model_size=-1):
+        h = self.ssvs_create(suf, prior)
+        self.lib.bo_ssvs_set_options(h, max_model_size, float("inf"), 0.8, -1,
+                                     1, 1)
+        out = []
+        for g in gammas:
+            g = np.ascontiguousarray(g, dtype=np.uint8)
+            st = C.c_int(0)
+            out.append(self.lib.bo_ssvs_log_model_prob(h, _u8(g), C.byref(st)))
+        self.lib.bo_ssvs_destroy(h)
+        return np.array(out)
+
+    def prior_ctor1(self, suf, prior_nobs, expected_rsq, expected_model_size,
+                    first_term_is_intercept):
+        p = len(suf["xty"])
+        b = np.zeros(p)
+        om = np.zeros(p * p)
+        pi = np.zeros(p)
+        df = C.c_double()
+        sg = C.c_double()
+        self.lib.bo_breg_prior_ctor1.argtypes = [
+            C.c_int, c_double_p, C.c_double, C.c_double, C.c_double, C.c_double,
+            C.c_double, C.c_double, C.c_int, c_double_p, c_double_p, c_double_p,
+            c_double_p, c_double_p]
+        self.lib.bo_breg_prior_ctor1(p, _dp(fcol(suf["xtx"])), suf["yty"],
+                                     suf["n"], suf["sumy"], prior_nobs,
+                                     expected_rsq, expected_model_size,
+                                     int(first_term_is_intercept), _dp(b),
+                                     _dp(om), _dp(pi), C.byref(df), C.byref(sg))
+        return dict(b=b, ominv=om.reshape(p, p).T.copy(), pi=pi, df=df.value,
+                    sigma_guess=sg.value)
+
+    def prior_ctor2(self, suf, prior_sigma_nobs, prior_sigma_guess,
+                    prior_beta_nobs, diagonal_shrinkage,
+                    prior_inclusion_probability, force_intercept):
+        p = len(suf["xty"])
+        b = np.zeros(p)
+        om = np.zeros(p * p)
+        pi = np.zeros(p)
+        df = C.c_double()
+        sg = C.c_double()
+        self.lib.bo_breg_prior_ctor2.argtypes = [
+            C.c_int, c_double_p, C.c_double, C.c_double, C.c_double, C.c_double,
+            C.c_double, C.c_double, C.c_double, C.c_int, c_double_p, c_double_p,
+            c_double_p, c_double_p, c_double_p]
+        self.lib.bo_breg_prior_ctor2(p, _dp(fcol(suf["xtx"])), suf["n"],
+                                     suf["sumy"], prior_sigma_nobs,
+                                     prior_sigma_guess, prior_beta_nobs,
+                                     diagonal_shrinkage,
+                                     prior_inclusion_probability,
+                                     int(force_intercept), _dp(b), _dp(om),
+                                     _dp(pi), C.byref(df), C.byref(sg))
+        return dict(b=b, ominv=om.reshape(p, p).T.copy(), pi=pi, df=df.value,
+                    sigma_guess=sg.value)
+
+    def run_chains(self, suf, prior, opts, seed, chains, nsweeps, nthreads,
+                   init_gamma, init_beta=None, init_sigsq=None):
+        p = len(suf["xty"])
+        gam = np.ascontiguousarray(
+            np.broadcast_to(np.asarray(init_gamma, dtype=np.uint8),
+                            (chains, p))).copy()
+        beta = (np.zeros((chains, p)) if init_beta is None
+                else f64(np.broadcast_to(init_beta, (chains, p))).copy())
+        sig = (np.ones(chains) if init_sigsq is None
+               else f64(np.broadcast_to(init_sigsq, (chains,))).copy())
+        st = self.lib.bo_ssvs_run_chains(
+            p, _dp(fcol(suf["xtx"])), _dp(f64(suf["xty"])), suf["yty"],
+            suf["n"], suf["sumy"], _dp(f64(suf["xsum"])), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), prior["df"], prior["sigma_guess"],
+            _dp(f64(prior["pi"])), opts["max_model_size"],
+            opts["sigma_upper_limit"], opts["swap_threshold"],
+            opts["max_flips"], int(seed), chains, nsweeps, nthreads, _u8(gam),
+            _dp(beta), _dp(sig))
+        return dict(gamma=gam, beta=beta, sigsq=sig, status=st)
+
+    # -- state space -----------------------------------------------------------
+    def ss_create(self, y, X, observed, prior, ss):
+        T, p = X.shape
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        self._keep = (obs,)
+        return self.lib.bo_ss_create(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), prior["df"], prior["sigma_guess"],
+            _dp(f64(prior["pi"])), ss["level_df"], ss["level_sigma_guess"],
+            ss["level_sigma_upper_limit"], ss["initial_state_mean"],
+            ss["initial_state_variance"], ss["initial_level_sigma"])
+
+    def ss_run(self, y, X, observed, prior, opts, ss, rng_setup, init_gamma,
+               nsweeps):
+        T, p = X.shape
+        m = self.ss_create(y, X, observed, prior, ss)
+        reg = self.lib.bo_ss_regression(m)
+        self.lib.bo_ssvs_set_options(reg, opts["max_model_size"],
+                                     opts["sigma_upper_limit"],
+                                     opts["swap_threshold"], opts["max_flips"],
+                                     opts["draw_beta"], opts["draw_sigma"])
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self.lib.bo_ssvs_set_state(reg, _u8(g0), _dp(np.zeros(p)), 1.0)
+        rngs = [self.lib.bo_ssvs_rng(reg), self.lib.bo_ss_level_rng(m),
+                self.lib.bo_ss_state_rng(m)]
+        if rng_setup[0] == "mt":
+            glob = self.rng_mt(rng_setup[1])
+            for rp in rngs:  # construction order: regression, level, state
+                self.lib.bo_rng_seed_mt(rp, self.lib.bo_seed_rng(C.byref(glob)))
+        else:
+            for sid, rp in enumerate(rngs):
+                self.lib.bo_rng_seed_philox(rp, int(rng_setup[1]),
+                                            int(rng_setup[2]), sid, 0)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        lev = np.zeros(nsweeps)
+        state = np.zeros((nsweeps, T))
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        s = C.c_double()
+        status = 0
+        for i in range(nsweeps):
+            status = self.lib.bo_ss_draw(m)
+            if status:
+                break
+            self.lib.bo_ssvs_get_state(reg, _u8(g), _dp(b), C.byref(s))
+            gam[i] = g
+            beta[i] = b
+            sig[i] = s.value
+            lev[i] = self.lib.bo_ss_level_sigsq(m)
+            state[i] = np.ctypeslib.as_array(self.lib.bo_ss_state(m), (T,))
+        self.lib.bo_ss_destroy(m)
+        return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
+                    state=state, status=status)
+
+    def ss_impute_state(self, y, X, observed, beta, gamma, sigsq_obs,
+                        sigsq_level, a0, P0, rng):
+        T, p = X.shape
+        prior = dict(b=np.zeros(p), ominv=np.eye(p), df=1.0, sigma_guess=1.0,
+                     pi=np.full(p, 0.5))
+        ss = dict(level_df=1.0, level_sigma_guess=1.0,
+                  level_sigma_upper_limit=float("inf"), initial_state_mean=a0,
+                  initial_state_variance=P0,
+                  initial_level_sigma=float(np.sqrt(sigsq_level)))
+        m = self.ss_create(y, X, observed, prior, ss)
+        self.lib.bo_ss_set_level_sigsq(m, float(sigsq_level))
+        reg = self.lib.bo_ss_regression(m)
+        g = np.ascontiguousarray(gamma, dtype=np.uint8)
+        bb = f64(beta) * g
+        self.lib.bo_ssvs_set_state(reg, _u8(g), _dp(bb), float(sigsq_obs))
+        st = self.lib.bo_ss_impute_state(m, C.byref(rng))
+        assert st == 0
+        state = np.ctypeslib.as_array(self.lib.bo_ss_state(m), (T,)).copy()
+        n = C.c_double()
+        ssq = C.c_double()
+        self.lib.bo_ss_level_suf(m, C.byref(n), C.byref(ssq))
+        # regression suf lives in the bo_ssvs; read back through a tiny probe:
+        out = dict(state=state, level_n=n.value, level_sumsq=ssq.value)
+        self.lib.bo_ss_destroy(m)
+        return out
+
+
+# ---------------------------------------------------------------------------
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+class Ref:
+    """The compiled, unmodified reference (build container only)."""
+
+    def __init__(self):
+        self.lib = L = C.CDLL(REF_SO)
+        L.ref_last_error.restype = C.c_char_p
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.ref_last_error().decode())
+
+    def uniforms(self, seed, n):
+        out = np.zeros(n)
+        self._check(self.lib.ref_rng_uniform(C.c_uint64(seed), n, _dp(out)))
+        return out
+
+    def seed_rngs(self, seed, n):
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(self.lib.ref_seed_rng(C.c_uint64(seed), n,
+                                          out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def norms(self, seed, n):
+        out = np.zeros(n)
+        self._check(self.lib.ref_rng_norm(C.c_uint64(seed), n, _dp(out)))
+        return out
+
+    def exps(self, seed, n):
+        out = np.zeros(n)
+        self._check(self.lib.ref_rng_exp(C.c_uint64(seed), n, _dp(out)))
+        return out
+
+    def gammas(self, seed, a, b, n):
+        out = np.zeros(n)
+        self._check(self.lib.ref_rng_gamma(C.c_uint64(seed), C.c_double(a),
+                                           C.c_double(b), n, _dp(out)))
+        return out
+
+    def trun_gammas(self, seed, a, b, cut, n):
+        out = np.zeros(n)
+        self._check(self.lib.ref_rng_trun_gamma(C.c_uint64(seed), C.c_double(a),
+                                                C.c_double(b), C.c_double(cut),
+                                                n, _dp(out)))
+        return out
+
+    def random_ints(self, seed, lo, hi, n):
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.ref_rng_random_int(C.c_uint64(seed), lo, hi, n,
+                                                _ip(out)))
+        return out
+
+    def shuffles(self, seed, p, nrep):
+        out = np.zeros((nrep, p), dtype=np.int32)
+        self._check(self.lib.ref_rng_shuffle(C.c_uint64(seed), p, nrep,
+                                             _ip(out)))
+        return out
+
+    def rmultis(self, seed, prob, n):
+        prob = f64(prob)
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.ref_rng_rmulti(C.c_uint64(seed), len(prob),
+                                            _dp(prob), n, _ip(out)))
+        return out
+
+    def chol(self, A):
+        n = A.shape[0]
+        L = np.zeros(n * n)
+        ok = C.c_int()
+        self._check(self.lib.ref_spd_chol(n, _dp(fcol(A)), _dp(L), C.byref(ok)))
+        return L.reshape(n, n).T.copy(), bool(ok.value)
+
+    def logdet(self, A):
+        out = C.c_double()
+        ok = C.c_int()
+        self._check(self.lib.ref_spd_logdet(A.shape[0], _dp(fcol(A)),
+                                            C.byref(out), C.byref(ok)))
+        return out.value, bool(ok.value)
+
+    def solve(self, A, rhs):
+        n = A.shape[0]
+        x = np.zeros(n)
+        ok = C.c_int()
+        self._check(self.lib.ref_spd_solve(n, _dp(fcol(A)), _dp(f64(rhs)),
+                                           _dp(x), C.byref(ok)))
+        return x, bool(ok.value)
+
+    def mdist(self, A, x):
+        out = C.c_double()
+        self._check(self.lib.ref_spd_mdist(A.shape[0], _dp(fcol(A)),
+                                           _dp(f64(x)), C.byref(out)))
+        return out.value
+
+    def neregsuf(self, X, y):
+        n, p = X.shape
+        xtx = np.zeros(p * p)
+        xty = np.zeros(p)
+        yty = C.c_double()
+        ybar = C.c_double()
+        xbar = np.zeros(p)
+        self._check(self.lib.ref_neregsuf(n, p, _dp(fcol(X)), _dp(f64(y)),
+                                          _dp(xtx), _dp(xty), C.byref(yty),
+                                          C.byref(ybar), _dp(xbar)))
+        return dict(xtx=xtx.reshape(p, p).T.copy(), xty=xty, yty=yty.value,
+                    n=float(n), sumy=ybar.value * n, xsum=xbar * n,
+                    ybar=ybar.value, xbar=xbar)
+
+    def _opts(self, opts):
+        return RefSsvsOptions(**opts)
+
+    def ssvs_run(self, X, y, suf, prior, opts, seed, init_gamma, nsweeps):
+        """X,y given -> data path; else sufficient-statistics path."""
+        if X is not None:
+            n, p = X.shape
+        else:
+            n, p = int(suf["n"]), len(suf["xty"])
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        o = self._opts(opts)
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        if X is not None:
+            args = (_dp(fcol(X)), _dp(f64(y)), None, None, C.c_double(0),
+                    C.c_double(0), None)
+        else:
+            args = (None, None, _dp(fcol(suf["xtx"])), _dp(f64(suf["xty"])),
+                    C.c_double(suf["yty"]), C.c_double(suf["sumy"] / suf["n"]),
+                    _dp(f64(suf["xsum"] / suf["n"])))
+        self._check(self.lib.ref_ssvs_run(
+            n, p, *args, _dp(f64(prior["b"])), _dp(fcol(prior["ominv"])),
+            C.c_double(prior["df"]), C.c_double(prior["sigma_guess"]),
+            _dp(f64(prior["pi"])), C.byref(o), C.c_uint64(seed), _u8(g0),
+            nsweeps, _u8(gam), _dp(beta), _dp(sig)))
+        return dict(gamma=gam, beta=beta, sigsq=sig)
+
+    def ssvs_run_ctor(self, which, X, y, args5, flag, opts, seed, init_gamma,
+                      nsweeps):
+        n, p = X.shape
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        o = self._opts(opts)
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        a = [C.c_double(v) for v in args5]
+        self._check(self.lib.ref_ssvs_run_ctor(
+            which, n, p, _dp(fcol(X)), _dp(f64(y)), *a, int(flag), C.byref(o),
+            C.c_uint64(seed), _u8(g0), nsweeps, _u8(gam), _dp(beta), _dp(sig)))
+        return dict(gamma=gam, beta=beta, sigsq=sig)
+
+    def log_model_prob(self, suf, prior, gammas, max_model_size=-1):
+        p = len(suf["xty"])
+        G = np.ascontiguousarray(gammas, dtype=np.uint8)
+        out = np.zeros(len(G))
+        self._check(self.lib.ref_ssvs_log_model_prob(
+            int(suf["n"]), p, _dp(fcol(suf["xtx"])), _dp(f64(suf["xty"])),
+            C.c_double(suf["yty"]), C.c_double(suf["sumy"] / suf["n"]),
+            _dp(f64(suf["xsum"] / suf["n"])), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
+            C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+            C.c_int64(max_model_size), len(G), _u8(G), _dp(out)))
+        return out
+
+    def ss_run(self, y, X, observed, prior, opts, ss, seed, init_gamma,
+               nsweeps):
+        T, p = X.shape
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        lev = np.zeros(nsweeps)
+        state = np.zeros((nsweeps, T))
+        o = self._opts(opts)
+        so = RefSsOptions(**ss)
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self._check(self.lib.ref_ss_run(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
+            C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+            C.byref(o), C.byref(so), C.c_uint64(seed), _u8(g0), nsweeps,
+            _u8(gam), _dp(beta), _dp(sig), _dp(lev), _dp(state)))
+        return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
+                    state=state)
+
+    def ss_impute_state(self, y, X, observed, beta, gamma, sigsq_obs,
+                        sigsq_level, a0, P0, seed):
+        T, p = X.shape
+        state = np.zeros(T)
+        xty = np.zeros(p)
+        yty = C.c_double()
+        n = C.c_double()
+        ls = C.c_double()
+        ln = C.c_double()
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        g = np.ascontiguousarray(gamma, dtype=np.uint8)
+        self._check(self.lib.ref_ss_impute_state(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs), _dp(f64(beta)), _u8(g),
+            C.c_double(sigsq_obs), C.c_double(sigsq_level), C.c_double(a0),
+            C.c_double(P0), C.c_uint64(seed), _dp(state), _dp(xty),
+            C.byref(yty), C.byref(n), C.byref(ls), C.byref(ln)))
+        return dict(state=state, xty=xty, yty=yty.value, n=n.value,
+                    level_sumsq=ls.value, level_n=ln.value)
