@@ -1,0 +1,222 @@
+"""Pins the CPU oracle (oracle/boom_oracle.c) against fixtures produced by the
+compiled, unmodified reference (tests/golden/make_golden.py).  Runs anywhere:
+no GPU, no /root/reference.
+
+Tolerances: discrete outputs (inclusion indicators, permutations, integer
+draws) bit-exact; scalar RNG transforms bit-exact (same libm); continuous
+draws that go through Eigen-vectorised reductions in the reference <= 1e-9
+relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import ssvs_options
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-9
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def relerr(a, b, floor=1e-3):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def prior_of(g):
+    return dict(b=g["prior_b"], ominv=g["prior_ominv"], df=float(g["prior_df"]),
+                sigma_guess=float(g["prior_sigma_guess"]), pi=g["prior_pi"])
+
+
+def opts_of(g):
+    return ssvs_options(max_model_size=int(g["opt_max_model_size"]),
+                        sigma_upper_limit=float(g["opt_sigma_upper_limit"]),
+                        swap_threshold=float(g["opt_swap_threshold"]),
+                        max_flips=int(g["opt_max_flips"]))
+
+
+# --------------------------------------------------------------------- RNG
+def test_rng_known_answers(oracle):
+    g = load("kat_rng")
+    seed = int(g["seed"])
+    O = oracle
+    assert np.array_equal(O.uniforms(O.rng_mt(seed), 512), g["uniform"])
+    assert np.array_equal(O.seed_rngs(O.rng_mt(seed), 32), g["seed_rng"])
+    assert np.array_equal(O.norms(O.rng_mt(seed), 2048), g["norm"])
+    assert np.array_equal(O.exps(O.rng_mt(seed), 1024), g["exp"])
+    for a, want in zip(g["gamma_shapes"], g["gamma"]):
+        got = O.gammas(O.rng_mt(seed), float(a), float(g["gamma_rate"]), 1024)
+        assert np.array_equal(got, want), a
+    a, b, cut = g["trun_gamma_args"]
+    assert np.array_equal(O.trun_gammas(O.rng_mt(seed), a, b, cut, 1024),
+                          g["trun_gamma"])
+    assert np.array_equal(O.random_ints(O.rng_mt(seed), 0, 511, 1024),
+                          g["random_int"])
+    assert np.array_equal(O.shuffles(O.rng_mt(seed), 512, 4), g["shuffle"])
+    assert np.array_equal(O.rmultis(O.rng_mt(seed), g["rmulti_prob"], 512),
+                          g["rmulti"])
+
+
+def test_philox_known_answers(oracle):
+    """Published Philox4x32-10 test vectors (Random123 kat_vectors)."""
+    import ctypes as C
+    vec = [
+        ((0, 0, 0, 0), (0, 0),
+         (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff, 0xffffffff),
+         (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+         (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in vec:
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        oracle.lib.bo_philox4x32_10(c, k, o)
+        assert tuple(o) == want
+
+
+def test_philox_stream_layout(oracle):
+    """uniform i of a stream = half (i&1) of block (i>>1), (x>>11)*2^-53;
+    streams are random-access via pos."""
+    a = oracle.uniforms(oracle.rng_philox(123, chain=5, stream=0), 64)
+    b = oracle.uniforms(oracle.rng_philox(123, chain=5, stream=0, pos=17), 8)
+    assert np.array_equal(a[17:25], b)
+    assert np.all((a >= 0) & (a < 1))
+    c = oracle.uniforms(oracle.rng_philox(123, chain=6, stream=0), 64)
+    assert not np.any(a == c)
+
+
+# ------------------------------------------------------------------ LinAlg
+def test_linalg_known_answers(oracle):
+    g = load("kat_linalg")
+    oa = ol = ov = 0
+    for i, n in enumerate(g["sizes"]):
+        A = g["A"][oa:oa + n * n].reshape(n, n)
+        Lw = g["L"][ol:ol + n * n].reshape(n, n)
+        rhs = g["rhs"][ov:ov + n]
+        x = g["x"][ov:ov + n]
+        L, ok = oracle.chol(A)
+        assert ok and relerr(L, Lw, 1e-6) < 1e-11
+        ld, ok = oracle.logdet(A)
+        assert ok and abs(ld - g["logdet"][i]) < 1e-11 * max(1, abs(ld))
+        sol, ok = oracle.solve(A, rhs)
+        assert ok and relerr(sol, g["sol"][ov:ov + n], 1e-6) < 1e-9
+        assert abs(oracle.mdist(A, x) - g["mdist"][i]) < 1e-11 * g["mdist"][i]
+        oa += n * n
+        ol += n * n
+        ov += n
+    assert oracle.logdet(g["notpd"])[1] == bool(g["notpd_logdet_ok"]) is False
+    assert oracle.solve(g["notpd"], np.ones(3))[1] == bool(g["notpd_solve_ok"])
+
+
+def test_neregsuf(oracle):
+    g = load("ssvs_c1")
+    suf = oracle.neregsuf(g["X"], g["y"])
+    n = g["X"].shape[0]
+    assert relerr(suf["xtx"], g["xtx"], 1e-6) < 1e-12
+    assert relerr(suf["xty"], g["xty"], 1e-6) < 1e-12
+    assert abs(suf["yty"] - g["yty"]) < 1e-12 * g["yty"]
+    assert abs(suf["sumy"] / n - g["ybar"]) < 1e-13
+    assert relerr(suf["xsum"] / n, g["xbar"], 1e-6) < 1e-12
+
+
+# -------------------------------------------------------------------- SSVS
+def test_log_model_prob(oracle):
+    g = load("kat_log_model_prob")
+    n = float(g["n"])
+    suf = dict(xtx=g["xtx"], xty=g["xty"], yty=float(g["yty"]), n=n,
+               sumy=float(g["ybar"]) * n, xsum=g["xbar"] * n)
+    prior = prior_of(g)
+    got = oracle.log_model_prob(suf, prior, g["gammas"])
+    assert relerr(got, g["logp"]) < 1e-12
+    got3 = oracle.log_model_prob(suf, prior, g["gammas"], max_model_size=3)
+    want3 = g["logp_max3"]
+    assert np.array_equal(np.isneginf(got3), np.isneginf(want3))
+    m = np.isfinite(want3)
+    assert relerr(got3[m], want3[m]) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["ssvs_c1", "ssvs_p64", "ssvs_collinear",
+                                  "ssvs_general", "ssvs_maxflips"])
+def test_ssvs_sweeps_match_reference(oracle, name):
+    g = load(name)
+    suf = oracle.neregsuf(g["X"], g["y"])
+    prior = prior_of(g)
+    opts = opts_of(g)
+    for i, seed in enumerate(g["seeds"]):
+        o = oracle.ssvs_run(suf, prior, opts, ("mt", int(seed)),
+                            g["init_gamma"], int(g["nsweeps"]),
+                            want_margin=True)
+        assert o["status"] == 0
+        assert np.array_equal(o["gamma"], g["gamma"][i]), name
+        assert relerr(o["beta"], g["beta"][i]) < RTOL
+        assert relerr(o["sigsq"], g["sigsq"][i]) < RTOL
+        # decisions were never within rounding of the accept boundary
+        assert o["min_margin"] > 1e-7
+
+
+def test_ssvs_reference_acceptance_criteria():
+    """The reference's own statistical checks re-expressed on its draws
+    (regression_spike_slab_test.cc:124-171, :207-257)."""
+    g = load("ssvs_general")
+    assert g["gamma"][0].sum(axis=1).max() <= 4          # max_model_size
+    assert np.sqrt(g["sigsq"][0]).max() <= 1.08          # sigma upper limit
+    g = load("ssvs_collinear")
+    inc = g["gamma"][0][:, [1, 2, 3, 7]]
+    assert inc.sum(axis=1).mean() > 0.9   # one of the collinear set is in
+    g = load("ssvs_maxflips")
+    ch = np.abs(np.diff(g["gamma"][0].astype(int), axis=0)).sum(axis=1)
+    assert ch.max() <= 5 + 2              # <= max_flips (+ one swap move)
+
+
+def test_convenience_ctor_priors(oracle):
+    g = load("ssvs_ctors")
+    suf = oracle.neregsuf(g["X"], g["y"])
+    a = g["ctor1_args"]
+    p1 = oracle.prior_ctor1(suf, a[0], a[1], a[2], bool(g["ctor1_flag"]))
+    o = oracle.ssvs_run(suf, p1, ssvs_options(), ("mt", int(g["seed"])),
+                        g["init_gamma"], int(g["nsweeps"]))
+    assert np.array_equal(o["gamma"], g["gamma1"])
+    assert relerr(o["beta"], g["beta1"]) < RTOL
+    assert relerr(o["sigsq"], g["sigsq1"]) < RTOL
+    a = g["ctor2_args"]
+    p2 = oracle.prior_ctor2(suf, a[0], a[1], a[2], a[3], a[4],
+                            bool(g["ctor2_flag"]))
+    o = oracle.ssvs_run(suf, p2, ssvs_options(), ("mt", int(g["seed"])),
+                        g["init_gamma"], int(g["nsweeps"]))
+    assert np.array_equal(o["gamma"], g["gamma2"])
+    assert relerr(o["beta"], g["beta2"]) < RTOL
+    assert relerr(o["sigsq"], g["sigsq2"]) < RTOL
+
+
+# ------------------------------------------------------------- state space
+@pytest.mark.parametrize("name", ["ss_t200", "ss_t200_missing"])
+def test_state_space_sweeps_match_reference(oracle, name):
+    g = load(name)
+    ss = dict(zip([str(k) for k in g["ss_keys"]], [float(v) for v in g["ss_vals"]]))
+    obs = g["observed"]
+    o = oracle.ss_run(g["y"], g["X"], None if obs.all() else obs, prior_of(g),
+                      opts_of(g), ss, ("mt", int(g["seed"])), g["init_gamma"],
+                      int(g["nsweeps"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < RTOL
+    assert relerr(o["sigsq"], g["sigsq"]) < RTOL
+    assert relerr(o["level_sigsq"], g["level_sigsq"]) < RTOL
+    assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
+
+
+def test_impute_state_known_answer(oracle):
+    g = load("kat_impute_state")
+    o = oracle.ss_impute_state(g["y"], g["X"], g["observed"], g["beta"],
+                               g["gamma"], float(g["sigsq_obs"]),
+                               float(g["sigsq_level"]), float(g["a0"]),
+                               float(g["P0"]), oracle.rng_mt(int(g["seed"])))
+    assert np.max(np.abs(o["state"] - g["state"])) < 1e-11
+    assert o["level_n"] == float(g["level_n"])
+    assert abs(o["level_sumsq"] - float(g["level_sumsq"])) < 1e-11 * float(g["level_sumsq"])
