@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gibbs sweeps/sec (all chains) for BOOM's spike-and-slab
+sampler at BASELINE.json config 2 -- n=1e4, p=512, 1024 chains per MI355X, fp64.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: SWEEPS_PER_STEP
+BregVsSampler::draw() sweeps of every chain resident on the GPU, issued as one
+kernel launch through the C-ABI.  Inputs (XtX, priors, chain state) are resident
+in HBM before the timed region.  Weak scaling: every rank owns 1024 chains
+(global chain ids rank*1024 ..), no collective on the data path, one RCCL
+all-gather of the posterior-summary block at the end.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_OBS, P, N_SIGNAL = 10000, 512, 16
+CHAINS_PER_GPU = 1024
+SWEEPS_PER_STEP = 20
+BURN_IN = 200
+ESS_SWEEPS = 400
+DATA_SEED = 8675309
+SAMPLER_SEED = 8675309
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def geyer_ess(x):
+    """ESS of one scalar trace by Geyer's initial positive sequence on the
+    autocorrelation (BOOM has no ESS routine; stats/acf.hpp:28 is its only
+    building block -- SURVEY 8d)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    x = x - x.mean()
+    var = float(x @ x) / n
+    if var <= 0 or n < 4:
+        return float(n)
+    f = np.fft.rfft(x, 2 * n)
+    acf = np.fft.irfft(f * np.conj(f))[:n].real / (n * var)
+    s = 0.0
+    for m in range(0, n // 2 - 1):
+        pair = acf[2 * m] + acf[2 * m + 1]
+        if pair <= 0:
+            break
+        s += pair
+    tau = max(2.0 * s - 1.0, 1.0 / n)
+    return min(float(n), n / tau)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import boom_amd
+    from cases import regression_data, spike_slab_prior
+
+    # ---- synthetic workload -------------------------------
+    X, y, _ = regression_data(N_OBS, P, N_SIGNAL, seed=DATA_SEED)
+    eng = boom_amd.Engine(CHAINS_PER_GPU, seed=SAMPLER_SEED, device=local_rank,
+                          chain_offset=rank * CHAINS_PER_GPU)
+    # X, y go to HBM as torch tensors; XtX / Xty are built on the device
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()  # column-major n x p
+    yd = torch.from_numpy(y).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.build_suf_from_xy_device(N_OBS, P, Xd.data_ptr(), yd.data_ptr())
+    suf_build_s = time.perf_counter() - t0
+    s = eng.get_suf()
+    suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"],
+               sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])
+    prior = spike_slab_prior(suf, N_SIGNAL)  # pi_0 = 1, pi_j = 16/p
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"],
+                   prior["sigma_guess"])
+    g0 = np.zeros(P, np.uint8)
+    g0[0] = 1
+    eng.set_state(g0)
+    eng.sweep(BURN_IN)
+
+    # ---- timed region -------------------------------------------------------
+    est = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", local_rank))
+    for _ in range(args.warmup):
+        eng.sweep(SWEEPS_PER_STEP, sync=False)
+    eng.sync()
+    eng.reset_summaries()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(est)
+    for _ in range(args.steps):
+        eng.sweep(SWEEPS_PER_STEP, sync=False)
+    ev1.record(est)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # avg launch duration
+
+    # ---- posterior summaries: one RCCL all-gather at the end ----------------
+    block = torch.empty(3 * P + 8, dtype=torch.float64, device="cuda")
+    eng.summaries_device(block.data_ptr())
+    if world > 1:
+        gathered = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(gathered, block)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        allb = torch.stack(gathered).cpu().numpy()
+    else:
+        allb = block.cpu().numpy()[None, :]
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    sc = allb[:, 3 * P:]
+    total_sweeps = float(sc[:, 0].sum())
+    kbar = float(sc[:, 3].sum() / total_sweeps)
+    incl = allb[:, :P].sum(axis=0) / total_sweeps
+    value = total_sweeps / elapsed
+
+    # ESS/s: an extra, untimed run of ESS_SWEEPS traced sweeps on rank 0
+    # (sigma^2, |gamma|, log posterior); ESS fraction x measured sweeps/s
+    trace_len = ESS_SWEEPS
+    eng.enable_traces(trace_len)
+    eng.sweep(trace_len)
+    tr = eng.get_traces(trace_len)
+    ess = {}
+    for name in ("sigsq", "model_size", "logp"):
+        ess[name] = sum(geyer_ess(tr[name][c]) for c in range(CHAINS_PER_GPU))
+    ess_frac = min(ess.values()) / (CHAINS_PER_GPU * trace_len)
+    ess_per_sec = ess_frac * value
+
+    # ---- roofline of the dominant kernel (ssvs_sweep_kernel) ----------------
+    f = 8.0
+    bytes_per_sweep = P * f * (2 * kbar + 4) + f * (3 * kbar + 4) + P / 8.0
+    flops_per_sweep = P * (4 * kbar ** 2 + 12 * kbar + 40) + kbar ** 3 / 3 + 4 * kbar ** 2
+    launch_bytes = bytes_per_sweep * CHAINS_PER_GPU * SWEEPS_PER_STEP
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel": "ssvs_sweep_kernel", "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_sweep": round(bytes_per_sweep, 1),
+                "algorithmic_flops_per_sweep": round(flops_per_sweep, 1),
+                "gflops": round(flops_per_sweep * CHAINS_PER_GPU * SWEEPS_PER_STEP
+                                / (kernel_ms * 1e-3) / 1e9, 2),
+                "note": "working set is cache/LDS resident: the HBM roofline is "
+                        "not the binding limit for this kernel (BASELINE.md sec. 3)"}
+
+    # ---- CPU baseline: the oracle (a port of the reference algorithm) -------
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle_lib import Oracle, ssvs_options
+        O = Oracle()
+        cores = os.cpu_count() or 1
+        nchains = max(cores, 8)
+        # warm start from the GPU's current state so that kbar matches
+        gam, beta, sig = eng.get_states()
+        nsw = 2
+        t0 = time.perf_counter()
+        O.run_chains(suf, prior, ssvs_options(), SAMPLER_SEED, nchains, nsw, cores,
+                     gam[0], beta[0], float(sig[0]))
+        dt = time.perf_counter() - t0
+        rate = nchains * nsw / dt
+        # scale the sample to ~10-20 s
+        nsw2 = int(max(2, min(2000, 15.0 * rate / nchains)))
+        t0 = time.perf_counter()
+        O.run_chains(suf, prior, ssvs_options(), SAMPLER_SEED, nchains, nsw2, cores,
+                     gam[0], beta[0], float(sig[0]))
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(nchains * nsw2 / dt, 2), "unit": "sweeps/s",
+               "cores": cores, "kind": "port",
+               "sample": "%d chains x %d sweeps of the same n=1e4 p=512 workload, "
+                         "warm-started at the GPU chains' state (kbar~%.1f), "
+                         "oracle/boom_oracle.c with %d pthreads"
+                         % (nchains, nsw2, kbar, cores)}
+
+    out = {
+        "metric": "Gibbs sweeps/sec (all chains), n=1e4 p=512 spike-slab",
+        "value": round(value, 1),
+        "unit": "sweeps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "BregVsSampler spike-and-slab n=1e4 p=512, "
+                               "1024 chains per GPU, fp64 (BASELINE configs[1])",
+                   "chains_per_gpu": CHAINS_PER_GPU,
+                   "sweeps_per_step": SWEEPS_PER_STEP,
+                   "true_signals": N_SIGNAL, "mean_model_size": round(kbar, 2),
+                   "burn_in": BURN_IN, "parallelism": "chains sharded, %d GPU(s)" % world},
+        "ess_per_sec": round(ess_per_sec, 1),
+        "ess_fraction": round(ess_frac, 4),
+        "suf_build_ms": round(suf_build_s * 1e3, 2),
+        "signal_inclusion_min": round(float(incl[:N_SIGNAL].min()), 4),
+        "null_inclusion_max": round(float(incl[N_SIGNAL:].max()), 4),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,313 @@
+"""ctypes plumbing over the C-ABI (include/boom_amd.h, boom_amd/libboomamd.so).
+
+This is NOT a compute path: every call goes straight into the HIP library and
+fails loudly when the library or a GPU is missing.  There is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libboomamd.so")
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+SUMMARY_SCALARS = 8
+
+
+class BoomAmdError(RuntimeError):
+    """The C-ABI returned an error; mirrors BOOM's report_error ->
+    std::runtime_error (cpputil/report_error.cpp:30-32)."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+class BaConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("chains", C.c_int32),
+                ("chain_offset", C.c_int64), ("seed", C.c_uint64),
+                ("max_model_size_hint", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol include/boom_amd.h declares
+SIGNATURES = {
+    "ba_last_error": (C.c_char_p, []),
+    "ba_engine_create": (C.c_int, [C.POINTER(BaConfig), C.POINTER(C.c_void_p)]),
+    "ba_engine_destroy": (None, [C.c_void_p]),
+    "ba_engine_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ba_build_suf_from_xy": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp]),
+    "ba_build_suf_from_xy_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
+                                              C.c_void_p, C.c_void_p]),
+    "ba_upload_regression_suf": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp,
+                                           C.c_double, C.c_double, C.c_double, _dp]),
+    "ba_get_regression_suf": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "ba_set_slab": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "ba_set_spike": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
+    "ba_set_sigma_prior": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "ba_set_priors_ctor1": (C.c_int, [C.c_void_p, C.c_double, C.c_double,
+                                      C.c_double, C.c_int32]),
+    "ba_set_priors_ctor2": (C.c_int, [C.c_void_p, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, C.c_double, C.c_int32]),
+    "ba_get_priors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
+    "ba_set_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
+    "ba_set_state": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _dp, C.c_double]),
+    "ba_get_state": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _dp, _dp]),
+    "ba_get_states": (C.c_int, [C.c_void_p, _u8p, _dp, _dp]),
+    "ba_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "ba_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_sync": (C.c_int, [C.c_void_p]),
+    "ba_log_model_prob": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _dp]),
+    "ba_reset_summaries": (C.c_int, [C.c_void_p]),
+    "ba_get_summaries": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "ba_summaries_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ba_enable_traces": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_get_traces": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
+    "ba_stream": (C.c_void_p, [C.c_void_p]),
+    "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
+    "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
+    "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_ss_impute_state": (C.c_int, [C.c_void_p]),
+    "ba_ss_get_state": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
+    "ba_ss_set_level_sigsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_double]),
+    "ba_ss_get_chain_suf": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp]),
+}
+
+
+def load_library():
+    """Load libboomamd.so (no GPU needed just to load it)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "boom_amd/libboomamd.so is missing: run `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (hipcc, gfx950).  There is "
+                "no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _fcol(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).T).ravel()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _b(a):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+class Engine:
+    """One engine = `chains` independent chains on one HIP device."""
+
+    def __init__(self, chains, seed=8675309, device=0, chain_offset=0,
+                 max_model_size_hint=0):
+        self.lib = load_library()
+        cfg = BaConfig(device, chains, chain_offset, seed, max_model_size_hint, 0)
+        h = C.c_void_p()
+        self._h = None
+        self._check(self.lib.ba_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.chains = chains
+        self.p = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BoomAmdError(rc, self.lib.ba_last_error().decode())
+
+    def close(self):
+        if self._h is not None:
+            self.lib.ba_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data ---------------------------------------------------------------
+    def build_suf_from_xy(self, X, y):
+        n, p = X.shape
+        self._check(self.lib.ba_build_suf_from_xy(self._h, n, p, _p(_fcol(X)), _p(_f64(y))))
+        self.p = p
+
+    def build_suf_from_xy_device(self, n, p, x_ptr, y_ptr):
+        self._check(self.lib.ba_build_suf_from_xy_device(self._h, n, p, x_ptr, y_ptr))
+        self.p = p
+
+    def upload_suf(self, xtx, xty, yty, n, ybar, xbar):
+        p = len(xty)
+        self._check(self.lib.ba_upload_regression_suf(
+            self._h, p, _p(_fcol(xtx)), _p(_f64(xty)), yty, n, ybar, _p(_f64(xbar))))
+        self.p = p
+
+    def get_suf(self):
+        p = self.p
+        xtx = np.zeros(p * p)
+        xty = np.zeros(p)
+        xbar = np.zeros(p)
+        yty, n, ybar = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.ba_get_regression_suf(self._h, _p(xtx), _p(xty), C.byref(yty),
+                                                   C.byref(n), C.byref(ybar), _p(xbar)))
+        return dict(xtx=xtx.reshape(p, p).T.copy(), xty=xty, yty=yty.value,
+                    n=n.value, ybar=ybar.value, xbar=xbar)
+
+    # ---- priors -------------------------------------------------------------
+    def set_priors(self, b, ominv, pi, prior_df, sigma_guess,
+                   max_model_size=-1, sigma_upper_limit=float("inf")):
+        self._check(self.lib.ba_set_slab(self._h, _p(_f64(b)), _p(_fcol(ominv))))
+        self._check(self.lib.ba_set_spike(self._h, _p(_f64(pi)), int(max_model_size)))
+        self._check(self.lib.ba_set_sigma_prior(self._h, prior_df, sigma_guess,
+                                                sigma_upper_limit))
+
+    def set_priors_ctor1(self, prior_nobs, expected_rsq, expected_model_size,
+                         first_term_is_intercept=True):
+        self._check(self.lib.ba_set_priors_ctor1(self._h, prior_nobs, expected_rsq,
+                                                 expected_model_size,
+                                                 int(first_term_is_intercept)))
+
+    def set_priors_ctor2(self, prior_sigma_nobs, prior_sigma_guess, prior_beta_nobs,
+                         diagonal_shrinkage, prior_inclusion_probability,
+                         force_intercept=True):
+        self._check(self.lib.ba_set_priors_ctor2(
+            self._h, prior_sigma_nobs, prior_sigma_guess, prior_beta_nobs,
+            diagonal_shrinkage, prior_inclusion_probability, int(force_intercept)))
+
+    def get_priors(self):
+        p = self.p
+        b, om, pi = np.zeros(p), np.zeros(p * p), np.zeros(p)
+        df, ss = C.c_double(), C.c_double()
+        self._check(self.lib.ba_get_priors(self._h, _p(b), _p(om), _p(pi),
+                                           C.byref(df), C.byref(ss)))
+        return dict(b=b, ominv=om.reshape(p, p).T.copy(), pi=pi, df=df.value, ss=ss.value)
+
+    def set_options(self, max_flips=-1, swap_threshold=0.8, draw_beta=True,
+                    draw_sigma=True):
+        self._check(self.lib.ba_set_options(self._h, max_flips, swap_threshold,
+                                            int(draw_beta), int(draw_sigma)))
+
+    # ---- state --------------------------------------------------------------
+    def set_state(self, gamma, beta=None, sigsq=1.0, chain=-1):
+        g = np.ascontiguousarray(gamma, dtype=np.uint8)
+        bb = None if beta is None else _f64(beta)
+        self._check(self.lib.ba_set_state(self._h, chain, _b(g), _p(bb), sigsq))
+
+    def get_state(self, chain):
+        p = self.p
+        g = np.zeros(p, np.uint8)
+        b = np.zeros(p)
+        s = C.c_double()
+        self._check(self.lib.ba_get_state(self._h, chain, _b(g), _p(b), C.byref(s)))
+        return g, b, s.value
+
+    def get_states(self):
+        p, c = self.p, self.chains
+        g = np.zeros((c, p), np.uint8)
+        b = np.zeros((c, p))
+        s = np.zeros(c)
+        self._check(self.lib.ba_get_states(self._h, _b(g), _p(b), _p(s)))
+        return g, b, s
+
+    def seed(self, seed):
+        self._check(self.lib.ba_seed(self._h, seed))
+
+    # ---- sampling -----------------------------------------------------------
+    def sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._check(self.lib.ba_sync(self._h))
+
+    def log_model_prob(self, gammas):
+        G = np.ascontiguousarray(gammas, dtype=np.uint8)
+        out = np.zeros(len(G))
+        self._check(self.lib.ba_log_model_prob(self._h, len(G), _b(G), _p(out)))
+        return out
+
+    # ---- summaries ----------------------------------------------------------
+    def reset_summaries(self):
+        self._check(self.lib.ba_reset_summaries(self._h))
+
+    def get_summaries(self):
+        p = self.p
+        inc, bs, bs2 = np.zeros(p), np.zeros(p), np.zeros(p)
+        sc = np.zeros(SUMMARY_SCALARS)
+        self._check(self.lib.ba_get_summaries(self._h, _p(inc), _p(bs), _p(bs2), _p(sc)))
+        return dict(inclusion_count=inc, beta_sum=bs, beta_sumsq=bs2,
+                    sweeps=sc[0], sigsq_sum=sc[1], sigsq_sumsq=sc[2], k_sum=sc[3],
+                    accepts=sc[4], proposals=sc[5], min_margin=sc[6])
+
+    def summaries_device(self, ptr):
+        self._check(self.lib.ba_summaries_device(self._h, ptr))
+
+    def enable_traces(self, max_sweeps):
+        self._check(self.lib.ba_enable_traces(self._h, max_sweeps))
+
+    def get_traces(self, nsweeps):
+        c = self.chains
+        s, l, k = (np.zeros((c, nsweeps)) for _ in range(3))
+        self._check(self.lib.ba_get_traces(self._h, nsweeps, _p(s), _p(l), _p(k)))
+        return dict(sigsq=s, logp=l, model_size=k)
+
+    def stream(self):
+        return self.lib.ba_stream(self._h)
+
+    # ---- state space --------------------------------------------------------
+    def ss_set_data(self, y, X, observed=None):
+        T, p = X.shape
+        obs = None if observed is None else np.ascontiguousarray(observed, np.uint8)
+        self._check(self.lib.ba_ss_set_data(self._h, T, p, _p(_f64(y)), _p(_fcol(X)), _b(obs)))
+        self.p = p
+        self.T = T
+
+    def ss_set_local_level(self, level_df, level_sigma_guess, level_sigma_upper_limit,
+                           initial_state_mean, initial_state_variance,
+                           initial_level_sigma):
+        self._check(self.lib.ba_ss_set_local_level(
+            self._h, level_df, level_sigma_guess, level_sigma_upper_limit,
+            initial_state_mean, initial_state_variance, initial_level_sigma))
+
+    def ss_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_ss_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
+
+    def ss_impute_state(self):
+        self._check(self.lib.ba_ss_impute_state(self._h))
+        self.sync()
+
+    def ss_get_state(self, chain):
+        st = np.zeros(self.T)
+        ls, n, ss = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.ba_ss_get_state(self._h, chain, _p(st), C.byref(ls),
+                                             C.byref(n), C.byref(ss)))
+        return dict(state=st, level_sigsq=ls.value, level_n=n.value, level_sumsq=ss.value)
+
+    def ss_set_level_sigsq(self, sigsq, chain=-1):
+        self._check(self.lib.ba_ss_set_level_sigsq(self._h, chain, sigsq))
+
+    def ss_get_chain_suf(self, chain):
+        xty = np.zeros(self.p)
+        yty, n = C.c_double(), C.c_double()
+        self._check(self.lib.ba_ss_get_chain_suf(self._h, chain, _p(xty), C.byref(yty),
+                                                 C.byref(n)))
+        return dict(xty=xty, yty=yty.value, n=n.value)

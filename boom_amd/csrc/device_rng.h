@@ -1,0 +1,276 @@
+// Device-side random number streams for the many-chain engine (gfx950).
+//
+// One Philox4x32-10 counter stream per (sampler seed, global chain id, stream
+// id) stands in for the private BOOM::RNG every PosteriorSampler owns
+// (Models/PosteriorSamplers/PosteriorSampler.cpp:34-40, distributions/rng.hpp:27-54).
+// Uniform number i of a stream is 64-bit half (i & 1) of Philox block (i >> 1),
+// mapped to [0,1) as (x >> 11) * 2^-53, so any lane can fetch any position:
+// the p-1 shuffle uniforms and the p flip uniforms of a sweep are generated
+// lane-parallel, the data-dependent tail (swap move, sigma, beta) walks the
+// stream sequentially exactly like the reference's rng() calls.
+//
+// The transforms below follow the reference's Bmath routines so that a chain
+// consumes the stream in the reference's order:
+//   runif_mt      Bmath/runif.cpp:45-52
+//   random_int_mt distributions/random_int.cpp:26-29
+//   norm_rand     Bmath/snorm.cpp:287-340 (Kinderman-Ramage, Leydold fix)
+//   exp_rand      Bmath/sexp.cpp:58-104
+//   rgamma_mt     Bmath/rgamma.cpp:80-259 (GD for a >= 1, GS for .3 <= a < 1)
+//   rtrun_gamma   distributions/trun_gamma.cpp:73-81 (rejection branch)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace boom_amd {
+
+struct PhiloxKey {
+  uint32_t k0, k1;   // sampler seed
+  uint32_t chain;    // global chain id
+  uint32_t stream;   // sampler id within the chain
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
+                                              uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0);
+    const uint32_t lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2);
+    const uint32_t lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0;
+    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform number `idx` of the stream, in [0, 1)
+__device__ __forceinline__ double philox_uniform(const PhiloxKey &key,
+                                                 uint64_t idx) {
+  const uint64_t block = idx >> 1;
+  uint32_t o[4];
+  philox4x32_10((uint32_t)block, (uint32_t)(block >> 32), key.chain,
+                key.stream, key.k0, key.k1, o);
+  const uint64_t x = (idx & 1) ? ((uint64_t)o[2] | ((uint64_t)o[3] << 32))
+                               : ((uint64_t)o[0] | ((uint64_t)o[1] << 32));
+  return (double)(x >> 11) * 0x1.0p-53;
+}
+
+// Sequential view of a stream (the reference's `rng()`).
+struct SeqRng {
+  PhiloxKey key;
+  uint64_t pos;
+  __device__ __forceinline__ double operator()() {
+    return philox_uniform(key, pos++);
+  }
+};
+
+__device__ __forceinline__ double d_runif(SeqRng &r, double a, double b) {
+  if (a == b) return a;
+  return a + (b - a) * r();
+}
+
+__device__ __forceinline__ int d_random_int(SeqRng &r, int lo, int hi) {
+  return (int)floor(d_runif(r, (double)lo, (double)(hi + 1)));
+}
+
+__device__ inline double d_norm_rand(SeqRng &r) {
+  const double A = 2.216035867166471;
+  const double C1 = 0.398942280401433, C2 = 0.180025191068563;
+#define BA_KR_G(x) (C1 * exp(-(x) * (x) / 2.0) - C2 * (A - (x)))
+  double u1 = r(), u2, u3, tt;
+  if (u1 < 0.884070402298758) {
+    u2 = r();
+    return A * (1.131131635444180 * u1 + u2 - 1);
+  }
+  if (u1 >= 0.973310954173898) {
+    for (;;) {
+      u2 = r();
+      u3 = r();
+      tt = (A * A - 2 * log(u3));
+      if (u2 * u2 < (A * A) / tt)
+        return (u1 < 0.986655477086949) ? sqrt(tt) : -sqrt(tt);
+    }
+  }
+  if (u1 >= 0.958720824790463) {
+    for (;;) {
+      u2 = r();
+      u3 = r();
+      tt = A - 0.630834801921960 * fmin(u2, u3);
+      if (fmax(u2, u3) <= 0.755591531667601) return (u2 < u3) ? tt : -tt;
+      if (0.034240503750111 * fabs(u2 - u3) <= BA_KR_G(tt))
+        return (u2 < u3) ? tt : -tt;
+    }
+  }
+  if (u1 >= 0.911312780288703) {
+    for (;;) {
+      u2 = r();
+      u3 = r();
+      tt = 0.479727404222441 + 1.105473661022070 * fmin(u2, u3);
+      if (fmax(u2, u3) <= 0.872834976671790) return (u2 < u3) ? tt : -tt;
+      if (0.049264496373128 * fabs(u2 - u3) <= BA_KR_G(tt))
+        return (u2 < u3) ? tt : -tt;
+    }
+  }
+  for (;;) {
+    u2 = r();
+    u3 = r();
+    tt = 0.479727404222441 - 0.595507138015940 * fmin(u2, u3);
+    if (tt < 0.) continue;
+    if (fmax(u2, u3) <= 0.805577924423817) return (u2 < u3) ? tt : -tt;
+    if (0.053377549506886 * fabs(u2 - u3) <= BA_KR_G(tt))
+      return (u2 < u3) ? tt : -tt;
+  }
+#undef BA_KR_G
+}
+
+// rnorm_mt, Bmath/rnorm.cpp:55-67: no draw when sigma == 0
+__device__ __forceinline__ double d_rnorm(SeqRng &r, double mu, double sigma) {
+  if (sigma == 0.) return mu;
+  return mu + sigma * d_norm_rand(r);
+}
+
+__device__ inline double d_exp_rand(SeqRng &r) {
+  // q[k-1] = sum_{i=1..k} log(2)^i / i!
+  const double q[16] = {
+      0.6931471805599453, 0.9333736875190459, 0.9888777961838675,
+      0.9984959252914960, 0.9998292811061389, 0.9999833164100727,
+      0.9999985691438767, 0.9999998906925558, 0.9999999924734159,
+      0.9999999995283275, 0.9999999999728814, 0.9999999999985598,
+      0.9999999999999289, 0.9999999999999968, 0.9999999999999999,
+      1.0000000000000000};
+  double a = 0., u = r();
+  while (u <= 0.0 || u >= 1.0) u = r();
+  for (;;) {
+    u += u;
+    if (u > 1.0) break;
+    a += q[0];
+  }
+  u -= 1.;
+  if (u <= q[0]) return a + u;
+  int i = 0;
+  double ustar = r(), umin = ustar;
+  do {
+    ustar = r();
+    if (ustar < umin) umin = ustar;
+    i++;
+  } while (u > q[i]);
+  return a + umin * q[0];
+}
+
+// Rmath::rgamma_mt(rng, a, scale).  *bad is set for a < 0.3 (the reference's
+// rloggamma_small_alpha branch, unreachable when shape = DF/2 with n >= 1).
+__device__ inline double d_rgamma_scale(SeqRng &rng, double a, double scale,
+                                        int *bad) {
+  const double sqrt32 = 5.656854, exp_m1 = 0.36787944117144232159;
+  const double q1 = 0.04166669, q2 = 0.02083148, q3 = 0.00801191,
+               q4 = 0.00144121, q5 = -7.388e-5, q6 = 2.4511e-4, q7 = 2.424e-4;
+  const double a1 = 0.3333333, a2 = -0.250003, a3 = 0.2000062,
+               a4 = -0.1662921, a5 = 0.1423657, a6 = -0.1367177,
+               a7 = 0.1233795;
+  if (a < .3) {
+    *bad = 1;
+    return 1.0;
+  }
+  if (a < 1.) {  // GS
+    const double e = 1.0 + exp_m1 * a;
+    double x;
+    for (;;) {
+      for (;;) {
+        const double p = e * rng();
+        if (p >= 1.0) {
+          x = -log((e - p) / a);
+          if (d_exp_rand(rng) >= (1.0 - a) * log(x)) break;
+        } else {
+          x = exp(log(p) / a);
+          if (d_exp_rand(rng) >= x) break;
+        }
+      }
+      if (x > 0) return scale * x;
+    }
+  }
+  const double s2 = a - 0.5, s = sqrt(s2), d = sqrt32 - s * 12.0;
+  double t = d_norm_rand(rng);
+  double x = s + 0.5 * t;
+  const double ret_val = x * x;
+  if (t >= 0.0) return scale * ret_val;
+  double u = rng();
+  if (d * u <= t * t * t) return scale * ret_val;
+  const double rr = 1.0 / a;
+  const double q0 =
+      ((((((q7 * rr + q6) * rr + q5) * rr + q4) * rr + q3) * rr + q2) * rr + q1) * rr;
+  double b, si, c;
+  if (a <= 3.686) {
+    b = 0.463 + s + 0.178 * s2;
+    si = 1.235;
+    c = 0.195 / s - 0.079 + 0.16 * s;
+  } else if (a <= 13.022) {
+    b = 1.654 + 0.0076 * s2;
+    si = 1.68 / s + 0.275;
+    c = 0.062 / s + 0.024;
+  } else {
+    b = 1.77;
+    si = 0.75;
+    c = 0.1515 / s;
+  }
+  double q, v;
+  if (x > 0.0) {
+    v = t / (s + s);
+    if (fabs(v) <= 0.25)
+      q = q0 + 0.5 * t * t *
+                   ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+    else
+      q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log1p(v);
+    if (log(1.0 - u) <= q) return scale * ret_val;
+  }
+  for (;;) {
+    const double e = d_exp_rand(rng);
+    u = rng();
+    u = u + u - 1.0;
+    t = (u < 0.0) ? b - si * e : b + si * e;
+    if (t >= -0.71874483771719) {
+      v = t / (s + s);
+      if (fabs(v) <= 0.25)
+        q = q0 + 0.5 * t * t *
+                     ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+      else
+        q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+      if (q > 0.0) {
+        const double w = expm1(q);
+        if (c * fabs(u) <= w * exp(e - 0.5 * t * t)) break;
+      }
+    }
+  }
+  x = s + 0.5 * t;
+  return scale * x * x;
+}
+
+// GenericGaussianVarianceSampler::draw,
+// Models/PosteriorSamplers/GenericGaussianVarianceSampler.cpp:44-63:
+// sigma^2 = 1 / Gamma(shape = DF/2, rate = SS/2), truncated to
+// sigma <= sigma_max when that is finite.  *bad: 1 = shape < .3, 2 = the
+// truncation point is at or above the mode (adaptive-rejection / slice
+// branches of rtrun_gamma_mt, not implemented on the device).
+__device__ inline double d_draw_variance(SeqRng &rng, double DF, double SS,
+                                         double sigma_max, int *bad) {
+  if (sigma_max == 0.0) return 0.0;
+  const double a = DF / 2, b = SS / 2;
+  if (isinf(sigma_max)) return 1.0 / d_rgamma_scale(rng, a, 1.0 / b, bad);
+  const double cut = 1.0 / (sigma_max * sigma_max);
+  const double mode = (a - 1) / b;
+  if (!(cut < mode)) {
+    *bad = 2;
+    return 1.0;
+  }
+  double x;
+  do {
+    x = d_rgamma_scale(rng, a, 1.0 / b, bad);
+  } while (x < cut && !*bad);
+  return 1.0 / x;
+}
+
+}  // namespace boom_amd

@@ -1,0 +1,872 @@
+// Host side of the C-ABI (include/boom_amd.h): owns the device buffers of one
+// engine, assembles priors the way BregVsSampler's constructors do, launches
+// the kernels and turns per-chain status words back into the reference's
+// error messages.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/boom_amd.h"
+#include "ssvs_params.h"
+
+namespace boom_amd {
+// ssvs_kernel.hip
+hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P, int nsweeps);
+hipError_t launch_ssvs_logp(hipStream_t stream, const SsvsParams &P,
+                            const uint8_t *gammas, int ngamma, double *out,
+                            int *status_out);
+hipError_t launch_ssvs_reduce_summaries(hipStream_t stream, const SsvsParams &P,
+                                        double *out);
+// suf_kernel.hip
+int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
+                       const double *y, double *xtx, double *xty,
+                       double *scalars /* yty, sumy */, double *xsum);
+// kalman_kernel.hip
+struct SsParams;
+}  // namespace boom_amd
+
+using namespace boom_amd;
+
+namespace {
+
+thread_local std::string g_error = "";
+
+int fail(int code, const std::string &msg) {
+  g_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                       \
+  do {                                                                      \
+    hipError_t err__ = (expr);                                              \
+    if (err__ != hipSuccess) {                                              \
+      return fail(BA_E_HIP, std::string(#expr) + ": " +                     \
+                                hipGetErrorString(err__));                  \
+    }                                                                       \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *ptr = nullptr;
+  size_t count = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  hipError_t resize(size_t n) {
+    if (n == count && ptr) return hipSuccess;
+    release();
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void **)&ptr, n * sizeof(T));
+    if (e == hipSuccess) count = n;
+    return e;
+  }
+};
+
+const char *status_message(int st) {
+  switch (st) {
+    case CHAIN_NOT_PD:
+      return "The posterior information matrix is not positive definite.  "
+             "Check your data or consider adjusting your prior.";
+    case CHAIN_NEGATIVE_SS:
+      return "Illegal data caused negative sum of squares in "
+             "Breg::set_reg_post_params.";
+    case CHAIN_ILLEGAL_START:
+      return "BregVsSampler did not start with a legal configuration.";
+    case CHAIN_RNG_BRANCH:
+      return "Truncated gamma draw: the truncation point is not below the "
+             "mode (sigma upper limit too tight), or the shape is below 0.3; "
+             "this regime is not implemented on the device.";
+    case CHAIN_FORECAST_VARIANCE:
+      return "Found a zero (or negative) forecast variance!";
+    case CHAIN_MODEL_TOO_LARGE:
+      return "A chain's model size exceeded the engine's working capacity "
+             "(create the engine with a larger max_model_size_hint or fewer "
+             "chains per device).";
+    default:
+      return "unknown chain status";
+  }
+}
+
+int status_code(int st) {
+  switch (st) {
+    case CHAIN_NOT_PD: return BA_E_NOT_PD;
+    case CHAIN_NEGATIVE_SS: return BA_E_NEGATIVE_SS;
+    case CHAIN_ILLEGAL_START: return BA_E_ILLEGAL_START;
+    case CHAIN_RNG_BRANCH: return BA_E_RNG_BRANCH;
+    case CHAIN_FORECAST_VARIANCE: return BA_E_FORECAST_VARIANCE;
+    case CHAIN_MODEL_TOO_LARGE: return BA_E_MODEL_TOO_LARGE;
+    default: return BA_E_INVALID;
+  }
+}
+
+}  // namespace
+
+struct ba_engine {
+  ba_config cfg{};
+  hipStream_t stream = nullptr;
+  int p = 0;
+  int cu_count = 256;
+  size_t lds_per_cu = 160 * 1024;
+
+  // ---- host copies (RegSuf + priors)
+  bool have_suf = false, have_slab = false, have_spike = false,
+       have_sigma = false;
+  std::vector<double> xtx, xty, xsum;
+  double yty = 0, n = 0, sumy = 0;
+  std::vector<double> b, ominv, pi;
+  int64_t max_model_size = -1;
+  double prior_df = 0, prior_ss = 0, sigma_guess = 0;
+  double sigma_max = std::numeric_limits<double>::infinity();
+  int max_flips = -1;  // < 0: p
+  double swap_threshold = 0.8;
+  int draw_beta = 1, draw_sigma = 1;
+  bool device_dirty = true;   // V/A/b/logpi/cm need (re)upload
+  bool state_ready = false;
+
+  // ---- device: shared
+  DevBuf<double> dV, dA, db, dl1, dl0, dpi, dxty, dscal /* yty, n */;
+  DevBuf<int32_t> dcm_start, dcm_idx;
+  DevBuf<double> dcm_cor;
+  bool cm_enabled = false;
+  // ---- device: per chain
+  DevBuf<uint8_t> dgamma;
+  DevBuf<double> dbeta, dsigsq;
+  DevBuf<uint16_t> dperm;
+  DevBuf<uint64_t> dpos;
+  DevBuf<int32_t> dstatus, dfail;
+  DevBuf<uint32_t> dinc;
+  DevBuf<double> dbsum, dbsumsq, dacc, dsummary;
+  DevBuf<double> dtr_sig, dtr_logp, dtr_k;
+  int trace_stride = 0;
+  // scratch for suf build
+  DevBuf<double> dX, dy, dxtx, dxsum, dsufscal;
+
+  int kcap = 0;
+  uint64_t seed = 0;
+};
+
+namespace {
+
+// CorrelationMap::fill, Models/Glm/PosteriorSamplers/CorrelationMap.cpp:41-59
+void build_correlation_map(const ba_engine &e, std::vector<int32_t> &start,
+                           std::vector<int32_t> &idx,
+                           std::vector<double> &cor) {
+  const int p = e.p;
+  const double n = e.n;
+  std::vector<double> xbar(p), sd(p);
+  for (int i = 0; i < p; ++i) xbar[i] = e.xsum[i] / n;
+  auto cov = [&](int i, int j) {
+    return (e.xtx[(size_t)j * p + i] + (-n) * xbar[i] * xbar[j]) / (n - 1);
+  };
+  for (int i = 0; i < p; ++i) {
+    sd[i] = std::sqrt(cov(i, i));
+    if (!(sd[i] > 0.0)) sd[i] = 1.0;
+  }
+  start.assign(p + 1, 0);
+  idx.clear();
+  cor.clear();
+  for (int i = 0; i < p; ++i) {
+    start[i] = (int32_t)idx.size();
+    for (int j = 0; j < p; ++j) {
+      if (j == i) continue;
+      const double c = std::fabs(cov(i, j) / (sd[i] * sd[j]));
+      if (c >= e.swap_threshold) {
+        idx.push_back(j);
+        cor.push_back(c);
+      }
+    }
+  }
+  start[p] = (int32_t)idx.size();
+}
+
+int choose_kcap(const ba_engine &e) {
+  const int p = e.p;
+  int want = std::min(64, p);
+  if (e.cfg.max_model_size_hint > 0) want = std::min(want, std::max(1, (int)e.cfg.max_model_size_hint));
+  if (e.max_model_size >= 0) want = std::min<int64_t>(want, std::max<int64_t>(1, e.max_model_size));
+  // every chain resident at once when possible: blocks per CU needed
+  const int per_cu = std::max(1, (e.cfg.chains + e.cu_count - 1) / e.cu_count);
+  const size_t budget_all = e.lds_per_cu / (size_t)per_cu;
+  int k = want;
+  if (e.cfg.max_model_size_hint <= 0) {
+    while (k > 8 && ssvs_lds_layout(p, k).total > budget_all) --k;
+  }
+  while (k > 1 && ssvs_lds_layout(p, k).total > e.lds_per_cu) --k;
+  return k;
+}
+
+int upload_shared(ba_engine *e) {
+  if (!e->device_dirty) return BA_OK;
+  const int p = e->p;
+  if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
+  if (!e->have_slab || !e->have_spike || !e->have_sigma)
+    return fail(BA_E_STATE, "priors (slab, spike, sigma) must be set before sampling");
+  const size_t pp = (size_t)p * p;
+  std::vector<double> V(pp), l1(p), l0(p), scal(2);
+  for (size_t i = 0; i < pp; ++i) V[i] = e->ominv[i] + e->xtx[i];
+  // VariableSelectionPrior::ensure_log_probabilities,
+  // VariableSelectionPrior.cpp:310-317
+  for (int j = 0; j < p; ++j) {
+    l1[j] = std::log(e->pi[j]);
+    l0[j] = std::log(1 - e->pi[j]);
+  }
+  scal[0] = e->yty;
+  scal[1] = e->n;
+  HIP_TRY(e->dV.resize(pp));
+  HIP_TRY(e->dA.resize(pp));
+  HIP_TRY(e->db.resize(p));
+  HIP_TRY(e->dl1.resize(p));
+  HIP_TRY(e->dl0.resize(p));
+  HIP_TRY(e->dpi.resize(p));
+  HIP_TRY(e->dxty.resize(p));
+  HIP_TRY(e->dscal.resize(2));
+  hipStream_t s = e->stream;
+  HIP_TRY(hipMemcpyAsync(e->dV.ptr, V.data(), pp * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->dA.ptr, e->ominv.data(), pp * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->db.ptr, e->b.data(), p * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->dl1.ptr, l1.data(), p * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->dl0.ptr, l0.data(), p * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->dpi.ptr, e->pi.data(), p * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->dxty.ptr, e->xty.data(), p * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->dscal.ptr, scal.data(), 16, hipMemcpyHostToDevice, s));
+  e->cm_enabled = e->swap_threshold < 1.0;
+  if (e->cm_enabled) {
+    std::vector<int32_t> start, idx;
+    std::vector<double> cor;
+    build_correlation_map(*e, start, idx, cor);
+    HIP_TRY(e->dcm_start.resize(start.size()));
+    HIP_TRY(e->dcm_idx.resize(std::max<size_t>(1, idx.size())));
+    HIP_TRY(e->dcm_cor.resize(std::max<size_t>(1, cor.size())));
+    HIP_TRY(hipMemcpyAsync(e->dcm_start.ptr, start.data(), start.size() * 4, hipMemcpyHostToDevice, s));
+    if (!idx.empty()) {
+      HIP_TRY(hipMemcpyAsync(e->dcm_idx.ptr, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(e->dcm_cor.ptr, cor.data(), cor.size() * 8, hipMemcpyHostToDevice, s));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  e->kcap = choose_kcap(*e);
+  e->device_dirty = false;
+  return BA_OK;
+}
+
+int alloc_chain_state(ba_engine *e) {
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
+  if (e->state_ready && e->dgamma.count == C * p) return BA_OK;
+  HIP_TRY(e->dgamma.resize(C * p));
+  HIP_TRY(e->dbeta.resize(C * p));
+  HIP_TRY(e->dsigsq.resize(C));
+  HIP_TRY(e->dperm.resize(C * p));
+  HIP_TRY(e->dpos.resize(C));
+  HIP_TRY(e->dstatus.resize(C));
+  HIP_TRY(e->dfail.resize(C));
+  HIP_TRY(e->dinc.resize(C * p));
+  HIP_TRY(e->dbsum.resize(C * p));
+  HIP_TRY(e->dbsumsq.resize(C * p));
+  HIP_TRY(e->dacc.resize(C * ACC_COUNT));
+  HIP_TRY(e->dsummary.resize(3 * p + SUMMARY_SCALARS));
+  // defaults: gamma = 0, beta = 0, sigsq = 1 (RegressionModel(xdim)), perm =
+  // identity (seq<uint>(0, p-1), BregVsSampler.cpp:186), stream position 0
+  std::vector<uint16_t> perm(C * p);
+  for (size_t c = 0; c < C; ++c)
+    for (size_t j = 0; j < p; ++j) perm[c * p + j] = (uint16_t)j;
+  std::vector<double> ones(C, 1.0);
+  hipStream_t s = e->stream;
+  HIP_TRY(hipMemsetAsync(e->dgamma.ptr, 0, C * p, s));
+  HIP_TRY(hipMemsetAsync(e->dbeta.ptr, 0, C * p * 8, s));
+  HIP_TRY(hipMemcpyAsync(e->dsigsq.ptr, ones.data(), C * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->dperm.ptr, perm.data(), C * p * 2, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(e->dpos.ptr, 0, C * 8, s));
+  HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, C * 4, s));
+  HIP_TRY(hipMemsetAsync(e->dfail.ptr, 0, C * 4, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  e->state_ready = true;
+  return ba_reset_summaries(e);
+}
+
+void fill_params(ba_engine *e, SsvsParams &P) {
+  std::memset(&P, 0, sizeof(P));
+  P.p = e->p;
+  P.chains = e->cfg.chains;
+  P.chain_offset = e->cfg.chain_offset;
+  P.kcap = e->kcap;
+  P.V = e->dV.ptr;
+  P.A = e->dA.ptr;
+  P.b = e->db.ptr;
+  P.l1 = e->dl1.ptr;
+  P.l0 = e->dl0.ptr;
+  P.pi = e->dpi.ptr;
+  P.xty = e->dxty.ptr;
+  P.xty_stride = 0;
+  P.yty = e->dscal.ptr;
+  P.nobs = e->dscal.ptr + 1;
+  P.suf_stride = 0;
+  P.prior_df = e->prior_df;
+  P.prior_ss = e->prior_ss;
+  P.sigma_max = e->sigma_max;
+  P.swap_threshold = e->swap_threshold;
+  P.max_model_size = e->max_model_size;
+  const int mf = e->max_flips < 0 ? e->p : e->max_flips;
+  P.max_flips = std::min(mf, e->p);
+  P.draw_beta = e->draw_beta;
+  P.draw_sigma = e->draw_sigma;
+  P.cm_start = e->cm_enabled ? e->dcm_start.ptr : nullptr;
+  P.cm_idx = e->dcm_idx.ptr;
+  P.cm_cor = e->dcm_cor.ptr;
+  P.gamma = e->dgamma.ptr;
+  P.beta = e->dbeta.ptr;
+  P.sigsq = e->dsigsq.ptr;
+  P.perm = e->dperm.ptr;
+  P.rng_pos = e->dpos.ptr;
+  P.status = e->dstatus.ptr;
+  P.failures = e->dfail.ptr;
+  P.seed_lo = (uint32_t)e->seed;
+  P.seed_hi = (uint32_t)(e->seed >> 32);
+  P.stream = 0;
+  P.inc_count = e->dinc.ptr;
+  P.beta_sum = e->dbsum.ptr;
+  P.beta_sumsq = e->dbsumsq.ptr;
+  P.acc = e->dacc.ptr;
+  P.trace_sigsq = e->dtr_sig.ptr;
+  P.trace_logp = e->dtr_logp.ptr;
+  P.trace_k = e->dtr_k.ptr;
+  P.trace_stride = e->trace_stride;
+}
+
+int check_chain_status(ba_engine *e) {
+  const size_t C = (size_t)e->cfg.chains;
+  if (!e->state_ready) return BA_OK;
+  std::vector<int32_t> st(C);
+  HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+  for (size_t c = 0; c < C; ++c) {
+    if (st[c] != CHAIN_OK) {
+      char buf[64];
+      std::snprintf(buf, sizeof buf, " (chain %lld)",
+                    (long long)(e->cfg.chain_offset + (int64_t)c));
+      return fail(status_code(st[c]), std::string(status_message(st[c])) + buf);
+    }
+  }
+  return BA_OK;
+}
+
+int set_device(const ba_engine *e) {
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  return BA_OK;
+}
+
+#define ENGINE_PROLOGUE(e)                                     \
+  if (!(e)) return fail(BA_E_INVALID, "null engine");          \
+  {                                                            \
+    int rc__ = set_device(e);                                  \
+    if (rc__) return rc__;                                     \
+  }
+
+}  // namespace
+
+extern "C" {
+
+const char *ba_last_error(void) { return g_error.c_str(); }
+
+int ba_engine_create(const ba_config *cfg, ba_engine **out) {
+  if (!cfg || !out) return fail(BA_E_INVALID, "null argument");
+  if (cfg->chains <= 0) return fail(BA_E_INVALID, "chains must be positive");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0)
+    return fail(BA_E_HIP, "no HIP device visible: boom_amd has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(BA_E_INVALID, "device ordinal out of range");
+  ba_engine *e = new ba_engine();
+  e->cfg = *cfg;
+  e->seed = cfg->seed;
+  hipError_t err = hipSetDevice(cfg->device);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (err != hipSuccess) {
+    delete e;
+    return fail(BA_E_HIP, std::string("stream creation: ") + hipGetErrorString(err));
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
+    e->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.maxSharedMemoryPerMultiProcessor > 0)
+      e->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+  }
+  *out = e;
+  return BA_OK;
+}
+
+void ba_engine_destroy(ba_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamDestroy(e->stream);
+  }
+  delete e;
+}
+
+int ba_engine_info(const ba_engine *e, int32_t *device, int32_t *chains,
+                   int32_t *p) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (device) *device = e->cfg.device;
+  if (chains) *chains = e->cfg.chains;
+  if (p) *p = e->p;
+  return BA_OK;
+}
+
+void *ba_stream(ba_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+// ---------------------------------------------------------------- data
+static int set_dimension(ba_engine *e, int p) {
+  if (p <= 0 || p > 65535)
+    return fail(BA_E_INVALID, "number of predictors must be in [1, 65535]");
+  if (e->p != p) {
+    e->p = p;
+    e->have_slab = e->have_spike = false;
+    e->state_ready = false;
+  }
+  return BA_OK;
+}
+
+int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
+                             const double *xty, double yty, double n,
+                             double ybar, const double *xbar) {
+  ENGINE_PROLOGUE(e);
+  if (!xtx || !xty || !xbar) return fail(BA_E_INVALID, "null argument");
+  int rc = set_dimension(e, p);
+  if (rc) return rc;
+  e->xtx.assign(xtx, xtx + (size_t)p * p);
+  e->xty.assign(xty, xty + p);
+  e->xsum.resize(p);
+  for (int j = 0; j < p; ++j) e->xsum[j] = xbar[j] * n;
+  e->yty = yty;
+  e->n = n;
+  e->sumy = ybar * n;
+  e->have_suf = true;
+  e->device_dirty = true;
+  return BA_OK;
+}
+
+int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
+                                const void *X_device, const void *y_device) {
+  ENGINE_PROLOGUE(e);
+  if (!X_device || !y_device) return fail(BA_E_INVALID, "null argument");
+  if (n <= 0) return fail(BA_E_INVALID, "n must be positive");
+  int rc = set_dimension(e, p);
+  if (rc) return rc;
+  HIP_TRY(e->dxtx.resize((size_t)p * p));
+  HIP_TRY(e->dxty.resize(p));
+  HIP_TRY(e->dxsum.resize(p));
+  HIP_TRY(e->dsufscal.resize(2));
+  rc = launch_suf_from_xy(e->stream, n, p, (const double *)X_device,
+                          (const double *)y_device, e->dxtx.ptr, e->dxty.ptr,
+                          e->dsufscal.ptr, e->dxsum.ptr);
+  if (rc) return fail(BA_E_HIP, "suf kernel launch failed");
+  e->xtx.resize((size_t)p * p);
+  e->xty.resize(p);
+  e->xsum.resize(p);
+  double sc[2];
+  HIP_TRY(hipMemcpyAsync(e->xtx.data(), e->dxtx.ptr, (size_t)p * p * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->xty.data(), e->dxty.ptr, (size_t)p * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->xsum.data(), e->dxsum.ptr, (size_t)p * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(sc, e->dsufscal.ptr, 16, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->yty = sc[0];
+  e->sumy = sc[1];
+  e->n = (double)n;
+  e->have_suf = true;
+  e->device_dirty = true;
+  return BA_OK;
+}
+
+int ba_build_suf_from_xy(ba_engine *e, int64_t n, int32_t p, const double *X,
+                         const double *y) {
+  ENGINE_PROLOGUE(e);
+  if (!X || !y) return fail(BA_E_INVALID, "null argument");
+  if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
+  HIP_TRY(e->dX.resize((size_t)n * p));
+  HIP_TRY(e->dy.resize((size_t)n));
+  HIP_TRY(hipMemcpyAsync(e->dX.ptr, X, (size_t)n * p * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->dy.ptr, y, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+  int rc = ba_build_suf_from_xy_device(e, n, p, e->dX.ptr, e->dy.ptr);
+  e->dX.release();
+  e->dy.release();
+  return rc;
+}
+
+int ba_get_regression_suf(ba_engine *e, double *xtx, double *xty, double *yty,
+                          double *n, double *ybar, double *xbar) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
+  const int p = e->p;
+  if (xtx) std::memcpy(xtx, e->xtx.data(), (size_t)p * p * 8);
+  if (xty) std::memcpy(xty, e->xty.data(), (size_t)p * 8);
+  if (yty) *yty = e->yty;
+  if (n) *n = e->n;
+  if (ybar) *ybar = e->sumy / e->n;
+  if (xbar)
+    for (int j = 0; j < p; ++j) xbar[j] = e->xsum[j] / e->n;
+  return BA_OK;
+}
+
+// -------------------------------------------------------------- priors
+int ba_set_slab(ba_engine *e, const double *prior_mean,
+                const double *unscaled_prior_precision) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!prior_mean || !unscaled_prior_precision) return fail(BA_E_INVALID, "null argument");
+  if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
+  const int p = e->p;
+  e->b.assign(prior_mean, prior_mean + p);
+  e->ominv.assign(unscaled_prior_precision, unscaled_prior_precision + (size_t)p * p);
+  e->have_slab = true;
+  e->device_dirty = true;
+  return BA_OK;
+}
+
+int ba_set_spike(ba_engine *e, const double *pi, int64_t max_model_size) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!pi) return fail(BA_E_INVALID, "null argument");
+  if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
+  for (int j = 0; j < e->p; ++j)
+    if (!(pi[j] >= 0.0 && pi[j] <= 1.0))
+      return fail(BA_E_INVALID, "prior inclusion probabilities must be in [0, 1]");
+  e->pi.assign(pi, pi + e->p);
+  e->max_model_size = max_model_size;
+  e->have_spike = true;
+  e->device_dirty = true;
+  return BA_OK;
+}
+
+int ba_set_sigma_prior(ba_engine *e, double prior_df, double sigma_guess,
+                       double sigma_upper_limit) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (sigma_upper_limit < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
+  // ChisqModel(df, sigma): alpha = df/2, beta = df sigma^2/2 (ChisqModel.cpp:56-57)
+  const double alpha = prior_df / 2.0;
+  const double beta = prior_df * sigma_guess * sigma_guess / 2.0;
+  e->prior_df = 2 * alpha;
+  e->prior_ss = 2 * beta;
+  e->sigma_guess = sigma_guess;
+  e->sigma_max = sigma_upper_limit;
+  e->have_sigma = true;
+  return BA_OK;
+}
+
+int ba_set_priors_ctor1(ba_engine *e, double prior_nobs, double expected_rsq,
+                        double expected_model_size,
+                        int32_t first_term_is_intercept) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
+  if (!(expected_rsq > 0 && expected_rsq < 1)) return fail(BA_E_INVALID, "expected_rsq must be in (0, 1)");
+  // BregVsSampler.cpp:37-44, 48-85
+  const int p = e->p;
+  const double n = e->n, ybar = e->sumy / n;
+  const double sst = e->yty - n * ybar * ybar;
+  const double sigma_guess = std::sqrt(sst / (n - 1) * (1 - expected_rsq));
+  std::vector<double> b(p, 0.0), om((size_t)p * p), pi(p);
+  if (first_term_is_intercept) b[0] = ybar;
+  for (size_t i = 0; i < (size_t)p * p; ++i) om[i] = e->xtx[i] * (prior_nobs / n);
+  double prob = expected_model_size / p;
+  if (prob > 1) prob = 1.0;
+  std::fill(pi.begin(), pi.end(), prob);
+  if (first_term_is_intercept) pi[0] = 1.0;
+  int rc = ba_set_slab(e, b.data(), om.data());
+  if (!rc) rc = ba_set_spike(e, pi.data(), -1);
+  if (!rc) rc = ba_set_sigma_prior(e, prior_nobs, sigma_guess, e->sigma_max);
+  return rc;
+}
+
+int ba_set_priors_ctor2(ba_engine *e, double prior_sigma_nobs,
+                        double prior_sigma_guess, double prior_beta_nobs,
+                        double diagonal_shrinkage,
+                        double prior_inclusion_probability,
+                        int32_t force_intercept) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
+  // BregVsSampler.cpp:87-142
+  if (prior_sigma_guess <= 0)
+    return fail(BA_E_INVALID, "illegal value of prior_sigma_guess in constructor to BregVsSampler");
+  const double alpha = diagonal_shrinkage;
+  if (alpha > 1.0 || alpha < 0.0)
+    return fail(BA_E_INVALID, "illegal value of 'diagonal_shrinkage' in BregVsSampler constructor.");
+  const int p = e->p;
+  const double n = e->n;
+  std::vector<double> b(p, 0.0), om((size_t)p * p), pi(p, prior_inclusion_probability);
+  b[0] = e->sumy / n;
+  for (size_t i = 0; i < (size_t)p * p; ++i) om[i] = e->xtx[i] * (prior_beta_nobs / n);
+  if (alpha < 1.0) {
+    for (int j = 0; j < p; ++j) {
+      const double d = om[(size_t)j * p + j];
+      om[(size_t)j * p + j] = d + d * (alpha / (1 - alpha));
+    }
+    for (auto &v : om) v *= (1 - alpha);
+  } else {
+    for (int j = 0; j < p; ++j)
+      for (int i = 0; i < p; ++i)
+        if (i != j) om[(size_t)j * p + i] = 0.0;
+  }
+  if (force_intercept) pi[0] = 1.0;
+  int rc = ba_set_slab(e, b.data(), om.data());
+  if (!rc) rc = ba_set_spike(e, pi.data(), -1);
+  if (!rc) rc = ba_set_sigma_prior(e, prior_sigma_nobs, prior_sigma_guess, e->sigma_max);
+  return rc;
+}
+
+int ba_get_priors(ba_engine *e, double *prior_mean, double *ominv, double *pi,
+                  double *prior_df, double *prior_ss) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!e->have_slab || !e->have_spike || !e->have_sigma)
+    return fail(BA_E_STATE, "priors not set");
+  const int p = e->p;
+  if (prior_mean) std::memcpy(prior_mean, e->b.data(), (size_t)p * 8);
+  if (ominv) std::memcpy(ominv, e->ominv.data(), (size_t)p * p * 8);
+  if (pi) std::memcpy(pi, e->pi.data(), (size_t)p * 8);
+  if (prior_df) *prior_df = e->prior_df;
+  if (prior_ss) *prior_ss = e->prior_ss;
+  return BA_OK;
+}
+
+int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
+                   int32_t draw_beta, int32_t draw_sigma) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  e->max_flips = max_flips;
+  if (swap_threshold != e->swap_threshold) e->device_dirty = true;
+  e->swap_threshold = swap_threshold;
+  e->draw_beta = draw_beta;
+  e->draw_sigma = draw_sigma;
+  return BA_OK;
+}
+
+// --------------------------------------------------------------- state
+int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
+                 const double *beta, double sigsq) {
+  ENGINE_PROLOGUE(e);
+  if (e->p <= 0) return fail(BA_E_STATE, "set the regression data first");
+  if (!gamma) return fail(BA_E_INVALID, "null argument");
+  const int64_t C = e->cfg.chains;
+  if (chain < -1 || chain >= C) return fail(BA_E_INVALID, "chain index out of range");
+  int rc = alloc_chain_state(e);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p;
+  std::vector<double> zeros;
+  if (!beta) {
+    zeros.assign(p, 0.0);
+    beta = zeros.data();
+  }
+  const int64_t lo = chain < 0 ? 0 : chain, hi = chain < 0 ? C : chain + 1;
+  if (chain < 0) {
+    std::vector<uint8_t> G((size_t)C * p);
+    std::vector<double> B((size_t)C * p), S((size_t)C, sigsq);
+    for (int64_t c = 0; c < C; ++c) {
+      std::memcpy(&G[(size_t)c * p], gamma, p);
+      std::memcpy(&B[(size_t)c * p], beta, p * 8);
+    }
+    HIP_TRY(hipMemcpy(e->dgamma.ptr, G.data(), G.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->dbeta.ptr, B.data(), B.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->dsigsq.ptr, S.data(), S.size() * 8, hipMemcpyHostToDevice));
+  } else {
+    for (int64_t c = lo; c < hi; ++c) {
+      HIP_TRY(hipMemcpy(e->dgamma.ptr + (size_t)c * p, gamma, p, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(e->dbeta.ptr + (size_t)c * p, beta, p * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(e->dsigsq.ptr + c, &sigsq, 8, hipMemcpyHostToDevice));
+    }
+  }
+  return BA_OK;
+}
+
+int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
+                 double *sigsq) {
+  ENGINE_PROLOGUE(e);
+  if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p;
+  if (gamma) HIP_TRY(hipMemcpy(gamma, e->dgamma.ptr + (size_t)chain * p, p, hipMemcpyDeviceToHost));
+  if (beta) HIP_TRY(hipMemcpy(beta, e->dbeta.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost));
+  if (sigsq) HIP_TRY(hipMemcpy(sigsq, e->dsigsq.ptr + chain, 8, hipMemcpyDeviceToHost));
+  return BA_OK;
+}
+
+int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
+  ENGINE_PROLOGUE(e);
+  if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p, C = (size_t)e->cfg.chains;
+  if (gamma) HIP_TRY(hipMemcpy(gamma, e->dgamma.ptr, C * p, hipMemcpyDeviceToHost));
+  if (beta) HIP_TRY(hipMemcpy(beta, e->dbeta.ptr, C * p * 8, hipMemcpyDeviceToHost));
+  if (sigsq) HIP_TRY(hipMemcpy(sigsq, e->dsigsq.ptr, C * 8, hipMemcpyDeviceToHost));
+  return BA_OK;
+}
+
+int ba_seed(ba_engine *e, uint64_t seed) {
+  ENGINE_PROLOGUE(e);
+  e->seed = seed;
+  if (e->state_ready) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemset(e->dpos.ptr, 0, (size_t)e->cfg.chains * 8));
+  }
+  return BA_OK;
+}
+
+// ------------------------------------------------------------ hot path
+int ba_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  int rc = upload_shared(e);
+  if (rc) return rc;
+  rc = alloc_chain_state(e);
+  if (rc) return rc;
+  if (e->trace_stride > 0 && nsweeps > e->trace_stride)
+    return fail(BA_E_INVALID, "nsweeps exceeds the enabled trace length");
+  SsvsParams P;
+  fill_params(e, P);
+  const SsvsLds lay = ssvs_lds_layout(e->p, e->kcap);
+  if (lay.total > e->lds_per_cu)
+    return fail(BA_E_INVALID, "problem does not fit the LDS working set");
+  HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
+  return BA_OK;
+}
+
+int ba_sync(ba_engine *e) {
+  ENGINE_PROLOGUE(e);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return check_chain_status(e);
+}
+
+int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
+                      double *out) {
+  ENGINE_PROLOGUE(e);
+  if (!gammas || !out || ngamma <= 0) return fail(BA_E_INVALID, "bad argument");
+  int rc = upload_shared(e);
+  if (rc) return rc;
+  rc = alloc_chain_state(e);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p;
+  DevBuf<uint8_t> dg;
+  DevBuf<double> dout;
+  DevBuf<int32_t> dst;
+  HIP_TRY(dg.resize((size_t)ngamma * p));
+  HIP_TRY(dout.resize(ngamma));
+  HIP_TRY(dst.resize(ngamma));
+  HIP_TRY(hipMemcpyAsync(dg.ptr, gammas, (size_t)ngamma * p, hipMemcpyHostToDevice, e->stream));
+  SsvsParams P;
+  fill_params(e, P);
+  // this entry evaluates arbitrary models: use the largest working set
+  P.kcap = std::min(64, e->p);
+  while (P.kcap > 1 && ssvs_lds_layout(e->p, P.kcap).total > e->lds_per_cu) --P.kcap;
+  HIP_TRY(launch_ssvs_logp(e->stream, P, (const uint8_t *)dg.ptr, (int)ngamma,
+                           dout.ptr, dst.ptr));
+  std::vector<int32_t> st(ngamma);
+  HIP_TRY(hipMemcpyAsync(out, dout.ptr, (size_t)ngamma * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(st.data(), dst.ptr, (size_t)ngamma * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < ngamma; ++i)
+    if (st[i] != CHAIN_OK) return fail(status_code(st[i]), status_message(st[i]));
+  return BA_OK;
+}
+
+// ----------------------------------------------------------- summaries
+int ba_reset_summaries(ba_engine *e) {
+  ENGINE_PROLOGUE(e);
+  if (!e->state_ready) return BA_OK;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
+  hipStream_t s = e->stream;
+  HIP_TRY(hipMemsetAsync(e->dinc.ptr, 0, C * p * 4, s));
+  HIP_TRY(hipMemsetAsync(e->dbsum.ptr, 0, C * p * 8, s));
+  HIP_TRY(hipMemsetAsync(e->dbsumsq.ptr, 0, C * p * 8, s));
+  std::vector<double> acc(C * ACC_COUNT, 0.0);
+  for (size_t c = 0; c < C; ++c)
+    acc[c * ACC_COUNT + ACC_MIN_MARGIN] = std::numeric_limits<double>::infinity();
+  HIP_TRY(hipMemcpyAsync(e->dacc.ptr, acc.data(), acc.size() * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return BA_OK;
+}
+
+int ba_summaries_device(ba_engine *e, void *out_device) {
+  ENGINE_PROLOGUE(e);
+  if (!out_device) return fail(BA_E_INVALID, "null argument");
+  if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
+  SsvsParams P;
+  fill_params(e, P);
+  HIP_TRY(launch_ssvs_reduce_summaries(e->stream, P, (double *)out_device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return BA_OK;
+}
+
+int ba_get_summaries(ba_engine *e, double *inclusion_count, double *beta_sum,
+                     double *beta_sumsq, double *scalars) {
+  ENGINE_PROLOGUE(e);
+  int rc = ba_summaries_device(e, e->dsummary.ptr);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p;
+  std::vector<double> h(3 * p + SUMMARY_SCALARS);
+  HIP_TRY(hipMemcpy(h.data(), e->dsummary.ptr, h.size() * 8, hipMemcpyDeviceToHost));
+  if (inclusion_count) std::memcpy(inclusion_count, &h[0], p * 8);
+  if (beta_sum) std::memcpy(beta_sum, &h[p], p * 8);
+  if (beta_sumsq) std::memcpy(beta_sumsq, &h[2 * p], p * 8);
+  if (scalars) std::memcpy(scalars, &h[3 * p], SUMMARY_SCALARS * 8);
+  return BA_OK;
+}
+
+int ba_enable_traces(ba_engine *e, int32_t max_sweeps) {
+  ENGINE_PROLOGUE(e);
+  if (max_sweeps < 0) return fail(BA_E_INVALID, "max_sweeps must be non-negative");
+  const size_t C = (size_t)e->cfg.chains;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(e->dtr_sig.resize(C * max_sweeps));
+  HIP_TRY(e->dtr_logp.resize(C * max_sweeps));
+  HIP_TRY(e->dtr_k.resize(C * max_sweeps));
+  e->trace_stride = max_sweeps;
+  return BA_OK;
+}
+
+int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
+                  double *model_size) {
+  ENGINE_PROLOGUE(e);
+  if (e->trace_stride <= 0) return fail(BA_E_STATE, "traces are not enabled");
+  if (nsweeps <= 0 || nsweeps > e->trace_stride) return fail(BA_E_INVALID, "nsweeps out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains;
+  auto fetch = [&](double *dst, const double *src) -> hipError_t {
+    if (!dst) return hipSuccess;
+    return hipMemcpy2D(dst, (size_t)nsweeps * 8, src, (size_t)e->trace_stride * 8,
+                       (size_t)nsweeps * 8, C, hipMemcpyDeviceToHost);
+  };
+  HIP_TRY(fetch(sigsq, e->dtr_sig.ptr));
+  HIP_TRY(fetch(logp, e->dtr_logp.ptr));
+  HIP_TRY(fetch(model_size, e->dtr_k.ptr));
+  return BA_OK;
+}
+
+// --------------------------------------------------- state space (kalman)
+// Implemented in a later milestone of this round; the entry points exist so
+// that the ABI is complete and callers fail loudly rather than at link time.
+static int ss_unavailable() {
+  return fail(BA_E_STATE, "state-space path not built into this library yet");
+}
+int ba_ss_set_data(ba_engine *, int32_t, int32_t, const double *, const double *,
+                   const uint8_t *) { return ss_unavailable(); }
+int ba_ss_set_local_level(ba_engine *, double, double, double, double, double,
+                          double) { return ss_unavailable(); }
+int ba_ss_sweep(ba_engine *, int32_t) { return ss_unavailable(); }
+int ba_ss_impute_state(ba_engine *) { return ss_unavailable(); }
+int ba_ss_get_state(ba_engine *, int64_t, double *, double *, double *, double *) {
+  return ss_unavailable();
+}
+int ba_ss_set_level_sigsq(ba_engine *, int64_t, double) { return ss_unavailable(); }
+int ba_ss_get_chain_suf(ba_engine *, int64_t, double *, double *, double *) {
+  return ss_unavailable();
+}
+
+}  // extern "C"

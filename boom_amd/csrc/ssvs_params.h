@@ -1,0 +1,112 @@
+// Launch parameters and memory layout shared by the host side (engine.hip) and
+// the SSVS sweep kernel (ssvs_kernel.hip).
+#pragma once
+#include <stdint.h>
+
+namespace boom_amd {
+
+// per-chain status words written by the kernels (0 = ok)
+enum ChainStatus : int32_t {
+  CHAIN_OK = 0,
+  CHAIN_NOT_PD = 1,
+  CHAIN_NEGATIVE_SS = 2,
+  CHAIN_ILLEGAL_START = 3,
+  CHAIN_RNG_BRANCH = 4,
+  CHAIN_FORECAST_VARIANCE = 5,
+  CHAIN_MODEL_TOO_LARGE = 6
+};
+
+// number of doubles in the reduced summary block: 3p + SUMMARY_SCALARS
+enum { SUMMARY_SCALARS = 8 };
+// per-chain scalar accumulators (doubles)
+enum {
+  ACC_SWEEPS = 0,
+  ACC_SIGSQ = 1,
+  ACC_SIGSQ2 = 2,
+  ACC_K = 3,
+  ACC_ACCEPTS = 4,
+  ACC_PROPOSALS = 5,
+  ACC_MIN_MARGIN = 6,
+  ACC_RESERVED = 7,
+  ACC_COUNT = 8
+};
+
+struct SsvsParams {
+  int32_t p;
+  int32_t chains;
+  int64_t chain_offset;
+  int32_t kcap;  // largest model the LDS working set can hold (<= 64)
+
+  // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
+  const double *V;    // XtX + Omega^{-1}, p x p (symmetric, full storage)
+  const double *A;    // Omega^{-1}, p x p
+  const double *b;    // prior mean, p
+  const double *l1;   // log pi_j
+  const double *l0;   // log(1 - pi_j)
+  const double *pi;   // pi_j (make_valid)
+  // sufficient statistics: shared (stride 0) or per chain (state space)
+  const double *xty;  // [chain * xty_stride + j]
+  int64_t xty_stride;
+  const double *yty;  // [chain * suf_stride]
+  const double *nobs; // [chain * suf_stride]
+  int32_t suf_stride;
+
+  double prior_df, prior_ss, sigma_max, swap_threshold;
+  int64_t max_model_size;  // < 0: none
+  int32_t max_flips;       // min(max_nflips_, p) already applied; 0 = no selection
+  int32_t draw_beta, draw_sigma;
+
+  // CorrelationMap as CSR (CorrelationMap.cpp:41-59); cm_start == nullptr when
+  // the swap move is disabled (threshold >= 1)
+  const int32_t *cm_start;
+  const int32_t *cm_idx;
+  const double *cm_cor;
+
+  // per-chain state (HBM)
+  uint8_t *gamma;     // chains x p
+  double *beta;       // chains x p
+  double *sigsq;      // chains
+  uint16_t *perm;     // chains x p   (BregVsSampler::indx, persistent)
+  uint64_t *rng_pos;  // chains       (position in the sampler's stream)
+  int32_t *status;    // chains
+  int32_t *failures;  // chains       (failure_count_)
+
+  // RNG key
+  uint32_t seed_lo, seed_hi, stream;
+
+  // summaries (per chain; reduced over chains by a second kernel)
+  uint32_t *inc_count;  // chains x p
+  double *beta_sum;     // chains x p
+  double *beta_sumsq;   // chains x p
+  double *acc;          // chains x ACC_COUNT
+  // optional traces (nullptr = off): chains x trace_stride
+  double *trace_sigsq, *trace_logp, *trace_k;
+  int32_t trace_stride;
+};
+
+// ---- LDS layout of one chain (one wavefront) --------------------------------
+// doubles first, then 16-bit, then bytes; all offsets in bytes.
+struct SsvsLds {
+  uint32_t Lv, La, rdv, rda, w, bg, buf, g, perm, oth, gam, total;
+};
+
+static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
+  SsvsLds L;
+  const uint32_t tri = (uint32_t)kcap * (kcap + 1) / 2;
+  uint32_t o = 0;
+  L.Lv = o;   o += tri * 8;
+  L.La = o;   o += tri * 8;
+  L.rdv = o;  o += (uint32_t)kcap * 8;
+  L.rda = o;  o += (uint32_t)kcap * 8;
+  L.w = o;    o += (uint32_t)kcap * 8;
+  L.bg = o;   o += (uint32_t)kcap * 8;
+  L.buf = o;  o += (uint32_t)kcap * 64 * 8;
+  L.g = o;    o += (((uint32_t)kcap * 2) + 7u) & ~7u;
+  L.perm = o; o += (((uint32_t)p * 2) + 7u) & ~7u;
+  L.oth = o;  o += (((uint32_t)p * 2) + 7u) & ~7u;
+  L.gam = o;  o += ((uint32_t)p + 15u) & ~15u;
+  L.total = o;
+  return L;
+}
+
+}  // namespace boom_amd

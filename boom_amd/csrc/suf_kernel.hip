@@ -1,0 +1,153 @@
+// Sufficient statistics of a regression, built once per data set:
+//   XtX = X'X, Xty = X'y, yty = y'y, sum(y), column sums of X
+// (NeRegSuf(X, y), Models/Glm/RegressionModel.cpp:309-328; Matrix::inner,
+// LinAlg/Matrix.cpp:770-774).
+//
+// XtX is the one GEMM-shaped piece of the hot path (2 n p^2 flops, arithmetic
+// intensity p/8 flop/byte), so it goes to the f64 matrix cores:
+// v_mfma_f64_16x16x4_f64.  A 256-thread workgroup owns a 64 x 64 tile of XtX;
+// each of its 4 wavefronts accumulates a 32 x 32 quadrant as 2 x 2 MFMA tiles.
+// X is column-major n x p, so a column's rows are contiguous: the 32-row
+// panels of the two 64-column strips are staged through LDS with coalesced
+// 256-byte reads and a row stride of 34 doubles (== 2 mod 32 banks) so that
+// the A/B fragment reads (16 columns x 4 rows per instruction) are
+// conflict-free.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace boom_amd {
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TILE = 64;    // XtX tile edge per workgroup
+constexpr int KC = 32;      // rows of X per staging step
+constexpr int LDP = KC + 2; // padded panel stride (doubles)
+
+__global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict__ X,
+                                                       int64_t n, int p,
+                                                       double *__restrict__ xtx) {
+  __shared__ double sA[TILE * LDP];
+  __shared__ double sB[TILE * LDP];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (tj > ti) return;  // lower block-triangle only; mirrored on store
+  const int I0 = ti * TILE, J0 = tj * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;  // quadrant of the 64 x 64 tile
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int fr = lane >> 4;   // k index inside an MFMA step (0..3)
+  const int fc = lane & 15;   // row (A) / column (B) inside a 16-wide tile
+
+  for (int64_t r0 = 0; r0 < n; r0 += KC) {
+    // stage 64 columns x 32 rows of each strip: 2048 doubles, 8 per thread
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = it * 256 + tid;
+      const int col = e >> 5, row = e & 31;
+      const int64_t r = r0 + row;
+      const int ci = I0 + col, cj = J0 + col;
+      sA[col * LDP + row] = (r < n && ci < p) ? X[(int64_t)ci * n + r] : 0.0;
+      sB[col * LDP + row] = (r < n && cj < p) ? X[(int64_t)cj * n + r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      double a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = sA[(wi * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
+        b[t] = sB[(wj * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
+      }
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+          acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D layout of v_mfma_f64_16x16x4_f64: register q of lane l holds
+  // row (l >> 4) + 4 q, column l & 15.
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = I0 + wi * 32 + ta * 16 + (lane >> 4) + 4 * q;
+        const int j = J0 + wj * 32 + tb * 16 + (lane & 15);
+        if (i < p && j < p) {
+          const double v = acc[ta][tb][q];
+          xtx[(int64_t)j * p + i] = v;
+          xtx[(int64_t)i * p + j] = v;
+        }
+      }
+}
+
+// block j < p: sum_r X[r,j], sum_r X[r,j] y[r];  block p: sum y, sum y^2.
+// Fixed-shape tree reduction: bitwise reproducible run to run.
+__global__ __launch_bounds__(256) void col_reduce_kernel(const double *__restrict__ X,
+                                                         const double *__restrict__ y,
+                                                         int64_t n, int p,
+                                                         double *__restrict__ xty,
+                                                         double *__restrict__ xsum,
+                                                         double *__restrict__ scalars) {
+  __shared__ double s0[256], s1[256];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  if (j < p) {
+    const double *col = X + (int64_t)j * n;
+    for (int64_t r = tid; r < n; r += 256) {
+      const double x = col[r];
+      a += x;
+      b += x * y[r];
+    }
+  } else {
+    for (int64_t r = tid; r < n; r += 256) {
+      const double v = y[r];
+      a += v;
+      b += v * v;
+    }
+  }
+  s0[tid] = a;
+  s1[tid] = b;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (tid < w) {
+      s0[tid] += s0[tid + w];
+      s1[tid] += s1[tid + w];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (j < p) {
+      xsum[j] = s0[0];
+      xty[j] = s1[0];
+    } else {
+      scalars[0] = s1[0];  // yty
+      scalars[1] = s0[0];  // sum y
+    }
+  }
+}
+
+}  // namespace
+
+int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
+                       const double *y, double *xtx, double *xty,
+                       double *scalars, double *xsum) {
+  const int tiles = (p + TILE - 1) / TILE;
+  hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, stream,
+                     X, n, p, xtx);
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(p + 1), dim3(256), 0, stream, X, y,
+                     n, p, xty, xsum, scalars);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+}  // namespace boom_amd

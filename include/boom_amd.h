@@ -1,0 +1,205 @@
+/* boom_amd -- C-ABI of the MI355X many-chain engine for BOOM's spike-and-slab
+ * (BregVsSampler) and bsts local-level + regression (StateSpacePosteriorSampler)
+ * hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types, no exceptions.  Every entry point names the reference interface it
+ * stands in for (paths relative to the BOOM tree).  INTEGRATION.md shows the
+ * binding a BOOM maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns BA_OK (0) or a negative BA_E_* code;
+ *     ba_last_error() gives the message (same wording as the reference's
+ *     report_error() text where one exists, cpputil/report_error.cpp:30-32);
+ *   - matrices are column-major doubles exactly like BOOM::Matrix
+ *     (LinAlg/Matrix.hpp:429); host pointers unless the name says _device;
+ *   - caller owns every buffer it passes; the engine copies on call;
+ *   - an engine lives on ONE HIP device and runs `chains` independent chains,
+ *     global chain ids chain_offset .. chain_offset+chains-1 (the id keys the
+ *     Philox stream, so a job sharded over ranks draws the same numbers as the
+ *     same job on one device);
+ *   - "chain = -1" addresses all chains at once.
+ */
+#ifndef BOOM_AMD_H
+#define BOOM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  BA_OK = 0,
+  BA_E_INVALID = -1,       /* bad argument / dimension mismatch */
+  BA_E_HIP = -2,           /* HIP runtime failure (message has the HIP error) */
+  BA_E_NOT_PD = -3,        /* "The posterior information matrix is not positive
+                              definite..." BregVsSampler.cpp:339-350 */
+  BA_E_NEGATIVE_SS = -4,   /* "Illegal data caused negative sum of squares..."
+                              BregVsSampler.cpp:448-478 */
+  BA_E_ILLEGAL_START = -5, /* "BregVsSampler did not start with a legal
+                              configuration." BregVsSampler.cpp:364-370 */
+  BA_E_RNG_BRANCH = -6,    /* truncated-gamma regime (cut >= mode) that the
+                              device does not implement (trun_gamma.cpp:82-104) */
+  BA_E_FORECAST_VARIANCE = -7, /* "Found a zero (or negative) forecast
+                              variance!" ScalarKalmanFilter.cpp:48-52 */
+  BA_E_MODEL_TOO_LARGE = -8,   /* model size exceeded the engine's capacity */
+  BA_E_STATE = -9          /* call sequence error (e.g. sweep before priors) */
+};
+
+typedef struct ba_engine ba_engine;
+
+typedef struct ba_config {
+  int32_t device;        /* HIP device ordinal */
+  int32_t chains;        /* chains resident on this device */
+  int64_t chain_offset;  /* global id of local chain 0 */
+  uint64_t seed;         /* sampler seed: PosteriorSampler::set_seed,
+                            Models/PosteriorSamplers/PosteriorSampler.hpp:60 */
+  int32_t max_model_size_hint; /* <=0: engine chooses its working capacity */
+  int32_t reserved;
+} ba_config;
+
+/* message of the last failing call on this thread (never NULL) */
+const char *ba_last_error(void);
+
+/* ---- engine lifetime ---------------------------------------------------- */
+int ba_engine_create(const ba_config *cfg, ba_engine **out);
+void ba_engine_destroy(ba_engine *e);
+/* device ordinal, chain count, predictors (0 until data are set) */
+int ba_engine_info(const ba_engine *e, int32_t *device, int32_t *chains,
+                   int32_t *p);
+
+/* ---- data: RegressionModel / NeRegSuf ------------------------------------ */
+/* NeRegSuf(X, y), Models/Glm/RegressionModel.cpp:309-328: builds XtX, Xty,
+ * yty, n, sum(y), column sums of X on the device (f64 MFMA syrk).  X is n x p
+ * column-major. */
+int ba_build_suf_from_xy(ba_engine *e, int64_t n, int32_t p, const double *X,
+                         const double *y);
+/* same, X / y already resident in device memory of e's device */
+int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
+                                const void *X_device, const void *y_device);
+/* NeRegSuf(XTX, XTY, YTY, n, ybar, xbar), RegressionModel.cpp:330-345 */
+int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
+                             const double *xty, double yty, double n,
+                             double ybar, const double *xbar);
+/* RegSuf accessors xtx()/xty()/yty()/n()/ybar()/xbar(),
+ * RegressionModel.hpp:58-101.  Any output pointer may be NULL. */
+int ba_get_regression_suf(ba_engine *e, double *xtx, double *xty, double *yty,
+                          double *n, double *ybar, double *xbar);
+
+/* ---- priors: BregVsSampler ctor #5 pieces -------------------------------- */
+/* slab: MvnGivenScalarSigma(b, Omega^{-1}) (Models/MvnGivenScalarSigma.hpp:57-109;
+ * BregVsSampler::set_slab, BregVsSampler.hpp:111-113) */
+int ba_set_slab(ba_engine *e, const double *prior_mean,
+                const double *unscaled_prior_precision);
+/* spike: VariableSelectionPrior(pi) + set_max_model_size (< 0: none)
+ * (VariableSelectionPrior.hpp:101,133; BregVsSampler::set_spike) */
+int ba_set_spike(ba_engine *e, const double *prior_inclusion_probabilities,
+                 int64_t max_model_size);
+/* residual precision prior ChisqModel(df, sigma_guess) + set_sigma_upper_limit
+ * (ChisqModel.cpp:56-57; BregVsSampler.cpp:264-266); sigma_upper_limit = +inf
+ * for none */
+int ba_set_sigma_prior(ba_engine *e, double prior_df, double sigma_guess,
+                       double sigma_upper_limit);
+/* convenience ctors #1 and #2 (BregVsSampler.cpp:48-85, :87-142): assemble the
+ * three priors above from the current sufficient statistics */
+int ba_set_priors_ctor1(ba_engine *e, double prior_nobs, double expected_rsq,
+                        double expected_model_size,
+                        int32_t first_term_is_intercept);
+int ba_set_priors_ctor2(ba_engine *e, double prior_sigma_nobs,
+                        double prior_sigma_guess, double prior_beta_nobs,
+                        double diagonal_shrinkage,
+                        double prior_inclusion_probability,
+                        int32_t force_intercept);
+/* read back the assembled priors (any pointer may be NULL) */
+int ba_get_priors(ba_engine *e, double *prior_mean, double *ominv, double *pi,
+                  double *prior_df, double *prior_ss);
+
+/* limit_model_selection / suppress_model_selection (max_flips: <0 = p, 0 =
+ * none), set_correlation_swap_threshold, suppress_beta_draw /
+ * suppress_sigma_draw (BregVsSampler.hpp:131-161) */
+int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
+                   int32_t draw_beta, int32_t draw_sigma);
+
+/* ---- chain state: GlmCoefs (beta, inc) + sigsq ----------------------------- */
+/* coef().set_inc / set_Beta / set_sigsq.  gamma: p bytes (0/1), beta: p
+ * doubles (may be NULL = zeros).  chain = -1 sets every chain. */
+int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
+                 const double *beta, double sigsq);
+/* coef().inc() / Beta() / sigsq() of one chain (local index) */
+int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
+                 double *sigsq);
+/* all chains at once: gamma chains x p, beta chains x p, sigsq chains */
+int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq);
+/* PosteriorSampler::set_seed: re-keys every chain's stream, position 0 */
+int ba_seed(ba_engine *e, uint64_t seed);
+
+/* ---- the hot path ---------------------------------------------------------- */
+/* nsweeps x BregVsSampler::draw() (BregVsSampler.cpp:252-261) on every chain.
+ * Asynchronous: returns after the launch.  Errors raised by chains surface at
+ * the next ba_sync()/ba_get_*(). */
+int ba_sweep(ba_engine *e, int32_t nsweeps);
+/* wait for outstanding work and report the first chain error, if any */
+int ba_sync(ba_engine *e);
+/* log_model_prob(gamma) for ngamma inclusion vectors (BregVsSampler.cpp:216-239) */
+int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
+                      double *out);
+
+/* ---- posterior summaries --------------------------------------------------- */
+/* Running sums over every sweep since the last ba_reset_summaries(), reduced
+ * over this engine's chains on the device:
+ *   inclusion_count[p] (as double), beta_sum[p], beta_sumsq[p],
+ *   scalars[8] = {sweeps*chains, sum sigsq, sum sigsq^2, sum |gamma|,
+ *                 accepted flips, proposed flips, min accept margin, reserved}
+ * The layout is one contiguous block of (3p + 8) doubles so that a single
+ * collective moves it (see ba_summaries_device). */
+int ba_reset_summaries(ba_engine *e);
+int ba_get_summaries(ba_engine *e, double *inclusion_count, double *beta_sum,
+                     double *beta_sumsq, double *scalars);
+/* reduce into a device buffer of (3p + 8) doubles owned by the caller (e.g. a
+ * torch tensor that then goes through RCCL); stream-ordered on the engine's
+ * stream followed by a sync */
+int ba_summaries_device(ba_engine *e, void *out_device);
+/* per-sweep traces of the last ba_sweep call for ESS: each chains x nsweeps,
+ * row-major; any pointer may be NULL.  Tracing must be enabled first. */
+int ba_enable_traces(ba_engine *e, int32_t max_sweeps);
+int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
+                  double *model_size);
+
+/* the engine's HIP stream (hipStream_t) for callers that order their own work */
+void *ba_stream(ba_engine *e);
+
+/* ---- bsts: StateSpaceRegressionModel + LocalLevelStateModel ----------------- */
+/* StateSpaceRegressionModel(y, X, observed) (StateSpaceRegressionModel.cpp:100-125):
+ * X is T x p column-major; observed may be NULL.  Replaces the engine's data:
+ * XtX is fixed, per-chain Xty / yty / n are rebuilt by every impute_state. */
+int ba_ss_set_data(ba_engine *e, int32_t T, int32_t p, const double *y,
+                   const double *X, const uint8_t *observed);
+/* LocalLevelStateModel + ZeroMeanGaussianConjSampler(df, sigma_guess) with
+ * set_sigma_upper_limit, set_initial_state_mean / _variance
+ * (LocalLevelStateModel.cpp:32-91; ZeroMeanGaussianConjSampler.cpp:37-60) */
+int ba_ss_set_local_level(ba_engine *e, double level_df,
+                          double level_sigma_guess,
+                          double level_sigma_upper_limit,
+                          double initial_state_mean,
+                          double initial_state_variance,
+                          double initial_level_sigma);
+/* nsweeps x StateSpacePosteriorSampler::draw()
+ * (StateSpacePosteriorSampler.cpp:42-64) on every chain */
+int ba_ss_sweep(ba_engine *e, int32_t nsweeps);
+/* one Base::impute_state (StateSpaceModelBase.cpp:278-291) with the current
+ * parameters, on every chain */
+int ba_ss_impute_state(ba_engine *e);
+/* state(): T doubles of one chain; level sigsq; level suf (n, sumsq) */
+int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
+                    double *level_sigsq, double *level_n, double *level_sumsq);
+int ba_ss_set_level_sigsq(ba_engine *e, int64_t chain, double sigsq);
+/* per-chain regression sufficient statistics left by impute_state */
+int ba_ss_get_chain_suf(ba_engine *e, int64_t chain, double *xty, double *yty,
+                        double *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOOM_AMD_H */
