@@ -679,6 +679,12 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
     for (int j = lane; j < p; j += WAVE) g_beta[j] = 0.0;
     __syncthreads();
     if (lane < k) g_beta[ch.g[lane]] = beta_m;
+  } else if (nflips > 0) {
+    // coef().set_inc(g) zeroes the coefficients of excluded variables
+    // (Models/Glm/GlmCoefs.cpp:89-94) even when the beta draw is suppressed
+    double *g_beta = P.beta + (size_t)chain * p;
+    for (int j = lane; j < p; j += WAVE)
+      if (!ch.gam[j]) g_beta[j] = 0.0;
   }
   if (lane == 0) {
     P.sigsq[chain] = sigsq;

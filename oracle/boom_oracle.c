@@ -823,6 +823,14 @@ static void correlation_map_fill(bo_ssvs *s) {
   s->cm_filled = 1;
 }
 
+/* GlmCoefs::set_inc, Models/Glm/GlmCoefs.cpp:89-94: installing a new
+ * inclusion pattern zeroes the coefficients of the excluded variables. */
+static void set_inc(bo_ssvs *s, const uint8_t *g) {
+  memcpy(s->gamma, g, s->p);
+  for (int j = 0; j < s->p; ++j)
+    if (!g[j]) s->beta[j] = 0.0;
+}
+
 /* BregVsSampler::attempt_swap, BregVsSampler.cpp:277-310, with
  * CorrelationMap::propose_swap / proposal_weight (CorrelationMap.cpp:61-115)
  * and Selector::random_included_position (LinAlg/Selector.cpp:297-304). */
@@ -889,7 +897,7 @@ static void attempt_swap(bo_ssvs *s, int *status) {
   double log_num = log_model_prob(s, included, status) - log(forward_w);
   double log_den = original_logp - log(reverse_w);
   double logu = log(bo_runif(&s->rng, 0, 1));
-  if (logu < log_num - log_den) memcpy(s->gamma, included, p);
+  if (logu < log_num - log_den) set_inc(s, included);
   free(included);
 }
 
@@ -914,7 +922,7 @@ static void draw_model_indicators(bo_ssvs *s, int *status) {
   for (int i = 0; i < n && !*status; ++i) {
     logp = mcmc_one_flip(s, g, s->indx[i], logp, status);
   }
-  memcpy(s->gamma, g, p);
+  set_inc(s, g);
   free(g);
   if (*status) return;
   attempt_swap(s, status);

@@ -156,6 +156,13 @@ def main():
     ssvs_case("ssvs_maxflips", X, y, prior, ssvs_options(max_flips=5), [5], g0,
               300)
 
+    # pure-noise response, no forced intercept: the chain visits the EMPTY model
+    # (k = 0 closed form; set_inc zeroes excluded coefficients)
+    X, y, _ = regression_data(200, 6, 0, seed=8, intercept=False)
+    prior = spike_slab_prior(suf_from_xy(X, y), 1, force_intercept=False,
+                             prior_mean=np.zeros(6))
+    ssvs_case("ssvs_empty", X, y, prior, ssvs_options(), [3], np.zeros(6, np.uint8), 200)
+
     # ---- state space (local level + regression) -----------------------------
     for name, miss, sd in (("ss_t200", 0.0, 22), ("ss_t200_missing", 0.05, 21)):
         X, y, _, obs = state_space_data(200, 8, 3, seed=5, missing_frac=miss)

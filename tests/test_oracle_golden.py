@@ -142,7 +142,7 @@ def test_log_model_prob(oracle):
 
 
 @pytest.mark.parametrize("name", ["ssvs_c1", "ssvs_p64", "ssvs_collinear",
-                                  "ssvs_general", "ssvs_maxflips"])
+                                  "ssvs_general", "ssvs_maxflips", "ssvs_empty"])
 def test_ssvs_sweeps_match_reference(oracle, name):
     g = load(name)
     suf = oracle.neregsuf(g["X"], g["y"])
