@@ -129,7 +129,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # avg launch duration
 
     # ---- posterior summaries: one RCCL all-gather at the end ----------------
-    block = torch.empty(3 * P + 8, dtype=torch.float64, device="cuda")
+    block = torch.empty(3 * P + boom_amd.capi.SUMMARY_SCALARS, dtype=torch.float64, device="cuda")
     eng.summaries_device(block.data_ptr())
     if world > 1:
         gathered = [torch.empty_like(block) for _ in range(world)]

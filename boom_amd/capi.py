@@ -9,12 +9,14 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libboomamd.so")
+# BOOM_AMD_LIB selects another build of the SAME library (e.g. the -DBA_STAMPS
+# diagnostic build); it is never a different backend
+LIB_PATH = os.environ.get("BOOM_AMD_LIB", os.path.join(_HERE, "libboomamd.so"))
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
 
-SUMMARY_SCALARS = 8
+SUMMARY_SCALARS = 16
 
 
 class BoomAmdError(RuntimeError):
@@ -254,7 +256,8 @@ class Engine:
         self._check(self.lib.ba_get_summaries(self._h, _p(inc), _p(bs), _p(bs2), _p(sc)))
         return dict(inclusion_count=inc, beta_sum=bs, beta_sumsq=bs2,
                     sweeps=sc[0], sigsq_sum=sc[1], sigsq_sumsq=sc[2], k_sum=sc[3],
-                    accepts=sc[4], proposals=sc[5], min_margin=sc[6])
+                    accepts=sc[4], proposals=sc[5], min_margin=sc[6],
+                    phase_cycles=sc[8:16].copy())
 
     def summaries_device(self, ptr):
         self._check(self.lib.ba_summaries_device(self._h, ptr))

@@ -146,6 +146,7 @@ struct ba_engine {
   DevBuf<uint32_t> dinc;
   DevBuf<double> dbsum, dbsumsq, dacc, dsummary;
   DevBuf<double> dtr_sig, dtr_logp, dtr_k;
+  DevBuf<double> dmodel;  // per-chain model scratch (scalar-cache reads)
   int trace_stride = 0;
   // scratch for suf build
   DevBuf<double> dX, dy, dxtx, dxsum, dsufscal;
@@ -188,19 +189,23 @@ void build_correlation_map(const ba_engine &e, std::vector<int32_t> &start,
   start[p] = (int32_t)idx.size();
 }
 
+// Working capacity of a chain's LDS set: 16, 32, 48 or 64 variables (the sweep
+// kernel is instantiated per capacity).  Prefer the largest capacity that still
+// lets every chain be resident at once (one wavefront per chain, LDS-limited
+// workgroups per CU); a max_model_size prior or the caller's hint can lower it.
 int choose_kcap(const ba_engine &e) {
   const int p = e.p;
-  int want = std::min(64, p);
-  if (e.cfg.max_model_size_hint > 0) want = std::min(want, std::max(1, (int)e.cfg.max_model_size_hint));
-  if (e.max_model_size >= 0) want = std::min<int64_t>(want, std::max<int64_t>(1, e.max_model_size));
-  // every chain resident at once when possible: blocks per CU needed
+  int64_t need = std::min(64, p);
+  if (e.cfg.max_model_size_hint > 0) need = std::min<int64_t>(need, e.cfg.max_model_size_hint);
+  if (e.max_model_size >= 0) need = std::min<int64_t>(need, std::max<int64_t>(1, e.max_model_size));
+  const int cap_need = (int)std::min<int64_t>(64, ((need + 15) / 16) * 16);
   const int per_cu = std::max(1, (e.cfg.chains + e.cu_count - 1) / e.cu_count);
   const size_t budget_all = e.lds_per_cu / (size_t)per_cu;
-  int k = want;
+  int k = cap_need;
   if (e.cfg.max_model_size_hint <= 0) {
-    while (k > 8 && ssvs_lds_layout(p, k).total > budget_all) --k;
+    while (k > 16 && ssvs_lds_layout(p, k).total > budget_all) k -= 16;
   }
-  while (k > 1 && ssvs_lds_layout(p, k).total > e.lds_per_cu) --k;
+  while (k > 16 && ssvs_lds_layout(p, k).total > e.lds_per_cu) k -= 16;
   return k;
 }
 
@@ -328,6 +333,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.rng_pos = e->dpos.ptr;
   P.status = e->dstatus.ptr;
   P.failures = e->dfail.ptr;
+  P.model_scratch = e->dmodel.ptr;
+  P.model_scratch_stride = (int64_t)ssvs_scalar_layout(e->kcap).total;
   P.seed_lo = (uint32_t)e->seed;
   P.seed_hi = (uint32_t)(e->seed >> 32);
   P.stream = 0;
@@ -728,6 +735,7 @@ int ba_sweep(ba_engine *e, int32_t nsweeps) {
   if (rc) return rc;
   if (e->trace_stride > 0 && nsweeps > e->trace_stride)
     return fail(BA_E_INVALID, "nsweeps exceeds the enabled trace length");
+  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(e->kcap).total));
   SsvsParams P;
   fill_params(e, P);
   const SsvsLds lay = ssvs_lds_layout(e->p, e->kcap);
@@ -762,8 +770,8 @@ int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
   SsvsParams P;
   fill_params(e, P);
   // this entry evaluates arbitrary models: use the largest working set
-  P.kcap = std::min(64, e->p);
-  while (P.kcap > 1 && ssvs_lds_layout(e->p, P.kcap).total > e->lds_per_cu) --P.kcap;
+  P.kcap = 64;
+  while (P.kcap > 8 && ssvs_lds_layout(e->p, P.kcap).total > e->lds_per_cu) P.kcap -= 8;
   HIP_TRY(launch_ssvs_logp(e->stream, P, (const uint8_t *)dg.ptr, (int)ngamma,
                            dout.ptr, dst.ptr));
   std::vector<int32_t> st(ngamma);

@@ -29,8 +29,17 @@
 // reference's chain; only the arithmetic route differs (O(k^2) per proposal
 // and 64 proposals at a time instead of O(k^3) one at a time).
 //
+// Each lane's triangular solve keeps its solution vector in registers
+// (static indexing, fully unrolled over 8 x 8 blocks) and streams the factor's
+// blocks from LDS with wave-uniform reads: the FMAs of a block row are
+// independent, so the solve runs at FMA issue rate instead of LDS latency.
+//
 // Proposals for a variable with a non-zero prior mean b_j change r for the
 // whole model; they take the (rare) exact path: refactor the candidate model.
+//
+// The Fisher-Yates shuffle of the persistent permutation is done in parallel:
+// every final position follows a short chain of "who was swapped into this
+// slot last" links instead of replaying the p-1 swaps one after the other.
 #include <hip/hip_runtime.h>
 
 #include "device_rng.h"
@@ -43,20 +52,82 @@ namespace {
 constexpr int WAVE = 64;
 #define BA_INF (__builtin_inf())
 
+// Diagnostic build only (-DBA_STAMPS): cycles per phase, never in the product.
+#ifdef BA_STAMPS
+#define STAMP_DECL long long st_last = (long long)__builtin_readcyclecounter(); double st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); st_ph[i] += (double)(t_ - st_last); st_last = t_; } while (0)
+#else
+#define STAMP_DECL do { } while (0)
+#define STAMP(i) do { } while (0)
+#endif
+
+// ---- address spaces ---------------------------------------------------------
+// LDS pointers are typed as such so that every access is a ds_* instruction no
+// matter how the compiler inlines (a generic pointer would become flat_load).
+#define AS_LDS __attribute__((address_space(3)))
+typedef AS_LDS double lds_f64;
+typedef AS_LDS uint16_t lds_u16;
+typedef AS_LDS uint8_t lds_u8;
+template <class T>
+__device__ __forceinline__ AS_LDS T *to_lds(unsigned char *generic) {
+  return (AS_LDS T *)(uintptr_t)generic;
+}
+// Wave-uniform model data is read back through the scalar cache: a pointer in
+// the constant address space makes every (uniform-address) load an s_load, so
+// factor elements arrive in SGPRs and feed v_fma_f64 directly.  The data ARE
+// rewritten by this wavefront (publish_model); the pointer is re-derived
+// through an opaque asm after each rewrite so that no load can move above it.
+#define AS_CONST __attribute__((address_space(4)))
+typedef AS_CONST const double c_f64;
+typedef AS_CONST const int c_i32;
+
+// ---- cross-lane helpers (DPP / readlane: no LDS round trip) -----------------
+// lanes whose DPP source is outside their row (or whose row is masked off)
+// receive `fill`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x, double fill) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned long long f = __builtin_bit_cast(unsigned long long, fill);
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// value of lane `src` (wave-uniform index)
+__device__ __forceinline__ double bcast_u(double x, int src) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int bcast_u(int x, int src) {
+  return __builtin_amdgcn_readlane(x, src);
+}
+// Reductions over the wave, result in every lane.  row_shr 8/4/2/1 leaves each
+// row's total in its lane 15; row_bcast:15 / row_bcast:31 carry it to lane 63.
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, WAVE);
-  return x;
+  x += dpp_f64<0x118, 0xf>(x, 0.0);
+  x += dpp_f64<0x114, 0xf>(x, 0.0);
+  x += dpp_f64<0x112, 0xf>(x, 0.0);
+  x += dpp_f64<0x111, 0xf>(x, 0.0);
+  x += dpp_f64<0x142, 0xa>(x, 0.0);
+  x += dpp_f64<0x143, 0xc>(x, 0.0);
+  return bcast_u(x, 63);
 }
 __device__ __forceinline__ double wave_min(double x) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) x = fmin(x, __shfl_xor(x, off, WAVE));
-  return x;
+  x = fmin(x, dpp_f64<0x118, 0xf>(x, x));
+  x = fmin(x, dpp_f64<0x114, 0xf>(x, x));
+  x = fmin(x, dpp_f64<0x112, 0xf>(x, x));
+  x = fmin(x, dpp_f64<0x111, 0xf>(x, x));
+  x = fmin(x, dpp_f64<0x142, 0xa>(x, x));
+  x = fmin(x, dpp_f64<0x143, 0xc>(x, x));
+  return bcast_u(x, 63);
 }
-__device__ __forceinline__ double bcast(double x, int src) {
-  return __shfl(x, src, WAVE);
+
+// offset (in doubles) of element (m, n), n <= m, in the block-packed factor
+__device__ __forceinline__ int bidx(int m, int n) {
+  const int I = m >> 3, J = n >> 3;
+  return ((I * (I + 1)) / 2 + J) * 64 + (m & 7) * 8 + (n & 7);
 }
-__device__ __forceinline__ int tri(int m, int n) { return (m * (m + 1)) / 2 + n; }
 
 // wave-uniform description of the current model
 struct Model {
@@ -72,37 +143,77 @@ struct Model {
 };
 
 struct Chain {
-  const SsvsParams *P;
   int lane, p, k;
   // LDS
-  double *Lv, *La, *rdv, *rda, *w, *bg, *buf;
-  uint16_t *g, *perm, *oth;
-  uint8_t *gam;
+  lds_f64 *Lv, *La, *rdv, *rda, *w, *bg;
+  lds_u16 *g, *perm, *perm_alt, *oth, *last, *pred;
+  lds_u8 *gam;
+  // HBM copy of the model read through the scalar cache (see publish_model)
+  double *sc_store;   // global pointer used for the stores
+  c_f64 *sc;          // the same memory, constant address space
   // this chain's sufficient statistics
   const double *xty;
   double DF;    // n + prior_df
   double ss0q;  // prior_ss + yty
 };
 
-// In-place Cholesky of a packed lower triangle, lane i owns row i (k <= 64).
-// Left-looking by column: the subtraction order for every entry is that of
-// Eigen's unblocked LLT (Eigen/src/Cholesky/LLT.h:313-335) which the
+__device__ __forceinline__ void bind_lds(Chain &ch, unsigned char *smem,
+                                         const SsvsLds &lay) {
+  ch.Lv = to_lds<double>(smem + lay.Lv);
+  ch.La = to_lds<double>(smem + lay.La);
+  ch.rdv = to_lds<double>(smem + lay.rdv);
+  ch.rda = to_lds<double>(smem + lay.rda);
+  ch.w = to_lds<double>(smem + lay.w);
+  ch.bg = to_lds<double>(smem + lay.bg);
+  ch.g = to_lds<uint16_t>(smem + lay.g);
+  ch.perm = to_lds<uint16_t>(smem + lay.perm0);
+  ch.perm_alt = to_lds<uint16_t>(smem + lay.perm1);
+  ch.oth = to_lds<uint16_t>(smem + lay.oth);
+  ch.last = to_lds<uint16_t>(smem + lay.last);
+  ch.pred = to_lds<uint16_t>(smem + lay.pred);
+  ch.gam = to_lds<uint8_t>(smem + lay.gam);
+}
+
+// In-place Cholesky of a block-packed lower triangle, lane i owns row i
+// (k <= 64).  Left-looking by column: the subtraction order for every entry is
+// that of Eigen's unblocked LLT (Eigen/src/Cholesky/LLT.h:313-335) which the
 // reference uses (LinAlg/Cholesky.cpp:33-58).  Returns false at the first
 // non-positive pivot.  logdet = 2 * sum log L_jj.
-__device__ bool chol_packed(const Chain &ch, double *Lp, double *rd,
-                            double *logdet) {
+__device__ __forceinline__ bool chol_blocks(const Chain &ch, lds_f64 *LB,
+                                            lds_f64 *rd, double *logdet) {
   const int k = ch.k, i = ch.lane;
   double ld = 0.0;
   bool ok = true;
   for (int j = 0; j < k; ++j) {
     const bool mine = (i >= j) && (i < k);
-    double s = mine ? Lp[tri(i, j)] : 0.0;
-    if (mine) {
-      const double *ri = Lp + tri(i, 0);
-      const double *rj = Lp + tri(j, 0);
-      for (int n = 0; n < j; ++n) s -= ri[n] * rj[n];
+    const int ii = mine ? i : j;  // lanes without a row read row j (discarded)
+    double s = LB[bidx(ii, j)];
+    const int jb = j >> 3;
+    const lds_f64 *ri = LB + ((ii >> 3) * ((ii >> 3) + 1) / 2) * 64 + (ii & 7) * 8;
+    const lds_f64 *rj = LB + (jb * (jb + 1) / 2) * 64 + (j & 7) * 8;
+    for (int nb = 0; nb < jb; ++nb) {
+      double a[8], b[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        a[t] = ri[nb * 64 + t];
+        b[t] = rj[nb * 64 + t];
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) s -= a[t] * b[t];
     }
-    const double d = bcast(s, j);
+    {
+      const int rem = j & 7;
+      double a[8], b[8];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        a[t] = (t < rem) ? ri[jb * 64 + t] : 0.0;
+        b[t] = (t < rem) ? rj[jb * 64 + t] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+        if (t < rem) s -= a[t] * b[t];
+    }
+    const double d = bcast_u(s, j);
     if (!(d > 0.0)) {
       ok = false;
       break;
@@ -110,10 +221,10 @@ __device__ bool chol_packed(const Chain &ch, double *Lp, double *rd,
     const double sd = sqrt(d);
     ld += log(sd);
     if (i == j) {
-      Lp[tri(j, j)] = sd;
+      LB[bidx(j, j)] = sd;
       rd[j] = 1.0 / sd;
     } else if (mine) {
-      Lp[tri(i, j)] = s / sd;
+      LB[bidx(i, j)] = s / sd;
     }
     __syncthreads();
   }
@@ -123,8 +234,8 @@ __device__ bool chol_packed(const Chain &ch, double *Lp, double *rd,
 
 // Rebuild everything about the current model gamma (sorted index list g in
 // LDS) from scratch: BregVsSampler::set_reg_post_params + log_model_prob.
-__device__ void refactor(Chain &ch, Model &M) {
-  const SsvsParams &P = *ch.P;
+// Inlined at its (single) call site in each kernel.
+__device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &M) {
   const int lane = ch.lane, p = ch.p, k = ch.k;
   M.bad = 0;
   M.pd = true;
@@ -147,30 +258,55 @@ __device__ void refactor(Chain &ch, Model &M) {
     return;
   }
   __syncthreads();
-  // gather V_g, A_g (lower triangles) and b_g
-  for (int m = 0; m < k; ++m) {
-    const size_t row = (size_t)ch.g[m] * p;
-    if (lane <= m) {
-      const int gn = ch.g[lane];
-      ch.Lv[tri(m, lane)] = P.V[row + gn];
-      ch.La[tri(m, lane)] = P.A[row + gn];
+  // gather V_g, A_g (lower triangles, rows padded with zeros to a multiple of
+  // 8) with all loads independent: element e <-> (m, n), n <= m
+  const int kpad = (k + 7) & ~7;
+  const int nelem = kpad * (kpad + 1) / 2;
+  for (int e = lane; e < nelem; e += WAVE) {
+    int m = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while ((m + 1) * (m + 2) / 2 <= e) ++m;
+    while (m * (m + 1) / 2 > e) --m;
+    const int n = e - m * (m + 1) / 2;
+    double v = 0.0, a = 0.0;
+    if (m < k) {
+      const size_t o = (size_t)ch.g[m] * p + ch.g[n];
+      v = P.V[o];
+      a = P.A[o];
     }
+    ch.Lv[bidx(m, n)] = v;
+    ch.La[bidx(m, n)] = a;
   }
   const int gm = (lane < k) ? ch.g[lane] : 0;
-  if (lane < k) ch.bg[lane] = P.b[gm];
-  __syncthreads();
-  // r = A_g b_g + xty_g ; c = b_g' A_g b_g
-  double r = 0.0, ab = 0.0;
-  if (lane < k) {
-    for (int n = 0; n < k; ++n) {
-      const double bn = ch.bg[n];
-      if (bn != 0.0) ab += P.A[(size_t)gm * p + ch.g[n]] * bn;
+  const double bm = (lane < k) ? P.b[gm] : 0.0;
+  if (lane < kpad) {
+    ch.bg[lane] = bm;
+    if (lane >= k) {
+      ch.rdv[lane] = 0.0;
+      ch.rda[lane] = 0.0;
+      ch.w[lane] = 0.0;
     }
-    r = ab + ch.xty[gm];
   }
-  M.c = wave_sum(lane < k ? ch.bg[lane] * ab : 0.0);
-  const bool oka = chol_packed(ch, ch.La, ch.rda, &M.lda);
-  const bool okv = chol_packed(ch, ch.Lv, ch.rdv, &M.ldv);
+  // r = A_g b_g + xty_g ; c = b_g' A_g b_g   (only non-zero prior means cost)
+  double ab = 0.0;
+  unsigned long long nz = __ballot(bm != 0.0);
+  while (nz) {
+    const int n = __ffsll((long long)nz) - 1;
+    nz &= nz - 1;
+    const double bn = bcast_u(bm, n);
+    const int gn = bcast_u(gm, n);
+    if (lane < k) ab += P.A[(size_t)gm * p + gn] * bn;
+  }
+  const double r = (lane < k) ? ab + ch.xty[gm] : 0.0;
+  M.c = wave_sum(lane < k ? bm * ab : 0.0);
+  __syncthreads();
+  // the two factorisations share one (not unrolled) body
+  bool okv = true, oka = true;
+#pragma nounroll
+  for (int s = 0; s < 2; ++s) {
+    double ld;
+    const bool ok = chol_blocks(ch, s ? ch.Lv : ch.La, s ? ch.rdv : ch.rda, &ld);
+    if (s) { okv = ok; M.ldv = ld; } else { oka = ok; M.lda = ld; }
+  }
   if (!okv) {
     M.pd = false;
     M.logp = -BA_INF;
@@ -178,14 +314,16 @@ __device__ void refactor(Chain &ch, Model &M) {
   }
   // w = L_V^{-1} r, lane m ends up holding w_m
   double x = r;
+  const double rdm = (lane < k) ? ch.rdv[lane] : 0.0;
   for (int j = 0; j < k; ++j) {
-    const double wj = bcast(x, j) * ch.rdv[j];
+    const double wj = bcast_u(x, j) * bcast_u(rdm, j);
     if (lane == j) x = wj;
-    else if (lane > j && lane < k) x -= ch.Lv[tri(lane, j)] * wj;
+    else if (lane > j && lane < k) x -= ch.Lv[bidx(lane, j)] * wj;
   }
   if (lane < k) ch.w[lane] = x;
   M.Q = wave_sum(lane < k ? x * x : 0.0);
   M.SS = ch.ss0q + M.c - M.Q;
+  __syncthreads();
   if (!(M.SS >= 0.0) || isinf(M.SS)) {
     M.bad = CHAIN_NEGATIVE_SS;
     M.logp = -BA_INF;
@@ -197,11 +335,10 @@ __device__ void refactor(Chain &ch, Model &M) {
     return;
   }
   M.logp = lp + 0.5 * (M.lda - M.ldv) - (0.5 * ch.DF - 1.0) * log(M.SS);
-  __syncthreads();
 }
 
 // flip variable j in the LDS copy of gamma and in the sorted list g
-__device__ void apply_flip(Chain &ch, int j) {
+__device__ __forceinline__ void apply_flip(Chain &ch, int j) {
   const int lane = ch.lane, k = ch.k;
   const int gm = (lane < k) ? ch.g[lane] : 0x7fffffff;
   const int below = __popcll(__ballot(lane < k && gm < j));
@@ -222,25 +359,63 @@ __device__ void apply_flip(Chain &ch, int j) {
   __syncthreads();
 }
 
-// per-lane forward substitution L x = rhs with the rhs (and result) in this
-// lane's column of buf; returns |x|^2 and x.w
-__device__ __forceinline__ void lane_solve(const Chain &ch, const double *Lp,
-                                           const double *rd, double *nrm,
-                                           double *dotw) {
-  const int k = ch.k;
-  double *col = ch.buf + ch.lane;
-  double n2 = 0.0, dw = 0.0;
-  for (int m = 0; m < k; ++m) {
-    double acc = col[m * WAVE];
-    const double *row = Lp + tri(m, 0);
-    for (int n = 0; n < m; ++n) acc -= row[n] * col[n * WAVE];
-    const double x = acc * rd[m];
-    col[m * WAVE] = x;
-    n2 += x * x;
-    dw += x * ch.w[m];
+// Copy the current model's wave-uniform data from LDS to this chain's HBM
+// block, make it visible to the scalar cache and re-derive the read pointer.
+template <int NB>
+__device__ __forceinline__ void publish_model(Chain &ch) {
+  const int lane = ch.lane, k = ch.k;
+  constexpr int KCAP = NB * 8;
+  const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
+  const int kpad = (k + 7) & ~7;
+  const int nblk = (kpad / 8) * (kpad / 8 + 1) / 2;
+  double *dst = ch.sc_store;
+  for (int e = lane; e < nblk * 64; e += WAVE) {
+    dst[S.Lv + e] = ch.Lv[e];
+    dst[S.La + e] = ch.La[e];
   }
-  *nrm = n2;
-  *dotw = dw;
+  if (lane < kpad) {
+    dst[S.rdv + lane] = ch.rdv[lane];
+    dst[S.rda + lane] = ch.rda[lane];
+    dst[S.w + lane] = ch.w[lane];
+    dst[S.bg + lane] = ch.bg[lane];
+    ((int *)(dst + S.g))[lane] = (lane < k) ? (int)ch.g[lane] : 0;
+  }
+  unsigned long long u = (unsigned long long)dst;
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(u) : : "memory");
+  ch.sc = (c_f64 *)u;
+}
+
+// Per-lane forward substitution L x = rhs, x in registers (in: rhs, out:
+// solution).  The factor's blocks and reciprocal diagonal come through the
+// scalar cache (SGPR operands).  Rows >= k of the last block are zero with
+// rd = 0, so their x stays 0.
+template <int NB>
+__device__ __forceinline__ void solve_blocks(c_f64 *__restrict__ LB,
+                                             c_f64 *__restrict__ rd, int k,
+                                             double (&x)[NB * 8]) {
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    if (I * 8 < k) {
+      double acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = x[I * 8 + r];
+#pragma unroll
+      for (int J = 0; J < I; ++J) {
+        c_f64 *blk = LB + ((I * (I + 1)) / 2 + J) * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc[r] -= blk[r * 8 + c] * x[J * 8 + c];
+      }
+      c_f64 *blk = LB + ((I * (I + 1)) / 2 + I) * 64;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        x[I * 8 + r] = acc[r] * rd[I * 8 + r];
+#pragma unroll
+        for (int r2 = r + 1; r2 < 8; ++r2) acc[r2] -= blk[r2 * 8 + r] * x[I * 8 + r];
+      }
+    }
+  }
 }
 
 struct Proposal {
@@ -250,9 +425,11 @@ struct Proposal {
 };
 
 // Evaluate this lane's proposal "flip j" against the current model.
-__device__ Proposal eval_proposal(Chain &ch, const Model &M, int j, bool valid) {
-  const SsvsParams &P = *ch.P;
-  const int p = ch.p, k = ch.k, lane = ch.lane;
+template <int NB>
+__device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch,
+                                                  const Model &M, int j,
+                                                  bool valid) {
+  const int p = ch.p, k = ch.k;
   Proposal out;
   out.logp = -BA_INF;
   out.slow = false;
@@ -277,49 +454,75 @@ __device__ Proposal eval_proposal(Chain &ch, const Model &M, int j, bool valid) 
   if (empty_after) {
     out.logp = lpn - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
   }
-  // ---- V part: rhs = V[g, j] (add) or e_i (drop)
-  double ab = 0.0;     // A[j, g] . b_g   (adds)
-  double ajj = 0.0, vjj = 0.0;
-  {
-    double *col = ch.buf + lane;
-    for (int m = 0; m < k; ++m) {
-      const int gm = ch.g[m];
-      double v = 0.0;
-      if (fast) v = add ? P.V[(size_t)gm * p + j] : (gm == j ? 1.0 : 0.0);
-      col[m * WAVE] = v;
+  const double vjj = (fast && add) ? P.V[(size_t)j * p + j] : 0.0;
+  const double ajj = (fast && add) ? P.A[(size_t)j * p + j] : 0.0;
+  const double xtyj = (fast && add) ? ch.xty[j] : 0.0;
+
+  constexpr int KCAP = NB * 8;
+  const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
+  c_f64 *sc = ch.sc;
+  c_i32 *gsc = (c_i32 *)(sc + S.g);
+
+  double x[NB * 8];
+  double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
+#pragma nounroll
+  for (int s = 0; s < 2; ++s) {
+    const double *Mat = s ? P.A : P.V;
+    c_f64 *LB = sc + (s ? S.La : S.Lv);
+    c_f64 *rd = sc + (s ? S.rda : S.rdv);
+    // rhs = Mat[g, j] (add) or e_i (drop); branch-free inside a block so that
+    // the block's 8 gathers are in flight together
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      if (I * 8 < k) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int m = I * 8 + r;
+          const int gm = gsc[m];
+          const double v = Mat[(size_t)gm * p + j];
+          const double e = (gm == j) ? 1.0 : 0.0;
+          x[m] = (fast && m < k) ? (add ? v : e) : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[I * 8 + r] = 0.0;
+      }
     }
-  }
-  double nv, dv;
-  lane_solve(ch, ch.Lv, ch.rdv, &nv, &dv);
-  // ---- A part
-  {
-    double *col = ch.buf + lane;
-    for (int m = 0; m < k; ++m) {
-      const int gm = ch.g[m];
-      double a = 0.0;
-      if (fast) {
-        if (add) {
-          a = P.A[(size_t)gm * p + j];
-          ab += a * ch.bg[m];
-        } else {
-          a = (gm == j ? 1.0 : 0.0);
+    if (s == 1) {
+      // A[j, g] . b_g for the new element of r
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (I * 8 < k) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ab += x[I * 8 + r] * sc[S.bg + I * 8 + r];
+        }
+    }
+    solve_blocks<NB>(LB, rd, k, x);
+    double n2 = 0.0, dw = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+      if (I * 8 < k) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          n2 += x[I * 8 + r] * x[I * 8 + r];
+          dw += x[I * 8 + r] * sc[S.w + I * 8 + r];
         }
       }
-      col[m * WAVE] = a;
+    if (s == 0) {
+      nv = n2;
+      dv = dw;
+    } else {
+      na = n2;
     }
   }
-  double na, da_unused;
-  lane_solve(ch, ch.La, ch.rda, &na, &da_unused);
   if (fast) {
     double ldv, lda, Q;
     bool ok = true;
     if (add) {
-      vjj = P.V[(size_t)j * p + j];
-      ajj = P.A[(size_t)j * p + j];
       const double d2 = vjj - nv;
       const double da2 = ajj - na;
       if (!(d2 > 0.0) || !(da2 > 0.0)) ok = false;
-      const double rj = ch.xty[j] + ab;  // b_j == 0 on this path
+      const double rj = xtyj + ab;  // b_j == 0 on this path
       const double wn = (rj - dv) / sqrt(d2);
       Q = M.Q + wn * wn;
       ldv = M.ldv + log(d2);
@@ -342,11 +545,127 @@ __device__ Proposal eval_proposal(Chain &ch, const Model &M, int j, bool valid) 
   return out;
 }
 
-// BregVsSampler::attempt_swap (BregVsSampler.cpp:277-310) with
+// shuffle(indx) of cpputil/shuffle.hpp:36-46 -- for i = p-1..1: swap(a[i],
+// a[oth[i]]) -- without replaying the swaps serially.  Position i is final
+// after step i and receives what position x = oth[i] held just before step i.
+// That content was deposited by the most recent earlier step t' > i with
+// oth[t'] == x (pred[i]); it was position t's content before step t', which
+// in turn was deposited by the smallest t'' > t' with oth[t''] == t' (nxt),
+// and so on until a slot nobody wrote, which still holds its original value.
+// oth[] must be filled for i = 1..p-1.  Result goes to ch.perm (buffers swap).
+__device__ __forceinline__ void parallel_shuffle(Chain &ch) {
+  const int p = ch.p, lane = ch.lane;
+  constexpr int NONE = 0xFFFF;
+  for (int j = lane; j < p; j += WAVE) ch.last[j] = (uint16_t)NONE;
+  int nbits = 1;
+  while ((1 << nbits) < p) ++nbits;
+  __syncthreads();
+  // ---- previous step with the same target, rounds over decreasing t
+  for (int T = p - 1; T >= 1; T -= WAVE) {
+    const int t = T - lane;
+    const bool valid = t >= 1;
+    const int key = valid ? ch.oth[t] : 0;
+    unsigned long long mask = __ballot(valid);
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = (key >> b) & 1;
+      const unsigned long long bal = __ballot(valid && bit);
+      mask &= bit ? bal : ~bal;
+    }
+    if (valid) {
+      const unsigned long long lower = mask & ((1ull << lane) - 1ull);  // larger t
+      int pr;
+      if (lower) pr = T - (63 - __clzll((long long)lower));
+      else pr = ch.last[key];
+      ch.pred[t] = (uint16_t)pr;
+    }
+    __syncthreads();
+    if (valid && (lane == 63 || (mask >> (lane + 1)) == 0)) ch.last[key] = (uint16_t)t;
+    __syncthreads();
+  }
+  // last[x] = smallest t >= 1 with oth[t] == x.  nxt(t) = smallest t' > t with
+  // oth[t'] == t: last[t] unless that is the self swap t, then pred[t].
+  const int pred0 = ch.last[0];
+  __syncthreads();
+  for (int t = lane; t < p; t += WAVE) {
+    if (t >= 1) {
+      const int l = ch.last[t];
+      ch.last[t] = (uint16_t)((l == t) ? (int)ch.pred[t] : l);
+    }
+  }
+  __syncthreads();
+  const lds_u16 *src_perm = ch.perm;
+  lds_u16 *dst = ch.perm_alt;
+  for (int i = lane; i < p; i += WAVE) {
+    int c = (i == 0) ? pred0 : (int)ch.pred[i];
+    int src;
+    if (c == NONE) {
+      src = (i == 0) ? 0 : (int)ch.oth[i];
+    } else {
+      int n = ch.last[c];
+      while (n != NONE) {
+        c = n;
+        n = ch.last[c];
+      }
+      src = c;
+    }
+    dst[i] = src_perm[src];
+  }
+  __syncthreads();
+  lds_u16 *tmp = ch.perm;
+  ch.perm = ch.perm_alt;
+  ch.perm_alt = tmp;
+}
+
+// k standard normals in stream order (distributions/mvn.cpp:114-122), lane m
+// receives z_m.  Every lane evaluates the Kinderman-Ramage transform starting
+// at its own stream offset; a scalar walk then picks the draws that a
+// sequential reader of the stream would have produced.
+__device__ __forceinline__ double draw_normals(const PhiloxKey &key, uint64_t *pos,
+                                               int k, int lane) {
+  double z = 0.0;
+  int m = 0;
+  uint64_t base = *pos;
+  while (m < k) {
+    SeqRng r{key, base + (uint64_t)lane};
+    const double v = d_norm_rand(r);
+    const int used = (int)(r.pos - (base + (uint64_t)lane));
+    int cur = 0;
+    while (m < k && cur < WAVE) {
+      const double zm = bcast_u(v, cur);
+      if (lane == m) z = zm;
+      cur += bcast_u(used, cur);
+      ++m;
+    }
+    base += (uint64_t)cur;
+  }
+  *pos = base;
+  return z;
+}
+
+// A request to (re)build the model after changing gamma, served at the single
+// place in the sweep loop where refactor() is instantiated.
+enum : int {
+  EV_NONE = 0,
+  EV_INIT,     // rebuild, no decision (launch start; after make_valid)
+  EV_FORCE,    // flip f1 was accepted on the fast path: rebuild
+  EV_TRY_GE,   // exact evaluation of a flip: reject iff log u >  delta
+  EV_TRY_LT    // swap move:                  accept iff log u <  delta
+};
+struct Pending {
+  int kind;
+  int f1, f2;         // variables to flip (-1: none)
+  double lu;          // log u of the decision
+  double lfw, lrev;   // log forward / reverse proposal weights (0 for flips)
+  bool check_legal;   // EV_INIT after make_valid: -inf => ILLEGAL_START
+};
+
+// BregVsSampler::attempt_swap (BregVsSampler.cpp:277-310), proposal half:
 // CorrelationMap::propose_swap / proposal_weight (CorrelationMap.cpp:61-115).
-// Wave-uniform control flow; every lane walks the same CSR lists.
-__device__ void attempt_swap(Chain &ch, Model &M, SeqRng &rng, int *status) {
-  const SsvsParams &P = *ch.P;
+// Wave-uniform control flow; every lane walks the same CSR lists.  Fills `pe`
+// when a swap is proposed; the evaluation happens at the refactor site.
+__device__ __forceinline__ void propose_swap(const SsvsParams &P, Chain &ch,
+                                             SeqRng &rng, Pending &pe,
+                                             int *status) {
   if (P.cm_start == nullptr) return;
   const int k = ch.k, p = ch.p;
   if (k == 0 || k == p) return;
@@ -380,43 +699,36 @@ __device__ void attempt_swap(Chain &ch, Model &M, SeqRng &rng, int *status) {
     *status = CHAIN_RNG_BRANCH;
     return;
   }
-  const double original_logp = M.logp;
-  const Model saved = M;
-  apply_flip(ch, index);
-  apply_flip(ch, candidate);
-  Model Mn;
-  refactor(ch, Mn);
-  if (Mn.bad) { *status = Mn.bad; return; }
-  // reverse weight = proposal_weight(included', candidate, index)
+  // reverse weight = proposal_weight(included', candidate, index) where
+  // included' = gamma - index + candidate
   double rev;
   {
     const int l2 = P.cm_start[candidate], h2 = P.cm_start[candidate + 1];
     double ans = -BA_INF, tot = 0.0;
     for (int i = l2; i < h2; ++i) {
-      if (!ch.gam[P.cm_idx[i]]) {
-        if (P.cm_idx[i] == index) ans = P.cm_cor[i];
+      const int v = P.cm_idx[i];
+      const bool inc = (v == candidate) ? true : ((v == index) ? false : (bool)ch.gam[v]);
+      if (!inc) {
+        if (v == index) ans = P.cm_cor[i];
         tot += P.cm_cor[i];
       }
     }
     rev = (tot == 0.0) ? 0.0 : ans / tot;
   }
-  const double log_num = Mn.logp - log(forward_w);
-  const double log_den = original_logp - log(rev);
-  const double logu = log(d_runif(rng, 0.0, 1.0));
-  if (logu < log_num - log_den) {
-    M = Mn;
-  } else {
-    apply_flip(ch, candidate);
-    apply_flip(ch, index);
-    refactor(ch, M);
-    (void)saved;
-  }
+  pe.kind = EV_TRY_LT;
+  pe.f1 = index;
+  pe.f2 = candidate;
+  pe.lfw = log(forward_w);
+  pe.lrev = log(rev);
+  pe.lu = log(d_runif(rng, 0.0, 1.0));
+  pe.check_legal = false;
 }
 
 }  // namespace
 
 // ============================================================================
-// grid = chains, block = 64
+// grid = chains, block = 64; NB = kcap / 8
+template <int NB>
 __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
                                                         int nsweeps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -426,23 +738,15 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
   if (chain >= P.chains) return;
   if (P.status[chain] != CHAIN_OK) return;
 
-  const SsvsLds lay = ssvs_lds_layout(p, P.kcap);
+  constexpr int KCAP = NB * 8;
+  const SsvsLds lay = ssvs_lds_layout(p, KCAP);
   Chain ch;
-  ch.P = &P;
   ch.lane = lane;
   ch.p = p;
-  ch.Lv = (double *)(smem + lay.Lv);
-  ch.La = (double *)(smem + lay.La);
-  ch.rdv = (double *)(smem + lay.rdv);
-  ch.rda = (double *)(smem + lay.rda);
-  ch.w = (double *)(smem + lay.w);
-  ch.bg = (double *)(smem + lay.bg);
-  ch.buf = (double *)(smem + lay.buf);
-  ch.g = (uint16_t *)(smem + lay.g);
-  ch.perm = (uint16_t *)(smem + lay.perm);
-  ch.oth = (uint16_t *)(smem + lay.oth);
-  ch.gam = (uint8_t *)(smem + lay.gam);
+  bind_lds(ch, smem, lay);
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
+  ch.sc_store = P.model_scratch + (size_t)chain * P.model_scratch_stride;
+  ch.sc = (c_f64 *)(unsigned long long)ch.sc_store;
   const double yty = P.yty[(size_t)chain * P.suf_stride];
   const double nobs = P.nobs[(size_t)chain * P.suf_stride];
   ch.DF = nobs + P.prior_df;
@@ -462,10 +766,10 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
     }
     const unsigned long long mask = __ballot(inc != 0);
     const int slot = k + __popcll(mask & ((1ull << lane) - 1ull));
-    if (inc && slot < P.kcap) ch.g[slot] = (uint16_t)j;
+    if (inc && slot < KCAP) ch.g[slot] = (uint16_t)j;
     k += __popcll(mask);
   }
-  if (k > P.kcap) {
+  if (k > KCAP) {
     if (lane == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
     return;
   }
@@ -485,131 +789,169 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
   int done = 0;
 
   const int nflips = P.max_flips;  // already min(max_nflips_, p)
+  STAMP_DECL;
 
-  for (int sweep = 0; sweep < nsweeps && status == CHAIN_OK; ++sweep) {
-    Model M;
-    if (nflips > 0) {
-      // ---- shuffle(indx): cpputil/shuffle.hpp:36-46, in place on the
-      // persistent permutation.  Uniform t (t = 0..p-2) belongs to i = p-1-t.
-      for (int t = lane; t < p - 1; t += WAVE) {
-        const int i = p - 1 - t;
-        const double u = philox_uniform(key, pos + (uint64_t)t);
-        ch.oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u);
-      }
-      __syncthreads();
-      if (lane == 0) {
-        for (int i = p - 1; i > 0; --i) {
-          const int o = ch.oth[i];
-          const uint16_t a = ch.perm[i];
-          ch.perm[i] = ch.perm[o];
-          ch.perm[o] = a;
-        }
-      }
-      __syncthreads();
-      const uint64_t flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
-      pos = flip_pos + (uint64_t)nflips;
+  // The factors / scalars of the current model are built once per launch and
+  // after every change of gamma; they stay valid across sweeps (they depend on
+  // gamma only, not on sigma or beta).
+  Model M;
+  M.bad = 0; M.pd = true; M.logp = 0; M.lp = 0; M.ldv = 0; M.lda = 0; M.Q = 0; M.c = 0; M.SS = 0;
+  Pending pe;
+  pe.kind = EV_INIT; pe.f1 = pe.f2 = -1; pe.lu = 0; pe.lfw = pe.lrev = 0; pe.check_legal = false;
+  enum { PH_BEGIN, PH_FLIPS, PH_SWAP, PH_TAIL };
+  int phase = PH_BEGIN, sweep = 0, i0 = 0;
+  bool model_checked = false;  // legality of the start is checked in sweep 0
+  uint64_t flip_pos = 0;
+  SeqRng rng{key, pos};
 
-      refactor(ch, M);
-      if (!M.bad && !(M.logp > -BA_INF && M.logp < BA_INF)) {
-        // VariableSelectionPrior::make_valid, VariableSelectionPrior.cpp:287-300
-        for (int j = 0; j < p; ++j) {
-          const double pj = P.pi[j];
-          const bool inc = ch.gam[j];
-          if ((pj <= 0.0 && inc) || (pj >= 1.0 && !inc)) {
-            if (!inc && ch.k >= P.kcap) { status = CHAIN_MODEL_TOO_LARGE; break; }
-            apply_flip(ch, j);
-          }
+  while (status == CHAIN_OK) {
+    if (pe.kind != EV_NONE) {
+      // ---- the one place where a model is (re)built --------------------------
+      const Model keep = M;
+      if (pe.f1 >= 0) apply_flip(ch, pe.f1);
+      if (pe.f2 >= 0) apply_flip(ch, pe.f2);
+#pragma nounroll
+      for (int pass = 0; pass < 2; ++pass) {
+        Model Mn;
+        refactor(P, ch, Mn);
+        if (Mn.bad) { status = Mn.bad; break; }
+        bool acc = true;
+        if (pass == 0 && (pe.kind == EV_TRY_GE || pe.kind == EV_TRY_LT)) {
+          const double d = (Mn.logp - pe.lfw) - (keep.logp - pe.lrev);
+          if (Mn.logp > -BA_INF) min_margin = fmin(min_margin, fabs(pe.lu - d));
+          acc = (pe.kind == EV_TRY_GE) ? !(pe.lu > d) : (pe.lu < d);
         }
-        if (status == CHAIN_OK) refactor(ch, M);
-        if (status == CHAIN_OK && !M.bad &&
+        if (acc) {
+          M = Mn;
+          if (pass == 0 && pe.kind != EV_INIT) acc_acc += 1;
+          break;
+        }
+        // rejected: restore gamma and rebuild its factors
+        if (pe.f2 >= 0) apply_flip(ch, pe.f2);
+        if (pe.f1 >= 0) apply_flip(ch, pe.f1);
+      }
+      if (status == CHAIN_OK) {
+        publish_model<NB>(ch);
+        if (pe.kind == EV_FORCE && !M.pd) status = CHAIN_NOT_PD;
+        if (pe.kind == EV_INIT && pe.check_legal &&
             !(M.logp > -BA_INF && M.logp < BA_INF))
           status = CHAIN_ILLEGAL_START;
       }
-      if (M.bad) status = M.bad;
+      pe.kind = EV_NONE;
+      pe.f1 = pe.f2 = -1;
+      pe.lfw = pe.lrev = 0.0;
+      pe.check_legal = false;
+      STAMP(2);
+      continue;
+    }
 
-      // ---- p Metropolised flips, 64 proposals at a time
-      int i0 = 0;
-      while (i0 < nflips && status == CHAIN_OK) {
-        const int idx = i0 + lane;
-        const bool valid = idx < nflips;
-        const int j = valid ? ch.perm[idx] : 0;
-        const double u = philox_uniform(key, flip_pos + (uint64_t)idx);
-        const double logu = log(u);
-        Proposal pr = eval_proposal(ch, M, j, valid);
-        const double delta = pr.logp - M.logp;
-        const bool accept = valid && !pr.slow && !pr.bad_ss && !(logu > delta);
-        const unsigned long long m_acc = __ballot(accept);
-        const unsigned long long m_slow = __ballot(valid && pr.slow);
-        const unsigned long long m_bad = __ballot(valid && pr.bad_ss);
-        const unsigned long long m_stop = m_acc | m_slow | m_bad;
-        const int f = m_stop ? (__ffsll((long long)m_stop) - 1) : WAVE;
-        // lanes before f are settled rejections
-        {
-          const bool counted = valid && lane < f;
-          const double mg = counted && (pr.logp > -BA_INF) ? fabs(logu - delta) : BA_INF;
-          min_margin = fmin(min_margin, wave_min(mg));
+    if (phase == PH_BEGIN) {
+      if (sweep >= nsweeps) break;
+      STAMP(7);
+      if (nflips > 0) {
+        // ---- shuffle(indx): cpputil/shuffle.hpp:36-46, in place on the
+        // persistent permutation.  Uniform t (t = 0..p-2) belongs to i = p-1-t.
+        for (int t = lane; t < p - 1; t += WAVE) {
+          const int i = p - 1 - t;
+          const double u = philox_uniform(key, pos + (uint64_t)t);
+          ch.oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u);
         }
-        if (f == WAVE) {
-          const int n = (nflips - i0 < WAVE) ? (nflips - i0) : WAVE;
-          acc_prop += n;
-          i0 += WAVE;
-          continue;
-        }
-        acc_prop += f + 1;
-        const int jf = __shfl(j, f, WAVE);
-        if ((m_bad >> f) & 1ull) {
-          status = CHAIN_NEGATIVE_SS;
-          break;
-        }
-        const bool adding = !ch.gam[jf];
-        if (adding && ch.k >= P.kcap) {
-          // the candidate cannot be held in LDS; if it is a sure rejection
-          // that is fine, but we cannot tell without evaluating it
-          status = CHAIN_MODEL_TOO_LARGE;
-          break;
-        }
-        if ((m_acc >> f) & 1ull) {
-          // accepted on the fast path: move to the new model
-          const double mg = fabs(bcast(logu, f) - bcast(delta, f));
-          min_margin = fmin(min_margin, mg);
-          apply_flip(ch, jf);
-          refactor(ch, M);
-          if (M.bad) { status = M.bad; break; }
-          if (!M.pd) { status = CHAIN_NOT_PD; break; }
-          acc_acc += 1;
-        } else {
-          // exact path: evaluate the flipped model from scratch
-          const double lu = bcast(logu, f);
-          const Model keep = M;
-          apply_flip(ch, jf);
-          Model Mn;
-          refactor(ch, Mn);
-          if (Mn.bad) { status = Mn.bad; break; }
-          const double dl = Mn.logp - keep.logp;
-          if (Mn.logp > -BA_INF) min_margin = fmin(min_margin, fabs(lu - dl));
-          if (lu > dl) {
-            apply_flip(ch, jf);
-            refactor(ch, M);
-          } else {
-            M = Mn;
-            acc_acc += 1;
+        __syncthreads();
+        STAMP(0);
+        if (p > 1) parallel_shuffle(ch);
+        flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
+        pos = flip_pos + (uint64_t)nflips;
+        STAMP(1);
+        if (!model_checked) {
+          model_checked = true;
+          if (!(M.logp > -BA_INF && M.logp < BA_INF)) {
+            // VariableSelectionPrior::make_valid, VariableSelectionPrior.cpp:287-300
+            for (int j = 0; j < p; ++j) {
+              const double pj = P.pi[j];
+              const bool inc = ch.gam[j];
+              if ((pj <= 0.0 && inc) || (pj >= 1.0 && !inc)) {
+                if (!inc && ch.k >= KCAP) { status = CHAIN_MODEL_TOO_LARGE; break; }
+                apply_flip(ch, j);
+              }
+            }
+            pe.kind = EV_INIT;
+            pe.check_legal = true;
           }
         }
-        i0 += f + 1;
       }
-      if (status != CHAIN_OK) break;
+      i0 = 0;
+      phase = PH_FLIPS;
+      continue;
     }
 
-    SeqRng rng{key, pos};
-    if (nflips > 0) attempt_swap(ch, M, rng, &status);
-    if (status != CHAIN_OK) break;
-    if (nflips == 0) {
-      refactor(ch, M);  // set_reg_post_params(inc, false)
-      if (M.bad) { status = M.bad; break; }
+    if (phase == PH_FLIPS) {
+      if (nflips == 0 || i0 >= nflips) {
+        phase = PH_SWAP;
+        continue;
+      }
+      // ---- Metropolised flips, 64 proposals at a time
+      const int idx = i0 + lane;
+      const bool valid = idx < nflips;
+      const int j = valid ? ch.perm[idx] : 0;
+      const double u = philox_uniform(key, flip_pos + (uint64_t)idx);
+      const double logu = log(u);
+      Proposal pr = eval_proposal<NB>(P, ch, M, j, valid);
+      const double delta = pr.logp - M.logp;
+      const bool accept = valid && !pr.slow && !pr.bad_ss && !(logu > delta);
+      const unsigned long long m_acc = __ballot(accept);
+      const unsigned long long m_slow = __ballot(valid && pr.slow);
+      const unsigned long long m_bad = __ballot(valid && pr.bad_ss);
+      const unsigned long long m_stop = m_acc | m_slow | m_bad;
+      const int f = m_stop ? (__ffsll((long long)m_stop) - 1) : WAVE;
+      // lanes before f are settled rejections; f itself counts if accepted
+      {
+        const bool counted = valid && (lane < f || (lane == f && ((m_acc >> f) & 1ull)));
+        const double mg = counted && (pr.logp > -BA_INF) ? fabs(logu - delta) : BA_INF;
+        min_margin = fmin(min_margin, wave_min(mg));
+      }
+      STAMP(3);
+      if (f == WAVE) {
+        const int n = (nflips - i0 < WAVE) ? (nflips - i0) : WAVE;
+        acc_prop += n;
+        i0 += WAVE;
+        continue;
+      }
+      acc_prop += f + 1;
+      const int jf = bcast_u(j, f);
+      if ((m_bad >> f) & 1ull) {
+        status = CHAIN_NEGATIVE_SS;
+        break;
+      }
+      if (!ch.gam[jf] && ch.k >= KCAP) {
+        // the candidate cannot be held in LDS; if it is a sure rejection that
+        // is fine, but we cannot tell without evaluating it
+        status = CHAIN_MODEL_TOO_LARGE;
+        break;
+      }
+      pe.f1 = jf;
+      if ((m_acc >> f) & 1ull) {
+        pe.kind = EV_FORCE;  // accepted on the fast path: move to the new model
+      } else {
+        pe.kind = EV_TRY_GE;  // exact path: evaluate the flipped model
+        pe.lu = bcast_u(logu, f);
+      }
+      i0 += f + 1;
+      continue;
     }
+
+    if (phase == PH_SWAP) {
+      rng.pos = pos;
+      if (nflips > 0) propose_swap(P, ch, rng, pe, &status);
+      pos = rng.pos;
+      phase = PH_TAIL;
+      STAMP(4);
+      continue;
+    }
+
+    // ---- PH_TAIL: sigma, beta, summaries
     k = ch.k;
-
-    // ---- draw_sigma (BregVsSampler.cpp:313-324)
+    rng.pos = pos;
+    // draw_sigma (BregVsSampler.cpp:313-324)
     if (P.draw_sigma) {
       int bad = 0;
       const double DF = (k == 0) ? ch.DF : ((ch.DF - P.prior_df) + P.prior_df);
@@ -617,7 +959,9 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
       sigsq = d_draw_variance(rng, DF, SS, P.sigma_max, &bad);
       if (bad) { status = CHAIN_RNG_BRANCH; break; }
     }
-    // ---- draw_beta (BregVsSampler.cpp:326-351)
+    pos = rng.pos;
+    STAMP(5);
+    // draw_beta (BregVsSampler.cpp:326-351)
     if (P.draw_beta && k > 0) {
       if (!M.pd) {
         ++failures;
@@ -625,28 +969,24 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
         break;
       }
       failures = 0;
-      // z_i ~ N(0,1) in coefficient order (distributions/mvn.cpp:114-122)
-      double z = 0.0;
-      for (int m = 0; m < k; ++m) {
-        const double zm = d_norm_rand(rng);
-        if (lane == m) z = zm;
-      }
+      const double z = draw_normals(key, &pos, k, lane);
       // beta = L^{-T}(w + sigma z): chol(V / sigma^2) = L / sigma
       const double sigma = sqrt(sigsq);
       double y = (lane < k) ? ch.w[lane] + sigma * z : 0.0;
+      const double rdm = (lane < k) ? ch.rdv[lane] : 0.0;
       for (int i = k - 1; i >= 0; --i) {
-        const double xi = bcast(y, i) * ch.rdv[i];
+        const double xi = bcast_u(y, i) * bcast_u(rdm, i);
         if (lane == i) y = xi;
-        else if (lane < i) y -= ch.Lv[tri(i, lane)] * xi;
+        else if (lane < i) y -= ch.Lv[bidx(i, lane)] * xi;
       }
       beta_m = y;
       beta_valid = true;
     } else if (P.draw_beta) {
       beta_valid = true;  // empty model: all coefficients zero
     }
-    pos = rng.pos;
+    STAMP(6);
 
-    // ---- summaries
+    // summaries
     if (lane < k) {
       const size_t o = (size_t)chain * p + ch.g[lane];
       P.inc_count[o] += 1u;
@@ -665,6 +1005,8 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
       P.trace_k[o] = (double)k;
     }
     ++done;
+    ++sweep;
+    phase = PH_BEGIN;
   }
 
   // ---- write the chain back
@@ -699,6 +1041,9 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
     a[ACC_ACCEPTS] += acc_acc;
     a[ACC_PROPOSALS] += acc_prop;
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], min_margin);
+#ifdef BA_STAMPS
+    for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += st_ph[i];
+#endif
   }
 }
 
@@ -713,20 +1058,9 @@ __global__ __launch_bounds__(64) void ssvs_logp_kernel(SsvsParams P,
   if (which >= ngamma) return;
   const SsvsLds lay = ssvs_lds_layout(p, P.kcap);
   Chain ch;
-  ch.P = &P;
   ch.lane = lane;
   ch.p = p;
-  ch.Lv = (double *)(smem + lay.Lv);
-  ch.La = (double *)(smem + lay.La);
-  ch.rdv = (double *)(smem + lay.rdv);
-  ch.rda = (double *)(smem + lay.rda);
-  ch.w = (double *)(smem + lay.w);
-  ch.bg = (double *)(smem + lay.bg);
-  ch.buf = (double *)(smem + lay.buf);
-  ch.g = (uint16_t *)(smem + lay.g);
-  ch.perm = (uint16_t *)(smem + lay.perm);
-  ch.oth = (uint16_t *)(smem + lay.oth);
-  ch.gam = (uint8_t *)(smem + lay.gam);
+  bind_lds(ch, smem, lay);
   ch.xty = P.xty;
   ch.DF = P.nobs[0] + P.prior_df;
   ch.ss0q = P.prior_ss + P.yty[0];
@@ -748,51 +1082,80 @@ __global__ __launch_bounds__(64) void ssvs_logp_kernel(SsvsParams P,
   ch.k = k;
   __syncthreads();
   Model M;
-  refactor(ch, M);
+  refactor(P, ch, M);
   if (lane == 0) {
     out[which] = M.logp;
     status_out[which] = M.bad;
   }
 }
 
-// Reduce the per-chain summaries over chains into one block of (3p + 8)
-// doubles: [inclusion counts | beta sums | beta sums of squares | scalars].
-__global__ void ssvs_reduce_summaries_kernel(SsvsParams P, double *out) {
-  const int p = P.p;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < p) {
-    double c = 0, s = 0, s2 = 0;
-    for (int ch = 0; ch < P.chains; ++ch) {
-      const size_t o = (size_t)ch * p + j;
-      c += (double)P.inc_count[o];
-      s += P.beta_sum[o];
-      s2 += P.beta_sumsq[o];
+// Reduce the per-chain summaries over chains into one block of
+// (3p + SUMMARY_SCALARS) doubles:
+// [inclusion counts | beta sums | beta sums of squares | scalars].
+// One workgroup per output column, chains strided over its threads, fixed
+// tree: bitwise reproducible.
+__global__ __launch_bounds__(256) void ssvs_reduce_summaries_kernel(SsvsParams P,
+                                                                    double *out) {
+  __shared__ double s0[256], s1[256], s2[256];
+  const int p = P.p, j = blockIdx.x, tid = threadIdx.x;
+  double a = 0, b = 0, c = 0;
+  const bool is_min = (j >= p) && (j - p == ACC_MIN_MARGIN);
+  if (is_min) a = BA_INF;
+  for (int chn = tid; chn < P.chains; chn += 256) {
+    if (j < p) {
+      const size_t o = (size_t)chn * p + j;
+      a += (double)P.inc_count[o];
+      b += P.beta_sum[o];
+      c += P.beta_sumsq[o];
+    } else {
+      const double x = P.acc[(size_t)chn * ACC_COUNT + (j - p)];
+      a = is_min ? fmin(a, x) : a + x;
     }
-    out[j] = c;
-    out[p + j] = s;
-    out[2 * p + j] = s2;
-  } else if (j < p + SUMMARY_SCALARS) {
-    const int a = j - p;
-    double v = (a == ACC_MIN_MARGIN) ? BA_INF : 0.0;
-    for (int ch = 0; ch < P.chains; ++ch) {
-      const double x = P.acc[(size_t)ch * ACC_COUNT + a];
-      v = (a == ACC_MIN_MARGIN) ? fmin(v, x) : v + x;
+  }
+  s0[tid] = a; s1[tid] = b; s2[tid] = c;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (tid < w) {
+      s0[tid] = is_min ? fmin(s0[tid], s0[tid + w]) : s0[tid] + s0[tid + w];
+      s1[tid] += s1[tid + w];
+      s2[tid] += s2[tid + w];
     }
-    out[3 * p + a] = v;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (j < p) {
+      out[j] = s0[0];
+      out[p + j] = s1[0];
+      out[2 * p + j] = s2[0];
+    } else {
+      out[3 * p + (j - p)] = s0[0];
+    }
   }
 }
 
 // ---- host-side launchers (kept in the kernels' translation unit) -----------
-hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P,
-                             int nsweeps) {
-  const SsvsLds lay = ssvs_lds_layout(P.p, P.kcap);
-  hipError_t e = hipFuncSetAttribute((const void *)ssvs_sweep_kernel,
+template <int NB>
+static hipError_t launch_sweep_nb(hipStream_t stream, const SsvsParams &P,
+                                  int nsweeps) {
+  const SsvsLds lay = ssvs_lds_layout(P.p, NB * 8);
+  hipError_t e = hipFuncSetAttribute((const void *)ssvs_sweep_kernel<NB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lay.total);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ssvs_sweep_kernel, dim3(P.chains), dim3(WAVE), lay.total,
+  hipLaunchKernelGGL(ssvs_sweep_kernel<NB>, dim3(P.chains), dim3(WAVE), lay.total,
                      stream, P, nsweeps);
   return hipGetLastError();
+}
+
+hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P,
+                             int nsweeps) {
+  switch (P.kcap) {
+    case 16: return launch_sweep_nb<2>(stream, P, nsweeps);
+    case 32: return launch_sweep_nb<4>(stream, P, nsweeps);
+    case 48: return launch_sweep_nb<6>(stream, P, nsweeps);
+    case 64: return launch_sweep_nb<8>(stream, P, nsweeps);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_ssvs_logp(hipStream_t stream, const SsvsParams &P,
@@ -810,8 +1173,7 @@ hipError_t launch_ssvs_logp(hipStream_t stream, const SsvsParams &P,
 
 hipError_t launch_ssvs_reduce_summaries(hipStream_t stream, const SsvsParams &P,
                                         double *out) {
-  const int total = P.p + SUMMARY_SCALARS;
-  hipLaunchKernelGGL(ssvs_reduce_summaries_kernel, dim3((total + 255) / 256),
+  hipLaunchKernelGGL(ssvs_reduce_summaries_kernel, dim3(P.p + SUMMARY_SCALARS),
                      dim3(256), 0, stream, P, out);
   return hipGetLastError();
 }

@@ -17,7 +17,7 @@ enum ChainStatus : int32_t {
 };
 
 // number of doubles in the reduced summary block: 3p + SUMMARY_SCALARS
-enum { SUMMARY_SCALARS = 8 };
+enum { SUMMARY_SCALARS = 16 };
 // per-chain scalar accumulators (doubles)
 enum {
   ACC_SWEEPS = 0,
@@ -28,14 +28,18 @@ enum {
   ACC_PROPOSALS = 5,
   ACC_MIN_MARGIN = 6,
   ACC_RESERVED = 7,
-  ACC_COUNT = 8
+  // 8..15: per-phase cycle counters, filled only by the -DBA_STAMPS diagnostic
+  // build (shuffle uniforms, shuffle serial, refactor, proposal batches, swap,
+  // sigma, beta, rest); zero in the production library
+  ACC_PHASE0 = 8,
+  ACC_COUNT = 16
 };
 
 struct SsvsParams {
   int32_t p;
   int32_t chains;
   int64_t chain_offset;
-  int32_t kcap;  // largest model the LDS working set can hold (<= 64)
+  int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
 
   // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
   const double *V;    // XtX + Omega^{-1}, p x p (symmetric, full storage)
@@ -74,6 +78,13 @@ struct SsvsParams {
   // RNG key
   uint32_t seed_lo, seed_hi, stream;
 
+  // Per-chain copy of the current model's wave-uniform data (both Cholesky
+  // factors, their reciprocal diagonals, w, b_g, g) in HBM, laid out by
+  // ssvs_scalar_layout(); the proposal evaluation reads it through the scalar
+  // cache (s_load) so that factor elements arrive as SGPR operands of the FMAs.
+  double *model_scratch;        // chains x model_scratch_stride doubles
+  int64_t model_scratch_stride;
+
   // summaries (per chain; reduced over chains by a second kernel)
   uint32_t *inc_count;  // chains x p
   double *beta_sum;     // chains x p
@@ -85,28 +96,57 @@ struct SsvsParams {
 };
 
 // ---- LDS layout of one chain (one wavefront) --------------------------------
+// The two Cholesky factors are stored "block packed": 8 x 8 blocks, lower
+// block-triangle only, block (I, J) at index I(I+1)/2 + J, each block 64
+// doubles row-major (512 B, 16-byte aligned rows) so that a proposal's
+// per-lane triangular solve streams whole blocks with ds_read_b128 and keeps
+// its solution vector in registers.  kcap is a multiple of 8.
 // doubles first, then 16-bit, then bytes; all offsets in bytes.
 struct SsvsLds {
-  uint32_t Lv, La, rdv, rda, w, bg, buf, g, perm, oth, gam, total;
+  uint32_t Lv, La, rdv, rda, w, bg, g, perm0, perm1, oth, last, pred, gam, total;
 };
 
 static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
   SsvsLds L;
-  const uint32_t tri = (uint32_t)kcap * (kcap + 1) / 2;
+  const uint32_t nb = (uint32_t)kcap / 8;
+  const uint32_t fac = nb * (nb + 1) / 2 * 64 * 8;
+  const uint32_t pv = (((uint32_t)p * 2) + 15u) & ~15u;
   uint32_t o = 0;
-  L.Lv = o;   o += tri * 8;
-  L.La = o;   o += tri * 8;
-  L.rdv = o;  o += (uint32_t)kcap * 8;
-  L.rda = o;  o += (uint32_t)kcap * 8;
-  L.w = o;    o += (uint32_t)kcap * 8;
-  L.bg = o;   o += (uint32_t)kcap * 8;
-  L.buf = o;  o += (uint32_t)kcap * 64 * 8;
-  L.g = o;    o += (((uint32_t)kcap * 2) + 7u) & ~7u;
-  L.perm = o; o += (((uint32_t)p * 2) + 7u) & ~7u;
-  L.oth = o;  o += (((uint32_t)p * 2) + 7u) & ~7u;
-  L.gam = o;  o += ((uint32_t)p + 15u) & ~15u;
+  L.Lv = o;    o += fac;
+  L.La = o;    o += fac;
+  L.rdv = o;   o += (uint32_t)kcap * 8;
+  L.rda = o;   o += (uint32_t)kcap * 8;
+  L.w = o;     o += (uint32_t)kcap * 8;
+  L.bg = o;    o += (uint32_t)kcap * 8;
+  L.g = o;     o += (((uint32_t)kcap * 2) + 15u) & ~15u;
+  L.perm0 = o; o += pv;
+  L.perm1 = o; o += pv;
+  L.oth = o;   o += pv;
+  L.last = o;  o += pv;
+  L.pred = o;  o += pv;
+  L.gam = o;   o += ((uint32_t)p + 15u) & ~15u;
   L.total = o;
   return L;
+}
+
+// offsets (in doubles) inside one chain's model_scratch block
+struct SsvsScalarLayout {
+  uint32_t Lv, La, rdv, rda, w, bg, g, total;
+};
+static inline __host__ __device__ SsvsScalarLayout ssvs_scalar_layout(int kcap) {
+  SsvsScalarLayout S;
+  const uint32_t nb = (uint32_t)kcap / 8;
+  const uint32_t fac = nb * (nb + 1) / 2 * 64;
+  uint32_t o = 0;
+  S.Lv = o;  o += fac;
+  S.La = o;  o += fac;
+  S.rdv = o; o += (uint32_t)kcap;
+  S.rda = o; o += (uint32_t)kcap;
+  S.w = o;   o += (uint32_t)kcap;
+  S.bg = o;  o += (uint32_t)kcap;
+  S.g = o;   o += (uint32_t)kcap / 2;  // int32 indices, two per double
+  S.total = (o + 7u) & ~7u;            // whole 64-byte lines per chain
+  return S;
 }
 
 }  // namespace boom_amd

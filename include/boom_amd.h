@@ -150,14 +150,16 @@ int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
 /* Running sums over every sweep since the last ba_reset_summaries(), reduced
  * over this engine's chains on the device:
  *   inclusion_count[p] (as double), beta_sum[p], beta_sumsq[p],
- *   scalars[8] = {sweeps*chains, sum sigsq, sum sigsq^2, sum |gamma|,
- *                 accepted flips, proposed flips, min accept margin, reserved}
- * The layout is one contiguous block of (3p + 8) doubles so that a single
+ *   scalars[16] = {sweeps*chains, sum sigsq, sum sigsq^2, sum |gamma|,
+ *                  accepted flips, proposed flips, min accept margin, reserved,
+ *                  [8..15] per-phase cycle counters of the diagnostic build
+ *                  (zero in the production library)}
+ * The layout is one contiguous block of (3p + 16) doubles so that a single
  * collective moves it (see ba_summaries_device). */
 int ba_reset_summaries(ba_engine *e);
 int ba_get_summaries(ba_engine *e, double *inclusion_count, double *beta_sum,
                      double *beta_sumsq, double *scalars);
-/* reduce into a device buffer of (3p + 8) doubles owned by the caller (e.g. a
+/* reduce into a device buffer of (3p + 16) doubles owned by the caller (e.g. a
  * torch tensor that then goes through RCCL); stream-ordered on the engine's
  * stream followed by a sync */
 int ba_summaries_device(ba_engine *e, void *out_device);

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of ssvs_sweep_kernel from the -DBA_STAMPS
+build (boom_amd/libboomamd_stamps.so).  Read the SHARES, not the run time."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", "libboomamd_stamps.so")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import time
+import numpy as np
+import boom_amd
+from cases import regression_data, spike_slab_prior
+
+n, p, nsig = 10000, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 16
+chains = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+X, y, _ = regression_data(n, p, nsig, seed=8675309)
+eng = boom_amd.Engine(chains, seed=1)
+eng.build_suf_from_xy(X, y)
+s = eng.get_suf()
+suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"],
+           sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])
+prior = spike_slab_prior(suf, nsig)
+eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+g0 = np.zeros(p, np.uint8); g0[0] = 1
+eng.set_state(g0)
+eng.sweep(200)
+eng.reset_summaries()
+t0 = time.perf_counter()
+eng.sweep(100)
+dt = time.perf_counter() - t0
+sm = eng.get_summaries()
+ph = sm["phase_cycles"]
+names = ["shuffle uniforms", "shuffle serial", "refactor", "proposal batches",
+         "swap", "sigma", "beta", "rest"]
+tot = ph.sum()
+print("signals %d chains %d: %.1f us per sweep-round, kbar %.2f, accepts/sweep %.3f, proposals/sweep %.1f"
+      % (nsig, chains, dt / 100 * 1e6, sm["k_sum"] / sm["sweeps"], sm["accepts"] / sm["sweeps"],
+         sm["proposals"] / sm["sweeps"]))
+for nm, v in zip(names, ph):
+    print("  %-18s %6.2f %%   %10.0f cycles/sweep" % (nm, 100 * v / tot, v / sm["sweeps"]))
