@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/boom_amd.h"
+#include "kalman_params.h"
 #include "ssvs_params.h"
 
 namespace boom_amd {
@@ -28,7 +29,8 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        const double *y, double *xtx, double *xty,
                        double *scalars /* yty, sumy */, double *xsum);
 // kalman_kernel.hip
-struct SsParams;
+hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
+                                   int draw_level);
 }  // namespace boom_amd
 
 using namespace boom_amd;
@@ -153,6 +155,18 @@ struct ba_engine {
 
   int kcap = 0;
   uint64_t seed = 0;
+
+  // ---- state space (bsts local level + regression)
+  bool ss_mode = false, ss_level_set = false, ss_initialized = false;
+  int T = 0;
+  DevBuf<double> dss_y, dss_X, dss_scratch;
+  DevBuf<uint8_t> dss_obs;
+  DevBuf<double> dxty_c, dyty_c, dnobs_c;       // per-chain regression suf
+  DevBuf<double> dlev_sigsq, dlev_n, dlev_sumsq;
+  DevBuf<uint64_t> dpos_level, dpos_state;
+  double level_prior_df = 0, level_prior_ss = 0;
+  double level_sigma_max = std::numeric_limits<double>::infinity();
+  double ss_a0 = 0, ss_P0 = 1, ss_initial_level_sigsq = 1;
 };
 
 namespace {
@@ -309,11 +323,19 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.l1 = e->dl1.ptr;
   P.l0 = e->dl0.ptr;
   P.pi = e->dpi.ptr;
-  P.xty = e->dxty.ptr;
-  P.xty_stride = 0;
-  P.yty = e->dscal.ptr;
-  P.nobs = e->dscal.ptr + 1;
-  P.suf_stride = 0;
+  if (e->ss_mode) {
+    P.xty = e->dxty_c.ptr;
+    P.xty_stride = e->p;
+    P.yty = e->dyty_c.ptr;
+    P.nobs = e->dnobs_c.ptr;
+    P.suf_stride = 1;
+  } else {
+    P.xty = e->dxty.ptr;
+    P.xty_stride = 0;
+    P.yty = e->dscal.ptr;
+    P.nobs = e->dscal.ptr + 1;
+    P.suf_stride = 0;
+  }
   P.prior_df = e->prior_df;
   P.prior_ss = e->prior_ss;
   P.sigma_max = e->sigma_max;
@@ -858,23 +880,208 @@ int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
 }
 
 // --------------------------------------------------- state space (kalman)
-// Implemented in a later milestone of this round; the entry points exist so
-// that the ABI is complete and callers fail loudly rather than at link time.
-static int ss_unavailable() {
-  return fail(BA_E_STATE, "state-space path not built into this library yet");
+static void fill_ss_params(ba_engine *e, SsParams &S) {
+  std::memset(&S, 0, sizeof(S));
+  S.T = e->T;
+  S.p = e->p;
+  S.chains = e->cfg.chains;
+  S.chain_offset = e->cfg.chain_offset;
+  S.y = e->dss_y.ptr;
+  S.X = e->dss_X.ptr;
+  S.observed = e->dss_obs.ptr;
+  S.gamma = e->dgamma.ptr;
+  S.beta = e->dbeta.ptr;
+  S.sigsq = e->dsigsq.ptr;
+  S.level_sigsq = e->dlev_sigsq.ptr;
+  S.level_n = e->dlev_n.ptr;
+  S.level_sumsq = e->dlev_sumsq.ptr;
+  S.level_prior_df = e->level_prior_df;
+  S.level_prior_ss = e->level_prior_ss;
+  S.level_sigma_max = e->level_sigma_max;
+  S.a0 = e->ss_a0;
+  S.P0 = e->ss_P0;
+  S.seed_lo = (uint32_t)e->seed;
+  S.seed_hi = (uint32_t)(e->seed >> 32);
+  S.pos_level = e->dpos_level.ptr;
+  S.pos_state = e->dpos_state.ptr;
+  S.status = e->dstatus.ptr;
+  S.scratch = e->dss_scratch.ptr;
+  S.scratch_stride = (int64_t)SS_SCRATCH_ARRAYS * e->T;
+  S.xty = e->dxty_c.ptr;
+  S.yty = e->dyty_c.ptr;
+  S.nobs = e->dnobs_c.ptr;
 }
-int ba_ss_set_data(ba_engine *, int32_t, int32_t, const double *, const double *,
-                   const uint8_t *) { return ss_unavailable(); }
-int ba_ss_set_local_level(ba_engine *, double, double, double, double, double,
-                          double) { return ss_unavailable(); }
-int ba_ss_sweep(ba_engine *, int32_t) { return ss_unavailable(); }
-int ba_ss_impute_state(ba_engine *) { return ss_unavailable(); }
-int ba_ss_get_state(ba_engine *, int64_t, double *, double *, double *, double *) {
-  return ss_unavailable();
+
+static int ss_prepare(ba_engine *e) {
+  if (!e->ss_mode) return fail(BA_E_STATE, "call ba_ss_set_data first");
+  if (!e->ss_level_set) return fail(BA_E_STATE, "call ba_ss_set_local_level first");
+  int rc = upload_shared(e);
+  if (rc) return rc;
+  rc = alloc_chain_state(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, T = (size_t)e->T;
+  if (e->dss_scratch.count != C * SS_SCRATCH_ARRAYS * T) {
+    HIP_TRY(e->dss_scratch.resize(C * SS_SCRATCH_ARRAYS * T));
+    HIP_TRY(e->dxty_c.resize(C * p));
+    HIP_TRY(e->dyty_c.resize(C));
+    HIP_TRY(e->dnobs_c.resize(C));
+    HIP_TRY(e->dlev_sigsq.resize(C));
+    HIP_TRY(e->dlev_n.resize(C));
+    HIP_TRY(e->dlev_sumsq.resize(C));
+    HIP_TRY(e->dpos_level.resize(C));
+    HIP_TRY(e->dpos_state.resize(C));
+    // regression suf starts as the data's own (before the first impute_state)
+    std::vector<double> xty(C * p), yty(C, e->yty), nobs(C, e->n),
+        lev(C, e->ss_initial_level_sigsq);
+    for (size_t c = 0; c < C; ++c) std::memcpy(&xty[c * p], e->xty.data(), p * 8);
+    HIP_TRY(hipMemcpy(e->dxty_c.ptr, xty.data(), xty.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->dyty_c.ptr, yty.data(), C * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->dnobs_c.ptr, nobs.data(), C * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->dlev_sigsq.ptr, lev.data(), C * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(e->dlev_n.ptr, 0, C * 8));
+    HIP_TRY(hipMemset(e->dlev_sumsq.ptr, 0, C * 8));
+    HIP_TRY(hipMemset(e->dpos_level.ptr, 0, C * 8));
+    HIP_TRY(hipMemset(e->dpos_state.ptr, 0, C * 8));
+    HIP_TRY(hipMemset(e->dss_scratch.ptr, 0, C * SS_SCRATCH_ARRAYS * T * 8));
+    e->ss_initialized = false;
+  }
+  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(e->kcap).total));
+  return BA_OK;
 }
-int ba_ss_set_level_sigsq(ba_engine *, int64_t, double) { return ss_unavailable(); }
-int ba_ss_get_chain_suf(ba_engine *, int64_t, double *, double *, double *) {
-  return ss_unavailable();
+
+int ba_ss_set_data(ba_engine *e, int32_t T, int32_t p, const double *y,
+                   const double *X, const uint8_t *observed) {
+  ENGINE_PROLOGUE(e);
+  if (!y || !X) return fail(BA_E_INVALID, "null argument");
+  if (T <= 0 || p <= 0) return fail(BA_E_INVALID, "T and p must be positive");
+  // The regression model's fixed XtX (and the initial Xty, ...) are over the
+  // OBSERVED rows only: missing points never update the sufficient statistics
+  // (StateSpaceRegressionModel.cpp:100-125, SufstatDataPolicy.hpp:166-167).
+  std::vector<double> Xo((size_t)T * p), yo(T);
+  std::vector<uint8_t> obs(T, 1);
+  double nobs = 0;
+  for (int t = 0; t < T; ++t) {
+    if (observed) obs[t] = observed[t] ? 1 : 0;
+    nobs += obs[t];
+    yo[t] = obs[t] ? y[t] : 0.0;
+  }
+  for (int j = 0; j < p; ++j)
+    for (int t = 0; t < T; ++t)
+      Xo[(size_t)j * T + t] = obs[t] ? X[(size_t)j * T + t] : 0.0;
+  int rc = ba_build_suf_from_xy(e, T, p, Xo.data(), yo.data());
+  if (rc) return rc;
+  e->n = nobs;
+  e->T = T;
+  HIP_TRY(e->dss_y.resize(T));
+  HIP_TRY(e->dss_X.resize((size_t)T * p));
+  HIP_TRY(e->dss_obs.resize(T));
+  HIP_TRY(hipMemcpy(e->dss_y.ptr, y, (size_t)T * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dss_X.ptr, X, (size_t)T * p * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dss_obs.ptr, obs.data(), T, hipMemcpyHostToDevice));
+  e->ss_mode = true;
+  e->ss_initialized = false;
+  e->dss_scratch.release();
+  e->device_dirty = true;
+  return BA_OK;
+}
+
+int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_guess,
+                          double level_sigma_upper_limit,
+                          double initial_state_mean,
+                          double initial_state_variance,
+                          double initial_level_sigma) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (level_sigma_upper_limit < 0 || initial_state_variance < 0)
+    return fail(BA_E_INVALID, "sigma_max must be non-negative.");
+  // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
+  e->level_prior_df = 2 * (level_df / 2.0);
+  e->level_prior_ss = 2 * (level_df * level_sigma_guess * level_sigma_guess / 2.0);
+  e->level_sigma_max = level_sigma_upper_limit;
+  e->ss_a0 = initial_state_mean;
+  e->ss_P0 = initial_state_variance;
+  e->ss_initial_level_sigsq = initial_level_sigma * initial_level_sigma;
+  e->ss_level_set = true;
+  e->dss_scratch.release();
+  return BA_OK;
+}
+
+int ba_ss_impute_state(ba_engine *e) {
+  ENGINE_PROLOGUE(e);
+  int rc = ss_prepare(e);
+  if (rc) return rc;
+  SsParams S;
+  fill_ss_params(e, S);
+  HIP_TRY(launch_kalman_simsmooth(e->stream, S, 0));
+  e->ss_initialized = true;
+  return BA_OK;
+}
+
+int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  int rc = ss_prepare(e);
+  if (rc) return rc;
+  SsvsParams P;
+  fill_params(e, P);
+  SsParams S;
+  fill_ss_params(e, S);
+  // StateSpacePosteriorSampler::draw (StateSpacePosteriorSampler.cpp:42-64)
+  if (!e->ss_initialized) {
+    HIP_TRY(launch_kalman_simsmooth(e->stream, S, 0));
+    e->ss_initialized = true;
+  }
+  for (int i = 0; i < nsweeps; ++i) {
+    HIP_TRY(launch_ssvs_sweep(e->stream, P, 1));     // observation model
+    HIP_TRY(launch_kalman_simsmooth(e->stream, S, 1));  // level model, state
+  }
+  return BA_OK;
+}
+
+int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
+                    double *level_sigsq, double *level_n, double *level_sumsq) {
+  ENGINE_PROLOGUE(e);
+  if (!e->ss_mode || e->dss_scratch.count == 0) return fail(BA_E_STATE, "no state-space run yet");
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t T = (size_t)e->T;
+  if (state)
+    HIP_TRY(hipMemcpy(state, e->dss_scratch.ptr + ((size_t)chain * SS_SCRATCH_ARRAYS + SS_STATE_ARRAY) * T,
+                      T * 8, hipMemcpyDeviceToHost));
+  if (level_sigsq) HIP_TRY(hipMemcpy(level_sigsq, e->dlev_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost));
+  if (level_n) HIP_TRY(hipMemcpy(level_n, e->dlev_n.ptr + chain, 8, hipMemcpyDeviceToHost));
+  if (level_sumsq) HIP_TRY(hipMemcpy(level_sumsq, e->dlev_sumsq.ptr + chain, 8, hipMemcpyDeviceToHost));
+  return BA_OK;
+}
+
+int ba_ss_set_level_sigsq(ba_engine *e, int64_t chain, double sigsq) {
+  ENGINE_PROLOGUE(e);
+  int rc = ss_prepare(e);
+  if (rc) return rc;
+  const int64_t C = e->cfg.chains;
+  if (chain < -1 || chain >= C) return fail(BA_E_INVALID, "chain index out of range");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (chain < 0) {
+    std::vector<double> v((size_t)C, sigsq);
+    HIP_TRY(hipMemcpy(e->dlev_sigsq.ptr, v.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy(e->dlev_sigsq.ptr + chain, &sigsq, 8, hipMemcpyHostToDevice));
+  }
+  return BA_OK;
+}
+
+int ba_ss_get_chain_suf(ba_engine *e, int64_t chain, double *xty, double *yty,
+                        double *n) {
+  ENGINE_PROLOGUE(e);
+  if (!e->ss_mode || e->dxty_c.count == 0) return fail(BA_E_STATE, "no state-space run yet");
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p;
+  if (xty) HIP_TRY(hipMemcpy(xty, e->dxty_c.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost));
+  if (yty) HIP_TRY(hipMemcpy(yty, e->dyty_c.ptr + chain, 8, hipMemcpyDeviceToHost));
+  if (n) HIP_TRY(hipMemcpy(n, e->dnobs_c.ptr + chain, 8, hipMemcpyDeviceToHost));
+  return BA_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,42 @@
+// Launch parameters of the Kalman filter / simulation smoother kernel
+// (kalman_kernel.hip), shared with the host side (engine.hip).
+#pragma once
+#include <stdint.h>
+
+#include "ssvs_params.h"
+
+namespace boom_amd {
+
+struct SsParams {
+  int32_t T, p, chains;
+  int64_t chain_offset;
+  // shared data: StateSpaceRegressionModel(y, X, observed)
+  const double *y;          // T
+  const double *X;          // T x p column-major
+  const uint8_t *observed;  // T
+  // regression parameters of every chain (written by the SSVS kernel)
+  const uint8_t *gamma;     // chains x p
+  const double *beta;       // chains x p
+  const double *sigsq;      // chains
+  // local level state model + its sampler
+  double *level_sigsq;      // chains
+  double *level_n;          // chains  (ZeroMeanGaussianModel suf)
+  double *level_sumsq;      // chains
+  double level_prior_df, level_prior_ss, level_sigma_max;
+  double a0, P0;            // initial state mean / variance
+  // RNG: stream 1 = level sampler, stream 2 = state imputation
+  uint32_t seed_lo, seed_hi;
+  uint64_t *pos_level, *pos_state;
+  int32_t *status;
+  // per-chain work arrays in HBM: v, F, K, v_sim, state, r, r_sim (T each)
+  double *scratch;
+  int64_t scratch_stride;   // >= 7 T
+  // per-chain regression sufficient statistics rebuilt by impute_state
+  double *xty;              // chains x p
+  double *yty;              // chains
+  double *nobs;             // chains
+};
+
+enum { SS_SCRATCH_ARRAYS = 7, SS_STATE_ARRAY = 4 };
+
+}  // namespace boom_amd

@@ -1,0 +1,109 @@
+"""GPU parity of the bsts local-level + regression path (Kalman filter +
+Durbin-Koopman simulation smoother + per-chain regression sufficient statistics
++ SSVS on them) against the CPU oracle, through the C-ABI.
+
+Bars: inclusion indicators bit-exact; beta, sigma^2_obs, sigma^2_level and the
+state draw within RTOL (fp64; the kernel reduces X'e and e'e with a different
+summation order than the sequential oracle).
+"""
+import numpy as np
+import pytest
+
+from cases import bsts_priors, state_space_data
+from oracle_lib import ssvs_options
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+def relerr(a, b, floor=1e-3):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def make_engine(chains, seed, y, X, obs, prior, ss, sig_up, g0):
+    import boom_amd
+    eng = boom_amd.Engine(chains, seed=seed)
+    eng.ss_set_data(y, X, obs)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"],
+                   prior["sigma_guess"], sigma_upper_limit=sig_up)
+    eng.ss_set_local_level(ss["level_df"], ss["level_sigma_guess"],
+                           ss["level_sigma_upper_limit"], ss["initial_state_mean"],
+                           ss["initial_state_variance"], ss["initial_level_sigma"])
+    eng.set_state(g0)
+    return eng
+
+
+@pytest.mark.parametrize("missing", [0.0, 0.05])
+def test_state_space_every_sweep(oracle, missing):
+    T, p, chains, nsw, seed = 200, 8, 6, 40, 31
+    X, y, _, obs = state_space_data(T, p, 3, seed=5, missing_frac=missing)
+    prior, ss, sig_up = bsts_priors(X, y, 3)
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(p, np.uint8)
+    eng = make_engine(chains, seed, y, X, obs, prior, ss, sig_up, g0)
+    ora = [oracle.ss_run(y, X, obs, prior, opts, ss, ("philox", seed, c), g0, nsw)
+           for c in range(chains)]
+    for o in ora:
+        assert o["status"] == 0
+    for s in range(nsw):
+        eng.ss_sweep(1)
+        gam, beta, sig = eng.get_states()
+        for c in range(chains):
+            o = ora[c]
+            assert np.array_equal(gam[c], o["gamma"][s]), (c, s)
+            assert relerr(beta[c], o["beta"][s]) < RTOL, (c, s)
+            assert abs(sig[c] - o["sigsq"][s]) < RTOL * sig[c], (c, s)
+            st = eng.ss_get_state(c)
+            assert abs(st["level_sigsq"] - o["level_sigsq"][s]) < RTOL * st["level_sigsq"]
+            assert np.max(np.abs(st["state"] - o["state"][s])) < 1e-8 * np.abs(o["state"][s]).max()
+
+
+def test_impute_state_sufficient_statistics(oracle):
+    """one impute_state with fixed parameters: state draw and the regression /
+    level sufficient statistics it leaves behind (a14-a19)."""
+    import ctypes as C
+    T, p, seed = 200, 8, 77
+    X, y, _, obs = state_space_data(T, p, 3, seed=5, missing_frac=0.05)
+    prior, ss, sig_up = bsts_priors(X, y, 3)
+    beta = np.array([3, 6, 9, 0, 0, 0, 0, 0.])
+    gam = (beta != 0).astype(np.uint8)
+    ss2 = dict(ss, initial_state_mean=float(y[0]), initial_state_variance=4.0,
+               initial_level_sigma=0.5)
+    eng = make_engine(2, seed, y, X, obs, prior, ss2, sig_up, gam)
+    eng.set_state(gam, beta, 0.04)
+    eng.ss_impute_state()
+    for c in range(2):
+        rng = oracle.rng_philox(seed, chain=c, stream=2)
+        o = oracle.ss_impute_state(y, X, obs, beta, gam, 0.04, 0.25, float(y[0]), 4.0, rng)
+        st = eng.ss_get_state(c)
+        assert np.max(np.abs(st["state"] - o["state"])) < 1e-10
+        assert st["level_n"] == o["level_n"]
+        assert abs(st["level_sumsq"] - o["level_sumsq"]) < 1e-11 * o["level_sumsq"]
+        suf = eng.ss_get_chain_suf(c)
+        e = np.where(obs.astype(bool), y - o["state"], 0.0)
+        assert relerr(suf["xty"], X.T @ e, 1e-6) < 1e-10
+        assert abs(suf["yty"] - e @ e) < 1e-10 * (e @ e)
+        assert suf["n"] == obs.sum()
+
+
+def test_config3_shape_properties():
+    """BASELINE config 3 shape (T=2000, p=100, 1024 chains): size-independent
+    properties of the draws."""
+    T, p, nsig, chains = 2000, 100, 5, 1024
+    X, y, btrue, _ = state_space_data(T, p, nsig, seed=8675309)
+    prior, ss, sig_up = bsts_priors(X, y, 5)
+    g0 = np.zeros(p, np.uint8)
+    eng = make_engine(chains, 4, y, X, None, prior, ss, sig_up, g0)
+    eng.ss_sweep(30)
+    gam, beta, sig = eng.get_states()
+    assert np.all(np.isfinite(beta)) and np.all(sig > 0)
+    assert np.sqrt(sig).max() <= sig_up * (1 + 1e-12)
+    assert gam[:, :nsig].mean() > 0.99
+    assert np.abs(beta[:, :nsig].mean(axis=0) - btrue[:nsig]).max() < 0.1
+    st = eng.ss_get_state(17)
+    assert st["level_n"] == T - 1
+    assert np.sqrt(st["level_sigsq"]) <= ss["level_sigma_upper_limit"] * (1 + 1e-12)
+    # residual sd = observation noise (+ the state draw's posterior spread)
+    resid = y - X @ beta[17] - st["state"]
+    assert 0.15 < resid.std() < 0.4
+    assert 0.1 < np.sqrt(sig).mean() < 0.5   # truth 0.2; 30 sweeps from a cold start
