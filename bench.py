@@ -129,17 +129,11 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # avg launch duration
 
     # ---- posterior summaries: one RCCL all-gather at the end ----------------
-    block = torch.empty(3 * P + boom_amd.capi.SUMMARY_SCALARS, dtype=torch.float64, device="cuda")
+    from boom_amd import dist as bd
+    block = torch.empty(bd.summary_block_size(P), dtype=torch.float64, device="cuda")
     eng.summaries_device(block.data_ptr())
-    if world > 1:
-        gathered = [torch.empty_like(block) for _ in range(world)]
-        dist.all_gather(gathered, block)
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        allb = torch.stack(gathered).cpu().numpy()
-    else:
-        allb = block.cpu().numpy()[None, :]
+    allb = bd.gather_blocks(block, world)          # ONE RCCL all-gather
+    elapsed = bd.max_over_ranks(elapsed, world, "cuda")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

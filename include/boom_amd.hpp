@@ -1,0 +1,326 @@
+// boom_amd.hpp -- header-only C++ host side over the C-ABI (boom_amd.h),
+// mirroring the slice of BOOM's class surface that sits on the hot path so
+// that callers (and our C++ parity test) read like code written against BOOM:
+//
+//   RegressionModel, GlmCoefs-style accessors   Models/Glm/RegressionModel.hpp:256-420
+//   MvnGivenScalarSigma                         Models/MvnGivenScalarSigma.hpp:57-109
+//   ChisqModel                                  Models/ChisqModel.hpp:28-39
+//   VariableSelectionPrior                      Models/Glm/VariableSelectionPrior.hpp:99-135
+//   BregVsSampler (5 ctors, setters, draw)      Models/Glm/PosteriorSamplers/BregVsSampler.hpp:64-161
+//   StateSpaceRegressionModel                   Models/StateSpace/StateSpaceRegressionModel.hpp:82-113
+//   LocalLevelStateModel                        Models/StateSpace/StateModels/LocalLevelStateModel.hpp
+//   StateSpacePosteriorSampler                  Models/StateSpace/PosteriorSamplers/StateSpacePosteriorSampler.hpp:26-38
+//   Model::sample_posterior / set_method        Models/ModelTypes.hpp:93-99, Policies/PriorPolicy.cpp:26-30
+//   report_error -> std::runtime_error          cpputil/report_error.cpp:30-32
+//
+// Differences that are the point of the exercise: a sampler owns `chains`
+// independent chains on one MI355X; draw() advances all of them; chain 0 backs
+// the model's classic single-chain accessors; Ptr<T> is std::shared_ptr<T>.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "boom_amd.h"
+
+namespace boom_amd_api {
+
+template <class T>
+using Ptr = std::shared_ptr<T>;
+typedef std::vector<double> Vector;
+typedef unsigned int uint;
+
+inline void report_error(const std::string &msg) { throw std::runtime_error(msg); }
+inline double infinity() { return std::numeric_limits<double>::infinity(); }
+
+// column-major dense matrix, BOOM::Matrix layout (LinAlg/Matrix.hpp:429)
+class Matrix {
+ public:
+  Matrix() : nr_(0), nc_(0) {}
+  Matrix(int nr, int nc, double x = 0.0) : nr_(nr), nc_(nc), v_((size_t)nr * nc, x) {}
+  int nrow() const { return nr_; }
+  int ncol() const { return nc_; }
+  double &operator()(int i, int j) { return v_[(size_t)j * nr_ + i]; }
+  double operator()(int i, int j) const { return v_[(size_t)j * nr_ + i]; }
+  double *data() { return v_.data(); }
+  const double *data() const { return v_.data(); }
+ private:
+  int nr_, nc_;
+  std::vector<double> v_;
+};
+typedef Matrix SpdMatrix;
+
+// inclusion indicators (LinAlg/Selector.hpp)
+class Selector {
+ public:
+  explicit Selector(int n = 0, bool all = false) : inc_(n, all ? 1 : 0) {}
+  int nvars_possible() const { return (int)inc_.size(); }
+  int nvars() const { int k = 0; for (auto b : inc_) k += b; return k; }
+  bool operator[](int i) const { return inc_[i] != 0; }
+  void add(int i) { inc_[i] = 1; }
+  void drop(int i) { inc_[i] = 0; }
+  void drop_all() { for (auto &b : inc_) b = 0; }
+  std::vector<uint8_t> &bytes() { return inc_; }
+  const std::vector<uint8_t> &bytes() const { return inc_; }
+ private:
+  std::vector<uint8_t> inc_;
+};
+
+class PosteriorSampler {
+ public:
+  virtual ~PosteriorSampler() {}
+  virtual void draw() = 0;
+};
+
+class Model {
+ public:
+  virtual ~Model() {}
+  void set_method(const Ptr<PosteriorSampler> &s) { samplers_.push_back(s); }
+  void clear_methods() { samplers_.clear(); }
+  int number_of_sampling_methods() const { return (int)samplers_.size(); }
+  // PriorPolicy::sample_posterior
+  void sample_posterior() { for (auto &s : samplers_) s->draw(); }
+ private:
+  std::vector<Ptr<PosteriorSampler>> samplers_;
+};
+
+// ---- priors ---------------------------------------------------------------
+struct MvnGivenScalarSigma {
+  MvnGivenScalarSigma(const Vector &mean, const SpdMatrix &ominv) : mu_(mean), ominv_(ominv) {}
+  const Vector &mu() const { return mu_; }
+  const SpdMatrix &unscaled_precision() const { return ominv_; }
+  int dim() const { return (int)mu_.size(); }
+  Vector mu_;
+  SpdMatrix ominv_;
+};
+struct ChisqModel {  // ChisqModel(df, sigma) == GammaModel(df/2, df sigma^2/2)
+  explicit ChisqModel(double df = 1.0, double sigma_estimate = 1.0) : df_(df), sigma_(sigma_estimate) {}
+  double df() const { return df_; }
+  double sigma() const { return sigma_; }
+  double alpha() const { return df_ / 2; }
+  double beta() const { return df_ * sigma_ * sigma_ / 2; }
+  double df_, sigma_;
+};
+struct VariableSelectionPrior {
+  explicit VariableSelectionPrior(const Vector &pi) : pi_(pi), max_model_size_(-1) {}
+  VariableSelectionPrior(uint n, double p) : pi_(n, p), max_model_size_(-1) {}
+  void set_max_model_size(int64_t m) { max_model_size_ = m; }
+  int64_t max_model_size() const { return max_model_size_; }
+  const Vector &prior_inclusion_probabilities() const { return pi_; }
+  uint potential_nvars() const { return (uint)pi_.size(); }
+  Vector pi_;
+  int64_t max_model_size_;
+};
+
+// ---- engine handle shared by a model and its sampler ------------------------
+class Engine {
+ public:
+  Engine(int chains, uint64_t seed, int device) {
+    ba_config cfg{device, chains, 0, seed, 0, 0};
+    if (ba_engine_create(&cfg, &e_) != BA_OK) report_error(ba_last_error());
+    chains_ = chains;
+  }
+  ~Engine() { ba_engine_destroy(e_); }
+  Engine(const Engine &) = delete;
+  ba_engine *get() const { return e_; }
+  int chains() const { return chains_; }
+  void check(int rc) const { if (rc != BA_OK) report_error(ba_last_error()); }
+ private:
+  ba_engine *e_ = nullptr;
+  int chains_ = 0;
+};
+
+// ---- RegressionModel ----------------------------------------------------------
+class RegressionModel : public Model {
+ public:
+  // RegressionModel(X, y, start_at_mle = false): sufficient statistics are
+  // built on the device (NeRegSuf(X, y))
+  RegressionModel(const Matrix &X, const Vector &y, int chains = 1,
+                  uint64_t seed = 8675309, int device = 0)
+      : eng_(new Engine(chains, seed, device)), p_(X.ncol()), inc_(X.ncol(), true),
+        beta_(X.ncol(), 0.0), sigsq_(1.0) {
+    if (X.nrow() != (int)y.size()) report_error("Number of rows of X must match the length of y.");
+    eng_->check(ba_build_suf_from_xy(eng_->get(), X.nrow(), X.ncol(), X.data(), y.data()));
+  }
+  int xdim() const { return p_; }
+  int nvars_possible() const { return p_; }
+  Selector &inc() { return inc_; }            // coef().inc()
+  const Selector &inc() const { return inc_; }
+  void drop_all() { inc_.drop_all(); }        // coef().drop_all()
+  void add(int i) { inc_.add(i); }            // coef().add(i)
+  const Vector &Beta() const { return beta_; }
+  double sigsq() const { return sigsq_; }
+  void set_sigsq(double s) { sigsq_ = s; }
+  const Ptr<Engine> &engine() const { return eng_; }
+  // all chains (chains x p row-major gamma / beta, chains sigsq)
+  void chain_states(std::vector<uint8_t> &gamma, Vector &beta, Vector &sigsq) const {
+    const size_t C = eng_->chains();
+    gamma.resize(C * p_); beta.resize(C * p_); sigsq.resize(C);
+    eng_->check(ba_get_states(eng_->get(), gamma.data(), beta.data(), sigsq.data()));
+  }
+  // used by the sampler
+  void push_state() { eng_->check(ba_set_state(eng_->get(), -1, inc_.bytes().data(), beta_.data(), sigsq_)); }
+  void pull_chain0() { eng_->check(ba_get_state(eng_->get(), 0, inc_.bytes().data(), beta_.data(), &sigsq_)); }
+ private:
+  Ptr<Engine> eng_;
+  int p_;
+  Selector inc_;
+  Vector beta_;
+  double sigsq_;
+};
+
+// ---- BregVsSampler ---------------------------------------------------------------
+class BregVsSampler : public PosteriorSampler {
+ public:
+  // ctor #1 (BregVsSampler.cpp:48-85)
+  BregVsSampler(RegressionModel *model, double prior_nobs, double expected_rsq,
+                double expected_model_size, bool first_term_is_intercept = true)
+      : model_(model) {
+    check(ba_set_priors_ctor1(h(), prior_nobs, expected_rsq, expected_model_size,
+                              first_term_is_intercept));
+  }
+  // ctor #2 (BregVsSampler.cpp:87-142)
+  BregVsSampler(RegressionModel *model, double prior_sigma_nobs, double prior_sigma_guess,
+                double prior_beta_nobs, double diagonal_shrinkage,
+                double prior_inclusion_probability, bool force_intercept = true)
+      : model_(model) {
+    check(ba_set_priors_ctor2(h(), prior_sigma_nobs, prior_sigma_guess, prior_beta_nobs,
+                              diagonal_shrinkage, prior_inclusion_probability, force_intercept));
+  }
+  // ctor #3 (BregVsSampler.cpp:144-160)
+  BregVsSampler(RegressionModel *model, const Vector &prior_mean,
+                const SpdMatrix &unscaled_prior_precision, double sigma_guess, double df,
+                const Vector &prior_inclusion_probs)
+      : model_(model) {
+    set_raw(prior_mean, unscaled_prior_precision, df, sigma_guess, prior_inclusion_probs, -1);
+  }
+  // ctor #5 (BregVsSampler.cpp:180-194)
+  BregVsSampler(RegressionModel *model, const Ptr<MvnGivenScalarSigma> &slab,
+                const Ptr<ChisqModel> &residual_precision_prior,
+                const Ptr<VariableSelectionPrior> &spike)
+      : model_(model) {
+    if (slab->dim() != model->xdim()) report_error("Slab dimension did not match model dimension.");
+    if ((int)spike->potential_nvars() != model->xdim()) report_error("Spike dimension did not match model dimension.");
+    set_raw(slab->mu(), slab->unscaled_precision(), residual_precision_prior->df(),
+            residual_precision_prior->sigma(), spike->prior_inclusion_probabilities(),
+            spike->max_model_size());
+  }
+
+  void draw() override {                     // BregVsSampler.cpp:252-261
+    if (!pushed_) { model_->push_state(); pushed_ = true; }
+    check(ba_sweep(h(), 1));
+    model_->pull_chain0();
+  }
+  void draw(int nsweeps) {                   // many sweeps in one launch
+    if (!pushed_) { model_->push_state(); pushed_ = true; }
+    check(ba_sweep(h(), nsweeps));
+    model_->pull_chain0();
+  }
+  void limit_model_selection(uint n) { max_flips_ = (int)n; options(); }
+  void suppress_model_selection() { max_flips_ = 0; options(); }
+  void allow_model_selection(bool allow = true) { max_flips_ = allow ? -1 : 0; options(); }
+  void suppress_beta_draw() { draw_beta_ = 0; options(); }
+  void suppress_sigma_draw() { draw_sigma_ = 0; options(); }
+  void set_correlation_swap_threshold(double t) { swap_ = t; options(); }
+  void set_sigma_upper_limit(double s) {
+    double df, ss;
+    check(ba_get_priors(h(), nullptr, nullptr, nullptr, &df, &ss));
+    check(ba_set_sigma_prior(h(), df, std::sqrt(ss / df), s));
+  }
+  void set_seed(unsigned long s) { check(ba_seed(h(), s)); }
+  double prior_df() const { double df; check(ba_get_priors(h(), nullptr, nullptr, nullptr, &df, nullptr)); return df; }
+  double prior_ss() const { double ss; check(ba_get_priors(h(), nullptr, nullptr, nullptr, nullptr, &ss)); return ss; }
+  double log_model_prob(const Selector &g) const {
+    double out;
+    check(ba_log_model_prob(h(), 1, g.bytes().data(), &out));
+    return out;
+  }
+ private:
+  ba_engine *h() const { return model_->engine()->get(); }
+  void check(int rc) const { model_->engine()->check(rc); }
+  void options() { check(ba_set_options(h(), max_flips_, swap_, draw_beta_, draw_sigma_)); }
+  void set_raw(const Vector &b, const SpdMatrix &om, double df, double guess, const Vector &pi, int64_t mms) {
+    check(ba_set_slab(h(), b.data(), om.data()));
+    check(ba_set_spike(h(), pi.data(), mms));
+    check(ba_set_sigma_prior(h(), df, guess, infinity()));
+  }
+  RegressionModel *model_;
+  bool pushed_ = false;
+  int max_flips_ = -1, draw_beta_ = 1, draw_sigma_ = 1;
+  double swap_ = 0.8;
+};
+
+// ---- bsts: local level + regression ----------------------------------------------
+class LocalLevelStateModel {
+ public:
+  explicit LocalLevelStateModel(double sigma = 1.0) : sigma_(sigma) {}
+  void set_initial_state_mean(double m) { a0_ = m; }
+  void set_initial_state_variance(double v) { P0_ = v; }
+  // ZeroMeanGaussianConjSampler(model, df, sigma_guess) + set_sigma_upper_limit
+  void set_prior(double df, double sigma_guess, double sigma_upper_limit = infinity()) {
+    df_ = df; guess_ = sigma_guess; upper_ = sigma_upper_limit;
+  }
+  double sigma_, a0_ = 0.0, P0_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
+};
+
+class StateSpaceRegressionModel : public Model {
+ public:
+  StateSpaceRegressionModel(const Vector &y, const Matrix &X, const std::vector<bool> &observed,
+                            int chains = 1, uint64_t seed = 8675309, int device = 0)
+      : eng_(new Engine(chains, seed, device)), T_((int)y.size()), p_(X.ncol()) {
+    if (X.nrow() != T_) report_error("X and y are incompatible in constructor for StateSpaceRegressionModel.");
+    std::vector<uint8_t> obs;
+    if (!observed.empty()) { obs.resize(T_); for (int t = 0; t < T_; ++t) obs[t] = observed[t]; }
+    eng_->check(ba_ss_set_data(eng_->get(), T_, p_, y.data(), X.data(), obs.empty() ? nullptr : obs.data()));
+  }
+  void add_state(const Ptr<LocalLevelStateModel> &s) {
+    level_ = s;
+    eng_->check(ba_ss_set_local_level(eng_->get(), s->df_, s->guess_, s->upper_, s->a0_, s->P0_, s->sigma_));
+  }
+  int time_dimension() const { return T_; }
+  int xdim() const { return p_; }
+  const Ptr<Engine> &engine() const { return eng_; }
+  Vector state(int chain = 0) const {
+    Vector st(T_);
+    eng_->check(ba_ss_get_state(eng_->get(), chain, st.data(), nullptr, nullptr, nullptr));
+    return st;
+  }
+  double level_sigsq(int chain = 0) const {
+    double v;
+    eng_->check(ba_ss_get_state(eng_->get(), chain, nullptr, &v, nullptr, nullptr));
+    return v;
+  }
+ private:
+  Ptr<Engine> eng_;
+  int T_, p_;
+  Ptr<LocalLevelStateModel> level_;
+};
+
+// regression priors are set through the same three pieces as BregVsSampler
+class StateSpacePosteriorSampler : public PosteriorSampler {
+ public:
+  StateSpacePosteriorSampler(StateSpaceRegressionModel *model, const Ptr<MvnGivenScalarSigma> &slab,
+                             const Ptr<ChisqModel> &residual_precision_prior,
+                             const Ptr<VariableSelectionPrior> &spike,
+                             double sigma_upper_limit = infinity())
+      : model_(model) {
+    ba_engine *h = model->engine()->get();
+    model->engine()->check(ba_set_slab(h, slab->mu().data(), slab->unscaled_precision().data()));
+    model->engine()->check(ba_set_spike(h, spike->prior_inclusion_probabilities().data(), spike->max_model_size()));
+    model->engine()->check(ba_set_sigma_prior(h, residual_precision_prior->df(), residual_precision_prior->sigma(), sigma_upper_limit));
+    std::vector<uint8_t> g0(model->xdim(), 0);
+    model->engine()->check(ba_set_state(h, -1, g0.data(), nullptr, 1.0));
+  }
+  void draw() override {                     // StateSpacePosteriorSampler.cpp:42-64
+    model_->engine()->check(ba_ss_sweep(model_->engine()->get(), 1));
+    model_->engine()->check(ba_sync(model_->engine()->get()));
+  }
+ private:
+  StateSpaceRegressionModel *model_;
+};
+
+}  // namespace boom_amd_api

@@ -1,0 +1,250 @@
+// C++ test of the BOOM-shaped host side (include/boom_amd.hpp) over the C-ABI.
+// It re-expresses the reference's own acceptance tests for this path on
+// many-chain output (Models/Glm/tests/regression_spike_slab_test.cc):
+//   Small                :69-120   posterior covers the truth
+//   TestMaxSizeControl   :124-171  set_max_model_size(2) => |gamma| <= 2
+//   Large                :173-205  p = 100 => P(|gamma| <= 8) >= .95
+//   PerfectCollinearity  :207-257  collinear columns share the inclusion
+// plus the error conventions (report_error -> std::runtime_error) and the
+// state-space classes.  Needs a GPU.  Prints "ALL OK" on success.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <string>
+
+#include "boom_amd.hpp"
+
+using namespace boom_amd_api;
+
+static int failures = 0;
+#define EXPECT(cond)                                                     \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      std::printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond);      \
+      ++failures;                                                        \
+    }                                                                    \
+  } while (0)
+
+struct Sim {
+  Matrix X;
+  Vector y, beta;
+};
+
+static Sim simulate(int n, int p, const Vector &beta, double sd, unsigned seed) {
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> N(0, 1);
+  Sim s{Matrix(n, p), Vector(n), beta};
+  for (int i = 0; i < n; ++i) {
+    s.X(i, 0) = 1.0;
+    for (int j = 1; j < p; ++j) s.X(i, j) = N(gen);
+  }
+  for (int i = 0; i < n; ++i) {
+    double mu = 0;
+    for (int j = 0; j < p; ++j) mu += s.X(i, j) * beta[j];
+    s.y[i] = mu + sd * N(gen);
+  }
+  return s;
+}
+
+static void Small() {
+  const int n = 1000, p = 10, chains = 64, niter = 200;
+  Vector beta(p, 0.0);
+  beta[0] = 1.5; beta[1] = -2.0; beta[2] = 3.0;
+  Sim s = simulate(n, p, beta, 1.0, 1);
+  RegressionModel model(s.X, s.y, chains, 8675309);
+  Ptr<BregVsSampler> sampler(new BregVsSampler(&model, 1.0, 0.5, 3.0, true));
+  model.set_method(sampler);
+  model.drop_all();
+  model.add(0);
+  for (int i = 0; i < 50; ++i) model.sample_posterior();   // burn-in, one draw() per call
+  Vector mean(p, 0.0), sig(1, 0.0);
+  for (int i = 0; i < niter; ++i) {
+    model.sample_posterior();
+    std::vector<uint8_t> g; Vector b, s2;
+    model.chain_states(g, b, s2);
+    for (int c = 0; c < chains; ++c) {
+      for (int j = 0; j < p; ++j) mean[j] += b[(size_t)c * p + j];
+      sig[0] += std::sqrt(s2[c]);
+    }
+  }
+  const double N = (double)niter * chains;
+  for (int j = 0; j < p; ++j) EXPECT(std::fabs(mean[j] / N - beta[j]) < 0.12);
+  EXPECT(std::fabs(sig[0] / N - 1.0) < 0.08);
+  EXPECT(model.inc()[0] && model.sigsq() > 0);   // chain 0 through the classic accessors
+}
+
+static void TestMaxSizeControl() {
+  const int n = 500, p = 12, chains = 32;
+  Vector beta(p, 0.0);
+  for (int j = 0; j < 6; ++j) beta[j] = 2.0 + j;
+  Sim s = simulate(n, p, beta, 1.0, 2);
+  RegressionModel model(s.X, s.y, chains, 11);
+  Vector b(p, 0.0);
+  SpdMatrix om(p, p, 0.0);
+  for (int j = 0; j < p; ++j) om(j, j) = 0.01;
+  Ptr<MvnGivenScalarSigma> slab(new MvnGivenScalarSigma(b, om));
+  Ptr<ChisqModel> siginv(new ChisqModel(1.0, 1.0));
+  Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(p, 0.5));
+  spike->set_max_model_size(2);
+  Ptr<BregVsSampler> sampler(new BregVsSampler(&model, slab, siginv, spike));
+  model.set_method(sampler);
+  model.drop_all();
+  int worst = 0;
+  for (int i = 0; i < 100; ++i) {
+    model.sample_posterior();
+    std::vector<uint8_t> g; Vector bb, s2;
+    model.chain_states(g, bb, s2);
+    for (int c = 0; c < chains; ++c) {
+      int k = 0;
+      for (int j = 0; j < p; ++j) k += g[(size_t)c * p + j];
+      worst = std::max(worst, k);
+    }
+  }
+  EXPECT(worst <= 2);
+}
+
+static void Large() {
+  const int n = 2000, p = 100, chains = 64;
+  Vector beta(p, 0.0);
+  beta[0] = 1; beta[1] = 3; beta[2] = -3; beta[3] = 2;
+  Sim s = simulate(n, p, beta, 1.0, 3);
+  RegressionModel model(s.X, s.y, chains, 5);
+  Ptr<BregVsSampler> sampler(new BregVsSampler(&model, 1.0, 0.5, 4.0, true));
+  model.set_method(sampler);
+  model.drop_all();
+  model.add(0);
+  sampler->draw(100);
+  int small = 0, total = 0;
+  for (int i = 0; i < 50; ++i) {
+    sampler->draw(4);
+    std::vector<uint8_t> g; Vector bb, s2;
+    model.chain_states(g, bb, s2);
+    for (int c = 0; c < chains; ++c) {
+      int k = 0;
+      for (int j = 0; j < p; ++j) k += g[(size_t)c * p + j];
+      small += (k <= 8);
+      ++total;
+    }
+  }
+  EXPECT(small >= 0.95 * total);
+}
+
+static void PerfectCollinearity() {
+  const int n = 400, p = 8, chains = 128;
+  Vector beta(p, 0.0);
+  beta[0] = 1.0; beta[1] = 2.0;
+  Sim s = simulate(n, p, beta, 1.0, 4);
+  // columns 2 and 3 are (near) copies of column 1
+  std::mt19937_64 gen(99);
+  std::normal_distribution<double> N(0, 1);
+  for (int i = 0; i < n; ++i) {
+    s.X(i, 2) = s.X(i, 1) + 1e-3 * N(gen);
+    s.X(i, 3) = s.X(i, 1) + 1e-3 * N(gen);
+  }
+  RegressionModel model(s.X, s.y, chains, 17);
+  Ptr<BregVsSampler> sampler(new BregVsSampler(&model, 1.0, 1.0, 0.5, 0.5, 0.3, true));
+  model.set_method(sampler);
+  model.drop_all();
+  model.add(0);
+  sampler->draw(200);
+  double inc[4] = {0, 0, 0, 0};
+  int draws = 0;
+  for (int i = 0; i < 100; ++i) {
+    sampler->draw(5);
+    std::vector<uint8_t> g; Vector bb, s2;
+    model.chain_states(g, bb, s2);
+    for (int c = 0; c < chains; ++c) {
+      for (int j = 1; j <= 3; ++j) inc[j] += g[(size_t)c * p + j];
+      ++draws;
+    }
+  }
+  // the signal is shared among the three copies: at least one is in, none
+  // dominates completely
+  const double any = (inc[1] + inc[2] + inc[3]) / draws;
+  EXPECT(any > 0.95);
+  for (int j = 1; j <= 3; ++j) EXPECT(inc[j] / draws > 0.1 && inc[j] / draws < 0.7);
+}
+
+static void ErrorConventions() {
+  Vector beta(4, 0.0);
+  Sim s = simulate(50, 4, beta, 1.0, 5);
+  RegressionModel model(s.X, s.y, 2, 1);
+  bool threw = false;
+  try {
+    Ptr<MvnGivenScalarSigma> slab(new MvnGivenScalarSigma(Vector(3, 0.0), SpdMatrix(3, 3, 0.0)));
+    Ptr<ChisqModel> siginv(new ChisqModel(1.0, 1.0));
+    Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(4, 0.5));
+    BregVsSampler bad(&model, slab, siginv, spike);
+  } catch (std::runtime_error &e) {
+    threw = std::string(e.what()).find("Slab dimension") != std::string::npos;
+  }
+  EXPECT(threw);
+  threw = false;
+  try {
+    BregVsSampler bad(&model, 1.0, 1.0, 0.5, 1.5 /* illegal shrinkage */, 0.3, true);
+  } catch (std::runtime_error &e) {
+    threw = std::string(e.what()).find("diagonal_shrinkage") != std::string::npos;
+  }
+  EXPECT(threw);
+}
+
+static void StateSpace() {
+  const int T = 300, p = 4, chains = 16;
+  std::mt19937_64 gen(7);
+  std::normal_distribution<double> N(0, 1);
+  Matrix X(T, p);
+  Vector y(T), coef = {5.0, -4.0, 0.0, 0.0};
+  double level = 0;
+  for (int t = 0; t < T; ++t) {
+    level += 0.3 * N(gen);
+    double mu = level;
+    for (int j = 0; j < p; ++j) { X(t, j) = N(gen); mu += X(t, j) * coef[j]; }
+    y[t] = mu + 0.2 * N(gen);
+  }
+  StateSpaceRegressionModel model(y, X, std::vector<bool>(), chains, 3);
+  Ptr<LocalLevelStateModel> level_model(new LocalLevelStateModel(1.0));
+  level_model->set_initial_state_mean(y[0]);
+  level_model->set_initial_state_variance(4.0);
+  level_model->set_prior(1.0, 0.3);
+  model.add_state(level_model);
+  SpdMatrix om(p, p, 0.0);
+  for (int j = 0; j < p; ++j) om(j, j) = 0.01;
+  Ptr<MvnGivenScalarSigma> slab(new MvnGivenScalarSigma(Vector(p, 0.0), om));
+  Ptr<ChisqModel> siginv(new ChisqModel(1.0, 0.5));
+  Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(p, 0.5));
+  Ptr<StateSpacePosteriorSampler> sampler(new StateSpacePosteriorSampler(&model, slab, siginv, spike));
+  model.set_method(sampler);
+  for (int i = 0; i < 100; ++i) model.sample_posterior();
+  Vector st = model.state(3);
+  EXPECT((int)st.size() == T);
+  double err = 0;
+  // the drawn state tracks y - X coef
+  for (int t = 0; t < T; ++t) {
+    double target = y[t];
+    for (int j = 0; j < p; ++j) target -= X(t, j) * coef[j];
+    err += std::fabs(st[t] - target);
+  }
+  EXPECT(err / T < 0.5);
+  EXPECT(model.level_sigsq(3) > 0.01 && model.level_sigsq(3) < 1.0);
+}
+
+int main() {
+  try {
+    Small();
+    TestMaxSizeControl();
+    Large();
+    PerfectCollinearity();
+    ErrorConventions();
+    StateSpace();
+  } catch (std::exception &e) {
+    std::printf("EXCEPTION: %s\n", e.what());
+    return 2;
+  }
+  if (failures) {
+    std::printf("%d check(s) failed\n", failures);
+    return 1;
+  }
+  std::printf("ALL OK\n");
+  return 0;
+}
