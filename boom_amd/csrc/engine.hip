@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -154,6 +155,7 @@ struct ba_engine {
   DevBuf<double> dX, dy, dxtx, dxsum, dsufscal;
 
   int kcap = 0;
+  int waves = 1;  // wavefronts per chain
   uint64_t seed = 0;
 
   // ---- state space (bsts local level + regression)
@@ -223,6 +225,21 @@ int choose_kcap(const ba_engine &e) {
   return k;
 }
 
+// Wavefronts per chain.  The proposal batches scale with the number of waves
+// (64 proposals each, evaluated speculatively), and several resident waves per
+// SIMD hide the gather / scalar-load latencies; the register budget of the
+// 4-wave kernels only exists for capacities <= 32.  BOOM_AMD_WAVES overrides.
+int choose_waves(const ba_engine &e, int kcap) {
+  if (const char *s = std::getenv("BOOM_AMD_WAVES")) {
+    const int w = std::atoi(s);
+    if (w == 1 || w == 2 || (w == 4 && kcap <= 32)) return w;
+  }
+  const int per_cu = std::max(1, (e.cfg.chains + e.cu_count - 1) / e.cu_count);
+  if (kcap <= 32 && per_cu * 4 <= 16) return 4;
+  if (per_cu * 2 <= 8) return 2;
+  return 1;
+}
+
 int upload_shared(ba_engine *e) {
   if (!e->device_dirty) return BA_OK;
   const int p = e->p;
@@ -273,6 +290,7 @@ int upload_shared(ba_engine *e) {
   }
   HIP_TRY(hipStreamSynchronize(s));
   e->kcap = choose_kcap(*e);
+  e->waves = choose_waves(*e, e->kcap);
   e->device_dirty = false;
   return BA_OK;
 }
@@ -317,6 +335,7 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.chains = e->cfg.chains;
   P.chain_offset = e->cfg.chain_offset;
   P.kcap = e->kcap;
+  P.waves = e->waves;
   P.V = e->dV.ptr;
   P.A = e->dA.ptr;
   P.b = e->db.ptr;

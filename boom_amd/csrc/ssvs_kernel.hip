@@ -81,6 +81,15 @@ __device__ __forceinline__ AS_LDS T *to_lds(unsigned char *generic) {
 typedef AS_CONST const double c_f64;
 typedef AS_CONST const int c_i32;
 
+// LDS hand-off between the lanes of ONE wavefront (the wave-cooperative
+// routines below are run by a single wave of the workgroup): DS operations of a
+// wave complete in order, so only the compiler has to be told.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- cross-lane helpers (DPP / readlane: no LDS round trip) -----------------
 // lanes whose DPP source is outside their row (or whose row is masked off)
 // receive `fill`
@@ -226,7 +235,7 @@ __device__ __forceinline__ bool chol_blocks(const Chain &ch, lds_f64 *LB,
     } else if (mine) {
       LB[bidx(i, j)] = s / sd;
     }
-    __syncthreads();
+    wave_sync();
   }
   *logdet = 2.0 * ld;
   return ok;
@@ -257,7 +266,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     M.pd = false;
     return;
   }
-  __syncthreads();
+  wave_sync();
   // gather V_g, A_g (lower triangles, rows padded with zeros to a multiple of
   // 8) with all loads independent: element e <-> (m, n), n <= m
   const int kpad = (k + 7) & ~7;
@@ -298,7 +307,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   }
   const double r = (lane < k) ? ab + ch.xty[gm] : 0.0;
   M.c = wave_sum(lane < k ? bm * ab : 0.0);
-  __syncthreads();
+  wave_sync();
   // the two factorisations share one (not unrolled) body
   bool okv = true, oka = true;
 #pragma nounroll
@@ -323,7 +332,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   if (lane < k) ch.w[lane] = x;
   M.Q = wave_sum(lane < k ? x * x : 0.0);
   M.SS = ch.ss0q + M.c - M.Q;
-  __syncthreads();
+  wave_sync();
   if (!(M.SS >= 0.0) || isinf(M.SS)) {
     M.bad = CHAIN_NEGATIVE_SS;
     M.logp = -BA_INF;
@@ -343,7 +352,7 @@ __device__ __forceinline__ void apply_flip(Chain &ch, int j) {
   const int gm = (lane < k) ? ch.g[lane] : 0x7fffffff;
   const int below = __popcll(__ballot(lane < k && gm < j));
   const bool add = !ch.gam[j];
-  __syncthreads();
+  wave_sync();
   if (add) {
     const int up = __shfl_up(gm, 1, WAVE);
     if (lane == below) ch.g[lane] = (uint16_t)j;
@@ -356,7 +365,7 @@ __device__ __forceinline__ void apply_flip(Chain &ch, int j) {
     if (lane == 0) ch.gam[j] = 0;
     ch.k = k - 1;
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // Copy the current model's wave-uniform data from LDS to this chain's HBM
@@ -559,7 +568,7 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch) {
   for (int j = lane; j < p; j += WAVE) ch.last[j] = (uint16_t)NONE;
   int nbits = 1;
   while ((1 << nbits) < p) ++nbits;
-  __syncthreads();
+  wave_sync();
   // ---- previous step with the same target, rounds over decreasing t
   for (int T = p - 1; T >= 1; T -= WAVE) {
     const int t = T - lane;
@@ -578,21 +587,21 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch) {
       else pr = ch.last[key];
       ch.pred[t] = (uint16_t)pr;
     }
-    __syncthreads();
+    wave_sync();
     if (valid && (lane == 63 || (mask >> (lane + 1)) == 0)) ch.last[key] = (uint16_t)t;
-    __syncthreads();
+    wave_sync();
   }
   // last[x] = smallest t >= 1 with oth[t] == x.  nxt(t) = smallest t' > t with
   // oth[t'] == t: last[t] unless that is the self swap t, then pred[t].
   const int pred0 = ch.last[0];
-  __syncthreads();
+  wave_sync();
   for (int t = lane; t < p; t += WAVE) {
     if (t >= 1) {
       const int l = ch.last[t];
       ch.last[t] = (uint16_t)((l == t) ? (int)ch.pred[t] : l);
     }
   }
-  __syncthreads();
+  wave_sync();
   const lds_u16 *src_perm = ch.perm;
   lds_u16 *dst = ch.perm_alt;
   for (int i = lane; i < p; i += WAVE) {
@@ -610,7 +619,7 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch) {
     }
     dst[i] = src_perm[src];
   }
-  __syncthreads();
+  wave_sync();
   lds_u16 *tmp = ch.perm;
   ch.perm = ch.perm_alt;
   ch.perm_alt = tmp;
@@ -727,13 +736,70 @@ __device__ __forceinline__ void propose_swap(const SsvsParams &P, Chain &ch,
 }  // namespace
 
 // ============================================================================
-// grid = chains, block = 64; NB = kcap / 8
+// grid = chains, block = 64 * W; NB = kcap / 8.
+//
+// A workgroup of W wavefronts serves one chain.  Wave 0 (the master) runs the
+// sweep; the other waves exist for the proposal batches: a batch is 64 * W
+// proposals, wave w evaluating positions i0 + 64 w + lane against the current
+// model, and for the lane-parallel uniforms of the shuffle.  The waves meet at
+// two workgroup barriers per command; the current model reaches the helpers
+// through the LDS control block (scalars) and the chain's HBM model block
+// (factors, read through the scalar cache).
+
+enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2 };
+// control block (doubles): 0 cmd, 1 k, 2 i0, 3..8 model scalars, 9 nflips;
+// u64 view at 10: flip_pos / uniform base position; wave slots from 16
+enum : int { CT_CMD = 0, CT_K = 1, CT_I0 = 2, CT_LOGP = 3, CT_LP = 4, CT_LDV = 5,
+             CT_LDA = 6, CT_Q = 7, CT_C = 8, CT_NFLIPS = 9, CT_POS = 10, CT_PERMSEL = 12,
+             CT_SLOT0 = 16, CT_SLOT_STRIDE = 6 };
+enum : int { SL_F = 0, SL_J = 1, SL_KIND = 2, SL_LOGU = 3, SL_MARGIN = 4, SL_DELTA = 5 };
+enum : int { STOP_ACCEPT = 1, STOP_SLOW = 2, STOP_BAD = 3 };
+
+// One wave's share of a proposal batch: evaluates, decides, and leaves its
+// first "stop" (accepted / needs the exact path / negative SS) in its slot.
 template <int NB>
-__global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
-                                                        int nsweeps) {
+__device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
+                                           const Model &M, const PhiloxKey &key,
+                                           uint64_t flip_pos, int nflips, int i0,
+                                           int wave, lds_f64 *ctl) {
+  const int lane = ch.lane;
+  const int idx = i0 + WAVE * wave + lane;
+  const bool valid = idx < nflips;
+  const int j = valid ? (int)ch.perm[idx] : 0;
+  const double u = philox_uniform(key, flip_pos + (uint64_t)idx);
+  const double logu = log(u);
+  const Proposal pr = eval_proposal<NB>(P, ch, M, j, valid);
+  const double delta = pr.logp - M.logp;
+  const bool accept = valid && !pr.slow && !pr.bad_ss && !(logu > delta);
+  const unsigned long long m_acc = __ballot(accept);
+  const unsigned long long m_slow = __ballot(valid && pr.slow);
+  const unsigned long long m_bad = __ballot(valid && pr.bad_ss);
+  const unsigned long long m_stop = m_acc | m_slow | m_bad;
+  const int f = m_stop ? (__ffsll((long long)m_stop) - 1) : WAVE;
+  // lanes before f are settled rejections; f itself counts if accepted
+  const bool counted = valid && (lane < f || (lane == f && ((m_acc >> f) & 1ull)));
+  const double mg = counted && (pr.logp > -BA_INF) ? fabs(logu - delta) : BA_INF;
+  const double mmin = wave_min(mg);
+  if (lane == (f < WAVE ? f : 0)) {
+    lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * wave;
+    int kind = 0;
+    if (f < WAVE) kind = ((m_bad >> f) & 1ull) ? STOP_BAD : (((m_acc >> f) & 1ull) ? STOP_ACCEPT : STOP_SLOW);
+    sl[SL_F] = (double)f;
+    sl[SL_J] = (double)j;
+    sl[SL_KIND] = (double)kind;
+    sl[SL_LOGU] = logu;
+    sl[SL_MARGIN] = mmin;
+    sl[SL_DELTA] = delta;
+  }
+}
+
+template <int NB, int W, int WPE>
+__global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
+                                                            int nsweeps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int chain = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x >> 6;
   const int p = P.p;
   if (chain >= P.chains) return;
   if (P.status[chain] != CHAIN_OK) return;
@@ -743,7 +809,9 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
   Chain ch;
   ch.lane = lane;
   ch.p = p;
+  ch.k = 0;
   bind_lds(ch, smem, lay);
+  lds_f64 *ctl = to_lds<double>(smem + lay.ctrl);
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
   ch.sc_store = P.model_scratch + (size_t)chain * P.model_scratch_stride;
   ch.sc = (c_f64 *)(unsigned long long)ch.sc_store;
@@ -751,8 +819,40 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
   const double nobs = P.nobs[(size_t)chain * P.suf_stride];
   ch.DF = nobs + P.prior_df;
   ch.ss0q = P.prior_ss + yty;
+  const PhiloxKey key{P.seed_lo, P.seed_hi,
+                      (uint32_t)(P.chain_offset + chain), P.stream};
 
-  // ---- load chain state
+  if (W > 1 && wave != 0) {
+    // ---- helper waves: serve the master's commands ---------------------------
+    for (;;) {
+      __syncthreads();
+      const int cmd = (int)ctl[CT_CMD];
+      if (cmd == CMD_EXIT) break;
+      const uint64_t upos = ((AS_LDS const uint64_t *)(ctl + CT_POS))[0];
+      if (cmd == CMD_EVAL) {
+        Model M;
+        M.logp = ctl[CT_LOGP]; M.lp = ctl[CT_LP]; M.ldv = ctl[CT_LDV];
+        M.lda = ctl[CT_LDA]; M.Q = ctl[CT_Q]; M.c = ctl[CT_C];
+        M.SS = 0; M.pd = true; M.bad = 0;
+        ch.k = (int)ctl[CT_K];
+        ch.perm = to_lds<uint16_t>(smem + (((int)ctl[CT_PERMSEL]) ? lay.perm1 : lay.perm0));
+        unsigned long long a = (unsigned long long)ch.sc_store;
+        asm volatile("" : "+s"(a) : : "memory");
+        ch.sc = (c_f64 *)a;
+        eval_share<NB>(P, ch, M, key, upos, (int)ctl[CT_NFLIPS], (int)ctl[CT_I0], wave, ctl);
+      } else {  // CMD_UNIF: this wave's share of the shuffle uniforms
+        for (int t = threadIdx.x; t < p - 1; t += WAVE * W) {
+          const int i = p - 1 - t;
+          const double u = philox_uniform(key, upos + (uint64_t)t);
+          ch.oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- master wave -------------------------------------------------------------
   uint8_t *g_gamma = P.gamma + (size_t)chain * p;
   uint16_t *g_perm = P.perm + (size_t)chain * p;
   int k = 0;
@@ -769,15 +869,10 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
     if (inc && slot < KCAP) ch.g[slot] = (uint16_t)j;
     k += __popcll(mask);
   }
-  if (k > KCAP) {
-    if (lane == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
-    return;
-  }
+  if (k > KCAP) status = CHAIN_MODEL_TOO_LARGE;
   ch.k = k;
-  __syncthreads();
+  wave_sync();
 
-  PhiloxKey key{P.seed_lo, P.seed_hi,
-                (uint32_t)(P.chain_offset + chain), P.stream};
   uint64_t pos = P.rng_pos[chain];
   int failures = P.failures[chain];
   double sigsq = P.sigsq[chain];
@@ -801,6 +896,7 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
   enum { PH_BEGIN, PH_FLIPS, PH_SWAP, PH_TAIL };
   int phase = PH_BEGIN, sweep = 0, i0 = 0;
   bool model_checked = false;  // legality of the start is checked in sweep 0
+  int perm_sel = 0;            // which LDS buffer holds the current permutation
   uint64_t flip_pos = 0;
   SeqRng rng{key, pos};
 
@@ -851,14 +947,21 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
       if (nflips > 0) {
         // ---- shuffle(indx): cpputil/shuffle.hpp:36-46, in place on the
         // persistent permutation.  Uniform t (t = 0..p-2) belongs to i = p-1-t.
-        for (int t = lane; t < p - 1; t += WAVE) {
+        if (W > 1) {
+          if (lane == 0) {
+            ctl[CT_CMD] = (double)CMD_UNIF;
+            ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = pos;
+          }
+          __syncthreads();
+        }
+        for (int t = threadIdx.x; t < p - 1; t += WAVE * W) {
           const int i = p - 1 - t;
           const double u = philox_uniform(key, pos + (uint64_t)t);
           ch.oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u);
         }
-        __syncthreads();
+        if (W > 1) __syncthreads(); else wave_sync();
         STAMP(0);
-        if (p > 1) parallel_shuffle(ch);
+        if (p > 1) { parallel_shuffle(ch); perm_sel ^= 1; }
         flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
         pos = flip_pos + (uint64_t)nflips;
         STAMP(1);
@@ -889,36 +992,46 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
         phase = PH_SWAP;
         continue;
       }
-      // ---- Metropolised flips, 64 proposals at a time
-      const int idx = i0 + lane;
-      const bool valid = idx < nflips;
-      const int j = valid ? ch.perm[idx] : 0;
-      const double u = philox_uniform(key, flip_pos + (uint64_t)idx);
-      const double logu = log(u);
-      Proposal pr = eval_proposal<NB>(P, ch, M, j, valid);
-      const double delta = pr.logp - M.logp;
-      const bool accept = valid && !pr.slow && !pr.bad_ss && !(logu > delta);
-      const unsigned long long m_acc = __ballot(accept);
-      const unsigned long long m_slow = __ballot(valid && pr.slow);
-      const unsigned long long m_bad = __ballot(valid && pr.bad_ss);
-      const unsigned long long m_stop = m_acc | m_slow | m_bad;
-      const int f = m_stop ? (__ffsll((long long)m_stop) - 1) : WAVE;
-      // lanes before f are settled rejections; f itself counts if accepted
-      {
-        const bool counted = valid && (lane < f || (lane == f && ((m_acc >> f) & 1ull)));
-        const double mg = counted && (pr.logp > -BA_INF) ? fabs(logu - delta) : BA_INF;
-        min_margin = fmin(min_margin, wave_min(mg));
+      // ---- Metropolised flips, 64 * W proposals at a time
+      if (W > 1) {
+        if (lane == 0) {
+          ctl[CT_CMD] = (double)CMD_EVAL;
+          ctl[CT_K] = (double)ch.k;
+          ctl[CT_I0] = (double)i0;
+          ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
+          ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
+          ctl[CT_NFLIPS] = (double)nflips;
+          ctl[CT_PERMSEL] = (double)perm_sel;
+          ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = flip_pos;
+        }
+        __syncthreads();
+      }
+      eval_share<NB>(P, ch, M, key, flip_pos, nflips, i0, 0, ctl);
+      if (W > 1) __syncthreads(); else wave_sync();
+      // first stop over the whole batch, in sweep order
+      int wstop = -1, f = WAVE;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * w;
+        if (wstop < 0) {
+          min_margin = fmin(min_margin, sl[SL_MARGIN]);
+          const int fw = (int)sl[SL_F];
+          if (fw < WAVE) { wstop = w; f = fw; }
+        }
       }
       STAMP(3);
-      if (f == WAVE) {
-        const int n = (nflips - i0 < WAVE) ? (nflips - i0) : WAVE;
+      if (wstop < 0) {
+        const int n = (nflips - i0 < WAVE * W) ? (nflips - i0) : WAVE * W;
         acc_prop += n;
-        i0 += WAVE;
+        i0 += WAVE * W;
         continue;
       }
-      acc_prop += f + 1;
-      const int jf = bcast_u(j, f);
-      if ((m_bad >> f) & 1ull) {
+      const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * wstop;
+      const int jf = (int)sl[SL_J];
+      const int kind = (int)sl[SL_KIND];
+      const int nprop = WAVE * wstop + f + 1;
+      acc_prop += nprop;
+      if (kind == STOP_BAD) {
         status = CHAIN_NEGATIVE_SS;
         break;
       }
@@ -929,13 +1042,13 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
         break;
       }
       pe.f1 = jf;
-      if ((m_acc >> f) & 1ull) {
+      if (kind == STOP_ACCEPT) {
         pe.kind = EV_FORCE;  // accepted on the fast path: move to the new model
       } else {
         pe.kind = EV_TRY_GE;  // exact path: evaluate the flipped model
-        pe.lu = bcast_u(logu, f);
+        pe.lu = sl[SL_LOGU];
       }
-      i0 += f + 1;
+      i0 += nprop;
       continue;
     }
 
@@ -1009,17 +1122,25 @@ __global__ __launch_bounds__(64) void ssvs_sweep_kernel(SsvsParams P,
     phase = PH_BEGIN;
   }
 
+  // release the helper waves
+  if (W > 1) {
+    if (lane == 0) ctl[CT_CMD] = (double)CMD_EXIT;
+    __syncthreads();
+  }
+
   // ---- write the chain back
   k = ch.k;
-  __syncthreads();
-  for (int j = lane; j < p; j += WAVE) {
-    g_gamma[j] = ch.gam[j];
-    g_perm[j] = ch.perm[j];
+  wave_sync();
+  if (status != CHAIN_MODEL_TOO_LARGE || k <= KCAP) {
+    for (int j = lane; j < p; j += WAVE) {
+      g_gamma[j] = ch.gam[j];
+      g_perm[j] = ch.perm[j];
+    }
   }
   if (beta_valid) {
     double *g_beta = P.beta + (size_t)chain * p;
     for (int j = lane; j < p; j += WAVE) g_beta[j] = 0.0;
-    __syncthreads();
+    wave_sync();
     if (lane < k) g_beta[ch.g[lane]] = beta_m;
   } else if (nflips > 0) {
     // coef().set_inc(g) zeroes the coefficients of excluded variables
@@ -1134,26 +1255,36 @@ __global__ __launch_bounds__(256) void ssvs_reduce_summaries_kernel(SsvsParams P
 }
 
 // ---- host-side launchers (kept in the kernels' translation unit) -----------
-template <int NB>
-static hipError_t launch_sweep_nb(hipStream_t stream, const SsvsParams &P,
-                                  int nsweeps) {
+// (NB, W, WPE): model capacity 8 NB; W wavefronts per chain; WPE = waves per
+// SIMD the register budget is sized for (W = 4 needs 4 resident waves per SIMD
+// for 4 chains per CU, i.e. <= 128 VGPRs, which only the small capacities reach)
+template <int NB, int W, int WPE>
+static hipError_t launch_sweep_t(hipStream_t stream, const SsvsParams &P,
+                                 int nsweeps) {
   const SsvsLds lay = ssvs_lds_layout(P.p, NB * 8);
-  hipError_t e = hipFuncSetAttribute((const void *)ssvs_sweep_kernel<NB>,
+  hipError_t e = hipFuncSetAttribute((const void *)ssvs_sweep_kernel<NB, W, WPE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lay.total);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ssvs_sweep_kernel<NB>, dim3(P.chains), dim3(WAVE), lay.total,
-                     stream, P, nsweeps);
+  hipLaunchKernelGGL((ssvs_sweep_kernel<NB, W, WPE>), dim3(P.chains), dim3(WAVE * W),
+                     lay.total, stream, P, nsweeps);
   return hipGetLastError();
 }
 
 hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P,
                              int nsweeps) {
-  switch (P.kcap) {
-    case 16: return launch_sweep_nb<2>(stream, P, nsweeps);
-    case 32: return launch_sweep_nb<4>(stream, P, nsweeps);
-    case 48: return launch_sweep_nb<6>(stream, P, nsweeps);
-    case 64: return launch_sweep_nb<8>(stream, P, nsweeps);
+  const int key = P.kcap * 10 + P.waves;
+  switch (key) {
+    case 161: return launch_sweep_t<2, 1, 1>(stream, P, nsweeps);
+    case 321: return launch_sweep_t<4, 1, 1>(stream, P, nsweeps);
+    case 481: return launch_sweep_t<6, 1, 1>(stream, P, nsweeps);
+    case 641: return launch_sweep_t<8, 1, 1>(stream, P, nsweeps);
+    case 162: return launch_sweep_t<2, 2, 2>(stream, P, nsweeps);
+    case 322: return launch_sweep_t<4, 2, 2>(stream, P, nsweeps);
+    case 482: return launch_sweep_t<6, 2, 2>(stream, P, nsweeps);
+    case 642: return launch_sweep_t<8, 2, 2>(stream, P, nsweeps);
+    case 164: return launch_sweep_t<2, 4, 4>(stream, P, nsweeps);
+    case 324: return launch_sweep_t<4, 4, 4>(stream, P, nsweeps);
     default: return hipErrorInvalidValue;
   }
 }

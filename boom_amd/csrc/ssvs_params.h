@@ -40,6 +40,7 @@ struct SsvsParams {
   int32_t chains;
   int64_t chain_offset;
   int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
+  int32_t waves; // wavefronts per chain (1, 2 or 4)
 
   // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
   const double *V;    // XtX + Omega^{-1}, p x p (symmetric, full storage)
@@ -103,7 +104,7 @@ struct SsvsParams {
 // its solution vector in registers.  kcap is a multiple of 8.
 // doubles first, then 16-bit, then bytes; all offsets in bytes.
 struct SsvsLds {
-  uint32_t Lv, La, rdv, rda, w, bg, g, perm0, perm1, oth, last, pred, gam, total;
+  uint32_t Lv, La, rdv, rda, w, bg, ctrl, g, perm0, perm1, oth, last, pred, gam, total;
 };
 
 static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
@@ -118,6 +119,7 @@ static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
   L.rda = o;   o += (uint32_t)kcap * 8;
   L.w = o;     o += (uint32_t)kcap * 8;
   L.bg = o;    o += (uint32_t)kcap * 8;
+  L.ctrl = o;  o += 512;  // control block shared by a chain's wavefronts
   L.g = o;     o += (((uint32_t)kcap * 2) + 15u) & ~15u;
   L.perm0 = o; o += pv;
   L.perm1 = o; o += pv;

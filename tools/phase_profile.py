@@ -16,7 +16,7 @@ from cases import regression_data, spike_slab_prior
 n, p, nsig = 10000, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 16
 chains = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 X, y, _ = regression_data(n, p, nsig, seed=8675309)
-eng = boom_amd.Engine(chains, seed=1)
+eng = boom_amd.Engine(chains, seed=1, max_model_size_hint=int(os.environ.get('KCAP_HINT', '0')))
 eng.build_suf_from_xy(X, y)
 s = eng.get_suf()
 suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"],
@@ -35,7 +35,7 @@ ph = sm["phase_cycles"]
 names = ["shuffle uniforms", "shuffle serial", "refactor", "proposal batches",
          "swap", "sigma", "beta", "rest"]
 tot = ph.sum()
-print("signals %d chains %d: %.1f us per sweep-round, kbar %.2f, accepts/sweep %.3f, proposals/sweep %.1f"
+print("waves=%s hint=%s" % (os.environ.get("BOOM_AMD_WAVES","auto"), os.environ.get("KCAP_HINT","0")), end=" "); print("signals %d chains %d: %.1f us per sweep-round, kbar %.2f, accepts/sweep %.3f, proposals/sweep %.1f"
       % (nsig, chains, dt / 100 * 1e6, sm["k_sum"] / sm["sweeps"], sm["accepts"] / sm["sweeps"],
          sm["proposals"] / sm["sweeps"]))
 for nm, v in zip(names, ph):
