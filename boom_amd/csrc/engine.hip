@@ -145,7 +145,7 @@ struct ba_engine {
   DevBuf<double> dbeta, dsigsq;
   DevBuf<uint16_t> dperm;
   DevBuf<uint64_t> dpos;
-  DevBuf<int32_t> dstatus, dfail;
+  DevBuf<int32_t> dstatus, dfail, dtodo, dmaxk, dtrace_idx;
   DevBuf<uint32_t> dinc;
   DevBuf<double> dbsum, dbsumsq, dacc, dsummary;
   DevBuf<double> dtr_sig, dtr_logp, dtr_k;
@@ -206,23 +206,30 @@ void build_correlation_map(const ba_engine &e, std::vector<int32_t> &start,
 }
 
 // Working capacity of a chain's LDS set: 16, 32, 48 or 64 variables (the sweep
-// kernel is instantiated per capacity).  Prefer the largest capacity that still
-// lets every chain be resident at once (one wavefront per chain, LDS-limited
-// workgroups per CU); a max_model_size prior or the caller's hint can lower it.
-int choose_kcap(const ba_engine &e) {
-  const int p = e.p;
-  int64_t need = std::min(64, p);
-  if (e.cfg.max_model_size_hint > 0) need = std::min<int64_t>(need, e.cfg.max_model_size_hint);
-  if (e.max_model_size >= 0) need = std::min<int64_t>(need, std::max<int64_t>(1, e.max_model_size));
-  const int cap_need = (int)std::min<int64_t>(64, ((need + 15) / 16) * 16);
-  const int per_cu = std::max(1, (e.cfg.chains + e.cu_count - 1) / e.cu_count);
-  const size_t budget_all = e.lds_per_cu / (size_t)per_cu;
-  int k = cap_need;
-  if (e.cfg.max_model_size_hint <= 0) {
-    while (k > 16 && ssvs_lds_layout(p, k).total > budget_all) k -= 16;
-  }
-  while (k > 16 && ssvs_lds_layout(p, k).total > e.lds_per_cu) k -= 16;
+// kernel is instantiated per capacity; smaller is faster).  The capacity is
+// ADAPTIVE: launches run with the current capacity, a chain that outgrows it
+// stops at a sweep boundary and is resumed by ba_sync() with the next size
+// (escalate()), and the capacity follows the largest model seen.  A
+// max_model_size prior caps it; ba_config.max_model_size_hint pins it.
+int lds_cap(const ba_engine &e) {   // largest capacity whose LDS set fits a CU
+  int k = 64;
+  while (k > 16 && ssvs_lds_layout(e.p, k).total > e.lds_per_cu) k -= 16;
   return k;
+}
+int cap_limit(const ba_engine &e) {
+  int64_t need = std::min(64, e.p);
+  if (e.max_model_size >= 0) need = std::min<int64_t>(need, std::max<int64_t>(1, e.max_model_size));
+  const int k = (int)std::min<int64_t>(64, ((need + 15) / 16) * 16);
+  return std::min(k, lds_cap(e));
+}
+int choose_kcap(const ba_engine &e) {
+  const int limit = cap_limit(e);
+  if (e.cfg.max_model_size_hint > 0) {
+    const int k = (int)std::min<int64_t>(64, (((int64_t)e.cfg.max_model_size_hint + 15) / 16) * 16);
+    return std::min(k, lds_cap(e));
+  }
+  if (e.ss_mode) return limit;  // coupled launches: no mid-run escalation
+  return std::min(32, limit);
 }
 
 // Wavefronts per chain.  The proposal batches scale with the number of waves
@@ -235,7 +242,6 @@ int choose_waves(const ba_engine &e, int kcap) {
     if (w == 1 || w == 2 || (w == 4 && kcap <= 32)) return w;
   }
   const int per_cu = std::max(1, (e.cfg.chains + e.cu_count - 1) / e.cu_count);
-  if (kcap <= 32 && per_cu * 4 <= 16) return 4;
   if (per_cu * 2 <= 8) return 2;
   return 1;
 }
@@ -305,6 +311,9 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(e->dpos.resize(C));
   HIP_TRY(e->dstatus.resize(C));
   HIP_TRY(e->dfail.resize(C));
+  HIP_TRY(e->dtodo.resize(C));
+  HIP_TRY(e->dmaxk.resize(1));
+  HIP_TRY(e->dtrace_idx.resize(C));
   HIP_TRY(e->dinc.resize(C * p));
   HIP_TRY(e->dbsum.resize(C * p));
   HIP_TRY(e->dbsumsq.resize(C * p));
@@ -324,6 +333,9 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(hipMemsetAsync(e->dpos.ptr, 0, C * 8, s));
   HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, C * 4, s));
   HIP_TRY(hipMemsetAsync(e->dfail.ptr, 0, C * 4, s));
+  HIP_TRY(hipMemsetAsync(e->dtodo.ptr, 0, C * 4, s));
+  HIP_TRY(hipMemsetAsync(e->dmaxk.ptr, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, C * 4, s));
   HIP_TRY(hipStreamSynchronize(s));
   e->state_ready = true;
   return ba_reset_summaries(e);
@@ -374,8 +386,11 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.rng_pos = e->dpos.ptr;
   P.status = e->dstatus.ptr;
   P.failures = e->dfail.ptr;
+  P.todo = e->dtodo.ptr;
+  P.maxk = e->dmaxk.ptr;
+  P.trace_idx = e->dtrace_idx.ptr;
   P.model_scratch = e->dmodel.ptr;
-  P.model_scratch_stride = (int64_t)ssvs_scalar_layout(e->kcap).total;
+  P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
   P.seed_lo = (uint32_t)e->seed;
   P.seed_hi = (uint32_t)(e->seed >> 32);
   P.stream = 0;
@@ -389,11 +404,48 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.trace_stride = e->trace_stride;
 }
 
+// Resume chains that outgrew the capacity of the launch they were in, with the
+// next larger capacity; then follow the largest model size seen.
+int escalate(ba_engine *e, std::vector<int32_t> &st) {
+  const size_t C = (size_t)e->cfg.chains;
+  for (;;) {
+    bool any = false;
+    for (size_t c = 0; c < C; ++c) any = any || (st[c] == CHAIN_MODEL_TOO_LARGE);
+    if (!any) return BA_OK;
+    if (e->cfg.max_model_size_hint > 0 || e->kcap >= cap_limit(*e)) return BA_OK;  // stays an error
+    e->kcap += 16;
+    e->waves = choose_waves(*e, e->kcap);
+    for (size_t c = 0; c < C; ++c)
+      if (st[c] == CHAIN_MODEL_TOO_LARGE) st[c] = CHAIN_OK;
+    HIP_TRY(hipMemcpy(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice));
+    SsvsParams P;
+    fill_params(e, P);
+    HIP_TRY(launch_ssvs_sweep(e->stream, P, 0));   // runs the sweeps still owed
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+  }
+}
+
 int check_chain_status(ba_engine *e) {
   const size_t C = (size_t)e->cfg.chains;
   if (!e->state_ready) return BA_OK;
   std::vector<int32_t> st(C);
   HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+  if (!e->ss_mode) {
+    int rc = escalate(e, st);
+    if (rc) return rc;
+    // capacity follows the models: room for growth, no more
+    if (e->cfg.max_model_size_hint <= 0 && e->kcap > 0) {
+      int32_t maxk = 0;
+      HIP_TRY(hipMemcpy(&maxk, e->dmaxk.ptr, 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemset(e->dmaxk.ptr, 0, 4));
+      const int want = std::min(cap_limit(*e), std::max(16, ((maxk + 8 + 15) / 16) * 16));
+      if (maxk > 0 && want < e->kcap) {
+        e->kcap = want;
+        e->waves = choose_waves(*e, e->kcap);
+      }
+    }
+  }
   for (size_t c = 0; c < C; ++c) {
     if (st[c] != CHAIN_OK) {
       char buf[64];
@@ -776,12 +828,14 @@ int ba_sweep(ba_engine *e, int32_t nsweeps) {
   if (rc) return rc;
   if (e->trace_stride > 0 && nsweeps > e->trace_stride)
     return fail(BA_E_INVALID, "nsweeps exceeds the enabled trace length");
-  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(e->kcap).total));
+  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
   SsvsParams P;
   fill_params(e, P);
   const SsvsLds lay = ssvs_lds_layout(e->p, e->kcap);
   if (lay.total > e->lds_per_cu)
     return fail(BA_E_INVALID, "problem does not fit the LDS working set");
+  if (e->trace_stride > 0)  // traces are those of the last ba_sweep call
+    HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
   HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
   return BA_OK;
 }
@@ -964,7 +1018,7 @@ static int ss_prepare(ba_engine *e) {
     HIP_TRY(hipMemset(e->dss_scratch.ptr, 0, C * SS_SCRATCH_ARRAYS * T * 8));
     e->ss_initialized = false;
   }
-  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(e->kcap).total));
+  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
   return BA_OK;
 }
 

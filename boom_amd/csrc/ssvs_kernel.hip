@@ -156,7 +156,7 @@ struct Chain {
   // LDS
   lds_f64 *Lv, *La, *rdv, *rda, *w, *bg;
   lds_u16 *g, *perm, *perm_alt, *oth, *last, *pred;
-  lds_u8 *gam;
+  lds_u8 *gam, *gam0;
   // HBM copy of the model read through the scalar cache (see publish_model)
   double *sc_store;   // global pointer used for the stores
   c_f64 *sc;          // the same memory, constant address space
@@ -181,6 +181,7 @@ __device__ __forceinline__ void bind_lds(Chain &ch, unsigned char *smem,
   ch.last = to_lds<uint16_t>(smem + lay.last);
   ch.pred = to_lds<uint16_t>(smem + lay.pred);
   ch.gam = to_lds<uint8_t>(smem + lay.gam);
+  ch.gam0 = to_lds<uint8_t>(smem + lay.gam0);
 }
 
 // In-place Cholesky of a block-packed lower triangle, lane i owns row i
@@ -802,7 +803,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   const int wave = threadIdx.x >> 6;
   const int p = P.p;
   if (chain >= P.chains) return;
-  if (P.status[chain] != CHAIN_OK) return;
+  if (P.status[chain] != CHAIN_OK) {
+    // a chain waiting for a larger-capacity kernel (or in error) just books
+    // the sweeps it is owed
+    if (threadIdx.x == 0) P.todo[chain] += nsweeps;
+    return;
+  }
 
   constexpr int KCAP = NB * 8;
   const SsvsLds lay = ssvs_lds_layout(p, KCAP);
@@ -872,11 +878,16 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   if (k > KCAP) status = CHAIN_MODEL_TOO_LARGE;
   ch.k = k;
   wave_sync();
+  nsweeps += P.todo[chain];  // sweeps owed from earlier launches
+  bool aborted = false;      // stopped inside a sweep: restore its start
+  int kmax = k;
+  int trace_at = P.trace_idx ? P.trace_idx[chain] : 0;
 
   uint64_t pos = P.rng_pos[chain];
   int failures = P.failures[chain];
   double sigsq = P.sigsq[chain];
-  double beta_m = 0.0;  // lane m: coefficient of g[m] after the last draw
+  double beta_m = 0.0;  // lane m: coefficient of variable gprev after the last draw
+  int gprev = 0, kprev = 0;
   bool beta_valid = false;
 
   double acc_sig = 0, acc_sig2 = 0, acc_k = 0, acc_acc = 0, acc_prop = 0;
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   int phase = PH_BEGIN, sweep = 0, i0 = 0;
   bool model_checked = false;  // legality of the start is checked in sweep 0
   int perm_sel = 0;            // which LDS buffer holds the current permutation
-  uint64_t flip_pos = 0;
+  uint64_t flip_pos = 0, pos0 = pos;
   SeqRng rng{key, pos};
 
   while (status == CHAIN_OK) {
@@ -945,6 +956,10 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       if (sweep >= nsweeps) break;
       STAMP(7);
       if (nflips > 0) {
+        // remember the sweep's starting point (restored if the chain has to
+        // stop inside this sweep for lack of model capacity)
+        for (int j = lane; j < p; j += WAVE) ch.gam0[j] = ch.gam[j];
+        pos0 = pos;
         // ---- shuffle(indx): cpputil/shuffle.hpp:36-46, in place on the
         // persistent permutation.  Uniform t (t = 0..p-2) belongs to i = p-1-t.
         if (W > 1) {
@@ -973,7 +988,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
               const double pj = P.pi[j];
               const bool inc = ch.gam[j];
               if ((pj <= 0.0 && inc) || (pj >= 1.0 && !inc)) {
-                if (!inc && ch.k >= KCAP) { status = CHAIN_MODEL_TOO_LARGE; break; }
+                if (!inc && ch.k >= KCAP) { status = CHAIN_MODEL_TOO_LARGE; aborted = true; break; }
                 apply_flip(ch, j);
               }
             }
@@ -1039,6 +1054,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         // the candidate cannot be held in LDS; if it is a sure rejection that
         // is fine, but we cannot tell without evaluating it
         status = CHAIN_MODEL_TOO_LARGE;
+        aborted = true;
         break;
       }
       pe.f1 = jf;
@@ -1097,6 +1113,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     } else if (P.draw_beta) {
       beta_valid = true;  // empty model: all coefficients zero
     }
+    gprev = (lane < k) ? (int)ch.g[lane] : 0;
+    kprev = k;
+    kmax = k > kmax ? k : kmax;
     STAMP(6);
 
     // summaries
@@ -1111,8 +1130,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     acc_sig += sigsq;
     acc_sig2 += sigsq * sigsq;
     acc_k += k;
-    if (P.trace_sigsq && sweep < P.trace_stride && lane == 0) {
-      const size_t o = (size_t)chain * P.trace_stride + sweep;
+    if (P.trace_sigsq && trace_at + sweep < P.trace_stride && lane == 0) {
+      const size_t o = (size_t)chain * P.trace_stride + trace_at + sweep;
       P.trace_sigsq[o] = sigsq;
       P.trace_logp[o] = M.logp;
       P.trace_k[o] = (double)k;
@@ -1128,32 +1147,40 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     __syncthreads();
   }
 
-  // ---- write the chain back
-  k = ch.k;
+  // ---- write the chain back (an aborted sweep leaves no trace: gamma, the
+  // permutation and the stream position go back to the sweep's start; sigma,
+  // beta are those of the last complete sweep anyway)
   wave_sync();
-  if (status != CHAIN_MODEL_TOO_LARGE || k <= KCAP) {
+  {
+    const lds_u8 *gsrc = aborted ? ch.gam0 : ch.gam;
+    const lds_u16 *psrc = (aborted && p > 1) ? ch.perm_alt : ch.perm;
     for (int j = lane; j < p; j += WAVE) {
-      g_gamma[j] = ch.gam[j];
-      g_perm[j] = ch.perm[j];
+      g_gamma[j] = gsrc[j];
+      g_perm[j] = psrc[j];
     }
+    if (aborted) pos = pos0;
   }
   if (beta_valid) {
     double *g_beta = P.beta + (size_t)chain * p;
     for (int j = lane; j < p; j += WAVE) g_beta[j] = 0.0;
     wave_sync();
-    if (lane < k) g_beta[ch.g[lane]] = beta_m;
-  } else if (nflips > 0) {
+    if (lane < kprev) g_beta[gprev] = beta_m;
+  } else if (nflips > 0 && done > 0) {
     // coef().set_inc(g) zeroes the coefficients of excluded variables
     // (Models/Glm/GlmCoefs.cpp:89-94) even when the beta draw is suppressed
+    const lds_u8 *gsrc = aborted ? ch.gam0 : ch.gam;
     double *g_beta = P.beta + (size_t)chain * p;
     for (int j = lane; j < p; j += WAVE)
-      if (!ch.gam[j]) g_beta[j] = 0.0;
+      if (!gsrc[j]) g_beta[j] = 0.0;
   }
   if (lane == 0) {
     P.sigsq[chain] = sigsq;
     P.rng_pos[chain] = pos;
     P.failures[chain] = failures;
     P.status[chain] = status;
+    P.todo[chain] = nsweeps - done;
+    if (P.trace_idx) P.trace_idx[chain] = trace_at + done;
+    if (P.maxk) atomicMax(P.maxk, kmax);
     double *a = P.acc + (size_t)chain * ACC_COUNT;
     a[ACC_SWEEPS] += done;
     a[ACC_SIGSQ] += acc_sig;

@@ -75,6 +75,14 @@ struct SsvsParams {
   uint64_t *rng_pos;  // chains       (position in the sampler's stream)
   int32_t *status;    // chains
   int32_t *failures;  // chains       (failure_count_)
+  // Sweeps still owed to each chain.  A launch adds its nsweeps and runs the
+  // total; a chain that outgrows the launch's model capacity stops at a sweep
+  // boundary (state restored to the end of its last complete sweep), keeps its
+  // remaining count here with status CHAIN_MODEL_TOO_LARGE, and is resumed by
+  // the host with a larger-capacity kernel.
+  int32_t *todo;      // chains
+  int32_t *maxk;      // 1: largest model size seen (capacity adaptation)
+  int32_t *trace_idx; // chains: next trace slot
 
   // RNG key
   uint32_t seed_lo, seed_hi, stream;
@@ -104,7 +112,7 @@ struct SsvsParams {
 // its solution vector in registers.  kcap is a multiple of 8.
 // doubles first, then 16-bit, then bytes; all offsets in bytes.
 struct SsvsLds {
-  uint32_t Lv, La, rdv, rda, w, bg, ctrl, g, perm0, perm1, oth, last, pred, gam, total;
+  uint32_t Lv, La, rdv, rda, w, bg, ctrl, g, perm0, perm1, oth, last, pred, gam, gam0, total;
 };
 
 static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
@@ -127,6 +135,7 @@ static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
   L.last = o;  o += pv;
   L.pred = o;  o += pv;
   L.gam = o;   o += ((uint32_t)p + 15u) & ~15u;
+  L.gam0 = o;  o += ((uint32_t)p + 15u) & ~15u;  // gamma at the start of the sweep
   L.total = o;
   return L;
 }

@@ -209,6 +209,36 @@ def test_empty_and_full_models(oracle):
                            range(4), step=5)
 
 
+def test_capacity_escalation(oracle):
+    """a dense posterior (40 true signals, p = 64) started from the intercept
+    alone: chains outgrow the 32-variable working set mid-run, are stopped at a
+    sweep boundary and resumed with larger capacities -- invisibly to the
+    draws, which still match the oracle sweep for sweep."""
+    import boom_amd
+    X, y, _ = regression_data(800, 64, 40, seed=13)
+    suf = oracle.neregsuf(X, y)
+    prior = spike_slab_prior(suf, 40)
+    g0 = np.zeros(64, np.uint8)
+    g0[0] = 1
+    eng = make_engine(8, 21, suf=suf, prior=prior, g0=g0)
+    ora = compare_chain_by_chain(oracle, eng, suf, prior, ssvs_options(), 21, g0, 60,
+                                 range(8), step=12)
+    assert max(o["gamma"].sum(axis=1).max() for o in ora.values()) > 34
+    # asynchronous launches queued behind a chain that stopped: nothing is lost
+    eng2 = make_engine(8, 21, suf=suf, prior=prior, g0=g0)
+    for _ in range(5):
+        eng2.sweep(12, sync=False)
+    eng2.sync()
+    a, b = eng.get_states(), eng2.get_states()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert eng2.get_summaries()["sweeps"] == 8 * 60
+    # a pinned capacity turns the same situation into a reported error
+    eng3 = make_engine(8, 21, suf=suf, prior=prior, g0=g0, max_model_size_hint=16)
+    with pytest.raises(boom_amd.BoomAmdError) as ei:
+        eng3.sweep(60)
+    assert "working capacity" in str(ei.value)
+
+
 def test_chain_offset_sharding(oracle):
     """chains keyed by GLOBAL id: an engine holding chains [8, 12) draws what
     chains 8..11 of a single big engine draw (multi-GPU sharding contract)."""
