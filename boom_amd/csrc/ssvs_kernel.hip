@@ -60,6 +60,15 @@ constexpr int WAVE = 64;
 #define STAMP_DECL do { } while (0)
 #define STAMP(i) do { } while (0)
 #endif
+// -DBA_STAMPS -DBA_STAMPS2: the 8 slots time the inside of a proposal batch
+// instead (0 uniform+log, 1 classify, 2 V gather, 3 V solve, 4 A gather,
+// 5 A solve, 6 epilogue, 7 everything outside the batch)
+struct StampCtx { long long last; double ph[8]; };
+#if defined(BA_STAMPS) && defined(BA_STAMPS2)
+#define SUBSTAMP(c, i) do { const long long t_ = (long long)__builtin_readcyclecounter(); (c).ph[i] += (double)(t_ - (c).last); (c).last = t_; } while (0)
+#else
+#define SUBSTAMP(c, i) do { } while (0)
+#endif
 
 // ---- address spaces ---------------------------------------------------------
 // LDS pointers are typed as such so that every access is a ds_* instruction no
@@ -438,7 +447,7 @@ struct Proposal {
 template <int NB>
 __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch,
                                                   const Model &M, int j,
-                                                  bool valid) {
+                                                  bool valid, StampCtx &sx) {
   const int p = ch.p, k = ch.k;
   Proposal out;
   out.logp = -BA_INF;
@@ -475,6 +484,7 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 
   double x[NB * 8];
   double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
+  SUBSTAMP(sx, 1);
 #pragma nounroll
   for (int s = 0; s < 2; ++s) {
     const double *Mat = s ? P.A : P.V;
@@ -507,6 +517,10 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
           for (int r = 0; r < 8; ++r) ab += x[I * 8 + r] * sc[S.bg + I * 8 + r];
         }
     }
+#if defined(BA_STAMPS2)
+    asm volatile("" :: "v"(x[0]), "v"(x[1]) : "memory");
+#endif
+    SUBSTAMP(sx, s ? 4 : 2);
     solve_blocks<NB>(LB, rd, k, x);
     double n2 = 0.0, dw = 0.0;
 #pragma unroll
@@ -524,6 +538,10 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
     } else {
       na = n2;
     }
+#if defined(BA_STAMPS2)
+    asm volatile("" :: "v"(n2), "v"(dw) : "memory");
+#endif
+    SUBSTAMP(sx, s ? 5 : 3);
   }
   if (fast) {
     double ldv, lda, Q;
@@ -762,14 +780,19 @@ template <int NB>
 __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
                                            const Model &M, const PhiloxKey &key,
                                            uint64_t flip_pos, int nflips, int i0,
-                                           int wave, lds_f64 *ctl) {
+                                           int wave, lds_f64 *ctl, StampCtx &sx) {
   const int lane = ch.lane;
+  SUBSTAMP(sx, 7);
   const int idx = i0 + WAVE * wave + lane;
   const bool valid = idx < nflips;
   const int j = valid ? (int)ch.perm[idx] : 0;
   const double u = philox_uniform(key, flip_pos + (uint64_t)idx);
   const double logu = log(u);
-  const Proposal pr = eval_proposal<NB>(P, ch, M, j, valid);
+#if defined(BA_STAMPS2)
+  asm volatile("" :: "v"(logu) : "memory");
+#endif
+  SUBSTAMP(sx, 0);
+  const Proposal pr = eval_proposal<NB>(P, ch, M, j, valid, sx);
   const double delta = pr.logp - M.logp;
   const bool accept = valid && !pr.slow && !pr.bad_ss && !(logu > delta);
   const unsigned long long m_acc = __ballot(accept);
@@ -792,6 +815,7 @@ __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
     sl[SL_MARGIN] = mmin;
     sl[SL_DELTA] = delta;
   }
+  SUBSTAMP(sx, 6);
 }
 
 template <int NB, int W, int WPE>
@@ -828,6 +852,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   const PhiloxKey key{P.seed_lo, P.seed_hi,
                       (uint32_t)(P.chain_offset + chain), P.stream};
 
+  StampCtx sx_unused;
+  sx_unused.last = 0;
   if (W > 1 && wave != 0) {
     // ---- helper waves: serve the master's commands ---------------------------
     for (;;) {
@@ -845,7 +871,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         unsigned long long a = (unsigned long long)ch.sc_store;
         asm volatile("" : "+s"(a) : : "memory");
         ch.sc = (c_f64 *)a;
-        eval_share<NB>(P, ch, M, key, upos, (int)ctl[CT_NFLIPS], (int)ctl[CT_I0], wave, ctl);
+        eval_share<NB>(P, ch, M, key, upos, (int)ctl[CT_NFLIPS], (int)ctl[CT_I0], wave, ctl, sx_unused);
       } else {  // CMD_UNIF: this wave's share of the shuffle uniforms
         for (int t = threadIdx.x; t < p - 1; t += WAVE * W) {
           const int i = p - 1 - t;
@@ -896,6 +922,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
 
   const int nflips = P.max_flips;  // already min(max_nflips_, p)
   STAMP_DECL;
+  StampCtx sx;
+  sx.last = (long long)__builtin_readcyclecounter();
+  for (int i = 0; i < 8; ++i) sx.ph[i] = 0.0;
 
   // The factors / scalars of the current model are built once per launch and
   // after every change of gamma; they stay valid across sweeps (they depend on
@@ -1021,7 +1050,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         }
         __syncthreads();
       }
-      eval_share<NB>(P, ch, M, key, flip_pos, nflips, i0, 0, ctl);
+      eval_share<NB>(P, ch, M, key, flip_pos, nflips, i0, 0, ctl, sx);
       if (W > 1) __syncthreads(); else wave_sync();
       // first stop over the whole batch, in sweep order
       int wstop = -1, f = WAVE;
@@ -1189,7 +1218,10 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     a[ACC_ACCEPTS] += acc_acc;
     a[ACC_PROPOSALS] += acc_prop;
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], min_margin);
-#ifdef BA_STAMPS
+#if defined(BA_STAMPS) && defined(BA_STAMPS2)
+    SUBSTAMP(sx, 7);
+    for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += sx.ph[i];
+#elif defined(BA_STAMPS)
     for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += st_ph[i];
 #endif
   }

@@ -1126,6 +1126,221 @@ int bo_ssvs_run_chains(int p, const double *xtx, const double *xty, double yty,
 }
 
 /* ====================================================================== */
+/*                 SpikeSlabSampler (sigma^2-conditional SSVS)            */
+/* ====================================================================== */
+struct bo_sss {
+  int p, slab_kind;
+  double *xtx, *xty, *mu, *prec, *pi, *logpi, *logcpi;
+  int64_t max_model_size;
+  int max_flips;
+  uint8_t *gamma;
+  double *beta;
+  bo_rng rng;
+  int *g, *indx;
+  double *w1, *w2, *w3, *M1, *M2, *M3;
+};
+
+bo_sss *bo_sss_create(int p, const double *xtx, const double *xty, int slab_kind,
+                      const double *mu, const double *prec, const double *pi) {
+  bo_sss *s = (bo_sss *)xcalloc(1, sizeof(bo_sss));
+  size_t pp = (size_t)p * p;
+  s->p = p;
+  s->slab_kind = slab_kind;
+  s->xtx = (double *)xcalloc(pp, sizeof(double));
+  s->xty = (double *)xcalloc(p, sizeof(double));
+  s->mu = (double *)xcalloc(p, sizeof(double));
+  s->prec = (double *)xcalloc(pp, sizeof(double));
+  s->pi = (double *)xcalloc(p, sizeof(double));
+  s->logpi = (double *)xcalloc(p, sizeof(double));
+  s->logcpi = (double *)xcalloc(p, sizeof(double));
+  memcpy(s->xtx, xtx, pp * sizeof(double));
+  memcpy(s->xty, xty, p * sizeof(double));
+  memcpy(s->mu, mu, p * sizeof(double));
+  memcpy(s->prec, prec, pp * sizeof(double));
+  memcpy(s->pi, pi, p * sizeof(double));
+  for (int j = 0; j < p; ++j) {
+    s->logpi[j] = log(pi[j]);
+    s->logcpi[j] = log(1 - pi[j]);
+  }
+  s->max_model_size = -1;
+  s->max_flips = -1;
+  s->gamma = (uint8_t *)xcalloc(p, 1);
+  s->beta = (double *)xcalloc(p, sizeof(double));
+  s->g = (int *)xcalloc(p, sizeof(int));
+  s->indx = (int *)xcalloc(p, sizeof(int));
+  s->w1 = (double *)xcalloc(p, sizeof(double));
+  s->w2 = (double *)xcalloc(p, sizeof(double));
+  s->w3 = (double *)xcalloc(p, sizeof(double));
+  s->M1 = (double *)xcalloc(pp, sizeof(double));
+  s->M2 = (double *)xcalloc(pp, sizeof(double));
+  s->M3 = (double *)xcalloc(pp, sizeof(double));
+  bo_rng_seed_philox(&s->rng, 0, 0, 3, 0);
+  return s;
+}
+void bo_sss_destroy(bo_sss *s) {
+  if (!s) return;
+  free(s->xtx); free(s->xty); free(s->mu); free(s->prec); free(s->pi);
+  free(s->logpi); free(s->logcpi); free(s->gamma); free(s->beta); free(s->g);
+  free(s->indx); free(s->w1); free(s->w2); free(s->w3); free(s->M1); free(s->M2);
+  free(s->M3);
+  free(s);
+}
+void bo_sss_set_options(bo_sss *s, int64_t max_model_size, int max_flips) {
+  s->max_model_size = max_model_size;
+  s->max_flips = max_flips;
+}
+void bo_sss_set_state(bo_sss *s, const uint8_t *gamma, const double *beta) {
+  memcpy(s->gamma, gamma, s->p);
+  if (beta) memcpy(s->beta, beta, sizeof(double) * s->p);
+}
+void bo_sss_get_state(const bo_sss *s, uint8_t *gamma, double *beta) {
+  if (gamma) memcpy(gamma, s->gamma, s->p);
+  if (beta) memcpy(beta, s->beta, sizeof(double) * s->p);
+}
+bo_rng *bo_sss_rng(bo_sss *s) { return &s->rng; }
+
+static double sss_spike_logp(const bo_sss *s, const uint8_t *g, int nvars) {
+  if (s->max_model_size >= 0 && nvars > s->max_model_size) return BO_NEG_INF;
+  double ans = 0;
+  for (int i = 0; i < s->p; ++i) {
+    ans += g[i] ? s->logpi[i] : s->logcpi[i];
+    if (!isfinite(ans)) return BO_NEG_INF;
+  }
+  return ans;
+}
+
+/* slab_prior_->siginv() restricted to the model: prec or prec / sigsq */
+static void sss_select_precision(const bo_sss *s, const int *idx, int k,
+                                 double sigsq, double *out) {
+  for (int c = 0; c < k; ++c)
+    for (int r = 0; r < k; ++r) {
+      double v = s->prec[IDX(idx[r], idx[c], s->p)];
+      out[IDX(r, c, k)] = (s->slab_kind == 1) ? v / sigsq : v;
+    }
+}
+
+/* SpikeSlabSampler::log_model_prob, SpikeSlabSampler.cpp:171-203 */
+double bo_sss_log_model_prob(bo_sss *s, const uint8_t *g, double sigsq) {
+  int *idx = s->g;
+  int k = 0;
+  for (int j = 0; j < s->p; ++j)
+    if (g[j]) idx[k++] = j;
+  double numerator = sss_spike_logp(s, g, k);
+  if (numerator == BO_NEG_INF || k == 0) return numerator;
+  double *prec = s->M1;
+  sss_select_precision(s, idx, k, sigsq, prec);
+  int ok = 1;
+  numerator += .5 * bo_spd_logdet(k, prec, &ok);
+  if (numerator == BO_NEG_INF) return numerator;
+  double *mu = s->w1, *pmu = s->w2;
+  for (int i = 0; i < k; ++i) mu[i] = s->mu[idx[i]];
+  double dot = 0;
+  for (int i = 0; i < k; ++i) {
+    double acc = 0;
+    for (int j = 0; j < k; ++j) acc += prec[IDX(i, j, k)] * mu[j];
+    pmu[i] = acc;
+  }
+  for (int i = 0; i < k; ++i) dot += mu[i] * pmu[i];
+  numerator -= .5 * dot;
+  for (int c = 0; c < k; ++c)
+    for (int r = 0; r < k; ++r)
+      prec[IDX(r, c, k)] += s->xtx[IDX(idx[r], idx[c], s->p)] / sigsq;
+  double *L = s->M2;
+  if (!bo_chol(k, prec, L)) return BO_NEG_INF;
+  double denominator = 0;
+  for (int i = 0; i < k; ++i) denominator += log(L[IDX(i, i, k)]);
+  double *S = s->w3;
+  for (int i = 0; i < k; ++i) S[i] = s->xty[idx[i]] / sigsq + pmu[i];
+  lsolve_inplace(k, L, S);
+  double nsq = 0;
+  for (int i = 0; i < k; ++i) nsq += S[i] * S[i];
+  denominator -= .5 * nsq;
+  return numerator - denominator;
+}
+
+/* draw_inclusion_indicators + draw_model_indicators,
+ * SpikeSlabSampler.cpp:40-95 (the permutation restarts from the identity on
+ * every call; max_flips_ limits only when > 0) */
+int bo_sss_draw_model_indicators(bo_sss *s, double sigsq) {
+  int p = s->p;
+  uint8_t *g = (uint8_t *)malloc(p);
+  memcpy(g, s->gamma, p);
+  for (int j = 0; j < p; ++j) s->indx[j] = j;
+  for (int i = p - 1; i > 0; --i) {
+    int j = bo_random_int(&s->rng, 0, i);
+    if (j != i) {
+      int t = s->indx[i];
+      s->indx[i] = s->indx[j];
+      s->indx[j] = t;
+    }
+  }
+  double logp = bo_sss_log_model_prob(s, g, sigsq);
+  if (!isfinite(logp)) {
+    for (int i = 0; i < p; ++i) {
+      if (s->pi[i] <= 0.0 && g[i]) g[i] = 0;
+      if (s->pi[i] >= 1.0 && !g[i]) g[i] = 1;
+    }
+    logp = bo_sss_log_model_prob(s, g, sigsq);
+  }
+  if (!isfinite(logp)) {
+    free(g);
+    return BO_ERR_ILLEGAL_START;
+  }
+  int n = p;
+  if (s->max_flips > 0 && s->max_flips < n) n = s->max_flips;
+  for (int i = 0; i < n; ++i) {
+    int which = s->indx[i];
+    g[which] = !g[which];
+    double logp_new = bo_sss_log_model_prob(s, g, sigsq);
+    double u = bo_runif(&s->rng, 0, 1);
+    if (log(u) > logp_new - logp) {
+      g[which] = !g[which];
+    } else {
+      logp = logp_new;
+    }
+  }
+  /* coef().set_inc: excluded coefficients go to zero */
+  memcpy(s->gamma, g, p);
+  for (int j = 0; j < p; ++j)
+    if (!g[j]) s->beta[j] = 0.0;
+  free(g);
+  return BO_OK;
+}
+
+/* draw_beta / draw_coefficients_given_inclusion, SpikeSlabSampler.cpp:97-138,
+ * rmvn_ivar_mt, distributions/mvn.cpp:104-122 */
+int bo_sss_draw_beta(bo_sss *s, double sigsq) {
+  int p = s->p;
+  int *idx = s->g;
+  int k = 0;
+  for (int j = 0; j < p; ++j)
+    if (s->gamma[j]) idx[k++] = j;
+  if (k == 0) {
+    memset(s->beta, 0, sizeof(double) * p);  /* model_->drop_all() */
+    return BO_OK;
+  }
+  double *prec = s->M1, *pmu = s->w2, *mean = s->w3, *L = s->M2;
+  sss_select_precision(s, idx, k, sigsq, prec);
+  for (int i = 0; i < k; ++i) {
+    double acc = 0;
+    for (int j = 0; j < k; ++j) acc += prec[IDX(i, j, k)] * s->mu[idx[j]];
+    pmu[i] = acc;
+  }
+  for (int c = 0; c < k; ++c)
+    for (int r = 0; r < k; ++r)
+      prec[IDX(r, c, k)] += s->xtx[IDX(idx[r], idx[c], p)] / sigsq;
+  for (int i = 0; i < k; ++i) pmu[i] += s->xty[idx[i]] / sigsq;
+  if (!bo_spd_solve(k, prec, pmu, mean)) return BO_ERR_NOT_PD;
+  if (!bo_chol(k, prec, L)) return BO_ERR_NOT_PD;
+  double *z = s->w1;
+  for (int i = 0; i < k; ++i) z[i] = bo_rnorm(&s->rng, 0, 1);
+  ltsolve_inplace(k, L, z);
+  memset(s->beta, 0, sizeof(double) * p);
+  for (int i = 0; i < k; ++i) s->beta[idx[i]] = z[i] + mean[i];
+  return BO_OK;
+}
+
+/* ====================================================================== */
 /*                               state space                              */
 /* ====================================================================== */
 struct bo_ss {

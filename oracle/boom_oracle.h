@@ -149,6 +149,26 @@ int bo_ssvs_run_chains(int p, const double *xtx, const double *xty, double yty,
                        int chains, int nsweeps, int nthreads, uint8_t *gamma,
                        double *beta, double *sigsq);
 
+/* ------------------------------------- SpikeSlabSampler (sigma^2 given) */
+/* The sigma^2-conditional SSVS helper, Models/Glm/PosteriorSamplers/
+ * SpikeSlabSampler.cpp:40-82 (draw_inclusion_indicators), :115-138
+ * (draw_coefficients_given_inclusion), :171-203 (log_model_prob), :205-216.
+ * slab_kind 0: precision `prec` independent of sigma^2 (MvnModel);
+ * slab_kind 1: precision prec / sigsq (MvnGivenScalarSigma::siginv,
+ * MvnGivenScalarSigma.cpp:74-77).  xtx / xty are (weighted) sufficient
+ * statistics (WeightedRegSuf). */
+typedef struct bo_sss bo_sss;
+bo_sss *bo_sss_create(int p, const double *xtx, const double *xty, int slab_kind,
+                      const double *mu, const double *prec, const double *pi);
+void bo_sss_destroy(bo_sss *s);
+void bo_sss_set_options(bo_sss *s, int64_t max_model_size, int max_flips);
+void bo_sss_set_state(bo_sss *s, const uint8_t *gamma, const double *beta);
+void bo_sss_get_state(const bo_sss *s, uint8_t *gamma, double *beta);
+bo_rng *bo_sss_rng(bo_sss *s);
+double bo_sss_log_model_prob(bo_sss *s, const uint8_t *gamma, double sigsq);
+int bo_sss_draw_model_indicators(bo_sss *s, double sigsq);
+int bo_sss_draw_beta(bo_sss *s, double sigsq);
+
 /* ---------------------------------------------------------- state space */
 typedef struct bo_ss bo_ss;
 

@@ -24,6 +24,9 @@
 #include "LinAlg/Vector.hpp"
 #include "Models/ChisqModel.hpp"
 #include "Models/Glm/PosteriorSamplers/BregVsSampler.hpp"
+#include "Models/Glm/PosteriorSamplers/SpikeSlabSampler.hpp"
+#include "Models/Glm/WeightedRegressionModel.hpp"
+#include "Models/MvnModel.hpp"
 #include "Models/Glm/RegressionModel.hpp"
 #include "Models/Glm/VariableSelectionPrior.hpp"
 #include "Models/MvnGivenScalarSigma.hpp"
@@ -454,6 +457,71 @@ int ref_ss_impute_state(int T, int p, const double *y, const double *X,
   *out_n = reg->suf()->n();
   *out_level_sumsq = level->suf()->sumsq();
   *out_level_n = level->suf()->n();
+  REF_CATCH
+}
+
+// ------------------------------------------- SpikeSlabSampler (sigma given)
+// The sigma^2-conditional SSVS helper used by the logit / probit / Poisson /
+// Student samplers (SpikeSlabSampler.cpp:40-82, 115-138, 171-216), driven the
+// way those samplers drive it: per iteration draw_model_indicators(rng, suf,
+// sigsq) then draw_beta(rng, suf, sigsq).  slab_kind 0: MvnModel(mu, ivar)
+// (precision independent of sigma^2); 1: MvnGivenScalarSigma(mu, ominv) whose
+// siginv() is ominv / sigsq.  The weighted sufficient statistics come from
+// (X, y, w).  sigsq[i] is the residual variance handed to iteration i.
+int ref_sss_run(int n, int p, const double *X, const double *y, const double *w,
+                int slab_kind, const double *mu, const double *prec,
+                const double *pi, int64_t max_model_size, int max_flips,
+                uint64_t seed, const uint8_t *init_gamma, int nsweeps,
+                const double *sigsq, uint8_t *out_gamma, double *out_beta) {
+  REF_TRY
+  Matrix Xm = make_matrix(n, p, X);
+  Vector yv = make_vector(n, y);
+  Vector wv = w ? make_vector(n, w) : Vector(n, 1.0);
+  // (the (X, y, w) constructor prepends an intercept column; recompute() takes
+  // the design matrix as it is)
+  WeightedRegSuf suf(p);
+  suf.recompute(Xm, yv, wv);
+  NEW(RegressionModel, model)(p);
+  Ptr<MvnBase> slab;
+  if (slab_kind == 0) {
+    slab = new MvnModel(make_vector(p, mu), make_spd(p, prec), true);
+  } else {
+    slab = new MvnGivenScalarSigma(make_vector(p, mu), make_spd(p, prec),
+                                   model->Sigsq_prm());
+  }
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
+  SpikeSlabSampler sam(model.get(), slab, spike);
+  if (max_flips >= 0) sam.limit_model_selection(max_flips);
+  model->coef().drop_all();
+  for (int j = 0; j < p; ++j)
+    if (init_gamma[j]) model->coef().add(j);
+  RNG rng(seed);
+  for (int i = 0; i < nsweeps; ++i) {
+    model->set_sigsq(sigsq[i]);
+    sam.draw_model_indicators(rng, suf, sigsq[i]);
+    sam.draw_beta(rng, suf, sigsq[i]);
+    const Selector &inc(model->coef().inc());
+    const Vector &beta(model->Beta());
+    for (int j = 0; j < p; ++j) {
+      out_gamma[(size_t)i * p + j] = inc[j] ? 1 : 0;
+      out_beta[(size_t)i * p + j] = beta[j];
+    }
+  }
+  REF_CATCH
+}
+
+// weighted sufficient statistics (WeightedRegSuf(X, y, w))
+int ref_weighted_suf(int n, int p, const double *X, const double *y,
+                     const double *w, double *xtx, double *xty) {
+  REF_TRY
+  WeightedRegSuf suf(p);
+  suf.recompute(make_matrix(n, p, X), make_vector(n, y),
+                w ? make_vector(n, w) : Vector(n, 1.0));
+  SpdMatrix S = suf.xtx();
+  std::memcpy(xtx, S.data(), sizeof(double) * p * p);
+  Vector s = suf.xty();
+  std::memcpy(xty, s.data(), sizeof(double) * p);
   REF_CATCH
 }
 

@@ -163,6 +163,33 @@ def main():
                              prior_mean=np.zeros(6))
     ssvs_case("ssvs_empty", X, y, prior, ssvs_options(), [3], np.zeros(6, np.uint8), 200)
 
+    # ---- SpikeSlabSampler: the sigma^2-conditional sweep (a11) ----------------
+    rng = np.random.Generator(np.random.PCG64(5))
+    for kind in (0, 1):
+        for case in range(2):
+            n, p = (400, 24) if case == 0 else (150, 10)
+            X, y, _ = regression_data(n, p, 5 if case == 0 else 3, seed=30 + case)
+            w = rng.uniform(0.3, 2.0, n) if case == 0 else np.ones(n)
+            xtx, xty = R.weighted_suf(X, y, w)
+            mu = np.zeros(p)
+            mu[0] = y.mean()
+            if case == 1:
+                mu = np.linspace(-0.5, 0.5, p)   # non-zero prior mean everywhere
+            prec = 0.01 * (0.5 * np.diag(np.diag(xtx / n)) + 0.5 * xtx / n)
+            pi = np.full(p, 0.25)
+            if case == 0:
+                pi[0] = 1.0
+            sig = np.exp(rng.normal(0, 0.2, 150))
+            g0 = np.zeros(p, np.uint8)
+            g0[0] = 1
+            mms, mf = (4, 6) if case == 1 else (-1, -1)
+            o = R.sss_run(X, y, w, kind, mu, prec, pi, 77, g0, sig, max_model_size=mms,
+                          max_flips=mf)
+            save("sss_kind%d_case%d" % (kind, case), X=X, y=y, w=w, xtx=xtx, xty=xty,
+                 slab_kind=kind, mu=mu, prec=prec, pi=pi, seed=77, init_gamma=g0,
+                 sigsq=sig, max_model_size=mms, max_flips=mf, gamma=o["gamma"],
+                 beta=o["beta"])
+
     # ---- state space (local level + regression) -----------------------------
     for name, miss, sd in (("ss_t200", 0.0, 22), ("ss_t200_missing", 0.05, 21)):
         X, y, _, obs = state_space_data(200, 8, 3, seed=5, missing_frac=miss)

@@ -373,6 +373,51 @@ class Oracle:
             _dp(beta), _dp(sig))
         return dict(gamma=gam, beta=beta, sigsq=sig, status=st)
 
+    # -- SpikeSlabSampler (sigma^2 given) ---------------------------------------
+    def sss_run(self, xtx, xty, slab_kind, mu, prec, pi, rng_setup, init_gamma,
+                sigsq_seq, max_model_size=-1, max_flips=-1):
+        L = self.lib
+        L.bo_sss_create.restype = C.c_void_p
+        L.bo_sss_create.argtypes = [C.c_int, c_double_p, c_double_p, C.c_int,
+                                    c_double_p, c_double_p, c_double_p]
+        L.bo_sss_destroy.argtypes = [C.c_void_p]
+        L.bo_sss_set_options.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        L.bo_sss_set_state.argtypes = [C.c_void_p, c_u8_p, c_double_p]
+        L.bo_sss_get_state.argtypes = [C.c_void_p, c_u8_p, c_double_p]
+        L.bo_sss_rng.restype = C.c_void_p
+        L.bo_sss_rng.argtypes = [C.c_void_p]
+        L.bo_sss_draw_model_indicators.argtypes = [C.c_void_p, C.c_double]
+        L.bo_sss_draw_beta.argtypes = [C.c_void_p, C.c_double]
+        p = len(xty)
+        h = L.bo_sss_create(p, _dp(fcol(xtx)), _dp(f64(xty)), int(slab_kind),
+                            _dp(f64(mu)), _dp(fcol(prec)), _dp(f64(pi)))
+        L.bo_sss_set_options(h, int(max_model_size), int(max_flips))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        L.bo_sss_set_state(h, _u8(g0), _dp(np.zeros(p)))
+        rp = L.bo_sss_rng(h)
+        if rng_setup[0] == "mt":
+            L.bo_rng_seed_mt(rp, int(rng_setup[1]))
+        else:
+            L.bo_rng_seed_philox(rp, int(rng_setup[1]), int(rng_setup[2]), 3, 0)
+        n = len(sigsq_seq)
+        gam = np.zeros((n, p), dtype=np.uint8)
+        beta = np.zeros((n, p))
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        status = 0
+        for i, s2 in enumerate(sigsq_seq):
+            status = L.bo_sss_draw_model_indicators(h, float(s2))
+            if status:
+                break
+            status = L.bo_sss_draw_beta(h, float(s2))
+            if status:
+                break
+            L.bo_sss_get_state(h, _u8(g), _dp(b))
+            gam[i] = g
+            beta[i] = b
+        L.bo_sss_destroy(h)
+        return dict(gamma=gam, beta=beta, status=status)
+
     # -- state space -----------------------------------------------------------
     def ss_create(self, y, X, observed, prior, ss):
         T, p = X.shape
@@ -622,6 +667,29 @@ class Ref:
             C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
             C.c_int64(max_model_size), len(G), _u8(G), _dp(out)))
         return out
+
+    def sss_run(self, X, y, w, slab_kind, mu, prec, pi, seed, init_gamma,
+                sigsq_seq, max_model_size=-1, max_flips=-1):
+        n, p = X.shape
+        ns = len(sigsq_seq)
+        gam = np.zeros((ns, p), dtype=np.uint8)
+        beta = np.zeros((ns, p))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        ww = None if w is None else f64(w)
+        self._check(self.lib.ref_sss_run(
+            n, p, _dp(fcol(X)), _dp(f64(y)), _dp(ww), int(slab_kind), _dp(f64(mu)),
+            _dp(fcol(prec)), _dp(f64(pi)), C.c_int64(max_model_size), int(max_flips),
+            C.c_uint64(seed), _u8(g0), ns, _dp(f64(sigsq_seq)), _u8(gam), _dp(beta)))
+        return dict(gamma=gam, beta=beta)
+
+    def weighted_suf(self, X, y, w):
+        n, p = X.shape
+        xtx = np.zeros(p * p)
+        xty = np.zeros(p)
+        ww = None if w is None else f64(w)
+        self._check(self.lib.ref_weighted_suf(n, p, _dp(fcol(X)), _dp(f64(y)), _dp(ww),
+                                              _dp(xtx), _dp(xty)))
+        return xtx.reshape(p, p).T.copy(), xty
 
     def ss_run(self, y, X, observed, prior, opts, ss, seed, init_gamma,
                nsweeps):

@@ -194,6 +194,24 @@ def test_convenience_ctor_priors(oracle):
     assert relerr(o["sigsq"], g["sigsq2"]) < RTOL
 
 
+# ------------------------------------------------- SpikeSlabSampler (a11)
+@pytest.mark.parametrize("name", ["sss_kind0_case0", "sss_kind0_case1",
+                                  "sss_kind1_case0", "sss_kind1_case1"])
+def test_spike_slab_sampler_matches_reference(oracle, name):
+    g = load(name)
+    n, p = g["X"].shape
+    W = g["w"]
+    xtx = (g["X"].T * W) @ g["X"]
+    assert relerr(xtx, g["xtx"], 1e-6) < 1e-12      # WeightedRegSuf
+    o = oracle.sss_run(g["xtx"], g["xty"], int(g["slab_kind"]), g["mu"], g["prec"],
+                       g["pi"], ("mt", int(g["seed"])), g["init_gamma"], g["sigsq"],
+                       max_model_size=int(g["max_model_size"]),
+                       max_flips=int(g["max_flips"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < RTOL
+
+
 # ------------------------------------------------------------- state space
 @pytest.mark.parametrize("name", ["ss_t200", "ss_t200_missing"])
 def test_state_space_sweeps_match_reference(oracle, name):

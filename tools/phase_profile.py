@@ -5,7 +5,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", "libboomamd_stamps.so")
+SUB = os.environ.get("SUBSTAMPS", "0") == "1"
+os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", "libboomamd_stamps2.so" if SUB else "libboomamd_stamps.so")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import time
@@ -34,6 +35,9 @@ sm = eng.get_summaries()
 ph = sm["phase_cycles"]
 names = ["shuffle uniforms", "shuffle serial", "refactor", "proposal batches",
          "swap", "sigma", "beta", "rest"]
+if SUB:
+    names = ["batch: uniform+log", "batch: classify", "batch: V gather", "batch: V solve",
+             "batch: A gather", "batch: A solve", "batch: epilogue", "outside batches"]
 tot = ph.sum()
 print("waves=%s hint=%s" % (os.environ.get("BOOM_AMD_WAVES","auto"), os.environ.get("KCAP_HINT","0")), end=" "); print("signals %d chains %d: %.1f us per sweep-round, kbar %.2f, accepts/sweep %.3f, proposals/sweep %.1f"
       % (nsig, chains, dt / 100 * 1e6, sm["k_sum"] / sm["sweeps"], sm["accepts"] / sm["sweeps"],
