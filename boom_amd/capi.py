@@ -65,6 +65,9 @@ SIGNATURES = {
     "ba_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_sync": (C.c_int, [C.c_void_p]),
     "ba_log_model_prob": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _dp]),
+    "ba_set_sigsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_double]),
+    "ba_sss_set_slab": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, C.c_int32]),
+    "ba_sss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_reset_summaries": (C.c_int, [C.c_void_p]),
     "ba_get_summaries": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "ba_summaries_device": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -244,6 +247,22 @@ class Engine:
         out = np.zeros(len(G))
         self._check(self.lib.ba_log_model_prob(self._h, len(G), _b(G), _p(out)))
         return out
+
+    # ---- SpikeSlabSampler (sigma^2 given) --------------------------------------
+    def set_sigsq(self, sigsq, chain=-1):
+        self._check(self.lib.ba_set_sigsq(self._h, chain, float(sigsq)))
+
+    def sss_set_slab(self, mu, precision, scales_with_sigsq=True, max_flips=-1):
+        self._check(self.lib.ba_sss_set_slab(self._h, _p(_f64(mu)), _p(_fcol(precision)),
+                                             int(scales_with_sigsq), int(max_flips)))
+
+    def set_spike(self, pi, max_model_size=-1):
+        self._check(self.lib.ba_set_spike(self._h, _p(_f64(pi)), int(max_model_size)))
+
+    def sss_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_sss_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
 
     # ---- summaries ----------------------------------------------------------
     def reset_summaries(self):

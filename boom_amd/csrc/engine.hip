@@ -156,6 +156,13 @@ struct ba_engine {
 
   int kcap = 0;
   int waves = 1;  // wavefronts per chain
+  // SpikeSlabSampler (sigma^2 given) mode
+  int cur_mode = 0;          // mode of the launches in flight (0 BregVs, 1 SSS)
+  int sss_slab_scales = 1;   // slab precision = Omega^{-1} / sigma^2
+  int sss_max_flips = -1;    // limits only when > 0 (SpikeSlabSampler.cpp:77)
+  double v_scale = 1.0;      // V = Omega^{-1} + v_scale * XtX currently on the device
+  double v_scale_want = 1.0;
+  DevBuf<uint64_t> dpos_sss;
   uint64_t seed = 0;
 
   // ---- state space (bsts local level + regression)
@@ -254,7 +261,8 @@ int upload_shared(ba_engine *e) {
     return fail(BA_E_STATE, "priors (slab, spike, sigma) must be set before sampling");
   const size_t pp = (size_t)p * p;
   std::vector<double> V(pp), l1(p), l0(p), scal(2);
-  for (size_t i = 0; i < pp; ++i) V[i] = e->ominv[i] + e->xtx[i];
+  for (size_t i = 0; i < pp; ++i) V[i] = e->ominv[i] + e->xtx[i] * e->v_scale_want;
+  e->v_scale = e->v_scale_want;
   // VariableSelectionPrior::ensure_log_probabilities,
   // VariableSelectionPrior.cpp:310-317
   for (int j = 0; j < p; ++j) {
@@ -309,6 +317,7 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(e->dsigsq.resize(C));
   HIP_TRY(e->dperm.resize(C * p));
   HIP_TRY(e->dpos.resize(C));
+  HIP_TRY(e->dpos_sss.resize(C));
   HIP_TRY(e->dstatus.resize(C));
   HIP_TRY(e->dfail.resize(C));
   HIP_TRY(e->dtodo.resize(C));
@@ -331,6 +340,7 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(hipMemcpyAsync(e->dsigsq.ptr, ones.data(), C * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(e->dperm.ptr, perm.data(), C * p * 2, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(e->dpos.ptr, 0, C * 8, s));
+  HIP_TRY(hipMemsetAsync(e->dpos_sss.ptr, 0, C * 8, s));
   HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, C * 4, s));
   HIP_TRY(hipMemsetAsync(e->dfail.ptr, 0, C * 4, s));
   HIP_TRY(hipMemsetAsync(e->dtodo.ptr, 0, C * 4, s));
@@ -394,6 +404,17 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.seed_lo = (uint32_t)e->seed;
   P.seed_hi = (uint32_t)(e->seed >> 32);
   P.stream = 0;
+  P.mode = e->cur_mode;
+  if (e->cur_mode == 1) {
+    // SpikeSlabSampler: given sigma^2, no sigma draw, no swap move, own stream
+    P.slab_scales = e->sss_slab_scales;
+    P.stream = 3;
+    P.rng_pos = e->dpos_sss.ptr;
+    P.draw_sigma = 0;
+    P.draw_beta = 1;
+    P.cm_start = nullptr;
+    P.max_flips = (e->sss_max_flips > 0) ? std::min(e->sss_max_flips, e->p) : e->p;
+  }
   P.inc_count = e->dinc.ptr;
   P.beta_sum = e->dbsum.ptr;
   P.beta_sumsq = e->dbsumsq.ptr;
@@ -818,11 +839,30 @@ int ba_seed(ba_engine *e, uint64_t seed) {
   return BA_OK;
 }
 
+// A change of sampler (BregVs <-> SpikeSlab) or of the XtX scale inside V has
+// to wait for the launches in flight (they may still be escalated).
+static int switch_mode(ba_engine *e, int mode, double v_scale) {
+  if (e->cur_mode == mode && e->v_scale_want == v_scale) return BA_OK;
+  if (e->state_ready) {
+    int rc = ba_sync(e);
+    if (rc) return rc;
+  }
+  e->cur_mode = mode;
+  if (e->v_scale_want != v_scale) {
+    e->v_scale_want = v_scale;
+    e->device_dirty = true;
+  }
+  return BA_OK;
+}
+
 // ------------------------------------------------------------ hot path
 int ba_sweep(ba_engine *e, int32_t nsweeps) {
   ENGINE_PROLOGUE(e);
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
-  int rc = upload_shared(e);
+  if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
+  int rc = switch_mode(e, 0, 1.0);
+  if (rc) return rc;
+  rc = upload_shared(e);
   if (rc) return rc;
   rc = alloc_chain_state(e);
   if (rc) return rc;
@@ -949,6 +989,74 @@ int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
   HIP_TRY(fetch(sigsq, e->dtr_sig.ptr));
   HIP_TRY(fetch(logp, e->dtr_logp.ptr));
   HIP_TRY(fetch(model_size, e->dtr_k.ptr));
+  return BA_OK;
+}
+
+// ------------------------------------------- SpikeSlabSampler (sigma^2 given)
+int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq) {
+  ENGINE_PROLOGUE(e);
+  if (!(sigsq > 0)) return fail(BA_E_INVALID, "sigsq must be positive");
+  int rc = alloc_chain_state(e);
+  if (rc) return rc;
+  const int64_t C = e->cfg.chains;
+  if (chain < -1 || chain >= C) return fail(BA_E_INVALID, "chain index out of range");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (chain < 0) {
+    std::vector<double> v((size_t)C, sigsq);
+    HIP_TRY(hipMemcpy(e->dsigsq.ptr, v.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy(e->dsigsq.ptr + chain, &sigsq, 8, hipMemcpyHostToDevice));
+  }
+  return BA_OK;
+}
+
+int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
+                    int32_t precision_scales_with_sigsq, int32_t max_flips) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  int rc = ba_set_slab(e, mu, precision);
+  if (rc) return rc;
+  e->sss_slab_scales = precision_scales_with_sigsq ? 1 : 0;
+  e->sss_max_flips = max_flips;
+  if (!e->have_sigma) {  // the sigma prior plays no role given sigma^2
+    e->prior_df = 1.0;
+    e->prior_ss = 1.0;
+    e->have_sigma = true;
+  }
+  return BA_OK;
+}
+
+int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
+  if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
+  int rc = alloc_chain_state(e);
+  if (rc) return rc;
+  double v_scale = 1.0;
+  if (!e->sss_slab_scales) {
+    // a slab precision that does not scale with sigma^2 makes V = P + XtX /
+    // sigma^2 chain specific; the shared-matrix engine takes one sigma^2 for
+    // all chains in this case (it is 1 for the logit / probit / Poisson users)
+    const size_t C = (size_t)e->cfg.chains;
+    rc = ba_sync(e);
+    if (rc) return rc;
+    std::vector<double> s2(C);
+    HIP_TRY(hipMemcpy(s2.data(), e->dsigsq.ptr, C * 8, hipMemcpyDeviceToHost));
+    for (size_t c = 1; c < C; ++c)
+      if (s2[c] != s2[0])
+        return fail(BA_E_INVALID, "a slab precision independent of sigma^2 needs the same sigma^2 in every chain");
+    v_scale = 1.0 / s2[0];
+  }
+  rc = switch_mode(e, 1, v_scale);
+  if (rc) return rc;
+  rc = upload_shared(e);
+  if (rc) return rc;
+  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
+  SsvsParams P;
+  fill_params(e, P);
+  if (e->trace_stride > 0)
+    HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
+  HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
   return BA_OK;
 }
 

@@ -173,6 +173,11 @@ struct Chain {
   const double *xty;
   double DF;    // n + prior_df
   double ss0q;  // prior_ss + yty
+  // SSVS_MODE_SIGMA_GIVEN (SpikeSlabSampler): scale factors that turn the
+  // shared matrices into this chain's, V_c = sv V, A_c = sa A, xty_c = sx xty
+  // (all 1 for BregVsSampler, where sigma^2 is integrated out)
+  int mode;
+  double sv, sa, sx;
 };
 
 __device__ __forceinline__ void bind_lds(Chain &ch, unsigned char *smem,
@@ -268,7 +273,8 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   M.ldv = M.lda = M.Q = M.c = 0.0;
   M.SS = ch.ss0q;
   if (k == 0) {
-    M.logp = lp - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
+    // empty model: BregVsSampler.cpp:217-227 / SpikeSlabSampler.cpp:173-183
+    M.logp = ch.mode ? lp : lp - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
     return;
   }
   if (lp == -BA_INF) {
@@ -289,8 +295,8 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     double v = 0.0, a = 0.0;
     if (m < k) {
       const size_t o = (size_t)ch.g[m] * p + ch.g[n];
-      v = P.V[o];
-      a = P.A[o];
+      v = P.V[o] * ch.sv;
+      a = P.A[o] * ch.sa;
     }
     ch.Lv[bidx(m, n)] = v;
     ch.La[bidx(m, n)] = a;
@@ -313,9 +319,9 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     nz &= nz - 1;
     const double bn = bcast_u(bm, n);
     const int gn = bcast_u(gm, n);
-    if (lane < k) ab += P.A[(size_t)gm * p + gn] * bn;
+    if (lane < k) ab += (P.A[(size_t)gm * p + gn] * ch.sa) * bn;
   }
-  const double r = (lane < k) ? ab + ch.xty[gm] : 0.0;
+  const double r = (lane < k) ? ab + ch.xty[gm] * ch.sx : 0.0;
   M.c = wave_sum(lane < k ? bm * ab : 0.0);
   wave_sync();
   // the two factorisations share one (not unrolled) body
@@ -343,6 +349,17 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   M.Q = wave_sum(lane < k ? x * x : 0.0);
   M.SS = ch.ss0q + M.c - M.Q;
   wave_sync();
+  if (ch.mode) {
+    // SpikeSlabSampler::log_model_prob, SpikeSlabSampler.cpp:171-203:
+    // log pi(g) + .5 log|P_g| - .5 mu'P mu - [.5 log|V_g| - .5 |L^{-1} r|^2]
+    if (!oka) {
+      M.lda = -BA_INF;
+      M.logp = -BA_INF;
+      return;
+    }
+    M.logp = lp + 0.5 * (M.lda - M.ldv) - 0.5 * (M.c - M.Q);
+    return;
+  }
   if (!(M.SS >= 0.0) || isinf(M.SS)) {
     M.bad = CHAIN_NEGATIVE_SS;
     M.logp = -BA_INF;
@@ -471,11 +488,11 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
   const bool fast = live && !empty_after && !slow;
   out.slow = slow;
   if (empty_after) {
-    out.logp = lpn - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
+    out.logp = ch.mode ? lpn : lpn - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
   }
-  const double vjj = (fast && add) ? P.V[(size_t)j * p + j] : 0.0;
-  const double ajj = (fast && add) ? P.A[(size_t)j * p + j] : 0.0;
-  const double xtyj = (fast && add) ? ch.xty[j] : 0.0;
+  const double vjj = (fast && add) ? P.V[(size_t)j * p + j] * ch.sv : 0.0;
+  const double ajj = (fast && add) ? P.A[(size_t)j * p + j] * ch.sa : 0.0;
+  const double xtyj = (fast && add) ? ch.xty[j] * ch.sx : 0.0;
 
   constexpr int KCAP = NB * 8;
   const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
@@ -488,6 +505,7 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 #pragma nounroll
   for (int s = 0; s < 2; ++s) {
     const double *Mat = s ? P.A : P.V;
+    const double msc = s ? ch.sa : ch.sv;
     c_f64 *LB = sc + (s ? S.La : S.Lv);
     c_f64 *rd = sc + (s ? S.rda : S.rdv);
     // rhs = Mat[g, j] (add) or e_i (drop); branch-free inside a block so that
@@ -499,7 +517,7 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
         for (int r = 0; r < 8; ++r) {
           const int m = I * 8 + r;
           const int gm = gsc[m];
-          const double v = Mat[(size_t)gm * p + j];
+          const double v = Mat[(size_t)gm * p + j] * msc;
           const double e = (gm == j) ? 1.0 : 0.0;
           x[m] = (fast && m < k) ? (add ? v : e) : 0.0;
         }
@@ -561,7 +579,9 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
       ldv = M.ldv + log(nv);
       lda = M.lda + log(na);
     }
-    if (ok) {
+    if (ok && ch.mode) {
+      out.logp = lpn + 0.5 * (lda - ldv) - 0.5 * (M.c - Q);
+    } else if (ok) {
       const double SS = ch.ss0q + M.c - Q;
       if (!(SS >= 0.0) || isinf(SS)) {
         out.bad_ss = true;
@@ -849,6 +869,14 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   const double nobs = P.nobs[(size_t)chain * P.suf_stride];
   ch.DF = nobs + P.prior_df;
   ch.ss0q = P.prior_ss + yty;
+  ch.mode = P.mode;
+  ch.sv = ch.sa = ch.sx = 1.0;
+  if (P.mode) {
+    // SpikeSlabSampler works given this chain's sigma^2
+    const double inv = 1.0 / P.sigsq[chain];
+    ch.sx = inv;
+    if (P.slab_scales) { ch.sv = inv; ch.sa = inv; }
+  }
   const PhiloxKey key{P.seed_lo, P.seed_hi,
                       (uint32_t)(P.chain_offset + chain), P.stream};
 
@@ -987,7 +1015,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       if (nflips > 0) {
         // remember the sweep's starting point (restored if the chain has to
         // stop inside this sweep for lack of model capacity)
-        for (int j = lane; j < p; j += WAVE) ch.gam0[j] = ch.gam[j];
+        for (int j = lane; j < p; j += WAVE) {
+          ch.gam0[j] = ch.gam[j];
+          // SpikeSlabSampler shuffles a fresh identity permutation every call
+          // (SpikeSlabSampler.cpp:48-57); BregVsSampler's indx persists
+          if (P.mode) ch.perm[j] = (uint16_t)j;
+        }
         pos0 = pos;
         // ---- shuffle(indx): cpputil/shuffle.hpp:36-46, in place on the
         // persistent permutation.  Uniform t (t = 0..p-2) belongs to i = p-1-t.
@@ -1129,7 +1162,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       failures = 0;
       const double z = draw_normals(key, &pos, k, lane);
       // beta = L^{-T}(w + sigma z): chol(V / sigma^2) = L / sigma
-      const double sigma = sqrt(sigsq);
+      // (SpikeSlabSampler: rmvn_ivar_mt with the sigma-scaled precision itself)
+      const double sigma = P.mode ? 1.0 : sqrt(sigsq);
       double y = (lane < k) ? ch.w[lane] + sigma * z : 0.0;
       const double rdm = (lane < k) ? ch.rdv[lane] : 0.0;
       for (int i = k - 1; i >= 0; --i) {
@@ -1244,6 +1278,8 @@ __global__ __launch_bounds__(64) void ssvs_logp_kernel(SsvsParams P,
   ch.xty = P.xty;
   ch.DF = P.nobs[0] + P.prior_df;
   ch.ss0q = P.prior_ss + P.yty[0];
+  ch.mode = 0;
+  ch.sv = ch.sa = ch.sx = 1.0;
   const uint8_t *gg = gammas + (size_t)which * p;
   int k = 0;
   for (int base = 0; base < p; base += WAVE) {

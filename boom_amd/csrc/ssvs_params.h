@@ -41,6 +41,8 @@ struct SsvsParams {
   int64_t chain_offset;
   int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
   int32_t waves; // wavefronts per chain (1, 2 or 4)
+  int32_t mode;  // 0: BregVsSampler (sigma^2 integrated out); 1: SpikeSlabSampler (given sigma^2)
+  int32_t slab_scales;  // mode 1: slab precision is Omega^{-1} / sigma^2 (MvnGivenScalarSigma)
 
   // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
   const double *V;    // XtX + Omega^{-1}, p x p (symmetric, full storage)

@@ -146,6 +146,26 @@ int ba_sync(ba_engine *e);
 int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
                       double *out);
 
+/* ---- SpikeSlabSampler: the sigma^2-conditional sweep ---------------------------- */
+/* Models/Glm/PosteriorSamplers/SpikeSlabSampler.{hpp,cpp}: the helper that the
+ * logit / probit / Poisson / Student / quantile samplers drive with their own
+ * (weighted) sufficient statistics and the current residual variance.
+ *   slab      SpikeSlabSampler(model, slab_prior, spike_prior) (.hpp:47): mean mu
+ *             and precision; precision_scales_with_sigsq = 1 for
+ *             MvnGivenScalarSigma (siginv() = Omega^{-1} / sigma^2,
+ *             MvnGivenScalarSigma.cpp:74-77), 0 for a fixed-precision MvnBase
+ *             (then every chain must hold the same sigma^2);
+ *   max_flips limit_model_selection(max_flips) (.hpp:132): limits only if > 0;
+ *   spike     ba_set_spike; data: ba_upload_regression_suf with the weighted
+ *             X'WX, X'Wy (WeightedRegSuf; yty, n, ybar, xbar are not used);
+ *   sigma^2   per chain, ba_set_sigsq / ba_set_state.
+ * ba_sss_sweep runs nsweeps x { draw_model_indicators(rng, suf, sigsq);
+ * draw_beta(rng, suf, sigsq) } (SpikeSlabSampler.cpp:40-138) on every chain. */
+int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq);
+int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
+                    int32_t precision_scales_with_sigsq, int32_t max_flips);
+int ba_sss_sweep(ba_engine *e, int32_t nsweeps);
+
 /* ---- posterior summaries --------------------------------------------------- */
 /* Running sums over every sweep since the last ba_reset_summaries(), reduced
  * over this engine's chains on the device:
