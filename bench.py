@@ -163,9 +163,17 @@ def main():
     flops_per_sweep = P * (4 * kbar ** 2 + 12 * kbar + 40) + kbar ** 3 / 3 + 4 * kbar ** 2
     launch_bytes = bytes_per_sweep * CHAINS_PER_GPU * SWEEPS_PER_STEP
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed PMC passes of this same command
+    # (profiles/pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["traffic_bytes"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": "ssvs_sweep_kernel", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_sweep": round(bytes_per_sweep, 1),
                 "algorithmic_flops_per_sweep": round(flops_per_sweep, 1),
