@@ -60,6 +60,16 @@ __device__ __forceinline__ double philox_uniform(const PhiloxKey &key,
   return (double)(x >> 11) * 0x1.0p-53;
 }
 
+// both uniforms of one Philox block: numbers 2 * block and 2 * block + 1
+__device__ __forceinline__ void philox_pair(const PhiloxKey &key, uint64_t block,
+                                            double *u0, double *u1) {
+  uint32_t o[4];
+  philox4x32_10((uint32_t)block, (uint32_t)(block >> 32), key.chain,
+                key.stream, key.k0, key.k1, o);
+  *u0 = (double)(((uint64_t)o[0] | ((uint64_t)o[1] << 32)) >> 11) * 0x1.0p-53;
+  *u1 = (double)(((uint64_t)o[2] | ((uint64_t)o[3] << 32)) >> 11) * 0x1.0p-53;
+}
+
 // Sequential view of a stream (the reference's `rng()`).
 struct SeqRng {
   PhiloxKey key;
@@ -69,16 +79,50 @@ struct SeqRng {
   }
 };
 
-__device__ __forceinline__ double d_runif(SeqRng &r, double a, double b) {
+// The same sequential view for code that a whole wavefront executes in
+// lockstep (all 64 lanes active, wave-uniform control flow): the wave
+// generates a window of 128 consecutive uniforms at once -- lane l holds both
+// numbers of block (window base >> 1) + l -- and every rng() is a v_readlane
+// instead of ten Philox rounds.
+struct WinRng {
+  PhiloxKey key;
+  uint64_t pos;
+  int lane;
+  uint64_t wbase;   // even stream position of the window's first number
+  double w0, w1;
+  bool have;
+  __device__ __forceinline__ void reset(uint64_t p) {
+    pos = p;  // the window is kept: positions only move forward inside a sweep
+  }
+  __device__ __forceinline__ double operator()() {
+    if (!have || pos < wbase || pos - wbase >= 128) {
+      wbase = pos & ~1ull;
+      philox_pair(key, (wbase >> 1) + (uint64_t)lane, &w0, &w1);
+      have = true;
+    }
+    const int off = __builtin_amdgcn_readfirstlane((int)(pos - wbase));
+    ++pos;
+    const double w = (off & 1) ? w1 : w0;
+    const int src = off >> 1;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(w), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(w), src);
+    return __hiloint2double(hi, lo);
+  }
+};
+
+template <class R>
+__device__ __forceinline__ double d_runif(R &r, double a, double b) {
   if (a == b) return a;
   return a + (b - a) * r();
 }
 
-__device__ __forceinline__ int d_random_int(SeqRng &r, int lo, int hi) {
+template <class R>
+__device__ __forceinline__ int d_random_int(R &r, int lo, int hi) {
   return (int)floor(d_runif(r, (double)lo, (double)(hi + 1)));
 }
 
-__device__ inline double d_norm_rand(SeqRng &r) {
+template <class R>
+__device__ __forceinline__ double d_norm_rand(R &r) {
   const double A = 2.216035867166471;
   const double C1 = 0.398942280401433, C2 = 0.180025191068563;
 #define BA_KR_G(x) (C1 * exp(-(x) * (x) / 2.0) - C2 * (A - (x)))
@@ -129,12 +173,14 @@ __device__ inline double d_norm_rand(SeqRng &r) {
 }
 
 // rnorm_mt, Bmath/rnorm.cpp:55-67: no draw when sigma == 0
-__device__ __forceinline__ double d_rnorm(SeqRng &r, double mu, double sigma) {
+template <class R>
+__device__ __forceinline__ double d_rnorm(R &r, double mu, double sigma) {
   if (sigma == 0.) return mu;
   return mu + sigma * d_norm_rand(r);
 }
 
-__device__ inline double d_exp_rand(SeqRng &r) {
+template <class R>
+__device__ __forceinline__ double d_exp_rand(R &r) {
   // q[k-1] = sum_{i=1..k} log(2)^i / i!
   const double q[16] = {
       0.6931471805599453, 0.9333736875190459, 0.9888777961838675,
@@ -164,7 +210,8 @@ __device__ inline double d_exp_rand(SeqRng &r) {
 
 // Rmath::rgamma_mt(rng, a, scale).  *bad is set for a < 0.3 (the reference's
 // rloggamma_small_alpha branch, unreachable when shape = DF/2 with n >= 1).
-__device__ inline double d_rgamma_scale(SeqRng &rng, double a, double scale,
+template <class R>
+__device__ __forceinline__ double d_rgamma_scale(R &rng, double a, double scale,
                                         int *bad) {
   const double sqrt32 = 5.656854, exp_m1 = 0.36787944117144232159;
   const double q1 = 0.04166669, q2 = 0.02083148, q3 = 0.00801191,
@@ -255,7 +302,8 @@ __device__ inline double d_rgamma_scale(SeqRng &rng, double a, double scale,
 // sigma <= sigma_max when that is finite.  *bad: 1 = shape < .3, 2 = the
 // truncation point is at or above the mode (adaptive-rejection / slice
 // branches of rtrun_gamma_mt, not implemented on the device).
-__device__ inline double d_draw_variance(SeqRng &rng, double DF, double SS,
+template <class R>
+__device__ __forceinline__ double d_draw_variance(R &rng, double DF, double SS,
                                          double sigma_max, int *bad) {
   if (sigma_max == 0.0) return 0.0;
   const double a = DF / 2, b = SS / 2;

@@ -150,6 +150,10 @@ struct ba_engine {
   DevBuf<double> dbsum, dbsumsq, dacc, dsummary;
   DevBuf<double> dtr_sig, dtr_logp, dtr_k;
   DevBuf<double> dmodel;  // per-chain model scratch (scalar-cache reads)
+  DevBuf<double> dtab_lp;   // per-chain proposal table
+  DevBuf<uint8_t> dtab_kind;
+  DevBuf<int32_t> dtab_tag;
+  bool table_ok = false;  // nothing but ba_sweep launches since the tables were built
   int trace_stride = 0;
   // scratch for suf build
   DevBuf<double> dX, dy, dxtx, dxsum, dsufscal;
@@ -306,6 +310,7 @@ int upload_shared(ba_engine *e) {
   e->kcap = choose_kcap(*e);
   e->waves = choose_waves(*e, e->kcap);
   e->device_dirty = false;
+  e->table_ok = false;
   return BA_OK;
 }
 
@@ -321,6 +326,10 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(e->dstatus.resize(C));
   HIP_TRY(e->dfail.resize(C));
   HIP_TRY(e->dtodo.resize(C));
+  HIP_TRY(e->dtab_lp.resize(C * p));
+  HIP_TRY(e->dtab_kind.resize(C * p));
+  HIP_TRY(e->dtab_tag.resize(C));
+  e->table_ok = false;
   HIP_TRY(e->dmaxk.resize(1));
   HIP_TRY(e->dtrace_idx.resize(C));
   HIP_TRY(e->dinc.resize(C * p));
@@ -400,11 +409,17 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.maxk = e->dmaxk.ptr;
   P.trace_idx = e->dtrace_idx.ptr;
   P.model_scratch = e->dmodel.ptr;
+  P.table_lp = e->dtab_lp.ptr;
+  P.table_kind = e->dtab_kind.ptr;
+  P.table_tag = e->dtab_tag.ptr;
+  P.table_keep = e->table_ok ? 1 : 0;
   P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
   P.seed_lo = (uint32_t)e->seed;
   P.seed_hi = (uint32_t)(e->seed >> 32);
   P.stream = 0;
   P.mode = e->cur_mode;
+  P.scan_policy = 1;
+  if (const char *sp = std::getenv("BOOM_AMD_SCAN")) P.scan_policy = std::atoi(sp);
   if (e->cur_mode == 1) {
     // SpikeSlabSampler: given sigma^2, no sigma draw, no swap move, own stream
     P.slab_scales = e->sss_slab_scales;
@@ -561,6 +576,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
                              const double *xty, double yty, double n,
                              double ybar, const double *xbar) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (!xtx || !xty || !xbar) return fail(BA_E_INVALID, "null argument");
   int rc = set_dimension(e, p);
   if (rc) return rc;
@@ -579,6 +595,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
 int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
                                 const void *X_device, const void *y_device) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (!X_device || !y_device) return fail(BA_E_INVALID, "null argument");
   if (n <= 0) return fail(BA_E_INVALID, "n must be positive");
   int rc = set_dimension(e, p);
@@ -611,6 +628,7 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
 int ba_build_suf_from_xy(ba_engine *e, int64_t n, int32_t p, const double *X,
                          const double *y) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (!X || !y) return fail(BA_E_INVALID, "null argument");
   if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
   HIP_TRY(e->dX.resize((size_t)n * p));
@@ -642,6 +660,7 @@ int ba_get_regression_suf(ba_engine *e, double *xtx, double *xty, double *yty,
 int ba_set_slab(ba_engine *e, const double *prior_mean,
                 const double *unscaled_prior_precision) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   if (!prior_mean || !unscaled_prior_precision) return fail(BA_E_INVALID, "null argument");
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
   const int p = e->p;
@@ -654,6 +673,7 @@ int ba_set_slab(ba_engine *e, const double *prior_mean,
 
 int ba_set_spike(ba_engine *e, const double *pi, int64_t max_model_size) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   if (!pi) return fail(BA_E_INVALID, "null argument");
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
   for (int j = 0; j < e->p; ++j)
@@ -669,6 +689,7 @@ int ba_set_spike(ba_engine *e, const double *pi, int64_t max_model_size) {
 int ba_set_sigma_prior(ba_engine *e, double prior_df, double sigma_guess,
                        double sigma_upper_limit) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   if (sigma_upper_limit < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
   // ChisqModel(df, sigma): alpha = df/2, beta = df sigma^2/2 (ChisqModel.cpp:56-57)
   const double alpha = prior_df / 2.0;
@@ -685,6 +706,7 @@ int ba_set_priors_ctor1(ba_engine *e, double prior_nobs, double expected_rsq,
                         double expected_model_size,
                         int32_t first_term_is_intercept) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
   if (!(expected_rsq > 0 && expected_rsq < 1)) return fail(BA_E_INVALID, "expected_rsq must be in (0, 1)");
   // BregVsSampler.cpp:37-44, 48-85
@@ -711,6 +733,7 @@ int ba_set_priors_ctor2(ba_engine *e, double prior_sigma_nobs,
                         double prior_inclusion_probability,
                         int32_t force_intercept) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
   // BregVsSampler.cpp:87-142
   if (prior_sigma_guess <= 0)
@@ -758,6 +781,7 @@ int ba_get_priors(ba_engine *e, double *prior_mean, double *ominv, double *pi,
 int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
                    int32_t draw_beta, int32_t draw_sigma) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   e->max_flips = max_flips;
   if (swap_threshold != e->swap_threshold) e->device_dirty = true;
   e->swap_threshold = swap_threshold;
@@ -770,6 +794,7 @@ int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
 int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
                  const double *beta, double sigsq) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data first");
   if (!gamma) return fail(BA_E_INVALID, "null argument");
   const int64_t C = e->cfg.chains;
@@ -831,6 +856,7 @@ int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
 
 int ba_seed(ba_engine *e, uint64_t seed) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   e->seed = seed;
   if (e->state_ready) {
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -848,6 +874,7 @@ static int switch_mode(ba_engine *e, int mode, double v_scale) {
     if (rc) return rc;
   }
   e->cur_mode = mode;
+  e->table_ok = false;
   if (e->v_scale_want != v_scale) {
     e->v_scale_want = v_scale;
     e->device_dirty = true;
@@ -877,6 +904,7 @@ int ba_sweep(ba_engine *e, int32_t nsweeps) {
   if (e->trace_stride > 0)  // traces are those of the last ba_sweep call
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
   HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
+  e->table_ok = true;  // until anything but another ba_sweep touches the engine
   return BA_OK;
 }
 
@@ -995,6 +1023,7 @@ int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
 // ------------------------------------------- SpikeSlabSampler (sigma^2 given)
 int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (!(sigsq > 0)) return fail(BA_E_INVALID, "sigsq must be positive");
   int rc = alloc_chain_state(e);
   if (rc) return rc;
@@ -1013,6 +1042,7 @@ int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq) {
 int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
                     int32_t precision_scales_with_sigsq, int32_t max_flips) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   int rc = ba_set_slab(e, mu, precision);
   if (rc) return rc;
   e->sss_slab_scales = precision_scales_with_sigsq ? 1 : 0;
@@ -1027,6 +1057,7 @@ int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
 
 int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
   if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
@@ -1133,6 +1164,7 @@ static int ss_prepare(ba_engine *e) {
 int ba_ss_set_data(ba_engine *e, int32_t T, int32_t p, const double *y,
                    const double *X, const uint8_t *observed) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (!y || !X) return fail(BA_E_INVALID, "null argument");
   if (T <= 0 || p <= 0) return fail(BA_E_INVALID, "T and p must be positive");
   // The regression model's fixed XtX (and the initial Xty, ...) are over the
@@ -1172,6 +1204,7 @@ int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_gues
                           double initial_state_variance,
                           double initial_level_sigma) {
   if (!e) return fail(BA_E_INVALID, "null engine");
+  e->table_ok = false;
   if (level_sigma_upper_limit < 0 || initial_state_variance < 0)
     return fail(BA_E_INVALID, "sigma_max must be non-negative.");
   // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
@@ -1188,6 +1221,7 @@ int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_gues
 
 int ba_ss_impute_state(ba_engine *e) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   int rc = ss_prepare(e);
   if (rc) return rc;
   SsParams S;
@@ -1199,6 +1233,7 @@ int ba_ss_impute_state(ba_engine *e) {
 
 int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   int rc = ss_prepare(e);
   if (rc) return rc;
@@ -1237,6 +1272,7 @@ int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
 
 int ba_ss_set_level_sigsq(ba_engine *e, int64_t chain, double sigsq) {
   ENGINE_PROLOGUE(e);
+  e->table_ok = false;
   int rc = ss_prepare(e);
   if (rc) return rc;
   const int64_t C = e->cfg.chains;

@@ -69,6 +69,15 @@ struct StampCtx { long long last; double ph[8]; };
 #else
 #define SUBSTAMP(c, i) do { } while (0)
 #endif
+// -DBA_STAMPS -DBA_STAMPS3: the 8 slots time the serial parts of a sweep
+// (0 shuffle: previous-step rounds, 1 shuffle: links, 2 shuffle: walks,
+// 3 normals, 4 back substitution, 5 summaries, 6 sweep start + shuffle
+// uniforms, 7 everything else)
+#if defined(BA_STAMPS) && defined(BA_STAMPS3)
+#define TSTAMP(c, i) do { const long long t_ = (long long)__builtin_readcyclecounter(); (c).ph[i] += (double)(t_ - (c).last); (c).last = t_; } while (0)
+#else
+#define TSTAMP(c, i) do { } while (0)
+#endif
 
 // ---- address spaces ---------------------------------------------------------
 // LDS pointers are typed as such so that every access is a ds_* instruction no
@@ -167,6 +176,8 @@ struct Chain {
   lds_u16 *g, *perm, *perm_alt, *oth, *last, *pred;
   lds_u8 *gam, *gam0;
   // HBM copy of the model read through the scalar cache (see publish_model)
+  double *tab_lp;     // table of log_model_prob(gamma ^ {j}), j = 0..p-1 (HBM)
+  uint8_t *tab_kind;  // 0 / STOP_SLOW / STOP_BAD per j
   double *sc_store;   // global pointer used for the stores
   c_f64 *sc;          // the same memory, constant address space
   // this chain's sufficient statistics
@@ -517,7 +528,10 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
         for (int r = 0; r < 8; ++r) {
           const int m = I * 8 + r;
           const int gm = gsc[m];
-          const double v = Mat[(size_t)gm * p + j] * msc;
+          // column j of the symmetric matrix read as ROW j: a lane's k elements
+          // share a few cache lines of its own row, and different lanes touch
+          // different rows (no hot rows shared by every chain on the device)
+          const double v = Mat[(size_t)j * p + gm] * msc;
           const double e = (gm == j) ? 1.0 : 0.0;
           x[m] = (fast && m < k) ? (add ? v : e) : 0.0;
         }
@@ -601,7 +615,8 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 // in turn was deposited by the smallest t'' > t' with oth[t''] == t' (nxt),
 // and so on until a slot nobody wrote, which still holds its original value.
 // oth[] must be filled for i = 1..p-1.  Result goes to ch.perm (buffers swap).
-__device__ __forceinline__ void parallel_shuffle(Chain &ch) {
+__device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
+  TSTAMP(sx, 6);
   const int p = ch.p, lane = ch.lane;
   constexpr int NONE = 0xFFFF;
   for (int j = lane; j < p; j += WAVE) ch.last[j] = (uint16_t)NONE;
@@ -630,6 +645,7 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch) {
     if (valid && (lane == 63 || (mask >> (lane + 1)) == 0)) ch.last[key] = (uint16_t)t;
     wave_sync();
   }
+  TSTAMP(sx, 0);
   // last[x] = smallest t >= 1 with oth[t] == x.  nxt(t) = smallest t' > t with
   // oth[t'] == t: last[t] unless that is the self swap t, then pred[t].
   const int pred0 = ch.last[0];
@@ -641,53 +657,52 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch) {
     }
   }
   wave_sync();
+  TSTAMP(sx, 1);
   const lds_u16 *src_perm = ch.perm;
   lds_u16 *dst = ch.perm_alt;
-  for (int i = lane; i < p; i += WAVE) {
-    int c = (i == 0) ? pred0 : (int)ch.pred[i];
-    int src;
-    if (c == NONE) {
-      src = (i == 0) ? 0 : (int)ch.oth[i];
-    } else {
-      int n = ch.last[c];
-      while (n != NONE) {
-        c = n;
-        n = ch.last[c];
+  // eight independent walks per lane, advanced together, so that the dependent
+  // LDS reads of one walk hide behind the other seven
+  constexpr int U = 8;
+  for (int ib = 0; ib < p; ib += U * WAVE) {
+    int c[U], n[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = ib + u * WAVE + lane;
+      const bool valid = i < p;
+      const int c0 = !valid ? NONE : ((i == 0) ? pred0 : (int)ch.pred[i]);
+      if (c0 == NONE) {
+        c[u] = (!valid || i == 0) ? 0 : (int)ch.oth[i];
+        n[u] = NONE;
+      } else {
+        c[u] = c0;
+        n[u] = ch.last[c0];
       }
-      src = c;
     }
-    dst[i] = src_perm[src];
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) more |= (n[u] != NONE);
+    while (__any(more)) {
+      more = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool act = n[u] != NONE;
+        const int nn = ch.last[act ? n[u] : 0];
+        c[u] = act ? n[u] : c[u];
+        n[u] = act ? nn : NONE;
+        more |= (n[u] != NONE);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = ib + u * WAVE + lane;
+      if (i < p) dst[i] = src_perm[c[u]];
+    }
   }
   wave_sync();
   lds_u16 *tmp = ch.perm;
   ch.perm = ch.perm_alt;
   ch.perm_alt = tmp;
-}
-
-// k standard normals in stream order (distributions/mvn.cpp:114-122), lane m
-// receives z_m.  Every lane evaluates the Kinderman-Ramage transform starting
-// at its own stream offset; a scalar walk then picks the draws that a
-// sequential reader of the stream would have produced.
-__device__ __forceinline__ double draw_normals(const PhiloxKey &key, uint64_t *pos,
-                                               int k, int lane) {
-  double z = 0.0;
-  int m = 0;
-  uint64_t base = *pos;
-  while (m < k) {
-    SeqRng r{key, base + (uint64_t)lane};
-    const double v = d_norm_rand(r);
-    const int used = (int)(r.pos - (base + (uint64_t)lane));
-    int cur = 0;
-    while (m < k && cur < WAVE) {
-      const double zm = bcast_u(v, cur);
-      if (lane == m) z = zm;
-      cur += bcast_u(used, cur);
-      ++m;
-    }
-    base += (uint64_t)cur;
-  }
-  *pos = base;
-  return z;
+  TSTAMP(sx, 2);
 }
 
 // A request to (re)build the model after changing gamma, served at the single
@@ -711,8 +726,9 @@ struct Pending {
 // CorrelationMap::propose_swap / proposal_weight (CorrelationMap.cpp:61-115).
 // Wave-uniform control flow; every lane walks the same CSR lists.  Fills `pe`
 // when a swap is proposed; the evaluation happens at the refactor site.
+template <class R>
 __device__ __forceinline__ void propose_swap(const SsvsParams &P, Chain &ch,
-                                             SeqRng &rng, Pending &pe,
+                                             R &rng, Pending &pe,
                                              int *status) {
   if (P.cm_start == nullptr) return;
   const int k = ch.k, p = ch.p;
@@ -784,26 +800,96 @@ __device__ __forceinline__ void propose_swap(const SsvsParams &P, Chain &ch,
 // two workgroup barriers per command; the current model reaches the helpers
 // through the LDS control block (scalars) and the chain's HBM model block
 // (factors, read through the scalar cache).
+//
+// Two equivalent ways of walking a sweep's proposals (same decisions, same
+// chain):
+//   batch mode  evaluate the next 64 W positions of the permutation; what was
+//               evaluated behind the first stop is thrown away.  Best while
+//               flips are accepted often (burn-in, ridge-like posteriors).
+//   cache mode  log_model_prob(gamma ^ {j}) depends on the current model only,
+//               and the model changes only when a flip is accepted.  So it is
+//               evaluated ONCE for every j after each change (p / (64 W) fill
+//               rounds, natural variable order) into a per-chain table, and a
+//               sweep's decisions are table look-ups against fresh uniforms:
+//               log u_i <= table[perm[i]] - logp.  At stationarity (well under
+//               one accepted flip per sweep) most sweeps need no evaluation
+//               at all.
+// The master picks the mode per sweep from the previous sweep's stop count.
 
-enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2 };
+enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2, CMD_DECIDE = 3 };
 // control block (doubles): 0 cmd, 1 k, 2 i0, 3..8 model scalars, 9 nflips;
 // u64 view at 10: flip_pos / uniform base position; wave slots from 16
 enum : int { CT_CMD = 0, CT_K = 1, CT_I0 = 2, CT_LOGP = 3, CT_LP = 4, CT_LDV = 5,
              CT_LDA = 6, CT_Q = 7, CT_C = 8, CT_NFLIPS = 9, CT_POS = 10, CT_PERMSEL = 12,
+             CT_EVMODE = 13,
              CT_SLOT0 = 16, CT_SLOT_STRIDE = 6 };
+// slot: SL_F = permutation position of the wave's earliest stop (-1: none)
 enum : int { SL_F = 0, SL_J = 1, SL_KIND = 2, SL_LOGU = 3, SL_MARGIN = 4, SL_DELTA = 5 };
 enum : int { STOP_ACCEPT = 1, STOP_SLOW = 2, STOP_BAD = 3 };
 
-// One wave's share of a proposal batch: evaluates, decides, and leaves its
-// first "stop" (accepted / needs the exact path / negative SS) in its slot.
+// minimum over the wave of a non-negative int (DPP), result in every lane
+__device__ __forceinline__ int wave_min_int(int x) {
+#define BA_DPP_MIN(ctrl, mask)                                                  \
+  x = min(x, __builtin_amdgcn_update_dpp(x, x, ctrl, mask, 0xf, false))
+  BA_DPP_MIN(0x118, 0xf);
+  BA_DPP_MIN(0x114, 0xf);
+  BA_DPP_MIN(0x112, 0xf);
+  BA_DPP_MIN(0x111, 0xf);
+  BA_DPP_MIN(0x142, 0xa);
+  BA_DPP_MIN(0x143, 0xc);
+#undef BA_DPP_MIN
+  return __builtin_amdgcn_readlane(x, 63);
+}
+
+__device__ __forceinline__ void shuffle_targets(const PhiloxKey &key, uint64_t pos,
+                                                int p, int tid, int nthreads,
+                                                lds_u16 *oth) {
+  // uniform number pos + t (t = 0..p-2) picks the partner of i = p-1-t:
+  // random_int_mt(rng, 0, i) (cpputil/shuffle.hpp:36-46); one Philox block
+  // serves two consecutive steps
+  const uint64_t b0 = pos >> 1, b1 = (pos + (uint64_t)(p - 2)) >> 1;
+  for (uint64_t b = b0 + (uint64_t)tid; b <= b1; b += (uint64_t)nthreads) {
+    double u[2];
+    philox_pair(key, b, &u[0], &u[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long t = (long long)(2 * b + h) - (long long)pos;
+      if (t >= 0 && t < p - 1) {
+        const int i = p - 1 - (int)t;
+        oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u[h]);
+      }
+    }
+  }
+}
+
+enum : int { EVM_BATCH = 0, EVM_FILL = 1 };
+
+// One wave's share of a round.
+//   EVM_BATCH   lane = position i0 + 64 wave + lane: evaluate perm[position],
+//               decide, leave the wave's earliest stop (accepted / needs the
+//               exact path / negative SS) in its slot;
+//   EVM_FILL    lane = variable i0 + 64 wave + lane: evaluate it against the
+//               current model and store the result in the chain's table;
+// (Decisions by table look-up are the master's own loop, see the kernel.)
 template <int NB>
 __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
                                            const Model &M, const PhiloxKey &key,
                                            uint64_t flip_pos, int nflips, int i0,
-                                           int wave, lds_f64 *ctl, StampCtx &sx) {
+                                           int evmode, int wave, lds_f64 *ctl,
+                                           StampCtx &sx) {
   const int lane = ch.lane;
   SUBSTAMP(sx, 7);
   const int idx = i0 + WAVE * wave + lane;
+  if (evmode == EVM_FILL) {
+    const bool valid = idx < ch.p;
+    const Proposal pr = eval_proposal<NB>(P, ch, M, valid ? idx : 0, valid, sx);
+    if (valid) {
+      ch.tab_lp[idx] = pr.logp;
+      ch.tab_kind[idx] = (uint8_t)(pr.bad_ss ? STOP_BAD : (pr.slow ? STOP_SLOW : 0));
+    }
+    SUBSTAMP(sx, 6);
+    return;
+  }
   const bool valid = idx < nflips;
   const int j = valid ? (int)ch.perm[idx] : 0;
   const double u = philox_uniform(key, flip_pos + (uint64_t)idx);
@@ -813,22 +899,25 @@ __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
 #endif
   SUBSTAMP(sx, 0);
   const Proposal pr = eval_proposal<NB>(P, ch, M, j, valid, sx);
-  const double delta = pr.logp - M.logp;
-  const bool accept = valid && !pr.slow && !pr.bad_ss && !(logu > delta);
+  const double lpj = pr.logp;
+  const bool slow = valid && pr.slow;
+  const bool bad = valid && pr.bad_ss;
+  const double delta = lpj - M.logp;
+  const bool accept = valid && !slow && !bad && !(logu > delta);
   const unsigned long long m_acc = __ballot(accept);
-  const unsigned long long m_slow = __ballot(valid && pr.slow);
-  const unsigned long long m_bad = __ballot(valid && pr.bad_ss);
+  const unsigned long long m_slow = __ballot(slow);
+  const unsigned long long m_bad = __ballot(bad);
   const unsigned long long m_stop = m_acc | m_slow | m_bad;
   const int f = m_stop ? (__ffsll((long long)m_stop) - 1) : WAVE;
   // lanes before f are settled rejections; f itself counts if accepted
   const bool counted = valid && (lane < f || (lane == f && ((m_acc >> f) & 1ull)));
-  const double mg = counted && (pr.logp > -BA_INF) ? fabs(logu - delta) : BA_INF;
+  const double mg = counted && (lpj > -BA_INF) ? fabs(logu - delta) : BA_INF;
   const double mmin = wave_min(mg);
   if (lane == (f < WAVE ? f : 0)) {
     lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * wave;
     int kind = 0;
     if (f < WAVE) kind = ((m_bad >> f) & 1ull) ? STOP_BAD : (((m_acc >> f) & 1ull) ? STOP_ACCEPT : STOP_SLOW);
-    sl[SL_F] = (double)f;
+    sl[SL_F] = (f < WAVE) ? (double)(idx) : -1.0;
     sl[SL_J] = (double)j;
     sl[SL_KIND] = (double)kind;
     sl[SL_LOGU] = logu;
@@ -836,6 +925,68 @@ __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
     sl[SL_DELTA] = delta;
   }
   SUBSTAMP(sx, 6);
+}
+
+// A sweep's decisions by table look-up, from position i0 to the first stop:
+// one wavefront, two positions per lane and round (both uniforms of the lane's
+// Philox block).  spos = -1: reached nflips without a stop.
+struct DecideResult {
+  int spos, j, kind;
+  double logu, margin;
+};
+__device__ __forceinline__ void decide_walk(const Chain &ch, const PhiloxKey &key,
+                                            uint64_t flip_pos, int i0, int nflips,
+                                            double logp, DecideResult &out) {
+  const int lane = ch.lane;
+  double lane_margin = BA_INF;
+  out.spos = -1; out.j = 0; out.kind = 0; out.logu = 0.0;
+  while (i0 < nflips) {
+    const uint64_t blk = ((flip_pos + (uint64_t)i0) >> 1) + (uint64_t)lane;
+    double u[2];
+    philox_pair(key, blk, &u[0], &u[1]);
+    const int q0 = (int)((long long)(2 * blk) - (long long)flip_pos);
+    bool acc[2], val[2];
+    double lu[2], dl[2];
+    int jj[2], kd[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = q0 + h;
+      val[h] = q >= i0 && q < nflips;
+      jj[h] = val[h] ? (int)ch.perm[q] : 0;
+    }
+    unsigned long long mstop[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double lpj = ch.tab_lp[jj[h]];
+      kd[h] = ch.tab_kind[jj[h]];
+      lu[h] = log(u[h]);
+      dl[h] = lpj - logp;
+      const bool special = kd[h] != 0;
+      acc[h] = val[h] && !special && !(lu[h] > dl[h]);
+      mstop[h] = __ballot(val[h] && (special || acc[h]));
+      if (!(lpj > -BA_INF)) dl[h] = BA_INF;  // no margin against -inf
+    }
+    const int f0 = mstop[0] ? 2 * (__ffsll((long long)mstop[0]) - 1) : 1 << 20;
+    const int f1 = mstop[1] ? 2 * (__ffsll((long long)mstop[1]) - 1) + 1 : 1 << 20;
+    const int f = f0 < f1 ? f0 : f1;  // first stop, as 2 lane + half
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int me = 2 * lane + h;
+      const bool counted = val[h] && (me < f || (me == f && acc[h])) && dl[h] < BA_INF;
+      if (counted) lane_margin = fmin(lane_margin, fabs(lu[h] - dl[h]));
+    }
+    if (f >= (1 << 20)) {
+      i0 = q0 - 2 * lane + 2 * WAVE;  // first position of the next round
+      continue;
+    }
+    const int fl = f >> 1, fh = f & 1;
+    out.spos = __builtin_amdgcn_readlane(q0 + fh, fl);
+    out.j = __builtin_amdgcn_readlane(fh ? jj[1] : jj[0], fl);
+    out.kind = __builtin_amdgcn_readlane(fh ? kd[1] : kd[0], fl);
+    out.logu = bcast_u(fh ? lu[1] : lu[0], fl);
+    break;
+  }
+  out.margin = wave_min(lane_margin);
 }
 
 template <int NB, int W, int WPE>
@@ -863,6 +1014,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   bind_lds(ch, smem, lay);
   lds_f64 *ctl = to_lds<double>(smem + lay.ctrl);
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
+  ch.tab_lp = P.table_lp + (size_t)chain * p;
+  ch.tab_kind = P.table_kind + (size_t)chain * p;
   ch.sc_store = P.model_scratch + (size_t)chain * P.model_scratch_stride;
   ch.sc = (c_f64 *)(unsigned long long)ch.sc_store;
   const double yty = P.yty[(size_t)chain * P.suf_stride];
@@ -899,13 +1052,24 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         unsigned long long a = (unsigned long long)ch.sc_store;
         asm volatile("" : "+s"(a) : : "memory");
         ch.sc = (c_f64 *)a;
-        eval_share<NB>(P, ch, M, key, upos, (int)ctl[CT_NFLIPS], (int)ctl[CT_I0], wave, ctl, sx_unused);
-      } else {  // CMD_UNIF: this wave's share of the shuffle uniforms
-        for (int t = threadIdx.x; t < p - 1; t += WAVE * W) {
-          const int i = p - 1 - t;
-          const double u = philox_uniform(key, upos + (uint64_t)t);
-          ch.oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u);
+        eval_share<NB>(P, ch, M, key, upos, (int)ctl[CT_NFLIPS], (int)ctl[CT_I0],
+                       (int)ctl[CT_EVMODE], wave, ctl, sx_unused);
+      } else if (cmd == CMD_DECIDE) {
+        if (wave == 1) {
+          ch.perm = to_lds<uint16_t>(smem + (((int)ctl[CT_PERMSEL]) ? lay.perm1 : lay.perm0));
+          DecideResult dr;
+          decide_walk(ch, key, upos, (int)ctl[CT_I0], (int)ctl[CT_NFLIPS], ctl[CT_LOGP], dr);
+          if (lane == 0) {
+            lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * 1;
+            sl[SL_F] = (double)dr.spos;
+            sl[SL_J] = (double)dr.j;
+            sl[SL_KIND] = (double)dr.kind;
+            sl[SL_LOGU] = dr.logu;
+            sl[SL_MARGIN] = dr.margin;
+          }
         }
+      } else {  // CMD_UNIF: this wave's share of the shuffle uniforms
+        if (p > 1) shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth);
       }
       __syncthreads();
     }
@@ -965,8 +1129,18 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   int phase = PH_BEGIN, sweep = 0, i0 = 0;
   bool model_checked = false;  // legality of the start is checked in sweep 0
   int perm_sel = 0;            // which LDS buffer holds the current permutation
+  // walking mode of the current sweep and its bookkeeping (see the kernel's
+  // header comment): scan mode decides positions [0, pos_done) so far
+  bool use_table = false;     // this sweep decides by table look-up
+  // the table of the chain's last launch is still good when nothing but
+  // sweeps happened since (the host clears table_keep otherwise)
+  bool table_valid = P.table_keep && P.table_tag[chain] == KCAP && status == CHAIN_OK;
+  int fill_j = 0;             // next variable of a fill in progress
+  int stops_prev = table_valid ? 0 : (1 << 20), stops_now = 0;
   uint64_t flip_pos = 0, pos0 = pos;
-  SeqRng rng{key, pos};
+  WinRng rng;
+  rng.key = key; rng.pos = pos;
+  rng.lane = lane; rng.have = false; rng.wbase = 0; rng.w0 = rng.w1 = 0.0;
 
   while (status == CHAIN_OK) {
     if (pe.kind != EV_NONE) {
@@ -987,6 +1161,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         }
         if (acc) {
           M = Mn;
+          // (a rebuilt-after-reject model is the old one; so is the launch's
+          // first build unless make_valid changed gamma)
+          if (pass == 0 && (pe.kind != EV_INIT || pe.check_legal)) table_valid = false;
           if (pass == 0 && pe.kind != EV_INIT) acc_acc += 1;
           break;
         }
@@ -1012,6 +1189,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     if (phase == PH_BEGIN) {
       if (sweep >= nsweeps) break;
       STAMP(7);
+      TSTAMP(sx, 5);
       if (nflips > 0) {
         // remember the sweep's starting point (restored if the chain has to
         // stop inside this sweep for lack of model capacity)
@@ -1031,14 +1209,13 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
           __syncthreads();
         }
-        for (int t = threadIdx.x; t < p - 1; t += WAVE * W) {
-          const int i = p - 1 - t;
-          const double u = philox_uniform(key, pos + (uint64_t)t);
-          ch.oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u);
-        }
+        if (p > 1) shuffle_targets(key, pos, p, threadIdx.x, WAVE * W, ch.oth);
         if (W > 1) __syncthreads(); else wave_sync();
         STAMP(0);
-        if (p > 1) { parallel_shuffle(ch); perm_sel ^= 1; }
+        if (p > 1) { parallel_shuffle(ch, sx); perm_sel ^= 1; }
+        use_table = (P.scan_policy != 0) && (stops_prev <= 1 || P.scan_policy == 2);
+        stops_prev = stops_now;
+        stops_now = 0;
         flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
         pos = flip_pos + (uint64_t)nflips;
         STAMP(1);
@@ -1069,31 +1246,99 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         phase = PH_SWAP;
         continue;
       }
-      // ---- Metropolised flips, 64 * W proposals at a time
+      // ---- Metropolised flips, 64 * W proposals per round
+      if (use_table && table_valid) {
+        // ---- decisions by table look-up, up to the first stop.  With helper
+        // waves the walk is wave 1's job (the master's registers are full of
+        // chain state; wave 1 has none), otherwise the master's own.
+        DecideResult dr;
+        if (W > 1) {
+          if (lane == 0) {
+            ctl[CT_CMD] = (double)CMD_DECIDE;
+            ctl[CT_I0] = (double)i0;
+            ctl[CT_LOGP] = M.logp;
+            ctl[CT_NFLIPS] = (double)nflips;
+            ctl[CT_PERMSEL] = (double)perm_sel;
+            ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = flip_pos;
+          }
+          __syncthreads();
+          __syncthreads();
+          const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * 1;
+          dr.spos = (int)sl[SL_F];
+          dr.j = (int)sl[SL_J];
+          dr.kind = (int)sl[SL_KIND];
+          dr.logu = sl[SL_LOGU];
+          dr.margin = sl[SL_MARGIN];
+        } else {
+          decide_walk(ch, key, flip_pos, i0, nflips, M.logp, dr);
+        }
+        min_margin = fmin(min_margin, dr.margin);
+        STAMP(3);
+        if (dr.spos < 0) {  // walked to the end without a stop
+          acc_prop += nflips - i0;
+          i0 = nflips;
+          continue;
+        }
+        acc_prop += dr.spos + 1 - i0;
+        ++stops_now;
+        i0 = dr.spos + 1;
+        if (dr.kind == STOP_BAD) {
+          status = CHAIN_NEGATIVE_SS;
+          break;
+        }
+        if (!ch.gam[dr.j] && ch.k >= KCAP) {
+          status = CHAIN_MODEL_TOO_LARGE;
+          aborted = true;
+          break;
+        }
+        pe.f1 = dr.j;
+        if (dr.kind == 0) {
+          pe.kind = EV_FORCE;
+        } else {
+          pe.kind = EV_TRY_GE;
+          pe.lu = dr.logu;
+        }
+        continue;
+      }
+      int evmode = EVM_BATCH, base = i0;
+      if (use_table) {
+        evmode = EVM_FILL;   // (re)build the table for the current model
+        base = fill_j;
+      }
       if (W > 1) {
         if (lane == 0) {
           ctl[CT_CMD] = (double)CMD_EVAL;
           ctl[CT_K] = (double)ch.k;
-          ctl[CT_I0] = (double)i0;
+          ctl[CT_I0] = (double)base;
           ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
           ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
           ctl[CT_NFLIPS] = (double)nflips;
           ctl[CT_PERMSEL] = (double)perm_sel;
+          ctl[CT_EVMODE] = (double)evmode;
           ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = flip_pos;
         }
         __syncthreads();
       }
-      eval_share<NB>(P, ch, M, key, flip_pos, nflips, i0, 0, ctl, sx);
+      eval_share<NB>(P, ch, M, key, flip_pos, nflips, base, evmode, 0, ctl, sx);
       if (W > 1) __syncthreads(); else wave_sync();
-      // first stop over the whole batch, in sweep order
-      int wstop = -1, f = WAVE;
+      if (evmode == EVM_FILL) {
+        fill_j += WAVE * W;
+        if (fill_j >= p) {
+          fill_j = 0;
+          table_valid = true;
+        }
+        STAMP(3);
+        continue;
+      }
+      // first stop over the whole round, in sweep order
+      int wstop = -1, spos = 0;
 #pragma unroll
       for (int w = 0; w < W; ++w) {
         const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * w;
         if (wstop < 0) {
           min_margin = fmin(min_margin, sl[SL_MARGIN]);
           const int fw = (int)sl[SL_F];
-          if (fw < WAVE) { wstop = w; f = fw; }
+          if (fw >= 0) { wstop = w; spos = fw; }
         }
       }
       STAMP(3);
@@ -1106,8 +1351,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * wstop;
       const int jf = (int)sl[SL_J];
       const int kind = (int)sl[SL_KIND];
-      const int nprop = WAVE * wstop + f + 1;
+      const int nprop = spos + 1 - i0;
       acc_prop += nprop;
+      ++stops_now;
       if (kind == STOP_BAD) {
         status = CHAIN_NEGATIVE_SS;
         break;
@@ -1160,7 +1406,16 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         break;
       }
       failures = 0;
-      const double z = draw_normals(key, &pos, k, lane);
+      TSTAMP(sx, 7);
+      // k standard normals in stream order (distributions/mvn.cpp:114-122),
+      // lane m keeps z_m
+      double z = 0.0;
+      for (int m = 0; m < k; ++m) {
+        const double zm = d_norm_rand(rng);
+        if (lane == m) z = zm;
+      }
+      pos = rng.pos;
+      TSTAMP(sx, 3);
       // beta = L^{-T}(w + sigma z): chol(V / sigma^2) = L / sigma
       // (SpikeSlabSampler: rmvn_ivar_mt with the sigma-scaled precision itself)
       const double sigma = P.mode ? 1.0 : sqrt(sigsq);
@@ -1173,6 +1428,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       }
       beta_m = y;
       beta_valid = true;
+      TSTAMP(sx, 4);
     } else if (P.draw_beta) {
       beta_valid = true;  // empty model: all coefficients zero
     }
@@ -1242,6 +1498,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     P.failures[chain] = failures;
     P.status[chain] = status;
     P.todo[chain] = nsweeps - done;
+    P.table_tag[chain] = (table_valid && !aborted && status == CHAIN_OK) ? KCAP : 0;
     if (P.trace_idx) P.trace_idx[chain] = trace_at + done;
     if (P.maxk) atomicMax(P.maxk, kmax);
     double *a = P.acc + (size_t)chain * ACC_COUNT;
@@ -1252,8 +1509,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     a[ACC_ACCEPTS] += acc_acc;
     a[ACC_PROPOSALS] += acc_prop;
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], min_margin);
-#if defined(BA_STAMPS) && defined(BA_STAMPS2)
+#if defined(BA_STAMPS) && (defined(BA_STAMPS2) || defined(BA_STAMPS3))
     SUBSTAMP(sx, 7);
+    TSTAMP(sx, 7);
     for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += sx.ph[i];
 #elif defined(BA_STAMPS)
     for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += st_ph[i];

@@ -42,6 +42,7 @@ struct SsvsParams {
   int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
   int32_t waves; // wavefronts per chain (1, 2 or 4)
   int32_t mode;  // 0: BregVsSampler (sigma^2 integrated out); 1: SpikeSlabSampler (given sigma^2)
+  int32_t scan_policy;  // 0 batch mode only, 1 adaptive (table look-ups after quiet sweeps), 2 always the table
   int32_t slab_scales;  // mode 1: slab precision is Omega^{-1} / sigma^2 (MvnGivenScalarSigma)
 
   // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
@@ -93,6 +94,11 @@ struct SsvsParams {
   // factors, their reciprocal diagonals, w, b_g, g) in HBM, laid out by
   // ssvs_scalar_layout(); the proposal evaluation reads it through the scalar
   // cache (s_load) so that factor elements arrive as SGPR operands of the FMAs.
+  // per-chain table of log_model_prob(gamma ^ {j}) for the current model
+  double *table_lp;             // chains x p
+  uint8_t *table_kind;          // chains x p
+  int32_t *table_tag;           // chains: capacity the table was built with, 0 = stale
+  int32_t table_keep;           // 0: ignore the tags (something other than sweeps happened)
   double *model_scratch;        // chains x model_scratch_stride doubles
   int64_t model_scratch_stride;
 

@@ -5,8 +5,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUB = os.environ.get("SUBSTAMPS", "0") == "1"
-os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", "libboomamd_stamps2.so" if SUB else "libboomamd_stamps.so")
+SUBN = os.environ.get("SUBSTAMPS", "0")
+SUB = SUBN != "0"
+os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", {"0": "libboomamd_stamps.so", "1": "libboomamd_stamps2.so", "2": "libboomamd_stamps3.so"}[SUBN])
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import time
@@ -35,7 +36,10 @@ sm = eng.get_summaries()
 ph = sm["phase_cycles"]
 names = ["shuffle uniforms", "shuffle serial", "refactor", "proposal batches",
          "swap", "sigma", "beta", "rest"]
-if SUB:
+if SUBN == "2":
+    names = ["shuffle: prev-step rounds", "shuffle: links", "shuffle: walks", "normals",
+             "back substitution", "summaries", "sweep start + uniforms", "everything else"]
+elif SUB:
     names = ["batch: uniform+log", "batch: classify", "batch: V gather", "batch: V solve",
              "batch: A gather", "batch: A solve", "batch: epilogue", "outside batches"]
 tot = ph.sum()
@@ -43,4 +47,4 @@ print("waves=%s hint=%s" % (os.environ.get("BOOM_AMD_WAVES","auto"), os.environ.
       % (nsig, chains, dt / 100 * 1e6, sm["k_sum"] / sm["sweeps"], sm["accepts"] / sm["sweeps"],
          sm["proposals"] / sm["sweeps"]))
 for nm, v in zip(names, ph):
-    print("  %-18s %6.2f %%   %10.0f cycles/sweep" % (nm, 100 * v / tot, v / sm["sweeps"]))
+    print("  %-26s %6.2f %%   %10.0f cycles/sweep" % (nm, 100 * v / tot, v / sm["sweeps"]))
