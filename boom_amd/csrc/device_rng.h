@@ -83,27 +83,42 @@ struct SeqRng {
 // lockstep (all 64 lanes active, wave-uniform control flow): the wave
 // generates a window of 128 consecutive uniforms at once -- lane l holds both
 // numbers of block (window base >> 1) + l -- and every rng() is a v_readlane
-// instead of ten Philox rounds.
+// instead of ten Philox rounds.  The cursor is a wave-uniform 32-bit offset so
+// that the bookkeeping stays on the scalar unit.
 struct WinRng {
   PhiloxKey key;
-  uint64_t pos;
   int lane;
   uint64_t wbase;   // even stream position of the window's first number
+  int off;          // next number = wbase + off
+  bool have;        // a window is loaded (then off <= 128)
   double w0, w1;
-  bool have;
-  __device__ __forceinline__ void reset(uint64_t p) {
-    pos = p;  // the window is kept: positions only move forward inside a sweep
+  __device__ __forceinline__ void init(const PhiloxKey &k, int l, uint64_t p) {
+    key = k; lane = l; w0 = w1 = 0.0;
+    wbase = p; off = 0; have = false;
+  }
+  __device__ __forceinline__ uint64_t get_pos() const { return wbase + (uint64_t)off; }
+  __device__ __forceinline__ void fill(uint64_t p) {
+    wbase = p & ~1ull;
+    off = __builtin_amdgcn_readfirstlane((int)(p & 1ull));
+    have = true;
+    philox_pair(key, (wbase >> 1) + (uint64_t)lane, &w0, &w1);
+  }
+  // move the cursor (forward or back inside the window keeps the window)
+  __device__ __forceinline__ void set_pos(uint64_t p) {
+    if (have && p >= wbase && p - wbase <= 128) {
+      off = __builtin_amdgcn_readfirstlane((int)(p - wbase));
+    } else {
+      wbase = p;
+      off = 0;
+      have = false;
+    }
   }
   __device__ __forceinline__ double operator()() {
-    if (!have || pos < wbase || pos - wbase >= 128) {
-      wbase = pos & ~1ull;
-      philox_pair(key, (wbase >> 1) + (uint64_t)lane, &w0, &w1);
-      have = true;
-    }
-    const int off = __builtin_amdgcn_readfirstlane((int)(pos - wbase));
-    ++pos;
-    const double w = (off & 1) ? w1 : w0;
-    const int src = off >> 1;
+    if (!have || off > 127) fill(get_pos());
+    const int o = off;
+    off = o + 1;
+    const double w = (o & 1) ? w1 : w0;
+    const int src = o >> 1;
     const int lo = __builtin_amdgcn_readlane(__double2loint(w), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(w), src);
     return __hiloint2double(hi, lo);

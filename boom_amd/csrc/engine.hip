@@ -23,6 +23,7 @@ hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P, int nsweep
 hipError_t launch_ssvs_logp(hipStream_t stream, const SsvsParams &P,
                             const uint8_t *gammas, int ngamma, double *out,
                             int *status_out);
+hipError_t launch_lds_exchange_order(hipStream_t stream, int *bad_device);
 hipError_t launch_ssvs_reduce_summaries(hipStream_t stream, const SsvsParams &P,
                                         double *out);
 // suf_kernel.hip
@@ -534,6 +535,23 @@ int ba_engine_create(const ba_config *cfg, ba_engine **out) {
     e->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (prop.maxSharedMemoryPerMultiProcessor > 0)
       e->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+  }
+  // the shuffle's LDS-exchange search needs same-address exchanges resolved in
+  // lane order; refuse a device that does not
+  {
+    int *dbad = nullptr, hbad = -1;
+    err = hipMalloc((void **)&dbad, sizeof(int));
+    if (err == hipSuccess) err = hipMemsetAsync(dbad, 0, sizeof(int), e->stream);
+    if (err == hipSuccess) err = launch_lds_exchange_order(e->stream, dbad);
+    if (err == hipSuccess) err = hipMemcpyAsync(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (dbad) (void)hipFree(dbad);
+    if (err != hipSuccess || hbad != 0) {
+      (void)hipStreamDestroy(e->stream);
+      delete e;
+      if (err != hipSuccess) return fail(BA_E_HIP, std::string("device self-test: ") + hipGetErrorString(err));
+      return fail(BA_E_HIP, "device self-test: LDS exchanges are not resolved in lane order on this device");
+    }
   }
   *out = e;
   return BA_OK;

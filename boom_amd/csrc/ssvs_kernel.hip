@@ -73,6 +73,14 @@ struct StampCtx { long long last; double ph[8]; };
 // (0 shuffle: previous-step rounds, 1 shuffle: links, 2 shuffle: walks,
 // 3 normals, 4 back substitution, 5 summaries, 6 sweep start + shuffle
 // uniforms, 7 everything else)
+// -DBA_STAMPS -DBA_STAMPS4: the 8 slots time helper wave 1 (0 shuffle uniforms,
+// 1 matching rounds, 2 links, 3 walks, 4 table walk, 5 waiting for commands,
+// 6 its share of proposal rounds, 7 other)
+#if defined(BA_STAMPS) && defined(BA_STAMPS4)
+#define HSTAMP(c, i) do { const long long t_ = (long long)__builtin_readcyclecounter(); (c).ph[i] += (double)(t_ - (c).last); (c).last = t_; } while (0)
+#else
+#define HSTAMP(c, i) do { } while (0)
+#endif
 #if defined(BA_STAMPS) && defined(BA_STAMPS3)
 #define TSTAMP(c, i) do { const long long t_ = (long long)__builtin_readcyclecounter(); (c).ph[i] += (double)(t_ - (c).last); (c).last = t_; } while (0)
 #else
@@ -85,6 +93,7 @@ struct StampCtx { long long last; double ph[8]; };
 #define AS_LDS __attribute__((address_space(3)))
 typedef AS_LDS double lds_f64;
 typedef AS_LDS uint16_t lds_u16;
+typedef AS_LDS uint32_t lds_u32;
 typedef AS_LDS uint8_t lds_u8;
 template <class T>
 __device__ __forceinline__ AS_LDS T *to_lds(unsigned char *generic) {
@@ -173,10 +182,11 @@ struct Chain {
   int lane, p, k;
   // LDS
   lds_f64 *Lv, *La, *rdv, *rda, *w, *bg;
-  lds_u16 *g, *perm, *perm_alt, *oth, *last, *pred;
-  lds_u8 *gam, *gam0;
+  lds_u16 *g, *perm, *perm_alt, *oth, *pred;
+  lds_u32 *last;
+  lds_u8 *gam, *gam0, *nbr;
   // HBM copy of the model read through the scalar cache (see publish_model)
-  double *tab_lp;     // table of log_model_prob(gamma ^ {j}), j = 0..p-1 (HBM)
+  double *tab_lp;     // table of exp(log_model_prob(gamma ^ {j}) - log_model_prob(gamma)), j = 0..p-1 (HBM)
   uint8_t *tab_kind;  // 0 / STOP_SLOW / STOP_BAD per j
   double *sc_store;   // global pointer used for the stores
   c_f64 *sc;          // the same memory, constant address space
@@ -203,10 +213,11 @@ __device__ __forceinline__ void bind_lds(Chain &ch, unsigned char *smem,
   ch.perm = to_lds<uint16_t>(smem + lay.perm0);
   ch.perm_alt = to_lds<uint16_t>(smem + lay.perm1);
   ch.oth = to_lds<uint16_t>(smem + lay.oth);
-  ch.last = to_lds<uint16_t>(smem + lay.last);
+  ch.last = to_lds<uint32_t>(smem + lay.last);
   ch.pred = to_lds<uint16_t>(smem + lay.pred);
   ch.gam = to_lds<uint8_t>(smem + lay.gam);
   ch.gam0 = to_lds<uint8_t>(smem + lay.gam0);
+  ch.nbr = to_lds<uint8_t>(smem + lay.nbr);
 }
 
 // In-place Cholesky of a block-packed lower triangle, lane i owns row i
@@ -254,7 +265,6 @@ __device__ __forceinline__ bool chol_blocks(const Chain &ch, lds_f64 *LB,
       break;
     }
     const double sd = sqrt(d);
-    ld += log(sd);
     if (i == j) {
       LB[bidx(j, j)] = sd;
       rd[j] = 1.0 / sd;
@@ -263,6 +273,11 @@ __device__ __forceinline__ bool chol_blocks(const Chain &ch, lds_f64 *LB,
     }
     wave_sync();
   }
+  if (ok) {
+    // sum_j log L_jj in column order, the logarithms taken side by side
+    const double lg = (i < k) ? log(LB[bidx(i, i)]) : 0.0;
+    for (int j = 0; j < k; ++j) ld += bcast_u(lg, j);
+  }
   *logdet = 2.0 * ld;
   return ok;
 }
@@ -270,8 +285,9 @@ __device__ __forceinline__ bool chol_blocks(const Chain &ch, lds_f64 *LB,
 // Rebuild everything about the current model gamma (sorted index list g in
 // LDS) from scratch: BregVsSampler::set_reg_post_params + log_model_prob.
 // Inlined at its (single) call site in each kernel.
-__device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &M) {
+__device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &M, StampCtx &sx) {
   const int lane = ch.lane, p = ch.p, k = ch.k;
+  TSTAMP(sx, 7);
   M.bad = 0;
   M.pd = true;
   // VariableSelectionPrior::logp (VariableSelectionPrior.cpp:271-285)
@@ -294,6 +310,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     return;
   }
   wave_sync();
+  TSTAMP(sx, 0);
   // gather V_g, A_g (lower triangles, rows padded with zeros to a multiple of
   // 8) with all loads independent: element e <-> (m, n), n <= m
   const int kpad = (k + 7) & ~7;
@@ -335,6 +352,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   const double r = (lane < k) ? ab + ch.xty[gm] * ch.sx : 0.0;
   M.c = wave_sum(lane < k ? bm * ab : 0.0);
   wave_sync();
+  TSTAMP(sx, 1);
   // the two factorisations share one (not unrolled) body
   bool okv = true, oka = true;
 #pragma nounroll
@@ -342,6 +360,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     double ld;
     const bool ok = chol_blocks(ch, s ? ch.Lv : ch.La, s ? ch.rdv : ch.rda, &ld);
     if (s) { okv = ok; M.ldv = ld; } else { oka = ok; M.lda = ld; }
+    TSTAMP(sx, s ? 3 : 2);
   }
   if (!okv) {
     M.pd = false;
@@ -360,6 +379,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   M.Q = wave_sum(lane < k ? x * x : 0.0);
   M.SS = ch.ss0q + M.c - M.Q;
   wave_sync();
+  TSTAMP(sx, 4);
   if (ch.mode) {
     // SpikeSlabSampler::log_model_prob, SpikeSlabSampler.cpp:171-203:
     // log pi(g) + .5 log|P_g| - .5 mu'P mu - [.5 log|V_g| - .5 |L^{-1} r|^2]
@@ -432,6 +452,30 @@ __device__ __forceinline__ void publish_model(Chain &ch) {
   ch.sc = (c_f64 *)u;
 }
 
+// The inverse copy: after a rejected exact evaluation the factors of the
+// current model come back from the chain's HBM block (bitwise what a second
+// factorisation would produce, at the cost of one coalesced read).
+template <int NB>
+__device__ __forceinline__ void restore_model(Chain &ch) {
+  const int lane = ch.lane, k = ch.k;
+  constexpr int KCAP = NB * 8;
+  const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
+  const int kpad = (k + 7) & ~7;
+  const int nblk = (kpad / 8) * (kpad / 8 + 1) / 2;
+  const double *src = ch.sc_store;
+  for (int e = lane; e < nblk * 64; e += WAVE) {
+    ch.Lv[e] = src[S.Lv + e];
+    ch.La[e] = src[S.La + e];
+  }
+  if (lane < kpad) {
+    ch.rdv[lane] = src[S.rdv + lane];
+    ch.rda[lane] = src[S.rda + lane];
+    ch.w[lane] = src[S.w + lane];
+    ch.bg[lane] = src[S.bg + lane];
+  }
+  wave_sync();
+}
+
 // Per-lane forward substitution L x = rhs, x in registers (in: rhs, out:
 // solution).  The factor's blocks and reciprocal diagonal come through the
 // scalar cache (SGPR operands).  Rows >= k of the last block are zero with
@@ -472,7 +516,11 @@ struct Proposal {
 };
 
 // Evaluate this lane's proposal "flip j" against the current model.
-template <int NB>
+// NAT: the wave's lanes hold CONSECUTIVE variables j (table fill), so element
+// (g_m, j) of the symmetric matrix is read down column j of row g_m and the 64
+// lanes share four cache lines; otherwise (arbitrary j per lane) it is read
+// as element (j, g_m), the lane's k elements sharing a few lines of its row.
+template <int NB, bool NAT>
 __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch,
                                                   const Model &M, int j,
                                                   bool valid, StampCtx &sx) {
@@ -508,7 +556,6 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
   constexpr int KCAP = NB * 8;
   const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
   c_f64 *sc = ch.sc;
-  c_i32 *gsc = (c_i32 *)(sc + S.g);
 
   double x[NB * 8];
   double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
@@ -527,11 +574,8 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int m = I * 8 + r;
-          const int gm = gsc[m];
-          // column j of the symmetric matrix read as ROW j: a lane's k elements
-          // share a few cache lines of its own row, and different lanes touch
-          // different rows (no hot rows shared by every chain on the device)
-          const double v = Mat[(size_t)j * p + gm] * msc;
+          const int gm = (m < k) ? (int)ch.g[m] : 0;  // LDS broadcast read
+          const double v = (NAT ? Mat[(size_t)gm * p + j] : Mat[(size_t)j * p + gm]) * msc;
           const double e = (gm == j) ? 1.0 : 0.0;
           x[m] = (fast && m < k) ? (add ? v : e) : 0.0;
         }
@@ -616,36 +660,37 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 // and so on until a slot nobody wrote, which still holds its original value.
 // oth[] must be filled for i = 1..p-1.  Result goes to ch.perm (buffers swap).
 __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
-  TSTAMP(sx, 6);
   const int p = ch.p, lane = ch.lane;
   constexpr int NONE = 0xFFFF;
-  for (int j = lane; j < p; j += WAVE) ch.last[j] = (uint16_t)NONE;
-  int nbits = 1;
-  while ((1 << nbits) < p) ++nbits;
+  for (int j = lane; j < p; j += WAVE) ch.last[j] = (uint32_t)NONE;
   wave_sync();
-  // ---- previous step with the same target, rounds over decreasing t
-  for (int T = p - 1; T >= 1; T -= WAVE) {
-    const int t = T - lane;
-    const bool valid = t >= 1;
-    const int key = valid ? ch.oth[t] : 0;
-    unsigned long long mask = __ballot(valid);
-    for (int b = 0; b < nbits; ++b) {
-      const bool bit = (key >> b) & 1;
-      const unsigned long long bal = __ballot(valid && bit);
-      mask &= bit ? bal : ~bal;
+  HSTAMP(sx, 0);
+  // ---- previous step with the same target: rounds of 64 steps over decreasing
+  // t, lane l <-> step T - l.  One LDS exchange per round does the search: the
+  // LDS resolves same-address exchanges of a wavefront instruction in ascending
+  // lane order (checked when the engine is created), so a lane gets back the
+  // step of the nearest lower lane with its target -- or what earlier rounds
+  // left there -- and the array ends up holding each target's smallest step.
+  constexpr int RC = 8;
+  for (int T0 = p - 1; T0 >= 1; T0 -= RC * WAVE) {
+    int key[RC];
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+      const int t = T0 - r * WAVE - lane;
+      key[r] = (t >= 1) ? (int)ch.oth[t] : 0;
     }
-    if (valid) {
-      const unsigned long long lower = mask & ((1ull << lane) - 1ull);  // larger t
-      int pr;
-      if (lower) pr = T - (63 - __clzll((long long)lower));
-      else pr = ch.last[key];
-      ch.pred[t] = (uint16_t)pr;
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+      const int t = T0 - r * WAVE - lane;
+      if (t >= 1) {
+        const uint32_t old = __hip_atomic_exchange(&ch.last[key[r]], (uint32_t)t, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        ch.pred[t] = (uint16_t)old;
+      }
     }
-    wave_sync();
-    if (valid && (lane == 63 || (mask >> (lane + 1)) == 0)) ch.last[key] = (uint16_t)t;
-    wave_sync();
   }
-  TSTAMP(sx, 0);
+  wave_sync();
+  HSTAMP(sx, 1);
   // last[x] = smallest t >= 1 with oth[t] == x.  nxt(t) = smallest t' > t with
   // oth[t'] == t: last[t] unless that is the self swap t, then pred[t].
   const int pred0 = ch.last[0];
@@ -653,11 +698,11 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
   for (int t = lane; t < p; t += WAVE) {
     if (t >= 1) {
       const int l = ch.last[t];
-      ch.last[t] = (uint16_t)((l == t) ? (int)ch.pred[t] : l);
+      ch.last[t] = (uint32_t)((l == t) ? (int)ch.pred[t] : l);
     }
   }
   wave_sync();
-  TSTAMP(sx, 1);
+  HSTAMP(sx, 2);
   const lds_u16 *src_perm = ch.perm;
   lds_u16 *dst = ch.perm_alt;
   // eight independent walks per lane, advanced together, so that the dependent
@@ -678,19 +723,24 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
         n[u] = ch.last[c0];
       }
     }
-    bool more = false;
+    // (most walks end within a few links; a group whose 64 walks are all done
+    // costs one scalar test per level)
+    unsigned live = 0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) more |= (n[u] != NONE);
-    while (__any(more)) {
-      more = false;
+    for (int u = 0; u < U; ++u) live |= __any(n[u] != NONE) ? (1u << u) : 0u;
+    while (live) {
+      unsigned nlive = 0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool act = n[u] != NONE;
-        const int nn = ch.last[act ? n[u] : 0];
-        c[u] = act ? n[u] : c[u];
-        n[u] = act ? nn : NONE;
-        more |= (n[u] != NONE);
+        if (live & (1u << u)) {
+          const bool act = n[u] != NONE;
+          const int nn = ch.last[act ? n[u] : 0];
+          c[u] = act ? n[u] : c[u];
+          n[u] = act ? nn : NONE;
+          nlive |= __any(n[u] != NONE) ? (1u << u) : 0u;
+        }
       }
+      live = nlive;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -702,7 +752,54 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
   lds_u16 *tmp = ch.perm;
   ch.perm = ch.perm_alt;
   ch.perm_alt = tmp;
-  TSTAMP(sx, 2);
+  HSTAMP(sx, 3);
+}
+
+// k standard normals in stream order (distributions/mvn.cpp:114-122), lane m
+// receives z_m.  Seven times out of eight Kinderman-Ramage takes its first
+// branch (two uniforms, one line of arithmetic); that branch is evaluated for
+// every window position at once and a scalar walk picks the draws a
+// sequential reader would have made, falling back to the generic transform
+// where another branch is due.
+__device__ __forceinline__ double draw_normals(WinRng &rng, int k) {
+  const double A = 2.216035867166471;
+  const int lane = rng.lane;
+  double z = 0.0;
+  int m = 0;
+  while (m < k) {
+    if (!rng.have || rng.off > 125) rng.fill(rng.get_pos());
+    const uint64_t wb = rng.wbase;
+    // start at even offset 2l: (w0, w1) of lane l; at odd offset 2l+1: w1 of
+    // lane l and w0 of lane l+1
+    const double w0n = __shfl_down(rng.w0, 1);
+    const double zE = A * (1.131131635444180 * rng.w0 + rng.w1 - 1);
+    const double zO = A * (1.131131635444180 * rng.w1 + w0n - 1);
+    const unsigned long long mE = __ballot(rng.w0 < 0.884070402298758);
+    const unsigned long long mO = __ballot(rng.w1 < 0.884070402298758);
+    int o = rng.off;
+    while (m < k && o <= 125) {
+      const int l = o >> 1;
+      const bool odd = o & 1;
+      double zm;
+      if (((odd ? mO : mE) >> l) & 1ull) {
+        zm = bcast_u(odd ? zO : zE, l);
+        o += 2;
+      } else {
+        rng.off = o;
+        zm = d_norm_rand(rng);
+        o = rng.off;
+        if (rng.wbase != wb) {  // the window moved: recompute the candidates
+          if (lane == m) z = zm;
+          ++m;
+          break;
+        }
+      }
+      if (lane == m) z = zm;
+      ++m;
+    }
+    rng.off = o;
+  }
+  return z;
 }
 
 // A request to (re)build the model after changing gamma, served at the single
@@ -736,6 +833,7 @@ __device__ __forceinline__ void propose_swap(const SsvsParams &P, Chain &ch,
   // Selector::random_included_position, LinAlg/Selector.cpp:297-304
   const int pos = d_random_int(rng, 0, k - 1);
   const int index = ch.g[pos];
+  if (!ch.nbr[index]) return;  // no partner above the threshold (the usual case)
   const int lo = P.cm_start[index], hi = P.cm_start[index + 1];
   if (lo == hi) return;
   double total = 0.0;
@@ -816,7 +914,7 @@ __device__ __forceinline__ void propose_swap(const SsvsParams &P, Chain &ch,
 //               at all.
 // The master picks the mode per sweep from the previous sweep's stop count.
 
-enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2, CMD_DECIDE = 3 };
+enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2, CMD_DECIDE = 3, CMD_SHUFFLE_DECIDE = 4 };
 // control block (doubles): 0 cmd, 1 k, 2 i0, 3..8 model scalars, 9 nflips;
 // u64 view at 10: flip_pos / uniform base position; wave slots from 16
 enum : int { CT_CMD = 0, CT_K = 1, CT_I0 = 2, CT_LOGP = 3, CT_LP = 4, CT_LDV = 5,
@@ -882,9 +980,12 @@ __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
   const int idx = i0 + WAVE * wave + lane;
   if (evmode == EVM_FILL) {
     const bool valid = idx < ch.p;
-    const Proposal pr = eval_proposal<NB>(P, ch, M, valid ? idx : 0, valid, sx);
+    const Proposal pr = eval_proposal<NB, true>(P, ch, M, valid ? idx : 0, valid, sx);
     if (valid) {
-      ch.tab_lp[idx] = pr.logp;
+      // acceptance threshold in the uniform's own scale: log u <= logp' - logp
+      // <=> u <= exp(logp' - logp)   (0 for an impossible model, inf / NaN --
+      // never exceeded -- when the current model itself is impossible)
+      ch.tab_lp[idx] = exp(pr.logp - M.logp);
       ch.tab_kind[idx] = (uint8_t)(pr.bad_ss ? STOP_BAD : (pr.slow ? STOP_SLOW : 0));
     }
     SUBSTAMP(sx, 6);
@@ -897,8 +998,8 @@ __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
 #if defined(BA_STAMPS2)
   asm volatile("" :: "v"(logu) : "memory");
 #endif
-  SUBSTAMP(sx, 0);
-  const Proposal pr = eval_proposal<NB>(P, ch, M, j, valid, sx);
+  SUBSTAMP(sx, 7);
+  const Proposal pr = eval_proposal<NB, false>(P, ch, M, j, valid, sx);
   const double lpj = pr.logp;
   const bool slow = valid && pr.slow;
   const bool bad = valid && pr.bad_ss;
@@ -936,54 +1037,89 @@ struct DecideResult {
 };
 __device__ __forceinline__ void decide_walk(const Chain &ch, const PhiloxKey &key,
                                             uint64_t flip_pos, int i0, int nflips,
-                                            double logp, DecideResult &out) {
+                                            DecideResult &out) {
+  // R Philox blocks (2 R positions) per lane and round, all loads of a round
+  // in flight together: the table look-ups are latency, not bandwidth.  The
+  // table holds E_j = exp(logp_j' - logp), so a decision is u <= E_j and no
+  // logarithm is taken except for the one uniform of a stop.
+  constexpr int R = 4;
   const int lane = ch.lane;
   double lane_margin = BA_INF;
   out.spos = -1; out.j = 0; out.kind = 0; out.logu = 0.0;
   while (i0 < nflips) {
-    const uint64_t blk = ((flip_pos + (uint64_t)i0) >> 1) + (uint64_t)lane;
-    double u[2];
-    philox_pair(key, blk, &u[0], &u[1]);
-    const int q0 = (int)((long long)(2 * blk) - (long long)flip_pos);
-    bool acc[2], val[2];
-    double lu[2], dl[2];
-    int jj[2], kd[2];
+    const uint64_t blk0 = (flip_pos + (uint64_t)i0) >> 1;
+    const int qb = (int)((long long)(2 * blk0) - (long long)flip_pos);  // position of block blk0, half 0
+    double u[R][2], ej[R][2];
+    int jj[R][2], kd[R][2];
+    bool val[R][2], acc[R][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = q0 + h;
-      val[h] = q >= i0 && q < nflips;
-      jj[h] = val[h] ? (int)ch.perm[q] : 0;
-    }
-    unsigned long long mstop[2];
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const double lpj = ch.tab_lp[jj[h]];
-      kd[h] = ch.tab_kind[jj[h]];
-      lu[h] = log(u[h]);
-      dl[h] = lpj - logp;
-      const bool special = kd[h] != 0;
-      acc[h] = val[h] && !special && !(lu[h] > dl[h]);
-      mstop[h] = __ballot(val[h] && (special || acc[h]));
-      if (!(lpj > -BA_INF)) dl[h] = BA_INF;  // no margin against -inf
+      for (int h = 0; h < 2; ++h) {
+        const int q = qb + 2 * (r * WAVE + lane) + h;
+        val[r][h] = q >= i0 && q < nflips;
+        jj[r][h] = val[r][h] ? (int)ch.perm[q] : 0;
+      }
     }
-    const int f0 = mstop[0] ? 2 * (__ffsll((long long)mstop[0]) - 1) : 1 << 20;
-    const int f1 = mstop[1] ? 2 * (__ffsll((long long)mstop[1]) - 1) + 1 : 1 << 20;
-    const int f = f0 < f1 ? f0 : f1;  // first stop, as 2 lane + half
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int me = 2 * lane + h;
-      const bool counted = val[h] && (me < f || (me == f && acc[h])) && dl[h] < BA_INF;
-      if (counted) lane_margin = fmin(lane_margin, fabs(lu[h] - dl[h]));
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ej[r][h] = ch.tab_lp[jj[r][h]];
+        kd[r][h] = ch.tab_kind[jj[r][h]];
+      }
     }
-    if (f >= (1 << 20)) {
-      i0 = q0 - 2 * lane + 2 * WAVE;  // first position of the next round
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      philox_pair(key, blk0 + (uint64_t)(r * WAVE + lane), &u[r][0], &u[r][1]);
+    int f = 1 << 20, fr = 0;  // first stop: 2 lane + half within sub-round fr
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      unsigned long long mstop[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool special = kd[r][h] != 0;
+        acc[r][h] = val[r][h] && !special && !(u[r][h] > ej[r][h]);
+        mstop[h] = __ballot(val[r][h] && (special || acc[r][h]));
+      }
+      if (f == (1 << 20)) {
+        const int f0 = mstop[0] ? 2 * (__ffsll((long long)mstop[0]) - 1) : 1 << 20;
+        const int f1 = mstop[1] ? 2 * (__ffsll((long long)mstop[1]) - 1) + 1 : 1 << 20;
+        const int fm = f0 < f1 ? f0 : f1;
+        if (fm < (1 << 20)) { f = fm; fr = r; }
+      }
+    }
+    const int fkey = (f == (1 << 20)) ? (1 << 30) : fr * 2 * WAVE + f;  // order within the round
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // |u / E - 1|, to first order the distance |log u - (logp' - logp)|
+        const int me = r * 2 * WAVE + 2 * lane + h;
+        const bool counted = val[r][h] && (me < fkey || (me == fkey && acc[r][h])) && ej[r][h] > 0.0;
+        const double mg = fabs(u[r][h] - ej[r][h]) * __builtin_amdgcn_rcp(ej[r][h]);
+        if (counted) lane_margin = fmin(lane_margin, mg);
+      }
+    }
+    if (f == (1 << 20)) {
+      i0 = qb + 2 * R * WAVE;  // first position of the next round
       continue;
     }
     const int fl = f >> 1, fh = f & 1;
-    out.spos = __builtin_amdgcn_readlane(q0 + fh, fl);
-    out.j = __builtin_amdgcn_readlane(fh ? jj[1] : jj[0], fl);
-    out.kind = __builtin_amdgcn_readlane(fh ? kd[1] : kd[0], fl);
-    out.logu = bcast_u(fh ? lu[1] : lu[0], fl);
+    int sj = 0, sk = 0;
+    double su = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r == fr) {
+        sj = fh ? jj[r][1] : jj[r][0];
+        sk = fh ? kd[r][1] : kd[r][0];
+        su = fh ? u[r][1] : u[r][0];
+      }
+    }
+    out.spos = qb + fr * 2 * WAVE + f;
+    out.j = __builtin_amdgcn_readlane(sj, fl);
+    out.kind = __builtin_amdgcn_readlane(sk, fl);
+    out.logu = log(bcast_u(su, fl));
     break;
   }
   out.margin = wave_min(lane_margin);
@@ -1037,8 +1173,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   sx_unused.last = 0;
   if (W > 1 && wave != 0) {
     // ---- helper waves: serve the master's commands ---------------------------
+    sx_unused.last = (long long)__builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) sx_unused.ph[i] = 0.0;
     for (;;) {
+      HSTAMP(sx_unused, 7);
       __syncthreads();
+      HSTAMP(sx_unused, 5);
       const int cmd = (int)ctl[CT_CMD];
       if (cmd == CMD_EXIT) break;
       const uint64_t upos = ((AS_LDS const uint64_t *)(ctl + CT_POS))[0];
@@ -1054,11 +1194,24 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         ch.sc = (c_f64 *)a;
         eval_share<NB>(P, ch, M, key, upos, (int)ctl[CT_NFLIPS], (int)ctl[CT_I0],
                        (int)ctl[CT_EVMODE], wave, ctl, sx_unused);
-      } else if (cmd == CMD_DECIDE) {
+        HSTAMP(sx_unused, 6);
+      } else if (cmd == CMD_DECIDE || cmd == CMD_SHUFFLE_DECIDE) {
         if (wave == 1) {
-          ch.perm = to_lds<uint16_t>(smem + (((int)ctl[CT_PERMSEL]) ? lay.perm1 : lay.perm0));
+          const int sel = (int)ctl[CT_PERMSEL];
+          ch.perm = to_lds<uint16_t>(smem + (sel ? lay.perm1 : lay.perm0));
+          ch.perm_alt = to_lds<uint16_t>(smem + (sel ? lay.perm0 : lay.perm1));
+          uint64_t fpos = upos;
+          if (cmd == CMD_SHUFFLE_DECIDE) {
+            // the whole permutation side of a quiet sweep: shuffle(indx) from
+            // stream position upos, then the walk over the new order
+            shuffle_targets(key, upos, p, lane, WAVE, ch.oth);
+            wave_sync();
+            parallel_shuffle(ch, sx_unused);
+            fpos = upos + (uint64_t)(p - 1);
+          }
           DecideResult dr;
-          decide_walk(ch, key, upos, (int)ctl[CT_I0], (int)ctl[CT_NFLIPS], ctl[CT_LOGP], dr);
+          decide_walk(ch, key, fpos, (int)ctl[CT_I0], (int)ctl[CT_NFLIPS], dr);
+          HSTAMP(sx_unused, 4);
           if (lane == 0) {
             lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * 1;
             sl[SL_F] = (double)dr.spos;
@@ -1071,8 +1224,16 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       } else {  // CMD_UNIF: this wave's share of the shuffle uniforms
         if (p > 1) shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth);
       }
+      HSTAMP(sx_unused, 7);
       __syncthreads();
+      HSTAMP(sx_unused, 5);
     }
+#if defined(BA_STAMPS) && defined(BA_STAMPS4)
+    if (wave == 1 && lane == 0) {
+      double *a = P.acc + (size_t)chain * ACC_COUNT;
+      for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += sx_unused.ph[i];
+    }
+#endif
     return;
   }
 
@@ -1087,6 +1248,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     if (j < p) {
       ch.gam[j] = (uint8_t)inc;
       ch.perm[j] = g_perm[j];
+      ch.nbr[j] = (uint8_t)((P.cm_start != nullptr) && (P.cm_start[j + 1] > P.cm_start[j]));
     }
     const unsigned long long mask = __ballot(inc != 0);
     const int slot = k + __popcll(mask & ((1ull << lane) - 1ull));
@@ -1109,6 +1271,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   bool beta_valid = false;
 
   double acc_sig = 0, acc_sig2 = 0, acc_k = 0, acc_acc = 0, acc_prop = 0;
+  int g_r = -1;  // summaries held in registers for variable g_r
+  unsigned cnt_r = 0u;
+  double bsum_r = 0.0, bsq_r = 0.0;
   double min_margin = BA_INF;
   int done = 0;
 
@@ -1125,7 +1290,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   M.bad = 0; M.pd = true; M.logp = 0; M.lp = 0; M.ldv = 0; M.lda = 0; M.Q = 0; M.c = 0; M.SS = 0;
   Pending pe;
   pe.kind = EV_INIT; pe.f1 = pe.f2 = -1; pe.lu = 0; pe.lfw = pe.lrev = 0; pe.check_legal = false;
-  enum { PH_BEGIN, PH_FLIPS, PH_SWAP, PH_TAIL };
+  enum { PH_BEGIN, PH_FLIPS, PH_SWAP, PH_TAIL, PH_JOIN, PH_COMMIT };
   int phase = PH_BEGIN, sweep = 0, i0 = 0;
   bool model_checked = false;  // legality of the start is checked in sweep 0
   int perm_sel = 0;            // which LDS buffer holds the current permutation
@@ -1136,43 +1301,64 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   // sweeps happened since (the host clears table_keep otherwise)
   bool table_valid = P.table_keep && P.table_tag[chain] == KCAP && status == CHAIN_OK;
   int fill_j = 0;             // next variable of a fill in progress
+  // Quiet sweeps fork: wave 1 shuffles and walks the table while the master
+  // runs the sweep's tail (swap proposal, sigma, beta) on the assumption that
+  // no flip will be accepted -- the tail's stream position is known up front
+  // (shuffle and flips consume p - 1 + nflips numbers whatever happens).  At
+  // the join a stop in the walk rolls the tail back.
+  bool spec = false;          // a forked walk is outstanding
+  bool have_dr = false;       // wave 1's slot holds a walk result not yet handled
+  int after_join = PH_COMMIT, spec_status = CHAIN_OK;
+  double sigsq_s = 0.0, beta_m_s = 0.0;
+  int gprev_s = 0, kprev_s = 0, failures_s = 0;
+  bool beta_valid_s = false;
   int stops_prev = table_valid ? 0 : (1 << 20), stops_now = 0;
   uint64_t flip_pos = 0, pos0 = pos;
   WinRng rng;
-  rng.key = key; rng.pos = pos;
-  rng.lane = lane; rng.have = false; rng.wbase = 0; rng.w0 = rng.w1 = 0.0;
+  rng.init(key, lane, pos);
 
   while (status == CHAIN_OK) {
-    if (pe.kind != EV_NONE) {
-      // ---- the one place where a model is (re)built --------------------------
+    if (pe.kind != EV_NONE && !spec) {
+      // ---- the one place where a model is (re)built (a swap proposed by a
+      // tail running ahead waits for the join) --------------------------
       const Model keep = M;
+      TSTAMP(sx, 7);
       if (pe.f1 >= 0) apply_flip(ch, pe.f1);
       if (pe.f2 >= 0) apply_flip(ch, pe.f2);
-#pragma nounroll
-      for (int pass = 0; pass < 2; ++pass) {
+      TSTAMP(sx, 6);
+      bool rejected = false;
+      {
         Model Mn;
-        refactor(P, ch, Mn);
-        if (Mn.bad) { status = Mn.bad; break; }
-        bool acc = true;
-        if (pass == 0 && (pe.kind == EV_TRY_GE || pe.kind == EV_TRY_LT)) {
-          const double d = (Mn.logp - pe.lfw) - (keep.logp - pe.lrev);
-          if (Mn.logp > -BA_INF) min_margin = fmin(min_margin, fabs(pe.lu - d));
-          acc = (pe.kind == EV_TRY_GE) ? !(pe.lu > d) : (pe.lu < d);
+        refactor(P, ch, Mn, sx);
+        if (Mn.bad) {
+          status = Mn.bad;
+        } else {
+          bool acc = true;
+          if (pe.kind == EV_TRY_GE || pe.kind == EV_TRY_LT) {
+            const double d = (Mn.logp - pe.lfw) - (keep.logp - pe.lrev);
+            if (Mn.logp > -BA_INF) min_margin = fmin(min_margin, fabs(pe.lu - d));
+            acc = (pe.kind == EV_TRY_GE) ? !(pe.lu > d) : (pe.lu < d);
+          }
+          if (acc) {
+            M = Mn;
+            // (the launch's first build is the old model unless make_valid
+            // changed gamma)
+            if (pe.kind != EV_INIT || pe.check_legal) table_valid = false;
+            if (pe.kind != EV_INIT) acc_acc += 1;
+          } else {
+            // rejected: gamma back, and the old factors from the chain's block
+            if (pe.f2 >= 0) apply_flip(ch, pe.f2);
+            if (pe.f1 >= 0) apply_flip(ch, pe.f1);
+            restore_model<NB>(ch);
+            M = keep;
+            rejected = true;
+          }
         }
-        if (acc) {
-          M = Mn;
-          // (a rebuilt-after-reject model is the old one; so is the launch's
-          // first build unless make_valid changed gamma)
-          if (pass == 0 && (pe.kind != EV_INIT || pe.check_legal)) table_valid = false;
-          if (pass == 0 && pe.kind != EV_INIT) acc_acc += 1;
-          break;
-        }
-        // rejected: restore gamma and rebuild its factors
-        if (pe.f2 >= 0) apply_flip(ch, pe.f2);
-        if (pe.f1 >= 0) apply_flip(ch, pe.f1);
       }
       if (status == CHAIN_OK) {
-        publish_model<NB>(ch);
+        TSTAMP(sx, 7);
+        if (!rejected) publish_model<NB>(ch);
+        TSTAMP(sx, 5);
         if (pe.kind == EV_FORCE && !M.pd) status = CHAIN_NOT_PD;
         if (pe.kind == EV_INIT && pe.check_legal &&
             !(M.logp > -BA_INF && M.logp < BA_INF))
@@ -1189,7 +1375,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     if (phase == PH_BEGIN) {
       if (sweep >= nsweeps) break;
       STAMP(7);
-      TSTAMP(sx, 5);
       if (nflips > 0) {
         // remember the sweep's starting point (restored if the chain has to
         // stop inside this sweep for lack of model capacity)
@@ -1200,6 +1385,39 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           if (P.mode) ch.perm[j] = (uint16_t)j;
         }
         pos0 = pos;
+        if (!model_checked && M.logp > -BA_INF && M.logp < BA_INF) model_checked = true;
+        use_table = (P.scan_policy != 0) && (stops_prev <= 1 || P.scan_policy == 2);
+        stops_prev = stops_now;
+        stops_now = 0;
+        if (W > 1 && use_table && table_valid && model_checked && p > 1 && P.scan_policy != 3) {
+          // ---- fork: wave 1 takes the permutation side of the sweep
+          wave_sync();
+          if (lane == 0) {
+            ctl[CT_CMD] = (double)CMD_SHUFFLE_DECIDE;
+            ctl[CT_I0] = 0.0;
+            ctl[CT_LOGP] = M.logp;
+            ctl[CT_NFLIPS] = (double)nflips;
+            ctl[CT_PERMSEL] = (double)perm_sel;
+            ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = pos;
+          }
+          __syncthreads();
+          {  // the shuffled order will be in the other buffer
+            lds_u16 *tmp = ch.perm;
+            ch.perm = ch.perm_alt;
+            ch.perm_alt = tmp;
+            perm_sel ^= 1;
+          }
+          flip_pos = pos + (uint64_t)(p - 1);
+          pos = flip_pos + (uint64_t)nflips;
+          spec = true;
+          spec_status = CHAIN_OK;
+          sigsq_s = sigsq; beta_m_s = beta_m; gprev_s = gprev; kprev_s = kprev;
+          failures_s = failures; beta_valid_s = beta_valid;
+          i0 = 0;
+          phase = PH_SWAP;
+          STAMP(1);
+          continue;
+        }
         // ---- shuffle(indx): cpputil/shuffle.hpp:36-46, in place on the
         // persistent permutation.  Uniform t (t = 0..p-2) belongs to i = p-1-t.
         if (W > 1) {
@@ -1213,9 +1431,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         if (W > 1) __syncthreads(); else wave_sync();
         STAMP(0);
         if (p > 1) { parallel_shuffle(ch, sx); perm_sel ^= 1; }
-        use_table = (P.scan_policy != 0) && (stops_prev <= 1 || P.scan_policy == 2);
-        stops_prev = stops_now;
-        stops_now = 0;
         flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
         pos = flip_pos + (uint64_t)nflips;
         STAMP(1);
@@ -1253,6 +1468,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         // chain state; wave 1 has none), otherwise the master's own.
         DecideResult dr;
         if (W > 1) {
+          if (!have_dr) {
           if (lane == 0) {
             ctl[CT_CMD] = (double)CMD_DECIDE;
             ctl[CT_I0] = (double)i0;
@@ -1263,6 +1479,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
           __syncthreads();
           __syncthreads();
+          }
+          have_dr = false;
           const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * 1;
           dr.spos = (int)sl[SL_F];
           dr.j = (int)sl[SL_J];
@@ -1270,7 +1488,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           dr.logu = sl[SL_LOGU];
           dr.margin = sl[SL_MARGIN];
         } else {
-          decide_walk(ch, key, flip_pos, i0, nflips, M.logp, dr);
+          decide_walk(ch, key, flip_pos, i0, nflips, dr);
         }
         min_margin = fmin(min_margin, dr.margin);
         STAMP(3);
@@ -1377,87 +1595,138 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     }
 
     if (phase == PH_SWAP) {
-      rng.pos = pos;
+      rng.set_pos(pos);
       if (nflips > 0) propose_swap(P, ch, rng, pe, &status);
-      pos = rng.pos;
+      pos = rng.get_pos();
       phase = PH_TAIL;
+      if (spec && (pe.kind != EV_NONE || status != CHAIN_OK)) {
+        // a swap was proposed (or the proposal failed): its evaluation has to
+        // wait for the walk
+        spec_status = status;
+        status = CHAIN_OK;
+        after_join = PH_TAIL;
+        phase = PH_JOIN;
+      }
       STAMP(4);
+      continue;
+    }
+
+    if (phase == PH_JOIN) {
+      __syncthreads();
+      spec = false;
+      const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * 1;
+      if ((int)sl[SL_F] < 0) {
+        // no stop: the sweep's flips are all rejected and what ran ahead stands
+        min_margin = fmin(min_margin, sl[SL_MARGIN]);
+        acc_prop += nflips;
+        status = spec_status;
+        phase = after_join;
+      } else {
+        // roll the tail back and handle the stop
+        pos = flip_pos + (uint64_t)nflips;
+        sigsq = sigsq_s; beta_m = beta_m_s; gprev = gprev_s; kprev = kprev_s;
+        failures = failures_s; beta_valid = beta_valid_s;
+        pe.kind = EV_NONE; pe.f1 = pe.f2 = -1; pe.lfw = pe.lrev = 0.0; pe.check_legal = false;
+        have_dr = true;
+        phase = PH_FLIPS;
+      }
+      STAMP(3);
+      continue;
+    }
+
+    if (phase == PH_COMMIT) {
+      // ---- summaries
+      k = ch.k;
+      gprev = (lane < k) ? (int)ch.g[lane] : 0;
+      kprev = k;
+      kmax = k > kmax ? k : kmax;
+      // inclusion counts and coefficient moments pile up in registers while
+      // the model stands still (lane m <-> variable g_r) and go to HBM when it
+      // moves
+      {
+        const int gnow = (lane < k) ? gprev : -1;
+        if (__any(gnow != g_r)) {
+          if (g_r >= 0 && cnt_r) {
+            const size_t o = (size_t)chain * p + g_r;
+            P.inc_count[o] += cnt_r;
+            P.beta_sum[o] += bsum_r;
+            P.beta_sumsq[o] += bsq_r;
+          }
+          g_r = gnow; cnt_r = 0u; bsum_r = 0.0; bsq_r = 0.0;
+        }
+        if (lane < k) {
+          cnt_r += 1u;
+          if (beta_valid) { bsum_r += beta_m; bsq_r += beta_m * beta_m; }
+        }
+      }
+      acc_sig += sigsq;
+      acc_sig2 += sigsq * sigsq;
+      acc_k += k;
+      if (P.trace_sigsq && trace_at + sweep < P.trace_stride && lane == 0) {
+        const size_t o = (size_t)chain * P.trace_stride + trace_at + sweep;
+        P.trace_sigsq[o] = sigsq;
+        P.trace_logp[o] = M.logp;
+        P.trace_k[o] = (double)k;
+      }
+      ++done;
+      ++sweep;
+      phase = PH_BEGIN;
       continue;
     }
 
     // ---- PH_TAIL: sigma, beta, summaries
     k = ch.k;
-    rng.pos = pos;
+    rng.set_pos(pos);
     // draw_sigma (BregVsSampler.cpp:313-324)
     if (P.draw_sigma) {
       int bad = 0;
       const double DF = (k == 0) ? ch.DF : ((ch.DF - P.prior_df) + P.prior_df);
       const double SS = (k == 0) ? ch.ss0q : ((M.SS - P.prior_ss) + P.prior_ss);
       sigsq = d_draw_variance(rng, DF, SS, P.sigma_max, &bad);
-      if (bad) { status = CHAIN_RNG_BRANCH; break; }
+      if (bad) {
+        if (!spec) { status = CHAIN_RNG_BRANCH; break; }
+        spec_status = CHAIN_RNG_BRANCH; after_join = PH_COMMIT; phase = PH_JOIN;
+        continue;
+      }
     }
-    pos = rng.pos;
+    pos = rng.get_pos();
     STAMP(5);
     // draw_beta (BregVsSampler.cpp:326-351)
     if (P.draw_beta && k > 0) {
       if (!M.pd) {
         ++failures;
-        status = CHAIN_NOT_PD;
-        break;
+        if (!spec) { status = CHAIN_NOT_PD; break; }
+        spec_status = CHAIN_NOT_PD; after_join = PH_COMMIT; phase = PH_JOIN;
+        continue;
       }
       failures = 0;
-      TSTAMP(sx, 7);
       // k standard normals in stream order (distributions/mvn.cpp:114-122),
       // lane m keeps z_m
-      double z = 0.0;
-      for (int m = 0; m < k; ++m) {
-        const double zm = d_norm_rand(rng);
-        if (lane == m) z = zm;
-      }
-      pos = rng.pos;
-      TSTAMP(sx, 3);
+      const double z = draw_normals(rng, k);
+      pos = rng.get_pos();
       // beta = L^{-T}(w + sigma z): chol(V / sigma^2) = L / sigma
       // (SpikeSlabSampler: rmvn_ivar_mt with the sigma-scaled precision itself)
       const double sigma = P.mode ? 1.0 : sqrt(sigsq);
       double y = (lane < k) ? ch.w[lane] + sigma * z : 0.0;
       const double rdm = (lane < k) ? ch.rdv[lane] : 0.0;
+      // column sweep of the back substitution; row i of L is fetched one step
+      // ahead of its use
+      double lrow = (k > 0 && lane < k - 1) ? ch.Lv[bidx(k - 1, lane)] : 0.0;
       for (int i = k - 1; i >= 0; --i) {
-        const double xi = bcast_u(y, i) * bcast_u(rdm, i);
+        const double lcur = lrow;
+        if (i > 0) lrow = (lane < i - 1) ? ch.Lv[bidx(i - 1, lane)] : 0.0;
+        const double xi = bcast_u(y * rdm, i);
         if (lane == i) y = xi;
-        else if (lane < i) y -= ch.Lv[bidx(i, lane)] * xi;
+        else if (lane < i) y -= lcur * xi;
       }
       beta_m = y;
       beta_valid = true;
-      TSTAMP(sx, 4);
     } else if (P.draw_beta) {
       beta_valid = true;  // empty model: all coefficients zero
     }
-    gprev = (lane < k) ? (int)ch.g[lane] : 0;
-    kprev = k;
-    kmax = k > kmax ? k : kmax;
     STAMP(6);
-
-    // summaries
-    if (lane < k) {
-      const size_t o = (size_t)chain * p + ch.g[lane];
-      P.inc_count[o] += 1u;
-      if (beta_valid) {
-        P.beta_sum[o] += beta_m;
-        P.beta_sumsq[o] += beta_m * beta_m;
-      }
-    }
-    acc_sig += sigsq;
-    acc_sig2 += sigsq * sigsq;
-    acc_k += k;
-    if (P.trace_sigsq && trace_at + sweep < P.trace_stride && lane == 0) {
-      const size_t o = (size_t)chain * P.trace_stride + trace_at + sweep;
-      P.trace_sigsq[o] = sigsq;
-      P.trace_logp[o] = M.logp;
-      P.trace_k[o] = (double)k;
-    }
-    ++done;
-    ++sweep;
-    phase = PH_BEGIN;
+    after_join = PH_COMMIT;
+    phase = spec ? PH_JOIN : PH_COMMIT;
   }
 
   // release the helper waves
@@ -1466,6 +1735,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     __syncthreads();
   }
 
+  if (g_r >= 0 && cnt_r) {
+    const size_t o = (size_t)chain * p + g_r;
+    P.inc_count[o] += cnt_r;
+    P.beta_sum[o] += bsum_r;
+    P.beta_sumsq[o] += bsq_r;
+  }
   // ---- write the chain back (an aborted sweep leaves no trace: gamma, the
   // permutation and the stream position go back to the sweep's start; sigma,
   // beta are those of the last complete sweep anyway)
@@ -1509,12 +1784,13 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     a[ACC_ACCEPTS] += acc_acc;
     a[ACC_PROPOSALS] += acc_prop;
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], min_margin);
-#if defined(BA_STAMPS) && (defined(BA_STAMPS2) || defined(BA_STAMPS3))
+#if defined(BA_STAMPS) && defined(BA_STAMPS4)
+    // (phases are wave 1's)
+#elif defined(BA_STAMPS) && (defined(BA_STAMPS2) || defined(BA_STAMPS3))
     SUBSTAMP(sx, 7);
-    TSTAMP(sx, 7);
     for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += sx.ph[i];
 #elif defined(BA_STAMPS)
-    for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += st_ph[i];
+    for (int i = 0; i < 8; ++i) { a[ACC_PHASE0 + i] += st_ph[i]; a[ACC_RESERVED] += st_ph[i]; }
 #endif
   }
 }
@@ -1556,7 +1832,9 @@ __global__ __launch_bounds__(64) void ssvs_logp_kernel(SsvsParams P,
   ch.k = k;
   __syncthreads();
   Model M;
-  refactor(P, ch, M);
+  StampCtx sx;
+  sx.last = 0;
+  refactor(P, ch, M, sx);
   if (lane == 0) {
     out[which] = M.logp;
     status_out[which] = M.bad;
@@ -1574,6 +1852,7 @@ __global__ __launch_bounds__(256) void ssvs_reduce_summaries_kernel(SsvsParams P
   const int p = P.p, j = blockIdx.x, tid = threadIdx.x;
   double a = 0, b = 0, c = 0;
   const bool is_min = (j >= p) && (j - p == ACC_MIN_MARGIN);
+  const bool is_max = (j >= p) && (j - p == ACC_RESERVED);  // diagnostic builds: slowest chain
   if (is_min) a = BA_INF;
   for (int chn = tid; chn < P.chains; chn += 256) {
     if (j < p) {
@@ -1583,14 +1862,14 @@ __global__ __launch_bounds__(256) void ssvs_reduce_summaries_kernel(SsvsParams P
       c += P.beta_sumsq[o];
     } else {
       const double x = P.acc[(size_t)chn * ACC_COUNT + (j - p)];
-      a = is_min ? fmin(a, x) : a + x;
+      a = is_min ? fmin(a, x) : (is_max ? fmax(a, x) : a + x);
     }
   }
   s0[tid] = a; s1[tid] = b; s2[tid] = c;
   __syncthreads();
   for (int w = 128; w >= 1; w >>= 1) {
     if (tid < w) {
-      s0[tid] = is_min ? fmin(s0[tid], s0[tid + w]) : s0[tid] + s0[tid + w];
+      s0[tid] = is_min ? fmin(s0[tid], s0[tid + w]) : (is_max ? fmax(s0[tid], s0[tid + w]) : s0[tid] + s0[tid + w]);
       s1[tid] += s1[tid + w];
       s2[tid] += s2[tid + w];
     }
@@ -1652,6 +1931,39 @@ hipError_t launch_ssvs_logp(hipStream_t stream, const SsvsParams &P,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ssvs_logp_kernel, dim3(ngamma), dim3(WAVE), lay.total,
                      stream, P, gammas, ngamma, out, status_out);
+  return hipGetLastError();
+}
+
+// Device property the shuffle relies on (see parallel_shuffle): same-address
+// LDS exchanges of one wavefront instruction are resolved in ascending lane
+// order.  One wavefront tries 64 target patterns; *bad counts the lanes whose
+// returned value is not that of the nearest lower lane with the same target.
+__global__ __launch_bounds__(64) void lds_exchange_order_kernel(int *bad) {
+  __shared__ uint32_t X[64];
+  const int lane = threadIdx.x;
+  int nbad = 0;
+  for (int c = 0; c < 64; ++c) {
+    X[lane] = 0xFFFFu;
+    __syncthreads();
+    const int key = (int)((((unsigned)lane * 2654435761u) >> 7) + (unsigned)c * 40503u) % (c + 1);
+    const uint32_t old = __hip_atomic_exchange(&X[key], (uint32_t)(lane + 100), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+    unsigned long long mask = ~0ull;
+    for (int b = 0; b < 6; ++b) {
+      const bool bit = (key >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      mask &= bit ? bal : ~bal;
+    }
+    const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+    const uint32_t want = lower ? (uint32_t)(63 - __clzll((long long)lower) + 100) : 0xFFFFu;
+    if (old != want) ++nbad;
+    __syncthreads();
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+hipError_t launch_lds_exchange_order(hipStream_t stream, int *bad_device) {
+  hipLaunchKernelGGL(lds_exchange_order_kernel, dim3(1), dim3(64), 0, stream, bad_device);
   return hipGetLastError();
 }
 

@@ -42,7 +42,7 @@ struct SsvsParams {
   int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
   int32_t waves; // wavefronts per chain (1, 2 or 4)
   int32_t mode;  // 0: BregVsSampler (sigma^2 integrated out); 1: SpikeSlabSampler (given sigma^2)
-  int32_t scan_policy;  // 0 batch mode only, 1 adaptive (table look-ups after quiet sweeps), 2 always the table
+  int32_t scan_policy;  // 0 batch mode only, 1 adaptive (table look-ups after quiet sweeps), 2 always the table, 3 adaptive without the forked quiet sweep (A/B)
   int32_t slab_scales;  // mode 1: slab precision is Omega^{-1} / sigma^2 (MvnGivenScalarSigma)
 
   // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
@@ -94,7 +94,8 @@ struct SsvsParams {
   // factors, their reciprocal diagonals, w, b_g, g) in HBM, laid out by
   // ssvs_scalar_layout(); the proposal evaluation reads it through the scalar
   // cache (s_load) so that factor elements arrive as SGPR operands of the FMAs.
-  // per-chain table of log_model_prob(gamma ^ {j}) for the current model
+  // per-chain table of acceptance thresholds exp(logp(gamma ^ {j}) - logp(gamma))
+  // for the current model
   double *table_lp;             // chains x p
   uint8_t *table_kind;          // chains x p
   int32_t *table_tag;           // chains: capacity the table was built with, 0 = stale
@@ -120,7 +121,7 @@ struct SsvsParams {
 // its solution vector in registers.  kcap is a multiple of 8.
 // doubles first, then 16-bit, then bytes; all offsets in bytes.
 struct SsvsLds {
-  uint32_t Lv, La, rdv, rda, w, bg, ctrl, g, perm0, perm1, oth, last, pred, gam, gam0, total;
+  uint32_t Lv, La, rdv, rda, w, bg, ctrl, g, perm0, perm1, oth, last, pred, gam, gam0, nbr, total;
 };
 
 static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
@@ -140,10 +141,11 @@ static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
   L.perm0 = o; o += pv;
   L.perm1 = o; o += pv;
   L.oth = o;   o += pv;
-  L.last = o;  o += pv;
+  L.last = o;  o += 2 * pv;  // 32-bit entries (LDS exchange)
   L.pred = o;  o += pv;
   L.gam = o;   o += ((uint32_t)p + 15u) & ~15u;
   L.gam0 = o;  o += ((uint32_t)p + 15u) & ~15u;  // gamma at the start of the sweep
+  L.nbr = o;   o += ((uint32_t)p + 15u) & ~15u;  // 1: the variable has partners in the correlation map
   L.total = o;
   return L;
 }

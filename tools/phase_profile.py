@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUBN = os.environ.get("SUBSTAMPS", "0")
 SUB = SUBN != "0"
-os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", {"0": "libboomamd_stamps.so", "1": "libboomamd_stamps2.so", "2": "libboomamd_stamps3.so"}[SUBN])
+os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", {"0": "libboomamd_stamps.so", "1": "libboomamd_stamps2.so", "2": "libboomamd_stamps3.so", "3": "libboomamd_stamps4.so"}[SUBN])
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import time
@@ -30,21 +30,30 @@ eng.set_state(g0)
 eng.sweep(200)
 eng.reset_summaries()
 t0 = time.perf_counter()
-eng.sweep(100)
+NSW = int(os.environ.get("NSWEEP", "100"))
+NL = int(os.environ.get("NLAUNCH", "1"))
+for _ in range(NL):
+    eng.sweep(NSW, sync=False)
+eng.sync()
 dt = time.perf_counter() - t0
 sm = eng.get_summaries()
 ph = sm["phase_cycles"]
 names = ["shuffle uniforms", "shuffle serial", "refactor", "proposal batches",
          "swap", "sigma", "beta", "rest"]
 if SUBN == "2":
-    names = ["shuffle: prev-step rounds", "shuffle: links", "shuffle: walks", "normals",
-             "back substitution", "summaries", "sweep start + uniforms", "everything else"]
+    names = ["event: prior sum", "event: gather V_g A_g", "event: chol A", "event: chol V",
+             "event: w solve", "event: publish", "event: apply_flip", "everything else"]
+elif SUBN == "3":
+    names = ["wave 1: shuffle uniforms", "wave 1: matching rounds", "wave 1: links", "wave 1: walks",
+             "wave 1: table walk", "wave 1: waiting", "wave 1: proposal rounds", "wave 1: other"]
 elif SUB:
-    names = ["batch: uniform+log", "batch: classify", "batch: V gather", "batch: V solve",
+    names = ["batch: index fetch", "batch: classify", "batch: V gather", "batch: V solve",
              "batch: A gather", "batch: A solve", "batch: epilogue", "outside batches"]
 tot = ph.sum()
+if not SUB:
+    print("  per chain: mean %.0f cycles, slowest %.0f cycles (%.2fx)" % (tot / chains, sm["slowest_chain_cycles"], sm["slowest_chain_cycles"] * chains / tot))
 print("waves=%s hint=%s" % (os.environ.get("BOOM_AMD_WAVES","auto"), os.environ.get("KCAP_HINT","0")), end=" "); print("signals %d chains %d: %.1f us per sweep-round, kbar %.2f, accepts/sweep %.3f, proposals/sweep %.1f"
-      % (nsig, chains, dt / 100 * 1e6, sm["k_sum"] / sm["sweeps"], sm["accepts"] / sm["sweeps"],
+      % (nsig, chains, dt / (NSW * NL) * 1e6, sm["k_sum"] / sm["sweeps"], sm["accepts"] / sm["sweeps"],
          sm["proposals"] / sm["sweeps"]))
 for nm, v in zip(names, ph):
     print("  %-26s %6.2f %%   %10.0f cycles/sweep" % (nm, 100 * v / tot, v / sm["sweeps"]))
