@@ -11,14 +11,27 @@
 //     observe_state / observe_data_given_state
 //       (LocalLevelStateModel.cpp:52-58, StateSpaceRegressionModel.cpp:188-200)
 //
-// State dimension 1 (Z = 1, T = 1, RQR = sigma^2_level), so every per-time-step
-// quantity is a scalar.  The recursions are sequential in t: they run as
-// wave-uniform scalar code over chunks of 64 time steps whose inputs sit one per
-// lane (picked with v_readlane, results put back with a lane select), while
-// everything that is independent across t (adjusted observations y - x'beta,
-// v/F, residuals, X'r) is lane-parallel with coalesced reads of the shared
-// column-major design matrix.  The stream of normals is consumed in the
-// reference's order: state error then observation for every t.
+// State dimension 1 (Z = 1, T = 1, RQR = sigma^2_level): every per-time-step
+// quantity is a scalar, and given the gains K_t every recursion of the
+// reference is an affine map x -> A_t x + B_t applied in time order.  The
+// kernel therefore works on the time axis 64 steps at a time, lane = step:
+//   1. y*_t = y_t - x_t'beta            lane-parallel, coalesced X columns
+//   2. the sweep's standard normals     in the reference's stream order (state
+//                                       error, then observation, for every t)
+//   3. P_t, F_t, K_t                    the one truly serial recursion (a
+//                                       Riccati map); it is data independent and
+//                                       stops iterating once P_t repeats bitwise
+//   4. forward: simulated states (prefix sum), and ONE filter on
+//      w_t = y*_t - y+_t: the data filter and the simulation filter share K_t,
+//      so their difference delta_t = a_t - a+_t obeys
+//      delta_{t+1} = (1 - K_t) delta_t + K_t w_t (a wave scan of affine maps)
+//   5. backward: d_{t-1} = e_t / F_t + (1 - K_t) d_t for d = r - r+ (same scan,
+//      lanes reversed)
+//   6. forward: mean correction (prefix sum of q d_{t-1}), state_t, level suf
+//   7. residuals, X'e, e'e             lane-parallel
+// The reference runs the two filters / smoothers separately and subtracts at
+// the end; by linearity the difference recursion gives the same state draw up
+// to rounding (parity tolerance in tests/test_state_space_gpu.py).
 #include <hip/hip_runtime.h>
 
 #include "device_rng.h"
@@ -29,6 +42,13 @@ namespace boom_amd {
 namespace {
 
 constexpr int WAVE = 64;
+
+// diagnostic build (-DBA_KSTAMPS): chain 0 prints its cycles per phase
+#ifdef BA_KSTAMPS
+#define KSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
+#else
+#define KSTAMP(i) do { } while (0)
+#endif
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double x, double fill) {
@@ -57,49 +77,135 @@ __device__ __forceinline__ double wave_sum(double x) {
   return bcast_u(x, 63);
 }
 
-// Sequential reader of standard normals from a Philox stream: every lane
-// evaluates the Kinderman-Ramage transform at its own offset of a 64-uniform
-// window; next() walks the window the way a sequential reader would.
-struct NormalStream {
-  PhiloxKey key;
-  uint64_t pos;  // stream position of the next draw
-  double v;      // this lane's speculative draw (window offset = lane)
-  int used;      // uniforms it consumed
-  int cur;       // window offset of the next draw (>= 64: window exhausted)
-  int lane;
-  __device__ __forceinline__ void init(const PhiloxKey &k, uint64_t p, int l) {
-    key = k; pos = p; lane = l; cur = WAVE; v = 0.0; used = 0;
-  }
-  __device__ __forceinline__ double next() {
-    if (cur >= WAVE) {
-      SeqRng r{key, pos + (uint64_t)lane};
-      v = d_norm_rand(r);
-      used = (int)(r.pos - (pos + (uint64_t)lane));
-      cur = 0;
+// x -> A x + B
+struct Aff { double A, B; };
+__device__ __forceinline__ Aff aff_after(const Aff &later, const Aff &earlier) {
+  Aff r;
+  r.A = later.A * earlier.A;
+  r.B = later.A * earlier.B + later.B;
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Aff aff_dpp(const Aff &f) {
+  Aff r;
+  r.A = dpp_f64<CTRL, ROW_MASK>(f.A, 1.0);  // lanes without a source get the identity
+  r.B = dpp_f64<CTRL, ROW_MASK>(f.B, 0.0);
+  return r;
+}
+// inclusive scan over the wave: lane i ends with f_i o f_{i-1} o ... o f_0
+__device__ __forceinline__ Aff wave_scan(Aff f) {
+  f = aff_after(f, aff_dpp<0x111, 0xf>(f));  // row_shr:1
+  f = aff_after(f, aff_dpp<0x112, 0xf>(f));  // row_shr:2
+  f = aff_after(f, aff_dpp<0x114, 0xf>(f));  // row_shr:4
+  f = aff_after(f, aff_dpp<0x118, 0xf>(f));  // row_shr:8
+  f = aff_after(f, aff_dpp<0x142, 0xa>(f));  // row_bcast:15 into rows 1, 3
+  f = aff_after(f, aff_dpp<0x143, 0xc>(f));  // row_bcast:31 into rows 2, 3
+  return f;
+}
+// inclusive prefix sum, lane order
+__device__ __forceinline__ double wave_prefix_sum(double x) {
+  x += dpp_f64<0x111, 0xf>(x, 0.0);
+  x += dpp_f64<0x112, 0xf>(x, 0.0);
+  x += dpp_f64<0x114, 0xf>(x, 0.0);
+  x += dpp_f64<0x118, 0xf>(x, 0.0);
+  x += dpp_f64<0x142, 0xa>(x, 0.0);
+  x += dpp_f64<0x143, 0xc>(x, 0.0);
+  return x;
+}
+// the value of lane - 1 (lane 0 gets `first`): wave_shr:1
+__device__ __forceinline__ double lane_before(double x, double first) {
+  return dpp_f64<0x138, 0xf>(x, first);
+}
+
+// Kinderman-Ramage (Bmath/snorm.cpp:287-340, the transform of d_norm_rand) on
+// uniforms that sit in LDS, starting at offset o; *used = uniforms consumed, 0
+// if the draw would read past `limit`.
+__device__ __forceinline__ double norm_from_lds(const double *u, int o, int limit, int *used) {
+  const double A = 2.216035867166471;
+  const double C1 = 0.398942280401433, C2 = 0.180025191068563;
+#define BA_KR_G(x) (C1 * exp(-(x) * (x) / 2.0) - C2 * (A - (x)))
+  int pos = o;
+  *used = 0;
+  if (pos + 2 > limit) return 0.0;
+  const double u1 = u[pos++];
+  double u2, u3, tt, z = 0.0;
+  bool done = false;
+  if (u1 < 0.884070402298758) {
+    u2 = u[pos++];
+    z = A * (1.131131635444180 * u1 + u2 - 1);
+    done = true;
+  } else if (u1 >= 0.973310954173898) {
+    while (!done && pos + 2 <= limit) {
+      u2 = u[pos++];
+      u3 = u[pos++];
+      tt = (A * A - 2 * log(u3));
+      if (u2 * u2 < (A * A) / tt) {
+        z = (u1 < 0.986655477086949) ? sqrt(tt) : -sqrt(tt);
+        done = true;
+      }
     }
-    const double z = bcast_u(v, cur);
-    const int adv = bcast_u(used, cur);
-    cur += adv;
-    pos += (uint64_t)adv;
-    return z;
+  } else if (u1 >= 0.958720824790463) {
+    while (!done && pos + 2 <= limit) {
+      u2 = u[pos++];
+      u3 = u[pos++];
+      tt = A - 0.630834801921960 * fmin(u2, u3);
+      if (fmax(u2, u3) <= 0.755591531667601 ||
+          0.034240503750111 * fabs(u2 - u3) <= BA_KR_G(tt)) {
+        z = (u2 < u3) ? tt : -tt;
+        done = true;
+      }
+    }
+  } else if (u1 >= 0.911312780288703) {
+    while (!done && pos + 2 <= limit) {
+      u2 = u[pos++];
+      u3 = u[pos++];
+      tt = 0.479727404222441 + 1.105473661022070 * fmin(u2, u3);
+      if (fmax(u2, u3) <= 0.872834976671790 ||
+          0.049264496373128 * fabs(u2 - u3) <= BA_KR_G(tt)) {
+        z = (u2 < u3) ? tt : -tt;
+        done = true;
+      }
+    }
+  } else {
+    while (!done && pos + 2 <= limit) {
+      u2 = u[pos++];
+      u3 = u[pos++];
+      tt = 0.479727404222441 - 0.595507138015940 * fmin(u2, u3);
+      if (tt < 0.) continue;
+      if (fmax(u2, u3) <= 0.805577924423817 ||
+          0.053377549506886 * fabs(u2 - u3) <= BA_KR_G(tt)) {
+        z = (u2 < u3) ? tt : -tt;
+        done = true;
+      }
+    }
   }
-  // rnorm_mt(mu, sigma): no draw when sigma == 0 (Bmath/rnorm.cpp:63-64)
-  __device__ __forceinline__ double rnorm(double mu, double sigma) {
-    if (sigma == 0.0) return mu;
-    return mu + sigma * next();
-  }
-};
+#undef BA_KR_G
+  if (done) *used = pos - o;
+  return z;
+}
+
+enum : int { NB_START = 512, NB_UNIF = NB_START + 64 };
+enum : int { NR = 32 };  // registers per lane of a time panel
 
 }  // namespace
 
 // grid = chains, block = 64
 __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
                                                               int draw_level) {
+  __shared__ double s_u[NB_UNIF];      // a block of the stream's uniforms
+  __shared__ double s_z[NB_START];     // the normal that starts at each offset
+  __shared__ double s_z2[NB_START];    // ... and the one after it
+  __shared__ uint8_t s_n1[NB_START];   // uniforms the first consumes (0: ran out)
+  __shared__ uint16_t s_n2[NB_START];  // uniforms both consume (0: second ran out)
+  __shared__ uint16_t s_slow[NB_START];  // offsets whose draw leaves the first branch
   const int chain = blockIdx.x, lane = threadIdx.x;
   if (chain >= P.chains) return;
   if (P.status[chain] != CHAIN_OK) return;
   const int T = P.T, p = P.p;
   int status = CHAIN_OK;
+#ifdef BA_KSTAMPS
+  long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
+#endif
 
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
   double level_sigsq = P.level_sigsq[chain];
@@ -125,164 +231,328 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   // ---- impute_state ------------------------------------------------------
   const double sigsq_obs = P.sigsq[chain];
   const double *beta = P.beta + (size_t)chain * p;
-  const uint8_t *gamma = P.gamma + (size_t)chain * p;
-  double *sv = P.scratch + (size_t)chain * P.scratch_stride;  // v  (data filter)
-  double *sF = sv + T;                                        // F
-  double *sK = sF + T;                                        // K
-  double *svs = sK + T;                                       // v  (simulation)
-  double *sst = svs + T;                                      // state draw
-  double *sr = sst + T;                                       // r  (data)
-  double *srs = sr + T;                                       // r  (simulation)
+  double *w0 = P.scratch + (size_t)chain * P.scratch_stride;  // y* -> e/F -> d -> residual
+  double *sF = w0 + T;                                        // F_t
+  double *sK = sF + T;                                        // K_t
+  double *sal = sK + T;                                       // simulated state alpha+_t
+  double *sst = sal + T;                                      // the state draw (SS_STATE_ARRAY)
+  double *szz = sst + T;                                      // the sweep's normals, stream order (2 T)
 
-  // adjusted observations y*_t = y_t - x_t'beta, lane-parallel over t
-  // (StateSpaceRegressionModel.cpp:65-77, 179-181; GlmCoefs::predict is a
-  // dense dot with Beta(), zeros outside gamma)
-  {
-    int nvars = 0;
-    for (int base = 0; base < p; base += WAVE) {
-      const int j = base + lane;
-      nvars += __popcll(__ballot(j < p && gamma[j] != 0));
-    }
-    for (int t0 = 0; t0 < T; t0 += WAVE) {
-      const int t = t0 + lane;
-      double pred = 0.0;
-      if (nvars > 0 && t < T) {
-        for (int j = 0; j < p; ++j) {
-          const double bj = beta[j];
-          if (bj != 0.0) pred += P.X[(size_t)j * T + t] * bj;
-        }
-      }
-      if (t < T) sv[t] = (P.y[t] - pred) / 1;
-    }
-  }
-  __syncthreads();
-
-  // forward pass: variance recursion, data filter, simulation + its filter
   const double q = level_sigsq;
   const double level_sigma = sqrt(level_sigsq);
   const double H = sigsq_obs;  // one observation per time point (n_t = 1)
   const double sqrtH = sqrt(H);
-  NormalStream ns;
-  ns.init(PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], lane);
-  double Pv = P.P0, a = P.a0, as = P.a0, alpha = 0.0;
-  for (int t0 = 0; t0 < T && status == CHAIN_OK; t0 += WAVE) {
-    const int t = t0 + lane;
-    const double yreg = (t < T) ? sv[t] : 0.0;
-    const unsigned long long obsmask = __ballot(t < T && P.observed[t] != 0);
-    double vreg = 0, Freg = 0, Kreg = 0, vsreg = 0, streg = 0;
-    const int nthis = (T - t0 < WAVE) ? (T - t0) : WAVE;
-    for (int i = 0; i < nthis; ++i) {
-      const bool miss = !((obsmask >> i) & 1ull);
-      const double y = bcast_u(yreg, i);
-      // ScalarMarginalDistribution::update
-      const double PZ = Pv;
-      const double F = PZ + H;
-      if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
-      const double K = miss ? 0.0 : PZ / F;
-      const double v = miss ? 0.0 : y - a;
-      if (!miss) a = a + K * v;
-      // simulate_initial_state / simulate_next_state, then
-      // simulate_adjusted_observation
-      if (t0 + i == 0) alpha = ns.rnorm(P.a0, sqrt(P.P0));
-      else alpha = alpha + ns.rnorm(0.0, level_sigma);
-      const double ysim = ns.rnorm(alpha, sqrtH);
-      const double vs = miss ? 0.0 : ysim - as;
-      if (!miss) as = as + K * vs;
-      if (!miss) Pv = Pv + (-1.0) * PZ * K;
-      Pv = Pv + q;
-      if (lane == i) { vreg = v; Freg = F; Kreg = K; vsreg = vs; streg = alpha; }
+  const double sd0 = sqrt(P.P0);
+
+  KSTAMP(0);
+  // ---- 1. adjusted observations y*_t = y_t - x_t'beta
+  // (StateSpaceRegressionModel.cpp:65-77, 179-181; GlmCoefs::predict is a dense
+  // dot with Beta(), zeros outside gamma): included variables in batches of 64,
+  // lane m of a batch holding (j_m, beta_m)
+  // A panel of NR * 64 time steps lives in registers (element i of lane l is
+  // step tb + 64 i + l), so that a variable's column is NR independent loads.
+  for (int tb = 0; tb < T; tb += NR * WAVE) {
+    double pred[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) pred[i] = 0.0;
+    for (int base = 0; base < p; base += WAVE) {
+      const int j = base + lane;
+      const double bj = (j < p) ? beta[j] : 0.0;
+      unsigned long long m = __ballot(bj != 0.0);
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const double b = bcast_u(bj, l);
+        // (branch-free: steps past T read the last row and are never stored)
+        const double *col = P.X + (size_t)(base + l) * T;
+#pragma unroll
+        for (int h = 0; h < NR; h += NR / 2) {
+          double xv[NR / 2];
+#pragma unroll
+          for (int i = 0; i < NR / 2; ++i) {
+            const int t = tb + (h + i) * WAVE + lane;
+            xv[i] = col[t < T ? t : T - 1];
+          }
+#pragma unroll
+          for (int i = 0; i < NR / 2; ++i) pred[h + i] += xv[i] * b;
+        }
+      }
     }
-    if (t < T) { sv[t] = vreg; sF[t] = Freg; sK[t] = Kreg; svs[t] = vsreg; sst[t] = streg; }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int t = tb + i * WAVE + lane;
+      if (t < T) w0[t] = P.y[t] - pred[i];
+    }
+  }
+  __syncthreads();
+  KSTAMP(1);
+  // ---- 2. the standard normals of simulate_forward, in stream order:
+  // t = 0: initial state (if P0 > 0), observation (if sigma_obs > 0);
+  // t >= 1: state error (if sigma_level > 0), observation.  rnorm_mt draws
+  // nothing when its sigma is 0 (Bmath/rnorm.cpp:63-64).
+  const int dI = (sd0 != 0.0), dL = (level_sigma != 0.0), dH = (sqrtH != 0.0);
+  const int nfirst = dI + dH, nper = dL + dH;
+  const int N = nfirst + (T - 1) * nper;
+  uint64_t bpos = P.pos_state[chain];
+  {
+    const PhiloxKey key{P.seed_lo, P.seed_hi, gchain, 2u};
+    int n = 0;
+    double zkeep = 0.0;
+    while (n < N && status == CHAIN_OK) {
+      // uniforms bpos .. bpos + NB_UNIF - 1, both numbers of every Philox block
+      const uint64_t b0 = bpos >> 1;
+      for (int i = 0; i * WAVE < NB_UNIF / 2 + 1; ++i) {
+        const uint64_t blk = b0 + (uint64_t)(i * WAVE + lane);
+        double u0, u1;
+        philox_pair(key, blk, &u0, &u1);
+        const long long o0 = (long long)(2 * blk) - (long long)bpos;
+        if (o0 >= 0 && o0 < NB_UNIF) s_u[o0] = u0;
+        if (o0 + 1 >= 0 && o0 + 1 < NB_UNIF) s_u[o0 + 1] = u1;
+      }
+      __syncthreads();
+      // the draw that would start at every offset, lane-parallel and
+      // speculative: the first Kinderman-Ramage branch (88 % of the draws, two
+      // uniforms, one line) for all of them; the offsets that take another
+      // branch are compacted so that the divergent code runs once per block,
+      // not once per pass
+      int nslow = 0;
+      for (int ob = 0; ob < NB_START; ob += WAVE) {
+        const int o = ob + lane;
+        const double u1 = s_u[o];
+        const bool fast = u1 < 0.884070402298758;
+        if (fast) {
+          s_z[o] = 2.216035867166471 * (1.131131635444180 * u1 + s_u[o + 1] - 1);
+          s_n1[o] = 2;
+        }
+        const unsigned long long sm = __ballot(!fast);
+        if (!fast) s_slow[nslow + __popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)o;
+        nslow += __popcll(sm);
+      }
+      __syncthreads();
+      for (int sb = 0; sb < nslow; sb += WAVE) {
+        if (sb + lane < nslow) {
+          const int o = s_slow[sb + lane];
+          int used;
+          const double z = norm_from_lds(s_u, o, NB_UNIF, &used);
+          s_z[o] = z;
+          s_n1[o] = (uint8_t)used;
+        }
+      }
+      __syncthreads();
+      // ... and the draw after it, so that the walk below makes two per step
+      for (int o = lane; o < NB_START; o += WAVE) {
+        const int u1 = s_n1[o];
+        const int o2 = o + u1;
+        const int u2 = (u1 > 0 && o2 < NB_START) ? (int)s_n1[o2] : 0;
+        s_z2[o] = (u2 > 0) ? s_z[o2] : 0.0;
+        s_n2[o] = (uint16_t)((u2 > 0) ? u1 + u2 : 0);
+      }
+      __syncthreads();
+      // the sequential reader's walk; 64 draws at a time go out coalesced
+      auto emit = [&](double zval) {
+        if (lane == (n & 63)) zkeep = zval;
+        ++n;
+        if ((n & 63) == 0) szz[n - WAVE + lane] = zkeep;
+      };
+      int o = 0;
+      while (n < N && o < NB_START) {
+        const int two = s_n2[o];
+        if (two > 0 && n + 2 <= N) {
+          const double za = s_z[o], zb = s_z2[o];
+          emit(za);
+          emit(zb);
+          o += two;
+        } else {
+          const int one = s_n1[o];
+          if (one == 0) break;
+          emit(s_z[o]);
+          o += one;
+        }
+      }
+      if (o == 0) status = CHAIN_RNG_BRANCH;  // a draw longer than a whole block
+      bpos += (uint64_t)o;
+      __syncthreads();
+    }
+    if ((n & 63) != 0 && lane < (n & 63)) szz[(n & ~63) + lane] = zkeep;
   }
   if (status != CHAIN_OK) {
     if (lane == 0) P.status[chain] = status;
     return;
   }
   __syncthreads();
-
-  // backward pass: fast_disturbance_smooth for both filters
-  double r = 0.0, rs = 0.0;
-  for (int t0 = ((T - 1) / WAVE) * WAVE; t0 >= 0; t0 -= WAVE) {
-    const int t = t0 + lane;
-    const bool in = t < T;
-    const double F = in ? sF[t] : 1.0, K = in ? sK[t] : 0.0;
-    const double u = in ? sv[t] / F : 0.0, us = in ? svs[t] / F : 0.0;
-    double rreg = 0.0, rsreg = 0.0;
-    const int nthis = (T - t0 < WAVE) ? (T - t0) : WAVE;
-    for (int i = nthis - 1; i >= 0; --i) {
-      const double Ki = bcast_u(K, i);
-      const double c = bcast_u(u, i) - Ki * r;
-      const double cs = bcast_u(us, i) - Ki * rs;
-      if (lane == i) { rreg = r; rsreg = rs; }
-      r = r + c;
-      rs = rs + cs;
+  KSTAMP(2);
+  // ---- 3. variance recursion (ScalarMarginalDistribution::update, the part that
+  // does not look at the data): F_t = P_t + H, K_t = P_t / F_t, P_{t+1} = P_t -
+  // P_t K_t + q; a missing observation only adds q.  Wave-uniform serial code,
+  // step i of a chunk parked in lane i; once an observed step maps P to itself
+  // bitwise every later observed step repeats it and whole chunks are filled.
+  {
+    double Pv = P.P0, Fs = 0.0, Ks = 0.0;
+    bool steady = false;
+    for (int t0 = 0; t0 < T && status == CHAIN_OK; t0 += WAVE) {
+      const int t = t0 + lane;
+      const int nthis = (T - t0 < WAVE) ? (T - t0) : WAVE;
+      const unsigned long long inmask = (nthis == WAVE) ? ~0ull : ((1ull << nthis) - 1ull);
+      const unsigned long long obsmask = __ballot(t < T && P.observed[t] != 0);
+      double Freg = Fs, Kreg = Ks;
+      if (!(steady && obsmask == inmask)) {
+        for (int i = 0; i < nthis; ++i) {
+          const bool miss = !((obsmask >> i) & 1ull);
+          const double PZ = Pv;
+          const double F = PZ + H;
+          if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
+          const double K = miss ? 0.0 : PZ / F;
+          if (!miss) Pv = Pv + (-1.0) * PZ * K;
+          Pv = Pv + q;
+          if (lane == i) { Freg = F; Kreg = K; }
+          steady = !miss && (Pv == PZ);
+          Fs = F; Ks = K;
+        }
+      }
+      if (t < T) { sF[t] = Freg; sK[t] = Kreg; }
     }
-    if (in) { sr[t] = rreg; srs[t] = rsreg; }
+  }
+  if (status != CHAIN_OK) {
+    if (lane == 0) P.status[chain] = status;
+    return;
+  }
+
+  KSTAMP(3);
+  // ---- 4. forward: simulate_initial_state / simulate_next_state (alpha+),
+  // simulate_adjusted_observation (y+), and the filter on w = y* - y+
+  {
+    double alpha_in = 0.0, delta_in = 0.0;
+    for (int t0 = 0; t0 < T; t0 += WAVE) {
+      const int t = t0 + lane;
+      const bool in = t < T;
+      // ordinals of this step's normals in the stream
+      const int nb = (t == 0) ? 0 : nfirst + (t - 1) * nper;
+      const bool hasL = in && ((t == 0) ? dI : dL);
+      const double zL = hasL ? szz[nb] : 0.0;
+      const double zH = (in && dH) ? szz[nb + (hasL ? 1 : 0)] : 0.0;
+      // alpha+_0 = rnorm(a0, sqrt(P0)); alpha+_t = alpha+_{t-1} + rnorm(0, sigma_level)
+      const double inc = !in ? 0.0 : ((t == 0) ? P.a0 + sd0 * zL : level_sigma * zL);
+      const double alpha = alpha_in + wave_prefix_sum(inc);
+      const double ysim = alpha + sqrtH * zH;
+      const double w = in ? w0[t] - ysim : 0.0;
+      const double K = in ? sK[t] : 0.0;   // 0 at a missing observation: delta stays
+      Aff f;
+      f.A = 1.0 - K;
+      f.B = K * w;
+      const Aff g = wave_scan(f);
+      const double delta_next = g.A * delta_in + g.B;            // delta_{t+1}
+      const double delta = lane_before(delta_next, delta_in);    // delta_t
+      const bool obs = in && P.observed[t] != 0;
+      if (in) {
+        sal[t] = alpha;
+        w0[t] = obs ? (w - delta) / sF[t] : 0.0;   // (v_t - v+_t) / F_t
+      }
+      alpha_in = bcast_u(alpha, 63);
+      delta_in = bcast_u(delta_next, 63);
+    }
   }
   __syncthreads();
 
-  // forward mean correction + level sufficient statistics (sequential sums in
-  // the reference's order)
-  double mean_sim = P.a0 + P.P0 * rs;
-  double mean_obs = P.a0 + P.P0 * r;
-  double lev_n = 0.0, lev_ss = 0.0, prev_state = 0.0;
-  for (int t0 = 0; t0 < T; t0 += WAVE) {
-    const int t = t0 + lane;
-    const bool in = t < T;
-    const double rprev = (in && t > 0) ? sr[t - 1] : 0.0;
-    const double rsprev = (in && t > 0) ? srs[t - 1] : 0.0;
-    const double st0 = in ? sst[t] : 0.0;
-    double streg = 0.0;
-    const int nthis = (T - t0 < WAVE) ? (T - t0) : WAVE;
-    for (int i = 0; i < nthis; ++i) {
-      if (t0 + i > 0) {
-        mean_sim = mean_sim + q * bcast_u(rsprev, i);
-        mean_obs = mean_obs + q * bcast_u(rprev, i);
-      }
-      const double s = bcast_u(st0, i) + (mean_obs - mean_sim);
-      if (t0 + i > 0) {
-        const double diff = s - prev_state;
-        lev_n += 1.0;
-        lev_ss += diff * diff;
-      }
-      prev_state = s;
-      if (lane == i) streg = s;
+  KSTAMP(4);
+  // ---- 5. backward: fast_disturbance_smooth for d = r - r+:
+  // d_{t-1} = e_t / F_t + (1 - K_t) d_t, d_{T-1} = 0; lane l <-> t0 + 63 - l
+  double d_first;  // d_{-1}
+  {
+    double d_in = 0.0;
+    for (int t0 = ((T - 1) / WAVE) * WAVE; t0 >= 0; t0 -= WAVE) {
+      const int t = t0 + (WAVE - 1 - lane);
+      const bool in = t < T;
+      Aff f;
+      f.A = in ? 1.0 - sK[t] : 1.0;
+      f.B = in ? w0[t] : 0.0;
+      const Aff g = wave_scan(f);
+      const double d_prev = g.A * d_in + g.B;               // d_{t-1}
+      const double d_here = lane_before(d_prev, d_in);      // d_t
+      if (in) w0[t] = d_here;
+      d_in = bcast_u(d_prev, 63);
     }
-    if (in) sst[t] = streg;
+    d_first = d_in;
   }
   __syncthreads();
 
+  KSTAMP(5);
+  // ---- 6. forward: mean correction m_t = E(alpha_t | y) - E(alpha_t | y+) =
+  // P0 d_{-1} + q sum_{s<t} d_s, the state draw alpha+_t + m_t, and the level
+  // model's sufficient statistics (LocalLevelStateModel::observe_state)
+  double lev_ss_part = 0.0;
+  {
+    double m_in = 0.0, st_in = 0.0;
+    for (int t0 = 0; t0 < T; t0 += WAVE) {
+      const int t = t0 + lane;
+      const bool in = t < T;
+      const double inc = !in ? 0.0 : ((t == 0) ? P.P0 * d_first : q * w0[t - 1]);
+      const double m = m_in + wave_prefix_sum(inc);
+      const double st = in ? sal[t] + m : 0.0;
+      const double prev = lane_before(st, st_in);
+      if (in && t > 0) {
+        const double diff = st - prev;
+        lev_ss_part += diff * diff;
+      }
+      if (in) sst[t] = st;
+      m_in = bcast_u(m, 63);
+      st_in = bcast_u(st, 63);
+    }
+  }
+  const double lev_ss = wave_sum(lev_ss_part);
+  const double lev_n = (double)(T - 1);
+  __syncthreads();
+
+  KSTAMP(6);
   // regression sufficient statistics given the state
   // (observe_data_given_state + NeRegSuf::add_mixture_data): residual
   // e_t = y_t - alpha_t on observed t; xty = X'e, yty = e'e, n = #observed
   double part_q = 0.0, part_n = 0.0;
-  for (int t0 = 0; t0 < T; t0 += WAVE) {
-    const int t = t0 + lane;
-    double e = 0.0;
-    if (t < T && P.observed[t]) {
-      e = P.y[t] - sst[t];
-      part_q += e * e;
-      part_n += 1.0;
+  double *xty = P.xty + (size_t)chain * p;
+  for (int tb = 0; tb < T; tb += NR * WAVE) {
+    double e[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int t = tb + i * WAVE + lane;
+      e[i] = 0.0;  // zero where unobserved
+      if (t < T && P.observed[t]) {
+        e[i] = P.y[t] - sst[t];
+        part_q += e[i] * e[i];
+        part_n += 1.0;
+      }
     }
-    if (t < T) sv[t] = e;  // residual, zero where unobserved
+    for (int j = 0; j < p; ++j) {
+      const double *col = P.X + (size_t)j * T;
+      double acc = 0.0;
+      // branch-free (e is 0 past T), the loads of half a panel in flight together
+#pragma unroll
+      for (int h = 0; h < NR; h += NR / 2) {
+        double xv[NR / 2];
+#pragma unroll
+        for (int i = 0; i < NR / 2; ++i) {
+          const int t = tb + (h + i) * WAVE + lane;
+          xv[i] = col[t < T ? t : T - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NR / 2; ++i) acc += xv[i] * e[h + i];
+      }
+      const double tot = wave_sum(acc);
+      if (lane == 0) xty[j] = (tb == 0) ? tot : xty[j] + tot;
+    }
   }
   const double yty = wave_sum(part_q);
   const double nobs = wave_sum(part_n);
-  __syncthreads();
-  double *xty = P.xty + (size_t)chain * p;
-  for (int j = 0; j < p; ++j) {
-    const double *col = P.X + (size_t)j * T;
-    double acc = 0.0;
-    for (int t = lane; t < T; t += WAVE) acc += col[t] * sv[t];
-    const double tot = wave_sum(acc);
-    if (lane == 0) xty[j] = tot;
-  }
   if (lane == 0) {
     P.yty[chain] = yty;
     P.nobs[chain] = nobs;
     P.level_n[chain] = lev_n;
     P.level_sumsq[chain] = lev_ss;
-    P.pos_state[chain] = ns.pos;
+    P.pos_state[chain] = bpos;
+#ifdef BA_KSTAMPS
+    KSTAMP(7);
+    if (chain == 0 && draw_level)
+      printf("kalman phases (cycles): level %lld ystar %lld normals %lld riccati %lld forward %lld backward %lld correction %lld suf %lld\n",
+             kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
+#endif
     P.status[chain] = status;
   }
 }
