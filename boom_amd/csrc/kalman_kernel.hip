@@ -102,6 +102,34 @@ __device__ __forceinline__ Aff wave_scan(Aff f) {
   f = aff_after(f, aff_dpp<0x143, 0xc>(f));  // row_bcast:31 into rows 2, 3
   return f;
 }
+// x -> (a x + b) / (c x + d)
+struct Mob { double a, b, c, d; };
+__device__ __forceinline__ Mob mob_after(const Mob &l, const Mob &e) {
+  Mob r;
+  r.a = l.a * e.a + l.b * e.c;
+  r.b = l.a * e.b + l.b * e.d;
+  r.c = l.c * e.a + l.d * e.c;
+  r.d = l.c * e.b + l.d * e.d;
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Mob mob_dpp(const Mob &f) {
+  Mob r;
+  r.a = dpp_f64<CTRL, ROW_MASK>(f.a, 1.0);
+  r.b = dpp_f64<CTRL, ROW_MASK>(f.b, 0.0);
+  r.c = dpp_f64<CTRL, ROW_MASK>(f.c, 0.0);
+  r.d = dpp_f64<CTRL, ROW_MASK>(f.d, 1.0);
+  return r;
+}
+__device__ __forceinline__ Mob wave_scan(Mob f) {
+  f = mob_after(f, mob_dpp<0x111, 0xf>(f));
+  f = mob_after(f, mob_dpp<0x112, 0xf>(f));
+  f = mob_after(f, mob_dpp<0x114, 0xf>(f));
+  f = mob_after(f, mob_dpp<0x118, 0xf>(f));
+  f = mob_after(f, mob_dpp<0x142, 0xa>(f));
+  f = mob_after(f, mob_dpp<0x143, 0xc>(f));
+  return f;
+}
 // inclusive prefix sum, lane order
 __device__ __forceinline__ double wave_prefix_sum(double x) {
   x += dpp_f64<0x111, 0xf>(x, 0.0);
@@ -185,6 +213,7 @@ __device__ __forceinline__ double norm_from_lds(const double *u, int o, int limi
 }
 
 enum : int { NB_START = 512, NB_UNIF = NB_START + 64 };
+enum : int { NLEV = 8, NORD = NB_START / 2 / WAVE, JT = 0xFFFF };  // <= 256 draws per block
 enum : int { NR = 32 };  // registers per lane of a time panel
 
 }  // namespace
@@ -194,9 +223,8 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
                                                               int draw_level) {
   __shared__ double s_u[NB_UNIF];      // a block of the stream's uniforms
   __shared__ double s_z[NB_START];     // the normal that starts at each offset
-  __shared__ double s_z2[NB_START];    // ... and the one after it
   __shared__ uint8_t s_n1[NB_START];   // uniforms the first consumes (0: ran out)
-  __shared__ uint16_t s_n2[NB_START];  // uniforms both consume (0: second ran out)
+  __shared__ uint16_t s_j[NLEV][NB_START];  // jump tables of the stream walk
   __shared__ uint16_t s_slow[NB_START];  // offsets whose draw leaves the first branch
   const int chain = blockIdx.x, lane = threadIdx.x;
   if (chain >= P.chains) return;
@@ -232,7 +260,7 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   const double sigsq_obs = P.sigsq[chain];
   const double *beta = P.beta + (size_t)chain * p;
   double *w0 = P.scratch + (size_t)chain * P.scratch_stride;  // y* -> e/F -> d -> residual
-  double *sF = w0 + T;                                        // F_t
+  double *sF = w0 + T;                                        // (unused)
   double *sK = sF + T;                                        // K_t
   double *sal = sK + T;                                       // simulated state alpha+_t
   double *sst = sal + T;                                      // the state draw (SS_STATE_ARRAY)
@@ -297,7 +325,6 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   {
     const PhiloxKey key{P.seed_lo, P.seed_hi, gchain, 2u};
     int n = 0;
-    double zkeep = 0.0;
     while (n < N && status == CHAIN_OK) {
       // uniforms bpos .. bpos + NB_UNIF - 1, both numbers of every Philox block
       const uint64_t b0 = bpos >> 1;
@@ -339,41 +366,59 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
         }
       }
       __syncthreads();
-      // ... and the draw after it, so that the walk below makes two per step
+      // The sequential reader's walk 0 -> 0 + used(0) -> ... without walking:
+      // jump tables J_k[o] = offset after 2^k draws from o (binary lifting), then
+      // draw number r of the block starts where the bits of r lead from 0.
       for (int o = lane; o < NB_START; o += WAVE) {
         const int u1 = s_n1[o];
-        const int o2 = o + u1;
-        const int u2 = (u1 > 0 && o2 < NB_START) ? (int)s_n1[o2] : 0;
-        s_z2[o] = (u2 > 0) ? s_z[o2] : 0.0;
-        s_n2[o] = (uint16_t)((u2 > 0) ? u1 + u2 : 0);
+        s_j[0][o] = (uint16_t)(u1 ? o + u1 : JT);
       }
       __syncthreads();
-      // the sequential reader's walk; 64 draws at a time go out coalesced
-      auto emit = [&](double zval) {
-        if (lane == (n & 63)) zkeep = zval;
-        ++n;
-        if ((n & 63) == 0) szz[n - WAVE + lane] = zkeep;
-      };
-      int o = 0;
-      while (n < N && o < NB_START) {
-        const int two = s_n2[o];
-        if (two > 0 && n + 2 <= N) {
-          const double za = s_z[o], zb = s_z2[o];
-          emit(za);
-          emit(zb);
-          o += two;
-        } else {
-          const int one = s_n1[o];
-          if (one == 0) break;
-          emit(s_z[o]);
-          o += one;
+      for (int k = 1; k < NLEV; ++k) {
+        for (int o = lane; o < NB_START; o += WAVE) {
+          const int a1 = s_j[k - 1][o];
+          s_j[k][o] = (uint16_t)((a1 < NB_START) ? (int)s_j[k - 1][a1] : JT);
+        }
+        __syncthreads();
+      }
+      const int want = N - n;
+      int m = 0, o = 0;
+      {
+        int node[NORD];
+        bool ok[NORD];
+#pragma unroll
+        for (int i = 0; i < NORD; ++i) node[i] = 0;
+#pragma unroll
+        for (int k = 0; k < NLEV; ++k) {
+#pragma unroll
+          for (int i = 0; i < NORD; ++i) {
+            const int r = lane + i * WAVE;
+            const int nx = s_j[k][node[i] < NB_START ? node[i] : 0];
+            if ((r >> k) & 1) node[i] = (node[i] < NB_START) ? nx : JT;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NORD; ++i) {
+          const int r = lane + i * WAVE;
+          const int u1 = s_n1[node[i] < NB_START ? node[i] : 0];
+          ok[i] = node[i] < NB_START && u1 > 0 && r < want;
+          if (ok[i]) szz[n + r] = s_z[node[i]];
+          m += __popcll(__ballot(ok[i]));
+          node[i] = ok[i] ? node[i] + u1 : 0;  // where the draw after this one starts
+        }
+        // the block's draws are numbers 0 .. m-1; the next block starts after the last
+        if (m > 0) {
+          const int li = (m - 1) >> 6, ll = (m - 1) & 63;
+#pragma unroll
+          for (int i = 0; i < NORD; ++i)
+            if (i == li) o = __builtin_amdgcn_readlane(node[i], ll);
         }
       }
-      if (o == 0) status = CHAIN_RNG_BRANCH;  // a draw longer than a whole block
+      n += m;
+      if (m == 0) status = CHAIN_RNG_BRANCH;  // a draw longer than a whole block
       bpos += (uint64_t)o;
       __syncthreads();
     }
-    if ((n & 63) != 0 && lane < (n & 63)) szz[(n & ~63) + lane] = zkeep;
   }
   if (status != CHAIN_OK) {
     if (lane == 0) P.status[chain] = status;
@@ -381,50 +426,55 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   }
   __syncthreads();
   KSTAMP(2);
-  // ---- 3. variance recursion (ScalarMarginalDistribution::update, the part that
-  // does not look at the data): F_t = P_t + H, K_t = P_t / F_t, P_{t+1} = P_t -
-  // P_t K_t + q; a missing observation only adds q.  Wave-uniform serial code,
-  // step i of a chunk parked in lane i; once an observed step maps P to itself
-  // bitwise every later observed step repeats it and whole chunks are filled.
-  {
-    double Pv = P.P0, Fs = 0.0, Ks = 0.0;
-    bool steady = false;
-    for (int t0 = 0; t0 < T && status == CHAIN_OK; t0 += WAVE) {
-      const int t = t0 + lane;
-      const int nthis = (T - t0 < WAVE) ? (T - t0) : WAVE;
-      const unsigned long long inmask = (nthis == WAVE) ? ~0ull : ((1ull << nthis) - 1ull);
-      const unsigned long long obsmask = __ballot(t < T && P.observed[t] != 0);
-      double Freg = Fs, Kreg = Ks;
-      if (!(steady && obsmask == inmask)) {
-        for (int i = 0; i < nthis; ++i) {
-          const bool miss = !((obsmask >> i) & 1ull);
-          const double PZ = Pv;
-          const double F = PZ + H;
-          if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
-          const double K = miss ? 0.0 : PZ / F;
-          if (!miss) Pv = Pv + (-1.0) * PZ * K;
-          Pv = Pv + q;
-          if (lane == i) { Freg = F; Kreg = K; }
-          steady = !miss && (Pv == PZ);
-          Fs = F; Ks = K;
-        }
-      }
-      if (t < T) { sF[t] = Freg; sK[t] = Kreg; }
-    }
-  }
-  if (status != CHAIN_OK) {
-    if (lane == 0) P.status[chain] = status;
-    return;
-  }
-
+  // ---- 3 + 4. forward pass over chunks of 64 steps.
+  // Variances (ScalarMarginalDistribution::update, the part that does not look
+  // at the data): P_{t+1} = P_t - P_t^2 / (P_t + H) + q at an observed step,
+  // P_t + q at a missing one.  In units of H (u = P / H, r = q / H) that is the
+  // Moebius map u -> ((1 + r) u + r) / (u + 1), resp. u + r, so its composition
+  // over a chunk is a scan of 2 x 2 matrices (divided by 1 + r: determinant 1,
+  // entries <= 1, spectral radius within [1, 1.34], no over- or underflow)
+  // applied to the chunk's incoming u.  Then F_t = H (u_t + 1), K_t = u_t /
+  // (u_t + 1); simulate_initial_state / simulate_next_state
+  // (alpha+), simulate_adjusted_observation (y+), and the filter on w = y* - y+.
   KSTAMP(3);
-  // ---- 4. forward: simulate_initial_state / simulate_next_state (alpha+),
-  // simulate_adjusted_observation (y+), and the filter on w = y* - y+
   {
-    double alpha_in = 0.0, delta_in = 0.0;
+    const bool moebius = H > 0.0;  // (H == 0: the plain recursion, wave-uniform)
+    const double r = moebius ? q / H : 0.0, s1 = 1.0 / (1.0 + r);
+    double P_in = P.P0, alpha_in = 0.0, delta_in = 0.0;
     for (int t0 = 0; t0 < T; t0 += WAVE) {
       const int t = t0 + lane;
       const bool in = t < T;
+      const bool obs = in && P.observed[t] != 0;
+      double F, K, P_next;
+      if (moebius) {
+        Mob mt;
+        mt.a = obs ? 1.0 : 1.0;
+        mt.b = obs ? r * s1 : (in ? r : 0.0);
+        mt.c = obs ? s1 : 0.0;
+        mt.d = obs ? s1 : 1.0;
+        const Mob g = wave_scan(mt);
+        const double u_in = P_in / H;
+        const double u_next = (g.a * u_in + g.b) / (g.c * u_in + g.d);  // u_{t+1}
+        const double u = lane_before(u_next, u_in);                     // u_t
+        F = H * (u + 1.0);
+        K = obs ? u / (u + 1.0) : 0.0;   // 0 at a missing observation: delta stays
+        P_next = u_next * H;
+      } else {
+        const unsigned long long obsmask = __ballot(obs);
+        const int nthis = (T - t0 < WAVE) ? (T - t0) : WAVE;
+        double Pv = P_in;
+        F = 1.0; K = 0.0;
+        for (int i = 0; i < nthis; ++i) {
+          const bool miss = !((obsmask >> i) & 1ull);
+          const double PZ = Pv, Fi = PZ + H;
+          const double Ki = miss ? 0.0 : PZ / Fi;
+          if (!miss) Pv = Pv + (-1.0) * PZ * Ki;
+          Pv = Pv + q;
+          if (lane == i) { F = Fi; K = Ki; }
+        }
+        P_next = Pv;  // (wave-uniform; lane 63's copy is the carry)
+      }
+      if (__any(in && !(F > 0.0))) { status = CHAIN_FORECAST_VARIANCE; break; }
       // ordinals of this step's normals in the stream
       const int nb = (t == 0) ? 0 : nfirst + (t - 1) * nper;
       const bool hasL = in && ((t == 0) ? dI : dL);
@@ -435,21 +485,25 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
       const double alpha = alpha_in + wave_prefix_sum(inc);
       const double ysim = alpha + sqrtH * zH;
       const double w = in ? w0[t] - ysim : 0.0;
-      const double K = in ? sK[t] : 0.0;   // 0 at a missing observation: delta stays
       Aff f;
       f.A = 1.0 - K;
       f.B = K * w;
-      const Aff g = wave_scan(f);
-      const double delta_next = g.A * delta_in + g.B;            // delta_{t+1}
+      const Aff ga = wave_scan(f);
+      const double delta_next = ga.A * delta_in + ga.B;          // delta_{t+1}
       const double delta = lane_before(delta_next, delta_in);    // delta_t
-      const bool obs = in && P.observed[t] != 0;
       if (in) {
         sal[t] = alpha;
-        w0[t] = obs ? (w - delta) / sF[t] : 0.0;   // (v_t - v+_t) / F_t
+        sK[t] = K;
+        w0[t] = obs ? (w - delta) / F : 0.0;   // (v_t - v+_t) / F_t
       }
+      P_in = bcast_u(P_next, 63);
       alpha_in = bcast_u(alpha, 63);
       delta_in = bcast_u(delta_next, 63);
     }
+  }
+  if (status != CHAIN_OK) {
+    if (lane == 0) P.status[chain] = status;
+    return;
   }
   __syncthreads();
 
@@ -507,7 +561,6 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   // (observe_data_given_state + NeRegSuf::add_mixture_data): residual
   // e_t = y_t - alpha_t on observed t; xty = X'e, yty = e'e, n = #observed
   double part_q = 0.0, part_n = 0.0;
-  double *xty = P.xty + (size_t)chain * p;
   for (int tb = 0; tb < T; tb += NR * WAVE) {
     double e[NR];
 #pragma unroll
@@ -520,23 +573,10 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
         part_n += 1.0;
       }
     }
-    for (int j = 0; j < p; ++j) {
-      const double *col = P.X + (size_t)j * T;
-      double acc = 0.0;
-      // branch-free (e is 0 past T), the loads of half a panel in flight together
 #pragma unroll
-      for (int h = 0; h < NR; h += NR / 2) {
-        double xv[NR / 2];
-#pragma unroll
-        for (int i = 0; i < NR / 2; ++i) {
-          const int t = tb + (h + i) * WAVE + lane;
-          xv[i] = col[t < T ? t : T - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < NR / 2; ++i) acc += xv[i] * e[h + i];
-      }
-      const double tot = wave_sum(acc);
-      if (lane == 0) xty[j] = (tb == 0) ? tot : xty[j] + tot;
+    for (int i = 0; i < NR; ++i) {
+      const int t = tb + i * WAVE + lane;
+      if (t < T) w0[t] = e[i];  // X'e for all chains is one GEMM after this kernel
     }
   }
   const double yty = wave_sum(part_q);
@@ -557,11 +597,20 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   }
 }
 
+hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
+                           const double *B, int64_t ldb, int N, int K, double *C, int ldc);
+
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level) {
   hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chains), dim3(WAVE), 0,
                      stream, P, draw_level);
-  return hipGetLastError();
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  // xty[chain, j] = x_j' e_chain: residual series are array 0 of every chain's
+  // scratch block (zero where unobserved, and for a chain in error the previous
+  // sweep's -- its status stops it anyway)
+  return launch_atb_mfma(stream, P.scratch, P.scratch_stride, P.chains, P.X, (int64_t)P.T, P.p,
+                         P.T, P.xty, P.p);
 }
 
 }  // namespace boom_amd

@@ -137,7 +137,67 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const double *__restric
   }
 }
 
+// C = A'B for two matrices stored as K-contiguous columns (A: K x M, column c at
+// A + c lda; B: K x N, column j at B + j ldb), C row-major M x N.  This is the
+// regression half of observe_data_given_state for all chains at once
+// (StateSpaceRegressionModel.cpp:188-200): A = the chains' residual series
+// (one column per chain), B = the design matrix, C[chain, j] = x_j'e_chain --
+// the design matrix is read once per 16 chains instead of once per chain.
+// One wavefront per 16 x 16 tile of C; MFMA step s of an 8-row slab uses rows
+// k0 + 2 (l >> 4) + s, so that a lane's two operands per matrix are adjacent in
+// memory.  The order of the k summation is fixed: bitwise reproducible.
+__global__ __launch_bounds__(64) void atb_mfma_kernel(const double *__restrict__ A,
+                                                      int64_t lda, int M,
+                                                      const double *__restrict__ B,
+                                                      int64_t ldb, int N, int K,
+                                                      double *__restrict__ C, int ldc) {
+  const int lane = threadIdx.x;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int fc = lane & 15, fr = lane >> 4;
+  const bool ia = (i0 + fc) < M, jb = (j0 + fc) < N;
+  const double *pa = A + (int64_t)(ia ? i0 + fc : 0) * lda + 2 * fr;
+  const double *pb = B + (int64_t)(jb ? j0 + fc : 0) * ldb + 2 * fr;
+  double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+  constexpr int UN = 4;  // slabs in flight
+  int k0 = 0;
+  for (; k0 + 8 * UN <= K; k0 += 8 * UN) {
+    double a0[UN], a1[UN], b0[UN], b1[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      a0[u] = pa[k0 + 8 * u];
+      a1[u] = pa[k0 + 8 * u + 1];
+      b0[u] = pb[k0 + 8 * u];
+      b1[u] = pb[k0 + 8 * u + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ia ? a0[u] : 0.0, jb ? b0[u] : 0.0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ia ? a1[u] : 0.0, jb ? b1[u] : 0.0, acc, 0, 0, 0);
+    }
+  }
+  for (; k0 < K; k0 += 8) {
+    const int ka = k0 + 2 * fr;
+    const double a0 = (ia && ka < K) ? pa[k0] : 0.0, a1 = (ia && ka + 1 < K) ? pa[k0 + 1] : 0.0;
+    const double b0 = (jb && ka < K) ? pb[k0] : 0.0, b1 = (jb && ka + 1 < K) ? pb[k0 + 1] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+  }
+  // register q of lane l holds row (l >> 4) + 4 q, column l & 15
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = i0 + fr + 4 * q, j = j0 + fc;
+    if (i < M && j < N) C[(int64_t)i * ldc + j] = acc[q];
+  }
+}
+
 }  // namespace
+
+hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
+                           const double *B, int64_t ldb, int N, int K, double *C, int ldc) {
+  hipLaunchKernelGGL(atb_mfma_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, stream,
+                     A, lda, M, B, ldb, N, K, C, ldc);
+  return hipGetLastError();
+}
 
 int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        const double *y, double *xtx, double *xty,
