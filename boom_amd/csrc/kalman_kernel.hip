@@ -148,7 +148,8 @@ __device__ __forceinline__ double lane_before(double x, double first) {
 // Kinderman-Ramage (Bmath/snorm.cpp:287-340, the transform of d_norm_rand) on
 // uniforms that sit in LDS, starting at offset o; *used = uniforms consumed, 0
 // if the draw would read past `limit`.
-__device__ __forceinline__ double norm_from_lds(const double *u, int o, int limit, int *used) {
+__device__ __forceinline__ double norm_from_lds(const __attribute__((address_space(3))) double *u, int o,
+                                             int limit, int *used) {
   const double A = 2.216035867166471;
   const double C1 = 0.398942280401433, C2 = 0.180025191068563;
 #define BA_KR_G(x) (C1 * exp(-(x) * (x) / 2.0) - C2 * (A - (x)))
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   const int T = P.T, p = P.p;
   int status = CHAIN_OK;
 #ifdef BA_KSTAMPS
-  long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
+  long long kph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
 #endif
 
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
         if (o0 + 1 >= 0 && o0 + 1 < NB_UNIF) s_u[o0 + 1] = u1;
       }
       __syncthreads();
+      KSTAMP(2);
       // the draw that would start at every offset, lane-parallel and
       // speculative: the first Kinderman-Ramage branch (88 % of the draws, two
       // uniforms, one line) for all of them; the offsets that take another
@@ -356,16 +358,18 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
         nslow += __popcll(sm);
       }
       __syncthreads();
+      KSTAMP(8);
       for (int sb = 0; sb < nslow; sb += WAVE) {
         if (sb + lane < nslow) {
           const int o = s_slow[sb + lane];
           int used;
-          const double z = norm_from_lds(s_u, o, NB_UNIF, &used);
+          const double z = norm_from_lds((const __attribute__((address_space(3))) double *)s_u, o, NB_UNIF, &used);
           s_z[o] = z;
           s_n1[o] = (uint8_t)used;
         }
       }
       __syncthreads();
+      KSTAMP(9);
       // The sequential reader's walk 0 -> 0 + used(0) -> ... without walking:
       // jump tables J_k[o] = offset after 2^k draws from o (binary lifting), then
       // draw number r of the block starts where the bits of r lead from 0.
@@ -375,12 +379,18 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
       }
       __syncthreads();
       for (int k = 1; k < NLEV; ++k) {
-        for (int o = lane; o < NB_START; o += WAVE) {
-          const int a1 = s_j[k - 1][o];
-          s_j[k][o] = (uint16_t)((a1 < NB_START) ? (int)s_j[k - 1][a1] : JT);
-        }
+        // (a lane's NB_START / 64 entries side by side: two LDS round trips per level)
+        int a1[NB_START / WAVE], a2[NB_START / WAVE];
+#pragma unroll
+        for (int i = 0; i < NB_START / WAVE; ++i) a1[i] = s_j[k - 1][lane + i * WAVE];
+#pragma unroll
+        for (int i = 0; i < NB_START / WAVE; ++i) a2[i] = s_j[k - 1][a1[i] < NB_START ? a1[i] : 0];
+#pragma unroll
+        for (int i = 0; i < NB_START / WAVE; ++i)
+          s_j[k][lane + i * WAVE] = (uint16_t)((a1[i] < NB_START) ? a2[i] : JT);
         __syncthreads();
       }
+      KSTAMP(10);
       const int want = N - n;
       int m = 0, o = 0;
       {
@@ -390,21 +400,30 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
         for (int i = 0; i < NORD; ++i) node[i] = 0;
 #pragma unroll
         for (int k = 0; k < NLEV; ++k) {
+          int nx[NORD];
+#pragma unroll
+          for (int i = 0; i < NORD; ++i) nx[i] = s_j[k][node[i] < NB_START ? node[i] : 0];
 #pragma unroll
           for (int i = 0; i < NORD; ++i) {
             const int r = lane + i * WAVE;
-            const int nx = s_j[k][node[i] < NB_START ? node[i] : 0];
-            if ((r >> k) & 1) node[i] = (node[i] < NB_START) ? nx : JT;
+            if ((r >> k) & 1) node[i] = (node[i] < NB_START) ? nx[i] : JT;
           }
+        }
+        int u1[NORD];
+        double zr[NORD];
+#pragma unroll
+        for (int i = 0; i < NORD; ++i) {
+          const int nd = node[i] < NB_START ? node[i] : 0;
+          u1[i] = s_n1[nd];
+          zr[i] = s_z[nd];
         }
 #pragma unroll
         for (int i = 0; i < NORD; ++i) {
           const int r = lane + i * WAVE;
-          const int u1 = s_n1[node[i] < NB_START ? node[i] : 0];
-          ok[i] = node[i] < NB_START && u1 > 0 && r < want;
-          if (ok[i]) szz[n + r] = s_z[node[i]];
+          ok[i] = node[i] < NB_START && u1[i] > 0 && r < want;
+          if (ok[i]) szz[n + r] = zr[i];
           m += __popcll(__ballot(ok[i]));
-          node[i] = ok[i] ? node[i] + u1 : 0;  // where the draw after this one starts
+          node[i] = ok[i] ? node[i] + u1[i] : 0;  // where the draw after this one starts
         }
         // the block's draws are numbers 0 .. m-1; the next block starts after the last
         if (m > 0) {
@@ -414,6 +433,7 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
             if (i == li) o = __builtin_amdgcn_readlane(node[i], ll);
         }
       }
+      KSTAMP(11);
       n += m;
       if (m == 0) status = CHAIN_RNG_BRANCH;  // a draw longer than a whole block
       bpos += (uint64_t)o;
@@ -590,8 +610,8 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
 #ifdef BA_KSTAMPS
     KSTAMP(7);
     if (chain == 0 && draw_level)
-      printf("kalman phases (cycles): level %lld ystar %lld normals %lld riccati %lld forward %lld backward %lld correction %lld suf %lld\n",
-             kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
+      printf("kalman phases (cycles): level %lld ystar %lld | normals: philox %lld fast %lld slow %lld tables %lld lookup %lld | forward %lld backward %lld correction %lld suf %lld\n",
+             kph[0], kph[1], kph[2], kph[8], kph[9], kph[10], kph[11], kph[3] + kph[4], kph[5], kph[6], kph[7]);
 #endif
     P.status[chain] = status;
   }

@@ -10,7 +10,7 @@ from cases import bsts_priors, state_space_data
 T, p, nsig, chains = 2000, 100, 5, 1024
 X, y, btrue, _ = state_space_data(T, p, nsig, seed=8675309)
 prior, ss, sig_up = bsts_priors(X, y, 5)
-eng = boom_amd.Engine(chains, seed=4)
+eng = boom_amd.Engine(chains, seed=4, max_model_size_hint=int(os.environ.get("KCAP_HINT", "0")))
 eng.ss_set_data(y, X, None)
 eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"], sigma_upper_limit=sig_up)
 eng.ss_set_local_level(ss["level_df"], ss["level_sigma_guess"], ss["level_sigma_upper_limit"],
