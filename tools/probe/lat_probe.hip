@@ -79,6 +79,20 @@ __global__ void fma_chain(int steps, long long *out) {
   if (threadIdx.x == 0) { out[blockIdx.x * 4] = t1 - t0; out[blockIdx.x * 4 + 1] = t3 - t2; out[blockIdx.x * 4 + 2] = (long long)(x + z) + s; }
 }
 
+__global__ void barrier_probe(int steps, long long *out) {
+  __shared__ double slot[8];
+  long long t0 = __builtin_readcyclecounter();
+  double x = threadIdx.x;
+  for (int i = 0; i < steps; ++i) {
+    if (threadIdx.x == 0) slot[0] = x;
+    __syncthreads();
+    x += slot[0];
+    __syncthreads();
+  }
+  long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0; out[blockIdx.x * 2 + 1] = (long long)x; }
+}
+
 int main() {
   long long *dout; CK(hipMalloc(&dout, 1 << 20));
   std::vector<long long> h(4096);
@@ -126,6 +140,12 @@ int main() {
       double sum = 0; for (int b = 0; b < 1024; ++b) sum += h[b * 2];
       printf("burst of %2d loads/lane from a 2 MB matrix, %d waves, %s: %.0f clocks per burst (incl. 16 dependent adds)\n", nl, nb, co ? "coalesced rows" : "scattered     ", sum / 1024 / 200);
     }
+  }
+  for (int nt : {64, 128, 256}) {
+    barrier_probe<<<1024, nt>>>(1000, dout); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h.data(), dout, 1024 * 16, hipMemcpyDeviceToHost));
+    double sum = 0; for (int b = 0; b < 1024; ++b) sum += h[b * 2];
+    printf("write + barrier + read + barrier, %d threads per workgroup: %.0f clocks per pair of barriers\n", nt, sum / 1024 / 1000);
   }
   lds_chase<<<blocks, 64>>>(2000, dout); CK(hipDeviceSynchronize());
   CK(hipMemcpy(h.data(), dout, 16, hipMemcpyDeviceToHost));
