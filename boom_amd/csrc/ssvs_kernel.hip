@@ -920,7 +920,7 @@ enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2, CMD_DECIDE = 3, CMD_SHUFF
 enum : int { CT_CMD = 0, CT_K = 1, CT_I0 = 2, CT_LOGP = 3, CT_LP = 4, CT_LDV = 5,
              CT_LDA = 6, CT_Q = 7, CT_C = 8, CT_NFLIPS = 9, CT_POS = 10, CT_PERMSEL = 12,
              CT_EVMODE = 13,
-             CT_SLOT0 = 16, CT_SLOT_STRIDE = 6 };
+             CT_SLOT0 = 16, CT_SLOT_STRIDE = 6, CT_ROLL = 44, CT_ACC = 48 };
 // slot: SL_F = permutation position of the wave's earliest stop (-1: none)
 enum : int { SL_F = 0, SL_J = 1, SL_KIND = 2, SL_LOGU = 3, SL_MARGIN = 4, SL_DELTA = 5 };
 enum : int { STOP_ACCEPT = 1, STOP_SLOW = 2, STOP_BAD = 3 };
@@ -1270,11 +1270,19 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   int gprev = 0, kprev = 0;
   bool beta_valid = false;
 
-  double acc_sig = 0, acc_sig2 = 0, acc_k = 0, acc_acc = 0, acc_prop = 0;
-  int g_r = -1;  // summaries held in registers for variable g_r
-  unsigned cnt_r = 0u;
-  double bsum_r = 0.0, bsq_r = 0.0;
-  double min_margin = BA_INF;
+  // The launch's accumulators live in LDS, not in registers (the master's
+  // registers are needed for what it touches every few instructions): scalars
+  // in the control block (slots CT_ACC + ACC_*), the per-variable summaries of
+  // the standing model -- lane m <-> variable sum_g[m] -- in four lane arrays.
+  lds_f64 *sum_b = to_lds<double>(smem + lay.park + 512);    // sum of beta
+  lds_f64 *sum_b2 = to_lds<double>(smem + lay.park + 1024);  // sum of beta^2
+  AS_LDS int *sum_n = to_lds<int>(smem + lay.park + 1536);   // sweeps counted
+  AS_LDS int *sum_g = to_lds<int>(smem + lay.park + 1792);   // variable (-1: none)
+  sum_b[lane] = 0.0; sum_b2[lane] = 0.0; sum_n[lane] = 0; sum_g[lane] = -1;
+  if (lane < 8) ctl[CT_ACC + lane] = (lane == ACC_MIN_MARGIN) ? BA_INF : 0.0;
+  wave_sync();
+#define ACC_ADD(slot, x) do { if (lane == 0) ctl[CT_ACC + (slot)] += (double)(x); } while (0)
+#define ACC_MIN(x) do { if (lane == 0) ctl[CT_ACC + ACC_MIN_MARGIN] = fmin(ctl[CT_ACC + ACC_MIN_MARGIN], (x)); } while (0)
   int done = 0;
 
   const int nflips = P.max_flips;  // already min(max_nflips_, p)
@@ -1309,9 +1317,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   bool spec = false;          // a forked walk is outstanding
   bool have_dr = false;       // wave 1's slot holds a walk result not yet handled
   int after_join = PH_COMMIT, spec_status = CHAIN_OK;
-  double sigsq_s = 0.0, beta_m_s = 0.0;
-  int gprev_s = 0, kprev_s = 0, failures_s = 0;
-  bool beta_valid_s = false;
+  // (what a roll-back restores is parked in LDS, not in registers: park[lane] =
+  // beta_m, control-block slots CT_ROLL.. = sigma^2, failures, beta_valid)
+  lds_f64 *park = to_lds<double>(smem + lay.park);
   int stops_prev = table_valid ? 0 : (1 << 20), stops_now = 0;
   uint64_t flip_pos = 0, pos0 = pos;
   WinRng rng;
@@ -1321,7 +1329,11 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     if (pe.kind != EV_NONE && !spec) {
       // ---- the one place where a model is (re)built (a swap proposed by a
       // tail running ahead waits for the join) --------------------------
-      const Model keep = M;
+      // (outside this block only logp, SS and pd of the model live in registers;
+      // the scalars the evaluations need have their home in the control block)
+      Model keep = M;
+      keep.lp = ctl[CT_LP]; keep.ldv = ctl[CT_LDV]; keep.lda = ctl[CT_LDA];
+      keep.Q = ctl[CT_Q]; keep.c = ctl[CT_C];
       TSTAMP(sx, 7);
       if (pe.f1 >= 0) apply_flip(ch, pe.f1);
       if (pe.f2 >= 0) apply_flip(ch, pe.f2);
@@ -1336,7 +1348,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           bool acc = true;
           if (pe.kind == EV_TRY_GE || pe.kind == EV_TRY_LT) {
             const double d = (Mn.logp - pe.lfw) - (keep.logp - pe.lrev);
-            if (Mn.logp > -BA_INF) min_margin = fmin(min_margin, fabs(pe.lu - d));
+            if (Mn.logp > -BA_INF) ACC_MIN(fabs(pe.lu - d));
             acc = (pe.kind == EV_TRY_GE) ? !(pe.lu > d) : (pe.lu < d);
           }
           if (acc) {
@@ -1344,7 +1356,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
             // (the launch's first build is the old model unless make_valid
             // changed gamma)
             if (pe.kind != EV_INIT || pe.check_legal) table_valid = false;
-            if (pe.kind != EV_INIT) acc_acc += 1;
+            if (pe.kind != EV_INIT) ACC_ADD(ACC_ACCEPTS, 1);
           } else {
             // rejected: gamma back, and the old factors from the chain's block
             if (pe.f2 >= 0) apply_flip(ch, pe.f2);
@@ -1357,7 +1369,14 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       }
       if (status == CHAIN_OK) {
         TSTAMP(sx, 7);
-        if (!rejected) publish_model<NB>(ch);
+        if (!rejected) {
+          publish_model<NB>(ch);
+          if (lane == 0) {
+            ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
+            ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
+          }
+          wave_sync();
+        }
         TSTAMP(sx, 5);
         if (pe.kind == EV_FORCE && !M.pd) status = CHAIN_NOT_PD;
         if (pe.kind == EV_INIT && pe.check_legal &&
@@ -1395,7 +1414,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           if (lane == 0) {
             ctl[CT_CMD] = (double)CMD_SHUFFLE_DECIDE;
             ctl[CT_I0] = 0.0;
-            ctl[CT_LOGP] = M.logp;
             ctl[CT_NFLIPS] = (double)nflips;
             ctl[CT_PERMSEL] = (double)perm_sel;
             ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = pos;
@@ -1411,8 +1429,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           pos = flip_pos + (uint64_t)nflips;
           spec = true;
           spec_status = CHAIN_OK;
-          sigsq_s = sigsq; beta_m_s = beta_m; gprev_s = gprev; kprev_s = kprev;
-          failures_s = failures; beta_valid_s = beta_valid;
+          park[lane] = beta_m;
+          if (lane == 0) {
+            ctl[CT_ROLL + 0] = sigsq;
+            ctl[CT_ROLL + 1] = (double)failures;
+            ctl[CT_ROLL + 2] = beta_valid ? 1.0 : 0.0;
+          }
           i0 = 0;
           phase = PH_SWAP;
           STAMP(1);
@@ -1472,7 +1494,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           if (lane == 0) {
             ctl[CT_CMD] = (double)CMD_DECIDE;
             ctl[CT_I0] = (double)i0;
-            ctl[CT_LOGP] = M.logp;
             ctl[CT_NFLIPS] = (double)nflips;
             ctl[CT_PERMSEL] = (double)perm_sel;
             ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = flip_pos;
@@ -1490,14 +1511,14 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         } else {
           decide_walk(ch, key, flip_pos, i0, nflips, dr);
         }
-        min_margin = fmin(min_margin, dr.margin);
+        ACC_MIN(dr.margin);
         STAMP(3);
         if (dr.spos < 0) {  // walked to the end without a stop
-          acc_prop += nflips - i0;
+          ACC_ADD(ACC_PROPOSALS, nflips - i0);
           i0 = nflips;
           continue;
         }
-        acc_prop += dr.spos + 1 - i0;
+        ACC_ADD(ACC_PROPOSALS, dr.spos + 1 - i0);
         ++stops_now;
         i0 = dr.spos + 1;
         if (dr.kind == STOP_BAD) {
@@ -1528,8 +1549,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           ctl[CT_CMD] = (double)CMD_EVAL;
           ctl[CT_K] = (double)ch.k;
           ctl[CT_I0] = (double)base;
-          ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
-          ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
           ctl[CT_NFLIPS] = (double)nflips;
           ctl[CT_PERMSEL] = (double)perm_sel;
           ctl[CT_EVMODE] = (double)evmode;
@@ -1537,7 +1556,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         }
         __syncthreads();
       }
-      eval_share<NB>(P, ch, M, key, flip_pos, nflips, base, evmode, 0, ctl, sx);
+      {
+        Model Me;
+        Me.logp = M.logp; Me.lp = ctl[CT_LP]; Me.ldv = ctl[CT_LDV]; Me.lda = ctl[CT_LDA];
+        Me.Q = ctl[CT_Q]; Me.c = ctl[CT_C]; Me.SS = 0; Me.pd = true; Me.bad = 0;
+        eval_share<NB>(P, ch, Me, key, flip_pos, nflips, base, evmode, 0, ctl, sx);
+      }
       if (W > 1) __syncthreads(); else wave_sync();
       if (evmode == EVM_FILL) {
         fill_j += WAVE * W;
@@ -1554,7 +1578,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       for (int w = 0; w < W; ++w) {
         const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * w;
         if (wstop < 0) {
-          min_margin = fmin(min_margin, sl[SL_MARGIN]);
+          ACC_MIN(sl[SL_MARGIN]);
           const int fw = (int)sl[SL_F];
           if (fw >= 0) { wstop = w; spos = fw; }
         }
@@ -1562,7 +1586,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       STAMP(3);
       if (wstop < 0) {
         const int n = (nflips - i0 < WAVE * W) ? (nflips - i0) : WAVE * W;
-        acc_prop += n;
+        ACC_ADD(ACC_PROPOSALS, n);
         i0 += WAVE * W;
         continue;
       }
@@ -1570,7 +1594,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       const int jf = (int)sl[SL_J];
       const int kind = (int)sl[SL_KIND];
       const int nprop = spos + 1 - i0;
-      acc_prop += nprop;
+      ACC_ADD(ACC_PROPOSALS, nprop);
       ++stops_now;
       if (kind == STOP_BAD) {
         status = CHAIN_NEGATIVE_SS;
@@ -1617,15 +1641,18 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * 1;
       if ((int)sl[SL_F] < 0) {
         // no stop: the sweep's flips are all rejected and what ran ahead stands
-        min_margin = fmin(min_margin, sl[SL_MARGIN]);
-        acc_prop += nflips;
+        ACC_MIN(sl[SL_MARGIN]);
+        ACC_ADD(ACC_PROPOSALS, nflips);
         status = spec_status;
         phase = after_join;
       } else {
         // roll the tail back and handle the stop
         pos = flip_pos + (uint64_t)nflips;
-        sigsq = sigsq_s; beta_m = beta_m_s; gprev = gprev_s; kprev = kprev_s;
-        failures = failures_s; beta_valid = beta_valid_s;
+        // (gprev / kprev are only set at a commit)
+        beta_m = park[lane];
+        sigsq = ctl[CT_ROLL + 0];
+        failures = (int)ctl[CT_ROLL + 1];
+        beta_valid = ctl[CT_ROLL + 2] != 0.0;
         pe.kind = EV_NONE; pe.f1 = pe.f2 = -1; pe.lfw = pe.lrev = 0.0; pe.check_legal = false;
         have_dr = true;
         phase = PH_FLIPS;
@@ -1640,28 +1667,30 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       gprev = (lane < k) ? (int)ch.g[lane] : 0;
       kprev = k;
       kmax = k > kmax ? k : kmax;
-      // inclusion counts and coefficient moments pile up in registers while
-      // the model stands still (lane m <-> variable g_r) and go to HBM when it
+      // inclusion counts and coefficient moments pile up on chip while the
+      // model stands still (lane m <-> variable sum_g[m]) and go to HBM when it
       // moves
       {
         const int gnow = (lane < k) ? gprev : -1;
-        if (__any(gnow != g_r)) {
-          if (g_r >= 0 && cnt_r) {
-            const size_t o = (size_t)chain * p + g_r;
-            P.inc_count[o] += cnt_r;
-            P.beta_sum[o] += bsum_r;
-            P.beta_sumsq[o] += bsq_r;
+        const int gold = sum_g[lane];
+        if (__any(gnow != gold)) {
+          const int n_old = sum_n[lane];
+          if (gold >= 0 && n_old) {
+            const size_t o = (size_t)chain * p + gold;
+            P.inc_count[o] += (unsigned)n_old;
+            P.beta_sum[o] += sum_b[lane];
+            P.beta_sumsq[o] += sum_b2[lane];
           }
-          g_r = gnow; cnt_r = 0u; bsum_r = 0.0; bsq_r = 0.0;
+          sum_g[lane] = gnow; sum_n[lane] = 0; sum_b[lane] = 0.0; sum_b2[lane] = 0.0;
         }
         if (lane < k) {
-          cnt_r += 1u;
-          if (beta_valid) { bsum_r += beta_m; bsq_r += beta_m * beta_m; }
+          sum_n[lane] += 1;
+          if (beta_valid) { sum_b[lane] += beta_m; sum_b2[lane] += beta_m * beta_m; }
         }
       }
-      acc_sig += sigsq;
-      acc_sig2 += sigsq * sigsq;
-      acc_k += k;
+      ACC_ADD(ACC_SIGSQ, sigsq);
+      ACC_ADD(ACC_SIGSQ2, sigsq * sigsq);
+      ACC_ADD(ACC_K, k);
       if (P.trace_sigsq && trace_at + sweep < P.trace_stride && lane == 0) {
         const size_t o = (size_t)chain * P.trace_stride + trace_at + sweep;
         P.trace_sigsq[o] = sigsq;
@@ -1735,11 +1764,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     __syncthreads();
   }
 
-  if (g_r >= 0 && cnt_r) {
-    const size_t o = (size_t)chain * p + g_r;
-    P.inc_count[o] += cnt_r;
-    P.beta_sum[o] += bsum_r;
-    P.beta_sumsq[o] += bsq_r;
+  wave_sync();
+  if (sum_g[lane] >= 0 && sum_n[lane]) {
+    const size_t o = (size_t)chain * p + sum_g[lane];
+    P.inc_count[o] += (unsigned)sum_n[lane];
+    P.beta_sum[o] += sum_b[lane];
+    P.beta_sumsq[o] += sum_b2[lane];
   }
   // ---- write the chain back (an aborted sweep leaves no trace: gamma, the
   // permutation and the stream position go back to the sweep's start; sigma,
@@ -1778,12 +1808,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     if (P.maxk) atomicMax(P.maxk, kmax);
     double *a = P.acc + (size_t)chain * ACC_COUNT;
     a[ACC_SWEEPS] += done;
-    a[ACC_SIGSQ] += acc_sig;
-    a[ACC_SIGSQ2] += acc_sig2;
-    a[ACC_K] += acc_k;
-    a[ACC_ACCEPTS] += acc_acc;
-    a[ACC_PROPOSALS] += acc_prop;
-    a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], min_margin);
+    a[ACC_SIGSQ] += ctl[CT_ACC + ACC_SIGSQ];
+    a[ACC_SIGSQ2] += ctl[CT_ACC + ACC_SIGSQ2];
+    a[ACC_K] += ctl[CT_ACC + ACC_K];
+    a[ACC_ACCEPTS] += ctl[CT_ACC + ACC_ACCEPTS];
+    a[ACC_PROPOSALS] += ctl[CT_ACC + ACC_PROPOSALS];
+    a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], ctl[CT_ACC + ACC_MIN_MARGIN]);
 #if defined(BA_STAMPS) && defined(BA_STAMPS4)
     // (phases are wave 1's)
 #elif defined(BA_STAMPS) && (defined(BA_STAMPS2) || defined(BA_STAMPS3))

@@ -121,7 +121,7 @@ struct SsvsParams {
 // its solution vector in registers.  kcap is a multiple of 8.
 // doubles first, then 16-bit, then bytes; all offsets in bytes.
 struct SsvsLds {
-  uint32_t Lv, La, rdv, rda, w, bg, ctrl, g, perm0, perm1, oth, last, pred, gam, gam0, nbr, total;
+  uint32_t Lv, La, rdv, rda, w, bg, ctrl, park, g, perm0, perm1, oth, last, pred, gam, gam0, nbr, total;
 };
 
 static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
@@ -137,6 +137,9 @@ static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
   L.w = o;     o += (uint32_t)kcap * 8;
   L.bg = o;    o += (uint32_t)kcap * 8;
   L.ctrl = o;  o += 512;  // control block shared by a chain's wavefronts
+  // per-lane state of the master parked in LDS rather than in registers:
+  // beta across a forked sweep, coefficient sums, sums of squares, counts | variable
+  L.park = o;  o += 4 * 512;
   L.g = o;     o += (((uint32_t)kcap * 2) + 15u) & ~15u;
   L.perm0 = o; o += pv;
   L.perm1 = o; o += pv;
