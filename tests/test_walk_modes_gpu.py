@@ -1,0 +1,106 @@
+"""The sweep kernel has several equivalent ways of walking a sweep (batch /
+table look-ups, forked quiet sweeps, 1 or 2 wavefronts per chain, one long or
+many short launches).  They must produce the SAME chains bit for bit -- same
+decisions, same arithmetic -- so the oracle parity of the default path
+(test_ssvs_gpu.py) carries over to every one of them.  Through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import regression_data, spike_slab_prior, suf_from_xy
+from oracle_lib import ssvs_options
+from test_ssvs_gpu import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    out = {}
+    # plain: p spans several 64-proposal rounds
+    X, y, _ = regression_data(600, 130, 7, seed=5)
+    suf = suf_from_xy(X, y)
+    out["plain_p130"] = (suf, spike_slab_prior(suf, 7), ssvs_options())
+    # swap move with real candidates (collinear columns), low threshold
+    X, y, _ = regression_data(400, 40, 4, seed=6, collinear=[1, 7, 9, 20])
+    suf = suf_from_xy(X, y)
+    out["collinear_swap"] = (suf, spike_slab_prior(suf, 4), ssvs_options(swap_threshold=0.5))
+    # non-zero prior means (exact-path stops), model-size cap, few flips per sweep
+    X, y, _ = regression_data(300, 70, 5, seed=7)
+    suf = suf_from_xy(X, y)
+    pm = np.zeros(70)
+    pm[[0, 3, 11, 40]] = [0.5, -0.2, 0.1, 0.3]
+    out["general"] = (suf, spike_slab_prior(suf, 5, prior_mean=pm),
+                      ssvs_options(max_model_size=9, max_flips=50))
+    return out
+
+
+CASES = _cases()
+
+
+def _run(case, waves, policy, launches, chains=12, seed=77):
+    suf, prior, opts = CASES[case]
+    p = len(suf["xty"])
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    os.environ["BOOM_AMD_WAVES"] = str(waves)
+    os.environ["BOOM_AMD_SCAN"] = str(policy)
+    try:
+        eng = make_engine(chains, seed, suf=suf, prior=prior, opts=opts, g0=g0)
+        for n in launches:
+            eng.sweep(n)
+        gam, beta, sig = eng.get_states()
+        sm = eng.get_summaries()
+    finally:
+        os.environ.pop("BOOM_AMD_WAVES", None)
+        os.environ.pop("BOOM_AMD_SCAN", None)
+    return gam, beta, sig, sm
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_all_walks_give_the_same_chains(case):
+    ref = _run(case, waves=1, policy=0, launches=[60])
+    for waves, policy, launches in [(1, 2, [60]), (2, 0, [60]), (2, 1, [60]), (2, 2, [60]),
+                                    (2, 3, [60]), (2, 2, [1] * 7 + [13, 40]),
+                                    (1, 1, [20, 20, 20])]:
+        got = _run(case, waves, policy, launches)
+        tag = (case, waves, policy, launches)
+        assert np.array_equal(ref[0], got[0]), tag
+        assert np.array_equal(ref[1], got[1]), tag
+        assert np.array_equal(ref[2], got[2]), tag
+        assert ref[3]["sweeps"] == got[3]["sweeps"] and ref[3]["accepts"] == got[3]["accepts"], tag
+        assert ref[3]["proposals"] == got[3]["proposals"], tag
+        assert np.array_equal(ref[3]["inclusion_count"], got[3]["inclusion_count"]), tag
+        assert np.allclose(ref[3]["beta_sum"], got[3]["beta_sum"], rtol=1e-12, atol=1e-12), tag
+
+
+def test_tables_are_dropped_when_anything_else_is_called():
+    """the per-chain proposal tables survive from one ba_sweep to the next; any
+    other call in between (here: new sufficient statistics) must drop them"""
+    suf, prior, opts = CASES["plain_p130"]
+    p = len(suf["xty"])
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    X2, y2, _ = regression_data(600, 130, 7, seed=99)
+    suf2 = suf_from_xy(X2, y2)
+    os.environ["BOOM_AMD_SCAN"] = "2"
+    try:
+        a = make_engine(8, 5, suf=suf, prior=prior, opts=opts, g0=g0)
+        a.sweep(30)
+        a.upload_suf(suf2["xtx"], suf2["xty"], suf2["yty"], suf2["n"],
+                     suf2["sumy"] / suf2["n"], suf2["xsum"] / suf2["n"])
+        a.sweep(30)
+        ga, ba_, sa = a.get_states()
+    finally:
+        os.environ.pop("BOOM_AMD_SCAN", None)
+    os.environ["BOOM_AMD_SCAN"] = "0"
+    try:
+        b = make_engine(8, 5, suf=suf, prior=prior, opts=opts, g0=g0)
+        b.sweep(30)
+        b.upload_suf(suf2["xtx"], suf2["xty"], suf2["yty"], suf2["n"],
+                     suf2["sumy"] / suf2["n"], suf2["xsum"] / suf2["n"])
+        b.sweep(30)
+        gb, bb, sb = b.get_states()
+    finally:
+        os.environ.pop("BOOM_AMD_SCAN", None)
+    assert np.array_equal(ga, gb) and np.array_equal(ba_, bb) and np.array_equal(sa, sb)
