@@ -705,47 +705,62 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
   HSTAMP(sx, 2);
   const lds_u16 *src_perm = ch.perm;
   lds_u16 *dst = ch.perm_alt;
-  // eight independent walks per lane, advanced together, so that the dependent
-  // LDS reads of one walk hide behind the other seven
-  constexpr int U = 8;
-  for (int ib = 0; ib < p; ib += U * WAVE) {
-    int c[U], n[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = ib + u * WAVE + lane;
-      const bool valid = i < p;
-      const int c0 = !valid ? NONE : ((i == 0) ? pred0 : (int)ch.pred[i]);
-      if (c0 == NONE) {
-        c[u] = (!valid || i == 0) ? 0 : (int)ch.oth[i];
-        n[u] = NONE;
-      } else {
-        c[u] = c0;
-        n[u] = ch.last[c0];
-      }
+  // Each position's source is the END of a chain of nxt links.  Chains are not
+  // walked: pointer jumping R[c] <- R[R[c]] (R[c] = nxt(c), or c itself at a
+  // chain's end) halves every distance per round, all steps at once, in place
+  // (any mix of old and new values still points down the chain).  A lane holds
+  // NW steps, their LDS round trips side by side.
+  constexpr int NW = 8;
+  for (int t = lane; t < p; t += WAVE) {
+    if (t >= 1) {
+      const uint32_t l = ch.last[t];
+      if (l == (uint32_t)NONE) ch.last[t] = (uint32_t)t;
     }
-    // (most walks end within a few links; a group whose 64 walks are all done
-    // costs one scalar test per level)
-    unsigned live = 0;
+  }
+  wave_sync();
+  for (bool moved = true; moved;) {
+    moved = false;
+    for (int tb = 0; tb < p; tb += NW * WAVE) {
+      int r1[NW], r2[NW];
 #pragma unroll
-    for (int u = 0; u < U; ++u) live |= __any(n[u] != NONE) ? (1u << u) : 0u;
-    while (live) {
-      unsigned nlive = 0;
+      for (int u = 0; u < NW; ++u) {
+        const int t = tb + u * WAVE + lane;
+        r1[u] = (t >= 1 && t < p) ? (int)ch.last[t] : 1;
+      }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (live & (1u << u)) {
-          const bool act = n[u] != NONE;
-          const int nn = ch.last[act ? n[u] : 0];
-          c[u] = act ? n[u] : c[u];
-          n[u] = act ? nn : NONE;
-          nlive |= __any(n[u] != NONE) ? (1u << u) : 0u;
+      for (int u = 0; u < NW; ++u) r2[u] = (int)ch.last[r1[u]];
+      bool ch_any = false;
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        const int t = tb + u * WAVE + lane;
+        if (t >= 1 && t < p && r2[u] != r1[u]) {
+          ch.last[t] = (uint32_t)r2[u];
+          ch_any = true;
         }
       }
-      live = nlive;
+      moved |= (__any(ch_any) != 0);
+      wave_sync();
+    }
+  }
+  for (int ib = 0; ib < p; ib += NW * WAVE) {
+    int c0[NW], src[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int i = ib + u * WAVE + lane;
+      c0[u] = (i >= p) ? NONE : ((i == 0) ? pred0 : (int)ch.pred[i]);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < NW; ++u) {
       const int i = ib + u * WAVE + lane;
-      if (i < p) dst[i] = src_perm[c[u]];
+      // nobody deposited anything: the partner's original content (slot 0 keeps its own)
+      const int direct = (i >= p || i == 0) ? 0 : (int)ch.oth[i];
+      const int via = (int)ch.last[c0[u] == NONE ? 0 : c0[u]];
+      src[u] = (c0[u] == NONE) ? direct : via;
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int i = ib + u * WAVE + lane;
+      if (i < p) dst[i] = src_perm[src[u]];
     }
   }
   wave_sync();
