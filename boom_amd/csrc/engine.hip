@@ -154,6 +154,7 @@ struct ba_engine {
   DevBuf<double> dtab_lp;   // per-chain proposal table
   DevBuf<uint8_t> dtab_kind;
   DevBuf<int32_t> dtab_tag;
+  DevBuf<int32_t> dran;  // catch-up launches of the state-space path: sweeps done per chain
   bool table_ok = false;  // nothing but ba_sweep launches since the tables were built
   int trace_stride = 0;
   // scratch for suf build
@@ -240,8 +241,9 @@ int choose_kcap(const ba_engine &e) {
     const int k = (int)std::min<int64_t>(64, (((int64_t)e.cfg.max_model_size_hint + 15) / 16) * 16);
     return std::min(k, lds_cap(e));
   }
-  if (e.ss_mode) return limit;  // coupled launches: no mid-run escalation
-  return std::min(32, limit);
+  int start = 32;  // (BOOM_AMD_KCAP_START: tests force early escalations)
+  if (const char *s = std::getenv("BOOM_AMD_KCAP_START")) start = std::max(16, (std::atoi(s) / 16) * 16);
+  return std::min(start, limit);
 }
 
 // Wavefronts per chain.  The proposal batches scale with the number of waves
@@ -330,6 +332,7 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(e->dtab_lp.resize(C * p));
   HIP_TRY(e->dtab_kind.resize(C * p));
   HIP_TRY(e->dtab_tag.resize(C));
+  HIP_TRY(e->dran.resize(C));
   e->table_ok = false;
   HIP_TRY(e->dmaxk.resize(1));
   HIP_TRY(e->dtrace_idx.resize(C));
@@ -414,6 +417,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.table_kind = e->dtab_kind.ptr;
   P.table_tag = e->dtab_tag.ptr;
   P.table_keep = e->table_ok ? 1 : 0;
+  P.run_limit = 0;
+  P.ran = nullptr;
   P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
   P.seed_lo = (uint32_t)e->seed;
   P.seed_hi = (uint32_t)(e->seed >> 32);
@@ -463,13 +468,85 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
   }
 }
 
+void fill_ss_params(ba_engine *e, SsParams &S) {
+  std::memset(&S, 0, sizeof(S));  // (only_ran = nullptr: every chain)
+  S.T = e->T;
+  S.p = e->p;
+  S.chains = e->cfg.chains;
+  S.chain_offset = e->cfg.chain_offset;
+  S.y = e->dss_y.ptr;
+  S.X = e->dss_X.ptr;
+  S.observed = e->dss_obs.ptr;
+  S.gamma = e->dgamma.ptr;
+  S.beta = e->dbeta.ptr;
+  S.sigsq = e->dsigsq.ptr;
+  S.level_sigsq = e->dlev_sigsq.ptr;
+  S.level_n = e->dlev_n.ptr;
+  S.level_sumsq = e->dlev_sumsq.ptr;
+  S.level_prior_df = e->level_prior_df;
+  S.level_prior_ss = e->level_prior_ss;
+  S.level_sigma_max = e->level_sigma_max;
+  S.a0 = e->ss_a0;
+  S.P0 = e->ss_P0;
+  S.seed_lo = (uint32_t)e->seed;
+  S.seed_hi = (uint32_t)(e->seed >> 32);
+  S.pos_level = e->dpos_level.ptr;
+  S.pos_state = e->dpos_state.ptr;
+  S.status = e->dstatus.ptr;
+  S.scratch = e->dss_scratch.ptr;
+  S.scratch_stride = (int64_t)SS_SCRATCH_ARRAYS * e->T;
+  S.xty = e->dxty_c.ptr;
+  S.yty = e->dyty_c.ptr;
+  S.nobs = e->dnobs_c.ptr;
+}
+
+// The same for the state-space path, where a chain's sweeps alternate with the
+// Kalman kernel: a chain that outgrew the capacity sat out the rest of the call
+// (its SSVS launches booked the sweeps, its Kalman launches were skipped), so
+// it is caught up one (SSVS, Kalman) pair at a time; chains that owe nothing
+// leave both kernels at once.
+int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
+  const size_t C = (size_t)e->cfg.chains;
+  for (;;) {
+    bool any = false;
+    for (size_t c = 0; c < C; ++c) any = any || (st[c] == CHAIN_MODEL_TOO_LARGE);
+    if (!any) return BA_OK;
+    if (e->cfg.max_model_size_hint > 0 || e->kcap >= cap_limit(*e)) return BA_OK;  // stays an error
+    e->kcap += 16;
+    e->waves = choose_waves(*e, e->kcap);
+    std::vector<int32_t> todo(C);
+    HIP_TRY(hipMemcpy(todo.data(), e->dtodo.ptr, C * 4, hipMemcpyDeviceToHost));
+    int rounds = 0;
+    for (size_t c = 0; c < C; ++c) {
+      if (st[c] == CHAIN_MODEL_TOO_LARGE) {
+        st[c] = CHAIN_OK;
+        rounds = std::max(rounds, (int)todo[c]);
+      }
+    }
+    HIP_TRY(hipMemcpy(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice));
+    SsvsParams P;
+    fill_params(e, P);
+    P.run_limit = 1;
+    P.ran = e->dran.ptr;
+    SsParams S;
+    fill_ss_params(e, S);
+    S.only_ran = e->dran.ptr;
+    for (int r = 0; r < rounds; ++r) {
+      HIP_TRY(launch_ssvs_sweep(e->stream, P, 0));
+      HIP_TRY(launch_kalman_simsmooth(e->stream, S, 1));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+  }
+}
+
 int check_chain_status(ba_engine *e) {
   const size_t C = (size_t)e->cfg.chains;
   if (!e->state_ready) return BA_OK;
   std::vector<int32_t> st(C);
   HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
-  if (!e->ss_mode) {
-    int rc = escalate(e, st);
+  {
+    int rc = e->ss_mode ? ss_escalate(e, st) : escalate(e, st);
     if (rc) return rc;
     // capacity follows the models: room for growth, no more
     if (e->cfg.max_model_size_hint <= 0 && e->kcap > 0) {
@@ -1110,38 +1187,6 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
 }
 
 // --------------------------------------------------- state space (kalman)
-static void fill_ss_params(ba_engine *e, SsParams &S) {
-  std::memset(&S, 0, sizeof(S));
-  S.T = e->T;
-  S.p = e->p;
-  S.chains = e->cfg.chains;
-  S.chain_offset = e->cfg.chain_offset;
-  S.y = e->dss_y.ptr;
-  S.X = e->dss_X.ptr;
-  S.observed = e->dss_obs.ptr;
-  S.gamma = e->dgamma.ptr;
-  S.beta = e->dbeta.ptr;
-  S.sigsq = e->dsigsq.ptr;
-  S.level_sigsq = e->dlev_sigsq.ptr;
-  S.level_n = e->dlev_n.ptr;
-  S.level_sumsq = e->dlev_sumsq.ptr;
-  S.level_prior_df = e->level_prior_df;
-  S.level_prior_ss = e->level_prior_ss;
-  S.level_sigma_max = e->level_sigma_max;
-  S.a0 = e->ss_a0;
-  S.P0 = e->ss_P0;
-  S.seed_lo = (uint32_t)e->seed;
-  S.seed_hi = (uint32_t)(e->seed >> 32);
-  S.pos_level = e->dpos_level.ptr;
-  S.pos_state = e->dpos_state.ptr;
-  S.status = e->dstatus.ptr;
-  S.scratch = e->dss_scratch.ptr;
-  S.scratch_stride = (int64_t)SS_SCRATCH_ARRAYS * e->T;
-  S.xty = e->dxty_c.ptr;
-  S.yty = e->dyty_c.ptr;
-  S.nobs = e->dnobs_c.ptr;
-}
-
 static int ss_prepare(ba_engine *e) {
   if (!e->ss_mode) return fail(BA_E_STATE, "call ba_ss_set_data first");
   if (!e->ss_level_set) return fail(BA_E_STATE, "call ba_ss_set_local_level first");

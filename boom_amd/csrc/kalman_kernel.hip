@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   const int chain = blockIdx.x, lane = threadIdx.x;
   if (chain >= P.chains) return;
   if (P.status[chain] != CHAIN_OK) return;
+  if (P.only_ran && P.only_ran[chain] == 0) return;
   const int T = P.T, p = P.p;
   int status = CHAIN_OK;
 #ifdef BA_KSTAMPS

@@ -28,6 +28,7 @@ struct SsParams {
   uint32_t seed_lo, seed_hi;
   uint64_t *pos_level, *pos_state;
   int32_t *status;
+  const int32_t *only_ran;  // catch-up launches: skip chains whose entry is 0 (nullptr: all)
   // per-chain work arrays in HBM: v, F, K, v_sim, state, r, r_sim (T each)
   double *scratch;
   int64_t scratch_stride;   // >= 7 T

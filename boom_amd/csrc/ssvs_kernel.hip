@@ -1152,8 +1152,26 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   if (P.status[chain] != CHAIN_OK) {
     // a chain waiting for a larger-capacity kernel (or in error) just books
     // the sweeps it is owed
-    if (threadIdx.x == 0) P.todo[chain] += nsweeps;
+    if (threadIdx.x == 0) {
+      P.todo[chain] += nsweeps;
+      if (P.ran) P.ran[chain] = 0;
+    }
     return;
+  }
+  // sweeps to run now: this launch's plus what earlier launches owe, capped by
+  // run_limit (the rest stays owed)
+  int owed_after = 0;
+  {
+    int total = nsweeps + P.todo[chain];
+    if (P.run_limit > 0 && total > P.run_limit) {
+      owed_after = total - P.run_limit;
+      total = P.run_limit;
+    }
+    if (total == 0) {
+      if (threadIdx.x == 0 && P.ran) P.ran[chain] = 0;
+      return;  // (every wave of the workgroup takes this exit)
+    }
+    nsweeps = total;
   }
 
   constexpr int KCAP = NB * 8;
@@ -1273,7 +1291,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   if (k > KCAP) status = CHAIN_MODEL_TOO_LARGE;
   ch.k = k;
   wave_sync();
-  nsweeps += P.todo[chain];  // sweeps owed from earlier launches
   bool aborted = false;      // stopped inside a sweep: restore its start
   int kmax = k;
   int trace_at = P.trace_idx ? P.trace_idx[chain] : 0;
@@ -1817,7 +1834,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     P.rng_pos[chain] = pos;
     P.failures[chain] = failures;
     P.status[chain] = status;
-    P.todo[chain] = nsweeps - done;
+    P.todo[chain] = nsweeps - done + owed_after;
+    if (P.ran) P.ran[chain] = done;
     P.table_tag[chain] = (table_valid && !aborted && status == CHAIN_OK) ? KCAP : 0;
     if (P.trace_idx) P.trace_idx[chain] = trace_at + done;
     if (P.maxk) atomicMax(P.maxk, kmax);

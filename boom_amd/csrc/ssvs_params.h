@@ -84,6 +84,11 @@ struct SsvsParams {
   // remaining count here with status CHAIN_MODEL_TOO_LARGE, and is resumed by
   // the host with a larger-capacity kernel.
   int32_t *todo;      // chains
+  // Catch-up launches of the state-space path (sweeps alternate with the Kalman
+  // kernel, so owed sweeps are repaid one per launch): at most run_limit sweeps
+  // per chain and launch (0 = no limit), ran[chain] = sweeps done by this launch.
+  int32_t run_limit;
+  int32_t *ran;       // chains, or nullptr
   int32_t *maxk;      // 1: largest model size seen (capacity adaptation)
   int32_t *trace_idx; // chains: next trace slot
 

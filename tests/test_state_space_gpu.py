@@ -107,3 +107,43 @@ def test_config3_shape_properties():
     resid = y - X @ beta[17] - st["state"]
     assert 0.15 < resid.std() < 0.4
     assert 0.1 < np.sqrt(sig).mean() < 0.5   # truth 0.2; 30 sweeps from a cold start
+
+
+def test_capacity_escalation_in_stream(monkeypatch):
+    """A chain that outgrows the launch capacity in state-space mode sits out
+    the rest of the call and is caught up, one (SSVS, Kalman) pair at a time,
+    with a larger capacity: the draws must be those of a run whose capacity was
+    large enough from the start."""
+    import boom_amd
+    T, p, nsig = 300, 48, 26
+    X, y, btrue, _ = state_space_data(T, p, nsig, seed=31)
+    prior, ss, sig_up = bsts_priors(X, y, nsig)
+
+    def run(hint, start):
+        if start:
+            monkeypatch.setenv("BOOM_AMD_KCAP_START", str(start))
+        else:
+            monkeypatch.delenv("BOOM_AMD_KCAP_START", raising=False)
+        eng = boom_amd.Engine(6, seed=9, max_model_size_hint=hint)
+        eng.ss_set_data(y, X, None)
+        eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"],
+                       prior["sigma_guess"], sigma_upper_limit=sig_up)
+        eng.ss_set_local_level(ss["level_df"], ss["level_sigma_guess"],
+                               ss["level_sigma_upper_limit"], ss["initial_state_mean"],
+                               ss["initial_state_variance"], ss["initial_level_sigma"])
+        eng.set_state(np.zeros(p, np.uint8))
+        eng.ss_sweep(25)
+        eng.ss_sweep(10)
+        gam, beta, sig = eng.get_states()
+        st = [eng.ss_get_state(c) for c in range(6)]
+        return gam, beta, sig, st
+
+    ref = run(64, 0)
+    got = run(0, 16)
+    assert ref[0].sum(1).max() > 16     # the models did outgrow the first capacity
+    assert np.array_equal(ref[0], got[0])
+    assert np.array_equal(ref[1], got[1])
+    assert np.array_equal(ref[2], got[2])
+    for a, b in zip(ref[3], got[3]):
+        assert np.array_equal(a["state"], b["state"])
+        assert a["level_sigsq"] == b["level_sigsq"]
