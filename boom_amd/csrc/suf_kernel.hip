@@ -143,24 +143,30 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const double *__restric
 // (StateSpaceRegressionModel.cpp:188-200): A = the chains' residual series
 // (one column per chain), B = the design matrix, C[chain, j] = x_j'e_chain --
 // the design matrix is read once per 16 chains instead of once per chain.
-// One wavefront per 16 x 16 tile of C; MFMA step s of an 8-row slab uses rows
+// Four wavefronts per 16 x 16 tile of C; MFMA step s of an 8-row slab uses rows
 // k0 + 2 (l >> 4) + s, so that a lane's two operands per matrix are adjacent in
 // memory.  The order of the k summation is fixed: bitwise reproducible.
-__global__ __launch_bounds__(64) void atb_mfma_kernel(const double *__restrict__ A,
-                                                      int64_t lda, int M,
-                                                      const double *__restrict__ B,
-                                                      int64_t ldb, int N, int K,
-                                                      double *__restrict__ C, int ldc) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void atb_mfma_kernel(const double *__restrict__ A,
+                                                       int64_t lda, int M,
+                                                       const double *__restrict__ B,
+                                                       int64_t ldb, int N, int K,
+                                                       double *__restrict__ C, int ldc) {
+  // four wavefronts per tile, each a quarter of the k range (whole 8-row
+  // slabs); the partial tiles are added in wave order
+  __shared__ double part[3][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
   const int fc = lane & 15, fr = lane >> 4;
   const bool ia = (i0 + fc) < M, jb = (j0 + fc) < N;
   const double *pa = A + (int64_t)(ia ? i0 + fc : 0) * lda + 2 * fr;
   const double *pb = B + (int64_t)(jb ? j0 + fc : 0) * ldb + 2 * fr;
+  const int slabs = (K + 7) / 8, per = (slabs + 3) / 4;
+  const int kbeg = wave * per * 8;
+  const int kend = (wave + 1) * per * 8 < K ? (wave + 1) * per * 8 : K;
   double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
   constexpr int UN = 4;  // slabs in flight
-  int k0 = 0;
-  for (; k0 + 8 * UN <= K; k0 += 8 * UN) {
+  int k0 = kbeg;
+  for (; k0 + 8 * UN <= kend; k0 += 8 * UN) {
     double a0[UN], a1[UN], b0[UN], b1[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -175,18 +181,26 @@ __global__ __launch_bounds__(64) void atb_mfma_kernel(const double *__restrict__
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ia ? a1[u] : 0.0, jb ? b1[u] : 0.0, acc, 0, 0, 0);
     }
   }
-  for (; k0 < K; k0 += 8) {
+  for (; k0 < kend; k0 += 8) {
     const int ka = k0 + 2 * fr;
-    const double a0 = (ia && ka < K) ? pa[k0] : 0.0, a1 = (ia && ka + 1 < K) ? pa[k0 + 1] : 0.0;
-    const double b0 = (jb && ka < K) ? pb[k0] : 0.0, b1 = (jb && ka + 1 < K) ? pb[k0 + 1] : 0.0;
+    const double a0 = (ia && ka < kend) ? pa[k0] : 0.0, a1 = (ia && ka + 1 < kend) ? pa[k0 + 1] : 0.0;
+    const double b0 = (jb && ka < kend) ? pb[k0] : 0.0, b1 = (jb && ka + 1 < kend) ? pb[k0 + 1] : 0.0;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
   }
-  // register q of lane l holds row (l >> 4) + 4 q, column l & 15
+  if (wave > 0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = i0 + fr + 4 * q, j = j0 + fc;
-    if (i < M && j < N) C[(int64_t)i * ldc + j] = acc[q];
+    for (int q = 0; q < 4; ++q) part[wave - 1][q][lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // register q of lane l holds row (l >> 4) + 4 q, column l & 15
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double v = ((acc[q] + part[0][q][lane]) + part[1][q][lane]) + part[2][q][lane];
+      const int i = i0 + fr + 4 * q, j = j0 + fc;
+      if (i < M && j < N) C[(int64_t)i * ldc + j] = v;
+    }
   }
 }
 
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(64) void atb_mfma_kernel(const double *__restrict__
 
 hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
                            const double *B, int64_t ldb, int N, int K, double *C, int ldc) {
-  hipLaunchKernelGGL(atb_mfma_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, stream,
+  hipLaunchKernelGGL(atb_mfma_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, stream,
                      A, lda, M, B, ldb, N, K, C, ldc);
   return hipGetLastError();
 }
