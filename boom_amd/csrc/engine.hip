@@ -424,8 +424,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.seed_hi = (uint32_t)(e->seed >> 32);
   P.stream = 0;
   P.mode = e->cur_mode;
-  P.scan_policy = 1;
-  if (const char *sp = std::getenv("BOOM_AMD_SCAN")) P.scan_policy = std::atoi(sp);
+  P.walk_policy = 1;  // (BOOM_AMD_SCAN: diagnostic override, see ssvs_params.h)
+  if (const char *sp = std::getenv("BOOM_AMD_SCAN")) P.walk_policy = std::atoi(sp);
   if (e->cur_mode == 1) {
     // SpikeSlabSampler: given sigma^2, no sigma draw, no swap move, own stream
     P.slab_scales = e->sss_slab_scales;

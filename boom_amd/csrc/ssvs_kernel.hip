@@ -220,66 +220,92 @@ __device__ __forceinline__ void bind_lds(Chain &ch, unsigned char *smem,
   ch.nbr = to_lds<uint8_t>(smem + lay.nbr);
 }
 
-// In-place Cholesky of a block-packed lower triangle, lane i owns row i
+// In-place Cholesky of block-packed lower triangles, lane i owns row i
 // (k <= 64).  Left-looking by column: the subtraction order for every entry is
 // that of Eigen's unblocked LLT (Eigen/src/Cholesky/LLT.h:313-335) which the
-// reference uses (LinAlg/Cholesky.cpp:33-58).  Returns false at the first
+// reference uses (LinAlg/Cholesky.cpp:33-58); a factorisation stops at its first
 // non-positive pivot.  logdet = 2 * sum log L_jj.
-__device__ __forceinline__ bool chol_blocks(const Chain &ch, lds_f64 *LB,
-                                            lds_f64 *rd, double *logdet) {
+// The two factorisations of a rebuild (A_g and V_g) side by side: the same
+// column-by-column arithmetic as chol_blocks for each, but the two dependent
+// chains (dot product, sqrt, divide) interleave, which is what a single
+// wavefront per SIMD needs.  A failed factorisation stops advancing (its
+// remaining columns are never used); the other one carries on.
+__device__ __forceinline__ void chol_blocks2(const Chain &ch, lds_f64 *LA, lds_f64 *rdA,
+                                             lds_f64 *LV, lds_f64 *rdV, bool *okA,
+                                             bool *okV, double *ldA, double *ldV) {
   const int k = ch.k, i = ch.lane;
-  double ld = 0.0;
-  bool ok = true;
-  for (int j = 0; j < k; ++j) {
+  bool oa = true, ov = true;
+  for (int j = 0; j < k && (oa || ov); ++j) {
     const bool mine = (i >= j) && (i < k);
     const int ii = mine ? i : j;  // lanes without a row read row j (discarded)
-    double s = LB[bidx(ii, j)];
     const int jb = j >> 3;
-    const lds_f64 *ri = LB + ((ii >> 3) * ((ii >> 3) + 1) / 2) * 64 + (ii & 7) * 8;
-    const lds_f64 *rj = LB + (jb * (jb + 1) / 2) * 64 + (j & 7) * 8;
+    const int offi = ((ii >> 3) * ((ii >> 3) + 1) / 2) * 64 + (ii & 7) * 8;
+    const int offj = (jb * (jb + 1) / 2) * 64 + (j & 7) * 8;
+    double sa = LA[bidx(ii, j)], sv = LV[bidx(ii, j)];
     for (int nb = 0; nb < jb; ++nb) {
-      double a[8], b[8];
+      double a[8], b[8], c[8], d[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        a[t] = ri[nb * 64 + t];
-        b[t] = rj[nb * 64 + t];
+        a[t] = LA[offi + nb * 64 + t];
+        b[t] = LA[offj + nb * 64 + t];
+        c[t] = LV[offi + nb * 64 + t];
+        d[t] = LV[offj + nb * 64 + t];
       }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) s -= a[t] * b[t];
+      for (int t = 0; t < 8; ++t) {
+        sa -= a[t] * b[t];
+        sv -= c[t] * d[t];
+      }
     }
     {
       const int rem = j & 7;
-      double a[8], b[8];
+      double a[8], b[8], c[8], d[8];
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
-        a[t] = (t < rem) ? ri[jb * 64 + t] : 0.0;
-        b[t] = (t < rem) ? rj[jb * 64 + t] : 0.0;
+        a[t] = (t < rem) ? LA[offi + jb * 64 + t] : 0.0;
+        b[t] = (t < rem) ? LA[offj + jb * 64 + t] : 0.0;
+        c[t] = (t < rem) ? LV[offi + jb * 64 + t] : 0.0;
+        d[t] = (t < rem) ? LV[offj + jb * 64 + t] : 0.0;
       }
 #pragma unroll
       for (int t = 0; t < 7; ++t)
-        if (t < rem) s -= a[t] * b[t];
+        if (t < rem) {
+          sa -= a[t] * b[t];
+          sv -= c[t] * d[t];
+        }
     }
-    const double d = bcast_u(s, j);
-    if (!(d > 0.0)) {
-      ok = false;
-      break;
+    const double da = bcast_u(sa, j), dv = bcast_u(sv, j);
+    if (oa && !(da > 0.0)) oa = false;
+    if (ov && !(dv > 0.0)) ov = false;
+    const double sda = sqrt(da), sdv = sqrt(dv);
+    if (oa) {
+      if (i == j) {
+        LA[bidx(j, j)] = sda;
+        rdA[j] = 1.0 / sda;
+      } else if (mine) {
+        LA[bidx(i, j)] = sa / sda;
+      }
     }
-    const double sd = sqrt(d);
-    if (i == j) {
-      LB[bidx(j, j)] = sd;
-      rd[j] = 1.0 / sd;
-    } else if (mine) {
-      LB[bidx(i, j)] = s / sd;
+    if (ov) {
+      if (i == j) {
+        LV[bidx(j, j)] = sdv;
+        rdV[j] = 1.0 / sdv;
+      } else if (mine) {
+        LV[bidx(i, j)] = sv / sdv;
+      }
     }
     wave_sync();
   }
-  if (ok) {
-    // sum_j log L_jj in column order, the logarithms taken side by side
-    const double lg = (i < k) ? log(LB[bidx(i, i)]) : 0.0;
-    for (int j = 0; j < k; ++j) ld += bcast_u(lg, j);
+  // sum_j log L_jj in column order, the logarithms taken side by side
+  double la = 0.0, lv = 0.0;
+  const double lga = (oa && i < k) ? log(LA[bidx(i, i)]) : 0.0;
+  const double lgv = (ov && i < k) ? log(LV[bidx(i, i)]) : 0.0;
+  for (int j = 0; j < k; ++j) {
+    la += bcast_u(lga, j);
+    lv += bcast_u(lgv, j);
   }
-  *logdet = 2.0 * ld;
-  return ok;
+  *okA = oa; *okV = ov;
+  *ldA = 2.0 * la; *ldV = 2.0 * lv;
 }
 
 // Rebuild everything about the current model gamma (sorted index list g in
@@ -353,15 +379,9 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   M.c = wave_sum(lane < k ? bm * ab : 0.0);
   wave_sync();
   TSTAMP(sx, 1);
-  // the two factorisations share one (not unrolled) body
   bool okv = true, oka = true;
-#pragma nounroll
-  for (int s = 0; s < 2; ++s) {
-    double ld;
-    const bool ok = chol_blocks(ch, s ? ch.Lv : ch.La, s ? ch.rdv : ch.rda, &ld);
-    if (s) { okv = ok; M.ldv = ld; } else { oka = ok; M.lda = ld; }
-    TSTAMP(sx, s ? 3 : 2);
-  }
+  chol_blocks2(ch, ch.La, ch.rda, ch.Lv, ch.rdv, &oka, &okv, &M.lda, &M.ldv);
+  TSTAMP(sx, 3);
   if (!okv) {
     M.pd = false;
     M.logp = -BA_INF;
@@ -919,19 +939,32 @@ __device__ __forceinline__ void propose_swap(const SsvsParams &P, Chain &ch,
 //   batch mode  evaluate the next 64 W positions of the permutation; what was
 //               evaluated behind the first stop is thrown away.  Best while
 //               flips are accepted often (burn-in, ridge-like posteriors).
-//   cache mode  log_model_prob(gamma ^ {j}) depends on the current model only,
+//   table mode  log_model_prob(gamma ^ {j}) depends on the current model only,
 //               and the model changes only when a flip is accepted.  So it is
 //               evaluated ONCE for every j after each change (p / (64 W) fill
-//               rounds, natural variable order) into a per-chain table, and a
-//               sweep's decisions are table look-ups against fresh uniforms:
-//               log u_i <= table[perm[i]] - logp.  At stationarity (well under
-//               one accepted flip per sweep) most sweeps need no evaluation
-//               at all.
+//               rounds, natural variable order) into a per-chain table of
+//               acceptance thresholds E_j = exp(logp_j' - logp), and a sweep's
+//               decisions are look-ups against fresh uniforms: u_i <= E[perm[i]].
+//               At stationarity (well under one accepted flip per sweep) most
+//               sweeps need no evaluation at all.  The table outlives the launch.
 // The master picks the mode per sweep from the previous sweep's stop count.
+//
+// Quiet sweeps fork (table mode, W > 1): shuffle and flips consume p - 1 + nflips
+// stream numbers whatever happens, so the tail's stream position is known when
+// the sweep starts.  Wave 1 shuffles and walks the table while the master runs
+// the tail (swap proposal, sigma, beta) as if no flip were going to be accepted;
+// at the join a stop in the walk rolls the tail back.
+//
+// The master's state machine: PH_BEGIN (shuffle or fork) -> PH_FLIPS (rounds of
+// proposals / table walks up to the next stop; a stop queues an event) ->
+// PH_SWAP -> PH_TAIL -> [PH_JOIN] -> PH_COMMIT, with model rebuilds served as
+// events at the top of the loop.
 
 enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2, CMD_DECIDE = 3, CMD_SHUFFLE_DECIDE = 4 };
-// control block (doubles): 0 cmd, 1 k, 2 i0, 3..8 model scalars, 9 nflips;
-// u64 view at 10: flip_pos / uniform base position; wave slots from 16
+// control block (doubles): 0 cmd, 1 k, 2 i0, 3..8 the current model's scalars
+// (their home), 9 nflips; u64 view at 10: flip_pos / uniform base position;
+// evaluator slots from 16; 44.. the forked tail's roll-back copy; 48.. the
+// launch's scalar accumulators (ACC_* order)
 enum : int { CT_CMD = 0, CT_K = 1, CT_I0 = 2, CT_LOGP = 3, CT_LP = 4, CT_LDV = 5,
              CT_LDA = 6, CT_Q = 7, CT_C = 8, CT_NFLIPS = 9, CT_POS = 10, CT_PERMSEL = 12,
              CT_EVMODE = 13,
@@ -939,20 +972,6 @@ enum : int { CT_CMD = 0, CT_K = 1, CT_I0 = 2, CT_LOGP = 3, CT_LP = 4, CT_LDV = 5
 // slot: SL_F = permutation position of the wave's earliest stop (-1: none)
 enum : int { SL_F = 0, SL_J = 1, SL_KIND = 2, SL_LOGU = 3, SL_MARGIN = 4, SL_DELTA = 5 };
 enum : int { STOP_ACCEPT = 1, STOP_SLOW = 2, STOP_BAD = 3 };
-
-// minimum over the wave of a non-negative int (DPP), result in every lane
-__device__ __forceinline__ int wave_min_int(int x) {
-#define BA_DPP_MIN(ctrl, mask)                                                  \
-  x = min(x, __builtin_amdgcn_update_dpp(x, x, ctrl, mask, 0xf, false))
-  BA_DPP_MIN(0x118, 0xf);
-  BA_DPP_MIN(0x114, 0xf);
-  BA_DPP_MIN(0x112, 0xf);
-  BA_DPP_MIN(0x111, 0xf);
-  BA_DPP_MIN(0x142, 0xa);
-  BA_DPP_MIN(0x143, 0xc);
-#undef BA_DPP_MIN
-  return __builtin_amdgcn_readlane(x, 63);
-}
 
 __device__ __forceinline__ void shuffle_targets(const PhiloxKey &key, uint64_t pos,
                                                 int p, int tid, int nthreads,
@@ -983,7 +1002,7 @@ enum : int { EVM_BATCH = 0, EVM_FILL = 1 };
 //               exact path / negative SS) in its slot;
 //   EVM_FILL    lane = variable i0 + 64 wave + lane: evaluate it against the
 //               current model and store the result in the chain's table;
-// (Decisions by table look-up are the master's own loop, see the kernel.)
+// (Decisions by table look-up are decide_walk below.)
 template <int NB>
 __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
                                            const Model &M, const PhiloxKey &key,
@@ -1334,8 +1353,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   int phase = PH_BEGIN, sweep = 0, i0 = 0;
   bool model_checked = false;  // legality of the start is checked in sweep 0
   int perm_sel = 0;            // which LDS buffer holds the current permutation
-  // walking mode of the current sweep and its bookkeeping (see the kernel's
-  // header comment): scan mode decides positions [0, pos_done) so far
+  // walking mode of the current sweep (see the kernel's header comment)
   bool use_table = false;     // this sweep decides by table look-up
   // the table of the chain's last launch is still good when nothing but
   // sweeps happened since (the host clears table_keep otherwise)
@@ -1437,10 +1455,10 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         }
         pos0 = pos;
         if (!model_checked && M.logp > -BA_INF && M.logp < BA_INF) model_checked = true;
-        use_table = (P.scan_policy != 0) && (stops_prev <= 1 || P.scan_policy == 2);
+        use_table = (P.walk_policy != 0) && (stops_prev <= 1 || P.walk_policy == 2);
         stops_prev = stops_now;
         stops_now = 0;
-        if (W > 1 && use_table && table_valid && model_checked && p > 1 && P.scan_policy != 3) {
+        if (W > 1 && use_table && table_valid && model_checked && p > 1 && P.walk_policy != 3) {
           // ---- fork: wave 1 takes the permutation side of the sweep
           wave_sync();
           if (lane == 0) {

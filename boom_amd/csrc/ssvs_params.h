@@ -42,7 +42,10 @@ struct SsvsParams {
   int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
   int32_t waves; // wavefronts per chain (1, 2 or 4)
   int32_t mode;  // 0: BregVsSampler (sigma^2 integrated out); 1: SpikeSlabSampler (given sigma^2)
-  int32_t scan_policy;  // 0 batch mode only, 1 adaptive (table look-ups after quiet sweeps), 2 always the table, 3 adaptive without the forked quiet sweep (A/B)
+  // how a sweep's proposals are walked (ssvs_kernel.hip): 0 batch mode only, 1
+  // adaptive (table look-ups after quiet sweeps; the default), 2 always the
+  // table, 3 adaptive without the forked quiet sweep (diagnostic A/B)
+  int32_t walk_policy;
   int32_t slab_scales;  // mode 1: slab precision is Omega^{-1} / sigma^2 (MvnGivenScalarSigma)
 
   // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
