@@ -153,9 +153,10 @@ struct ba_engine {
   DevBuf<double> dmodel;  // per-chain model scratch (scalar-cache reads)
   DevBuf<double> dtab_lp;   // per-chain proposal table
   DevBuf<uint8_t> dtab_kind;
-  DevBuf<int32_t> dtab_tag;
+  DevBuf<int32_t> dtab_tag, dmodel_tag;
   DevBuf<int32_t> dran;  // catch-up launches of the state-space path: sweeps done per chain
   bool table_ok = false;  // nothing but ba_sweep launches since the tables were built
+  bool model_ok = false;  // nothing that changes a model's factors since the last sweep launch
   int trace_stride = 0;
   // scratch for suf build
   DevBuf<double> dX, dy, dxtx, dxsum, dsufscal;
@@ -314,6 +315,7 @@ int upload_shared(ba_engine *e) {
   e->waves = choose_waves(*e, e->kcap);
   e->device_dirty = false;
   e->table_ok = false;
+  e->model_ok = false;
   return BA_OK;
 }
 
@@ -332,8 +334,11 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(e->dtab_lp.resize(C * p));
   HIP_TRY(e->dtab_kind.resize(C * p));
   HIP_TRY(e->dtab_tag.resize(C));
+  HIP_TRY(e->dmodel_tag.resize(C));
+  e->model_ok = false;
   HIP_TRY(e->dran.resize(C));
   e->table_ok = false;
+  e->model_ok = false;
   HIP_TRY(e->dmaxk.resize(1));
   HIP_TRY(e->dtrace_idx.resize(C));
   HIP_TRY(e->dinc.resize(C * p));
@@ -417,6 +422,9 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.table_kind = e->dtab_kind.ptr;
   P.table_tag = e->dtab_tag.ptr;
   P.table_keep = e->table_ok ? 1 : 0;
+  P.model_tag = e->dmodel_tag.ptr;
+  P.model_keep = e->model_ok ? 1 : 0;
+  P.suf_changed = e->ss_mode ? 1 : 0;
   P.run_limit = 0;
   P.ran = nullptr;
   P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
@@ -672,6 +680,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
                              double ybar, const double *xbar) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   if (!xtx || !xty || !xbar) return fail(BA_E_INVALID, "null argument");
   int rc = set_dimension(e, p);
   if (rc) return rc;
@@ -691,6 +700,7 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
                                 const void *X_device, const void *y_device) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   if (!X_device || !y_device) return fail(BA_E_INVALID, "null argument");
   if (n <= 0) return fail(BA_E_INVALID, "n must be positive");
   int rc = set_dimension(e, p);
@@ -724,6 +734,7 @@ int ba_build_suf_from_xy(ba_engine *e, int64_t n, int32_t p, const double *X,
                          const double *y) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   if (!X || !y) return fail(BA_E_INVALID, "null argument");
   if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
   HIP_TRY(e->dX.resize((size_t)n * p));
@@ -756,6 +767,7 @@ int ba_set_slab(ba_engine *e, const double *prior_mean,
                 const double *unscaled_prior_precision) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   if (!prior_mean || !unscaled_prior_precision) return fail(BA_E_INVALID, "null argument");
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
   const int p = e->p;
@@ -769,6 +781,7 @@ int ba_set_slab(ba_engine *e, const double *prior_mean,
 int ba_set_spike(ba_engine *e, const double *pi, int64_t max_model_size) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   if (!pi) return fail(BA_E_INVALID, "null argument");
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
   for (int j = 0; j < e->p; ++j)
@@ -785,6 +798,7 @@ int ba_set_sigma_prior(ba_engine *e, double prior_df, double sigma_guess,
                        double sigma_upper_limit) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   if (sigma_upper_limit < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
   // ChisqModel(df, sigma): alpha = df/2, beta = df sigma^2/2 (ChisqModel.cpp:56-57)
   const double alpha = prior_df / 2.0;
@@ -802,6 +816,7 @@ int ba_set_priors_ctor1(ba_engine *e, double prior_nobs, double expected_rsq,
                         int32_t first_term_is_intercept) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
   if (!(expected_rsq > 0 && expected_rsq < 1)) return fail(BA_E_INVALID, "expected_rsq must be in (0, 1)");
   // BregVsSampler.cpp:37-44, 48-85
@@ -829,6 +844,7 @@ int ba_set_priors_ctor2(ba_engine *e, double prior_sigma_nobs,
                         int32_t force_intercept) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
   // BregVsSampler.cpp:87-142
   if (prior_sigma_guess <= 0)
@@ -877,6 +893,7 @@ int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
                    int32_t draw_beta, int32_t draw_sigma) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   e->max_flips = max_flips;
   if (swap_threshold != e->swap_threshold) e->device_dirty = true;
   e->swap_threshold = swap_threshold;
@@ -890,6 +907,7 @@ int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
                  const double *beta, double sigsq) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data first");
   if (!gamma) return fail(BA_E_INVALID, "null argument");
   const int64_t C = e->cfg.chains;
@@ -952,6 +970,7 @@ int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
 int ba_seed(ba_engine *e, uint64_t seed) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   e->seed = seed;
   if (e->state_ready) {
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -970,6 +989,7 @@ static int switch_mode(ba_engine *e, int mode, double v_scale) {
   }
   e->cur_mode = mode;
   e->table_ok = false;
+  e->model_ok = false;
   if (e->v_scale_want != v_scale) {
     e->v_scale_want = v_scale;
     e->device_dirty = true;
@@ -1000,6 +1020,7 @@ int ba_sweep(ba_engine *e, int32_t nsweeps) {
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
   HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
   e->table_ok = true;  // until anything but another ba_sweep touches the engine
+  e->model_ok = true;
   return BA_OK;
 }
 
@@ -1119,6 +1140,7 @@ int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
 int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   if (!(sigsq > 0)) return fail(BA_E_INVALID, "sigsq must be positive");
   int rc = alloc_chain_state(e);
   if (rc) return rc;
@@ -1138,6 +1160,7 @@ int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
                     int32_t precision_scales_with_sigsq, int32_t max_flips) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   int rc = ba_set_slab(e, mu, precision);
   if (rc) return rc;
   e->sss_slab_scales = precision_scales_with_sigsq ? 1 : 0;
@@ -1153,6 +1176,7 @@ int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
 int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
   if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
@@ -1228,6 +1252,7 @@ int ba_ss_set_data(ba_engine *e, int32_t T, int32_t p, const double *y,
                    const double *X, const uint8_t *observed) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   if (!y || !X) return fail(BA_E_INVALID, "null argument");
   if (T <= 0 || p <= 0) return fail(BA_E_INVALID, "T and p must be positive");
   // The regression model's fixed XtX (and the initial Xty, ...) are over the
@@ -1268,6 +1293,7 @@ int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_gues
                           double initial_level_sigma) {
   if (!e) return fail(BA_E_INVALID, "null engine");
   e->table_ok = false;
+  e->model_ok = false;
   if (level_sigma_upper_limit < 0 || initial_state_variance < 0)
     return fail(BA_E_INVALID, "sigma_max must be non-negative.");
   // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
@@ -1312,6 +1338,8 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
   for (int i = 0; i < nsweeps; ++i) {
     HIP_TRY(launch_ssvs_sweep(e->stream, P, 1));     // observation model
     HIP_TRY(launch_kalman_simsmooth(e->stream, S, 1));  // level model, state
+    P.model_keep = 1;  // from here on the chains' model blocks are their own last launch's
+    e->model_ok = true;
   }
   return BA_OK;
 }
@@ -1336,6 +1364,7 @@ int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
 int ba_ss_set_level_sigsq(ba_engine *e, int64_t chain, double sigsq) {
   ENGINE_PROLOGUE(e);
   e->table_ok = false;
+  e->model_ok = false;
   int rc = ss_prepare(e);
   if (rc) return rc;
   const int64_t C = e->cfg.chains;

@@ -311,17 +311,28 @@ __device__ __forceinline__ void chol_blocks2(const Chain &ch, lds_f64 *LA, lds_f
 // Rebuild everything about the current model gamma (sorted index list g in
 // LDS) from scratch: BregVsSampler::set_reg_post_params + log_model_prob.
 // Inlined at its (single) call site in each kernel.
+// REUSE: the factors (and log prior, log determinants) of this very model are
+// already in LDS / M -- restored from the chain's block at the start of a
+// launch -- and only what depends on the sufficient statistics X'y, y'y is
+// recomputed (state-space path: they move every sweep).
+template <bool REUSE>
 __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &M, StampCtx &sx) {
   const int lane = ch.lane, p = ch.p, k = ch.k;
   TSTAMP(sx, 7);
   M.bad = 0;
   M.pd = true;
-  // VariableSelectionPrior::logp (VariableSelectionPrior.cpp:271-285)
-  double part = 0.0;
-  for (int j = lane; j < p; j += WAVE) part += ch.gam[j] ? P.l1[j] : P.l0[j];
-  double lp = wave_sum(part);
-  if (P.max_model_size >= 0 && k > P.max_model_size) lp = -BA_INF;
-  if (!(lp > -BA_INF)) lp = -BA_INF;  // also catches NaN from inf - inf
+  double lp;
+  const double ldv_in = M.ldv, lda_in = M.lda;
+  if (REUSE) {
+    lp = M.lp;
+  } else {
+    // VariableSelectionPrior::logp (VariableSelectionPrior.cpp:271-285)
+    double part = 0.0;
+    for (int j = lane; j < p; j += WAVE) part += ch.gam[j] ? P.l1[j] : P.l0[j];
+    lp = wave_sum(part);
+    if (P.max_model_size >= 0 && k > P.max_model_size) lp = -BA_INF;
+    if (!(lp > -BA_INF)) lp = -BA_INF;  // also catches NaN from inf - inf
+  }
   M.lp = lp;
   M.ldv = M.lda = M.Q = M.c = 0.0;
   M.SS = ch.ss0q;
@@ -340,7 +351,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   // gather V_g, A_g (lower triangles, rows padded with zeros to a multiple of
   // 8) with all loads independent: element e <-> (m, n), n <= m
   const int kpad = (k + 7) & ~7;
-  const int nelem = kpad * (kpad + 1) / 2;
+  const int nelem = REUSE ? 0 : kpad * (kpad + 1) / 2;
   for (int e = lane; e < nelem; e += WAVE) {
     int m = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
     while ((m + 1) * (m + 2) / 2 <= e) ++m;
@@ -357,7 +368,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   }
   const int gm = (lane < k) ? ch.g[lane] : 0;
   const double bm = (lane < k) ? P.b[gm] : 0.0;
-  if (lane < kpad) {
+  if (!REUSE && lane < kpad) {
     ch.bg[lane] = bm;
     if (lane >= k) {
       ch.rdv[lane] = 0.0;
@@ -380,7 +391,12 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   wave_sync();
   TSTAMP(sx, 1);
   bool okv = true, oka = true;
-  chol_blocks2(ch, ch.La, ch.rda, ch.Lv, ch.rdv, &oka, &okv, &M.lda, &M.ldv);
+  if (REUSE) {
+    M.lda = lda_in;
+    M.ldv = ldv_in;
+  } else {
+    chol_blocks2(ch, ch.La, ch.rda, ch.Lv, ch.rdv, &oka, &okv, &M.lda, &M.ldv);
+  }
   TSTAMP(sx, 3);
   if (!okv) {
     M.pd = false;
@@ -449,7 +465,7 @@ __device__ __forceinline__ void apply_flip(Chain &ch, int j) {
 // Copy the current model's wave-uniform data from LDS to this chain's HBM
 // block, make it visible to the scalar cache and re-derive the read pointer.
 template <int NB>
-__device__ __forceinline__ void publish_model(Chain &ch) {
+__device__ __forceinline__ void publish_model(Chain &ch, const Model &M) {
   const int lane = ch.lane, k = ch.k;
   constexpr int KCAP = NB * 8;
   const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
@@ -466,6 +482,11 @@ __device__ __forceinline__ void publish_model(Chain &ch) {
     dst[S.w + lane] = ch.w[lane];
     dst[S.bg + lane] = ch.bg[lane];
     ((int *)(dst + S.g))[lane] = (lane < k) ? (int)ch.g[lane] : 0;
+  }
+  if (lane == 0) {
+    double *sc = dst + S.scal;
+    sc[0] = M.logp; sc[1] = M.lp; sc[2] = M.ldv; sc[3] = M.lda;
+    sc[4] = M.Q; sc[5] = M.c; sc[6] = M.SS; sc[7] = M.pd ? 1.0 : 0.0;
   }
   unsigned long long u = (unsigned long long)dst;
   asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(u) : : "memory");
@@ -1375,6 +1396,32 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   WinRng rng;
   rng.init(key, lane, pos);
 
+  // The chain's model block of the last launch is still this model (nothing but
+  // sweeps happened since): take the factors from there instead of factoring.
+  if (P.model_keep && P.model_tag[chain] == KCAP && status == CHAIN_OK) {
+    restore_model<NB>(ch);
+    {
+      const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
+      const double *sc = ch.sc_store + S.scal;
+      M.logp = sc[0]; M.lp = sc[1]; M.ldv = sc[2]; M.lda = sc[3];
+      M.Q = sc[4]; M.c = sc[5]; M.SS = sc[6]; M.pd = sc[7] != 0.0;
+      unsigned long long u = (unsigned long long)ch.sc_store;
+      asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(u) : : "memory");
+      ch.sc = (c_f64 *)u;
+    }
+    if (P.suf_changed) {
+      refactor<true>(P, ch, M, sx);
+      if (M.bad) status = M.bad;
+      else publish_model<NB>(ch, M);
+    }
+    if (lane == 0) {
+      ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
+      ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
+    }
+    wave_sync();
+    pe.kind = EV_NONE;
+  }
+
   while (status == CHAIN_OK) {
     if (pe.kind != EV_NONE && !spec) {
       // ---- the one place where a model is (re)built (a swap proposed by a
@@ -1391,7 +1438,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       bool rejected = false;
       {
         Model Mn;
-        refactor(P, ch, Mn, sx);
+        refactor<false>(P, ch, Mn, sx);
         if (Mn.bad) {
           status = Mn.bad;
         } else {
@@ -1420,7 +1467,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       if (status == CHAIN_OK) {
         TSTAMP(sx, 7);
         if (!rejected) {
-          publish_model<NB>(ch);
+          publish_model<NB>(ch, M);
           if (lane == 0) {
             ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
             ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
@@ -1855,6 +1902,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     P.todo[chain] = nsweeps - done + owed_after;
     if (P.ran) P.ran[chain] = done;
     P.table_tag[chain] = (table_valid && !aborted && status == CHAIN_OK) ? KCAP : 0;
+    P.model_tag[chain] = (!aborted && status == CHAIN_OK) ? KCAP : 0;
     if (P.trace_idx) P.trace_idx[chain] = trace_at + done;
     if (P.maxk) atomicMax(P.maxk, kmax);
     double *a = P.acc + (size_t)chain * ACC_COUNT;
@@ -1915,7 +1963,7 @@ __global__ __launch_bounds__(64) void ssvs_logp_kernel(SsvsParams P,
   Model M;
   StampCtx sx;
   sx.last = 0;
-  refactor(P, ch, M, sx);
+  refactor<false>(P, ch, M, sx);
   if (lane == 0) {
     out[which] = M.logp;
     status_out[which] = M.bad;

@@ -107,6 +107,12 @@ struct SsvsParams {
   double *table_lp;             // chains x p
   uint8_t *table_kind;          // chains x p
   int32_t *table_tag;           // chains: capacity the table was built with, 0 = stale
+  // The model block itself survives a launch the same way: model_tag[chain] =
+  // capacity it was published with (0: rebuild); model_keep as table_keep;
+  // suf_changed: xty / yty moved since (state-space path) -- the factors are
+  // reused, the right-hand side and everything after it recomputed.
+  int32_t *model_tag;
+  int32_t model_keep, suf_changed;
   int32_t table_keep;           // 0: ignore the tags (something other than sweeps happened)
   double *model_scratch;        // chains x model_scratch_stride doubles
   int64_t model_scratch_stride;
@@ -163,7 +169,7 @@ static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
 
 // offsets (in doubles) inside one chain's model_scratch block
 struct SsvsScalarLayout {
-  uint32_t Lv, La, rdv, rda, w, bg, g, total;
+  uint32_t Lv, La, rdv, rda, w, bg, g, scal, total;
 };
 static inline __host__ __device__ SsvsScalarLayout ssvs_scalar_layout(int kcap) {
   SsvsScalarLayout S;
@@ -177,6 +183,7 @@ static inline __host__ __device__ SsvsScalarLayout ssvs_scalar_layout(int kcap) 
   S.w = o;   o += (uint32_t)kcap;
   S.bg = o;  o += (uint32_t)kcap;
   S.g = o;   o += (uint32_t)kcap / 2;  // int32 indices, two per double
+  S.scal = o; o += 8;                  // logp, lp, ldv, lda, Q, c, SS, pd (the model's scalars)
   S.total = (o + 7u) & ~7u;            // whole 64-byte lines per chain
   return S;
 }
