@@ -77,6 +77,14 @@ __device__ __forceinline__ double wave_sum(double x) {
   return bcast_u(x, 63);
 }
 
+// LDS hand-off between the lanes of one wavefront (DS operations of a wave
+// complete in order: only the compiler has to be told)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // x -> A x + B
 struct Aff { double A, B; };
 __device__ __forceinline__ Aff aff_after(const Aff &later, const Aff &earlier) {
@@ -219,15 +227,24 @@ enum : int { NR = 32 };  // registers per lane of a time panel
 
 }  // namespace
 
-// grid = chains, block = 64
-__global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
-                                                              int draw_level) {
-  __shared__ double s_u[NB_UNIF];      // a block of the stream's uniforms
-  __shared__ double s_z[NB_START];     // the normal that starts at each offset
-  __shared__ uint8_t s_n1[NB_START];   // uniforms the first consumes (0: ran out)
-  __shared__ uint16_t s_j[NLEV][NB_START];  // jump tables of the stream walk
-  __shared__ uint16_t s_slow[NB_START];  // offsets whose draw leaves the first branch
-  const int chain = blockIdx.x, lane = threadIdx.x;
+// grid = chains, block = 128: wave 0 runs the chain; wave 1 only helps with the
+// sweep's normals (windows of the stream alternate between the two waves) and
+// leaves after that phase.
+__global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
+                                                               int draw_level) {
+  // per wave: one window of the stream
+  __shared__ double s_u_[2][NB_UNIF];      // the window's uniforms
+  __shared__ double s_z_[2][NB_START];     // the normal that starts at each offset
+  __shared__ uint8_t s_n1_[2][NB_START];   // uniforms it consumes (0: ran out)
+  __shared__ uint16_t s_j_[2][NLEV][NB_START];  // jump tables of the stream walk
+  __shared__ uint16_t s_slow_[2][NB_START];  // offsets whose draw leaves the first branch
+  __shared__ int s_hand[4];                // entry offset of the next window, draws so far, done, status
+  const int chain = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *s_u = s_u_[wave];
+  double *s_z = s_z_[wave];
+  uint8_t *s_n1 = s_n1_[wave];
+  uint16_t (*s_j)[NB_START] = s_j_[wave];
+  uint16_t *s_slow = s_slow_[wave];
   if (chain >= P.chains) return;
   if (P.status[chain] != CHAIN_OK) return;
   if (P.only_ran && P.only_ran[chain] == 0) return;
@@ -248,13 +265,13 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
     const double SS = P.level_sumsq[chain] + P.level_prior_ss;
     level_sigsq = d_draw_variance(rng, DF, SS, P.level_sigma_max, &bad);
     if (bad) status = CHAIN_RNG_BRANCH;
-    if (lane == 0) {
+    if (lane == 0 && wave == 0) {  // (wave 1 repeats the draw: it needs sigma_level != 0)
       P.pos_level[chain] = rng.pos;
       P.level_sigsq[chain] = level_sigsq;
     }
   }
   if (status != CHAIN_OK) {
-    if (lane == 0) P.status[chain] = status;
+    if (lane == 0 && wave == 0) P.status[chain] = status;
     return;
   }
 
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   // lane m of a batch holding (j_m, beta_m)
   // A panel of NR * 64 time steps lives in registers (element i of lane l is
   // step tb + 64 i + l), so that a variable's column is NR independent loads.
-  for (int tb = 0; tb < T; tb += NR * WAVE) {
+  for (int tb = 0; tb < T && wave == 0; tb += NR * WAVE) {
     double pred[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) pred[i] = 0.0;
@@ -314,7 +331,6 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
       if (t < T) w0[t] = P.y[t] - pred[i];
     }
   }
-  __syncthreads();
   KSTAMP(1);
   // ---- 2. the standard normals of simulate_forward, in stream order:
   // t = 0: initial state (if P0 > 0), observation (if sigma_obs > 0);
@@ -323,27 +339,35 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
   const int dI = (sd0 != 0.0), dL = (level_sigma != 0.0), dH = (sqrtH != 0.0);
   const int nfirst = dI + dH, nper = dL + dH;
   const int N = nfirst + (T - 1) * nper;
-  uint64_t bpos = P.pos_state[chain];
+  // The stream is cut into fixed windows of NB_START offsets (+ a margin for
+  // draws that start near the end): window b belongs to wave b & 1.  Everything
+  // about a window except WHERE the sequential reader enters it -- uniforms,
+  // the draw starting at every offset, the jump tables -- is independent of the
+  // other windows, so the two waves build their windows side by side and only
+  // the look-ups are chained, through s_hand.
+  const uint64_t bpos0 = P.pos_state[chain];
   {
     const PhiloxKey key{P.seed_lo, P.seed_hi, gchain, 2u};
-    int n = 0;
-    while (n < N && status == CHAIN_OK) {
-      // uniforms bpos .. bpos + NB_UNIF - 1, both numbers of every Philox block
-      const uint64_t b0 = bpos >> 1;
+    if (threadIdx.x == 0) { s_hand[0] = 0; s_hand[1] = 0; s_hand[2] = (N == 0); s_hand[3] = CHAIN_OK; }
+    __syncthreads();
+    for (int round = 0; !s_hand[2]; ++round) {
+      const uint64_t wstart = bpos0 + (uint64_t)(2 * round + wave) * NB_START;
+      // uniforms wstart .. wstart + NB_UNIF - 1, both numbers of every Philox block
+      const uint64_t b0 = wstart >> 1;
       for (int i = 0; i * WAVE < NB_UNIF / 2 + 1; ++i) {
         const uint64_t blk = b0 + (uint64_t)(i * WAVE + lane);
         double u0, u1;
         philox_pair(key, blk, &u0, &u1);
-        const long long o0 = (long long)(2 * blk) - (long long)bpos;
+        const long long o0 = (long long)(2 * blk) - (long long)wstart;
         if (o0 >= 0 && o0 < NB_UNIF) s_u[o0] = u0;
         if (o0 + 1 >= 0 && o0 + 1 < NB_UNIF) s_u[o0 + 1] = u1;
       }
-      __syncthreads();
+      wave_lds_sync();
       KSTAMP(2);
       // the draw that would start at every offset, lane-parallel and
       // speculative: the first Kinderman-Ramage branch (88 % of the draws, two
       // uniforms, one line) for all of them; the offsets that take another
-      // branch are compacted so that the divergent code runs once per block,
+      // branch are compacted so that the divergent code runs once per window,
       // not once per pass
       int nslow = 0;
       for (int ob = 0; ob < NB_START; ob += WAVE) {
@@ -358,7 +382,7 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
         if (!fast) s_slow[nslow + __popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)o;
         nslow += __popcll(sm);
       }
-      __syncthreads();
+      wave_lds_sync();
       KSTAMP(8);
       for (int sb = 0; sb < nslow; sb += WAVE) {
         if (sb + lane < nslow) {
@@ -369,16 +393,16 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
           s_n1[o] = (uint8_t)used;
         }
       }
-      __syncthreads();
+      wave_lds_sync();
       KSTAMP(9);
-      // The sequential reader's walk 0 -> 0 + used(0) -> ... without walking:
+      // The sequential reader's walk e -> e + used(e) -> ... without walking:
       // jump tables J_k[o] = offset after 2^k draws from o (binary lifting), then
-      // draw number r of the block starts where the bits of r lead from 0.
+      // draw number r of the window starts where the bits of r lead from e.
       for (int o = lane; o < NB_START; o += WAVE) {
         const int u1 = s_n1[o];
         s_j[0][o] = (uint16_t)(u1 ? o + u1 : JT);
       }
-      __syncthreads();
+      wave_lds_sync();
       for (int k = 1; k < NLEV; ++k) {
         // (a lane's NB_START / 64 entries side by side: two LDS round trips per level)
         int a1[NB_START / WAVE], a2[NB_START / WAVE];
@@ -389,16 +413,20 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
 #pragma unroll
         for (int i = 0; i < NB_START / WAVE; ++i)
           s_j[k][lane + i * WAVE] = (uint16_t)((a1[i] < NB_START) ? a2[i] : JT);
-        __syncthreads();
+        wave_lds_sync();
       }
       KSTAMP(10);
-      const int want = N - n;
-      int m = 0, o = 0;
-      {
+      // the look-ups, in window order: wave 0's window, then wave 1's
+      for (int turn = 0; turn < 2; ++turn) {
+        __syncthreads();
+        if (turn != wave || s_hand[2]) continue;
+        const int entry = s_hand[0], n = s_hand[1];
+        const int want = N - n;
+        int m = 0, o = entry;
         int node[NORD];
         bool ok[NORD];
 #pragma unroll
-        for (int i = 0; i < NORD; ++i) node[i] = 0;
+        for (int i = 0; i < NORD; ++i) node[i] = entry;
 #pragma unroll
         for (int k = 0; k < NLEV; ++k) {
           int nx[NORD];
@@ -426,21 +454,32 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
           m += __popcll(__ballot(ok[i]));
           node[i] = ok[i] ? node[i] + u1[i] : 0;  // where the draw after this one starts
         }
-        // the block's draws are numbers 0 .. m-1; the next block starts after the last
+        // the window's draws are numbers 0 .. m-1; the reader leaves it after the last
         if (m > 0) {
           const int li = (m - 1) >> 6, ll = (m - 1) & 63;
 #pragma unroll
           for (int i = 0; i < NORD; ++i)
             if (i == li) o = __builtin_amdgcn_readlane(node[i], ll);
         }
+        const bool finished = (n + m >= N);
+        // a draw longer than the margin would break the fixed windows
+        const bool broken = !finished && (m == 0 || o < NB_START);
+        if (lane == 0) {
+          s_hand[0] = o - NB_START;
+          s_hand[1] = n + m;
+          s_hand[2] = finished || broken;
+          if (broken) s_hand[3] = CHAIN_RNG_BRANCH;
+          if (finished) {  // stream position after the sweep's last draw
+            P.pos_state[chain] = wstart + (uint64_t)o;
+          }
+        }
       }
-      KSTAMP(11);
-      n += m;
-      if (m == 0) status = CHAIN_RNG_BRANCH;  // a draw longer than a whole block
-      bpos += (uint64_t)o;
       __syncthreads();
+      KSTAMP(11);
     }
+    status = s_hand[3];
   }
+  if (wave != 0) return;  // (wave 0's later barriers only count live waves)
   if (status != CHAIN_OK) {
     if (lane == 0) P.status[chain] = status;
     return;
@@ -607,7 +646,6 @@ __global__ __launch_bounds__(64) void kalman_simsmooth_kernel(SsParams P,
     P.nobs[chain] = nobs;
     P.level_n[chain] = lev_n;
     P.level_sumsq[chain] = lev_ss;
-    P.pos_state[chain] = bpos;
 #ifdef BA_KSTAMPS
     KSTAMP(7);
     if (chain == 0 && draw_level)
@@ -623,7 +661,7 @@ hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int
 
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level) {
-  hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chains), dim3(WAVE), 0,
+  hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chains), dim3(2 * WAVE), 0,
                      stream, P, draw_level);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
