@@ -73,6 +73,8 @@ SIGNATURES = {
     "ba_summaries_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ba_enable_traces": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_get_traces": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
+    "ba_enable_draws": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_get_draws": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _u8p, _dp, _dp]),
     "ba_stream": (C.c_void_p, [C.c_void_p]),
     "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
@@ -283,6 +285,18 @@ class Engine:
 
     def enable_traces(self, max_sweeps):
         self._check(self.lib.ba_enable_traces(self._h, max_sweeps))
+
+    def enable_draws(self, max_sweeps):
+        self._check(self.lib.ba_enable_draws(self._h, max_sweeps))
+
+    def get_draws(self, chain, nsweeps):
+        """the recorded draws of one chain (global id) of the last sweep() call"""
+        p = self.p
+        g = np.zeros((nsweeps, p), np.uint8)
+        b = np.zeros((nsweeps, p))
+        s = np.zeros(nsweeps)
+        self._check(self.lib.ba_get_draws(self._h, chain, nsweeps, _b(g), _p(b), _p(s)))
+        return g, b, s
 
     def get_traces(self, nsweeps):
         c = self.chains

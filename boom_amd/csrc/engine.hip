@@ -150,6 +150,8 @@ struct ba_engine {
   DevBuf<uint32_t> dinc;
   DevBuf<double> dbsum, dbsumsq, dacc, dsummary;
   DevBuf<double> dtr_sig, dtr_logp, dtr_k;
+  DevBuf<uint16_t> drec_idx;  // recorded draws (ba_enable_draws)
+  DevBuf<double> drec_beta;
   DevBuf<double> dmodel;  // per-chain model scratch (scalar-cache reads)
   DevBuf<double> dtab_lp;   // per-chain proposal table
   DevBuf<uint8_t> dtab_kind;
@@ -452,6 +454,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.trace_logp = e->dtr_logp.ptr;
   P.trace_k = e->dtr_k.ptr;
   P.trace_stride = e->trace_stride;
+  P.rec_idx = e->drec_idx.ptr;
+  P.rec_beta = e->drec_beta.ptr;
 }
 
 // Resume chains that outgrew the capacity of the launch they were in, with the
@@ -1113,7 +1117,50 @@ int ba_enable_traces(ba_engine *e, int32_t max_sweeps) {
   HIP_TRY(e->dtr_sig.resize(C * max_sweeps));
   HIP_TRY(e->dtr_logp.resize(C * max_sweeps));
   HIP_TRY(e->dtr_k.resize(C * max_sweeps));
+  e->drec_idx.release();
+  e->drec_beta.release();
   e->trace_stride = max_sweeps;
+  return BA_OK;
+}
+
+int ba_enable_draws(ba_engine *e, int32_t max_sweeps) {
+  int rc = ba_enable_traces(e, max_sweeps);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains;
+  HIP_TRY(e->drec_idx.resize(C * max_sweeps * 64));
+  HIP_TRY(e->drec_beta.resize(C * max_sweeps * 64));
+  return BA_OK;
+}
+
+int ba_get_draws(ba_engine *e, int64_t chain, int32_t nsweeps, uint8_t *gamma,
+                 double *beta, double *sigsq) {
+  ENGINE_PROLOGUE(e);
+  if (e->trace_stride <= 0 || e->drec_idx.count == 0)
+    return fail(BA_E_STATE, "draw recording is not enabled");
+  if (nsweeps <= 0 || nsweeps > e->trace_stride) return fail(BA_E_INVALID, "nsweeps out of range");
+  const int64_t c = chain - e->cfg.chain_offset;
+  if (c < 0 || c >= e->cfg.chains) return fail(BA_E_INVALID, "chain id not owned by this engine");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p, base = (size_t)c * e->trace_stride;
+  std::vector<double> ks(nsweeps), sig(nsweeps), b((size_t)nsweeps * 64);
+  std::vector<uint16_t> idx((size_t)nsweeps * 64);
+  HIP_TRY(hipMemcpy(ks.data(), e->dtr_k.ptr + base, (size_t)nsweeps * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sig.data(), e->dtr_sig.ptr + base, (size_t)nsweeps * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(idx.data(), e->drec_idx.ptr + base * 64, idx.size() * 2, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b.data(), e->drec_beta.ptr + base * 64, b.size() * 8, hipMemcpyDeviceToHost));
+  if (gamma) std::memset(gamma, 0, (size_t)nsweeps * p);
+  if (beta) std::memset(beta, 0, (size_t)nsweeps * p * 8);
+  for (int s = 0; s < nsweeps; ++s) {
+    const int k = (int)ks[s];
+    for (int m = 0; m < k && m < 64; ++m) {
+      const size_t j = idx[(size_t)s * 64 + m];
+      if (j >= p) return fail(BA_E_STATE, "corrupt draw record");
+      if (gamma) gamma[(size_t)s * p + j] = 1;
+      if (beta) beta[(size_t)s * p + j] = b[(size_t)s * 64 + m];
+    }
+    if (sigsq) sigsq[s] = sig[s];
+  }
   return BA_OK;
 }
 

@@ -1788,11 +1788,17 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       ACC_ADD(ACC_SIGSQ, sigsq);
       ACC_ADD(ACC_SIGSQ2, sigsq * sigsq);
       ACC_ADD(ACC_K, k);
-      if (P.trace_sigsq && trace_at + sweep < P.trace_stride && lane == 0) {
+      if (P.trace_sigsq && trace_at + sweep < P.trace_stride) {
         const size_t o = (size_t)chain * P.trace_stride + trace_at + sweep;
-        P.trace_sigsq[o] = sigsq;
-        P.trace_logp[o] = M.logp;
-        P.trace_k[o] = (double)k;
+        if (lane == 0) {
+          P.trace_sigsq[o] = sigsq;
+          P.trace_logp[o] = M.logp;
+          P.trace_k[o] = (double)k;
+        }
+        if (P.rec_idx && lane < k) {  // the sweep's draw itself (recording step)
+          P.rec_idx[o * 64 + lane] = (uint16_t)gprev;
+          P.rec_beta[o * 64 + lane] = beta_valid ? beta_m : 0.0;
+        }
       }
       ++done;
       ++sweep;

@@ -125,6 +125,10 @@ struct SsvsParams {
   // optional traces (nullptr = off): chains x trace_stride
   double *trace_sigsq, *trace_logp, *trace_k;
   int32_t trace_stride;
+  // optional record of every sweep's draw (nullptr = off), same slots as the
+  // traces: the included variables and their coefficients, 64 per slot
+  uint16_t *rec_idx;   // chains x trace_stride x 64
+  double *rec_beta;    // chains x trace_stride x 64
 };
 
 // ---- LDS layout of one chain (one wavefront) --------------------------------

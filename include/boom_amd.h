@@ -188,6 +188,16 @@ int ba_summaries_device(ba_engine *e, void *out_device);
 int ba_enable_traces(ba_engine *e, int32_t max_sweeps);
 int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
                   double *model_size);
+/* Recording of every sweep's draw (the step the callers do on the host today:
+ * RListIoManager::write, Interfaces/R/list_io.cpp; spikeslab.py:191-207): with
+ * recording enabled a ba_sweep(n) call keeps the n draws of every chain on the
+ * device (traces included), so a `for (i < niter) sample_posterior(); record()`
+ * loop becomes one launch and niter reads.  ba_get_draws expands one chain's
+ * draws: gamma nsweeps x p, beta nsweeps x p (zeros outside gamma), sigsq
+ * nsweeps; any pointer may be NULL. */
+int ba_enable_draws(ba_engine *e, int32_t max_sweeps);
+int ba_get_draws(ba_engine *e, int64_t chain, int32_t nsweeps, uint8_t *gamma,
+                 double *beta, double *sigsq);
 
 /* the engine's HIP stream (hipStream_t) for callers that order their own work */
 void *ba_stream(ba_engine *e);

@@ -104,3 +104,36 @@ def test_tables_are_dropped_when_anything_else_is_called():
     finally:
         os.environ.pop("BOOM_AMD_SCAN", None)
     assert np.array_equal(ga, gb) and np.array_equal(ba_, bb) and np.array_equal(sa, sb)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("waves,policy", [(2, 1), (2, 2), (1, 2)])
+def test_every_draw_of_one_long_launch_matches_the_oracle(oracle, case, waves, policy):
+    """ONE launch of many sweeps (table look-ups, forked quiet sweeps, kept
+    model blocks all in play), every sweep's draw recorded on the device and
+    compared with the oracle's draw of the same sweep: gamma bit-exact, beta and
+    sigma^2 within the stated fp64 tolerance."""
+    suf, prior, opts = CASES[case]
+    p = len(suf["xty"])
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    chains, seed, nsw = 6, 2024, 80
+    os.environ["BOOM_AMD_WAVES"] = str(waves)
+    os.environ["BOOM_AMD_SCAN"] = str(policy)
+    try:
+        eng = make_engine(chains, seed, suf=suf, prior=prior, opts=opts, g0=g0)
+        eng.enable_draws(nsw)
+        eng.sweep(nsw)
+        draws = [eng.get_draws(c, nsw) for c in range(chains)]
+    finally:
+        os.environ.pop("BOOM_AMD_WAVES", None)
+        os.environ.pop("BOOM_AMD_SCAN", None)
+    for c in range(chains):
+        o = oracle.ssvs_run(suf, prior, opts, ("philox", seed, c), g0, nsw)
+        assert o["status"] == 0
+        gam, beta, sig = draws[c]
+        for s in range(nsw):
+            assert np.array_equal(gam[s], o["gamma"][s]), (case, c, s)
+            err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
+            assert err < 1e-8, (case, c, s, err)
+            assert abs(sig[s] - o["sigsq"][s]) < 1e-8 * sig[s], (case, c, s)
