@@ -165,6 +165,15 @@ class RegressionModel : public Model {
   // used by the sampler
   void push_state() { eng_->check(ba_set_state(eng_->get(), -1, inc_.bytes().data(), beta_.data(), sigsq_)); }
   void pull_chain0() { eng_->check(ba_get_state(eng_->get(), 0, inc_.bytes().data(), beta_.data(), &sigsq_)); }
+  // chain 0's parameters from a recorded draw (row `row` of gamma / beta)
+  void set_from_record(const std::vector<uint8_t> &gamma, const std::vector<double> &beta,
+                       const std::vector<double> &sigsq, int row) {
+    for (int j = 0; j < p_; ++j) {
+      inc_.bytes()[j] = gamma[(size_t)row * p_ + j];
+      beta_[j] = beta[(size_t)row * p_ + j];
+    }
+    sigsq_ = sigsq[row];
+  }
  private:
   Ptr<Engine> eng_;
   int p_;
@@ -212,8 +221,33 @@ class BregVsSampler : public PosteriorSampler {
 
   void draw() override {                     // BregVsSampler.cpp:252-261
     if (!pushed_) { model_->push_state(); pushed_ = true; }
+    if (lookahead_ > 1) {
+      // the caller's one-draw-per-iteration loop served from draws recorded on
+      // the device: one launch per `lookahead_` iterations
+      if (served_ == avail_) {
+        check(ba_sweep(h(), lookahead_));
+        check(ba_get_draws(h(), 0, lookahead_, rec_gamma_.data(), rec_beta_.data(), rec_sigsq_.data()));
+        avail_ = lookahead_;
+        served_ = 0;
+      }
+      model_->set_from_record(rec_gamma_, rec_beta_, rec_sigsq_, served_++);
+      return;
+    }
     check(ba_sweep(h(), 1));
     model_->pull_chain0();
+  }
+  // run `n` sweeps ahead per launch and hand them out one draw() at a time
+  // (chain 0 backs the model's parameters; a setter called in between discards
+  // the draws not handed out yet: the chain is then simply thinned)
+  void set_lookahead(int n) {
+    lookahead_ = n;
+    served_ = avail_ = 0;
+    if (n > 1) {
+      check(ba_enable_draws(h(), n));
+      rec_gamma_.assign((size_t)n * model_->xdim(), 0);
+      rec_beta_.assign((size_t)n * model_->xdim(), 0.0);
+      rec_sigsq_.assign(n, 0.0);
+    }
   }
   void draw(int nsweeps) {                   // many sweeps in one launch
     if (!pushed_) { model_->push_state(); pushed_ = true; }
@@ -242,13 +276,16 @@ class BregVsSampler : public PosteriorSampler {
  private:
   ba_engine *h() const { return model_->engine()->get(); }
   void check(int rc) const { model_->engine()->check(rc); }
-  void options() { check(ba_set_options(h(), max_flips_, swap_, draw_beta_, draw_sigma_)); }
+  void options() { served_ = avail_ = 0; check(ba_set_options(h(), max_flips_, swap_, draw_beta_, draw_sigma_)); }
   void set_raw(const Vector &b, const SpdMatrix &om, double df, double guess, const Vector &pi, int64_t mms) {
     check(ba_set_slab(h(), b.data(), om.data()));
     check(ba_set_spike(h(), pi.data(), mms));
     check(ba_set_sigma_prior(h(), df, guess, infinity()));
   }
   RegressionModel *model_;
+  int lookahead_ = 1, served_ = 0, avail_ = 0;
+  std::vector<uint8_t> rec_gamma_;
+  std::vector<double> rec_beta_, rec_sigsq_;
   bool pushed_ = false;
   int max_flips_ = -1, draw_beta_ = 1, draw_sigma_ = 1;
   double swap_ = 0.8;

@@ -229,9 +229,38 @@ static void StateSpace() {
   EXPECT(model.level_sigsq(3) > 0.01 && model.level_sigsq(3) < 1.0);
 }
 
+// The reference's callers draw once per iteration and record the model's
+// parameters; with a look-ahead the sampler runs many sweeps per launch and
+// serves them one by one: the recorded sequence must be the same.
+static void LookAhead() {
+  const int n = 400, p = 12, chains = 4, niter = 45;
+  Vector beta(p, 0.0);
+  beta[0] = 1.0; beta[3] = -2.0; beta[7] = 1.5;
+  Sim s = simulate(n, p, beta, 1.0, 5);
+  std::vector<double> rec[2];
+  for (int mode = 0; mode < 2; ++mode) {
+    RegressionModel model(s.X, s.y, chains, 99);
+    Ptr<BregVsSampler> sampler(new BregVsSampler(&model, 1.0, 0.5, 3.0, true));
+    model.set_method(sampler);
+    model.drop_all();
+    model.add(0);
+    if (mode == 1) sampler->set_lookahead(20);
+    for (int i = 0; i < niter; ++i) {
+      model.sample_posterior();
+      for (int j = 0; j < p; ++j) rec[mode].push_back(model.inc()[j] ? model.Beta()[j] : 0.0);
+      rec[mode].push_back(model.sigsq());
+    }
+  }
+  EXPECT(rec[0].size() == rec[1].size());
+  bool same = true;
+  for (size_t i = 0; i < rec[0].size() && i < rec[1].size(); ++i) same = same && (rec[0][i] == rec[1][i]);
+  EXPECT(same);
+}
+
 int main() {
   try {
     Small();
+    LookAhead();
     TestMaxSizeControl();
     Large();
     PerfectCollinearity();
