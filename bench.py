@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_OBS, P, N_SIGNAL = 10000, 512, 16
 CHAINS_PER_GPU = 1024
-SWEEPS_PER_STEP = 200
+SWEEPS_PER_STEP = 1000  # "200 burn-in + 1000 timed sweeps" -- one launch
 BURN_IN = 200
 ESS_SWEEPS = 400
 DATA_SEED = 8675309
@@ -60,8 +60,8 @@ def geyer_ess(x):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
