@@ -28,8 +28,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_OBS, P, N_SIGNAL = 10000, 512, 16
 CHAINS_PER_GPU = 1024
 SWEEPS_PER_STEP = 1000  # "200 burn-in + 1000 timed sweeps" -- one launch
-BURN_IN = 200
-ESS_SWEEPS = 400
+BURN_IN = 1000   # (every launch of the run is 1000 sweeps, so that a profiler's per-kernel average is the step time)
+ESS_SWEEPS = 1000
 DATA_SEED = 8675309
 SAMPLER_SEED = 8675309
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
