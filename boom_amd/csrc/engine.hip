@@ -333,8 +333,8 @@ int alloc_chain_state(ba_engine *e) {
   HIP_TRY(e->dstatus.resize(C));
   HIP_TRY(e->dfail.resize(C));
   HIP_TRY(e->dtodo.resize(C));
-  HIP_TRY(e->dtab_lp.resize(C * p));
-  HIP_TRY(e->dtab_kind.resize(C * p));
+  HIP_TRY(e->dtab_lp.resize(2 * C * p));    // two slots per chain (ssvs_params.h)
+  HIP_TRY(e->dtab_kind.resize(2 * C * p));
   HIP_TRY(e->dtab_tag.resize(C));
   HIP_TRY(e->dmodel_tag.resize(C));
   e->model_ok = false;
@@ -1014,7 +1014,7 @@ int ba_sweep(ba_engine *e, int32_t nsweeps) {
   if (rc) return rc;
   if (e->trace_stride > 0 && nsweeps > e->trace_stride)
     return fail(BA_E_INVALID, "nsweeps exceeds the enabled trace length");
-  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
+  HIP_TRY(e->dmodel.resize(2 * (size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
   SsvsParams P;
   fill_params(e, P);
   const SsvsLds lay = ssvs_lds_layout(e->p, e->kcap);
@@ -1248,7 +1248,7 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   if (rc) return rc;
   rc = upload_shared(e);
   if (rc) return rc;
-  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
+  HIP_TRY(e->dmodel.resize(2 * (size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
   SsvsParams P;
   fill_params(e, P);
   if (e->trace_stride > 0)
@@ -1291,7 +1291,7 @@ static int ss_prepare(ba_engine *e) {
     HIP_TRY(hipMemset(e->dss_scratch.ptr, 0, C * SS_SCRATCH_ARRAYS * T * 8));
     e->ss_initialized = false;
   }
-  HIP_TRY(e->dmodel.resize((size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
+  HIP_TRY(e->dmodel.resize(2 * (size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
   return BA_OK;
 }
 

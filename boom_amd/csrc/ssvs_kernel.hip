@@ -462,6 +462,14 @@ __device__ __forceinline__ void apply_flip(Chain &ch, int j) {
   wave_sync();
 }
 
+// point the chain at one of its two (table, model block) slots
+__device__ __forceinline__ void bind_slot(Chain &ch, const SsvsParams &P, int chain, int slot) {
+  const size_t c = (size_t)slot * P.chains + chain;
+  ch.tab_lp = P.table_lp + c * ch.p;
+  ch.tab_kind = P.table_kind + c * ch.p;
+  ch.sc_store = P.model_scratch + c * P.model_scratch_stride;
+}
+
 // Copy the current model's wave-uniform data from LDS to this chain's HBM
 // block, make it visible to the scalar cache and re-derive the read pointer.
 template <int NB>
@@ -988,7 +996,7 @@ enum : int { CMD_EXIT = 0, CMD_EVAL = 1, CMD_UNIF = 2, CMD_DECIDE = 3, CMD_SHUFF
 // launch's scalar accumulators (ACC_* order)
 enum : int { CT_CMD = 0, CT_K = 1, CT_I0 = 2, CT_LOGP = 3, CT_LP = 4, CT_LDV = 5,
              CT_LDA = 6, CT_Q = 7, CT_C = 8, CT_NFLIPS = 9, CT_POS = 10, CT_PERMSEL = 12,
-             CT_EVMODE = 13,
+             CT_EVMODE = 13, CT_CUR = 14,
              CT_SLOT0 = 16, CT_SLOT_STRIDE = 6, CT_ROLL = 44, CT_ACC = 48 };
 // slot: SL_F = permutation position of the wave's earliest stop (-1: none)
 enum : int { SL_F = 0, SL_J = 1, SL_KIND = 2, SL_LOGU = 3, SL_MARGIN = 4, SL_DELTA = 5 };
@@ -1223,9 +1231,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   bind_lds(ch, smem, lay);
   lds_f64 *ctl = to_lds<double>(smem + lay.ctrl);
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
-  ch.tab_lp = P.table_lp + (size_t)chain * p;
-  ch.tab_kind = P.table_kind + (size_t)chain * p;
-  ch.sc_store = P.model_scratch + (size_t)chain * P.model_scratch_stride;
+  bind_slot(ch, P, chain, 0);
   ch.sc = (c_f64 *)(unsigned long long)ch.sc_store;
   const double yty = P.yty[(size_t)chain * P.suf_stride];
   const double nobs = P.nobs[(size_t)chain * P.suf_stride];
@@ -1262,6 +1268,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         M.SS = 0; M.pd = true; M.bad = 0;
         ch.k = (int)ctl[CT_K];
         ch.perm = to_lds<uint16_t>(smem + (((int)ctl[CT_PERMSEL]) ? lay.perm1 : lay.perm0));
+        bind_slot(ch, P, chain, (int)ctl[CT_CUR]);
         unsigned long long a = (unsigned long long)ch.sc_store;
         asm volatile("" : "+s"(a) : : "memory");
         ch.sc = (c_f64 *)a;
@@ -1271,6 +1278,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       } else if (cmd == CMD_DECIDE || cmd == CMD_SHUFFLE_DECIDE) {
         if (wave == 1) {
           const int sel = (int)ctl[CT_PERMSEL];
+          bind_slot(ch, P, chain, (int)ctl[CT_CUR]);
           ch.perm = to_lds<uint16_t>(smem + (sel ? lay.perm1 : lay.perm0));
           ch.perm_alt = to_lds<uint16_t>(smem + (sel ? lay.perm0 : lay.perm1));
           uint64_t fpos = upos;
@@ -1378,7 +1386,15 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   bool use_table = false;     // this sweep decides by table look-up
   // the table of the chain's last launch is still good when nothing but
   // sweeps happened since (the host clears table_keep otherwise)
-  bool table_valid = P.table_keep && P.table_tag[chain] == KCAP && status == CHAIN_OK;
+  // which of the chain's two (table, model block) slots is in use, and what the
+  // other one holds: the model one flip (of variable other_var) away, or nothing
+  int cur = 0, other_var = -1;
+  bool other_ok = false, table_valid_other = false;
+  const int model_tag_in = P.model_keep ? P.model_tag[chain] : 0;
+  const bool model_kept = (model_tag_in & 0xff) == KCAP && status == CHAIN_OK;
+  if (model_kept) cur = (model_tag_in >> 8) & 1;
+  bind_slot(ch, P, chain, cur);
+  bool table_valid = P.table_keep && model_kept && P.table_tag[chain] == model_tag_in;
   int fill_j = 0;             // next variable of a fill in progress
   // Quiet sweeps fork: wave 1 shuffles and walks the table while the master
   // runs the sweep's tail (swap proposal, sigma, beta) on the assumption that
@@ -1398,7 +1414,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
 
   // The chain's model block of the last launch is still this model (nothing but
   // sweeps happened since): take the factors from there instead of factoring.
-  if (P.model_keep && P.model_tag[chain] == KCAP && status == CHAIN_OK) {
+  if (model_kept) {
     restore_model<NB>(ch);
     {
       const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
@@ -1428,6 +1444,42 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       // tail running ahead waits for the join) --------------------------
       // (outside this block only logp, SS and pd of the model live in registers;
       // the scalars the evaluations need have their home in the control block)
+      if (pe.kind == EV_FORCE && pe.f2 < 0 && other_ok && pe.f1 == other_var) {
+        // The accepted flip leads to the model the other slot still holds (a
+        // variable leaving again, or coming back): its factors, scalars and
+        // table are there -- bitwise what a rebuild would compute.
+        apply_flip(ch, pe.f1);
+        cur ^= 1;
+        bind_slot(ch, P, chain, cur);
+        restore_model<NB>(ch);
+        {
+          const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
+          const double *sc = ch.sc_store + S.scal;
+          M.logp = sc[0]; M.lp = sc[1]; M.ldv = sc[2]; M.lda = sc[3];
+          M.Q = sc[4]; M.c = sc[5]; M.SS = sc[6]; M.pd = sc[7] != 0.0;
+          unsigned long long u = (unsigned long long)ch.sc_store;
+          asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(u) : : "memory");
+          ch.sc = (c_f64 *)u;
+        }
+        if (lane == 0) {
+          ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
+          ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
+        }
+        wave_sync();
+        {  // the slot left behind keeps the model just left: one flip of the same variable away
+          const bool t = table_valid;
+          table_valid = table_valid_other;
+          table_valid_other = t;
+        }
+        ACC_ADD(ACC_ACCEPTS, 1);
+        if (!M.pd) status = CHAIN_NOT_PD;
+        pe.kind = EV_NONE;
+        pe.f1 = pe.f2 = -1;
+        pe.lfw = pe.lrev = 0.0;
+        pe.check_legal = false;
+        STAMP(2);
+        continue;
+      }
       Model keep = M;
       keep.lp = ctl[CT_LP]; keep.ldv = ctl[CT_LDV]; keep.lda = ctl[CT_LDA];
       keep.Q = ctl[CT_Q]; keep.c = ctl[CT_C];
@@ -1452,7 +1504,16 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
             M = Mn;
             // (the launch's first build is the old model unless make_valid
             // changed gamma)
-            if (pe.kind != EV_INIT || pe.check_legal) table_valid = false;
+            if (pe.kind != EV_INIT || pe.check_legal) {
+              // a new model: it goes to the other slot, the one in use keeps the
+              // model being left (reachable again by one flip if one flip led here)
+              table_valid_other = table_valid;
+              table_valid = false;
+              other_ok = (pe.kind != EV_INIT) && pe.f1 >= 0 && pe.f2 < 0;
+              other_var = pe.f1;
+              cur ^= 1;
+              bind_slot(ch, P, chain, cur);
+            }
             if (pe.kind != EV_INIT) ACC_ADD(ACC_ACCEPTS, 1);
           } else {
             // rejected: gamma back, and the old factors from the chain's block
@@ -1513,6 +1574,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
             ctl[CT_I0] = 0.0;
             ctl[CT_NFLIPS] = (double)nflips;
             ctl[CT_PERMSEL] = (double)perm_sel;
+            ctl[CT_CUR] = (double)cur;
             ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = pos;
           }
           __syncthreads();
@@ -1593,6 +1655,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
             ctl[CT_I0] = (double)i0;
             ctl[CT_NFLIPS] = (double)nflips;
             ctl[CT_PERMSEL] = (double)perm_sel;
+            ctl[CT_CUR] = (double)cur;
             ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = flip_pos;
           }
           __syncthreads();
@@ -1648,6 +1711,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           ctl[CT_I0] = (double)base;
           ctl[CT_NFLIPS] = (double)nflips;
           ctl[CT_PERMSEL] = (double)perm_sel;
+            ctl[CT_CUR] = (double)cur;
           ctl[CT_EVMODE] = (double)evmode;
           ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = flip_pos;
         }
@@ -1907,8 +1971,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     P.status[chain] = status;
     P.todo[chain] = nsweeps - done + owed_after;
     if (P.ran) P.ran[chain] = done;
-    P.table_tag[chain] = (table_valid && !aborted && status == CHAIN_OK) ? KCAP : 0;
-    P.model_tag[chain] = (!aborted && status == CHAIN_OK) ? KCAP : 0;
+    const int tag = KCAP | (cur << 8);
+    P.table_tag[chain] = (table_valid && !aborted && status == CHAIN_OK) ? tag : 0;
+    P.model_tag[chain] = (!aborted && status == CHAIN_OK) ? tag : 0;
     if (P.trace_idx) P.trace_idx[chain] = trace_at + done;
     if (P.maxk) atomicMax(P.maxk, kmax);
     double *a = P.acc + (size_t)chain * ACC_COUNT;

@@ -114,8 +114,13 @@ struct SsvsParams {
   int32_t *model_tag;
   int32_t model_keep, suf_changed;
   int32_t table_keep;           // 0: ignore the tags (something other than sweeps happened)
-  double *model_scratch;        // chains x model_scratch_stride doubles
+  double *model_scratch;        // 2 slots x chains x model_scratch_stride doubles
   int64_t model_scratch_stride;
+  // Tables and model blocks exist twice per chain (slot s of chain c at
+  // [s * chains + c]): the slot a chain is not using keeps the model it just
+  // left, one flip away.  Noise variables enter a model and leave it again, so
+  // the flip that undoes the last accepted one -- or redoes it -- finds factors
+  // and table ready.  The tags carry the slot in bits 8+.
 
   // summaries (per chain; reduced over chains by a second kernel)
   uint32_t *inc_count;  // chains x p
