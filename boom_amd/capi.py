@@ -278,7 +278,8 @@ class Engine:
         return dict(inclusion_count=inc, beta_sum=bs, beta_sumsq=bs2,
                     sweeps=sc[0], sigsq_sum=sc[1], sigsq_sumsq=sc[2], k_sum=sc[3],
                     accepts=sc[4], proposals=sc[5], min_margin=sc[6],
-                    phase_cycles=sc[8:16].copy(), slowest_chain_cycles=float(sc[7]))
+                    phase_cycles=sc[8:16].copy(), slot_hits=float(sc[7]),
+                    slowest_chain_cycles=float(sc[7]))
 
     def summaries_device(self, ptr):
         self._check(self.lib.ba_summaries_device(self._h, ptr))

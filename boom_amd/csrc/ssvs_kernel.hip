@@ -1472,6 +1472,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           table_valid_other = t;
         }
         ACC_ADD(ACC_ACCEPTS, 1);
+#ifndef BA_STAMPS
+        ACC_ADD(ACC_SLOT_HITS, 1);
+#endif
         if (!M.pd) status = CHAIN_NOT_PD;
         pe.kind = EV_NONE;
         pe.f1 = pe.f2 = -1;
@@ -1983,6 +1986,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     a[ACC_K] += ctl[CT_ACC + ACC_K];
     a[ACC_ACCEPTS] += ctl[CT_ACC + ACC_ACCEPTS];
     a[ACC_PROPOSALS] += ctl[CT_ACC + ACC_PROPOSALS];
+#ifndef BA_STAMPS
+    a[ACC_SLOT_HITS] += ctl[CT_ACC + ACC_SLOT_HITS];
+#endif
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], ctl[CT_ACC + ACC_MIN_MARGIN]);
 #if defined(BA_STAMPS) && defined(BA_STAMPS4)
     // (phases are wave 1's)
@@ -1990,7 +1996,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     SUBSTAMP(sx, 7);
     for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += sx.ph[i];
 #elif defined(BA_STAMPS)
-    for (int i = 0; i < 8; ++i) { a[ACC_PHASE0 + i] += st_ph[i]; a[ACC_RESERVED] += st_ph[i]; }
+    for (int i = 0; i < 8; ++i) { a[ACC_PHASE0 + i] += st_ph[i]; a[ACC_SLOT_HITS] += st_ph[i]; }
 #endif
   }
 }
@@ -2052,7 +2058,11 @@ __global__ __launch_bounds__(256) void ssvs_reduce_summaries_kernel(SsvsParams P
   const int p = P.p, j = blockIdx.x, tid = threadIdx.x;
   double a = 0, b = 0, c = 0;
   const bool is_min = (j >= p) && (j - p == ACC_MIN_MARGIN);
-  const bool is_max = (j >= p) && (j - p == ACC_RESERVED);  // diagnostic builds: slowest chain
+#ifdef BA_STAMPS
+  const bool is_max = (j >= p) && (j - p == ACC_SLOT_HITS);  // diagnostic builds: the slot carries the slowest chain's cycles
+#else
+  const bool is_max = false;
+#endif
   if (is_min) a = BA_INF;
   for (int chn = tid; chn < P.chains; chn += 256) {
     if (j < p) {

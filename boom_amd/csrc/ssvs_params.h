@@ -27,7 +27,7 @@ enum {
   ACC_ACCEPTS = 4,
   ACC_PROPOSALS = 5,
   ACC_MIN_MARGIN = 6,
-  ACC_RESERVED = 7,
+  ACC_SLOT_HITS = 7,  // accepted flips served from the chain's other slot (diagnostic stamp builds: slowest chain's cycles)
   // 8..15: per-phase cycle counters, filled only by the -DBA_STAMPS diagnostic
   // build (shuffle uniforms, shuffle serial, refactor, proposal batches, swap,
   // sigma, beta, rest); zero in the production library
