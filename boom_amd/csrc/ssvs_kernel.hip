@@ -138,6 +138,22 @@ __device__ __forceinline__ double bcast_u(double x, int src) {
 __device__ __forceinline__ int bcast_u(int x, int src) {
   return __builtin_amdgcn_readlane(x, src);
 }
+// A wave-uniform value the compiler cannot see to be uniform (it came out of
+// vector arithmetic) is moved to scalar registers: it then costs no vector
+// register while it waits for its next use, and if it has to be spilled it goes
+// to a lane of a vector register, not to scratch memory.
+__device__ __forceinline__ double uni(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint64_t uni(uint64_t u) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
 // Reductions over the wave, result in every lane.  row_shr 8/4/2/1 leaves each
 // row's total in its lane 15; row_bcast:15 / row_bcast:31 carry it to lane 63.
 __device__ __forceinline__ double wave_sum(double x) {
@@ -1343,9 +1359,9 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   int kmax = k;
   int trace_at = P.trace_idx ? P.trace_idx[chain] : 0;
 
-  uint64_t pos = P.rng_pos[chain];
-  int failures = P.failures[chain];
-  double sigsq = P.sigsq[chain];
+  uint64_t pos = uni((uint64_t)P.rng_pos[chain]);
+  int failures = uni((int)P.failures[chain]);
+  double sigsq = uni((double)P.sigsq[chain]);
   double beta_m = 0.0;  // lane m: coefficient of variable gprev after the last draw
   int gprev = 0, kprev = 0;
   bool beta_valid = false;
@@ -1505,6 +1521,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
           if (acc) {
             M = Mn;
+            M.logp = uni(M.logp);
+            M.SS = uni(M.SS);
             // (the launch's first build is the old model unless make_valid
             // changed gamma)
             if (pe.kind != EV_INIT || pe.check_legal) {
@@ -1666,11 +1684,11 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
           have_dr = false;
           const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * 1;
-          dr.spos = (int)sl[SL_F];
-          dr.j = (int)sl[SL_J];
-          dr.kind = (int)sl[SL_KIND];
-          dr.logu = sl[SL_LOGU];
-          dr.margin = sl[SL_MARGIN];
+          dr.spos = uni((int)sl[SL_F]);
+          dr.j = uni((int)sl[SL_J]);
+          dr.kind = uni((int)sl[SL_KIND]);
+          dr.logu = uni((double)sl[SL_LOGU]);
+          dr.margin = uni((double)sl[SL_MARGIN]);
         } else {
           decide_walk(ch, key, flip_pos, i0, nflips, dr);
         }
@@ -1743,7 +1761,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * w;
         if (wstop < 0) {
           ACC_MIN(sl[SL_MARGIN]);
-          const int fw = (int)sl[SL_F];
+          const int fw = uni((int)sl[SL_F]);
           if (fw >= 0) { wstop = w; spos = fw; }
         }
       }
@@ -1755,8 +1773,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         continue;
       }
       const lds_f64 *sl = ctl + CT_SLOT0 + CT_SLOT_STRIDE * wstop;
-      const int jf = (int)sl[SL_J];
-      const int kind = (int)sl[SL_KIND];
+      const int jf = uni((int)sl[SL_J]);
+      const int kind = uni((int)sl[SL_KIND]);
       const int nprop = spos + 1 - i0;
       ACC_ADD(ACC_PROPOSALS, nprop);
       ++stops_now;
@@ -1776,7 +1794,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         pe.kind = EV_FORCE;  // accepted on the fast path: move to the new model
       } else {
         pe.kind = EV_TRY_GE;  // exact path: evaluate the flipped model
-        pe.lu = sl[SL_LOGU];
+        pe.lu = uni((double)sl[SL_LOGU]);
       }
       i0 += nprop;
       continue;
@@ -1881,14 +1899,14 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       int bad = 0;
       const double DF = (k == 0) ? ch.DF : ((ch.DF - P.prior_df) + P.prior_df);
       const double SS = (k == 0) ? ch.ss0q : ((M.SS - P.prior_ss) + P.prior_ss);
-      sigsq = d_draw_variance(rng, DF, SS, P.sigma_max, &bad);
+      sigsq = uni(d_draw_variance(rng, DF, SS, P.sigma_max, &bad));
       if (bad) {
         if (!spec) { status = CHAIN_RNG_BRANCH; break; }
         spec_status = CHAIN_RNG_BRANCH; after_join = PH_COMMIT; phase = PH_JOIN;
         continue;
       }
     }
-    pos = rng.get_pos();
+    pos = uni(rng.get_pos());
     STAMP(5);
     // draw_beta (BregVsSampler.cpp:326-351)
     if (P.draw_beta && k > 0) {
@@ -1902,7 +1920,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       // k standard normals in stream order (distributions/mvn.cpp:114-122),
       // lane m keeps z_m
       const double z = draw_normals(rng, k);
-      pos = rng.get_pos();
+      pos = uni(rng.get_pos());
       // beta = L^{-T}(w + sigma z): chol(V / sigma^2) = L / sigma
       // (SpikeSlabSampler: rmvn_ivar_mt with the sigma-scaled precision itself)
       const double sigma = P.mode ? 1.0 : sqrt(sigsq);
