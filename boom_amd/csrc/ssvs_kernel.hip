@@ -69,10 +69,9 @@ struct StampCtx { long long last; double ph[8]; };
 #else
 #define SUBSTAMP(c, i) do { } while (0)
 #endif
-// -DBA_STAMPS -DBA_STAMPS3: the 8 slots time the serial parts of a sweep
-// (0 shuffle: previous-step rounds, 1 shuffle: links, 2 shuffle: walks,
-// 3 normals, 4 back substitution, 5 summaries, 6 sweep start + shuffle
-// uniforms, 7 everything else)
+// -DBA_STAMPS -DBA_STAMPS3: the 8 slots time the master's pieces of a forked
+// sweep (0 commit, 1 sweep-start copy, 2 fork, 3 swap proposal, 4 sigma,
+// 5 normals, 6 back substitution, 7 everything else)
 // -DBA_STAMPS -DBA_STAMPS4: the 8 slots time helper wave 1 (0 shuffle uniforms,
 // 1 matching rounds, 2 links, 3 walks, 4 table walk, 5 waiting for commands,
 // 6 its share of proposal rounds, 7 other)
@@ -334,7 +333,6 @@ __device__ __forceinline__ void chol_blocks2(const Chain &ch, lds_f64 *LA, lds_f
 template <bool REUSE>
 __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &M, StampCtx &sx) {
   const int lane = ch.lane, p = ch.p, k = ch.k;
-  TSTAMP(sx, 7);
   M.bad = 0;
   M.pd = true;
   double lp;
@@ -363,7 +361,6 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     return;
   }
   wave_sync();
-  TSTAMP(sx, 0);
   // gather V_g, A_g (lower triangles, rows padded with zeros to a multiple of
   // 8) with all loads independent: element e <-> (m, n), n <= m
   const int kpad = (k + 7) & ~7;
@@ -405,7 +402,6 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   const double r = (lane < k) ? ab + ch.xty[gm] * ch.sx : 0.0;
   M.c = wave_sum(lane < k ? bm * ab : 0.0);
   wave_sync();
-  TSTAMP(sx, 1);
   bool okv = true, oka = true;
   if (REUSE) {
     M.lda = lda_in;
@@ -413,7 +409,6 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   } else {
     chol_blocks2(ch, ch.La, ch.rda, ch.Lv, ch.rdv, &oka, &okv, &M.lda, &M.ldv);
   }
-  TSTAMP(sx, 3);
   if (!okv) {
     M.pd = false;
     M.logp = -BA_INF;
@@ -431,7 +426,6 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   M.Q = wave_sum(lane < k ? x * x : 0.0);
   M.SS = ch.ss0q + M.c - M.Q;
   wave_sync();
-  TSTAMP(sx, 4);
   if (ch.mode) {
     // SpikeSlabSampler::log_model_prob, SpikeSlabSampler.cpp:171-203:
     // log pi(g) + .5 log|P_g| - .5 mu'P mu - [.5 log|V_g| - .5 |L^{-1} r|^2]
@@ -1502,10 +1496,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       Model keep = M;
       keep.lp = ctl[CT_LP]; keep.ldv = ctl[CT_LDV]; keep.lda = ctl[CT_LDA];
       keep.Q = ctl[CT_Q]; keep.c = ctl[CT_C];
-      TSTAMP(sx, 7);
       if (pe.f1 >= 0) apply_flip(ch, pe.f1);
       if (pe.f2 >= 0) apply_flip(ch, pe.f2);
-      TSTAMP(sx, 6);
       bool rejected = false;
       {
         Model Mn;
@@ -1547,7 +1539,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         }
       }
       if (status == CHAIN_OK) {
-        TSTAMP(sx, 7);
         if (!rejected) {
           publish_model<NB>(ch, M);
           if (lane == 0) {
@@ -1556,7 +1547,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
           wave_sync();
         }
-        TSTAMP(sx, 5);
         if (pe.kind == EV_FORCE && !M.pd) status = CHAIN_NOT_PD;
         if (pe.kind == EV_INIT && pe.check_legal &&
             !(M.logp > -BA_INF && M.logp < BA_INF))
@@ -1573,6 +1563,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     if (phase == PH_BEGIN) {
       if (sweep >= nsweeps) break;
       STAMP(7);
+      TSTAMP(sx, 7);
       if (nflips > 0) {
         // remember the sweep's starting point (restored if the chain has to
         // stop inside this sweep for lack of model capacity)
@@ -1582,6 +1573,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           // (SpikeSlabSampler.cpp:48-57); BregVsSampler's indx persists
           if (P.mode) ch.perm[j] = (uint16_t)j;
         }
+        TSTAMP(sx, 1);
         pos0 = pos;
         if (!model_checked && M.logp > -BA_INF && M.logp < BA_INF) model_checked = true;
         use_table = (P.walk_policy != 0) && (stops_prev <= 1 || P.walk_policy == 2);
@@ -1607,6 +1599,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
           flip_pos = pos + (uint64_t)(p - 1);
           pos = flip_pos + (uint64_t)nflips;
+          TSTAMP(sx, 2);
           spec = true;
           spec_status = CHAIN_OK;
           park[lane] = beta_m;
@@ -1801,6 +1794,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     }
 
     if (phase == PH_SWAP) {
+      TSTAMP(sx, 7);
       rng.set_pos(pos);
       if (nflips > 0) propose_swap(P, ch, rng, pe, &status);
       pos = rng.get_pos();
@@ -1814,6 +1808,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         phase = PH_JOIN;
       }
       STAMP(4);
+      TSTAMP(sx, 3);
       continue;
     }
 
@@ -1845,6 +1840,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
 
     if (phase == PH_COMMIT) {
       // ---- summaries
+      TSTAMP(sx, 7);
       k = ch.k;
       gprev = (lane < k) ? (int)ch.g[lane] : 0;
       kprev = k;
@@ -1888,10 +1884,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       ++done;
       ++sweep;
       phase = PH_BEGIN;
+      TSTAMP(sx, 0);
       continue;
     }
 
     // ---- PH_TAIL: sigma, beta, summaries
+    TSTAMP(sx, 7);
     k = ch.k;
     rng.set_pos(pos);
     // draw_sigma (BregVsSampler.cpp:313-324)
@@ -1908,6 +1906,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     }
     pos = uni(rng.get_pos());
     STAMP(5);
+    TSTAMP(sx, 4);
     // draw_beta (BregVsSampler.cpp:326-351)
     if (P.draw_beta && k > 0) {
       if (!M.pd) {
@@ -1921,6 +1920,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       // lane m keeps z_m
       const double z = draw_normals(rng, k);
       pos = uni(rng.get_pos());
+      TSTAMP(sx, 5);
       // beta = L^{-T}(w + sigma z): chol(V / sigma^2) = L / sigma
       // (SpikeSlabSampler: rmvn_ivar_mt with the sigma-scaled precision itself)
       const double sigma = P.mode ? 1.0 : sqrt(sigsq);
@@ -1938,6 +1938,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       }
       beta_m = y;
       beta_valid = true;
+      TSTAMP(sx, 6);
     } else if (P.draw_beta) {
       beta_valid = true;  // empty model: all coefficients zero
     }

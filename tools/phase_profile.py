@@ -41,8 +41,8 @@ ph = sm["phase_cycles"]
 names = ["shuffle uniforms", "shuffle serial", "refactor", "proposal batches",
          "swap", "sigma", "beta", "rest"]
 if SUBN == "2":
-    names = ["event: prior sum", "event: gather V_g A_g", "event: chol A", "event: chol V",
-             "event: w solve", "event: publish", "event: apply_flip", "everything else"]
+    names = ["master: commit", "master: sweep start copy", "master: fork", "master: swap proposal",
+             "master: sigma", "master: normals", "master: back substitution", "everything else"]
 elif SUBN == "3":
     names = ["wave 1: shuffle uniforms", "wave 1: matching rounds", "wave 1: links", "wave 1: walks",
              "wave 1: table walk", "wave 1: waiting", "wave 1: proposal rounds", "wave 1: other"]
