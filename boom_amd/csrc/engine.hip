@@ -375,6 +375,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   std::memset(&P, 0, sizeof(P));
   P.p = e->p;
   P.chains = e->cfg.chains;
+  P.chain_first = 0;
+  P.chain_count = e->cfg.chains;
   P.chain_offset = e->cfg.chain_offset;
   P.kcap = e->kcap;
   P.waves = e->waves;
@@ -485,6 +487,8 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.T = e->T;
   S.p = e->p;
   S.chains = e->cfg.chains;
+  S.chain_first = 0;
+  S.chain_count = e->cfg.chains;
   S.chain_offset = e->cfg.chain_offset;
   S.y = e->dss_y.ptr;
   S.X = e->dss_X.ptr;

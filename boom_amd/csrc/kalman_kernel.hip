@@ -239,13 +239,13 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   __shared__ uint16_t s_j_[2][NLEV][NB_START];  // jump tables of the stream walk
   __shared__ uint16_t s_slow_[2][NB_START];  // offsets whose draw leaves the first branch
   __shared__ int s_hand[4];                // entry offset of the next window, draws so far, done, status
-  const int chain = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double *s_u = s_u_[wave];
   double *s_z = s_z_[wave];
   uint8_t *s_n1 = s_n1_[wave];
   uint16_t (*s_j)[NB_START] = s_j_[wave];
   uint16_t *s_slow = s_slow_[wave];
-  if (chain >= P.chains) return;
+  if ((int)blockIdx.x >= P.chain_count) return;
   if (P.status[chain] != CHAIN_OK) return;
   if (P.only_ran && P.only_ran[chain] == 0) return;
   const int T = P.T, p = P.p;
@@ -661,15 +661,16 @@ hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int
 
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level) {
-  hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chains), dim3(2 * WAVE), 0,
+  hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chain_count), dim3(2 * WAVE), 0,
                      stream, P, draw_level);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
   // xty[chain, j] = x_j' e_chain: residual series are array 0 of every chain's
   // scratch block (zero where unobserved, and for a chain in error the previous
   // sweep's -- its status stops it anyway)
-  return launch_atb_mfma(stream, P.scratch, P.scratch_stride, P.chains, P.X, (int64_t)P.T, P.p,
-                         P.T, P.xty, P.p);
+  return launch_atb_mfma(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride, P.scratch_stride,
+                         P.chain_count, P.X, (int64_t)P.T, P.p, P.T,
+                         P.xty + (size_t)P.chain_first * P.p, P.p);
 }
 
 }  // namespace boom_amd

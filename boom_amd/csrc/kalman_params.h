@@ -9,6 +9,7 @@ namespace boom_amd {
 
 struct SsParams {
   int32_t T, p, chains;
+  int32_t chain_first, chain_count;  // this launch: chains [chain_first, chain_first + chain_count)
   int64_t chain_offset;
   // shared data: StateSpaceRegressionModel(y, X, observed)
   const double *y;          // T

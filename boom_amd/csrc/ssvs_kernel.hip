@@ -1202,11 +1202,11 @@ template <int NB, int W, int WPE>
 __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
                                                             int nsweeps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int chain = blockIdx.x;
+  const int chain = (int)blockIdx.x + P.chain_first;
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int p = P.p;
-  if (chain >= P.chains) return;
+  if ((int)blockIdx.x >= P.chain_count) return;
   if (P.status[chain] != CHAIN_OK) {
     // a chain waiting for a larger-capacity kernel (or in error) just books
     // the sweeps it is owed
@@ -2127,7 +2127,7 @@ static hipError_t launch_sweep_t(hipStream_t stream, const SsvsParams &P,
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lay.total);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((ssvs_sweep_kernel<NB, W, WPE>), dim3(P.chains), dim3(WAVE * W),
+  hipLaunchKernelGGL((ssvs_sweep_kernel<NB, W, WPE>), dim3(P.chain_count), dim3(WAVE * W),
                      lay.total, stream, P, nsweeps);
   return hipGetLastError();
 }

@@ -37,7 +37,9 @@ enum {
 
 struct SsvsParams {
   int32_t p;
-  int32_t chains;
+  int32_t chains;        // chains of the engine (array extents)
+  int32_t chain_first;   // this launch works on chains [chain_first, chain_first + chain_count)
+  int32_t chain_count;
   int64_t chain_offset;
   int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
   int32_t waves; // wavefronts per chain (1, 2 or 4)
