@@ -45,7 +45,14 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
   const int fr = lane >> 4;   // k index inside an MFMA step (0..3)
   const int fc = lane & 15;   // row (A) / column (B) inside a 16-wide tile
 
-  for (int64_t r0 = 0; r0 < n; r0 += KC) {
+  // split-K: slice z of gridDim.z takes rows [z, z + 1) * rows_per_slice (whole
+  // staging steps) and writes its partial tile to plane z of the output
+  const int64_t steps = (n + KC - 1) / KC;
+  const int64_t per = (steps + gridDim.z - 1) / gridDim.z;
+  const int64_t rbeg = (int64_t)blockIdx.z * per * KC;
+  const int64_t rend = (rbeg + per * KC < n) ? rbeg + per * KC : n;
+  xtx += (size_t)blockIdx.z * (size_t)p * (size_t)p;
+  for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
     // stage 64 columns x 32 rows of each strip: 2048 doubles, 8 per thread
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -53,8 +60,8 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
       const int col = e >> 5, row = e & 31;
       const int64_t r = r0 + row;
       const int ci = I0 + col, cj = J0 + col;
-      sA[col * LDP + row] = (r < n && ci < p) ? X[(int64_t)ci * n + r] : 0.0;
-      sB[col * LDP + row] = (r < n && cj < p) ? X[(int64_t)cj * n + r] : 0.0;
+      sA[col * LDP + row] = (r < rend && ci < p) ? X[(int64_t)ci * n + r] : 0.0;
+      sB[col * LDP + row] = (r < rend && cj < p) ? X[(int64_t)cj * n + r] : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -89,6 +96,17 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
           xtx[(int64_t)i * p + j] = v;
         }
       }
+}
+
+// sum of the split-K planes in plane order (bitwise reproducible)
+__global__ __launch_bounds__(256) void plane_sum_kernel(const double *__restrict__ planes,
+                                                        int nplanes, size_t count,
+                                                        double *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  double a = planes[i];
+  for (int z = 1; z < nplanes; ++z) a += planes[(size_t)z * count + i];
+  out[i] = a;
 }
 
 // block j < p: sum_r X[r,j], sum_r X[r,j] y[r];  block p: sum y, sum y^2.
@@ -217,8 +235,25 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        const double *y, double *xtx, double *xty,
                        double *scalars, double *xsum) {
   const int tiles = (p + TILE - 1) / TILE;
-  hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, stream,
-                     X, n, p, xtx);
+  // few tiles (p = 512: 36 of them for 256 CUs): split the rows as well, the
+  // partial products summed in a fixed order by a second kernel
+  const int lower = tiles * (tiles + 1) / 2;
+  int ksplit = (512 + lower - 1) / lower;
+  const int64_t steps = (n + KC - 1) / KC;
+  if (ksplit > 16) ksplit = 16;
+  if (ksplit > steps) ksplit = (int)steps;
+  while (ksplit > 1 && (size_t)ksplit * p * p * 8 > ((size_t)256 << 20)) --ksplit;
+  if (ksplit <= 1) {
+    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles, 1), dim3(256), 0, stream, X, n, p, xtx);
+  } else {
+    double *planes = nullptr;
+    const size_t count = (size_t)p * p;
+    if (hipMallocAsync((void **)&planes, (size_t)ksplit * count * 8, stream) != hipSuccess) return 1;
+    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles, ksplit), dim3(256), 0, stream, X, n, p, planes);
+    hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       planes, ksplit, count, xtx);
+    (void)hipFreeAsync(planes, stream);
+  }
   hipLaunchKernelGGL(col_reduce_kernel, dim3(p + 1), dim3(256), 0, stream, X, y,
                      n, p, xty, xsum, scalars);
   return hipGetLastError() == hipSuccess ? 0 : 1;
