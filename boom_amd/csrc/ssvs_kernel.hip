@@ -1414,6 +1414,11 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   bool spec = false;          // a forked walk is outstanding
   bool have_dr = false;       // wave 1's slot holds a walk result not yet handled
   int after_join = PH_COMMIT, spec_status = CHAIN_OK;
+  // Between a join and the next fork wave 1 has nothing to do, so the master
+  // keeps that stretch short: a joined sweep's summaries are committed AFTER the
+  // next sweep has been forked, and the sweep-start copy of gamma is skipped
+  // while gamma has not moved.
+  bool commit_pending = false, gam0_fresh = false;
   // (what a roll-back restores is parked in LDS, not in registers: park[lane] =
   // beta_m, control-block slots CT_ROLL.. = sigma^2, failures, beta_valid)
   lds_f64 *park = to_lds<double>(smem + lay.park);
@@ -1455,6 +1460,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       // (outside this block only logp, SS and pd of the model live in registers;
       // the scalars the evaluations need have their home in the control block)
       if (pe.kind == EV_FORCE && pe.f2 < 0 && other_ok && pe.f1 == other_var) {
+        gam0_fresh = false;
         // The accepted flip leads to the model the other slot still holds (a
         // variable leaving again, or coming back): its factors, scalars and
         // table are there -- bitwise what a rebuild would compute.
@@ -1493,6 +1499,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         STAMP(2);
         continue;
       }
+      gam0_fresh = false;
       Model keep = M;
       keep.lp = ctl[CT_LP]; keep.ldv = ctl[CT_LDV]; keep.lda = ctl[CT_LDA];
       keep.Q = ctl[CT_Q]; keep.c = ctl[CT_C];
@@ -1561,17 +1568,33 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     }
 
     if (phase == PH_BEGIN) {
-      if (sweep >= nsweeps) break;
+      if (sweep + (commit_pending ? 1 : 0) >= nsweeps) {
+        if (!commit_pending) break;
+        phase = PH_COMMIT;  // the last sweep's summaries, then out
+        continue;
+      }
+      {
+        const bool ut = (P.walk_policy != 0) && (stops_prev <= 1 || P.walk_policy == 2);
+        const bool mc = model_checked || (M.logp > -BA_INF && M.logp < BA_INF);
+        const bool will_fork = nflips > 0 && W > 1 && ut && table_valid && mc && p > 1 && P.walk_policy != 3;
+        if (commit_pending && !will_fork) {
+          phase = PH_COMMIT;  // nothing to overlap with: commit first
+          continue;
+        }
+      }
       STAMP(7);
       TSTAMP(sx, 7);
       if (nflips > 0) {
         // remember the sweep's starting point (restored if the chain has to
         // stop inside this sweep for lack of model capacity)
-        for (int j = lane; j < p; j += WAVE) {
-          ch.gam0[j] = ch.gam[j];
-          // SpikeSlabSampler shuffles a fresh identity permutation every call
-          // (SpikeSlabSampler.cpp:48-57); BregVsSampler's indx persists
-          if (P.mode) ch.perm[j] = (uint16_t)j;
+        if (!gam0_fresh || P.mode) {
+          for (int j = lane; j < p; j += WAVE) {
+            ch.gam0[j] = ch.gam[j];
+            // SpikeSlabSampler shuffles a fresh identity permutation every call
+            // (SpikeSlabSampler.cpp:48-57); BregVsSampler's indx persists
+            if (P.mode) ch.perm[j] = (uint16_t)j;
+          }
+          gam0_fresh = true;
         }
         TSTAMP(sx, 1);
         pos0 = pos;
@@ -1609,7 +1632,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
             ctl[CT_ROLL + 2] = beta_valid ? 1.0 : 0.0;
           }
           i0 = 0;
-          phase = PH_SWAP;
+          phase = commit_pending ? PH_COMMIT : PH_SWAP;  // (the joined sweep's summaries ride along)
           STAMP(1);
           continue;
         }
@@ -1822,6 +1845,10 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         ACC_ADD(ACC_PROPOSALS, nflips);
         status = spec_status;
         phase = after_join;
+        if (after_join == PH_COMMIT && status == CHAIN_OK) {
+          commit_pending = true;  // committed after the next fork
+          phase = PH_BEGIN;
+        }
       } else {
         // roll the tail back and handle the stop
         pos = flip_pos + (uint64_t)nflips;
@@ -1883,7 +1910,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       }
       ++done;
       ++sweep;
-      phase = PH_BEGIN;
+      commit_pending = false;
+      phase = spec ? PH_SWAP : PH_BEGIN;  // (spec: this was the previous sweep's commit, riding on a fork)
       TSTAMP(sx, 0);
       continue;
     }
