@@ -27,9 +27,11 @@ hipError_t launch_lds_exchange_order(hipStream_t stream, int *bad_device);
 hipError_t launch_ssvs_reduce_summaries(hipStream_t stream, const SsvsParams &P,
                                         double *out);
 // suf_kernel.hip
+int suf_row_slices(int64_t n, int p);
 int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        const double *y, double *xtx, double *xty,
-                       double *scalars /* yty, sumy */, double *xsum);
+                       double *scalars /* yty, sumy */, double *xsum,
+                       double *planes /* suf_row_slices(n, p) * p * p doubles, or null */);
 // kalman_kernel.hip
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
@@ -717,9 +719,12 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
   HIP_TRY(e->dxty.resize(p));
   HIP_TRY(e->dxsum.resize(p));
   HIP_TRY(e->dsufscal.resize(2));
+  DevBuf<double> planes;  // split-K partial products (freed after the sync below)
+  const int slices = suf_row_slices(n, p);
+  if (slices > 1) HIP_TRY(planes.resize((size_t)slices * p * p));
   rc = launch_suf_from_xy(e->stream, n, p, (const double *)X_device,
                           (const double *)y_device, e->dxtx.ptr, e->dxty.ptr,
-                          e->dsufscal.ptr, e->dxsum.ptr);
+                          e->dsufscal.ptr, e->dxsum.ptr, planes.ptr);
   if (rc) return fail(BA_E_HIP, "suf kernel launch failed");
   e->xtx.resize((size_t)p * p);
   e->xty.resize(p);

@@ -231,28 +231,33 @@ hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int
   return hipGetLastError();
 }
 
-int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
-                       const double *y, double *xtx, double *xty,
-                       double *scalars, double *xsum) {
+// how many row slices the XtX build wants for this shape: few tiles (p = 512:
+// 36 of them for 256 CUs) -> split the rows as well, the partial products
+// summed in a fixed order by a second kernel.  The caller provides the
+// workspace of suf_row_slices(n, p) * p * p doubles (none for 1 slice).
+int suf_row_slices(int64_t n, int p) {
   const int tiles = (p + TILE - 1) / TILE;
-  // few tiles (p = 512: 36 of them for 256 CUs): split the rows as well, the
-  // partial products summed in a fixed order by a second kernel
   const int lower = tiles * (tiles + 1) / 2;
   int ksplit = (512 + lower - 1) / lower;
   const int64_t steps = (n + KC - 1) / KC;
   if (ksplit > 16) ksplit = 16;
   if (ksplit > steps) ksplit = (int)steps;
   while (ksplit > 1 && (size_t)ksplit * p * p * 8 > ((size_t)256 << 20)) --ksplit;
+  return ksplit < 1 ? 1 : ksplit;
+}
+
+int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
+                       const double *y, double *xtx, double *xty,
+                       double *scalars, double *xsum, double *planes) {
+  const int tiles = (p + TILE - 1) / TILE;
+  const int ksplit = planes ? suf_row_slices(n, p) : 1;
   if (ksplit <= 1) {
     hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles, 1), dim3(256), 0, stream, X, n, p, xtx);
   } else {
-    double *planes = nullptr;
     const size_t count = (size_t)p * p;
-    if (hipMallocAsync((void **)&planes, (size_t)ksplit * count * 8, stream) != hipSuccess) return 1;
     hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles, ksplit), dim3(256), 0, stream, X, n, p, planes);
     hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
                        planes, ksplit, count, xtx);
-    (void)hipFreeAsync(planes, stream);
   }
   hipLaunchKernelGGL(col_reduce_kernel, dim3(p + 1), dim3(256), 0, stream, X, y,
                      n, p, xty, xsum, scalars);

@@ -75,7 +75,14 @@ def test_suf_kernel_matches_reference_xtx():
     assert abs(s["yty"] - g["yty"]) < 1e-12 * g["yty"]
     assert abs(s["ybar"] - g["ybar"]) < 1e-12
     assert relerr(s["xbar"], g["xbar"], 1e-6) < 1e-12
-    # ragged sizes (n, p not multiples of the tile)
+    # ragged sizes (n, p not multiples of the tile), shapes changing on one engine
+    for n, p, seed in [(333, 71, 21), (64, 5, 2), (500, 130, 3), (333, 71, 21)]:
+        X, y, _ = regression_data(n, p, min(5, p - 1), seed=seed)
+        eng.build_suf_from_xy(X, y)
+        s = eng.get_suf()
+        ref = X.T @ X
+        assert np.max(np.abs(s["xtx"] - ref)) < 1e-12 * np.abs(ref).max(), (n, p)
+        assert np.array_equal(s["xtx"], s["xtx"].T)
     X, y, _ = regression_data(333, 71, 5, seed=21)
     eng.build_suf_from_xy(X, y)
     s = eng.get_suf()
@@ -275,6 +282,20 @@ def test_error_reporting_matches_reference_messages():
     eng2 = boom_amd.Engine(2)
     with pytest.raises(boom_amd.BoomAmdError):
         eng2.sweep(1)  # no data, no priors
+    # draw records: only after ba_enable_draws, only for chains the engine owns,
+    # and a sweep() longer than the record is refused
+    eng3 = make_engine(2, 1, suf=suf, prior=prior, g0=g0, chain_offset=10)
+    eng3.sweep(3)
+    with pytest.raises(boom_amd.BoomAmdError):
+        eng3.get_draws(10, 3)
+    eng3.enable_draws(4)
+    eng3.sweep(4)
+    gam, beta, sig = eng3.get_draws(11, 4)
+    assert gam.shape == (4, 5) and np.all(sig > 0) and np.all(beta[gam == 0] == 0)
+    with pytest.raises(boom_amd.BoomAmdError):
+        eng3.get_draws(3, 4)       # global chain id outside [10, 12)
+    with pytest.raises(boom_amd.BoomAmdError):
+        eng3.sweep(5)              # more sweeps than record slots
 
 
 def test_summaries_and_traces(oracle):
