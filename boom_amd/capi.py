@@ -61,6 +61,7 @@ SIGNATURES = {
     "ba_set_state": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _dp, C.c_double]),
     "ba_get_state": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _dp, _dp]),
     "ba_get_states": (C.c_int, [C.c_void_p, _u8p, _dp, _dp]),
+    "ba_logpri": (C.c_int, [C.c_void_p, C.c_int64, _dp]),
     "ba_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "ba_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_sync": (C.c_int, [C.c_void_p]),
@@ -286,6 +287,11 @@ class Engine:
 
     def enable_traces(self, max_sweeps):
         self._check(self.lib.ba_enable_traces(self._h, max_sweeps))
+
+    def logpri(self, chain=0):
+        out = C.c_double()
+        self._check(self.lib.ba_logpri(self._h, chain, C.byref(out)))
+        return out.value
 
     def enable_draws(self, max_sweeps):
         self._check(self.lib.ba_enable_draws(self._h, max_sweeps))

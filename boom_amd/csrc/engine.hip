@@ -968,6 +968,71 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
   return BA_OK;
 }
 
+// PosteriorSampler::logpri() of BregVsSampler (BregVsSampler.cpp:380-393) for one
+// chain's current state: log p(gamma) + log p(sigma^2) + log N(beta_g | b_g,
+// sigma^2 Omega_g).  Host arithmetic on the chain's state and the host copies of
+// the priors (a k x k Cholesky): it is interface, not hot path.
+int ba_logpri(ba_engine *e, int64_t chain, double *out) {
+  ENGINE_PROLOGUE(e);
+  if (!out) return fail(BA_E_INVALID, "null argument");
+  if (!e->have_slab || e->pi.empty()) return fail(BA_E_STATE, "priors are not set");
+  const size_t p = (size_t)e->p;
+  std::vector<uint8_t> g(p);
+  std::vector<double> beta(p);
+  double sigsq = 0.0;
+  int rc = ba_get_state(e, chain, g.data(), beta.data(), &sigsq);
+  if (rc) return rc;
+  const double ninf = -std::numeric_limits<double>::infinity();
+  std::vector<int> idx;
+  for (size_t j = 0; j < p; ++j)
+    if (g[j]) idx.push_back((int)j);
+  const int k = (int)idx.size();
+  // VariableSelectionPrior::logp (VariableSelectionPrior.cpp:271-285)
+  double ans = 0.0;
+  if (e->max_model_size >= 0 && k > e->max_model_size) ans = ninf;
+  for (size_t j = 0; j < p && ans > ninf; ++j) {
+    ans += g[j] ? std::log(e->pi[j]) : std::log(1.0 - e->pi[j]);
+    if (!std::isfinite(ans)) ans = ninf;
+  }
+  if (!(ans > ninf)) {
+    *out = ninf;
+    return BA_OK;
+  }
+  // GenericGaussianVarianceSampler::log_prior: Gamma(df/2, ss/2) density of
+  // 1/sigma^2 and the Jacobian of the reciprocal
+  const double a = 0.5 * e->prior_df, b = 0.5 * e->prior_ss, x = 1.0 / sigsq;
+  ans += a * std::log(b) - std::lgamma(a) + (a - 1.0) * std::log(x) - b * x - 2.0 * std::log(sigsq);
+  if (k > 0) {
+    // dmvn(beta_g, b_g, Omega^{-1}_g / sigma^2, log)
+    std::vector<double> L((size_t)k * k, 0.0), d(k);
+    for (int c = 0; c < k; ++c)
+      for (int r = c; r < k; ++r) L[(size_t)r * k + c] = e->ominv[(size_t)idx[c] * p + idx[r]] / sigsq;
+    for (int i = 0; i < k; ++i) d[i] = beta[idx[i]] - e->b[idx[i]];
+    double quad = 0.0;  // Mdist on the matrix itself, before it is overwritten
+    for (int c = 0; c < k; ++c) {
+      quad += d[c] * d[c] * L[(size_t)c * k + c];
+      for (int r = c + 1; r < k; ++r) quad += 2.0 * d[c] * d[r] * L[(size_t)r * k + c];
+    }
+    double ld = 0.0;
+    for (int c = 0; c < k; ++c) {  // left-looking Cholesky, lower triangle in place
+      double s = L[(size_t)c * k + c];
+      for (int t = 0; t < c; ++t) s -= L[(size_t)c * k + t] * L[(size_t)c * k + t];
+      if (!(s > 0.0)) { ld = ninf; break; }
+      const double sd = std::sqrt(s);
+      L[(size_t)c * k + c] = sd;
+      ld += 2.0 * std::log(sd);
+      for (int r = c + 1; r < k; ++r) {
+        double v = L[(size_t)r * k + c];
+        for (int t = 0; t < c; ++t) v -= L[(size_t)r * k + t] * L[(size_t)c * k + t];
+        L[(size_t)r * k + c] = v / sd;
+      }
+    }
+    ans += -0.5 * k * std::log(2.0 * M_PI) + 0.5 * ld - 0.5 * quad;
+  }
+  *out = ans;
+  return BA_OK;
+}
+
 int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
   ENGINE_PROLOGUE(e);
   if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");

@@ -132,6 +132,10 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
                  double *sigsq);
 /* all chains at once: gamma chains x p, beta chains x p, sigsq chains */
 int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq);
+/* PosteriorSampler::logpri() of BregVsSampler (BregVsSampler.cpp:380-393) at the
+ * current state of one chain (local index): log p(gamma) + log p(sigma^2) +
+ * log N(beta_gamma | b_gamma, sigma^2 Omega_gamma) */
+int ba_logpri(ba_engine *e, int64_t chain, double *out);
 /* PosteriorSampler::set_seed: re-keys every chain's stream, position 0 */
 int ba_seed(ba_engine *e, uint64_t seed);
 

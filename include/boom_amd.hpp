@@ -266,6 +266,11 @@ class BregVsSampler : public PosteriorSampler {
     check(ba_set_sigma_prior(h(), df, std::sqrt(ss / df), s));
   }
   void set_seed(unsigned long s) { check(ba_seed(h(), s)); }
+  double logpri() const {                    // BregVsSampler.cpp:380-393, chain 0
+    double out;
+    check(ba_logpri(h(), 0, &out));
+    return out;
+  }
   double prior_df() const { double df; check(ba_get_priors(h(), nullptr, nullptr, nullptr, &df, nullptr)); return df; }
   double prior_ss() const { double ss; check(ba_get_priors(h(), nullptr, nullptr, nullptr, nullptr, &ss)); return ss; }
   double log_model_prob(const Selector &g) const {

@@ -1002,6 +1002,36 @@ static int ssvs_draw(bo_ssvs *s) {
 
 int bo_ssvs_draw(bo_ssvs *s) { return ssvs_draw(s); }
 
+/* BregVsSampler::logpri, BregVsSampler.cpp:380-393, at the sampler's current
+ * state: log p(gamma) + log p(sigma^2) + log N(beta_g | b_g, sigma^2 Omega_g).
+ *   p(sigma^2): GenericGaussianVarianceSampler::log_prior
+ *     (GenericGaussianVarianceSampler.cpp:81-91) = Gamma(df/2, ss/2) log
+ *     density of 1/sigma^2 plus the Jacobian -2 log sigma^2;
+ *   dmvn(y, mu, siginv, log) (distributions/mvn.cpp): -k/2 log 2pi +
+ *     1/2 log|siginv| - 1/2 Mdist(y - mu; siginv), siginv = Omega^{-1}_g / sigma^2
+ *     (MvnGivenScalarSigma.cpp:74-77). */
+double bo_ssvs_logpri(bo_ssvs *s) {
+  const int p = s->p;
+  const int k = gather_index(s, s->gamma, s->g);
+  double ans = spike_logp(s, s->gamma, k);
+  if (!(ans > BO_NEG_INF)) return ans;
+  const double a = 0.5 * s->prior_df, b = 0.5 * s->prior_ss, x = 1.0 / s->sigsq;
+  ans += a * log(b) - lgamma(a) + (a - 1.0) * log(x) - b * x - 2.0 * log(s->sigsq);
+  if (k > 0) {
+    double *P = (double *)xcalloc((size_t)k * k, sizeof(double));
+    double *d = (double *)xcalloc((size_t)k, sizeof(double));
+    select_spd(s->ominv, p, s->g, k, P);
+    for (int i = 0; i < k * k; ++i) P[i] /= s->sigsq;
+    for (int i = 0; i < k; ++i) d[i] = s->beta[s->g[i]] - s->b[s->g[i]];
+    int ok = 1;
+    const double ld = bo_spd_logdet(k, P, &ok);
+    ans += -0.5 * k * log(2.0 * M_PI) + 0.5 * ld - 0.5 * bo_spd_mdist(k, P, d);
+    free(P);
+    free(d);
+  }
+  return ans;
+}
+
 /* ---- convenience-ctor prior assembly ---------------------------------- */
 /* BregVsSampler ctor #1, BregVsSampler.cpp:37-44, 48-85 */
 void bo_breg_prior_ctor1(int p, const double *xtx, double yty, double n,

@@ -116,6 +116,8 @@ bo_rng *bo_ssvs_rng(bo_ssvs *s);
 double bo_ssvs_log_model_prob(bo_ssvs *s, const uint8_t *gamma, int *status);
 /* BregVsSampler::draw, BregVsSampler.cpp:252-261.  Returns BO_OK or an error. */
 int bo_ssvs_draw(bo_ssvs *s);
+/* BregVsSampler::logpri, BregVsSampler.cpp:380-393, at the current state */
+double bo_ssvs_logpri(bo_ssvs *s);
 /* smallest |log(u) - (logp_new - logp_old)| seen over all flips so far */
 double bo_ssvs_min_margin(const bo_ssvs *s);
 /* replace the sufficient statistics that change under the state-space model */

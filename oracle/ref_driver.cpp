@@ -345,6 +345,37 @@ int ref_ssvs_log_model_prob(int n, int p, const double *xtx, const double *xty,
   REF_CATCH
 }
 
+// BregVsSampler::logpri() (BregVsSampler.cpp:380-393) at given states.
+int ref_ssvs_logpri(int n, int p, const double *xtx, const double *xty,
+                    double yty, double ybar, const double *xbar,
+                    const double *prior_mean, const double *ominv,
+                    double prior_df, double sigma_guess, const double *pi,
+                    int64_t max_model_size, int nstates, const uint8_t *gammas,
+                    const double *betas, const double *sigsqs, double *out) {
+  REF_TRY
+  GlobalRng::rng.seed(1);
+  NEW(NeRegSuf, suf)(make_spd(p, xtx), make_vector(p, xty), yty, (double)n,
+                     ybar, make_vector(p, xbar));
+  NEW(RegressionModel, model)(Ptr<RegSuf>(suf));
+  NEW(MvnGivenScalarSigma, slab)(make_vector(p, prior_mean), make_spd(p, ominv),
+                                 model->Sigsq_prm());
+  NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
+  NEW(BregVsSampler, sampler)(model.get(), slab, siginv_prior, spike);
+  for (int s = 0; s < nstates; ++s) {
+    Selector inc(p, false);
+    for (int j = 0; j < p; ++j) {
+      if (gammas[(size_t)s * p + j]) inc.add(j);
+    }
+    model->coef().set_inc(inc);
+    model->set_Beta(make_vector(p, betas + (size_t)s * p));
+    model->set_sigsq(sigsqs[s]);
+    out[s] = sampler->logpri();
+  }
+  REF_CATCH
+}
+
 // ------------------------------------------------------ state-space runs
 // bsts "local level + regression" (SURVEY 3.3): StateSpaceRegressionModel with
 // one LocalLevelStateModel, BregVsSampler on the observation model,

@@ -117,6 +117,17 @@ def main():
          logp_max3=R.log_model_prob(suf, pr2, G, max_model_size=3),
          **prior_kw(pr2))
 
+    # logpri() at arbitrary states on the C1 data (a prior with non-zero means)
+    rs = np.random.default_rng(4)
+    pr3 = spike_slab_prior(suf, 5, force_intercept=False, prior_mean=0.3 * rs.standard_normal(20))
+    Gp = (rs.random((32, 20)) < 0.3).astype(np.uint8)
+    Gp[0] = 0
+    Bp = rs.standard_normal((32, 20)) * Gp
+    Sp = np.exp(rs.normal(0, 0.5, 32))
+    save("kat_logpri", xtx=suf["xtx"], xty=suf["xty"], yty=suf["yty"],
+         n=suf["n"], ybar=suf["ybar"], xbar=suf["xbar"], gammas=Gp, betas=Bp, sigsqs=Sp,
+         logpri=R.logpri(suf, pr3, Gp, Bp, Sp), **prior_kw(pr3))
+
     # convenience ctors #1 / #2 on the C1 data
     o1 = R.ssvs_run_ctor(1, X, y, [1.0, 0.5, 3.0, 0, 0], 1, ssvs_options(), 9,
                          g0, 100)

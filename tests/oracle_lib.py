@@ -310,6 +310,21 @@ class Oracle:
         self.lib.bo_ssvs_destroy(h)
         return np.array(out)
 
+    def logpri(self, suf, prior, gammas, betas, sigsqs, max_model_size=-1):
+        """BregVsSampler::logpri() at the given states"""
+        h = self.ssvs_create(suf, prior)
+        self.lib.bo_ssvs_set_options(h, max_model_size, float("inf"), 0.8, -1,
+                                     1, 1)
+        self.lib.bo_ssvs_logpri.restype = C.c_double
+        self.lib.bo_ssvs_logpri.argtypes = [C.c_void_p]
+        out = []
+        for g, b, s2 in zip(gammas, betas, sigsqs):
+            g = np.ascontiguousarray(g, dtype=np.uint8)
+            self.lib.bo_ssvs_set_state(h, _u8(g), _dp(f64(b)), C.c_double(float(s2)))
+            out.append(self.lib.bo_ssvs_logpri(h))
+        self.lib.bo_ssvs_destroy(h)
+        return np.array(out)
+
     def prior_ctor1(self, suf, prior_nobs, expected_rsq, expected_model_size,
                     first_term_is_intercept):
         p = len(suf["xty"])
@@ -666,6 +681,21 @@ class Ref:
             _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
             C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
             C.c_int64(max_model_size), len(G), _u8(G), _dp(out)))
+        return out
+
+    def logpri(self, suf, prior, gammas, betas, sigsqs, max_model_size=-1):
+        p = len(suf["xty"])
+        G = np.ascontiguousarray(gammas, dtype=np.uint8)
+        B = np.ascontiguousarray(betas, dtype=np.float64)
+        S = np.ascontiguousarray(sigsqs, dtype=np.float64)
+        out = np.zeros(len(G))
+        self._check(self.lib.ref_ssvs_logpri(
+            int(suf["n"]), p, _dp(fcol(suf["xtx"])), _dp(f64(suf["xty"])),
+            C.c_double(suf["yty"]), C.c_double(suf["sumy"] / suf["n"]),
+            _dp(f64(suf["xsum"] / suf["n"])), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
+            C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+            C.c_int64(max_model_size), len(G), _u8(G), _dp(B), _dp(S), _dp(out)))
         return out
 
     def sss_run(self, X, y, w, slab_kind, mu, prec, pi, seed, init_gamma,

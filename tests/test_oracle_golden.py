@@ -141,6 +141,16 @@ def test_log_model_prob(oracle):
     assert relerr(got3[m], want3[m]) < 1e-12
 
 
+def test_logpri(oracle):
+    """BregVsSampler::logpri() (the PosteriorSampler interface's log prior)"""
+    g = load("kat_logpri")
+    n = float(g["n"])
+    suf = dict(xtx=g["xtx"], xty=g["xty"], yty=float(g["yty"]), n=n,
+               sumy=float(g["ybar"]) * n, xsum=g["xbar"] * n)
+    got = oracle.logpri(suf, prior_of(g), g["gammas"], g["betas"], g["sigsqs"])
+    assert relerr(got, g["logpri"]) < 1e-12
+
+
 @pytest.mark.parametrize("name", ["ssvs_c1", "ssvs_p64", "ssvs_collinear",
                                   "ssvs_general", "ssvs_maxflips", "ssvs_empty"])
 def test_ssvs_sweeps_match_reference(oracle, name):

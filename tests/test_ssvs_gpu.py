@@ -298,6 +298,23 @@ def test_error_reporting_matches_reference_messages():
         eng3.sweep(5)              # more sweeps than record slots
 
 
+def test_logpri_matches_oracle(oracle):
+    """PosteriorSampler::logpri() of the chains' current states"""
+    X, y, _ = regression_data(300, 16, 4, seed=6)
+    suf = oracle.neregsuf(X, y)
+    pm = np.zeros(16)
+    pm[[0, 2, 9]] = [0.4, -0.3, 0.2]
+    prior = spike_slab_prior(suf, 4, prior_mean=pm)
+    g0 = np.zeros(16, np.uint8)
+    g0[0] = 1
+    eng = make_engine(5, 7, suf=suf, prior=prior, g0=g0)
+    eng.sweep(25)
+    gam, beta, sig = eng.get_states()
+    want = oracle.logpri(suf, prior, gam, beta, sig)
+    got = np.array([eng.logpri(c) for c in range(5)])
+    assert relerr(got, want) < 1e-12
+
+
 def test_summaries_and_traces(oracle):
     X, y, _ = regression_data(300, 16, 4, seed=6)
     suf = oracle.neregsuf(X, y)
