@@ -58,6 +58,9 @@ SIGNATURES = {
                                       C.c_double, C.c_double, C.c_double, C.c_int32]),
     "ba_get_priors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "ba_set_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
+    "ba_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "ba_set_lookahead": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_draw_next": (C.c_int, [C.c_void_p]),
     "ba_set_state": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _dp, C.c_double]),
     "ba_get_state": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _dp, _dp]),
     "ba_get_states": (C.c_int, [C.c_void_p, _u8p, _dp, _dp]),
@@ -76,6 +79,8 @@ SIGNATURES = {
     "ba_get_traces": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "ba_enable_draws": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_get_draws": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _u8p, _dp, _dp]),
+    "ba_get_coefficient_traces": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
+                                            C.POINTER(C.c_int32), _dp]),
     "ba_stream": (C.c_void_p, [C.c_void_p]),
     "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
@@ -211,6 +216,9 @@ class Engine:
         self._check(self.lib.ba_set_options(self._h, max_flips, swap_threshold,
                                             int(draw_beta), int(draw_sigma)))
 
+    def set_tuning(self, waves_per_chain=0, walk_policy=-1, kcap_start=0):
+        self._check(self.lib.ba_set_tuning(self._h, waves_per_chain, walk_policy, kcap_start))
+
     # ---- state --------------------------------------------------------------
     def set_state(self, gamma, beta=None, sigsq=1.0, chain=-1):
         g = np.ascontiguousarray(gamma, dtype=np.uint8)
@@ -244,6 +252,12 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.ba_sync(self._h))
+
+    def set_lookahead(self, n):
+        self._check(self.lib.ba_set_lookahead(self._h, n))
+
+    def draw_next(self):
+        self._check(self.lib.ba_draw_next(self._h))
 
     def log_model_prob(self, gammas):
         G = np.ascontiguousarray(gammas, dtype=np.uint8)
@@ -279,8 +293,9 @@ class Engine:
         return dict(inclusion_count=inc, beta_sum=bs, beta_sumsq=bs2,
                     sweeps=sc[0], sigsq_sum=sc[1], sigsq_sumsq=sc[2], k_sum=sc[3],
                     accepts=sc[4], proposals=sc[5], min_margin=sc[6],
-                    phase_cycles=sc[8:16].copy(), slot_hits=float(sc[7]),
-                    slowest_chain_cycles=float(sc[7]))
+                    # scalar 7: accepted flips served from a chain's other slot
+                    # (diagnostic stamp builds reuse it for the slowest chain's cycles)
+                    slot_hits=float(sc[7]), phase_cycles=sc[8:16].copy())
 
     def summaries_device(self, ptr):
         self._check(self.lib.ba_summaries_device(self._h, ptr))
@@ -297,13 +312,20 @@ class Engine:
         self._check(self.lib.ba_enable_draws(self._h, max_sweeps))
 
     def get_draws(self, chain, nsweeps):
-        """the recorded draws of one chain (global id) of the last sweep() call"""
+        """the recorded draws of one chain (local index) of the last sweep() call"""
         p = self.p
         g = np.zeros((nsweeps, p), np.uint8)
         b = np.zeros((nsweeps, p))
         s = np.zeros(nsweeps)
         self._check(self.lib.ba_get_draws(self._h, chain, nsweeps, _b(g), _p(b), _p(s)))
         return g, b, s
+
+    def get_coefficient_traces(self, nsweeps, variables):
+        v = np.ascontiguousarray(variables, dtype=np.int32)
+        out = np.zeros((self.chains, len(v), nsweeps))
+        self._check(self.lib.ba_get_coefficient_traces(
+            self._h, nsweeps, len(v), v.ctypes.data_as(C.POINTER(C.c_int32)), _p(out)))
+        return out
 
     def get_traces(self, nsweeps):
         c = self.chains

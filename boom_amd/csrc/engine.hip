@@ -167,6 +167,20 @@ struct ba_engine {
 
   int kcap = 0;
   int waves = 1;  // wavefronts per chain
+  // ba_draw_next: the look-ahead batch.  la_avail draws are recorded on the
+  // device, la_served of them have been handed out; the snapshot is the chains'
+  // state (and the running summaries) at the start of the batch, which is what
+  // a rewind restores before replaying the la_served draws already seen.
+  int la_len = 1, la_avail = 0, la_served = 0;
+  DevBuf<uint8_t> snap_gamma;
+  DevBuf<double> snap_beta, snap_sigsq, snap_bsum, snap_bsumsq, snap_acc;
+  DevBuf<uint16_t> snap_perm;
+  DevBuf<uint64_t> snap_pos;
+  DevBuf<int32_t> snap_fail;
+  DevBuf<uint32_t> snap_inc;
+  int rec_cap = 64;  // variables per recorded draw (ba_enable_draws)
+  // ba_set_tuning overrides (0 / -1: the engine chooses)
+  int tune_waves = 0, tune_walk_policy = -1, tune_kcap_start = 0;
   // SpikeSlabSampler (sigma^2 given) mode
   int cur_mode = 0;          // mode of the launches in flight (0 BregVs, 1 SSS)
   int sss_slab_scales = 1;   // slab precision = Omega^{-1} / sigma^2
@@ -246,18 +260,18 @@ int choose_kcap(const ba_engine &e) {
     const int k = (int)std::min<int64_t>(64, (((int64_t)e.cfg.max_model_size_hint + 15) / 16) * 16);
     return std::min(k, lds_cap(e));
   }
-  int start = 32;  // (BOOM_AMD_KCAP_START: tests force early escalations)
-  if (const char *s = std::getenv("BOOM_AMD_KCAP_START")) start = std::max(16, (std::atoi(s) / 16) * 16);
+  int start = 32;  // (ba_set_tuning: tests force early escalations)
+  if (e.tune_kcap_start > 0) start = std::max(16, (e.tune_kcap_start / 16) * 16);
   return std::min(start, limit);
 }
 
 // Wavefronts per chain.  The proposal batches scale with the number of waves
 // (64 proposals each, evaluated speculatively), and several resident waves per
 // SIMD hide the gather / scalar-load latencies; the register budget of the
-// 4-wave kernels only exists for capacities <= 32.  BOOM_AMD_WAVES overrides.
+// 4-wave kernels only exists for capacities <= 32.  ba_set_tuning overrides.
 int choose_waves(const ba_engine &e, int kcap) {
-  if (const char *s = std::getenv("BOOM_AMD_WAVES")) {
-    const int w = std::atoi(s);
+  {
+    const int w = e.tune_waves;
     if (w == 1 || w == 2 || (w == 4 && kcap <= 32)) return w;
   }
   const int per_cu = std::max(1, (e.cfg.chains + e.cu_count - 1) / e.cu_count);
@@ -438,8 +452,7 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.seed_hi = (uint32_t)(e->seed >> 32);
   P.stream = 0;
   P.mode = e->cur_mode;
-  P.walk_policy = 1;  // (BOOM_AMD_SCAN: diagnostic override, see ssvs_params.h)
-  if (const char *sp = std::getenv("BOOM_AMD_SCAN")) P.walk_policy = std::atoi(sp);
+  P.walk_policy = e->tune_walk_policy >= 0 ? e->tune_walk_policy : 1;  // (see ssvs_params.h)
   if (e->cur_mode == 1) {
     // SpikeSlabSampler: given sigma^2, no sigma draw, no swap move, own stream
     P.slab_scales = e->sss_slab_scales;
@@ -460,6 +473,7 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.trace_stride = e->trace_stride;
   P.rec_idx = e->drec_idx.ptr;
   P.rec_beta = e->drec_beta.ptr;
+  P.rec_cap = e->rec_cap;
 }
 
 // Resume chains that outgrew the capacity of the launch they were in, with the
@@ -475,7 +489,7 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
     e->waves = choose_waves(*e, e->kcap);
     for (size_t c = 0; c < C; ++c)
       if (st[c] == CHAIN_MODEL_TOO_LARGE) st[c] = CHAIN_OK;
-    HIP_TRY(hipMemcpy(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice, e->stream));
     SsvsParams P;
     fill_params(e, P);
     HIP_TRY(launch_ssvs_sweep(e->stream, P, 0));   // runs the sweeps still owed
@@ -541,7 +555,7 @@ int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
         rounds = std::max(rounds, (int)todo[c]);
       }
     }
-    HIP_TRY(hipMemcpy(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice, e->stream));
     SsvsParams P;
     fill_params(e, P);
     P.run_limit = 1;
@@ -569,8 +583,9 @@ int check_chain_status(ba_engine *e) {
     // capacity follows the models: room for growth, no more
     if (e->cfg.max_model_size_hint <= 0 && e->kcap > 0) {
       int32_t maxk = 0;
-      HIP_TRY(hipMemcpy(&maxk, e->dmaxk.ptr, 4, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemset(e->dmaxk.ptr, 0, 4));
+      HIP_TRY(hipMemcpyAsync(&maxk, e->dmaxk.ptr, 4, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemsetAsync(e->dmaxk.ptr, 0, 4, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
       const int want = std::min(cap_limit(*e), std::max(16, ((maxk + 8 + 15) / 16) * 16));
       if (maxk > 0 && want < e->kcap) {
         e->kcap = want;
@@ -593,6 +608,83 @@ int set_device(const ba_engine *e) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   return BA_OK;
 }
+
+// ---- look-ahead serving (ba_draw_next) ------------------------------------------
+int sweep_impl(ba_engine *e, int32_t nsweeps, bool record = true);
+int read_record(ba_engine *e, int64_t c, int row0, int nrows, uint8_t *gamma,
+                double *beta, double *sigsq);
+int read_record_row_all(ba_engine *e, int row, uint8_t *gamma, double *beta, double *sigsq);
+
+void la_discard(ba_engine *e) { e->la_avail = e->la_served = 0; }
+
+int la_copy(ba_engine *e, bool save) {
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
+  hipStream_t s = e->stream;
+  if (save) {
+    HIP_TRY(e->snap_gamma.resize(C * p));
+    HIP_TRY(e->snap_beta.resize(C * p));
+    HIP_TRY(e->snap_sigsq.resize(C));
+    HIP_TRY(e->snap_perm.resize(C * p));
+    HIP_TRY(e->snap_pos.resize(C));
+    HIP_TRY(e->snap_fail.resize(C));
+    HIP_TRY(e->snap_inc.resize(C * p));
+    HIP_TRY(e->snap_bsum.resize(C * p));
+    HIP_TRY(e->snap_bsumsq.resize(C * p));
+    HIP_TRY(e->snap_acc.resize(C * ACC_COUNT));
+  }
+#define LA_CP(snap, live, bytes)                                                      \
+  HIP_TRY(hipMemcpyAsync(save ? (void *)(snap) : (void *)(live),                       \
+                         save ? (const void *)(live) : (const void *)(snap), (bytes), \
+                         hipMemcpyDeviceToDevice, s))
+  LA_CP(e->snap_gamma.ptr, e->dgamma.ptr, C * p);
+  LA_CP(e->snap_beta.ptr, e->dbeta.ptr, C * p * 8);
+  LA_CP(e->snap_sigsq.ptr, e->dsigsq.ptr, C * 8);
+  LA_CP(e->snap_perm.ptr, e->dperm.ptr, C * p * 2);
+  LA_CP(e->snap_pos.ptr, e->dpos.ptr, C * 8);
+  LA_CP(e->snap_fail.ptr, e->dfail.ptr, C * 4);
+  LA_CP(e->snap_inc.ptr, e->dinc.ptr, C * p * 4);
+  LA_CP(e->snap_bsum.ptr, e->dbsum.ptr, C * p * 8);
+  LA_CP(e->snap_bsumsq.ptr, e->dbsumsq.ptr, C * p * 8);
+  LA_CP(e->snap_acc.ptr, e->dacc.ptr, C * ACC_COUNT * 8);
+#undef LA_CP
+  return BA_OK;
+}
+
+// Something other than ba_draw_next is about to touch the engine while draws of
+// the look-ahead batch are still unserved: put the chains where the caller has
+// seen them -- the batch's start, replayed up to the last draw handed out (same
+// stream positions, so the same draws).
+int la_rewind(ba_engine *e) {
+  if (e->la_served >= e->la_avail) {
+    la_discard(e);
+    return BA_OK;
+  }
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int replay = e->la_served;
+  la_discard(e);
+  int rc = check_chain_status(e);
+  if (rc) return rc;
+  rc = la_copy(e, false);
+  if (rc) return rc;
+  e->table_ok = false;
+  e->model_ok = false;
+  if (replay > 0) {
+    rc = sweep_impl(e, replay, /*record=*/false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    rc = check_chain_status(e);
+  }
+  return rc;
+}
+
+#define MUTATE(e)                        \
+  do {                                   \
+    int rc_m__ = la_rewind(e);           \
+    if (rc_m__) return rc_m__;           \
+    (e)->table_ok = false;               \
+    (e)->model_ok = false;               \
+  } while (0)
 
 #define ENGINE_PROLOGUE(e)                                     \
   if (!(e)) return fail(BA_E_INVALID, "null engine");          \
@@ -689,8 +781,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
                              const double *xty, double yty, double n,
                              double ybar, const double *xbar) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!xtx || !xty || !xbar) return fail(BA_E_INVALID, "null argument");
   int rc = set_dimension(e, p);
   if (rc) return rc;
@@ -709,8 +800,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
 int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
                                 const void *X_device, const void *y_device) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!X_device || !y_device) return fail(BA_E_INVALID, "null argument");
   if (n <= 0) return fail(BA_E_INVALID, "n must be positive");
   int rc = set_dimension(e, p);
@@ -746,8 +836,7 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
 int ba_build_suf_from_xy(ba_engine *e, int64_t n, int32_t p, const double *X,
                          const double *y) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!X || !y) return fail(BA_E_INVALID, "null argument");
   if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
   HIP_TRY(e->dX.resize((size_t)n * p));
@@ -779,8 +868,7 @@ int ba_get_regression_suf(ba_engine *e, double *xtx, double *xty, double *yty,
 int ba_set_slab(ba_engine *e, const double *prior_mean,
                 const double *unscaled_prior_precision) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!prior_mean || !unscaled_prior_precision) return fail(BA_E_INVALID, "null argument");
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
   const int p = e->p;
@@ -793,8 +881,7 @@ int ba_set_slab(ba_engine *e, const double *prior_mean,
 
 int ba_set_spike(ba_engine *e, const double *pi, int64_t max_model_size) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!pi) return fail(BA_E_INVALID, "null argument");
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data before the priors");
   for (int j = 0; j < e->p; ++j)
@@ -810,8 +897,7 @@ int ba_set_spike(ba_engine *e, const double *pi, int64_t max_model_size) {
 int ba_set_sigma_prior(ba_engine *e, double prior_df, double sigma_guess,
                        double sigma_upper_limit) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (sigma_upper_limit < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
   // ChisqModel(df, sigma): alpha = df/2, beta = df sigma^2/2 (ChisqModel.cpp:56-57)
   const double alpha = prior_df / 2.0;
@@ -828,8 +914,7 @@ int ba_set_priors_ctor1(ba_engine *e, double prior_nobs, double expected_rsq,
                         double expected_model_size,
                         int32_t first_term_is_intercept) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
   if (!(expected_rsq > 0 && expected_rsq < 1)) return fail(BA_E_INVALID, "expected_rsq must be in (0, 1)");
   // BregVsSampler.cpp:37-44, 48-85
@@ -856,8 +941,7 @@ int ba_set_priors_ctor2(ba_engine *e, double prior_sigma_nobs,
                         double prior_inclusion_probability,
                         int32_t force_intercept) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!e->have_suf) return fail(BA_E_STATE, "no regression data set");
   // BregVsSampler.cpp:87-142
   if (prior_sigma_guess <= 0)
@@ -905,8 +989,7 @@ int ba_get_priors(ba_engine *e, double *prior_mean, double *ominv, double *pi,
 int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
                    int32_t draw_beta, int32_t draw_sigma) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   e->max_flips = max_flips;
   if (swap_threshold != e->swap_threshold) e->device_dirty = true;
   e->swap_threshold = swap_threshold;
@@ -915,16 +998,47 @@ int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
   return BA_OK;
 }
 
+int ba_set_tuning(ba_engine *e, int32_t waves_per_chain, int32_t walk_policy,
+                  int32_t kcap_start) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!(waves_per_chain == 0 || waves_per_chain == 1 || waves_per_chain == 2 || waves_per_chain == 4))
+    return fail(BA_E_INVALID, "waves_per_chain must be 0, 1, 2 or 4");
+  if (walk_policy < -1 || walk_policy > 3) return fail(BA_E_INVALID, "walk_policy must be in [-1, 3]");
+  if (kcap_start < 0) return fail(BA_E_INVALID, "kcap_start must be non-negative");
+  MUTATE(e);
+  if (e->state_ready) {
+    int rc = set_device(e);
+    if (!rc) rc = ba_sync(e);
+    if (rc) return rc;
+  }
+  e->tune_waves = waves_per_chain;
+  e->tune_walk_policy = walk_policy;
+  e->tune_kcap_start = kcap_start;
+  e->device_dirty = true;  // capacity and waves are chosen again
+  return BA_OK;
+}
+
 // --------------------------------------------------------------- state
 int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
                  const double *beta, double sigsq) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
   if (e->p <= 0) return fail(BA_E_STATE, "set the regression data first");
   if (!gamma) return fail(BA_E_INVALID, "null argument");
   const int64_t C = e->cfg.chains;
   if (chain < -1 || chain >= C) return fail(BA_E_INVALID, "chain index out of range");
+  if (chain < 0) la_discard(e);  // every chain is overwritten: nothing to rewind to
+  MUTATE(e);
+  // launches in flight (and sweeps still owed after a capacity stop) belong to
+  // the OLD state: resolve them before it is overwritten.  Setting every chain
+  // also clears chain errors (the caller starts over).
+  if (e->state_ready) {
+    int rc = ba_sync(e);
+    if (rc && chain >= 0) return rc;
+    if (rc) {
+      HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, (size_t)C * 4, e->stream));
+      HIP_TRY(hipMemsetAsync(e->dtodo.ptr, 0, (size_t)C * 4, e->stream));
+    }
+  }
   int rc = alloc_chain_state(e);
   if (rc) return rc;
   const size_t p = (size_t)e->p;
@@ -933,7 +1047,7 @@ int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
     zeros.assign(p, 0.0);
     beta = zeros.data();
   }
-  const int64_t lo = chain < 0 ? 0 : chain, hi = chain < 0 ? C : chain + 1;
+  hipStream_t s = e->stream;
   if (chain < 0) {
     std::vector<uint8_t> G((size_t)C * p);
     std::vector<double> B((size_t)C * p), S((size_t)C, sigsq);
@@ -941,15 +1055,15 @@ int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
       std::memcpy(&G[(size_t)c * p], gamma, p);
       std::memcpy(&B[(size_t)c * p], beta, p * 8);
     }
-    HIP_TRY(hipMemcpy(e->dgamma.ptr, G.data(), G.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->dbeta.ptr, B.data(), B.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->dsigsq.ptr, S.data(), S.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(e->dgamma.ptr, G.data(), G.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dbeta.ptr, B.data(), B.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dsigsq.ptr, S.data(), S.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
   } else {
-    for (int64_t c = lo; c < hi; ++c) {
-      HIP_TRY(hipMemcpy(e->dgamma.ptr + (size_t)c * p, gamma, p, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(e->dbeta.ptr + (size_t)c * p, beta, p * 8, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(e->dsigsq.ptr + c, &sigsq, 8, hipMemcpyHostToDevice));
-    }
+    HIP_TRY(hipMemcpyAsync(e->dgamma.ptr + (size_t)chain * p, gamma, p, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dbeta.ptr + (size_t)chain * p, beta, p * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dsigsq.ptr + chain, &sigsq, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
   }
   return BA_OK;
 }
@@ -961,6 +1075,8 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   int rc = ba_sync(e);
   if (rc) return rc;
+  if (e->la_served > 0 && e->la_served < e->la_avail)  // the draw ba_draw_next is serving
+    return read_record(e, chain, e->la_served - 1, 1, gamma, beta, sigsq);
   const size_t p = (size_t)e->p;
   if (gamma) HIP_TRY(hipMemcpy(gamma, e->dgamma.ptr + (size_t)chain * p, p, hipMemcpyDeviceToHost));
   if (beta) HIP_TRY(hipMemcpy(beta, e->dbeta.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost));
@@ -1038,6 +1154,8 @@ int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
   if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
   int rc = ba_sync(e);
   if (rc) return rc;
+  if (e->la_served > 0 && e->la_served < e->la_avail)
+    return read_record_row_all(e, e->la_served - 1, gamma, beta, sigsq);
   const size_t p = (size_t)e->p, C = (size_t)e->cfg.chains;
   if (gamma) HIP_TRY(hipMemcpy(gamma, e->dgamma.ptr, C * p, hipMemcpyDeviceToHost));
   if (beta) HIP_TRY(hipMemcpy(beta, e->dbeta.ptr, C * p * 8, hipMemcpyDeviceToHost));
@@ -1047,13 +1165,22 @@ int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
 
 int ba_seed(ba_engine *e, uint64_t seed) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
-  e->seed = seed;
+  MUTATE(e);
+  // sweeps in flight -- and sweeps still owed after a capacity stop -- belong
+  // to the old key
   if (e->state_ready) {
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemset(e->dpos.ptr, 0, (size_t)e->cfg.chains * 8));
+    int rc = ba_sync(e);
+    if (rc) return rc;
   }
+  e->seed = seed;
+  const size_t C = (size_t)e->cfg.chains;
+  hipStream_t s = e->stream;
+  // every sampler of every chain restarts at position 0 of its new stream
+  if (e->dpos.ptr) HIP_TRY(hipMemsetAsync(e->dpos.ptr, 0, C * 8, s));
+  if (e->dpos_sss.ptr) HIP_TRY(hipMemsetAsync(e->dpos_sss.ptr, 0, C * 8, s));
+  if (e->dpos_level.ptr) HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
+  if (e->dpos_state.ptr) HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return BA_OK;
 }
 
@@ -1076,8 +1203,10 @@ static int switch_mode(ba_engine *e, int mode, double v_scale) {
 }
 
 // ------------------------------------------------------------ hot path
-int ba_sweep(ba_engine *e, int32_t nsweeps) {
-  ENGINE_PROLOGUE(e);
+}  // extern "C"
+
+namespace {
+int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
   int rc = switch_mode(e, 0, 1.0);
@@ -1086,19 +1215,66 @@ int ba_sweep(ba_engine *e, int32_t nsweeps) {
   if (rc) return rc;
   rc = alloc_chain_state(e);
   if (rc) return rc;
-  if (e->trace_stride > 0 && nsweeps > e->trace_stride)
+  if (record && e->trace_stride > 0 && nsweeps > e->trace_stride)
     return fail(BA_E_INVALID, "nsweeps exceeds the enabled trace length");
   HIP_TRY(e->dmodel.resize(2 * (size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
   SsvsParams P;
   fill_params(e, P);
+  if (!record) {  // (the record buffers belong to the look-ahead batches)
+    P.trace_sigsq = P.trace_logp = P.trace_k = nullptr;
+    P.rec_idx = nullptr;
+    P.rec_beta = nullptr;
+    P.trace_stride = 0;
+  }
   const SsvsLds lay = ssvs_lds_layout(e->p, e->kcap);
   if (lay.total > e->lds_per_cu)
     return fail(BA_E_INVALID, "problem does not fit the LDS working set");
-  if (e->trace_stride > 0)  // traces are those of the last ba_sweep call
+  if (record && e->trace_stride > 0)  // traces are those of the last ba_sweep call
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
   HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
   e->table_ok = true;  // until anything but another ba_sweep touches the engine
   e->model_ok = true;
+  return BA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ba_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  // unserved look-ahead draws: the sweeps asked for here come after the last one served
+  int rc = la_rewind(e);
+  if (rc) return rc;
+  return sweep_impl(e, nsweeps, /*record=*/e->la_len <= 1);
+}
+
+int ba_set_lookahead(ba_engine *e, int32_t lookahead) {
+  ENGINE_PROLOGUE(e);
+  if (lookahead < 1) return fail(BA_E_INVALID, "lookahead must be at least 1");
+  MUTATE(e);
+  if (lookahead > 1) {
+    int rc = ba_enable_draws(e, lookahead);
+    if (rc) return rc;
+  }
+  e->la_len = lookahead;
+  return BA_OK;
+}
+
+int ba_draw_next(ba_engine *e) {
+  ENGINE_PROLOGUE(e);
+  if (e->la_len <= 1) return ba_sweep(e, 1);
+  if (e->la_served == e->la_avail) {
+    // the record is used up: the next batch, from the chains' current state
+    la_discard(e);
+    int rc = switch_mode(e, 0, 1.0);
+    if (!rc) rc = upload_shared(e);
+    if (!rc) rc = alloc_chain_state(e);
+    if (!rc) rc = la_copy(e, true);
+    if (!rc) rc = sweep_impl(e, e->la_len);
+    if (rc) return rc;
+    e->la_avail = e->la_len;
+  }
+  ++e->la_served;
   return BA_OK;
 }
 
@@ -1112,7 +1288,15 @@ int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
                       double *out) {
   ENGINE_PROLOGUE(e);
   if (!gammas || !out || ngamma <= 0) return fail(BA_E_INVALID, "bad argument");
-  int rc = upload_shared(e);
+  // the regression model's own sufficient statistics: in state-space mode they
+  // are per chain and move every sweep, so there is no one answer
+  if (e->ss_mode)
+    return fail(BA_E_STATE, "ba_log_model_prob is not defined once state-space data are set (per-chain sufficient statistics)");
+  // BregVsSampler's V = Omega^{-1} + XtX (a SpikeSlabSampler launch with a fixed
+  // slab precision leaves XtX / sigma^2 in it)
+  int rc = switch_mode(e, 0, 1.0);
+  if (rc) return rc;
+  rc = upload_shared(e);
   if (rc) return rc;
   rc = alloc_chain_state(e);
   if (rc) return rc;
@@ -1186,6 +1370,11 @@ int ba_get_summaries(ba_engine *e, double *inclusion_count, double *beta_sum,
 int ba_enable_traces(ba_engine *e, int32_t max_sweeps) {
   ENGINE_PROLOGUE(e);
   if (max_sweeps < 0) return fail(BA_E_INVALID, "max_sweeps must be non-negative");
+  {  // (the recording buffers are the look-ahead's as well)
+    int rc = la_rewind(e);
+    if (rc) return rc;
+    e->la_len = 1;
+  }
   const size_t C = (size_t)e->cfg.chains;
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(e->dtr_sig.resize(C * max_sweeps));
@@ -1201,10 +1390,72 @@ int ba_enable_draws(ba_engine *e, int32_t max_sweeps) {
   int rc = ba_enable_traces(e, max_sweeps);
   if (rc) return rc;
   const size_t C = (size_t)e->cfg.chains;
-  HIP_TRY(e->drec_idx.resize(C * max_sweeps * 64));
-  HIP_TRY(e->drec_beta.resize(C * max_sweeps * 64));
+  e->rec_cap = std::max(64, e->kcap);
+  HIP_TRY(e->drec_idx.resize(C * max_sweeps * e->rec_cap));
+  HIP_TRY(e->drec_beta.resize(C * max_sweeps * e->rec_cap));
   return BA_OK;
 }
+
+}  // extern "C"
+
+namespace {
+// rows [row0, row0 + nrows) of one chain's record, expanded to dense gamma / beta
+int read_record(ba_engine *e, int64_t c, int row0, int nrows, uint8_t *gamma,
+                double *beta, double *sigsq) {
+  const size_t p = (size_t)e->p, cap = (size_t)e->rec_cap;
+  const size_t base = (size_t)c * e->trace_stride + row0;
+  std::vector<double> ks(nrows), sig(nrows), b((size_t)nrows * cap);
+  std::vector<uint16_t> idx((size_t)nrows * cap);
+  HIP_TRY(hipMemcpy(ks.data(), e->dtr_k.ptr + base, (size_t)nrows * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sig.data(), e->dtr_sig.ptr + base, (size_t)nrows * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(idx.data(), e->drec_idx.ptr + base * cap, idx.size() * 2, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b.data(), e->drec_beta.ptr + base * cap, b.size() * 8, hipMemcpyDeviceToHost));
+  if (gamma) std::memset(gamma, 0, (size_t)nrows * p);
+  if (beta) std::memset(beta, 0, (size_t)nrows * p * 8);
+  for (int s = 0; s < nrows; ++s) {
+    const int k = (int)ks[s];
+    if (k < 0 || (size_t)k > cap) return fail(BA_E_STATE, "corrupt draw record");
+    for (int m = 0; m < k; ++m) {
+      const size_t j = idx[(size_t)s * cap + m];
+      if (j >= p) return fail(BA_E_STATE, "corrupt draw record");
+      if (gamma) gamma[(size_t)s * p + j] = 1;
+      if (beta) beta[(size_t)s * p + j] = b[(size_t)s * cap + m];
+    }
+    if (sigsq) sigsq[s] = sig[s];
+  }
+  return BA_OK;
+}
+
+// one row of EVERY chain's record (the draw ba_draw_next is serving)
+int read_record_row_all(ba_engine *e, int row, uint8_t *gamma, double *beta, double *sigsq) {
+  const size_t p = (size_t)e->p, cap = (size_t)e->rec_cap, C = (size_t)e->cfg.chains;
+  const size_t stride = (size_t)e->trace_stride;
+  std::vector<double> ks(C), sig(C), b(C * cap);
+  std::vector<uint16_t> idx(C * cap);
+  HIP_TRY(hipMemcpy2D(ks.data(), 8, e->dtr_k.ptr + row, stride * 8, 8, C, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(sig.data(), 8, e->dtr_sig.ptr + row, stride * 8, 8, C, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(idx.data(), cap * 2, e->drec_idx.ptr + (size_t)row * cap, stride * cap * 2,
+                      cap * 2, C, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(b.data(), cap * 8, e->drec_beta.ptr + (size_t)row * cap, stride * cap * 8,
+                      cap * 8, C, hipMemcpyDeviceToHost));
+  if (gamma) std::memset(gamma, 0, C * p);
+  if (beta) std::memset(beta, 0, C * p * 8);
+  for (size_t c = 0; c < C; ++c) {
+    const int k = (int)ks[c];
+    if (k < 0 || (size_t)k > cap) return fail(BA_E_STATE, "corrupt draw record");
+    for (int m = 0; m < k; ++m) {
+      const size_t j = idx[c * cap + m];
+      if (j >= p) return fail(BA_E_STATE, "corrupt draw record");
+      if (gamma) gamma[c * p + j] = 1;
+      if (beta) beta[c * p + j] = b[c * cap + m];
+    }
+    if (sigsq) sigsq[c] = sig[c];
+  }
+  return BA_OK;
+}
+}  // namespace
+
+extern "C" {
 
 int ba_get_draws(ba_engine *e, int64_t chain, int32_t nsweeps, uint8_t *gamma,
                  double *beta, double *sigsq) {
@@ -1212,28 +1463,41 @@ int ba_get_draws(ba_engine *e, int64_t chain, int32_t nsweeps, uint8_t *gamma,
   if (e->trace_stride <= 0 || e->drec_idx.count == 0)
     return fail(BA_E_STATE, "draw recording is not enabled");
   if (nsweeps <= 0 || nsweeps > e->trace_stride) return fail(BA_E_INVALID, "nsweeps out of range");
-  const int64_t c = chain - e->cfg.chain_offset;
-  if (c < 0 || c >= e->cfg.chains) return fail(BA_E_INVALID, "chain id not owned by this engine");
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   int rc = ba_sync(e);
   if (rc) return rc;
-  const size_t p = (size_t)e->p, base = (size_t)c * e->trace_stride;
-  std::vector<double> ks(nsweeps), sig(nsweeps), b((size_t)nsweeps * 64);
-  std::vector<uint16_t> idx((size_t)nsweeps * 64);
-  HIP_TRY(hipMemcpy(ks.data(), e->dtr_k.ptr + base, (size_t)nsweeps * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(sig.data(), e->dtr_sig.ptr + base, (size_t)nsweeps * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(idx.data(), e->drec_idx.ptr + base * 64, idx.size() * 2, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(b.data(), e->drec_beta.ptr + base * 64, b.size() * 8, hipMemcpyDeviceToHost));
-  if (gamma) std::memset(gamma, 0, (size_t)nsweeps * p);
-  if (beta) std::memset(beta, 0, (size_t)nsweeps * p * 8);
-  for (int s = 0; s < nsweeps; ++s) {
-    const int k = (int)ks[s];
-    for (int m = 0; m < k && m < 64; ++m) {
-      const size_t j = idx[(size_t)s * 64 + m];
-      if (j >= p) return fail(BA_E_STATE, "corrupt draw record");
-      if (gamma) gamma[(size_t)s * p + j] = 1;
-      if (beta) beta[(size_t)s * p + j] = b[(size_t)s * 64 + m];
+  return read_record(e, chain, 0, nsweeps, gamma, beta, sigsq);
+}
+
+int ba_get_coefficient_traces(ba_engine *e, int32_t nsweeps, int32_t nvars,
+                              const int32_t *vars, double *out) {
+  ENGINE_PROLOGUE(e);
+  if (e->trace_stride <= 0 || e->drec_idx.count == 0)
+    return fail(BA_E_STATE, "draw recording is not enabled");
+  if (nsweeps <= 0 || nsweeps > e->trace_stride) return fail(BA_E_INVALID, "nsweeps out of range");
+  if (nvars <= 0 || !vars || !out) return fail(BA_E_INVALID, "bad argument");
+  for (int v = 0; v < nvars; ++v)
+    if (vars[v] < 0 || vars[v] >= e->p) return fail(BA_E_INVALID, "variable index out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains, cap = (size_t)e->rec_cap, stride = (size_t)e->trace_stride;
+  std::vector<int> slot(e->p, -1);
+  for (int v = 0; v < nvars; ++v) slot[vars[v]] = v;
+  std::vector<double> ks(nsweeps), b((size_t)nsweeps * cap);
+  std::vector<uint16_t> idx((size_t)nsweeps * cap);
+  std::memset(out, 0, C * (size_t)nvars * nsweeps * 8);
+  for (size_t c = 0; c < C; ++c) {
+    const size_t base = c * stride;
+    HIP_TRY(hipMemcpy(ks.data(), e->dtr_k.ptr + base, (size_t)nsweeps * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(idx.data(), e->drec_idx.ptr + base * cap, idx.size() * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b.data(), e->drec_beta.ptr + base * cap, b.size() * 8, hipMemcpyDeviceToHost));
+    for (int s = 0; s < nsweeps; ++s) {
+      const int k = (int)ks[s];
+      for (int m = 0; m < k && (size_t)m < cap; ++m) {
+        const int v = slot[idx[(size_t)s * cap + m] % (size_t)e->p];
+        if (v >= 0) out[(c * nvars + v) * nsweeps + s] = b[(size_t)s * cap + m];
+      }
     }
-    if (sigsq) sigsq[s] = sig[s];
   }
   return BA_OK;
 }
@@ -1260,8 +1524,7 @@ int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
 // ------------------------------------------- SpikeSlabSampler (sigma^2 given)
 int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!(sigsq > 0)) return fail(BA_E_INVALID, "sigsq must be positive");
   int rc = alloc_chain_state(e);
   if (rc) return rc;
@@ -1280,8 +1543,7 @@ int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq) {
 int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
                     int32_t precision_scales_with_sigsq, int32_t max_flips) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   int rc = ba_set_slab(e, mu, precision);
   if (rc) return rc;
   e->sss_slab_scales = precision_scales_with_sigsq ? 1 : 0;
@@ -1296,8 +1558,7 @@ int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
 
 int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
   if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
@@ -1354,15 +1615,17 @@ static int ss_prepare(ba_engine *e) {
     std::vector<double> xty(C * p), yty(C, e->yty), nobs(C, e->n),
         lev(C, e->ss_initial_level_sigsq);
     for (size_t c = 0; c < C; ++c) std::memcpy(&xty[c * p], e->xty.data(), p * 8);
-    HIP_TRY(hipMemcpy(e->dxty_c.ptr, xty.data(), xty.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->dyty_c.ptr, yty.data(), C * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->dnobs_c.ptr, nobs.data(), C * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->dlev_sigsq.ptr, lev.data(), C * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(e->dlev_n.ptr, 0, C * 8));
-    HIP_TRY(hipMemset(e->dlev_sumsq.ptr, 0, C * 8));
-    HIP_TRY(hipMemset(e->dpos_level.ptr, 0, C * 8));
-    HIP_TRY(hipMemset(e->dpos_state.ptr, 0, C * 8));
-    HIP_TRY(hipMemset(e->dss_scratch.ptr, 0, C * SS_SCRATCH_ARRAYS * T * 8));
+    hipStream_t s = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->dxty_c.ptr, xty.data(), xty.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dyty_c.ptr, yty.data(), C * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dnobs_c.ptr, nobs.data(), C * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dlev_sigsq.ptr, lev.data(), C * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->dlev_n.ptr, 0, C * 8, s));
+    HIP_TRY(hipMemsetAsync(e->dlev_sumsq.ptr, 0, C * 8, s));
+    HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
+    HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
+    HIP_TRY(hipMemsetAsync(e->dss_scratch.ptr, 0, C * SS_SCRATCH_ARRAYS * T * 8, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (the host vectors above go out of scope)
     e->ss_initialized = false;
   }
   HIP_TRY(e->dmodel.resize(2 * (size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
@@ -1372,8 +1635,7 @@ static int ss_prepare(ba_engine *e) {
 int ba_ss_set_data(ba_engine *e, int32_t T, int32_t p, const double *y,
                    const double *X, const uint8_t *observed) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (!y || !X) return fail(BA_E_INVALID, "null argument");
   if (T <= 0 || p <= 0) return fail(BA_E_INVALID, "T and p must be positive");
   // The regression model's fixed XtX (and the initial Xty, ...) are over the
@@ -1413,8 +1675,7 @@ int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_gues
                           double initial_state_variance,
                           double initial_level_sigma) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   if (level_sigma_upper_limit < 0 || initial_state_variance < 0)
     return fail(BA_E_INVALID, "sigma_max must be non-negative.");
   // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
@@ -1484,8 +1745,7 @@ int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
 
 int ba_ss_set_level_sigsq(ba_engine *e, int64_t chain, double sigsq) {
   ENGINE_PROLOGUE(e);
-  e->table_ok = false;
-  e->model_ok = false;
+  MUTATE(e);
   int rc = ss_prepare(e);
   if (rc) return rc;
   const int64_t C = e->cfg.chains;

@@ -1904,8 +1904,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           P.trace_k[o] = (double)k;
         }
         if (P.rec_idx && lane < k) {  // the sweep's draw itself (recording step)
-          P.rec_idx[o * 64 + lane] = (uint16_t)gprev;
-          P.rec_beta[o * 64 + lane] = beta_valid ? beta_m : 0.0;
+          P.rec_idx[o * P.rec_cap + lane] = (uint16_t)gprev;
+          P.rec_beta[o * P.rec_cap + lane] = beta_valid ? beta_m : 0.0;
         }
       }
       ++done;

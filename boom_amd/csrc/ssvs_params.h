@@ -133,9 +133,10 @@ struct SsvsParams {
   double *trace_sigsq, *trace_logp, *trace_k;
   int32_t trace_stride;
   // optional record of every sweep's draw (nullptr = off), same slots as the
-  // traces: the included variables and their coefficients, 64 per slot
-  uint16_t *rec_idx;   // chains x trace_stride x 64
-  double *rec_beta;    // chains x trace_stride x 64
+  // traces: the included variables and their coefficients, rec_cap per slot
+  uint16_t *rec_idx;   // chains x trace_stride x rec_cap
+  double *rec_beta;    // chains x trace_stride x rec_cap
+  int32_t rec_cap;     // >= the launch's model capacity
 };
 
 // ---- LDS layout of one chain (one wavefront) --------------------------------

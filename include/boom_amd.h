@@ -122,12 +122,25 @@ int ba_get_priors(ba_engine *e, double *prior_mean, double *ominv, double *pi,
 int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
                    int32_t draw_beta, int32_t draw_sigma);
 
+/* Overrides of choices the engine otherwise makes itself; never needed for
+ * correctness (every setting produces the same chains), used by the tests to
+ * force every code path and by diagnostics:
+ *   waves_per_chain  0 = engine chooses; 1, 2 or 4 wavefronts per chain
+ *   walk_policy      -1 = default (adaptive); 0 batch mode only, 1 adaptive,
+ *                    2 always the proposal table, 3 adaptive without forked
+ *                    quiet sweeps
+ *   kcap_start       0 = default; first model capacity tried (16, 32, ...) */
+int ba_set_tuning(ba_engine *e, int32_t waves_per_chain, int32_t walk_policy,
+                  int32_t kcap_start);
+
 /* ---- chain state: GlmCoefs (beta, inc) + sigsq ----------------------------- */
 /* coef().set_inc / set_Beta / set_sigsq.  gamma: p bytes (0/1), beta: p
  * doubles (may be NULL = zeros).  chain = -1 sets every chain. */
 int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
                  const double *beta, double sigsq);
-/* coef().inc() / Beta() / sigsq() of one chain (local index) */
+/* coef().inc() / Beta() / sigsq() of one chain (local index).  While
+ * ba_draw_next() is serving a look-ahead batch these are the draw being served,
+ * not the end of the batch. */
 int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
                  double *sigsq);
 /* all chains at once: gamma chains x p, beta chains x p, sigsq chains */
@@ -136,7 +149,8 @@ int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq);
  * current state of one chain (local index): log p(gamma) + log p(sigma^2) +
  * log N(beta_gamma | b_gamma, sigma^2 Omega_gamma) */
 int ba_logpri(ba_engine *e, int64_t chain, double *out);
-/* PosteriorSampler::set_seed: re-keys every chain's stream, position 0 */
+/* PosteriorSampler::set_seed: re-keys the streams of every sampler of every
+ * chain (regression, SpikeSlab, level, state), all at position 0 */
 int ba_seed(ba_engine *e, uint64_t seed);
 
 /* ---- the hot path ---------------------------------------------------------- */
@@ -146,7 +160,26 @@ int ba_seed(ba_engine *e, uint64_t seed);
 int ba_sweep(ba_engine *e, int32_t nsweeps);
 /* wait for outstanding work and report the first chain error, if any */
 int ba_sync(ba_engine *e);
-/* log_model_prob(gamma) for ngamma inclusion vectors (BregVsSampler.cpp:216-239) */
+/* The reference's calling pattern is ONE draw() per MCMC iteration with the
+ * caller reading the parameters in between (spike_slab_wrapper.cc:233-242,
+ * spikeslab.py:191-207; Model::sample_posterior, Models/ModelTypes.hpp:93).
+ * ba_draw_next() keeps that pattern at the long-launch rate: every `lookahead`
+ * calls it launches `lookahead` sweeps of EVERY chain with the draws recorded
+ * on the device, the calls in between only move a cursor, and
+ * ba_get_state / ba_get_states / ba_logpri return the draw under the cursor --
+ * bitwise what `ba_sweep(e, 1)` per iteration leaves there.  Any other call
+ * that touches the engine (data, priors, options, state, seed, ba_sweep) first
+ * puts the chains back where the caller has seen them (the batch's start state
+ * replayed up to the cursor), so the sequence of draws never depends on the
+ * look-ahead length.  Running summaries count launched sweeps, i.e. they run
+ * ahead of the cursor by up to lookahead - 1 draws.
+ * ba_set_lookahead(e, n): n >= 1 (1 = one launch per call; replaces any
+ * ba_enable_traces / ba_enable_draws setting). */
+int ba_set_lookahead(ba_engine *e, int32_t lookahead);
+int ba_draw_next(ba_engine *e);
+/* log_model_prob(gamma) for ngamma inclusion vectors (BregVsSampler.cpp:216-239)
+ * on the regression model's sufficient statistics; BA_E_STATE once state-space
+ * data are set (there they are per chain and move every sweep) */
 int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
                       double *out);
 
@@ -197,11 +230,17 @@ int ba_get_traces(ba_engine *e, int32_t nsweeps, double *sigsq, double *logp,
  * recording enabled a ba_sweep(n) call keeps the n draws of every chain on the
  * device (traces included), so a `for (i < niter) sample_posterior(); record()`
  * loop becomes one launch and niter reads.  ba_get_draws expands one chain's
- * draws: gamma nsweeps x p, beta nsweeps x p (zeros outside gamma), sigsq
- * nsweeps; any pointer may be NULL. */
+ * (local index, as everywhere) draws: gamma nsweeps x p, beta nsweeps x p
+ * (zeros outside gamma), sigsq nsweeps; any pointer may be NULL. */
 int ba_enable_draws(ba_engine *e, int32_t max_sweeps);
 int ba_get_draws(ba_engine *e, int64_t chain, int32_t nsweeps, uint8_t *gamma,
                  double *beta, double *sigsq);
+
+/* the recorded coefficient paths of chosen variables (ESS of the largest
+ * coefficients): out is chains x nvars x nsweeps, 0 where a variable was
+ * excluded */
+int ba_get_coefficient_traces(ba_engine *e, int32_t nsweeps, int32_t nvars,
+                              const int32_t *vars, double *out);
 
 /* the engine's HIP stream (hipStream_t) for callers that order their own work */
 void *ba_stream(ba_engine *e);

@@ -538,6 +538,9 @@ struct bo_ssvs {
   int *g;
   double *w1, *w2, *w3, *M1, *M2;
   double min_margin;
+  /* 1: the read-only inputs (sufficient statistics, priors, correlation map)
+   * belong to another bo_ssvs (bo_ssvs_clone_shared, many-chain baseline) */
+  int shared;
 };
 
 static void *xcalloc(size_t n, size_t sz) {
@@ -611,10 +614,14 @@ bo_ssvs *bo_ssvs_create(int p, const double *xtx, const double *xty,
 
 void bo_ssvs_destroy(bo_ssvs *s) {
   if (!s) return;
-  free(s->xtx); free(s->xty); free(s->xsum); free(s->b); free(s->ominv);
-  free(s->pi); free(s->logpi); free(s->logcpi); free(s->gamma); free(s->beta);
-  free(s->indx); free(s->pm); free(s->V); free(s->cm_start); free(s->cm_idx);
-  free(s->cm_cor); free(s->g); free(s->w1); free(s->w2); free(s->w3);
+  if (!s->shared) {
+    free(s->xtx); free(s->xty); free(s->xsum); free(s->b); free(s->ominv);
+    free(s->pi); free(s->logpi); free(s->logcpi);
+    free(s->cm_start); free(s->cm_idx); free(s->cm_cor);
+  }
+  free(s->gamma); free(s->beta);
+  free(s->indx); free(s->pm); free(s->V);
+  free(s->g); free(s->w1); free(s->w2); free(s->w3);
   free(s->M1); free(s->M2);
   free(s);
 }
@@ -1096,18 +1103,53 @@ typedef struct {
   uint8_t *gamma;
   double *beta, *sigsq;
   int status;
+  const bo_ssvs *shared_template;
 } chain_job;
+
+/* A second sampler on the SAME read-only inputs as `t` (pointers shared: X'X,
+ * Omega^{-1}, the prior vectors and the already filled correlation map), with
+ * its own state, stream and workspace -- what running many chains of one
+ * model on a multi-core host looks like.  `t` must outlive the clone and its
+ * correlation map must be filled and left alone. */
+static bo_ssvs *bo_ssvs_clone_shared(const bo_ssvs *t) {
+  bo_ssvs *s = (bo_ssvs *)xcalloc(1, sizeof(bo_ssvs));
+  const int p = t->p;
+  const size_t pp = (size_t)p * p;
+  *s = *t;
+  s->shared = 1;
+  s->gamma = (uint8_t *)xcalloc(p, 1);
+  s->beta = (double *)xcalloc(p, sizeof(double));
+  s->sigsq = 1.0;
+  s->indx = (int *)xcalloc(p, sizeof(int));
+  for (int j = 0; j < p; ++j) s->indx[j] = j;
+  s->pm = (double *)xcalloc(p, sizeof(double));
+  s->V = (double *)xcalloc(pp, sizeof(double));
+  s->DF = BO_NEG_INF;
+  s->SS = BO_NEG_INF;
+  s->k = 0;
+  s->failure_count = 0;
+  s->g = (int *)xcalloc(p, sizeof(int));
+  s->w1 = (double *)xcalloc(p, sizeof(double));
+  s->w2 = (double *)xcalloc(p, sizeof(double));
+  s->w3 = (double *)xcalloc(p, sizeof(double));
+  s->M1 = (double *)xcalloc(pp, sizeof(double));
+  s->M2 = (double *)xcalloc(pp, sizeof(double));
+  s->min_margin = INFINITY;
+  return s;
+}
 
 static void *chain_worker(void *arg) {
   chain_job *j = (chain_job *)arg;
+  /* one sampler object per thread, re-pointed at chain after chain: the
+   * workspace stays hot and nothing read-only is copied */
+  bo_ssvs *s = bo_ssvs_clone_shared(j->shared_template);
   for (int c = j->chain_lo; c < j->chain_hi; ++c) {
-    bo_ssvs *s = bo_ssvs_create(j->p, j->xtx, j->xty, j->yty, j->n, j->sumy,
-                                j->xsum, j->prior_mean, j->ominv, j->prior_df,
-                                j->sigma_guess, j->pi);
-    bo_ssvs_set_options(s, j->max_model_size, j->sigma_upper_limit,
-                        j->swap_threshold, j->max_flips, 1, 1);
     bo_ssvs_set_state(s, j->gamma + (size_t)c * j->p, j->beta + (size_t)c * j->p,
                       j->sigsq[c]);
+    for (int i = 0; i < j->p; ++i) s->indx[i] = i;
+    s->DF = BO_NEG_INF;
+    s->SS = BO_NEG_INF;
+    s->failure_count = 0;
     bo_rng_seed_philox(&s->rng, j->seed, (uint32_t)c, 0, 0);
     for (int i = 0; i < j->nsweeps; ++i) {
       int st = ssvs_draw(s);
@@ -1115,8 +1157,8 @@ static void *chain_worker(void *arg) {
     }
     bo_ssvs_get_state(s, j->gamma + (size_t)c * j->p, j->beta + (size_t)c * j->p,
                       &j->sigsq[c]);
-    bo_ssvs_destroy(s);
   }
+  bo_ssvs_destroy(s);
   return NULL;
 }
 
@@ -1130,6 +1172,12 @@ int bo_ssvs_run_chains(int p, const double *xtx, const double *xty, double yty,
                        double *beta, double *sigsq) {
   if (nthreads < 1) nthreads = 1;
   if (nthreads > chains) nthreads = chains;
+  /* the read-only inputs and the correlation map exist once */
+  bo_ssvs *tmpl = bo_ssvs_create(p, xtx, xty, yty, n, sumy, xsum, prior_mean, ominv,
+                                 prior_df, sigma_guess, pi);
+  bo_ssvs_set_options(tmpl, max_model_size, sigma_upper_limit, swap_threshold,
+                      max_flips, 1, 1);
+  if (swap_threshold < 1.0) correlation_map_fill(tmpl);
   pthread_t *th = (pthread_t *)xcalloc(nthreads, sizeof(pthread_t));
   chain_job *jobs = (chain_job *)xcalloc(nthreads, sizeof(chain_job));
   for (int t = 0; t < nthreads; ++t) {
@@ -1143,6 +1191,7 @@ int bo_ssvs_run_chains(int p, const double *xtx, const double *xty, double yty,
     j->chain_lo = (int)((int64_t)chains * t / nthreads);
     j->chain_hi = (int)((int64_t)chains * (t + 1) / nthreads);
     j->gamma = gamma; j->beta = beta; j->sigsq = sigsq;
+    j->shared_template = tmpl;
     pthread_create(&th[t], NULL, chain_worker, j);
   }
   int status = 0;
@@ -1152,6 +1201,7 @@ int bo_ssvs_run_chains(int p, const double *xtx, const double *xty, double yty,
   }
   free(th);
   free(jobs);
+  bo_ssvs_destroy(tmpl);
   return status;
 }
 

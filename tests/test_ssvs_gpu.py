@@ -24,9 +24,11 @@ def relerr(a, b, floor=1e-3):
 
 
 def make_engine(chains, seed, suf=None, X=None, y=None, prior=None, opts=None,
-                g0=None, **kw):
+                g0=None, tuning=None, **kw):
     import boom_amd
     eng = boom_amd.Engine(chains, seed=seed, **kw)
+    if tuning:
+        eng.set_tuning(**tuning)
     if X is not None:
         eng.build_suf_from_xy(X, y)
     else:
@@ -287,13 +289,15 @@ def test_error_reporting_matches_reference_messages():
     eng3 = make_engine(2, 1, suf=suf, prior=prior, g0=g0, chain_offset=10)
     eng3.sweep(3)
     with pytest.raises(boom_amd.BoomAmdError):
-        eng3.get_draws(10, 3)
+        eng3.get_draws(0, 3)
     eng3.enable_draws(4)
     eng3.sweep(4)
-    gam, beta, sig = eng3.get_draws(11, 4)
+    gam, beta, sig = eng3.get_draws(1, 4)   # local index, like get_state
     assert gam.shape == (4, 5) and np.all(sig > 0) and np.all(beta[gam == 0] == 0)
+    g1, b1, s1 = eng3.get_state(1)
+    assert np.array_equal(gam[3], g1) and np.array_equal(beta[3], b1) and sig[3] == s1
     with pytest.raises(boom_amd.BoomAmdError):
-        eng3.get_draws(3, 4)       # global chain id outside [10, 12)
+        eng3.get_draws(2, 4)       # index outside [0, 2)
     with pytest.raises(boom_amd.BoomAmdError):
         eng3.sweep(5)              # more sweeps than record slots
 

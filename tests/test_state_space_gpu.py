@@ -109,7 +109,7 @@ def test_config3_shape_properties():
     assert 0.1 < np.sqrt(sig).mean() < 0.5   # truth 0.2; 30 sweeps from a cold start
 
 
-def test_capacity_escalation_in_stream(monkeypatch):
+def test_capacity_escalation_in_stream():
     """A chain that outgrows the launch capacity in state-space mode sits out
     the rest of the call and is caught up, one (SSVS, Kalman) pair at a time,
     with a larger capacity: the draws must be those of a run whose capacity was
@@ -120,11 +120,9 @@ def test_capacity_escalation_in_stream(monkeypatch):
     prior, ss, sig_up = bsts_priors(X, y, nsig)
 
     def run(hint, start):
-        if start:
-            monkeypatch.setenv("BOOM_AMD_KCAP_START", str(start))
-        else:
-            monkeypatch.delenv("BOOM_AMD_KCAP_START", raising=False)
         eng = boom_amd.Engine(6, seed=9, max_model_size_hint=hint)
+        if start:
+            eng.set_tuning(kcap_start=start)
         eng.ss_set_data(y, X, None)
         eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"],
                        prior["sigma_guess"], sigma_upper_limit=sig_up)

@@ -43,17 +43,12 @@ def _run(case, waves, policy, launches, chains=12, seed=77):
     p = len(suf["xty"])
     g0 = np.zeros(p, np.uint8)
     g0[0] = 1
-    os.environ["BOOM_AMD_WAVES"] = str(waves)
-    os.environ["BOOM_AMD_SCAN"] = str(policy)
-    try:
-        eng = make_engine(chains, seed, suf=suf, prior=prior, opts=opts, g0=g0)
-        for n in launches:
-            eng.sweep(n)
-        gam, beta, sig = eng.get_states()
-        sm = eng.get_summaries()
-    finally:
-        os.environ.pop("BOOM_AMD_WAVES", None)
-        os.environ.pop("BOOM_AMD_SCAN", None)
+    eng = make_engine(chains, seed, suf=suf, prior=prior, opts=opts, g0=g0,
+                      tuning=dict(waves_per_chain=waves, walk_policy=policy))
+    for n in launches:
+        eng.sweep(n)
+    gam, beta, sig = eng.get_states()
+    sm = eng.get_summaries()
     return gam, beta, sig, sm
 
 
@@ -83,26 +78,20 @@ def test_tables_are_dropped_when_anything_else_is_called():
     g0[0] = 1
     X2, y2, _ = regression_data(600, 130, 7, seed=99)
     suf2 = suf_from_xy(X2, y2)
-    os.environ["BOOM_AMD_SCAN"] = "2"
-    try:
-        a = make_engine(8, 5, suf=suf, prior=prior, opts=opts, g0=g0)
-        a.sweep(30)
-        a.upload_suf(suf2["xtx"], suf2["xty"], suf2["yty"], suf2["n"],
-                     suf2["sumy"] / suf2["n"], suf2["xsum"] / suf2["n"])
-        a.sweep(30)
-        ga, ba_, sa = a.get_states()
-    finally:
-        os.environ.pop("BOOM_AMD_SCAN", None)
-    os.environ["BOOM_AMD_SCAN"] = "0"
-    try:
-        b = make_engine(8, 5, suf=suf, prior=prior, opts=opts, g0=g0)
-        b.sweep(30)
-        b.upload_suf(suf2["xtx"], suf2["xty"], suf2["yty"], suf2["n"],
-                     suf2["sumy"] / suf2["n"], suf2["xsum"] / suf2["n"])
-        b.sweep(30)
-        gb, bb, sb = b.get_states()
-    finally:
-        os.environ.pop("BOOM_AMD_SCAN", None)
+    a = make_engine(8, 5, suf=suf, prior=prior, opts=opts, g0=g0,
+                    tuning=dict(walk_policy=2))
+    a.sweep(30)
+    a.upload_suf(suf2["xtx"], suf2["xty"], suf2["yty"], suf2["n"],
+                 suf2["sumy"] / suf2["n"], suf2["xsum"] / suf2["n"])
+    a.sweep(30)
+    ga, ba_, sa = a.get_states()
+    b = make_engine(8, 5, suf=suf, prior=prior, opts=opts, g0=g0,
+                    tuning=dict(walk_policy=0))
+    b.sweep(30)
+    b.upload_suf(suf2["xtx"], suf2["xty"], suf2["yty"], suf2["n"],
+                 suf2["sumy"] / suf2["n"], suf2["xsum"] / suf2["n"])
+    b.sweep(30)
+    gb, bb, sb = b.get_states()
     assert np.array_equal(ga, gb) and np.array_equal(ba_, bb) and np.array_equal(sa, sb)
 
 
@@ -118,16 +107,11 @@ def test_every_draw_of_one_long_launch_matches_the_oracle(oracle, case, waves, p
     g0 = np.zeros(p, np.uint8)
     g0[0] = 1
     chains, seed, nsw = 6, 2024, 80
-    os.environ["BOOM_AMD_WAVES"] = str(waves)
-    os.environ["BOOM_AMD_SCAN"] = str(policy)
-    try:
-        eng = make_engine(chains, seed, suf=suf, prior=prior, opts=opts, g0=g0)
-        eng.enable_draws(nsw)
-        eng.sweep(nsw)
-        draws = [eng.get_draws(c, nsw) for c in range(chains)]
-    finally:
-        os.environ.pop("BOOM_AMD_WAVES", None)
-        os.environ.pop("BOOM_AMD_SCAN", None)
+    eng = make_engine(chains, seed, suf=suf, prior=prior, opts=opts, g0=g0,
+                      tuning=dict(waves_per_chain=waves, walk_policy=policy))
+    eng.enable_draws(nsw)
+    eng.sweep(nsw)
+    draws = [eng.get_draws(c, nsw) for c in range(chains)]
     for c in range(chains):
         o = oracle.ssvs_run(suf, prior, opts, ("philox", seed, c), g0, nsw)
         assert o["status"] == 0

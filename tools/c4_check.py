@@ -27,7 +27,7 @@ gam, beta, sig = eng.get_states()
 sm = eng.get_summaries()
 if "phase_cycles" in sm and sm["phase_cycles"].sum() > 0:
     names = ["shuffle uniforms", "shuffle serial", "refactor", "proposal batches", "swap", "sigma", "beta", "rest"]
-    print("  accepts/sweep %.3f; per chain: mean %.0f cycles/sweep, slowest %.0f" % (sm["accepts"] / sm["sweeps"], sm["phase_cycles"].sum() / sm["sweeps"], sm["slowest_chain_cycles"] / 20))
+    print("  accepts/sweep %.3f; per chain: mean %.0f cycles/sweep, slowest %.0f" % (sm["accepts"] / sm["sweeps"], sm["phase_cycles"].sum() / sm["sweeps"], sm["slot_hits"] / 20))
     for nm, v in zip(names, sm["phase_cycles"]):
         print("  %-18s %10.0f cycles/sweep" % (nm, v / sm["sweeps"]))
 print("C4 shard: %.1f us per sweep-round, %.3g sweeps/s, kbar %.2f, signals in %.3f, nulls in %.5f, sigma %.3f"

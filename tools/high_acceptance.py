@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: a posterior with weak signals (variables come and go three times as
 often as on the C2 workload, mean model size 24) -- adaptive walking vs
-BOOM_AMD_SCAN=0 (batch mode only)."""
+WALK=0 (ba_set_tuning walk_policy: batch mode only)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,7 @@ from cases import regression_data, spike_slab_prior
 n, p, nsig, chains = 2000, 512, 24, 1024
 X, y, _ = regression_data(n, p, nsig, seed=5, noise_sd=6.0)   # weak signals: many variables come and go
 eng = boom_amd.Engine(chains, seed=1)
+eng.set_tuning(walk_policy=int(os.environ.get("WALK", "-1")))
 eng.build_suf_from_xy(X, y)
 s = eng.get_suf()
 suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"], sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])

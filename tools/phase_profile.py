@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUBN = os.environ.get("SUBSTAMPS", "0")
 SUB = SUBN != "0"
-os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "boom_amd", {"0": "libboomamd_stamps.so", "1": "libboomamd_stamps2.so", "2": "libboomamd_stamps3.so", "3": "libboomamd_stamps4.so"}[SUBN])
+os.environ["BOOM_AMD_LIB"] = os.path.join(ROOT, "tools", "build", {"0": "libboomamd_stamps.so", "1": "libboomamd_stamps2.so", "2": "libboomamd_stamps3.so", "3": "libboomamd_stamps4.so"}[SUBN])
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import time
@@ -19,6 +19,7 @@ n, p, nsig = 10000, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 16
 chains = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 X, y, _ = regression_data(n, p, nsig, seed=8675309)
 eng = boom_amd.Engine(chains, seed=1, max_model_size_hint=int(os.environ.get('KCAP_HINT', '0')))
+eng.set_tuning(waves_per_chain=int(os.environ.get("WAVES", "0")), walk_policy=int(os.environ.get("WALK", "-1")))
 eng.build_suf_from_xy(X, y)
 s = eng.get_suf()
 suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"],
@@ -51,8 +52,8 @@ elif SUB:
              "batch: A gather", "batch: A solve", "batch: epilogue", "outside batches"]
 tot = ph.sum()
 if not SUB:
-    print("  per chain: mean %.0f cycles, slowest %.0f cycles (%.2fx)" % (tot / chains, sm["slowest_chain_cycles"], sm["slowest_chain_cycles"] * chains / tot))
-print("waves=%s hint=%s" % (os.environ.get("BOOM_AMD_WAVES","auto"), os.environ.get("KCAP_HINT","0")), end=" "); print("signals %d chains %d: %.1f us per sweep-round, kbar %.2f, accepts/sweep %.3f, proposals/sweep %.1f"
+    print("  per chain: mean %.0f cycles, slowest %.0f cycles (%.2fx)" % (tot / chains, sm["slot_hits"], sm["slot_hits"] * chains / tot))
+print("waves=%s hint=%s" % (os.environ.get("WAVES","auto"), os.environ.get("KCAP_HINT","0")), end=" "); print("signals %d chains %d: %.1f us per sweep-round, kbar %.2f, accepts/sweep %.3f, proposals/sweep %.1f"
       % (nsig, chains, dt / (NSW * NL) * 1e6, sm["k_sum"] / sm["sweeps"], sm["accepts"] / sm["sweeps"],
          sm["proposals"] / sm["sweeps"]))
 for nm, v in zip(names, ph):

@@ -11,8 +11,8 @@ n, p, nsig, chains = 400, int(os.environ.get("P", "40")), 5, 8
 X, y, _ = regression_data(n, p, nsig, seed=3)
 engs = []
 for w in ("1", "2"):
-    os.environ["BOOM_AMD_WAVES"] = w
     eng = boom_amd.Engine(chains, seed=11)
+    eng.set_tuning(waves_per_chain=int(w))
     eng.build_suf_from_xy(X, y)
     s = eng.get_suf()
     suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"], sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])
@@ -24,7 +24,6 @@ for w in ("1", "2"):
 for it in range(30):
     out = []
     for w, eng in zip(("1", "2"), engs):
-        os.environ["BOOM_AMD_WAVES"] = w
         eng.sweep(1)
         out.append(eng.get_states())
     g_same = np.array_equal(out[0][0], out[1][0])
