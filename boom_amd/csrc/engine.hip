@@ -20,6 +20,8 @@
 namespace boom_amd {
 // ssvs_kernel.hip
 hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P, int nsweeps);
+// ssvs_big_kernel.hip
+hipError_t launch_ssvs_big(hipStream_t stream, const SsvsParams &P, int nsweeps);
 hipError_t launch_ssvs_logp(hipStream_t stream, const SsvsParams &P,
                             const uint8_t *gammas, int ngamma, double *out,
                             int *status_out);
@@ -95,8 +97,8 @@ const char *status_message(int st) {
       return "Found a zero (or negative) forecast variance!";
     case CHAIN_MODEL_TOO_LARGE:
       return "A chain's model size exceeded the engine's working capacity "
-             "(create the engine with a larger max_model_size_hint or fewer "
-             "chains per device).";
+             "(a pinned max_model_size_hint, or more than 1024 variables in "
+             "the model).";
     default:
       return "unknown chain status";
   }
@@ -179,6 +181,11 @@ struct ba_engine {
   DevBuf<int32_t> snap_fail;
   DevBuf<uint32_t> snap_inc;
   int rec_cap = 64;  // variables per recorded draw (ba_enable_draws)
+  // HBM-resident path for models of more than 64 variables (ssvs_big_kernel.hip):
+  // active once a chain has outgrown the LDS kernel, capacity grows on demand
+  bool big_active = false;
+  int big_kcap = 0;
+  DevBuf<double> dbig_model, dbig_xs;
   // ba_set_tuning overrides (0 / -1: the engine chooses)
   int tune_waves = 0, tune_walk_policy = -1, tune_kcap_start = 0;
   // SpikeSlabSampler (sigma^2 given) mode
@@ -448,6 +455,10 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.run_limit = 0;
   P.ran = nullptr;
   P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
+  P.big_kcap = e->big_kcap;
+  P.big_model = e->dbig_model.ptr;
+  P.big_model_stride = e->big_kcap > 0 ? (int64_t)ssvs_scalar_layout(e->big_kcap).total : 0;
+  P.big_xs = e->dbig_xs.ptr;
   P.seed_lo = (uint32_t)e->seed;
   P.seed_hi = (uint32_t)(e->seed >> 32);
   P.stream = 0;
@@ -476,6 +487,70 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.rec_cap = e->rec_cap;
 }
 
+// ---- models of more than 64 variables: the HBM-resident kernel -------------------
+enum { BIG_KCAP_MAX = 1024 };
+// largest capacity that can ever be needed (0: the LDS kernel covers everything)
+int big_limit(const ba_engine &e) {
+  int64_t need = e.p;
+  if (e.max_model_size >= 0) need = std::min<int64_t>(need, e.max_model_size);
+  if (need <= 64) return 0;
+  return (int)std::min<int64_t>(BIG_KCAP_MAX, ((need + 63) / 64) * 64);
+}
+int ensure_big_buffers(ba_engine *e) {
+  const size_t C = (size_t)e->cfg.chains, kc = (size_t)e->big_kcap;
+  const size_t want_model = 2 * C * ssvs_scalar_layout(e->big_kcap).total;
+  const size_t want_xs = C * 2 * kc * 64;
+  if (e->dbig_model.count != want_model) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(e->dbig_model.resize(want_model));
+    HIP_TRY(e->dbig_xs.resize(want_xs));
+  }
+  const SsvsBigLds lay = ssvs_big_lds_layout(e->p, e->big_kcap);
+  if (lay.total > e->lds_per_cu)
+    return fail(BA_E_MODEL_TOO_LARGE, "the model does not fit the large-model kernel's LDS working set");
+  // the draw record holds rec_cap variables per draw: widen it (keeping what is recorded)
+  if (e->drec_idx.count > 0 && e->rec_cap < e->big_kcap) {
+    const size_t rows = C * (size_t)e->trace_stride, oc = (size_t)e->rec_cap;
+    DevBuf<uint16_t> ni;
+    DevBuf<double> nb;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(ni.resize(rows * kc));
+    HIP_TRY(nb.resize(rows * kc));
+    HIP_TRY(hipMemcpy2DAsync(ni.ptr, kc * 2, e->drec_idx.ptr, oc * 2, oc * 2, rows, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemcpy2DAsync(nb.ptr, kc * 8, e->drec_beta.ptr, oc * 8, oc * 8, rows, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::swap(ni.ptr, e->drec_idx.ptr);
+    std::swap(ni.count, e->drec_idx.count);
+    std::swap(nb.ptr, e->drec_beta.ptr);
+    std::swap(nb.count, e->drec_beta.count);
+    e->rec_cap = e->big_kcap;
+  }
+  return BA_OK;
+}
+// one launch of the sweep: the LDS kernel for every chain it can hold, and --
+// once any chain has outgrown it -- the HBM-resident kernel right behind it for
+// the chains the first one parked (status CHAIN_MODEL_TOO_LARGE)
+hipError_t launch_sweeps(ba_engine *e, const SsvsParams &P, int nsweeps) {
+  hipError_t err = launch_ssvs_sweep(e->stream, P, nsweeps);
+  if (err == hipSuccess && e->big_active) err = launch_ssvs_big(e->stream, P, 0);
+  return err;
+}
+// the chains parked by the last launches need (more) large-model capacity;
+// returns 1 when nothing more can be done (the status stays an error)
+int grow_big(ba_engine *e, int *stuck) {
+  *stuck = 0;
+  const int bl = big_limit(*e);
+  if (bl == 0) { *stuck = 1; return BA_OK; }
+  if (!e->big_active) {
+    e->big_active = true;
+    if (e->big_kcap == 0) e->big_kcap = std::min(bl, 128);
+  } else {
+    if (e->big_kcap >= bl) { *stuck = 1; return BA_OK; }
+    e->big_kcap = std::min(bl, e->big_kcap * 2);
+  }
+  return ensure_big_buffers(e);
+}
+
 // Resume chains that outgrew the capacity of the launch they were in, with the
 // next larger capacity; then follow the largest model size seen.
 int escalate(ba_engine *e, std::vector<int32_t> &st) {
@@ -484,7 +559,20 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
     bool any = false;
     for (size_t c = 0; c < C; ++c) any = any || (st[c] == CHAIN_MODEL_TOO_LARGE);
     if (!any) return BA_OK;
-    if (e->cfg.max_model_size_hint > 0 || e->kcap >= cap_limit(*e)) return BA_OK;  // stays an error
+    if (e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
+    if (e->kcap >= cap_limit(*e)) {
+      // beyond the LDS kernel: the parked chains go to the HBM-resident one
+      int stuck = 0;
+      int rc = grow_big(e, &stuck);
+      if (rc) return rc;
+      if (stuck) return BA_OK;
+      SsvsParams P;
+      fill_params(e, P);
+      HIP_TRY(launch_ssvs_big(e->stream, P, 0));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+      continue;
+    }
     e->kcap += 16;
     e->waves = choose_waves(*e, e->kcap);
     for (size_t c = 0; c < C; ++c)
@@ -492,7 +580,7 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
     HIP_TRY(hipMemcpyAsync(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice, e->stream));
     SsvsParams P;
     fill_params(e, P);
-    HIP_TRY(launch_ssvs_sweep(e->stream, P, 0));   // runs the sweeps still owed
+    HIP_TRY(launch_sweeps(e, P, 0));   // runs the sweeps still owed
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
   }
@@ -543,15 +631,23 @@ int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
     bool any = false;
     for (size_t c = 0; c < C; ++c) any = any || (st[c] == CHAIN_MODEL_TOO_LARGE);
     if (!any) return BA_OK;
-    if (e->cfg.max_model_size_hint > 0 || e->kcap >= cap_limit(*e)) return BA_OK;  // stays an error
-    e->kcap += 16;
-    e->waves = choose_waves(*e, e->kcap);
+    if (e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
+    const bool to_big = e->kcap >= cap_limit(*e);
+    if (to_big) {
+      int stuck = 0;
+      int rc = grow_big(e, &stuck);
+      if (rc) return rc;
+      if (stuck) return BA_OK;
+    } else {
+      e->kcap += 16;
+      e->waves = choose_waves(*e, e->kcap);
+    }
     std::vector<int32_t> todo(C);
     HIP_TRY(hipMemcpy(todo.data(), e->dtodo.ptr, C * 4, hipMemcpyDeviceToHost));
     int rounds = 0;
     for (size_t c = 0; c < C; ++c) {
       if (st[c] == CHAIN_MODEL_TOO_LARGE) {
-        st[c] = CHAIN_OK;
+        if (!to_big) st[c] = CHAIN_OK;   // (the large-model kernel takes parked chains as they are)
         rounds = std::max(rounds, (int)todo[c]);
       }
     }
@@ -564,7 +660,7 @@ int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
     fill_ss_params(e, S);
     S.only_ran = e->dran.ptr;
     for (int r = 0; r < rounds; ++r) {
-      HIP_TRY(launch_ssvs_sweep(e->stream, P, 0));
+      HIP_TRY(launch_sweeps(e, P, 0));
       HIP_TRY(launch_kalman_simsmooth(e->stream, S, 1));
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -591,6 +687,7 @@ int check_chain_status(ba_engine *e) {
         e->kcap = want;
         e->waves = choose_waves(*e, e->kcap);
       }
+      if (maxk > 0 && maxk <= 56) e->big_active = false;  // every chain is back in the LDS kernel
     }
   }
   for (size_t c = 0; c < C; ++c) {
@@ -1231,7 +1328,7 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
     return fail(BA_E_INVALID, "problem does not fit the LDS working set");
   if (record && e->trace_stride > 0)  // traces are those of the last ba_sweep call
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
-  HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
+  HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
   e->table_ok = true;  // until anything but another ba_sweep touches the engine
   e->model_ok = true;
   return BA_OK;
@@ -1390,7 +1487,7 @@ int ba_enable_draws(ba_engine *e, int32_t max_sweeps) {
   int rc = ba_enable_traces(e, max_sweeps);
   if (rc) return rc;
   const size_t C = (size_t)e->cfg.chains;
-  e->rec_cap = std::max(64, e->kcap);
+  e->rec_cap = std::max(64, e->big_active ? e->big_kcap : 0);
   HIP_TRY(e->drec_idx.resize(C * max_sweeps * e->rec_cap));
   HIP_TRY(e->drec_beta.resize(C * max_sweeps * e->rec_cap));
   return BA_OK;
@@ -1588,7 +1685,7 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   fill_params(e, P);
   if (e->trace_stride > 0)
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
-  HIP_TRY(launch_ssvs_sweep(e->stream, P, (int)nsweeps));
+  HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
   return BA_OK;
 }
 
@@ -1718,7 +1815,7 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
     e->ss_initialized = true;
   }
   for (int i = 0; i < nsweeps; ++i) {
-    HIP_TRY(launch_ssvs_sweep(e->stream, P, 1));     // observation model
+    HIP_TRY(launch_sweeps(e, P, 1));                  // observation model
     HIP_TRY(launch_kalman_simsmooth(e->stream, S, 1));  // level model, state
     P.model_keep = 1;  // from here on the chains' model blocks are their own last launch's
     e->model_ok = true;

@@ -1,0 +1,1097 @@
+// SSVS Gibbs sweep for chains whose model has outgrown the LDS-resident kernel
+// (ssvs_kernel.hip: at most 64 included variables).  The reference has no size
+// limit -- BregVsSampler::set_reg_post_params factors whatever k x k system the
+// current model asks for (Models/Glm/PosteriorSamplers/BregVsSampler.cpp:395-426)
+// -- so neither has the engine: a chain that stops with
+// CHAIN_MODEL_TOO_LARGE in the LDS kernel is picked up here, with its factors
+// resident in HBM (the chain's model block, ssvs_scalar_layout(big_kcap)) and
+// streamed through the scalar cache.
+//
+// Same Markov chain, same stream positions, same table / two-slot scheme as the
+// LDS kernel (see its header comment); what differs is where things live and
+// how the k-sized pieces are cut:
+//   * per-lane triangular solves (one proposal, or one row of a factor, per
+//     lane) run over PANELS of 64 rows: the panel being solved sits in 64
+//     registers, finished panels are parked in a per-wave HBM scratch
+//     (coalesced [row][lane] layout) and re-read 8 values at a time while the
+//     factor's 8 x 8 blocks arrive as SGPR operands (s_load);
+//   * a model is (re)built by the bordering method: row i of chol(M_g) is the
+//     solution of L[0:i,0:i] x = M_g[0:i, i], i.e. the SAME per-lane solve, 64
+//     rows at a time against the finished panels, followed by the 64 x 64
+//     diagonal tile (trailing update with the wave's own parked rows through
+//     the scalar cache, then a lane = row Cholesky in LDS);
+//   * the back substitution of the beta draw works tile by tile on coalesced
+//     reads of the factor.
+// One workgroup of two wavefronts per chain: the master (wave 0) runs the
+// sweep, wave 1 shares the table fills and the shuffle uniforms.  No forked
+// quiet sweeps here: the chains that need this kernel are few and their cost
+// is the O(p k^2) table fill after every accepted flip.
+#include "ssvs_device.h"
+
+namespace boom_amd {
+
+namespace {
+
+enum : int { BCMD_EXIT = 0, BCMD_EVAL = 1, BCMD_UNIF = 2 };
+
+// offset (doubles) of 8 x 8 block (I, J), J <= I, of a block-packed factor
+__device__ __forceinline__ int blk_off(int I, int J) { return ((I * (I + 1)) / 2 + J) * 64; }
+
+// make this wave's global stores visible to its own scalar loads and re-derive
+// a constant-address-space pointer that no load can be hoisted above
+__device__ __forceinline__ c_f64 *scalar_view(const double *ptr) {
+  unsigned long long u = uni((uint64_t)ptr);  // (wave-uniform by construction; tell the compiler)
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(u) : : "memory");
+  return (c_f64 *)u;
+}
+
+// Per-lane forward substitution L x = rhs over panels of 64 rows.
+//   LB, rd   block-packed factor and reciprocal diagonal (scalar cache)
+//   k        rows of the system (rows >= k of the last 8-block are zero, rd = 0)
+//   npan     panels to solve (ceil(k / 64))
+//   xs       this wave's parking space, element (row m, lane l) at m * 64 + l
+//   rhs(I, a)  fills a[0..63] with the right-hand side of rows 64 I ..
+//   fin(I, a)  sees the solved panel
+//   park_all   also park the last panel (callers that read xs afterwards)
+template <class Rhs, class Fin>
+__device__ __forceinline__ void big_solve(c_f64 *__restrict__ LB, c_f64 *__restrict__ rd, int k,
+                                          int npan, bool park_all, double *__restrict__ xs,
+                                          int lane, Rhs rhs, Fin fin) {
+  for (int I = 0; I < npan; ++I) {
+    double a[64];
+    rhs(I, a);
+    for (int J = 0; J < I; ++J) {
+#pragma nounroll
+      for (int cb = 0; cb < 8; ++cb) {
+        double xj[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xj[c] = xs[(size_t)(J * 64 + cb * 8 + c) * 64 + lane];
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) {
+          if (I * 64 + rb * 8 < k) {
+            c_f64 *blk = LB + blk_off(I * 8 + rb, J * 8 + cb);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+              for (int c = 0; c < 8; ++c) a[rb * 8 + r] -= blk[r * 8 + c] * xj[c];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+      if (I * 64 + rb * 8 < k) {
+#pragma unroll
+        for (int cb = 0; cb < rb; ++cb) {
+          c_f64 *blk = LB + blk_off(I * 8 + rb, I * 8 + cb);
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[rb * 8 + r] -= blk[r * 8 + c] * a[cb * 8 + c];
+        }
+        c_f64 *blk = LB + blk_off(I * 8 + rb, I * 8 + rb);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          a[rb * 8 + r] = a[rb * 8 + r] * rd[I * 64 + rb * 8 + r];
+#pragma unroll
+          for (int r2 = r + 1; r2 < 8; ++r2) a[rb * 8 + r2] -= blk[r2 * 8 + r] * a[rb * 8 + r];
+        }
+      }
+    }
+    fin(I, a);
+    if (park_all || I + 1 < npan) {
+#pragma unroll
+      for (int r = 0; r < 64; ++r) xs[(size_t)(I * 64 + r) * 64 + lane] = a[r];
+    }
+  }
+}
+
+// In-place Cholesky of one 64 x 64 tile in LDS (block-packed lower triangle,
+// lane i owns row i, kk <= 64 rows): the single-matrix form of chol_blocks2.
+__device__ __forceinline__ void chol_tile(lds_f64 *T, lds_f64 *rdt, int kk, int lane,
+                                          bool *ok_out, double *logdet_sum) {
+  const int i = lane;
+  bool ok = true;
+  for (int j = 0; j < kk && ok; ++j) {
+    const bool mine = (i >= j) && (i < kk);
+    const int ii = mine ? i : j;
+    const int jb = j >> 3;
+    const int offi = ((ii >> 3) * ((ii >> 3) + 1) / 2) * 64 + (ii & 7) * 8;
+    const int offj = (jb * (jb + 1) / 2) * 64 + (j & 7) * 8;
+    double s = T[bidx(ii, j)];
+    for (int nb = 0; nb < jb; ++nb) {
+      double a[8], b[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        a[t] = T[offi + nb * 64 + t];
+        b[t] = T[offj + nb * 64 + t];
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) s -= a[t] * b[t];
+    }
+    {
+      const int rem = j & 7;
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+        if (t < rem) s -= T[offi + jb * 64 + t] * T[offj + jb * 64 + t];
+    }
+    const double d = bcast_u(s, j);
+    if (!(d > 0.0)) { ok = false; break; }
+    const double sd = sqrt(d);
+    if (i == j) {
+      T[bidx(j, j)] = sd;
+      rdt[j] = 1.0 / sd;
+    } else if (mine) {
+      T[bidx(i, j)] = s / sd;
+    }
+    wave_sync();
+  }
+  double l = 0.0;
+  const double lg = (ok && i < kk) ? log(T[bidx(i, i)]) : 0.0;
+  for (int j = 0; j < kk; ++j) l += bcast_u(lg, j);
+  *ok_out = ok;
+  *logdet_sum = l;
+}
+
+struct BigCtx {
+  int kcap;
+  SsvsScalarLayout S;
+  double *xs;        // this wave's solve parking space
+  lds_f64 *tile, *rdt, *y, *bst;
+  lds_u16 *gst;
+};
+
+// The heavy routines below are real functions (one copy of their unrolled
+// solves each): their arguments arrive in vector registers / through memory, so
+// what is wave-uniform has to be declared uniform again for the factor loads to
+// be scalar loads and the branches scalar branches.
+template <class T>
+__device__ __forceinline__ T *uni_ptr(T *q) { return (T *)uni((uint64_t)q); }
+__device__ __forceinline__ uint32_t uni_u(uint32_t x) { return (uint32_t)uni((int)x); }
+__device__ __forceinline__ void uniform_copy(Chain &c, const Chain &in, int lane) {
+  c = in;
+  c.lane = lane;
+  c.p = uni(in.p);
+  c.k = uni(in.k);
+  c.tab_lp = uni_ptr(in.tab_lp);
+  c.tab_kind = uni_ptr(in.tab_kind);
+  c.sc_store = uni_ptr(in.sc_store);
+  c.xty = uni_ptr(in.xty);
+  c.DF = uni(in.DF);
+  c.ss0q = uni(in.ss0q);
+  c.mode = uni(in.mode);
+  c.sv = uni(in.sv);
+  c.sa = uni(in.sa);
+  c.sx = uni(in.sx);
+}
+__device__ __forceinline__ void uniform_copy(BigCtx &b, const BigCtx &in) {
+  b = in;
+  b.kcap = uni(in.kcap);
+  b.xs = uni_ptr(in.xs);
+  b.S.Lv = uni_u(in.S.Lv); b.S.La = uni_u(in.S.La); b.S.rdv = uni_u(in.S.rdv); b.S.rda = uni_u(in.S.rda);
+  b.S.w = uni_u(in.S.w); b.S.bg = uni_u(in.S.bg); b.S.g = uni_u(in.S.g); b.S.scal = uni_u(in.S.scal);
+  b.S.total = uni_u(in.S.total);
+}
+__device__ __forceinline__ void uniform_copy(Model &m, const Model &in) {
+  m.logp = uni(in.logp); m.lp = uni(in.lp); m.ldv = uni(in.ldv); m.lda = uni(in.lda);
+  m.Q = uni(in.Q); m.c = uni(in.c); m.SS = uni(in.SS);
+  m.pd = uni((int)in.pd) != 0; m.bad = uni(in.bad);
+}
+// the launch parameters the heavy routines use
+struct BigP {
+  const double *V, *A, *b, *l1, *l0;
+  int64_t max_model_size;
+};
+__device__ __forceinline__ void uniform_copy(BigP &q, const SsvsParams &P) {
+  q.V = uni_ptr(P.V); q.A = uni_ptr(P.A); q.b = uni_ptr(P.b); q.l1 = uni_ptr(P.l1); q.l0 = uni_ptr(P.l0);
+  q.max_model_size = (int64_t)uni((uint64_t)P.max_model_size);
+}
+
+// the sorted index list of the model in LDS from the LDS copy of gamma
+__device__ __forceinline__ void rebuild_g(Chain &ch, int kcap) {
+  const int lane = ch.lane, p = ch.p;
+  wave_sync();
+  int k = 0;
+  for (int base = 0; base < p; base += WAVE) {
+    const int j = base + lane;
+    const int inc = (j < p) ? (int)ch.gam[j] : 0;
+    const unsigned long long mask = __ballot(inc != 0);
+    const int slot = k + __popcll(mask & ((1ull << lane) - 1ull));
+    if (inc && slot < kcap) ch.g[slot] = (uint16_t)j;
+    k += __popcll(mask);
+  }
+  ch.k = k;
+  wave_sync();
+}
+
+// Build everything about the model in ch.g (k <= kcap variables) into the HBM
+// block `dst`: both factors (unless REUSE: they are there already), b_g, g,
+// w = L_V^{-1} r, the scalars.  One wavefront.  BregVsSampler::
+// set_reg_post_params + log_model_prob (BregVsSampler.cpp:216-239, :395-484).
+// A real function (not inlined at its call sites): it is the rare path and its
+// unrolled solves are large.
+__device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &M, double *dst,
+                                               const BigCtx &bx, const bool REUSE) {
+  const int lane = ch.lane, p = ch.p, k = ch.k, kcap = bx.kcap;
+  const SsvsScalarLayout &S = bx.S;
+  M.bad = 0;
+  M.pd = true;
+  double lp;
+  const double ldv_in = M.ldv, lda_in = M.lda;
+  if (REUSE) {
+    lp = M.lp;
+  } else {
+    double part = 0.0;
+    for (int j = lane; j < p; j += WAVE) part += ch.gam[j] ? P.l1[j] : P.l0[j];
+    lp = wave_sum(part);
+    if (P.max_model_size >= 0 && k > P.max_model_size) lp = -BA_INF;
+    if (!(lp > -BA_INF)) lp = -BA_INF;
+  }
+  M.lp = lp;
+  M.ldv = M.lda = M.Q = M.c = 0.0;
+  M.SS = ch.ss0q;
+  if (k == 0) {
+    M.logp = ch.mode ? lp : lp - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
+    return;
+  }
+  if (lp == -BA_INF) {
+    M.logp = -BA_INF;
+    M.pd = false;
+    return;
+  }
+  const int npan = (k + 63) >> 6;
+  const int kpad8 = (k + 7) & ~7;
+  // index list, prior means; zero tails of the k-vectors
+  for (int m = lane; m < kcap; m += WAVE) {
+    ((int *)(dst + S.g))[m] = (m < k) ? (int)ch.g[m] : 0;
+    dst[S.bg + m] = (m < k) ? P.b[ch.g[m]] : 0.0;
+    if (m >= k) {
+      dst[S.w + m] = 0.0;
+      if (!REUSE) { dst[S.rdv + m] = 0.0; dst[S.rda + m] = 0.0; }
+      ch.w[m] = 0.0;
+      ch.rdv[m] = 0.0;
+    }
+  }
+  bool okv = true, oka = true;
+  if (REUSE) {
+    M.lda = lda_in;
+    M.ldv = ldv_in;
+    for (int m = lane; m < k; m += WAVE) ch.rdv[m] = dst[S.rdv + m];
+  } else {
+#pragma nounroll
+    for (int s = 1; s >= 0; --s) {       // A first, then V (order of chol_blocks2's pair is immaterial)
+      const double *Mat = s ? P.A : P.V;
+      const double msc = s ? ch.sa : ch.sv;
+      double *Lst = dst + (s ? S.La : S.Lv);
+      double *rdst = dst + (s ? S.rda : S.rdv);
+      bool ok = true;
+      double ld = 0.0;
+      for (int I = 0; I < npan && ok; ++I) {
+        const int row = I * 64 + lane;
+        const bool valid = row < k;
+        const int gi = valid ? (int)ch.g[row] : 0;
+        const double *Mrow = Mat + (size_t)gi * p;
+        if (I > 0) {
+          c_f64 *LB = scalar_view(Lst);
+          c_f64 *rd = (c_f64 *)((unsigned long long)LB + ((unsigned long long)rdst - (unsigned long long)Lst));
+          big_solve(LB, rd, I * 64, I, true, bx.xs, lane,
+                    [&](int J, double (&a)[64]) {
+#pragma unroll
+                      for (int r = 0; r < 64; ++r) {
+                        const int gm = (int)ch.g[J * 64 + r];  // (J < I: a full panel of real variables)
+                        const double v = Mrow[gm] * msc;
+                        a[r] = valid ? v : 0.0;
+                      }
+                    },
+                    [&](int, double (&)[64]) {});
+        }
+        // diagonal tile: M[g_i, g_c] - sum_m x_i[m] x_c[m]
+        double acc[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+          const int col = I * 64 + c;
+          const int gc = (col < k) ? (int)ch.g[col] : 0;
+          const double v = Mrow[gc] * msc;
+          acc[c] = (valid && col <= row) ? v : 0.0;
+        }
+        if (I > 0) {
+          c_f64 *XS = scalar_view(bx.xs);
+          for (int m0 = 0; m0 < I * 64; m0 += 8) {
+            double xi[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xi[t] = bx.xs[(size_t)(m0 + t) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+              for (int c = 0; c < 64; ++c) acc[c] -= xi[t] * XS[(size_t)(m0 + t) * 64 + c];
+          }
+        }
+        const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < 64; ++c)
+          if ((c >> 3) <= (lane >> 3)) bx.tile[bidx(lane, c)] = (valid && c <= lane) ? acc[c] : 0.0;
+        bx.rdt[lane] = 0.0;
+        wave_sync();
+        double ldt = 0.0;
+        chol_tile(bx.tile, bx.rdt, kk, lane, &ok, &ldt);
+        ld += ldt;
+        wave_sync();
+        if (!ok) break;
+        // rows of this tile row go to the factor: parked off-diagonal part, the tile, rd
+        if (row < kpad8) {
+          for (int m = 0; m < I * 64; ++m) Lst[bidx(row, m)] = valid ? bx.xs[(size_t)m * 64 + lane] : 0.0;
+#pragma unroll
+          for (int c = 0; c < 64; ++c)
+            if ((c >> 3) <= (lane >> 3))
+              Lst[bidx(row, I * 64 + c)] = (valid && c <= lane && c < kk) ? bx.tile[bidx(lane, c)] : 0.0;
+          rdst[row] = valid ? bx.rdt[lane] : 0.0;
+        }
+        if (s == 0 && valid) ch.rdv[row] = bx.rdt[lane];
+      }
+      if (s) { oka = ok; M.lda = 2.0 * ld; }
+      else   { okv = ok; M.ldv = 2.0 * ld; }
+    }
+  }
+  // the factor just stored is read back below (and by the tail) with vector loads
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  if (!okv) {
+    M.pd = false;
+    M.logp = -BA_INF;
+    return;
+  }
+  // r = A_g b_g + xty_g, c = b_g' A_g b_g (only non-zero prior means cost)
+  double cpart = 0.0;
+  {
+    bool anyb = false;
+    for (int m = lane; m < k; m += WAVE) anyb = anyb || (P.b[ch.g[m]] != 0.0);
+    const bool any = __any(anyb) != 0;
+    for (int m = lane; m < kcap; m += WAVE) {
+      double r = 0.0;
+      if (m < k) {
+        const int gm = ch.g[m];
+        double ab = 0.0;
+        if (any) {
+          for (int n = 0; n < k; ++n) {
+            const int gn = ch.g[n];
+            const double bn = P.b[gn];
+            if (bn != 0.0) ab += (P.A[(size_t)gm * p + gn] * ch.sa) * bn;
+          }
+          cpart += P.b[gm] * ab;
+        }
+        r = ab + ch.xty[gm] * ch.sx;
+      }
+      bx.y[m] = r;
+    }
+  }
+  M.c = wave_sum(cpart);
+  wave_sync();
+  // w = L_V^{-1} r, tile row by tile row: t_i = r_i - sum_{m < 64 I} L[i, m] w_m, then
+  // the forward substitution inside the tile (lane = local row)
+  const double *Lv = dst + S.Lv;
+  __builtin_amdgcn_s_waitcnt(0);
+  double qpart = 0.0;
+  for (int I = 0; I < npan; ++I) {
+    const int row = I * 64 + lane;
+    const bool valid = row < k;
+    double t = valid ? bx.y[row] : 0.0;
+    if (valid)
+      for (int m = 0; m < I * 64; ++m) t -= Lv[bidx(row, m)] * ch.w[m];
+    double lt[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) lt[j] = (valid && j < lane) ? Lv[bidx(row, I * 64 + j)] : 0.0;
+    const double rdm = valid ? ch.rdv[row] : 0.0;
+    const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      if (j < kk) {
+        const double wj = bcast_u(t, j) * bcast_u(rdm, j);
+        if (lane == j) t = wj;
+        else if (lane > j) t -= lt[j] * wj;
+      }
+    }
+    if (valid) {
+      ch.w[row] = t;
+      dst[S.w + row] = t;
+      qpart += t * t;
+    }
+    wave_sync();
+  }
+  M.Q = wave_sum(qpart);
+  M.SS = ch.ss0q + M.c - M.Q;
+  if (ch.mode) {
+    if (!oka) { M.lda = -BA_INF; M.logp = -BA_INF; return; }
+    M.logp = lp + 0.5 * (M.lda - M.ldv) - 0.5 * (M.c - M.Q);
+    return;
+  }
+  if (!(M.SS >= 0.0) || isinf(M.SS)) {
+    M.bad = CHAIN_NEGATIVE_SS;
+    M.logp = -BA_INF;
+    return;
+  }
+  if (!oka) { M.lda = -BA_INF; M.logp = -BA_INF; return; }
+  M.logp = lp + 0.5 * (M.lda - M.ldv) - (0.5 * ch.DF - 1.0) * log(M.SS);
+}
+
+__device__ __forceinline__ void store_scalars(double *dst, const SsvsScalarLayout &S, const Model &M, int lane) {
+  if (lane == 0) {
+    double *sc = dst + S.scal;
+    sc[0] = M.logp; sc[1] = M.lp; sc[2] = M.ldv; sc[3] = M.lda;
+    sc[4] = M.Q; sc[5] = M.c; sc[6] = M.SS; sc[7] = M.pd ? 1.0 : 0.0;
+  }
+}
+__device__ __forceinline__ void load_scalars(const double *src, const SsvsScalarLayout &S, Model &M) {
+  const double *sc = src + S.scal;
+  M.logp = sc[0]; M.lp = sc[1]; M.ldv = sc[2]; M.lda = sc[3];
+  M.Q = sc[4]; M.c = sc[5]; M.SS = sc[6]; M.pd = sc[7] != 0.0;
+  M.bad = 0;
+}
+
+// this lane's proposal "flip j" against the current model (factors through sc)
+template <bool NAT>
+__device__ __forceinline__ Proposal big_eval(const BigP &P, Chain &ch, const Model &M,
+                                             const BigCtx &bx, c_f64 *sc, int j, bool valid) {
+  const int p = ch.p, k = ch.k, lane = ch.lane;
+  const SsvsScalarLayout &S = bx.S;
+  Proposal out;
+  out.logp = -BA_INF;
+  out.slow = false;
+  out.bad_ss = false;
+  const bool add = valid && !ch.gam[j];
+  const bool drop = valid && !add;
+  const int kn = add ? k + 1 : k - 1;
+  double lpn = -BA_INF;
+  if (valid) {
+    const double l1 = P.l1[j], l0 = P.l0[j];
+    if (add) lpn = (l1 == -BA_INF) ? -BA_INF : ((l0 == -BA_INF) ? -BA_INF : M.lp + (l1 - l0));
+    else     lpn = (l0 == -BA_INF) ? -BA_INF : ((l1 == -BA_INF) ? -BA_INF : M.lp + (l0 - l1));
+    if (P.max_model_size >= 0 && kn > P.max_model_size) lpn = -BA_INF;
+  }
+  const bool live = valid && (lpn > -BA_INF);
+  const double bj = live ? P.b[j] : 0.0;
+  const bool empty_after = live && drop && (kn == 0);
+  const bool slow = live && !empty_after && (bj != 0.0);
+  const bool fast = live && !empty_after && !slow;
+  out.slow = slow;
+  if (empty_after) out.logp = ch.mode ? lpn : lpn - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
+  const double vjj = (fast && add) ? P.V[(size_t)j * p + j] * ch.sv : 0.0;
+  const double ajj = (fast && add) ? P.A[(size_t)j * p + j] * ch.sa : 0.0;
+  const double xtyj = (fast && add) ? ch.xty[j] * ch.sx : 0.0;
+  const int npan = (k + 63) >> 6;
+  double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
+#pragma nounroll
+  for (int s = 0; s < 2; ++s) {
+    const double *Mat = s ? P.A : P.V;
+    const double msc = s ? ch.sa : ch.sv;
+    c_f64 *LB = sc + (s ? S.La : S.Lv);
+    c_f64 *rd = sc + (s ? S.rda : S.rdv);
+    double n2 = 0.0, dw = 0.0, abl = 0.0;
+    big_solve(LB, rd, k, npan, false, bx.xs, lane,
+              [&](int I, double (&a)[64]) {
+#pragma unroll
+                for (int r = 0; r < 64; ++r) {
+                  // (16 gathers in flight at a time: their addresses need registers too)
+                  if ((r & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+                  const int m = I * 64 + r;
+                  const int gm = (m < k) ? (int)ch.g[m] : 0;
+                  const double v = (NAT ? Mat[(size_t)gm * p + j] : Mat[(size_t)j * p + gm]) * msc;
+                  const double e = (gm == j) ? 1.0 : 0.0;
+                  a[r] = (fast && m < k) ? (add ? v : e) : 0.0;
+                  abl += a[r] * sc[S.bg + m];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              },
+              [&](int I, double (&a)[64]) {
+#pragma unroll
+                for (int r = 0; r < 64; ++r) {
+                  n2 += a[r] * a[r];
+                  dw += a[r] * sc[S.w + I * 64 + r];
+                }
+              });
+    if (s == 0) { nv = n2; dv = dw; }
+    else        { na = n2; ab = abl; }
+  }
+  if (fast) {
+    double ldv, lda, Q;
+    bool ok = true;
+    if (add) {
+      const double d2 = vjj - nv;
+      const double da2 = ajj - na;
+      if (!(d2 > 0.0) || !(da2 > 0.0)) ok = false;
+      const double rj = xtyj + ab;
+      const double wn = (rj - dv) / sqrt(d2);
+      Q = M.Q + wn * wn;
+      ldv = M.ldv + log(d2);
+      lda = M.lda + log(da2);
+    } else {
+      Q = M.Q - dv * dv / nv;
+      ldv = M.ldv + log(nv);
+      lda = M.lda + log(na);
+    }
+    if (ok && ch.mode) {
+      out.logp = lpn + 0.5 * (lda - ldv) - 0.5 * (M.c - Q);
+    } else if (ok) {
+      const double SS = ch.ss0q + M.c - Q;
+      if (!(SS >= 0.0) || isinf(SS)) out.bad_ss = true;
+      else out.logp = lpn + 0.5 * (lda - ldv) - (0.5 * ch.DF - 1.0) * log(SS);
+    }
+  }
+  return out;
+}
+
+}  // namespace
+
+// grid = chains, block = 128.  Only chains parked with CHAIN_MODEL_TOO_LARGE
+// are this kernel's; it runs the sweeps they are owed (todo) and hands them back
+// with status CHAIN_OK (or parks them again if even big_kcap is too small).
+//
+// Both wavefronts run ONE loop: the master (wave 0) advances its state machine
+// until it needs something the workgroup does together -- a table-fill round,
+// the shuffle uniforms -- or something big enough to exist only once in the
+// code (a model build); it posts that as a command, the waves meet at a barrier,
+// do it, and meet again.  So every heavy routine has a single call site.
+__global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nsweeps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int W = 2;
+  const int chain = (int)blockIdx.x + P.chain_first;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int p = P.p, kcap = P.big_kcap;
+  if ((int)blockIdx.x >= P.chain_count) return;
+  const int status_in = P.status[chain];
+  __syncthreads();
+  if (status_in != CHAIN_MODEL_TOO_LARGE) return;
+  int owed_after = 0;
+  {
+    int total = nsweeps + P.todo[chain];
+    if (P.run_limit > 0 && total > P.run_limit) {
+      owed_after = total - P.run_limit;
+      total = P.run_limit;
+    }
+    nsweeps = total;
+  }
+  __syncthreads();
+
+  const SsvsBigLds lay = ssvs_big_lds_layout(p, kcap);
+  Chain ch;
+  ch.lane = lane;
+  ch.p = p;
+  ch.k = 0;
+  ch.Lv = ch.La = nullptr;
+  ch.rda = nullptr;
+  ch.bg = nullptr;
+  ch.rdv = to_lds<double>(smem + lay.rd);
+  ch.w = to_lds<double>(smem + lay.w);
+  ch.g = to_lds<uint16_t>(smem + lay.g);
+  ch.perm = to_lds<uint16_t>(smem + lay.perm0);
+  ch.perm_alt = to_lds<uint16_t>(smem + lay.perm1);
+  ch.oth = to_lds<uint16_t>(smem + lay.oth);
+  ch.last = to_lds<uint32_t>(smem + lay.last);
+  ch.pred = to_lds<uint16_t>(smem + lay.pred);
+  ch.gam = to_lds<uint8_t>(smem + lay.gam);
+  ch.gam0 = to_lds<uint8_t>(smem + lay.gam0);
+  ch.nbr = to_lds<uint8_t>(smem + lay.nbr);
+  lds_f64 *ctl = to_lds<double>(smem + lay.ctrl);
+  BigCtx bx;
+  bx.kcap = kcap;
+  bx.S = ssvs_scalar_layout(kcap);
+  bx.xs = P.big_xs + ((size_t)chain * W + wave) * (size_t)kcap * 64;
+  bx.tile = to_lds<double>(smem + lay.tile);
+  bx.rdt = to_lds<double>(smem + lay.rdt);
+  bx.y = to_lds<double>(smem + lay.y);
+  bx.bst = to_lds<double>(smem + lay.bst);
+  bx.gst = to_lds<uint16_t>(smem + lay.gst);
+  BigP BP;
+  BP.V = P.V; BP.A = P.A; BP.b = P.b; BP.l1 = P.l1; BP.l0 = P.l0;
+  BP.max_model_size = P.max_model_size;
+  ch.xty = P.xty + (size_t)chain * P.xty_stride;
+  const double yty = P.yty[(size_t)chain * P.suf_stride];
+  const double nobs = P.nobs[(size_t)chain * P.suf_stride];
+  ch.DF = nobs + P.prior_df;
+  ch.ss0q = P.prior_ss + yty;
+  ch.mode = P.mode;
+  ch.sv = ch.sa = ch.sx = 1.0;
+  if (P.mode) {
+    const double inv = 1.0 / P.sigsq[chain];
+    ch.sx = inv;
+    if (P.slab_scales) { ch.sv = inv; ch.sa = inv; }
+  }
+  const PhiloxKey key{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), P.stream};
+  auto slot_block = [&](int slot) {
+    return P.big_model + ((size_t)slot * P.chains + chain) * P.big_model_stride;
+  };
+  auto bind = [&](int slot) {
+    const size_t c = (size_t)slot * P.chains + chain;
+    ch.tab_lp = P.table_lp + c * p;
+    ch.tab_kind = P.table_kind + c * p;
+    ch.sc_store = slot_block(slot);
+  };
+
+  enum : int { BCMD_NONE = -1, BCMD_BUILD = 3 };
+  enum : int { PH_INIT, PH_BEGIN, PH_SHUFFLED, PH_FLIPS, PH_SWAP, PH_TAIL };
+  enum : int { BR_INIT, BR_VALID, BR_TRY };
+
+  // ---- master-only state (wave 1 carries it along unused) ---------------------
+  uint8_t *g_gamma = P.gamma + (size_t)chain * p;
+  uint16_t *g_perm = P.perm + (size_t)chain * p;
+  int status = CHAIN_OK;
+  bool aborted = false;
+  int kmax = 0, trace_at = 0, failures = 0, done = 0, klast = 0;
+  uint64_t pos = 0, flip_pos = 0, pos0 = 0;
+  double sigsq = 1.0;
+  bool beta_valid = false;
+  const int nflips = P.max_flips;
+  const int big_tag = 0x40000000 | (kcap << 1);
+  Model M;
+  M.bad = 0; M.pd = true; M.logp = 0; M.lp = 0; M.ldv = 0; M.lda = 0; M.Q = 0; M.c = 0; M.SS = 0;
+  int cur = 0, other_var = -1;
+  bool other_ok = false, table_valid = false, table_valid_other = false;
+  bool model_checked = false;
+  int phase = PH_INIT, sweep = 0, i0 = 0, fill_base = 0;
+  // a pending build: reason, where, and (BR_TRY) the decision riding on it
+  int b_reason = BR_INIT, b_slot = 0, b_after = PH_BEGIN;
+  bool b_reuse = false;
+  int t_f1 = -1, t_f2 = -1, t_kind = 0;
+  double t_lu = 0.0, t_lfw = 0.0, t_lrev = 0.0;
+  WinRng rng;
+  rng.init(key, lane, 0);
+
+#define BACC_ADD(slot, x) do { if (lane == 0) ctl[CT_ACC + (slot)] += (double)(x); } while (0)
+#define BACC_MIN(x) do { if (lane == 0) ctl[CT_ACC + ACC_MIN_MARGIN] = fmin(ctl[CT_ACC + ACC_MIN_MARGIN], (x)); } while (0)
+  auto publish_ctl = [&]() {
+    if (lane == 0) {
+      ctl[CT_LOGP] = M.logp; ctl[CT_LP] = M.lp; ctl[CT_LDV] = M.ldv;
+      ctl[CT_LDA] = M.lda; ctl[CT_Q] = M.Q; ctl[CT_C] = M.c;
+    }
+    wave_sync();
+  };
+  auto reload_tail_vectors = [&]() {  // w, 1 / diag(L_V) of the model in the bound slot
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int m = lane; m < kcap; m += WAVE) {
+      ch.w[m] = ch.sc_store[bx.S.w + m];
+      ch.rdv[m] = ch.sc_store[bx.S.rdv + m];
+    }
+    wave_sync();
+  };
+  auto flip_in_lds = [&](int f1, int f2) {
+    wave_sync();
+    if (lane == 0) {
+      ch.gam[f1] = (uint8_t)!ch.gam[f1];
+      if (f2 >= 0) ch.gam[f2] = (uint8_t)!ch.gam[f2];
+    }
+    rebuild_g(ch, kcap);
+  };
+  auto request_try = [&](int f1, int f2, int kind, double lu, double lfw, double lrev, int after) {
+    t_f1 = f1; t_f2 = f2; t_kind = kind; t_lu = lu; t_lfw = lfw; t_lrev = lrev;
+    flip_in_lds(f1, f2);
+    b_reason = BR_TRY; b_slot = cur ^ 1; b_reuse = false; b_after = after;
+  };
+
+  if (wave == 0) {
+    for (int j = lane; j < p; j += WAVE) {
+      ch.gam[j] = g_gamma[j];
+      ch.perm[j] = g_perm[j];
+      ch.nbr[j] = (uint8_t)((P.cm_start != nullptr) && (P.cm_start[j + 1] > P.cm_start[j]));
+    }
+    rebuild_g(ch, kcap);
+    if (ch.k > kcap) status = CHAIN_MODEL_TOO_LARGE;  // parked again: the host grows big_kcap
+    kmax = ch.k;
+    trace_at = P.trace_idx ? P.trace_idx[chain] : 0;
+    pos = uni((uint64_t)P.rng_pos[chain]);
+    pos0 = pos;
+    failures = uni((int)P.failures[chain]);
+    sigsq = uni((double)P.sigsq[chain]);
+    rng.init(key, lane, pos);
+    if (lane < 8) ctl[CT_ACC + lane] = (lane == ACC_MIN_MARGIN) ? BA_INF : 0.0;
+    wave_sync();
+  }
+
+  for (;;) {
+    if (wave == 0) {
+      int cmd = BCMD_NONE;
+      while (cmd == BCMD_NONE) {
+        if (status != CHAIN_OK) { cmd = BCMD_EXIT; break; }
+        if (phase == PH_INIT) {
+          if (nsweeps <= 0) { cmd = BCMD_EXIT; break; }
+          // the current model: kept from the chain's last launch, or built now
+          const int tag_in = P.model_keep ? P.model_tag[chain] : 0;
+          const bool kept = (tag_in & ~1) == big_tag;
+          phase = PH_BEGIN;
+          if (kept) {
+            cur = tag_in & 1;
+            bind(cur);
+            load_scalars(ch.sc_store, bx.S, M);
+            reload_tail_vectors();
+            if (!P.suf_changed) {
+              table_valid = P.table_keep && P.table_tag[chain] == tag_in;
+              publish_ctl();
+              continue;
+            }
+          }
+          bind(cur);
+          b_reason = BR_INIT; b_slot = cur; b_reuse = kept; b_after = PH_BEGIN;
+          cmd = BCMD_BUILD;
+          break;
+        }
+        if (phase == PH_BEGIN) {
+          if (sweep >= nsweeps) { cmd = BCMD_EXIT; break; }
+          // ---- draw_model_indicators (BregVsSampler.cpp:353-378)
+          pos0 = pos;
+          if (nflips <= 0) { phase = PH_SWAP; continue; }
+          for (int j = lane; j < p; j += WAVE) {
+            ch.gam0[j] = ch.gam[j];
+            if (P.mode) ch.perm[j] = (uint16_t)j;
+          }
+          wave_sync();
+          if (lane == 0) ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = pos;
+          phase = PH_SHUFFLED;
+          cmd = BCMD_UNIF;
+          break;
+        }
+        if (phase == PH_SHUFFLED) {
+          StampCtx sx;
+          sx.last = 0;
+          if (p > 1) parallel_shuffle(ch, sx);
+          flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
+          pos = flip_pos + (uint64_t)nflips;
+          i0 = 0;
+          phase = PH_FLIPS;
+          if (!model_checked) {
+            model_checked = true;
+            if (!(M.logp > -BA_INF && M.logp < BA_INF)) {
+              // VariableSelectionPrior::make_valid (VariableSelectionPrior.cpp:287-300)
+              for (int j = 0; j < p; ++j) {
+                const double pj = P.pi[j];
+                const bool inc = ch.gam[j];
+                if ((pj <= 0.0 && inc) || (pj >= 1.0 && !inc)) {
+                  wave_sync();
+                  if (lane == 0) ch.gam[j] = (uint8_t)!inc;
+                  wave_sync();
+                }
+              }
+              rebuild_g(ch, kcap);
+              if (ch.k > kcap) { status = CHAIN_MODEL_TOO_LARGE; aborted = true; continue; }
+              bind(cur);
+              b_reason = BR_VALID; b_slot = cur; b_reuse = false; b_after = PH_FLIPS;
+              cmd = BCMD_BUILD;
+              break;
+            }
+          }
+          continue;
+        }
+        if (phase == PH_FLIPS) {
+          if (i0 >= nflips) { phase = PH_SWAP; continue; }
+          if (!table_valid) {
+            // (re)build the table of acceptance thresholds for the current model:
+            // p / 128 rounds of the whole workgroup
+            if (fill_base >= p) {
+              fill_base = 0;
+              table_valid = true;
+              continue;
+            }
+            if (lane == 0) {
+              ctl[CT_K] = (double)ch.k;
+              ctl[CT_I0] = (double)fill_base;
+              ctl[CT_CUR] = (double)cur;
+            }
+            fill_base += WAVE * W;
+            cmd = BCMD_EVAL;
+            break;
+          }
+          DecideResult dr;
+          decide_walk(ch, key, flip_pos, i0, nflips, dr);
+          BACC_MIN(dr.margin);
+          if (dr.spos < 0) {
+            BACC_ADD(ACC_PROPOSALS, nflips - i0);
+            i0 = nflips;
+            continue;
+          }
+          BACC_ADD(ACC_PROPOSALS, dr.spos + 1 - i0);
+          i0 = dr.spos + 1;
+          if (dr.kind == STOP_BAD) { status = CHAIN_NEGATIVE_SS; continue; }
+          if (!ch.gam[dr.j] && ch.k >= kcap) { status = CHAIN_MODEL_TOO_LARGE; aborted = true; continue; }
+          if (dr.kind == 0 && other_ok && dr.j == other_var) {
+            // the flip leads back to the model the other slot still holds
+            flip_in_lds(dr.j, -1);
+            cur ^= 1;
+            bind(cur);
+            __builtin_amdgcn_s_waitcnt(0);
+            load_scalars(ch.sc_store, bx.S, M);
+            reload_tail_vectors();
+            const bool t = table_valid;
+            table_valid = table_valid_other;
+            table_valid_other = t;
+            publish_ctl();
+            BACC_ADD(ACC_ACCEPTS, 1);
+            BACC_ADD(ACC_SLOT_HITS, 1);
+            if (!M.pd) status = CHAIN_NOT_PD;
+            continue;
+          }
+          if (dr.kind == 0) request_try(dr.j, -1, 0, 0.0, 0.0, 0.0, PH_FLIPS);
+          else              request_try(dr.j, -1, 1, dr.logu, 0.0, 0.0, PH_FLIPS);
+          cmd = BCMD_BUILD;
+          break;
+        }
+        if (phase == PH_SWAP) {
+          // ---- attempt_swap (BregVsSampler.cpp:277-310)
+          phase = PH_TAIL;
+          rng.set_pos(pos);
+          if (nflips > 0) {
+            Pending pe;
+            pe.kind = EV_NONE; pe.f1 = pe.f2 = -1; pe.lu = 0; pe.lfw = pe.lrev = 0; pe.check_legal = false;
+            propose_swap(P, ch, rng, pe, &status);
+            pos = rng.get_pos();
+            if (status != CHAIN_OK) continue;
+            if (pe.kind == EV_TRY_LT) {  // (a swap keeps the model size)
+              request_try(pe.f1, pe.f2, 2, pe.lu, pe.lfw, pe.lrev, PH_TAIL);
+              cmd = BCMD_BUILD;
+              break;
+            }
+          }
+          continue;
+        }
+        // ---- PH_TAIL: draw_sigma (BregVsSampler.cpp:313-324)
+        const int k = ch.k;
+        rng.set_pos(pos);
+        if (P.draw_sigma) {
+          int bad = 0;
+          const double DF = (k == 0) ? ch.DF : ((ch.DF - P.prior_df) + P.prior_df);
+          const double SS = (k == 0) ? ch.ss0q : ((M.SS - P.prior_ss) + P.prior_ss);
+          sigsq = uni(d_draw_variance(rng, DF, SS, P.sigma_max, &bad));
+          if (bad) { status = CHAIN_RNG_BRANCH; continue; }
+        }
+        pos = uni(rng.get_pos());
+        // ---- draw_beta (BregVsSampler.cpp:326-351): beta = L^{-T}(w + sigma z)
+        if (P.draw_beta && k > 0) {
+          if (!M.pd) { ++failures; status = CHAIN_NOT_PD; continue; }
+          failures = 0;
+          const double sigma = P.mode ? 1.0 : sqrt(sigsq);
+          const int npan = (k + 63) >> 6;
+          for (int q = 0; q < npan; ++q) {
+            const int kq = (k - q * 64 < 64) ? (k - q * 64) : 64;
+            const double z = draw_normals(rng, kq);
+            if (lane < kq) bx.y[q * 64 + lane] = ch.w[q * 64 + lane] + sigma * z;
+          }
+          pos = uni(rng.get_pos());
+          wave_sync();
+          const double *Lv = ch.sc_store + bx.S.Lv;
+          for (int I = npan - 1; I >= 0; --I) {
+            const int col = I * 64 + lane;            // this lane's unknown in the tile
+            const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
+            double yv = (lane < kk) ? bx.y[col] : 0.0;
+            const double rdm = (lane < kk) ? ch.rdv[col] : 0.0;
+            // column `col` of the tile below the diagonal, 16 rows at a time
+#pragma nounroll
+            for (int ib = 48; ib >= 0; ib -= 16) {
+              if (ib < kk) {
+                double lt[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                  lt[t] = (ib + t > lane && ib + t < kk) ? Lv[bidx(I * 64 + ib + t, col)] : 0.0;
+#pragma unroll
+                for (int t = 15; t >= 0; --t) {
+                  const int i = ib + t;
+                  if (i < kk) {
+                    const double xi = bcast_u(yv * rdm, i);
+                    if (lane == i) yv = xi;
+                    else if (lane < i) yv -= lt[t] * xi;
+                  }
+                }
+              }
+            }
+            if (lane < kk) bx.y[col] = yv;
+            wave_sync();
+            // earlier tiles: y_J[c] -= sum_i L[64 I + i][64 J + c] x_I[i]
+            for (int J = 0; J < I; ++J) {
+              double acc = 0.0;
+              for (int ii = 0; ii < kk; ii += 8) {
+                double l8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                  l8[t] = (ii + t < kk) ? Lv[bidx(I * 64 + ii + t, J * 64 + lane)] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc += l8[t] * bx.y[I * 64 + ((ii + t < kk) ? ii + t : 0)];
+              }
+              bx.y[J * 64 + lane] -= acc;
+            }
+            wave_sync();
+          }
+          beta_valid = true;
+        } else if (P.draw_beta) {
+          beta_valid = true;
+        }
+        // ---- summaries, traces, the draw record
+        kmax = k > kmax ? k : kmax;
+        for (int m = lane; m < k; m += WAVE) {
+          const size_t o = (size_t)chain * p + ch.g[m];
+          P.inc_count[o] += 1u;
+          if (beta_valid) {
+            const double b = bx.y[m];
+            P.beta_sum[o] += b;
+            P.beta_sumsq[o] += b * b;
+          }
+        }
+        BACC_ADD(ACC_SIGSQ, sigsq);
+        BACC_ADD(ACC_SIGSQ2, sigsq * sigsq);
+        BACC_ADD(ACC_K, k);
+        if (P.trace_sigsq && trace_at + sweep < P.trace_stride) {
+          const size_t o = (size_t)chain * P.trace_stride + trace_at + sweep;
+          if (lane == 0) {
+            P.trace_sigsq[o] = sigsq;
+            P.trace_logp[o] = M.logp;
+            P.trace_k[o] = (double)k;
+          }
+          if (P.rec_idx) {
+            for (int m = lane; m < k && m < P.rec_cap; m += WAVE) {
+              P.rec_idx[o * P.rec_cap + m] = ch.g[m];
+              P.rec_beta[o * P.rec_cap + m] = beta_valid ? bx.y[m] : 0.0;
+            }
+          }
+        }
+        if (beta_valid) {  // coefficients of the last complete draw (written back at the end)
+          for (int m = lane; m < k; m += WAVE) {
+            bx.bst[m] = bx.y[m];
+            bx.gst[m] = ch.g[m];
+          }
+          klast = k;
+        }
+        wave_sync();
+        ++done;
+        ++sweep;
+        phase = PH_BEGIN;
+      }
+      if (lane == 0) ctl[CT_CMD] = (double)cmd;
+    }
+    __syncthreads();
+    const int cmd = (int)ctl[CT_CMD];
+    if (cmd == BCMD_EXIT) break;
+    if (cmd == BCMD_UNIF) {
+      const uint64_t upos = ((AS_LDS const uint64_t *)(ctl + CT_POS))[0];
+      if (p > 1) shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth);
+    } else if (cmd == BCMD_EVAL) {
+      Model Me;
+      Me.logp = ctl[CT_LOGP]; Me.lp = ctl[CT_LP]; Me.ldv = ctl[CT_LDV];
+      Me.lda = ctl[CT_LDA]; Me.Q = ctl[CT_Q]; Me.c = ctl[CT_C];
+      Me.SS = 0; Me.pd = true; Me.bad = 0;
+      if (wave != 0) {
+        ch.k = (int)ctl[CT_K];
+        bind((int)ctl[CT_CUR]);
+      }
+      c_f64 *sc = scalar_view(ch.sc_store);
+      const int idx = (int)ctl[CT_I0] + WAVE * wave + lane;
+      const bool valid = idx < p;
+      const Proposal pr = big_eval<true>(BP, ch, Me, bx, sc, valid ? idx : 0, valid);
+      if (valid) {
+        ch.tab_lp[idx] = exp(pr.logp - Me.logp);
+        ch.tab_kind[idx] = (uint8_t)(pr.bad_ss ? STOP_BAD : (pr.slow ? STOP_SLOW : 0));
+      }
+    } else if (wave == 0) {  // BCMD_BUILD
+      double *dst = slot_block(b_slot);
+      Model Mn = M;
+      big_build_body(BP, ch, Mn, dst, bx, b_reuse);
+      if (Mn.bad) {
+        status = Mn.bad;
+      } else if (b_reason != BR_TRY) {
+        M = Mn;
+        store_scalars(dst, bx.S, M, lane);
+        table_valid = false;
+        other_ok = false;
+        table_valid_other = false;
+        publish_ctl();
+        if (b_reason == BR_VALID && !(M.logp > -BA_INF && M.logp < BA_INF)) status = CHAIN_ILLEGAL_START;
+        phase = b_after;
+      } else {
+        // the decision riding on the build: t_kind 0 forced (accepted on the
+        // table), 1 accept unless log u > delta (flip), 2 accept iff log u <
+        // delta (swap move)
+        bool acc = true;
+        if (t_kind != 0) {
+          const double d = (Mn.logp - t_lfw) - (M.logp - t_lrev);
+          if (Mn.logp > -BA_INF) BACC_MIN(fabs(t_lu - d));
+          acc = (t_kind == 1) ? !(t_lu > d) : (t_lu < d);
+        }
+        if (acc) {
+          M = Mn;
+          store_scalars(dst, bx.S, M, lane);
+          table_valid_other = table_valid;
+          table_valid = false;
+          other_ok = (t_f2 < 0);
+          other_var = t_f1;
+          cur ^= 1;
+          bind(cur);
+          publish_ctl();
+          BACC_ADD(ACC_ACCEPTS, 1);
+          if (t_kind == 0 && !M.pd) status = CHAIN_NOT_PD;
+        } else {
+          // rejected: gamma back; the slot in use was never touched, the other
+          // one no longer holds the model left behind
+          flip_in_lds(t_f1, t_f2);
+          other_ok = false;
+          table_valid_other = false;
+          reload_tail_vectors();
+        }
+        phase = b_after;
+      }
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+
+  // ---- write the chain back
+  wave_sync();
+  {
+    const lds_u8 *gsrc = aborted ? ch.gam0 : ch.gam;
+    const lds_u16 *psrc = (aborted && p > 1) ? ch.perm_alt : ch.perm;
+    for (int j = lane; j < p; j += WAVE) {
+      g_gamma[j] = gsrc[j];
+      g_perm[j] = psrc[j];
+    }
+    if (aborted) pos = pos0;
+  }
+  if (beta_valid && done > 0) {
+    double *g_beta = P.beta + (size_t)chain * p;
+    for (int j = lane; j < p; j += WAVE) g_beta[j] = 0.0;
+    wave_sync();
+    for (int m = lane; m < klast; m += WAVE) g_beta[bx.gst[m]] = bx.bst[m];
+  } else if (nflips > 0 && done > 0) {
+    const lds_u8 *gsrc = aborted ? ch.gam0 : ch.gam;
+    double *g_beta = P.beta + (size_t)chain * p;
+    for (int j = lane; j < p; j += WAVE)
+      if (!gsrc[j]) g_beta[j] = 0.0;
+  }
+  if (lane == 0) {
+    P.sigsq[chain] = sigsq;
+    P.rng_pos[chain] = pos;
+    P.failures[chain] = failures;
+    P.status[chain] = status;
+    P.todo[chain] = nsweeps - done + owed_after;
+    if (P.ran) P.ran[chain] = done;
+    const int tag = big_tag | cur;
+    const bool good = !aborted && status == CHAIN_OK && nsweeps > 0;
+    P.table_tag[chain] = (table_valid && good) ? tag : 0;
+    P.model_tag[chain] = good ? tag : 0;
+    if (P.trace_idx) P.trace_idx[chain] = trace_at + done;
+    if (P.maxk) atomicMax(P.maxk, kmax);
+    double *a = P.acc + (size_t)chain * ACC_COUNT;
+    a[ACC_SWEEPS] += done;
+    a[ACC_SIGSQ] += ctl[CT_ACC + ACC_SIGSQ];
+    a[ACC_SIGSQ2] += ctl[CT_ACC + ACC_SIGSQ2];
+    a[ACC_K] += ctl[CT_ACC + ACC_K];
+    a[ACC_ACCEPTS] += ctl[CT_ACC + ACC_ACCEPTS];
+    a[ACC_PROPOSALS] += ctl[CT_ACC + ACC_PROPOSALS];
+    a[ACC_SLOT_HITS] += ctl[CT_ACC + ACC_SLOT_HITS];
+    a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], ctl[CT_ACC + ACC_MIN_MARGIN]);
+  }
+}
+
+hipError_t launch_ssvs_big(hipStream_t stream, const SsvsParams &P, int nsweeps) {
+  const SsvsBigLds lay = ssvs_big_lds_layout(P.p, P.big_kcap);
+  hipError_t e = hipFuncSetAttribute((const void *)ssvs_big_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ssvs_big_kernel, dim3(P.chain_count), dim3(2 * WAVE), lay.total, stream, P,
+                     nsweeps);
+  return hipGetLastError();
+}
+
+}  // namespace boom_amd

@@ -137,6 +137,15 @@ struct SsvsParams {
   uint16_t *rec_idx;   // chains x trace_stride x rec_cap
   double *rec_beta;    // chains x trace_stride x rec_cap
   int32_t rec_cap;     // >= the launch's model capacity
+
+  // ---- HBM-resident path (ssvs_big_kernel.hip): models of more than 64
+  // variables.  Capacity big_kcap (a multiple of 64); per-chain model blocks laid
+  // out by ssvs_scalar_layout(big_kcap), two slots like model_scratch; per-wave
+  // parking space for the solution panels of the per-lane triangular solves.
+  int32_t big_kcap;
+  double *big_model;          // 2 slots x chains x big_model_stride doubles
+  int64_t big_model_stride;
+  double *big_xs;             // chains x 2 waves x big_kcap x 64 doubles
 };
 
 // ---- LDS layout of one chain (one wavefront) --------------------------------
@@ -175,6 +184,38 @@ static inline __host__ __device__ SsvsLds ssvs_lds_layout(int p, int kcap) {
   L.gam = o;   o += ((uint32_t)p + 15u) & ~15u;
   L.gam0 = o;  o += ((uint32_t)p + 15u) & ~15u;  // gamma at the start of the sweep
   L.nbr = o;   o += ((uint32_t)p + 15u) & ~15u;  // 1: the variable has partners in the correlation map
+  L.total = o;
+  return L;
+}
+
+// ---- LDS layout of one chain in the HBM-resident kernel -------------------------
+// No factors here (they live in the chain's HBM block): one 64 x 64 diagonal
+// tile while it is being factored, the k-vectors the tail needs, the
+// permutation work arrays and gamma.
+struct SsvsBigLds {
+  uint32_t tile, rdt, w, y, rd, bst, ctrl, g, gst, perm0, perm1, oth, last, pred, gam, gam0, nbr, total;
+};
+static inline __host__ __device__ SsvsBigLds ssvs_big_lds_layout(int p, int kcap) {
+  SsvsBigLds L;
+  const uint32_t pv = (((uint32_t)p * 2) + 15u) & ~15u;
+  uint32_t o = 0;
+  L.tile = o;  o += 36 * 64 * 8;            // lower block-triangle of 8 x 8 blocks
+  L.rdt = o;   o += 64 * 8;
+  L.w = o;     o += (uint32_t)kcap * 8;
+  L.y = o;     o += (uint32_t)kcap * 8;
+  L.rd = o;    o += (uint32_t)kcap * 8;
+  L.bst = o;   o += (uint32_t)kcap * 8;     // coefficients of the last complete draw
+  L.ctrl = o;  o += 512;
+  L.g = o;     o += (((uint32_t)kcap * 2) + 15u) & ~15u;
+  L.gst = o;   o += (((uint32_t)kcap * 2) + 15u) & ~15u;  // ... and their variables
+  L.perm0 = o; o += pv;
+  L.perm1 = o; o += pv;
+  L.oth = o;   o += pv;
+  L.last = o;  o += 2 * pv;
+  L.pred = o;  o += pv;
+  L.gam = o;   o += ((uint32_t)p + 15u) & ~15u;
+  L.gam0 = o;  o += ((uint32_t)p + 15u) & ~15u;
+  L.nbr = o;   o += ((uint32_t)p + 15u) & ~15u;
   L.total = o;
   return L;
 }
