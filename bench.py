@@ -63,6 +63,33 @@ def geyer_ess(x):
     return min(float(n), n / tau)
 
 
+def usable_cores():
+    """host threads this process may actually use: the affinity mask capped by a
+    cgroup CPU quota (os.cpu_count() reports the machine, not the container)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            with open(path) as fh:
+                txt = fh.read().strip()
+            if parse:
+                q, per = parse(txt)
+                if q != "max":
+                    n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+            else:
+                q = int(txt)
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    per = int(fh.read().strip())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,7 +271,7 @@ def main():
     if not args.no_cpu_baseline:
         from oracle_lib import Oracle, ssvs_options
         O = Oracle()
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         # warm start from the GPU's current state so that kbar matches
         gam, beta, sig = eng.get_states()
 
@@ -256,10 +283,12 @@ def main():
         one = timed(1, 200, 1)                      # calibrates the sample sizes
         nsw1 = int(max(200, min(4000, 5.0 * one)))
         one = timed(1, nsw1, 1)                     # ~5 s, one thread
-        nchains = 4 * cores
-        nswc = int(max(20, min(2000, 12.0 * one / 4)))
-        allc = timed(nchains, nswc, cores)          # ~12 s if the cores scale
+        nchains = 2 * cores
+        cal = timed(nchains, 20, cores)             # all-core rate, short calibration run
+        nswc = int(max(20, min(4000, 12.0 * cal / nchains)))
+        allc = timed(nchains, nswc, cores)          # ~12 s
         cpu = {"value": round(allc, 2), "unit": "sweeps/s", "cores": cores, "kind": "port",
+               "host_threads_visible": os.cpu_count(),
                "one_thread": round(one, 2),
                "sample": "all-core: %d chains x %d sweeps on %d pthreads; one thread: 1 chain x "
                          "%d sweeps; same n=1e4 p=512 workload, warm-started at the GPU chains' "

@@ -75,6 +75,29 @@ def test_hundred_signals_p256_sweep_for_sweep(oracle):
     assert "working capacity" in str(ei.value)
 
 
+def test_capacity_grows_past_128(oracle):
+    """150 signals: the large-model kernel itself is outgrown (128 -> 256), the
+    per-lane solves run over three panels"""
+    X, y, _ = regression_data(4000, 320, 150, seed=59)
+    suf = oracle.neregsuf(X, y)
+    prior = spike_slab_prior(suf, 150)
+    g0 = np.zeros(320, np.uint8)
+    g0[0] = 1
+    chains, seed, nsw = 3, 31, 8
+    eng = make_engine(chains, seed, suf=suf, prior=prior, g0=g0)
+    ora = _oracle_runs(oracle, suf, prior, ssvs_options(), seed, g0, nsw, [0, 2])
+    for s in range(0, nsw, 2):
+        eng.sweep(2)
+        gam, beta, sig = eng.get_states()
+        for c in (0, 2):
+            o = ora[c]
+            assert o["status"] == 0
+            assert np.array_equal(gam[c], o["gamma"][s + 1]), (c, s)
+            assert relerr(beta[c], o["beta"][s + 1]) < RTOL, (c, s)
+            assert abs(sig[c] - o["sigsq"][s + 1]) < RTOL * sig[c], (c, s)
+    assert max(o["gamma"].sum(axis=1).max() for o in ora.values()) > 140
+
+
 def test_recorded_draws_and_lookahead_with_large_models(oracle):
     """every draw of one launch recorded (the record widens beyond 64 variables
     per draw), and ba_draw_next serving the same draws"""
