@@ -85,6 +85,8 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef __attribute__((address_space(3))) double AS_LDS_F64;
+
 // x -> A x + B
 struct Aff { double A, B; };
 __device__ __forceinline__ Aff aff_after(const Aff &later, const Aff &earlier) {
@@ -160,7 +162,6 @@ __device__ __forceinline__ double norm_from_lds(const __attribute__((address_spa
                                              int limit, int *used) {
   const double A = 2.216035867166471;
   const double C1 = 0.398942280401433, C2 = 0.180025191068563;
-#define BA_KR_G(x) (C1 * exp(-(x) * (x) / 2.0) - C2 * (A - (x)))
   int pos = o;
   *used = 0;
   if (pos + 2 > limit) return 0.0;
@@ -181,49 +182,40 @@ __device__ __forceinline__ double norm_from_lds(const __attribute__((address_spa
         done = true;
       }
     }
-  } else if (u1 >= 0.958720824790463) {
-    while (!done && pos + 2 <= limit) {
-      u2 = u[pos++];
-      u3 = u[pos++];
-      tt = A - 0.630834801921960 * fmin(u2, u3);
-      if (fmax(u2, u3) <= 0.755591531667601 ||
-          0.034240503750111 * fabs(u2 - u3) <= BA_KR_G(tt)) {
-        z = (u2 < u3) ? tt : -tt;
-        done = true;
-      }
-    }
-  } else if (u1 >= 0.911312780288703) {
-    while (!done && pos + 2 <= limit) {
-      u2 = u[pos++];
-      u3 = u[pos++];
-      tt = 0.479727404222441 + 1.105473661022070 * fmin(u2, u3);
-      if (fmax(u2, u3) <= 0.872834976671790 ||
-          0.049264496373128 * fabs(u2 - u3) <= BA_KR_G(tt)) {
-        z = (u2 < u3) ? tt : -tt;
-        done = true;
-      }
-    }
   } else {
+    // the three middle regions run ONE loop with per-lane constants (the same
+    // operations on the same numbers as the reference's three copies of it, so
+    // the same draws; one exp per round instead of three code paths):
+    //   tt = t0 + t1 min(u2, u3);  accept when max(u2, u3) <= thr or
+    //   coef |u2 - u3| <= C1 exp(-tt^2 / 2) - C2 (A - tt)
+    const bool r2 = u1 >= 0.958720824790463, r3 = !r2 && u1 >= 0.911312780288703;
+    const double t0 = r2 ? A : 0.479727404222441;
+    const double t1 = r2 ? -0.630834801921960 : (r3 ? 1.105473661022070 : -0.595507138015940);
+    const double thr = r2 ? 0.755591531667601 : (r3 ? 0.872834976671790 : 0.805577924423817);
+    const double coef = r2 ? 0.034240503750111 : (r3 ? 0.049264496373128 : 0.053377549506886);
     while (!done && pos + 2 <= limit) {
       u2 = u[pos++];
       u3 = u[pos++];
-      tt = 0.479727404222441 - 0.595507138015940 * fmin(u2, u3);
-      if (tt < 0.) continue;
-      if (fmax(u2, u3) <= 0.805577924423817 ||
-          0.053377549506886 * fabs(u2 - u3) <= BA_KR_G(tt)) {
+      // (written as the reference writes it: A - c min, resp. c0 + c min, c0 - c min)
+      tt = r2 ? A - 0.630834801921960 * fmin(u2, u3)
+              : (r3 ? 0.479727404222441 + 1.105473661022070 * fmin(u2, u3)
+                    : 0.479727404222441 - 0.595507138015940 * fmin(u2, u3));
+      if (tt < 0.) continue;   // (only the last region can get there)
+      if (fmax(u2, u3) <= thr ||
+          coef * fabs(u2 - u3) <= (C1 * exp(-(tt) * (tt) / 2.0) - C2 * (A - (tt)))) {
         z = (u2 < u3) ? tt : -tt;
         done = true;
       }
     }
+    (void)t0; (void)t1;
   }
-#undef BA_KR_G
   if (done) *used = pos - o;
   return z;
 }
 
 enum : int { NB_START = 512, NB_UNIF = NB_START + 64 };
 enum : int { NLEV = 8, NORD = NB_START / 2 / WAVE, JT = 0xFFFF };  // <= 256 draws per block
-enum : int { NR = 32 };  // registers per lane of a time panel
+enum : int { NR = 16 };  // registers per lane of a time panel
 
 }  // namespace
 
@@ -279,7 +271,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   const double sigsq_obs = P.sigsq[chain];
   const double *beta = P.beta + (size_t)chain * p;
   double *w0 = P.scratch + (size_t)chain * P.scratch_stride;  // y* -> e/F -> d -> residual
-  double *sF = w0 + T;                                        // (unused)
+  double *sF = w0 + T;                                        // residuals y - state (input of the X'e GEMM)
   double *sK = sF + T;                                        // K_t
   double *sal = sK + T;                                       // simulated state alpha+_t
   double *sst = sal + T;                                      // the state draw (SS_STATE_ARRAY)
@@ -298,7 +290,8 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   // lane m of a batch holding (j_m, beta_m)
   // A panel of NR * 64 time steps lives in registers (element i of lane l is
   // step tb + 64 i + l), so that a variable's column is NR independent loads.
-  for (int tb = 0; tb < T && wave == 0; tb += NR * WAVE) {
+  // (panels alternate between the two waves)
+  for (int tb = wave * NR * WAVE; tb < T; tb += 2 * NR * WAVE) {
     double pred[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) pred[i] = 0.0;
@@ -312,17 +305,14 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         const double b = bcast_u(bj, l);
         // (branch-free: steps past T read the last row and are never stored)
         const double *col = P.X + (size_t)(base + l) * T;
+        double xv[NR];
 #pragma unroll
-        for (int h = 0; h < NR; h += NR / 2) {
-          double xv[NR / 2];
-#pragma unroll
-          for (int i = 0; i < NR / 2; ++i) {
-            const int t = tb + (h + i) * WAVE + lane;
-            xv[i] = col[t < T ? t : T - 1];
-          }
-#pragma unroll
-          for (int i = 0; i < NR / 2; ++i) pred[h + i] += xv[i] * b;
+        for (int i = 0; i < NR; ++i) {
+          const int t = tb + i * WAVE + lane;
+          xv[i] = col[t < T ? t : T - 1];
         }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) pred[i] += xv[i] * b;
       }
     }
 #pragma unroll
@@ -497,68 +487,126 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   // (u_t + 1); simulate_initial_state / simulate_next_state
   // (alpha+), simulate_adjusted_observation (y+), and the filter on w = y* - y+.
   KSTAMP(3);
+  // Every pass below gives a lane BS CONSECUTIVE time steps (a chunk = 64 BS
+  // steps): the lane composes its own steps' maps serially, ONE wave scan per
+  // chunk combines the lanes' composites, and the lane walks its steps again from
+  // the value the scan hands it.  The kernel is bound by instruction issue (two
+  // waves per SIMD, both busy), and this cuts the instructions of a pass by the
+  // factor the scan's 6 DPP rounds no longer repeat for every 64 steps.
+  constexpr int BS = 8;
   {
-    const bool moebius = H > 0.0;  // (H == 0: the plain recursion, wave-uniform)
-    const double r = moebius ? q / H : 0.0, s1 = 1.0 / (1.0 + r);
-    double P_in = P.P0, alpha_in = 0.0, delta_in = 0.0;
-    for (int t0 = 0; t0 < T; t0 += WAVE) {
-      const int t = t0 + lane;
-      const bool in = t < T;
-      const bool obs = in && P.observed[t] != 0;
-      double F, K, P_next;
+    const bool moebius = H > 0.0;  // (H == 0: the plain recursion, lane after lane)
+    const double r = moebius ? q / H : 0.0, s1 = 1.0 / (1.0 + r), rH = moebius ? 1.0 / H : 0.0;
+    double u_in = moebius ? P.P0 / H : P.P0;   // variance carried in units of H (of 1 when H == 0)
+    double alpha_in = 0.0, delta_in = 0.0;
+    for (int t0 = 0; t0 < T; t0 += WAVE * BS) {
+      const int tl = t0 + BS * lane;
+      bool in[BS], obs[BS];
+      double zL[BS], zH[BS], ys[BS];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = tl + j;
+        in[j] = t < T;
+        obs[j] = in[j] && P.observed[in[j] ? t : 0] != 0;
+        const int nb = (t == 0) ? 0 : nfirst + (t - 1) * nper;
+        const bool hasL = in[j] && ((t == 0) ? dI : dL);
+        zL[j] = hasL ? szz[nb] : 0.0;
+        zH[j] = (in[j] && dH) ? szz[nb + (hasL ? 1 : 0)] : 0.0;
+        ys[j] = in[j] ? w0[t] : 0.0;
+      }
+      // ---- variances: u_{t+1} = ((1 + r) u_t + r) / (u_t + 1) at an observed step,
+      // u_t + r at a missing one; K_t = u_t / (u_t + 1), so u_{t+1} = K_t + r
+      double K[BS], Fv[BS];
       if (moebius) {
-        Mob mt;
-        mt.a = obs ? 1.0 : 1.0;
-        mt.b = obs ? r * s1 : (in ? r : 0.0);
-        mt.c = obs ? s1 : 0.0;
-        mt.d = obs ? s1 : 1.0;
-        const Mob g = wave_scan(mt);
-        const double u_in = P_in / H;
-        const double u_next = (g.a * u_in + g.b) / (g.c * u_in + g.d);  // u_{t+1}
-        const double u = lane_before(u_next, u_in);                     // u_t
-        F = H * (u + 1.0);
-        K = obs ? u / (u + 1.0) : 0.0;   // 0 at a missing observation: delta stays
-        P_next = u_next * H;
-      } else {
-        const unsigned long long obsmask = __ballot(obs);
-        const int nthis = (T - t0 < WAVE) ? (T - t0) : WAVE;
-        double Pv = P_in;
-        F = 1.0; K = 0.0;
-        for (int i = 0; i < nthis; ++i) {
-          const bool miss = !((obsmask >> i) & 1ull);
-          const double PZ = Pv, Fi = PZ + H;
-          const double Ki = miss ? 0.0 : PZ / Fi;
-          if (!miss) Pv = Pv + (-1.0) * PZ * Ki;
-          Pv = Pv + q;
-          if (lane == i) { F = Fi; K = Ki; }
+        Mob M;
+        M.a = 1.0; M.b = 0.0; M.c = 0.0; M.d = 1.0;
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          Mob mt;
+          mt.a = 1.0;
+          mt.b = obs[j] ? r * s1 : (in[j] ? r : 0.0);
+          mt.c = obs[j] ? s1 : 0.0;
+          mt.d = obs[j] ? s1 : 1.0;
+          M = mob_after(mt, M);
         }
-        P_next = Pv;  // (wave-uniform; lane 63's copy is the carry)
+        const Mob G = wave_scan(M);
+        Mob E;  // the lanes before this one
+        E.a = lane_before(G.a, 1.0);
+        E.b = lane_before(G.b, 0.0);
+        E.c = lane_before(G.c, 0.0);
+        E.d = lane_before(G.d, 1.0);
+        double u = (E.a * u_in + E.b) / (E.c * u_in + E.d);
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const double kk = u / (u + 1.0);
+          Fv[j] = H * (u + 1.0);
+          K[j] = obs[j] ? kk : 0.0;   // 0 at a missing observation: delta stays
+          u = obs[j] ? kk + r : (in[j] ? u + r : u);
+        }
+        u_in = bcast_u(u, 63);
+      } else {
+        double Pv = u_in;
+        for (int l = 0; l < WAVE; ++l) {
+          double Pl = Pv;
+#pragma unroll
+          for (int j = 0; j < BS; ++j) {
+            const double PZ = Pl, Fi = PZ + H;
+            const double Ki = obs[j] ? PZ / Fi : 0.0;
+            if (lane == l) { Fv[j] = Fi; K[j] = Ki; }
+            if (obs[j]) Pl = Pl + (-1.0) * PZ * Ki;
+            if (in[j]) Pl = Pl + q;
+          }
+          Pv = bcast_u(Pl, l);
+        }
+        u_in = Pv;
       }
-      if (__any(in && !(F > 0.0))) { status = CHAIN_FORECAST_VARIANCE; break; }
-      // ordinals of this step's normals in the stream
-      const int nb = (t == 0) ? 0 : nfirst + (t - 1) * nper;
-      const bool hasL = in && ((t == 0) ? dI : dL);
-      const double zL = hasL ? szz[nb] : 0.0;
-      const double zH = (in && dH) ? szz[nb + (hasL ? 1 : 0)] : 0.0;
-      // alpha+_0 = rnorm(a0, sqrt(P0)); alpha+_t = alpha+_{t-1} + rnorm(0, sigma_level)
-      const double inc = !in ? 0.0 : ((t == 0) ? P.a0 + sd0 * zL : level_sigma * zL);
-      const double alpha = alpha_in + wave_prefix_sum(inc);
-      const double ysim = alpha + sqrtH * zH;
-      const double w = in ? w0[t] - ysim : 0.0;
-      Aff f;
-      f.A = 1.0 - K;
-      f.B = K * w;
-      const Aff ga = wave_scan(f);
-      const double delta_next = ga.A * delta_in + ga.B;          // delta_{t+1}
-      const double delta = lane_before(delta_next, delta_in);    // delta_t
-      if (in) {
-        sal[t] = alpha;
-        sK[t] = K;
-        w0[t] = obs ? (w - delta) / F : 0.0;   // (v_t - v+_t) / F_t
+      bool badF = false;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) badF = badF || (in[j] && !(Fv[j] > 0.0));
+      if (__any(badF)) { status = CHAIN_FORECAST_VARIANCE; break; }
+      // ---- alpha+_0 = rnorm(a0, sqrt(P0)); alpha+_t = alpha+_{t-1} + rnorm(0, sigma_level)
+      double al[BS];
+      {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          const int t = tl + j;
+          acc += !in[j] ? 0.0 : ((t == 0) ? P.a0 + sd0 * zL[j] : level_sigma * zL[j]);
+          al[j] = acc;
+        }
+        const double incl = wave_prefix_sum(acc);
+        const double base = alpha_in + (incl - acc);
+#pragma unroll
+        for (int j = 0; j < BS; ++j) al[j] += base;
+        alpha_in = bcast_u(base + acc, 63);
       }
-      P_in = bcast_u(P_next, 63);
-      alpha_in = bcast_u(alpha, 63);
-      delta_in = bcast_u(delta_next, 63);
+      // ---- the filter on w = y* - y+:  delta_{t+1} = (1 - K_t) delta_t + K_t w_t
+      double w[BS];
+      Aff C;
+      C.A = 1.0; C.B = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        w[j] = in[j] ? ys[j] - (al[j] + sqrtH * zH[j]) : 0.0;
+        Aff f;
+        f.A = 1.0 - K[j];
+        f.B = K[j] * w[j];
+        C = aff_after(f, C);
+      }
+      const Aff Gd = wave_scan(C);
+      const double eA = lane_before(Gd.A, 1.0), eB = lane_before(Gd.B, 0.0);
+      double delta = eA * delta_in + eB;
+      delta_in = bcast_u(Gd.A * delta_in + Gd.B, 63);
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = tl + j;
+        if (in[j]) {
+          sal[t] = al[j];
+          sK[t] = K[j];
+          w0[t] = obs[j] ? (w[j] - delta) / Fv[j] : 0.0;   // (v_t - v+_t) / F_t
+        }
+        delta = (1.0 - K[j]) * delta + K[j] * w[j];
+      }
+      (void)rH;
     }
   }
   if (status != CHAIN_OK) {
@@ -569,21 +617,37 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
 
   KSTAMP(4);
   // ---- 5. backward: fast_disturbance_smooth for d = r - r+:
-  // d_{t-1} = e_t / F_t + (1 - K_t) d_t, d_{T-1} = 0; lane l <-> t0 + 63 - l
+  // d_{t-1} = e_t / F_t + (1 - K_t) d_t, d_{T-1} = 0; lane l owns the BS steps
+  // ending at t0 + BS (64 - l) - 1, latest first
   double d_first;  // d_{-1}
   {
     double d_in = 0.0;
-    for (int t0 = ((T - 1) / WAVE) * WAVE; t0 >= 0; t0 -= WAVE) {
-      const int t = t0 + (WAVE - 1 - lane);
-      const bool in = t < T;
-      Aff f;
-      f.A = in ? 1.0 - sK[t] : 1.0;
-      f.B = in ? w0[t] : 0.0;
-      const Aff g = wave_scan(f);
-      const double d_prev = g.A * d_in + g.B;               // d_{t-1}
-      const double d_here = lane_before(d_prev, d_in);      // d_t
-      if (in) w0[t] = d_here;
-      d_in = bcast_u(d_prev, 63);
+    const int tlast = ((T - 1) / (WAVE * BS)) * (WAVE * BS);
+    for (int t0 = tlast; t0 >= 0; t0 -= WAVE * BS) {
+      const int th = t0 + BS * (WAVE - 1 - lane) + (BS - 1);   // this lane's latest step
+      double fa[BS], fb[BS];
+      Aff C;
+      C.A = 1.0; C.B = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = th - j;
+        const bool in = t < T;
+        fa[j] = in ? 1.0 - sK[in ? t : 0] : 1.0;
+        fb[j] = in ? w0[in ? t : 0] : 0.0;
+        Aff f;
+        f.A = fa[j]; f.B = fb[j];
+        C = aff_after(f, C);
+      }
+      const Aff G = wave_scan(C);
+      const double eA = lane_before(G.A, 1.0), eB = lane_before(G.B, 0.0);
+      double d = eA * d_in + eB;                 // d_t of this lane's latest step
+      d_in = bcast_u(G.A * d_in + G.B, 63);
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = th - j;
+        if (t < T) w0[t] = d;
+        d = fa[j] * d + fb[j];                   // d_{t-1}
+      }
     }
     d_first = d_in;
   }
@@ -593,52 +657,70 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   // ---- 6. forward: mean correction m_t = E(alpha_t | y) - E(alpha_t | y+) =
   // P0 d_{-1} + q sum_{s<t} d_s, the state draw alpha+_t + m_t, and the level
   // model's sufficient statistics (LocalLevelStateModel::observe_state)
-  double lev_ss_part = 0.0;
+  // ... and, in the same pass, the regression sufficient statistics given the
+  // state (observe_data_given_state + NeRegSuf::add_mixture_data): residual
+  // e_t = y_t - alpha_t on observed t (zero elsewhere) goes to array 1 of the
+  // chain's block -- X'e for all chains is one GEMM after this kernel --
+  // yty = e'e, n = #observed
+  double lev_ss_part = 0.0, part_q = 0.0, part_n = 0.0;
   {
     double m_in = 0.0, st_in = 0.0;
-    for (int t0 = 0; t0 < T; t0 += WAVE) {
-      const int t = t0 + lane;
-      const bool in = t < T;
-      const double inc = !in ? 0.0 : ((t == 0) ? P.P0 * d_first : q * w0[t - 1]);
-      const double m = m_in + wave_prefix_sum(inc);
-      const double st = in ? sal[t] + m : 0.0;
-      const double prev = lane_before(st, st_in);
-      if (in && t > 0) {
-        const double diff = st - prev;
-        lev_ss_part += diff * diff;
+    for (int t0 = 0; t0 < T; t0 += WAVE * BS) {
+      const int tl = t0 + BS * lane;
+      // (all of the chunk's loads first: the stores below may alias them as far
+      // as the compiler knows, and would serialise them)
+      double dm[BS], al[BS], yv[BS];
+      bool inr[BS], ob[BS];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = tl + j;
+        inr[j] = t < T;
+        dm[j] = (inr[j] && t > 0) ? w0[t - 1] : 0.0;
+        al[j] = inr[j] ? sal[t] : 0.0;
+        yv[j] = inr[j] ? P.y[t] : 0.0;
+        ob[j] = inr[j] && P.observed[inr[j] ? t : 0] != 0;
       }
-      if (in) sst[t] = st;
-      m_in = bcast_u(m, 63);
-      st_in = bcast_u(st, 63);
+      double mm[BS], st[BS];
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = tl + j;
+        acc += !inr[j] ? 0.0 : ((t == 0) ? P.P0 * d_first : q * dm[j]);
+        mm[j] = acc;
+      }
+      const double incl = wave_prefix_sum(acc);
+      const double base = m_in + (incl - acc);
+      m_in = bcast_u(base + acc, 63);
+      double last = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        st[j] = inr[j] ? al[j] + (mm[j] + base) : 0.0;
+        if (inr[j]) last = st[j];
+      }
+      // the state just before this lane's first step
+      const double prev0 = lane_before(last, st_in);
+      double ev[BS];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = tl + j;
+        if (inr[j] && t > 0) {
+          const double diff = st[j] - (j == 0 ? prev0 : st[j - 1]);
+          lev_ss_part += diff * diff;
+        }
+        ev[j] = ob[j] ? yv[j] - st[j] : 0.0;
+        if (ob[j]) { part_q += ev[j] * ev[j]; part_n += 1.0; }
+      }
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int t = tl + j;
+        if (inr[j]) { sst[t] = st[j]; sF[t] = ev[j]; }
+      }
+      st_in = bcast_u(last, 63);
     }
   }
   const double lev_ss = wave_sum(lev_ss_part);
   const double lev_n = (double)(T - 1);
-  __syncthreads();
-
   KSTAMP(6);
-  // regression sufficient statistics given the state
-  // (observe_data_given_state + NeRegSuf::add_mixture_data): residual
-  // e_t = y_t - alpha_t on observed t; xty = X'e, yty = e'e, n = #observed
-  double part_q = 0.0, part_n = 0.0;
-  for (int tb = 0; tb < T; tb += NR * WAVE) {
-    double e[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int t = tb + i * WAVE + lane;
-      e[i] = 0.0;  // zero where unobserved
-      if (t < T && P.observed[t]) {
-        e[i] = P.y[t] - sst[t];
-        part_q += e[i] * e[i];
-        part_n += 1.0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int t = tb + i * WAVE + lane;
-      if (t < T) w0[t] = e[i];  // X'e for all chains is one GEMM after this kernel
-    }
-  }
   const double yty = wave_sum(part_q);
   const double nobs = wave_sum(part_n);
   if (lane == 0) {
@@ -665,10 +747,10 @@ hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                      stream, P, draw_level);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
-  // xty[chain, j] = x_j' e_chain: residual series are array 0 of every chain's
+  // xty[chain, j] = x_j' e_chain: residual series are array 1 of every chain's
   // scratch block (zero where unobserved, and for a chain in error the previous
   // sweep's -- its status stops it anyway)
-  return launch_atb_mfma(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride, P.scratch_stride,
+  return launch_atb_mfma(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.T, P.scratch_stride,
                          P.chain_count, P.X, (int64_t)P.T, P.p, P.T,
                          P.xty + (size_t)P.chain_first * P.p, P.p);
 }
