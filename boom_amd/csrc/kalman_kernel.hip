@@ -230,6 +230,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   __shared__ uint8_t s_n1_[2][NB_START];   // uniforms it consumes (0: ran out)
   __shared__ uint16_t s_j_[2][NLEV][NB_START];  // jump tables of the stream walk
   __shared__ uint16_t s_slow_[2][NB_START];  // offsets whose draw leaves the first branch
+  __shared__ double s_x[2][8];             // the two waves' scan totals, swapped at the seam between their stretches
   __shared__ int s_hand[4];                // entry offset of the next window, draws so far, done, status
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double *s_u = s_u_[wave];
@@ -406,17 +407,50 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         wave_lds_sync();
       }
       KSTAMP(10);
-      // the look-ups, in window order: wave 0's window, then wave 1's
+      // The hand-off, in window order (wave 0's window, then wave 1's), is only
+      // the reader's way THROUGH the window -- how many draws start inside it and
+      // where it leaves -- found by one descent over the jump tables (the largest
+      // number of draws that stay inside, level by level); the look-ups that find
+      // and write the draws themselves follow outside the chain, both waves at once.
+      int my_entry = 0, my_n = 0, my_m = 0;
       for (int turn = 0; turn < 2; ++turn) {
         __syncthreads();
         if (turn != wave || s_hand[2]) continue;
-        const int entry = s_hand[0], n = s_hand[1];
+        const int entry = __builtin_amdgcn_readfirstlane(s_hand[0]);
+        const int n = __builtin_amdgcn_readfirstlane(s_hand[1]);
         const int want = N - n;
-        int m = 0, o = entry;
-        int node[NORD];
-        bool ok[NORD];
+        int o = entry, cnt = 0;
 #pragma unroll
-        for (int i = 0; i < NORD; ++i) node[i] = entry;
+        for (int k = NLEV - 1; k >= 0; --k) {
+          const int nx = __builtin_amdgcn_readfirstlane((int)s_j[k][o]);
+          if (nx < NB_START) { o = nx; cnt += 1 << k; }
+        }
+        int m = cnt + 1;                                   // draws that start inside the window
+        int ex = __builtin_amdgcn_readfirstlane((int)s_j[0][o]);   // where the last of them ends
+        const bool finished = (m >= want);
+        if (finished) {  // the sweep's last draw is in this window: the position after `want` draws
+          m = want;
+          ex = entry;
+#pragma unroll
+          for (int k = 0; k < NLEV; ++k)
+            if ((want >> k) & 1) ex = __builtin_amdgcn_readfirstlane((int)s_j[k][ex < NB_START ? ex : 0]);
+        }
+        // a draw longer than the margin would break the fixed windows
+        const bool broken = (ex == JT) || (!finished && ex < NB_START);
+        if (lane == 0) {
+          s_hand[0] = ex - NB_START;
+          s_hand[1] = n + m;
+          s_hand[2] = finished || broken;
+          if (broken) s_hand[3] = CHAIN_RNG_BRANCH;
+          if (finished && !broken) P.pos_state[chain] = wstart + (uint64_t)ex;  // stream position after the sweep's last draw
+        }
+        my_entry = entry; my_n = n; my_m = broken ? 0 : m;
+      }
+      if (my_m > 0) {
+        // draw number r of the window starts where the bits of r lead from the entry
+        int node[NORD];
+#pragma unroll
+        for (int i = 0; i < NORD; ++i) node[i] = my_entry;
 #pragma unroll
         for (int k = 0; k < NLEV; ++k) {
           int nx[NORD];
@@ -428,40 +462,10 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
             if ((r >> k) & 1) node[i] = (node[i] < NB_START) ? nx[i] : JT;
           }
         }
-        int u1[NORD];
-        double zr[NORD];
-#pragma unroll
-        for (int i = 0; i < NORD; ++i) {
-          const int nd = node[i] < NB_START ? node[i] : 0;
-          u1[i] = s_n1[nd];
-          zr[i] = s_z[nd];
-        }
 #pragma unroll
         for (int i = 0; i < NORD; ++i) {
           const int r = lane + i * WAVE;
-          ok[i] = node[i] < NB_START && u1[i] > 0 && r < want;
-          if (ok[i]) szz[n + r] = zr[i];
-          m += __popcll(__ballot(ok[i]));
-          node[i] = ok[i] ? node[i] + u1[i] : 0;  // where the draw after this one starts
-        }
-        // the window's draws are numbers 0 .. m-1; the reader leaves it after the last
-        if (m > 0) {
-          const int li = (m - 1) >> 6, ll = (m - 1) & 63;
-#pragma unroll
-          for (int i = 0; i < NORD; ++i)
-            if (i == li) o = __builtin_amdgcn_readlane(node[i], ll);
-        }
-        const bool finished = (n + m >= N);
-        // a draw longer than the margin would break the fixed windows
-        const bool broken = !finished && (m == 0 || o < NB_START);
-        if (lane == 0) {
-          s_hand[0] = o - NB_START;
-          s_hand[1] = n + m;
-          s_hand[2] = finished || broken;
-          if (broken) s_hand[3] = CHAIN_RNG_BRANCH;
-          if (finished) {  // stream position after the sweep's last draw
-            P.pos_state[chain] = wstart + (uint64_t)o;
-          }
+          if (r < my_m && node[i] < NB_START) szz[my_n + r] = s_z[node[i]];
         }
       }
       __syncthreads();
@@ -469,38 +473,38 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
     }
     status = s_hand[3];
   }
-  if (wave != 0) return;  // (wave 0's later barriers only count live waves)
-  if (status != CHAIN_OK) {
-    if (lane == 0) P.status[chain] = status;
+  if (status != CHAIN_OK) {   // (s_hand[3]: the same in both waves)
+    if (threadIdx.x == 0) P.status[chain] = status;
     return;
   }
   __syncthreads();
   KSTAMP(2);
-  // ---- 3 + 4. forward pass over chunks of 64 steps.
+  // ---- 3 + 4. forward pass.
   // Variances (ScalarMarginalDistribution::update, the part that does not look
   // at the data): P_{t+1} = P_t - P_t^2 / (P_t + H) + q at an observed step,
   // P_t + q at a missing one.  In units of H (u = P / H, r = q / H) that is the
   // Moebius map u -> ((1 + r) u + r) / (u + 1), resp. u + r, so its composition
-  // over a chunk is a scan of 2 x 2 matrices (divided by 1 + r: determinant 1,
-  // entries <= 1, spectral radius within [1, 1.34], no over- or underflow)
-  // applied to the chunk's incoming u.  Then F_t = H (u_t + 1), K_t = u_t /
-  // (u_t + 1); simulate_initial_state / simulate_next_state
-  // (alpha+), simulate_adjusted_observation (y+), and the filter on w = y* - y+.
+  // over any stretch of time is a product of 2 x 2 matrices (divided by 1 + r:
+  // determinant 1, entries <= 1, no over- or underflow) applied to the incoming
+  // u.  Then F_t = H (u_t + 1), K_t = u_t / (u_t + 1); simulate_initial_state /
+  // simulate_next_state (alpha+), simulate_adjusted_observation (y+), and the
+  // filter on w = y* - y+.
+  //
+  // Every pass below gives a lane BS CONSECUTIVE time steps and a wave 64 BS of
+  // them; a chunk is the two waves' stretches side by side (wave 0 first in scan
+  // order).  A lane composes its own steps' maps serially, ONE wave scan combines
+  // the lanes' composites, the two waves swap their totals through LDS (one
+  // barrier), and each lane walks its steps again from the value this hands it.
+  // That is ~1/BS of the scan work of a lane-per-step pass, on both waves.
   KSTAMP(3);
-  // Every pass below gives a lane BS CONSECUTIVE time steps (a chunk = 64 BS
-  // steps): the lane composes its own steps' maps serially, ONE wave scan per
-  // chunk combines the lanes' composites, and the lane walks its steps again from
-  // the value the scan hands it.  The kernel is bound by instruction issue (two
-  // waves per SIMD, both busy), and this cuts the instructions of a pass by the
-  // factor the scan's 6 DPP rounds no longer repeat for every 64 steps.
-  constexpr int BS = 8;
+  constexpr int BS = 8, WS = WAVE * BS, CS = 2 * WS;   // steps per lane, per wave, per chunk
   {
     const bool moebius = H > 0.0;  // (H == 0: the plain recursion, lane after lane)
-    const double r = moebius ? q / H : 0.0, s1 = 1.0 / (1.0 + r), rH = moebius ? 1.0 / H : 0.0;
+    const double r = moebius ? q / H : 0.0, s1 = 1.0 / (1.0 + r);
     double u_in = moebius ? P.P0 / H : P.P0;   // variance carried in units of H (of 1 when H == 0)
     double alpha_in = 0.0, delta_in = 0.0;
-    for (int t0 = 0; t0 < T; t0 += WAVE * BS) {
-      const int tl = t0 + BS * lane;
+    for (int t0 = 0; t0 < T; t0 += CS) {
+      const int tl = t0 + WS * wave + BS * lane;
       bool in[BS], obs[BS];
       double zL[BS], zH[BS], ys[BS];
 #pragma unroll
@@ -514,27 +518,46 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         zH[j] = (in[j] && dH) ? szz[nb + (hasL ? 1 : 0)] : 0.0;
         ys[j] = in[j] ? w0[t] : 0.0;
       }
-      // ---- variances: u_{t+1} = ((1 + r) u_t + r) / (u_t + 1) at an observed step,
-      // u_t + r at a missing one; K_t = u_t / (u_t + 1), so u_{t+1} = K_t + r
+      // ---- what does not depend on the carries: the lane's composite variance
+      // map and its partial sums of the simulated state's increments
+      Mob M;
+      M.a = 1.0; M.b = 0.0; M.c = 0.0; M.d = 1.0;
+      double al[BS], asum = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        Mob mt;
+        mt.a = 1.0;
+        mt.b = obs[j] ? r * s1 : (in[j] ? r : 0.0);
+        mt.c = obs[j] ? s1 : 0.0;
+        mt.d = obs[j] ? s1 : 1.0;
+        M = mob_after(mt, M);
+        // alpha+_0 = rnorm(a0, sqrt(P0)); alpha+_t = alpha+_{t-1} + rnorm(0, sigma_level)
+        const int t = tl + j;
+        asum += !in[j] ? 0.0 : ((t == 0) ? P.a0 + sd0 * zL[j] : level_sigma * zL[j]);
+        al[j] = asum;
+      }
+      Mob G;
+      G.a = 1.0; G.b = 0.0; G.c = 0.0; G.d = 1.0;
+      if (moebius) G = wave_scan(M);
+      const double aincl = wave_prefix_sum(asum);
+      if (lane == WAVE - 1) {
+        s_x[wave][0] = G.a; s_x[wave][1] = G.b; s_x[wave][2] = G.c; s_x[wave][3] = G.d;
+        s_x[wave][4] = aincl;
+      }
+      __syncthreads();
+      Mob G0, G1;   // the two waves' totals
+      G0.a = s_x[0][0]; G0.b = s_x[0][1]; G0.c = s_x[0][2]; G0.d = s_x[0][3];
+      G1.a = s_x[1][0]; G1.b = s_x[1][1]; G1.c = s_x[1][2]; G1.d = s_x[1][3];
+      const double a0tot = s_x[0][4], a1tot = s_x[1][4];
+      // ---- variances: K_t = u_t / (u_t + 1), so u_{t+1} = K_t + r
       double K[BS], Fv[BS];
       if (moebius) {
-        Mob M;
-        M.a = 1.0; M.b = 0.0; M.c = 0.0; M.d = 1.0;
-#pragma unroll
-        for (int j = 0; j < BS; ++j) {
-          Mob mt;
-          mt.a = 1.0;
-          mt.b = obs[j] ? r * s1 : (in[j] ? r : 0.0);
-          mt.c = obs[j] ? s1 : 0.0;
-          mt.d = obs[j] ? s1 : 1.0;
-          M = mob_after(mt, M);
-        }
-        const Mob G = wave_scan(M);
-        Mob E;  // the lanes before this one
+        Mob E;  // the lanes before this one (in this wave, and all of wave 0 for wave 1)
         E.a = lane_before(G.a, 1.0);
         E.b = lane_before(G.b, 0.0);
         E.c = lane_before(G.c, 0.0);
         E.d = lane_before(G.d, 1.0);
+        if (wave == 1) E = mob_after(E, G0);
         double u = (E.a * u_in + E.b) / (E.c * u_in + E.d);
 #pragma unroll
         for (int j = 0; j < BS; ++j) {
@@ -543,42 +566,43 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
           K[j] = obs[j] ? kk : 0.0;   // 0 at a missing observation: delta stays
           u = obs[j] ? kk + r : (in[j] ? u + r : u);
         }
-        u_in = bcast_u(u, 63);
+        const Mob GT = mob_after(G1, G0);
+        u_in = (GT.a * u_in + GT.b) / (GT.c * u_in + GT.d);
       } else {
+        // lane after lane, wave 0 then wave 1 (both waves run all of it; a wave
+        // keeps the values of its own lanes)
         double Pv = u_in;
-        for (int l = 0; l < WAVE; ++l) {
-          double Pl = Pv;
+        for (int hw = 0; hw < 2; ++hw) {
+          for (int l = 0; l < WAVE; ++l) {
+            // (the stretch of lane l of wave hw: flags come from its owner through LDS)
+            const int tb = t0 + WS * hw + BS * l;
+            double Pl = Pv;
 #pragma unroll
-          for (int j = 0; j < BS; ++j) {
-            const double PZ = Pl, Fi = PZ + H;
-            const double Ki = obs[j] ? PZ / Fi : 0.0;
-            if (lane == l) { Fv[j] = Fi; K[j] = Ki; }
-            if (obs[j]) Pl = Pl + (-1.0) * PZ * Ki;
-            if (in[j]) Pl = Pl + q;
+            for (int j = 0; j < BS; ++j) {
+              const int t = tb + j;
+              const bool inx = t < T;
+              const bool obx = inx && P.observed[inx ? t : 0] != 0;
+              const double PZ = Pl, Fi = PZ + H;
+              const double Ki = obx ? PZ / Fi : 0.0;
+              if (hw == wave && lane == l) { Fv[j] = Fi; K[j] = Ki; }
+              if (obx) Pl = Pl + (-1.0) * PZ * Ki;
+              if (inx) Pl = Pl + q;
+            }
+            Pv = Pl;
           }
-          Pv = bcast_u(Pl, l);
         }
         u_in = Pv;
       }
       bool badF = false;
 #pragma unroll
       for (int j = 0; j < BS; ++j) badF = badF || (in[j] && !(Fv[j] > 0.0));
-      if (__any(badF)) { status = CHAIN_FORECAST_VARIANCE; break; }
-      // ---- alpha+_0 = rnorm(a0, sqrt(P0)); alpha+_t = alpha+_{t-1} + rnorm(0, sigma_level)
-      double al[BS];
+      const bool anybad = __any(badF) != 0;
+      // ---- alpha+ with the carries in
       {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < BS; ++j) {
-          const int t = tl + j;
-          acc += !in[j] ? 0.0 : ((t == 0) ? P.a0 + sd0 * zL[j] : level_sigma * zL[j]);
-          al[j] = acc;
-        }
-        const double incl = wave_prefix_sum(acc);
-        const double base = alpha_in + (incl - acc);
+        const double base = alpha_in + (wave == 1 ? a0tot : 0.0) + (aincl - asum);
 #pragma unroll
         for (int j = 0; j < BS; ++j) al[j] += base;
-        alpha_in = bcast_u(base + acc, 63);
+        alpha_in += a0tot + a1tot;
       }
       // ---- the filter on w = y* - y+:  delta_{t+1} = (1 - K_t) delta_t + K_t w_t
       double w[BS];
@@ -593,9 +617,26 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         C = aff_after(f, C);
       }
       const Aff Gd = wave_scan(C);
-      const double eA = lane_before(Gd.A, 1.0), eB = lane_before(Gd.B, 0.0);
-      double delta = eA * delta_in + eB;
-      delta_in = bcast_u(Gd.A * delta_in + Gd.B, 63);
+      __syncthreads();   // (everyone has read the first exchange)
+      if (lane == WAVE - 1) {
+        s_x[wave][0] = Gd.A; s_x[wave][1] = Gd.B; s_x[wave][2] = anybad ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      Aff D0, D1;
+      D0.A = s_x[0][0]; D0.B = s_x[0][1];
+      D1.A = s_x[1][0]; D1.B = s_x[1][1];
+      const bool bad_any = (s_x[0][2] != 0.0) || (s_x[1][2] != 0.0);
+      __syncthreads();   // (... and the second, before the next chunk overwrites it)
+      if (bad_any) { status = CHAIN_FORECAST_VARIANCE; break; }
+      Aff Ed;
+      Ed.A = lane_before(Gd.A, 1.0);
+      Ed.B = lane_before(Gd.B, 0.0);
+      if (wave == 1) Ed = aff_after(Ed, D0);
+      double delta = Ed.A * delta_in + Ed.B;
+      {
+        const Aff DT = aff_after(D1, D0);
+        delta_in = DT.A * delta_in + DT.B;
+      }
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
         const int t = tl + j;
@@ -606,25 +647,25 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         }
         delta = (1.0 - K[j]) * delta + K[j] * w[j];
       }
-      (void)rH;
     }
   }
   if (status != CHAIN_OK) {
-    if (lane == 0) P.status[chain] = status;
+    if (threadIdx.x == 0) P.status[chain] = status;
     return;
   }
   __syncthreads();
 
   KSTAMP(4);
   // ---- 5. backward: fast_disturbance_smooth for d = r - r+:
-  // d_{t-1} = e_t / F_t + (1 - K_t) d_t, d_{T-1} = 0; lane l owns the BS steps
-  // ending at t0 + BS (64 - l) - 1, latest first
+  // d_{t-1} = e_t / F_t + (1 - K_t) d_t, d_{T-1} = 0; latest steps first: wave 0
+  // has the later half of a chunk, lane l of a wave the BS steps ending at
+  // (its wave's end) - BS l - 1
   double d_first;  // d_{-1}
   {
     double d_in = 0.0;
-    const int tlast = ((T - 1) / (WAVE * BS)) * (WAVE * BS);
-    for (int t0 = tlast; t0 >= 0; t0 -= WAVE * BS) {
-      const int th = t0 + BS * (WAVE - 1 - lane) + (BS - 1);   // this lane's latest step
+    const int tlast = ((T - 1) / CS) * CS;
+    for (int t0 = tlast; t0 >= 0; t0 -= CS) {
+      const int th = t0 + CS - 1 - WS * wave - BS * lane;   // this lane's latest step
       double fa[BS], fb[BS];
       Aff C;
       C.A = 1.0; C.B = 0.0;
@@ -639,9 +680,21 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         C = aff_after(f, C);
       }
       const Aff G = wave_scan(C);
-      const double eA = lane_before(G.A, 1.0), eB = lane_before(G.B, 0.0);
-      double d = eA * d_in + eB;                 // d_t of this lane's latest step
-      d_in = bcast_u(G.A * d_in + G.B, 63);
+      if (lane == WAVE - 1) { s_x[wave][0] = G.A; s_x[wave][1] = G.B; }
+      __syncthreads();
+      Aff D0, D1;
+      D0.A = s_x[0][0]; D0.B = s_x[0][1];
+      D1.A = s_x[1][0]; D1.B = s_x[1][1];
+      __syncthreads();
+      Aff E;
+      E.A = lane_before(G.A, 1.0);
+      E.B = lane_before(G.B, 0.0);
+      if (wave == 1) E = aff_after(E, D0);
+      double d = E.A * d_in + E.B;                 // d_t of this lane's latest step
+      {
+        const Aff DT = aff_after(D1, D0);
+        d_in = DT.A * d_in + DT.B;
+      }
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
         const int t = th - j;
@@ -665,8 +718,8 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   double lev_ss_part = 0.0, part_q = 0.0, part_n = 0.0;
   {
     double m_in = 0.0, st_in = 0.0;
-    for (int t0 = 0; t0 < T; t0 += WAVE * BS) {
-      const int tl = t0 + BS * lane;
+    for (int t0 = 0; t0 < T; t0 += CS) {
+      const int tl = t0 + WS * wave + BS * lane;
       // (all of the chunk's loads first: the stores below may alias them as far
       // as the compiler knows, and would serialise them)
       double dm[BS], al[BS], yv[BS];
@@ -689,16 +742,26 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         mm[j] = acc;
       }
       const double incl = wave_prefix_sum(acc);
-      const double base = m_in + (incl - acc);
-      m_in = bcast_u(base + acc, 63);
+      // the state's value at a wave's last step needs the other wave's sum first:
+      // swap the sums, then (below) the states at the seams
+      if (lane == WAVE - 1) s_x[wave][0] = incl;
+      __syncthreads();
+      const double m0tot = s_x[0][0], m1tot = s_x[1][0];
+      const double base = m_in + (wave == 1 ? m0tot : 0.0) + (incl - acc);
+      m_in += m0tot + m1tot;
       double last = 0.0;
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
         st[j] = inr[j] ? al[j] + (mm[j] + base) : 0.0;
         if (inr[j]) last = st[j];
       }
+      if (lane == WAVE - 1) s_x[wave][1] = last;
+      __syncthreads();
+      const double seam0 = s_x[0][1], seam1 = s_x[1][1];   // states at the two waves' last steps
+      __syncthreads();
       // the state just before this lane's first step
-      const double prev0 = lane_before(last, st_in);
+      const double prev0 = lane_before(last, wave == 1 ? seam0 : st_in);
+      st_in = seam1;
       double ev[BS];
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
@@ -715,14 +778,20 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         const int t = tl + j;
         if (inr[j]) { sst[t] = st[j]; sF[t] = ev[j]; }
       }
-      st_in = bcast_u(last, 63);
     }
   }
-  const double lev_ss = wave_sum(lev_ss_part);
+  // the two waves' partial sums
+  {
+    const double a = wave_sum(lev_ss_part), b2 = wave_sum(part_q), c = wave_sum(part_n);
+    if (lane == 0) { s_x[wave][0] = a; s_x[wave][1] = b2; s_x[wave][2] = c; }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  const double lev_ss = s_x[0][0] + s_x[1][0];
   const double lev_n = (double)(T - 1);
   KSTAMP(6);
-  const double yty = wave_sum(part_q);
-  const double nobs = wave_sum(part_n);
+  const double yty = s_x[0][1] + s_x[1][1];
+  const double nobs = s_x[0][2] + s_x[1][2];
   if (lane == 0) {
     P.yty[chain] = yty;
     P.nobs[chain] = nobs;
