@@ -1090,6 +1090,244 @@ void bo_breg_prior_ctor2(int p, const double *xtx, double n, double sumy,
   if (force_intercept) pi[0] = 1.0;
 }
 
+/* ====================================================================== */
+/*     AdaptiveSpikeSlabRegressionSampler (birth / death moves, rates)     */
+/* ====================================================================== */
+/* Models/Glm/PosteriorSamplers/AdaptiveSpikeSlabRegressionSampler.cpp:62-225:
+ * what lm.spike uses for more than 100 predictors.  Works on a bo_ssvs (same
+ * sufficient statistics, priors, state and stream), plus the adaptive birth /
+ * death rates. */
+struct bo_adaptive {
+  bo_ssvs *s;
+  double *birth, *death;     /* birth_rates_, death_rates_ (all 1 at the start) */
+  int max_flips;             /* max_flips_ = 100 */
+  int allow_model_selection;
+  uint64_t iteration;        /* iteration_count_ */
+  double step, target;       /* step_size_ = .001, target_acceptance_rate_ = .345 */
+  double cur_logp;           /* current_log_model_prob_ */
+  /* set_posterior_moments' members */
+  double ldoi, DF, SS;
+  int k;
+  /* smallest |log u - log MH ratio| and smallest relative distance of an
+   * rmulti uniform from a boundary of its cumulative sums (decision margins) */
+  double min_margin, min_multi_margin;
+};
+
+bo_adaptive *bo_adaptive_create(bo_ssvs *s) {
+  bo_adaptive *a = (bo_adaptive *)xcalloc(1, sizeof(bo_adaptive));
+  a->s = s;
+  a->birth = (double *)xcalloc(s->p, sizeof(double));
+  a->death = (double *)xcalloc(s->p, sizeof(double));
+  for (int j = 0; j < s->p; ++j) a->birth[j] = a->death[j] = 1.0;
+  a->max_flips = 100;
+  a->allow_model_selection = 1;
+  a->step = .001;
+  a->target = .345;
+  a->cur_logp = BO_NEG_INF;
+  a->min_margin = INFINITY;
+  a->min_multi_margin = INFINITY;
+  return a;
+}
+void bo_adaptive_destroy(bo_adaptive *a) {
+  if (!a) return;
+  free(a->birth);
+  free(a->death);
+  free(a);
+}
+void bo_adaptive_set_options(bo_adaptive *a, int max_flips, double step,
+                             double target) {
+  if (max_flips >= 0) a->max_flips = max_flips;
+  if (step > 0) a->step = step;
+  if (target > 0) a->target = target;
+}
+void bo_adaptive_get_rates(const bo_adaptive *a, double *birth, double *death) {
+  memcpy(birth, a->birth, sizeof(double) * a->s->p);
+  memcpy(death, a->death, sizeof(double) * a->s->p);
+}
+double bo_adaptive_min_margin(const bo_adaptive *a) { return a->min_margin; }
+double bo_adaptive_min_multi_margin(const bo_adaptive *a) { return a->min_multi_margin; }
+
+/* set_posterior_moments, .cpp:129-151 (posterior mean into s->pm, unscaled
+ * posterior precision into s->V) */
+static void adaptive_set_posterior_moments(bo_adaptive *a, const uint8_t *g) {
+  bo_ssvs *s = a->s;
+  int *idx = s->g;
+  int k = gather_index(s, g, idx);
+  a->k = s->k = k;
+  double *Om = s->M1, *V = s->V, *mu = s->w1, *rhs = s->w2;
+  select_spd(s->ominv, s->p, idx, k, Om);
+  int ok;
+  a->ldoi = bo_spd_logdet(k, Om, &ok);
+  for (int i = 0; i < k; ++i) mu[i] = s->b[idx[i]];
+  select_spd(s->xtx, s->p, idx, k, V);
+  for (size_t i = 0; i < (size_t)k * k; ++i) V[i] = Om[i] + V[i];
+  /* xty_g + Omega^{-1}_g mu_g */
+  for (int i = 0; i < k; ++i) {
+    double t = 0;
+    for (int j = 0; j < k; ++j) t += Om[IDX(i, j, k)] * mu[j];
+    rhs[i] = s->xty[idx[i]] + t;
+  }
+  bo_spd_solve(k, V, rhs, s->pm);
+  a->DF = s->prior_df + s->n;
+  /* relative_sse(GlmCoefs(posterior_mean, inc)): yty + b'XtX_g b - 2 b'xty_g
+   * (RegressionModel.cpp:59-70) */
+  double sse = s->yty;
+  if (k > 0) {
+    double quad = 0, lin = 0;
+    for (int i = 0; i < k; ++i) {
+      double t = 0;
+      for (int j = 0; j < k; ++j) t += s->xtx[IDX(idx[i], idx[j], s->p)] * s->pm[j];
+      quad += s->pm[i] * t;
+      lin += s->pm[i] * s->xty[idx[i]];
+    }
+    sse += quad - 2 * lin;
+  }
+  double *d = s->w3;
+  for (int i = 0; i < k; ++i) d[i] = s->pm[i] - mu[i];
+  a->SS = s->prior_ss + sse + bo_spd_mdist(k, Om, d);
+}
+
+/* log_model_prob, .cpp:87-126 (the memo map returns what a recomputation
+ * returns: the value is a function of gamma alone) */
+static double adaptive_log_model_prob(bo_adaptive *a, const uint8_t *g) {
+  bo_ssvs *s = a->s;
+  int nvars = 0;
+  for (int j = 0; j < s->p; ++j) nvars += g[j];
+  if (nvars == 0) {
+    double ss = s->yty + s->prior_ss;
+    double df = s->n + s->prior_df;
+    return spike_logp(s, g, nvars) - (.5 * df - 1) * log(ss);
+  }
+  double ans = spike_logp(s, g, nvars);
+  if (ans == BO_NEG_INF) return ans;
+  adaptive_set_posterior_moments(a, g);
+  if (a->ldoi <= BO_NEG_INF) return BO_NEG_INF;
+  int ok;
+  double ldv = bo_spd_logdet(a->k, s->V, &ok);
+  ans += .5 * (a->ldoi - ldv) - (.5 * a->DF - 1) * log(a->SS);
+  return ans;
+}
+
+/* rmulti_mt on a weight vector (distributions/rmulti.cpp:41-78), recording
+ * how close the uniform came to a boundary */
+static int adaptive_rmulti(bo_adaptive *a, const double *w, int n, int *status) {
+  double probsum = 0;
+  for (int i = 0; i < n; ++i) probsum += w[i];
+  if (!isfinite(probsum) || probsum <= 0) {
+    *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+    return 0;
+  }
+  double tmp = bo_runif(&a->s->rng, 0, probsum);
+  double psum = 0;
+  int ans = -1;
+  for (int i = 0; i < n; ++i) {
+    psum += w[i];
+    double m = fabs(tmp - psum) / probsum;
+    if (m < a->min_multi_margin) a->min_multi_margin = m;
+    if (ans < 0 && tmp <= psum) ans = i;
+  }
+  if (ans < 0) {
+    *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+    return 0;
+  }
+  return ans;
+}
+
+static void adaptive_adjust(bo_adaptive *a, double *rate, double mh_alpha) {
+  if (mh_alpha > 1.0) mh_alpha = 1.0;
+  double adjustment = a->step / ((1.0 + (double)a->iteration) / a->s->p);
+  adjustment *= (mh_alpha - a->target);
+  *rate *= exp(adjustment);
+}
+
+/* birth_move (.cpp:165-192) when birth != 0, death_move (.cpp:202-226) otherwise */
+static void adaptive_move(bo_adaptive *a, uint8_t *g, int birth, int *status) {
+  bo_ssvs *s = a->s;
+  const int p = s->p;
+  const double *from = birth ? a->birth : a->death;   /* rates of the candidates */
+  const double *back = birth ? a->death : a->birth;   /* rates of the reverse move */
+  int *cand = s->g;   /* candidate variables, ascending */
+  double *w = s->w1;
+  int m = 0;
+  for (int j = 0; j < p; ++j)
+    if ((g[j] != 0) != (birth != 0)) { cand[m] = j; w[m] = from[j]; ++m; }
+  if (m == 0) return;
+  int which = adaptive_rmulti(a, w, m, status);
+  if (*status) return;
+  const int j = cand[which];
+  double wsum = 0;
+  for (int i = 0; i < m; ++i) wsum += w[i];
+  const double wj = w[which];
+  g[j] = (uint8_t)(birth ? 1 : 0);
+  const double cand_logp = adaptive_log_model_prob(a, g);
+  const double num = cand_logp - log(wj / wsum);
+  /* the reverse move's candidates: the new model's included (birth) or excluded
+   * (death) variables, summed in index order (Selector::sparse_sum) */
+  double bsum = 0;
+  for (int i = 0; i < p; ++i)
+    if ((g[i] != 0) == (birth != 0)) bsum += back[i];
+  const double den = a->cur_logp - log(back[j] / bsum);
+  const double ratio = num - den;
+  const double logu = log(bo_runif(&s->rng, 0, 1));
+  const double margin = fabs(logu - ratio);
+  if (margin < a->min_margin) a->min_margin = margin;
+  if (logu < ratio) {
+    a->cur_logp = cand_logp;
+    adaptive_adjust(a, birth ? &a->birth[j] : &a->death[j], exp(ratio));
+  } else {
+    g[j] = (uint8_t)(birth ? 0 : 1);
+  }
+}
+
+/* draw(), .cpp:62-85 */
+int bo_adaptive_draw(bo_adaptive *a) {
+  bo_ssvs *s = a->s;
+  int status = 0;
+  uint8_t *g = (uint8_t *)malloc(s->p);
+  memcpy(g, s->gamma, s->p);
+  if (a->allow_model_selection) {
+    int flips = a->max_flips < s->p ? a->max_flips : s->p;
+    a->cur_logp = adaptive_log_model_prob(a, g);
+    for (int i = 0; i < flips && !status; ++i) {
+      double u = bo_runif(&s->rng, 0, 1);
+      adaptive_move(a, g, u < .5, &status);
+    }
+    /* coef().set_inc: excluded coefficients are zeroed (GlmCoefs.cpp:89-94) */
+    memcpy(s->gamma, g, s->p);
+    for (int j = 0; j < s->p; ++j)
+      if (!g[j]) s->beta[j] = 0.0;
+  }
+  if (!status) {
+    adaptive_set_posterior_moments(a, g);
+    s->DF = a->DF;
+    s->SS = a->SS;
+    /* draw_residual_variance, .cpp:158-163 */
+    s->sigsq = variance_draw(&s->rng, s->prior_df, s->prior_ss, s->sigma_max,
+                             a->DF - s->prior_df, a->SS - s->prior_ss, &status);
+  }
+  if (!status && a->k > 0) {
+    /* draw_coefficients: rmvn_ivar_mt(mean, V / sigsq) (mvn.cpp:103-122) */
+    int k = a->k;
+    double *P = s->M1, *L = s->M2;
+    for (size_t i = 0; i < (size_t)k * k; ++i) P[i] = s->V[i] / s->sigsq;
+    if (!bo_chol(k, P, L)) {
+      status = BO_ERR_NOT_PD;
+    } else {
+      double *z = s->w1;
+      for (int i = 0; i < k; ++i) z[i] = bo_rnorm(&s->rng, 0, 1);
+      ltsolve_inplace(k, L, z);
+      memset(s->beta, 0, sizeof(double) * s->p);
+      for (int j = 0, c = 0; j < s->p; ++j)
+        if (g[j]) { s->beta[j] = z[c] + s->pm[c]; ++c; }
+    }
+  } else if (!status) {
+    memset(s->beta, 0, sizeof(double) * s->p);
+  }
+  free(g);
+  ++a->iteration;
+  return status;
+}
+
 /* ---- many chains (cpu_baseline leg) ------------------------------------ */
 typedef struct {
   int p;

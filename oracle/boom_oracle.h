@@ -197,6 +197,18 @@ int bo_ss_impute_state(bo_ss *m, bo_rng *rng);
 /* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64 */
 int bo_ss_draw(bo_ss *m);
 
+/* AdaptiveSpikeSlabRegressionSampler on top of a bo_ssvs
+ * (AdaptiveSpikeSlabRegressionSampler.cpp:62-225) */
+typedef struct bo_adaptive bo_adaptive;
+bo_adaptive *bo_adaptive_create(bo_ssvs *s);
+void bo_adaptive_destroy(bo_adaptive *a);
+void bo_adaptive_set_options(bo_adaptive *a, int max_flips, double step,
+                             double target);
+void bo_adaptive_get_rates(const bo_adaptive *a, double *birth, double *death);
+double bo_adaptive_min_margin(const bo_adaptive *a);
+double bo_adaptive_min_multi_margin(const bo_adaptive *a);
+int bo_adaptive_draw(bo_adaptive *a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@
 #include "LinAlg/SpdMatrix.hpp"
 #include "LinAlg/Vector.hpp"
 #include "Models/ChisqModel.hpp"
+#include "Models/Glm/PosteriorSamplers/AdaptiveSpikeSlabRegressionSampler.hpp"
 #include "Models/Glm/PosteriorSamplers/BregVsSampler.hpp"
 #include "Models/Glm/PosteriorSamplers/SpikeSlabSampler.hpp"
 #include "Models/Glm/WeightedRegressionModel.hpp"
@@ -266,6 +267,43 @@ int ref_ssvs_run(int n, int p, const double *X, const double *y,
   NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
   NEW(BregVsSampler, sampler)(model.get(), slab, siginv_prior, spike);
   apply_options(*sampler, spike, opt);
+  model->set_method(sampler);
+  model->coef().drop_all();
+  for (int j = 0; j < p; ++j) {
+    if (init_gamma[j]) model->coef().add(j);
+  }
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    record(*model, p, i, out_gamma, out_beta, out_sigsq);
+  }
+  REF_CATCH
+}
+
+// ---- AdaptiveSpikeSlabRegressionSampler (what lm.spike uses for p > 100)
+//      Models/Glm/PosteriorSamplers/AdaptiveSpikeSlabRegressionSampler.cpp:62-225
+int ref_adaptive_run(int n, int p, const double *xtx, const double *xty, double yty,
+                     double ybar, const double *xbar, const double *prior_mean,
+                     const double *ominv, double prior_df, double sigma_guess,
+                     const double *pi, int64_t max_model_size,
+                     double sigma_upper_limit, int max_flips, double step_size,
+                     double target_acceptance_rate, uint64_t seed,
+                     const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                     double *out_beta, double *out_sigsq) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  NEW(NeRegSuf, suf)(make_spd(p, xtx), make_vector(p, xty), yty, (double)n, ybar,
+                     make_vector(p, xbar));
+  Ptr<RegressionModel> model(new RegressionModel(Ptr<RegSuf>(suf)));
+  NEW(MvnGivenScalarSigma, slab)(make_vector(p, prior_mean), make_spd(p, ominv),
+                                 model->Sigsq_prm());
+  NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
+  NEW(AdaptiveSpikeSlabRegressionSampler, sampler)(model.get(), slab, siginv_prior, spike);
+  if (std::isfinite(sigma_upper_limit)) sampler->set_sigma_upper_limit(sigma_upper_limit);
+  if (max_flips >= 0) sampler->limit_model_selection(max_flips);
+  if (step_size > 0) sampler->set_step_size(step_size);
+  if (target_acceptance_rate > 0) sampler->set_target_acceptance_rate(target_acceptance_rate);
   model->set_method(sampler);
   model->coef().drop_all();
   for (int j = 0; j < p; ++j) {

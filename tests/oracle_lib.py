@@ -368,6 +368,64 @@ class Oracle:
         return dict(b=b, ominv=om.reshape(p, p).T.copy(), pi=pi, df=df.value,
                     sigma_guess=sg.value)
 
+    def adaptive_run(self, suf, prior, opts, rng_setup, init_gamma, nsweeps,
+                     max_flips=-1, step_size=-1.0, target=-1.0, want_margin=False):
+        """AdaptiveSpikeSlabRegressionSampler::draw() x nsweeps.  rng_setup:
+        ('mt', global_seed) -> sampler seeded by seed_rng(global) like every
+        PosteriorSampler; or ('philox', seed, chain) (stream 4)."""
+        L = self.lib
+        L.bo_adaptive_create.restype = C.c_void_p
+        L.bo_adaptive_create.argtypes = [C.c_void_p]
+        L.bo_adaptive_destroy.argtypes = [C.c_void_p]
+        L.bo_adaptive_set_options.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        L.bo_adaptive_get_rates.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.bo_adaptive_min_margin.restype = C.c_double
+        L.bo_adaptive_min_margin.argtypes = [C.c_void_p]
+        L.bo_adaptive_min_multi_margin.restype = C.c_double
+        L.bo_adaptive_min_multi_margin.argtypes = [C.c_void_p]
+        L.bo_adaptive_draw.argtypes = [C.c_void_p]
+        p = len(suf["xty"])
+        h = self.ssvs_create(suf, prior)
+        L.bo_ssvs_set_options(h, opts["max_model_size"], opts["sigma_upper_limit"],
+                              opts["swap_threshold"], opts["max_flips"],
+                              opts["draw_beta"], opts["draw_sigma"])
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        L.bo_ssvs_set_state(h, _u8(g0), _dp(np.zeros(p)), 1.0)
+        rp = L.bo_ssvs_rng(h)
+        if rng_setup[0] == "mt":
+            glob = self.rng_mt(rng_setup[1])
+            L.bo_rng_seed_mt(rp, L.bo_seed_rng(C.byref(glob)))
+        else:
+            L.bo_rng_seed_philox(rp, int(rng_setup[1]), int(rng_setup[2]), 4, 0)
+        a = L.bo_adaptive_create(h)
+        L.bo_adaptive_set_options(a, int(max_flips), float(step_size), float(target))
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        sv = C.c_double()
+        status = 0
+        for i in range(nsweeps):
+            status = L.bo_adaptive_draw(a)
+            if status:
+                break
+            L.bo_ssvs_get_state(h, _u8(g), _dp(b), C.byref(sv))
+            gam[i] = g
+            beta[i] = b
+            sig[i] = sv.value
+        birth = np.zeros(p)
+        death = np.zeros(p)
+        L.bo_adaptive_get_rates(a, _dp(birth), _dp(death))
+        out = dict(gamma=gam, beta=beta, sigsq=sig, status=status, birth=birth,
+                   death=death)
+        if want_margin:
+            out["min_margin"] = L.bo_adaptive_min_margin(a)
+            out["min_multi_margin"] = L.bo_adaptive_min_multi_margin(a)
+        L.bo_adaptive_destroy(a)
+        L.bo_ssvs_destroy(h)
+        return out
+
     def run_chains(self, suf, prior, opts, seed, chains, nsweeps, nthreads,
                    init_gamma, init_beta=None, init_sigsq=None):
         p = len(suf["xty"])
@@ -667,6 +725,24 @@ class Ref:
         a = [C.c_double(v) for v in args5]
         self._check(self.lib.ref_ssvs_run_ctor(
             which, n, p, _dp(fcol(X)), _dp(f64(y)), *a, int(flag), C.byref(o),
+            C.c_uint64(seed), _u8(g0), nsweeps, _u8(gam), _dp(beta), _dp(sig)))
+        return dict(gamma=gam, beta=beta, sigsq=sig)
+
+    def adaptive_run(self, suf, prior, opts, seed, init_gamma, nsweeps,
+                     max_flips=-1, step_size=-1.0, target=-1.0):
+        p = len(suf["xty"])
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self._check(self.lib.ref_adaptive_run(
+            int(suf["n"]), p, _dp(fcol(suf["xtx"])), _dp(f64(suf["xty"])),
+            C.c_double(suf["yty"]), C.c_double(suf["sumy"] / suf["n"]),
+            _dp(f64(suf["xsum"] / suf["n"])), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
+            C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+            C.c_int64(opts["max_model_size"]), C.c_double(opts["sigma_upper_limit"]),
+            int(max_flips), C.c_double(step_size), C.c_double(target),
             C.c_uint64(seed), _u8(g0), nsweeps, _u8(gam), _dp(beta), _dp(sig)))
         return dict(gamma=gam, beta=beta, sigsq=sig)
 

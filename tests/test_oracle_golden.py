@@ -248,3 +248,30 @@ def test_impute_state_known_answer(oracle):
     assert np.max(np.abs(o["state"] - g["state"])) < 1e-11
     assert o["level_n"] == float(g["level_n"])
     assert abs(o["level_sumsq"] - float(g["level_sumsq"])) < 1e-11 * float(g["level_sumsq"])
+
+
+@pytest.mark.parametrize("name", ["adaptive_c1", "adaptive_p150", "adaptive_collinear",
+                                  "adaptive_options"])
+def test_adaptive_sampler_matches_reference(oracle, name):
+    """AdaptiveSpikeSlabRegressionSampler (what lm.spike runs for p > 100): the
+    oracle's restatement on the reference's engine and seed against the
+    reference's own draws: inclusion indicators identical, beta / sigma^2 to
+    rounding."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    suf = dict(xtx=g["xtx"], xty=g["xty"], yty=float(g["yty"]), n=float(g["n"]),
+               sumy=float(g["sumy"]), xsum=g["xsum"])
+    prior = dict(b=g["prior_b"], ominv=g["prior_ominv"], df=float(g["prior_df"]),
+                 sigma_guess=float(g["prior_sigma_guess"]), pi=g["prior_pi"])
+    opts = ssvs_options(max_model_size=int(g["opt_max_model_size"]),
+                        sigma_upper_limit=float(g["opt_sigma_upper_limit"]))
+    p = len(suf["xty"])
+    want = np.unpackbits(g["gamma"], axis=1)[:, :p]
+    nsw = want.shape[0]
+    o = oracle.adaptive_run(suf, prior, opts, ("mt", int(g["seed"])), g["init_gamma"], nsw,
+                            int(g["max_flips"]), float(g["step_size"]), float(g["target"]),
+                            want_margin=True)
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], want)
+    assert np.max(np.abs(o["beta"] - g["beta"]) / np.maximum(np.abs(g["beta"]), 1e-3)) < 1e-11
+    assert np.max(np.abs(o["sigsq"] - g["sigsq"]) / g["sigsq"]) < 1e-11
+    assert o["min_margin"] > 1e-9 and o["min_multi_margin"] > 1e-12
