@@ -72,6 +72,10 @@ SIGNATURES = {
     "ba_set_sigsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_double]),
     "ba_sss_set_slab": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, C.c_int32]),
     "ba_sss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_adaptive_set_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double]),
+    "ba_adaptive_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_adaptive_get_rates": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp,
+                                        C.POINTER(C.c_uint64)]),
     "ba_reset_summaries": (C.c_int, [C.c_void_p]),
     "ba_get_summaries": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "ba_summaries_device": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -281,6 +285,21 @@ class Engine:
         if sync:
             self.sync()
 
+    # ---- AdaptiveSpikeSlabRegressionSampler ---------------------------------------
+    def adaptive_set_options(self, max_flips=-1, step_size=-1.0, target=-1.0):
+        self._check(self.lib.ba_adaptive_set_options(self._h, max_flips, step_size, target))
+
+    def adaptive_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_adaptive_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
+
+    def adaptive_get_rates(self, chain):
+        b, d = np.zeros(self.p), np.zeros(self.p)
+        it = C.c_uint64()
+        self._check(self.lib.ba_adaptive_get_rates(self._h, chain, _p(b), _p(d), C.byref(it)))
+        return b, d, it.value
+
     # ---- summaries ----------------------------------------------------------
     def reset_summaries(self):
         self._check(self.lib.ba_reset_summaries(self._h))
@@ -295,7 +314,10 @@ class Engine:
                     accepts=sc[4], proposals=sc[5], min_margin=sc[6],
                     # scalar 7: accepted flips served from a chain's other slot
                     # (diagnostic stamp builds reuse it for the slowest chain's cycles)
-                    slot_hits=float(sc[7]), phase_cycles=sc[8:16].copy())
+                    slot_hits=float(sc[7]), phase_cycles=sc[8:16].copy(),
+                    # after adaptive sweeps: closest approach of a weighted-draw
+                    # uniform to a boundary of the cumulative rates
+                    min_multi_margin=float(sc[8]))
 
     def summaries_device(self, ptr):
         self._check(self.lib.ba_summaries_device(self._h, ptr))

@@ -22,6 +22,8 @@ namespace boom_amd {
 hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P, int nsweeps);
 // ssvs_big_kernel.hip
 hipError_t launch_ssvs_big(hipStream_t stream, const SsvsParams &P, int nsweeps);
+// ssvs_adaptive_kernel.hip
+hipError_t launch_ssvs_adaptive(hipStream_t stream, const SsvsParams &P, int nsweeps);
 hipError_t launch_ssvs_logp(hipStream_t stream, const SsvsParams &P,
                             const uint8_t *gammas, int ngamma, double *out,
                             int *status_out);
@@ -196,6 +198,11 @@ struct ba_engine {
   double v_scale_want = 1.0;
   DevBuf<uint64_t> dpos_sss;
   uint64_t seed = 0;
+  // AdaptiveSpikeSlabRegressionSampler (mode 2): rates, iteration counts, options
+  DevBuf<double> dada_birth, dada_death;
+  DevBuf<uint64_t> dada_iter, dpos_ada;
+  int ada_max_flips = 100;
+  double ada_step = .001, ada_target = .345;
 
   // ---- state space (bsts local level + regression)
   bool ss_mode = false, ss_level_set = false, ss_initialized = false;
@@ -474,6 +481,19 @@ void fill_params(ba_engine *e, SsvsParams &P) {
     P.cm_start = nullptr;
     P.max_flips = (e->sss_max_flips > 0) ? std::min(e->sss_max_flips, e->p) : e->p;
   }
+  if (e->cur_mode == 2) {
+    // AdaptiveSpikeSlabRegressionSampler: own stream, no swap move
+    P.mode = 0;
+    P.stream = 4;
+    P.rng_pos = e->dpos_ada.ptr;
+    P.cm_start = nullptr;
+  }
+  P.ada_birth = e->dada_birth.ptr;
+  P.ada_death = e->dada_death.ptr;
+  P.ada_iter = e->dada_iter.ptr;
+  P.ada_step = e->ada_step;
+  P.ada_target = e->ada_target;
+  P.ada_max_flips = e->ada_max_flips;
   P.inc_count = e->dinc.ptr;
   P.beta_sum = e->dbsum.ptr;
   P.beta_sumsq = e->dbsumsq.ptr;
@@ -531,6 +551,7 @@ int ensure_big_buffers(ba_engine *e) {
 // once any chain has outgrown it -- the HBM-resident kernel right behind it for
 // the chains the first one parked (status CHAIN_MODEL_TOO_LARGE)
 hipError_t launch_sweeps(ba_engine *e, const SsvsParams &P, int nsweeps) {
+  if (e->cur_mode == 2) return launch_ssvs_adaptive(e->stream, P, nsweeps);
   hipError_t err = launch_ssvs_sweep(e->stream, P, nsweeps);
   if (err == hipSuccess && e->big_active) err = launch_ssvs_big(e->stream, P, 0);
   return err;
@@ -561,6 +582,7 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
     if (!any) return BA_OK;
     if (e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
     if (e->kcap >= cap_limit(*e)) {
+      if (e->cur_mode == 2) return BA_OK;  // (the adaptive kernel stops at 64 variables: stays an error)
       // beyond the LDS kernel: the parked chains go to the HBM-resident one
       int stuck = 0;
       int rc = grow_big(e, &stuck);
@@ -1275,6 +1297,7 @@ int ba_seed(ba_engine *e, uint64_t seed) {
   // every sampler of every chain restarts at position 0 of its new stream
   if (e->dpos.ptr) HIP_TRY(hipMemsetAsync(e->dpos.ptr, 0, C * 8, s));
   if (e->dpos_sss.ptr) HIP_TRY(hipMemsetAsync(e->dpos_sss.ptr, 0, C * 8, s));
+  if (e->dpos_ada.ptr) HIP_TRY(hipMemsetAsync(e->dpos_ada.ptr, 0, C * 8, s));
   if (e->dpos_level.ptr) HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
   if (e->dpos_state.ptr) HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1686,6 +1709,76 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   if (e->trace_stride > 0)
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
   HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
+  return BA_OK;
+}
+
+// ------------------------ AdaptiveSpikeSlabRegressionSampler (birth / death)
+static int ada_prepare(ba_engine *e) {
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
+  if (e->dada_birth.count == C * p) return BA_OK;
+  HIP_TRY(e->dada_birth.resize(C * p));
+  HIP_TRY(e->dada_death.resize(C * p));
+  HIP_TRY(e->dada_iter.resize(C));
+  HIP_TRY(e->dpos_ada.resize(C));
+  std::vector<double> ones(C * p, 1.0);   // birth_rates_, death_rates_ start at 1
+  HIP_TRY(hipMemcpyAsync(e->dada_birth.ptr, ones.data(), C * p * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->dada_death.ptr, ones.data(), C * p * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemsetAsync(e->dada_iter.ptr, 0, C * 8, e->stream));
+  HIP_TRY(hipMemsetAsync(e->dpos_ada.ptr, 0, C * 8, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return BA_OK;
+}
+
+int ba_adaptive_set_options(ba_engine *e, int32_t max_flips, double step_size,
+                            double target_acceptance_rate) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (step_size == 0 || step_size < -1) return fail(BA_E_INVALID, "Step size must be positive.");
+  if (target_acceptance_rate == 0 || target_acceptance_rate >= 1 || target_acceptance_rate < -1)
+    return fail(BA_E_INVALID, "Target acceptance rate must be strictly between 0 and 1.");
+  MUTATE(e);
+  if (max_flips >= 0) e->ada_max_flips = max_flips;
+  if (step_size > 0) e->ada_step = step_size;
+  if (target_acceptance_rate > 0) e->ada_target = target_acceptance_rate;
+  return BA_OK;
+}
+
+int ba_adaptive_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
+  int rc = alloc_chain_state(e);
+  if (rc) return rc;
+  rc = switch_mode(e, 2, 1.0);
+  if (rc) return rc;
+  rc = upload_shared(e);
+  if (rc) return rc;
+  rc = ada_prepare(e);
+  if (rc) return rc;
+  if (e->trace_stride > 0 && nsweeps > e->trace_stride)
+    return fail(BA_E_INVALID, "nsweeps exceeds the enabled trace length");
+  HIP_TRY(e->dmodel.resize(2 * (size_t)e->cfg.chains * ssvs_scalar_layout(64).total));
+  SsvsParams P;
+  fill_params(e, P);
+  if (ssvs_ada_lds_layout(e->p, e->kcap).total > e->lds_per_cu)
+    return fail(BA_E_INVALID, "problem does not fit the LDS working set of the adaptive kernel");
+  if (e->trace_stride > 0)
+    HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
+  HIP_TRY(launch_ssvs_adaptive(e->stream, P, (int)nsweeps));
+  return BA_OK;
+}
+
+int ba_adaptive_get_rates(ba_engine *e, int64_t chain, double *birth_rates,
+                          double *death_rates, uint64_t *iteration_count) {
+  ENGINE_PROLOGUE(e);
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  if (e->dada_birth.count == 0) return fail(BA_E_STATE, "no adaptive sweep yet");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t p = (size_t)e->p;
+  if (birth_rates) HIP_TRY(hipMemcpy(birth_rates, e->dada_birth.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost));
+  if (death_rates) HIP_TRY(hipMemcpy(death_rates, e->dada_death.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost));
+  if (iteration_count) HIP_TRY(hipMemcpy(iteration_count, e->dada_iter.ptr + chain, 8, hipMemcpyDeviceToHost));
   return BA_OK;
 }
 

@@ -138,6 +138,13 @@ struct SsvsParams {
   double *rec_beta;    // chains x trace_stride x rec_cap
   int32_t rec_cap;     // >= the launch's model capacity
 
+  // ---- AdaptiveSpikeSlabRegressionSampler (ssvs_adaptive_kernel.hip; mode 2):
+  // per-chain birth / death rates and iteration counts, the sampler's options
+  double *ada_birth, *ada_death;   // chains x p
+  uint64_t *ada_iter;              // chains
+  double ada_step, ada_target;     // step_size_, target_acceptance_rate_
+  int32_t ada_max_flips;           // max_flips_ (100); 0 = no model selection
+
   // ---- HBM-resident path (ssvs_big_kernel.hip): models of more than 64
   // variables.  Capacity big_kcap (a multiple of 64); per-chain model blocks laid
   // out by ssvs_scalar_layout(big_kcap), two slots like model_scratch; per-wave
@@ -216,6 +223,37 @@ static inline __host__ __device__ SsvsBigLds ssvs_big_lds_layout(int p, int kcap
   L.gam = o;   o += ((uint32_t)p + 15u) & ~15u;
   L.gam0 = o;  o += ((uint32_t)p + 15u) & ~15u;
   L.nbr = o;   o += ((uint32_t)p + 15u) & ~15u;
+  L.total = o;
+  return L;
+}
+
+// ---- LDS layout of one chain in the adaptive (birth / death) kernel -------------
+struct SsvsAdaLds {
+  uint32_t Lv, La, rdv, rda, w, bg, ctrl, birth, death, cumb, cumd, undo_v, undo_j, g, gam, gam0, total;
+};
+enum { ADA_UNDO_CAP = 128 };
+static inline __host__ __device__ SsvsAdaLds ssvs_ada_lds_layout(int p, int kcap) {
+  SsvsAdaLds L;
+  const uint32_t nb = (uint32_t)kcap / 8;
+  const uint32_t fac = nb * (nb + 1) / 2 * 64 * 8;
+  const uint32_t pd = (uint32_t)p * 8;
+  uint32_t o = 0;
+  L.Lv = o;     o += fac;
+  L.La = o;     o += fac;
+  L.rdv = o;    o += (uint32_t)kcap * 8;
+  L.rda = o;    o += (uint32_t)kcap * 8;
+  L.w = o;      o += (uint32_t)kcap * 8;
+  L.bg = o;     o += (uint32_t)kcap * 8;
+  L.ctrl = o;   o += 512;
+  L.birth = o;  o += pd;
+  L.death = o;  o += pd;
+  L.cumb = o;   o += pd;      // inclusive prefix sums of the excluded variables' birth rates
+  L.cumd = o;   o += pd;      // ... of the included variables' death rates
+  L.undo_v = o; o += ADA_UNDO_CAP * 8;   // rates changed by the sweep in progress (old values)
+  L.undo_j = o; o += ADA_UNDO_CAP * 4;
+  L.g = o;      o += (((uint32_t)kcap * 2) + 15u) & ~15u;
+  L.gam = o;    o += ((uint32_t)p + 15u) & ~15u;
+  L.gam0 = o;   o += ((uint32_t)p + 15u) & ~15u;
   L.total = o;
   return L;
 }

@@ -203,14 +203,38 @@ int ba_sss_set_slab(ba_engine *e, const double *mu, const double *precision,
                     int32_t precision_scales_with_sigsq, int32_t max_flips);
 int ba_sss_sweep(ba_engine *e, int32_t nsweeps);
 
+/* ---- AdaptiveSpikeSlabRegressionSampler: what lm.spike runs for p > 100 -------- */
+/* Models/Glm/PosteriorSamplers/AdaptiveSpikeSlabRegressionSampler.{hpp,cpp}
+ * (Interfaces/R/BoomSpikeSlab/src/spike_slab_wrapper.cc:99-140): same model,
+ * priors (ba_set_slab / ba_set_spike / ba_set_sigma_prior) and chain state as
+ * BregVsSampler; a sweep is min(max_flips, p) birth / death moves with adaptive
+ * proposal rates, then sigma^2 and beta.
+ *   ba_adaptive_set_options  limit_model_selection(max_flips) (default 100; 0 =
+ *                            allow_model_selection(false)), set_step_size
+ *                            (.001), set_target_acceptance_rate (.345); a
+ *                            negative value keeps the current setting
+ *   ba_adaptive_sweep        nsweeps x draw() (.cpp:62-85) on every chain
+ *   ba_adaptive_get_rates    birth_rates_, death_rates_, iteration_count_ of a
+ *                            chain (any pointer may be NULL)
+ * Models of more than 64 variables are not supported by this sampler's kernel
+ * yet (BA_E_MODEL_TOO_LARGE). */
+int ba_adaptive_set_options(ba_engine *e, int32_t max_flips, double step_size,
+                            double target_acceptance_rate);
+int ba_adaptive_sweep(ba_engine *e, int32_t nsweeps);
+int ba_adaptive_get_rates(ba_engine *e, int64_t chain, double *birth_rates,
+                          double *death_rates, uint64_t *iteration_count);
+
 /* ---- posterior summaries --------------------------------------------------- */
 /* Running sums over every sweep since the last ba_reset_summaries(), reduced
  * over this engine's chains on the device:
  *   inclusion_count[p] (as double), beta_sum[p], beta_sumsq[p],
  *   scalars[16] = {sweeps*chains, sum sigsq, sum sigsq^2, sum |gamma|,
- *                  accepted flips, proposed flips, min accept margin, reserved,
+ *                  accepted flips, proposed flips, min accept margin, accepted
+ *                  flips served from a chain's other slot,
  *                  [8..15] per-phase cycle counters of the diagnostic build
- *                  (zero in the production library)}
+ *                  (zero in the production library; after ba_adaptive_sweep
+ *                  scalar 8 is the smallest relative distance of a weighted-
+ *                  draw uniform from a boundary of the cumulative rates)}
  * The layout is one contiguous block of (3p + 16) doubles so that a single
  * collective moves it (see ba_summaries_device). */
 int ba_reset_summaries(ba_engine *e);
