@@ -1,0 +1,77 @@
+// The reference-side binding INTEGRATION.md sec. 1 describes, as a real file:
+// a BOOM PosteriorSampler that forwards draw() to the boom_amd engine through
+// the C-ABI (include/boom_amd.h).  This is OUR code, written against the
+// reference's public headers; it is compiled only where /root/reference exists
+// (oracle/Makefile, target `binding`) so that the boundary claim is checked by a
+// compiler and -- through oracle/binding/binding_driver.cpp -- exercised on the
+// GPU box by the reference's own `model->sample_posterior()` loop.  It is what a
+// BOOM maintainer would add under Models/Glm/PosteriorSamplers/.
+#ifndef BOOM_AMD_DEVICE_BREG_VS_SAMPLER_HPP_
+#define BOOM_AMD_DEVICE_BREG_VS_SAMPLER_HPP_
+
+#include "LinAlg/Selector.hpp"
+#include "LinAlg/Vector.hpp"
+#include "Models/GammaModel.hpp"
+#include "Models/Glm/RegressionModel.hpp"
+#include "Models/Glm/VariableSelectionPrior.hpp"
+#include "Models/MvnGivenScalarSigma.hpp"
+#include "Models/PosteriorSamplers/PosteriorSampler.hpp"
+
+extern "C" {
+#include "boom_amd.h"
+}
+
+namespace BOOM {
+
+  // Many-chain drop-in for BregVsSampler (same constructor arguments as its
+  // ctor #5, BregVsSampler.hpp:102-106, plus the chain count).  Chain 0 backs
+  // the model's own parameters, so code that reads model->Beta() / sigsq() /
+  // coef().inc() between draws keeps working; the other chains are read with
+  // chain_state().
+  class DeviceBregVsSampler : public PosteriorSampler {
+   public:
+    DeviceBregVsSampler(RegressionModel *model,
+                        const Ptr<MvnGivenScalarSigmaBase> &slab,
+                        const Ptr<GammaModelBase> &residual_precision_prior,
+                        const Ptr<VariableSelectionPrior> &spike,
+                        int chains, int device = 0, int lookahead = 1,
+                        RNG &seeding_rng = GlobalRng::rng);
+    ~DeviceBregVsSampler() override;
+
+    void draw() override;            // BregVsSampler::draw, BregVsSampler.cpp:252-261
+    double logpri() const override;  // BregVsSampler::logpri, :380-393 (chain 0)
+
+    // PosteriorSampler::set_seed is not virtual in BOOM; the engine's streams
+    // are re-keyed through this one
+    void set_device_seed(unsigned long seed);
+    unsigned long device_seed() const { return device_seed_; }
+
+    // BregVsSampler's setters, same names and meaning (BregVsSampler.hpp:131-161)
+    void limit_model_selection(uint max_flips);
+    void suppress_model_selection();
+    void allow_model_selection();
+    void set_correlation_swap_threshold(double threshold);
+    void set_sigma_upper_limit(double sigma_upper_limit);
+
+    // new: how many draws a launch runs ahead of the caller (ba_set_lookahead)
+    void set_lookahead(int n);
+    // new: the other chains
+    int number_of_chains() const { return chains_; }
+    void chain_state(int chain, Selector &inc, Vector &beta, double &sigsq) const;
+
+   private:
+    void check(int rc) const;
+    void options();
+    void push_state();   // coef().inc(), Beta(), sigsq() -> every chain
+    void pull_chain0();  // chain 0 -> coef().set_inc / set_Beta / set_sigsq
+    RegressionModel *model_;
+    ba_engine *engine_;
+    int chains_;
+    unsigned long device_seed_;
+    int max_flips_;
+    double swap_threshold_;
+    double prior_df_, prior_sigma_guess_;
+  };
+
+}  // namespace BOOM
+#endif  // BOOM_AMD_DEVICE_BREG_VS_SAMPLER_HPP_
