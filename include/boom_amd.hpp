@@ -70,10 +70,15 @@ class Selector {
   std::vector<uint8_t> inc_;
 };
 
+// PosteriorSampler (Models/PosteriorSamplers/PosteriorSampler.hpp:49-66): the
+// virtual surface of the path -- draw(), logpri(), the seed of the sampler's
+// private stream(s)
 class PosteriorSampler {
  public:
   virtual ~PosteriorSampler() {}
   virtual void draw() = 0;
+  virtual double logpri() const = 0;
+  virtual void set_seed(unsigned long seed) = 0;
 };
 
 class Model {
@@ -84,6 +89,7 @@ class Model {
   int number_of_sampling_methods() const { return (int)samplers_.size(); }
   // PriorPolicy::sample_posterior
   void sample_posterior() { for (auto &s : samplers_) s->draw(); }
+  Ptr<PosteriorSampler> sampler(int i) const { return samplers_[i]; }
  private:
   std::vector<Ptr<PosteriorSampler>> samplers_;
 };
@@ -114,6 +120,16 @@ struct VariableSelectionPrior {
   uint potential_nvars() const { return (uint)pi_.size(); }
   Vector pi_;
   int64_t max_model_size_;
+};
+
+// BregVsSampler.hpp:33-40
+struct ZellnerPriorParameters {
+  Vector prior_inclusion_probabilities;
+  Vector prior_beta_guess;
+  double prior_beta_guess_weight;
+  SpdMatrix prior_beta_information;  // Omega^{-1}
+  double prior_sigma_guess;
+  double prior_sigma_guess_weight;
 };
 
 // ---- engine handle shared by a model and its sampler ------------------------
@@ -148,13 +164,19 @@ class RegressionModel : public Model {
   }
   int xdim() const { return p_; }
   int nvars_possible() const { return p_; }
-  Selector &inc() { return inc_; }            // coef().inc()
-  const Selector &inc() const { return inc_; }
-  void drop_all() { inc_.drop_all(); }        // coef().drop_all()
-  void add(int i) { inc_.add(i); }            // coef().add(i)
+  // (a change made through the mutators below goes to every chain before the
+  // sampler's next draw, as BOOM's sampler reads the model's current state on
+  // every draw)
+  const Selector &inc() const { return inc_; }               // coef().inc()
+  void set_inc(const Selector &g) { inc_ = g; dirty_ = true; }  // coef().set_inc(g)
+  void drop_all() { inc_.drop_all(); dirty_ = true; }        // coef().drop_all()
+  void add(int i) { inc_.add(i); dirty_ = true; }            // coef().add(i)
+  void drop(int i) { inc_.drop(i); dirty_ = true; }          // coef().drop(i)
   const Vector &Beta() const { return beta_; }
+  void set_Beta(const Vector &b) { beta_ = b; dirty_ = true; }
   double sigsq() const { return sigsq_; }
-  void set_sigsq(double s) { sigsq_ = s; }
+  void set_sigsq(double s) { sigsq_ = s; dirty_ = true; }
+  bool dirty() const { return dirty_; }
   const Ptr<Engine> &engine() const { return eng_; }
   // all chains (chains x p row-major gamma / beta, chains sigsq)
   void chain_states(std::vector<uint8_t> &gamma, Vector &beta, Vector &sigsq) const {
@@ -163,16 +185,14 @@ class RegressionModel : public Model {
     eng_->check(ba_get_states(eng_->get(), gamma.data(), beta.data(), sigsq.data()));
   }
   // used by the sampler
-  void push_state() { eng_->check(ba_set_state(eng_->get(), -1, inc_.bytes().data(), beta_.data(), sigsq_)); }
-  void pull_chain0() { eng_->check(ba_get_state(eng_->get(), 0, inc_.bytes().data(), beta_.data(), &sigsq_)); }
-  // chain 0's parameters from a recorded draw (row `row` of gamma / beta)
-  void set_from_record(const std::vector<uint8_t> &gamma, const std::vector<double> &beta,
-                       const std::vector<double> &sigsq, int row) {
-    for (int j = 0; j < p_; ++j) {
-      inc_.bytes()[j] = gamma[(size_t)row * p_ + j];
-      beta_[j] = beta[(size_t)row * p_ + j];
-    }
-    sigsq_ = sigsq[row];
+  void push_state() {
+    eng_->check(ba_set_state(eng_->get(), -1, inc_.bytes().data(), beta_.data(), sigsq_));
+    dirty_ = false;
+  }
+  // (while ba_draw_next serves a look-ahead batch, ba_get_state is the draw being served)
+  void pull_chain0() {
+    eng_->check(ba_get_state(eng_->get(), 0, inc_.bytes().data(), beta_.data(), &sigsq_));
+    dirty_ = false;
   }
  private:
   Ptr<Engine> eng_;
@@ -180,6 +200,7 @@ class RegressionModel : public Model {
   Selector inc_;
   Vector beta_;
   double sigsq_;
+  bool dirty_ = true;
 };
 
 // ---- BregVsSampler ---------------------------------------------------------------
@@ -207,6 +228,14 @@ class BregVsSampler : public PosteriorSampler {
       : model_(model) {
     set_raw(prior_mean, unscaled_prior_precision, df, sigma_guess, prior_inclusion_probs, -1);
   }
+  // ctor #4 (BregVsSampler.cpp:162-178)
+  BregVsSampler(RegressionModel *model, const ZellnerPriorParameters &prior)
+      : model_(model) {
+    if ((int)prior.prior_beta_guess.size() != model->xdim()) report_error("Slab dimension did not match model dimension.");
+    if ((int)prior.prior_inclusion_probabilities.size() != model->xdim()) report_error("Spike dimension did not match model dimension.");
+    set_raw(prior.prior_beta_guess, prior.prior_beta_information, prior.prior_sigma_guess_weight,
+            prior.prior_sigma_guess, prior.prior_inclusion_probabilities, -1);
+  }
   // ctor #5 (BregVsSampler.cpp:180-194)
   BregVsSampler(RegressionModel *model, const Ptr<MvnGivenScalarSigma> &slab,
                 const Ptr<ChisqModel> &residual_precision_prior,
@@ -220,37 +249,19 @@ class BregVsSampler : public PosteriorSampler {
   }
 
   void draw() override {                     // BregVsSampler.cpp:252-261
-    if (!pushed_) { model_->push_state(); pushed_ = true; }
-    if (lookahead_ > 1) {
-      // the caller's one-draw-per-iteration loop served from draws recorded on
-      // the device: one launch per `lookahead_` iterations
-      if (served_ == avail_) {
-        check(ba_sweep(h(), lookahead_));
-        check(ba_get_draws(h(), 0, lookahead_, rec_gamma_.data(), rec_beta_.data(), rec_sigsq_.data()));
-        avail_ = lookahead_;
-        served_ = 0;
-      }
-      model_->set_from_record(rec_gamma_, rec_beta_, rec_sigsq_, served_++);
-      return;
-    }
-    check(ba_sweep(h(), 1));
+    // the model's parameters as the caller left them (a host-side change since
+    // the last draw goes to every chain first; the engine then rewinds any
+    // look-ahead draws not handed out yet)
+    if (model_->dirty()) model_->push_state();
+    check(ba_draw_next(h()));                // one launch per `lookahead` calls
     model_->pull_chain0();
   }
-  // run `n` sweeps ahead per launch and hand them out one draw() at a time
-  // (chain 0 backs the model's parameters; a setter called in between discards
-  // the draws not handed out yet: the chain is then simply thinned)
-  void set_lookahead(int n) {
-    lookahead_ = n;
-    served_ = avail_ = 0;
-    if (n > 1) {
-      check(ba_enable_draws(h(), n));
-      rec_gamma_.assign((size_t)n * model_->xdim(), 0);
-      rec_beta_.assign((size_t)n * model_->xdim(), 0.0);
-      rec_sigsq_.assign(n, 0.0);
-    }
-  }
+  // run `n` sweeps ahead per launch and hand them out one draw() at a time, for
+  // EVERY chain (ba_set_lookahead: the draws are the ones one launch per call
+  // would give, whatever is called in between)
+  void set_lookahead(int n) { check(ba_set_lookahead(h(), n < 1 ? 1 : n)); }
   void draw(int nsweeps) {                   // many sweeps in one launch
-    if (!pushed_) { model_->push_state(); pushed_ = true; }
+    if (model_->dirty()) model_->push_state();
     check(ba_sweep(h(), nsweeps));
     model_->pull_chain0();
   }
@@ -265,8 +276,8 @@ class BregVsSampler : public PosteriorSampler {
     check(ba_get_priors(h(), nullptr, nullptr, nullptr, &df, &ss));
     check(ba_set_sigma_prior(h(), df, std::sqrt(ss / df), s));
   }
-  void set_seed(unsigned long s) { check(ba_seed(h(), s)); }
-  double logpri() const {                    // BregVsSampler.cpp:380-393, chain 0
+  void set_seed(unsigned long s) override { check(ba_seed(h(), s)); }
+  double logpri() const override {           // BregVsSampler.cpp:380-393, chain 0 (the draw being served)
     double out;
     check(ba_logpri(h(), 0, &out));
     return out;
@@ -281,17 +292,13 @@ class BregVsSampler : public PosteriorSampler {
  private:
   ba_engine *h() const { return model_->engine()->get(); }
   void check(int rc) const { model_->engine()->check(rc); }
-  void options() { served_ = avail_ = 0; check(ba_set_options(h(), max_flips_, swap_, draw_beta_, draw_sigma_)); }
+  void options() { check(ba_set_options(h(), max_flips_, swap_, draw_beta_, draw_sigma_)); }
   void set_raw(const Vector &b, const SpdMatrix &om, double df, double guess, const Vector &pi, int64_t mms) {
     check(ba_set_slab(h(), b.data(), om.data()));
     check(ba_set_spike(h(), pi.data(), mms));
     check(ba_set_sigma_prior(h(), df, guess, infinity()));
   }
   RegressionModel *model_;
-  int lookahead_ = 1, served_ = 0, avail_ = 0;
-  std::vector<uint8_t> rec_gamma_;
-  std::vector<double> rec_beta_, rec_sigsq_;
-  bool pushed_ = false;
   int max_flips_ = -1, draw_beta_ = 1, draw_sigma_ = 1;
   double swap_ = 0.8;
 };
@@ -326,6 +333,7 @@ class StateSpaceRegressionModel : public Model {
   int time_dimension() const { return T_; }
   int xdim() const { return p_; }
   const Ptr<Engine> &engine() const { return eng_; }
+  const LocalLevelStateModel *level() const { return level_.get(); }
   Vector state(int chain = 0) const {
     Vector st(T_);
     eng_->check(ba_ss_get_state(eng_->get(), chain, st.data(), nullptr, nullptr, nullptr));
@@ -360,6 +368,26 @@ class StateSpacePosteriorSampler : public PosteriorSampler {
   void draw() override {                     // StateSpacePosteriorSampler.cpp:42-64
     model_->engine()->check(ba_ss_sweep(model_->engine()->get(), 1));
     model_->engine()->check(ba_sync(model_->engine()->get()));
+  }
+  // StateSpacePosteriorSampler::logpri (StateSpacePosteriorSampler.cpp:66-74) sums
+  // the observation model's and the state models' log priors; the regression
+  // part is what the engine evaluates (chain 0)
+  double logpri() const override {
+    double out;
+    model_->engine()->check(ba_logpri(model_->engine()->get(), 0, &out));
+    // + LocalLevelStateModel's sampler: ZeroMeanGaussianConjSampler::logpri =
+    // GenericGaussianVarianceSampler::log_prior(sigma^2_level)
+    // (GenericGaussianVarianceSampler.cpp: Gamma(df/2, ss/2) density of the
+    // precision and the Jacobian of the reciprocal)
+    if (const LocalLevelStateModel *lv = model_->level()) {
+      const double a = lv->df_ / 2, b = lv->df_ * lv->guess_ * lv->guess_ / 2;
+      const double s2 = model_->level_sigsq(0), x = 1.0 / s2;
+      out += a * std::log(b) - std::lgamma(a) + (a - 1.0) * std::log(x) - b * x - 2.0 * std::log(s2);
+    }
+    return out;
+  }
+  void set_seed(unsigned long s) override {
+    model_->engine()->check(ba_seed(model_->engine()->get(), s));
   }
  private:
   StateSpaceRegressionModel *model_;

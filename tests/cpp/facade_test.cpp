@@ -257,10 +257,67 @@ static void LookAhead() {
   EXPECT(same);
 }
 
+// The virtual surface (draw / logpri / set_seed through a base pointer), ctor #4
+// (ZellnerPriorParameters) against ctor #3 with the same numbers, and a change of
+// the model's parameters between draws reaching the chains.
+static void VirtualSurfaceAndCtor4() {
+  const int n = 300, p = 10, chains = 3;
+  Vector beta(p, 0.0);
+  beta[0] = 1.0; beta[2] = 2.0;
+  Sim s = simulate(n, p, beta, 1.0, 9);
+  Vector b(p, 0.0), pi(p, 0.3);
+  pi[0] = 1.0;
+  SpdMatrix om(p, p, 0.0);
+  for (int j = 0; j < p; ++j) om(j, j) = 0.5;
+  ZellnerPriorParameters zp;
+  zp.prior_inclusion_probabilities = pi;
+  zp.prior_beta_guess = b;
+  zp.prior_beta_guess_weight = 1.0;
+  zp.prior_beta_information = om;
+  zp.prior_sigma_guess = 1.1;
+  zp.prior_sigma_guess_weight = 2.0;
+  std::vector<double> rec[2];
+  for (int mode = 0; mode < 2; ++mode) {
+    RegressionModel model(s.X, s.y, chains, 7);
+    Ptr<BregVsSampler> bvs;
+    if (mode == 0) bvs.reset(new BregVsSampler(&model, zp));
+    else bvs.reset(new BregVsSampler(&model, b, om, 1.1, 2.0, pi));
+    Ptr<PosteriorSampler> sampler = bvs;       // the callers only ever see this
+    model.set_method(sampler);
+    model.drop_all();
+    model.add(0);
+    for (int i = 0; i < 12; ++i) {
+      model.sample_posterior();
+      rec[mode].push_back(model.sigsq());
+      rec[mode].push_back(model.sampler(0)->logpri());
+      if (i == 5) {
+        // the caller changes the model between draws; with model selection
+        // switched off for the next draw the change must still be there after it
+        model.drop_all();
+        model.add(0);
+        model.add(4);
+        model.set_sigsq(2.0);
+        bvs->suppress_model_selection();
+        model.sample_posterior();
+        EXPECT(model.inc()[0] && model.inc()[4] && model.inc().nvars() == 2);
+        EXPECT(model.Beta()[4] != 0.0);
+        rec[mode].push_back(model.Beta()[4]);
+        bvs->allow_model_selection();
+      }
+      if (i == 8) model.sampler(0)->set_seed(1234);
+    }
+    EXPECT(std::isfinite(rec[mode].back()));
+  }
+  bool same = rec[0].size() == rec[1].size();
+  for (size_t i = 0; same && i < rec[0].size(); ++i) same = rec[0][i] == rec[1][i];
+  EXPECT(same);
+}
+
 int main() {
   try {
     Small();
     LookAhead();
+    VirtualSurfaceAndCtor4();
     TestMaxSizeControl();
     Large();
     PerfectCollinearity();
