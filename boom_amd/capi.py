@@ -46,6 +46,10 @@ SIGNATURES = {
     "ba_build_suf_from_xy": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp]),
     "ba_build_suf_from_xy_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
                                               C.c_void_p, C.c_void_p]),
+    "ba_suf_block_size": (C.c_size_t, [C.c_int32]),
+    "ba_suf_partial_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "ba_set_suf_from_block_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "ba_upload_regression_suf": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp,
                                            C.c_double, C.c_double, C.c_double, _dp]),
     "ba_get_regression_suf": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -167,6 +171,16 @@ class Engine:
 
     def build_suf_from_xy_device(self, n, p, x_ptr, y_ptr):
         self._check(self.lib.ba_build_suf_from_xy_device(self._h, n, p, x_ptr, y_ptr))
+        self.p = p
+
+    def suf_block_size(self, p):
+        return int(self.lib.ba_suf_block_size(p))
+
+    def suf_partial_device(self, n_rows, p, x_ptr, y_ptr, block_ptr):
+        self._check(self.lib.ba_suf_partial_device(self._h, n_rows, p, x_ptr, y_ptr, block_ptr))
+
+    def set_suf_from_block_device(self, n_total, p, block_ptr):
+        self._check(self.lib.ba_set_suf_from_block_device(self._h, n_total, p, block_ptr))
         self.p = p
 
     def upload_suf(self, xtx, xty, yty, n, ybar, xbar):

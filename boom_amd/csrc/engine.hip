@@ -952,6 +952,51 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
   return BA_OK;
 }
 
+// ---- row-sharded build: partial statistics of a shard of rows, summed by the
+// caller over its ranks (one all-reduce), then installed on every rank
+size_t ba_suf_block_size(int32_t p) { return (size_t)p * p + 2 * (size_t)p + 2; }
+
+int ba_suf_partial_device(ba_engine *e, int64_t n_rows, int32_t p, const void *X_device,
+                          const void *y_device, void *block_device) {
+  ENGINE_PROLOGUE(e);
+  if (!X_device || !y_device || !block_device) return fail(BA_E_INVALID, "null argument");
+  if (n_rows <= 0 || p <= 0 || p > 65535) return fail(BA_E_INVALID, "bad shard dimensions");
+  double *blk = (double *)block_device;
+  DevBuf<double> planes;
+  const int slices = suf_row_slices(n_rows, p);
+  if (slices > 1) HIP_TRY(planes.resize((size_t)slices * p * p));
+  // block layout: [XtX p*p | Xty p | yty, sum y | column sums of X p]
+  int rc = launch_suf_from_xy(e->stream, n_rows, p, (const double *)X_device,
+                              (const double *)y_device, blk, blk + (size_t)p * p,
+                              blk + (size_t)p * p + p, blk + (size_t)p * p + p + 2, planes.ptr);
+  if (rc) return fail(BA_E_HIP, "suf kernel launch failed");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return BA_OK;
+}
+
+int ba_set_suf_from_block_device(ba_engine *e, int64_t n_total, int32_t p,
+                                 const void *block_device) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (!block_device) return fail(BA_E_INVALID, "null argument");
+  if (n_total <= 0) return fail(BA_E_INVALID, "n must be positive");
+  int rc = set_dimension(e, p);
+  if (rc) return rc;
+  const size_t pp = (size_t)p * p;
+  std::vector<double> h(ba_suf_block_size(p));
+  HIP_TRY(hipMemcpyAsync(h.data(), block_device, h.size() * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->xtx.assign(h.begin(), h.begin() + pp);
+  e->xty.assign(h.begin() + pp, h.begin() + pp + p);
+  e->yty = h[pp + p];
+  e->sumy = h[pp + p + 1];
+  e->xsum.assign(h.begin() + pp + p + 2, h.end());
+  e->n = (double)n_total;
+  e->have_suf = true;
+  e->device_dirty = true;
+  return BA_OK;
+}
+
 int ba_build_suf_from_xy(ba_engine *e, int64_t n, int32_t p, const double *X,
                          const double *y) {
   ENGINE_PROLOGUE(e);

@@ -42,6 +42,52 @@ def max_over_ranks(value, world, device):
     return float(t.item())
 
 
+def suf_block_size(p):
+    """doubles in a sufficient-statistics block: X'X | X'y | y'y, sum y | col sums"""
+    return p * p + 2 * p + 2
+
+
+def row_shard(n, rank, world):
+    """rows [lo, hi) of an n-row design matrix owned by `rank`"""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def reduce_suf_block(block, world):
+    """sum the ranks' partial sufficient-statistics blocks in place: ONE
+    all-reduce (RCCL on GPUs; gloo in the CPU tests).  `block` is a 1-d float64
+    torch tensor on the backend's device."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.all_reduce(block, op=dist.ReduceOp.SUM)
+    return block
+
+
+def unpack_suf_block(block, p, n_total):
+    """the block as the dict the tests / oracle use"""
+    b = np.asarray(block, dtype=np.float64)
+    pp = p * p
+    return dict(xtx=b[:pp].reshape(p, p).T.copy(), xty=b[pp:pp + p].copy(),
+                yty=float(b[pp + p]), sumy=float(b[pp + p + 1]),
+                xsum=b[pp + p + 2:].copy(), n=float(n_total))
+
+
+def build_suf_row_sharded(engine, X_local, y_local, n_total, world):
+    """Config-4 data path: this rank's rows -> local MFMA syrk -> one all-reduce
+    of (X'X | X'y | y'y | sum y | sum x) -> installed on the engine.  X_local is
+    a column-major (p, n_local)-shaped CUDA tensor (n_local x p matrix), y_local
+    a CUDA vector."""
+    import torch
+    p, n_local = X_local.shape
+    block = torch.empty(suf_block_size(p), dtype=torch.float64, device=X_local.device)
+    engine.suf_partial_device(n_local, p, X_local.data_ptr(), y_local.data_ptr(),
+                              block.data_ptr())
+    reduce_suf_block(block, world)
+    if world > 1:
+        torch.cuda.synchronize()
+    engine.set_suf_from_block_device(n_total, p, block.data_ptr())
+    return block
+
+
 def aggregate(blocks, p):
     """whole-job posterior summaries from the gathered per-rank blocks"""
     blocks = np.asarray(blocks, dtype=np.float64)

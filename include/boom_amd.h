@@ -79,6 +79,21 @@ int ba_build_suf_from_xy(ba_engine *e, int64_t n, int32_t p, const double *X,
 /* same, X / y already resident in device memory of e's device */
 int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
                                 const void *X_device, const void *y_device);
+/* The same build for a design matrix SHARDED BY ROWS over the ranks of a job
+ * (config 4: X = 3.3 GB): every rank computes the statistics of its own rows
+ * into a device block of ba_suf_block_size(p) doubles laid out as
+ *   [ X'X (p x p, column-major) | X'y (p) | y'y, sum y | column sums of X (p) ],
+ * the caller sums the blocks over ranks -- ONE all-reduce (RCCL over xGMI;
+ * boom_amd/dist.py: build_suf_row_sharded) -- and every rank installs the total.
+ * The sums are what NeRegSuf(X, y) holds (RegressionModel.cpp:309-328); every
+ * rank ends up with bitwise the same statistics, so chains do not depend on
+ * which rank runs them.  X_device is the shard, n_rows x p column-major. */
+size_t ba_suf_block_size(int32_t p);
+int ba_suf_partial_device(ba_engine *e, int64_t n_rows, int32_t p,
+                          const void *X_device, const void *y_device,
+                          void *block_device);
+int ba_set_suf_from_block_device(ba_engine *e, int64_t n_total, int32_t p,
+                                 const void *block_device);
 /* NeRegSuf(XTX, XTY, YTY, n, ybar, xbar), RegressionModel.cpp:330-345 */
 int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
                              const double *xty, double yty, double n,

@@ -226,3 +226,49 @@ def test_convenience_ctor_priors_match_oracle(oracle):
         o = oracle.ssvs_run(suf, want, ssvs_options(), ("philox", 1, c), g0, 30)
         assert np.array_equal(gam[c], o["gamma"][-1])
         assert relerr(beta[c], o["beta"][-1]) < RTOL
+
+
+def test_row_sharded_suf_build_matches_single_shot(oracle):
+    """config-4 data path on one device: the rows in three uneven shards, a
+    partial block each (ba_suf_partial_device, the MFMA syrk on the shard),
+    summed as the all-reduce would, installed with ba_set_suf_from_block_device:
+    the statistics equal the single-shot build's to rounding, and the chains run
+    on them are the oracle's chains on the same statistics"""
+    import boom_amd
+    import torch
+    from boom_amd import dist as bd
+    n, p = 5000, 96
+    X, y, _ = regression_data(n, p, 7, seed=61)
+    whole = boom_amd.Engine(4, seed=3)
+    whole.build_suf_from_xy(X, y)
+    ref = whole.get_suf()
+    eng = boom_amd.Engine(4, seed=3)
+    total = torch.zeros(bd.suf_block_size(p), dtype=torch.float64, device="cuda")
+    bounds = [0, 1700, 1701, n]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        Xs = torch.from_numpy(np.ascontiguousarray(X[lo:hi].T)).cuda()   # column-major shard
+        ys = torch.from_numpy(np.ascontiguousarray(y[lo:hi])).cuda()
+        blk = torch.empty_like(total)
+        eng.suf_partial_device(hi - lo, p, Xs.data_ptr(), ys.data_ptr(), blk.data_ptr())
+        total += blk
+    torch.cuda.synchronize()
+    eng.set_suf_from_block_device(n, p, total.data_ptr())
+    got = eng.get_suf()
+    assert np.max(np.abs(got["xtx"] - ref["xtx"])) < 1e-12 * np.abs(ref["xtx"]).max()
+    assert np.array_equal(got["xtx"], got["xtx"].T)
+    assert relerr(got["xty"], ref["xty"], 1e-6) < 1e-12
+    assert abs(got["yty"] - ref["yty"]) < 1e-12 * ref["yty"]
+    assert abs(got["ybar"] - ref["ybar"]) < 1e-13 and got["n"] == n
+    assert relerr(got["xbar"], ref["xbar"], 1e-6) < 1e-12
+    suf = _engine_suf(eng)
+    prior = spike_slab_prior(suf, 7)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    eng.set_state(g0)
+    eng.sweep(40)
+    gam, beta, sig = eng.get_states()
+    for c in (0, 3):
+        o = oracle.ssvs_run(suf, prior, ssvs_options(), ("philox", 3, c), g0, 40)
+        assert np.array_equal(gam[c], o["gamma"][-1])
+        assert relerr(beta[c], o["beta"][-1]) < RTOL

@@ -96,3 +96,66 @@ def test_shard_ids_are_disjoint_and_cover():
         off, n = bd.shard(1024, r)
         ids.extend(range(off, off + n))
     assert ids == list(range(8 * 1024))
+
+
+# ---- config-4 data path: design matrix sharded by rows, ONE all-reduce of the
+# sufficient-statistics block (here the partial blocks come from the oracle's
+# NeRegSuf restatement; on GPUs from ba_suf_partial_device -- same layout)
+N_ROWS, P_SUF = 257, 9
+
+
+def _suf_partial_block(lo, hi):
+    from boom_amd import dist as bd
+    from cases import regression_data
+    from oracle_lib import Oracle
+    X, y, _ = regression_data(N_ROWS, P_SUF, 3, seed=77)
+    s = Oracle().neregsuf(X[lo:hi], y[lo:hi])
+    blk = np.zeros(bd.suf_block_size(P_SUF))
+    pp = P_SUF * P_SUF
+    blk[:pp] = s["xtx"].T.ravel()          # column-major
+    blk[pp:pp + P_SUF] = s["xty"]
+    blk[pp + P_SUF] = s["yty"]
+    blk[pp + P_SUF + 1] = s["sumy"]
+    blk[pp + P_SUF + 2:] = s["xsum"]
+    return blk
+
+
+def _suf_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from boom_amd import dist as bd
+    lo, hi = bd.row_shard(N_ROWS, rank, world)
+    blk = torch.from_numpy(_suf_partial_block(lo, hi))
+    bd.reduce_suf_block(blk, world)
+    q.put((rank, lo, hi, blk.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_sufficient_statistics_all_reduce():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_suf_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    from boom_amd import dist as bd
+    from cases import regression_data
+    # the shards tile the rows, every rank holds the same total, bit for bit
+    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == N_ROWS
+    assert np.array_equal(got[0][3], got[1][3])
+    X, y, _ = regression_data(N_ROWS, P_SUF, 3, seed=77)
+    suf = bd.unpack_suf_block(got[0][3], P_SUF, N_ROWS)
+    assert np.allclose(suf["xtx"], X.T @ X, rtol=1e-13, atol=1e-11)
+    assert np.allclose(suf["xty"], X.T @ y, rtol=1e-13, atol=1e-11)
+    assert abs(suf["yty"] - y @ y) < 1e-11 * (y @ y)
+    assert abs(suf["sumy"] - y.sum()) < 1e-11
+    assert np.allclose(suf["xsum"], X.sum(axis=0), rtol=1e-13, atol=1e-11)
+    assert suf["n"] == N_ROWS
