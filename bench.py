@@ -121,10 +121,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # (BOOM_AMD_BENCH_BACKEND=gloo: dry run of the multi-rank path on fewer GPUs
+    # than ranks -- ranks share devices, collectives go through the host; the
+    # driver's runs use RCCL, one rank per GPU)
+    backend = os.environ.get("BOOM_AMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import boom_amd
     from cases import regression_data, spike_slab_prior
@@ -137,8 +146,18 @@ def main():
     Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()  # column-major n x p
     yd = torch.from_numpy(y).cuda()
     torch.cuda.synchronize()
+    from boom_amd import dist as bd
     t0 = time.perf_counter()
-    eng.build_suf_from_xy_device(N_OBS, P, Xd.data_ptr(), yd.data_ptr())
+    if world > 1:
+        # the multi-GPU data path: every rank takes its rows, local
+        # MFMA syrk, ONE all-reduce of (X'X | X'y | y'y | sums) over RCCL, every
+        # rank installs the (bitwise identical) total
+        lo, hi = bd.row_shard(N_OBS, rank, world)
+        Xs = torch.from_numpy(np.ascontiguousarray(X[lo:hi].T)).cuda()
+        ys = torch.from_numpy(np.ascontiguousarray(y[lo:hi])).cuda()
+        bd.build_suf_row_sharded(eng, Xs, ys, N_OBS, world)
+    else:
+        eng.build_suf_from_xy_device(N_OBS, P, Xd.data_ptr(), yd.data_ptr())
     suf_build_s = time.perf_counter() - t0
     s = eng.get_suf()
     suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"],
@@ -175,7 +194,6 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # avg launch duration
 
     # ---- posterior summaries: one RCCL all-gather at the end ----------------
-    from boom_amd import dist as bd
     block = torch.empty(bd.summary_block_size(P), dtype=torch.float64, device="cuda")
     eng.summaries_device(block.data_ptr())
     allb = bd.gather_blocks(block, world)          # ONE RCCL all-gather
@@ -316,7 +334,9 @@ def main():
                    "chains_per_gpu": CHAINS_PER_GPU,
                    "sweeps_per_step": SWEEPS_PER_STEP,
                    "true_signals": N_SIGNAL, "mean_model_size": round(kbar, 2),
-                   "burn_in": BURN_IN, "parallelism": "chains sharded, %d GPU(s)" % world},
+                   "burn_in": BURN_IN, "parallelism": "chains sharded, %d GPU(s)" % world,
+                   "suf_build": ("rows sharded, local MFMA syrk, one all-reduce" if world > 1
+                                 else "single device MFMA syrk")},
         "ess_per_sec": round(ess_per_sec, 1),
         "ess_fraction": round(ess_frac, 4),
         "ess_traces": {k: round(v / (CHAINS_PER_GPU * trace_len), 4) for k, v in ess.items()},

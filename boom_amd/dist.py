@@ -20,6 +20,16 @@ def summary_block_size(p):
     return 3 * p + SUMMARY_SCALARS
 
 
+def _staged(t):
+    """the tensor a collective runs on: the tensor itself with RCCL, a host copy
+    when the job's backend is gloo but the data sit on a GPU (single-GPU dry runs
+    of the multi-rank path)"""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        return t.cpu(), True
+    return t, False
+
+
 def gather_blocks(block, world):
     """all-gather one summary block per rank -> (world, 3p+16) numpy array.
     `block` is a 1-d float64 torch tensor on the backend's device."""
@@ -27,8 +37,9 @@ def gather_blocks(block, world):
     import torch.distributed as dist
     if world == 1:
         return block.detach().cpu().numpy()[None, :]
-    out = [torch.empty_like(block) for _ in range(world)]
-    dist.all_gather(out, block)
+    blk, _ = _staged(block)
+    out = [torch.empty_like(blk) for _ in range(world)]
+    dist.all_gather(out, blk)
     return torch.stack(out).cpu().numpy()
 
 
@@ -37,6 +48,8 @@ def max_over_ranks(value, world, device):
     import torch.distributed as dist
     if world == 1:
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -58,7 +71,10 @@ def reduce_suf_block(block, world):
     torch tensor on the backend's device."""
     import torch.distributed as dist
     if world > 1:
-        dist.all_reduce(block, op=dist.ReduceOp.SUM)
+        blk, staged = _staged(block)
+        dist.all_reduce(blk, op=dist.ReduceOp.SUM)
+        if staged:
+            block.copy_(blk)
     return block
 
 
