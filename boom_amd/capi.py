@@ -94,6 +94,7 @@ SIGNATURES = {
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_impute_state": (C.c_int, [C.c_void_p]),
+    "ba_ss_forecast": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     "ba_ss_get_state": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
     "ba_ss_set_level_sigsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_double]),
     "ba_ss_get_chain_suf": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp]),
@@ -395,6 +396,13 @@ class Engine:
     def ss_impute_state(self):
         self._check(self.lib.ba_ss_impute_state(self._h))
         self.sync()
+
+    def ss_forecast(self, newX):
+        """one predictive draw of the next len(newX) observations per chain"""
+        h = newX.shape[0]
+        out = np.zeros((self.chains, h))
+        self._check(self.lib.ba_ss_forecast(self._h, h, _p(_fcol(newX)), _p(out)))
+        return out
 
     def ss_get_state(self, chain):
         st = np.zeros(self.T)

@@ -9,7 +9,27 @@
 // lane-parallel, the data-dependent tail (swap move, sigma, beta) walks the
 // stream sequentially exactly like the reference's rng() calls.
 //
-// The transforms below follow the reference's Bmath routines so that a chain
+// PROVENANCE.  The transforms below have to reproduce, draw for draw, what the
+// reference's Bmath routines make of a stream of uniforms -- same constants,
+// same operation order, same number of uniforms consumed on every branch --
+// because the parity bar is "the reference's chain on the same stream".  Bmath is
+// BOOM's in-tree fork of R's nmath (GPL-2+ / LGPL, (C) R Core Team and the
+// authors below); the algorithms are published ones:
+//   normal       A. J. Kinderman and J. G. Ramage (1976), "Computer generation of
+//                normal random variables", JASA 71, 893-896, with J. Leydold's
+//                correction of the tail branch (R's KINDERMAN_RAMAGE)
+//   exponential  J. H. Ahrens and U. Dieter (1972), "Computer methods for sampling
+//                from the exponential and normal distributions", CACM 15, 873-882
+//   gamma        J. H. Ahrens and U. Dieter (1982), "Generating gamma variates by
+//                a modified rejection technique" (GD, a >= 1), CACM 25, 47-54;
+//                (1974) "Computer methods for sampling from gamma, beta, Poisson
+//                and binomial distributions" (GS, a < 1), Computing 12, 223-246
+// The arithmetic therefore cannot differ from nmath's; what is ours is the
+// form: templates over the stream type (sequential Philox view / register
+// window), loops instead of recursion, no R_FINITE / ML_ERROR handling (the
+// callers guarantee the argument ranges), wave-uniform execution.
+//
+// The transforms follow the reference's Bmath routines so that a chain
 // consumes the stream in the reference's order:
 //   runif_mt      Bmath/runif.cpp:45-52
 //   random_int_mt distributions/random_int.cpp:26-29
@@ -230,7 +250,7 @@ __device__ __forceinline__ double d_exp_rand(R &r) {
 template <class R>
 __device__ __forceinline__ double d_rgamma_scale(R &rng, double a, double scale,
                                         int *bad) {
-  const double sqrt32 = 5.656854, exp_m1 = 0.36787944117144232159;
+  const double kSqrt32 = 5.656854, kInvE = 0.36787944117144232159;
   const double q1 = 0.04166669, q2 = 0.02083148, q3 = 0.00801191,
                q4 = 0.00144121, q5 = -7.388e-5, q6 = 2.4511e-4, q7 = 2.424e-4;
   const double a1 = 0.3333333, a2 = -0.250003, a3 = 0.2000062,
@@ -241,7 +261,7 @@ __device__ __forceinline__ double d_rgamma_scale(R &rng, double a, double scale,
     return 1.0;
   }
   if (a < 1.) {  // GS
-    const double e = 1.0 + exp_m1 * a;
+    const double e = 1.0 + kInvE * a;
     double x;
     for (;;) {
       for (;;) {
@@ -257,52 +277,52 @@ __device__ __forceinline__ double d_rgamma_scale(R &rng, double a, double scale,
       if (x > 0) return scale * x;
     }
   }
-  const double s2 = a - 0.5, s = sqrt(s2), d = sqrt32 - s * 12.0;
+  const double s2 = a - 0.5, s = sqrt(s2), d = kSqrt32 - s * 12.0;
   double t = d_norm_rand(rng);
   double x = s + 0.5 * t;
-  const double ret_val = x * x;
-  if (t >= 0.0) return scale * ret_val;
+  const double x_squared = x * x;
+  if (t >= 0.0) return scale * x_squared;
   double u = rng();
-  if (d * u <= t * t * t) return scale * ret_val;
+  if (d * u <= t * t * t) return scale * x_squared;
   const double rr = 1.0 / a;
-  const double q0 =
+  const double q_zero =
       ((((((q7 * rr + q6) * rr + q5) * rr + q4) * rr + q3) * rr + q2) * rr + q1) * rr;
-  double b, si, c;
+  double b, slope, c;
   if (a <= 3.686) {
     b = 0.463 + s + 0.178 * s2;
-    si = 1.235;
+    slope = 1.235;
     c = 0.195 / s - 0.079 + 0.16 * s;
   } else if (a <= 13.022) {
     b = 1.654 + 0.0076 * s2;
-    si = 1.68 / s + 0.275;
+    slope = 1.68 / s + 0.275;
     c = 0.062 / s + 0.024;
   } else {
     b = 1.77;
-    si = 0.75;
+    slope = 0.75;
     c = 0.1515 / s;
   }
   double q, v;
   if (x > 0.0) {
     v = t / (s + s);
     if (fabs(v) <= 0.25)
-      q = q0 + 0.5 * t * t *
+      q = q_zero + 0.5 * t * t *
                    ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
     else
-      q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log1p(v);
-    if (log(1.0 - u) <= q) return scale * ret_val;
+      q = q_zero - s * t + 0.25 * t * t + (s2 + s2) * log1p(v);
+    if (log(1.0 - u) <= q) return scale * x_squared;
   }
   for (;;) {
     const double e = d_exp_rand(rng);
     u = rng();
     u = u + u - 1.0;
-    t = (u < 0.0) ? b - si * e : b + si * e;
+    t = (u < 0.0) ? b - slope * e : b + slope * e;
     if (t >= -0.71874483771719) {
       v = t / (s + s);
       if (fabs(v) <= 0.25)
-        q = q0 + 0.5 * t * t *
+        q = q_zero + 0.5 * t * t *
                      ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
       else
-        q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+        q = q_zero - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
       if (q > 0.0) {
         const double w = expm1(q);
         if (c * fabs(u) <= w * exp(e - 0.5 * t * t)) break;

@@ -39,6 +39,8 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
 // kalman_kernel.hip
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
+hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
+                              uint64_t *pos_forecast, double *out);
 }  // namespace boom_amd
 
 using namespace boom_amd;
@@ -211,7 +213,7 @@ struct ba_engine {
   DevBuf<uint8_t> dss_obs;
   DevBuf<double> dxty_c, dyty_c, dnobs_c;       // per-chain regression suf
   DevBuf<double> dlev_sigsq, dlev_n, dlev_sumsq;
-  DevBuf<uint64_t> dpos_level, dpos_state;
+  DevBuf<uint64_t> dpos_level, dpos_state, dpos_forecast;
   double level_prior_df = 0, level_prior_ss = 0;
   double level_sigma_max = std::numeric_limits<double>::infinity();
   double ss_a0 = 0, ss_P0 = 1, ss_initial_level_sigsq = 1;
@@ -1345,6 +1347,7 @@ int ba_seed(ba_engine *e, uint64_t seed) {
   if (e->dpos_ada.ptr) HIP_TRY(hipMemsetAsync(e->dpos_ada.ptr, 0, C * 8, s));
   if (e->dpos_level.ptr) HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
   if (e->dpos_state.ptr) HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
+  if (e->dpos_forecast.ptr) HIP_TRY(hipMemsetAsync(e->dpos_forecast.ptr, 0, C * 8, s));
   HIP_TRY(hipStreamSynchronize(s));
   return BA_OK;
 }
@@ -1846,6 +1849,8 @@ static int ss_prepare(ba_engine *e) {
     HIP_TRY(e->dlev_sumsq.resize(C));
     HIP_TRY(e->dpos_level.resize(C));
     HIP_TRY(e->dpos_state.resize(C));
+    HIP_TRY(e->dpos_forecast.resize(C));
+    HIP_TRY(hipMemsetAsync(e->dpos_forecast.ptr, 0, C * 8, e->stream));
     // regression suf starts as the data's own (before the first impute_state)
     std::vector<double> xty(C * p), yty(C, e->yty), nobs(C, e->n),
         lev(C, e->ss_initial_level_sigsq);
@@ -1958,6 +1963,26 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
     P.model_keep = 1;  // from here on the chains' model blocks are their own last launch's
     e->model_ok = true;
   }
+  return BA_OK;
+}
+
+int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *out) {
+  ENGINE_PROLOGUE(e);
+  if (!newX || !out || horizon <= 0) return fail(BA_E_INVALID, "bad argument");
+  if (!e->ss_mode || e->dss_scratch.count == 0 || !e->ss_initialized)
+    return fail(BA_E_STATE, "no state draw yet: run ba_ss_sweep or ba_ss_impute_state first");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, h = (size_t)horizon;
+  DevBuf<double> dnx, dout;
+  HIP_TRY(dnx.resize(h * p));
+  HIP_TRY(dout.resize(C * h));
+  HIP_TRY(hipMemcpyAsync(dnx.ptr, newX, h * p * 8, hipMemcpyHostToDevice, e->stream));
+  SsParams S;
+  fill_ss_params(e, S);
+  HIP_TRY(launch_ss_forecast(e->stream, S, horizon, dnx.ptr, e->dpos_forecast.ptr, dout.ptr));
+  HIP_TRY(hipMemcpyAsync(out, dout.ptr, C * h * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return BA_OK;
 }
 

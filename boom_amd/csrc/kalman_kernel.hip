@@ -807,6 +807,40 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   }
 }
 
+// StateSpaceRegressionModel::simulate_forecast for every chain's current draw
+// (StateSpaceRegressionModel.cpp:214-219, :256-278): state_i = state_{i-1} +
+// N(0, sigma_level) starting from the final state, y_i = N(state_i, sigma_obs) +
+// x_i'beta; the normals in the reference's order (state error, then
+// observation) on the chain's forecast stream (id 5).  One wavefront per chain:
+// the stream is read by the whole wave in lockstep, the lanes share x_i'beta.
+__global__ __launch_bounds__(64) void ss_forecast_kernel(SsParams P, int horizon, const double *newX,
+                                                         uint64_t *pos_forecast, double *out) {
+  const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x;
+  if ((int)blockIdx.x >= P.chain_count) return;
+  if (P.status[chain] != CHAIN_OK) return;
+  const int T = P.T, p = P.p;
+  const double *beta = P.beta + (size_t)chain * p;
+  const double sd_obs = sqrt(P.sigsq[chain]), sd_level = sqrt(P.level_sigsq[chain]);
+  double state = P.scratch[(size_t)chain * P.scratch_stride + (size_t)SS_STATE_ARRAY * T + (T - 1)];
+  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 5u}, pos_forecast[chain]};
+  for (int i = 0; i < horizon; ++i) {
+    state = state + d_rnorm(rng, 0.0, sd_level);
+    const double obs = d_rnorm(rng, state, sd_obs);
+    double part = 0.0;
+    for (int j = lane; j < p; j += WAVE) part += newX[(size_t)j * horizon + i] * beta[j];
+    const double pred = wave_sum(part);
+    if (lane == 0) out[(size_t)chain * horizon + i] = obs + pred;
+  }
+  if (lane == 0) pos_forecast[chain] = rng.pos;
+}
+
+hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
+                              uint64_t *pos_forecast, double *out) {
+  hipLaunchKernelGGL(ss_forecast_kernel, dim3(P.chain_count), dim3(WAVE), 0, stream, P, horizon, newX,
+                     pos_forecast, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
                            const double *B, int64_t ldb, int N, int K, double *C, int ldc);
 

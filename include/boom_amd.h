@@ -305,6 +305,13 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps);
 /* one Base::impute_state (StateSpaceModelBase.cpp:278-291) with the current
  * parameters, on every chain */
 int ba_ss_impute_state(ba_engine *e);
+/* StateSpaceRegressionModel::simulate_forecast(rng, newX, final_state)
+ * (StateSpaceRegressionModel.cpp:214-219, :256-278; what bsts' predict does for
+ * every saved draw): one draw from the predictive distribution of the next
+ * `horizon` observations for EVERY chain's current parameters and final state.
+ * newX is horizon x p column-major (host); out is chains x horizon (host),
+ * row-major.  Each call continues the chains' forecast streams. */
+int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *out);
 /* state(): T doubles of one chain; level sigsq; level suf (n, sumsq) */
 int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
                     double *level_sigsq, double *level_n, double *level_sumsq);

@@ -1328,6 +1328,25 @@ int bo_adaptive_draw(bo_adaptive *a) {
   return status;
 }
 
+/* StateSpaceRegressionModel::simulate_forecast with a local level
+ * (StateSpaceRegressionModel.cpp:214-219, :256-278; advance_to_timestamp
+ * StateSpaceModelBase.cpp:455-467; simulate_next_state :439-452): per step the
+ * state error, then the observation noise, plus the regression prediction
+ * x_i'beta (GlmCoefs::predict: a dense dot with Beta()). */
+void bo_ss_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,
+                             const double *beta, double sigsq_obs,
+                             double sigsq_level, double final_state, double *out) {
+  double state = final_state;
+  const double sd_level = sqrt(sigsq_level), sd_obs = sqrt(sigsq_obs);
+  for (int i = 0; i < horizon; ++i) {
+    state = state + bo_rnorm(rng, 0, sd_level);
+    double ans = bo_rnorm(rng, state, sd_obs);
+    double pred = 0;
+    for (int j = 0; j < p; ++j) pred += newX[IDX(i, j, horizon)] * beta[j];
+    out[i] = ans + pred;
+  }
+}
+
 /* ---- many chains (cpu_baseline leg) ------------------------------------ */
 typedef struct {
   int p;

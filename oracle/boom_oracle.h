@@ -197,6 +197,12 @@ int bo_ss_impute_state(bo_ss *m, bo_rng *rng);
 /* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64 */
 int bo_ss_draw(bo_ss *m);
 
+/* simulate_forecast of the local level + regression model
+ * (StateSpaceRegressionModel.cpp:214-219, :256-278); newX horizon x p column-major */
+void bo_ss_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,
+                             const double *beta, double sigsq_obs,
+                             double sigsq_level, double final_state, double *out);
+
 /* AdaptiveSpikeSlabRegressionSampler on top of a bo_ssvs
  * (AdaptiveSpikeSlabRegressionSampler.cpp:62-225) */
 typedef struct bo_adaptive bo_adaptive;

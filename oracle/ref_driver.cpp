@@ -529,6 +529,37 @@ int ref_ss_impute_state(int T, int p, const double *y, const double *X,
   REF_CATCH
 }
 
+// simulate_forecast (StateSpaceRegressionModel.cpp:214-219, :256-278): the draw
+// from the predictive distribution of the next `horizon` observations given
+// the parameters and the final state of one MCMC draw (what bsts' predict does
+// per saved draw)
+int ref_ss_forecast(int T, int p, const double *y, const double *X,
+                    const double *beta, const uint8_t *gamma, double sigsq_obs,
+                    double sigsq_level, double final_state, int horizon,
+                    const double *newX, uint64_t seed, double *out) {
+  REF_TRY
+  NEW(StateSpaceRegressionModel, model)(make_vector(T, y), make_matrix(T, p, X),
+                                        std::vector<bool>());
+  RegressionModel *reg = model->observation_model();
+  reg->coef().drop_all();
+  Vector b(p, 0.0);
+  for (int j = 0; j < p; ++j) {
+    if (gamma[j]) {
+      reg->coef().add(j);
+      b[j] = beta[j];
+    }
+  }
+  reg->coef().set_Beta(b);
+  reg->set_sigsq(sigsq_obs);
+  NEW(LocalLevelStateModel, level)(std::sqrt(sigsq_level));
+  model->add_state(level);
+  RNG rng(seed);
+  Vector fs(1, final_state);
+  Vector ans = model->simulate_forecast(rng, make_matrix(horizon, p, newX), fs);
+  for (int i = 0; i < horizon; ++i) out[i] = ans[i];
+  REF_CATCH
+}
+
 // ------------------------------------------- SpikeSlabSampler (sigma given)
 // The sigma^2-conditional SSVS helper used by the logit / probit / Poisson /
 // Student samplers (SpikeSlabSampler.cpp:40-82, 115-138, 171-216), driven the

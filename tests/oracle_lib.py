@@ -575,6 +575,18 @@ class Oracle:
         return out
 
 
+    def ss_forecast(self, rng, newX, beta, sigsq_obs, sigsq_level, final_state):
+        h, p = newX.shape
+        out = np.zeros(h)
+        self.lib.bo_ss_simulate_forecast.argtypes = [
+            C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.c_double,
+            C.c_double, C.c_double, c_double_p]
+        self.lib.bo_ss_simulate_forecast(C.byref(rng), h, p, _dp(fcol(newX)), _dp(f64(beta)),
+                                         float(sigsq_obs), float(sigsq_level),
+                                         float(final_state), _dp(out))
+        return out
+
+
 # ---------------------------------------------------------------------------
 def have_ref():
     return os.path.exists(REF_SO)
@@ -818,6 +830,18 @@ class Ref:
             _u8(gam), _dp(beta), _dp(sig), _dp(lev), _dp(state)))
         return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
                     state=state)
+
+    def ss_forecast(self, y, X, beta, gamma, sigsq_obs, sigsq_level, final_state,
+                    newX, seed):
+        T, p = X.shape
+        h = newX.shape[0]
+        out = np.zeros(h)
+        g = np.ascontiguousarray(gamma, dtype=np.uint8)
+        self._check(self.lib.ref_ss_forecast(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _dp(f64(beta)), _u8(g),
+            C.c_double(sigsq_obs), C.c_double(sigsq_level), C.c_double(final_state),
+            h, _dp(fcol(newX)), C.c_uint64(seed), _dp(out)))
+        return out
 
     def ss_impute_state(self, y, X, observed, beta, gamma, sigsq_obs,
                         sigsq_level, a0, P0, seed):

@@ -275,3 +275,13 @@ def test_adaptive_sampler_matches_reference(oracle, name):
     assert np.max(np.abs(o["beta"] - g["beta"]) / np.maximum(np.abs(g["beta"]), 1e-3)) < 1e-11
     assert np.max(np.abs(o["sigsq"] - g["sigsq"]) / g["sigsq"]) < 1e-11
     assert o["min_margin"] > 1e-9 and o["min_multi_margin"] > 1e-12
+
+
+def test_simulate_forecast_known_answer(oracle):
+    """StateSpaceRegressionModel::simulate_forecast (local level + regression)
+    against the reference's own output for fixed parameters and final state."""
+    g = np.load(os.path.join(GOLD, "kat_forecast.npz"))
+    got = oracle.ss_forecast(oracle.rng_mt(int(g["seed"])), g["newX"], g["beta"],
+                             float(g["sigsq_obs"]), float(g["sigsq_level"]),
+                             float(g["final_state"]))
+    assert np.max(np.abs(got - g["forecast"])) < 1e-13

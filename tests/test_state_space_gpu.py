@@ -145,3 +145,30 @@ def test_capacity_escalation_in_stream():
     for a, b in zip(ref[3], got[3]):
         assert np.array_equal(a["state"], b["state"])
         assert a["level_sigsq"] == b["level_sigsq"]
+
+
+def test_forecast_matches_oracle(oracle):
+    """f4: simulate_forecast for every chain's current draw -- the next `horizon`
+    observations given the chain's beta, sigma^2, level variance and final state,
+    normals in the reference's order on the chain's forecast stream"""
+    T, p, chains, seed, h = 300, 8, 7, 23, 30
+    X, y, _, obs = state_space_data(T, p, 3, seed=5, missing_frac=0.03)
+    prior, ss, sig_up = bsts_priors(X, y, 3)
+    g0 = np.zeros(p, np.uint8)
+    eng = make_engine(chains, seed, y, X, obs, prior, ss, sig_up, g0)
+    eng.ss_sweep(25)
+    newX = np.random.Generator(np.random.PCG64(8)).standard_normal((h, p))
+    f1 = eng.ss_forecast(newX)
+    f2 = eng.ss_forecast(newX)          # the streams continue: a second, different draw
+    gam, beta, sig = eng.get_states()
+    assert f1.shape == (chains, h) and not np.array_equal(f1, f2)
+    for c in range(chains):
+        st = eng.ss_get_state(c)
+        rng = oracle.rng_philox(seed, chain=c, stream=5)
+        want1 = oracle.ss_forecast(rng, newX, beta[c], sig[c], st["level_sigsq"], st["state"][-1])
+        want2 = oracle.ss_forecast(rng, newX, beta[c], sig[c], st["level_sigsq"], st["state"][-1])
+        assert np.max(np.abs(f1[c] - want1)) < 1e-9 * np.abs(want1).max()
+        assert np.max(np.abs(f2[c] - want2)) < 1e-9 * np.abs(want2).max()
+    # forecasts centre on level + regression: the predictive mean over chains tracks it
+    mid = np.array([eng.ss_get_state(c)["state"][-1] for c in range(chains)]).mean()
+    assert abs(np.median(f1[:, 0] - newX[0] @ beta.mean(axis=0)) - mid) < 3.0
