@@ -45,3 +45,17 @@ def test_product_does_not_touch_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "boom_oracle" not in txt and "oracle_lib" not in txt, f
                 assert "libboomref" not in txt, f
+
+
+def test_pybind_module_imports_and_mirrors_the_boom_names():
+    """boom_amd._boom: the BayesBoom-shaped names of the path (no GPU needed to
+    import it or to build the prior objects)"""
+    import numpy as np
+    import boom_amd._boom as boom
+    for name in ("RegressionModel", "BregVsSampler", "MvnGivenScalarSigma", "ChisqModel",
+                 "VariableSelectionPrior", "PosteriorSampler", "GlmCoefs"):
+        assert hasattr(boom, name), name
+    slab = boom.MvnGivenScalarSigma(np.zeros(3), np.eye(3))
+    assert slab.dim == 3
+    assert boom.ChisqModel(2.0, 1.5).sigma == 1.5
+    assert boom.VariableSelectionPrior(np.full(3, 0.5)).potential_nvars == 3
