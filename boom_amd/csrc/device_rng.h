@@ -36,7 +36,8 @@
 //   norm_rand     Bmath/snorm.cpp:287-340 (Kinderman-Ramage, Leydold fix)
 //   exp_rand      Bmath/sexp.cpp:58-104
 //   rgamma_mt     Bmath/rgamma.cpp:80-259 (GD for a >= 1, GS for .3 <= a < 1)
-//   rtrun_gamma   distributions/trun_gamma.cpp:73-81 (rejection branch)
+//   rtrun_gamma   distributions/trun_gamma.cpp:73-148 (rejection, adaptive
+//                 rejection (BoundedAdaptiveRejectionSampler.cpp), slice)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -146,6 +147,19 @@ struct WinRng {
     return __hiloint2double(hi, lo);
   }
 };
+
+// key / position of either view of a stream
+__device__ __forceinline__ PhiloxKey stream_key(const SeqRng &r) { return r.key; }
+__device__ __forceinline__ PhiloxKey stream_key(const WinRng &r) { return r.key; }
+__device__ __forceinline__ uint64_t stream_pos(const SeqRng &r) { return r.pos; }
+__device__ __forceinline__ uint64_t stream_pos(const WinRng &r) { return r.get_pos(); }
+__device__ __forceinline__ void stream_seek(SeqRng &r, uint64_t p) { r.pos = p; }
+__device__ __forceinline__ void stream_seek(WinRng &r, uint64_t p) {
+  // (wave-uniform by construction)
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+  r.set_pos(((uint64_t)hi << 32) | lo);
+}
 
 template <class R>
 __device__ __forceinline__ double d_runif(R &r, double a, double b) {
@@ -333,13 +347,167 @@ __device__ __forceinline__ double d_rgamma_scale(R &rng, double a, double scale,
   return scale * x * x;
 }
 
+// ---- rtrun_gamma_mt beyond the plain rejection branch --------------------------
+// (distributions/trun_gamma.cpp:82-104: the truncation point is at or above the
+// mode).  Rare -- a sigma upper limit tighter than the posterior wants -- and
+// scalar by nature, so it is kept out of line (one copy per kernel, nothing of
+// it in the hot path's registers): wave-uniform callers execute it in lockstep.
+
+#ifndef BA_RARE
+#define BA_RARE __forceinline__
+#endif
+// dtrun_gamma(x, a, b, cut, log = true, normalize = false), trun_gamma.cpp:34-48
+__device__ __forceinline__ double d_dtrun_gamma_log(double x, double a, double b, double cut) {
+  if (a < 0 || b < 0 || cut < 0 || x < cut) return -__builtin_inf();
+  return (a - 1) * log(x) - b * x;
+}
+// rexp_mt(rng, lam) (Rmath_dist.cpp:221-223)
+template <class R>
+__device__ __forceinline__ double d_rexp(R &r, double lam) { return (1.0 / lam) * d_exp_rand(r); }
+// rtrun_exp_mt(rng, lam, lo, hi) = rpiecewise_log_linear_mt(rng, -lam, lo, hi)
+// (distributions/trun_exp.cpp:38-70; finite lo < hi here)
+template <class R>
+__device__ __forceinline__ double d_rtrun_exp(R &r, double lam, double lo, double hi) {
+  const double slope = -lam;
+  if (fabs(hi - lo) < 1e-7) return lo;
+  double u = 0.0;
+  const double eps = 2.2250738585072014e-308;
+  while (u < eps || u >= 1.0 - eps) u = r();
+  double x = log(u) + slope * hi;
+  double y = log(1 - u) + slope * lo;
+  if (x < y) { const double t = x; x = y; y = t; }
+  return (x + log1p(exp(y - x))) / slope;
+}
+
+// BoundedAdaptiveRejectionSampler (distributions/BoundedAdaptiveRejectionSampler.cpp)
+// on logf(x) = (a - 1) log x - b x over [cut, inf), cut to the right of the mode.
+// The hull lives across the wave: lane i holds point i (abscissa, log density,
+// slope, knot, cdf), up to ARS_CAP = 64 points (the oracle's cap; the hull of a
+// gamma tail is tight after a handful), so there is no per-lane array and no
+// scratch memory.  Every lane of the calling wave must be active; all lanes
+// consume the same numbers and return the same draw.  Searches follow
+// std::lower_bound's probe sequence, which is what the reference runs over its
+// knots_ / cdf_ vectors -- also where rounding has left them out of order.
+enum { ARS_CAP = 64 };
+__device__ __forceinline__ double ars_lane(double v, int k) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int ars_lower_bound(double v, int n, double value) {
+  int first = 0, count = n;
+  while (count > 0) {
+    const int step = count / 2;
+    if (ars_lane(v, first + step) < value) {
+      first += step + 1;
+      count -= step + 1;
+    } else {
+      count = step;
+    }
+  }
+  return first;
+}
+__device__ BA_RARE double d_ars_gamma_tail(SeqRng &rng, double a, double b, double cut, int *bad) {
+  const int lane = (int)(threadIdx.x & 63);
+  int n = 1;
+  // (lanes past n hold copies of older points: never read)
+  double xs = cut, ys = d_dtrun_gamma_log(cut, a, b, cut), ds = (a - 1) / cut - b, kn = cut, cdf = 0.0;
+  if (ds >= 0) { *bad = 2; return 1.0; }
+  for (int level = 0; level <= 1001; ++level) {
+    // update_cdf (.cpp:109-138): cdf[k] = (cdf[k - 1] + inc1[k]) - inc2[k], in order
+    {
+      const double y = ys - ars_lane(ys, 0), dinv = 1.0 / ds;
+      const double knext = __shfl_down(kn, 1);
+      const double inc1 = (lane == n - 1) ? 0 : dinv * exp(y - ds * xs + ds * knext);
+      const double inc2 = dinv * exp(y - ds * xs + ds * kn);
+      double last = 0;
+      for (int k = 0; k < n; ++k) {
+        last = (last + ars_lane(inc1, k)) - ars_lane(inc2, k);
+        if (lane == k) cdf = last;
+      }
+    }
+    // draw_safely (.cpp:150-183)
+    const double u = d_runif(rng, 0.0, ars_lane(cdf, n - 1));
+    int k = ars_lower_bound(cdf, n, u);
+    double cand;
+    if (k + 1 >= n) {   // (k == n cannot happen: u <= cdf[n - 1])
+      k = n - 1;
+      cand = ars_lane(kn, k) + d_rexp(rng, -1 * ars_lane(ds, k));
+    } else {
+      cand = d_rtrun_exp(rng, -1 * ars_lane(ds, k), ars_lane(kn, k), ars_lane(kn, k + 1));
+    }
+    const double target = d_dtrun_gamma_log(cand, a, b, cut);
+    const double hull = ars_lane(ys, k) + ars_lane(ds, k) * (cand - ars_lane(xs, k));
+    const double logu = hull - d_rexp(rng, 1.0);
+    if (logu <= target) return cand;
+    // add_point (.cpp:61-83): insert before the first knot >= cand
+    if (n >= ARS_CAP) { *bad = 2; return 1.0; }
+    const int pos = ars_lower_bound(kn, n, cand);
+    {
+      const double xu = __shfl_up(xs, 1), yu = __shfl_up(ys, 1), du = __shfl_up(ds, 1);
+      if (lane > pos) { xs = xu; ys = yu; ds = du; }
+      if (lane == pos) { xs = cand; ys = target; ds = (a - 1) / cand - b; }
+    }
+    ++n;
+    // refresh_knots / compute_knot (:85-107)
+    {
+      const double x1 = __shfl_up(xs, 1), y1 = __shfl_up(ys, 1), d1 = __shfl_up(ds, 1);
+      if (lane == 0 || ds == d1) {
+        kn = (lane == 0) ? xs : x1;
+      } else {
+        double ans = (y1 - d1 * x1) - (ys - ds * xs);
+        ans /= (ds - d1);
+        kn = ans;
+      }
+    }
+  }
+  *bad = 2;
+  return 1.0;
+}
+
+// rtg_init / rtg_slice x 5 (trun_gamma.cpp:100-104, :110-148): shape <= 1
+__device__ BA_RARE double d_slice_gamma_tail(SeqRng &rng, double a, double b, double cut) {
+  double x = cut;
+  for (int it = 0; it < 5; ++it) {
+    const double logpstar = d_dtrun_gamma_log(x, a, b, cut) - d_rexp(rng, 1.0);
+    const double lo = cut;
+    double hi = x;
+    {  // rtg_init
+      double f = d_dtrun_gamma_log(hi, a, b, cut) - logpstar;
+      double fprime = ((a - 1) / hi) - b;
+      int attempts = 0;
+      while (f > sqrt(2.220446049250313e-16)) {
+        hi -= f / fprime;
+        f = d_dtrun_gamma_log(hi, a, b, cut) - logpstar;
+        fprime = ((a - 1) / cut) - b;
+        if (++attempts > 1000) break;
+      }
+    }
+    x = d_runif(rng, lo, hi);
+    int trials = 0;
+    bool gave_up = false;
+    while (d_dtrun_gamma_log(x, a, b, cut) < logpstar) {
+      hi = x;
+      x = d_runif(rng, lo, hi);
+      if (++trials > 1000) { gave_up = true; break; }
+    }
+    if (gave_up) x = cut;
+  }
+  return x;
+}
+
 // GenericGaussianVarianceSampler::draw,
 // Models/PosteriorSamplers/GenericGaussianVarianceSampler.cpp:44-63:
 // sigma^2 = 1 / Gamma(shape = DF/2, rate = SS/2), truncated to
-// sigma <= sigma_max when that is finite.  *bad: 1 = shape < .3, 2 = the
-// truncation point is at or above the mode (adaptive-rejection / slice
-// branches of rtrun_gamma_mt, not implemented on the device).
-template <class R>
+// sigma <= sigma_max when that is finite (rtrun_gamma_mt,
+// distributions/trun_gamma.cpp:73-106).  FULL = false leaves the two rare
+// branches (truncation point at or above the mode) out of the code: the LDS
+// sweep kernel's hot instances are built that way -- the branches cost it
+// registers it does not have -- and hand a chain that needs them to their FULL
+// twins (*bad = 3; ssvs_kernel.hip).  *bad: 1 = shape < .3 in the plain gamma
+// draw, 2 = the adaptive-rejection sampler gave up, 3 = needs FULL.
+template <bool FULL = true, class R>
 __device__ __forceinline__ double d_draw_variance(R &rng, double DF, double SS,
                                          double sigma_max, int *bad) {
   if (sigma_max == 0.0) return 0.0;
@@ -347,9 +515,24 @@ __device__ __forceinline__ double d_draw_variance(R &rng, double DF, double SS,
   if (isinf(sigma_max)) return 1.0 / d_rgamma_scale(rng, a, 1.0 / b, bad);
   const double cut = 1.0 / (sigma_max * sigma_max);
   const double mode = (a - 1) / b;
-  if (!(cut < mode)) {
-    *bad = 2;
+  if (!FULL && !(cut < mode)) {
+    *bad = 3;
     return 1.0;
+  }
+  if (FULL && !(cut < mode)) {
+    // (the out-of-line routines read the stream through the plain sequential
+    // view, whatever view the caller uses: same numbers, same positions)
+    SeqRng sr{stream_key(rng), stream_pos(rng)};
+    int b2 = 0;
+    const double x = (a > 1) ? d_ars_gamma_tail(sr, a, b, cut, &b2) : d_slice_gamma_tail(sr, a, b, cut);
+    stream_seek(rng, sr.pos);
+    // (every lane computed the same thing; tell the compiler, whose callers
+    // steer wave-uniform control flow by these values)
+    *bad |= __builtin_amdgcn_readfirstlane(b2);
+    const unsigned long long xb = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32));
+    return 1.0 / __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
   }
   double x;
   do {

@@ -338,9 +338,154 @@ double bo_rgamma(bo_rng *r, double a, double b, int *status) {
   return rgamma_scale(r, a, 1.0 / b, status);
 }
 
-/* rtrun_gamma_mt, distributions/trun_gamma.cpp:73-106.  Only the rejection
- * branch (cut < mode) is restated; the adaptive-rejection and slice branches
- * set *status. */
+/* dtrun_gamma(x, a, b, cut, logscale = true, normalize = false),
+ * distributions/trun_gamma.cpp:34-48 */
+static double dtrun_gamma_log(double x, double a, double b, double cut) {
+  if (a < 0 || b < 0 || cut < 0 || x < cut) return BO_NEG_INF;
+  return (a - 1) * log(x) - b * x;
+}
+
+/* rexp_mt(rng, lam) = exp_rand / lam (Rmath_dist.cpp:221-223, Bmath/rexp.cpp:53-59) */
+static double bo_rexp(bo_rng *r, double lam) { return (1.0 / lam) * bo_exp_rand(r); }
+
+/* rtrun_exp_mt(rng, lam, lo, hi) = rpiecewise_log_linear_mt(rng, -lam, lo, hi),
+ * distributions/trun_exp.cpp:38-70 (finite limits, lo < hi on this path) */
+static double bo_rtrun_exp(bo_rng *r, double lam, double lo, double hi) {
+  const double slope = -lam;
+  if (fabs(hi - lo) < 1e-7) return lo;
+  double u = 0.0;
+  const double eps = 2.2250738585072014e-308; /* numeric_limits<double>::min() */
+  while (u < eps || u >= 1.0 - eps) u = bo_runif(r, 0, 1);
+  double x = log(u) + slope * hi;
+  double y = log(1 - u) + slope * lo;
+  if (x < y) { double t = x; x = y; y = t; }
+  return (x + log1p(exp(y - x))) / slope;   /* lse2, cpputil/lse.hpp:31-39 */
+}
+
+/* BoundedAdaptiveRejectionSampler for the log-concave tail of a gamma density
+ * to the right of its mode (distributions/BoundedAdaptiveRejectionSampler.cpp):
+ * target logf(x) = (a - 1) log x - b x, dlogf(x) = (a - 1) / x - b, support
+ * [cut, inf).  Points are kept sorted; knots are where neighbouring tangents
+ * cross; cdf_[k] integrates the outer hull over [knots_[k], knots_[k + 1]). */
+#define BO_ARS_CAP 64
+typedef struct {
+  int n;
+  double x[BO_ARS_CAP], y[BO_ARS_CAP], d[BO_ARS_CAP], knots[BO_ARS_CAP], cdf[BO_ARS_CAP];
+  double a, b, cut;
+} bo_ars;
+
+static void ars_refresh(bo_ars *s) {
+  /* refresh_knots, :85-91 + compute_knot, :93-107 */
+  s->knots[0] = s->x[0];
+  for (int k = 1; k < s->n; ++k) {
+    double y2 = s->y[k], y1 = s->y[k - 1], d2 = s->d[k], d1 = s->d[k - 1];
+    double x2 = s->x[k], x1 = s->x[k - 1];
+    if (d2 == d1) {
+      s->knots[k] = x1;
+    } else {
+      double ans = (y1 - d1 * x1) - (y2 - d2 * x2);
+      ans /= (d2 - d1);
+      s->knots[k] = ans;
+    }
+  }
+}
+static void ars_update_cdf(bo_ars *s) {
+  /* update_cdf, :109-138 */
+  const int n = s->n;
+  const double y0 = s->y[0];
+  double last = 0;
+  for (int k = 0; k < n; ++k) {
+    double d = s->d[k];
+    double y = s->y[k] - y0;
+    double z = s->x[k];
+    double dinv = 1.0 / d;
+    double inc1 = (k == n - 1) ? 0 : dinv * exp(y - d * z + d * s->knots[k + 1]);
+    double inc2 = dinv * exp(y - d * z + d * s->knots[k]);
+    s->cdf[k] = last + inc1 - inc2;
+    last = s->cdf[k];
+  }
+}
+/* std::lower_bound's probe sequence: the reference searches knots_ and cdf_ with
+ * it, and follows it even where rounding has left those arrays out of order */
+static int ars_lower_bound(const double *v, int n, double value) {
+  int first = 0, count = n;
+  while (count > 0) {
+    int step = count / 2;
+    if (v[first + step] < value) {
+      first += step + 1;
+      count -= step + 1;
+    } else {
+      count = step;
+    }
+  }
+  return first;
+}
+static double ars_draw(bo_rng *r, double a, double b, double cut, int *status) {
+  bo_ars s;
+  s.n = 1; s.a = a; s.b = b; s.cut = cut;
+  s.x[0] = cut;
+  s.y[0] = dtrun_gamma_log(cut, a, b, cut);
+  s.d[0] = (a - 1) / cut - b;
+  s.knots[0] = cut;
+  if (s.d[0] >= 0) { *status = BO_ERR_UNSUPPORTED_RNG_BRANCH; return NAN; }
+  ars_update_cdf(&s);
+  for (int level = 0; level <= 1001; ++level) {
+    /* draw_safely, :150-183 */
+    double u = bo_runif(r, 0, s.cdf[s.n - 1]);
+    int k = ars_lower_bound(s.cdf, s.n, u);
+    double cand;
+    if (k + 1 == s.n) {
+      cand = s.knots[s.n - 1] + bo_rexp(r, -1 * s.d[s.n - 1]);
+    } else {
+      cand = bo_rtrun_exp(r, -1 * s.d[k], s.knots[k], s.knots[k + 1]);
+    }
+    double target = dtrun_gamma_log(cand, a, b, cut);
+    double hull = s.y[k] + s.d[k] * (cand - s.x[k]);
+    double logu = hull - bo_rexp(r, 1);
+    if (logu <= target) return cand;
+    /* add_point, :61-83 (knots_ is what lower_bound searches) */
+    if (s.n >= BO_ARS_CAP) { *status = BO_ERR_UNSUPPORTED_RNG_BRANCH; return NAN; }
+    int pos = ars_lower_bound(s.knots, s.n, cand);
+    for (int i = s.n; i > pos; --i) { s.x[i] = s.x[i - 1]; s.y[i] = s.y[i - 1]; s.d[i] = s.d[i - 1]; }
+    s.x[pos] = cand;
+    s.y[pos] = dtrun_gamma_log(cand, a, b, cut);
+    s.d[pos] = (a - 1) / cand - b;
+    ++s.n;
+    ars_refresh(&s);
+    ars_update_cdf(&s);
+  }
+  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  return NAN;
+}
+
+/* rtg_init / rtg_slice, distributions/trun_gamma.cpp:110-148 */
+static double rtg_init(double x, double a, double b, double cut, double logpstar) {
+  double f = dtrun_gamma_log(x, a, b, cut) - logpstar;
+  double fprime = ((a - 1) / x) - b;
+  int attempts = 0;
+  while (f > sqrt(2.220446049250313e-16)) {
+    x -= f / fprime;
+    f = dtrun_gamma_log(x, a, b, cut) - logpstar;
+    fprime = ((a - 1) / cut) - b;
+    if (++attempts > 1000) break;
+  }
+  return x;
+}
+static double rtg_slice(bo_rng *r, double x, double a, double b, double cut) {
+  double logpstar = dtrun_gamma_log(x, a, b, cut) - bo_rexp(r, 1.0);
+  double lo = cut;
+  double hi = rtg_init(x, a, b, cut, logpstar);
+  x = bo_runif(r, lo, hi);
+  int trials = 0;
+  while (dtrun_gamma_log(x, a, b, cut) < logpstar) {
+    hi = x;
+    x = bo_runif(r, lo, hi);
+    if (++trials > 1000) return cut;
+  }
+  return x;
+}
+
+/* rtrun_gamma_mt(rng, a, b, cut, nslice = 5), distributions/trun_gamma.cpp:73-106 */
 double bo_rtrun_gamma(bo_rng *r, double a, double b, double cut, int *status) {
   double mode = (a - 1) / b;
   double x = cut;
@@ -351,8 +496,9 @@ double bo_rtrun_gamma(bo_rng *r, double a, double b, double cut, int *status) {
     } while (x < cut);
     return x;
   }
-  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
-  return NAN;
+  if (a > 1) return ars_draw(r, a, b, cut, status);
+  for (int i = 0; i < 5; ++i) x = rtg_slice(r, x, a, b, cut);
+  return x;
 }
 
 /* rmulti_mt_impl, distributions/rmulti.cpp:41-78 (probsum by plain sum; the
