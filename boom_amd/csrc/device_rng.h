@@ -501,13 +501,13 @@ __device__ BA_RARE double d_slice_gamma_tail(SeqRng &rng, double a, double b, do
 // Models/PosteriorSamplers/GenericGaussianVarianceSampler.cpp:44-63:
 // sigma^2 = 1 / Gamma(shape = DF/2, rate = SS/2), truncated to
 // sigma <= sigma_max when that is finite (rtrun_gamma_mt,
-// distributions/trun_gamma.cpp:73-106).  FULL = false leaves the two rare
-// branches (truncation point at or above the mode) out of the code: the LDS
-// sweep kernel's hot instances are built that way -- the branches cost it
-// registers it does not have -- and hand a chain that needs them to their FULL
-// twins (*bad = 3; ssvs_kernel.hip).  *bad: 1 = shape < .3 in the plain gamma
-// draw, 2 = the adaptive-rejection sampler gave up, 3 = needs FULL.
-template <bool FULL = true, class R>
+// distributions/trun_gamma.cpp:73-106), all three regimes: rejection from the
+// plain gamma (truncation point below the mode -- the common case, inline),
+// adaptive rejection (beyond the mode, shape > 1) and the slice sampler
+// (shape <= 1), both out of line.  Every lane of the calling wave must be active.
+// *bad: 1 = shape < .3 in the plain gamma draw, 2 = the adaptive-rejection
+// sampler gave up (truncation point exactly at the mode, or 64 hull points).
+template <class R>
 __device__ __forceinline__ double d_draw_variance(R &rng, double DF, double SS,
                                          double sigma_max, int *bad) {
   if (sigma_max == 0.0) return 0.0;
@@ -515,11 +515,7 @@ __device__ __forceinline__ double d_draw_variance(R &rng, double DF, double SS,
   if (isinf(sigma_max)) return 1.0 / d_rgamma_scale(rng, a, 1.0 / b, bad);
   const double cut = 1.0 / (sigma_max * sigma_max);
   const double mode = (a - 1) / b;
-  if (!FULL && !(cut < mode)) {
-    *bad = 3;
-    return 1.0;
-  }
-  if (FULL && !(cut < mode)) {
+  if (!(cut < mode)) {
     // (the out-of-line routines read the stream through the plain sequential
     // view, whatever view the caller uses: same numbers, same positions)
     SeqRng sr{stream_key(rng), stream_pos(rng)};

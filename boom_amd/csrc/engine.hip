@@ -99,8 +99,6 @@ const char *status_message(int st) {
              "this regime is not implemented on the device.";
     case CHAIN_FORECAST_VARIANCE:
       return "Found a zero (or negative) forecast variance!";
-    case CHAIN_NEEDS_FULL_RNG:
-      return "Truncated gamma draw: a chain needs the full sampler and could not be handed to it.";
     case CHAIN_MODEL_TOO_LARGE:
       return "A chain's model size exceeded the engine's working capacity "
              "(a pinned max_model_size_hint, or more than 1024 variables in "
@@ -118,7 +116,6 @@ int status_code(int st) {
     case CHAIN_RNG_BRANCH: return BA_E_RNG_BRANCH;
     case CHAIN_FORECAST_VARIANCE: return BA_E_FORECAST_VARIANCE;
     case CHAIN_MODEL_TOO_LARGE: return BA_E_MODEL_TOO_LARGE;
-    case CHAIN_NEEDS_FULL_RNG: return BA_E_RNG_BRANCH;
     default: return BA_E_INVALID;
   }
 }
@@ -190,7 +187,6 @@ struct ba_engine {
   int rec_cap = 64;  // variables per recorded draw (ba_enable_draws)
   // HBM-resident path for models of more than 64 variables (ssvs_big_kernel.hip):
   // active once a chain has outgrown the LDS kernel, capacity grows on demand
-  bool full_rng = false;   // a chain needed the rare truncated-gamma branches: use the full-sampler instances
   bool big_active = false;
   int big_kcap = 0;
   DevBuf<double> dbig_model, dbig_xs;
@@ -290,7 +286,6 @@ int choose_kcap(const ba_engine &e) {
 // SIMD hide the gather / scalar-load latencies; the register budget of the
 // 4-wave kernels only exists for capacities <= 32.  ba_set_tuning overrides.
 int choose_waves(const ba_engine &e, int kcap) {
-  if (e.full_rng) return 1;   // (the full-sampler instances are single-wave)
   {
     const int w = e.tune_waves;
     if (w == 1 || w == 2 || (w == 4 && kcap <= 32)) return w;
@@ -469,7 +464,6 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.run_limit = 0;
   P.ran = nullptr;
   P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
-  P.full_rng = e->full_rng ? 1 : 0;
   P.big_kcap = e->big_kcap;
   P.big_model = e->dbig_model.ptr;
   P.big_model_stride = e->big_kcap > 0 ? (int64_t)ssvs_scalar_layout(e->big_kcap).total : 0;
@@ -582,44 +576,9 @@ int grow_big(ba_engine *e, int *stuck) {
 
 // Resume chains that outgrew the capacity of the launch they were in, with the
 // next larger capacity; then follow the largest model size seen.
-// chains that stopped because their sigma^2 draw needs the rare branches of the
-// truncated gamma sampler: from now on the engine launches the instances that
-// carry them (one wave per chain, slower), and these chains replay what they owe
-int hand_to_full_rng(ba_engine *e, std::vector<int32_t> &st, bool *any_out) {
-  const size_t C = (size_t)e->cfg.chains;
-  bool any = false;
-  for (size_t c = 0; c < C; ++c) {
-    if (st[c] == CHAIN_NEEDS_FULL_RNG) {
-      any = true;
-      st[c] = CHAIN_OK;
-    }
-  }
-  *any_out = any;
-  if (!any) return BA_OK;
-  e->full_rng = true;
-  e->waves = 1;
-  e->table_ok = false;
-  e->model_ok = false;
-  HIP_TRY(hipMemcpyAsync(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice, e->stream));
-  return BA_OK;
-}
-
 int escalate(ba_engine *e, std::vector<int32_t> &st) {
   const size_t C = (size_t)e->cfg.chains;
   for (;;) {
-    {
-      bool handed = false;
-      int rc = hand_to_full_rng(e, st, &handed);
-      if (rc) return rc;
-      if (handed) {
-        SsvsParams P;
-        fill_params(e, P);
-        HIP_TRY(launch_sweeps(e, P, 0));   // runs the sweeps still owed
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
-        continue;
-      }
-    }
     bool any = false;
     for (size_t c = 0; c < C; ++c) any = any || (st[c] == CHAIN_MODEL_TOO_LARGE);
     if (!any) return BA_OK;
@@ -693,19 +652,12 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
 int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
   const size_t C = (size_t)e->cfg.chains;
   for (;;) {
-    bool handed = false;
-    {
-      int rc = hand_to_full_rng(e, st, &handed);
-      if (rc) return rc;
-    }
-    bool any = handed;
+    bool any = false;
     for (size_t c = 0; c < C; ++c) any = any || (st[c] == CHAIN_MODEL_TOO_LARGE);
     if (!any) return BA_OK;
-    if (!handed && e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
-    const bool to_big = !handed && e->kcap >= cap_limit(*e);
-    if (handed) {
-      // (same capacity: only the kernel instances change)
-    } else if (to_big) {
+    if (e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
+    const bool to_big = e->kcap >= cap_limit(*e);
+    if (to_big) {
       int stuck = 0;
       int rc = grow_big(e, &stuck);
       if (rc) return rc;
@@ -720,8 +672,6 @@ int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
     for (size_t c = 0; c < C; ++c) {
       if (st[c] == CHAIN_MODEL_TOO_LARGE) {
         if (!to_big) st[c] = CHAIN_OK;   // (the large-model kernel takes parked chains as they are)
-        rounds = std::max(rounds, (int)todo[c]);
-      } else if (handed && todo[c] > 0) {
         rounds = std::max(rounds, (int)todo[c]);
       }
     }
@@ -1122,7 +1072,6 @@ int ba_set_sigma_prior(ba_engine *e, double prior_df, double sigma_guess,
   e->prior_ss = 2 * beta;
   e->sigma_guess = sigma_guess;
   e->sigma_max = sigma_upper_limit;
-  e->full_rng = false;   // (a new limit: the hot instances get their chance again)
   e->have_sigma = true;
   return BA_OK;
 }

@@ -44,7 +44,7 @@
 
 namespace boom_amd {
 
-template <int NB, int W, int WPE, bool FULLRNG>
+template <int NB, int W, int WPE>
 __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
                                                             int nsweeps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -690,7 +690,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         ACC_MIN(sl[SL_MARGIN]);
         ACC_ADD(ACC_PROPOSALS, nflips);
         status = spec_status;
-        if (status == CHAIN_NEEDS_FULL_RNG) aborted = true;
         phase = after_join;
         if (after_join == PH_COMMIT && status == CHAIN_OK) {
           commit_pending = true;  // committed after the next fork
@@ -772,14 +771,10 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       int bad = 0;
       const double DF = (k == 0) ? ch.DF : ((ch.DF - P.prior_df) + P.prior_df);
       const double SS = (k == 0) ? ch.ss0q : ((M.SS - P.prior_ss) + P.prior_ss);
-      const double s2new = uni(d_draw_variance<FULLRNG>(rng, DF, SS, P.sigma_max, &bad));
-      if (!bad) sigsq = s2new;
+      sigsq = uni(d_draw_variance(rng, DF, SS, P.sigma_max, &bad));
       if (bad) {
-        // (3: this instance does not carry the branch the draw needs: the sweep is
-        // taken back -- like a capacity stop -- and replayed by the FULL twin)
-        const int st = (bad == 3) ? CHAIN_NEEDS_FULL_RNG : CHAIN_RNG_BRANCH;
-        if (!spec) { status = st; aborted = (bad == 3); break; }
-        spec_status = st; after_join = PH_COMMIT; phase = PH_JOIN;
+        if (!spec) { status = CHAIN_RNG_BRANCH; break; }
+        spec_status = CHAIN_RNG_BRANCH; after_join = PH_COMMIT; phase = PH_JOIN;
         continue;
       }
     }
@@ -998,31 +993,21 @@ __global__ __launch_bounds__(256) void ssvs_reduce_summaries_kernel(SsvsParams P
 // (NB, W, WPE): model capacity 8 NB; W wavefronts per chain; WPE = waves per
 // SIMD the register budget is sized for (W = 4 needs 4 resident waves per SIMD
 // for 4 chains per CU, i.e. <= 128 VGPRs, which only the small capacities reach)
-template <int NB, int W, int WPE, bool FULLRNG = false>
+template <int NB, int W, int WPE>
 static hipError_t launch_sweep_t(hipStream_t stream, const SsvsParams &P,
                                  int nsweeps) {
   const SsvsLds lay = ssvs_lds_layout(P.p, NB * 8);
-  hipError_t e = hipFuncSetAttribute((const void *)ssvs_sweep_kernel<NB, W, WPE, FULLRNG>,
+  hipError_t e = hipFuncSetAttribute((const void *)ssvs_sweep_kernel<NB, W, WPE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lay.total);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((ssvs_sweep_kernel<NB, W, WPE, FULLRNG>), dim3(P.chain_count), dim3(WAVE * W),
+  hipLaunchKernelGGL((ssvs_sweep_kernel<NB, W, WPE>), dim3(P.chain_count), dim3(WAVE * W),
                      lay.total, stream, P, nsweeps);
   return hipGetLastError();
 }
 
 hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P,
                              int nsweeps) {
-  if (P.full_rng) {
-    // the instances with the complete truncated-gamma sampler (one wave per chain)
-    switch (P.kcap) {
-      case 16: return launch_sweep_t<2, 1, 1, true>(stream, P, nsweeps);
-      case 32: return launch_sweep_t<4, 1, 1, true>(stream, P, nsweeps);
-      case 48: return launch_sweep_t<6, 1, 1, true>(stream, P, nsweeps);
-      case 64: return launch_sweep_t<8, 1, 1, true>(stream, P, nsweeps);
-      default: return hipErrorInvalidValue;
-    }
-  }
   const int key = P.kcap * 10 + P.waves;
   switch (key) {
     case 161: return launch_sweep_t<2, 1, 1>(stream, P, nsweeps);

@@ -13,10 +13,7 @@ enum ChainStatus : int32_t {
   CHAIN_ILLEGAL_START = 3,
   CHAIN_RNG_BRANCH = 4,
   CHAIN_FORECAST_VARIANCE = 5,
-  CHAIN_MODEL_TOO_LARGE = 6,
-  // the sigma^2 draw needs the rare branches of the truncated gamma sampler:
-  // the sweep was taken back; the host relaunches with the full-sampler kernels
-  CHAIN_NEEDS_FULL_RNG = 7
+  CHAIN_MODEL_TOO_LARGE = 6
 };
 
 // number of doubles in the reduced summary block: 3p + SUMMARY_SCALARS
@@ -52,7 +49,6 @@ struct SsvsParams {
   // table, 3 adaptive without the forked quiet sweep (diagnostic A/B)
   int32_t walk_policy;
   int32_t slab_scales;  // mode 1: slab precision is Omega^{-1} / sigma^2 (MvnGivenScalarSigma)
-  int32_t full_rng;     // 1: launch the instances that carry the full truncated-gamma sampler
 
   // shared, read-only (HBM; L2 / Infinity-Cache resident in practice)
   const double *V;    // XtX + Omega^{-1}, p x p (symmetric, full storage)

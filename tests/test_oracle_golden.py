@@ -60,6 +60,24 @@ def test_rng_known_answers(oracle):
                           g["rmulti"])
 
 
+def test_truncated_gamma_all_regimes(oracle):
+    """rtrun_gamma_mt: rejection, adaptive rejection and slice regimes
+    (distributions/trun_gamma.cpp:74-100), vectors of the compiled reference"""
+    g = load("kat_trun_gamma")
+    seed = int(g["seed"])
+    for (a, b, cut), want in zip(g["cases"], g["draws"]):
+        got = oracle.trun_gammas(oracle.rng_mt(seed), float(a), float(b), float(cut),
+                                 want.shape[0])
+        assert np.array_equal(got, want), (a, b, cut)
+        assert np.all(want >= cut)
+    # a truncation point exactly at the mode is the reference's reported error
+    import ctypes as C
+    st = C.c_int(0)
+    r = oracle.rng_mt(seed)
+    oracle.lib.bo_rtrun_gamma(C.byref(r), 10.0, 2.0, 4.5, C.byref(st))
+    assert st.value != 0
+
+
 def test_philox_known_answers(oracle):
     """Published Philox4x32-10 test vectors (Random123 kat_vectors)."""
     import ctypes as C
@@ -152,7 +170,8 @@ def test_logpri(oracle):
 
 
 @pytest.mark.parametrize("name", ["ssvs_c1", "ssvs_p64", "ssvs_collinear",
-                                  "ssvs_general", "ssvs_maxflips", "ssvs_empty"])
+                                  "ssvs_general", "ssvs_maxflips", "ssvs_empty",
+                                  "ssvs_tight_sigma", "ssvs_binding_sigma"])
 def test_ssvs_sweeps_match_reference(oracle, name):
     g = load(name)
     suf = oracle.neregsuf(g["X"], g["y"])
@@ -223,7 +242,7 @@ def test_spike_slab_sampler_matches_reference(oracle, name):
 
 
 # ------------------------------------------------------------- state space
-@pytest.mark.parametrize("name", ["ss_t200", "ss_t200_missing"])
+@pytest.mark.parametrize("name", ["ss_t200", "ss_t200_missing", "ss_t3"])
 def test_state_space_sweeps_match_reference(oracle, name):
     g = load(name)
     ss = dict(zip([str(k) for k in g["ss_keys"]], [float(v) for v in g["ss_vals"]]))
