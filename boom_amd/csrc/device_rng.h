@@ -259,8 +259,32 @@ __device__ __forceinline__ double d_exp_rand(R &r) {
   return a + umin * q[0];
 }
 
-// Rmath::rgamma_mt(rng, a, scale).  *bad is set for a < 0.3 (the reference's
-// rloggamma_small_alpha branch, unreachable when shape = DF/2 with n >= 1).
+// rloggamma_small_alpha (Bmath/rloggamma_small_alpha.cpp:43-79): log of a
+// Gamma(alpha, 1) draw for alpha < 0.3, the rejection sampler of Liu, Martin and
+// Syring.  A rare branch (shape = DF / 2 < 0.3 needs fewer than 0.6 degrees of
+// freedom); kept out of line.  *bad = 1 after 1000 rejections, as the reference.
+#ifndef BA_RARE
+#define BA_RARE __forceinline__
+#endif
+__device__ BA_RARE double d_rloggamma_small_alpha(SeqRng &rng, double alpha, int *bad) {
+  const double e = 2.718281828459045;   // exp(1)
+  const double w = alpha / (e * (1 - alpha));
+  const double r = 1.0 / (1 + w);
+  const double lambda = (1.0 / alpha) - 1.0;
+  const double log_w = log(w), log_lambda = log(lambda);
+  for (int i = 0; i < 1000; ++i) {
+    const double u = rng();
+    const double z = (u <= r) ? -log(u / r) : log(rng()) / lambda;
+    const double log_h = -z - exp(-z / alpha);
+    const double log_eta = (z >= 0) ? -z : log_w + log_lambda + lambda * z;
+    if (log_h >= log(rng()) + log_eta) return -z / alpha;
+  }
+  *bad = 1;
+  return 0.0;
+}
+
+// Rmath::rgamma_mt(rng, a, scale): rloggamma_small_alpha for a < 0.3, GS for
+// a < 1, GD otherwise (Bmath/rgamma.cpp:80-259).
 template <class R>
 __device__ __forceinline__ double d_rgamma_scale(R &rng, double a, double scale,
                                         int *bad) {
@@ -271,8 +295,18 @@ __device__ __forceinline__ double d_rgamma_scale(R &rng, double a, double scale,
                a4 = -0.1662921, a5 = 0.1423657, a6 = -0.1367177,
                a7 = 0.1233795;
   if (a < .3) {
-    *bad = 1;
-    return 1.0;
+    // (the out-of-line routine reads the stream through the plain sequential
+    // view, whatever view the caller uses: same numbers, same positions)
+    SeqRng sr{stream_key(rng), stream_pos(rng)};
+    int b2 = 0;
+    const double lg = d_rloggamma_small_alpha(sr, a, &b2);
+    stream_seek(rng, sr.pos);
+    *bad |= __builtin_amdgcn_readfirstlane(b2);
+    const double x = exp(lg + log(scale));
+    const unsigned long long xb = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
   }
   if (a < 1.) {  // GS
     const double e = 1.0 + kInvE * a;

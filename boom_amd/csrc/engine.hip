@@ -94,9 +94,9 @@ const char *status_message(int st) {
     case CHAIN_ILLEGAL_START:
       return "BregVsSampler did not start with a legal configuration.";
     case CHAIN_RNG_BRANCH:
-      return "Truncated gamma draw: the truncation point is not below the "
-             "mode (sigma upper limit too tight), or the shape is below 0.3; "
-             "this regime is not implemented on the device.";
+      return "Variance draw failed: lower bound must be to the right of the mode "
+             "of logf in BoundedAdaptiveRejectionSampler, or a rejection sampler "
+             "exceeded its number of attempts.";
     case CHAIN_FORECAST_VARIANCE:
       return "Found a zero (or negative) forecast variance!";
     case CHAIN_MODEL_TOO_LARGE:

@@ -40,8 +40,11 @@ enum {
                               BregVsSampler.cpp:448-478 */
   BA_E_ILLEGAL_START = -5, /* "BregVsSampler did not start with a legal
                               configuration." BregVsSampler.cpp:364-370 */
-  BA_E_RNG_BRANCH = -6,    /* truncated-gamma regime (cut >= mode) that the
-                              device does not implement (trun_gamma.cpp:82-104) */
+  BA_E_RNG_BRANCH = -6,    /* a sigma^2 draw the reference itself reports as an
+                              error: truncation point exactly at the gamma's mode
+                              (BoundedAdaptiveRejectionSampler.cpp:50-59), or the
+                              samplers' attempt limits (1000 rejections; 64 hull
+                              points here) */
   BA_E_FORECAST_VARIANCE = -7, /* "Found a zero (or negative) forecast
                               variance!" ScalarKalmanFilter.cpp:48-52 */
   BA_E_MODEL_TOO_LARGE = -8,   /* model size exceeded the engine's capacity */

@@ -254,9 +254,21 @@ static double rgamma_scale(bo_rng *rng, double a, double scale, int *status) {
   double e, p, q, r, t, u, v, w, x, ret_val;
 
   if (a < .3) {
-    /* rloggamma_small_alpha branch: not on the hot path (shape = DF/2 with
-     * DF >= n >= 2); not restated. */
-    *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+    /* rloggamma_small_alpha, Bmath/rloggamma_small_alpha.cpp:43-79 (Liu, Martin
+     * and Syring's rejection sampler for the log of a small-shape gamma) */
+    const double ee = 2.718281828459045; /* exp(1) */
+    const double w0 = a / (ee * (1 - a));
+    const double r0 = 1.0 / (1 + w0);
+    const double lambda = (1.0 / a) - 1.0;
+    const double log_w = log(w0), log_lambda = log(lambda);
+    for (int i = 0; i < 1000; ++i) {
+      double u0 = bo_unif(rng);
+      double z = u0 <= r0 ? -log(u0 / r0) : log(bo_unif(rng)) / lambda;
+      double log_h = -z - exp(-z / a);
+      double log_eta = (z >= 0) ? -z : log_w + log_lambda + lambda * z;
+      if (log_h >= log(bo_unif(rng)) + log_eta) return exp(-z / a + log(scale));
+    }
+    *status = BO_ERR_UNSUPPORTED_RNG_BRANCH; /* "Max number of attempts exceeded." */
     return NAN;
   } else if (a < 1.) { /* GS */
     e = 1.0 + exp_m1 * a;

@@ -33,7 +33,10 @@ def main():
     R = Ref()
     seed, n = 20260, 256
     out = np.stack([R.trun_gammas(seed, a, b, cut, n) for a, b, cut in CASES])
-    save("kat_trun_gamma", seed=seed, cases=CASES, draws=out)
+    # plain gamma draws of shape < 0.3 (rloggamma_small_alpha)
+    small = np.array([0.005, 0.1, 0.25, 0.29])
+    save("kat_trun_gamma", seed=seed, cases=CASES, draws=out, small_shapes=small,
+         small_rate=3.0, small_draws=np.stack([R.gammas(seed, a, 3.0, 512) for a in small]))
 
     # BregVsSampler with a sigma upper limit below / around the residual sd: every
     # / some sigma^2 draws come from the adaptive rejection sampler
@@ -63,6 +66,23 @@ def main():
     g0 = np.zeros(p, np.uint8)
     o = R.ss_run(y, X, obs, prior, opts, ss, 23, g0, 100)
     save("ss_t3", X=X, y=y, observed=np.ones(T, np.uint8), seed=23, init_gamma=g0,
+         nsweeps=100, ss_keys=np.array(sorted(ss.keys())),
+         ss_vals=np.array([ss[k] for k in sorted(ss.keys())]),
+         gamma=o["gamma"], beta=o["beta"], sigsq=o["sigsq"],
+         level_sigsq=o["level_sigsq"], state=o["state"],
+         **prior_kw(prior), **opts_kw(opts))
+
+    # a single observation, no upper limits, level prior df 0.5: the level
+    # variance is an untruncated gamma draw of shape 0.25 (rloggamma_small_alpha)
+    T, p = 1, 3
+    X, y, _, _ = state_space_data(8, p, 2, seed=201)
+    prior, ss, _ = bsts_priors(X, y, 2)
+    X, y = X[:T], y[:T]
+    ss = dict(ss, level_df=0.5, level_sigma_upper_limit=np.inf)
+    opts = ssvs_options(sigma_upper_limit=np.inf)
+    g0 = np.zeros(p, np.uint8)
+    o = R.ss_run(y, X, None, prior, opts, ss, 29, g0, 100)
+    save("ss_t1", X=X, y=y, observed=np.ones(T, np.uint8), seed=29, init_gamma=g0,
          nsweeps=100, ss_keys=np.array(sorted(ss.keys())),
          ss_vals=np.array([ss[k] for k in sorted(ss.keys())]),
          gamma=o["gamma"], beta=o["beta"], sigsq=o["sigsq"],

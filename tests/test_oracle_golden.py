@@ -70,6 +70,10 @@ def test_truncated_gamma_all_regimes(oracle):
                                  want.shape[0])
         assert np.array_equal(got, want), (a, b, cut)
         assert np.all(want >= cut)
+    for a, want in zip(g["small_shapes"], g["small_draws"]):   # shape < 0.3
+        got = oracle.gammas(oracle.rng_mt(seed), float(a), float(g["small_rate"]),
+                            want.shape[0])
+        assert np.array_equal(got, want), a
     # a truncation point exactly at the mode is the reference's reported error
     import ctypes as C
     st = C.c_int(0)
@@ -242,7 +246,7 @@ def test_spike_slab_sampler_matches_reference(oracle, name):
 
 
 # ------------------------------------------------------------- state space
-@pytest.mark.parametrize("name", ["ss_t200", "ss_t200_missing", "ss_t3"])
+@pytest.mark.parametrize("name", ["ss_t200", "ss_t200_missing", "ss_t3", "ss_t1"])
 def test_state_space_sweeps_match_reference(oracle, name):
     g = load(name)
     ss = dict(zip([str(k) for k in g["ss_keys"]], [float(v) for v in g["ss_vals"]]))

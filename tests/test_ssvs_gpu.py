@@ -298,6 +298,32 @@ def test_error_reporting_matches_reference_messages():
         eng3.sweep(5)              # more sweeps than record slots
 
 
+def test_rank_deficient_model_is_the_reference_error(oracle):
+    """a model whose posterior precision is singular (a zero column, no prior
+    precision).  With model selection on, the reference stops in
+    draw_model_indicators ("did not start with a legal configuration",
+    BregVsSampler.cpp:364-370); with it off, draw_beta's factorisation fails, the
+    reference re-enters draw() up to 10 times -- each attempt fails the same
+    way on the same matrix -- and reports "not positive definite"
+    (BregVsSampler.cpp:339-350).  The engine reports the same two errors."""
+    import boom_amd
+    X, y, _ = regression_data(100, 6, 2, seed=10)
+    X[:, 3] = 0.0
+    suf = oracle.neregsuf(X, y)
+    prior = spike_slab_prior(suf, 2)
+    prior["ominv"] = np.zeros((6, 6))
+    g0 = np.ones(6, np.uint8)
+    for max_flips, want, msg in ((0, 1, "not positive definite"),
+                                 (-1, 3, "did not start with a legal configuration")):
+        opts = ssvs_options(max_flips=max_flips)
+        o = oracle.ssvs_run(suf, prior, opts, ("philox", 3, 0), g0, 3)
+        assert o["status"] == want
+        eng = make_engine(3, 3, suf=suf, prior=prior, opts=opts, g0=g0)
+        with pytest.raises(boom_amd.BoomAmdError) as ei:
+            eng.sweep(3)
+        assert msg in str(ei.value)
+
+
 def test_logpri_matches_oracle(oracle):
     """PosteriorSampler::logpri() of the chains' current states"""
     X, y, _ = regression_data(300, 16, 4, seed=6)

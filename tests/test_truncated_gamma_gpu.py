@@ -140,3 +140,39 @@ def test_short_series_level_variance(oracle, T):
             st = eng.ss_get_state(c)
             assert abs(st["level_sigsq"] - o["level_sigsq"][s]) < RTOL * st["level_sigsq"], (c, s)
             assert np.max(np.abs(st["state"] - o["state"][s])) < 1e-8 * np.abs(o["state"][s]).max()
+
+
+def test_single_observation_small_shape_gamma(oracle):
+    """one observation, no upper limits, level prior df 0.5: the level variance
+    is an untruncated gamma of shape 0.25 -- rgamma's rloggamma_small_alpha
+    branch (Bmath/rloggamma_small_alpha.cpp:43-79)"""
+    import boom_amd
+    T, p = 1, 3
+    X, y, _, _ = state_space_data(8, p, 2, seed=201)
+    prior, ss, _ = bsts_priors(X, y, 2)
+    X, y = X[:T], y[:T]
+    ss = dict(ss, level_df=0.5, level_sigma_upper_limit=np.inf)
+    opts = ssvs_options(sigma_upper_limit=np.inf)
+    g0 = np.zeros(p, np.uint8)
+    eng = boom_amd.Engine(3, seed=41)
+    eng.ss_set_data(y, X, None)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"],
+                   prior["sigma_guess"], sigma_upper_limit=np.inf)
+    eng.ss_set_local_level(ss["level_df"], ss["level_sigma_guess"],
+                           ss["level_sigma_upper_limit"], ss["initial_state_mean"],
+                           ss["initial_state_variance"], ss["initial_level_sigma"])
+    eng.set_state(g0)
+    nsw = 40
+    ora = {c: oracle.ss_run(y, X, None, prior, opts, ss, ("philox", 41, c), g0, nsw)
+           for c in (0, 2)}
+    for s in range(nsw):
+        eng.ss_sweep(1)
+        gam, beta, sig = eng.get_states()
+        for c in (0, 2):
+            o = ora[c]
+            assert o["status"] == 0
+            assert np.array_equal(gam[c], o["gamma"][s]), (c, s)
+            assert abs(sig[c] - o["sigsq"][s]) < RTOL * sig[c], (c, s)
+            st = eng.ss_get_state(c)
+            assert abs(st["level_sigsq"] - o["level_sigsq"][s]) < RTOL * st["level_sigsq"], (c, s)
+            assert np.max(np.abs(st["state"] - o["state"][s])) < 1e-8 * np.abs(o["state"][s]).max()
