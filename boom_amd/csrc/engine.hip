@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/boom_amd.h"
@@ -178,6 +179,13 @@ struct ba_engine {
   // state (and the running summaries) at the start of the batch, which is what
   // a rewind restores before replaying the la_served draws already seen.
   int la_len = 1, la_avail = 0, la_served = 0;
+  // host copies of the batch's record for the chains the caller reads (the
+  // per-iteration loop reads chain 0 after every draw: one set of copies per
+  // batch instead of per call); la_synced: the batch's launch has been waited for
+  // and its chain statuses checked
+  struct LaRows { std::vector<double> k, sig, beta; std::vector<uint16_t> idx; };
+  std::unordered_map<int64_t, LaRows> la_cache;
+  bool la_synced = false;
   DevBuf<uint8_t> snap_gamma;
   DevBuf<double> snap_beta, snap_sigsq, snap_bsum, snap_bsumsq, snap_acc;
   DevBuf<uint16_t> snap_perm;
@@ -736,7 +744,48 @@ int read_record(ba_engine *e, int64_t c, int row0, int nrows, uint8_t *gamma,
                 double *beta, double *sigsq);
 int read_record_row_all(ba_engine *e, int row, uint8_t *gamma, double *beta, double *sigsq);
 
-void la_discard(ba_engine *e) { e->la_avail = e->la_served = 0; }
+void la_discard(ba_engine *e) {
+  e->la_avail = e->la_served = 0;
+  e->la_cache.clear();
+  e->la_synced = false;
+}
+
+// the draw ba_draw_next is serving, for one chain: from the host copy of the
+// chain's rows of the batch (fetched at the chain's first read in the batch)
+int la_read(ba_engine *e, int64_t c, uint8_t *gamma, double *beta, double *sigsq) {
+  if (!e->la_synced) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc = check_chain_status(e);
+    if (rc) return rc;
+    e->la_synced = true;
+  }
+  const size_t p = (size_t)e->p, cap = (size_t)e->rec_cap, n = (size_t)e->la_avail;
+  auto it = e->la_cache.find(c);
+  if (it == e->la_cache.end()) {
+    ba_engine::LaRows r;
+    r.k.resize(n); r.sig.resize(n); r.beta.resize(n * cap); r.idx.resize(n * cap);
+    const size_t base = (size_t)c * e->trace_stride;
+    HIP_TRY(hipMemcpy(r.k.data(), e->dtr_k.ptr + base, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.sig.data(), e->dtr_sig.ptr + base, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.idx.data(), e->drec_idx.ptr + base * cap, n * cap * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.beta.data(), e->drec_beta.ptr + base * cap, n * cap * 8, hipMemcpyDeviceToHost));
+    it = e->la_cache.emplace(c, std::move(r)).first;
+  }
+  const ba_engine::LaRows &r = it->second;
+  const size_t row = (size_t)e->la_served - 1;
+  const int k = (int)r.k[row];
+  if (k < 0 || (size_t)k > cap) return fail(BA_E_STATE, "corrupt draw record");
+  if (gamma) std::memset(gamma, 0, p);
+  if (beta) std::memset(beta, 0, p * 8);
+  for (int m = 0; m < k; ++m) {
+    const size_t j = r.idx[row * cap + m];
+    if (j >= p) return fail(BA_E_STATE, "corrupt draw record");
+    if (gamma) gamma[j] = 1;
+    if (beta) beta[j] = r.beta[row * cap + m];
+  }
+  if (sigsq) *sigsq = r.sig[row];
+  return BA_OK;
+}
 
 int la_copy(ba_engine *e, bool save) {
   const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
@@ -1239,10 +1288,10 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
   ENGINE_PROLOGUE(e);
   if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  if (e->la_served > 0 && e->la_served <= e->la_avail)  // the draw ba_draw_next is serving
+    return la_read(e, chain, gamma, beta, sigsq);
   int rc = ba_sync(e);
   if (rc) return rc;
-  if (e->la_served > 0 && e->la_served < e->la_avail)  // the draw ba_draw_next is serving
-    return read_record(e, chain, e->la_served - 1, 1, gamma, beta, sigsq);
   const size_t p = (size_t)e->p;
   if (gamma) HIP_TRY(hipMemcpy(gamma, e->dgamma.ptr + (size_t)chain * p, p, hipMemcpyDeviceToHost));
   if (beta) HIP_TRY(hipMemcpy(beta, e->dbeta.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost));

@@ -297,7 +297,11 @@ class BregVsSampler : public PosteriorSampler {
     check(ba_set_slab(h(), b.data(), om.data()));
     check(ba_set_spike(h(), pi.data(), mms));
     check(ba_set_sigma_prior(h(), df, guess, infinity()));
+    // the caller's `for i: sample_posterior()` loop runs at the long-launch rate
+    // by default; the draws do not depend on this number
+    check(ba_set_lookahead(h(), kDefaultLookahead));
   }
+  static constexpr int kDefaultLookahead = 64;
   RegressionModel *model_;
   int max_flips_ = -1, draw_beta_ = 1, draw_sigma_ = 1;
   double swap_ = 0.8;
