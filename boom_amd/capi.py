@@ -92,6 +92,8 @@ SIGNATURES = {
     "ba_stream": (C.c_void_p, [C.c_void_p]),
     "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
+    "ba_ss_set_structural": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_dp] * 6),
+    "ba_ss_get_structural": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_impute_state": (C.c_int, [C.c_void_p]),
     "ba_ss_forecast": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
@@ -387,6 +389,23 @@ class Engine:
         self._check(self.lib.ba_ss_set_local_level(
             self._h, level_df, level_sigma_guess, level_sigma_upper_limit,
             initial_state_mean, initial_state_variance, initial_level_sigma))
+
+    def ss_set_structural(self, trend, nseasons, var_df, var_sigma_guess,
+                          var_sigma_upper_limit, var_initial_sigma, initial_state_mean,
+                          initial_state_variance):
+        """trend (1 local level, 2 local linear trend) + optional seasonal state"""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in
+                (var_df, var_sigma_guess, var_sigma_upper_limit, var_initial_sigma,
+                 initial_state_mean, initial_state_variance)]
+        self._ssm_dim = int(trend) + (int(nseasons) - 1 if nseasons > 0 else 0)
+        self._check(self.lib.ba_ss_set_structural(self._h, int(trend), int(nseasons),
+                                                  *[_p(a) for a in arrs]))
+
+    def ss_get_structural(self, chain):
+        st = np.zeros((self.T, self._ssm_dim))
+        var, n, ss = np.zeros(3), np.zeros(3), np.zeros(3)
+        self._check(self.lib.ba_ss_get_structural(self._h, chain, _p(st), _p(var), _p(n), _p(ss)))
+        return dict(state=st, variances=var, suf_n=n, suf_ss=ss)
 
     def ss_sweep(self, nsweeps=1, sync=True):
         self._check(self.lib.ba_ss_sweep(self._h, nsweeps))

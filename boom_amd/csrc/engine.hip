@@ -38,6 +38,7 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        double *scalars /* yty, sumy */, double *xsum,
                        double *planes /* suf_row_slices(n, p) * p * p doubles, or null */);
 // kalman_kernel.hip
+hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances);
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
 hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
@@ -225,6 +226,12 @@ struct ba_engine {
   double level_prior_df = 0, level_prior_ss = 0;
   double level_sigma_max = std::numeric_limits<double>::infinity();
   double ss_a0 = 0, ss_P0 = 1, ss_initial_level_sigsq = 1;
+  // structural state (trend + seasonal, ssm_kernel.hip) instead of the local level
+  bool ssm_set = false;
+  SsmParams ssm{};                 // the host's copy of the specification (device pointers filled per launch)
+  double ssm_initial_sigsq[3] = {1, 1, 1};
+  DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;
+  DevBuf<uint64_t> dpos_var;
 };
 
 namespace {
@@ -618,6 +625,11 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
   }
 }
 
+// per chain: K (m T) | state (m T) | smoothed disturbances (3 T) | normals (<= 4 T + m + 1)
+int64_t ssm_work_stride(const ba_engine &e) {
+  return (int64_t)(2 * e.ssm.m + 3 + 4) * e.T + 64;
+}
+
 void fill_ss_params(ba_engine *e, SsParams &S) {
   std::memset(&S, 0, sizeof(S));  // (only_ran = nullptr: every chain)
   S.T = e->T;
@@ -650,6 +662,22 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.xty = e->dxty_c.ptr;
   S.yty = e->dyty_c.ptr;
   S.nobs = e->dnobs_c.ptr;
+  if (e->ssm_set) {
+    S.ssm = e->ssm;
+    S.ssm.var_sigsq = e->dssm_sigsq.ptr;
+    S.ssm.var_n = e->dssm_n.ptr;
+    S.ssm.var_ss = e->dssm_ss.ptr;
+    S.ssm.pos_var = e->dpos_var.ptr;
+    S.ssm.work = e->dssm_work.ptr;
+    S.ssm.work_stride = ssm_work_stride(*e);
+  }
+}
+
+// the state half of a state-space sweep: the structural kernel when a trend /
+// seasonal specification is set, the local-level kernel otherwise
+hipError_t launch_state_kernel(ba_engine *e, const SsParams &S, int draw) {
+  return e->ssm_set ? launch_ssm_simsmooth(e->stream, S, draw)
+                    : launch_kalman_simsmooth(e->stream, S, draw);
 }
 
 // The same for the state-space path, where a chain's sweeps alternate with the
@@ -693,7 +721,7 @@ int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
     S.only_ran = e->dran.ptr;
     for (int r = 0; r < rounds; ++r) {
       HIP_TRY(launch_sweeps(e, P, 0));
-      HIP_TRY(launch_kalman_simsmooth(e->stream, S, 1));
+      HIP_TRY(launch_state_kernel(e, S, 1));
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
@@ -1395,6 +1423,7 @@ int ba_seed(ba_engine *e, uint64_t seed) {
   if (e->dpos_sss.ptr) HIP_TRY(hipMemsetAsync(e->dpos_sss.ptr, 0, C * 8, s));
   if (e->dpos_ada.ptr) HIP_TRY(hipMemsetAsync(e->dpos_ada.ptr, 0, C * 8, s));
   if (e->dpos_level.ptr) HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
+  if (e->dpos_var.ptr) HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * 3 * 8, s));
   if (e->dpos_state.ptr) HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
   if (e->dpos_forecast.ptr) HIP_TRY(hipMemsetAsync(e->dpos_forecast.ptr, 0, C * 8, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1882,7 +1911,8 @@ int ba_adaptive_get_rates(ba_engine *e, int64_t chain, double *birth_rates,
 // --------------------------------------------------- state space (kalman)
 static int ss_prepare(ba_engine *e) {
   if (!e->ss_mode) return fail(BA_E_STATE, "call ba_ss_set_data first");
-  if (!e->ss_level_set) return fail(BA_E_STATE, "call ba_ss_set_local_level first");
+  if (!e->ss_level_set && !e->ssm_set)
+    return fail(BA_E_STATE, "call ba_ss_set_local_level or ba_ss_set_structural first");
   int rc = upload_shared(e);
   if (rc) return rc;
   rc = alloc_chain_state(e);
@@ -1914,6 +1944,21 @@ static int ss_prepare(ba_engine *e) {
     HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
     HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
     HIP_TRY(hipMemsetAsync(e->dss_scratch.ptr, 0, C * SS_SCRATCH_ARRAYS * T * 8, s));
+    if (e->ssm_set) {
+      HIP_TRY(e->dssm_sigsq.resize(C * 3));
+      HIP_TRY(e->dssm_n.resize(C * 3));
+      HIP_TRY(e->dssm_ss.resize(C * 3));
+      HIP_TRY(e->dpos_var.resize(C * 3));
+      HIP_TRY(e->dssm_work.resize(C * (size_t)ssm_work_stride(*e)));
+      std::vector<double> v0(C * 3);
+      for (size_t c = 0; c < C; ++c)
+        for (int i = 0; i < 3; ++i) v0[c * 3 + i] = e->ssm_initial_sigsq[i];
+      HIP_TRY(hipMemcpy(e->dssm_sigsq.ptr, v0.data(), C * 3 * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemsetAsync(e->dssm_n.ptr, 0, C * 3 * 8, s));
+      HIP_TRY(hipMemsetAsync(e->dssm_ss.ptr, 0, C * 3 * 8, s));
+      HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * 3 * 8, s));
+      HIP_TRY(hipMemsetAsync(e->dssm_work.ptr, 0, C * (size_t)ssm_work_stride(*e) * 8, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));  // (the host vectors above go out of scope)
     e->ss_initialized = false;
   }
@@ -1975,7 +2020,67 @@ int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_gues
   e->ss_P0 = initial_state_variance;
   e->ss_initial_level_sigsq = initial_level_sigma * initial_level_sigma;
   e->ss_level_set = true;
+  e->ssm_set = false;
   e->dss_scratch.release();
+  return BA_OK;
+}
+
+int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons, const double *var_df,
+                         const double *var_sigma_guess, const double *var_sigma_upper_limit,
+                         const double *var_initial_sigma, const double *initial_state_mean,
+                         const double *initial_state_variance) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  MUTATE(e);
+  if (!var_df || !var_sigma_guess || !var_sigma_upper_limit || !var_initial_sigma ||
+      !initial_state_mean || !initial_state_variance)
+    return fail(BA_E_INVALID, "null argument");
+  if (trend != 1 && trend != 2) return fail(BA_E_INVALID, "trend must be 1 (local level) or 2 (local linear trend)");
+  if (nseasons != 0 && nseasons < 2) return fail(BA_E_INVALID, "nseasons must be 0 or at least 2");
+  const int m = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  if (m > SSM_MAX) return fail(BA_E_INVALID, "state dimension exceeds 16");
+  SsmParams q{};
+  q.m = m;
+  q.trend = trend;
+  q.nseasons = nseasons;
+  q.s0 = nseasons > 0 ? trend : -1;
+  for (int i = 0; i < 3; ++i) {
+    if (var_sigma_upper_limit[i] < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
+    // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
+    q.prior_df[i] = 2 * (var_df[i] / 2.0);
+    q.prior_ss[i] = 2 * (var_df[i] * var_sigma_guess[i] * var_sigma_guess[i] / 2.0);
+    q.sigma_max[i] = var_sigma_upper_limit[i];
+    e->ssm_initial_sigsq[i] = var_initial_sigma[i] * var_initial_sigma[i];
+  }
+  for (int i = 0; i < m; ++i) {
+    // (a multivariate initial state goes through a Cholesky factor in the
+    // reference: it needs a positive variance; the local level model alone does not)
+    if (!(initial_state_variance[i] > 0.0) && !(trend == 1 && i == 0 && initial_state_variance[i] == 0.0))
+      return fail(BA_E_INVALID, "initial state variances must be positive");
+    q.a0[i] = initial_state_mean[i];
+    q.P0[i] = initial_state_variance[i];
+  }
+  e->ssm = q;
+  e->ssm_set = true;
+  e->ss_level_set = false;
+  e->dss_scratch.release();
+  return BA_OK;
+}
+
+int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state, double *variances,
+                         double *suf_n, double *suf_ss) {
+  ENGINE_PROLOGUE(e);
+  if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
+    return fail(BA_E_STATE, "no structural state-space run yet");
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t T = (size_t)e->T, m = (size_t)e->ssm.m;
+  if (state)
+    HIP_TRY(hipMemcpy(state, e->dssm_work.ptr + (size_t)chain * ssm_work_stride(*e) + m * T, m * T * 8,
+                      hipMemcpyDeviceToHost));
+  if (variances) HIP_TRY(hipMemcpy(variances, e->dssm_sigsq.ptr + chain * 3, 24, hipMemcpyDeviceToHost));
+  if (suf_n) HIP_TRY(hipMemcpy(suf_n, e->dssm_n.ptr + chain * 3, 24, hipMemcpyDeviceToHost));
+  if (suf_ss) HIP_TRY(hipMemcpy(suf_ss, e->dssm_ss.ptr + chain * 3, 24, hipMemcpyDeviceToHost));
   return BA_OK;
 }
 
@@ -1986,7 +2091,7 @@ int ba_ss_impute_state(ba_engine *e) {
   if (rc) return rc;
   SsParams S;
   fill_ss_params(e, S);
-  HIP_TRY(launch_kalman_simsmooth(e->stream, S, 0));
+  HIP_TRY(launch_state_kernel(e, S, 0));
   e->ss_initialized = true;
   return BA_OK;
 }
@@ -2003,12 +2108,12 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
   fill_ss_params(e, S);
   // StateSpacePosteriorSampler::draw (StateSpacePosteriorSampler.cpp:42-64)
   if (!e->ss_initialized) {
-    HIP_TRY(launch_kalman_simsmooth(e->stream, S, 0));
+    HIP_TRY(launch_state_kernel(e, S, 0));
     e->ss_initialized = true;
   }
   for (int i = 0; i < nsweeps; ++i) {
     HIP_TRY(launch_sweeps(e, P, 1));                  // observation model
-    HIP_TRY(launch_kalman_simsmooth(e->stream, S, 1));  // level model, state
+    HIP_TRY(launch_state_kernel(e, S, 1));  // state models, state
     P.model_keep = 1;  // from here on the chains' model blocks are their own last launch's
     e->model_ok = true;
   }
@@ -2020,6 +2125,7 @@ int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *ou
   if (!newX || !out || horizon <= 0) return fail(BA_E_INVALID, "bad argument");
   if (!e->ss_mode || e->dss_scratch.count == 0 || !e->ss_initialized)
     return fail(BA_E_STATE, "no state draw yet: run ba_ss_sweep or ba_ss_impute_state first");
+  if (e->ssm_set) return fail(BA_E_STATE, "forecasts are implemented for the local level model only");
   int rc = ba_sync(e);
   if (rc) return rc;
   const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, h = (size_t)horizon;
@@ -2039,6 +2145,7 @@ int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
                     double *level_sigsq, double *level_n, double *level_sumsq) {
   ENGINE_PROLOGUE(e);
   if (!e->ss_mode || e->dss_scratch.count == 0) return fail(BA_E_STATE, "no state-space run yet");
+  if (e->ssm_set) return fail(BA_E_STATE, "a structural state is set: use ba_ss_get_structural");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   int rc = ba_sync(e);
   if (rc) return rc;

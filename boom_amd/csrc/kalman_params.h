@@ -7,6 +7,21 @@
 
 namespace boom_amd {
 
+// Structural state (ssm_kernel.hip): trend block (local level, or local linear
+// trend) + optional seasonal block; state dimension m <= SSM_MAX.  Variance
+// parameters are indexed 0 level, 1 slope, 2 seasonal.
+enum { SSM_MAX = 16 };
+struct SsmParams {
+  int32_t m, trend, nseasons, s0;       // s0: first index of the seasonal block (-1: none)
+  double prior_df[3], prior_ss[3], sigma_max[3];
+  double a0[SSM_MAX], P0[SSM_MAX];      // initial state mean, variance (diagonal)
+  double *var_sigsq, *var_n, *var_ss;   // chains x 3
+  uint64_t *pos_var;                    // chains x 3: streams 1, 6, 7
+  // per chain: gains K (m x T) | state (m x T) | smoothed disturbances (3 x T) | normals
+  double *work;
+  int64_t work_stride;
+};
+
 struct SsParams {
   int32_t T, p, chains;
   int32_t chain_first, chain_count;  // this launch: chains [chain_first, chain_first + chain_count)
@@ -37,6 +52,7 @@ struct SsParams {
   double *xty;              // chains x p
   double *yty;              // chains
   double *nobs;             // chains
+  SsmParams ssm;            // (ssm_kernel.hip only)
 };
 
 enum { SS_SCRATCH_ARRAYS = 7, SS_STATE_ARRAY = 4 };

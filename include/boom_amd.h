@@ -302,6 +302,29 @@ int ba_ss_set_local_level(ba_engine *e, double level_df,
                           double initial_state_mean,
                           double initial_state_variance,
                           double initial_level_sigma);
+/* Richer state, instead of ba_ss_set_local_level: a trend state
+ * model -- trend = 1: LocalLevelStateModel; 2: LocalLinearTrendStateModel with one
+ * ZeroMeanMvnIndependenceSampler per variance, as bsts builds it
+ * (StateModels/LocalLinearTrend.cpp, PosteriorSamplers/
+ * ZeroMeanMvnIndependenceSampler.cpp:63-70) -- plus an optional
+ * SeasonalStateModel(nseasons, season_duration = 1) with a
+ * ZeroMeanGaussianConjSampler (StateModels/SeasonalStateModel.cpp); nseasons = 0:
+ * none.  State dimension m = trend + max(nseasons - 1, 0) <= 16.  The
+ * three-element arrays are indexed level, slope, seasonal (prior df, sigma guess,
+ * sigma upper limit, initial sigma of each variance parameter; unused entries are
+ * ignored); initial_state_mean / _variance have m entries (the variance diagonal;
+ * positive).  RNG streams: 1 level, 6 slope, 7 seasonal, 2 state. */
+int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons,
+                         const double *var_df, const double *var_sigma_guess,
+                         const double *var_sigma_upper_limit,
+                         const double *var_initial_sigma,
+                         const double *initial_state_mean,
+                         const double *initial_state_variance);
+/* one chain's state draw (T x m, step t at [t * m, (t + 1) * m)), the three
+ * variance parameters and the state models' sufficient statistics (n, sum of
+ * squares) of the last sweep; any pointer may be NULL */
+int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state,
+                         double *variances, double *suf_n, double *suf_ss);
 /* nsweeps x StateSpacePosteriorSampler::draw()
  * (StateSpacePosteriorSampler.cpp:42-64) on every chain */
 int ba_ss_sweep(ba_engine *e, int32_t nsweeps);

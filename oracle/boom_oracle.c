@@ -2091,3 +2091,431 @@ int bo_ss_draw(bo_ss *m) {
   if (status) return status;
   return bo_ss_impute_state(m, &m->state_rng);
 }
+
+/* ====================================================================== *
+ * Structural time series: StateSpaceRegressionModel with a trend state model
+ * (LocalLevelStateModel, or LocalLinearTrendStateModel with one
+ * ZeroMeanMvnIndependenceSampler per variance) and an optional
+ * SeasonalStateModel(nseasons, season_duration = 1).  SURVEY 8f row f2.
+ * State vector = [trend (1 or 2) | seasonal (nseasons - 1)], dimension m <= 16.
+ *   Z      ones at the first element of each block
+ *          (LocalLinearTrend.cpp:37, SeasonalStateModel.cpp:148-152)
+ *   T      trend: [1] resp. [[1, 1], [0, 1]] (LocalLinearTrendMatrix);
+ *          seasonal: first row -1, identity below the diagonal
+ *          (SeasonalStateSpaceMatrix, Filters/SparseMatrix.cpp:1141-1149)
+ *   RQR    diag(level, slope) and the seasonal block's upper-left element
+ * ====================================================================== */
+#define BO_SSM_MAX 16
+struct bo_ssm {
+  int T, p, m, dtrend, nseasons, s0; /* s0: index of the seasonal block (or -1) */
+  double *y, *X;
+  uint8_t *observed;
+  bo_ssvs *reg;
+  /* variance parameters: 0 level, 1 slope, 2 seasonal */
+  double sigsq[3], prior_df[3], prior_ss[3], sigma_max[3];
+  double suf_n[3], suf_ss[3];
+  /* MvnSuf of the trend's state errors (Welford form, MvnBase.cpp:71-86) */
+  double mv_n, mv_ybar[2], mv_sumsq[2];
+  double a0[BO_SSM_MAX], P0[BO_SSM_MAX]; /* initial mean, initial variance (diagonal) */
+  bo_rng var_rng[3], state_rng;
+  int latent_initialized;
+  double *state; /* m x T, column t = state at t */
+  double *v, *F, *K, *r, *vs, *Fs, *Ks, *rs;
+};
+
+bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
+                      const uint8_t *observed, const double *prior_mean,
+                      const double *ominv, double prior_df, double sigma_guess,
+                      const double *pi, int trend, int nseasons,
+                      const double *var_df, const double *var_sigma_guess,
+                      const double *var_sigma_upper_limit,
+                      const double *var_initial_sigma,
+                      const double *initial_state_mean,
+                      const double *initial_state_variance) {
+  bo_ssm *m = (bo_ssm *)xcalloc(1, sizeof(bo_ssm));
+  m->T = T;
+  m->p = p;
+  m->dtrend = trend;
+  m->nseasons = nseasons;
+  m->s0 = nseasons > 0 ? trend : -1;
+  m->m = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  m->y = (double *)xcalloc(T, sizeof(double));
+  m->X = (double *)xcalloc((size_t)T * p, sizeof(double));
+  m->observed = (uint8_t *)xcalloc(T, 1);
+  memcpy(m->y, y, sizeof(double) * T);
+  memcpy(m->X, X, sizeof(double) * (size_t)T * p);
+  for (int t = 0; t < T; ++t) m->observed[t] = observed ? observed[t] : 1;
+  /* (the regression part is bo_ss_create's: fixed xtx over the observed rows) */
+  double *xtx = (double *)xcalloc((size_t)p * p, sizeof(double));
+  double *xty = (double *)xcalloc(p, sizeof(double));
+  double *xsum = (double *)xcalloc(p, sizeof(double));
+  double yty = 0, sumy = 0, nobs0 = 0;
+  for (int t = 0; t < T; ++t) {
+    if (!m->observed[t]) continue;
+    nobs0 += 1;
+    for (int j = 0; j < p; ++j) {
+      double xj = X[IDX(t, j, T)];
+      xty[j] += xj * y[t];
+      xsum[j] += xj;
+      for (int i = 0; i < p; ++i) xtx[IDX(i, j, p)] += X[IDX(t, i, T)] * xj;
+    }
+    yty += y[t] * y[t];
+    sumy += y[t];
+  }
+  m->reg = bo_ssvs_create(p, xtx, xty, yty, nobs0, sumy, xsum, prior_mean,
+                          ominv, prior_df, sigma_guess, pi);
+  free(xtx); free(xty); free(xsum);
+  for (int i = 0; i < 3; ++i) {
+    m->sigsq[i] = var_initial_sigma[i] * var_initial_sigma[i];
+    m->prior_df[i] = 2 * (var_df[i] / 2.0);
+    m->prior_ss[i] = 2 * (var_df[i] * var_sigma_guess[i] * var_sigma_guess[i] / 2.0);
+    m->sigma_max[i] = var_sigma_upper_limit[i];
+  }
+  for (int i = 0; i < m->m; ++i) {
+    m->a0[i] = initial_state_mean[i];
+    m->P0[i] = initial_state_variance[i];
+  }
+  size_t mT = (size_t)m->m * T;
+  m->state = (double *)xcalloc(mT, sizeof(double));
+  m->v = (double *)xcalloc(T, sizeof(double));
+  m->F = (double *)xcalloc(T, sizeof(double));
+  m->K = (double *)xcalloc(mT, sizeof(double));
+  m->r = (double *)xcalloc(mT, sizeof(double));
+  m->vs = (double *)xcalloc(T, sizeof(double));
+  m->Fs = (double *)xcalloc(T, sizeof(double));
+  m->Ks = (double *)xcalloc(mT, sizeof(double));
+  m->rs = (double *)xcalloc(mT, sizeof(double));
+  bo_rng_seed_philox(&m->var_rng[0], 0, 0, 1, 0);
+  bo_rng_seed_philox(&m->var_rng[1], 0, 0, 6, 0);
+  bo_rng_seed_philox(&m->var_rng[2], 0, 0, 7, 0);
+  bo_rng_seed_philox(&m->state_rng, 0, 0, 2, 0);
+  return m;
+}
+
+void bo_ssm_destroy(bo_ssm *m) {
+  if (!m) return;
+  bo_ssvs_destroy(m->reg);
+  free(m->y); free(m->X); free(m->observed); free(m->state);
+  free(m->v); free(m->F); free(m->K); free(m->r);
+  free(m->vs); free(m->Fs); free(m->Ks); free(m->rs);
+  free(m);
+}
+bo_ssvs *bo_ssm_regression(bo_ssm *m) { return m->reg; }
+bo_rng *bo_ssm_variance_rng(bo_ssm *m, int which) { return &m->var_rng[which]; }
+bo_rng *bo_ssm_state_rng(bo_ssm *m) { return &m->state_rng; }
+int bo_ssm_state_dimension(const bo_ssm *m) { return m->m; }
+const double *bo_ssm_state(const bo_ssm *m) { return m->state; }
+void bo_ssm_get_variances(const bo_ssm *m, double *sigsq) {
+  for (int i = 0; i < 3; ++i) sigsq[i] = m->sigsq[i];
+}
+void bo_ssm_set_variances(bo_ssm *m, const double *sigsq) {
+  for (int i = 0; i < 3; ++i) m->sigsq[i] = sigsq[i];
+}
+
+/* x <- T x (multiply_inplace of the block-diagonal transition matrix) */
+static void ssm_T(const bo_ssm *m, double *x) {
+  if (m->dtrend == 2) x[0] = x[0] + x[1];
+  if (m->s0 >= 0) {
+    const int n = m->nseasons - 1;
+    double *s = x + m->s0, tmp[BO_SSM_MAX], first = 0;
+    for (int i = 0; i < n; ++i) {
+      first -= s[i];
+      if (i > 0) tmp[i] = s[i - 1];
+    }
+    tmp[0] = first;
+    for (int i = 0; i < n; ++i) s[i] = tmp[i];
+  }
+}
+/* x <- T' x (Tmult) */
+static void ssm_Tt(const bo_ssm *m, double *x) {
+  if (m->dtrend == 2) x[1] = x[0] + x[1];
+  if (m->s0 >= 0) {
+    const int n = m->nseasons - 1;
+    double *s = x + m->s0, tmp[BO_SSM_MAX];
+    for (int i = 0; i < n; ++i) tmp[i] = -s[0] + (i + 1 < n ? s[i + 1] : 0.0);
+    for (int i = 0; i < n; ++i) s[i] = tmp[i];
+  }
+}
+static double ssm_Zdot(const bo_ssm *m, const double *x) {
+  double ans = x[0];
+  if (m->s0 >= 0) ans += x[m->s0];
+  return ans;
+}
+/* the diagonal of RQR */
+static void ssm_rqr(const bo_ssm *m, double *d) {
+  for (int i = 0; i < m->m; ++i) d[i] = 0;
+  d[0] = m->sigsq[0];
+  if (m->dtrend == 2) d[1] = m->sigsq[1];
+  if (m->s0 >= 0) d[m->s0] = m->sigsq[2];
+}
+
+/* ScalarMarginalDistribution::update, ScalarKalmanFilter.cpp:41-83; P is m x m
+ * column-major, (a, P) enter as the one-step-ahead moments and leave as the
+ * next ones */
+static int ssm_update(const bo_ssm *M, double y, int missing, double H,
+                      double *a, double *P, double *v, double *F, double *K) {
+  const int m = M->m;
+  double PZ[BO_SSM_MAX], TPZ[BO_SSM_MAX], rqr[BO_SSM_MAX];
+  for (int i = 0; i < m; ++i) {
+    PZ[i] = P[IDX(i, 0, m)];
+    if (M->s0 >= 0) PZ[i] += P[IDX(i, M->s0, m)];
+  }
+  *F = ssm_Zdot(M, PZ) + H;
+  if (*F <= 0) return BO_ERR_FORECAST_VARIANCE;
+  for (int i = 0; i < m; ++i) TPZ[i] = PZ[i];
+  ssm_T(M, TPZ);
+  if (!missing) {
+    for (int i = 0; i < m; ++i) K[i] = TPZ[i] / *F;
+    *v = y - ssm_Zdot(M, a);
+  } else {
+    for (int i = 0; i < m; ++i) K[i] = 0.0;
+    *v = 0;
+  }
+  ssm_T(M, a);
+  if (!missing)
+    for (int i = 0; i < m; ++i) a[i] += K[i] * *v;
+  /* sandwich_inplace (Filters/SparseMatrix.cpp:1748-1763): T times every
+   * column, then T times every row */
+  double col[BO_SSM_MAX];
+  for (int j = 0; j < m; ++j) {
+    for (int i = 0; i < m; ++i) col[i] = P[IDX(i, j, m)];
+    ssm_T(M, col);
+    for (int i = 0; i < m; ++i) P[IDX(i, j, m)] = col[i];
+  }
+  for (int i = 0; i < m; ++i) {
+    for (int j = 0; j < m; ++j) col[j] = P[IDX(i, j, m)];
+    ssm_T(M, col);
+    for (int j = 0; j < m; ++j) P[IDX(i, j, m)] = col[j];
+  }
+  if (!missing)
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < m; ++i) P[IDX(i, j, m)] += -1.0 * TPZ[i] * K[j];
+  ssm_rqr(M, rqr);
+  for (int i = 0; i < m; ++i) P[IDX(i, i, m)] += rqr[i];
+  /* fix_near_symmetry, SpdMatrix.cpp:350-357 */
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < i; ++j) {
+      double value = .5 * (P[IDX(i, j, m)] + P[IDX(j, i, m)]);
+      P[IDX(i, j, m)] = P[IDX(j, i, m)] = value;
+    }
+  return 0;
+}
+
+/* fast_disturbance_smooth, ScalarKalmanFilter.cpp:168-196: rout[:, t] = r_t,
+ * r0 = the initial scaled state error */
+static void ssm_disturbance_smooth(const bo_ssm *M, const double *v,
+                                   const double *F, const double *K,
+                                   double *rout, double *r0) {
+  const int m = M->m, T = M->T;
+  double r[BO_SSM_MAX];
+  for (int i = 0; i < m; ++i) r[i] = 0.0;
+  for (int t = T - 1; t >= 0; --t) {
+    double kr = 0;
+    for (int i = 0; i < m; ++i) kr += K[IDX(i, t, m)] * r[i];
+    double coefficient = (v[t] / F[t]) - kr;
+    double rt_1[BO_SSM_MAX];
+    for (int i = 0; i < m; ++i) rt_1[i] = r[i];
+    ssm_Tt(M, rt_1);
+    rt_1[0] += coefficient;
+    if (M->s0 >= 0) rt_1[M->s0] += coefficient;
+    for (int i = 0; i < m; ++i) rout[IDX(i, t, m)] = r[i];
+    for (int i = 0; i < m; ++i) r[i] = rt_1[i];
+  }
+  for (int i = 0; i < m; ++i) r0[i] = r[i];
+}
+
+static double ssm_observation_variance(const bo_ssm *m, int t) {
+  (void)t;
+  return m->reg->sigsq; /* one observation per time point, missing or not (StateSpaceRegressionModel.cpp:167-177) */
+}
+
+/* Base::impute_state for the structural model */
+int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
+  const int T = M->T, p = M->p, m = M->m;
+  bo_ssvs *reg = M->reg;
+  double *xty = (double *)xcalloc(p, sizeof(double));
+  double *xsum = (double *)xcalloc(p, sizeof(double));
+  double yty = 0, nobs = 0, sumy = 0;
+  for (int i = 0; i < 3; ++i) { M->suf_n[i] = 0; M->suf_ss[i] = 0; }
+  M->mv_n = 0;
+  M->mv_ybar[0] = M->mv_ybar[1] = 0;
+  M->mv_sumsq[0] = M->mv_sumsq[1] = 0;
+
+  double a[BO_SSM_MAX], P[BO_SSM_MAX * BO_SSM_MAX];
+  for (int i = 0; i < m * m; ++i) P[i] = 0;
+  for (int i = 0; i < m; ++i) { a[i] = M->a0[i]; P[IDX(i, i, m)] = M->P0[i]; }
+  int status = 0;
+  int nvars = 0;
+  for (int j = 0; j < p; ++j) nvars += reg->gamma[j];
+  for (int t = 0; t < T && !status; ++t) {
+    int missing = !M->observed[t];
+    double ystar = BO_NEG_INF;
+    if (!missing) {
+      double pred = 0;
+      if (nvars > 0)
+        for (int j = 0; j < p; ++j) pred += M->X[IDX(t, j, T)] * reg->beta[j];
+      ystar = M->y[t] - pred;
+    }
+    status = ssm_update(M, ystar, missing, ssm_observation_variance(M, t), a, P,
+                        &M->v[t], &M->F[t], &M->K[(size_t)t * m]);
+  }
+  /* simulate_forward (StateSpaceModelBase.cpp:771-790): initial state by
+   * rmvn_mt(mean, variance) per state model (StateModel.cpp:47-56; a diagonal
+   * variance: mean_i + sd_i z_i, every z drawn, mvn.cpp:54-60, :80-85), state
+   * errors per model in order, then the observation */
+  double as[BO_SSM_MAX], Ps[BO_SSM_MAX * BO_SSM_MAX];
+  for (int i = 0; i < m * m; ++i) Ps[i] = 0;
+  for (int i = 0; i < m; ++i) { as[i] = M->a0[i]; Ps[IDX(i, i, m)] = M->P0[i]; }
+  const double sd_level = sqrt(M->sigsq[0]), sd_slope = sqrt(M->sigsq[1]),
+               sd_seas = sqrt(M->sigsq[2]);
+  for (int t = 0; t < T && !status; ++t) {
+    double *st = M->state + (size_t)t * m;
+    if (t == 0) {
+      if (M->dtrend == 1) {
+        /* LocalLevelStateModel::simulate_initial_state, LocalLevelStateModel.cpp:66-69 */
+        st[0] = bo_rnorm(rng, M->a0[0], sqrt(M->P0[0]));
+      } else {
+        double z0 = bo_rnorm(rng, 0, 1), z1 = bo_rnorm(rng, 0, 1);
+        st[0] = sqrt(M->P0[0]) * z0 + M->a0[0];
+        st[1] = sqrt(M->P0[1]) * z1 + M->a0[1];
+      }
+      if (M->s0 >= 0) {
+        double z[BO_SSM_MAX];
+        const int n = M->nseasons - 1;
+        for (int i = 0; i < n; ++i) z[i] = bo_rnorm(rng, 0, 1);
+        for (int i = 0; i < n; ++i)
+          st[M->s0 + i] = sqrt(M->P0[M->s0 + i]) * z[i] + M->a0[M->s0 + i];
+      }
+    } else {
+      double eta[BO_SSM_MAX];
+      for (int i = 0; i < m; ++i) eta[i] = 0;
+      if (M->dtrend == 1) {
+        eta[0] = bo_rnorm(rng, 0, sd_level);          /* LocalLevelStateModel.cpp:62-64 */
+      } else {
+        /* ZeroMeanMvnModel::sim = rmvn_mt(0, Sigma), Sigma diagonal (MvnBase.cpp:257) */
+        double z0 = bo_rnorm(rng, 0, 1), z1 = bo_rnorm(rng, 0, 1);
+        eta[0] = sd_level * z0 + 0.0;
+        eta[1] = sd_slope * z1 + 0.0;
+      }
+      if (M->s0 >= 0) eta[M->s0] = bo_rnorm(rng, 0, sd_seas);   /* SeasonalStateModel.cpp:141-145 */
+      const double *prev = M->state + (size_t)(t - 1) * m;
+      for (int i = 0; i < m; ++i) st[i] = prev[i];
+      ssm_T(M, st);
+      for (int i = 0; i < m; ++i) st[i] += eta[i];
+    }
+    const double H = ssm_observation_variance(M, t);
+    const double ysim = bo_rnorm(rng, ssm_Zdot(M, st), sqrt(H));
+    status = ssm_update(M, ysim, !M->observed[t], H, as, Ps, &M->vs[t], &M->Fs[t],
+                        &M->Ks[(size_t)t * m]);
+  }
+  if (status) { free(xty); free(xsum); return status; }
+
+  /* propagate_disturbances, StateSpaceModelBase.cpp:858-891 */
+  double r0[BO_SSM_MAX], r0s[BO_SSM_MAX], mean_sim[BO_SSM_MAX], mean_obs[BO_SSM_MAX],
+      rqr[BO_SSM_MAX];
+  ssm_disturbance_smooth(M, M->v, M->F, M->K, M->r, r0);
+  ssm_disturbance_smooth(M, M->vs, M->Fs, M->Ks, M->rs, r0s);
+  ssm_rqr(M, rqr);
+  for (int i = 0; i < m; ++i) {
+    mean_sim[i] = M->a0[i] + M->P0[i] * r0s[i];
+    mean_obs[i] = M->a0[i] + M->P0[i] * r0[i];
+  }
+  for (int t = 0; t < T; ++t) {
+    double *st = M->state + (size_t)t * m;
+    if (t > 0) {
+      ssm_T(M, mean_sim);
+      ssm_T(M, mean_obs);
+      for (int i = 0; i < m; ++i) {
+        mean_sim[i] += rqr[i] * M->rs[IDX(i, t - 1, m)];
+        mean_obs[i] += rqr[i] * M->r[IDX(i, t - 1, m)];
+      }
+    }
+    for (int i = 0; i < m; ++i) st[i] += mean_obs[i] - mean_sim[i];
+    if (t > 0) {
+      const double *then = M->state + (size_t)(t - 1) * m;
+      if (M->dtrend == 1) {
+        /* LocalLevelStateModel::observe_state, LocalLevelStateModel.cpp:52-58 */
+        double diff = st[0] - then[0];
+        M->suf_n[0] += 1;
+        M->suf_ss[0] += diff * diff;
+      } else {
+        /* LocalLinearTrendStateModel::observe_state, LocalLinearTrend.cpp:53-63
+         * + MvnSuf::update_raw, MvnBase.cpp:71-86 (diagonal of sumsq only) */
+        double err[2] = {st[0] - (then[0] + then[1]), st[1] - then[1]};
+        M->mv_n += 1.0;
+        for (int i = 0; i < 2; ++i) {
+          double w = (err[i] - M->mv_ybar[i]) / M->mv_n;
+          M->mv_ybar[i] += w;
+          M->mv_sumsq[i] += w * w * (M->mv_n - 1);
+          double w2 = err[i] - M->mv_ybar[i];
+          M->mv_sumsq[i] += w2 * w2 * 1;
+        }
+      }
+      if (M->s0 >= 0) {
+        /* SeasonalStateModelBase::observe_state, SeasonalStateModel.cpp:74-86 */
+        double sum = 0;
+        for (int i = 0; i < M->nseasons - 1; ++i) sum += then[M->s0 + i];
+        double mu = -1 * sum;
+        double delta = st[M->s0] - mu;
+        M->suf_n[2] += 1;
+        M->suf_ss[2] += delta * delta;
+      }
+    }
+    if (M->observed[t]) {
+      /* observe_data_given_state, StateSpaceRegressionModel.cpp:188-200 */
+      double resid = M->y[t] - ssm_Zdot(M, st);
+      for (int j = 0; j < p; ++j) {
+        double xj = M->X[IDX(t, j, T)];
+        xty[j] += xj * resid;
+        xsum[j] += xj;
+      }
+      yty += resid * resid;
+      nobs += 1.0;
+      sumy += resid;
+    }
+  }
+  if (M->dtrend == 2) {
+    /* ZeroMeanMvnIndependenceSampler::draw reads df = suf->n() and
+     * center_sumsq(mu = 0)(i, i) = sumsq_ii + n ybar_i^2 (MvnBase.cpp:157-161) */
+    for (int i = 0; i < 2; ++i) {
+      M->suf_n[i] = M->mv_n;
+      M->suf_ss[i] = M->mv_sumsq[i] + M->mv_ybar[i] * M->mv_ybar[i] * M->mv_n;
+    }
+  }
+  bo_ssvs_set_suf(reg, xty, yty, nobs, sumy, xsum);
+  free(xty);
+  free(xsum);
+  return 0;
+}
+void bo_ssm_get_suf(const bo_ssm *m, double *n, double *ss) {
+  for (int i = 0; i < 3; ++i) { n[i] = m->suf_n[i]; ss[i] = m->suf_ss[i]; }
+}
+
+/* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64: the
+ * regression, then each state model's samplers in order (trend: level [, slope];
+ * seasonal), then impute_state */
+int bo_ssm_draw(bo_ssm *m) {
+  int status = 0;
+  if (!m->latent_initialized) {
+    status = bo_ssm_impute_state(m, &m->state_rng);
+    if (status) return status;
+    m->latent_initialized = 1;
+  }
+  status = ssvs_draw(m->reg);
+  if (status) return status;
+  for (int i = 0; i < 3; ++i) {
+    if (i == 1 && m->dtrend != 2) continue;
+    if (i == 2 && m->s0 < 0) continue;
+    double draw = variance_draw(&m->var_rng[i], m->prior_df[i], m->prior_ss[i],
+                                m->sigma_max[i], m->suf_n[i], m->suf_ss[i], &status);
+    if (status) return status;
+    if (m->dtrend == 2 && i < 2) {
+      /* ZeroMeanMvnIndependenceSampler.cpp:63-70: siginv(i, i) = 1 / draw, and
+       * the model's Sigma is the inverse of that again */
+      double siginv = 1.0 / draw;
+      draw = 1.0 / siginv;
+    }
+    m->sigsq[i] = draw;
+  }
+  return bo_ssm_impute_state(m, &m->state_rng);
+}

@@ -203,6 +203,34 @@ void bo_ss_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX
                              const double *beta, double sigsq_obs,
                              double sigsq_level, double final_state, double *out);
 
+/* Structural time series: regression + trend state model
+ * (trend = 1: LocalLevelStateModel; 2: LocalLinearTrendStateModel with one
+ * ZeroMeanMvnIndependenceSampler per variance) + optional SeasonalStateModel
+ * (nseasons >= 2, season duration 1; 0 = none).  The three-element arrays are
+ * indexed level, slope, seasonal; initial state mean / variance (diagonal) have
+ * the state dimension trend + nseasons - 1. */
+typedef struct bo_ssm bo_ssm;
+bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
+                      const uint8_t *observed, const double *prior_mean,
+                      const double *ominv, double prior_df, double sigma_guess,
+                      const double *pi, int trend, int nseasons,
+                      const double *var_df, const double *var_sigma_guess,
+                      const double *var_sigma_upper_limit,
+                      const double *var_initial_sigma,
+                      const double *initial_state_mean,
+                      const double *initial_state_variance);
+void bo_ssm_destroy(bo_ssm *m);
+bo_ssvs *bo_ssm_regression(bo_ssm *m);
+bo_rng *bo_ssm_variance_rng(bo_ssm *m, int which);
+bo_rng *bo_ssm_state_rng(bo_ssm *m);
+int bo_ssm_state_dimension(const bo_ssm *m);
+const double *bo_ssm_state(const bo_ssm *m);   /* m x T, column t = state at t */
+void bo_ssm_get_variances(const bo_ssm *m, double *sigsq);
+void bo_ssm_set_variances(bo_ssm *m, const double *sigsq);
+void bo_ssm_get_suf(const bo_ssm *m, double *n, double *ss);
+int bo_ssm_impute_state(bo_ssm *m, bo_rng *rng);
+int bo_ssm_draw(bo_ssm *m);
+
 /* AdaptiveSpikeSlabRegressionSampler on top of a bo_ssvs
  * (AdaptiveSpikeSlabRegressionSampler.cpp:62-225) */
 typedef struct bo_adaptive bo_adaptive;

@@ -34,6 +34,9 @@
 #include "Models/PosteriorSamplers/ZeroMeanGaussianConjSampler.hpp"
 #include "Models/StateSpace/PosteriorSamplers/StateSpacePosteriorSampler.hpp"
 #include "Models/StateSpace/StateModels/LocalLevelStateModel.hpp"
+#include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
+#include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
+#include "Models/PosteriorSamplers/ZeroMeanMvnIndependenceSampler.hpp"
 #include "Models/StateSpace/StateSpaceRegressionModel.hpp"
 #include "cpputil/shuffle.hpp"
 #include "distributions.hpp"
@@ -478,6 +481,114 @@ int ref_ss_run(int T, int p, const double *y, const double *X,
     out_level_sigsq[i] = level->sigsq();
     const Matrix &state(model->state());
     for (int t = 0; t < T; ++t) out_state[(size_t)i * T + t] = state(0, t);
+  }
+  REF_CATCH
+}
+
+// Structural time series: regression + trend (local level or
+// local linear trend with independent variance samplers, as bsts builds it) +
+// optional seasonal state.  Three-element arrays: level, slope, seasonal.
+int ref_ssm_run(int T, int p, const double *y, const double *X,
+                const uint8_t *observed, const double *prior_mean,
+                const double *ominv, double prior_df, double sigma_guess,
+                const double *pi, const RefSsvsOptions *opt, int trend,
+                int nseasons, const double *var_df, const double *var_sigma_guess,
+                const double *var_sigma_upper_limit, const double *var_initial_sigma,
+                const double *initial_state_mean,
+                const double *initial_state_variance, uint64_t seed,
+                const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                double *out_beta, double *out_sigsq, double *out_variances,
+                double *out_state) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  std::vector<bool> obs;
+  if (observed) {
+    obs.resize(T);
+    for (int t = 0; t < T; ++t) obs[t] = observed[t] != 0;
+  }
+  NEW(StateSpaceRegressionModel, model)(make_vector(T, y), make_matrix(T, p, X),
+                                        obs);
+  RegressionModel *reg = model->observation_model();
+  NEW(MvnGivenScalarSigma, slab)(make_vector(p, prior_mean), make_spd(p, ominv),
+                                 reg->Sigsq_prm());
+  NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  NEW(BregVsSampler, reg_sampler)(reg, slab, siginv_prior, spike);
+  apply_options(*reg_sampler, spike, opt);
+  reg->set_method(reg_sampler);
+  reg->coef().drop_all();
+  for (int j = 0; j < p; ++j) {
+    if (init_gamma[j]) reg->coef().add(j);
+  }
+
+  Ptr<LocalLevelStateModel> level;
+  Ptr<LocalLinearTrendStateModel> llt;
+  Ptr<SeasonalStateModel> seasonal;
+  if (trend == 1) {
+    level = new LocalLevelStateModel(var_initial_sigma[0]);
+    NEW(ZeroMeanGaussianConjSampler, level_sampler)(level.get(), var_df[0],
+                                                   var_sigma_guess[0]);
+    if (std::isfinite(var_sigma_upper_limit[0]))
+      level_sampler->set_sigma_upper_limit(var_sigma_upper_limit[0]);
+    level->set_method(level_sampler);
+    level->set_initial_state_mean(initial_state_mean[0]);
+    level->set_initial_state_variance(initial_state_variance[0]);
+    model->add_state(level);
+  } else {
+    llt = new LocalLinearTrendStateModel;
+    SpdMatrix Sigma(2, 0.0);
+    Sigma(0, 0) = var_initial_sigma[0] * var_initial_sigma[0];
+    Sigma(1, 1) = var_initial_sigma[1] * var_initial_sigma[1];
+    llt->set_Sigma(Sigma);
+    for (int i = 0; i < 2; ++i) {
+      NEW(ZeroMeanMvnIndependenceSampler, s)(llt.get(), var_df[i],
+                                             var_sigma_guess[i], i);
+      if (std::isfinite(var_sigma_upper_limit[i]))
+        s->set_sigma_upper_limit(var_sigma_upper_limit[i]);
+      llt->set_method(s);
+    }
+    Vector a0(2);
+    SpdMatrix P0(2, 0.0);
+    for (int i = 0; i < 2; ++i) {
+      a0[i] = initial_state_mean[i];
+      P0(i, i) = initial_state_variance[i];
+    }
+    llt->set_initial_state_mean(a0);
+    llt->set_initial_state_variance(P0);
+    model->add_state(llt);
+  }
+  if (nseasons > 0) {
+    seasonal = new SeasonalStateModel(nseasons, 1);
+    seasonal->set_sigsq(var_initial_sigma[2] * var_initial_sigma[2]);
+    NEW(ZeroMeanGaussianConjSampler, seas_sampler)(seasonal.get(), var_df[2],
+                                                  var_sigma_guess[2]);
+    if (std::isfinite(var_sigma_upper_limit[2]))
+      seas_sampler->set_sigma_upper_limit(var_sigma_upper_limit[2]);
+    seasonal->set_method(seas_sampler);
+    const int n = nseasons - 1;
+    Vector a0(n);
+    SpdMatrix P0(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+      a0[i] = initial_state_mean[trend + i];
+      P0(i, i) = initial_state_variance[trend + i];
+    }
+    seasonal->set_initial_state_mean(a0);
+    seasonal->set_initial_state_variance(P0);
+    model->add_state(seasonal);
+  }
+
+  NEW(StateSpacePosteriorSampler, sampler)(model.get());
+  model->set_method(sampler);
+  const int m = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    record(*reg, p, i, out_gamma, out_beta, out_sigsq);
+    out_variances[3 * i + 0] = trend == 1 ? level->sigsq() : llt->Sigma()(0, 0);
+    out_variances[3 * i + 1] = trend == 1 ? 0.0 : llt->Sigma()(1, 1);
+    out_variances[3 * i + 2] = nseasons > 0 ? seasonal->sigsq() : 0.0;
+    const Matrix &state(model->state());
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < m; ++j) out_state[((size_t)i * T + t) * m + j] = state(j, t);
   }
   REF_CATCH
 }

@@ -87,3 +87,40 @@ def bsts_priors(X, y, expected_model_size):
               initial_state_variance=sdy * sdy, initial_level_sigma=1.0)
     sigma_upper = 1.2 * sdy
     return prior, ss, sigma_upper
+
+
+def structural_data(T, p, nsig, nseasons, seed, slope=0.02, missing_frac=0.0):
+    """y = trend (random walk with drift) + seasonal pattern + X beta + noise"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((T, p))
+    beta = np.zeros(p)
+    beta[:nsig] = 3.0 * (1 + np.arange(nsig))
+    level = np.cumsum(slope + 0.1 * rng.standard_normal(T))
+    seas = np.zeros(T)
+    if nseasons > 0:
+        pattern = rng.standard_normal(nseasons)
+        pattern -= pattern.mean()
+        seas = pattern[np.arange(T) % nseasons]
+    y = level + seas + X @ beta + 0.2 * rng.standard_normal(T)
+    observed = None
+    if missing_frac > 0:
+        observed = (rng.random(T) >= missing_frac).astype(np.uint8)
+        observed[0] = 1
+    return X, y, beta, observed
+
+
+def structural_spec(y, trend, nseasons):
+    """bsts-style defaults (add.local.linear.trend.R, add.seasonal.R): sd priors
+    with guess 0.01 sd(y), df 0.01, upper limit sd(y); initial state N(y[0] or 0,
+    sd(y)^2).  Three-element arrays: level, slope, seasonal."""
+    sdy = float(np.std(y, ddof=1))
+    m = trend + (nseasons - 1 if nseasons > 0 else 0)
+    a0 = np.zeros(m)
+    a0[0] = float(y[0])
+    return dict(trend=trend, nseasons=nseasons,
+                var_df=np.array([0.01, 0.01, 0.01]),
+                var_sigma_guess=np.array([0.01 * sdy] * 3),
+                var_sigma_upper_limit=np.array([sdy] * 3),
+                var_initial_sigma=np.array([1.0, 0.5, 0.7]),
+                initial_state_mean=a0,
+                initial_state_variance=np.full(m, sdy * sdy))

@@ -145,6 +145,27 @@ class Oracle:
         L.bo_ss_level_suf.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.bo_ss_impute_state.argtypes = [C.c_void_p, C.c_void_p]
         L.bo_ss_draw.argtypes = [C.c_void_p]
+        L.bo_ssm_create.restype = C.c_void_p
+        L.bo_ssm_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p,
+                                    C.POINTER(C.c_uint8), c_double_p, c_double_p,
+                                    C.c_double, C.c_double, c_double_p, C.c_int,
+                                    C.c_int, c_double_p, c_double_p, c_double_p,
+                                    c_double_p, c_double_p, c_double_p]
+        L.bo_ssm_destroy.argtypes = [C.c_void_p]
+        L.bo_ssm_regression.restype = C.c_void_p
+        L.bo_ssm_regression.argtypes = [C.c_void_p]
+        L.bo_ssm_variance_rng.restype = C.c_void_p
+        L.bo_ssm_variance_rng.argtypes = [C.c_void_p, C.c_int]
+        L.bo_ssm_state_rng.restype = C.c_void_p
+        L.bo_ssm_state_rng.argtypes = [C.c_void_p]
+        L.bo_ssm_state_dimension.argtypes = [C.c_void_p]
+        L.bo_ssm_state.restype = c_double_p
+        L.bo_ssm_state.argtypes = [C.c_void_p]
+        L.bo_ssm_get_variances.argtypes = [C.c_void_p, c_double_p]
+        L.bo_ssm_set_variances.argtypes = [C.c_void_p, c_double_p]
+        L.bo_ssm_get_suf.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.bo_ssm_impute_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.bo_ssm_draw.argtypes = [C.c_void_p]
 
     # -- RNG -----------------------------------------------------------------
     def rng_mt(self, seed):
@@ -548,6 +569,67 @@ class Oracle:
         return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
                     state=state, status=status)
 
+    def ssm_run(self, y, X, observed, prior, opts, spec, rng_setup, init_gamma,
+                nsweeps):
+        """structural model (f2): spec = structural_spec(...)"""
+        T, p = X.shape
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        trend, ns = int(spec["trend"]), int(spec["nseasons"])
+        m = self.lib.bo_ssm_create(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), prior["df"], prior["sigma_guess"],
+            _dp(f64(prior["pi"])), trend, ns, _dp(f64(spec["var_df"])),
+            _dp(f64(spec["var_sigma_guess"])), _dp(f64(spec["var_sigma_upper_limit"])),
+            _dp(f64(spec["var_initial_sigma"])), _dp(f64(spec["initial_state_mean"])),
+            _dp(f64(spec["initial_state_variance"])))
+        dim = self.lib.bo_ssm_state_dimension(m)
+        reg = self.lib.bo_ssm_regression(m)
+        self.lib.bo_ssvs_set_options(reg, opts["max_model_size"],
+                                     opts["sigma_upper_limit"],
+                                     opts["swap_threshold"], opts["max_flips"],
+                                     opts["draw_beta"], opts["draw_sigma"])
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self.lib.bo_ssvs_set_state(reg, _u8(g0), _dp(np.zeros(p)), 1.0)
+        which = [0] + ([1] if trend == 2 else []) + ([2] if ns > 0 else [])
+        if rng_setup[0] == "mt":
+            glob = self.rng_mt(rng_setup[1])
+            # construction order: regression, variance samplers, state
+            rngs = ([self.lib.bo_ssvs_rng(reg)]
+                    + [self.lib.bo_ssm_variance_rng(m, w) for w in which]
+                    + [self.lib.bo_ssm_state_rng(m)])
+            for rp in rngs:
+                self.lib.bo_rng_seed_mt(rp, self.lib.bo_seed_rng(C.byref(glob)))
+        else:
+            seed, chain = int(rng_setup[1]), int(rng_setup[2])
+            self.lib.bo_rng_seed_philox(self.lib.bo_ssvs_rng(reg), seed, chain, 0, 0)
+            for w, sid in ((0, 1), (1, 6), (2, 7)):
+                self.lib.bo_rng_seed_philox(self.lib.bo_ssm_variance_rng(m, w), seed,
+                                            chain, sid, 0)
+            self.lib.bo_rng_seed_philox(self.lib.bo_ssm_state_rng(m), seed, chain, 2, 0)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        var = np.zeros((nsweeps, 3))
+        state = np.zeros((nsweeps, T, dim))
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        s = C.c_double()
+        status = 0
+        for i in range(nsweeps):
+            status = self.lib.bo_ssm_draw(m)
+            if status:
+                break
+            self.lib.bo_ssvs_get_state(reg, _u8(g), _dp(b), C.byref(s))
+            gam[i] = g
+            beta[i] = b
+            sig[i] = s.value
+            self.lib.bo_ssm_get_variances(m, _dp(var[i]))
+            state[i] = np.ctypeslib.as_array(self.lib.bo_ssm_state(m), (T, dim))
+        self.lib.bo_ssm_destroy(m)
+        return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, state=state,
+                    status=status)
+
     def ss_impute_state(self, y, X, observed, beta, gamma, sigsq_obs,
                         sigsq_level, a0, P0, rng):
         T, p = X.shape
@@ -830,6 +912,30 @@ class Ref:
             _u8(gam), _dp(beta), _dp(sig), _dp(lev), _dp(state)))
         return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
                     state=state)
+
+    def ssm_run(self, y, X, observed, prior, opts, spec, seed, init_gamma, nsweeps):
+        T, p = X.shape
+        trend, ns = int(spec["trend"]), int(spec["nseasons"])
+        dim = trend + (ns - 1 if ns > 0 else 0)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        var = np.zeros((nsweeps, 3))
+        state = np.zeros((nsweeps, T, dim))
+        o = self._opts(opts)
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self._check(self.lib.ref_ssm_run(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
+            C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])), C.byref(o),
+            trend, ns, _dp(f64(spec["var_df"])), _dp(f64(spec["var_sigma_guess"])),
+            _dp(f64(spec["var_sigma_upper_limit"])), _dp(f64(spec["var_initial_sigma"])),
+            _dp(f64(spec["initial_state_mean"])), _dp(f64(spec["initial_state_variance"])),
+            C.c_uint64(seed), _u8(g0), nsweeps, _u8(gam), _dp(beta), _dp(sig),
+            _dp(var), _dp(state)))
+        return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, state=state)
 
     def ss_forecast(self, y, X, beta, gamma, sigsq_obs, sigsq_level, final_state,
                     newX, seed):

@@ -262,6 +262,30 @@ def test_state_space_sweeps_match_reference(oracle, name):
     assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
 
 
+@pytest.mark.parametrize("name", ["ssm_level", "ssm_trend", "ssm_level_seasonal7",
+                                  "ssm_trend_seasonal4_missing", "ssm_trend_seasonal12"])
+def test_structural_sweeps_match_reference(oracle, name):
+    """f2: regression + local level / local linear trend + seasonal state"""
+    g = load(name)
+    trend, ns = int(g["trend"]), int(g["nseasons"])
+    spec = dict(trend=trend, nseasons=ns, var_df=g["var_df"],
+                var_sigma_guess=g["var_sigma_guess"],
+                var_sigma_upper_limit=g["var_sigma_upper_limit"],
+                var_initial_sigma=g["var_initial_sigma"],
+                initial_state_mean=g["initial_state_mean"],
+                initial_state_variance=g["initial_state_variance"])
+    obs = g["observed"]
+    o = oracle.ssm_run(g["y"], g["X"], None if obs.all() else obs, prior_of(g), opts_of(g),
+                       spec, ("mt", int(g["seed"])), g["init_gamma"], int(g["nsweeps"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < RTOL
+    assert relerr(o["sigsq"], g["sigsq"]) < RTOL
+    idx = [0] + ([1] if trend == 2 else []) + ([2] if ns > 0 else [])
+    assert relerr(o["variances"][:, idx], g["variances"][:, idx], 1e-300) < RTOL
+    assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
+
+
 def test_impute_state_known_answer(oracle):
     g = load("kat_impute_state")
     o = oracle.ss_impute_state(g["y"], g["X"], g["observed"], g["beta"],
