@@ -83,9 +83,9 @@ enum : int { NLEV = 8, NORD = NB_START / 2 / 64, JT = 0xFFFF };  // <= 256 draws
 struct NormalsLds {
   double u[2][NB_UNIF];            // the window's uniforms
   double z[2][NB_START];           // the normal that starts at each offset
+  uint8_t n1[2][NB_START];         // uniforms it consumes (0: ran out)
   uint16_t j[2][NLEV][NB_START];   // jump tables of the stream walk
   uint16_t slow[2][NB_START];      // offsets whose draw leaves the first branch
-  uint8_t n1[2][NB_START];         // uniforms it consumes (0: ran out)
   int hand[4];                     // entry offset of the next window, draws so far, done, status
 };
 
