@@ -92,6 +92,8 @@ SIGNATURES = {
     "ba_stream": (C.c_void_p, [C.c_void_p]),
     "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
+    "ba_probit_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, C.c_int32]),
+    "ba_probit_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_set_structural": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_dp] * 6),
     "ba_ss_get_structural": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -389,6 +391,19 @@ class Engine:
         self._check(self.lib.ba_ss_set_local_level(
             self._h, level_df, level_sigma_guess, level_sigma_upper_limit,
             initial_state_mean, initial_state_variance, initial_level_sigma))
+
+    def probit_set_data(self, X, y, ntrials, clt_threshold=5):
+        X = np.asfortranarray(X, dtype=np.float64)
+        self.p = X.shape[1]
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        nt = np.ascontiguousarray(ntrials, dtype=np.float64)
+        self._check(self.lib.ba_probit_set_data(self._h, X.shape[0], X.shape[1], _p(X), _p(y),
+                                                _p(nt), int(clt_threshold)))
+
+    def probit_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_probit_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
 
     def ss_set_structural(self, trend, nseasons, var_df, var_sigma_guess,
                           var_sigma_upper_limit, var_initial_sigma, initial_state_mean,

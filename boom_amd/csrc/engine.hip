@@ -16,6 +16,7 @@
 
 #include "../../include/boom_amd.h"
 #include "kalman_params.h"
+#include "probit_params.h"
 #include "ssvs_params.h"
 
 namespace boom_amd {
@@ -39,6 +40,7 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        double *planes /* suf_row_slices(n, p) * p * p doubles, or null */);
 // kalman_kernel.hip
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances);
+hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P);
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
 hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
@@ -226,6 +228,13 @@ struct ba_engine {
   double level_prior_df = 0, level_prior_ss = 0;
   double level_sigma_max = std::numeric_limits<double>::infinity();
   double ss_a0 = 0, ss_P0 = 1, ss_initial_level_sigsq = 1;
+  // BinomialProbitSpikeSlabSampler (probit_kernel.hip): data on the device, the
+  // latent sums z (chains x n), imputations done so far
+  bool probit_mode = false;
+  int64_t probit_n = 0;
+  int probit_clt = 5;
+  uint64_t probit_sweep = 0;
+  DevBuf<double> dprob_X, dprob_y, dprob_nt, dprob_z;
   // structural state (trend + seasonal, ssm_kernel.hip) instead of the local level
   bool ssm_set = false;
   SsmParams ssm{};                 // the host's copy of the specification (device pointers filled per launch)
@@ -439,6 +448,12 @@ void fill_params(ba_engine *e, SsvsParams &P) {
     P.yty = e->dyty_c.ptr;
     P.nobs = e->dnobs_c.ptr;
     P.suf_stride = 1;
+  } else if (e->probit_mode && e->dxty_c.count) {
+    P.xty = e->dxty_c.ptr;      // X'z of every chain's own imputation
+    P.xty_stride = e->p;
+    P.yty = e->dscal.ptr;
+    P.nobs = e->dscal.ptr + 1;
+    P.suf_stride = 0;
   } else {
     P.xty = e->dxty.ptr;
     P.xty_stride = 0;
@@ -475,7 +490,7 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.table_keep = e->table_ok ? 1 : 0;
   P.model_tag = e->dmodel_tag.ptr;
   P.model_keep = e->model_ok ? 1 : 0;
-  P.suf_changed = e->ss_mode ? 1 : 0;
+  P.suf_changed = (e->ss_mode || e->probit_mode) ? 1 : 0;
   P.run_limit = 0;
   P.ran = nullptr;
   P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
@@ -1424,6 +1439,7 @@ int ba_seed(ba_engine *e, uint64_t seed) {
   if (e->dpos_ada.ptr) HIP_TRY(hipMemsetAsync(e->dpos_ada.ptr, 0, C * 8, s));
   if (e->dpos_level.ptr) HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
   if (e->dpos_var.ptr) HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * 3 * 8, s));
+  e->probit_sweep = 0;
   if (e->dpos_state.ptr) HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
   if (e->dpos_forecast.ptr) HIP_TRY(hipMemsetAsync(e->dpos_forecast.ptr, 0, C * 8, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1835,6 +1851,93 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   if (e->trace_stride > 0)
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
   HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
+  return BA_OK;
+}
+
+// ------------------------ BinomialProbitSpikeSlabSampler (data augmentation + SpikeSlabSampler)
+int ba_probit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const double *y,
+                       const double *ntrials, int32_t clt_threshold) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (!X || !y || !ntrials) return fail(BA_E_INVALID, "null argument");
+  if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
+  for (int64_t i = 0; i < n; ++i) {
+    if (y[i] < 0 || ntrials[i] < 0)
+      return fail(BA_E_INVALID, "Negative values not allowed in BinomialProbitDataImputer::impute().");
+    if (y[i] > ntrials[i])
+      return fail(BA_E_INVALID, "Success count exceeds trial count in BinomialProbitDataImputer::impute.");
+  }
+  // refresh_xtx (BinomialProbitSpikeSlabSampler.cpp:71-77): X'NX, built on the
+  // matrix cores from the rows scaled by sqrt(n_i) (exact for Bernoulli data)
+  std::vector<double> Xs((size_t)n * p), zero((size_t)n, 0.0);
+  for (int32_t j = 0; j < p; ++j)
+    for (int64_t i = 0; i < n; ++i) Xs[(size_t)j * n + i] = X[(size_t)j * n + i] * std::sqrt(ntrials[i]);
+  int rc = ba_build_suf_from_xy(e, n, p, Xs.data(), zero.data());
+  if (rc) return rc;
+  HIP_TRY(e->dprob_X.resize((size_t)n * p));
+  HIP_TRY(e->dprob_y.resize((size_t)n));
+  HIP_TRY(e->dprob_nt.resize((size_t)n));
+  HIP_TRY(hipMemcpy(e->dprob_X.ptr, X, (size_t)n * p * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dprob_y.ptr, y, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dprob_nt.ptr, ntrials, (size_t)n * 8, hipMemcpyHostToDevice));
+  e->probit_mode = true;
+  e->probit_n = n;
+  e->probit_clt = clt_threshold;
+  e->probit_sweep = 0;
+  e->ss_mode = false;
+  return BA_OK;
+}
+
+int ba_probit_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  if (!e->probit_mode) return fail(BA_E_STATE, "call ba_probit_set_data first");
+  if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
+  if (e->sss_slab_scales) return fail(BA_E_INVALID, "the probit sampler takes a fixed-precision slab (scales_with_sigsq = 0)");
+  int rc = alloc_chain_state(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, n = (size_t)e->probit_n;
+  if (e->dprob_z.count != C * n) {
+    HIP_TRY(e->dprob_z.resize(C * n));
+    HIP_TRY(e->dxty_c.resize(C * p));
+    // the latent data have unit variance: sigma^2 = 1 in every chain
+    std::vector<double> one(C, 1.0);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->dsigsq.ptr, one.data(), C * 8, hipMemcpyHostToDevice));
+  }
+  rc = switch_mode(e, 1, 1.0);
+  if (rc) return rc;
+  rc = upload_shared(e);
+  if (rc) return rc;
+  HIP_TRY(e->dmodel.resize(2 * C * ssvs_scalar_layout(64).total));
+  SsvsParams P;
+  fill_params(e, P);
+  ProbitParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.n = (int32_t)n;
+  Q.p = (int32_t)p;
+  Q.chains = (int32_t)C;
+  Q.clt_threshold = e->probit_clt;
+  Q.chain_offset = e->cfg.chain_offset;
+  Q.X = e->dprob_X.ptr;
+  Q.y = e->dprob_y.ptr;
+  Q.ntrials = e->dprob_nt.ptr;
+  Q.gamma = e->dgamma.ptr;
+  Q.beta = e->dbeta.ptr;
+  Q.z = e->dprob_z.ptr;
+  Q.xtz = e->dxty_c.ptr;
+  Q.seed_lo = (uint32_t)e->seed;
+  Q.seed_hi = (uint32_t)(e->seed >> 32);
+  Q.status = e->dstatus.ptr;
+  // BinomialProbitSpikeSlabSampler::draw (BinomialProbitSpikeSlabSampler.cpp:40-46)
+  for (int i = 0; i < nsweeps; ++i) {
+    Q.sweep = e->probit_sweep++;
+    HIP_TRY(launch_probit_impute(e->stream, Q));   // impute_latent_data, X'z
+    HIP_TRY(launch_sweeps(e, P, 1));               // draw_model_indicators, draw_beta
+    P.model_keep = 1;
+    e->model_ok = true;
+  }
   return BA_OK;
 }
 

@@ -1,0 +1,182 @@
+// BinomialProbitSpikeSlabSampler's data augmentation for many chains (SURVEY 8f
+// row f3, the probit member):
+//   BinomialProbitSpikeSlabSampler::impute_latent_data
+//       (Models/Glm/PosteriorSamplers/BinomialProbitSpikeSlabSampler.cpp:55-69)
+//   BinomialProbitDataImputer::impute          (BinomialProbitDataImputer.cpp:30-73)
+//   rtrun_norm_mt / trun_norm_mt / TnSampler   (distributions/trun_norm.cpp:36-47,
+//                                               :108-241)
+// One thread per (chain, observation): eta = x_i'beta over the chain's included
+// variables, the sum of the observation's latent normals -- each trial a
+// standard normal truncated to the side of zero its outcome says, or the
+// central-limit draw when there are more than clt_threshold of a kind -- goes
+// to z[chain][i]; X'z for all chains is then ONE MFMA GEMM (the same one the
+// state-space path uses for X'e), and the inclusion / coefficient draws are the
+// SpikeSlabSampler mode of the sweep kernels on (X'NX, X'z).
+//
+// The reference reads the sampler's RNG in sequence, observation after
+// observation, a data-dependent number of uniforms each.  Here observation i of
+// sweep s reads the chain's imputer stream (id 8) from position (s n + i) * 256:
+// a counter-based stream makes the observations independent.  (The oracle's
+// Philox mode does the same; its MT mode, pinned on the reference, reads in
+// sequence.)
+#include <hip/hip_runtime.h>
+
+#include "device_rng.h"
+#include "probit_params.h"
+
+namespace boom_amd {
+
+namespace {
+
+enum : int { TN_CAP = 64 };
+
+// TnSampler: bounded adaptive rejection for a standard normal given x > a, a > 0
+// (logf = -x^2 / 2); per-thread hull arrays, the reference's lower_bound probes
+__device__ __forceinline__ int tn_lower_bound(const double *v, int n, double value) {
+  int first = 0, count = n;
+  while (count > 0) {
+    const int step = count / 2;
+    if (v[first + step] < value) { first += step + 1; count -= step + 1; }
+    else count = step;
+  }
+  return first;
+}
+__device__ double tn_draw(SeqRng &rng, double a, int *bad) {
+  double xs[TN_CAP], ys[TN_CAP], ds[TN_CAP], kn[TN_CAP], cdf[TN_CAP];
+  int n = 1;
+  xs[0] = a; ys[0] = -.5 * a * a; ds[0] = -a; kn[0] = a;
+  for (int level = 0; level <= 1001; ++level) {
+    {  // update_cdf
+      const double y0 = ys[0];
+      double last = 0;
+      for (int k = 0; k < n; ++k) {
+        const double d = ds[k], y = ys[k] - y0, z = xs[k], dinv = 1.0 / d;
+        const double inc1 = (k == n - 1) ? 0 : dinv * exp(y - d * z + d * kn[k + 1]);
+        const double inc2 = dinv * exp(y - d * z + d * kn[k]);
+        cdf[k] = last + inc1 - inc2;
+        last = cdf[k];
+      }
+    }
+    const double u = d_runif(rng, 0.0, cdf[n - 1]);
+    const int k = tn_lower_bound(cdf, n, u);
+    double cand;
+    if (k + 1 == n) cand = kn[n - 1] + d_rexp(rng, -1 * ds[n - 1]);
+    else cand = d_rtrun_exp(rng, -1 * ds[k], kn[k], kn[k + 1]);
+    const double target = -.5 * cand * cand;
+    const double hull = ys[k] + ds[k] * (cand - xs[k]);
+    const double logu = hull - d_rexp(rng, 1.0);
+    if (logu < target) return cand;
+    if (n >= TN_CAP) { *bad = 1; return a; }
+    const int pos = tn_lower_bound(kn, n, cand);
+    for (int i = n; i > pos; --i) { xs[i] = xs[i - 1]; ys[i] = ys[i - 1]; ds[i] = ds[i - 1]; }
+    xs[pos] = cand; ys[pos] = target; ds[pos] = -cand;
+    ++n;
+    kn[0] = xs[0];
+    for (int i = 1; i < n; ++i) {
+      double ans = (ys[i - 1] - ds[i - 1] * xs[i - 1]) - (ys[i] - ds[i] * xs[i]);
+      ans /= (ds[i] - ds[i - 1]);
+      kn[i] = ans;
+    }
+  }
+  *bad = 1;
+  return a;
+}
+// trun_norm_mt(rng, a): a standard normal given x > a
+__device__ __forceinline__ double trun_norm_std(SeqRng &rng, double a, int *bad) {
+  if (a <= 0) {
+    for (;;) {
+      const double x = d_norm_rand(rng);
+      if (x > a) return x;
+    }
+  }
+  return tn_draw(rng, a, bad);
+}
+__device__ __forceinline__ double rtrun_norm(SeqRng &rng, double mu, double a, bool gt, int *bad) {
+  return gt ? mu + trun_norm_std(rng, a - mu, bad) : mu - trun_norm_std(rng, mu - a, bad);   // (sigma = 1)
+}
+__device__ __forceinline__ double log_pnorm_std(double x, bool lower) {
+  const double z = lower ? -x : x;
+  return log(0.5 * erfc(z / 1.4142135623730951));
+}
+// trun_norm_moments(mu, 1, 0, positive_support, ...)
+__device__ __forceinline__ void trun_norm_moments(double mu, bool positive, double *mean, double *variance) {
+  const double log_phi_const = -0.918938533204672741780329736406;
+  const double t = 0.0 - mu;
+  if (positive) {
+    const double phi_ratio = exp((log_phi_const - .5 * t * t) - log_pnorm_std(t, false));
+    *mean = mu + phi_ratio;
+    *variance = 1 - phi_ratio * (phi_ratio - t);
+  } else {
+    const double phi_ratio = exp((log_phi_const - .5 * t * t) - log_pnorm_std(t, true));
+    *mean = mu - phi_ratio;
+    *variance = 1 - t * phi_ratio - phi_ratio * phi_ratio;
+  }
+  if (*variance < 0) *variance = 0;
+}
+
+}  // namespace
+
+// grid = (ceil(n / 256), chains), block = 256
+__global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
+  const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (P.status[chain] != CHAIN_OK) return;
+  // the chain's included variables, once per workgroup
+  __shared__ int s_idx[PROBIT_KMAX];
+  __shared__ double s_beta[PROBIT_KMAX];
+  __shared__ int s_k;
+  if (threadIdx.x == 0) {
+    int k = 0;
+    const uint8_t *g = P.gamma + (size_t)chain * P.p;
+    const double *b = P.beta + (size_t)chain * P.p;
+    for (int j = 0; j < P.p; ++j) {
+      if (g[j]) {
+        if (k < PROBIT_KMAX) { s_idx[k] = j; s_beta[k] = b[j]; }
+        ++k;
+      }
+    }
+    s_k = k;
+  }
+  __syncthreads();
+  const int k = s_k;
+  if (k > PROBIT_KMAX) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
+    return;
+  }
+  if (i >= P.n) return;
+  double eta = 0.0;
+  for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
+  const long nt = lround(P.ntrials[i]), y = lround(P.y[i]);
+  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 8u},
+             (P.sweep * (uint64_t)P.n + (uint64_t)i) * PROBIT_STRIDE};
+  int bad = 0;
+  double mean, variance, ans = 0.0;
+  if (y > P.clt_threshold) {
+    trun_norm_moments(eta, true, &mean, &variance);
+    ans += d_rnorm(rng, y * mean, sqrt(y * variance));
+  } else {
+    for (long t = 0; t < y; ++t) ans += rtrun_norm(rng, eta, 0.0, true, &bad);
+  }
+  if (nt - y > P.clt_threshold) {
+    trun_norm_moments(eta, false, &mean, &variance);
+    ans += d_rnorm(rng, (nt - y) * mean, sqrt((nt - y) * variance));
+  } else {
+    for (long t = 0; t < nt - y; ++t) ans += rtrun_norm(rng, eta, 0.0, false, &bad);
+  }
+  // (a draw that outran its substream or its hull is reported, never mishandled)
+  if (bad || rng.pos - (P.sweep * (uint64_t)P.n + (uint64_t)i) * PROBIT_STRIDE > PROBIT_STRIDE)
+    P.status[chain] = CHAIN_RNG_BRANCH;
+  P.z[(size_t)chain * P.n + i] = ans;
+}
+
+hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
+                           const double *B, int64_t ldb, int N, int K, double *C, int ldc);
+
+// impute + X'z for every chain
+hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P) {
+  hipLaunchKernelGGL(probit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  return launch_atb_mfma(stream, P.z, (int64_t)P.n, P.chains, P.X, (int64_t)P.n, P.p, P.n, P.xtz, P.p);
+}
+
+}  // namespace boom_amd

@@ -1,0 +1,27 @@
+// Launch parameters of the probit data-augmentation kernel (probit_kernel.hip),
+// shared with the host side (engine.hip).
+#pragma once
+#include <stdint.h>
+
+#include "ssvs_params.h"
+
+namespace boom_amd {
+
+enum { PROBIT_STRIDE = 256, PROBIT_KMAX = 1024 };
+
+struct ProbitParams {
+  int32_t n, p, chains, clt_threshold;
+  int64_t chain_offset;
+  const double *X;        // n x p column-major
+  const double *y;        // successes
+  const double *ntrials;  // trials
+  const uint8_t *gamma;   // chains x p
+  const double *beta;     // chains x p
+  double *z;              // chains x n: the observations' sums of latent normals
+  double *xtz;            // chains x p: X'z
+  uint32_t seed_lo, seed_hi;
+  uint64_t sweep;         // imputations done so far (positions the substreams)
+  int32_t *status;
+};
+
+}  // namespace boom_amd

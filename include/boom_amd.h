@@ -242,6 +242,21 @@ int ba_adaptive_sweep(ba_engine *e, int32_t nsweeps);
 int ba_adaptive_get_rates(ba_engine *e, int64_t chain, double *birth_rates,
                           double *death_rates, uint64_t *iteration_count);
 
+/* ---- BinomialProbitSpikeSlabSampler (the probit member) -----
+ * Data augmentation (BinomialProbitDataImputer.cpp:30-73: a truncated normal per
+ * trial, or the central-limit draw beyond clt_threshold trials of a kind) followed
+ * by SpikeSlabSampler on the complete-data sufficient statistics X'NX (fixed) and
+ * X'z (BinomialProbitSpikeSlabSampler.cpp:40-85).  X is n x p column-major, y
+ * successes, ntrials trials.  Priors: ba_sss_set_slab(mu, precision,
+ * scales_with_sigsq = 0, max_flips) and ba_set_spike.  State through
+ * ba_set_state / ba_get_state(s) (sigma^2 is 1).  RNG: stream 3 for the
+ * inclusion / coefficient draws; the imputation of observation i in sweep s reads
+ * stream 8 from position (s n + i) * 256 -- the reference reads ONE stream in
+ * sequence, a counter-based one lets the observations go in parallel. */
+int ba_probit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X,
+                       const double *y, const double *ntrials, int32_t clt_threshold);
+int ba_probit_sweep(ba_engine *e, int32_t nsweeps);
+
 /* ---- posterior summaries --------------------------------------------------- */
 /* Running sums over every sweep since the last ba_reset_summaries(), reduced
  * over this engine's chains on the device:

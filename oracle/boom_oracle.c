@@ -2519,3 +2519,179 @@ int bo_ssm_draw(bo_ssm *m) {
   }
   return bo_ssm_impute_state(m, &m->state_rng);
 }
+
+/* ====================================================================== *
+ * BinomialProbitSpikeSlabSampler (the probit member):
+ * data augmentation with truncated normals, then SpikeSlabSampler (bo_sss) on
+ * the complete-data sufficient statistics X'NX (fixed) and X'z.
+ * Models/Glm/PosteriorSamplers/BinomialProbitSpikeSlabSampler.cpp:40-85,
+ * BinomialProbitDataImputer.cpp:30-73.
+ * ====================================================================== */
+
+/* TnSampler (distributions/trun_norm.cpp:108-228): the bounded adaptive
+ * rejection sampler for a standard normal restricted to x > a (a > 0), logf =
+ * -x^2/2.  Same structure as ars_draw above; the acceptance test is strict. */
+static double tn_draw(bo_rng *r, double a, int *status) {
+  bo_ars s;
+  s.n = 1;
+  s.x[0] = a;
+  s.y[0] = -.5 * a * a;
+  s.d[0] = -a;
+  s.knots[0] = a;
+  ars_update_cdf(&s);
+  for (int level = 0; level <= 1001; ++level) {
+    double u = bo_runif(r, 0, s.cdf[s.n - 1]);
+    int k = ars_lower_bound(s.cdf, s.n, u);
+    double cand;
+    if (k + 1 == s.n) {
+      cand = s.knots[s.n - 1] + bo_rexp(r, -1 * s.d[s.n - 1]);
+    } else {
+      cand = bo_rtrun_exp(r, -1 * s.d[k], s.knots[k], s.knots[k + 1]);
+    }
+    double target = -.5 * cand * cand;
+    double hull = s.y[k] + s.d[k] * (cand - s.x[k]);
+    double logu = hull - bo_rexp(r, 1);
+    if (logu < target) return cand;
+    if (s.n >= BO_ARS_CAP) { *status = BO_ERR_UNSUPPORTED_RNG_BRANCH; return NAN; }
+    int pos = ars_lower_bound(s.knots, s.n, cand);
+    for (int i = s.n; i > pos; --i) { s.x[i] = s.x[i - 1]; s.y[i] = s.y[i - 1]; s.d[i] = s.d[i - 1]; }
+    s.x[pos] = cand;
+    s.y[pos] = -.5 * cand * cand;
+    s.d[pos] = -cand;
+    ++s.n;
+    ars_refresh(&s);
+    ars_update_cdf(&s);
+  }
+  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  return NAN;
+}
+/* trun_norm_mt(rng, a): standard normal given x > a (trun_norm.cpp:231-241) */
+static double trun_norm_std(bo_rng *r, double a, int *status) {
+  if (a <= 0) {
+    for (;;) {
+      double x = bo_rnorm(r, 0, 1);
+      if (x > a) return x;
+    }
+  }
+  return tn_draw(r, a, status);
+}
+/* rtrun_norm_mt(rng, mu, sigma, a, gt), trun_norm.cpp:36-47 */
+double bo_rtrun_norm(bo_rng *r, double mu, double sigma, double a, int gt, int *status) {
+  if (gt) return mu + sigma * trun_norm_std(r, (a - mu) / sigma, status);
+  return mu - sigma * trun_norm_std(r, (mu - a) / sigma, status);
+}
+/* log of the standard normal cdf (lower or upper tail) */
+static double log_pnorm_std(double x, int lower) {
+  double z = lower ? -x : x;
+  return log(0.5 * erfc(z / 1.4142135623730951));
+}
+/* trun_norm_moments(mu, sigma, cutpoint, positive_support, ...), trun_norm.cpp:243-269 */
+static void trun_norm_moments(double mu, double sigma, double cut, int positive,
+                              double *mean, double *variance) {
+  const double sigsq = sigma * sigma;
+  const double log_phi_const = -0.918938533204672741780329736406; /* -log sqrt(2 pi) */
+  if (positive) {
+    double alpha = (cut - mu) / sigma;
+    double phi_ratio = exp((log_phi_const - .5 * alpha * alpha) - log_pnorm_std(alpha, 0));
+    *mean = mu + sigma * phi_ratio;
+    double delta = phi_ratio * (phi_ratio - alpha);
+    *variance = sigsq * (1 - delta);
+  } else {
+    double beta = (cut - mu) / sigma;
+    double phi_ratio = exp((log_phi_const - .5 * beta * beta) - log_pnorm_std(beta, 1));
+    *mean = mu - sigma * phi_ratio;
+    *variance = sigsq * (1 - beta * phi_ratio - phi_ratio * phi_ratio);
+  }
+  if (*variance < 0) *variance = 0;
+}
+/* BinomialProbitDataImputer::impute, BinomialProbitDataImputer.cpp:30-73 */
+static double probit_impute(bo_rng *r, int clt, double ntrials, double nsuccess,
+                            double eta, int *status) {
+  long n = lround(ntrials), y = lround(nsuccess);
+  double mean, variance, ans = 0;
+  if (y > clt) {
+    trun_norm_moments(eta, 1, 0, 1, &mean, &variance);
+    ans += bo_rnorm(r, y * mean, sqrt(y * variance));
+  } else {
+    for (long i = 0; i < y; ++i) ans += bo_rtrun_norm(r, eta, 1, 0, 1, status);
+  }
+  if (n - y > clt) {
+    trun_norm_moments(eta, 1, 0, 0, &mean, &variance);
+    ans += bo_rnorm(r, (n - y) * mean, sqrt((n - y) * variance));
+  } else {
+    for (long i = 0; i < n - y; ++i) ans += bo_rtrun_norm(r, eta, 1, 0, 0, status);
+  }
+  return ans;
+}
+
+struct bo_probit {
+  int n, p, clt;
+  double *X, *y, *nt; /* X n x p column-major */
+  bo_sss *sss;        /* holds X'NX, gamma, beta and the sampler's RNG */
+  /* substream = 0: the imputation reads the sampler's own RNG in sequence (the
+   * reference; MT engine).  substream = 1 (the device's convention, Philox):
+   * observation i of sweep s reads stream 8 from position (s n + i) 256 */
+  int substream;
+  bo_rng imp_rng;
+  uint64_t sweep;
+};
+#define BO_PROBIT_STRIDE 256
+
+bo_probit *bo_probit_create(int n, int p, const double *X, const double *y,
+                            const double *ntrials, const double *mu, const double *prec,
+                            const double *pi, int clt_threshold) {
+  bo_probit *m = (bo_probit *)xcalloc(1, sizeof(bo_probit));
+  m->n = n; m->p = p; m->clt = clt_threshold;
+  m->X = (double *)xcalloc((size_t)n * p, sizeof(double));
+  m->y = (double *)xcalloc(n, sizeof(double));
+  m->nt = (double *)xcalloc(n, sizeof(double));
+  memcpy(m->X, X, sizeof(double) * (size_t)n * p);
+  memcpy(m->y, y, sizeof(double) * n);
+  memcpy(m->nt, ntrials, sizeof(double) * n);
+  /* refresh_xtx: sum_i n_i x_i x_i' (BinomialProbitSpikeSlabSampler.cpp:71-77) */
+  double *xtx = (double *)xcalloc((size_t)p * p, sizeof(double));
+  double *xty = (double *)xcalloc(p, sizeof(double));
+  for (int i = 0; i < n; ++i)
+    for (int b = 0; b < p; ++b)
+      for (int a = 0; a < p; ++a)
+        xtx[IDX(a, b, p)] += X[IDX(i, a, n)] * X[IDX(i, b, n)] * ntrials[i];
+  m->sss = bo_sss_create(p, xtx, xty, 0, mu, prec, pi);
+  free(xtx); free(xty);
+  bo_rng_seed_philox(&m->imp_rng, 0, 0, 8, 0);
+  return m;
+}
+void bo_probit_destroy(bo_probit *m) {
+  if (!m) return;
+  bo_sss_destroy(m->sss);
+  free(m->X); free(m->y); free(m->nt);
+  free(m);
+}
+bo_sss *bo_probit_sss(bo_probit *m) { return m->sss; }
+bo_rng *bo_probit_imputer_rng(bo_probit *m) { return &m->imp_rng; }
+void bo_probit_use_substreams(bo_probit *m, int on) { m->substream = on; }
+
+/* BinomialProbitSpikeSlabSampler::draw */
+int bo_probit_draw(bo_probit *m) {
+  const int n = m->n, p = m->p;
+  bo_sss *s = m->sss;
+  int status = 0;
+  double *xtz = s->xty;
+  for (int j = 0; j < p; ++j) xtz[j] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double eta = 0;
+    for (int j = 0; j < p; ++j)
+      if (s->gamma[j]) eta += m->X[IDX(i, j, n)] * s->beta[j];
+    bo_rng *r = &s->rng;
+    if (m->substream) {
+      r = &m->imp_rng;
+      r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * BO_PROBIT_STRIDE;
+    }
+    double sum_of_z = probit_impute(r, m->clt, m->nt[i], m->y[i], eta, &status);
+    if (status) return status;
+    for (int j = 0; j < p; ++j) xtz[j] += m->X[IDX(i, j, n)] * sum_of_z;
+  }
+  ++m->sweep;
+  status = bo_sss_draw_model_indicators(s, 1.0);
+  if (status) return status;
+  return bo_sss_draw_beta(s, 1.0);
+}

@@ -231,6 +231,23 @@ void bo_ssm_get_suf(const bo_ssm *m, double *n, double *ss);
 int bo_ssm_impute_state(bo_ssm *m, bo_rng *rng);
 int bo_ssm_draw(bo_ssm *m);
 
+/* BinomialProbitSpikeSlabSampler (probit): truncated-normal
+ * data augmentation + SpikeSlabSampler on X'NX (fixed) and X'z.  X is n x p
+ * column-major, y successes, ntrials trials; the slab is a fixed-precision
+ * MvnModel(mu, prec). */
+typedef struct bo_probit bo_probit;
+bo_probit *bo_probit_create(int n, int p, const double *X, const double *y,
+                            const double *ntrials, const double *mu, const double *prec,
+                            const double *pi, int clt_threshold);
+void bo_probit_destroy(bo_probit *m);
+bo_sss *bo_probit_sss(bo_probit *m);           /* state, options, the sampler's RNG */
+bo_rng *bo_probit_imputer_rng(bo_probit *m);
+/* 0: the imputation reads the sampler's RNG in sequence (the reference);
+ * 1: observation i of sweep s reads the imputer stream at (s n + i) * 256 */
+void bo_probit_use_substreams(bo_probit *m, int on);
+int bo_probit_draw(bo_probit *m);
+double bo_rtrun_norm(bo_rng *r, double mu, double sigma, double a, int gt, int *status);
+
 /* AdaptiveSpikeSlabRegressionSampler on top of a bo_ssvs
  * (AdaptiveSpikeSlabRegressionSampler.cpp:62-225) */
 typedef struct bo_adaptive bo_adaptive;

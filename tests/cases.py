@@ -124,3 +124,28 @@ def structural_spec(y, trend, nseasons):
                 var_initial_sigma=np.array([1.0, 0.5, 0.7]),
                 initial_state_mean=a0,
                 initial_state_variance=np.full(m, sdy * sdy))
+
+
+def probit_data(n, p, nsig, seed, max_trials=1):
+    """binomial probit data: X[:, 0] = 1, successes y out of ntrials"""
+    from math import erf
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((n, p))
+    X[:, 0] = 1.0
+    beta = np.zeros(p)
+    beta[:nsig] = np.array([0.3, 1.0, -0.8, 0.6, -0.5, 0.4, 0.9, -0.7])[:nsig]
+    eta = X @ beta
+    prob = np.array([0.5 * (1 + erf(e / np.sqrt(2))) for e in eta])
+    nt = np.ones(n) if max_trials == 1 else rng.integers(1, max_trials + 1, n).astype(float)
+    y = rng.binomial(nt.astype(int), prob).astype(float)
+    return X, y, nt, beta
+
+
+def probit_slab(X, ntrials, expected_model_size, prior_nobs=1.0):
+    """a fixed-precision slab in the style of the reference's logit / probit spike-slab
+    priors: precision = prior_nobs * X'NX / n (shrunk to its diagonal by half)"""
+    n, p = X.shape
+    xtx = (X * ntrials[:, None]).T @ X
+    prec = prior_nobs * (0.5 * np.diag(np.diag(xtx / n)) + 0.5 * xtx / n)
+    pi = np.full(p, min(1.0, expected_model_size / p))
+    return dict(mu=np.zeros(p), prec=prec), pi

@@ -145,6 +145,18 @@ class Oracle:
         L.bo_ss_level_suf.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.bo_ss_impute_state.argtypes = [C.c_void_p, C.c_void_p]
         L.bo_ss_draw.argtypes = [C.c_void_p]
+        L.bo_probit_create.restype = C.c_void_p
+        L.bo_probit_create.argtypes = [C.c_int, C.c_int] + [c_double_p] * 6 + [C.c_int]
+        L.bo_probit_destroy.argtypes = [C.c_void_p]
+        L.bo_probit_sss.restype = C.c_void_p
+        L.bo_probit_sss.argtypes = [C.c_void_p]
+        L.bo_probit_imputer_rng.restype = C.c_void_p
+        L.bo_probit_imputer_rng.argtypes = [C.c_void_p]
+        L.bo_probit_use_substreams.argtypes = [C.c_void_p, C.c_int]
+        L.bo_probit_draw.argtypes = [C.c_void_p]
+        L.bo_rtrun_norm.restype = C.c_double
+        L.bo_rtrun_norm.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
+                                    C.c_void_p]
         L.bo_ssm_create.restype = C.c_void_p
         L.bo_ssm_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p,
                                     C.POINTER(C.c_uint8), c_double_p, c_double_p,
@@ -468,8 +480,7 @@ class Oracle:
         return dict(gamma=gam, beta=beta, sigsq=sig, status=st)
 
     # -- SpikeSlabSampler (sigma^2 given) ---------------------------------------
-    def sss_run(self, xtx, xty, slab_kind, mu, prec, pi, rng_setup, init_gamma,
-                sigsq_seq, max_model_size=-1, max_flips=-1):
+    def _declare_sss(self):
         L = self.lib
         L.bo_sss_create.restype = C.c_void_p
         L.bo_sss_create.argtypes = [C.c_int, c_double_p, c_double_p, C.c_int,
@@ -482,6 +493,11 @@ class Oracle:
         L.bo_sss_rng.argtypes = [C.c_void_p]
         L.bo_sss_draw_model_indicators.argtypes = [C.c_void_p, C.c_double]
         L.bo_sss_draw_beta.argtypes = [C.c_void_p, C.c_double]
+
+    def sss_run(self, xtx, xty, slab_kind, mu, prec, pi, rng_setup, init_gamma,
+                sigsq_seq, max_model_size=-1, max_flips=-1):
+        self._declare_sss()
+        L = self.lib
         p = len(xty)
         h = L.bo_sss_create(p, _dp(fcol(xtx)), _dp(f64(xty)), int(slab_kind),
                             _dp(f64(mu)), _dp(fcol(prec)), _dp(f64(pi)))
@@ -568,6 +584,50 @@ class Oracle:
         self.lib.bo_ss_destroy(m)
         return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
                     state=state, status=status)
+
+    def trun_norms(self, rng, mu, sigma, cut, above, n):
+        st = C.c_int(0)
+        out = np.array([self.lib.bo_rtrun_norm(C.byref(rng), mu, sigma, cut, int(above),
+                                               C.byref(st)) for _ in range(n)])
+        assert st.value == 0
+        return out
+
+    def probit_run(self, X, y, ntrials, slab, pi, rng_setup, init_gamma, init_beta, nsweeps,
+                   clt_threshold=5, max_model_size=-1, max_flips=-1):
+        """BinomialProbitSpikeSlabSampler (f3): slab = dict(mu, prec)"""
+        n, p = X.shape
+        self._declare_sss()
+        m = self.lib.bo_probit_create(n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(ntrials)),
+                                      _dp(f64(slab["mu"])), _dp(fcol(slab["prec"])),
+                                      _dp(f64(pi)), int(clt_threshold))
+        sss = self.lib.bo_probit_sss(m)
+        self.lib.bo_sss_set_options(sss, int(max_model_size), int(max_flips))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self.lib.bo_sss_set_state(sss, _u8(g0), _dp(f64(init_beta) * g0))
+        if rng_setup[0] == "mt":
+            # PosteriorSampler's rng is seeded from the global one
+            glob = self.rng_mt(rng_setup[1])
+            self.lib.bo_rng_seed_mt(self.lib.bo_sss_rng(sss),
+                                    self.lib.bo_seed_rng(C.byref(glob)))
+        else:
+            seed, chain = int(rng_setup[1]), int(rng_setup[2])
+            self.lib.bo_rng_seed_philox(self.lib.bo_sss_rng(sss), seed, chain, 3, 0)
+            self.lib.bo_rng_seed_philox(self.lib.bo_probit_imputer_rng(m), seed, chain, 8, 0)
+            self.lib.bo_probit_use_substreams(m, 1)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        status = 0
+        for i in range(nsweeps):
+            status = self.lib.bo_probit_draw(m)
+            if status:
+                break
+            self.lib.bo_sss_get_state(sss, _u8(g), _dp(b))
+            gam[i] = g
+            beta[i] = b
+        self.lib.bo_probit_destroy(m)
+        return dict(gamma=gam, beta=beta, status=status)
 
     def ssm_run(self, y, X, observed, prior, opts, spec, rng_setup, init_gamma,
                 nsweeps):
@@ -912,6 +972,25 @@ class Ref:
             _u8(gam), _dp(beta), _dp(sig), _dp(lev), _dp(state)))
         return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
                     state=state)
+
+    def trun_norms(self, seed, mu, sigma, cut, above, n):
+        out = np.zeros(n)
+        self._check(self.lib.ref_rng_trun_norm(C.c_uint64(seed), C.c_double(mu), C.c_double(sigma),
+                                               C.c_double(cut), int(above), n, _dp(out)))
+        return out
+
+    def probit_run(self, X, y, ntrials, slab, pi, seed, init_gamma, init_beta, nsweeps,
+                   clt_threshold=5, max_model_size=-1, max_flips=-1):
+        n, p = X.shape
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self._check(self.lib.ref_probit_run(
+            n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(ntrials)), _dp(f64(slab["mu"])),
+            _dp(fcol(slab["prec"])), _dp(f64(pi)), C.c_int64(max_model_size), int(max_flips),
+            int(clt_threshold), C.c_uint64(seed), _u8(g0), _dp(f64(init_beta)), nsweeps,
+            _u8(gam), _dp(beta)))
+        return dict(gamma=gam, beta=beta)
 
     def ssm_run(self, y, X, observed, prior, opts, spec, seed, init_gamma, nsweeps):
         T, p = X.shape

@@ -286,6 +286,32 @@ def test_structural_sweeps_match_reference(oracle, name):
     assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
 
 
+# ------------------------------------------------------------------ probit
+def test_truncated_normal_known_answers(oracle):
+    """rtrun_norm_mt: rejection from the normal (cut below the mean) and the
+    bounded adaptive rejection sampler TnSampler (distributions/trun_norm.cpp)"""
+    g = load("kat_trun_norm")
+    for (mu, sg, cut, ab), want in zip(g["cases"], g["draws"]):
+        got = oracle.trun_norms(oracle.rng_mt(int(g["seed"])), float(mu), float(sg), float(cut),
+                                int(ab), want.shape[0])
+        assert np.array_equal(got, want), (mu, sg, cut, ab)
+
+
+@pytest.mark.parametrize("name", ["probit_bernoulli", "probit_binomial8_clt3",
+                                  "probit_binomial12"])
+def test_probit_spike_slab_matches_reference(oracle, name):
+    """f3 (probit): BinomialProbitSpikeSlabSampler.  The latent data carry rounding
+    differences from sweep to sweep and amplify them; 12 sweeps stay below 1e-9."""
+    g = load(name)
+    p = g["X"].shape[1]
+    o = oracle.probit_run(g["X"], g["y"], g["ntrials"], dict(mu=g["mu"], prec=g["prec"]),
+                          g["pi"], ("mt", int(g["seed"])), g["init_gamma"], np.zeros(p),
+                          int(g["nsweeps"]), clt_threshold=int(g["clt_threshold"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < 1e-9
+
+
 def test_impute_state_known_answer(oracle):
     g = load("kat_impute_state")
     o = oracle.ss_impute_state(g["y"], g["X"], g["observed"], g["beta"],
