@@ -1628,6 +1628,7 @@ struct bo_sss {
   double *xtx, *xty, *mu, *prec, *pi, *logpi, *logcpi;
   int64_t max_model_size;
   int max_flips;
+  int shuffle_kind; /* 0: SpikeSlabSampler's Fisher-Yates; 1: BinomialLogitSpikeSlabSampler's */
   uint8_t *gamma;
   double *beta;
   bo_rng rng;
@@ -1693,6 +1694,7 @@ void bo_sss_get_state(const bo_sss *s, uint8_t *gamma, double *beta) {
   if (beta) memcpy(beta, s->beta, sizeof(double) * s->p);
 }
 bo_rng *bo_sss_rng(bo_sss *s) { return &s->rng; }
+void bo_sss_set_shuffle_kind(bo_sss *s, int kind) { s->shuffle_kind = kind; }
 
 static double sss_spike_logp(const bo_sss *s, const uint8_t *g, int nvars) {
   if (s->max_model_size >= 0 && nvars > s->max_model_size) return BO_NEG_INF;
@@ -1761,12 +1763,24 @@ int bo_sss_draw_model_indicators(bo_sss *s, double sigsq) {
   uint8_t *g = (uint8_t *)malloc(p);
   memcpy(g, s->gamma, p);
   for (int j = 0; j < p; ++j) s->indx[j] = j;
-  for (int i = p - 1; i > 0; --i) {
-    int j = bo_random_int(&s->rng, 0, i);
-    if (j != i) {
+  if (s->shuffle_kind == 1) {
+    /* BinomialLogitSpikeSlabSampler::draw_model_indicators,
+     * BinomialLogitSpikeSlabSampler.cpp:181-187: every position swaps with a
+     * position drawn from the whole range */
+    for (int i = 0; i < p; ++i) {
+      int j = bo_random_int(&s->rng, 0, p - 1);
       int t = s->indx[i];
       s->indx[i] = s->indx[j];
       s->indx[j] = t;
+    }
+  } else {
+    for (int i = p - 1; i > 0; --i) {
+      int j = bo_random_int(&s->rng, 0, i);
+      if (j != i) {
+        int t = s->indx[i];
+        s->indx[i] = s->indx[j];
+        s->indx[j] = t;
+      }
     }
   }
   double logp = bo_sss_log_model_prob(s, g, sigsq);
@@ -2689,6 +2703,123 @@ int bo_probit_draw(bo_probit *m) {
     double sum_of_z = probit_impute(r, m->clt, m->nt[i], m->y[i], eta, &status);
     if (status) return status;
     for (int j = 0; j < p; ++j) xtz[j] += m->X[IDX(i, j, n)] * sum_of_z;
+  }
+  ++m->sweep;
+  status = bo_sss_draw_model_indicators(s, 1.0);
+  if (status) return status;
+  return bo_sss_draw_beta(s, 1.0);
+}
+
+
+/* ====================================================================== *
+ * BinomialLogitSpikeSlabSampler (the logit member; BASELINE
+ * config 5 with the reference's own auxiliary-mixture imputer in place of the
+ * Polya-Gamma one it does not have):
+ *   BinomialLogitAuxmixSampler::impute_latent_data  (BinomialLogitAuxmixSampler.cpp:77-97)
+ *   BinomialLogitCltDataImputer::impute_small_sample (BinomialLogitDataImputer.cpp:128-144)
+ *   rtrun_logit_mt (distributions/trun_logit.cpp:163-174)
+ *   NormalMixtureApproximation::unmix (NormalMixtureApproximation.cpp:280-290)
+ *   BinomialLogitSpikeSlabSampler::draw (BinomialLogitSpikeSlabSampler.cpp:50-79,
+ *   :87-117, :178-226)
+ * Observations with more than clt_threshold trials take the reference's
+ * large-sample branch, which is not restated (status 4).
+ * ====================================================================== */
+static const double LOGIT_MIX_SIGMA[9] = {0.88437229872213, 1.16097607474416, 1.28021991084306,
+                                          1.3592552924727,  1.67589879794907, 2.20287232043947,
+                                          2.20507148325819, 2.91944313615144, 3.90807611741308};
+static const double LOGIT_MIX_WEIGHT[9] = {0.038483985581272, 0.13389889791451,  0.0657842076622429,
+                                           0.105680086433879, 0.345939491553619, 0.0442261124345564,
+                                           0.193289780660134, 0.068173066865908, 0.00452437089387876};
+
+struct bo_logit {
+  int n, p, clt;
+  double *X, *y, *nt;
+  bo_sss *sss;      /* (X'WX, X'Wz), gamma, beta, the sampler's RNG */
+  bo_rng worker_rng; /* the imputation worker's own RNG (Imputer.hpp:136-142) */
+  int substream;     /* 1: observation i of sweep s reads from position (s n + i) * 64 */
+  uint64_t sweep;
+  double logw[9];
+};
+#define BO_LOGIT_STRIDE 64
+
+bo_logit *bo_logit_create(int n, int p, const double *X, const double *y,
+                          const double *ntrials, const double *mu, const double *prec,
+                          const double *pi, int clt_threshold) {
+  bo_logit *m = (bo_logit *)xcalloc(1, sizeof(bo_logit));
+  m->n = n; m->p = p; m->clt = clt_threshold;
+  m->X = (double *)xcalloc((size_t)n * p, sizeof(double));
+  m->y = (double *)xcalloc(n, sizeof(double));
+  m->nt = (double *)xcalloc(n, sizeof(double));
+  memcpy(m->X, X, sizeof(double) * (size_t)n * p);
+  memcpy(m->y, y, sizeof(double) * n);
+  memcpy(m->nt, ntrials, sizeof(double) * n);
+  double *xtx = (double *)xcalloc((size_t)p * p, sizeof(double));
+  double *xty = (double *)xcalloc(p, sizeof(double));
+  m->sss = bo_sss_create(p, xtx, xty, 0, mu, prec, pi);
+  m->sss->shuffle_kind = 1;
+  free(xtx); free(xty);
+  for (int s = 0; s < 9; ++s) m->logw[s] = log(LOGIT_MIX_WEIGHT[s]);
+  bo_rng_seed_philox(&m->worker_rng, 0, 0, 9, 0);
+  return m;
+}
+void bo_logit_destroy(bo_logit *m) {
+  if (!m) return;
+  bo_sss_destroy(m->sss);
+  free(m->X); free(m->y); free(m->nt);
+  free(m);
+}
+bo_sss *bo_logit_sss(bo_logit *m) { return m->sss; }
+bo_rng *bo_logit_worker_rng(bo_logit *m) { return &m->worker_rng; }
+void bo_logit_use_substreams(bo_logit *m, int on) { m->substream = on; }
+void bo_logit_get_suf(const bo_logit *m, double *xtx, double *xty) {
+  memcpy(xtx, m->sss->xtx, sizeof(double) * (size_t)m->p * m->p);
+  memcpy(xty, m->sss->xty, sizeof(double) * m->p);
+}
+
+int bo_logit_draw(bo_logit *m) {
+  const int n = m->n, p = m->p;
+  bo_sss *s = m->sss;
+  int status = 0;
+  /* clear_latent_data + the worker's pass over the data */
+  memset(s->xtx, 0, sizeof(double) * (size_t)p * p);
+  memset(s->xty, 0, sizeof(double) * p);
+  for (int i = 0; i < n; ++i) {
+    double eta = 0;
+    for (int j = 0; j < p; ++j)
+      if (s->gamma[j]) eta += m->X[IDX(i, j, n)] * s->beta[j];
+    const long nt = lround(m->nt[i]), ys = lround(m->y[i]);
+    if (nt > m->clt) return BO_ERR_UNSUPPORTED_RNG_BRANCH;
+    bo_rng *r = &m->worker_rng;
+    if (m->substream) r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * BO_LOGIT_STRIDE;
+    double sum = 0, info = 0;
+    for (long t = 0; t < nt; ++t) {
+      const int success = t < ys;
+      /* rtrun_logit_mt(rng, eta, 0, success) */
+      const double cutpoint_prob = 1 / (1 + exp(-(0 - eta)));   /* plogis(cutpoint - mean) */
+      const double u = success ? bo_runif(r, cutpoint_prob, 1) : bo_runif(r, 0, cutpoint_prob);
+      const double latent = (0.0 + 1.0 * log(u / (1. - u))) + eta;   /* qlogis(u) + mean */
+      /* unmix(latent - eta) */
+      double wsp[9], mx = BO_NEG_INF, nc = 0;
+      const double v = latent - eta;
+      for (int c = 0; c < 9; ++c) {
+        const double xs = (v - 0.0) / LOGIT_MIX_SIGMA[c];
+        wsp[c] = m->logw[c] + -(0.918938533204672741780329736406 + 0.5 * xs * xs + log(LOGIT_MIX_SIGMA[c]));
+        if (wsp[c] > mx) mx = wsp[c];
+      }
+      for (int c = 0; c < 9; ++c) { wsp[c] = exp(wsp[c] - mx); nc += wsp[c]; }
+      for (int c = 0; c < 9; ++c) wsp[c] /= nc;
+      const int ind = bo_rmulti(r, wsp, 9, &status);
+      if (status) return status;
+      const double w = 1.0 / (LOGIT_MIX_SIGMA[ind] * LOGIT_MIX_SIGMA[ind]);
+      info += w;
+      sum += latent * w;
+    }
+    /* SufficientStatistics::update(x, sum, info): xtx += info x x', xty += sum x */
+    for (int b = 0; b < p; ++b) {
+      const double xb = m->X[IDX(i, b, n)];
+      s->xty[b] += xb * sum;
+      for (int a = 0; a < p; ++a) s->xtx[IDX(a, b, p)] += m->X[IDX(i, a, n)] * xb * info;
+    }
   }
   ++m->sweep;
   status = bo_sss_draw_model_indicators(s, 1.0);

@@ -248,6 +248,20 @@ void bo_probit_use_substreams(bo_probit *m, int on);
 int bo_probit_draw(bo_probit *m);
 double bo_rtrun_norm(bo_rng *r, double mu, double sigma, double a, int gt, int *status);
 
+/* BinomialLogitSpikeSlabSampler (logit; auxiliary-mixture data
+ * augmentation + its own inclusion / coefficient draws on X'WX, X'Wz) */
+typedef struct bo_logit bo_logit;
+bo_logit *bo_logit_create(int n, int p, const double *X, const double *y,
+                          const double *ntrials, const double *mu, const double *prec,
+                          const double *pi, int clt_threshold);
+void bo_logit_destroy(bo_logit *m);
+bo_sss *bo_logit_sss(bo_logit *m);
+bo_rng *bo_logit_worker_rng(bo_logit *m);
+void bo_logit_use_substreams(bo_logit *m, int on);
+void bo_logit_get_suf(const bo_logit *m, double *xtx, double *xty);
+int bo_logit_draw(bo_logit *m);
+void bo_sss_set_shuffle_kind(bo_sss *s, int kind);
+
 /* AdaptiveSpikeSlabRegressionSampler on top of a bo_ssvs
  * (AdaptiveSpikeSlabRegressionSampler.cpp:62-225) */
 typedef struct bo_adaptive bo_adaptive;

@@ -27,6 +27,8 @@
 #include "Models/Glm/PosteriorSamplers/BregVsSampler.hpp"
 #include "Models/Glm/PosteriorSamplers/SpikeSlabSampler.hpp"
 #include "Models/Glm/BinomialProbitModel.hpp"
+#include "Models/Glm/BinomialLogitModel.hpp"
+#include "Models/Glm/PosteriorSamplers/BinomialLogitSpikeSlabSampler.hpp"
 #include "Models/Glm/PosteriorSamplers/BinomialProbitSpikeSlabSampler.hpp"
 #include "Models/Glm/WeightedRegressionModel.hpp"
 #include "Models/MvnModel.hpp"
@@ -745,6 +747,47 @@ int ref_probit_run(int n, int p, const double *X, const double *y, const double 
   NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
   if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
   NEW(BinomialProbitSpikeSlabSampler, sam)(model.get(), slab, spike, clt_threshold);
+  if (max_flips >= 0) sam->limit_model_selection(max_flips);
+  model->set_method(sam);
+  model->coef().drop_all();
+  Vector b0(p, 0.0);
+  for (int j = 0; j < p; ++j)
+    if (init_gamma[j]) {
+      model->coef().add(j);
+      b0[j] = init_beta[j];
+    }
+  model->coef().set_Beta(b0);
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    const Selector &inc(model->coef().inc());
+    const Vector &beta(model->Beta());
+    for (int j = 0; j < p; ++j) {
+      out_gamma[(size_t)i * p + j] = inc[j] ? 1 : 0;
+      out_beta[(size_t)i * p + j] = beta[j];
+    }
+  }
+  REF_CATCH
+}
+
+// BinomialLogitSpikeSlabSampler (logit)
+int ref_logit_run(int n, int p, const double *X, const double *y, const double *ntrials,
+                  const double *mu, const double *prec, const double *pi,
+                  int64_t max_model_size, int max_flips, int clt_threshold, uint64_t seed,
+                  const uint8_t *init_gamma, const double *init_beta, int nsweeps,
+                  uint8_t *out_gamma, double *out_beta) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  NEW(BinomialLogitModel, model)(p);
+  for (int i = 0; i < n; ++i) {
+    Vector x(p);
+    for (int j = 0; j < p; ++j) x[j] = X[(size_t)j * n + i];
+    NEW(BinomialRegressionData, dp)(y[i], ntrials[i], x);
+    model->add_data(dp);
+  }
+  Ptr<MvnBase> slab(new MvnModel(make_vector(p, mu), make_spd(p, prec), true));
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
+  NEW(BinomialLogitSpikeSlabSampler, sam)(model.get(), slab, spike, clt_threshold);
   if (max_flips >= 0) sam->limit_model_selection(max_flips);
   model->set_method(sam);
   model->coef().drop_all();

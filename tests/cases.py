@@ -149,3 +149,16 @@ def probit_slab(X, ntrials, expected_model_size, prior_nobs=1.0):
     prec = prior_nobs * (0.5 * np.diag(np.diag(xtx / n)) + 0.5 * xtx / n)
     pi = np.full(p, min(1.0, expected_model_size / p))
     return dict(mu=np.zeros(p), prec=prec), pi
+
+
+def logit_data(n, p, nsig, seed, max_trials=1):
+    """binomial logit data: X[:, 0] = 1, successes y out of ntrials"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((n, p))
+    X[:, 0] = 1.0
+    beta = np.zeros(p)
+    beta[:nsig] = np.array([0.4, 1.5, -1.2, 1.0, -0.8, 0.7, 1.3, -1.1])[:nsig]
+    prob = 1.0 / (1.0 + np.exp(-(X @ beta)))
+    nt = np.ones(n) if max_trials == 1 else rng.integers(1, max_trials + 1, n).astype(float)
+    y = rng.binomial(nt.astype(int), prob).astype(float)
+    return X, y, nt, beta

@@ -157,6 +157,16 @@ class Oracle:
         L.bo_rtrun_norm.restype = C.c_double
         L.bo_rtrun_norm.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
                                     C.c_void_p]
+        L.bo_logit_create.restype = C.c_void_p
+        L.bo_logit_create.argtypes = [C.c_int, C.c_int] + [c_double_p] * 6 + [C.c_int]
+        L.bo_logit_destroy.argtypes = [C.c_void_p]
+        L.bo_logit_sss.restype = C.c_void_p
+        L.bo_logit_sss.argtypes = [C.c_void_p]
+        L.bo_logit_worker_rng.restype = C.c_void_p
+        L.bo_logit_worker_rng.argtypes = [C.c_void_p]
+        L.bo_logit_use_substreams.argtypes = [C.c_void_p, C.c_int]
+        L.bo_logit_get_suf.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.bo_logit_draw.argtypes = [C.c_void_p]
         L.bo_ssm_create.restype = C.c_void_p
         L.bo_ssm_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p,
                                     C.POINTER(C.c_uint8), c_double_p, c_double_p,
@@ -629,6 +639,50 @@ class Oracle:
         self.lib.bo_probit_destroy(m)
         return dict(gamma=gam, beta=beta, status=status)
 
+    def logit_run(self, X, y, ntrials, slab, pi, rng_setup, init_gamma, init_beta, nsweeps,
+                  clt_threshold=5, max_model_size=-1, max_flips=-1, want_suf=False):
+        """BinomialLogitSpikeSlabSampler (f3): slab = dict(mu, prec)"""
+        n, p = X.shape
+        self._declare_sss()
+        m = self.lib.bo_logit_create(n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(ntrials)),
+                                     _dp(f64(slab["mu"])), _dp(fcol(slab["prec"])),
+                                     _dp(f64(pi)), int(clt_threshold))
+        sss = self.lib.bo_logit_sss(m)
+        self.lib.bo_sss_set_options(sss, int(max_model_size), int(max_flips))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self.lib.bo_sss_set_state(sss, _u8(g0), _dp(f64(init_beta) * g0))
+        if rng_setup[0] == "mt":
+            # the sampler's rng is seeded from the global one; its imputation worker's
+            # from the sampler's (at construction)
+            glob = self.rng_mt(rng_setup[1])
+            srng = self.lib.bo_sss_rng(sss)
+            self.lib.bo_rng_seed_mt(srng, self.lib.bo_seed_rng(C.byref(glob)))
+            self.lib.bo_rng_seed_mt(self.lib.bo_logit_worker_rng(m),
+                                    self.lib.bo_seed_rng(C.c_void_p(srng)))
+        else:
+            seed, chain = int(rng_setup[1]), int(rng_setup[2])
+            self.lib.bo_rng_seed_philox(self.lib.bo_sss_rng(sss), seed, chain, 3, 0)
+            self.lib.bo_rng_seed_philox(self.lib.bo_logit_worker_rng(m), seed, chain, 9, 0)
+            self.lib.bo_logit_use_substreams(m, 1)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        xtx = np.zeros((nsweeps, p, p)) if want_suf else None
+        xty = np.zeros((nsweeps, p)) if want_suf else None
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        status = 0
+        for i in range(nsweeps):
+            status = self.lib.bo_logit_draw(m)
+            if status:
+                break
+            self.lib.bo_sss_get_state(sss, _u8(g), _dp(b))
+            gam[i] = g
+            beta[i] = b
+            if want_suf:
+                self.lib.bo_logit_get_suf(m, _dp(xtx[i]), _dp(xty[i]))
+        self.lib.bo_logit_destroy(m)
+        return dict(gamma=gam, beta=beta, status=status, xtx=xtx, xty=xty)
+
     def ssm_run(self, y, X, observed, prior, opts, spec, rng_setup, init_gamma,
                 nsweeps):
         """structural model (f2): spec = structural_spec(...)"""
@@ -986,6 +1040,19 @@ class Ref:
         beta = np.zeros((nsweeps, p))
         g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
         self._check(self.lib.ref_probit_run(
+            n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(ntrials)), _dp(f64(slab["mu"])),
+            _dp(fcol(slab["prec"])), _dp(f64(pi)), C.c_int64(max_model_size), int(max_flips),
+            int(clt_threshold), C.c_uint64(seed), _u8(g0), _dp(f64(init_beta)), nsweeps,
+            _u8(gam), _dp(beta)))
+        return dict(gamma=gam, beta=beta)
+
+    def logit_run(self, X, y, ntrials, slab, pi, seed, init_gamma, init_beta, nsweeps,
+                  clt_threshold=5, max_model_size=-1, max_flips=-1):
+        n, p = X.shape
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self._check(self.lib.ref_logit_run(
             n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(ntrials)), _dp(f64(slab["mu"])),
             _dp(fcol(slab["prec"])), _dp(f64(pi)), C.c_int64(max_model_size), int(max_flips),
             int(clt_threshold), C.c_uint64(seed), _u8(g0), _dp(f64(init_beta)), nsweeps,

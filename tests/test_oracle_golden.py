@@ -312,6 +312,21 @@ def test_probit_spike_slab_matches_reference(oracle, name):
     assert relerr(o["beta"], g["beta"]) < 1e-9
 
 
+@pytest.mark.parametrize("name", ["logit_bernoulli", "logit_binomial4",
+                                  "logit_bernoulli_p24_maxflips"])
+def test_logit_spike_slab_matches_reference(oracle, name):
+    """f3 (logit): BinomialLogitSpikeSlabSampler with its auxiliary-mixture imputer"""
+    g = load(name)
+    p = g["X"].shape[1]
+    o = oracle.logit_run(g["X"], g["y"], g["ntrials"], dict(mu=g["mu"], prec=g["prec"]),
+                         g["pi"], ("mt", int(g["seed"])), g["init_gamma"], np.zeros(p),
+                         int(g["nsweeps"]), clt_threshold=int(g["clt_threshold"]),
+                         max_flips=int(g["max_flips"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < 1e-9
+
+
 def test_impute_state_known_answer(oracle):
     g = load("kat_impute_state")
     o = oracle.ss_impute_state(g["y"], g["X"], g["observed"], g["beta"],
