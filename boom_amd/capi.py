@@ -94,6 +94,8 @@ SIGNATURES = {
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
     "ba_probit_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, C.c_int32]),
     "ba_probit_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_logit_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, C.c_int32]),
+    "ba_logit_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_set_structural": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_dp] * 6),
     "ba_ss_get_structural": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -402,6 +404,19 @@ class Engine:
 
     def probit_sweep(self, nsweeps=1, sync=True):
         self._check(self.lib.ba_probit_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
+
+    def logit_set_data(self, X, y, ntrials, clt_threshold=5):
+        X = np.asfortranarray(X, dtype=np.float64)
+        self.p = X.shape[1]
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        nt = np.ascontiguousarray(ntrials, dtype=np.float64)
+        self._check(self.lib.ba_logit_set_data(self._h, X.shape[0], X.shape[1], _p(X), _p(y),
+                                               _p(nt), int(clt_threshold)))
+
+    def logit_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_logit_sweep(self._h, nsweeps))
         if sync:
             self.sync()
 

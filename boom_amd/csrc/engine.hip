@@ -41,6 +41,8 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
 // kalman_kernel.hip
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances);
 hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P);
+hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *slab_precision,
+                               double *V);
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
 hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
@@ -235,6 +237,10 @@ struct ba_engine {
   int probit_clt = 5;
   uint64_t probit_sweep = 0;
   DevBuf<double> dprob_X, dprob_y, dprob_nt, dprob_z;
+  // BinomialLogitSpikeSlabSampler: the same buffers plus the observations' total
+  // precisions (chains x n) and every chain's own V = slab precision + X'WX
+  bool logit_mode = false;
+  DevBuf<double> dlogit_w, dlogit_V;
   // structural state (trend + seasonal, ssm_kernel.hip) instead of the local level
   bool ssm_set = false;
   SsmParams ssm{};                 // the host's copy of the specification (device pointers filled per launch)
@@ -448,7 +454,7 @@ void fill_params(ba_engine *e, SsvsParams &P) {
     P.yty = e->dyty_c.ptr;
     P.nobs = e->dnobs_c.ptr;
     P.suf_stride = 1;
-  } else if (e->probit_mode && e->dxty_c.count) {
+  } else if ((e->probit_mode || e->logit_mode) && e->dxty_c.count) {
     P.xty = e->dxty_c.ptr;      // X'z of every chain's own imputation
     P.xty_stride = e->p;
     P.yty = e->dscal.ptr;
@@ -490,7 +496,7 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.table_keep = e->table_ok ? 1 : 0;
   P.model_tag = e->dmodel_tag.ptr;
   P.model_keep = e->model_ok ? 1 : 0;
-  P.suf_changed = (e->ss_mode || e->probit_mode) ? 1 : 0;
+  P.suf_changed = (e->ss_mode || e->probit_mode || e->logit_mode) ? 1 : 0;
   P.run_limit = 0;
   P.ran = nullptr;
   P.model_scratch_stride = (int64_t)ssvs_scalar_layout(64).total;
@@ -512,6 +518,15 @@ void fill_params(ba_engine *e, SsvsParams &P) {
     P.draw_beta = 1;
     P.cm_start = nullptr;
     P.max_flips = (e->sss_max_flips > 0) ? std::min(e->sss_max_flips, e->p) : e->p;
+  }
+  if (e->cur_mode == 1 && e->logit_mode && e->dlogit_V.count) {
+    // BinomialLogitSpikeSlabSampler: the sampler's own shuffle, every chain's own V
+    // (which moves with the latent data: factors and tables are rebuilt)
+    P.mode = 2;
+    P.V = e->dlogit_V.ptr;
+    P.v_chain_stride = (int64_t)e->p * e->p;
+    P.model_keep = 0;
+    P.table_keep = 0;
   }
   if (e->cur_mode == 2) {
     // AdaptiveSpikeSlabRegressionSampler: own stream, no swap move
@@ -615,6 +630,7 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
     if (e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
     if (e->kcap >= cap_limit(*e)) {
       if (e->cur_mode == 2) return BA_OK;  // (the adaptive kernel stops at 64 variables: stays an error)
+      if (e->logit_mode) return BA_OK;     // (per-chain V is only in the LDS kernel: stays an error)
       // beyond the LDS kernel: the parked chains go to the HBM-resident one
       int stuck = 0;
       int rc = grow_big(e, &stuck);
@@ -1881,6 +1897,8 @@ int ba_probit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, cons
   HIP_TRY(hipMemcpy(e->dprob_y.ptr, y, (size_t)n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->dprob_nt.ptr, ntrials, (size_t)n * 8, hipMemcpyHostToDevice));
   e->probit_mode = true;
+  e->logit_mode = false;
+  e->dprob_z.release();
   e->probit_n = n;
   e->probit_clt = clt_threshold;
   e->probit_sweep = 0;
@@ -1935,9 +1953,114 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps) {
     Q.sweep = e->probit_sweep++;
     HIP_TRY(launch_probit_impute(e->stream, Q));   // impute_latent_data, X'z
     HIP_TRY(launch_sweeps(e, P, 1));               // draw_model_indicators, draw_beta
+    // (a chain that outgrew the launch's capacity replays THIS sweep's draws on
+    // this sweep's latent data before the next imputation)
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    rc = check_chain_status(e);
+    if (rc) return rc;
+    fill_params(e, P);
     P.model_keep = 1;
     e->model_ok = true;
   }
+  return BA_OK;
+}
+
+// ------------------------ BinomialLogitSpikeSlabSampler (auxiliary-mixture augmentation)
+int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const double *y,
+                      const double *ntrials, int32_t clt_threshold) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (!X || !y || !ntrials) return fail(BA_E_INVALID, "null argument");
+  if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
+  if (clt_threshold < 1 || 2 * clt_threshold > LOGIT_STRIDE)
+    return fail(BA_E_INVALID, "clt_threshold must be between 1 and 32");
+  for (int64_t i = 0; i < n; ++i) {
+    if (y[i] < 0 || ntrials[i] < 0)
+      return fail(BA_E_INVALID, "The number of successes and the number of trials must both be non-negative in BinomialLogitPartialAugmentationDataImputer::impute().");
+    if (y[i] > ntrials[i])
+      return fail(BA_E_INVALID, "The number of successes must not exceed the number of trials in BinomialLogitPartialAugmentationDataImputer::impute().");
+    if (ntrials[i] > clt_threshold)
+      return fail(BA_E_INVALID, "observations with more than clt_threshold trials (the reference's large-sample imputation) are not implemented on the device");
+  }
+  // (dimensions, the shared buffers and a placeholder X'X; the sweeps use every
+  // chain's own X'WX)
+  std::vector<double> zero((size_t)n, 0.0);
+  int rc = ba_build_suf_from_xy(e, n, p, X, zero.data());
+  if (rc) return rc;
+  HIP_TRY(e->dprob_X.resize((size_t)n * p));
+  HIP_TRY(e->dprob_y.resize((size_t)n));
+  HIP_TRY(e->dprob_nt.resize((size_t)n));
+  HIP_TRY(hipMemcpy(e->dprob_X.ptr, X, (size_t)n * p * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dprob_y.ptr, y, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dprob_nt.ptr, ntrials, (size_t)n * 8, hipMemcpyHostToDevice));
+  e->logit_mode = true;
+  e->probit_mode = false;
+  e->probit_n = n;
+  e->probit_clt = clt_threshold;
+  e->probit_sweep = 0;
+  e->ss_mode = false;
+  e->dprob_z.release();
+  return BA_OK;
+}
+
+int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  if (!e->logit_mode) return fail(BA_E_STATE, "call ba_logit_set_data first");
+  if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
+  if (e->sss_slab_scales) return fail(BA_E_INVALID, "the logit sampler takes a fixed-precision slab (scales_with_sigsq = 0)");
+  int rc = alloc_chain_state(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, n = (size_t)e->probit_n;
+  if (e->dprob_z.count != C * n || e->dlogit_V.count != C * p * p) {
+    HIP_TRY(e->dprob_z.resize(C * n));
+    HIP_TRY(e->dlogit_w.resize(C * n));
+    HIP_TRY(e->dlogit_V.resize(C * p * p));
+    HIP_TRY(e->dxty_c.resize(C * p));
+    std::vector<double> one(C, 1.0);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->dsigsq.ptr, one.data(), C * 8, hipMemcpyHostToDevice));
+  }
+  rc = switch_mode(e, 1, 1.0);
+  if (rc) return rc;
+  rc = upload_shared(e);
+  if (rc) return rc;
+  HIP_TRY(e->dmodel.resize(2 * C * ssvs_scalar_layout(64).total));
+  SsvsParams P;
+  fill_params(e, P);
+  ProbitParams Q;
+  std::memset(&Q, 0, sizeof(Q));
+  Q.n = (int32_t)n;
+  Q.p = (int32_t)p;
+  Q.chains = (int32_t)C;
+  Q.clt_threshold = e->probit_clt;
+  Q.chain_offset = e->cfg.chain_offset;
+  Q.X = e->dprob_X.ptr;
+  Q.y = e->dprob_y.ptr;
+  Q.ntrials = e->dprob_nt.ptr;
+  Q.gamma = e->dgamma.ptr;
+  Q.beta = e->dbeta.ptr;
+  Q.z = e->dprob_z.ptr;
+  Q.w = e->dlogit_w.ptr;
+  Q.xtz = e->dxty_c.ptr;
+  Q.seed_lo = (uint32_t)e->seed;
+  Q.seed_hi = (uint32_t)(e->seed >> 32);
+  Q.status = e->dstatus.ptr;
+  // BinomialLogitSpikeSlabSampler::draw (BinomialLogitSpikeSlabSampler.cpp:50-54)
+  for (int i = 0; i < nsweeps; ++i) {
+    Q.sweep = e->probit_sweep++;
+    HIP_TRY(launch_logit_impute(e->stream, Q, e->dA.ptr, e->dlogit_V.ptr));   // impute_latent_data
+    HIP_TRY(launch_sweeps(e, P, 1));                                         // draw_model_indicators, draw_beta
+    // (a chain that outgrew the launch's capacity replays THIS sweep's draws on
+    // this sweep's latent data before the next imputation)
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    rc = check_chain_status(e);
+    if (rc) return rc;
+    fill_params(e, P);
+  }
+  e->table_ok = false;
+  e->model_ok = false;
   return BA_OK;
 }
 

@@ -168,6 +168,92 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   P.z[(size_t)chain * P.n + i] = ans;
 }
 
+// BinomialLogitAuxmixSampler's imputation (BinomialLogitAuxmixSampler.cpp:77-97,
+// BinomialLogitCltDataImputer::impute_small_sample, BinomialLogitDataImputer.cpp:
+// 128-144): per trial a logistic draw truncated to the side of zero its outcome
+// says (inverse cdf, one uniform: distributions/trun_logit.cpp:163-174), the
+// component of the nine-normal mixture that approximates the logistic density
+// (NormalMixtureApproximation.cpp:280-290, :416-424; one uniform), and from it the
+// trial's precision.  z[chain][i] = sum of latent * precision, w[chain][i] = sum
+// of precisions.  Exactly two uniforms per trial: observation i of sweep s reads
+// the chain's worker stream (id 9) from position (s n + i) * 64.
+__global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
+  const double MIX_SIGMA[9] = {0.88437229872213, 1.16097607474416, 1.28021991084306,
+                               1.3592552924727,  1.67589879794907, 2.20287232043947,
+                               2.20507148325819, 2.91944313615144, 3.90807611741308};
+  const double MIX_WEIGHT[9] = {0.038483985581272, 0.13389889791451,  0.0657842076622429,
+                                0.105680086433879, 0.345939491553619, 0.0442261124345564,
+                                0.193289780660134, 0.068173066865908, 0.00452437089387876};
+  const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (P.status[chain] != CHAIN_OK) return;
+  __shared__ int s_idx[PROBIT_KMAX];
+  __shared__ double s_beta[PROBIT_KMAX];
+  __shared__ int s_k;
+  if (threadIdx.x == 0) {
+    int k = 0;
+    const uint8_t *g = P.gamma + (size_t)chain * P.p;
+    const double *b = P.beta + (size_t)chain * P.p;
+    for (int j = 0; j < P.p; ++j) {
+      if (g[j]) {
+        if (k < PROBIT_KMAX) { s_idx[k] = j; s_beta[k] = b[j]; }
+        ++k;
+      }
+    }
+    s_k = k;
+  }
+  __syncthreads();
+  const int k = s_k;
+  if (k > PROBIT_KMAX) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
+    return;
+  }
+  if (i >= P.n) return;
+  double eta = 0.0;
+  for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
+  const long nt = lround(P.ntrials[i]), ys = lround(P.y[i]);
+  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 9u},
+             (P.sweep * (uint64_t)P.n + (uint64_t)i) * LOGIT_STRIDE};
+  double sum = 0.0, info = 0.0;
+  if (nt > P.clt_threshold || 2 * nt > LOGIT_STRIDE) {
+    // (the reference's large-sample branch is not on the device: reported)
+    P.status[chain] = CHAIN_RNG_BRANCH;
+  } else {
+    const double cutpoint_prob = 1 / (1 + exp(-(0 - eta)));
+    for (long t = 0; t < nt; ++t) {
+      const bool success = t < ys;
+      const double u = success ? d_runif(rng, cutpoint_prob, 1.0) : d_runif(rng, 0.0, cutpoint_prob);
+      const double latent = (0.0 + 1.0 * log(u / (1. - u))) + eta;
+      const double v = latent - eta;
+      double wsp[9], mx = -__builtin_huge_val(), nc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const double xs = (v - 0.0) / MIX_SIGMA[c];
+        wsp[c] = log(MIX_WEIGHT[c]) + -(0.918938533204672741780329736406 + 0.5 * xs * xs + log(MIX_SIGMA[c]));
+        mx = wsp[c] > mx ? wsp[c] : mx;
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { wsp[c] = exp(wsp[c] - mx); nc += wsp[c]; }
+      double probsum = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { wsp[c] /= nc; probsum += wsp[c]; }
+      // rmulti_mt (distributions/rmulti.cpp:41-78)
+      const double tmp = d_runif(rng, 0.0, probsum);
+      double psum = 0.0, sig = MIX_SIGMA[8];
+      bool found = false;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        psum += wsp[c];
+        if (!found && tmp <= psum) { found = true; sig = MIX_SIGMA[c]; }
+      }
+      const double wgt = 1.0 / (sig * sig);
+      info += wgt;
+      sum += latent * wgt;
+    }
+  }
+  P.z[(size_t)chain * P.n + i] = sum;
+  P.w[(size_t)chain * P.n + i] = info;
+}
+
 hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
                            const double *B, int64_t ldb, int N, int K, double *C, int ldc);
 
@@ -177,6 +263,20 @@ hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P) {
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
   return launch_atb_mfma(stream, P.z, (int64_t)P.n, P.chains, P.X, (int64_t)P.n, P.p, P.n, P.xtz, P.p);
+}
+
+hipError_t launch_xtwx_mfma(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
+                            int chains, const double *base, double *out);
+
+// impute, X'Wz and V = slab precision + X'WX for every chain
+hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *slab_precision,
+                               double *V) {
+  hipLaunchKernelGGL(logit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  err = launch_atb_mfma(stream, P.z, (int64_t)P.n, P.chains, P.X, (int64_t)P.n, P.p, P.n, P.xtz, P.p);
+  if (err != hipSuccess) return err;
+  return launch_xtwx_mfma(stream, P.X, (int64_t)P.n, P.p, P.w, P.chains, slab_precision, V);
 }
 
 }  // namespace boom_amd

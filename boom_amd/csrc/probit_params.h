@@ -7,7 +7,7 @@
 
 namespace boom_amd {
 
-enum { PROBIT_STRIDE = 256, PROBIT_KMAX = 1024 };
+enum { PROBIT_STRIDE = 256, PROBIT_KMAX = 1024, LOGIT_STRIDE = 64 };
 
 struct ProbitParams {
   int32_t n, p, chains, clt_threshold;
@@ -19,6 +19,7 @@ struct ProbitParams {
   const double *beta;     // chains x p
   double *z;              // chains x n: the observations' sums of latent normals
   double *xtz;            // chains x p: X'z
+  double *w;              // chains x n: the observations' total precision (logit only)
   uint32_t seed_lo, seed_hi;
   uint64_t sweep;         // imputations done so far (positions the substreams)
   int32_t *status;

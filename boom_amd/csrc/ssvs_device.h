@@ -978,20 +978,26 @@ enum : int { STOP_ACCEPT = 1, STOP_SLOW = 2, STOP_BAD = 3 };
 
 __device__ __forceinline__ void shuffle_targets(const PhiloxKey &key, uint64_t pos,
                                                 int p, int tid, int nthreads,
-                                                lds_u16 *oth) {
+                                                lds_u16 *oth, bool whole_range = false) {
   // uniform number pos + t (t = 0..p-2) picks the partner of i = p-1-t:
   // random_int_mt(rng, 0, i) (cpputil/shuffle.hpp:36-46); one Philox block
-  // serves two consecutive steps
-  const uint64_t b0 = pos >> 1, b1 = (pos + (uint64_t)(p - 2)) >> 1;
+  // serves two consecutive steps.  whole_range (BinomialLogitSpikeSlabSampler.cpp:
+  // 181-187): uniform t (t = 0..p-1) picks the partner of i = t from 0..p-1.
+  const int nt = whole_range ? p : p - 1;
+  const uint64_t b0 = pos >> 1, b1 = (pos + (uint64_t)(nt - 1)) >> 1;
   for (uint64_t b = b0 + (uint64_t)tid; b <= b1; b += (uint64_t)nthreads) {
     double u[2];
     philox_pair(key, b, &u[0], &u[1]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const long long t = (long long)(2 * b + h) - (long long)pos;
-      if (t >= 0 && t < p - 1) {
-        const int i = p - 1 - (int)t;
-        oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u[h]);
+      if (t >= 0 && t < nt) {
+        if (whole_range) {
+          oth[t] = (uint16_t)(int)floor(0.0 + ((double)p - 0.0) * u[h]);
+        } else {
+          const int i = p - 1 - (int)t;
+          oth[i] = (uint16_t)(int)floor(0.0 + ((double)(i + 1) - 0.0) * u[h]);
+        }
       }
     }
   }

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
                                                             int nsweeps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int chain = (int)blockIdx.x + P.chain_first;
+  P.V += (size_t)chain * (size_t)P.v_chain_stride;   // (a chain's own V: the logit sampler's X'WX moves with its latent data)
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int p = P.p;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
         }
       } else {  // CMD_UNIF: this wave's share of the shuffle uniforms
-        if (p > 1) shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth);
+        if (p > 1) shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth, P.mode == 2);
       }
       HSTAMP(sx_unused, 7);
       __syncthreads();
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
       {
         const bool ut = (P.walk_policy != 0) && (stops_prev <= 1 || P.walk_policy == 2);
         const bool mc = model_checked || (M.logp > -BA_INF && M.logp < BA_INF);
-        const bool will_fork = nflips > 0 && W > 1 && ut && table_valid && mc && p > 1 && P.walk_policy != 3;
+        const bool will_fork = nflips > 0 && W > 1 && ut && table_valid && mc && p > 1 && P.walk_policy != 3 && P.mode != 2;
         if (commit_pending && !will_fork) {
           phase = PH_COMMIT;  // nothing to overlap with: commit first
           continue;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         use_table = (P.walk_policy != 0) && (stops_prev <= 1 || P.walk_policy == 2);
         stops_prev = stops_now;
         stops_now = 0;
-        if (W > 1 && use_table && table_valid && model_checked && p > 1 && P.walk_policy != 3) {
+        if (W > 1 && use_table && table_valid && model_checked && p > 1 && P.walk_policy != 3 && P.mode != 2) {
           // ---- fork: wave 1 takes the permutation side of the sweep
           wave_sync();
           if (lane == 0) {
@@ -491,11 +492,25 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
           }
           __syncthreads();
         }
-        if (p > 1) shuffle_targets(key, pos, p, threadIdx.x, WAVE * W, ch.oth);
+        if (p > 1) shuffle_targets(key, pos, p, threadIdx.x, WAVE * W, ch.oth, P.mode == 2);
         if (W > 1) __syncthreads(); else wave_sync();
         STAMP(0);
-        if (p > 1) { parallel_shuffle(ch, sx); perm_sel ^= 1; }
-        flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
+        if (P.mode == 2) {
+          // BinomialLogitSpikeSlabSampler's shuffle: for i = 0..p-1 swap(indx[i],
+          // indx[j_i]), j_i anywhere in the range -- a later step can move what an
+          // earlier one placed, so the steps run in order (a sweep of this
+          // sampler is dominated by its n p^2 sufficient statistics anyway)
+          if (lane == 0 && p > 1) {
+            for (int i = 0; i < p; ++i) {
+              const int j = ch.oth[i];
+              const uint16_t a = ch.perm[i];
+              ch.perm[i] = ch.perm[j];
+              ch.perm[j] = a;
+            }
+          }
+          wave_sync();
+        } else if (p > 1) { parallel_shuffle(ch, sx); perm_sel ^= 1; }
+        flip_pos = pos + (uint64_t)(P.mode == 2 ? p : (p > 0 ? p - 1 : 0));
         pos = flip_pos + (uint64_t)nflips;
         STAMP(1);
         if (!model_checked) {

@@ -43,7 +43,11 @@ struct SsvsParams {
   int64_t chain_offset;
   int32_t kcap;  // largest model the LDS working set can hold: 16/32/48/64
   int32_t waves; // wavefronts per chain (1, 2 or 4)
-  int32_t mode;  // 0: BregVsSampler (sigma^2 integrated out); 1: SpikeSlabSampler (given sigma^2)
+  // 0: BregVsSampler (sigma^2 integrated out); 1: SpikeSlabSampler (given sigma^2);
+  // 2: BinomialLogitSpikeSlabSampler -- as 1, with its own way of shuffling the visiting
+  // order (every position swaps with one drawn from the whole range: p uniforms) and V per chain
+  int32_t mode;
+  int64_t v_chain_stride;  // doubles between the chains' V matrices (0: one shared V)
   // how a sweep's proposals are walked (ssvs_kernel.hip): 0 batch mode only, 1
   // adaptive (table look-ups after quiet sweeps; the default), 2 always the
   // table, 3 adaptive without the forked quiet sweep (diagnostic A/B)

@@ -98,6 +98,79 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
       }
 }
 
+// Weighted, batched variant: out[c] = base + X' diag(w_c) X for every chain c
+// (blockIdx.z), w row-major chains x n.  The complete-data sufficient statistic
+// X'WX of BinomialLogitAuxmixSampler (BinomialLogitAuxmixSampler.cpp:64-70) with
+// the slab's precision added on the way out: the per-chain matrix V the sweep
+// kernel reads.  Same tiling as xtx_mfma_kernel; the batch supplies the
+// parallelism, so there is no split over rows (the k order is fixed: bitwise
+// reproducible).
+__global__ __launch_bounds__(256) void xtwx_mfma_kernel(const double *__restrict__ X, int64_t n,
+                                                        int p, const double *__restrict__ w,
+                                                        const double *__restrict__ base,
+                                                        double *__restrict__ out) {
+  __shared__ double sA[TILE * LDP];
+  __shared__ double sB[TILE * LDP];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (tj > ti) return;
+  const int I0 = ti * TILE, J0 = tj * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  w += (size_t)blockIdx.z * (size_t)n;
+  out += (size_t)blockIdx.z * (size_t)p * (size_t)p;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int fr = lane >> 4, fc = lane & 15;
+  for (int64_t r0 = 0; r0 < n; r0 += KC) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = it * 256 + tid;
+      const int col = e >> 5, row = e & 31;
+      const int64_t r = r0 + row;
+      const int ci = I0 + col, cj = J0 + col;
+      const double wr = (r < n) ? w[r] : 0.0;
+      sA[col * LDP + row] = (r < n && ci < p) ? X[(int64_t)ci * n + r] : 0.0;
+      sB[col * LDP + row] = (r < n && cj < p) ? X[(int64_t)cj * n + r] * wr : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      double a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = sA[(wi * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
+        b[t] = sB[(wj * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
+      }
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+          acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = I0 + wi * 32 + ta * 16 + (lane >> 4) + 4 * q;
+        const int j = J0 + wj * 32 + tb * 16 + (lane & 15);
+        if (i < p && j < p) {
+          // (the diagonal tiles compute both triangles: keep the lower one so that
+          // the matrix is exactly symmetric)
+          if (ti == tj && j > i) continue;
+          const double v = acc[ta][tb][q] + (base ? base[(int64_t)j * p + i] : 0.0);
+          out[(int64_t)j * p + i] = v;
+          out[(int64_t)i * p + j] = v;
+        }
+      }
+}
+
 // sum of the split-K planes in plane order (bitwise reproducible)
 __global__ __launch_bounds__(256) void plane_sum_kernel(const double *__restrict__ planes,
                                                         int nplanes, size_t count,
@@ -223,6 +296,14 @@ __global__ __launch_bounds__(256) void atb_mfma_kernel(const double *__restrict_
 }
 
 }  // namespace
+
+hipError_t launch_xtwx_mfma(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
+                            int chains, const double *base, double *out) {
+  const int tiles = (p + TILE - 1) / TILE;
+  hipLaunchKernelGGL(xtwx_mfma_kernel, dim3(tiles, tiles, chains), dim3(256), 0, stream, X, n, p, w,
+                     base, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
                            const double *B, int64_t ldb, int N, int K, double *C, int ldc) {

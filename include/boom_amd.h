@@ -257,6 +257,23 @@ int ba_probit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X,
                        const double *y, const double *ntrials, int32_t clt_threshold);
 int ba_probit_sweep(ba_engine *e, int32_t nsweeps);
 
+/* ---- BinomialLogitSpikeSlabSampler (the logit member; the
+ * sampler behind BASELINE config 5, with the reference's own auxiliary-mixture
+ * imputer -- it has no Polya-Gamma one) -------------------------------------------
+ * Per sweep: every trial's truncated logistic draw and mixture component
+ * (BinomialLogitAuxmixSampler.cpp:77-97, BinomialLogitDataImputer.cpp:128-144),
+ * X'Wz for all chains by one MFMA GEMM, every chain's own X'WX by a batched
+ * weighted MFMA syrk, then the sampler's inclusion / coefficient draws
+ * (BinomialLogitSpikeSlabSampler.cpp:50-117, :178-226; its shuffle of the visiting
+ * order differs from SpikeSlabSampler's).  Same prior setters and state accessors as
+ * the probit sampler.  Observations need ntrials <= clt_threshold <= 32 (the
+ * large-sample imputation is not on the device); models of up to 64 variables.  RNG:
+ * stream 3 for the sampler, stream 9 from position (s n + i) * 64 for the
+ * imputation of observation i in sweep s (exactly two uniforms per trial). */
+int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X,
+                      const double *y, const double *ntrials, int32_t clt_threshold);
+int ba_logit_sweep(ba_engine *e, int32_t nsweeps);
+
 /* ---- posterior summaries --------------------------------------------------- */
 /* Running sums over every sweep since the last ba_reset_summaries(), reduced
  * over this engine's chains on the device:

@@ -1,0 +1,95 @@
+"""BinomialLogitSpikeSlabSampler on the device (the logit
+member; the sampler behind BASELINE config 5 with the reference's own
+auxiliary-mixture imputer): per-trial truncated logistic + mixture component,
+X'Wz by one MFMA GEMM, every chain's X'WX by a batched weighted MFMA syrk, the
+sampler's inclusion / coefficient draws -- against the CPU oracle (pinned on the
+reference: tests/golden/logit_*.npz), through the C-ABI.
+
+Bar: inclusion indicators bit-exact, coefficients within 1e-8 relative.
+"""
+import numpy as np
+import pytest
+
+from cases import logit_data, probit_slab
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+def relerr(a, b, floor=1e-3):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def make_engine(chains, seed, X, y, nt, slab, pi, g0, clt=5, max_flips=-1, **kw):
+    import boom_amd
+    eng = boom_amd.Engine(chains, seed=seed, **kw)
+    eng.logit_set_data(X, y, nt, clt)
+    eng.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False, max_flips=max_flips)
+    eng.set_spike(pi)
+    eng.set_state(g0)
+    return eng
+
+
+@pytest.mark.parametrize("n,p,nsig,max_trials,max_flips",
+                         [(300, 10, 3, 1, -1), (300, 10, 3, 4, -1), (777, 24, 5, 1, 9),
+                          (500, 70, 6, 1, -1), (64, 5, 2, 3, -1)])
+def test_logit_sweeps_match_oracle(oracle, n, p, nsig, max_trials, max_flips):
+    X, y, nt, _ = logit_data(n, p, nsig, seed=5 + max_trials + p, max_trials=max_trials)
+    slab, pi = probit_slab(X, nt, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    chains, seed, nsw = 6, 17, 25
+    eng = make_engine(chains, seed, X, y, nt, slab, pi, g0, max_flips=max_flips)
+    check = [0, chains - 1]
+    ora = {c: oracle.logit_run(X, y, nt, slab, pi, ("philox", seed, c), g0, np.zeros(p), nsw,
+                               max_flips=max_flips) for c in check}
+    for s in range(nsw):
+        eng.logit_sweep(1)
+        gam, beta, _ = eng.get_states()
+        for c in check:
+            o = ora[c]
+            assert o["status"] == 0
+            assert np.array_equal(gam[c], o["gamma"][s]), (c, s)
+            assert relerr(beta[c], o["beta"][s]) < RTOL, (c, s)
+    # several sweeps in one call are the same draws
+    eng2 = make_engine(chains, seed, X, y, nt, slab, pi, g0, max_flips=max_flips)
+    eng2.logit_sweep(nsw)
+    a, b = eng.get_states(), eng2.get_states()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_logit_capacity_escalation_and_recovery(oracle):
+    """20 signals from a one-variable start: chains outgrow the 16-variable launch
+    capacity inside a sweep and replay it on the same latent data"""
+    n, p, nsig = 1500, 40, 8
+    rng = np.random.Generator(np.random.PCG64(2))
+    X = rng.standard_normal((n, p))
+    X[:, 0] = 1.0
+    btrue = np.zeros(p)
+    btrue[:20] = rng.choice([-1.0, 1.0], 20) * 1.2
+    y = rng.binomial(1, 1 / (1 + np.exp(-(X @ btrue)))).astype(float)
+    nt = np.ones(n)
+    slab, pi = probit_slab(X, nt, 20)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    chains, seed, nsw = 4, 5, 12
+    import boom_amd
+    eng = make_engine(chains, seed, X, y, nt, slab, pi, g0)
+    eng.set_tuning(kcap_start=16)
+    ora = {c: oracle.logit_run(X, y, nt, slab, pi, ("philox", seed, c), g0, np.zeros(p), nsw)
+           for c in (0, 3)}
+    eng.logit_sweep(nsw)
+    gam, beta, _ = eng.get_states()
+    for c in (0, 3):
+        assert np.array_equal(gam[c], ora[c]["gamma"][-1]), c
+        assert relerr(beta[c], ora[c]["beta"][-1]) < RTOL, c
+    assert gam.sum(axis=1).min() > 16
+
+
+def test_logit_rejects_large_trial_counts():
+    import boom_amd
+    X, y, nt, _ = logit_data(50, 4, 2, seed=1, max_trials=9)
+    eng = boom_amd.Engine(2, seed=1)
+    with pytest.raises(boom_amd.BoomAmdError) as ei:
+        eng.logit_set_data(X, y, nt, 5)
+    assert "large-sample" in str(ei.value)
