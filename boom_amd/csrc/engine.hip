@@ -40,6 +40,8 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        double *planes /* suf_row_slices(n, p) * p * p doubles, or null */);
 // kalman_kernel.hip
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances);
+hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
+                               uint64_t *pos_forecast, double *out);
 hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P);
 hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *slab_precision,
                                double *V);
@@ -2351,7 +2353,6 @@ int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *ou
   if (!newX || !out || horizon <= 0) return fail(BA_E_INVALID, "bad argument");
   if (!e->ss_mode || e->dss_scratch.count == 0 || !e->ss_initialized)
     return fail(BA_E_STATE, "no state draw yet: run ba_ss_sweep or ba_ss_impute_state first");
-  if (e->ssm_set) return fail(BA_E_STATE, "forecasts are implemented for the local level model only");
   int rc = ba_sync(e);
   if (rc) return rc;
   const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, h = (size_t)horizon;
@@ -2361,7 +2362,10 @@ int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *ou
   HIP_TRY(hipMemcpyAsync(dnx.ptr, newX, h * p * 8, hipMemcpyHostToDevice, e->stream));
   SsParams S;
   fill_ss_params(e, S);
-  HIP_TRY(launch_ss_forecast(e->stream, S, horizon, dnx.ptr, e->dpos_forecast.ptr, dout.ptr));
+  if (e->ssm_set)
+    HIP_TRY(launch_ssm_forecast(e->stream, S, horizon, dnx.ptr, e->dpos_forecast.ptr, dout.ptr));
+  else
+    HIP_TRY(launch_ss_forecast(e->stream, S, horizon, dnx.ptr, e->dpos_forecast.ptr, dout.ptr));
   HIP_TRY(hipMemcpyAsync(out, dout.ptr, C * h * 8, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return BA_OK;

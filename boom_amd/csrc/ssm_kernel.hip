@@ -594,6 +594,74 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   }
 }
 
+// StateSpaceRegressionModel::simulate_forecast for every chain's current draw of the
+// structural model (StateSpaceRegressionModel.cpp:216-219, :256-278): the state
+// advances by T state + state errors (trend, then seasonal), the observation is
+// rnorm(Z'state, sigma_obs) + x'beta; normals in the reference's order on the
+// chain's forecast stream (id 5).  One wavefront per chain, lane = state component
+// (logical order; the horizon is short, the seasonal block simply shifts).
+__global__ __launch_bounds__(64) void ssm_forecast_kernel(SsParams P, int horizon, const double *newX,
+                                                          uint64_t *pos_forecast, double *out) {
+  const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x;
+  if ((int)blockIdx.x >= P.chain_count) return;
+  if (P.status[chain] != CHAIN_OK) return;
+  const SsmParams &Q = P.ssm;
+  const int T = P.T, p = P.p, m = Q.m, trend = Q.trend, s0 = Q.s0;
+  const int ns = Q.nseasons > 0 ? Q.nseasons - 1 : 0;
+  const double *beta = P.beta + (size_t)chain * p;
+  const double sd_obs = sqrt(P.sigsq[chain]);
+  const double sd0 = sqrt(Q.var_sigsq[(size_t)chain * 3 + 0]), sd1 = sqrt(Q.var_sigsq[(size_t)chain * 3 + 1]),
+               sd2 = sqrt(Q.var_sigsq[(size_t)chain * 3 + 2]);
+  const double *gst = Q.work + (size_t)chain * Q.work_stride + (size_t)m * T;
+  double st = (lane < m) ? gst[(size_t)(T - 1) * m + lane] : 0.0;
+  const bool seas = ns > 0 && lane >= s0 && lane < s0 + ns;
+  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 5u}, pos_forecast[chain]};
+  for (int i = 0; i < horizon; ++i) {
+    // state errors, in the reference's order
+    double e0, e1 = 0.0, e2 = 0.0;
+    if (trend == 1) {
+      e0 = d_rnorm(rng, 0.0, sd0);
+    } else {
+      const double z0 = d_rnorm(rng, 0.0, 1.0), z1 = d_rnorm(rng, 0.0, 1.0);
+      e0 = sd0 * z0 + 0.0;
+      e1 = sd1 * z1 + 0.0;
+    }
+    if (ns > 0) e2 = d_rnorm(rng, 0.0, sd2);
+    // T state
+    double nx = st;
+    if (trend == 2) { const double x1 = rl(st, 1); if (lane == 0) nx = st + x1; }
+    if (ns > 0) {
+      // (first = 0 - s_0 - s_1 - ..., SeasonalStateSpaceMatrix::multiply)
+      double first = 0.0;
+      for (int q = 0; q < ns; ++q) first -= rl(st, s0 + q);
+      const double prev = sdpp<0x111, 0xf>(st, 0.0);
+      if (lane == s0) nx = first; else if (seas) nx = prev;
+    }
+    st = nx + ((lane == 0) ? e0 : ((trend == 2 && lane == 1) ? e1 : ((ns > 0 && lane == s0) ? e2 : 0.0)));
+    if (lane >= m) st = 0.0;
+    double zs = rl(st, 0);
+    if (ns > 0) zs += rl(st, s0);
+    const double obs = d_rnorm(rng, zs, sd_obs);
+    double part = 0.0;
+    for (int j = lane; j < p; j += WAVE) part += newX[(size_t)j * horizon + i] * beta[j];
+    // (sum over the wave: 64 lanes)
+    part += sdpp<0x111, 0xf>(part, 0.0);
+    part += sdpp<0x112, 0xf>(part, 0.0);
+    part += sdpp<0x114, 0xf>(part, 0.0);
+    part += sdpp<0x118, 0xf>(part, 0.0);
+    const double pred = rl(part, 15) + rl(part, 31) + rl(part, 47) + rl(part, 63);
+    if (lane == 0) out[(size_t)chain * horizon + i] = obs + pred;
+  }
+  if (lane == 0) pos_forecast[chain] = rng.pos;
+}
+
+hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
+                               uint64_t *pos_forecast, double *out) {
+  hipLaunchKernelGGL(ssm_forecast_kernel, dim3(P.chain_count), dim3(WAVE), 0, stream, P, horizon, newX,
+                     pos_forecast, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
                            const double *B, int64_t ldb, int N, int K, double *C, int ldc);
 

@@ -368,7 +368,8 @@ int ba_ss_impute_state(ba_engine *e);
  * every saved draw): one draw from the predictive distribution of the next
  * `horizon` observations for EVERY chain's current parameters and final state.
  * newX is horizon x p column-major (host); out is chains x horizon (host),
- * row-major.  Each call continues the chains' forecast streams. */
+ * row-major.  Each call continues the chains' forecast streams.  Works for the
+ * local level model and for the structural (trend + seasonal) one. */
 int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *out);
 /* state(): T doubles of one chain; level sigsq; level suf (n, sumsq) */
 int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,

@@ -2534,6 +2534,43 @@ int bo_ssm_draw(bo_ssm *m) {
   return bo_ssm_impute_state(m, &m->state_rng);
 }
 
+/* StateSpaceRegressionModel::simulate_forecast for the structural model
+ * (StateSpaceRegressionModel.cpp:216-219, :256-278; simulate_next_state
+ * StateSpaceModelBase.cpp:439-443): newX horizon x p column-major, final_state the
+ * state at the last time point (m values), sigsq = (level, slope, seasonal) */
+void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,
+                              const double *beta, double sigsq_obs, int trend, int nseasons,
+                              const double *sigsq, const double *final_state, double *out) {
+  bo_ssm M;
+  memset(&M, 0, sizeof(M));
+  M.dtrend = trend;
+  M.nseasons = nseasons;
+  M.s0 = nseasons > 0 ? trend : -1;
+  M.m = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  double st[BO_SSM_MAX];
+  for (int i = 0; i < M.m; ++i) st[i] = final_state[i];
+  const double sd_level = sqrt(sigsq[0]), sd_slope = sqrt(sigsq[1]), sd_seas = sqrt(sigsq[2]);
+  const double sd_obs = sqrt(sigsq_obs);
+  for (int i = 0; i < horizon; ++i) {
+    double eta[BO_SSM_MAX];
+    for (int k = 0; k < M.m; ++k) eta[k] = 0;
+    if (trend == 1) {
+      eta[0] = bo_rnorm(rng, 0, sd_level);
+    } else {
+      double z0 = bo_rnorm(rng, 0, 1), z1 = bo_rnorm(rng, 0, 1);
+      eta[0] = sd_level * z0 + 0.0;
+      eta[1] = sd_slope * z1 + 0.0;
+    }
+    if (M.s0 >= 0) eta[M.s0] = bo_rnorm(rng, 0, sd_seas);
+    ssm_T(&M, st);
+    for (int k = 0; k < M.m; ++k) st[k] += eta[k];
+    double ans = bo_rnorm(rng, ssm_Zdot(&M, st), sd_obs);
+    double pred = 0;
+    for (int j = 0; j < p; ++j) pred += newX[IDX(i, j, horizon)] * beta[j];
+    out[i] = ans + pred;
+  }
+}
+
 /* ====================================================================== *
  * BinomialProbitSpikeSlabSampler (the probit member):
  * data augmentation with truncated normals, then SpikeSlabSampler (bo_sss) on

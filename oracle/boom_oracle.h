@@ -230,6 +230,9 @@ void bo_ssm_set_variances(bo_ssm *m, const double *sigsq);
 void bo_ssm_get_suf(const bo_ssm *m, double *n, double *ss);
 int bo_ssm_impute_state(bo_ssm *m, bo_rng *rng);
 int bo_ssm_draw(bo_ssm *m);
+void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,
+                              const double *beta, double sigsq_obs, int trend, int nseasons,
+                              const double *sigsq, const double *final_state, double *out);
 
 /* BinomialProbitSpikeSlabSampler (probit): truncated-normal
  * data augmentation + SpikeSlabSampler on X'NX (fixed) and X'z.  X is n x p

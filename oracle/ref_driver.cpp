@@ -675,6 +675,52 @@ int ref_ss_forecast(int T, int p, const double *y, const double *X,
   REF_CATCH
 }
 
+// simulate_forecast of the structural model: fixed parameters and final state
+int ref_ssm_forecast(int T, int p, const double *y, const double *X, const double *beta,
+                     const uint8_t *gamma, double sigsq_obs, int trend, int nseasons,
+                     const double *sigsq, const double *final_state, int horizon,
+                     const double *newX, uint64_t seed, double *out) {
+  REF_TRY
+  NEW(StateSpaceRegressionModel, model)(make_vector(T, y), make_matrix(T, p, X),
+                                        std::vector<bool>());
+  RegressionModel *reg = model->observation_model();
+  reg->coef().drop_all();
+  Vector b(p, 0.0);
+  for (int j = 0; j < p; ++j) {
+    if (gamma[j]) {
+      reg->coef().add(j);
+      b[j] = beta[j];
+    }
+  }
+  reg->coef().set_Beta(b);
+  reg->set_sigsq(sigsq_obs);
+  if (trend == 1) {
+    NEW(LocalLevelStateModel, level)(std::sqrt(sigsq[0]));
+    model->add_state(level);
+  } else {
+    NEW(LocalLinearTrendStateModel, llt)();
+    SpdMatrix Sigma(2, 0.0);
+    Sigma(0, 0) = sigsq[0];
+    Sigma(1, 1) = sigsq[1];
+    llt->set_Sigma(Sigma);
+    model->add_state(llt);
+  }
+  if (nseasons > 0) {
+    NEW(SeasonalStateModel, seasonal)(nseasons, 1);
+    seasonal->set_sigsq(sigsq[2]);
+    seasonal->set_initial_state_mean(Vector(nseasons - 1, 0.0));
+    seasonal->set_initial_state_variance(SpdMatrix(nseasons - 1, 1.0));
+    model->add_state(seasonal);
+  }
+  const int m = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  RNG rng(seed);
+  Vector fs(m);
+  for (int i = 0; i < m; ++i) fs[i] = final_state[i];
+  Vector ans = model->simulate_forecast(rng, make_matrix(horizon, p, newX), fs);
+  for (int i = 0; i < horizon; ++i) out[i] = ans[i];
+  REF_CATCH
+}
+
 // ------------------------------------------- SpikeSlabSampler (sigma given)
 // The sigma^2-conditional SSVS helper used by the logit / probit / Poisson /
 // Student samplers (SpikeSlabSampler.cpp:40-82, 115-138, 171-216), driven the

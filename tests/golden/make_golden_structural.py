@@ -43,6 +43,24 @@ def main():
              gamma=o["gamma"], beta=o["beta"], sigsq=o["sigsq"], variances=o["variances"],
              state=o["state"].astype(np.float64), **prior_kw(prior), **opts_kw(opts))
 
+    # simulate_forecast with fixed parameters and final state
+    h = 40
+    fc = {}
+    for trend, ns in ((2, 0), (1, 7), (2, 12)):
+        X, y, _, _ = structural_data(80, p, 2, ns, seed=3)
+        newX = np.random.Generator(np.random.PCG64(3)).standard_normal((h, p))
+        m = trend + max(ns - 1, 0)
+        beta = np.array([3.0, 0.0, 0.5, 0.0, 0.0, 0.0])
+        fs = np.random.Generator(np.random.PCG64(4)).standard_normal(m)
+        sig = np.array([0.2, 0.05, 0.1])
+        out = R.ssm_forecast(y, X, beta, (beta != 0).astype(np.uint8), 0.04, trend, ns, sig, fs,
+                             newX, 99)
+        key = "t%d_s%d" % (trend, ns)
+        fc[key + "_final_state"] = fs
+        fc[key + "_forecast"] = out
+    save("kat_structural_forecast", seed=99, newX=newX, beta=beta, sigsq_obs=0.04, sigsq=sig,
+         shapes=np.array([(2, 0), (1, 7), (2, 12)]), **fc)
+
 
 if __name__ == "__main__":
     main()

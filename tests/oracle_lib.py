@@ -683,6 +683,17 @@ class Oracle:
         self.lib.bo_logit_destroy(m)
         return dict(gamma=gam, beta=beta, status=status, xtx=xtx, xty=xty)
 
+    def ssm_forecast(self, rng, newX, beta, sigsq_obs, trend, nseasons, sigsq, final_state):
+        h, p = newX.shape
+        out = np.zeros(h)
+        self.lib.bo_ssm_simulate_forecast.argtypes = [
+            C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.c_double, C.c_int, C.c_int,
+            c_double_p, c_double_p, c_double_p]
+        self.lib.bo_ssm_simulate_forecast(C.byref(rng), h, p, _dp(fcol(newX)), _dp(f64(beta)),
+                                          float(sigsq_obs), int(trend), int(nseasons),
+                                          _dp(f64(sigsq)), _dp(f64(final_state)), _dp(out))
+        return out
+
     def ssm_run(self, y, X, observed, prior, opts, spec, rng_setup, init_gamma,
                 nsweeps):
         """structural model (f2): spec = structural_spec(...)"""
@@ -1058,6 +1069,18 @@ class Ref:
             int(clt_threshold), C.c_uint64(seed), _u8(g0), _dp(f64(init_beta)), nsweeps,
             _u8(gam), _dp(beta)))
         return dict(gamma=gam, beta=beta)
+
+    def ssm_forecast(self, y, X, beta, gamma, sigsq_obs, trend, nseasons, sigsq, final_state,
+                     newX, seed):
+        T, p = X.shape
+        h = newX.shape[0]
+        out = np.zeros(h)
+        g = np.ascontiguousarray(gamma, dtype=np.uint8)
+        self._check(self.lib.ref_ssm_forecast(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _dp(f64(beta)), _u8(g), C.c_double(sigsq_obs),
+            int(trend), int(nseasons), _dp(f64(sigsq)), _dp(f64(final_state)), h,
+            _dp(fcol(newX)), C.c_uint64(seed), _dp(out)))
+        return out
 
     def ssm_run(self, y, X, observed, prior, opts, spec, seed, init_gamma, nsweeps):
         T, p = X.shape

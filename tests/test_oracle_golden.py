@@ -286,6 +286,16 @@ def test_structural_sweeps_match_reference(oracle, name):
     assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
 
 
+def test_structural_forecast_known_answers(oracle):
+    g = load("kat_structural_forecast")
+    for trend, ns in g["shapes"]:
+        key = "t%d_s%d" % (trend, ns)
+        got = oracle.ssm_forecast(oracle.rng_mt(int(g["seed"])), g["newX"], g["beta"],
+                                  float(g["sigsq_obs"]), int(trend), int(ns), g["sigsq"],
+                                  g[key + "_final_state"])
+        assert np.max(np.abs(got - g[key + "_forecast"])) < 1e-12, key
+
+
 # ------------------------------------------------------------------ probit
 def test_truncated_normal_known_answers(oracle):
     """rtrun_norm_mt: rejection from the normal (cut below the mean) and the

@@ -91,3 +91,31 @@ def test_structural_many_sweeps_in_one_call_and_shapes(oracle):
     fitted = st["state"][:, 0] + st["state"][:, 2] + X @ ba_[0]
     assert np.sqrt(np.mean((fitted - y) ** 2)) < 0.5
     assert np.all(st["variances"] > 0) and np.all(st["suf_n"] == T - 1)
+
+
+@pytest.mark.parametrize("trend,nseasons", [(1, 0), (2, 0), (1, 7), (2, 12)])
+def test_structural_forecast_matches_oracle(oracle, trend, nseasons):
+    """simulate_forecast for every chain's current draw: the state advances by its
+    transition plus state errors, the observation adds noise and x'beta; normals in
+    the reference's order on the chain's forecast stream"""
+    T, p, chains, seed, h = 150, 6, 5, 23, 30
+    X, y, _, obs = structural_data(T, p, 2, nseasons, seed=3 + nseasons)
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    spec = structural_spec(y, trend, nseasons)
+    g0 = np.zeros(p, np.uint8)
+    eng = make_engine(chains, seed, y, X, obs, prior, spec, sig_up, g0)
+    eng.ss_sweep(15)
+    newX = np.random.Generator(np.random.PCG64(8)).standard_normal((h, p))
+    f1 = eng.ss_forecast(newX)
+    f2 = eng.ss_forecast(newX)          # the streams continue: a second, different draw
+    gam, beta, sig = eng.get_states()
+    assert f1.shape == (chains, h) and not np.array_equal(f1, f2)
+    for c in range(chains):
+        st = eng.ss_get_structural(c)
+        rng = oracle.rng_philox(seed, chain=c, stream=5)
+        want1 = oracle.ssm_forecast(rng, newX, beta[c], sig[c], trend, nseasons, st["variances"],
+                                    st["state"][-1])
+        want2 = oracle.ssm_forecast(rng, newX, beta[c], sig[c], trend, nseasons, st["variances"],
+                                    st["state"][-1])
+        assert np.max(np.abs(f1[c] - want1)) < 1e-9 * np.abs(want1).max()
+        assert np.max(np.abs(f2[c] - want2)) < 1e-9 * np.abs(want2).max()
