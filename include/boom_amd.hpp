@@ -320,6 +320,42 @@ class LocalLevelStateModel {
   double sigma_, a0_ = 0.0, P0_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
 };
 
+// LocalLinearTrendStateModel with one ZeroMeanMvnIndependenceSampler per variance
+// (StateModels/LocalLinearTrend.cpp; the way bsts' AddLocalLinearTrend builds it)
+class LocalLinearTrendStateModel {
+ public:
+  LocalLinearTrendStateModel() {}
+  void set_initial_state_mean(const Vector &m) { a0_ = m; }
+  void set_initial_state_variance(const Vector &diagonal) { P0_ = diagonal; }
+  void set_initial_sigma(double level_sigma, double slope_sigma) { sigma_[0] = level_sigma; sigma_[1] = slope_sigma; }
+  // ZeroMeanMvnIndependenceSampler(model, df, sigma_guess, which_variable) + set_sigma_upper_limit
+  void set_prior(int which_variable, double df, double sigma_guess, double sigma_upper_limit = infinity()) {
+    df_[which_variable] = df; guess_[which_variable] = sigma_guess; upper_[which_variable] = sigma_upper_limit;
+  }
+  Vector a0_ = Vector(2, 0.0), P0_ = Vector(2, 1.0);
+  double sigma_[2] = {1.0, 1.0}, df_[2] = {1.0, 1.0}, guess_[2] = {1.0, 1.0}, upper_[2] = {infinity(), infinity()};
+};
+// SeasonalStateModel(nseasons, season_duration = 1) with a ZeroMeanGaussianConjSampler
+class SeasonalStateModel {
+ public:
+  explicit SeasonalStateModel(int nseasons, int season_duration = 1) : nseasons_(nseasons) {
+    if (nseasons <= 0) report_error("'nseasons' must be positive in constructor for SeasonalStateModelBase");
+    if (season_duration != 1) report_error("season durations other than 1 are not implemented on the device");
+    a0_ = Vector(nseasons - 1, 0.0);
+    P0_ = Vector(nseasons - 1, 1.0);
+  }
+  int state_dimension() const { return nseasons_ - 1; }
+  void set_sigsq(double s) { sigma_ = std::sqrt(s); }
+  void set_initial_state_mean(const Vector &m) { a0_ = m; }
+  void set_initial_state_variance(double v) { P0_ = Vector(nseasons_ - 1, v); }
+  void set_prior(double df, double sigma_guess, double sigma_upper_limit = infinity()) {
+    df_ = df; guess_ = sigma_guess; upper_ = sigma_upper_limit;
+  }
+  int nseasons_;
+  Vector a0_, P0_;
+  double sigma_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
+};
+
 class StateSpaceRegressionModel : public Model {
  public:
   StateSpaceRegressionModel(const Vector &y, const Matrix &X, const std::vector<bool> &observed,
@@ -334,10 +370,55 @@ class StateSpaceRegressionModel : public Model {
     level_ = s;
     eng_->check(ba_ss_set_local_level(eng_->get(), s->df_, s->guess_, s->upper_, s->a0_, s->P0_, s->sigma_));
   }
+  // trend + seasonal state: add_state in the reference's order (trend first);
+  // the structure goes to the device when the sampler is attached or at the
+  // first draw (finalize_state)
+  void add_state(const Ptr<LocalLinearTrendStateModel> &s) { trend_ = s; structural_ = true; }
+  void add_state(const Ptr<SeasonalStateModel> &s) { seasonal_ = s; structural_ = true; }
+  bool structural() const { return structural_; }
+  int state_dimension() const {
+    return (trend_ ? 2 : 1) + (seasonal_ ? seasonal_->state_dimension() : 0);
+  }
+  void finalize_state() {
+    if (!structural_ || finalized_) return;
+    if (!trend_ && !level_) report_error("a structural model needs a trend state model (local level or local linear trend) first");
+    const int tr = trend_ ? 2 : 1, ns = seasonal_ ? seasonal_->nseasons_ : 0, m = state_dimension();
+    double df[3] = {1, 1, 1}, guess[3] = {1, 1, 1}, upper[3] = {infinity(), infinity(), infinity()}, init[3] = {1, 1, 1};
+    Vector a0(m, 0.0), P0(m, 1.0);
+    if (trend_) {
+      for (int i = 0; i < 2; ++i) {
+        df[i] = trend_->df_[i]; guess[i] = trend_->guess_[i]; upper[i] = trend_->upper_[i]; init[i] = trend_->sigma_[i];
+        a0[i] = trend_->a0_[i]; P0[i] = trend_->P0_[i];
+      }
+    } else {
+      df[0] = level_->df_; guess[0] = level_->guess_; upper[0] = level_->upper_; init[0] = level_->sigma_;
+      a0[0] = level_->a0_; P0[0] = level_->P0_;
+    }
+    if (seasonal_) {
+      df[2] = seasonal_->df_; guess[2] = seasonal_->guess_; upper[2] = seasonal_->upper_; init[2] = seasonal_->sigma_;
+      for (int i = 0; i < ns - 1; ++i) { a0[tr + i] = seasonal_->a0_[i]; P0[tr + i] = seasonal_->P0_[i]; }
+    }
+    eng_->check(ba_ss_set_structural(eng_->get(), tr, ns, df, guess, upper, init, a0.data(), P0.data()));
+    finalized_ = true;
+  }
+  // the state draw, component `which` (0 = level / trend level, ...) of one chain
+  Matrix structural_state(int chain = 0) const {
+    const int m = state_dimension();
+    Vector buf((size_t)T_ * m);
+    eng_->check(ba_ss_get_structural(eng_->get(), chain, buf.data(), nullptr, nullptr, nullptr));
+    Matrix st(m, T_);
+    for (int t = 0; t < T_; ++t) for (int i = 0; i < m; ++i) st(i, t) = buf[(size_t)t * m + i];
+    return st;
+  }
+  Vector state_variances(int chain = 0) const {   // level, slope, seasonal
+    Vector v(3);
+    eng_->check(ba_ss_get_structural(eng_->get(), chain, nullptr, v.data(), nullptr, nullptr));
+    return v;
+  }
   int time_dimension() const { return T_; }
   int xdim() const { return p_; }
   const Ptr<Engine> &engine() const { return eng_; }
-  const LocalLevelStateModel *level() const { return level_.get(); }
+  const LocalLevelStateModel *level() const { return structural_ ? nullptr : level_.get(); }
   Vector state(int chain = 0) const {
     Vector st(T_);
     eng_->check(ba_ss_get_state(eng_->get(), chain, st.data(), nullptr, nullptr, nullptr));
@@ -352,6 +433,9 @@ class StateSpaceRegressionModel : public Model {
   Ptr<Engine> eng_;
   int T_, p_;
   Ptr<LocalLevelStateModel> level_;
+  Ptr<LocalLinearTrendStateModel> trend_;
+  Ptr<SeasonalStateModel> seasonal_;
+  bool structural_ = false, finalized_ = false;
 };
 
 // regression priors are set through the same three pieces as BregVsSampler
@@ -370,6 +454,7 @@ class StateSpacePosteriorSampler : public PosteriorSampler {
     model->engine()->check(ba_set_state(h, -1, g0.data(), nullptr, 1.0));
   }
   void draw() override {                     // StateSpacePosteriorSampler.cpp:42-64
+    model_->finalize_state();
     model_->engine()->check(ba_ss_sweep(model_->engine()->get(), 1));
     model_->engine()->check(ba_sync(model_->engine()->get()));
   }
@@ -395,6 +480,114 @@ class StateSpacePosteriorSampler : public PosteriorSampler {
   }
  private:
   StateSpaceRegressionModel *model_;
+};
+
+// ---- binomial probit / logit spike and slab -----------------------------------------
+struct MvnModel {   // a slab whose precision does not scale with sigma^2 (MvnBase)
+  MvnModel(const Vector &mean, const SpdMatrix &precision) : mu_(mean), siginv_(precision) {}
+  const Vector &mu() const { return mu_; }
+  const SpdMatrix &siginv() const { return siginv_; }
+  int dim() const { return (int)mu_.size(); }
+  Vector mu_;
+  SpdMatrix siginv_;
+};
+
+// BinomialLogitModel / BinomialProbitModel(X, y, n): the coefficients live in
+// coef() = (inc(), Beta()); many chains on the device, chain 0 backs the model
+class BinomialRegressionModelBase : public Model {
+ public:
+  BinomialRegressionModelBase(const Matrix &X, const Vector &y, const Vector &n, bool logit,
+                              int clt_threshold, int chains, uint64_t seed, int device)
+      : eng_(new Engine(chains, seed, device)), p_(X.ncol()), logit_(logit), inc_(X.ncol(), true),
+        beta_(X.ncol(), 0.0) {
+    if (X.nrow() != (int)y.size() || y.size() != n.size())
+      report_error("X, y and n are incompatible in the binomial regression model's constructor.");
+    eng_->check(logit ? ba_logit_set_data(eng_->get(), X.nrow(), X.ncol(), X.data(), y.data(), n.data(), clt_threshold)
+                      : ba_probit_set_data(eng_->get(), X.nrow(), X.ncol(), X.data(), y.data(), n.data(), clt_threshold));
+  }
+  int xdim() const { return p_; }
+  bool logit() const { return logit_; }
+  const Selector &inc() const { return inc_; }
+  void drop_all() { inc_.drop_all(); dirty_ = true; }
+  void add(int i) { inc_.add(i); dirty_ = true; }
+  void drop(int i) { inc_.drop(i); dirty_ = true; }
+  const Vector &Beta() const { return beta_; }
+  void set_Beta(const Vector &b) { beta_ = b; dirty_ = true; }
+  bool dirty() const { return dirty_; }
+  const Ptr<Engine> &engine() const { return eng_; }
+  void push_state() {
+    eng_->check(ba_set_state(eng_->get(), -1, inc_.bytes().data(), beta_.data(), 1.0));
+    dirty_ = false;
+  }
+  void pull_chain0() {
+    eng_->check(ba_get_state(eng_->get(), 0, inc_.bytes().data(), beta_.data(), nullptr));
+    dirty_ = false;
+  }
+  void chain_states(std::vector<uint8_t> &gamma, Vector &beta) const {
+    const size_t C = eng_->chains();
+    gamma.resize(C * p_); beta.resize(C * p_);
+    eng_->check(ba_get_states(eng_->get(), gamma.data(), beta.data(), nullptr));
+  }
+ private:
+  Ptr<Engine> eng_;
+  int p_;
+  bool logit_;
+  Selector inc_;
+  Vector beta_;
+  bool dirty_ = true;
+};
+class BinomialLogitModel : public BinomialRegressionModelBase {
+ public:
+  BinomialLogitModel(const Matrix &X, const Vector &y, const Vector &n, int clt_threshold = 5,
+                     int chains = 1, uint64_t seed = 8675309, int device = 0)
+      : BinomialRegressionModelBase(X, y, n, true, clt_threshold, chains, seed, device) {}
+};
+class BinomialProbitModel : public BinomialRegressionModelBase {
+ public:
+  BinomialProbitModel(const Matrix &X, const Vector &y, const Vector &n, int clt_threshold = 5,
+                      int chains = 1, uint64_t seed = 8675309, int device = 0)
+      : BinomialRegressionModelBase(X, y, n, false, clt_threshold, chains, seed, device) {}
+};
+
+// BinomialLogitSpikeSlabSampler / BinomialProbitSpikeSlabSampler(model, slab, spike, clt_threshold)
+class BinomialSpikeSlabSamplerBase : public PosteriorSampler {
+ public:
+  BinomialSpikeSlabSamplerBase(BinomialRegressionModelBase *model, const Ptr<MvnModel> &slab,
+                               const Ptr<VariableSelectionPrior> &spike)
+      : model_(model), slab_(slab) {
+    if (slab->dim() != model->xdim()) report_error("Slab does not match model dimension.");
+    if ((int)spike->potential_nvars() != model->xdim()) report_error("Spike does not match model dimension.");
+    check(ba_sss_set_slab(h(), slab->mu().data(), slab->siginv().data(), 0, -1));
+    check(ba_set_spike(h(), spike->prior_inclusion_probabilities().data(), spike->max_model_size()));
+  }
+  void draw() override {
+    if (model_->dirty()) model_->push_state();
+    check(model_->logit() ? ba_logit_sweep(h(), 1) : ba_probit_sweep(h(), 1));
+    check(ba_sync(h()));
+    model_->pull_chain0();
+  }
+  double logpri() const override { report_error("logpri() is not implemented for the binomial samplers"); return 0; }
+  void set_seed(unsigned long s) override { check(ba_seed(h(), s)); }
+  void limit_model_selection(int max_flips) {
+    check(ba_sss_set_slab(h(), slab_->mu().data(), slab_->siginv().data(), 0, max_flips));
+  }
+ private:
+  ba_engine *h() const { return model_->engine()->get(); }
+  void check(int rc) const { model_->engine()->check(rc); }
+  BinomialRegressionModelBase *model_;
+  Ptr<MvnModel> slab_;
+};
+class BinomialLogitSpikeSlabSampler : public BinomialSpikeSlabSamplerBase {
+ public:
+  BinomialLogitSpikeSlabSampler(BinomialLogitModel *model, const Ptr<MvnModel> &slab,
+                                const Ptr<VariableSelectionPrior> &spike)
+      : BinomialSpikeSlabSamplerBase(model, slab, spike) {}
+};
+class BinomialProbitSpikeSlabSampler : public BinomialSpikeSlabSamplerBase {
+ public:
+  BinomialProbitSpikeSlabSampler(BinomialProbitModel *model, const Ptr<MvnModel> &slab,
+                                 const Ptr<VariableSelectionPrior> &spike)
+      : BinomialSpikeSlabSamplerBase(model, slab, spike) {}
 };
 
 }  // namespace boom_amd_api

@@ -229,6 +229,96 @@ static void StateSpace() {
   EXPECT(model.level_sigsq(3) > 0.01 && model.level_sigsq(3) < 1.0);
 }
 
+// bsts' standard model: regression + local linear trend + seasonal state
+static void StructuralTimeSeries() {
+  const int T = 420, p = 3, chains = 8, S = 7;
+  std::mt19937_64 gen(11);
+  std::normal_distribution<double> N(0, 1);
+  Matrix X(T, p);
+  Vector y(T), coef = {4.0, 0.0, -3.0};
+  double pattern[S] = {1.5, -0.5, 0.3, -1.2, 0.8, -0.6, -0.3};
+  double level = 0, slope = 0.03;
+  for (int t = 0; t < T; ++t) {
+    slope += 0.002 * N(gen);
+    level += slope + 0.05 * N(gen);
+    double mu = level + pattern[t % S];
+    for (int j = 0; j < p; ++j) { X(t, j) = N(gen); mu += X(t, j) * coef[j]; }
+    y[t] = mu + 0.2 * N(gen);
+  }
+  StateSpaceRegressionModel model(y, X, std::vector<bool>(), chains, 3);
+  Ptr<LocalLinearTrendStateModel> trend(new LocalLinearTrendStateModel);
+  trend->set_initial_state_mean(Vector{y[0], 0.0});
+  trend->set_initial_state_variance(Vector{4.0, 1.0});
+  trend->set_initial_sigma(0.5, 0.1);
+  trend->set_prior(0, 1.0, 0.1);
+  trend->set_prior(1, 1.0, 0.01);
+  model.add_state(trend);
+  Ptr<SeasonalStateModel> seasonal(new SeasonalStateModel(S));
+  seasonal->set_sigsq(0.01);
+  seasonal->set_initial_state_variance(4.0);
+  seasonal->set_prior(1.0, 0.05);
+  model.add_state(seasonal);
+  EXPECT(model.state_dimension() == 2 + S - 1);
+  SpdMatrix om(p, p, 0.0);
+  for (int j = 0; j < p; ++j) om(j, j) = 0.01;
+  Ptr<MvnGivenScalarSigma> slab(new MvnGivenScalarSigma(Vector(p, 0.0), om));
+  Ptr<ChisqModel> siginv(new ChisqModel(1.0, 0.5));
+  Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(p, 0.5));
+  Ptr<StateSpacePosteriorSampler> sampler(new StateSpacePosteriorSampler(&model, slab, siginv, spike));
+  model.set_method(sampler);
+  for (int i = 0; i < 150; ++i) model.sample_posterior();
+  Matrix st = model.structural_state(5);
+  EXPECT(st.nrow() == 2 + S - 1 && st.ncol() == T);
+  // trend level + current seasonal effect track y - X coef
+  double err = 0;
+  for (int t = 0; t < T; ++t) {
+    double target = y[t];
+    for (int j = 0; j < p; ++j) target -= X(t, j) * coef[j];
+    err += std::fabs(st(0, t) + st(2, t) - target);
+  }
+  EXPECT(err / T < 0.5);
+  Vector v = model.state_variances(5);
+  EXPECT(v[0] > 0 && v[1] > 0 && v[2] > 0 && v[1] < v[0] + 1.0);
+}
+
+// the logit / probit spike-and-slab samplers in the reference's shape:
+// model.set_method(new BinomialLogitSpikeSlabSampler(&model, slab, spike))
+template <class MODEL, class SAMPLER>
+static void BinomialSpikeSlab(bool logit) {
+  const int n = 3000, p = 12, chains = 16;
+  std::mt19937_64 gen(5);
+  std::normal_distribution<double> N(0, 1);
+  std::uniform_real_distribution<double> U(0, 1);
+  Matrix X(n, p);
+  Vector y(n), nt(n, 1.0), coef(p, 0.0);
+  coef[0] = 0.3; coef[1] = 1.4; coef[2] = -1.1;
+  for (int i = 0; i < n; ++i) {
+    double eta = 0;
+    for (int j = 0; j < p; ++j) { X(i, j) = j == 0 ? 1.0 : N(gen); eta += X(i, j) * coef[j]; }
+    const double pr = logit ? 1 / (1 + std::exp(-eta)) : 0.5 * std::erfc(-eta / std::sqrt(2.0));
+    y[i] = U(gen) < pr ? 1.0 : 0.0;
+  }
+  MODEL model(X, y, nt, 5, chains, 9);
+  SpdMatrix prec(p, p, 0.0);
+  for (int j = 0; j < p; ++j) prec(j, j) = 0.5;
+  Ptr<MvnModel> slab(new MvnModel(Vector(p, 0.0), prec));
+  Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(p, 3.0 / p));
+  Ptr<SAMPLER> sampler(new SAMPLER(&model, slab, spike));
+  model.set_method(sampler);
+  model.drop_all();
+  model.add(0);
+  Vector inclusion(p, 0.0), mean(p, 0.0);
+  const int burn = 60, niter = 140;
+  for (int i = 0; i < burn + niter; ++i) {
+    model.sample_posterior();
+    if (i >= burn)
+      for (int j = 0; j < p; ++j) { inclusion[j] += model.inc()[j] / (double)niter; mean[j] += model.Beta()[j] / niter; }
+  }
+  EXPECT(inclusion[1] > 0.95 && inclusion[2] > 0.95);
+  for (int j = 3; j < p; ++j) EXPECT(inclusion[j] < 0.5);
+  EXPECT(std::fabs(mean[1] - coef[1]) < 0.25 && std::fabs(mean[2] - coef[2]) < 0.25);
+}
+
 // The reference's callers draw once per iteration and record the model's
 // parameters; with a look-ahead the sampler runs many sweeps per launch and
 // serves them one by one: the recorded sequence must be the same.
@@ -323,6 +413,9 @@ int main() {
     PerfectCollinearity();
     ErrorConventions();
     StateSpace();
+    StructuralTimeSeries();
+    BinomialSpikeSlab<BinomialLogitModel, BinomialLogitSpikeSlabSampler>(true);
+    BinomialSpikeSlab<BinomialProbitModel, BinomialProbitSpikeSlabSampler>(false);
   } catch (std::exception &e) {
     std::printf("EXCEPTION: %s\n", e.what());
     return 2;
