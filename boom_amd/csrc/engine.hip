@@ -632,7 +632,6 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
     if (e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
     if (e->kcap >= cap_limit(*e)) {
       if (e->cur_mode == 2) return BA_OK;  // (the adaptive kernel stops at 64 variables: stays an error)
-      if (e->logit_mode) return BA_OK;     // (per-chain V is only in the LDS kernel: stays an error)
       // beyond the LDS kernel: the parked chains go to the HBM-resident one
       int stuck = 0;
       int rc = grow_big(e, &stuck);

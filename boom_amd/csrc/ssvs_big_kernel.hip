@@ -602,7 +602,8 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   bx.bst = to_lds<double>(smem + lay.bst);
   bx.gst = to_lds<uint16_t>(smem + lay.gst);
   BigP BP;
-  BP.V = P.V; BP.A = P.A; BP.b = P.b; BP.l1 = P.l1; BP.l0 = P.l0;
+  BP.V = P.V + (size_t)chain * (size_t)P.v_chain_stride;   // (the logit sampler: every chain has its own V)
+  BP.A = P.A; BP.b = P.b; BP.l1 = P.l1; BP.l0 = P.l0;
   BP.max_model_size = P.max_model_size;
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
   const double yty = P.yty[(size_t)chain * P.suf_stride];
@@ -751,8 +752,19 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         if (phase == PH_SHUFFLED) {
           StampCtx sx;
           sx.last = 0;
-          if (p > 1) parallel_shuffle(ch, sx);
-          flip_pos = pos + (uint64_t)(p > 0 ? p - 1 : 0);
+          if (P.mode == 2) {
+            // BinomialLogitSpikeSlabSampler's shuffle (see ssvs_kernel.hip): the steps run in order
+            if (lane == 0 && p > 1) {
+              for (int i = 0; i < p; ++i) {
+                const int j = ch.oth[i];
+                const uint16_t a = ch.perm[i];
+                ch.perm[i] = ch.perm[j];
+                ch.perm[j] = a;
+              }
+            }
+            wave_sync();
+          } else if (p > 1) parallel_shuffle(ch, sx);
+          flip_pos = pos + (uint64_t)(P.mode == 2 ? p : (p > 0 ? p - 1 : 0));
           pos = flip_pos + (uint64_t)nflips;
           i0 = 0;
           phase = PH_FLIPS;
@@ -967,7 +979,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     if (cmd == BCMD_EXIT) break;
     if (cmd == BCMD_UNIF) {
       const uint64_t upos = ((AS_LDS const uint64_t *)(ctl + CT_POS))[0];
-      if (p > 1) shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth);
+      if (p > 1) shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth, P.mode == 2);
     } else if (cmd == BCMD_EVAL) {
       Model Me;
       Me.logp = ctl[CT_LOGP]; Me.lp = ctl[CT_LP]; Me.ldv = ctl[CT_LDV];

@@ -267,7 +267,7 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps);
  * (BinomialLogitSpikeSlabSampler.cpp:50-117, :178-226; its shuffle of the visiting
  * order differs from SpikeSlabSampler's).  Same prior setters and state accessors as
  * the probit sampler.  Observations need ntrials <= clt_threshold <= 32 (the
- * large-sample imputation is not on the device); models of up to 64 variables.  RNG:
+ * large-sample imputation is not on the device); models of any size.  RNG:
  * stream 3 for the sampler, stream 9 from position (s n + i) * 64 for the
  * imputation of observation i in sweep s (exactly two uniforms per trial). */
 int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X,

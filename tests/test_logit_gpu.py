@@ -86,6 +86,33 @@ def test_logit_capacity_escalation_and_recovery(oracle):
     assert gam.sum(axis=1).min() > 16
 
 
+def test_logit_models_of_more_than_64_variables(oracle):
+    """72 signals: the chains move on to the kernel whose factors live in HBM, with
+    their own V matrices and the logit sampler's shuffle"""
+    n, p, nsig = 2500, 96, 72
+    rng = np.random.Generator(np.random.PCG64(4))
+    X = rng.standard_normal((n, p))
+    X[:, 0] = 1.0
+    btrue = np.zeros(p)
+    btrue[:nsig] = rng.choice([-1.0, 1.0], nsig) * 1.5
+    y = rng.binomial(1, 1 / (1 + np.exp(-(X @ btrue)))).astype(float)
+    nt = np.ones(n)
+    slab, pi = probit_slab(X, nt, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    chains, seed, nsw = 3, 11, 14
+    eng = make_engine(chains, seed, X, y, nt, slab, pi, g0)
+    ora = {c: oracle.logit_run(X, y, nt, slab, pi, ("philox", seed, c), g0, np.zeros(p), nsw)
+           for c in (0, 2)}
+    for s in range(nsw):
+        eng.logit_sweep(1)
+        gam, beta, _ = eng.get_states()
+        for c in (0, 2):
+            assert np.array_equal(gam[c], ora[c]["gamma"][s]), (c, s)
+            assert relerr(beta[c], ora[c]["beta"][s]) < RTOL, (c, s)
+    assert max(o["gamma"].sum(axis=1).max() for o in ora.values()) > 64
+
+
 def test_logit_rejects_large_trial_counts():
     import boom_amd
     X, y, nt, _ = logit_data(50, 4, 2, seed=1, max_trials=9)
