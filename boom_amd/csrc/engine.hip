@@ -43,8 +43,16 @@ hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_
 hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
                                uint64_t *pos_forecast, double *out);
 hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P);
-hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *slab_precision,
-                               double *V);
+hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *Xsq,
+                               const double *slab_precision, double *v_diag, double *planes);
+// xtwx_cols_kernel.hip
+int xtwx_cols_planes(int64_t n);
+hipError_t launch_xtwx_cols(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
+                            const int32_t *req, int R, const double *base, double *V,
+                            uint32_t *valid, int words, double *planes);
+hipError_t launch_xtwx_cols_start(hipStream_t stream, const uint8_t *gamma, int chains, int p,
+                                  int32_t *req, int32_t *count, uint32_t *valid, int words);
+hipError_t launch_square(hipStream_t stream, const double *x, size_t count, double *out);
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
 hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
@@ -243,6 +251,16 @@ struct ba_engine {
   // precisions (chains x n) and every chain's own V = slab precision + X'WX
   bool logit_mode = false;
   DevBuf<double> dlogit_w, dlogit_V;
+  // ... V built a vector at a time (xtwx_cols_kernel.hip): the squared design matrix
+  // (for the diagonal), the diagonals (chains x p), which vectors hold this sweep's
+  // values (bits, logit_words words per chain), the request list (chain, variable) and
+  // its length, the variable a parked chain waits for, the GEMM's split-K planes
+  DevBuf<double> dlogit_Xsq, dlogit_vdiag, dlogit_planes;
+  DevBuf<uint32_t> dlogit_valid;
+  DevBuf<int32_t> dlogit_req, dlogit_cnt, dcol_request;
+  int logit_words = 0;
+  int64_t logit_req_batch = 0;     // requests per GEMM launch (bounds the planes)
+  int64_t logit_cols_built = 0, logit_cols_requested = 0, logit_replays = 0;   // (diagnostics)
   // structural state (trend + seasonal, ssm_kernel.hip) instead of the local level
   bool ssm_set = false;
   SsmParams ssm{};                 // the host's copy of the specification (device pointers filled per launch)
@@ -529,6 +547,10 @@ void fill_params(ba_engine *e, SsvsParams &P) {
     P.v_chain_stride = (int64_t)e->p * e->p;
     P.model_keep = 0;
     P.table_keep = 0;
+    P.col_valid = e->dlogit_valid.ptr;
+    P.col_words = e->logit_words;
+    P.col_request = e->dcol_request.ptr;
+    P.v_diag = e->dlogit_vdiag.ptr;
   }
   if (e->cur_mode == 2) {
     // AdaptiveSpikeSlabRegressionSampler: own stream, no swap move
@@ -621,11 +643,66 @@ int grow_big(ba_engine *e, int *stuck) {
   return ensure_big_buffers(e);
 }
 
+// the vectors of V named by dlogit_req[0, R), in batches the planes can hold
+int build_columns(ba_engine *e, int64_t R) {
+  const int64_t n = e->probit_n;
+  for (int64_t r0 = 0; r0 < R; r0 += e->logit_req_batch) {
+    const int64_t nr = std::min<int64_t>(e->logit_req_batch, R - r0);
+    HIP_TRY(launch_xtwx_cols(e->stream, e->dprob_X.ptr, n, e->p, e->dlogit_w.ptr,
+                             e->dlogit_req.ptr + 2 * r0, (int)nr, e->dA.ptr, e->dlogit_V.ptr,
+                             e->dlogit_valid.ptr, e->logit_words, e->dlogit_planes.ptr));
+  }
+  return BA_OK;
+}
+
+// Chains of the logit sampler parked at "add variable j" for want of vector j of
+// their V (CHAIN_NEED_COLUMN): the vectors are computed -- one GEMM for all of
+// them -- and the chains replay the sweep they were in, from its start and with the
+// same draws, now finding the vector.  *served: something was replayed (st is fresh).
+int serve_columns(ba_engine *e, std::vector<int32_t> &st, bool *served) {
+  *served = false;
+  if (!e->logit_mode || !e->dcol_request.count) return BA_OK;
+  const size_t C = (size_t)e->cfg.chains;
+  bool any = false;
+  for (size_t c = 0; c < C; ++c) any = any || st[c] == CHAIN_NEED_COLUMN || st[c] == CHAIN_NEED_COLUMN_BIG;
+  if (!any) return BA_OK;
+  std::vector<int32_t> want(C), req;
+  HIP_TRY(hipMemcpy(want.data(), e->dcol_request.ptr, C * 4, hipMemcpyDeviceToHost));
+  for (size_t c = 0; c < C; ++c) {
+    if (st[c] != CHAIN_NEED_COLUMN && st[c] != CHAIN_NEED_COLUMN_BIG) continue;
+    if (want[c] < 0 || want[c] >= e->p) return fail(BA_E_STATE, "a parked chain names no variable");
+    req.push_back((int32_t)c);
+    req.push_back(want[c]);
+    // (the large-model kernel takes its chains back in the parked state)
+    st[c] = (st[c] == CHAIN_NEED_COLUMN) ? CHAIN_OK : CHAIN_MODEL_TOO_LARGE;
+  }
+  const int64_t R = (int64_t)req.size() / 2;
+  HIP_TRY(hipMemcpyAsync(e->dlogit_req.ptr, req.data(), req.size() * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->dstatus.ptr, st.data(), C * 4, hipMemcpyHostToDevice, e->stream));
+  int rc = build_columns(e, R);
+  if (rc) return rc;
+  e->logit_cols_requested += R;
+  ++e->logit_replays;
+  SsvsParams P;
+  fill_params(e, P);
+  HIP_TRY(launch_sweeps(e, P, 0));   // the sweep still owed
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+  *served = true;
+  return BA_OK;
+}
+
 // Resume chains that outgrew the capacity of the launch they were in, with the
 // next larger capacity; then follow the largest model size seen.
 int escalate(ba_engine *e, std::vector<int32_t> &st) {
   const size_t C = (size_t)e->cfg.chains;
   for (;;) {
+    {
+      bool served = false;
+      int rc = serve_columns(e, st, &served);
+      if (rc) return rc;
+      if (served) continue;
+    }
     bool any = false;
     for (size_t c = 0; c < C; ++c) any = any || (st[c] == CHAIN_MODEL_TOO_LARGE);
     if (!any) return BA_OK;
@@ -1994,6 +2071,8 @@ int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const
   HIP_TRY(hipMemcpy(e->dprob_X.ptr, X, (size_t)n * p * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->dprob_y.ptr, y, (size_t)n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->dprob_nt.ptr, ntrials, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(e->dlogit_Xsq.resize((size_t)n * p));
+  HIP_TRY(launch_square(e->stream, e->dprob_X.ptr, (size_t)n * p, e->dlogit_Xsq.ptr));
   e->logit_mode = true;
   e->probit_mode = false;
   e->probit_n = n;
@@ -2019,6 +2098,17 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
     HIP_TRY(e->dlogit_w.resize(C * n));
     HIP_TRY(e->dlogit_V.resize(C * p * p));
     HIP_TRY(e->dxty_c.resize(C * p));
+    e->logit_words = (int)((p + 31) / 32);
+    HIP_TRY(e->dlogit_vdiag.resize(C * p));
+    HIP_TRY(e->dlogit_valid.resize(C * (size_t)e->logit_words));
+    HIP_TRY(e->dlogit_req.resize(2 * C * p));
+    HIP_TRY(e->dlogit_cnt.resize(1));
+    HIP_TRY(e->dcol_request.resize(C));
+    // the planes of one GEMM launch: at most 1 GiB, at least one request tile
+    const size_t per_req = (size_t)xtwx_cols_planes((int64_t)n) * p * 8;
+    e->logit_req_batch = (int64_t)std::min<size_t>(std::max<size_t>(((size_t)1 << 30) / per_req, 64), 32768);
+    e->logit_req_batch = std::min<int64_t>(e->logit_req_batch, (int64_t)(C * p));
+    HIP_TRY(e->dlogit_planes.resize((size_t)e->logit_req_batch * per_req / 8));
     std::vector<double> one(C, 1.0);
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->dsigsq.ptr, one.data(), C * 8, hipMemcpyHostToDevice));
@@ -2051,10 +2141,22 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
   // BinomialLogitSpikeSlabSampler::draw (BinomialLogitSpikeSlabSampler.cpp:50-54)
   for (int i = 0; i < nsweeps; ++i) {
     Q.sweep = e->probit_sweep++;
-    HIP_TRY(launch_logit_impute(e->stream, Q, e->dA.ptr, e->dlogit_V.ptr));   // impute_latent_data
+    // impute_latent_data: z, w, X'Wz and the diagonal of V = slab precision + X'WX ...
+    HIP_TRY(launch_logit_impute(e->stream, Q, e->dlogit_Xsq.ptr, e->dA.ptr, e->dlogit_vdiag.ptr,
+                                e->dlogit_planes.ptr));
+    // ... and the vectors of V the sweep starts from: those of the included variables
+    HIP_TRY(launch_xtwx_cols_start(e->stream, e->dgamma.ptr, (int)C, (int)p, e->dlogit_req.ptr,
+                                   e->dlogit_cnt.ptr, e->dlogit_valid.ptr, e->logit_words));
+    int32_t R = 0;
+    HIP_TRY(hipMemcpyAsync(&R, e->dlogit_cnt.ptr, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    rc = build_columns(e, R);
+    if (rc) return rc;
+    e->logit_cols_built += R;
     HIP_TRY(launch_sweeps(e, P, 1));                                         // draw_model_indicators, draw_beta
-    // (a chain that outgrew the launch's capacity replays THIS sweep's draws on
-    // this sweep's latent data before the next imputation)
+    // (a chain that stopped for a missing vector of V, or outgrew the launch's
+    // capacity, replays THIS sweep's draws on this sweep's latent data before the
+    // next imputation: check_chain_status serves both)
     HIP_TRY(hipStreamSynchronize(e->stream));
     rc = check_chain_status(e);
     if (rc) return rc;

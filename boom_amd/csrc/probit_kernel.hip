@@ -114,6 +114,40 @@ __device__ __forceinline__ void trun_norm_moments(double mu, bool positive, doub
   if (*variance < 0) *variance = 0;
 }
 
+// The chain's included variables and their coefficients, in ascending order (the
+// order x_i'beta is summed in), to LDS; returns how many there are (beyond
+// PROBIT_KMAX only counted).  All 256 threads: 256 variables per round, a
+// variable's place = included ones in earlier rounds + earlier waves + earlier lanes.
+__device__ __forceinline__ int included_coefficients(const ProbitParams &P, int chain, int *s_idx,
+                                                     double *s_beta) {
+  __shared__ int s_wave_count[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint8_t *g = P.gamma + (size_t)chain * P.p;
+  const double *b = P.beta + (size_t)chain * P.p;
+  int base = 0;
+  for (int j0 = 0; j0 < P.p; j0 += 256) {
+    const int j = j0 + tid;
+    const bool inc = j < P.p && g[j] != 0;
+    const unsigned long long m = __ballot(inc);
+    if (lane == 0) s_wave_count[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = s_wave_count[w];
+      before += (w < wave) ? c : 0;
+      total += c;
+    }
+    if (inc) {
+      const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < PROBIT_KMAX) { s_idx[pos] = j; s_beta[pos] = b[j]; }
+    }
+    base += total;
+    __syncthreads();
+  }
+  return base;
+}
+
 }  // namespace
 
 // grid = (ceil(n / 256), chains), block = 256
@@ -123,21 +157,7 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   // the chain's included variables, once per workgroup
   __shared__ int s_idx[PROBIT_KMAX];
   __shared__ double s_beta[PROBIT_KMAX];
-  __shared__ int s_k;
-  if (threadIdx.x == 0) {
-    int k = 0;
-    const uint8_t *g = P.gamma + (size_t)chain * P.p;
-    const double *b = P.beta + (size_t)chain * P.p;
-    for (int j = 0; j < P.p; ++j) {
-      if (g[j]) {
-        if (k < PROBIT_KMAX) { s_idx[k] = j; s_beta[k] = b[j]; }
-        ++k;
-      }
-    }
-    s_k = k;
-  }
-  __syncthreads();
-  const int k = s_k;
+  const int k = included_coefficients(P, chain, s_idx, s_beta);
   if (k > PROBIT_KMAX) {
     if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
     return;
@@ -188,21 +208,7 @@ __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
   if (P.status[chain] != CHAIN_OK) return;
   __shared__ int s_idx[PROBIT_KMAX];
   __shared__ double s_beta[PROBIT_KMAX];
-  __shared__ int s_k;
-  if (threadIdx.x == 0) {
-    int k = 0;
-    const uint8_t *g = P.gamma + (size_t)chain * P.p;
-    const double *b = P.beta + (size_t)chain * P.p;
-    for (int j = 0; j < P.p; ++j) {
-      if (g[j]) {
-        if (k < PROBIT_KMAX) { s_idx[k] = j; s_beta[k] = b[j]; }
-        ++k;
-      }
-    }
-    s_k = k;
-  }
-  __syncthreads();
-  const int k = s_k;
+  const int k = included_coefficients(P, chain, s_idx, s_beta);
   if (k > PROBIT_KMAX) {
     if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
     return;
@@ -265,18 +271,19 @@ hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P) {
   return launch_atb_mfma(stream, P.z, (int64_t)P.n, P.chains, P.X, (int64_t)P.n, P.p, P.n, P.xtz, P.p);
 }
 
-hipError_t launch_xtwx_mfma(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
-                            int chains, const double *base, double *out);
+hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R, const double *B, int64_t n,
+                                     int p, const double *diag_base, double *out, double *planes);
 
-// impute, X'Wz and V = slab precision + X'WX for every chain
-hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *slab_precision,
-                               double *V) {
+// impute, X'Wz and the diagonal of V = slab precision + X'WX for every chain (the rest
+// of V is built a vector at a time, as the sweep asks for it: xtwx_cols_kernel.hip)
+hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *Xsq,
+                               const double *slab_precision, double *v_diag, double *planes) {
   hipLaunchKernelGGL(logit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
-  err = launch_atb_mfma(stream, P.z, (int64_t)P.n, P.chains, P.X, (int64_t)P.n, P.p, P.n, P.xtz, P.p);
+  err = launch_rows_times_columns(stream, P.z, P.chains, P.X, (int64_t)P.n, P.p, nullptr, P.xtz, planes);
   if (err != hipSuccess) return err;
-  return launch_xtwx_mfma(stream, P.X, (int64_t)P.n, P.p, P.w, P.chains, slab_precision, V);
+  return launch_rows_times_columns(stream, P.w, P.chains, Xsq, (int64_t)P.n, P.p, slab_precision, v_diag, planes);
 }
 
 }  // namespace boom_amd

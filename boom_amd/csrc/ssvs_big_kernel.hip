@@ -200,11 +200,13 @@ __device__ __forceinline__ void uniform_copy(Model &m, const Model &in) {
 // the launch parameters the heavy routines use
 struct BigP {
   const double *V, *A, *b, *l1, *l0;
+  const double *vdiag;        // the chain's diagonal of V when V is computed column by column, or nullptr
   int64_t max_model_size;
 };
 __device__ __forceinline__ void uniform_copy(BigP &q, const SsvsParams &P) {
   q.V = uni_ptr(P.V); q.A = uni_ptr(P.A); q.b = uni_ptr(P.b); q.l1 = uni_ptr(P.l1); q.l0 = uni_ptr(P.l0);
   q.max_model_size = (int64_t)uni((uint64_t)P.max_model_size);
+  q.vdiag = nullptr;
 }
 
 // the sorted index list of the model in LDS from the LDS copy of gamma
@@ -474,7 +476,7 @@ __device__ __forceinline__ Proposal big_eval(const BigP &P, Chain &ch, const Mod
   const bool fast = live && !empty_after && !slow;
   out.slow = slow;
   if (empty_after) out.logp = ch.mode ? lpn : lpn - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
-  const double vjj = (fast && add) ? P.V[(size_t)j * p + j] * ch.sv : 0.0;
+  const double vjj = (fast && add) ? (P.vdiag ? P.vdiag[j] : P.V[(size_t)j * p + j]) * ch.sv : 0.0;
   const double ajj = (fast && add) ? P.A[(size_t)j * p + j] * ch.sa : 0.0;
   const double xtyj = (fast && add) ? ch.xty[j] * ch.sx : 0.0;
   const int npan = (k + 63) >> 6;
@@ -604,6 +606,11 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   BigP BP;
   BP.V = P.V + (size_t)chain * (size_t)P.v_chain_stride;   // (the logit sampler: every chain has its own V)
   BP.A = P.A; BP.b = P.b; BP.l1 = P.l1; BP.l0 = P.l0;
+  BP.vdiag = nullptr;
+  if (P.col_valid) {
+    P.col_valid += (size_t)chain * (size_t)P.col_words;
+    BP.vdiag = P.v_diag + (size_t)chain * (size_t)p;
+  }
   BP.max_model_size = P.max_model_size;
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
   const double yty = P.yty[(size_t)chain * P.suf_stride];
@@ -637,6 +644,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   uint16_t *g_perm = P.perm + (size_t)chain * p;
   int status = CHAIN_OK;
   bool aborted = false;
+  int need_col = -1;   // CHAIN_NEED_COLUMN_BIG: the variable whose vector of V is missing
   int kmax = 0, trace_at = 0, failures = 0, done = 0, klast = 0;
   uint64_t pos = 0, flip_pos = 0, pos0 = 0;
   double sigsq = 1.0;
@@ -776,11 +784,13 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
                 const double pj = P.pi[j];
                 const bool inc = ch.gam[j];
                 if ((pj <= 0.0 && inc) || (pj >= 1.0 && !inc)) {
+                  if (!inc && column_missing(P, j)) { status = CHAIN_NEED_COLUMN_BIG; need_col = j; aborted = true; break; }
                   wave_sync();
                   if (lane == 0) ch.gam[j] = (uint8_t)!inc;
                   wave_sync();
                 }
               }
+              if (aborted) continue;
               rebuild_g(ch, kcap);
               if (ch.k > kcap) { status = CHAIN_MODEL_TOO_LARGE; aborted = true; continue; }
               bind(cur);
@@ -822,6 +832,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
           i0 = dr.spos + 1;
           if (dr.kind == STOP_BAD) { status = CHAIN_NEGATIVE_SS; continue; }
           if (!ch.gam[dr.j] && ch.k >= kcap) { status = CHAIN_MODEL_TOO_LARGE; aborted = true; continue; }
+          if (!ch.gam[dr.j] && column_missing(P, dr.j)) { status = CHAIN_NEED_COLUMN_BIG; need_col = dr.j; aborted = true; continue; }
           if (dr.kind == 0 && other_ok && dr.j == other_var) {
             // the flip leads back to the model the other slot still holds
             flip_in_lds(dr.j, -1);
@@ -1076,6 +1087,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     P.rng_pos[chain] = pos;
     P.failures[chain] = failures;
     P.status[chain] = status;
+    if (P.col_request) P.col_request[chain] = need_col;
     P.todo[chain] = nsweeps - done + owed_after;
     if (P.ran) P.ran[chain] = done;
     const int tag = big_tag | cur;

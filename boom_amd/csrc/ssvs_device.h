@@ -532,6 +532,13 @@ __device__ __forceinline__ void solve_blocks(c_f64 *__restrict__ LB,
   }
 }
 
+// the logit sampler's V, computed column by column: is vector j of this chain's V
+// (needed by any model that includes j) still to be computed?  (P.col_valid is the
+// chain's own words here.)
+__device__ __forceinline__ bool column_missing(const SsvsParams &P, int j) {
+  return P.col_valid != nullptr && !((P.col_valid[j >> 5] >> (j & 31)) & 1u);
+}
+
 struct Proposal {
   double logp;   // log_model_prob of the flipped model (-inf: impossible)
   bool slow;     // needs the exact path (non-zero prior mean on j)
@@ -572,13 +579,15 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
   if (empty_after) {
     out.logp = ch.mode ? lpn : lpn - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
   }
-  const double vjj = (fast && add) ? P.V[(size_t)j * p + j] * ch.sv : 0.0;
+  const double vjj = (fast && add) ? (P.v_diag ? P.v_diag[j] : P.V[(size_t)j * p + j]) * ch.sv : 0.0;
   const double ajj = (fast && add) ? P.A[(size_t)j * p + j] * ch.sa : 0.0;
   const double xtyj = (fast && add) ? ch.xty[j] * ch.sx : 0.0;
 
   constexpr int KCAP = NB * 8;
   const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
   c_f64 *sc = ch.sc;
+  // (a V computed column by column holds the vectors of included variables only)
+  const bool nat = NAT || (P.col_valid != nullptr);
 
   double x[NB * 8];
   double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
@@ -598,7 +607,7 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
         for (int r = 0; r < 8; ++r) {
           const int m = I * 8 + r;
           const int gm = (m < k) ? (int)ch.g[m] : 0;  // LDS broadcast read
-          const double v = (NAT ? Mat[(size_t)gm * p + j] : Mat[(size_t)j * p + gm]) * msc;
+          const double v = (nat ? Mat[(size_t)gm * p + j] : Mat[(size_t)j * p + gm]) * msc;
           const double e = (gm == j) ? 1.0 : 0.0;
           x[m] = (fast && m < k) ? (add ? v : e) : 0.0;
         }

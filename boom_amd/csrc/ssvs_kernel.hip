@@ -50,6 +50,10 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int chain = (int)blockIdx.x + P.chain_first;
   P.V += (size_t)chain * (size_t)P.v_chain_stride;   // (a chain's own V: the logit sampler's X'WX moves with its latent data)
+  if (P.col_valid) {
+    P.col_valid += (size_t)chain * (size_t)P.col_words;
+    P.v_diag += (size_t)chain * (size_t)P.p;
+  }
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int p = P.p;
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   ch.k = k;
   wave_sync();
   bool aborted = false;      // stopped inside a sweep: restore its start
+  int need_col = -1;         // CHAIN_NEED_COLUMN: the variable whose vector of V is missing
   int kmax = k;
   int trace_at = P.trace_idx ? P.trace_idx[chain] : 0;
 
@@ -522,6 +527,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
               const bool inc = ch.gam[j];
               if ((pj <= 0.0 && inc) || (pj >= 1.0 && !inc)) {
                 if (!inc && ch.k >= KCAP) { status = CHAIN_MODEL_TOO_LARGE; aborted = true; break; }
+                if (!inc && column_missing(P, j)) { status = CHAIN_NEED_COLUMN; need_col = j; aborted = true; break; }
                 apply_flip(ch, j);
               }
             }
@@ -585,6 +591,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         }
         if (!ch.gam[dr.j] && ch.k >= KCAP) {
           status = CHAIN_MODEL_TOO_LARGE;
+          aborted = true;
+          break;
+        }
+        if (!ch.gam[dr.j] && column_missing(P, dr.j)) {
+          status = CHAIN_NEED_COLUMN;
+          need_col = dr.j;
           aborted = true;
           break;
         }
@@ -663,6 +675,13 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         // the candidate cannot be held in LDS; if it is a sure rejection that
         // is fine, but we cannot tell without evaluating it
         status = CHAIN_MODEL_TOO_LARGE;
+        aborted = true;
+        break;
+      }
+      if (!ch.gam[jf] && column_missing(P, jf)) {
+        // the model with jf needs vector jf of this chain's V: the host computes it
+        status = CHAIN_NEED_COLUMN;
+        need_col = jf;
         aborted = true;
         break;
       }
@@ -880,6 +899,7 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
     P.rng_pos[chain] = pos;
     P.failures[chain] = failures;
     P.status[chain] = status;
+    if (P.col_request) P.col_request[chain] = need_col;
     P.todo[chain] = nsweeps - done + owed_after;
     if (P.ran) P.ran[chain] = done;
     const int tag = KCAP | (cur << 8);

@@ -13,7 +13,12 @@ enum ChainStatus : int32_t {
   CHAIN_ILLEGAL_START = 3,
   CHAIN_RNG_BRANCH = 4,
   CHAIN_FORECAST_VARIANCE = 5,
-  CHAIN_MODEL_TOO_LARGE = 6
+  CHAIN_MODEL_TOO_LARGE = 6,
+  // (never seen by a caller) the sweep stopped at a proposal to ADD a variable whose
+  // column of the chain's own V has not been computed for this sweep's latent data:
+  // the host computes it (col_request names it) and the sweep is replayed
+  CHAIN_NEED_COLUMN = 7,
+  CHAIN_NEED_COLUMN_BIG = 8   // the same, from the large-model kernel
 };
 
 // number of doubles in the reduced summary block: 3p + SUMMARY_SCALARS
@@ -48,6 +53,17 @@ struct SsvsParams {
   // order (every position swaps with one drawn from the whole range: p uniforms) and V per chain
   int32_t mode;
   int64_t v_chain_stride;  // doubles between the chains' V matrices (0: one shared V)
+  // A chain's own V computed column by column, as the sweep needs it (the logit
+  // sampler: V_c = Omega^{-1} + X'W_cX moves with the latent data of every sweep, and a
+  // sweep reads only the columns of variables that are or become included, p k of its
+  // p^2 elements).  col_valid: bit j of chain c's words = vector j of V_c (elements
+  // (., j), at V_c + j p) holds this sweep's values; v_diag: the diagonal, chains x p.
+  // A proposal to add j with the bit clear parks the chain (CHAIN_NEED_COLUMN,
+  // col_request[chain] = j).  nullptr: V is complete.
+  const uint32_t *col_valid;
+  int32_t col_words;       // words per chain
+  int32_t *col_request;    // chains
+  const double *v_diag;    // chains x p
   // how a sweep's proposals are walked (ssvs_kernel.hip): 0 batch mode only, 1
   // adaptive (table look-ups after quiet sweeps; the default), 2 always the
   // table, 3 adaptive without the forked quiet sweep (diagnostic A/B)

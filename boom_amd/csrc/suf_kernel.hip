@@ -98,122 +98,6 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
       }
 }
 
-// Weighted, batched variant: out[c] = base + X' diag(w_c) X for every chain c, w
-// row-major chains x n.  The complete-data sufficient statistic X'WX of
-// BinomialLogitAuxmixSampler (BinomialLogitAuxmixSampler.cpp:64-70) with the
-// slab's precision added on the way out: the per-chain matrix V the sweep kernel
-// reads.  Same tiling as xtx_mfma_kernel, but X is the same for every chain and
-// far larger than the caches (n p 8 bytes; 410 MB at config 5): a workgroup
-// stages a panel of X ONCE and uses it for NCH chains (blockIdx.z = chain
-// group), scaling the B fragment by the chain's weight as it leaves LDS -- a
-// 64 x 64 tile alone has 8 flop per byte of X and is bandwidth bound; NCH chains
-// per panel have 8 NCH.  The k order is fixed (bitwise reproducible).
-template <int NCH>
-__global__ __launch_bounds__(256) void xtwx_mfma_kernel(const double *__restrict__ X, int64_t n,
-                                                        int p, const double *__restrict__ w,
-                                                        int chains,
-                                                        const double *__restrict__ base,
-                                                        double *__restrict__ out) {
-  // two panels in LDS: the next one is fetched (into registers, then LDS) while the
-  // matrix cores work on the current one
-  __shared__ double sA[2][TILE * LDP];
-  __shared__ double sB[2][TILE * LDP];
-  __shared__ double sW[2][NCH][KC];
-  const int tj = blockIdx.x, ti = blockIdx.y;
-  if (tj > ti) return;
-  const int I0 = ti * TILE, J0 = tj * TILE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wi = wave >> 1, wj = wave & 1;
-  const int c0 = (int)blockIdx.z * NCH;
-  double4_t acc[NCH][2][2];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[c][a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const int fr = lane >> 4, fc = lane & 15;
-  // this thread's share of a panel: element e = it * 256 + tid -> column e >> 5, row e & 31
-  const int prow = tid & 31, pcol0 = tid >> 5;   // columns pcol0 + 8 it
-  const int wc = tid / KC, wrow = tid % KC;      // (tid < NCH * KC) the weight it fetches
-  double ra[8], rb[8], rw = 0.0;
-  auto fetch = [&](int64_t r0) {
-    const int64_t r = r0 + prow;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int col = pcol0 + 8 * it;
-      const int ci = I0 + col, cj = J0 + col;
-      ra[it] = (r < n && ci < p) ? X[(int64_t)ci * n + r] : 0.0;
-      rb[it] = (r < n && cj < p) ? X[(int64_t)cj * n + r] : 0.0;
-    }
-    if (tid < NCH * KC) {
-      const int64_t rr = r0 + wrow;
-      rw = (rr < n && c0 + wc < chains) ? w[(size_t)(c0 + wc) * (size_t)n + rr] : 0.0;
-    }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int col = pcol0 + 8 * it;
-      sA[buf][col * LDP + prow] = ra[it];
-      sB[buf][col * LDP + prow] = rb[it];
-    }
-    if (tid < NCH * KC) sW[buf][wc][wrow] = rw;
-  };
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  int cur = 0;
-  for (int64_t r0 = 0; r0 < n; r0 += KC) {
-    const bool more = r0 + KC < n;
-    if (more) fetch(r0 + KC);
-#pragma unroll
-    for (int kk = 0; kk < KC / 4; ++kk) {
-      double a[2], b[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = sA[cur][(wi * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
-        b[t] = sB[cur][(wj * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
-      }
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const double wv = sW[cur][c][kk * 4 + fr];
-        const double bw0 = b[0] * wv, bw1 = b[1] * wv;
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta) {
-          acc[c][ta][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], bw0, acc[c][ta][0], 0, 0, 0);
-          acc[c][ta][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], bw1, acc[c][ta][1], 0, 0, 0);
-        }
-      }
-    }
-    if (more) stash(cur ^ 1);   // (the other buffer was last read before the previous barrier)
-    __syncthreads();
-    cur ^= 1;
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    if (c0 + c >= chains) continue;
-    double *o = out + (size_t)(c0 + c) * (size_t)p * (size_t)p;
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = I0 + wi * 32 + ta * 16 + (lane >> 4) + 4 * q;
-          const int j = J0 + wj * 32 + tb * 16 + (lane & 15);
-          if (i < p && j < p) {
-            // (the diagonal tiles compute both triangles: keep the lower one so that
-            // the matrix is exactly symmetric)
-            if (ti == tj && j > i) continue;
-            const double v = acc[c][ta][tb][q] + (base ? base[(int64_t)j * p + i] : 0.0);
-            o[(int64_t)j * p + i] = v;
-            o[(int64_t)i * p + j] = v;
-          }
-        }
-  }
-}
-
 // sum of the split-K planes in plane order (bitwise reproducible)
 __global__ __launch_bounds__(256) void plane_sum_kernel(const double *__restrict__ planes,
                                                         int nplanes, size_t count,
@@ -339,15 +223,6 @@ __global__ __launch_bounds__(256) void atb_mfma_kernel(const double *__restrict_
 }
 
 }  // namespace
-
-hipError_t launch_xtwx_mfma(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
-                            int chains, const double *base, double *out) {
-  const int tiles = (p + TILE - 1) / TILE;
-  constexpr int NCH = 4;
-  hipLaunchKernelGGL((xtwx_mfma_kernel<NCH>), dim3(tiles, tiles, (chains + NCH - 1) / NCH), dim3(256), 0,
-                     stream, X, n, p, w, chains, base, out);
-  return hipGetLastError();
-}
 
 hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
                            const double *B, int64_t ldb, int N, int K, double *C, int ldc) {
