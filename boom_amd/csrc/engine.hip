@@ -42,7 +42,7 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances);
 hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
                                uint64_t *pos_forecast, double *out);
-hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P);
+hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P, double *planes);
 hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *Xsq,
                                const double *slab_precision, double *v_diag, double *planes);
 // xtwx_cols_kernel.hip
@@ -1997,6 +1997,7 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps) {
   if (e->dprob_z.count != C * n) {
     HIP_TRY(e->dprob_z.resize(C * n));
     HIP_TRY(e->dxty_c.resize(C * p));
+    HIP_TRY(e->dlogit_planes.resize((size_t)xtwx_cols_planes((int64_t)n) * C * p));   // (split-K planes of X'z)
     // the latent data have unit variance: sigma^2 = 1 in every chain
     std::vector<double> one(C, 1.0);
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2029,7 +2030,7 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps) {
   // BinomialProbitSpikeSlabSampler::draw (BinomialProbitSpikeSlabSampler.cpp:40-46)
   for (int i = 0; i < nsweeps; ++i) {
     Q.sweep = e->probit_sweep++;
-    HIP_TRY(launch_probit_impute(e->stream, Q));   // impute_latent_data, X'z
+    HIP_TRY(launch_probit_impute(e->stream, Q, e->dlogit_planes.ptr));   // impute_latent_data, X'z
     HIP_TRY(launch_sweeps(e, P, 1));               // draw_model_indicators, draw_beta
     // (a chain that outgrew the launch's capacity replays THIS sweep's draws on
     // this sweep's latent data before the next imputation)

@@ -260,19 +260,17 @@ __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
   P.w[(size_t)chain * P.n + i] = info;
 }
 
-hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
-                           const double *B, int64_t ldb, int N, int K, double *C, int ldc);
+hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R, const double *B, int64_t n,
+                                     int p, const double *diag_base, double *out, double *planes);
 
 // impute + X'z for every chain
-hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P) {
+hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P, double *planes) {
   hipLaunchKernelGGL(probit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
-  return launch_atb_mfma(stream, P.z, (int64_t)P.n, P.chains, P.X, (int64_t)P.n, P.p, P.n, P.xtz, P.p);
+  return launch_rows_times_columns(stream, P.z, P.chains, P.X, (int64_t)P.n, P.p, nullptr, P.xtz, planes);
 }
 
-hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R, const double *B, int64_t n,
-                                     int p, const double *diag_base, double *out, double *planes);
 
 // impute, X'Wz and the diagonal of V = slab precision + X'WX for every chain (the rest
 // of V is built a vector at a time, as the sweep asks for it: xtwx_cols_kernel.hip)

@@ -262,8 +262,10 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps);
  * imputer -- it has no Polya-Gamma one) -------------------------------------------
  * Per sweep: every trial's truncated logistic draw and mixture component
  * (BinomialLogitAuxmixSampler.cpp:77-97, BinomialLogitDataImputer.cpp:128-144),
- * X'Wz for all chains by one MFMA GEMM, every chain's own X'WX by a batched
- * weighted MFMA syrk, then the sampler's inclusion / coefficient draws
+ * X'Wz for all chains by one MFMA GEMM, of every chain's own slab precision + X'WX
+ * the vectors the sweep reads (those of included variables, built by one gathered
+ * MFMA GEMM; a variable that enters mid-sweep has its vector built on request and
+ * the chain replays that sweep), then the sampler's inclusion / coefficient draws
  * (BinomialLogitSpikeSlabSampler.cpp:50-117, :178-226; its shuffle of the visiting
  * order differs from SpikeSlabSampler's).  Same prior setters and state accessors as
  * the probit sampler.  Observations need ntrials <= clt_threshold <= 32 (the

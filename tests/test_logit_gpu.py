@@ -120,3 +120,31 @@ def test_logit_rejects_large_trial_counts():
     with pytest.raises(boom_amd.BoomAmdError) as ei:
         eng.logit_set_data(X, y, nt, 5)
     assert "large-sample" in str(ei.value)
+
+
+def test_config5_shape_per_gpu():
+    """BASELINE config 5 at its per-GPU size (n = 5e4, p = 1024, 4096 chains over 8 GPUs
+    = 512 per rank), too large for an oracle run: the eight signals are found by every
+    chain, and a shard of four chains repeats the whole job's first four bit for bit --
+    which it can only do if no value depends on what else shares a launch (the request
+    GEMM's fixed row chunks, the replay of parked chains)."""
+    import boom_amd
+    n, p, nsig = 50000, 1024, 8
+    X, y, nt, _ = logit_data(n, p, nsig, seed=8675309)
+    slab, pi = probit_slab(X, nt, nsig)
+    out = []
+    for chains in (512, 4):
+        eng = boom_amd.Engine(chains, seed=4)
+        eng.logit_set_data(X, y, nt, 5)
+        eng.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+        eng.set_spike(pi)
+        g0 = np.zeros(p, np.uint8)
+        g0[0] = 1
+        eng.set_state(g0)
+        eng.logit_sweep(12)
+        out.append(eng.get_states()[:2])
+        del eng
+    (gam, beta), (gam4, beta4) = out
+    assert gam[:, :nsig].all()
+    assert gam.sum(1).max() < 40
+    assert np.array_equal(gam[:4], gam4) and np.array_equal(beta[:4], beta4)
