@@ -1101,6 +1101,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
   e->sumy = ybar * n;
   e->have_suf = true;
   e->device_dirty = true;
+  e->probit_mode = e->logit_mode = false;   // (regression data now; the binomial setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1137,6 +1138,7 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
   e->n = (double)n;
   e->have_suf = true;
   e->device_dirty = true;
+  e->probit_mode = e->logit_mode = false;   // (regression data now; the binomial setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1182,6 +1184,7 @@ int ba_set_suf_from_block_device(ba_engine *e, int64_t n_total, int32_t p,
   e->n = (double)n_total;
   e->have_suf = true;
   e->device_dirty = true;
+  e->probit_mode = e->logit_mode = false;   // (regression data now; the binomial setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1917,6 +1920,8 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps) {
   MUTATE(e);
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
+  if (e->logit_mode || e->probit_mode)
+    return fail(BA_E_STATE, "binomial data are set: use ba_logit_sweep / ba_probit_sweep (a sweep without the imputation is not a draw of those samplers)");
   if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
   int rc = alloc_chain_state(e);
   if (rc) return rc;

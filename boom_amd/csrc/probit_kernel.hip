@@ -41,41 +41,57 @@ __device__ __forceinline__ int tn_lower_bound(const double *v, int n, double val
   }
   return first;
 }
+// The hull's points are x_0 = a < x_1 < ...; the reference keeps logf(x_k) = -x_k^2 / 2
+// and its derivative -x_k beside them and, after every rejected candidate, recomputes
+// ALL knots and ALL segment integrals (TnSampler::add_point / update_cdf,
+// Samplers/TnSampler.cpp) -- O(n) divisions and 2 n exponentials per candidate.  A knot
+// depends on its two neighbouring points only and a segment's two integrals on its
+// point and its two knots, so an insertion at position pos changes knots pos, pos + 1
+// and the integrals of segments pos - 1 .. pos + 1; everything else is the value the
+// reference would recompute from the same inputs.  Here those are kept (inc1, inc2) and
+// only the changed ones evaluated: same numbers, O(1) transcendentals per candidate.
 __device__ double tn_draw(SeqRng &rng, double a, int *bad) {
-  double xs[TN_CAP], ys[TN_CAP], ds[TN_CAP], kn[TN_CAP], cdf[TN_CAP];
+  double xs[TN_CAP], kn[TN_CAP], cdf[TN_CAP], inc1[TN_CAP], inc2[TN_CAP];
+  auto yv = [](double x) { return __dmul_rn(__dmul_rn(-.5, x), x); };   // (a stored value in the reference: rounded)
+  const double y0 = yv(a);
+  // the integrals of segment k (point k between knots k and k + 1; the last one is open)
+  auto segment = [&](int k, int n) {
+    const double z = xs[k], d = -z, y = yv(z) - y0, dinv = 1.0 / d;
+    inc1[k] = (k == n - 1) ? 0 : dinv * exp(y - d * z + d * kn[k + 1]);
+    inc2[k] = dinv * exp(y - d * z + d * kn[k]);
+  };
   int n = 1;
-  xs[0] = a; ys[0] = -.5 * a * a; ds[0] = -a; kn[0] = a;
+  xs[0] = a; kn[0] = a;
+  segment(0, 1);
+  cdf[0] = 0 + inc1[0] - inc2[0];
   for (int level = 0; level <= 1001; ++level) {
-    {  // update_cdf
-      const double y0 = ys[0];
-      double last = 0;
-      for (int k = 0; k < n; ++k) {
-        const double d = ds[k], y = ys[k] - y0, z = xs[k], dinv = 1.0 / d;
-        const double inc1 = (k == n - 1) ? 0 : dinv * exp(y - d * z + d * kn[k + 1]);
-        const double inc2 = dinv * exp(y - d * z + d * kn[k]);
-        cdf[k] = last + inc1 - inc2;
-        last = cdf[k];
-      }
-    }
     const double u = d_runif(rng, 0.0, cdf[n - 1]);
     const int k = tn_lower_bound(cdf, n, u);
     double cand;
-    if (k + 1 == n) cand = kn[n - 1] + d_rexp(rng, -1 * ds[n - 1]);
-    else cand = d_rtrun_exp(rng, -1 * ds[k], kn[k], kn[k + 1]);
-    const double target = -.5 * cand * cand;
-    const double hull = ys[k] + ds[k] * (cand - xs[k]);
+    if (k + 1 == n) cand = kn[n - 1] + d_rexp(rng, -1 * -xs[n - 1]);
+    else cand = d_rtrun_exp(rng, -1 * -xs[k], kn[k], kn[k + 1]);
+    const double target = yv(cand);
+    const double hull = yv(xs[k]) + -xs[k] * (cand - xs[k]);
     const double logu = hull - d_rexp(rng, 1.0);
     if (logu < target) return cand;
     if (n >= TN_CAP) { *bad = 1; return a; }
     const int pos = tn_lower_bound(kn, n, cand);
-    for (int i = n; i > pos; --i) { xs[i] = xs[i - 1]; ys[i] = ys[i - 1]; ds[i] = ds[i - 1]; }
-    xs[pos] = cand; ys[pos] = target; ds[pos] = -cand;
+    if (pos == 0) { *bad = 1; return a; }   // (a candidate at the truncation point itself: never)
+    for (int i = n; i > pos; --i) { xs[i] = xs[i - 1]; inc1[i] = inc1[i - 1]; inc2[i] = inc2[i - 1]; }
+    for (int i = n; i > pos + 1; --i) kn[i] = kn[i - 1];
+    xs[pos] = cand;
     ++n;
-    kn[0] = xs[0];
-    for (int i = 1; i < n; ++i) {
-      double ans = (ys[i - 1] - ds[i - 1] * xs[i - 1]) - (ys[i] - ds[i] * xs[i]);
-      ans /= (ds[i] - ds[i - 1]);
+    for (int i = pos; i <= pos + 1 && i < n; ++i) {
+      const double xl = xs[i - 1], xr = xs[i];
+      double ans = (yv(xl) - -xl * xl) - (yv(xr) - -xr * xr);
+      ans /= (-xr - -xl);
       kn[i] = ans;
+    }
+    for (int kk = pos - 1; kk <= pos + 1 && kk < n; ++kk) segment(kk, n);
+    double last = pos >= 2 ? cdf[pos - 2] : 0;
+    for (int kk = pos - 1; kk < n; ++kk) {
+      cdf[kk] = last + inc1[kk] - inc2[kk];
+      last = cdf[kk];
     }
   }
   *bad = 1;

@@ -588,6 +588,7 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
   c_f64 *sc = ch.sc;
   // (a V computed column by column holds the vectors of included variables only)
   const bool nat = NAT || (P.col_valid != nullptr);
+  const size_t stride_g = nat ? (size_t)p : 1, lane_off = nat ? (size_t)j : (size_t)j * p;
 
   double x[NB * 8];
   double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
@@ -607,7 +608,7 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
         for (int r = 0; r < 8; ++r) {
           const int m = I * 8 + r;
           const int gm = (m < k) ? (int)ch.g[m] : 0;  // LDS broadcast read
-          const double v = (nat ? Mat[(size_t)gm * p + j] : Mat[(size_t)j * p + gm]) * msc;
+          const double v = Mat[(size_t)gm * stride_g + lane_off] * msc;
           const double e = (gm == j) ? 1.0 : 0.0;
           x[m] = (fast && m < k) ? (add ? v : e) : 0.0;
         }

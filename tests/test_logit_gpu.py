@@ -148,3 +148,22 @@ def test_config5_shape_per_gpu():
     assert gam[:, :nsig].all()
     assert gam.sum(1).max() < 40
     assert np.array_equal(gam[:4], gam4) and np.array_equal(beta[:4], beta4)
+
+
+def test_plain_sweep_is_refused_while_binomial_data_are_set():
+    """SpikeSlabSampler's sweep without the imputation is not a draw of the binomial
+    samplers (and the logit sampler's V holds only the vectors its last sweep asked
+    for): refused until regression data are installed again."""
+    import boom_amd
+    from boom_amd.capi import BoomAmdError
+    X, y, nt, _ = logit_data(200, 6, 2, seed=3)
+    slab, pi = probit_slab(X, nt, 2)
+    eng = make_engine(4, 5, X, y, nt, slab, pi, np.zeros(6, np.uint8))
+    eng.logit_sweep(2)
+    with pytest.raises(BoomAmdError, match="binomial data are set"):
+        eng.sss_sweep(1)
+    eng.build_suf_from_xy(X, y)
+    eng.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+    eng.set_spike(pi)
+    eng.set_state(np.zeros(6, np.uint8), sigsq=1.0)
+    eng.sss_sweep(3)
