@@ -46,6 +46,9 @@ hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P, doubl
 hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *Xsq,
                                const double *slab_precision, double *v_diag, double *planes);
 // xtwx_cols_kernel.hip
+hipError_t launch_ssvs_big_logp(hipStream_t stream, const SsvsParams &P, int kcap, const uint8_t *gammas,
+                                const int *which, int nwhich, double *model_ws, double *xs_ws, double *out,
+                                int *status_out);
 int xtwx_cols_planes(int64_t n);
 hipError_t launch_xtwx_cols(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
                             const int32_t *req, int R, const double *base, double *V,
@@ -1678,6 +1681,38 @@ int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
   HIP_TRY(hipMemcpyAsync(out, dout.ptr, (size_t)ngamma * 8, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(st.data(), dst.ptr, (size_t)ngamma * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  // vectors of more models than the LDS kernel holds: the large-model build, a few at
+  // a time (each has a model block of two k x k factors in HBM)
+  std::vector<int32_t> big;
+  for (int i = 0; i < ngamma; ++i)
+    if (st[i] == CHAIN_MODEL_TOO_LARGE) big.push_back(i);
+  if (!big.empty()) {
+    int kmax = 0;
+    for (int32_t i : big) {
+      int k = 0;
+      for (size_t j = 0; j < p; ++j) k += gammas[(size_t)i * p + j] ? 1 : 0;
+      kmax = std::max(kmax, k);
+    }
+    const int kcap = ((kmax + 63) / 64) * 64;
+    if (kcap > BIG_KCAP_MAX || ssvs_big_lds_layout(e->p, kcap).total > e->lds_per_cu)
+      return fail(BA_E_MODEL_TOO_LARGE, status_message(CHAIN_MODEL_TOO_LARGE));
+    const size_t block = ssvs_scalar_layout(kcap).total, xs = (size_t)kcap * 64;
+    const size_t batch = std::max<size_t>(1, std::min<size_t>(big.size(), ((size_t)256 << 20) / ((block + xs) * 8)));
+    DevBuf<double> dmodel_ws, dxs_ws;
+    DevBuf<int32_t> dwhich;
+    HIP_TRY(dmodel_ws.resize(batch * block));
+    HIP_TRY(dxs_ws.resize(batch * xs));
+    HIP_TRY(dwhich.resize(big.size()));
+    HIP_TRY(hipMemcpyAsync(dwhich.ptr, big.data(), big.size() * 4, hipMemcpyHostToDevice, e->stream));
+    for (size_t b0 = 0; b0 < big.size(); b0 += batch) {
+      const size_t nb = std::min(batch, big.size() - b0);
+      HIP_TRY(launch_ssvs_big_logp(e->stream, P, kcap, (const uint8_t *)dg.ptr, dwhich.ptr + b0, (int)nb,
+                                   dmodel_ws.ptr, dxs_ws.ptr, dout.ptr, dst.ptr));
+    }
+    HIP_TRY(hipMemcpyAsync(out, dout.ptr, (size_t)ngamma * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(st.data(), dst.ptr, (size_t)ngamma * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   for (int i = 0; i < ngamma; ++i)
     if (st[i] != CHAIN_OK) return fail(status_code(st[i]), status_message(st[i]));
   return BA_OK;

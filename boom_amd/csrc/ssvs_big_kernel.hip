@@ -1108,6 +1108,77 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   }
 }
 
+// log_model_prob of inclusion vectors of more than 64 variables (BregVsSampler::
+// log_model_prob, BregVsSampler.cpp:216-239): one wavefront per vector, the
+// large-model kernel's build on a private model block and solve workspace.
+// which[w] = the vector's row in gammas / out / status_out.
+__global__ __launch_bounds__(64) void ssvs_big_logp_kernel(SsvsParams P, int kcap, const uint8_t *gammas,
+                                                           const int *which, int nwhich, double *model_ws,
+                                                           double *xs_ws, double *out, int *status_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int w = (int)blockIdx.x, lane = threadIdx.x, p = P.p;
+  if (w >= nwhich) return;
+  const int row = which[w];
+  const SsvsBigLds lay = ssvs_big_lds_layout(p, kcap);
+  Chain ch;
+  ch.lane = lane;
+  ch.p = p;
+  ch.k = 0;
+  ch.Lv = ch.La = nullptr;
+  ch.rda = nullptr;
+  ch.bg = nullptr;
+  ch.rdv = to_lds<double>(smem + lay.rd);
+  ch.w = to_lds<double>(smem + lay.w);
+  ch.g = to_lds<uint16_t>(smem + lay.g);
+  ch.gam = to_lds<uint8_t>(smem + lay.gam);
+  BigCtx bx;
+  bx.kcap = kcap;
+  bx.S = ssvs_scalar_layout(kcap);
+  bx.xs = xs_ws + (size_t)w * (size_t)kcap * 64;
+  bx.tile = to_lds<double>(smem + lay.tile);
+  bx.rdt = to_lds<double>(smem + lay.rdt);
+  bx.y = to_lds<double>(smem + lay.y);
+  bx.bst = to_lds<double>(smem + lay.bst);
+  bx.gst = to_lds<uint16_t>(smem + lay.gst);
+  BigP BP;
+  BP.V = P.V; BP.A = P.A; BP.b = P.b; BP.l1 = P.l1; BP.l0 = P.l0;
+  BP.vdiag = nullptr;
+  BP.max_model_size = P.max_model_size;
+  ch.xty = P.xty;
+  ch.DF = P.nobs[0] + P.prior_df;
+  ch.ss0q = P.prior_ss + P.yty[0];
+  ch.mode = 0;
+  ch.sv = ch.sa = ch.sx = 1.0;
+  const uint8_t *gg = gammas + (size_t)row * p;
+  for (int j = lane; j < p; j += WAVE) ch.gam[j] = gg[j];
+  rebuild_g(ch, kcap);
+  if (ch.k > kcap) {
+    if (lane == 0) { out[row] = __builtin_nan(""); status_out[row] = CHAIN_MODEL_TOO_LARGE; }
+    return;
+  }
+  Model M;
+  M.logp = M.lp = M.ldv = M.lda = M.Q = M.c = M.SS = 0.0;
+  M.pd = true;
+  M.bad = 0;
+  big_build_body(BP, ch, M, model_ws + (size_t)w * bx.S.total, bx, false);
+  if (lane == 0) {
+    out[row] = M.logp;
+    status_out[row] = M.bad;
+  }
+}
+
+hipError_t launch_ssvs_big_logp(hipStream_t stream, const SsvsParams &P, int kcap, const uint8_t *gammas,
+                                const int *which, int nwhich, double *model_ws, double *xs_ws, double *out,
+                                int *status_out) {
+  const SsvsBigLds lay = ssvs_big_lds_layout(P.p, kcap);
+  hipError_t e = hipFuncSetAttribute((const void *)ssvs_big_logp_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ssvs_big_logp_kernel, dim3(nwhich), dim3(WAVE), lay.total, stream, P, kcap, gammas, which,
+                     nwhich, model_ws, xs_ws, out, status_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_ssvs_big(hipStream_t stream, const SsvsParams &P, int nsweeps) {
   const SsvsBigLds lay = ssvs_big_lds_layout(P.p, P.big_kcap);
   hipError_t e = hipFuncSetAttribute((const void *)ssvs_big_kernel,

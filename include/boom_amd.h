@@ -196,8 +196,9 @@ int ba_sync(ba_engine *e);
 int ba_set_lookahead(ba_engine *e, int32_t lookahead);
 int ba_draw_next(ba_engine *e);
 /* log_model_prob(gamma) for ngamma inclusion vectors (BregVsSampler.cpp:216-239)
- * on the regression model's sufficient statistics; BA_E_STATE once state-space
- * data are set (there they are per chain and move every sweep) */
+ * on the regression model's sufficient statistics, models of any size (up to 1024
+ * included variables); BA_E_STATE once state-space data are set (there they are per
+ * chain and move every sweep) */
 int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
                       double *out);
 

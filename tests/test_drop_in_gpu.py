@@ -19,8 +19,8 @@ from test_ssvs_gpu import make_engine
 pytestmark = pytest.mark.gpu
 
 
-def _case(p=40, nsig=5, seed=3):
-    X, y, _ = regression_data(400, p, nsig, seed=seed)
+def _case(p=40, nsig=5, seed=3, n=400):
+    X, y, _ = regression_data(n, p, nsig, seed=seed)
     suf = suf_from_xy(X, y)
     prior = spike_slab_prior(suf, nsig)
     g0 = np.zeros(p, np.uint8)
@@ -201,3 +201,27 @@ def test_log_model_prob_is_refused_in_state_space_mode():
                    sigma_upper_limit=sig_up)
     with pytest.raises(boom_amd.BoomAmdError):
         eng.log_model_prob(np.ones((1, p), np.uint8))
+
+
+def test_log_model_prob_of_models_beyond_64_variables(oracle):
+    """BregVsSampler::log_model_prob has no size limit (BregVsSampler.cpp:216-239): vectors
+    with more included variables than the LDS kernel holds go through the large-model
+    build, mixed freely with small ones in one call."""
+    suf, prior, g0 = _case(p=300, nsig=6, seed=13, n=1500)
+    eng = make_engine(2, 4, suf=suf, prior=prior, g0=g0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    gammas = np.zeros((9, 300), np.uint8)
+    for row, k in enumerate([3, 65, 100, 64, 129, 200, 0, 300, 70]):
+        gammas[row, rng.choice(300, k, replace=False)] = 1
+    gammas[:8, 0] = 1             # (the prior forces the intercept in: the last row stays illegal)
+    gammas[8, 0] = 0
+    want = oracle.log_model_prob(suf, prior, gammas)
+    got = eng.log_model_prob(gammas)
+    fin = np.isfinite(want)
+    assert fin[:8].all() and not fin[8] and np.array_equal(got[~fin], want[~fin])
+    assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(1.0, np.abs(want[fin]))) < 1e-9
+    # the chains' own models are untouched by it
+    eng.sweep(3)
+    ref = make_engine(2, 4, suf=suf, prior=prior, g0=g0)
+    ref.sweep(3)
+    assert _same(eng.get_states(), ref.get_states())
