@@ -284,6 +284,54 @@ def main():
             e2.close()
         curve[str(CHAINS_PER_GPU)] = round(value / world, 1)
 
+    # ---- the other BASELINE configurations at their per-GPU shapes (diagnostic extra
+    # key, outside the timed region: parity for them lives in tests/, these are rates
+    # measured in the same run as the headline) ----------------------------------
+    other = None
+    if not args.no_curve and world == 1:
+        from cases import bsts_priors, logit_data, probit_slab, state_space_data
+        other = {}
+        # configs[2]: bsts local level + regression, T=2000 p=100, 1024 chains
+        Xs, ys, _, _ = state_space_data(2000, 100, 5, seed=DATA_SEED)
+        pr3, ss3, sig_up = bsts_priors(Xs, ys, 5)
+        e3 = boom_amd.Engine(1024, seed=SAMPLER_SEED, device=local_rank)
+        e3.ss_set_data(ys, Xs, None)
+        e3.set_priors(pr3["b"], pr3["ominv"], pr3["pi"], pr3["df"], pr3["sigma_guess"],
+                      sigma_upper_limit=sig_up)
+        e3.ss_set_local_level(ss3["level_df"], ss3["level_sigma_guess"], ss3["level_sigma_upper_limit"],
+                              ss3["initial_state_mean"], ss3["initial_state_variance"],
+                              ss3["initial_level_sigma"])
+        e3.set_state(np.zeros(100, np.uint8))
+        e3.ss_sweep(50)
+        t0 = time.perf_counter()
+        e3.ss_sweep(200)
+        dt = time.perf_counter() - t0
+        other["configs[2] bsts local level + regression T=2000 p=100, 1024 chains"] = {
+            "sweeps_per_s": round(1024 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
+            "mean_model_size": round(float(e3.get_states()[0].sum(1).mean()), 2)}
+        e3.close()
+        # configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 4096 chains / 8 GPUs = 512
+        # (the reference's auxiliary-mixture imputer; it has no Polya-Gamma sampler)
+        Xl, yl, ntl, _ = logit_data(50000, 1024, 8, seed=DATA_SEED)
+        slab5, pi5 = probit_slab(Xl, ntl, 8)
+        e5 = boom_amd.Engine(512, seed=SAMPLER_SEED, device=local_rank)
+        e5.logit_set_data(Xl, yl, ntl, 5)
+        e5.sss_set_slab(slab5["mu"], slab5["prec"], scales_with_sigsq=False)
+        e5.set_spike(pi5)
+        g5 = np.zeros(1024, np.uint8)
+        g5[0] = 1
+        e5.set_state(g5)
+        e5.logit_sweep(15)
+        t0 = time.perf_counter()
+        e5.logit_sweep(30)
+        dt = time.perf_counter() - t0
+        gam5 = e5.get_states()[0]
+        other["configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 512 chains"] = {
+            "sweeps_per_s": round(512 * 30 / dt, 1), "ms_per_round": round(dt / 30 * 1e3, 2),
+            "mean_model_size": round(float(gam5.sum(1).mean()), 2),
+            "signal_inclusion_min": round(float(gam5[:, :8].mean(0).min()), 4)}
+        e5.close()
+
     # ---- CPU baseline: the oracle (a port of the reference algorithm) -------
     cpu = None
     if not args.no_cpu_baseline:
@@ -342,6 +390,7 @@ def main():
         "ess_traces": {k: round(v / (CHAINS_PER_GPU * trace_len), 4) for k, v in ess.items()},
         "decisions": decisions,
         "sweeps_per_sec_vs_chains_per_gpu": curve,
+        "other_configs": other,
         "suf_build_ms": round(suf_build_s * 1e3, 2),
         "signal_inclusion_min": round(float(incl[:N_SIGNAL].min()), 4),
         "null_inclusion_max": round(float(incl[N_SIGNAL:].max()), 4),
