@@ -55,6 +55,82 @@ struct CoefView {
   RegressionModel *model;
 };
 
+// boom.BinomialLogitModel(xdim, include_all) / BinomialProbitModel, filled by
+// add_dataset(successes, trials, predictors) as in BayesBoom (GlmModel_def.cpp:549-590).
+// The reference's sampler reads the model's data at every draw; here the data go to
+// the device once, when the sampler -- which brings clt_threshold -- is attached.
+struct PyBinomialModel {
+  int xdim;
+  bool logit;
+  int chains;
+  uint64_t seed;
+  int device;
+  std::vector<uint8_t> inc;          // coef.inc until the device model exists
+  Matrix X;
+  Vector y, n;
+  bool have_data = false;
+  Ptr<BinomialRegressionModelBase> impl;
+
+  PyBinomialModel(int xdim_, bool include_all, bool logit_, int chains_, uint64_t seed_, int device_)
+      : xdim(xdim_), logit(logit_), chains(chains_), seed(seed_), device(device_),
+        inc((size_t)xdim_, include_all ? 1 : 0) {
+    if (xdim_ <= 0) throw std::runtime_error("xdim must be positive");
+    if (!include_all) inc[0] = 1;    // "only the intercept starts out included"
+  }
+  void materialise(int clt_threshold) {
+    if (!have_data) throw std::runtime_error("add_dataset(successes, trials, predictors) before attaching a sampler");
+    if (logit) impl.reset(new BinomialLogitModel(X, y, n, clt_threshold, chains, seed, device));
+    else impl.reset(new BinomialProbitModel(X, y, n, clt_threshold, chains, seed, device));
+    impl->drop_all();
+    for (int j = 0; j < xdim; ++j)
+      if (inc[j]) impl->add(j);
+  }
+  void need_impl() const {
+    if (!impl) throw std::runtime_error("no sampler attached to the model yet");
+  }
+};
+struct BinomialCoefView {
+  PyBinomialModel *model;
+};
+
+template <class SamplerT, class ModelT>
+Ptr<SamplerT> make_binomial_sampler(PyBinomialModel &m, const Ptr<MvnModel> &slab,
+                                    const Ptr<VariableSelectionPrior> &spike, int clt_threshold) {
+  m.materialise(clt_threshold);
+  return Ptr<SamplerT>(new SamplerT(static_cast<ModelT *>(m.impl.get()), slab, spike));
+}
+
+template <class PyClass>
+void bind_binomial_model(PyClass &c) {
+  c.def("add_dataset",
+        [](PyBinomialModel &m, const NpArray &successes, const NpArray &trials, const NpArray &predictors) {
+          m.X = matrix_from(predictors);
+          m.y = vector_from(successes);
+          m.n = vector_from(trials);
+          if (m.X.ncol() != m.xdim) throw std::runtime_error("predictors do not match xdim");
+          m.have_data = true;
+        },
+        py::arg("successes"), py::arg("trials"), py::arg("predictors"))
+      .def_property_readonly("xdim", [](const PyBinomialModel &m) { return m.xdim; })
+      .def_property_readonly("coef", py::cpp_function([](PyBinomialModel &m) { return BinomialCoefView{&m}; },
+                                                      py::keep_alive<0, 1>()))
+      .def_property_readonly("Beta", [](const PyBinomialModel &m) { m.need_impl(); return to_numpy(m.impl->Beta()); })
+      .def("set_method", [](PyBinomialModel &m, const Ptr<PosteriorSampler> &s) { m.need_impl(); m.impl->set_method(s); })
+      .def("sample_posterior", [](PyBinomialModel &m) { m.need_impl(); m.impl->sample_posterior(); })
+      .def("chain_states", [](const PyBinomialModel &m) {
+        m.need_impl();
+        std::vector<uint8_t> g;
+        Vector b;
+        m.impl->chain_states(g, b);
+        const py::ssize_t p = m.xdim, C = (py::ssize_t)g.size() / p;
+        py::array_t<uint8_t> G({C, p});
+        py::array_t<double> B({C, p});
+        std::memcpy(G.mutable_data(), g.data(), g.size());
+        std::memcpy(B.mutable_data(), b.data(), b.size() * 8);
+        return py::make_tuple(G, B);
+      }, "inclusion indicators and coefficients of EVERY chain");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_boom, boom) {
@@ -148,4 +224,153 @@ PYBIND11_MODULE(_boom, boom) {
       .def("set_correlation_swap_threshold", &BregVsSampler::set_correlation_swap_threshold)
       .def("set_lookahead", &BregVsSampler::set_lookahead,
            "run n sweeps per launch and hand them out one sample_posterior() at a time");
+
+  // ---- logit / probit spike and slab (GlmModel_def.cpp:549-590, :966-1010) ----------
+  py::class_<MvnModel, Ptr<MvnModel>>(boom, "MvnModel")
+      .def(py::init([](const NpArray &mu, const NpArray &Sigma, bool ivar) {
+             if (!ivar) throw std::runtime_error("MvnModel: pass the precision (ivar=True); the engine works in precisions");
+             return new MvnModel(vector_from(mu), matrix_from(Sigma));
+           }),
+           py::arg("mu"), py::arg("Sigma"), py::arg("ivar") = false,
+           "A slab whose precision does not scale with sigma^2 (MvnBase).")
+      .def_property_readonly("dim", &MvnModel::dim);
+
+  py::class_<BinomialCoefView>(boom, "BinomialGlmCoefs")
+      .def("drop_all", [](BinomialCoefView &c) {
+        std::fill(c.model->inc.begin(), c.model->inc.end(), 0);
+        if (c.model->impl) c.model->impl->drop_all();
+      })
+      .def("add", [](BinomialCoefView &c, int i) {
+        c.model->inc.at(i) = 1;
+        if (c.model->impl) c.model->impl->add(i);
+      })
+      .def("drop", [](BinomialCoefView &c, int i) {
+        c.model->inc.at(i) = 0;
+        if (c.model->impl) c.model->impl->drop(i);
+      })
+      .def_property_readonly("inc", [](const BinomialCoefView &c) {
+        std::vector<bool> g(c.model->xdim);
+        for (int j = 0; j < c.model->xdim; ++j) g[j] = c.model->impl ? c.model->impl->inc()[j] : c.model->inc[j] != 0;
+        return g;
+      })
+      .def_property_readonly("Beta", [](const BinomialCoefView &c) {
+        c.model->need_impl();
+        return to_numpy(c.model->impl->Beta());
+      });
+
+  struct PyLogit : PyBinomialModel { using PyBinomialModel::PyBinomialModel; };
+  struct PyProbit : PyBinomialModel { using PyBinomialModel::PyBinomialModel; };
+  py::class_<PyBinomialModel>(boom, "_BinomialRegressionModel");
+  py::class_<PyLogit, PyBinomialModel> logit(boom, "BinomialLogitModel");
+  logit.def(py::init([](int xdim, bool include_all, int chains, uint64_t seed, int device) {
+              return new PyLogit(xdim, include_all, true, chains, seed, device);
+            }),
+            py::arg("xdim"), py::arg("include_all") = true, py::arg("chains") = 1,
+            py::arg("seed") = 8675309ull, py::arg("device") = 0);
+  bind_binomial_model(logit);
+  py::class_<PyProbit, PyBinomialModel> probit(boom, "BinomialProbitModel");
+  probit.def(py::init([](int xdim, bool include_all, int chains, uint64_t seed, int device) {
+               return new PyProbit(xdim, include_all, false, chains, seed, device);
+             }),
+             py::arg("xdim"), py::arg("include_all") = true, py::arg("chains") = 1,
+             py::arg("seed") = 8675309ull, py::arg("device") = 0);
+  bind_binomial_model(probit);
+
+  py::class_<BinomialLogitSpikeSlabSampler, PosteriorSampler, Ptr<BinomialLogitSpikeSlabSampler>>(
+      boom, "BinomialLogitSpikeSlabSampler")
+      .def(py::init([](PyLogit &model, const Ptr<MvnModel> &slab, const Ptr<VariableSelectionPrior> &spike,
+                       int clt_threshold, py::object) {
+             return make_binomial_sampler<BinomialLogitSpikeSlabSampler, BinomialLogitModel>(model, slab, spike,
+                                                                                             clt_threshold);
+           }),
+           py::arg("model"), py::arg("slab"), py::arg("spike"), py::arg("clt_threshold") = 5,
+           py::arg("seeding_rng") = py::none(), py::keep_alive<1, 2>())
+      .def("limit_model_selection", &BinomialLogitSpikeSlabSampler::limit_model_selection);
+  py::class_<BinomialProbitSpikeSlabSampler, PosteriorSampler, Ptr<BinomialProbitSpikeSlabSampler>>(
+      boom, "BinomialProbitSpikeSlabSampler")
+      .def(py::init([](PyProbit &model, const Ptr<MvnModel> &slab, const Ptr<VariableSelectionPrior> &spike,
+                       int clt_threshold, py::object) {
+             return make_binomial_sampler<BinomialProbitSpikeSlabSampler, BinomialProbitModel>(model, slab, spike,
+                                                                                               clt_threshold);
+           }),
+           py::arg("model"), py::arg("slab"), py::arg("spike"), py::arg("clt_threshold") = 5,
+           py::arg("seeding_rng") = py::none(), py::keep_alive<1, 2>())
+      .def("limit_model_selection", &BinomialProbitSpikeSlabSampler::limit_model_selection);
+
+  // ---- bsts: state models, the state-space regression and its sampler
+  // (StateModelWrapper.cpp:73-260, StateSpaceModelWrapper.cpp:203-260, :476-490).  The
+  // reference attaches one sampler object per variance and one to the observation
+  // model; here each state model takes its prior through set_prior and the
+  // observation model's three priors go to StateSpacePosteriorSampler.
+  py::class_<LocalLevelStateModel, Ptr<LocalLevelStateModel>>(boom, "LocalLevelStateModel")
+      .def(py::init<double>(), py::arg("sigma") = 1.0)
+      .def("set_initial_state_mean", &LocalLevelStateModel::set_initial_state_mean)
+      .def("set_initial_state_variance", &LocalLevelStateModel::set_initial_state_variance)
+      .def("set_prior", &LocalLevelStateModel::set_prior, py::arg("df"), py::arg("sigma_guess"),
+           py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
+           "ZeroMeanGaussianConjSampler(model, df, sigma_guess) + set_sigma_upper_limit");
+  py::class_<LocalLinearTrendStateModel, Ptr<LocalLinearTrendStateModel>>(boom, "LocalLinearTrendStateModel")
+      .def(py::init<>())
+      .def("set_initial_state_mean", [](LocalLinearTrendStateModel &m, const NpArray &v) { m.set_initial_state_mean(vector_from(v)); })
+      .def("set_initial_state_variance", [](LocalLinearTrendStateModel &m, const NpArray &diag) { m.set_initial_state_variance(vector_from(diag)); })
+      .def("set_initial_sigma", &LocalLinearTrendStateModel::set_initial_sigma)
+      .def("set_prior", &LocalLinearTrendStateModel::set_prior, py::arg("which_variable"), py::arg("df"),
+           py::arg("sigma_guess"), py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
+           "ZeroMeanMvnIndependenceSampler(model, df, sigma_guess, which_variable) + set_sigma_upper_limit");
+  py::class_<SeasonalStateModel, Ptr<SeasonalStateModel>>(boom, "SeasonalStateModel")
+      .def(py::init<int, int>(), py::arg("nseasons"), py::arg("season_duration") = 1)
+      .def_property_readonly("state_dimension", &SeasonalStateModel::state_dimension)
+      .def("set_sigsq", &SeasonalStateModel::set_sigsq)
+      .def("set_initial_state_mean", [](SeasonalStateModel &m, const NpArray &v) { m.set_initial_state_mean(vector_from(v)); })
+      .def("set_initial_state_variance", &SeasonalStateModel::set_initial_state_variance)
+      .def("set_prior", &SeasonalStateModel::set_prior, py::arg("df"), py::arg("sigma_guess"),
+           py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity());
+
+  py::class_<StateSpaceRegressionModel, Ptr<StateSpaceRegressionModel>>(boom, "StateSpaceRegressionModel")
+      .def(py::init([](const NpArray &response, const NpArray &predictors, const std::vector<bool> &is_observed,
+                       int chains, uint64_t seed, int device) {
+             return new StateSpaceRegressionModel(vector_from(response), matrix_from(predictors), is_observed,
+                                                  chains, seed, device);
+           }),
+           py::arg("response"), py::arg("predictors"), py::arg("is_observed") = std::vector<bool>(),
+           py::arg("chains") = 1, py::arg("seed") = 8675309ull, py::arg("device") = 0)
+      .def_property_readonly("xdim", &StateSpaceRegressionModel::xdim)
+      .def_property_readonly("time_dimension", &StateSpaceRegressionModel::time_dimension)
+      .def_property_readonly("state_dimension", &StateSpaceRegressionModel::state_dimension)
+      .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<LocalLevelStateModel> &s) { m.add_state(s); })
+      .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<LocalLinearTrendStateModel> &s) { m.add_state(s); })
+      .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<SeasonalStateModel> &s) { m.add_state(s); })
+      .def("set_method", [](StateSpaceRegressionModel &m, const Ptr<PosteriorSampler> &s) { m.set_method(s); })
+      .def("sample_posterior", &StateSpaceRegressionModel::sample_posterior)
+      .def("state", [](const StateSpaceRegressionModel &m, int chain) {
+        if (!m.structural()) return py::array(to_numpy(m.state(chain)));
+        const Matrix st = m.structural_state(chain);
+        py::array_t<double> out({(py::ssize_t)st.nrow(), (py::ssize_t)st.ncol()});
+        auto w = out.mutable_unchecked<2>();
+        for (int i = 0; i < st.nrow(); ++i)
+          for (int j = 0; j < st.ncol(); ++j) w(i, j) = st(i, j);
+        return py::array(out);
+      }, py::arg("chain") = 0, "the state draw of one chain: (T,) for the local level, (state_dimension, T) otherwise")
+      .def("state_variances", [](const StateSpaceRegressionModel &m, int chain) {
+        if (!m.structural()) { Vector v(1, m.level_sigsq(chain)); return to_numpy(v); }
+        return to_numpy(m.state_variances(chain));
+      }, py::arg("chain") = 0)
+      .def("chain_states", [](const StateSpaceRegressionModel &m) {
+        const py::ssize_t C = m.engine()->chains(), p = m.xdim();
+        py::array_t<uint8_t> G({C, p});
+        py::array_t<double> B({C, p}), S((py::ssize_t)C);
+        m.engine()->check(ba_get_states(m.engine()->get(), G.mutable_data(), B.mutable_data(), S.mutable_data()));
+        return py::make_tuple(G, B, S);
+      }, "inclusion indicators, coefficients and residual variances of EVERY chain");
+
+  py::class_<StateSpacePosteriorSampler, PosteriorSampler, Ptr<StateSpacePosteriorSampler>>(
+      boom, "StateSpacePosteriorSampler")
+      .def(py::init([](StateSpaceRegressionModel *model, const Ptr<MvnGivenScalarSigma> &slab,
+                       const Ptr<ChisqModel> &residual_precision_prior, const Ptr<VariableSelectionPrior> &spike,
+                       double sigma_upper_limit, py::object) {
+             return new StateSpacePosteriorSampler(model, slab, residual_precision_prior, spike, sigma_upper_limit);
+           }),
+           py::arg("model"), py::arg("slab"), py::arg("residual_precision_prior"), py::arg("spike"),
+           py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
+           py::arg("seeding_rng") = py::none(), py::keep_alive<1, 2>());
 }

@@ -59,3 +59,88 @@ def test_lm_spike_driver_loop_on_the_pybind_module(oracle, lookahead):
     ol = oracle.ssvs_run(suf, prior, ssvs_options(), ("philox", seed, chains - 1), g0, niter)
     if lookahead == 1:
         assert np.array_equal(G[-1], ol["gamma"][-1])
+
+
+@pytest.mark.parametrize("kind", ["logit", "probit"])
+def test_binomial_spike_slab_on_the_pybind_module(kind):
+    """boom.BinomialLogitModel(xdim, include_all).add_dataset(...) +
+    boom.BinomialLogitSpikeSlabSampler(model, slab, spike, clt_threshold) (BayesBoom's
+    call shapes, GlmModel_def.cpp:549-590, :966-1010): the loop's draws are those of the
+    engine driven through the C-ABI with the same seed (which the oracle checks)."""
+    import boom_amd
+    import boom_amd._boom as boom
+    from cases import logit_data, probit_data, probit_slab
+    n, p, nsig, niter, seed, chains = 300, 9, 3, 10, 77, 4
+    X, y, nt, _ = (logit_data if kind == "logit" else probit_data)(n, p, nsig, seed=4, max_trials=3)
+    slab, pi = probit_slab(X, nt, nsig)
+    Model = boom.BinomialLogitModel if kind == "logit" else boom.BinomialProbitModel
+    Sampler = boom.BinomialLogitSpikeSlabSampler if kind == "logit" else boom.BinomialProbitSpikeSlabSampler
+    model = Model(p, False, chains=chains, seed=seed)
+    model.add_dataset(y, nt, X)
+    sampler = Sampler(model, boom.MvnModel(slab["mu"], slab["prec"], True),
+                      boom.VariableSelectionPrior(pi), 5)
+    model.set_method(sampler)
+    assert list(model.coef.inc) == [True] + [False] * (p - 1)
+    draws = np.zeros((niter, p))
+    for i in range(niter):
+        model.sample_posterior()
+        draws[i] = model.coef.Beta
+    eng = boom_amd.Engine(chains, seed=seed)
+    (eng.logit_set_data if kind == "logit" else eng.probit_set_data)(X, y, nt, 5)
+    eng.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+    eng.set_spike(pi)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    eng.set_state(g0)
+    for i in range(niter):
+        (eng.logit_sweep if kind == "logit" else eng.probit_sweep)(1)
+        assert np.array_equal(draws[i], eng.get_state(0)[1]), i
+    G, B = model.chain_states()
+    assert np.array_equal(G, eng.get_states()[0]) and np.array_equal(B, eng.get_states()[1])
+
+
+def test_structural_time_series_on_the_pybind_module():
+    """boom.StateSpaceRegressionModel + LocalLinearTrendStateModel + SeasonalStateModel +
+    StateSpacePosteriorSampler: same draws as the engine through the C-ABI."""
+    import boom_amd
+    import boom_amd._boom as boom
+    from cases import bsts_priors, structural_data, structural_spec
+    T, p, seed, chains, niter = 120, 4, 5, 3, 6
+    X, y, _, obs = structural_data(T, p, 2, 4, seed=3, missing_frac=0.05)
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    spec = structural_spec(y, 2, 4)
+    model = boom.StateSpaceRegressionModel(y, X, [bool(o) for o in obs], chains=chains, seed=seed)
+    trend = boom.LocalLinearTrendStateModel()
+    trend.set_initial_sigma(spec["var_initial_sigma"][0], spec["var_initial_sigma"][1])
+    for i in range(2):
+        trend.set_prior(i, spec["var_df"][i], spec["var_sigma_guess"][i], spec["var_sigma_upper_limit"][i])
+    trend.set_initial_state_mean(spec["initial_state_mean"][:2])
+    trend.set_initial_state_variance(spec["initial_state_variance"][:2])
+    seas = boom.SeasonalStateModel(4)
+    seas.set_sigsq(spec["var_initial_sigma"][2] ** 2)
+    seas.set_prior(spec["var_df"][2], spec["var_sigma_guess"][2], spec["var_sigma_upper_limit"][2])
+    seas.set_initial_state_mean(spec["initial_state_mean"][2:])
+    seas.set_initial_state_variance(spec["initial_state_variance"][2])
+    model.add_state(trend)
+    model.add_state(seas)
+    sampler = boom.StateSpacePosteriorSampler(model, boom.MvnGivenScalarSigma(prior["b"], prior["ominv"]),
+                                              boom.ChisqModel(prior["df"], prior["sigma_guess"]),
+                                              boom.VariableSelectionPrior(prior["pi"]), sig_up)
+    model.set_method(sampler)
+    assert model.state_dimension == 5
+    for _ in range(niter):
+        model.sample_posterior()
+    eng = boom_amd.Engine(chains, seed=seed)
+    eng.ss_set_data(y, X, obs)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
+                   sigma_upper_limit=sig_up)
+    eng.ss_set_structural(2, 4, spec["var_df"], spec["var_sigma_guess"], spec["var_sigma_upper_limit"],
+                          spec["var_initial_sigma"], spec["initial_state_mean"], spec["initial_state_variance"])
+    eng.set_state(np.zeros(p, np.uint8))
+    eng.ss_sweep(niter)
+    G, B, S = model.chain_states()
+    g, b, s = eng.get_states()
+    assert np.array_equal(G, g) and np.array_equal(B, b) and np.array_equal(S, s)
+    want = eng.ss_get_structural(chains - 1)
+    assert np.array_equal(model.state(chains - 1), want["state"].T)
+    assert np.array_equal(model.state_variances(chains - 1), want["variances"])
