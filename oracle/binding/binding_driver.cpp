@@ -8,7 +8,9 @@
 #include <cstring>
 #include <string>
 
+#include "DeviceBinomialLogitSpikeSlabSampler.hpp"
 #include "DeviceBregVsSampler.hpp"
+#include "Models/MvnModel.hpp"
 #include "LinAlg/Matrix.hpp"
 #include "LinAlg/SpdMatrix.hpp"
 #include "Models/ChisqModel.hpp"
@@ -85,6 +87,65 @@ int ref_binding_run(int n, int p, const double *X, const double *y,
         probe_beta[j] = beta[j];
       }
       *probe_sigsq = s2;
+    }
+    return 0;
+  } catch (std::exception &e) {
+    g_binding_error = e.what();
+    return -1;
+  }
+}
+
+// The same for the logit sampler: BOOM's BinomialLogitModel (data added one
+// BinomialRegressionData at a time, as the reference's callers do), MvnModel slab,
+// VariableSelectionPrior, and sample_posterior() with the device sampler attached.
+int ref_binding_logit_run(int n, int p, const double *X, const double *y, const double *ntrials,
+                          const double *slab_mean, const double *slab_precision, const double *pi,
+                          int clt_threshold, int max_flips, int chains, uint64_t seed,
+                          const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                          double *out_beta, uint64_t *out_seed, int probe_chain,
+                          uint8_t *probe_gamma, double *probe_beta) {
+  try {
+    GlobalRng::rng.seed(seed);
+    Ptr<BinomialLogitModel> model(new BinomialLogitModel(p, true));
+    for (int i = 0; i < n; ++i) {
+      Vector x(p);
+      for (int j = 0; j < p; ++j) x[j] = X[(size_t)j * n + i];
+      NEW(BinomialRegressionData, dp)(y[i], ntrials[i], x);
+      model->add_data(dp);
+    }
+    Vector mu(p), piv(p);
+    SpdMatrix prec(p);
+    for (int j = 0; j < p; ++j) {
+      mu[j] = slab_mean[j];
+      piv[j] = pi[j];
+      for (int i = 0; i < p; ++i) prec(i, j) = slab_precision[(size_t)j * p + i];
+    }
+    NEW(MvnModel, slab)(mu, prec, true);
+    NEW(VariableSelectionPrior, spike)(piv);
+    model->coef().drop_all();
+    for (int j = 0; j < p; ++j)
+      if (init_gamma[j]) model->coef().add(j);
+    NEW(DeviceBinomialLogitSpikeSlabSampler, sampler)(model.get(), slab, spike, clt_threshold, chains);
+    if (max_flips > 0) sampler->limit_model_selection(max_flips);
+    if (out_seed) *out_seed = sampler->device_seed();
+    model->set_method(sampler);
+    for (int s = 0; s < nsweeps; ++s) {
+      model->sample_posterior();
+      const Selector &inc(model->coef().inc());
+      const Vector beta = model->Beta();
+      for (int j = 0; j < p; ++j) {
+        out_gamma[(size_t)s * p + j] = inc[j] ? 1 : 0;
+        out_beta[(size_t)s * p + j] = beta[j];
+      }
+    }
+    if (probe_gamma) {
+      Selector inc(p, false);
+      Vector beta;
+      sampler->chain_state(probe_chain, inc, beta);
+      for (int j = 0; j < p; ++j) {
+        probe_gamma[j] = inc[j] ? 1 : 0;
+        probe_beta[j] = beta[j];
+      }
     }
     return 0;
   } catch (std::exception &e) {

@@ -68,3 +68,42 @@ def test_boom_model_driven_by_the_device_sampler(oracle, lookahead):
     ol = oracle.ssvs_run(suf, prior, opts, ("philox", dev_seed.value, chains - 1), g0, nsw)
     assert np.array_equal(pg, ol["gamma"][-1])
     assert abs(ps.value - ol["sigsq"][-1]) < 1e-8 * ps.value
+
+
+@pytest.mark.skipif(not os.path.exists(BINDING_SO),
+                    reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
+@pytest.mark.parametrize("max_trials,max_flips", [(1, -1), (3, 7)])
+def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_flips):
+    """BOOM's BinomialLogitModel (data added observation by observation), MvnModel slab and
+    VariableSelectionPrior, stepped by model->sample_posterior() with
+    oracle/binding/DeviceBinomialLogitSpikeSlabSampler attached: what the BOOM model sees
+    after every draw is the oracle's chain 0 on the same Philox key (f3's boundary)."""
+    from cases import logit_data, probit_slab
+    L = C.CDLL(BINDING_SO)
+    L.ref_binding_last_error.restype = C.c_char_p
+    n, p, nsig, chains, nsw, seed = 400, 12, 4, 5, 20, 99
+    X, y, nt, _ = logit_data(n, p, nsig, seed=8, max_trials=max_trials)
+    slab, pi = probit_slab(X, nt, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    gam = np.zeros((nsw, p), np.uint8)
+    beta = np.zeros((nsw, p))
+    dev_seed = C.c_uint64()
+    pg = np.zeros(p, np.uint8)
+    pb = np.zeros(p)
+    rc = L.ref_binding_logit_run(
+        n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(nt)), _dp(f64(slab["mu"])), _dp(fcol(slab["prec"])),
+        _dp(f64(pi)), 5, C.c_int(max_flips), chains, C.c_uint64(seed), _u8(g0), nsw, _u8(gam), _dp(beta),
+        C.byref(dev_seed), chains - 1, _u8(pg), _dp(pb))
+    assert rc == 0, L.ref_binding_last_error().decode()
+    o = oracle.logit_run(X, y, nt, slab, pi, ("philox", dev_seed.value, 0), g0, np.zeros(p), nsw,
+                         max_flips=max_flips)
+    assert o["status"] == 0
+    for s in range(nsw):
+        assert np.array_equal(gam[s], o["gamma"][s]), s
+        err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
+        assert err < 1e-8, (s, err)
+    ol = oracle.logit_run(X, y, nt, slab, pi, ("philox", dev_seed.value, chains - 1), g0, np.zeros(p), nsw,
+                          max_flips=max_flips)
+    assert np.array_equal(pg, ol["gamma"][-1])
+    assert np.max(np.abs(pb - ol["beta"][-1]) / np.maximum(np.abs(ol["beta"][-1]), 1e-3)) < 1e-8
