@@ -310,6 +310,44 @@ def main():
             "sweeps_per_s": round(1024 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
             "mean_model_size": round(float(e3.get_states()[0].sum(1).mean()), 2)}
         e3.close()
+        # configs[3] per GPU: n=1e5 p=4096, 8192 chains / 8 GPUs = 1024 (the design matrix is
+        # drawn on the device: 3.3 GB; X'X by the MFMA syrk; 32 signals)
+        n4, p4, sig4 = 100000, 4096, 32
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(DATA_SEED)
+        X4 = torch.randn((p4, n4), dtype=torch.float64, device="cuda", generator=gen)   # column-major n x p
+        X4[0].fill_(1.0)
+        b4 = torch.zeros(p4, dtype=torch.float64, device="cuda")
+        b4[:sig4] = torch.tensor([(1.0 + 0.1 * (i % 7)) * (-1.0) ** i for i in range(sig4)],
+                                 dtype=torch.float64, device="cuda")
+        y4 = (b4[:sig4, None] * X4[:sig4]).sum(0) + torch.randn(n4, dtype=torch.float64, device="cuda", generator=gen)
+        torch.cuda.synchronize()
+        e4 = boom_amd.Engine(1024, seed=SAMPLER_SEED, device=local_rank)
+        t0 = time.perf_counter()
+        e4.build_suf_from_xy_device(n4, p4, X4.data_ptr(), y4.data_ptr())
+        e4.sync()
+        build4 = time.perf_counter() - t0
+        del X4
+        s4 = e4.get_suf()
+        pr4 = spike_slab_prior(dict(xtx=s4["xtx"], xty=s4["xty"], yty=s4["yty"], n=s4["n"],
+                                    sumy=s4["ybar"] * s4["n"], xsum=s4["xbar"] * s4["n"]), sig4)
+        e4.set_priors(pr4["b"], pr4["ominv"], pr4["pi"], pr4["df"], pr4["sigma_guess"])
+        g4 = np.zeros(p4, np.uint8)
+        g4[0] = 1
+        e4.set_state(g4)
+        e4.sweep(60)
+        t0 = time.perf_counter()
+        e4.sweep(40)
+        dt = time.perf_counter() - t0
+        gam4 = e4.get_states()[0]
+        other["configs[3] per GPU: spike-and-slab n=1e5 p=4096, 1024 chains"] = {
+            "sweeps_per_s": round(1024 * 40 / dt, 1), "ms_per_round": round(dt / 40 * 1e3, 3),
+            "suf_build_ms": round(build4 * 1e3, 1),
+            "mean_model_size": round(float(gam4.sum(1).mean()), 2),
+            "signal_inclusion_min": round(float(gam4[:, :sig4].mean(0).min()), 4)}
+        e4.close()
+        del s4, pr4
+        torch.cuda.empty_cache()
         # configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 4096 chains / 8 GPUs = 512
         # (the reference's auxiliary-mixture imputer; it has no Polya-Gamma sampler)
         Xl, yl, ntl, _ = logit_data(50000, 1024, 8, seed=DATA_SEED)
