@@ -87,6 +87,7 @@ SIGNATURES = {
     "ba_get_traces": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "ba_enable_draws": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_get_draws": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _u8p, _dp, _dp]),
+    "ba_predict": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "ba_get_coefficient_traces": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
                                             C.POINTER(C.c_int32), _dp]),
     "ba_stream": (C.c_void_p, [C.c_void_p]),
@@ -362,6 +363,15 @@ class Engine:
         s = np.zeros(nsweeps)
         self._check(self.lib.ba_get_draws(self._h, chain, nsweeps, _b(g), _p(b), _p(s)))
         return g, b, s
+
+    def predict(self, newX, first_draw, ndraws):
+        """posterior predictive means newX beta for the recorded draws [first_draw,
+        first_draw + ndraws) of every chain: chains x ndraws x len(newX)"""
+        Xn = np.asfortranarray(np.atleast_2d(newX), dtype=np.float64)
+        out = np.zeros((self.chains, ndraws, Xn.shape[0]))
+        self._check(self.lib.ba_predict(self._h, first_draw, ndraws, Xn.shape[0],
+                                        Xn.ctypes.data_as(_dp), _p(out)))
+        return out
 
     def get_coefficient_traces(self, nsweeps, variables):
         v = np.ascontiguousarray(variables, dtype=np.int32)

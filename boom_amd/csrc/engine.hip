@@ -49,6 +49,9 @@ hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const 
 hipError_t launch_ssvs_big_logp(hipStream_t stream, const SsvsParams &P, int kcap, const uint8_t *gammas,
                                 const int *which, int nwhich, double *model_ws, double *xs_ws, double *out,
                                 int *status_out);
+hipError_t launch_predict(hipStream_t stream, const double *trace_k, const uint16_t *rec_idx,
+                          const double *rec_beta, int stride, int cap, int first_draw, int ndraws,
+                          int chains, int p, const double *newX, int nnew, double *out);
 int xtwx_cols_planes(int64_t n);
 hipError_t launch_xtwx_cols(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
                             const int32_t *req, int R, const double *base, double *V,
@@ -1861,6 +1864,29 @@ int ba_get_draws(ba_engine *e, int64_t chain, int32_t nsweeps, uint8_t *gamma,
   int rc = ba_sync(e);
   if (rc) return rc;
   return read_record(e, chain, 0, nsweeps, gamma, beta, sigsq);
+}
+
+int ba_predict(ba_engine *e, int32_t first_draw, int32_t ndraws, int32_t nnew, const double *newX,
+               double *out) {
+  ENGINE_PROLOGUE(e);
+  if (e->trace_stride <= 0 || e->drec_idx.count == 0)
+    return fail(BA_E_STATE, "draw recording is not enabled");
+  if (!newX || !out || nnew <= 0) return fail(BA_E_INVALID, "bad argument");
+  if (first_draw < 0 || ndraws <= 0 || first_draw + ndraws > e->trace_stride)
+    return fail(BA_E_INVALID, "draw range out of the record");
+  if (ndraws > 65535 || e->cfg.chains > 65535) return fail(BA_E_INVALID, "too many draws or chains for one call");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains;
+  DevBuf<double> dX, dout;
+  HIP_TRY(dX.resize((size_t)nnew * e->p));
+  HIP_TRY(dout.resize(C * (size_t)ndraws * nnew));
+  HIP_TRY(hipMemcpyAsync(dX.ptr, newX, (size_t)nnew * e->p * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(launch_predict(e->stream, e->dtr_k.ptr, e->drec_idx.ptr, e->drec_beta.ptr, e->trace_stride,
+                         e->rec_cap, first_draw, ndraws, (int)C, e->p, dX.ptr, nnew, dout.ptr));
+  HIP_TRY(hipMemcpyAsync(out, dout.ptr, C * (size_t)ndraws * nnew * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return BA_OK;
 }
 
 int ba_get_coefficient_traces(ba_engine *e, int32_t nsweeps, int32_t nvars,

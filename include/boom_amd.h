@@ -313,6 +313,13 @@ int ba_enable_draws(ba_engine *e, int32_t max_sweeps);
 int ba_get_draws(ba_engine *e, int64_t chain, int32_t nsweeps, uint8_t *gamma,
                  double *beta, double *sigsq);
 
+/* Posterior predictive means from the record (lm_spike.predict, spikeslab.py:530-546:
+ * coefficient_draws[burn:, :] @ predictors.T), all chains at once: draws
+ * [first_draw, first_draw + ndraws) of the last recorded ba_sweep call (first_draw =
+ * the caller's burn-in), newX column-major nnew x p, out chains x ndraws x nnew. */
+int ba_predict(ba_engine *e, int32_t first_draw, int32_t ndraws, int32_t nnew,
+               const double *newX, double *out);
+
 /* the recorded coefficient paths of chosen variables (ESS of the largest
  * coefficients): out is chains x nvars x nsweeps, 0 where a variable was
  * excluded */

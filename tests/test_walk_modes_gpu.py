@@ -121,3 +121,29 @@ def test_every_draw_of_one_long_launch_matches_the_oracle(oracle, case, waves, p
             err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
             assert err < 1e-8, (case, c, s, err)
             assert abs(sig[s] - o["sigsq"][s]) < 1e-8 * sig[s], (case, c, s)
+
+
+def test_predict_from_the_record():
+    """lm_spike.predict (spikeslab.py:530-546) is coefficient_draws[burn:, :] @
+    predictors.T on the draws the caller kept; ba_predict forms it on the device from
+    its own record, for every chain."""
+    import boom_amd
+    X, y, _ = regression_data(500, 40, 5, seed=2)
+    suf = suf_from_xy(X, y)
+    prior = spike_slab_prior(suf, 5)
+    eng = boom_amd.Engine(6, seed=9)
+    eng.build_suf_from_xy(X, y)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+    g0 = np.zeros(40, np.uint8)
+    g0[0] = 1
+    eng.set_state(g0)
+    nsw, burn = 50, 12
+    eng.enable_draws(nsw)
+    eng.sweep(nsw)
+    newX = np.random.Generator(np.random.PCG64(3)).standard_normal((33, 40))
+    got = eng.predict(newX, burn, nsw - burn)
+    assert got.shape == (6, nsw - burn, 33)
+    for c in (0, 5):
+        _, beta, _ = eng.get_draws(c, nsw)
+        want = beta[burn:] @ newX.T
+        assert np.max(np.abs(got[c] - want)) < 1e-12 * max(1.0, np.abs(want).max())
