@@ -28,8 +28,10 @@ constexpr int LDP = KC + 2; // padded panel stride (doubles)
 __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict__ X,
                                                        int64_t n, int p,
                                                        double *__restrict__ xtx) {
-  __shared__ double sA[TILE * LDP];
-  __shared__ double sB[TILE * LDP];
+  // two panels in LDS: the next one is fetched (into registers, then LDS) while the
+  // matrix cores work on the current one
+  __shared__ double sA[2][TILE * LDP];
+  __shared__ double sB[2][TILE * LDP];
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (tj > ti) return;  // lower block-triangle only; mirrored on store
   const int I0 = ti * TILE, J0 = tj * TILE;
@@ -52,25 +54,43 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
   const int64_t rbeg = (int64_t)blockIdx.z * per * KC;
   const int64_t rend = (rbeg + per * KC < n) ? rbeg + per * KC : n;
   xtx += (size_t)blockIdx.z * (size_t)p * (size_t)p;
-  for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
-    // stage 64 columns x 32 rows of each strip: 2048 doubles, 8 per thread
+  // a panel = 64 columns x 32 rows of each strip: 2048 doubles, 8 per thread
+  const int prow = tid & 31, pcol0 = tid >> 5;   // columns pcol0 + 8 it
+  double ra[8], rb[8];
+  auto fetch = [&](int64_t r0) {
+    const int64_t r = r0 + prow;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int e = it * 256 + tid;
-      const int col = e >> 5, row = e & 31;
-      const int64_t r = r0 + row;
+      const int col = pcol0 + 8 * it;
       const int ci = I0 + col, cj = J0 + col;
-      sA[col * LDP + row] = (r < rend && ci < p) ? X[(int64_t)ci * n + r] : 0.0;
-      sB[col * LDP + row] = (r < rend && cj < p) ? X[(int64_t)cj * n + r] : 0.0;
+      ra[it] = (r < rend && ci < p) ? X[(int64_t)ci * n + r] : 0.0;
+      rb[it] = (r < rend && cj < p) ? X[(int64_t)cj * n + r] : 0.0;
     }
-    __syncthreads();
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int col = pcol0 + 8 * it;
+      sA[buf][col * LDP + prow] = ra[it];
+      sB[buf][col * LDP + prow] = rb[it];
+    }
+  };
+  if (rbeg < rend) {
+    fetch(rbeg);
+    stash(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
+    const bool more = r0 + KC < rend;
+    if (more) fetch(r0 + KC);
 #pragma unroll
     for (int kk = 0; kk < KC / 4; ++kk) {
       double a[2], b[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        a[t] = sA[(wi * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
-        b[t] = sB[(wj * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
+        a[t] = sA[cur][(wi * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
+        b[t] = sB[cur][(wj * 32 + t * 16 + fc) * LDP + kk * 4 + fr];
       }
 #pragma unroll
       for (int ta = 0; ta < 2; ++ta)
@@ -78,7 +98,9 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
         for (int tb = 0; tb < 2; ++tb)
           acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
+    if (more) stash(cur ^ 1);   // (the other buffer was last read before the previous barrier)
     __syncthreads();
+    cur ^= 1;
   }
   // D layout of v_mfma_f64_16x16x4_f64: register q of lane l holds
   // row (l >> 4) + 4 q, column l & 15.
