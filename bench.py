@@ -268,7 +268,7 @@ def main():
     curve = None
     if not args.no_curve:
         curve = {}
-        for nch in (2048, 4096):
+        for nch in (2048, 4096, 8192):
             e2 = boom_amd.Engine(nch, seed=SAMPLER_SEED, device=local_rank)
             e2.build_suf_from_xy_device(N_OBS, P, Xd.data_ptr(), yd.data_ptr())
             e2.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"],

