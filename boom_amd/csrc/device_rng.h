@@ -102,6 +102,30 @@ struct SeqRng {
   }
 };
 
+// Sequential view that keeps the Philox block it last computed: the two numbers of a
+// block cost one evaluation (a draw that starts at an even position and consumes two
+// uniforms -- the common case of norm_rand -- is one Philox call).
+struct PairRng {
+  PhiloxKey key;
+  uint64_t pos, block;
+  double w0, w1;
+  bool have;
+  __device__ __forceinline__ void init(const PhiloxKey &k, uint64_t p) {
+    key = k; pos = p; block = 0; w0 = w1 = 0.0; have = false;
+  }
+  __device__ __forceinline__ double operator()() {
+    const uint64_t b = pos >> 1;
+    if (!have || b != block) {
+      philox_pair(key, b, &w0, &w1);
+      block = b;
+      have = true;
+    }
+    const double u = (pos & 1) ? w1 : w0;
+    ++pos;
+    return u;
+  }
+};
+
 // The same sequential view for code that a whole wavefront executes in
 // lockstep (all 64 lanes active, wave-uniform control flow): the wave
 // generates a window of 128 consecutive uniforms at once -- lane l holds both

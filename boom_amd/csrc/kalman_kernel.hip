@@ -157,7 +157,7 @@ enum : int { NR = 16 };  // registers per lane of a time panel
 // leaves after that phase.
 __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
                                                                int draw_level) {
-  __shared__ NormalsLds s_norm;             // the normals generator's windows
+  __shared__ NormalsLds s_norm;             // the normals generator's lists
   __shared__ double s_x[2][8];             // the two waves' scan totals, swapped at the seam between their stretches
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;

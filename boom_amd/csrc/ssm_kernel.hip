@@ -150,7 +150,6 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   };
   __shared__ SharedLds s_lds;
   __shared__ int s_flag;
-  NormalsLds &s_norm = s_lds.norm;
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
   double (&s_P)[SSM_MAX * SSM_MAX] = s_lds.pass.P;
   double (&s_tv)[SSM_MAX] = s_lds.pass.tv;
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   const int dS = (SEAS && sdv[2] != 0.0) ? 1 : 0;
   const int nper = dT + dS + dH;
   const int N = nfirst + (T - 1) * nper;
-  status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
+  status = stream_normals(s_lds.norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
                           szz, &P.pos_state[chain]);
   if (status != CHAIN_OK) {
     if (threadIdx.x == 0) P.status[chain] = status;

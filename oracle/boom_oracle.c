@@ -81,6 +81,10 @@ void bo_rng_seed_philox(bo_rng *r, uint64_t seed, uint32_t chain,
   r->chain = chain;
   r->stream = stream;
   r->pos = pos;
+  if (stream == 2) {
+    r->slot_stride = BO_STATE_SLOT_STRIDE;
+    r->slot = pos / BO_STATE_SLOT_STRIDE;
+  }
 }
 
 /* RNG::operator(), distributions/rng.hpp:45.  For the MT engine this is
@@ -205,6 +209,14 @@ double bo_norm_rand(bo_rng *r) {
 /* rnorm_mt, Bmath/rnorm.cpp:55-67 (no draw when sigma == 0) */
 double bo_rnorm(bo_rng *r, double mu, double sigma) {
   if (sigma == 0.) return mu;
+  if (r->kind == BO_RNG_PHILOX && r->slot_stride) {
+    /* (the state stream's normals have a slot each, see bo_rng) */
+    r->pos = r->slot * r->slot_stride;
+    r->slot += 1;
+    const double z = bo_norm_rand(r);
+    r->pos = r->slot * r->slot_stride;
+    return mu + sigma * z;
+  }
   return mu + sigma * bo_norm_rand(r);
 }
 

@@ -49,7 +49,13 @@ typedef struct bo_rng {
   uint32_t chain;
   uint32_t stream;
   uint64_t pos; /* index of the next uniform */
+  /* The chain's state stream (stream 2: the normals of simulate_forward): normal
+   * number `slot` reads its uniforms from the fixed position slot * slot_stride, as
+   * the device does (stream_normals.h) -- every draw independent of the others.
+   * 0 for every other stream, and the MT engine reads in sequence as the reference. */
+  uint64_t slot_stride, slot;
 } bo_rng;
+#define BO_STATE_SLOT_STRIDE 64
 
 void bo_rng_seed_mt(bo_rng *r, uint64_t seed);
 void bo_rng_seed_philox(bo_rng *r, uint64_t seed, uint32_t chain,

@@ -56,7 +56,8 @@ def build_oracle():
 class BoRng(C.Structure):
     _fields_ = [("kind", C.c_int), ("mt", C.c_uint64 * 312), ("mti", C.c_int),
                 ("seed", C.c_uint64), ("chain", C.c_uint32),
-                ("stream", C.c_uint32), ("pos", C.c_uint64)]
+                ("stream", C.c_uint32), ("pos", C.c_uint64),
+                ("slot_stride", C.c_uint64), ("slot", C.c_uint64)]
 
 
 class RefSsvsOptions(C.Structure):
