@@ -16,11 +16,11 @@
 // reference is an affine map x -> A_t x + B_t applied in time order.  The
 // kernel therefore works on the time axis 64 steps at a time, lane = step:
 //   1. y*_t = y_t - x_t'beta            lane-parallel, coalesced X columns
-//   2. the sweep's standard normals     in the reference's stream order (state
-//                                       error, then observation, for every t)
-//   3. P_t, F_t, K_t                    the one truly serial recursion (a
-//                                       Riccati map); it is data independent and
-//                                       stops iterating once P_t repeats bitwise
+//   2. the sweep's standard normals     one substream position per draw (state
+//                                       error, then observation, for every t:
+//                                       stream_normals.h)
+//   3. P_t, F_t, K_t                    a Riccati recursion, i.e. a Moebius map of
+//                                       P_t / H: a scan of 2 x 2 matrices
 //   4. forward: simulated states (prefix sum), and ONE filter on
 //      w_t = y*_t - y+_t: the data filter and the simulation filter share K_t,
 //      so their difference delta_t = a_t - a+_t obeys
@@ -152,9 +152,8 @@ enum : int { NR = 16 };  // registers per lane of a time panel
 
 }  // namespace
 
-// grid = chains, block = 128: wave 0 runs the chain; wave 1 only helps with the
-// sweep's normals (windows of the stream alternate between the two waves) and
-// leaves after that phase.
+// grid = chains, block = 128: both waves share every phase (y* panels, the sweep's
+// normals, the time-blocked scans of the three passes); wave 0 publishes the results.
 __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
                                                                int draw_level) {
   __shared__ NormalsLds s_norm;             // the normals generator's lists
@@ -252,12 +251,8 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   const int dI = (sd0 != 0.0), dL = (level_sigma != 0.0), dH = (sqrtH != 0.0);
   const int nfirst = dI + dH, nper = dL + dH;
   const int N = nfirst + (T - 1) * nper;
-  // The stream is cut into fixed windows of NB_START offsets (+ a margin for
-  // draws that start near the end): window b belongs to wave b & 1.  Everything
-  // about a window except WHERE the sequential reader enters it -- uniforms,
-  // the draw starting at every offset, the jump tables -- is independent of the
-  // other windows, so the two waves build their windows side by side and only
-  // the look-ups are chained, through s_hand.
+  // Normal i of the sweep reads its uniforms from position bpos0 + 64 i of the
+  // chain's state stream (stream_normals.h); szz holds them in draw order.
   const uint64_t bpos0 = P.pos_state[chain];
   status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,
                           &P.pos_state[chain]);

@@ -137,7 +137,7 @@ __device__ __forceinline__ void blk_store(double *g, const double *lds, int n, i
 // seasonal block follows
 template <int TREND, bool SEAS>
 __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw_variances) {
-  // (the passes' buffers take the place of the normals generator's windows, which
+  // (the passes' buffers take the place of the normals generator's lists, which
   // are done by then: 37 KB per workgroup, four workgroups per CU)
   struct PassLds {
     double blk[2][WAVE * SSM_MAX];   // a block of 64 steps of a state-sized series, per wave
