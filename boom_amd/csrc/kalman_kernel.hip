@@ -150,13 +150,67 @@ __device__ __forceinline__ double lane_before(double x, double first) {
 
 enum : int { NR = 16 };  // registers per lane of a time panel
 
+// In the three passes a lane owns CONSECUTIVE time steps, so a plain load of "my
+// j-th step" touches 64 different cache lines per instruction -- the passes were bound
+// by exactly that (24 such loads and as many stores per chunk and wave).  Instead a
+// wave moves its stretch between HBM and registers through LDS: coalesced rows of 64
+// (8 lines per instruction), transposed in a padded staging buffer (element e at
+// e + e / 8: a lane's CNT consecutive elements and a row's 64 both spread over the
+// banks).  reverse: the lane's j-th value is element 64 CNT - 1 - (CNT lane + j) (the
+// backward pass walks time downwards).
+__device__ __forceinline__ int stage_at(int e) { return e + (e >> 3); }
+enum : int { STAGE_DOUBLES = 2 * 8 * WAVE + 2 * 8 * WAVE / 8 };   // room for CNT = 16
+
+// out[j] = g[first + CNT lane + j] where that index is in [0, n), else fill
+template <int CNT>
+__device__ __forceinline__ void wave_block_load(double *stage, const double *__restrict__ g, int64_t first,
+                                                int64_t n, int lane, double fill, bool reverse,
+                                                double (&out)[CNT]) {
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    const int e = i * WAVE + lane;
+    const int64_t idx = first + e;
+    stage[stage_at(e)] = (idx >= 0 && idx < n) ? g[idx] : fill;
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int e = reverse ? (WAVE * CNT - 1 - (CNT * lane + j)) : (CNT * lane + j);
+    out[j] = stage[stage_at(e)];
+  }
+  wave_lds_sync();
+}
+// g[first + CNT lane + j] = v[j] where that index is in [0, n)
+template <int CNT>
+__device__ __forceinline__ void wave_block_store(double *stage, double *__restrict__ g, int64_t first,
+                                                 int64_t n, int lane, bool reverse, const double (&v)[CNT]) {
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int e = reverse ? (WAVE * CNT - 1 - (CNT * lane + j)) : (CNT * lane + j);
+    stage[stage_at(e)] = v[j];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    const int e = i * WAVE + lane;
+    const int64_t idx = first + e;
+    if (idx >= 0 && idx < n) g[idx] = stage[stage_at(e)];
+  }
+  wave_lds_sync();
+}
+
 }  // namespace
 
 // grid = chains, block = 128: both waves share every phase (y* panels, the sweep's
 // normals, the time-blocked scans of the three passes); wave 0 publishes the results.
 __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
                                                                int draw_level) {
-  __shared__ NormalsLds s_norm;             // the normals generator's lists
+  union KalmanLds {
+    NormalsLds norm;                        // the normals generator's lists, then ...
+    double stage[2][STAGE_DOUBLES];         // ... the passes' staging buffers, one per wave
+  };
+  __shared__ KalmanLds s_u;
+  NormalsLds &s_norm = s_u.norm;
   __shared__ double s_x[2][8];             // the two waves' scan totals, swapped at the seam between their stretches
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;
@@ -261,6 +315,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
     return;
   }
   __syncthreads();
+  double *stage = s_u.stage[wave];   // (the lists are done with)
   KSTAMP(2);
   // ---- 3 + 4. forward pass.
   // Variances (ScalarMarginalDistribution::update, the part that does not look
@@ -290,16 +345,40 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
       const int tl = t0 + WS * wave + BS * lane;
       bool in[BS], obs[BS];
       double zL[BS], zH[BS], ys[BS];
+      const int tw = t0 + WS * wave;   // the wave's first step
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
         const int t = tl + j;
         in[j] = t < T;
         obs[j] = in[j] && P.observed[in[j] ? t : 0] != 0;
-        const int nb = (t == 0) ? 0 : nfirst + (t - 1) * nper;
-        const bool hasL = in[j] && ((t == 0) ? dI : dL);
-        zL[j] = hasL ? szz[nb] : 0.0;
-        zH[j] = (in[j] && dH) ? szz[nb + (hasL ? 1 : 0)] : 0.0;
-        ys[j] = in[j] ? w0[t] : 0.0;
+      }
+      wave_block_load<BS>(stage, w0, tw, T, lane, 0.0, false, ys);
+      // the normals of steps t >= 1 sit nper to a step from nfirst on: state error (if
+      // any), then observation error (if any)
+      {
+        const int64_t gfirst = (int64_t)nfirst + (int64_t)(tw - 1) * nper;
+        if (nper == 2) {
+          double zz[2 * BS];
+          wave_block_load<2 * BS>(stage, szz, gfirst, N, lane, 0.0, false, zz);
+#pragma unroll
+          for (int j = 0; j < BS; ++j) { zL[j] = zz[2 * j]; zH[j] = zz[2 * j + 1]; }
+        } else if (nper == 1) {
+          double z1[BS];
+          wave_block_load<BS>(stage, szz, gfirst, N, lane, 0.0, false, z1);
+#pragma unroll
+          for (int j = 0; j < BS; ++j) { zL[j] = dL ? z1[j] : 0.0; zH[j] = dL ? 0.0 : z1[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < BS; ++j) { zL[j] = 0.0; zH[j] = 0.0; }
+        }
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          if (!in[j]) { zL[j] = 0.0; zH[j] = 0.0; }
+        }
+        if (tl == 0) {   // step 0: initial state (if any), then observation error (if any)
+          zL[0] = dI ? szz[0] : 0.0;
+          zH[0] = dH ? szz[dI] : 0.0;
+        }
       }
       // ---- what does not depend on the carries: the lane's composite variance
       // map and its partial sums of the simulated state's increments
@@ -420,16 +499,15 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         const Aff DT = aff_after(D1, D0);
         delta_in = DT.A * delta_in + DT.B;
       }
+      double ef[BS];
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
-        const int t = tl + j;
-        if (in[j]) {
-          sal[t] = al[j];
-          sK[t] = K[j];
-          w0[t] = obs[j] ? (w[j] - delta) / Fv[j] : 0.0;   // (v_t - v+_t) / F_t
-        }
+        ef[j] = obs[j] ? (w[j] - delta) / Fv[j] : 0.0;   // (v_t - v+_t) / F_t
         delta = (1.0 - K[j]) * delta + K[j] * w[j];
       }
+      wave_block_store<BS>(stage, sal, tw, T, lane, false, al);
+      wave_block_store<BS>(stage, sK, tw, T, lane, false, K);
+      wave_block_store<BS>(stage, w0, tw, T, lane, false, ef);
     }
   }
   if (status != CHAIN_OK) {
@@ -448,16 +526,15 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
     double d_in = 0.0;
     const int tlast = ((T - 1) / CS) * CS;
     for (int t0 = tlast; t0 >= 0; t0 -= CS) {
-      const int th = t0 + CS - 1 - WS * wave - BS * lane;   // this lane's latest step
       double fa[BS], fb[BS];
+      const int tw = t0 + CS - WS * (wave + 1);   // the wave's earliest step
+      wave_block_load<BS>(stage, sK, tw, T, lane, 0.0, true, fa);
+      wave_block_load<BS>(stage, w0, tw, T, lane, 0.0, true, fb);
       Aff C;
       C.A = 1.0; C.B = 0.0;
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
-        const int t = th - j;
-        const bool in = t < T;
-        fa[j] = in ? 1.0 - sK[in ? t : 0] : 1.0;
-        fb[j] = in ? w0[in ? t : 0] : 0.0;
+        fa[j] = 1.0 - fa[j];   // (1 at steps past T: K reads as 0 there)
         Aff f;
         f.A = fa[j]; f.B = fb[j];
         C = aff_after(f, C);
@@ -478,12 +555,13 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         const Aff DT = aff_after(D1, D0);
         d_in = DT.A * d_in + DT.B;
       }
+      double dv[BS];
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
-        const int t = th - j;
-        if (t < T) w0[t] = d;
+        dv[j] = d;
         d = fa[j] * d + fb[j];                   // d_{t-1}
       }
+      wave_block_store<BS>(stage, w0, tw, T, lane, true, dv);
     }
     d_first = d_in;
   }
@@ -507,15 +585,16 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
       // as the compiler knows, and would serialise them)
       double dm[BS], al[BS], yv[BS];
       bool inr[BS], ob[BS];
+      const int tw = t0 + WS * wave;   // the wave's first step
 #pragma unroll
       for (int j = 0; j < BS; ++j) {
         const int t = tl + j;
         inr[j] = t < T;
-        dm[j] = (inr[j] && t > 0) ? w0[t - 1] : 0.0;
-        al[j] = inr[j] ? sal[t] : 0.0;
-        yv[j] = inr[j] ? P.y[t] : 0.0;
         ob[j] = inr[j] && P.observed[inr[j] ? t : 0] != 0;
       }
+      wave_block_load<BS>(stage, w0, (int64_t)tw - 1, (int64_t)T - 1, lane, 0.0, false, dm);   // d_{t-1}, 0 at t = 0 and past T
+      wave_block_load<BS>(stage, sal, tw, T, lane, 0.0, false, al);
+      wave_block_load<BS>(stage, P.y, tw, T, lane, 0.0, false, yv);
       double mm[BS], st[BS];
       double acc = 0.0;
 #pragma unroll
@@ -556,11 +635,8 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         ev[j] = ob[j] ? yv[j] - st[j] : 0.0;
         if (ob[j]) { part_q += ev[j] * ev[j]; part_n += 1.0; }
       }
-#pragma unroll
-      for (int j = 0; j < BS; ++j) {
-        const int t = tl + j;
-        if (inr[j]) { sst[t] = st[j]; sF[t] = ev[j]; }
-      }
+      wave_block_store<BS>(stage, sst, tw, T, lane, false, st);
+      wave_block_store<BS>(stage, sF, tw, T, lane, false, ev);
     }
   }
   // the two waves' partial sums
