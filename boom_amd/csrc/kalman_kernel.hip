@@ -161,17 +161,25 @@ enum : int { NR = 16 };  // registers per lane of a time panel
 __device__ __forceinline__ int stage_at(int e) { return e + (e >> 3); }
 enum : int { STAGE_DOUBLES = 2 * 8 * WAVE + 2 * 8 * WAVE / 8 };   // room for CNT = 16
 
-// out[j] = g[first + CNT lane + j] where that index is in [0, n), else fill
+// raw[i] = g[first + 64 i + lane] where that index is in [0, n), else fill: the
+// coalesced half of a block load (all of a chunk's are issued before any transpose, so
+// that their latencies overlap)
 template <int CNT>
-__device__ __forceinline__ void wave_block_load(double *stage, const double *__restrict__ g, int64_t first,
-                                                int64_t n, int lane, double fill, bool reverse,
-                                                double (&out)[CNT]) {
+__device__ __forceinline__ void wave_block_fetch(const double *__restrict__ g, int64_t first, int64_t n,
+                                                 int lane, double fill, double (&raw)[CNT]) {
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
-    const int e = i * WAVE + lane;
-    const int64_t idx = first + e;
-    stage[stage_at(e)] = (idx >= 0 && idx < n) ? g[idx] : fill;
+    const int64_t idx = first + i * WAVE + lane;
+    raw[i] = (idx >= 0 && idx < n) ? g[idx] : fill;
   }
+}
+// ... and the transpose: out[j] = element CNT lane + j of the block (reverse: counted
+// from its end)
+template <int CNT>
+__device__ __forceinline__ void wave_block_turn(double *stage, int lane, bool reverse,
+                                                const double (&raw)[CNT], double (&out)[CNT]) {
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) stage[stage_at(i * WAVE + lane)] = raw[i];
   wave_lds_sync();
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
@@ -352,22 +360,28 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         in[j] = t < T;
         obs[j] = in[j] && P.observed[in[j] ? t : 0] != 0;
       }
-      wave_block_load<BS>(stage, w0, tw, T, lane, 0.0, false, ys);
       // the normals of steps t >= 1 sit nper to a step from nfirst on: state error (if
       // any), then observation error (if any)
       {
         const int64_t gfirst = (int64_t)nfirst + (int64_t)(tw - 1) * nper;
+        double yraw[BS];
+        wave_block_fetch<BS>(w0, tw, T, lane, 0.0, yraw);
         if (nper == 2) {
-          double zz[2 * BS];
-          wave_block_load<2 * BS>(stage, szz, gfirst, N, lane, 0.0, false, zz);
+          double zraw[2 * BS], zz[2 * BS];
+          wave_block_fetch<2 * BS>(szz, gfirst, N, lane, 0.0, zraw);
+          wave_block_turn<BS>(stage, lane, false, yraw, ys);
+          wave_block_turn<2 * BS>(stage, lane, false, zraw, zz);
 #pragma unroll
           for (int j = 0; j < BS; ++j) { zL[j] = zz[2 * j]; zH[j] = zz[2 * j + 1]; }
         } else if (nper == 1) {
-          double z1[BS];
-          wave_block_load<BS>(stage, szz, gfirst, N, lane, 0.0, false, z1);
+          double zraw[BS], z1[BS];
+          wave_block_fetch<BS>(szz, gfirst, N, lane, 0.0, zraw);
+          wave_block_turn<BS>(stage, lane, false, yraw, ys);
+          wave_block_turn<BS>(stage, lane, false, zraw, z1);
 #pragma unroll
           for (int j = 0; j < BS; ++j) { zL[j] = dL ? z1[j] : 0.0; zH[j] = dL ? 0.0 : z1[j]; }
         } else {
+          wave_block_turn<BS>(stage, lane, false, yraw, ys);
 #pragma unroll
           for (int j = 0; j < BS; ++j) { zL[j] = 0.0; zH[j] = 0.0; }
         }
@@ -528,8 +542,13 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
     for (int t0 = tlast; t0 >= 0; t0 -= CS) {
       double fa[BS], fb[BS];
       const int tw = t0 + CS - WS * (wave + 1);   // the wave's earliest step
-      wave_block_load<BS>(stage, sK, tw, T, lane, 0.0, true, fa);
-      wave_block_load<BS>(stage, w0, tw, T, lane, 0.0, true, fb);
+      {
+        double kraw[BS], eraw[BS];
+        wave_block_fetch<BS>(sK, tw, T, lane, 0.0, kraw);
+        wave_block_fetch<BS>(w0, tw, T, lane, 0.0, eraw);
+        wave_block_turn<BS>(stage, lane, true, kraw, fa);
+        wave_block_turn<BS>(stage, lane, true, eraw, fb);
+      }
       Aff C;
       C.A = 1.0; C.B = 0.0;
 #pragma unroll
@@ -592,9 +611,15 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
         inr[j] = t < T;
         ob[j] = inr[j] && P.observed[inr[j] ? t : 0] != 0;
       }
-      wave_block_load<BS>(stage, w0, (int64_t)tw - 1, (int64_t)T - 1, lane, 0.0, false, dm);   // d_{t-1}, 0 at t = 0 and past T
-      wave_block_load<BS>(stage, sal, tw, T, lane, 0.0, false, al);
-      wave_block_load<BS>(stage, P.y, tw, T, lane, 0.0, false, yv);
+      {
+        double draw[BS], araw[BS], yraw[BS];
+        wave_block_fetch<BS>(w0, (int64_t)tw - 1, (int64_t)T - 1, lane, 0.0, draw);   // d_{t-1}, 0 at t = 0 and past T
+        wave_block_fetch<BS>(sal, tw, T, lane, 0.0, araw);
+        wave_block_fetch<BS>(P.y, tw, T, lane, 0.0, yraw);
+        wave_block_turn<BS>(stage, lane, false, draw, dm);
+        wave_block_turn<BS>(stage, lane, false, araw, al);
+        wave_block_turn<BS>(stage, lane, false, yraw, yv);
+      }
       double mm[BS], st[BS];
       double acc = 0.0;
 #pragma unroll
