@@ -155,11 +155,11 @@ enum : int { NR = 16 };  // registers per lane of a time panel
 // by exactly that (24 such loads and as many stores per chunk and wave).  Instead a
 // wave moves its stretch between HBM and registers through LDS: coalesced rows of 64
 // (8 lines per instruction), transposed in a padded staging buffer (element e at
-// e + e / 8: a lane's CNT consecutive elements and a row's 64 both spread over the
-// banks).  reverse: the lane's j-th value is element 64 CNT - 1 - (CNT lane + j) (the
+// e + e / 32: a half-wave's 32 row elements sit in 32 different banks, and so do the
+// j-th elements of 32 lanes' stretches of 8 -- 8 l + l / 4 + j mod 32 is one-to-one in l).  reverse: the lane's j-th value is element 64 CNT - 1 - (CNT lane + j) (the
 // backward pass walks time downwards).
-__device__ __forceinline__ int stage_at(int e) { return e + (e >> 3); }
-enum : int { STAGE_DOUBLES = 2 * 8 * WAVE + 2 * 8 * WAVE / 8 };   // room for CNT = 16
+__device__ __forceinline__ int stage_at(int e) { return e + (e >> 5); }
+enum : int { STAGE_DOUBLES = 2 * 8 * WAVE + 2 * 8 * WAVE / 32 };   // room for CNT = 16
 
 // raw[i] = g[first + 64 i + lane] where that index is in [0, n), else fill: the
 // coalesced half of a block load (all of a chunk's are issued before any transpose, so
