@@ -97,18 +97,105 @@ __device__ double tn_draw(SeqRng &rng, double a, int *bad) {
   *bad = 1;
   return a;
 }
+// The same sampler with its hull in LDS.  tn_draw's arrays are indexed by numbers that
+// differ from lane to lane, so in scratch memory every access is 64 cache lines for the
+// texture path -- the probit imputation was bound by exactly that.  In LDS, laid out
+// [array][point][slot], a lane's bank depends on its slot only, whatever point it
+// touches.  A workgroup has TN_SLOTS hulls of TN_LDS_CAP points (the draws that need
+// one take a slot on first use; the others, and a hull that outgrows its slot, use
+// tn_draw -- the same numbers either way: same expressions on the same inputs).
+enum : int { TN_LDS_CAP = 16, TN_SLOTS = 72 };
+struct TnSlot {
+  double *hull;   // the workgroup's 3 TN_LDS_CAP TN_SLOTS doubles
+  int *taken;     // slots handed out
+  int slot;       // this thread's (-1: none yet, -2: none left)
+};
+// returns false when the hull outgrew the slot (nothing is left consumed: the caller
+// rewinds the stream)
+__device__ __forceinline__ bool tn_draw_lds(SeqRng &rng, double a, const TnSlot &S, double *out) {
+  auto yv = [](double x) { return __dmul_rn(__dmul_rn(-.5, x), x); };
+  double *xs = S.hull + S.slot, *kn = xs + TN_LDS_CAP * TN_SLOTS, *cdf = kn + TN_LDS_CAP * TN_SLOTS;
+#define AT(arr, k) arr[(k) * TN_SLOTS]
+  const double y0 = yv(a);
+  int n = 1;
+  AT(xs, 0) = a; AT(kn, 0) = a;
+  for (int level = 0; level <= 1001; ++level) {
+    {  // update_cdf
+      double last = 0;
+      for (int k = 0; k < n; ++k) {
+        const double z = AT(xs, k), d = -z, y = yv(z) - y0, dinv = 1.0 / d;
+        const double inc1 = (k == n - 1) ? 0 : dinv * exp(y - d * z + d * AT(kn, k + 1));
+        const double inc2 = dinv * exp(y - d * z + d * AT(kn, k));
+        last = last + inc1 - inc2;
+        AT(cdf, k) = last;
+      }
+    }
+    const double u = d_runif(rng, 0.0, AT(cdf, n - 1));
+    int k = 0;
+    {  // std::lower_bound(cdf, cdf + n, u)
+      int count = n;
+      while (count > 0) {
+        const int step = count / 2;
+        if (AT(cdf, k + step) < u) { k += step + 1; count -= step + 1; }
+        else count = step;
+      }
+    }
+    const double xk = AT(xs, k);
+    double cand;
+    if (k + 1 == n) cand = AT(kn, n - 1) + d_rexp(rng, -1 * -AT(xs, n - 1));
+    else cand = d_rtrun_exp(rng, -1 * -xk, AT(kn, k), AT(kn, k + 1));
+    const double target = yv(cand);
+    const double hull = yv(xk) + -xk * (cand - xk);
+    const double logu = hull - d_rexp(rng, 1.0);
+    if (logu < target) { *out = cand; return true; }
+    if (n >= TN_LDS_CAP) return false;
+    int pos = 0;
+    {  // std::lower_bound(knots, knots + n, cand)
+      int count = n;
+      while (count > 0) {
+        const int step = count / 2;
+        if (AT(kn, pos + step) < cand) { pos += step + 1; count -= step + 1; }
+        else count = step;
+      }
+    }
+    if (pos == 0) return false;   // (a candidate at the truncation point itself: never)
+    for (int i = n; i > pos; --i) AT(xs, i) = AT(xs, i - 1);
+    for (int i = n; i > pos + 1; --i) AT(kn, i) = AT(kn, i - 1);
+    AT(xs, pos) = cand;
+    ++n;
+    for (int i = pos; i <= pos + 1 && i < n; ++i) {
+      const double xl = AT(xs, i - 1), xr = AT(xs, i);
+      double ans = (yv(xl) - -xl * xl) - (yv(xr) - -xr * xr);
+      ans /= (-xr - -xl);
+      AT(kn, i) = ans;
+    }
+  }
+#undef AT
+  return false;
+}
+
 // trun_norm_mt(rng, a): a standard normal given x > a
-__device__ __forceinline__ double trun_norm_std(SeqRng &rng, double a, int *bad) {
+__device__ __forceinline__ double trun_norm_std(SeqRng &rng, double a, int *bad, TnSlot &S) {
   if (a <= 0) {
     for (;;) {
       const double x = d_norm_rand(rng);
       if (x > a) return x;
     }
   }
+  if (S.slot == -1) {
+    const int got = atomicAdd(S.taken, 1);
+    S.slot = got < TN_SLOTS ? got : -2;
+  }
+  if (S.slot >= 0) {
+    const uint64_t start = rng.pos;
+    double z;
+    if (tn_draw_lds(rng, a, S, &z)) return z;
+    rng.pos = start;
+  }
   return tn_draw(rng, a, bad);
 }
-__device__ __forceinline__ double rtrun_norm(SeqRng &rng, double mu, double a, bool gt, int *bad) {
-  return gt ? mu + trun_norm_std(rng, a - mu, bad) : mu - trun_norm_std(rng, mu - a, bad);   // (sigma = 1)
+__device__ __forceinline__ double rtrun_norm(SeqRng &rng, double mu, double a, bool gt, int *bad, TnSlot &S) {
+  return gt ? mu + trun_norm_std(rng, a - mu, bad, S) : mu - trun_norm_std(rng, mu - a, bad, S);   // (sigma = 1)
 }
 __device__ __forceinline__ double log_pnorm_std(double x, bool lower) {
   const double z = lower ? -x : x;
@@ -173,12 +260,16 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   // the chain's included variables, once per workgroup
   __shared__ int s_idx[PROBIT_KMAX];
   __shared__ double s_beta[PROBIT_KMAX];
+  __shared__ double s_hull[3 * TN_LDS_CAP * TN_SLOTS];   // the adaptive-rejection hulls (tn_draw_lds)
+  __shared__ int s_taken;
+  if (threadIdx.x == 0) s_taken = 0;
   const int k = included_coefficients(P, chain, s_idx, s_beta);
   if (k > PROBIT_KMAX) {
     if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
     return;
   }
   if (i >= P.n) return;
+  TnSlot slot{s_hull, &s_taken, -1};
   double eta = 0.0;
   for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
   const long nt = lround(P.ntrials[i]), y = lround(P.y[i]);
@@ -190,13 +281,13 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
     trun_norm_moments(eta, true, &mean, &variance);
     ans += d_rnorm(rng, y * mean, sqrt(y * variance));
   } else {
-    for (long t = 0; t < y; ++t) ans += rtrun_norm(rng, eta, 0.0, true, &bad);
+    for (long t = 0; t < y; ++t) ans += rtrun_norm(rng, eta, 0.0, true, &bad, slot);
   }
   if (nt - y > P.clt_threshold) {
     trun_norm_moments(eta, false, &mean, &variance);
     ans += d_rnorm(rng, (nt - y) * mean, sqrt((nt - y) * variance));
   } else {
-    for (long t = 0; t < nt - y; ++t) ans += rtrun_norm(rng, eta, 0.0, false, &bad);
+    for (long t = 0; t < nt - y; ++t) ans += rtrun_norm(rng, eta, 0.0, false, &bad, slot);
   }
   // (a draw that outran its substream or its hull is reported, never mishandled)
   if (bad || rng.pos - (P.sweep * (uint64_t)P.n + (uint64_t)i) * PROBIT_STRIDE > PROBIT_STRIDE)
