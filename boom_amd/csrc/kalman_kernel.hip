@@ -313,7 +313,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   const int dI = (sd0 != 0.0), dL = (level_sigma != 0.0), dH = (sqrtH != 0.0);
   const int nfirst = dI + dH, nper = dL + dH;
   const int N = nfirst + (T - 1) * nper;
-  // Normal i of the sweep reads its uniforms from position bpos0 + 64 i of the
+  // Normal i of the sweep reads its uniforms from position bpos0 + 256 i of the
   // chain's state stream (stream_normals.h); szz holds them in draw order.
   const uint64_t bpos0 = P.pos_state[chain];
   status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,

@@ -15,7 +15,7 @@
 //
 // The reference reads the sampler's RNG in sequence, observation after
 // observation, a data-dependent number of uniforms each.  Here observation i of
-// sweep s reads the chain's imputer stream (id 8) from position (s n + i) * 256:
+// sweep s reads the chain's imputer stream (id 8) from position (s n + i) * 4096:
 // a counter-based stream makes the observations independent.  (The oracle's
 // Philox mode does the same; its MT mode, pinned on the reference, reads in
 // sequence.)

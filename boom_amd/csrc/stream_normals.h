@@ -8,7 +8,7 @@
 // and 2 did exactly that (windows of uniforms in LDS, the draw starting at every
 // offset, jump tables, a binary-lifting walk): parity-exact, and 55 % of the Kalman
 // kernel.  A counter-based generator does not need it: normal i of the chain's state
-// stream reads its uniforms from the FIXED position i * STATE_SLOT_STRIDE (the way the
+// stream reads its uniforms from the FIXED position i * STATE_SLOT_STRIDE (256 i) (the way the
 // probit / logit imputers give every observation its own substream, probit_kernel.hip),
 // so every draw is independent of every other and costs its own uniforms only.  The
 // oracle's Philox mode does the same (bo_rnorm on stream 2); its MT mode -- the one
@@ -21,10 +21,13 @@
 
 namespace boom_amd {
 
-// uniforms reserved per normal of the state stream (a draw that ran past them would
-// read the next draw's: reported as CHAIN_RNG_BRANCH; at the tail regions' acceptance
-// rates that needs some thirty rejections in a row)
-enum : int { STATE_SLOT_STRIDE = 64 };
+// uniforms reserved per normal of the state stream.  A draw that ran past them would
+// read the next draw's (reported as CHAIN_RNG_BRANCH): the rejection loops accept with
+// probability ~0.55 per round of two uniforms, so 64 uniforms (31 rounds) would be
+// exceeded about once per 1e11 slow draws -- every few hundred thousand sweep rounds of
+// 1024 chains -- and 256 (127 rounds) never (1e-44).  The stride costs nothing: counters,
+// not memory.
+enum : int { STATE_SLOT_STRIDE = 256 };
 
 // LDS hand-off between the lanes of one wavefront (DS operations of a wave
 // complete in order: only the compiler has to be told)

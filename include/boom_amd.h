@@ -252,7 +252,7 @@ int ba_adaptive_get_rates(ba_engine *e, int64_t chain, double *birth_rates,
  * scales_with_sigsq = 0, max_flips) and ba_set_spike.  State through
  * ba_set_state / ba_get_state(s) (sigma^2 is 1).  RNG: stream 3 for the
  * inclusion / coefficient draws; the imputation of observation i in sweep s reads
- * stream 8 from position (s n + i) * 256 -- the reference reads ONE stream in
+ * stream 8 from position (s n + i) * 4096 -- the reference reads ONE stream in
  * sequence, a counter-based one lets the observations go in parallel. */
 int ba_probit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X,
                        const double *y, const double *ntrials, int32_t clt_threshold);

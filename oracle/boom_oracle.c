@@ -2698,7 +2698,7 @@ struct bo_probit {
   bo_rng imp_rng;
   uint64_t sweep;
 };
-#define BO_PROBIT_STRIDE 256
+#define BO_PROBIT_STRIDE 4096
 
 bo_probit *bo_probit_create(int n, int p, const double *X, const double *y,
                             const double *ntrials, const double *mu, const double *prec,

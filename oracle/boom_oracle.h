@@ -55,7 +55,7 @@ typedef struct bo_rng {
    * 0 for every other stream, and the MT engine reads in sequence as the reference. */
   uint64_t slot_stride, slot;
 } bo_rng;
-#define BO_STATE_SLOT_STRIDE 64
+#define BO_STATE_SLOT_STRIDE 256
 
 void bo_rng_seed_mt(bo_rng *r, uint64_t seed);
 void bo_rng_seed_philox(bo_rng *r, uint64_t seed, uint32_t chain,

@@ -115,7 +115,7 @@ def test_philox_stream_layout(oracle):
 
 def test_state_stream_gives_every_normal_its_own_position(oracle):
     """Stream 2 (the normals of simulate_forward) in Philox mode: draw number i reads its
-    uniforms from position 64 i, whatever the draws before it consumed -- the contract the
+    uniforms from position 256 i, whatever the draws before it consumed -- the contract the
     device's stream_normals.h implements (the MT engine, pinned on the reference, reads in
     sequence; so does every other Philox stream)."""
     import ctypes as C
@@ -125,11 +125,11 @@ def test_state_stream_gives_every_normal_its_own_position(oracle):
     r = oracle.rng_philox(99, chain=3, stream=2)
     seq = [L.bo_rnorm(C.byref(r), 0.0, 1.0) for _ in range(200)]
     assert L.bo_rnorm(C.byref(r), 5.0, 0.0) == 5.0 and r.slot == 200      # sigma = 0: no draw, no slot
-    assert r.pos == 200 * 64
+    assert r.pos == 200 * 256
     for i in (0, 1, 57, 199):
         # the same draw from a plain sequential stream positioned there (stream ids differ
         # in the key, so compare through the normal transform of that position's uniforms)
-        one = oracle.rng_philox(99, chain=3, stream=2, pos=64 * i)
+        one = oracle.rng_philox(99, chain=3, stream=2, pos=256 * i)
         assert L.bo_rnorm(C.byref(one), 0.0, 1.0) == seq[i]
     # another stream reads in sequence: the second normal starts where the first stopped
     s0 = oracle.rng_philox(99, chain=3, stream=0)
