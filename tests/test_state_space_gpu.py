@@ -172,3 +172,56 @@ def test_forecast_matches_oracle(oracle):
     # forecasts centre on level + regression: the predictive mean over chains tracks it
     mid = np.array([eng.ss_get_state(c)["state"][-1] for c in range(chains)]).mean()
     assert abs(np.median(f1[:, 0] - newX[0] @ beta.mean(axis=0)) - mid) < 3.0
+
+
+def test_posterior_agrees_with_the_sequential_stream_sampler(oracle):
+    """The device (and the oracle's Philox mode) give every state-stream normal its own
+    substream position; the oracle's MT mode -- the one pinned draw for draw on the
+    compiled reference -- reads one sequential stream.  Same transforms on independent
+    uniforms either way, so the posteriors must agree: long run of the MT oracle against
+    many device chains, posterior means within 5 standard errors (batch means)."""
+    T, p, seed = 120, 6, 7
+    X, y, _, obs = state_space_data(T, p, 2, seed=8, missing_frac=0.03)
+    prior, ss, sig_up = bsts_priors(X, y, 2)
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(p, np.uint8)
+    nsw_o, burn_o = 6000, 500
+    o = oracle.ss_run(y, X, obs, prior, opts, ss, ("mt", 2024), g0, nsw_o)
+    assert o["status"] == 0
+    chains, burn, keep = 256, 150, 120
+    eng = make_engine(chains, seed, y, X, obs, prior, ss, sig_up, g0)
+    eng.ss_sweep(burn)
+    acc = {k: [] for k in ("sig", "lev", "inc", "s0", "s1")}
+    for _ in range(keep // 10):
+        eng.ss_sweep(10)
+        gam, beta, sig = eng.get_states()
+        acc["sig"].append(np.log(sig))
+        acc["inc"].append(gam.astype(float))
+        lev, s0, s1 = [], [], []
+        for c in range(0, chains, 8):
+            st = eng.ss_get_state(c)
+            lev.append(np.log(st["level_sigsq"]))
+            s0.append(st["state"][10])
+            s1.append(st["state"][T - 5])
+        acc["lev"].append(np.array(lev)); acc["s0"].append(np.array(s0)); acc["s1"].append(np.array(s1))
+
+    def batch_se(x, nb=20):
+        b = np.array_split(np.asarray(x, float), nb)
+        m = np.array([v.mean(0) for v in b])
+        return m.std(0, ddof=1) / np.sqrt(nb)
+
+    def device_stats(key):
+        a = np.array(acc[key])            # rounds x chains[...]
+        per_chain = a.mean(0)             # chains are independent: SE across chains
+        return per_chain.mean(0), per_chain.std(0, ddof=1) / np.sqrt(per_chain.shape[0])
+
+    checks = {
+        "sig": np.log(o["sigsq"][burn_o:]), "lev": np.log(o["level_sigsq"][burn_o:]),
+        "inc": o["gamma"][burn_o:].astype(float), "s0": o["state"][burn_o:, 10],
+        "s1": o["state"][burn_o:, T - 5],
+    }
+    for key, series in checks.items():
+        m_d, se_d = device_stats(key)
+        m_o, se_o = series.mean(0), batch_se(series)
+        z = np.abs(m_d - m_o) / np.sqrt(se_d ** 2 + se_o ** 2 + 1e-12)
+        assert np.all(z < 5.0), (key, m_d, m_o, z)
