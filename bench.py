@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-curve", action="store_true",
                     help="skip the sweeps/s-vs-chains diagnostic (extra key, untimed)")
+    ap.add_argument("--dump-blocks", default=None,
+                    help="rank 0 writes the gathered per-rank summary blocks, the ranks' chain "
+                         "offsets and a digest of every rank's installed sufficient statistics "
+                         "to this .npz (tests/test_00_two_rank_bench_gpu.py)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -142,23 +146,24 @@ def main():
     X, y, _ = regression_data(N_OBS, P, N_SIGNAL, seed=DATA_SEED)
     eng = boom_amd.Engine(CHAINS_PER_GPU, seed=SAMPLER_SEED, device=local_rank,
                           chain_offset=rank * CHAINS_PER_GPU)
-    # X, y go to HBM as torch tensors; XtX / Xty are built on the device
-    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()  # column-major n x p
-    yd = torch.from_numpy(y).cuda()
-    torch.cuda.synchronize()
+    # X, y go to HBM as torch tensors; XtX / Xty are built on the device.  With more
+    # than one rank a rank uploads ITS ROWS only (at configs[3] the whole
+    # matrix is 3.3 GB per rank of waste).
     from boom_amd import dist as bd
+    lo, hi = bd.row_shard(N_OBS, rank, world)
+    Xd = torch.from_numpy(np.ascontiguousarray(X[lo:hi].T)).cuda()  # column-major rows x p
+    yd = torch.from_numpy(np.ascontiguousarray(y[lo:hi])).cuda()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     if world > 1:
-        # the multi-GPU data path: every rank takes its rows, local
-        # MFMA syrk, ONE all-reduce of (X'X | X'y | y'y | sums) over RCCL, every
-        # rank installs the (bitwise identical) total
-        lo, hi = bd.row_shard(N_OBS, rank, world)
-        Xs = torch.from_numpy(np.ascontiguousarray(X[lo:hi].T)).cuda()
-        ys = torch.from_numpy(np.ascontiguousarray(y[lo:hi])).cuda()
-        bd.build_suf_row_sharded(eng, Xs, ys, N_OBS, world)
+        # the multi-GPU data path: local MFMA syrk on the rank's rows, ONE all-reduce
+        # of (X'X | X'y | y'y | sums) over RCCL, every rank installs the (bitwise
+        # identical) total
+        bd.build_suf_row_sharded(eng, Xd, yd, N_OBS, world)
     else:
         eng.build_suf_from_xy_device(N_OBS, P, Xd.data_ptr(), yd.data_ptr())
     suf_build_s = time.perf_counter() - t0
+    del Xd, yd
     s = eng.get_suf()
     suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"],
                sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])
@@ -198,6 +203,15 @@ def main():
     eng.summaries_device(block.data_ptr())
     allb = bd.gather_blocks(block, world)          # ONE RCCL all-gather
     elapsed = bd.max_over_ranks(elapsed, world, "cuda")
+    if args.dump_blocks:
+        # (test hook, outside the timed region: what every rank holds, side by side)
+        sr = eng.get_suf()
+        dig = torch.tensor([float(rank * CHAINS_PER_GPU), float(sr["xtx"].sum()), float(np.abs(sr["xtx"]).sum()),
+                            float(sr["xty"].sum()), float(sr["yty"]), float(sr["ybar"]), float(sr["xbar"].sum()),
+                            float(sr["n"])], dtype=torch.float64, device="cuda")
+        digs = bd.gather_blocks(dig, world)
+        if rank == 0:
+            np.savez(args.dump_blocks, blocks=allb, digests=digs, xtx=sr["xtx"], xty=sr["xty"])
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -270,7 +284,7 @@ def main():
         curve = {}
         for nch in (2048, 4096, 8192):
             e2 = boom_amd.Engine(nch, seed=SAMPLER_SEED, device=local_rank)
-            e2.build_suf_from_xy_device(N_OBS, P, Xd.data_ptr(), yd.data_ptr())
+            e2.upload_suf(s["xtx"], s["xty"], s["yty"], s["n"], s["ybar"], s["xbar"])
             e2.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"],
                           prior["sigma_guess"])
             e2.set_state(g0)

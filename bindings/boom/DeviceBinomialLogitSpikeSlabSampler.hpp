@@ -2,8 +2,9 @@
 // PosteriorSampler with BinomialLogitSpikeSlabSampler's constructor
 // (BinomialLogitSpikeSlabSampler.hpp:29-33) plus a chain count, forwarding draw() to
 // ba_logit_sweep through the C-ABI.  OUR code, written against the reference's public
-// headers and compiled only where /root/reference exists (oracle/Makefile, target
-// `binding`); oracle/binding/binding_driver.cpp runs it under the reference's own
+// headers and compiled only where /root/reference exists (bindings/boom/Makefile;
+// oracle/Makefile target `binding` links the test driver);
+// bindings/boom/binding_driver.cpp runs it under the reference's own
 // `model->sample_posterior()` loop.  It is what a BOOM maintainer would add under
 // Models/Glm/PosteriorSamplers/.
 #ifndef BOOM_AMD_DEVICE_BINOMIAL_LOGIT_SPIKE_SLAB_SAMPLER_HPP_

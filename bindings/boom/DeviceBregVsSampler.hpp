@@ -2,10 +2,11 @@
 // a BOOM PosteriorSampler that forwards draw() to the boom_amd engine through
 // the C-ABI (include/boom_amd.h).  This is OUR code, written against the
 // reference's public headers; it is compiled only where /root/reference exists
-// (oracle/Makefile, target `binding`) so that the boundary claim is checked by a
-// compiler and -- through oracle/binding/binding_driver.cpp -- exercised on the
-// GPU box by the reference's own `model->sample_posterior()` loop.  It is what a
-// BOOM maintainer would add under Models/Glm/PosteriorSamplers/.
+// (bindings/boom/Makefile; oracle/Makefile target `binding` links the test
+// driver) so that the boundary claim is checked by a compiler and -- through
+// bindings/boom/binding_driver.cpp -- exercised on the GPU box by the
+// reference's own `model->sample_posterior()` loop.  It is what a BOOM
+// maintainer would add under Models/Glm/PosteriorSamplers/.
 #ifndef BOOM_AMD_DEVICE_BREG_VS_SAMPLER_HPP_
 #define BOOM_AMD_DEVICE_BREG_VS_SAMPLER_HPP_
 

@@ -10,6 +10,10 @@
 
 #include "DeviceBinomialLogitSpikeSlabSampler.hpp"
 #include "DeviceBregVsSampler.hpp"
+#include "DeviceStateSpacePosteriorSampler.hpp"
+#include "Models/StateSpace/StateModels/LocalLevelStateModel.hpp"
+#include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
+#include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
 #include "Models/MvnModel.hpp"
 #include "LinAlg/Matrix.hpp"
 #include "LinAlg/SpdMatrix.hpp"
@@ -146,6 +150,148 @@ int ref_binding_logit_run(int n, int p, const double *X, const double *y, const 
         probe_gamma[j] = inc[j] ? 1 : 0;
         probe_beta[j] = beta[j];
       }
+    }
+    return 0;
+  } catch (std::exception &e) {
+    g_binding_error = e.what();
+    return -1;
+  }
+}
+
+// The bsts half: BOOM's StateSpaceRegressionModel(y, X, observed) with a
+// LocalLevelStateModel (trend = 1) or LocalLinearTrendStateModel (trend = 2) and an
+// optional SeasonalStateModel(nseasons) added with add_state, stepped by
+// model->sample_posterior() with DeviceStateSpacePosteriorSampler as the model's
+// sampling method.  Recorded after every draw, from the BOOM objects: the regression
+// model's inc / Beta / sigsq, the state models' variances (level, slope, seasonal;
+// unused 0) and model->state() (T x m per draw, step t at [t m, (t + 1) m)).
+// Three-element arrays are indexed level, slope, seasonal.
+int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uint8_t *observed,
+                       const double *prior_mean, const double *ominv, double prior_df,
+                       double sigma_guess, const double *pi, double sigma_upper_limit,
+                       int trend, int nseasons, const double *var_df,
+                       const double *var_sigma_guess, const double *var_sigma_upper_limit,
+                       const double *var_initial_sigma, const double *initial_state_mean,
+                       const double *initial_state_variance, int chains, uint64_t seed,
+                       const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                       double *out_beta, double *out_sigsq, double *out_variances,
+                       double *out_state, double *out_logpri, uint64_t *out_seed,
+                       int probe_chain, uint8_t *probe_gamma, double *probe_state) {
+  try {
+    GlobalRng::rng.seed(seed);
+    Matrix Xm(T, p);
+    for (int j = 0; j < p; ++j)
+      for (int t = 0; t < T; ++t) Xm(t, j) = X[(size_t)j * T + t];
+    Vector yv(T);
+    for (int t = 0; t < T; ++t) yv[t] = y[t];
+    std::vector<bool> obs;
+    if (observed) {
+      obs.resize(T);
+      for (int t = 0; t < T; ++t) obs[t] = observed[t] != 0;
+    }
+    NEW(StateSpaceRegressionModel, model)(yv, Xm, obs);
+    RegressionModel *reg = model->observation_model();
+    Vector mu(p), piv(p);
+    SpdMatrix om(p);
+    for (int j = 0; j < p; ++j) {
+      mu[j] = prior_mean[j];
+      piv[j] = pi[j];
+      for (int i = 0; i < p; ++i) om(i, j) = ominv[(size_t)j * p + i];
+    }
+    NEW(MvnGivenScalarSigma, slab)(mu, om, reg->Sigsq_prm());
+    NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+    NEW(VariableSelectionPrior, spike)(piv);
+    reg->coef().drop_all();
+    for (int j = 0; j < p; ++j)
+      if (init_gamma[j]) reg->coef().add(j);
+
+    const int ns1 = nseasons > 0 ? nseasons - 1 : 0, m = trend + ns1;
+    std::vector<DeviceStateVariancePrior> vpriors;
+    auto vprior = [&](int slot) {
+      DeviceStateVariancePrior pr;
+      pr.precision_prior = new ChisqModel(var_df[slot], var_sigma_guess[slot]);
+      pr.sigma_upper_limit = var_sigma_upper_limit[slot];
+      vpriors.push_back(pr);
+    };
+    Ptr<LocalLevelStateModel> level;
+    Ptr<LocalLinearTrendStateModel> llt;
+    Ptr<SeasonalStateModel> seasonal;
+    if (trend == 1) {
+      level = new LocalLevelStateModel(var_initial_sigma[0]);
+      level->set_initial_state_mean(initial_state_mean[0]);
+      level->set_initial_state_variance(initial_state_variance[0]);
+      model->add_state(level);
+      vprior(0);
+    } else {
+      llt = new LocalLinearTrendStateModel;
+      SpdMatrix Sigma(2, 0.0);
+      Sigma(0, 0) = var_initial_sigma[0] * var_initial_sigma[0];
+      Sigma(1, 1) = var_initial_sigma[1] * var_initial_sigma[1];
+      llt->set_Sigma(Sigma);
+      Vector a0(2);
+      SpdMatrix P0(2, 0.0);
+      for (int i = 0; i < 2; ++i) {
+        a0[i] = initial_state_mean[i];
+        P0(i, i) = initial_state_variance[i];
+      }
+      llt->set_initial_state_mean(a0);
+      llt->set_initial_state_variance(P0);
+      model->add_state(llt);
+      vprior(0);
+      vprior(1);
+    }
+    if (nseasons > 0) {
+      seasonal = new SeasonalStateModel(nseasons, 1);
+      seasonal->set_sigsq(var_initial_sigma[2] * var_initial_sigma[2]);
+      Vector a0(ns1);
+      SpdMatrix P0(ns1, 0.0);
+      for (int i = 0; i < ns1; ++i) {
+        a0[i] = initial_state_mean[trend + i];
+        P0(i, i) = initial_state_variance[trend + i];
+      }
+      seasonal->set_initial_state_mean(a0);
+      seasonal->set_initial_state_variance(P0);
+      model->add_state(seasonal);
+      vprior(2);
+    }
+
+    NEW(DeviceStateSpacePosteriorSampler, sampler)(model.get(), slab, siginv_prior, spike,
+                                                   sigma_upper_limit, vpriors, chains);
+    if (out_seed) *out_seed = sampler->device_seed();
+    model->set_method(sampler);
+    for (int s = 0; s < nsweeps; ++s) {
+      model->sample_posterior();   // PriorPolicy::sample_posterior -> sampler->draw()
+      const Selector &inc(reg->coef().inc());
+      const Vector beta = reg->Beta();
+      for (int j = 0; j < p; ++j) {
+        out_gamma[(size_t)s * p + j] = inc[j] ? 1 : 0;
+        out_beta[(size_t)s * p + j] = beta[j];
+      }
+      out_sigsq[s] = reg->sigsq();
+      double *v = out_variances + (size_t)s * 3;
+      v[0] = v[1] = v[2] = 0.0;
+      if (level) {
+        v[0] = level->sigsq();
+      } else {
+        v[0] = llt->Sigma()(0, 0);
+        v[1] = llt->Sigma()(1, 1);
+      }
+      if (seasonal) v[2] = seasonal->sigsq();
+      const Matrix &state(model->state());
+      if (state.nrow() != m || state.ncol() != T) throw std::runtime_error("state has the wrong shape");
+      for (int t = 0; t < T; ++t)
+        for (int i = 0; i < m; ++i) out_state[((size_t)s * T + t) * m + i] = state(i, t);
+      if (out_logpri) out_logpri[s] = sampler->logpri();
+    }
+    if (probe_gamma) {
+      Selector inc(p, false);
+      Vector beta, variances;
+      Matrix state;
+      double s2 = 0;
+      sampler->chain_state(probe_chain, inc, beta, s2, variances, state);
+      for (int j = 0; j < p; ++j) probe_gamma[j] = inc[j] ? 1 : 0;
+      for (int t = 0; t < T; ++t)
+        for (int i = 0; i < m; ++i) probe_state[(size_t)t * m + i] = state(i, t);
     }
     return 0;
   } catch (std::exception &e) {

@@ -1110,7 +1110,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
   e->sumy = ybar * n;
   e->have_suf = true;
   e->device_dirty = true;
-  e->probit_mode = e->logit_mode = false;   // (regression data now; the binomial setters say otherwise after this)
+  e->probit_mode = e->logit_mode = e->ss_mode = false;   // (plain regression data now; the binomial and state-space setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1147,7 +1147,7 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
   e->n = (double)n;
   e->have_suf = true;
   e->device_dirty = true;
-  e->probit_mode = e->logit_mode = false;   // (regression data now; the binomial setters say otherwise after this)
+  e->probit_mode = e->logit_mode = e->ss_mode = false;   // (plain regression data now; the binomial and state-space setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1193,7 +1193,7 @@ int ba_set_suf_from_block_device(ba_engine *e, int64_t n_total, int32_t p,
   e->n = (double)n_total;
   e->have_suf = true;
   e->device_dirty = true;
-  e->probit_mode = e->logit_mode = false;   // (regression data now; the binomial setters say otherwise after this)
+  e->probit_mode = e->logit_mode = e->ss_mode = false;   // (plain regression data now; the binomial and state-space setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1390,6 +1390,8 @@ int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
   if (!gamma) return fail(BA_E_INVALID, "null argument");
   const int64_t C = e->cfg.chains;
   if (chain < -1 || chain >= C) return fail(BA_E_INVALID, "chain index out of range");
+  if ((e->probit_mode || e->logit_mode) && sigsq != 1.0)
+    return fail(BA_E_INVALID, "the binomial samplers' latent data have unit variance: sigsq must be 1");
   if (chain < 0) la_discard(e);  // every chain is overwritten: nothing to rewind to
   MUTATE(e);
   // launches in flight (and sweeps still owed after a capacity stop) belong to
@@ -1577,6 +1579,8 @@ namespace {
 int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
+  if (e->logit_mode || e->probit_mode)
+    return fail(BA_E_STATE, "binomial data are set: use ba_logit_sweep / ba_probit_sweep (the regression sampler has no meaning on latent data)");
   int rc = switch_mode(e, 0, 1.0);
   if (rc) return rc;
   rc = upload_shared(e);
@@ -1593,6 +1597,9 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
     P.rec_idx = nullptr;
     P.rec_beta = nullptr;
     P.trace_stride = 0;
+    P.trace_idx = nullptr;   // ... and nothing of the record is valid any more (ba_predict checks)
+    if (e->trace_stride > 0)
+      HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
   }
   const SsvsLds lay = ssvs_lds_layout(e->p, e->kcap);
   if (lay.total > e->lds_per_cu)
@@ -1881,6 +1888,14 @@ int ba_predict(ba_engine *e, int32_t first_draw, int32_t ndraws, int32_t nnew, c
   int rc = ba_sync(e);
   if (rc) return rc;
   const size_t C = (size_t)e->cfg.chains;
+  {
+    // only rows that the last recorded call actually wrote hold a draw
+    std::vector<int32_t> rows(C);
+    HIP_TRY(hipMemcpy(rows.data(), e->dtrace_idx.ptr, C * 4, hipMemcpyDeviceToHost));
+    const int32_t have = *std::min_element(rows.begin(), rows.end());
+    if (first_draw + ndraws > have)
+      return fail(BA_E_INVALID, "draw range extends beyond the draws recorded by the last sweep call");
+  }
   DevBuf<double> dX, dout;
   HIP_TRY(dX.resize((size_t)nnew * e->p));
   HIP_TRY(dout.resize(C * (size_t)ndraws * nnew));
@@ -1949,6 +1964,8 @@ int ba_set_sigsq(ba_engine *e, int64_t chain, double sigsq) {
   ENGINE_PROLOGUE(e);
   MUTATE(e);
   if (!(sigsq > 0)) return fail(BA_E_INVALID, "sigsq must be positive");
+  if ((e->probit_mode || e->logit_mode) && sigsq != 1.0)
+    return fail(BA_E_INVALID, "the binomial samplers' latent data have unit variance: sigsq must be 1");
   int rc = alloc_chain_state(e);
   if (rc) return rc;
   const int64_t C = e->cfg.chains;
@@ -2024,6 +2041,10 @@ int ba_probit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, cons
   MUTATE(e);
   if (!X || !y || !ntrials) return fail(BA_E_INVALID, "null argument");
   if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
+  // up to 2 * clt_threshold truncated-normal draws per observation read the
+  // observation's substream of PROBIT_STRIDE uniforms (a draw takes 2 - 20 of them)
+  if (clt_threshold < 0 || clt_threshold > 64)
+    return fail(BA_E_INVALID, "clt_threshold must be between 0 and 64");
   for (int64_t i = 0; i < n; ++i) {
     if (y[i] < 0 || ntrials[i] < 0)
       return fail(BA_E_INVALID, "Negative values not allowed in BinomialProbitDataImputer::impute().");
@@ -2031,7 +2052,12 @@ int ba_probit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, cons
       return fail(BA_E_INVALID, "Success count exceeds trial count in BinomialProbitDataImputer::impute.");
   }
   // refresh_xtx (BinomialProbitSpikeSlabSampler.cpp:71-77): X'NX, built on the
-  // matrix cores from the rows scaled by sqrt(n_i) (exact for Bernoulli data)
+  // matrix cores from the rows scaled by sqrt(n_i).  Exact for Bernoulli data; for
+  // trial counts that are not perfect squares sqrt(n_i)^2 differs from n_i by one
+  // rounding, i.e. an element differs from the reference's sum_i n_i x x' by no more
+  // than the two summation orders already differ (~1e-16 relative per term).  The
+  // binomial cases of tests/test_probit_gpu.py (1 - 8 and 1 - 12 trials) hold the
+  // inclusion indicators bit-exact against the oracle on this matrix.
   std::vector<double> Xs((size_t)n * p), zero((size_t)n, 0.0);
   for (int32_t j = 0; j < p; ++j)
     for (int64_t i = 0; i < n; ++i) Xs[(size_t)j * n + i] = X[(size_t)j * n + i] * std::sqrt(ntrials[i]);
@@ -2067,7 +2093,10 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps) {
     HIP_TRY(e->dprob_z.resize(C * n));
     HIP_TRY(e->dxty_c.resize(C * p));
     HIP_TRY(e->dlogit_planes.resize((size_t)xtwx_cols_planes((int64_t)n) * C * p));   // (split-K planes of X'z)
-    // the latent data have unit variance: sigma^2 = 1 in every chain
+  }
+  {
+    // the latent data have unit variance: sigma^2 = 1 in every chain, whatever a
+    // caller left there before the binomial data were set
     std::vector<double> one(C, 1.0);
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->dsigsq.ptr, one.data(), C * 8, hipMemcpyHostToDevice));
@@ -2179,7 +2208,9 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
     e->logit_req_batch = (int64_t)std::min<size_t>(std::max<size_t>(((size_t)1 << 30) / per_req, 64), 32768);
     e->logit_req_batch = std::min<int64_t>(e->logit_req_batch, (int64_t)(C * p));
     HIP_TRY(e->dlogit_planes.resize((size_t)e->logit_req_batch * per_req / 8));
-    std::vector<double> one(C, 1.0);
+  }
+  {
+    std::vector<double> one(C, 1.0);   // (sigma^2 = 1: see ba_probit_sweep)
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->dsigsq.ptr, one.data(), C * 8, hipMemcpyHostToDevice));
   }
@@ -2272,6 +2303,8 @@ int ba_adaptive_sweep(ba_engine *e, int32_t nsweeps) {
   MUTATE(e);
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
+  if (e->logit_mode || e->probit_mode)
+    return fail(BA_E_STATE, "binomial data are set: use ba_logit_sweep / ba_probit_sweep (the regression sampler has no meaning on latent data)");
   int rc = alloc_chain_state(e);
   if (rc) return rc;
   rc = switch_mode(e, 2, 1.0);

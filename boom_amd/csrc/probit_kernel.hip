@@ -256,7 +256,14 @@ __device__ __forceinline__ int included_coefficients(const ProbitParams &P, int 
 // grid = (ceil(n / 256), chains), block = 256
 __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (P.status[chain] != CHAIN_OK) return;
+  // Other workgroups of this chain may write the status word during this launch
+  // (CHAIN_RNG_BRANCH, CHAIN_MODEL_TOO_LARGE below): the decision to skip a chain in
+  // error is taken ONCE per workgroup and shared, so that every wave of the workgroup
+  // reaches the barriers below or none does.
+  __shared__ int s_status;
+  if (threadIdx.x == 0) s_status = __atomic_load_n(P.status + chain, __ATOMIC_RELAXED);
+  __syncthreads();
+  if (s_status != CHAIN_OK) return;
   // the chain's included variables, once per workgroup
   __shared__ int s_idx[PROBIT_KMAX];
   __shared__ double s_beta[PROBIT_KMAX];
@@ -312,7 +319,10 @@ __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
                                 0.105680086433879, 0.345939491553619, 0.0442261124345564,
                                 0.193289780660134, 0.068173066865908, 0.00452437089387876};
   const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (P.status[chain] != CHAIN_OK) return;
+  __shared__ int s_status;   // (one decision per workgroup: see probit_impute_kernel)
+  if (threadIdx.x == 0) s_status = __atomic_load_n(P.status + chain, __ATOMIC_RELAXED);
+  __syncthreads();
+  if (s_status != CHAIN_OK) return;
   __shared__ int s_idx[PROBIT_KMAX];
   __shared__ double s_beta[PROBIT_KMAX];
   const int k = included_coefficients(P, chain, s_idx, s_beta);

@@ -79,6 +79,10 @@ struct PyBinomialModel {
   }
   void materialise(int clt_threshold) {
     if (!have_data) throw std::runtime_error("add_dataset(successes, trials, predictors) before attaching a sampler");
+    // a sampler holds a raw pointer to the device model (as BOOM's samplers hold their
+    // model): replacing it under a sampler already attached would leave that sampler
+    // dangling, so the device model is created exactly once
+    if (impl) throw std::runtime_error("a sampler has already been attached to this model: create a new model to change clt_threshold or the sampler");
     if (logit) impl.reset(new BinomialLogitModel(X, y, n, clt_threshold, chains, seed, device));
     else impl.reset(new BinomialProbitModel(X, y, n, clt_threshold, chains, seed, device));
     impl->drop_all();

@@ -1,10 +1,10 @@
 """The drop-in boundary exercised from the REFERENCE's side: BOOM's own
-RegressionModel, prior objects and `model->sample_posterior()` loop, with
-oracle/binding/DeviceBregVsSampler (a BOOM::PosteriorSampler subclass that
-forwards draw() to the C-ABI) as the sampling method.  The library
-oracle/_ref/libboomref_binding.so is built in the build container from the
-reference's sources + our binding + libboomamd.so (oracle/Makefile, target
-`binding`) and travels to the GPU box as a built file.
+RegressionModel / BinomialLogitModel / StateSpaceRegressionModel, prior objects and
+`model->sample_posterior()` loop, with the samplers of bindings/boom/
+(BOOM::PosteriorSampler subclasses that forward draw() to the C-ABI) as the sampling
+method.  The library oracle/_ref/libboomref_binding.so is built in the build
+container from the reference's sources + our bindings + libboomamd.so
+(oracle/Makefile, target `binding`) and travels to the GPU box as a built file.
 
 What the BOOM model object sees after every draw (coef().inc(), Beta(),
 sigsq()) must be the oracle's chain 0 on the same Philox key: gamma bit-exact,
@@ -76,7 +76,7 @@ def test_boom_model_driven_by_the_device_sampler(oracle, lookahead):
 def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_flips):
     """BOOM's BinomialLogitModel (data added observation by observation), MvnModel slab and
     VariableSelectionPrior, stepped by model->sample_posterior() with
-    oracle/binding/DeviceBinomialLogitSpikeSlabSampler attached: what the BOOM model sees
+    bindings/boom/DeviceBinomialLogitSpikeSlabSampler attached: what the BOOM model sees
     after every draw is the oracle's chain 0 on the same Philox key (f3's boundary)."""
     from cases import logit_data, probit_slab
     L = C.CDLL(BINDING_SO)
@@ -107,3 +107,80 @@ def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_f
                           max_flips=max_flips)
     assert np.array_equal(pg, ol["gamma"][-1])
     assert np.max(np.abs(pb - ol["beta"][-1]) / np.maximum(np.abs(ol["beta"][-1]), 1e-3)) < 1e-8
+
+
+@pytest.mark.skipif(not os.path.exists(BINDING_SO),
+                    reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
+@pytest.mark.parametrize("trend,nseasons,T,missing", [(1, 0, 300, 0.04), (2, 0, 150, 0.0),
+                                                        (1, 7, 200, 0.0), (2, 4, 150, 0.05)])
+def test_boom_state_space_model_driven_by_the_device_sampler(oracle, trend, nseasons, T, missing):
+    """The bsts half of the boundary: BOOM's own
+    StateSpaceRegressionModel(y, X, observed) with a LocalLevelStateModel -- or a local
+    linear trend and / or a SeasonalStateModel added with add_state -- stepped by
+    model->sample_posterior() with bindings/boom/DeviceStateSpacePosteriorSampler as its
+    sampling method (in StateSpacePosteriorSampler's place,
+    Models/StateSpace/PosteriorSamplers/StateSpacePosteriorSampler.cpp:42-64).  What the
+    BOOM objects hold after every draw -- regression_model()'s inc / Beta / sigsq, the
+    state models' variances, model->state() -- is the oracle's chain 0 on the same
+    Philox key: gamma bit-exact, the rest within 1e-8."""
+    from cases import bsts_priors, structural_data, structural_spec
+    L = C.CDLL(BINDING_SO)
+    L.ref_binding_last_error.restype = C.c_char_p
+    p, chains, nsw, seed = 7, 6, 15, 4242
+    X, y, _, obs = structural_data(T, p, 2, nseasons, seed=21 + nseasons, missing_frac=missing)
+    prior, ss, sig_up = bsts_priors(X, y, 2)
+    spec = structural_spec(y, trend, nseasons)
+    m = trend + (nseasons - 1 if nseasons > 0 else 0)
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(p, np.uint8)
+    gam = np.zeros((nsw, p), np.uint8)
+    beta = np.zeros((nsw, p))
+    sig = np.zeros(nsw)
+    var = np.zeros((nsw, 3))
+    state = np.zeros((nsw, T, m))
+    logpri = np.zeros(nsw)
+    dev_seed = C.c_uint64()
+    pg = np.zeros(p, np.uint8)
+    pstate = np.zeros((T, m))
+    obs8 = None if obs is None else np.ascontiguousarray(obs, np.uint8)
+    rc = L.ref_binding_ss_run(
+        T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs8), _dp(f64(prior["b"])), _dp(fcol(prior["ominv"])),
+        C.c_double(prior["df"]), C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+        C.c_double(sig_up), trend, nseasons, _dp(f64(spec["var_df"])),
+        _dp(f64(spec["var_sigma_guess"])), _dp(f64(spec["var_sigma_upper_limit"])),
+        _dp(f64(spec["var_initial_sigma"])), _dp(f64(spec["initial_state_mean"])),
+        _dp(f64(spec["initial_state_variance"])), chains, C.c_uint64(seed), _u8(g0), nsw,
+        _u8(gam), _dp(beta), _dp(sig), _dp(var), _dp(state), _dp(logpri), C.byref(dev_seed),
+        chains - 1, _u8(pg), _dp(pstate))
+    assert rc == 0, L.ref_binding_last_error().decode()
+
+    def run(c):
+        return oracle.ssm_run(y, X, obs, prior, opts, spec, ("philox", dev_seed.value, c), g0, nsw)
+    o = run(0)
+    assert o["status"] == 0
+    idx = [0] + ([1] if trend == 2 else []) + ([2] if nseasons > 0 else [])
+    for s in range(nsw):
+        assert np.array_equal(gam[s], o["gamma"][s]), s
+        err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
+        assert err < 1e-8, (s, err)
+        assert abs(sig[s] - o["sigsq"][s]) < 1e-8 * sig[s], s
+        assert np.max(np.abs(var[s][idx] - o["variances"][s][idx]) / o["variances"][s][idx]) < 1e-8, s
+        scale = np.abs(o["state"][s]).max()
+        assert np.max(np.abs(state[s] - o["state"][s])) < 1e-8 * scale, s
+    assert np.all(np.isfinite(logpri))
+    # the lone local level goes through the local-level kernel (ba_ss_set_local_level):
+    # the same chain as the oracle's dedicated local-level sampler
+    if trend == 1 and nseasons == 0:
+        ss1 = dict(level_df=spec["var_df"][0], level_sigma_guess=spec["var_sigma_guess"][0],
+                   level_sigma_upper_limit=spec["var_sigma_upper_limit"][0],
+                   initial_state_mean=spec["initial_state_mean"][0],
+                   initial_state_variance=spec["initial_state_variance"][0],
+                   initial_level_sigma=spec["var_initial_sigma"][0])
+        o1 = oracle.ss_run(y, X, obs, prior, opts, ss1, ("philox", dev_seed.value, 0), g0, nsw)
+        assert np.array_equal(gam, o1["gamma"])
+        assert np.max(np.abs(var[:, 0] - o1["level_sigsq"]) / o1["level_sigsq"]) < 1e-8
+        assert np.max(np.abs(state[:, :, 0] - o1["state"])) < 1e-8 * np.abs(o1["state"]).max()
+    # the other chains are there too
+    ol = run(chains - 1)
+    assert np.array_equal(pg, ol["gamma"][-1])
+    assert np.max(np.abs(pstate - ol["state"][-1])) < 1e-8 * np.abs(ol["state"][-1]).max()
