@@ -90,6 +90,215 @@ def usable_cores():
     return max(1, n)
 
 
+F64_MATRIX_PEAK_TF = 78.6   # MI355X FP64 matrix spec (the guide's table stops at FP32; AMD data sheet)
+
+
+def _per_launch(times):
+    return {k: round(ms / max(1, n) * 1e3, 2) for k, (ms, n) in times.items()}   # microseconds
+
+
+def _cpu_rate(fn, nchains, cores, target_s=6.0, first=4):
+    """sweeps/s of `fn(chain, nsweeps)` run for nchains chains on `cores` threads:
+    one short calibration run, then a run sized for about target_s seconds"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def timed(nsw):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda c: fn(c, nsw), range(nchains)))
+        return time.perf_counter() - t0
+    dt = timed(first)
+    nsw = int(max(first, min(2000, target_s / max(dt / first, 1e-9))))
+    if nsw > first:
+        dt = timed(nsw)
+    else:
+        nsw = first
+    return nchains * nsw / dt, nsw
+
+
+def other_configs(boom_amd, torch, device, cpu=True):
+    from cases import bsts_priors, logit_data, probit_slab, spike_slab_prior, state_space_data
+    from oracle_lib import Oracle, ssvs_options
+    cores = usable_cores()
+    O = Oracle() if cpu else None
+    other = {}
+
+    # ---- configs[2]: bsts local level + regression, T=2000 p=100, 1024 chains ---------
+    T3, p3, C3 = 2000, 100, 1024
+    Xs, ys, _, _ = state_space_data(T3, p3, 5, seed=DATA_SEED)
+    pr3, ss3, sig_up = bsts_priors(Xs, ys, 5)
+    e3 = boom_amd.Engine(C3, seed=SAMPLER_SEED, device=device)
+    e3.ss_set_data(ys, Xs, None)
+    e3.set_priors(pr3["b"], pr3["ominv"], pr3["pi"], pr3["df"], pr3["sigma_guess"],
+                  sigma_upper_limit=sig_up)
+    e3.ss_set_local_level(ss3["level_df"], ss3["level_sigma_guess"], ss3["level_sigma_upper_limit"],
+                          ss3["initial_state_mean"], ss3["initial_state_variance"],
+                          ss3["initial_level_sigma"])
+    e3.set_state(np.zeros(p3, np.uint8))
+    e3.ss_sweep(50)
+    t0 = time.perf_counter()
+    e3.ss_sweep(200)
+    dt = time.perf_counter() - t0
+    k3 = float(e3.get_states()[0].sum(1).mean())
+    e3.set_kernel_timing(True)
+    e3.ss_sweep(100)
+    kt = _per_launch(e3.kernel_times())
+    e3.set_kernel_timing(False)
+    # SURVEY 8(d): Kalman bytes per chain-sweep f (T + 2T); the regression half reads the
+    # shared design matrix once per launch: T p f
+    bytes3 = C3 * 3 * T3 * 8 + T3 * p3 * 8
+    dom = max(kt, key=kt.get)
+    rec = {"sweeps_per_s": round(C3 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
+           "mean_model_size": round(k3, 2), "kernel_us_per_launch": kt,
+           "roofline": {"bound": "hbm", "kernel": "kalman_simsmooth_kernel",
+                        "algorithmic_bytes_per_round": bytes3,
+                        "achieved": round(bytes3 / (kt["kalman_simsmooth_kernel"] * 1e-6) / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(bytes3 / (kt["kalman_simsmooth_kernel"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        "round_frac": round(bytes3 / dt * 200 / 1e9 / HBM_PEAK_GBS, 4),
+                        "slowest_kernel_of_the_round": dom, "traffic": None}}
+    if cpu:
+        opts3 = ssvs_options(sigma_upper_limit=sig_up)
+        g3 = np.zeros(p3, np.uint8)
+        rate, nsw = _cpu_rate(lambda c, n: O.ss_run(ys, Xs, None, pr3, opts3, ss3,
+                                                    ("philox", SAMPLER_SEED, c), g3, n),
+                              cores, cores)
+        rec["cpu_baseline"] = {"value": round(rate, 2), "unit": "sweeps/s", "cores": cores, "kind": "port",
+                               "sample": "%d chains x %d sweeps from the empty model on %d threads "
+                                         "(oracle bo_ss_draw), same T=2000 p=100 data" % (cores, nsw, cores)}
+    other["configs[2] bsts local level + regression T=2000 p=100, 1024 chains"] = rec
+    e3.close()
+
+    # ---- configs[3] per GPU: n=1e5 p=4096, 8192 chains / 8 GPUs = 1024 (the design matrix
+    # is drawn on the device: 3.3 GB; X'X by the MFMA syrk; 32 signals) --------------------
+    n4, p4, sig4, C4 = 100000, 4096, 32, 1024
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(DATA_SEED)
+    X4 = torch.randn((p4, n4), dtype=torch.float64, device="cuda", generator=gen)   # column-major n x p
+    X4[0].fill_(1.0)
+    b4 = torch.zeros(p4, dtype=torch.float64, device="cuda")
+    b4[:sig4] = torch.tensor([(1.0 + 0.1 * (i % 7)) * (-1.0) ** i for i in range(sig4)],
+                             dtype=torch.float64, device="cuda")
+    y4 = (b4[:sig4, None] * X4[:sig4]).sum(0) + torch.randn(n4, dtype=torch.float64, device="cuda", generator=gen)
+    torch.cuda.synchronize()
+    e4 = boom_amd.Engine(C4, seed=SAMPLER_SEED, device=device)
+    e4.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    e4.build_suf_from_xy_device(n4, p4, X4.data_ptr(), y4.data_ptr())
+    e4.sync()
+    build4 = time.perf_counter() - t0
+    suf_ms = e4.kernel_times()["xtx_mfma_kernel+plane_sum_kernel+col_reduce_kernel"][0]
+    e4.set_kernel_timing(False)
+    del X4
+    s4 = e4.get_suf()
+    suf4 = dict(xtx=s4["xtx"], xty=s4["xty"], yty=s4["yty"], n=s4["n"], sumy=s4["ybar"] * s4["n"],
+                xsum=s4["xbar"] * s4["n"])
+    pr4 = spike_slab_prior(suf4, sig4)
+    e4.set_priors(pr4["b"], pr4["ominv"], pr4["pi"], pr4["df"], pr4["sigma_guess"])
+    g4 = np.zeros(p4, np.uint8)
+    g4[0] = 1
+    e4.set_state(g4)
+    e4.sweep(60)
+    e4.reset_summaries()
+    t0 = time.perf_counter()
+    e4.sweep(40)
+    dt = time.perf_counter() - t0
+    sm4 = e4.get_summaries()
+    k4 = sm4["k_sum"] / sm4["sweeps"]
+    gam4, beta4, sig4v = e4.get_states()
+    e4.set_kernel_timing(True)
+    e4.sweep(40)
+    kt = e4.kernel_times()
+    e4.set_kernel_timing(False)
+    ms40 = sum(ms for ms, _ in kt.values())      # (the LDS kernel, and the large-model one if any chain needed it)
+    bytes4 = (p4 * 8.0 * (2 * k4 + 4) + 8.0 * (3 * k4 + 4) + p4 / 8.0) * C4 * 40
+    rec = {"sweeps_per_s": round(C4 * 40 / dt, 1), "ms_per_round": round(dt / 40 * 1e3, 3),
+           "suf_build_ms": round(build4 * 1e3, 1),
+           "mean_model_size": round(float(k4), 2),
+           "signal_inclusion_min": round(float(gam4[:, :sig4].mean(0).min()), 4),
+           "kernel_ms_per_40_sweep_launch": {k: round(ms, 3) for k, (ms, _) in kt.items()},
+           "roofline": {"bound": "hbm", "kernel": "ssvs_sweep_kernel",
+                        "algorithmic_bytes_per_launch": round(bytes4, 0),
+                        "achieved": round(bytes4 / (ms40 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(bytes4 / (ms40 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic": None},
+           "suf_roofline": {"bound": "mfma", "kernel": "xtx_mfma_kernel", "ms": round(suf_ms, 3),
+                            "achieved": round(n4 * float(p4) * p4 / (suf_ms * 1e-3) / 1e12, 2),
+                            "peak": F64_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": round(n4 * float(p4) * p4 / (suf_ms * 1e-3) / 1e12 / F64_MATRIX_PEAK_TF, 4),
+                            "note": "flops = n p^2 (SURVEY 8d: syrk half); the whole build incl. X'y and sums"}}
+    if cpu:
+        def run4(nchains, nsw, nthreads):
+            t0 = time.perf_counter()
+            O.run_chains(suf4, pr4, ssvs_options(), SAMPLER_SEED, nchains, nsw, nthreads,
+                         gam4[0], beta4[0], float(sig4v[0]))
+            return nchains * nsw / (time.perf_counter() - t0)
+        cal = run4(cores, 2, cores)
+        nsw = int(max(2, min(400, 6.0 * cal / cores)))
+        rate = run4(cores, nsw, cores)
+        rec["cpu_baseline"] = {"value": round(rate, 2), "unit": "sweeps/s", "cores": cores, "kind": "port",
+                               "sample": "%d chains x %d sweeps on %d pthreads, warm-started at a GPU chain's "
+                                         "state (kbar~%.1f), same n=1e5 p=4096 statistics" % (cores, nsw, cores, k4)}
+    other["configs[3] per GPU: spike-and-slab n=1e5 p=4096, 1024 chains"] = rec
+    e4.close()
+    del s4, suf4, pr4
+    torch.cuda.empty_cache()
+
+    # ---- configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 4096 chains / 8 GPUs = 512
+    # (the reference's auxiliary-mixture imputer; it has no Polya-Gamma sampler) ----------
+    n5, p5, C5 = 50000, 1024, 512
+    Xl, yl, ntl, _ = logit_data(n5, p5, 8, seed=DATA_SEED)
+    slab5, pi5 = probit_slab(Xl, ntl, 8)
+    e5 = boom_amd.Engine(C5, seed=SAMPLER_SEED, device=device)
+    e5.logit_set_data(Xl, yl, ntl, 5)
+    e5.sss_set_slab(slab5["mu"], slab5["prec"], scales_with_sigsq=False)
+    e5.set_spike(pi5)
+    g5 = np.zeros(p5, np.uint8)
+    g5[0] = 1
+    e5.set_state(g5)
+    e5.logit_sweep(15)
+    t0 = time.perf_counter()
+    e5.logit_sweep(30)
+    dt = time.perf_counter() - t0
+    gam5 = e5.get_states()[0]
+    k5 = float(gam5.sum(1).mean())
+    e5.set_kernel_timing(True)
+    e5.logit_sweep(10)
+    kt = {k: round(ms / 10, 3) for k, (ms, _) in e5.kernel_times().items()}    # ms per round
+    e5.set_kernel_timing(False)
+    cols = "xtwx_cols_kernel<true>+xtwx_cols_reduce_kernel"
+    flops5 = 2.0 * n5 * p5 * k5 * C5       # the request GEMM: R = sum of model sizes rows of p, n deep
+    rec = {"sweeps_per_s": round(C5 * 30 / dt, 1), "ms_per_round": round(dt / 30 * 1e3, 2),
+           "mean_model_size": round(k5, 2),
+           "signal_inclusion_min": round(float(gam5[:, :8].mean(0).min()), 4),
+           "kernel_ms_per_round": kt,
+           "roofline": {"bound": "mfma", "kernel": "xtwx_cols_kernel<true>",
+                        "flops_per_round": flops5, "achieved": round(flops5 / (kt[cols] * 1e-3) / 1e12, 2),
+                        "peak": F64_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(flops5 / (kt[cols] * 1e-3) / 1e12 / F64_MATRIX_PEAK_TF, 4),
+                        "traffic": None,
+                        "note": "v_mfma_f64_16x16x4_f64; R taken as chains x mean model size (the vectors "
+                                "requested mid-sweep add a few percent)"}}
+    if cpu:
+        nsub = 5000
+        th = min(cores, 8)
+        Xsub, ysub, ntsub = np.ascontiguousarray(Xl[:nsub]), yl[:nsub], ntl[:nsub]
+        slabs, pis = probit_slab(Xsub, ntsub, 8)
+        rate, nsw = _cpu_rate(lambda c, n: O.logit_run(Xsub, ysub, ntsub, slabs, pis,
+                                                       ("philox", SAMPLER_SEED, c), g5, np.zeros(p5), n),
+                              th, th, target_s=10.0, first=1)
+        rec["cpu_baseline"] = {"value": round(rate * nsub / n5, 3), "unit": "sweeps/s", "cores": th,
+                               "kind": "port",
+                               "sample": "%d chains x %d sweeps on %d threads on the FIRST %d of the %d "
+                                         "observations, rate scaled by %d/%d (a sweep of the reference "
+                                         "algorithm is dominated by the n p^2 rebuild of X'WX, linear in n: "
+                                         "one full-size sweep takes about a minute per chain)"
+                                         % (th, nsw, th, nsub, n5, nsub, n5)}
+    other["configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 512 chains"] = rec
+    e5.close()
+    return other
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +368,8 @@ def main():
         # the multi-GPU data path: local MFMA syrk on the rank's rows, ONE all-reduce
         # of (X'X | X'y | y'y | sums) over RCCL, every rank installs the (bitwise
         # identical) total
-        bd.build_suf_row_sharded(eng, Xd, yd, N_OBS, world)
+        suf_block = bd.build_suf_row_sharded(eng, Xd, yd, N_OBS, world)
+        suf_block = suf_block.cpu().numpy() if args.dump_blocks else None
     else:
         eng.build_suf_from_xy_device(N_OBS, P, Xd.data_ptr(), yd.data_ptr())
     suf_build_s = time.perf_counter() - t0
@@ -211,7 +421,7 @@ def main():
                             float(sr["n"])], dtype=torch.float64, device="cuda")
         digs = bd.gather_blocks(dig, world)
         if rank == 0:
-            np.savez(args.dump_blocks, blocks=allb, digests=digs, xtx=sr["xtx"], xty=sr["xty"])
+            np.savez(args.dump_blocks, blocks=allb, digests=digs, suf_block=suf_block)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -256,15 +466,22 @@ def main():
     flops_per_sweep = P * (4 * kbar ** 2 + 12 * kbar + 40) + kbar ** 3 / 3 + 4 * kbar ** 2
     launch_bytes = bytes_per_sweep * CHAINS_PER_GPU * SWEEPS_PER_STEP
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-    # HBM bytes per launch: NOT measured by this run -- read from the committed
-    # PMC passes of this same command (profiles/pmc_traffic.json: separate
-    # FETCH_SIZE / WRITE_SIZE rocprofv3 runs by the builder), and labelled so
+    # HBM bytes per launch: NOT measured by this run (counters need a profiler pass) --
+    # read from the committed PMC passes of this same command (tools/regen_profiles.sh:
+    # separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs, corrected as the guide says), and
+    # labelled with the commit they were taken at
     traffic, traffic_source = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_pmc_traffic.json")))
+        with open(cand[-1]) as fh:
             tj = json.load(fh)
-        traffic = tj["traffic_bytes"]
-        traffic_source = "profiles/pmc_traffic.json (builder's rocprofv3 --pmc run, %s)" % tj.get("round", "r01")
+        ent = [v for k, v in tj["kernels"].items() if k.startswith("ssvs_sweep_kernel")]
+        ent = max(ent, key=lambda v: v["dispatches"])
+        traffic = ent["traffic_bytes"]
+        traffic_source = ("profiles/%s: rocprofv3 --pmc passes of this command at commit %s; FETCH_SIZE "
+                          "doubled (upper bound), raw sum %d bytes"
+                          % (os.path.basename(cand[-1]), tj.get("commit"), ent["traffic_bytes_raw"]))
     except Exception:
         pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -298,91 +515,15 @@ def main():
             e2.close()
         curve[str(CHAINS_PER_GPU)] = round(value / world, 1)
 
-    # ---- the other BASELINE configurations at their per-GPU shapes (diagnostic extra
-    # key, outside the timed region: parity for them lives in tests/, these are rates
-    # measured in the same run as the headline) ----------------------------------
+    # ---- the other BASELINE configurations at their per-GPU shapes (extra key, outside
+    # the timed region; parity for them lives in tests/).  Per configuration: the rate of
+    # a plain throughput pass, then a second pass with the engine's per-kernel HIP-event
+    # timing on (ba_set_kernel_timing: events on the engine's stream around every
+    # launch) for the dominant kernel's roofline against SURVEY 8(d)'s bytes, and the
+    # oracle on the host cores on a bounded sample -------------------------------------
     other = None
     if not args.no_curve and world == 1:
-        from cases import bsts_priors, logit_data, probit_slab, state_space_data
-        other = {}
-        # configs[2]: bsts local level + regression, T=2000 p=100, 1024 chains
-        Xs, ys, _, _ = state_space_data(2000, 100, 5, seed=DATA_SEED)
-        pr3, ss3, sig_up = bsts_priors(Xs, ys, 5)
-        e3 = boom_amd.Engine(1024, seed=SAMPLER_SEED, device=local_rank)
-        e3.ss_set_data(ys, Xs, None)
-        e3.set_priors(pr3["b"], pr3["ominv"], pr3["pi"], pr3["df"], pr3["sigma_guess"],
-                      sigma_upper_limit=sig_up)
-        e3.ss_set_local_level(ss3["level_df"], ss3["level_sigma_guess"], ss3["level_sigma_upper_limit"],
-                              ss3["initial_state_mean"], ss3["initial_state_variance"],
-                              ss3["initial_level_sigma"])
-        e3.set_state(np.zeros(100, np.uint8))
-        e3.ss_sweep(50)
-        t0 = time.perf_counter()
-        e3.ss_sweep(200)
-        dt = time.perf_counter() - t0
-        other["configs[2] bsts local level + regression T=2000 p=100, 1024 chains"] = {
-            "sweeps_per_s": round(1024 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
-            "mean_model_size": round(float(e3.get_states()[0].sum(1).mean()), 2)}
-        e3.close()
-        # configs[3] per GPU: n=1e5 p=4096, 8192 chains / 8 GPUs = 1024 (the design matrix is
-        # drawn on the device: 3.3 GB; X'X by the MFMA syrk; 32 signals)
-        n4, p4, sig4 = 100000, 4096, 32
-        gen = torch.Generator(device="cuda")
-        gen.manual_seed(DATA_SEED)
-        X4 = torch.randn((p4, n4), dtype=torch.float64, device="cuda", generator=gen)   # column-major n x p
-        X4[0].fill_(1.0)
-        b4 = torch.zeros(p4, dtype=torch.float64, device="cuda")
-        b4[:sig4] = torch.tensor([(1.0 + 0.1 * (i % 7)) * (-1.0) ** i for i in range(sig4)],
-                                 dtype=torch.float64, device="cuda")
-        y4 = (b4[:sig4, None] * X4[:sig4]).sum(0) + torch.randn(n4, dtype=torch.float64, device="cuda", generator=gen)
-        torch.cuda.synchronize()
-        e4 = boom_amd.Engine(1024, seed=SAMPLER_SEED, device=local_rank)
-        t0 = time.perf_counter()
-        e4.build_suf_from_xy_device(n4, p4, X4.data_ptr(), y4.data_ptr())
-        e4.sync()
-        build4 = time.perf_counter() - t0
-        del X4
-        s4 = e4.get_suf()
-        pr4 = spike_slab_prior(dict(xtx=s4["xtx"], xty=s4["xty"], yty=s4["yty"], n=s4["n"],
-                                    sumy=s4["ybar"] * s4["n"], xsum=s4["xbar"] * s4["n"]), sig4)
-        e4.set_priors(pr4["b"], pr4["ominv"], pr4["pi"], pr4["df"], pr4["sigma_guess"])
-        g4 = np.zeros(p4, np.uint8)
-        g4[0] = 1
-        e4.set_state(g4)
-        e4.sweep(60)
-        t0 = time.perf_counter()
-        e4.sweep(40)
-        dt = time.perf_counter() - t0
-        gam4 = e4.get_states()[0]
-        other["configs[3] per GPU: spike-and-slab n=1e5 p=4096, 1024 chains"] = {
-            "sweeps_per_s": round(1024 * 40 / dt, 1), "ms_per_round": round(dt / 40 * 1e3, 3),
-            "suf_build_ms": round(build4 * 1e3, 1),
-            "mean_model_size": round(float(gam4.sum(1).mean()), 2),
-            "signal_inclusion_min": round(float(gam4[:, :sig4].mean(0).min()), 4)}
-        e4.close()
-        del s4, pr4
-        torch.cuda.empty_cache()
-        # configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 4096 chains / 8 GPUs = 512
-        # (the reference's auxiliary-mixture imputer; it has no Polya-Gamma sampler)
-        Xl, yl, ntl, _ = logit_data(50000, 1024, 8, seed=DATA_SEED)
-        slab5, pi5 = probit_slab(Xl, ntl, 8)
-        e5 = boom_amd.Engine(512, seed=SAMPLER_SEED, device=local_rank)
-        e5.logit_set_data(Xl, yl, ntl, 5)
-        e5.sss_set_slab(slab5["mu"], slab5["prec"], scales_with_sigsq=False)
-        e5.set_spike(pi5)
-        g5 = np.zeros(1024, np.uint8)
-        g5[0] = 1
-        e5.set_state(g5)
-        e5.logit_sweep(15)
-        t0 = time.perf_counter()
-        e5.logit_sweep(30)
-        dt = time.perf_counter() - t0
-        gam5 = e5.get_states()[0]
-        other["configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 512 chains"] = {
-            "sweeps_per_s": round(512 * 30 / dt, 1), "ms_per_round": round(dt / 30 * 1e3, 2),
-            "mean_model_size": round(float(gam5.sum(1).mean()), 2),
-            "signal_inclusion_min": round(float(gam5[:, :8].mean(0).min()), 4)}
-        e5.close()
+        other = other_configs(boom_amd, torch, local_rank, cpu=not args.no_cpu_baseline)
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) -------
     cpu = None
@@ -414,7 +555,8 @@ def main():
                          "correlation map shared by the threads" % (nchains, nswc, cores, nsw1, kbar),
                "port_vs_reference": "2.2x faster than the compiled reference per thread in the "
                                     "build container (317 vs 146 sweeps/s at this shape, 8-core "
-                                    "container; oracle/_ref never runs on the GPU box)"}
+                                    "container; on the GPU box the compiled reference is loaded by the tests "
+                                    "only -- reference-side binding, goldens -- and is not timed there)"}
 
     out = {
         "metric": "Gibbs sweeps/sec (all chains), n=1e4 p=512 spike-slab",

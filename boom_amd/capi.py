@@ -91,6 +91,10 @@ SIGNATURES = {
     "ba_get_coefficient_traces": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
                                             C.POINTER(C.c_int32), _dp]),
     "ba_stream": (C.c_void_p, [C.c_void_p]),
+    "ba_kernel_classes": (C.c_int32, []),
+    "ba_kernel_class_name": (C.c_char_p, [C.c_int32]),
+    "ba_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_get_kernel_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64), C.c_int32]),
     "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
     "ba_probit_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, C.c_int32]),
@@ -388,6 +392,20 @@ class Engine:
 
     def stream(self):
         return self.lib.ba_stream(self._h)
+
+    # ---- measurement ----------------------------------------------------------
+    def set_kernel_timing(self, enabled=True):
+        self._check(self.lib.ba_set_kernel_timing(self._h, int(enabled)))
+
+    def kernel_times(self, reset=True):
+        """{kernel class: (milliseconds, launches)} since the last reset"""
+        n = self.lib.ba_kernel_classes()
+        ms = np.zeros(n)
+        cnt = np.zeros(n, np.int64)
+        self._check(self.lib.ba_get_kernel_times(
+            self._h, _p(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64)), int(reset)))
+        return {self.lib.ba_kernel_class_name(i).decode(): (float(ms[i]), int(cnt[i]))
+                for i in range(n) if cnt[i] > 0}
 
     # ---- state space --------------------------------------------------------
     def ss_set_data(self, y, X, observed=None):

@@ -16,6 +16,7 @@
 
 #include "../../include/boom_amd.h"
 #include "kalman_params.h"
+#include "ktimer.h"
 #include "probit_params.h"
 #include "ssvs_params.h"
 
@@ -144,8 +145,63 @@ int status_code(int st) {
 
 }  // namespace
 
+// ba_set_kernel_timing: the event pairs of the launches since the last read
+struct KtSpan { int cls; hipEvent_t a, b; };
+struct KTimer {
+  std::vector<KtSpan> spans;
+  std::vector<hipEvent_t> open;   // begin events by class (launches do not nest within a class)
+  std::vector<hipEvent_t> pool;
+  double ms[KT_CLASSES] = {};
+  int64_t launches[KT_CLASSES] = {};
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  // fold the finished spans into the totals (the caller has synchronised the stream)
+  void collect() {
+    for (const KtSpan &sp : spans) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) { ms[sp.cls] += t; ++launches[sp.cls]; }
+      pool.push_back(sp.a);
+      pool.push_back(sp.b);
+    }
+    spans.clear();
+  }
+  ~KTimer() {
+    for (const KtSpan &sp : spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t e : open) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+  }
+};
+namespace {
+thread_local KTimer *g_kt = nullptr;   // the timer of the engine whose entry point this thread is in
+}
+namespace boom_amd {
+bool kt_active() { return g_kt != nullptr; }
+void kt_mark(hipStream_t stream, int cls, bool begin) {
+  KTimer *k = g_kt;
+  if (!k || cls < 0 || cls >= KT_CLASSES) return;
+  if (k->open.size() < (size_t)KT_CLASSES) k->open.resize(KT_CLASSES, nullptr);
+  hipEvent_t ev = k->get();
+  (void)hipEventRecord(ev, stream);
+  if (begin) {
+    if (k->open[cls]) k->pool.push_back(k->open[cls]);
+    k->open[cls] = ev;
+  } else if (k->open[cls]) {
+    k->spans.push_back(KtSpan{cls, k->open[cls], ev});
+    k->open[cls] = nullptr;
+  } else {
+    k->pool.push_back(ev);
+  }
+}
+}  // namespace boom_amd
+
 struct ba_engine {
   ba_config cfg{};
+  bool kt_enabled = false;
+  KTimer kt;
   hipStream_t stream = nullptr;
   int p = 0;
   int cu_count = 256;
@@ -1004,6 +1060,7 @@ int la_rewind(ba_engine *e) {
 
 #define ENGINE_PROLOGUE(e)                                     \
   if (!(e)) return fail(BA_E_INVALID, "null engine");          \
+  g_kt = (e)->kt_enabled ? &(e)->kt : nullptr;                 \
   {                                                            \
     int rc__ = set_device(e);                                  \
     if (rc__) return rc__;                                     \
@@ -1080,6 +1137,39 @@ int ba_engine_info(const ba_engine *e, int32_t *device, int32_t *chains,
 }
 
 void *ba_stream(ba_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+// ---- measurement: device time per kernel class (ktimer.h) ------------------------
+int32_t ba_kernel_classes(void) { return KT_CLASSES; }
+
+const char *ba_kernel_class_name(int32_t cls) {
+  static const char *const names[KT_CLASSES] = {
+      "ssvs_sweep_kernel", "ssvs_big_kernel", "ssvs_adaptive_kernel", "kalman_simsmooth_kernel",
+      "ssm_simsmooth_kernel", "atb_mfma_kernel", "probit_impute_kernel", "logit_impute_kernel",
+      "xtwx_cols_kernel<false>+plain_reduce_kernel", "xtwx_cols_kernel<true>+xtwx_cols_reduce_kernel",
+      "xtx_mfma_kernel+plane_sum_kernel+col_reduce_kernel", "poisson_impute_kernel"};
+  return (cls >= 0 && cls < KT_CLASSES) ? names[cls] : "";
+}
+
+int ba_set_kernel_timing(ba_engine *e, int32_t enabled) {
+  ENGINE_PROLOGUE(e);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->kt.collect();
+  e->kt_enabled = enabled != 0;
+  g_kt = e->kt_enabled ? &e->kt : nullptr;
+  return BA_OK;
+}
+
+int ba_get_kernel_times(ba_engine *e, double *ms, int64_t *launches, int32_t reset) {
+  ENGINE_PROLOGUE(e);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->kt.collect();
+  for (int c = 0; c < KT_CLASSES; ++c) {
+    if (ms) ms[c] = e->kt.ms[c];
+    if (launches) launches[c] = e->kt.launches[c];
+    if (reset) { e->kt.ms[c] = 0; e->kt.launches[c] = 0; }
+  }
+  return BA_OK;
+}
 
 // ---------------------------------------------------------------- data
 static int set_dimension(ba_engine *e, int p) {

@@ -34,6 +34,8 @@
 // to rounding (parity tolerance in tests/test_state_space_gpu.py).
 #include <hip/hip_runtime.h>
 
+#include "ktimer.h"
+
 #include "device_rng.h"
 #include "kalman_params.h"
 #include "stream_normals.h"
@@ -730,9 +732,13 @@ hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int
 
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level) {
-  hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chain_count), dim3(2 * WAVE), 0,
-                     stream, P, draw_level);
-  hipError_t err = hipGetLastError();
+  hipError_t err;
+  {
+    KtScope kt(stream, KT_KALMAN);
+    hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chain_count), dim3(2 * WAVE), 0,
+                       stream, P, draw_level);
+    err = hipGetLastError();
+  }
   if (err != hipSuccess) return err;
   // xty[chain, j] = x_j' e_chain: residual series are array 1 of every chain's
   // scratch block (zero where unobserved, and for a chain in error the previous

@@ -21,6 +21,8 @@
 // sequence.)
 #include <hip/hip_runtime.h>
 
+#include "ktimer.h"
+
 #include "device_rng.h"
 #include "probit_params.h"
 
@@ -382,8 +384,12 @@ hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R,
 
 // impute + X'z for every chain
 hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P, double *planes) {
-  hipLaunchKernelGGL(probit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
-  hipError_t err = hipGetLastError();
+  hipError_t err;
+  {
+    KtScope kt(stream, KT_PROBIT_IMPUTE);
+    hipLaunchKernelGGL(probit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
+    err = hipGetLastError();
+  }
   if (err != hipSuccess) return err;
   return launch_rows_times_columns(stream, P.z, P.chains, P.X, (int64_t)P.n, P.p, nullptr, P.xtz, planes);
 }
@@ -393,8 +399,12 @@ hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P, doubl
 // of V is built a vector at a time, as the sweep asks for it: xtwx_cols_kernel.hip)
 hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *Xsq,
                                const double *slab_precision, double *v_diag, double *planes) {
-  hipLaunchKernelGGL(logit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
-  hipError_t err = hipGetLastError();
+  hipError_t err;
+  {
+    KtScope kt(stream, KT_LOGIT_IMPUTE);
+    hipLaunchKernelGGL(logit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
+    err = hipGetLastError();
+  }
   if (err != hipSuccess) return err;
   err = launch_rows_times_columns(stream, P.z, P.chains, P.X, (int64_t)P.n, P.p, nullptr, P.xtz, planes);
   if (err != hipSuccess) return err;

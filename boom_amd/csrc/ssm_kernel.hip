@@ -31,6 +31,8 @@
 // ONE filter runs on w = y* - y+, and one smoother on the difference.
 #include <hip/hip_runtime.h>
 
+#include "ktimer.h"
+
 #include "device_rng.h"
 #include "kalman_params.h"
 #include "stream_normals.h"
@@ -668,13 +670,17 @@ hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_
   const dim3 grid(P.chain_count), block(2 * WAVE);
   const bool seas = P.ssm.nseasons > 0;
 #define SSM_LAUNCH(TR, SE) hipLaunchKernelGGL((ssm_simsmooth_kernel<TR, SE>), grid, block, 0, stream, P, draw_variances)
-  if (!seas) {
-    if (P.ssm.trend == 1) SSM_LAUNCH(1, false); else SSM_LAUNCH(2, false);
-  } else {
-    if (P.ssm.trend == 1) SSM_LAUNCH(1, true); else SSM_LAUNCH(2, true);
+  hipError_t err;
+  {
+    KtScope kt(stream, KT_SSM);
+    if (!seas) {
+      if (P.ssm.trend == 1) SSM_LAUNCH(1, false); else SSM_LAUNCH(2, false);
+    } else {
+      if (P.ssm.trend == 1) SSM_LAUNCH(1, true); else SSM_LAUNCH(2, true);
+    }
+    err = hipGetLastError();
   }
 #undef SSM_LAUNCH
-  hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
   // xty[chain, j] = x_j' e_chain (the residual series are array 1 of every chain's scratch block)
   return launch_atb_mfma(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.T, P.scratch_stride,

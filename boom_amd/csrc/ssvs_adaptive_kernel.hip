@@ -18,6 +18,7 @@
 // model against the current factors through the scalar cache); the first lane
 // that accepts wins, the lanes before it were correct rejections, and the model
 // is rebuilt once per ACCEPTED move instead of once per proposal.
+#include "ktimer.h"
 #include "ssvs_device.h"
 
 namespace boom_amd {
@@ -411,6 +412,7 @@ static hipError_t launch_adaptive_t(hipStream_t stream, const SsvsParams &P, int
   hipError_t e = hipFuncSetAttribute((const void *)ssvs_adaptive_kernel<NB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
   if (e != hipSuccess) return e;
+  KtScope kt(stream, KT_SSVS_ADAPTIVE);
   hipLaunchKernelGGL((ssvs_adaptive_kernel<NB>), dim3(P.chain_count), dim3(WAVE), lay.total, stream,
                      P, nsweeps);
   return hipGetLastError();

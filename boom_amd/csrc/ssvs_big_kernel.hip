@@ -26,6 +26,7 @@
 // sweep, wave 1 shares the table fills and the shuffle uniforms.  No forked
 // quiet sweeps here: the chains that need this kernel are few and their cost
 // is the O(p k^2) table fill after every accepted flip.
+#include "ktimer.h"
 #include "ssvs_device.h"
 
 namespace boom_amd {
@@ -1184,6 +1185,7 @@ hipError_t launch_ssvs_big(hipStream_t stream, const SsvsParams &P, int nsweeps)
   hipError_t e = hipFuncSetAttribute((const void *)ssvs_big_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
   if (e != hipSuccess) return e;
+  KtScope kt(stream, KT_SSVS_BIG);
   hipLaunchKernelGGL(ssvs_big_kernel, dim3(P.chain_count), dim3(2 * WAVE), lay.total, stream, P,
                      nsweeps);
   return hipGetLastError();

@@ -40,6 +40,7 @@
 // The Fisher-Yates shuffle of the persistent permutation is done in parallel:
 // every final position follows a short chain of "who was swapped into this
 // slot last" links instead of replaying the p-1 swaps one after the other.
+#include "ktimer.h"
 #include "ssvs_device.h"
 
 namespace boom_amd {
@@ -1036,6 +1037,7 @@ static hipError_t launch_sweep_t(hipStream_t stream, const SsvsParams &P,
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lay.total);
   if (e != hipSuccess) return e;
+  KtScope kt(stream, KT_SSVS);
   hipLaunchKernelGGL((ssvs_sweep_kernel<NB, W, WPE>), dim3(P.chain_count), dim3(WAVE * W),
                      lay.total, stream, P, nsweeps);
   return hipGetLastError();

@@ -13,6 +13,7 @@
 // the A/B fragment reads (16 columns x 4 rows per instruction) are
 // conflict-free.
 #include <hip/hip_runtime.h>
+#include "ktimer.h"
 #include <stdint.h>
 
 namespace boom_amd {
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256) void atb_mfma_kernel(const double *__restrict_
 
 hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
                            const double *B, int64_t ldb, int N, int K, double *C, int ldc) {
+  KtScope kt(stream, KT_XTE_GEMM);
   hipLaunchKernelGGL(atb_mfma_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, stream,
                      A, lda, M, B, ldb, N, K, C, ldc);
   return hipGetLastError();
@@ -273,6 +275,7 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        double *scalars, double *xsum, double *planes) {
   const int tiles = (p + TILE - 1) / TILE;
   const int ksplit = planes ? suf_row_slices(n, p) : 1;
+  KtScope kt(stream, KT_SUF);
   if (ksplit <= 1) {
     hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles, 1), dim3(256), 0, stream, X, n, p, xtx);
   } else {

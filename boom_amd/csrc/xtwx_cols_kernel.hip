@@ -27,6 +27,7 @@
 // panels double-buffered in LDS with a stride of 18 doubles (== 2 mod 32), so
 // that the 16 x 4 fragment reads are conflict-free.
 #include <hip/hip_runtime.h>
+#include "ktimer.h"
 #include <stdint.h>
 
 namespace boom_amd {
@@ -219,6 +220,7 @@ hipError_t launch_xtwx_cols(hipStream_t stream, const double *X, int64_t n, int 
                             uint32_t *valid, int words, double *planes) {
   if (R <= 0) return hipSuccess;
   const int np = xtwx_cols_planes(n);
+  KtScope kt(stream, KT_COLS_GEMM);
   hipLaunchKernelGGL(xtwx_cols_kernel<true>, dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np), dim3(256), 0, stream,
                      X, n, p, w, (const int2 *)req, R, planes);
   hipLaunchKernelGGL(xtwx_cols_reduce_kernel, dim3((p + 255) / 256, R), dim3(256), 0, stream,
@@ -232,6 +234,7 @@ hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R,
                                      int p, const double *diag_base, double *out, double *planes) {
   if (R <= 0) return hipSuccess;
   const int np = xtwx_cols_planes(n);
+  KtScope kt(stream, KT_ROWS_GEMM);
   hipLaunchKernelGGL(xtwx_cols_kernel<false>, dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np), dim3(256), 0, stream,
                      B, n, p, U, (const int2 *)nullptr, R, planes);
   const size_t cnt = (size_t)R * p;

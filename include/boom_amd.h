@@ -329,6 +329,21 @@ int ba_get_coefficient_traces(ba_engine *e, int32_t nsweeps, int32_t nvars,
 /* the engine's HIP stream (hipStream_t) for callers that order their own work */
 void *ba_stream(ba_engine *e);
 
+/* ---- measurement -------------------------------------------------------------
+ * Device time per kernel class (new; no reference counterpart -- the reference has
+ * no profiler hook).  With timing enabled every kernel launch of the
+ * engine is bracketed by a pair of HIP events on the engine's stream;
+ * ba_get_kernel_times waits for the stream and returns, per class, the summed
+ * milliseconds and the number of launches since the last reset (arrays of
+ * ba_kernel_classes() entries; either may be NULL).  A sweep round that is several
+ * kernels (bsts: SSVS + Kalman + X'e GEMM) is timed kernel by kernel this way;
+ * bench.py's roofline objects come from here.  Disabled (the default) it costs
+ * nothing; it never changes a draw. */
+int32_t ba_kernel_classes(void);
+const char *ba_kernel_class_name(int32_t cls);
+int ba_set_kernel_timing(ba_engine *e, int32_t enabled);
+int ba_get_kernel_times(ba_engine *e, double *ms, int64_t *launches, int32_t reset);
+
 /* ---- bsts: StateSpaceRegressionModel + LocalLevelStateModel ----------------- */
 /* StateSpaceRegressionModel(y, X, observed) (StateSpaceRegressionModel.cpp:100-125):
  * X is T x p column-major; observed may be NULL.  Replaces the engine's data:

@@ -70,13 +70,18 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     import bench
     from cases import regression_data, spike_slab_prior
     X, y, _ = regression_data(bench.N_OBS, P, bench.N_SIGNAL, seed=bench.DATA_SEED)
-    # single-shot build: equal to the sharded one to rounding
+    job = bd.unpack_suf_block(d["suf_block"], P, bench.N_OBS)     # what the ranks installed
+    # single-shot build: equal to the sharded one to rounding.  (Not bitwise, and not
+    # only because of the summation order: y = X beta + noise is a BLAS product whose
+    # last bits depend on the thread count, and torch.distributed.run gives its ranks
+    # OMP_NUM_THREADS=1.)
     one = boom_amd.Engine(4, seed=1)
     one.build_suf_from_xy(X, y)
     ref = one.get_suf()
     one.close()
-    assert np.max(np.abs(d["xtx"] - ref["xtx"])) < 1e-12 * np.abs(ref["xtx"]).max()
-    assert np.max(np.abs(d["xty"] - ref["xty"])) < 1e-12 * np.abs(ref["xty"]).max()
+    assert np.max(np.abs(job["xtx"] - ref["xtx"])) < 1e-12 * np.abs(ref["xtx"]).max()
+    assert np.max(np.abs(job["xty"] - ref["xty"])) < 1e-12 * np.abs(ref["xty"]).max()
+    assert abs(job["yty"] - ref["yty"]) < 1e-12 * ref["yty"]
     # the sharded build again, both shards on this device, summed as the all-reduce sums
     eng = [boom_amd.Engine(C, seed=bench.SAMPLER_SEED, chain_offset=r * C) for r in range(2)]
     tot = torch.zeros(bd.suf_block_size(P), dtype=torch.float64, device="cuda")
@@ -88,6 +93,13 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
         eng[r].suf_partial_device(hi - lo, P, Xs.data_ptr(), ys.data_ptr(), blk.data_ptr())
         tot += blk
     torch.cuda.synchronize()
+    mine_block = tot.cpu().numpy()
+    # X'X and the column sums do not involve y: bitwise what the two ranks summed
+    assert np.array_equal(mine_block[:P * P], d["suf_block"][:P * P])
+    assert np.array_equal(mine_block[P * P + P + 2:], d["suf_block"][P * P + P + 2:])
+    assert np.max(np.abs(mine_block - d["suf_block"])) < 1e-12 * np.abs(mine_block).max()
+    # from here on: the job's own statistics, so that the chains can be compared bit for bit
+    tot = torch.from_numpy(d["suf_block"]).cuda()
     g0 = np.zeros(P, np.uint8)
     g0[0] = 1
     mine = []
@@ -95,7 +107,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
         e = eng[r]
         e.set_suf_from_block_device(bench.N_OBS, P, tot.data_ptr())
         s = e.get_suf()
-        assert np.array_equal(s["xtx"], d["xtx"]) and np.array_equal(s["xty"], d["xty"])
+        assert np.array_equal(s["xtx"], job["xtx"]) and np.array_equal(s["xty"], job["xty"])
         suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"], sumy=s["ybar"] * s["n"],
                    xsum=s["xbar"] * s["n"])
         prior = spike_slab_prior(suf, bench.N_SIGNAL)

@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of tools/profile_bench.sh into what is kept
-under profiles/: the kernel-stats table as is, and per-dispatch counter rows of
-OUR kernels only (the raw collection also lists every rocclr copy kernel).
+"""Condense the rocprofv3 outputs of tools/regen_profiles.sh into what is kept under
+profiles/: the kernel-stats table as is, per-dispatch counter rows of OUR kernels only
+(the raw collection also lists every rocclr copy kernel), a summary with derived
+fractions, and -- when the FETCH_SIZE / WRITE_SIZE passes are there -- the HBM traffic
+per dispatch of every kernel, corrected as MI355X_MICROARCH.md prescribes (counters in
+KiB; FETCH_SIZE may report half the bytes of wide coalesced reads on gfx950: both the
+raw and the doubled figure are kept, the doubled one is the upper bound).
 
-usage: tools/summarize_pmc.py gpurun_out/<dir> profiles/<prefix> [kernel-substring ...]
+usage: tools/summarize_pmc.py gpurun_out/<dir> profiles/<prefix> [--commit HASH]
+                              [--command "..."] [kernel-substring ...]
 """
 import collections
 import csv
@@ -12,14 +17,50 @@ import os
 import shutil
 import sys
 
-src, prefix = sys.argv[1], sys.argv[2]
-keys = sys.argv[3:] or ["ssvs_", "kalman", "atb_mfma", "xtx_mfma"]
-shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), prefix + "_kernel_stats.csv")
-summary = {"source": src, "kernels": {}}
+args = sys.argv[1:]
+commit, command = "unknown", ""
+if "--commit" in args:
+    i = args.index("--commit")
+    commit = args[i + 1]
+    del args[i:i + 2]
+if "--command" in args:
+    i = args.index("--command")
+    command = args[i + 1]
+    del args[i:i + 2]
+src, prefix = args[0], args[1]
+keys = []
+for a in args[2:]:
+    keys += a.split()
+keys = keys or ["ssvs_", "kalman", "atb_mfma", "xtx_mfma"]
+
+
+def short_name(kn):
+    return (kn.split("(")[0].replace("void ", "").replace("boom_amd::", "")
+            .replace("(anonymous namespace)::", ""))
+
+
+stats = os.path.join(src, "stats", "stats_kernel_stats.csv")
+if not os.path.exists(stats):   # (rocprofv3 nests the output under the host name)
+    for root, _, files in os.walk(os.path.join(src, "stats")):
+        for fn in files:
+            if fn.endswith("kernel_stats.csv"):
+                stats = os.path.join(root, fn)
+with open(stats) as fh:
+    body = fh.read()
+with open(prefix + "_kernel_stats.csv", "w") as fh:
+    fh.write("# commit %s | rocprofv3 --kernel-trace --stats -- python3 %s\n" % (commit, command))
+    fh.write(body)
+summary = {"commit": commit, "command": "python3 " + command, "source": src, "kernels": {}}
 rows_out = []
 for name in sorted(os.listdir(src)):
-    path = os.path.join(src, name, "pmc_counter_collection.csv")
-    if not (name.startswith("pmc_") and os.path.exists(path)):
+    if not name.startswith("pmc_") or not os.path.isdir(os.path.join(src, name)):
+        continue
+    path = None
+    for root, _, files in os.walk(os.path.join(src, name)):
+        for fn in files:
+            if fn.endswith("counter_collection.csv"):
+                path = os.path.join(root, fn)
+    if path is None:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
@@ -27,7 +68,7 @@ for name in sorted(os.listdir(src)):
         kn = r["Kernel_Name"]
         if not any(k in kn for k in keys):
             continue
-        short = kn.split("(")[0].replace("void ", "").replace("boom_amd::", "").replace("(anonymous namespace)::", "")
+        short = short_name(kn)
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[short] = dict(grid=r["Grid_Size"], workgroup=r["Workgroup_Size"], lds=r["LDS_Block_Size"],
                            scratch=r["Scratch_Size"], vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"])
@@ -37,10 +78,18 @@ for name in sorted(os.listdir(src)):
         d = summary["kernels"].setdefault(short, {"launch_config": meta[short], "counters_avg_per_dispatch": {}})
         for c, v in cs.items():
             d["counters_avg_per_dispatch"][c] = {"dispatches": len(v), "mean": sum(v) / len(v)}
-with open(prefix + "_pmc_dispatches.csv", "w", newline="") as fh:
-    w = csv.writer(fh)
-    w.writerow(["pass", "dispatch", "kernel", "counter", "value", "duration_ns"])
-    w.writerows(rows_out)
+if rows_out:
+    # (per-dispatch rows of long runs are many: keep at most 400 per kernel and counter)
+    seen = collections.Counter()
+    with open(prefix + "_pmc_dispatches.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["# commit " + commit])
+        w.writerow(["pass", "dispatch", "kernel", "counter", "value", "duration_ns"])
+        for row in rows_out:
+            seen[(row[2], row[3])] += 1
+            if seen[(row[2], row[3])] <= 400:
+                w.writerow(row)
+traffic = {}
 for k, d in summary["kernels"].items():
     c = {n: v["mean"] for n, v in d["counters_avg_per_dispatch"].items()}
     if "SQ_WAVE_CYCLES" in c:
@@ -50,8 +99,25 @@ for k, d in summary["kernels"].items():
                         "active_inst_any_frac": c.get("SQ_ACTIVE_INST_ANY", 0) / wc}
     if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"] > 0:
         d.setdefault("derived", {})["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
-    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
-        d.setdefault("derived", {})["hbm_bytes_per_dispatch_raw"] = (c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024
-with open(prefix + "_pmc_summary.json", "w") as fh:
-    json.dump(summary, fh, indent=1)
-print(json.dumps(summary, indent=1)[:3000])
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        hi = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        d.setdefault("derived", {}).update(hbm_bytes_per_dispatch_raw=raw,
+                                           hbm_bytes_per_dispatch_fetch_doubled=hi)
+        traffic[k] = {"FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
+                      "traffic_bytes_raw": raw, "traffic_bytes": hi,
+                      "dispatches": d["counters_avg_per_dispatch"]["FETCH_SIZE"]["dispatches"],
+                      "scratch_bytes_per_lane": d["launch_config"]["scratch"]}
+if summary["kernels"]:
+    with open(prefix + "_pmc_summary.json", "w") as fh:
+        json.dump(summary, fh, indent=1)
+if traffic:
+    with open(prefix + "_pmc_traffic.json", "w") as fh:
+        json.dump({"commit": commit, "command": "python3 " + command,
+                   "method": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, per-dispatch "
+                             "means; KiB -> bytes; traffic_bytes doubles FETCH_SIZE (MI355X_MICROARCH.md: on "
+                             "gfx950 it reports half the bytes of wide coalesced reads; uncalibrated for "
+                             "8-byte gathers, so the doubled figure is an upper bound), traffic_bytes_raw "
+                             "does not",
+                   "kernels": traffic}, fh, indent=1)
+print(json.dumps(summary, indent=1)[:2000])
