@@ -1088,6 +1088,28 @@ struct DecideResult {
   int spos, j, kind;
   double logu, margin;
 };
+// one position of a walk round (a lane holds 2 R of them).  Named scalars, not arrays:
+// any array here ends up indexed by the (run-time) sub-round or half of the stop, which
+// keeps the whole array in scratch memory -- 128 bytes per lane written in every round
+// of every walk with the first version of this routine.
+struct WalkPos {
+  double u, e;
+  int j, kd;
+  bool val, acc;
+};
+__device__ __forceinline__ void walk_pos_load(const Chain &ch, int q, int i0, int nflips, WalkPos &w) {
+  w.val = q >= i0 && q < nflips;
+  w.j = w.val ? (int)ch.perm[q] : 0;
+}
+__device__ __forceinline__ void walk_pos_table(const Chain &ch, WalkPos &w) {
+  w.e = ch.tab_lp[w.j];
+  w.kd = ch.tab_kind[w.j];
+}
+__device__ __forceinline__ unsigned long long walk_pos_stop(WalkPos &w) {
+  const bool special = w.kd != 0;
+  w.acc = w.val && !special && !(w.u > w.e);
+  return __ballot(w.val && (special || w.acc));
+}
 __device__ __forceinline__ void decide_walk(const Chain &ch, const PhiloxKey &key,
                                             uint64_t flip_pos, int i0, int nflips,
                                             DecideResult &out) {
@@ -1102,73 +1124,62 @@ __device__ __forceinline__ void decide_walk(const Chain &ch, const PhiloxKey &ke
   while (i0 < nflips) {
     const uint64_t blk0 = (flip_pos + (uint64_t)i0) >> 1;
     const int qb = (int)((long long)(2 * blk0) - (long long)flip_pos);  // position of block blk0, half 0
-    double u[R][2], ej[R][2];
-    int jj[R][2], kd[R][2];
-    bool val[R][2], acc[R][2];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int q = qb + 2 * (r * WAVE + lane) + h;
-        val[r][h] = q >= i0 && q < nflips;
-        jj[r][h] = val[r][h] ? (int)ch.perm[q] : 0;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ej[r][h] = ch.tab_lp[jj[r][h]];
-        kd[r][h] = ch.tab_kind[jj[r][h]];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      philox_pair(key, blk0 + (uint64_t)(r * WAVE + lane), &u[r][0], &u[r][1]);
+    WalkPos a0, a1, b0, b1, c0, c1, d0, d1;   // sub-rounds 0..3, halves 0 / 1
+#define WALK_ALL(OP) OP(0, a0, a1) OP(1, b0, b1) OP(2, c0, c1) OP(3, d0, d1)
+#define WALK_LOAD(r, x0, x1)                                            \
+    walk_pos_load(ch, qb + 2 * ((r) * WAVE + lane), i0, nflips, x0);     \
+    walk_pos_load(ch, qb + 2 * ((r) * WAVE + lane) + 1, i0, nflips, x1);
+    WALK_ALL(WALK_LOAD)
+#define WALK_TABLE(r, x0, x1) walk_pos_table(ch, x0); walk_pos_table(ch, x1);
+    WALK_ALL(WALK_TABLE)
+#define WALK_UNIF(r, x0, x1) philox_pair(key, blk0 + (uint64_t)((r) * WAVE + lane), &x0.u, &x1.u);
+    WALK_ALL(WALK_UNIF)
     int f = 1 << 20, fr = 0;  // first stop: 2 lane + half within sub-round fr
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      unsigned long long mstop[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const bool special = kd[r][h] != 0;
-        acc[r][h] = val[r][h] && !special && !(u[r][h] > ej[r][h]);
-        mstop[h] = __ballot(val[r][h] && (special || acc[r][h]));
-      }
-      if (f == (1 << 20)) {
-        const int f0 = mstop[0] ? 2 * (__ffsll((long long)mstop[0]) - 1) : 1 << 20;
-        const int f1 = mstop[1] ? 2 * (__ffsll((long long)mstop[1]) - 1) + 1 : 1 << 20;
-        const int fm = f0 < f1 ? f0 : f1;
-        if (fm < (1 << 20)) { f = fm; fr = r; }
-      }
+    // the stopping position's variable, kind and uniform, taken where the stop is found
+    // (every lane keeps ITS candidates of that sub-round; the stop's lane is read below)
+    int sj = 0, sk = 0;
+    double su = 0.0;
+#define WALK_STOP(r, x0, x1)                                                              \
+    {                                                                                     \
+      const unsigned long long m0 = walk_pos_stop(x0), m1 = walk_pos_stop(x1);            \
+      if (f == (1 << 20)) {                                                               \
+        const int f0 = m0 ? 2 * (__ffsll((long long)m0) - 1) : 1 << 20;                   \
+        const int f1 = m1 ? 2 * (__ffsll((long long)m1) - 1) + 1 : 1 << 20;               \
+        const int fm = f0 < f1 ? f0 : f1;                                                 \
+        if (fm < (1 << 20)) {                                                             \
+          f = fm;                                                                         \
+          fr = (r);                                                                       \
+          const bool h1 = (fm & 1) != 0;                                                  \
+          sj = h1 ? x1.j : x0.j;                                                          \
+          sk = h1 ? x1.kd : x0.kd;                                                        \
+          su = h1 ? x1.u : x0.u;                                                          \
+        }                                                                                 \
+      }                                                                                   \
     }
+    WALK_ALL(WALK_STOP)
     const int fkey = (f == (1 << 20)) ? (1 << 30) : fr * 2 * WAVE + f;  // order within the round
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        // |u / E - 1|, to first order the distance |log u - (logp' - logp)|
-        const int me = r * 2 * WAVE + 2 * lane + h;
-        const bool counted = val[r][h] && (me < fkey || (me == fkey && acc[r][h])) && ej[r][h] > 0.0;
-        const double mg = fabs(u[r][h] - ej[r][h]) * __builtin_amdgcn_rcp(ej[r][h]);
-        if (counted) lane_margin = fmin(lane_margin, mg);
-      }
+    // |u / E - 1|, to first order the distance |log u - (logp' - logp)|
+#define WALK_MARGIN1(r, h, x)                                                                   \
+    {                                                                                           \
+      const int me = (r) * 2 * WAVE + 2 * lane + (h);                                           \
+      const bool counted = x.val && (me < fkey || (me == fkey && x.acc)) && x.e > 0.0;          \
+      const double mg = fabs(x.u - x.e) * __builtin_amdgcn_rcp(x.e);                            \
+      if (counted) lane_margin = fmin(lane_margin, mg);                                         \
     }
+#define WALK_MARGIN(r, x0, x1) WALK_MARGIN1(r, 0, x0) WALK_MARGIN1(r, 1, x1)
+    WALK_ALL(WALK_MARGIN)
+#undef WALK_MARGIN
+#undef WALK_MARGIN1
+#undef WALK_STOP
+#undef WALK_UNIF
+#undef WALK_TABLE
+#undef WALK_LOAD
+#undef WALK_ALL
     if (f == (1 << 20)) {
       i0 = qb + 2 * R * WAVE;  // first position of the next round
       continue;
     }
-    const int fl = f >> 1, fh = f & 1;
-    int sj = 0, sk = 0;
-    double su = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (r == fr) {
-        sj = fh ? jj[r][1] : jj[r][0];
-        sk = fh ? kd[r][1] : kd[r][0];
-        su = fh ? u[r][1] : u[r][0];
-      }
-    }
+    const int fl = f >> 1;
     out.spos = qb + fr * 2 * WAVE + f;
     out.j = __builtin_amdgcn_readlane(sj, fl);
     out.kind = __builtin_amdgcn_readlane(sk, fl);

@@ -353,7 +353,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
         continue;
       }
       gam0_fresh = false;
-      Model keep = M;
+      Model keep;   // (member by member: a struct copy goes through a stack slot)
+      keep.logp = M.logp; keep.SS = M.SS; keep.pd = M.pd; keep.bad = M.bad;
       keep.lp = ctl[CT_LP]; keep.ldv = ctl[CT_LDV]; keep.lda = ctl[CT_LDA];
       keep.Q = ctl[CT_Q]; keep.c = ctl[CT_C];
       if (pe.f1 >= 0) apply_flip(ch, pe.f1);
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
             if (pe.f2 >= 0) apply_flip(ch, pe.f2);
             if (pe.f1 >= 0) apply_flip(ch, pe.f1);
             restore_model<NB>(ch);
-            M = keep;
+            M.logp = keep.logp; M.lp = keep.lp; M.ldv = keep.ldv; M.lda = keep.lda;
+            M.Q = keep.Q; M.c = keep.c; M.SS = keep.SS; M.pd = keep.pd; M.bad = keep.bad;
             rejected = true;
           }
         }
@@ -1047,6 +1049,10 @@ hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P,
                              int nsweeps) {
   const int key = P.kcap * 10 + P.waves;
   switch (key) {
+#ifdef BA_ONLY_322   // (compile-time experiments on the hot instance only)
+    case 322: return launch_sweep_t<4, 2, 2>(stream, P, nsweeps);
+    default: return hipErrorInvalidValue;
+#else
     case 161: return launch_sweep_t<2, 1, 1>(stream, P, nsweeps);
     case 321: return launch_sweep_t<4, 1, 1>(stream, P, nsweeps);
     case 481: return launch_sweep_t<6, 1, 1>(stream, P, nsweeps);
@@ -1058,6 +1064,7 @@ hipError_t launch_ssvs_sweep(hipStream_t stream, const SsvsParams &P,
     case 164: return launch_sweep_t<2, 4, 4>(stream, P, nsweeps);
     case 324: return launch_sweep_t<4, 4, 4>(stream, P, nsweeps);
     default: return hipErrorInvalidValue;
+#endif
   }
 }
 
