@@ -57,11 +57,12 @@ for w in what:
         dt = float(np.median(tb)) / L
         print("[%s] loop64: %.1f us per iteration, %.2f M sweeps/s" % (tag, dt * 1e6, 1024 / dt / 1e6), flush=True)
         eng.close()
-    elif w == "c3":
+    elif w == "c3" or w.startswith("c3x"):
+        c3chains = 1024 if w == "c3" else int(w[3:])
         T, p = 2000, 100
         X, y, _, _ = state_space_data(T, p, 5, seed=8675309)
         prior, ss, sig_up = bsts_priors(X, y, 5)
-        eng = boom_amd.Engine(1024, seed=4)
+        eng = boom_amd.Engine(c3chains, seed=4)
         eng.ss_set_data(y, X, None)
         eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"], sigma_upper_limit=sig_up)
         eng.ss_set_local_level(ss["level_df"], ss["level_sigma_guess"], ss["level_sigma_upper_limit"],
@@ -74,8 +75,8 @@ for w in what:
         eng.set_kernel_timing(True)
         eng.ss_sweep(100)
         kt = {k.split("_kernel")[0]: round(ms / n * 1e3, 1) for k, (ms, n) in eng.kernel_times().items()}
-        print("[%s] c3: %.1f us per round (min %.1f), %.2f M sweeps/s, kernels %s"
-              % (tag, np.median(ts) * 1e6, min(ts) * 1e6, 1024 / np.median(ts) / 1e6, kt), flush=True)
+        print("[%s] %s: %.1f us per round (min %.1f), %.2f M sweeps/s, kernels %s"
+              % (tag, w, np.median(ts) * 1e6, min(ts) * 1e6, c3chains / np.median(ts) / 1e6, kt), flush=True)
         eng.close()
     elif w == "structural":
         T, p = 2000, 100
