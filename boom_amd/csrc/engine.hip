@@ -2239,15 +2239,15 @@ int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const
   MUTATE(e);
   if (!X || !y || !ntrials) return fail(BA_E_INVALID, "null argument");
   if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
-  if (clt_threshold < 1 || 2 * clt_threshold > LOGIT_STRIDE)
-    return fail(BA_E_INVALID, "clt_threshold must be between 1 and 32");
+  // (per-trial imputation reads two uniforms per trial of the observation's substream
+  // of LOGIT_STRIDE; the large-sample branch beyond the threshold a few dozen)
+  if (clt_threshold < 1 || 4 * clt_threshold > LOGIT_STRIDE)
+    return fail(BA_E_INVALID, "clt_threshold must be between 1 and 64");
   for (int64_t i = 0; i < n; ++i) {
     if (y[i] < 0 || ntrials[i] < 0)
       return fail(BA_E_INVALID, "The number of successes and the number of trials must both be non-negative in BinomialLogitPartialAugmentationDataImputer::impute().");
     if (y[i] > ntrials[i])
       return fail(BA_E_INVALID, "The number of successes must not exceed the number of trials in BinomialLogitPartialAugmentationDataImputer::impute().");
-    if (ntrials[i] > clt_threshold)
-      return fail(BA_E_INVALID, "observations with more than clt_threshold trials (the reference's large-sample imputation) are not implemented on the device");
   }
   // (dimensions, the shared buffers and a placeholder X'X; the sweeps use every
   // chain's own X'WX)

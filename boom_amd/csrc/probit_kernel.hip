@@ -219,6 +219,138 @@ __device__ __forceinline__ void trun_norm_moments(double mu, bool positive, doub
   if (*variance < 0) *variance = 0;
 }
 
+// trun_norm_moments(mu, sigma, 0, positive_support, ...) (distributions/trun_norm.cpp:243-269)
+__device__ __forceinline__ void trun_norm_moments_s(double mu, double sigma, bool positive, double *mean,
+                                                    double *variance) {
+  const double log_phi_const = -0.918938533204672741780329736406;
+  const double sigsq = sigma * sigma;
+  const double t = (0.0 - mu) / sigma;
+  if (positive) {
+    const double phi_ratio = exp((log_phi_const - .5 * t * t) - log_pnorm_std(t, false));
+    *mean = mu + sigma * phi_ratio;
+    const double delta = phi_ratio * (phi_ratio - t);
+    *variance = sigsq * (1 - delta);
+  } else {
+    const double phi_ratio = exp((log_phi_const - .5 * t * t) - log_pnorm_std(t, true));
+    *mean = mu - sigma * phi_ratio;
+    *variance = sigsq * (1 - t * phi_ratio - phi_ratio * phi_ratio);
+  }
+  if (*variance < 0) *variance = 0;
+}
+
+// BOOM::binomial_distribution(n, p)(rng) (distributions/BinomialDistribution.cpp:24-158;
+// what Rmath::rbinom_mt calls, Bmath/rbinom.cpp:66-69): Kachitvichyanukul and
+// Schmeiser's BTPE for n p >= 30, sequential inversion below -- the statements and the
+// uniforms they consume in the reference's order.
+__device__ __noinline__ unsigned d_rbinom(SeqRng &rng, unsigned n, double pp) {
+  double c = 0, fm = 0, npq = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+  double xl = 0, xll = 0, xlr = 0, xm = 0, xr = 0;
+  int m = 0, ix = 0;
+  const double p = (pp < 1. - pp) ? pp : 1. - pp;
+  const double q = 1. - p;
+  const double np = n * p;
+  const double r = p / q;
+  const double g = r * (n + 1);
+  bool done = false;
+  if (np < 30) {
+    const double qn = pow(q, (double)n);
+    while (!done) {
+      ix = 0;
+      double f = qn;
+      double u = rng();
+      for (;;) {
+        if (u < f) { done = true; break; }
+        if (ix > 110) break;
+        u -= f;
+        ix++;
+        f *= (g / ix - r);
+      }
+    }
+  } else {
+    const double ffm = np + p;
+    m = (int)ffm;
+    fm = m;
+    npq = np * q;
+    p1 = (int)(2.195 * sqrt(npq) - 4.6 * q) + 0.5;
+    xm = fm + 0.5;
+    xl = xm - p1;
+    xr = xm + p1;
+    c = 0.134 + 20.5 / (15.3 + fm);
+    double al = (ffm - xl) / (ffm - xl * p);
+    xll = al * (1.0 + 0.5 * al);
+    al = (xr - ffm) / (xr * q);
+    xlr = al * (1.0 + 0.5 * al);
+    p2 = p1 * (1.0 + c + c);
+    p3 = p2 + c / xll;
+    p4 = p3 + c / xlr;
+  }
+  while (!done) {
+    const double u = rng() * p4;
+    double v = rng();
+    if (u <= p1) {  // triangular region
+      ix = (int)(xm - p1 * v + u);
+      break;
+    }
+    if (u <= p2) {  // parallelogram region
+      const double x = xl + (u - p1) / c;
+      v = v * c + 1.0 - fabs(xm - x) / p1;
+      if (v > 1.0 || v <= 0.) continue;
+      ix = (int)x;
+    } else if (u > p3) {  // right tail
+      ix = (int)(xr - log(v) / xlr);
+      if ((unsigned)ix > n) continue;
+      v = v * (u - p3) * xlr;
+    } else {  // left tail
+      ix = (int)(xl + log(v) / xll);
+      if (ix < 0) continue;
+      v = v * (u - p2) * xll;
+    }
+    const int k = abs(ix - m);
+    if (k <= 20 || k >= npq / 2 - 1) {
+      double f = 1.0;
+      if (m < ix) {
+        for (int i = m + 1; i <= ix; i++) f *= (g / i - r);
+      } else if (m != ix) {
+        for (int i = ix + 1; i <= m; i++) f /= (g / i - r);
+      }
+      if (v <= f) break;
+    } else {
+      const double amaxp = (k / npq) * ((k * (k / 3. + 0.625) + 0.1666666666666) / npq + 0.5);
+      const double ynorm = -1.0 * k * k / (2.0 * npq);
+      const double alv = log(v);
+      if (alv < ynorm - amaxp) break;
+      if (alv <= ynorm + amaxp) {
+        const double x1 = ix + 1, f1 = fm + 1.0, z = n + 1 - fm, w = n - ix + 1.0;
+        const double z2 = z * z, x2 = x1 * x1, f2 = f1 * f1, w2 = w * w;
+        if (alv <= xm * log(f1 / x1) + (n - m + 0.5) * log(z / w) + (ix - m) * log(w * p / (x1 * q)) +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / f2) / f2) / f2) / f2) / f1 / 166320.0 +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / z2) / z2) / z2) / z2) / z / 166320.0 +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x1 / 166320.0 +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / w2) / w2) / w2) / w2) / w / 166320.)
+          break;
+      }
+    }
+  }
+  if (pp > 0.5) ix = (int)n - ix;
+  return (unsigned)ix;
+}
+
+// Rmath::rmultinom_mt (Bmath/rmultinom.cpp:82-136) for probabilities that sum to one
+__device__ __forceinline__ void d_rmultinom9(SeqRng &rng, int n, const double (&prob)[9], int (&rN)[9]) {
+  double p_tot = 0.;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { p_tot += prob[k]; rN[k] = 0; }
+  if (n == 0) return;
+  for (int k = 0; k < 8; ++k) {
+    const double pp = prob[k] / p_tot;
+    rN[k] = (int)d_rbinom(rng, (unsigned)n, pp);
+    n -= rN[k];
+    if (n <= 0) return;
+    p_tot -= prob[k];
+  }
+  rN[8] = n;
+}
+
 // The chain's included variables and their coefficients, in ascending order (the
 // order x_i'beta is summed in), to LDS; returns how many there are (beyond
 // PROBIT_KMAX only counted).  All 256 threads: 256 variables per round, a
@@ -311,8 +443,10 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
 // component of the nine-normal mixture that approximates the logistic density
 // (NormalMixtureApproximation.cpp:280-290, :416-424; one uniform), and from it the
 // trial's precision.  z[chain][i] = sum of latent * precision, w[chain][i] = sum
-// of precisions.  Exactly two uniforms per trial: observation i of sweep s reads
-// the chain's worker stream (id 9) from position (s n + i) * 64.
+// of precisions.  Exactly two uniforms per trial; an observation with more than
+// clt_threshold trials takes the large-sample branch below (16 binomial draws and a
+// normal one, a data-dependent number of uniforms).  Observation i of sweep s reads
+// the chain's worker stream (id 9) from position (s n + i) * LOGIT_STRIDE.
 __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
   const double MIX_SIGMA[9] = {0.88437229872213, 1.16097607474416, 1.28021991084306,
                                1.3592552924727,  1.67589879794907, 2.20287232043947,
@@ -339,8 +473,52 @@ __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
   SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 9u},
              (P.sweep * (uint64_t)P.n + (uint64_t)i) * LOGIT_STRIDE};
   double sum = 0.0, info = 0.0;
-  if (nt > P.clt_threshold || 2 * nt > LOGIT_STRIDE) {
-    // (the reference's large-sample branch is not on the device: reported)
+  if (nt > P.clt_threshold) {
+    // BinomialLogitCltDataImputer::impute_large_sample (BinomialLogitDataImputer.cpp:
+    // 155-211): how many failures / successes belong to each mixture component (two
+    // multinomial draws), then one normal draw for the information-weighted sum from the
+    // truncated-normal moments of the occupied cells
+    const uint64_t start = rng.pos;
+    double p0[9], p1[9];
+    int N0[9], N1[9];
+    const double xz = (0 - eta) / 1.0;
+    const double neg_support = 1 / (1 + exp(-xz)), pos_support = 1 / (1 + exp(xz));   // plogis(0, eta, 1, lower / upper)
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+      const double z = (0 - eta) / MIX_SIGMA[m];
+      p0[m] = MIX_WEIGHT[m] / neg_support * (0.5 * erfc(-z / 1.4142135623730951));
+      p1[m] = MIX_WEIGHT[m] / pos_support * (0.5 * erfc(z / 1.4142135623730951));
+    }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) { s0 += p0[m]; s1 += p1[m]; }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) { p0[m] /= s0; p1[m] /= s1; }
+    d_rmultinom9(rng, (int)(nt - ys), p0, N0);
+    d_rmultinom9(rng, (int)ys, p1, N1);
+    double simulation_mean = 0.0, simulation_variance = 0.0;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+      const int total_obs = N0[m] + N1[m];
+      if (total_obs == 0) continue;
+      const double sigsq = MIX_SIGMA[m] * MIX_SIGMA[m], sig4 = sigsq * sigsq;
+      info += total_obs / sigsq;
+      double tmean, tvar;
+      if (N0[m] > 0) {
+        trun_norm_moments_s(eta, MIX_SIGMA[m], false, &tmean, &tvar);
+        simulation_mean += N0[m] * tmean / sigsq;
+        simulation_variance += N0[m] * tvar / sig4;
+      }
+      if (N1[m] > 0) {
+        trun_norm_moments_s(eta, MIX_SIGMA[m], true, &tmean, &tvar);
+        simulation_mean += N1[m] * tmean / sigsq;
+        simulation_variance += N1[m] * tvar / sig4;
+      }
+    }
+    sum = d_rnorm(rng, simulation_mean, sqrt(simulation_variance));
+    // (a draw that outran its substream is reported, never mishandled)
+    if (rng.pos - start > (uint64_t)LOGIT_STRIDE) P.status[chain] = CHAIN_RNG_BRANCH;
+  } else if (2 * nt > LOGIT_STRIDE) {
     P.status[chain] = CHAIN_RNG_BRANCH;
   } else {
     const double cutpoint_prob = 1 / (1 + exp(-(0 - eta)));

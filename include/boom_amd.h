@@ -269,10 +269,12 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps);
  * the chain replays that sweep), then the sampler's inclusion / coefficient draws
  * (BinomialLogitSpikeSlabSampler.cpp:50-117, :178-226; its shuffle of the visiting
  * order differs from SpikeSlabSampler's).  Same prior setters and state accessors as
- * the probit sampler.  Observations need ntrials <= clt_threshold <= 32 (the
- * large-sample imputation is not on the device); models of any size.  RNG:
- * stream 3 for the sampler, stream 9 from position (s n + i) * 64 for the
- * imputation of observation i in sweep s (exactly two uniforms per trial). */
+ * the probit sampler.  Observations with more than clt_threshold (1 .. 64) trials take
+ * the reference's large-sample imputation (BinomialLogitCltDataImputer::
+ * impute_large_sample, BinomialLogitDataImputer.cpp:155-211: multinomial counts per
+ * mixture component, one normal draw); models of any size.  RNG: stream 3 for the
+ * sampler, stream 9 from position (s n + i) * 256 for the imputation of observation i
+ * in sweep s (two uniforms per trial, or the large-sample branch's few dozen). */
 int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X,
                       const double *y, const double *ntrials, int32_t clt_threshold);
 int ba_logit_sweep(ba_engine *e, int32_t nsweeps);

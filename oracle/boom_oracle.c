@@ -2771,7 +2771,12 @@ int bo_probit_draw(bo_probit *m) {
  *   BinomialLogitSpikeSlabSampler::draw (BinomialLogitSpikeSlabSampler.cpp:50-79,
  *   :87-117, :178-226)
  * Observations with more than clt_threshold trials take the reference's
- * large-sample branch, which is not restated (status 4).
+ * large-sample branch (BinomialLogitCltDataImputer::impute_large_sample,
+ * BinomialLogitDataImputer.cpp:155-211): the counts of failures / successes per
+ * mixture component by two multinomial draws (Bmath/rmultinom.cpp:82-136 over
+ * BOOM::binomial_distribution, distributions/BinomialDistribution.cpp: Kachitvichyanukul
+ * and Schmeiser's BTPE for n p >= 30, inversion below), then ONE normal draw for the
+ * information-weighted sum with the truncated-normal moments of every cell.
  * ====================================================================== */
 static const double LOGIT_MIX_SIGMA[9] = {0.88437229872213, 1.16097607474416, 1.28021991084306,
                                           1.3592552924727,  1.67589879794907, 2.20287232043947,
@@ -2780,16 +2785,187 @@ static const double LOGIT_MIX_WEIGHT[9] = {0.038483985581272, 0.13389889791451, 
                                            0.105680086433879, 0.345939491553619, 0.0442261124345564,
                                            0.193289780660134, 0.068173066865908, 0.00452437089387876};
 
+/* BOOM::binomial_distribution(n, p)(rng) (distributions/BinomialDistribution.cpp:24-158),
+ * what Rmath::rbinom_mt calls (Bmath/rbinom.cpp:66-69): BTPE for n p >= 30, sequential
+ * inversion below.  Same statements in the same order, so the same uniforms are consumed. */
+unsigned bo_rbinom(bo_rng *rng, unsigned n, double pp) {
+  double c = 0, fm = 0, npq = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, qn = 0;
+  double xl = 0, xll = 0, xlr = 0, xm = 0, xr = 0;
+  int m = 0, ix = 0;
+  double p = (pp < 1. - pp) ? pp : 1. - pp;
+  double q = 1. - p;
+  double np = n * p;
+  double r = p / q;
+  double g = r * (n + 1);
+  const double psave = pp;
+  if (np < 30) {
+    qn = pow(q, (double)n);
+    /* draw_np_small */
+    for (;;) {
+      ix = 0;
+      double f = qn;
+      double u = bo_unif(rng);
+      for (;;) {
+        if (u < f) goto finis;
+        if (ix > 110) break;
+        u -= f;
+        ix++;
+        f *= (g / ix - r);
+      }
+    }
+  } else {
+    double ffm = np + p, al;
+    m = (int)ffm;
+    fm = m;
+    npq = np * q;
+    p1 = (int)(2.195 * sqrt(npq) - 4.6 * q) + 0.5;
+    xm = fm + 0.5;
+    xl = xm - p1;
+    xr = xm + p1;
+    c = 0.134 + 20.5 / (15.3 + fm);
+    al = (ffm - xl) / (ffm - xl * p);
+    xll = al * (1.0 + 0.5 * al);
+    al = (xr - ffm) / (xr * q);
+    xlr = al * (1.0 + 0.5 * al);
+    p2 = p1 * (1.0 + c + c);
+    p3 = p2 + c / xll;
+    p4 = p3 + c / xlr;
+  }
+  for (;;) {
+    double u = bo_unif(rng) * p4;
+    double v = bo_unif(rng);
+    double x;
+    int k;
+    if (u <= p1) { /* triangular region */
+      ix = (int)(xm - p1 * v + u);
+      goto finis;
+    }
+    if (u <= p2) { /* parallelogram region */
+      x = xl + (u - p1) / c;
+      v = v * c + 1.0 - fabs(xm - x) / p1;
+      if (v > 1.0 || v <= 0.) continue;
+      ix = (int)x;
+    } else {
+      if (u > p3) { /* right tail */
+        ix = (int)(xr - log(v) / xlr);
+        if ((unsigned)ix > n) continue;
+        v = v * (u - p3) * xlr;
+      } else { /* left tail */
+        ix = (int)(xl + log(v) / xll);
+        if (ix < 0) continue;
+        v = v * (u - p2) * xll;
+      }
+    }
+    k = abs(ix - m);
+    if (k <= 20 || k >= npq / 2 - 1) {
+      double f = 1.0;
+      if (m < ix) {
+        for (int i = m + 1; i <= ix; i++) f *= (g / i - r);
+      } else if (m != ix) {
+        for (int i = ix + 1; i <= m; i++) f /= (g / i - r);
+      }
+      if (v <= f) goto finis;
+    } else {
+      double amaxp = (k / npq) * ((k * (k / 3. + 0.625) + 0.1666666666666) / npq + 0.5);
+      double ynorm = -1.0 * k * k / (2.0 * npq);
+      double alv = log(v);
+      if (alv < ynorm - amaxp) goto finis;
+      if (alv <= ynorm + amaxp) {
+        double x1 = ix + 1, f1 = fm + 1.0, z = n + 1 - fm, w = n - ix + 1.0;
+        double z2 = z * z, x2 = x1 * x1, f2 = f1 * f1, w2 = w * w;
+        if (alv <= xm * log(f1 / x1) + (n - m + 0.5) * log(z / w) + (ix - m) * log(w * p / (x1 * q)) +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / f2) / f2) / f2) / f2) / f1 / 166320.0 +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / z2) / z2) / z2) / z2) / z / 166320.0 +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x1 / 166320.0 +
+                       (13860.0 - (462.0 - (132.0 - (99.0 - 140.0 / w2) / w2) / w2) / w2) / w / 166320.)
+          goto finis;
+      }
+    }
+  }
+finis:
+  if (psave > 0.5) ix = (int)n - ix;
+  return (unsigned)ix;
+}
+
+/* Rmath::rmultinom_mt(rng, n, prob, rN), Bmath/rmultinom.cpp:82-136 (prob sums to 1) */
+static int bo_rmultinom(bo_rng *rng, int n, const double *prob, int K, int *rN) {
+  double p_tot = 0.;
+  for (int k = 0; k < K; ++k) {
+    const double pp = prob[k];
+    if (!isfinite(pp) || pp < 0. || pp > 1.) return BO_ERR_UNSUPPORTED_RNG_BRANCH;
+    p_tot += pp;
+    rN[k] = 0;
+  }
+  if (fabs(p_tot - 1.) > 1e-7) return BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  if (n == 0) return 0;
+  for (int k = 0; k < K - 1; ++k) {
+    const double pp = prob[k] / p_tot;
+    /* Rmath::rbinom_mt -> binomial_distribution: n = 0, p = 0 and p = 1 go through the
+     * same code (inversion with qn = 1, resp. 0): one uniform either way */
+    rN[k] = (int)bo_rbinom(rng, (unsigned)n, pp);
+    n -= rN[k];
+    if (n <= 0) return 0;
+    p_tot -= prob[k];
+  }
+  rN[K - 1] = n;
+  return 0;
+}
+unsigned bo_test_rbinom(bo_rng *r, unsigned n, double p) { return bo_rbinom(r, n, p); }
+
+/* BinomialLogitCltDataImputer::impute_large_sample, BinomialLogitDataImputer.cpp:155-211 */
+static int logit_impute_large(bo_rng *rng, double ntrials, double nsuccess, double eta,
+                              double *sum_out, double *info_out) {
+  double information = 0.0;
+  double p0[9], p1[9];
+  int N0[9], N1[9];
+  /* plogis(0, eta, 1, lower / upper), Bmath/plogis.cpp:43-63 */
+  const double xz = (0 - eta) / 1.0;
+  const double neg_support = 1 / (1 + exp(-xz)), pos_support = 1 / (1 + exp(xz));
+  double s0 = 0, s1 = 0;
+  for (int m = 0; m < 9; ++m) {
+    const double z = (0 - eta) / LOGIT_MIX_SIGMA[m];
+    p0[m] = LOGIT_MIX_WEIGHT[m] / neg_support * (0.5 * erfc(-z / 1.4142135623730951));  /* pnorm(0, eta, sigma, true) */
+    p1[m] = LOGIT_MIX_WEIGHT[m] / pos_support * (0.5 * erfc(z / 1.4142135623730951));   /* ... upper tail */
+  }
+  for (int m = 0; m < 9; ++m) { s0 += p0[m]; s1 += p1[m]; }
+  for (int m = 0; m < 9; ++m) { p0[m] /= s0; p1[m] /= s1; }
+  int rc = bo_rmultinom(rng, (int)(ntrials - nsuccess), p0, 9, N0);
+  if (rc) return rc;
+  rc = bo_rmultinom(rng, (int)nsuccess, p1, 9, N1);
+  if (rc) return rc;
+  double simulation_mean = 0, simulation_variance = 0;
+  for (int m = 0; m < 9; ++m) {
+    const int total_obs = N0[m] + N1[m];
+    if (total_obs == 0) continue;
+    const double sigsq = LOGIT_MIX_SIGMA[m] * LOGIT_MIX_SIGMA[m], sig4 = sigsq * sigsq;
+    information += total_obs / sigsq;
+    double tmean, tvar;
+    if (N0[m] > 0) {
+      trun_norm_moments(eta, LOGIT_MIX_SIGMA[m], 0, 0, &tmean, &tvar);
+      simulation_mean += N0[m] * tmean / sigsq;
+      simulation_variance += N0[m] * tvar / sig4;
+    }
+    if (N1[m] > 0) {
+      trun_norm_moments(eta, LOGIT_MIX_SIGMA[m], 0, 1, &tmean, &tvar);
+      simulation_mean += N1[m] * tmean / sigsq;
+      simulation_variance += N1[m] * tvar / sig4;
+    }
+  }
+  *sum_out = bo_rnorm(rng, simulation_mean, sqrt(simulation_variance));
+  *info_out = information;
+  return 0;
+}
+
 struct bo_logit {
   int n, p, clt;
   double *X, *y, *nt;
   bo_sss *sss;      /* (X'WX, X'Wz), gamma, beta, the sampler's RNG */
   bo_rng worker_rng; /* the imputation worker's own RNG (Imputer.hpp:136-142) */
-  int substream;     /* 1: observation i of sweep s reads from position (s n + i) * 64 */
+  int substream;     /* 1: observation i of sweep s reads from position (s n + i) * 256 */
   uint64_t sweep;
   double logw[9];
 };
-#define BO_LOGIT_STRIDE 64
+#define BO_LOGIT_STRIDE 256
 
 bo_logit *bo_logit_create(int n, int p, const double *X, const double *y,
                           const double *ntrials, const double *mu, const double *prec,
@@ -2837,11 +3013,14 @@ int bo_logit_draw(bo_logit *m) {
     for (int j = 0; j < p; ++j)
       if (s->gamma[j]) eta += m->X[IDX(i, j, n)] * s->beta[j];
     const long nt = lround(m->nt[i]), ys = lround(m->y[i]);
-    if (nt > m->clt) return BO_ERR_UNSUPPORTED_RNG_BRANCH;
     bo_rng *r = &m->worker_rng;
     if (m->substream) r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * BO_LOGIT_STRIDE;
     double sum = 0, info = 0;
-    for (long t = 0; t < nt; ++t) {
+    if (nt > m->clt) {
+      status = logit_impute_large(r, m->nt[i], m->y[i], eta, &sum, &info);
+      if (status) return status;
+    }
+    for (long t = 0; t < nt && nt <= m->clt; ++t) {
       const int success = t < ys;
       /* rtrun_logit_mt(rng, eta, 0, success) */
       const double cutpoint_prob = 1 / (1 + exp(-(0 - eta)));   /* plogis(cutpoint - mean) */

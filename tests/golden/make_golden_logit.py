@@ -17,6 +17,11 @@ CASES = [  # name, n, p, signals, max trials, clt threshold, seed, max_flips
     ("logit_bernoulli", 300, 10, 3, 1, 5, 21, -1),
     ("logit_binomial4", 300, 10, 3, 4, 5, 22, -1),
     ("logit_bernoulli_p24_maxflips", 500, 24, 5, 1, 5, 23, 9),
+    # trial counts up to 60 with clt_threshold 5: most observations take
+    # BinomialLogitCltDataImputer::impute_large_sample (multinomial counts by BTPE /
+    # inversion binomials, then one normal draw)
+    ("logit_binomial60_large_sample", 250, 8, 3, 60, 5, 24, -1),
+    ("logit_binomial200_large_sample", 120, 6, 2, 200, 10, 25, -1),
 ]
 
 

@@ -212,3 +212,31 @@ def test_posterior_agrees_with_the_sequential_stream_sampler(oracle, kind):
         m_o, se_o = ora.mean(0), batch_se(ora)
         z = np.abs(m_d - m_o) / np.sqrt(se_d ** 2 + se_o ** 2 + 1e-12)
         assert np.all(z < 5.0), (kind, m_d, m_o, z)
+
+
+@pytest.mark.parametrize("n,p,nsig,max_trials,clt", [(250, 8, 3, 60, 5), (120, 6, 2, 200, 10),
+                                                      (400, 12, 4, 30, 64)])
+def test_logit_large_sample_imputation_matches_oracle(oracle, n, p, nsig, max_trials, clt):
+    """Observations with more than clt_threshold trials: BinomialLogitCltDataImputer::
+    impute_large_sample (BinomialLogitDataImputer.cpp:155-211) on the device -- two
+    multinomial draws over the nine mixture components (BTPE / inversion binomials) and
+    one normal draw per observation.  The oracle's restatement is pinned on the compiled
+    reference by tests/golden/logit_binomial{60,200}_large_sample.npz; the last case
+    keeps every observation on the per-trial branch up to 30 trials (clt_threshold 64)."""
+    X, y, nt, _ = logit_data(n, p, nsig, seed=5 + max_trials + p, max_trials=max_trials)
+    slab, pi = probit_slab(X, nt, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    chains, seed, nsw = 5, 23, 20
+    eng = make_engine(chains, seed, X, y, nt, slab, pi, g0, clt=clt)
+    check = [0, chains - 1]
+    ora = {c: oracle.logit_run(X, y, nt, slab, pi, ("philox", seed, c), g0, np.zeros(p), nsw,
+                               clt_threshold=clt) for c in check}
+    for s in range(nsw):
+        eng.logit_sweep(1)
+        gam, beta, _ = eng.get_states()
+        for c in check:
+            o = ora[c]
+            assert o["status"] == 0
+            assert np.array_equal(gam[c], o["gamma"][s]), (c, s)
+            assert relerr(beta[c], o["beta"][s]) < RTOL, (c, s)

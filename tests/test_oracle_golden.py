@@ -350,7 +350,8 @@ def test_probit_spike_slab_matches_reference(oracle, name):
 
 
 @pytest.mark.parametrize("name", ["logit_bernoulli", "logit_binomial4",
-                                  "logit_bernoulli_p24_maxflips"])
+                                  "logit_bernoulli_p24_maxflips", "logit_binomial60_large_sample",
+                                  "logit_binomial200_large_sample"])
 def test_logit_spike_slab_matches_reference(oracle, name):
     """f3 (logit): BinomialLogitSpikeSlabSampler with its auxiliary-mixture imputer"""
     g = load(name)
