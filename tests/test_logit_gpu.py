@@ -113,13 +113,21 @@ def test_logit_models_of_more_than_64_variables(oracle):
     assert max(o["gamma"].sum(axis=1).max() for o in ora.values()) > 64
 
 
-def test_logit_rejects_large_trial_counts():
+def test_logit_rejects_bad_arguments():
+    """the reference's own argument checks (BinomialLogitDataImputer.cpp:42-60) and the
+    bound on clt_threshold that the observation substreams impose"""
     import boom_amd
     X, y, nt, _ = logit_data(50, 4, 2, seed=1, max_trials=9)
     eng = boom_amd.Engine(2, seed=1)
     with pytest.raises(boom_amd.BoomAmdError) as ei:
-        eng.logit_set_data(X, y, nt, 5)
-    assert "large-sample" in str(ei.value)
+        eng.logit_set_data(X, y, nt, 65)
+    assert "clt_threshold" in str(ei.value)
+    bad = y.copy()
+    bad[3] = nt[3] + 1
+    with pytest.raises(boom_amd.BoomAmdError) as ei:
+        eng.logit_set_data(X, bad, nt, 5)
+    assert "must not exceed the number of trials" in str(ei.value)
+    eng.logit_set_data(X, y, nt, 5)      # trial counts above the threshold are served now
 
 
 def test_config5_shape_per_gpu():
