@@ -101,6 +101,7 @@ SIGNATURES = {
     "ba_probit_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_logit_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, C.c_int32]),
     "ba_logit_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_logit_set_imputer": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_set_structural": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_dp] * 6),
     "ba_ss_get_structural": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -442,6 +443,10 @@ class Engine:
         nt = np.ascontiguousarray(ntrials, dtype=np.float64)
         self._check(self.lib.ba_logit_set_data(self._h, X.shape[0], X.shape[1], _p(X), _p(y),
                                                _p(nt), int(clt_threshold)))
+
+    def logit_set_imputer(self, kind):
+        """0: the reference's auxiliary mixture (default); 1: Polya-Gamma"""
+        self._check(self.lib.ba_logit_set_imputer(self._h, int(kind)))
 
     def logit_sweep(self, nsweeps=1, sync=True):
         self._check(self.lib.ba_logit_sweep(self._h, nsweeps))

@@ -45,7 +45,8 @@ hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizo
                                uint64_t *pos_forecast, double *out);
 hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P, double *planes);
 hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *Xsq,
-                               const double *slab_precision, double *v_diag, double *planes);
+                               const double *slab_precision, double *v_diag, double *planes,
+                               int polya_gamma);
 // xtwx_cols_kernel.hip
 hipError_t launch_ssvs_big_logp(hipStream_t stream, const SsvsParams &P, int kcap, const uint8_t *gammas,
                                 const int *which, int nwhich, double *model_ws, double *xs_ws, double *out,
@@ -312,6 +313,7 @@ struct ba_engine {
   // BinomialLogitSpikeSlabSampler: the same buffers plus the observations' total
   // precisions (chains x n) and every chain's own V = slab precision + X'WX
   bool logit_mode = false;
+  int logit_imputer = 0;           // 0: the reference's auxiliary mixture, 1: Polya-Gamma
   DevBuf<double> dlogit_w, dlogit_V;
   // ... V built a vector at a time (xtwx_cols_kernel.hip): the squared design matrix
   // (for the diagonal), the diagonals (chains x p), which vectors hold this sweep's
@@ -2272,6 +2274,14 @@ int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const
   return BA_OK;
 }
 
+int ba_logit_set_imputer(ba_engine *e, int32_t kind) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (kind != 0 && kind != 1) return fail(BA_E_INVALID, "imputer must be 0 (auxiliary mixture) or 1 (Polya-Gamma)");
+  MUTATE(e);
+  e->logit_imputer = kind;
+  return BA_OK;
+}
+
 int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
   ENGINE_PROLOGUE(e);
   MUTATE(e);
@@ -2334,7 +2344,7 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
     Q.sweep = e->probit_sweep++;
     // impute_latent_data: z, w, X'Wz and the diagonal of V = slab precision + X'WX ...
     HIP_TRY(launch_logit_impute(e->stream, Q, e->dlogit_Xsq.ptr, e->dA.ptr, e->dlogit_vdiag.ptr,
-                                e->dlogit_planes.ptr));
+                                e->dlogit_planes.ptr, e->logit_imputer));
     // ... and the vectors of V the sweep starts from: those of the included variables
     HIP_TRY(launch_xtwx_cols_start(e->stream, e->dgamma.ptr, (int)C, (int)p, e->dlogit_req.ptr,
                                    e->dlogit_cnt.ptr, e->dlogit_valid.ptr, e->logit_words));

@@ -557,6 +557,133 @@ __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
   P.w[(size_t)chain * P.n + i] = info;
 }
 
+// ---- Polya-Gamma augmentation (BASELINE config 5 as worded) ---------------------------
+// BOOM has no Polya-Gamma sampler: this is the published algorithm --
+// Polson, Scott and Windle (2013), JASA 108, sec. 4 / supplement Algorithm 1: PG(1, z) =
+// J*(1, z / 2) / 4 by Devroye's alternating-series method with a truncated
+// inverse-Gaussian proposal below t = 0.64 and an exponential one above -- with the
+// oracle's bo_logit (imputer = 1) as its CPU twin, draw for draw.  omega_i ~ PG(n_i,
+// x_i'beta) is the observation's information, kappa_i = y_i - n_i / 2 its
+// information-weighted response: the same (sum, information) pair the auxiliary-mixture
+// imputer produces, so everything after the imputation is the logit path unchanged.
+// Observation i of sweep s reads the chain's stream 10 from position (s n + i) * PG_STRIDE.
+namespace {
+constexpr double PG_T = 0.64, PG_PI = 3.14159265358979323846;
+__device__ __forceinline__ double pg_pnorm(double x) { return 0.5 * erfc(-x / 1.4142135623730951); }
+__device__ __forceinline__ double pg_a(int n, double x) {
+  const double K = (n + 0.5) * PG_PI;
+  if (x > PG_T) return K * exp(-0.5 * K * K * x);
+  const double expnt = -1.5 * (log(0.5 * PG_PI) + log(x)) + log(K) - 2.0 * (n + 0.5) * (n + 0.5) / x;
+  return exp(expnt);
+}
+__device__ __forceinline__ double pg_rtigauss(SeqRng &r, double z, int *bad) {
+  const double t = PG_T;
+  double X = t + 1.0;
+  if (z < 1.0 / t) {   // mu = 1 / z > t (z = 0: the Levy limit, alpha = 1)
+    double alpha = 0.0;
+    int it = 0;
+    while (r() > alpha) {
+      double E1 = d_exp_rand(r), E2 = d_exp_rand(r);
+      while (E1 * E1 > 2 * E2 / t) { E1 = d_exp_rand(r); E2 = d_exp_rand(r); }
+      X = 1 + E1 * t;
+      X = t / (X * X);
+      alpha = exp(-0.5 * z * z * X);
+      if (++it > 10000) { *bad = 1; return t; }
+    }
+  } else {
+    const double mu = 1.0 / z;
+    int it = 0;
+    while (X > t) {
+      double Y = d_norm_rand(r);
+      Y *= Y;
+      const double half_mu = 0.5 * mu, mu_Y = mu * Y;
+      X = mu + half_mu * mu_Y - half_mu * sqrt(4 * mu_Y + mu_Y * mu_Y);
+      if (r() > mu / (mu + X)) X = mu * mu / X;
+      if (++it > 10000) { *bad = 1; return t; }
+    }
+  }
+  return X;
+}
+__device__ __forceinline__ double pg_draw1(SeqRng &r, double z, int *bad) {
+  z = fabs(z) * 0.5;
+  const double t = PG_T;
+  const double fz = 0.125 * PG_PI * PG_PI + 0.5 * z * z;
+  for (int tries = 0; tries < 10000; ++tries) {
+    double X;
+    {
+      const double b = sqrt(1.0 / t) * (t * z - 1), a = -1.0 * sqrt(1.0 / t) * (t * z + 1);
+      const double x0 = log(fz) + fz * t;
+      const double xb = x0 - z + log(pg_pnorm(b)), xa = x0 + z + log(pg_pnorm(a));
+      const double qdivp = 4 / PG_PI * (exp(xb) + exp(xa));
+      if (r() < 1.0 / (1.0 + qdivp)) X = t + d_exp_rand(r) / fz;
+      else X = pg_rtigauss(r, z, bad);
+    }
+    if (*bad) return 0.25 * X;
+    double S = pg_a(0, X);
+    const double Y = r() * S;
+    int n = 0;
+    bool go = true;
+    while (go) {
+      ++n;
+      if (n & 1) {
+        S -= pg_a(n, X);
+        if (Y <= S) return 0.25 * X;
+      } else {
+        S += pg_a(n, X);
+        if (Y > S) go = false;
+      }
+      if (n > 1000) { *bad = 1; return 0.25 * X; }
+    }
+  }
+  *bad = 1;
+  return 0.0;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void logit_pg_impute_kernel(ProbitParams P) {
+  const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  __shared__ int s_status;   // (one decision per workgroup: see probit_impute_kernel)
+  if (threadIdx.x == 0) s_status = __atomic_load_n(P.status + chain, __ATOMIC_RELAXED);
+  __syncthreads();
+  if (s_status != CHAIN_OK) return;
+  __shared__ int s_idx[PROBIT_KMAX];
+  __shared__ double s_beta[PROBIT_KMAX];
+  const int k = included_coefficients(P, chain, s_idx, s_beta);
+  if (k > PROBIT_KMAX) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
+    return;
+  }
+  if (i >= P.n) return;
+  double eta = 0.0;
+  for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
+  const long nt = lround(P.ntrials[i]), ys = lround(P.y[i]);
+  const uint64_t start = (P.sweep * (uint64_t)P.n + (uint64_t)i) * PG_STRIDE;
+  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 10u}, start};
+  int bad = 0;
+  double omega = 0.0;
+  if (nt > P.clt_threshold) {
+    // the normal with PG(n, z)'s mean n tanh(z/2) / (2 z) and variance
+    // n (sinh z - z) / (4 z^3 cosh^2(z/2))
+    const double az = fabs(eta);
+    double mean, var;
+    if (az < 1e-4) {
+      mean = nt * (0.25 - az * az / 48.0);
+      var = nt * (1.0 / 24.0 - az * az / 120.0);
+    } else {
+      const double th = tanh(0.5 * az), ch = cosh(0.5 * az);
+      mean = nt * th / (2 * az);
+      var = nt * (sinh(az) - az) / (4 * az * az * az * ch * ch);
+    }
+    omega = d_rnorm(rng, mean, sqrt(var));
+    if (!(omega > 0)) omega = mean;
+  } else {
+    for (long t = 0; t < nt; ++t) omega += pg_draw1(rng, eta, &bad);
+  }
+  if (bad || rng.pos - start > (uint64_t)PG_STRIDE) P.status[chain] = CHAIN_RNG_BRANCH;
+  P.z[(size_t)chain * P.n + i] = (double)ys - 0.5 * (double)nt;
+  P.w[(size_t)chain * P.n + i] = omega;
+}
+
 hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R, const double *B, int64_t n,
                                      int p, const double *diag_base, double *out, double *planes);
 
@@ -576,11 +703,15 @@ hipError_t launch_probit_impute(hipStream_t stream, const ProbitParams &P, doubl
 // impute, X'Wz and the diagonal of V = slab precision + X'WX for every chain (the rest
 // of V is built a vector at a time, as the sweep asks for it: xtwx_cols_kernel.hip)
 hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const double *Xsq,
-                               const double *slab_precision, double *v_diag, double *planes) {
+                               const double *slab_precision, double *v_diag, double *planes,
+                               int polya_gamma) {
   hipError_t err;
   {
     KtScope kt(stream, KT_LOGIT_IMPUTE);
-    hipLaunchKernelGGL(logit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
+    if (polya_gamma)
+      hipLaunchKernelGGL(logit_pg_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
+    else
+      hipLaunchKernelGGL(logit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
     err = hipGetLastError();
   }
   if (err != hipSuccess) return err;

@@ -7,7 +7,7 @@
 
 namespace boom_amd {
 
-enum { PROBIT_STRIDE = 4096, PROBIT_KMAX = 1024, LOGIT_STRIDE = 256 };
+enum { PROBIT_STRIDE = 4096, PROBIT_KMAX = 1024, LOGIT_STRIDE = 256, PG_STRIDE = 4096 };
 
 struct ProbitParams {
   int32_t n, p, chains, clt_threshold;

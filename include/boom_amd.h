@@ -278,6 +278,17 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps);
 int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X,
                       const double *y, const double *ntrials, int32_t clt_threshold);
 int ba_logit_sweep(ba_engine *e, int32_t nsweeps);
+/* The imputation step of the logit sampler: 0 (default) the reference's auxiliary
+ * mixture; 1 Polya-Gamma augmentation -- omega_i ~ PG(n_i, x_i'beta) by Devroye's exact
+ * sampler (Polson, Scott and Windle 2013), the normal with PG's moments beyond
+ * clt_threshold trials; (y_i - n_i / 2, omega_i) takes the place of the mixture's
+ * (information-weighted sum, information), everything else is the same sweep.  BOOM has
+ * NO Polya-Gamma sampler (BASELINE config 5 names one): there is nothing to be
+ * bit-compared with; the chain it defines has the same stationary distribution as the
+ * logit likelihood's exact posterior, which the auxiliary-mixture sampler approximates,
+ * and is checked against that sampler distributionally.  RNG: stream 10, observation i
+ * of sweep s from position (s n + i) * 4096. */
+int ba_logit_set_imputer(ba_engine *e, int32_t kind);
 
 /* ---- posterior summaries --------------------------------------------------- */
 /* Running sums over every sweep since the last ba_reset_summaries(), reduced

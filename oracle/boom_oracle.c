@@ -2956,15 +2956,131 @@ static int logit_impute_large(bo_rng *rng, double ntrials, double nsuccess, doub
   return 0;
 }
 
+
+/* ---- Polya-Gamma augmentation (BASELINE config 5 as worded) ---------------------------
+ * NO REFERENCE: BOOM has no Polya-Gamma sampler.  What is restated here
+ * is the published algorithm -- Polson, Scott and Windle (2013), "Bayesian inference for
+ * logistic models using Polya-Gamma latent variables", JASA 108, sec. 4 and the
+ * supplement's Algorithm 1: PG(1, z) = J*(1, z / 2) / 4 by Devroye's alternating-series
+ * method, the proposal a truncated inverse-Gaussian below t = 0.64 and an exponential
+ * above it -- so that the device kernel has a CPU twin to be compared with draw for draw.
+ * PARITY UNPINNED: the posterior it leads to is checked against the (reference-pinned)
+ * auxiliary-mixture sampler's distributionally (tests/test_polya_gamma.py).
+ *   omega_i ~ PG(n_i, x_i'beta) = sum of n_i PG(1, .) draws; beyond clt_threshold trials
+ *   a normal draw with the exact mean n tanh(z/2) / (2 z) and variance
+ *   n (sinh z - z) / (4 z^3 cosh^2(z/2)) (the moments of PG(n, z)) -- the same switch to a
+ *   central-limit draw the reference's own imputers make at that threshold.
+ * Given omega: y_i - n_i / 2 = kappa_i is the information-weighted response and omega_i
+ * the information, exactly the (sum, information) pair the auxiliary-mixture imputer
+ * hands to SufficientStatistics::update (BinomialLogitAuxmixSampler.cpp:60-66). */
+#define BO_PG_TRUNC 0.64
+static double pg_pnorm(double x) { return 0.5 * erfc(-x / 1.4142135623730951); }
+/* series coefficient a_n(x) of the Jacobi density */
+static double pg_a(int n, double x) {
+  const double K = (n + 0.5) * 3.14159265358979323846;
+  if (x > BO_PG_TRUNC) return K * exp(-0.5 * K * K * x);
+  const double expnt = -1.5 * (log(0.5 * 3.14159265358979323846) + log(x)) + log(K) - 2.0 * (n + 0.5) * (n + 0.5) / x;
+  return exp(expnt);
+}
+/* inverse Gaussian IG(1 / z, 1) truncated to (0, t) */
+static double pg_rtigauss(bo_rng *r, double z, int *status) {
+  const double t = BO_PG_TRUNC;
+  double X = t + 1.0;
+  if (z < 1.0 / t) {   /* mu = 1 / z > t (z = 0: the Levy limit, alpha = 1) */
+    double alpha = 0.0;
+    int it = 0;
+    while (bo_unif(r) > alpha) {
+      double E1 = bo_exp_rand(r), E2 = bo_exp_rand(r);
+      while (E1 * E1 > 2 * E2 / t) { E1 = bo_exp_rand(r); E2 = bo_exp_rand(r); }
+      X = 1 + E1 * t;
+      X = t / (X * X);
+      alpha = exp(-0.5 * z * z * X);
+      if (++it > 10000) { *status = BO_ERR_UNSUPPORTED_RNG_BRANCH; return t; }
+    }
+  } else {
+    const double mu = 1.0 / z;
+    int it = 0;
+    while (X > t) {
+      double Y = bo_norm_rand(r);
+      Y *= Y;
+      const double half_mu = 0.5 * mu, mu_Y = mu * Y;
+      X = mu + half_mu * mu_Y - half_mu * sqrt(4 * mu_Y + mu_Y * mu_Y);
+      if (bo_unif(r) > mu / (mu + X)) X = mu * mu / X;
+      if (++it > 10000) { *status = BO_ERR_UNSUPPORTED_RNG_BRANCH; return t; }
+    }
+  }
+  return X;
+}
+/* PG(1, z) */
+static double pg_draw1(bo_rng *r, double z, int *status) {
+  z = fabs(z) * 0.5;
+  const double t = BO_PG_TRUNC;
+  const double fz = 0.125 * 3.14159265358979323846 * 3.14159265358979323846 + 0.5 * z * z;
+  for (int tries = 0; tries < 10000; ++tries) {
+    double X;
+    {
+      /* p = (pi / 2 / fz) exp(-fz t): mass of the exponential tail; q = 2 exp(-z) P(IG(1/z, 1) < t) */
+      const double b = sqrt(1.0 / t) * (t * z - 1), a = -1.0 * sqrt(1.0 / t) * (t * z + 1);
+      const double x0 = log(fz) + fz * t;
+      const double xb = x0 - z + log(pg_pnorm(b)), xa = x0 + z + log(pg_pnorm(a));
+      const double qdivp = 4 / 3.14159265358979323846 * (exp(xb) + exp(xa));
+      if (bo_unif(r) < 1.0 / (1.0 + qdivp)) X = t + bo_exp_rand(r) / fz;
+      else X = pg_rtigauss(r, z, status);
+    }
+    if (*status) return 0.25 * X;
+    double S = pg_a(0, X);
+    const double Y = bo_unif(r) * S;
+    int n = 0, go = 1;
+    while (go) {
+      ++n;
+      if (n & 1) {
+        S -= pg_a(n, X);
+        if (Y <= S) return 0.25 * X;
+      } else {
+        S += pg_a(n, X);
+        if (Y > S) go = 0;
+      }
+      if (n > 1000) { *status = BO_ERR_UNSUPPORTED_RNG_BRANCH; return 0.25 * X; }
+    }
+  }
+  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  return 0.0;
+}
+/* PG(n, z): the sum of n PG(1, z) draws, or beyond `clt` trials the normal with PG(n, z)'s mean and variance */
+static double pg_draw(bo_rng *r, long n, double z, long clt, int *status) {
+  if (n <= 0) return 0.0;
+  if (n > clt) {
+    const double az = fabs(z);
+    double mean, var;
+    if (az < 1e-4) {   /* the two ratios' series around 0 */
+      mean = n * (0.25 - az * az / 48.0);
+      var = n * (1.0 / 24.0 - az * az / 120.0);
+    } else {
+      const double th = tanh(0.5 * az), ch = cosh(0.5 * az);
+      mean = n * th / (2 * az);
+      var = n * (sinh(az) - az) / (4 * az * az * az * ch * ch);
+    }
+    double x = bo_rnorm(r, mean, sqrt(var));
+    if (!(x > 0)) x = mean;   /* (a draw in the far lower tail of the approximation) */
+    return x;
+  }
+  double sum = 0.0;
+  for (long i = 0; i < n; ++i) sum += pg_draw1(r, z, status);
+  return sum;
+}
+double bo_test_rpg(bo_rng *r, long n, double z, long clt, int *status) { return pg_draw(r, n, z, clt, status); }
+
 struct bo_logit {
   int n, p, clt;
   double *X, *y, *nt;
   bo_sss *sss;      /* (X'WX, X'Wz), gamma, beta, the sampler's RNG */
   bo_rng worker_rng; /* the imputation worker's own RNG (Imputer.hpp:136-142) */
   int substream;     /* 1: observation i of sweep s reads from position (s n + i) * 256 */
+  int imputer;       /* 0: the reference's auxiliary mixture; 1: Polya-Gamma (stream 10, stride BO_PG_STRIDE) */
   uint64_t sweep;
   double logw[9];
 };
+#define BO_PG_STRIDE 4096
 #define BO_LOGIT_STRIDE 256
 
 bo_logit *bo_logit_create(int n, int p, const double *X, const double *y,
@@ -2996,6 +3112,7 @@ void bo_logit_destroy(bo_logit *m) {
 bo_sss *bo_logit_sss(bo_logit *m) { return m->sss; }
 bo_rng *bo_logit_worker_rng(bo_logit *m) { return &m->worker_rng; }
 void bo_logit_use_substreams(bo_logit *m, int on) { m->substream = on; }
+void bo_logit_set_imputer(bo_logit *m, int kind) { m->imputer = kind; }
 void bo_logit_get_suf(const bo_logit *m, double *xtx, double *xty) {
   memcpy(xtx, m->sss->xtx, sizeof(double) * (size_t)m->p * m->p);
   memcpy(xty, m->sss->xty, sizeof(double) * m->p);
@@ -3014,13 +3131,18 @@ int bo_logit_draw(bo_logit *m) {
       if (s->gamma[j]) eta += m->X[IDX(i, j, n)] * s->beta[j];
     const long nt = lround(m->nt[i]), ys = lround(m->y[i]);
     bo_rng *r = &m->worker_rng;
-    if (m->substream) r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * BO_LOGIT_STRIDE;
+    if (m->substream) r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * (m->imputer ? BO_PG_STRIDE : BO_LOGIT_STRIDE);
     double sum = 0, info = 0;
-    if (nt > m->clt) {
+    if (m->imputer == 1) {
+      /* omega ~ PG(n_i, eta); (kappa, omega) is the (sum, information) pair */
+      info = pg_draw(r, nt, eta, m->clt, &status);
+      if (status) return status;
+      sum = (double)ys - 0.5 * (double)nt;
+    } else if (nt > m->clt) {
       status = logit_impute_large(r, m->nt[i], m->y[i], eta, &sum, &info);
       if (status) return status;
     }
-    for (long t = 0; t < nt && nt <= m->clt; ++t) {
+    for (long t = 0; t < nt && nt <= m->clt && m->imputer == 0; ++t) {
       const int success = t < ys;
       /* rtrun_logit_mt(rng, eta, 0, success) */
       const double cutpoint_prob = 1 / (1 + exp(-(0 - eta)));   /* plogis(cutpoint - mean) */

@@ -267,6 +267,9 @@ void bo_logit_destroy(bo_logit *m);
 bo_sss *bo_logit_sss(bo_logit *m);
 bo_rng *bo_logit_worker_rng(bo_logit *m);
 void bo_logit_use_substreams(bo_logit *m, int on);
+/* 0: the reference's auxiliary-mixture imputer (default); 1: Polya-Gamma augmentation (no
+ * reference: Polson, Scott and Windle 2013; the device's CPU twin) */
+void bo_logit_set_imputer(bo_logit *m, int kind);
 void bo_logit_get_suf(const bo_logit *m, double *xtx, double *xty);
 int bo_logit_draw(bo_logit *m);
 void bo_sss_set_shuffle_kind(bo_sss *s, int kind);

@@ -641,7 +641,7 @@ class Oracle:
         return dict(gamma=gam, beta=beta, status=status)
 
     def logit_run(self, X, y, ntrials, slab, pi, rng_setup, init_gamma, init_beta, nsweeps,
-                  clt_threshold=5, max_model_size=-1, max_flips=-1, want_suf=False):
+                  clt_threshold=5, max_model_size=-1, max_flips=-1, want_suf=False, imputer=0):
         """BinomialLogitSpikeSlabSampler (f3): slab = dict(mu, prec)"""
         n, p = X.shape
         self._declare_sss()
@@ -663,8 +663,12 @@ class Oracle:
         else:
             seed, chain = int(rng_setup[1]), int(rng_setup[2])
             self.lib.bo_rng_seed_philox(self.lib.bo_sss_rng(sss), seed, chain, 3, 0)
-            self.lib.bo_rng_seed_philox(self.lib.bo_logit_worker_rng(m), seed, chain, 9, 0)
+            self.lib.bo_rng_seed_philox(self.lib.bo_logit_worker_rng(m), seed, chain,
+                                        10 if imputer else 9, 0)
             self.lib.bo_logit_use_substreams(m, 1)
+        if imputer:
+            self.lib.bo_logit_set_imputer.argtypes = [C.c_void_p, C.c_int]
+            self.lib.bo_logit_set_imputer(m, int(imputer))
         gam = np.zeros((nsweeps, p), dtype=np.uint8)
         beta = np.zeros((nsweeps, p))
         xtx = np.zeros((nsweeps, p, p)) if want_suf else None
