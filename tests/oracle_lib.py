@@ -553,7 +553,7 @@ class Oracle:
             ss["initial_state_variance"], ss["initial_level_sigma"])
 
     def ss_run(self, y, X, observed, prior, opts, ss, rng_setup, init_gamma,
-               nsweeps):
+               nsweeps, keep_state=None):
         T, p = X.shape
         m = self.ss_create(y, X, observed, prior, ss)
         reg = self.lib.bo_ss_regression(m)
@@ -573,11 +573,15 @@ class Oracle:
             for sid, rp in enumerate(rngs):
                 self.lib.bo_rng_seed_philox(rp, int(rng_setup[1]),
                                             int(rng_setup[2]), sid, 0)
+            if rng_setup[0] == "philox_seq":
+                # the state stream read in sequence, as the reference reads its RNG,
+                # instead of one substream per normal (tests of the substream bridge)
+                C.cast(rngs[2], C.POINTER(BoRng)).contents.slot_stride = 0
         gam = np.zeros((nsweeps, p), dtype=np.uint8)
         beta = np.zeros((nsweeps, p))
         sig = np.zeros(nsweeps)
         lev = np.zeros(nsweeps)
-        state = np.zeros((nsweeps, T))
+        state = np.zeros((nsweeps, T)) if keep_state is None else np.zeros((nsweeps, len(keep_state)))
         g = np.zeros(p, dtype=np.uint8)
         b = np.zeros(p)
         s = C.c_double()
@@ -591,7 +595,8 @@ class Oracle:
             beta[i] = b
             sig[i] = s.value
             lev[i] = self.lib.bo_ss_level_sigsq(m)
-            state[i] = np.ctypeslib.as_array(self.lib.bo_ss_state(m), (T,))
+            st = np.ctypeslib.as_array(self.lib.bo_ss_state(m), (T,))
+            state[i] = st if keep_state is None else st[keep_state]
         self.lib.bo_ss_destroy(m)
         return dict(gamma=gam, beta=beta, sigsq=sig, level_sigsq=lev,
                     state=state, status=status)

@@ -1,0 +1,137 @@
+"""The bridge between the reference's SEQUENTIAL reading of the state stream and the
+per-draw substreams of the device (VERDICT r2 "what's weak" 1, task 7).
+
+The bsts state normals (stream 2) sit at fixed stream positions on the device and in the
+oracle's Philox mode: normal i reads from position 256 i.  The reference -- and the
+oracle's MT mode, which is pinned on the compiled reference draw for draw -- reads ONE
+stream in sequence.  Same transform (Kinderman-Ramage on the uniforms it is handed),
+different uniforms: same-seed equality with a sequential reader is impossible by design,
+so what has to hold is equality of the sampled distribution.  Checked here AT THE
+BENCHMARK SHAPE (BASELINE configs[2]: T = 2000, p = 100), not on a toy:
+
+  oracle, Philox, substreams  (what the device is bit-compared with)
+  oracle, Philox, sequential  (same generator, the reference's reading order)
+  oracle, MT19937-64, sequential (the mode pinned on the reference)
+
+2e4 post-burn-in draws each; sigma^2, sigma^2_level, the inclusion indicators and
+coefficients of the five signals and three noise variables, eight state coordinates:
+posterior means within 3 standard errors (batch means) pairwise, and a two-sample
+Kolmogorov-Smirnov test on thinned sigma^2 and sigma^2_level draws.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from cases import bsts_priors, state_space_data
+from oracle_lib import ssvs_options
+
+T, P, NSIG = 2000, 100, 5
+BURN, DRAWS = 500, 20000
+KEEP_STATE = [0, 1, 250, 777, 1000, 1500, 1998, 1999]
+VARS = [0, 1, 2, 3, 4, 17, 50, 99]
+
+
+def batch_mean_se(x, nb=40):
+    m = np.array([v.mean(0) for v in np.array_split(np.asarray(x, float), nb)])
+    return m.mean(0), m.std(0, ddof=1) / np.sqrt(nb)
+
+
+def summaries(o):
+    s = slice(BURN, None)
+    cols = [np.log(o["sigsq"][s])[:, None], np.log(o["level_sigsq"][s])[:, None],
+            o["gamma"][s][:, VARS].astype(float), o["beta"][s][:, VARS], o["state"][s]]
+    return np.concatenate(cols, axis=1)
+
+
+@pytest.fixture(scope="module")
+def runs(oracle):
+    X, y, _, _ = state_space_data(T, P, NSIG, seed=8675309)
+    prior, ss, sig_up = bsts_priors(X, y, NSIG)
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(P, np.uint8)
+    modes = {"substream": ("philox", 2024, 0), "sequential": ("philox_seq", 2024, 1), "mt": ("mt", 4242)}
+
+    def run(mode):
+        o = oracle.ss_run(y, X, None, prior, opts, ss, modes[mode], g0, BURN + DRAWS,
+                          keep_state=KEEP_STATE)
+        assert o["status"] == 0
+        return o
+    with ThreadPoolExecutor(3) as ex:
+        out = dict(zip(modes, ex.map(run, modes)))
+    return out
+
+
+@pytest.mark.parametrize("a,b", [("substream", "sequential"), ("substream", "mt"), ("sequential", "mt")])
+def test_posterior_means_agree_at_the_benchmark_shape(runs, a, b):
+    ma, sa = batch_mean_se(summaries(runs[a]))
+    mb, sb = batch_mean_se(summaries(runs[b]))
+    z = np.abs(ma - mb) / np.sqrt(sa ** 2 + sb ** 2 + 1e-30)
+    # (indicators that never moved in either run have zero variance: equal means, z = 0)
+    assert np.all(z < 3.0), (a, b, np.round(z, 2))
+    # the runs are runs of the same model: the five signals in, the observation sd of the
+    # order of the truth (0.2; the level absorbs part of the noise)
+    assert np.all(ma[2:7] > 0.99) and 0.15 < np.exp(0.5 * ma[0]) < 0.4
+
+
+@pytest.mark.parametrize("a,b", [("substream", "sequential"), ("substream", "mt")])
+def test_variance_draws_have_the_same_distribution(runs, a, b):
+    """two-sample KS on every 20th draw (autocorrelation of the variance traces dies
+    within a few sweeps)"""
+    for key in ("sigsq", "level_sigsq"):
+        xa, xb = runs[a][key][BURN::20], runs[b][key][BURN::20]
+        ks = stats.ks_2samp(xa, xb)
+        assert ks.pvalue > 0.003, (key, a, b, ks)
+
+
+@pytest.mark.gpu
+def test_device_chains_agree_with_the_mt_run_at_the_benchmark_shape(runs):
+    """BASELINE configs[2] as benchmarked -- 1024 device chains, per-draw substreams --
+    against the oracle's long MT run: the same summaries, means over chains with
+    across-chain standard errors, within 3 standard errors of the MT run's batch means."""
+    import boom_amd
+    X, y, _, _ = state_space_data(T, P, NSIG, seed=8675309)
+    prior, ss, sig_up = bsts_priors(X, y, NSIG)
+    chains, burn, rounds, per = 1024, 400, 40, 5
+    eng = boom_amd.Engine(chains, seed=99)
+    eng.ss_set_data(y, X, None)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
+                   sigma_upper_limit=sig_up)
+    eng.ss_set_local_level(ss["level_df"], ss["level_sigma_guess"], ss["level_sigma_upper_limit"],
+                           ss["initial_state_mean"], ss["initial_state_variance"],
+                           ss["initial_level_sigma"])
+    eng.set_state(np.zeros(P, np.uint8))
+    eng.ss_sweep(burn)
+    acc = np.zeros((chains, 2 + 2 * len(VARS) + len(KEEP_STATE)))
+    probe = list(range(0, chains, 16))     # state and level variance are read chain by chain
+    lev = np.zeros((rounds, len(probe)))
+    st = np.zeros((rounds, len(probe), len(KEEP_STATE)))
+    for r in range(rounds):
+        eng.ss_sweep(per)
+        gam, beta, sig = eng.get_states()
+        acc[:, 0] += np.log(sig)
+        acc[:, 2:2 + len(VARS)] += gam[:, VARS]
+        acc[:, 2 + len(VARS):2 + 2 * len(VARS)] += beta[:, VARS]
+        for i, c in enumerate(probe):
+            s = eng.ss_get_state(c)
+            lev[r, i] = np.log(s["level_sigsq"])
+            st[r, i] = s["state"][KEEP_STATE]
+    acc /= rounds
+    o = summaries(runs["mt"])
+    mo, so = batch_mean_se(o)
+    nv = len(VARS)
+    # regression side: all 1024 chains
+    for col in [0] + list(range(2, 2 + 2 * nv)):
+        md, sd = acc[:, col].mean(), acc[:, col].std(ddof=1) / np.sqrt(chains)
+        z = abs(md - mo[col]) / np.sqrt(sd ** 2 + so[col] ** 2 + 1e-30)
+        assert z < 3.0, (col, md, mo[col], z)
+    # state side: the probed chains
+    lm = lev.mean(0)
+    z = abs(lm.mean() - mo[1]) / np.sqrt(lm.var(ddof=1) / len(probe) + so[1] ** 2)
+    assert z < 3.0, ("level", lm.mean(), mo[1], z)
+    sm = st.mean(0)
+    for j in range(len(KEEP_STATE)):
+        col = 2 + 2 * nv + j
+        z = abs(sm[:, j].mean() - mo[col]) / np.sqrt(sm[:, j].var(ddof=1) / len(probe) + so[col] ** 2)
+        assert z < 3.0, ("state", KEEP_STATE[j], sm[:, j].mean(), mo[col], z)
