@@ -14,4 +14,4 @@ try:
 except ImportError:   # (the C-ABI library itself does not need PyTorch)
     pass
 
-from .capi import BoomAmdError, Engine, LIB_PATH, load_library  # noqa: F401
+from .capi import BoomAmdError, Engine, Group, LIB_PATH, load_library  # noqa: F401

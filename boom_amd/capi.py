@@ -95,6 +95,21 @@ SIGNATURES = {
     "ba_kernel_class_name": (C.c_char_p, [C.c_int32]),
     "ba_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_get_kernel_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64), C.c_int32]),
+    "ba_group_last_error": (C.c_char_p, []),
+    "ba_group_create": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint64,
+                                  C.POINTER(C.c_void_p)]),
+    "ba_group_destroy": (None, [C.c_void_p]),
+    "ba_group_size": (C.c_int32, [C.c_void_p]),
+    "ba_group_engine": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "ba_group_locate": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "ba_group_build_suf_from_xy": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp]),
+    "ba_group_set_priors": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double,
+                                      C.c_double]),
+    "ba_group_set_state": (C.c_int, [C.c_void_p, _u8p, _dp, C.c_double]),
+    "ba_group_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_group_sync": (C.c_int, [C.c_void_p]),
+    "ba_group_reset_summaries": (C.c_int, [C.c_void_p]),
+    "ba_group_get_summaries": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
     "ba_ss_set_local_level": (C.c_int, [C.c_void_p] + [C.c_double] * 6),
     "ba_probit_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, C.c_int32]),
@@ -151,13 +166,17 @@ class Engine:
     """One engine = `chains` independent chains on one HIP device."""
 
     def __init__(self, chains, seed=8675309, device=0, chain_offset=0,
-                 max_model_size_hint=0):
+                 max_model_size_hint=0, _borrowed=None):
         self.lib = load_library()
-        cfg = BaConfig(device, chains, chain_offset, seed, max_model_size_hint, 0)
-        h = C.c_void_p()
+        self._owned = _borrowed is None
         self._h = None
-        self._check(self.lib.ba_engine_create(C.byref(cfg), C.byref(h)))
-        self._h = h
+        if _borrowed is None:
+            cfg = BaConfig(device, chains, chain_offset, seed, max_model_size_hint, 0)
+            h = C.c_void_p()
+            self._check(self.lib.ba_engine_create(C.byref(cfg), C.byref(h)))
+            self._h = h
+        else:
+            self._h = C.c_void_p(_borrowed)   # an engine of a Group: the group owns it
         self.chains = chains
         self.p = 0
 
@@ -167,7 +186,8 @@ class Engine:
 
     def close(self):
         if self._h is not None:
-            self.lib.ba_engine_destroy(self._h)
+            if self._owned:
+                self.lib.ba_engine_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -502,3 +522,83 @@ class Engine:
         self._check(self.lib.ba_ss_get_chain_suf(self._h, chain, _p(xty), C.byref(yty),
                                                  C.byref(n)))
         return dict(xty=xty, yty=yty.value, n=n.value)
+
+
+class Group:
+    """Several engines behind one handle (ba_group_*): one per entry of `devices`, chains
+    sharded by global id; the data build and the summaries are the two collectives."""
+
+    def __init__(self, devices, chains_per_device, seed=8675309):
+        self.lib = load_library()
+        dv = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        self._h = None
+        rc = self.lib.ba_group_create(dv, len(devices), chains_per_device, seed, C.byref(h))
+        if rc != 0:
+            raise BoomAmdError(rc, self.lib.ba_group_last_error().decode())
+        self._h = h
+        self.size = len(devices)
+        self.chains_per_device = chains_per_device
+        self.p = 0
+        self.engines = [Engine(chains_per_device, _borrowed=self.lib.ba_group_engine(h, i))
+                        for i in range(self.size)]
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BoomAmdError(rc, self.lib.ba_group_last_error().decode())
+
+    def close(self):
+        if self._h is not None:
+            for e in self.engines:
+                e.close()
+            self.lib.ba_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def locate(self, global_chain):
+        e, c = C.c_int32(), C.c_int64()
+        self._check(self.lib.ba_group_locate(self._h, global_chain, C.byref(e), C.byref(c)))
+        return e.value, c.value
+
+    def build_suf_from_xy(self, X, y):
+        n, p = X.shape
+        self._check(self.lib.ba_group_build_suf_from_xy(self._h, n, p, _p(_fcol(X)), _p(_f64(y))))
+        self.p = p
+        for e in self.engines:
+            e.p = p
+
+    def set_priors(self, b, ominv, pi, prior_df, sigma_guess, max_model_size=-1,
+                   sigma_upper_limit=float("inf")):
+        self._check(self.lib.ba_group_set_priors(self._h, _p(_f64(b)), _p(_fcol(ominv)), _p(_f64(pi)),
+                                                 int(max_model_size), prior_df, sigma_guess,
+                                                 sigma_upper_limit))
+
+    def set_state(self, gamma, beta=None, sigsq=1.0):
+        g = np.ascontiguousarray(gamma, dtype=np.uint8)
+        bb = None if beta is None else _f64(beta)
+        self._check(self.lib.ba_group_set_state(self._h, _b(g), _p(bb), sigsq))
+
+    def sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_group_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._check(self.lib.ba_group_sync(self._h))
+
+    def reset_summaries(self):
+        self._check(self.lib.ba_group_reset_summaries(self._h))
+
+    def get_summaries(self):
+        p = self.p
+        inc, bs, bs2 = np.zeros(p), np.zeros(p), np.zeros(p)
+        sc = np.zeros(SUMMARY_SCALARS)
+        blocks = np.zeros((self.size, 3 * p + SUMMARY_SCALARS))
+        self._check(self.lib.ba_group_get_summaries(self._h, _p(inc), _p(bs), _p(bs2), _p(sc), _p(blocks)))
+        return dict(inclusion_count=inc, beta_sum=bs, beta_sumsq=bs2, sweeps=sc[0], sigsq_sum=sc[1],
+                    k_sum=sc[3], accepts=sc[4], proposals=sc[5], min_margin=sc[6], blocks=blocks)

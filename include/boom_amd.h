@@ -417,6 +417,52 @@ int ba_ss_set_level_sigsq(ba_engine *e, int64_t chain, double sigsq);
 int ba_ss_get_chain_suf(ba_engine *e, int64_t chain, double *xty, double *yty,
                         double *n);
 
+/* ---- several devices behind one handle (north-star: "C++ host code ...
+ * chains shard across the GPUs of one node with a single RCCL gather") --------------
+ * A group is one engine per entry of `devices` in ONE process: engine i lives on HIP
+ * device devices[i] with its own stream and owns the global chains
+ * [i * chains_per_device, (i + 1) * chains_per_device), so a chain's draws do not
+ * depend on the device that runs it.  Nothing on the sampling path crosses devices;
+ * the two collectives go through librccl directly (loaded on demand; xGMI between the
+ * devices of a node): ba_group_build_suf_from_xy = rows of X sharded over the devices,
+ * local f64-MFMA syrk, ONE ncclAllReduce of (X'X | X'y | y'y, sum y | sum x), every
+ * engine installs the bitwise identical total; ba_group_get_summaries = ONE
+ * ncclAllGather of the per-device summary blocks, summed on the host.  A device list
+ * that repeats ONE device is allowed (no collective: blocks are summed on the device);
+ * a mixed list is not.  Everything that is per engine (priors beyond the common ones
+ * below, options, state accessors, look-ahead, the other samplers) is reached through
+ * ba_group_engine(g, i) with the single-engine entry points; ba_group_locate maps a
+ * global chain id to (engine, local chain).  Errors: the BA_E_* codes, message from
+ * ba_group_last_error().  New: the reference has no multi-chain or multi-device
+ * driver. */
+typedef struct ba_group ba_group;
+const char *ba_group_last_error(void);
+int ba_group_create(const int32_t *devices, int32_t ndevices, int32_t chains_per_device,
+                    uint64_t seed, ba_group **out);
+void ba_group_destroy(ba_group *g);
+int32_t ba_group_size(const ba_group *g);
+ba_engine *ba_group_engine(ba_group *g, int32_t i);
+int ba_group_locate(const ba_group *g, int64_t global_chain, int32_t *engine_index,
+                    int64_t *local_chain);
+/* NeRegSuf(X, y) for a host matrix (n x p column-major): see above */
+int ba_group_build_suf_from_xy(ba_group *g, int64_t n, int32_t p, const double *X,
+                               const double *y);
+/* ba_set_slab + ba_set_spike + ba_set_sigma_prior on every engine */
+int ba_group_set_priors(ba_group *g, const double *prior_mean,
+                        const double *unscaled_prior_precision,
+                        const double *prior_inclusion_probabilities, int64_t max_model_size,
+                        double prior_df, double sigma_guess, double sigma_upper_limit);
+/* ba_set_state(e, -1, ...) on every engine */
+int ba_group_set_state(ba_group *g, const uint8_t *gamma, const double *beta, double sigsq);
+/* ba_sweep on every engine (asynchronous: the devices run side by side); ba_sync */
+int ba_group_sweep(ba_group *g, int32_t nsweeps);
+int ba_group_sync(ba_group *g);
+int ba_group_reset_summaries(ba_group *g);
+/* whole-job summaries, laid out as ba_get_summaries; blocks (may be NULL) receives the
+ * gathered per-device blocks, ba_group_size(g) x (3p + 16) doubles */
+int ba_group_get_summaries(ba_group *g, double *inclusion_count, double *beta_sum,
+                           double *beta_sumsq, double *scalars, double *blocks);
+
 #ifdef __cplusplus
 }
 #endif
