@@ -96,6 +96,7 @@ SIGNATURES = {
     "ba_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_get_kernel_times": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64), C.c_int32]),
     "ba_group_last_error": (C.c_char_p, []),
+    "ba_group_rccl_available": (C.c_int32, []),
     "ba_group_create": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint64,
                                   C.POINTER(C.c_void_p)]),
     "ba_group_destroy": (None, [C.c_void_p]),

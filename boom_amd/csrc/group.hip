@@ -121,6 +121,16 @@ extern "C" {
 
 const char *ba_group_last_error(void) { return g_group_error.c_str(); }
 
+// 1 when librccl can be loaded and exports every entry point a multi-device group uses
+int32_t ba_group_rccl_available(void) {
+  Rccl r;
+  std::string err;
+  const bool ok = r.load(&err);
+  if (r.lib) dlclose(r.lib);
+  if (!ok) g_group_error = err;
+  return ok ? 1 : 0;
+}
+
 int ba_group_create(const int32_t *devices, int32_t ndevices, int32_t chains_per_device, uint64_t seed,
                     ba_group **out) {
   if (!devices || !out || ndevices <= 0) return gfail(BA_E_INVALID, "bad device list");

@@ -437,6 +437,8 @@ int ba_ss_get_chain_suf(ba_engine *e, int64_t chain, double *xty, double *yty,
  * driver. */
 typedef struct ba_group ba_group;
 const char *ba_group_last_error(void);
+/* 1 when librccl can be loaded and exports what a multi-device group calls */
+int32_t ba_group_rccl_available(void);
 int ba_group_create(const int32_t *devices, int32_t ndevices, int32_t chains_per_device,
                     uint64_t seed, ba_group **out);
 void ba_group_destroy(ba_group *g);

@@ -97,3 +97,11 @@ def test_group_argument_errors():
     with pytest.raises(boom_amd.BoomAmdError):
         g.get_summaries()                 # no data yet
     g.close()
+
+
+def test_librccl_is_loadable_with_every_symbol_the_group_uses():
+    """the multi-device path itself needs more than one GPU; what can be checked on one is
+    that the collective library resolves (dlopen + the seven entry points)"""
+    import boom_amd
+    lib = boom_amd.load_library()
+    assert lib.ba_group_rccl_available() == 1, lib.ba_group_last_error().decode()
