@@ -55,6 +55,7 @@ hipError_t launch_predict(hipStream_t stream, const double *trace_k, const uint1
                           const double *rec_beta, int stride, int cap, int first_draw, int ndraws,
                           int chains, int p, const double *newX, int nnew, double *out);
 int xtwx_cols_planes(int64_t n);
+int xte_planes(int64_t n);
 hipError_t launch_xtwx_cols(hipStream_t stream, const double *X, int64_t n, int p, const double *w,
                             const int32_t *req, int R, const double *base, double *V,
                             uint32_t *valid, int words, double *planes);
@@ -63,6 +64,9 @@ hipError_t launch_xtwx_cols_start(hipStream_t stream, const uint8_t *gamma, int 
 hipError_t launch_square(hipStream_t stream, const double *x, size_t count, double *out);
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
+hipError_t launch_kalman_main(hipStream_t stream, const SsParams &P, int draw_level);
+hipError_t launch_kalman_xte(hipStream_t stream, const SsParams &P);
+hipError_t launch_kalman_prepare(hipStream_t stream, const SsParams &P, int draw_level);
 hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
                               uint64_t *pos_forecast, double *out);
 }  // namespace boom_amd
@@ -300,6 +304,14 @@ struct ba_engine {
   DevBuf<double> dxty_c, dyty_c, dnobs_c;       // per-chain regression suf
   DevBuf<double> dlev_sigsq, dlev_n, dlev_sumsq;
   DevBuf<uint64_t> dpos_level, dpos_state, dpos_forecast;
+  // kalman_prepare_kernel (level variance + normals of the next state draw) runs on a
+  // second stream beside the X'e GEMM and the SSVS launch
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_state = nullptr, ev_prep = nullptr;
+  DevBuf<int32_t> dprep_n;
+  DevBuf<uint64_t> dprep_pos_state, dprep_pos_level;
+  DevBuf<double> dprep_level;
+  DevBuf<double> dxte_planes;   // split-K planes of the X'e GEMM
   double level_prior_df = 0, level_prior_ss = 0;
   double level_sigma_max = std::numeric_limits<double>::infinity();
   double ss_a0 = 0, ss_P0 = 1, ss_initial_level_sigsq = 1;
@@ -838,6 +850,12 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.xty = e->dxty_c.ptr;
   S.yty = e->dyty_c.ptr;
   S.nobs = e->dnobs_c.ptr;
+  S.xte_planes = e->dxte_planes.ptr;
+  S.prepared = 0;
+  S.prep_n = e->dprep_n.ptr;
+  S.prep_pos_state = e->dprep_pos_state.ptr;
+  S.prep_pos_level = e->dprep_pos_level.ptr;
+  S.prep_level_sigsq = e->dprep_level.ptr;
   if (e->ssm_set) {
     S.ssm = e->ssm;
     S.ssm.var_sigsq = e->dssm_sigsq.ptr;
@@ -1122,6 +1140,12 @@ int ba_engine_create(const ba_config *cfg, ba_engine **out) {
 void ba_engine_destroy(ba_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
+  if (e->stream2) {
+    (void)hipStreamSynchronize(e->stream2);
+    (void)hipStreamDestroy(e->stream2);
+  }
+  if (e->ev_state) (void)hipEventDestroy(e->ev_state);
+  if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
   if (e->stream) {
     (void)hipStreamSynchronize(e->stream);
     (void)hipStreamDestroy(e->stream);
@@ -1148,7 +1172,8 @@ const char *ba_kernel_class_name(int32_t cls) {
       "ssvs_sweep_kernel", "ssvs_big_kernel", "ssvs_adaptive_kernel", "kalman_simsmooth_kernel",
       "ssm_simsmooth_kernel", "atb_mfma_kernel", "probit_impute_kernel", "logit_impute_kernel",
       "xtwx_cols_kernel<false>+plain_reduce_kernel", "xtwx_cols_kernel<true>+xtwx_cols_reduce_kernel",
-      "xtx_mfma_kernel+plane_sum_kernel+col_reduce_kernel", "poisson_impute_kernel"};
+      "xtx_mfma_kernel+plane_sum_kernel+col_reduce_kernel", "poisson_impute_kernel",
+      "kalman_prepare_kernel"};
   return (cls >= 0 && cls < KT_CLASSES) ? names[cls] : "";
 }
 
@@ -2462,6 +2487,12 @@ static int ss_prepare(ba_engine *e) {
     HIP_TRY(e->dpos_state.resize(C));
     HIP_TRY(e->dpos_forecast.resize(C));
     HIP_TRY(hipMemsetAsync(e->dpos_forecast.ptr, 0, C * 8, e->stream));
+    HIP_TRY(e->dprep_n.resize(C));
+    HIP_TRY(e->dprep_pos_state.resize(C));
+    HIP_TRY(e->dprep_pos_level.resize(C));
+    HIP_TRY(e->dprep_level.resize(C));
+    HIP_TRY(hipMemsetAsync(e->dprep_n.ptr, 0, C * 4, e->stream));
+    HIP_TRY(e->dxte_planes.resize((size_t)xte_planes((int64_t)T) * C * p));
     // regression suf starts as the data's own (before the first impute_state)
     std::vector<double> xty(C * p), yty(C, e->yty), nobs(C, e->n),
         lev(C, e->ss_initial_level_sigsq);
@@ -2643,9 +2674,38 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
     HIP_TRY(launch_state_kernel(e, S, 0));
     e->ss_initialized = true;
   }
+  // The local-level state draw in two pieces: what does not depend on the round's
+  // regression sweep (level variance, the normals) ahead of it on the second stream,
+  // beside the previous round's X'e GEMM and this round's SSVS launch.
+  const bool ahead = !e->ssm_set && nsweeps > 0;
+  if (ahead && !e->stream2) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_state, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
+  }
+  if (ahead) {
+    // (the level model's sufficient statistics of the state draw in flight, if any)
+    HIP_TRY(hipEventRecord(e->ev_state, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_state, 0));
+    HIP_TRY(launch_kalman_prepare(e->stream2, S, 1));
+    HIP_TRY(hipEventRecord(e->ev_prep, e->stream2));
+    S.prepared = 1;
+  }
   for (int i = 0; i < nsweeps; ++i) {
     HIP_TRY(launch_sweeps(e, P, 1));                  // observation model
-    HIP_TRY(launch_state_kernel(e, S, 1));  // state models, state
+    if (ahead) {
+      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_prep, 0));
+      HIP_TRY(launch_kalman_main(e->stream, S, 1));   // state models, state
+      if (i + 1 < nsweeps) {
+        HIP_TRY(hipEventRecord(e->ev_state, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_state, 0));
+        HIP_TRY(launch_kalman_prepare(e->stream2, S, 1));
+        HIP_TRY(hipEventRecord(e->ev_prep, e->stream2));
+      }
+      HIP_TRY(launch_kalman_xte(e->stream, S));       // ... and the regression's X'e
+    } else {
+      HIP_TRY(launch_state_kernel(e, S, 1));          // state models, state
+    }
     P.model_keep = 1;  // from here on the chains' model blocks are their own last launch's
     e->model_ok = true;
   }

@@ -224,8 +224,17 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   __shared__ double s_x[2][8];             // the two waves' scan totals, swapped at the seam between their stretches
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;
-  if (P.status[chain] != CHAIN_OK) return;
-  if (P.only_ran && P.only_ran[chain] == 0) return;
+  const bool prepared = P.prepared != 0 && P.prep_n[chain] > 0;
+  if (P.status[chain] != CHAIN_OK || (P.only_ran && P.only_ran[chain] == 0)) {
+    // a chain that sits this round out: what kalman_prepare_kernel did ahead for it is undone
+    if (prepared && threadIdx.x == 0) {
+      P.pos_state[chain] = P.prep_pos_state[chain];
+      P.pos_level[chain] = P.prep_pos_level[chain];
+      P.level_sigsq[chain] = P.prep_level_sigsq[chain];
+      P.prep_n[chain] = 0;
+    }
+    return;
+  }
   const int T = P.T, p = P.p;
   int status = CHAIN_OK;
 #ifdef BA_KSTAMPS
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   double level_sigsq = P.level_sigsq[chain];
 
   // ---- ZeroMeanGaussianConjSampler::draw: sigma^2_level | state
-  if (draw_level) {
+  if (draw_level && !prepared) {
     SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, 1u}, P.pos_level[chain]};
     int bad = 0;
     const double DF = P.level_n[chain] + P.level_prior_df;
@@ -317,14 +326,19 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   const int N = nfirst + (T - 1) * nper;
   // Normal i of the sweep reads its uniforms from position bpos0 + 256 i of the
   // chain's state stream (stream_normals.h); szz holds them in draw order.
-  const uint64_t bpos0 = P.pos_state[chain];
-  status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,
-                          &P.pos_state[chain]);
-  if (status != CHAIN_OK) {   // (s_hand[3]: the same in both waves)
-    if (threadIdx.x == 0) P.status[chain] = status;
-    return;
+  if (!prepared || P.prep_n[chain] != N) {
+    // (prepared with another count: the observation variance turned out to be exactly
+    // zero, which the prepare step cannot know -- the normals again, from where it started)
+    const uint64_t bpos0 = prepared ? P.prep_pos_state[chain] : P.pos_state[chain];
+    status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,
+                            &P.pos_state[chain]);
+    if (status != CHAIN_OK) {   // (s_hand[3]: the same in both waves)
+      if (threadIdx.x == 0) P.status[chain] = status;
+      return;
+    }
   }
   __syncthreads();
+  if (prepared && threadIdx.x == 0) P.prep_n[chain] = 0;   // consumed
   double *stage = s_u.stage[wave];   // (the lists are done with)
   KSTAMP(2);
   // ---- 3 + 4. forward pass.
@@ -693,6 +707,56 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   }
 }
 
+// The two pieces of a state draw that do not depend on the same round's regression
+// sweep, done ahead of it (SsParams::prepared): ZeroMeanGaussianConjSampler::draw for the
+// level variance (its own stream, the level model's sufficient statistics of the
+// previous state draw) and the standard normals of simulate_forward (stream positions
+// only).  Runs on the engine's second stream beside the X'e GEMM and the SSVS launch:
+// neither of them fills the chip -- the GEMM is 448 small workgroups, and the SSVS launch
+// lasts as long as its slowest chain while most chains finish in half that time.
+__global__ __launch_bounds__(128) void kalman_prepare_kernel(SsParams P, int draw_level) {
+  __shared__ NormalsLds s_norm;
+  const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= P.chain_count) return;
+  if (P.status[chain] != CHAIN_OK) return;
+  const int T = P.T;
+  const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
+  const uint64_t pos_level0 = P.pos_level[chain], pos_state0 = P.pos_state[chain];
+  const double level0 = P.level_sigsq[chain];
+  double level_sigsq = level0;
+  int status = CHAIN_OK;
+  if (draw_level) {
+    SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, 1u}, pos_level0};
+    int bad = 0;
+    const double DF = P.level_n[chain] + P.level_prior_df;
+    const double SS = P.level_sumsq[chain] + P.level_prior_ss;
+    level_sigsq = d_draw_variance(rng, DF, SS, P.level_sigma_max, &bad);
+    if (bad) status = CHAIN_RNG_BRANCH;
+    if (lane == 0 && wave == 0) {
+      P.pos_level[chain] = rng.pos;
+      P.level_sigsq[chain] = level_sigsq;
+    }
+  }
+  if (status != CHAIN_OK) {
+    if (lane == 0 && wave == 0) P.status[chain] = status;
+    return;
+  }
+  // (the observation variance is this round's regression draw: taken to be positive, the
+  // main kernel checks the count)
+  const int dI = (sqrt(P.P0) != 0.0), dL = (sqrt(level_sigsq) != 0.0), dH = 1;
+  const int N = (dI + dH) + (T - 1) * (dL + dH);
+  double *szz = P.scratch + (size_t)chain * P.scratch_stride + (size_t)5 * T;
+  status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, pos_state0, N, szz,
+                          &P.pos_state[chain]);
+  if (threadIdx.x == 0) {
+    if (status != CHAIN_OK) P.status[chain] = status;
+    P.prep_n[chain] = N;
+    P.prep_pos_state[chain] = pos_state0;
+    P.prep_pos_level[chain] = pos_level0;
+    P.prep_level_sigsq[chain] = level0;
+  }
+}
+
 // StateSpaceRegressionModel::simulate_forecast for every chain's current draw
 // (StateSpaceRegressionModel.cpp:214-219, :256-278): state_i = state_{i-1} +
 // N(0, sigma_level) starting from the final state, y_i = N(state_i, sigma_obs) +
@@ -727,25 +791,36 @@ hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon
   return hipGetLastError();
 }
 
-hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
-                           const double *B, int64_t ldb, int N, int K, double *C, int ldc);
+hipError_t launch_xte_tiled(hipStream_t stream, const double *U, int64_t ldu, int R, const double *B, int64_t n,
+                            int p, double *out, double *planes);
+
+hipError_t launch_kalman_prepare(hipStream_t stream, const SsParams &P, int draw_level) {
+  KtScope kt(stream, KT_KALMAN_PREPARE);
+  hipLaunchKernelGGL(kalman_prepare_kernel, dim3(P.chain_count), dim3(2 * WAVE), 0, stream, P, draw_level);
+  return hipGetLastError();
+}
+
+// the state draw itself ...
+hipError_t launch_kalman_main(hipStream_t stream, const SsParams &P, int draw_level) {
+  KtScope kt(stream, KT_KALMAN);
+  hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chain_count), dim3(2 * WAVE), 0,
+                     stream, P, draw_level);
+  return hipGetLastError();
+}
+// ... and xty[chain, j] = x_j' e_chain: residual series are array 1 of every chain's
+// scratch block (zero where unobserved, and for a chain in error the previous
+// sweep's -- its status stops it anyway)
+hipError_t launch_kalman_xte(hipStream_t stream, const SsParams &P) {
+  return launch_xte_tiled(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.T, P.scratch_stride,
+                          P.chain_count, P.X, (int64_t)P.T, P.p, P.xty + (size_t)P.chain_first * P.p,
+                          P.xte_planes);
+}
 
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level) {
-  hipError_t err;
-  {
-    KtScope kt(stream, KT_KALMAN);
-    hipLaunchKernelGGL(kalman_simsmooth_kernel, dim3(P.chain_count), dim3(2 * WAVE), 0,
-                       stream, P, draw_level);
-    err = hipGetLastError();
-  }
+  hipError_t err = launch_kalman_main(stream, P, draw_level);
   if (err != hipSuccess) return err;
-  // xty[chain, j] = x_j' e_chain: residual series are array 1 of every chain's
-  // scratch block (zero where unobserved, and for a chain in error the previous
-  // sweep's -- its status stops it anyway)
-  return launch_atb_mfma(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.T, P.scratch_stride,
-                         P.chain_count, P.X, (int64_t)P.T, P.p, P.T,
-                         P.xty + (size_t)P.chain_first * P.p, P.p);
+  return launch_kalman_xte(stream, P);
 }
 
 }  // namespace boom_amd

@@ -52,6 +52,19 @@ struct SsParams {
   double *xty;              // chains x p
   double *yty;              // chains
   double *nobs;             // chains
+  double *xte_planes;       // workspace of the X'e GEMM: xte_planes(T) x chains x p doubles
+  // The part of a state draw that depends on nothing the same round's regression sweep
+  // produces -- the level-variance draw and the sweep's standard normals -- can be done
+  // ahead by kalman_prepare_kernel (on a second stream, beside the X'e GEMM and the SSVS
+  // launch).  prepared = 1: the main kernel finds them done (prep_n[chain] normals in the
+  // chain's scratch, level_sigsq drawn) and only checks the count; a chain the main
+  // kernel skips (parked by the sweep for want of capacity) gets the prepare step rolled
+  // back from the prep_* copies, so that its catch-up draws the same numbers.
+  int32_t prepared;
+  int32_t *prep_n;             // chains: normals generated ahead (0: none)
+  uint64_t *prep_pos_state;    // chains: stream positions / level variance before the prepare step
+  uint64_t *prep_pos_level;
+  double *prep_level_sigsq;
   SsmParams ssm;            // (ssm_kernel.hip only)
 };
 

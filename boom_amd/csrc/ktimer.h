@@ -24,6 +24,7 @@ enum KernelClass {
   KT_COLS_GEMM,     // xtwx_cols_kernel<true> + xtwx_cols_reduce_kernel (vectors of V)
   KT_SUF,           // xtx_mfma_kernel + plane_sum_kernel + col_reduce_kernel
   KT_POISSON_IMPUTE,// poisson_impute_kernel
+  KT_KALMAN_PREPARE,// kalman_prepare_kernel (level variance + normals, second stream)
   KT_CLASSES
 };
 

@@ -663,8 +663,8 @@ hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizo
   return hipGetLastError();
 }
 
-hipError_t launch_atb_mfma(hipStream_t stream, const double *A, int64_t lda, int M,
-                           const double *B, int64_t ldb, int N, int K, double *C, int ldc);
+hipError_t launch_xte_tiled(hipStream_t stream, const double *U, int64_t ldu, int R, const double *B, int64_t n,
+                            int p, double *out, double *planes);
 
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances) {
   const dim3 grid(P.chain_count), block(2 * WAVE);
@@ -683,9 +683,9 @@ hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_
 #undef SSM_LAUNCH
   if (err != hipSuccess) return err;
   // xty[chain, j] = x_j' e_chain (the residual series are array 1 of every chain's scratch block)
-  return launch_atb_mfma(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.T, P.scratch_stride,
-                         P.chain_count, P.X, (int64_t)P.T, P.p, P.T,
-                         P.xty + (size_t)P.chain_first * P.p, P.p);
+  return launch_xte_tiled(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.T, P.scratch_stride,
+                          P.chain_count, P.X, (int64_t)P.T, P.p, P.xty + (size_t)P.chain_first * P.p,
+                          P.xte_planes);
 }
 
 }  // namespace boom_amd

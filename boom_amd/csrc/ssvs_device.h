@@ -562,16 +562,24 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
   const bool add = valid && !ch.gam[j];
   const bool drop = valid && !add;
   const int kn = add ? k + 1 : k - 1;
+  // Everything the classification and the epilogue read about variable j is fetched up
+  // front, all loads independent of each other (j is a valid index whatever `valid` says):
+  // as conditional loads they formed a chain of three dependent round trips to L2 --
+  // log prior -> prior mean -> diagonals -- in every proposal round.
+  const double l1 = P.l1[j], l0 = P.l0[j];
+  const double bj_raw = P.b[j];
+  const double vjj_raw = P.v_diag ? P.v_diag[j] : P.V[(size_t)j * p + j];
+  const double ajj_raw = P.A[(size_t)j * p + j];
+  const double xtyj_raw = ch.xty[j];
   double lpn = -BA_INF;
   if (valid) {
-    const double l1 = P.l1[j], l0 = P.l0[j];
     // log prior of the flipped model; -inf terms must not meet +inf
     if (add) lpn = (l1 == -BA_INF) ? -BA_INF : ((l0 == -BA_INF) ? -BA_INF : M.lp + (l1 - l0));
     else     lpn = (l0 == -BA_INF) ? -BA_INF : ((l1 == -BA_INF) ? -BA_INF : M.lp + (l0 - l1));
     if (P.max_model_size >= 0 && kn > P.max_model_size) lpn = -BA_INF;
   }
   const bool live = valid && (lpn > -BA_INF);
-  const double bj = live ? P.b[j] : 0.0;
+  const double bj = live ? bj_raw : 0.0;
   const bool empty_after = live && drop && (kn == 0);
   const bool slow = live && !empty_after && (bj != 0.0);
   const bool fast = live && !empty_after && !slow;
@@ -579,9 +587,9 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
   if (empty_after) {
     out.logp = ch.mode ? lpn : lpn - (0.5 * ch.DF - 1.0) * log(ch.ss0q);
   }
-  const double vjj = (fast && add) ? (P.v_diag ? P.v_diag[j] : P.V[(size_t)j * p + j]) * ch.sv : 0.0;
-  const double ajj = (fast && add) ? P.A[(size_t)j * p + j] * ch.sa : 0.0;
-  const double xtyj = (fast && add) ? ch.xty[j] * ch.sx : 0.0;
+  const double vjj = (fast && add) ? vjj_raw * ch.sv : 0.0;
+  const double ajj = (fast && add) ? ajj_raw * ch.sa : 0.0;
+  const double xtyj = (fast && add) ? xtyj_raw * ch.sx : 0.0;
 
   constexpr int KCAP = NB * 8;
   const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);

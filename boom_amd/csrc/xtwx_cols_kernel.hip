@@ -45,16 +45,17 @@ constexpr int KCHUNK = 2048;  // rows per plane (fixed: see above)
 // GATHER: row r of the left operand is w_{c_r} o x_{g_r} (the requests); otherwise it
 // is row r of w as it stands (R rows of n: the plain product w X, e.g. X'Wz of every
 // chain with w = the chains' weighted latent sums)
-template <bool GATHER>
+// KCH: rows per plane.  ldw (GATHER = false): doubles between the rows of the left operand.
+template <bool GATHER, int KCH>
 __global__ __launch_bounds__(256, 2) void xtwx_cols_kernel(const double *__restrict__ X, int64_t n, int p,
-                                                          const double *__restrict__ w,
+                                                          const double *__restrict__ w, int64_t ldw,
                                                           const int2 *__restrict__ req, int R,
                                                           double *__restrict__ planes) {
   __shared__ double sA[2][RT * LDS_LD];
   __shared__ double sB[2][JT * LDS_LD];
   const int J0 = blockIdx.x * JT, R0 = blockIdx.y * RT;
-  const int64_t kbeg = (int64_t)blockIdx.z * KCHUNK;
-  const int64_t kend = (kbeg + KCHUNK < n) ? kbeg + KCHUNK : n;
+  const int64_t kbeg = (int64_t)blockIdx.z * KCH;
+  const int64_t kend = (kbeg + KCH < n) ? kbeg + KCH : n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wj = wave & 1;   // the wave's 32 x 64 part of the tile
   const int fr = lane >> 4, fc = lane & 15;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void xtwx_cols_kernel(const double *__restr
     if (r < R) {
       const int2 q = GATHER ? req[r] : make_int2(r, 0);
       xa[it] = X + (int64_t)q.y * n;
-      wa[it] = w + (int64_t)q.x * n;
+      wa[it] = w + (int64_t)q.x * (GATHER ? n : ldw);
     } else {
       xa[it] = nullptr;
       wa[it] = nullptr;
@@ -221,8 +222,8 @@ hipError_t launch_xtwx_cols(hipStream_t stream, const double *X, int64_t n, int 
   if (R <= 0) return hipSuccess;
   const int np = xtwx_cols_planes(n);
   KtScope kt(stream, KT_COLS_GEMM);
-  hipLaunchKernelGGL(xtwx_cols_kernel<true>, dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np), dim3(256), 0, stream,
-                     X, n, p, w, (const int2 *)req, R, planes);
+  hipLaunchKernelGGL((xtwx_cols_kernel<true, KCHUNK>), dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np), dim3(256), 0,
+                     stream, X, n, p, w, n, (const int2 *)req, R, planes);
   hipLaunchKernelGGL(xtwx_cols_reduce_kernel, dim3((p + 255) / 256, R), dim3(256), 0, stream,
                      planes, np, (const int2 *)req, R, p, base, V, valid, words);
   return hipGetLastError();
@@ -235,11 +236,32 @@ hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R,
   if (R <= 0) return hipSuccess;
   const int np = xtwx_cols_planes(n);
   KtScope kt(stream, KT_ROWS_GEMM);
-  hipLaunchKernelGGL(xtwx_cols_kernel<false>, dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np), dim3(256), 0, stream,
-                     B, n, p, U, (const int2 *)nullptr, R, planes);
+  hipLaunchKernelGGL((xtwx_cols_kernel<false, KCHUNK>), dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np), dim3(256), 0,
+                     stream, B, n, p, U, n, (const int2 *)nullptr, R, planes);
   const size_t cnt = (size_t)R * p;
   hipLaunchKernelGGL(plain_reduce_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, planes, np, R,
                      p, diag_base, out);
+  return hipGetLastError();
+}
+
+// The same product for SHORT rows (the bsts path's X'e: chains x p x T with T a few
+// thousand): rows cut into planes of XTE_KCHUNK so that the launch has enough workgroups
+// -- 16 row tiles x 16 planes at 1024 chains, T = 2000 -- each reading a 64-chain x
+// 128-step slab of the residuals and a 128-variable x 128-step slab of X ONCE, coalesced,
+// through LDS (the 16 x 16 tiles of atb_mfma_kernel re-read both operands per tile: 220 MB
+// of L2 traffic per round against 42 MB).  ldu: doubles between the rows of U.
+constexpr int XTE_KCHUNK = 64;
+int xte_planes(int64_t n) { return (int)((n + XTE_KCHUNK - 1) / XTE_KCHUNK); }
+hipError_t launch_xte_tiled(hipStream_t stream, const double *U, int64_t ldu, int R, const double *B, int64_t n,
+                            int p, double *out, double *planes) {
+  if (R <= 0) return hipSuccess;
+  const int np = xte_planes(n);
+  KtScope kt(stream, KT_XTE_GEMM);
+  hipLaunchKernelGGL((xtwx_cols_kernel<false, XTE_KCHUNK>), dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np),
+                     dim3(256), 0, stream, B, n, p, U, ldu, (const int2 *)nullptr, R, planes);
+  const size_t cnt = (size_t)R * p;
+  hipLaunchKernelGGL(plain_reduce_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, planes, np, R,
+                     p, (const double *)nullptr, out);
   return hipGetLastError();
 }
 
