@@ -598,9 +598,57 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
   const bool nat = NAT || (P.col_valid != nullptr);
   const size_t stride_g = nat ? (size_t)p : 1, lane_off = nat ? (size_t)j : (size_t)j * p;
 
-  double x[NB * 8];
   double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
   SUBSTAMP(sx, 1);
+  if constexpr (NB <= 2) {
+    // Small capacities (the bsts path: a handful of variables, a fresh table every sweep
+    // because X'y moves): BOTH right-hand sides are gathered before either solve, so that
+    // a proposal round is one trip to L2 instead of two in a row (32 more registers for
+    // the second vector, which only these instances can afford).
+    double xv[NB * 8], xa[NB * 8];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      if (I * 8 < k) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int m = I * 8 + r;
+          const int gm = (m < k) ? (int)ch.g[m] : 0;  // LDS broadcast read
+          const size_t o = (size_t)gm * stride_g + lane_off;
+          const double v = P.V[o] * ch.sv, a = P.A[o] * ch.sa;
+          const double e = (gm == j) ? 1.0 : 0.0;
+          const bool on = fast && m < k;
+          xv[m] = on ? (add ? v : e) : 0.0;
+          xa[m] = on ? (add ? a : e) : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { xv[I * 8 + r] = 0.0; xa[I * 8 + r] = 0.0; }
+      }
+    }
+    // A[j, g] . b_g for the new element of r
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+      if (I * 8 < k) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ab += xa[I * 8 + r] * sc[S.bg + I * 8 + r];
+      }
+    SUBSTAMP(sx, 2);
+    solve_blocks<NB>(sc + S.Lv, sc + S.rdv, k, xv);
+    SUBSTAMP(sx, 3);
+    solve_blocks<NB>(sc + S.La, sc + S.rda, k, xa);
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+      if (I * 8 < k) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          nv += xv[I * 8 + r] * xv[I * 8 + r];
+          dv += xv[I * 8 + r] * sc[S.w + I * 8 + r];
+          na += xa[I * 8 + r] * xa[I * 8 + r];
+        }
+      }
+    SUBSTAMP(sx, 5);
+  } else {
+  double x[NB * 8];
 #pragma nounroll
   for (int s = 0; s < 2; ++s) {
     const double *Mat = s ? P.A : P.V;
@@ -659,6 +707,7 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
     asm volatile("" :: "v"(n2), "v"(dw) : "memory");
 #endif
     SUBSTAMP(sx, s ? 5 : 3);
+  }
   }
   if (fast) {
     double ldv, lda, Q;

@@ -250,7 +250,7 @@ hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R,
 // 128-step slab of the residuals and a 128-variable x 128-step slab of X ONCE, coalesced,
 // through LDS (the 16 x 16 tiles of atb_mfma_kernel re-read both operands per tile: 220 MB
 // of L2 traffic per round against 42 MB).  ldu: doubles between the rows of U.
-constexpr int XTE_KCHUNK = 64;
+constexpr int XTE_KCHUNK = 128;
 int xte_planes(int64_t n) { return (int)((n + XTE_KCHUNK - 1) / XTE_KCHUNK); }
 hipError_t launch_xte_tiled(hipStream_t stream, const double *U, int64_t ldu, int R, const double *B, int64_t n,
                             int p, double *out, double *planes) {
