@@ -515,6 +515,27 @@ def main():
             e2.close()
         curve[str(CHAINS_PER_GPU)] = round(value / world, 1)
 
+    # ---- the reference callers' loop (extra key): one sample_posterior() per iteration
+    # with the parameters read back after each (spike_slab_wrapper.cc:233-242), served by
+    # ba_draw_next at the hosts' default look-ahead
+    loop = None
+    if not args.no_curve and world == 1:
+        loop = {}
+        for L in (64, 256):
+            eng.set_lookahead(L)
+            for _ in range(L):
+                eng.draw_next()
+            eng.get_state(0)
+            tb = []
+            for _ in range(6):
+                t0 = time.perf_counter()
+                for _ in range(L):
+                    eng.draw_next()
+                    eng.get_state(0)
+                tb.append(time.perf_counter() - t0)
+            loop["lookahead_%d" % L] = round(CHAINS_PER_GPU * L / float(np.median(tb)), 1)
+        eng.set_lookahead(1)
+
     # ---- the other BASELINE configurations at their per-GPU shapes (extra key, outside
     # the timed region; parity for them lives in tests/).  Per configuration: the rate of
     # a plain throughput pass, then a second pass with the engine's per-kernel HIP-event
@@ -584,6 +605,7 @@ def main():
         "ess_traces": {k: round(v / (CHAINS_PER_GPU * trace_len), 4) for k, v in ess.items()},
         "decisions": decisions,
         "sweeps_per_sec_vs_chains_per_gpu": curve,
+        "drop_in_loop_sweeps_per_sec": loop,
         "other_configs": other,
         "suf_build_ms": round(suf_build_s * 1e3, 2),
         "signal_inclusion_min": round(float(incl[:N_SIGNAL].min()), 4),

@@ -35,7 +35,7 @@ namespace BOOM {
                         const Ptr<MvnGivenScalarSigmaBase> &slab,
                         const Ptr<GammaModelBase> &residual_precision_prior,
                         const Ptr<VariableSelectionPrior> &spike,
-                        int chains, int device = 0, int lookahead = 64,
+                        int chains, int device = 0, int lookahead = 256,
                         RNG &seeding_rng = GlobalRng::rng);
     ~DeviceBregVsSampler() override;
 

@@ -301,7 +301,7 @@ class BregVsSampler : public PosteriorSampler {
     // by default; the draws do not depend on this number
     check(ba_set_lookahead(h(), kDefaultLookahead));
   }
-  static constexpr int kDefaultLookahead = 64;
+  static constexpr int kDefaultLookahead = 256;
   RegressionModel *model_;
   int max_flips_ = -1, draw_beta_ = 1, draw_sigma_ = 1;
   double swap_ = 0.8;
