@@ -118,6 +118,10 @@ SIGNATURES = {
     "ba_logit_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, C.c_int32]),
     "ba_logit_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_logit_set_imputer": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_poisson_set_data": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp]),
+    "ba_poisson_set_mixtures": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int32), _dp, _dp, _dp, C.c_int64]),
+    "ba_poisson_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_set_structural": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_dp] * 6),
     "ba_ss_get_structural": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -464,6 +468,25 @@ class Engine:
         nt = np.ascontiguousarray(ntrials, dtype=np.float64)
         self._check(self.lib.ba_logit_set_data(self._h, X.shape[0], X.shape[1], _p(X), _p(y),
                                                _p(nt), int(clt_threshold)))
+
+    def poisson_set_data(self, X, y, exposure, mix):
+        """mix: dict(counts, ncomp, mu, sigma, weight, largest_index) -- the reference
+        table's mixtures for 1 and the positive counts in y"""
+        X = np.asfortranarray(X, dtype=np.float64)
+        self.p = X.shape[1]
+        self._check(self.lib.ba_poisson_set_data(self._h, X.shape[0], X.shape[1], _p(X), _p(_f64(y)),
+                                                 _p(_f64(exposure))))
+        counts = np.ascontiguousarray(mix["counts"], dtype=np.int64)
+        ncomp = np.ascontiguousarray(mix["ncomp"], dtype=np.int32)
+        self._check(self.lib.ba_poisson_set_mixtures(
+            self._h, len(counts), counts.ctypes.data_as(C.POINTER(C.c_int64)),
+            ncomp.ctypes.data_as(C.POINTER(C.c_int32)), _p(_f64(mix["mu"])), _p(_f64(mix["sigma"])),
+            _p(_f64(mix["weight"])), int(mix["largest_index"])))
+
+    def poisson_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_poisson_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
 
     def logit_set_imputer(self, kind):
         """0: the reference's auxiliary mixture (default); 1: Polya-Gamma"""

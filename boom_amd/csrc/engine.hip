@@ -326,6 +326,15 @@ struct ba_engine {
   // precisions (chains x n) and every chain's own V = slab precision + X'WX
   bool logit_mode = false;
   int logit_imputer = 0;           // 0: the reference's auxiliary mixture, 1: Polya-Gamma
+  // PoissonRegressionSpikeSlabSampler: the logit path's machinery (every chain's own V a
+  // vector at a time) with its own imputation kernel and SpikeSlabSampler's shuffle;
+  // dprob_nt holds the exposures; the reference table's mixtures by count
+  bool poisson_mode = false;
+  bool poisson_mix_set = false;
+  std::vector<int64_t> poisson_y;             // host copy of the counts (to map them to mixtures)
+  DevBuf<int32_t> dpois_off, dpois_obs;
+  DevBuf<double> dpois_mu, dpois_sigma, dpois_logw;
+  int poisson_mix_one = -1;
   DevBuf<double> dlogit_w, dlogit_V;
   // ... V built a vector at a time (xtwx_cols_kernel.hip): the squared design matrix
   // (for the diagonal), the diagonals (chains x p), which vectors hold this sweep's
@@ -621,7 +630,7 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   if (e->cur_mode == 1 && e->logit_mode && e->dlogit_V.count) {
     // BinomialLogitSpikeSlabSampler: the sampler's own shuffle, every chain's own V
     // (which moves with the latent data: factors and tables are rebuilt)
-    P.mode = 2;
+    P.mode = e->poisson_mode ? 1 : 2;   // (the Poisson sampler drives the plain SpikeSlabSampler)
     P.V = e->dlogit_V.ptr;
     P.v_chain_stride = (int64_t)e->p * e->p;
     P.model_keep = 0;
@@ -1227,7 +1236,7 @@ int ba_upload_regression_suf(ba_engine *e, int32_t p, const double *xtx,
   e->sumy = ybar * n;
   e->have_suf = true;
   e->device_dirty = true;
-  e->probit_mode = e->logit_mode = e->ss_mode = false;   // (plain regression data now; the binomial and state-space setters say otherwise after this)
+  e->probit_mode = e->logit_mode = e->ss_mode = e->poisson_mode = false;   // (plain regression data now; the binomial, Poisson and state-space setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1264,7 +1273,7 @@ int ba_build_suf_from_xy_device(ba_engine *e, int64_t n, int32_t p,
   e->n = (double)n;
   e->have_suf = true;
   e->device_dirty = true;
-  e->probit_mode = e->logit_mode = e->ss_mode = false;   // (plain regression data now; the binomial and state-space setters say otherwise after this)
+  e->probit_mode = e->logit_mode = e->ss_mode = e->poisson_mode = false;   // (plain regression data now; the binomial, Poisson and state-space setters say otherwise after this)
   return BA_OK;
 }
 
@@ -1310,7 +1319,7 @@ int ba_set_suf_from_block_device(ba_engine *e, int64_t n_total, int32_t p,
   e->n = (double)n_total;
   e->have_suf = true;
   e->device_dirty = true;
-  e->probit_mode = e->logit_mode = e->ss_mode = false;   // (plain regression data now; the binomial and state-space setters say otherwise after this)
+  e->probit_mode = e->logit_mode = e->ss_mode = e->poisson_mode = false;   // (plain regression data now; the binomial, Poisson and state-space setters say otherwise after this)
   return BA_OK;
 }
 
@@ -2290,6 +2299,7 @@ int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const
   HIP_TRY(e->dlogit_Xsq.resize((size_t)n * p));
   HIP_TRY(launch_square(e->stream, e->dprob_X.ptr, (size_t)n * p, e->dlogit_Xsq.ptr));
   e->logit_mode = true;
+  e->poisson_mode = false;
   e->probit_mode = false;
   e->probit_n = n;
   e->probit_clt = clt_threshold;
@@ -2298,6 +2308,96 @@ int ba_logit_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const
   e->dprob_z.release();
   return BA_OK;
 }
+
+// ------------------------ PoissonRegressionSpikeSlabSampler
+int ba_poisson_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const double *y,
+                        const double *exposure) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (!X || !y || !exposure) return fail(BA_E_INVALID, "null argument");
+  if (n <= 0 || p <= 0) return fail(BA_E_INVALID, "n and p must be positive");
+  for (int64_t i = 0; i < n; ++i) {
+    if (y[i] < 0 || y[i] != std::floor(y[i])) return fail(BA_E_INVALID, "counts must be non-negative integers");
+    if (!(exposure[i] > 0)) return fail(BA_E_INVALID, "exposures must be positive");
+  }
+  std::vector<double> zero((size_t)n, 0.0);
+  int rc = ba_build_suf_from_xy(e, n, p, X, zero.data());   // (dimensions and the shared buffers)
+  if (rc) return rc;
+  HIP_TRY(e->dprob_X.resize((size_t)n * p));
+  HIP_TRY(e->dprob_y.resize((size_t)n));
+  HIP_TRY(e->dprob_nt.resize((size_t)n));
+  HIP_TRY(hipMemcpy(e->dprob_X.ptr, X, (size_t)n * p * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dprob_y.ptr, y, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dprob_nt.ptr, exposure, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(e->dlogit_Xsq.resize((size_t)n * p));
+  HIP_TRY(launch_square(e->stream, e->dprob_X.ptr, (size_t)n * p, e->dlogit_Xsq.ptr));
+  e->poisson_y.resize((size_t)n);
+  for (int64_t i = 0; i < n; ++i) e->poisson_y[(size_t)i] = (int64_t)std::llround(y[i]);
+  e->logit_mode = true;      // (the logit path's buffers and column service)
+  e->poisson_mode = true;
+  e->poisson_mix_set = false;
+  e->probit_mode = false;
+  e->probit_n = n;
+  e->probit_clt = 0;
+  e->probit_sweep = 0;
+  e->ss_mode = false;
+  e->dprob_z.release();
+  return BA_OK;
+}
+
+int ba_poisson_set_mixtures(ba_engine *e, int32_t ncounts, const int64_t *counts, const int32_t *ncomp,
+                            const double *mu, const double *sigma, const double *weight,
+                            int64_t largest_index) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (!e->poisson_mode) return fail(BA_E_STATE, "call ba_poisson_set_data first");
+  if (ncounts <= 0 || !counts || !ncomp || !mu || !sigma || !weight) return fail(BA_E_INVALID, "null argument");
+  std::vector<int32_t> off((size_t)ncounts + 1, 0);
+  for (int i = 0; i < ncounts; ++i) {
+    if (i > 0 && counts[i] <= counts[i - 1]) return fail(BA_E_INVALID, "counts must be ascending and distinct");
+    if (ncomp[i] <= 0 || ncomp[i] > POISSON_MAX_COMP) return fail(BA_E_INVALID, "a mixture has 1 .. 32 components");
+    off[(size_t)i + 1] = off[(size_t)i] + ncomp[i];
+  }
+  const size_t tot = (size_t)off[(size_t)ncounts];
+  std::vector<double> logw(tot);
+  for (size_t c = 0; c < tot; ++c) {
+    if (!(weight[c] > 0) || !(sigma[c] > 0)) return fail(BA_E_INVALID, "mixture weights and standard deviations must be positive");
+    logw[c] = std::log(weight[c]);
+  }
+  auto find = [&](int64_t v) -> int {
+    const int64_t *it = std::lower_bound(counts, counts + ncounts, v);
+    return (it != counts + ncounts && *it == v) ? (int)(it - counts) : -2;
+  };
+  const size_t n = e->poisson_y.size();
+  std::vector<int32_t> obs(n, -1);
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t v = e->poisson_y[i];
+    if (v <= 0) continue;
+    if (v >= largest_index) { obs[i] = -1; continue; }   // the Gaussian limit (poisson_mixture_approximation_table.cpp:49-55)
+    const int m = find(v);
+    if (m < 0) return fail(BA_E_INVALID, "no mixture was given for a count that occurs in the data");
+    obs[i] = m;
+  }
+  const int one = find(1);
+  if (one < 0) return fail(BA_E_INVALID, "the mixture of count 1 (the event past the interval) is needed");
+  HIP_TRY(e->dpois_off.resize(off.size()));
+  HIP_TRY(e->dpois_mu.resize(tot));
+  HIP_TRY(e->dpois_sigma.resize(tot));
+  HIP_TRY(e->dpois_logw.resize(tot));
+  HIP_TRY(e->dpois_obs.resize(n));
+  HIP_TRY(hipMemcpy(e->dpois_off.ptr, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dpois_mu.ptr, mu, tot * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dpois_sigma.ptr, sigma, tot * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dpois_logw.ptr, logw.data(), tot * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->dpois_obs.ptr, obs.data(), n * 4, hipMemcpyHostToDevice));
+  e->poisson_mix_one = one;
+  e->poisson_mix_set = true;
+  return BA_OK;
+}
+
+}  // extern "C"
+static int logit_family_sweep(ba_engine *e, int32_t nsweeps);
+extern "C" {
 
 int ba_logit_set_imputer(ba_engine *e, int32_t kind) {
   if (!e) return fail(BA_E_INVALID, "null engine");
@@ -2311,7 +2411,27 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
   ENGINE_PROLOGUE(e);
   MUTATE(e);
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  if (e->poisson_mode) return fail(BA_E_STATE, "Poisson data are set: use ba_poisson_sweep");
   if (!e->logit_mode) return fail(BA_E_STATE, "call ba_logit_set_data first");
+  return logit_family_sweep(e, nsweeps);
+}
+
+int ba_poisson_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);
+  MUTATE(e);
+  if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
+  if (!e->poisson_mode) return fail(BA_E_STATE, "call ba_poisson_set_data first");
+  if (!e->poisson_mix_set) return fail(BA_E_STATE, "call ba_poisson_set_mixtures first");
+  return logit_family_sweep(e, nsweeps);
+}
+
+}  // extern "C"
+
+// the sweep loop shared by the logit and the Poisson samplers: imputation (per family),
+// X'Wz and the diagonal, the vectors of V the sweep starts from, the inclusion /
+// coefficient draws with park-and-replay for vectors requested mid-sweep
+static int logit_family_sweep(ba_engine *e, int32_t nsweeps) {
+  {
   if (!e->have_slab) return fail(BA_E_STATE, "call ba_sss_set_slab first");
   if (e->sss_slab_scales) return fail(BA_E_INVALID, "the logit sampler takes a fixed-precision slab (scales_with_sigsq = 0)");
   int rc = alloc_chain_state(e);
@@ -2364,12 +2484,20 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
   Q.seed_lo = (uint32_t)e->seed;
   Q.seed_hi = (uint32_t)(e->seed >> 32);
   Q.status = e->dstatus.ptr;
-  // BinomialLogitSpikeSlabSampler::draw (BinomialLogitSpikeSlabSampler.cpp:50-54)
+  Q.mix_off = e->dpois_off.ptr;
+  Q.mix_mu = e->dpois_mu.ptr;
+  Q.mix_sigma = e->dpois_sigma.ptr;
+  Q.mix_logw = e->dpois_logw.ptr;
+  Q.obs_mix = e->dpois_obs.ptr;
+  Q.mix_one = e->poisson_mix_one;
+  const int imputer = e->poisson_mode ? 2 : e->logit_imputer;
+  // BinomialLogitSpikeSlabSampler::draw (BinomialLogitSpikeSlabSampler.cpp:50-54) /
+  // PoissonRegressionSpikeSlabSampler::draw (PoissonRegressionSpikeSlabSampler.cpp:55-59)
   for (int i = 0; i < nsweeps; ++i) {
     Q.sweep = e->probit_sweep++;
     // impute_latent_data: z, w, X'Wz and the diagonal of V = slab precision + X'WX ...
     HIP_TRY(launch_logit_impute(e->stream, Q, e->dlogit_Xsq.ptr, e->dA.ptr, e->dlogit_vdiag.ptr,
-                                e->dlogit_planes.ptr, e->logit_imputer));
+                                e->dlogit_planes.ptr, imputer));
     // ... and the vectors of V the sweep starts from: those of the included variables
     HIP_TRY(launch_xtwx_cols_start(e->stream, e->dgamma.ptr, (int)C, (int)p, e->dlogit_req.ptr,
                                    e->dlogit_cnt.ptr, e->dlogit_valid.ptr, e->logit_words));
@@ -2391,7 +2519,10 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps) {
   e->table_ok = false;
   e->model_ok = false;
   return BA_OK;
+  }
 }
+
+extern "C" {
 
 // ------------------------ AdaptiveSpikeSlabRegressionSampler (birth / death)
 static int ada_prepare(ba_engine *e) {

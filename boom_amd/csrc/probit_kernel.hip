@@ -684,6 +684,147 @@ __global__ __launch_bounds__(256) void logit_pg_impute_kernel(ProbitParams P) {
   P.w[(size_t)chain * P.n + i] = omega;
 }
 
+// ---- PoissonRegressionSpikeSlabSampler's imputation (the Poisson member)
+// PoissonRegressionDataImputer::impute_latent_data_point (PoissonRegressionAuxMixSampler.cpp:
+// 59-81) / PoissonDataImputer::impute (PoissonDataImputer.cpp:36-96): the time of the last
+// of the y events in the exposure interval (exposure x Beta(y, 1), Cheng's algorithm BC,
+// Bmath/rbeta.cpp:59-128), the first event past the interval (an exponential, or its
+// extreme-value form when exp(eta) would overflow), and for both negative log times the
+// component of the normal mixture that approximates NegLogGamma(count) (unmix:
+// NormalMixtureApproximation.cpp:280-290; the mixtures are the reference table's, handed
+// in by the caller).  z[chain][i] = sum of weight x (time - component mean), w[chain][i] =
+// sum of weights: the (sum, information) pair of the logit path.  Observation i of sweep s
+// reads the chain's stream 11 from position (s n + i) * POISSON_STRIDE.
+namespace {
+// Rmath::rbeta_mt(rng, aa, 1), aa >= 1: a = min = 1, b = aa, algorithm BC
+__device__ __forceinline__ double d_rbeta_a_1(SeqRng &rng, double aa) {
+  const double expmax = 1024 * 0.693147180559945309417232121458;
+  const double a = (aa < 1.0) ? aa : 1.0, b = (aa < 1.0) ? 1.0 : aa;
+  const double alpha = a + b;
+  const double beta = 1.0 / a, delta = 1.0 + b - a;
+  const double k1 = delta * (0.0138889 + 0.0416667 * a) / (b * beta - 0.777778);
+  const double k2 = 0.25 + (0.5 + 0.25 / delta) * a;
+  double u1, u2, v, w, y, z;
+  for (;;) {
+    u1 = rng();
+    u2 = rng();
+    if (u1 < 0.5) {
+      y = u1 * u2;
+      z = u1 * y;
+      if (0.25 * u2 + z - y >= k1) continue;
+    } else {
+      z = u1 * u1 * u2;
+      if (z <= 0.25) {
+        v = beta * log(u1 / (1.0 - u1));
+        w = (v <= expmax) ? b * exp(v) : 1.7976931348623157e308;
+        break;
+      }
+      if (z >= k2) continue;
+    }
+    v = beta * log(u1 / (1.0 - u1));
+    w = (v <= expmax) ? b * exp(v) : 1.7976931348623157e308;
+    if (alpha * (log(alpha / (a + w)) + v) - 1.3862944 >= log(z)) break;
+  }
+  const double ans = (aa == a) ? a / (a + w) : w / (a + w);
+  if (ans != ans) {
+    const double zero = 2.220446049250313e-16, one = 1.0 - zero;
+    if (aa == a) return isfinite(a) ? zero : one;
+    return isfinite(w) ? zero : one;
+  }
+  return ans;
+}
+// unmix_poisson_augmented_data: mixture `mix` (-1: the Gaussian limit of `nevents` events)
+__device__ __forceinline__ void poisson_unmix(const ProbitParams &P, SeqRng &rng, double u, int mix,
+                                              double nevents, double *mu, double *sigsq, int *bad) {
+  if (mix < 0) {
+    *mu = -log(nevents);
+    *sigsq = 1.0 / nevents;
+    return;
+  }
+  const int c0 = P.mix_off[mix], nc = P.mix_off[mix + 1] - c0;
+  double wsp[POISSON_MAX_COMP];
+  double mx = -__builtin_huge_val(), tot = 0.0;
+  for (int c = 0; c < nc; ++c) {
+    const double sg = P.mix_sigma[c0 + c];
+    const double xs = (u - P.mix_mu[c0 + c]) / sg;
+    wsp[c] = P.mix_logw[c0 + c] + -(0.918938533204672741780329736406 + 0.5 * xs * xs + log(sg));
+    mx = wsp[c] > mx ? wsp[c] : mx;
+  }
+  for (int c = 0; c < nc; ++c) { wsp[c] = exp(wsp[c] - mx); tot += wsp[c]; }
+  double probsum = 0.0;
+  for (int c = 0; c < nc; ++c) { wsp[c] /= tot; probsum += wsp[c]; }
+  // rmulti_mt (distributions/rmulti.cpp:41-78)
+  const double tmp = d_runif(rng, 0.0, probsum);
+  double psum = 0.0;
+  int ind = -1;
+  for (int c = 0; c < nc; ++c) {
+    psum += wsp[c];
+    if (ind < 0 && tmp <= psum) ind = c;
+  }
+  if (ind < 0) { *bad = 1; ind = nc - 1; }
+  const double sg = P.mix_sigma[c0 + ind];
+  *mu = P.mix_mu[c0 + ind];
+  *sigsq = sg * sg;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void poisson_impute_kernel(ProbitParams P) {
+  const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  __shared__ int s_status;   // (one decision per workgroup: see probit_impute_kernel)
+  if (threadIdx.x == 0) s_status = __atomic_load_n(P.status + chain, __ATOMIC_RELAXED);
+  __syncthreads();
+  if (s_status != CHAIN_OK) return;
+  __shared__ int s_idx[PROBIT_KMAX];
+  __shared__ double s_beta[PROBIT_KMAX];
+  const int k = included_coefficients(P, chain, s_idx, s_beta);
+  if (k > PROBIT_KMAX) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
+    return;
+  }
+  if (i >= P.n) return;
+  double eta = 0.0;
+  for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
+  const long long y = llround(P.y[i]);
+  const double exposure = P.ntrials[i];
+  const uint64_t start = (P.sweep * (uint64_t)P.n + (uint64_t)i) * POISSON_STRIDE;
+  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 11u}, start};
+  int bad = 0;
+  const double t_final = y > 0 ? exposure * d_rbeta_a_1(rng, (double)y) : 0.0;
+  const double delta = exposure - t_final;
+  double z_ext;
+  if (fabs(eta) < 600) {
+    z_ext = -log(delta + (1.0 / exp(eta)) * d_exp_rand(rng));
+  } else if (delta > 0) {
+    const double err = -log((1.0 / 1.0) * d_exp_rand(rng)) * 1.0 + 0.0;   // rexv_mt(rng, 0, 1)
+    const double xx = log(delta), yy = -err - eta;
+    const double hi2 = xx < yy ? yy : xx, lo2 = xx < yy ? xx : yy;
+    z_ext = -(hi2 + log1p(exp(lo2 - hi2)));                                // -lse2
+  } else {
+    z_ext = eta + (-log((1.0 / 1.0) * d_exp_rand(rng)) * 1.0 + 0.0);
+  }
+  double mu_e, sig_e, mu_i = 0.0, sig_i = 1.0, z_int = 0.0;
+  poisson_unmix(P, rng, z_ext - eta, P.mix_one, 1.0, &mu_e, &sig_e, &bad);
+  if (y > 0) {
+    z_int = -log(t_final);
+    poisson_unmix(P, rng, z_int - eta, P.obs_mix[i], (double)y, &mu_i, &sig_i, &bad);
+  }
+  // the internal point first, then the external one (the order the reference adds them in)
+  double sum = 0.0, info = 0.0;
+  if (y > 0) {
+    const double w = 1.0 / sig_i;
+    sum += w * (z_int - mu_i);
+    info += w;
+  }
+  {
+    const double w = 1.0 / sig_e;
+    sum += w * (z_ext - mu_e);
+    info += w;
+  }
+  if (bad || rng.pos - start > (uint64_t)POISSON_STRIDE) P.status[chain] = CHAIN_RNG_BRANCH;
+  P.z[(size_t)chain * P.n + i] = sum;
+  P.w[(size_t)chain * P.n + i] = info;
+}
+
 hipError_t launch_rows_times_columns(hipStream_t stream, const double *U, int R, const double *B, int64_t n,
                                      int p, const double *diag_base, double *out, double *planes);
 
@@ -707,8 +848,10 @@ hipError_t launch_logit_impute(hipStream_t stream, const ProbitParams &P, const 
                                int polya_gamma) {
   hipError_t err;
   {
-    KtScope kt(stream, KT_LOGIT_IMPUTE);
-    if (polya_gamma)
+    KtScope kt(stream, polya_gamma == 2 ? KT_POISSON_IMPUTE : KT_LOGIT_IMPUTE);
+    if (polya_gamma == 2)   // (the Poisson member of the family: same outputs, its own imputation)
+      hipLaunchKernelGGL(poisson_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
+    else if (polya_gamma)
       hipLaunchKernelGGL(logit_pg_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);
     else
       hipLaunchKernelGGL(logit_impute_kernel, dim3((P.n + 255) / 256, P.chains), dim3(256), 0, stream, P);

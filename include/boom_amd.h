@@ -290,6 +290,35 @@ int ba_logit_sweep(ba_engine *e, int32_t nsweeps);
  * of sweep s from position (s n + i) * 4096. */
 int ba_logit_set_imputer(ba_engine *e, int32_t kind);
 
+/* ---- PoissonRegressionSpikeSlabSampler (the Poisson member) -----------
+ * Models/Glm/PosteriorSamplers/PoissonRegressionSpikeSlabSampler.cpp:55-59: per sweep the
+ * auxiliary-mixture imputation of Fruehwirth-Schnatter et al. (PoissonDataImputer.cpp:36-96:
+ * the last event time inside the exposure interval ~ exposure x Beta(y, 1), the first
+ * event after it, each negative log time unmixed against a normal mixture of
+ * NegLogGamma(count)), then SpikeSlabSampler's inclusion / coefficient draws on the
+ * complete-data sufficient statistics -- on the device the logit path's machinery: X'Wz by
+ * one MFMA GEMM, every chain's own slab precision + X'WX a vector at a time.
+ *   ba_poisson_set_data      X n x p column-major, y counts, exposure (> 0)
+ *   ba_poisson_set_mixtures  the mixtures, BY THE CALLER: the reference keeps them in a
+ *                            table that interpolates and refits on demand
+ *                            (create_poisson_mixture_approximation_table /
+ *                            NormalMixtureApproximationTable::approximate); the BOOM-side
+ *                            binding reads its table, the tests a fixture generated from
+ *                            the compiled reference.  counts ascending (must cover 1 and
+ *                            every positive count in the data below largest_index, from
+ *                            where on the Gaussian limit is used); mixture i has ncomp[i]
+ *                            (<= 32) components, packed in mu / sigma / weight
+ *   priors, state            ba_sss_set_slab(mu, precision, 0, max_flips), ba_set_spike,
+ *                            ba_set_state / ba_get_state(s) as for the logit sampler
+ * RNG: stream 3 for the sampler, stream 11 from position (s n + i) * 256 for the
+ * imputation of observation i in sweep s. */
+int ba_poisson_set_data(ba_engine *e, int64_t n, int32_t p, const double *X, const double *y,
+                        const double *exposure);
+int ba_poisson_set_mixtures(ba_engine *e, int32_t ncounts, const int64_t *counts,
+                            const int32_t *ncomp, const double *mu, const double *sigma,
+                            const double *weight, int64_t largest_index);
+int ba_poisson_sweep(ba_engine *e, int32_t nsweeps);
+
 /* ---- posterior summaries --------------------------------------------------- */
 /* Running sums over every sweep since the last ba_reset_summaries(), reduced
  * over this engine's chains on the device:

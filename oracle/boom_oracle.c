@@ -4,6 +4,7 @@
 #define _GNU_SOURCE
 #include "boom_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -3169,6 +3170,214 @@ int bo_logit_draw(bo_logit *m) {
       const double xb = m->X[IDX(i, b, n)];
       s->xty[b] += xb * sum;
       for (int a = 0; a < p; ++a) s->xtx[IDX(a, b, p)] += m->X[IDX(i, a, n)] * xb * info;
+    }
+  }
+  ++m->sweep;
+  status = bo_sss_draw_model_indicators(s, 1.0);
+  if (status) return status;
+  return bo_sss_draw_beta(s, 1.0);
+}
+
+/* ======================================================================
+ * PoissonRegressionSpikeSlabSampler (the Poisson member)
+ *   PoissonRegressionSpikeSlabSampler::draw   (PoissonRegressionSpikeSlabSampler.cpp:55-59)
+ *   PoissonRegressionDataImputer::impute_latent_data_point
+ *                                             (PoissonRegressionAuxMixSampler.cpp:59-81)
+ *   PoissonDataImputer::impute                (PoissonDataImputer.cpp:36-96)
+ *   unmix_poisson_augmented_data              (poisson_mixture_approximation_table.cpp:45-62)
+ *   NormalMixtureApproximation::unmix         (NormalMixtureApproximation.cpp:280-290)
+ *   Rmath::rbeta_mt, Cheng's algorithm BC     (Bmath/rbeta.cpp:59-128; the shape pair is
+ *                                             always (y, 1): min = 1 <= 1)
+ *   rexv_mt                                   (distributions/extreme_value.cpp:60-67)
+ * The normal-mixture approximations of NegLogGamma(n) are DATA of the reference
+ * (create_poisson_mixture_approximation_table, with the interpolation / refit its
+ * approximate(n) performs): the caller hands in, for every distinct count in the data
+ * and for 1, the mixture the reference's table yields (tests: a fixture generated from
+ * the compiled reference; a BOOM-side binding: the table itself).
+ * ====================================================================== */
+struct bo_poisson {
+  int n, p;
+  double *X, *y, *exposure;
+  bo_sss *sss;          /* (X'WX, X'Wz), gamma, beta, the sampler's RNG */
+  bo_rng worker_rng;    /* the imputation worker's own RNG */
+  int substream;        /* 1: observation i of sweep s reads from position (s n + i) * BO_POISSON_STRIDE */
+  uint64_t sweep;
+  /* mixtures: for count counts[m] (ascending), components [off[m], off[m + 1]) */
+  int ncounts;
+  int64_t *counts;
+  int *off;
+  double *mu, *sigma, *logw;
+  int64_t largest_index;   /* counts at or beyond it: the Gaussian limit */
+};
+#define BO_POISSON_STRIDE 256
+
+bo_poisson *bo_poisson_create(int n, int p, const double *X, const double *y, const double *exposure,
+                              const double *mu, const double *prec, const double *pi, int ncounts,
+                              const int64_t *counts, const int *ncomp, const double *mix_mu,
+                              const double *mix_sigma, const double *mix_weight, int64_t largest_index) {
+  bo_poisson *m = (bo_poisson *)xcalloc(1, sizeof(bo_poisson));
+  m->n = n; m->p = p;
+  m->X = (double *)xcalloc((size_t)n * p, sizeof(double));
+  m->y = (double *)xcalloc(n, sizeof(double));
+  m->exposure = (double *)xcalloc(n, sizeof(double));
+  memcpy(m->X, X, sizeof(double) * (size_t)n * p);
+  memcpy(m->y, y, sizeof(double) * n);
+  memcpy(m->exposure, exposure, sizeof(double) * n);
+  double *xtx = (double *)xcalloc((size_t)p * p, sizeof(double));
+  double *xty = (double *)xcalloc(p, sizeof(double));
+  m->sss = bo_sss_create(p, xtx, xty, 0, mu, prec, pi);
+  free(xtx); free(xty);
+  m->ncounts = ncounts;
+  m->counts = (int64_t *)xcalloc(ncounts, sizeof(int64_t));
+  m->off = (int *)xcalloc(ncounts + 1, sizeof(int));
+  memcpy(m->counts, counts, sizeof(int64_t) * ncounts);
+  for (int i = 0; i < ncounts; ++i) m->off[i + 1] = m->off[i] + ncomp[i];
+  const int tot = m->off[ncounts];
+  m->mu = (double *)xcalloc(tot, sizeof(double));
+  m->sigma = (double *)xcalloc(tot, sizeof(double));
+  m->logw = (double *)xcalloc(tot, sizeof(double));
+  memcpy(m->mu, mix_mu, sizeof(double) * tot);
+  memcpy(m->sigma, mix_sigma, sizeof(double) * tot);
+  for (int i = 0; i < tot; ++i) m->logw[i] = log(mix_weight[i]);
+  m->largest_index = largest_index;
+  bo_rng_seed_philox(&m->worker_rng, 0, 0, 11, 0);
+  return m;
+}
+void bo_poisson_destroy(bo_poisson *m) {
+  if (!m) return;
+  bo_sss_destroy(m->sss);
+  free(m->X); free(m->y); free(m->exposure);
+  free(m->counts); free(m->off); free(m->mu); free(m->sigma); free(m->logw);
+  free(m);
+}
+bo_sss *bo_poisson_sss(bo_poisson *m) { return m->sss; }
+bo_rng *bo_poisson_worker_rng(bo_poisson *m) { return &m->worker_rng; }
+void bo_poisson_use_substreams(bo_poisson *m, int on) { m->substream = on; }
+void bo_poisson_get_suf(const bo_poisson *m, double *xtx, double *xty) {
+  memcpy(xtx, m->sss->xtx, sizeof(double) * (size_t)m->p * m->p);
+  memcpy(xty, m->sss->xty, sizeof(double) * m->p);
+}
+
+/* Rmath::rbeta_mt(rng, aa, 1) with aa >= 1 (Bmath/rbeta.cpp: a = min = 1, b = aa: algorithm BC) */
+static double poisson_rbeta_a_1(bo_rng *rng, double aa) {
+  const double expmax = 1024 * 0.693147180559945309417232121458;   /* max_exponent * M_LN2 */
+  const double a = (aa < 1.0) ? aa : 1.0, b = (aa < 1.0) ? 1.0 : aa;
+  const double alpha = a + b;
+  const double beta = 1.0 / a, delta = 1.0 + b - a;
+  const double k1 = delta * (0.0138889 + 0.0416667 * a) / (b * beta - 0.777778);
+  const double k2 = 0.25 + (0.5 + 0.25 / delta) * a;
+  double u1, u2, v, w, y, z;
+  for (;;) {
+    u1 = bo_unif(rng);
+    u2 = bo_unif(rng);
+    if (u1 < 0.5) {
+      y = u1 * u2;
+      z = u1 * y;
+      if (0.25 * u2 + z - y >= k1) continue;
+    } else {
+      z = u1 * u1 * u2;
+      if (z <= 0.25) {
+        v = beta * log(u1 / (1.0 - u1));
+        w = (v <= expmax) ? b * exp(v) : DBL_MAX;
+        break;
+      }
+      if (z >= k2) continue;
+    }
+    v = beta * log(u1 / (1.0 - u1));
+    w = (v <= expmax) ? b * exp(v) : DBL_MAX;
+    if (alpha * (log(alpha / (a + w)) + v) - 1.3862944 >= log(z)) break;
+  }
+  /* aa == a only when aa <= 1 (then a / (a + w)); here aa >= 1 = a: for aa == 1 both are 1 */
+  double ans = (aa == a) ? a / (a + w) : w / (a + w);
+  if (isnan(ans)) {
+    const double zero = DBL_EPSILON, one = 1.0 - zero;
+    if (aa == a) return isfinite(a) ? zero : one;
+    return isfinite(w) ? zero : one;
+  }
+  return ans;
+}
+double bo_test_rbeta_a1(bo_rng *r, double a) { return poisson_rbeta_a_1(r, a); }
+
+/* unmix_poisson_augmented_data (poisson_mixture_approximation_table.cpp:45-62) */
+static int poisson_unmix(const bo_poisson *m, bo_rng *rng, double u, int64_t nevents, double *mu,
+                         double *sigsq) {
+  if (nevents >= m->largest_index) {
+    *mu = -log((double)nevents);
+    *sigsq = 1.0 / (double)nevents;
+    return 0;
+  }
+  int lo = 0, hi = m->ncounts;
+  while (lo < hi) {
+    const int mid = (lo + hi) / 2;
+    if (m->counts[mid] < nevents) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= m->ncounts || m->counts[lo] != nevents) return BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  const int c0 = m->off[lo], nc = m->off[lo + 1] - c0;
+  double wsp[32], mx = BO_NEG_INF, tot = 0;
+  if (nc > 32) return BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  for (int c = 0; c < nc; ++c) {
+    const double xs = (u - m->mu[c0 + c]) / m->sigma[c0 + c];
+    wsp[c] = m->logw[c0 + c] + -(0.918938533204672741780329736406 + 0.5 * xs * xs + log(m->sigma[c0 + c]));
+    if (wsp[c] > mx) mx = wsp[c];
+  }
+  for (int c = 0; c < nc; ++c) { wsp[c] = exp(wsp[c] - mx); tot += wsp[c]; }
+  for (int c = 0; c < nc; ++c) wsp[c] /= tot;
+  int status = 0;
+  const int ind = bo_rmulti(rng, wsp, nc, &status);
+  if (status) return status;
+  *mu = m->mu[c0 + ind];
+  *sigsq = m->sigma[c0 + ind] * m->sigma[c0 + ind];
+  return 0;
+}
+
+int bo_poisson_draw(bo_poisson *m) {
+  const int n = m->n, p = m->p;
+  bo_sss *s = m->sss;
+  int status = 0;
+  memset(s->xtx, 0, sizeof(double) * (size_t)p * p);
+  memset(s->xty, 0, sizeof(double) * p);
+  for (int i = 0; i < n; ++i) {
+    double eta = 0;
+    for (int j = 0; j < p; ++j)
+      if (s->gamma[j]) eta += m->X[IDX(i, j, n)] * s->beta[j];
+    const int64_t y = (int64_t)llround(m->y[i]);
+    const double exposure = m->exposure[i];
+    bo_rng *r = &m->worker_rng;
+    if (m->substream) r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * BO_POISSON_STRIDE;
+    /* PoissonDataImputer::impute: eta here is log_lambda = x'beta (the exposure enters
+     * through the event times) */
+    const double t_final = y > 0 ? exposure * poisson_rbeta_a_1(r, (double)y) : 0.0;
+    const double delta = exposure - t_final;
+    double z_ext;
+    if (fabs(eta) < 600) {
+      z_ext = -log(delta + (1.0 / exp(eta)) * bo_exp_rand(r));   /* rexp_mt(rng, lambda) = exp_rand / lambda */
+    } else if (delta > 0) {
+      const double err = -log((1.0 / 1.0) * bo_exp_rand(r)) * 1.0 + 0.0;   /* rexv_mt(rng, 0, 1) */
+      const double xx = log(delta), yy = -err - eta;
+      const double hi2 = xx < yy ? yy : xx, lo2 = xx < yy ? xx : yy;
+      z_ext = -(hi2 + log1p(exp(lo2 - hi2)));                    /* -lse2(log(delta), -err - eta) */
+    } else {
+      z_ext = eta + (-log((1.0 / 1.0) * bo_exp_rand(r)) * 1.0 + 0.0);
+    }
+    double mu_e, sig_e, mu_i = 0, sig_i = 1;
+    status = poisson_unmix(m, r, z_ext - eta, 1, &mu_e, &sig_e);
+    if (status) return status;
+    double z_int = 0;
+    if (y > 0) {
+      z_int = -log(t_final);
+      status = poisson_unmix(m, r, z_int - eta, y, &mu_i, &sig_i);
+      if (status) return status;
+    }
+    /* WeightedRegSuf::add_data(x, y, w): xtx += w x x', xty += w y x -- the internal point
+     * first, then the external one (PoissonRegressionAuxMixSampler.cpp:74-80) */
+    for (int pass = (y > 0 ? 0 : 1); pass < 2; ++pass) {
+      const double w = pass == 0 ? 1.0 / sig_i : 1.0 / sig_e;
+      const double resp = pass == 0 ? z_int - mu_i : z_ext - mu_e;
+      for (int b = 0; b < p; ++b) {
+        const double xb = m->X[IDX(i, b, n)];
+        s->xty[b] += xb * (w * resp);
+        for (int a = 0; a < p; ++a) s->xtx[IDX(a, b, p)] += m->X[IDX(i, a, n)] * xb * w;
+      }
     }
   }
   ++m->sweep;

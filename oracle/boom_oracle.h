@@ -286,6 +286,21 @@ double bo_adaptive_min_margin(const bo_adaptive *a);
 double bo_adaptive_min_multi_margin(const bo_adaptive *a);
 int bo_adaptive_draw(bo_adaptive *a);
 
+
+/* ---- PoissonRegressionSpikeSlabSampler (f3, Poisson member): the mixtures of the
+ * reference's NegLogGamma table for the counts in the data are an INPUT */
+typedef struct bo_poisson bo_poisson;
+bo_poisson *bo_poisson_create(int n, int p, const double *X, const double *y, const double *exposure,
+                              const double *mu, const double *prec, const double *pi, int ncounts,
+                              const int64_t *counts, const int *ncomp, const double *mix_mu,
+                              const double *mix_sigma, const double *mix_weight, int64_t largest_index);
+void bo_poisson_destroy(bo_poisson *m);
+bo_sss *bo_poisson_sss(bo_poisson *m);
+bo_rng *bo_poisson_worker_rng(bo_poisson *m);
+void bo_poisson_use_substreams(bo_poisson *m, int on);
+void bo_poisson_get_suf(const bo_poisson *m, double *xtx, double *xty);
+int bo_poisson_draw(bo_poisson *m);
+
 #ifdef __cplusplus
 }
 #endif

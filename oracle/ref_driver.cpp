@@ -17,6 +17,10 @@
 #include <string>
 #include <vector>
 
+#include "Models/Glm/PoissonRegressionModel.hpp"
+#include "Models/Glm/PosteriorSamplers/PoissonRegressionSpikeSlabSampler.hpp"
+#include "Models/Glm/PosteriorSamplers/NormalMixtureApproximation.hpp"
+#include "Models/Glm/PosteriorSamplers/poisson_mixture_approximation_table.hpp"
 #include "LinAlg/Cholesky.hpp"
 #include "LinAlg/Matrix.hpp"
 #include "LinAlg/Selector.hpp"
@@ -834,6 +838,81 @@ int ref_logit_run(int n, int p, const double *X, const double *y, const double *
   NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
   if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
   NEW(BinomialLogitSpikeSlabSampler, sam)(model.get(), slab, spike, clt_threshold);
+  if (max_flips >= 0) sam->limit_model_selection(max_flips);
+  model->set_method(sam);
+  model->coef().drop_all();
+  Vector b0(p, 0.0);
+  for (int j = 0; j < p; ++j)
+    if (init_gamma[j]) {
+      model->coef().add(j);
+      b0[j] = init_beta[j];
+    }
+  model->coef().set_Beta(b0);
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    const Selector &inc(model->coef().inc());
+    const Vector &beta(model->Beta());
+    for (int j = 0; j < p; ++j) {
+      out_gamma[(size_t)i * p + j] = inc[j] ? 1 : 0;
+      out_beta[(size_t)i * p + j] = beta[j];
+    }
+  }
+  REF_CATCH
+}
+
+// ---- PoissonRegressionSpikeSlabSampler (the Poisson member) --------
+// The normal-mixture approximations of NegLogGamma(n) the reference's table yields
+// (create_poisson_mixture_approximation_table + approximate(n)), DATA for the oracle, the
+// device and the golden fixtures.  approximate(n) interpolates between the tabulated
+// orders and, where that is too coarse, refits and ADDS the result to the table, so that
+// what a later request returns can depend on the earlier ones: `requests` replays the
+// order in which a sampler asks (for every observation: 1, then its count if positive);
+// `counts` (ascending, distinct) are then read from the table.  Out arrays hold up to
+// max_comp components per count; a count at or beyond the table's largest order has
+// none (the Gaussian limit is used).
+int ref_poisson_mixtures(int nrequests, const int64_t *requests, int ncounts, const int64_t *counts,
+                         int max_comp, int *ncomp, double *mu, double *sigma, double *weight,
+                         int64_t *largest_index) {
+  REF_TRY
+  NormalMixtureApproximationTable table = create_poisson_mixture_approximation_table();
+  *largest_index = table.largest_index();
+  for (int i = 0; i < nrequests; ++i)
+    if (requests[i] > 0 && requests[i] < table.largest_index()) table.approximate((int)requests[i]);
+  for (int i = 0; i < ncounts; ++i) {
+    if (counts[i] >= table.largest_index()) {
+      ncomp[i] = 0;
+      continue;
+    }
+    const NormalMixtureApproximation &a(table.approximate((int)counts[i]));
+    if (a.dim() > max_comp) throw std::runtime_error("more mixture components than room");
+    ncomp[i] = a.dim();
+    for (int c = 0; c < a.dim(); ++c) {
+      mu[(size_t)i * max_comp + c] = a.mu()[c];
+      sigma[(size_t)i * max_comp + c] = a.sigma()[c];
+      weight[(size_t)i * max_comp + c] = a.weights()[c];
+    }
+  }
+  REF_CATCH
+}
+
+int ref_poisson_run(int n, int p, const double *X, const double *y, const double *exposure,
+                    const double *mu, const double *prec, const double *pi,
+                    int64_t max_model_size, int max_flips, uint64_t seed,
+                    const uint8_t *init_gamma, const double *init_beta, int nsweeps,
+                    uint8_t *out_gamma, double *out_beta) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  NEW(PoissonRegressionModel, model)(p);
+  for (int i = 0; i < n; ++i) {
+    Vector x(p);
+    for (int j = 0; j < p; ++j) x[j] = X[(size_t)j * n + i];
+    NEW(PoissonRegressionData, dp)((int64_t)llround(y[i]), x, exposure[i]);
+    model->add_data(dp);
+  }
+  Ptr<MvnBase> slab(new MvnModel(make_vector(p, mu), make_spd(p, prec), true));
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  if (max_model_size >= 0) spike->set_max_model_size(max_model_size);
+  NEW(PoissonRegressionSpikeSlabSampler, sam)(model.get(), slab, spike, 1);
   if (max_flips >= 0) sam->limit_model_selection(max_flips);
   model->set_method(sam);
   model->coef().drop_all();

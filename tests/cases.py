@@ -162,3 +162,15 @@ def logit_data(n, p, nsig, seed, max_trials=1):
     nt = np.ones(n) if max_trials == 1 else rng.integers(1, max_trials + 1, n).astype(float)
     y = rng.binomial(nt.astype(int), prob).astype(float)
     return X, y, nt, beta
+
+
+def poisson_data(n, p, nsig, seed, max_exposure=1.0, intercept=0.5):
+    """Poisson regression data: X[:, 0] = 1, counts y with log rate x'beta + log exposure"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((n, p))
+    X[:, 0] = 1.0
+    beta = np.zeros(p)
+    beta[:nsig] = np.array([intercept, 0.6, -0.5, 0.4, -0.35, 0.3, 0.5, -0.45])[:nsig]
+    exposure = np.ones(n) if max_exposure == 1.0 else rng.uniform(0.5, max_exposure, n)
+    y = rng.poisson(exposure * np.exp(X @ beta)).astype(float)
+    return X, y, exposure, beta

@@ -693,6 +693,64 @@ class Oracle:
         self.lib.bo_logit_destroy(m)
         return dict(gamma=gam, beta=beta, status=status, xtx=xtx, xty=xty)
 
+    def poisson_run(self, X, y, exposure, slab, pi, mix, rng_setup, init_gamma, init_beta, nsweeps,
+                    max_model_size=-1, max_flips=-1, want_suf=False):
+        """PoissonRegressionSpikeSlabSampler (f3): slab = dict(mu, prec); mix = the reference
+        table's mixtures for the counts in the data (poisson_mixtures / the golden fixture)"""
+        n, p = X.shape
+        self._declare_sss()
+        L = self.lib
+        L.bo_poisson_create.restype = C.c_void_p
+        L.bo_poisson_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
+                                        c_double_p, c_double_p, C.c_int, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int), c_double_p, c_double_p, c_double_p, C.c_int64]
+        for name in ("bo_poisson_sss", "bo_poisson_worker_rng"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.bo_poisson_destroy.argtypes = [C.c_void_p]
+        L.bo_poisson_use_substreams.argtypes = [C.c_void_p, C.c_int]
+        L.bo_poisson_draw.argtypes = [C.c_void_p]
+        L.bo_poisson_get_suf.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        counts = np.ascontiguousarray(mix["counts"], dtype=np.int64)
+        ncomp = np.ascontiguousarray(mix["ncomp"], dtype=np.int32)
+        m = L.bo_poisson_create(n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(exposure)), _dp(f64(slab["mu"])),
+                                _dp(fcol(slab["prec"])), _dp(f64(pi)), len(counts),
+                                counts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                ncomp.ctypes.data_as(C.POINTER(C.c_int)), _dp(f64(mix["mu"])),
+                                _dp(f64(mix["sigma"])), _dp(f64(mix["weight"])), int(mix["largest_index"]))
+        sss = L.bo_poisson_sss(m)
+        L.bo_sss_set_options(sss, int(max_model_size), int(max_flips))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        L.bo_sss_set_state(sss, _u8(g0), _dp(f64(init_beta) * g0))
+        if rng_setup[0] == "mt":
+            glob = self.rng_mt(rng_setup[1])
+            srng = L.bo_sss_rng(sss)
+            L.bo_rng_seed_mt(srng, L.bo_seed_rng(C.byref(glob)))
+            L.bo_rng_seed_mt(L.bo_poisson_worker_rng(m), L.bo_seed_rng(C.c_void_p(srng)))
+        else:
+            seed, chain = int(rng_setup[1]), int(rng_setup[2])
+            L.bo_rng_seed_philox(L.bo_sss_rng(sss), seed, chain, 3, 0)
+            L.bo_rng_seed_philox(L.bo_poisson_worker_rng(m), seed, chain, 11, 0)
+            L.bo_poisson_use_substreams(m, 1)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        xtx = np.zeros((nsweeps, p, p)) if want_suf else None
+        xty = np.zeros((nsweeps, p)) if want_suf else None
+        g = np.zeros(p, dtype=np.uint8)
+        b = np.zeros(p)
+        status = 0
+        for i in range(nsweeps):
+            status = L.bo_poisson_draw(m)
+            if status:
+                break
+            L.bo_sss_get_state(sss, _u8(g), _dp(b))
+            gam[i] = g
+            beta[i] = b
+            if want_suf:
+                L.bo_poisson_get_suf(m, _dp(xtx[i]), _dp(xty[i]))
+        L.bo_poisson_destroy(m)
+        return dict(gamma=gam, beta=beta, status=status, xtx=xtx, xty=xty)
+
     def ssm_forecast(self, rng, newX, beta, sigsq_obs, trend, nseasons, sigsq, final_state):
         h, p = newX.shape
         out = np.zeros(h)
@@ -1078,6 +1136,44 @@ class Ref:
             _dp(fcol(slab["prec"])), _dp(f64(pi)), C.c_int64(max_model_size), int(max_flips),
             int(clt_threshold), C.c_uint64(seed), _u8(g0), _dp(f64(init_beta)), nsweeps,
             _u8(gam), _dp(beta)))
+        return dict(gamma=gam, beta=beta)
+
+    def poisson_mixtures(self, y, max_comp=16):
+        """the reference table's normal-mixture approximation of NegLogGamma(n) for 1 and
+        every positive count in y, asked for in the order a sampler's pass over the data
+        asks (the table refits and grows on demand: see ref_poisson_mixtures); packed
+        arrays as the oracle / the C-ABI take them"""
+        req = []
+        for v in np.asarray(y):
+            req.append(1)
+            if v > 0:
+                req.append(int(v))
+        req = np.ascontiguousarray(req, dtype=np.int64)
+        counts = np.ascontiguousarray(sorted(set(int(c) for c in req)), dtype=np.int64)
+        nc = np.zeros(len(counts), np.int32)
+        mu = np.zeros((len(counts), max_comp))
+        sg = np.zeros((len(counts), max_comp))
+        wt = np.zeros((len(counts), max_comp))
+        li = C.c_int64()
+        self._check(self.lib.ref_poisson_mixtures(
+            len(req), req.ctypes.data_as(C.POINTER(C.c_int64)),
+            len(counts), counts.ctypes.data_as(C.POINTER(C.c_int64)), max_comp,
+            nc.ctypes.data_as(C.POINTER(C.c_int)), _dp(mu), _dp(sg), _dp(wt), C.byref(li)))
+        keep = nc > 0
+        pack = lambda a: np.concatenate([a[i, :nc[i]] for i in range(len(counts)) if keep[i]])  # noqa: E731
+        return dict(counts=counts[keep], ncomp=nc[keep], mu=pack(mu), sigma=pack(sg), weight=pack(wt),
+                    largest_index=li.value)
+
+    def poisson_run(self, X, y, exposure, slab, pi, seed, init_gamma, init_beta, nsweeps,
+                    max_model_size=-1, max_flips=-1):
+        n, p = X.shape
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self._check(self.lib.ref_poisson_run(
+            n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(exposure)), _dp(f64(slab["mu"])),
+            _dp(fcol(slab["prec"])), _dp(f64(pi)), C.c_int64(max_model_size), int(max_flips),
+            C.c_uint64(seed), _u8(g0), _dp(f64(init_beta)), nsweeps, _u8(gam), _dp(beta)))
         return dict(gamma=gam, beta=beta)
 
     def ssm_forecast(self, y, X, beta, gamma, sigsq_obs, trend, nseasons, sigsq, final_state,

@@ -365,6 +365,28 @@ def test_logit_spike_slab_matches_reference(oracle, name):
     assert relerr(o["beta"], g["beta"]) < 1e-9
 
 
+def _golden_mix(g):
+    return dict(counts=g["mix_counts"], ncomp=g["mix_ncomp"], mu=g["mix_mu"], sigma=g["mix_sigma"],
+                weight=g["mix_weight"], largest_index=int(g["mix_largest_index"]))
+
+
+@pytest.mark.parametrize("name", ["poisson_small_counts", "poisson_exposure", "poisson_large_counts",
+                                  "poisson_p24_maxflips"])
+def test_poisson_spike_slab_matches_reference(oracle, name):
+    """f3 (Poisson): PoissonRegressionSpikeSlabSampler -- Cheng's beta draws for the last
+    event time, the exponential / extreme-value draw past the interval, the unmixing of
+    both NegLogGamma residuals against the reference table's mixtures (fixture data),
+    SpikeSlabSampler on the complete-data sufficient statistics"""
+    g = load(name)
+    p = g["X"].shape[1]
+    o = oracle.poisson_run(g["X"], g["y"], g["exposure"], dict(mu=g["mu"], prec=g["prec"]), g["pi"],
+                           _golden_mix(g), ("mt", int(g["seed"])), g["init_gamma"], np.zeros(p),
+                           int(g["nsweeps"]), max_flips=int(g["max_flips"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < 1e-9
+
+
 def test_impute_state_known_answer(oracle):
     g = load("kat_impute_state")
     o = oracle.ss_impute_state(g["y"], g["X"], g["observed"], g["beta"],
