@@ -10,6 +10,7 @@
 
 #include "DeviceBinomialLogitSpikeSlabSampler.hpp"
 #include "DeviceBregVsSampler.hpp"
+#include "DevicePoissonRegressionSpikeSlabSampler.hpp"
 #include "DeviceStateSpacePosteriorSampler.hpp"
 #include "Models/StateSpace/StateModels/LocalLevelStateModel.hpp"
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
@@ -292,6 +293,54 @@ int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uin
       for (int j = 0; j < p; ++j) probe_gamma[j] = inc[j] ? 1 : 0;
       for (int t = 0; t < T; ++t)
         for (int i = 0; i < m; ++i) probe_state[(size_t)t * m + i] = state(i, t);
+    }
+    return 0;
+  } catch (std::exception &e) {
+    g_binding_error = e.what();
+    return -1;
+  }
+}
+
+// ... and for the Poisson sampler: BOOM's PoissonRegressionModel (one PoissonRegressionData
+// per observation), MvnModel slab, VariableSelectionPrior, sample_posterior() with the
+// device sampler attached -- which reads BOOM's own NegLogGamma mixture table.
+int ref_binding_poisson_run(int n, int p, const double *X, const double *y, const double *exposure,
+                            const double *slab_mean, const double *slab_precision, const double *pi,
+                            int max_flips, int chains, uint64_t seed, const uint8_t *init_gamma,
+                            int nsweeps, uint8_t *out_gamma, double *out_beta, uint64_t *out_seed) {
+  try {
+    GlobalRng::rng.seed(seed);
+    Ptr<PoissonRegressionModel> model(new PoissonRegressionModel(p));
+    for (int i = 0; i < n; ++i) {
+      Vector x(p);
+      for (int j = 0; j < p; ++j) x[j] = X[(size_t)j * n + i];
+      NEW(PoissonRegressionData, dp)((int64_t)llround(y[i]), x, exposure[i]);
+      model->add_data(dp);
+    }
+    Vector mu(p), piv(p);
+    SpdMatrix prec(p);
+    for (int j = 0; j < p; ++j) {
+      mu[j] = slab_mean[j];
+      piv[j] = pi[j];
+      for (int i = 0; i < p; ++i) prec(i, j) = slab_precision[(size_t)j * p + i];
+    }
+    NEW(MvnModel, slab)(mu, prec, true);
+    NEW(VariableSelectionPrior, spike)(piv);
+    model->coef().drop_all();
+    for (int j = 0; j < p; ++j)
+      if (init_gamma[j]) model->coef().add(j);
+    NEW(DevicePoissonRegressionSpikeSlabSampler, sampler)(model.get(), slab, spike, chains);
+    if (max_flips > 0) sampler->limit_model_selection(max_flips);
+    if (out_seed) *out_seed = sampler->device_seed();
+    model->set_method(sampler);
+    for (int s = 0; s < nsweeps; ++s) {
+      model->sample_posterior();
+      const Selector &inc(model->coef().inc());
+      const Vector beta = model->Beta();
+      for (int j = 0; j < p; ++j) {
+        out_gamma[(size_t)s * p + j] = inc[j] ? 1 : 0;
+        out_beta[(size_t)s * p + j] = beta[j];
+      }
     }
     return 0;
   } catch (std::exception &e) {

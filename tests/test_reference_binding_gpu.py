@@ -184,3 +184,39 @@ def test_boom_state_space_model_driven_by_the_device_sampler(oracle, trend, nsea
     ol = run(chains - 1)
     assert np.array_equal(pg, ol["gamma"][-1])
     assert np.max(np.abs(pstate - ol["state"][-1])) < 1e-8 * np.abs(ol["state"][-1]).max()
+
+
+@pytest.mark.skipif(not os.path.exists(BINDING_SO),
+                    reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
+@pytest.mark.parametrize("name,max_flips", [("poisson_exposure", -1), ("poisson_large_counts", 5)])
+def test_boom_poisson_model_driven_by_the_device_sampler(oracle, name, max_flips):
+    """BOOM's PoissonRegressionModel stepped by model->sample_posterior() with
+    bindings/boom/DevicePoissonRegressionSpikeSlabSampler attached.  The binding reads the
+    normal mixtures from BOOM's OWN table (create_poisson_mixture_approximation_table,
+    asked in the imputer's order): what the BOOM model sees after every draw is the
+    oracle's chain 0 on the same Philox key with the mixtures of the golden fixture (which
+    were generated from the same table the same way)."""
+    from test_oracle_golden import _golden_mix, load
+    L = C.CDLL(BINDING_SO)
+    L.ref_binding_last_error.restype = C.c_char_p
+    g = load(name)
+    X, y, ex = g["X"], g["y"], g["exposure"]
+    n, p = X.shape
+    slab = dict(mu=g["mu"], prec=g["prec"])
+    pi, g0 = g["pi"], g["init_gamma"]
+    chains, nsw, seed = 4, 15, 515
+    gam = np.zeros((nsw, p), np.uint8)
+    beta = np.zeros((nsw, p))
+    dev_seed = C.c_uint64()
+    rc = L.ref_binding_poisson_run(
+        n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(ex)), _dp(f64(slab["mu"])), _dp(fcol(slab["prec"])),
+        _dp(f64(pi)), C.c_int(max_flips), chains, C.c_uint64(seed), _u8(g0), nsw, _u8(gam), _dp(beta),
+        C.byref(dev_seed))
+    assert rc == 0, L.ref_binding_last_error().decode()
+    o = oracle.poisson_run(X, y, ex, slab, pi, _golden_mix(g), ("philox", dev_seed.value, 0), g0,
+                           np.zeros(p), nsw, max_flips=max_flips)
+    assert o["status"] == 0
+    for s in range(nsw):
+        assert np.array_equal(gam[s], o["gamma"][s]), s
+        err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
+        assert err < 1e-8, (s, err)
