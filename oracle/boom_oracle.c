@@ -2148,6 +2148,17 @@ struct bo_ssm {
   int latent_initialized;
   double *state; /* m x T, column t = state at t */
   double *v, *F, *K, *r, *vs, *Fs, *Ks, *rs;
+  /* an ArStateModel(ar_lags) block after the trend / seasonal blocks (ar0: its first
+   * index, -1: none): coefficients phi, error variance, the NeRegSuf of the block's
+   * first element on the block's previous value, the ArPosteriorSampler's prior */
+  int ar_lags, ar0;
+  double phi[BO_SSM_MAX], ar_sigsq, ar_prior_df, ar_prior_ss, ar_sigma_max;
+  double ar_xtx[BO_SSM_MAX * BO_SSM_MAX], ar_xty[BO_SSM_MAX], ar_yty, ar_n;
+  bo_rng ar_rng;
+  /* draw_phi's proposals come from rmvn_ivar (no _mt): the reference draws them from
+   * GlobalRng::rng, not from the sampler's generator.  MT mode points this at the
+   * restated global generator (after it seeded the samplers); NULL: ar_rng. */
+  bo_rng *ar_global_rng;
 };
 
 bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
@@ -2165,6 +2176,7 @@ bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
   m->dtrend = trend;
   m->nseasons = nseasons;
   m->s0 = nseasons > 0 ? trend : -1;
+  m->ar0 = -1;
   m->m = trend + (nseasons > 0 ? nseasons - 1 : 0);
   m->y = (double *)xcalloc(T, sizeof(double));
   m->X = (double *)xcalloc((size_t)T * p, sizeof(double));
@@ -2216,7 +2228,50 @@ bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
   bo_rng_seed_philox(&m->var_rng[1], 0, 0, 6, 0);
   bo_rng_seed_philox(&m->var_rng[2], 0, 0, 7, 0);
   bo_rng_seed_philox(&m->state_rng, 0, 0, 2, 0);
+  bo_rng_seed_philox(&m->ar_rng, 0, 0, 12, 0);
   return m;
+}
+
+/* model->add_state(new ArStateModel(lags)) with an ArPosteriorSampler(ChisqModel(df,
+ * sigma_guess)) [+ set_sigma_upper_limit]; before the first draw.  The block's
+ * initial state is N(mean, diag(variance)). */
+int bo_ssm_add_ar(bo_ssm *m, int lags, double prior_df, double sigma_guess,
+                  double sigma_upper_limit, double initial_sigma, const double *initial_phi,
+                  const double *initial_state_mean, const double *initial_state_variance) {
+  if (lags < 1 || m->ar0 >= 0 || m->m + lags > BO_SSM_MAX) return BO_ERR_INVALID;
+  m->ar0 = m->m;
+  m->ar_lags = lags;
+  m->m += lags;
+  for (int i = 0; i < lags; ++i) {
+    m->phi[i] = initial_phi ? initial_phi[i] : 0.0;
+    m->a0[m->ar0 + i] = initial_state_mean[i];
+    m->P0[m->ar0 + i] = initial_state_variance[i];
+  }
+  m->ar_sigsq = initial_sigma * initial_sigma;
+  m->ar_prior_df = 2 * (prior_df / 2.0);
+  m->ar_prior_ss = 2 * (prior_df * sigma_guess * sigma_guess / 2.0);
+  m->ar_sigma_max = sigma_upper_limit;
+  const size_t mT = (size_t)m->m * m->T;
+  free(m->state); free(m->K); free(m->r); free(m->Ks); free(m->rs);
+  m->state = (double *)xcalloc(mT, sizeof(double));
+  m->K = (double *)xcalloc(mT, sizeof(double));
+  m->r = (double *)xcalloc(mT, sizeof(double));
+  m->Ks = (double *)xcalloc(mT, sizeof(double));
+  m->rs = (double *)xcalloc(mT, sizeof(double));
+  return 0;
+}
+bo_rng *bo_ssm_ar_rng(bo_ssm *m) { return &m->ar_rng; }
+void bo_ssm_set_global_rng(bo_ssm *m, bo_rng *global) { m->ar_global_rng = global; }
+void bo_ssm_get_ar(const bo_ssm *m, double *phi, double *sigsq) {
+  for (int i = 0; i < m->ar_lags; ++i) phi[i] = m->phi[i];
+  *sigsq = m->ar_sigsq;
+}
+void bo_ssm_get_ar_suf(const bo_ssm *m, double *xtx, double *xty, double *yty, double *n) {
+  const int L = m->ar_lags;
+  for (int i = 0; i < L * L; ++i) xtx[i] = m->ar_xtx[i];
+  for (int i = 0; i < L; ++i) xty[i] = m->ar_xty[i];
+  *yty = m->ar_yty;
+  *n = m->ar_n;
 }
 
 void bo_ssm_destroy(bo_ssm *m) {
@@ -2252,6 +2307,14 @@ static void ssm_T(const bo_ssm *m, double *x) {
     tmp[0] = first;
     for (int i = 0; i < n; ++i) s[i] = tmp[i];
   }
+  if (m->ar0 >= 0) {
+    /* AutoRegressionTransitionMatrix::multiply_inplace, Filters/SparseMatrix.cpp:1297-1310 */
+    double *s = x + m->ar0, first_entry = 0;
+    for (int i = m->ar_lags - 1; i >= 0; --i) {
+      first_entry += m->phi[i] * s[i];
+      if (i > 0) s[i] = s[i - 1]; else s[i] = first_entry;
+    }
+  }
 }
 /* x <- T' x (Tmult) */
 static void ssm_Tt(const bo_ssm *m, double *x) {
@@ -2262,10 +2325,18 @@ static void ssm_Tt(const bo_ssm *m, double *x) {
     for (int i = 0; i < n; ++i) tmp[i] = -s[0] + (i + 1 < n ? s[i + 1] : 0.0);
     for (int i = 0; i < n; ++i) s[i] = tmp[i];
   }
+  if (m->ar0 >= 0) {
+    /* AutoRegressionTransitionMatrix::Tmult, Filters/SparseMatrix.cpp:1286-1295 */
+    const int n = m->ar_lags;
+    double *s = x + m->ar0, tmp[BO_SSM_MAX];
+    for (int i = 0; i < n; ++i) tmp[i] = m->phi[i] * s[0] + (i + 1 < n ? s[i + 1] : 0);
+    for (int i = 0; i < n; ++i) s[i] = tmp[i];
+  }
 }
 static double ssm_Zdot(const bo_ssm *m, const double *x) {
   double ans = x[0];
   if (m->s0 >= 0) ans += x[m->s0];
+  if (m->ar0 >= 0) ans += x[m->ar0];   /* ArStateModel.cpp: observation_matrix_[0] = 1 */
   return ans;
 }
 /* the diagonal of RQR */
@@ -2274,6 +2345,7 @@ static void ssm_rqr(const bo_ssm *m, double *d) {
   d[0] = m->sigsq[0];
   if (m->dtrend == 2) d[1] = m->sigsq[1];
   if (m->s0 >= 0) d[m->s0] = m->sigsq[2];
+  if (m->ar0 >= 0) d[m->ar0] = m->ar_sigsq;
 }
 
 /* ScalarMarginalDistribution::update, ScalarKalmanFilter.cpp:41-83; P is m x m
@@ -2286,6 +2358,7 @@ static int ssm_update(const bo_ssm *M, double y, int missing, double H,
   for (int i = 0; i < m; ++i) {
     PZ[i] = P[IDX(i, 0, m)];
     if (M->s0 >= 0) PZ[i] += P[IDX(i, M->s0, m)];
+    if (M->ar0 >= 0) PZ[i] += P[IDX(i, M->ar0, m)];
   }
   *F = ssm_Zdot(M, PZ) + H;
   if (*F <= 0) return BO_ERR_FORECAST_VARIANCE;
@@ -2345,6 +2418,7 @@ static void ssm_disturbance_smooth(const bo_ssm *M, const double *v,
     ssm_Tt(M, rt_1);
     rt_1[0] += coefficient;
     if (M->s0 >= 0) rt_1[M->s0] += coefficient;
+    if (M->ar0 >= 0) rt_1[M->ar0] += coefficient;
     for (int i = 0; i < m; ++i) rout[IDX(i, t, m)] = r[i];
     for (int i = 0; i < m; ++i) r[i] = rt_1[i];
   }
@@ -2367,6 +2441,13 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
   M->mv_n = 0;
   M->mv_ybar[0] = M->mv_ybar[1] = 0;
   M->mv_sumsq[0] = M->mv_sumsq[1] = 0;
+  if (M->ar0 >= 0) {
+    /* clear_client_data -> ArModel's NeRegSuf::clear */
+    for (int i = 0; i < M->ar_lags * M->ar_lags; ++i) M->ar_xtx[i] = 0;
+    for (int i = 0; i < M->ar_lags; ++i) M->ar_xty[i] = 0;
+    M->ar_yty = 0;
+    M->ar_n = 0;
+  }
 
   double a[BO_SSM_MAX], P[BO_SSM_MAX * BO_SSM_MAX];
   for (int i = 0; i < m * m; ++i) P[i] = 0;
@@ -2413,6 +2494,13 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
         for (int i = 0; i < n; ++i)
           st[M->s0 + i] = sqrt(M->P0[M->s0 + i]) * z[i] + M->a0[M->s0 + i];
       }
+      if (M->ar0 >= 0) {
+        /* StateModelBase::simulate_initial_state: rmvn_mt(mean, variance), diagonal here */
+        double z[BO_SSM_MAX];
+        for (int i = 0; i < M->ar_lags; ++i) z[i] = bo_rnorm(rng, 0, 1);
+        for (int i = 0; i < M->ar_lags; ++i)
+          st[M->ar0 + i] = sqrt(M->P0[M->ar0 + i]) * z[i] + M->a0[M->ar0 + i];
+      }
     } else {
       double eta[BO_SSM_MAX];
       for (int i = 0; i < m; ++i) eta[i] = 0;
@@ -2425,6 +2513,8 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
         eta[1] = sd_slope * z1 + 0.0;
       }
       if (M->s0 >= 0) eta[M->s0] = bo_rnorm(rng, 0, sd_seas);   /* SeasonalStateModel.cpp:141-145 */
+      /* ArStateModel::simulate_state_error, ArStateModel.cpp:85-90: rnorm_mt(rng) * sigma() */
+      if (M->ar0 >= 0) eta[M->ar0] = bo_rnorm(rng, 0, 1) * sqrt(M->ar_sigsq);
       const double *prev = M->state + (size_t)(t - 1) * m;
       for (int i = 0; i < m; ++i) st[i] = prev[i];
       ssm_T(M, st);
@@ -2487,6 +2577,17 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
         M->suf_n[2] += 1;
         M->suf_ss[2] += delta * delta;
       }
+      if (M->ar0 >= 0) {
+        /* ArStateModel::observe_state (ArStateModel.cpp:64-69): suf()->add_mixture_data(
+         * now[0], then, 1.0), NeRegSuf::add_mixture_data RegressionModel.cpp:356-370 */
+        const int L = M->ar_lags;
+        const double yy = st[M->ar0], *x = then + M->ar0;
+        for (int j = 0; j < L; ++j)
+          for (int i = 0; i < L; ++i) M->ar_xtx[IDX(i, j, L)] += x[i] * x[j] * 1.0;
+        for (int i = 0; i < L; ++i) M->ar_xty[i] += (yy * 1.0) * x[i];
+        M->ar_yty += yy * yy * 1.0;
+        M->ar_n += 1.0;
+      }
     }
     if (M->observed[t]) {
       /* observe_data_given_state, StateSpaceRegressionModel.cpp:188-200 */
@@ -2518,9 +2619,113 @@ void bo_ssm_get_suf(const bo_ssm *m, double *n, double *ss) {
   for (int i = 0; i < 3; ++i) { n[i] = m->suf_n[i]; ss[i] = m->suf_ss[i]; }
 }
 
+/* ArModel::check_stationary (Models/TimeSeries/ArModel.cpp:142-170): true if
+ * sum |phi| < 1; otherwise the reference finds the roots of 1 - phi_1 z - ... -
+ * phi_p z^p with a Jenkins-Traub solver (cpputil/Polynomial.cpp, TOMS 493) and wants
+ * them all outside the unit circle.  Restated with the equivalent step-down
+ * (Levinson) recursion: all roots lie outside the unit circle iff every partial
+ * autocorrelation has modulus < 1.  The two can only disagree when a root sits
+ * within rounding of the circle. */
+static int ar_check_stationary(int L, const double *phi) {
+  double s = 0, a[BO_SSM_MAX], b[BO_SSM_MAX];
+  for (int i = 0; i < L; ++i) s += fabs(phi[i]);
+  if (s < 1) return 1;
+  for (int i = 0; i < L; ++i) a[i] = phi[i];
+  for (int k = L; k >= 1; --k) {
+    const double r = a[k - 1];
+    if (!(fabs(r) < 1)) return 0;
+    const double den = 1 - r * r;
+    for (int j = 0; j + 1 < k; ++j) b[j] = (a[j] + r * a[k - 2 - j]) / den;
+    for (int j = 0; j + 1 < k; ++j) a[j] = b[j];
+  }
+  return 1;
+}
+int bo_test_ar_check_stationary(int L, const double *phi) { return ar_check_stationary(L, phi); }
+
+/* rtrun_norm_2_mt (distributions/trun_norm.cpp:273-325) for lo, hi finite: the two
+ * rejection samplers of the case lo < mu < hi; the tail cases build a Tn2Sampler
+ * (adaptive rejection), which is not restated: unsupported-branch error. */
+static double rtrun_norm_2(bo_rng *rng, double mu, double sigma, double lo, double hi,
+                           int *status) {
+  if (lo < mu && hi > mu) {
+    if ((hi - lo) / sigma > .5) {
+      double y = lo - 1;
+      while (y < lo || y > hi) y = bo_rnorm(rng, mu, sigma);
+      return y;
+    } else {
+      const double ln_sqrt_2pi = 0.918938533204672741780329736406;
+      const double phi_mu = -(ln_sqrt_2pi + 0.5 * 0.0 * 0.0 + log(sigma));   /* dnorm(mu, mu, sigma, true) */
+      double phi = phi_mu, u = phi + 1, y = 0;
+      while (u > phi) {
+        y = bo_runif(rng, lo, hi);
+        const double x = (y - mu) / sigma;
+        phi = -(ln_sqrt_2pi + 0.5 * x * x + log(sigma));
+        u = phi_mu - bo_rexp(rng, 1);
+      }
+      return y;
+    }
+  }
+  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  return NAN;
+}
+
+/* ArPosteriorSampler::draw_phi / draw_phi_univariate / draw_sigma,
+ * Models/TimeSeries/PosteriorSamplers/ArPosteriorSampler.cpp:91-143, :78-89 */
+static void ar_draw(bo_ssm *M, int *status) {
+  const int L = M->ar_lags;
+  double phi_hat[BO_SSM_MAX], P[BO_SSM_MAX * BO_SSM_MAX], Lc[BO_SSM_MAX * BO_SSM_MAX],
+      z[BO_SSM_MAX];
+  bo_rng *rng = &M->ar_rng;
+  if (!bo_spd_solve(L, M->ar_xtx, M->ar_xty, phi_hat)) { *status = BO_ERR_NOT_PD; return; }
+  int ok = 0, attempts = 0;
+  while (!ok && ++attempts <= 3) {
+    /* rmvn_ivar(phi_hat, xtx / sigsq), mvn.cpp:99-122: on GlobalRng::rng */
+    bo_rng *grng = M->ar_global_rng ? M->ar_global_rng : rng;
+    for (int i = 0; i < L * L; ++i) P[i] = M->ar_xtx[i] / M->ar_sigsq;
+    if (!bo_chol(L, P, Lc)) { *status = BO_ERR_NOT_PD; return; }
+    for (int i = 0; i < L; ++i) z[i] = bo_rnorm(grng, 0, 1);
+    ltsolve_inplace(L, Lc, z);
+    for (int i = 0; i < L; ++i) z[i] = z[i] + phi_hat[i];
+    ok = ar_check_stationary(L, z);
+    if (ok) for (int i = 0; i < L; ++i) M->phi[i] = z[i];
+  }
+  if (!ok) {
+    double phi[BO_SSM_MAX] = {0};
+    for (int i = 0; i < L; ++i) phi[i] = M->phi[i];
+    if (!ar_check_stationary(L, phi)) { *status = BO_ERR_INVALID; return; }
+    for (int i = 0; i < L; ++i) {
+      const double initial_phi = phi[i];
+      double lo = -1, hi = 1;
+      const double ivar = M->ar_xtx[IDX(i, i, L)];
+      double dot = 0;
+      for (int j = 0; j < L; ++j) dot += phi[j] * M->ar_xtx[IDX(j, i, L)];
+      const double mu = (M->ar_xty[i] - (dot - phi[i] * M->ar_xtx[IDX(i, i, L)])) / ivar;
+      for (;;) {
+        const double candidate = rtrun_norm_2(rng, mu, sqrt(1.0 / ivar), lo, hi, status);
+        if (*status) return;
+        phi[i] = candidate;
+        if (ar_check_stationary(L, phi)) break;
+        if (candidate > initial_phi) hi = candidate; else lo = candidate;
+      }
+    }
+    for (int i = 0; i < L; ++i) M->phi[i] = phi[i];
+  }
+  /* draw_sigma: ss = phi' xtx phi - 2 phi' xty + yty, df = n */
+  double quad = 0, lin = 0;
+  for (int i = 0; i < L; ++i) {
+    double row = 0;
+    for (int j = 0; j < L; ++j) row += M->ar_xtx[IDX(i, j, L)] * M->phi[j];
+    quad += M->phi[i] * row;
+    lin += M->phi[i] * M->ar_xty[i];
+  }
+  const double ss = quad - 2 * lin + M->ar_yty;
+  M->ar_sigsq = variance_draw(rng, M->ar_prior_df, M->ar_prior_ss, M->ar_sigma_max, M->ar_n, ss,
+                              status);
+}
+
 /* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64: the
  * regression, then each state model's samplers in order (trend: level [, slope];
- * seasonal), then impute_state */
+ * seasonal; AR), then impute_state */
 int bo_ssm_draw(bo_ssm *m) {
   int status = 0;
   if (!m->latent_initialized) {
@@ -2544,6 +2749,10 @@ int bo_ssm_draw(bo_ssm *m) {
     }
     m->sigsq[i] = draw;
   }
+  if (m->ar0 >= 0) {
+    ar_draw(m, &status);
+    if (status) return status;
+  }
   return bo_ssm_impute_state(m, &m->state_rng);
 }
 
@@ -2551,15 +2760,23 @@ int bo_ssm_draw(bo_ssm *m) {
  * (StateSpaceRegressionModel.cpp:216-219, :256-278; simulate_next_state
  * StateSpaceModelBase.cpp:439-443): newX horizon x p column-major, final_state the
  * state at the last time point (m values), sigsq = (level, slope, seasonal) */
-void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,
-                              const double *beta, double sigsq_obs, int trend, int nseasons,
-                              const double *sigsq, const double *final_state, double *out) {
+void bo_ssm_simulate_forecast_ar(bo_rng *rng, int horizon, int p, const double *newX,
+                                 const double *beta, double sigsq_obs, int trend, int nseasons,
+                                 const double *sigsq, int ar_lags, const double *phi,
+                                 double ar_sigsq, const double *final_state, double *out) {
   bo_ssm M;
   memset(&M, 0, sizeof(M));
   M.dtrend = trend;
   M.nseasons = nseasons;
   M.s0 = nseasons > 0 ? trend : -1;
   M.m = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  M.ar0 = -1;
+  if (ar_lags > 0) {
+    M.ar0 = M.m;
+    M.ar_lags = ar_lags;
+    M.m += ar_lags;
+    for (int i = 0; i < ar_lags; ++i) M.phi[i] = phi[i];
+  }
   double st[BO_SSM_MAX];
   for (int i = 0; i < M.m; ++i) st[i] = final_state[i];
   const double sd_level = sqrt(sigsq[0]), sd_slope = sqrt(sigsq[1]), sd_seas = sqrt(sigsq[2]);
@@ -2575,6 +2792,7 @@ void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *new
       eta[1] = sd_slope * z1 + 0.0;
     }
     if (M.s0 >= 0) eta[M.s0] = bo_rnorm(rng, 0, sd_seas);
+    if (M.ar0 >= 0) eta[M.ar0] = bo_rnorm(rng, 0, 1) * sqrt(ar_sigsq);
     ssm_T(&M, st);
     for (int k = 0; k < M.m; ++k) st[k] += eta[k];
     double ans = bo_rnorm(rng, ssm_Zdot(&M, st), sd_obs);
@@ -2582,6 +2800,12 @@ void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *new
     for (int j = 0; j < p; ++j) pred += newX[IDX(i, j, horizon)] * beta[j];
     out[i] = ans + pred;
   }
+}
+void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,
+                              const double *beta, double sigsq_obs, int trend, int nseasons,
+                              const double *sigsq, const double *final_state, double *out) {
+  bo_ssm_simulate_forecast_ar(rng, horizon, p, newX, beta, sigsq_obs, trend, nseasons, sigsq, 0,
+                              NULL, 0.0, final_state, out);
 }
 
 /* ====================================================================== *

@@ -96,7 +96,8 @@ enum {
   BO_ERR_NEGATIVE_SS = 2,   /* set_reg_post_params: SS < 0 or non-finite */
   BO_ERR_ILLEGAL_START = 3, /* draw_model_indicators: no legal configuration */
   BO_ERR_UNSUPPORTED_RNG_BRANCH = 4,
-  BO_ERR_FORECAST_VARIANCE = 5
+  BO_ERR_FORECAST_VARIANCE = 5,
+  BO_ERR_INVALID = 6        /* an argument or a state the reference reports as an error */
 };
 
 typedef struct bo_ssvs bo_ssvs;
@@ -225,6 +226,20 @@ bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
                       const double *var_initial_sigma,
                       const double *initial_state_mean,
                       const double *initial_state_variance);
+/* adds an ArStateModel(lags) block (+ ArPosteriorSampler) after the trend / seasonal blocks */
+int bo_ssm_add_ar(bo_ssm *m, int lags, double prior_df, double sigma_guess,
+                  double sigma_upper_limit, double initial_sigma, const double *initial_phi,
+                  const double *initial_state_mean, const double *initial_state_variance);
+bo_rng *bo_ssm_ar_rng(bo_ssm *m);
+/* MT mode: the restated GlobalRng::rng, which draw_phi's proposals use (rmvn_ivar) */
+void bo_ssm_set_global_rng(bo_ssm *m, bo_rng *global);
+void bo_ssm_get_ar(const bo_ssm *m, double *phi, double *sigsq);
+void bo_ssm_get_ar_suf(const bo_ssm *m, double *xtx, double *xty, double *yty, double *n);
+int bo_test_ar_check_stationary(int L, const double *phi);
+void bo_ssm_simulate_forecast_ar(bo_rng *rng, int horizon, int p, const double *newX,
+                                 const double *beta, double sigsq_obs, int trend, int nseasons,
+                                 const double *sigsq, int ar_lags, const double *phi,
+                                 double ar_sigsq, const double *final_state, double *out);
 void bo_ssm_destroy(bo_ssm *m);
 bo_ssvs *bo_ssm_regression(bo_ssm *m);
 bo_rng *bo_ssm_variance_rng(bo_ssm *m, int which);

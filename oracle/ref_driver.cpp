@@ -41,7 +41,9 @@
 #include "Models/MvnGivenScalarSigma.hpp"
 #include "Models/PosteriorSamplers/ZeroMeanGaussianConjSampler.hpp"
 #include "Models/StateSpace/PosteriorSamplers/StateSpacePosteriorSampler.hpp"
+#include "Models/StateSpace/StateModels/ArStateModel.hpp"
 #include "Models/StateSpace/StateModels/LocalLevelStateModel.hpp"
+#include "Models/TimeSeries/PosteriorSamplers/ArPosteriorSampler.hpp"
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
 #include "Models/PosteriorSamplers/ZeroMeanMvnIndependenceSampler.hpp"
@@ -496,17 +498,23 @@ int ref_ss_run(int T, int p, const double *y, const double *X,
 // Structural time series: regression + trend (local level or
 // local linear trend with independent variance samplers, as bsts builds it) +
 // optional seasonal state.  Three-element arrays: level, slope, seasonal.
-int ref_ssm_run(int T, int p, const double *y, const double *X,
+// ar_lags > 0 adds an ArStateModel(ar_lags) + ArPosteriorSampler after the trend /
+// seasonal blocks: ar[] = {prior df, prior sigma guess, sigma upper limit,
+// initial sigma}, initial phi ar_phi0[lags]; the block's initial state moments
+// follow the others in initial_state_mean / _variance.  out_ar: nsweeps x (lags + 1)
+// = phi, sigsq.
+static int ssm_run_impl(int T, int p, const double *y, const double *X,
                 const uint8_t *observed, const double *prior_mean,
                 const double *ominv, double prior_df, double sigma_guess,
                 const double *pi, const RefSsvsOptions *opt, int trend,
                 int nseasons, const double *var_df, const double *var_sigma_guess,
                 const double *var_sigma_upper_limit, const double *var_initial_sigma,
                 const double *initial_state_mean,
-                const double *initial_state_variance, uint64_t seed,
+                const double *initial_state_variance, int ar_lags, const double *ar,
+                const double *ar_phi0, uint64_t seed,
                 const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
                 double *out_beta, double *out_sigsq, double *out_variances,
-                double *out_state) {
+                double *out_state, double *out_ar) {
   REF_TRY
   GlobalRng::rng.seed(seed);
   std::vector<bool> obs;
@@ -585,20 +593,92 @@ int ref_ssm_run(int T, int p, const double *y, const double *X,
     model->add_state(seasonal);
   }
 
+  Ptr<ArStateModel> arm;
+  const int m0 = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  if (ar_lags > 0) {
+    arm = new ArStateModel(ar_lags);
+    arm->set_phi(make_vector(ar_lags, ar_phi0));
+    arm->set_sigma(ar[3]);
+    NEW(ChisqModel, ar_prior)(ar[0], ar[1]);
+    NEW(ArPosteriorSampler, ar_sampler)(arm.get(), ar_prior);
+    if (std::isfinite(ar[2])) ar_sampler->set_sigma_upper_limit(ar[2]);
+    arm->set_method(ar_sampler);
+    Vector a0(ar_lags);
+    SpdMatrix P0(ar_lags, 0.0);
+    for (int i = 0; i < ar_lags; ++i) {
+      a0[i] = initial_state_mean[m0 + i];
+      P0(i, i) = initial_state_variance[m0 + i];
+    }
+    arm->set_initial_state_mean(a0);
+    arm->set_initial_state_variance(P0);
+    model->add_state(arm);
+  }
+
   NEW(StateSpacePosteriorSampler, sampler)(model.get());
   model->set_method(sampler);
-  const int m = trend + (nseasons > 0 ? nseasons - 1 : 0);
+  const int m = m0 + ar_lags;
   for (int i = 0; i < nsweeps; ++i) {
     model->sample_posterior();
     record(*reg, p, i, out_gamma, out_beta, out_sigsq);
     out_variances[3 * i + 0] = trend == 1 ? level->sigsq() : llt->Sigma()(0, 0);
     out_variances[3 * i + 1] = trend == 1 ? 0.0 : llt->Sigma()(1, 1);
     out_variances[3 * i + 2] = nseasons > 0 ? seasonal->sigsq() : 0.0;
+    if (ar_lags > 0) {
+      for (int j = 0; j < ar_lags; ++j) out_ar[(size_t)i * (ar_lags + 1) + j] = arm->phi()[j];
+      out_ar[(size_t)i * (ar_lags + 1) + ar_lags] = arm->sigsq();
+    }
     const Matrix &state(model->state());
     for (int t = 0; t < T; ++t)
       for (int j = 0; j < m; ++j) out_state[((size_t)i * T + t) * m + j] = state(j, t);
   }
   REF_CATCH
+}
+
+int ref_ssm_run(int T, int p, const double *y, const double *X,
+                const uint8_t *observed, const double *prior_mean,
+                const double *ominv, double prior_df, double sigma_guess,
+                const double *pi, const RefSsvsOptions *opt, int trend,
+                int nseasons, const double *var_df, const double *var_sigma_guess,
+                const double *var_sigma_upper_limit, const double *var_initial_sigma,
+                const double *initial_state_mean,
+                const double *initial_state_variance, uint64_t seed,
+                const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                double *out_beta, double *out_sigsq, double *out_variances,
+                double *out_state) {
+  return ssm_run_impl(T, p, y, X, observed, prior_mean, ominv, prior_df, sigma_guess, pi, opt,
+                      trend, nseasons, var_df, var_sigma_guess, var_sigma_upper_limit,
+                      var_initial_sigma, initial_state_mean, initial_state_variance, 0, nullptr,
+                      nullptr, seed, init_gamma, nsweeps, out_gamma, out_beta, out_sigsq,
+                      out_variances, out_state, nullptr);
+}
+
+// ArModel::check_stationary (the quick bound, then Jenkins-Traub roots)
+int ref_ar_check_stationary(int lags, const double *phi) {
+  try {
+    return ArModel::check_stationary(make_vector(lags, phi)) ? 1 : 0;
+  } catch (...) {
+    return -1;
+  }
+}
+
+// the same with an ArStateModel block (see ssm_run_impl)
+int ref_ssm_ar_run(int T, int p, const double *y, const double *X,
+                   const uint8_t *observed, const double *prior_mean,
+                   const double *ominv, double prior_df, double sigma_guess,
+                   const double *pi, const RefSsvsOptions *opt, int trend,
+                   int nseasons, const double *var_df, const double *var_sigma_guess,
+                   const double *var_sigma_upper_limit, const double *var_initial_sigma,
+                   const double *initial_state_mean,
+                   const double *initial_state_variance, int ar_lags, const double *ar,
+                   const double *ar_phi0, uint64_t seed,
+                   const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                   double *out_beta, double *out_sigsq, double *out_variances,
+                   double *out_state, double *out_ar) {
+  return ssm_run_impl(T, p, y, X, observed, prior_mean, ominv, prior_df, sigma_guess, pi, opt,
+                      trend, nseasons, var_df, var_sigma_guess, var_sigma_upper_limit,
+                      var_initial_sigma, initial_state_mean, initial_state_variance, ar_lags, ar,
+                      ar_phi0, seed, init_gamma, nsweeps, out_gamma, out_beta, out_sigsq,
+                      out_variances, out_state, out_ar);
 }
 
 // One isolated impute_state() with fixed parameters: pins a14-a18 (filter,

@@ -89,8 +89,9 @@ def bsts_priors(X, y, expected_model_size):
     return prior, ss, sigma_upper
 
 
-def structural_data(T, p, nsig, nseasons, seed, slope=0.02, missing_frac=0.0):
-    """y = trend (random walk with drift) + seasonal pattern + X beta + noise"""
+def structural_data(T, p, nsig, nseasons, seed, slope=0.02, missing_frac=0.0, ar_coef=None):
+    """y = trend (random walk with drift) + seasonal pattern + X beta + noise
+    [+ a stationary autoregression with coefficients ar_coef, innovation sd 0.5]"""
     rng = np.random.Generator(np.random.PCG64(seed))
     X = rng.standard_normal((T, p))
     beta = np.zeros(p)
@@ -102,6 +103,15 @@ def structural_data(T, p, nsig, nseasons, seed, slope=0.02, missing_frac=0.0):
         pattern -= pattern.mean()
         seas = pattern[np.arange(T) % nseasons]
     y = level + seas + X @ beta + 0.2 * rng.standard_normal(T)
+    if ar_coef is not None:
+        # (drawn from a generator of its own: the cases without it keep their data)
+        r2 = np.random.Generator(np.random.PCG64(seed + 1000))
+        L = len(ar_coef)
+        u = np.zeros(T + 50 + L)
+        e = 0.5 * r2.standard_normal(T + 50 + L)
+        for t in range(L, len(u)):
+            u[t] = sum(ar_coef[i] * u[t - 1 - i] for i in range(L)) + e[t]
+        y = y + u[-T:]
     observed = None
     if missing_frac > 0:
         observed = (rng.random(T) >= missing_frac).astype(np.uint8)
@@ -109,15 +119,20 @@ def structural_data(T, p, nsig, nseasons, seed, slope=0.02, missing_frac=0.0):
     return X, y, beta, observed
 
 
-def structural_spec(y, trend, nseasons):
-    """bsts-style defaults (add.local.linear.trend.R, add.seasonal.R): sd priors
-    with guess 0.01 sd(y), df 0.01, upper limit sd(y); initial state N(y[0] or 0,
-    sd(y)^2).  Three-element arrays: level, slope, seasonal."""
+def structural_spec(y, trend, nseasons, ar_lags=0):
+    """bsts-style defaults (add.local.linear.trend.R, add.seasonal.R, add.ar.R): sd
+    priors with guess 0.01 sd(y), df 0.01, upper limit sd(y); initial state N(y[0] or
+    0, sd(y)^2).  Three-element arrays: level, slope, seasonal; ar_lags > 0 adds an
+    ArStateModel block (spec["ar"]) after them."""
     sdy = float(np.std(y, ddof=1))
-    m = trend + (nseasons - 1 if nseasons > 0 else 0)
+    m = trend + (nseasons - 1 if nseasons > 0 else 0) + ar_lags
     a0 = np.zeros(m)
     a0[0] = float(y[0])
-    return dict(trend=trend, nseasons=nseasons,
+    ar = None
+    if ar_lags > 0:
+        ar = dict(lags=ar_lags, df=0.01, sigma_guess=0.01 * sdy, sigma_upper_limit=sdy,
+                  initial_sigma=1.0, initial_phi=np.zeros(ar_lags))
+    return dict(trend=trend, nseasons=nseasons, ar=ar,
                 var_df=np.array([0.01, 0.01, 0.01]),
                 var_sigma_guess=np.array([0.01 * sdy] * 3),
                 var_sigma_upper_limit=np.array([sdy] * 3),

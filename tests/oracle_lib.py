@@ -189,6 +189,14 @@ class Oracle:
         L.bo_ssm_get_suf.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.bo_ssm_impute_state.argtypes = [C.c_void_p, C.c_void_p]
         L.bo_ssm_draw.argtypes = [C.c_void_p]
+        L.bo_ssm_add_ar.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, c_double_p, c_double_p, c_double_p]
+        L.bo_ssm_ar_rng.restype = C.c_void_p
+        L.bo_ssm_ar_rng.argtypes = [C.c_void_p]
+        L.bo_ssm_get_ar.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.bo_ssm_get_ar_suf.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p,
+                                        c_double_p]
+        L.bo_test_ar_check_stationary.argtypes = [C.c_int, c_double_p]
 
     # -- RNG -----------------------------------------------------------------
     def rng_mt(self, seed):
@@ -751,9 +759,19 @@ class Oracle:
         L.bo_poisson_destroy(m)
         return dict(gamma=gam, beta=beta, status=status, xtx=xtx, xty=xty)
 
-    def ssm_forecast(self, rng, newX, beta, sigsq_obs, trend, nseasons, sigsq, final_state):
+    def ssm_forecast(self, rng, newX, beta, sigsq_obs, trend, nseasons, sigsq, final_state,
+                     ar_phi=None, ar_sigsq=0.0):
         h, p = newX.shape
         out = np.zeros(h)
+        if ar_phi is not None:
+            self.lib.bo_ssm_simulate_forecast_ar.argtypes = [
+                C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.c_double, C.c_int,
+                C.c_int, c_double_p, C.c_int, c_double_p, C.c_double, c_double_p, c_double_p]
+            self.lib.bo_ssm_simulate_forecast_ar(
+                C.byref(rng), h, p, _dp(fcol(newX)), _dp(f64(beta)), float(sigsq_obs),
+                int(trend), int(nseasons), _dp(f64(sigsq)), len(ar_phi), _dp(f64(ar_phi)),
+                float(ar_sigsq), _dp(f64(final_state)), _dp(out))
+            return out
         self.lib.bo_ssm_simulate_forecast.argtypes = [
             C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.c_double, C.c_int, C.c_int,
             c_double_p, c_double_p, c_double_p]
@@ -776,6 +794,15 @@ class Oracle:
             _dp(f64(spec["var_sigma_guess"])), _dp(f64(spec["var_sigma_upper_limit"])),
             _dp(f64(spec["var_initial_sigma"])), _dp(f64(spec["initial_state_mean"])),
             _dp(f64(spec["initial_state_variance"])))
+        ar = spec.get("ar")
+        m0 = self.lib.bo_ssm_state_dimension(m)
+        if ar:
+            rc = self.lib.bo_ssm_add_ar(
+                m, int(ar["lags"]), float(ar["df"]), float(ar["sigma_guess"]),
+                float(ar["sigma_upper_limit"]), float(ar["initial_sigma"]),
+                _dp(f64(ar["initial_phi"])), _dp(f64(spec["initial_state_mean"][m0:])),
+                _dp(f64(spec["initial_state_variance"][m0:])))
+            assert rc == 0
         dim = self.lib.bo_ssm_state_dimension(m)
         reg = self.lib.bo_ssm_regression(m)
         self.lib.bo_ssvs_set_options(reg, opts["max_model_size"],
@@ -790,9 +817,14 @@ class Oracle:
             # construction order: regression, variance samplers, state
             rngs = ([self.lib.bo_ssvs_rng(reg)]
                     + [self.lib.bo_ssm_variance_rng(m, w) for w in which]
+                    + ([self.lib.bo_ssm_ar_rng(m)] if ar else [])
                     + [self.lib.bo_ssm_state_rng(m)])
             for rp in rngs:
                 self.lib.bo_rng_seed_mt(rp, self.lib.bo_seed_rng(C.byref(glob)))
+            if ar:
+                # (ArPosteriorSampler::draw_phi proposes with rmvn_ivar: GlobalRng::rng)
+                self.lib.bo_ssm_set_global_rng.argtypes = [C.c_void_p, C.c_void_p]
+                self.lib.bo_ssm_set_global_rng(m, C.byref(glob))
         else:
             seed, chain = int(rng_setup[1]), int(rng_setup[2])
             self.lib.bo_rng_seed_philox(self.lib.bo_ssvs_rng(reg), seed, chain, 0, 0)
@@ -800,6 +832,10 @@ class Oracle:
                 self.lib.bo_rng_seed_philox(self.lib.bo_ssm_variance_rng(m, w), seed,
                                             chain, sid, 0)
             self.lib.bo_rng_seed_philox(self.lib.bo_ssm_state_rng(m), seed, chain, 2, 0)
+            self.lib.bo_rng_seed_philox(self.lib.bo_ssm_ar_rng(m), seed, chain, 12, 0)
+        nlag = int(ar["lags"]) if ar else 0
+        ar_phi = np.zeros((nsweeps, nlag))
+        ar_sig = np.zeros(nsweeps)
         gam = np.zeros((nsweeps, p), dtype=np.uint8)
         beta = np.zeros((nsweeps, p))
         sig = np.zeros(nsweeps)
@@ -819,9 +855,13 @@ class Oracle:
             sig[i] = s.value
             self.lib.bo_ssm_get_variances(m, _dp(var[i]))
             state[i] = np.ctypeslib.as_array(self.lib.bo_ssm_state(m), (T, dim))
+            if ar:
+                sa = C.c_double()
+                self.lib.bo_ssm_get_ar(m, _dp(ar_phi[i]), C.byref(sa))
+                ar_sig[i] = sa.value
         self.lib.bo_ssm_destroy(m)
         return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, state=state,
-                    status=status)
+                    status=status, ar_phi=ar_phi, ar_sigsq=ar_sig)
 
     def ss_impute_state(self, y, X, observed, beta, gamma, sigsq_obs,
                         sigsq_level, a0, P0, rng):
@@ -1192,6 +1232,9 @@ class Ref:
         T, p = X.shape
         trend, ns = int(spec["trend"]), int(spec["nseasons"])
         dim = trend + (ns - 1 if ns > 0 else 0)
+        if spec.get("ar"):
+            return self._ssm_ar_run(y, X, observed, prior, opts, spec, seed, init_gamma,
+                                    nsweeps)
         gam = np.zeros((nsweeps, p), dtype=np.uint8)
         beta = np.zeros((nsweeps, p))
         sig = np.zeros(nsweeps)
@@ -1211,6 +1254,35 @@ class Ref:
             C.c_uint64(seed), _u8(g0), nsweeps, _u8(gam), _dp(beta), _dp(sig),
             _dp(var), _dp(state)))
         return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, state=state)
+
+    def _ssm_ar_run(self, y, X, observed, prior, opts, spec, seed, init_gamma, nsweeps):
+        T, p = X.shape
+        trend, ns, ar = int(spec["trend"]), int(spec["nseasons"]), spec["ar"]
+        L = int(ar["lags"])
+        dim = trend + (ns - 1 if ns > 0 else 0) + L
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        var = np.zeros((nsweeps, 3))
+        state = np.zeros((nsweeps, T, dim))
+        out_ar = np.zeros((nsweeps, L + 1))
+        o = self._opts(opts)
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        arv = f64([ar["df"], ar["sigma_guess"], ar["sigma_upper_limit"], ar["initial_sigma"]])
+        self._check(self.lib.ref_ssm_ar_run(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
+            C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])), C.byref(o),
+            trend, ns, _dp(f64(spec["var_df"])), _dp(f64(spec["var_sigma_guess"])),
+            _dp(f64(spec["var_sigma_upper_limit"])), _dp(f64(spec["var_initial_sigma"])),
+            _dp(f64(spec["initial_state_mean"])), _dp(f64(spec["initial_state_variance"])),
+            L, _dp(arv), _dp(f64(ar["initial_phi"])),
+            C.c_uint64(seed), _u8(g0), nsweeps, _u8(gam), _dp(beta), _dp(sig),
+            _dp(var), _dp(state), _dp(out_ar)))
+        return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, state=state,
+                    ar_phi=out_ar[:, :L].copy(), ar_sigsq=out_ar[:, L].copy())
 
     def ss_forecast(self, y, X, beta, gamma, sigsq_obs, sigsq_level, final_state,
                     newX, seed):

@@ -313,6 +313,55 @@ def test_structural_sweeps_match_reference(oracle, name):
     assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
 
 
+def ar_spec_of(g):
+    return dict(trend=int(g["trend"]), nseasons=int(g["nseasons"]), var_df=g["var_df"],
+                var_sigma_guess=g["var_sigma_guess"],
+                var_sigma_upper_limit=g["var_sigma_upper_limit"],
+                var_initial_sigma=g["var_initial_sigma"],
+                initial_state_mean=g["initial_state_mean"],
+                initial_state_variance=g["initial_state_variance"],
+                ar=dict(lags=int(g["ar_lags"]), df=float(g["ar_df"]),
+                        sigma_guess=float(g["ar_sigma_guess"]),
+                        sigma_upper_limit=float(g["ar_sigma_upper_limit"]),
+                        initial_sigma=float(g["ar_initial_sigma"]),
+                        initial_phi=g["ar_initial_phi"]))
+
+
+@pytest.mark.parametrize("name", ["ssm_level_ar1", "ssm_trend_seasonal4_ar2_missing",
+                                  "ssm_level_ar3"])
+def test_structural_ar_sweeps_match_reference(oracle, name):
+    """f2: an ArStateModel block + ArPosteriorSampler after the trend / seasonal state.
+    In the second and third case many of the accepted coefficient vectors have
+    sum |phi| >= 1, where the reference decides stationarity by finding roots and the
+    oracle by the step-down recursion."""
+    g = load(name)
+    spec = ar_spec_of(g)
+    trend, ns = spec["trend"], spec["nseasons"]
+    obs = g["observed"]
+    o = oracle.ssm_run(g["y"], g["X"], None if obs.all() else obs, prior_of(g), opts_of(g),
+                       spec, ("mt", int(g["seed"])), g["init_gamma"], int(g["nsweeps"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < RTOL
+    assert relerr(o["sigsq"], g["sigsq"]) < RTOL
+    idx = [0] + ([1] if trend == 2 else []) + ([2] if ns > 0 else [])
+    assert relerr(o["variances"][:, idx], g["variances"][:, idx], 1e-300) < RTOL
+    assert relerr(o["ar_phi"], g["ar_phi"]) < RTOL
+    assert relerr(o["ar_sigsq"], g["ar_sigsq"], 1e-300) < RTOL
+    assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
+
+
+def test_ar_stationarity_known_answers(oracle):
+    """ArModel::check_stationary on 400 coefficient vectors with sum |phi| around and
+    above 1 (lags 1..8): the step-down recursion decides as the reference's root finder"""
+    g = load("kat_ar_stationary")
+    for phi, L, want in zip(g["phi"], g["lags"], g["stationary"]):
+        v = np.ascontiguousarray(phi[:L])
+        got = oracle.lib.bo_test_ar_check_stationary(int(L), v.ctypes.data_as(
+            __import__("ctypes").POINTER(__import__("ctypes").c_double)))
+        assert got == want, (phi[:L], want)
+
+
 def test_structural_forecast_known_answers(oracle):
     g = load("kat_structural_forecast")
     for trend, ns in g["shapes"]:
