@@ -124,6 +124,9 @@ SIGNATURES = {
     "ba_poisson_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_set_structural": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_dp] * 6),
     "ba_ss_get_structural": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
+    "ba_ss_add_ar": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
+                               C.c_double, _dp, _dp, _dp]),
+    "ba_ss_get_ar": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_impute_state": (C.c_int, [C.c_void_p]),
     "ba_ss_forecast": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
@@ -505,8 +508,32 @@ class Engine:
                 (var_df, var_sigma_guess, var_sigma_upper_limit, var_initial_sigma,
                  initial_state_mean, initial_state_variance)]
         self._ssm_dim = int(trend) + (int(nseasons) - 1 if nseasons > 0 else 0)
+        self._ar_lags = 0
         self._check(self.lib.ba_ss_set_structural(self._h, int(trend), int(nseasons),
                                                   *[_p(a) for a in arrs]))
+
+    def ss_add_ar(self, lags, df, sigma_guess, sigma_upper_limit, initial_sigma, initial_phi,
+                  initial_state_mean, initial_state_variance):
+        """appends an ArStateModel(lags) block (+ ArPosteriorSampler) to the structural state"""
+        ph = (None if initial_phi is None
+              else np.ascontiguousarray(initial_phi, dtype=np.float64))
+        a0 = np.ascontiguousarray(initial_state_mean, dtype=np.float64)
+        p0 = np.ascontiguousarray(initial_state_variance, dtype=np.float64)
+        if a0.shape != (lags,) or p0.shape != (lags,) or (ph is not None and ph.shape != (lags,)):
+            raise ValueError("the block's initial moments and coefficients have `lags` entries")
+        self._check(self.lib.ba_ss_add_ar(self._h, int(lags), float(df), float(sigma_guess),
+                                          float(sigma_upper_limit), float(initial_sigma),
+                                          _p(ph) if ph is not None else None, _p(a0), _p(p0)))
+        self._ssm_dim += int(lags)
+        self._ar_lags = int(lags)
+
+    def ss_get_ar(self, chain):
+        L = self._ar_lags
+        phi, xtx, xty = np.zeros(L), np.zeros((L, L)), np.zeros(L)
+        sig, yty, n = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.ba_ss_get_ar(self._h, chain, _p(phi), C.byref(sig), _p(xtx), _p(xty),
+                                          C.byref(yty), C.byref(n)))
+        return dict(phi=phi, sigsq=sig.value, xtx=xtx, xty=xty, yty=yty.value, n=n.value)
 
     def ss_get_structural(self, chain):
         st = np.zeros((self.T, self._ssm_dim))

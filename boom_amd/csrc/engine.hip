@@ -351,6 +351,10 @@ struct ba_engine {
   SsmParams ssm{};                 // the host's copy of the specification (device pointers filled per launch)
   double ssm_initial_sigsq[3] = {1, 1, 1};
   DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;
+  // the structural state's ArStateModel block (ssm.ar_lags > 0)
+  double ar_initial_sigsq = 1.0, ar_initial_phi[SSM_MAX] = {};
+  DevBuf<double> dar_phi, dar_sigsq, dar_suf;
+  DevBuf<uint64_t> dpos_ar;
   DevBuf<uint64_t> dpos_var;
 };
 
@@ -822,9 +826,9 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
   }
 }
 
-// per chain: K (m T) | state (m T) | smoothed disturbances (3 T) | normals (<= 4 T + m + 1)
+// per chain: K (m T) | state (m T) | smoothed disturbances (4 T) | normals (<= 5 T + m + 1)
 int64_t ssm_work_stride(const ba_engine &e) {
-  return (int64_t)(2 * e.ssm.m + 3 + 4) * e.T + 64;
+  return (int64_t)(2 * e.ssm.m + 4 + 5) * e.T + 64;
 }
 
 void fill_ss_params(ba_engine *e, SsParams &S) {
@@ -871,6 +875,10 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
     S.ssm.var_n = e->dssm_n.ptr;
     S.ssm.var_ss = e->dssm_ss.ptr;
     S.ssm.pos_var = e->dpos_var.ptr;
+    S.ssm.ar_phi = e->dar_phi.ptr;
+    S.ssm.ar_sigsq = e->dar_sigsq.ptr;
+    S.ssm.ar_suf = e->dar_suf.ptr;
+    S.ssm.pos_ar = e->dpos_ar.ptr;
     S.ssm.work = e->dssm_work.ptr;
     S.ssm.work_stride = ssm_work_stride(*e);
   }
@@ -2652,6 +2660,19 @@ static int ss_prepare(ba_engine *e) {
       HIP_TRY(hipMemsetAsync(e->dssm_ss.ptr, 0, C * 3 * 8, s));
       HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * 3 * 8, s));
       HIP_TRY(hipMemsetAsync(e->dssm_work.ptr, 0, C * (size_t)ssm_work_stride(*e) * 8, s));
+      if (e->ssm.ar_lags > 0) {
+        HIP_TRY(e->dar_phi.resize(C * SSM_MAX));
+        HIP_TRY(e->dar_sigsq.resize(C));
+        HIP_TRY(e->dar_suf.resize(C * AR_SUF_STRIDE));
+        HIP_TRY(e->dpos_ar.resize(C));
+        std::vector<double> ph(C * SSM_MAX, 0.0), sg(C, e->ar_initial_sigsq);
+        for (size_t c = 0; c < C; ++c)
+          for (int i = 0; i < e->ssm.ar_lags; ++i) ph[c * SSM_MAX + i] = e->ar_initial_phi[i];
+        HIP_TRY(hipMemcpy(e->dar_phi.ptr, ph.data(), ph.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->dar_sigsq.ptr, sg.data(), C * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemsetAsync(e->dar_suf.ptr, 0, C * AR_SUF_STRIDE * 8, s));
+        HIP_TRY(hipMemsetAsync(e->dpos_ar.ptr, 0, C * 8, s));
+      }
     }
     HIP_TRY(hipStreamSynchronize(s));  // (the host vectors above go out of scope)
     e->ss_initialized = false;
@@ -2753,10 +2774,86 @@ int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons, const do
     q.a0[i] = initial_state_mean[i];
     q.P0[i] = initial_state_variance[i];
   }
+  q.ar_lags = 0;
+  q.ar0 = m;
   e->ssm = q;
   e->ssm_set = true;
   e->ss_level_set = false;
   e->dss_scratch.release();
+  return BA_OK;
+}
+
+int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess,
+                 double sigma_upper_limit, double initial_sigma, const double *initial_phi,
+                 const double *initial_state_mean, const double *initial_state_variance) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  MUTATE(e);
+  if (!e->ssm_set) return fail(BA_E_STATE, "call ba_ss_set_structural first");
+  if (e->ssm.ar_lags > 0) return fail(BA_E_STATE, "the state already has an autoregression block");
+  if (!initial_state_mean || !initial_state_variance) return fail(BA_E_INVALID, "null argument");
+  if (lags < 1) return fail(BA_E_INVALID, "lags must be positive");
+  if (e->ssm.m + lags > SSM_MAX) return fail(BA_E_INVALID, "state dimension exceeds 16");
+  if (sigma_upper_limit < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
+  if (!(initial_sigma > 0)) return fail(BA_E_INVALID, "initial sigma must be positive");
+  if (initial_phi) {
+    // ArModel's constructor: "Attempt to initialize ArModel with an illegal value of the
+    // autoregression coefficients." (the quick bound, then the step-down recursion)
+    double a[SSM_MAX], b[SSM_MAX], sum = 0;
+    for (int i = 0; i < lags; ++i) { a[i] = initial_phi[i]; sum += std::fabs(a[i]); }
+    bool ok = sum < 1;
+    if (!ok) {
+      ok = true;
+      for (int k = lags; k >= 1 && ok; --k) {
+        const double r = a[k - 1];
+        if (!(std::fabs(r) < 1)) { ok = false; break; }
+        for (int j = 0; j + 1 < k; ++j) b[j] = (a[j] + r * a[k - 2 - j]) / (1 - r * r);
+        for (int j = 0; j + 1 < k; ++j) a[j] = b[j];
+      }
+    }
+    if (!ok) return fail(BA_E_INVALID, "the initial autoregression coefficients are not stationary");
+  }
+  SsmParams &q = e->ssm;
+  for (int i = 0; i < lags; ++i) {
+    if (!(initial_state_variance[i] > 0.0)) return fail(BA_E_INVALID, "initial state variances must be positive");
+  }
+  q.ar0 = q.m;
+  q.ar_lags = lags;
+  for (int i = 0; i < lags; ++i) {
+    q.a0[q.m + i] = initial_state_mean[i];
+    q.P0[q.m + i] = initial_state_variance[i];
+    e->ar_initial_phi[i] = initial_phi ? initial_phi[i] : 0.0;
+  }
+  q.m += lags;
+  // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
+  q.ar_prior_df = 2 * (prior_df / 2.0);
+  q.ar_prior_ss = 2 * (prior_df * sigma_guess * sigma_guess / 2.0);
+  q.ar_sigma_max = sigma_upper_limit;
+  e->ar_initial_sigsq = initial_sigma * initial_sigma;
+  e->dss_scratch.release();
+  return BA_OK;
+}
+
+int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq, double *suf_xtx,
+                 double *suf_xty, double *suf_yty, double *suf_n) {
+  ENGINE_PROLOGUE(e);
+  if (!e->ss_mode || !e->ssm_set || e->ssm.ar_lags == 0 || e->dar_phi.count == 0)
+    return fail(BA_E_STATE, "no structural run with an autoregression block yet");
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const int L = e->ssm.ar_lags;
+  if (phi) HIP_TRY(hipMemcpy(phi, e->dar_phi.ptr + chain * SSM_MAX, (size_t)L * 8, hipMemcpyDeviceToHost));
+  if (sigsq) HIP_TRY(hipMemcpy(sigsq, e->dar_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost));
+  if (suf_xtx || suf_xty || suf_yty || suf_n) {
+    std::vector<double> suf(AR_SUF_STRIDE);
+    HIP_TRY(hipMemcpy(suf.data(), e->dar_suf.ptr + chain * AR_SUF_STRIDE, AR_SUF_STRIDE * 8, hipMemcpyDeviceToHost));
+    if (suf_xtx)
+      for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) suf_xtx[(size_t)j * L + i] = suf[(size_t)i * SSM_MAX + j];
+    if (suf_xty) std::memcpy(suf_xty, &suf[AR_SUF_XTY], (size_t)L * 8);
+    if (suf_yty) *suf_yty = suf[AR_SUF_YTY];
+    if (suf_n) *suf_n = suf[AR_SUF_N];
+  }
   return BA_OK;
 }
 

@@ -9,15 +9,26 @@ namespace boom_amd {
 
 // Structural state (ssm_kernel.hip): trend block (local level, or local linear
 // trend) + optional seasonal block; state dimension m <= SSM_MAX.  Variance
-// parameters are indexed 0 level, 1 slope, 2 seasonal.
+// parameters are indexed 0 level, 1 slope, 2 seasonal.  An ArStateModel block
+// (ar_lags coefficients, one error variance, its own sampler) may follow.
 enum { SSM_MAX = 16 };
+// a chain's ArModel sufficient statistics: xtx (lags x lags at leading dimension
+// SSM_MAX) | xty | yty | n
+enum { AR_SUF_XTY = SSM_MAX * SSM_MAX, AR_SUF_YTY = AR_SUF_XTY + SSM_MAX, AR_SUF_N = AR_SUF_YTY + 1,
+       AR_SUF_STRIDE = AR_SUF_N + 1 };
 struct SsmParams {
   int32_t m, trend, nseasons, s0;       // s0: first index of the seasonal block (-1: none)
+  int32_t ar_lags, ar0;                 // the autoregression block: size (0: none), first index
   double prior_df[3], prior_ss[3], sigma_max[3];
+  double ar_prior_df, ar_prior_ss, ar_sigma_max;
   double a0[SSM_MAX], P0[SSM_MAX];      // initial state mean, variance (diagonal)
   double *var_sigsq, *var_n, *var_ss;   // chains x 3
   uint64_t *pos_var;                    // chains x 3: streams 1, 6, 7
-  // per chain: gains K (m x T) | state (m x T) | smoothed disturbances (3 x T) | normals
+  double *ar_phi;                       // chains x SSM_MAX
+  double *ar_sigsq;                     // chains
+  double *ar_suf;                       // chains x AR_SUF_STRIDE
+  uint64_t *pos_ar;                     // chains: stream 12 (the ArPosteriorSampler)
+  // per chain: gains K (m x T) | state (m x T) | smoothed disturbances (4 x T) | normals
   double *work;
   int64_t work_stride;
 };

@@ -2,7 +2,8 @@
 // StateSpacePosteriorSampler::draw() when the state is a trend block
 // (LocalLevelStateModel, or LocalLinearTrendStateModel with one
 // ZeroMeanMvnIndependenceSampler per variance) plus an optional
-// SeasonalStateModel(nseasons, season_duration = 1).  SURVEY 8f row f2.
+// SeasonalStateModel(nseasons, season_duration = 1) and an optional
+// ArStateModel(lags) with its ArPosteriorSampler.  SURVEY 8f row f2.
 //
 //   state model samplers                 (ZeroMeanGaussianConjSampler.cpp:57-60,
 //                                         ZeroMeanMvnIndependenceSampler.cpp:63-70)
@@ -15,12 +16,16 @@
 //     Base::propagate_disturbances       (:858-891), fast_disturbance_smooth
 //                                          (ScalarKalmanFilter.cpp:168-196)
 //     observe_state (LocalLevelStateModel.cpp:52-58, LocalLinearTrend.cpp:53-63,
-//                    SeasonalStateModel.cpp:74-86), observe_data_given_state
+//                    SeasonalStateModel.cpp:74-86, ArStateModel.cpp:64-69),
+//     observe_data_given_state
+//   ArPosteriorSampler::draw             (ArPosteriorSampler.cpp:52-143)
 //
-// State vector [trend (1 or 2) | seasonal (nseasons - 1)], dimension m <= 16.
+// State vector [trend (1 or 2) | seasonal (nseasons - 1) | autoregression (lags)],
+// dimension m <= 16.
 //   Z    ones at the first element of each block
-//   T    trend [1] or [[1, 1], [0, 1]]; seasonal: first row -1, ones below the diagonal
-//   RQR  diagonal: level, slope and the seasonal block's first element
+//   T    trend [1] or [[1, 1], [0, 1]]; seasonal: first row -1, ones below the diagonal;
+//        autoregression: first row phi, ones below the diagonal
+//   RQR  diagonal: level, slope and the first element of the seasonal / autoregression block
 // One chain per workgroup of two wavefronts: both share the adjusted
 // observations and the sweep's normals (stream_normals.h), then wave 0 runs the
 // three passes over time.  Lane j < m holds component j of every state-sized
@@ -70,7 +75,9 @@ __device__ __forceinline__ double row_total(double x) {
 // the structure of the transition matrix
 struct Shape {
   int m, trend, s0, ns;   // ns: size of the seasonal block (0: none)
+  int a0, na;             // the autoregression block: first index, size (0: none)
   __device__ __forceinline__ bool seasonal(int i) const { return ns > 0 && i >= s0 && i < s0 + ns; }
+  __device__ __forceinline__ bool ar(int i) const { return na > 0 && i >= a0 && i < a0 + na; }
 };
 
 // The seasonal block is kept in a ROTATING layout: logical component i at time
@@ -88,8 +95,10 @@ __device__ __forceinline__ int cursor_prev(int c, int ns) { return c == 0 ? ns -
 
 // y = T x for a vector held one component per lane; c: cursor of x's layout (the
 // result is in the next step's layout)
-template <int TREND, bool SEAS>
-__device__ __forceinline__ double vecT(const Shape &S, double x, int lane, int c) {
+// The autoregression block keeps its logical order (lane a0 + i = lag i); phl: this
+// lane's coefficient (0 outside the block).
+template <int TREND, bool SEAS, bool AR>
+__device__ __forceinline__ double vecT(const Shape &S, double x, int lane, int c, double phl) {
   double y = x;
   if (TREND == 2) {
     const double x1 = rl(x, 1);
@@ -99,11 +108,17 @@ __device__ __forceinline__ double vecT(const Shape &S, double x, int lane, int c
     const double tot = row_total(S.seasonal(lane) ? x : 0.0);
     if (lane == S.s0 + cursor_prev(c, S.ns)) y = -tot;
   }
+  if (AR) {
+    // new[0] = phi'old, new[i] = old[i - 1]  (AutoRegressionTransitionMatrix, SparseMatrix.cpp:1261-1310)
+    const double tot = row_total(phl * x);
+    const double below = sdpp<0x111, 0xf>(x, 0.0);   // row_shr:1
+    if (S.ar(lane)) y = (lane == S.a0) ? tot : below;
+  }
   return y;
 }
 // y = T' x; c1: cursor of x's layout (the result is in the previous step's)
-template <int TREND, bool SEAS>
-__device__ __forceinline__ double vecTt(const Shape &S, double x, int lane, int c1) {
+template <int TREND, bool SEAS, bool AR>
+__device__ __forceinline__ double vecTt(const Shape &S, double x, int lane, int c1, double phl) {
   double y = x;
   if (TREND == 2) {
     const double x0 = rl(x, 0);
@@ -113,13 +128,20 @@ __device__ __forceinline__ double vecTt(const Shape &S, double x, int lane, int 
     const double first = rl(x, S.s0 + c1);
     if (S.seasonal(lane)) y = (lane == S.s0 + c1) ? -first : x - first;
   }
+  if (AR) {
+    // out[i] = phi_i x[0] + x[i + 1]  (Tmult, SparseMatrix.cpp:1286-1295)
+    const double first = rl(x, S.a0);
+    const double above = sdpp<0x101, 0xf>(x, 0.0);   // row_shl:1
+    if (S.ar(lane)) y = phl * first + ((lane + 1 < S.a0 + S.na) ? above : 0.0);
+  }
   return y;
 }
 // Z'x, c: cursor of x's layout
-template <bool SEAS>
+template <bool SEAS, bool AR>
 __device__ __forceinline__ double zdot(const Shape &S, double x, int c) {
   double a = rl(x, 0);
   if (SEAS) a += rl(x, S.s0 + c);
+  if (AR) a += rl(x, S.a0);
   return a;
 }
 // a block of `n` doubles between HBM and LDS, by one wave
@@ -133,11 +155,220 @@ __device__ __forceinline__ void blk_store(double *g, const double *lds, int n, i
   __builtin_amdgcn_wave_barrier();
 }
 
+// ---- ArPosteriorSampler::draw for one chain, by one (whole) wave.  Vectors sit one
+// component per lane (lane i < L), the L x L matrices in LDS at leading dimension
+// SSM_MAX; every lane reads the same random numbers.
+struct ArLds {
+  double X[SSM_MAX * SSM_MAX];    // xtx
+  double Lc[SSM_MAX * SSM_MAX];   // chol(xtx)
+  double Lp[SSM_MAX * SSM_MAX];   // chol(xtx / sigsq)
+};
+// lower Cholesky factor of `scale` * A (A symmetric, full storage); false: not positive definite
+__device__ __forceinline__ bool ar_chol(const double *A, double scale, double *Lc, int L, int lane) {
+  for (int j = 0; j < L; ++j) {
+    double sacc = 0.0;
+    if (lane >= j && lane < L) {
+      sacc = A[lane * SSM_MAX + j] * scale;
+      for (int k = 0; k < j; ++k) sacc -= Lc[lane * SSM_MAX + k] * Lc[j * SSM_MAX + k];
+    }
+    const double djj = rl(sacc, j);
+    if (!(djj > 0.0)) return false;
+    const double d = sqrt(djj);
+    if (lane == j) Lc[j * SSM_MAX + j] = d;
+    else if (lane > j && lane < L) Lc[lane * SSM_MAX + j] = sacc / d;
+    __builtin_amdgcn_wave_barrier();
+  }
+  return true;
+}
+// x: Lc x = b
+__device__ __forceinline__ double ar_lsolve(const double *Lc, double b, int L, int lane) {
+  double x = 0.0;
+  for (int i = 0; i < L; ++i) {
+    const double tot = row_total((lane < i) ? Lc[i * SSM_MAX + lane] * x : 0.0);
+    const double xi = (rl(b, i) - tot) / Lc[i * SSM_MAX + i];
+    if (lane == i) x = xi;
+  }
+  return x;
+}
+// x: Lc' x = b
+__device__ __forceinline__ double ar_ltsolve(const double *Lc, double b, int L, int lane) {
+  double x = 0.0;
+  for (int i = L - 1; i >= 0; --i) {
+    const double tot = row_total((lane > i && lane < L) ? Lc[lane * SSM_MAX + i] * x : 0.0);
+    const double xi = (rl(b, i) - tot) / Lc[i * SSM_MAX + i];
+    if (lane == i) x = xi;
+  }
+  return x;
+}
+// ArModel::check_stationary (ArModel.cpp:142-170).  The quick bound sum |phi| < 1,
+// then -- where the reference finds the polynomial's roots (Jenkins-Traub) -- the
+// equivalent step-down recursion: every partial autocorrelation inside (-1, 1).
+__device__ __forceinline__ bool ar_stationary(double a, int L, int lane) {
+  if (row_total((lane < L) ? fabs(a) : 0.0) < 1.0) return true;
+  for (int k = L; k >= 1; --k) {
+    const double r = rl(a, k - 1);
+    if (!(fabs(r) < 1.0)) return false;
+    const double den = 1.0 - r * r;
+    const int src = k - 2 - lane;
+    const double rev = __shfl(a, src < 0 ? 0 : src);
+    if (lane < k - 1) a = (a + r * rev) / den;
+  }
+  return true;
+}
+// Tn2Sampler (distributions/Tn2Sampler.cpp:25-131): adaptive rejection sampling of a
+// standard normal on [lo, hi] under the hull of tangents at the points x (logf =
+// -x^2/2).  As in d_ars_gamma_tail the hull lives across the wave: lane i holds
+// point i (abscissa, log density, slope, cdf) and knot i; lane n holds the last knot,
+// so up to 63 points.  Every lane of the wave must be active.  Restated as written,
+// update_cdf's increment (exp(y - y0) / d) * expm1(d * knots[k + 1] - knots[k]) included.
+__device__ __noinline__ double ar_tn2_draw(SeqRng &rng, double lo, double hi, int *bad) {
+  const int lane = (int)(threadIdx.x & 63);
+  int n = 2;
+  double xs = (lane == 0) ? lo : hi;   // (lanes past n - 1 hold copies of the last point)
+  double ys = -.5 * xs * xs, ds = -xs, kn = 0.0, cdf = 0.0;
+  for (int level = 0; level <= 1001; ++level) {
+    // refresh_knots: knots[0] = x[0], knots[n] = x[n - 1], compute_knot in between
+    {
+      const double x1 = __shfl_up(xs, 1), y1 = __shfl_up(ys, 1), d1 = __shfl_up(ds, 1);
+      double ans = (y1 - d1 * x1) - (ys - ds * xs);
+      ans /= (ds - d1);
+      kn = (lane == 0) ? xs : ((lane >= n) ? x1 : ans);
+    }
+    // update_cdf
+    {
+      const double y0 = ars_lane(ys, 0);
+      const double knext = __shfl_down(kn, 1);
+      const double y = ys + ds * (kn - xs);
+      const double inc = (fabs(ds) < .00000000001) ? exp(y - y0) * (knext - kn)
+                                                  : (exp(y - y0) / ds) * expm1(ds * knext - kn);
+      double last = 0.0;
+      for (int k = 0; k < n; ++k) {
+        const double ik = ars_lane(inc, k);
+        last = (k == 0) ? ik : last + ik;
+        if (lane == k) cdf = last;
+      }
+    }
+    const double u = d_runif(rng, 0.0, ars_lane(cdf, n - 1));
+    const int k = ars_lower_bound(cdf, n, u);
+    if (k >= n) break;   // (past the end of cdf in the reference)
+    const double klo = ars_lane(kn, k), khi = ars_lane(kn, k + 1);
+    const double dk = ars_lane(ds, k);
+    const double lam = -1 * dk;
+    double cand;
+    if (lam == 0 || fabs(khi - klo) < 1.4901161193847656e-08) cand = d_runif(rng, klo, khi);   // sqrt(epsilon)
+    else cand = d_rtrun_exp(rng, lam, klo, khi);
+    const double target = -.5 * cand * cand;
+    const double logu = (ars_lane(ys, k) + dk * (cand - ars_lane(xs, k))) - d_rexp(rng, 1.0);
+    if (logu < target) return cand;
+    // add_point (an error in the reference when the candidate left [x[0], x.back()])
+    if (cand > ars_lane(xs, n - 1) || cand < ars_lane(xs, 0) || n >= 63) break;
+    const int pos = ars_lower_bound(xs, n, cand);
+    {
+      const double xu = __shfl_up(xs, 1), yu = __shfl_up(ys, 1), du = __shfl_up(ds, 1);
+      if (lane > pos) { xs = xu; ys = yu; ds = du; }
+      if (lane == pos) { xs = cand; ys = target; ds = -cand; }
+    }
+    ++n;
+  }
+  *bad = 1;
+  return 0.0;
+}
+// rtrun_norm_2_mt (trun_norm.cpp:273-325), lo and hi finite: the two rejection samplers
+// of lo < mu < hi, the Tn2Sampler in the tails
+__device__ __forceinline__ double ar_rtrun_norm_2(SeqRng &rng, double mu, double sigma, double lo, double hi,
+                                                  int *bad) {
+  if (lo < mu && hi > mu) {
+    if ((hi - lo) / sigma > .5) {
+      double y = lo - 1;
+      while (y < lo || y > hi) y = d_rnorm(rng, mu, sigma);
+      return y;
+    }
+    const double ln_sqrt_2pi = 0.918938533204672741780329736406;
+    const double phi_mu = -(ln_sqrt_2pi + 0.5 * 0.0 * 0.0 + log(sigma));
+    double phi = phi_mu, u = phi + 1, y = 0;
+    while (u > phi) {
+      y = d_runif(rng, lo, hi);
+      const double x = (y - mu) / sigma;
+      phi = -(ln_sqrt_2pi + 0.5 * x * x + log(sigma));
+      u = phi_mu - d_rexp(rng, 1.0);
+    }
+    return y;
+  }
+  hi = (hi - mu) / sigma;
+  lo = (lo - mu) / sigma;
+  if (hi < 0) {
+    // (the reference recurses with (0, 1, -hi, -lo), which lands in its Tn2Sampler)
+    const double y = ar_tn2_draw(rng, -hi, -lo, bad);
+    return mu - sigma * y;
+  }
+  const double y = ar_tn2_draw(rng, lo, hi, bad);
+  return y * sigma + mu;
+}
+// draw_phi (up to three multivariate proposals, else one coefficient at a time) and
+// draw_sigma.  phi_l: the lane's coefficient (in: current, out: drawn); *sigsq likewise.
+__device__ __forceinline__ int ar_draw(ArLds &W, const SsmParams &Q, int chain, SeqRng &rng, double &phi_l,
+                                       double &sigsq, int lane) {
+  const int L = Q.ar_lags;
+  const double *suf = Q.ar_suf + (size_t)chain * AR_SUF_STRIDE;
+  for (int e = lane; e < SSM_MAX * SSM_MAX; e += WAVE) W.X[e] = suf[e];
+  const double xty = (lane < L) ? suf[AR_SUF_XTY + lane] : 0.0;
+  const double yty = suf[AR_SUF_YTY], n = suf[AR_SUF_N];
+  __builtin_amdgcn_wave_barrier();
+  if (!ar_chol(W.X, 1.0, W.Lc, L, lane)) return CHAIN_NOT_PD;
+  const double phi_hat = ar_ltsolve(W.Lc, ar_lsolve(W.Lc, xty, L, lane), L, lane);
+  // rmvn_ivar(phi_hat, xtx / sigsq)
+  if (!ar_chol(W.X, 1.0 / sigsq, W.Lp, L, lane)) return CHAIN_NOT_PD;
+  bool ok = false;
+  for (int attempt = 0; attempt < 3 && !ok; ++attempt) {
+    double z = 0.0;
+    for (int i = 0; i < L; ++i) {
+      const double zi = d_rnorm(rng, 0.0, 1.0);
+      if (lane == i) z = zi;
+    }
+    const double zs = ar_ltsolve(W.Lp, z, L, lane);   // (whole wave: the lanes talk to each other)
+    const double cand = (lane < L) ? zs + phi_hat : 0.0;
+    ok = ar_stationary(cand, L, lane);
+    if (ok) phi_l = cand;
+  }
+  if (!ok) {
+    double ph = phi_l;
+    if (!ar_stationary(ph, L, lane)) return CHAIN_RNG_BRANCH;
+    for (int i = 0; i < L; ++i) {
+      const double initial_phi = rl(ph, i);
+      double lo = -1, hi = 1;
+      const double ivar = W.X[i * SSM_MAX + i];
+      const double dot = row_total((lane < L) ? ph * W.X[lane * SSM_MAX + i] : 0.0);
+      const double mu = (rl(xty, i) - (dot - initial_phi * ivar)) / ivar;
+      for (;;) {
+        int bad = 0;
+        const double candidate = ar_rtrun_norm_2(rng, mu, sqrt(1.0 / ivar), lo, hi, &bad);
+        if (bad) return CHAIN_RNG_BRANCH;
+        if (lane == i) ph = candidate;
+        if (ar_stationary(ph, L, lane)) break;
+        if (candidate > initial_phi) hi = candidate; else lo = candidate;
+      }
+    }
+    phi_l = ph;
+  }
+  // draw_sigma: ss = phi' xtx phi - 2 phi' xty + yty, df = n
+  double row = 0.0;
+  for (int j = 0; j < L; ++j) {
+    const double pj = rl(phi_l, j);
+    if (lane < L) row += W.X[lane * SSM_MAX + j] * pj;
+  }
+  const double quad = row_total((lane < L) ? phi_l * row : 0.0);
+  const double lin = row_total((lane < L) ? phi_l * xty : 0.0);
+  const double ss = quad - 2 * lin + yty;
+  int bad = 0;
+  sigsq = d_draw_variance(rng, n + Q.ar_prior_df, ss + Q.ar_prior_ss, Q.ar_sigma_max, &bad);
+  return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
+}
+
 }  // namespace
 
 // grid = chains, block = 128.  TREND: 1 local level, 2 local linear trend; SEAS: a
-// seasonal block follows
-template <int TREND, bool SEAS>
+// seasonal block follows; AR: an autoregression block follows
+template <int TREND, bool SEAS, bool AR>
 __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw_variances) {
   // (the passes' buffers take the place of the normals generator's lists, which
   // are done by then: 37 KB per workgroup, four workgroups per CU)
@@ -149,9 +380,11 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   union SharedLds {
     NormalsLds norm;
     PassLds pass;
+    ArLds ar;
   };
   __shared__ SharedLds s_lds;
   __shared__ int s_flag;
+  __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
   double (&s_P)[SSM_MAX * SSM_MAX] = s_lds.pass.P;
   double (&s_tv)[SSM_MAX] = s_lds.pass.tv;
@@ -163,6 +396,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   const int T = P.T, p = P.p, m = Q.m;
   Shape S;
   S.m = m; S.trend = TREND; S.s0 = TREND; S.ns = SEAS ? Q.nseasons - 1 : 0;
+  S.a0 = AR ? Q.ar0 : 0; S.na = AR ? Q.ar_lags : 0;
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
   int status = CHAIN_OK;
   if (threadIdx.x == 0) s_flag = CHAIN_OK;
@@ -204,6 +438,46 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     if (threadIdx.x == 0) P.status[chain] = status;
     return;
   }
+  // ---- the autoregression block's sampler (after the seasonal model's), by wave 0
+  double phl = 0.0, sig2a = 0.0;
+  if (AR) {
+    if (wave == 0) {
+      phl = S.ar(lane) ? Q.ar_phi[(size_t)chain * SSM_MAX + (lane - S.a0)] : 0.0;
+      sig2a = Q.ar_sigsq[chain];
+      if (draw_variances) {
+        SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, 12u}, Q.pos_ar[chain]};
+        // (the sampler's vectors sit at lanes 0 .. L - 1)
+        double ph = __shfl(phl, lane + S.a0);
+        if (lane >= S.na) ph = 0.0;
+        const int st = ar_draw(s_lds.ar, Q, chain, rng, ph, sig2a, lane);
+        if (st != CHAIN_OK) {
+          if (lane == 0) s_flag = st;
+        } else {
+          if (lane < S.na) Q.ar_phi[(size_t)chain * SSM_MAX + lane] = ph;
+          if (lane == 0) {
+            Q.ar_sigsq[chain] = sig2a;
+            Q.pos_ar[chain] = rng.pos;
+          }
+        }
+        phl = __shfl(ph, lane >= S.a0 ? lane - S.a0 : 0);
+        if (!S.ar(lane)) phl = 0.0;
+      }
+      const double pv = __shfl(phl, (lane + S.a0) & 63);
+      if (lane < SSM_MAX) s_phi[lane] = (lane < S.na) ? pv : 0.0;
+      if (lane == 0) s_phi[SSM_MAX] = sig2a;
+    }
+    __syncthreads();
+    status = s_flag;
+    if (status != CHAIN_OK) {
+      if (threadIdx.x == 0) P.status[chain] = status;
+      return;
+    }
+    if (wave == 1) {
+      phl = S.ar(lane) ? s_phi[lane - S.a0] : 0.0;
+      sig2a = s_phi[SSM_MAX];
+    }
+  }
+  const double sda = sqrt(sig2a);
 
   const double H = P.sigsq[chain], sqrtH = sqrt(H);
   const double sdv[3] = {sqrt(sig2[0]), sqrt(sig2[1]), sqrt(sig2[2])};
@@ -213,8 +487,8 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   double *wk = Q.work + (size_t)chain * Q.work_stride;
   double *gK = wk;                                 // K_t, m per step (layout of step t + 1)
   double *gst = gK + (size_t)m * T;                // alpha+_t (layout of step t), then the state draw
-  double *gd = gst + (size_t)m * T;                // r_t (difference) at the three rows with state error: 3 series of T
-  double *szz = gd + (size_t)3 * T;                // the sweep's normals
+  double *gd = gst + (size_t)m * T;                // r_t (difference) at the four rows with state error: 4 series of T
+  double *szz = gd + (size_t)4 * T;                // the sweep's normals
 
   SSTAMP(0);
   // ---- 1. adjusted observations y*_t = y_t - x_t'beta (blocks of 64 steps, the waves in turn)
@@ -240,13 +514,15 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   // state of every state model (rmvn_mt draws every component; the local level
   // model draws rnorm_mt(a0, sd0): nothing if sd0 == 0), then the observation;
   // t >= 1: the state errors (local level: one if sigma != 0; local linear trend:
-  // two, always; seasonal: one if sigma != 0), then the observation.
+  // two, always; seasonal: one if sigma != 0; autoregression: one, always --
+  // rnorm_mt(rng) * sigma, ArStateModel.cpp:85-90), then the observation.
   const int dH = (sqrtH != 0.0);
   const int d0 = (TREND == 1) ? (Q.P0[0] != 0.0 ? 1 : 0) : 2;
-  const int nfirst = d0 + S.ns + dH;
+  const int nfirst = d0 + S.ns + S.na + dH;
   const int dT = (TREND == 1) ? (sdv[0] != 0.0 ? 1 : 0) : 2;
   const int dS = (SEAS && sdv[2] != 0.0) ? 1 : 0;
-  const int nper = dT + dS + dH;
+  const int dA = AR ? 1 : 0;
+  const int nper = dT + dS + dA + dH;
   const int N = nfirst + (T - 1) * nper;
   status = stream_normals(s_lds.norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
                           szz, &P.pos_state[chain]);
@@ -299,10 +575,11 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         if (mylane) {
           PZ = s_P[lane];
           if (SEAS) PZ += s_P[rc * SSM_MAX + lane];
+          if (AR) PZ += s_P[S.a0 * SSM_MAX + lane];
         }
-        const double F = zdot<SEAS>(S, PZ, c) + H;
+        const double F = zdot<SEAS, AR>(S, PZ, c) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
-        const double TPZ = vecT<TREND, SEAS>(S, PZ, lane, c);
+        const double TPZ = vecT<TREND, SEAS, AR>(S, PZ, lane, c, phl);
         const double K = obs ? TPZ / F : 0.0;
         if (mylane) {
           blk[s * m + lane] = K;
@@ -335,6 +612,32 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           if (lane == rw) s_P[rw * (SSM_MAX + 1)] = -tot;
           __builtin_amdgcn_wave_barrier();
         }
+        // -- the autoregression block (logical order): T P, then (T P) T'.  Lane k owns
+        // column k of the block's rows, then row k of the block's columns; either way
+        // it reads and writes its own entries only, and a symmetric P stays symmetric
+        // (P'(a0, k) and P'(k, a0) are the same sum in the same order).
+        if (AR) {
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            if (mylane) {
+              const int sr = pass == 0 ? SSM_MAX : 1, sc = pass == 0 ? 1 : SSM_MAX;   // strides along / across the block
+              double old[SSM_MAX - 1];
+              double cs = 0.0;
+#pragma unroll
+              for (int q = 0; q < SSM_MAX - 1; ++q) {
+                if (q < S.na) {
+                  old[q] = s_P[(S.a0 + q) * sr + lane * sc];
+                  cs += s_phi[q] * old[q];
+                }
+              }
+#pragma unroll
+              for (int q = 1; q < SSM_MAX - 1; ++q)
+                if (q < S.na) s_P[(S.a0 + q) * sr + lane * sc] = old[q - 1];
+              s_P[S.a0 * sr + lane * sc] = cs;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
         // - TPZ K' at an observed step (as (TPZ_i TPZ_j) / F: exactly symmetric)
         if (obs) {
           const double Finv = 1.0 / F;
@@ -350,6 +653,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         if (lane == 0) s_P[0] += sig2[0];
         if (TREND == 2 && lane == 1) s_P[SSM_MAX + 1] += sig2[1];
         if (SEAS && lane == rw) s_P[rw * (SSM_MAX + 1)] += sig2[2];
+        if (AR && lane == S.a0) s_P[S.a0 * (SSM_MAX + 1)] += sig2a;
         __builtin_amdgcn_wave_barrier();
         c = cn;
       }
@@ -366,15 +670,16 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       const bool in_l = tt < T;
       const double ys_l = in_l ? w0[tt] : 0.0;
       const int nb_l = (tt == 0) ? 0 : nfirst + (tt - 1) * nper;
-      double z0_l = 0.0, z1_l = 0.0, zs_l = 0.0, zh_l = 0.0;
+      double z0_l = 0.0, z1_l = 0.0, zs_l = 0.0, za_l = 0.0, zh_l = 0.0;
       if (in_l && tt > 0) {
         int o = nb_l;
         if (dT >= 1) z0_l = szz[o++];
         if (dT == 2) z1_l = szz[o++];
         if (dS) zs_l = szz[o++];
+        if (dA) za_l = szz[o++];
         if (dH) zh_l = szz[o];
       } else if (in_l) {
-        if (dH) zh_l = szz[d0 + S.ns];
+        if (dH) zh_l = szz[d0 + S.ns + S.na];
       }
       double w_l = 0.0;
       const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
@@ -384,21 +689,23 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           // simulate_initial_state: mean_i + sd_i z_i
           double z = 0.0;
           if (mylane) {
+            // (the blocks follow one another: seasonal and autoregression lanes alike)
             if (lane < TREND) z = (lane < d0) ? szz[lane] : 0.0;
-            else z = szz[d0 + (lane - S.s0)];
+            else z = szz[d0 + (lane - TREND)];
           }
           alpha = mylane ? sqrt(P0l) * z + a0l : 0.0;
         } else {
           // simulate_next_state: T alpha + eta
           const double z0 = rl(z0_l, s);
           const int cn = SEAS ? cursor_prev(c, S.ns) : 0;
-          alpha = vecT<TREND, SEAS>(S, alpha, lane, c);
+          alpha = vecT<TREND, SEAS, AR>(S, alpha, lane, c, phl);
           if (TREND == 2) alpha += sd_tr * ((lane == 0) ? z0 : rl(z1_l, s));
           else alpha += sd_tr * z0;
           if (SEAS) { if (lane == S.s0 + cn) alpha += sdv[2] * rl(zs_l, s); }
+          if (AR) { if (lane == S.a0) alpha += rl(za_l, s) * sda; }
           c = cn;
         }
-        const double yplus = zdot<SEAS>(S, alpha, c) + sqrtH * rl(zh_l, s);   // simulate_adjusted_observation
+        const double yplus = zdot<SEAS, AR>(S, alpha, c) + sqrtH * rl(zh_l, s);   // simulate_adjusted_observation
         const double w = rl(ys_l, s) - yplus;
         if (lane == s) w_l = w;
         if (mylane) blk[s * m + lane] = alpha;
@@ -435,9 +742,9 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       for (int s = 0; s < nstep; ++s) {
         const double K = mylane ? blk[s * m + lane] : 0.0;
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
-        const double e = obs ? rl(w_l, s) - zdot<SEAS>(S, delta, c) : 0.0;
+        const double e = obs ? rl(w_l, s) - zdot<SEAS, AR>(S, delta, c) : 0.0;
         if (lane == s) ef_l = obs ? e / F_l : 0.0;
-        delta = vecT<TREND, SEAS>(S, delta, lane, c) + K * e;
+        delta = vecT<TREND, SEAS, AR>(S, delta, lane, c, phl) + K * e;
         if (SEAS) c = cursor_prev(c, S.ns);
       }
       __builtin_amdgcn_wave_barrier();
@@ -458,7 +765,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
     blk_load(blk, gK + (size_t)tb * m, nstep * m, lane);
     const double ef_l = in_l ? w0[tt] : 0.0;
-    double d0_l = 0.0, d1_l = 0.0, d2_l = 0.0;
+    double d0_l = 0.0, d1_l = 0.0, d2_l = 0.0, d3_l = 0.0;
     int c1 = SEAS ? cursor_at(tb + nstep, S.ns) : 0;   // layout of r at the block's last step
 #pragma nounroll
     for (int s = nstep - 1; s >= 0; --s) {
@@ -469,10 +776,11 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       if (lane == s) d0_l = q0;
       if (TREND == 2) { const double q1 = rl(r, 1); if (lane == s) d1_l = q1; }
       if (SEAS) { const double q2 = rl(r, S.s0 + c1); if (lane == s) d2_l = q2; }
+      if (AR) { const double q3 = rl(r, S.a0); if (lane == s) d3_l = q3; }
       const double kr = row_total(K * r);
       const double coef = rl(ef_l, s) - kr;
-      r = vecTt<TREND, SEAS>(S, r, lane, c1);
-      if (lane == 0 || (SEAS && lane == S.s0 + c0)) r += coef;
+      r = vecTt<TREND, SEAS, AR>(S, r, lane, c1, phl);
+      if (lane == 0 || (SEAS && lane == S.s0 + c0) || (AR && lane == S.a0)) r += coef;
       if (!mylane) r = 0.0;
       c1 = c0;
     }
@@ -481,6 +789,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       gd[tt] = d0_l;
       if (TREND == 2) gd[(size_t)T + tt] = d1_l;
       if (SEAS) gd[(size_t)2 * T + tt] = d2_l;
+      if (AR) gd[(size_t)3 * T + tt] = d3_l;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -494,6 +803,10 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   double suf0 = 0.0, suf2 = 0.0;
   double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of the trend errors (lanes 0, 1)
   double yty = 0.0, nobs = 0.0;
+  // ArModel's NeRegSuf of now[a0] on then[a0 ..]: lane a0 + i keeps row i of xtx and xty_i
+  double axx[SSM_MAX - 1], axy = 0.0, ayy = 0.0;
+#pragma unroll
+  for (int q = 0; q < SSM_MAX - 1; ++q) axx[q] = 0.0;
   double *oblk = s_blk[1];
   {
     int c = 0;
@@ -506,6 +819,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       const double d0_l = dd ? gd[tt - 1] : 0.0;
       const double d1_l = (dd && TREND == 2) ? gd[(size_t)T + tt - 1] : 0.0;
       const double d2_l = (dd && SEAS) ? gd[(size_t)2 * T + tt - 1] : 0.0;
+      const double d3_l = (dd && AR) ? gd[(size_t)3 * T + tt - 1] : 0.0;
       const double y_l = in_l ? P.y[tt] : 0.0;
       const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
       double res_l = 0.0;
@@ -514,10 +828,11 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         const double ap = mylane ? blk[s * m + lane] : 0.0;
         if (tb + s > 0) {
           const int cn = SEAS ? cursor_prev(c, S.ns) : 0;
-          mc = vecT<TREND, SEAS>(S, mc, lane, c);
+          mc = vecT<TREND, SEAS, AR>(S, mc, lane, c, phl);
           if (TREND == 2) mc += sig_tr * ((lane == 0) ? rl(d0_l, s) : rl(d1_l, s));
           else mc += sig_tr * rl(d0_l, s);
           if (SEAS) { if (lane == S.s0 + cn) mc += sig2[2] * rl(d2_l, s); }
+          if (AR) { if (lane == S.a0) mc += sig2a * rl(d3_l, s); }
           c = cn;
         }
         const double st = mylane ? ap + mc : 0.0;
@@ -542,19 +857,28 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
             const double dl = st - (-1.0 * tot);
             if (lane == S.s0 + c) suf2 += dl * dl;
           }
+          if (AR) {
+            // add_mixture_data(now[0], then, 1.0): xtx += then then', xty += now[0] then, yty += now[0]^2
+            const double yy = rl(st, S.a0);
+#pragma unroll
+            for (int q = 0; q < SSM_MAX - 1; ++q)
+              if (q < S.na) axx[q] += prev * rl(prev, S.a0 + q) * 1.0;
+            axy += (yy * 1.0) * prev;
+            ayy += yy * yy * 1.0;
+          }
         }
         prev = st;
         if (mylane) {
           // the state draw goes out in logical order
           int idx = lane;
-          if (SEAS && lane >= S.s0) {
+          if (SEAS && S.seasonal(lane)) {
             const int q = lane - S.s0;
             idx = S.s0 + (q >= c ? q - c : q - c + S.ns);
           }
           oblk[s * m + idx] = st;
         }
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
-        const double resid = obs ? rl(y_l, s) - zdot<SEAS>(S, st, c) : 0.0;
+        const double resid = obs ? rl(y_l, s) - zdot<SEAS, AR>(S, st, c) : 0.0;
         if (lane == s) res_l = resid;
         if (obs) { yty += resid * resid; nobs += 1.0; }
       }
@@ -588,6 +912,20 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       Q.var_ss[(size_t)chain * 3 + 2] = tot;
     }
   }
+  if (AR) {
+    double *suf = Q.ar_suf + (size_t)chain * AR_SUF_STRIDE;
+    if (S.ar(lane)) {
+      const int i = lane - S.a0;
+#pragma unroll
+      for (int q = 0; q < SSM_MAX - 1; ++q)
+        if (q < S.na) suf[i * SSM_MAX + q] = axx[q];
+      suf[AR_SUF_XTY + i] = axy;
+    }
+    if (lane == 0) {
+      suf[AR_SUF_YTY] = ayy;
+      suf[AR_SUF_N] = (double)(T - 1);
+    }
+  }
   if (lane == 0) {
     P.yty[chain] = yty;
     P.nobs[chain] = nobs;
@@ -616,6 +954,10 @@ __global__ __launch_bounds__(64) void ssm_forecast_kernel(SsParams P, int horizo
   const double *gst = Q.work + (size_t)chain * Q.work_stride + (size_t)m * T;
   double st = (lane < m) ? gst[(size_t)(T - 1) * m + lane] : 0.0;
   const bool seas = ns > 0 && lane >= s0 && lane < s0 + ns;
+  const int na = Q.ar_lags, a0 = Q.ar0;
+  const bool arl = na > 0 && lane >= a0 && lane < a0 + na;
+  const double phl = arl ? Q.ar_phi[(size_t)chain * SSM_MAX + (lane - a0)] : 0.0;
+  const double sda = na > 0 ? sqrt(Q.ar_sigsq[chain]) : 0.0;
   SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 5u}, pos_forecast[chain]};
   for (int i = 0; i < horizon; ++i) {
     // state errors, in the reference's order
@@ -628,6 +970,8 @@ __global__ __launch_bounds__(64) void ssm_forecast_kernel(SsParams P, int horizo
       e1 = sd1 * z1 + 0.0;
     }
     if (ns > 0) e2 = d_rnorm(rng, 0.0, sd2);
+    double e3 = 0.0;
+    if (na > 0) e3 = d_rnorm(rng, 0.0, 1.0) * sda;
     // T state
     double nx = st;
     if (trend == 2) { const double x1 = rl(st, 1); if (lane == 0) nx = st + x1; }
@@ -638,10 +982,19 @@ __global__ __launch_bounds__(64) void ssm_forecast_kernel(SsParams P, int horizo
       const double prev = sdpp<0x111, 0xf>(st, 0.0);
       if (lane == s0) nx = first; else if (seas) nx = prev;
     }
-    st = nx + ((lane == 0) ? e0 : ((trend == 2 && lane == 1) ? e1 : ((ns > 0 && lane == s0) ? e2 : 0.0)));
+    if (na > 0) {
+      // (first = sum of phi_i s_i from the last lag down, AutoRegressionTransitionMatrix::multiply_inplace)
+      double first = 0.0;
+      for (int q = na - 1; q >= 0; --q) first += rl(phl, a0 + q) * rl(st, a0 + q);
+      const double prev = sdpp<0x111, 0xf>(st, 0.0);
+      if (lane == a0) nx = first; else if (arl) nx = prev;
+    }
+    st = nx + ((lane == 0) ? e0 : ((trend == 2 && lane == 1) ? e1 : ((ns > 0 && lane == s0) ? e2 :
+                                                                   ((na > 0 && lane == a0) ? e3 : 0.0))));
     if (lane >= m) st = 0.0;
     double zs = rl(st, 0);
     if (ns > 0) zs += rl(st, s0);
+    if (na > 0) zs += rl(st, a0);
     const double obs = d_rnorm(rng, zs, sd_obs);
     double part = 0.0;
     for (int j = lane; j < p; j += WAVE) part += newX[(size_t)j * horizon + i] * beta[j];
@@ -668,18 +1021,20 @@ hipError_t launch_xte_tiled(hipStream_t stream, const double *U, int64_t ldu, in
 
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances) {
   const dim3 grid(P.chain_count), block(2 * WAVE);
-  const bool seas = P.ssm.nseasons > 0;
-#define SSM_LAUNCH(TR, SE) hipLaunchKernelGGL((ssm_simsmooth_kernel<TR, SE>), grid, block, 0, stream, P, draw_variances)
+  const bool seas = P.ssm.nseasons > 0, ar = P.ssm.ar_lags > 0;
+#define SSM_LAUNCH(TR, SE, AR) hipLaunchKernelGGL((ssm_simsmooth_kernel<TR, SE, AR>), grid, block, 0, stream, P, draw_variances)
+#define SSM_LAUNCH_AR(TR, SE) do { if (ar) SSM_LAUNCH(TR, SE, true); else SSM_LAUNCH(TR, SE, false); } while (0)
   hipError_t err;
   {
     KtScope kt(stream, KT_SSM);
     if (!seas) {
-      if (P.ssm.trend == 1) SSM_LAUNCH(1, false); else SSM_LAUNCH(2, false);
+      if (P.ssm.trend == 1) SSM_LAUNCH_AR(1, false); else SSM_LAUNCH_AR(2, false);
     } else {
-      if (P.ssm.trend == 1) SSM_LAUNCH(1, true); else SSM_LAUNCH(2, true);
+      if (P.ssm.trend == 1) SSM_LAUNCH_AR(1, true); else SSM_LAUNCH_AR(2, true);
     }
     err = hipGetLastError();
   }
+#undef SSM_LAUNCH_AR
 #undef SSM_LAUNCH
   if (err != hipSuccess) return err;
   // xty[chain, j] = x_j' e_chain (the residual series are array 1 of every chain's scratch block)

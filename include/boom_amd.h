@@ -419,6 +419,31 @@ int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons,
                          const double *var_initial_sigma,
                          const double *initial_state_mean,
                          const double *initial_state_variance);
+/* After ba_ss_set_structural: appends an ArStateModel(lags) block to the state
+ * (StateModels/ArStateModel.cpp: transition = first row phi, ones below the
+ * diagonal; one error variance; observation coefficient 1 at the block's first
+ * element) with an ArPosteriorSampler(ChisqModel(prior_df, sigma_guess)) and
+ * set_sigma_upper_limit (Models/TimeSeries/PosteriorSamplers/ArPosteriorSampler.cpp
+ * :52-143: up to three multivariate proposals for phi, accepted when stationary,
+ * else one coefficient at a time from a truncated normal; then sigma).  The state
+ * dimension grows by lags (still <= 16).  initial_phi (lags entries, NULL: zeros)
+ * must be stationary, as ArModel's constructor demands; initial_state_mean /
+ * _variance: the block's lags entries (variances positive).  Stationarity
+ * (ArModel::check_stationary, ArModel.cpp:142-170) is decided by the quick bound
+ * sum |phi| < 1 and then, where the reference finds polynomial roots, by the
+ * equivalent step-down recursion.  The tail cases of the coefficient-at-a-time
+ * draw (a Tn2Sampler in the reference) are reported as a chain error.  RNG stream
+ * 12: the proposals' normals, then the sigma draw (the reference takes the
+ * proposals from GlobalRng::rng and the rest from the sampler's generator). */
+int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess,
+                 double sigma_upper_limit, double initial_sigma,
+                 const double *initial_phi, const double *initial_state_mean,
+                 const double *initial_state_variance);
+/* one chain's autoregression coefficients (lags), error variance and the ArModel's
+ * sufficient statistics of the last sweep (xtx lags x lags column-major, xty, yty,
+ * n); any pointer may be NULL */
+int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq,
+                 double *suf_xtx, double *suf_xty, double *suf_yty, double *suf_n);
 /* one chain's state draw (T x m, step t at [t * m, (t + 1) * m)), the three
  * variance parameters and the state models' sufficient statistics (n, sum of
  * squares) of the last sweep; any pointer may be NULL */

@@ -2642,11 +2642,78 @@ static int ar_check_stationary(int L, const double *phi) {
 }
 int bo_test_ar_check_stationary(int L, const double *phi) { return ar_check_stationary(L, phi); }
 
-/* rtrun_norm_2_mt (distributions/trun_norm.cpp:273-325) for lo, hi finite: the two
- * rejection samplers of the case lo < mu < hi; the tail cases build a Tn2Sampler
- * (adaptive rejection), which is not restated: unsupported-branch error. */
-static double rtrun_norm_2(bo_rng *rng, double mu, double sigma, double lo, double hi,
-                           int *status) {
+/* Tn2Sampler (distributions/Tn2Sampler.cpp:25-131): adaptive rejection sampling of a
+ * standard normal restricted to [lo, hi], logf = -x^2/2, outer hull of tangents at
+ * the points x.  Restated as written, including update_cdf's increment
+ * (exp(y - y0) / d) * expm1(d * knots[k + 1] - knots[k]). */
+typedef struct {
+  int n;
+  double x[BO_ARS_CAP], logf[BO_ARS_CAP], dlogf[BO_ARS_CAP], knots[BO_ARS_CAP + 1],
+      cdf[BO_ARS_CAP];
+} bo_tn2;
+static void tn2_refresh(bo_tn2 *s) {
+  const int n = s->n;
+  s->knots[0] = s->x[0];
+  s->knots[n] = s->x[n - 1];
+  for (int k = 1; k < n; ++k) {   /* compute_knot(k) */
+    double y2 = s->logf[k], y1 = s->logf[k - 1], d2 = s->dlogf[k], d1 = s->dlogf[k - 1];
+    double x2 = s->x[k], x1 = s->x[k - 1];
+    double ans = (y1 - d1 * x1) - (y2 - d2 * x2);
+    ans /= (d2 - d1);
+    s->knots[k] = ans;
+  }
+  const double y0 = s->logf[0];
+  for (int k = 0; k < n; ++k) {   /* update_cdf */
+    double d = s->dlogf[k];
+    double y = s->logf[k] + d * (s->knots[k] - s->x[k]);
+    double increment;
+    if (fabs(d) < .00000000001) {
+      increment = exp(y - y0) * (s->knots[k + 1] - s->knots[k]);
+    } else {
+      increment = (exp(y - y0) / d) * expm1(d * s->knots[k + 1] - s->knots[k]);
+    }
+    s->cdf[k] = (k == 0 ? increment : s->cdf[k - 1] + increment);
+  }
+}
+static double tn2_draw(bo_rng *r, double lo, double hi, int *status) {
+  bo_tn2 s;
+  s.n = 2;
+  s.x[0] = lo; s.x[1] = hi;
+  s.logf[0] = -.5 * lo * lo; s.logf[1] = -.5 * hi * hi;
+  s.dlogf[0] = -lo; s.dlogf[1] = -hi;
+  tn2_refresh(&s);
+  for (int level = 0; level <= 1001; ++level) {
+    double u = bo_runif(r, 0, s.cdf[s.n - 1]);
+    int k = ars_lower_bound(s.cdf, s.n, u);
+    if (k >= s.n) break;   /* (past the end of cdf in the reference) */
+    double klo = s.knots[k], khi = s.knots[k + 1];
+    double lam = -1 * s.dlogf[k];
+    double cand;
+    if (lam == 0 || fabs(khi - klo) < sqrt(DBL_EPSILON)) {
+      cand = bo_runif(r, klo, khi);
+    } else {
+      cand = bo_rtrun_exp(r, lam, klo, khi);
+    }
+    double target = -.5 * cand * cand;
+    double logu = (s.logf[k] + s.dlogf[k] * (cand - s.x[k])) - bo_rexp(r, 1);
+    if (logu < target) return cand;
+    /* add_point: report_error when the candidate is outside [x[0], x.back()] */
+    if (cand > s.x[s.n - 1] || cand < s.x[0] || s.n >= BO_ARS_CAP) break;
+    int pos = ars_lower_bound(s.x, s.n, cand);
+    for (int i = s.n; i > pos; --i) { s.x[i] = s.x[i - 1]; s.logf[i] = s.logf[i - 1]; s.dlogf[i] = s.dlogf[i - 1]; }
+    s.x[pos] = cand;
+    s.logf[pos] = -.5 * cand * cand;
+    s.dlogf[pos] = -cand;
+    ++s.n;
+    tn2_refresh(&s);
+  }
+  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
+  return NAN;
+}
+
+/* rtrun_norm_2_mt (distributions/trun_norm.cpp:273-325) for lo, hi finite */
+double bo_rtrun_norm_2(bo_rng *rng, double mu, double sigma, double lo, double hi,
+                       int *status) {
   if (lo < mu && hi > mu) {
     if ((hi - lo) / sigma > .5) {
       double y = lo - 1;
@@ -2665,9 +2732,17 @@ static double rtrun_norm_2(bo_rng *rng, double mu, double sigma, double lo, doub
       return y;
     }
   }
-  *status = BO_ERR_UNSUPPORTED_RNG_BRANCH;
-  return NAN;
+  hi = (hi - mu) / sigma;
+  lo = (lo - mu) / sigma;
+  if (hi < 0) {
+    /* rtrun_norm_2_mt(rng, 0, 1, -hi, -lo): not interior, standardising by (0, 1) changes nothing */
+    double y = tn2_draw(rng, -hi, -lo, status);
+    return mu - sigma * y;
+  }
+  double y = tn2_draw(rng, lo, hi, status);
+  return y * sigma + mu;
 }
+#define rtrun_norm_2 bo_rtrun_norm_2
 
 /* ArPosteriorSampler::draw_phi / draw_phi_univariate / draw_sigma,
  * Models/TimeSeries/PosteriorSamplers/ArPosteriorSampler.cpp:91-143, :78-89 */

@@ -236,6 +236,8 @@ void bo_ssm_set_global_rng(bo_ssm *m, bo_rng *global);
 void bo_ssm_get_ar(const bo_ssm *m, double *phi, double *sigsq);
 void bo_ssm_get_ar_suf(const bo_ssm *m, double *xtx, double *xty, double *yty, double *n);
 int bo_test_ar_check_stationary(int L, const double *phi);
+/* rtrun_norm_2_mt(rng, mu, sigma, lo, hi), lo and hi finite (trun_norm.cpp:273-325, Tn2Sampler.cpp) */
+double bo_rtrun_norm_2(bo_rng *rng, double mu, double sigma, double lo, double hi, int *status);
 void bo_ssm_simulate_forecast_ar(bo_rng *rng, int horizon, int p, const double *newX,
                                  const double *beta, double sigsq_obs, int trend, int nseasons,
                                  const double *sigsq, int ar_lags, const double *phi,

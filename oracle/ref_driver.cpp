@@ -1015,6 +1015,15 @@ int ref_poisson_run(int n, int p, const double *X, const double *y, const double
   REF_CATCH
 }
 
+// two-sided truncated normal draws: rtrun_norm_2_mt(rng, mu, sigma, lo, hi)
+int ref_rng_trun_norm_2(uint64_t seed, double mu, double sigma, double lo, double hi, int n,
+                        double *out) {
+  REF_TRY
+  RNG rng(seed);
+  for (int i = 0; i < n; ++i) out[i] = rtrun_norm_2_mt(rng, mu, sigma, lo, hi);
+  REF_CATCH
+}
+
 // truncated normal draws: rtrun_norm_mt(rng, mu, sigma, cut, above)
 int ref_rng_trun_norm(uint64_t seed, double mu, double sigma, double cut, int above, int n,
                       double *out) {

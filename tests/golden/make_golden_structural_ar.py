@@ -64,6 +64,18 @@ def main():
     print("stationary:", int(want.sum()), "of", len(want))
     save("kat_ar_stationary", phi=phis, lags=lags, stationary=want)
 
+    # rtrun_norm_2_mt(mu, sigma, lo, hi): the normal and the uniform envelope of the
+    # interior case, and the Tn2Sampler tails (right, left through the mirror image)
+    TN2 = np.array([(0.3, 0.4, -1, 1), (1.6, 0.3, -1, 1), (-2.5, 0.2, -1, 1),
+                    (1.2, 0.05, -1, 1), (0.0, 5.0, -0.1, 0.1), (1.0, 0.1, -1, 1),
+                    (3.0, 1.0, -1, 0.2), (-1.0, 0.3, -0.5, 1), (5, 1, -1, 1),
+                    (0.99, 0.001, -1, 0.5)], dtype=np.float64)
+    draws = np.zeros((len(TN2), 200))
+    for i, c in enumerate(TN2):
+        R._check(R.lib.ref_rng_trun_norm_2(C.c_uint64(5), *[C.c_double(v) for v in c], 200,
+                                           draws[i].ctypes.data_as(C.POINTER(C.c_double))))
+    save("kat_trun_norm_2", seed=5, cases=TN2, draws=draws)
+
 
 if __name__ == "__main__":
     main()

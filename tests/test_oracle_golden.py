@@ -362,6 +362,20 @@ def test_ar_stationarity_known_answers(oracle):
         assert got == want, (phi[:L], want)
 
 
+def test_two_sided_truncated_normal_known_answers(oracle):
+    """rtrun_norm_2_mt (ArPosteriorSampler::draw_phi_univariate): both rejection
+    samplers of the interior case and the Tn2Sampler tails, bit for bit"""
+    import ctypes as C
+    g = load("kat_trun_norm_2")
+    oracle.lib.bo_rtrun_norm_2.restype = C.c_double
+    oracle.lib.bo_rtrun_norm_2.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.POINTER(C.c_int)]
+    for case, want in zip(g["cases"], g["draws"]):
+        rng, st = oracle.rng_mt(int(g["seed"])), C.c_int(0)
+        got = np.array([oracle.lib.bo_rtrun_norm_2(C.byref(rng), *[float(v) for v in case],
+                                                   C.byref(st)) for _ in range(want.shape[0])])
+        assert st.value == 0 and np.array_equal(got, want), case
+
+
 def test_structural_forecast_known_answers(oracle):
     g = load("kat_structural_forecast")
     for trend, ns in g["shapes"]:
