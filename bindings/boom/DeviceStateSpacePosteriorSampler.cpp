@@ -53,9 +53,16 @@ namespace BOOM {
 
     // ---- which state models: a trend (local level | local linear trend), then an
     // optional seasonal component
-    const int nstate = model->number_of_state_models();
+    int nstate = model->number_of_state_models();
+    // an ArStateModel may come last (bsts: AddAr after the trend / seasonal components)
+    const ArStateModel *ar = nstate >= 2
+        ? dynamic_cast<const ArStateModel *>(model->state_model(nstate - 1)) : nullptr;
+    ar_index_ = ar ? nstate - 1 : -1;
+    ar_lags_ = ar ? ar->number_of_lags() : 0;
+    if (ar) --nstate;
     if (nstate < 1 || nstate > 2)
-      report_error("The device sampler takes a trend state model, optionally followed by a seasonal one.");
+      report_error("The device sampler takes a trend state model, optionally followed by a seasonal "
+                   "one and / or an autoregression.");
     const LocalLevelStateModel *level = dynamic_cast<const LocalLevelStateModel *>(model->state_model(0));
     const LocalLinearTrendStateModel *llt =
         dynamic_cast<const LocalLinearTrendStateModel *>(model->state_model(0));
@@ -70,9 +77,9 @@ namespace BOOM {
         report_error("Season durations other than 1 are not implemented on the device.");
       nseasons_ = seasonal->nseasons();
     }
-    state_dim_ = trend_ + (nseasons_ > 0 ? nseasons_ - 1 : 0);
-    structural_ = (trend_ == 2) || (nseasons_ > 0);
-    const size_t nvar = static_cast<size_t>(trend_ + (nseasons_ > 0 ? 1 : 0));
+    state_dim_ = trend_ + (nseasons_ > 0 ? nseasons_ - 1 : 0) + ar_lags_;
+    structural_ = (trend_ == 2) || (nseasons_ > 0) || ar;
+    const size_t nvar = static_cast<size_t>(trend_ + (nseasons_ > 0 ? 1 : 0) + (ar ? 1 : 0));
     if (variance_priors_.size() != nvar)
       report_error("state_variance_priors needs one entry per state variance parameter.");
 
@@ -156,6 +163,18 @@ namespace BOOM {
       }
       check(ba_ss_set_structural(engine_, trend_, nseasons_, df, guess, upper, init, a0.data(),
                                  P0.data()));
+      if (ar) {
+        // ArPosteriorSampler(model, siginv_prior) + set_sigma_upper_limit
+        const DeviceStateVariancePrior &pr(variance_priors_.back());
+        const Vector m = ar->initial_state_mean();
+        const SpdMatrix V = ar->initial_state_variance();
+        diagonal_or_die(V, "the autoregression");
+        const Vector v0 = V.diag();
+        const Vector phi = ar->phi();
+        check(ba_ss_add_ar(engine_, ar_lags_, prior_df(pr.precision_prior),
+                           prior_sigma_guess(pr.precision_prior), pr.sigma_upper_limit, ar->sigma(),
+                           phi.data(), m.data(), v0.data()));
+      }
     }
 
     // ---- the chains start where the model stands
@@ -207,6 +226,12 @@ namespace BOOM {
     }
   }
 
+  void DeviceStateSpacePosteriorSampler::chain_ar(int chain, Vector &phi, double &sigsq) const {
+    if (ar_index_ < 0) report_error("The model has no ArStateModel.");
+    phi.resize(ar_lags_);
+    check(ba_ss_get_ar(engine_, chain, phi.data(), &sigsq, nullptr, nullptr, nullptr, nullptr));
+  }
+
   void DeviceStateSpacePosteriorSampler::pull_chain0() {
     Selector inc(model_->xdim(), false);
     Vector beta, variances;
@@ -227,6 +252,14 @@ namespace BOOM {
     }
     if (nseasons_ > 0)
       dynamic_cast<SeasonalStateModel *>(model_->state_model(1))->set_sigsq(variances[2]);
+    if (ar_index_ >= 0) {
+      Vector phi(ar_lags_, 0.0);
+      double ar_sigsq = 1.0;
+      check(ba_ss_get_ar(engine_, 0, phi.data(), &ar_sigsq, nullptr, nullptr, nullptr, nullptr));
+      ArStateModel *arm = dynamic_cast<ArStateModel *>(model_->state_model(ar_index_));
+      arm->set_phi(phi);
+      arm->set_sigsq(ar_sigsq);
+    }
     // the model's state matrix: the only public way to install one is
     // permanently_set_state (StateSpaceModelBase.cpp:199-212), which also tells the
     // model not to impute the state itself -- the device does
@@ -246,10 +279,20 @@ namespace BOOM {
     } else {
       check(ba_ss_get_state(engine_, 0, nullptr, &v[0], nullptr, nullptr));
     }
-    for (size_t i = 0; i < variance_priors_.size(); ++i) {
+    const size_t nplain = variance_priors_.size() - (ar_index_ >= 0 ? 1 : 0);
+    for (size_t i = 0; i < nplain; ++i) {
       const int slot = (i < static_cast<size_t>(trend_)) ? static_cast<int>(i) : 2;
       const double sigsq = v[slot];
       ans += variance_priors_[i].precision_prior->logp(1.0 / sigsq) - 2 * std::log(sigsq);
+    }
+    if (ar_index_ >= 0) {
+      // ArPosteriorSampler::log_prior_density (ArPosteriorSampler.cpp:66-70): the
+      // stationarity indicator and the variance prior
+      Vector phi(ar_lags_, 0.0);
+      double sigsq = 1.0;
+      check(ba_ss_get_ar(engine_, 0, phi.data(), &sigsq, nullptr, nullptr, nullptr, nullptr));
+      if (!ArModel::check_stationary(phi)) return negative_infinity();
+      ans += variance_priors_.back().precision_prior->logp(1.0 / sigsq) - 2 * std::log(sigsq);
     }
     return ans;
   }

@@ -23,6 +23,7 @@
 #include "Models/Glm/VariableSelectionPrior.hpp"
 #include "Models/MvnGivenScalarSigma.hpp"
 #include "Models/PosteriorSamplers/PosteriorSampler.hpp"
+#include "Models/StateSpace/StateModels/ArStateModel.hpp"
 #include "Models/StateSpace/StateSpaceRegressionModel.hpp"
 
 extern "C" {
@@ -52,7 +53,8 @@ namespace BOOM {
   //   state_variance_priors
   //       one entry per variance parameter in state-model order: (level) for a
   //       LocalLevelStateModel, (level, slope) for a LocalLinearTrendStateModel, then
-  //       (seasonal) if a SeasonalStateModel follows.
+  //       (seasonal) if a SeasonalStateModel follows, then the ArPosteriorSampler's
+  //       prior if an ArStateModel comes last.
   // The data, the state models' initial-state distributions and the parameters' current
   // values are read from the model in the constructor: add the data and the state
   // models first.  Chain 0 backs the model's own objects: after every draw
@@ -78,6 +80,8 @@ namespace BOOM {
 
     int number_of_chains() const { return chains_; }
     int state_dimension() const { return state_dim_; }
+    // one chain's autoregression coefficients and error variance (an ArStateModel last)
+    void chain_ar(int chain, Vector &phi, double &sigsq) const;
     // the other chains: regression parameters, state variances (level, slope,
     // seasonal; unused entries 0) and the state draw (state_dimension x time_dimension)
     void chain_state(int chain, Selector &inc, Vector &beta, double &sigsq,
@@ -97,6 +101,8 @@ namespace BOOM {
     int trend_;      // 1 local level, 2 local linear trend
     int nseasons_;   // 0: no seasonal state model
     int state_dim_;
+    int ar_index_ = -1;   // position of the ArStateModel among the state models (-1: none)
+    int ar_lags_ = 0;
     bool structural_;  // the engine runs ba_ss_set_structural (anything but a lone local level)
     std::vector<DeviceStateVariancePrior> variance_priors_;
   };

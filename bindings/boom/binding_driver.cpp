@@ -167,16 +167,21 @@ int ref_binding_logit_run(int n, int p, const double *X, const double *y, const 
 // model's inc / Beta / sigsq, the state models' variances (level, slope, seasonal;
 // unused 0) and model->state() (T x m per draw, step t at [t m, (t + 1) m)).
 // Three-element arrays are indexed level, slope, seasonal.
-int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uint8_t *observed,
+// ar_lags > 0: an ArStateModel(ar_lags) comes last; ar[] = {prior df, prior sigma guess,
+// sigma upper limit, initial sigma}, ar_phi0 its initial coefficients, its initial state
+// moments follow the others; out_ar: nsweeps x (ar_lags + 1) = phi, sigsq as the BOOM
+// ArStateModel object holds them after every draw
+static int binding_ss_impl(int T, int p, const double *y, const double *X, const uint8_t *observed,
                        const double *prior_mean, const double *ominv, double prior_df,
                        double sigma_guess, const double *pi, double sigma_upper_limit,
                        int trend, int nseasons, const double *var_df,
                        const double *var_sigma_guess, const double *var_sigma_upper_limit,
                        const double *var_initial_sigma, const double *initial_state_mean,
-                       const double *initial_state_variance, int chains, uint64_t seed,
+                       const double *initial_state_variance, int ar_lags, const double *ar,
+                       const double *ar_phi0, int chains, uint64_t seed,
                        const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
                        double *out_beta, double *out_sigsq, double *out_variances,
-                       double *out_state, double *out_logpri, uint64_t *out_seed,
+                       double *out_state, double *out_ar, double *out_logpri, uint64_t *out_seed,
                        int probe_chain, uint8_t *probe_gamma, double *probe_state) {
   try {
     GlobalRng::rng.seed(seed);
@@ -206,7 +211,7 @@ int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uin
     for (int j = 0; j < p; ++j)
       if (init_gamma[j]) reg->coef().add(j);
 
-    const int ns1 = nseasons > 0 ? nseasons - 1 : 0, m = trend + ns1;
+    const int ns1 = nseasons > 0 ? nseasons - 1 : 0, m = trend + ns1 + ar_lags;
     std::vector<DeviceStateVariancePrior> vpriors;
     auto vprior = [&](int slot) {
       DeviceStateVariancePrior pr;
@@ -255,6 +260,27 @@ int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uin
       model->add_state(seasonal);
       vprior(2);
     }
+    Ptr<ArStateModel> arm;
+    if (ar_lags > 0) {
+      arm = new ArStateModel(ar_lags);
+      Vector phi0(ar_lags);
+      for (int i = 0; i < ar_lags; ++i) phi0[i] = ar_phi0[i];
+      arm->set_phi(phi0);
+      arm->set_sigma(ar[3]);
+      Vector a0(ar_lags);
+      SpdMatrix P0(ar_lags, 0.0);
+      for (int i = 0; i < ar_lags; ++i) {
+        a0[i] = initial_state_mean[trend + ns1 + i];
+        P0(i, i) = initial_state_variance[trend + ns1 + i];
+      }
+      arm->set_initial_state_mean(a0);
+      arm->set_initial_state_variance(P0);
+      model->add_state(arm);
+      DeviceStateVariancePrior pr;
+      pr.precision_prior = new ChisqModel(ar[0], ar[1]);
+      pr.sigma_upper_limit = ar[2];
+      vpriors.push_back(pr);
+    }
 
     NEW(DeviceStateSpacePosteriorSampler, sampler)(model.get(), slab, siginv_prior, spike,
                                                    sigma_upper_limit, vpriors, chains);
@@ -278,6 +304,10 @@ int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uin
         v[1] = llt->Sigma()(1, 1);
       }
       if (seasonal) v[2] = seasonal->sigsq();
+      if (arm) {
+        for (int i = 0; i < ar_lags; ++i) out_ar[(size_t)s * (ar_lags + 1) + i] = arm->phi()[i];
+        out_ar[(size_t)s * (ar_lags + 1) + ar_lags] = arm->sigsq();
+      }
       const Matrix &state(model->state());
       if (state.nrow() != m || state.ncol() != T) throw std::runtime_error("state has the wrong shape");
       for (int t = 0; t < T; ++t)
@@ -299,6 +329,46 @@ int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uin
     g_binding_error = e.what();
     return -1;
   }
+}
+
+int ref_binding_ss_run(int T, int p, const double *y, const double *X, const uint8_t *observed,
+                       const double *prior_mean, const double *ominv, double prior_df,
+                       double sigma_guess, const double *pi, double sigma_upper_limit,
+                       int trend, int nseasons, const double *var_df,
+                       const double *var_sigma_guess, const double *var_sigma_upper_limit,
+                       const double *var_initial_sigma, const double *initial_state_mean,
+                       const double *initial_state_variance, int chains, uint64_t seed,
+                       const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                       double *out_beta, double *out_sigsq, double *out_variances,
+                       double *out_state, double *out_logpri, uint64_t *out_seed,
+                       int probe_chain, uint8_t *probe_gamma, double *probe_state) {
+  return binding_ss_impl(T, p, y, X, observed, prior_mean, ominv, prior_df, sigma_guess, pi,
+                         sigma_upper_limit, trend, nseasons, var_df, var_sigma_guess,
+                         var_sigma_upper_limit, var_initial_sigma, initial_state_mean,
+                         initial_state_variance, 0, nullptr, nullptr, chains, seed, init_gamma,
+                         nsweeps, out_gamma, out_beta, out_sigsq, out_variances, out_state, nullptr,
+                         out_logpri, out_seed, probe_chain, probe_gamma, probe_state);
+}
+
+// the same with an ArStateModel added last (see binding_ss_impl)
+int ref_binding_ss_ar_run(int T, int p, const double *y, const double *X, const uint8_t *observed,
+                          const double *prior_mean, const double *ominv, double prior_df,
+                          double sigma_guess, const double *pi, double sigma_upper_limit,
+                          int trend, int nseasons, const double *var_df,
+                          const double *var_sigma_guess, const double *var_sigma_upper_limit,
+                          const double *var_initial_sigma, const double *initial_state_mean,
+                          const double *initial_state_variance, int ar_lags, const double *ar,
+                          const double *ar_phi0, int chains, uint64_t seed,
+                          const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                          double *out_beta, double *out_sigsq, double *out_variances,
+                          double *out_state, double *out_ar, double *out_logpri, uint64_t *out_seed,
+                          int probe_chain, uint8_t *probe_gamma, double *probe_state) {
+  return binding_ss_impl(T, p, y, X, observed, prior_mean, ominv, prior_df, sigma_guess, pi,
+                         sigma_upper_limit, trend, nseasons, var_df, var_sigma_guess,
+                         var_sigma_upper_limit, var_initial_sigma, initial_state_mean,
+                         initial_state_variance, ar_lags, ar, ar_phi0, chains, seed, init_gamma,
+                         nsweeps, out_gamma, out_beta, out_sigsq, out_variances, out_state, out_ar,
+                         out_logpri, out_seed, probe_chain, probe_gamma, probe_state);
 }
 
 // ... and for the Poisson sampler: BOOM's PoissonRegressionModel (one PoissonRegressionData

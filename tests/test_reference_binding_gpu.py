@@ -185,6 +185,64 @@ def test_boom_state_space_model_driven_by_the_device_sampler(oracle, trend, nsea
     assert np.array_equal(pg, ol["gamma"][-1])
     assert np.max(np.abs(pstate - ol["state"][-1])) < 1e-8 * np.abs(ol["state"][-1]).max()
 
+@pytest.mark.skipif(not os.path.exists(BINDING_SO),
+                    reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
+@pytest.mark.parametrize("trend,nseasons,T,coef", [(1, 0, 200, [0.8]), (2, 4, 160, [1.2, -0.4])])
+def test_boom_state_space_model_with_ar_state_driven_by_the_device_sampler(oracle, trend, nseasons, T,
+                                                                          coef):
+    """... with an ArStateModel added last (bsts AddAr): after every draw BOOM's own
+    ArStateModel object holds chain 0's coefficients and error variance, model->state()
+    the chain's state draw including the autoregression block"""
+    from cases import bsts_priors, structural_data, structural_spec
+    L = C.CDLL(BINDING_SO)
+    L.ref_binding_last_error.restype = C.c_char_p
+    p, chains, nsw, seed = 7, 4, 12, 777
+    lags = len(coef)
+    X, y, _, obs = structural_data(T, p, 2, nseasons, seed=21 + nseasons, ar_coef=coef)
+    prior, ss, sig_up = bsts_priors(X, y, 2)
+    spec = structural_spec(y, trend, nseasons, ar_lags=lags)
+    ar = spec["ar"]
+    m = trend + (nseasons - 1 if nseasons > 0 else 0) + lags
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(p, np.uint8)
+    gam = np.zeros((nsw, p), np.uint8)
+    beta = np.zeros((nsw, p))
+    sig = np.zeros(nsw)
+    var = np.zeros((nsw, 3))
+    state = np.zeros((nsw, T, m))
+    out_ar = np.zeros((nsw, lags + 1))
+    logpri = np.zeros(nsw)
+    dev_seed = C.c_uint64()
+    pg = np.zeros(p, np.uint8)
+    pstate = np.zeros((T, m))
+    arv = f64([ar["df"], ar["sigma_guess"], ar["sigma_upper_limit"], ar["initial_sigma"]])
+    rc = L.ref_binding_ss_ar_run(
+        T, p, _dp(f64(y)), _dp(fcol(X)), _u8(None), _dp(f64(prior["b"])), _dp(fcol(prior["ominv"])),
+        C.c_double(prior["df"]), C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+        C.c_double(sig_up), trend, nseasons, _dp(f64(spec["var_df"])),
+        _dp(f64(spec["var_sigma_guess"])), _dp(f64(spec["var_sigma_upper_limit"])),
+        _dp(f64(spec["var_initial_sigma"])), _dp(f64(spec["initial_state_mean"])),
+        _dp(f64(spec["initial_state_variance"])), lags, _dp(arv), _dp(f64(ar["initial_phi"])),
+        chains, C.c_uint64(seed), _u8(g0), nsw,
+        _u8(gam), _dp(beta), _dp(sig), _dp(var), _dp(state), _dp(out_ar), _dp(logpri),
+        C.byref(dev_seed), chains - 1, _u8(pg), _dp(pstate))
+    assert rc == 0, L.ref_binding_last_error().decode()
+    o = oracle.ssm_run(y, X, obs, prior, opts, spec, ("philox", dev_seed.value, 0), g0, nsw)
+    assert o["status"] == 0
+    for s in range(nsw):
+        assert np.array_equal(gam[s], o["gamma"][s]), s
+        err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
+        assert err < 1e-8, (s, err)
+        assert np.max(np.abs(out_ar[s, :lags] - o["ar_phi"][s])) < 1e-7, s
+        assert abs(out_ar[s, lags] - o["ar_sigsq"][s]) < 1e-7 * o["ar_sigsq"][s], s
+        scale = np.abs(o["state"][s]).max()
+        assert np.max(np.abs(state[s] - o["state"][s])) < 1e-8 * scale, s
+    assert np.all(np.isfinite(logpri))
+    ol = oracle.ssm_run(y, X, obs, prior, opts, spec, ("philox", dev_seed.value, chains - 1), g0, nsw)
+    assert np.array_equal(pg, ol["gamma"][-1])
+    assert np.max(np.abs(pstate - ol["state"][-1])) < 1e-8 * np.abs(ol["state"][-1]).max()
+
+
 
 @pytest.mark.skipif(not os.path.exists(BINDING_SO),
                     reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
