@@ -291,7 +291,7 @@ struct ba_engine {
   DevBuf<uint64_t> dpos_sss;
   uint64_t seed = 0;
   // AdaptiveSpikeSlabRegressionSampler (mode 2): rates, iteration counts, options
-  DevBuf<double> dada_birth, dada_death;
+  DevBuf<double> dada_birth, dada_death, dada_ws;
   DevBuf<uint64_t> dada_iter, dpos_ada;
   int ada_max_flips = 100;
   double ada_step = .001, ada_target = .345;
@@ -657,6 +657,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.ada_step = e->ada_step;
   P.ada_target = e->ada_target;
   P.ada_max_flips = e->ada_max_flips;
+  P.adaptive = (e->cur_mode == 2) ? 1 : 0;
+  P.ada_ws = e->dada_ws.ptr;
   P.inc_count = e->dinc.ptr;
   P.beta_sum = e->dbsum.ptr;
   P.beta_sumsq = e->dbsumsq.ptr;
@@ -714,8 +716,8 @@ int ensure_big_buffers(ba_engine *e) {
 // once any chain has outgrown it -- the HBM-resident kernel right behind it for
 // the chains the first one parked (status CHAIN_MODEL_TOO_LARGE)
 hipError_t launch_sweeps(ba_engine *e, const SsvsParams &P, int nsweeps) {
-  if (e->cur_mode == 2) return launch_ssvs_adaptive(e->stream, P, nsweeps);
-  hipError_t err = launch_ssvs_sweep(e->stream, P, nsweeps);
+  hipError_t err = (e->cur_mode == 2) ? launch_ssvs_adaptive(e->stream, P, nsweeps)
+                                      : launch_ssvs_sweep(e->stream, P, nsweeps);
   if (err == hipSuccess && e->big_active) err = launch_ssvs_big(e->stream, P, 0);
   return err;
 }
@@ -800,7 +802,6 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
     if (!any) return BA_OK;
     if (e->cfg.max_model_size_hint > 0) return BA_OK;  // stays an error
     if (e->kcap >= cap_limit(*e)) {
-      if (e->cur_mode == 2) return BA_OK;  // (the adaptive kernel stops at 64 variables: stays an error)
       // beyond the LDS kernel: the parked chains go to the HBM-resident one
       int stuck = 0;
       int rc = grow_big(e, &stuck);
@@ -2539,6 +2540,7 @@ static int ada_prepare(ba_engine *e) {
   HIP_TRY(e->dada_birth.resize(C * p));
   HIP_TRY(e->dada_death.resize(C * p));
   HIP_TRY(e->dada_iter.resize(C));
+  HIP_TRY(e->dada_ws.resize(C * 4 * p));   // (the large-model kernel's: cumulative rates, the sweep's undo copy)
   HIP_TRY(e->dpos_ada.resize(C));
   std::vector<double> ones(C * p, 1.0);   // birth_rates_, death_rates_ start at 1
   HIP_TRY(hipMemcpyAsync(e->dada_birth.ptr, ones.data(), C * p * 8, hipMemcpyHostToDevice, e->stream));
@@ -2586,7 +2588,7 @@ int ba_adaptive_sweep(ba_engine *e, int32_t nsweeps) {
     return fail(BA_E_INVALID, "problem does not fit the LDS working set of the adaptive kernel");
   if (e->trace_stride > 0)
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
-  HIP_TRY(launch_ssvs_adaptive(e->stream, P, (int)nsweeps));
+  HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
   return BA_OK;
 }
 

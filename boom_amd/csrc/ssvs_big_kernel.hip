@@ -35,6 +35,17 @@ namespace {
 
 enum : int { BCMD_EXIT = 0, BCMD_EVAL = 1, BCMD_UNIF = 2 };
 
+// inclusive prefix sum over the wave, lane order
+__device__ __forceinline__ double big_prefix(double x) {
+  x += dpp_f64<0x111, 0xf>(x, 0.0);
+  x += dpp_f64<0x112, 0xf>(x, 0.0);
+  x += dpp_f64<0x114, 0xf>(x, 0.0);
+  x += dpp_f64<0x118, 0xf>(x, 0.0);
+  x += dpp_f64<0x142, 0xa>(x, 0.0);
+  x += dpp_f64<0x143, 0xc>(x, 0.0);
+  return x;
+}
+
 // offset (doubles) of 8 x 8 block (I, J), J <= I, of a block-packed factor
 __device__ __forceinline__ int blk_off(int I, int J) { return ((I * (I + 1)) / 2 + J) * 64; }
 
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   };
 
   enum : int { BCMD_NONE = -1, BCMD_BUILD = 3 };
-  enum : int { PH_INIT, PH_BEGIN, PH_SHUFFLED, PH_FLIPS, PH_SWAP, PH_TAIL };
+  enum : int { PH_INIT, PH_BEGIN, PH_SHUFFLED, PH_FLIPS, PH_SWAP, PH_TAIL, PH_ADA };
   enum : int { BR_INIT, BR_VALID, BR_TRY };
 
   // ---- master-only state (wave 1 carries it along unused) ---------------------
@@ -665,6 +676,19 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   double t_lu = 0.0, t_lfw = 0.0, t_lrev = 0.0;
   WinRng rng;
   rng.init(key, lane, 0);
+  // ---- the adaptive sampler's moves (AdaptiveSpikeSlabRegressionSampler.cpp:62-225, see
+  // ssvs_adaptive_kernel.hip) on a model of more than 64 variables: the rates and
+  // their cumulative sums live in HBM, a move's candidate model is read off the table
+  const bool adaptive = P.adaptive != 0;
+  double *g_birth = adaptive ? P.ada_birth + (size_t)chain * p : nullptr;
+  double *g_death = adaptive ? P.ada_death + (size_t)chain * p : nullptr;
+  double *cumb = adaptive ? P.ada_ws + (size_t)chain * 4 * (size_t)p : nullptr;
+  double *cumd = cumb + p, *birth0 = cumb + 2 * (size_t)p, *death0 = cumb + 3 * (size_t)p;
+  const int ada_flips = (P.ada_max_flips < p) ? P.ada_max_flips : p;
+  uint64_t iteration = 0;
+  int ada_i = 0;
+  bool cum_dirty = true, t_birth = false, rates_saved = false;
+  double Bsum = 0.0, Dsum = 0.0;
 
 #define BACC_ADD(slot, x) do { if (lane == 0) ctl[CT_ACC + (slot)] += (double)(x); } while (0)
 #define BACC_MIN(x) do { if (lane == 0) ctl[CT_ACC + ACC_MIN_MARGIN] = fmin(ctl[CT_ACC + ACC_MIN_MARGIN], (x)); } while (0)
@@ -711,8 +735,9 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     pos0 = pos;
     failures = uni((int)P.failures[chain]);
     sigsq = uni((double)P.sigsq[chain]);
+    if (adaptive) iteration = uni((uint64_t)P.ada_iter[chain]);
     rng.init(key, lane, pos);
-    if (lane < 8) ctl[CT_ACC + lane] = (lane == ACC_MIN_MARGIN) ? BA_INF : 0.0;
+    if (lane < 16) ctl[CT_ACC + lane] = (lane == ACC_MIN_MARGIN || (adaptive && lane == ACC_PHASE0)) ? BA_INF : 0.0;
     wave_sync();
   }
 
@@ -745,8 +770,23 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         }
         if (phase == PH_BEGIN) {
           if (sweep >= nsweeps) { cmd = BCMD_EXIT; break; }
-          // ---- draw_model_indicators (BregVsSampler.cpp:353-378)
           pos0 = pos;
+          if (adaptive) {
+            // ---- the sweep's birth / death moves; what an aborted sweep has to undo is saved first
+            if (ada_flips <= 0) { phase = PH_TAIL; continue; }
+            for (int j = lane; j < p; j += WAVE) {
+              ch.gam0[j] = ch.gam[j];
+              birth0[j] = g_birth[j];
+              death0[j] = g_death[j];
+            }
+            wave_sync();
+            rates_saved = true;
+            ada_i = 0;
+            cum_dirty = true;
+            phase = PH_ADA;
+            continue;
+          }
+          // ---- draw_model_indicators (BregVsSampler.cpp:353-378)
           if (nflips <= 0) { phase = PH_SWAP; continue; }
           for (int j = lane; j < p; j += WAVE) {
             ch.gam0[j] = ch.gam[j];
@@ -853,6 +893,120 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
           }
           if (dr.kind == 0) request_try(dr.j, -1, 0, 0.0, 0.0, 0.0, PH_FLIPS);
           else              request_try(dr.j, -1, 1, dr.logu, 0.0, 0.0, PH_FLIPS);
+          cmd = BCMD_BUILD;
+          break;
+        }
+        if (phase == PH_ADA) {
+          if (ada_i >= ada_flips) { phase = PH_TAIL; continue; }
+          if (!table_valid) {
+            // log_model_prob of every single-variable change of the current model
+            if (fill_base >= p) {
+              fill_base = 0;
+              table_valid = true;
+              continue;
+            }
+            if (lane == 0) {
+              ctl[CT_K] = (double)ch.k;
+              ctl[CT_I0] = (double)fill_base;
+              ctl[CT_CUR] = (double)cur;
+            }
+            fill_base += WAVE * W;
+            cmd = BCMD_EVAL;
+            break;
+          }
+          if (cum_dirty) {
+            // cumulative rates of the candidates of either move, in variable order
+            double cb = 0.0, cd = 0.0;
+            __builtin_amdgcn_s_waitcnt(0);
+            for (int base = 0; base < p; base += WAVE) {
+              const int j = base + lane;
+              const bool in = j < p;
+              const bool inc = in && ch.gam[j];
+              const double wb = (in && !inc) ? g_birth[j] : 0.0;
+              const double wd = inc ? g_death[j] : 0.0;
+              const double pb = big_prefix(wb), pd = big_prefix(wd);
+              if (in) { cumb[j] = cb + pb; cumd[j] = cd + pd; }
+              cb += bcast_u(pb, 63);
+              cd += bcast_u(pd, 63);
+            }
+            Bsum = cb;
+            Dsum = cd;
+            cum_dirty = false;
+            __builtin_amdgcn_s_waitcnt(0);
+            wave_sync();
+          }
+          // the next (up to) 64 moves, one per lane, as long as none is accepted
+          const int kk = ch.k;
+          const bool edge = (kk == 0 || kk == p);
+          const int nb = edge ? 1 : ((ada_flips - ada_i < WAVE) ? ada_flips - ada_i : WAVE);
+          const bool valid = lane < nb;
+          const uint64_t mypos = pos + 3ull * (uint64_t)lane;
+          const double u0 = philox_uniform(key, mypos);
+          const bool isbirth = u0 < .5;
+          const bool possible = isbirth ? (kk < p) : (kk > 0);
+          const double u1 = philox_uniform(key, mypos + 1);
+          const double u2 = philox_uniform(key, mypos + 2);
+          const double tot = isbirth ? Bsum : Dsum;
+          const double *cum = isbirth ? cumb : cumd;
+          const double tmp = 0.0 + (tot - 0.0) * u1;
+          int lo = 0, hi = p - 1;
+          if (valid && possible) {
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (cum[mid] >= tmp) hi = mid; else lo = mid + 1;
+            }
+          }
+          int j = lo;
+          if (valid && possible) {
+            while (j < p - 1 && ((ch.gam[j] != 0) == isbirth)) ++j;
+          }
+          const bool cand_ok = valid && possible && ((ch.gam[j] != 0) != isbirth);
+          const bool broken_multi = valid && possible && !cand_ok;
+          double mmargin = BA_INF;
+          if (cand_ok) {
+            const double below = (j > 0) ? cum[j - 1] : 0.0;
+            mmargin = fmin(fabs(tmp - cum[j]), (tmp > below || j == 0) ? fabs(tmp - below) : BA_INF) / tot;
+          }
+          const double plogp = cand_ok ? ch.tab_lp[j] : 0.0;
+          const int pkind = cand_ok ? (int)ch.tab_kind[j] : 0;
+          const double wj = cand_ok ? (isbirth ? g_birth[j] : g_death[j]) : 1.0;
+          const double bj = cand_ok ? (isbirth ? g_death[j] : g_birth[j]) : 1.0;
+          const double fwd = log(wj / tot);
+          const double rev = log(bj / ((isbirth ? Dsum : Bsum) + bj));
+          const double logu = log(u2);
+          const double ratio = (plogp - fwd) - (M.logp - rev);
+          const bool slow = cand_ok && pkind == STOP_SLOW;
+          const bool bad = cand_ok && pkind == STOP_BAD;
+          const bool accept = cand_ok && !slow && !bad && (logu < ratio);
+          const unsigned long long m_acc = __ballot(accept), m_slow = __ballot(slow),
+                                   m_bad = __ballot(bad), m_brk = __ballot(broken_multi);
+          const unsigned long long m_stop = m_acc | m_slow | m_bad | m_brk;
+          const int f = m_stop ? (__ffsll((long long)m_stop) - 1) : WAVE;
+          const bool counted = cand_ok && (lane < f || (lane == f && ((m_acc >> f) & 1ull)));
+          const double mg = (counted && plogp > -BA_INF && M.logp > -BA_INF) ? fabs(logu - ratio) : BA_INF;
+          {
+            const double wm = wave_min(mg), wmm = wave_min(counted ? mmargin : BA_INF);
+            BACC_MIN(wm);
+            if (lane == 0) ctl[CT_ACC + ACC_PHASE0] = fmin(ctl[CT_ACC + ACC_PHASE0], wmm);
+          }
+          if (f == WAVE) {
+            BACC_ADD(ACC_PROPOSALS, nb);
+            ada_i += nb;
+            pos += edge ? (uni((int)possible) ? 3ull : 1ull) : 3ull * (uint64_t)nb;
+            continue;
+          }
+          BACC_ADD(ACC_PROPOSALS, f + 1);
+          ada_i += f + 1;
+          pos += 3ull * (uint64_t)(f + 1);
+          if ((m_brk >> f) & 1ull) { status = CHAIN_RNG_BRANCH; continue; }
+          if ((m_bad >> f) & 1ull) { status = CHAIN_NEGATIVE_SS; continue; }
+          const int jf = bcast_u(j, f);
+          t_birth = bcast_u((int)isbirth, f) != 0;
+          if (t_birth && ch.k >= kcap) { status = CHAIN_MODEL_TOO_LARGE; aborted = true; continue; }
+          // the candidate model is built in the other slot; a variable with a non-zero
+          // prior mean (the exact path) decides only then
+          request_try(jf, -1, ((m_slow >> f) & 1ull) ? 2 : 0, bcast_u(logu, f), bcast_u(fwd, f),
+                      bcast_u(rev, f), PH_ADA);
           cmd = BCMD_BUILD;
           break;
         }
@@ -982,6 +1136,8 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         wave_sync();
         ++done;
         ++sweep;
+        ++iteration;
+        rates_saved = false;
         phase = PH_BEGIN;
       }
       if (lane == 0) ctl[CT_CMD] = (double)cmd;
@@ -1006,7 +1162,8 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
       const bool valid = idx < p;
       const Proposal pr = big_eval<true>(BP, ch, Me, bx, sc, valid ? idx : 0, valid);
       if (valid) {
-        ch.tab_lp[idx] = exp(pr.logp - Me.logp);
+        // (the adaptive moves compare log model probabilities themselves)
+        ch.tab_lp[idx] = adaptive ? pr.logp : exp(pr.logp - Me.logp);
         ch.tab_kind[idx] = (uint8_t)(pr.bad_ss ? STOP_BAD : (pr.slow ? STOP_SLOW : 0));
       }
     } else if (wave == 0) {  // BCMD_BUILD
@@ -1033,6 +1190,18 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
           const double d = (Mn.logp - t_lfw) - (M.logp - t_lrev);
           if (Mn.logp > -BA_INF) BACC_MIN(fabs(t_lu - d));
           acc = (t_kind == 1) ? !(t_lu > d) : (t_lu < d);
+        }
+        if (acc && adaptive) {
+          // adjust_birth_rate / adjust_death_rate (.cpp:194-200, :228-234) with the
+          // acceptance probability of the move just made
+          double alpha = exp((Mn.logp - t_lfw) - (M.logp - t_lrev));
+          if (alpha > 1.0) alpha = 1.0;
+          double adjustment = P.ada_step / ((1.0 + (double)iteration) / (double)p);
+          adjustment *= (alpha - P.ada_target);
+          double *rate = t_birth ? g_birth : g_death;
+          if (lane == 0) rate[t_f1] = rate[t_f1] * exp(adjustment);
+          cum_dirty = true;
+          if (!Mn.pd) status = CHAIN_NOT_PD;
         }
         if (acc) {
           M = Mn;
@@ -1068,7 +1237,11 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     const lds_u16 *psrc = (aborted && p > 1) ? ch.perm_alt : ch.perm;
     for (int j = lane; j < p; j += WAVE) {
       g_gamma[j] = gsrc[j];
-      g_perm[j] = psrc[j];
+      if (!adaptive) g_perm[j] = psrc[j];
+      if (adaptive && aborted && rates_saved) {   // the aborted sweep's rate changes
+        g_birth[j] = birth0[j];
+        g_death[j] = death0[j];
+      }
     }
     if (aborted) pos = pos0;
   }
@@ -1088,6 +1261,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     P.rng_pos[chain] = pos;
     P.failures[chain] = failures;
     P.status[chain] = status;
+    if (adaptive) P.ada_iter[chain] = iteration;
     if (P.col_request) P.col_request[chain] = need_col;
     P.todo[chain] = nsweeps - done + owed_after;
     if (P.ran) P.ran[chain] = done;
@@ -1106,6 +1280,9 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     a[ACC_PROPOSALS] += ctl[CT_ACC + ACC_PROPOSALS];
     a[ACC_SLOT_HITS] += ctl[CT_ACC + ACC_SLOT_HITS];
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], ctl[CT_ACC + ACC_MIN_MARGIN]);
+    if (adaptive)
+      a[ACC_PHASE0] = (a[ACC_PHASE0] == 0.0) ? ctl[CT_ACC + ACC_PHASE0]
+                                             : fmin(a[ACC_PHASE0], ctl[CT_ACC + ACC_PHASE0]);
   }
 }
 

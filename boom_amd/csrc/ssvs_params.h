@@ -164,6 +164,8 @@ struct SsvsParams {
   uint64_t *ada_iter;              // chains
   double ada_step, ada_target;     // step_size_, target_acceptance_rate_
   int32_t ada_max_flips;           // max_flips_ (100); 0 = no model selection
+  int32_t adaptive;                // 1: the launch serves the adaptive sampler (ssvs_big_kernel's mode switch)
+  double *ada_ws;                  // chains x 4 p (large-model kernel): cumulative birth / death rates, the rates at the sweep's start
 
   // ---- HBM-resident path (ssvs_big_kernel.hip): models of more than 64
   // variables.  Capacity big_kcap (a multiple of 64); per-chain model blocks laid

@@ -235,8 +235,10 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps);
  *   ba_adaptive_sweep        nsweeps x draw() (.cpp:62-85) on every chain
  *   ba_adaptive_get_rates    birth_rates_, death_rates_, iteration_count_ of a
  *                            chain (any pointer may be NULL)
- * Models of more than 64 variables are not supported by this sampler's kernel
- * yet (BA_E_MODEL_TOO_LARGE). */
+ * A chain whose model grows beyond 64 variables moves to the large-model kernel, as
+ * BregVsSampler's chains do (its moves are then read off that kernel's table of
+ * log model probabilities, rebuilt after every accepted move); the limit is the
+ * large-model kernel's (512 variables), beyond it BA_E_MODEL_TOO_LARGE. */
 int ba_adaptive_set_options(ba_engine *e, int32_t max_flips, double step_size,
                             double target_acceptance_rate);
 int ba_adaptive_sweep(ba_engine *e, int32_t nsweeps);

@@ -110,3 +110,44 @@ def test_adaptive_c2_shape_properties():
     assert gam[:, nsig:].mean() < 0.01
     assert np.all(beta[gam == 0] == 0.0)
     assert abs(np.sqrt(sig).mean() - 1.0) < 0.05
+
+
+# ------------------------------------------------- models of more than 64 variables
+def test_adaptive_wide_start_above_64(oracle):
+    """The chains start with 80 variables included: the LDS kernel parks them at once
+    and the large-model kernel runs the birth / death moves from its table
+    (tests/golden/adaptive_wide_start80.npz pins the oracle on the reference)."""
+    n, p, nsig = 900, 160, 90
+    X, y, _ = regression_data(n, p, nsig, seed=11)
+    suf = suf_from_xy(X, y)
+    prior = spike_slab_prior(suf, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[:80] = 1
+    eng = make_engine(6, 5, suf=suf, prior=prior, g0=g0)
+    ora = _compare(oracle, eng, suf, prior, ssvs_options(), 5, g0, 30, [0, 3, 5], 10)
+    assert min(o["gamma"].sum(axis=1).min() for o in ora.values()) > 64
+    sm = eng.get_summaries()
+    assert sm["min_margin"] > 1e-9 and sm["min_multi_margin"] > 1e-12
+
+
+def test_adaptive_wide_growth_through_64(oracle):
+    """a start at one variable and 100 true signals: the model grows through the LDS
+    kernel's capacities (16, 32, 48, 64: sweeps aborted and replayed) into the
+    large-model kernel and through its capacities (128)"""
+    n, p, nsig = 900, 130, 100
+    X, y, _ = regression_data(n, p, nsig, seed=12)
+    suf = suf_from_xy(X, y)
+    prior = spike_slab_prior(suf, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    eng = make_engine(5, 9, suf=suf, prior=prior, g0=g0, tuning=dict(kcap_start=16))
+    eng.adaptive_set_options(max_flips=130, step_size=-1.0, target=-1.0)
+    ora = _compare(oracle, eng, suf, prior, ssvs_options(), 9, g0, 40, [0, 4], 8, max_flips=130)
+    assert max(o["gamma"].sum(axis=1).max() for o in ora.values()) > 90
+    # sweeps one at a time from here: the same chain
+    _ = eng.get_states()
+    eng2 = make_engine(5, 9, suf=suf, prior=prior, g0=g0)
+    eng2.adaptive_set_options(max_flips=130, step_size=-1.0, target=-1.0)
+    for _ in range(40):
+        eng2.adaptive_sweep(1)
+    assert all(np.array_equal(a, b) for a, b in zip(eng.get_states(), eng2.get_states()))

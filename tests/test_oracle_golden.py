@@ -462,7 +462,8 @@ def test_impute_state_known_answer(oracle):
 
 
 @pytest.mark.parametrize("name", ["adaptive_c1", "adaptive_p150", "adaptive_collinear",
-                                  "adaptive_options"])
+                                  "adaptive_options", "adaptive_wide_start80",
+                                  "adaptive_wide_growth"])
 def test_adaptive_sampler_matches_reference(oracle, name):
     """AdaptiveSpikeSlabRegressionSampler (what lm.spike runs for p > 100): the
     oracle's restatement on the reference's engine and seed against the
