@@ -238,7 +238,7 @@ int ba_sss_sweep(ba_engine *e, int32_t nsweeps);
  * A chain whose model grows beyond 64 variables moves to the large-model kernel, as
  * BregVsSampler's chains do (its moves are then read off that kernel's table of
  * log model probabilities, rebuilt after every accepted move); the limit is the
- * large-model kernel's (512 variables), beyond it BA_E_MODEL_TOO_LARGE. */
+ * large-model kernel's (1024 variables), beyond it BA_E_MODEL_TOO_LARGE. */
 int ba_adaptive_set_options(ba_engine *e, int32_t max_flips, double step_size,
                             double target_acceptance_rate);
 int ba_adaptive_sweep(ba_engine *e, int32_t nsweeps);
