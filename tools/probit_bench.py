@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic timing of the probit / logit spike-and-slab paths (f3) at BASELINE
 config 5's per-GPU shape: n=5e4, p=1024, Bernoulli data, 512 chains.  Not a bench
-line.  usage: probit_bench.py [n p signals chains [probit|logit [timed sweeps]]]"""
+line.  usage: probit_bench.py [n p signals chains [probit|logit|pg [timed sweeps]]]
+(pg: the logit sampler with the Polya-Gamma imputer)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -18,6 +19,8 @@ eng = boom_amd.Engine(chains, seed=4)
 t0 = time.perf_counter()
 (eng.probit_set_data if kind == "probit" else eng.logit_set_data)(X, y, nt, 5)
 print("set_data (X'NX build incl. upload): %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+if kind == "pg":
+    eng.logit_set_imputer(1)
 eng.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
 eng.set_spike(pi)
 g0 = np.zeros(p, np.uint8); g0[0] = 1

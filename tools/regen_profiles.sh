@@ -14,7 +14,7 @@ set -u
 ROUND=${1:-r03}
 COMMIT=${2:-unknown}
 shift; shift
-ONLY=${@:-c2 c3 structural logit probit xtx_c2 xtx_c4}
+ONLY=${@:-c2 c3 structural structural_ar logit pg probit xtx_c2 xtx_c4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 DEST=$ROOT/gpurun_out/profiles_$ROUND
 mkdir -p $DEST
@@ -44,8 +44,10 @@ profile() {   # name, pmc (yes|no), kernel substrings for the summary, then the 
 for w in $ONLY; do
   case $w in
     c2)         profile c2 yes "ssvs_ xtx_mfma plane_sum col_reduce" $ROOT/bench.py --no-cpu-baseline --no-curve ;;
-    c3)         profile c3 yes "ssvs_ kalman atb_mfma" $ROOT/tools/ss_bench.py ;;
-    structural) profile structural yes "ssvs_ ssm_ atb_mfma" $ROOT/tools/structural_bench.py 2,12,1024 ;;
+    c3)         profile c3 yes "ssvs_ kalman xtwx_" $ROOT/tools/ss_bench.py ;;
+    structural) profile structural yes "ssvs_ ssm_ xtwx_" $ROOT/tools/structural_bench.py 2,12,1024 ;;
+    structural_ar) profile structural_ar no "ssvs_ ssm_ xtwx_" $ROOT/tools/structural_bench.py 2,12,1024,2 ;;
+    pg)         profile pg no "ssvs_ logit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 pg 12 ;;
     logit)      profile logit yes "ssvs_ logit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 logit 12 ;;
     probit)     profile probit yes "ssvs_ probit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 probit 12 ;;
     xtx_c2)     profile xtx_c2 no "xtx_mfma plane_sum col_reduce" $ROOT/tools/suf_bench.py 10000 512 20 ;;

@@ -10,17 +10,25 @@ import boom_amd
 from cases import bsts_priors, structural_data, structural_spec
 
 T, p, nsig = 2000, 100, 5
-for trend, ns, chains in [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or ((1, 0, 1024), (2, 0, 1024), (2, 7, 1024), (2, 12, 1024), (2, 12, 4096)):
-    X, y, btrue, _ = structural_data(T, p, nsig, ns, seed=8675309)
+# arguments: trend,nseasons,chains[,ar lags]
+for spec_arg in [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or ((1, 0, 1024), (2, 0, 1024), (2, 7, 1024), (2, 12, 1024), (2, 12, 4096), (2, 12, 1024, 2)):
+    trend, ns, chains = spec_arg[:3]
+    lags = spec_arg[3] if len(spec_arg) > 3 else 0
+    X, y, btrue, _ = structural_data(T, p, nsig, ns, seed=8675309, ar_coef=[1.2, -0.4][:lags] if 0 < lags <= 2 else ([0.3] * lags if lags else None))
     prior, _, sig_up = bsts_priors(X, y, 5)
-    spec = structural_spec(y, trend, ns)
+    spec = structural_spec(y, trend, ns, ar_lags=lags)
+    m0 = trend + max(ns - 1, 0)
     eng = boom_amd.Engine(chains, seed=4)
     eng.ss_set_data(y, X, None)
     eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
                    sigma_upper_limit=sig_up)
     eng.ss_set_structural(trend, ns, spec["var_df"], spec["var_sigma_guess"],
                           spec["var_sigma_upper_limit"], spec["var_initial_sigma"],
-                          spec["initial_state_mean"], spec["initial_state_variance"])
+                          spec["initial_state_mean"][:m0], spec["initial_state_variance"][:m0])
+    if lags:
+        ar = spec["ar"]
+        eng.ss_add_ar(lags, ar["df"], ar["sigma_guess"], ar["sigma_upper_limit"], ar["initial_sigma"],
+                      ar["initial_phi"], spec["initial_state_mean"][m0:], spec["initial_state_variance"][m0:])
     eng.set_state(np.zeros(p, np.uint8))
     eng.ss_sweep(20)
     n = 30
@@ -28,5 +36,5 @@ for trend, ns, chains in [tuple(int(v) for v in a.split(",")) for a in sys.argv[
     eng.ss_sweep(n)
     dt = time.perf_counter() - t0
     gam, beta, sig = eng.get_states()
-    print("trend %d nseasons %2d (m=%2d) chains %4d: %8.1f us per sweep-round, %.3g sweeps/s, kbar %.2f"
-          % (trend, ns, trend + max(ns - 1, 0), chains, dt / n * 1e6, chains * n / dt, gam.sum(1).mean()))
+    print("trend %d nseasons %2d ar %d (m=%2d) chains %4d: %8.1f us per sweep-round, %.3g sweeps/s, kbar %.2f"
+          % (trend, ns, lags, m0 + lags, chains, dt / n * 1e6, chains * n / dt, gam.sum(1).mean()))
