@@ -47,6 +47,7 @@ namespace boom_amd {
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int PLD = SSM_MAX + 1;   // leading dimension of the state variance in LDS
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double sdpp(double x, double fill) {
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   // are done by then: 37 KB per workgroup, four workgroups per CU)
   struct PassLds {
     double blk[2][WAVE * SSM_MAX];   // a block of 64 steps of a state-sized series, per wave
-    double P[SSM_MAX * SSM_MAX];     // the state variance (wave 1)
+    double P[SSM_MAX * PLD];         // the state variance (wave 1), rows PLD apart
     double tv[SSM_MAX];
   };
   union SharedLds {
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   __shared__ int s_flag;
   __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
-  double (&s_P)[SSM_MAX * SSM_MAX] = s_lds.pass.P;
+  double (&s_P)[SSM_MAX * PLD] = s_lds.pass.P;
   double (&s_tv)[SSM_MAX] = s_lds.pass.tv;
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;
@@ -550,14 +551,15 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   // (read with v_readlane), its state-sized series in LDS, and what a block
   // produces goes out in one coalesced piece.
   if (wave == 1) {
-    // P lives in LDS (s_P[row * 16 + column], both indices in the rotating
+    // P lives in LDS (s_P[row * PLD + column], PLD = 17: a lane per column and a lane per
+    // row are both free of bank conflicts; both indices in the rotating
     // layout, kept exactly symmetric): the rows and columns a step touches move
     // with the cursor, which registers cannot follow.  Lane k < m owns column k;
     // the rank-one update runs over all 256 entries on all 64 lanes.
-    for (int e = lane; e < SSM_MAX * SSM_MAX; e += WAVE) s_P[e] = 0.0;
+    for (int e = lane; e < SSM_MAX * PLD; e += WAVE) s_P[e] = 0.0;
     if (lane < SSM_MAX) s_tv[lane] = 0.0;
     __builtin_amdgcn_wave_barrier();
-    if (mylane) s_P[lane * (SSM_MAX + 1)] = P0l;
+    if (mylane) s_P[lane * (PLD + 1)] = P0l;
     __builtin_amdgcn_wave_barrier();
     int c = 0;
     for (int tb = 0; tb < T; tb += WAVE) {
@@ -574,8 +576,8 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         double PZ = 0.0;
         if (mylane) {
           PZ = s_P[lane];
-          if (SEAS) PZ += s_P[rc * SSM_MAX + lane];
-          if (AR) PZ += s_P[S.a0 * SSM_MAX + lane];
+          if (SEAS) PZ += s_P[rc * PLD + lane];
+          if (AR) PZ += s_P[S.a0 * PLD + lane];
         }
         const double F = zdot<SEAS, AR>(S, PZ, c) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
@@ -588,9 +590,9 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         if (lane == s) F_l = F;
         // T P T' -- the trend block: row 0 += row 1, then column 0 += column 1
         if (TREND == 2) {
-          if (mylane) s_P[lane] = s_P[lane] + s_P[SSM_MAX + lane];
+          if (mylane) s_P[lane] = s_P[lane] + s_P[PLD + lane];
           __builtin_amdgcn_wave_barrier();
-          if (mylane) s_P[lane * SSM_MAX] = s_P[lane * SSM_MAX] + s_P[lane * SSM_MAX + 1];
+          if (mylane) s_P[lane * PLD] = s_P[lane * PLD] + s_P[lane * PLD + 1];
           __builtin_amdgcn_wave_barrier();
         }
         // -- the seasonal block: the row / column of the component that drops out
@@ -600,16 +602,16 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           if (mylane) {
 #pragma unroll
             for (int q = 0; q < SSM_MAX - 1; ++q)
-              if (q < S.ns) cs -= s_P[(TREND + q) * SSM_MAX + lane];
+              if (q < S.ns) cs -= s_P[(TREND + q) * PLD + lane];
           }
           const double tot = row_total(S.seasonal(lane) ? cs : 0.0);
           __builtin_amdgcn_wave_barrier();
           if (mylane) {
-            s_P[rw * SSM_MAX + lane] = cs;
-            s_P[lane * SSM_MAX + rw] = cs;
+            s_P[rw * PLD + lane] = cs;
+            s_P[lane * PLD + rw] = cs;
           }
           __builtin_amdgcn_wave_barrier();
-          if (lane == rw) s_P[rw * (SSM_MAX + 1)] = -tot;
+          if (lane == rw) s_P[rw * (PLD + 1)] = -tot;
           __builtin_amdgcn_wave_barrier();
         }
         // -- the autoregression block (logical order): T P, then (T P) T'.  Lane k owns
@@ -620,19 +622,16 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 #pragma unroll
           for (int pass = 0; pass < 2; ++pass) {
             if (mylane) {
-              const int sr = pass == 0 ? SSM_MAX : 1, sc = pass == 0 ? 1 : SSM_MAX;   // strides along / across the block
-              double old[SSM_MAX - 1];
+              const int sr = pass == 0 ? PLD : 1, sc = pass == 0 ? 1 : PLD;   // strides along / across the block
+              // from the last lag down, moving each entry one place on as it is read (a
+              // rolled loop: fifteen guarded copies of its body cost 3 400 cycles a step)
               double cs = 0.0;
-#pragma unroll
-              for (int q = 0; q < SSM_MAX - 1; ++q) {
-                if (q < S.na) {
-                  old[q] = s_P[(S.a0 + q) * sr + lane * sc];
-                  cs += s_phi[q] * old[q];
-                }
+#pragma nounroll
+              for (int q = S.na - 1; q >= 0; --q) {
+                const double v = s_P[(S.a0 + q) * sr + lane * sc];
+                cs += s_phi[q] * v;
+                if (q + 1 < S.na) s_P[(S.a0 + q + 1) * sr + lane * sc] = v;
               }
-#pragma unroll
-              for (int q = 1; q < SSM_MAX - 1; ++q)
-                if (q < S.na) s_P[(S.a0 + q) * sr + lane * sc] = old[q - 1];
               s_P[S.a0 * sr + lane * sc] = cs;
             }
             __builtin_amdgcn_wave_barrier();
@@ -645,15 +644,15 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           for (int e4 = 0; e4 < SSM_MAX * SSM_MAX / WAVE; ++e4) {
             const int e = lane + WAVE * e4;
             const int i = e >> 4, k2 = e & 15;
-            if (i < m && k2 < m) s_P[e] -= (s_tv[i] * s_tv[k2]) * Finv;
+            if (i < m && k2 < m) s_P[i * PLD + k2] -= (s_tv[i] * s_tv[k2]) * Finv;
           }
           __builtin_amdgcn_wave_barrier();
         }
         // + RQR
         if (lane == 0) s_P[0] += sig2[0];
-        if (TREND == 2 && lane == 1) s_P[SSM_MAX + 1] += sig2[1];
-        if (SEAS && lane == rw) s_P[rw * (SSM_MAX + 1)] += sig2[2];
-        if (AR && lane == S.a0) s_P[S.a0 * (SSM_MAX + 1)] += sig2a;
+        if (TREND == 2 && lane == 1) s_P[PLD + 1] += sig2[1];
+        if (SEAS && lane == rw) s_P[rw * (PLD + 1)] += sig2[2];
+        if (AR && lane == S.a0) s_P[S.a0 * (PLD + 1)] += sig2a;
         __builtin_amdgcn_wave_barrier();
         c = cn;
       }
@@ -803,10 +802,14 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   double suf0 = 0.0, suf2 = 0.0;
   double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of the trend errors (lanes 0, 1)
   double yty = 0.0, nobs = 0.0;
-  // ArModel's NeRegSuf of now[a0] on then[a0 ..]: lane a0 + i keeps row i of xtx and xty_i
-  double axx[SSM_MAX - 1], axy = 0.0, ayy = 0.0;
-#pragma unroll
-  for (int q = 0; q < SSM_MAX - 1; ++q) axx[q] = 0.0;
+  // ArModel's NeRegSuf of now[a0] on then[a0 ..]: lane a0 + i keeps xty_i and row i of xtx,
+  // the row in LDS (s_P is free by now: wave 1 has left), at s_axx[i * PLD + q]
+  double axy = 0.0, ayy = 0.0;
+  double *s_axx = s_P;
+  if (AR) {
+    for (int e2 = lane; e2 < SSM_MAX * PLD; e2 += WAVE) s_axx[e2] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+  }
   double *oblk = s_blk[1];
   {
     int c = 0;
@@ -860,9 +863,14 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           if (AR) {
             // add_mixture_data(now[0], then, 1.0): xtx += then then', xty += now[0] then, yty += now[0]^2
             const double yy = rl(st, S.a0);
-#pragma unroll
-            for (int q = 0; q < SSM_MAX - 1; ++q)
-              if (q < S.na) axx[q] += prev * rl(prev, S.a0 + q) * 1.0;
+            {
+              double *row = s_axx + (S.ar(lane) ? lane - S.a0 : 0) * PLD;
+#pragma nounroll
+              for (int q = 0; q < S.na; ++q) {
+                const double pq = rl(prev, S.a0 + q);
+                if (S.ar(lane)) row[q] += prev * pq * 1.0;
+              }
+            }
             axy += (yy * 1.0) * prev;
             ayy += yy * yy * 1.0;
           }
@@ -916,9 +924,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     double *suf = Q.ar_suf + (size_t)chain * AR_SUF_STRIDE;
     if (S.ar(lane)) {
       const int i = lane - S.a0;
-#pragma unroll
-      for (int q = 0; q < SSM_MAX - 1; ++q)
-        if (q < S.na) suf[i * SSM_MAX + q] = axx[q];
+      for (int q = 0; q < S.na; ++q) suf[i * SSM_MAX + q] = s_axx[i * PLD + q];
       suf[AR_SUF_XTY + i] = axy;
     }
     if (lane == 0) {

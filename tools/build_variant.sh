@@ -10,13 +10,13 @@ OUT=$ROOT/tools/build/$NAME
 mkdir -p $OUT
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
-for f in engine ssvs_kernel ssvs_big_kernel ssvs_adaptive_kernel ssm_kernel probit_kernel xtwx_cols_kernel predict_kernel suf_kernel kalman_kernel; do
+for f in engine group ssvs_kernel ssvs_big_kernel ssvs_adaptive_kernel ssm_kernel probit_kernel xtwx_cols_kernel predict_kernel suf_kernel kalman_kernel; do
   fl=$OTHER_FLAGS
   [ $f = ssvs_kernel ] && fl=$SSVS_FLAGS
-  [ $f = engine ] && fl=""
+  { [ $f = engine ] || [ $f = group ]; } && fl=""
   ( /opt/rocm/bin/hipcc $BASE $fl -c $SRC/$f.hip -o $OUT/$f.o 2>/dev/null ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/*.o -o $OUT/libboomamd.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/*.o -ldl -o $OUT/libboomamd.so
 ls -la $OUT/libboomamd.so
