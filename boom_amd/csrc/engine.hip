@@ -434,6 +434,11 @@ int choose_waves(const ba_engine &e, int kcap) {
   // 1 / 2 wavefronts: 1024 chains 28 / 41 M, 2048 30 / 36 M, 4096 31 / 43 M, 8192
   // 32 / 46 M), so chains beyond 4 per CU simply run in further rounds.
   (void)kcap;
+  // The state-space path alternates ONE sweep with the state draw: no table survives a round
+  // and there is no quiet sweep to fork, the helper wave has little to do; one wavefront per
+  // chain measured better at every size (T=2000, p=100, us per round with 1 / 2 wavefronts:
+  // 512 chains 144 / 144, 1024 167 / 172, 2048 279 / 304, 4096 545 / 590).
+  if (e.ss_mode) return 1;
   return 2;
 }
 
