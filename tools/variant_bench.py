@@ -31,7 +31,7 @@ def c2_engine(chains):
 
 
 for w in what:
-    if w in ("c2", "c2x2048", "c2x4096"):
+    if w == "c2" or w.startswith("c2x"):
         chains = 1024 if w == "c2" else int(w[3:])
         eng = c2_engine(chains)
         eng.sweep(1000)
