@@ -308,6 +308,13 @@ struct ba_engine {
   // second stream beside the X'e GEMM and the SSVS launch
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_state = nullptr, ev_prep = nullptr;
+  // pipelined sweeps: consecutive ba_sweep launches alternate between `stream` and
+  // pipe_stream and hand chains over through a ring of four queues (ssvs_kernel.hip)
+  hipStream_t pipe_stream = nullptr;
+  hipEvent_t pipe_ev[4] = {}, pipe_join_ev = nullptr;
+  DevBuf<int32_t> dpipe_q, dpipe_err;
+  bool pipe_on = false;      // the last thing enqueued was a pipelined sweep launch
+  int pipe_k = 0;            // launches in the current pipeline
   DevBuf<int32_t> dprep_n;
   DevBuf<uint64_t> dprep_pos_state, dprep_pos_level;
   DevBuf<double> dprep_level;
@@ -662,6 +669,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.ada_step = e->ada_step;
   P.ada_target = e->ada_target;
   P.ada_max_flips = e->ada_max_flips;
+  P.q_in = P.q_out = nullptr;
+  P.q_error = nullptr;
   P.adaptive = (e->cur_mode == 2) ? 1 : 0;
   P.ada_ws = e->dada_ws.ptr;
   P.inc_count = e->dinc.ptr;
@@ -983,6 +992,29 @@ int set_device(const ba_engine *e) {
   return BA_OK;
 }
 
+// ---- pipelined sweeps ---------------------------------------------------------------
+// The end of a pipeline: the main stream waits for the other one, so that whatever is
+// enqueued next comes after every sweep launch; a workgroup that waited for its chain in
+// vain (it cannot happen while the chains fit the machine; bounded all the same) is an error.
+int pipe_join(ba_engine *e) {
+  if (!e->pipe_on) return BA_OK;
+  e->pipe_on = false;
+  e->pipe_k = 0;
+  HIP_TRY(hipEventRecord(e->pipe_join_ev, e->pipe_stream));
+  HIP_TRY(hipStreamWaitEvent(e->stream, e->pipe_join_ev, 0));
+  return BA_OK;
+}
+int pipe_check(ba_engine *e) {
+  if (e->dpipe_err.count == 0) return BA_OK;
+  int32_t err = 0;
+  HIP_TRY(hipMemcpy(&err, e->dpipe_err.ptr, 4, hipMemcpyDeviceToHost));
+  if (err) {
+    HIP_TRY(hipMemset(e->dpipe_err.ptr, 0, 4));
+    return fail(BA_E_HIP, "a pipelined sweep launch waited for a chain in vain");
+  }
+  return BA_OK;
+}
+
 // ---- look-ahead serving (ba_draw_next) ------------------------------------------
 int sweep_impl(ba_engine *e, int32_t nsweeps, bool record = true);
 int read_record(ba_engine *e, int64_t c, int row0, int nrows, uint8_t *gamma,
@@ -1101,11 +1133,19 @@ int la_rewind(ba_engine *e) {
     (e)->model_ok = false;               \
   } while (0)
 
-#define ENGINE_PROLOGUE(e)                                     \
+#define ENGINE_PROLOGUE_NOJOIN(e)                              \
   if (!(e)) return fail(BA_E_INVALID, "null engine");          \
   g_kt = (e)->kt_enabled ? &(e)->kt : nullptr;                 \
   {                                                            \
     int rc__ = set_device(e);                                  \
+    if (rc__) return rc__;                                     \
+  }
+// (everything but ba_sweep itself first lets the main stream catch up with a pipeline
+// of sweep launches)
+#define ENGINE_PROLOGUE(e)                                     \
+  ENGINE_PROLOGUE_NOJOIN(e)                                    \
+  {                                                            \
+    int rc__ = pipe_join(e);                                   \
     if (rc__) return rc__;                                     \
   }
 
@@ -1166,6 +1206,12 @@ void ba_engine_destroy(ba_engine *e) {
   if (e->stream2) {
     (void)hipStreamSynchronize(e->stream2);
     (void)hipStreamDestroy(e->stream2);
+  }
+  if (e->pipe_stream) {
+    (void)hipStreamSynchronize(e->pipe_stream);
+    (void)hipStreamDestroy(e->pipe_stream);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e->pipe_ev[i]);
+    (void)hipEventDestroy(e->pipe_join_ev);
   }
   if (e->ev_state) (void)hipEventDestroy(e->ev_state);
   if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
@@ -1746,7 +1792,53 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
     return fail(BA_E_INVALID, "problem does not fit the LDS working set");
   if (record && e->trace_stride > 0)  // traces are those of the last ba_sweep call
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
-  HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
+#ifndef BA_PIPELINE
+#define BA_PIPELINE 1
+#endif
+  // Consecutive ba_sweep calls with nothing in between: the launches alternate between two
+  // streams and hand the chains over one by one (ssvs_kernel.hip), so that the next launch
+  // fills the slots the current one's early finishers leave instead of waiting for its
+  // slowest chain.  Only while every chain's workgroup is resident at once, no trace is
+  // recorded (its cursor is reset per call) and no chain lives in the large-model kernel.
+  const int resident_per_cu = (int)std::min<size_t>(4, e->lds_per_cu / lay.total);
+  const bool pipelined = BA_PIPELINE && nsweeps > 0 && e->trace_stride == 0 && !e->big_active &&
+                         e->cfg.chains <= resident_per_cu * e->cu_count && !e->kt_enabled;
+  if (!pipelined) {
+    int rcj = pipe_join(e);
+    if (rcj) return rcj;
+    HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
+  } else {
+    const size_t C = (size_t)e->cfg.chains, qlen = C + 2;
+    if (!e->pipe_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&e->pipe_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&e->pipe_ev[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->pipe_join_ev, hipEventDisableTiming));
+    }
+    if (e->dpipe_q.count != 4 * qlen) {
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      HIP_TRY(e->dpipe_q.resize(4 * qlen));
+      HIP_TRY(e->dpipe_err.resize(1));
+      HIP_TRY(hipMemset(e->dpipe_err.ptr, 0, 4));
+    }
+    const int k = e->pipe_on ? e->pipe_k : 0;     // (a new pipeline starts on the main stream)
+    hipStream_t st = (k & 1) ? e->pipe_stream : e->stream;
+    int32_t *qout = e->dpipe_q.ptr + (size_t)(k & 3) * qlen;
+    // the queue this launch fills: emptied on its own stream (after the launch two before
+    // it, whose hand-over to the launch before it used the queue four back at the latest)
+    HIP_TRY(hipMemsetAsync(qout, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(qout + 2, 0xFF, C * 4, st));
+    HIP_TRY(hipEventRecord(e->pipe_ev[k & 3], st));
+    P.q_out = qout;
+    P.q_error = e->dpipe_err.ptr;
+    if (k > 0) {
+      P.q_in = e->dpipe_q.ptr + (size_t)((k - 1) & 3) * qlen;
+      // (... which the previous launch's stream has emptied before that launch)
+      HIP_TRY(hipStreamWaitEvent(st, e->pipe_ev[(k - 1) & 3], 0));
+    }
+    HIP_TRY(launch_ssvs_sweep(st, P, (int)nsweeps));
+    e->pipe_on = true;
+    e->pipe_k = k + 1;
+  }
   e->table_ok = true;  // until anything but another ba_sweep touches the engine
   e->model_ok = true;
   return BA_OK;
@@ -1756,7 +1848,11 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
 extern "C" {
 
 int ba_sweep(ba_engine *e, int32_t nsweeps) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_PROLOGUE_NOJOIN(e);
+  if (e->la_served < e->la_avail || e->ss_mode || e->logit_mode || e->probit_mode || e->cur_mode != 0) {
+    int rcj = pipe_join(e);   // (anything but a plain continuation)
+    if (rcj) return rcj;
+  }
   // unserved look-ahead draws: the sweeps asked for here come after the last one served
   int rc = la_rewind(e);
   if (rc) return rc;
@@ -1796,6 +1892,8 @@ int ba_draw_next(ba_engine *e) {
 int ba_sync(ba_engine *e) {
   ENGINE_PROLOGUE(e);
   HIP_TRY(hipStreamSynchronize(e->stream));
+  int rc = pipe_check(e);
+  if (rc) return rc;
   return check_chain_status(e);
 }
 

@@ -46,10 +46,8 @@
 namespace boom_amd {
 
 template <int NB, int W, int WPE>
-__global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
-                                                            int nsweeps) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int chain = (int)blockIdx.x + P.chain_first;
+__device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const int chain,
+                                                unsigned char *smem) {
   P.V += (size_t)chain * (size_t)P.v_chain_stride;   // (a chain's own V: the logit sampler's X'WX moves with its latent data)
   if (P.col_valid) {
     P.col_valid += (size_t)chain * (size_t)P.col_words;
@@ -58,7 +56,6 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P,
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int p = P.p;
-  if ((int)blockIdx.x >= P.chain_count) return;
   if (P.status[chain] != CHAIN_OK) {
     // a chain waiting for a larger-capacity kernel (or in error) just books
     // the sweeps it is owed
@@ -1023,6 +1020,51 @@ __global__ __launch_bounds__(256) void ssvs_reduce_summaries_kernel(SsvsParams P
       out[2 * p + j] = s2[0];
     } else {
       out[3 * p + (j - p)] = s0[0];
+    }
+  }
+}
+
+// The kernel: which chain, the sweeps, and -- between launches that overlap (engine.hip,
+// pipelined sweeps) -- the hand-over.  A launch lasts as long as its slowest chain; when the
+// next launch is already queued on another stream its workgroups move into the slots the
+// early finishers leave, each taking over a chain that IS done (in the order the chains
+// finish), so nothing idles between two launches and no chain is ever in two places.
+enum : int { Q_PUSH = 0, Q_POP = 1, Q_READY = 2 };
+template <int NB, int W, int WPE>
+__global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P, int nsweeps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_chain;
+  if ((int)blockIdx.x >= P.chain_count) return;
+  int chain = (int)blockIdx.x + P.chain_first;
+  if (P.q_in) {
+    if (threadIdx.x == 0) {
+      // every workgroup of this launch started in a slot that a workgroup of the previous
+      // launch left AFTER appending its chain, or beside previous-launch workgroups that are
+      // still running and will append: ticket t is served after a bounded wait
+      const int t = atomicAdd(P.q_in + Q_POP, 1);
+      int c = -1;
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        c = __hip_atomic_load(P.q_in + Q_READY + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (c >= 0) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+      s_chain = c;
+    }
+    __syncthreads();
+    chain = s_chain;
+    if (chain < 0) {   // (seconds of waiting: reported, not hung)
+      if (threadIdx.x == 0) atomicExch(P.q_error, 1);
+      return;
+    }
+    __threadfence();   // the chain's state as the workgroup that appended it left it
+  }
+  ssvs_sweep_body<NB, W, WPE>(P, nsweeps, chain, smem);
+  if (P.q_out) {
+    __syncthreads();
+    __threadfence();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(P.q_out + Q_PUSH, 1);
+      __hip_atomic_store(P.q_out + Q_READY + t, chain, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

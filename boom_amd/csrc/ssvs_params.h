@@ -164,6 +164,13 @@ struct SsvsParams {
   uint64_t *ada_iter;              // chains
   double ada_step, ada_target;     // step_size_, target_acceptance_rate_
   int32_t ada_max_flips;           // max_flips_ (100); 0 = no model selection
+  // Launches that hand chains over to one another (engine.hip: pipelined sweeps).  A
+  // queue is int32 [push count | pop count | ready[chains]]: a workgroup of the launch that
+  // fills q_out appends its chain when it is done with it; a workgroup of the next launch
+  // (q_in = that queue) takes the next ready chain instead of chain blockIdx.x.  nullptr:
+  // chain blockIdx.x, nothing appended.
+  int32_t *q_in, *q_out;
+  int32_t *q_error;                // set to 1 by a workgroup that waited for a chain in vain
   int32_t adaptive;                // 1: the launch serves the adaptive sampler (ssvs_big_kernel's mode switch)
   double *ada_ws;                  // chains x 4 p (large-model kernel): cumulative birth / death rates, the rates at the sweep's start
 

@@ -225,3 +225,44 @@ def test_log_model_prob_of_models_beyond_64_variables(oracle):
     ref = make_engine(2, 4, suf=suf, prior=prior, g0=g0)
     ref.sweep(3)
     assert _same(eng.get_states(), ref.get_states())
+
+
+def test_overlapping_sweep_launches_hand_chains_over(oracle):
+    """Consecutive ba_sweep calls with nothing in between run on two streams and hand the
+    chains over one by one (a workgroup of the next launch takes a chain the current launch
+    is done with): the draws are those of one launch at a time, for every chain, and any
+    other call in between (a state read, a prior change) joins the pipeline first."""
+    import boom_amd
+    n, p, nsig, chains = 2000, 64, 6, 96
+    X, y, _ = regression_data(n, p, nsig, seed=17)
+    suf = suf_from_xy(X, y)
+    prior = spike_slab_prior(suf, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+
+    def fresh():
+        return make_engine(chains, 123, suf=suf, prior=prior, g0=g0)
+    a, b = fresh(), fresh()
+    plan = [7, 1, 30, 2, 2, 19, 64, 1, 1, 40]
+    for i, k in enumerate(plan):
+        a.sweep(k, sync=False)            # (no sync: the launches overlap)
+        if i == 5:
+            ga, _, _ = a.get_states()     # a reader in the middle joins the pipeline
+            a.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+    a.sync()
+    for i, k in enumerate(plan):
+        b.sweep(k, sync=True)
+        if i == 5:
+            gb, _, _ = b.get_states()
+            b.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+    assert np.array_equal(ga, gb)
+    for u, v in zip(a.get_states(), b.get_states()):
+        assert np.array_equal(u, v)
+    sa, sb = a.get_summaries(), b.get_summaries()
+    assert sa["sweeps"] == sb["sweeps"] and sa["sweeps"] > 0
+    assert np.array_equal(sa["inclusion_count"], sb["inclusion_count"])
+    # ... and the chains are the oracle's
+    o = oracle.ssvs_run(suf, prior, ssvs_options(), ("philox", 123, chains - 1), g0, sum(plan))
+    gam, beta, sig = a.get_states()
+    assert np.array_equal(gam[chains - 1], o["gamma"][-1])
+    assert abs(sig[chains - 1] - o["sigsq"][-1]) < 1e-8 * sig[chains - 1]
