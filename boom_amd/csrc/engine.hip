@@ -268,6 +268,15 @@ struct ba_engine {
   struct LaRows { std::vector<double> k, sig, beta; std::vector<uint16_t> idx; };
   std::unordered_map<int64_t, LaRows> la_cache;
   bool la_synced = false;
+  // Overlapping look-ahead batches: the record holds two batches (halves la_slot and
+  // la_slot ^ 1 of 2 la_len rows), the batch after the one being served is launched as soon
+  // as serving starts (la_ahead) and the launches hand chains over (pipelined sweeps); each
+  // batch's workgroups save their chain's state on entry (snapshot set = half) for rewinds.
+  bool la_pipe = true;        // allowed (off for good after a batch had to be redone the old way)
+  bool la_cur_piped = false;  // the batch being served was launched that way
+  bool la_ahead = false;
+  int la_slot = 0;
+  hipEvent_t la_done[2] = {nullptr, nullptr};
   DevBuf<uint8_t> snap_gamma;
   DevBuf<double> snap_beta, snap_sigsq, snap_bsum, snap_bsumsq, snap_acc;
   DevBuf<uint16_t> snap_perm;
@@ -671,6 +680,8 @@ void fill_params(ba_engine *e, SsvsParams &P) {
   P.ada_max_flips = e->ada_max_flips;
   P.q_in = P.q_out = nullptr;
   P.q_error = nullptr;
+  P.trace_row0 = -1;
+  P.snap_gamma = nullptr;
   P.adaptive = (e->cur_mode == 2) ? 1 : 0;
   P.ada_ws = e->dada_ws.ptr;
   P.inc_count = e->dinc.ptr;
@@ -1016,7 +1027,7 @@ int pipe_check(ba_engine *e) {
 }
 
 // ---- look-ahead serving (ba_draw_next) ------------------------------------------
-int sweep_impl(ba_engine *e, int32_t nsweeps, bool record = true);
+int sweep_impl(ba_engine *e, int32_t nsweeps, bool record = true, int la_half = -1);
 int read_record(ba_engine *e, int64_t c, int row0, int nrows, uint8_t *gamma,
                 double *beta, double *sigsq);
 int read_record_row_all(ba_engine *e, int row, uint8_t *gamma, double *beta, double *sigsq);
@@ -1027,21 +1038,48 @@ void la_discard(ba_engine *e) {
   e->la_synced = false;
 }
 
-// the draw ba_draw_next is serving, for one chain: from the host copy of the
-// chain's rows of the batch (fetched at the chain's first read in the batch)
-int la_read(ba_engine *e, int64_t c, uint8_t *gamma, double *beta, double *sigsq) {
-  if (!e->la_synced) {
+int la_copy(ba_engine *e, bool save, int set = 0);
+int la_redo_batch(ba_engine *e);
+
+// the batch being served is complete and sound; a pipelined batch in which a chain stopped
+// (capacity, an error) is run again the old way -- same draws -- where those are dealt with
+int la_wait(ba_engine *e) {
+  if (e->la_synced) return BA_OK;
+  if (e->la_cur_piped) {
+    HIP_TRY(hipEventSynchronize(e->la_done[e->la_slot]));
+    int rc = pipe_check(e);
+    if (rc) return rc;
+    const size_t C = (size_t)e->cfg.chains;
+    std::vector<int32_t> st(C);
+    HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+    bool ok = true;
+    for (size_t c = 0; c < C; ++c) ok = ok && st[c] == CHAIN_OK;
+    if (!ok) {
+      rc = la_redo_batch(e);
+      if (rc) return rc;
+    }
+  } else {
     HIP_TRY(hipStreamSynchronize(e->stream));
     int rc = check_chain_status(e);
     if (rc) return rc;
-    e->la_synced = true;
+  }
+  e->la_synced = true;
+  return BA_OK;
+}
+
+// the draw ba_draw_next is serving, for one chain: from the host copy of the
+// chain's rows of the batch (fetched at the chain's first read in the batch)
+int la_read(ba_engine *e, int64_t c, uint8_t *gamma, double *beta, double *sigsq) {
+  {
+    int rc = la_wait(e);
+    if (rc) return rc;
   }
   const size_t p = (size_t)e->p, cap = (size_t)e->rec_cap, n = (size_t)e->la_avail;
   auto it = e->la_cache.find(c);
   if (it == e->la_cache.end()) {
     ba_engine::LaRows r;
     r.k.resize(n); r.sig.resize(n); r.beta.resize(n * cap); r.idx.resize(n * cap);
-    const size_t base = (size_t)c * e->trace_stride;
+    const size_t base = (size_t)c * e->trace_stride + (size_t)e->la_slot * (size_t)e->la_len;
     HIP_TRY(hipMemcpy(r.k.data(), e->dtr_k.ptr + base, n * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(r.sig.data(), e->dtr_sig.ptr + base, n * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(r.idx.data(), e->drec_idx.ptr + base * cap, n * cap * 2, hipMemcpyDeviceToHost));
@@ -1064,37 +1102,86 @@ int la_read(ba_engine *e, int64_t c, uint8_t *gamma, double *beta, double *sigsq
   return BA_OK;
 }
 
-int la_copy(ba_engine *e, bool save) {
+// snapshot set `set` (0 / 1) <-> the live chain state
+int la_snap_alloc(ba_engine *e) {
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
+  HIP_TRY(e->snap_gamma.resize(2 * C * p));
+  HIP_TRY(e->snap_beta.resize(2 * C * p));
+  HIP_TRY(e->snap_sigsq.resize(2 * C));
+  HIP_TRY(e->snap_perm.resize(2 * C * p));
+  HIP_TRY(e->snap_pos.resize(2 * C));
+  HIP_TRY(e->snap_fail.resize(2 * C));
+  HIP_TRY(e->snap_inc.resize(2 * C * p));
+  HIP_TRY(e->snap_bsum.resize(2 * C * p));
+  HIP_TRY(e->snap_bsumsq.resize(2 * C * p));
+  HIP_TRY(e->snap_acc.resize(2 * C * ACC_COUNT));
+  return BA_OK;
+}
+int la_copy(ba_engine *e, bool save, int set) {
   const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
   hipStream_t s = e->stream;
   if (save) {
-    HIP_TRY(e->snap_gamma.resize(C * p));
-    HIP_TRY(e->snap_beta.resize(C * p));
-    HIP_TRY(e->snap_sigsq.resize(C));
-    HIP_TRY(e->snap_perm.resize(C * p));
-    HIP_TRY(e->snap_pos.resize(C));
-    HIP_TRY(e->snap_fail.resize(C));
-    HIP_TRY(e->snap_inc.resize(C * p));
-    HIP_TRY(e->snap_bsum.resize(C * p));
-    HIP_TRY(e->snap_bsumsq.resize(C * p));
-    HIP_TRY(e->snap_acc.resize(C * ACC_COUNT));
+    int rc = la_snap_alloc(e);
+    if (rc) return rc;
   }
+  const size_t o1 = (size_t)set * C, op = (size_t)set * C * p;
 #define LA_CP(snap, live, bytes)                                                      \
   HIP_TRY(hipMemcpyAsync(save ? (void *)(snap) : (void *)(live),                       \
                          save ? (const void *)(live) : (const void *)(snap), (bytes), \
                          hipMemcpyDeviceToDevice, s))
-  LA_CP(e->snap_gamma.ptr, e->dgamma.ptr, C * p);
-  LA_CP(e->snap_beta.ptr, e->dbeta.ptr, C * p * 8);
-  LA_CP(e->snap_sigsq.ptr, e->dsigsq.ptr, C * 8);
-  LA_CP(e->snap_perm.ptr, e->dperm.ptr, C * p * 2);
-  LA_CP(e->snap_pos.ptr, e->dpos.ptr, C * 8);
-  LA_CP(e->snap_fail.ptr, e->dfail.ptr, C * 4);
-  LA_CP(e->snap_inc.ptr, e->dinc.ptr, C * p * 4);
-  LA_CP(e->snap_bsum.ptr, e->dbsum.ptr, C * p * 8);
-  LA_CP(e->snap_bsumsq.ptr, e->dbsumsq.ptr, C * p * 8);
-  LA_CP(e->snap_acc.ptr, e->dacc.ptr, C * ACC_COUNT * 8);
+  LA_CP(e->snap_gamma.ptr + op, e->dgamma.ptr, C * p);
+  LA_CP(e->snap_beta.ptr + op, e->dbeta.ptr, C * p * 8);
+  LA_CP(e->snap_sigsq.ptr + o1, e->dsigsq.ptr, C * 8);
+  LA_CP(e->snap_perm.ptr + op, e->dperm.ptr, C * p * 2);
+  LA_CP(e->snap_pos.ptr + o1, e->dpos.ptr, C * 8);
+  LA_CP(e->snap_fail.ptr + o1, e->dfail.ptr, C * 4);
+  LA_CP(e->snap_inc.ptr + op, e->dinc.ptr, C * p * 4);
+  LA_CP(e->snap_bsum.ptr + op, e->dbsum.ptr, C * p * 8);
+  LA_CP(e->snap_bsumsq.ptr + op, e->dbsumsq.ptr, C * p * 8);
+  LA_CP(e->snap_acc.ptr + (size_t)set * C * ACC_COUNT, e->dacc.ptr, C * ACC_COUNT * 8);
 #undef LA_CP
   return BA_OK;
+}
+
+// every launch of the look-ahead has finished (the main stream has caught up with the other
+// one) and nothing is ahead any more; *ahead_was: a batch beyond the one being served ran
+int la_quiesce(ba_engine *e, bool *ahead_was) {
+  *ahead_was = e->la_ahead;
+  e->la_ahead = false;
+  int rc = pipe_join(e);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return BA_OK;
+}
+
+// A pipelined batch met a chain that cannot go on as it is (model beyond the launch's
+// capacity, an error): everything in flight is dropped, the chains go back to the batch's
+// start and the batch runs again the way batches ran before they overlapped -- the same
+// draws, with the escalation / error report of that path.  Overlap stays off afterwards.
+int la_redo_batch(ba_engine *e) {
+  bool ahead = false;
+  int rc = la_quiesce(e, &ahead);
+  if (rc) return rc;
+  const int served = e->la_served;
+  rc = la_copy(e, false, e->la_slot);
+  if (rc) return rc;
+  {  // (the statuses and the sweeps booked as owed belong to the dropped launches)
+    const size_t C = (size_t)e->cfg.chains;
+    HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, C * 4, e->stream));
+    HIP_TRY(hipMemsetAsync(e->dtodo.ptr, 0, C * 4, e->stream));
+  }
+  e->la_pipe = false;
+  e->la_cur_piped = false;
+  e->la_slot = 0;
+  e->table_ok = false;
+  e->model_ok = false;
+  rc = la_copy(e, true, 0);
+  if (!rc) rc = sweep_impl(e, e->la_len);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->la_cache.clear();
+  e->la_served = served;
+  return check_chain_status(e);
 }
 
 // Something other than ba_draw_next is about to touch the engine while draws of
@@ -1102,18 +1189,36 @@ int la_copy(ba_engine *e, bool save) {
 // seen them -- the batch's start, replayed up to the last draw handed out (same
 // stream positions, so the same draws).
 int la_rewind(ba_engine *e) {
-  if (e->la_served >= e->la_avail) {
+  if (e->la_served >= e->la_avail && !e->la_ahead) {
     la_discard(e);
     return BA_OK;
   }
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  const int replay = e->la_served;
+  bool ahead = false;
+  int rc = la_quiesce(e, &ahead);
+  if (rc) return rc;
+  const bool all_served = e->la_served >= e->la_avail;
+  const int replay = all_served ? 0 : e->la_served;
+  // where to go back to: the start of the batch being served, or -- every draw of it
+  // served, the next one already run -- the start of that next one
+  const int set = all_served ? (e->la_slot ^ 1) : e->la_slot;
+  const bool piped = e->la_cur_piped;
   la_discard(e);
-  int rc = check_chain_status(e);
+  if (piped) {
+    rc = pipe_check(e);
+    if (rc) return rc;
+    const size_t C = (size_t)e->cfg.chains;
+    // (a chain that stopped in the dropped launches stopped after the point we return to)
+    HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, C * 4, e->stream));
+    HIP_TRY(hipMemsetAsync(e->dtodo.ptr, 0, C * 4, e->stream));
+  } else {
+    rc = check_chain_status(e);
+    if (rc) return rc;
+  }
+  rc = la_copy(e, false, piped ? set : 0);
   if (rc) return rc;
-  rc = la_copy(e, false);
-  if (rc) return rc;
+  e->la_cur_piped = false;
+  e->la_slot = 0;
   e->table_ok = false;
   e->model_ok = false;
   if (replay > 0) {
@@ -1622,11 +1727,15 @@ int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
 
 int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
                  double *sigsq) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_PROLOGUE_NOJOIN(e);
   if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   if (e->la_served > 0 && e->la_served <= e->la_avail)  // the draw ba_draw_next is serving
     return la_read(e, chain, gamma, beta, sigsq);
+  {
+    int rcj = pipe_join(e);
+    if (rcj) return rcj;
+  }
   int rc = ba_sync(e);
   if (rc) return rc;
   const size_t p = (size_t)e->p;
@@ -1704,10 +1813,14 @@ int ba_logpri(ba_engine *e, int64_t chain, double *out) {
 int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
   ENGINE_PROLOGUE(e);
   if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
+  if (e->la_served > 0 && e->la_served <= e->la_avail && (e->la_served < e->la_avail || e->la_ahead)) {
+    // the draw being served, every chain: from the record (the chains themselves are ahead)
+    int rcw = la_wait(e);
+    if (rcw) return rcw;
+    return read_record_row_all(e, e->la_slot * e->la_len + e->la_served - 1, gamma, beta, sigsq);
+  }
   int rc = ba_sync(e);
   if (rc) return rc;
-  if (e->la_served > 0 && e->la_served < e->la_avail)
-    return read_record_row_all(e, e->la_served - 1, gamma, beta, sigsq);
   const size_t p = (size_t)e->p, C = (size_t)e->cfg.chains;
   if (gamma) HIP_TRY(hipMemcpy(gamma, e->dgamma.ptr, C * p, hipMemcpyDeviceToHost));
   if (beta) HIP_TRY(hipMemcpy(beta, e->dbeta.ptr, C * p * 8, hipMemcpyDeviceToHost));
@@ -1762,7 +1875,10 @@ static int switch_mode(ba_engine *e, int mode, double v_scale) {
 }  // extern "C"
 
 namespace {
-int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
+// la_half >= 0: a look-ahead batch that overlaps its neighbours -- recorded into that half of
+// the draw record, the chains' state on entry saved into that snapshot set (the caller has
+// checked la_can_overlap)
+int sweep_impl(ba_engine *e, int32_t nsweeps, bool record, int la_half) {
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   if (e->ss_mode) return fail(BA_E_STATE, "state-space data are set: use ba_ss_sweep");
   if (e->logit_mode || e->probit_mode)
@@ -1790,8 +1906,23 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
   const SsvsLds lay = ssvs_lds_layout(e->p, e->kcap);
   if (lay.total > e->lds_per_cu)
     return fail(BA_E_INVALID, "problem does not fit the LDS working set");
-  if (record && e->trace_stride > 0)  // traces are those of the last ba_sweep call
+  if (record && e->trace_stride > 0 && la_half < 0)  // traces are those of the last ba_sweep call
     HIP_TRY(hipMemsetAsync(e->dtrace_idx.ptr, 0, (size_t)e->cfg.chains * 4, e->stream));
+  if (la_half >= 0) {
+    const size_t C = (size_t)e->cfg.chains, pp = (size_t)e->p;
+    const size_t o1 = (size_t)la_half * C, op = (size_t)la_half * C * pp;
+    P.trace_row0 = la_half * e->la_len;
+    P.snap_gamma = e->snap_gamma.ptr + op;
+    P.snap_beta = e->snap_beta.ptr + op;
+    P.snap_sigsq = e->snap_sigsq.ptr + o1;
+    P.snap_perm = e->snap_perm.ptr + op;
+    P.snap_pos = e->snap_pos.ptr + o1;
+    P.snap_fail = e->snap_fail.ptr + o1;
+    P.snap_inc = e->snap_inc.ptr + op;
+    P.snap_bsum = e->snap_bsum.ptr + op;
+    P.snap_bsumsq = e->snap_bsumsq.ptr + op;
+    P.snap_acc = e->snap_acc.ptr + (size_t)la_half * C * ACC_COUNT;
+  }
 #ifndef BA_PIPELINE
 #define BA_PIPELINE 1
 #endif
@@ -1801,8 +1932,9 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
   // slowest chain.  Only while every chain's workgroup is resident at once, no trace is
   // recorded (its cursor is reset per call) and no chain lives in the large-model kernel.
   const int resident_per_cu = (int)std::min<size_t>(4, e->lds_per_cu / lay.total);
-  const bool pipelined = BA_PIPELINE && nsweeps > 0 && e->trace_stride == 0 && !e->big_active &&
+  const bool pipelined = BA_PIPELINE && nsweeps > 0 && (e->trace_stride == 0 || la_half >= 0) && !e->big_active &&
                          e->cfg.chains <= resident_per_cu * e->cu_count && !e->kt_enabled;
+  if (la_half >= 0 && !pipelined) return fail(BA_E_STATE, "look-ahead batch cannot overlap");
   if (!pipelined) {
     int rcj = pipe_join(e);
     if (rcj) return rcj;
@@ -1836,6 +1968,7 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record) {
       HIP_TRY(hipStreamWaitEvent(st, e->pipe_ev[(k - 1) & 3], 0));
     }
     HIP_TRY(launch_ssvs_sweep(st, P, (int)nsweeps));
+    if (la_half >= 0) HIP_TRY(hipEventRecord(e->la_done[la_half], st));
     e->pipe_on = true;
     e->pipe_k = k + 1;
   }
@@ -1864,26 +1997,69 @@ int ba_set_lookahead(ba_engine *e, int32_t lookahead) {
   if (lookahead < 1) return fail(BA_E_INVALID, "lookahead must be at least 1");
   MUTATE(e);
   if (lookahead > 1) {
-    int rc = ba_enable_draws(e, lookahead);
+    // (room for two batches: the one being served and the one launched ahead of it)
+    int rc = ba_enable_draws(e, 2 * lookahead);
     if (rc) return rc;
   }
   e->la_len = lookahead;
+  e->la_pipe = true;
   return BA_OK;
 }
 
+// can the next look-ahead batch overlap its neighbours (sweep_impl's conditions)
+static bool la_can_overlap(const ba_engine *e) {
+  if (!BA_PIPELINE || !e->la_pipe || e->big_active || e->kt_enabled || e->kcap <= 0) return false;
+  const size_t lds = ssvs_lds_layout(e->p, e->kcap).total;
+  if (lds > e->lds_per_cu) return false;
+  const int resident_per_cu = (int)std::min<size_t>(4, e->lds_per_cu / lds);
+  return e->cfg.chains <= resident_per_cu * e->cu_count;
+}
+
 int ba_draw_next(ba_engine *e) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_PROLOGUE_NOJOIN(e);
   if (e->la_len <= 1) return ba_sweep(e, 1);
   if (e->la_served == e->la_avail) {
-    // the record is used up: the next batch, from the chains' current state
-    la_discard(e);
-    int rc = switch_mode(e, 0, 1.0);
-    if (!rc) rc = upload_shared(e);
-    if (!rc) rc = alloc_chain_state(e);
-    if (!rc) rc = la_copy(e, true);
-    if (!rc) rc = sweep_impl(e, e->la_len);
-    if (rc) return rc;
+    // the record is used up: on to the next batch
+    if (e->la_ahead) {
+      // ... which is already running (or done): the other half of the record
+      e->la_slot ^= 1;
+      e->la_ahead = false;
+      e->la_avail = e->la_served = 0;
+      e->la_cache.clear();
+      e->la_synced = false;
+      e->la_cur_piped = true;
+    } else {
+      // ... from the chains' current state
+      int rc = pipe_join(e);
+      if (rc) return rc;
+      la_discard(e);
+      rc = switch_mode(e, 0, 1.0);
+      if (!rc) rc = upload_shared(e);
+      if (!rc) rc = alloc_chain_state(e);
+      if (rc) return rc;
+      if (!e->la_done[0]) {
+        HIP_TRY(hipEventCreateWithFlags(&e->la_done[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->la_done[1], hipEventDisableTiming));
+      }
+      e->la_slot = 0;
+      if (la_can_overlap(e)) {
+        rc = la_snap_alloc(e);
+        if (!rc) rc = sweep_impl(e, e->la_len, true, 0);
+        e->la_cur_piped = true;
+      } else {
+        rc = la_copy(e, true, 0);
+        if (!rc) rc = sweep_impl(e, e->la_len);
+        e->la_cur_piped = false;
+      }
+      if (rc) return rc;
+    }
     e->la_avail = e->la_len;
+    // the batch after this one goes out now, into the other half
+    if (e->la_cur_piped && la_can_overlap(e)) {
+      int rc = sweep_impl(e, e->la_len, true, e->la_slot ^ 1);
+      if (rc) return rc;
+      e->la_ahead = true;
+    }
   }
   ++e->la_served;
   return BA_OK;

@@ -201,7 +201,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   bool aborted = false;      // stopped inside a sweep: restore its start
   int need_col = -1;         // CHAIN_NEED_COLUMN: the variable whose vector of V is missing
   int kmax = k;
-  int trace_at = P.trace_idx ? P.trace_idx[chain] : 0;
+  int trace_at = (P.trace_row0 >= 0) ? P.trace_row0 : (P.trace_idx ? P.trace_idx[chain] : 0);
 
   uint64_t pos = uni((uint64_t)P.rng_pos[chain]);
   int failures = uni((int)P.failures[chain]);
@@ -1057,6 +1057,25 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P, i
       return;
     }
     __threadfence();   // the chain's state as the workgroup that appended it left it
+  }
+  if (P.snap_gamma) {
+    // the chain as this launch finds it (la_copy's list, engine.hip)
+    const size_t o = (size_t)chain * (size_t)P.p;
+    for (int j = threadIdx.x; j < P.p; j += WAVE * W) {
+      P.snap_gamma[o + j] = P.gamma[o + j];
+      P.snap_beta[o + j] = P.beta[o + j];
+      P.snap_perm[o + j] = P.perm[o + j];
+      P.snap_inc[o + j] = P.inc_count[o + j];
+      P.snap_bsum[o + j] = P.beta_sum[o + j];
+      P.snap_bsumsq[o + j] = P.beta_sumsq[o + j];
+    }
+    if (threadIdx.x < ACC_COUNT)
+      P.snap_acc[(size_t)chain * ACC_COUNT + threadIdx.x] = P.acc[(size_t)chain * ACC_COUNT + threadIdx.x];
+    if (threadIdx.x == 0) {
+      P.snap_sigsq[chain] = P.sigsq[chain];
+      P.snap_pos[chain] = P.rng_pos[chain];
+      P.snap_fail[chain] = P.failures[chain];
+    }
   }
   ssvs_sweep_body<NB, W, WPE>(P, nsweeps, chain, smem);
   if (P.q_out) {

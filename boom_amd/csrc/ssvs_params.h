@@ -171,6 +171,17 @@ struct SsvsParams {
   // chain blockIdx.x, nothing appended.
   int32_t *q_in, *q_out;
   int32_t *q_error;                // set to 1 by a workgroup that waited for a chain in vain
+  // Look-ahead batches that overlap (engine.hip): the batch's rows of the draw record start
+  // at trace_row0 (>= 0; -1: at trace_idx[chain]), and the chain's state at the batch's
+  // start is saved by the workgroup that takes the chain over (snap_gamma != nullptr) --
+  // what a rewind restores.
+  int32_t trace_row0;
+  uint8_t *snap_gamma;
+  double *snap_beta, *snap_sigsq, *snap_bsum, *snap_bsumsq, *snap_acc;
+  uint16_t *snap_perm;
+  uint64_t *snap_pos;
+  int32_t *snap_fail;
+  uint32_t *snap_inc;
   int32_t adaptive;                // 1: the launch serves the adaptive sampler (ssvs_big_kernel's mode switch)
   double *ada_ws;                  // chains x 4 p (large-model kernel): cumulative birth / death rates, the rates at the sweep's start
 

@@ -266,3 +266,57 @@ def test_overlapping_sweep_launches_hand_chains_over(oracle):
     gam, beta, sig = a.get_states()
     assert np.array_equal(gam[chains - 1], o["gamma"][-1])
     assert abs(sig[chains - 1] - o["sigsq"][-1]) < 1e-8 * sig[chains - 1]
+
+
+def test_overlapping_lookahead_batches_serve_the_per_call_draws():
+    """the callers' loop as they write it -- draw_next(); get_state(0) -- over many batches:
+    the batch after the one being served is already running (handing chains over launch to
+    launch), the served draws are those of one launch per call, for chain 0 at every
+    iteration and for every chain wherever one looks; a mutator in the middle of a batch
+    (with the next batch in flight) and one exactly at a batch's end rewind correctly"""
+    suf, prior, g0 = _case(p=48, nsig=6, seed=5, n=600)
+    chains, L = 40, 16
+    a = make_engine(chains, 21, suf=suf, prior=prior, g0=g0)
+    b = make_engine(chains, 21, suf=suf, prior=prior, g0=g0)
+    b.set_lookahead(L)
+    for it in range(1, 5 * L + 4):
+        a.sweep(1)
+        b.draw_next()
+        ga, ba_, sa = a.get_state(0)
+        gb, bb, sb = b.get_state(0)
+        assert np.array_equal(ga, gb) and np.array_equal(ba_, bb) and sa == sb, it
+        if it % 13 == 0:
+            assert _same(a.get_state(chains - 1), b.get_state(chains - 1)), it
+        if it == 2 * L + 5:          # mid-batch, next batch in flight
+            a.set_options(max_flips=30)
+            b.set_options(max_flips=30)
+        if it == 4 * L:              # the batch's last draw served, next batch in flight
+            assert _same(a.get_states(), b.get_states())
+            a.set_options(max_flips=-1)
+            b.set_options(max_flips=-1)
+    assert _same(a.get_states(), b.get_states())
+    a.sync()
+    b.sync()
+    for x in (a, b):
+        x.set_options(max_flips=-1)  # (a mutator: the look-ahead engine drops what it ran ahead)
+    sa, sb = a.get_summaries(), b.get_summaries()
+    assert sa["sweeps"] == sb["sweeps"]
+    assert np.array_equal(sa["inclusion_count"], sb["inclusion_count"])
+
+
+def test_overlapping_lookahead_batches_survive_a_capacity_stop():
+    """chains that outgrow the launch's capacity inside an overlapped batch: the batch is
+    run again the way batches ran before (escalation included), with the same draws"""
+    suf, prior, g0 = _case(p=64, nsig=28, seed=9, n=800)
+    chains, L = 12, 8
+    a = make_engine(chains, 3, suf=suf, prior=prior, g0=g0, tuning=dict(kcap_start=16))
+    b = make_engine(chains, 3, suf=suf, prior=prior, g0=g0, tuning=dict(kcap_start=16))
+    b.set_lookahead(L)
+    for it in range(6 * L):
+        a.sweep(1)
+        b.draw_next()
+        assert _same(a.get_state(0), b.get_state(0)), it
+        assert _same(a.get_state(chains - 1), b.get_state(chains - 1)), it
+    assert _same(a.get_states(), b.get_states())
+    gam, _, _ = a.get_states()
+    assert gam.sum(axis=1).max() > 16       # the models did outgrow the first capacity
