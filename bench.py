@@ -400,6 +400,11 @@ def main():
     ev0.record(est)
     for _ in range(args.steps):
         eng.sweep(SWEEPS_PER_STEP, sync=False)
+        # (ba_stream joins: every step is ONE launch that starts when the previous one has
+        # ended, so that a launch's duration here is what rocprofv3 reports for it; launches
+        # that overlap -- consecutive ba_sweep calls do, left alone -- are measured below as
+        # `overlapped_launches`)
+        eng.stream()
     ev1.record(est)
     eng.sync()
     torch.cuda.synchronize()
@@ -536,6 +541,25 @@ def main():
             loop["lookahead_%d" % L] = round(CHAINS_PER_GPU * L / float(np.median(tb)), 1)
         eng.set_lookahead(1)
 
+    # ---- launches that overlap (extra key): consecutive ba_sweep calls with nothing in
+    # between run on two streams and hand chains over launch to launch (a workgroup of the
+    # next launch takes a chain the current one is done with), so no launch waits for the
+    # previous one's slowest chain.  The headline's steps above are kept apart on purpose.
+    overlapped = None
+    if not args.no_curve and world == 1:
+        overlapped = {}
+        eng.enable_traces(0)       # (the look-ahead's record: not wanted here)
+        for L, K in ((1000, 8), (250, 32), (64, 125)):
+            eng.sync()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(K):
+                    eng.sweep(L, sync=False)
+                eng.sync()
+                ts.append(time.perf_counter() - t0)
+            overlapped["%d_sweeps_x_%d_launches" % (L, K)] = round(CHAINS_PER_GPU * L * K / min(ts), 1)
+
     # ---- the other BASELINE configurations at their per-GPU shapes (extra key, outside
     # the timed region; parity for them lives in tests/).  Per configuration: the rate of
     # a plain throughput pass, then a second pass with the engine's per-kernel HIP-event
@@ -606,6 +630,7 @@ def main():
         "decisions": decisions,
         "sweeps_per_sec_vs_chains_per_gpu": curve,
         "drop_in_loop_sweeps_per_sec": loop,
+        "overlapped_launches_sweeps_per_sec": overlapped,
         "other_configs": other,
         "suf_build_ms": round(suf_build_s * 1e3, 2),
         "signal_inclusion_min": round(float(incl[:N_SIGNAL].min()), 4),

@@ -1336,7 +1336,14 @@ int ba_engine_info(const ba_engine *e, int32_t *device, int32_t *chains,
   return BA_OK;
 }
 
-void *ba_stream(ba_engine *e) { return e ? (void *)e->stream : nullptr; }
+// (work the caller puts on the stream after this call comes after every launch of the engine:
+// sweeps that overlap on the engine's second stream are joined first)
+void *ba_stream(ba_engine *e) {
+  if (!e) return nullptr;
+  if (hipSetDevice(e->cfg.device) != hipSuccess) return nullptr;
+  if (pipe_join(e) != BA_OK) return nullptr;
+  return (void *)e->stream;
+}
 
 // ---- measurement: device time per kernel class (ktimer.h) ------------------------
 int32_t ba_kernel_classes(void) { return KT_CLASSES; }

@@ -370,7 +370,9 @@ int ba_predict(ba_engine *e, int32_t first_draw, int32_t ndraws, int32_t nnew,
 int ba_get_coefficient_traces(ba_engine *e, int32_t nsweeps, int32_t nvars,
                               const int32_t *vars, double *out);
 
-/* the engine's HIP stream (hipStream_t) for callers that order their own work */
+/* the engine's HIP stream (hipStream_t) for callers that order their own work: what is put
+ * on it after this call runs after every launch the engine has issued (consecutive
+ * ba_sweep calls overlap on a second stream of the engine; this call joins them) */
 void *ba_stream(ba_engine *e);
 
 /* ---- measurement -------------------------------------------------------------
