@@ -330,6 +330,19 @@ PYBIND11_MODULE(_boom, boom) {
       .def("set_prior", &SeasonalStateModel::set_prior, py::arg("df"), py::arg("sigma_guess"),
            py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity());
 
+  py::class_<ArStateModel, Ptr<ArStateModel>>(boom, "ArStateModel")
+      .def(py::init<int>(), py::arg("number_of_lags"))
+      .def_property_readonly("state_dimension", &ArStateModel::state_dimension)
+      .def_property_readonly("number_of_lags", &ArStateModel::number_of_lags)
+      .def("set_phi", [](ArStateModel &m, const NpArray &v) { m.set_phi(vector_from(v)); })
+      .def("set_sigma", &ArStateModel::set_sigma)
+      .def("set_sigsq", &ArStateModel::set_sigsq)
+      .def("set_initial_state_mean", [](ArStateModel &m, const NpArray &v) { m.set_initial_state_mean(vector_from(v)); })
+      .def("set_initial_state_variance", &ArStateModel::set_initial_state_variance)
+      .def("set_prior", &ArStateModel::set_prior, py::arg("df"), py::arg("sigma_guess"),
+           py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
+           "ArPosteriorSampler(model, ChisqModel(df, sigma_guess)) + set_sigma_upper_limit");
+
   py::class_<StateSpaceRegressionModel, Ptr<StateSpaceRegressionModel>>(boom, "StateSpaceRegressionModel")
       .def(py::init([](const NpArray &response, const NpArray &predictors, const std::vector<bool> &is_observed,
                        int chains, uint64_t seed, int device) {
@@ -344,6 +357,10 @@ PYBIND11_MODULE(_boom, boom) {
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<LocalLevelStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<LocalLinearTrendStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<SeasonalStateModel> &s) { m.add_state(s); })
+      .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<ArStateModel> &s) { m.add_state(s); })
+      .def("ar_phi", [](const StateSpaceRegressionModel &m, int chain) { return to_numpy(m.ar_phi(chain)); },
+           py::arg("chain") = 0, "the autoregression coefficients in one chain's current draw")
+      .def("ar_sigsq", &StateSpaceRegressionModel::ar_sigsq, py::arg("chain") = 0)
       .def("set_method", [](StateSpaceRegressionModel &m, const Ptr<PosteriorSampler> &s) { m.set_method(s); })
       .def("sample_posterior", &StateSpaceRegressionModel::sample_posterior)
       .def("state", [](const StateSpaceRegressionModel &m, int chain) {

@@ -356,6 +356,32 @@ class SeasonalStateModel {
   double sigma_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
 };
 
+// ArStateModel(number_of_lags) with an ArPosteriorSampler (StateModels/ArStateModel.hpp:53,
+// TimeSeries/PosteriorSamplers/ArPosteriorSampler.hpp): added after the trend / seasonal models
+class ArStateModel {
+ public:
+  explicit ArStateModel(int number_of_lags) : lags_(number_of_lags) {
+    if (number_of_lags < 1) report_error("the number of lags must be positive in the constructor for ArStateModel");
+    phi_ = Vector(number_of_lags, 0.0);
+    a0_ = Vector(number_of_lags, 0.0);
+    P0_ = Vector(number_of_lags, 1.0);
+  }
+  int state_dimension() const { return lags_; }
+  int number_of_lags() const { return lags_; }
+  void set_phi(const Vector &phi) { phi_ = phi; }
+  void set_sigma(double s) { sigma_ = s; }
+  void set_sigsq(double s) { sigma_ = std::sqrt(s); }
+  void set_initial_state_mean(const Vector &m) { a0_ = m; }
+  void set_initial_state_variance(double v) { P0_ = Vector(lags_, v); }
+  // ArPosteriorSampler(model, ChisqModel(df, sigma_guess)) [+ set_sigma_upper_limit]
+  void set_prior(double df, double sigma_guess, double sigma_upper_limit = infinity()) {
+    df_ = df; guess_ = sigma_guess; upper_ = sigma_upper_limit;
+  }
+  int lags_;
+  Vector phi_, a0_, P0_;
+  double sigma_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
+};
+
 class StateSpaceRegressionModel : public Model {
  public:
   StateSpaceRegressionModel(const Vector &y, const Matrix &X, const std::vector<bool> &observed,
@@ -375,14 +401,16 @@ class StateSpaceRegressionModel : public Model {
   // first draw (finalize_state)
   void add_state(const Ptr<LocalLinearTrendStateModel> &s) { trend_ = s; structural_ = true; }
   void add_state(const Ptr<SeasonalStateModel> &s) { seasonal_ = s; structural_ = true; }
+  void add_state(const Ptr<ArStateModel> &s) { ar_ = s; structural_ = true; }
   bool structural() const { return structural_; }
   int state_dimension() const {
-    return (trend_ ? 2 : 1) + (seasonal_ ? seasonal_->state_dimension() : 0);
+    return (trend_ ? 2 : 1) + (seasonal_ ? seasonal_->state_dimension() : 0) + (ar_ ? ar_->lags_ : 0);
   }
   void finalize_state() {
     if (!structural_ || finalized_) return;
     if (!trend_ && !level_) report_error("a structural model needs a trend state model (local level or local linear trend) first");
-    const int tr = trend_ ? 2 : 1, ns = seasonal_ ? seasonal_->nseasons_ : 0, m = state_dimension();
+    const int tr = trend_ ? 2 : 1, ns = seasonal_ ? seasonal_->nseasons_ : 0,
+              m = state_dimension() - (ar_ ? ar_->lags_ : 0);
     double df[3] = {1, 1, 1}, guess[3] = {1, 1, 1}, upper[3] = {infinity(), infinity(), infinity()}, init[3] = {1, 1, 1};
     Vector a0(m, 0.0), P0(m, 1.0);
     if (trend_) {
@@ -399,7 +427,22 @@ class StateSpaceRegressionModel : public Model {
       for (int i = 0; i < ns - 1; ++i) { a0[tr + i] = seasonal_->a0_[i]; P0[tr + i] = seasonal_->P0_[i]; }
     }
     eng_->check(ba_ss_set_structural(eng_->get(), tr, ns, df, guess, upper, init, a0.data(), P0.data()));
+    if (ar_)
+      eng_->check(ba_ss_add_ar(eng_->get(), ar_->lags_, ar_->df_, ar_->guess_, ar_->upper_, ar_->sigma_,
+                               ar_->phi_.data(), ar_->a0_.data(), ar_->P0_.data()));
     finalized_ = true;
+  }
+  // the autoregression's coefficients and error variance in one chain's current draw
+  Vector ar_phi(int chain = 0) const {
+    Vector v(ar_ ? ar_->lags_ : 0);
+    double s2;
+    eng_->check(ba_ss_get_ar(eng_->get(), chain, v.data(), &s2, nullptr, nullptr, nullptr, nullptr));
+    return v;
+  }
+  double ar_sigsq(int chain = 0) const {
+    double s2;
+    eng_->check(ba_ss_get_ar(eng_->get(), chain, nullptr, &s2, nullptr, nullptr, nullptr, nullptr));
+    return s2;
   }
   // the state draw, component `which` (0 = level / trend level, ...) of one chain
   Matrix structural_state(int chain = 0) const {
@@ -435,6 +478,7 @@ class StateSpaceRegressionModel : public Model {
   Ptr<LocalLevelStateModel> level_;
   Ptr<LocalLinearTrendStateModel> trend_;
   Ptr<SeasonalStateModel> seasonal_;
+  Ptr<ArStateModel> ar_;
   bool structural_ = false, finalized_ = false;
 };
 

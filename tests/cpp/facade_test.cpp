@@ -281,6 +281,55 @@ static void StructuralTimeSeries() {
   EXPECT(v[0] > 0 && v[1] > 0 && v[2] > 0 && v[1] < v[0] + 1.0);
 }
 
+// ... with an autoregressive component (bsts AddAr) on top of a local level
+static void AutoregressiveState() {
+  const int T = 600, p = 3, chains = 8;
+  std::mt19937_64 gen(17);
+  std::normal_distribution<double> N(0, 1);
+  Matrix X(T, p);
+  Vector y(T), coef = {2.0, 0.0, -1.5};
+  double level = 0, u1 = 0, u2 = 0;
+  for (int t = 0; t < T; ++t) {
+    level += 0.02 * N(gen);
+    const double u = 1.1 * u1 - 0.4 * u2 + 0.5 * N(gen);
+    u2 = u1; u1 = u;
+    double mu = level + u;
+    for (int j = 0; j < p; ++j) { X(t, j) = N(gen); mu += X(t, j) * coef[j]; }
+    y[t] = mu + 0.1 * N(gen);
+  }
+  StateSpaceRegressionModel model(y, X, std::vector<bool>(), chains, 5);
+  Ptr<LocalLevelStateModel> level_model(new LocalLevelStateModel(0.1));
+  level_model->set_initial_state_mean(y[0]);
+  level_model->set_initial_state_variance(4.0);
+  level_model->set_prior(1.0, 0.05, 0.2);
+  model.add_state(level_model);
+  Ptr<ArStateModel> ar(new ArStateModel(2));
+  ar->set_sigma(0.5);
+  ar->set_initial_state_variance(2.0);
+  ar->set_prior(1.0, 0.5);
+  model.add_state(ar);
+  EXPECT(model.state_dimension() == 3);
+  SpdMatrix om(p, p, 0.0);
+  for (int j = 0; j < p; ++j) om(j, j) = 0.01;
+  Ptr<MvnGivenScalarSigma> slab(new MvnGivenScalarSigma(Vector(p, 0.0), om));
+  Ptr<ChisqModel> siginv(new ChisqModel(1.0, 0.5));
+  Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(p, 0.5));
+  Ptr<StateSpacePosteriorSampler> sampler(new StateSpacePosteriorSampler(&model, slab, siginv, spike));
+  model.set_method(sampler);
+  for (int i = 0; i < 300; ++i) model.sample_posterior();
+  double p1 = 0, p2 = 0, s2 = 0;
+  for (int c = 0; c < chains; ++c) {
+    const Vector phi = model.ar_phi(c);
+    EXPECT(phi.size() == 2);
+    p1 += phi[0] / chains; p2 += phi[1] / chains; s2 += model.ar_sigsq(c) / chains;
+  }
+  // the data's autoregression (1.1, -0.4; innovation variance 0.25) is found
+  EXPECT(std::fabs(p1 - 1.1) < 0.25 && std::fabs(p2 + 0.4) < 0.25);
+  EXPECT(s2 > 0.1 && s2 < 0.6);
+  Matrix st = model.structural_state(2);
+  EXPECT(st.nrow() == 3 && st.ncol() == T);
+}
+
 // the logit / probit spike-and-slab samplers in the reference's shape:
 // model.set_method(new BinomialLogitSpikeSlabSampler(&model, slab, spike))
 template <class MODEL, class SAMPLER>
@@ -414,6 +463,7 @@ int main() {
     ErrorConventions();
     StateSpace();
     StructuralTimeSeries();
+    AutoregressiveState();
     BinomialSpikeSlab<BinomialLogitModel, BinomialLogitSpikeSlabSampler>(true);
     BinomialSpikeSlab<BinomialProbitModel, BinomialProbitSpikeSlabSampler>(false);
   } catch (std::exception &e) {

@@ -144,3 +144,39 @@ def test_structural_time_series_on_the_pybind_module():
     want = eng.ss_get_structural(chains - 1)
     assert np.array_equal(model.state(chains - 1), want["state"].T)
     assert np.array_equal(model.state_variances(chains - 1), want["variances"])
+
+
+def test_state_space_regression_with_an_ar_state_model():
+    """bsts AddAr through the module: add_state(ArStateModel(lags)) after the trend"""
+    import boom_amd._boom as boom
+    rng = np.random.Generator(np.random.PCG64(3))
+    T, p = 400, 3
+    X = rng.standard_normal((T, p))
+    u = np.zeros(T)
+    for t in range(2, T):
+        u[t] = 1.1 * u[t - 1] - 0.4 * u[t - 2] + 0.5 * rng.standard_normal()
+    y = np.cumsum(0.02 * rng.standard_normal(T)) + u + X @ np.array([2.0, 0.0, -1.5]) \
+        + 0.1 * rng.standard_normal(T)
+    model = boom.StateSpaceRegressionModel(y, X, chains=4, seed=11)
+    level = boom.LocalLevelStateModel(0.1)
+    level.set_initial_state_mean(float(y[0]))
+    level.set_initial_state_variance(4.0)
+    level.set_prior(1.0, 0.05, 0.2)
+    model.add_state(level)
+    ar = boom.ArStateModel(2)
+    ar.set_sigma(0.5)
+    ar.set_initial_state_variance(2.0)
+    ar.set_prior(1.0, 0.5)
+    model.add_state(ar)
+    assert model.state_dimension == 3
+    slab = boom.MvnGivenScalarSigma(np.zeros(p), 0.01 * np.eye(p))
+    sampler = boom.StateSpacePosteriorSampler(model, slab, boom.ChisqModel(1.0, 0.5),
+                                              boom.VariableSelectionPrior(np.full(p, 0.5)))
+    model.set_method(sampler)
+    for _ in range(200):
+        model.sample_posterior()
+    phi = np.array([model.ar_phi(c) for c in range(4)])
+    assert phi.shape == (4, 2)
+    assert abs(phi[:, 0].mean() - 1.1) < 0.3 and abs(phi[:, 1].mean() + 0.4) < 0.3
+    assert model.state(1).shape == (3, T)
+    assert 0.05 < model.ar_sigsq(0) < 0.8
