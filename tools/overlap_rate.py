@@ -1,5 +1,9 @@
+"""Sweep launches that overlap (consecutive ba_sweep calls, no sync) against launches kept
+apart: equality of the draws, then the rates at 1000 / 250 / 64 sweeps per launch.  Diagnostic."""
 import sys, time, numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import boom_amd
 from cases import regression_data, spike_slab_prior
 
