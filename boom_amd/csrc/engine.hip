@@ -454,7 +454,9 @@ int choose_waves(const ba_engine &e, int kcap) {
   // and there is no quiet sweep to fork, the helper wave has little to do; one wavefront per
   // chain measured better at every size (T=2000, p=100, us per round with 1 / 2 wavefronts:
   // 512 chains 144 / 144, 1024 167 / 172, 2048 279 / 304, 4096 545 / 590).
-  if (e.ss_mode) return 1;
+  // (the local-level round only: with the structural kernel behind it the same choice makes
+  // THAT kernel slower -- 5.72 vs 5.06 ms per round at m = 13 -- for reasons not understood)
+  if (e.ss_mode && !e.ssm_set) return 1;
   return 2;
 }
 
