@@ -598,11 +598,18 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         // -- the seasonal block: the row / column of the component that drops out
         // becomes that of the new first component, -sum over the block
         if (SEAS) {
+          // (every load issued before the first use, from addresses that are valid whatever
+          // the block's size: fifteen guarded load-and-subtract steps each waited for their
+          // own LDS round trip)
           double cs = 0.0;
-          if (mylane) {
+          {
+            double v[SSM_MAX - 1];
+            const int col = mylane ? lane : 0;
 #pragma unroll
-            for (int q = 0; q < SSM_MAX - 1; ++q)
-              if (q < S.ns) cs -= s_P[(TREND + q) * PLD + lane];
+            for (int q = 0; q < SSM_MAX - 1; ++q) v[q] = s_P[(TREND + (q < S.ns ? q : 0)) * PLD + col];
+#pragma unroll
+            for (int q = 0; q < SSM_MAX - 1; ++q) cs -= (q < S.ns) ? v[q] : 0.0;
+            if (!mylane) cs = 0.0;
           }
           const double tot = row_total(S.seasonal(lane) ? cs : 0.0);
           __builtin_amdgcn_wave_barrier();
