@@ -1005,6 +1005,52 @@ int set_device(const ba_engine *e) {
   return BA_OK;
 }
 
+// ---- a second stream that really runs beside the first --------------------------------
+// HIP maps streams onto a few hardware queues; two streams on one queue run one after the
+// other, whatever the program meant (measured: the bsts round 207 instead of 167 us when
+// the engine's two streams happen to share a queue, which depends on how many streams the
+// process created before).  So a candidate is TESTED: a kernel on the main stream waits
+// (bounded: 20 ms) for a flag that a kernel on the candidate sets; the first candidate whose
+// kernel gets through while the other is waiting is kept.
+__global__ void stream_probe_wait_kernel(volatile int *flag, int *saw, long long ticks) {
+  const long long t0 = wall_clock64();
+  int v = 0;
+  while ((v = *flag) == 0 && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  *saw = v;
+}
+__global__ void stream_probe_set_kernel(volatile int *flag) { *flag = 1; }
+
+int concurrent_stream(ba_engine *e, hipStream_t *out) {
+  DevBuf<int32_t> buf;
+  HIP_TRY(buf.resize(2));
+  hipStream_t tried[8];
+  int ntried = 0;
+  hipStream_t good = nullptr;
+  for (; ntried < 8 && !good; ++ntried) {
+    hipStream_t c = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    tried[ntried] = c;
+    HIP_TRY(hipMemsetAsync(buf.ptr, 0, 8, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    // (wall_clock64 counts at 100 MHz: 2e6 ticks = 20 ms)
+    hipLaunchKernelGGL(stream_probe_wait_kernel, dim3(1), dim3(1), 0, e->stream, (volatile int *)buf.ptr,
+                       (int *)buf.ptr + 1, 2000000ll);
+    hipLaunchKernelGGL(stream_probe_set_kernel, dim3(1), dim3(1), 0, c, (volatile int *)buf.ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(c));
+    int32_t saw = 0;
+    HIP_TRY(hipMemcpy(&saw, buf.ptr + 1, 4, hipMemcpyDeviceToHost));
+    if (saw) good = c;
+  }
+  // (none ran beside the main stream: the last one serves, in sequence)
+  if (!good) good = tried[ntried - 1];
+  for (int i = 0; i < ntried; ++i)
+    if (tried[i] != good) (void)hipStreamDestroy(tried[i]);
+  *out = good;
+  return BA_OK;
+}
+
 // ---- pipelined sweeps ---------------------------------------------------------------
 // The end of a pipeline: the main stream waits for the other one, so that whatever is
 // enqueued next comes after every sweep launch; a workgroup that waited for its chain in
@@ -1951,7 +1997,10 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record, int la_half) {
   } else {
     const size_t C = (size_t)e->cfg.chains, qlen = C + 2;
     if (!e->pipe_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&e->pipe_stream, hipStreamNonBlocking));
+      {
+        int rcs = concurrent_stream(e, &e->pipe_stream);
+        if (rcs) return rcs;
+      }
       for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&e->pipe_ev[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&e->pipe_join_ev, hipEventDisableTiming));
     }
@@ -3197,7 +3246,10 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
   // beside the previous round's X'e GEMM and this round's SSVS launch.
   const bool ahead = !e->ssm_set && nsweeps > 0;
   if (ahead && !e->stream2) {
-    HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    {
+      int rcs = concurrent_stream(e, &e->stream2);
+      if (rcs) return rcs;
+    }
     HIP_TRY(hipEventCreateWithFlags(&e->ev_state, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
   }
