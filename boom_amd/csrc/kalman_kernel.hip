@@ -281,41 +281,9 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   KSTAMP(0);
   // ---- 1. adjusted observations y*_t = y_t - x_t'beta
   // (StateSpaceRegressionModel.cpp:65-77, 179-181; GlmCoefs::predict is a dense
-  // dot with Beta(), zeros outside gamma): included variables in batches of 64,
-  // lane m of a batch holding (j_m, beta_m)
-  // A panel of NR * 64 time steps lives in registers (element i of lane l is
-  // step tb + 64 i + l), so that a variable's column is NR independent loads.
-  // (panels alternate between the two waves)
-  for (int tb = wave * NR * WAVE; tb < T; tb += 2 * NR * WAVE) {
-    double pred[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) pred[i] = 0.0;
-    for (int base = 0; base < p; base += WAVE) {
-      const int j = base + lane;
-      const double bj = (j < p) ? beta[j] : 0.0;
-      unsigned long long m = __ballot(bj != 0.0);
-      while (m) {
-        const int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const double b = bcast_u(bj, l);
-        // (branch-free: steps past T read the last row and are never stored)
-        const double *col = P.X + (size_t)(base + l) * T;
-        double xv[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-          const int t = tb + i * WAVE + lane;
-          xv[i] = col[t < T ? t : T - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) pred[i] += xv[i] * b;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int t = tb + i * WAVE + lane;
-      if (t < T) w0[t] = P.y[t] - pred[i];
-    }
-  }
+  // dot with Beta(), zeros outside gamma).  Not a pass of its own any more: the forward
+  // pass computes its chunk's y* where it used to fetch it (ystar_block below) -- one
+  // array less written and read back per chain and sweep.
   KSTAMP(1);
   // ---- 2. the standard normals of simulate_forward, in stream order:
   // t = 0: initial state (if P0 > 0), observation (if sigma_obs > 0);
@@ -380,8 +348,40 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
       // any), then observation error (if any)
       {
         const int64_t gfirst = (int64_t)nfirst + (int64_t)(tw - 1) * nper;
+        // y* of the wave's stretch in the fetch layout (element i = step tw + 64 i + lane, so
+        // that a variable's column is BS coalesced loads): included variables in batches of
+        // 64, lane m of a batch holding (j_m, beta_m)
         double yraw[BS];
-        wave_block_fetch<BS>(w0, tw, T, lane, 0.0, yraw);
+        {
+          double pred[BS];
+#pragma unroll
+          for (int i = 0; i < BS; ++i) pred[i] = 0.0;
+          for (int base = 0; base < p; base += WAVE) {
+            const int jv = base + lane;
+            const double bj = (jv < p) ? beta[jv] : 0.0;
+            unsigned long long mk = __ballot(bj != 0.0);
+            while (mk) {
+              const int l = __ffsll((long long)mk) - 1;
+              mk &= mk - 1;
+              const double b = bcast_u(bj, l);
+              // (branch-free: steps past T read the last row and are never used)
+              const double *col = P.X + (size_t)(base + l) * T;
+              double xv[BS];
+#pragma unroll
+              for (int i = 0; i < BS; ++i) {
+                const int t = tw + i * WAVE + lane;
+                xv[i] = col[t < T ? t : T - 1];
+              }
+#pragma unroll
+              for (int i = 0; i < BS; ++i) pred[i] += xv[i] * b;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const int t = tw + i * WAVE + lane;
+            yraw[i] = (t < T) ? P.y[t] - pred[i] : 0.0;
+          }
+        }
         if (nper == 2) {
           double zraw[2 * BS], zz[2 * BS];
           wave_block_fetch<2 * BS>(szz, gfirst, N, lane, 0.0, zraw);
