@@ -1993,7 +1993,25 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record, int la_half) {
   if (!pipelined) {
     int rcj = pipe_join(e);
     if (rcj) return rcj;
-    HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
+    // More chains than the machine holds.  One launch of more workgroups than fit runs in
+    // rounds, and on this machine a few workgroups of the last round then start a whole
+    // round late (measured at 2048 chains: 2 - 12 workgroups start at 33 ms, when round-2
+    // workgroups end, although every round-1 workgroup is gone by 23 ms -- 53 ms per launch
+    // where two launches of 1024 take 46).  With many rounds that is a small share and the
+    // rounds hide each other's slowest chains (8192 chains: 166 ms against 184 for eight
+    // launches); with exactly two or three it is not: those go out as separate launches of
+    // as many workgroups as fit, one after the other.
+    const int C = e->cfg.chains, group = resident_per_cu * e->cu_count;
+    if (nsweeps > 0 && e->cur_mode != 2 && !e->big_active && (C == 2 * group || C == 3 * group)) {
+      SsvsParams Pg = P;
+      for (int first = 0; first < C; first += group) {
+        Pg.chain_first = first;
+        Pg.chain_count = group;
+        HIP_TRY(launch_ssvs_sweep(e->stream, Pg, (int)nsweeps));
+      }
+    } else {
+      HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
+    }
   } else {
     const size_t C = (size_t)e->cfg.chains, qlen = C + 2;
     if (!e->pipe_stream) {

@@ -320,3 +320,23 @@ def test_overlapping_lookahead_batches_survive_a_capacity_stop():
     assert _same(a.get_states(), b.get_states())
     gam, _, _ = a.get_states()
     assert gam.sum(axis=1).max() > 16       # the models did outgrow the first capacity
+
+
+def test_twice_as_many_chains_as_fit_go_out_as_two_launches(oracle):
+    """exactly 2 x (4 chains per CU) chains: the engine issues the sweep as two launches of
+    resident size (one multi-round launch starts a few workgroups a round late on this
+    machine); chains of both halves are the oracle's, and a second call continues them"""
+    import boom_amd
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    chains = 8 * cus
+    suf, prior, g0 = _case(p=24, nsig=4, seed=2, n=300)
+    eng = make_engine(chains, 77, suf=suf, prior=prior, g0=g0)
+    eng.sweep(12)
+    eng.sweep(13)
+    gam, beta, sig = eng.get_states()
+    for c in (0, chains // 2 - 1, chains // 2, chains - 1):
+        o = oracle.ssvs_run(suf, prior, ssvs_options(), ("philox", 77, c), g0, 25)
+        assert np.array_equal(gam[c], o["gamma"][-1]), c
+        assert abs(sig[c] - o["sigsq"][-1]) < 1e-8 * sig[c], c
+    assert eng.get_summaries()["sweeps"] == chains * 25
