@@ -323,6 +323,7 @@ struct ba_engine {
   hipEvent_t pipe_ev[4] = {}, pipe_join_ev = nullptr;
   DevBuf<int32_t> dpipe_q, dpipe_err;
   bool pipe_on = false;      // the last thing enqueued was a pipelined sweep launch
+  bool pipe_unchecked = false;   // a pipelined launch has gone out since the error word was last read
   int pipe_k = 0;            // launches in the current pipeline
   DevBuf<int32_t> dprep_n;
   DevBuf<uint64_t> dprep_pos_state, dprep_pos_level;
@@ -1063,8 +1064,11 @@ int pipe_join(ba_engine *e) {
   HIP_TRY(hipStreamWaitEvent(e->stream, e->pipe_join_ev, 0));
   return BA_OK;
 }
-int pipe_check(ba_engine *e) {
-  if (e->dpipe_err.count == 0) return BA_OK;
+// (force: read the word whatever the flag says -- the look-ahead's batches, whose launches
+// and checks interleave)
+int pipe_check(ba_engine *e, bool force = false) {
+  if (e->dpipe_err.count == 0 || (!force && !e->pipe_unchecked)) return BA_OK;
+  e->pipe_unchecked = false;
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->dpipe_err.ptr, 4, hipMemcpyDeviceToHost));
   if (err) {
@@ -1095,7 +1099,7 @@ int la_wait(ba_engine *e) {
   if (e->la_synced) return BA_OK;
   if (e->la_cur_piped) {
     HIP_TRY(hipEventSynchronize(e->la_done[e->la_slot]));
-    int rc = pipe_check(e);
+    int rc = pipe_check(e, true);
     if (rc) return rc;
     const size_t C = (size_t)e->cfg.chains;
     std::vector<int32_t> st(C);
@@ -1253,7 +1257,7 @@ int la_rewind(ba_engine *e) {
   const bool piped = e->la_cur_piped;
   la_discard(e);
   if (piped) {
-    rc = pipe_check(e);
+    rc = pipe_check(e, true);
     if (rc) return rc;
     const size_t C = (size_t)e->cfg.chains;
     // (a chain that stopped in the dropped launches stopped after the point we return to)
@@ -1360,6 +1364,8 @@ void ba_engine_destroy(ba_engine *e) {
     (void)hipStreamSynchronize(e->stream2);
     (void)hipStreamDestroy(e->stream2);
   }
+  for (int i = 0; i < 2; ++i)
+    if (e->la_done[i]) (void)hipEventDestroy(e->la_done[i]);
   if (e->pipe_stream) {
     (void)hipStreamSynchronize(e->pipe_stream);
     (void)hipStreamDestroy(e->pipe_stream);
@@ -2046,6 +2052,7 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record, int la_half) {
     HIP_TRY(launch_ssvs_sweep(st, P, (int)nsweeps));
     if (la_half >= 0) HIP_TRY(hipEventRecord(e->la_done[la_half], st));
     e->pipe_on = true;
+    e->pipe_unchecked = true;
     e->pipe_k = k + 1;
   }
   e->table_ok = true;  // until anything but another ba_sweep touches the engine
