@@ -298,6 +298,31 @@ def other_configs(boom_amd, torch, device, cpu=True):
                                          "one full-size sweep takes about a minute per chain)"
                                          % (th, nsw, th, nsub, n5, nsub, n5)}
     other["configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 512 chains"] = rec
+    # ... and with the imputer BASELINE words the configuration with: Polya-Gamma augmentation
+    # (ba_logit_set_imputer(1); BOOM has no such sampler -- parity for it is distributional,
+    # tests/test_polya_gamma.py), same data, same chains, continuing from the state above
+    e5.logit_set_imputer(1)
+    e5.logit_sweep(10)
+    t0 = time.perf_counter()
+    e5.logit_sweep(30)
+    dtp = time.perf_counter() - t0
+    gamp = e5.get_states()[0]
+    e5.set_kernel_timing(True)
+    e5.logit_sweep(10)
+    ktp = {k: round(ms / 10, 3) for k, (ms, _) in e5.kernel_times().items()}
+    e5.set_kernel_timing(False)
+    kp = float(gamp.sum(1).mean())
+    flopsp = 2.0 * n5 * p5 * kp * C5
+    other["configs[4] per GPU with the Polya-Gamma imputer"] = {
+        "sweeps_per_s": round(C5 * 30 / dtp, 1), "ms_per_round": round(dtp / 30 * 1e3, 2),
+        "mean_model_size": round(kp, 2),
+        "signal_inclusion_min": round(float(gamp[:, :8].mean(0).min()), 4),
+        "kernel_ms_per_round": ktp,
+        "roofline": {"bound": "mfma", "kernel": "xtwx_cols_kernel<true>", "flops_per_round": flopsp,
+                     "achieved": round(flopsp / (ktp[cols] * 1e-3) / 1e12, 2), "peak": F64_MATRIX_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": round(flopsp / (ktp[cols] * 1e-3) / 1e12 / F64_MATRIX_PEAK_TF, 4),
+                     "traffic": None},
+        "cpu_baseline": None}
     e5.close()
     return other
 
