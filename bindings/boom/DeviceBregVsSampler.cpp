@@ -17,64 +17,108 @@ namespace BOOM {
       int lookahead, RNG &seeding_rng)
       : PosteriorSampler(seeding_rng),
         model_(model),
-        engine_(nullptr),
+        group_(nullptr),
         chains_(chains),
         max_flips_(-1),
         swap_threshold_(0.8) {
-    if (slab->dim() != static_cast<int>(model->xdim())) {
-      report_error("Slab dimension did not match model dimension.");
-    }
-    if (spike->potential_nvars() != model->xdim()) {
-      report_error("Spike dimension did not match model dimension.");
-    }
     device_seed_ = seed_rng(seeding_rng);
     ba_config cfg{device, chains, 0, static_cast<uint64_t>(device_seed_), 0, 0};
-    check(ba_engine_create(&cfg, &engine_));
-    Ptr<RegSuf> suf = model->suf();
+    ba_engine *engine = nullptr;
+    check(ba_engine_create(&cfg, &engine));
+    engines_.push_back(engine);
+    configure(slab, residual_precision_prior, spike, lookahead);
+  }
+
+  DeviceBregVsSampler::DeviceBregVsSampler(
+      RegressionModel *model, const Ptr<MvnGivenScalarSigmaBase> &slab,
+      const Ptr<GammaModelBase> &residual_precision_prior,
+      const Ptr<VariableSelectionPrior> &spike, int chains_per_device,
+      const std::vector<int> &devices, int lookahead, RNG &seeding_rng)
+      : PosteriorSampler(seeding_rng),
+        model_(model),
+        group_(nullptr),
+        chains_(chains_per_device * static_cast<int>(devices.size())),
+        max_flips_(-1),
+        swap_threshold_(0.8) {
+    device_seed_ = seed_rng(seeding_rng);
+    std::vector<int32_t> dev(devices.begin(), devices.end());
+    if (ba_group_create(dev.data(), static_cast<int32_t>(dev.size()), chains_per_device,
+                        static_cast<uint64_t>(device_seed_), &group_) != BA_OK) {
+      report_error(ba_group_last_error());
+    }
+    for (int32_t i = 0; i < ba_group_size(group_); ++i) {
+      engines_.push_back(ba_group_engine(group_, i));
+    }
+    configure(slab, residual_precision_prior, spike, lookahead);
+  }
+
+  void DeviceBregVsSampler::configure(
+      const Ptr<MvnGivenScalarSigmaBase> &slab,
+      const Ptr<GammaModelBase> &residual_precision_prior,
+      const Ptr<VariableSelectionPrior> &spike, int lookahead) {
+    if (slab->dim() != static_cast<int>(model_->xdim())) {
+      report_error("Slab dimension did not match model dimension.");
+    }
+    if (spike->potential_nvars() != model_->xdim()) {
+      report_error("Spike dimension did not match model dimension.");
+    }
+    Ptr<RegSuf> suf = model_->suf();
     const SpdMatrix xtx = suf->xtx();  // column-major, full storage
     const Vector xty = suf->xty();
     const Vector xbar = suf->xbar();
-    check(ba_upload_regression_suf(engine_, xtx.nrow(), xtx.data(), xty.data(),
-                                   suf->yty(), suf->n(), suf->ybar(), xbar.data()));
     const Vector mu = slab->mu();
     const SpdMatrix ominv = slab->unscaled_precision();
-    check(ba_set_slab(engine_, mu.data(), ominv.data()));
     const Vector pi = spike->prior_inclusion_probabilities();
-    check(ba_set_spike(engine_, pi.data(), spike->max_model_size()));
     // GammaModel(alpha, beta) == ChisqModel(df = 2 alpha, sigma = sqrt(beta / alpha))
     const double a = residual_precision_prior->alpha();
     const double b = residual_precision_prior->beta();
     prior_df_ = 2 * a;
     prior_sigma_guess_ = std::sqrt(b / a);
-    check(ba_set_sigma_prior(engine_, prior_df_, prior_sigma_guess_, infinity()));
+    for (ba_engine *engine : engines_) {
+      check(ba_upload_regression_suf(engine, xtx.nrow(), xtx.data(), xty.data(),
+                                     suf->yty(), suf->n(), suf->ybar(), xbar.data()));
+      check(ba_set_slab(engine, mu.data(), ominv.data()));
+      check(ba_set_spike(engine, pi.data(), spike->max_model_size()));
+      check(ba_set_sigma_prior(engine, prior_df_, prior_sigma_guess_, infinity()));
+    }
     push_state();
-    if (lookahead > 1) check(ba_set_lookahead(engine_, lookahead));
+    if (lookahead > 1) set_lookahead(lookahead);
   }
 
-  DeviceBregVsSampler::~DeviceBregVsSampler() { ba_engine_destroy(engine_); }
+  DeviceBregVsSampler::~DeviceBregVsSampler() {
+    if (group_) {
+      ba_group_destroy(group_);
+    } else {
+      for (ba_engine *engine : engines_) ba_engine_destroy(engine);
+    }
+  }
 
   void DeviceBregVsSampler::check(int rc) const {
     if (rc != BA_OK) report_error(ba_last_error());
   }
 
   void DeviceBregVsSampler::draw() {
-    check(ba_draw_next(engine_));
+    // every engine is asked first (the launches are asynchronous, so the devices
+    // run side by side); chain 0 is then read from engine 0
+    for (ba_engine *engine : engines_) check(ba_draw_next(engine));
     pull_chain0();
   }
 
   double DeviceBregVsSampler::logpri() const {
     double ans = negative_infinity();
-    check(ba_logpri(engine_, 0, &ans));
+    check(ba_logpri(engines_[0], 0, &ans));
     return ans;
   }
 
   void DeviceBregVsSampler::set_device_seed(unsigned long seed) {
     device_seed_ = seed;
-    check(ba_seed(engine_, seed));
+    for (ba_engine *engine : engines_) check(ba_seed(engine, seed));
   }
 
   void DeviceBregVsSampler::options() {
-    check(ba_set_options(engine_, max_flips_, swap_threshold_, 1, 1));
+    for (ba_engine *engine : engines_) {
+      check(ba_set_options(engine, max_flips_, swap_threshold_, 1, 1));
+    }
   }
   void DeviceBregVsSampler::limit_model_selection(uint max_flips) {
     max_flips_ = static_cast<int>(max_flips);
@@ -93,10 +137,12 @@ namespace BOOM {
     options();
   }
   void DeviceBregVsSampler::set_sigma_upper_limit(double sigma_upper_limit) {
-    check(ba_set_sigma_prior(engine_, prior_df_, prior_sigma_guess_, sigma_upper_limit));
+    for (ba_engine *engine : engines_) {
+      check(ba_set_sigma_prior(engine, prior_df_, prior_sigma_guess_, sigma_upper_limit));
+    }
   }
   void DeviceBregVsSampler::set_lookahead(int n) {
-    check(ba_set_lookahead(engine_, n));
+    for (ba_engine *engine : engines_) check(ba_set_lookahead(engine, n));
   }
 
   void DeviceBregVsSampler::push_state() {
@@ -105,7 +151,9 @@ namespace BOOM {
     std::vector<uint8_t> gamma(p, 0);
     for (uint j = 0; j < p; ++j) gamma[j] = inc[j] ? 1 : 0;
     const Vector beta = model_->Beta();
-    check(ba_set_state(engine_, -1, gamma.data(), beta.data(), model_->sigsq()));
+    for (ba_engine *engine : engines_) {
+      check(ba_set_state(engine, -1, gamma.data(), beta.data(), model_->sigsq()));
+    }
   }
 
   void DeviceBregVsSampler::chain_state(int chain, Selector &inc, Vector &beta,
@@ -113,7 +161,12 @@ namespace BOOM {
     const uint p = model_->xdim();
     std::vector<uint8_t> gamma(p, 0);
     beta.resize(p);
-    check(ba_get_state(engine_, chain, gamma.data(), beta.data(), &sigsq));
+    int32_t owner = 0;
+    int64_t local = chain;
+    if (group_ && ba_group_locate(group_, chain, &owner, &local) != BA_OK) {
+      report_error(ba_group_last_error());
+    }
+    check(ba_get_state(engines_[owner], local, gamma.data(), beta.data(), &sigsq));
     inc = Selector(p, false);
     for (uint j = 0; j < p; ++j) {
       if (gamma[j]) inc.add(j);

@@ -10,6 +10,7 @@
 #ifndef BOOM_AMD_DEVICE_BREG_VS_SAMPLER_HPP_
 #define BOOM_AMD_DEVICE_BREG_VS_SAMPLER_HPP_
 
+#include <vector>
 #include "LinAlg/Selector.hpp"
 #include "LinAlg/Vector.hpp"
 #include "Models/GammaModel.hpp"
@@ -37,6 +38,16 @@ namespace BOOM {
                         const Ptr<VariableSelectionPrior> &spike,
                         int chains, int device = 0, int lookahead = 256,
                         RNG &seeding_rng = GlobalRng::rng);
+    // The same sampler over several devices of one node (ba_group_*): engine i on
+    // devices[i] owns the global chains [i * chains_per_device, (i + 1) *
+    // chains_per_device), so the draws of a chain do not depend on the device list.
+    // Chain 0 (the one the model sees) lives on devices[0].
+    DeviceBregVsSampler(RegressionModel *model,
+                        const Ptr<MvnGivenScalarSigmaBase> &slab,
+                        const Ptr<GammaModelBase> &residual_precision_prior,
+                        const Ptr<VariableSelectionPrior> &spike,
+                        int chains_per_device, const std::vector<int> &devices,
+                        int lookahead = 256, RNG &seeding_rng = GlobalRng::rng);
     ~DeviceBregVsSampler() override;
 
     void draw() override;            // BregVsSampler::draw, BregVsSampler.cpp:252-261
@@ -58,15 +69,20 @@ namespace BOOM {
     void set_lookahead(int n);
     // new: the other chains
     int number_of_chains() const { return chains_; }
+    int number_of_devices() const { return static_cast<int>(engines_.size()); }
     void chain_state(int chain, Selector &inc, Vector &beta, double &sigsq) const;
 
    private:
     void check(int rc) const;
+    void configure(const Ptr<MvnGivenScalarSigmaBase> &slab,
+                   const Ptr<GammaModelBase> &residual_precision_prior,
+                   const Ptr<VariableSelectionPrior> &spike, int lookahead);
     void options();
     void push_state();   // coef().inc(), Beta(), sigsq() -> every chain
     void pull_chain0();  // chain 0 -> coef().set_inc / set_Beta / set_sigsq
     RegressionModel *model_;
-    ba_engine *engine_;
+    ba_group *group_;                 // null for the single-device constructor
+    std::vector<ba_engine *> engines_;  // owned by group_ when there is one
     int chains_;
     unsigned long device_seed_;
     int max_flips_;

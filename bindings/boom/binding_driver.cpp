@@ -32,11 +32,16 @@ const char *ref_binding_last_error() { return g_binding_error.c_str(); }
 // X n x p column-major.  Returns 0 or -1 (message in ref_binding_last_error).
 // out_seed receives the seed the binding gave the engine (seed_rng(GlobalRng)
 // after GlobalRng::rng.seed(seed)), i.e. the key of the oracle run to compare with.
-int ref_binding_run(int n, int p, const double *X, const double *y,
+// ndevices == 0: the single-device constructor on device 0; ndevices >= 1: the
+// device-list constructor with device 0 repeated ndevices times and `chains` chains
+// per entry (a one-GPU box can check the list path: the draws of a global chain do not
+// depend on the list).
+static int binding_run_impl(int n, int p, const double *X, const double *y,
                     const double *prior_mean, const double *ominv, double prior_df,
                     double sigma_guess, const double *pi, int64_t max_model_size,
                     double sigma_upper_limit, int max_flips, double swap_threshold,
-                    int chains, int lookahead, uint64_t seed, const uint8_t *init_gamma,
+                    int chains, int ndevices, int lookahead, uint64_t seed,
+                    const uint8_t *init_gamma,
                     int nsweeps, uint8_t *out_gamma, double *out_beta, double *out_sigsq,
                     double *out_logpri, uint64_t *out_seed,
                     int probe_chain, uint8_t *probe_gamma, double *probe_beta,
@@ -64,8 +69,14 @@ int ref_binding_run(int n, int p, const double *X, const double *y,
     model->coef().drop_all();
     for (int j = 0; j < p; ++j)
       if (init_gamma[j]) model->coef().add(j);
-    NEW(DeviceBregVsSampler, sampler)(model.get(), slab, siginv_prior, spike, chains, 0,
-                                      lookahead);
+    Ptr<DeviceBregVsSampler> sampler;
+    if (ndevices <= 0) {
+      sampler.reset(new DeviceBregVsSampler(model.get(), slab, siginv_prior, spike, chains,
+                                            0, lookahead));
+    } else {
+      sampler.reset(new DeviceBregVsSampler(model.get(), slab, siginv_prior, spike, chains,
+                                            std::vector<int>(ndevices, 0), lookahead));
+    }
     if (std::isfinite(sigma_upper_limit)) sampler->set_sigma_upper_limit(sigma_upper_limit);
     if (max_flips >= 0) sampler->limit_model_selection(max_flips);
     if (swap_threshold != 0.8) sampler->set_correlation_swap_threshold(swap_threshold);
@@ -98,6 +109,40 @@ int ref_binding_run(int n, int p, const double *X, const double *y,
     g_binding_error = e.what();
     return -1;
   }
+}
+
+int ref_binding_run(int n, int p, const double *X, const double *y,
+                    const double *prior_mean, const double *ominv, double prior_df,
+                    double sigma_guess, const double *pi, int64_t max_model_size,
+                    double sigma_upper_limit, int max_flips, double swap_threshold,
+                    int chains, int lookahead, uint64_t seed, const uint8_t *init_gamma,
+                    int nsweeps, uint8_t *out_gamma, double *out_beta, double *out_sigsq,
+                    double *out_logpri, uint64_t *out_seed,
+                    int probe_chain, uint8_t *probe_gamma, double *probe_beta,
+                    double *probe_sigsq) {
+  return binding_run_impl(n, p, X, y, prior_mean, ominv, prior_df, sigma_guess, pi,
+                          max_model_size, sigma_upper_limit, max_flips, swap_threshold,
+                          chains, 0, lookahead, seed, init_gamma, nsweeps, out_gamma,
+                          out_beta, out_sigsq, out_logpri, out_seed, probe_chain,
+                          probe_gamma, probe_beta, probe_sigsq);
+}
+
+// The device-list constructor (see binding_run_impl); probe_chain is a GLOBAL chain id
+int ref_binding_group_run(int n, int p, const double *X, const double *y,
+                    const double *prior_mean, const double *ominv, double prior_df,
+                    double sigma_guess, const double *pi, int64_t max_model_size,
+                    double sigma_upper_limit, int max_flips, double swap_threshold,
+                    int chains_per_device, int ndevices, int lookahead, uint64_t seed,
+                    const uint8_t *init_gamma,
+                    int nsweeps, uint8_t *out_gamma, double *out_beta, double *out_sigsq,
+                    double *out_logpri, uint64_t *out_seed,
+                    int probe_chain, uint8_t *probe_gamma, double *probe_beta,
+                    double *probe_sigsq) {
+  return binding_run_impl(n, p, X, y, prior_mean, ominv, prior_df, sigma_guess, pi,
+                          max_model_size, sigma_upper_limit, max_flips, swap_threshold,
+                          chains_per_device, ndevices, lookahead, seed, init_gamma, nsweeps,
+                          out_gamma, out_beta, out_sigsq, out_logpri, out_seed, probe_chain,
+                          probe_gamma, probe_beta, probe_sigsq);
 }
 
 // The same for the logit sampler: BOOM's BinomialLogitModel (data added one

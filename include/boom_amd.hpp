@@ -140,13 +140,30 @@ class Engine {
     if (ba_engine_create(&cfg, &e_) != BA_OK) report_error(ba_last_error());
     chains_ = chains;
   }
-  ~Engine() { ba_engine_destroy(e_); }
+  // several devices of one node behind the handle (ba_group_*): engine i on devices[i]
+  // owns the global chains [i * chains_per_device, (i + 1) * chains_per_device); get()
+  // is the engine of chain 0.  Only RegressionModel / BregVsSampler take a device list.
+  Engine(int chains_per_device, uint64_t seed, const std::vector<int> &devices) {
+    std::vector<int32_t> dev(devices.begin(), devices.end());
+    if (ba_group_create(dev.data(), (int32_t)dev.size(), chains_per_device, seed, &g_) != BA_OK)
+      report_error(ba_group_last_error());
+    e_ = ba_group_engine(g_, 0);
+    chains_ = chains_per_device * (int)dev.size();
+  }
+  ~Engine() { if (g_) ba_group_destroy(g_); else ba_engine_destroy(e_); }
   Engine(const Engine &) = delete;
   ba_engine *get() const { return e_; }
+  ba_group *group() const { return g_; }
+  int size() const { return g_ ? ba_group_size(g_) : 1; }
+  ba_engine *get(int i) const { return g_ ? ba_group_engine(g_, i) : e_; }
   int chains() const { return chains_; }
   void check(int rc) const { if (rc != BA_OK) report_error(ba_last_error()); }
+  void check_group(int rc) const { if (rc != BA_OK) report_error(ba_group_last_error()); }
+  // f(engine) on every engine of the handle
+  template <class F> void each(F f) const { for (int i = 0; i < size(); ++i) check(f(get(i))); }
  private:
   ba_engine *e_ = nullptr;
+  ba_group *g_ = nullptr;
   int chains_ = 0;
 };
 
@@ -161,6 +178,16 @@ class RegressionModel : public Model {
         beta_(X.ncol(), 0.0), sigsq_(1.0) {
     if (X.nrow() != (int)y.size()) report_error("Number of rows of X must match the length of y.");
     eng_->check(ba_build_suf_from_xy(eng_->get(), X.nrow(), X.ncol(), X.data(), y.data()));
+  }
+  // the same over a device list: rows of X are sharded over the devices, one f64-MFMA
+  // syrk per device and ONE all-reduce give every engine the identical NeRegSuf
+  // (ba_group_build_suf_from_xy); `chains_per_device` chains on each entry of `devices`
+  RegressionModel(const Matrix &X, const Vector &y, int chains_per_device,
+                  const std::vector<int> &devices, uint64_t seed = 8675309)
+      : eng_(new Engine(chains_per_device, seed, devices)), p_(X.ncol()), inc_(X.ncol(), true),
+        beta_(X.ncol(), 0.0), sigsq_(1.0) {
+    if (X.nrow() != (int)y.size()) report_error("Number of rows of X must match the length of y.");
+    eng_->check_group(ba_group_build_suf_from_xy(eng_->group(), X.nrow(), X.ncol(), X.data(), y.data()));
   }
   int xdim() const { return p_; }
   int nvars_possible() const { return p_; }
@@ -180,13 +207,15 @@ class RegressionModel : public Model {
   const Ptr<Engine> &engine() const { return eng_; }
   // all chains (chains x p row-major gamma / beta, chains sigsq)
   void chain_states(std::vector<uint8_t> &gamma, Vector &beta, Vector &sigsq) const {
-    const size_t C = eng_->chains();
+    const size_t C = eng_->chains(), per = C / eng_->size();
     gamma.resize(C * p_); beta.resize(C * p_); sigsq.resize(C);
-    eng_->check(ba_get_states(eng_->get(), gamma.data(), beta.data(), sigsq.data()));
+    for (int i = 0; i < eng_->size(); ++i)   // global chain order
+      eng_->check(ba_get_states(eng_->get(i), gamma.data() + i * per * p_, beta.data() + i * per * p_,
+                                sigsq.data() + i * per));
   }
   // used by the sampler
   void push_state() {
-    eng_->check(ba_set_state(eng_->get(), -1, inc_.bytes().data(), beta_.data(), sigsq_));
+    eng_->each([&](ba_engine *e) { return ba_set_state(e, -1, inc_.bytes().data(), beta_.data(), sigsq_); });
     dirty_ = false;
   }
   // (while ba_draw_next serves a look-ahead batch, ba_get_state is the draw being served)
@@ -210,16 +239,19 @@ class BregVsSampler : public PosteriorSampler {
   BregVsSampler(RegressionModel *model, double prior_nobs, double expected_rsq,
                 double expected_model_size, bool first_term_is_intercept = true)
       : model_(model) {
-    check(ba_set_priors_ctor1(h(), prior_nobs, expected_rsq, expected_model_size,
-                              first_term_is_intercept));
+    all([&](ba_engine *e) { return ba_set_priors_ctor1(e, prior_nobs, expected_rsq, expected_model_size,
+                                                        first_term_is_intercept); });
+    all([&](ba_engine *e) { return ba_set_lookahead(e, kDefaultLookahead); });
   }
   // ctor #2 (BregVsSampler.cpp:87-142)
   BregVsSampler(RegressionModel *model, double prior_sigma_nobs, double prior_sigma_guess,
                 double prior_beta_nobs, double diagonal_shrinkage,
                 double prior_inclusion_probability, bool force_intercept = true)
       : model_(model) {
-    check(ba_set_priors_ctor2(h(), prior_sigma_nobs, prior_sigma_guess, prior_beta_nobs,
-                              diagonal_shrinkage, prior_inclusion_probability, force_intercept));
+    all([&](ba_engine *e) { return ba_set_priors_ctor2(e, prior_sigma_nobs, prior_sigma_guess, prior_beta_nobs,
+                                                        diagonal_shrinkage, prior_inclusion_probability,
+                                                        force_intercept); });
+    all([&](ba_engine *e) { return ba_set_lookahead(e, kDefaultLookahead); });
   }
   // ctor #3 (BregVsSampler.cpp:144-160)
   BregVsSampler(RegressionModel *model, const Vector &prior_mean,
@@ -253,16 +285,16 @@ class BregVsSampler : public PosteriorSampler {
     // the last draw goes to every chain first; the engine then rewinds any
     // look-ahead draws not handed out yet)
     if (model_->dirty()) model_->push_state();
-    check(ba_draw_next(h()));                // one launch per `lookahead` calls
+    all([](ba_engine *e) { return ba_draw_next(e); });   // one launch per `lookahead` calls and device
     model_->pull_chain0();
   }
   // run `n` sweeps ahead per launch and hand them out one draw() at a time, for
   // EVERY chain (ba_set_lookahead: the draws are the ones one launch per call
   // would give, whatever is called in between)
-  void set_lookahead(int n) { check(ba_set_lookahead(h(), n < 1 ? 1 : n)); }
-  void draw(int nsweeps) {                   // many sweeps in one launch
+  void set_lookahead(int n) { all([&](ba_engine *e) { return ba_set_lookahead(e, n < 1 ? 1 : n); }); }
+  void draw(int nsweeps) {                   // many sweeps in one launch (per device, side by side)
     if (model_->dirty()) model_->push_state();
-    check(ba_sweep(h(), nsweeps));
+    all([&](ba_engine *e) { return ba_sweep(e, nsweeps); });
     model_->pull_chain0();
   }
   void limit_model_selection(uint n) { max_flips_ = (int)n; options(); }
@@ -274,9 +306,9 @@ class BregVsSampler : public PosteriorSampler {
   void set_sigma_upper_limit(double s) {
     double df, ss;
     check(ba_get_priors(h(), nullptr, nullptr, nullptr, &df, &ss));
-    check(ba_set_sigma_prior(h(), df, std::sqrt(ss / df), s));
+    all([&](ba_engine *e) { return ba_set_sigma_prior(e, df, std::sqrt(ss / df), s); });
   }
-  void set_seed(unsigned long s) override { check(ba_seed(h(), s)); }
+  void set_seed(unsigned long s) override { all([&](ba_engine *e) { return ba_seed(e, s); }); }
   double logpri() const override {           // BregVsSampler.cpp:380-393, chain 0 (the draw being served)
     double out;
     check(ba_logpri(h(), 0, &out));
@@ -292,14 +324,15 @@ class BregVsSampler : public PosteriorSampler {
  private:
   ba_engine *h() const { return model_->engine()->get(); }
   void check(int rc) const { model_->engine()->check(rc); }
-  void options() { check(ba_set_options(h(), max_flips_, swap_, draw_beta_, draw_sigma_)); }
+  template <class F> void all(F f) const { model_->engine()->each(f); }
+  void options() { all([&](ba_engine *e) { return ba_set_options(e, max_flips_, swap_, draw_beta_, draw_sigma_); }); }
   void set_raw(const Vector &b, const SpdMatrix &om, double df, double guess, const Vector &pi, int64_t mms) {
-    check(ba_set_slab(h(), b.data(), om.data()));
-    check(ba_set_spike(h(), pi.data(), mms));
-    check(ba_set_sigma_prior(h(), df, guess, infinity()));
+    all([&](ba_engine *e) { return ba_set_slab(e, b.data(), om.data()); });
+    all([&](ba_engine *e) { return ba_set_spike(e, pi.data(), mms); });
+    all([&](ba_engine *e) { return ba_set_sigma_prior(e, df, guess, infinity()); });
     // the caller's `for i: sample_posterior()` loop runs at the long-launch rate
     // by default; the draws do not depend on this number
-    check(ba_set_lookahead(h(), kDefaultLookahead));
+    all([&](ba_engine *e) { return ba_set_lookahead(e, kDefaultLookahead); });
   }
   static constexpr int kDefaultLookahead = 256;
   RegressionModel *model_;

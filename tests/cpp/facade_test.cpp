@@ -396,6 +396,43 @@ static void LookAhead() {
   EXPECT(same);
 }
 
+// A device list behind the same classes (Engine over ba_group_*): the list repeats
+// device 0 so that a one-GPU box runs it.  Global chain c of the list is chain c of one
+// engine with all the chains (the sufficient statistics come from row shards summed in
+// another order, hence a tolerance instead of equality).
+static void DeviceList() {
+  const int n = 500, p = 14, per = 3, niter = 30;
+  Vector beta(p, 0.0);
+  beta[0] = 1.0; beta[2] = -1.5; beta[9] = 2.0;
+  Sim s = simulate(n, p, beta, 1.0, 21);
+  std::vector<uint8_t> g[2];
+  Vector b[2], s2[2];
+  std::vector<double> rec[2];
+  for (int mode = 0; mode < 2; ++mode) {
+    Ptr<RegressionModel> model;
+    if (mode == 0) model.reset(new RegressionModel(s.X, s.y, 2 * per, 31));
+    else model.reset(new RegressionModel(s.X, s.y, per, std::vector<int>{0, 0}, 31));
+    Ptr<BregVsSampler> sampler(new BregVsSampler(model.get(), 1.0, 0.5, 3.0, true));
+    sampler->set_lookahead(8);
+    sampler->set_correlation_swap_threshold(0.7);
+    model->set_method(sampler);
+    model->drop_all();
+    model->add(0);
+    for (int i = 0; i < niter; ++i) {
+      model->sample_posterior();
+      rec[mode].push_back(model->sigsq());
+    }
+    model->chain_states(g[mode], b[mode], s2[mode]);
+  }
+  EXPECT(g[0].size() == (size_t)2 * per * p && g[0] == g[1]);
+  bool close = b[0].size() == b[1].size() && s2[0].size() == s2[1].size();
+  for (size_t i = 0; close && i < b[0].size(); ++i)
+    close = std::fabs(b[0][i] - b[1][i]) <= 1e-8 * std::max(1.0, std::fabs(b[0][i]));
+  for (size_t i = 0; close && i < s2[0].size(); ++i) close = std::fabs(s2[0][i] - s2[1][i]) <= 1e-8 * s2[0][i];
+  for (size_t i = 0; close && i < rec[0].size(); ++i) close = std::fabs(rec[0][i] - rec[1][i]) <= 1e-8 * rec[0][i];
+  EXPECT(close);
+}
+
 // The virtual surface (draw / logpri / set_seed through a base pointer), ctor #4
 // (ZellnerPriorParameters) against ctor #3 with the same numbers, and a change of
 // the model's parameters between draws reaching the chains.
@@ -457,6 +494,7 @@ int main() {
     Small();
     LookAhead();
     VirtualSurfaceAndCtor4();
+    DeviceList();
     TestMaxSizeControl();
     Large();
     PerfectCollinearity();

@@ -72,6 +72,53 @@ def test_boom_model_driven_by_the_device_sampler(oracle, lookahead):
 
 @pytest.mark.skipif(not os.path.exists(BINDING_SO),
                     reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
+@pytest.mark.parametrize("ndevices,lookahead", [(2, 16), (3, 1)])
+def test_boom_model_driven_by_the_device_sampler_over_a_device_list(oracle, ndevices, lookahead):
+    """DeviceBregVsSampler's device-list constructor (ba_group_* behind it).
+    The list repeats device 0 so that a one-GPU box runs it: what BOOM's RegressionModel sees
+    is the oracle's chain 0, and a chain that lives on the LAST engine of the list is the
+    oracle's chain with that GLOBAL id -- i.e. the draws do not depend on the device list."""
+    L = C.CDLL(BINDING_SO)
+    L.ref_binding_last_error.restype = C.c_char_p
+    n, p, nsig, per_device, nsw, seed = 600, 24, 5, 5, 40, 77
+    X, y, _ = regression_data(n, p, nsig, seed=15)
+    suf = oracle.neregsuf(X, y)
+    prior = spike_slab_prior(suf, nsig)
+    opts = ssvs_options(max_model_size=10)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    gam = np.zeros((nsw, p), np.uint8)
+    beta = np.zeros((nsw, p))
+    sig = np.zeros(nsw)
+    logpri = np.zeros(nsw)
+    dev_seed = C.c_uint64()
+    pg = np.zeros(p, np.uint8)
+    pb = np.zeros(p)
+    ps = C.c_double()
+    last = ndevices * per_device - 2   # on the last engine, local chain per_device - 2
+    rc = L.ref_binding_group_run(
+        n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(prior["b"])), _dp(fcol(prior["ominv"])),
+        C.c_double(prior["df"]), C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+        C.c_int64(opts["max_model_size"]), C.c_double(opts["sigma_upper_limit"]),
+        C.c_int(-1), C.c_double(opts["swap_threshold"]), per_device, ndevices, lookahead,
+        C.c_uint64(seed), _u8(g0), nsw, _u8(gam), _dp(beta), _dp(sig), _dp(logpri),
+        C.byref(dev_seed), last, _u8(pg), _dp(pb), C.byref(ps))
+    assert rc == 0, L.ref_binding_last_error().decode()
+    o = oracle.ssvs_run(suf, prior, opts, ("philox", dev_seed.value, 0), g0, nsw)
+    assert o["status"] == 0
+    for s in range(nsw):
+        assert np.array_equal(gam[s], o["gamma"][s]), s
+        err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
+        assert err < 1e-8, (s, err)
+        assert abs(sig[s] - o["sigsq"][s]) < 1e-8 * sig[s], s
+    ol = oracle.ssvs_run(suf, prior, opts, ("philox", dev_seed.value, last), g0, nsw)
+    assert np.array_equal(pg, ol["gamma"][-1])
+    assert np.max(np.abs(pb - ol["beta"][-1]) / np.maximum(np.abs(ol["beta"][-1]), 1e-3)) < 1e-8
+    assert abs(ps.value - ol["sigsq"][-1]) < 1e-8 * ps.value
+
+
+@pytest.mark.skipif(not os.path.exists(BINDING_SO),
+                    reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
 @pytest.mark.parametrize("max_trials,max_flips", [(1, -1), (3, 7)])
 def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_flips):
     """BOOM's BinomialLogitModel (data added observation by observation), MvnModel slab and
