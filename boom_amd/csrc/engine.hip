@@ -309,6 +309,9 @@ struct ba_engine {
   bool ss_mode = false, ss_level_set = false, ss_initialized = false;
   int T = 0;
   DevBuf<double> dss_y, dss_X, dss_scratch;
+  // lane-major copies for kalman_lm_kernel (kalman_params.h): local level, T <= LM_TP
+  DevBuf<double> dss_yt, dss_Xt;
+  DevBuf<uint32_t> dss_obs_mask;
   DevBuf<uint8_t> dss_obs;
   DevBuf<double> dxty_c, dyty_c, dnobs_c;       // per-chain regression suf
   DevBuf<double> dlev_sigsq, dlev_n, dlev_sumsq;
@@ -316,7 +319,8 @@ struct ba_engine {
   // kalman_prepare_kernel (level variance + normals of the next state draw) runs on a
   // second stream beside the X'e GEMM and the SSVS launch
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_state = nullptr, ev_prep = nullptr;
+  hipEvent_t ev_state = nullptr, ev_prep[2] = {nullptr, nullptr};
+  int ss_zbuf = 0;   // the normals buffer the next state draw reads
   // pipelined sweeps: consecutive ba_sweep launches alternate between `stream` and
   // pipe_stream and hand chains over through a ring of four queues (ssvs_kernel.hip)
   hipStream_t pipe_stream = nullptr;
@@ -860,6 +864,11 @@ int64_t ssm_work_stride(const ba_engine &e) {
   return (int64_t)(2 * e.ssm.m + 4 + 5) * e.T + 64;
 }
 
+// the local-level path of a series of at most LM_TP steps runs lane-major
+// (kalman_lm_kernel): its scratch arrays have pitch LM_TP
+static bool ss_lane_major(const ba_engine &e) { return !e.ssm_set && e.T <= LM_TP; }
+static size_t ss_pitch(const ba_engine &e) { return ss_lane_major(e) ? (size_t)LM_TP : (size_t)e.T; }
+
 void fill_ss_params(ba_engine *e, SsParams &S) {
   std::memset(&S, 0, sizeof(S));  // (only_ran = nullptr: every chain)
   S.T = e->T;
@@ -871,6 +880,11 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.y = e->dss_y.ptr;
   S.X = e->dss_X.ptr;
   S.observed = e->dss_obs.ptr;
+  S.Xt = e->dss_Xt.ptr;
+  S.yt = e->dss_yt.ptr;
+  S.obs_mask = e->dss_obs_mask.ptr;
+  S.lane_major = ss_lane_major(*e) ? 1 : 0;
+  S.TP = (int32_t)ss_pitch(*e);
   S.gamma = e->dgamma.ptr;
   S.beta = e->dbeta.ptr;
   S.sigsq = e->dsigsq.ptr;
@@ -888,7 +902,7 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.pos_state = e->dpos_state.ptr;
   S.status = e->dstatus.ptr;
   S.scratch = e->dss_scratch.ptr;
-  S.scratch_stride = (int64_t)SS_SCRATCH_ARRAYS * e->T;
+  S.scratch_stride = (int64_t)SS_SCRATCH_ARRAYS * (int64_t)ss_pitch(*e);
   S.xty = e->dxty_c.ptr;
   S.yty = e->dyty_c.ptr;
   S.nobs = e->dnobs_c.ptr;
@@ -898,6 +912,7 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.prep_pos_state = e->dprep_pos_state.ptr;
   S.prep_pos_level = e->dprep_pos_level.ptr;
   S.prep_level_sigsq = e->dprep_level.ptr;
+  S.zbuf = e->ss_zbuf;
   if (e->ssm_set) {
     S.ssm = e->ssm;
     S.ssm.var_sigsq = e->dssm_sigsq.ptr;
@@ -1373,7 +1388,8 @@ void ba_engine_destroy(ba_engine *e) {
     (void)hipEventDestroy(e->pipe_join_ev);
   }
   if (e->ev_state) (void)hipEventDestroy(e->ev_state);
-  if (e->ev_prep) (void)hipEventDestroy(e->ev_prep);
+  for (int i = 0; i < 2; ++i)
+    if (e->ev_prep[i]) (void)hipEventDestroy(e->ev_prep[i]);
   if (e->stream) {
     (void)hipStreamSynchronize(e->stream);
     (void)hipStreamDestroy(e->stream);
@@ -2977,7 +2993,7 @@ static int ss_prepare(ba_engine *e) {
   if (rc) return rc;
   rc = alloc_chain_state(e);
   if (rc) return rc;
-  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, T = (size_t)e->T;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, T = ss_pitch(*e);
   if (e->dss_scratch.count != C * SS_SCRATCH_ARRAYS * T) {
     HIP_TRY(e->dss_scratch.resize(C * SS_SCRATCH_ARRAYS * T));
     HIP_TRY(e->dxty_c.resize(C * p));
@@ -2990,11 +3006,12 @@ static int ss_prepare(ba_engine *e) {
     HIP_TRY(e->dpos_state.resize(C));
     HIP_TRY(e->dpos_forecast.resize(C));
     HIP_TRY(hipMemsetAsync(e->dpos_forecast.ptr, 0, C * 8, e->stream));
-    HIP_TRY(e->dprep_n.resize(C));
-    HIP_TRY(e->dprep_pos_state.resize(C));
-    HIP_TRY(e->dprep_pos_level.resize(C));
-    HIP_TRY(e->dprep_level.resize(C));
-    HIP_TRY(hipMemsetAsync(e->dprep_n.ptr, 0, C * 4, e->stream));
+    HIP_TRY(e->dprep_n.resize(2 * C));
+    HIP_TRY(e->dprep_pos_state.resize(2 * C));
+    HIP_TRY(e->dprep_pos_level.resize(2 * C));
+    HIP_TRY(e->dprep_level.resize(2 * C));
+    HIP_TRY(hipMemsetAsync(e->dprep_n.ptr, 0, 2 * C * 4, e->stream));
+    e->ss_zbuf = 0;
     HIP_TRY(e->dxte_planes.resize((size_t)xte_planes((int64_t)T) * C * p));
     // regression suf starts as the data's own (before the first impute_state)
     std::vector<double> xty(C * p), yty(C, e->yty), nobs(C, e->n),
@@ -3075,6 +3092,26 @@ int ba_ss_set_data(ba_engine *e, int32_t T, int32_t p, const double *y,
   HIP_TRY(hipMemcpy(e->dss_y.ptr, y, (size_t)T * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->dss_X.ptr, X, (size_t)T * p * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->dss_obs.ptr, obs.data(), T, hipMemcpyHostToDevice));
+  if (T <= LM_TP) {
+    std::vector<double> Xt((size_t)LM_TP * p, 0.0), yt(LM_TP, 0.0);
+    std::vector<uint32_t> mask(LM_THREADS, 0u);
+    for (int t = 0; t < T; ++t) {
+      yt[lm_at(t)] = y[t];
+      if (obs[t]) mask[t / LM_BS] |= 1u << (t % LM_BS);
+    }
+    for (int j = 0; j < p; ++j)
+      for (int t = 0; t < T; ++t) Xt[(size_t)j * LM_TP + lm_at(t)] = X[(size_t)j * T + t];
+    HIP_TRY(e->dss_yt.resize(LM_TP));
+    HIP_TRY(e->dss_Xt.resize((size_t)LM_TP * p));
+    HIP_TRY(e->dss_obs_mask.resize(LM_THREADS));
+    HIP_TRY(hipMemcpy(e->dss_yt.ptr, yt.data(), (size_t)LM_TP * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->dss_Xt.ptr, Xt.data(), (size_t)LM_TP * p * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->dss_obs_mask.ptr, mask.data(), LM_THREADS * 4, hipMemcpyHostToDevice));
+  } else {
+    e->dss_yt.release();
+    e->dss_Xt.release();
+    e->dss_obs_mask.release();
+  }
   e->ss_mode = true;
   e->ss_initialized = false;
   e->dss_scratch.release();
@@ -3267,8 +3304,10 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
     e->ss_initialized = true;
   }
   // The local-level state draw in two pieces: what does not depend on the round's
-  // regression sweep (level variance, the normals) ahead of it on the second stream,
-  // beside the previous round's X'e GEMM and this round's SSVS launch.
+  // regression sweep (level variance, the normals) is done ahead on a second stream into
+  // the chains' other normals buffer -- the step for round i + 1 goes out behind round
+  // i's state draw, beside its X'e GEMM, its plane sum and the start of round i + 1's
+  // SSVS launch (kalman_prepare_kernel).
   const bool ahead = !e->ssm_set && nsweeps > 0;
   if (ahead && !e->stream2) {
     {
@@ -3276,28 +3315,37 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
       if (rcs) return rcs;
     }
     HIP_TRY(hipEventCreateWithFlags(&e->ev_state, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&e->ev_prep, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming));
   }
+  auto prepare_ahead = [&](int zbuf) -> hipError_t {
+    // (after everything enqueued on the main stream so far: the chains' status words of the
+    // sweep just launched, the buffer's last reader)
+    hipError_t err = hipEventRecord(e->ev_state, e->stream);
+    if (err != hipSuccess) return err;
+    err = hipStreamWaitEvent(e->stream2, e->ev_state, 0);
+    if (err != hipSuccess) return err;
+    SsParams A = S;
+    A.zbuf = zbuf;
+    err = launch_kalman_prepare(e->stream2, A, 1);
+    if (err != hipSuccess) return err;
+    return hipEventRecord(e->ev_prep[zbuf], e->stream2);
+  };
   if (ahead) {
-    // (the level model's sufficient statistics of the state draw in flight, if any)
-    HIP_TRY(hipEventRecord(e->ev_state, e->stream));
-    HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_state, 0));
-    HIP_TRY(launch_kalman_prepare(e->stream2, S, 1));
-    HIP_TRY(hipEventRecord(e->ev_prep, e->stream2));
+    HIP_TRY(prepare_ahead(e->ss_zbuf));   // the call's first round: nothing to run beside
     S.prepared = 1;
   }
   for (int i = 0; i < nsweeps; ++i) {
     HIP_TRY(launch_sweeps(e, P, 1));                  // observation model
     if (ahead) {
-      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_prep, 0));
+      const int cur = e->ss_zbuf;
+      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_prep[cur], 0));
+      S.zbuf = cur;
       HIP_TRY(launch_kalman_main(e->stream, S, 1));   // state models, state
-      if (i + 1 < nsweeps) {
-        HIP_TRY(hipEventRecord(e->ev_state, e->stream));
-        HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_state, 0));
-        HIP_TRY(launch_kalman_prepare(e->stream2, S, 1));
-        HIP_TRY(hipEventRecord(e->ev_prep, e->stream2));
-      }
+      // (the state draw's wavefronts fill the register files -- 2 x 256 registers to a
+      // SIMD -- so a prepare step launched beside it only delays it: it goes out behind)
+      if (i + 1 < nsweeps) HIP_TRY(prepare_ahead(cur ^ 1));
       HIP_TRY(launch_kalman_xte(e->stream, S));       // ... and the regression's X'e
+      e->ss_zbuf = cur ^ 1;
     } else {
       HIP_TRY(launch_state_kernel(e, S, 1));          // state models, state
     }
@@ -3338,10 +3386,17 @@ int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   int rc = ba_sync(e);
   if (rc) return rc;
-  const size_t T = (size_t)e->T;
-  if (state)
-    HIP_TRY(hipMemcpy(state, e->dss_scratch.ptr + ((size_t)chain * SS_SCRATCH_ARRAYS + SS_STATE_ARRAY) * T,
-                      T * 8, hipMemcpyDeviceToHost));
+  const size_t T = (size_t)e->T, TP = ss_pitch(*e);
+  if (state) {
+    const double *src = e->dss_scratch.ptr + ((size_t)chain * SS_SCRATCH_ARRAYS + SS_STATE_ARRAY) * TP;
+    if (ss_lane_major(*e)) {
+      std::vector<double> lm(TP);
+      HIP_TRY(hipMemcpy(lm.data(), src, TP * 8, hipMemcpyDeviceToHost));
+      for (size_t t = 0; t < T; ++t) state[t] = lm[(size_t)lm_at((int)t)];
+    } else {
+      HIP_TRY(hipMemcpy(state, src, T * 8, hipMemcpyDeviceToHost));
+    }
+  }
   if (level_sigsq) HIP_TRY(hipMemcpy(level_sigsq, e->dlev_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost));
   if (level_n) HIP_TRY(hipMemcpy(level_n, e->dlev_n.ptr + chain, 8, hipMemcpyDeviceToHost));
   if (level_sumsq) HIP_TRY(hipMemcpy(level_sumsq, e->dlev_sumsq.ptr + chain, 8, hipMemcpyDeviceToHost));

@@ -50,39 +50,81 @@ struct NormalsLds {
   int ntail, nmid;
 };
 
-// szz[i] = normal i of this sweep, i < N; the stream position moves on by N slots.
+// szz[i] = normal i of this sweep, i < N (or the slots' layout); the stream position moves on by N slots.
 // Every thread of the workgroup calls it (it contains barriers); returns the chain
 // status, the same in every thread.
+// Which draw lands in which slot of the output array.  count(): slots; draw(s): the
+// index of the draw that belongs in slot s, or -1 (none).  Threads walk the SLOTS, so
+// the stores are coalesced whatever the layout.
+struct NormalsInOrder {   // szz[i] = draw i
+  int N;
+  __device__ __forceinline__ int count() const { return N; }
+  __device__ __forceinline__ int draw(int s) const { return s; }
+};
+template <class Slots>
 __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
-                                              double *szz, uint64_t *pos_out) {
+                                              double *szz, uint64_t *pos_out, const Slots slots) {
   const double A = 2.216035867166471;
   const double C1 = 0.398942280401433, C2 = 0.180025191068563;
   const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
+  const int S = slots.count();
   int bad = 0;
-  for (int c0 = 0; c0 < N; c0 += SN_CHUNK) {
-    const int nc = (N - c0 < SN_CHUNK) ? N - c0 : SN_CHUNK;
+  for (int c0 = 0; c0 < S; c0 += SN_CHUNK) {
+    const int nc = (S - c0 < SN_CHUNK) ? S - c0 : SN_CHUNK;
     if (tid == 0) { L.ntail = 0; L.nmid = 0; }
     __syncthreads();
+#ifdef BA_KSTAMPS
+    const long long sn_t0 = (long long)__builtin_readcyclecounter();
+#endif
     // ---- phase 1: u1 and u2 of every draw (one Philox block: a slot starts at an even
     // position), the first branch where it applies
-    for (int i = tid; i < nc; i += nth) {
-      const uint64_t start = bpos0 + (uint64_t)(c0 + i) * STATE_SLOT_STRIDE;
-      double u1, u2;
-      philox_pair(key, start >> 1, &u1, &u2);
-      if (u1 < 0.884070402298758) {
-        szz[c0 + i] = A * (1.131131635444180 * u1 + u2 - 1);
-      } else if (u1 >= 0.973310954173898) {
-        L.tail[atomicAdd(&L.ntail, 1)] = (uint16_t)i;
-      } else {
-        L.mid[atomicAdd(&L.nmid, 1)] = (uint16_t)i;
+    // (four slots per thread and round: four independent Philox blocks in flight -- one
+    // block is a chain of ten dependent rounds, and the kernel runs two waves to a SIMD)
+    for (int i0 = tid; i0 < nc; i0 += 4 * nth) {
+      int dr[4];
+      double u1[4], u2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * nth;
+        dr[u] = (i < nc) ? slots.draw(c0 + i) : -1;
+        const uint64_t start = bpos0 + (uint64_t)(dr[u] < 0 ? 0 : dr[u]) * STATE_SLOT_STRIDE;
+        philox_pair(key, start >> 1, &u1[u], &u2[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * nth;
+        const bool live = dr[u] >= 0;
+        const bool fast = live && u1[u] < 0.884070402298758;
+        const bool tail = live && u1[u] >= 0.973310954173898;
+        const bool mid = live && !fast && !tail;
+        if (fast) szz[c0 + i] = A * (1.131131635444180 * u1[u] + u2[u] - 1);
+        // one list reservation per wavefront and list (same-address LDS atomics of many
+        // lanes run one after the other: they were most of this function's time)
+        const unsigned long long mt = __ballot(tail), mm = __ballot(mid);
+        const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+        if (mt) {
+          int base = 0;
+          if ((int)(threadIdx.x & 63) == __ffsll((long long)mt) - 1) base = atomicAdd(&L.ntail, __popcll(mt));
+          base = __builtin_amdgcn_readlane(base, __ffsll((long long)mt) - 1);
+          if (tail) L.tail[base + __popcll(mt & below)] = (uint16_t)i;
+        }
+        if (mm) {
+          int base = 0;
+          if ((int)(threadIdx.x & 63) == __ffsll((long long)mm) - 1) base = atomicAdd(&L.nmid, __popcll(mm));
+          base = __builtin_amdgcn_readlane(base, __ffsll((long long)mm) - 1);
+          if (mid) L.mid[base + __popcll(mm & below)] = (uint16_t)i;
+        }
       }
     }
     __syncthreads();
+#ifdef BA_KSTAMPS
+    const long long sn_t1 = (long long)__builtin_readcyclecounter();
+#endif
     // ---- phase 2a: the tail region
     const int ntail = L.ntail, nmid = L.nmid;
     for (int q = tid; q < ntail; q += nth) {
       const int i = L.tail[q];
-      const uint64_t start = bpos0 + (uint64_t)(c0 + i) * STATE_SLOT_STRIDE;
+      const uint64_t start = bpos0 + (uint64_t)slots.draw(c0 + i) * STATE_SLOT_STRIDE;
       PairRng r;
       r.init(key, start);
       const double u1 = r();
@@ -100,12 +142,15 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
       if (r.pos - start > (uint64_t)STATE_SLOT_STRIDE) bad = 1;
       szz[c0 + i] = z;
     }
+#ifdef BA_KSTAMPS
+    const long long sn_t2 = (long long)__builtin_readcyclecounter();
+#endif
     // ---- phase 2b: the middle regions, one loop:
     //   tt = t0 + t1 min(u2, u3);  accept when max(u2, u3) <= thr or
     //   coef |u2 - u3| <= C1 exp(-tt^2 / 2) - C2 (A - tt)
     for (int q = tid; q < nmid; q += nth) {
       const int i = L.mid[q];
-      const uint64_t start = bpos0 + (uint64_t)(c0 + i) * STATE_SLOT_STRIDE;
+      const uint64_t start = bpos0 + (uint64_t)slots.draw(c0 + i) * STATE_SLOT_STRIDE;
       PairRng r;
       r.init(key, start);
       const double u1 = r();
@@ -131,11 +176,23 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
       if (r.pos - start > (uint64_t)STATE_SLOT_STRIDE) bad = 1;
       szz[c0 + i] = z;
     }
+#ifdef BA_KSTAMPS
+    const long long sn_t3 = (long long)__builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef BA_KSTAMPS
+    if (blockIdx.x == 0 && (tid == 0 || tid == 127))
+      printf("stream_normals tid %d: phase 1 %lld, tail (%d) %lld, mid (%d) %lld, wait %lld\n", tid, sn_t1 - sn_t0, ntail,
+             sn_t2 - sn_t1, nmid, sn_t3 - sn_t2, (long long)__builtin_readcyclecounter() - sn_t3);
+#endif
   }
   bad = __syncthreads_or(bad);
   if (tid == 0) *pos_out = bpos0 + (uint64_t)N * STATE_SLOT_STRIDE;
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
+}
+__device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
+                                              double *szz, uint64_t *pos_out) {
+  return stream_normals(L, key, bpos0, N, szz, pos_out, NormalsInOrder{N});
 }
 
 }  // namespace boom_amd

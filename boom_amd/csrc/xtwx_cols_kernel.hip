@@ -151,7 +151,14 @@ __global__ __launch_bounds__(256) void xtwx_cols_reduce_kernel(const double *__r
     const size_t plane = (size_t)R * (size_t)p;
     const double *s = planes + (size_t)r * p + j;
     double a = s[0];
-    for (int z = 1; z < nplanes; ++z) a += s[(size_t)z * plane];
+    for (int z0 = 1; z0 < nplanes; z0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (z0 + u < nplanes) ? s[(size_t)(z0 + u) * plane] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (z0 + u < nplanes) a += v[u];
+    }
     V[((size_t)q.x * p + (size_t)q.y) * (size_t)p + j] = a + base[(size_t)q.y * p + j];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(valid + (size_t)q.x * words + (q.y >> 5), 1u << (q.y & 31));
@@ -164,8 +171,16 @@ __global__ __launch_bounds__(256) void plain_reduce_kernel(const double *__restr
   const size_t count = (size_t)R * (size_t)p;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
+  // (eight planes' loads in flight at a time; the sum stays in plane order)
   double a = planes[i];
-  for (int z = 1; z < nplanes; ++z) a += planes[(size_t)z * count + i];
+  for (int z0 = 1; z0 < nplanes; z0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (z0 + u < nplanes) ? planes[(size_t)(z0 + u) * count + i] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z0 + u < nplanes) a += v[u];
+  }
   if (diag_base) {
     const size_t j = i % (size_t)p;
     a += diag_base[j * p + j];

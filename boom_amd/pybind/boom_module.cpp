@@ -184,13 +184,17 @@ PYBIND11_MODULE(_boom, boom) {
       });
 
   py::class_<RegressionModel, Ptr<RegressionModel>>(boom, "RegressionModel")
-      .def(py::init([](const NpArray &X, const NpArray &y, bool, int chains, uint64_t seed, int device) {
+      .def(py::init([](const NpArray &X, const NpArray &y, bool, int chains, uint64_t seed, int device,
+                       const std::vector<int> &devices) {
+             if (!devices.empty())
+               return new RegressionModel(matrix_from(X), vector_from(y), chains, devices, seed);
              return new RegressionModel(matrix_from(X), vector_from(y), chains, seed, device);
            }),
            py::arg("X"), py::arg("y"), py::arg("start_at_mle") = false, py::arg("chains") = 1,
-           py::arg("seed") = 8675309ull, py::arg("device") = 0,
+           py::arg("seed") = 8675309ull, py::arg("device") = 0, py::arg("devices") = std::vector<int>(),
            "RegressionModel(X, y, start_at_mle): sufficient statistics are built on the "
-           "device.  chains / seed / device: the many-chain engine behind the model.")
+           "device.  chains / seed / device: the many-chain engine behind the model; "
+           "devices=[...]: `chains` chains on EACH listed device behind the one model.")
       .def_property_readonly("xdim", &RegressionModel::xdim)
       .def_property_readonly("coef", py::cpp_function([](RegressionModel &m) { return CoefView{&m}; },
                                                       py::keep_alive<0, 1>()))

@@ -134,11 +134,12 @@ def test_c3_benchmark_shape_every_sweep(oracle):
                 seed=4, data_seed=8675309)
 
 
-@pytest.mark.parametrize("T,missing", [(2500, 0.0), (2049, 0.03), (4100, 0.0),
+@pytest.mark.parametrize("T,missing", [(2500, 0.0), (2049, 0.03), (4100, 0.0), (2048, 0.02), (2033, 0.0),
                                         (65, 0.0), (63, 0.1), (20, 0.0), (2, 0.0)])
 def test_state_space_long_and_ragged_T(oracle, T, missing):
-    """T beyond one 2048-step y* panel, T = 64 k + 1, T < 64, T = 2 (the level
-    variance comes from the slice sampler)."""
+    """T beyond the lane-major kernel's 2048 steps (the natural-layout kernel), exactly 2048
+    and a ragged last thread, T = 64 k + 1, T < 64, T = 2 (the level variance comes from the
+    slice sampler)."""
     _ss_compare(oracle, T=T, p=8, nsig=3, chains=5, check=[0, 4], nsw=4, seed=17,
                 data_seed=100 + T, missing=missing)
 

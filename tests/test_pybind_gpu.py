@@ -12,9 +12,9 @@ from oracle_lib import ssvs_options
 pytestmark = pytest.mark.gpu
 
 
-def _lm_spike_loop(boom, X, y, prior, niter, seed, chains, lookahead=1):
+def _lm_spike_loop(boom, X, y, prior, niter, seed, chains, lookahead=1, devices=()):
     """the body of lm_spike.__init__, boom.* calls only"""
-    model = boom.RegressionModel(X, y, False, chains=chains, seed=seed)
+    model = boom.RegressionModel(X, y, False, chains=chains, seed=seed, devices=list(devices))
     slab = boom.MvnGivenScalarSigma(prior["b"], prior["ominv"])
     siginv_prior = boom.ChisqModel(prior["df"], prior["sigma_guess"])
     spike = boom.VariableSelectionPrior(prior["pi"])
@@ -32,6 +32,30 @@ def _lm_spike_loop(boom, X, y, prior, niter, seed, chains, lookahead=1):
         residual_sd[i] = model.sigma
         coefficient_draws[i, :] = model.coef.Beta
     return model, sampler, coefficient_draws, residual_sd
+
+
+def test_lm_spike_driver_loop_over_a_device_list(oracle):
+    """devices=[0, 0]: `chains` chains on each entry; chain 0 and the last global chain are
+    the oracle's chains with those ids (beta within 1e-8: the row-sharded X'X sums in
+    another order)."""
+    import boom_amd._boom as boom
+    n, p, nsig, niter, seed, per = 500, 20, 4, 40, 4711, 4
+    X, y, _ = regression_data(n, p, nsig, seed=22)
+    suf = oracle.neregsuf(X, y)
+    prior = spike_slab_prior(suf, nsig)
+    model, sampler, draws, sd = _lm_spike_loop(boom, X, y, prior, niter, seed, per, 10, devices=(0, 0))
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    o = oracle.ssvs_run(suf, prior, ssvs_options(), ("philox", seed, 0), g0, niter)
+    for i in range(niter):
+        assert np.array_equal(draws[i] != 0, o["gamma"][i] != 0), i
+        err = np.max(np.abs(draws[i] - o["beta"][i]) / np.maximum(np.abs(o["beta"][i]), 1e-3))
+        assert err < 1e-8, (i, err)
+    G, B, S = model.chain_states()
+    assert G.shape == (2 * per, p) and S.shape == (2 * per,)
+    ol = oracle.ssvs_run(suf, prior, ssvs_options(), ("philox", seed, 2 * per - 1), g0, niter)
+    assert np.array_equal(G[-1], ol["gamma"][-1])
+    assert abs(S[-1] - ol["sigsq"][-1]) < 1e-8 * S[-1]
 
 
 @pytest.mark.parametrize("lookahead", [1, 25])

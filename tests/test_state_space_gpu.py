@@ -58,6 +58,39 @@ def test_state_space_every_sweep(oracle, missing):
             assert np.max(np.abs(st["state"] - o["state"][s])) < 1e-8 * np.abs(o["state"][s]).max()
 
 
+@pytest.mark.parametrize("T", [120, 2100])
+@pytest.mark.parametrize("case", ["known_initial_state", "level_fixed_at_zero"])
+def test_state_space_zero_variances(oracle, T, case):
+    """A zero standard deviation draws nothing (Bmath/rnorm.cpp:63-64), so the sweep's
+    normals are fewer and sit elsewhere on the stream: a known initial state (P0 = 0) and a
+    level variance held at zero (upper limit 0), on the lane-major kernel (T <= 2048, normals
+    prepared a round ahead in their slots) and on the natural-layout one."""
+    p, chains, nsw, seed = 6, 3, 6, 5
+    X, y, _, obs = state_space_data(T, p, 2, seed=3, missing_frac=0.05)
+    prior, ss, sig_up = bsts_priors(X, y, 2)
+    ss = dict(ss)
+    if case == "known_initial_state":
+        ss["initial_state_variance"] = 0.0
+    else:
+        ss["level_sigma_upper_limit"] = 0.0
+        ss["initial_level_sigma"] = 0.0
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(p, np.uint8)
+    eng = make_engine(chains, seed, y, X, obs, prior, ss, sig_up, g0)
+    ora = [oracle.ss_run(y, X, obs, prior, opts, ss, ("philox", seed, c), g0, nsw) for c in range(chains)]
+    eng.ss_sweep(2)          # (two rounds in one call: the second one's normals come prepared)
+    eng.ss_sweep(nsw - 2)
+    gam, beta, sig = eng.get_states()
+    for c in range(chains):
+        o = ora[c]
+        assert o["status"] == 0
+        assert np.array_equal(gam[c], o["gamma"][-1]), c
+        assert relerr(beta[c], o["beta"][-1]) < RTOL, c
+        st = eng.ss_get_state(c)
+        assert abs(st["level_sigsq"] - o["level_sigsq"][-1]) <= RTOL * o["level_sigsq"][-1]
+        assert np.max(np.abs(st["state"] - o["state"][-1])) < 1e-8 * np.abs(o["state"][-1]).max()
+
+
 def test_impute_state_sufficient_statistics(oracle):
     """one impute_state with fixed parameters: state draw and the regression /
     level sufficient statistics it leaves behind (a14-a19)."""

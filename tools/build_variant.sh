@@ -13,7 +13,7 @@ pids=()
 for f in engine group ssvs_kernel ssvs_big_kernel ssvs_adaptive_kernel ssm_kernel probit_kernel xtwx_cols_kernel predict_kernel suf_kernel kalman_kernel; do
   fl=$OTHER_FLAGS
   [ $f = ssvs_kernel ] && fl=$SSVS_FLAGS
-  { [ $f = engine ] || [ $f = group ]; } && fl=""
+  [ $f = group ] && fl=""; [ $f = engine ] && fl=$ENGINE_FLAGS
   ( /opt/rocm/bin/hipcc $BASE $fl -c $SRC/$f.hip -o $OUT/$f.o 2>/dev/null ) &
   pids+=($!)
 done
