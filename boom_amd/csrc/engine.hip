@@ -65,7 +65,7 @@ hipError_t launch_square(hipStream_t stream, const double *x, size_t count, doub
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level);
 hipError_t launch_kalman_main(hipStream_t stream, const SsParams &P, int draw_level);
-hipError_t launch_kalman_xte(hipStream_t stream, const SsParams &P);
+hipError_t launch_kalman_xte(hipStream_t stream, const SsParams &P, bool planes_only);
 hipError_t launch_kalman_prepare(hipStream_t stream, const SsParams &P, int draw_level);
 hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
                               uint64_t *pos_forecast, double *out);
@@ -3344,7 +3344,13 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
       // (the state draw's wavefronts fill the register files -- 2 x 256 registers to a
       // SIMD -- so a prepare step launched beside it only delays it: it goes out behind)
       if (i + 1 < nsweeps) HIP_TRY(prepare_ahead(cur ^ 1));
-      HIP_TRY(launch_kalman_xte(e->stream, S));       // ... and the regression's X'e
+      // ... and the regression's X'e: inside a call the plane sum is left to the next
+      // round's sweep launch (one wave per chain on this path)
+      const bool fold = i + 1 < nsweeps && !e->big_active && e->waves == 1 && e->cur_mode != 2;
+      HIP_TRY(launch_kalman_xte(e->stream, S, fold));
+      P.xty_planes = fold ? e->dxte_planes.ptr : nullptr;
+      P.xty_nplanes = xte_planes((int64_t)S.TP);
+      P.xty_plane_stride = (int64_t)e->cfg.chains * e->p;
       e->ss_zbuf = cur ^ 1;
     } else {
       HIP_TRY(launch_state_kernel(e, S, 1));          // state models, state

@@ -1223,18 +1223,19 @@ hipError_t launch_kalman_main(hipStream_t stream, const SsParams &P, int draw_le
 // ... and xty[chain, j] = x_j' e_chain: residual series are array 1 of every chain's
 // scratch block (zero where unobserved, and for a chain in error the previous
 // sweep's -- its status stops it anyway)
-hipError_t launch_kalman_xte(hipStream_t stream, const SsParams &P) {
+// planes_only: the plane sum is left to the next SSVS launch (SsvsParams::xty_planes)
+hipError_t launch_kalman_xte(hipStream_t stream, const SsParams &P, bool planes_only) {
   // (lane-major: residuals and Xt are the same permutation of time, zero past T)
   return launch_xte_tiled(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.TP, P.scratch_stride,
                           P.chain_count, P.lane_major ? P.Xt : P.X, (int64_t)P.TP, P.p,
-                          P.xty + (size_t)P.chain_first * P.p, P.xte_planes);
+                          planes_only ? nullptr : P.xty + (size_t)P.chain_first * P.p, P.xte_planes);
 }
 
 hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
                                    int draw_level) {
   hipError_t err = launch_kalman_main(stream, P, draw_level);
   if (err != hipSuccess) return err;
-  return launch_kalman_xte(stream, P);
+  return launch_kalman_xte(stream, P, false);
 }
 
 }  // namespace boom_amd

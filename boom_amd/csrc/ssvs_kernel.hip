@@ -90,6 +90,27 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   bind_lds(ch, smem, lay);
   lds_f64 *ctl = to_lds<double>(smem + lay.ctrl);
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
+  if (W == 1 && P.xty_planes) {
+    // the plane sum of the X'e GEMM that fed this launch (plain_reduce_kernel's values in
+    // its order: one kernel, its launch gap and a 13 MB round trip less per round)
+    double *dst = const_cast<double *>(P.xty) + (size_t)chain * P.xty_stride;
+    const double *src = P.xty_planes + (size_t)chain * p;
+    for (int j = lane; j < p; j += WAVE) {
+      double a = src[j];
+      for (int z0 = 1; z0 < P.xty_nplanes; z0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = (z0 + u < P.xty_nplanes) ? src[(size_t)(z0 + u) * P.xty_plane_stride + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (z0 + u < P.xty_nplanes) a += v[u];
+      }
+      dst[j] = a;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);   // (vmcnt(0): the stores are in before the sweep's first look)
+  }
   bind_slot(ch, P, chain, 0);
   ch.sc = (c_f64 *)(unsigned long long)ch.sc_store;
   const double yty = P.yty[(size_t)chain * P.suf_stride];

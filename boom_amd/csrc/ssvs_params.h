@@ -79,6 +79,13 @@ struct SsvsParams {
   const double *pi;   // pi_j (make_valid)
   // sufficient statistics: shared (stride 0) or per chain (state space)
   const double *xty;  // [chain * xty_stride + j]
+  // state-space rounds: the X'e GEMM's split-K planes are still to be added (the plane
+  // sum folded into this launch -- one-wave launches over all chains only): xty of a
+  // chain is written from xty_planes[z][chain * p + j], z < xty_nplanes, in plane order,
+  // before anything reads it.  nullptr: xty is there.
+  const double *xty_planes;
+  int32_t xty_nplanes;
+  int64_t xty_plane_stride;
   int64_t xty_stride;
   const double *yty;  // [chain * suf_stride]
   const double *nobs; // [chain * suf_stride]

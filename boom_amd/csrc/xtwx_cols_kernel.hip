@@ -274,6 +274,7 @@ hipError_t launch_xte_tiled(hipStream_t stream, const double *U, int64_t ldu, in
   KtScope kt(stream, KT_XTE_GEMM);
   hipLaunchKernelGGL((xtwx_cols_kernel<false, XTE_KCHUNK>), dim3((p + JT - 1) / JT, (R + RT - 1) / RT, np),
                      dim3(256), 0, stream, B, n, p, U, ldu, (const int2 *)nullptr, R, planes);
+  if (!out) return hipGetLastError();   // (planes only: the caller's next kernel adds them)
   const size_t cnt = (size_t)R * p;
   hipLaunchKernelGGL(plain_reduce_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, planes, np, R,
                      p, (const double *)nullptr, out);
