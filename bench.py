@@ -153,7 +153,8 @@ def other_configs(boom_amd, torch, device, cpu=True):
     dom = max(kt, key=kt.get)
     rec = {"sweeps_per_s": round(C3 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
            "mean_model_size": round(k3, 2), "kernel_us_per_launch": kt,
-           "roofline": {"bound": "hbm", "kernel": "kalman_simsmooth_kernel",
+           "roofline": {"bound": "hbm", "kernel": "kalman_lm_kernel (the timing class is named after "
+                                                   "kalman_simsmooth_kernel, its T > 2048 sibling)",
                         "algorithmic_bytes_per_round": bytes3,
                         "achieved": round(bytes3 / (kt["kalman_simsmooth_kernel"] * 1e-6) / 1e9, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -746,6 +746,7 @@ struct LmSlots {   // slot s of the normals array: row s / 128 = 2 j + kind, thr
 
 __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, int draw_level) {
   constexpr int BS = LM_BS, NT = LM_THREADS;
+  constexpr int LM_VB = 5;                 // variables' columns in flight together in the y* pass
   __shared__ NormalsLds s_norm;            // (only a chain whose normals were not prepared uses it)
   __shared__ double s_x[2][8];             // the two waves' scan totals
   __shared__ uint32_t s_mask[NT];          // (H == 0 only: the threads' observed masks)
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
 #define LM_IN(j) (((inm >> (j)) & 1u) != 0u)
 #define LM_OB(j) (((obm >> (j)) & 1u) != 0u)
 
-  // ---- 1. y*_t = y_t - x_t'beta: the included variables' columns four at a time (their
+  // ---- 1. y*_t = y_t - x_t'beta: the included variables' columns LM_VB at a time (their
   // loads in flight together); products accumulate in variable order, as GlmCoefs::predict
   double ys[BS];
   {
@@ -840,30 +841,30 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
       const double bj = (jv < p) ? beta[jv] : 0.0;
       unsigned long long mk = __ballot(bj != 0.0);
       while (mk) {
-        // up to four variables of the batch (absent ones repeat the first with a zero
+        // up to LM_VB variables of the batch (absent ones repeat the first with a zero
         // coefficient that is never added)
-        int l[4];
+        int l[LM_VB];
         int cnt = 0;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < LM_VB; ++v) {
           const bool have = mk != 0;
           l[v] = have ? __ffsll((long long)mk) - 1 : l[0];
           if (have) { mk &= mk - 1; ++cnt; }
         }
-        double b[4];
-        const double *c[4];
+        double b[LM_VB];
+        const double *c[LM_VB];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < LM_VB; ++v) {
           b[v] = bcast_u(bj, l[v]);
           c[v] = P.Xt + (size_t)(vb + l[v]) * LM_TP + tid;
         }
-        double x[4][BS];
+        double x[LM_VB][BS];
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int v = 0; v < LM_VB; ++v)
 #pragma unroll
           for (int j = 0; j < BS; ++j) x[v][j] = c[v][j * NT];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < LM_VB; ++v) {
           if (v < cnt) {
 #pragma unroll
             for (int j = 0; j < BS; ++j) pred[j] += x[v][j] * b[v];
@@ -1050,6 +1051,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
   // the state: residual e_t = y_t - alpha_t at observed t (0 elsewhere), e'e, #observed
   // (nothing is stored before the last exchange: a barrier waits for the stores in flight)
   {
+    // (loaded here, not under the forward pass: a barrier there would wait for it)
     double yv[BS];
 #pragma unroll
     for (int j = 0; j < BS; ++j) yv[j] = P.yt[j * NT + tid];
