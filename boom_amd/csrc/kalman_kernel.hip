@@ -300,15 +300,12 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
   const int N = nfirst + (T - 1) * nper;
   // Normal i of the sweep reads its uniforms from position bpos0 + 256 i of the
   // chain's state stream (stream_normals.h); szz holds them in draw order.
-  if (prepared && *prep_n_slot != N) {
-    // prepared with another count: a variance turned out to be exactly zero (or stopped
-    // being), which the prepare step -- by now two rounds ahead on the stream -- could
-    // not know.  No continuous draw does that; the chain stops rather than leave its stream.
-    if (threadIdx.x == 0) P.status[chain] = CHAIN_RNG_BRANCH;
-    return;
-  }
-  if (!prepared) {
-    const uint64_t bpos0 = P.pos_state[chain];
+  if (!prepared || *prep_n_slot != N) {
+    // (prepared with another count: the observation variance turned out to be exactly
+    // zero, which the prepare step cannot know -- the normals again, from where it
+    // started; the next prepare step goes out behind this kernel, so the stream position
+    // written here is the one it reads)
+    const uint64_t bpos0 = prepared ? *prep_pos_slot : P.pos_state[chain];
     status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,
                             &P.pos_state[chain]);
     if (status != CHAIN_OK) {   // (s_hand[3]: the same in both waves)
@@ -750,8 +747,8 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
   __shared__ NormalsLds s_norm;            // (only a chain whose normals were not prepared uses it)
   __shared__ double s_x[2][8];             // the two waves' scan totals
   __shared__ uint32_t s_mask[NT];          // (H == 0 only: the threads' observed masks)
-  const int chain = (int)blockIdx.x + P.chain_first, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;
+  const int chain = (int)blockIdx.x + P.chain_first, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (the chain's scalars first, all in flight together, then the decisions)
   int32_t *prep_n_slot = P.prep_n + (size_t)P.zbuf * P.chains + chain;
   const int prep_n = *prep_n_slot, status_in = P.status[chain];
@@ -805,12 +802,8 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
   const int nfirst = dI + dH, nper = dL + dH;
   const int N = nfirst + (T - 1) * nper;
   KSTAMP(0);
-  if (prepared && prep_n != N) {   // (see kalman_simsmooth_kernel)
-    if (tid == 0) P.status[chain] = CHAIN_RNG_BRANCH;
-    return;
-  }
-  if (!prepared) {
-    const uint64_t bpos0 = P.pos_state[chain];
+  if (!prepared || prep_n != N) {   // (another count: see kalman_simsmooth_kernel)
+    const uint64_t bpos0 = prepared ? P.prep_pos_state[(size_t)P.zbuf * P.chains + chain] : P.pos_state[chain];
     status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,
                             &P.pos_state[chain], LmSlots{T, nfirst, nper, dI, dL, dH});
     if (status != CHAIN_OK) {
@@ -1127,8 +1120,8 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
 // checks the count.  A failure is handed over as a negative count.
 __global__ __launch_bounds__(128) void kalman_prepare_kernel(SsParams P, int draw_level) {
   __shared__ NormalsLds s_norm;
-  const int chain = (int)blockIdx.x + P.chain_first;
   if ((int)blockIdx.x >= P.chain_count) return;
+  const int chain = (int)blockIdx.x + P.chain_first;
   if (P.status[chain] != CHAIN_OK) return;
   const int T = P.T;
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);

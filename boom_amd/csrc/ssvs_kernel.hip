@@ -56,6 +56,31 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int p = P.p;
+#ifdef BA_PSTAMPS
+  long long pst[8];
+  pst[0] = (long long)__builtin_readcyclecounter();
+#define PSTAMP(i) pst[i] = (long long)__builtin_readcyclecounter()
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+  // State-space rounds: the planes of the X'e GEMM that fed this launch are added here
+  // (SsvsParams::xty_planes).  Their loads go out FIRST, ahead of everything the prologue
+  // waits for, so that they cost no round trip of their own (a chain's one-sweep launch is
+  // a chain of such trips; in place this one was 6-7 k cycles of 95 k).
+  constexpr int FOLD_Z = 16;
+  const bool fold = (W == 1) && P.xty_planes != nullptr;
+  const bool fold_early = fold && P.xty_nplanes <= FOLD_Z && p <= 2 * WAVE;
+  double pl[2][FOLD_Z];
+  if (fold_early) {
+    const double *src = P.xty_planes + (size_t)chain * p;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = lane + e * WAVE;
+#pragma unroll
+      for (int z = 0; z < FOLD_Z; ++z)
+        pl[e][z] = (j < p && z < P.xty_nplanes) ? src[(size_t)z * P.xty_plane_stride + j] : 0.0;
+    }
+  }
   if (P.status[chain] != CHAIN_OK) {
     // a chain waiting for a larger-capacity kernel (or in error) just books
     // the sweeps it is owed
@@ -89,10 +114,24 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   ch.k = 0;
   bind_lds(ch, smem, lay);
   lds_f64 *ctl = to_lds<double>(smem + lay.ctrl);
+  PSTAMP(1);
   ch.xty = P.xty + (size_t)chain * P.xty_stride;
-  if (W == 1 && P.xty_planes) {
-    // the plane sum of the X'e GEMM that fed this launch (plain_reduce_kernel's values in
-    // its order: one kernel, its launch gap and a 13 MB round trip less per round)
+  if (fold_early) {
+    // (plain_reduce_kernel's values in its order: one kernel, its launch gap and a 13 MB
+    // round trip less per round)
+    double *dst = const_cast<double *>(P.xty) + (size_t)chain * P.xty_stride;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = lane + e * WAVE;
+      double a = pl[e][0];
+#pragma unroll
+      for (int z = 1; z < FOLD_Z; ++z)
+        if (z < P.xty_nplanes) a += pl[e][z];
+      if (j < p) dst[j] = a;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);   // (vmcnt(0): the stores are in before the sweep's first look)
+  } else if (fold) {
     double *dst = const_cast<double *>(P.xty) + (size_t)chain * P.xty_stride;
     const double *src = P.xty_planes + (size_t)chain * p;
     for (int j = lane; j < p; j += WAVE) {
@@ -111,6 +150,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0);   // (vmcnt(0): the stores are in before the sweep's first look)
   }
+  PSTAMP(2);
   bind_slot(ch, P, chain, 0);
   ch.sc = (c_f64 *)(unsigned long long)ch.sc_store;
   const double yty = P.yty[(size_t)chain * P.suf_stride];
@@ -298,6 +338,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   WinRng rng;
   rng.init(key, lane, pos);
 
+  PSTAMP(3);
   // The chain's model block of the last launch is still this model (nothing but
   // sweeps happened since): take the factors from there instead of factoring.
   if (model_kept) {
@@ -324,6 +365,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
     pe.kind = EV_NONE;
   }
 
+  PSTAMP(4);
   while (status == CHAIN_OK) {
     if (pe.kind != EV_NONE && !spec) {
       // ---- the one place where a model is (re)built (a swap proposed by a
@@ -876,6 +918,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
     phase = spec ? PH_JOIN : PH_COMMIT;
   }
 
+  PSTAMP(5);
   // release the helper waves
   if (W > 1) {
     if (lane == 0) ctl[CT_CMD] = (double)CMD_EXIT;
@@ -939,6 +982,12 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
     a[ACC_SLOT_HITS] += ctl[CT_ACC + ACC_SLOT_HITS];
 #endif
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], ctl[CT_ACC + ACC_MIN_MARGIN]);
+#ifdef BA_PSTAMPS
+    PSTAMP(6);
+    if (chain == 0 || chain == 517)
+      printf("ssvs chain %d: status/todo %lld, plane sum %lld, gamma+scalars %lld, restore+refactor %lld, sweeps %lld, epilogue %lld\n",
+             chain, pst[1] - pst[0], pst[2] - pst[1], pst[3] - pst[2], pst[4] - pst[3], pst[5] - pst[4], pst[6] - pst[5]);
+#endif
 #if defined(BA_STAMPS) && defined(BA_STAMPS4)
     // (phases are wave 1's)
 #elif defined(BA_STAMPS) && (defined(BA_STAMPS2) || defined(BA_STAMPS3))
