@@ -1105,10 +1105,12 @@ __global__ __launch_bounds__(64 * W, WPE) void ssvs_sweep_kernel(SsvsParams P, i
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_chain;
   if ((int)blockIdx.x >= P.chain_count) return;
-  // A chain's sweep is one long chain of dependent instructions: whenever this wavefront
-  // has one ready it goes first (the state-space path runs its normals generator, two
-  // multiply-bound wavefronts to a SIMD, beside the start of this launch).
-  __builtin_amdgcn_s_setprio(3);
+  // A one-wave chain's sweep is one long chain of dependent instructions: whenever this
+  // wavefront has one ready it goes first (the state-space path runs its normals
+  // generator, two multiply-bound wavefronts to a SIMD, beside the start of this launch).
+  // (Not for the multi-wave instances: with every wavefront of the launch raised, config
+  // 2 measured 43.7 instead of 44.6 M sweeps/s.)
+  if (W == 1) __builtin_amdgcn_s_setprio(3);
   int chain = (int)blockIdx.x + P.chain_first;
   if (P.q_in) {
     if (threadIdx.x == 0) {

@@ -79,13 +79,6 @@ struct SsvsParams {
   const double *pi;   // pi_j (make_valid)
   // sufficient statistics: shared (stride 0) or per chain (state space)
   const double *xty;  // [chain * xty_stride + j]
-  // state-space rounds: the X'e GEMM's split-K planes are still to be added (the plane
-  // sum folded into this launch -- one-wave launches over all chains only): xty of a
-  // chain is written from xty_planes[z][chain * p + j], z < xty_nplanes, in plane order,
-  // before anything reads it.  nullptr: xty is there.
-  const double *xty_planes;
-  int32_t xty_nplanes;
-  int64_t xty_plane_stride;
   int64_t xty_stride;
   const double *yty;  // [chain * suf_stride]
   const double *nobs; // [chain * suf_stride]
@@ -200,6 +193,13 @@ struct SsvsParams {
   double *big_model;          // 2 slots x chains x big_model_stride doubles
   int64_t big_model_stride;
   double *big_xs;             // chains x 2 waves x big_kcap x 64 doubles
+  // state-space rounds: the X'e GEMM's split-K planes are still to be added (the plane
+  // sum folded into this launch -- one-wave launches over all chains only): xty of a
+  // chain is written from xty_planes[z][chain * p + j], z < xty_nplanes, in plane order,
+  // before anything reads it.  nullptr: xty is there.
+  const double *xty_planes;
+  int32_t xty_nplanes;
+  int64_t xty_plane_stride;
 };
 
 // ---- LDS layout of one chain (one wavefront) --------------------------------
