@@ -309,6 +309,15 @@ struct ba_engine {
   bool ss_mode = false, ss_level_set = false, ss_initialized = false;
   int T = 0;
   DevBuf<double> dss_y, dss_X, dss_scratch;
+  // The callers' loop is "one round, then read chain 0": what the accessors copy goes
+  // through ONE pinned staging buffer per call (a batch of asynchronous copies, one
+  // synchronisation) instead of one blocking copy per field, and a ba_sync() that follows
+  // a clean ba_sync() with no call in between that could have enqueued or changed anything
+  // is free (api_seq counts such calls, clean_seq remembers the last clean check).
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  uint64_t api_seq = 1, clean_seq = 0;
+  int api_depth = 0;   // calls other than accessors in progress (they may enqueue after an inner ba_sync)
   // lane-major copies for kalman_lm_kernel (kalman_params.h): local level, T <= LM_TP
   DevBuf<double> dss_yt, dss_Xt;
   DevBuf<uint32_t> dss_obs_mask;
@@ -983,20 +992,46 @@ int ss_escalate(ba_engine *e, std::vector<int32_t> &st) {
   }
 }
 
+// the pinned staging buffer of the accessors' batched copies (engine struct)
+hipError_t pinned_reserve(ba_engine *e, size_t bytes) {
+  if (bytes <= e->pinned_bytes) return hipSuccess;
+  if (e->pinned) (void)hipHostFree(e->pinned);
+  e->pinned = nullptr;
+  e->pinned_bytes = 0;
+  const size_t want = std::max<size_t>(bytes, (size_t)1 << 16);
+  hipError_t err = hipHostMalloc(&e->pinned, want, hipHostMallocDefault);
+  if (err == hipSuccess) e->pinned_bytes = want;
+  return err;
+}
+
 int check_chain_status(ba_engine *e) {
   const size_t C = (size_t)e->cfg.chains;
   if (!e->state_ready) return BA_OK;
   std::vector<int32_t> st(C);
-  HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+  // the status words and the launches' largest model in ONE round trip
+  const bool follow = e->cfg.max_model_size_hint <= 0 && e->kcap > 0;
+  HIP_TRY(pinned_reserve(e, C * 4 + 16));
+  int32_t *hst = (int32_t *)e->pinned, *hmaxk = hst + C;
+  HIP_TRY(hipMemcpyAsync(hst, e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost, e->stream));
+  if (follow) HIP_TRY(hipMemcpyAsync(hmaxk, e->dmaxk.ptr, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::memcpy(st.data(), hst, C * 4);
+  bool all_ok = true;
+  for (size_t c = 0; c < C; ++c) all_ok = all_ok && st[c] == CHAIN_OK;
   {
-    int rc = e->ss_mode ? ss_escalate(e, st) : escalate(e, st);
+    int rc = BA_OK;
+    if (!all_ok) rc = e->ss_mode ? ss_escalate(e, st) : escalate(e, st);
     if (rc) return rc;
     // capacity follows the models: room for growth, no more
-    if (e->cfg.max_model_size_hint <= 0 && e->kcap > 0) {
-      int32_t maxk = 0;
-      HIP_TRY(hipMemcpyAsync(&maxk, e->dmaxk.ptr, 4, hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(hipMemsetAsync(e->dmaxk.ptr, 0, 4, e->stream));
-      HIP_TRY(hipStreamSynchronize(e->stream));
+    if (follow) {
+      int32_t maxk = *hmaxk;
+      if (all_ok) {
+        HIP_TRY(hipMemsetAsync(e->dmaxk.ptr, 0, 4, e->stream));   // (in order before the next launch)
+      } else {   // (a catch-up has run since the copy above)
+        HIP_TRY(hipMemcpyAsync(&maxk, e->dmaxk.ptr, 4, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemsetAsync(e->dmaxk.ptr, 0, 4, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+      }
       const int want = std::min(cap_limit(*e), std::max(16, ((maxk + 8 + 15) / 16) * 16));
       if (maxk > 0 && want < e->kcap) {
         e->kcap = want;
@@ -1297,25 +1332,44 @@ int la_rewind(ba_engine *e) {
   return rc;
 }
 
+struct ApiScope {
+  ba_engine *e;
+  explicit ApiScope(ba_engine *en) : e(en) { e->api_seq++; e->api_depth++; }
+  ~ApiScope() { e->api_depth--; }
+  ApiScope(const ApiScope &) = delete;
+};
+
 #define MUTATE(e)                        \
   do {                                   \
+    (e)->api_seq++;                      \
     int rc_m__ = la_rewind(e);           \
     if (rc_m__) return rc_m__;           \
     (e)->table_ok = false;               \
     (e)->model_ok = false;               \
   } while (0)
 
-#define ENGINE_PROLOGUE_NOJOIN(e)                              \
+// (accessors that enqueue nothing and change nothing: they do not count as a call
+// between two ba_sync()s)
+#define ENGINE_ACCESSOR_NOJOIN(e)                              \
   if (!(e)) return fail(BA_E_INVALID, "null engine");          \
   g_kt = (e)->kt_enabled ? &(e)->kt : nullptr;                 \
   {                                                            \
     int rc__ = set_device(e);                                  \
     if (rc__) return rc__;                                     \
   }
+#define ENGINE_PROLOGUE_NOJOIN(e)                              \
+  ENGINE_ACCESSOR_NOJOIN(e)                                    \
+  ApiScope api_scope__(e);
 // (everything but ba_sweep itself first lets the main stream catch up with a pipeline
 // of sweep launches)
 #define ENGINE_PROLOGUE(e)                                     \
   ENGINE_PROLOGUE_NOJOIN(e)                                    \
+  {                                                            \
+    int rc__ = pipe_join(e);                                   \
+    if (rc__) return rc__;                                     \
+  }
+#define ENGINE_ACCESSOR(e)                                     \
+  ENGINE_ACCESSOR_NOJOIN(e)                                    \
   {                                                            \
     int rc__ = pipe_join(e);                                   \
     if (rc__) return rc__;                                     \
@@ -1388,6 +1442,7 @@ void ba_engine_destroy(ba_engine *e) {
     (void)hipEventDestroy(e->pipe_join_ev);
   }
   if (e->ev_state) (void)hipEventDestroy(e->ev_state);
+  if (e->pinned) (void)hipHostFree(e->pinned);
   for (int i = 0; i < 2; ++i)
     if (e->ev_prep[i]) (void)hipEventDestroy(e->ev_prep[i]);
   if (e->stream) {
@@ -1804,7 +1859,7 @@ int ba_set_state(ba_engine *e, int64_t chain, const uint8_t *gamma,
 
 int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
                  double *sigsq) {
-  ENGINE_PROLOGUE_NOJOIN(e);
+  ENGINE_ACCESSOR_NOJOIN(e);
   if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   if (e->la_served > 0 && e->la_served <= e->la_avail)  // the draw ba_draw_next is serving
@@ -1815,10 +1870,18 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
   }
   int rc = ba_sync(e);
   if (rc) return rc;
+  // (one batch through the pinned staging buffer: beta | sigsq | gamma)
   const size_t p = (size_t)e->p;
-  if (gamma) HIP_TRY(hipMemcpy(gamma, e->dgamma.ptr + (size_t)chain * p, p, hipMemcpyDeviceToHost));
-  if (beta) HIP_TRY(hipMemcpy(beta, e->dbeta.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost));
-  if (sigsq) HIP_TRY(hipMemcpy(sigsq, e->dsigsq.ptr + chain, 8, hipMemcpyDeviceToHost));
+  HIP_TRY(pinned_reserve(e, p * 9 + 16));
+  double *hb = (double *)e->pinned, *hs = hb + p;
+  uint8_t *hg = (uint8_t *)(hs + 1);
+  if (gamma) HIP_TRY(hipMemcpyAsync(hg, e->dgamma.ptr + (size_t)chain * p, p, hipMemcpyDeviceToHost, e->stream));
+  if (beta) HIP_TRY(hipMemcpyAsync(hb, e->dbeta.ptr + (size_t)chain * p, p * 8, hipMemcpyDeviceToHost, e->stream));
+  if (sigsq) HIP_TRY(hipMemcpyAsync(hs, e->dsigsq.ptr + chain, 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (gamma) std::memcpy(gamma, hg, p);
+  if (beta) std::memcpy(beta, hb, p * 8);
+  if (sigsq) *sigsq = *hs;
   return BA_OK;
 }
 
@@ -1827,7 +1890,7 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
 // sigma^2 Omega_g).  Host arithmetic on the chain's state and the host copies of
 // the priors (a k x k Cholesky): it is interface, not hot path.
 int ba_logpri(ba_engine *e, int64_t chain, double *out) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_ACCESSOR(e);
   if (!out) return fail(BA_E_INVALID, "null argument");
   if (!e->have_slab || e->pi.empty()) return fail(BA_E_STATE, "priors are not set");
   const size_t p = (size_t)e->p;
@@ -2165,11 +2228,16 @@ int ba_draw_next(ba_engine *e) {
 }
 
 int ba_sync(ba_engine *e) {
-  ENGINE_PROLOGUE(e);
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  ENGINE_ACCESSOR(e);
+  HIP_TRY(hipStreamSynchronize(e->stream));   // (also the caller's own work on ba_stream())
+  if (e->clean_seq == e->api_seq) return BA_OK;   // (no call since the last clean check: the status words are as they were)
   int rc = pipe_check(e);
   if (rc) return rc;
-  return check_chain_status(e);
+  const uint64_t seq = e->api_seq;   // (a catch-up inside the check is the check's own business)
+  rc = check_chain_status(e);
+  // (only at top level or from an accessor: a call in progress may enqueue more after this)
+  if (rc == BA_OK && e->api_depth == 0) e->clean_seq = seq;
+  return rc;
 }
 
 int ba_log_model_prob(ba_engine *e, int32_t ngamma, const uint8_t *gammas,
@@ -3236,7 +3304,7 @@ int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess
 
 int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq, double *suf_xtx,
                  double *suf_xty, double *suf_yty, double *suf_n) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_ACCESSOR(e);
   if (!e->ss_mode || !e->ssm_set || e->ssm.ar_lags == 0 || e->dar_phi.count == 0)
     return fail(BA_E_STATE, "no structural run with an autoregression block yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
@@ -3260,7 +3328,7 @@ int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq, double
 
 int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state, double *variances,
                          double *suf_n, double *suf_ss) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_ACCESSOR(e);
   if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
     return fail(BA_E_STATE, "no structural state-space run yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
@@ -3386,26 +3454,33 @@ int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *ou
 
 int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
                     double *level_sigsq, double *level_n, double *level_sumsq) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_ACCESSOR(e);
   if (!e->ss_mode || e->dss_scratch.count == 0) return fail(BA_E_STATE, "no state-space run yet");
   if (e->ssm_set) return fail(BA_E_STATE, "a structural state is set: use ba_ss_get_structural");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   int rc = ba_sync(e);
   if (rc) return rc;
+  // (one batch through the pinned staging buffer: state | level variance | n | sum of squares)
   const size_t T = (size_t)e->T, TP = ss_pitch(*e);
+  HIP_TRY(pinned_reserve(e, (TP + 3) * 8));
+  double *hstate = (double *)e->pinned, *hl = hstate + TP;
+  if (state)
+    HIP_TRY(hipMemcpyAsync(hstate, e->dss_scratch.ptr + ((size_t)chain * SS_SCRATCH_ARRAYS + SS_STATE_ARRAY) * TP,
+                           (ss_lane_major(*e) ? TP : T) * 8, hipMemcpyDeviceToHost, e->stream));
+  if (level_sigsq) HIP_TRY(hipMemcpyAsync(hl, e->dlev_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost, e->stream));
+  if (level_n) HIP_TRY(hipMemcpyAsync(hl + 1, e->dlev_n.ptr + chain, 8, hipMemcpyDeviceToHost, e->stream));
+  if (level_sumsq) HIP_TRY(hipMemcpyAsync(hl + 2, e->dlev_sumsq.ptr + chain, 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   if (state) {
-    const double *src = e->dss_scratch.ptr + ((size_t)chain * SS_SCRATCH_ARRAYS + SS_STATE_ARRAY) * TP;
     if (ss_lane_major(*e)) {
-      std::vector<double> lm(TP);
-      HIP_TRY(hipMemcpy(lm.data(), src, TP * 8, hipMemcpyDeviceToHost));
-      for (size_t t = 0; t < T; ++t) state[t] = lm[(size_t)lm_at((int)t)];
+      for (size_t t = 0; t < T; ++t) state[t] = hstate[(size_t)lm_at((int)t)];
     } else {
-      HIP_TRY(hipMemcpy(state, src, T * 8, hipMemcpyDeviceToHost));
+      std::memcpy(state, hstate, T * 8);
     }
   }
-  if (level_sigsq) HIP_TRY(hipMemcpy(level_sigsq, e->dlev_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost));
-  if (level_n) HIP_TRY(hipMemcpy(level_n, e->dlev_n.ptr + chain, 8, hipMemcpyDeviceToHost));
-  if (level_sumsq) HIP_TRY(hipMemcpy(level_sumsq, e->dlev_sumsq.ptr + chain, 8, hipMemcpyDeviceToHost));
+  if (level_sigsq) *level_sigsq = hl[0];
+  if (level_n) *level_n = hl[1];
+  if (level_sumsq) *level_sumsq = hl[2];
   return BA_OK;
 }
 
