@@ -176,7 +176,10 @@ int ba_seed(ba_engine *e, uint64_t seed);
  * Asynchronous: returns after the launch.  Errors raised by chains surface at
  * the next ba_sync()/ba_get_*(). */
 int ba_sweep(ba_engine *e, int32_t nsweeps);
-/* wait for outstanding work and report the first chain error, if any */
+/* wait for outstanding work and report the first chain error, if any.  (The chains'
+ * status words come back in one batched copy; a ba_sync() that follows a clean one with
+ * nothing in between but accessors -- ba_get_state, ba_ss_get_state, ba_logpri ... , each
+ * of which begins with one -- is only the wait.) */
 int ba_sync(ba_engine *e);
 /* The reference's calling pattern is ONE draw() per MCMC iteration with the
  * caller reading the parameters in between (spike_slab_wrapper.cc:233-242,
