@@ -301,12 +301,45 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   M.pd = true;
   double lp;
   const double ldv_in = M.ldv, lda_in = M.lda;
+  // Everything this function reads from global memory depends on gamma and the list g
+  // alone, so all of it is asked for before anything is used: the prior's terms, V_g and
+  // A_g (lower triangles, rows padded with zeros to a multiple of 8; element e <-> (m, n),
+  // n <= m), b_g and X'y_g.  As written before -- prior sum, then the gathers, then b, then
+  // X'y -- a rebuild was four round trips in a row, and a chain that accepts a flip in a
+  // one-sweep launch is the chain the whole launch waits for.
+  wave_sync();
+  const int kpad = (k + 7) & ~7;
+  const int nelem = REUSE ? 0 : kpad * (kpad + 1) / 2;
+  const int gm = (lane < k) ? ch.g[lane] : 0;
+  const double bm = (lane < k) ? P.b[gm] : 0.0;
+  const double xg = (lane < k) ? ch.xty[gm] : 0.0;
+  // (the first 64 elements of the triangles -- all of them up to k = 8 -- and the first 128
+  // prior terms go out here; what is left of either takes the loops below)
+  int m0 = 0, n0 = 0;
+  double v0 = 0.0, a0 = 0.0;
+  if (!REUSE && lane < nelem) {
+    int m = (int)((sqrtf(8.0f * (float)lane + 1.0f) - 1.0f) * 0.5f);
+    while ((m + 1) * (m + 2) / 2 <= lane) ++m;
+    while (m * (m + 1) / 2 > lane) --m;
+    m0 = m;
+    n0 = lane - m * (m + 1) / 2;
+    if (m < k) {
+      const size_t o = (size_t)ch.g[m] * p + ch.g[n0];
+      v0 = P.V[o] * ch.sv;
+      a0 = P.A[o] * ch.sa;
+    }
+  }
   if (REUSE) {
     lp = M.lp;
   } else {
     // VariableSelectionPrior::logp (VariableSelectionPrior.cpp:271-285)
+    double t0 = 0.0, t1 = 0.0;
+    if (lane < p) t0 = ch.gam[lane] ? P.l1[lane] : P.l0[lane];
+    if (lane + WAVE < p) t1 = ch.gam[lane + WAVE] ? P.l1[lane + WAVE] : P.l0[lane + WAVE];
     double part = 0.0;
-    for (int j = lane; j < p; j += WAVE) part += ch.gam[j] ? P.l1[j] : P.l0[j];
+    if (lane < p) part += t0;
+    if (lane + WAVE < p) part += t1;
+    for (int j = lane + 2 * WAVE; j < p; j += WAVE) part += ch.gam[j] ? P.l1[j] : P.l0[j];
     lp = wave_sum(part);
     if (P.max_model_size >= 0 && k > P.max_model_size) lp = -BA_INF;
     if (!(lp > -BA_INF)) lp = -BA_INF;  // also catches NaN from inf - inf
@@ -324,12 +357,11 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     M.pd = false;
     return;
   }
-  wave_sync();
-  // gather V_g, A_g (lower triangles, rows padded with zeros to a multiple of
-  // 8) with all loads independent: element e <-> (m, n), n <= m
-  const int kpad = (k + 7) & ~7;
-  const int nelem = REUSE ? 0 : kpad * (kpad + 1) / 2;
-  for (int e = lane; e < nelem; e += WAVE) {
+  if (!REUSE && lane < nelem) {
+    ch.Lv[bidx(m0, n0)] = v0;
+    ch.La[bidx(m0, n0)] = a0;
+  }
+  for (int e = lane + WAVE; e < nelem; e += WAVE) {
     int m = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
     while ((m + 1) * (m + 2) / 2 <= e) ++m;
     while (m * (m + 1) / 2 > e) --m;
@@ -343,8 +375,6 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     ch.Lv[bidx(m, n)] = v;
     ch.La[bidx(m, n)] = a;
   }
-  const int gm = (lane < k) ? ch.g[lane] : 0;
-  const double bm = (lane < k) ? P.b[gm] : 0.0;
   if (!REUSE && lane < kpad) {
     ch.bg[lane] = bm;
     if (lane >= k) {
@@ -363,7 +393,7 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
     const int gn = bcast_u(gm, n);
     if (lane < k) ab += (P.A[(size_t)gm * p + gn] * ch.sa) * bn;
   }
-  const double r = (lane < k) ? ab + ch.xty[gm] * ch.sx : 0.0;
+  const double r = (lane < k) ? ab + xg * ch.sx : 0.0;
   M.c = wave_sum(lane < k ? bm * ab : 0.0);
   wave_sync();
   bool okv = true, oka = true;
