@@ -3311,11 +3311,19 @@ int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq, double
   int rc = ba_sync(e);
   if (rc) return rc;
   const int L = e->ssm.ar_lags;
-  if (phi) HIP_TRY(hipMemcpy(phi, e->dar_phi.ptr + chain * SSM_MAX, (size_t)L * 8, hipMemcpyDeviceToHost));
-  if (sigsq) HIP_TRY(hipMemcpy(sigsq, e->dar_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost));
-  if (suf_xtx || suf_xty || suf_yty || suf_n) {
-    std::vector<double> suf(AR_SUF_STRIDE);
-    HIP_TRY(hipMemcpy(suf.data(), e->dar_suf.ptr + chain * AR_SUF_STRIDE, AR_SUF_STRIDE * 8, hipMemcpyDeviceToHost));
+  const bool want_suf = suf_xtx || suf_xty || suf_yty || suf_n;
+  HIP_TRY(pinned_reserve(e, (SSM_MAX + 1 + AR_SUF_STRIDE) * 8));
+  double *hphi = (double *)e->pinned, *hsig = hphi + SSM_MAX, *hsuf = hsig + 1;
+  if (phi) HIP_TRY(hipMemcpyAsync(hphi, e->dar_phi.ptr + chain * SSM_MAX, (size_t)L * 8, hipMemcpyDeviceToHost, e->stream));
+  if (sigsq) HIP_TRY(hipMemcpyAsync(hsig, e->dar_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost, e->stream));
+  if (want_suf)
+    HIP_TRY(hipMemcpyAsync(hsuf, e->dar_suf.ptr + chain * AR_SUF_STRIDE, AR_SUF_STRIDE * 8, hipMemcpyDeviceToHost,
+                           e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (phi) std::memcpy(phi, hphi, (size_t)L * 8);
+  if (sigsq) *sigsq = *hsig;
+  if (want_suf) {
+    std::vector<double> suf(hsuf, hsuf + AR_SUF_STRIDE);
     if (suf_xtx)
       for (int i = 0; i < L; ++i)
         for (int j = 0; j < L; ++j) suf_xtx[(size_t)j * L + i] = suf[(size_t)i * SSM_MAX + j];
@@ -3334,13 +3342,21 @@ int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state, double *var
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   int rc = ba_sync(e);
   if (rc) return rc;
+  // (one batch through the pinned staging buffer: state | variances | n | sums of squares)
   const size_t T = (size_t)e->T, m = (size_t)e->ssm.m;
+  HIP_TRY(pinned_reserve(e, (m * T + 9) * 8));
+  double *hstate = (double *)e->pinned, *hv = hstate + m * T;
   if (state)
-    HIP_TRY(hipMemcpy(state, e->dssm_work.ptr + (size_t)chain * ssm_work_stride(*e) + m * T, m * T * 8,
-                      hipMemcpyDeviceToHost));
-  if (variances) HIP_TRY(hipMemcpy(variances, e->dssm_sigsq.ptr + chain * 3, 24, hipMemcpyDeviceToHost));
-  if (suf_n) HIP_TRY(hipMemcpy(suf_n, e->dssm_n.ptr + chain * 3, 24, hipMemcpyDeviceToHost));
-  if (suf_ss) HIP_TRY(hipMemcpy(suf_ss, e->dssm_ss.ptr + chain * 3, 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(hstate, e->dssm_work.ptr + (size_t)chain * ssm_work_stride(*e) + m * T, m * T * 8,
+                           hipMemcpyDeviceToHost, e->stream));
+  if (variances) HIP_TRY(hipMemcpyAsync(hv, e->dssm_sigsq.ptr + chain * 3, 24, hipMemcpyDeviceToHost, e->stream));
+  if (suf_n) HIP_TRY(hipMemcpyAsync(hv + 3, e->dssm_n.ptr + chain * 3, 24, hipMemcpyDeviceToHost, e->stream));
+  if (suf_ss) HIP_TRY(hipMemcpyAsync(hv + 6, e->dssm_ss.ptr + chain * 3, 24, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (state) std::memcpy(state, hstate, m * T * 8);
+  if (variances) std::memcpy(variances, hv, 24);
+  if (suf_n) std::memcpy(suf_n, hv + 3, 24);
+  if (suf_ss) std::memcpy(suf_ss, hv + 6, 24);
   return BA_OK;
 }
 
