@@ -926,6 +926,12 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   }
 
   wave_sync();
+#ifndef BA_STAMPS
+  // (the chain's scalar accumulators, lane i <-> slot i: read here, with the summaries'
+  // loads, written at the end -- not a round trip of lane 0's own after everything else)
+  double *acc_row = P.acc + (size_t)chain * ACC_COUNT;
+  const double acc_old = (lane < 8) ? acc_row[lane] : 0.0;
+#endif
   if (sum_g[lane] >= 0 && sum_n[lane]) {
     const size_t o = (size_t)chain * p + sum_g[lane];
     P.inc_count[o] += (unsigned)sum_n[lane];
@@ -971,6 +977,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
     P.model_tag[chain] = (!aborted && status == CHAIN_OK) ? tag : 0;
     if (P.trace_idx) P.trace_idx[chain] = trace_at + done;
     if (P.maxk) atomicMax(P.maxk, kmax);
+#ifdef BA_STAMPS
     double *a = P.acc + (size_t)chain * ACC_COUNT;
     a[ACC_SWEEPS] += done;
     a[ACC_SIGSQ] += ctl[CT_ACC + ACC_SIGSQ];
@@ -978,10 +985,8 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
     a[ACC_K] += ctl[CT_ACC + ACC_K];
     a[ACC_ACCEPTS] += ctl[CT_ACC + ACC_ACCEPTS];
     a[ACC_PROPOSALS] += ctl[CT_ACC + ACC_PROPOSALS];
-#ifndef BA_STAMPS
-    a[ACC_SLOT_HITS] += ctl[CT_ACC + ACC_SLOT_HITS];
-#endif
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], ctl[CT_ACC + ACC_MIN_MARGIN]);
+#endif
 #ifdef BA_PSTAMPS
     PSTAMP(6);
     if (chain == 0 || chain == 517)
@@ -997,6 +1002,12 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
     for (int i = 0; i < 8; ++i) { a[ACC_PHASE0 + i] += st_ph[i]; a[ACC_SLOT_HITS] += st_ph[i]; }
 #endif
   }
+#ifndef BA_STAMPS
+  if (lane < 8) {
+    const double inc = (lane == ACC_SWEEPS) ? (double)done : ctl[CT_ACC + lane];
+    acc_row[lane] = (lane == ACC_MIN_MARGIN) ? fmin(acc_old, inc) : acc_old + inc;
+  }
+#endif
 }
 
 // log_model_prob of arbitrary inclusion vectors: one wavefront per vector.
