@@ -342,12 +342,14 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   // The chain's model block of the last launch is still this model (nothing but
   // sweeps happened since): take the factors from there instead of factoring.
   if (model_kept) {
-    restore_model<NB>(ch);
     {
+      // (the model's scalars are asked for BEFORE the factors: one round trip for both)
       const SsvsScalarLayout S = ssvs_scalar_layout(KCAP);
       const double *sc = ch.sc_store + S.scal;
-      M.logp = sc[0]; M.lp = sc[1]; M.ldv = sc[2]; M.lda = sc[3];
-      M.Q = sc[4]; M.c = sc[5]; M.SS = sc[6]; M.pd = sc[7] != 0.0;
+      const double s0 = sc[0], s1 = sc[1], s2 = sc[2], s3 = sc[3], s4 = sc[4], s5 = sc[5], s6 = sc[6], s7 = sc[7];
+      restore_model<NB>(ch);
+      M.logp = s0; M.lp = s1; M.ldv = s2; M.lda = s3;
+      M.Q = s4; M.c = s5; M.SS = s6; M.pd = s7 != 0.0;
       unsigned long long u = (unsigned long long)ch.sc_store;
       asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(u) : : "memory");
       ch.sc = (c_f64 *)u;
