@@ -246,6 +246,22 @@ def test_capacity_escalation(oracle):
     with pytest.raises(boom_amd.BoomAmdError) as ei:
         eng3.sweep(60)
     assert "working capacity" in str(ei.value)
+    # ... and it stays reported: an accessor after the failed check still begins with a
+    # full check (only a CLEAN ba_sync lets the next one be a bare stream wait)
+    for _ in range(2):
+        with pytest.raises(boom_amd.BoomAmdError) as ei:
+            eng3.get_state(0)
+        assert "working capacity" in str(ei.value)
+    with pytest.raises(boom_amd.BoomAmdError):
+        eng3.sync()
+    # a clean engine: accessors in a row, then work, then accessors again see the new draw
+    g1, b1, s1 = eng.get_state(3)
+    g2, b2, s2 = eng.get_state(3)
+    assert np.array_equal(g1, g2) and np.array_equal(b1, b2) and s1 == s2
+    eng.sweep(1, sync=False)
+    g3, b3, s3 = eng.get_state(3)
+    assert s3 != s1
+    assert np.array_equal(eng.get_states()[1][3], b3)
 
 
 def test_chain_offset_sharding(oracle):
