@@ -143,6 +143,14 @@ def other_configs(boom_amd, torch, device, cpu=True):
         dts.append(time.perf_counter() - t0)
     dt = float(np.median(dts))
     k3 = float(e3.get_states()[0].sum(1).mean())
+    # the callers' loop on this path (bindings/boom/DeviceStateSpacePosteriorSampler::draw):
+    # one round per call, then chain 0's regression draw, level variance and state
+    t0 = time.perf_counter()
+    for _ in range(200):
+        e3.ss_sweep(1)
+        e3.get_state(0)
+        e3.ss_get_state(0)
+    loop3 = (time.perf_counter() - t0) / 200
     e3.set_kernel_timing(True)
     e3.ss_sweep(100)
     kt = _per_launch(e3.kernel_times())
@@ -153,6 +161,7 @@ def other_configs(boom_amd, torch, device, cpu=True):
     dom = max(kt, key=kt.get)
     rec = {"sweeps_per_s": round(C3 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
            "mean_model_size": round(k3, 2), "kernel_us_per_launch": kt,
+           "callers_loop_us_per_draw": round(loop3 * 1e6, 1),
            "roofline": {"bound": "hbm", "kernel": "kalman_lm_kernel (the timing class is named after "
                                                    "kalman_simsmooth_kernel, its T > 2048 sibling)",
                         "algorithmic_bytes_per_round": bytes3,
