@@ -1339,10 +1339,15 @@ struct ApiScope {
   ApiScope(const ApiScope &) = delete;
 };
 
+// (a mutator changes what the next launch reads -- priors, data, options -- through copies
+// on the main stream: a pipelined sweep launch still running on the other stream must be
+// behind the main stream first, or it would see half of the new values)
 #define MUTATE(e)                        \
   do {                                   \
     (e)->api_seq++;                      \
-    int rc_m__ = la_rewind(e);           \
+    int rc_m__ = set_device(e);          \
+    if (!rc_m__) rc_m__ = pipe_join(e);  \
+    if (!rc_m__) rc_m__ = la_rewind(e);  \
     if (rc_m__) return rc_m__;           \
     (e)->table_ok = false;               \
     (e)->model_ok = false;               \

@@ -439,7 +439,8 @@ int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons,
  * (ArModel::check_stationary, ArModel.cpp:142-170) is decided by the quick bound
  * sum |phi| < 1 and then, where the reference finds polynomial roots, by the
  * equivalent step-down recursion.  The tail cases of the coefficient-at-a-time
- * draw (a Tn2Sampler in the reference) are reported as a chain error.  RNG stream
+ * draw run the reference's Tn2Sampler on the device (hull across the wave,
+ * distributions/Tn2Sampler.cpp:25-131).  RNG stream
  * 12: the proposals' normals, then the sigma draw (the reference takes the
  * proposals from GlobalRng::rng and the rest from the sampler's generator). */
 int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess,

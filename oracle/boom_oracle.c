@@ -2120,64 +2120,100 @@ int bo_ss_draw(bo_ss *m) {
 }
 
 /* ====================================================================== *
- * Structural time series: StateSpaceRegressionModel with a trend state model
- * (LocalLevelStateModel, or LocalLinearTrendStateModel with one
- * ZeroMeanMvnIndependenceSampler per variance) and an optional
- * SeasonalStateModel(nseasons, season_duration = 1).  SURVEY 8f row f2.
- * State vector = [trend (1 or 2) | seasonal (nseasons - 1)], dimension m <= 16.
+ * Structural time series: StateSpaceRegressionModel with ANY list of state
+ * models added by add_state, in any order (StateSpaceModelBase.hpp:637-638; the
+ * transition / variance matrices are block diagonal, Filters/SparseMatrix.hpp:2196):
+ *   LocalLevelStateModel                       (1 component, 1 variance)
+ *   LocalLinearTrendStateModel                 (2 components, one
+ *                                               ZeroMeanMvnIndependenceSampler per
+ *                                               variance, as bsts builds it)
+ *   SeasonalStateModel(nseasons, duration)     (nseasons - 1 components, 1 variance;
+ *                                               T / RQR are the seasonal matrices on
+ *                                               steps INTO a new season and identity /
+ *                                               zero inside one,
+ *                                               SeasonalStateModel.cpp:89-104, :248-258)
+ *   ArStateModel(lags)                         (lags components, phi, 1 variance,
+ *                                               ArPosteriorSampler)
+ * SURVEY 8f row f2.  State vector = the blocks one after the other, dimension
+ * m <= 64.
  *   Z      ones at the first element of each block
- *          (LocalLinearTrend.cpp:37, SeasonalStateModel.cpp:148-152)
- *   T      trend: [1] resp. [[1, 1], [0, 1]] (LocalLinearTrendMatrix);
+ *          (LocalLinearTrend.cpp:37, SeasonalStateModel.cpp:148-152, ArStateModel.cpp)
+ *   T      local level [1]; trend [[1, 1], [0, 1]] (LocalLinearTrendMatrix);
  *          seasonal: first row -1, identity below the diagonal
- *          (SeasonalStateSpaceMatrix, Filters/SparseMatrix.cpp:1141-1149)
- *   RQR    diag(level, slope) and the seasonal block's upper-left element
+ *          (SeasonalStateSpaceMatrix, Filters/SparseMatrix.cpp:1141-1149);
+ *          autoregression: first row phi, identity below the diagonal
+ *   RQR    diagonal: level; level, slope; the seasonal / autoregression block's
+ *          first element
  * ====================================================================== */
-#define BO_SSM_MAX 16
+#define BO_SSM_MAX 64
+#define BO_SSM_BLOCKS 8
+#define BO_AR_MAX 16
+typedef struct {
+  int kind;            /* BO_BLK_* */
+  int first, dim;      /* position in the state vector */
+  int nvar;            /* variance parameters: 2 for the local linear trend, else 1 */
+  int nseasons, duration, t0;   /* seasonal: t0 = time_of_first_observation */
+  int lags;                     /* autoregression */
+  double sigsq[2], prior_df[2], prior_ss[2], sigma_max[2];
+  double suf_n[2], suf_ss[2];
+  /* MvnSuf of the trend's state errors (Welford form, MvnBase.cpp:71-86) */
+  double mv_n, mv_ybar[2], mv_sumsq[2];
+  bo_rng rng[2];       /* one per variance sampler (autoregression: the ArPosteriorSampler's) */
+  /* ArStateModel: coefficients and the NeRegSuf of the block's first element on the
+   * block's previous value */
+  double phi[BO_AR_MAX], ar_xtx[BO_AR_MAX * BO_AR_MAX], ar_xty[BO_AR_MAX], ar_yty, ar_n;
+} bo_ssm_block;
+
 struct bo_ssm {
-  int T, p, m, dtrend, nseasons, s0; /* s0: index of the seasonal block (or -1) */
+  int T, p, m, nblocks;
+  bo_ssm_block blk[BO_SSM_BLOCKS];
   double *y, *X;
   uint8_t *observed;
   bo_ssvs *reg;
-  /* variance parameters: 0 level, 1 slope, 2 seasonal */
-  double sigsq[3], prior_df[3], prior_ss[3], sigma_max[3];
-  double suf_n[3], suf_ss[3];
-  /* MvnSuf of the trend's state errors (Welford form, MvnBase.cpp:71-86) */
-  double mv_n, mv_ybar[2], mv_sumsq[2];
   double a0[BO_SSM_MAX], P0[BO_SSM_MAX]; /* initial mean, initial variance (diagonal) */
-  bo_rng var_rng[3], state_rng;
+  bo_rng state_rng;
   int latent_initialized;
   double *state; /* m x T, column t = state at t */
   double *v, *F, *K, *r, *vs, *Fs, *Ks, *rs;
-  /* an ArStateModel(ar_lags) block after the trend / seasonal blocks (ar0: its first
-   * index, -1: none): coefficients phi, error variance, the NeRegSuf of the block's
-   * first element on the block's previous value, the ArPosteriorSampler's prior */
-  int ar_lags, ar0;
-  double phi[BO_SSM_MAX], ar_sigsq, ar_prior_df, ar_prior_ss, ar_sigma_max;
-  double ar_xtx[BO_SSM_MAX * BO_SSM_MAX], ar_xty[BO_SSM_MAX], ar_yty, ar_n;
-  bo_rng ar_rng;
   /* draw_phi's proposals come from rmvn_ivar (no _mt): the reference draws them from
    * GlobalRng::rng, not from the sampler's generator.  MT mode points this at the
-   * restated global generator (after it seeded the samplers); NULL: ar_rng. */
+   * restated global generator (after it seeded the samplers); NULL: the block's rng. */
   bo_rng *ar_global_rng;
 };
 
-bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
-                      const uint8_t *observed, const double *prior_mean,
-                      const double *ominv, double prior_df, double sigma_guess,
-                      const double *pi, int trend, int nseasons,
-                      const double *var_df, const double *var_sigma_guess,
-                      const double *var_sigma_upper_limit,
-                      const double *var_initial_sigma,
-                      const double *initial_state_mean,
-                      const double *initial_state_variance) {
+static void ssm_alloc_series(bo_ssm *m) {
+  const size_t mT = (size_t)(m->m > 0 ? m->m : 1) * m->T;
+  free(m->state); free(m->K); free(m->r); free(m->Ks); free(m->rs);
+  m->state = (double *)xcalloc(mT, sizeof(double));
+  m->K = (double *)xcalloc(mT, sizeof(double));
+  m->r = (double *)xcalloc(mT, sizeof(double));
+  m->Ks = (double *)xcalloc(mT, sizeof(double));
+  m->rs = (double *)xcalloc(mT, sizeof(double));
+}
+
+/* the Philox sampler id of variance parameter v of block b: level 1, slope 6,
+ * seasonal 7, autoregression 12 for the first block of its family (local level and
+ * local linear trend are one family), + 16 for every earlier block of the family */
+int bo_ssm_block_stream_id(const bo_ssm *m, int b, int v) {
+  const int kind = m->blk[b].kind;
+  const int fam = (kind == BO_BLK_LOCAL_LINEAR_TREND) ? BO_BLK_LOCAL_LEVEL : kind;
+  int occ = 0;
+  for (int i = 0; i < b; ++i) {
+    const int k = m->blk[i].kind;
+    if (((k == BO_BLK_LOCAL_LINEAR_TREND) ? BO_BLK_LOCAL_LEVEL : k) == fam) ++occ;
+  }
+  const int base = (kind == BO_BLK_SEASONAL) ? 7 : (kind == BO_BLK_AR) ? 12 : (v == 0 ? 1 : 6);
+  return base + 16 * occ;
+}
+
+/* StateSpaceRegressionModel(y, X, observed) + BregVsSampler, no state yet */
+bo_ssm *bo_ssm_create_empty(int T, int p, const double *y, const double *X,
+                            const uint8_t *observed, const double *prior_mean,
+                            const double *ominv, double prior_df, double sigma_guess,
+                            const double *pi) {
   bo_ssm *m = (bo_ssm *)xcalloc(1, sizeof(bo_ssm));
   m->T = T;
   m->p = p;
-  m->dtrend = trend;
-  m->nseasons = nseasons;
-  m->s0 = nseasons > 0 ? trend : -1;
-  m->ar0 = -1;
-  m->m = trend + (nseasons > 0 ? nseasons - 1 : 0);
   m->y = (double *)xcalloc(T, sizeof(double));
   m->X = (double *)xcalloc((size_t)T * p, sizeof(double));
   m->observed = (uint8_t *)xcalloc(T, 1);
@@ -2204,31 +2240,100 @@ bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
   m->reg = bo_ssvs_create(p, xtx, xty, yty, nobs0, sumy, xsum, prior_mean,
                           ominv, prior_df, sigma_guess, pi);
   free(xtx); free(xty); free(xsum);
-  for (int i = 0; i < 3; ++i) {
-    m->sigsq[i] = var_initial_sigma[i] * var_initial_sigma[i];
-    m->prior_df[i] = 2 * (var_df[i] / 2.0);
-    m->prior_ss[i] = 2 * (var_df[i] * var_sigma_guess[i] * var_sigma_guess[i] / 2.0);
-    m->sigma_max[i] = var_sigma_upper_limit[i];
-  }
-  for (int i = 0; i < m->m; ++i) {
-    m->a0[i] = initial_state_mean[i];
-    m->P0[i] = initial_state_variance[i];
-  }
-  size_t mT = (size_t)m->m * T;
-  m->state = (double *)xcalloc(mT, sizeof(double));
   m->v = (double *)xcalloc(T, sizeof(double));
   m->F = (double *)xcalloc(T, sizeof(double));
-  m->K = (double *)xcalloc(mT, sizeof(double));
-  m->r = (double *)xcalloc(mT, sizeof(double));
   m->vs = (double *)xcalloc(T, sizeof(double));
   m->Fs = (double *)xcalloc(T, sizeof(double));
-  m->Ks = (double *)xcalloc(mT, sizeof(double));
-  m->rs = (double *)xcalloc(mT, sizeof(double));
-  bo_rng_seed_philox(&m->var_rng[0], 0, 0, 1, 0);
-  bo_rng_seed_philox(&m->var_rng[1], 0, 0, 6, 0);
-  bo_rng_seed_philox(&m->var_rng[2], 0, 0, 7, 0);
+  ssm_alloc_series(m);
   bo_rng_seed_philox(&m->state_rng, 0, 0, 2, 0);
-  bo_rng_seed_philox(&m->ar_rng, 0, 0, 12, 0);
+  return m;
+}
+
+/* model->add_state(...): kind BO_BLK_*; iparams = {nseasons, season_duration,
+ * time_of_first_observation} (seasonal) or {lags} (autoregression), ignored otherwise;
+ * the variance arrays have one entry per variance parameter (two for the local linear
+ * trend: level, slope): ChisqModel(df, sigma_guess) prior, sigma upper limit (inf:
+ * none), initial sigma; initial_phi: lags entries (NULL: zeros); the block's initial
+ * state is N(mean, diag(variance)), dim entries each.  Before the first draw. */
+int bo_ssm_add_block(bo_ssm *m, int kind, const int *iparams, const double *var_df,
+                     const double *var_sigma_guess, const double *var_sigma_upper_limit,
+                     const double *var_initial_sigma, const double *initial_phi,
+                     const double *initial_state_mean, const double *initial_state_variance) {
+  if (m->nblocks >= BO_SSM_BLOCKS) return BO_ERR_INVALID;
+  bo_ssm_block *b = &m->blk[m->nblocks];
+  memset(b, 0, sizeof(*b));
+  b->kind = kind;
+  b->nvar = 1;
+  b->duration = 1;
+  switch (kind) {
+    case BO_BLK_LOCAL_LEVEL: b->dim = 1; break;
+    case BO_BLK_LOCAL_LINEAR_TREND: b->dim = 2; b->nvar = 2; break;
+    case BO_BLK_SEASONAL:
+      if (!iparams || iparams[0] < 2 || iparams[1] < 1) return BO_ERR_INVALID;
+      b->nseasons = iparams[0];
+      b->duration = iparams[1];
+      b->t0 = iparams[2];
+      b->dim = b->nseasons - 1;
+      break;
+    case BO_BLK_AR:
+      if (!iparams || iparams[0] < 1 || iparams[0] > BO_AR_MAX) return BO_ERR_INVALID;
+      b->lags = iparams[0];
+      b->dim = b->lags;
+      break;
+    default: return BO_ERR_INVALID;
+  }
+  if (m->m + b->dim > BO_SSM_MAX) return BO_ERR_INVALID;
+  b->first = m->m;
+  for (int v = 0; v < b->nvar; ++v) {
+    b->sigsq[v] = var_initial_sigma[v] * var_initial_sigma[v];
+    b->prior_df[v] = 2 * (var_df[v] / 2.0);
+    b->prior_ss[v] = 2 * (var_df[v] * var_sigma_guess[v] * var_sigma_guess[v] / 2.0);
+    b->sigma_max[v] = var_sigma_upper_limit[v];
+  }
+  for (int i = 0; i < b->dim; ++i) {
+    m->a0[b->first + i] = initial_state_mean[i];
+    m->P0[b->first + i] = initial_state_variance[i];
+  }
+  if (kind == BO_BLK_AR)
+    for (int i = 0; i < b->lags; ++i) b->phi[i] = initial_phi ? initial_phi[i] : 0.0;
+  m->m += b->dim;
+  m->nblocks += 1;
+  for (int v = 0; v < b->nvar; ++v)
+    bo_rng_seed_philox(&b->rng[v], 0, 0, (uint32_t)bo_ssm_block_stream_id(m, m->nblocks - 1, v), 0);
+  ssm_alloc_series(m);
+  return 0;
+}
+
+/* the first block of a kind (-1: none) */
+static int ssm_find(const bo_ssm *m, int kind) {
+  for (int b = 0; b < m->nblocks; ++b)
+    if (m->blk[b].kind == kind) return b;
+  return -1;
+}
+
+/* the template of rounds 2-3: a trend block (trend = 1: local level, 2: local linear
+ * trend) + an optional SeasonalStateModel(nseasons, 1); three-element arrays indexed
+ * level, slope, seasonal */
+bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
+                      const uint8_t *observed, const double *prior_mean,
+                      const double *ominv, double prior_df, double sigma_guess,
+                      const double *pi, int trend, int nseasons,
+                      const double *var_df, const double *var_sigma_guess,
+                      const double *var_sigma_upper_limit,
+                      const double *var_initial_sigma,
+                      const double *initial_state_mean,
+                      const double *initial_state_variance) {
+  bo_ssm *m = bo_ssm_create_empty(T, p, y, X, observed, prior_mean, ominv, prior_df,
+                                  sigma_guess, pi);
+  bo_ssm_add_block(m, trend == 2 ? BO_BLK_LOCAL_LINEAR_TREND : BO_BLK_LOCAL_LEVEL, NULL, var_df,
+                   var_sigma_guess, var_sigma_upper_limit, var_initial_sigma, NULL,
+                   initial_state_mean, initial_state_variance);
+  if (nseasons > 0) {
+    const int ip[3] = {nseasons, 1, 0};
+    bo_ssm_add_block(m, BO_BLK_SEASONAL, ip, var_df + 2, var_sigma_guess + 2,
+                     var_sigma_upper_limit + 2, var_initial_sigma + 2, NULL,
+                     initial_state_mean + trend, initial_state_variance + trend);
+  }
   return m;
 }
 
@@ -2238,40 +2343,44 @@ bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
 int bo_ssm_add_ar(bo_ssm *m, int lags, double prior_df, double sigma_guess,
                   double sigma_upper_limit, double initial_sigma, const double *initial_phi,
                   const double *initial_state_mean, const double *initial_state_variance) {
-  if (lags < 1 || m->ar0 >= 0 || m->m + lags > BO_SSM_MAX) return BO_ERR_INVALID;
-  m->ar0 = m->m;
-  m->ar_lags = lags;
-  m->m += lags;
-  for (int i = 0; i < lags; ++i) {
-    m->phi[i] = initial_phi ? initial_phi[i] : 0.0;
-    m->a0[m->ar0 + i] = initial_state_mean[i];
-    m->P0[m->ar0 + i] = initial_state_variance[i];
-  }
-  m->ar_sigsq = initial_sigma * initial_sigma;
-  m->ar_prior_df = 2 * (prior_df / 2.0);
-  m->ar_prior_ss = 2 * (prior_df * sigma_guess * sigma_guess / 2.0);
-  m->ar_sigma_max = sigma_upper_limit;
-  const size_t mT = (size_t)m->m * m->T;
-  free(m->state); free(m->K); free(m->r); free(m->Ks); free(m->rs);
-  m->state = (double *)xcalloc(mT, sizeof(double));
-  m->K = (double *)xcalloc(mT, sizeof(double));
-  m->r = (double *)xcalloc(mT, sizeof(double));
-  m->Ks = (double *)xcalloc(mT, sizeof(double));
-  m->rs = (double *)xcalloc(mT, sizeof(double));
-  return 0;
+  if (ssm_find(m, BO_BLK_AR) >= 0) return BO_ERR_INVALID;
+  const int ip[3] = {lags, 0, 0};
+  return bo_ssm_add_block(m, BO_BLK_AR, ip, &prior_df, &sigma_guess, &sigma_upper_limit,
+                          &initial_sigma, initial_phi, initial_state_mean, initial_state_variance);
 }
-bo_rng *bo_ssm_ar_rng(bo_ssm *m) { return &m->ar_rng; }
+int bo_ssm_nblocks(const bo_ssm *m) { return m->nblocks; }
+bo_rng *bo_ssm_block_rng(bo_ssm *m, int b, int v) { return &m->blk[b].rng[v]; }
+/* block b: variances (nvar), sufficient statistics (n, sum of squares per variance),
+ * autoregression coefficients (lags); any pointer may be NULL */
+void bo_ssm_block_get(const bo_ssm *m, int b, double *sigsq, double *suf_n, double *suf_ss,
+                      double *phi) {
+  const bo_ssm_block *B = &m->blk[b];
+  for (int v = 0; v < B->nvar; ++v) {
+    if (sigsq) sigsq[v] = B->sigsq[v];
+    if (suf_n) suf_n[v] = B->suf_n[v];
+    if (suf_ss) suf_ss[v] = B->suf_ss[v];
+  }
+  if (phi) for (int i = 0; i < B->lags; ++i) phi[i] = B->phi[i];
+}
+void bo_ssm_block_set_sigsq(bo_ssm *m, int b, const double *sigsq) {
+  for (int v = 0; v < m->blk[b].nvar; ++v) m->blk[b].sigsq[v] = sigsq[v];
+}
+void bo_ssm_block_get_ar_suf(const bo_ssm *m, int b, double *xtx, double *xty, double *yty,
+                             double *n) {
+  const bo_ssm_block *B = &m->blk[b];
+  const int L = B->lags;
+  for (int i = 0; i < L * L; ++i) xtx[i] = B->ar_xtx[i];
+  for (int i = 0; i < L; ++i) xty[i] = B->ar_xty[i];
+  *yty = B->ar_yty;
+  *n = B->ar_n;
+}
+bo_rng *bo_ssm_ar_rng(bo_ssm *m) { return &m->blk[ssm_find(m, BO_BLK_AR)].rng[0]; }
 void bo_ssm_set_global_rng(bo_ssm *m, bo_rng *global) { m->ar_global_rng = global; }
 void bo_ssm_get_ar(const bo_ssm *m, double *phi, double *sigsq) {
-  for (int i = 0; i < m->ar_lags; ++i) phi[i] = m->phi[i];
-  *sigsq = m->ar_sigsq;
+  bo_ssm_block_get(m, ssm_find(m, BO_BLK_AR), sigsq, NULL, NULL, phi);
 }
 void bo_ssm_get_ar_suf(const bo_ssm *m, double *xtx, double *xty, double *yty, double *n) {
-  const int L = m->ar_lags;
-  for (int i = 0; i < L * L; ++i) xtx[i] = m->ar_xtx[i];
-  for (int i = 0; i < L; ++i) xty[i] = m->ar_xty[i];
-  *yty = m->ar_yty;
-  *n = m->ar_n;
+  bo_ssm_block_get_ar_suf(m, ssm_find(m, BO_BLK_AR), xtx, xty, yty, n);
 }
 
 void bo_ssm_destroy(bo_ssm *m) {
@@ -2283,87 +2392,129 @@ void bo_ssm_destroy(bo_ssm *m) {
   free(m);
 }
 bo_ssvs *bo_ssm_regression(bo_ssm *m) { return m->reg; }
-bo_rng *bo_ssm_variance_rng(bo_ssm *m, int which) { return &m->var_rng[which]; }
+/* the template's variance parameters: 0 level, 1 slope (block 0), 2 the first seasonal block */
+static bo_ssm_block *ssm_template_var(const bo_ssm *m, int which, int *v) {
+  *v = which == 1 ? 1 : 0;
+  if (which < 2) return (bo_ssm_block *)&m->blk[0];
+  const int b = ssm_find(m, BO_BLK_SEASONAL);
+  return b < 0 ? NULL : (bo_ssm_block *)&m->blk[b];
+}
+static bo_rng g_unused_rng;
+bo_rng *bo_ssm_variance_rng(bo_ssm *m, int which) {
+  int v;
+  bo_ssm_block *B = ssm_template_var(m, which, &v);
+  return (B && v < B->nvar) ? &B->rng[v] : &g_unused_rng;
+}
 bo_rng *bo_ssm_state_rng(bo_ssm *m) { return &m->state_rng; }
 int bo_ssm_state_dimension(const bo_ssm *m) { return m->m; }
 const double *bo_ssm_state(const bo_ssm *m) { return m->state; }
 void bo_ssm_get_variances(const bo_ssm *m, double *sigsq) {
-  for (int i = 0; i < 3; ++i) sigsq[i] = m->sigsq[i];
+  for (int i = 0; i < 3; ++i) {
+    int v;
+    const bo_ssm_block *B = ssm_template_var(m, i, &v);
+    sigsq[i] = (B && v < B->nvar) ? B->sigsq[v] : 0.0;
+  }
 }
 void bo_ssm_set_variances(bo_ssm *m, const double *sigsq) {
-  for (int i = 0; i < 3; ++i) m->sigsq[i] = sigsq[i];
+  for (int i = 0; i < 3; ++i) {
+    int v;
+    bo_ssm_block *B = ssm_template_var(m, i, &v);
+    if (B && v < B->nvar) B->sigsq[v] = sigsq[i];
+  }
 }
 
-/* x <- T x (multiply_inplace of the block-diagonal transition matrix) */
-static void ssm_T(const bo_ssm *m, double *x) {
-  if (m->dtrend == 2) x[0] = x[0] + x[1];
-  if (m->s0 >= 0) {
-    const int n = m->nseasons - 1;
-    double *s = x + m->s0, tmp[BO_SSM_MAX], first = 0;
-    for (int i = 0; i < n; ++i) {
-      first -= s[i];
-      if (i > 0) tmp[i] = s[i - 1];
-    }
-    tmp[0] = first;
-    for (int i = 0; i < n; ++i) s[i] = tmp[i];
-  }
-  if (m->ar0 >= 0) {
-    /* AutoRegressionTransitionMatrix::multiply_inplace, Filters/SparseMatrix.cpp:1297-1310 */
-    double *s = x + m->ar0, first_entry = 0;
-    for (int i = m->ar_lags - 1; i >= 0; --i) {
-      first_entry += m->phi[i] * s[i];
-      if (i > 0) s[i] = s[i - 1]; else s[i] = first_entry;
+/* SeasonalStateModel::new_season, SeasonalStateModel.cpp:248-258 */
+static int blk_new_season(const bo_ssm_block *b, int t) {
+  t -= b->t0;
+  if (t < 0) t -= b->duration * t;
+  return (t % b->duration) == 0;
+}
+/* does block b's transition matrix of time t (the step from t to t + 1) move anything?
+ * (state_transition_matrix(t), SeasonalStateModel.cpp:89-92: identity inside a season) */
+static int blk_moves(const bo_ssm_block *b, int t) {
+  return b->kind != BO_BLK_SEASONAL || blk_new_season(b, t + 1);
+}
+
+/* x <- T_t x (multiply_inplace of the block-diagonal transition matrix) */
+static void ssm_T(const bo_ssm *m, double *x, int t) {
+  for (int bi = 0; bi < m->nblocks; ++bi) {
+    const bo_ssm_block *b = &m->blk[bi];
+    double *s = x + b->first;
+    if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) {
+      s[0] = s[0] + s[1];
+    } else if (b->kind == BO_BLK_SEASONAL) {
+      if (!blk_moves(b, t)) continue;
+      const int n = b->dim;
+      double tmp[BO_SSM_MAX], first = 0;
+      for (int i = 0; i < n; ++i) {
+        first -= s[i];
+        if (i > 0) tmp[i] = s[i - 1];
+      }
+      tmp[0] = first;
+      for (int i = 0; i < n; ++i) s[i] = tmp[i];
+    } else if (b->kind == BO_BLK_AR) {
+      /* AutoRegressionTransitionMatrix::multiply_inplace, Filters/SparseMatrix.cpp:1297-1310 */
+      double first_entry = 0;
+      for (int i = b->lags - 1; i >= 0; --i) {
+        first_entry += b->phi[i] * s[i];
+        if (i > 0) s[i] = s[i - 1]; else s[i] = first_entry;
+      }
     }
   }
 }
-/* x <- T' x (Tmult) */
-static void ssm_Tt(const bo_ssm *m, double *x) {
-  if (m->dtrend == 2) x[1] = x[0] + x[1];
-  if (m->s0 >= 0) {
-    const int n = m->nseasons - 1;
-    double *s = x + m->s0, tmp[BO_SSM_MAX];
-    for (int i = 0; i < n; ++i) tmp[i] = -s[0] + (i + 1 < n ? s[i + 1] : 0.0);
-    for (int i = 0; i < n; ++i) s[i] = tmp[i];
-  }
-  if (m->ar0 >= 0) {
-    /* AutoRegressionTransitionMatrix::Tmult, Filters/SparseMatrix.cpp:1286-1295 */
-    const int n = m->ar_lags;
-    double *s = x + m->ar0, tmp[BO_SSM_MAX];
-    for (int i = 0; i < n; ++i) tmp[i] = m->phi[i] * s[0] + (i + 1 < n ? s[i + 1] : 0);
-    for (int i = 0; i < n; ++i) s[i] = tmp[i];
+/* x <- T_t' x (Tmult) */
+static void ssm_Tt(const bo_ssm *m, double *x, int t) {
+  for (int bi = 0; bi < m->nblocks; ++bi) {
+    const bo_ssm_block *b = &m->blk[bi];
+    double *s = x + b->first;
+    if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) {
+      s[1] = s[0] + s[1];
+    } else if (b->kind == BO_BLK_SEASONAL) {
+      if (!blk_moves(b, t)) continue;
+      const int n = b->dim;
+      double tmp[BO_SSM_MAX];
+      for (int i = 0; i < n; ++i) tmp[i] = -s[0] + (i + 1 < n ? s[i + 1] : 0.0);
+      for (int i = 0; i < n; ++i) s[i] = tmp[i];
+    } else if (b->kind == BO_BLK_AR) {
+      /* AutoRegressionTransitionMatrix::Tmult, Filters/SparseMatrix.cpp:1286-1295 */
+      const int n = b->lags;
+      double tmp[BO_AR_MAX];
+      for (int i = 0; i < n; ++i) tmp[i] = b->phi[i] * s[0] + (i + 1 < n ? s[i + 1] : 0);
+      for (int i = 0; i < n; ++i) s[i] = tmp[i];
+    }
   }
 }
 static double ssm_Zdot(const bo_ssm *m, const double *x) {
-  double ans = x[0];
-  if (m->s0 >= 0) ans += x[m->s0];
-  if (m->ar0 >= 0) ans += x[m->ar0];   /* ArStateModel.cpp: observation_matrix_[0] = 1 */
+  double ans = x[m->blk[0].first];
+  for (int b = 1; b < m->nblocks; ++b) ans += x[m->blk[b].first];
   return ans;
 }
-/* the diagonal of RQR */
-static void ssm_rqr(const bo_ssm *m, double *d) {
+/* the diagonal of RQR_t */
+static void ssm_rqr(const bo_ssm *m, double *d, int t) {
   for (int i = 0; i < m->m; ++i) d[i] = 0;
-  d[0] = m->sigsq[0];
-  if (m->dtrend == 2) d[1] = m->sigsq[1];
-  if (m->s0 >= 0) d[m->s0] = m->sigsq[2];
-  if (m->ar0 >= 0) d[m->ar0] = m->ar_sigsq;
+  for (int bi = 0; bi < m->nblocks; ++bi) {
+    const bo_ssm_block *b = &m->blk[bi];
+    if (b->kind == BO_BLK_SEASONAL && !blk_moves(b, t)) continue;   /* RQR1_ = ZeroMatrix */
+    d[b->first] = b->sigsq[0];
+    if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) d[b->first + 1] = b->sigsq[1];
+  }
 }
 
 /* ScalarMarginalDistribution::update, ScalarKalmanFilter.cpp:41-83; P is m x m
- * column-major, (a, P) enter as the one-step-ahead moments and leave as the
- * next ones */
-static int ssm_update(const bo_ssm *M, double y, int missing, double H,
+ * column-major, (a, P) enter as the one-step-ahead moments of time t and leave as
+ * those of t + 1 */
+static int ssm_update(const bo_ssm *M, int t, double y, int missing, double H,
                       double *a, double *P, double *v, double *F, double *K) {
   const int m = M->m;
   double PZ[BO_SSM_MAX], TPZ[BO_SSM_MAX], rqr[BO_SSM_MAX];
   for (int i = 0; i < m; ++i) {
-    PZ[i] = P[IDX(i, 0, m)];
-    if (M->s0 >= 0) PZ[i] += P[IDX(i, M->s0, m)];
-    if (M->ar0 >= 0) PZ[i] += P[IDX(i, M->ar0, m)];
+    PZ[i] = P[IDX(i, M->blk[0].first, m)];
+    for (int b = 1; b < M->nblocks; ++b) PZ[i] += P[IDX(i, M->blk[b].first, m)];
   }
   *F = ssm_Zdot(M, PZ) + H;
   if (*F <= 0) return BO_ERR_FORECAST_VARIANCE;
   for (int i = 0; i < m; ++i) TPZ[i] = PZ[i];
-  ssm_T(M, TPZ);
+  ssm_T(M, TPZ, t);
   if (!missing) {
     for (int i = 0; i < m; ++i) K[i] = TPZ[i] / *F;
     *v = y - ssm_Zdot(M, a);
@@ -2371,7 +2522,7 @@ static int ssm_update(const bo_ssm *M, double y, int missing, double H,
     for (int i = 0; i < m; ++i) K[i] = 0.0;
     *v = 0;
   }
-  ssm_T(M, a);
+  ssm_T(M, a, t);
   if (!missing)
     for (int i = 0; i < m; ++i) a[i] += K[i] * *v;
   /* sandwich_inplace (Filters/SparseMatrix.cpp:1748-1763): T times every
@@ -2379,18 +2530,18 @@ static int ssm_update(const bo_ssm *M, double y, int missing, double H,
   double col[BO_SSM_MAX];
   for (int j = 0; j < m; ++j) {
     for (int i = 0; i < m; ++i) col[i] = P[IDX(i, j, m)];
-    ssm_T(M, col);
+    ssm_T(M, col, t);
     for (int i = 0; i < m; ++i) P[IDX(i, j, m)] = col[i];
   }
   for (int i = 0; i < m; ++i) {
     for (int j = 0; j < m; ++j) col[j] = P[IDX(i, j, m)];
-    ssm_T(M, col);
+    ssm_T(M, col, t);
     for (int j = 0; j < m; ++j) P[IDX(i, j, m)] = col[j];
   }
   if (!missing)
     for (int j = 0; j < m; ++j)
       for (int i = 0; i < m; ++i) P[IDX(i, j, m)] += -1.0 * TPZ[i] * K[j];
-  ssm_rqr(M, rqr);
+  ssm_rqr(M, rqr, t);
   for (int i = 0; i < m; ++i) P[IDX(i, i, m)] += rqr[i];
   /* fix_near_symmetry, SpdMatrix.cpp:350-357 */
   for (int i = 0; i < m; ++i)
@@ -2415,10 +2566,8 @@ static void ssm_disturbance_smooth(const bo_ssm *M, const double *v,
     double coefficient = (v[t] / F[t]) - kr;
     double rt_1[BO_SSM_MAX];
     for (int i = 0; i < m; ++i) rt_1[i] = r[i];
-    ssm_Tt(M, rt_1);
-    rt_1[0] += coefficient;
-    if (M->s0 >= 0) rt_1[M->s0] += coefficient;
-    if (M->ar0 >= 0) rt_1[M->ar0] += coefficient;
+    ssm_Tt(M, rt_1, t);
+    for (int b = 0; b < M->nblocks; ++b) rt_1[M->blk[b].first] += coefficient;
     for (int i = 0; i < m; ++i) rout[IDX(i, t, m)] = r[i];
     for (int i = 0; i < m; ++i) r[i] = rt_1[i];
   }
@@ -2430,27 +2579,54 @@ static double ssm_observation_variance(const bo_ssm *m, int t) {
   return m->reg->sigsq; /* one observation per time point, missing or not (StateSpaceRegressionModel.cpp:167-177) */
 }
 
+/* the state errors of the step from t to t + 1, every state model in turn
+ * (simulate_state_error(rng, eta, t)) */
+static void ssm_state_error(const bo_ssm *M, bo_rng *rng, double *eta, int t) {
+  for (int i = 0; i < M->m; ++i) eta[i] = 0;
+  for (int bi = 0; bi < M->nblocks; ++bi) {
+    const bo_ssm_block *b = &M->blk[bi];
+    if (b->kind == BO_BLK_LOCAL_LEVEL) {
+      eta[b->first] = bo_rnorm(rng, 0, sqrt(b->sigsq[0]));          /* LocalLevelStateModel.cpp:62-64 */
+    } else if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) {
+      /* ZeroMeanMvnModel::sim = rmvn_mt(0, Sigma), Sigma diagonal (MvnBase.cpp:257) */
+      double z0 = bo_rnorm(rng, 0, 1), z1 = bo_rnorm(rng, 0, 1);
+      eta[b->first] = sqrt(b->sigsq[0]) * z0 + 0.0;
+      eta[b->first + 1] = sqrt(b->sigsq[1]) * z1 + 0.0;
+    } else if (b->kind == BO_BLK_SEASONAL) {
+      /* SeasonalStateModel.cpp:124-146: only when the next time point starts a season */
+      if (blk_new_season(b, t + 1)) eta[b->first] = bo_rnorm(rng, 0, sqrt(b->sigsq[0]));
+    } else {
+      /* ArStateModel::simulate_state_error, ArStateModel.cpp:85-90: rnorm_mt(rng) * sigma() */
+      eta[b->first] = bo_rnorm(rng, 0, 1) * sqrt(b->sigsq[0]);
+    }
+  }
+}
+
 /* Base::impute_state for the structural model */
 int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
   const int T = M->T, p = M->p, m = M->m;
   bo_ssvs *reg = M->reg;
+  if (M->nblocks == 0) return BO_ERR_INVALID;   /* "No state has been defined." */
   double *xty = (double *)xcalloc(p, sizeof(double));
   double *xsum = (double *)xcalloc(p, sizeof(double));
   double yty = 0, nobs = 0, sumy = 0;
-  for (int i = 0; i < 3; ++i) { M->suf_n[i] = 0; M->suf_ss[i] = 0; }
-  M->mv_n = 0;
-  M->mv_ybar[0] = M->mv_ybar[1] = 0;
-  M->mv_sumsq[0] = M->mv_sumsq[1] = 0;
-  if (M->ar0 >= 0) {
-    /* clear_client_data -> ArModel's NeRegSuf::clear */
-    for (int i = 0; i < M->ar_lags * M->ar_lags; ++i) M->ar_xtx[i] = 0;
-    for (int i = 0; i < M->ar_lags; ++i) M->ar_xty[i] = 0;
-    M->ar_yty = 0;
-    M->ar_n = 0;
+  for (int bi = 0; bi < M->nblocks; ++bi) {
+    bo_ssm_block *b = &M->blk[bi];
+    for (int i = 0; i < 2; ++i) { b->suf_n[i] = 0; b->suf_ss[i] = 0; }
+    b->mv_n = 0;
+    b->mv_ybar[0] = b->mv_ybar[1] = 0;
+    b->mv_sumsq[0] = b->mv_sumsq[1] = 0;
+    if (b->kind == BO_BLK_AR) {
+      /* clear_client_data -> ArModel's NeRegSuf::clear */
+      for (int i = 0; i < b->lags * b->lags; ++i) b->ar_xtx[i] = 0;
+      for (int i = 0; i < b->lags; ++i) b->ar_xty[i] = 0;
+      b->ar_yty = 0;
+      b->ar_n = 0;
+    }
   }
 
-  double a[BO_SSM_MAX], P[BO_SSM_MAX * BO_SSM_MAX];
-  for (int i = 0; i < m * m; ++i) P[i] = 0;
+  double a[BO_SSM_MAX];
+  double *P = (double *)xcalloc((size_t)m * m, sizeof(double));
   for (int i = 0; i < m; ++i) { a[i] = M->a0[i]; P[IDX(i, i, m)] = M->P0[i]; }
   int status = 0;
   int nvars = 0;
@@ -2464,67 +2640,46 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
         for (int j = 0; j < p; ++j) pred += M->X[IDX(t, j, T)] * reg->beta[j];
       ystar = M->y[t] - pred;
     }
-    status = ssm_update(M, ystar, missing, ssm_observation_variance(M, t), a, P,
+    status = ssm_update(M, t, ystar, missing, ssm_observation_variance(M, t), a, P,
                         &M->v[t], &M->F[t], &M->K[(size_t)t * m]);
   }
   /* simulate_forward (StateSpaceModelBase.cpp:771-790): initial state by
    * rmvn_mt(mean, variance) per state model (StateModel.cpp:47-56; a diagonal
    * variance: mean_i + sd_i z_i, every z drawn, mvn.cpp:54-60, :80-85), state
    * errors per model in order, then the observation */
-  double as[BO_SSM_MAX], Ps[BO_SSM_MAX * BO_SSM_MAX];
-  for (int i = 0; i < m * m; ++i) Ps[i] = 0;
-  for (int i = 0; i < m; ++i) { as[i] = M->a0[i]; Ps[IDX(i, i, m)] = M->P0[i]; }
-  const double sd_level = sqrt(M->sigsq[0]), sd_slope = sqrt(M->sigsq[1]),
-               sd_seas = sqrt(M->sigsq[2]);
+  double as[BO_SSM_MAX];
+  for (int i = 0; i < m * m; ++i) P[i] = 0;
+  for (int i = 0; i < m; ++i) { as[i] = M->a0[i]; P[IDX(i, i, m)] = M->P0[i]; }
   for (int t = 0; t < T && !status; ++t) {
     double *st = M->state + (size_t)t * m;
     if (t == 0) {
-      if (M->dtrend == 1) {
-        /* LocalLevelStateModel::simulate_initial_state, LocalLevelStateModel.cpp:66-69 */
-        st[0] = bo_rnorm(rng, M->a0[0], sqrt(M->P0[0]));
-      } else {
-        double z0 = bo_rnorm(rng, 0, 1), z1 = bo_rnorm(rng, 0, 1);
-        st[0] = sqrt(M->P0[0]) * z0 + M->a0[0];
-        st[1] = sqrt(M->P0[1]) * z1 + M->a0[1];
-      }
-      if (M->s0 >= 0) {
-        double z[BO_SSM_MAX];
-        const int n = M->nseasons - 1;
-        for (int i = 0; i < n; ++i) z[i] = bo_rnorm(rng, 0, 1);
-        for (int i = 0; i < n; ++i)
-          st[M->s0 + i] = sqrt(M->P0[M->s0 + i]) * z[i] + M->a0[M->s0 + i];
-      }
-      if (M->ar0 >= 0) {
-        /* StateModelBase::simulate_initial_state: rmvn_mt(mean, variance), diagonal here */
-        double z[BO_SSM_MAX];
-        for (int i = 0; i < M->ar_lags; ++i) z[i] = bo_rnorm(rng, 0, 1);
-        for (int i = 0; i < M->ar_lags; ++i)
-          st[M->ar0 + i] = sqrt(M->P0[M->ar0 + i]) * z[i] + M->a0[M->ar0 + i];
+      for (int bi = 0; bi < M->nblocks; ++bi) {
+        const bo_ssm_block *b = &M->blk[bi];
+        const int f = b->first;
+        if (b->kind == BO_BLK_LOCAL_LEVEL) {
+          /* LocalLevelStateModel::simulate_initial_state, LocalLevelStateModel.cpp:66-69 */
+          st[f] = bo_rnorm(rng, M->a0[f], sqrt(M->P0[f]));
+        } else {
+          /* StateModelBase::simulate_initial_state: rmvn_mt(mean, variance), diagonal here */
+          double z[BO_SSM_MAX];
+          for (int i = 0; i < b->dim; ++i) z[i] = bo_rnorm(rng, 0, 1);
+          for (int i = 0; i < b->dim; ++i) st[f + i] = sqrt(M->P0[f + i]) * z[i] + M->a0[f + i];
+        }
       }
     } else {
       double eta[BO_SSM_MAX];
-      for (int i = 0; i < m; ++i) eta[i] = 0;
-      if (M->dtrend == 1) {
-        eta[0] = bo_rnorm(rng, 0, sd_level);          /* LocalLevelStateModel.cpp:62-64 */
-      } else {
-        /* ZeroMeanMvnModel::sim = rmvn_mt(0, Sigma), Sigma diagonal (MvnBase.cpp:257) */
-        double z0 = bo_rnorm(rng, 0, 1), z1 = bo_rnorm(rng, 0, 1);
-        eta[0] = sd_level * z0 + 0.0;
-        eta[1] = sd_slope * z1 + 0.0;
-      }
-      if (M->s0 >= 0) eta[M->s0] = bo_rnorm(rng, 0, sd_seas);   /* SeasonalStateModel.cpp:141-145 */
-      /* ArStateModel::simulate_state_error, ArStateModel.cpp:85-90: rnorm_mt(rng) * sigma() */
-      if (M->ar0 >= 0) eta[M->ar0] = bo_rnorm(rng, 0, 1) * sqrt(M->ar_sigsq);
+      ssm_state_error(M, rng, eta, t - 1);
       const double *prev = M->state + (size_t)(t - 1) * m;
       for (int i = 0; i < m; ++i) st[i] = prev[i];
-      ssm_T(M, st);
+      ssm_T(M, st, t - 1);
       for (int i = 0; i < m; ++i) st[i] += eta[i];
     }
     const double H = ssm_observation_variance(M, t);
     const double ysim = bo_rnorm(rng, ssm_Zdot(M, st), sqrt(H));
-    status = ssm_update(M, ysim, !M->observed[t], H, as, Ps, &M->vs[t], &M->Fs[t],
+    status = ssm_update(M, t, ysim, !M->observed[t], H, as, P, &M->vs[t], &M->Fs[t],
                         &M->Ks[(size_t)t * m]);
   }
+  free(P);
   if (status) { free(xty); free(xsum); return status; }
 
   /* propagate_disturbances, StateSpaceModelBase.cpp:858-891 */
@@ -2532,7 +2687,6 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
       rqr[BO_SSM_MAX];
   ssm_disturbance_smooth(M, M->v, M->F, M->K, M->r, r0);
   ssm_disturbance_smooth(M, M->vs, M->Fs, M->Ks, M->rs, r0s);
-  ssm_rqr(M, rqr);
   for (int i = 0; i < m; ++i) {
     mean_sim[i] = M->a0[i] + M->P0[i] * r0s[i];
     mean_obs[i] = M->a0[i] + M->P0[i] * r0[i];
@@ -2540,8 +2694,9 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
   for (int t = 0; t < T; ++t) {
     double *st = M->state + (size_t)t * m;
     if (t > 0) {
-      ssm_T(M, mean_sim);
-      ssm_T(M, mean_obs);
+      ssm_T(M, mean_sim, t - 1);
+      ssm_T(M, mean_obs, t - 1);
+      ssm_rqr(M, rqr, t - 1);
       for (int i = 0; i < m; ++i) {
         mean_sim[i] += rqr[i] * M->rs[IDX(i, t - 1, m)];
         mean_obs[i] += rqr[i] * M->r[IDX(i, t - 1, m)];
@@ -2550,43 +2705,47 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
     for (int i = 0; i < m; ++i) st[i] += mean_obs[i] - mean_sim[i];
     if (t > 0) {
       const double *then = M->state + (size_t)(t - 1) * m;
-      if (M->dtrend == 1) {
-        /* LocalLevelStateModel::observe_state, LocalLevelStateModel.cpp:52-58 */
-        double diff = st[0] - then[0];
-        M->suf_n[0] += 1;
-        M->suf_ss[0] += diff * diff;
-      } else {
-        /* LocalLinearTrendStateModel::observe_state, LocalLinearTrend.cpp:53-63
-         * + MvnSuf::update_raw, MvnBase.cpp:71-86 (diagonal of sumsq only) */
-        double err[2] = {st[0] - (then[0] + then[1]), st[1] - then[1]};
-        M->mv_n += 1.0;
-        for (int i = 0; i < 2; ++i) {
-          double w = (err[i] - M->mv_ybar[i]) / M->mv_n;
-          M->mv_ybar[i] += w;
-          M->mv_sumsq[i] += w * w * (M->mv_n - 1);
-          double w2 = err[i] - M->mv_ybar[i];
-          M->mv_sumsq[i] += w2 * w2 * 1;
+      for (int bi = 0; bi < M->nblocks; ++bi) {
+        bo_ssm_block *b = &M->blk[bi];
+        const int f = b->first;
+        if (b->kind == BO_BLK_LOCAL_LEVEL) {
+          /* LocalLevelStateModel::observe_state, LocalLevelStateModel.cpp:52-58 */
+          double diff = st[f] - then[f];
+          b->suf_n[0] += 1;
+          b->suf_ss[0] += diff * diff;
+        } else if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) {
+          /* LocalLinearTrendStateModel::observe_state, LocalLinearTrend.cpp:53-63
+           * + MvnSuf::update_raw, MvnBase.cpp:71-86 (diagonal of sumsq only) */
+          double err[2] = {st[f] - (then[f] + then[f + 1]), st[f + 1] - then[f + 1]};
+          b->mv_n += 1.0;
+          for (int i = 0; i < 2; ++i) {
+            double w = (err[i] - b->mv_ybar[i]) / b->mv_n;
+            b->mv_ybar[i] += w;
+            b->mv_sumsq[i] += w * w * (b->mv_n - 1);
+            double w2 = err[i] - b->mv_ybar[i];
+            b->mv_sumsq[i] += w2 * w2 * 1;
+          }
+        } else if (b->kind == BO_BLK_SEASONAL) {
+          /* SeasonalStateModelBase::observe_state, SeasonalStateModel.cpp:74-86 */
+          if (blk_new_season(b, t)) {
+            double sum = 0;
+            for (int i = 0; i < b->dim; ++i) sum += then[f + i];
+            double mu = -1 * sum;
+            double delta = st[f] - mu;
+            b->suf_n[0] += 1;
+            b->suf_ss[0] += delta * delta;
+          }
+        } else {
+          /* ArStateModel::observe_state (ArStateModel.cpp:64-69): suf()->add_mixture_data(
+           * now[0], then, 1.0), NeRegSuf::add_mixture_data RegressionModel.cpp:356-370 */
+          const int L = b->lags;
+          const double yy = st[f], *x = then + f;
+          for (int j = 0; j < L; ++j)
+            for (int i = 0; i < L; ++i) b->ar_xtx[IDX(i, j, L)] += x[i] * x[j] * 1.0;
+          for (int i = 0; i < L; ++i) b->ar_xty[i] += (yy * 1.0) * x[i];
+          b->ar_yty += yy * yy * 1.0;
+          b->ar_n += 1.0;
         }
-      }
-      if (M->s0 >= 0) {
-        /* SeasonalStateModelBase::observe_state, SeasonalStateModel.cpp:74-86 */
-        double sum = 0;
-        for (int i = 0; i < M->nseasons - 1; ++i) sum += then[M->s0 + i];
-        double mu = -1 * sum;
-        double delta = st[M->s0] - mu;
-        M->suf_n[2] += 1;
-        M->suf_ss[2] += delta * delta;
-      }
-      if (M->ar0 >= 0) {
-        /* ArStateModel::observe_state (ArStateModel.cpp:64-69): suf()->add_mixture_data(
-         * now[0], then, 1.0), NeRegSuf::add_mixture_data RegressionModel.cpp:356-370 */
-        const int L = M->ar_lags;
-        const double yy = st[M->ar0], *x = then + M->ar0;
-        for (int j = 0; j < L; ++j)
-          for (int i = 0; i < L; ++i) M->ar_xtx[IDX(i, j, L)] += x[i] * x[j] * 1.0;
-        for (int i = 0; i < L; ++i) M->ar_xty[i] += (yy * 1.0) * x[i];
-        M->ar_yty += yy * yy * 1.0;
-        M->ar_n += 1.0;
       }
     }
     if (M->observed[t]) {
@@ -2602,12 +2761,14 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
       sumy += resid;
     }
   }
-  if (M->dtrend == 2) {
+  for (int bi = 0; bi < M->nblocks; ++bi) {
+    bo_ssm_block *b = &M->blk[bi];
+    if (b->kind != BO_BLK_LOCAL_LINEAR_TREND) continue;
     /* ZeroMeanMvnIndependenceSampler::draw reads df = suf->n() and
      * center_sumsq(mu = 0)(i, i) = sumsq_ii + n ybar_i^2 (MvnBase.cpp:157-161) */
     for (int i = 0; i < 2; ++i) {
-      M->suf_n[i] = M->mv_n;
-      M->suf_ss[i] = M->mv_sumsq[i] + M->mv_ybar[i] * M->mv_ybar[i] * M->mv_n;
+      b->suf_n[i] = b->mv_n;
+      b->suf_ss[i] = b->mv_sumsq[i] + b->mv_ybar[i] * b->mv_ybar[i] * b->mv_n;
     }
   }
   bo_ssvs_set_suf(reg, xty, yty, nobs, sumy, xsum);
@@ -2616,7 +2777,12 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
   return 0;
 }
 void bo_ssm_get_suf(const bo_ssm *m, double *n, double *ss) {
-  for (int i = 0; i < 3; ++i) { n[i] = m->suf_n[i]; ss[i] = m->suf_ss[i]; }
+  for (int i = 0; i < 3; ++i) {
+    int v;
+    const bo_ssm_block *B = ssm_template_var(m, i, &v);
+    n[i] = (B && v < B->nvar) ? B->suf_n[v] : 0.0;
+    ss[i] = (B && v < B->nvar) ? B->suf_ss[v] : 0.0;
+  }
 }
 
 /* ArModel::check_stationary (Models/TimeSeries/ArModel.cpp:142-170): true if
@@ -2746,35 +2912,35 @@ double bo_rtrun_norm_2(bo_rng *rng, double mu, double sigma, double lo, double h
 
 /* ArPosteriorSampler::draw_phi / draw_phi_univariate / draw_sigma,
  * Models/TimeSeries/PosteriorSamplers/ArPosteriorSampler.cpp:91-143, :78-89 */
-static void ar_draw(bo_ssm *M, int *status) {
-  const int L = M->ar_lags;
-  double phi_hat[BO_SSM_MAX], P[BO_SSM_MAX * BO_SSM_MAX], Lc[BO_SSM_MAX * BO_SSM_MAX],
-      z[BO_SSM_MAX];
-  bo_rng *rng = &M->ar_rng;
-  if (!bo_spd_solve(L, M->ar_xtx, M->ar_xty, phi_hat)) { *status = BO_ERR_NOT_PD; return; }
+static void ar_draw(bo_ssm *M, bo_ssm_block *B, int *status) {
+  const int L = B->lags;
+  double phi_hat[BO_AR_MAX], P[BO_AR_MAX * BO_AR_MAX], Lc[BO_AR_MAX * BO_AR_MAX],
+      z[BO_AR_MAX];
+  bo_rng *rng = &B->rng[0];
+  if (!bo_spd_solve(L, B->ar_xtx, B->ar_xty, phi_hat)) { *status = BO_ERR_NOT_PD; return; }
   int ok = 0, attempts = 0;
   while (!ok && ++attempts <= 3) {
     /* rmvn_ivar(phi_hat, xtx / sigsq), mvn.cpp:99-122: on GlobalRng::rng */
     bo_rng *grng = M->ar_global_rng ? M->ar_global_rng : rng;
-    for (int i = 0; i < L * L; ++i) P[i] = M->ar_xtx[i] / M->ar_sigsq;
+    for (int i = 0; i < L * L; ++i) P[i] = B->ar_xtx[i] / B->sigsq[0];
     if (!bo_chol(L, P, Lc)) { *status = BO_ERR_NOT_PD; return; }
     for (int i = 0; i < L; ++i) z[i] = bo_rnorm(grng, 0, 1);
     ltsolve_inplace(L, Lc, z);
     for (int i = 0; i < L; ++i) z[i] = z[i] + phi_hat[i];
     ok = ar_check_stationary(L, z);
-    if (ok) for (int i = 0; i < L; ++i) M->phi[i] = z[i];
+    if (ok) for (int i = 0; i < L; ++i) B->phi[i] = z[i];
   }
   if (!ok) {
-    double phi[BO_SSM_MAX] = {0};
-    for (int i = 0; i < L; ++i) phi[i] = M->phi[i];
+    double phi[BO_AR_MAX] = {0};
+    for (int i = 0; i < L; ++i) phi[i] = B->phi[i];
     if (!ar_check_stationary(L, phi)) { *status = BO_ERR_INVALID; return; }
     for (int i = 0; i < L; ++i) {
       const double initial_phi = phi[i];
       double lo = -1, hi = 1;
-      const double ivar = M->ar_xtx[IDX(i, i, L)];
+      const double ivar = B->ar_xtx[IDX(i, i, L)];
       double dot = 0;
-      for (int j = 0; j < L; ++j) dot += phi[j] * M->ar_xtx[IDX(j, i, L)];
-      const double mu = (M->ar_xty[i] - (dot - phi[i] * M->ar_xtx[IDX(i, i, L)])) / ivar;
+      for (int j = 0; j < L; ++j) dot += phi[j] * B->ar_xtx[IDX(j, i, L)];
+      const double mu = (B->ar_xty[i] - (dot - phi[i] * B->ar_xtx[IDX(i, i, L)])) / ivar;
       for (;;) {
         const double candidate = rtrun_norm_2(rng, mu, sqrt(1.0 / ivar), lo, hi, status);
         if (*status) return;
@@ -2783,24 +2949,25 @@ static void ar_draw(bo_ssm *M, int *status) {
         if (candidate > initial_phi) hi = candidate; else lo = candidate;
       }
     }
-    for (int i = 0; i < L; ++i) M->phi[i] = phi[i];
+    for (int i = 0; i < L; ++i) B->phi[i] = phi[i];
   }
   /* draw_sigma: ss = phi' xtx phi - 2 phi' xty + yty, df = n */
   double quad = 0, lin = 0;
   for (int i = 0; i < L; ++i) {
     double row = 0;
-    for (int j = 0; j < L; ++j) row += M->ar_xtx[IDX(i, j, L)] * M->phi[j];
-    quad += M->phi[i] * row;
-    lin += M->phi[i] * M->ar_xty[i];
+    for (int j = 0; j < L; ++j) row += B->ar_xtx[IDX(i, j, L)] * B->phi[j];
+    quad += B->phi[i] * row;
+    lin += B->phi[i] * B->ar_xty[i];
   }
-  const double ss = quad - 2 * lin + M->ar_yty;
-  M->ar_sigsq = variance_draw(rng, M->ar_prior_df, M->ar_prior_ss, M->ar_sigma_max, M->ar_n, ss,
+  const double ss = quad - 2 * lin + B->ar_yty;
+  B->sigsq[0] = variance_draw(rng, B->prior_df[0], B->prior_ss[0], B->sigma_max[0], B->ar_n, ss,
                               status);
 }
 
 /* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64: the
- * regression, then each state model's samplers in order (trend: level [, slope];
- * seasonal; AR), then impute_state */
+ * regression, then each state model's samplers in the order the models were added
+ * (local level: its variance; local linear trend: level, slope; seasonal: its
+ * variance; autoregression: phi, sigma), then impute_state */
 int bo_ssm_draw(bo_ssm *m) {
   int status = 0;
   if (!m->latent_initialized) {
@@ -2810,71 +2977,82 @@ int bo_ssm_draw(bo_ssm *m) {
   }
   status = ssvs_draw(m->reg);
   if (status) return status;
-  for (int i = 0; i < 3; ++i) {
-    if (i == 1 && m->dtrend != 2) continue;
-    if (i == 2 && m->s0 < 0) continue;
-    double draw = variance_draw(&m->var_rng[i], m->prior_df[i], m->prior_ss[i],
-                                m->sigma_max[i], m->suf_n[i], m->suf_ss[i], &status);
-    if (status) return status;
-    if (m->dtrend == 2 && i < 2) {
-      /* ZeroMeanMvnIndependenceSampler.cpp:63-70: siginv(i, i) = 1 / draw, and
-       * the model's Sigma is the inverse of that again */
-      double siginv = 1.0 / draw;
-      draw = 1.0 / siginv;
+  for (int bi = 0; bi < m->nblocks; ++bi) {
+    bo_ssm_block *b = &m->blk[bi];
+    if (b->kind == BO_BLK_AR) {
+      ar_draw(m, b, &status);
+      if (status) return status;
+      continue;
     }
-    m->sigsq[i] = draw;
-  }
-  if (m->ar0 >= 0) {
-    ar_draw(m, &status);
-    if (status) return status;
+    for (int i = 0; i < b->nvar; ++i) {
+      double draw = variance_draw(&b->rng[i], b->prior_df[i], b->prior_ss[i],
+                                  b->sigma_max[i], b->suf_n[i], b->suf_ss[i], &status);
+      if (status) return status;
+      if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) {
+        /* ZeroMeanMvnIndependenceSampler.cpp:63-70: siginv(i, i) = 1 / draw, and
+         * the model's Sigma is the inverse of that again */
+        double siginv = 1.0 / draw;
+        draw = 1.0 / siginv;
+      }
+      b->sigsq[i] = draw;
+    }
   }
   return bo_ssm_impute_state(m, &m->state_rng);
 }
 
 /* StateSpaceRegressionModel::simulate_forecast for the structural model
  * (StateSpaceRegressionModel.cpp:216-219, :256-278; simulate_next_state
- * StateSpaceModelBase.cpp:439-443): newX horizon x p column-major, final_state the
- * state at the last time point (m values), sigsq = (level, slope, seasonal) */
+ * StateSpaceModelBase.cpp:439-443) from a model object that holds the blocks, their
+ * variances and coefficients: newX horizon x p column-major, final_state the state at
+ * the last time point T - 1 (m values); forecast step i is time T + i */
+void bo_ssm_forecast_model(const bo_ssm *M, bo_rng *rng, int horizon, int p, const double *newX,
+                           const double *beta, double sigsq_obs, const double *final_state,
+                           double *out) {
+  double st[BO_SSM_MAX];
+  for (int i = 0; i < M->m; ++i) st[i] = final_state[i];
+  const double sd_obs = sqrt(sigsq_obs);
+  for (int i = 0; i < horizon; ++i) {
+    double eta[BO_SSM_MAX];
+    /* advance_to_timestamp (StateSpaceModelBase.cpp:455-459) calls simulate_next_state(rng,
+     * state, time_dimension() + time++) with time starting at -1: forecast step i is
+     * simulated as "time period T - 1 + i", i.e. with the transition matrix and the state
+     * errors of index T - 2 + i (it matters for a seasonal model with duration > 1 only) */
+    const int tm = M->T - 2 + i;
+    ssm_state_error(M, rng, eta, tm);
+    ssm_T(M, st, tm);
+    for (int k = 0; k < M->m; ++k) st[k] += eta[k];
+    double ans = bo_rnorm(rng, ssm_Zdot(M, st), sd_obs);
+    double pred = 0;
+    for (int j = 0; j < p; ++j) pred += newX[IDX(i, j, horizon)] * beta[j];
+    out[i] = ans + pred;
+  }
+}
+/* the template's form: sigsq = (level, slope, seasonal) */
 void bo_ssm_simulate_forecast_ar(bo_rng *rng, int horizon, int p, const double *newX,
                                  const double *beta, double sigsq_obs, int trend, int nseasons,
                                  const double *sigsq, int ar_lags, const double *phi,
                                  double ar_sigsq, const double *final_state, double *out) {
   bo_ssm M;
   memset(&M, 0, sizeof(M));
-  M.dtrend = trend;
-  M.nseasons = nseasons;
-  M.s0 = nseasons > 0 ? trend : -1;
-  M.m = trend + (nseasons > 0 ? nseasons - 1 : 0);
-  M.ar0 = -1;
+  bo_ssm_block *b = &M.blk[M.nblocks++];
+  b->kind = trend == 2 ? BO_BLK_LOCAL_LINEAR_TREND : BO_BLK_LOCAL_LEVEL;
+  b->first = 0; b->dim = trend; b->nvar = trend; b->duration = 1;
+  b->sigsq[0] = sigsq[0]; b->sigsq[1] = sigsq[1];
+  M.m = trend;
+  if (nseasons > 0) {
+    b = &M.blk[M.nblocks++];
+    b->kind = BO_BLK_SEASONAL; b->first = M.m; b->dim = nseasons - 1; b->nvar = 1;
+    b->nseasons = nseasons; b->duration = 1; b->sigsq[0] = sigsq[2];
+    M.m += b->dim;
+  }
   if (ar_lags > 0) {
-    M.ar0 = M.m;
-    M.ar_lags = ar_lags;
+    b = &M.blk[M.nblocks++];
+    b->kind = BO_BLK_AR; b->first = M.m; b->dim = ar_lags; b->lags = ar_lags; b->nvar = 1;
+    b->duration = 1; b->sigsq[0] = ar_sigsq;
+    for (int i = 0; i < ar_lags; ++i) b->phi[i] = phi[i];
     M.m += ar_lags;
-    for (int i = 0; i < ar_lags; ++i) M.phi[i] = phi[i];
   }
-  double st[BO_SSM_MAX];
-  for (int i = 0; i < M.m; ++i) st[i] = final_state[i];
-  const double sd_level = sqrt(sigsq[0]), sd_slope = sqrt(sigsq[1]), sd_seas = sqrt(sigsq[2]);
-  const double sd_obs = sqrt(sigsq_obs);
-  for (int i = 0; i < horizon; ++i) {
-    double eta[BO_SSM_MAX];
-    for (int k = 0; k < M.m; ++k) eta[k] = 0;
-    if (trend == 1) {
-      eta[0] = bo_rnorm(rng, 0, sd_level);
-    } else {
-      double z0 = bo_rnorm(rng, 0, 1), z1 = bo_rnorm(rng, 0, 1);
-      eta[0] = sd_level * z0 + 0.0;
-      eta[1] = sd_slope * z1 + 0.0;
-    }
-    if (M.s0 >= 0) eta[M.s0] = bo_rnorm(rng, 0, sd_seas);
-    if (M.ar0 >= 0) eta[M.ar0] = bo_rnorm(rng, 0, 1) * sqrt(ar_sigsq);
-    ssm_T(&M, st);
-    for (int k = 0; k < M.m; ++k) st[k] += eta[k];
-    double ans = bo_rnorm(rng, ssm_Zdot(&M, st), sd_obs);
-    double pred = 0;
-    for (int j = 0; j < p; ++j) pred += newX[IDX(i, j, horizon)] * beta[j];
-    out[i] = ans + pred;
-  }
+  bo_ssm_forecast_model(&M, rng, horizon, p, newX, beta, sigsq_obs, final_state, out);
 }
 void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,
                               const double *beta, double sigsq_obs, int trend, int nseasons,

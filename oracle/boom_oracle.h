@@ -210,12 +210,15 @@ void bo_ss_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX
                              const double *beta, double sigsq_obs,
                              double sigsq_level, double final_state, double *out);
 
-/* Structural time series: regression + trend state model
- * (trend = 1: LocalLevelStateModel; 2: LocalLinearTrendStateModel with one
- * ZeroMeanMvnIndependenceSampler per variance) + optional SeasonalStateModel
- * (nseasons >= 2, season duration 1; 0 = none).  The three-element arrays are
- * indexed level, slope, seasonal; initial state mean / variance (diagonal) have
- * the state dimension trend + nseasons - 1. */
+/* Structural time series: regression + any list of state models
+ * in any order (StateSpaceModelBase::add_state): LocalLevelStateModel,
+ * LocalLinearTrendStateModel (one ZeroMeanMvnIndependenceSampler per variance),
+ * SeasonalStateModel(nseasons, season_duration), ArStateModel(lags); state dimension
+ * <= 64, at most 8 blocks.  bo_ssm_create is the template of rounds 2-3 (trend = 1:
+ * local level; 2: local linear trend; + optional SeasonalStateModel(nseasons, 1);
+ * three-element arrays indexed level, slope, seasonal); bo_ssm_create_empty +
+ * bo_ssm_add_block build any list. */
+enum { BO_BLK_LOCAL_LEVEL = 1, BO_BLK_LOCAL_LINEAR_TREND = 2, BO_BLK_SEASONAL = 3, BO_BLK_AR = 4 };
 typedef struct bo_ssm bo_ssm;
 bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
                       const uint8_t *observed, const double *prior_mean,
@@ -226,6 +229,33 @@ bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
                       const double *var_initial_sigma,
                       const double *initial_state_mean,
                       const double *initial_state_variance);
+bo_ssm *bo_ssm_create_empty(int T, int p, const double *y, const double *X,
+                            const uint8_t *observed, const double *prior_mean,
+                            const double *ominv, double prior_df, double sigma_guess,
+                            const double *pi);
+/* model->add_state(...): iparams = {nseasons, season_duration, time_of_first_observation}
+ * (seasonal) or {lags} (autoregression); one entry per variance parameter in the var_*
+ * arrays (two for the local linear trend: level, slope); the block's initial state is
+ * N(mean, diag(variance)) */
+int bo_ssm_add_block(bo_ssm *m, int kind, const int *iparams, const double *var_df,
+                     const double *var_sigma_guess, const double *var_sigma_upper_limit,
+                     const double *var_initial_sigma, const double *initial_phi,
+                     const double *initial_state_mean, const double *initial_state_variance);
+int bo_ssm_nblocks(const bo_ssm *m);
+/* the generator of block b's v-th variance sampler (autoregression: the ArPosteriorSampler's) */
+bo_rng *bo_ssm_block_rng(bo_ssm *m, int b, int v);
+/* its Philox sampler id: level 1, slope 6, seasonal 7, autoregression 12, + 16 for every
+ * earlier block of the same family */
+int bo_ssm_block_stream_id(const bo_ssm *m, int b, int v);
+void bo_ssm_block_get(const bo_ssm *m, int b, double *sigsq, double *suf_n, double *suf_ss,
+                      double *phi);
+void bo_ssm_block_set_sigsq(bo_ssm *m, int b, const double *sigsq);
+void bo_ssm_block_get_ar_suf(const bo_ssm *m, int b, double *xtx, double *xty, double *yty,
+                             double *n);
+/* simulate_forecast from the model's current parameters */
+void bo_ssm_forecast_model(const bo_ssm *m, bo_rng *rng, int horizon, int p, const double *newX,
+                           const double *beta, double sigsq_obs, const double *final_state,
+                           double *out);
 /* adds an ArStateModel(lags) block (+ ArPosteriorSampler) after the trend / seasonal blocks */
 int bo_ssm_add_ar(bo_ssm *m, int lags, double prior_df, double sigma_guess,
                   double sigma_upper_limit, double initial_sigma, const double *initial_phi,

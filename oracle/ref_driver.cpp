@@ -805,6 +805,216 @@ int ref_ssm_forecast(int T, int p, const double *y, const double *X, const doubl
   REF_CATCH
 }
 
+// ---- the general form (round 4): ANY list of state models in any order.
+// nblocks blocks; kinds[b] = 1 LocalLevelStateModel, 2 LocalLinearTrendStateModel (one
+// ZeroMeanMvnIndependenceSampler per variance), 3 SeasonalStateModel(iparams[3 b],
+// iparams[3 b + 1]) with set_time_of_first_observation(iparams[3 b + 2]), 4
+// ArStateModel(iparams[3 b]) + ArPosteriorSampler.  vpar[8 b + 4 v + {0, 1, 2, 3}] = prior
+// df, prior sigma guess, sigma upper limit (inf: none), initial sigma of variance v of
+// block b; phi0[16 b ..] the initial autoregression coefficients; a0 / P0: the blocks'
+// initial state means / variances (diagonal) one after the other.
+// Outputs per sweep: variances (nblocks x 2), phi (nblocks x 16); the state draw of
+// sweeps i with i % state_every == state_every - 1 (T x m each, in order).
+struct GeneralState {
+  std::vector<Ptr<LocalLevelStateModel>> level;
+  std::vector<Ptr<LocalLinearTrendStateModel>> llt;
+  std::vector<Ptr<SeasonalStateModel>> seasonal;
+  std::vector<Ptr<ArStateModel>> ar;
+  std::vector<int> kind, slot;   // per block: which vector, which element
+};
+
+static void add_general_state(StateSpaceRegressionModel *model, GeneralState &G, int nblocks,
+                              const int *kinds, const int *iparams, const double *vpar,
+                              const double *phi0, const double *a0, const double *P0,
+                              bool with_samplers) {
+  int first = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const double *vp = vpar + 8 * b;
+    G.kind.push_back(kinds[b]);
+    if (kinds[b] == 1) {
+      Ptr<LocalLevelStateModel> level(new LocalLevelStateModel(vp[3]));
+      if (with_samplers) {
+        NEW(ZeroMeanGaussianConjSampler, s)(level.get(), vp[0], vp[1]);
+        if (std::isfinite(vp[2])) s->set_sigma_upper_limit(vp[2]);
+        level->set_method(s);
+      }
+      level->set_initial_state_mean(a0[first]);
+      level->set_initial_state_variance(P0[first]);
+      model->add_state(level);
+      G.slot.push_back((int)G.level.size());
+      G.level.push_back(level);
+      first += 1;
+    } else if (kinds[b] == 2) {
+      Ptr<LocalLinearTrendStateModel> llt(new LocalLinearTrendStateModel);
+      SpdMatrix Sigma(2, 0.0);
+      Sigma(0, 0) = vp[3] * vp[3];
+      Sigma(1, 1) = vp[7] * vp[7];
+      llt->set_Sigma(Sigma);
+      if (with_samplers) {
+        for (int i = 0; i < 2; ++i) {
+          NEW(ZeroMeanMvnIndependenceSampler, s)(llt.get(), vp[4 * i], vp[4 * i + 1], i);
+          if (std::isfinite(vp[4 * i + 2])) s->set_sigma_upper_limit(vp[4 * i + 2]);
+          llt->set_method(s);
+        }
+      }
+      Vector mean(2);
+      SpdMatrix var(2, 0.0);
+      for (int i = 0; i < 2; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+      llt->set_initial_state_mean(mean);
+      llt->set_initial_state_variance(var);
+      model->add_state(llt);
+      G.slot.push_back((int)G.llt.size());
+      G.llt.push_back(llt);
+      first += 2;
+    } else if (kinds[b] == 3) {
+      const int ns = iparams[3 * b], dur = iparams[3 * b + 1];
+      Ptr<SeasonalStateModel> seasonal(new SeasonalStateModel(ns, dur));
+      seasonal->set_time_of_first_observation(iparams[3 * b + 2]);
+      seasonal->set_sigsq(vp[3] * vp[3]);
+      if (with_samplers) {
+        NEW(ZeroMeanGaussianConjSampler, s)(seasonal.get(), vp[0], vp[1]);
+        if (std::isfinite(vp[2])) s->set_sigma_upper_limit(vp[2]);
+        seasonal->set_method(s);
+      }
+      const int n = ns - 1;
+      Vector mean(n);
+      SpdMatrix var(n, 0.0);
+      for (int i = 0; i < n; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+      seasonal->set_initial_state_mean(mean);
+      seasonal->set_initial_state_variance(var);
+      model->add_state(seasonal);
+      G.slot.push_back((int)G.seasonal.size());
+      G.seasonal.push_back(seasonal);
+      first += n;
+    } else {
+      const int L = iparams[3 * b];
+      Ptr<ArStateModel> arm(new ArStateModel(L));
+      arm->set_phi(make_vector(L, phi0 + 16 * b));
+      arm->set_sigma(vp[3]);
+      if (with_samplers) {
+        NEW(ChisqModel, ar_prior)(vp[0], vp[1]);
+        NEW(ArPosteriorSampler, s)(arm.get(), ar_prior);
+        if (std::isfinite(vp[2])) s->set_sigma_upper_limit(vp[2]);
+        arm->set_method(s);
+      }
+      Vector mean(L);
+      SpdMatrix var(L, 0.0);
+      for (int i = 0; i < L; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+      arm->set_initial_state_mean(mean);
+      arm->set_initial_state_variance(var);
+      model->add_state(arm);
+      G.slot.push_back((int)G.ar.size());
+      G.ar.push_back(arm);
+      first += L;
+    }
+  }
+}
+
+int ref_ssg_run(int T, int p, const double *y, const double *X, const uint8_t *observed,
+                const double *prior_mean, const double *ominv, double prior_df,
+                double sigma_guess, const double *pi, const RefSsvsOptions *opt, int nblocks,
+                const int *kinds, const int *iparams, const double *vpar, const double *phi0,
+                const double *a0, const double *P0, uint64_t seed, const uint8_t *init_gamma,
+                int nsweeps, int state_every, uint8_t *out_gamma, double *out_beta,
+                double *out_sigsq, double *out_variances, double *out_phi, double *out_state) {
+  REF_TRY
+  GlobalRng::rng.seed(seed);
+  std::vector<bool> obs;
+  if (observed) {
+    obs.resize(T);
+    for (int t = 0; t < T; ++t) obs[t] = observed[t] != 0;
+  }
+  NEW(StateSpaceRegressionModel, model)(make_vector(T, y), make_matrix(T, p, X), obs);
+  RegressionModel *reg = model->observation_model();
+  NEW(MvnGivenScalarSigma, slab)(make_vector(p, prior_mean), make_spd(p, ominv),
+                                 reg->Sigsq_prm());
+  NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+  NEW(VariableSelectionPrior, spike)(make_vector(p, pi));
+  NEW(BregVsSampler, reg_sampler)(reg, slab, siginv_prior, spike);
+  apply_options(*reg_sampler, spike, opt);
+  reg->set_method(reg_sampler);
+  reg->coef().drop_all();
+  for (int j = 0; j < p; ++j) {
+    if (init_gamma[j]) reg->coef().add(j);
+  }
+  GeneralState G;
+  add_general_state(model.get(), G, nblocks, kinds, iparams, vpar, phi0, a0, P0, true);
+  NEW(StateSpacePosteriorSampler, sampler)(model.get());
+  model->set_method(sampler);
+  const int m = model->state_dimension();
+  size_t kept = 0;
+  for (int i = 0; i < nsweeps; ++i) {
+    model->sample_posterior();
+    record(*reg, p, i, out_gamma, out_beta, out_sigsq);
+    for (int b = 0; b < nblocks; ++b) {
+      double *v = out_variances + ((size_t)i * nblocks + b) * 2;
+      double *ph = out_phi + ((size_t)i * nblocks + b) * 16;
+      v[0] = v[1] = 0.0;
+      for (int j = 0; j < 16; ++j) ph[j] = 0.0;
+      const int s = G.slot[b];
+      if (G.kind[b] == 1) {
+        v[0] = G.level[s]->sigsq();
+      } else if (G.kind[b] == 2) {
+        v[0] = G.llt[s]->Sigma()(0, 0);
+        v[1] = G.llt[s]->Sigma()(1, 1);
+      } else if (G.kind[b] == 3) {
+        v[0] = G.seasonal[s]->sigsq();
+      } else {
+        v[0] = G.ar[s]->sigsq();
+        const int L = iparams[3 * b];
+        for (int j = 0; j < L; ++j) ph[j] = G.ar[s]->phi()[j];
+      }
+    }
+    if (state_every > 0 && i % state_every == state_every - 1) {
+      const Matrix &state(model->state());
+      for (int t = 0; t < T; ++t)
+        for (int j = 0; j < m; ++j) out_state[(kept * T + t) * m + j] = state(j, t);
+      ++kept;
+    }
+  }
+  REF_CATCH
+}
+
+// simulate_forecast of the general model: fixed parameters (sigsq[2 b + v], phi[16 b ..])
+// and final state
+int ref_ssg_forecast(int T, int p, const double *y, const double *X, const double *beta,
+                     const uint8_t *gamma, double sigsq_obs, int nblocks, const int *kinds,
+                     const int *iparams, const double *sigsq, const double *phi,
+                     const double *final_state, int horizon, const double *newX, uint64_t seed,
+                     double *out) {
+  REF_TRY
+  NEW(StateSpaceRegressionModel, model)(make_vector(T, y), make_matrix(T, p, X),
+                                        std::vector<bool>());
+  RegressionModel *reg = model->observation_model();
+  reg->coef().drop_all();
+  Vector b(p, 0.0);
+  for (int j = 0; j < p; ++j) {
+    if (gamma[j]) {
+      reg->coef().add(j);
+      b[j] = beta[j];
+    }
+  }
+  reg->coef().set_Beta(b);
+  reg->set_sigsq(sigsq_obs);
+  int m = 0;
+  std::vector<double> vpar(8 * (size_t)nblocks, 1.0);
+  for (int k = 0; k < nblocks; ++k) {
+    vpar[8 * k + 3] = std::sqrt(sigsq[2 * k]);
+    vpar[8 * k + 7] = std::sqrt(sigsq[2 * k + 1]);
+    m += kinds[k] == 1 ? 1 : kinds[k] == 2 ? 2 : kinds[k] == 3 ? iparams[3 * k] - 1 : iparams[3 * k];
+  }
+  std::vector<double> a0(m, 0.0), P0(m, 1.0);
+  GeneralState G;
+  add_general_state(model.get(), G, nblocks, kinds, iparams, vpar.data(), phi, a0.data(),
+                    P0.data(), false);
+  RNG rng(seed);
+  Vector fs(m);
+  for (int i = 0; i < m; ++i) fs[i] = final_state[i];
+  Vector ans = model->simulate_forecast(rng, make_matrix(horizon, p, newX), fs);
+  for (int i = 0; i < horizon; ++i) out[i] = ans[i];
+  REF_CATCH
+}
+
 // ------------------------------------------- SpikeSlabSampler (sigma given)
 // The sigma^2-conditional SSVS helper used by the logit / probit / Poisson /
 // Student samplers (SpikeSlabSampler.cpp:40-82, 115-138, 171-216), driven the

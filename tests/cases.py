@@ -141,6 +141,125 @@ def structural_spec(y, trend, nseasons, ar_lags=0):
                 initial_state_variance=np.full(m, sdy * sdy))
 
 
+KIND_LOCAL_LEVEL, KIND_LOCAL_LINEAR_TREND, KIND_SEASONAL, KIND_AR = 1, 2, 3, 4
+
+
+def general_spec(y, blocks):
+    """a list of state models in the order they are added (add_state), bsts-style
+    defaults as structural_spec.  blocks: tuples ("level",), ("trend",), ("seasonal",
+    nseasons, duration[, time_of_first_observation]), ("ar", lags[, initial_phi]).
+    Returns the list of block dicts the oracle / reference / engine wrappers take."""
+    sdy = float(np.std(y, ddof=1))
+    out = []
+    first = True
+    init_sigma = {"level": [1.0], "trend": [1.0, 0.5], "seasonal": [0.7], "ar": [1.0]}
+    for b in blocks:
+        name = b[0]
+        kind = {"level": KIND_LOCAL_LEVEL, "trend": KIND_LOCAL_LINEAR_TREND,
+                "seasonal": KIND_SEASONAL, "ar": KIND_AR}[name]
+        nv = 2 if name == "trend" else 1
+        d = dict(kind=kind, nseasons=0, duration=1, t0=0, lags=0,
+                 df=np.full(nv, 0.01), sigma_guess=np.full(nv, 0.01 * sdy),
+                 sigma_upper_limit=np.full(nv, sdy),
+                 initial_sigma=np.array(init_sigma[name]), initial_phi=np.zeros(0))
+        if name == "seasonal":
+            d["nseasons"], d["duration"] = int(b[1]), int(b[2])
+            d["t0"] = int(b[3]) if len(b) > 3 else 0
+            dim = d["nseasons"] - 1
+        elif name == "ar":
+            d["lags"] = int(b[1])
+            d["initial_phi"] = (np.asarray(b[2], float) if len(b) > 2
+                                else np.zeros(d["lags"]))
+            dim = d["lags"]
+        else:
+            dim = nv
+        a0 = np.zeros(dim)
+        if first and name in ("level", "trend"):
+            a0[0] = float(y[0])
+            first = False
+        d["a0"] = a0
+        d["P0"] = np.full(dim, sdy * sdy)
+        d["dim"] = dim
+        out.append(d)
+    return out
+
+
+def general_arrays(blocks):
+    """the flat arrays of ref_ssg_run / bo_ssm_add_block / ba_ss_add_state"""
+    nb = len(blocks)
+    kinds = np.array([b["kind"] for b in blocks], np.int32)
+    ip = np.zeros((nb, 3), np.int32)
+    vpar = np.ones((nb, 2, 4))
+    phi0 = np.zeros((nb, 16))
+    for i, b in enumerate(blocks):
+        if b["kind"] == KIND_SEASONAL:
+            ip[i] = (b["nseasons"], b["duration"], b["t0"])
+        elif b["kind"] == KIND_AR:
+            ip[i, 0] = b["lags"]
+            phi0[i, :b["lags"]] = b["initial_phi"]
+        for v in range(len(b["df"])):
+            vpar[i, v] = (b["df"][v], b["sigma_guess"][v], b["sigma_upper_limit"][v],
+                          b["initial_sigma"][v])
+    a0 = np.concatenate([b["a0"] for b in blocks])
+    P0 = np.concatenate([b["P0"] for b in blocks])
+    return kinds, ip, vpar, phi0, a0, P0
+
+
+def blocks_of(g, prefix=""):
+    """the block list of a golden file written by make_golden_structural_general.py"""
+    kinds, ip, vpar = g[prefix + "kinds"], g[prefix + "iparams"], g[prefix + "vpar"]
+    phi0, a0, P0 = g[prefix + "phi0"], g[prefix + "a0"], g[prefix + "P0"]
+    out, first = [], 0
+    for i, k in enumerate(kinds):
+        k = int(k)
+        nv = 2 if k == KIND_LOCAL_LINEAR_TREND else 1
+        d = dict(kind=k, nseasons=0, duration=1, t0=0, lags=0, df=vpar[i, :nv, 0],
+                 sigma_guess=vpar[i, :nv, 1], sigma_upper_limit=vpar[i, :nv, 2],
+                 initial_sigma=vpar[i, :nv, 3], initial_phi=np.zeros(0))
+        if k == KIND_SEASONAL:
+            d["nseasons"], d["duration"], d["t0"] = (int(v) for v in ip[i])
+            dim = d["nseasons"] - 1
+        elif k == KIND_AR:
+            d["lags"] = int(ip[i, 0])
+            d["initial_phi"] = phi0[i, :d["lags"]]
+            dim = d["lags"]
+        else:
+            dim = nv
+        d["a0"], d["P0"], d["dim"] = a0[first:first + dim], P0[first:first + dim], dim
+        first += dim
+        out.append(d)
+    return out
+
+
+def general_data(T, p, nsig, seasonals, seed, slope=0.02, missing_frac=0.0, ar_coef=None,
+                 level=True):
+    """y = [random walk with drift] + seasonal patterns ((nseasons, duration) pairs) +
+    X beta + noise [+ a stationary autoregression]"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.standard_normal((T, p))
+    beta = np.zeros(p)
+    beta[:nsig] = 3.0 * (1 + np.arange(nsig))
+    y = X @ beta + 0.2 * rng.standard_normal(T)
+    if level:
+        y = y + np.cumsum(slope + 0.1 * rng.standard_normal(T))
+    for ns, dur in seasonals:
+        pattern = rng.standard_normal(ns)
+        pattern -= pattern.mean()
+        y = y + pattern[(np.arange(T) // dur) % ns]
+    if ar_coef is not None:
+        L = len(ar_coef)
+        u = np.zeros(T + 50 + L)
+        e = 0.5 * rng.standard_normal(T + 50 + L)
+        for t in range(L, len(u)):
+            u[t] = sum(ar_coef[i] * u[t - 1 - i] for i in range(L)) + e[t]
+        y = y + u[-T:]
+    observed = None
+    if missing_frac > 0:
+        observed = (rng.random(T) >= missing_frac).astype(np.uint8)
+        observed[0] = 1
+    return X, y, beta, observed
+
+
 def probit_data(n, p, nsig, seed, max_trials=1):
     """binomial probit data: X[:, 0] = 1, successes y out of ntrials"""
     from math import erf

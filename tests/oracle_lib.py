@@ -863,6 +863,145 @@ class Oracle:
         return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, state=state,
                     status=status, ar_phi=ar_phi, ar_sigsq=ar_sig)
 
+    def _ssg_build(self, y, X, observed, prior, blocks):
+        from cases import general_arrays
+        T, p = X.shape
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        L = self.lib
+        L.bo_ssm_create_empty.restype = C.c_void_p
+        L.bo_ssm_create_empty.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, c_u8_p,
+                                          c_double_p, c_double_p, C.c_double, C.c_double,
+                                          c_double_p]
+        L.bo_ssm_add_block.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)] + [c_double_p] * 7
+        L.bo_ssm_block_rng.restype = C.c_void_p
+        L.bo_ssm_block_rng.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.bo_ssm_block_stream_id.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.bo_ssm_block_get.argtypes = [C.c_void_p, C.c_int] + [c_double_p] * 4
+        L.bo_ssm_block_set_sigsq.argtypes = [C.c_void_p, C.c_int, c_double_p]
+        L.bo_ssm_block_get_ar_suf.argtypes = [C.c_void_p, C.c_int] + [c_double_p] * 4
+        m = L.bo_ssm_create_empty(T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs),
+                                  _dp(f64(prior["b"])), _dp(fcol(prior["ominv"])),
+                                  prior["df"], prior["sigma_guess"], _dp(f64(prior["pi"])))
+        kinds, ip, vpar, phi0, a0, P0 = general_arrays(blocks)
+        first = 0
+        for i, b in enumerate(blocks):
+            ipi = np.ascontiguousarray(ip[i], np.int32)
+            vp = np.ascontiguousarray(vpar[i].T)   # rows: df, guess, upper limit, initial sigma
+            rc = L.bo_ssm_add_block(
+                m, int(kinds[i]), ipi.ctypes.data_as(C.POINTER(C.c_int)), _dp(vp[0]), _dp(vp[1]),
+                _dp(vp[2]), _dp(vp[3]), _dp(f64(phi0[i])), _dp(f64(a0[first:first + b["dim"]])),
+                _dp(f64(P0[first:first + b["dim"]])))
+            assert rc == 0, rc
+            first += b["dim"]
+        return m
+
+    def ssg_run(self, y, X, observed, prior, opts, blocks, rng_setup, init_gamma, nsweeps,
+                state_every=1, set_sigsq=None):
+        """general structural model: blocks = cases.general_spec(...).  Returns per sweep
+        gamma, beta, sigsq, variances (nblocks x 2), phi (nblocks x 16), the ArModel /
+        variance sufficient statistics of the LAST sweep, and the state draws of the
+        sweeps i with i % state_every == state_every - 1."""
+        T, p = X.shape
+        L = self.lib
+        m = self._ssg_build(y, X, observed, prior, blocks)
+        nb = len(blocks)
+        dim = L.bo_ssm_state_dimension(m)
+        reg = L.bo_ssm_regression(m)
+        L.bo_ssvs_set_options(reg, opts["max_model_size"], opts["sigma_upper_limit"],
+                              opts["swap_threshold"], opts["max_flips"], opts["draw_beta"],
+                              opts["draw_sigma"])
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        L.bo_ssvs_set_state(reg, _u8(g0), _dp(np.zeros(p)), 1.0)
+        nvar = [2 if b["kind"] == 2 else 1 for b in blocks]
+        if rng_setup[0] == "mt":
+            glob = self.rng_mt(rng_setup[1])
+            # construction order: regression, every state model's samplers, state
+            rngs = [L.bo_ssvs_rng(reg)]
+            for b in range(nb):
+                rngs += [L.bo_ssm_block_rng(m, b, v) for v in range(nvar[b])]
+            rngs.append(L.bo_ssm_state_rng(m))
+            for rp in rngs:
+                L.bo_rng_seed_mt(C.c_void_p(rp) if isinstance(rp, int) else rp,
+                                 L.bo_seed_rng(C.byref(glob)))
+            # (ArPosteriorSampler::draw_phi proposes with rmvn_ivar: GlobalRng::rng)
+            L.bo_ssm_set_global_rng.argtypes = [C.c_void_p, C.c_void_p]
+            L.bo_ssm_set_global_rng(m, C.byref(glob))
+        else:
+            seed, chain = int(rng_setup[1]), int(rng_setup[2])
+            L.bo_rng_seed_philox(L.bo_ssvs_rng(reg), seed, chain, 0, 0)
+            for b in range(nb):
+                for v in range(nvar[b]):
+                    L.bo_rng_seed_philox(C.c_void_p(L.bo_ssm_block_rng(m, b, v)), seed, chain,
+                                         L.bo_ssm_block_stream_id(m, b, v), 0)
+            L.bo_rng_seed_philox(L.bo_ssm_state_rng(m), seed, chain, 2, 0)
+        if set_sigsq is not None:
+            for b in range(nb):
+                L.bo_ssm_block_set_sigsq(m, b, _dp(f64(set_sigsq[b])))
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        var = np.zeros((nsweeps, nb, 2))
+        phi = np.zeros((nsweeps, nb, 16))
+        nkeep = nsweeps // state_every if state_every > 0 else 0
+        state = np.zeros((nkeep, T, dim))
+        g = np.zeros(p, dtype=np.uint8)
+        bb = np.zeros(p)
+        s = C.c_double()
+        status = 0
+        kept = 0
+        for i in range(nsweeps):
+            status = L.bo_ssm_draw(m)
+            if status:
+                break
+            L.bo_ssvs_get_state(reg, _u8(g), _dp(bb), C.byref(s))
+            gam[i] = g
+            beta[i] = bb
+            sig[i] = s.value
+            for b in range(nb):
+                L.bo_ssm_block_get(m, b, _dp(var[i, b]), None, None, _dp(phi[i, b]))
+            if state_every > 0 and i % state_every == state_every - 1:
+                state[kept] = np.ctypeslib.as_array(L.bo_ssm_state(m), (T, dim))
+                kept += 1
+        suf_n = np.zeros((nb, 2))
+        suf_ss = np.zeros((nb, 2))
+        ar_suf = {}
+        for b in range(nb):
+            L.bo_ssm_block_get(m, b, None, _dp(suf_n[b]), _dp(suf_ss[b]), None)
+            if blocks[b]["kind"] == 4:
+                Lg = blocks[b]["lags"]
+                xtx = np.zeros((Lg, Lg)); xty = np.zeros(Lg)
+                yty = C.c_double(); n = C.c_double()
+                L.bo_ssm_block_get_ar_suf.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p,
+                                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
+                L.bo_ssm_block_get_ar_suf(m, b, _dp(xtx), _dp(xty), C.byref(yty), C.byref(n))
+                ar_suf[b] = dict(xtx=xtx, xty=xty, yty=yty.value, n=n.value)
+        L.bo_ssm_destroy(m)
+        return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, phi=phi, state=state,
+                    status=status, suf_n=suf_n, suf_ss=suf_ss, ar_suf=ar_suf)
+
+    def ssg_forecast(self, rng, T, newX, beta, sigsq_obs, blocks, sigsq, phi, final_state):
+        """simulate_forecast of the general model at fixed parameters: sigsq (nblocks x 2),
+        phi (nblocks x 16)"""
+        h, p = newX.shape
+        prior = dict(b=np.zeros(p), ominv=np.eye(p), df=1.0, sigma_guess=1.0,
+                     pi=np.full(p, 0.5))
+        blocks = [dict(b) for b in blocks]
+        for i, b in enumerate(blocks):
+            if b["kind"] == 4:
+                b["initial_phi"] = np.asarray(phi[i][:b["lags"]], float)
+        m = self._ssg_build(np.zeros(T), np.zeros((T, p)), None, prior, blocks)
+        for b in range(len(blocks)):
+            self.lib.bo_ssm_block_set_sigsq(m, b, _dp(f64(sigsq[b])))
+        out = np.zeros(h)
+        self.lib.bo_ssm_forecast_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                   c_double_p, c_double_p, C.c_double, c_double_p,
+                                                   c_double_p]
+        self.lib.bo_ssm_forecast_model(m, C.byref(rng), h, p, _dp(fcol(newX)), _dp(f64(beta)),
+                                       float(sigsq_obs), _dp(f64(final_state)), _dp(out))
+        self.lib.bo_ssm_destroy(m)
+        return out
+
     def ss_impute_state(self, y, X, observed, beta, gamma, sigsq_obs,
                         sigsq_level, a0, P0, rng):
         T, p = X.shape
@@ -1283,6 +1422,51 @@ class Ref:
             _dp(var), _dp(state), _dp(out_ar)))
         return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, state=state,
                     ar_phi=out_ar[:, :L].copy(), ar_sigsq=out_ar[:, L].copy())
+
+    def ssg_run(self, y, X, observed, prior, opts, blocks, seed, init_gamma, nsweeps,
+                state_every=1):
+        """the compiled reference on a general list of state models (ref_ssg_run)"""
+        from cases import general_arrays
+        T, p = X.shape
+        nb = len(blocks)
+        kinds, ip, vpar, phi0, a0, P0 = general_arrays(blocks)
+        dim = len(a0)
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        var = np.zeros((nsweeps, nb, 2))
+        phi = np.zeros((nsweeps, nb, 16))
+        nkeep = nsweeps // state_every if state_every > 0 else 0
+        state = np.zeros((max(nkeep, 1), T, dim))
+        o = self._opts(opts)
+        obs = (None if observed is None
+               else np.ascontiguousarray(observed, dtype=np.uint8))
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        ipc = np.ascontiguousarray(ip, np.int32)
+        self._check(self.lib.ref_ssg_run(
+            T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs), _dp(f64(prior["b"])),
+            _dp(fcol(prior["ominv"])), C.c_double(prior["df"]),
+            C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])), C.byref(o), nb,
+            kinds.ctypes.data_as(C.POINTER(C.c_int)), ipc.ctypes.data_as(C.POINTER(C.c_int)),
+            _dp(f64(vpar)), _dp(f64(phi0)), _dp(f64(a0)), _dp(f64(P0)), C.c_uint64(seed),
+            _u8(g0), nsweeps, int(state_every), _u8(gam), _dp(beta), _dp(sig), _dp(var),
+            _dp(phi), _dp(state)))
+        return dict(gamma=gam, beta=beta, sigsq=sig, variances=var, phi=phi,
+                    state=state[:nkeep])
+
+    def ssg_forecast(self, T, newX, beta, sigsq_obs, blocks, sigsq, phi, final_state, seed):
+        from cases import general_arrays
+        h, p = newX.shape
+        kinds, ip, _, _, _, _ = general_arrays(blocks)
+        out = np.zeros(h)
+        g = (np.asarray(beta) != 0).astype(np.uint8)
+        ipc = np.ascontiguousarray(ip, np.int32)
+        self._check(self.lib.ref_ssg_forecast(
+            T, p, _dp(np.zeros(T)), _dp(np.zeros((T, p))), _dp(f64(beta)), _u8(g),
+            C.c_double(sigsq_obs), len(blocks), kinds.ctypes.data_as(C.POINTER(C.c_int)),
+            ipc.ctypes.data_as(C.POINTER(C.c_int)), _dp(f64(sigsq)), _dp(f64(phi)),
+            _dp(f64(final_state)), h, _dp(fcol(newX)), C.c_uint64(seed), _dp(out)))
+        return out
 
     def ss_forecast(self, y, X, beta, gamma, sigsq_obs, sigsq_level, final_state,
                     newX, seed):

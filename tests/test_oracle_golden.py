@@ -386,6 +386,72 @@ def test_structural_forecast_known_answers(oracle):
         assert np.max(np.abs(got - g[key + "_forecast"])) < 1e-12, key
 
 
+GENERAL_GOLDENS = ["ssg_seasonal_only", "ssg_ar_only", "ssg_weekly_annual",
+                   "ssg_seasonal_first_missing", "ssg_duration_t0", "ssg_two_ar",
+                   "ssg_level_and_trend", "ssg_big52"]
+
+
+@pytest.mark.parametrize("name", GENERAL_GOLDENS)
+def test_general_state_lists_match_reference(oracle, name):
+    """f2, the general form: state models added in any order -- a seasonal-only and an
+    autoregression-only model, seasonal blocks with season_duration > 1 (T / RQR switch at
+    new_season) and a time_of_first_observation, two seasonal blocks (weekly + a 4-season
+    cycle of duration 7), a seasonal block ahead of the level, two autoregression blocks,
+    a local level beside a local linear trend, nseasons = 52 with duration 7 (m = 53)"""
+    from cases import blocks_of
+    g = load(name)
+    blocks = blocks_of(g)
+    obs = g["observed"]
+    o = oracle.ssg_run(g["y"], g["X"], None if obs.all() else obs, prior_of(g), opts_of(g),
+                       blocks, ("mt", int(g["seed"])), g["init_gamma"], int(g["nsweeps"]),
+                       int(g["state_every"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < RTOL
+    assert relerr(o["sigsq"], g["sigsq"]) < RTOL
+    assert relerr(o["variances"], g["variances"], 1e-300) < RTOL
+    assert relerr(o["phi"], g["phi"], 1e-300) < RTOL
+    assert o["state"].shape == g["state"].shape
+    assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
+
+
+def test_general_forecast_known_answers(oracle):
+    """simulate_forecast with seasonal blocks of duration > 1: the reference simulates
+    forecast step i with the transition matrix and state errors of time T - 2 + i"""
+    from cases import blocks_of
+    g = load("kat_general_forecast")
+    for key in g["shapes"]:
+        key = str(key)
+        blocks = blocks_of(g, key + "_")
+        got = oracle.ssg_forecast(oracle.rng_mt(int(g["seed"])), int(g[key + "_T"]), g["newX"],
+                                  g["beta"], float(g["sigsq_obs"]), blocks, g[key + "_sigsq"],
+                                  g[key + "_phi"], g[key + "_final_state"])
+        assert np.max(np.abs(got - g[key + "_forecast"])) < 1e-12, key
+
+
+def test_general_form_repeats_the_template(oracle):
+    """the block list [trend, seasonal(ns, 1), ar] is the template of rounds 2-3, draw for
+    draw (both Philox and MT generators)"""
+    from cases import bsts_priors, general_spec, structural_data, structural_spec
+    X, y, _, obs = structural_data(90, 5, 2, 4, seed=8, missing_frac=0.05, ar_coef=[0.5])
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    spec = structural_spec(y, 2, 4, ar_lags=1)
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(5, np.uint8)
+    blocks = general_spec(y, [("trend",), ("seasonal", 4, 1), ("ar", 1)])
+    for setup in (("philox", 5, 3), ("mt", 77)):
+        a = oracle.ssm_run(y, X, obs, prior, opts, spec, setup, g0, 15)
+        b = oracle.ssg_run(y, X, obs, prior, opts, blocks, setup, g0, 15)
+        assert a["status"] == 0 and b["status"] == 0
+        assert np.array_equal(a["gamma"], b["gamma"])
+        assert np.array_equal(a["beta"], b["beta"]) and np.array_equal(a["state"], b["state"])
+        assert np.array_equal(a["variances"][:, 0], b["variances"][:, 0, 0])
+        assert np.array_equal(a["variances"][:, 1], b["variances"][:, 0, 1])
+        assert np.array_equal(a["variances"][:, 2], b["variances"][:, 1, 0])
+        assert np.array_equal(a["ar_phi"][:, 0], b["phi"][:, 2, 0])
+        assert np.array_equal(a["ar_sigsq"], b["variances"][:, 2, 0])
+
+
 # ------------------------------------------------------------------ probit
 def test_truncated_normal_known_answers(oracle):
     """rtrun_norm_mt: rejection from the normal (cut below the mean) and the
