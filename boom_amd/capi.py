@@ -127,6 +127,11 @@ SIGNATURES = {
     "ba_ss_add_ar": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
                                C.c_double, _dp, _dp, _dp]),
     "ba_ss_get_ar": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "ba_ss_clear_state_models": (C.c_int, [C.c_void_p]),
+    "ba_ss_add_state_model": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)] + [_dp] * 7),
+    "ba_ss_state_dimension": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ba_ss_get_state_model": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32] + [_dp] * 8),
+    "ba_ss_get_state_draw": (C.c_int, [C.c_void_p, C.c_int64, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_impute_state": (C.c_int, [C.c_void_p]),
     "ba_ss_forecast": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
@@ -534,6 +539,57 @@ class Engine:
         self._check(self.lib.ba_ss_get_ar(self._h, chain, _p(phi), C.byref(sig), _p(xtx), _p(xty),
                                           C.byref(yty), C.byref(n)))
         return dict(phi=phi, sigsq=sig.value, xtx=xtx, xty=xty, yty=yty.value, n=n.value)
+
+    def ss_set_state_models(self, blocks):
+        """a general list of state models, in the order they are added: dicts with kind
+        (1 local level, 2 local linear trend, 3 seasonal, 4 autoregression), nseasons,
+        duration, t0, lags, df, sigma_guess, sigma_upper_limit, initial_sigma (one entry
+        per variance parameter), initial_phi, a0, P0 (tests/cases.py: general_spec)"""
+        self._check(self.lib.ba_ss_clear_state_models(self._h))
+        self._blocks = []
+        for b in blocks:
+            kind = int(b["kind"])
+            ip = np.zeros(3, np.int32)
+            if kind == 3:
+                ip[:] = (b["nseasons"], b["duration"], b.get("t0", 0))
+            elif kind == 4:
+                ip[0] = b["lags"]
+            arrs = [np.ascontiguousarray(b[k], dtype=np.float64) for k in
+                    ("df", "sigma_guess", "sigma_upper_limit", "initial_sigma")]
+            ph = np.ascontiguousarray(b.get("initial_phi", np.zeros(0)), dtype=np.float64)
+            a0 = np.ascontiguousarray(b["a0"], dtype=np.float64)
+            p0 = np.ascontiguousarray(b["P0"], dtype=np.float64)
+            self._check(self.lib.ba_ss_add_state_model(
+                self._h, kind, ip.ctypes.data_as(C.POINTER(C.c_int32)), *[_p(a) for a in arrs],
+                _p(ph) if (kind == 4 and ph.size) else None, _p(a0), _p(p0)))
+            self._blocks.append(dict(kind=kind, nvar=2 if kind == 2 else 1,
+                                     lags=int(ip[0]) if kind == 4 else 0))
+        m, nb = C.c_int32(), C.c_int32()
+        self._check(self.lib.ba_ss_state_dimension(self._h, C.byref(m), C.byref(nb)))
+        self._ssm_dim = m.value
+        self._ar_lags = 0
+
+    def ss_get_state_model(self, chain, block):
+        b = self._blocks[block]
+        nv, L = b["nvar"], b["lags"]
+        var, n, ss = np.zeros(nv), np.zeros(nv), np.zeros(nv)
+        out = dict(variances=var, suf_n=n, suf_ss=ss)
+        if L:
+            phi, xtx, xty = np.zeros(L), np.zeros((L, L)), np.zeros(L)
+            yty, an = C.c_double(), C.c_double()
+            self._check(self.lib.ba_ss_get_state_model(
+                self._h, chain, block, _p(var), _p(n), _p(ss), _p(phi), _p(xtx), _p(xty),
+                C.cast(C.byref(yty), _dp), C.cast(C.byref(an), _dp)))
+            out.update(phi=phi, xtx=xtx, xty=xty, yty=yty.value, n=an.value)
+        else:
+            self._check(self.lib.ba_ss_get_state_model(self._h, chain, block, _p(var), _p(n), _p(ss),
+                                                       None, None, None, None, None))
+        return out
+
+    def ss_get_state_draw(self, chain):
+        st = np.zeros((self.T, self._ssm_dim))
+        self._check(self.lib.ba_ss_get_state_draw(self._h, chain, _p(st)))
+        return st
 
     def ss_get_structural(self, chain):
         st = np.zeros((self.T, self._ssm_dim))

@@ -376,16 +376,18 @@ struct ba_engine {
   int logit_words = 0;
   int64_t logit_req_batch = 0;     // requests per GEMM launch (bounds the planes)
   int64_t logit_cols_built = 0, logit_cols_requested = 0, logit_replays = 0;   // (diagnostics)
-  // structural state (trend + seasonal, ssm_kernel.hip) instead of the local level
+  // structural state (a list of state models, ssm_kernel.hip) instead of the local level
   bool ssm_set = false;
-  SsmParams ssm{};                 // the host's copy of the specification (device pointers filled per launch)
-  double ssm_initial_sigsq[3] = {1, 1, 1};
-  DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;
-  // the structural state's ArStateModel block (ssm.ar_lags > 0)
-  double ar_initial_sigsq = 1.0, ar_initial_phi[SSM_MAX] = {};
-  DevBuf<double> dar_phi, dar_sigsq, dar_suf;
-  DevBuf<uint64_t> dpos_ar;
-  DevBuf<uint64_t> dpos_var;
+  SsgSpec ssg{};                   // the host's copy of the specification
+  DevBuf<uint8_t> dssg_spec;       // ... and the device's
+  double ssg_initial_sigsq[SSG_MAX_VAR] = {};
+  double ssg_initial_phi[SSG_MAX_AR][AR_MAX] = {};
+  // the template of ba_ss_set_structural (level / slope / seasonal -> variance index, -1: none)
+  int ssg_template_var[3] = {-1, -1, -1};
+  int ssg_template_ar = -1;        // ... and the block ba_ss_add_ar appended
+  DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;   // chains x SSG_MAX_VAR (sigsq, n, ss)
+  DevBuf<double> dar_phi, dar_suf;                         // chains x SSG_MAX_AR x (AR_MAX | AR_SUF_STRIDE)
+  DevBuf<uint64_t> dpos_var;                               // chains x SSG_MAX_VAR
 };
 
 namespace {
@@ -868,9 +870,9 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
   }
 }
 
-// per chain: K (m T) | state (m T) | smoothed disturbances (4 T) | normals (<= 5 T + m + 1)
+// per chain: K (m T) | state (m T) | smoothed disturbances (nvar T) | normals (<= (nvar + 1) T + m + 1)
 int64_t ssm_work_stride(const ba_engine &e) {
-  return (int64_t)(2 * e.ssm.m + 4 + 5) * e.T + 64;
+  return (int64_t)(2 * e.ssg.m + 2 * e.ssg.nvar + 1) * e.T + SSG_MAX_STATE + 72;
 }
 
 // the local-level path of a series of at most LM_TP steps runs lane-major
@@ -923,15 +925,20 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.prep_level_sigsq = e->dprep_level.ptr;
   S.zbuf = e->ss_zbuf;
   if (e->ssm_set) {
-    S.ssm = e->ssm;
+    S.ssm.spec = reinterpret_cast<const SsgSpec *>(e->dssg_spec.ptr);
+    S.ssm.m = e->ssg.m;
+    S.ssm.nblocks = e->ssg.nblocks;
+    S.ssm.nvar = e->ssg.nvar;
+    S.ssm.nar = e->ssg.nar;
+    S.ssm.ld = e->ssg.ld;
+    S.ssm.bl = e->ssg.bl;
+    S.ssm.nerr = e->ssg.nerr;
     S.ssm.var_sigsq = e->dssm_sigsq.ptr;
     S.ssm.var_n = e->dssm_n.ptr;
     S.ssm.var_ss = e->dssm_ss.ptr;
     S.ssm.pos_var = e->dpos_var.ptr;
     S.ssm.ar_phi = e->dar_phi.ptr;
-    S.ssm.ar_sigsq = e->dar_sigsq.ptr;
     S.ssm.ar_suf = e->dar_suf.ptr;
-    S.ssm.pos_ar = e->dpos_ar.ptr;
     S.ssm.work = e->dssm_work.ptr;
     S.ssm.work_stride = ssm_work_stride(*e);
   }
@@ -1990,7 +1997,7 @@ int ba_seed(ba_engine *e, uint64_t seed) {
   if (e->dpos_sss.ptr) HIP_TRY(hipMemsetAsync(e->dpos_sss.ptr, 0, C * 8, s));
   if (e->dpos_ada.ptr) HIP_TRY(hipMemsetAsync(e->dpos_ada.ptr, 0, C * 8, s));
   if (e->dpos_level.ptr) HIP_TRY(hipMemsetAsync(e->dpos_level.ptr, 0, C * 8, s));
-  if (e->dpos_var.ptr) HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * 3 * 8, s));
+  if (e->dpos_var.ptr) HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * SSG_MAX_VAR * 8, s));
   e->probit_sweep = 0;
   if (e->dpos_state.ptr) HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
   if (e->dpos_forecast.ptr) HIP_TRY(hipMemsetAsync(e->dpos_forecast.ptr, 0, C * 8, s));
@@ -3101,31 +3108,31 @@ static int ss_prepare(ba_engine *e) {
     HIP_TRY(hipMemsetAsync(e->dpos_state.ptr, 0, C * 8, s));
     HIP_TRY(hipMemsetAsync(e->dss_scratch.ptr, 0, C * SS_SCRATCH_ARRAYS * T * 8, s));
     if (e->ssm_set) {
-      HIP_TRY(e->dssm_sigsq.resize(C * 3));
-      HIP_TRY(e->dssm_n.resize(C * 3));
-      HIP_TRY(e->dssm_ss.resize(C * 3));
-      HIP_TRY(e->dpos_var.resize(C * 3));
+      const size_t NV = SSG_MAX_VAR;
+      HIP_TRY(e->dssm_sigsq.resize(C * NV));
+      HIP_TRY(e->dssm_n.resize(C * NV));
+      HIP_TRY(e->dssm_ss.resize(C * NV));
+      HIP_TRY(e->dpos_var.resize(C * NV));
       HIP_TRY(e->dssm_work.resize(C * (size_t)ssm_work_stride(*e)));
-      std::vector<double> v0(C * 3);
+      HIP_TRY(e->dssg_spec.resize(sizeof(SsgSpec)));
+      HIP_TRY(hipMemcpy(e->dssg_spec.ptr, &e->ssg, sizeof(SsgSpec), hipMemcpyHostToDevice));
+      std::vector<double> v0(C * NV);
       for (size_t c = 0; c < C; ++c)
-        for (int i = 0; i < 3; ++i) v0[c * 3 + i] = e->ssm_initial_sigsq[i];
-      HIP_TRY(hipMemcpy(e->dssm_sigsq.ptr, v0.data(), C * 3 * 8, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemsetAsync(e->dssm_n.ptr, 0, C * 3 * 8, s));
-      HIP_TRY(hipMemsetAsync(e->dssm_ss.ptr, 0, C * 3 * 8, s));
-      HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * 3 * 8, s));
+        for (size_t i = 0; i < NV; ++i) v0[c * NV + i] = e->ssg_initial_sigsq[i];
+      HIP_TRY(hipMemcpy(e->dssm_sigsq.ptr, v0.data(), C * NV * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemsetAsync(e->dssm_n.ptr, 0, C * NV * 8, s));
+      HIP_TRY(hipMemsetAsync(e->dssm_ss.ptr, 0, C * NV * 8, s));
+      HIP_TRY(hipMemsetAsync(e->dpos_var.ptr, 0, C * NV * 8, s));
       HIP_TRY(hipMemsetAsync(e->dssm_work.ptr, 0, C * (size_t)ssm_work_stride(*e) * 8, s));
-      if (e->ssm.ar_lags > 0) {
-        HIP_TRY(e->dar_phi.resize(C * SSM_MAX));
-        HIP_TRY(e->dar_sigsq.resize(C));
-        HIP_TRY(e->dar_suf.resize(C * AR_SUF_STRIDE));
-        HIP_TRY(e->dpos_ar.resize(C));
-        std::vector<double> ph(C * SSM_MAX, 0.0), sg(C, e->ar_initial_sigsq);
+      if (e->ssg.nar > 0) {
+        HIP_TRY(e->dar_phi.resize(C * SSG_MAX_AR * AR_MAX));
+        HIP_TRY(e->dar_suf.resize(C * SSG_MAX_AR * AR_SUF_STRIDE));
+        std::vector<double> ph(C * SSG_MAX_AR * AR_MAX, 0.0);
         for (size_t c = 0; c < C; ++c)
-          for (int i = 0; i < e->ssm.ar_lags; ++i) ph[c * SSM_MAX + i] = e->ar_initial_phi[i];
+          for (int a = 0; a < SSG_MAX_AR; ++a)
+            for (int i = 0; i < AR_MAX; ++i) ph[(c * SSG_MAX_AR + a) * AR_MAX + i] = e->ssg_initial_phi[a][i];
         HIP_TRY(hipMemcpy(e->dar_phi.ptr, ph.data(), ph.size() * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e->dar_sigsq.ptr, sg.data(), C * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemsetAsync(e->dar_suf.ptr, 0, C * AR_SUF_STRIDE * 8, s));
-        HIP_TRY(hipMemsetAsync(e->dpos_ar.ptr, 0, C * 8, s));
+        HIP_TRY(hipMemsetAsync(e->dar_suf.ptr, 0, C * SSG_MAX_AR * AR_SUF_STRIDE * 8, s));
       }
     }
     HIP_TRY(hipStreamSynchronize(s));  // (the host vectors above go out of scope)
@@ -3214,6 +3221,166 @@ int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_gues
   return BA_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// the scalars of the specification that follow from the block list
+void ssg_finish(SsgSpec &q) {
+  q.ld = q.m | 1;
+  q.bl = q.m <= 16 ? 64 : (q.m <= 32 ? 32 : 16);
+  q.nerr = q.nvar;
+}
+// ArModel's constructor: "Attempt to initialize ArModel with an illegal value of the
+// autoregression coefficients." (the quick bound, then the step-down recursion)
+bool ar_stationary_host(const double *phi, int lags) {
+  double a[AR_MAX], b[AR_MAX], sum = 0;
+  for (int i = 0; i < lags; ++i) { a[i] = phi[i]; sum += std::fabs(a[i]); }
+  if (sum < 1) return true;
+  for (int k = lags; k >= 1; --k) {
+    const double r = a[k - 1];
+    if (!(std::fabs(r) < 1)) return false;
+    for (int j = 0; j + 1 < k; ++j) b[j] = (a[j] + r * a[k - 2 - j]) / (1 - r * r);
+    for (int j = 0; j + 1 < k; ++j) a[j] = b[j];
+  }
+  return true;
+}
+// the Philox sampler id of variance parameter v of the block about to be appended: level 1,
+// slope 6, seasonal 7, autoregression 12 for the first block of its family (local level
+// and local linear trend are one family), + 16 for every earlier block of the family
+int ssg_stream_id(const SsgSpec &q, int kind, int v) {
+  const int fam = kind == SSG_LOCAL_LINEAR_TREND ? SSG_LOCAL_LEVEL : kind;
+  int occ = 0;
+  for (int i = 0; i < q.nblocks; ++i) {
+    const int k = q.blk[i].kind;
+    if ((k == SSG_LOCAL_LINEAR_TREND ? SSG_LOCAL_LEVEL : k) == fam) ++occ;
+  }
+  const int base = kind == SSG_SEASONAL ? 7 : (kind == SSG_AR ? 12 : (v == 0 ? 1 : 6));
+  return base + 16 * occ;
+}
+// model->add_state(...) on the engine's copy of the specification
+int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *var_df,
+            const double *var_sigma_guess, const double *var_sigma_upper_limit,
+            const double *var_initial_sigma, const double *initial_phi,
+            const double *initial_state_mean, const double *initial_state_variance) {
+  SsgSpec &q = e->ssg;
+  if (!var_df || !var_sigma_guess || !var_sigma_upper_limit || !var_initial_sigma ||
+      !initial_state_mean || !initial_state_variance)
+    return fail(BA_E_INVALID, "null argument");
+  if (q.nblocks >= SSG_MAX_BLOCKS) return fail(BA_E_INVALID, "more than 8 state models");
+  SsgBlock k{};
+  k.kind = kind;
+  k.nvar = 1;
+  k.duration = 1;
+  k.ar_index = -1;
+  switch (kind) {
+    case SSG_LOCAL_LEVEL: k.dim = 1; break;
+    case SSG_LOCAL_LINEAR_TREND: k.dim = 2; k.nvar = 2; break;
+    case SSG_SEASONAL: {
+      if (!iparams) return fail(BA_E_INVALID, "null argument");
+      // SeasonalStateModelBase: "'nseasons' must be positive"; one season has no state
+      if (iparams[0] < 2) return fail(BA_E_INVALID, "nseasons must be at least 2");
+      if (iparams[1] < 1) return fail(BA_E_INVALID, "season_duration must be positive");
+      k.nseasons = iparams[0];
+      k.duration = iparams[1];
+      // new_season(t): (t - time_of_first_observation) is a multiple of the duration
+      k.phase = ((iparams[2] % k.duration) + k.duration) % k.duration;
+      k.dim = k.nseasons - 1;
+      break;
+    }
+    case SSG_AR:
+      if (!iparams) return fail(BA_E_INVALID, "null argument");
+      if (iparams[0] < 1) return fail(BA_E_INVALID, "lags must be positive");
+      if (iparams[0] > AR_MAX) return fail(BA_E_INVALID, "more than 16 lags");
+      if (q.nar >= SSG_MAX_AR) return fail(BA_E_INVALID, "more than 4 autoregression state models");
+      k.lags = iparams[0];
+      k.dim = k.lags;
+      k.ar_index = q.nar;
+      break;
+    default:
+      return fail(BA_E_INVALID, "state model kind must be 1 (local level), 2 (local linear trend), 3 (seasonal) or 4 (autoregression)");
+  }
+  if (q.m + k.dim > SSG_MAX_STATE) return fail(BA_E_INVALID, "state dimension exceeds 64");
+  if (q.nvar + k.nvar > SSG_MAX_VAR) return fail(BA_E_INVALID, "more than 16 variance parameters");
+  for (int v = 0; v < k.nvar; ++v) {
+    if (var_sigma_upper_limit[v] < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
+    if (kind == SSG_AR && !(var_initial_sigma[v] > 0)) return fail(BA_E_INVALID, "initial sigma must be positive");
+  }
+  for (int i = 0; i < k.dim; ++i) {
+    // (a multivariate initial state goes through a Cholesky factor in the reference: it
+    // needs a positive variance; the local level model alone does not)
+    const bool ok = initial_state_variance[i] > 0.0 ||
+                    (kind == SSG_LOCAL_LEVEL && initial_state_variance[i] == 0.0);
+    if (!ok) return fail(BA_E_INVALID, "initial state variances must be positive");
+  }
+  if (kind == SSG_AR && initial_phi && !ar_stationary_host(initial_phi, k.lags))
+    return fail(BA_E_INVALID, "the initial autoregression coefficients are not stationary");
+  k.first = q.m;
+  k.var0 = q.nvar;
+  for (int v = 0; v < k.nvar; ++v) {
+    const int vi = k.var0 + v;
+    // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
+    q.prior_df[vi] = 2 * (var_df[v] / 2.0);
+    q.prior_ss[vi] = 2 * (var_df[v] * var_sigma_guess[v] * var_sigma_guess[v] / 2.0);
+    q.sigma_max[vi] = var_sigma_upper_limit[v];
+    e->ssg_initial_sigsq[vi] = var_initial_sigma[v] * var_initial_sigma[v];
+    k.sid[v] = ssg_stream_id(q, kind, v);
+  }
+  for (int i = 0; i < k.dim; ++i) {
+    q.a0[k.first + i] = initial_state_mean[i];
+    q.P0[k.first + i] = initial_state_variance[i];
+  }
+  if (kind == SSG_AR) {
+    for (int i = 0; i < AR_MAX; ++i)
+      e->ssg_initial_phi[k.ar_index][i] = (initial_phi && i < k.lags) ? initial_phi[i] : 0.0;
+    q.nar += 1;
+  }
+  q.blk[q.nblocks] = k;
+  q.nblocks += 1;
+  q.m += k.dim;
+  q.nvar += k.nvar;
+  ssg_finish(q);
+  e->ssm_set = true;
+  e->ss_level_set = false;
+  e->dss_scratch.release();
+  return BA_OK;
+}
+void ssg_clear(ba_engine *e) {
+  e->ssg = SsgSpec{};
+  for (int i = 0; i < 3; ++i) e->ssg_template_var[i] = -1;
+  e->ssg_template_ar = -1;
+  e->ssm_set = false;
+  e->dss_scratch.release();
+}
+}  // namespace
+
+extern "C" {
+
+int ba_ss_clear_state_models(ba_engine *e) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  MUTATE(e);
+  ssg_clear(e);
+  return BA_OK;
+}
+
+int ba_ss_add_state_model(ba_engine *e, int32_t kind, const int32_t *iparams, const double *var_df,
+                          const double *var_sigma_guess, const double *var_sigma_upper_limit,
+                          const double *var_initial_sigma, const double *initial_phi,
+                          const double *initial_state_mean, const double *initial_state_variance) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  MUTATE(e);
+  if (e->ss_level_set) ssg_clear(e);   // (a local-level specification is replaced, not extended)
+  e->ss_level_set = false;
+  return ssg_add(e, kind, iparams, var_df, var_sigma_guess, var_sigma_upper_limit, var_initial_sigma,
+                 initial_phi, initial_state_mean, initial_state_variance);
+}
+
+int ba_ss_state_dimension(ba_engine *e, int32_t *state_dimension, int32_t *nblocks) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (state_dimension) *state_dimension = e->ssm_set ? e->ssg.m : (e->ss_level_set ? 1 : 0);
+  if (nblocks) *nblocks = e->ssm_set ? e->ssg.nblocks : (e->ss_level_set ? 1 : 0);
+  return BA_OK;
+}
+
 int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons, const double *var_df,
                          const double *var_sigma_guess, const double *var_sigma_upper_limit,
                          const double *var_initial_sigma, const double *initial_state_mean,
@@ -3226,34 +3393,26 @@ int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons, const do
   if (trend != 1 && trend != 2) return fail(BA_E_INVALID, "trend must be 1 (local level) or 2 (local linear trend)");
   if (nseasons != 0 && nseasons < 2) return fail(BA_E_INVALID, "nseasons must be 0 or at least 2");
   const int m = trend + (nseasons > 0 ? nseasons - 1 : 0);
-  if (m > SSM_MAX) return fail(BA_E_INVALID, "state dimension exceeds 16");
-  SsmParams q{};
-  q.m = m;
-  q.trend = trend;
-  q.nseasons = nseasons;
-  q.s0 = nseasons > 0 ? trend : -1;
+  if (m > SSG_MAX_STATE) return fail(BA_E_INVALID, "state dimension exceeds 64");
   for (int i = 0; i < 3; ++i) {
-    if (var_sigma_upper_limit[i] < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
-    // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
-    q.prior_df[i] = 2 * (var_df[i] / 2.0);
-    q.prior_ss[i] = 2 * (var_df[i] * var_sigma_guess[i] * var_sigma_guess[i] / 2.0);
-    q.sigma_max[i] = var_sigma_upper_limit[i];
-    e->ssm_initial_sigsq[i] = var_initial_sigma[i] * var_initial_sigma[i];
+    const bool used = i == 0 || (i == 1 && trend == 2) || (i == 2 && nseasons > 0);
+    if (used && var_sigma_upper_limit[i] < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
   }
-  for (int i = 0; i < m; ++i) {
-    // (a multivariate initial state goes through a Cholesky factor in the
-    // reference: it needs a positive variance; the local level model alone does not)
-    if (!(initial_state_variance[i] > 0.0) && !(trend == 1 && i == 0 && initial_state_variance[i] == 0.0))
-      return fail(BA_E_INVALID, "initial state variances must be positive");
-    q.a0[i] = initial_state_mean[i];
-    q.P0[i] = initial_state_variance[i];
+  ssg_clear(e);
+  int rc = ssg_add(e, trend == 2 ? SSG_LOCAL_LINEAR_TREND : SSG_LOCAL_LEVEL, nullptr, var_df, var_sigma_guess,
+                   var_sigma_upper_limit, var_initial_sigma, nullptr, initial_state_mean, initial_state_variance);
+  if (!rc && nseasons > 0) {
+    const int32_t ip[3] = {nseasons, 1, 0};
+    rc = ssg_add(e, SSG_SEASONAL, ip, var_df + 2, var_sigma_guess + 2, var_sigma_upper_limit + 2,
+                 var_initial_sigma + 2, nullptr, initial_state_mean + trend, initial_state_variance + trend);
   }
-  q.ar_lags = 0;
-  q.ar0 = m;
-  e->ssm = q;
-  e->ssm_set = true;
-  e->ss_level_set = false;
-  e->dss_scratch.release();
+  if (rc) {
+    ssg_clear(e);
+    return rc;
+  }
+  e->ssg_template_var[0] = 0;
+  e->ssg_template_var[1] = trend == 2 ? 1 : -1;
+  e->ssg_template_var[2] = nseasons > 0 ? trend : -1;
   return BA_OK;
 }
 
@@ -3263,79 +3422,89 @@ int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess
   if (!e) return fail(BA_E_INVALID, "null engine");
   MUTATE(e);
   if (!e->ssm_set) return fail(BA_E_STATE, "call ba_ss_set_structural first");
-  if (e->ssm.ar_lags > 0) return fail(BA_E_STATE, "the state already has an autoregression block");
+  if (e->ssg_template_ar >= 0) return fail(BA_E_STATE, "the state already has an autoregression block");
   if (!initial_state_mean || !initial_state_variance) return fail(BA_E_INVALID, "null argument");
   if (lags < 1) return fail(BA_E_INVALID, "lags must be positive");
-  if (e->ssm.m + lags > SSM_MAX) return fail(BA_E_INVALID, "state dimension exceeds 16");
-  if (sigma_upper_limit < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
-  if (!(initial_sigma > 0)) return fail(BA_E_INVALID, "initial sigma must be positive");
-  if (initial_phi) {
-    // ArModel's constructor: "Attempt to initialize ArModel with an illegal value of the
-    // autoregression coefficients." (the quick bound, then the step-down recursion)
-    double a[SSM_MAX], b[SSM_MAX], sum = 0;
-    for (int i = 0; i < lags; ++i) { a[i] = initial_phi[i]; sum += std::fabs(a[i]); }
-    bool ok = sum < 1;
-    if (!ok) {
-      ok = true;
-      for (int k = lags; k >= 1 && ok; --k) {
-        const double r = a[k - 1];
-        if (!(std::fabs(r) < 1)) { ok = false; break; }
-        for (int j = 0; j + 1 < k; ++j) b[j] = (a[j] + r * a[k - 2 - j]) / (1 - r * r);
-        for (int j = 0; j + 1 < k; ++j) a[j] = b[j];
-      }
-    }
-    if (!ok) return fail(BA_E_INVALID, "the initial autoregression coefficients are not stationary");
+  const int32_t ip[3] = {lags, 0, 0};
+  const int rc = ssg_add(e, SSG_AR, ip, &prior_df, &sigma_guess, &sigma_upper_limit, &initial_sigma, initial_phi,
+                         initial_state_mean, initial_state_variance);
+  if (rc) return rc;
+  e->ssg_template_ar = e->ssg.nblocks - 1;
+  return BA_OK;
+}
+
+// block `block` of one chain: its variance parameters, the state model's sufficient
+// statistics of the last sweep, and for an autoregression block its coefficients and ArModel
+// sufficient statistics
+int ba_ss_get_state_model(ba_engine *e, int64_t chain, int32_t block, double *variances, double *suf_n,
+                          double *suf_ss, double *phi, double *ar_xtx, double *ar_xty, double *ar_yty,
+                          double *ar_n) {
+  ENGINE_ACCESSOR(e);
+  if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
+    return fail(BA_E_STATE, "no structural state-space run yet");
+  if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  if (block < 0 || block >= e->ssg.nblocks) return fail(BA_E_INVALID, "state model index out of range");
+  int rc = ba_sync(e);
+  if (rc) return rc;
+  const SsgBlock &k = e->ssg.blk[block];
+  const bool is_ar = k.kind == SSG_AR;
+  if (!is_ar && (phi || ar_xtx || ar_xty || ar_yty || ar_n))
+    return fail(BA_E_INVALID, "not an autoregression state model");
+  HIP_TRY(pinned_reserve(e, (6 + AR_MAX + AR_SUF_STRIDE) * 8));
+  double *hv = (double *)e->pinned, *hphi = hv + 6, *hsuf = hphi + AR_MAX;
+  const size_t at = (size_t)chain * SSG_MAX_VAR + k.var0;
+  HIP_TRY(hipMemcpyAsync(hv, e->dssm_sigsq.ptr + at, (size_t)k.nvar * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(hv + 2, e->dssm_n.ptr + at, (size_t)k.nvar * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(hv + 4, e->dssm_ss.ptr + at, (size_t)k.nvar * 8, hipMemcpyDeviceToHost, e->stream));
+  if (is_ar) {
+    const size_t slot = (size_t)chain * SSG_MAX_AR + k.ar_index;
+    HIP_TRY(hipMemcpyAsync(hphi, e->dar_phi.ptr + slot * AR_MAX, AR_MAX * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(hsuf, e->dar_suf.ptr + slot * AR_SUF_STRIDE, AR_SUF_STRIDE * 8, hipMemcpyDeviceToHost,
+                           e->stream));
   }
-  SsmParams &q = e->ssm;
-  for (int i = 0; i < lags; ++i) {
-    if (!(initial_state_variance[i] > 0.0)) return fail(BA_E_INVALID, "initial state variances must be positive");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int v = 0; v < k.nvar; ++v) {
+    if (variances) variances[v] = hv[v];
+    if (suf_n) suf_n[v] = hv[2 + v];
+    if (suf_ss) suf_ss[v] = hv[4 + v];
   }
-  q.ar0 = q.m;
-  q.ar_lags = lags;
-  for (int i = 0; i < lags; ++i) {
-    q.a0[q.m + i] = initial_state_mean[i];
-    q.P0[q.m + i] = initial_state_variance[i];
-    e->ar_initial_phi[i] = initial_phi ? initial_phi[i] : 0.0;
+  if (is_ar) {
+    const int L = k.lags;
+    if (phi) std::memcpy(phi, hphi, (size_t)L * 8);
+    if (ar_xtx)
+      for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) ar_xtx[(size_t)j * L + i] = hsuf[(size_t)i * AR_MAX + j];
+    if (ar_xty) std::memcpy(ar_xty, hsuf + AR_SUF_XTY, (size_t)L * 8);
+    if (ar_yty) *ar_yty = hsuf[AR_SUF_YTY];
+    if (ar_n) *ar_n = hsuf[AR_SUF_N];
   }
-  q.m += lags;
-  // ChisqModel(df, sigma_guess): 2 alpha = df, 2 beta = df sigma^2
-  q.ar_prior_df = 2 * (prior_df / 2.0);
-  q.ar_prior_ss = 2 * (prior_df * sigma_guess * sigma_guess / 2.0);
-  q.ar_sigma_max = sigma_upper_limit;
-  e->ar_initial_sigsq = initial_sigma * initial_sigma;
-  e->dss_scratch.release();
   return BA_OK;
 }
 
 int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq, double *suf_xtx,
                  double *suf_xty, double *suf_yty, double *suf_n) {
-  ENGINE_ACCESSOR(e);
-  if (!e->ss_mode || !e->ssm_set || e->ssm.ar_lags == 0 || e->dar_phi.count == 0)
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (!e->ss_mode || !e->ssm_set || e->ssg_template_ar < 0 || e->dar_phi.count == 0)
     return fail(BA_E_STATE, "no structural run with an autoregression block yet");
+  return ba_ss_get_state_model(e, chain, e->ssg_template_ar, sigsq, nullptr, nullptr, phi, suf_xtx, suf_xty,
+                               suf_yty, suf_n);
+}
+
+// one chain's state draw, T x m (step t at [t * m, (t + 1) * m))
+int ba_ss_get_state_draw(ba_engine *e, int64_t chain, double *state) {
+  ENGINE_ACCESSOR(e);
+  if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
+    return fail(BA_E_STATE, "no structural state-space run yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  if (!state) return fail(BA_E_INVALID, "null argument");
   int rc = ba_sync(e);
   if (rc) return rc;
-  const int L = e->ssm.ar_lags;
-  const bool want_suf = suf_xtx || suf_xty || suf_yty || suf_n;
-  HIP_TRY(pinned_reserve(e, (SSM_MAX + 1 + AR_SUF_STRIDE) * 8));
-  double *hphi = (double *)e->pinned, *hsig = hphi + SSM_MAX, *hsuf = hsig + 1;
-  if (phi) HIP_TRY(hipMemcpyAsync(hphi, e->dar_phi.ptr + chain * SSM_MAX, (size_t)L * 8, hipMemcpyDeviceToHost, e->stream));
-  if (sigsq) HIP_TRY(hipMemcpyAsync(hsig, e->dar_sigsq.ptr + chain, 8, hipMemcpyDeviceToHost, e->stream));
-  if (want_suf)
-    HIP_TRY(hipMemcpyAsync(hsuf, e->dar_suf.ptr + chain * AR_SUF_STRIDE, AR_SUF_STRIDE * 8, hipMemcpyDeviceToHost,
-                           e->stream));
+  const size_t T = (size_t)e->T, m = (size_t)e->ssg.m;
+  HIP_TRY(pinned_reserve(e, m * T * 8));
+  HIP_TRY(hipMemcpyAsync(e->pinned, e->dssm_work.ptr + (size_t)chain * ssm_work_stride(*e) + m * T, m * T * 8,
+                         hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  if (phi) std::memcpy(phi, hphi, (size_t)L * 8);
-  if (sigsq) *sigsq = *hsig;
-  if (want_suf) {
-    std::vector<double> suf(hsuf, hsuf + AR_SUF_STRIDE);
-    if (suf_xtx)
-      for (int i = 0; i < L; ++i)
-        for (int j = 0; j < L; ++j) suf_xtx[(size_t)j * L + i] = suf[(size_t)i * SSM_MAX + j];
-    if (suf_xty) std::memcpy(suf_xty, &suf[AR_SUF_XTY], (size_t)L * 8);
-    if (suf_yty) *suf_yty = suf[AR_SUF_YTY];
-    if (suf_n) *suf_n = suf[AR_SUF_N];
-  }
+  std::memcpy(state, e->pinned, m * T * 8);
   return BA_OK;
 }
 
@@ -3345,23 +3514,29 @@ int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state, double *var
   if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
     return fail(BA_E_STATE, "no structural state-space run yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  if ((variances || suf_n || suf_ss) && e->ssg_template_var[0] < 0)
+    return fail(BA_E_STATE, "the state was not set with ba_ss_set_structural: use ba_ss_get_state_model");
+  if (state) {
+    const int rc = ba_ss_get_state_draw(e, chain, state);
+    if (rc) return rc;
+  }
   int rc = ba_sync(e);
   if (rc) return rc;
-  // (one batch through the pinned staging buffer: state | variances | n | sums of squares)
-  const size_t T = (size_t)e->T, m = (size_t)e->ssm.m;
-  HIP_TRY(pinned_reserve(e, (m * T + 9) * 8));
-  double *hstate = (double *)e->pinned, *hv = hstate + m * T;
-  if (state)
-    HIP_TRY(hipMemcpyAsync(hstate, e->dssm_work.ptr + (size_t)chain * ssm_work_stride(*e) + m * T, m * T * 8,
-                           hipMemcpyDeviceToHost, e->stream));
-  if (variances) HIP_TRY(hipMemcpyAsync(hv, e->dssm_sigsq.ptr + chain * 3, 24, hipMemcpyDeviceToHost, e->stream));
-  if (suf_n) HIP_TRY(hipMemcpyAsync(hv + 3, e->dssm_n.ptr + chain * 3, 24, hipMemcpyDeviceToHost, e->stream));
-  if (suf_ss) HIP_TRY(hipMemcpyAsync(hv + 6, e->dssm_ss.ptr + chain * 3, 24, hipMemcpyDeviceToHost, e->stream));
+  // (one batch through the pinned staging buffer: variances | n | sums of squares)
+  const size_t NV = SSG_MAX_VAR;
+  HIP_TRY(pinned_reserve(e, 3 * NV * 8));
+  double *hv = (double *)e->pinned;
+  HIP_TRY(hipMemcpyAsync(hv, e->dssm_sigsq.ptr + chain * NV, NV * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(hv + NV, e->dssm_n.ptr + chain * NV, NV * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(hv + 2 * NV, e->dssm_ss.ptr + chain * NV, NV * 8, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  if (state) std::memcpy(state, hstate, m * T * 8);
-  if (variances) std::memcpy(variances, hv, 24);
-  if (suf_n) std::memcpy(suf_n, hv + 3, 24);
-  if (suf_ss) std::memcpy(suf_ss, hv + 6, 24);
+  for (int i = 0; i < 3; ++i) {
+    const int vi = e->ssg_template_var[i];
+    // (an unused slot reports what it was given: the initial value, no statistics)
+    if (variances) variances[i] = vi >= 0 ? hv[vi] : 0.0;
+    if (suf_n) suf_n[i] = vi >= 0 ? hv[NV + vi] : 0.0;
+    if (suf_ss) suf_ss[i] = vi >= 0 ? hv[2 * NV + vi] : 0.0;
+  }
   return BA_OK;
 }
 

@@ -8,28 +8,45 @@
 
 namespace boom_amd {
 
-// Structural state (ssm_kernel.hip): trend block (local level, or local linear
-// trend) + optional seasonal block; state dimension m <= SSM_MAX.  Variance
-// parameters are indexed 0 level, 1 slope, 2 seasonal.  An ArStateModel block
-// (ar_lags coefficients, one error variance, its own sampler) may follow.
-enum { SSM_MAX = 16 };
-// a chain's ArModel sufficient statistics: xtx (lags x lags at leading dimension
-// SSM_MAX) | xty | yty | n
-enum { AR_SUF_XTY = SSM_MAX * SSM_MAX, AR_SUF_YTY = AR_SUF_XTY + SSM_MAX, AR_SUF_N = AR_SUF_YTY + 1,
+// Structural state (ssm_kernel.hip): BOOM's block-diagonal state -- any list of state
+// models in the order they were added (StateSpaceModelBase::add_state): local level,
+// local linear trend, seasonal (nseasons, season duration), autoregression.  State
+// dimension m <= SSG_MAX_STATE (one lane per component), at most SSG_MAX_BLOCKS blocks,
+// SSG_MAX_VAR variance parameters (two for a local linear trend, one otherwise; an
+// autoregression block's error variance is one of them), SSG_MAX_AR autoregression
+// blocks of at most AR_MAX lags.
+enum { SSG_MAX_STATE = 64, SSG_MAX_BLOCKS = 8, SSG_MAX_VAR = 16, SSG_MAX_AR = 4, AR_MAX = 16 };
+enum { SSG_LOCAL_LEVEL = 1, SSG_LOCAL_LINEAR_TREND = 2, SSG_SEASONAL = 3, SSG_AR = 4 };
+// a chain's ArModel sufficient statistics (per autoregression block): xtx (lags x lags at
+// leading dimension AR_MAX) | xty | yty | n
+enum { AR_SUF_XTY = AR_MAX * AR_MAX, AR_SUF_YTY = AR_SUF_XTY + AR_MAX, AR_SUF_N = AR_SUF_YTY + 1,
        AR_SUF_STRIDE = AR_SUF_N + 1 };
+struct SsgBlock {
+  int32_t kind, first, dim, nvar;
+  int32_t var0;        // index of the block's first variance parameter
+  int32_t nseasons, duration, phase;   // seasonal: a new season starts at the times u with u % duration == phase
+  int32_t lags, ar_index;              // autoregression: which of the chain's coefficient / suf slots
+  int32_t sid[2];      // Philox sampler ids of the variance samplers (autoregression: its ArPosteriorSampler's)
+};
+// the specification, in device memory (read through the scalar cache)
+struct SsgSpec {
+  int32_t m, nblocks, nvar, nar;
+  int32_t ld;          // leading dimension of the state variance in LDS (odd)
+  int32_t bl;          // steps per block of the passes (64 for m <= 16, ... 16 for m <= 64)
+  int32_t nerr;        // state-error terms per step (one per variance parameter)
+  int32_t pad;
+  SsgBlock blk[SSG_MAX_BLOCKS];
+  double prior_df[SSG_MAX_VAR], prior_ss[SSG_MAX_VAR], sigma_max[SSG_MAX_VAR];
+  double a0[SSG_MAX_STATE], P0[SSG_MAX_STATE];   // initial state mean, variance (diagonal)
+};
 struct SsmParams {
-  int32_t m, trend, nseasons, s0;       // s0: first index of the seasonal block (-1: none)
-  int32_t ar_lags, ar0;                 // the autoregression block: size (0: none), first index
-  double prior_df[3], prior_ss[3], sigma_max[3];
-  double ar_prior_df, ar_prior_ss, ar_sigma_max;
-  double a0[SSM_MAX], P0[SSM_MAX];      // initial state mean, variance (diagonal)
-  double *var_sigsq, *var_n, *var_ss;   // chains x 3
-  uint64_t *pos_var;                    // chains x 3: streams 1, 6, 7
-  double *ar_phi;                       // chains x SSM_MAX
-  double *ar_sigsq;                     // chains
-  double *ar_suf;                       // chains x AR_SUF_STRIDE
-  uint64_t *pos_ar;                     // chains: stream 12 (the ArPosteriorSampler)
-  // per chain: gains K (m x T) | state (m x T) | smoothed disturbances (4 x T) | normals
+  const SsgSpec *spec;                  // device copy
+  int32_t m, nblocks, nvar, nar, ld, bl, nerr, pad;   // (the launch's copies of the scalars)
+  double *var_sigsq, *var_n, *var_ss;   // chains x SSG_MAX_VAR
+  uint64_t *pos_var;                    // chains x SSG_MAX_VAR: the variance samplers' stream positions
+  double *ar_phi;                       // chains x SSG_MAX_AR x AR_MAX
+  double *ar_suf;                       // chains x SSG_MAX_AR x AR_SUF_STRIDE
+  // per chain: gains K (m x T) | state (m x T) | smoothed disturbances (nerr x T) | normals
   double *work;
   int64_t work_stride;
 };

@@ -1,9 +1,16 @@
 // bsts structural time series for many chains: the state half of
-// StateSpacePosteriorSampler::draw() when the state is a trend block
-// (LocalLevelStateModel, or LocalLinearTrendStateModel with one
-// ZeroMeanMvnIndependenceSampler per variance) plus an optional
-// SeasonalStateModel(nseasons, season_duration = 1) and an optional
-// ArStateModel(lags) with its ArPosteriorSampler.  SURVEY 8f row f2.
+// StateSpacePosteriorSampler::draw() for BOOM's block-diagonal state -- ANY list of state
+// models in the order they were added with add_state (StateSpaceModelBase.hpp:637-638,
+// Filters/SparseMatrix.hpp:2196 BlockDiagonalMatrix):
+//   LocalLevelStateModel                     1 component,  ZeroMeanGaussianConjSampler
+//   LocalLinearTrendStateModel               2 components, one ZeroMeanMvnIndependenceSampler
+//                                            per variance (as bsts builds it)
+//   SeasonalStateModel(nseasons, duration)   nseasons - 1 components; T / RQR are the seasonal
+//                                            matrices on the steps INTO a new season and
+//                                            identity / zero inside one
+//                                            (SeasonalStateModel.cpp:89-104, :248-258)
+//   ArStateModel(lags)                       lags components, ArPosteriorSampler
+// SURVEY 8f row f2.
 //
 //   state model samplers                 (ZeroMeanGaussianConjSampler.cpp:57-60,
 //                                         ZeroMeanMvnIndependenceSampler.cpp:63-70)
@@ -12,7 +19,7 @@
 //       ScalarMarginalDistribution::update (ScalarKalmanFilter.cpp:41-83), vector state
 //       StateModelBase::simulate_initial_state (StateModel.cpp:47-56)
 //       simulate_state_error (LocalLevelStateModel.cpp:62-64, MvnBase.cpp:257,
-//                             SeasonalStateModel.cpp:124-146)
+//                             SeasonalStateModel.cpp:124-146, ArStateModel.cpp:85-90)
 //     Base::propagate_disturbances       (:858-891), fast_disturbance_smooth
 //                                          (ScalarKalmanFilter.cpp:168-196)
 //     observe_state (LocalLevelStateModel.cpp:52-58, LocalLinearTrend.cpp:53-63,
@@ -20,20 +27,29 @@
 //     observe_data_given_state
 //   ArPosteriorSampler::draw             (ArPosteriorSampler.cpp:52-143)
 //
-// State vector [trend (1 or 2) | seasonal (nseasons - 1) | autoregression (lags)],
-// dimension m <= 16.
+// State vector = the blocks one after the other, dimension m <= 64: lane j of a wavefront
+// holds component j of every state-sized vector.
 //   Z    ones at the first element of each block
-//   T    trend [1] or [[1, 1], [0, 1]]; seasonal: first row -1, ones below the diagonal;
-//        autoregression: first row phi, ones below the diagonal
-//   RQR  diagonal: level, slope and the first element of the seasonal / autoregression block
-// One chain per workgroup of two wavefronts: both share the adjusted
-// observations and the sweep's normals (stream_normals.h), then wave 0 runs the
-// three passes over time.  Lane j < m holds component j of every state-sized
-// vector and column j of the state variance P (16 registers).  Unlike the
-// local-level kernel (kalman_kernel.hip) the passes are SERIAL in time: the
-// per-step maps are m x m here and their compositions no longer fit a wave
-// scan.  As there, the data filter and the simulation filter share the gains, so
-// ONE filter runs on w = y* - y+, and one smoother on the difference.
+//   T    local level [1]; trend [[1, 1], [0, 1]]; seasonal: first row -1, ones below the
+//        diagonal; autoregression: first row phi, ones below the diagonal
+//   RQR  diagonal: level; level, slope; the first element of a seasonal / autoregression block
+// One chain per workgroup of two wavefronts: both share the adjusted observations and the
+// sweep's normals (stream_normals.h); then wave 1 runs the variance recursion (P_t, F_t,
+// K_t: it does not look at the data) while wave 0 simulates alpha+, y+, and wave 0 goes on
+// with the filter on w = y* - y+ (the data filter and the simulation filter share the
+// gains, so ONE filter runs on the difference), the backward pass and the mean correction.
+// The passes are SERIAL in time (the per-step maps are m x m and their compositions do not
+// fit a wave scan), so the design is about the length of a step's dependent chain:
+//   * every seasonal block sits in a ROTATING layout (its own cursor, advanced on the
+//     steps into a new season only): the transition moves nothing;
+//   * the state variance P lives in LDS (leading dimension odd: a lane per column and a
+//     lane per row are both conflict-free) and is advanced in the FILTERED form
+//     P_{t+1} = T (P_t - PZ PZ' / F) T' + RQR -- the same matrix as the reference's
+//     T P T' - (T PZ) K' + RQR -- because then one pass of lane k over ITS column applies
+//     the rank-one term and T from the left (three LDS round trips per step: the rows Z
+//     selects, the column pass, the pass over the lane's row that applies T' from the
+//     right).  (PZ_i PZ_k) / F is formed as a commutative product first and the two passes
+//     sum in the same order, so P stays exactly symmetric.
 #include <hip/hip_runtime.h>
 
 #include "ktimer.h"
@@ -47,7 +63,7 @@ namespace boom_amd {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int PLD = SSM_MAX + 1;   // leading dimension of the state variance in LDS
+constexpr int NB = SSG_MAX_BLOCKS;
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double sdpp(double x, double fill) {
@@ -64,7 +80,7 @@ __device__ __forceinline__ double rl(double x, int src) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// sum over the first 16 lanes (the vector's lanes; the others hold 0), everywhere
+// sum over the first 16 lanes (the others hold 0), everywhere
 __device__ __forceinline__ double row_total(double x) {
   x += sdpp<0x111, 0xf>(x, 0.0);  // row_shr:1
   x += sdpp<0x112, 0xf>(x, 0.0);
@@ -72,111 +88,61 @@ __device__ __forceinline__ double row_total(double x) {
   x += sdpp<0x118, 0xf>(x, 0.0);
   return rl(x, 15);
 }
+// sum over the wave (lanes that do not take part hold 0), everywhere.  SMALL: the state
+// has at most 16 components -- one row of lanes
+template <bool SMALL>
+__device__ __forceinline__ double wsum(double x) {
+  x += sdpp<0x111, 0xf>(x, 0.0);
+  x += sdpp<0x112, 0xf>(x, 0.0);
+  x += sdpp<0x114, 0xf>(x, 0.0);
+  x += sdpp<0x118, 0xf>(x, 0.0);
+  if (SMALL) return rl(x, 15);
+  return ((rl(x, 15) + rl(x, 31)) + rl(x, 47)) + rl(x, 63);
+}
+// the value of lane - 1 (lane 0: 0) / of lane + 1 (lane 63: 0): wave_shr:1 / wave_shl:1
+__device__ __forceinline__ double from_below(double x) { return sdpp<0x138, 0xf>(x, 0.0); }
+__device__ __forceinline__ double from_above(double x) { return sdpp<0x130, 0xf>(x, 0.0); }
 
-// the structure of the transition matrix
-struct Shape {
-  int m, trend, s0, ns;   // ns: size of the seasonal block (0: none)
-  int a0, na;             // the autoregression block: first index, size (0: none)
-  __device__ __forceinline__ bool seasonal(int i) const { return ns > 0 && i >= s0 && i < s0 + ns; }
-  __device__ __forceinline__ bool ar(int i) const { return na > 0 && i >= a0 && i < a0 + na; }
-};
+__device__ __forceinline__ int sprev(int c, int ns) { return c == 0 ? ns - 1 : c - 1; }   // the cursor after a move
+__device__ __forceinline__ int snext(int c, int ns) { return c + 1 == ns ? 0 : c + 1; }   // ... before it
+// how many of the times 1 .. t start a new season (u % duration == phase)
+__device__ __forceinline__ int seasons_started(int t, int duration, int phase) {
+  if (t < 0) return 0;
+  return (t >= phase ? (t - phase) / duration + 1 : 0) - (phase == 0 ? 1 : 0);
+}
 
-// The seasonal block is kept in a ROTATING layout: logical component i at time
-// t (0 = the current season's effect, i = the effect i seasons back) lives in
-// physical slot (c_t + i) mod ns, c_t = (-t) mod ns.  The transition
-// (new[0] = -sum(old), new[i] = old[i - 1]) then moves nothing: the slot of the
-// component that drops out, c_t - 1, receives the new first component and
-// becomes c_{t+1}.  For the variance that turns T P T' from O(m^2) data
-// movement into one new row / column per step.
-__device__ __forceinline__ int cursor_at(int t, int ns) {
-  const int r = t % ns;
-  return r == 0 ? 0 : ns - r;
-}
-__device__ __forceinline__ int cursor_prev(int c, int ns) { return c == 0 ? ns - 1 : c - 1; }   // c_{t+1} from c_t
-
-// y = T x for a vector held one component per lane; c: cursor of x's layout (the
-// result is in the next step's layout)
-// The autoregression block keeps its logical order (lane a0 + i = lag i); phl: this
-// lane's coefficient (0 outside the block).
-template <int TREND, bool SEAS, bool AR>
-__device__ __forceinline__ double vecT(const Shape &S, double x, int lane, int c, double phl) {
-  double y = x;
-  if (TREND == 2) {
-    const double x1 = rl(x, 1);
-    if (lane == 0) y = x + x1;
-  }
-  if (SEAS) {
-    const double tot = row_total(S.seasonal(lane) ? x : 0.0);
-    if (lane == S.s0 + cursor_prev(c, S.ns)) y = -tot;
-  }
-  if (AR) {
-    // new[0] = phi'old, new[i] = old[i - 1]  (AutoRegressionTransitionMatrix, SparseMatrix.cpp:1261-1310)
-    const double tot = row_total(phl * x);
-    const double below = sdpp<0x111, 0xf>(x, 0.0);   // row_shr:1
-    if (S.ar(lane)) y = (lane == S.a0) ? tot : below;
-  }
-  return y;
-}
-// y = T' x; c1: cursor of x's layout (the result is in the previous step's)
-template <int TREND, bool SEAS, bool AR>
-__device__ __forceinline__ double vecTt(const Shape &S, double x, int lane, int c1, double phl) {
-  double y = x;
-  if (TREND == 2) {
-    const double x0 = rl(x, 0);
-    if (lane == 1) y = x0 + x;
-  }
-  if (SEAS) {
-    const double first = rl(x, S.s0 + c1);
-    if (S.seasonal(lane)) y = (lane == S.s0 + c1) ? -first : x - first;
-  }
-  if (AR) {
-    // out[i] = phi_i x[0] + x[i + 1]  (Tmult, SparseMatrix.cpp:1286-1295)
-    const double first = rl(x, S.a0);
-    const double above = sdpp<0x101, 0xf>(x, 0.0);   // row_shl:1
-    if (S.ar(lane)) y = phl * first + ((lane + 1 < S.a0 + S.na) ? above : 0.0);
-  }
-  return y;
-}
-// Z'x, c: cursor of x's layout
-template <bool SEAS, bool AR>
-__device__ __forceinline__ double zdot(const Shape &S, double x, int c) {
-  double a = rl(x, 0);
-  if (SEAS) a += rl(x, S.s0 + c);
-  if (AR) a += rl(x, S.a0);
-  return a;
-}
 // a block of `n` doubles between HBM and LDS, by one wave
 __device__ __forceinline__ void blk_load(double *lds, const double *g, int n, int lane) {
   for (int i = lane; i < n; i += WAVE) lds[i] = g[i];
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
 }
 __device__ __forceinline__ void blk_store(double *g, const double *lds, int n, int lane) {
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
   for (int i = lane; i < n; i += WAVE) g[i] = lds[i];
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
 }
 
 // ---- ArPosteriorSampler::draw for one chain, by one (whole) wave.  Vectors sit one
 // component per lane (lane i < L), the L x L matrices in LDS at leading dimension
-// SSM_MAX; every lane reads the same random numbers.
+// AR_MAX; every lane reads the same random numbers.
 struct ArLds {
-  double X[SSM_MAX * SSM_MAX];    // xtx
-  double Lc[SSM_MAX * SSM_MAX];   // chol(xtx)
-  double Lp[SSM_MAX * SSM_MAX];   // chol(xtx / sigsq)
+  double X[AR_MAX * AR_MAX];    // xtx
+  double Lc[AR_MAX * AR_MAX];   // chol(xtx)
+  double Lp[AR_MAX * AR_MAX];   // chol(xtx / sigsq)
 };
 // lower Cholesky factor of `scale` * A (A symmetric, full storage); false: not positive definite
 __device__ __forceinline__ bool ar_chol(const double *A, double scale, double *Lc, int L, int lane) {
   for (int j = 0; j < L; ++j) {
     double sacc = 0.0;
     if (lane >= j && lane < L) {
-      sacc = A[lane * SSM_MAX + j] * scale;
-      for (int k = 0; k < j; ++k) sacc -= Lc[lane * SSM_MAX + k] * Lc[j * SSM_MAX + k];
+      sacc = A[lane * AR_MAX + j] * scale;
+      for (int k = 0; k < j; ++k) sacc -= Lc[lane * AR_MAX + k] * Lc[j * AR_MAX + k];
     }
     const double djj = rl(sacc, j);
     if (!(djj > 0.0)) return false;
     const double d = sqrt(djj);
-    if (lane == j) Lc[j * SSM_MAX + j] = d;
-    else if (lane > j && lane < L) Lc[lane * SSM_MAX + j] = sacc / d;
+    if (lane == j) Lc[j * AR_MAX + j] = d;
+    else if (lane > j && lane < L) Lc[lane * AR_MAX + j] = sacc / d;
     __builtin_amdgcn_wave_barrier();
   }
   return true;
@@ -185,8 +151,8 @@ __device__ __forceinline__ bool ar_chol(const double *A, double scale, double *L
 __device__ __forceinline__ double ar_lsolve(const double *Lc, double b, int L, int lane) {
   double x = 0.0;
   for (int i = 0; i < L; ++i) {
-    const double tot = row_total((lane < i) ? Lc[i * SSM_MAX + lane] * x : 0.0);
-    const double xi = (rl(b, i) - tot) / Lc[i * SSM_MAX + i];
+    const double tot = row_total((lane < i) ? Lc[i * AR_MAX + lane] * x : 0.0);
+    const double xi = (rl(b, i) - tot) / Lc[i * AR_MAX + i];
     if (lane == i) x = xi;
   }
   return x;
@@ -195,8 +161,8 @@ __device__ __forceinline__ double ar_lsolve(const double *Lc, double b, int L, i
 __device__ __forceinline__ double ar_ltsolve(const double *Lc, double b, int L, int lane) {
   double x = 0.0;
   for (int i = L - 1; i >= 0; --i) {
-    const double tot = row_total((lane > i && lane < L) ? Lc[lane * SSM_MAX + i] * x : 0.0);
-    const double xi = (rl(b, i) - tot) / Lc[i * SSM_MAX + i];
+    const double tot = row_total((lane > i && lane < L) ? Lc[lane * AR_MAX + i] * x : 0.0);
+    const double xi = (rl(b, i) - tot) / Lc[i * AR_MAX + i];
     if (lane == i) x = xi;
   }
   return x;
@@ -306,12 +272,11 @@ __device__ __forceinline__ double ar_rtrun_norm_2(SeqRng &rng, double mu, double
   return y * sigma + mu;
 }
 // draw_phi (up to three multivariate proposals, else one coefficient at a time) and
-// draw_sigma.  phi_l: the lane's coefficient (in: current, out: drawn); *sigsq likewise.
-__device__ __forceinline__ int ar_draw(ArLds &W, const SsmParams &Q, int chain, SeqRng &rng, double &phi_l,
-                                       double &sigsq, int lane) {
-  const int L = Q.ar_lags;
-  const double *suf = Q.ar_suf + (size_t)chain * AR_SUF_STRIDE;
-  for (int e = lane; e < SSM_MAX * SSM_MAX; e += WAVE) W.X[e] = suf[e];
+// draw_sigma.  suf: the block's sufficient statistics; phi_l: the lane's coefficient
+// (in: current, out: drawn); *sigsq likewise.
+__device__ __forceinline__ int ar_draw(ArLds &W, const double *suf, int L, double prior_df, double prior_ss,
+                                       double sigma_max, SeqRng &rng, double &phi_l, double &sigsq, int lane) {
+  for (int e = lane; e < AR_MAX * AR_MAX; e += WAVE) W.X[e] = suf[e];
   const double xty = (lane < L) ? suf[AR_SUF_XTY + lane] : 0.0;
   const double yty = suf[AR_SUF_YTY], n = suf[AR_SUF_N];
   __builtin_amdgcn_wave_barrier();
@@ -337,8 +302,8 @@ __device__ __forceinline__ int ar_draw(ArLds &W, const SsmParams &Q, int chain, 
     for (int i = 0; i < L; ++i) {
       const double initial_phi = rl(ph, i);
       double lo = -1, hi = 1;
-      const double ivar = W.X[i * SSM_MAX + i];
-      const double dot = row_total((lane < L) ? ph * W.X[lane * SSM_MAX + i] : 0.0);
+      const double ivar = W.X[i * AR_MAX + i];
+      const double dot = row_total((lane < L) ? ph * W.X[lane * AR_MAX + i] : 0.0);
       const double mu = (rl(xty, i) - (dot - initial_phi * ivar)) / ivar;
       for (;;) {
         int bad = 0;
@@ -355,52 +320,215 @@ __device__ __forceinline__ int ar_draw(ArLds &W, const SsmParams &Q, int chain, 
   double row = 0.0;
   for (int j = 0; j < L; ++j) {
     const double pj = rl(phi_l, j);
-    if (lane < L) row += W.X[lane * SSM_MAX + j] * pj;
+    if (lane < L) row += W.X[lane * AR_MAX + j] * pj;
   }
   const double quad = row_total((lane < L) ? phi_l * row : 0.0);
   const double lin = row_total((lane < L) ? phi_l * xty : 0.0);
   const double ss = quad - 2 * lin + yty;
   int bad = 0;
-  sigsq = d_draw_variance(rng, n + Q.ar_prior_df, ss + Q.ar_prior_ss, Q.ar_sigma_max, &bad);
+  sigsq = d_draw_variance(rng, n + prior_df, ss + prior_ss, sigma_max, &bad);
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
+}
+
+// ---- the block list in wave-uniform registers (every loop over it is unrolled with a
+// uniform early exit, so the indices are compile-time constants).  Three words a block:
+// the kernel's scalar registers are few.
+struct Blocks {
+  int nb;
+  unsigned desc[NB];   // kind (3 bits) | first (7) | dim (7) | index of its first variance parameter (5) | autoregression slot (3)
+  unsigned dp[NB];     // seasonal: duration (16 bits) | phase (16)
+  unsigned rc[NB];     // seasonal: (index of the step's transition + 1 - phase) mod duration (16 bits: 0 = it moves) |
+                       //           the rotating layout's cursor (16): physical slot of the block's first component
+  unsigned always;     // bit b: block b's transition is never the identity (trend, autoregression)
+  __device__ __forceinline__ int kind(int b) const { return (int)(desc[b] & 7u); }
+  __device__ __forceinline__ int first(int b) const { return (int)((desc[b] >> 3) & 127u); }
+  __device__ __forceinline__ int dim(int b) const { return (int)((desc[b] >> 10) & 127u); }
+  __device__ __forceinline__ int var0(int b) const { return (int)((desc[b] >> 17) & 31u); }
+  __device__ __forceinline__ int arx(int b) const { return (int)((desc[b] >> 22) & 7u); }
+  __device__ __forceinline__ int dur(int b) const { return (int)(dp[b] & 0xffffu); }
+  __device__ __forceinline__ int phase(int b) const { return (int)(dp[b] >> 16); }
+  __device__ __forceinline__ int cur(int b) const { return (int)(rc[b] >> 16); }
+  __device__ __forceinline__ void load(const SsgSpec &Q, int nblocks) {
+    nb = nblocks;
+    always = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      desc[b] = 0; dp[b] = 1; rc[b] = 0;
+      if (b < nblocks) {
+        const SsgBlock &K = Q.blk[b];
+        desc[b] = (unsigned)K.kind | ((unsigned)K.first << 3) | ((unsigned)K.dim << 10) |
+                  ((unsigned)K.var0 << 17) | ((unsigned)(K.ar_index < 0 ? 0 : K.ar_index) << 22);
+        dp[b] = (unsigned)K.duration | ((unsigned)K.phase << 16);
+        if (K.kind == SSG_LOCAL_LINEAR_TREND || K.kind == SSG_AR) always |= 1u << b;
+      }
+    }
+  }
+  // the lane Z selects in block b
+  __device__ __forceinline__ int zlane(int b) const { return first(b) + cur(b); }
+  // the layout of time t; the transitions are walked from index t + shift on (0: the
+  // transition OUT of the time, T_t; -1: the one INTO it, T_{t-1})
+  __device__ __forceinline__ void seek(int t, int shift) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < nb && kind(b) == SSG_SEASONAL) {
+        const int d = dur(b), n = dim(b);
+        const int q = seasons_started(t, d, phase(b)) % n;
+        const int c = q == 0 ? 0 : n - q;
+        int r = (t + shift + 1 - phase(b)) % d;
+        if (r < 0) r += d;
+        rc[b] = (unsigned)r | ((unsigned)c << 16);
+      }
+    }
+  }
+  // bit b = block b's transition of this step is not the identity
+  __device__ __forceinline__ unsigned moving() const {
+    unsigned mv = always;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (b < nb && kind(b) == SSG_SEASONAL && (rc[b] & 0xffffu) == 0u) mv |= 1u << b;
+    return mv;
+  }
+};
+
+// per-lane constants of the lane's component
+struct LaneInfo {
+  int blk, kind, first, dim;    // its block (kind 0: the lane holds no component)
+  int cur;                      // seasonal: its block's cursor (a per-lane copy of Blocks::cur)
+  double phi;                   // autoregression: the lane's coefficient
+  __device__ __forceinline__ bool moves(unsigned mv) const { return kind == SSG_SEASONAL && ((mv >> blk) & 1u); }
+};
+
+// Z'x
+__device__ __forceinline__ double zdot(const Blocks &B, double x) {
+  double a = rl(x, B.zlane(0));
+#pragma unroll
+  for (int b = 1; b < NB; ++b)
+    if (b < B.nb) a += rl(x, B.zlane(b));
+  return a;
+}
+// y = T x for a vector held one component per lane, in the layout the cursors say; mv:
+// bit b = block b's transition moves at this step (seasonal: the step into a new season);
+// the result is in the next layout (the caller advances the cursors)
+template <bool SMALL>
+__device__ __forceinline__ double vecT(const Blocks &B, const LaneInfo &L, double x, int lane, unsigned mv) {
+  double y = x;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b >= B.nb) break;
+    const int f = B.first(b), kd = B.kind(b);
+    if (kd == SSG_LOCAL_LINEAR_TREND) {
+      const double x1 = rl(x, f + 1);
+      if (lane == f) y = x + x1;
+    } else if (kd == SSG_SEASONAL) {
+      if ((mv >> b) & 1u) {
+        const double tot = wsum<SMALL>(L.blk == b ? x : 0.0);
+        if (lane == f + sprev(B.cur(b), B.dim(b))) y = -tot;
+      }
+    } else if (kd == SSG_AR) {
+      // new[0] = phi'old, new[i] = old[i - 1]  (AutoRegressionTransitionMatrix, SparseMatrix.cpp:1261-1310)
+      const double tot = wsum<SMALL>(L.blk == b ? L.phi * x : 0.0);
+      const double below = from_below(x);
+      if (L.blk == b) y = (lane == f) ? tot : below;
+    }
+  }
+  return y;
+}
+// y = T' x; the cursors are those of x's layout (time t + 1); mv as above for the step t -> t + 1
+__device__ __forceinline__ double vecTt(const Blocks &B, const LaneInfo &L, double x, int lane, unsigned mv) {
+  double y = x;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b >= B.nb) break;
+    const int f = B.first(b), kd = B.kind(b);
+    if (kd == SSG_LOCAL_LINEAR_TREND) {
+      const double x0 = rl(x, f);
+      if (lane == f + 1) y = x0 + x;
+    } else if (kd == SSG_SEASONAL) {
+      if ((mv >> b) & 1u) {
+        const int c1 = f + B.cur(b);
+        const double firstv = rl(x, c1);
+        if (L.blk == b) y = (lane == c1) ? -firstv : x - firstv;
+      }
+    } else if (kd == SSG_AR) {
+      // out[i] = phi_i x[0] + x[i + 1]  (Tmult, SparseMatrix.cpp:1286-1295)
+      const double firstv = rl(x, f);
+      const double above = from_above(x);
+      if (L.blk == b) y = L.phi * firstv + ((lane + 1 < f + B.dim(b)) ? above : 0.0);
+    }
+  }
+  return y;
+}
+// one step on: the layout after the transitions `mv` moved, the next transition's phase
+__device__ __forceinline__ void advance(Blocks &B, LaneInfo &L, unsigned mv) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b < B.nb && B.kind(b) == SSG_SEASONAL) {
+      int r = (int)(B.rc[b] & 0xffffu) + 1, c = B.cur(b);
+      if (r == B.dur(b)) r = 0;
+      if ((mv >> b) & 1u) c = sprev(c, B.dim(b));
+      B.rc[b] = (unsigned)r | ((unsigned)c << 16);
+    }
+  }
+  if (L.moves(mv)) L.cur = sprev(L.cur, L.dim);
+}
+// one step back
+__device__ __forceinline__ void retreat(Blocks &B, LaneInfo &L, unsigned mv) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b < B.nb && B.kind(b) == SSG_SEASONAL) {
+      int r = (int)(B.rc[b] & 0xffffu), c = B.cur(b);
+      r = r == 0 ? B.dur(b) - 1 : r - 1;
+      if ((mv >> b) & 1u) c = snext(c, B.dim(b));
+      B.rc[b] = (unsigned)r | ((unsigned)c << 16);
+    }
+  }
+  if (L.moves(mv)) L.cur = snext(L.cur, L.dim);
+}
+// the layout of time t (see Blocks::seek)
+__device__ __forceinline__ void seek(Blocks &B, LaneInfo &L, int t, int shift) {
+  B.seek(t, shift);
+  L.cur = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b < B.nb && L.blk == b) L.cur = B.cur(b);
 }
 
 }  // namespace
 
-// grid = chains, block = 128.  TREND: 1 local level, 2 local linear trend; SEAS: a
-// seasonal block follows; AR: an autoregression block follows
-template <int TREND, bool SEAS, bool AR>
-__global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw_variances) {
-  // (the passes' buffers take the place of the normals generator's lists, which
-  // are done by then: 37 KB per workgroup, four workgroups per CU)
-  struct PassLds {
-    double blk[2][WAVE * SSM_MAX];   // a block of 64 steps of a state-sized series, per wave
-    double P[SSM_MAX * PLD];         // the state variance (wave 1), rows PLD apart
-    double tv[SSM_MAX];
-  };
-  union SharedLds {
-    NormalsLds norm;
-    PassLds pass;
-    ArLds ar;
-  };
-  __shared__ SharedLds s_lds;
+// LDS of the passes, in doubles: two block buffers (bl x m each) | P (m x ld) | a block's
+// normals / smoothed disturbances | the autoregression blocks' xtx rows
+__host__ __device__ inline int ssg_pass_lds_doubles(int m, int ld, int bl, int nerr, int nar) {
+  return 2 * bl * m + m * ld + (bl * (nerr + 1) + SSG_MAX_STATE + 8) + nar * AR_MAX * (AR_MAX + 1);
+}
+
+// grid = chains, block = 128, dynamic LDS = max(the normals generator's lists, the
+// sampler's matrices, ssg_pass_lds_doubles).  SMALL: m <= 16.
+template <bool SMALL>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void ssg_simsmooth_kernel(SsParams P, int draw_variances) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
   __shared__ int s_flag;
-  __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
-  double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
-  double (&s_P)[SSM_MAX * PLD] = s_lds.pass.P;
-  double (&s_tv)[SSM_MAX] = s_lds.pass.tv;
+  __shared__ double s_sig2[SSG_MAX_VAR];
+  __shared__ double s_phi[SSG_MAX_AR * AR_MAX];
+  __shared__ double s_tv[SSG_MAX_STATE];
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;
   if (P.status[chain] != CHAIN_OK) return;
   if (P.only_ran && P.only_ran[chain] == 0) return;
-  const SsmParams &Q = P.ssm;
-  const int T = P.T, p = P.p, m = Q.m;
-  Shape S;
-  S.m = m; S.trend = TREND; S.s0 = TREND; S.ns = SEAS ? Q.nseasons - 1 : 0;
-  S.a0 = AR ? Q.ar0 : 0; S.na = AR ? Q.ar_lags : 0;
+  const SsmParams &M = P.ssm;
+  const SsgSpec &Q = *M.spec;
+  const int T = P.T, p = P.p, m = M.m, nb = M.nblocks, ld = M.ld, BL = M.bl, NE = M.nerr;
+  NormalsLds &s_norm = *reinterpret_cast<NormalsLds *>(s_raw);
+  ArLds &s_ar = *reinterpret_cast<ArLds *>(s_raw);
+  double *s_blk0 = reinterpret_cast<double *>(s_raw);
+  double *s_blk1 = s_blk0 + BL * m;
+  double *s_P = s_blk1 + BL * m;
+  double *s_z = s_P + m * ld;
+  double *s_axx = s_z + (BL * (NE + 1) + SSG_MAX_STATE + 8);
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
   int status = CHAIN_OK;
   if (threadIdx.x == 0) s_flag = CHAIN_OK;
+  if (threadIdx.x < SSG_MAX_VAR) s_sig2[threadIdx.x] = M.var_sigsq[(size_t)chain * SSG_MAX_VAR + threadIdx.x];
+  __syncthreads();
 #ifdef BA_KSTAMPS
   long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
 #define SSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
@@ -408,29 +536,28 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 #define SSTAMP(i) do { } while (0)
 #endif
 
-  // ---- the state models' variance draws, in model order: level [, slope], seasonal
-  double sig2[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) sig2[i] = Q.var_sigsq[(size_t)chain * 3 + i];
+  // ---- the state models' samplers, in model order (every sampler reads its own stream)
   if (draw_variances) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const bool active = (i == 0) || (i == 1 && TREND == 2) || (i == 2 && SEAS);
-      if (active) {
-        const uint32_t sid = (i == 0) ? 1u : (i == 1 ? 6u : 7u);
-        SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, sid}, Q.pos_var[(size_t)chain * 3 + i]};
+    for (int b = 0; b < nb; ++b) {
+      const SsgBlock &K = Q.blk[b];
+      if (K.kind == SSG_AR) continue;
+      for (int v = 0; v < K.nvar; ++v) {
+        const int vi = K.var0 + v;
+        const size_t at = (size_t)chain * SSG_MAX_VAR + vi;
+        SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, (uint32_t)K.sid[v]}, M.pos_var[at]};
         int bad = 0;
-        const double DF = Q.var_n[(size_t)chain * 3 + i] + Q.prior_df[i];
-        const double SSQ = Q.var_ss[(size_t)chain * 3 + i] + Q.prior_ss[i];
-        double draw = d_draw_variance(rng, DF, SSQ, Q.sigma_max[i], &bad);
+        const double DF = M.var_n[at] + Q.prior_df[vi];
+        const double SSQ = M.var_ss[at] + Q.prior_ss[vi];
+        double draw = d_draw_variance(rng, DF, SSQ, Q.sigma_max[vi], &bad);
         if (bad) status = CHAIN_RNG_BRANCH;
         // ZeroMeanMvnIndependenceSampler sets siginv(i, i) = 1 / draw; the model's
         // Sigma is the inverse of that again
-        if (TREND == 2 && i < 2) draw = 1.0 / (1.0 / draw);
-        sig2[i] = draw;
-        if (lane == 0 && wave == 0) {
-          Q.pos_var[(size_t)chain * 3 + i] = rng.pos;
-          Q.var_sigsq[(size_t)chain * 3 + i] = draw;
+        if (K.kind == SSG_LOCAL_LINEAR_TREND) draw = 1.0 / (1.0 / draw);
+        __syncthreads();   // (everybody has read the old position)
+        if (threadIdx.x == 0) {
+          M.pos_var[at] = rng.pos;
+          M.var_sigsq[at] = draw;
+          s_sig2[vi] = draw;
         }
       }
     }
@@ -439,57 +566,108 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     if (threadIdx.x == 0) P.status[chain] = status;
     return;
   }
-  // ---- the autoregression block's sampler (after the seasonal model's), by wave 0
-  double phl = 0.0, sig2a = 0.0;
-  if (AR) {
+  // ---- the autoregression blocks' samplers, by wave 0 (the sampler's vectors sit at lanes 0 .. L - 1)
+  for (int b = 0; b < nb; ++b) {
+    const SsgBlock &K = Q.blk[b];
+    if (K.kind != SSG_AR) continue;
+    const int L = K.lags, vi = K.var0;
+    const size_t at = (size_t)chain * SSG_MAX_VAR + vi;
+    double *gphi = M.ar_phi + ((size_t)chain * SSG_MAX_AR + K.ar_index) * AR_MAX;
     if (wave == 0) {
-      phl = S.ar(lane) ? Q.ar_phi[(size_t)chain * SSM_MAX + (lane - S.a0)] : 0.0;
-      sig2a = Q.ar_sigsq[chain];
+      double ph = (lane < L) ? gphi[lane] : 0.0;
+      double sig2a = M.var_sigsq[at];
       if (draw_variances) {
-        SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, 12u}, Q.pos_ar[chain]};
-        // (the sampler's vectors sit at lanes 0 .. L - 1)
-        double ph = __shfl(phl, lane + S.a0);
-        if (lane >= S.na) ph = 0.0;
-        const int st = ar_draw(s_lds.ar, Q, chain, rng, ph, sig2a, lane);
+        SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, (uint32_t)K.sid[0]}, M.pos_var[at]};
+        const double *suf = M.ar_suf + ((size_t)chain * SSG_MAX_AR + K.ar_index) * AR_SUF_STRIDE;
+        const int st = ar_draw(s_ar, suf, L, Q.prior_df[vi], Q.prior_ss[vi], Q.sigma_max[vi], rng, ph, sig2a, lane);
         if (st != CHAIN_OK) {
           if (lane == 0) s_flag = st;
         } else {
-          if (lane < S.na) Q.ar_phi[(size_t)chain * SSM_MAX + lane] = ph;
+          if (lane < L) gphi[lane] = ph;
           if (lane == 0) {
-            Q.ar_sigsq[chain] = sig2a;
-            Q.pos_ar[chain] = rng.pos;
+            M.var_sigsq[at] = sig2a;
+            M.pos_var[at] = rng.pos;
           }
         }
-        phl = __shfl(ph, lane >= S.a0 ? lane - S.a0 : 0);
-        if (!S.ar(lane)) phl = 0.0;
       }
-      const double pv = __shfl(phl, (lane + S.a0) & 63);
-      if (lane < SSM_MAX) s_phi[lane] = (lane < S.na) ? pv : 0.0;
-      if (lane == 0) s_phi[SSM_MAX] = sig2a;
+      if (lane < AR_MAX) s_phi[K.ar_index * AR_MAX + lane] = (lane < L) ? ph : 0.0;
+      if (lane == 0) s_sig2[vi] = sig2a;
     }
     __syncthreads();
-    status = s_flag;
-    if (status != CHAIN_OK) {
-      if (threadIdx.x == 0) P.status[chain] = status;
-      return;
-    }
-    if (wave == 1) {
-      phl = S.ar(lane) ? s_phi[lane - S.a0] : 0.0;
-      sig2a = s_phi[SSM_MAX];
-    }
   }
-  const double sda = sqrt(sig2a);
+  __syncthreads();
+  status = s_flag;
+  if (status != CHAIN_OK) {
+    if (threadIdx.x == 0) P.status[chain] = status;
+    return;
+  }
+
+  // ---- the block list in uniform registers, the lane's own constants
+  Blocks B;
+  B.load(Q, nb);
+  LaneInfo LI{-1, 0, 0, 0, 0, 0.0};
+  int var_l = 0;          // the variance parameter behind this lane's state error
+  int cbefore_l = 0;      // error terms drawn at EVERY step ahead of this lane's term
+  unsigned sbefore_l = 0; // seasonal blocks ahead of it (their terms are drawn on some steps only)
+  int ipos_l = 0;         // position of this lane's normal among those of the initial state
+  bool init_l = false;    // ... if it has one
+  double a0l = 0.0, P0l = 0.0;
+  int nconst_err = 0;     // error normals drawn at every step
+  unsigned seas_active = 0;   // seasonal blocks whose error is drawn at all (sigma != 0)
+  int nfirst = 0;         // normals of the initial state
+  {
+    int cb = 0, ip = 0;
+    unsigned sb = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= nb) break;
+      const int f = B.first(b), n = B.dim(b), kd = B.kind(b);
+      const bool mine = lane >= f && lane < f + n;
+      if (mine) {
+        LI.blk = b; LI.kind = kd; LI.first = f; LI.dim = n;
+        var_l = B.var0(b) + ((kd == SSG_LOCAL_LINEAR_TREND && lane == f + 1) ? 1 : 0);
+        cbefore_l = cb + ((kd == SSG_LOCAL_LINEAR_TREND && lane == f + 1) ? 1 : 0);
+        sbefore_l = sb;
+        if (kd == SSG_AR) LI.phi = s_phi[B.arx(b) * AR_MAX + (lane - f)];
+      }
+      // the initial state's normals: a local level draws rnorm(a0, sd0) (nothing when
+      // sd0 == 0), every other model rmvn: one per component
+      if (kd == SSG_LOCAL_LEVEL) {
+        const bool drawn = Q.P0[f] != 0.0;
+        if (mine) { ipos_l = ip; init_l = drawn; }
+        ip += drawn ? 1 : 0;
+      } else {
+        if (mine) { ipos_l = ip + (lane - f); init_l = true; }
+        ip += n;
+      }
+      // the state errors of a step: local level: one if sigma != 0; trend: two, always;
+      // seasonal: one on the steps into a new season if sigma != 0; autoregression: one, always
+      if (kd == SSG_LOCAL_LEVEL) cb += (s_sig2[B.var0(b)] != 0.0) ? 1 : 0;
+      else if (kd == SSG_LOCAL_LINEAR_TREND) cb += 2;
+      else if (kd == SSG_AR) cb += 1;
+      else {
+        if (s_sig2[B.var0(b)] != 0.0) seas_active |= 1u << b;
+        sb |= 1u << b;
+      }
+    }
+    nconst_err = cb;
+    nfirst = ip;
+  }
+  const bool mylane = lane < m;
+  if (mylane) { a0l = Q.a0[lane]; P0l = Q.P0[lane]; }
+  const double sig_l = mylane ? s_sig2[var_l] : 0.0;
+  const double sd_l = sqrt(sig_l);
 
   const double H = P.sigsq[chain], sqrtH = sqrt(H);
-  const double sdv[3] = {sqrt(sig2[0]), sqrt(sig2[1]), sqrt(sig2[2])};
+  const int dH = (sqrtH != 0.0);
   const double *beta = P.beta + (size_t)chain * p;
   double *w0 = P.scratch + (size_t)chain * P.scratch_stride;   // y* -> w = y* - y+ -> (v - v+) / F
   double *sres = w0 + T;                                       // F_t, then residuals (input of the X'e GEMM)
-  double *wk = Q.work + (size_t)chain * Q.work_stride;
+  double *wk = M.work + (size_t)chain * M.work_stride;
   double *gK = wk;                                 // K_t, m per step (layout of step t + 1)
   double *gst = gK + (size_t)m * T;                // alpha+_t (layout of step t), then the state draw
-  double *gd = gst + (size_t)m * T;                // r_t (difference) at the four rows with state error: 4 series of T
-  double *szz = gd + (size_t)4 * T;                // the sweep's normals
+  double *gd = gst + (size_t)m * T;                // r_t (difference) at the rows with state error: nerr series of T
+  double *szz = gd + (size_t)NE * T;               // the sweep's normals
 
   SSTAMP(0);
   // ---- 1. adjusted observations y*_t = y_t - x_t'beta (blocks of 64 steps, the waves in turn)
@@ -503,29 +681,23 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       while (mk) {
         const int l = __ffsll((long long)mk) - 1;
         mk &= mk - 1;
-        const double b = rl(bj, l);
-        pred += P.X[(size_t)(base + l) * T + (t < T ? t : T - 1)] * b;
+        const double bb = rl(bj, l);
+        pred += P.X[(size_t)(base + l) * T + (t < T ? t : T - 1)] * bb;
       }
     }
     if (t < T) w0[t] = P.y[t] - pred;
   }
 
   SSTAMP(1);
-  // ---- 2. the normals of simulate_forward, in stream order.  t = 0: the initial
-  // state of every state model (rmvn_mt draws every component; the local level
-  // model draws rnorm_mt(a0, sd0): nothing if sd0 == 0), then the observation;
-  // t >= 1: the state errors (local level: one if sigma != 0; local linear trend:
-  // two, always; seasonal: one if sigma != 0; autoregression: one, always --
-  // rnorm_mt(rng) * sigma, ArStateModel.cpp:85-90), then the observation.
-  const int dH = (sqrtH != 0.0);
-  const int d0 = (TREND == 1) ? (Q.P0[0] != 0.0 ? 1 : 0) : 2;
-  const int nfirst = d0 + S.ns + S.na + dH;
-  const int dT = (TREND == 1) ? (sdv[0] != 0.0 ? 1 : 0) : 2;
-  const int dS = (SEAS && sdv[2] != 0.0) ? 1 : 0;
-  const int dA = AR ? 1 : 0;
-  const int nper = dT + dS + dA + dH;
-  const int N = nfirst + (T - 1) * nper;
-  status = stream_normals(s_lds.norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
+  // ---- 2. the normals of simulate_forward, in stream order.  t = 0: the initial state of
+  // every state model, then the observation; t >= 1: the state errors of the step into t
+  // (model by model), then the observation.  off(t) = index of step t's first normal.
+  int nseas_tot = 0;   // seasonal error draws over the steps into times 1 .. T - 1
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b < nb && ((seas_active >> b) & 1u)) nseas_tot += seasons_started(T - 1, B.dur(b), B.phase(b));
+  const int N = (nfirst + dH) + (T - 1) * (nconst_err + dH) + nseas_tot;
+  status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
                           szz, &P.pos_state[chain]);
   if (status != CHAIN_OK) {
     if (threadIdx.x == 0) P.status[chain] = status;
@@ -533,185 +705,192 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   }
   __syncthreads();
   SSTAMP(2);
-
-  const bool mylane = lane < m;
-  // which variance parameter drives this lane's state error (the seasonal one moves with the cursor)
-  const double sig_tr = (lane == 0) ? sig2[0] : ((TREND == 2 && lane == 1) ? sig2[1] : 0.0);
-  const double sd_tr = (lane == 0) ? sdv[0] : ((TREND == 2 && lane == 1) ? sdv[1] : 0.0);
-  double a0l = 0.0, P0l = 0.0;
+  auto zoffset = [&](int t) -> int {   // t >= 1
+    int o = (nfirst + dH) + (t - 1) * (nconst_err + dH);
 #pragma unroll
-  for (int i = 0; i < SSM_MAX; ++i) if (lane == i) { a0l = Q.a0[i]; P0l = Q.P0[i]; }
-  double *blk = s_blk[wave];
+    for (int b = 0; b < NB; ++b)
+      if (b < nb && ((seas_active >> b) & 1u)) o += seasons_started(t - 1, B.dur(b), B.phase(b));
+    return o;
+  };
+
+  double *blk = wave == 0 ? s_blk0 : s_blk1;
 
   // ---- 3. forward, the two waves side by side (neither needs the other's results):
   //   wave 1: the variances P_t -> F_t, K_t (ScalarMarginalDistribution::update, the
   //           part that does not look at the data);
   //   wave 0: simulate alpha+_t, y+_t and w_t = y*_t - y+_t.
-  // Time runs in blocks of 64 steps: a block's scalar inputs sit one step per lane
-  // (read with v_readlane), its state-sized series in LDS, and what a block
-  // produces goes out in one coalesced piece.
+  // Time runs in blocks of BL steps: a block's scalar inputs sit one step per lane
+  // (read with v_readlane), its state-sized series in LDS, and what a block produces
+  // goes out in one coalesced piece.
   if (wave == 1) {
-    // P lives in LDS (s_P[row * PLD + column], PLD = 17: a lane per column and a lane per
-    // row are both free of bank conflicts; both indices in the rotating
-    // layout, kept exactly symmetric): the rows and columns a step touches move
-    // with the cursor, which registers cannot follow.  Lane k < m owns column k;
-    // the rank-one update runs over all 256 entries on all 64 lanes.
-    for (int e = lane; e < SSM_MAX * PLD; e += WAVE) s_P[e] = 0.0;
-    if (lane < SSM_MAX) s_tv[lane] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-    if (mylane) s_P[lane * (PLD + 1)] = P0l;
-    __builtin_amdgcn_wave_barrier();
-    int c = 0;
-    for (int tb = 0; tb < T; tb += WAVE) {
+    for (int e = lane; e < m * ld; e += WAVE) s_P[e] = 0.0;
+    wave_lds_sync();
+    if (mylane) s_P[lane * ld + lane] = P0l;
+    wave_lds_sync();
+    seek(B, LI, 0, 0);
+    for (int tb = 0; tb < T; tb += BL) {
       const int tt = tb + lane;
-      const int ob_l = (tt < T && P.observed[tt]) ? 1 : 0;
+      const int nstep = (T - tb < BL) ? T - tb : BL;
+      const int ob_l = (lane < nstep && P.observed[tt]) ? 1 : 0;
       double F_l = 1.0;
-      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
 #pragma nounroll
       for (int s = 0; s < nstep; ++s) {
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
-        const int cn = SEAS ? cursor_prev(c, S.ns) : 0;   // the next layout's cursor
-        const int rc = S.s0 + c, rw = S.s0 + cn;          // rows / columns of the current and the new first component
-        // PZ_k = P(k, 0) + P(k, first seasonal) = P(0, k) + P(first seasonal, k)
+        const unsigned mv = B.moving();
+        // PZ_k = sum over the blocks of P(first of the block, k)  [= P(k, first), P symmetric]
         double PZ = 0.0;
         if (mylane) {
-          PZ = s_P[lane];
-          if (SEAS) PZ += s_P[rc * PLD + lane];
-          if (AR) PZ += s_P[S.a0 * PLD + lane];
+          PZ = s_P[B.zlane(0) * ld + lane];
+#pragma unroll
+          for (int b = 1; b < NB; ++b)
+            if (b < nb) PZ += s_P[B.zlane(b) * ld + lane];
         }
-        const double F = zdot<SEAS, AR>(S, PZ, c) + H;
+        const double F = zdot(B, PZ) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
-        const double TPZ = vecT<TREND, SEAS, AR>(S, PZ, lane, c, phl);
-        const double K = obs ? TPZ / F : 0.0;
-        if (mylane) {
-          blk[s * m + lane] = K;
-          s_tv[lane] = TPZ;
-        }
         if (lane == s) F_l = F;
-        // T P T' -- the trend block: row 0 += row 1, then column 0 += column 1
-        if (TREND == 2) {
-          if (mylane) s_P[lane] = s_P[lane] + s_P[PLD + lane];
-          __builtin_amdgcn_wave_barrier();
-          if (mylane) s_P[lane * PLD] = s_P[lane * PLD] + s_P[lane * PLD + 1];
-          __builtin_amdgcn_wave_barrier();
+        const double Finv = 1.0 / F;
+        // K_t = T PZ / F (layout of t + 1)
+        const double TPZ = vecT<SMALL>(B, LI, PZ, lane, mv);
+        if (mylane) {
+          blk[s * m + lane] = obs ? TPZ * Finv : 0.0;
+          s_tv[lane] = PZ;
         }
-        // -- the seasonal block: the row / column of the component that drops out
-        // becomes that of the new first component, -sum over the block
-        if (SEAS) {
-          // (every load issued before the first use, from addresses that are valid whatever
-          // the block's size: fifteen guarded load-and-subtract steps each waited for their
-          // own LDS round trip)
-          double cs = 0.0;
-          {
-            double v[SSM_MAX - 1];
-            const int col = mylane ? lane : 0;
+        wave_lds_sync();
+        // -- the column pass: lane k walks ITS column: the rank-one term of an observed step,
+        // then T from the left, block by block
+        if (mylane) {
 #pragma unroll
-            for (int q = 0; q < SSM_MAX - 1; ++q) v[q] = s_P[(TREND + (q < S.ns ? q : 0)) * PLD + col];
-#pragma unroll
-            for (int q = 0; q < SSM_MAX - 1; ++q) cs -= (q < S.ns) ? v[q] : 0.0;
-            if (!mylane) cs = 0.0;
-          }
-          const double tot = row_total(S.seasonal(lane) ? cs : 0.0);
-          __builtin_amdgcn_wave_barrier();
-          if (mylane) {
-            s_P[rw * PLD + lane] = cs;
-            s_P[lane * PLD + rw] = cs;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (lane == rw) s_P[rw * (PLD + 1)] = -tot;
-          __builtin_amdgcn_wave_barrier();
-        }
-        // -- the autoregression block (logical order): T P, then (T P) T'.  Lane k owns
-        // column k of the block's rows, then row k of the block's columns; either way
-        // it reads and writes its own entries only, and a symmetric P stays symmetric
-        // (P'(a0, k) and P'(k, a0) are the same sum in the same order).
-        if (AR) {
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
-            if (mylane) {
-              const int sr = pass == 0 ? PLD : 1, sc = pass == 0 ? 1 : PLD;   // strides along / across the block
-              // from the last lag down, moving each entry one place on as it is read (a
-              // rolled loop: fifteen guarded copies of its body cost 3 400 cycles a step)
+          for (int b = 0; b < NB; ++b) {
+            if (b >= nb) break;
+            const int f = B.first(b), n = B.dim(b);
+            double *col = s_P + f * ld + lane;
+            if (B.kind(b) == SSG_LOCAL_LEVEL) {
+              double v = col[0];
+              if (obs) v -= (s_tv[f] * PZ) * Finv;
+              if (lane == f) v += s_sig2[B.var0(b)];   // (+ RQR: this block's T is the identity)
+              col[0] = v;
+            } else if (B.kind(b) == SSG_LOCAL_LINEAR_TREND) {
+              double v0 = col[0], v1 = col[ld];
+              if (obs) {
+                v0 -= (s_tv[f] * PZ) * Finv;
+                v1 -= (s_tv[f + 1] * PZ) * Finv;
+                col[ld] = v1;
+              }
+              col[0] = v0 + v1;   // row 0 += row 1
+            } else if (B.kind(b) == SSG_SEASONAL) {
+              const bool moves = (mv >> b) & 1u;
+              if (obs || moves) {
+                double cs = 0.0;
+#pragma unroll 4
+                for (int i = 0; i < n; ++i) {
+                  double v = col[i * ld];
+                  if (obs) {
+                    v -= (s_tv[f + i] * PZ) * Finv;
+                    col[i * ld] = v;
+                  }
+                  cs -= v;
+                }
+                // the row of the component that drops out becomes that of the new first
+                // component, -(sum over the block)
+                if (moves) col[sprev(B.cur(b), n) * ld] = cs;
+              }
+            } else {
+              // autoregression (logical order): from the last lag down, moving each entry
+              // one place on as it is read
+              const double *ph = s_phi + B.arx(b) * AR_MAX;
               double cs = 0.0;
 #pragma nounroll
-              for (int q = S.na - 1; q >= 0; --q) {
-                const double v = s_P[(S.a0 + q) * sr + lane * sc];
-                cs += s_phi[q] * v;
-                if (q + 1 < S.na) s_P[(S.a0 + q + 1) * sr + lane * sc] = v;
+              for (int q = n - 1; q >= 0; --q) {
+                double v = col[q * ld];
+                if (obs) v -= (s_tv[f + q] * PZ) * Finv;
+                cs += ph[q] * v;
+                if (q + 1 < n) col[(q + 1) * ld] = v;
               }
-              s_P[S.a0 * sr + lane * sc] = cs;
+              col[0] = cs;
             }
-            __builtin_amdgcn_wave_barrier();
           }
         }
-        // - TPZ K' at an observed step (as (TPZ_i TPZ_j) / F: exactly symmetric)
-        if (obs) {
-          const double Finv = 1.0 / F;
+        wave_lds_sync();
+        // -- the row pass: lane k walks ITS row: T' from the right, + RQR
+        if (mylane) {
 #pragma unroll
-          for (int e4 = 0; e4 < SSM_MAX * SSM_MAX / WAVE; ++e4) {
-            const int e = lane + WAVE * e4;
-            const int i = e >> 4, k2 = e & 15;
-            if (i < m && k2 < m) s_P[i * PLD + k2] -= (s_tv[i] * s_tv[k2]) * Finv;
+          for (int b = 0; b < NB; ++b) {
+            if (b >= nb) break;
+            const int f = B.first(b), n = B.dim(b);
+            double *row = s_P + lane * ld + f;
+            if (B.kind(b) == SSG_LOCAL_LINEAR_TREND) {
+              const double a = row[0], bb = row[1];
+              row[0] = (a + bb) + (lane == f ? s_sig2[B.var0(b)] : 0.0);   // column 0 += column 1
+              if (lane == f + 1) row[1] = bb + s_sig2[B.var0(b) + 1];
+            } else if (B.kind(b) == SSG_SEASONAL) {
+              if ((mv >> b) & 1u) {
+                const int w = sprev(B.cur(b), n);
+                double cs = 0.0;
+#pragma unroll 4
+                for (int j = 0; j < n; ++j) cs -= row[j];
+                row[w] = cs + (lane == f + w ? s_sig2[B.var0(b)] : 0.0);
+              }
+            } else if (B.kind(b) == SSG_AR) {
+              const double *ph = s_phi + B.arx(b) * AR_MAX;
+              double cs = 0.0;
+#pragma nounroll
+              for (int q = n - 1; q >= 0; --q) {
+                const double v = row[q];
+                cs += ph[q] * v;
+                if (q + 1 < n) row[q + 1] = v;
+              }
+              row[0] = cs + (lane == f ? s_sig2[B.var0(b)] : 0.0);
+            }
           }
-          __builtin_amdgcn_wave_barrier();
         }
-        // + RQR
-        if (lane == 0) s_P[0] += sig2[0];
-        if (TREND == 2 && lane == 1) s_P[PLD + 1] += sig2[1];
-        if (SEAS && lane == rw) s_P[rw * (PLD + 1)] += sig2[2];
-        if (AR && lane == S.a0) s_P[S.a0 * (PLD + 1)] += sig2a;
-        __builtin_amdgcn_wave_barrier();
-        c = cn;
+        wave_lds_sync();
+        advance(B, LI, mv);
       }
       if (status != CHAIN_OK) break;
       blk_store(gK + (size_t)tb * m, blk, nstep * m, lane);
-      if (tt < T) sres[tt] = F_l;
+      if (lane < nstep) sres[tt] = F_l;
     }
     if (status != CHAIN_OK && lane == 0) s_flag = status;
   } else {
     double alpha = 0.0;
-    int c = 0;
-    for (int tb = 0; tb < T; tb += WAVE) {
+    seek(B, LI, 0, -1);   // (at time t the transition INTO t)
+    for (int tb = 0; tb < T; tb += BL) {
       const int tt = tb + lane;
-      const bool in_l = tt < T;
+      const int nstep = (T - tb < BL) ? T - tb : BL;
+      const bool in_l = lane < nstep;
       const double ys_l = in_l ? w0[tt] : 0.0;
-      const int nb_l = (tt == 0) ? 0 : nfirst + (tt - 1) * nper;
-      double z0_l = 0.0, z1_l = 0.0, zs_l = 0.0, za_l = 0.0, zh_l = 0.0;
-      if (in_l && tt > 0) {
-        int o = nb_l;
-        if (dT >= 1) z0_l = szz[o++];
-        if (dT == 2) z1_l = szz[o++];
-        if (dS) zs_l = szz[o++];
-        if (dA) za_l = szz[o++];
-        if (dH) zh_l = szz[o];
-      } else if (in_l) {
-        if (dH) zh_l = szz[d0 + S.ns + S.na];
-      }
+      // the block's normals, in stream order
+      const int zstart = tb == 0 ? 0 : zoffset(tb);
+      const int zend = (tb + nstep >= T) ? N : zoffset(tb + nstep);
+      blk_load(s_z, szz + zstart, zend - zstart, lane);
+      int zo = 0;
       double w_l = 0.0;
-      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
 #pragma nounroll
       for (int s = 0; s < nstep; ++s) {
         if (tb + s == 0) {
           // simulate_initial_state: mean_i + sd_i z_i
-          double z = 0.0;
-          if (mylane) {
-            // (the blocks follow one another: seasonal and autoregression lanes alike)
-            if (lane < TREND) z = (lane < d0) ? szz[lane] : 0.0;
-            else z = szz[d0 + (lane - TREND)];
-          }
+          const double z = (mylane && init_l) ? s_z[ipos_l] : 0.0;
           alpha = mylane ? sqrt(P0l) * z + a0l : 0.0;
+          zo = nfirst;
+          advance(B, LI, 0u);
         } else {
           // simulate_next_state: T alpha + eta
-          const double z0 = rl(z0_l, s);
-          const int cn = SEAS ? cursor_prev(c, S.ns) : 0;
-          alpha = vecT<TREND, SEAS, AR>(S, alpha, lane, c, phl);
-          if (TREND == 2) alpha += sd_tr * ((lane == 0) ? z0 : rl(z1_l, s));
-          else alpha += sd_tr * z0;
-          if (SEAS) { if (lane == S.s0 + cn) alpha += sdv[2] * rl(zs_l, s); }
-          if (AR) { if (lane == S.a0) alpha += rl(za_l, s) * sda; }
-          c = cn;
+          const unsigned mv = B.moving();
+          const unsigned act = mv & seas_active;
+          alpha = vecT<SMALL>(B, LI, alpha, lane, mv);
+          advance(B, LI, mv);
+          bool err = false;
+          if (LI.kind == SSG_LOCAL_LEVEL) err = sig_l != 0.0;
+          else if (LI.kind == SSG_LOCAL_LINEAR_TREND) err = true;
+          else if (LI.kind == SSG_AR) err = lane == LI.first;
+          else if (LI.kind == SSG_SEASONAL) err = ((act >> LI.blk) & 1u) && lane == LI.first + LI.cur;
+          const double z = err ? s_z[zo + cbefore_l + __popc(act & sbefore_l)] : 0.0;
+          alpha += sd_l * z;
+          zo += nconst_err + __popc(act);
         }
-        const double yplus = zdot<SEAS, AR>(S, alpha, c) + sqrtH * rl(zh_l, s);   // simulate_adjusted_observation
+        const double zh = dH ? s_z[zo] : 0.0;
+        zo += dH;
+        const double yplus = zdot(B, alpha) + sqrtH * zh;   // simulate_adjusted_observation
         const double w = rl(ys_l, s) - yplus;
         if (lane == s) w_l = w;
         if (mylane) blk[s * m + lane] = alpha;
@@ -735,11 +914,11 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   // filter; they share the gains): v - v+ = w - Z'(a - a+); a - a+ <- T (a - a+) + K (v - v+)
   {
     double delta = 0.0;
-    int c = 0;
-    for (int tb = 0; tb < T; tb += WAVE) {
+    seek(B, LI, 0, 0);
+    for (int tb = 0; tb < T; tb += BL) {
       const int tt = tb + lane;
-      const bool in_l = tt < T;
-      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      const int nstep = (T - tb < BL) ? T - tb : BL;
+      const bool in_l = lane < nstep;
       blk_load(blk, gK + (size_t)tb * m, nstep * m, lane);
       const double w_l = in_l ? w0[tt] : 0.0, F_l = in_l ? sres[tt] : 1.0;
       const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
@@ -748,10 +927,11 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       for (int s = 0; s < nstep; ++s) {
         const double K = mylane ? blk[s * m + lane] : 0.0;
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
-        const double e = obs ? rl(w_l, s) - zdot<SEAS, AR>(S, delta, c) : 0.0;
+        const unsigned mv = B.moving();
+        const double e = obs ? rl(w_l, s) - zdot(B, delta) : 0.0;
         if (lane == s) ef_l = obs ? e / F_l : 0.0;
-        delta = vecT<TREND, SEAS, AR>(S, delta, lane, c, phl) + K * e;
-        if (SEAS) c = cursor_prev(c, S.ns);
+        delta = vecT<SMALL>(B, LI, delta, lane, mv) + K * e;
+        advance(B, LI, mv);
       }
       __builtin_amdgcn_wave_barrier();
       if (in_l) w0[tt] = ef_l;
@@ -762,41 +942,45 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 
   SSTAMP(5);
   // ---- 4. backward: fast_disturbance_smooth for d = r - r+:
-  // r_{t-1} = T' r_t + Z ((v_t - v+_t) / F_t - K_t' r_t), r_{T-1} = 0.  r_t is in the
-  // layout of step t + 1.
+  // r_{t-1} = T_t' r_t + Z ((v_t - v+_t) / F_t - K_t' r_t), r_{T-1} = 0.  r_t is in the
+  // layout of step t + 1.  What the correction pass needs of r_t is its value at the rows
+  // that carry state error: one series per variance parameter.
   double r = 0.0;
-  for (int tb = ((T - 1) / WAVE) * WAVE; tb >= 0; tb -= WAVE) {
+  seek(B, LI, T, -1);   // (the layout of time T, the transition T - 1)
+  for (int tb = ((T - 1) / BL) * BL; tb >= 0; tb -= BL) {
     const int tt = tb + lane;
-    const bool in_l = tt < T;
-    const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+    const int nstep = (T - tb < BL) ? T - tb : BL;
+    const bool in_l = lane < nstep;
     blk_load(blk, gK + (size_t)tb * m, nstep * m, lane);
     const double ef_l = in_l ? w0[tt] : 0.0;
-    double d0_l = 0.0, d1_l = 0.0, d2_l = 0.0, d3_l = 0.0;
-    int c1 = SEAS ? cursor_at(tb + nstep, S.ns) : 0;   // layout of r at the block's last step
 #pragma nounroll
     for (int s = nstep - 1; s >= 0; --s) {
       const double K = mylane ? blk[s * m + lane] : 0.0;
-      const int c0 = SEAS ? (c1 + 1 == S.ns ? 0 : c1 + 1) : 0;   // c_t from c_{t+1}
-      // r_t at the rows that carry state error: what the correction pass needs
-      const double q0 = rl(r, 0);
-      if (lane == s) d0_l = q0;
-      if (TREND == 2) { const double q1 = rl(r, 1); if (lane == s) d1_l = q1; }
-      if (SEAS) { const double q2 = rl(r, S.s0 + c1); if (lane == s) d2_l = q2; }
-      if (AR) { const double q3 = rl(r, S.a0); if (lane == s) d3_l = q3; }
-      const double kr = row_total(K * r);
+      const unsigned mv = B.moving();
+      // r_t at the error rows (layout of t + 1), one value per step and variance parameter
+      if (mylane) {
+        bool carrier;
+        if (LI.kind == SSG_SEASONAL) carrier = lane == LI.first + LI.cur;
+        else if (LI.kind == SSG_LOCAL_LINEAR_TREND) carrier = true;
+        else carrier = lane == LI.first;
+        if (carrier) s_z[var_l * BL + s] = r;
+      }
+      const double kr = wsum<SMALL>(K * r);
       const double coef = rl(ef_l, s) - kr;
-      r = vecTt<TREND, SEAS, AR>(S, r, lane, c1, phl);
-      if (lane == 0 || (SEAS && lane == S.s0 + c0) || (AR && lane == S.a0)) r += coef;
+      r = vecTt(B, LI, r, lane, mv);
+      retreat(B, LI, mv);
+      // + Z coef (layout of t)
+      bool zl = false;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (b < nb && lane == B.zlane(b)) zl = true;
+      if (zl) r += coef;
       if (!mylane) r = 0.0;
-      c1 = c0;
     }
-    __builtin_amdgcn_wave_barrier();
-    if (in_l) {
-      gd[tt] = d0_l;
-      if (TREND == 2) gd[(size_t)T + tt] = d1_l;
-      if (SEAS) gd[(size_t)2 * T + tt] = d2_l;
-      if (AR) gd[(size_t)3 * T + tt] = d3_l;
-    }
+    wave_lds_sync();
+    for (int e = 0; e < NE; ++e)
+      if (in_l) gd[(size_t)e * T + tt] = s_z[e * BL + lane];
+    wave_lds_sync();
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -806,94 +990,109 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   // draw, the state models' and the regression's sufficient statistics
   double mc = P0l * r;          // a0 + P0 r0 - (a0 + P0 r0+)
   double prev = 0.0;            // state_{t-1} (its own layout)
-  double suf0 = 0.0, suf2 = 0.0;
-  double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of the trend errors (lanes 0, 1)
+  double suf_l = 0.0;           // local level / seasonal: sum of squared state errors (at the lane that carried them)
+  double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of a trend block's errors (its two lanes)
   double yty = 0.0, nobs = 0.0;
-  // ArModel's NeRegSuf of now[a0] on then[a0 ..]: lane a0 + i keeps xty_i and row i of xtx,
-  // the row in LDS (s_P is free by now: wave 1 has left), at s_axx[i * PLD + q]
+  // ArModel's NeRegSuf of now[first] on then[first ..]: lane first + i keeps xty_i and row i
+  // of xtx, the row in LDS at s_axx[(block's slot * AR_MAX + i) * (AR_MAX + 1) + q]
   double axy = 0.0, ayy = 0.0;
-  double *s_axx = s_P;
-  if (AR) {
-    for (int e2 = lane; e2 < SSM_MAX * PLD; e2 += WAVE) s_axx[e2] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-  }
-  double *oblk = s_blk[1];
+  for (int e2 = lane; e2 < M.nar * AR_MAX * (AR_MAX + 1); e2 += WAVE) s_axx[e2] = 0.0;
+  wave_lds_sync();
+  double *oblk = s_blk1;
+  seek(B, LI, 0, -1);
   {
-    int c = 0;
-    for (int tb = 0; tb < T; tb += WAVE) {
+    for (int tb = 0; tb < T; tb += BL) {
       const int tt = tb + lane;
-      const bool in_l = tt < T;
-      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      const int nstep = (T - tb < BL) ? T - tb : BL;
+      const bool in_l = lane < nstep;
       blk_load(blk, gst + (size_t)tb * m, nstep * m, lane);
-      const bool dd = in_l && tt > 0;
-      const double d0_l = dd ? gd[tt - 1] : 0.0;
-      const double d1_l = (dd && TREND == 2) ? gd[(size_t)T + tt - 1] : 0.0;
-      const double d2_l = (dd && SEAS) ? gd[(size_t)2 * T + tt - 1] : 0.0;
-      const double d3_l = (dd && AR) ? gd[(size_t)3 * T + tt - 1] : 0.0;
+      // r_{t-1} at the error rows, for the steps into tb .. tb + nstep - 1
+      for (int e = 0; e < NE; ++e) s_z[e * BL + lane] = (in_l && tt > 0) ? gd[(size_t)e * T + tt - 1] : 0.0;
+      wave_lds_sync();
       const double y_l = in_l ? P.y[tt] : 0.0;
       const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
       double res_l = 0.0;
 #pragma nounroll
       for (int s = 0; s < nstep; ++s) {
         const double ap = mylane ? blk[s * m + lane] : 0.0;
+        unsigned mv = 0;
+        double tot_then = 0.0;   // seasonal: sum of the block at t - 1 (uniform per block: kept per lane of the block)
         if (tb + s > 0) {
-          const int cn = SEAS ? cursor_prev(c, S.ns) : 0;
-          mc = vecT<TREND, SEAS, AR>(S, mc, lane, c, phl);
-          if (TREND == 2) mc += sig_tr * ((lane == 0) ? rl(d0_l, s) : rl(d1_l, s));
-          else mc += sig_tr * rl(d0_l, s);
-          if (SEAS) { if (lane == S.s0 + cn) mc += sig2[2] * rl(d2_l, s); }
-          if (AR) { if (lane == S.a0) mc += sig2a * rl(d3_l, s); }
-          c = cn;
+          mv = B.moving();
+          // (the seasonal models' observe_state needs the sum of `then` over the block)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            if (b < nb && B.kind(b) == SSG_SEASONAL && ((mv >> b) & 1u)) {
+              const double tb_ = wsum<SMALL>(LI.blk == b ? prev : 0.0);
+              if (LI.blk == b) tot_then = tb_;
+            }
+          }
+          mc = vecT<SMALL>(B, LI, mc, lane, mv);
+          advance(B, LI, mv);
+          // + RQR_{t-1} r_{t-1}
+          bool carrier = false;
+          if (mylane) {
+            if (LI.kind == SSG_SEASONAL) carrier = LI.moves(mv) && lane == LI.first + LI.cur;
+            else if (LI.kind == SSG_LOCAL_LINEAR_TREND) carrier = true;
+            else carrier = lane == LI.first;
+          }
+          if (carrier) mc += sig_l * s_z[var_l * BL + s];
+        } else {
+          advance(B, LI, 0u);
         }
         const double st = mylane ? ap + mc : 0.0;
         if (tb + s > 0) {
-          if (TREND == 1) {
-            const double diff = st - prev;                 // (lane 0)
-            if (lane == 0) suf0 += diff * diff;
-          } else {
+          if (LI.kind == SSG_LOCAL_LEVEL) {
+            const double diff = st - prev;
+            suf_l += diff * diff;
+          } else if (LI.kind == SSG_LOCAL_LINEAR_TREND) {
             // err = now - T then; MvnSuf::update_raw (MvnBase.cpp:71-86), diagonal only
-            const double then1 = rl(prev, 1);
-            const double err = st - ((lane == 0) ? prev + then1 : prev);
+            const double then1 = from_above(prev);
+            const double err = st - ((lane == LI.first) ? prev + then1 : prev);
             mv_n += 1.0;
             const double wv = (err - mv_ybar) / mv_n;
             mv_ybar += wv;
             mv_sumsq += wv * wv * (mv_n - 1);
             const double w2 = err - mv_ybar;
             mv_sumsq += w2 * w2;
+          } else if (LI.kind == SSG_SEASONAL) {
+            // delta = now[0] + sum(then) over the block, on the steps into a new season
+            if (LI.moves(mv) && lane == LI.first + LI.cur) {
+              const double dl = st - (-1.0 * tot_then);
+              suf_l += dl * dl;
+            }
           }
-          if (SEAS) {
-            // delta = now[0] + sum(then) over the seasonal block
-            const double tot = row_total(S.seasonal(lane) ? prev : 0.0);
-            const double dl = st - (-1.0 * tot);
-            if (lane == S.s0 + c) suf2 += dl * dl;
-          }
-          if (AR) {
-            // add_mixture_data(now[0], then, 1.0): xtx += then then', xty += now[0] then, yty += now[0]^2
-            const double yy = rl(st, S.a0);
-            {
-              double *row = s_axx + (S.ar(lane) ? lane - S.a0 : 0) * PLD;
+          // autoregression: add_mixture_data(now[0], then, 1.0): xtx += then then', xty += now[0] then, yty += now[0]^2
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            if (b < nb && B.kind(b) == SSG_AR) {
+              const int f = B.first(b), n = B.dim(b);
+              const double yy = rl(st, f);
+              double *rowx = s_axx + ((size_t)B.arx(b) * AR_MAX + (LI.blk == b ? lane - f : 0)) * (AR_MAX + 1);
 #pragma nounroll
-              for (int q = 0; q < S.na; ++q) {
-                const double pq = rl(prev, S.a0 + q);
-                if (S.ar(lane)) row[q] += prev * pq * 1.0;
+              for (int q = 0; q < n; ++q) {
+                const double pq = rl(prev, f + q);
+                if (LI.blk == b) rowx[q] += prev * pq * 1.0;
+              }
+              if (LI.blk == b) {
+                axy += (yy * 1.0) * prev;
+                ayy += yy * yy * 1.0;
               }
             }
-            axy += (yy * 1.0) * prev;
-            ayy += yy * yy * 1.0;
           }
         }
         prev = st;
         if (mylane) {
           // the state draw goes out in logical order
           int idx = lane;
-          if (SEAS && S.seasonal(lane)) {
-            const int q = lane - S.s0;
-            idx = S.s0 + (q >= c ? q - c : q - c + S.ns);
+          if (LI.kind == SSG_SEASONAL) {
+            const int q = lane - LI.first, c = LI.cur;
+            idx = LI.first + (q >= c ? q - c : q - c + LI.dim);
           }
           oblk[s * m + idx] = st;
         }
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
-        const double resid = obs ? rl(y_l, s) - zdot<SEAS, AR>(S, st, c) : 0.0;
+        const double resid = obs ? rl(y_l, s) - zdot(B, st) : 0.0;
         if (lane == s) res_l = resid;
         if (obs) { yty += resid * resid; nobs += 1.0; }
       }
@@ -908,35 +1107,42 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
            kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
 #endif
   // publish the sufficient statistics
-  if (TREND == 2) {
-    // center_sumsq(mu = 0)(i, i) = sumsq_ii + n ybar_i^2
-    const double ssv = mv_sumsq + mv_ybar * mv_ybar * mv_n;
-    if (lane < 2) {
-      Q.var_n[(size_t)chain * 3 + lane] = mv_n;
-      Q.var_ss[(size_t)chain * 3 + lane] = ssv;
-    }
-  } else if (lane == 0) {
-    Q.var_n[(size_t)chain * 3 + 0] = (double)(T - 1);
-    Q.var_ss[(size_t)chain * 3 + 0] = suf0;
-  }
-  if (SEAS) {
-    // (the lane that accumulated moved with the cursor: sum over the block)
-    const double tot = row_total(S.seasonal(lane) ? suf2 : 0.0);
-    if (lane == 0) {
-      Q.var_n[(size_t)chain * 3 + 2] = (double)(T - 1);
-      Q.var_ss[(size_t)chain * 3 + 2] = tot;
-    }
-  }
-  if (AR) {
-    double *suf = Q.ar_suf + (size_t)chain * AR_SUF_STRIDE;
-    if (S.ar(lane)) {
-      const int i = lane - S.a0;
-      for (int q = 0; q < S.na; ++q) suf[i * SSM_MAX + q] = s_axx[i * PLD + q];
-      suf[AR_SUF_XTY + i] = axy;
-    }
-    if (lane == 0) {
-      suf[AR_SUF_YTY] = ayy;
-      suf[AR_SUF_N] = (double)(T - 1);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b >= nb) break;
+    const int f = B.first(b), n = B.dim(b), kd = B.kind(b);
+    const size_t at = (size_t)chain * SSG_MAX_VAR + B.var0(b);
+    if (kd == SSG_LOCAL_LEVEL) {
+      if (lane == f) {
+        M.var_n[at] = (double)(T - 1);
+        M.var_ss[at] = suf_l;
+      }
+    } else if (kd == SSG_LOCAL_LINEAR_TREND) {
+      // center_sumsq(mu = 0)(i, i) = sumsq_ii + n ybar_i^2
+      const double ssv = mv_sumsq + mv_ybar * mv_ybar * mv_n;
+      if (lane == f || lane == f + 1) {
+        M.var_n[at + (lane - f)] = mv_n;
+        M.var_ss[at + (lane - f)] = ssv;
+      }
+    } else if (kd == SSG_SEASONAL) {
+      // (the lane that accumulated moved with the cursor: sum over the block)
+      const double tot = wsum<SMALL>(LI.blk == b ? suf_l : 0.0);
+      if (lane == f) {
+        M.var_n[at] = (double)seasons_started(T - 1, B.dur(b), B.phase(b));
+        M.var_ss[at] = tot;
+      }
+    } else {
+      double *suf = M.ar_suf + ((size_t)chain * SSG_MAX_AR + B.arx(b)) * AR_SUF_STRIDE;
+      if (LI.blk == b) {
+        const int i = lane - f;
+        const double *rowx = s_axx + ((size_t)B.arx(b) * AR_MAX + i) * (AR_MAX + 1);
+        for (int q = 0; q < n; ++q) suf[i * AR_MAX + q] = rowx[q];
+        suf[AR_SUF_XTY + i] = axy;
+      }
+      if (lane == f) {
+        suf[AR_SUF_YTY] = ayy;
+        suf[AR_SUF_N] = (double)(T - 1);
+      }
     }
   }
   if (lane == 0) {
@@ -948,75 +1154,67 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 
 // StateSpaceRegressionModel::simulate_forecast for every chain's current draw of the
 // structural model (StateSpaceRegressionModel.cpp:216-219, :256-278): the state
-// advances by T state + state errors (trend, then seasonal), the observation is
+// advances by T state + state errors (model by model), the observation is
 // rnorm(Z'state, sigma_obs) + x'beta; normals in the reference's order on the
 // chain's forecast stream (id 5).  One wavefront per chain, lane = state component
-// (logical order; the horizon is short, the seasonal block simply shifts).
-__global__ __launch_bounds__(64) void ssm_forecast_kernel(SsParams P, int horizon, const double *newX,
+// (logical order; the horizon is short, a seasonal block simply shifts).  As the
+// reference (advance_to_timestamp, StateSpaceModelBase.cpp:455-459) forecast step i
+// uses the transition matrix and state errors of time T - 2 + i.
+__global__ __launch_bounds__(64) void ssg_forecast_kernel(SsParams P, int horizon, const double *newX,
                                                           uint64_t *pos_forecast, double *out) {
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x;
   if ((int)blockIdx.x >= P.chain_count) return;
   if (P.status[chain] != CHAIN_OK) return;
-  const SsmParams &Q = P.ssm;
-  const int T = P.T, p = P.p, m = Q.m, trend = Q.trend, s0 = Q.s0;
-  const int ns = Q.nseasons > 0 ? Q.nseasons - 1 : 0;
+  const SsmParams &M = P.ssm;
+  const SsgSpec &Q = *M.spec;
+  const int T = P.T, p = P.p, m = M.m, nb = M.nblocks;
   const double *beta = P.beta + (size_t)chain * p;
   const double sd_obs = sqrt(P.sigsq[chain]);
-  const double sd0 = sqrt(Q.var_sigsq[(size_t)chain * 3 + 0]), sd1 = sqrt(Q.var_sigsq[(size_t)chain * 3 + 1]),
-               sd2 = sqrt(Q.var_sigsq[(size_t)chain * 3 + 2]);
-  const double *gst = Q.work + (size_t)chain * Q.work_stride + (size_t)m * T;
+  const double *gst = M.work + (size_t)chain * M.work_stride + (size_t)m * T;
   double st = (lane < m) ? gst[(size_t)(T - 1) * m + lane] : 0.0;
-  const bool seas = ns > 0 && lane >= s0 && lane < s0 + ns;
-  const int na = Q.ar_lags, a0 = Q.ar0;
-  const bool arl = na > 0 && lane >= a0 && lane < a0 + na;
-  const double phl = arl ? Q.ar_phi[(size_t)chain * SSM_MAX + (lane - a0)] : 0.0;
-  const double sda = na > 0 ? sqrt(Q.ar_sigsq[chain]) : 0.0;
   SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 5u}, pos_forecast[chain]};
   for (int i = 0; i < horizon; ++i) {
-    // state errors, in the reference's order
-    double e0, e1 = 0.0, e2 = 0.0;
-    if (trend == 1) {
-      e0 = d_rnorm(rng, 0.0, sd0);
-    } else {
-      const double z0 = d_rnorm(rng, 0.0, 1.0), z1 = d_rnorm(rng, 0.0, 1.0);
-      e0 = sd0 * z0 + 0.0;
-      e1 = sd1 * z1 + 0.0;
-    }
-    if (ns > 0) e2 = d_rnorm(rng, 0.0, sd2);
-    double e3 = 0.0;
-    if (na > 0) e3 = d_rnorm(rng, 0.0, 1.0) * sda;
-    // T state
+    const int tm = T - 2 + i;   // the transition's index
     double nx = st;
-    if (trend == 2) { const double x1 = rl(st, 1); if (lane == 0) nx = st + x1; }
-    if (ns > 0) {
-      // (first = 0 - s_0 - s_1 - ..., SeasonalStateSpaceMatrix::multiply)
-      double first = 0.0;
-      for (int q = 0; q < ns; ++q) first -= rl(st, s0 + q);
-      const double prev = sdpp<0x111, 0xf>(st, 0.0);
-      if (lane == s0) nx = first; else if (seas) nx = prev;
+    for (int b = 0; b < nb; ++b) {
+      const SsgBlock &K = Q.blk[b];
+      const int f = K.first, n = K.dim;
+      const bool mine = lane >= f && lane < f + n;
+      const double *sg = M.var_sigsq + (size_t)chain * SSG_MAX_VAR + K.var0;
+      if (K.kind == SSG_LOCAL_LEVEL) {
+        const double e0 = d_rnorm(rng, 0.0, sqrt(sg[0]));
+        if (lane == f) nx = st + e0;
+      } else if (K.kind == SSG_LOCAL_LINEAR_TREND) {
+        const double z0 = d_rnorm(rng, 0.0, 1.0), z1 = d_rnorm(rng, 0.0, 1.0);
+        const double x1 = rl(st, f + 1);
+        if (lane == f) nx = (st + x1) + (sqrt(sg[0]) * z0 + 0.0);
+        if (lane == f + 1) nx = st + (sqrt(sg[1]) * z1 + 0.0);
+      } else if (K.kind == SSG_SEASONAL) {
+        if ((tm + 1) % K.duration == K.phase) {
+          const double e2 = d_rnorm(rng, 0.0, sqrt(sg[0]));
+          // (first = 0 - s_0 - s_1 - ..., SeasonalStateSpaceMatrix::multiply)
+          double firstv = 0.0;
+          for (int q = 0; q < n; ++q) firstv -= rl(st, f + q);
+          const double below = from_below(st);
+          if (lane == f) nx = firstv + e2; else if (mine) nx = below;
+        }
+      } else {
+        const double *ph = M.ar_phi + ((size_t)chain * SSG_MAX_AR + K.ar_index) * AR_MAX;
+        const double e3 = d_rnorm(rng, 0.0, 1.0) * sqrt(sg[0]);
+        // (first = sum of phi_i s_i from the last lag down, AutoRegressionTransitionMatrix::multiply_inplace)
+        double firstv = 0.0;
+        for (int q = n - 1; q >= 0; --q) firstv += ph[q] * rl(st, f + q);
+        const double below = from_below(st);
+        if (lane == f) nx = firstv + e3; else if (mine) nx = below;
+      }
     }
-    if (na > 0) {
-      // (first = sum of phi_i s_i from the last lag down, AutoRegressionTransitionMatrix::multiply_inplace)
-      double first = 0.0;
-      for (int q = na - 1; q >= 0; --q) first += rl(phl, a0 + q) * rl(st, a0 + q);
-      const double prev = sdpp<0x111, 0xf>(st, 0.0);
-      if (lane == a0) nx = first; else if (arl) nx = prev;
-    }
-    st = nx + ((lane == 0) ? e0 : ((trend == 2 && lane == 1) ? e1 : ((ns > 0 && lane == s0) ? e2 :
-                                                                   ((na > 0 && lane == a0) ? e3 : 0.0))));
-    if (lane >= m) st = 0.0;
-    double zs = rl(st, 0);
-    if (ns > 0) zs += rl(st, s0);
-    if (na > 0) zs += rl(st, a0);
+    st = (lane < m) ? nx : 0.0;
+    double zs = rl(st, Q.blk[0].first);
+    for (int b = 1; b < nb; ++b) zs += rl(st, Q.blk[b].first);
     const double obs = d_rnorm(rng, zs, sd_obs);
     double part = 0.0;
     for (int j = lane; j < p; j += WAVE) part += newX[(size_t)j * horizon + i] * beta[j];
-    // (sum over the wave: 64 lanes)
-    part += sdpp<0x111, 0xf>(part, 0.0);
-    part += sdpp<0x112, 0xf>(part, 0.0);
-    part += sdpp<0x114, 0xf>(part, 0.0);
-    part += sdpp<0x118, 0xf>(part, 0.0);
-    const double pred = rl(part, 15) + rl(part, 31) + rl(part, 47) + rl(part, 63);
+    const double pred = wsum<false>(part);
     if (lane == 0) out[(size_t)chain * horizon + i] = obs + pred;
   }
   if (lane == 0) pos_forecast[chain] = rng.pos;
@@ -1024,7 +1222,7 @@ __global__ __launch_bounds__(64) void ssm_forecast_kernel(SsParams P, int horizo
 
 hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
                                uint64_t *pos_forecast, double *out) {
-  hipLaunchKernelGGL(ssm_forecast_kernel, dim3(P.chain_count), dim3(WAVE), 0, stream, P, horizon, newX,
+  hipLaunchKernelGGL(ssg_forecast_kernel, dim3(P.chain_count), dim3(WAVE), 0, stream, P, horizon, newX,
                      pos_forecast, out);
   return hipGetLastError();
 }
@@ -1032,23 +1230,34 @@ hipError_t launch_ssm_forecast(hipStream_t stream, const SsParams &P, int horizo
 hipError_t launch_xte_tiled(hipStream_t stream, const double *U, int64_t ldu, int R, const double *B, int64_t n,
                             int p, double *out, double *planes);
 
+size_t ssm_dynamic_lds(const SsmParams &M) {
+  size_t need = (size_t)ssg_pass_lds_doubles(M.m, M.ld, M.bl, M.nerr, M.nar) * sizeof(double);
+  if (need < sizeof(NormalsLds)) need = sizeof(NormalsLds);
+  if (need < sizeof(ArLds)) need = sizeof(ArLds);
+  return (need + 15) & ~(size_t)15;
+}
+
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances) {
   const dim3 grid(P.chain_count), block(2 * WAVE);
-  const bool seas = P.ssm.nseasons > 0, ar = P.ssm.ar_lags > 0;
-#define SSM_LAUNCH(TR, SE, AR) hipLaunchKernelGGL((ssm_simsmooth_kernel<TR, SE, AR>), grid, block, 0, stream, P, draw_variances)
-#define SSM_LAUNCH_AR(TR, SE) do { if (ar) SSM_LAUNCH(TR, SE, true); else SSM_LAUNCH(TR, SE, false); } while (0)
+  const size_t lds = ssm_dynamic_lds(P.ssm);
   hipError_t err;
   {
     KtScope kt(stream, KT_SSM);
-    if (!seas) {
-      if (P.ssm.trend == 1) SSM_LAUNCH_AR(1, false); else SSM_LAUNCH_AR(2, false);
+    if (P.ssm.m <= 16) {
+      hipLaunchKernelGGL((ssg_simsmooth_kernel<true>), grid, block, lds, stream, P, draw_variances);
     } else {
-      if (P.ssm.trend == 1) SSM_LAUNCH_AR(1, true); else SSM_LAUNCH_AR(2, true);
+      // (more than 64 KB of dynamic LDS has to be asked for, once per process and size)
+      static size_t allowed = 65536;
+      if (lds > allowed) {
+        err = hipFuncSetAttribute((const void *)ssg_simsmooth_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        allowed = lds;
+      }
+      hipLaunchKernelGGL((ssg_simsmooth_kernel<false>), grid, block, lds, stream, P, draw_variances);
     }
     err = hipGetLastError();
   }
-#undef SSM_LAUNCH_AR
-#undef SSM_LAUNCH
   if (err != hipSuccess) return err;
   // xty[chain, j] = x_j' e_chain (the residual series are array 1 of every chain's scratch block)
   return launch_xte_tiled(stream, P.scratch + (size_t)P.chain_first * P.scratch_stride + P.T, P.scratch_stride,

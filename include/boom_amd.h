@@ -408,41 +408,78 @@ int ba_ss_set_local_level(ba_engine *e, double level_df,
                           double initial_state_mean,
                           double initial_state_variance,
                           double initial_level_sigma);
-/* Richer state, instead of ba_ss_set_local_level: a trend state
- * model -- trend = 1: LocalLevelStateModel; 2: LocalLinearTrendStateModel with one
- * ZeroMeanMvnIndependenceSampler per variance, as bsts builds it
- * (StateModels/LocalLinearTrend.cpp, PosteriorSamplers/
- * ZeroMeanMvnIndependenceSampler.cpp:63-70) -- plus an optional
- * SeasonalStateModel(nseasons, season_duration = 1) with a
- * ZeroMeanGaussianConjSampler (StateModels/SeasonalStateModel.cpp); nseasons = 0:
- * none.  State dimension m = trend + max(nseasons - 1, 0) <= 16.  The
- * three-element arrays are indexed level, slope, seasonal (prior df, sigma guess,
+/* Richer state, instead of ba_ss_set_local_level: BOOM's
+ * block-diagonal state -- any list of state models, in the order add_state receives
+ * them (Models/StateSpace/StateSpaceModelBase.hpp:637-638; the transition / variance
+ * matrices are block diagonal, Filters/SparseMatrix.hpp:2196).
+ *
+ * ba_ss_add_state_model appends ONE state model (the first call after
+ * ba_ss_set_local_level / ba_ss_clear_state_models starts a new list):
+ *   kind 1  LocalLevelStateModel + ZeroMeanGaussianConjSampler
+ *           (StateModels/LocalLevelStateModel.cpp)                      1 component
+ *   kind 2  LocalLinearTrendStateModel with one ZeroMeanMvnIndependenceSampler per
+ *           variance, as bsts builds it (StateModels/LocalLinearTrend.cpp,
+ *           PosteriorSamplers/ZeroMeanMvnIndependenceSampler.cpp:63-70)  2 components
+ *   kind 3  SeasonalStateModel(nseasons = iparams[0], season_duration = iparams[1])
+ *           with set_time_of_first_observation(iparams[2]) and a
+ *           ZeroMeanGaussianConjSampler (StateModels/SeasonalStateModel.cpp: the
+ *           transition / state-error variance are the seasonal matrices on the steps
+ *           INTO a new season, :89-104, :248-258, and identity / zero inside one)
+ *                                                                        nseasons - 1
+ *   kind 4  ArStateModel(lags = iparams[0] <= 16) + ArPosteriorSampler(ChisqModel(df,
+ *           sigma_guess)) (StateModels/ArStateModel.cpp; Models/TimeSeries/
+ *           PosteriorSamplers/ArPosteriorSampler.cpp:52-143: up to three multivariate
+ *           proposals for phi, accepted when stationary, else one coefficient at a time
+ *           from a truncated normal -- the reference's Tn2Sampler on the device,
+ *           distributions/Tn2Sampler.cpp:25-131 --; then sigma)          lags
+ * iparams is ignored for kinds 1 and 2 (may be NULL).  The var_* arrays hold one entry
+ * per variance parameter of the model (two for kind 2: level, slope; one otherwise):
+ * ChisqModel(df, sigma_guess) prior, sigma upper limit (infinity: none), initial sigma.
+ * initial_phi: lags entries, NULL = zeros; must be stationary, as ArModel's constructor
+ * demands (ArModel::check_stationary, ArModel.cpp:142-170, decided by the quick bound
+ * sum |phi| < 1 and then, where the reference finds polynomial roots, by the equivalent
+ * step-down recursion).  initial_state_mean / _variance: the model's components (the
+ * variance's diagonal; positive, a local level's may be 0).  Limits: state dimension
+ * <= 64, 8 state models, 16 variance parameters, 4 autoregression models.
+ * RNG streams: variance parameter v of a model reads the chain's sampler id 1 (level),
+ * 6 (slope), 7 (seasonal) or 12 (ArPosteriorSampler: the proposals' normals, then the
+ * sigma draw -- the reference takes the proposals from GlobalRng::rng and the rest from
+ * the sampler's generator) + 16 for every earlier model of the same family (local level
+ * and local linear trend are one family); the state draw reads stream 2. */
+int ba_ss_clear_state_models(ba_engine *e);
+int ba_ss_add_state_model(ba_engine *e, int32_t kind, const int32_t *iparams,
+                          const double *var_df, const double *var_sigma_guess,
+                          const double *var_sigma_upper_limit,
+                          const double *var_initial_sigma, const double *initial_phi,
+                          const double *initial_state_mean,
+                          const double *initial_state_variance);
+/* the state dimension and the number of state models of the specification */
+int ba_ss_state_dimension(ba_engine *e, int32_t *state_dimension, int32_t *nblocks);
+/* state model `block` of one chain: its variance parameters (nvar), the model's
+ * sufficient statistics of the last sweep (n, sum of squares per variance) and, for an
+ * autoregression model, its coefficients (lags) and the ArModel's sufficient
+ * statistics (xtx lags x lags column-major, xty, yty, n); any pointer may be NULL */
+int ba_ss_get_state_model(ba_engine *e, int64_t chain, int32_t block, double *variances,
+                          double *suf_n, double *suf_ss, double *phi, double *ar_xtx,
+                          double *ar_xty, double *ar_yty, double *ar_n);
+/* one chain's state draw (T x m, step t at [t * m, (t + 1) * m), the models' components
+ * in the order the models were added) */
+int ba_ss_get_state_draw(ba_engine *e, int64_t chain, double *state);
+/* The template of rounds 2-3, kept: a trend state model -- trend = 1: local level; 2:
+ * local linear trend -- plus an optional SeasonalStateModel(nseasons, season_duration =
+ * 1); nseasons = 0: none.  Equivalent to ba_ss_add_state_model(trend) [+ (seasonal)].
+ * The three-element arrays are indexed level, slope, seasonal (prior df, sigma guess,
  * sigma upper limit, initial sigma of each variance parameter; unused entries are
- * ignored); initial_state_mean / _variance have m entries (the variance diagonal;
- * positive).  RNG streams: 1 level, 6 slope, 7 seasonal, 2 state. */
+ * ignored); initial_state_mean / _variance have m = trend + max(nseasons - 1, 0)
+ * entries.  RNG streams: 1 level, 6 slope, 7 seasonal, 2 state. */
 int ba_ss_set_structural(ba_engine *e, int32_t trend, int32_t nseasons,
                          const double *var_df, const double *var_sigma_guess,
                          const double *var_sigma_upper_limit,
                          const double *var_initial_sigma,
                          const double *initial_state_mean,
                          const double *initial_state_variance);
-/* After ba_ss_set_structural: appends an ArStateModel(lags) block to the state
- * (StateModels/ArStateModel.cpp: transition = first row phi, ones below the
- * diagonal; one error variance; observation coefficient 1 at the block's first
- * element) with an ArPosteriorSampler(ChisqModel(prior_df, sigma_guess)) and
- * set_sigma_upper_limit (Models/TimeSeries/PosteriorSamplers/ArPosteriorSampler.cpp
- * :52-143: up to three multivariate proposals for phi, accepted when stationary,
- * else one coefficient at a time from a truncated normal; then sigma).  The state
- * dimension grows by lags (still <= 16).  initial_phi (lags entries, NULL: zeros)
- * must be stationary, as ArModel's constructor demands; initial_state_mean /
- * _variance: the block's lags entries (variances positive).  Stationarity
- * (ArModel::check_stationary, ArModel.cpp:142-170) is decided by the quick bound
- * sum |phi| < 1 and then, where the reference finds polynomial roots, by the
- * equivalent step-down recursion.  The tail cases of the coefficient-at-a-time
- * draw run the reference's Tn2Sampler on the device (hull across the wave,
- * distributions/Tn2Sampler.cpp:25-131).  RNG stream
- * 12: the proposals' normals, then the sigma draw (the reference takes the
- * proposals from GlobalRng::rng and the rest from the sampler's generator). */
+/* After ba_ss_set_structural: appends ONE ArStateModel(lags) (kind 4 above) to the
+ * template; ba_ss_get_ar reads it.  RNG stream 12. */
 int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess,
                  double sigma_upper_limit, double initial_sigma,
                  const double *initial_phi, const double *initial_state_mean,
@@ -452,9 +489,9 @@ int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess
  * n); any pointer may be NULL */
 int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq,
                  double *suf_xtx, double *suf_xty, double *suf_yty, double *suf_n);
-/* one chain's state draw (T x m, step t at [t * m, (t + 1) * m)), the three
- * variance parameters and the state models' sufficient statistics (n, sum of
- * squares) of the last sweep; any pointer may be NULL */
+/* (the template's accessor) one chain's state draw (T x m, step t at [t * m, (t + 1) * m)),
+ * the three variance parameters level / slope / seasonal and the state models'
+ * sufficient statistics (n, sum of squares) of the last sweep; any pointer may be NULL */
 int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state,
                          double *variances, double *suf_n, double *suf_ss);
 /* nsweeps x StateSpacePosteriorSampler::draw()

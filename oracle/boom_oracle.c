@@ -2374,7 +2374,11 @@ void bo_ssm_block_get_ar_suf(const bo_ssm *m, int b, double *xtx, double *xty, d
   *yty = B->ar_yty;
   *n = B->ar_n;
 }
-bo_rng *bo_ssm_ar_rng(bo_ssm *m) { return &m->blk[ssm_find(m, BO_BLK_AR)].rng[0]; }
+static bo_rng g_unused_rng;   /* (what the template's accessors hand out for a sampler the model does not have) */
+bo_rng *bo_ssm_ar_rng(bo_ssm *m) {
+  const int b = ssm_find(m, BO_BLK_AR);
+  return b < 0 ? &g_unused_rng : &m->blk[b].rng[0];
+}
 void bo_ssm_set_global_rng(bo_ssm *m, bo_rng *global) { m->ar_global_rng = global; }
 void bo_ssm_get_ar(const bo_ssm *m, double *phi, double *sigsq) {
   bo_ssm_block_get(m, ssm_find(m, BO_BLK_AR), sigsq, NULL, NULL, phi);
@@ -2399,7 +2403,6 @@ static bo_ssm_block *ssm_template_var(const bo_ssm *m, int which, int *v) {
   const int b = ssm_find(m, BO_BLK_SEASONAL);
   return b < 0 ? NULL : (bo_ssm_block *)&m->blk[b];
 }
-static bo_rng g_unused_rng;
 bo_rng *bo_ssm_variance_rng(bo_ssm *m, int which) {
   int v;
   bo_ssm_block *B = ssm_template_var(m, which, &v);

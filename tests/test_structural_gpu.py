@@ -238,12 +238,18 @@ def test_structural_ar_rejects_bad_arguments():
     eng.ss_set_data(y, X, obs)
     with pytest.raises(boom_amd.BoomAmdError):            # before ba_ss_set_structural
         eng.ss_add_ar(1, 0.01, 0.1, 1.0, 1.0, None, np.zeros(1), np.ones(1))
+    spec = structural_spec(y, 2, 61)
+    eng.ss_set_structural(2, 61, spec["var_df"], spec["var_sigma_guess"],
+                          spec["var_sigma_upper_limit"], spec["var_initial_sigma"],
+                          spec["initial_state_mean"], spec["initial_state_variance"])
+    with pytest.raises(boom_amd.BoomAmdError):            # 62 + 4 > 64
+        eng.ss_add_ar(4, 0.01, 0.1, 1.0, 1.0, None, np.zeros(4), np.ones(4))
+    with pytest.raises(boom_amd.BoomAmdError):            # more than 16 lags
+        eng.ss_add_ar(17, 0.01, 0.1, 1.0, 1.0, None, np.zeros(17), np.ones(17))
     spec = structural_spec(y, 2, 12)
     eng.ss_set_structural(2, 12, spec["var_df"], spec["var_sigma_guess"],
                           spec["var_sigma_upper_limit"], spec["var_initial_sigma"],
                           spec["initial_state_mean"], spec["initial_state_variance"])
-    with pytest.raises(boom_amd.BoomAmdError):            # 13 + 4 > 16
-        eng.ss_add_ar(4, 0.01, 0.1, 1.0, 1.0, None, np.zeros(4), np.ones(4))
     with pytest.raises(boom_amd.BoomAmdError):            # a unit root
         eng.ss_add_ar(2, 0.01, 0.1, 1.0, 1.0, np.array([1.5, -0.5]), np.zeros(2), np.ones(2))
     with pytest.raises(boom_amd.BoomAmdError):            # variance 0
