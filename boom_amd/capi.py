@@ -128,6 +128,7 @@ SIGNATURES = {
                                C.c_double, _dp, _dp, _dp]),
     "ba_ss_get_ar": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
     "ba_ss_clear_state_models": (C.c_int, [C.c_void_p]),
+    "ba_ss_set_tuning": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_add_state_model": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)] + [_dp] * 7),
     "ba_ss_state_dimension": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ba_ss_get_state_model": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32] + [_dp] * 8),
@@ -568,6 +569,9 @@ class Engine:
         self._check(self.lib.ba_ss_state_dimension(self._h, C.byref(m), C.byref(nb)))
         self._ssm_dim = m.value
         self._ar_lags = 0
+
+    def ss_set_tuning(self, use_template_kernel=True):
+        self._check(self.lib.ba_ss_set_tuning(self._h, 1 if use_template_kernel else 0))
 
     def ss_get_state_model(self, chain, block):
         b = self._blocks[block]

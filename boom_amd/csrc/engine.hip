@@ -385,6 +385,7 @@ struct ba_engine {
   // the template of ba_ss_set_structural (level / slope / seasonal -> variance index, -1: none)
   int ssg_template_var[3] = {-1, -1, -1};
   int ssg_template_ar = -1;        // ... and the block ba_ss_add_ar appended
+  bool ssg_use_template = true;    // (ba_set_tuning: the shape-specialised kernel where it applies)
   DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;   // chains x SSG_MAX_VAR (sigsq, n, ss)
   DevBuf<double> dar_phi, dar_suf;                         // chains x SSG_MAX_AR x (AR_MAX | AR_SUF_STRIDE)
   DevBuf<uint64_t> dpos_var;                               // chains x SSG_MAX_VAR
@@ -872,7 +873,34 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
 
 // per chain: K (m T) | state (m T) | smoothed disturbances (nvar T) | normals (<= (nvar + 1) T + m + 1)
 int64_t ssm_work_stride(const ba_engine &e) {
-  return (int64_t)(2 * e.ssg.m + 2 * e.ssg.nvar + 1) * e.T + SSG_MAX_STATE + 72;
+  // (the template kernel keeps four disturbance series and up to five normals a step)
+  const int64_t per_step = std::max(2 * e.ssg.m + 2 * e.ssg.nvar + 1, 2 * e.ssg.m + 9);
+  return per_step * e.T + SSG_MAX_STATE + 72;
+}
+
+// does the block list have the shape the template kernel is compiled for?
+// [local level | local linear trend] [seasonal, duration 1] [autoregression], m <= 16
+void ssg_template_shape(const SsgSpec &q, int32_t *trend, int32_t *nseasons, int32_t *ar_lags) {
+  *trend = *nseasons = *ar_lags = 0;
+  if (q.nblocks < 1 || q.nblocks > 3 || q.m > 16) return;
+  int b = 0, tr = 0, ns = 0, lags = 0;
+  if (q.blk[0].kind == SSG_LOCAL_LEVEL) tr = 1;
+  else if (q.blk[0].kind == SSG_LOCAL_LINEAR_TREND) tr = 2;
+  else return;
+  b = 1;
+  if (b < q.nblocks && q.blk[b].kind == SSG_SEASONAL) {
+    if (q.blk[b].duration != 1) return;
+    ns = q.blk[b].nseasons;
+    ++b;
+  }
+  if (b < q.nblocks && q.blk[b].kind == SSG_AR) {
+    lags = q.blk[b].lags;
+    ++b;
+  }
+  if (b != q.nblocks) return;
+  *trend = tr;
+  *nseasons = ns;
+  *ar_lags = lags;
 }
 
 // the local-level path of a series of at most LM_TP steps runs lane-major
@@ -933,6 +961,7 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
     S.ssm.ld = e->ssg.ld;
     S.ssm.bl = e->ssg.bl;
     S.ssm.nerr = e->ssg.nerr;
+    if (e->ssg_use_template) ssg_template_shape(e->ssg, &S.ssm.tpl_trend, &S.ssm.tpl_nseasons, &S.ssm.tpl_ar_lags);
     S.ssm.var_sigsq = e->dssm_sigsq.ptr;
     S.ssm.var_n = e->dssm_n.ptr;
     S.ssm.var_ss = e->dssm_ss.ptr;
@@ -3354,6 +3383,16 @@ void ssg_clear(ba_engine *e) {
 }  // namespace
 
 extern "C" {
+
+// diagnostic, changes no draw: 0 = the general kernel also where the shape-specialised one
+// applies (the two are compared by the tests), 1 = the default
+int ba_ss_set_tuning(ba_engine *e, int32_t use_template_kernel) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (use_template_kernel != 0 && use_template_kernel != 1) return fail(BA_E_INVALID, "use_template_kernel must be 0 or 1");
+  MUTATE(e);
+  e->ssg_use_template = use_template_kernel != 0;
+  return BA_OK;
+}
 
 int ba_ss_clear_state_models(ba_engine *e) {
   if (!e) return fail(BA_E_INVALID, "null engine");

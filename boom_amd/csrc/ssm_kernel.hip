@@ -63,7 +63,6 @@ namespace boom_amd {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int NB = SSG_MAX_BLOCKS;
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double sdpp(double x, double fill) {
@@ -330,81 +329,90 @@ __device__ __forceinline__ int ar_draw(ArLds &W, const double *suf, int L, doubl
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
 }
 
-// ---- the block list in wave-uniform registers (every loop over it is unrolled with a
-// uniform early exit, so the indices are compile-time constants).  Three words a block:
-// the kernel's scalar registers are few.
+// ---- the block list: lane b of each of three registers holds block b (so that all blocks
+// advance in one vector operation and a loop over blocks is a ROLLED loop that fetches its
+// block with v_readlane -- eight unrolled copies of every per-block code path made a kernel
+// of 60 000 instructions that ran out of the instruction cache).
 struct Blocks {
+  unsigned desc;   // kind (3 bits) | first (7) | dim (7) | index of its first variance parameter (5) | autoregression slot (3)
+  unsigned dp;     // seasonal: duration (16 bits) | phase (16)
+  unsigned rc;     // seasonal: (index of the step's transition + 1 - phase) mod duration (16 bits: 0 = it moves) |
+                   //           the rotating layout's cursor (16): physical slot of the block's first component
   int nb;
-  unsigned desc[NB];   // kind (3 bits) | first (7) | dim (7) | index of its first variance parameter (5) | autoregression slot (3)
-  unsigned dp[NB];     // seasonal: duration (16 bits) | phase (16)
-  unsigned rc[NB];     // seasonal: (index of the step's transition + 1 - phase) mod duration (16 bits: 0 = it moves) |
-                       //           the rotating layout's cursor (16): physical slot of the block's first component
   unsigned always;     // bit b: block b's transition is never the identity (trend, autoregression)
-  __device__ __forceinline__ int kind(int b) const { return (int)(desc[b] & 7u); }
-  __device__ __forceinline__ int first(int b) const { return (int)((desc[b] >> 3) & 127u); }
-  __device__ __forceinline__ int dim(int b) const { return (int)((desc[b] >> 10) & 127u); }
-  __device__ __forceinline__ int var0(int b) const { return (int)((desc[b] >> 17) & 31u); }
-  __device__ __forceinline__ int arx(int b) const { return (int)((desc[b] >> 22) & 7u); }
-  __device__ __forceinline__ int dur(int b) const { return (int)(dp[b] & 0xffffu); }
-  __device__ __forceinline__ int phase(int b) const { return (int)(dp[b] >> 16); }
-  __device__ __forceinline__ int cur(int b) const { return (int)(rc[b] >> 16); }
-  __device__ __forceinline__ void load(const SsgSpec &Q, int nblocks) {
+  unsigned seasmask;   // bit b: block b is seasonal
+  unsigned armask;     // bit b: block b is an autoregression
+  static __device__ __forceinline__ int kind_of(unsigned d) { return (int)(d & 7u); }
+  static __device__ __forceinline__ int first_of(unsigned d) { return (int)((d >> 3) & 127u); }
+  static __device__ __forceinline__ int dim_of(unsigned d) { return (int)((d >> 10) & 127u); }
+  static __device__ __forceinline__ int var0_of(unsigned d) { return (int)((d >> 17) & 31u); }
+  static __device__ __forceinline__ int arx_of(unsigned d) { return (int)((d >> 22) & 7u); }
+  // block b's words, wave-uniform
+  __device__ __forceinline__ unsigned udesc(int b) const { return (unsigned)__builtin_amdgcn_readlane((int)desc, b); }
+  __device__ __forceinline__ unsigned urc(int b) const { return (unsigned)__builtin_amdgcn_readlane((int)rc, b); }
+  __device__ __forceinline__ void load(const SsgSpec &Q, int nblocks, int lane) {
     nb = nblocks;
-    always = 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      desc[b] = 0; dp[b] = 1; rc[b] = 0;
-      if (b < nblocks) {
-        const SsgBlock &K = Q.blk[b];
-        desc[b] = (unsigned)K.kind | ((unsigned)K.first << 3) | ((unsigned)K.dim << 10) |
-                  ((unsigned)K.var0 << 17) | ((unsigned)(K.ar_index < 0 ? 0 : K.ar_index) << 22);
-        dp[b] = (unsigned)K.duration | ((unsigned)K.phase << 16);
-        if (K.kind == SSG_LOCAL_LINEAR_TREND || K.kind == SSG_AR) always |= 1u << b;
-      }
+    desc = 0; dp = 1; rc = 0;
+    if (lane < nblocks) {
+      const SsgBlock &K = Q.blk[lane];
+      desc = (unsigned)K.kind | ((unsigned)K.first << 3) | ((unsigned)K.dim << 10) |
+             ((unsigned)K.var0 << 17) | ((unsigned)(K.ar_index < 0 ? 0 : K.ar_index) << 22);
+      dp = (unsigned)K.duration | ((unsigned)K.phase << 16);
     }
+    const int kd = kind_of(desc);
+    always = (unsigned)__ballot(kd == SSG_LOCAL_LINEAR_TREND || kd == SSG_AR);
+    seasmask = (unsigned)__ballot(kd == SSG_SEASONAL);
+    armask = (unsigned)__ballot(kd == SSG_AR);
   }
-  // the lane Z selects in block b
-  __device__ __forceinline__ int zlane(int b) const { return first(b) + cur(b); }
   // the layout of time t; the transitions are walked from index t + shift on (0: the
   // transition OUT of the time, T_t; -1: the one INTO it, T_{t-1})
   __device__ __forceinline__ void seek(int t, int shift) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b < nb && kind(b) == SSG_SEASONAL) {
-        const int d = dur(b), n = dim(b);
-        const int q = seasons_started(t, d, phase(b)) % n;
-        const int c = q == 0 ? 0 : n - q;
-        int r = (t + shift + 1 - phase(b)) % d;
-        if (r < 0) r += d;
-        rc[b] = (unsigned)r | ((unsigned)c << 16);
-      }
+    if (kind_of(desc) == SSG_SEASONAL) {
+      const int d = (int)(dp & 0xffffu), ph = (int)(dp >> 16), n = dim_of(desc);
+      const int q = seasons_started(t, d, ph) % n;
+      const int c = q == 0 ? 0 : n - q;
+      int r = (t + shift + 1 - ph) % d;
+      if (r < 0) r += d;
+      rc = (unsigned)r | ((unsigned)c << 16);
     }
   }
   // bit b = block b's transition of this step is not the identity
   __device__ __forceinline__ unsigned moving() const {
-    unsigned mv = always;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-      if (b < nb && kind(b) == SSG_SEASONAL && (rc[b] & 0xffffu) == 0u) mv |= 1u << b;
-    return mv;
+    return always | (unsigned)__ballot(kind_of(desc) == SSG_SEASONAL && (rc & 0xffffu) == 0u);
+  }
+  // one step on / back: the layout after (before) the transitions `mv`, the next (previous) transition's phase
+  __device__ __forceinline__ void advance(unsigned mv, int lane) {
+    if (kind_of(desc) == SSG_SEASONAL) {
+      int r = (int)(rc & 0xffffu) + 1, c = (int)(rc >> 16);
+      if (r == (int)(dp & 0xffffu)) r = 0;
+      if ((mv >> lane) & 1u) c = sprev(c, dim_of(desc));
+      rc = (unsigned)r | ((unsigned)c << 16);
+    }
+  }
+  __device__ __forceinline__ void retreat(unsigned mv, int lane) {
+    if (kind_of(desc) == SSG_SEASONAL) {
+      int r = (int)(rc & 0xffffu), c = (int)(rc >> 16);
+      r = r == 0 ? (int)(dp & 0xffffu) - 1 : r - 1;
+      if ((mv >> lane) & 1u) c = snext(c, dim_of(desc));
+      rc = (unsigned)r | ((unsigned)c << 16);
+    }
   }
 };
 
 // per-lane constants of the lane's component
 struct LaneInfo {
   int blk, kind, first, dim;    // its block (kind 0: the lane holds no component)
-  int cur;                      // seasonal: its block's cursor (a per-lane copy of Blocks::cur)
+  int cur;                      // seasonal: its block's cursor (a per-lane copy)
   double phi;                   // autoregression: the lane's coefficient
   __device__ __forceinline__ bool moves(unsigned mv) const { return kind == SSG_SEASONAL && ((mv >> blk) & 1u); }
+  // is this the lane Z selects in its block (the block's first component)?
+  __device__ __forceinline__ bool zsel(int lane) const { return kind != 0 && lane == first + cur; }
 };
 
 // Z'x
-__device__ __forceinline__ double zdot(const Blocks &B, double x) {
-  double a = rl(x, B.zlane(0));
-#pragma unroll
-  for (int b = 1; b < NB; ++b)
-    if (b < B.nb) a += rl(x, B.zlane(b));
-  return a;
+template <bool SMALL>
+__device__ __forceinline__ double zdot(const LaneInfo &L, double x, int lane) {
+  return wsum<SMALL>(L.zsel(lane) ? x : 0.0);
 }
 // y = T x for a vector held one component per lane, in the layout the cursors say; mv:
 // bit b = block b's transition moves at this step (seasonal: the step into a new season);
@@ -412,85 +420,73 @@ __device__ __forceinline__ double zdot(const Blocks &B, double x) {
 template <bool SMALL>
 __device__ __forceinline__ double vecT(const Blocks &B, const LaneInfo &L, double x, int lane, unsigned mv) {
   double y = x;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b >= B.nb) break;
-    const int f = B.first(b), kd = B.kind(b);
-    if (kd == SSG_LOCAL_LINEAR_TREND) {
-      const double x1 = rl(x, f + 1);
-      if (lane == f) y = x + x1;
-    } else if (kd == SSG_SEASONAL) {
-      if ((mv >> b) & 1u) {
-        const double tot = wsum<SMALL>(L.blk == b ? x : 0.0);
-        if (lane == f + sprev(B.cur(b), B.dim(b))) y = -tot;
-      }
-    } else if (kd == SSG_AR) {
-      // new[0] = phi'old, new[i] = old[i - 1]  (AutoRegressionTransitionMatrix, SparseMatrix.cpp:1261-1310)
+  // (cross-lane moves read INACTIVE lanes as nothing: they stay outside the per-lane branches)
+  const double above = from_above(x);
+  if (L.kind == SSG_LOCAL_LINEAR_TREND && lane == L.first) y = x + above;
+  // autoregression: new[0] = phi'old, new[i] = old[i - 1]  (AutoRegressionTransitionMatrix, SparseMatrix.cpp:1261-1310)
+  if (B.armask) {
+    const double below = from_below(x);
+    if (L.kind == SSG_AR) y = below;
+    unsigned am = B.armask;
+    while (am) {
+      const int b = __ffs((int)am) - 1;
+      am &= am - 1;
       const double tot = wsum<SMALL>(L.blk == b ? L.phi * x : 0.0);
-      const double below = from_below(x);
-      if (L.blk == b) y = (lane == f) ? tot : below;
+      if (L.blk == b && lane == L.first) y = tot;
     }
+  }
+  // seasonal, a step into a new season: the slot of the component that drops out receives
+  // -(sum over the block)
+  unsigned sm = mv & B.seasmask;
+  while (sm) {
+    const int b = __ffs((int)sm) - 1;
+    sm &= sm - 1;
+    const double tot = wsum<SMALL>(L.blk == b ? x : 0.0);
+    if (L.blk == b && lane == L.first + sprev(L.cur, L.dim)) y = -tot;
   }
   return y;
 }
 // y = T' x; the cursors are those of x's layout (time t + 1); mv as above for the step t -> t + 1
 __device__ __forceinline__ double vecTt(const Blocks &B, const LaneInfo &L, double x, int lane, unsigned mv) {
   double y = x;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b >= B.nb) break;
-    const int f = B.first(b), kd = B.kind(b);
-    if (kd == SSG_LOCAL_LINEAR_TREND) {
-      const double x0 = rl(x, f);
-      if (lane == f + 1) y = x0 + x;
-    } else if (kd == SSG_SEASONAL) {
-      if ((mv >> b) & 1u) {
-        const int c1 = f + B.cur(b);
-        const double firstv = rl(x, c1);
-        if (L.blk == b) y = (lane == c1) ? -firstv : x - firstv;
-      }
-    } else if (kd == SSG_AR) {
-      // out[i] = phi_i x[0] + x[i + 1]  (Tmult, SparseMatrix.cpp:1286-1295)
-      const double firstv = rl(x, f);
-      const double above = from_above(x);
-      if (L.blk == b) y = L.phi * firstv + ((lane + 1 < f + B.dim(b)) ? above : 0.0);
+  const double below = from_below(x);
+  if (L.kind == SSG_LOCAL_LINEAR_TREND && lane == L.first + 1) y = below + x;
+  if (B.armask) {
+    // out[i] = phi_i x[0] + x[i + 1]  (Tmult, SparseMatrix.cpp:1286-1295)
+    const double above = from_above(x);
+    unsigned am = B.armask;
+    while (am) {
+      const int b = __ffs((int)am) - 1;
+      am &= am - 1;
+      const double firstv = rl(x, Blocks::first_of(B.udesc(b)));
+      if (L.blk == b) y = L.phi * firstv + ((lane + 1 < L.first + L.dim) ? above : 0.0);
     }
+  }
+  unsigned sm = mv & B.seasmask;
+  while (sm) {
+    const int b = __ffs((int)sm) - 1;
+    sm &= sm - 1;
+    const int c1 = Blocks::first_of(B.udesc(b)) + (int)(B.urc(b) >> 16);
+    const double firstv = rl(x, c1);
+    if (L.blk == b) y = (lane == c1) ? -firstv : x - firstv;
   }
   return y;
 }
-// one step on: the layout after the transitions `mv` moved, the next transition's phase
-__device__ __forceinline__ void advance(Blocks &B, LaneInfo &L, unsigned mv) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b < B.nb && B.kind(b) == SSG_SEASONAL) {
-      int r = (int)(B.rc[b] & 0xffffu) + 1, c = B.cur(b);
-      if (r == B.dur(b)) r = 0;
-      if ((mv >> b) & 1u) c = sprev(c, B.dim(b));
-      B.rc[b] = (unsigned)r | ((unsigned)c << 16);
-    }
-  }
+__device__ __forceinline__ void advance(Blocks &B, LaneInfo &L, unsigned mv, int lane) {
+  B.advance(mv, lane);
   if (L.moves(mv)) L.cur = sprev(L.cur, L.dim);
 }
-// one step back
-__device__ __forceinline__ void retreat(Blocks &B, LaneInfo &L, unsigned mv) {
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b < B.nb && B.kind(b) == SSG_SEASONAL) {
-      int r = (int)(B.rc[b] & 0xffffu), c = B.cur(b);
-      r = r == 0 ? B.dur(b) - 1 : r - 1;
-      if ((mv >> b) & 1u) c = snext(c, B.dim(b));
-      B.rc[b] = (unsigned)r | ((unsigned)c << 16);
-    }
-  }
+__device__ __forceinline__ void retreat(Blocks &B, LaneInfo &L, unsigned mv, int lane) {
+  B.retreat(mv, lane);
   if (L.moves(mv)) L.cur = snext(L.cur, L.dim);
 }
 // the layout of time t (see Blocks::seek)
 __device__ __forceinline__ void seek(Blocks &B, LaneInfo &L, int t, int shift) {
   B.seek(t, shift);
-  L.cur = 0;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-    if (b < B.nb && L.blk == b) L.cur = B.cur(b);
+  // (every lane takes part: a lane that is switched off is read as 0 by the others)
+  const unsigned mine = (unsigned)__shfl((int)B.rc, L.blk < 0 ? 0 : L.blk);
+  __builtin_amdgcn_wave_barrier();
+  L.cur = (L.kind == SSG_SEASONAL) ? (int)(mine >> 16) : 0;
 }
 
 }  // namespace
@@ -602,9 +598,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
     return;
   }
 
-  // ---- the block list in uniform registers, the lane's own constants
+  // ---- the block list, the lane's own constants
   Blocks B;
-  B.load(Q, nb);
+  B.load(Q, nb, lane);
   LaneInfo LI{-1, 0, 0, 0, 0, 0.0};
   int var_l = 0;          // the variance parameter behind this lane's state error
   int cbefore_l = 0;      // error terms drawn at EVERY step ahead of this lane's term
@@ -618,17 +614,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   {
     int cb = 0, ip = 0;
     unsigned sb = 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b >= nb) break;
-      const int f = B.first(b), n = B.dim(b), kd = B.kind(b);
+    for (int b = 0; b < nb; ++b) {
+      const unsigned d = B.udesc(b);
+      const int f = Blocks::first_of(d), n = Blocks::dim_of(d), kd = Blocks::kind_of(d), v0 = Blocks::var0_of(d);
       const bool mine = lane >= f && lane < f + n;
+      const bool second = kd == SSG_LOCAL_LINEAR_TREND && lane == f + 1;
       if (mine) {
         LI.blk = b; LI.kind = kd; LI.first = f; LI.dim = n;
-        var_l = B.var0(b) + ((kd == SSG_LOCAL_LINEAR_TREND && lane == f + 1) ? 1 : 0);
-        cbefore_l = cb + ((kd == SSG_LOCAL_LINEAR_TREND && lane == f + 1) ? 1 : 0);
+        var_l = v0 + (second ? 1 : 0);
+        cbefore_l = cb + (second ? 1 : 0);
         sbefore_l = sb;
-        if (kd == SSG_AR) LI.phi = s_phi[B.arx(b) * AR_MAX + (lane - f)];
+        if (kd == SSG_AR) LI.phi = s_phi[Blocks::arx_of(d) * AR_MAX + (lane - f)];
       }
       // the initial state's normals: a local level draws rnorm(a0, sd0) (nothing when
       // sd0 == 0), every other model rmvn: one per component
@@ -642,16 +638,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       }
       // the state errors of a step: local level: one if sigma != 0; trend: two, always;
       // seasonal: one on the steps into a new season if sigma != 0; autoregression: one, always
-      if (kd == SSG_LOCAL_LEVEL) cb += (s_sig2[B.var0(b)] != 0.0) ? 1 : 0;
+      const bool nz = s_sig2[v0] != 0.0;
+      if (kd == SSG_LOCAL_LEVEL) cb += nz ? 1 : 0;
       else if (kd == SSG_LOCAL_LINEAR_TREND) cb += 2;
       else if (kd == SSG_AR) cb += 1;
       else {
-        if (s_sig2[B.var0(b)] != 0.0) seas_active |= 1u << b;
+        if (nz) seas_active |= 1u << b;
         sb |= 1u << b;
       }
     }
-    nconst_err = cb;
-    nfirst = ip;
+    nconst_err = __builtin_amdgcn_readfirstlane(cb);
+    nfirst = __builtin_amdgcn_readfirstlane(ip);
+    seas_active = (unsigned)__builtin_amdgcn_readfirstlane((int)seas_active);
   }
   const bool mylane = lane < m;
   if (mylane) { a0l = Q.a0[lane]; P0l = Q.P0[lane]; }
@@ -691,12 +689,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   SSTAMP(1);
   // ---- 2. the normals of simulate_forward, in stream order.  t = 0: the initial state of
   // every state model, then the observation; t >= 1: the state errors of the step into t
-  // (model by model), then the observation.  off(t) = index of step t's first normal.
-  int nseas_tot = 0;   // seasonal error draws over the steps into times 1 .. T - 1
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-    if (b < nb && ((seas_active >> b) & 1u)) nseas_tot += seasons_started(T - 1, B.dur(b), B.phase(b));
-  const int N = (nfirst + dH) + (T - 1) * (nconst_err + dH) + nseas_tot;
+  // (model by model), then the observation.  zoffset(t) = index of step t's first normal.
+  auto seasonal_draws = [&](int t) -> int {   // seasonal error draws over the steps into times 1 .. t
+    int o = 0;
+    unsigned sm = seas_active;
+    while (sm) {
+      const int b = __ffs((int)sm) - 1;
+      sm &= sm - 1;
+      const unsigned dpw = (unsigned)__builtin_amdgcn_readlane((int)B.dp, b);
+      o += seasons_started(t, (int)(dpw & 0xffffu), (int)(dpw >> 16));
+    }
+    return o;
+  };
+  const int N = (nfirst + dH) + (T - 1) * (nconst_err + dH) + seasonal_draws(T - 1);
   status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
                           szz, &P.pos_state[chain]);
   if (status != CHAIN_OK) {
@@ -706,11 +711,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   __syncthreads();
   SSTAMP(2);
   auto zoffset = [&](int t) -> int {   // t >= 1
-    int o = (nfirst + dH) + (t - 1) * (nconst_err + dH);
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-      if (b < nb && ((seas_active >> b) & 1u)) o += seasons_started(t - 1, B.dur(b), B.phase(b));
-    return o;
+    return (nfirst + dH) + (t - 1) * (nconst_err + dH) + seasonal_draws(t - 1);
   };
 
   double *blk = wave == 0 ? s_blk0 : s_blk1;
@@ -739,13 +740,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         const unsigned mv = B.moving();
         // PZ_k = sum over the blocks of P(first of the block, k)  [= P(k, first), P symmetric]
         double PZ = 0.0;
-        if (mylane) {
-          PZ = s_P[B.zlane(0) * ld + lane];
-#pragma unroll
-          for (int b = 1; b < NB; ++b)
-            if (b < nb) PZ += s_P[B.zlane(b) * ld + lane];
+#pragma nounroll
+        for (int b = 0; b < nb; ++b) {
+          const int zl = Blocks::first_of(B.udesc(b)) + (int)(B.urc(b) >> 16);
+          if (mylane) PZ += s_P[zl * ld + lane];
         }
-        const double F = zdot(B, PZ) + H;
+        const double F = zdot<SMALL>(LI, PZ, lane) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
         if (lane == s) F_l = F;
         const double Finv = 1.0 / F;
@@ -758,93 +758,92 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         wave_lds_sync();
         // -- the column pass: lane k walks ITS column: the rank-one term of an observed step,
         // then T from the left, block by block
-        if (mylane) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            if (b >= nb) break;
-            const int f = B.first(b), n = B.dim(b);
-            double *col = s_P + f * ld + lane;
-            if (B.kind(b) == SSG_LOCAL_LEVEL) {
-              double v = col[0];
-              if (obs) v -= (s_tv[f] * PZ) * Finv;
-              if (lane == f) v += s_sig2[B.var0(b)];   // (+ RQR: this block's T is the identity)
-              col[0] = v;
-            } else if (B.kind(b) == SSG_LOCAL_LINEAR_TREND) {
-              double v0 = col[0], v1 = col[ld];
-              if (obs) {
-                v0 -= (s_tv[f] * PZ) * Finv;
-                v1 -= (s_tv[f + 1] * PZ) * Finv;
-                col[ld] = v1;
-              }
-              col[0] = v0 + v1;   // row 0 += row 1
-            } else if (B.kind(b) == SSG_SEASONAL) {
-              const bool moves = (mv >> b) & 1u;
-              if (obs || moves) {
-                double cs = 0.0;
-#pragma unroll 4
-                for (int i = 0; i < n; ++i) {
-                  double v = col[i * ld];
-                  if (obs) {
-                    v -= (s_tv[f + i] * PZ) * Finv;
-                    col[i * ld] = v;
-                  }
-                  cs -= v;
-                }
-                // the row of the component that drops out becomes that of the new first
-                // component, -(sum over the block)
-                if (moves) col[sprev(B.cur(b), n) * ld] = cs;
-              }
-            } else {
-              // autoregression (logical order): from the last lag down, moving each entry
-              // one place on as it is read
-              const double *ph = s_phi + B.arx(b) * AR_MAX;
+#pragma nounroll
+        for (int b = 0; b < nb; ++b) {
+          const unsigned d = B.udesc(b);
+          const int f = Blocks::first_of(d), n = Blocks::dim_of(d), kd = Blocks::kind_of(d);
+          if (!mylane) continue;
+          double *col = s_P + f * ld + lane;
+          if (kd == SSG_LOCAL_LEVEL) {
+            double v = col[0];
+            if (obs) v -= (s_tv[f] * PZ) * Finv;
+            if (lane == f) v += s_sig2[Blocks::var0_of(d)];   // (+ RQR: this block's T is the identity)
+            col[0] = v;
+          } else if (kd == SSG_LOCAL_LINEAR_TREND) {
+            double v0 = col[0], v1 = col[ld];
+            if (obs) {
+              v0 -= (s_tv[f] * PZ) * Finv;
+              v1 -= (s_tv[f + 1] * PZ) * Finv;
+              col[ld] = v1;
+            }
+            col[0] = v0 + v1;   // row 0 += row 1
+          } else if (kd == SSG_SEASONAL) {
+            const bool moves = (mv >> b) & 1u;
+            if (obs || moves) {
               double cs = 0.0;
 #pragma nounroll
-              for (int q = n - 1; q >= 0; --q) {
-                double v = col[q * ld];
-                if (obs) v -= (s_tv[f + q] * PZ) * Finv;
-                cs += ph[q] * v;
-                if (q + 1 < n) col[(q + 1) * ld] = v;
+              for (int i = 0; i < n; ++i) {
+                double v = col[i * ld];
+                if (obs) {
+                  v -= (s_tv[f + i] * PZ) * Finv;
+                  col[i * ld] = v;
+                }
+                cs -= v;
               }
-              col[0] = cs;
+              // the row of the component that drops out becomes that of the new first
+              // component, -(sum over the block)
+              if (moves) col[sprev((int)(B.urc(b) >> 16), n) * ld] = cs;
             }
+          } else {
+            // autoregression (logical order): from the last lag down, moving each entry
+            // one place on as it is read
+            const double *ph = s_phi + Blocks::arx_of(d) * AR_MAX;
+            double cs = 0.0;
+#pragma nounroll
+            for (int q = n - 1; q >= 0; --q) {
+              double v = col[q * ld];
+              if (obs) v -= (s_tv[f + q] * PZ) * Finv;
+              cs += ph[q] * v;
+              if (q + 1 < n) col[(q + 1) * ld] = v;
+            }
+            col[0] = cs;
           }
         }
         wave_lds_sync();
         // -- the row pass: lane k walks ITS row: T' from the right, + RQR
-        if (mylane) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            if (b >= nb) break;
-            const int f = B.first(b), n = B.dim(b);
-            double *row = s_P + lane * ld + f;
-            if (B.kind(b) == SSG_LOCAL_LINEAR_TREND) {
-              const double a = row[0], bb = row[1];
-              row[0] = (a + bb) + (lane == f ? s_sig2[B.var0(b)] : 0.0);   // column 0 += column 1
-              if (lane == f + 1) row[1] = bb + s_sig2[B.var0(b) + 1];
-            } else if (B.kind(b) == SSG_SEASONAL) {
-              if ((mv >> b) & 1u) {
-                const int w = sprev(B.cur(b), n);
-                double cs = 0.0;
-#pragma unroll 4
-                for (int j = 0; j < n; ++j) cs -= row[j];
-                row[w] = cs + (lane == f + w ? s_sig2[B.var0(b)] : 0.0);
-              }
-            } else if (B.kind(b) == SSG_AR) {
-              const double *ph = s_phi + B.arx(b) * AR_MAX;
-              double cs = 0.0;
+        unsigned tm = mv & ~(unsigned)__ballot(Blocks::kind_of(B.desc) == SSG_LOCAL_LEVEL);
+        while (tm) {
+          const int b = __ffs((int)tm) - 1;
+          tm &= tm - 1;
+          const unsigned d = B.udesc(b);
+          const int f = Blocks::first_of(d), n = Blocks::dim_of(d), kd = Blocks::kind_of(d);
+          if (!mylane) continue;
+          double *row = s_P + lane * ld + f;
+          const double sg = s_sig2[Blocks::var0_of(d)];
+          if (kd == SSG_LOCAL_LINEAR_TREND) {
+            const double a = row[0], bb = row[1];
+            row[0] = (a + bb) + (lane == f ? sg : 0.0);   // column 0 += column 1
+            if (lane == f + 1) row[1] = bb + s_sig2[Blocks::var0_of(d) + 1];
+          } else if (kd == SSG_SEASONAL) {
+            const int w = sprev((int)(B.urc(b) >> 16), n);
+            double cs = 0.0;
 #pragma nounroll
-              for (int q = n - 1; q >= 0; --q) {
-                const double v = row[q];
-                cs += ph[q] * v;
-                if (q + 1 < n) row[q + 1] = v;
-              }
-              row[0] = cs + (lane == f ? s_sig2[B.var0(b)] : 0.0);
+            for (int j = 0; j < n; ++j) cs -= row[j];
+            row[w] = cs + (lane == f + w ? sg : 0.0);
+          } else {
+            const double *ph = s_phi + Blocks::arx_of(d) * AR_MAX;
+            double cs = 0.0;
+#pragma nounroll
+            for (int q = n - 1; q >= 0; --q) {
+              const double v = row[q];
+              cs += ph[q] * v;
+              if (q + 1 < n) row[q + 1] = v;
             }
+            row[0] = cs + (lane == f ? sg : 0.0);
           }
         }
         wave_lds_sync();
-        advance(B, LI, mv);
+        advance(B, LI, mv, lane);
       }
       if (status != CHAIN_OK) break;
       blk_store(gK + (size_t)tb * m, blk, nstep * m, lane);
@@ -872,13 +871,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           const double z = (mylane && init_l) ? s_z[ipos_l] : 0.0;
           alpha = mylane ? sqrt(P0l) * z + a0l : 0.0;
           zo = nfirst;
-          advance(B, LI, 0u);
+          advance(B, LI, 0u, lane);
         } else {
           // simulate_next_state: T alpha + eta
           const unsigned mv = B.moving();
           const unsigned act = mv & seas_active;
           alpha = vecT<SMALL>(B, LI, alpha, lane, mv);
-          advance(B, LI, mv);
+          advance(B, LI, mv, lane);
           bool err = false;
           if (LI.kind == SSG_LOCAL_LEVEL) err = sig_l != 0.0;
           else if (LI.kind == SSG_LOCAL_LINEAR_TREND) err = true;
@@ -890,7 +889,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         }
         const double zh = dH ? s_z[zo] : 0.0;
         zo += dH;
-        const double yplus = zdot(B, alpha) + sqrtH * zh;   // simulate_adjusted_observation
+        const double yplus = zdot<SMALL>(LI, alpha, lane) + sqrtH * zh;   // simulate_adjusted_observation
         const double w = rl(ys_l, s) - yplus;
         if (lane == s) w_l = w;
         if (mylane) blk[s * m + lane] = alpha;
@@ -928,10 +927,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         const double K = mylane ? blk[s * m + lane] : 0.0;
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
         const unsigned mv = B.moving();
-        const double e = obs ? rl(w_l, s) - zdot(B, delta) : 0.0;
+        const double e = obs ? rl(w_l, s) - zdot<SMALL>(LI, delta, lane) : 0.0;
         if (lane == s) ef_l = obs ? e / F_l : 0.0;
         delta = vecT<SMALL>(B, LI, delta, lane, mv) + K * e;
-        advance(B, LI, mv);
+        advance(B, LI, mv, lane);
       }
       __builtin_amdgcn_wave_barrier();
       if (in_l) w0[tt] = ef_l;
@@ -968,13 +967,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       const double kr = wsum<SMALL>(K * r);
       const double coef = rl(ef_l, s) - kr;
       r = vecTt(B, LI, r, lane, mv);
-      retreat(B, LI, mv);
+      retreat(B, LI, mv, lane);
       // + Z coef (layout of t)
-      bool zl = false;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        if (b < nb && lane == B.zlane(b)) zl = true;
-      if (zl) r += coef;
+      if (LI.zsel(lane)) r += coef;
       if (!mylane) r = 0.0;
     }
     wave_lds_sync();
@@ -1016,19 +1011,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       for (int s = 0; s < nstep; ++s) {
         const double ap = mylane ? blk[s * m + lane] : 0.0;
         unsigned mv = 0;
-        double tot_then = 0.0;   // seasonal: sum of the block at t - 1 (uniform per block: kept per lane of the block)
+        double tot_then = 0.0;   // seasonal: sum of the block at t - 1 (kept by the lanes of the block)
         if (tb + s > 0) {
           mv = B.moving();
           // (the seasonal models' observe_state needs the sum of `then` over the block)
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            if (b < nb && B.kind(b) == SSG_SEASONAL && ((mv >> b) & 1u)) {
-              const double tb_ = wsum<SMALL>(LI.blk == b ? prev : 0.0);
-              if (LI.blk == b) tot_then = tb_;
-            }
+          unsigned sm = mv & B.seasmask;
+          while (sm) {
+            const int b = __ffs((int)sm) - 1;
+            sm &= sm - 1;
+            const double tb_ = wsum<SMALL>(LI.blk == b ? prev : 0.0);
+            if (LI.blk == b) tot_then = tb_;
           }
           mc = vecT<SMALL>(B, LI, mc, lane, mv);
-          advance(B, LI, mv);
+          advance(B, LI, mv, lane);
           // + RQR_{t-1} r_{t-1}
           bool carrier = false;
           if (mylane) {
@@ -1038,16 +1033,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           }
           if (carrier) mc += sig_l * s_z[var_l * BL + s];
         } else {
-          advance(B, LI, 0u);
+          advance(B, LI, 0u, lane);
         }
         const double st = mylane ? ap + mc : 0.0;
+        const double then1 = from_above(prev);
         if (tb + s > 0) {
           if (LI.kind == SSG_LOCAL_LEVEL) {
             const double diff = st - prev;
             suf_l += diff * diff;
           } else if (LI.kind == SSG_LOCAL_LINEAR_TREND) {
             // err = now - T then; MvnSuf::update_raw (MvnBase.cpp:71-86), diagonal only
-            const double then1 = from_above(prev);
             const double err = st - ((lane == LI.first) ? prev + then1 : prev);
             mv_n += 1.0;
             const double wv = (err - mv_ybar) / mv_n;
@@ -1063,21 +1058,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
             }
           }
           // autoregression: add_mixture_data(now[0], then, 1.0): xtx += then then', xty += now[0] then, yty += now[0]^2
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            if (b < nb && B.kind(b) == SSG_AR) {
-              const int f = B.first(b), n = B.dim(b);
-              const double yy = rl(st, f);
-              double *rowx = s_axx + ((size_t)B.arx(b) * AR_MAX + (LI.blk == b ? lane - f : 0)) * (AR_MAX + 1);
+          unsigned am = B.armask;
+          while (am) {
+            const int b = __ffs((int)am) - 1;
+            am &= am - 1;
+            const unsigned d = B.udesc(b);
+            const int f = Blocks::first_of(d), n = Blocks::dim_of(d);
+            const double yy = rl(st, f);
+            double *rowx = s_axx + ((size_t)Blocks::arx_of(d) * AR_MAX + (LI.blk == b ? lane - f : 0)) * (AR_MAX + 1);
 #pragma nounroll
-              for (int q = 0; q < n; ++q) {
-                const double pq = rl(prev, f + q);
-                if (LI.blk == b) rowx[q] += prev * pq * 1.0;
-              }
-              if (LI.blk == b) {
-                axy += (yy * 1.0) * prev;
-                ayy += yy * yy * 1.0;
-              }
+            for (int q = 0; q < n; ++q) {
+              const double pq = rl(prev, f + q);
+              if (LI.blk == b) rowx[q] += prev * pq * 1.0;
+            }
+            if (LI.blk == b) {
+              axy += (yy * 1.0) * prev;
+              ayy += yy * yy * 1.0;
             }
           }
         }
@@ -1092,7 +1088,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           oblk[s * m + idx] = st;
         }
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
-        const double resid = obs ? rl(y_l, s) - zdot(B, st) : 0.0;
+        const double resid = obs ? rl(y_l, s) - zdot<SMALL>(LI, st, lane) : 0.0;
         if (lane == s) res_l = resid;
         if (obs) { yty += resid * resid; nobs += 1.0; }
       }
@@ -1107,11 +1103,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
            kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
 #endif
   // publish the sufficient statistics
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b >= nb) break;
-    const int f = B.first(b), n = B.dim(b), kd = B.kind(b);
-    const size_t at = (size_t)chain * SSG_MAX_VAR + B.var0(b);
+  for (int b = 0; b < nb; ++b) {
+    const unsigned d = B.udesc(b);
+    const int f = Blocks::first_of(d), n = Blocks::dim_of(d), kd = Blocks::kind_of(d);
+    const size_t at = (size_t)chain * SSG_MAX_VAR + Blocks::var0_of(d);
     if (kd == SSG_LOCAL_LEVEL) {
       if (lane == f) {
         M.var_n[at] = (double)(T - 1);
@@ -1127,15 +1122,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
     } else if (kd == SSG_SEASONAL) {
       // (the lane that accumulated moved with the cursor: sum over the block)
       const double tot = wsum<SMALL>(LI.blk == b ? suf_l : 0.0);
+      const unsigned dpw = (unsigned)__builtin_amdgcn_readlane((int)B.dp, b);
       if (lane == f) {
-        M.var_n[at] = (double)seasons_started(T - 1, B.dur(b), B.phase(b));
+        M.var_n[at] = (double)seasons_started(T - 1, (int)(dpw & 0xffffu), (int)(dpw >> 16));
         M.var_ss[at] = tot;
       }
     } else {
-      double *suf = M.ar_suf + ((size_t)chain * SSG_MAX_AR + B.arx(b)) * AR_SUF_STRIDE;
+      double *suf = M.ar_suf + ((size_t)chain * SSG_MAX_AR + Blocks::arx_of(d)) * AR_SUF_STRIDE;
       if (LI.blk == b) {
         const int i = lane - f;
-        const double *rowx = s_axx + ((size_t)B.arx(b) * AR_MAX + i) * (AR_MAX + 1);
+        const double *rowx = s_axx + ((size_t)Blocks::arx_of(d) * AR_MAX + i) * (AR_MAX + 1);
         for (int q = 0; q < n; ++q) suf[i * AR_MAX + q] = rowx[q];
         suf[AR_SUF_XTY + i] = axy;
       }
@@ -1237,13 +1233,18 @@ size_t ssm_dynamic_lds(const SsmParams &M) {
   return (need + 15) & ~(size_t)15;
 }
 
+hipError_t launch_ssm_template(hipStream_t stream, const SsParams &P, int draw_variances);
+
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances) {
   const dim3 grid(P.chain_count), block(2 * WAVE);
   const size_t lds = ssm_dynamic_lds(P.ssm);
   hipError_t err;
   {
     KtScope kt(stream, KT_SSM);
-    if (P.ssm.m <= 16) {
+    if (P.ssm.tpl_trend > 0) {
+      err = launch_ssm_template(stream, P, draw_variances);
+      if (err != hipSuccess) return err;
+    } else if (P.ssm.m <= 16) {
       hipLaunchKernelGGL((ssg_simsmooth_kernel<true>), grid, block, lds, stream, P, draw_variances);
     } else {
       // (more than 64 KB of dynamic LDS has to be asked for, once per process and size)

@@ -1,0 +1,992 @@
+// bsts structural time series for many chains: the state half of
+// StateSpacePosteriorSampler::draw() when the state is a trend block
+// (LocalLevelStateModel, or LocalLinearTrendStateModel with one
+// ZeroMeanMvnIndependenceSampler per variance) plus an optional
+// SeasonalStateModel(nseasons, season_duration = 1) and an optional
+// ArStateModel(lags) with its ArPosteriorSampler.  SURVEY 8f row f2.
+//
+//   state model samplers                 (ZeroMeanGaussianConjSampler.cpp:57-60,
+//                                         ZeroMeanMvnIndependenceSampler.cpp:63-70)
+//   Base::impute_state                   (StateSpaceModelBase.cpp:278-291)
+//     ScalarBase::simulate_forward       (:771-790) with
+//       ScalarMarginalDistribution::update (ScalarKalmanFilter.cpp:41-83), vector state
+//       StateModelBase::simulate_initial_state (StateModel.cpp:47-56)
+//       simulate_state_error (LocalLevelStateModel.cpp:62-64, MvnBase.cpp:257,
+//                             SeasonalStateModel.cpp:124-146)
+//     Base::propagate_disturbances       (:858-891), fast_disturbance_smooth
+//                                          (ScalarKalmanFilter.cpp:168-196)
+//     observe_state (LocalLevelStateModel.cpp:52-58, LocalLinearTrend.cpp:53-63,
+//                    SeasonalStateModel.cpp:74-86, ArStateModel.cpp:64-69),
+//     observe_data_given_state
+//   ArPosteriorSampler::draw             (ArPosteriorSampler.cpp:52-143)
+//
+// State vector [trend (1 or 2) | seasonal (nseasons - 1) | autoregression (lags)],
+// dimension m <= 16.
+//   Z    ones at the first element of each block
+//   T    trend [1] or [[1, 1], [0, 1]]; seasonal: first row -1, ones below the diagonal;
+//        autoregression: first row phi, ones below the diagonal
+//   RQR  diagonal: level, slope and the first element of the seasonal / autoregression block
+// One chain per workgroup of two wavefronts: both share the adjusted
+// observations and the sweep's normals (stream_normals.h), then wave 0 runs the
+// three passes over time.  Lane j < m holds component j of every state-sized
+// vector and column j of the state variance P (16 registers).  Unlike the
+// local-level kernel (kalman_kernel.hip) the passes are SERIAL in time: the
+// per-step maps are m x m here and their compositions no longer fit a wave
+// scan.  As there, the data filter and the simulation filter share the gains, so
+// ONE filter runs on w = y* - y+, and one smoother on the difference.
+#include <hip/hip_runtime.h>
+
+#include "ktimer.h"
+
+#include "device_rng.h"
+#include "kalman_params.h"
+#include "stream_normals.h"
+
+// (round 4) This is the round-3 kernel, kept as the FAST PATH of the block lists that
+// are its template -- [local level | local linear trend] [+ seasonal of duration 1]
+// [+ autoregression], state dimension <= 16: its passes are compiled for the shape
+// (template flags), where the general kernel (ssm_kernel.hip) walks a block list.  Same
+// draws, same storage: Tpl below maps the template's names onto the general layout.
+
+namespace boom_amd {
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int SSM_MAX = 16;        // the template's state dimension limit (= AR_MAX)
+constexpr int PLD = SSM_MAX + 1;   // leading dimension of the state variance in LDS
+
+// the template's view of the general specification / storage (no arrays: an index the
+// compiler does not see as a constant would put them in scratch memory)
+struct Tpl {
+  const SsgSpec *S;
+  const SsmParams &M;
+  int m, trend, nseasons, s0, ar_lags, ar0;
+  int av;         // variance index of the autoregression's error variance
+  // variance index of level (0), slope (1), seasonal (2): 0, 1, trend
+  __device__ __forceinline__ int vi(int i) const { return i == 2 ? trend : i; }
+  __device__ __forceinline__ size_t at(int chain, int i) const { return (size_t)chain * SSG_MAX_VAR + vi(i); }
+  __device__ __forceinline__ size_t ar_at(int chain) const { return (size_t)chain * SSG_MAX_VAR + av; }
+  __device__ __forceinline__ double *ar_phi(int chain) const { return M.ar_phi + (size_t)chain * SSG_MAX_AR * AR_MAX; }
+  __device__ __forceinline__ double *ar_suf(int chain) const { return M.ar_suf + (size_t)chain * SSG_MAX_AR * AR_SUF_STRIDE; }
+};
+__device__ __forceinline__ Tpl make_tpl(const SsmParams &M) {
+  const int ar0 = M.tpl_trend + (M.tpl_nseasons > 0 ? M.tpl_nseasons - 1 : 0);
+  return Tpl{M.spec, M, M.m, M.tpl_trend, M.tpl_nseasons, M.tpl_nseasons > 0 ? M.tpl_trend : -1,
+             M.tpl_ar_lags, ar0, M.tpl_trend + (M.tpl_nseasons > 0 ? 1 : 0)};
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double sdpp(double x, double fill) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned long long f = __builtin_bit_cast(unsigned long long, fill);
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// value of lane `src` (wave-uniform src)
+__device__ __forceinline__ double rl(double x, int src) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// sum over the first 16 lanes (the vector's lanes; the others hold 0), everywhere
+__device__ __forceinline__ double row_total(double x) {
+  x += sdpp<0x111, 0xf>(x, 0.0);  // row_shr:1
+  x += sdpp<0x112, 0xf>(x, 0.0);
+  x += sdpp<0x114, 0xf>(x, 0.0);
+  x += sdpp<0x118, 0xf>(x, 0.0);
+  return rl(x, 15);
+}
+
+// the structure of the transition matrix
+struct Shape {
+  int m, trend, s0, ns;   // ns: size of the seasonal block (0: none)
+  int a0, na;             // the autoregression block: first index, size (0: none)
+  __device__ __forceinline__ bool seasonal(int i) const { return ns > 0 && i >= s0 && i < s0 + ns; }
+  __device__ __forceinline__ bool ar(int i) const { return na > 0 && i >= a0 && i < a0 + na; }
+};
+
+// The seasonal block is kept in a ROTATING layout: logical component i at time
+// t (0 = the current season's effect, i = the effect i seasons back) lives in
+// physical slot (c_t + i) mod ns, c_t = (-t) mod ns.  The transition
+// (new[0] = -sum(old), new[i] = old[i - 1]) then moves nothing: the slot of the
+// component that drops out, c_t - 1, receives the new first component and
+// becomes c_{t+1}.  For the variance that turns T P T' from O(m^2) data
+// movement into one new row / column per step.
+__device__ __forceinline__ int cursor_at(int t, int ns) {
+  const int r = t % ns;
+  return r == 0 ? 0 : ns - r;
+}
+__device__ __forceinline__ int cursor_prev(int c, int ns) { return c == 0 ? ns - 1 : c - 1; }   // c_{t+1} from c_t
+
+// y = T x for a vector held one component per lane; c: cursor of x's layout (the
+// result is in the next step's layout)
+// The autoregression block keeps its logical order (lane a0 + i = lag i); phl: this
+// lane's coefficient (0 outside the block).
+template <int TREND, bool SEAS, bool AR>
+__device__ __forceinline__ double vecT(const Shape &S, double x, int lane, int c, double phl) {
+  double y = x;
+  if (TREND == 2) {
+    const double x1 = rl(x, 1);
+    if (lane == 0) y = x + x1;
+  }
+  if (SEAS) {
+    const double tot = row_total(S.seasonal(lane) ? x : 0.0);
+    if (lane == S.s0 + cursor_prev(c, S.ns)) y = -tot;
+  }
+  if (AR) {
+    // new[0] = phi'old, new[i] = old[i - 1]  (AutoRegressionTransitionMatrix, SparseMatrix.cpp:1261-1310)
+    const double tot = row_total(phl * x);
+    const double below = sdpp<0x111, 0xf>(x, 0.0);   // row_shr:1
+    if (S.ar(lane)) y = (lane == S.a0) ? tot : below;
+  }
+  return y;
+}
+// y = T' x; c1: cursor of x's layout (the result is in the previous step's)
+template <int TREND, bool SEAS, bool AR>
+__device__ __forceinline__ double vecTt(const Shape &S, double x, int lane, int c1, double phl) {
+  double y = x;
+  if (TREND == 2) {
+    const double x0 = rl(x, 0);
+    if (lane == 1) y = x0 + x;
+  }
+  if (SEAS) {
+    const double first = rl(x, S.s0 + c1);
+    if (S.seasonal(lane)) y = (lane == S.s0 + c1) ? -first : x - first;
+  }
+  if (AR) {
+    // out[i] = phi_i x[0] + x[i + 1]  (Tmult, SparseMatrix.cpp:1286-1295)
+    const double first = rl(x, S.a0);
+    const double above = sdpp<0x101, 0xf>(x, 0.0);   // row_shl:1
+    if (S.ar(lane)) y = phl * first + ((lane + 1 < S.a0 + S.na) ? above : 0.0);
+  }
+  return y;
+}
+// Z'x, c: cursor of x's layout
+template <bool SEAS, bool AR>
+__device__ __forceinline__ double zdot(const Shape &S, double x, int c) {
+  double a = rl(x, 0);
+  if (SEAS) a += rl(x, S.s0 + c);
+  if (AR) a += rl(x, S.a0);
+  return a;
+}
+// a block of `n` doubles between HBM and LDS, by one wave
+__device__ __forceinline__ void blk_load(double *lds, const double *g, int n, int lane) {
+  for (int i = lane; i < n; i += WAVE) lds[i] = g[i];
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void blk_store(double *g, const double *lds, int n, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < n; i += WAVE) g[i] = lds[i];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- ArPosteriorSampler::draw for one chain, by one (whole) wave.  Vectors sit one
+// component per lane (lane i < L), the L x L matrices in LDS at leading dimension
+// SSM_MAX; every lane reads the same random numbers.
+struct ArLds {
+  double X[SSM_MAX * SSM_MAX];    // xtx
+  double Lc[SSM_MAX * SSM_MAX];   // chol(xtx)
+  double Lp[SSM_MAX * SSM_MAX];   // chol(xtx / sigsq)
+};
+// lower Cholesky factor of `scale` * A (A symmetric, full storage); false: not positive definite
+__device__ __forceinline__ bool ar_chol(const double *A, double scale, double *Lc, int L, int lane) {
+  for (int j = 0; j < L; ++j) {
+    double sacc = 0.0;
+    if (lane >= j && lane < L) {
+      sacc = A[lane * SSM_MAX + j] * scale;
+      for (int k = 0; k < j; ++k) sacc -= Lc[lane * SSM_MAX + k] * Lc[j * SSM_MAX + k];
+    }
+    const double djj = rl(sacc, j);
+    if (!(djj > 0.0)) return false;
+    const double d = sqrt(djj);
+    if (lane == j) Lc[j * SSM_MAX + j] = d;
+    else if (lane > j && lane < L) Lc[lane * SSM_MAX + j] = sacc / d;
+    __builtin_amdgcn_wave_barrier();
+  }
+  return true;
+}
+// x: Lc x = b
+__device__ __forceinline__ double ar_lsolve(const double *Lc, double b, int L, int lane) {
+  double x = 0.0;
+  for (int i = 0; i < L; ++i) {
+    const double tot = row_total((lane < i) ? Lc[i * SSM_MAX + lane] * x : 0.0);
+    const double xi = (rl(b, i) - tot) / Lc[i * SSM_MAX + i];
+    if (lane == i) x = xi;
+  }
+  return x;
+}
+// x: Lc' x = b
+__device__ __forceinline__ double ar_ltsolve(const double *Lc, double b, int L, int lane) {
+  double x = 0.0;
+  for (int i = L - 1; i >= 0; --i) {
+    const double tot = row_total((lane > i && lane < L) ? Lc[lane * SSM_MAX + i] * x : 0.0);
+    const double xi = (rl(b, i) - tot) / Lc[i * SSM_MAX + i];
+    if (lane == i) x = xi;
+  }
+  return x;
+}
+// ArModel::check_stationary (ArModel.cpp:142-170).  The quick bound sum |phi| < 1,
+// then -- where the reference finds the polynomial's roots (Jenkins-Traub) -- the
+// equivalent step-down recursion: every partial autocorrelation inside (-1, 1).
+__device__ __forceinline__ bool ar_stationary(double a, int L, int lane) {
+  if (row_total((lane < L) ? fabs(a) : 0.0) < 1.0) return true;
+  for (int k = L; k >= 1; --k) {
+    const double r = rl(a, k - 1);
+    if (!(fabs(r) < 1.0)) return false;
+    const double den = 1.0 - r * r;
+    const int src = k - 2 - lane;
+    const double rev = __shfl(a, src < 0 ? 0 : src);
+    if (lane < k - 1) a = (a + r * rev) / den;
+  }
+  return true;
+}
+// Tn2Sampler (distributions/Tn2Sampler.cpp:25-131): adaptive rejection sampling of a
+// standard normal on [lo, hi] under the hull of tangents at the points x (logf =
+// -x^2/2).  As in d_ars_gamma_tail the hull lives across the wave: lane i holds
+// point i (abscissa, log density, slope, cdf) and knot i; lane n holds the last knot,
+// so up to 63 points.  Every lane of the wave must be active.  Restated as written,
+// update_cdf's increment (exp(y - y0) / d) * expm1(d * knots[k + 1] - knots[k]) included.
+__device__ __noinline__ double ar_tn2_draw(SeqRng &rng, double lo, double hi, int *bad) {
+  const int lane = (int)(threadIdx.x & 63);
+  int n = 2;
+  double xs = (lane == 0) ? lo : hi;   // (lanes past n - 1 hold copies of the last point)
+  double ys = -.5 * xs * xs, ds = -xs, kn = 0.0, cdf = 0.0;
+  for (int level = 0; level <= 1001; ++level) {
+    // refresh_knots: knots[0] = x[0], knots[n] = x[n - 1], compute_knot in between
+    {
+      const double x1 = __shfl_up(xs, 1), y1 = __shfl_up(ys, 1), d1 = __shfl_up(ds, 1);
+      double ans = (y1 - d1 * x1) - (ys - ds * xs);
+      ans /= (ds - d1);
+      kn = (lane == 0) ? xs : ((lane >= n) ? x1 : ans);
+    }
+    // update_cdf
+    {
+      const double y0 = ars_lane(ys, 0);
+      const double knext = __shfl_down(kn, 1);
+      const double y = ys + ds * (kn - xs);
+      const double inc = (fabs(ds) < .00000000001) ? exp(y - y0) * (knext - kn)
+                                                  : (exp(y - y0) / ds) * expm1(ds * knext - kn);
+      double last = 0.0;
+      for (int k = 0; k < n; ++k) {
+        const double ik = ars_lane(inc, k);
+        last = (k == 0) ? ik : last + ik;
+        if (lane == k) cdf = last;
+      }
+    }
+    const double u = d_runif(rng, 0.0, ars_lane(cdf, n - 1));
+    const int k = ars_lower_bound(cdf, n, u);
+    if (k >= n) break;   // (past the end of cdf in the reference)
+    const double klo = ars_lane(kn, k), khi = ars_lane(kn, k + 1);
+    const double dk = ars_lane(ds, k);
+    const double lam = -1 * dk;
+    double cand;
+    if (lam == 0 || fabs(khi - klo) < 1.4901161193847656e-08) cand = d_runif(rng, klo, khi);   // sqrt(epsilon)
+    else cand = d_rtrun_exp(rng, lam, klo, khi);
+    const double target = -.5 * cand * cand;
+    const double logu = (ars_lane(ys, k) + dk * (cand - ars_lane(xs, k))) - d_rexp(rng, 1.0);
+    if (logu < target) return cand;
+    // add_point (an error in the reference when the candidate left [x[0], x.back()])
+    if (cand > ars_lane(xs, n - 1) || cand < ars_lane(xs, 0) || n >= 63) break;
+    const int pos = ars_lower_bound(xs, n, cand);
+    {
+      const double xu = __shfl_up(xs, 1), yu = __shfl_up(ys, 1), du = __shfl_up(ds, 1);
+      if (lane > pos) { xs = xu; ys = yu; ds = du; }
+      if (lane == pos) { xs = cand; ys = target; ds = -cand; }
+    }
+    ++n;
+  }
+  *bad = 1;
+  return 0.0;
+}
+// rtrun_norm_2_mt (trun_norm.cpp:273-325), lo and hi finite: the two rejection samplers
+// of lo < mu < hi, the Tn2Sampler in the tails
+__device__ __forceinline__ double ar_rtrun_norm_2(SeqRng &rng, double mu, double sigma, double lo, double hi,
+                                                  int *bad) {
+  if (lo < mu && hi > mu) {
+    if ((hi - lo) / sigma > .5) {
+      double y = lo - 1;
+      while (y < lo || y > hi) y = d_rnorm(rng, mu, sigma);
+      return y;
+    }
+    const double ln_sqrt_2pi = 0.918938533204672741780329736406;
+    const double phi_mu = -(ln_sqrt_2pi + 0.5 * 0.0 * 0.0 + log(sigma));
+    double phi = phi_mu, u = phi + 1, y = 0;
+    while (u > phi) {
+      y = d_runif(rng, lo, hi);
+      const double x = (y - mu) / sigma;
+      phi = -(ln_sqrt_2pi + 0.5 * x * x + log(sigma));
+      u = phi_mu - d_rexp(rng, 1.0);
+    }
+    return y;
+  }
+  hi = (hi - mu) / sigma;
+  lo = (lo - mu) / sigma;
+  if (hi < 0) {
+    // (the reference recurses with (0, 1, -hi, -lo), which lands in its Tn2Sampler)
+    const double y = ar_tn2_draw(rng, -hi, -lo, bad);
+    return mu - sigma * y;
+  }
+  const double y = ar_tn2_draw(rng, lo, hi, bad);
+  return y * sigma + mu;
+}
+// draw_phi (up to three multivariate proposals, else one coefficient at a time) and
+// draw_sigma.  phi_l: the lane's coefficient (in: current, out: drawn); *sigsq likewise.
+__device__ __forceinline__ int ar_draw(ArLds &W, const Tpl &Q, int chain, SeqRng &rng, double &phi_l,
+                                       double &sigsq, int lane) {
+  const int L = Q.ar_lags;
+  const double *suf = Q.ar_suf(chain);
+  for (int e = lane; e < SSM_MAX * SSM_MAX; e += WAVE) W.X[e] = suf[e];
+  const double xty = (lane < L) ? suf[AR_SUF_XTY + lane] : 0.0;
+  const double yty = suf[AR_SUF_YTY], n = suf[AR_SUF_N];
+  __builtin_amdgcn_wave_barrier();
+  if (!ar_chol(W.X, 1.0, W.Lc, L, lane)) return CHAIN_NOT_PD;
+  const double phi_hat = ar_ltsolve(W.Lc, ar_lsolve(W.Lc, xty, L, lane), L, lane);
+  // rmvn_ivar(phi_hat, xtx / sigsq)
+  if (!ar_chol(W.X, 1.0 / sigsq, W.Lp, L, lane)) return CHAIN_NOT_PD;
+  bool ok = false;
+  for (int attempt = 0; attempt < 3 && !ok; ++attempt) {
+    double z = 0.0;
+    for (int i = 0; i < L; ++i) {
+      const double zi = d_rnorm(rng, 0.0, 1.0);
+      if (lane == i) z = zi;
+    }
+    const double zs = ar_ltsolve(W.Lp, z, L, lane);   // (whole wave: the lanes talk to each other)
+    const double cand = (lane < L) ? zs + phi_hat : 0.0;
+    ok = ar_stationary(cand, L, lane);
+    if (ok) phi_l = cand;
+  }
+  if (!ok) {
+    double ph = phi_l;
+    if (!ar_stationary(ph, L, lane)) return CHAIN_RNG_BRANCH;
+    for (int i = 0; i < L; ++i) {
+      const double initial_phi = rl(ph, i);
+      double lo = -1, hi = 1;
+      const double ivar = W.X[i * SSM_MAX + i];
+      const double dot = row_total((lane < L) ? ph * W.X[lane * SSM_MAX + i] : 0.0);
+      const double mu = (rl(xty, i) - (dot - initial_phi * ivar)) / ivar;
+      for (;;) {
+        int bad = 0;
+        const double candidate = ar_rtrun_norm_2(rng, mu, sqrt(1.0 / ivar), lo, hi, &bad);
+        if (bad) return CHAIN_RNG_BRANCH;
+        if (lane == i) ph = candidate;
+        if (ar_stationary(ph, L, lane)) break;
+        if (candidate > initial_phi) hi = candidate; else lo = candidate;
+      }
+    }
+    phi_l = ph;
+  }
+  // draw_sigma: ss = phi' xtx phi - 2 phi' xty + yty, df = n
+  double row = 0.0;
+  for (int j = 0; j < L; ++j) {
+    const double pj = rl(phi_l, j);
+    if (lane < L) row += W.X[lane * SSM_MAX + j] * pj;
+  }
+  const double quad = row_total((lane < L) ? phi_l * row : 0.0);
+  const double lin = row_total((lane < L) ? phi_l * xty : 0.0);
+  const double ss = quad - 2 * lin + yty;
+  int bad = 0;
+  sigsq = d_draw_variance(rng, n + Q.S->prior_df[Q.av], ss + Q.S->prior_ss[Q.av], Q.S->sigma_max[Q.av], &bad);
+  return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
+}
+
+}  // namespace
+
+// grid = chains, block = 128.  TREND: 1 local level, 2 local linear trend; SEAS: a
+// seasonal block follows; AR: an autoregression block follows
+template <int TREND, bool SEAS, bool AR>
+__global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw_variances) {
+  // (the passes' buffers take the place of the normals generator's lists, which
+  // are done by then: 37 KB per workgroup, four workgroups per CU)
+  struct PassLds {
+    double blk[2][WAVE * SSM_MAX];   // a block of 64 steps of a state-sized series, per wave
+    double P[SSM_MAX * PLD];         // the state variance (wave 1), rows PLD apart
+    double tv[SSM_MAX];
+  };
+  union SharedLds {
+    NormalsLds norm;
+    PassLds pass;
+    ArLds ar;
+  };
+  __shared__ SharedLds s_lds;
+  __shared__ int s_flag;
+  __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
+  double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
+  double (&s_P)[SSM_MAX * PLD] = s_lds.pass.P;
+  double (&s_tv)[SSM_MAX] = s_lds.pass.tv;
+  const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= P.chain_count) return;
+  if (P.status[chain] != CHAIN_OK) return;
+  if (P.only_ran && P.only_ran[chain] == 0) return;
+  const Tpl Q = make_tpl(P.ssm);
+  const int T = P.T, p = P.p, m = Q.m;
+  Shape S;
+  S.m = m; S.trend = TREND; S.s0 = TREND; S.ns = SEAS ? Q.nseasons - 1 : 0;
+  S.a0 = AR ? Q.ar0 : 0; S.na = AR ? Q.ar_lags : 0;
+  const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
+  int status = CHAIN_OK;
+  if (threadIdx.x == 0) s_flag = CHAIN_OK;
+#ifdef BA_KSTAMPS
+  long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
+#define SSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+
+  // ---- the state models' variance draws, in model order: level [, slope], seasonal
+  double sig2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sig2[i] = Q.M.var_sigsq[Q.at(chain, i)];
+  if (draw_variances) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bool active = (i == 0) || (i == 1 && TREND == 2) || (i == 2 && SEAS);
+      if (active) {
+        const uint32_t sid = (i == 0) ? 1u : (i == 1 ? 6u : 7u);
+        SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, sid}, Q.M.pos_var[Q.at(chain, i)]};
+        int bad = 0;
+        const double DF = Q.M.var_n[Q.at(chain, i)] + Q.S->prior_df[Q.vi(i)];
+        const double SSQ = Q.M.var_ss[Q.at(chain, i)] + Q.S->prior_ss[Q.vi(i)];
+        double draw = d_draw_variance(rng, DF, SSQ, Q.S->sigma_max[Q.vi(i)], &bad);
+        if (bad) status = CHAIN_RNG_BRANCH;
+        // ZeroMeanMvnIndependenceSampler sets siginv(i, i) = 1 / draw; the model's
+        // Sigma is the inverse of that again
+        if (TREND == 2 && i < 2) draw = 1.0 / (1.0 / draw);
+        sig2[i] = draw;
+        if (lane == 0 && wave == 0) {
+          Q.M.pos_var[Q.at(chain, i)] = rng.pos;
+          Q.M.var_sigsq[Q.at(chain, i)] = draw;
+        }
+      }
+    }
+  }
+  if (status != CHAIN_OK) {
+    if (threadIdx.x == 0) P.status[chain] = status;
+    return;
+  }
+  // ---- the autoregression block's sampler (after the seasonal model's), by wave 0
+  double phl = 0.0, sig2a = 0.0;
+  if (AR) {
+    if (wave == 0) {
+      phl = S.ar(lane) ? Q.ar_phi(chain)[lane - S.a0] : 0.0;
+      sig2a = Q.M.var_sigsq[Q.ar_at(chain)];
+      if (draw_variances) {
+        SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, 12u}, Q.M.pos_var[Q.ar_at(chain)]};
+        // (the sampler's vectors sit at lanes 0 .. L - 1)
+        double ph = __shfl(phl, lane + S.a0);
+        if (lane >= S.na) ph = 0.0;
+        const int st = ar_draw(s_lds.ar, Q, chain, rng, ph, sig2a, lane);
+        if (st != CHAIN_OK) {
+          if (lane == 0) s_flag = st;
+        } else {
+          if (lane < S.na) Q.ar_phi(chain)[lane] = ph;
+          if (lane == 0) {
+            Q.M.var_sigsq[Q.ar_at(chain)] = sig2a;
+            Q.M.pos_var[Q.ar_at(chain)] = rng.pos;
+          }
+        }
+        phl = __shfl(ph, lane >= S.a0 ? lane - S.a0 : 0);
+        if (!S.ar(lane)) phl = 0.0;
+      }
+      const double pv = __shfl(phl, (lane + S.a0) & 63);
+      if (lane < SSM_MAX) s_phi[lane] = (lane < S.na) ? pv : 0.0;
+      if (lane == 0) s_phi[SSM_MAX] = sig2a;
+    }
+    __syncthreads();
+    status = s_flag;
+    if (status != CHAIN_OK) {
+      if (threadIdx.x == 0) P.status[chain] = status;
+      return;
+    }
+    if (wave == 1) {
+      phl = S.ar(lane) ? s_phi[lane - S.a0] : 0.0;
+      sig2a = s_phi[SSM_MAX];
+    }
+  }
+  const double sda = sqrt(sig2a);
+
+  const double H = P.sigsq[chain], sqrtH = sqrt(H);
+  const double sdv[3] = {sqrt(sig2[0]), sqrt(sig2[1]), sqrt(sig2[2])};
+  const double *beta = P.beta + (size_t)chain * p;
+  double *w0 = P.scratch + (size_t)chain * P.scratch_stride;   // y* -> w = y* - y+ -> (v - v+) / F
+  double *sres = w0 + T;                                       // F_t, then residuals (input of the X'e GEMM)
+  double *wk = Q.M.work + (size_t)chain * Q.M.work_stride;
+  double *gK = wk;                                 // K_t, m per step (layout of step t + 1)
+  double *gst = gK + (size_t)m * T;                // alpha+_t (layout of step t), then the state draw
+  double *gd = gst + (size_t)m * T;                // r_t (difference) at the four rows with state error: 4 series of T
+  double *szz = gd + (size_t)4 * T;                // the sweep's normals
+
+  SSTAMP(0);
+  // ---- 1. adjusted observations y*_t = y_t - x_t'beta (blocks of 64 steps, the waves in turn)
+  for (int tb = wave * WAVE; tb < T; tb += 2 * WAVE) {
+    const int t = tb + lane;
+    double pred = 0.0;
+    for (int base = 0; base < p; base += WAVE) {
+      const int j = base + lane;
+      const double bj = (j < p) ? beta[j] : 0.0;
+      unsigned long long mk = __ballot(bj != 0.0);
+      while (mk) {
+        const int l = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        const double b = rl(bj, l);
+        pred += P.X[(size_t)(base + l) * T + (t < T ? t : T - 1)] * b;
+      }
+    }
+    if (t < T) w0[t] = P.y[t] - pred;
+  }
+
+  SSTAMP(1);
+  // ---- 2. the normals of simulate_forward, in stream order.  t = 0: the initial
+  // state of every state model (rmvn_mt draws every component; the local level
+  // model draws rnorm_mt(a0, sd0): nothing if sd0 == 0), then the observation;
+  // t >= 1: the state errors (local level: one if sigma != 0; local linear trend:
+  // two, always; seasonal: one if sigma != 0; autoregression: one, always --
+  // rnorm_mt(rng) * sigma, ArStateModel.cpp:85-90), then the observation.
+  const int dH = (sqrtH != 0.0);
+  const int d0 = (TREND == 1) ? (Q.S->P0[0] != 0.0 ? 1 : 0) : 2;
+  const int nfirst = d0 + S.ns + S.na + dH;
+  const int dT = (TREND == 1) ? (sdv[0] != 0.0 ? 1 : 0) : 2;
+  const int dS = (SEAS && sdv[2] != 0.0) ? 1 : 0;
+  const int dA = AR ? 1 : 0;
+  const int nper = dT + dS + dA + dH;
+  const int N = nfirst + (T - 1) * nper;
+  status = stream_normals(s_lds.norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
+                          szz, &P.pos_state[chain]);
+  if (status != CHAIN_OK) {
+    if (threadIdx.x == 0) P.status[chain] = status;
+    return;
+  }
+  __syncthreads();
+  SSTAMP(2);
+
+  const bool mylane = lane < m;
+  // which variance parameter drives this lane's state error (the seasonal one moves with the cursor)
+  const double sig_tr = (lane == 0) ? sig2[0] : ((TREND == 2 && lane == 1) ? sig2[1] : 0.0);
+  const double sd_tr = (lane == 0) ? sdv[0] : ((TREND == 2 && lane == 1) ? sdv[1] : 0.0);
+  double a0l = 0.0, P0l = 0.0;
+#pragma unroll
+  for (int i = 0; i < SSM_MAX; ++i) if (lane == i) { a0l = Q.S->a0[i]; P0l = Q.S->P0[i]; }
+  double *blk = s_blk[wave];
+
+  // ---- 3. forward, the two waves side by side (neither needs the other's results):
+  //   wave 1: the variances P_t -> F_t, K_t (ScalarMarginalDistribution::update, the
+  //           part that does not look at the data);
+  //   wave 0: simulate alpha+_t, y+_t and w_t = y*_t - y+_t.
+  // Time runs in blocks of 64 steps: a block's scalar inputs sit one step per lane
+  // (read with v_readlane), its state-sized series in LDS, and what a block
+  // produces goes out in one coalesced piece.
+  if (wave == 1) {
+    // P lives in LDS (s_P[row * PLD + column], PLD = 17: a lane per column and a lane per
+    // row are both free of bank conflicts; both indices in the rotating
+    // layout, kept exactly symmetric): the rows and columns a step touches move
+    // with the cursor, which registers cannot follow.  Lane k < m owns column k;
+    // the rank-one update runs over all 256 entries on all 64 lanes.
+    for (int e = lane; e < SSM_MAX * PLD; e += WAVE) s_P[e] = 0.0;
+    if (lane < SSM_MAX) s_tv[lane] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (mylane) s_P[lane * (PLD + 1)] = P0l;
+    __builtin_amdgcn_wave_barrier();
+    int c = 0;
+    for (int tb = 0; tb < T; tb += WAVE) {
+      const int tt = tb + lane;
+      const int ob_l = (tt < T && P.observed[tt]) ? 1 : 0;
+      double F_l = 1.0;
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+#pragma nounroll
+      for (int s = 0; s < nstep; ++s) {
+        const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
+        const int cn = SEAS ? cursor_prev(c, S.ns) : 0;   // the next layout's cursor
+        const int rc = S.s0 + c, rw = S.s0 + cn;          // rows / columns of the current and the new first component
+        // PZ_k = P(k, 0) + P(k, first seasonal) = P(0, k) + P(first seasonal, k)
+        double PZ = 0.0;
+        if (mylane) {
+          PZ = s_P[lane];
+          if (SEAS) PZ += s_P[rc * PLD + lane];
+          if (AR) PZ += s_P[S.a0 * PLD + lane];
+        }
+        const double F = zdot<SEAS, AR>(S, PZ, c) + H;
+        if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
+        const double TPZ = vecT<TREND, SEAS, AR>(S, PZ, lane, c, phl);
+        const double K = obs ? TPZ / F : 0.0;
+        if (mylane) {
+          blk[s * m + lane] = K;
+          s_tv[lane] = TPZ;
+        }
+        if (lane == s) F_l = F;
+        // T P T' -- the trend block: row 0 += row 1, then column 0 += column 1
+        if (TREND == 2) {
+          if (mylane) s_P[lane] = s_P[lane] + s_P[PLD + lane];
+          __builtin_amdgcn_wave_barrier();
+          if (mylane) s_P[lane * PLD] = s_P[lane * PLD] + s_P[lane * PLD + 1];
+          __builtin_amdgcn_wave_barrier();
+        }
+        // -- the seasonal block: the row / column of the component that drops out
+        // becomes that of the new first component, -sum over the block
+        if (SEAS) {
+          // (every load issued before the first use, from addresses that are valid whatever
+          // the block's size: fifteen guarded load-and-subtract steps each waited for their
+          // own LDS round trip)
+          double cs = 0.0;
+          {
+            double v[SSM_MAX - 1];
+            const int col = mylane ? lane : 0;
+#pragma unroll
+            for (int q = 0; q < SSM_MAX - 1; ++q) v[q] = s_P[(TREND + (q < S.ns ? q : 0)) * PLD + col];
+#pragma unroll
+            for (int q = 0; q < SSM_MAX - 1; ++q) cs -= (q < S.ns) ? v[q] : 0.0;
+            if (!mylane) cs = 0.0;
+          }
+          const double tot = row_total(S.seasonal(lane) ? cs : 0.0);
+          __builtin_amdgcn_wave_barrier();
+          if (mylane) {
+            s_P[rw * PLD + lane] = cs;
+            s_P[lane * PLD + rw] = cs;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane == rw) s_P[rw * (PLD + 1)] = -tot;
+          __builtin_amdgcn_wave_barrier();
+        }
+        // -- the autoregression block (logical order): T P, then (T P) T'.  Lane k owns
+        // column k of the block's rows, then row k of the block's columns; either way
+        // it reads and writes its own entries only, and a symmetric P stays symmetric
+        // (P'(a0, k) and P'(k, a0) are the same sum in the same order).
+        if (AR) {
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            if (mylane) {
+              const int sr = pass == 0 ? PLD : 1, sc = pass == 0 ? 1 : PLD;   // strides along / across the block
+              // from the last lag down, moving each entry one place on as it is read (a
+              // rolled loop: fifteen guarded copies of its body cost 3 400 cycles a step)
+              double cs = 0.0;
+#pragma nounroll
+              for (int q = S.na - 1; q >= 0; --q) {
+                const double v = s_P[(S.a0 + q) * sr + lane * sc];
+                cs += s_phi[q] * v;
+                if (q + 1 < S.na) s_P[(S.a0 + q + 1) * sr + lane * sc] = v;
+              }
+              s_P[S.a0 * sr + lane * sc] = cs;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        // - TPZ K' at an observed step (as (TPZ_i TPZ_j) / F: exactly symmetric)
+        if (obs) {
+          const double Finv = 1.0 / F;
+#pragma unroll
+          for (int e4 = 0; e4 < SSM_MAX * SSM_MAX / WAVE; ++e4) {
+            const int e = lane + WAVE * e4;
+            const int i = e >> 4, k2 = e & 15;
+            if (i < m && k2 < m) s_P[i * PLD + k2] -= (s_tv[i] * s_tv[k2]) * Finv;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        // + RQR
+        if (lane == 0) s_P[0] += sig2[0];
+        if (TREND == 2 && lane == 1) s_P[PLD + 1] += sig2[1];
+        if (SEAS && lane == rw) s_P[rw * (PLD + 1)] += sig2[2];
+        if (AR && lane == S.a0) s_P[S.a0 * (PLD + 1)] += sig2a;
+        __builtin_amdgcn_wave_barrier();
+        c = cn;
+      }
+      if (status != CHAIN_OK) break;
+      blk_store(gK + (size_t)tb * m, blk, nstep * m, lane);
+      if (tt < T) sres[tt] = F_l;
+    }
+    if (status != CHAIN_OK && lane == 0) s_flag = status;
+  } else {
+    double alpha = 0.0;
+    int c = 0;
+    for (int tb = 0; tb < T; tb += WAVE) {
+      const int tt = tb + lane;
+      const bool in_l = tt < T;
+      const double ys_l = in_l ? w0[tt] : 0.0;
+      const int nb_l = (tt == 0) ? 0 : nfirst + (tt - 1) * nper;
+      double z0_l = 0.0, z1_l = 0.0, zs_l = 0.0, za_l = 0.0, zh_l = 0.0;
+      if (in_l && tt > 0) {
+        int o = nb_l;
+        if (dT >= 1) z0_l = szz[o++];
+        if (dT == 2) z1_l = szz[o++];
+        if (dS) zs_l = szz[o++];
+        if (dA) za_l = szz[o++];
+        if (dH) zh_l = szz[o];
+      } else if (in_l) {
+        if (dH) zh_l = szz[d0 + S.ns + S.na];
+      }
+      double w_l = 0.0;
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+#pragma nounroll
+      for (int s = 0; s < nstep; ++s) {
+        if (tb + s == 0) {
+          // simulate_initial_state: mean_i + sd_i z_i
+          double z = 0.0;
+          if (mylane) {
+            // (the blocks follow one another: seasonal and autoregression lanes alike)
+            if (lane < TREND) z = (lane < d0) ? szz[lane] : 0.0;
+            else z = szz[d0 + (lane - TREND)];
+          }
+          alpha = mylane ? sqrt(P0l) * z + a0l : 0.0;
+        } else {
+          // simulate_next_state: T alpha + eta
+          const double z0 = rl(z0_l, s);
+          const int cn = SEAS ? cursor_prev(c, S.ns) : 0;
+          alpha = vecT<TREND, SEAS, AR>(S, alpha, lane, c, phl);
+          if (TREND == 2) alpha += sd_tr * ((lane == 0) ? z0 : rl(z1_l, s));
+          else alpha += sd_tr * z0;
+          if (SEAS) { if (lane == S.s0 + cn) alpha += sdv[2] * rl(zs_l, s); }
+          if (AR) { if (lane == S.a0) alpha += rl(za_l, s) * sda; }
+          c = cn;
+        }
+        const double yplus = zdot<SEAS, AR>(S, alpha, c) + sqrtH * rl(zh_l, s);   // simulate_adjusted_observation
+        const double w = rl(ys_l, s) - yplus;
+        if (lane == s) w_l = w;
+        if (mylane) blk[s * m + lane] = alpha;
+      }
+      blk_store(gst + (size_t)tb * m, blk, nstep * m, lane);
+      if (in_l) w0[tt] = w_l;
+    }
+  }
+  SSTAMP(3);
+  __threadfence_block();
+  __syncthreads();
+  SSTAMP(4);
+  status = s_flag;
+  if (status != CHAIN_OK) {
+    if (threadIdx.x == 0) P.status[chain] = status;
+    return;
+  }
+  if (wave != 0) return;
+
+  // ---- 3b. the filter on w = y* - y+ (the data filter minus the simulation
+  // filter; they share the gains): v - v+ = w - Z'(a - a+); a - a+ <- T (a - a+) + K (v - v+)
+  {
+    double delta = 0.0;
+    int c = 0;
+    for (int tb = 0; tb < T; tb += WAVE) {
+      const int tt = tb + lane;
+      const bool in_l = tt < T;
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      blk_load(blk, gK + (size_t)tb * m, nstep * m, lane);
+      const double w_l = in_l ? w0[tt] : 0.0, F_l = in_l ? sres[tt] : 1.0;
+      const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
+      double ef_l = 0.0;
+#pragma nounroll
+      for (int s = 0; s < nstep; ++s) {
+        const double K = mylane ? blk[s * m + lane] : 0.0;
+        const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
+        const double e = obs ? rl(w_l, s) - zdot<SEAS, AR>(S, delta, c) : 0.0;
+        if (lane == s) ef_l = obs ? e / F_l : 0.0;
+        delta = vecT<TREND, SEAS, AR>(S, delta, lane, c, phl) + K * e;
+        if (SEAS) c = cursor_prev(c, S.ns);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (in_l) w0[tt] = ef_l;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+
+  SSTAMP(5);
+  // ---- 4. backward: fast_disturbance_smooth for d = r - r+:
+  // r_{t-1} = T' r_t + Z ((v_t - v+_t) / F_t - K_t' r_t), r_{T-1} = 0.  r_t is in the
+  // layout of step t + 1.
+  double r = 0.0;
+  for (int tb = ((T - 1) / WAVE) * WAVE; tb >= 0; tb -= WAVE) {
+    const int tt = tb + lane;
+    const bool in_l = tt < T;
+    const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+    blk_load(blk, gK + (size_t)tb * m, nstep * m, lane);
+    const double ef_l = in_l ? w0[tt] : 0.0;
+    double d0_l = 0.0, d1_l = 0.0, d2_l = 0.0, d3_l = 0.0;
+    int c1 = SEAS ? cursor_at(tb + nstep, S.ns) : 0;   // layout of r at the block's last step
+#pragma nounroll
+    for (int s = nstep - 1; s >= 0; --s) {
+      const double K = mylane ? blk[s * m + lane] : 0.0;
+      const int c0 = SEAS ? (c1 + 1 == S.ns ? 0 : c1 + 1) : 0;   // c_t from c_{t+1}
+      // r_t at the rows that carry state error: what the correction pass needs
+      const double q0 = rl(r, 0);
+      if (lane == s) d0_l = q0;
+      if (TREND == 2) { const double q1 = rl(r, 1); if (lane == s) d1_l = q1; }
+      if (SEAS) { const double q2 = rl(r, S.s0 + c1); if (lane == s) d2_l = q2; }
+      if (AR) { const double q3 = rl(r, S.a0); if (lane == s) d3_l = q3; }
+      const double kr = row_total(K * r);
+      const double coef = rl(ef_l, s) - kr;
+      r = vecTt<TREND, SEAS, AR>(S, r, lane, c1, phl);
+      if (lane == 0 || (SEAS && lane == S.s0 + c0) || (AR && lane == S.a0)) r += coef;
+      if (!mylane) r = 0.0;
+      c1 = c0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (in_l) {
+      gd[tt] = d0_l;
+      if (TREND == 2) gd[(size_t)T + tt] = d1_l;
+      if (SEAS) gd[(size_t)2 * T + tt] = d2_l;
+      if (AR) gd[(size_t)3 * T + tt] = d3_l;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+
+  SSTAMP(6);
+  // ---- 5. forward: the mean correction E(alpha | y) - E(alpha | y+), the state
+  // draw, the state models' and the regression's sufficient statistics
+  double mc = P0l * r;          // a0 + P0 r0 - (a0 + P0 r0+)
+  double prev = 0.0;            // state_{t-1} (its own layout)
+  double suf0 = 0.0, suf2 = 0.0;
+  double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of the trend errors (lanes 0, 1)
+  double yty = 0.0, nobs = 0.0;
+  // ArModel's NeRegSuf of now[a0] on then[a0 ..]: lane a0 + i keeps xty_i and row i of xtx,
+  // the row in LDS (s_P is free by now: wave 1 has left), at s_axx[i * PLD + q]
+  double axy = 0.0, ayy = 0.0;
+  double *s_axx = s_P;
+  if (AR) {
+    for (int e2 = lane; e2 < SSM_MAX * PLD; e2 += WAVE) s_axx[e2] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  double *oblk = s_blk[1];
+  {
+    int c = 0;
+    for (int tb = 0; tb < T; tb += WAVE) {
+      const int tt = tb + lane;
+      const bool in_l = tt < T;
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      blk_load(blk, gst + (size_t)tb * m, nstep * m, lane);
+      const bool dd = in_l && tt > 0;
+      const double d0_l = dd ? gd[tt - 1] : 0.0;
+      const double d1_l = (dd && TREND == 2) ? gd[(size_t)T + tt - 1] : 0.0;
+      const double d2_l = (dd && SEAS) ? gd[(size_t)2 * T + tt - 1] : 0.0;
+      const double d3_l = (dd && AR) ? gd[(size_t)3 * T + tt - 1] : 0.0;
+      const double y_l = in_l ? P.y[tt] : 0.0;
+      const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
+      double res_l = 0.0;
+#pragma nounroll
+      for (int s = 0; s < nstep; ++s) {
+        const double ap = mylane ? blk[s * m + lane] : 0.0;
+        if (tb + s > 0) {
+          const int cn = SEAS ? cursor_prev(c, S.ns) : 0;
+          mc = vecT<TREND, SEAS, AR>(S, mc, lane, c, phl);
+          if (TREND == 2) mc += sig_tr * ((lane == 0) ? rl(d0_l, s) : rl(d1_l, s));
+          else mc += sig_tr * rl(d0_l, s);
+          if (SEAS) { if (lane == S.s0 + cn) mc += sig2[2] * rl(d2_l, s); }
+          if (AR) { if (lane == S.a0) mc += sig2a * rl(d3_l, s); }
+          c = cn;
+        }
+        const double st = mylane ? ap + mc : 0.0;
+        if (tb + s > 0) {
+          if (TREND == 1) {
+            const double diff = st - prev;                 // (lane 0)
+            if (lane == 0) suf0 += diff * diff;
+          } else {
+            // err = now - T then; MvnSuf::update_raw (MvnBase.cpp:71-86), diagonal only
+            const double then1 = rl(prev, 1);
+            const double err = st - ((lane == 0) ? prev + then1 : prev);
+            mv_n += 1.0;
+            const double wv = (err - mv_ybar) / mv_n;
+            mv_ybar += wv;
+            mv_sumsq += wv * wv * (mv_n - 1);
+            const double w2 = err - mv_ybar;
+            mv_sumsq += w2 * w2;
+          }
+          if (SEAS) {
+            // delta = now[0] + sum(then) over the seasonal block
+            const double tot = row_total(S.seasonal(lane) ? prev : 0.0);
+            const double dl = st - (-1.0 * tot);
+            if (lane == S.s0 + c) suf2 += dl * dl;
+          }
+          if (AR) {
+            // add_mixture_data(now[0], then, 1.0): xtx += then then', xty += now[0] then, yty += now[0]^2
+            const double yy = rl(st, S.a0);
+            {
+              double *row = s_axx + (S.ar(lane) ? lane - S.a0 : 0) * PLD;
+#pragma nounroll
+              for (int q = 0; q < S.na; ++q) {
+                const double pq = rl(prev, S.a0 + q);
+                if (S.ar(lane)) row[q] += prev * pq * 1.0;
+              }
+            }
+            axy += (yy * 1.0) * prev;
+            ayy += yy * yy * 1.0;
+          }
+        }
+        prev = st;
+        if (mylane) {
+          // the state draw goes out in logical order
+          int idx = lane;
+          if (SEAS && S.seasonal(lane)) {
+            const int q = lane - S.s0;
+            idx = S.s0 + (q >= c ? q - c : q - c + S.ns);
+          }
+          oblk[s * m + idx] = st;
+        }
+        const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
+        const double resid = obs ? rl(y_l, s) - zdot<SEAS, AR>(S, st, c) : 0.0;
+        if (lane == s) res_l = resid;
+        if (obs) { yty += resid * resid; nobs += 1.0; }
+      }
+      blk_store(gst + (size_t)tb * m, oblk, nstep * m, lane);
+      if (in_l) sres[tt] = res_l;
+    }
+  }
+  SSTAMP(7);
+#ifdef BA_KSTAMPS
+  if (chain == 0 && lane == 0 && draw_variances)
+    printf("ssm phases (cycles, wave 0): variances %lld ystar %lld normals %lld sim %lld wait-for-P %lld filter %lld backward %lld correction %lld\n",
+           kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
+#endif
+  // publish the sufficient statistics
+  if (TREND == 2) {
+    // center_sumsq(mu = 0)(i, i) = sumsq_ii + n ybar_i^2
+    const double ssv = mv_sumsq + mv_ybar * mv_ybar * mv_n;
+    if (lane < 2) {
+      Q.M.var_n[(size_t)chain * SSG_MAX_VAR + lane] = mv_n;   // (level, slope: variance parameters 0, 1)
+      Q.M.var_ss[(size_t)chain * SSG_MAX_VAR + lane] = ssv;
+    }
+  } else if (lane == 0) {
+    Q.M.var_n[Q.at(chain, 0)] = (double)(T - 1);
+    Q.M.var_ss[Q.at(chain, 0)] = suf0;
+  }
+  if (SEAS) {
+    // (the lane that accumulated moved with the cursor: sum over the block)
+    const double tot = row_total(S.seasonal(lane) ? suf2 : 0.0);
+    if (lane == 0) {
+      Q.M.var_n[Q.at(chain, 2)] = (double)(T - 1);
+      Q.M.var_ss[Q.at(chain, 2)] = tot;
+    }
+  }
+  if (AR) {
+    double *suf = Q.ar_suf(chain);
+    if (S.ar(lane)) {
+      const int i = lane - S.a0;
+      for (int q = 0; q < S.na; ++q) suf[i * SSM_MAX + q] = s_axx[i * PLD + q];
+      suf[AR_SUF_XTY + i] = axy;
+    }
+    if (lane == 0) {
+      suf[AR_SUF_YTY] = ayy;
+      suf[AR_SUF_N] = (double)(T - 1);
+    }
+  }
+  if (lane == 0) {
+    P.yty[chain] = yty;
+    P.nobs[chain] = nobs;
+    P.status[chain] = status;
+  }
+}
+
+// the template kernel for the launch's shape (ssm_kernel.hip runs the X'e GEMM behind it)
+hipError_t launch_ssm_template(hipStream_t stream, const SsParams &P, int draw_variances) {
+  const dim3 grid(P.chain_count), block(2 * WAVE);
+  const bool seas = P.ssm.tpl_nseasons > 0, ar = P.ssm.tpl_ar_lags > 0;
+#define SSM_LAUNCH(TR, SE, AR) hipLaunchKernelGGL((ssm_simsmooth_kernel<TR, SE, AR>), grid, block, 0, stream, P, draw_variances)
+#define SSM_LAUNCH_AR(TR, SE) do { if (ar) SSM_LAUNCH(TR, SE, true); else SSM_LAUNCH(TR, SE, false); } while (0)
+  if (!seas) {
+    if (P.ssm.tpl_trend == 1) SSM_LAUNCH_AR(1, false); else SSM_LAUNCH_AR(2, false);
+  } else {
+    if (P.ssm.tpl_trend == 1) SSM_LAUNCH_AR(1, true); else SSM_LAUNCH_AR(2, true);
+  }
+#undef SSM_LAUNCH_AR
+#undef SSM_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace boom_amd

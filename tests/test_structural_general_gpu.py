@@ -155,6 +155,40 @@ def test_general_form_equals_the_template():
     assert np.array_equal(a.ss_get_ar(2)["phi"], b.ss_get_state_model(2, 2)["phi"])
 
 
+@pytest.mark.parametrize("desc,T", [
+    ([("level",)], 130), ([("trend",), ("seasonal", 12, 1)], 300),
+    ([("level",), ("seasonal", 7, 1), ("ar", 2)], 97), ([("trend",), ("ar", 3)], 150)])
+def test_general_kernel_equals_the_shape_specialised_one(desc, T):
+    """block lists of the template's shape run a kernel compiled for the shape
+    (ssm_template_kernel.hip); ba_ss_set_tuning(0) sends them through the general kernel:
+    the same chains (inclusion indicators identical, the rest within 1e-9 -- the two
+    kernels sum in different orders)"""
+    p, chains, seed = 5, 6, 13
+    seas = [(b[1], b[2]) for b in desc if b[0] == "seasonal"]
+    X, y, _, obs = general_data(T, p, 2, seas, seed=T, missing_frac=0.03,
+                                ar_coef=[0.5] if any(b[0] == "ar" for b in desc) else None)
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    blocks = general_spec(y, desc)
+    g0 = np.zeros(p, np.uint8)
+    a = make_engine(chains, seed, y, X, obs, prior, blocks, sig_up, g0)
+    b = make_engine(chains, seed, y, X, obs, prior, blocks, sig_up, g0)
+    b.ss_set_tuning(use_template_kernel=False)
+    for s in range(8):
+        a.ss_sweep(1)
+        b.ss_sweep(1)
+        ga, ba_, sa = a.get_states()
+        gb, bb, sb = b.get_states()
+        assert np.array_equal(ga, gb), s
+        assert relerr(ba_, bb) < 1e-9 and relerr(sa, sb, 1e-300) < 1e-9, s
+        for c in (0, chains - 1):
+            u, v = a.ss_get_state_draw(c), b.ss_get_state_draw(c)
+            assert np.max(np.abs(u - v)) < 1e-9 * np.abs(v).max(), (s, c)
+            for k in range(len(blocks)):
+                mu, mv = a.ss_get_state_model(c, k), b.ss_get_state_model(c, k)
+                assert relerr(mu["variances"], mv["variances"], 1e-300) < 1e-9, (s, c, k)
+                assert relerr(mu["suf_ss"], mv["suf_ss"], 1e-300) < 1e-9, (s, c, k)
+
+
 @pytest.mark.parametrize("key", ["a", "b", "c"])
 def test_general_forecast_matches_oracle(oracle, key):
     """simulate_forecast with seasonal blocks of duration > 1 (the reference simulates
