@@ -151,6 +151,22 @@ def other_configs(boom_amd, torch, device, cpu=True):
         e3.get_state(0)
         e3.ss_get_state(0)
     loop3 = (time.perf_counter() - t0) / 200
+    # ... and the same loop with the look-ahead the bindings switch on by default
+    # (ba_ss_set_lookahead(64) + ba_ss_draw_next: batches of 64 rounds enqueued ahead, every
+    # round's draw recorded on the device): median and quartiles over 20 batches of 64 calls
+    e3.ss_set_lookahead(64)
+    for _ in range(64):
+        e3.ss_draw_next()
+    per_batch = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        for _ in range(64):
+            e3.ss_draw_next()
+            e3.get_state(0)
+            e3.ss_get_state(0, suf=False)
+        per_batch.append((time.perf_counter() - t0) / 64)
+    q1, med, q3 = (float(v) for v in np.percentile(per_batch, [25, 50, 75]))
+    e3.ss_set_lookahead(1)
     e3.set_kernel_timing(True)
     e3.ss_sweep(100)
     kt = _per_launch(e3.kernel_times())
@@ -161,7 +177,12 @@ def other_configs(boom_amd, torch, device, cpu=True):
     dom = max(kt, key=kt.get)
     rec = {"sweeps_per_s": round(C3 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
            "mean_model_size": round(k3, 2), "kernel_us_per_launch": kt,
-           "callers_loop_us_per_draw": round(loop3 * 1e6, 1),
+           "callers_loop_us_per_draw": round(med * 1e6, 1),
+           "callers_loop_detail": {"lookahead": 64, "median_us": round(med * 1e6, 1),
+                                   "iqr_us": [round(q1 * 1e6, 1), round(q3 * 1e6, 1)],
+                                   "one_round_per_call_us": round(loop3 * 1e6, 1),
+                                   "what": "draw_next(); get_state(0); ss_get_state(0) -- chain 0's "
+                                           "regression draw, level variance and state path per draw"},
            "roofline": {"bound": "hbm", "kernel": "kalman_lm_kernel (the timing class is named after "
                                                    "kalman_simsmooth_kernel, its T > 2048 sibling)",
                         "algorithmic_bytes_per_round": bytes3,

@@ -34,13 +34,12 @@ namespace BOOM {
       const Ptr<GammaModelBase> &residual_precision_prior,
       const Ptr<VariableSelectionPrior> &spike, double sigma_upper_limit,
       const std::vector<DeviceStateVariancePrior> &state_variance_priors, int chains,
-      int device, RNG &seeding_rng)
+      int device, RNG &seeding_rng, const std::vector<int> &seasonal_time_of_first_observation,
+      int lookahead)
       : PosteriorSampler(seeding_rng),
         model_(model),
         engine_(nullptr),
         chains_(chains),
-        trend_(0),
-        nseasons_(0),
         state_dim_(0),
         structural_(false),
         variance_priors_(state_variance_priors) {
@@ -51,143 +50,138 @@ namespace BOOM {
       report_error("Spike dimension did not match model dimension.");
     if (T <= 0) report_error("Add the data to the model before creating the device sampler.");
 
-    // ---- which state models: a trend (local level | local linear trend), then an
-    // optional seasonal component
-    int nstate = model->number_of_state_models();
-    // an ArStateModel may come last (bsts: AddAr after the trend / seasonal components)
-    const ArStateModel *ar = nstate >= 2
-        ? dynamic_cast<const ArStateModel *>(model->state_model(nstate - 1)) : nullptr;
-    ar_index_ = ar ? nstate - 1 : -1;
-    ar_lags_ = ar ? ar->number_of_lags() : 0;
-    if (ar) --nstate;
-    if (nstate < 1 || nstate > 2)
-      report_error("The device sampler takes a trend state model, optionally followed by a seasonal "
-                   "one and / or an autoregression.");
-    const LocalLevelStateModel *level = dynamic_cast<const LocalLevelStateModel *>(model->state_model(0));
-    const LocalLinearTrendStateModel *llt =
-        dynamic_cast<const LocalLinearTrendStateModel *>(model->state_model(0));
-    if (!level && !llt)
-      report_error("The first state model must be a LocalLevelStateModel or a LocalLinearTrendStateModel.");
-    trend_ = level ? 1 : 2;
-    const SeasonalStateModel *seasonal = nullptr;
-    if (nstate == 2) {
-      seasonal = dynamic_cast<const SeasonalStateModel *>(model->state_model(1));
-      if (!seasonal) report_error("The second state model must be a SeasonalStateModel.");
-      if (seasonal->season_duration() != 1)
-        report_error("Season durations other than 1 are not implemented on the device.");
-      nseasons_ = seasonal->nseasons();
+    // ---- which state models, in the order add_state received them
+    const int nstate = model->number_of_state_models();
+    if (nstate < 1) report_error("No state has been defined.");
+    int nvar = 0;
+    for (int s = 0; s < nstate; ++s) {
+      const StateModel *sm = model->state_model(s);
+      Block b{0, nvar, 1, 0, 0};
+      if (dynamic_cast<const LocalLevelStateModel *>(sm)) {
+        b.kind = 1; b.dim = 1;
+      } else if (dynamic_cast<const LocalLinearTrendStateModel *>(sm)) {
+        b.kind = 2; b.dim = 2; b.nvar = 2;
+      } else if (const SeasonalStateModel *seas = dynamic_cast<const SeasonalStateModel *>(sm)) {
+        b.kind = 3; b.dim = seas->nseasons() - 1;
+      } else if (const ArStateModel *ar = dynamic_cast<const ArStateModel *>(sm)) {
+        b.kind = 4; b.lags = ar->number_of_lags(); b.dim = b.lags;
+      } else {
+        report_error("The device sampler takes LocalLevelStateModel, LocalLinearTrendStateModel, "
+                     "SeasonalStateModel and ArStateModel state models.");
+      }
+      nvar += b.nvar;
+      state_dim_ += b.dim;
+      blocks_.push_back(b);
     }
-    state_dim_ = trend_ + (nseasons_ > 0 ? nseasons_ - 1 : 0) + ar_lags_;
-    structural_ = (trend_ == 2) || (nseasons_ > 0) || ar;
-    const size_t nvar = static_cast<size_t>(trend_ + (nseasons_ > 0 ? 1 : 0) + (ar ? 1 : 0));
-    if (variance_priors_.size() != nvar)
+    structural_ = !(nstate == 1 && blocks_[0].kind == 1);
+    if (variance_priors_.size() != static_cast<size_t>(nvar))
       report_error("state_variance_priors needs one entry per state variance parameter.");
 
     device_seed_ = seed_rng(seeding_rng);
     ba_config cfg{device, chains, 0, static_cast<uint64_t>(device_seed_), 0, 0};
     check(ba_engine_create(&cfg, &engine_));
-
-    // ---- data: one RegressionData per time point (StateSpaceRegressionModel.cpp:100-125)
-    Vector y(T, 0.0);
-    Matrix X(T, p);
-    std::vector<uint8_t> observed(T, 1);
-    for (int t = 0; t < T; ++t) {
-      const Ptr<StateSpace::MultiplexedRegressionData> &dp(model->dat()[t]);
-      if (dp->total_sample_size() != 1)
-        report_error("The device sampler takes one observation per time point.");
-      const RegressionData &rd(dp->regression_data(0));
-      X.row(t) = rd.x();
-      if (model->is_missing_observation(t)) {
-        observed[t] = 0;
-      } else {
-        y[t] = rd.y();
-      }
-    }
-    check(ba_ss_set_data(engine_, T, p, y.data(), X.data(), observed.data()));
-
-    // ---- regression priors: BregVsSampler's ctor #5 pieces
-    const Vector mu = slab->mu();
-    const SpdMatrix ominv = slab->unscaled_precision();
-    check(ba_set_slab(engine_, mu.data(), ominv.data()));
-    const Vector pi = spike->prior_inclusion_probabilities();
-    check(ba_set_spike(engine_, pi.data(), spike->max_model_size()));
-    check(ba_set_sigma_prior(engine_, prior_df(residual_precision_prior),
-                             prior_sigma_guess(residual_precision_prior), sigma_upper_limit));
-
-    // ---- state models
-    if (!structural_) {
-      const DeviceStateVariancePrior &lp(variance_priors_[0]);
-      check(ba_ss_set_local_level(engine_, prior_df(lp.precision_prior),
-                                  prior_sigma_guess(lp.precision_prior), lp.sigma_upper_limit,
-                                  level->initial_state_mean()[0],
-                                  level->initial_state_variance()(0, 0),
-                                  std::sqrt(level->sigsq())));
-    } else {
-      double df[3] = {1, 1, 1}, guess[3] = {1, 1, 1}, init[3] = {1, 1, 1};
-      double upper[3] = {infinity(), infinity(), infinity()};
-      Vector a0(state_dim_, 0.0), P0(state_dim_, 1.0);
-      auto set_var = [&](int slot, const DeviceStateVariancePrior &pr, double sigsq) {
-        df[slot] = prior_df(pr.precision_prior);
-        guess[slot] = prior_sigma_guess(pr.precision_prior);
-        upper[slot] = pr.sigma_upper_limit;
-        init[slot] = std::sqrt(sigsq);
-      };
-      if (level) {
-        set_var(0, variance_priors_[0], level->sigsq());
-        a0[0] = level->initial_state_mean()[0];
-        P0[0] = level->initial_state_variance()(0, 0);
-      } else {
-        const SpdMatrix Sigma = llt->Sigma();
-        if (Sigma(0, 1) != 0.0)
-          report_error("The device sampler draws the trend's two variances independently "
-                       "(ZeroMeanMvnIndependenceSampler): Sigma must be diagonal.");
-        set_var(0, variance_priors_[0], Sigma(0, 0));
-        set_var(1, variance_priors_[1], Sigma(1, 1));
-        const Vector m = llt->initial_state_mean();
-        const SpdMatrix V = llt->initial_state_variance();
-        diagonal_or_die(V, "the local linear trend");
-        for (int i = 0; i < 2; ++i) {
-          a0[i] = m[i];
-          P0[i] = V(i, i);
+    // (from here on a failure must not leak the engine: report_error throws)
+    try {
+      // ---- data: one RegressionData per time point (StateSpaceRegressionModel.cpp:100-125)
+      Vector y(T, 0.0);
+      Matrix X(T, p);
+      std::vector<uint8_t> observed(T, 1);
+      for (int t = 0; t < T; ++t) {
+        const Ptr<StateSpace::MultiplexedRegressionData> &dp(model->dat()[t]);
+        if (dp->total_sample_size() != 1)
+          report_error("The device sampler takes one observation per time point.");
+        const RegressionData &rd(dp->regression_data(0));
+        X.row(t) = rd.x();
+        if (model->is_missing_observation(t)) {
+          observed[t] = 0;
+        } else {
+          y[t] = rd.y();
         }
       }
-      if (seasonal) {
-        set_var(2, variance_priors_[trend_], seasonal->sigsq());
-        const Vector m = seasonal->initial_state_mean();
-        const SpdMatrix V = seasonal->initial_state_variance();
-        diagonal_or_die(V, "the seasonal component");
-        for (int i = 0; i < nseasons_ - 1; ++i) {
-          a0[trend_ + i] = m[i];
-          P0[trend_ + i] = V(i, i);
+      check(ba_ss_set_data(engine_, T, p, y.data(), X.data(), observed.data()));
+
+      // ---- regression priors: BregVsSampler's ctor #5 pieces
+      const Vector mu = slab->mu();
+      const SpdMatrix ominv = slab->unscaled_precision();
+      check(ba_set_slab(engine_, mu.data(), ominv.data()));
+      const Vector pi = spike->prior_inclusion_probabilities();
+      check(ba_set_spike(engine_, pi.data(), spike->max_model_size()));
+      check(ba_set_sigma_prior(engine_, prior_df(residual_precision_prior),
+                               prior_sigma_guess(residual_precision_prior), sigma_upper_limit));
+
+      // ---- state models
+      if (!structural_) {
+        const LocalLevelStateModel *level = dynamic_cast<const LocalLevelStateModel *>(model->state_model(0));
+        const DeviceStateVariancePrior &lp(variance_priors_[0]);
+        check(ba_ss_set_local_level(engine_, prior_df(lp.precision_prior),
+                                    prior_sigma_guess(lp.precision_prior), lp.sigma_upper_limit,
+                                    level->initial_state_mean()[0],
+                                    level->initial_state_variance()(0, 0),
+                                    std::sqrt(level->sigsq())));
+      } else {
+        check(ba_ss_clear_state_models(engine_));
+        size_t nseasonal = 0;
+        for (int s = 0; s < nstate; ++s) {
+          const Block &b(blocks_[s]);
+          const StateModel *sm = model->state_model(s);
+          double df[2] = {1, 1}, guess[2] = {1, 1}, upper[2] = {infinity(), infinity()}, init[2] = {1, 1};
+          for (int v = 0; v < b.nvar; ++v) {
+            const DeviceStateVariancePrior &pr(variance_priors_[b.var0 + v]);
+            df[v] = prior_df(pr.precision_prior);
+            guess[v] = prior_sigma_guess(pr.precision_prior);
+            upper[v] = pr.sigma_upper_limit;
+          }
+          const Vector a0 = sm->initial_state_mean();
+          const SpdMatrix V0 = sm->initial_state_variance();
+          diagonal_or_die(V0, "a state model");
+          const Vector v0 = V0.diag();
+          int32_t ip[3] = {0, 1, 0};
+          Vector phi;
+          if (b.kind == 1) {
+            init[0] = std::sqrt(dynamic_cast<const LocalLevelStateModel *>(sm)->sigsq());
+          } else if (b.kind == 2) {
+            const SpdMatrix Sigma = dynamic_cast<const LocalLinearTrendStateModel *>(sm)->Sigma();
+            if (Sigma(0, 1) != 0.0)
+              report_error("The device sampler draws the trend's two variances independently "
+                           "(ZeroMeanMvnIndependenceSampler): Sigma must be diagonal.");
+            init[0] = std::sqrt(Sigma(0, 0));
+            init[1] = std::sqrt(Sigma(1, 1));
+          } else if (b.kind == 3) {
+            const SeasonalStateModel *seas = dynamic_cast<const SeasonalStateModel *>(sm);
+            init[0] = std::sqrt(seas->sigsq());
+            ip[0] = seas->nseasons();
+            ip[1] = seas->season_duration();
+            ip[2] = nseasonal < seasonal_time_of_first_observation.size()
+                        ? seasonal_time_of_first_observation[nseasonal] : 0;
+            ++nseasonal;
+          } else {
+            const ArStateModel *ar = dynamic_cast<const ArStateModel *>(sm);
+            init[0] = ar->sigma();
+            ip[0] = b.lags;
+            phi = ar->phi();
+          }
+          check(ba_ss_add_state_model(engine_, b.kind, ip, df, guess, upper, init,
+                                      b.kind == 4 ? phi.data() : nullptr, a0.data(), v0.data()));
         }
       }
-      check(ba_ss_set_structural(engine_, trend_, nseasons_, df, guess, upper, init, a0.data(),
-                                 P0.data()));
-      if (ar) {
-        // ArPosteriorSampler(model, siginv_prior) + set_sigma_upper_limit
-        const DeviceStateVariancePrior &pr(variance_priors_.back());
-        const Vector m = ar->initial_state_mean();
-        const SpdMatrix V = ar->initial_state_variance();
-        diagonal_or_die(V, "the autoregression");
-        const Vector v0 = V.diag();
-        const Vector phi = ar->phi();
-        check(ba_ss_add_ar(engine_, ar_lags_, prior_df(pr.precision_prior),
-                           prior_sigma_guess(pr.precision_prior), pr.sigma_upper_limit, ar->sigma(),
-                           phi.data(), m.data(), v0.data()));
-      }
-    }
 
-    // ---- the chains start where the model stands
-    const RegressionModel *reg = model->observation_model();
-    const Selector &inc(reg->coef().inc());
-    std::vector<uint8_t> gamma(p, 0);
-    for (int j = 0; j < p; ++j) gamma[j] = inc[j] ? 1 : 0;
-    const Vector beta = reg->Beta();
-    check(ba_set_state(engine_, -1, gamma.data(), beta.data(), reg->sigsq()));
+      // ---- the chains start where the model stands
+      const RegressionModel *reg = model->observation_model();
+      const Selector &inc(reg->coef().inc());
+      std::vector<uint8_t> gamma(p, 0);
+      for (int j = 0; j < p; ++j) gamma[j] = inc[j] ? 1 : 0;
+      const Vector beta = reg->Beta();
+      check(ba_set_state(engine_, -1, gamma.data(), beta.data(), reg->sigsq()));
+      if (lookahead > 1) check(ba_ss_set_lookahead(engine_, lookahead));
+    } catch (...) {
+      ba_engine_destroy(engine_);
+      engine_ = nullptr;
+      throw;
+    }
   }
 
   DeviceStateSpacePosteriorSampler::~DeviceStateSpacePosteriorSampler() {
-    ba_engine_destroy(engine_);
+    if (engine_) ba_engine_destroy(engine_);
   }
 
   void DeviceStateSpacePosteriorSampler::check(int rc) const {
@@ -199,9 +193,17 @@ namespace BOOM {
     check(ba_seed(engine_, seed));
   }
 
+  void DeviceStateSpacePosteriorSampler::record_state_of_chains(const std::vector<int> &chains) {
+    std::vector<int64_t> c(1, 0);   // (chain 0 backs the model: always)
+    for (int v : chains)
+      if (v != 0) c.push_back(v);
+    check(ba_ss_lookahead_chains(engine_, static_cast<int32_t>(c.size()), c.data()));
+  }
+
   void DeviceStateSpacePosteriorSampler::draw() {
-    check(ba_ss_sweep(engine_, 1));
-    check(ba_sync(engine_));
+    // (one round of every chain; with the look-ahead the round has usually run already and
+    // this hands out its record)
+    check(ba_ss_draw_next(engine_));
     pull_chain0();
   }
 
@@ -217,19 +219,28 @@ namespace BOOM {
       if (gamma[j]) inc.add(j);
     // the engine's layout -- step t at [t m, (t + 1) m) -- is a column-major m x T Matrix
     state = Matrix(state_dim_, T);
-    state_variances = Vector(3, 0.0);
+    state_variances = Vector(variance_priors_.size(), 0.0);
     if (structural_) {
-      check(ba_ss_get_structural(engine_, chain, state.data(), state_variances.data(), nullptr,
-                                 nullptr));
+      check(ba_ss_get_state_draw(engine_, chain, state.data()));
+      for (size_t s = 0; s < blocks_.size(); ++s)
+        check(ba_ss_get_state_model(engine_, chain, static_cast<int32_t>(s),
+                                    &state_variances[blocks_[s].var0], nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr));
     } else {
       check(ba_ss_get_state(engine_, chain, state.data(), &state_variances[0], nullptr, nullptr));
     }
   }
 
-  void DeviceStateSpacePosteriorSampler::chain_ar(int chain, Vector &phi, double &sigsq) const {
-    if (ar_index_ < 0) report_error("The model has no ArStateModel.");
-    phi.resize(ar_lags_);
-    check(ba_ss_get_ar(engine_, chain, phi.data(), &sigsq, nullptr, nullptr, nullptr, nullptr));
+  void DeviceStateSpacePosteriorSampler::chain_ar(int chain, Vector &phi, double &sigsq, int which) const {
+    int seen = 0;
+    for (size_t s = 0; s < blocks_.size(); ++s) {
+      if (blocks_[s].kind != 4 || seen++ != which) continue;
+      phi.resize(blocks_[s].lags);
+      check(ba_ss_get_state_model(engine_, chain, static_cast<int32_t>(s), &sigsq, nullptr, nullptr,
+                                  phi.data(), nullptr, nullptr, nullptr, nullptr));
+      return;
+    }
+    report_error("The model has no such ArStateModel.");
   }
 
   void DeviceStateSpacePosteriorSampler::pull_chain0() {
@@ -242,23 +253,27 @@ namespace BOOM {
     reg->coef().set_inc(inc);
     reg->set_included_coefficients(inc.select(beta));
     reg->set_sigsq(sigsq);
-    if (trend_ == 1) {
-      dynamic_cast<LocalLevelStateModel *>(model_->state_model(0))->set_sigsq(variances[0]);
-    } else {
-      SpdMatrix Sigma(2, 0.0);
-      Sigma(0, 0) = variances[0];
-      Sigma(1, 1) = variances[1];
-      dynamic_cast<LocalLinearTrendStateModel *>(model_->state_model(0))->set_Sigma(Sigma);
-    }
-    if (nseasons_ > 0)
-      dynamic_cast<SeasonalStateModel *>(model_->state_model(1))->set_sigsq(variances[2]);
-    if (ar_index_ >= 0) {
-      Vector phi(ar_lags_, 0.0);
-      double ar_sigsq = 1.0;
-      check(ba_ss_get_ar(engine_, 0, phi.data(), &ar_sigsq, nullptr, nullptr, nullptr, nullptr));
-      ArStateModel *arm = dynamic_cast<ArStateModel *>(model_->state_model(ar_index_));
-      arm->set_phi(phi);
-      arm->set_sigsq(ar_sigsq);
+    for (size_t s = 0; s < blocks_.size(); ++s) {
+      const Block &b(blocks_[s]);
+      StateModel *sm = model_->state_model(static_cast<int>(s));
+      if (b.kind == 1) {
+        dynamic_cast<LocalLevelStateModel *>(sm)->set_sigsq(variances[b.var0]);
+      } else if (b.kind == 2) {
+        SpdMatrix Sigma(2, 0.0);
+        Sigma(0, 0) = variances[b.var0];
+        Sigma(1, 1) = variances[b.var0 + 1];
+        dynamic_cast<LocalLinearTrendStateModel *>(sm)->set_Sigma(Sigma);
+      } else if (b.kind == 3) {
+        dynamic_cast<SeasonalStateModel *>(sm)->set_sigsq(variances[b.var0]);
+      } else {
+        Vector phi(b.lags, 0.0);
+        double ar_sigsq = 1.0;
+        check(ba_ss_get_state_model(engine_, 0, static_cast<int32_t>(s), &ar_sigsq, nullptr, nullptr,
+                                    phi.data(), nullptr, nullptr, nullptr, nullptr));
+        ArStateModel *arm = dynamic_cast<ArStateModel *>(sm);
+        arm->set_phi(phi);
+        arm->set_sigsq(ar_sigsq);
+      }
     }
     // the model's state matrix: the only public way to install one is
     // permanently_set_state (StateSpaceModelBase.cpp:199-212), which also tells the
@@ -273,26 +288,26 @@ namespace BOOM {
   double DeviceStateSpacePosteriorSampler::logpri() const {
     double ans = negative_infinity();
     check(ba_logpri(engine_, 0, &ans));
-    Vector v(3, 0.0);
-    if (structural_) {
-      check(ba_ss_get_structural(engine_, 0, nullptr, v.data(), nullptr, nullptr));
-    } else {
-      check(ba_ss_get_state(engine_, 0, nullptr, &v[0], nullptr, nullptr));
-    }
-    const size_t nplain = variance_priors_.size() - (ar_index_ >= 0 ? 1 : 0);
-    for (size_t i = 0; i < nplain; ++i) {
-      const int slot = (i < static_cast<size_t>(trend_)) ? static_cast<int>(i) : 2;
-      const double sigsq = v[slot];
-      ans += variance_priors_[i].precision_prior->logp(1.0 / sigsq) - 2 * std::log(sigsq);
-    }
-    if (ar_index_ >= 0) {
-      // ArPosteriorSampler::log_prior_density (ArPosteriorSampler.cpp:66-70): the
-      // stationarity indicator and the variance prior
-      Vector phi(ar_lags_, 0.0);
-      double sigsq = 1.0;
-      check(ba_ss_get_ar(engine_, 0, phi.data(), &sigsq, nullptr, nullptr, nullptr, nullptr));
-      if (!ArModel::check_stationary(phi)) return negative_infinity();
-      ans += variance_priors_.back().precision_prior->logp(1.0 / sigsq) - 2 * std::log(sigsq);
+    Selector inc(model_->xdim(), false);
+    Vector beta, v;
+    Matrix state;
+    double sigsq_obs = 1.0;
+    chain_state(0, inc, beta, sigsq_obs, v, state);
+    for (size_t s = 0; s < blocks_.size(); ++s) {
+      const Block &b(blocks_[s]);
+      if (b.kind == 4) {
+        // ArPosteriorSampler::log_prior_density (ArPosteriorSampler.cpp:66-70): the
+        // stationarity indicator and the variance prior
+        Vector phi(b.lags, 0.0);
+        double sigsq = 1.0;
+        check(ba_ss_get_state_model(engine_, 0, static_cast<int32_t>(s), &sigsq, nullptr, nullptr,
+                                    phi.data(), nullptr, nullptr, nullptr, nullptr));
+        if (!ArModel::check_stationary(phi)) return negative_infinity();
+      }
+      for (int k = 0; k < b.nvar; ++k) {
+        const double sigsq = v[b.var0 + k];
+        ans += variance_priors_[b.var0 + k].precision_prior->logp(1.0 / sigsq) - 2 * std::log(sigsq);
+      }
     }
     return ans;
   }

@@ -1,9 +1,10 @@
 // The reference-side binding for the bsts half of the path: a BOOM PosteriorSampler
 // that stands where StateSpacePosteriorSampler stands
 // (Models/StateSpace/PosteriorSamplers/StateSpacePosteriorSampler.hpp:27-33) for a
-// StateSpaceRegressionModel whose state is a LocalLevelStateModel -- or a
-// LocalLinearTrendStateModel / LocalLevelStateModel followed by a SeasonalStateModel --
-// and forwards draw() to ba_ss_sweep through the C-ABI (include/boom_amd.h).
+// StateSpaceRegressionModel with WHATEVER list of state models add_state gave it --
+// LocalLevelStateModel, LocalLinearTrendStateModel, SeasonalStateModel (any season
+// duration), ArStateModel, in any order and number (state dimension <= 64) -- and
+// forwards draw() to the engine through the C-ABI (include/boom_amd.h).
 //
 // OUR code, written against the reference's public headers.  It is compiled where the
 // reference tree exists (bindings/boom/Makefile; oracle/Makefile target `binding` links
@@ -51,15 +52,23 @@ namespace BOOM {
   //   slab, residual_precision_prior, spike, sigma_upper_limit
   //       BregVsSampler's ctor #5 on model->regression_model() + set_sigma_upper_limit;
   //   state_variance_priors
-  //       one entry per variance parameter in state-model order: (level) for a
-  //       LocalLevelStateModel, (level, slope) for a LocalLinearTrendStateModel, then
-  //       (seasonal) if a SeasonalStateModel follows, then the ArPosteriorSampler's
-  //       prior if an ArStateModel comes last.
+  //       one entry per variance parameter, in the order the state models were added:
+  //       (level) for a LocalLevelStateModel, (level, slope) for a
+  //       LocalLinearTrendStateModel, (seasonal) for a SeasonalStateModel, the
+  //       ArPosteriorSampler's prior for an ArStateModel.
+  //   seasonal_time_of_first_observation
+  //       SeasonalStateModel keeps what set_time_of_first_observation was given to itself:
+  //       one entry per SeasonalStateModel, in order (empty: all 0).
   // The data, the state models' initial-state distributions and the parameters' current
   // values are read from the model in the constructor: add the data and the state
   // models first.  Chain 0 backs the model's own objects: after every draw
   // regression_model()'s coefficients / inclusion indicators / sigsq, the state models'
-  // variances and model->state() hold chain 0's draw.
+  // variances (and coefficients) and model->state() hold chain 0's draw.
+  // draw() is served from the engine's look-ahead (ba_ss_set_lookahead /
+  // ba_ss_draw_next: rounds enqueued `lookahead` at a time, every round's draw recorded
+  // on the device), which no caller can observe: the loop
+  //     for (i in niter) { model->sample_posterior(); record }
+  // (Interfaces/R/bsts/src/bsts.cc:82-119) runs at the device's rate.
   class DeviceStateSpacePosteriorSampler : public PosteriorSampler {
    public:
     DeviceStateSpacePosteriorSampler(
@@ -69,7 +78,9 @@ namespace BOOM {
         const Ptr<VariableSelectionPrior> &spike,
         double sigma_upper_limit,
         const std::vector<DeviceStateVariancePrior> &state_variance_priors,
-        int chains, int device = 0, RNG &seeding_rng = GlobalRng::rng);
+        int chains, int device = 0, RNG &seeding_rng = GlobalRng::rng,
+        const std::vector<int> &seasonal_time_of_first_observation = std::vector<int>(),
+        int lookahead = 64);
     ~DeviceStateSpacePosteriorSampler() override;
 
     void draw() override;            // StateSpacePosteriorSampler::draw, .cpp:42-64
@@ -80,12 +91,17 @@ namespace BOOM {
 
     int number_of_chains() const { return chains_; }
     int state_dimension() const { return state_dim_; }
-    // one chain's autoregression coefficients and error variance (an ArStateModel last)
-    void chain_ar(int chain, Vector &phi, double &sigsq) const;
-    // the other chains: regression parameters, state variances (level, slope,
-    // seasonal; unused entries 0) and the state draw (state_dimension x time_dimension)
+    // one chain's autoregression coefficients and error variance (the model's first --
+    // or `which`-th -- ArStateModel)
+    void chain_ar(int chain, Vector &phi, double &sigsq, int which = 0) const;
+    // the other chains: regression parameters, the state variances (one entry per
+    // variance parameter, in state-model order -- state_variance_priors' order) and the
+    // state draw (state_dimension x time_dimension)
     void chain_state(int chain, Selector &inc, Vector &beta, double &sigsq,
                      Vector &state_variances, Matrix &state) const;
+    // whose state paths the look-ahead keeps besides chain 0's (reading another chain's
+    // state is correct all the same, and slow)
+    void record_state_of_chains(const std::vector<int> &chains);
     // StateSpaceRegressionModel::simulate_forecast(rng, newX, final_state)
     // (StateSpaceRegressionModel.cpp:214-219) for EVERY chain's current draw: one row
     // per chain, nrow(newX) columns
@@ -98,12 +114,15 @@ namespace BOOM {
     ba_engine *engine_;
     int chains_;
     unsigned long device_seed_;
-    int trend_;      // 1 local level, 2 local linear trend
-    int nseasons_;   // 0: no seasonal state model
+    // the state models as the engine knows them
+    struct Block {
+      int kind;    // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression
+      int var0;    // index of its first variance parameter (into state_variance_priors)
+      int nvar, dim, lags;
+    };
+    std::vector<Block> blocks_;
     int state_dim_;
-    int ar_index_ = -1;   // position of the ArStateModel among the state models (-1: none)
-    int ar_lags_ = 0;
-    bool structural_;  // the engine runs ba_ss_set_structural (anything but a lone local level)
+    bool structural_;  // anything but a lone local level: the engine runs a state-model list
     std::vector<DeviceStateVariancePrior> variance_priors_;
   };
 

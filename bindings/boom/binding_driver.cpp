@@ -416,6 +416,172 @@ int ref_binding_ss_ar_run(int T, int p, const double *y, const double *X, const 
                          out_logpri, out_seed, probe_chain, probe_gamma, probe_state);
 }
 
+// The general form: ANY list of state models (the flat arrays of oracle/ref_driver.cpp's
+// ref_ssg_run: kinds, iparams = {nseasons, duration, time of first observation} or {lags},
+// vpar[8 b + 4 v + {df, sigma guess, upper limit, initial sigma}], phi0[16 b ..], a0 / P0).
+// Per draw: the model's inc / Beta / sigsq, every state model's variance parameters
+// (2 per block) and coefficients (16 per block) as BOOM's own objects hold them after
+// sample_posterior(), model->state(), the sampler's logpri(); at the end one other chain.
+int ref_binding_ssg_run(int T, int p, const double *y, const double *X, const uint8_t *observed,
+                        const double *prior_mean, const double *ominv, double prior_df,
+                        double sigma_guess, const double *pi, double sigma_upper_limit, int nblocks,
+                        const int *kinds, const int *iparams, const double *vpar, const double *phi0,
+                        const double *a0, const double *P0, int chains, uint64_t seed,
+                        const uint8_t *init_gamma, int nsweeps, int lookahead, uint8_t *out_gamma,
+                        double *out_beta, double *out_sigsq, double *out_variances, double *out_phi,
+                        double *out_state, double *out_logpri, uint64_t *out_seed, int probe_chain,
+                        uint8_t *probe_gamma, double *probe_state) {
+  try {
+    GlobalRng::rng.seed(seed);
+    Matrix Xm(T, p);
+    for (int j = 0; j < p; ++j)
+      for (int t = 0; t < T; ++t) Xm(t, j) = X[(size_t)j * T + t];
+    Vector yv(T);
+    for (int t = 0; t < T; ++t) yv[t] = y[t];
+    std::vector<bool> obs;
+    if (observed) {
+      obs.resize(T);
+      for (int t = 0; t < T; ++t) obs[t] = observed[t] != 0;
+    }
+    NEW(StateSpaceRegressionModel, model)(yv, Xm, obs);
+    RegressionModel *reg = model->observation_model();
+    Vector mu(p), piv(p);
+    SpdMatrix om(p);
+    for (int j = 0; j < p; ++j) {
+      mu[j] = prior_mean[j];
+      piv[j] = pi[j];
+      for (int i = 0; i < p; ++i) om(i, j) = ominv[(size_t)j * p + i];
+    }
+    NEW(MvnGivenScalarSigma, slab)(mu, om, reg->Sigsq_prm());
+    NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+    NEW(VariableSelectionPrior, spike)(piv);
+    reg->coef().drop_all();
+    for (int j = 0; j < p; ++j)
+      if (init_gamma[j]) reg->coef().add(j);
+
+    std::vector<DeviceStateVariancePrior> vpriors;
+    std::vector<int> t0s;
+    int first = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      const double *vp = vpar + 8 * b;
+      auto vprior = [&](int v) {
+        DeviceStateVariancePrior pr;
+        pr.precision_prior = new ChisqModel(vp[4 * v], vp[4 * v + 1]);
+        pr.sigma_upper_limit = vp[4 * v + 2];
+        vpriors.push_back(pr);
+      };
+      int dim = 0;
+      if (kinds[b] == 1) {
+        NEW(LocalLevelStateModel, level)(vp[3]);
+        level->set_initial_state_mean(a0[first]);
+        level->set_initial_state_variance(P0[first]);
+        model->add_state(level);
+        vprior(0);
+        dim = 1;
+      } else if (kinds[b] == 2) {
+        NEW(LocalLinearTrendStateModel, llt)();
+        SpdMatrix Sigma(2, 0.0);
+        Sigma(0, 0) = vp[3] * vp[3];
+        Sigma(1, 1) = vp[7] * vp[7];
+        llt->set_Sigma(Sigma);
+        Vector mean(2);
+        SpdMatrix var(2, 0.0);
+        for (int i = 0; i < 2; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+        llt->set_initial_state_mean(mean);
+        llt->set_initial_state_variance(var);
+        model->add_state(llt);
+        vprior(0);
+        vprior(1);
+        dim = 2;
+      } else if (kinds[b] == 3) {
+        const int ns = iparams[3 * b];
+        NEW(SeasonalStateModel, seasonal)(ns, iparams[3 * b + 1]);
+        seasonal->set_time_of_first_observation(iparams[3 * b + 2]);
+        t0s.push_back(iparams[3 * b + 2]);
+        seasonal->set_sigsq(vp[3] * vp[3]);
+        dim = ns - 1;
+        Vector mean(dim);
+        SpdMatrix var(dim, 0.0);
+        for (int i = 0; i < dim; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+        seasonal->set_initial_state_mean(mean);
+        seasonal->set_initial_state_variance(var);
+        model->add_state(seasonal);
+        vprior(0);
+      } else {
+        dim = iparams[3 * b];
+        NEW(ArStateModel, arm)(dim);
+        Vector ph(dim);
+        for (int i = 0; i < dim; ++i) ph[i] = phi0[16 * b + i];
+        arm->set_phi(ph);
+        arm->set_sigma(vp[3]);
+        Vector mean(dim);
+        SpdMatrix var(dim, 0.0);
+        for (int i = 0; i < dim; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+        arm->set_initial_state_mean(mean);
+        arm->set_initial_state_variance(var);
+        model->add_state(arm);
+        vprior(0);
+      }
+      first += dim;
+    }
+    const int m = first;
+    NEW(DeviceStateSpacePosteriorSampler, sampler)(model.get(), slab, siginv_prior, spike,
+                                                   sigma_upper_limit, vpriors, chains, 0, GlobalRng::rng,
+                                                   t0s, lookahead);
+    if (out_seed) *out_seed = sampler->device_seed();
+    model->set_method(sampler);
+    for (int s = 0; s < nsweeps; ++s) {
+      model->sample_posterior();   // PriorPolicy::sample_posterior -> sampler->draw()
+      const Selector &inc(reg->coef().inc());
+      const Vector beta = reg->Beta();
+      for (int j = 0; j < p; ++j) {
+        out_gamma[(size_t)s * p + j] = inc[j] ? 1 : 0;
+        out_beta[(size_t)s * p + j] = beta[j];
+      }
+      out_sigsq[s] = reg->sigsq();
+      for (int b = 0; b < nblocks; ++b) {
+        double *v = out_variances + ((size_t)s * nblocks + b) * 2;
+        double *ph = out_phi + ((size_t)s * nblocks + b) * 16;
+        v[0] = v[1] = 0.0;
+        for (int i = 0; i < 16; ++i) ph[i] = 0.0;
+        StateModel *sm = model->state_model(b);
+        if (kinds[b] == 1) {
+          v[0] = dynamic_cast<LocalLevelStateModel *>(sm)->sigsq();
+        } else if (kinds[b] == 2) {
+          const SpdMatrix S = dynamic_cast<LocalLinearTrendStateModel *>(sm)->Sigma();
+          v[0] = S(0, 0);
+          v[1] = S(1, 1);
+        } else if (kinds[b] == 3) {
+          v[0] = dynamic_cast<SeasonalStateModel *>(sm)->sigsq();
+        } else {
+          ArStateModel *arm = dynamic_cast<ArStateModel *>(sm);
+          v[0] = arm->sigsq();
+          for (int i = 0; i < iparams[3 * b]; ++i) ph[i] = arm->phi()[i];
+        }
+      }
+      const Matrix &state(model->state());
+      if (state.nrow() != m || state.ncol() != T) throw std::runtime_error("state has the wrong shape");
+      for (int t = 0; t < T; ++t)
+        for (int i = 0; i < m; ++i) out_state[((size_t)s * T + t) * m + i] = state(i, t);
+      if (out_logpri) out_logpri[s] = sampler->logpri();
+    }
+    if (probe_gamma) {
+      Selector inc(p, false);
+      Vector beta, variances;
+      Matrix state;
+      double s2 = 0;
+      sampler->chain_state(probe_chain, inc, beta, s2, variances, state);
+      for (int j = 0; j < p; ++j) probe_gamma[j] = inc[j] ? 1 : 0;
+      for (int t = 0; t < T; ++t)
+        for (int i = 0; i < m; ++i) probe_state[(size_t)t * m + i] = state(i, t);
+    }
+    return 0;
+  } catch (std::exception &e) {
+    g_binding_error = e.what();
+    return -1;
+  }
+}
+
 // ... and for the Poisson sampler: BOOM's PoissonRegressionModel (one PoissonRegressionData
 // per observation), MvnModel slab, VariableSelectionPrior, sample_posterior() with the
 // device sampler attached -- which reads BOOM's own NegLogGamma mixture table.

@@ -134,6 +134,9 @@ SIGNATURES = {
     "ba_ss_get_state_model": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32] + [_dp] * 8),
     "ba_ss_get_state_draw": (C.c_int, [C.c_void_p, C.c_int64, _dp]),
     "ba_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_ss_set_lookahead": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_ss_lookahead_chains": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "ba_ss_draw_next": (C.c_int, [C.c_void_p]),
     "ba_ss_impute_state": (C.c_int, [C.c_void_p]),
     "ba_ss_forecast": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     "ba_ss_get_state": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
@@ -573,11 +576,19 @@ class Engine:
     def ss_set_tuning(self, use_template_kernel=True):
         self._check(self.lib.ba_ss_set_tuning(self._h, 1 if use_template_kernel else 0))
 
-    def ss_get_state_model(self, chain, block):
+    def ss_get_state_model(self, chain, block, suf=True):
+        """suf=False: the variance parameters / coefficients only"""
         b = self._blocks[block]
         nv, L = b["nvar"], b["lags"]
         var, n, ss = np.zeros(nv), np.zeros(nv), np.zeros(nv)
         out = dict(variances=var, suf_n=n, suf_ss=ss)
+        if not suf:
+            phi = np.zeros(L) if L else None
+            self._check(self.lib.ba_ss_get_state_model(self._h, chain, block, _p(var), None, None,
+                                                       _p(phi), None, None, None, None))
+            if L:
+                out["phi"] = phi
+            return out
         if L:
             phi, xtx, xty = np.zeros(L), np.zeros((L, L)), np.zeros(L)
             yty, an = C.c_double(), C.c_double()
@@ -606,6 +617,18 @@ class Engine:
         if sync:
             self.sync()
 
+    def ss_set_lookahead(self, lookahead, chains=None):
+        """ba_ss_draw_next enqueues `lookahead` rounds at a time; chains: whose state path
+        is recorded (default: chain 0)"""
+        if chains is not None:
+            arr = np.ascontiguousarray(chains, dtype=np.int64)
+            self._check(self.lib.ba_ss_lookahead_chains(self._h, len(arr),
+                                                        arr.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._check(self.lib.ba_ss_set_lookahead(self._h, int(lookahead)))
+
+    def ss_draw_next(self):
+        self._check(self.lib.ba_ss_draw_next(self._h))
+
     def ss_impute_state(self):
         self._check(self.lib.ba_ss_impute_state(self._h))
         self.sync()
@@ -617,11 +640,13 @@ class Engine:
         self._check(self.lib.ba_ss_forecast(self._h, h, _p(_fcol(newX)), _p(out)))
         return out
 
-    def ss_get_state(self, chain):
-        st = np.zeros(self.T)
+    def ss_get_state(self, chain, state=True, suf=True):
+        """state=False / suf=False: do not ask for the state path / the level model's
+        sufficient statistics (NULL pointers)"""
+        st = np.zeros(self.T) if state else None
         ls, n, ss = C.c_double(), C.c_double(), C.c_double()
         self._check(self.lib.ba_ss_get_state(self._h, chain, _p(st), C.byref(ls),
-                                             C.byref(n), C.byref(ss)))
+                                             C.byref(n) if suf else None, C.byref(ss) if suf else None))
         return dict(state=st, level_sigsq=ls.value, level_n=n.value, level_sumsq=ss.value)
 
     def ss_set_level_sigsq(self, sigsq, chain=-1):

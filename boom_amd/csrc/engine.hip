@@ -389,6 +389,34 @@ struct ba_engine {
   DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;   // chains x SSG_MAX_VAR (sigsq, n, ss)
   DevBuf<double> dar_phi, dar_suf;                         // chains x SSG_MAX_AR x (AR_MAX | AR_SUF_STRIDE)
   DevBuf<uint64_t> dpos_var;                               // chains x SSG_MAX_VAR
+  // ---- look-ahead on the bsts path (ba_ss_set_lookahead / ba_ss_draw_next): a batch of
+  // `len` sweep rounds per enqueue, every round's draw recorded on the device -- gamma,
+  // beta, sigma^2, the state models' variances and coefficients for EVERY chain, the
+  // state path for the registered chains -- and handed out one per call.  Two halves:
+  // the batch after the one being served is enqueued as soon as serving starts.  Any
+  // entry point that is not served from the record first puts the chains where the
+  // caller has seen them (ss_la_settle: the snapshot of the batch's start, replayed up
+  // to the draw being served), so the look-ahead is unobservable.
+  struct SsLa {
+    int len = 0;                // rounds per batch (<= 1: off)
+    int avail = 0, served = 0, slot = 0;
+    bool ahead = false;         // the next batch is enqueued (half slot ^ 1)
+    bool synced = false;        // the batch being served is complete and its chains sound
+    bool busy = false;          // (a settle in progress: entry points it calls do not settle again)
+    hipEvent_t done[2] = {nullptr, nullptr};
+    std::vector<int32_t> reg{0};            // chains whose state path is recorded
+    DevBuf<int32_t> dreg;
+    DevBuf<double> lev_used;                // the level variance every chain's last state draw used
+    size_t nvar = 0, nphi = 0, state_doubles = 0;   // per chain and round
+    DevBuf<uint8_t> rgamma;                 // [slot][chain][round][p]
+    DevBuf<double> rbeta, rsig, rvar, rphi; // [slot][chain][round][...]
+    DevBuf<double> rstate;                  // [slot][registered chain][round][state_doubles]
+    DevBuf<double> snap;                    // the state-space half of the chain state, two sets
+    DevBuf<uint64_t> snap_pos;
+    size_t snap_doubles = 0, snap_words = 0;
+    struct Rows { std::vector<uint8_t> gamma; std::vector<double> beta, sig, var, phi, state; bool has_state = false; };
+    std::unordered_map<int64_t, Rows> cache;
+  } ssla;
 };
 
 namespace {
@@ -952,6 +980,7 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
   S.prep_pos_level = e->dprep_pos_level.ptr;
   S.prep_level_sigsq = e->dprep_level.ptr;
   S.zbuf = e->ss_zbuf;
+  S.level_used = e->ssla.lev_used.ptr;
   if (e->ssm_set) {
     S.ssm.spec = reinterpret_cast<const SsgSpec *>(e->dssg_spec.ptr);
     S.ssm.m = e->ssg.m;
@@ -1178,6 +1207,7 @@ void la_discard(ba_engine *e) {
 
 int la_copy(ba_engine *e, bool save, int set = 0);
 int la_redo_batch(ba_engine *e);
+int ss_la_settle(ba_engine *e);
 
 // the batch being served is complete and sound; a pipelined batch in which a chain stopped
 // (capacity, an error) is run again the old way -- same draws -- where those are dealt with
@@ -1368,6 +1398,291 @@ int la_rewind(ba_engine *e) {
   return rc;
 }
 
+// ---- look-ahead on the bsts path --------------------------------------------------------
+int ss_sweep_impl(ba_engine *e, int32_t nsweeps, int rec_slot);
+
+// what a round leaves for the callers' loop, copied into the record: one workgroup per
+// chain (gamma, beta, sigma^2, the state models' variances and coefficients), then one per
+// registered chain (its state path)
+struct SsRecParams {
+  int32_t C, p, nvar, nphi, nreg, L, row;   // row: slot * L + round
+  int64_t var_stride, phi_stride, state_stride, state_doubles;
+  const uint8_t *gamma;
+  const double *beta, *sigsq, *var, *phi, *state;
+  const int32_t *reg;
+  uint8_t *rgamma;
+  double *rbeta, *rsig, *rvar, *rphi, *rstate;
+};
+__global__ __launch_bounds__(256) void ss_record_kernel(SsRecParams R) {
+  const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const int slot = R.row / R.L, i = R.row % R.L;
+  if (b < R.C) {
+    const size_t at = ((size_t)slot * R.C + b) * R.L + i;
+    const size_t p = (size_t)R.p;
+    for (size_t j = tid; j < p; j += 256) {
+      R.rgamma[at * p + j] = R.gamma[(size_t)b * p + j];
+      R.rbeta[at * p + j] = R.beta[(size_t)b * p + j];
+    }
+    if (tid == 0) R.rsig[at] = R.sigsq[b];
+    if (tid < R.nvar) R.rvar[at * R.nvar + tid] = R.var[(size_t)b * R.var_stride + tid];
+    if (tid < R.nphi) R.rphi[at * R.nphi + tid] = R.phi[(size_t)b * R.phi_stride + tid];
+  } else {
+    const int r = b - R.C;
+    const size_t c = (size_t)R.reg[r];
+    const size_t at = ((size_t)slot * R.nreg + r) * R.L + i;
+    const double *src = R.state + c * (size_t)R.state_stride;
+    double *dst = R.rstate + at * (size_t)R.state_doubles;
+    for (int64_t j = tid; j < R.state_doubles; j += 256) dst[j] = src[j];
+  }
+}
+
+bool ss_la_on(const ba_engine *e) { return e->ssla.len > 1; }
+bool ss_la_serving(const ba_engine *e) { return e->ssla.len > 1 && e->ssla.avail > 0 && !e->ssla.busy; }
+
+hipError_t ss_la_record(ba_engine *e, int slot, int round) {
+  ba_engine::SsLa &A = e->ssla;
+  SsRecParams R{};
+  R.C = e->cfg.chains;
+  R.p = e->p;
+  R.nvar = (int32_t)A.nvar;
+  R.nphi = (int32_t)A.nphi;
+  R.nreg = (int32_t)A.reg.size();
+  R.L = A.len;
+  R.row = slot * A.len + round;
+  R.gamma = e->dgamma.ptr;
+  R.beta = e->dbeta.ptr;
+  R.sigsq = e->dsigsq.ptr;
+  if (e->ssm_set) {
+    R.var = e->dssm_sigsq.ptr;
+    R.var_stride = SSG_MAX_VAR;
+    R.phi = e->dar_phi.ptr;
+    R.phi_stride = SSG_MAX_AR * AR_MAX;
+    R.state = e->dssm_work.ptr + (size_t)e->ssg.m * e->T;
+    R.state_stride = ssm_work_stride(*e);
+  } else {
+    R.var = e->ssla.lev_used.ptr;   // (the live value may be the NEXT round's: drawn ahead)
+    R.var_stride = 1;
+    R.phi = nullptr;
+    R.phi_stride = 0;
+    R.state = e->dss_scratch.ptr + (size_t)SS_STATE_ARRAY * ss_pitch(*e);
+    R.state_stride = (int64_t)SS_SCRATCH_ARRAYS * (int64_t)ss_pitch(*e);
+  }
+  R.state_doubles = (int64_t)A.state_doubles;
+  R.reg = A.dreg.ptr;
+  R.rgamma = A.rgamma.ptr;
+  R.rbeta = A.rbeta.ptr;
+  R.rsig = A.rsig.ptr;
+  R.rvar = A.rvar.ptr;
+  R.rphi = A.rphi.ptr;
+  R.rstate = A.rstate.ptr;
+  hipLaunchKernelGGL(ss_record_kernel, dim3((unsigned)(R.C + R.nreg)), dim3(256), 0, e->stream, R);
+  return hipGetLastError();
+}
+
+// the record's and the snapshots' buffers for the current specification
+int ss_la_alloc(ba_engine *e) {
+  ba_engine::SsLa &A = e->ssla;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, L = (size_t)A.len, nreg = A.reg.size();
+  A.nvar = e->ssm_set ? (size_t)e->ssg.nvar : 1;
+  A.nphi = e->ssm_set ? (size_t)e->ssg.nar * AR_MAX : 0;
+  A.state_doubles = e->ssm_set ? (size_t)e->ssg.m * e->T : ss_pitch(*e);
+  HIP_TRY(A.rgamma.resize(2 * C * L * p));
+  HIP_TRY(A.rbeta.resize(2 * C * L * p));
+  HIP_TRY(A.rsig.resize(2 * C * L));
+  HIP_TRY(A.rvar.resize(2 * C * L * A.nvar));
+  HIP_TRY(A.rphi.resize(2 * C * L * std::max<size_t>(A.nphi, 1)));
+  HIP_TRY(A.rstate.resize(2 * nreg * L * A.state_doubles));
+  HIP_TRY(A.dreg.resize(nreg));
+  HIP_TRY(A.lev_used.resize(C));
+  HIP_TRY(hipMemcpy(A.dreg.ptr, A.reg.data(), nreg * 4, hipMemcpyHostToDevice));
+  // snapshot: level (sigsq, n, sumsq) | xty | yty | nobs [| state models: sigsq, n, ss | phi | ar suf]
+  A.snap_doubles = C * (3 + p + 2);
+  A.snap_words = 2 * C;
+  if (e->ssm_set) {
+    A.snap_doubles += C * (3 * SSG_MAX_VAR + SSG_MAX_AR * AR_MAX + SSG_MAX_AR * AR_SUF_STRIDE);
+    A.snap_words += C * SSG_MAX_VAR;
+  }
+  HIP_TRY(A.snap.resize(2 * A.snap_doubles));
+  HIP_TRY(A.snap_pos.resize(2 * A.snap_words));
+  for (int i = 0; i < 2; ++i)
+    if (!A.done[i]) HIP_TRY(hipEventCreateWithFlags(&A.done[i], hipEventDisableTiming));
+  return BA_OK;
+}
+
+// snapshot set `set` <-> the live chain state (both halves: the regression's by la_copy)
+int ss_la_copy(ba_engine *e, bool save, int set) {
+  ba_engine::SsLa &A = e->ssla;
+  int rc = la_copy(e, save, set);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p;
+  hipStream_t s = e->stream;
+  double *d = A.snap.ptr + (size_t)set * A.snap_doubles;
+  uint64_t *w = A.snap_pos.ptr + (size_t)set * A.snap_words;
+#define SS_CP(live, n, T_)                                                                     \
+  do {                                                                                          \
+    const size_t bytes__ = (size_t)(n) * sizeof(T_);                                            \
+    if ((live) && bytes__)                                                                      \
+      HIP_TRY(hipMemcpyAsync(save ? (void *)cur__ : (void *)(live), save ? (const void *)(live) : (const void *)cur__, \
+                             bytes__, hipMemcpyDeviceToDevice, s));                             \
+    cur__ += (n);                                                                               \
+  } while (0)
+  {
+    double *cur__ = d;
+    SS_CP(e->dlev_sigsq.ptr, C, double);
+    SS_CP(e->dlev_n.ptr, C, double);
+    SS_CP(e->dlev_sumsq.ptr, C, double);
+    SS_CP(e->dxty_c.ptr, C * p, double);
+    SS_CP(e->dyty_c.ptr, C, double);
+    SS_CP(e->dnobs_c.ptr, C, double);
+    if (e->ssm_set) {
+      SS_CP(e->dssm_sigsq.ptr, C * SSG_MAX_VAR, double);
+      SS_CP(e->dssm_n.ptr, C * SSG_MAX_VAR, double);
+      SS_CP(e->dssm_ss.ptr, C * SSG_MAX_VAR, double);
+      SS_CP(e->dar_phi.ptr, e->ssg.nar > 0 ? C * SSG_MAX_AR * AR_MAX : 0, double);
+      SS_CP(e->dar_suf.ptr, e->ssg.nar > 0 ? C * SSG_MAX_AR * AR_SUF_STRIDE : 0, double);
+    }
+  }
+  {
+    uint64_t *cur__ = w;
+    SS_CP(e->dpos_level.ptr, C, uint64_t);
+    SS_CP(e->dpos_state.ptr, C, uint64_t);
+    if (e->ssm_set) SS_CP(e->dpos_var.ptr, C * SSG_MAX_VAR, uint64_t);
+  }
+#undef SS_CP
+  return BA_OK;
+}
+
+// enqueue one batch into half `slot`: the snapshot of where it starts, then `len` rounds,
+// each followed by its record
+int ss_la_launch(ba_engine *e, int slot) {
+  ba_engine::SsLa &A = e->ssla;
+  A.busy = true;
+  int rc = ss_la_copy(e, true, slot);
+  if (!rc) rc = ss_sweep_impl(e, A.len, slot);
+  A.busy = false;
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(A.done[slot], e->stream));
+  return BA_OK;
+}
+
+void ss_la_reset(ba_engine *e) {
+  ba_engine::SsLa &A = e->ssla;
+  A.avail = A.served = 0;
+  A.slot = 0;
+  A.ahead = false;
+  A.synced = false;
+  A.cache.clear();
+}
+
+// The chains as the caller has seen them: nothing of the look-ahead left in flight.  The
+// batch being served is restored to its start and replayed up to the draw handed out
+// last (same stream positions, so the same draws).
+int ss_la_settle(ba_engine *e) {
+  ba_engine::SsLa &A = e->ssla;
+  if (A.len <= 1 || A.busy || A.avail == 0) return BA_OK;
+  A.busy = true;
+  struct Unbusy { ba_engine::SsLa &a; ~Unbusy() { a.busy = false; } } unbusy{A};
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->stream2) HIP_TRY(hipStreamSynchronize(e->stream2));
+  const int served = A.served, slot = A.slot;
+  const bool at_end = served >= A.avail && !A.ahead;   // the chains ARE at the draw served last
+  ss_la_reset(e);
+  if (at_end) return check_chain_status(e);
+  int rc = ss_la_copy(e, false, slot);
+  if (rc) return rc;
+  {  // (a chain that stopped in the dropped rounds stopped after the point we return to)
+    const size_t C = (size_t)e->cfg.chains;
+    HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, C * 4, e->stream));
+    HIP_TRY(hipMemsetAsync(e->dtodo.ptr, 0, C * 4, e->stream));
+  }
+  e->table_ok = false;
+  e->model_ok = false;
+  if (served > 0) {
+    rc = ss_sweep_impl(e, served, -1);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return check_chain_status(e);
+}
+
+// the batch being served is complete and every chain went through it; a batch in which
+// a chain stopped (capacity, an error) is run again round by round, with the stops dealt
+// with where they happen -- the same draws
+int ss_la_wait(ba_engine *e) {
+  ba_engine::SsLa &A = e->ssla;
+  if (A.synced) return BA_OK;
+  HIP_TRY(hipEventSynchronize(A.done[A.slot]));
+  const size_t C = (size_t)e->cfg.chains;
+  std::vector<int32_t> st(C);
+  HIP_TRY(hipMemcpy(st.data(), e->dstatus.ptr, C * 4, hipMemcpyDeviceToHost));
+  bool ok = true;
+  for (size_t c = 0; c < C; ++c) ok = ok && st[c] == CHAIN_OK;
+  if (!ok) {
+    A.busy = true;
+    struct Unbusy { ba_engine::SsLa &a; ~Unbusy() { a.busy = false; } } unbusy{A};
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->stream2) HIP_TRY(hipStreamSynchronize(e->stream2));
+    const int slot = A.slot;
+    A.ahead = false;
+    int rc = ss_la_copy(e, false, slot);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(e->dstatus.ptr, 0, C * 4, e->stream));
+    HIP_TRY(hipMemsetAsync(e->dtodo.ptr, 0, C * 4, e->stream));
+    e->table_ok = false;
+    e->model_ok = false;
+    rc = ss_la_copy(e, true, slot);   // (the same starting point, for a later settle)
+    for (int i = 0; i < A.len && !rc; ++i) {
+      rc = ss_sweep_impl(e, 1, -1);
+      if (!rc) HIP_TRY(hipStreamSynchronize(e->stream));
+      if (!rc) rc = check_chain_status(e);   // (escalates, catches the chain up, reports errors)
+      if (!rc) HIP_TRY(ss_la_record(e, slot, i));
+    }
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    A.cache.clear();
+  }
+  A.synced = true;
+  return BA_OK;
+}
+
+// one chain's rows of the batch being served, on the host (one set of copies per batch)
+int ss_la_rows(ba_engine *e, int64_t c, bool want_state, const ba_engine::SsLa::Rows **out) {
+  ba_engine::SsLa &A = e->ssla;
+  int rc = ss_la_wait(e);
+  if (rc) return rc;
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, L = (size_t)A.len;
+  auto it = A.cache.find(c);
+  if (it == A.cache.end()) {
+    ba_engine::SsLa::Rows r;
+    r.gamma.resize(L * p); r.beta.resize(L * p); r.sig.resize(L); r.var.resize(L * A.nvar); r.phi.resize(L * A.nphi);
+    const size_t at = ((size_t)A.slot * C + (size_t)c) * L;
+    HIP_TRY(hipMemcpy(r.gamma.data(), A.rgamma.ptr + at * p, L * p, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.beta.data(), A.rbeta.ptr + at * p, L * p * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.sig.data(), A.rsig.ptr + at, L * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.var.data(), A.rvar.ptr + at * A.nvar, L * A.nvar * 8, hipMemcpyDeviceToHost));
+    if (A.nphi) HIP_TRY(hipMemcpy(r.phi.data(), A.rphi.ptr + at * A.nphi, L * A.nphi * 8, hipMemcpyDeviceToHost));
+    it = A.cache.emplace(c, std::move(r)).first;
+  }
+  if (want_state && !it->second.has_state) {
+    size_t ri = 0;
+    while (ri < A.reg.size() && A.reg[ri] != c) ++ri;
+    if (ri == A.reg.size()) return fail(BA_E_STATE, "the chain's state path is not in the look-ahead's record");
+    it->second.state.resize(L * A.state_doubles);
+    const size_t at = ((size_t)A.slot * A.reg.size() + ri) * L;
+    HIP_TRY(hipMemcpy(it->second.state.data(), A.rstate.ptr + at * A.state_doubles, L * A.state_doubles * 8,
+                      hipMemcpyDeviceToHost));
+    it->second.has_state = true;
+  }
+  *out = &it->second;
+  return BA_OK;
+}
+bool ss_la_registered(const ba_engine *e, int64_t c) {
+  for (int32_t r : e->ssla.reg)
+    if (r == c) return true;
+  return false;
+}
+
 struct ApiScope {
   ba_engine *e;
   explicit ApiScope(ba_engine *en) : e(en) { e->api_seq++; e->api_depth++; }
@@ -1383,6 +1698,7 @@ struct ApiScope {
     (e)->api_seq++;                      \
     int rc_m__ = set_device(e);          \
     if (!rc_m__) rc_m__ = pipe_join(e);  \
+    if (!rc_m__) rc_m__ = ss_la_settle(e); \
     if (!rc_m__) rc_m__ = la_rewind(e);  \
     if (rc_m__) return rc_m__;           \
     (e)->table_ok = false;               \
@@ -1407,9 +1723,18 @@ struct ApiScope {
   ENGINE_PROLOGUE_NOJOIN(e)                                    \
   {                                                            \
     int rc__ = pipe_join(e);                                   \
+    if (!rc__) rc__ = ss_la_settle(e);                         \
     if (rc__) return rc__;                                     \
   }
 #define ENGINE_ACCESSOR(e)                                     \
+  ENGINE_ACCESSOR_NOJOIN(e)                                    \
+  {                                                            \
+    int rc__ = pipe_join(e);                                   \
+    if (!rc__) rc__ = ss_la_settle(e);                         \
+    if (rc__) return rc__;                                     \
+  }
+// (the entry points that serve the draw of ba_ss_draw_next from the device's record)
+#define ENGINE_ACCESSOR_SERVED(e)                              \
   ENGINE_ACCESSOR_NOJOIN(e)                                    \
   {                                                            \
     int rc__ = pipe_join(e);                                   \
@@ -1474,8 +1799,10 @@ void ba_engine_destroy(ba_engine *e) {
     (void)hipStreamSynchronize(e->stream2);
     (void)hipStreamDestroy(e->stream2);
   }
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
     if (e->la_done[i]) (void)hipEventDestroy(e->la_done[i]);
+    if (e->ssla.done[i]) (void)hipEventDestroy(e->ssla.done[i]);
+  }
   if (e->pipe_stream) {
     (void)hipStreamSynchronize(e->pipe_stream);
     (void)hipStreamDestroy(e->pipe_stream);
@@ -1909,6 +2236,16 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
     int rcj = pipe_join(e);
     if (rcj) return rcj;
   }
+  if (ss_la_serving(e)) {   // the draw ba_ss_draw_next is serving
+    const ba_engine::SsLa::Rows *r = nullptr;
+    int rcr = ss_la_rows(e, chain, false, &r);
+    if (rcr) return rcr;
+    const size_t p = (size_t)e->p, row = (size_t)e->ssla.served - 1;
+    if (gamma) std::memcpy(gamma, &r->gamma[row * p], p);
+    if (beta) std::memcpy(beta, &r->beta[row * p], p * 8);
+    if (sigsq) *sigsq = r->sig[row];
+    return BA_OK;
+  }
   int rc = ba_sync(e);
   if (rc) return rc;
   // (one batch through the pinned staging buffer: beta | sigsq | gamma)
@@ -1931,7 +2268,7 @@ int ba_get_state(ba_engine *e, int64_t chain, uint8_t *gamma, double *beta,
 // sigma^2 Omega_g).  Host arithmetic on the chain's state and the host copies of
 // the priors (a k x k Cholesky): it is interface, not hot path.
 int ba_logpri(ba_engine *e, int64_t chain, double *out) {
-  ENGINE_ACCESSOR(e);
+  ENGINE_ACCESSOR_SERVED(e);   // (ba_get_state below sees the draw being served)
   if (!out) return fail(BA_E_INVALID, "null argument");
   if (!e->have_slab || e->pi.empty()) return fail(BA_E_STATE, "priors are not set");
   const size_t p = (size_t)e->p;
@@ -1992,8 +2329,20 @@ int ba_logpri(ba_engine *e, int64_t chain, double *out) {
 }
 
 int ba_get_states(ba_engine *e, uint8_t *gamma, double *beta, double *sigsq) {
-  ENGINE_PROLOGUE(e);
+  ENGINE_ACCESSOR_SERVED(e);
   if (!e->state_ready) return fail(BA_E_STATE, "no chain state yet");
+  if (ss_la_serving(e)) {
+    // the draw being served, every chain: row `served - 1` of every chain's block of the record
+    int rcw = ss_la_wait(e);
+    if (rcw) return rcw;
+    const ba_engine::SsLa &A = e->ssla;
+    const size_t p = (size_t)e->p, C = (size_t)e->cfg.chains, L = (size_t)A.len;
+    const size_t at = (size_t)A.slot * C * L + (size_t)A.served - 1;
+    if (gamma) HIP_TRY(hipMemcpy2D(gamma, p, A.rgamma.ptr + at * p, L * p, p, C, hipMemcpyDeviceToHost));
+    if (beta) HIP_TRY(hipMemcpy2D(beta, p * 8, A.rbeta.ptr + at * p, L * p * 8, p * 8, C, hipMemcpyDeviceToHost));
+    if (sigsq) HIP_TRY(hipMemcpy2D(sigsq, 8, A.rsig.ptr + at, L * 8, 8, C, hipMemcpyDeviceToHost));
+    return BA_OK;
+  }
   if (e->la_served > 0 && e->la_served <= e->la_avail && (e->la_served < e->la_avail || e->la_ahead)) {
     // the draw being served, every chain: from the record (the chains themselves are ahead)
     int rcw = la_wait(e);
@@ -2269,7 +2618,10 @@ int ba_draw_next(ba_engine *e) {
 }
 
 int ba_sync(ba_engine *e) {
-  ENGINE_ACCESSOR(e);
+  ENGINE_ACCESSOR_SERVED(e);
+  // (while ba_ss_draw_next serves a batch the chains run ahead on purpose: what the caller
+  // waits for is the batch being served)
+  if (ss_la_serving(e)) return ss_la_wait(e);
   HIP_TRY(hipStreamSynchronize(e->stream));   // (also the caller's own work on ba_stream())
   if (e->clean_seq == e->api_seq) return BA_OK;   // (no call since the last clean check: the status words are as they were)
   int rc = pipe_check(e);
@@ -3478,17 +3830,33 @@ int ba_ss_add_ar(ba_engine *e, int32_t lags, double prior_df, double sigma_guess
 int ba_ss_get_state_model(ba_engine *e, int64_t chain, int32_t block, double *variances, double *suf_n,
                           double *suf_ss, double *phi, double *ar_xtx, double *ar_xty, double *ar_yty,
                           double *ar_n) {
-  ENGINE_ACCESSOR(e);
+  ENGINE_ACCESSOR_SERVED(e);
   if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
     return fail(BA_E_STATE, "no structural state-space run yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   if (block < 0 || block >= e->ssg.nblocks) return fail(BA_E_INVALID, "state model index out of range");
-  int rc = ba_sync(e);
-  if (rc) return rc;
   const SsgBlock &k = e->ssg.blk[block];
   const bool is_ar = k.kind == SSG_AR;
   if (!is_ar && (phi || ar_xtx || ar_xty || ar_yty || ar_n))
     return fail(BA_E_INVALID, "not an autoregression state model");
+  if (ss_la_serving(e)) {
+    if (!suf_n && !suf_ss && !ar_xtx && !ar_xty && !ar_yty && !ar_n) {
+      // the draw ba_ss_draw_next is serving, from the record
+      const ba_engine::SsLa::Rows *r = nullptr;
+      int rcr = ss_la_rows(e, chain, false, &r);
+      if (rcr) return rcr;
+      const size_t row = (size_t)e->ssla.served - 1;
+      if (variances)
+        for (int v = 0; v < k.nvar; ++v) variances[v] = r->var[row * e->ssla.nvar + k.var0 + v];
+      if (phi)
+        for (int i = 0; i < k.lags; ++i) phi[i] = r->phi[row * e->ssla.nphi + (size_t)k.ar_index * AR_MAX + i];
+      return BA_OK;
+    }
+    int rcs = ss_la_settle(e);   // (sufficient statistics are not in the record)
+    if (rcs) return rcs;
+  }
+  int rc = ba_sync(e);
+  if (rc) return rc;
   HIP_TRY(pinned_reserve(e, (6 + AR_MAX + AR_SUF_STRIDE) * 8));
   double *hv = (double *)e->pinned, *hphi = hv + 6, *hsuf = hphi + AR_MAX;
   const size_t at = (size_t)chain * SSG_MAX_VAR + k.var0;
@@ -3531,11 +3899,23 @@ int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq, double
 
 // one chain's state draw, T x m (step t at [t * m, (t + 1) * m))
 int ba_ss_get_state_draw(ba_engine *e, int64_t chain, double *state) {
-  ENGINE_ACCESSOR(e);
+  ENGINE_ACCESSOR_SERVED(e);
   if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
     return fail(BA_E_STATE, "no structural state-space run yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   if (!state) return fail(BA_E_INVALID, "null argument");
+  if (ss_la_serving(e)) {
+    if (ss_la_registered(e, chain)) {
+      const ba_engine::SsLa::Rows *r = nullptr;
+      int rcr = ss_la_rows(e, chain, true, &r);
+      if (rcr) return rcr;
+      const size_t SD = e->ssla.state_doubles;
+      std::memcpy(state, &r->state[((size_t)e->ssla.served - 1) * SD], SD * 8);
+      return BA_OK;
+    }
+    int rcs = ss_la_settle(e);
+    if (rcs) return rcs;
+  }
   int rc = ba_sync(e);
   if (rc) return rc;
   const size_t T = (size_t)e->T, m = (size_t)e->ssg.m;
@@ -3549,12 +3929,29 @@ int ba_ss_get_state_draw(ba_engine *e, int64_t chain, double *state) {
 
 int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state, double *variances,
                          double *suf_n, double *suf_ss) {
-  ENGINE_ACCESSOR(e);
+  ENGINE_ACCESSOR_SERVED(e);
   if (!e->ss_mode || !e->ssm_set || e->dssm_work.count == 0)
     return fail(BA_E_STATE, "no structural state-space run yet");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   if ((variances || suf_n || suf_ss) && e->ssg_template_var[0] < 0)
     return fail(BA_E_STATE, "the state was not set with ba_ss_set_structural: use ba_ss_get_state_model");
+  if (ss_la_serving(e)) {
+    if (!suf_n && !suf_ss && (!state || ss_la_registered(e, chain))) {
+      const ba_engine::SsLa::Rows *r = nullptr;
+      int rcr = ss_la_rows(e, chain, state != nullptr, &r);
+      if (rcr) return rcr;
+      const size_t row = (size_t)e->ssla.served - 1, SD = e->ssla.state_doubles;
+      if (state) std::memcpy(state, &r->state[row * SD], SD * 8);
+      if (variances)
+        for (int i = 0; i < 3; ++i) {
+          const int vi = e->ssg_template_var[i];
+          variances[i] = vi >= 0 ? r->var[row * e->ssla.nvar + vi] : 0.0;
+        }
+      return BA_OK;
+    }
+    int rcs = ss_la_settle(e);
+    if (rcs) return rcs;
+  }
   if (state) {
     const int rc = ba_ss_get_state_draw(e, chain, state);
     if (rc) return rc;
@@ -3591,8 +3988,11 @@ int ba_ss_impute_state(ba_engine *e) {
   return BA_OK;
 }
 
-int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
-  ENGINE_PROLOGUE(e);
+}  // extern "C"
+namespace {
+// nsweeps x StateSpacePosteriorSampler::draw on every chain; rec_slot >= 0: every round's
+// draw goes to that half of the look-ahead's record
+int ss_sweep_impl(ba_engine *e, int32_t nsweeps, int rec_slot) {
   e->table_ok = false;
   if (nsweeps < 0) return fail(BA_E_INVALID, "nsweeps must be non-negative");
   int rc = ss_prepare(e);
@@ -3658,9 +4058,85 @@ int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
     } else {
       HIP_TRY(launch_state_kernel(e, S, 1));          // state models, state
     }
+    if (rec_slot >= 0) HIP_TRY(ss_la_record(e, rec_slot, i));
     P.model_keep = 1;  // from here on the chains' model blocks are their own last launch's
     e->model_ok = true;
   }
+  return BA_OK;
+}
+
+}  // namespace
+extern "C" {
+
+int ba_ss_sweep(ba_engine *e, int32_t nsweeps) {
+  ENGINE_PROLOGUE(e);   // (unserved look-ahead draws: the rounds asked for here come after the last one served)
+  return ss_sweep_impl(e, nsweeps, -1);
+}
+
+// The callers' loop on the bsts path -- for (i in niter) { model.sample_posterior(); record }
+// (Interfaces/R/bsts/src/bsts.cc:82-119) -- at the device's rate: rounds are enqueued
+// `lookahead` at a time, every round's draw recorded on the device, and ba_ss_draw_next
+// hands them out one per call; the accessors below see the draw being served.
+int ba_ss_set_lookahead(ba_engine *e, int32_t lookahead) {
+  ENGINE_PROLOGUE(e);
+  if (lookahead < 1) return fail(BA_E_INVALID, "lookahead must be at least 1");
+  MUTATE(e);
+  e->ssla.len = lookahead;
+  ss_la_reset(e);
+  return BA_OK;
+}
+
+// the chains whose STATE PATH the look-ahead records (default: chain 0); the other chains'
+// state is read by going back to the draw being served (correct, and slow)
+int ba_ss_lookahead_chains(ba_engine *e, int32_t nchains, const int64_t *chains) {
+  ENGINE_PROLOGUE(e);
+  if (nchains < 0 || (nchains > 0 && !chains)) return fail(BA_E_INVALID, "bad argument");
+  for (int i = 0; i < nchains; ++i)
+    if (chains[i] < 0 || chains[i] >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  MUTATE(e);
+  e->ssla.reg.clear();
+  for (int i = 0; i < nchains; ++i) e->ssla.reg.push_back((int32_t)chains[i]);
+  ss_la_reset(e);
+  return BA_OK;
+}
+
+int ba_ss_draw_next(ba_engine *e) {
+  ENGINE_PROLOGUE_NOJOIN(e);
+  {
+    int rcj = pipe_join(e);
+    if (rcj) return rcj;
+  }
+  ba_engine::SsLa &A = e->ssla;
+  if (A.len <= 1) return ss_sweep_impl(e, 1, -1);
+  if (A.served == A.avail) {
+    if (A.ahead) {
+      // the record is used up: on to the batch that is already running (or done)
+      A.slot ^= 1;
+      A.ahead = false;
+    } else {
+      // ... or from the chains' current state
+      int rc = ss_la_settle(e);
+      if (!rc) rc = la_rewind(e);
+      if (!rc) rc = ss_prepare(e);
+      if (!rc) rc = ss_la_alloc(e);
+      // (the first impute_state of a run, if it is still to come, is not part of a batch:
+      // a batch's snapshot is a point between two rounds)
+      if (!rc) rc = ss_sweep_impl(e, 0, -1);
+      if (rc) return rc;
+      A.slot = 0;
+      rc = ss_la_launch(e, 0);
+      if (rc) return rc;
+    }
+    A.avail = A.len;
+    A.served = 0;
+    A.synced = false;
+    A.cache.clear();
+    // the batch after this one goes out now, into the other half
+    int rc = ss_la_launch(e, A.slot ^ 1);
+    if (rc) return rc;
+    A.ahead = true;
+  }
+  ++A.served;
   return BA_OK;
 }
 
@@ -3689,10 +4165,31 @@ int ba_ss_forecast(ba_engine *e, int32_t horizon, const double *newX, double *ou
 
 int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
                     double *level_sigsq, double *level_n, double *level_sumsq) {
-  ENGINE_ACCESSOR(e);
+  ENGINE_ACCESSOR_SERVED(e);
   if (!e->ss_mode || e->dss_scratch.count == 0) return fail(BA_E_STATE, "no state-space run yet");
   if (e->ssm_set) return fail(BA_E_STATE, "a structural state is set: use ba_ss_get_structural");
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
+  if (ss_la_serving(e)) {
+    if (!level_n && !level_sumsq && (!state || ss_la_registered(e, chain))) {
+      // the draw ba_ss_draw_next is serving, from the record
+      const ba_engine::SsLa::Rows *r = nullptr;
+      int rcr = ss_la_rows(e, chain, state != nullptr, &r);
+      if (rcr) return rcr;
+      const size_t row = (size_t)e->ssla.served - 1, T = (size_t)e->T, SD = e->ssla.state_doubles;
+      if (level_sigsq) *level_sigsq = r->var[row];
+      if (state) {
+        const double *src = &r->state[row * SD];
+        if (ss_lane_major(*e)) {
+          for (size_t t = 0; t < T; ++t) state[t] = src[(size_t)lm_at((int)t)];
+        } else {
+          std::memcpy(state, src, T * 8);
+        }
+      }
+      return BA_OK;
+    }
+    int rcs = ss_la_settle(e);   // (not in the record: the chains go back to the draw being served)
+    if (rcs) return rcs;
+  }
   int rc = ba_sync(e);
   if (rc) return rc;
   // (one batch through the pinned staging buffer: state | level variance | n | sum of squares)

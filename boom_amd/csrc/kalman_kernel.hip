@@ -267,6 +267,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
     if (lane == 0 && wave == 0) P.status[chain] = status;
     return;
   }
+  if (P.level_used && lane == 0 && wave == 0) P.level_used[chain] = level_sigsq;
 
   // ---- impute_state ------------------------------------------------------
   const double sigsq_obs = P.sigsq[chain];
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
     if (tid == 0) P.status[chain] = status;
     return;
   }
+  if (P.level_used && tid == 0) P.level_used[chain] = level_sigsq;
   const double *beta = P.beta + (size_t)chain * p;
   double *base = P.scratch + (size_t)chain * P.scratch_stride;
   double *sF = base + (size_t)P.TP;                         // residuals (input of the X'e GEMM)

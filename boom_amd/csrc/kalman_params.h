@@ -111,6 +111,9 @@ struct SsParams {
   uint64_t *prep_pos_state;    // 2 x chains: stream positions / level variance before the prepare step
   uint64_t *prep_pos_level;
   double *prep_level_sigsq;
+  // the level variance THIS state draw used (the live value may already be the next round's:
+  // the prepare step draws ahead); nullptr: not wanted.  Read by the look-ahead's record.
+  double *level_used;
   SsmParams ssm;            // (ssm_kernel.hip only)
 };
 

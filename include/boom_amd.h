@@ -498,6 +498,23 @@ int ba_ss_get_ar(ba_engine *e, int64_t chain, double *phi, double *sigsq,
  * sufficient statistics (n, sum of squares) of the last sweep; any pointer may be NULL */
 int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state,
                          double *variances, double *suf_n, double *suf_ss);
+/* The callers' loop on the bsts path -- for (i in niter) { model->sample_posterior();
+ * record the draw } (Interfaces/R/bsts/src/bsts.cc:82-119) -- at the device's rate.
+ * ba_ss_set_lookahead(e, L), L > 1: ba_ss_draw_next enqueues the sweep rounds L at a
+ * time (the batch after the one being served goes out as soon as serving starts), every
+ * round's draw is recorded on the device and handed out one per call: ba_get_state,
+ * ba_get_states, ba_logpri, ba_ss_get_state, ba_ss_get_structural, ba_ss_get_state_model,
+ * ba_ss_get_state_draw and ba_ss_get_ar see the draw being served -- gamma, beta, sigma^2
+ * and the state models' variances / coefficients of EVERY chain, the state path of the
+ * chains named with ba_ss_lookahead_chains (default: chain 0).  Anything else -- a
+ * mutator, ba_ss_sweep, a sufficient statistic, the state path of another chain, a
+ * forecast -- first puts the chains back where the caller has seen them (the snapshot
+ * taken at the batch's start, replayed up to the draw being served: same stream
+ * positions, same draws), so the look-ahead is unobservable.  L = 1 (default): one
+ * round per call.  ba_sync while a batch is being served waits for THAT batch. */
+int ba_ss_set_lookahead(ba_engine *e, int32_t lookahead);
+int ba_ss_lookahead_chains(ba_engine *e, int32_t nchains, const int64_t *chains);
+int ba_ss_draw_next(ba_engine *e);
 /* nsweeps x StateSpacePosteriorSampler::draw()
  * (StateSpacePosteriorSampler.cpp:42-64) on every chain */
 int ba_ss_sweep(ba_engine *e, int32_t nsweeps);

@@ -234,6 +234,78 @@ def test_boom_state_space_model_driven_by_the_device_sampler(oracle, trend, nsea
 
 @pytest.mark.skipif(not os.path.exists(BINDING_SO),
                     reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
+@pytest.mark.parametrize("desc,T,missing,lookahead", [
+    ([("seasonal", 7, 1)], 120, 0.0, 8),                                   # no trend block
+    ([("trend",), ("seasonal", 7, 1), ("seasonal", 4, 7)], 200, 0.03, 8),  # weekly + a 4 x 7 cycle
+    ([("seasonal", 4, 3, 2), ("level",), ("ar", 2)], 150, 0.0, 1),         # any order, a first-observation offset
+    ([("trend",), ("seasonal", 52, 7)], 400, 0.0, 4),                      # m = 53
+])
+def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler(oracle, desc, T, missing,
+                                                                                 lookahead):
+    """f2, the general form, at the boundary: BOOM's own StateSpaceRegressionModel with
+    WHATEVER add_state gave it (Models/StateSpace/StateSpaceModelBase.hpp:637-638) --
+    seasonal models with season_duration > 1 and a time_of_first_observation, two seasonal
+    blocks, a model without a trend block, state dimension 53 -- stepped by
+    model->sample_posterior() with bindings/boom/DeviceStateSpacePosteriorSampler as its
+    sampling method, the draws served from the engine's look-ahead (batches of `lookahead`
+    rounds enqueued ahead).  What the BOOM objects hold after every draw is the oracle's
+    chain 0 on the same Philox key."""
+    from cases import bsts_priors, general_arrays, general_data, general_spec
+    L = C.CDLL(BINDING_SO)
+    L.ref_binding_last_error.restype = C.c_char_p
+    p, chains, nsw, seed = 6, 5, 13, 777
+    seas = [(b[1], b[2]) for b in desc if b[0] == "seasonal"]
+    X, y, _, obs = general_data(T, p, 2, seas[:2], seed=31 + T, missing_frac=missing,
+                                ar_coef=[0.5] if any(b[0] == "ar" for b in desc) else None,
+                                level=any(b[0] in ("level", "trend") for b in desc))
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    blocks = general_spec(y, desc)
+    kinds, ip, vpar, phi0, a0, P0 = general_arrays(blocks)
+    nb, m = len(blocks), len(a0)
+    opts = ssvs_options(sigma_upper_limit=sig_up)
+    g0 = np.zeros(p, np.uint8)
+    gam = np.zeros((nsw, p), np.uint8)
+    beta = np.zeros((nsw, p))
+    sig = np.zeros(nsw)
+    var = np.zeros((nsw, nb, 2))
+    phi = np.zeros((nsw, nb, 16))
+    state = np.zeros((nsw, T, m))
+    logpri = np.zeros(nsw)
+    dev_seed = C.c_uint64()
+    pg = np.zeros(p, np.uint8)
+    pstate = np.zeros((T, m))
+    obs8 = None if obs is None else np.ascontiguousarray(obs, np.uint8)
+    ipc = np.ascontiguousarray(ip, np.int32)
+    rc = L.ref_binding_ssg_run(
+        T, p, _dp(f64(y)), _dp(fcol(X)), _u8(obs8), _dp(f64(prior["b"])), _dp(fcol(prior["ominv"])),
+        C.c_double(prior["df"]), C.c_double(prior["sigma_guess"]), _dp(f64(prior["pi"])),
+        C.c_double(sig_up), nb, kinds.ctypes.data_as(C.POINTER(C.c_int)),
+        ipc.ctypes.data_as(C.POINTER(C.c_int)), _dp(f64(vpar)), _dp(f64(phi0)), _dp(f64(a0)), _dp(f64(P0)),
+        chains, C.c_uint64(seed), _u8(g0), nsw, lookahead, _u8(gam), _dp(beta), _dp(sig), _dp(var), _dp(phi),
+        _dp(state), _dp(logpri), C.byref(dev_seed), chains - 1, _u8(pg), _dp(pstate))
+    assert rc == 0, L.ref_binding_last_error().decode()
+
+    def run(c):
+        return oracle.ssg_run(y, X, obs, prior, opts, blocks, ("philox", dev_seed.value, c), g0, nsw)
+    o = run(0)
+    assert o["status"] == 0
+    for s in range(nsw):
+        assert np.array_equal(gam[s], o["gamma"][s]), s
+        err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
+        assert err < 1e-8, (s, err)
+        assert abs(sig[s] - o["sigsq"][s]) < 1e-8 * sig[s], s
+        assert np.max(np.abs(var[s] - o["variances"][s]) / np.maximum(o["variances"][s], 1e-300)) < 1e-8, s
+        assert np.max(np.abs(phi[s] - o["phi"][s])) < 1e-8, s
+        scale = np.abs(o["state"][s]).max()
+        assert np.max(np.abs(state[s] - o["state"][s])) < 1e-8 * scale, s
+    assert np.all(np.isfinite(logpri))
+    ol = run(chains - 1)
+    assert np.array_equal(pg, ol["gamma"][-1])
+    assert np.max(np.abs(pstate - ol["state"][-1])) < 1e-8 * np.abs(ol["state"][-1]).max()
+
+
+@pytest.mark.skipif(not os.path.exists(BINDING_SO),
+                    reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
 @pytest.mark.parametrize("trend,nseasons,T,coef", [(1, 0, 200, [0.8]), (2, 4, 160, [1.2, -0.4])])
 def test_boom_state_space_model_with_ar_state_driven_by_the_device_sampler(oracle, trend, nseasons, T,
                                                                           coef):

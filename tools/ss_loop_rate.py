@@ -33,4 +33,31 @@ dt2 = (time.perf_counter() - t0) / n
 t0 = time.perf_counter()
 eng.ss_sweep(n); eng.sync()
 dt3 = (time.perf_counter() - t0) / n
+eng.ss_set_lookahead(64)
+for _ in range(64):
+    eng.ss_draw_next()
+t0 = time.perf_counter()
+for _ in range(n):
+    eng.ss_draw_next()
+    g, b, s2 = eng.get_state(0)
+    st = eng.ss_get_state(0, suf=False)
+dt4 = (time.perf_counter() - t0) / n
+print("look-ahead 64: draw_next + chain 0's draw pulled %.1f us per draw" % (dt4 * 1e6))
 print("per draw: sweep(1)+sync %.1f us, + chain 0's draw pulled %.1f us, inside one call %.1f us" % (dt1 * 1e6, dt2 * 1e6, dt3 * 1e6))
+for L in (64, 256):
+    eng.ss_set_lookahead(L)
+    for _ in range(L):
+        eng.ss_draw_next()
+    m = 4 * L
+    t0 = time.perf_counter()
+    for _ in range(m):
+        eng.ss_draw_next()
+    eng.get_state(0)
+    dt5 = (time.perf_counter() - t0) / m
+    t0 = time.perf_counter()
+    for _ in range(m):
+        eng.ss_draw_next()
+        g, b, s2 = eng.get_state(0)
+        st = eng.ss_get_state(0, suf=False)
+    dt6 = (time.perf_counter() - t0) / m
+    print("look-ahead %d: draw_next only %.1f us per draw; with chain 0 pulled %.1f us" % (L, dt5 * 1e6, dt6 * 1e6))
