@@ -328,6 +328,9 @@ PYBIND11_MODULE(_boom, boom) {
   py::class_<SeasonalStateModel, Ptr<SeasonalStateModel>>(boom, "SeasonalStateModel")
       .def(py::init<int, int>(), py::arg("nseasons"), py::arg("season_duration") = 1)
       .def_property_readonly("state_dimension", &SeasonalStateModel::state_dimension)
+      .def_property_readonly("nseasons", &SeasonalStateModel::nseasons)
+      .def_property_readonly("season_duration", &SeasonalStateModel::season_duration)
+      .def("set_time_of_first_observation", &SeasonalStateModel::set_time_of_first_observation)
       .def("set_sigsq", &SeasonalStateModel::set_sigsq)
       .def("set_initial_state_mean", [](SeasonalStateModel &m, const NpArray &v) { m.set_initial_state_mean(vector_from(v)); })
       .def("set_initial_state_variance", &SeasonalStateModel::set_initial_state_variance)
@@ -362,9 +365,11 @@ PYBIND11_MODULE(_boom, boom) {
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<LocalLinearTrendStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<SeasonalStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<ArStateModel> &s) { m.add_state(s); })
-      .def("ar_phi", [](const StateSpaceRegressionModel &m, int chain) { return to_numpy(m.ar_phi(chain)); },
-           py::arg("chain") = 0, "the autoregression coefficients in one chain's current draw")
-      .def("ar_sigsq", &StateSpaceRegressionModel::ar_sigsq, py::arg("chain") = 0)
+      .def_property_readonly("number_of_state_models", &StateSpaceRegressionModel::number_of_state_models)
+      .def("ar_phi", [](const StateSpaceRegressionModel &m, int chain, int which) { return to_numpy(m.ar_phi(chain, which)); },
+           py::arg("chain") = 0, py::arg("which") = 0,
+           "the coefficients of the which-th ArStateModel in one chain's current draw")
+      .def("ar_sigsq", &StateSpaceRegressionModel::ar_sigsq, py::arg("chain") = 0, py::arg("which") = 0)
       .def("set_method", [](StateSpaceRegressionModel &m, const Ptr<PosteriorSampler> &s) { m.set_method(s); })
       .def("sample_posterior", &StateSpaceRegressionModel::sample_posterior)
       .def("state", [](const StateSpaceRegressionModel &m, int chain) {
@@ -379,7 +384,7 @@ PYBIND11_MODULE(_boom, boom) {
       .def("state_variances", [](const StateSpaceRegressionModel &m, int chain) {
         if (!m.structural()) { Vector v(1, m.level_sigsq(chain)); return to_numpy(v); }
         return to_numpy(m.state_variances(chain));
-      }, py::arg("chain") = 0)
+      }, py::arg("chain") = 0, "every variance parameter in state-model order (a local linear trend has two)")
       .def("chain_states", [](const StateSpaceRegressionModel &m) {
         const py::ssize_t C = m.engine()->chains(), p = m.xdim();
         py::array_t<uint8_t> G({C, p});
@@ -397,5 +402,59 @@ PYBIND11_MODULE(_boom, boom) {
            }),
            py::arg("model"), py::arg("slab"), py::arg("residual_precision_prior"), py::arg("spike"),
            py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
-           py::arg("seeding_rng") = py::none(), py::keep_alive<1, 2>());
+           py::arg("seeding_rng") = py::none(), py::keep_alive<1, 2>())
+      .def("set_lookahead", &StateSpacePosteriorSampler::set_lookahead,
+           "enqueue n sweep rounds at a time and hand them out one sample_posterior() at a time (default 64)");
+
+  // ---- Poisson regression spike and slab (GlmModel_def.cpp: PoissonRegressionModel,
+  // PoissonRegressionSpikeSlabSampler) ---------------------------------------------------
+  py::class_<PoissonRegressionModel, Ptr<PoissonRegressionModel>>(boom, "PoissonRegressionModel")
+      .def(py::init([](const NpArray &X, const NpArray &y, const NpArray &exposure, int chains, uint64_t seed,
+                       int device) {
+             return new PoissonRegressionModel(matrix_from(X), vector_from(y), vector_from(exposure), chains, seed,
+                                               device);
+           }),
+           py::arg("predictors"), py::arg("response"), py::arg("exposure"), py::arg("chains") = 1,
+           py::arg("seed") = 8675309ull, py::arg("device") = 0)
+      .def_property_readonly("xdim", &PoissonRegressionModel::xdim)
+      .def("set_mixture_table", [](PoissonRegressionModel &m, const std::vector<int64_t> &counts,
+                                   const std::vector<int32_t> &ncomp, const NpArray &mu, const NpArray &sigma,
+                                   const NpArray &weight, int64_t largest_index) {
+             NormalMixtureTable t;
+             t.counts = counts; t.ncomp = ncomp;
+             t.mu = vector_from(mu); t.sigma = vector_from(sigma); t.weight = vector_from(weight);
+             t.largest_index = largest_index;
+             m.set_mixture_table(t);
+           },
+           py::arg("counts"), py::arg("ncomp"), py::arg("mu"), py::arg("sigma"), py::arg("weight"),
+           py::arg("largest_index"),
+           "the reference's normal mixtures for the negative log-gamma densities (its data)")
+      .def("drop_all", &PoissonRegressionModel::drop_all)
+      .def("add", &PoissonRegressionModel::add)
+      .def("drop", &PoissonRegressionModel::drop)
+      .def_property_readonly("inc", [](const PoissonRegressionModel &m) {
+        std::vector<bool> g(m.xdim());
+        for (int j = 0; j < m.xdim(); ++j) g[j] = m.inc()[j];
+        return g;
+      })
+      .def_property_readonly("Beta", [](const PoissonRegressionModel &m) { return to_numpy(m.Beta()); })
+      .def("set_Beta", [](PoissonRegressionModel &m, const NpArray &b) { m.set_Beta(vector_from(b)); })
+      .def("set_method", [](PoissonRegressionModel &m, const Ptr<PosteriorSampler> &s) { m.set_method(s); })
+      .def("sample_posterior", &PoissonRegressionModel::sample_posterior)
+      .def("chain_states", [](const PoissonRegressionModel &m) {
+        const py::ssize_t C = m.engine()->chains(), p = m.xdim();
+        py::array_t<uint8_t> G({C, p});
+        py::array_t<double> B({C, p});
+        m.engine()->check(ba_get_states(m.engine()->get(), G.mutable_data(), B.mutable_data(), nullptr));
+        return py::make_tuple(G, B);
+      }, "inclusion indicators and coefficients of EVERY chain");
+  py::class_<PoissonRegressionSpikeSlabSampler, PosteriorSampler, Ptr<PoissonRegressionSpikeSlabSampler>>(
+      boom, "PoissonRegressionSpikeSlabSampler")
+      .def(py::init([](PoissonRegressionModel *model, const Ptr<MvnModel> &slab,
+                       const Ptr<VariableSelectionPrior> &spike, int, py::object) {
+             return new PoissonRegressionSpikeSlabSampler(model, slab, spike);
+           }),
+           py::arg("model"), py::arg("slab"), py::arg("spike"), py::arg("number_of_threads") = 1,
+           py::arg("seeding_rng") = py::none(), py::keep_alive<1, 2>())
+      .def("limit_model_selection", &PoissonRegressionSpikeSlabSampler::limit_model_selection);
 }

@@ -368,29 +368,35 @@ class LocalLinearTrendStateModel {
   Vector a0_ = Vector(2, 0.0), P0_ = Vector(2, 1.0);
   double sigma_[2] = {1.0, 1.0}, df_[2] = {1.0, 1.0}, guess_[2] = {1.0, 1.0}, upper_[2] = {infinity(), infinity()};
 };
-// SeasonalStateModel(nseasons, season_duration = 1) with a ZeroMeanGaussianConjSampler
+// SeasonalStateModel(nseasons, season_duration) with a ZeroMeanGaussianConjSampler: the
+// transition is the seasonal matrix on the steps INTO a new season and the identity
+// inside one (StateModels/SeasonalStateModel.cpp:89-104, :248-258)
 class SeasonalStateModel {
  public:
-  explicit SeasonalStateModel(int nseasons, int season_duration = 1) : nseasons_(nseasons) {
+  explicit SeasonalStateModel(int nseasons, int season_duration = 1)
+      : nseasons_(nseasons), duration_(season_duration) {
     if (nseasons <= 0) report_error("'nseasons' must be positive in constructor for SeasonalStateModelBase");
-    if (season_duration != 1) report_error("season durations other than 1 are not implemented on the device");
+    if (season_duration < 1) report_error("season_duration must be positive");
     a0_ = Vector(nseasons - 1, 0.0);
     P0_ = Vector(nseasons - 1, 1.0);
   }
   int state_dimension() const { return nseasons_ - 1; }
+  int nseasons() const { return nseasons_; }
+  int season_duration() const { return duration_; }
+  void set_time_of_first_observation(int t0) { t0_ = t0; }
   void set_sigsq(double s) { sigma_ = std::sqrt(s); }
   void set_initial_state_mean(const Vector &m) { a0_ = m; }
   void set_initial_state_variance(double v) { P0_ = Vector(nseasons_ - 1, v); }
   void set_prior(double df, double sigma_guess, double sigma_upper_limit = infinity()) {
     df_ = df; guess_ = sigma_guess; upper_ = sigma_upper_limit;
   }
-  int nseasons_;
+  int nseasons_, duration_, t0_ = 0;
   Vector a0_, P0_;
   double sigma_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
 };
 
 // ArStateModel(number_of_lags) with an ArPosteriorSampler (StateModels/ArStateModel.hpp:53,
-// TimeSeries/PosteriorSamplers/ArPosteriorSampler.hpp): added after the trend / seasonal models
+// TimeSeries/PosteriorSamplers/ArPosteriorSampler.hpp)
 class ArStateModel {
  public:
   explicit ArStateModel(int number_of_lags) : lags_(number_of_lags) {
@@ -425,76 +431,90 @@ class StateSpaceRegressionModel : public Model {
     if (!observed.empty()) { obs.resize(T_); for (int t = 0; t < T_; ++t) obs[t] = observed[t]; }
     eng_->check(ba_ss_set_data(eng_->get(), T_, p_, y.data(), X.data(), obs.empty() ? nullptr : obs.data()));
   }
-  void add_state(const Ptr<LocalLevelStateModel> &s) {
-    level_ = s;
-    eng_->check(ba_ss_set_local_level(eng_->get(), s->df_, s->guess_, s->upper_, s->a0_, s->P0_, s->sigma_));
-  }
-  // trend + seasonal state: add_state in the reference's order (trend first);
-  // the structure goes to the device when the sampler is attached or at the
-  // first draw (finalize_state)
-  void add_state(const Ptr<LocalLinearTrendStateModel> &s) { trend_ = s; structural_ = true; }
-  void add_state(const Ptr<SeasonalStateModel> &s) { seasonal_ = s; structural_ = true; }
-  void add_state(const Ptr<ArStateModel> &s) { ar_ = s; structural_ = true; }
-  bool structural() const { return structural_; }
+  // add_state, in any order and number (StateSpaceModelBase.hpp:637-638): the list goes to
+  // the device when the sampler is attached or at the first draw (finalize_state)
+  void add_state(const Ptr<LocalLevelStateModel> &s) { models_.push_back(Entry{1, s, nullptr, nullptr, nullptr}); finalized_ = false; }
+  void add_state(const Ptr<LocalLinearTrendStateModel> &s) { models_.push_back(Entry{2, nullptr, s, nullptr, nullptr}); finalized_ = false; }
+  void add_state(const Ptr<SeasonalStateModel> &s) { models_.push_back(Entry{3, nullptr, nullptr, s, nullptr}); finalized_ = false; }
+  void add_state(const Ptr<ArStateModel> &s) { models_.push_back(Entry{4, nullptr, nullptr, nullptr, s}); finalized_ = false; }
+  int number_of_state_models() const { return (int)models_.size(); }
+  // anything but a lone local level (which runs the local-level kernels)
+  bool structural() const { return !(models_.size() == 1 && models_[0].kind == 1); }
   int state_dimension() const {
-    return (trend_ ? 2 : 1) + (seasonal_ ? seasonal_->state_dimension() : 0) + (ar_ ? ar_->lags_ : 0);
+    int m = 0;
+    for (const Entry &e : models_)
+      m += e.kind == 1 ? 1 : e.kind == 2 ? 2 : e.kind == 3 ? e.seasonal->state_dimension() : e.ar->lags_;
+    return m;
   }
   void finalize_state() {
-    if (!structural_ || finalized_) return;
-    if (!trend_ && !level_) report_error("a structural model needs a trend state model (local level or local linear trend) first");
-    const int tr = trend_ ? 2 : 1, ns = seasonal_ ? seasonal_->nseasons_ : 0,
-              m = state_dimension() - (ar_ ? ar_->lags_ : 0);
-    double df[3] = {1, 1, 1}, guess[3] = {1, 1, 1}, upper[3] = {infinity(), infinity(), infinity()}, init[3] = {1, 1, 1};
-    Vector a0(m, 0.0), P0(m, 1.0);
-    if (trend_) {
-      for (int i = 0; i < 2; ++i) {
-        df[i] = trend_->df_[i]; guess[i] = trend_->guess_[i]; upper[i] = trend_->upper_[i]; init[i] = trend_->sigma_[i];
-        a0[i] = trend_->a0_[i]; P0[i] = trend_->P0_[i];
-      }
+    if (finalized_) return;
+    if (models_.empty()) report_error("No state has been defined.");
+    ba_engine *h = eng_->get();
+    if (!structural()) {
+      const LocalLevelStateModel &s = *models_[0].level;
+      eng_->check(ba_ss_set_local_level(h, s.df_, s.guess_, s.upper_, s.a0_, s.P0_, s.sigma_));
     } else {
-      df[0] = level_->df_; guess[0] = level_->guess_; upper[0] = level_->upper_; init[0] = level_->sigma_;
-      a0[0] = level_->a0_; P0[0] = level_->P0_;
+      eng_->check(ba_ss_clear_state_models(h));
+      for (const Entry &e : models_) {
+        if (e.kind == 1) {
+          const LocalLevelStateModel &s = *e.level;
+          eng_->check(ba_ss_add_state_model(h, 1, nullptr, &s.df_, &s.guess_, &s.upper_, &s.sigma_, nullptr, &s.a0_, &s.P0_));
+        } else if (e.kind == 2) {
+          const LocalLinearTrendStateModel &s = *e.trend;
+          eng_->check(ba_ss_add_state_model(h, 2, nullptr, s.df_, s.guess_, s.upper_, s.sigma_, nullptr, s.a0_.data(), s.P0_.data()));
+        } else if (e.kind == 3) {
+          const SeasonalStateModel &s = *e.seasonal;
+          const int32_t ip[3] = {s.nseasons_, s.duration_, s.t0_};
+          eng_->check(ba_ss_add_state_model(h, 3, ip, &s.df_, &s.guess_, &s.upper_, &s.sigma_, nullptr, s.a0_.data(), s.P0_.data()));
+        } else {
+          const ArStateModel &s = *e.ar;
+          const int32_t ip[3] = {s.lags_, 0, 0};
+          eng_->check(ba_ss_add_state_model(h, 4, ip, &s.df_, &s.guess_, &s.upper_, &s.sigma_, s.phi_.data(), s.a0_.data(), s.P0_.data()));
+        }
+      }
     }
-    if (seasonal_) {
-      df[2] = seasonal_->df_; guess[2] = seasonal_->guess_; upper[2] = seasonal_->upper_; init[2] = seasonal_->sigma_;
-      for (int i = 0; i < ns - 1; ++i) { a0[tr + i] = seasonal_->a0_[i]; P0[tr + i] = seasonal_->P0_[i]; }
-    }
-    eng_->check(ba_ss_set_structural(eng_->get(), tr, ns, df, guess, upper, init, a0.data(), P0.data()));
-    if (ar_)
-      eng_->check(ba_ss_add_ar(eng_->get(), ar_->lags_, ar_->df_, ar_->guess_, ar_->upper_, ar_->sigma_,
-                               ar_->phi_.data(), ar_->a0_.data(), ar_->P0_.data()));
     finalized_ = true;
   }
-  // the autoregression's coefficients and error variance in one chain's current draw
-  Vector ar_phi(int chain = 0) const {
-    Vector v(ar_ ? ar_->lags_ : 0);
-    double s2;
-    eng_->check(ba_ss_get_ar(eng_->get(), chain, v.data(), &s2, nullptr, nullptr, nullptr, nullptr));
+  // the coefficients and error variance of the `which`-th ArStateModel in one chain's current draw
+  Vector ar_phi(int chain = 0, int which = 0) const {
+    const int b = ar_block(which);
+    Vector v(models_[b].ar->lags_);
+    eng_->check(ba_ss_get_state_model(eng_->get(), chain, b, nullptr, nullptr, nullptr, v.data(), nullptr, nullptr, nullptr, nullptr));
     return v;
   }
-  double ar_sigsq(int chain = 0) const {
+  double ar_sigsq(int chain = 0, int which = 0) const {
     double s2;
-    eng_->check(ba_ss_get_ar(eng_->get(), chain, nullptr, &s2, nullptr, nullptr, nullptr, nullptr));
+    eng_->check(ba_ss_get_state_model(eng_->get(), chain, ar_block(which), &s2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
     return s2;
   }
-  // the state draw, component `which` (0 = level / trend level, ...) of one chain
+  // one chain's state draw: state_dimension x time_dimension, the models' components in
+  // the order the models were added
   Matrix structural_state(int chain = 0) const {
     const int m = state_dimension();
     Vector buf((size_t)T_ * m);
-    eng_->check(ba_ss_get_structural(eng_->get(), chain, buf.data(), nullptr, nullptr, nullptr));
+    eng_->check(ba_ss_get_state_draw(eng_->get(), chain, buf.data()));
     Matrix st(m, T_);
     for (int t = 0; t < T_; ++t) for (int i = 0; i < m; ++i) st(i, t) = buf[(size_t)t * m + i];
     return st;
   }
-  Vector state_variances(int chain = 0) const {   // level, slope, seasonal
-    Vector v(3);
-    eng_->check(ba_ss_get_structural(eng_->get(), chain, nullptr, v.data(), nullptr, nullptr));
-    return v;
+  // every variance parameter in state-model order (a local linear trend has two: level,
+  // slope; an autoregression's is its error variance)
+  Vector state_variances(int chain = 0) const {
+    std::vector<double> out;
+    for (size_t b = 0; b < models_.size(); ++b) {
+      double v[2] = {0, 0};
+      eng_->check(ba_ss_get_state_model(eng_->get(), chain, (int32_t)b, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+      out.push_back(v[0]);
+      if (models_[b].kind == 2) out.push_back(v[1]);
+    }
+    Vector ans(out.size());
+    for (size_t i = 0; i < out.size(); ++i) ans[i] = out[i];
+    return ans;
   }
   int time_dimension() const { return T_; }
   int xdim() const { return p_; }
   const Ptr<Engine> &engine() const { return eng_; }
-  const LocalLevelStateModel *level() const { return structural_ ? nullptr : level_.get(); }
+  const LocalLevelStateModel *level() const { return structural() ? nullptr : models_[0].level.get(); }
   Vector state(int chain = 0) const {
     Vector st(T_);
     eng_->check(ba_ss_get_state(eng_->get(), chain, st.data(), nullptr, nullptr, nullptr));
@@ -506,13 +526,24 @@ class StateSpaceRegressionModel : public Model {
     return v;
   }
  private:
+  struct Entry {
+    int kind;   // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression
+    Ptr<LocalLevelStateModel> level;
+    Ptr<LocalLinearTrendStateModel> trend;
+    Ptr<SeasonalStateModel> seasonal;
+    Ptr<ArStateModel> ar;
+  };
+  int ar_block(int which) const {
+    int seen = 0;
+    for (size_t b = 0; b < models_.size(); ++b)
+      if (models_[b].kind == 4 && seen++ == which) return (int)b;
+    report_error("The model has no such ArStateModel.");
+    return -1;
+  }
   Ptr<Engine> eng_;
   int T_, p_;
-  Ptr<LocalLevelStateModel> level_;
-  Ptr<LocalLinearTrendStateModel> trend_;
-  Ptr<SeasonalStateModel> seasonal_;
-  Ptr<ArStateModel> ar_;
-  bool structural_ = false, finalized_ = false;
+  std::vector<Entry> models_;
+  bool finalized_ = false;
 };
 
 // regression priors are set through the same three pieces as BregVsSampler
@@ -529,11 +560,14 @@ class StateSpacePosteriorSampler : public PosteriorSampler {
     model->engine()->check(ba_set_sigma_prior(h, residual_precision_prior->df(), residual_precision_prior->sigma(), sigma_upper_limit));
     std::vector<uint8_t> g0(model->xdim(), 0);
     model->engine()->check(ba_set_state(h, -1, g0.data(), nullptr, 1.0));
+    // the callers' per-iteration loop at the device's rate (ba_ss_draw_next serves the
+    // rounds from batches enqueued ahead; nothing a caller does can observe it)
+    model->engine()->check(ba_ss_set_lookahead(h, 64));
   }
+  void set_lookahead(int rounds) { model_->engine()->check(ba_ss_set_lookahead(model_->engine()->get(), rounds)); }
   void draw() override {                     // StateSpacePosteriorSampler.cpp:42-64
     model_->finalize_state();
-    model_->engine()->check(ba_ss_sweep(model_->engine()->get(), 1));
-    model_->engine()->check(ba_sync(model_->engine()->get()));
+    model_->engine()->check(ba_ss_draw_next(model_->engine()->get()));
   }
   // StateSpacePosteriorSampler::logpri (StateSpacePosteriorSampler.cpp:66-74) sums
   // the observation model's and the state models' log priors; the regression
@@ -665,6 +699,93 @@ class BinomialProbitSpikeSlabSampler : public BinomialSpikeSlabSamplerBase {
   BinomialProbitSpikeSlabSampler(BinomialProbitModel *model, const Ptr<MvnModel> &slab,
                                  const Ptr<VariableSelectionPrior> &spike)
       : BinomialSpikeSlabSamplerBase(model, slab, spike) {}
+};
+
+
+// ---- Poisson regression spike and slab ---------------------------------------------------
+// PoissonRegressionModel + PoissonRegressionSpikeSlabSampler (Models/Glm/
+// PoissonRegressionModel.hpp, PosteriorSamplers/PoissonRegressionSpikeSlabSampler.cpp:55-108;
+// the data augmentation of PoissonDataImputer.cpp:36-96).  The normal mixtures that
+// approximate the negative log-gamma densities are DATA of the reference
+// (create_poisson_mixture_approximation_table, NormalMixtureApproximationTable): the caller
+// hands them over, as a BOOM-side binding reads them from BOOM's own table
+// (bindings/boom/DevicePoissonRegressionSpikeSlabSampler.cpp).
+struct NormalMixtureTable {
+  std::vector<int64_t> counts;     // ascending; 1 and every positive count of the data below largest_index
+  std::vector<int32_t> ncomp;      // components of each count's mixture (<= 32)
+  Vector mu, sigma, weight;        // the mixtures one after the other
+  int64_t largest_index = 0;       // from here on the Gaussian limit is used
+};
+class PoissonRegressionModel : public Model {
+ public:
+  PoissonRegressionModel(const Matrix &X, const Vector &y, const Vector &exposure, int chains = 1,
+                         uint64_t seed = 8675309, int device = 0)
+      : eng_(new Engine(chains, seed, device)), p_(X.ncol()), inc_(X.ncol(), true), beta_(X.ncol(), 0.0) {
+    if (X.nrow() != (int)y.size() || y.size() != exposure.size())
+      report_error("X, y and exposure are incompatible in the Poisson regression model's constructor.");
+    eng_->check(ba_poisson_set_data(eng_->get(), X.nrow(), X.ncol(), X.data(), y.data(), exposure.data()));
+  }
+  void set_mixture_table(const NormalMixtureTable &t) {
+    if (t.counts.size() != t.ncomp.size()) report_error("the mixture table's counts and ncomp differ in length");
+    eng_->check(ba_poisson_set_mixtures(eng_->get(), (int32_t)t.counts.size(), t.counts.data(), t.ncomp.data(),
+                                        t.mu.data(), t.sigma.data(), t.weight.data(), t.largest_index));
+  }
+  int xdim() const { return p_; }
+  const Selector &inc() const { return inc_; }
+  void drop_all() { inc_.drop_all(); dirty_ = true; }
+  void add(int i) { inc_.add(i); dirty_ = true; }
+  void drop(int i) { inc_.drop(i); dirty_ = true; }
+  const Vector &Beta() const { return beta_; }
+  void set_Beta(const Vector &b) { beta_ = b; dirty_ = true; }
+  bool dirty() const { return dirty_; }
+  const Ptr<Engine> &engine() const { return eng_; }
+  void push_state() {
+    eng_->check(ba_set_state(eng_->get(), -1, inc_.bytes().data(), beta_.data(), 1.0));
+    dirty_ = false;
+  }
+  void pull_chain0() {
+    eng_->check(ba_get_state(eng_->get(), 0, inc_.bytes().data(), beta_.data(), nullptr));
+    dirty_ = false;
+  }
+  void chain_states(std::vector<uint8_t> &gamma, Vector &beta) const {
+    const size_t C = eng_->chains();
+    gamma.resize(C * p_); beta.resize(C * p_);
+    eng_->check(ba_get_states(eng_->get(), gamma.data(), beta.data(), nullptr));
+  }
+ private:
+  Ptr<Engine> eng_;
+  int p_;
+  Selector inc_;
+  Vector beta_;
+  bool dirty_ = true;
+};
+// PoissonRegressionSpikeSlabSampler(model, slab, spike, number_of_threads, seeding_rng)
+class PoissonRegressionSpikeSlabSampler : public PosteriorSampler {
+ public:
+  PoissonRegressionSpikeSlabSampler(PoissonRegressionModel *model, const Ptr<MvnModel> &slab,
+                                    const Ptr<VariableSelectionPrior> &spike)
+      : model_(model), slab_(slab) {
+    if (slab->dim() != model->xdim()) report_error("Slab does not match model dimension.");
+    if ((int)spike->potential_nvars() != model->xdim()) report_error("Spike does not match model dimension.");
+    check(ba_sss_set_slab(h(), slab->mu().data(), slab->siginv().data(), 0, -1));
+    check(ba_set_spike(h(), spike->prior_inclusion_probabilities().data(), spike->max_model_size()));
+  }
+  void draw() override {
+    if (model_->dirty()) model_->push_state();
+    check(ba_poisson_sweep(h(), 1));
+    check(ba_sync(h()));
+    model_->pull_chain0();
+  }
+  double logpri() const override { report_error("logpri() is not implemented for the Poisson sampler"); return 0; }
+  void set_seed(unsigned long s) override { check(ba_seed(h(), s)); }
+  void limit_model_selection(int max_flips) {
+    check(ba_sss_set_slab(h(), slab_->mu().data(), slab_->siginv().data(), 0, max_flips));
+  }
+ private:
+  ba_engine *h() const { return model_->engine()->get(); }
+  void check(int rc) const { model_->engine()->check(rc); }
+  PoissonRegressionModel *model_;
+  Ptr<MvnModel> slab_;
 };
 
 }  // namespace boom_amd_api

@@ -281,6 +281,68 @@ static void StructuralTimeSeries() {
   EXPECT(v[0] > 0 && v[1] > 0 && v[2] > 0 && v[1] < v[0] + 1.0);
 }
 
+// ... the general form: add_state in any order -- a weekly pattern of daily data whose
+// "season" lasts a week, beside a day-of-week pattern, and no trend block at all but a local
+// level added LAST (bsts: AddSeasonal(nseasons = 4, season.duration = 7) + AddSeasonal(7) +
+// AddLocalLevel); the draws come from the look-ahead (the sampler's default)
+static void AnyStateList() {
+  const int T = 560, p = 3, chains = 6, D = 7, W = 4;
+  std::mt19937_64 gen(23);
+  std::normal_distribution<double> N(0, 1);
+  Matrix X(T, p);
+  Vector y(T), coef = {3.0, 0.0, -2.0};
+  const double dow[D] = {1.0, -0.4, 0.2, -0.9, 0.6, -0.3, -0.2}, wk[W] = {0.8, -0.5, -0.6, 0.3};
+  double level = 0;
+  for (int t = 0; t < T; ++t) {
+    level += 0.03 * N(gen);
+    double mu = level + dow[t % D] + wk[(t / D) % W];
+    for (int j = 0; j < p; ++j) { X(t, j) = N(gen); mu += X(t, j) * coef[j]; }
+    y[t] = mu + 0.15 * N(gen);
+  }
+  StateSpaceRegressionModel model(y, X, std::vector<bool>(), chains, 11);
+  Ptr<SeasonalStateModel> weekly(new SeasonalStateModel(W, D));
+  weekly->set_sigsq(0.01);
+  weekly->set_initial_state_variance(4.0);
+  weekly->set_prior(1.0, 0.05);
+  model.add_state(weekly);
+  Ptr<SeasonalStateModel> daily(new SeasonalStateModel(D));
+  daily->set_sigsq(0.01);
+  daily->set_initial_state_variance(4.0);
+  daily->set_prior(1.0, 0.05);
+  model.add_state(daily);
+  Ptr<LocalLevelStateModel> lv(new LocalLevelStateModel(0.3));
+  lv->set_initial_state_mean(y[0]);
+  lv->set_initial_state_variance(4.0);
+  lv->set_prior(1.0, 0.1);
+  model.add_state(lv);
+  EXPECT(model.number_of_state_models() == 3);
+  EXPECT(model.state_dimension() == (W - 1) + (D - 1) + 1);
+  SpdMatrix om(p, p, 0.0);
+  for (int j = 0; j < p; ++j) om(j, j) = 0.01;
+  Ptr<MvnGivenScalarSigma> slab(new MvnGivenScalarSigma(Vector(p, 0.0), om));
+  Ptr<ChisqModel> siginv(new ChisqModel(1.0, 0.5));
+  Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(p, 0.5));
+  Ptr<StateSpacePosteriorSampler> sampler(new StateSpacePosteriorSampler(&model, slab, siginv, spike));
+  model.set_method(sampler);
+  for (int i = 0; i < 200; ++i) model.sample_posterior();
+  Matrix st = model.structural_state(0);
+  EXPECT(st.nrow() == 10 && st.ncol() == T);
+  // weekly effect + day-of-week effect + level track y - X coef
+  double err = 0;
+  for (int t = 0; t < T; ++t) {
+    double target = y[t];
+    for (int j = 0; j < p; ++j) target -= X(t, j) * coef[j];
+    err += std::fabs(st(0, t) + st(W - 1, t) + st(W - 1 + D - 1, t) - target);
+  }
+  EXPECT(err / T < 0.4);
+  // the weekly component holds still inside a week
+  int moved = 0;
+  for (int t = 1; t < T; ++t) moved += (t % D != 0 && st(0, t) != st(0, t - 1)) ? 1 : 0;
+  EXPECT(moved == 0);
+  Vector v = model.state_variances(0);
+  EXPECT(v.size() == 3 && v[0] > 0 && v[1] > 0 && v[2] > 0);
+}
+
 // ... with an autoregressive component (bsts AddAr) on top of a local level
 static void AutoregressiveState() {
   const int T = 600, p = 3, chains = 8;
@@ -502,6 +564,7 @@ int main() {
     StateSpace();
     StructuralTimeSeries();
     AutoregressiveState();
+    AnyStateList();
     BinomialSpikeSlab<BinomialLogitModel, BinomialLogitSpikeSlabSampler>(true);
     BinomialSpikeSlab<BinomialProbitModel, BinomialProbitSpikeSlabSampler>(false);
   } catch (std::exception &e) {

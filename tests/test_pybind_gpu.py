@@ -204,3 +204,98 @@ def test_state_space_regression_with_an_ar_state_model():
     assert abs(phi[:, 0].mean() - 1.1) < 0.3 and abs(phi[:, 1].mean() + 0.4) < 0.3
     assert model.state(1).shape == (3, T)
     assert 0.05 < model.ar_sigsq(0) < 0.8
+
+
+def test_any_state_list_on_the_pybind_module():
+    """add_state in any order and number, a seasonal model with season_duration > 1 and a
+    time_of_first_observation: boom.StateSpaceRegressionModel served from the look-ahead
+    == the engine through the C-ABI, one ba_ss_sweep per iteration"""
+    import boom_amd
+    import boom_amd._boom as boom
+    from cases import bsts_priors, general_data, general_spec
+    T, p, seed, chains, niter = 100, 4, 8, 4, 9
+    desc = [("seasonal", 4, 3, 2), ("trend",), ("ar", 2)]
+    X, y, _, obs = general_data(T, p, 2, [(4, 3)], seed=14, missing_frac=0.04, ar_coef=[0.5])
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    blocks = general_spec(y, desc)
+    model = boom.StateSpaceRegressionModel(y, X, [bool(o) for o in obs], chains=chains, seed=seed)
+    b = blocks[0]
+    seas = boom.SeasonalStateModel(4, 3)
+    seas.set_time_of_first_observation(2)
+    seas.set_sigsq(b["initial_sigma"][0] ** 2)
+    seas.set_prior(b["df"][0], b["sigma_guess"][0], b["sigma_upper_limit"][0])
+    seas.set_initial_state_mean(b["a0"])
+    seas.set_initial_state_variance(b["P0"][0])
+    b = blocks[1]
+    trend = boom.LocalLinearTrendStateModel()
+    trend.set_initial_sigma(b["initial_sigma"][0], b["initial_sigma"][1])
+    for i in range(2):
+        trend.set_prior(i, b["df"][i], b["sigma_guess"][i], b["sigma_upper_limit"][i])
+    trend.set_initial_state_mean(b["a0"])
+    trend.set_initial_state_variance(b["P0"])
+    b = blocks[2]
+    ar = boom.ArStateModel(2)
+    ar.set_sigma(b["initial_sigma"][0])
+    ar.set_prior(b["df"][0], b["sigma_guess"][0], b["sigma_upper_limit"][0])
+    ar.set_initial_state_mean(b["a0"])
+    ar.set_initial_state_variance(b["P0"][0])
+    model.add_state(seas)
+    model.add_state(trend)
+    model.add_state(ar)
+    assert model.number_of_state_models == 3 and model.state_dimension == 7
+    sampler = boom.StateSpacePosteriorSampler(model, boom.MvnGivenScalarSigma(prior["b"], prior["ominv"]),
+                                              boom.ChisqModel(prior["df"], prior["sigma_guess"]),
+                                              boom.VariableSelectionPrior(prior["pi"]), sig_up)
+    sampler.set_lookahead(4)
+    model.set_method(sampler)
+    eng = boom_amd.Engine(chains, seed=seed)
+    eng.ss_set_data(y, X, obs)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
+                   sigma_upper_limit=sig_up)
+    eng.ss_set_state_models(blocks)
+    eng.set_state(np.zeros(p, np.uint8))
+    for it in range(niter):
+        model.sample_posterior()
+        eng.ss_sweep(1)
+        G, B, S = model.chain_states()
+        g, bb, s = eng.get_states()
+        assert np.array_equal(G, g) and np.array_equal(B, bb) and np.array_equal(S, s), it
+        assert np.array_equal(model.state(0), eng.ss_get_state_draw(0).T), it
+        want = np.concatenate([eng.ss_get_state_model(0, k)["variances"] for k in range(3)])
+        assert np.array_equal(model.state_variances(0), want), it
+        assert np.array_equal(model.ar_phi(0), eng.ss_get_state_model(0, 2)["phi"]), it
+    # a chain whose state path the look-ahead does not keep
+    assert np.array_equal(model.state(chains - 1), eng.ss_get_state_draw(chains - 1).T)
+
+
+def test_poisson_spike_slab_on_the_pybind_module():
+    """boom.PoissonRegressionModel + PoissonRegressionSpikeSlabSampler: the draws of the
+    engine through the C-ABI (ba_poisson_*), the mixture table handed over as data"""
+    import boom_amd
+    import boom_amd._boom as boom
+    from test_oracle_golden import _golden_mix, load
+    g = load("poisson_exposure")
+    X, y, ex, mix = g["X"], g["y"], g["exposure"], _golden_mix(g)
+    p = X.shape[1]
+    chains, seed, niter = 4, 23, 8
+    model = boom.PoissonRegressionModel(X, y, ex, chains=chains, seed=seed)
+    model.set_mixture_table([int(c) for c in mix["counts"]], [int(c) for c in mix["ncomp"]], mix["mu"],
+                            mix["sigma"], mix["weight"], int(mix["largest_index"]))
+    model.drop_all()
+    for j in np.flatnonzero(g["init_gamma"]):
+        model.add(int(j))
+    sampler = boom.PoissonRegressionSpikeSlabSampler(model, boom.MvnModel(g["mu"], g["prec"], True),
+                                                     boom.VariableSelectionPrior(g["pi"]))
+    model.set_method(sampler)
+    eng = boom_amd.Engine(chains, seed=seed)
+    eng.poisson_set_data(X, y, ex, mix)
+    eng.sss_set_slab(g["mu"], g["prec"], scales_with_sigsq=False)
+    eng.set_spike(g["pi"])
+    eng.set_state(g["init_gamma"])
+    for it in range(niter):
+        model.sample_posterior()
+        eng.poisson_sweep(1)
+        assert np.array_equal(np.asarray(model.inc, np.uint8), eng.get_state(0)[0]), it
+        assert np.array_equal(model.Beta, eng.get_state(0)[1]), it
+    G, B = model.chain_states()
+    assert np.array_equal(G, eng.get_states()[0]) and np.array_equal(B, eng.get_states()[1])
