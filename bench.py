@@ -358,6 +358,184 @@ def other_configs(boom_amd, torch, device, cpu=True):
     return other
 
 
+def _timed_steps(torch, dist, eng, world, local_rank, steps, warmup, step):
+    """W untimed + K timed steps between barriers; returns (wall seconds, ms per step by
+    HIP events on the engine's stream)"""
+    est = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", local_rank))
+    for _ in range(warmup):
+        step()
+    eng.sync()
+    eng.reset_summaries()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(est)
+    for _ in range(steps):
+        step()
+        eng.stream()       # (steps kept apart, as in the headline)
+    ev1.record(est)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / max(1, steps)
+
+
+def run_config3(args, boom_amd, torch, dist, rank, local_rank, world):
+    """BASELINE configs[3]: spike-and-slab n=1e5 p=4096, 1024 chains per GPU.  SURVEY 8(e):
+    the design matrix is ROW-SHARDED -- every rank draws its own rows on its device (3.3 GB
+    over the job, never through the host) --, each rank runs the MFMA syrk on its rows, ONE
+    all-reduce of the (p^2 + 2p + 2)-double block (134 MB) over RCCL, every rank installs
+    the bitwise-identical total; the chains never communicate; one all-gather of the
+    posterior summaries at the end.  A step = one launch of 40 sweeps of every chain."""
+    from boom_amd import dist as bd
+    from cases import spike_slab_prior
+    n, p, C = args.n_obs or 100000, args.p or 4096, args.chains or 1024
+    nsig, SW, BURN = 32, 40, 60
+    lo, hi = bd.row_shard(n, rank, world)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(DATA_SEED + 104729 * rank)      # (a rank's rows are its own)
+    Xs = torch.randn((p, hi - lo), dtype=torch.float64, device="cuda", generator=gen)   # column-major rows x p
+    Xs[0].fill_(1.0)
+    b = torch.zeros(p, dtype=torch.float64, device="cuda")
+    b[:nsig] = torch.tensor([(1.0 + 0.1 * (i % 7)) * (-1.0) ** i for i in range(nsig)],
+                            dtype=torch.float64, device="cuda")
+    ys = (b[:nsig, None] * Xs[:nsig]).sum(0) + torch.randn(hi - lo, dtype=torch.float64, device="cuda", generator=gen)
+    torch.cuda.synchronize()
+    eng = boom_amd.Engine(C, seed=SAMPLER_SEED, device=local_rank, chain_offset=rank * C)
+    t0 = time.perf_counter()
+    if world > 1:
+        block = bd.build_suf_row_sharded(eng, Xs, ys, n, world)
+    else:
+        eng.build_suf_from_xy_device(n, p, Xs.data_ptr(), ys.data_ptr())
+        block = None
+    eng.sync()
+    suf_build_s = time.perf_counter() - t0
+    del Xs, ys
+    s = eng.get_suf()
+    suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"], sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])
+    prior = spike_slab_prior(suf, nsig)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    eng.set_state(g0)
+    eng.sweep(BURN)
+    elapsed, kernel_ms = _timed_steps(torch, dist, eng, world, local_rank, args.steps, args.warmup,
+                                      lambda: eng.sweep(SW, sync=False))
+    blk = torch.empty(bd.summary_block_size(p), dtype=torch.float64, device="cuda")
+    eng.summaries_device(blk.data_ptr())
+    allb = bd.gather_blocks(blk, world)
+    elapsed = bd.max_over_ranks(elapsed, world, "cuda")
+    if args.dump_blocks:
+        dig = torch.tensor([float(rank * C), float(s["xtx"].sum()), float(np.abs(s["xtx"]).sum()), float(s["xty"].sum()),
+                            float(s["yty"]), float(s["ybar"]), float(s["xbar"].sum()), float(s["n"])],
+                           dtype=torch.float64, device="cuda")
+        digs = bd.gather_blocks(dig, world)
+        if rank == 0:
+            np.savez(args.dump_blocks, blocks=allb, digests=digs,
+                     suf_block=(block.cpu().numpy() if block is not None else np.zeros(0)))
+    if rank != 0:
+        return
+    sc = allb[:, 3 * p:]
+    total = float(sc[:, 0].sum())
+    kbar = float(sc[:, 3].sum() / total)
+    incl = allb[:, :p].sum(axis=0) / total
+    bytes_per_sweep = p * 8.0 * (2 * kbar + 4) + 8.0 * (3 * kbar + 4) + p / 8.0
+    achieved = bytes_per_sweep * C * SW / (kernel_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "Gibbs sweeps/sec (all chains), n=%g p=%d spike-slab" % (n, p),
+        "value": round(total / elapsed, 1), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BregVsSampler spike-and-slab n=%g p=%d, %d chains per GPU, fp64 (BASELINE "
+                               "configs[3]: 8192 chains over 8 GPUs)" % (n, p, C),
+                   "chains_per_gpu": C, "sweeps_per_step": SW, "true_signals": nsig,
+                   "mean_model_size": round(kbar, 2), "burn_in": BURN,
+                   "parallelism": "chains sharded, %d GPU(s)" % world,
+                   "suf_build": ("rows sharded (each rank draws its rows on its device), local MFMA syrk, ONE "
+                                 "all-reduce of %d bytes" % (8 * bd.suf_block_size(p))) if world > 1
+                                else "single device MFMA syrk"},
+        "suf_build_ms": round(suf_build_s * 1e3, 1),
+        "decisions": {"min_margin": float(sc[:, 6].min()), "accepted_flips": float(sc[:, 4].sum()),
+                      "proposed_flips": float(sc[:, 5].sum())},
+        "signal_inclusion_min": round(float(incl[:nsig].min()), 4),
+        "roofline": {"bound": "hbm", "kernel": "ssvs_sweep_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_sweep": round(bytes_per_sweep, 1), "achieved": round(achieved, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": _profile_traffic("c4", "ssvs_sweep_kernel")},
+        "cpu_baseline": None}))
+
+
+def run_config4(args, boom_amd, torch, dist, rank, local_rank, world):
+    """BASELINE configs[4]: logit spike-and-slab n=5e4 p=1024, 512 chains per GPU (4096 over
+    8 GPUs).  The data are replicated (every rank holds X: 410 MB), the chains sharded, no
+    collective on the sampling path, one all-gather of the summaries at the end.  A step =
+    5 sweep rounds (imputation, X'z, the requested vectors of X'WX, the sweep)."""
+    from boom_amd import dist as bd
+    from cases import logit_data, probit_slab
+    n, p, C = args.n_obs or 50000, args.p or 1024, args.chains or 512
+    R, BURN = 5, 15
+    X, y, nt, _ = logit_data(n, p, 8, seed=DATA_SEED)
+    slab, pi = probit_slab(X, nt, 8)
+    eng = boom_amd.Engine(C, seed=SAMPLER_SEED, device=local_rank, chain_offset=rank * C)
+    eng.logit_set_data(X, y, nt, 5)
+    if args.imputer == "pg":
+        eng.logit_set_imputer(1)
+    eng.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+    eng.set_spike(pi)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    eng.set_state(g0)
+    eng.logit_sweep(BURN)
+    elapsed, step_ms = _timed_steps(torch, dist, eng, world, local_rank, args.steps, args.warmup,
+                                    lambda: eng.logit_sweep(R, sync=False))
+    blk = torch.empty(bd.summary_block_size(p), dtype=torch.float64, device="cuda")
+    eng.summaries_device(blk.data_ptr())
+    allb = bd.gather_blocks(blk, world)
+    elapsed = bd.max_over_ranks(elapsed, world, "cuda")
+    gam = eng.get_states()[0]
+    if args.dump_blocks and rank == 0:
+        np.savez(args.dump_blocks, blocks=allb)
+    if rank != 0:
+        return
+    total = float(world * C * R * args.steps)
+    counted = float(allb[:, 3 * p].sum())
+    incl = allb[:, :p].sum(axis=0) / max(counted, 1.0)
+    print(json.dumps({
+        "metric": "Gibbs sweeps/sec (all chains), logit spike-slab n=%g p=%d" % (n, p),
+        "value": round(total / elapsed, 1), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BinomialLogitSpikeSlabSampler n=%g p=%d, %d chains per GPU, fp64 (BASELINE "
+                               "configs[4]: 4096 chains over 8 GPUs), imputer: %s"
+                               % (n, p, C, "Polya-Gamma" if args.imputer == "pg" else
+                                  "auxiliary mixture (the reference's)"),
+                   "chains_per_gpu": C, "rounds_per_step": R, "burn_in": BURN,
+                   "mean_model_size": round(float(gam.sum(1).mean()), 2),
+                   "parallelism": "chains sharded, data replicated, %d GPU(s)" % world},
+        "sweeps_in_the_summaries": counted,
+        "signal_inclusion_min": round(float(incl[:8].min()), 4),
+        "ms_per_round": round(step_ms / R, 3),
+        "cpu_baseline": None}))
+
+
+def _profile_traffic(tag, kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed PMC passes
+    (profiles/r*_<tag>_pmc_traffic.json, tools/regen_profiles.sh), or None"""
+    try:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % tag)))
+        with open(cand[-1]) as fh:
+            tj = json.load(fh)
+        ent = [v for k, v in tj["kernels"].items() if k.startswith(kernel_prefix)]
+        return max(ent, key=lambda v: v["dispatches"])["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,6 +544,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-curve", action="store_true",
                     help="skip the sweeps/s-vs-chains diagnostic (extra key, untimed)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3, 4),
+                    help="1 (default): BASELINE configs[1], the headline; 3: configs[3], n=1e5 p=4096, "
+                         "1024 chains per GPU, the design matrix row-sharded over the ranks and ONE "
+                         "all-reduce of the 134 MB sufficient-statistics block; 4: configs[4], logit "
+                         "spike-and-slab n=5e4 p=1024, 512 chains per GPU, the data replicated")
+    ap.add_argument("--n-obs", type=int, default=0, help="(configs 3 / 4) rows, for dry runs")
+    ap.add_argument("--p", type=int, default=0, help="(configs 3 / 4) predictors, for dry runs")
+    ap.add_argument("--chains", type=int, default=0, help="(configs 3 / 4) chains per rank, for dry runs")
+    ap.add_argument("--imputer", default="mixture", choices=("mixture", "pg"),
+                    help="(config 4) the reference's auxiliary-mixture imputer or Polya-Gamma")
     ap.add_argument("--dump-blocks", default=None,
                     help="rank 0 writes the gathered per-rank summary blocks, the ranks' chain "
                          "offsets and a digest of every rank's installed sufficient statistics "
@@ -409,6 +597,13 @@ def main():
 
     import boom_amd
     from cases import regression_data, spike_slab_prior
+
+    if args.config != 1:
+        run = run_config3 if args.config == 3 else run_config4
+        run(args, boom_amd, torch, dist, rank, local_rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- synthetic workload -------------------------------
     X, y, _ = regression_data(N_OBS, P, N_SIGNAL, seed=DATA_SEED)

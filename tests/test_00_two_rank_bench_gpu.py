@@ -135,3 +135,140 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert np.array_equal(agg["inclusion_prob"], mine[:, :P].sum(0) / agg["sweeps"])
     # and the two ranks really ran different chains
     assert not np.array_equal(blocks[0, P:2 * P], blocks[1, P:2 * P])
+
+
+def _run_bench(extra, tmp_path, name):
+    dump = str(tmp_path / (name + ".npz"))
+    env = dict(os.environ, BOOM_AMD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(STEPS),
+           "--warmup", str(WARMUP), "--no-cpu-baseline", "--no-curve", "--dump-blocks", dump] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-4000:]
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "two_rank_gloo_dry_run_%s.json" % name), "w") as fh:
+            fh.write(lines[0] + "\n")
+    except OSError:
+        pass
+    return json.loads(lines[0]), np.load(dump)
+
+
+def test_bench_config3_two_ranks_the_134_mb_block(tmp_path):
+    """bench.py --config 3 (BASELINE configs[3]) as two ranks on the one GPU: p = 4096, so the
+    ONE all-reduce of the sufficient-statistics block carries its real 134 MB (n is cut to
+    8192 rows and the chains to 64 per rank -- the block's size does not depend on either).
+    Each rank draws ITS rows on the device; the reduced block is bitwise the sum of the two
+    shards' blocks built here; the gathered summaries are bitwise those of two engines with
+    the ranks' chain offsets run here on that block."""
+    import torch
+    import boom_amd
+    from boom_amd import dist as bd
+    sys.path.insert(0, ROOT)
+    import bench
+    from cases import spike_slab_prior
+    n, p, C, SW = 8192, 4096, 64, 40
+    rec, d = _run_bench(["--config", "3", "--n-obs", str(n), "--p", str(p), "--chains", str(C)], tmp_path, "c3")
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "configs[3]" in rec["config"]["workload"]
+    assert str(8 * bd.suf_block_size(p)) in rec["config"]["suf_build"]
+    assert 8 * bd.suf_block_size(p) > 134e6
+    blocks, digests, job = d["blocks"], d["digests"], d["suf_block"]
+    assert list(digests[:, 0]) == [0.0, float(C)]
+    assert np.array_equal(digests[0, 1:], digests[1, 1:])      # both ranks installed the same statistics
+    assert blocks[:, 3 * p].sum() == 2 * C * SW * STEPS
+    # the two shards again, here
+    eng = [boom_amd.Engine(C, seed=bench.SAMPLER_SEED, chain_offset=r * C) for r in range(2)]
+    tot = torch.zeros(bd.suf_block_size(p), dtype=torch.float64, device="cuda")
+    nsig = 32
+    for r in range(2):
+        lo, hi = bd.row_shard(n, r, 2)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(bench.DATA_SEED + 104729 * r)
+        Xs = torch.randn((p, hi - lo), dtype=torch.float64, device="cuda", generator=gen)
+        Xs[0].fill_(1.0)
+        b = torch.zeros(p, dtype=torch.float64, device="cuda")
+        b[:nsig] = torch.tensor([(1.0 + 0.1 * (i % 7)) * (-1.0) ** i for i in range(nsig)],
+                                dtype=torch.float64, device="cuda")
+        ys = (b[:nsig, None] * Xs[:nsig]).sum(0) + torch.randn(hi - lo, dtype=torch.float64, device="cuda",
+                                                               generator=gen)
+        blk = torch.empty_like(tot)
+        eng[r].suf_partial_device(hi - lo, p, Xs.data_ptr(), ys.data_ptr(), blk.data_ptr())
+        tot += blk
+        del Xs
+    torch.cuda.synchronize()
+    assert np.array_equal(tot.cpu().numpy(), job)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    mine = []
+    for r in range(2):
+        e = eng[r]
+        e.set_suf_from_block_device(n, p, tot.data_ptr())
+        s = e.get_suf()
+        suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"], sumy=s["ybar"] * s["n"],
+                   xsum=s["xbar"] * s["n"])
+        prior = spike_slab_prior(suf, nsig)
+        e.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+        e.set_state(g0)
+        e.sweep(60)
+        for _ in range(WARMUP):
+            e.sweep(SW, sync=False)
+        e.sync()
+        e.reset_summaries()
+        for _ in range(STEPS):
+            e.sweep(SW, sync=False)
+            e.stream()
+        e.sync()
+        bb = torch.empty(bd.summary_block_size(p), dtype=torch.float64, device="cuda")
+        e.summaries_device(bb.data_ptr())
+        mine.append(bb.cpu().numpy())
+        e.close()
+    mine = np.stack(mine)
+    assert np.array_equal(blocks[:, :3 * p + 7], mine[:, :3 * p + 7])
+    assert not np.array_equal(blocks[0, p:2 * p], blocks[1, p:2 * p])
+
+
+def test_bench_config4_two_ranks_logit(tmp_path):
+    """bench.py --config 4 (BASELINE configs[4], the logit sampler) as two ranks on the one
+    GPU, at a reduced shape: the data replicated, the chains sharded by global id -- the
+    gathered summary blocks are bitwise those of two engines with the ranks' chain offsets
+    run here."""
+    import torch
+    import boom_amd
+    from boom_amd import dist as bd
+    sys.path.insert(0, ROOT)
+    import bench
+    from cases import logit_data, probit_slab
+    n, p, C, R = 4000, 256, 48, 5
+    rec, d = _run_bench(["--config", "4", "--n-obs", str(n), "--p", str(p), "--chains", str(C)], tmp_path, "c4")
+    assert rec["n_gpus"] == 2 and "configs[4]" in rec["config"]["workload"]
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 * STEPS - 2 * C * R * STEPS) < 1e-3 * 2 * C * R * STEPS
+    blocks = d["blocks"]
+    X, y, nt, _ = logit_data(n, p, 8, seed=bench.DATA_SEED)
+    slab, pi = probit_slab(X, nt, 8)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    mine = []
+    for r in range(2):
+        e = boom_amd.Engine(C, seed=bench.SAMPLER_SEED, chain_offset=r * C)
+        e.logit_set_data(X, y, nt, 5)
+        e.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+        e.set_spike(pi)
+        e.set_state(g0)
+        e.logit_sweep(15)
+        for _ in range(WARMUP):
+            e.logit_sweep(R, sync=False)
+        e.sync()
+        e.reset_summaries()
+        for _ in range(STEPS):
+            e.logit_sweep(R, sync=False)
+            e.stream()
+        e.sync()
+        bb = torch.empty(bd.summary_block_size(p), dtype=torch.float64, device="cuda")
+        e.summaries_device(bb.data_ptr())
+        mine.append(bb.cpu().numpy())
+        e.close()
+    mine = np.stack(mine)
+    assert np.array_equal(blocks[:, :3 * p + 1], mine[:, :3 * p + 1])
+    assert not np.array_equal(blocks[0, p:2 * p], blocks[1, p:2 * p])
