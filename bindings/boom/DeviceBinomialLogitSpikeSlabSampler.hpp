@@ -17,6 +17,8 @@
 #include "Models/MvnBase.hpp"
 #include "Models/PosteriorSamplers/PosteriorSampler.hpp"
 
+#include <vector>
+
 extern "C" {
 #include "boom_amd.h"
 }
@@ -32,6 +34,13 @@ namespace BOOM {
                                         const Ptr<VariableSelectionPrior> &spike,
                                         int clt_threshold, int chains, int device = 0,
                                         RNG &seeding_rng = GlobalRng::rng);
+    // ... over several devices behind one handle (ba_group_*): chains_per_device chains on
+    // every entry of `devices`, global chain ids device-major, the data replicated
+    DeviceBinomialLogitSpikeSlabSampler(BinomialLogitModel *model, const Ptr<MvnBase> &slab,
+                                        const Ptr<VariableSelectionPrior> &spike,
+                                        int clt_threshold, int chains_per_device,
+                                        const std::vector<int> &devices,
+                                        RNG &seeding_rng = GlobalRng::rng);
     ~DeviceBinomialLogitSpikeSlabSampler() override;
 
     void draw() override;            // BinomialLogitSpikeSlabSampler::draw, .cpp:50-54
@@ -46,10 +55,14 @@ namespace BOOM {
     void check(int rc) const;
     void push_state();
     void pull_chain0();
+    void configure(const Ptr<VariableSelectionPrior> &spike, int clt_threshold);
+    ba_engine *locate(int chain, int64_t *local) const;
     BinomialLogitModel *model_;
     Ptr<MvnBase> slab_;
-    ba_engine *engine_;
-    int chains_;
+    ba_engine *engine_;               // chain 0's engine
+    ba_group *group_ = nullptr;       // the device list's handle (nullptr: one engine)
+    std::vector<ba_engine *> engines_;
+    int chains_;                      // all chains
     unsigned long device_seed_;
   };
 

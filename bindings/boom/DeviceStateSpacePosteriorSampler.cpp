@@ -43,6 +43,60 @@ namespace BOOM {
         state_dim_(0),
         structural_(false),
         variance_priors_(state_variance_priors) {
+    classify(slab, spike);
+    device_seed_ = seed_rng(seeding_rng);
+    ba_config cfg{device, chains, 0, static_cast<uint64_t>(device_seed_), 0, 0};
+    check(ba_engine_create(&cfg, &engine_));
+    engines_.assign(1, engine_);
+    // (from here on a failure must not leak the engine: report_error throws)
+    try {
+      configure(slab, residual_precision_prior, spike, sigma_upper_limit, seasonal_time_of_first_observation,
+                lookahead);
+    } catch (...) {
+      ba_engine_destroy(engine_);
+      engine_ = nullptr;
+      throw;
+    }
+  }
+
+  DeviceStateSpacePosteriorSampler::DeviceStateSpacePosteriorSampler(
+      StateSpaceRegressionModel *model, const Ptr<MvnGivenScalarSigmaBase> &slab,
+      const Ptr<GammaModelBase> &residual_precision_prior,
+      const Ptr<VariableSelectionPrior> &spike, double sigma_upper_limit,
+      const std::vector<DeviceStateVariancePrior> &state_variance_priors, int chains_per_device,
+      const std::vector<int> &devices, RNG &seeding_rng,
+      const std::vector<int> &seasonal_time_of_first_observation, int lookahead)
+      : PosteriorSampler(seeding_rng),
+        model_(model),
+        engine_(nullptr),
+        chains_(chains_per_device * static_cast<int>(devices.size())),
+        state_dim_(0),
+        structural_(false),
+        variance_priors_(state_variance_priors) {
+    if (devices.empty()) report_error("The device list is empty.");
+    classify(slab, spike);
+    device_seed_ = seed_rng(seeding_rng);
+    std::vector<int32_t> dv(devices.begin(), devices.end());
+    if (ba_group_create(dv.data(), static_cast<int32_t>(dv.size()), chains_per_device,
+                        static_cast<uint64_t>(device_seed_), &group_) != BA_OK)
+      report_error(ba_group_last_error());
+    for (int i = 0; i < ba_group_size(group_); ++i) engines_.push_back(ba_group_engine(group_, i));
+    engine_ = engines_[0];
+    try {
+      configure(slab, residual_precision_prior, spike, sigma_upper_limit, seasonal_time_of_first_observation,
+                lookahead);
+    } catch (...) {
+      ba_group_destroy(group_);
+      group_ = nullptr;
+      engine_ = nullptr;
+      throw;
+    }
+  }
+
+  // which state models, in the order add_state received them
+  void DeviceStateSpacePosteriorSampler::classify(const Ptr<MvnGivenScalarSigmaBase> &slab,
+                                                  const Ptr<VariableSelectionPrior> &spike) {
+    StateSpaceRegressionModel *model = model_;
     const int p = model->xdim();
     const int T = model->time_dimension();
     if (slab->dim() != p) report_error("Slab dimension did not match model dimension.");
@@ -77,111 +131,127 @@ namespace BOOM {
     if (variance_priors_.size() != static_cast<size_t>(nvar))
       report_error("state_variance_priors needs one entry per state variance parameter.");
 
-    device_seed_ = seed_rng(seeding_rng);
-    ba_config cfg{device, chains, 0, static_cast<uint64_t>(device_seed_), 0, 0};
-    check(ba_engine_create(&cfg, &engine_));
-    // (from here on a failure must not leak the engine: report_error throws)
-    try {
-      // ---- data: one RegressionData per time point (StateSpaceRegressionModel.cpp:100-125)
-      Vector y(T, 0.0);
-      Matrix X(T, p);
-      std::vector<uint8_t> observed(T, 1);
-      for (int t = 0; t < T; ++t) {
-        const Ptr<StateSpace::MultiplexedRegressionData> &dp(model->dat()[t]);
-        if (dp->total_sample_size() != 1)
-          report_error("The device sampler takes one observation per time point.");
-        const RegressionData &rd(dp->regression_data(0));
-        X.row(t) = rd.x();
-        if (model->is_missing_observation(t)) {
-          observed[t] = 0;
-        } else {
-          y[t] = rd.y();
-        }
-      }
-      check(ba_ss_set_data(engine_, T, p, y.data(), X.data(), observed.data()));
+  }
 
-      // ---- regression priors: BregVsSampler's ctor #5 pieces
-      const Vector mu = slab->mu();
-      const SpdMatrix ominv = slab->unscaled_precision();
-      check(ba_set_slab(engine_, mu.data(), ominv.data()));
-      const Vector pi = spike->prior_inclusion_probabilities();
-      check(ba_set_spike(engine_, pi.data(), spike->max_model_size()));
-      check(ba_set_sigma_prior(engine_, prior_df(residual_precision_prior),
+  void DeviceStateSpacePosteriorSampler::configure(
+      const Ptr<MvnGivenScalarSigmaBase> &slab, const Ptr<GammaModelBase> &residual_precision_prior,
+      const Ptr<VariableSelectionPrior> &spike, double sigma_upper_limit,
+      const std::vector<int> &seasonal_time_of_first_observation, int lookahead) {
+    StateSpaceRegressionModel *model = model_;
+    const int p = model->xdim();
+    const int T = model->time_dimension();
+    const int nstate = model->number_of_state_models();
+    // ---- data: one RegressionData per time point (StateSpaceRegressionModel.cpp:100-125)
+    Vector y(T, 0.0);
+    Matrix X(T, p);
+    std::vector<uint8_t> observed(T, 1);
+    for (int t = 0; t < T; ++t) {
+      const Ptr<StateSpace::MultiplexedRegressionData> &dp(model->dat()[t]);
+      if (dp->total_sample_size() != 1)
+        report_error("The device sampler takes one observation per time point.");
+      const RegressionData &rd(dp->regression_data(0));
+      X.row(t) = rd.x();
+      if (model->is_missing_observation(t)) {
+        observed[t] = 0;
+      } else {
+        y[t] = rd.y();
+      }
+    }
+    for (ba_engine *e : engines_) check(ba_ss_set_data(e, T, p, y.data(), X.data(), observed.data()));
+
+    // ---- regression priors: BregVsSampler's ctor #5 pieces
+    const Vector mu = slab->mu();
+    const SpdMatrix ominv = slab->unscaled_precision();
+    for (ba_engine *e : engines_) check(ba_set_slab(e, mu.data(), ominv.data()));
+    const Vector pi = spike->prior_inclusion_probabilities();
+    for (ba_engine *e : engines_) check(ba_set_spike(e, pi.data(), spike->max_model_size()));
+    for (ba_engine *e : engines_)
+      check(ba_set_sigma_prior(e, prior_df(residual_precision_prior),
                                prior_sigma_guess(residual_precision_prior), sigma_upper_limit));
 
-      // ---- state models
-      if (!structural_) {
-        const LocalLevelStateModel *level = dynamic_cast<const LocalLevelStateModel *>(model->state_model(0));
-        const DeviceStateVariancePrior &lp(variance_priors_[0]);
-        check(ba_ss_set_local_level(engine_, prior_df(lp.precision_prior),
+    // ---- state models
+    if (!structural_) {
+      const LocalLevelStateModel *level = dynamic_cast<const LocalLevelStateModel *>(model->state_model(0));
+      const DeviceStateVariancePrior &lp(variance_priors_[0]);
+      for (ba_engine *e : engines_)
+        check(ba_ss_set_local_level(e, prior_df(lp.precision_prior),
                                     prior_sigma_guess(lp.precision_prior), lp.sigma_upper_limit,
                                     level->initial_state_mean()[0],
                                     level->initial_state_variance()(0, 0),
                                     std::sqrt(level->sigsq())));
-      } else {
-        check(ba_ss_clear_state_models(engine_));
-        size_t nseasonal = 0;
-        for (int s = 0; s < nstate; ++s) {
-          const Block &b(blocks_[s]);
-          const StateModel *sm = model->state_model(s);
-          double df[2] = {1, 1}, guess[2] = {1, 1}, upper[2] = {infinity(), infinity()}, init[2] = {1, 1};
-          for (int v = 0; v < b.nvar; ++v) {
-            const DeviceStateVariancePrior &pr(variance_priors_[b.var0 + v]);
-            df[v] = prior_df(pr.precision_prior);
-            guess[v] = prior_sigma_guess(pr.precision_prior);
-            upper[v] = pr.sigma_upper_limit;
-          }
-          const Vector a0 = sm->initial_state_mean();
-          const SpdMatrix V0 = sm->initial_state_variance();
-          diagonal_or_die(V0, "a state model");
-          const Vector v0 = V0.diag();
-          int32_t ip[3] = {0, 1, 0};
-          Vector phi;
-          if (b.kind == 1) {
-            init[0] = std::sqrt(dynamic_cast<const LocalLevelStateModel *>(sm)->sigsq());
-          } else if (b.kind == 2) {
-            const SpdMatrix Sigma = dynamic_cast<const LocalLinearTrendStateModel *>(sm)->Sigma();
-            if (Sigma(0, 1) != 0.0)
-              report_error("The device sampler draws the trend's two variances independently "
-                           "(ZeroMeanMvnIndependenceSampler): Sigma must be diagonal.");
-            init[0] = std::sqrt(Sigma(0, 0));
-            init[1] = std::sqrt(Sigma(1, 1));
-          } else if (b.kind == 3) {
-            const SeasonalStateModel *seas = dynamic_cast<const SeasonalStateModel *>(sm);
-            init[0] = std::sqrt(seas->sigsq());
-            ip[0] = seas->nseasons();
-            ip[1] = seas->season_duration();
-            ip[2] = nseasonal < seasonal_time_of_first_observation.size()
-                        ? seasonal_time_of_first_observation[nseasonal] : 0;
-            ++nseasonal;
-          } else {
-            const ArStateModel *ar = dynamic_cast<const ArStateModel *>(sm);
-            init[0] = ar->sigma();
-            ip[0] = b.lags;
-            phi = ar->phi();
-          }
-          check(ba_ss_add_state_model(engine_, b.kind, ip, df, guess, upper, init,
-                                      b.kind == 4 ? phi.data() : nullptr, a0.data(), v0.data()));
+    } else {
+      for (ba_engine *e : engines_) check(ba_ss_clear_state_models(e));
+      size_t nseasonal = 0;
+      for (int s = 0; s < nstate; ++s) {
+        const Block &b(blocks_[s]);
+        const StateModel *sm = model->state_model(s);
+        double df[2] = {1, 1}, guess[2] = {1, 1}, upper[2] = {infinity(), infinity()}, init[2] = {1, 1};
+        for (int v = 0; v < b.nvar; ++v) {
+          const DeviceStateVariancePrior &pr(variance_priors_[b.var0 + v]);
+          df[v] = prior_df(pr.precision_prior);
+          guess[v] = prior_sigma_guess(pr.precision_prior);
+          upper[v] = pr.sigma_upper_limit;
         }
+        const Vector a0 = sm->initial_state_mean();
+        const SpdMatrix V0 = sm->initial_state_variance();
+        diagonal_or_die(V0, "a state model");
+        const Vector v0 = V0.diag();
+        int32_t ip[3] = {0, 1, 0};
+        Vector phi;
+        if (b.kind == 1) {
+          init[0] = std::sqrt(dynamic_cast<const LocalLevelStateModel *>(sm)->sigsq());
+        } else if (b.kind == 2) {
+          const SpdMatrix Sigma = dynamic_cast<const LocalLinearTrendStateModel *>(sm)->Sigma();
+          if (Sigma(0, 1) != 0.0)
+            report_error("The device sampler draws the trend's two variances independently "
+                         "(ZeroMeanMvnIndependenceSampler): Sigma must be diagonal.");
+          init[0] = std::sqrt(Sigma(0, 0));
+          init[1] = std::sqrt(Sigma(1, 1));
+        } else if (b.kind == 3) {
+          const SeasonalStateModel *seas = dynamic_cast<const SeasonalStateModel *>(sm);
+          init[0] = std::sqrt(seas->sigsq());
+          ip[0] = seas->nseasons();
+          ip[1] = seas->season_duration();
+          ip[2] = nseasonal < seasonal_time_of_first_observation.size()
+                      ? seasonal_time_of_first_observation[nseasonal] : 0;
+          ++nseasonal;
+        } else {
+          const ArStateModel *ar = dynamic_cast<const ArStateModel *>(sm);
+          init[0] = ar->sigma();
+          ip[0] = b.lags;
+          phi = ar->phi();
+        }
+        for (ba_engine *e : engines_)
+          check(ba_ss_add_state_model(e, b.kind, ip, df, guess, upper, init,
+                                      b.kind == 4 ? phi.data() : nullptr, a0.data(), v0.data()));
       }
+    }
 
-      // ---- the chains start where the model stands
-      const RegressionModel *reg = model->observation_model();
-      const Selector &inc(reg->coef().inc());
-      std::vector<uint8_t> gamma(p, 0);
-      for (int j = 0; j < p; ++j) gamma[j] = inc[j] ? 1 : 0;
-      const Vector beta = reg->Beta();
-      check(ba_set_state(engine_, -1, gamma.data(), beta.data(), reg->sigsq()));
-      if (lookahead > 1) check(ba_ss_set_lookahead(engine_, lookahead));
-    } catch (...) {
-      ba_engine_destroy(engine_);
-      engine_ = nullptr;
-      throw;
+    // ---- the chains start where the model stands
+    const RegressionModel *reg = model->observation_model();
+    const Selector &inc(reg->coef().inc());
+    std::vector<uint8_t> gamma(p, 0);
+    for (int j = 0; j < p; ++j) gamma[j] = inc[j] ? 1 : 0;
+    const Vector beta = reg->Beta();
+    for (ba_engine *e : engines_) {
+      check(ba_set_state(e, -1, gamma.data(), beta.data(), reg->sigsq()));
+      if (lookahead > 1) check(ba_ss_set_lookahead(e, lookahead));
     }
   }
 
   DeviceStateSpacePosteriorSampler::~DeviceStateSpacePosteriorSampler() {
-    if (engine_) ba_engine_destroy(engine_);
+    if (group_) ba_group_destroy(group_);
+    else if (engine_) ba_engine_destroy(engine_);
+  }
+
+  ba_engine *DeviceStateSpacePosteriorSampler::locate(int chain, int64_t *local) const {
+    if (!group_) {
+      *local = chain;
+      return engine_;
+    }
+    int32_t ei = 0;
+    if (ba_group_locate(group_, chain, &ei, local) != BA_OK) report_error(ba_group_last_error());
+    return engines_[ei];
   }
 
   void DeviceStateSpacePosteriorSampler::check(int rc) const {
@@ -190,20 +260,29 @@ namespace BOOM {
 
   void DeviceStateSpacePosteriorSampler::set_device_seed(unsigned long seed) {
     device_seed_ = seed;
-    check(ba_seed(engine_, seed));
+    for (ba_engine *e : engines_) check(ba_seed(e, seed));
   }
 
   void DeviceStateSpacePosteriorSampler::record_state_of_chains(const std::vector<int> &chains) {
     std::vector<int64_t> c(1, 0);   // (chain 0 backs the model: always)
     for (int v : chains)
       if (v != 0) c.push_back(v);
-    check(ba_ss_lookahead_chains(engine_, static_cast<int32_t>(c.size()), c.data()));
+    // (a device list: every engine keeps the chains that are its own)
+    for (size_t i = 0; i < engines_.size(); ++i) {
+      std::vector<int64_t> own;
+      for (int64_t v : c) {
+        int64_t local = 0;
+        if (locate(static_cast<int>(v), &local) == engines_[i]) own.push_back(local);
+      }
+      if (i == 0 || !own.empty())
+        check(ba_ss_lookahead_chains(engines_[i], static_cast<int32_t>(own.size()), own.data()));
+    }
   }
 
   void DeviceStateSpacePosteriorSampler::draw() {
     // (one round of every chain; with the look-ahead the round has usually run already and
     // this hands out its record)
-    check(ba_ss_draw_next(engine_));
+    for (ba_engine *e : engines_) check(ba_ss_draw_next(e));   // (every device's rounds are out before any is read)
     pull_chain0();
   }
 
@@ -213,7 +292,9 @@ namespace BOOM {
     const int p = model_->xdim(), T = model_->time_dimension();
     std::vector<uint8_t> gamma(p, 0);
     beta.resize(p);
-    check(ba_get_state(engine_, chain, gamma.data(), beta.data(), &sigsq));
+    int64_t lc = 0;
+    ba_engine *eng = locate(chain, &lc);
+    check(ba_get_state(eng, lc, gamma.data(), beta.data(), &sigsq));
     inc = Selector(p, false);
     for (int j = 0; j < p; ++j)
       if (gamma[j]) inc.add(j);
@@ -221,13 +302,13 @@ namespace BOOM {
     state = Matrix(state_dim_, T);
     state_variances = Vector(variance_priors_.size(), 0.0);
     if (structural_) {
-      check(ba_ss_get_state_draw(engine_, chain, state.data()));
+      check(ba_ss_get_state_draw(eng, lc, state.data()));
       for (size_t s = 0; s < blocks_.size(); ++s)
-        check(ba_ss_get_state_model(engine_, chain, static_cast<int32_t>(s),
+        check(ba_ss_get_state_model(eng, lc, static_cast<int32_t>(s),
                                     &state_variances[blocks_[s].var0], nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr));
     } else {
-      check(ba_ss_get_state(engine_, chain, state.data(), &state_variances[0], nullptr, nullptr));
+      check(ba_ss_get_state(eng, lc, state.data(), &state_variances[0], nullptr, nullptr));
     }
   }
 
@@ -236,7 +317,9 @@ namespace BOOM {
     for (size_t s = 0; s < blocks_.size(); ++s) {
       if (blocks_[s].kind != 4 || seen++ != which) continue;
       phi.resize(blocks_[s].lags);
-      check(ba_ss_get_state_model(engine_, chain, static_cast<int32_t>(s), &sigsq, nullptr, nullptr,
+      int64_t lc = 0;
+      ba_engine *eng = locate(chain, &lc);
+      check(ba_ss_get_state_model(eng, lc, static_cast<int32_t>(s), &sigsq, nullptr, nullptr,
                                   phi.data(), nullptr, nullptr, nullptr, nullptr));
       return;
     }
@@ -316,7 +399,9 @@ namespace BOOM {
     if (newX.ncol() != model_->xdim()) report_error("newX does not match the model's predictors.");
     const int h = newX.nrow();
     std::vector<double> out(static_cast<size_t>(chains_) * h);
-    check(ba_ss_forecast(engine_, h, newX.data(), out.data()));
+    const size_t per = static_cast<size_t>(chains_) / engines_.size();
+    for (size_t i = 0; i < engines_.size(); ++i)
+      check(ba_ss_forecast(engines_[i], h, newX.data(), out.data() + i * per * h));
     Matrix ans(chains_, h);
     for (int c = 0; c < chains_; ++c)
       for (int t = 0; t < h; ++t) ans(c, t) = out[static_cast<size_t>(c) * h + t];

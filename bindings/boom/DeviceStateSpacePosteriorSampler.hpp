@@ -81,6 +81,20 @@ namespace BOOM {
         int chains, int device = 0, RNG &seeding_rng = GlobalRng::rng,
         const std::vector<int> &seasonal_time_of_first_observation = std::vector<int>(),
         int lookahead = 64);
+    // ... over several devices behind one handle (ba_group_*): chains_per_device chains on
+    // every entry of `devices`, global chain ids device-major; the data are replicated and
+    // the chains never communicate, every device's rounds are enqueued before
+    // any is waited for.  Chain 0 (device 0) backs the model.
+    DeviceStateSpacePosteriorSampler(
+        StateSpaceRegressionModel *model,
+        const Ptr<MvnGivenScalarSigmaBase> &slab,
+        const Ptr<GammaModelBase> &residual_precision_prior,
+        const Ptr<VariableSelectionPrior> &spike,
+        double sigma_upper_limit,
+        const std::vector<DeviceStateVariancePrior> &state_variance_priors,
+        int chains_per_device, const std::vector<int> &devices, RNG &seeding_rng = GlobalRng::rng,
+        const std::vector<int> &seasonal_time_of_first_observation = std::vector<int>(),
+        int lookahead = 64);
     ~DeviceStateSpacePosteriorSampler() override;
 
     void draw() override;            // StateSpacePosteriorSampler::draw, .cpp:42-64
@@ -110,9 +124,17 @@ namespace BOOM {
    private:
     void check(int rc) const;
     void pull_chain0();
+    void classify(const Ptr<MvnGivenScalarSigmaBase> &slab, const Ptr<VariableSelectionPrior> &spike);
+    void configure(const Ptr<MvnGivenScalarSigmaBase> &slab, const Ptr<GammaModelBase> &residual_precision_prior,
+                   const Ptr<VariableSelectionPrior> &spike, double sigma_upper_limit,
+                   const std::vector<int> &seasonal_time_of_first_observation, int lookahead);
+    // the engine that holds a (global) chain, and the chain's index there
+    ba_engine *locate(int chain, int64_t *local) const;
     StateSpaceRegressionModel *model_;
-    ba_engine *engine_;
-    int chains_;
+    ba_engine *engine_;               // chain 0's engine (= engines_[0])
+    ba_group *group_ = nullptr;       // the device list's handle (nullptr: one engine)
+    std::vector<ba_engine *> engines_;
+    int chains_;                      // all chains
     unsigned long device_seed_;
     // the state models as the engine knows them
     struct Block {

@@ -153,7 +153,7 @@ int ref_binding_logit_run(int n, int p, const double *X, const double *y, const 
                           int clt_threshold, int max_flips, int chains, uint64_t seed,
                           const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
                           double *out_beta, uint64_t *out_seed, int probe_chain,
-                          uint8_t *probe_gamma, double *probe_beta) {
+                          uint8_t *probe_gamma, double *probe_beta, int ndevices) {
   try {
     GlobalRng::rng.seed(seed);
     Ptr<BinomialLogitModel> model(new BinomialLogitModel(p, true));
@@ -175,7 +175,11 @@ int ref_binding_logit_run(int n, int p, const double *X, const double *y, const 
     model->coef().drop_all();
     for (int j = 0; j < p; ++j)
       if (init_gamma[j]) model->coef().add(j);
-    NEW(DeviceBinomialLogitSpikeSlabSampler, sampler)(model.get(), slab, spike, clt_threshold, chains);
+    // (ndevices > 0: `chains` per entry of a device list that names device 0 ndevices times)
+    Ptr<DeviceBinomialLogitSpikeSlabSampler> sampler(
+        ndevices > 0 ? new DeviceBinomialLogitSpikeSlabSampler(model.get(), slab, spike, clt_threshold, chains,
+                                                               std::vector<int>(ndevices, 0))
+                     : new DeviceBinomialLogitSpikeSlabSampler(model.get(), slab, spike, clt_threshold, chains));
     if (max_flips > 0) sampler->limit_model_selection(max_flips);
     if (out_seed) *out_seed = sampler->device_seed();
     model->set_method(sampler);
@@ -430,7 +434,7 @@ int ref_binding_ssg_run(int T, int p, const double *y, const double *X, const ui
                         const uint8_t *init_gamma, int nsweeps, int lookahead, uint8_t *out_gamma,
                         double *out_beta, double *out_sigsq, double *out_variances, double *out_phi,
                         double *out_state, double *out_logpri, uint64_t *out_seed, int probe_chain,
-                        uint8_t *probe_gamma, double *probe_state) {
+                        uint8_t *probe_gamma, double *probe_state, int ndevices) {
   try {
     GlobalRng::rng.seed(seed);
     Matrix Xm(T, p);
@@ -525,9 +529,13 @@ int ref_binding_ssg_run(int T, int p, const double *y, const double *X, const ui
       first += dim;
     }
     const int m = first;
-    NEW(DeviceStateSpacePosteriorSampler, sampler)(model.get(), slab, siginv_prior, spike,
-                                                   sigma_upper_limit, vpriors, chains, 0, GlobalRng::rng,
-                                                   t0s, lookahead);
+    // (ndevices > 0: `chains` per entry of a device list that names device 0 ndevices times)
+    Ptr<DeviceStateSpacePosteriorSampler> sampler(
+        ndevices > 0 ? new DeviceStateSpacePosteriorSampler(model.get(), slab, siginv_prior, spike, sigma_upper_limit,
+                                                            vpriors, chains, std::vector<int>(ndevices, 0),
+                                                            GlobalRng::rng, t0s, lookahead)
+                     : new DeviceStateSpacePosteriorSampler(model.get(), slab, siginv_prior, spike, sigma_upper_limit,
+                                                            vpriors, chains, 0, GlobalRng::rng, t0s, lookahead));
     if (out_seed) *out_seed = sampler->device_seed();
     model->set_method(sampler);
     for (int s = 0; s < nsweeps; ++s) {

@@ -109,6 +109,11 @@ SIGNATURES = {
     "ba_group_set_state": (C.c_int, [C.c_void_p, _u8p, _dp, C.c_double]),
     "ba_group_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_group_sync": (C.c_int, [C.c_void_p]),
+    "ba_group_call": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ba_group_ss_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_group_ss_draw_next": (C.c_int, [C.c_void_p]),
+    "ba_group_logit_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_group_poisson_sweep": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_group_reset_summaries": (C.c_int, [C.c_void_p]),
     "ba_group_get_summaries": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "ba_ss_set_data": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
@@ -695,6 +700,38 @@ class Group:
             self.close()
         except Exception:
             pass
+
+    def call(self, fn):
+        """fn(engine) on every engine of the group through ba_group_call (the C-ABI's own
+        loop: stops at the first error)"""
+        by_handle = {e._h.value: e for e in self.engines}
+        err = []
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+        def tramp(h, _):
+            try:
+                fn(by_handle[h])
+                return 0
+            except BoomAmdError as ex:
+                err.append(ex)
+                return ex.args[0] if ex.args and isinstance(ex.args[0], int) and ex.args[0] else -1
+        rc = self.lib.ba_group_call(self._h, C.cast(tramp, C.c_void_p), None)
+        if err:
+            raise err[0]
+        self._check(rc)
+
+    def ss_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_group_ss_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
+
+    def ss_draw_next(self):
+        self._check(self.lib.ba_group_ss_draw_next(self._h))
+
+    def logit_sweep(self, nsweeps=1, sync=True):
+        self._check(self.lib.ba_group_logit_sweep(self._h, nsweeps))
+        if sync:
+            self.sync()
 
     def locate(self, global_chain):
         e, c = C.c_int32(), C.c_int64()

@@ -218,6 +218,19 @@ int ba_group_build_suf_from_xy(ba_group *g, int64_t n, int32_t p, const double *
   // ---- every device: its rows up, partial statistics into its block (asynchronous
   // per device: the uploads and syrks of different devices overlap)
   std::vector<double *> dX(G, nullptr), dy(G, nullptr);
+  // (freed on every way out, the error returns of the macros below included)
+  struct Shards {
+    ba_group *g;
+    std::vector<double *> &dX, &dy;
+    ~Shards() {
+      for (size_t i = 0; i < dX.size(); ++i) {
+        if (!dX[i] && !dy[i]) continue;
+        (void)hipSetDevice(g->dev[i]);
+        if (dX[i]) (void)hipFree(dX[i]);
+        if (dy[i]) (void)hipFree(dy[i]);
+      }
+    }
+  } shards{g, dX, dy};
   std::vector<std::vector<double>> hX(G);
   for (int i = 0; i < G; ++i) {
     const int64_t lo = n * i / G, hi = n * (i + 1) / G, ni = hi - lo;
@@ -235,10 +248,10 @@ int ba_group_build_suf_from_xy(ba_group *g, int64_t n, int32_t p, const double *
     const int64_t lo = n * i / G, hi = n * (i + 1) / G;
     G_BA(ba_suf_partial_device(g->eng[i], hi - lo, p, dX[i], dy[i], g->dbuf[i]));
   }
+  // every engine's block is complete before any other stream (or device) reads it
   for (int i = 0; i < G; ++i) {
     G_HIP(hipSetDevice(g->dev[i]));
-    G_HIP(hipFree(dX[i]));
-    G_HIP(hipFree(dy[i]));
+    G_HIP(hipStreamSynchronize((hipStream_t)ba_stream(g->eng[i])));
   }
   // ---- ONE all-reduce of the blocks
   if (g->one_device) {
@@ -290,6 +303,39 @@ int ba_group_sweep(ba_group *g, int32_t nsweeps) {
   return BA_OK;
 }
 
+// fn(engine, arg) on every engine of the group, in order; stops at the first error (whose
+// text ba_group_last_error() then holds).  Everything that is the SAME on every device --
+// the bsts / logit / Poisson data (replicated: SURVEY 8e), priors, state models, options,
+// the look-ahead -- is set this way with the single-engine entry points.
+int ba_group_call(ba_group *g, int (*fn)(ba_engine *, void *), void *arg) {
+  if (!g || !fn) return gfail(BA_E_INVALID, "null argument");
+  for (ba_engine *e : g->eng) G_BA(fn(e, arg));
+  return BA_OK;
+}
+
+// the samplers' rounds on every device: each call only ENQUEUES (the single-engine entry
+// points return once their launches are out), so the devices run side by side
+int ba_group_ss_sweep(ba_group *g, int32_t nsweeps) {
+  if (!g) return gfail(BA_E_INVALID, "null group");
+  for (ba_engine *e : g->eng) G_BA(ba_ss_sweep(e, nsweeps));
+  return BA_OK;
+}
+int ba_group_ss_draw_next(ba_group *g) {
+  if (!g) return gfail(BA_E_INVALID, "null group");
+  for (ba_engine *e : g->eng) G_BA(ba_ss_draw_next(e));
+  return BA_OK;
+}
+int ba_group_logit_sweep(ba_group *g, int32_t nsweeps) {
+  if (!g) return gfail(BA_E_INVALID, "null group");
+  for (ba_engine *e : g->eng) G_BA(ba_logit_sweep(e, nsweeps));
+  return BA_OK;
+}
+int ba_group_poisson_sweep(ba_group *g, int32_t nsweeps) {
+  if (!g) return gfail(BA_E_INVALID, "null group");
+  for (ba_engine *e : g->eng) G_BA(ba_poisson_sweep(e, nsweeps));
+  return BA_OK;
+}
+
 int ba_group_sync(ba_group *g) {
   if (!g) return gfail(BA_E_INVALID, "null group");
   for (ba_engine *e : g->eng) G_BA(ba_sync(e));
@@ -317,6 +363,7 @@ int ba_group_get_summaries(ba_group *g, double *inclusion_count, double *beta_su
   for (int i = 0; i < G; ++i) G_BA(ba_summaries_device(g->eng[i], g->dbuf[i] + (size_t)G * blk));
   if (g->one_device) {
     G_HIP(hipSetDevice(g->dev[0]));
+    for (int i = 0; i < G; ++i) G_HIP(hipStreamSynchronize((hipStream_t)ba_stream(g->eng[i])));
     for (int i = 0; i < G; ++i)
       G_HIP(hipMemcpy(g->dbuf[0] + (size_t)i * blk, g->dbuf[i] + (size_t)G * blk, blk * sizeof(double),
                       hipMemcpyDeviceToDevice));

@@ -578,6 +578,15 @@ int ba_group_set_priors(ba_group *g, const double *prior_mean,
 int ba_group_set_state(ba_group *g, const uint8_t *gamma, const double *beta, double sigsq);
 /* ba_sweep on every engine (asynchronous: the devices run side by side); ba_sync */
 int ba_group_sweep(ba_group *g, int32_t nsweeps);
+/* fn(engine, arg) on every engine of the group, in order; stops at the first error.  What
+ * is the same on every device -- the bsts / logit / Poisson data (replicated), priors, the
+ * state models, options, the look-ahead -- is set this way with the single-engine entry
+ * points; the sweeps of those samplers go out on every device before any is waited for. */
+int ba_group_call(ba_group *g, int (*fn)(ba_engine *, void *), void *arg);
+int ba_group_ss_sweep(ba_group *g, int32_t nsweeps);
+int ba_group_ss_draw_next(ba_group *g);
+int ba_group_logit_sweep(ba_group *g, int32_t nsweeps);
+int ba_group_poisson_sweep(ba_group *g, int32_t nsweeps);
 int ba_group_sync(ba_group *g);
 int ba_group_reset_summaries(ba_group *g);
 /* whole-job summaries, laid out as ba_get_summaries; blocks (may be NULL) receives the

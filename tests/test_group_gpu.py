@@ -105,3 +105,70 @@ def test_librccl_is_loadable_with_every_symbol_the_group_uses():
     import boom_amd
     lib = boom_amd.load_library()
     assert lib.ba_group_rccl_available() == 1, lib.ba_group_last_error().decode()
+
+
+def test_group_runs_the_bsts_and_logit_samplers(oracle):
+    """the samplers whose data are replicated -- bsts (any state list, with the look-ahead)
+    and logit -- behind one group handle: ba_group_call sets every engine up, the group's
+    sweeps enqueue on every device before any is waited for, and the group's two engines of
+    C chains ARE chains 0 .. 2C - 1 of one engine of 2C chains, bit for bit"""
+    import boom_amd
+    from cases import bsts_priors, general_data, general_spec, logit_data, probit_slab
+    # ---- bsts: a seasonal block of duration 3, a trend, served from the look-ahead
+    T, p, per, seed = 80, 5, 6, 41
+    X, y, _, obs = general_data(T, p, 2, [(4, 3)], seed=3, missing_frac=0.03)
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    blocks = general_spec(y, [("seasonal", 4, 3), ("trend",)])
+    g0 = np.zeros(p, np.uint8)
+
+    def setup(e):
+        e.ss_set_data(y, X, obs)
+        e.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
+                     sigma_upper_limit=sig_up)
+        e.ss_set_state_models(blocks)
+        e.set_state(g0)
+    grp = boom_amd.Group([0, 0], per, seed=seed)
+    grp.call(setup)
+    grp.call(lambda e: e.ss_set_lookahead(4))
+    one = boom_amd.Engine(2 * per, seed=seed)
+    setup(one)
+    for it in range(9):
+        grp.ss_draw_next()
+        one.ss_sweep(1)
+        go, bo, so = one.get_states()
+        for i, e in enumerate(grp.engines):
+            gg, bg, sg = e.get_states()
+            sl = slice(i * per, (i + 1) * per)
+            assert np.array_equal(gg, go[sl]) and np.array_equal(bg, bo[sl]) and np.array_equal(sg, so[sl]), (it, i)
+    ei, ci = grp.locate(per + 2)
+    assert np.array_equal(grp.engines[ei].ss_get_state_draw(ci), one.ss_get_state_draw(per + 2))
+    grp.ss_sweep(3)
+    one.ss_sweep(3)
+    assert np.array_equal(grp.engines[1].get_states()[1], one.get_states()[1][per:])
+    # an error inside ba_group_call stops the loop and comes out as the engine's error
+    with pytest.raises(boom_amd.BoomAmdError):
+        grp.call(lambda e: e.ss_set_lookahead(0))
+    grp.close()
+    one.close()
+    # ---- logit
+    n, p, per = 600, 12, 8
+    Xl, yl, nt, _ = logit_data(n, p, 3, seed=5)
+    slab, pi = probit_slab(Xl, nt, 3)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+
+    def setup_logit(e):
+        e.logit_set_data(Xl, yl, nt, 5)
+        e.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+        e.set_spike(pi)
+        e.set_state(g0)
+    grp = boom_amd.Group([0, 0], per, seed=seed)
+    grp.call(setup_logit)
+    one = boom_amd.Engine(2 * per, seed=seed)
+    setup_logit(one)
+    grp.logit_sweep(12)
+    one.logit_sweep(12)
+    go, bo, _ = one.get_states()
+    for i, e in enumerate(grp.engines):
+        gg, bg, _ = e.get_states()
+        assert np.array_equal(gg, go[i * per:(i + 1) * per]) and np.array_equal(bg, bo[i * per:(i + 1) * per])

@@ -119,12 +119,14 @@ def test_boom_model_driven_by_the_device_sampler_over_a_device_list(oracle, ndev
 
 @pytest.mark.skipif(not os.path.exists(BINDING_SO),
                     reason="oracle/_ref/libboomref_binding.so is built only where /root/reference exists")
-@pytest.mark.parametrize("max_trials,max_flips", [(1, -1), (3, 7)])
-def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_flips):
+@pytest.mark.parametrize("max_trials,max_flips,ndevices", [(1, -1, 0), (3, 7, 0), (1, -1, 2)])
+def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_flips, ndevices):
     """BOOM's BinomialLogitModel (data added observation by observation), MvnModel slab and
     VariableSelectionPrior, stepped by model->sample_posterior() with
     bindings/boom/DeviceBinomialLogitSpikeSlabSampler attached: what the BOOM model sees
-    after every draw is the oracle's chain 0 on the same Philox key (f3's boundary)."""
+    after every draw is the oracle's chain 0 on the same Philox key (f3's boundary).
+    ndevices > 0: the sampler's device-list constructor (ba_group_*) over a list that names
+    device 0 that many times -- `chains` per entry, global chain ids device-major."""
     from cases import logit_data, probit_slab
     L = C.CDLL(BINDING_SO)
     L.ref_binding_last_error.restype = C.c_char_p
@@ -141,7 +143,7 @@ def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_f
     rc = L.ref_binding_logit_run(
         n, p, _dp(fcol(X)), _dp(f64(y)), _dp(f64(nt)), _dp(f64(slab["mu"])), _dp(fcol(slab["prec"])),
         _dp(f64(pi)), 5, C.c_int(max_flips), chains, C.c_uint64(seed), _u8(g0), nsw, _u8(gam), _dp(beta),
-        C.byref(dev_seed), chains - 1, _u8(pg), _dp(pb))
+        C.byref(dev_seed), max(ndevices, 1) * chains - 1, _u8(pg), _dp(pb), ndevices)
     assert rc == 0, L.ref_binding_last_error().decode()
     o = oracle.logit_run(X, y, nt, slab, pi, ("philox", dev_seed.value, 0), g0, np.zeros(p), nsw,
                          max_flips=max_flips)
@@ -150,8 +152,8 @@ def test_boom_logit_model_driven_by_the_device_sampler(oracle, max_trials, max_f
         assert np.array_equal(gam[s], o["gamma"][s]), s
         err = np.max(np.abs(beta[s] - o["beta"][s]) / np.maximum(np.abs(o["beta"][s]), 1e-3))
         assert err < 1e-8, (s, err)
-    ol = oracle.logit_run(X, y, nt, slab, pi, ("philox", dev_seed.value, chains - 1), g0, np.zeros(p), nsw,
-                          max_flips=max_flips)
+    ol = oracle.logit_run(X, y, nt, slab, pi, ("philox", dev_seed.value, max(ndevices, 1) * chains - 1), g0,
+                          np.zeros(p), nsw, max_flips=max_flips)
     assert np.array_equal(pg, ol["gamma"][-1])
     assert np.max(np.abs(pb - ol["beta"][-1]) / np.maximum(np.abs(ol["beta"][-1]), 1e-3)) < 1e-8
 
@@ -239,6 +241,7 @@ def test_boom_state_space_model_driven_by_the_device_sampler(oracle, trend, nsea
     ([("trend",), ("seasonal", 7, 1), ("seasonal", 4, 7)], 200, 0.03, 8),  # weekly + a 4 x 7 cycle
     ([("seasonal", 4, 3, 2), ("level",), ("ar", 2)], 150, 0.0, 1),         # any order, a first-observation offset
     ([("trend",), ("seasonal", 52, 7)], 400, 0.0, 4),                      # m = 53
+    ([("level",), ("seasonal", 5, 2)], 90, 0.0, -3),                       # a device list of two (look-ahead 3)
 ])
 def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler(oracle, desc, T, missing,
                                                                                  lookahead):
@@ -254,6 +257,11 @@ def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler
     L = C.CDLL(BINDING_SO)
     L.ref_binding_last_error.restype = C.c_char_p
     p, chains, nsw, seed = 6, 5, 13, 777
+    # (a negative look-ahead: the sampler's device-list constructor -- ba_group_* -- over a
+    # list that names device 0 twice, `chains` per entry)
+    ndevices = 2 if lookahead < 0 else 0
+    lookahead = abs(lookahead)
+    last = max(ndevices, 1) * chains - 1
     seas = [(b[1], b[2]) for b in desc if b[0] == "seasonal"]
     X, y, _, obs = general_data(T, p, 2, seas[:2], seed=31 + T, missing_frac=missing,
                                 ar_coef=[0.5] if any(b[0] == "ar" for b in desc) else None,
@@ -282,7 +290,7 @@ def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler
         C.c_double(sig_up), nb, kinds.ctypes.data_as(C.POINTER(C.c_int)),
         ipc.ctypes.data_as(C.POINTER(C.c_int)), _dp(f64(vpar)), _dp(f64(phi0)), _dp(f64(a0)), _dp(f64(P0)),
         chains, C.c_uint64(seed), _u8(g0), nsw, lookahead, _u8(gam), _dp(beta), _dp(sig), _dp(var), _dp(phi),
-        _dp(state), _dp(logpri), C.byref(dev_seed), chains - 1, _u8(pg), _dp(pstate))
+        _dp(state), _dp(logpri), C.byref(dev_seed), last, _u8(pg), _dp(pstate), ndevices)
     assert rc == 0, L.ref_binding_last_error().decode()
 
     def run(c):
@@ -299,7 +307,7 @@ def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler
         scale = np.abs(o["state"][s]).max()
         assert np.max(np.abs(state[s] - o["state"][s])) < 1e-8 * scale, s
     assert np.all(np.isfinite(logpri))
-    ol = run(chains - 1)
+    ol = run(last)
     assert np.array_equal(pg, ol["gamma"][-1])
     assert np.max(np.abs(pstate - ol["state"][-1])) < 1e-8 * np.abs(ol["state"][-1]).max()
 
