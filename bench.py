@@ -255,7 +255,9 @@ def other_configs(boom_amd, torch, device, cpu=True):
                         "algorithmic_bytes_per_launch": round(bytes4, 0),
                         "achieved": round(bytes4 / (ms40 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(bytes4 / (ms40 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "traffic": None},
+                        "traffic": _profile_traffic("c4", "ssvs_sweep_kernel"),
+                        "traffic_source": "profiles/r*_c4_pmc_traffic.json (rocprofv3 --pmc passes of "
+                                          "`bench.py --config 3`, tools/regen_profiles.sh), per 40-sweep launch"},
            "suf_roofline": {"bound": "mfma", "kernel": "xtx_mfma_kernel", "ms": round(suf_ms, 3),
                             "achieved": round(n4 * float(p4) * p4 / (suf_ms * 1e-3) / 1e12, 2),
                             "peak": F64_MATRIX_PEAK_TF, "unit": "TFLOP/s",
@@ -354,7 +356,69 @@ def other_configs(boom_amd, torch, device, cpu=True):
                      "unit": "TFLOP/s", "frac": round(flopsp / (ktp[cols] * 1e-3) / 1e12 / F64_MATRIX_PEAK_TF, 4),
                      "traffic": None},
         "cpu_baseline": None}
+    if cpu:
+        rate, nsw = _cpu_rate(lambda c, n: O.logit_run(Xsub, ysub, ntsub, slabs, pis,
+                                                       ("philox", SAMPLER_SEED, c), g5, np.zeros(p5), n, imputer=1),
+                              th, th, target_s=10.0, first=1)
+        other["configs[4] per GPU with the Polya-Gamma imputer"]["cpu_baseline"] = {
+            "value": round(rate * nsub / n5, 3), "unit": "sweeps/s", "cores": th, "kind": "port",
+            "sample": "%d chains x %d sweeps on %d threads on the FIRST %d of the %d observations with the "
+                      "oracle's Polya-Gamma imputer (bo_logit_set_imputer(1)), rate scaled by %d/%d as for the "
+                      "auxiliary-mixture line" % (th, nsw, th, nsub, n5, nsub, n5)}
     e5.close()
+
+    # ---- SURVEY 8(d)'s dense-posterior variant of configs[1]: the same n=1e4, p=512, 1024
+    # chains with 64 true signals (the models sit at the LDS kernel's 64-variable limit)
+    from cases import regression_data
+    nd, pd_, sigd, Cd = 10000, 512, 64, 1024
+    Xd, yd, _ = regression_data(nd, pd_, sigd, seed=DATA_SEED)
+    ed = boom_amd.Engine(Cd, seed=SAMPLER_SEED, device=device)
+    ed.build_suf_from_xy(Xd, yd)
+    sd = ed.get_suf()
+    sufd = dict(xtx=sd["xtx"], xty=sd["xty"], yty=sd["yty"], n=sd["n"], sumy=sd["ybar"] * sd["n"],
+                xsum=sd["xbar"] * sd["n"])
+    prd = spike_slab_prior(sufd, sigd)
+    ed.set_priors(prd["b"], prd["ominv"], prd["pi"], prd["df"], prd["sigma_guess"])
+    gd = np.zeros(pd_, np.uint8)
+    gd[0] = 1
+    ed.set_state(gd)
+    ed.sweep(200)
+    ed.reset_summaries()
+    t0 = time.perf_counter()
+    ed.sweep(200)
+    dtd = time.perf_counter() - t0
+    smd = ed.get_summaries()
+    kd = smd["k_sum"] / smd["sweeps"]
+    gamd, betad, sigdv = ed.get_states()
+    ed.set_kernel_timing(True)
+    ed.sweep(200)
+    ktd = ed.kernel_times()
+    ed.set_kernel_timing(False)
+    msd = sum(ms for ms, _ in ktd.values())
+    bytesd = (pd_ * 8.0 * (2 * kd + 4) + 8.0 * (3 * kd + 4) + pd_ / 8.0) * Cd * 200
+    recd = {"sweeps_per_s": round(Cd * 200 / dtd, 1), "us_per_sweep_round": round(dtd / 200 * 1e6, 1),
+            "mean_model_size": round(float(kd), 2),
+            "signal_inclusion_min": round(float(gamd[:, :sigd].mean(0).min()), 4),
+            "kernel_ms_per_200_sweep_launch": {k: round(ms, 3) for k, (ms, _) in ktd.items()},
+            "roofline": {"bound": "hbm", "kernel": max(ktd, key=lambda k: ktd[k][0]),
+                         "algorithmic_bytes_per_launch": round(bytesd, 0),
+                         "achieved": round(bytesd / (msd * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(bytesd / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": _profile_traffic("dense64", "ssvs_")}}
+    if cpu:
+        def rund(nchains, nsw, nthreads):
+            t0 = time.perf_counter()
+            O.run_chains(sufd, prd, ssvs_options(), SAMPLER_SEED, nchains, nsw, nthreads,
+                         gamd[0], betad[0], float(sigdv[0]))
+            return nchains * nsw / (time.perf_counter() - t0)
+        cal = rund(cores, 10, cores)
+        nsw = int(max(10, min(2000, 6.0 * cal / cores)))
+        rate = rund(cores, nsw, cores)
+        recd["cpu_baseline"] = {"value": round(rate, 2), "unit": "sweeps/s", "cores": cores, "kind": "port",
+                                "sample": "%d chains x %d sweeps on %d pthreads, warm-started at a GPU chain's "
+                                          "state (kbar~%.1f), same statistics" % (cores, nsw, cores, kd)}
+    other["dense_variant_64_signals (configs[1] data shape, 64 true signals)"] = recd
+    ed.close()
     return other
 
 
@@ -854,8 +918,9 @@ def main():
                          "correlation map shared by the threads" % (nchains, nswc, cores, nsw1, kbar),
                "port_vs_reference": "2.2x faster than the compiled reference per thread in the "
                                     "build container (317 vs 146 sweeps/s at this shape, 8-core "
-                                    "container; on the GPU box the compiled reference is loaded by the tests "
-                                    "only -- reference-side binding, goldens -- and is not timed there)"}
+                                    "container; the compiled reference travels to the GPU box as a BUILT "
+                                    "file -- git-ignored, not gpurun-ignored -- and is loaded there by the "
+                                    "tests only: reference-side binding, goldens; it is not timed there)"}
 
     out = {
         "metric": "Gibbs sweeps/sec (all chains), n=1e4 p=512 spike-slab",

@@ -26,7 +26,13 @@ namespace BOOM {
     ba_engine *engine = nullptr;
     check(ba_engine_create(&cfg, &engine));
     engines_.push_back(engine);
-    configure(slab, residual_precision_prior, spike, lookahead);
+    try {   // (report_error throws and a throwing constructor runs no destructor: nothing may leak)
+      configure(slab, residual_precision_prior, spike, lookahead);
+    } catch (...) {
+      ba_engine_destroy(engine);
+      engines_.clear();
+      throw;
+    }
   }
 
   DeviceBregVsSampler::DeviceBregVsSampler(
@@ -49,7 +55,14 @@ namespace BOOM {
     for (int32_t i = 0; i < ba_group_size(group_); ++i) {
       engines_.push_back(ba_group_engine(group_, i));
     }
-    configure(slab, residual_precision_prior, spike, lookahead);
+    try {
+      configure(slab, residual_precision_prior, spike, lookahead);
+    } catch (...) {
+      ba_group_destroy(group_);
+      group_ = nullptr;
+      engines_.clear();
+      throw;
+    }
   }
 
   void DeviceBregVsSampler::configure(

@@ -23,6 +23,7 @@ namespace BOOM {
     device_seed_ = seed_rng(seeding_rng);
     ba_config cfg{device, chains, 0, static_cast<uint64_t>(device_seed_), 0, 0};
     check(ba_engine_create(&cfg, &engine_));
+    try {   // (report_error throws and a throwing constructor runs no destructor: the engine must not leak)
     // model->dat(): one PoissonRegressionData per observation -> column-major X, y, exposure
     const std::vector<Ptr<PoissonRegressionData>> &data(model->dat());
     const size_t n = data.size();
@@ -68,6 +69,11 @@ namespace BOOM {
     const Vector pi = spike->prior_inclusion_probabilities();
     check(ba_set_spike(engine_, pi.data(), spike->max_model_size()));
     push_state();
+    } catch (...) {
+      ba_engine_destroy(engine_);
+      engine_ = nullptr;
+      throw;
+    }
   }
 
   DevicePoissonRegressionSpikeSlabSampler::~DevicePoissonRegressionSpikeSlabSampler() {

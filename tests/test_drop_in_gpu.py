@@ -268,6 +268,37 @@ def test_overlapping_sweep_launches_hand_chains_over(oracle):
     assert abs(sig[chains - 1] - o["sigsq"][-1]) < 1e-8 * sig[chains - 1]
 
 
+def test_a_prior_change_between_two_unsynced_sweeps_joins_the_pipeline():
+    """ba_sweep; ba_sweep; ba_set_spike; ba_sweep with nothing synced in between.
+    The second launch is still running on the other stream when the setter arrives: it must
+    be behind the main stream before the shared prior arrays are overwritten, or it reads
+    half of the new values.  Same chains as the synced sequence, bit for bit."""
+    suf, prior, g0 = _case(p=64, nsig=6, seed=17, n=2000)
+    chains = 96
+    a = make_engine(chains, 123, suf=suf, prior=prior, g0=g0)
+    b = make_engine(chains, 123, suf=suf, prior=prior, g0=g0)
+    pi2 = np.clip(prior["pi"] * 3.0, 0.0, 1.0)
+    for rep in range(3):
+        a.sweep(40, sync=False)
+        a.sweep(40, sync=False)
+        a.set_spike(pi2 if rep % 2 == 0 else prior["pi"])        # (no sync: the launches overlap)
+        a.sweep(25, sync=False)
+        a.set_options(max_flips=20 if rep == 1 else -1)
+        a.sweep(10, sync=False)
+    a.sync()
+    for rep in range(3):
+        b.sweep(40)
+        b.sweep(40)
+        b.set_spike(pi2 if rep % 2 == 0 else prior["pi"])
+        b.sweep(25)
+        b.set_options(max_flips=20 if rep == 1 else -1)
+        b.sweep(10)
+    for u, v in zip(a.get_states(), b.get_states()):
+        assert np.array_equal(u, v)
+    sa, sb = a.get_summaries(), b.get_summaries()
+    assert np.array_equal(sa["inclusion_count"], sb["inclusion_count"])
+
+
 def test_overlapping_lookahead_batches_serve_the_per_call_draws():
     """the callers' loop as they write it -- draw_next(); get_state(0) -- over many batches:
     the batch after the one being served is already running (handing chains over launch to
