@@ -437,8 +437,9 @@ class Engine:
         return self.lib.ba_stream(self._h)
 
     # ---- measurement ----------------------------------------------------------
-    def set_kernel_timing(self, enabled=True):
-        self._check(self.lib.ba_set_kernel_timing(self._h, int(enabled)))
+    def set_kernel_timing(self, enabled=True, overlap=False):
+        """overlap=True: consecutive sweep launches still overlap while timed (mode 2)"""
+        self._check(self.lib.ba_set_kernel_timing(self._h, 2 if (enabled and overlap) else int(enabled)))
 
     def kernel_times(self, reset=True):
         """{kernel class: (milliseconds, launches)} since the last reset"""

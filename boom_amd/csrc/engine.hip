@@ -206,6 +206,7 @@ void kt_mark(hipStream_t stream, int cls, bool begin) {
 struct ba_engine {
   ba_config cfg{};
   bool kt_enabled = false;
+  bool kt_overlap = false;   // (timing on, consecutive sweep launches still overlap: ba_set_kernel_timing(e, 2))
   KTimer kt;
   hipStream_t stream = nullptr;
   int p = 0;
@@ -1856,6 +1857,7 @@ int ba_set_kernel_timing(ba_engine *e, int32_t enabled) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->kt.collect();
   e->kt_enabled = enabled != 0;
+  e->kt_overlap = enabled == 2;
   g_kt = e->kt_enabled ? &e->kt : nullptr;
   return BA_OK;
 }
@@ -2463,7 +2465,7 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record, int la_half) {
   // recorded (its cursor is reset per call) and no chain lives in the large-model kernel.
   const int resident_per_cu = (int)std::min<size_t>(4, e->lds_per_cu / lay.total);
   const bool pipelined = BA_PIPELINE && nsweeps > 0 && (e->trace_stride == 0 || la_half >= 0) && !e->big_active &&
-                         e->cfg.chains <= resident_per_cu * e->cu_count && !e->kt_enabled;
+                         e->cfg.chains <= resident_per_cu * e->cu_count && (!e->kt_enabled || e->kt_overlap);
   if (la_half >= 0 && !pipelined) return fail(BA_E_STATE, "look-ahead batch cannot overlap");
   if (!pipelined) {
     int rcj = pipe_join(e);
@@ -2560,7 +2562,7 @@ int ba_set_lookahead(ba_engine *e, int32_t lookahead) {
 
 // can the next look-ahead batch overlap its neighbours (sweep_impl's conditions)
 static bool la_can_overlap(const ba_engine *e) {
-  if (!BA_PIPELINE || !e->la_pipe || e->big_active || e->kt_enabled || e->kcap <= 0) return false;
+  if (!BA_PIPELINE || !e->la_pipe || e->big_active || (e->kt_enabled && !e->kt_overlap) || e->kcap <= 0) return false;
   const size_t lds = ssvs_lds_layout(e->p, e->kcap).total;
   if (lds > e->lds_per_cu) return false;
   const int resident_per_cu = (int)std::min<size_t>(4, e->lds_per_cu / lds);

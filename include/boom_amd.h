@@ -387,7 +387,9 @@ void *ba_stream(ba_engine *e);
  * ba_kernel_classes() entries; either may be NULL).  A sweep round that is several
  * kernels (bsts: SSVS + Kalman + X'e GEMM) is timed kernel by kernel this way;
  * bench.py's roofline objects come from here.  Disabled (the default) it costs
- * nothing; it never changes a draw. */
+ * nothing; it never changes a draw.  enabled = 1 also keeps consecutive ba_sweep launches
+ * apart (one launch at a time: clean per-kernel figures); enabled = 2 lets them overlap as
+ * they do untimed (each launch's pair sits on the stream the launch went to). */
 int32_t ba_kernel_classes(void);
 const char *ba_kernel_class_name(int32_t cls);
 int ba_set_kernel_timing(ba_engine *e, int32_t enabled);
