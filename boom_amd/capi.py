@@ -579,8 +579,12 @@ class Engine:
         self._ssm_dim = m.value
         self._ar_lags = 0
 
-    def ss_set_tuning(self, use_template_kernel=True):
-        self._check(self.lib.ba_ss_set_tuning(self._h, 1 if use_template_kernel else 0))
+    def ss_set_tuning(self, use_template_kernel=True, kernel=None):
+        """kernel: 0 general, 1 the default choice, 2 four chains per wavefront (m <= 16),
+        3 compiled for the shape (where it applies)"""
+        if kernel is None:
+            kernel = 1 if use_template_kernel else 0
+        self._check(self.lib.ba_ss_set_tuning(self._h, int(kernel)))
 
     def ss_get_state_model(self, chain, block, suf=True):
         """suf=False: the variance parameters / coefficients only"""

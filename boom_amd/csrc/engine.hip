@@ -386,7 +386,7 @@ struct ba_engine {
   // the template of ba_ss_set_structural (level / slope / seasonal -> variance index, -1: none)
   int ssg_template_var[3] = {-1, -1, -1};
   int ssg_template_ar = -1;        // ... and the block ba_ss_add_ar appended
-  bool ssg_use_template = true;    // (ba_set_tuning: the shape-specialised kernel where it applies)
+  int ssg_kernel_choice = 1;       // (ba_ss_set_tuning: 0 general, 1 the default choice, 2 packed, 3 shape-specialised)
   DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;   // chains x SSG_MAX_VAR (sigsq, n, ss)
   DevBuf<double> dar_phi, dar_suf;                         // chains x SSG_MAX_AR x (AR_MAX | AR_SUF_STRIDE)
   DevBuf<uint64_t> dpos_var;                               // chains x SSG_MAX_VAR
@@ -991,7 +991,9 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
     S.ssm.ld = e->ssg.ld;
     S.ssm.bl = e->ssg.bl;
     S.ssm.nerr = e->ssg.nerr;
-    if (e->ssg_use_template) ssg_template_shape(e->ssg, &S.ssm.tpl_trend, &S.ssm.tpl_nseasons, &S.ssm.tpl_ar_lags);
+    if (e->ssg_kernel_choice == 1 || e->ssg_kernel_choice == 3)
+      ssg_template_shape(e->ssg, &S.ssm.tpl_trend, &S.ssm.tpl_nseasons, &S.ssm.tpl_ar_lags);
+    S.ssm.packed = (e->ssg_kernel_choice == 2 && e->ssg.m <= 16) ? 1 : 0;
     S.ssm.var_sigsq = e->dssm_sigsq.ptr;
     S.ssm.var_n = e->dssm_n.ptr;
     S.ssm.var_ss = e->dssm_ss.ptr;
@@ -3740,11 +3742,11 @@ extern "C" {
 
 // diagnostic, changes no draw: 0 = the general kernel also where the shape-specialised one
 // applies (the two are compared by the tests), 1 = the default
-int ba_ss_set_tuning(ba_engine *e, int32_t use_template_kernel) {
+int ba_ss_set_tuning(ba_engine *e, int32_t kernel) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  if (use_template_kernel != 0 && use_template_kernel != 1) return fail(BA_E_INVALID, "use_template_kernel must be 0 or 1");
+  if (kernel < 0 || kernel > 3) return fail(BA_E_INVALID, "kernel must be 0 .. 3");
   MUTATE(e);
-  e->ssg_use_template = use_template_kernel != 0;
+  e->ssg_kernel_choice = kernel;
   return BA_OK;
 }
 

@@ -455,10 +455,11 @@ int ba_ss_add_state_model(ba_engine *e, int32_t kind, const int32_t *iparams,
                           const double *var_initial_sigma, const double *initial_phi,
                           const double *initial_state_mean,
                           const double *initial_state_variance);
-/* diagnostic, changes no draw: block lists of the shape [level | trend] [+ seasonal of
- * duration 1] [+ one autoregression] with m <= 16 run a kernel compiled for the shape;
- * use_template_kernel = 0 sends them through the general kernel too (default 1) */
-int ba_ss_set_tuning(ba_engine *e, int32_t use_template_kernel);
+/* which kernel draws the state (changes no draw): 0 = the general kernel, one chain per
+ * workgroup; 2 = four chains per wavefront (state dimension <= 16; the general kernel
+ * beyond); 3 = the kernel compiled for the shape [level | trend] [+ seasonal of duration 1]
+ * [+ one autoregression] with m <= 16 where the list has that shape; 1 = the default choice */
+int ba_ss_set_tuning(ba_engine *e, int32_t kernel);
 /* the state dimension and the number of state models of the specification */
 int ba_ss_state_dimension(ba_engine *e, int32_t *state_dimension, int32_t *nblocks);
 /* state model `block` of one chain: its variance parameters (nvar), the model's

@@ -10,8 +10,15 @@ import boom_amd
 from cases import bsts_priors, structural_data, structural_spec
 
 T, p, nsig = 2000, 100, 5
-# arguments: trend,nseasons,chains[,ar lags]
-for spec_arg in [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or ((1, 0, 1024), (2, 0, 1024), (2, 7, 1024), (2, 12, 1024), (2, 12, 4096), (2, 12, 1024, 2)):
+# arguments: [--kernel=K] trend,nseasons,chains[,ar lags]
+KERNEL = 1
+args = []
+for a in sys.argv[1:]:
+    if a.startswith("--kernel="):
+        KERNEL = int(a.split("=")[1])
+    else:
+        args.append(a)
+for spec_arg in [tuple(int(v) for v in a.split(",")) for a in args] or ((1, 0, 1024), (2, 0, 1024), (2, 7, 1024), (2, 12, 1024), (2, 12, 4096), (2, 12, 1024, 2)):
     trend, ns, chains = spec_arg[:3]
     lags = spec_arg[3] if len(spec_arg) > 3 else 0
     X, y, btrue, _ = structural_data(T, p, nsig, ns, seed=8675309, ar_coef=[1.2, -0.4][:lags] if 0 < lags <= 2 else ([0.2] * lags if lags else None))
@@ -30,11 +37,16 @@ for spec_arg in [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or (
         eng.ss_add_ar(lags, ar["df"], ar["sigma_guess"], ar["sigma_upper_limit"], ar["initial_sigma"],
                       ar["initial_phi"], spec["initial_state_mean"][m0:], spec["initial_state_variance"][m0:])
     eng.set_state(np.zeros(p, np.uint8))
+    eng.ss_set_tuning(kernel=KERNEL)
+    eng.set_kernel_timing(True)
     eng.ss_sweep(20)
+    eng.kernel_times()
     n = 30
     t0 = time.perf_counter()
     eng.ss_sweep(n)
     dt = time.perf_counter() - t0
     gam, beta, sig = eng.get_states()
-    print("trend %d nseasons %2d ar %d (m=%2d) chains %4d: %8.1f us per sweep-round, %.3g sweeps/s, kbar %.2f"
-          % (trend, ns, lags, m0 + lags, chains, dt / n * 1e6, chains * n / dt, gam.sum(1).mean()))
+    kt = eng.kernel_times()
+    print("kernel %d trend %d nseasons %2d ar %d (m=%2d) chains %4d: %8.1f us per sweep-round, %.3g sweeps/s, kbar %.2f; state kernel %s"
+          % (KERNEL, trend, ns, lags, m0 + lags, chains, dt / n * 1e6, chains * n / dt, gam.sum(1).mean(),
+             {k: v for k, v in kt.items() if "ssm" in k.lower() or "state" in k.lower()}))
