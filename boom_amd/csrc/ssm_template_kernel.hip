@@ -55,6 +55,7 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int SSM_MAX = 16;        // the template's state dimension limit (= AR_MAX)
 constexpr int PLD = SSM_MAX + 1;   // leading dimension of the state variance in LDS
+constexpr int V_FAILED = 1 << 30;  // s_vprog: the variance pass stopped (F <= 0)
 
 // the template's view of the general specification / storage (no arrays: an index the
 // compiler does not see as a constant would put them in scratch memory)
@@ -412,10 +413,10 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   };
   __shared__ SharedLds s_lds;
   __shared__ int s_flag;
+  __shared__ int s_vprog;                 // blocks of 64 steps the variance pass has put out (wave 1 -> wave 0)
   __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
   double (&s_P)[SSM_MAX * PLD] = s_lds.pass.P;
-  double (&s_tv)[SSM_MAX] = s_lds.pass.tv;
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;
   if (P.status[chain] != CHAIN_OK) return;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   S.a0 = AR ? Q.ar0 : 0; S.na = AR ? Q.ar_lags : 0;
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
   int status = CHAIN_OK;
-  if (threadIdx.x == 0) s_flag = CHAIN_OK;
+  if (threadIdx.x == 0) { s_flag = CHAIN_OK; s_vprog = 0; }
 #ifdef BA_KSTAMPS
   long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
 #define SSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
@@ -579,16 +580,24 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   // produces goes out in one coalesced piece.
   if (wave == 1) {
     // P lives in LDS (s_P[row * PLD + column], PLD = 17: a lane per column and a lane per
-    // row are both free of bank conflicts; both indices in the rotating
-    // layout, kept exactly symmetric): the rows and columns a step touches move
-    // with the cursor, which registers cannot follow.  Lane k < m owns column k;
-    // the rank-one update runs over all 256 entries on all 64 lanes.
+    // row are both free of bank conflicts; both indices in the rotating layout): the rows
+    // and columns a step touches move with the cursor, which registers cannot follow.
+    // A step is P <- T (P - PZ PZ' / F) T' + RQR in TWO phases (the predicted form of
+    // round 3 took seven LDS round trips a step, and the pass is bound by exactly those):
+    //   column phase: lane k reads ITS column, takes the rank-one term off all of it
+    //     ((PZ_i PZ_k) / F: the same product in entry (i, k) and (k, i)) and applies T from the
+    //     left -- the trend's row 0 += row 1, the seasonal block's new first row;
+    //   row phase: lane k reads the entries of ITS row that T' from the right touches, and
+    //     what it writes -- P'(k, 0), P'(k, new first seasonal), P'(k, first lag) -- is
+    //     PZ_k of the next step (P is symmetric), which therefore needs no read of its own.
     for (int e = lane; e < SSM_MAX * PLD; e += WAVE) s_P[e] = 0.0;
-    if (lane < SSM_MAX) s_tv[lane] = 0.0;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     if (mylane) s_P[lane * (PLD + 1)] = P0l;
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     int c = 0;
+    const int col = mylane ? lane : 0;
+    // PZ_k of step 0: P0 is diagonal
+    double PZ = (mylane && (lane == 0 || (SEAS && lane == S.s0) || (AR && lane == S.a0))) ? P0l : 0.0;
     for (int tb = 0; tb < T; tb += WAVE) {
       const int tt = tb + lane;
       const int ob_l = (tt < T && P.observed[tt]) ? 1 : 0;
@@ -598,103 +607,111 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       for (int s = 0; s < nstep; ++s) {
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
         const int cn = SEAS ? cursor_prev(c, S.ns) : 0;   // the next layout's cursor
-        const int rc = S.s0 + c, rw = S.s0 + cn;          // rows / columns of the current and the new first component
-        // PZ_k = P(k, 0) + P(k, first seasonal) = P(0, k) + P(first seasonal, k)
-        double PZ = 0.0;
-        if (mylane) {
-          PZ = s_P[lane];
-          if (SEAS) PZ += s_P[rc * PLD + lane];
-          if (AR) PZ += s_P[S.a0 * PLD + lane];
-        }
+        const int rw = S.s0 + cn;                          // row / column of the new first seasonal component
         const double F = zdot<SEAS, AR>(S, PZ, c) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
+        const double Finv = 1.0 / F;
         const double TPZ = vecT<TREND, SEAS, AR>(S, PZ, lane, c, phl);
-        const double K = obs ? TPZ / F : 0.0;
-        if (mylane) {
-          blk[s * m + lane] = K;
-          s_tv[lane] = TPZ;
-        }
+        if (mylane) blk[s * m + lane] = obs ? TPZ * Finv : 0.0;
         if (lane == s) F_l = F;
-        // T P T' -- the trend block: row 0 += row 1, then column 0 += column 1
-        if (TREND == 2) {
-          if (mylane) s_P[lane] = s_P[lane] + s_P[PLD + lane];
-          __builtin_amdgcn_wave_barrier();
-          if (mylane) s_P[lane * PLD] = s_P[lane * PLD] + s_P[lane * PLD + 1];
-          __builtin_amdgcn_wave_barrier();
-        }
-        // -- the seasonal block: the row / column of the component that drops out
-        // becomes that of the new first component, -sum over the block
-        if (SEAS) {
-          // (every load issued before the first use, from addresses that are valid whatever
-          // the block's size: fifteen guarded load-and-subtract steps each waited for their
-          // own LDS round trip)
+        // -- the column phase
+        {
+          double v[SSM_MAX];
+#pragma unroll
+          for (int i = 0; i < SSM_MAX; ++i) v[i] = s_P[i * PLD + col];
+          if (obs) {
+#pragma unroll
+            for (int i = 0; i < SSM_MAX; ++i) v[i] -= (rl(PZ, i) * PZ) * Finv;
+          }
+          if (TREND == 2) v[0] += v[1];
           double cs = 0.0;
-          {
-            double v[SSM_MAX - 1];
-            const int col = mylane ? lane : 0;
+          if (SEAS) {
+            double t[SSM_MAX];
 #pragma unroll
-            for (int q = 0; q < SSM_MAX - 1; ++q) v[q] = s_P[(TREND + (q < S.ns ? q : 0)) * PLD + col];
-#pragma unroll
-            for (int q = 0; q < SSM_MAX - 1; ++q) cs -= (q < S.ns) ? v[q] : 0.0;
-            if (!mylane) cs = 0.0;
+            for (int q = 0; q < SSM_MAX; ++q) t[q] = (q < S.ns && TREND + q < SSM_MAX) ? v[(TREND + q) & (SSM_MAX - 1)] : 0.0;
+            cs = -((((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                   (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]))));
           }
-          const double tot = row_total(S.seasonal(lane) ? cs : 0.0);
-          __builtin_amdgcn_wave_barrier();
           if (mylane) {
-            s_P[rw * PLD + lane] = cs;
-            s_P[lane * PLD + rw] = cs;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (lane == rw) s_P[rw * (PLD + 1)] = -tot;
-          __builtin_amdgcn_wave_barrier();
-        }
-        // -- the autoregression block (logical order): T P, then (T P) T'.  Lane k owns
-        // column k of the block's rows, then row k of the block's columns; either way
-        // it reads and writes its own entries only, and a symmetric P stays symmetric
-        // (P'(a0, k) and P'(k, a0) are the same sum in the same order).
-        if (AR) {
+            if (obs) {
 #pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
+              for (int i = 0; i < SSM_MAX; ++i) s_P[i * PLD + lane] = v[i];
+            } else if (TREND == 2) {
+              s_P[lane] = v[0];
+            }
+            if (SEAS) s_P[rw * PLD + lane] = cs;
+          }
+          wave_lds_sync();
+          if (AR) {
+            // the autoregression block's rows (logical order): from the last lag down, moving each
+            // entry one place on as it is read
             if (mylane) {
-              const int sr = pass == 0 ? PLD : 1, sc = pass == 0 ? 1 : PLD;   // strides along / across the block
-              // from the last lag down, moving each entry one place on as it is read (a
-              // rolled loop: fifteen guarded copies of its body cost 3 400 cycles a step)
-              double cs = 0.0;
+              double ca = 0.0;
 #pragma nounroll
               for (int q = S.na - 1; q >= 0; --q) {
-                const double v = s_P[(S.a0 + q) * sr + lane * sc];
-                cs += s_phi[q] * v;
-                if (q + 1 < S.na) s_P[(S.a0 + q + 1) * sr + lane * sc] = v;
+                const double x = s_P[(S.a0 + q) * PLD + lane];
+                ca += s_phi[q] * x;
+                if (q + 1 < S.na) s_P[(S.a0 + q + 1) * PLD + lane] = x;
               }
-              s_P[S.a0 * sr + lane * sc] = cs;
+              s_P[S.a0 * PLD + lane] = ca;
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
           }
         }
-        // - TPZ K' at an observed step (as (TPZ_i TPZ_j) / F: exactly symmetric)
-        if (obs) {
-          const double Finv = 1.0 / F;
+        // -- the row phase
+        {
+          double *row = s_P + col * PLD;
+          const double w0 = row[0];
+          double n0 = w0;
+          if (TREND == 2) {
+            const double w1 = row[1];
+            n0 = w0 + w1;
+            if (lane == 1) row[1] = w1 + sig2[1];
+          }
+          if (lane == 0) n0 += sig2[0];
+          double nz = n0;
+          if (SEAS) {
+            double t[SSM_MAX];
 #pragma unroll
-          for (int e4 = 0; e4 < SSM_MAX * SSM_MAX / WAVE; ++e4) {
-            const int e = lane + WAVE * e4;
-            const int i = e >> 4, k2 = e & 15;
-            if (i < m && k2 < m) s_P[i * PLD + k2] -= (s_tv[i] * s_tv[k2]) * Finv;
+            for (int q = 0; q < SSM_MAX; ++q) t[q] = (q < S.ns && TREND + q < SSM_MAX) ? row[(TREND + q) & (SSM_MAX - 1)] : 0.0;
+            double cr = -((((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                          (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]))));
+            if (lane == rw) cr += sig2[2];
+            if (mylane) row[rw] = cr;
+            nz += cr;
           }
-          __builtin_amdgcn_wave_barrier();
+          if (AR) {
+            double ca = 0.0;
+            if (mylane) {
+#pragma nounroll
+              for (int q = S.na - 1; q >= 0; --q) {
+                const double x = row[S.a0 + q];
+                ca += s_phi[q] * x;
+                if (q + 1 < S.na) row[S.a0 + q + 1] = x;
+              }
+              if (lane == S.a0) ca += sig2a;
+              row[S.a0] = ca;
+            }
+            nz += ca;
+          }
+          if (mylane && (TREND == 2 || lane == 0)) row[0] = n0;
+          PZ = mylane ? nz : 0.0;
+          wave_lds_sync();
         }
-        // + RQR
-        if (lane == 0) s_P[0] += sig2[0];
-        if (TREND == 2 && lane == 1) s_P[PLD + 1] += sig2[1];
-        if (SEAS && lane == rw) s_P[rw * (PLD + 1)] += sig2[2];
-        if (AR && lane == S.a0) s_P[S.a0 * (PLD + 1)] += sig2a;
-        __builtin_amdgcn_wave_barrier();
         c = cn;
       }
       if (status != CHAIN_OK) break;
       blk_store(gK + (size_t)tb * m, blk, nstep * m, lane);
       if (tt < T) sres[tt] = F_l;
+      // the block is out: the filter (wave 0, once it has simulated) follows a block behind
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&s_vprog, tb / WAVE + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (status != CHAIN_OK && lane == 0) s_flag = status;
+    if (status != CHAIN_OK && lane == 0) {
+      s_flag = status;
+      __hip_atomic_store(&s_vprog, V_FAILED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
   } else {
     double alpha = 0.0;
     int c = 0;
@@ -748,15 +765,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     }
   }
   SSTAMP(3);
-  __threadfence_block();
-  __syncthreads();
   SSTAMP(4);
-  status = s_flag;
-  if (status != CHAIN_OK) {
-    if (threadIdx.x == 0) P.status[chain] = status;
-    return;
-  }
-  if (wave != 0) return;
 
   // ---- 3b. the filter on w = y* - y+ (the data filter minus the simulation
   // filter; they share the gains): v - v+ = w - Z'(a - a+); a - a+ <- T (a - a+) + K (v - v+)
@@ -767,6 +776,14 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       const int tt = tb + lane;
       const bool in_l = tt < T;
       const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      // (the gains and F_t of this block: wave 1 is somewhere ahead, or about to be)
+      int vp;
+      while ((vp = __hip_atomic_load(&s_vprog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= tb / WAVE)
+        __builtin_amdgcn_s_sleep(8);
+      if (vp == V_FAILED) {
+        if (lane == 0) P.status[chain] = __hip_atomic_load(&s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
       blk_load(blk, gK + (size_t)tb * m, nstep * m, lane);
       const double w_l = in_l ? w0[tt] : 0.0, F_l = in_l ? sres[tt] : 1.0;
       const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
