@@ -414,6 +414,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   __shared__ SharedLds s_lds;
   __shared__ int s_flag;
   __shared__ int s_vprog;                 // blocks of 64 steps the variance pass has put out (wave 1 -> wave 0)
+  __shared__ int s_cprog, s_cdone;        // the last pass: blocks of state draws wave 0 has made / wave 1 has taken
   __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
   double (&s_P)[SSM_MAX * PLD] = s_lds.pass.P;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   S.a0 = AR ? Q.ar0 : 0; S.na = AR ? Q.ar_lags : 0;
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
   int status = CHAIN_OK;
-  if (threadIdx.x == 0) { s_flag = CHAIN_OK; s_vprog = 0; }
+  if (threadIdx.x == 0) { s_flag = CHAIN_OK; s_vprog = 0; s_cprog = 0; s_cdone = 0; }
 #ifdef BA_KSTAMPS
   long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
 #define SSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
@@ -707,11 +708,13 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&s_vprog, tb / WAVE + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (status != CHAIN_OK && lane == 0) {
-      s_flag = status;
-      __hip_atomic_store(&s_vprog, V_FAILED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (status != CHAIN_OK) {
+      if (lane == 0) {
+        s_flag = status;
+        __hip_atomic_store(&s_vprog, V_FAILED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      return;
     }
-    return;
   } else {
     double alpha = 0.0;
     int c = 0;
@@ -767,6 +770,8 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   SSTAMP(3);
   SSTAMP(4);
 
+  double r = 0.0;
+  if (wave == 0) {
   // ---- 3b. the filter on w = y* - y+ (the data filter minus the simulation
   // filter; they share the gains): v - v+ = w - Z'(a - a+); a - a+ <- T (a - a+) + K (v - v+)
   {
@@ -808,7 +813,6 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   // ---- 4. backward: fast_disturbance_smooth for d = r - r+:
   // r_{t-1} = T' r_t + Z ((v_t - v+_t) / F_t - K_t' r_t), r_{T-1} = 0.  r_t is in the
   // layout of step t + 1.
-  double r = 0.0;
   for (int tb = ((T - 1) / WAVE) * WAVE; tb >= 0; tb -= WAVE) {
     const int tt = tb + lane;
     const bool in_l = tt < T;
@@ -845,41 +849,33 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
 
+  }
   SSTAMP(6);
   // ---- 5. forward: the mean correction E(alpha | y) - E(alpha | y+), the state
-  // draw, the state models' and the regression's sufficient statistics
-  double mc = P0l * r;          // a0 + P0 r0 - (a0 + P0 r0+)
-  double prev = 0.0;            // state_{t-1} (its own layout)
-  double suf0 = 0.0, suf2 = 0.0;
-  double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of the trend errors (lanes 0, 1)
-  double yty = 0.0, nobs = 0.0;
-  // ArModel's NeRegSuf of now[a0] on then[a0 ..]: lane a0 + i keeps xty_i and row i of xtx,
-  // the row in LDS (s_P is free by now: wave 1 has left), at s_axx[i * PLD + q]
-  double axy = 0.0, ayy = 0.0;
-  double *s_axx = s_P;
-  if (AR) {
-    for (int e2 = lane; e2 < SSM_MAX * PLD; e2 += WAVE) s_axx[e2] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-  }
-  double *oblk = s_blk[1];
-  {
+  // draw, the state models' and the regression's sufficient statistics -- by BOTH waves:
+  // wave 0 runs the recursion of the correction and turns a block of alpha+ (LDS) into the
+  // block of state draws; wave 1 (its variance pass long over) follows one block behind with
+  // everything that only READS the draws: the state models' sufficient statistics, the
+  // residuals, the copy in logical order that goes out.  Two block buffers take turns.
+  if (wave == 0) {
+    double mc = P0l * r;          // a0 + P0 r0 - (a0 + P0 r0+)
     int c = 0;
     for (int tb = 0; tb < T; tb += WAVE) {
-      const int tt = tb + lane;
+      const int tt = tb + lane, b = tb / WAVE;
       const bool in_l = tt < T;
       const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
-      blk_load(blk, gst + (size_t)tb * m, nstep * m, lane);
+      double *buf = s_blk[b & 1];
+      while (__hip_atomic_load(&s_cdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < b - 1)
+        __builtin_amdgcn_s_sleep(4);
+      blk_load(buf, gst + (size_t)tb * m, nstep * m, lane);
       const bool dd = in_l && tt > 0;
       const double d0_l = dd ? gd[tt - 1] : 0.0;
       const double d1_l = (dd && TREND == 2) ? gd[(size_t)T + tt - 1] : 0.0;
       const double d2_l = (dd && SEAS) ? gd[(size_t)2 * T + tt - 1] : 0.0;
       const double d3_l = (dd && AR) ? gd[(size_t)3 * T + tt - 1] : 0.0;
-      const double y_l = in_l ? P.y[tt] : 0.0;
-      const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
-      double res_l = 0.0;
 #pragma nounroll
       for (int s = 0; s < nstep; ++s) {
-        const double ap = mylane ? blk[s * m + lane] : 0.0;
+        const double ap = mylane ? buf[s * m + lane] : 0.0;
         if (tb + s > 0) {
           const int cn = SEAS ? cursor_prev(c, S.ns) : 0;
           mc = vecT<TREND, SEAS, AR>(S, mc, lane, c, phl);
@@ -889,7 +885,49 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           if (AR) { if (lane == S.a0) mc += sig2a * rl(d3_l, s); }
           c = cn;
         }
-        const double st = mylane ? ap + mc : 0.0;
+        if (mylane) buf[s * m + lane] = ap + mc;
+      }
+      wave_lds_sync();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&s_cprog, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    SSTAMP(7);
+#ifdef BA_KSTAMPS
+    if (chain == 0 && lane == 0 && draw_variances)
+      printf("ssm phases (cycles, wave 0): variances %lld ystar %lld normals %lld sim %lld wait-for-P %lld filter %lld backward %lld correction %lld\n",
+             kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
+#endif
+    return;
+  }
+  double prev = 0.0;            // state_{t-1} (its own layout)
+  double suf0 = 0.0, suf2 = 0.0;
+  double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of the trend errors (lanes 0, 1)
+  double yty = 0.0, nobs = 0.0;
+  // ArModel's NeRegSuf of now[a0] on then[a0 ..]: lane a0 + i keeps xty_i and row i of xtx,
+  // the row in LDS (s_P is free by now), at s_axx[i * PLD + q]
+  double axy = 0.0, ayy = 0.0;
+  double *s_axx = s_P;
+  if (AR) {
+    for (int e2 = lane; e2 < SSM_MAX * PLD; e2 += WAVE) s_axx[e2] = 0.0;
+    wave_lds_sync();
+  }
+  {
+    int c = 0;
+    for (int tb = 0; tb < T; tb += WAVE) {
+      const int tt = tb + lane, b = tb / WAVE;
+      const bool in_l = tt < T;
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      double *buf = s_blk[b & 1];
+      const double y_l = in_l ? P.y[tt] : 0.0;
+      const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
+      // (wave 0 only leaves early when THIS wave's variance pass failed, and then this wave has left too)
+      while (__hip_atomic_load(&s_cprog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= b)
+        __builtin_amdgcn_s_sleep(8);
+      double res_l = 0.0;
+#pragma nounroll
+      for (int s = 0; s < nstep; ++s) {
+        const double st = mylane ? buf[s * m + lane] : 0.0;
+        if (tb + s > 0 && SEAS) c = cursor_prev(c, S.ns);
         if (tb + s > 0) {
           if (TREND == 1) {
             const double diff = st - prev;                 // (lane 0)
@@ -927,30 +965,24 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           }
         }
         prev = st;
-        if (mylane) {
-          // the state draw goes out in logical order
-          int idx = lane;
-          if (SEAS && S.seasonal(lane)) {
+        if (SEAS) {
+          // the state draw goes out in logical order (in place: every lane has read its entry)
+          if (mylane && S.seasonal(lane)) {
             const int q = lane - S.s0;
-            idx = S.s0 + (q >= c ? q - c : q - c + S.ns);
+            buf[s * m + S.s0 + (q >= c ? q - c : q - c + S.ns)] = st;
           }
-          oblk[s * m + idx] = st;
         }
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
         const double resid = obs ? rl(y_l, s) - zdot<SEAS, AR>(S, st, c) : 0.0;
         if (lane == s) res_l = resid;
         if (obs) { yty += resid * resid; nobs += 1.0; }
       }
-      blk_store(gst + (size_t)tb * m, oblk, nstep * m, lane);
+      blk_store(gst + (size_t)tb * m, buf, nstep * m, lane);
       if (in_l) sres[tt] = res_l;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&s_cdone, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  SSTAMP(7);
-#ifdef BA_KSTAMPS
-  if (chain == 0 && lane == 0 && draw_variances)
-    printf("ssm phases (cycles, wave 0): variances %lld ystar %lld normals %lld sim %lld wait-for-P %lld filter %lld backward %lld correction %lld\n",
-           kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
-#endif
   // publish the sufficient statistics
   if (TREND == 2) {
     // center_sumsq(mu = 0)(i, i) = sumsq_ii + n ybar_i^2
