@@ -130,12 +130,14 @@ def test_logit_rejects_bad_arguments():
     eng.logit_set_data(X, y, nt, 5)      # trial counts above the threshold are served now
 
 
-def test_config5_shape_per_gpu():
+@pytest.mark.parametrize("imputer", [0, 1])
+def test_config5_shape_per_gpu(imputer):
     """BASELINE config 5 at its per-GPU size (n = 5e4, p = 1024, 4096 chains over 8 GPUs
     = 512 per rank), too large for an oracle run: the eight signals are found by every
     chain, and a shard of four chains repeats the whole job's first four bit for bit --
     which it can only do if no value depends on what else shares a launch (the request
-    GEMM's fixed row chunks, the replay of parked chains)."""
+    GEMM's fixed row chunks, the replay of parked chains).  imputer 0: the reference's
+    mixture-of-normals imputation, 1: the Polya-Gamma imputer (logit_pg_impute_kernel)."""
     import boom_amd
     n, p, nsig = 50000, 1024, 8
     X, y, nt, _ = logit_data(n, p, nsig, seed=8675309)
@@ -144,6 +146,7 @@ def test_config5_shape_per_gpu():
     for chains in (512, 4):
         eng = boom_amd.Engine(chains, seed=4)
         eng.logit_set_data(X, y, nt, 5)
+        eng.logit_set_imputer(imputer)
         eng.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
         eng.set_spike(pi)
         g0 = np.zeros(p, np.uint8)
