@@ -1048,8 +1048,18 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
   {
     // (loaded here, not under the forward pass: a barrier there would wait for it)
     double yv[BS];
+    {
+      // (four steps per address register, made HERE: the sixteen addresses computed at the
+      // top of the kernel sat in scratch memory until now -- ten serial reloads)
+      const double *yb = P.yt + tid;
 #pragma unroll
-    for (int j = 0; j < BS; ++j) yv[j] = P.yt[j * NT + tid];
+      for (int g = 0; g < BS / 4; ++g) {
+        const double *q = yb + (size_t)4 * g * NT;
+        asm volatile("" : "+v"(q));
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) yv[4 * g + jj] = q[jj * NT];
+      }
+    }
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < BS; ++j) {
