@@ -134,6 +134,7 @@ SIGNATURES = {
     "ba_ss_get_ar": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
     "ba_ss_clear_state_models": (C.c_int, [C.c_void_p]),
     "ba_ss_set_tuning": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ba_set_slot_limit": (C.c_int, [C.c_void_p, C.c_int32]),
     "ba_ss_add_state_model": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)] + [_dp] * 7),
     "ba_ss_state_dimension": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ba_ss_get_state_model": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32] + [_dp] * 8),
@@ -578,6 +579,10 @@ class Engine:
         self._check(self.lib.ba_ss_state_dimension(self._h, C.byref(m), C.byref(nb)))
         self._ssm_dim = m.value
         self._ar_lags = 0
+
+    def set_slot_limit(self, uniforms):
+        """tests: a substream slot hands out `uniforms` numbers, then its spill stream (0: default)"""
+        self._check(self.lib.ba_set_slot_limit(self._h, int(uniforms)))
 
     def ss_set_tuning(self, use_template_kernel=True, kernel=None):
         """kernel: 0 general, 1 the default choice, 2 four chains per wavefront (m <= 16),

@@ -93,12 +93,34 @@ __device__ __forceinline__ void philox_pair(const PhiloxKey &key, uint64_t block
   *u1 = (double)(((uint64_t)o[2] | ((uint64_t)o[3] << 32)) >> 11) * 0x1.0p-53;
 }
 
+// A SLOT of a substream (stream_normals.h, the imputers of probit_kernel.hip): draw `index`
+// of a stream owns the positions [index * stride, (index + 1) * stride).  A draw that needs
+// more uniforms than its slot serves goes on in the slot's SPILL stream -- the same chain,
+// the stream id with its top bit set, position index << SPILL_SHIFT -- instead of reading
+// the next draw's numbers (rounds 1-3 stopped the chain there).  The oracle's Philox mode
+// does the same (bo_rng_slot).  A million uniforms further the draw is given up.
+enum : uint32_t { SPILL_STREAM_BIT = 0x80000000u };
+enum : int { SPILL_SHIFT = 20 };
+
 // Sequential view of a stream (the reference's `rng()`).
 struct SeqRng {
   PhiloxKey key;
   uint64_t pos;
+  uint64_t limit = ~0ull;   // a slot: the first position that is not its own ...
+  uint64_t spill = 0;       // ... and where the draw goes on in the spill stream
   __device__ __forceinline__ double operator()() {
+    if (pos >= limit) { key.stream |= SPILL_STREAM_BIT; pos = spill; limit = ~0ull; }
     return philox_uniform(key, pos++);
+  }
+  // slot `index` of a stream of `stride` positions per draw, `serve` <= stride of them handed out
+  static __device__ __forceinline__ SeqRng slot(const PhiloxKey &k, uint64_t index, uint32_t stride, uint32_t serve) {
+    SeqRng r{k, index * stride};
+    r.limit = r.pos + serve;
+    r.spill = index << SPILL_SHIFT;
+    return r;
+  }
+  __device__ __forceinline__ bool overran() const {
+    return (key.stream & SPILL_STREAM_BIT) && pos - spill > (1ull << SPILL_SHIFT);
   }
 };
 
@@ -110,10 +132,17 @@ struct PairRng {
   uint64_t pos, block;
   double w0, w1;
   bool have;
+  uint64_t limit, spill;   // (see SeqRng)
   __device__ __forceinline__ void init(const PhiloxKey &k, uint64_t p) {
-    key = k; pos = p; block = 0; w0 = w1 = 0.0; have = false;
+    key = k; pos = p; block = 0; w0 = w1 = 0.0; have = false; limit = ~0ull; spill = 0;
+  }
+  __device__ __forceinline__ void init_slot(const PhiloxKey &k, uint64_t index, uint32_t stride, uint32_t serve) {
+    init(k, index * stride);
+    limit = pos + serve;
+    spill = index << SPILL_SHIFT;
   }
   __device__ __forceinline__ double operator()() {
+    if (pos >= limit) { key.stream |= SPILL_STREAM_BIT; pos = spill; limit = ~0ull; have = false; }
     const uint64_t b = pos >> 1;
     if (!have || b != block) {
       philox_pair(key, b, &w0, &w1);
@@ -123,6 +152,9 @@ struct PairRng {
     const double u = (pos & 1) ? w1 : w0;
     ++pos;
     return u;
+  }
+  __device__ __forceinline__ bool overran() const {
+    return (key.stream & SPILL_STREAM_BIT) && pos - spill > (1ull << SPILL_SHIFT);
   }
 };
 

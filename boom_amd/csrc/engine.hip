@@ -366,6 +366,7 @@ struct ba_engine {
   DevBuf<int32_t> dpois_off, dpois_obs;
   DevBuf<double> dpois_mu, dpois_sigma, dpois_logw;
   int poisson_mix_one = -1;
+  int slot_limit = 0;              // (ba_set_slot_limit)
   DevBuf<double> dlogit_w, dlogit_V;
   // ... V built a vector at a time (xtwx_cols_kernel.hip): the squared design matrix
   // (for the diagonal), the diagonals (chains x p), which vectors hold this sweep's
@@ -940,6 +941,7 @@ static size_t ss_pitch(const ba_engine &e) { return ss_lane_major(e) ? (size_t)L
 void fill_ss_params(ba_engine *e, SsParams &S) {
   std::memset(&S, 0, sizeof(S));  // (only_ran = nullptr: every chain)
   S.T = e->T;
+  S.slot_limit = e->slot_limit;
   S.p = e->p;
   S.chains = e->cfg.chains;
   S.chain_first = 0;
@@ -3092,6 +3094,7 @@ int ba_probit_sweep(ba_engine *e, int32_t nsweeps) {
   Q.p = (int32_t)p;
   Q.chains = (int32_t)C;
   Q.clt_threshold = e->probit_clt;
+  Q.slot_limit = e->slot_limit;
   Q.chain_offset = e->cfg.chain_offset;
   Q.X = e->dprob_X.ptr;
   Q.y = e->dprob_y.ptr;
@@ -3324,6 +3327,7 @@ static int logit_family_sweep(ba_engine *e, int32_t nsweeps) {
   Q.p = (int32_t)p;
   Q.chains = (int32_t)C;
   Q.clt_threshold = e->probit_clt;
+  Q.slot_limit = e->slot_limit;
   Q.chain_offset = e->cfg.chain_offset;
   Q.X = e->dprob_X.ptr;
   Q.y = e->dprob_y.ptr;
@@ -3739,6 +3743,16 @@ void ssg_clear(ba_engine *e) {
 }  // namespace
 
 extern "C" {
+
+// for the tests of the spill streams (device_rng.h): a slot of a substream hands out `uniforms`
+// numbers, not its whole stride (0: the default again).  Changes the draws.
+int ba_set_slot_limit(ba_engine *e, int32_t uniforms) {
+  if (!e) return fail(BA_E_INVALID, "null engine");
+  if (uniforms < 0 || (uniforms & 1)) return fail(BA_E_INVALID, "uniforms must be even and non-negative");
+  MUTATE(e);
+  e->slot_limit = uniforms;
+  return BA_OK;
+}
 
 // diagnostic, changes no draw: 0 = the general kernel also where the shape-specialised one
 // applies (the two are compared by the tests), 1 = the default

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
     // written here is the one it reads)
     const uint64_t bpos0 = prepared ? *prep_pos_slot : P.pos_state[chain];
     status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,
-                            &P.pos_state[chain]);
+                            &P.pos_state[chain], ss_slot_serve(P));
     if (status != CHAIN_OK) {   // (s_hand[3]: the same in both waves)
       if (threadIdx.x == 0) P.status[chain] = status;
       return;
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
   if (!prepared || prep_n != N) {   // (another count: see kalman_simsmooth_kernel)
     const uint64_t bpos0 = prepared ? P.prep_pos_state[(size_t)P.zbuf * P.chains + chain] : P.pos_state[chain];
     status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, bpos0, N, szz,
-                            &P.pos_state[chain], LmSlots{T, nfirst, nper, dI, dL, dH});
+                            &P.pos_state[chain], LmSlots{T, nfirst, nper, dI, dL, dH}, ss_slot_serve(P));
     if (status != CHAIN_OK) {
       if (tid == 0) P.status[chain] = status;
       return;
@@ -1159,10 +1159,10 @@ __global__ __launch_bounds__(128) void kalman_prepare_kernel(SsParams P, int dra
   if (status == CHAIN_OK) {   // (uniform: every thread made the same draw)
     if (P.lane_major)
       status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, pos_state0, N, szz,
-                              &P.pos_state[chain], LmSlots{T, dI + dH, dL + dH, dI, dL, dH});
+                              &P.pos_state[chain], LmSlots{T, dI + dH, dL + dH, dI, dL, dH}, ss_slot_serve(P));
     else
       status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, pos_state0, N, szz,
-                              &P.pos_state[chain]);
+                              &P.pos_state[chain], ss_slot_serve(P));
   }
   if (threadIdx.x == 0) {
     const size_t slot = (size_t)P.zbuf * P.chains + chain;

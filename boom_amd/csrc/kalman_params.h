@@ -58,6 +58,7 @@ struct SsmParams {
 
 struct SsParams {
   int32_t T, p, chains;
+  int32_t slot_limit;     // > 0: uniforms a slot of the state stream serves before its spill stream (default: the stride)
   int32_t chain_first, chain_count;  // this launch: chains [chain_first, chain_first + chain_count)
   int64_t chain_offset;
   // shared data: StateSpaceRegressionModel(y, X, observed)

@@ -34,6 +34,11 @@ enum : int { TN_CAP = 64 };
 
 // TnSampler: bounded adaptive rejection for a standard normal given x > a, a > 0
 // (logf = -x^2 / 2); per-thread hull arrays, the reference's lower_bound probes
+// how many uniforms a slot of an imputer's substream hands out before the draw goes on in the
+// spill stream (device_rng.h): the whole stride, or what ba_set_slot_limit asked for (tests)
+__device__ __forceinline__ uint32_t slot_serve(const ProbitParams &P, uint32_t stride) {
+  return (P.slot_limit > 0 && (uint32_t)P.slot_limit < stride) ? (uint32_t)P.slot_limit : stride;
+}
 __device__ __forceinline__ int tn_lower_bound(const double *v, int n, double value) {
   int first = 0, count = n;
   while (count > 0) {
@@ -189,10 +194,10 @@ __device__ __forceinline__ double trun_norm_std(SeqRng &rng, double a, int *bad,
     S.slot = got < TN_SLOTS ? got : -2;
   }
   if (S.slot >= 0) {
-    const uint64_t start = rng.pos;
+    const SeqRng start = rng;
     double z;
     if (tn_draw_lds(rng, a, S, &z)) return z;
-    rng.pos = start;
+    rng = start;
   }
   return tn_draw(rng, a, bad);
 }
@@ -414,8 +419,8 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   double eta = 0.0;
   for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
   const long nt = lround(P.ntrials[i]), y = lround(P.y[i]);
-  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 8u},
-             (P.sweep * (uint64_t)P.n + (uint64_t)i) * PROBIT_STRIDE};
+  SeqRng rng = SeqRng::slot(PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 8u},
+                            P.sweep * (uint64_t)P.n + (uint64_t)i, PROBIT_STRIDE, slot_serve(P, PROBIT_STRIDE));
   int bad = 0;
   double mean, variance, ans = 0.0;
   if (y > P.clt_threshold) {
@@ -430,9 +435,9 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   } else {
     for (long t = 0; t < nt - y; ++t) ans += rtrun_norm(rng, eta, 0.0, false, &bad, slot);
   }
-  // (a draw that outran its substream or its hull is reported, never mishandled)
-  if (bad || rng.pos - (P.sweep * (uint64_t)P.n + (uint64_t)i) * PROBIT_STRIDE > PROBIT_STRIDE)
-    P.status[chain] = CHAIN_RNG_BRANCH;
+  // (a draw that outran its hull is reported, never mishandled; one that outruns its
+  // slot of the stream goes on in the slot's spill stream, device_rng.h)
+  if (bad || rng.overran()) P.status[chain] = CHAIN_RNG_BRANCH;
   P.z[(size_t)chain * P.n + i] = ans;
 }
 
@@ -470,15 +475,14 @@ __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
   double eta = 0.0;
   for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
   const long nt = lround(P.ntrials[i]), ys = lround(P.y[i]);
-  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 9u},
-             (P.sweep * (uint64_t)P.n + (uint64_t)i) * LOGIT_STRIDE};
+  SeqRng rng = SeqRng::slot(PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 9u},
+                            P.sweep * (uint64_t)P.n + (uint64_t)i, LOGIT_STRIDE, slot_serve(P, LOGIT_STRIDE));
   double sum = 0.0, info = 0.0;
   if (nt > P.clt_threshold) {
     // BinomialLogitCltDataImputer::impute_large_sample (BinomialLogitDataImputer.cpp:
     // 155-211): how many failures / successes belong to each mixture component (two
     // multinomial draws), then one normal draw for the information-weighted sum from the
     // truncated-normal moments of the occupied cells
-    const uint64_t start = rng.pos;
     double p0[9], p1[9];
     int N0[9], N1[9];
     const double xz = (0 - eta) / 1.0;
@@ -516,10 +520,6 @@ __global__ __launch_bounds__(256) void logit_impute_kernel(ProbitParams P) {
       }
     }
     sum = d_rnorm(rng, simulation_mean, sqrt(simulation_variance));
-    // (a draw that outran its substream is reported, never mishandled)
-    if (rng.pos - start > (uint64_t)LOGIT_STRIDE) P.status[chain] = CHAIN_RNG_BRANCH;
-  } else if (2 * nt > LOGIT_STRIDE) {
-    P.status[chain] = CHAIN_RNG_BRANCH;
   } else {
     const double cutpoint_prob = 1 / (1 + exp(-(0 - eta)));
     for (long t = 0; t < nt; ++t) {
@@ -657,8 +657,8 @@ __global__ __launch_bounds__(256) void logit_pg_impute_kernel(ProbitParams P) {
   double eta = 0.0;
   for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
   const long nt = lround(P.ntrials[i]), ys = lround(P.y[i]);
-  const uint64_t start = (P.sweep * (uint64_t)P.n + (uint64_t)i) * PG_STRIDE;
-  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 10u}, start};
+  SeqRng rng = SeqRng::slot(PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 10u},
+                            P.sweep * (uint64_t)P.n + (uint64_t)i, PG_STRIDE, slot_serve(P, PG_STRIDE));
   int bad = 0;
   double omega = 0.0;
   if (nt > P.clt_threshold) {
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void logit_pg_impute_kernel(ProbitParams P) {
   } else {
     for (long t = 0; t < nt; ++t) omega += pg_draw1(rng, eta, &bad);
   }
-  if (bad || rng.pos - start > (uint64_t)PG_STRIDE) P.status[chain] = CHAIN_RNG_BRANCH;
+  if (bad || rng.overran()) P.status[chain] = CHAIN_RNG_BRANCH;
   P.z[(size_t)chain * P.n + i] = (double)ys - 0.5 * (double)nt;
   P.w[(size_t)chain * P.n + i] = omega;
 }
@@ -786,8 +786,8 @@ __global__ __launch_bounds__(256) void poisson_impute_kernel(ProbitParams P) {
   for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
   const long long y = llround(P.y[i]);
   const double exposure = P.ntrials[i];
-  const uint64_t start = (P.sweep * (uint64_t)P.n + (uint64_t)i) * POISSON_STRIDE;
-  SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 11u}, start};
+  SeqRng rng = SeqRng::slot(PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 11u},
+                            P.sweep * (uint64_t)P.n + (uint64_t)i, POISSON_STRIDE, slot_serve(P, POISSON_STRIDE));
   int bad = 0;
   const double t_final = y > 0 ? exposure * d_rbeta_a_1(rng, (double)y) : 0.0;
   const double delta = exposure - t_final;
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void poisson_impute_kernel(ProbitParams P) {
     sum += w * (z_ext - mu_e);
     info += w;
   }
-  if (bad || rng.pos - start > (uint64_t)POISSON_STRIDE) P.status[chain] = CHAIN_RNG_BRANCH;
+  if (bad || rng.overran()) P.status[chain] = CHAIN_RNG_BRANCH;
   P.z[(size_t)chain * P.n + i] = sum;
   P.w[(size_t)chain * P.n + i] = info;
 }

@@ -33,6 +33,7 @@ struct ProbitParams {
   const double *mix_mu, *mix_sigma, *mix_logw;
   const int32_t *obs_mix;
   int32_t mix_one;
+  int32_t slot_limit;     // > 0: uniforms a substream slot serves before its spill stream (default: the stride)
 };
 
 }  // namespace boom_amd

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   };
   const int N = (nfirst + dH) + (T - 1) * (nconst_err + dH) + seasonal_draws(T - 1);
   status = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
-                          szz, &P.pos_state[chain]);
+                          szz, &P.pos_state[chain], ss_slot_serve(P));
   if (status != CHAIN_OK) {
     if (threadIdx.x == 0) P.status[chain] = status;
     return;

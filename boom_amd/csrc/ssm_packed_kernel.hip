@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     const int N = (nfirst + dH) + (T - 1) * (nconst + dH) + nseas;
     const int st = stream_normals(s_norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
-                                  szz, &P.pos_state[chain]);
+                                  szz, &P.pos_state[chain], ss_slot_serve(P));
     if (st != CHAIN_OK && tid == 0) s_flag[c4] = st;
     __syncthreads();
   }

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   const int nper = dT + dS + dA + dH;
   const int N = nfirst + (T - 1) * nper;
   status = stream_normals(s_lds.norm, PhiloxKey{P.seed_lo, P.seed_hi, gchain, 2u}, P.pos_state[chain], N,
-                          szz, &P.pos_state[chain]);
+                          szz, &P.pos_state[chain], ss_slot_serve(P));
   if (status != CHAIN_OK) {
     if (threadIdx.x == 0) P.status[chain] = status;
     return;

@@ -21,13 +21,19 @@
 
 namespace boom_amd {
 
-// uniforms reserved per normal of the state stream.  A draw that ran past them would
-// read the next draw's (reported as CHAIN_RNG_BRANCH): the rejection loops accept with
+// uniforms reserved per normal of the state stream.  A draw that runs past them goes on in
+// its slot's spill stream (device_rng.h; rounds 1-3 reported CHAIN_RNG_BRANCH and stopped
+// the chain): the rejection loops accept with
 // probability ~0.55 per round of two uniforms, so 64 uniforms (31 rounds) would be
 // exceeded about once per 1e11 slow draws -- every few hundred thousand sweep rounds of
 // 1024 chains -- and 256 (127 rounds) never (1e-44).  The stride costs nothing: counters,
 // not memory.
 enum : int { STATE_SLOT_STRIDE = 256 };
+// (ba_set_slot_limit, for the tests: at least the two uniforms of the first branch, an even number)
+template <class Params>
+__host__ __device__ inline int ss_slot_serve(const Params &P) {
+  return (P.slot_limit >= 2 && P.slot_limit < STATE_SLOT_STRIDE) ? (P.slot_limit & ~1) : STATE_SLOT_STRIDE;
+}
 
 // LDS hand-off between the lanes of one wavefront (DS operations of a wave
 // complete in order: only the compiler has to be told)
@@ -63,11 +69,13 @@ struct NormalsInOrder {   // szz[i] = draw i
 };
 template <class Slots>
 __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
-                                              double *szz, uint64_t *pos_out, const Slots slots) {
+                                              double *szz, uint64_t *pos_out, const Slots slots,
+                                              int serve = STATE_SLOT_STRIDE) {
   const double A = 2.216035867166471;
   const double C1 = 0.398942280401433, C2 = 0.180025191068563;
   const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
   const int S = slots.count();
+  const uint64_t bslot0 = bpos0 / STATE_SLOT_STRIDE;   // (the stream position is a whole number of slots)
   int bad = 0;
   for (int c0 = 0; c0 < S; c0 += SN_CHUNK) {
     const int nc = (S - c0 < SN_CHUNK) ? S - c0 : SN_CHUNK;
@@ -124,9 +132,8 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
     const int ntail = L.ntail, nmid = L.nmid;
     for (int q = tid; q < ntail; q += nth) {
       const int i = L.tail[q];
-      const uint64_t start = bpos0 + (uint64_t)slots.draw(c0 + i) * STATE_SLOT_STRIDE;
       PairRng r;
-      r.init(key, start);
+      r.init_slot(key, bslot0 + (uint64_t)slots.draw(c0 + i), STATE_SLOT_STRIDE, (uint32_t)serve);
       const double u1 = r();
       double z;
       for (;;) {
@@ -137,9 +144,8 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
           z = (u1 < 0.986655477086949) ? sqrt(tt) : -sqrt(tt);
           break;
         }
-        if (r.pos - start > (uint64_t)STATE_SLOT_STRIDE) { bad = 1; z = 0.0; break; }
+        if (r.overran()) { bad = 1; z = 0.0; break; }
       }
-      if (r.pos - start > (uint64_t)STATE_SLOT_STRIDE) bad = 1;
       szz[c0 + i] = z;
     }
 #ifdef BA_KSTAMPS
@@ -150,9 +156,8 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
     //   coef |u2 - u3| <= C1 exp(-tt^2 / 2) - C2 (A - tt)
     for (int q = tid; q < nmid; q += nth) {
       const int i = L.mid[q];
-      const uint64_t start = bpos0 + (uint64_t)slots.draw(c0 + i) * STATE_SLOT_STRIDE;
       PairRng r;
-      r.init(key, start);
+      r.init_slot(key, bslot0 + (uint64_t)slots.draw(c0 + i), STATE_SLOT_STRIDE, (uint32_t)serve);
       const double u1 = r();
       const bool r2 = u1 >= 0.958720824790463, r3 = !r2 && u1 >= 0.911312780288703;
       const double thr = r2 ? 0.755591531667601 : (r3 ? 0.872834976671790 : 0.805577924423817);
@@ -171,9 +176,8 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
           z = (u2 < u3) ? tt : -tt;
           break;
         }
-        if (r.pos - start > (uint64_t)STATE_SLOT_STRIDE) { bad = 1; z = 0.0; break; }
+        if (r.overran()) { bad = 1; z = 0.0; break; }
       }
-      if (r.pos - start > (uint64_t)STATE_SLOT_STRIDE) bad = 1;
       szz[c0 + i] = z;
     }
 #ifdef BA_KSTAMPS
@@ -191,8 +195,8 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
 }
 __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
-                                              double *szz, uint64_t *pos_out) {
-  return stream_normals(L, key, bpos0, N, szz, pos_out, NormalsInOrder{N});
+                                              double *szz, uint64_t *pos_out, int serve = STATE_SLOT_STRIDE) {
+  return stream_normals(L, key, bpos0, N, szz, pos_out, NormalsInOrder{N}, serve);
 }
 
 }  // namespace boom_amd

@@ -150,6 +150,15 @@ int ba_set_options(ba_engine *e, int32_t max_flips, double swap_threshold,
  *   kcap_start       0 = default; first model capacity tried (16, 32, ...) */
 int ba_set_tuning(ba_engine *e, int32_t waves_per_chain, int32_t walk_policy,
                   int32_t kcap_start);
+/* The samplers that give every draw its own slot of a stream (the bsts state draw's normals:
+ * 256 positions a normal; the probit / logit / Polya-Gamma / Poisson imputers: 4096 / 256 /
+ * 4096 / 256 positions an observation) let a draw that needs more uniforms than its slot
+ * holds go on in the slot's SPILL stream (same chain, stream id | 0x80000000, position
+ * slot << 20) -- an event of probability < 1e-40 at these strides.  For the tests of that
+ * path: a slot hands out only `uniforms` numbers (even; 0 = the whole stride again), so
+ * that the spill streams are read all the time.  The oracle's bo_set_slot_limit is the
+ * same switch.  Changes the draws. */
+int ba_set_slot_limit(ba_engine *e, int32_t uniforms);
 
 /* ---- chain state: GlmCoefs (beta, inc) + sigsq ----------------------------- */
 /* coef().set_inc / set_Beta / set_sigsq.  gamma: p bytes (0/1), beta: p

@@ -88,6 +88,25 @@ void bo_rng_seed_philox(bo_rng *r, uint64_t seed, uint32_t chain,
   }
 }
 
+static int g_slot_limit = 0;
+void bo_set_slot_limit(int uniforms) { g_slot_limit = uniforms; }
+void bo_rng_slot(bo_rng *r, uint64_t index, uint64_t stride) {
+  uint64_t serve = stride;
+  if (g_slot_limit > 0 && (uint64_t)g_slot_limit < stride) {
+    serve = (uint64_t)g_slot_limit;
+    /* (the state stream: a whole Philox block, the two uniforms of norm_rand's first branch) */
+    if (r->stream == 2 || r->stream == (2 | BO_SPILL_STREAM_BIT)) serve = serve >= 2 ? (serve & ~(uint64_t)1) : stride;
+  }
+  r->stream &= ~BO_SPILL_STREAM_BIT;
+  r->pos = index * stride;
+  r->limit = r->pos + serve;
+  r->spill = index << BO_SPILL_SHIFT;
+}
+static void bo_rng_unslot(bo_rng *r) {
+  r->stream &= ~BO_SPILL_STREAM_BIT;
+  r->limit = 0;
+}
+
 /* RNG::operator(), distributions/rng.hpp:45.  For the MT engine this is
  * libstdc++'s uniform_real_distribution<double>(0,1) = generate_canonical<
  * double,53>(mt19937_64): one 64-bit draw, converted to double (round to
@@ -99,6 +118,11 @@ double bo_unif(bo_rng *r) {
     if (u >= 1.0) u = nextafter(1.0, 0.0);
     return u;
   } else {
+    if (r->limit && r->pos >= r->limit) {   /* the slot is used up: on in its spill stream */
+      r->stream |= BO_SPILL_STREAM_BIT;
+      r->pos = r->spill;
+      r->limit = 0;
+    }
     uint64_t block = r->pos >> 1;
     uint32_t ctr[4] = {(uint32_t)block, (uint32_t)(block >> 32), r->chain,
                        r->stream};
@@ -212,9 +236,10 @@ double bo_rnorm(bo_rng *r, double mu, double sigma) {
   if (sigma == 0.) return mu;
   if (r->kind == BO_RNG_PHILOX && r->slot_stride) {
     /* (the state stream's normals have a slot each, see bo_rng) */
-    r->pos = r->slot * r->slot_stride;
+    bo_rng_slot(r, r->slot, r->slot_stride);
     r->slot += 1;
     const double z = bo_norm_rand(r);
+    bo_rng_unslot(r);
     r->pos = r->slot * r->slot_stride;
     return mu + sigma * z;
   }
@@ -3228,7 +3253,7 @@ int bo_probit_draw(bo_probit *m) {
     bo_rng *r = &s->rng;
     if (m->substream) {
       r = &m->imp_rng;
-      r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * BO_PROBIT_STRIDE;
+      bo_rng_slot(r, m->sweep * (uint64_t)n + (uint64_t)i, BO_PROBIT_STRIDE);
     }
     double sum_of_z = probit_impute(r, m->clt, m->nt[i], m->y[i], eta, &status);
     if (status) return status;
@@ -3612,7 +3637,7 @@ int bo_logit_draw(bo_logit *m) {
       if (s->gamma[j]) eta += m->X[IDX(i, j, n)] * s->beta[j];
     const long nt = lround(m->nt[i]), ys = lround(m->y[i]);
     bo_rng *r = &m->worker_rng;
-    if (m->substream) r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * (m->imputer ? BO_PG_STRIDE : BO_LOGIT_STRIDE);
+    if (m->substream) bo_rng_slot(r, m->sweep * (uint64_t)n + (uint64_t)i, m->imputer ? BO_PG_STRIDE : BO_LOGIT_STRIDE);
     double sum = 0, info = 0;
     if (m->imputer == 1) {
       /* omega ~ PG(n_i, eta); (kappa, omega) is the (sum, information) pair */
@@ -3823,7 +3848,7 @@ int bo_poisson_draw(bo_poisson *m) {
     const int64_t y = (int64_t)llround(m->y[i]);
     const double exposure = m->exposure[i];
     bo_rng *r = &m->worker_rng;
-    if (m->substream) r->pos = (m->sweep * (uint64_t)n + (uint64_t)i) * BO_POISSON_STRIDE;
+    if (m->substream) bo_rng_slot(r, m->sweep * (uint64_t)n + (uint64_t)i, BO_POISSON_STRIDE);
     /* PoissonDataImputer::impute: eta here is log_lambda = x'beta (the exposure enters
      * through the event times) */
     const double t_final = y > 0 ? exposure * poisson_rbeta_a_1(r, (double)y) : 0.0;

@@ -54,8 +54,21 @@ typedef struct bo_rng {
    * the device does (stream_normals.h) -- every draw independent of the others.
    * 0 for every other stream, and the MT engine reads in sequence as the reference. */
   uint64_t slot_stride, slot;
+  /* A slot of a substream (the state stream's normals, the imputers' observations): the
+   * first position that is not the slot's own, and where its SPILL stream starts (stream
+   * id | BO_SPILL_STREAM_BIT, position index << BO_SPILL_SHIFT) -- a draw that needs more
+   * uniforms than the slot serves goes on there (device_rng.h does the same).  limit 0:
+   * no slot. */
+  uint64_t limit, spill;
 } bo_rng;
 #define BO_STATE_SLOT_STRIDE 256
+#define BO_SPILL_STREAM_BIT 0x80000000u
+#define BO_SPILL_SHIFT 20
+/* slot `index` of a stream with `stride` positions per draw */
+void bo_rng_slot(bo_rng *r, uint64_t index, uint64_t stride);
+/* tests: a slot serves only `uniforms` numbers before its spill stream (0: the whole
+ * stride; the device's ba_set_slot_limit is the same switch) */
+void bo_set_slot_limit(int uniforms);
 
 void bo_rng_seed_mt(bo_rng *r, uint64_t seed);
 void bo_rng_seed_philox(bo_rng *r, uint64_t seed, uint32_t chain,

@@ -57,7 +57,8 @@ class BoRng(C.Structure):
     _fields_ = [("kind", C.c_int), ("mt", C.c_uint64 * 312), ("mti", C.c_int),
                 ("seed", C.c_uint64), ("chain", C.c_uint32),
                 ("stream", C.c_uint32), ("pos", C.c_uint64),
-                ("slot_stride", C.c_uint64), ("slot", C.c_uint64)]
+                ("slot_stride", C.c_uint64), ("slot", C.c_uint64),
+                ("limit", C.c_uint64), ("spill", C.c_uint64)]
 
 
 class RefSsvsOptions(C.Structure):
@@ -84,8 +85,14 @@ def ssvs_options(max_model_size=-1, sigma_upper_limit=float("inf"),
 
 # ---------------------------------------------------------------------------
 class Oracle:
+    def set_slot_limit(self, uniforms):
+        """tests of the spill streams: a substream slot serves `uniforms` numbers (0: its stride)"""
+        self.lib.bo_set_slot_limit(int(uniforms))
+
     def __init__(self):
         self.lib = L = C.CDLL(build_oracle())
+        L.bo_set_slot_limit.argtypes = [C.c_int]
+        L.bo_set_slot_limit.restype = None
         L.bo_unif.restype = C.c_double
         L.bo_norm_rand.restype = C.c_double
         L.bo_exp_rand.restype = C.c_double
