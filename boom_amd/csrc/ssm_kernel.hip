@@ -63,6 +63,7 @@
 namespace boom_amd {
 
 namespace {
+constexpr int SSG_V_FAILED = 1 << 30;   // s_vprog: the variance pass stopped (F <= 0)
 }  // namespace
 
 // LDS of the passes, in doubles: two block buffers (bl x m each) | P (m x ld) | a block's
@@ -77,6 +78,8 @@ template <bool SMALL>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void ssg_simsmooth_kernel(SsParams P, int draw_variances) {
   extern __shared__ __align__(16) unsigned char s_raw[];
   __shared__ int s_flag;
+  __shared__ int s_vprog;            // blocks the variance pass has put out (wave 1 -> wave 0)
+  __shared__ int s_cprog, s_cdone;   // the last pass: blocks of state draws wave 0 has made / wave 1 has taken
   __shared__ double s_sig2[SSG_MAX_VAR];
   __shared__ double s_phi[SSG_MAX_AR * AR_MAX];
   __shared__ double s_tv[SSG_MAX_STATE];
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   double *s_axx = s_z + (BL * (NE + 1) + SSG_MAX_STATE + 8);
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
   int status = CHAIN_OK;
-  if (threadIdx.x == 0) s_flag = CHAIN_OK;
+  if (threadIdx.x == 0) { s_flag = CHAIN_OK; s_vprog = 0; s_cprog = 0; s_cdone = 0; }
   if (threadIdx.x < SSG_MAX_VAR) s_sig2[threadIdx.x] = M.var_sigsq[(size_t)chain * SSG_MAX_VAR + threadIdx.x];
   __syncthreads();
 #ifdef BA_KSTAMPS
@@ -422,8 +425,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       if (status != CHAIN_OK) break;
       blk_store(gK + (size_t)tb * m, blk, nstep * m, lane);
       if (lane < nstep) sres[tt] = F_l;
+      // the block is out: the filter (wave 0, once it has simulated) follows a block behind
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&s_vprog, tb / BL + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (status != CHAIN_OK && lane == 0) s_flag = status;
+    if (status != CHAIN_OK) {
+      if (lane == 0) {
+        s_flag = status;
+        __hip_atomic_store(&s_vprog, SSG_V_FAILED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      return;
+    }
   } else {
     double alpha = 0.0;
     seek(B, LI, 0, -1);   // (at time t the transition INTO t)
@@ -473,16 +485,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
     }
   }
   SSTAMP(3);
-  __threadfence_block();
-  __syncthreads();
   SSTAMP(4);
-  status = s_flag;
-  if (status != CHAIN_OK) {
-    if (threadIdx.x == 0) P.status[chain] = status;
-    return;
-  }
-  if (wave != 0) return;
 
+  double r = 0.0;
+  if (wave == 0) {
   // ---- 3b. the filter on w = y* - y+ (the data filter minus the simulation
   // filter; they share the gains): v - v+ = w - Z'(a - a+); a - a+ <- T (a - a+) + K (v - v+)
   {
@@ -492,6 +498,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       const int tt = tb + lane;
       const int nstep = (T - tb < BL) ? T - tb : BL;
       const bool in_l = lane < nstep;
+      // (the gains and F_t of this block: wave 1 is somewhere ahead, or about to be)
+      int vp;
+      while ((vp = __hip_atomic_load(&s_vprog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= tb / BL)
+        __builtin_amdgcn_s_sleep(8);
+      if (vp == SSG_V_FAILED) {
+        if (lane == 0) P.status[chain] = __hip_atomic_load(&s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
       blk_load(blk, gK + (size_t)tb * m, nstep * m, lane);
       const double w_l = in_l ? w0[tt] : 0.0, F_l = in_l ? sres[tt] : 1.0;
       const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
@@ -518,7 +532,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   // r_{t-1} = T_t' r_t + Z ((v_t - v+_t) / F_t - K_t' r_t), r_{T-1} = 0.  r_t is in the
   // layout of step t + 1.  What the correction pass needs of r_t is its value at the rows
   // that carry state error: one series per variance parameter.
-  double r = 0.0;
   seek(B, LI, T, -1);   // (the layout of time T, the transition T - 1)
   for (int tb = ((T - 1) / BL) * BL; tb >= 0; tb -= BL) {
     const int tt = tb + lane;
@@ -554,48 +567,33 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
 
+  }
   SSTAMP(6);
   // ---- 5. forward: the mean correction E(alpha | y) - E(alpha | y+), the state
-  // draw, the state models' and the regression's sufficient statistics
-  double mc = P0l * r;          // a0 + P0 r0 - (a0 + P0 r0+)
-  double prev = 0.0;            // state_{t-1} (its own layout)
-  double suf_l = 0.0;           // local level / seasonal: sum of squared state errors (at the lane that carried them)
-  double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of a trend block's errors (its two lanes)
-  double yty = 0.0, nobs = 0.0;
-  // ArModel's NeRegSuf of now[first] on then[first ..]: lane first + i keeps xty_i and row i
-  // of xtx, the row in LDS at s_axx[(block's slot * AR_MAX + i) * (AR_MAX + 1) + q]
-  double axy = 0.0, ayy = 0.0;
-  for (int e2 = lane; e2 < M.nar * AR_MAX * (AR_MAX + 1); e2 += WAVE) s_axx[e2] = 0.0;
-  wave_lds_sync();
-  double *oblk = s_blk1;
-  seek(B, LI, 0, -1);
-  {
+  // draw, the state models' and the regression's sufficient statistics -- by BOTH waves:
+  // wave 0 runs the recursion of the correction and turns a block of alpha+ (LDS) into the
+  // block of state draws; wave 1 (its variance pass long over) follows one block behind with
+  // everything that only READS the draws: the state models' sufficient statistics, the
+  // residuals, the copy in logical order that goes out.  The two block buffers take turns.
+  if (wave == 0) {
+    double mc = P0l * r;          // a0 + P0 r0 - (a0 + P0 r0+)
+    seek(B, LI, 0, -1);
     for (int tb = 0; tb < T; tb += BL) {
-      const int tt = tb + lane;
+      const int tt = tb + lane, bi = tb / BL;
       const int nstep = (T - tb < BL) ? T - tb : BL;
       const bool in_l = lane < nstep;
-      blk_load(blk, gst + (size_t)tb * m, nstep * m, lane);
+      double *buf = (bi & 1) ? s_blk1 : s_blk0;
+      while (__hip_atomic_load(&s_cdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < bi - 1)
+        __builtin_amdgcn_s_sleep(4);
+      blk_load(buf, gst + (size_t)tb * m, nstep * m, lane);
       // r_{t-1} at the error rows, for the steps into tb .. tb + nstep - 1
       for (int e = 0; e < NE; ++e) s_z[e * BL + lane] = (in_l && tt > 0) ? gd[(size_t)e * T + tt - 1] : 0.0;
       wave_lds_sync();
-      const double y_l = in_l ? P.y[tt] : 0.0;
-      const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
-      double res_l = 0.0;
 #pragma nounroll
       for (int s = 0; s < nstep; ++s) {
-        const double ap = mylane ? blk[s * m + lane] : 0.0;
-        unsigned mv = 0;
-        double tot_then = 0.0;   // seasonal: sum of the block at t - 1 (kept by the lanes of the block)
+        const double ap = mylane ? buf[s * m + lane] : 0.0;
         if (tb + s > 0) {
-          mv = B.moving();
-          // (the seasonal models' observe_state needs the sum of `then` over the block)
-          unsigned sm = mv & B.seasmask;
-          while (sm) {
-            const int b = __ffs((int)sm) - 1;
-            sm &= sm - 1;
-            const double tb_ = wsum<SMALL>(LI.blk == b ? prev : 0.0);
-            if (LI.blk == b) tot_then = tb_;
-          }
+          const unsigned mv = B.moving();
           mc = vecT<SMALL>(B, LI, mc, lane, mv);
           advance(B, LI, mv, lane);
           // + RQR_{t-1} r_{t-1}
@@ -609,7 +607,61 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         } else {
           advance(B, LI, 0u, lane);
         }
-        const double st = mylane ? ap + mc : 0.0;
+        if (mylane) buf[s * m + lane] = ap + mc;
+      }
+      wave_lds_sync();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&s_cprog, bi + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    SSTAMP(7);
+#ifdef BA_KSTAMPS
+    if (chain == 0 && lane == 0 && draw_variances)
+      printf("ssm phases (cycles, wave 0): variances %lld ystar %lld normals %lld sim %lld wait-for-P %lld filter %lld backward %lld correction %lld\n",
+             kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
+#endif
+    return;
+  }
+  double prev = 0.0;            // state_{t-1} (its own layout)
+  double suf_l = 0.0;           // local level / seasonal: sum of squared state errors (at the lane that carried them)
+  double mv_ybar = 0.0, mv_sumsq = 0.0, mv_n = 0.0;   // MvnSuf of a trend block's errors (its two lanes)
+  double yty = 0.0, nobs = 0.0;
+  // ArModel's NeRegSuf of now[first] on then[first ..]: lane first + i keeps xty_i and row i
+  // of xtx, the row in LDS at s_axx[(block's slot * AR_MAX + i) * (AR_MAX + 1) + q]
+  double axy = 0.0, ayy = 0.0;
+  for (int e2 = lane; e2 < M.nar * AR_MAX * (AR_MAX + 1); e2 += WAVE) s_axx[e2] = 0.0;
+  wave_lds_sync();
+  seek(B, LI, 0, -1);
+  {
+    for (int tb = 0; tb < T; tb += BL) {
+      const int tt = tb + lane, bi = tb / BL;
+      const int nstep = (T - tb < BL) ? T - tb : BL;
+      const bool in_l = lane < nstep;
+      double *buf = (bi & 1) ? s_blk1 : s_blk0;
+      const double y_l = in_l ? P.y[tt] : 0.0;
+      const int ob_l = (in_l && P.observed[tt]) ? 1 : 0;
+      // (wave 0 only leaves early when THIS wave's variance pass failed, and then this wave has left too)
+      while (__hip_atomic_load(&s_cprog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= bi)
+        __builtin_amdgcn_s_sleep(8);
+      double res_l = 0.0;
+#pragma nounroll
+      for (int s = 0; s < nstep; ++s) {
+        const double st = mylane ? buf[s * m + lane] : 0.0;
+        unsigned mv = 0;
+        double tot_then = 0.0;   // seasonal: sum of the block at t - 1 (kept by the lanes of the block)
+        if (tb + s > 0) {
+          mv = B.moving();
+          // (the seasonal models' observe_state needs the sum of `then` over the block)
+          unsigned sm = mv & B.seasmask;
+          while (sm) {
+            const int b = __ffs((int)sm) - 1;
+            sm &= sm - 1;
+            const double tb_ = wsum<SMALL>(LI.blk == b ? prev : 0.0);
+            if (LI.blk == b) tot_then = tb_;
+          }
+          advance(B, LI, mv, lane);
+        } else {
+          advance(B, LI, 0u, lane);
+        }
         const double then1 = from_above(prev);
         if (tb + s > 0) {
           if (LI.kind == SSG_LOCAL_LEVEL) {
@@ -652,30 +704,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           }
         }
         prev = st;
-        if (mylane) {
-          // the state draw goes out in logical order
-          int idx = lane;
-          if (LI.kind == SSG_SEASONAL) {
-            const int q = lane - LI.first, c = LI.cur;
-            idx = LI.first + (q >= c ? q - c : q - c + LI.dim);
-          }
-          oblk[s * m + idx] = st;
+        // the state draw goes out in logical order (in place: every lane has read its entry)
+        if (mylane && LI.kind == SSG_SEASONAL) {
+          const int q = lane - LI.first, c = LI.cur;
+          buf[s * m + LI.first + (q >= c ? q - c : q - c + LI.dim)] = st;
         }
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
         const double resid = obs ? rl(y_l, s) - zdot<SMALL>(LI, st, lane) : 0.0;
         if (lane == s) res_l = resid;
         if (obs) { yty += resid * resid; nobs += 1.0; }
       }
-      blk_store(gst + (size_t)tb * m, oblk, nstep * m, lane);
+      blk_store(gst + (size_t)tb * m, buf, nstep * m, lane);
       if (in_l) sres[tt] = res_l;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&s_cdone, bi + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  SSTAMP(7);
-#ifdef BA_KSTAMPS
-  if (chain == 0 && lane == 0 && draw_variances)
-    printf("ssm phases (cycles, wave 0): variances %lld ystar %lld normals %lld sim %lld wait-for-P %lld filter %lld backward %lld correction %lld\n",
-           kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
-#endif
   // publish the sufficient statistics
   for (int b = 0; b < nb; ++b) {
     const unsigned d = B.udesc(b);
