@@ -50,6 +50,35 @@ with open(stats) as fh:
 with open(prefix + "_kernel_stats.csv", "w") as fh:
     fh.write("# commit %s | rocprofv3 --kernel-trace --stats -- python3 %s\n" % (commit, command))
     fh.write(body)
+# every launch of the first kernel family of the list, in start order, from the stats run's
+# kernel trace: launches that overlap (consecutive sweep launches hand chains over, DESIGN
+# section 1) last longer than a lone one, so the stats table's average mixes two things;
+# this file keeps them apart
+trace = os.path.join(os.path.dirname(stats), os.path.basename(stats).replace("kernel_stats", "kernel_trace"))
+if os.path.exists(trace):
+    with open(trace) as fh:
+        tr = [r for r in csv.DictReader(fh) if keys[0] in r["Kernel_Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    launches, prev_end = [], 0
+    for i, r in enumerate(tr):
+        s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        nxt = int(tr[i + 1]["Start_Timestamp"]) if i + 1 < len(tr) else None
+        launches.append({"kernel": short_name(r["Kernel_Name"]), "ms": round((e0 - s0) / 1e6, 4),
+                         "stream": r.get("Stream_Id", ""),
+                         "overlaps_another": bool(s0 < prev_end or (nxt is not None and nxt < e0))})
+        prev_end = max(prev_end, e0)
+    if launches and len(launches) <= 4000:
+        per = {}
+        for l in launches:
+            d = per.setdefault(l["kernel"], {"overlapping": [], "alone": []})
+            d["overlapping" if l["overlaps_another"] else "alone"].append(l["ms"])
+        means = {k: {"mean_ms_overlapping": round(sum(v["overlapping"]) / len(v["overlapping"]), 4) if v["overlapping"] else None,
+                     "n_overlapping": len(v["overlapping"]),
+                     "mean_ms_alone": round(sum(v["alone"]) / len(v["alone"]), 4) if v["alone"] else None,
+                     "n_alone": len(v["alone"])} for k, v in per.items()}
+        with open(prefix + "_launches.json", "w") as fh:
+            json.dump({"commit": commit, "command": "python3 " + command, "kernel_family": keys[0],
+                       "per_kernel": means, "launches_in_start_order": launches}, fh, indent=1)
 summary = {"commit": commit, "command": "python3 " + command, "source": src, "kernels": {}}
 rows_out = []
 for name in sorted(os.listdir(src)):
