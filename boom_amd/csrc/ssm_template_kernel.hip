@@ -418,6 +418,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
   double (&s_P)[SSM_MAX * PLD] = s_lds.pass.P;
+  double (&s_pz)[SSM_MAX] = s_lds.pass.tv;   // PZ of the step, for every lane to read (broadcast)
   const int chain = (int)blockIdx.x + P.chain_first, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= P.chain_count) return;
   if (P.status[chain] != CHAIN_OK) return;
@@ -599,6 +600,8 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     const int col = mylane ? lane : 0;
     // PZ_k of step 0: P0 is diagonal
     double PZ = (mylane && (lane == 0 || (SEAS && lane == S.s0) || (AR && lane == S.a0))) ? P0l : 0.0;
+    if (lane < SSM_MAX) s_pz[lane] = PZ;
+    wave_lds_sync();
     for (int tb = 0; tb < T; tb += WAVE) {
       const int tt = tb + lane;
       const int ob_l = (tt < T && P.observed[tt]) ? 1 : 0;
@@ -621,15 +624,20 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 #pragma unroll
           for (int i = 0; i < SSM_MAX; ++i) v[i] = s_P[i * PLD + col];
           if (obs) {
+            // (the other lanes' PZ from LDS, all lanes the same addresses: 8 wide reads instead of 32 v_readlane)
+            double pz[SSM_MAX];
 #pragma unroll
-            for (int i = 0; i < SSM_MAX; ++i) v[i] -= (rl(PZ, i) * PZ) * Finv;
+            for (int i = 0; i < SSM_MAX; ++i) pz[i] = s_pz[i];
+#pragma unroll
+            for (int i = 0; i < SSM_MAX; ++i) v[i] -= (pz[i] * PZ) * Finv;
           }
           if (TREND == 2) v[0] += v[1];
           double cs = 0.0;
           if (SEAS) {
+            // (without an autoregression block the rows past the seasonal block are zero: no guard)
             double t[SSM_MAX];
 #pragma unroll
-            for (int q = 0; q < SSM_MAX; ++q) t[q] = (q < S.ns && TREND + q < SSM_MAX) ? v[(TREND + q) & (SSM_MAX - 1)] : 0.0;
+            for (int q = 0; q < SSM_MAX; ++q) t[q] = ((!AR || q < S.ns) && TREND + q < SSM_MAX) ? v[(TREND + q) & (SSM_MAX - 1)] : 0.0;
             cs = -((((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
                    (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]))));
           }
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           if (SEAS) {
             double t[SSM_MAX];
 #pragma unroll
-            for (int q = 0; q < SSM_MAX; ++q) t[q] = (q < S.ns && TREND + q < SSM_MAX) ? row[(TREND + q) & (SSM_MAX - 1)] : 0.0;
+            for (int q = 0; q < SSM_MAX; ++q) t[q] = ((!AR || q < S.ns) && TREND + q < SSM_MAX) ? row[(TREND + q) & (SSM_MAX - 1)] : 0.0;
             double cr = -((((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
                           (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]))));
             if (lane == rw) cr += sig2[2];
@@ -697,6 +705,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           }
           if (mylane && (TREND == 2 || lane == 0)) row[0] = n0;
           PZ = mylane ? nz : 0.0;
+          if (lane < SSM_MAX) s_pz[lane] = PZ;
           wave_lds_sync();
         }
         c = cn;
