@@ -393,6 +393,97 @@ __device__ __forceinline__ int ar_draw(ArLds &W, const Tpl &Q, int chain, SeqRng
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
 }
 
+// ---- time across the lanes (round 4).  Two of the five passes have no gain in them: the
+// simulation alpha+_{t+1} = T alpha+_t + eta_t and the mean correction m_{t+1} = T m_t +
+// RQR r_t are sums of their inputs --
+//   slope_t = slope_0 + sum_{s<=t} n1_s,   level_t = level_0 + sum_{s<=t} (slope_{s-1} + n0_s),
+//   seasonal, x_t = the block's first component at time t (component i is x_{t-i}):
+//     x_t = -(x_{t-1} + ... + x_{t-ns}) + N_t; subtracting the same line for t - 1:
+//     x_t = x_{t-ns-1} + (N_t - N_{t-1}) for t >= 2: ns + 1 interleaved running sums --
+// so lane l of a block of 64 steps takes time tb + l and the sums are wave scans (six
+// ds_bpermute steps; the seasonal one in strides of ns + 1), with the carries of the
+// previous block.  250 instructions per 64 steps where the serial passes spent 64 x 90
+// (simulation) and 64 x 180 (correction + statistics): the launch's critical path was
+// V + F + B + C and is V + B now.  (The autoregression block's recursion has its
+// coefficients in it: those shapes keep the serial passes.)  The sums are the
+// reference's sums in another order: results agree to rounding (1e-13 observed), inside
+// the stated 1e-8.
+__device__ __forceinline__ double scan_incl(double x, int lane, int first_shift) {
+  for (int d = first_shift; d < WAVE; d <<= 1) {
+    const double y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+__device__ __forceinline__ double wave_total(double x) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) x += __shfl_xor(x, d);
+  return x;
+}
+struct PathCarry {
+  double slope, level;   // the values at the previous block's last step
+  double nprev;          // the seasonal input of the previous block's last step
+  double prevx;          // lane l: x at the previous block's step l
+};
+struct PathStep {
+  double lev, slo;
+  double seas[SSM_MAX - 1];   // component i of the seasonal block (logical order)
+};
+// one block: lane = time t (in: t < T); n0, n1, N2: the level's, slope's and seasonal inputs
+// of time t (0 for t = 0 and past T); cidx: where lane l finds its predecessor of the
+// previous block in the strided sum, 64 - (ns + 1) + l mod (ns + 1)
+template <int TREND, bool SEAS>
+__device__ __forceinline__ void path_block(const Shape &S, int lane, int cidx, int t, bool in, double n0, double n1,
+                                           double N2, PathCarry &C, double *s_xw, PathStep &out) {
+  double sl = 0.0;
+  if (TREND == 2) sl = C.slope + scan_incl(n1, lane, 1);
+  double linc = n0;
+  if (TREND == 2) {
+    double slm1 = __shfl_up(sl, 1);
+    if (lane == 0) slm1 = C.slope;
+    linc = (in && t >= 1) ? slm1 + n0 : 0.0;
+  }
+  const double lv = C.level + scan_incl(linc, lane, 1);
+  out.lev = lv;
+  out.slo = sl;
+  if (SEAS) {
+    double np = __shfl_up(N2, 1);
+    if (lane == 0) np = C.nprev;
+    const double g = (in && t >= 2) ? N2 - np : 0.0;
+    const double x = scan_incl(g, lane, S.ns + 1) + __shfl(C.prevx, cidx);
+    // the window of the last sixteen values of x in front of the block's own
+    if (lane >= WAVE - 16) s_xw[lane - (WAVE - 16)] = C.prevx;
+    s_xw[16 + lane] = x;
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < SSM_MAX - 1; ++i) out.seas[i] = (i < S.ns) ? s_xw[16 + lane - i] : 0.0;
+    wave_lds_sync();
+    C.prevx = x;
+    C.nprev = rl(N2, WAVE - 1);
+  }
+  C.slope = rl(sl, WAVE - 1);
+  C.level = rl(lv, WAVE - 1);
+}
+// the carries in front of time 0: init = the vector at time 0, one component per lane
+// (cursor 0: physical = logical order); N2_1 = the seasonal input of time 1
+template <int TREND, bool SEAS>
+__device__ __forceinline__ void path_start(const Shape &S, int lane, double init, double N2_1, PathCarry &C) {
+  C.level = rl(init, 0);
+  C.slope = (TREND == 2) ? rl(init, 1) : 0.0;
+  C.nprev = 0.0;
+  C.prevx = 0.0;
+  if (SEAS) {
+    const int P = S.ns + 1;
+    const double x0 = rl(init, S.s0);
+    const double x1 = -row_total(S.seasonal(lane) ? init : 0.0) + N2_1;
+    // lane 64 - P + rho stands for time rho - P: x_{rho - P} = init[s0 + P - rho] for rho >= 2; the lanes of
+    // times -P and -P + 1 carry x_0 and x_1 (which have no predecessor of their own)
+    const int rho = lane - (WAVE - P);
+    const double v = __shfl(init, (rho >= 2) ? S.s0 + P - rho : 0);
+    C.prevx = (rho < 0) ? 0.0 : (rho == 0 ? x0 : (rho == 1 ? x1 : v));
+  }
+}
+
 }  // namespace
 
 // grid = chains, block = 128.  TREND: 1 local level, 2 local linear trend; SEAS: a
@@ -414,6 +505,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   __shared__ SharedLds s_lds;
   __shared__ int s_flag;
   __shared__ int s_vprog;                 // blocks of 64 steps the variance pass has put out (wave 1 -> wave 0)
+  __shared__ double s_xw[16 + WAVE];        // the seasonal scans' window (wave 0)
   __shared__ int s_cprog, s_cdone;        // the last pass: blocks of state draws wave 0 has made / wave 1 has taken
   __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
@@ -724,6 +816,53 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       }
       return;
     }
+    if (!AR) return;   // (the last pass is wave 0's alone: time across the lanes)
+  } else if (!AR) {
+    // ---- simulate alpha+_t, y+_t and w_t = y*_t - y+_t with time across the lanes
+    double alpha0;
+    {
+      double z = 0.0;
+      if (mylane) {
+        if (lane < TREND) z = (lane < d0) ? szz[lane] : 0.0;
+        else z = szz[d0 + (lane - TREND)];
+      }
+      alpha0 = mylane ? sqrt(P0l) * z + a0l : 0.0;   // simulate_initial_state: mean_i + sd_i z_i
+    }
+    PathCarry PC;
+    const double zs1 = (SEAS && dS && T > 1) ? szz[nfirst + dT] : 0.0;
+    path_start<TREND, SEAS>(S, lane, alpha0, sdv[2] * zs1, PC);
+    const int cidx = SEAS ? WAVE - (S.ns + 1) + lane % (S.ns + 1) : 0;
+    for (int tb = 0; tb < T; tb += WAVE) {
+      const int tt = tb + lane;
+      const bool in_l = tt < T;
+      const double ys_l = in_l ? w0[tt] : 0.0;
+      const int nb_l = (tt == 0) ? 0 : nfirst + (tt - 1) * nper;
+      double z0_l = 0.0, z1_l = 0.0, zs_l = 0.0, zh_l = 0.0;
+      if (in_l && tt > 0) {
+        int o = nb_l;
+        if (dT >= 1) z0_l = szz[o++];
+        if (dT == 2) z1_l = szz[o++];
+        if (dS) zs_l = szz[o++];
+        if (dH) zh_l = szz[o];
+      } else if (in_l) {
+        if (dH) zh_l = szz[d0 + S.ns + S.na];
+      }
+      PathStep a;
+      path_block<TREND, SEAS>(S, lane, cidx, tt, in_l, sdv[0] * z0_l, sdv[1] * z1_l, sdv[2] * zs_l, PC, s_xw, a);
+      const double yplus = (a.lev + (SEAS ? a.seas[0] : 0.0)) + sqrtH * zh_l;   // simulate_adjusted_observation
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      if (in_l) {
+        w0[tt] = ys_l - yplus;
+        blk[lane * m] = a.lev;
+        if (TREND == 2) blk[lane * m + 1] = a.slo;
+        if (SEAS) {
+#pragma unroll
+          for (int i = 0; i < SSM_MAX - 1; ++i)
+            if (i < S.ns) blk[lane * m + TREND + i] = a.seas[i];
+        }
+      }
+      blk_store(gst + (size_t)tb * m, blk, nstep * m, lane);   // (alpha+ in logical order: only the last pass reads it)
+    }
   } else {
     double alpha = 0.0;
     int c = 0;
@@ -860,6 +999,101 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 
   }
   SSTAMP(6);
+  if (!AR) {
+    // ---- 5'. the mean correction, the state draw and every sufficient statistic with
+    // time across the lanes (wave 0; wave 1 has left)
+    const double mc0 = mylane ? P0l * r : 0.0;   // a0 + P0 r0 - (a0 + P0 r0+), time 0's layout
+    PathCarry PC;
+    path_start<TREND, SEAS>(S, lane, mc0, (SEAS && T > 1) ? sig2[2] * gd[(size_t)2 * T] : 0.0, PC);
+    const int cidx = SEAS ? WAVE - (S.ns + 1) + lane % (S.ns + 1) : 0;
+    double c_lev = 0.0, c_slo = 0.0, c_sum = 0.0;   // the state of the previous block's last step
+    double ss0 = 0.0, ss1 = 0.0, ss2 = 0.0, yty = 0.0, nobs = 0.0;
+    for (int tb = 0; tb < T; tb += WAVE) {
+      const int tt = tb + lane;
+      const bool in_l = tt < T;
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      blk_load(blk, gst + (size_t)tb * m, nstep * m, lane);
+      const bool dd = in_l && tt > 0;
+      const double d0_l = dd ? gd[tt - 1] : 0.0;
+      const double d1_l = (dd && TREND == 2) ? gd[(size_t)T + tt - 1] : 0.0;
+      const double d2_l = (dd && SEAS) ? gd[(size_t)2 * T + tt - 1] : 0.0;
+      const double y_l = in_l ? P.y[tt] : 0.0;
+      const bool ob_l = in_l && P.observed[tt];
+      PathStep c;
+      path_block<TREND, SEAS>(S, lane, cidx, tt, in_l, sig2[0] * d0_l, sig2[1] * d1_l, sig2[2] * d2_l, PC, s_xw, c);
+      double st0 = 0.0, st1 = 0.0, sea0 = 0.0, bsum = 0.0;
+      double sea[SSM_MAX - 1];
+      if (in_l) {
+        st0 = blk[lane * m] + c.lev;
+        if (TREND == 2) st1 = blk[lane * m + 1] + c.slo;
+      }
+      if (SEAS) {
+#pragma unroll
+        for (int i = 0; i < SSM_MAX - 1; ++i) {
+          sea[i] = (in_l && i < S.ns) ? blk[lane * m + TREND + i] + c.seas[i] : 0.0;
+          bsum += sea[i];
+        }
+        sea0 = sea[0];
+      }
+      // the state before this step: the lane below (the previous block's last lane for lane 0)
+      double p0 = __shfl_up(st0, 1), p1 = __shfl_up(st1, 1), pb = __shfl_up(bsum, 1);
+      if (lane == 0) { p0 = c_lev; p1 = c_slo; pb = c_sum; }
+      if (dd) {
+        if (TREND == 1) {
+          const double diff = st0 - p0;
+          ss0 += diff * diff;
+        } else {
+          // err = now - T then (MvnSuf of the errors: what is published is sum err^2)
+          const double e0 = st0 - (p0 + p1), e1 = st1 - p1;
+          ss0 += e0 * e0;
+          ss1 += e1 * e1;
+        }
+        if (SEAS) {
+          const double dl = sea0 - (-1.0 * pb);   // now[0] + sum(then) over the block
+          ss2 += dl * dl;
+        }
+      }
+      const double resid = ob_l ? y_l - (st0 + (SEAS ? sea0 : 0.0)) : 0.0;
+      if (ob_l) { yty += resid * resid; nobs += 1.0; }
+      wave_lds_sync();
+      if (in_l) {
+        blk[lane * m] = st0;
+        if (TREND == 2) blk[lane * m + 1] = st1;
+        if (SEAS) {
+#pragma unroll
+          for (int i = 0; i < SSM_MAX - 1; ++i)
+            if (i < S.ns) blk[lane * m + TREND + i] = sea[i];
+        }
+        sres[tt] = resid;
+      }
+      blk_store(gst + (size_t)tb * m, blk, nstep * m, lane);
+      c_lev = rl(st0, WAVE - 1); c_slo = rl(st1, WAVE - 1); c_sum = rl(bsum, WAVE - 1);
+    }
+    ss0 = wave_total(ss0); ss1 = wave_total(ss1); ss2 = wave_total(ss2);
+    yty = wave_total(yty); nobs = wave_total(nobs);
+    SSTAMP(7);
+#ifdef BA_KSTAMPS
+    if (chain == 0 && lane == 0 && draw_variances)
+      printf("ssm phases (cycles, wave 0): variances %lld ystar %lld normals %lld sim %lld wait-for-P %lld filter %lld backward %lld correction %lld\n",
+             kph[0], kph[1], kph[2], kph[3], kph[4], kph[5], kph[6], kph[7]);
+#endif
+    if (lane == 0) {
+      Q.M.var_n[Q.at(chain, 0)] = (double)(T - 1);
+      Q.M.var_ss[Q.at(chain, 0)] = ss0;
+      if (TREND == 2) {
+        Q.M.var_n[Q.at(chain, 1)] = (double)(T - 1);
+        Q.M.var_ss[Q.at(chain, 1)] = ss1;
+      }
+      if (SEAS) {
+        Q.M.var_n[Q.at(chain, 2)] = (double)(T - 1);
+        Q.M.var_ss[Q.at(chain, 2)] = ss2;
+      }
+      P.yty[chain] = yty;
+      P.nobs[chain] = nobs;
+      P.status[chain] = status;
+    }
+    return;
+  }
   // ---- 5. forward: the mean correction E(alpha | y) - E(alpha | y+), the state
   // draw, the state models' and the regression's sufficient statistics -- by BOTH waves:
   // wave 0 runs the recursion of the correction and turns a block of alpha+ (LDS) into the
