@@ -710,6 +710,74 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         const double TPZ = vecT<TREND, SEAS, AR>(S, PZ, lane, c, phl);
         if (mylane) blk[s * m + lane] = obs ? TPZ * Finv : 0.0;
         if (lane == s) F_l = F;
+        if (!AR) {
+          // -- ONE phase (no autoregression block).  Lane k reads ITS column, takes the
+          // rank-one term off, applies T from the left: u = (T P~)[:, k].  T' from the right
+          // leaves a column alone unless its own row of T is not a unit row -- so for every
+          // lane but the block-first ones (lane 0 of a local linear trend, the lane of the new
+          // first seasonal component) u IS the new column, and the entries of the special
+          // columns are, P being symmetric, entries of the other lanes' u: lane k writes
+          // P'(0, k) also to (k, 0) and P'(rw, k) also to (k, rw).  What is left are the four
+          // entries where two special rows meet: sums of the neighbours' u (two v_readlane)
+          // and one total over the seasonal lanes.  The next step's PZ_k comes out of the
+          // same registers.  One LDS round trip a step instead of two.
+          double v[SSM_MAX];
+#pragma unroll
+          for (int i = 0; i < SSM_MAX; ++i) v[i] = s_P[i * PLD + col];
+          if (obs) {
+            double pz[SSM_MAX];
+#pragma unroll
+            for (int i = 0; i < SSM_MAX; ++i) pz[i] = s_pz[i];
+#pragma unroll
+            for (int i = 0; i < SSM_MAX; ++i) v[i] -= (pz[i] * PZ) * Finv;
+          }
+          double u0 = (TREND == 2) ? v[0] + v[1] : v[0];
+          double cs = 0.0;
+          if (SEAS) {
+            double t[SSM_MAX];
+#pragma unroll
+            for (int q = 0; q < SSM_MAX; ++q) t[q] = (TREND + q < SSM_MAX) ? v[(TREND + q) & (SSM_MAX - 1)] : 0.0;
+            cs = -((((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                   (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]))));
+          }
+          if (!mylane) { u0 = 0.0; cs = 0.0; }
+          // where the special rows meet (valid in lane 0 / everywhere)
+          double p00 = u0 + sig2[0], p0rw = cs;
+          if (TREND == 2) {
+            p00 = (u0 + rl(u0, 1)) + sig2[0];
+            p0rw = cs + rl(cs, 1);
+          }
+          const double p0rw_u = rl(p0rw, 0);                                               // P'(0, rw) = P'(rw, 0)
+          const double prwrw = SEAS ? -row_total(S.seasonal(lane) ? cs : 0.0) + sig2[2] : 0.0;   // P'(rw, rw)
+          const bool first_trend = TREND == 2 && lane == 0, first_seas = SEAS && lane == rw;
+          if (mylane) {
+            if (!first_trend && !first_seas) {
+              v[0] = (lane == 0) ? p00 : u0;            // (a local level's lane 0: an ordinary column, + RQR)
+              if (TREND == 2 && lane == 1) v[1] += sig2[1];
+#pragma unroll
+              for (int i = 0; i < SSM_MAX; ++i) s_P[i * PLD + lane] = v[i];
+              if (SEAS) {
+                s_P[rw * PLD + lane] = cs;
+                s_P[lane * PLD + rw] = cs;
+              }
+              if (TREND == 2) s_P[lane * PLD] = u0;
+            } else if (first_trend) {
+              s_P[0] = p00;
+              if (SEAS) { s_P[rw] = p0rw; s_P[rw * PLD] = p0rw; }
+            } else {
+              s_P[rw * (PLD + 1)] = prwrw;
+            }
+          }
+          // PZ_k of the next step: P'(0, k) + P'(new first seasonal, k)
+          double nz = (lane == 0) ? p00 : u0;
+          if (SEAS) nz += first_trend ? p0rw : (first_seas ? prwrw : cs);
+          if (SEAS && first_seas) nz = p0rw_u + prwrw;
+          PZ = mylane ? nz : 0.0;
+          if (lane < SSM_MAX) s_pz[lane] = PZ;
+          wave_lds_sync();
+          c = cn;
+          continue;
+        }
         // -- the column phase
         {
           double v[SSM_MAX];
