@@ -190,7 +190,10 @@ def other_configs(boom_amd, torch, device, cpu=True):
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(bytes3 / (kt["kalman_simsmooth_kernel"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "round_frac": round(bytes3 / dt * 200 / 1e9 / HBM_PEAK_GBS, 4),
-                        "slowest_kernel_of_the_round": dom, "traffic": None}}
+                        "slowest_kernel_of_the_round": dom,
+                        "traffic": _profile_traffic("c3", "kalman_lm_kernel"),
+                        "traffic_source": "profiles/r*_c3_pmc_traffic.json (rocprofv3 --pmc passes of "
+                                          "tools/ss_bench.py), per launch of the state draw"}}
     if cpu:
         opts3 = ssvs_options(sigma_upper_limit=sig_up)
         g3 = np.zeros(p3, np.uint8)
@@ -312,7 +315,9 @@ def other_configs(boom_amd, torch, device, cpu=True):
                         "flops_per_round": flops5, "achieved": round(flops5 / (kt[cols] * 1e-3) / 1e12, 2),
                         "peak": F64_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(flops5 / (kt[cols] * 1e-3) / 1e12 / F64_MATRIX_PEAK_TF, 4),
-                        "traffic": None,
+                        "traffic": _profile_traffic("logit", "xtwx_cols_kernel<true"),
+                        "traffic_source": "profiles/r*_logit_pmc_traffic.json, per launch of the request GEMM "
+                                          "(several launches a round)",
                         "note": "v_mfma_f64_16x16x4_f64; R taken as chains x mean model size (the vectors "
                                 "requested mid-sweep add a few percent)"}}
     if cpu:
@@ -354,7 +359,8 @@ def other_configs(boom_amd, torch, device, cpu=True):
         "roofline": {"bound": "mfma", "kernel": "xtwx_cols_kernel<true>", "flops_per_round": flopsp,
                      "achieved": round(flopsp / (ktp[cols] * 1e-3) / 1e12, 2), "peak": F64_MATRIX_PEAK_TF,
                      "unit": "TFLOP/s", "frac": round(flopsp / (ktp[cols] * 1e-3) / 1e12 / F64_MATRIX_PEAK_TF, 4),
-                     "traffic": None},
+                     "traffic": _profile_traffic("pg", "xtwx_cols_kernel<true"),
+                     "traffic_source": "profiles/r*_pg_pmc_traffic.json, per launch of the request GEMM"},
         "cpu_baseline": None}
     if cpu:
         rate, nsw = _cpu_rate(lambda c, n: O.logit_run(Xsub, ysub, ntsub, slabs, pis,
@@ -404,7 +410,8 @@ def other_configs(boom_amd, torch, device, cpu=True):
                          "algorithmic_bytes_per_launch": round(bytesd, 0),
                          "achieved": round(bytesd / (msd * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(bytesd / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": _profile_traffic("dense64", "ssvs_")}}
+                         "traffic": _profile_traffic("dense64", "ssvs_big_kernel"),
+                         "traffic_source": "profiles/r*_dense64_pmc_traffic.json, per 200-sweep launch of ssvs_big_kernel"}}
     if cpu:
         def rund(nchains, nsw, nthreads):
             t0 = time.perf_counter()

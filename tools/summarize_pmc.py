@@ -35,8 +35,9 @@ keys = keys or ["ssvs_", "kalman", "atb_mfma", "xtx_mfma"]
 
 
 def short_name(kn):
-    return (kn.split("(")[0].replace("void ", "").replace("boom_amd::", "")
-            .replace("(anonymous namespace)::", ""))
+    # ("(anonymous namespace)::" goes first: its bracket is not the argument list's)
+    return (kn.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            .replace("boom_amd::", ""))
 
 
 stats = os.path.join(src, "stats", "stats_kernel_stats.csv")
