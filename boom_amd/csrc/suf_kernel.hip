@@ -28,13 +28,35 @@ constexpr int LDP = KC + 2; // padded panel stride (doubles)
 
 __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict__ X,
                                                        int64_t n, int p,
-                                                       double *__restrict__ xtx) {
+                                                       double *__restrict__ xtx, int edge) {
   // two panels in LDS: the next one is fetched (into registers, then LDS) while the
   // matrix cores work on the current one
   __shared__ double sA[2][TILE * LDP];
   __shared__ double sB[2][TILE * LDP];
-  const int tj = blockIdx.x, ti = blockIdx.y;
-  if (tj > ti) return;  // lower block-triangle only; mirrored on store
+  // Which tile: blocks b and b + 8 share an XCD (and its L2; dealt round-robin -- observed,
+  // MI355X_MICROARCH.md "Workgroup dispatch, XCD placement": a speed assumption, never one
+  // of correctness), and the 64 workgroups an XCD holds at a time should be tiles that
+  // share panels of X.  So the j-th block of "XCD" x = b % 8 takes tile j % edge^2 of the
+  // (j / edge^2) * 8 + x -th edge x edge SUPERTILE of the lower block triangle (edge 8 at
+  // p = 4096: an XCD's resident set is one supertile -- 8 + 8 panels for 64 tiles), where
+  // the plain (tj, ti) order gave an XCD every eighth tile of a tile row, all eight L2s
+  // streaming every panel (52-103 GB of HBM traffic for 3.3 GB of X at n = 1e5, p = 4096:
+  // profiles/r04_c4_pmc_traffic.json).  The host picks the edge so that every XCD has work.
+  const int tiles = (p + TILE - 1) / TILE, S = (tiles + edge - 1) / edge;
+  int ti, tj;
+  {
+    const unsigned b = blockIdx.x, x = b % 8u, j = b / 8u, e2 = (unsigned)(edge * edge);
+    const unsigned q = (j / e2) * 8u + x, in = j % e2;
+    if (q >= (unsigned)(S * (S + 1) / 2)) return;
+    // supertile q of the lower triangle, row by row: (si, sj), sj <= si
+    int si = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+    while ((unsigned)((si + 1) * (si + 2) / 2) <= q) ++si;
+    while ((unsigned)(si * (si + 1) / 2) > q) --si;
+    const int sj = (int)q - si * (si + 1) / 2;
+    ti = si * edge + (int)(in / (unsigned)edge);
+    tj = sj * edge + (int)(in % (unsigned)edge);
+  }
+  if (ti >= tiles || tj > ti) return;  // lower block-triangle only; mirrored on store
   const int I0 = ti * TILE, J0 = tj * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;  // quadrant of the 64 x 64 tile
@@ -270,17 +292,33 @@ int suf_row_slices(int64_t n, int p) {
   return ksplit < 1 ? 1 : ksplit;
 }
 
+// supertile edge (see xtx_mfma_kernel): the largest of 8, 4, 2, 1 that leaves every XCD at
+// least four supertiles of the lower triangle
+static int suf_edge(int tiles) {
+  for (int e = 8; e > 1; e >>= 1) {
+    const int S = (tiles + e - 1) / e;
+    if (S * (S + 1) / 2 >= 32) return e;
+  }
+  return 1;
+}
+// 8 x edge^2 blocks for every eight supertiles of the lower triangle
+static unsigned suf_grid_blocks(int tiles, int edge) {
+  const int S = (tiles + edge - 1) / edge, lower = S * (S + 1) / 2;
+  return (unsigned)(((lower + 7) / 8) * 8 * edge * edge);
+}
+
 int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        const double *y, double *xtx, double *xty,
                        double *scalars, double *xsum, double *planes) {
   const int tiles = (p + TILE - 1) / TILE;
   const int ksplit = planes ? suf_row_slices(n, p) : 1;
+  const int edge = suf_edge(tiles);
   KtScope kt(stream, KT_SUF);
   if (ksplit <= 1) {
-    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles, 1), dim3(256), 0, stream, X, n, p, xtx);
+    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(suf_grid_blocks(tiles, edge), 1, 1), dim3(256), 0, stream, X, n, p, xtx, edge);
   } else {
     const size_t count = (size_t)p * p;
-    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(tiles, tiles, ksplit), dim3(256), 0, stream, X, n, p, planes);
+    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(suf_grid_blocks(tiles, edge), 1, ksplit), dim3(256), 0, stream, X, n, p, planes, edge);
     hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
                        planes, ksplit, count, xtx);
   }
