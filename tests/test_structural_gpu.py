@@ -52,7 +52,8 @@ def used(trend, ns):
                          [(1, 0, 150, 0.0), (2, 0, 150, 0.0), (1, 7, 200, 0.0),
                           (2, 4, 150, 0.05), (2, 12, 300, 0.0), (2, 15, 130, 0.03),
                           (1, 2, 65, 0.0), (2, 7, 700, 0.0), (2, 4, 3, 0.0), (1, 3, 2, 0.0),
-                          (2, 0, 64, 0.0), (2, 5, 128, 0.02)])
+                          (2, 0, 64, 0.0), (2, 5, 128, 0.02), (1, 16, 70, 0.0), (2, 12, 2100, 0.02),
+                          (1, 12, 13, 0.0)])
 def test_structural_sweeps_match_oracle(oracle, trend, nseasons, T, missing):
     p, chains, seed, nsw = 6, 5, 29, 12
     X, y, _, obs = structural_data(T, p, 2, nseasons, seed=3 + nseasons, missing_frac=missing)
