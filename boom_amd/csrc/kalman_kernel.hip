@@ -258,6 +258,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
     const double SS = P.level_sumsq[chain] + P.level_prior_ss;
     level_sigsq = d_draw_variance(rng, DF, SS, P.level_sigma_max, &bad);
     if (bad) status = CHAIN_RNG_BRANCH;
+    __syncthreads();   // (every thread has read the position it draws from: see ssm_template_kernel.hip)
     if (lane == 0 && wave == 0) {  // (wave 1 repeats the draw: it needs sigma_level != 0)
       P.pos_level[chain] = rng.pos;
       P.level_sigsq[chain] = level_sigsq;
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void kalman_lm_kernel(SsParams P, in
     const double SS = P.level_sumsq[chain] + P.level_prior_ss;
     level_sigsq = d_draw_variance(rng, DF, SS, P.level_sigma_max, &bad);
     if (bad) status = CHAIN_RNG_BRANCH;
+    __syncthreads();   // (every thread has read the position it draws from)
     if (tid == 0) {
       P.pos_level[chain] = rng.pos;
       P.level_sigsq[chain] = level_sigsq;
@@ -1148,6 +1150,7 @@ __global__ __launch_bounds__(128) void kalman_prepare_kernel(SsParams P, int dra
     const double SS = P.level_sumsq[chain] + P.level_prior_ss;
     level_sigsq = d_draw_variance(rng, DF, SS, P.level_sigma_max, &bad);
     if (bad) status = CHAIN_RNG_BRANCH;
+    __syncthreads();   // (every thread has read the statistics and the position it draws from)
     if (threadIdx.x == 0) {
       P.pos_level[chain] = rng.pos;
       P.level_sigsq[chain] = level_sigsq;

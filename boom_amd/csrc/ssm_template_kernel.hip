@@ -550,6 +550,9 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
         // Sigma is the inverse of that again
         if (TREND == 2 && i < 2) draw = 1.0 / (1.0 / draw);
         sig2[i] = draw;
+        // (every thread makes the draw from the position it READ: none may find the new one --
+        // a wave that fell one draw behind did, under load, until round 4's stress runs)
+        __syncthreads();
         if (lane == 0 && wave == 0) {
           Q.M.pos_var[Q.at(chain, i)] = rng.pos;
           Q.M.var_sigsq[Q.at(chain, i)] = draw;

@@ -108,6 +108,38 @@ def test_structural_draw_next_serves_the_per_call_draws():
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("desc", [[("trend",), ("seasonal", 7, 1)], [("level",), ("seasonal", 12, 1)],
+                                  [("trend",), ("seasonal", 12, 1), ("ar", 1)], [("trend",)]])
+def test_template_shapes_behind_the_look_ahead(desc):
+    """the shapes that run the kernel compiled for them (ssm_template_kernel.hip), batches
+    enqueued back to back while the other engine's launches run beside them.  (Round 4's
+    stress runs, tools/ss_la_stress.py, found a race here that the per-call tests could not
+    see: every thread of the state kernels draws the state models' variances from the stream
+    position it reads, and thread 0 stored the new position without waiting for the other
+    wave to have read the old one -- a wave that fell a draw behind under load drew another
+    variance than its neighbour.)"""
+    T, p, chains, L = 200, 8, 40, 6
+    seas = [(d[1], d[2]) for d in desc if d[0] == "seasonal"]
+    X, y, _, obs = general_data(T, p, 2, seas, seed=8, missing_frac=0.02,
+                                ar_coef=[0.5] if any(d[0] == "ar" for d in desc) else None)
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    blocks = general_spec(y, desc)
+    g0 = np.zeros(p, np.uint8)
+    a = make_general_engine(chains, 7, y, X, obs, prior, blocks, sig_up, g0)
+    b = make_general_engine(chains, 7, y, X, obs, prior, blocks, sig_up, g0)
+    b.ss_set_lookahead(L)
+    for it in range(60):
+        a.ss_sweep(1)
+        b.ss_draw_next()
+        for u, v in zip(a.get_states(), b.get_states()):
+            assert np.array_equal(u, v), it
+        if it % 7 == 3:
+            a.ss_sweep(2)
+            b.ss_sweep(2)
+        if it % 11 == 5:
+            assert np.array_equal(a.ss_get_state_draw(17), b.ss_get_state_draw(17)), it
+
+
 def test_a_capacity_stop_inside_a_batch():
     """chains that outgrow the sweep kernel's working capacity inside a look-ahead batch
     (40 signals from the empty model: 16 -> 32 -> 48): the batch is run again round by
