@@ -873,10 +873,10 @@ def main():
             e2.sweep(BURN_IN)
             e2.sweep(SWEEPS_PER_STEP)
             t0 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(4):
                 e2.sweep(SWEEPS_PER_STEP, sync=False)
             e2.sync()
-            curve[str(nch)] = round(2 * nch * SWEEPS_PER_STEP / (time.perf_counter() - t0), 1)
+            curve[str(nch)] = round(4 * nch * SWEEPS_PER_STEP / (time.perf_counter() - t0), 1)
             e2.close()
         curve[str(CHAINS_PER_GPU)] = round(value / world, 1)
 

@@ -339,6 +339,7 @@ struct ba_engine {
   bool pipe_on = false;      // the last thing enqueued was a pipelined sweep launch
   bool pipe_unchecked = false;   // a pipelined launch has gone out since the error word was last read
   int pipe_k = 0;            // launches in the current pipeline
+  bool pipe_groups = false;  // ... which are the chain GROUPS of an engine of more chains than the machine holds
   DevBuf<int32_t> dprep_n;
   DevBuf<uint64_t> dprep_pos_state, dprep_pos_level;
   DevBuf<double> dprep_level;
@@ -1180,6 +1181,7 @@ int pipe_join(ba_engine *e) {
   if (!e->pipe_on) return BA_OK;
   e->pipe_on = false;
   e->pipe_k = 0;
+  e->pipe_groups = false;
   HIP_TRY(hipEventRecord(e->pipe_join_ev, e->pipe_stream));
   HIP_TRY(hipStreamWaitEvent(e->stream, e->pipe_join_ev, 0));
   return BA_OK;
@@ -2472,25 +2474,45 @@ int sweep_impl(ba_engine *e, int32_t nsweeps, bool record, int la_half) {
                          e->cfg.chains <= resident_per_cu * e->cu_count && (!e->kt_enabled || e->kt_overlap);
   if (la_half >= 0 && !pipelined) return fail(BA_E_STATE, "look-ahead batch cannot overlap");
   if (!pipelined) {
-    int rcj = pipe_join(e);
-    if (rcj) return rcj;
-    // More chains than the machine holds.  One launch of more workgroups than fit runs in
-    // rounds, and on this machine a few workgroups of the last round then start a whole
-    // round late (measured at 2048 chains: 2 - 12 workgroups start at 33 ms, when round-2
-    // workgroups end, although every round-1 workgroup is gone by 23 ms -- 53 ms per launch
-    // where two launches of 1024 take 46).  With many rounds that is a small share and the
-    // rounds hide each other's slowest chains (8192 chains: 166 ms against 184 for eight
-    // launches); with exactly two or three it is not: those go out as separate launches of
-    // as many workgroups as fit, one after the other.
+    // More chains than the machine holds (round 4).  The chains go out in GROUPS of what fits
+    // at once, the groups alternating between the engine's two streams: group g + 1's
+    // workgroups move into the slots group g's early finishers leave -- different chains,
+    // so no hand-over is needed -- and a group's next launch follows its last one on the
+    // same stream.  (Rounds 1-3: one launch of more workgroups than fit -- a few workgroups
+    // of the last round then start a whole round late on this machine, 53 ms per
+    // 2048-chain launch where two launches of 1024 take 46 -- or, for exactly two or three
+    // groups, separate launches one after the other, each as long as its slowest chain.)
     const int C = e->cfg.chains, group = resident_per_cu * e->cu_count;
-    if (nsweeps > 0 && e->cur_mode != 2 && !e->big_active && (C == 2 * group || C == 3 * group)) {
-      SsvsParams Pg = P;
-      for (int first = 0; first < C; first += group) {
-        Pg.chain_first = first;
-        Pg.chain_count = group;
-        HIP_TRY(launch_ssvs_sweep(e->stream, Pg, (int)nsweeps));
+    const bool groups = BA_PIPELINE && nsweeps > 0 && e->cur_mode != 2 && !e->big_active && C > group &&
+                        e->trace_stride == 0 && (!e->kt_enabled || e->kt_overlap);
+    if (groups) {
+      if (!e->pipe_stream) {
+        {
+          int rcs = concurrent_stream(e, &e->pipe_stream);
+          if (rcs) return rcs;
+        }
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&e->pipe_ev[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->pipe_join_ev, hipEventDisableTiming));
       }
+      if (!(e->pipe_on && e->pipe_groups)) {
+        int rcj = pipe_join(e);
+        if (rcj) return rcj;
+        // (the other stream behind everything the main stream holds so far: uploads, mutators)
+        HIP_TRY(hipEventRecord(e->pipe_ev[0], e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->pipe_stream, e->pipe_ev[0], 0));
+      }
+      SsvsParams Pg = P;
+      int g = 0;
+      for (int first = 0; first < C; first += group, ++g) {
+        Pg.chain_first = first;
+        Pg.chain_count = std::min(group, C - first);
+        HIP_TRY(launch_ssvs_sweep((g & 1) ? e->pipe_stream : e->stream, Pg, (int)nsweeps));
+      }
+      e->pipe_on = true;
+      e->pipe_groups = true;
     } else {
+      int rcj = pipe_join(e);
+      if (rcj) return rcj;
       HIP_TRY(launch_sweeps(e, P, (int)nsweeps));
     }
   } else {

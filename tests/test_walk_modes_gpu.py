@@ -147,3 +147,47 @@ def test_predict_from_the_record():
         _, beta, _ = eng.get_draws(c, nsw)
         want = beta[burn:] @ newX.T
         assert np.max(np.abs(got[c] - want)) < 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_more_chains_than_the_machine_holds_go_out_in_groups():
+    """2304 chains on a GPU that holds 1024 workgroups of this kernel: the chains go out in
+    groups of 1024 on alternating streams (engine.hip, sweep_impl) -- calls left to overlap,
+    calls with readers and a mutator in between, and three engines of 768 chains with the
+    matching chain offsets all give the same chains, bit for bit"""
+    import boom_amd
+    from cases import regression_data, spike_slab_prior
+    X, y, _ = regression_data(3000, 96, 6, seed=12)
+    def make(chains, offset=0):
+        e = boom_amd.Engine(chains, seed=21, chain_offset=offset)
+        e.build_suf_from_xy(X, y)
+        s = e.get_suf()
+        suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"], sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])
+        pr = spike_slab_prior(suf, 6)
+        e.set_priors(pr["b"], pr["ominv"], pr["pi"], pr["df"], pr["sigma_guess"])
+        g0 = np.zeros(96, np.uint8)
+        g0[0] = 1
+        e.set_state(g0)
+        return e
+    a, b = make(2304), make(2304)
+    for it in range(6):
+        a.sweep(25, sync=False)            # left to overlap
+        b.sweep(25)                        # one call at a time
+        if it == 2:
+            a.set_options(max_flips=40)
+            b.set_options(max_flips=40)
+        if it == 3:
+            assert np.array_equal(a.get_state(1500)[1], b.get_state(1500)[1])
+    a.sync()
+    sa, sb = a.get_states(), b.get_states()
+    for u, v in zip(sa, sb):
+        assert np.array_equal(u, v)
+    parts = []
+    for k in range(3):
+        e = make(768, 768 * k)
+        for it in range(6):
+            e.sweep(25)
+            if it == 2:
+                e.set_options(max_flips=40)
+        parts.append(e.get_states())
+    for i in range(3):
+        assert np.array_equal(np.concatenate([q[i] for q in parts]), sa[i])
