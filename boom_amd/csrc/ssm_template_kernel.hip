@@ -818,14 +818,28 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
             // the autoregression block's rows (logical order): from the last lag down, moving each
             // entry one place on as it is read
             if (mylane) {
-              double ca = 0.0;
+              if (S.na <= 2) {
+                // (one or two lags -- what AddAr is used with -- in a straight line: both entries
+                // loaded together; the rolled loop below waits for every entry in turn)
+                const bool two = S.na == 2;
+                const double x0 = s_P[S.a0 * PLD + lane];
+                const double x1 = two ? s_P[(S.a0 + 1) * PLD + lane] : 0.0;
+                const double p0 = s_phi[0], p1 = two ? s_phi[1] : 0.0;
+                double ca = 0.0;
+                if (two) ca += p1 * x1;
+                ca += p0 * x0;
+                if (two) s_P[(S.a0 + 1) * PLD + lane] = x0;
+                s_P[S.a0 * PLD + lane] = ca;
+              } else {
+                double ca = 0.0;
 #pragma nounroll
-              for (int q = S.na - 1; q >= 0; --q) {
-                const double x = s_P[(S.a0 + q) * PLD + lane];
-                ca += s_phi[q] * x;
-                if (q + 1 < S.na) s_P[(S.a0 + q + 1) * PLD + lane] = x;
+                for (int q = S.na - 1; q >= 0; --q) {
+                  const double x = s_P[(S.a0 + q) * PLD + lane];
+                  ca += s_phi[q] * x;
+                  if (q + 1 < S.na) s_P[(S.a0 + q + 1) * PLD + lane] = x;
+                }
+                s_P[S.a0 * PLD + lane] = ca;
               }
-              s_P[S.a0 * PLD + lane] = ca;
             }
             wave_lds_sync();
           }
@@ -855,11 +869,21 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           if (AR) {
             double ca = 0.0;
             if (mylane) {
+              if (S.na <= 2) {
+                const bool two = S.na == 2;
+                const double x0 = row[S.a0];
+                const double x1 = two ? row[S.a0 + 1] : 0.0;
+                const double p0 = s_phi[0], p1 = two ? s_phi[1] : 0.0;
+                if (two) ca += p1 * x1;
+                ca += p0 * x0;
+                if (two) row[S.a0 + 1] = x0;
+              } else {
 #pragma nounroll
-              for (int q = S.na - 1; q >= 0; --q) {
-                const double x = row[S.a0 + q];
-                ca += s_phi[q] * x;
-                if (q + 1 < S.na) row[S.a0 + q + 1] = x;
+                for (int q = S.na - 1; q >= 0; --q) {
+                  const double x = row[S.a0 + q];
+                  ca += s_phi[q] * x;
+                  if (q + 1 < S.na) row[S.a0 + q + 1] = x;
+                }
               }
               if (lane == S.a0) ca += sig2a;
               row[S.a0] = ca;

@@ -21,7 +21,7 @@ for a in sys.argv[1:]:
 for spec_arg in [tuple(int(v) for v in a.split(",")) for a in args] or ((1, 0, 1024), (2, 0, 1024), (2, 7, 1024), (2, 12, 1024), (2, 12, 4096), (2, 12, 1024, 2)):
     trend, ns, chains = spec_arg[:3]
     lags = spec_arg[3] if len(spec_arg) > 3 else 0
-    X, y, btrue, _ = structural_data(T, p, nsig, ns, seed=8675309, ar_coef=[1.2, -0.4][:lags] if 0 < lags <= 2 else ([0.2] * lags if lags else None))
+    X, y, btrue, _ = structural_data(T, p, nsig, ns, seed=8675309, ar_coef=[1.2, -0.4] if lags == 2 else ([0.6] if lags == 1 else ([0.2] * lags if lags else None)))
     prior, _, sig_up = bsts_priors(X, y, 5)
     spec = structural_spec(y, trend, ns, ar_lags=lags)
     m0 = trend + max(ns - 1, 0)
