@@ -484,6 +484,23 @@ __device__ __forceinline__ void path_start(const Shape &S, int lane, double init
   }
 }
 
+// the AR block's first component (one or two lags) over the block's steps: every lane runs the
+// same short recursion, lane 0 leaves the values in LDS behind the two before the block
+// (s_aw[14], s_aw[15]); n_l: the step's input by lane = time; a1, a2: the values at t - 1, t - 2
+__device__ __forceinline__ void ar_block(double *s_aw, int lane, int tb, int nstep, double n_l, double init,
+                                         double ph0, double ph1, double &a1, double &a2) {
+  if (lane == 0) { s_aw[14] = a2; s_aw[15] = a1; }
+#pragma nounroll
+  for (int s = 0; s < nstep; ++s) {
+    // (the reference: phi . lags, then + the error)
+    const double an = (tb + s == 0) ? init : (ph0 * a1 + ph1 * a2) + rl(n_l, s);
+    if (lane == 0) s_aw[16 + s] = an;
+    a2 = a1;
+    a1 = an;
+  }
+  wave_lds_sync();
+}
+
 }  // namespace
 
 // grid = chains, block = 128.  TREND: 1 local level, 2 local linear trend; SEAS: a
@@ -506,6 +523,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   __shared__ int s_flag;
   __shared__ int s_vprog;                 // blocks of 64 steps the variance pass has put out (wave 1 -> wave 0)
   __shared__ double s_xw[16 + WAVE];        // the seasonal scans' window (wave 0)
+  __shared__ double s_aw[16 + WAVE];        // the AR block's first component over a block, behind its predecessors
   __shared__ int s_cprog, s_cdone;        // the last pass: blocks of state draws wave 0 has made / wave 1 has taken
   __shared__ double s_phi[SSM_MAX + 1];   // the autoregression coefficients, then the block's error variance
   double (&s_blk)[2][WAVE * SSM_MAX] = s_lds.pass.blk;
@@ -520,6 +538,9 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   Shape S;
   S.m = m; S.trend = TREND; S.s0 = TREND; S.ns = SEAS ? Q.nseasons - 1 : 0;
   S.a0 = AR ? Q.ar0 : 0; S.na = AR ? Q.ar_lags : 0;
+  // the simulation and the last pass with time across the lanes: every shape but an AR block of
+  // more than two lags (its first component is then a short serial recursion per block)
+  const bool scans = !AR || S.na <= 2;
   const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
   int status = CHAIN_OK;
   if (threadIdx.x == 0) { s_flag = CHAIN_OK; s_vprog = 0; s_cprog = 0; s_cdone = 0; }
@@ -911,8 +932,8 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       }
       return;
     }
-    if (!AR) return;   // (the last pass is wave 0's alone: time across the lanes)
-  } else if (!AR) {
+    if (scans) return;   // (the last pass is wave 0's alone: time across the lanes)
+  } else if (scans) {
     // ---- simulate alpha+_t, y+_t and w_t = y*_t - y+_t with time across the lanes
     double alpha0;
     {
@@ -927,25 +948,37 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     const double zs1 = (SEAS && dS && T > 1) ? szz[nfirst + dT] : 0.0;
     path_start<TREND, SEAS>(S, lane, alpha0, sdv[2] * zs1, PC);
     const int cidx = SEAS ? WAVE - (S.ns + 1) + lane % (S.ns + 1) : 0;
+    // the AR block (one or two lags): a_t = phi_0 a_{t-1} + phi_1 a_{t-2} + sigma z_t
+    const double ar_init = AR ? rl(alpha0, S.a0) : 0.0;
+    double ar1 = (AR && S.na == 2) ? rl(alpha0, S.a0 + 1) : 0.0, ar2 = 0.0;   // the values at t - 1, t - 2
+    const double ph0 = AR ? s_phi[0] : 0.0, ph1 = (AR && S.na == 2) ? s_phi[1] : 0.0;
     for (int tb = 0; tb < T; tb += WAVE) {
       const int tt = tb + lane;
       const bool in_l = tt < T;
       const double ys_l = in_l ? w0[tt] : 0.0;
       const int nb_l = (tt == 0) ? 0 : nfirst + (tt - 1) * nper;
-      double z0_l = 0.0, z1_l = 0.0, zs_l = 0.0, zh_l = 0.0;
+      double z0_l = 0.0, z1_l = 0.0, zs_l = 0.0, za_l = 0.0, zh_l = 0.0;
       if (in_l && tt > 0) {
         int o = nb_l;
         if (dT >= 1) z0_l = szz[o++];
         if (dT == 2) z1_l = szz[o++];
         if (dS) zs_l = szz[o++];
+        if (dA) za_l = szz[o++];
         if (dH) zh_l = szz[o];
       } else if (in_l) {
         if (dH) zh_l = szz[d0 + S.ns + S.na];
       }
+      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
       PathStep a;
       path_block<TREND, SEAS>(S, lane, cidx, tt, in_l, sdv[0] * z0_l, sdv[1] * z1_l, sdv[2] * zs_l, PC, s_xw, a);
-      const double yplus = (a.lev + (SEAS ? a.seas[0] : 0.0)) + sqrtH * zh_l;   // simulate_adjusted_observation
-      const int nstep = (T - tb < WAVE) ? T - tb : WAVE;
+      double a_ar0 = 0.0, a_ar1 = 0.0;
+      if (AR) {
+        ar_block(s_aw, lane, tb, nstep, sda * za_l, ar_init, ph0, ph1, ar1, ar2);
+        a_ar0 = s_aw[16 + lane];
+        a_ar1 = s_aw[15 + lane];
+        wave_lds_sync();
+      }
+      const double yplus = ((a.lev + (SEAS ? a.seas[0] : 0.0)) + (AR ? a_ar0 : 0.0)) + sqrtH * zh_l;   // simulate_adjusted_observation
       if (in_l) {
         w0[tt] = ys_l - yplus;
         blk[lane * m] = a.lev;
@@ -954,6 +987,10 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 #pragma unroll
           for (int i = 0; i < SSM_MAX - 1; ++i)
             if (i < S.ns) blk[lane * m + TREND + i] = a.seas[i];
+        }
+        if (AR) {
+          blk[lane * m + S.a0] = a_ar0;
+          if (S.na == 2) blk[lane * m + S.a0 + 1] = a_ar1;
         }
       }
       blk_store(gst + (size_t)tb * m, blk, nstep * m, lane);   // (alpha+ in logical order: only the last pass reads it)
@@ -1094,7 +1131,7 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
 
   }
   SSTAMP(6);
-  if (!AR) {
+  if (scans) {
     // ---- 5'. the mean correction, the state draw and every sufficient statistic with
     // time across the lanes (wave 0; wave 1 has left)
     const double mc0 = mylane ? P0l * r : 0.0;   // a0 + P0 r0 - (a0 + P0 r0+), time 0's layout
@@ -1103,6 +1140,11 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     const int cidx = SEAS ? WAVE - (S.ns + 1) + lane % (S.ns + 1) : 0;
     double c_lev = 0.0, c_slo = 0.0, c_sum = 0.0;   // the state of the previous block's last step
     double ss0 = 0.0, ss1 = 0.0, ss2 = 0.0, yty = 0.0, nobs = 0.0;
+    const double ar_init = AR ? rl(mc0, S.a0) : 0.0;
+    double ar1 = (AR && S.na == 2) ? rl(mc0, S.a0 + 1) : 0.0, ar2 = 0.0;
+    const double ph0 = AR ? s_phi[0] : 0.0, ph1 = (AR && S.na == 2) ? s_phi[1] : 0.0;
+    double c_a0 = 0.0, c_a1 = 0.0;
+    double x00 = 0.0, x01 = 0.0, x11 = 0.0, xy0 = 0.0, xy1 = 0.0, ayy = 0.0;   // the ArModel's sufficient statistics
     for (int tb = 0; tb < T; tb += WAVE) {
       const int tt = tb + lane;
       const bool in_l = tt < T;
@@ -1112,10 +1154,20 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       const double d0_l = dd ? gd[tt - 1] : 0.0;
       const double d1_l = (dd && TREND == 2) ? gd[(size_t)T + tt - 1] : 0.0;
       const double d2_l = (dd && SEAS) ? gd[(size_t)2 * T + tt - 1] : 0.0;
+      const double d3_l = (dd && AR) ? gd[(size_t)3 * T + tt - 1] : 0.0;
       const double y_l = in_l ? P.y[tt] : 0.0;
       const bool ob_l = in_l && P.observed[tt];
       PathStep c;
       path_block<TREND, SEAS>(S, lane, cidx, tt, in_l, sig2[0] * d0_l, sig2[1] * d1_l, sig2[2] * d2_l, PC, s_xw, c);
+      double sa0 = 0.0, sa1 = 0.0;
+      if (AR) {
+        ar_block(s_aw, lane, tb, nstep, sig2a * d3_l, ar_init, ph0, ph1, ar1, ar2);
+        if (in_l) {
+          sa0 = blk[lane * m + S.a0] + s_aw[16 + lane];
+          if (S.na == 2) sa1 = blk[lane * m + S.a0 + 1] + s_aw[15 + lane];
+        }
+        wave_lds_sync();
+      }
       double st0 = 0.0, st1 = 0.0, sea0 = 0.0, bsum = 0.0;
       double sea[SSM_MAX - 1];
       if (in_l) {
@@ -1148,7 +1200,18 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           ss2 += dl * dl;
         }
       }
-      const double resid = ob_l ? y_l - (st0 + (SEAS ? sea0 : 0.0)) : 0.0;
+      if (AR) {
+        // add_mixture_data(now[0], then, 1.0): xtx += then then', xty += now[0] then, yty += now[0]^2
+        double pa0 = __shfl_up(sa0, 1), pa1 = __shfl_up(sa1, 1);
+        if (lane == 0) { pa0 = c_a0; pa1 = c_a1; }
+        if (dd) {
+          x00 += pa0 * pa0; x01 += pa0 * pa1; x11 += pa1 * pa1;
+          xy0 += sa0 * pa0; xy1 += sa0 * pa1;
+          ayy += sa0 * sa0;
+        }
+        c_a0 = rl(sa0, WAVE - 1); c_a1 = rl(sa1, WAVE - 1);
+      }
+      const double resid = ob_l ? y_l - ((st0 + (SEAS ? sea0 : 0.0)) + (AR ? sa0 : 0.0)) : 0.0;
       if (ob_l) { yty += resid * resid; nobs += 1.0; }
       wave_lds_sync();
       if (in_l) {
@@ -1159,6 +1222,10 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
           for (int i = 0; i < SSM_MAX - 1; ++i)
             if (i < S.ns) blk[lane * m + TREND + i] = sea[i];
         }
+        if (AR) {
+          blk[lane * m + S.a0] = sa0;
+          if (S.na == 2) blk[lane * m + S.a0 + 1] = sa1;
+        }
         sres[tt] = resid;
       }
       blk_store(gst + (size_t)tb * m, blk, nstep * m, lane);
@@ -1166,6 +1233,10 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
     }
     ss0 = wave_total(ss0); ss1 = wave_total(ss1); ss2 = wave_total(ss2);
     yty = wave_total(yty); nobs = wave_total(nobs);
+    if (AR) {
+      x00 = wave_total(x00); x01 = wave_total(x01); x11 = wave_total(x11);
+      xy0 = wave_total(xy0); xy1 = wave_total(xy1); ayy = wave_total(ayy);
+    }
     SSTAMP(7);
 #ifdef BA_KSTAMPS
     if (chain == 0 && lane == 0 && draw_variances)
@@ -1182,6 +1253,17 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
       if (SEAS) {
         Q.M.var_n[Q.at(chain, 2)] = (double)(T - 1);
         Q.M.var_ss[Q.at(chain, 2)] = ss2;
+      }
+      if (AR) {
+        double *suf = Q.ar_suf(chain);
+        suf[0] = x00;
+        suf[AR_SUF_XTY] = xy0;
+        if (S.na == 2) {
+          suf[1] = x01; suf[SSM_MAX] = x01; suf[SSM_MAX + 1] = x11;
+          suf[AR_SUF_XTY + 1] = xy1;
+        }
+        suf[AR_SUF_YTY] = ayy;
+        suf[AR_SUF_N] = (double)(T - 1);
       }
       P.yty[chain] = yty;
       P.nobs[chain] = nobs;
