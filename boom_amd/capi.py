@@ -586,7 +586,8 @@ class Engine:
 
     def ss_set_tuning(self, use_template_kernel=True, kernel=None):
         """kernel: 0 general, 1 the default choice, 2 four chains per wavefront (m <= 16),
-        3 compiled for the shape (where it applies)"""
+        3 compiled for the shape (where it applies); 4 / 5: the local-level rounds as separate
+        launches / as the persistent round kernel (the default)"""
         if kernel is None:
             kernel = 1 if use_template_kernel else 0
         self._check(self.lib.ba_ss_set_tuning(self._h, int(kernel)))

@@ -42,6 +42,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The round kernel (ss_round_kernel.hip) runs the sweep and the state draw inside a loop
+// over rounds; the compiler then hoists every round-invariant address computation of both
+// to the top of the kernel and keeps it alive -- in scratch memory -- across everything.
+// There (BA_ROUND_KERNEL) the thread and chain indices are made opaque once per round, so
+// that what is derived from them is computed where it is used.  Elsewhere: nothing.
+#ifdef BA_ROUND_KERNEL
+#define BA_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#define BA_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#else
+#define BA_OPAQUE_V(x) do { } while (0)
+#define BA_OPAQUE_S(x) do { } while (0)
+#endif
+
 namespace boom_amd {
 
 struct PhiloxKey {

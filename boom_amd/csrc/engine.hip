@@ -67,6 +67,9 @@ hipError_t launch_kalman_simsmooth(hipStream_t stream, const SsParams &P,
 hipError_t launch_kalman_main(hipStream_t stream, const SsParams &P, int draw_level);
 hipError_t launch_kalman_xte(hipStream_t stream, const SsParams &P, bool planes_only);
 hipError_t launch_kalman_prepare(hipStream_t stream, const SsParams &P, int draw_level);
+hipError_t launch_ss_round(hipStream_t stream, const SsvsParams &P, const SsParams &S, const SsRoundParams &F,
+                           int *max_resident);
+size_t ss_round_lds(int p, int kcap);
 hipError_t launch_ss_forecast(hipStream_t stream, const SsParams &P, int horizon, const double *newX,
                               uint64_t *pos_forecast, double *out);
 }  // namespace boom_amd
@@ -389,6 +392,12 @@ struct ba_engine {
   int ssg_template_var[3] = {-1, -1, -1};
   int ssg_template_ar = -1;        // ... and the block ba_ss_add_ar appended
   int ssg_kernel_choice = 1;       // (ba_ss_set_tuning: 0 general, 1 the default choice, 2 packed, 3 shape-specialised)
+  // the local-level rounds of a call as one persistent launch (ss_round_kernel.hip); the
+  // tile words of its X'e step, zeroed before every launch; how many chains' workgroups the
+  // device holds at once, by launch capacity (0: not asked yet, < 0: the kernel does not fit)
+  bool ss_round_enabled = true;    // (ba_ss_set_tuning 4 / 5: the separate launches of rounds 1-4 / this)
+  DevBuf<int32_t> dround_ctl, dround_members, dround_reg;
+  int ss_round_resident[4] = {0, 0, 0, 0};
   DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;   // chains x SSG_MAX_VAR (sigsq, n, ss)
   DevBuf<double> dar_phi, dar_suf;                         // chains x SSG_MAX_AR x (AR_MAX | AR_SUF_STRIDE)
   DevBuf<uint64_t> dpos_var;                               // chains x SSG_MAX_VAR
@@ -1075,6 +1084,28 @@ hipError_t pinned_reserve(ba_engine *e, size_t bytes) {
   return err;
 }
 
+// (debugging sessions, BA_DEBUG_ROUND: what the round kernel noted, printed when a chain stops)
+DevBuf<int32_t> g_round_debug;
+void dump_round_debug() {
+  if (g_round_debug.count == 0) return;
+  int32_t h[16 * 17];
+  if (hipMemcpy(h, g_round_debug.ptr, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+  std::fprintf(stderr, "round kernel: %d sums that are not numbers\n", h[0]);
+  for (int i = 0; i < std::min(h[0], 15); ++i) {
+    const int32_t *o = h + 16 + i * 16;
+    std::fprintf(stderr, "  chain %d round %d of %d variable %d row %d tile %d slot %d members %d bits %08x%08x\n", o[0], o[1], o[9],
+                 o[2], o[3], o[4], o[5], o[6], (unsigned)o[7], (unsigned)o[8]);
+  }
+  {
+    double d[32];
+    if (hipMemcpy(d, g_round_debug.ptr + 16 * 17, sizeof d, hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int i = 0; i < std::min(h[1], 4); ++i)
+      std::fprintf(stderr, "  stopped in the state draw: chain %g round %g status %g sigsq %.17g level_sigsq %.17g prep_n %g level_sumsq %.17g level_n %g\n",
+                   d[i * 8], d[i * 8 + 1], d[i * 8 + 2], d[i * 8 + 3], d[i * 8 + 4], d[i * 8 + 5], d[i * 8 + 6], d[i * 8 + 7]);
+  }
+  (void)hipMemset(g_round_debug.ptr, 0, (16 * 17 + 64) * 4);
+}
+
 int check_chain_status(ba_engine *e) {
   const size_t C = (size_t)e->cfg.chains;
   if (!e->state_ready) return BA_OK;
@@ -1116,6 +1147,16 @@ int check_chain_status(ba_engine *e) {
       char buf[64];
       std::snprintf(buf, sizeof buf, " (chain %lld)",
                     (long long)(e->cfg.chain_offset + (int64_t)c));
+      dump_round_debug();
+      {  // (and which chains)
+        int bad = 0;
+        for (size_t d = 0; d < C; ++d) bad += st[d] != CHAIN_OK;
+        if (g_round_debug.count) {
+          std::fprintf(stderr, "  %d chains stopped:", bad);
+          for (size_t d = 0; d < C; ++d) if (st[d] != CHAIN_OK) std::fprintf(stderr, " %zu(%d)", d, st[d]);
+          std::fprintf(stderr, "\n");
+        }
+      }
       return fail(status_code(st[c]), std::string(status_message(st[c])) + buf);
     }
   }
@@ -1502,6 +1543,12 @@ int ss_la_alloc(ba_engine *e) {
   HIP_TRY(A.dreg.resize(nreg));
   HIP_TRY(A.lev_used.resize(C));
   HIP_TRY(hipMemcpy(A.dreg.ptr, A.reg.data(), nreg * 4, hipMemcpyHostToDevice));
+  {  // (the round kernel's view of the same list: chain -> its index among the registered)
+    std::vector<int32_t> of(C, -1);
+    for (size_t r = 0; r < nreg; ++r) of[(size_t)A.reg[r]] = (int32_t)r;
+    HIP_TRY(e->dround_reg.resize(C));
+    HIP_TRY(hipMemcpy(e->dround_reg.ptr, of.data(), C * 4, hipMemcpyHostToDevice));
+  }
   // snapshot: level (sigsq, n, sumsq) | xty | yty | nobs [| state models: sigsq, n, ss | phi | ar suf]
   A.snap_doubles = C * (3 + p + 2);
   A.snap_words = 2 * C;
@@ -1854,7 +1901,7 @@ const char *ba_kernel_class_name(int32_t cls) {
       "ssm_simsmooth_kernel", "atb_mfma_kernel", "probit_impute_kernel", "logit_impute_kernel",
       "xtwx_cols_kernel<false>+plain_reduce_kernel", "xtwx_cols_kernel<true>+xtwx_cols_reduce_kernel",
       "xtx_mfma_kernel+plane_sum_kernel+col_reduce_kernel", "poisson_impute_kernel",
-      "kalman_prepare_kernel"};
+      "kalman_prepare_kernel", "ss_round_kernel"};
   return (cls >= 0 && cls < KT_CLASSES) ? names[cls] : "";
 }
 
@@ -3780,9 +3827,12 @@ int ba_set_slot_limit(ba_engine *e, int32_t uniforms) {
 // applies (the two are compared by the tests), 1 = the default
 int ba_ss_set_tuning(ba_engine *e, int32_t kernel) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  if (kernel < 0 || kernel > 3) return fail(BA_E_INVALID, "kernel must be 0 .. 3");
+  if (kernel < 0 || kernel > 5) return fail(BA_E_INVALID, "kernel must be 0 .. 5");
   MUTATE(e);
-  e->ssg_kernel_choice = kernel;
+  // 4 / 5: the local-level rounds as the separate launches of rounds 1-4 / as the round
+  // kernel (the default where it applies); the structural kernels' choice stays
+  if (kernel >= 4) e->ss_round_enabled = kernel == 5;
+  else e->ssg_kernel_choice = kernel;
   return BA_OK;
 }
 
@@ -4030,6 +4080,101 @@ int ba_ss_impute_state(ba_engine *e) {
 
 }  // extern "C"
 namespace {
+#ifdef BA_RSTAMPS
+double *g_round_stamps = nullptr;
+size_t g_round_stamps_n = 0;
+#endif
+// The round kernel (ss_round_kernel.hip) serves the local-level model on a series of at most
+// LM_TP steps while every chain is in the LDS sweep kernel's range; how many chains one launch
+// can take (0: the separate launches instead).
+int ss_round_chains(ba_engine *e) {
+  if (!e->ss_round_enabled || e->ssm_set || !ss_lane_major(*e) || e->big_active || e->cur_mode != 0) return 0;
+  if (e->kcap != 16 && e->kcap != 32 && e->kcap != 48) return 0;
+  int &res = e->ss_round_resident[e->kcap / 16];
+  if (res == 0) {
+    res = -1;
+    if (ss_round_lds(e->p, e->kcap) <= (size_t)e->lds_per_cu / 2) {   // (two chains to a CU at least)
+      SsvsParams P{};
+      SsParams S{};
+      SsRoundParams F{};
+      P.kcap = e->kcap;
+      P.p = e->p;
+      int n = 0;
+      if (launch_ss_round(e->stream, P, S, F, &n) == hipSuccess && n > 0) res = n;
+      if (std::getenv("BA_DEBUG_ROUND")) std::fprintf(stderr, "round kernel: kcap %d lds %zu resident %d\n", e->kcap, ss_round_lds(e->p, e->kcap), n);
+    }
+  }
+  return res > 0 ? std::min<int>(res, e->cfg.chains) : 0;
+}
+
+// `rounds` rounds of every chain: one launch per group of co-resident chains and per
+// SS_ROUND_MAX_ROUNDS rounds; round i of the call goes to row rec_first + i of the record
+int ss_round_launches(ba_engine *e, SsvsParams &P, SsParams &S, int rounds, int rec_slot) {
+  const int per = ss_round_chains(e), C = e->cfg.chains;
+  const size_t ctl = (size_t)SS_ROUND_MAX_ROUNDS * (1 + 2 * (size_t)per);   // (ticket | sizes | diagnostic variants: a done count per tile)
+  const size_t mem = (size_t)SS_ROUND_MAX_ROUNDS * ((size_t)per * SS_ROUND_TILE + 2 * SS_ROUND_TILE);
+  if (e->dround_ctl.count != ctl) HIP_TRY(e->dround_ctl.resize(ctl));
+  if (e->dround_members.count != mem) HIP_TRY(e->dround_members.resize(mem));
+  SsRoundParams F{};
+  F.close_ticks = 100000;   // 1 ms: a tile is short of members only when another launch shares the machine (ss_round_kernel.hip)
+  F.ticket = e->dround_ctl.ptr;
+  F.sizes = F.ticket + SS_ROUND_MAX_ROUNDS;
+  F.members = e->dround_members.ptr;
+  F.planes = e->dxte_planes.ptr;
+  if (std::getenv("BA_DEBUG_ROUND")) {
+    if (g_round_debug.count == 0) {
+      HIP_TRY(g_round_debug.resize(16 * 17 + 64));
+      HIP_TRY(hipMemset(g_round_debug.ptr, 0, (16 * 17 + 64) * 4));
+    }
+    F.debug = g_round_debug.ptr;
+  }
+#ifdef BA_RSTAMPS
+  {  // (diagnostic build: printed per call by tools/ss_round_phases.py through BA_RSTAMPS_DUMP)
+    static DevBuf<double> stamps;
+    if (stamps.count != (size_t)C * 16) {
+      HIP_TRY(stamps.resize((size_t)C * 16));
+      HIP_TRY(hipMemsetAsync(stamps.ptr, 0, (size_t)C * 16 * 8, e->stream));
+    }
+    F.stamps = stamps.ptr;
+    g_round_stamps = stamps.ptr;
+    g_round_stamps_n = (size_t)C * 16;
+  }
+#endif
+  if (rec_slot >= 0) {
+    ba_engine::SsLa &A = e->ssla;
+    F.rgamma = A.rgamma.ptr;
+    F.rbeta = A.rbeta.ptr;
+    F.rsig = A.rsig.ptr;
+    F.rvar = A.rvar.ptr;
+    F.rstate = A.rstate.ptr;
+    F.reg_of_chain = e->dround_reg.ptr;
+    F.rec_slot = rec_slot;
+    F.rec_len = A.len;
+    F.nreg = (int32_t)A.reg.size();
+  }
+  for (int g0 = 0; g0 < C; g0 += per) {
+    const int gc = std::min(per, C - g0);
+    SsvsParams Pg = P;
+    SsParams Sg = S;
+    Pg.chain_first = Sg.chain_first = g0;
+    Pg.chain_count = Sg.chain_count = gc;
+    for (int r0 = 0; r0 < rounds; r0 += SS_ROUND_MAX_ROUNDS) {
+      F.rounds = std::min<int>(SS_ROUND_MAX_ROUNDS, rounds - r0);
+      F.rec_first = r0;
+#ifdef BA_RSTAMPS
+      { static int seq = 0; F.debug_seq = ++seq; }
+#endif
+      HIP_TRY(hipMemsetAsync(e->dround_ctl.ptr, 0, ctl * 4, e->stream));
+      HIP_TRY(hipMemsetAsync(e->dround_members.ptr, 0xff, mem * 4, e->stream));
+      HIP_TRY(launch_ss_round(e->stream, Pg, Sg, F, nullptr));
+      Pg.model_keep = 1;   // (from here on the chains' model blocks are their own last launch's)
+    }
+  }
+  P.model_keep = 1;
+  e->model_ok = true;
+  return BA_OK;
+}
+
 // nsweeps x StateSpacePosteriorSampler::draw on every chain; rec_slot >= 0: every round's
 // draw goes to that half of the look-ahead's record
 int ss_sweep_impl(ba_engine *e, int32_t nsweeps, int rec_slot) {
@@ -4051,6 +4196,7 @@ int ss_sweep_impl(ba_engine *e, int32_t nsweeps, int rec_slot) {
   // the chains' other normals buffer -- the step for round i + 1 goes out behind round
   // i's state draw, beside its X'e GEMM, its plane sum and the start of round i + 1's
   // SSVS launch (kalman_prepare_kernel).
+  if (nsweeps > 0 && ss_round_chains(e) > 0) return ss_round_launches(e, P, S, nsweeps, rec_slot);
   const bool ahead = !e->ssm_set && nsweeps > 0;
   if (ahead && !e->stream2) {
     {
@@ -4288,3 +4434,17 @@ int ba_ss_get_chain_suf(ba_engine *e, int64_t chain, double *xty, double *yty,
 }
 
 }  // extern "C"
+
+#ifdef BA_RSTAMPS
+// diagnostic build only (tools/build/libboomamd_rstamps.so): the round kernel's phase ticks
+// since the last call, chains x 2 x 8, and reset
+extern "C" int ba_debug_round_stamps(double *out, int64_t n) {
+  using namespace boom_amd;
+  if (!g_round_stamps) return -1;
+  const size_t m = std::min<size_t>((size_t)n, g_round_stamps_n);
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(out, g_round_stamps, m * 8, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  if (hipMemset(g_round_stamps, 0, g_round_stamps_n * 8) != hipSuccess) return -2;
+  return (int)m;
+}
+#endif

@@ -119,6 +119,31 @@ struct SsParams {
   SsmParams ssm;            // (ssm_kernel.hip only)
 };
 
+// The round kernel (ss_round_kernel.hip): every chain's workgroup loops over the rounds of a
+// call by itself; the chains meet only in the X'e tiles -- up to SS_ROUND_TILE chains in the
+// order they arrive.  Per round r: ticket[r] = the next place (tile * SS_ROUND_TILE + slot; a
+// tile closed early moves it to the next tile's first place), members = the chain index in
+// every place (-1: not yet written), sizes[tile] = members of a tile closed early (0: not).
+// At most one tile per chain and round.  The host zeroes them (members: -1) before every launch.
+enum { SS_ROUND_TILE = 16, SS_ROUND_MAX_ROUNDS = 64 };
+struct SsRoundParams {
+  int32_t rounds;           // rounds of this launch (<= SS_ROUND_MAX_ROUNDS)
+  int32_t close_ticks;      // 100 MHz ticks a tile's first member waits for company
+  int32_t *ticket;          // [rounds]
+  int32_t *sizes;           // [rounds][chain_count]
+  int32_t *members;         // [rounds][chain_count * SS_ROUND_TILE + 2 * SS_ROUND_TILE]
+  double *planes;           // SS_ROUND_TILE x chains x p: a chain's partial products, by row of the series
+  // the look-ahead's record of every round's draw (engine.hip; rgamma == nullptr: none):
+  // chain c's row of round r is (rec_slot * chains + c) * rec_len + rec_first + r
+  uint8_t *rgamma;
+  double *rbeta, *rsig, *rvar, *rstate;
+  const int32_t *reg_of_chain;      // chains: index among the chains whose state path is recorded, or -1
+  int32_t rec_slot, rec_len, rec_first, nreg;
+  int32_t *debug;           // diagnostic (BA_DEBUG_ROUND in the environment of a debugging session): 16 x 16 words, else nullptr
+  int32_t debug_seq;        // diagnostic build: a number per launch
+  double *stamps;           // diagnostic build (-DBA_RSTAMPS): chains x 2 waves x 8 phases, 100 MHz ticks; else unused
+};
+
 enum { SS_SCRATCH_ARRAYS = 9, SS_STATE_ARRAY = 4 };   // (arrays 5-6 and 7-8: the two normals buffers)
 enum { LM_BS = 16, LM_THREADS = 128, LM_TP = LM_BS * LM_THREADS };
 inline __host__ __device__ int lm_at(int t) { return (t % LM_BS) * LM_THREADS + t / LM_BS; }

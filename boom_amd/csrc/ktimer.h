@@ -25,6 +25,7 @@ enum KernelClass {
   KT_SUF,           // xtx_mfma_kernel + plane_sum_kernel + col_reduce_kernel
   KT_POISSON_IMPUTE,// poisson_impute_kernel
   KT_KALMAN_PREPARE,// kalman_prepare_kernel (level variance + normals, second stream)
+  KT_SS_ROUND,      // ss_round_kernel (the local-level bsts rounds of a call, one persistent launch)
   KT_CLASSES
 };
 

@@ -67,20 +67,40 @@ struct NormalsInOrder {   // szz[i] = draw i
   __device__ __forceinline__ int count() const { return N; }
   __device__ __forceinline__ int draw(int s) const { return s; }
 };
-template <class Slots>
+// ONE_WAVE: the calling wavefront alone makes the draws (the round kernel of
+// ss_round_kernel.hip: the chain's other wavefront is in the regression sweep meanwhile);
+// the team is then the wave's 64 lanes and the hand-offs are wave-level.
+template <bool ONE_WAVE>
+struct NormalsTeam {
+  static __device__ __forceinline__ int tid() {
+    int t = (int)threadIdx.x;
+    BA_OPAQUE_V(t);
+    return ONE_WAVE ? (t & 63) : t;
+  }
+  static __device__ __forceinline__ int nth() { return ONE_WAVE ? 64 : (int)blockDim.x; }
+  static __device__ __forceinline__ void sync() {
+    if (ONE_WAVE) wave_lds_sync(); else __syncthreads();
+  }
+  static __device__ __forceinline__ int sync_or(int x) {
+    if (ONE_WAVE) return __ballot(x != 0) != 0ull ? 1 : 0;
+    return __syncthreads_or(x);
+  }
+};
+template <bool ONE_WAVE = false, class Slots>
 __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
                                               double *szz, uint64_t *pos_out, const Slots slots,
                                               int serve = STATE_SLOT_STRIDE) {
+  typedef NormalsTeam<ONE_WAVE> Team;
   const double A = 2.216035867166471;
   const double C1 = 0.398942280401433, C2 = 0.180025191068563;
-  const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
+  const int tid = Team::tid(), nth = Team::nth();
   const int S = slots.count();
   const uint64_t bslot0 = bpos0 / STATE_SLOT_STRIDE;   // (the stream position is a whole number of slots)
   int bad = 0;
   for (int c0 = 0; c0 < S; c0 += SN_CHUNK) {
     const int nc = (S - c0 < SN_CHUNK) ? S - c0 : SN_CHUNK;
     if (tid == 0) { L.ntail = 0; L.nmid = 0; }
-    __syncthreads();
+    Team::sync();
 #ifdef BA_KSTAMPS
     const long long sn_t0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -124,7 +144,7 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
         }
       }
     }
-    __syncthreads();
+    Team::sync();
 #ifdef BA_KSTAMPS
     const long long sn_t1 = (long long)__builtin_readcyclecounter();
 #endif
@@ -183,20 +203,20 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
 #ifdef BA_KSTAMPS
     const long long sn_t3 = (long long)__builtin_readcyclecounter();
 #endif
-    __syncthreads();
+    Team::sync();
 #ifdef BA_KSTAMPS
     if (blockIdx.x == 0 && (tid == 0 || tid == 127))
       printf("stream_normals tid %d: phase 1 %lld, tail (%d) %lld, mid (%d) %lld, wait %lld\n", tid, sn_t1 - sn_t0, ntail,
              sn_t2 - sn_t1, nmid, sn_t3 - sn_t2, (long long)__builtin_readcyclecounter() - sn_t3);
 #endif
   }
-  bad = __syncthreads_or(bad);
+  bad = Team::sync_or(bad);
   if (tid == 0) *pos_out = bpos0 + (uint64_t)N * STATE_SLOT_STRIDE;
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
 }
 __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
                                               double *szz, uint64_t *pos_out, int serve = STATE_SLOT_STRIDE) {
-  return stream_normals(L, key, bpos0, N, szz, pos_out, NormalsInOrder{N}, serve);
+  return stream_normals<false>(L, key, bpos0, N, szz, pos_out, NormalsInOrder{N}, serve);
 }
 
 }  // namespace boom_amd

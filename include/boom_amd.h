@@ -467,7 +467,11 @@ int ba_ss_add_state_model(ba_engine *e, int32_t kind, const int32_t *iparams,
 /* which kernel draws the state (changes no draw): 0 = the general kernel, one chain per
  * workgroup; 2 = four chains per wavefront (state dimension <= 16; the general kernel
  * beyond); 3 = the kernel compiled for the shape [level | trend] [+ seasonal of duration 1]
- * [+ one autoregression] with m <= 16 where the list has that shape; 1 = the default choice */
+ * [+ one autoregression] with m <= 16 where the list has that shape; 1 = the default choice.
+ * Independently of those: 4 = the local-level model's rounds as separate launches per round
+ * (regression sweep, state draw, X'e), 5 = as one persistent launch per call in which every
+ * chain loops over the rounds by itself (the default where it applies: a series of at most
+ * 2048 steps, models of at most 48 variables) */
 int ba_ss_set_tuning(ba_engine *e, int32_t kernel);
 /* the state dimension and the number of state models of the specification */
 int ba_ss_state_dimension(ba_engine *e, int32_t *state_dimension, int32_t *nblocks);
