@@ -146,10 +146,27 @@ struct LmSlots {   // slot s of the normals array: row s / 128 = 2 j + kind, thr
   }
 };
 
+// The prepare step shared by the chain's two wavefronts (the round kernel,
+// ss_round_kernel.hip): the wave that leads draws the level variance and posts the job; both
+// take sub-chunks of SN_SUB slots from a counter in LDS until none is left (the regression's
+// wave joins when its sweep is done); the leader waits for the last one and finishes the step.
+enum : int { SN_SUB = 512 };
+struct NormalsShare {
+  int32_t seq;              // the job posted (> 0: its number), or -(number): none this time
+  // the leader takes sub-chunks 0, 1, ... and writes `lo` = the next one it will take; the
+  // helper takes nsub - 1, nsub - 2, ... and writes `hi` = the next one IT will take, `hfin` =
+  // the lowest one it has finished.  Plain words, no read-modify-write: where the two meet
+  // both may make the same sub-chunk -- the same numbers into the same places.
+  int32_t lo, hi, hfin, bad;
+  uint32_t pos_lo, pos_hi;  // the state stream's position the draws start from
+  int32_t N, nfirst, nper, dI, dL, dH;
+  int32_t cnt[2][2];        // the two waves' list counts
+};
 struct KalmanLmLds {
   NormalsLds norm;              // (only a chain whose normals were not prepared uses it)
   double x[2][8];               // the two waves' scan totals
   uint32_t mask[LM_THREADS];    // (H == 0 only: the threads' observed masks)
+  NormalsShare share;           // (the round kernel only)
 };
 // Every thread of the chain's workgroup (128) calls it; returns true when the chain's state
 // was drawn (false: the chain sat the round out or stopped -- the same in every thread).
@@ -602,6 +619,134 @@ __device__ __forceinline__ void kalman_prepare_body(const SsParams &P, const int
     P.prep_pos_state[slot] = pos_state0;
     P.prep_pos_level[slot] = pos_level0;
     P.prep_level_sigsq[slot] = level0;
+  }
+}
+
+// ---- the same step with the sub-chunks of the normals shared by the two wavefronts
+__device__ __forceinline__ int lds_ld(const int32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(int32_t *p, int32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The calling wavefront's part of a shared job (w = 0, 1: which half of the lists is its
+// own): phase 1 of a sub-chunk -- its lists go on growing over the sub-chunks it makes --, and
+// at the end phase 2 of everything on them, densely.
+struct NormalsShareCtx {
+  LmSlots slots;
+  uint64_t bpos0;
+  PhiloxKey key;
+  double *szz;
+  int serve;
+};
+__device__ __forceinline__ NormalsShareCtx normals_share_ctx(const SsParams &P, const int chain, KalmanLmLds &lds, const int w) {
+  NormalsShare &J = lds.share;
+  NormalsShareCtx c{LmSlots{P.T, J.nfirst, J.nper, J.dI, J.dL, J.dH}, ((uint64_t)J.pos_hi << 32) | J.pos_lo,
+                    PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 2u},
+                    P.scratch + (size_t)chain * P.scratch_stride + (size_t)(5 + 2 * P.zbuf) * P.TP, ss_slot_serve(P)};
+  if (NormalsTeam<true>::tid() == 0) { J.cnt[w][0] = 0; J.cnt[w][1] = 0; }
+  NormalsTeam<true>::sync();
+  return c;
+}
+__device__ __forceinline__ void normals_share_chunk(const NormalsShareCtx &X, KalmanLmLds &lds, const int w, const int c) {
+  NormalsShare &J = lds.share;
+  const int S = X.slots.count(), c0 = c * SN_SUB, nc = (S - c0 < SN_SUB) ? S - c0 : SN_SUB;
+  normals_phase1<NormalsTeam<true>>(lds.norm.tail + w * (SN_CHUNK / 2), lds.norm.mid + w * (SN_CHUNK / 2), &J.cnt[w][0],
+                                    &J.cnt[w][1], X.key, X.bpos0, X.szz, X.slots, c0, nc, c0);
+}
+__device__ __forceinline__ void normals_share_finish(const NormalsShareCtx &X, KalmanLmLds &lds, const int w) {
+  typedef NormalsTeam<true> Team;
+  NormalsShare &J = lds.share;
+  Team::sync();
+  const int bad = normals_phase2<Team>(lds.norm.tail + w * (SN_CHUNK / 2), lds.norm.mid + w * (SN_CHUNK / 2), &J.cnt[w][0],
+                                       &J.cnt[w][1], X.key, X.bpos0, X.szz, X.slots, X.serve, 0);
+  if (__ballot(bad != 0) != 0ull && Team::tid() == 0) lds_st(&J.bad, 1);
+}
+// the leading wavefront: what kalman_prepare_body does, the normals through the shared job;
+// seq: the job's number (the other wavefront asks for it by that number)
+__device__ __forceinline__ void kalman_prepare_lead(const SsParams &P, const int chain, const int status_in, const int seq,
+                                                    KalmanLmLds &lds) {
+  typedef NormalsTeam<true> Team;
+  NormalsShare &J = lds.share;
+  const int lane = Team::tid();
+  if (status_in != CHAIN_OK) {   // (a chain that is parked or stopped prepares nothing)
+    if (lane == 0) lds_st(&J.seq, -seq);
+    return;
+  }
+  const int T = P.T;
+  const uint32_t gchain = (uint32_t)(P.chain_offset + chain);
+  const uint64_t pos_level0 = P.pos_level[chain], pos_state0 = P.pos_state[chain];
+  const double level0 = P.level_sigsq[chain];
+  double level_sigsq = level0;
+  int status = CHAIN_OK;
+  {
+    SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, 1u}, pos_level0};
+    int bad = 0;
+    const double DF = P.level_n[chain] + P.level_prior_df;
+    const double SS = P.level_sumsq[chain] + P.level_prior_ss;
+    level_sigsq = d_draw_variance(rng, DF, SS, P.level_sigma_max, &bad);
+    if (bad) status = CHAIN_RNG_BRANCH;
+    Team::sync();   // (every lane has read the statistics and the position it draws from)
+    if (lane == 0) {
+      P.pos_level[chain] = rng.pos;
+      P.level_sigsq[chain] = level_sigsq;
+    }
+  }
+  const int dI = (sqrt(P.P0) != 0.0), dL = (sqrt(level_sigsq) != 0.0), dH = 1;
+  const int N = (dI + dH) + (T - 1) * (dL + dH);
+  if (status == CHAIN_OK) {
+    const int nsub = (2 * LM_TP + SN_SUB - 1) / SN_SUB;
+    if (lane == 0) {
+      J.lo = 0; J.hi = nsub - 1; J.hfin = nsub; J.bad = 0;
+      J.pos_lo = (uint32_t)pos_state0; J.pos_hi = (uint32_t)(pos_state0 >> 32);
+      J.N = N; J.nfirst = dI + dH; J.nper = dL + dH; J.dI = dI; J.dL = dL; J.dH = dH;
+      lds_st(&J.seq, seq);
+    }
+    Team::sync();
+    const NormalsShareCtx X = normals_share_ctx(P, chain, lds, 1);
+    int c = 0;
+    for (; c < nsub; ++c) {
+      if (c > __builtin_amdgcn_readfirstlane(lds_ld(&J.hi))) break;   // (the helper has the rest)
+      if (lane == 0) lds_st(&J.lo, c + 1);
+      normals_share_chunk(X, lds, 1, c);
+    }
+    normals_share_finish(X, lds, 1);
+    // (what the helper took is finished: sub-chunks c .. nsub - 1)
+    while (__builtin_amdgcn_readfirstlane(lds_ld(&J.hfin)) > c) __builtin_amdgcn_s_sleep(1);
+    if (lds_ld(&J.bad)) status = CHAIN_RNG_BRANCH;
+    if (lane == 0) P.pos_state[chain] = pos_state0 + (uint64_t)N * STATE_SLOT_STRIDE;
+  } else if (lane == 0) {
+    lds_st(&J.seq, -seq);
+  }
+  if (lane == 0) {
+    const size_t slot = (size_t)P.zbuf * P.chains + chain;
+    P.prep_n[slot] = (status == CHAIN_OK) ? N : -status;
+    P.prep_pos_state[slot] = pos_state0;
+    P.prep_pos_level[slot] = pos_level0;
+    P.prep_level_sigsq[slot] = level0;
+  }
+}
+// the other wavefront, when it has nothing else to do: job `seq`'s sub-chunks, if there are any left
+__device__ __forceinline__ void kalman_prepare_help(const SsParams &P, const int chain, const int seq, KalmanLmLds &lds) {
+  NormalsShare &J = lds.share;
+  int s;
+  while ((s = lds_ld(&J.seq)) != seq && s != -seq) __builtin_amdgcn_s_sleep(1);
+  if (s > 0) {
+    const int lane = NormalsTeam<true>::tid();
+    int lowest = -1;
+    NormalsShareCtx X{};
+    for (;;) {
+      const int h = __builtin_amdgcn_readfirstlane(lds_ld(&J.hi));
+      if (h < __builtin_amdgcn_readfirstlane(lds_ld(&J.lo))) break;   // (the leader has it, or had)
+      if (lane == 0) lds_st(&J.hi, h - 1);
+      if (lowest < 0) X = normals_share_ctx(P, chain, lds, 0);
+      normals_share_chunk(X, lds, 0, h);
+      lowest = h;
+    }
+    if (lowest >= 0) {
+      normals_share_finish(X, lds, 0);
+      if (lane == 0) lds_st(&J.hfin, lowest);
+    }
   }
 }
 

@@ -129,8 +129,10 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
     int chain = (int)blockIdx.x + P.chain_first, tid = threadIdx.x;
     BA_OPAQUE_S(chain);
     BA_OPAQUE_V(tid);
+    if (tid == 0) klds.share.seq = 0;
+    __syncthreads();
     if ((tid >> 6) == 1) {
-      kalman_prepare_body<true>(S, 1, chain, S.status[chain], klds.norm);
+      kalman_prepare_lead(S, chain, S.status[chain], 1, klds);
     } else {
       for (int z = 0; z < RT; ++z)
         for (int j = tid; j < p; j += WAVE)
@@ -146,13 +148,14 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
     // ---- 1. the regression's draw (wave 0; wave 1 is still making this round's normals)
     if (wave == 0) {
       fresh_scalars();   // (the plane sum just stored X'e, which the sweep reads as a scalar where it can)
-      __builtin_amdgcn_s_setprio(3);
+#ifndef RK_PRIO
+#define RK_PRIO 3
+#endif
+      __builtin_amdgcn_s_setprio(RK_PRIO);
       ssvs_sweep_body<NB, 1, 1>(P, 1, chain, smem);
       __builtin_amdgcn_s_setprio(0);
+      kalman_prepare_help(S, chain, r + 1, klds);   // (what is left of this round's normals)
     }
-#ifdef RK_NO_AHEAD
-    else if (r > 0) kalman_prepare_body<true>(S, 1, chain, S.status[chain], klds.norm);
-#endif
     stores_done();
     RSTAMP(0);   // wave 0: sweep; wave 1: the rest of variance + normals
     __syncthreads();
@@ -187,9 +190,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
     RSTAMP(2);   // state draw
     if (wave == 1) {
       // ---- 3a. the NEXT round's level variance (from this draw's statistics) and normals
-#ifndef RK_NO_AHEAD
-      if (r + 1 < F.rounds && drew) kalman_prepare_body<true>(S, 1, chain, CHAIN_OK, klds.norm);
-#endif
+      if (r + 1 < F.rounds) kalman_prepare_lead(S, chain, drew ? (int)CHAIN_OK : (int)CHAIN_RNG_BRANCH, r + 2, klds);
       continue;
     }
     // ---- 3b. X'e (wave 0).  A ticket, the chain's name into its place (sixteen places to a
@@ -257,20 +258,28 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
             xo[v] = (uint32_t)(((size_t)j * LM_TP + (size_t)rr * LM_THREADS) * 8) + 8u * fk;
           }
           const uint32_t er = eo + (uint32_t)rr * LM_THREADS * 8;
-          for (int m0 = 0; m0 < LM_THREADS / 4; m0 += 8) {
-            double a[8], b[8][VG];
+          // (eight batches of four steps; a batch's loads go out while the matrix cores are on
+          // the one before)
+          constexpr int NBAT = LM_THREADS / 16;
+          double a[2][4], b[2][4][VG];
+          auto fetch = [&](int bi, int m0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              a[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(eb, (int)(er + 32u * (m0 + u)), 0, 16));
+            for (int u = 0; u < 4; ++u) {
+              a[bi][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(eb, (int)(er + 32u * (m0 + u)), 0, 16));
 #pragma unroll
               for (int v = 0; v < VG; ++v)
-                b[u][v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)(xo[v] + 32u * (m0 + u)), 0, 0));
+                b[bi][u][v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)(xo[v] + 32u * (m0 + u)), 0, 0));
             }
+          };
+          fetch(0, 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+          for (int bt = 0; bt < NBAT; ++bt) {
+            if (bt + 1 < NBAT) fetch((bt + 1) & 1, 4 * (bt + 1));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
               for (int v = 0; v < VG; ++v)
-                acc[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][v], acc[v], 0, 0, 0);
+                acc[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bt & 1][u], b[bt & 1][u][v], acc[v], 0, 0, 0);
           }
           // to the members' planes of this row (register q of lane l: member (l >> 4) + 4 q)
 #pragma unroll
@@ -287,14 +296,6 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
       }
     }
     RSTAMP(4);   // the member's share of the product
-#ifdef RK_DONE_COUNTER
-    {
-      stores_done();
-      int32_t *dn = F.sizes + (size_t)F.rounds * 0 + (size_t)SS_ROUND_MAX_ROUNDS * C + (size_t)r * C + tile;
-      if (lane == 0) atomicAdd(dn, 1);
-      while (ld_coh(dn) < n) __builtin_amdgcn_s_sleep(2);
-    }
-#endif
     // ... and add the chain's own planes, in row order, once every member's share is there
     if (drew) {
       for (int j0 = 0; j0 < p; j0 += WAVE) {

@@ -86,24 +86,17 @@ struct NormalsTeam {
     return __syncthreads_or(x);
   }
 };
-template <bool ONE_WAVE = false, class Slots>
-__device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
-                                              double *szz, uint64_t *pos_out, const Slots slots,
-                                              int serve = STATE_SLOT_STRIDE) {
-  typedef NormalsTeam<ONE_WAVE> Team;
+// The two phases of a stretch of slots, for one team (a workgroup, or ONE wavefront:
+// NormalsTeam).  Phase 1, slots [c0, c0 + nc) of the output array: the draws of the first
+// branch, the others on the team's lists ltail / lmid (entry = slot - c0 + ioff; the counts
+// go on from where they stand).  Phase 2: the lists' draws (slot = origin + entry); returns
+// this thread's "a draw overran its slot and its spill stream" flag.
+template <class Team, class Slots>
+__device__ __forceinline__ void normals_phase1(uint16_t *ltail, uint16_t *lmid, int *lntail, int *lnmid,
+                                               const PhiloxKey &key, uint64_t bpos0, double *szz, const Slots slots,
+                                               const int c0, const int nc, const int ioff) {
   const double A = 2.216035867166471;
-  const double C1 = 0.398942280401433, C2 = 0.180025191068563;
   const int tid = Team::tid(), nth = Team::nth();
-  const int S = slots.count();
-  const uint64_t bslot0 = bpos0 / STATE_SLOT_STRIDE;   // (the stream position is a whole number of slots)
-  int bad = 0;
-  for (int c0 = 0; c0 < S; c0 += SN_CHUNK) {
-    const int nc = (S - c0 < SN_CHUNK) ? S - c0 : SN_CHUNK;
-    if (tid == 0) { L.ntail = 0; L.nmid = 0; }
-    Team::sync();
-#ifdef BA_KSTAMPS
-    const long long sn_t0 = (long long)__builtin_readcyclecounter();
-#endif
     // ---- phase 1: u1 and u2 of every draw (one Philox block: a slot starts at an even
     // position), the first branch where it applies
     // (four slots per thread and round: four independent Philox blocks in flight -- one
@@ -132,26 +125,32 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
         const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
         if (mt) {
           int base = 0;
-          if ((int)(threadIdx.x & 63) == __ffsll((long long)mt) - 1) base = atomicAdd(&L.ntail, __popcll(mt));
+          if ((int)(threadIdx.x & 63) == __ffsll((long long)mt) - 1) base = atomicAdd(lntail, __popcll(mt));
           base = __builtin_amdgcn_readlane(base, __ffsll((long long)mt) - 1);
-          if (tail) L.tail[base + __popcll(mt & below)] = (uint16_t)i;
+          if (tail) ltail[base + __popcll(mt & below)] = (uint16_t)(i + ioff);
         }
         if (mm) {
           int base = 0;
-          if ((int)(threadIdx.x & 63) == __ffsll((long long)mm) - 1) base = atomicAdd(&L.nmid, __popcll(mm));
+          if ((int)(threadIdx.x & 63) == __ffsll((long long)mm) - 1) base = atomicAdd(lnmid, __popcll(mm));
           base = __builtin_amdgcn_readlane(base, __ffsll((long long)mm) - 1);
-          if (mid) L.mid[base + __popcll(mm & below)] = (uint16_t)i;
+          if (mid) lmid[base + __popcll(mm & below)] = (uint16_t)(i + ioff);
         }
       }
     }
-    Team::sync();
-#ifdef BA_KSTAMPS
-    const long long sn_t1 = (long long)__builtin_readcyclecounter();
-#endif
+}
+template <class Team, class Slots>
+__device__ __forceinline__ int normals_phase2(const uint16_t *ltail, const uint16_t *lmid, const int *lntail,
+                                              const int *lnmid, const PhiloxKey &key, uint64_t bpos0, double *szz,
+                                              const Slots slots, int serve, const int c0) {
+  const double A = 2.216035867166471;
+  const double C1 = 0.398942280401433, C2 = 0.180025191068563;
+  const int tid = Team::tid(), nth = Team::nth();
+  const uint64_t bslot0 = bpos0 / STATE_SLOT_STRIDE;   // (the stream position is a whole number of slots)
+  int bad = 0;
     // ---- phase 2a: the tail region
-    const int ntail = L.ntail, nmid = L.nmid;
+    const int ntail = *lntail, nmid = *lnmid;
     for (int q = tid; q < ntail; q += nth) {
-      const int i = L.tail[q];
+      const int i = ltail[q];
       PairRng r;
       r.init_slot(key, bslot0 + (uint64_t)slots.draw(c0 + i), STATE_SLOT_STRIDE, (uint32_t)serve);
       const double u1 = r();
@@ -168,14 +167,11 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
       }
       szz[c0 + i] = z;
     }
-#ifdef BA_KSTAMPS
-    const long long sn_t2 = (long long)__builtin_readcyclecounter();
-#endif
     // ---- phase 2b: the middle regions, one loop:
     //   tt = t0 + t1 min(u2, u3);  accept when max(u2, u3) <= thr or
     //   coef |u2 - u3| <= C1 exp(-tt^2 / 2) - C2 (A - tt)
     for (int q = tid; q < nmid; q += nth) {
-      const int i = L.mid[q];
+      const int i = lmid[q];
       PairRng r;
       r.init_slot(key, bslot0 + (uint64_t)slots.draw(c0 + i), STATE_SLOT_STRIDE, (uint32_t)serve);
       const double u1 = r();
@@ -200,18 +196,34 @@ __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &ke
       }
       szz[c0 + i] = z;
     }
-#ifdef BA_KSTAMPS
-    const long long sn_t3 = (long long)__builtin_readcyclecounter();
-#endif
-    Team::sync();
-#ifdef BA_KSTAMPS
-    if (blockIdx.x == 0 && (tid == 0 || tid == 127))
-      printf("stream_normals tid %d: phase 1 %lld, tail (%d) %lld, mid (%d) %lld, wait %lld\n", tid, sn_t1 - sn_t0, ntail,
-             sn_t2 - sn_t1, nmid, sn_t3 - sn_t2, (long long)__builtin_readcyclecounter() - sn_t3);
-#endif
+  return bad;
+}
+// slots [c0, c0 + nc) by one team with lists of its own for the stretch
+template <class Team, class Slots>
+__device__ __forceinline__ int normals_chunk(uint16_t *ltail, uint16_t *lmid, int *lntail, int *lnmid,
+                                             const PhiloxKey &key, uint64_t bpos0, double *szz, const Slots slots,
+                                             int serve, const int c0, const int nc) {
+  if (Team::tid() == 0) { *lntail = 0; *lnmid = 0; }
+  Team::sync();
+  normals_phase1<Team>(ltail, lmid, lntail, lnmid, key, bpos0, szz, slots, c0, nc, 0);
+  Team::sync();
+  const int bad = normals_phase2<Team>(ltail, lmid, lntail, lnmid, key, bpos0, szz, slots, serve, c0);
+  Team::sync();
+  return bad;
+}
+template <bool ONE_WAVE = false, class Slots>
+__device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
+                                              double *szz, uint64_t *pos_out, const Slots slots,
+                                              int serve = STATE_SLOT_STRIDE) {
+  typedef NormalsTeam<ONE_WAVE> Team;
+  const int S = slots.count();
+  int bad = 0;
+  for (int c0 = 0; c0 < S; c0 += SN_CHUNK) {
+    const int nc = (S - c0 < SN_CHUNK) ? S - c0 : SN_CHUNK;
+    bad |= normals_chunk<Team>(L.tail, L.mid, &L.ntail, &L.nmid, key, bpos0, szz, slots, serve, c0, nc);
   }
   bad = Team::sync_or(bad);
-  if (tid == 0) *pos_out = bpos0 + (uint64_t)N * STATE_SLOT_STRIDE;
+  if (Team::tid() == 0) *pos_out = bpos0 + (uint64_t)N * STATE_SLOT_STRIDE;
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
 }
 __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,

@@ -44,7 +44,7 @@ profile() {   # name, pmc (yes|no), kernel substrings for the summary, then the 
 for w in $ONLY; do
   case $w in
     c2)         profile c2 yes "ssvs_ xtx_mfma plane_sum col_reduce" $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-curve ;;
-    c3)         profile c3 yes "ssvs_ kalman xtwx_" $ROOT/tools/ss_bench.py ;;
+    c3)         profile c3 yes "ss_round ssvs_ kalman xtwx_" $ROOT/tools/ss_bench.py ;;
     structural) profile structural yes "ssvs_ ssm_ xtwx_" $ROOT/tools/structural_bench.py 2,12,1024 ;;
     structural_ar) profile structural_ar no "ssvs_ ssm_ xtwx_" $ROOT/tools/structural_bench.py 2,12,1024,2 ;;
     c4)         profile c4 yes "ssvs_ xtx_mfma plane_sum col_reduce" $ROOT/bench.py --config 3 --steps 3 --warmup 1 ;;
