@@ -7,33 +7,156 @@
 #include "cpputil/math_utils.hpp"
 #include "cpputil/report_error.hpp"
 #include "distributions/rng.hpp"
+#include "Models/ChisqModel.hpp"
 
 namespace BOOM {
 
+  // ---- construction ---------------------------------------------------------------
+  void DeviceBregVsSampler::create_engine(int device, RNG &seeding_rng) {
+    device_seed_ = seed_rng(seeding_rng);
+    ba_config cfg{device, chains_, 0, static_cast<uint64_t>(device_seed_), 0, 0};
+    ba_engine *engine = nullptr;
+    check(ba_engine_create(&cfg, &engine));
+    engines_.push_back(engine);
+  }
+
+  void DeviceBregVsSampler::destroy_engines() {
+    if (group_) {
+      ba_group_destroy(group_);
+      group_ = nullptr;
+    } else {
+      for (ba_engine *engine : engines_) ba_engine_destroy(engine);
+    }
+    engines_.clear();
+  }
+
+  void DeviceBregVsSampler::upload_suf() {
+    Ptr<RegSuf> suf = model_->suf();
+    const SpdMatrix xtx = suf->xtx();  // column-major, full storage
+    const Vector xty = suf->xty();
+    const Vector xbar = suf->xbar();
+    for (ba_engine *engine : engines_) {
+      check(ba_upload_regression_suf(engine, xtx.nrow(), xtx.data(), xty.data(),
+                                     suf->yty(), suf->n(), suf->ybar(), xbar.data()));
+    }
+  }
+
+  // (#1, #2) engine 0 has assembled the priors: the sampler's objects hold the same numbers
+  void DeviceBregVsSampler::priors_from_engine() {
+    const uint p = model_->xdim();
+    Vector mu(p), pi(p);
+    SpdMatrix ominv(p);
+    double df = 0, ss = 0;
+    check(ba_get_priors(engines_[0], mu.data(), ominv.data(), pi.data(), &df, &ss));
+    slab_ = new MvnGivenScalarSigma(mu, ominv, model_->Sigsq_prm());
+    residual_precision_prior_ = new ChisqModel(df, std::sqrt(ss / df));
+    spike_ = new VariableSelectionPrior(pi);
+  }
+
+#define BOOM_AMD_SINGLE_DEVICE_INIT                                              \
+      : PosteriorSampler(seeding_rng), model_(model), group_(nullptr), chains_(chains), \
+        max_flips_(-1), swap_threshold_(0.8), sigma_upper_limit_(infinity()), priors_stale_(false)
+
+  // #1
+  DeviceBregVsSampler::DeviceBregVsSampler(RegressionModel *model, double prior_nobs,
+                                           double expected_rsq, double expected_model_size,
+                                           bool first_term_is_intercept, int chains, int device,
+                                           int lookahead, RNG &seeding_rng)
+      BOOM_AMD_SINGLE_DEVICE_INIT {
+    create_engine(device, seeding_rng);
+    try {
+      upload_suf();
+      check(ba_set_priors_ctor1(engines_[0], prior_nobs, expected_rsq, expected_model_size,
+                                first_term_is_intercept ? 1 : 0));
+      priors_from_engine();
+      configure(lookahead);
+    } catch (...) {   // (report_error throws and a throwing constructor runs no destructor)
+      destroy_engines();
+      throw;
+    }
+  }
+
+  // #2
+  DeviceBregVsSampler::DeviceBregVsSampler(RegressionModel *model, double prior_sigma_nobs,
+                                           double prior_sigma_guess, double prior_beta_nobs,
+                                           double diagonal_shrinkage,
+                                           double prior_inclusion_probability, bool force_intercept,
+                                           int chains, int device, int lookahead, RNG &seeding_rng)
+      BOOM_AMD_SINGLE_DEVICE_INIT {
+    create_engine(device, seeding_rng);
+    try {
+      upload_suf();
+      check(ba_set_priors_ctor2(engines_[0], prior_sigma_nobs, prior_sigma_guess, prior_beta_nobs,
+                                diagonal_shrinkage, prior_inclusion_probability,
+                                force_intercept ? 1 : 0));
+      priors_from_engine();
+      configure(lookahead);
+    } catch (...) {
+      destroy_engines();
+      throw;
+    }
+  }
+
+  // #3
+  DeviceBregVsSampler::DeviceBregVsSampler(RegressionModel *model, const Vector &prior_mean,
+                                           const SpdMatrix &unscaled_prior_precision,
+                                           double sigma_guess, double df,
+                                           const Vector &prior_inclusion_probs, int chains,
+                                           int device, int lookahead, RNG &seeding_rng)
+      BOOM_AMD_SINGLE_DEVICE_INIT {
+    slab_ = new MvnGivenScalarSigma(prior_mean, unscaled_prior_precision, model_->Sigsq_prm());
+    residual_precision_prior_ = new ChisqModel(df, sigma_guess);
+    spike_ = new VariableSelectionPrior(prior_inclusion_probs);
+    create_engine(device, seeding_rng);
+    try {
+      upload_suf();
+      configure(lookahead);
+    } catch (...) {
+      destroy_engines();
+      throw;
+    }
+  }
+
+  // #4
+  DeviceBregVsSampler::DeviceBregVsSampler(RegressionModel *model,
+                                           const ZellnerPriorParameters &prior, int chains,
+                                           int device, int lookahead, RNG &seeding_rng)
+      BOOM_AMD_SINGLE_DEVICE_INIT {
+    slab_ = new MvnGivenScalarSigma(prior.prior_beta_guess, prior.prior_beta_information,
+                                    model_->Sigsq_prm());
+    residual_precision_prior_ =
+        new ChisqModel(prior.prior_sigma_guess_weight, prior.prior_sigma_guess);
+    spike_ = new VariableSelectionPrior(prior.prior_inclusion_probabilities);
+    create_engine(device, seeding_rng);
+    try {
+      upload_suf();
+      configure(lookahead);
+    } catch (...) {
+      destroy_engines();
+      throw;
+    }
+  }
+
+  // #5
   DeviceBregVsSampler::DeviceBregVsSampler(
       RegressionModel *model, const Ptr<MvnGivenScalarSigmaBase> &slab,
       const Ptr<GammaModelBase> &residual_precision_prior,
       const Ptr<VariableSelectionPrior> &spike, int chains, int device,
       int lookahead, RNG &seeding_rng)
-      : PosteriorSampler(seeding_rng),
-        model_(model),
-        group_(nullptr),
-        chains_(chains),
-        max_flips_(-1),
-        swap_threshold_(0.8) {
-    device_seed_ = seed_rng(seeding_rng);
-    ba_config cfg{device, chains, 0, static_cast<uint64_t>(device_seed_), 0, 0};
-    ba_engine *engine = nullptr;
-    check(ba_engine_create(&cfg, &engine));
-    engines_.push_back(engine);
-    try {   // (report_error throws and a throwing constructor runs no destructor: nothing may leak)
-      configure(slab, residual_precision_prior, spike, lookahead);
+      BOOM_AMD_SINGLE_DEVICE_INIT {
+    slab_ = slab;
+    residual_precision_prior_ = residual_precision_prior;
+    spike_ = spike;
+    create_engine(device, seeding_rng);
+    try {
+      upload_suf();
+      configure(lookahead);
     } catch (...) {
-      ba_engine_destroy(engine);
-      engines_.clear();
+      destroy_engines();
       throw;
     }
   }
+#undef BOOM_AMD_SINGLE_DEVICE_INIT
 
   DeviceBregVsSampler::DeviceBregVsSampler(
       RegressionModel *model, const Ptr<MvnGivenScalarSigmaBase> &slab,
@@ -45,7 +168,12 @@ namespace BOOM {
         group_(nullptr),
         chains_(chains_per_device * static_cast<int>(devices.size())),
         max_flips_(-1),
-        swap_threshold_(0.8) {
+        swap_threshold_(0.8),
+        sigma_upper_limit_(infinity()),
+        slab_(slab),
+        residual_precision_prior_(residual_precision_prior),
+        spike_(spike),
+        priors_stale_(false) {
     device_seed_ = seed_rng(seeding_rng);
     std::vector<int32_t> dev(devices.begin(), devices.end());
     if (ba_group_create(dev.data(), static_cast<int32_t>(dev.size()), chains_per_device,
@@ -56,54 +184,70 @@ namespace BOOM {
       engines_.push_back(ba_group_engine(group_, i));
     }
     try {
-      configure(slab, residual_precision_prior, spike, lookahead);
+      upload_suf();
+      configure(lookahead);
     } catch (...) {
-      ba_group_destroy(group_);
-      group_ = nullptr;
-      engines_.clear();
+      destroy_engines();
       throw;
     }
   }
 
-  void DeviceBregVsSampler::configure(
-      const Ptr<MvnGivenScalarSigmaBase> &slab,
-      const Ptr<GammaModelBase> &residual_precision_prior,
-      const Ptr<VariableSelectionPrior> &spike, int lookahead) {
-    if (slab->dim() != static_cast<int>(model_->xdim())) {
+  // slab, spike, residual prior -> every engine (BregVsSampler reads them at every draw:
+  // set_reg_post_params, BregVsSampler.cpp:395-484; log_model_prob :216-239)
+  void DeviceBregVsSampler::upload_priors() {
+    if (slab_->dim() != static_cast<int>(model_->xdim())) {
       report_error("Slab dimension did not match model dimension.");
     }
-    if (spike->potential_nvars() != model_->xdim()) {
+    if (spike_->potential_nvars() != model_->xdim()) {
       report_error("Spike dimension did not match model dimension.");
     }
-    Ptr<RegSuf> suf = model_->suf();
-    const SpdMatrix xtx = suf->xtx();  // column-major, full storage
-    const Vector xty = suf->xty();
-    const Vector xbar = suf->xbar();
-    const Vector mu = slab->mu();
-    const SpdMatrix ominv = slab->unscaled_precision();
-    const Vector pi = spike->prior_inclusion_probabilities();
+    const Vector mu = slab_->mu();
+    const SpdMatrix ominv = slab_->unscaled_precision();
+    const Vector pi = spike_->prior_inclusion_probabilities();
     // GammaModel(alpha, beta) == ChisqModel(df = 2 alpha, sigma = sqrt(beta / alpha))
-    const double a = residual_precision_prior->alpha();
-    const double b = residual_precision_prior->beta();
+    const double a = residual_precision_prior_->alpha();
+    const double b = residual_precision_prior_->beta();
     prior_df_ = 2 * a;
     prior_sigma_guess_ = std::sqrt(b / a);
     for (ba_engine *engine : engines_) {
-      check(ba_upload_regression_suf(engine, xtx.nrow(), xtx.data(), xty.data(),
-                                     suf->yty(), suf->n(), suf->ybar(), xbar.data()));
       check(ba_set_slab(engine, mu.data(), ominv.data()));
-      check(ba_set_spike(engine, pi.data(), spike->max_model_size()));
-      check(ba_set_sigma_prior(engine, prior_df_, prior_sigma_guess_, infinity()));
+      check(ba_set_spike(engine, pi.data(), spike_->max_model_size()));
+      check(ba_set_sigma_prior(engine, prior_df_, prior_sigma_guess_, sigma_upper_limit_));
     }
+    priors_stale_ = false;
+  }
+
+  void DeviceBregVsSampler::configure(int lookahead) {
+    upload_priors();
+    observe();
     push_state();
     if (lookahead > 1) set_lookahead(lookahead);
   }
 
+  // Data::add_observer (DataTypes.hpp:76) on every parameter of the three prior models:
+  // a set() on any of them marks the device copies stale
+  void DeviceBregVsSampler::observe() {
+    auto watch = [this](Model *m) {
+      for (Ptr<Params> &prm : m->parameter_vector()) {
+        prm->add_observer(this, [this]() { this->priors_stale_ = true; });
+      }
+    };
+    watch(slab_.get());
+    watch(residual_precision_prior_.get());
+    watch(spike_.get());
+  }
+  void DeviceBregVsSampler::unobserve() {
+    auto unwatch = [this](Model *m) {
+      for (Ptr<Params> &prm : m->parameter_vector()) prm->remove_observer(this);
+    };
+    if (!!slab_) unwatch(slab_.get());
+    if (!!residual_precision_prior_) unwatch(residual_precision_prior_.get());
+    if (!!spike_) unwatch(spike_.get());
+  }
+
   DeviceBregVsSampler::~DeviceBregVsSampler() {
-    if (group_) {
-      ba_group_destroy(group_);
-    } else {
-      for (ba_engine *engine : engines_) ba_engine_destroy(engine);
-    }
+    unobserve();
+    destroy_engines();
   }
 
   void DeviceBregVsSampler::check(int rc) const {
@@ -111,6 +255,10 @@ namespace BOOM {
   }
 
   void DeviceBregVsSampler::draw() {
+    // (a prior that changed since the last draw: the engine puts the chains back at the
+    // draw the caller has seen before it takes the new values -- ba_set_slab and the others
+    // are mutators behind the look-ahead)
+    if (priors_stale_) upload_priors();
     // every engine is asked first (the launches are asynchronous, so the devices
     // run side by side); chain 0 is then read from engine 0
     for (ba_engine *engine : engines_) check(ba_draw_next(engine));
@@ -150,6 +298,7 @@ namespace BOOM {
     options();
   }
   void DeviceBregVsSampler::set_sigma_upper_limit(double sigma_upper_limit) {
+    sigma_upper_limit_ = sigma_upper_limit;
     for (ba_engine *engine : engines_) {
       check(ba_set_sigma_prior(engine, prior_df_, prior_sigma_guess_, sigma_upper_limit));
     }

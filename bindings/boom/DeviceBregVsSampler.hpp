@@ -14,6 +14,7 @@
 #include "LinAlg/Selector.hpp"
 #include "LinAlg/Vector.hpp"
 #include "Models/GammaModel.hpp"
+#include "Models/Glm/PosteriorSamplers/BregVsSampler.hpp"   // ZellnerPriorParameters
 #include "Models/Glm/RegressionModel.hpp"
 #include "Models/Glm/VariableSelectionPrior.hpp"
 #include "Models/MvnGivenScalarSigma.hpp"
@@ -32,6 +33,36 @@ namespace BOOM {
   // chain_state().
   class DeviceBregVsSampler : public PosteriorSampler {
    public:
+    // BregVsSampler's five constructors (BregVsSampler.hpp:64-106), each with the chain
+    // count, the device and the look-ahead behind the reference's own arguments.
+    // #1 (BregVsSampler.cpp:48-85) and #2 (:87-142) assemble slab, spike and residual prior
+    // from the model's sufficient statistics -- on the engine (ba_set_priors_ctor1 / _ctor2);
+    // the prior OBJECTS the sampler then holds are built from what the engine assembled.
+    DeviceBregVsSampler(RegressionModel *model, double prior_nobs, double expected_rsq,
+                        double expected_model_size, bool first_term_is_intercept,
+                        int chains, int device = 0, int lookahead = 256,
+                        RNG &seeding_rng = GlobalRng::rng);
+    DeviceBregVsSampler(RegressionModel *model, double prior_sigma_nobs,
+                        double prior_sigma_guess, double prior_beta_nobs,
+                        double diagonal_shrinkage, double prior_inclusion_probability,
+                        bool force_intercept,
+                        int chains, int device = 0, int lookahead = 256,
+                        RNG &seeding_rng = GlobalRng::rng);
+    // #3 (:144-160) and #4 (:162-180): the prior's parameters, as numbers or as a struct
+    DeviceBregVsSampler(RegressionModel *model, const Vector &prior_mean,
+                        const SpdMatrix &unscaled_prior_precision, double sigma_guess,
+                        double df, const Vector &prior_inclusion_probs,
+                        int chains, int device = 0, int lookahead = 256,
+                        RNG &seeding_rng = GlobalRng::rng);
+    DeviceBregVsSampler(RegressionModel *model, const ZellnerPriorParameters &prior,
+                        int chains, int device = 0, int lookahead = 256,
+                        RNG &seeding_rng = GlobalRng::rng);
+    // #5 (:182-194): the prior objects themselves.  "If external copies of the pointers
+    // supplied to the constructor are kept then the values of the prior parameters can be
+    // modified" (BregVsSampler.hpp:98-101): the sampler observes the three models'
+    // parameters (Data::add_observer, DataTypes.hpp:76) and the next draw() uploads what
+    // changed before it launches.  (What a model keeps outside its Params -- the slab's
+    // unscaled precision -- has no signal: call refresh_priors() after changing it.)
     DeviceBregVsSampler(RegressionModel *model,
                         const Ptr<MvnGivenScalarSigmaBase> &slab,
                         const Ptr<GammaModelBase> &residual_precision_prior,
@@ -65,6 +96,14 @@ namespace BOOM {
     void set_correlation_swap_threshold(double threshold);
     void set_sigma_upper_limit(double sigma_upper_limit);
 
+    // the prior objects (BregVsSampler has no accessors for them; kept for the callers of
+    // constructors #1 - #4, who have no pointers of their own)
+    const Ptr<MvnGivenScalarSigmaBase> &slab() const { return slab_; }
+    const Ptr<GammaModelBase> &residual_precision_prior() const { return residual_precision_prior_; }
+    const Ptr<VariableSelectionPrior> &spike() const { return spike_; }
+    // the device copies of the priors are stale: the next draw() reads the objects again
+    void refresh_priors() { priors_stale_ = true; }
+
     // new: how many draws a launch runs ahead of the caller (ba_set_lookahead)
     void set_lookahead(int n);
     // new: the other chains
@@ -74,9 +113,14 @@ namespace BOOM {
 
    private:
     void check(int rc) const;
-    void configure(const Ptr<MvnGivenScalarSigmaBase> &slab,
-                   const Ptr<GammaModelBase> &residual_precision_prior,
-                   const Ptr<VariableSelectionPrior> &spike, int lookahead);
+    void create_engine(int device, RNG &seeding_rng);   // the single-device constructors' first step
+    void destroy_engines();
+    void upload_suf();
+    void priors_from_engine();          // (#1, #2) the objects from what ba_set_priors_ctor* assembled
+    void configure(int lookahead);      // the objects -> every engine, observers, state, look-ahead
+    void upload_priors();
+    void observe();
+    void unobserve();
     void options();
     void push_state();   // coef().inc(), Beta(), sigsq() -> every chain
     void pull_chain0();  // chain 0 -> coef().set_inc / set_Beta / set_sigsq
@@ -88,6 +132,11 @@ namespace BOOM {
     int max_flips_;
     double swap_threshold_;
     double prior_df_, prior_sigma_guess_;
+    double sigma_upper_limit_;
+    Ptr<MvnGivenScalarSigmaBase> slab_;
+    Ptr<GammaModelBase> residual_precision_prior_;
+    Ptr<VariableSelectionPrior> spike_;
+    bool priors_stale_;
   };
 
 }  // namespace BOOM

@@ -159,15 +159,13 @@ namespace BOOM {
     }
     for (ba_engine *e : engines_) check(ba_ss_set_data(e, T, p, y.data(), X.data(), observed.data()));
 
-    // ---- regression priors: BregVsSampler's ctor #5 pieces
-    const Vector mu = slab->mu();
-    const SpdMatrix ominv = slab->unscaled_precision();
-    for (ba_engine *e : engines_) check(ba_set_slab(e, mu.data(), ominv.data()));
-    const Vector pi = spike->prior_inclusion_probabilities();
-    for (ba_engine *e : engines_) check(ba_set_spike(e, pi.data(), spike->max_model_size()));
-    for (ba_engine *e : engines_)
-      check(ba_set_sigma_prior(e, prior_df(residual_precision_prior),
-                               prior_sigma_guess(residual_precision_prior), sigma_upper_limit));
+    // ---- regression priors: BregVsSampler's ctor #5 pieces, kept and observed
+    slab_ = slab;
+    residual_precision_prior_ = residual_precision_prior;
+    spike_ = spike;
+    sigma_upper_limit_ = sigma_upper_limit;
+    upload_regression_priors();
+    observe();
 
     // ---- state models
     if (!structural_) {
@@ -240,6 +238,7 @@ namespace BOOM {
   }
 
   DeviceStateSpacePosteriorSampler::~DeviceStateSpacePosteriorSampler() {
+    unobserve();
     if (group_) ba_group_destroy(group_);
     else if (engine_) ba_engine_destroy(engine_);
   }
@@ -279,7 +278,41 @@ namespace BOOM {
     }
   }
 
+  void DeviceStateSpacePosteriorSampler::upload_regression_priors() {
+    const Vector mu = slab_->mu();
+    const SpdMatrix ominv = slab_->unscaled_precision();
+    const Vector pi = spike_->prior_inclusion_probabilities();
+    for (ba_engine *e : engines_) {
+      check(ba_set_slab(e, mu.data(), ominv.data()));
+      check(ba_set_spike(e, pi.data(), spike_->max_model_size()));
+      check(ba_set_sigma_prior(e, prior_df(residual_precision_prior_),
+                               prior_sigma_guess(residual_precision_prior_), sigma_upper_limit_));
+    }
+    priors_stale_ = false;
+  }
+  void DeviceStateSpacePosteriorSampler::observe() {
+    auto watch = [this](Model *m) {
+      for (Ptr<Params> &prm : m->parameter_vector()) {
+        prm->add_observer(this, [this]() { this->priors_stale_ = true; });
+      }
+    };
+    watch(slab_.get());
+    watch(residual_precision_prior_.get());
+    watch(spike_.get());
+  }
+  void DeviceStateSpacePosteriorSampler::unobserve() {
+    auto unwatch = [this](Model *m) {
+      for (Ptr<Params> &prm : m->parameter_vector()) prm->remove_observer(this);
+    };
+    if (!!slab_) unwatch(slab_.get());
+    if (!!residual_precision_prior_) unwatch(residual_precision_prior_.get());
+    if (!!spike_) unwatch(spike_.get());
+  }
+
   void DeviceStateSpacePosteriorSampler::draw() {
+    // (a regression prior changed since the last draw: the setters are mutators behind the
+    // look-ahead -- the chains go back to the draw the caller has seen, then take the values)
+    if (priors_stale_) upload_regression_priors();
     // (one round of every chain; with the look-ahead the round has usually run already and
     // this hands out its record)
     for (ba_engine *e : engines_) check(ba_ss_draw_next(e));   // (every device's rounds are out before any is read)

@@ -146,6 +146,22 @@ namespace BOOM {
     int state_dim_;
     bool structural_;  // anything but a lone local level: the engine runs a state-model list
     std::vector<DeviceStateVariancePrior> variance_priors_;
+    // The regression's three prior objects are the caller's (as BregVsSampler's ctor #5
+    // takes them, BregVsSampler.hpp:98-106): the sampler observes their parameters
+    // (Data::add_observer, DataTypes.hpp:76) and a draw() that finds them changed uploads them
+    // before it launches.  (The state models' variance priors are read at construction.)
+    Ptr<MvnGivenScalarSigmaBase> slab_;
+    Ptr<GammaModelBase> residual_precision_prior_;
+    Ptr<VariableSelectionPrior> spike_;
+    double sigma_upper_limit_ = 0;
+    bool priors_stale_ = false;
+    void upload_regression_priors();
+    void observe();
+    void unobserve();
+   public:
+    // the device copies of the regression's priors are stale (a change no parameter signals:
+    // the slab's unscaled precision): the next draw() reads the objects again
+    void refresh_priors() { priors_stale_ = true; }
   };
 
 }  // namespace BOOM

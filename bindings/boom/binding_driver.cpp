@@ -24,10 +24,21 @@
 using namespace BOOM;
 
 static std::string g_binding_error;
+// (the next ref_binding_ss_run: before draw `change_at` the spike's inclusion probabilities and
+// the slab's mean are set to these, through the prior objects' own setters)
+static int g_ss_change_at = -1;
+static Vector g_ss_pi2, g_ss_mu2;
 
 extern "C" {
 
 const char *ref_binding_last_error() { return g_binding_error.c_str(); }
+
+void ref_binding_ss_change_priors(int change_at, int p, const double *pi2, const double *mu2) {
+  g_ss_change_at = change_at;
+  g_ss_pi2 = Vector(p);
+  g_ss_mu2 = Vector(p);
+  for (int j = 0; j < p; ++j) { g_ss_pi2[j] = pi2[j]; g_ss_mu2[j] = mu2[j]; }
+}
 
 // X n x p column-major.  Returns 0 or -1 (message in ref_binding_last_error).
 // out_seed receives the seed the binding gave the engine (seed_rng(GlobalRng)
@@ -143,6 +154,139 @@ int ref_binding_group_run(int n, int p, const double *X, const double *y,
                           chains_per_device, ndevices, lookahead, seed, init_gamma, nsweeps,
                           out_gamma, out_beta, out_sigsq, out_logpri, out_seed, probe_chain,
                           probe_gamma, probe_beta, probe_sigsq);
+}
+
+// Priors changed under the sampler (ctor #5's purpose, BregVsSampler.hpp:98-101): the
+// caller keeps the Ptrs; after `change_at` draws it sets new prior inclusion probabilities
+// on the spike, a new mean on the slab and a new sum of squares on the residual prior --
+// through the objects' own setters, nothing is said to the sampler -- and goes on drawing.
+// ndevices as in binding_run_impl.
+int ref_binding_mutating_priors_run(int n, int p, const double *X, const double *y,
+                                    const double *prior_mean, const double *ominv, double prior_df,
+                                    double sigma_guess, const double *pi, const double *prior_mean2,
+                                    double sigma_guess2, const double *pi2, int change_at, int chains,
+                                    int ndevices, int lookahead, uint64_t seed,
+                                    const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma,
+                                    double *out_beta, double *out_sigsq, uint64_t *out_seed) {
+  try {
+    GlobalRng::rng.seed(seed);
+    Matrix Xm(n, p);
+    for (int j = 0; j < p; ++j)
+      for (int i = 0; i < n; ++i) Xm(i, j) = X[(size_t)j * n + i];
+    Vector yv(n);
+    for (int i = 0; i < n; ++i) yv[i] = y[i];
+    Ptr<RegressionModel> model(new RegressionModel(Xm, yv, false));
+    Vector mu(p), mu2(p), piv(p), piv2(p);
+    SpdMatrix om(p);
+    for (int j = 0; j < p; ++j) {
+      mu[j] = prior_mean[j];
+      mu2[j] = prior_mean2[j];
+      piv[j] = pi[j];
+      piv2[j] = pi2[j];
+      for (int i = 0; i < p; ++i) om(i, j) = ominv[(size_t)j * p + i];
+    }
+    NEW(MvnGivenScalarSigma, slab)(mu, om, model->Sigsq_prm());
+    NEW(ChisqModel, siginv_prior)(prior_df, sigma_guess);
+    NEW(VariableSelectionPrior, spike)(piv);
+    model->coef().drop_all();
+    for (int j = 0; j < p; ++j)
+      if (init_gamma[j]) model->coef().add(j);
+    Ptr<DeviceBregVsSampler> sampler;
+    if (ndevices <= 0) {
+      sampler.reset(new DeviceBregVsSampler(model.get(), slab, siginv_prior, spike, chains, 0, lookahead));
+    } else {
+      sampler.reset(new DeviceBregVsSampler(model.get(), slab, siginv_prior, spike, chains,
+                                            std::vector<int>(ndevices, 0), lookahead));
+    }
+    if (out_seed) *out_seed = sampler->device_seed();
+    model->set_method(sampler);
+    for (int s = 0; s < nsweeps; ++s) {
+      if (s == change_at) {
+        spike->set_prior_inclusion_probabilities(piv2);
+        slab->set_mu(mu2);
+        siginv_prior->set_sigma_estimate(sigma_guess2);   // ChisqModel: the same df, another guess
+      }
+      model->sample_posterior();
+      const Selector &inc(model->coef().inc());
+      const Vector beta = model->Beta();
+      for (int j = 0; j < p; ++j) {
+        out_gamma[(size_t)s * p + j] = inc[j] ? 1 : 0;
+        out_beta[(size_t)s * p + j] = beta[j];
+      }
+      out_sigsq[s] = model->sigsq();
+    }
+    return 0;
+  } catch (std::exception &e) {
+    g_binding_error = e.what();
+    return -1;
+  }
+}
+
+// BregVsSampler's constructors #1 - #4 on the device sampler (which: 1 .. 4).  #1: a =
+// {prior_nobs, expected_rsq, expected_model_size}, flag = first_term_is_intercept; #2: a =
+// {prior_sigma_nobs, prior_sigma_guess, prior_beta_nobs, diagonal_shrinkage,
+// prior_inclusion_probability}, flag = force_intercept; #3 / #4: the numbers of
+// ref_binding_run (as arguments / as a ZellnerPriorParameters).
+int ref_binding_ctor_run(int which, int n, int p, const double *X, const double *y, const double *a, int flag,
+                         const double *prior_mean, const double *ominv, double prior_df, double sigma_guess,
+                         const double *pi, int chains, int lookahead, uint64_t seed,
+                         const uint8_t *init_gamma, int nsweeps, uint8_t *out_gamma, double *out_beta,
+                         double *out_sigsq, uint64_t *out_seed) {
+  try {
+    GlobalRng::rng.seed(seed);
+    Matrix Xm(n, p);
+    for (int j = 0; j < p; ++j)
+      for (int i = 0; i < n; ++i) Xm(i, j) = X[(size_t)j * n + i];
+    Vector yv(n);
+    for (int i = 0; i < n; ++i) yv[i] = y[i];
+    Ptr<RegressionModel> model(new RegressionModel(Xm, yv, false));
+    model->coef().drop_all();
+    for (int j = 0; j < p; ++j)
+      if (init_gamma[j]) model->coef().add(j);
+    Ptr<DeviceBregVsSampler> sampler;
+    if (which == 1) {
+      sampler.reset(new DeviceBregVsSampler(model.get(), a[0], a[1], a[2], flag != 0, chains, 0, lookahead));
+    } else if (which == 2) {
+      sampler.reset(new DeviceBregVsSampler(model.get(), a[0], a[1], a[2], a[3], a[4], flag != 0, chains, 0,
+                                            lookahead));
+    } else {
+      Vector mu(p), piv(p);
+      SpdMatrix om(p);
+      for (int j = 0; j < p; ++j) {
+        mu[j] = prior_mean[j];
+        piv[j] = pi[j];
+        for (int i = 0; i < p; ++i) om(i, j) = ominv[(size_t)j * p + i];
+      }
+      if (which == 3) {
+        sampler.reset(new DeviceBregVsSampler(model.get(), mu, om, sigma_guess, prior_df, piv, chains, 0,
+                                              lookahead));
+      } else {
+        ZellnerPriorParameters z;
+        z.prior_inclusion_probabilities = piv;
+        z.prior_beta_guess = mu;
+        z.prior_beta_information = om;
+        z.prior_sigma_guess = sigma_guess;
+        z.prior_sigma_guess_weight = prior_df;
+        sampler.reset(new DeviceBregVsSampler(model.get(), z, chains, 0, lookahead));
+      }
+    }
+    if (out_seed) *out_seed = sampler->device_seed();
+    model->set_method(sampler);
+    for (int s = 0; s < nsweeps; ++s) {
+      model->sample_posterior();
+      const Selector &inc(model->coef().inc());
+      const Vector beta = model->Beta();
+      for (int j = 0; j < p; ++j) {
+        out_gamma[(size_t)s * p + j] = inc[j] ? 1 : 0;
+        out_beta[(size_t)s * p + j] = beta[j];
+      }
+      out_sigsq[s] = model->sigsq();
+    }
+    return 0;
+  } catch (std::exception &e) {
+    g_binding_error = e.what();
+    return -1;
+  }
 }
 
 // The same for the logit sampler: BOOM's BinomialLogitModel (data added one
@@ -336,6 +480,12 @@ static int binding_ss_impl(int T, int p, const double *y, const double *X, const
     if (out_seed) *out_seed = sampler->device_seed();
     model->set_method(sampler);
     for (int s = 0; s < nsweeps; ++s) {
+      if (s == g_ss_change_at && (int)g_ss_pi2.size() == p) {
+        // (ref_binding_ss_change_priors: the caller's spike and slab change under the sampler)
+        spike->set_prior_inclusion_probabilities(g_ss_pi2);
+        slab->set_mu(g_ss_mu2);
+        g_ss_change_at = -1;
+      }
       model->sample_posterior();   // PriorPolicy::sample_posterior -> sampler->draw()
       const Selector &inc(reg->coef().inc());
       const Vector beta = reg->Beta();

@@ -808,6 +808,27 @@ bo_ssvs *bo_ssvs_create(int p, const double *xtx, const double *xty,
   return s;
 }
 
+/* The prior objects a BregVsSampler was constructed with can be changed under it (ctor #5,
+ * BregVsSampler.hpp:98-106: "external copies of the pointers ... can be modified"): the
+ * next draw reads the new values.  Any argument may be NULL / NaN: unchanged. */
+void bo_ssvs_set_priors(bo_ssvs *s, const double *prior_mean, const double *ominv,
+                        double prior_df, double sigma_guess, const double *pi) {
+  const int p = s->p;
+  if (prior_mean) memcpy(s->b, prior_mean, (size_t)p * sizeof(double));
+  if (ominv) memcpy(s->ominv, ominv, (size_t)p * p * sizeof(double));
+  if (prior_df == prior_df && sigma_guess == sigma_guess) {
+    s->prior_df = 2 * (prior_df / 2.0);
+    s->prior_ss = 2 * (prior_df * sigma_guess * sigma_guess / 2.0);
+  }
+  if (pi) {
+    memcpy(s->pi, pi, (size_t)p * sizeof(double));
+    for (int j = 0; j < p; ++j) {
+      s->logpi[j] = log(pi[j]);
+      s->logcpi[j] = log(1 - pi[j]);
+    }
+  }
+}
+
 void bo_ssvs_destroy(bo_ssvs *s) {
   if (!s) return;
   if (!s->shared) {

@@ -122,6 +122,8 @@ bo_ssvs *bo_ssvs_create(int p, const double *xtx, const double *xty,
                         double yty, double n, double sumy, const double *xsum,
                         const double *prior_mean, const double *ominv,
                         double prior_df, double sigma_guess, const double *pi);
+void bo_ssvs_set_priors(bo_ssvs *s, const double *prior_mean, const double *ominv,
+                        double prior_df, double sigma_guess, const double *pi);
 void bo_ssvs_destroy(bo_ssvs *s);
 void bo_ssvs_set_options(bo_ssvs *s, int64_t max_model_size,
                          double sigma_upper_limit, double swap_threshold,

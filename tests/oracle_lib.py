@@ -357,6 +357,39 @@ class Oracle:
             out["min_margin"] = margin
         return out
 
+    def ssvs_run_priors_changed(self, suf, prior, prior2, change_at, opts, rng_setup, init_gamma, nsweeps):
+        """ssvs_run, with the priors replaced by prior2 before draw `change_at` (ctor #5's
+        prior objects modified under the sampler, BregVsSampler.hpp:98-101)"""
+        p = len(suf["xty"])
+        h = self.ssvs_create(suf, prior)
+        self.lib.bo_ssvs_set_options(h, opts["max_model_size"], opts["sigma_upper_limit"],
+                                     opts["swap_threshold"], opts["max_flips"],
+                                     opts["draw_beta"], opts["draw_sigma"])
+        g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
+        self.lib.bo_ssvs_set_state(h, _u8(g0), _dp(np.zeros(p)), 1.0)
+        self.lib.bo_rng_seed_philox(self.lib.bo_ssvs_rng(h), int(rng_setup[1]), int(rng_setup[2]), 0, 0)
+        self.lib.bo_ssvs_set_priors.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_double,
+                                                C.c_double, c_double_p]
+        self.lib.bo_ssvs_set_priors.restype = None
+        gam = np.zeros((nsweeps, p), dtype=np.uint8)
+        beta = np.zeros((nsweeps, p))
+        sig = np.zeros(nsweeps)
+        g, b, s = np.zeros(p, dtype=np.uint8), np.zeros(p), C.c_double()
+        status = 0
+        for i in range(nsweeps):
+            if i == change_at:
+                self.lib.bo_ssvs_set_priors(h, _dp(f64(prior2["b"])), _dp(fcol(prior2["ominv"])),
+                                            float(prior2["df"]), float(prior2["sigma_guess"]),
+                                            _dp(f64(prior2["pi"])))
+            status = self.lib.bo_ssvs_draw(h)
+            if status:
+                break
+            self.lib.bo_ssvs_get_state(h, _u8(g), _dp(b), C.byref(s))
+            gam[i], beta[i], sig[i] = g, b, s.value
+        margin = self.lib.bo_ssvs_min_margin(h)
+        self.lib.bo_ssvs_destroy(h)
+        return dict(gamma=gam, beta=beta, sigsq=sig, status=status, min_margin=margin)
+
     def log_model_prob(self, suf, prior, gammas, max_model_size=-1):
         h = self.ssvs_create(suf, prior)
         self.lib.bo_ssvs_set_options(h, max_model_size, float("inf"), 0.8, -1,
@@ -568,7 +601,9 @@ class Oracle:
             ss["initial_state_variance"], ss["initial_level_sigma"])
 
     def ss_run(self, y, X, observed, prior, opts, ss, rng_setup, init_gamma,
-               nsweeps, keep_state=None):
+               nsweeps, keep_state=None, prior2=None, change_at=-1):
+        """prior2 / change_at: the regression's priors replaced before draw `change_at` (prior
+        objects modified under the sampler)"""
         T, p = X.shape
         m = self.ss_create(y, X, observed, prior, ss)
         reg = self.lib.bo_ss_regression(m)
@@ -602,6 +637,13 @@ class Oracle:
         s = C.c_double()
         status = 0
         for i in range(nsweeps):
+            if prior2 is not None and i == change_at:
+                self.lib.bo_ssvs_set_priors.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_double,
+                                                        C.c_double, c_double_p]
+                self.lib.bo_ssvs_set_priors.restype = None
+                self.lib.bo_ssvs_set_priors(reg, _dp(f64(prior2["b"])), _dp(fcol(prior2["ominv"])),
+                                            float(prior2["df"]), float(prior2["sigma_guess"]),
+                                            _dp(f64(prior2["pi"])))
             status = self.lib.bo_ss_draw(m)
             if status:
                 break
