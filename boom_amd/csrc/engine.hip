@@ -410,7 +410,16 @@ struct ba_engine {
   // caller has seen them (ss_la_settle: the snapshot of the batch's start, replayed up
   // to the draw being served), so the look-ahead is unobservable.
   struct SsLa {
-    int len = 0;                // rounds per batch (<= 1: off)
+    int len = 0;                // rounds per batch at most (<= 1: off)
+    // rounds per batch NOW.  A caller whose loop reads something the record does not hold
+    // (another chain's state path, sufficient statistics, a forecast) or changes something
+    // (priors under the sampler) after every draw pays a rewind + replay of the batch each
+    // time: so a settle halves the batch, a batch served to its end doubles it again (up to
+    // len); at one round per call the look-ahead is off and is tried again after
+    // `probe_wait` calm draws (16, doubling while the tries keep failing).
+    int cur = 0, calm = 0, probe_wait = 16;
+    bool clean = true;          // nothing has settled the batch being served
+    int ahead_len = 0;          // rounds of the batch that is running ahead
     int avail = 0, served = 0, slot = 0;
     bool ahead = false;         // the next batch is enqueued (half slot ^ 1)
     bool synced = false;        // the batch being served is complete and its chains sound
@@ -1612,7 +1621,7 @@ int ss_la_launch(ba_engine *e, int slot) {
   ba_engine::SsLa &A = e->ssla;
   A.busy = true;
   int rc = ss_la_copy(e, true, slot);
-  if (!rc) rc = ss_sweep_impl(e, A.len, slot);
+  if (!rc) rc = ss_sweep_impl(e, A.cur, slot);
   A.busy = false;
   if (rc) return rc;
   HIP_TRY(hipEventRecord(A.done[slot], e->stream));
@@ -1641,9 +1650,19 @@ int ss_la_settle(ba_engine *e) {
   if (e->stream2) HIP_TRY(hipStreamSynchronize(e->stream2));
   const int served = A.served, slot = A.slot;
   const bool at_end = served >= A.avail && !A.ahead;   // the chains ARE at the draw served last
+  // (With the whole batch handed out and the next one running, the next batch's own snapshot
+  // IS the chains at the draw served last -- but not the state PATH of that draw, which a
+  // forecast or another chain's state read asks for and only the replay brings back: the
+  // batch is replayed here too.)
+  const bool at_boundary = false;
   ss_la_reset(e);
+  // (see SsLa::cur: whoever made this necessary may do so after every draw)
+  A.clean = false;
+  if (A.cur <= 2 && A.cur > 1) A.probe_wait = std::min(1024, A.probe_wait * 2);
+  A.cur = std::max(1, A.cur / 2);
+  A.calm = 0;
   if (at_end) return check_chain_status(e);
-  int rc = ss_la_copy(e, false, slot);
+  int rc = ss_la_copy(e, false, at_boundary ? slot ^ 1 : slot);
   if (rc) return rc;
   {  // (a chain that stopped in the dropped rounds stopped after the point we return to)
     const size_t C = (size_t)e->cfg.chains;
@@ -1652,7 +1671,7 @@ int ss_la_settle(ba_engine *e) {
   }
   e->table_ok = false;
   e->model_ok = false;
-  if (served > 0) {
+  if (served > 0 && !at_boundary) {
     rc = ss_sweep_impl(e, served, -1);
     if (rc) return rc;
   }
@@ -1686,7 +1705,7 @@ int ss_la_wait(ba_engine *e) {
     e->table_ok = false;
     e->model_ok = false;
     rc = ss_la_copy(e, true, slot);   // (the same starting point, for a later settle)
-    for (int i = 0; i < A.len && !rc; ++i) {
+    for (int i = 0; i < A.avail && !rc; ++i) {
       rc = ss_sweep_impl(e, 1, -1);
       if (!rc) HIP_TRY(hipStreamSynchronize(e->stream));
       if (!rc) rc = check_chain_status(e);   // (escalates, catches the chain up, reports errors)
@@ -1735,6 +1754,12 @@ bool ss_la_registered(const ba_engine *e, int64_t c) {
   for (int32_t r : e->ssla.reg)
     if (r == c) return true;
   return false;
+}
+// A chain whose state path was asked for and is not in the record: this read goes back to the
+// draw being served (ss_la_settle), the batches from here on record the chain too -- a caller
+// that reads chain c after every draw pays for it once, not every time.
+void ss_la_want_state(ba_engine *e, int64_t c) {
+  if (!ss_la_registered(e, c) && e->ssla.reg.size() < 32) e->ssla.reg.push_back((int32_t)c);
 }
 
 struct ApiScope {
@@ -3738,6 +3763,8 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
       // SeasonalStateModelBase: "'nseasons' must be positive"; one season has no state
       if (iparams[0] < 2) return fail(BA_E_INVALID, "nseasons must be at least 2");
       if (iparams[1] < 1) return fail(BA_E_INVALID, "season_duration must be positive");
+      // (the kernels keep a block's duration and its running phase in 16-bit fields)
+      if (iparams[1] > 65535) return fail(BA_E_INVALID, "season_duration exceeds 65535");
       k.nseasons = iparams[0];
       k.duration = iparams[1];
       // new_season(t): (t - time_of_first_observation) is a multiple of the duration
@@ -4003,6 +4030,7 @@ int ba_ss_get_state_draw(ba_engine *e, int64_t chain, double *state) {
       std::memcpy(state, &r->state[((size_t)e->ssla.served - 1) * SD], SD * 8);
       return BA_OK;
     }
+    ss_la_want_state(e, chain);
     int rcs = ss_la_settle(e);
     if (rcs) return rcs;
   }
@@ -4039,6 +4067,7 @@ int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state, double *var
         }
       return BA_OK;
     }
+    if (state) ss_la_want_state(e, chain);
     int rcs = ss_la_settle(e);
     if (rcs) return rcs;
   }
@@ -4267,7 +4296,18 @@ int ba_ss_set_lookahead(ba_engine *e, int32_t lookahead) {
   ENGINE_PROLOGUE(e);
   if (lookahead < 1) return fail(BA_E_INVALID, "lookahead must be at least 1");
   MUTATE(e);
+  {
+    // the record: two halves x chains x rounds x (gamma + beta [+ variances, coefficients]);
+    // a look-ahead it has no room for (p = 4096 with 1024 chains: 75 MB a round) is cut
+    // down to what 2 GiB hold rather than failing in hipMalloc
+    const double per_round = 2.0 * (double)e->cfg.chains * ((double)std::max(e->p, 1) * 9.0 + 8.0 * (SSG_MAX_VAR + SSG_MAX_AR * AR_MAX + 1));
+    const double budget = 2147483648.0;
+    if ((double)lookahead * per_round > budget) lookahead = std::max<int32_t>(1, (int32_t)(budget / per_round));
+  }
   e->ssla.len = lookahead;
+  e->ssla.cur = 0;
+  e->ssla.calm = 0;
+  e->ssla.probe_wait = 16;
   ss_la_reset(e);
   return BA_OK;
 }
@@ -4294,11 +4334,26 @@ int ba_ss_draw_next(ba_engine *e) {
   }
   ba_engine::SsLa &A = e->ssla;
   if (A.len <= 1) return ss_sweep_impl(e, 1, -1);
+  if (A.cur <= 1) {
+    // (every draw of late was followed by something the record could not serve: one round
+    // per call, and another try with a batch of two after a while)
+    if (A.cur < 1) A.cur = A.len;   // (first call after ba_ss_set_lookahead)
+    else {
+      if (++A.calm >= A.probe_wait) { A.cur = 2; A.calm = 0; }
+      return ss_sweep_impl(e, 1, -1);
+    }
+  }
   if (A.served == A.avail) {
+    if (A.avail > 0 && A.clean) {   // a batch served to its end in peace
+      A.cur = std::min(A.len, A.cur * 2);
+      A.probe_wait = 16;
+    }
+    A.clean = true;
     if (A.ahead) {
       // the record is used up: on to the batch that is already running (or done)
       A.slot ^= 1;
       A.ahead = false;
+      A.avail = A.ahead_len;
     } else {
       // ... or from the chains' current state
       int rc = ss_la_settle(e);
@@ -4312,12 +4367,13 @@ int ba_ss_draw_next(ba_engine *e) {
       A.slot = 0;
       rc = ss_la_launch(e, 0);
       if (rc) return rc;
+      A.avail = A.cur;
     }
-    A.avail = A.len;
     A.served = 0;
     A.synced = false;
     A.cache.clear();
     // the batch after this one goes out now, into the other half
+    A.ahead_len = A.cur;
     int rc = ss_la_launch(e, A.slot ^ 1);
     if (rc) return rc;
     A.ahead = true;
@@ -4373,6 +4429,7 @@ int ba_ss_get_state(ba_engine *e, int64_t chain, double *state,
       }
       return BA_OK;
     }
+    if (state) ss_la_want_state(e, chain);
     int rcs = ss_la_settle(e);   // (not in the record: the chains go back to the draw being served)
     if (rcs) return rcs;
   }

@@ -869,13 +869,11 @@ hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_
     } else if (P.ssm.m <= 16) {
       hipLaunchKernelGGL((ssg_simsmooth_kernel<true>), grid, block, lds, stream, P, draw_variances);
     } else {
-      // (more than 64 KB of dynamic LDS has to be asked for, once per process and size)
-      static size_t allowed = 65536;
-      if (lds > allowed) {
+      // (more than 64 KB of dynamic LDS has to be asked for -- per device, so every time)
+      if (lds > 65536) {
         err = hipFuncSetAttribute((const void *)ssg_simsmooth_kernel<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
-        allowed = lds;
       }
       hipLaunchKernelGGL((ssg_simsmooth_kernel<false>), grid, block, lds, stream, P, draw_variances);
     }

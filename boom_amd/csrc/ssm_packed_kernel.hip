@@ -737,11 +737,9 @@ size_t ssm_packed_lds(const SsmParams &M) {
 hipError_t launch_ssm_packed(hipStream_t stream, const SsParams &P, int draw_variances) {
   const dim3 grid((P.chain_count + PG - 1) / PG), block(256);
   const size_t lds = ssm_packed_lds(P.ssm);
-  static size_t allowed = 65536;
-  if (lds > allowed) {
+  if (lds > 65536) {   // (more than 64 KB of dynamic LDS has to be asked for -- per device, so every time)
     hipError_t err = hipFuncSetAttribute((const void *)ssg_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
-    allowed = lds;
   }
   hipLaunchKernelGGL(ssg_packed_kernel, grid, block, lds, stream, P, draw_variances);
   return hipGetLastError();

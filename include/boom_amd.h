@@ -188,7 +188,10 @@ int ba_sweep(ba_engine *e, int32_t nsweeps);
 /* wait for outstanding work and report the first chain error, if any.  (The chains'
  * status words come back in one batched copy; a ba_sync() that follows a clean one with
  * nothing in between but accessors -- ba_get_state, ba_ss_get_state, ba_logpri ... , each
- * of which begins with one -- is only the wait.) */
+ * of which begins with one -- is only the wait.)  While ba_ss_draw_next is serving draws
+ * from a look-ahead batch, ba_sync waits for THAT batch only: the batch running ahead of it
+ * stays in flight (a chain that stops there is reported when its draws are served), and it is
+ * no barrier for work the caller queued on ba_stream() -- synchronise that stream itself. */
 int ba_sync(ba_engine *e);
 /* The reference's calling pattern is ONE draw() per MCMC iteration with the
  * caller reading the parameters in between (spike_slab_wrapper.cc:233-242,
@@ -527,7 +530,11 @@ int ba_ss_get_structural(ba_engine *e, int64_t chain, double *state,
  * forecast -- first puts the chains back where the caller has seen them (the snapshot
  * taken at the batch's start, replayed up to the draw being served: same stream
  * positions, same draws), so the look-ahead is unobservable.  L = 1 (default): one
- * round per call.  ba_sync while a batch is being served waits for THAT batch. */
+ * round per call.  ba_sync while a batch is being served waits for THAT batch.
+ * What such a rewind costs is bounded: L is the LARGEST batch -- every rewind halves the
+ * batches that follow (down to one round per call: no look-ahead), every batch served to its
+ * end doubles them again; a chain whose state path was asked for joins the recorded chains
+ * (up to 32).  L is cut down to what a 2 GiB record holds. */
 int ba_ss_set_lookahead(ba_engine *e, int32_t lookahead);
 int ba_ss_lookahead_chains(ba_engine *e, int32_t nchains, const int64_t *chains);
 int ba_ss_draw_next(ba_engine *e);

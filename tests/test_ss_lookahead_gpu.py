@@ -159,3 +159,42 @@ def test_a_capacity_stop_inside_a_batch():
         ua, ub = a.ss_get_state(0, suf=False), b.ss_get_state(0, suf=False)
         assert ua["level_sigsq"] == ub["level_sigsq"] and np.array_equal(ua["state"], ub["state"]), it
     assert a.get_states()[0].sum(axis=1).min() > 30
+
+
+@pytest.mark.parametrize("habit", ["statistics", "another chain's state", "a mutator"])
+def test_callers_that_defeat_the_look_ahead(habit):
+    """A caller's loop that after EVERY draw asks for something the record does not hold
+    (sufficient statistics), reads the state path of a chain that is not recorded, or changes
+    something: each such call puts the chains back at the draw being served.  The engine
+    bounds what that costs -- the batches shrink (to one round per call) while it goes on and
+    grow back when it stops, a chain whose state was asked for joins the record -- and the
+    draws stay those of one round per call, through the shrinking, the tries with two rounds
+    and the growing back."""
+    T, p, chains, L = 180, 9, 10, 16
+    X, y, _, obs = state_space_data(T, p, 3, seed=19, missing_frac=0.03)
+    prior, ss, sig_up = bsts_priors(X, y, 3)
+    g0 = np.zeros(p, np.uint8)
+    a = make_level_engine(chains, 3, y, X, obs, prior, ss, sig_up, g0)
+    b = make_level_engine(chains, 3, y, X, obs, prior, ss, sig_up, g0)
+    b.ss_set_lookahead(L)
+    for it in range(90):
+        a.ss_sweep(1)
+        b.ss_draw_next()
+        bad_habit = it < 45 or it >= 70          # (25 calm draws in the middle: the batches grow back)
+        if bad_habit and habit == "statistics":
+            u, v = a.ss_get_state(4), b.ss_get_state(4)
+            assert u["level_sumsq"] == v["level_sumsq"] and np.array_equal(u["state"], v["state"]), it
+        elif bad_habit and habit == "another chain's state":
+            c = 2 + it % 3
+            assert np.array_equal(a.ss_get_state(c, suf=False)["state"], b.ss_get_state(c, suf=False)["state"]), it
+        elif bad_habit:
+            mf = 2 + it % (p - 1)
+            a.set_options(max_flips=mf)
+            b.set_options(max_flips=mf)
+        for u, v in zip(a.get_state(0), b.get_state(0)):
+            assert np.array_equal(u, v), it
+        assert np.array_equal(a.ss_get_state(0, suf=False)["state"], b.ss_get_state(0, suf=False)["state"]), it
+    for u, v in zip(a.get_states(), b.get_states()):
+        assert np.array_equal(u, v)
+    a.close()
+    b.close()
