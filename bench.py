@@ -168,32 +168,54 @@ def other_configs(boom_amd, torch, device, cpu=True):
     q1, med, q3 = (float(v) for v in np.percentile(per_batch, [25, 50, 75]))
     e3.ss_set_lookahead(1)
     e3.set_kernel_timing(True)
-    e3.ss_sweep(100)
-    kt = _per_launch(e3.kernel_times())
+    e3.ss_sweep(128)
+    raw3 = e3.kernel_times()
     e3.set_kernel_timing(False)
+    # the rounds of a call are ONE persistent launch per 64 of them (ss_round_kernel.hip):
+    # device time per round = the launches' time over the rounds they ran
+    kt = {k: round(ms / 128 * 1e3, 2) for k, (ms, _) in raw3.items()}       # us per round
+    # ... and the separate launches of rounds 1-4 (ba_ss_set_tuning(4)) beside it, same engine
+    e3.ss_set_tuning(kernel=4)
+    e3.ss_sweep(20)
+    t0 = time.perf_counter()
+    e3.ss_sweep(200)
+    dt_sep = time.perf_counter() - t0
+    e3.set_kernel_timing(True)
+    e3.ss_sweep(100)
+    kt_sep = _per_launch(e3.kernel_times())
+    e3.set_kernel_timing(False)
+    e3.ss_set_tuning(kernel=5)
     # Kalman bytes per chain-sweep f (T + 2T); the regression half reads the
     # shared design matrix once per launch: T p f
     bytes3 = C3 * 3 * T3 * 8 + T3 * p3 * 8
-    dom = max(kt, key=kt.get)
+    round_us = kt.get("ss_round_kernel", dt / 200 * 1e6)
     rec = {"sweeps_per_s": round(C3 * 200 / dt, 1), "us_per_round": round(dt / 200 * 1e6, 1),
-           "mean_model_size": round(k3, 2), "kernel_us_per_launch": kt,
+           "mean_model_size": round(k3, 2), "kernel_us_per_round": kt,
+           "separate_launches": {"what": "the same rounds as three launches each (regression sweep, state draw, "
+                                         "X'e GEMM; ba_ss_set_tuning(4)): rounds 1-4's path, the fallback for series "
+                                         "beyond 2048 steps and models beyond 48 variables",
+                                 "us_per_round": round(dt_sep / 200 * 1e6, 1), "kernel_us_per_launch": kt_sep},
            "callers_loop_us_per_draw": round(med * 1e6, 1),
            "callers_loop_detail": {"lookahead": 64, "median_us": round(med * 1e6, 1),
                                    "iqr_us": [round(q1 * 1e6, 1), round(q3 * 1e6, 1)],
                                    "one_round_per_call_us": round(loop3 * 1e6, 1),
                                    "what": "draw_next(); get_state(0); ss_get_state(0) -- chain 0's "
                                            "regression draw, level variance and state path per draw"},
-           "roofline": {"bound": "hbm", "kernel": "kalman_lm_kernel (the timing class is named after "
-                                                   "kalman_simsmooth_kernel, its T > 2048 sibling)",
+           "roofline": {"bound": "hbm", "kernel": "ss_round_kernel (every chain's rounds of a call in one persistent "
+                                                   "launch: sweep, level variance + normals, state draw, X'e tiles)",
                         "algorithmic_bytes_per_round": bytes3,
-                        "achieved": round(bytes3 / (kt["kalman_simsmooth_kernel"] * 1e-6) / 1e9, 1),
+                        "achieved": round(bytes3 / (round_us * 1e-6) / 1e9, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(bytes3 / (kt["kalman_simsmooth_kernel"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        "frac": round(bytes3 / (round_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "round_frac": round(bytes3 / dt * 200 / 1e9 / HBM_PEAK_GBS, 4),
-                        "slowest_kernel_of_the_round": dom,
-                        "traffic": _profile_traffic("c3", "kalman_lm_kernel"),
+                        "state_draw_alone": {"kernel": "kalman_lm_kernel as its own launch (separate launches)",
+                                             "us": kt_sep.get("kalman_simsmooth_kernel"),
+                                             "frac": round(bytes3 / (kt_sep.get("kalman_simsmooth_kernel", 1e9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "traffic": _profile_traffic("c3", "ss_round_kernel"),
                         "traffic_source": "profiles/r*_c3_pmc_traffic.json (rocprofv3 --pmc passes of "
-                                          "tools/ss_bench.py), per launch of the state draw"}}
+                                          "tools/ss_bench.py), per launch of 64 rounds",
+                        "note": "a round is bound by the two wavefronts' instruction streams (Philox for 2 T normals, "
+                                "the sweep's dependent round trips), not by bandwidth: DESIGN 3.5"}}
     if cpu:
         opts3 = ssvs_options(sigma_upper_limit=sig_up)
         g3 = np.zeros(p3, np.uint8)
@@ -321,20 +343,19 @@ def other_configs(boom_amd, torch, device, cpu=True):
                         "note": "v_mfma_f64_16x16x4_f64; R taken as chains x mean model size (the vectors "
                                 "requested mid-sweep add a few percent)"}}
     if cpu:
-        nsub = 5000
+        # ALL 50 000 observations, one sweep of one chain per thread (a sweep of the reference
+        # algorithm is dominated by the n p^2 rebuild of X'WX: about a minute per chain)
         th = min(cores, 8)
+        rate, nsw = _cpu_rate(lambda c, n: O.logit_run(Xl, yl, ntl, slab5, pi5,
+                                                       ("philox", SAMPLER_SEED, c), g5, np.zeros(p5), n),
+                              th, th, target_s=1.0, first=1)
+        rec["cpu_baseline"] = {"value": round(rate, 3), "unit": "sweeps/s", "cores": th,
+                               "kind": "port",
+                               "sample": "%d chains x %d sweep(s) on %d threads on all %d observations "
+                                         "(oracle bo_logit_draw from the one-variable model)" % (th, nsw, th, n5)}
+        nsub = 5000
         Xsub, ysub, ntsub = np.ascontiguousarray(Xl[:nsub]), yl[:nsub], ntl[:nsub]
         slabs, pis = probit_slab(Xsub, ntsub, 8)
-        rate, nsw = _cpu_rate(lambda c, n: O.logit_run(Xsub, ysub, ntsub, slabs, pis,
-                                                       ("philox", SAMPLER_SEED, c), g5, np.zeros(p5), n),
-                              th, th, target_s=10.0, first=1)
-        rec["cpu_baseline"] = {"value": round(rate * nsub / n5, 3), "unit": "sweeps/s", "cores": th,
-                               "kind": "port",
-                               "sample": "%d chains x %d sweeps on %d threads on the FIRST %d of the %d "
-                                         "observations, rate scaled by %d/%d (a sweep of the reference "
-                                         "algorithm is dominated by the n p^2 rebuild of X'WX, linear in n: "
-                                         "one full-size sweep takes about a minute per chain)"
-                                         % (th, nsw, th, nsub, n5, nsub, n5)}
     other["configs[4] per GPU: logit spike-and-slab n=5e4 p=1024, 512 chains"] = rec
     # ... and with the imputer BASELINE words the configuration with: Polya-Gamma augmentation
     # (ba_logit_set_imputer(1); BOOM has no such sampler -- parity for it is distributional,
@@ -426,7 +447,193 @@ def other_configs(boom_amd, torch, device, cpu=True):
                                           "state (kbar~%.1f), same statistics" % (cores, nsw, cores, kd)}
     other["dense_variant_64_signals (configs[1] data shape, 64 true signals)"] = recd
     ed.close()
+    other.update(family_configs(boom_amd, device, O, cores, cpu))
     return other
+
+
+def family_configs(boom_amd, device, O, cores, cpu):
+    """SURVEY 8(f)'s rows at the BASELINE shapes: the structural state
+    models (f2: the shapes the specialised kernel covers and two lists it does not), the
+    adaptive sampler (f1) on configs[1]'s data, the probit and Poisson samplers (f3) at
+    configs[4]'s per-GPU shape.  Each: sweeps/s, device time of its kernels per round, the
+    roofline of its dominant kernel (algorithmic bytes per DESIGN 3.x over that kernel's
+    time), and the oracle timed on this box's cores on a bounded sample of the same workload."""
+    from cases import (bsts_priors, general_data, general_spec, poisson_data, probit_data, probit_slab,
+                       regression_data, spike_slab_prior, structural_data, structural_spec)
+    from oracle_lib import ssvs_options
+    out = {}
+    T, p, nsig, C = 2000, 100, 5, 1024
+
+    def state_space(name, blocks_desc, template, ar_coef, tag, nrounds):
+        seas = [(d[1], d[2]) for d in blocks_desc if d[0] == "seasonal"]
+        X, y, _, _ = general_data(T, p, nsig, seas[:2], seed=DATA_SEED, ar_coef=ar_coef)
+        prior, _, sig_up = bsts_priors(X, y, 5)
+        blocks = general_spec(y, blocks_desc)
+        m = sum(bl["dim"] for bl in blocks)
+        nvar = sum(bl["nvar"] for bl in blocks)
+        eng = boom_amd.Engine(C, seed=SAMPLER_SEED, device=device)
+        eng.ss_set_data(y, X, None)
+        eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
+                       sigma_upper_limit=sig_up)
+        eng.ss_set_state_models(blocks)
+        eng.set_state(np.zeros(p, np.uint8))
+        eng.ss_sweep(max(6, nrounds // 2))
+        t0 = time.perf_counter()
+        eng.ss_sweep(nrounds)
+        dt = (time.perf_counter() - t0) / nrounds
+        eng.set_kernel_timing(True)
+        eng.ss_sweep(nrounds)
+        kt = {k: round(ms / nrounds * 1e3, 1) for k, (ms, _) in eng.kernel_times().items()}   # us per round
+        eng.set_kernel_timing(False)
+        kbar = float(eng.get_states()[0].sum(1).mean())
+        eng.close()
+        # DESIGN 3.6: per chain-sweep T f (2 m + 3 + nper + 6): gains and state (m each), three
+        # rows of smoothed disturbances, the step's normals, y*, F, residuals
+        bytes_ = float(C) * T * 8 * (2 * m + 3 + (nvar + 1) + 6)
+        kern = "ssm_simsmooth_kernel"
+        us = kt.get(kern, max(kt.values()))
+        rec = {"state_dimension": m, "kernel": "ssm_simsmooth_kernel<...> (shape-specialised)" if template
+               else "ssg_simsmooth_kernel (any list of state models)",
+               "sweeps_per_s": round(C / dt, 1), "ms_per_round": round(dt * 1e3, 3), "mean_model_size": round(kbar, 2),
+               "kernel_us_per_round": kt,
+               "roofline": {"bound": "hbm", "kernel": kern + " timing class (the state draw)",
+                            "algorithmic_bytes_per_round": bytes_,
+                            "achieved": round(bytes_ / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(bytes_ / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                            "traffic": _profile_traffic(tag, "ssm_simsmooth_kernel" if template else "ssg_simsmooth_kernel"),
+                            "traffic_source": "profiles/r*_%s_pmc_traffic.json, per launch of the state draw" % tag,
+                            "note": "serial in time: bound by the dependent-instruction chain of a step, not "
+                                    "by bandwidth (DESIGN 3.6)"}}
+        if cpu:
+            opts = ssvs_options(sigma_upper_limit=sig_up)
+            g0 = np.zeros(p, np.uint8)
+            rate, nsw = _cpu_rate(lambda c, n: O.ssg_run(y, X, None, prior, opts, blocks, ("philox", SAMPLER_SEED, c),
+                                                         g0, n, state_every=10 ** 6),
+                                  cores, cores, target_s=5.0, first=2)
+            rec["cpu_baseline"] = {"value": round(rate, 2), "unit": "sweeps/s", "cores": cores, "kind": "port",
+                                   "sample": "%d chains x %d sweeps from the empty model on %d threads (oracle "
+                                             "bo_ssm_draw), same T=2000 p=100 data and state models"
+                                             % (cores, nsw, cores)}
+        out[name] = rec
+
+    state_space("f2 structural: trend + 12 seasons (m=13), T=2000 p=100, 1024 chains",
+                [("trend",), ("seasonal", 12, 1)], True, None, "structural", 30)
+    state_space("f2 structural: trend + 12 seasons + AR(2) (m=15), T=2000 p=100, 1024 chains",
+                [("trend",), ("seasonal", 12, 1), ("ar", 2)], True, [1.2, -0.4], "structural_ar", 30)
+    state_space("f2 general list: trend + weekly + 4 x 7 cycle (m=11), T=2000 p=100, 1024 chains",
+                [("trend",), ("seasonal", 7, 1), ("seasonal", 4, 7)], False, None, "general", 16)
+    state_space("f2 general list: bsts daily model, trend + weekly + 52 x 7 cycle (m=59), T=2000 p=100, 1024 chains",
+                [("trend",), ("seasonal", 7, 1), ("seasonal", 52, 7)], False, None, "general", 8)
+
+    # ---- f1: AdaptiveSpikeSlabRegressionSampler on configs[1]'s data (what lm.spike runs for p > 100)
+    n2, p2, sig2, C2 = 10000, 512, 16, 1024
+    X2, y2, _ = regression_data(n2, p2, sig2, seed=DATA_SEED)
+    ea = boom_amd.Engine(C2, seed=SAMPLER_SEED, device=device)
+    ea.build_suf_from_xy(X2, y2)
+    s2 = ea.get_suf()
+    suf2 = dict(xtx=s2["xtx"], xty=s2["xty"], yty=s2["yty"], n=s2["n"], sumy=s2["ybar"] * s2["n"],
+                xsum=s2["xbar"] * s2["n"])
+    pr2 = spike_slab_prior(suf2, sig2)
+    ea.set_priors(pr2["b"], pr2["ominv"], pr2["pi"], pr2["df"], pr2["sigma_guess"])
+    ga = np.zeros(p2, np.uint8)
+    ga[0] = 1
+    ea.set_state(ga)
+    ea.adaptive_sweep(300)
+    ea.reset_summaries()
+    t0 = time.perf_counter()
+    ea.adaptive_sweep(500)
+    dta = time.perf_counter() - t0
+    sma = ea.get_summaries()
+    ka = sma["k_sum"] / sma["sweeps"]
+    ea.set_kernel_timing(True)
+    ea.adaptive_sweep(500)
+    kta = ea.kernel_times()
+    ea.set_kernel_timing(False)
+    gama, betaa, siga = ea.get_states()
+    ea.close()
+    msa = sum(ms for ms, _ in kta.values())
+    # the reference's iteration: max_flips (100) birth / death proposals, each a log_model_prob
+    # of a model one variable away: 100 x f (2 k + 4) gathered + the draw's 3 k + 4
+    bytesa = (100 * 8.0 * (2 * ka + 4) + 8.0 * (3 * ka + 4)) * C2 * 500
+    reca = {"sweeps_per_s": round(C2 * 500 / dta, 1), "us_per_sweep_round": round(dta / 500 * 1e6, 1),
+            "mean_model_size": round(float(ka), 2), "accepted_moves_per_sweep": round(sma["accepts"] / sma["sweeps"], 3),
+            "kernel_ms_per_500_sweep_launch": {k: round(ms, 3) for k, (ms, _) in kta.items()},
+            "roofline": {"bound": "hbm", "kernel": "ssvs_adaptive_kernel", "algorithmic_bytes_per_launch": round(bytesa, 0),
+                         "achieved": round(bytesa / (msa * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(bytesa / (msa * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "100 proposals a sweep instead of p = 512: a fifth of the headline's bytes per sweep"}}
+    if cpu:
+        rate, nsw = _cpu_rate(lambda c, n: O.adaptive_run(suf2, pr2, ssvs_options(), ("philox", SAMPLER_SEED, c), gama[c % C2], n),
+                              cores, cores, target_s=5.0, first=20)
+        reca["cpu_baseline"] = {"value": round(rate, 2), "unit": "sweeps/s", "cores": cores, "kind": "port",
+                                "sample": "%d chains x %d sweeps on %d threads, started at GPU chains' models "
+                                          "(kbar~%.1f), same statistics (oracle bo_adaptive_draw)" % (cores, nsw, cores, ka)}
+    out["f1 adaptive sampler (AdaptiveSpikeSlabRegressionSampler), configs[1]'s data: n=1e4 p=512, 1024 chains"] = reca
+
+    # ---- f3: probit and Poisson at configs[4]'s per-GPU shape (n = 5e4, p = 1024, 512 chains)
+    n5, p5, C5 = 50000, 1024, 512
+
+    def glm(name, kind):
+        if kind == "probit":
+            X, y, nt, _ = probit_data(n5, p5, 8, seed=DATA_SEED)
+            slab, pi = probit_slab(X, nt, 8)
+        else:
+            from test_oracle_golden import _golden_mix, load
+            mix = _golden_mix(load("poisson_small_counts"))
+            X, y, ex, _ = poisson_data(n5, p5, 8, seed=DATA_SEED)
+            y = np.minimum(y, 11.0)      # (the mixture table that travels with the goldens covers counts 1 .. 11)
+            slab, pi = probit_slab(X, np.ones(n5), 8)
+        e = boom_amd.Engine(C5, seed=SAMPLER_SEED, device=device)
+        if kind == "probit":
+            e.probit_set_data(X, y, nt, 5)
+            sweep = e.probit_sweep
+        else:
+            e.poisson_set_data(X, y, ex, mix)
+            sweep = e.poisson_sweep
+        e.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+        e.set_spike(pi)
+        g0 = np.zeros(p5, np.uint8)
+        g0[0] = 1
+        e.set_state(g0)
+        sweep(10)
+        t0 = time.perf_counter()
+        sweep(20)
+        dt = (time.perf_counter() - t0) / 20
+        e.set_kernel_timing(True)
+        sweep(10)
+        kt = {k: round(ms / 10, 3) for k, (ms, _) in e.kernel_times().items()}
+        e.set_kernel_timing(False)
+        gam = e.get_states()[0]
+        kbar = float(gam.sum(1).mean())
+        e.close()
+        imp = "probit_impute_kernel" if kind == "probit" else "poisson_impute_kernel"
+        # the imputation reads, per chain and observation, the included variables' entries of
+        # the row, y / trials / exposure, and writes the latent value(s)
+        bytes_ = float(C5) * n5 * 8.0 * (kbar + (3 if kind == "probit" else 5))
+        rec = {"sweeps_per_s": round(C5 / dt, 1), "ms_per_round": round(dt * 1e3, 2), "mean_model_size": round(kbar, 2),
+               "signal_inclusion_min": round(float(gam[:, :8].mean(0).min()), 4), "kernel_ms_per_round": kt,
+               "roofline": {"bound": "hbm", "kernel": imp, "algorithmic_bytes_per_round": bytes_,
+                            "achieved": round(bytes_ / (kt[imp] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(bytes_ / (kt[imp] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "traffic": _profile_traffic(kind, imp),
+                            "traffic_source": "profiles/r*_%s_pmc_traffic.json, per launch of the imputation" % kind,
+                            "note": "rejection / adaptive-rejection loops per observation: bound by their latency "
+                                    "and divergence, not by bandwidth (DESIGN 3.8)"}}
+        if cpu:
+            th = min(cores, 8)
+            if kind == "probit":
+                fn = lambda c, n: O.probit_run(X, y, nt, slab, pi, ("philox", SAMPLER_SEED, c), g0, np.zeros(p5), n)
+            else:
+                fn = lambda c, n: O.poisson_run(X, y, ex, slab, pi, mix, ("philox", SAMPLER_SEED, c), g0, np.zeros(p5), n)
+            rate, nsw = _cpu_rate(fn, th, th, target_s=8.0, first=1)
+            rec["cpu_baseline"] = {"value": round(rate, 3), "unit": "sweeps/s", "cores": th, "kind": "port",
+                                   "sample": "%d chains x %d sweeps on %d threads on all %d observations" % (th, nsw, th, n5)}
+        out[name] = rec
+
+    glm("f3 probit spike-and-slab at configs[4]'s per-GPU shape: n=5e4 p=1024, 512 chains", "probit")
+    glm("f3 Poisson spike-and-slab at configs[4]'s per-GPU shape: n=5e4 p=1024, 512 chains (counts capped at 11: "
+        "the goldens' mixture table)", "poisson")
+    return out
 
 
 def _timed_steps(torch, dist, eng, world, local_rank, steps, warmup, step):

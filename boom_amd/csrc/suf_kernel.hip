@@ -143,6 +143,122 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(const double *__restrict_
       }
 }
 
+// The same product with the panels brought in by LDS-DMA (global_load_lds_dwordx4: global ->
+// LDS with no vector register in between, 1 KB per wave instruction) instead of 16 loads + 16
+// ds_write_b64 per thread and panel ("try it and report").  A DMA writes its
+// 64 lanes' 16 bytes one after the other, so the LDS image cannot be padded per column; the
+// bank-conflict-free fragment reads come from an XOR swizzle instead, put on the SOURCE side
+// (cdna_hip_programming.md 5, rule 21): granule q (two rows) of column c sits at
+// c * 16 + (q ^ (c & 15)), i.e. the lane that writes that place loads rows 2 (q ^ (c & 15)) + {0, 1}
+// of the column.  Same products in the same order as xtx_mfma_kernel: bitwise the same X'X.
+// Needs n even and X 16-byte aligned (a granule is 16 bytes of one column); whole 32-row
+// steps by DMA, a last partial step through registers (zero fill).
+template <int KX>
+__device__ __forceinline__ int panel_at(int c, int k) { return c * KX + ((((k >> 1) ^ (c & (KX / 2 - 1))) << 1) | (k & 1)); }
+
+template <int KX>
+__global__ __launch_bounds__(256) void xtx_mfma_glds_kernel(const double *__restrict__ X,
+                                                            int64_t n, int p,
+                                                            double *__restrict__ xtx, int edge) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double (*sA)[TILE * KX] = reinterpret_cast<double (*)[TILE * KX]>(s_dyn);
+  double (*sB)[TILE * KX] = reinterpret_cast<double (*)[TILE * KX]>(s_dyn + 2 * TILE * KX);
+  const int tiles = (p + TILE - 1) / TILE, S = (tiles + edge - 1) / edge;
+  int ti, tj;
+  {
+    const unsigned b = blockIdx.x, x = b % 8u, j = b / 8u, e2 = (unsigned)(edge * edge);
+    const unsigned q = (j / e2) * 8u + x, in = j % e2;
+    if (q >= (unsigned)(S * (S + 1) / 2)) return;
+    // supertile q of the lower triangle, row by row: (si, sj), sj <= si
+    int si = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+    while ((unsigned)((si + 1) * (si + 2) / 2) <= q) ++si;
+    while ((unsigned)(si * (si + 1) / 2) > q) --si;
+    const int sj = (int)q - si * (si + 1) / 2;
+    ti = si * edge + (int)(in / (unsigned)edge);
+    tj = sj * edge + (int)(in % (unsigned)edge);
+  }
+  if (ti >= tiles || tj > ti) return;
+  const int I0 = ti * TILE, J0 = tj * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int fr = lane >> 4, fc = lane & 15;
+  // (the row slices are the register-staged kernel's: whole 32-row steps)
+  const int64_t steps = (n + KC - 1) / KC;
+  const int64_t per = (steps + gridDim.z - 1) / gridDim.z;
+  const int64_t rbeg = (int64_t)blockIdx.z * per * KC;
+  const int64_t rend = (rbeg + per * KC < n) ? rbeg + per * KC : n;
+  xtx += (size_t)blockIdx.z * (size_t)p * (size_t)p;
+  // (columns past p are never written: they stay zero)
+  for (int i = tid; i < 4 * TILE * KX; i += 256) s_dyn[i] = 0.0;
+  __syncthreads();
+  typedef __attribute__((address_space(1))) const void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  // DMA instruction I of a strip (16 of them, four per wave) fills granules [64 I, 64 I + 64):
+  // columns 4 I .. 4 I + 3; lane l: column 4 I + (l >> 4), place l & 15
+  auto stage = [&](int buf, int64_t r0) {
+    if (r0 + KX <= rend) {
+      constexpr int GPC = KX / 2;              // granules per column
+      constexpr int CPI = 64 / GPC;            // columns per DMA instruction
+#pragma unroll
+      for (int u = 0; u < GPC / 4; ++u) {
+        const int I = 4 * u + wave, c = CPI * I + lane / GPC, g = (lane & (GPC - 1)) ^ (c & (GPC - 1));
+        if (I0 + c < p)
+          __builtin_amdgcn_global_load_lds((gptr_t)(X + (int64_t)(I0 + c) * n + r0 + 2 * g), (lptr_t)(&sA[buf][128 * I]), 16, 0, 0);
+        if (J0 + c < p)
+          __builtin_amdgcn_global_load_lds((gptr_t)(X + (int64_t)(J0 + c) * n + r0 + 2 * g), (lptr_t)(&sB[buf][128 * I]), 16, 0, 0);
+      }
+    } else {
+      for (int e = tid; e < TILE * KX; e += 256) {
+        const int col = e / KX, prow = e % KX;
+        const int64_t r = r0 + prow;
+        sA[buf][panel_at<KX>(col, prow)] = (r < rend && I0 + col < p) ? X[(int64_t)(I0 + col) * n + r] : 0.0;
+        sB[buf][panel_at<KX>(col, prow)] = (r < rend && J0 + col < p) ? X[(int64_t)(J0 + col) * n + r] : 0.0;
+      }
+    }
+  };
+  if (rbeg < rend) stage(0, rbeg);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t r0 = rbeg; r0 < rend; r0 += KX) {
+    if (r0 + KX < rend) stage(cur ^ 1, r0 + KX);   // (the other buffer was last read before the previous barrier)
+#pragma unroll
+    for (int kk = 0; kk < KX / 4; ++kk) {
+      double a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = sA[cur][panel_at<KX>(wi * 32 + t * 16 + fc, kk * 4 + fr)];
+        b[t] = sB[cur][panel_at<KX>(wj * 32 + t * 16 + fc, kk * 4 + fr)];
+      }
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+          acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+    __syncthreads();   // (waits for the DMAs in flight too: the panel is there)
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = I0 + wi * 32 + ta * 16 + (lane >> 4) + 4 * q;
+        const int j = J0 + wj * 32 + tb * 16 + (lane & 15);
+        if (i < p && j < p) {
+          const double v = acc[ta][tb][q];
+          xtx[(int64_t)j * p + i] = v;
+          xtx[(int64_t)i * p + j] = v;
+        }
+      }
+}
+
 // sum of the split-K planes in plane order (bitwise reproducible)
 __global__ __launch_bounds__(256) void plane_sum_kernel(const double *__restrict__ planes,
                                                         int nplanes, size_t count,
@@ -307,6 +423,13 @@ static unsigned suf_grid_blocks(int tiles, int edge) {
   return (unsigned)(((lower + 7) / 8) * 8 * edge * edge);
 }
 
+// (A/B builds: -DBA_SUF_NO_DMA keeps the register-staged kernel everywhere)
+#ifdef BA_SUF_NO_DMA
+static const bool g_suf_dma = false;
+#else
+static const bool g_suf_dma = true;
+#endif
+
 int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
                        const double *y, double *xtx, double *xty,
                        double *scalars, double *xsum, double *planes) {
@@ -314,11 +437,21 @@ int launch_suf_from_xy(hipStream_t stream, int64_t n, int p, const double *X,
   const int ksplit = planes ? suf_row_slices(n, p) : 1;
   const int edge = suf_edge(tiles);
   KtScope kt(stream, KT_SUF);
+  // (panels by LDS-DMA where a 16-byte granule of a column is addressable: see xtx_mfma_glds_kernel)
+  const bool dma = g_suf_dma && (n % 2 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
+  // (32-row panels, two workgroups to a CU: 43.5 ms at n = 1e5, p = 4096 against 44.9 through
+  // registers; 64-row panels -- half the barriers, 128 KB of LDS, one workgroup per CU: 48.8)
+  constexpr int KX = 32;
+  auto kern = dma ? xtx_mfma_glds_kernel<KX> : xtx_mfma_kernel;
+  const size_t lds = dma ? (size_t)4 * TILE * KX * 8 : 0;
+  if (dma && lds > 65536) {
+    if (hipFuncSetAttribute((const void *)xtx_mfma_glds_kernel<KX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+  }
   if (ksplit <= 1) {
-    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(suf_grid_blocks(tiles, edge), 1, 1), dim3(256), 0, stream, X, n, p, xtx, edge);
+    hipLaunchKernelGGL(kern, dim3(suf_grid_blocks(tiles, edge), 1, 1), dim3(256), lds, stream, X, n, p, xtx, edge);
   } else {
     const size_t count = (size_t)p * p;
-    hipLaunchKernelGGL(xtx_mfma_kernel, dim3(suf_grid_blocks(tiles, edge), 1, ksplit), dim3(256), 0, stream, X, n, p, planes, edge);
+    hipLaunchKernelGGL(kern, dim3(suf_grid_blocks(tiles, edge), 1, ksplit), dim3(256), lds, stream, X, n, p, planes, edge);
     hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
                        planes, ksplit, count, xtx);
   }
