@@ -470,7 +470,7 @@ def family_configs(boom_amd, device, O, cores, cpu):
         prior, _, sig_up = bsts_priors(X, y, 5)
         blocks = general_spec(y, blocks_desc)
         m = sum(bl["dim"] for bl in blocks)
-        nvar = sum(bl["nvar"] for bl in blocks)
+        nvar = sum(len(bl["df"]) for bl in blocks)
         eng = boom_amd.Engine(C, seed=SAMPLER_SEED, device=device)
         eng.ss_set_data(y, X, None)
         eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
