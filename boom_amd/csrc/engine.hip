@@ -3710,8 +3710,14 @@ namespace {
 // the scalars of the specification that follow from the block list
 void ssg_finish(SsgSpec &q) {
   q.ld = q.m | 1;
-  q.bl = q.m <= 16 ? 64 : (q.m <= 32 ? 32 : 16);
   q.nerr = q.nvar;
+  // steps per block of the passes: the most that leaves FOUR workgroups to a CU's 160 KB of
+  // LDS (all 1024 chains of a launch resident; at m = 59 sixteen steps left room for three,
+  // and the launch ran as two rounds), never below 8; see ssg_pass_lds_doubles
+  q.bl = 64;
+  while (q.bl > 8 && (2 * q.bl * q.m + q.m * q.ld + q.bl * (q.nerr + 1) + SSG_MAX_STATE + 8 +
+                      q.nar * AR_MAX * (AR_MAX + 1)) * 8 > 39 * 1024)
+    q.bl /= 2;
 }
 // ArModel's constructor: "Attempt to initialize ArModel with an illegal value of the
 // autoregression coefficients." (the quick bound, then the step-down recursion)

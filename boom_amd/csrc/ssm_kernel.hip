@@ -76,6 +76,7 @@ __host__ __device__ inline int ssg_pass_lds_doubles(int m, int ld, int bl, int n
 // sampler's matrices, ssg_pass_lds_doubles).  SMALL: m <= 16.
 template <bool SMALL>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void ssg_simsmooth_kernel(SsParams P, int draw_variances) {
+  constexpr int SSG_BATCH = SMALL ? 1 : 8;   // entries of a column / row of P asked of the LDS together
   extern __shared__ __align__(16) unsigned char s_raw[];
   __shared__ int s_flag;
   __shared__ int s_vprog;            // blocks the variance pass has put out (wave 1 -> wave 0)
@@ -316,11 +317,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
         const unsigned mv = B.moving();
         // PZ_k = sum over the blocks of P(first of the block, k)  [= P(k, first), P symmetric]
+        // (the blocks' rows are asked for together: one LDS round trip, not one per block)
         double PZ = 0.0;
+        if (SMALL) {
 #pragma nounroll
-        for (int b = 0; b < nb; ++b) {
-          const int zl = Blocks::first_of(B.udesc(b)) + (int)(B.urc(b) >> 16);
-          if (mylane) PZ += s_P[zl * ld + lane];
+          for (int b = 0; b < nb; ++b) {
+            const int zl = Blocks::first_of(B.udesc(b)) + (int)(B.urc(b) >> 16);
+            if (mylane) PZ += s_P[zl * ld + lane];
+          }
+        } else {
+          double pz[SSG_MAX_BLOCKS];
+#pragma unroll
+          for (int b = 0; b < SSG_MAX_BLOCKS; ++b) {
+            const int zl = Blocks::first_of(B.udesc(b)) + (int)(B.urc(b) >> 16);
+            pz[b] = (b < nb && mylane) ? s_P[zl * ld + lane] : 0.0;
+          }
+#pragma unroll
+          for (int b = 0; b < SSG_MAX_BLOCKS; ++b)
+            if (b < nb) PZ += pz[b];
         }
         const double F = zdot<SMALL>(LI, PZ, lane) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
@@ -357,15 +371,29 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           } else if (kd == SSG_SEASONAL) {
             const bool moves = (mv >> b) & 1u;
             if (obs || moves) {
+              // (eight entries of the column in flight at a time: a rolled walk waited for
+              // one LDS round trip per entry -- 51 of them a step in bsts's daily model)
               double cs = 0.0;
 #pragma nounroll
-              for (int i = 0; i < n; ++i) {
-                double v = col[i * ld];
-                if (obs) {
-                  v -= (s_tv[f + i] * PZ) * Finv;
-                  col[i * ld] = v;
+              for (int i0 = 0; i0 < n; i0 += SSG_BATCH) {
+                const int nn = n - i0;
+                double v[SSG_BATCH], tv[SSG_BATCH];
+#pragma unroll
+                for (int u = 0; u < SSG_BATCH; ++u) {
+                  const int i = i0 + (u < nn ? u : nn - 1);
+                  v[u] = col[i * ld];
+                  tv[u] = s_tv[f + i];
                 }
-                cs -= v;
+#pragma unroll
+                for (int u = 0; u < SSG_BATCH; ++u) {
+                  if (u < nn) {
+                    if (obs) {
+                      v[u] -= (tv[u] * PZ) * Finv;
+                      col[(i0 + u) * ld] = v[u];
+                    }
+                    cs -= v[u];
+                  }
+                }
               }
               // the row of the component that drops out becomes that of the new first
               // component, -(sum over the block)
@@ -377,11 +405,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
             const double *ph = s_phi + Blocks::arx_of(d) * AR_MAX;
             double cs = 0.0;
 #pragma nounroll
-            for (int q = n - 1; q >= 0; --q) {
-              double v = col[q * ld];
-              if (obs) v -= (s_tv[f + q] * PZ) * Finv;
-              cs += ph[q] * v;
-              if (q + 1 < n) col[(q + 1) * ld] = v;
+            for (int q0 = n - 1; q0 >= 0; q0 -= SSG_BATCH) {
+              const int nn = q0 + 1;   // entries left, q0 the highest of them
+              double v[SSG_BATCH], tv[SSG_BATCH], pc[SSG_BATCH];
+#pragma unroll
+              for (int u = 0; u < SSG_BATCH; ++u) {
+                const int q = q0 - (u < nn ? u : nn - 1);
+                v[u] = col[q * ld];
+                tv[u] = s_tv[f + q];
+                pc[u] = ph[q];
+              }
+#pragma unroll
+              for (int u = 0; u < SSG_BATCH; ++u) {
+                if (u < nn) {
+                  const int q = q0 - u;
+                  if (obs) v[u] -= (tv[u] * PZ) * Finv;
+                  cs += pc[u] * v[u];
+                  if (q + 1 < n) col[(q + 1) * ld] = v[u];
+                }
+              }
             }
             col[0] = cs;
           }
@@ -405,16 +447,37 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
             const int w = sprev((int)(B.urc(b) >> 16), n);
             double cs = 0.0;
 #pragma nounroll
-            for (int j = 0; j < n; ++j) cs -= row[j];
+            for (int j0 = 0; j0 < n; j0 += SSG_BATCH) {
+              const int nn = n - j0;
+              double v[SSG_BATCH];
+#pragma unroll
+              for (int u = 0; u < SSG_BATCH; ++u) v[u] = row[j0 + (u < nn ? u : nn - 1)];
+#pragma unroll
+              for (int u = 0; u < SSG_BATCH; ++u)
+                if (u < nn) cs -= v[u];
+            }
             row[w] = cs + (lane == f + w ? sg : 0.0);
           } else {
             const double *ph = s_phi + Blocks::arx_of(d) * AR_MAX;
             double cs = 0.0;
 #pragma nounroll
-            for (int q = n - 1; q >= 0; --q) {
-              const double v = row[q];
-              cs += ph[q] * v;
-              if (q + 1 < n) row[q + 1] = v;
+            for (int q0 = n - 1; q0 >= 0; q0 -= SSG_BATCH) {
+              const int nn = q0 + 1;
+              double v[SSG_BATCH], pc[SSG_BATCH];
+#pragma unroll
+              for (int u = 0; u < SSG_BATCH; ++u) {
+                const int q = q0 - (u < nn ? u : nn - 1);
+                v[u] = row[q];
+                pc[u] = ph[q];
+              }
+#pragma unroll
+              for (int u = 0; u < SSG_BATCH; ++u) {
+                if (u < nn) {
+                  const int q = q0 - u;
+                  cs += pc[u] * v[u];
+                  if (q + 1 < n) row[q + 1] = v[u];
+                }
+              }
             }
             row[0] = cs + (lane == f ? sg : 0.0);
           }
