@@ -28,6 +28,7 @@
 // is the O(p k^2) table fill after every accepted flip.
 #include "ktimer.h"
 #include "ssvs_device.h"
+#include "ssvs_fill_mfma.h"
 
 namespace boom_amd {
 
@@ -203,6 +204,7 @@ __device__ __forceinline__ void uniform_copy(BigCtx &b, const BigCtx &in) {
   b.S.Lv = uni_u(in.S.Lv); b.S.La = uni_u(in.S.La); b.S.rdv = uni_u(in.S.rdv); b.S.rda = uni_u(in.S.rda);
   b.S.w = uni_u(in.S.w); b.S.bg = uni_u(in.S.bg); b.S.g = uni_u(in.S.g); b.S.scal = uni_u(in.S.scal);
   b.S.total = uni_u(in.S.total);
+  b.S.iv = uni_u(in.S.iv); b.S.ia = uni_u(in.S.ia);
 }
 __device__ __forceinline__ void uniform_copy(Model &m, const Model &in) {
   m.logp = uni(in.logp); m.lp = uni(in.lp); m.ldv = uni(in.ldv); m.lda = uni(in.lda);
@@ -244,9 +246,18 @@ __device__ __forceinline__ void rebuild_g(Chain &ch, int kcap) {
 // set_reg_post_params + log_model_prob (BregVsSampler.cpp:216-239, :395-484).
 // A real function (not inlined at its call sites): it is the rare path and its
 // unrolled solves are large.
+#ifdef BA_BSTAMPS
+__device__ unsigned long long g_bstamp[16];
+#define BST(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_bstamp[i], (unsigned long long)(t_ - bst_)); bst_ = t_; } while (0)
+#else
+#define BST(i) do { } while (0)
+#endif
 __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &M, double *dst,
                                                const BigCtx &bx, const bool REUSE) {
   const int lane = ch.lane, p = ch.p, k = ch.k, kcap = bx.kcap;
+#ifdef BA_BSTAMPS
+  long long bst_ = (long long)__builtin_readcyclecounter();
+#endif
   const SsvsScalarLayout &S = bx.S;
   M.bad = 0;
   M.pd = true;
@@ -319,6 +330,7 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
                     },
                     [&](int, double (&)[64]) {});
         }
+        BST(I > 0 ? 1 : 0);
         // diagonal tile: M[g_i, g_c] - sum_m x_i[m] x_c[m]
         double acc[64];
 #pragma unroll
@@ -341,6 +353,7 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
           }
         }
         const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
+        BST(2);
         wave_sync();
 #pragma unroll
         for (int c = 0; c < 64; ++c)
@@ -351,6 +364,7 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
         chol_tile(bx.tile, bx.rdt, kk, lane, &ok, &ldt);
         ld += ldt;
         wave_sync();
+        BST(3);
         if (!ok) break;
         // rows of this tile row go to the factor: parked off-diagonal part, the tile, rd
         if (row < kpad8) {
@@ -362,6 +376,7 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
           rdst[row] = valid ? bx.rdt[lane] : 0.0;
         }
         if (s == 0 && valid) ch.rdv[row] = bx.rdt[lane];
+        BST(4);
       }
       if (s) { oka = ok; M.lda = 2.0 * ld; }
       else   { okv = ok; M.ldv = 2.0 * ld; }
@@ -374,6 +389,14 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
     M.logp = -BA_INF;
     return;
   }
+  BST(5);
+  // what the table fills on the matrix cores multiply by (ssvs_fill_mfma.h)
+  if (!REUSE && k <= MF_ROWS * MF_MAX_BLOCK_ROWS) {
+    diag_inverses(dst + S.Lv, dst + S.rdv, dst + S.iv, k, lane);
+    if (oka) diag_inverses(dst + S.La, dst + S.rda, dst + S.ia, k, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  }
+  BST(6);
   // r = A_g b_g + xty_g, c = b_g' A_g b_g (only non-zero prior means cost)
   double cpart = 0.0;
   {
@@ -432,6 +455,7 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
     wave_sync();
   }
   M.Q = wave_sum(qpart);
+  BST(7);
   M.SS = ch.ss0q + M.c - M.Q;
   if (ch.mode) {
     if (!oka) { M.lda = -BA_INF; M.logp = -BA_INF; return; }
@@ -464,7 +488,7 @@ __device__ __forceinline__ void load_scalars(const double *src, const SsvsScalar
 // this lane's proposal "flip j" against the current model (factors through sc)
 template <bool NAT>
 __device__ __forceinline__ Proposal big_eval(const BigP &P, Chain &ch, const Model &M,
-                                             const BigCtx &bx, c_f64 *sc, int j, bool valid) {
+                                             const BigCtx &bx, c_f64 *sc, int j, bool valid, int jbase) {
   const int p = ch.p, k = ch.k, lane = ch.lane;
   const SsvsScalarLayout &S = bx.S;
   Proposal out;
@@ -493,6 +517,13 @@ __device__ __forceinline__ Proposal big_eval(const BigP &P, Chain &ch, const Mod
   const double xtyj = (fast && add) ? ch.xty[j] * ch.sx : 0.0;
   const int npan = (k + 63) >> 6;
   double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
+  if (NAT && k <= MF_ROWS * MF_MAX_BLOCK_ROWS) {
+    // a fill round of a model of at most 128 variables: the wavefront's 64 proposals
+    // jbase + lane together, on the matrix cores
+    const MfSums z = mf_proposal_sums(P.V, P.A, p, ch.sv, ch.sa, ch.sc_store, S, S.iv, S.ia, ch.g, k, jbase,
+                                      (fast ? 1 : 0) | (add ? 2 : 0), lane);
+    nv = z.nv; dv = z.dv; na = z.na; ab = z.ab;
+  } else
 #pragma nounroll
   for (int s = 0; s < 2; ++s) {
     const double *Mat = s ? P.A : P.V;
@@ -741,6 +772,11 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     wave_sync();
   }
 
+#ifdef BA_BSTAMPS
+  // diagnostic build: where the master's time goes, by command (tools/big_phases.py)
+  double bph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long bt0 = (long long)__builtin_readcyclecounter();
+#endif
   for (;;) {
     if (wave == 0) {
       int cmd = BCMD_NONE;
@@ -1142,8 +1178,15 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
       }
       if (lane == 0) ctl[CT_CMD] = (double)cmd;
     }
+#ifdef BA_BSTAMPS
+    const long long bt1 = (long long)__builtin_readcyclecounter();
+    bph[0] += (double)(bt1 - bt0);
+#endif
     __syncthreads();
     const int cmd = (int)ctl[CT_CMD];
+#ifdef BA_BSTAMPS
+    bph[4 + (cmd & 3)] += 1.0;
+#endif
     if (cmd == BCMD_EXIT) break;
     if (cmd == BCMD_UNIF) {
       const uint64_t upos = ((AS_LDS const uint64_t *)(ctl + CT_POS))[0];
@@ -1160,7 +1203,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
       c_f64 *sc = scalar_view(ch.sc_store);
       const int idx = (int)ctl[CT_I0] + WAVE * wave + lane;
       const bool valid = idx < p;
-      const Proposal pr = big_eval<true>(BP, ch, Me, bx, sc, valid ? idx : 0, valid);
+      const Proposal pr = big_eval<true>(BP, ch, Me, bx, sc, valid ? idx : 0, valid, idx - lane);
       if (valid) {
         // (the adaptive moves compare log model probabilities themselves)
         ch.tab_lp[idx] = adaptive ? pr.logp : exp(pr.logp - Me.logp);
@@ -1227,6 +1270,10 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
       }
     }
     __syncthreads();
+#ifdef BA_BSTAMPS
+    bt0 = (long long)__builtin_readcyclecounter();
+    bph[cmd & 3] += (cmd == 0) ? 0.0 : (double)(bt0 - bt1);
+#endif
   }
   if (wave != 0) return;
 
@@ -1280,6 +1327,13 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     a[ACC_PROPOSALS] += ctl[CT_ACC + ACC_PROPOSALS];
     a[ACC_SLOT_HITS] += ctl[CT_ACC + ACC_SLOT_HITS];
     a[ACC_MIN_MARGIN] = fmin(a[ACC_MIN_MARGIN], ctl[CT_ACC + ACC_MIN_MARGIN]);
+#ifdef BA_BSTAMPS
+    if (blockIdx.x == 0)
+      printf("build stamps (cycles, all chains so far): head/none %llu solve %llu update %llu chol_tile %llu store %llu fence %llu inverses %llu rhs+w %llu\n",
+             g_bstamp[0], g_bstamp[1], g_bstamp[2], g_bstamp[3], g_bstamp[4], g_bstamp[5], g_bstamp[6], g_bstamp[7]);
+    if (!adaptive)
+      for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += bph[i];   // master | EVAL | UNIF | BUILD cycles, then their counts (exit, EVAL, UNIF, BUILD)
+#endif
     if (adaptive)
       a[ACC_PHASE0] = (a[ACC_PHASE0] == 0.0) ? ctl[CT_ACC + ACC_PHASE0]
                                              : fmin(a[ACC_PHASE0], ctl[CT_ACC + ACC_PHASE0]);

@@ -307,7 +307,7 @@ static inline __host__ __device__ SsvsAdaLds ssvs_ada_lds_layout(int p, int kcap
 
 // offsets (in doubles) inside one chain's model_scratch block
 struct SsvsScalarLayout {
-  uint32_t Lv, La, rdv, rda, w, bg, g, scal, total;
+  uint32_t Lv, La, rdv, rda, w, bg, g, scal, iv, ia, total;
 };
 static inline __host__ __device__ SsvsScalarLayout ssvs_scalar_layout(int kcap) {
   SsvsScalarLayout S;
@@ -322,6 +322,9 @@ static inline __host__ __device__ SsvsScalarLayout ssvs_scalar_layout(int kcap) 
   S.bg = o;  o += (uint32_t)kcap;
   S.g = o;   o += (uint32_t)kcap / 2;  // int32 indices, two per double
   S.scal = o; o += 8;                  // logp, lp, ldv, lda, Q, c, SS, pd (the model's scalars)
+  // the inverses of the factors' 16 x 16 diagonal blocks (ssvs_fill_mfma.h), row-major
+  S.iv = o;  o += (uint32_t)kcap * 16;
+  S.ia = o;  o += (uint32_t)kcap * 16;
   S.total = (o + 7u) & ~7u;            // whole 64-byte lines per chain
   return S;
 }
