@@ -332,13 +332,25 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
         }
         BST(I > 0 ? 1 : 0);
         // diagonal tile: M[g_i, g_c] - sum_m x_i[m] x_c[m]
+        // (columns in blocks of eight, only those the tile has: a chain that hovers just
+        // above a multiple of 64 variables builds a last tile of one or two rows, and all
+        // 64 columns of it cost 4 096 FMAs a tile row for nothing)
+        const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
         double acc[64];
 #pragma unroll
-        for (int c = 0; c < 64; ++c) {
-          const int col = I * 64 + c;
-          const int gc = (col < k) ? (int)ch.g[col] : 0;
-          const double v = Mrow[gc] * msc;
-          acc[c] = (valid && col <= row) ? v : 0.0;
+        for (int cb = 0; cb < 8; ++cb) {
+          if (cb * 8 < kk) {
+#pragma unroll
+            for (int c = cb * 8; c < cb * 8 + 8; ++c) {
+              const int col = I * 64 + c;
+              const int gc = (col < k) ? (int)ch.g[col] : 0;
+              const double v = Mrow[gc] * msc;
+              acc[c] = (valid && col <= row) ? v : 0.0;
+            }
+          } else {
+#pragma unroll
+            for (int c = cb * 8; c < cb * 8 + 8; ++c) acc[c] = 0.0;
+          }
         }
         if (I > 0) {
           c_f64 *XS = scalar_view(bx.xs);
@@ -347,12 +359,16 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
 #pragma unroll
             for (int t = 0; t < 8; ++t) xi[t] = bx.xs[(size_t)(m0 + t) * 64 + lane];
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int cb = 0; cb < 8; ++cb) {
+              if (cb * 8 < kk) {
 #pragma unroll
-              for (int c = 0; c < 64; ++c) acc[c] -= xi[t] * XS[(size_t)(m0 + t) * 64 + c];
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                  for (int c = cb * 8; c < cb * 8 + 8; ++c) acc[c] -= xi[t] * XS[(size_t)(m0 + t) * 64 + c];
+              }
+            }
           }
         }
-        const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
         BST(2);
         wave_sync();
 #pragma unroll
@@ -368,7 +384,13 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
         if (!ok) break;
         // rows of this tile row go to the factor: parked off-diagonal part, the tile, rd
         if (row < kpad8) {
-          for (int m = 0; m < I * 64; ++m) Lst[bidx(row, m)] = valid ? bx.xs[(size_t)m * 64 + lane] : 0.0;
+          for (int m0 = 0; m0 < I * 64; m0 += 8) {   // (eight at a time: a rolled copy waited for every load)
+            double xv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xv[t] = bx.xs[(size_t)(m0 + t) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) Lst[bidx(row, m0 + t)] = valid ? xv[t] : 0.0;
+          }
 #pragma unroll
           for (int c = 0; c < 64; ++c)
             if ((c >> 3) <= (lane >> 3))
@@ -433,7 +455,13 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
     const bool valid = row < k;
     double t = valid ? bx.y[row] : 0.0;
     if (valid)
-      for (int m = 0; m < I * 64; ++m) t -= Lv[bidx(row, m)] * ch.w[m];
+      for (int m0 = 0; m0 < I * 64; m0 += 8) {
+        double lv8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lv8[u] = Lv[bidx(row, m0 + u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t -= lv8[u] * ch.w[m0 + u];
+      }
     double lt[64];
 #pragma unroll
     for (int j = 0; j < 64; ++j) lt[j] = (valid && j < lane) ? Lv[bidx(row, I * 64 + j)] : 0.0;
