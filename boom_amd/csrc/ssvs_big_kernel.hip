@@ -548,7 +548,7 @@ __device__ __forceinline__ Proposal big_eval(const BigP &P, Chain &ch, const Mod
   if (NAT && k <= MF_ROWS * MF_MAX_BLOCK_ROWS) {
     // a fill round of a model of at most 128 variables: the wavefront's 64 proposals
     // jbase + lane together, on the matrix cores
-    const MfSums z = mf_proposal_sums(P.V, P.A, p, ch.sv, ch.sa, ch.sc_store, S, S.iv, S.ia, ch.g, k, jbase,
+    const MfSums z = mf_proposal_sums<8>(P.V, P.A, p, ch.sv, ch.sa, ch.sc_store, S, S.iv, S.ia, ch.g, k, jbase,
                                       (fast ? 1 : 0) | (add ? 2 : 0), lane);
     nv = z.nv; dv = z.dv; na = z.na; ab = z.ab;
   } else

@@ -144,6 +144,12 @@ __device__ __forceinline__ int bidx(int m, int n) {
   return ((I * (I + 1)) / 2 + J) * 64 + (m & 7) * 8 + (n & 7);
 }
 
+}  // namespace
+}  // namespace boom_amd
+#include "ssvs_fill_mfma.h"
+namespace boom_amd {
+namespace {
+
 // wave-uniform description of the current model
 struct Model {
   double logp;  // log_model_prob(gamma)
@@ -500,6 +506,14 @@ __device__ __forceinline__ void publish_model(Chain &ch, const Model &M) {
     sc[0] = M.logp; sc[1] = M.lp; sc[2] = M.ldv; sc[3] = M.lda;
     sc[4] = M.Q; sc[5] = M.c; sc[6] = M.SS; sc[7] = M.pd ? 1.0 : 0.0;
   }
+  if constexpr (NB >= MF_MIN_NB) {
+    // what the table fills on the matrix cores multiply by (ssvs_fill_mfma.h); the fence
+    // also drops the CU's cached lines of the block's previous contents, for both waves
+    __builtin_amdgcn_s_waitcnt(0);
+    diag_inverses(dst + S.Lv, dst + S.rdv, dst + S.iv, k, lane);
+    diag_inverses(dst + S.La, dst + S.rda, dst + S.ia, k, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  }
   unsigned long long u = (unsigned long long)dst;
   asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(u) : : "memory");
   ch.sc = (c_f64 *)u;
@@ -583,7 +597,7 @@ struct Proposal {
 template <int NB, bool NAT>
 __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch,
                                                   const Model &M, int j,
-                                                  bool valid, StampCtx &sx) {
+                                                  bool valid, StampCtx &sx, int jbase = 0) {
   const int p = ch.p, k = ch.k;
   Proposal out;
   out.logp = -BA_INF;
@@ -630,7 +644,14 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 
   double nv = 0.0, dv = 0.0, na = 0.0, ab = 0.0;
   SUBSTAMP(sx, 1);
-  if constexpr (NB <= 2) {
+  if constexpr (NAT && NB >= MF_MIN_NB) {
+    // a fill round at capacity 48 / 64: the wavefront's 64 proposals jbase + lane together,
+    // on the matrix cores (ssvs_fill_mfma.h)
+    const MfSums z = mf_proposal_sums<NB / 2>(P.V, P.A, p, ch.sv, ch.sa, ch.sc_store, S, S.iv, S.ia, ch.g, k, jbase,
+                                              (fast ? 1 : 0) | (add ? 2 : 0), ch.lane);
+    nv = z.nv; dv = z.dv; na = z.na; ab = z.ab;
+    SUBSTAMP(sx, 5);
+  } else if constexpr (NB <= 2) {
     // Small capacities (the bsts path: a handful of variables, a fresh table every sweep
     // because X'y moves): BOTH right-hand sides are gathered before either solve, so that
     // a proposal round is one trip to L2 instead of two in a row (32 more registers for
@@ -1120,7 +1141,7 @@ __device__ __forceinline__ void eval_share(const SsvsParams &P, Chain &ch,
   const int idx = i0 + WAVE * wave + lane;
   if (evmode == EVM_FILL) {
     const bool valid = idx < ch.p;
-    const Proposal pr = eval_proposal<NB, true>(P, ch, M, valid ? idx : 0, valid, sx);
+    const Proposal pr = eval_proposal<NB, true>(P, ch, M, valid ? idx : 0, valid, sx, idx - lane);
     if (valid) {
       // acceptance threshold in the uniform's own scale: log u <= logp' - logp
       // <=> u <= exp(logp' - logp)   (0 for an impossible model, inf / NaN --

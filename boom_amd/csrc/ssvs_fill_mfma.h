@@ -26,7 +26,7 @@
 // two passes serve a wavefront's 64 proposals; up to 128 rows (8 block rows) fit the
 // registers.  Larger models keep the per-lane route.
 #pragma once
-#include "ssvs_device.h"
+// (included by ssvs_device.h, after its address-space types and bidx)
 
 namespace boom_amd {
 
@@ -34,11 +34,13 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-enum : int { MF_ROWS = 16, MF_NT = 2, MF_MAX_BLOCK_ROWS = 8 };
+enum : int { MF_ROWS = 16, MF_NT = 2, MF_MAX_BLOCK_ROWS = 8,
+             MF_MIN_NB = 6 };   // the LDS kernel's instances of capacity 8 MF_MIN_NB and more fill this way
 
-// block rows the MFMA route is compiled for: the smallest of {2, 4, 5, 6, 8} that holds k
+// block rows the MFMA route is compiled for: the smallest of {2, 3, 4, 5, 6, 8} that holds k
+// (never more than the capacity the model block was laid out for has)
 __host__ __device__ inline int mf_block_rows(int k) {
-  return k <= 32 ? 2 : (k <= 64 ? 4 : (k <= 80 ? 5 : (k <= 96 ? 6 : 8)));
+  return k <= 32 ? 2 : (k <= 48 ? 3 : (k <= 64 ? 4 : (k <= 80 ? 5 : (k <= 96 ? 6 : 8))));
 }
 // doubles of a model block's inverse diagonal blocks, per factor
 __host__ __device__ inline int mf_inv_doubles(int kcap) { return (kcap / MF_ROWS) * MF_ROWS * MF_ROWS; }
@@ -188,7 +190,7 @@ __device__ __forceinline__ void mf_factor(const double *__restrict__ Mat, const 
     for (int q = 0; q < 4; ++q) {
       const int m = MF_ROWS * I + 4 * q + g;
       double wm = 0.0;
-      if (SF) wm = wv[m];
+      if (SF) { const double wr = wv[m]; wm = (m < k) ? wr : 0.0; }
 #pragma unroll
       for (int t = 0; t < MF_NT; ++t) {
         const double e = (gmv[I][q] == jt[t]) ? dropf[t] : 0.0;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void mf_factor(const double *__restrict__ Mat, const 
     for (int q = 0; q < 4; ++q) {
       const int m = MF_ROWS * I + 4 * q + g;
       double wm = 0.0;
-      if (!SF) wm = wv[m];
+      if (!SF) { const double wr = wv[m]; wm = (m < k) ? wr : 0.0; }
 #pragma unroll
       for (int t = 0; t < MF_NT; ++t) {
         const double x = X[I][t][q];
@@ -264,7 +266,9 @@ __device__ __forceinline__ void mf_pass(const double *__restrict__ V, const doub
   }
 }
 
-// The sums of the wavefront's 64 proposals jbase + lane (k <= 128).
+// The sums of the wavefront's 64 proposals jbase + lane (k <= 128).  MAXNI: the block rows
+// the caller's capacity can reach (its kernel carries no code for more).
+template <int MAXNI>
 __device__ __forceinline__ MfSums mf_proposal_sums(const double *V, const double *A, int p, double sv, double sa,
                                                    const double *gblock, const SsvsScalarLayout &S,
                                                    uint32_t inv_v, uint32_t inv_a, lds_u16 *glist, int k,
@@ -273,13 +277,12 @@ __device__ __forceinline__ MfSums mf_proposal_sums(const double *V, const double
   const int nI = mf_block_rows(k);
 #pragma nounroll
   for (int ps = 0; ps < 2; ++ps) {
-    switch (nI) {
-      case 2: mf_pass<2>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); break;
-      case 4: mf_pass<4>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); break;
-      case 5: mf_pass<5>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); break;
-      case 6: mf_pass<6>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); break;
-      default: mf_pass<8>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); break;
-    }
+    if (nI == 2) mf_pass<2>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out);
+    if constexpr (MAXNI >= 3) { if (nI == 3) mf_pass<3>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); }
+    if constexpr (MAXNI >= 4) { if (nI == 4) mf_pass<4>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); }
+    if constexpr (MAXNI >= 5) { if (nI == 5) mf_pass<5>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); }
+    if constexpr (MAXNI >= 6) { if (nI == 6) mf_pass<6>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); }
+    if constexpr (MAXNI >= 8) { if (nI == 8) mf_pass<8>(V, A, p, sv, sa, gblock, S, inv_v, inv_a, glist, k, jbase, ps, flags, lane, out); }
   }
   return out;
 }
