@@ -409,30 +409,35 @@ def other_configs(boom_amd, torch, device, cpu=True):
     gd = np.zeros(pd_, np.uint8)
     gd[0] = 1
     ed.set_state(gd)
+    # (the headline's step: launches of SWEEPS_PER_STEP sweeps -- a launch lasts as long as its
+    # slowest chain, and over 200 sweeps the slowest of 1024 chains makes 1.4x the mean's
+    # accepted flips, over 1000 sweeps 1.15x)
+    NSD = SWEEPS_PER_STEP
     ed.sweep(200)
     ed.reset_summaries()
     t0 = time.perf_counter()
-    ed.sweep(200)
+    ed.sweep(NSD)
     dtd = time.perf_counter() - t0
     smd = ed.get_summaries()
     kd = smd["k_sum"] / smd["sweeps"]
     gamd, betad, sigdv = ed.get_states()
     ed.set_kernel_timing(True)
-    ed.sweep(200)
+    ed.sweep(NSD)
     ktd = ed.kernel_times()
     ed.set_kernel_timing(False)
     msd = sum(ms for ms, _ in ktd.values())
-    bytesd = (pd_ * 8.0 * (2 * kd + 4) + 8.0 * (3 * kd + 4) + pd_ / 8.0) * Cd * 200
-    recd = {"sweeps_per_s": round(Cd * 200 / dtd, 1), "us_per_sweep_round": round(dtd / 200 * 1e6, 1),
+    bytesd = (pd_ * 8.0 * (2 * kd + 4) + 8.0 * (3 * kd + 4) + pd_ / 8.0) * Cd * NSD
+    recd = {"sweeps_per_s": round(Cd * NSD / dtd, 1), "us_per_sweep_round": round(dtd / NSD * 1e6, 1),
             "mean_model_size": round(float(kd), 2),
             "signal_inclusion_min": round(float(gamd[:, :sigd].mean(0).min()), 4),
-            "kernel_ms_per_200_sweep_launch": {k: round(ms, 3) for k, (ms, _) in ktd.items()},
+            "kernel_ms_per_%d_sweep_launch" % NSD: {k: round(ms, 3) for k, (ms, _) in ktd.items()},
             "roofline": {"bound": "hbm", "kernel": max(ktd, key=lambda k: ktd[k][0]),
                          "algorithmic_bytes_per_launch": round(bytesd, 0),
                          "achieved": round(bytesd / (msd * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(bytesd / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": _profile_traffic("dense64", "ssvs_big_kernel"),
-                         "traffic_source": "profiles/r*_dense64_pmc_traffic.json, per 200-sweep launch of ssvs_big_kernel"}}
+                         "traffic_source": "profiles/r*_dense64_pmc_traffic.json, per %d-sweep launch of ssvs_big_kernel "
+                                           "(NSWEEP=%d tools/dense_variant.py 64)" % (NSD, NSD)}}
     if cpu:
         def rund(nchains, nsw, nthreads):
             t0 = time.perf_counter()
@@ -820,6 +825,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-apart", action="store_true",
+                    help="(profiling) join the engine's two streams after every launch of the timed region: "
+                         "hardware counters of overlapping dispatches cannot be told apart")
     ap.add_argument("--no-curve", action="store_true",
                     help="skip the sweeps/s-vs-chains diagnostic (extra key, untimed)")
     ap.add_argument("--config", type=int, default=1, choices=(1, 3, 4),
@@ -930,6 +938,8 @@ def main():
     # are measured right after as `separate_launches`.
     for _ in range(args.warmup):
         eng.sweep(SWEEPS_PER_STEP, sync=False)
+        if args.keep_apart:
+            eng.stream()
     eng.sync()
     eng.reset_summaries()
     eng.set_kernel_timing(True, overlap=True)
@@ -940,6 +950,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.sweep(SWEEPS_PER_STEP, sync=False)
+        if args.keep_apart:
+            eng.stream()
     eng.sync()
     torch.cuda.synchronize()
     if world > 1:

@@ -30,7 +30,7 @@ profile() {   # name, pmc (yes|no), kernel substrings for the summary, then the 
       local pn=$1; shift
       rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_$pn -o pmc -- python3 "${CMD[@]}" > $out/pmc_$pn.out 2> $out/pmc_$pn.err
     }
-    CMD=("$@")
+    CMD=("$@" $PMC_EXTRA)   # (PMC_EXTRA: flags for the counter passes only)
     pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES
     pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
     pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS
@@ -43,12 +43,12 @@ profile() {   # name, pmc (yes|no), kernel substrings for the summary, then the 
 
 for w in $ONLY; do
   case $w in
-    c2)         profile c2 yes "ssvs_ xtx_mfma plane_sum col_reduce" $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-curve ;;
+    c2)         PMC_EXTRA="--keep-apart" profile c2 yes "ssvs_ xtx_mfma plane_sum col_reduce" $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-curve ;;
     c3)         profile c3 yes "ss_round ssvs_ kalman xtwx_" $ROOT/tools/ss_bench.py ;;
     structural) profile structural yes "ssvs_ ssm_ xtwx_" $ROOT/tools/structural_bench.py 2,12,1024 ;;
     structural_ar) profile structural_ar no "ssvs_ ssm_ xtwx_" $ROOT/tools/structural_bench.py 2,12,1024,2 ;;
     c4)         profile c4 yes "ssvs_ xtx_mfma plane_sum col_reduce" $ROOT/bench.py --config 3 --steps 3 --warmup 1 ;;
-    dense64)    profile dense64 yes "ssvs_" $ROOT/tools/dense_variant.py 64 ;;
+    dense64)    export NSWEEP=1000; profile dense64 yes "ssvs_" $ROOT/tools/dense_variant.py 64; unset NSWEEP ;;
     general)    profile general yes "ssvs_ ssg_ ssm_ xtwx_" $ROOT/tools/ssg_bench.py ;;
     pg)         profile pg yes "ssvs_ logit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 pg 12 ;;
     logit)      profile logit yes "ssvs_ logit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 logit 12 ;;
