@@ -30,99 +30,37 @@ namespace boom_amd {
 
 namespace {
 
-enum : int { TN_CAP = 64 };
-
-// TnSampler: bounded adaptive rejection for a standard normal given x > a, a > 0
-// (logf = -x^2 / 2); per-thread hull arrays, the reference's lower_bound probes
 // how many uniforms a slot of an imputer's substream hands out before the draw goes on in the
 // spill stream (device_rng.h): the whole stride, or what ba_set_slot_limit asked for (tests)
 __device__ __forceinline__ uint32_t slot_serve(const ProbitParams &P, uint32_t stride) {
   return (P.slot_limit > 0 && (uint32_t)P.slot_limit < stride) ? (uint32_t)P.slot_limit : stride;
 }
-__device__ __forceinline__ int tn_lower_bound(const double *v, int n, double value) {
-  int first = 0, count = n;
-  while (count > 0) {
-    const int step = count / 2;
-    if (v[first + step] < value) { first += step + 1; count -= step + 1; }
-    else count = step;
-  }
-  return first;
-}
-// The hull's points are x_0 = a < x_1 < ...; the reference keeps logf(x_k) = -x_k^2 / 2
-// and its derivative -x_k beside them and, after every rejected candidate, recomputes
-// ALL knots and ALL segment integrals (TnSampler::add_point / update_cdf,
-// Samplers/TnSampler.cpp) -- O(n) divisions and 2 n exponentials per candidate.  A knot
-// depends on its two neighbouring points only and a segment's two integrals on its
-// point and its two knots, so an insertion at position pos changes knots pos, pos + 1
-// and the integrals of segments pos - 1 .. pos + 1; everything else is the value the
-// reference would recompute from the same inputs.  Here those are kept (inc1, inc2) and
-// only the changed ones evaluated: same numbers, O(1) transcendentals per candidate.
-__device__ double tn_draw(SeqRng &rng, double a, int *bad) {
-  double xs[TN_CAP], kn[TN_CAP], cdf[TN_CAP], inc1[TN_CAP], inc2[TN_CAP];
-  auto yv = [](double x) { return __dmul_rn(__dmul_rn(-.5, x), x); };   // (a stored value in the reference: rounded)
-  const double y0 = yv(a);
-  // the integrals of segment k (point k between knots k and k + 1; the last one is open)
-  auto segment = [&](int k, int n) {
-    const double z = xs[k], d = -z, y = yv(z) - y0, dinv = 1.0 / d;
-    inc1[k] = (k == n - 1) ? 0 : dinv * exp(y - d * z + d * kn[k + 1]);
-    inc2[k] = dinv * exp(y - d * z + d * kn[k]);
-  };
-  int n = 1;
-  xs[0] = a; kn[0] = a;
-  segment(0, 1);
-  cdf[0] = 0 + inc1[0] - inc2[0];
-  for (int level = 0; level <= 1001; ++level) {
-    const double u = d_runif(rng, 0.0, cdf[n - 1]);
-    const int k = tn_lower_bound(cdf, n, u);
-    double cand;
-    if (k + 1 == n) cand = kn[n - 1] + d_rexp(rng, -1 * -xs[n - 1]);
-    else cand = d_rtrun_exp(rng, -1 * -xs[k], kn[k], kn[k + 1]);
-    const double target = yv(cand);
-    const double hull = yv(xs[k]) + -xs[k] * (cand - xs[k]);
-    const double logu = hull - d_rexp(rng, 1.0);
-    if (logu < target) return cand;
-    if (n >= TN_CAP) { *bad = 1; return a; }
-    const int pos = tn_lower_bound(kn, n, cand);
-    if (pos == 0) { *bad = 1; return a; }   // (a candidate at the truncation point itself: never)
-    for (int i = n; i > pos; --i) { xs[i] = xs[i - 1]; inc1[i] = inc1[i - 1]; inc2[i] = inc2[i - 1]; }
-    for (int i = n; i > pos + 1; --i) kn[i] = kn[i - 1];
-    xs[pos] = cand;
-    ++n;
-    for (int i = pos; i <= pos + 1 && i < n; ++i) {
-      const double xl = xs[i - 1], xr = xs[i];
-      double ans = (yv(xl) - -xl * xl) - (yv(xr) - -xr * xr);
-      ans /= (-xr - -xl);
-      kn[i] = ans;
-    }
-    for (int kk = pos - 1; kk <= pos + 1 && kk < n; ++kk) segment(kk, n);
-    double last = pos >= 2 ? cdf[pos - 2] : 0;
-    for (int kk = pos - 1; kk < n; ++kk) {
-      cdf[kk] = last + inc1[kk] - inc2[kk];
-      last = cdf[kk];
-    }
-  }
-  *bad = 1;
-  return a;
-}
-// The same sampler with its hull in LDS.  tn_draw's arrays are indexed by numbers that
-// differ from lane to lane, so in scratch memory every access is 64 cache lines for the
-// texture path -- the probit imputation was bound by exactly that.  In LDS, laid out
-// [array][point][slot], a lane's bank depends on its slot only, whatever point it
-// touches.  A workgroup has TN_SLOTS hulls of TN_LDS_CAP points (the draws that need
-// one take a slot on first use; the others, and a hull that outgrows its slot, use
-// tn_draw -- the same numbers either way: same expressions on the same inputs).
-enum : int { TN_LDS_CAP = 16, TN_SLOTS = 72 };
-struct TnSlot {
-  double *hull;   // the workgroup's 3 TN_LDS_CAP TN_SLOTS doubles
-  int *taken;     // slots handed out
-  int slot;       // this thread's (-1: none yet, -2: none left)
+// TnSampler (Samplers/TnSampler.cpp): bounded adaptive rejection for a standard normal given
+// x > a, a > 0 (logf = -x^2 / 2).  The hull's points are x_0 = a < x_1 < ...; after every
+// rejected candidate the reference recomputes all knots and all segment integrals
+// (add_point / update_cdf) and probes the cdf and the knots with std::lower_bound: restated
+// here as written, on the same inputs.
+//
+// The hull lives in LDS, laid out [array][point][slot] (a lane's bank depends on its slot
+// only, whatever point it touches): per-thread arrays indexed by numbers that differ from lane
+// to lane were 2.5 KB of scratch memory per lane and 64 cache lines per access.  Two sizes:
+// TN_SLOTS hulls of TN_LDS_CAP points for the draws of the workgroup's SECOND phase (see the
+// kernel), TN_BIG_SLOTS of TN_BIG_CAP points for the few that outgrow those -- an observation
+// that does is done again from its first draw with a large hull (the same numbers: same
+// expressions on the same inputs, the stream is positional); a hull of more than TN_BIG_CAP
+// points is reported (CHAIN_RNG_BRANCH), as it always was.
+enum : int { TN_LDS_CAP = 16, TN_SLOTS = 64, TN_BIG_CAP = 64, TN_BIG_SLOTS = 4 };
+struct TnHull {
+  double *base;   // this thread's slot of the hull arrays: array a, point i at base[(a * cap + i) * stride]
+  int stride;     // slots side by side
+  int cap;        // points
 };
-// returns false when the hull outgrew the slot (nothing is left consumed: the caller
-// rewinds the stream)
-__device__ __forceinline__ bool tn_draw_lds(SeqRng &rng, double a, const TnSlot &S, double *out) {
-  auto yv = [](double x) { return __dmul_rn(__dmul_rn(-.5, x), x); };
-  double *xs = S.hull + S.slot, *kn = xs + TN_LDS_CAP * TN_SLOTS, *cdf = kn + TN_LDS_CAP * TN_SLOTS;
-#define AT(arr, k) arr[(k) * TN_SLOTS]
+// returns false when the hull outgrew its capacity (the caller redoes the observation)
+__device__ __forceinline__ bool tn_draw_lds(SeqRng &rng, double a, const TnHull &H, double *out) {
+  auto yv = [](double x) { return __dmul_rn(__dmul_rn(-.5, x), x); };   // (a stored value in the reference: rounded)
+  const int st = H.stride;
+  double *xs = H.base, *kn = xs + H.cap * st, *cdf = kn + H.cap * st;
+#define AT(arr, k) arr[(k) * st]
   const double y0 = yv(a);
   int n = 1;
   AT(xs, 0) = a; AT(kn, 0) = a;
@@ -155,7 +93,7 @@ __device__ __forceinline__ bool tn_draw_lds(SeqRng &rng, double a, const TnSlot 
     const double hull = yv(xk) + -xk * (cand - xk);
     const double logu = hull - d_rexp(rng, 1.0);
     if (logu < target) { *out = cand; return true; }
-    if (n >= TN_LDS_CAP) return false;
+    if (n >= H.cap) return false;
     int pos = 0;
     {  // std::lower_bound(knots, knots + n, cand)
       int count = n;
@@ -181,28 +119,25 @@ __device__ __forceinline__ bool tn_draw_lds(SeqRng &rng, double a, const TnSlot 
   return false;
 }
 
-// trun_norm_mt(rng, a): a standard normal given x > a
-__device__ __forceinline__ double trun_norm_std(SeqRng &rng, double a, int *bad, TnSlot &S) {
-  if (a <= 0) {
+// trun_norm_mt(rng, a): a standard normal given x > a.  ARS false: the caller knows a <= 0
+// (the kernel's first phase); *overflow: the hull outgrew its slot.
+template <bool ARS>
+__device__ __forceinline__ double trun_norm_std(SeqRng &rng, double a, const TnHull &H, bool *overflow) {
+  if (!ARS || a <= 0) {
     for (;;) {
       const double x = d_norm_rand(rng);
       if (x > a) return x;
     }
   }
-  if (S.slot == -1) {
-    const int got = atomicAdd(S.taken, 1);
-    S.slot = got < TN_SLOTS ? got : -2;
-  }
-  if (S.slot >= 0) {
-    const SeqRng start = rng;
-    double z;
-    if (tn_draw_lds(rng, a, S, &z)) return z;
-    rng = start;
-  }
-  return tn_draw(rng, a, bad);
+  double z = a;
+  if (!tn_draw_lds(rng, a, H, &z)) *overflow = true;
+  return z;
 }
-__device__ __forceinline__ double rtrun_norm(SeqRng &rng, double mu, double a, bool gt, int *bad, TnSlot &S) {
-  return gt ? mu + trun_norm_std(rng, a - mu, bad, S) : mu - trun_norm_std(rng, mu - a, bad, S);   // (sigma = 1)
+template <bool ARS>
+__device__ __forceinline__ double rtrun_norm(SeqRng &rng, double mu, double a, bool gt, const TnHull &H,
+                                             bool *overflow) {
+  return gt ? mu + trun_norm_std<ARS>(rng, a - mu, H, overflow)
+            : mu - trun_norm_std<ARS>(rng, mu - a, H, overflow);   // (sigma = 1)
 }
 __device__ __forceinline__ double log_pnorm_std(double x, bool lower) {
   const double z = lower ? -x : x;
@@ -392,7 +327,43 @@ __device__ __forceinline__ int included_coefficients(const ProbitParams &P, int 
 
 }  // namespace
 
-// grid = (ceil(n / 256), chains), block = 256
+// One observation's latent sum (BinomialProbitDataImputer::impute, .cpp:30-73).  ARS false:
+// the caller has checked that no draw of this observation is on the far side of its mean.
+template <bool ARS>
+__device__ __forceinline__ double probit_impute_one(const ProbitParams &P, int chain, int i, double eta, long nt,
+                                                    long y, const TnHull &H, bool *overflow, bool *bad) {
+  SeqRng rng = SeqRng::slot(PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 8u},
+                            P.sweep * (uint64_t)P.n + (uint64_t)i, PROBIT_STRIDE, slot_serve(P, PROBIT_STRIDE));
+  double mean, variance, ans = 0.0;
+  if (y > P.clt_threshold) {
+    trun_norm_moments(eta, true, &mean, &variance);
+    ans += d_rnorm(rng, y * mean, sqrt(y * variance));
+  } else {
+    for (long t = 0; t < y && !*overflow; ++t) ans += rtrun_norm<ARS>(rng, eta, 0.0, true, H, overflow);
+  }
+  if (nt - y > P.clt_threshold) {
+    trun_norm_moments(eta, false, &mean, &variance);
+    ans += d_rnorm(rng, (nt - y) * mean, sqrt((nt - y) * variance));
+  } else {
+    for (long t = 0; t < nt - y && !*overflow; ++t) ans += rtrun_norm<ARS>(rng, eta, 0.0, false, H, overflow);
+  }
+  // (a draw that outruns its slot of the stream goes on in the slot's spill stream, device_rng.h)
+  if (rng.overran()) *bad = true;
+  return ans;
+}
+
+// grid = (ceil(n / 256), chains), block = 256.
+//
+// Three phases.  A truncated normal on the near side of its mean (the cut at or below it) is
+// a rejection loop over plain normals; on the far side -- an outcome the linear predictor
+// speaks against -- it is the adaptive-rejection sampler: a hull, exponentials, logarithms,
+// several candidates.  With one thread per observation every wavefront held a few of the
+// second kind and ran their whole loop at a fifth of its lanes.  So: (1) every thread takes
+// its observation if all its draws are of the first kind, and queues it otherwise; (2) the
+// workgroup's FIRST wavefront takes the queue, 64 observations at a time, each lane a hull of
+// 16 points in LDS (the other three wavefronts are done); (3) what outgrew 16 points -- rare --
+// is done again, four at a time, with hulls of 64 points.  An observation's draws read its own
+// slot of the chain's stream whichever thread makes them: the same numbers as before.
 __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   // Other workgroups of this chain may write the status word during this launch
@@ -403,42 +374,79 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   if (threadIdx.x == 0) s_status = __atomic_load_n(P.status + chain, __ATOMIC_RELAXED);
   __syncthreads();
   if (s_status != CHAIN_OK) return;
-  // the chain's included variables, once per workgroup
-  __shared__ int s_idx[PROBIT_KMAX];
-  __shared__ double s_beta[PROBIT_KMAX];
-  __shared__ double s_hull[3 * TN_LDS_CAP * TN_SLOTS];   // the adaptive-rejection hulls (tn_draw_lds)
-  __shared__ int s_taken;
-  if (threadIdx.x == 0) s_taken = 0;
+  // the chain's included variables, once per workgroup -- and, once every thread has its
+  // linear predictor, the same memory is the hulls
+  constexpr size_t COEF_BYTES = PROBIT_KMAX * (sizeof(int) + sizeof(double));
+  constexpr size_t HULL_BYTES = 3 * sizeof(double) * (TN_LDS_CAP * TN_SLOTS + TN_BIG_CAP * TN_BIG_SLOTS);
+  __shared__ __align__(16) unsigned char s_mem[COEF_BYTES > HULL_BYTES ? COEF_BYTES : HULL_BYTES];
+  __shared__ double s_eta[256];
+  __shared__ unsigned char s_queue[256], s_again[256];
+  __shared__ int s_nqueue, s_nagain;
+  double *s_beta = reinterpret_cast<double *>(s_mem);
+  int *s_idx = reinterpret_cast<int *>(s_mem + PROBIT_KMAX * sizeof(double));
+  double *s_hull = reinterpret_cast<double *>(s_mem);
+  double *s_big = s_hull + 3 * TN_LDS_CAP * TN_SLOTS;
+  if (threadIdx.x == 0) { s_nqueue = 0; s_nagain = 0; }
   const int k = included_coefficients(P, chain, s_idx, s_beta);
   if (k > PROBIT_KMAX) {
     if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
     return;
   }
-  if (i >= P.n) return;
-  TnSlot slot{s_hull, &s_taken, -1};
-  double eta = 0.0;
-  for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
-  const long nt = lround(P.ntrials[i]), y = lround(P.y[i]);
-  SeqRng rng = SeqRng::slot(PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 8u},
-                            P.sweep * (uint64_t)P.n + (uint64_t)i, PROBIT_STRIDE, slot_serve(P, PROBIT_STRIDE));
-  int bad = 0;
-  double mean, variance, ans = 0.0;
-  if (y > P.clt_threshold) {
-    trun_norm_moments(eta, true, &mean, &variance);
-    ans += d_rnorm(rng, y * mean, sqrt(y * variance));
-  } else {
-    for (long t = 0; t < y; ++t) ans += rtrun_norm(rng, eta, 0.0, true, &bad, slot);
+  const TnHull none{nullptr, 0, 0};
+  bool bad = false;
+  // ---- (1)
+  if (i < P.n) {
+    double eta = 0.0;
+    for (int m = 0; m < k; ++m) eta += P.X[(size_t)s_idx[m] * P.n + i] * s_beta[m];
+    const long nt = lround(P.ntrials[i]), y = lround(P.y[i]);
+    // a success is drawn above 0 around eta (the far side if eta < 0), a failure below
+    const bool far = (y > 0 && y <= P.clt_threshold && eta < 0.0) ||
+                     (nt - y > 0 && nt - y <= P.clt_threshold && eta > 0.0);
+    if (far) {
+      s_eta[threadIdx.x] = eta;
+      s_queue[atomicAdd(&s_nqueue, 1)] = (unsigned char)threadIdx.x;
+    } else {
+      bool overflow = false;
+      P.z[(size_t)chain * P.n + i] = probit_impute_one<false>(P, chain, i, eta, nt, y, none, &overflow, &bad);
+    }
   }
-  if (nt - y > P.clt_threshold) {
-    trun_norm_moments(eta, false, &mean, &variance);
-    ans += d_rnorm(rng, (nt - y) * mean, sqrt((nt - y) * variance));
-  } else {
-    for (long t = 0; t < nt - y; ++t) ans += rtrun_norm(rng, eta, 0.0, false, &bad, slot);
+  __syncthreads();   // (the coefficients are no longer needed: their memory becomes the hulls)
+  if (threadIdx.x >= 64) {
+    if (bad) P.status[chain] = CHAIN_RNG_BRANCH;
+    return;
   }
-  // (a draw that outran its hull is reported, never mishandled; one that outruns its
-  // slot of the stream goes on in the slot's spill stream, device_rng.h)
-  if (bad || rng.overran()) P.status[chain] = CHAIN_RNG_BRANCH;
-  P.z[(size_t)chain * P.n + i] = ans;
+  // ---- (2)
+  const int lane = (int)threadIdx.x, nqueue = s_nqueue;
+  const int first = (int)(blockIdx.x * blockDim.x);
+  for (int base = 0; base < nqueue; base += TN_SLOTS) {
+    const int t = base + lane;
+    if (t < nqueue) {
+      const int li = s_queue[t], ii = first + li;
+      const TnHull H{s_hull + lane, TN_SLOTS, TN_LDS_CAP};
+      bool overflow = false;
+      const double ans = probit_impute_one<true>(P, chain, ii, s_eta[li], lround(P.ntrials[ii]), lround(P.y[ii]), H,
+                                                 &overflow, &bad);
+      if (overflow) s_again[atomicAdd(&s_nagain, 1)] = (unsigned char)li;
+      else P.z[(size_t)chain * P.n + ii] = ans;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- (3)
+  const int nagain = __hip_atomic_load(&s_nagain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int base = 0; base < nagain; base += TN_BIG_SLOTS) {
+    const int t = base + lane;
+    if (lane < TN_BIG_SLOTS && t < nagain) {
+      const int li = s_again[t], ii = first + li;
+      const TnHull H{s_big + lane, TN_BIG_SLOTS, TN_BIG_CAP};
+      bool overflow = false;
+      const double ans = probit_impute_one<true>(P, chain, ii, s_eta[li], lround(P.ntrials[ii]), lround(P.y[ii]), H,
+                                                 &overflow, &bad);
+      if (overflow) bad = true;   // (a hull of more than 64 points: reported, never mishandled)
+      P.z[(size_t)chain * P.n + ii] = ans;
+    }
+  }
+  if (bad) P.status[chain] = CHAIN_RNG_BRANCH;
 }
 
 // BinomialLogitAuxmixSampler's imputation (BinomialLogitAuxmixSampler.cpp:77-97,
