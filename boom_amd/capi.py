@@ -585,7 +585,7 @@ class Engine:
         self._check(self.lib.ba_set_slot_limit(self._h, int(uniforms)))
 
     def ss_set_tuning(self, use_template_kernel=True, kernel=None):
-        """kernel: 0 general, 1 the default choice, 2 four chains per wavefront (m <= 16),
+        """kernel: 0 general, 1 the default choice,
         3 compiled for the shape (where it applies); 4 / 5: the local-level rounds as separate
         launches / as the persistent round kernel (the default)"""
         if kernel is None:

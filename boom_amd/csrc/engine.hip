@@ -391,7 +391,7 @@ struct ba_engine {
   // the template of ba_ss_set_structural (level / slope / seasonal -> variance index, -1: none)
   int ssg_template_var[3] = {-1, -1, -1};
   int ssg_template_ar = -1;        // ... and the block ba_ss_add_ar appended
-  int ssg_kernel_choice = 1;       // (ba_ss_set_tuning: 0 general, 1 the default choice, 2 packed, 3 shape-specialised)
+  int ssg_kernel_choice = 1;       // (ba_ss_set_tuning: 0 general, 1 the default choice, 3 shape-specialised)
   // the local-level rounds of a call as one persistent launch (ss_round_kernel.hip); the
   // tile words of its X'e step, zeroed before every launch; how many chains' workgroups the
   // device holds at once, by launch capacity (0: not asked yet, < 0: the kernel does not fit)
@@ -1014,7 +1014,7 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
     S.ssm.nerr = e->ssg.nerr;
     if (e->ssg_kernel_choice == 1 || e->ssg_kernel_choice == 3)
       ssg_template_shape(e->ssg, &S.ssm.tpl_trend, &S.ssm.tpl_nseasons, &S.ssm.tpl_ar_lags);
-    S.ssm.packed = (e->ssg_kernel_choice == 2 && e->ssg.m <= 16) ? 1 : 0;
+    S.ssm.reserved0 = 0;
     S.ssm.var_sigsq = e->dssm_sigsq.ptr;
     S.ssm.var_n = e->dssm_n.ptr;
     S.ssm.var_ss = e->dssm_ss.ptr;
@@ -3860,7 +3860,8 @@ int ba_set_slot_limit(ba_engine *e, int32_t uniforms) {
 // applies (the two are compared by the tests), 1 = the default
 int ba_ss_set_tuning(ba_engine *e, int32_t kernel) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  if (kernel < 0 || kernel > 5) return fail(BA_E_INVALID, "kernel must be 0 .. 5");
+  if (kernel < 0 || kernel > 5 || kernel == 2)
+    return fail(BA_E_INVALID, "kernel must be 0, 1, 3, 4 or 5 (2, four chains per wavefront, was removed: it never won)");
   MUTATE(e);
   // 4 / 5: the local-level rounds as the separate launches of rounds 1-4 / as the round
   // kernel (the default where it applies); the structural kernels' choice stays

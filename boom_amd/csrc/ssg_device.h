@@ -1,6 +1,5 @@
-// Device helpers shared by the structural state-space kernels (ssm_kernel.hip: one chain per
-// workgroup, any state dimension <= 64; ssm_packed_kernel.hip: four chains per wavefront,
-// state dimension <= 16): cross-lane moves, the ArPosteriorSampler, the block list and the
+// Device helpers of the general structural state-space kernel (ssm_kernel.hip: one chain per
+// workgroup, any state dimension <= 64): cross-lane moves, the ArPosteriorSampler, the block list and the
 // transition's action on lane-distributed vectors.  See ssm_kernel.hip for the model.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -915,7 +915,6 @@ size_t ssm_dynamic_lds(const SsmParams &M) {
 }
 
 hipError_t launch_ssm_template(hipStream_t stream, const SsParams &P, int draw_variances);
-hipError_t launch_ssm_packed(hipStream_t stream, const SsParams &P, int draw_variances);
 
 hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_variances) {
   const dim3 grid(P.chain_count), block(2 * WAVE);
@@ -923,10 +922,7 @@ hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_
   hipError_t err;
   {
     KtScope kt(stream, KT_SSM);
-    if (P.ssm.packed) {
-      err = launch_ssm_packed(stream, P, draw_variances);
-      if (err != hipSuccess) return err;
-    } else if (P.ssm.tpl_trend > 0) {
+    if (P.ssm.tpl_trend > 0) {
       err = launch_ssm_template(stream, P, draw_variances);
       if (err != hipSuccess) return err;
     } else if (P.ssm.m <= 16) {

@@ -468,8 +468,8 @@ int ba_ss_add_state_model(ba_engine *e, int32_t kind, const int32_t *iparams,
                           const double *initial_state_mean,
                           const double *initial_state_variance);
 /* which kernel draws the state (changes no draw): 0 = the general kernel, one chain per
- * workgroup; 2 = four chains per wavefront (state dimension <= 16; the general kernel
- * beyond); 3 = the kernel compiled for the shape [level | trend] [+ seasonal of duration 1]
+ * workgroup; (2, four chains per wavefront, was removed in round 5: bit-identical and never
+ * faster -- BA_E_INVALID now); 3 = the kernel compiled for the shape [level | trend] [+ seasonal of duration 1]
  * [+ one autoregression] with m <= 16 where the list has that shape; 1 = the default choice.
  * Independently of those: 4 = the local-level model's rounds as separate launches per round
  * (regression sweep, state draw, X'e), 5 = as one persistent launch per call in which every

@@ -189,41 +189,6 @@ def test_general_kernel_equals_the_shape_specialised_one(desc, T):
                 assert relerr(mu["suf_ss"], mv["suf_ss"], 1e-300) < 1e-9, (s, c, k)
 
 
-@pytest.mark.parametrize("desc,T,chains", [
-    ([("level",)], 130, 6), ([("trend",), ("seasonal", 12, 1)], 300, 9),
-    ([("level",), ("seasonal", 7, 1), ("ar", 2)], 97, 4), ([("trend",), ("ar", 3)], 33, 7),
-    ([("seasonal", 4, 3, 2), ("trend",), ("seasonal", 3, 5), ("ar", 2), ("ar", 1)], 140, 5),
-    ([("seasonal", 16, 2)], 70, 1), ([("level",), ("level",), ("trend",), ("ar", 1), ("seasonal", 2, 1),
-                                      ("seasonal", 3, 4), ("ar", 2), ("level",)], 64, 10)])
-def test_four_chains_per_wavefront_equals_the_general_kernel(desc, T, chains):
-    """m <= 16: ssm_packed_kernel.hip runs four chains in the four rows of a wavefront
-    (ba_ss_set_tuning(2)).  Per chain the same arithmetic in the same order as the general
-    kernel: every draw identical, also where the chain count is no multiple of four and a
-    variance is exactly 0"""
-    p, seed = 5, 21
-    seas = [(b[1], b[2]) for b in desc if b[0] == "seasonal"]
-    X, y, _, obs = general_data(T, p, 2, seas, seed=T, missing_frac=0.04,
-                                ar_coef=[0.5] if any(b[0] == "ar" for b in desc) else None)
-    prior, _, sig_up = bsts_priors(X, y, 2)
-    blocks = general_spec(y, desc)
-    g0 = np.zeros(p, np.uint8)
-    a = make_engine(chains, seed, y, X, obs, prior, blocks, sig_up, g0)
-    b = make_engine(chains, seed, y, X, obs, prior, blocks, sig_up, g0)
-    a.ss_set_tuning(kernel=0)
-    b.ss_set_tuning(kernel=2)
-    for s in range(7):
-        a.ss_sweep(1)
-        b.ss_sweep(1)
-        for u, v in zip(a.get_states(), b.get_states()):
-            assert np.array_equal(u, v), s
-        for c in range(chains):
-            assert np.array_equal(a.ss_get_state_draw(c), b.ss_get_state_draw(c)), (s, c)
-            for k in range(len(blocks)):
-                mu, mv = a.ss_get_state_model(c, k), b.ss_get_state_model(c, k)
-                for key in mu:
-                    assert np.array_equal(mu[key], mv[key]), (s, c, k, key)
-
-
 @pytest.mark.parametrize("key", ["a", "b", "c"])
 def test_general_forecast_matches_oracle(oracle, key):
     """simulate_forecast with seasonal blocks of duration > 1 (the reference simulates
