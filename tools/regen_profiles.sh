@@ -30,7 +30,7 @@ profile() {   # name, pmc (yes|no), kernel substrings for the summary, then the 
       local pn=$1; shift
       rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_$pn -o pmc -- python3 "${CMD[@]}" > $out/pmc_$pn.out 2> $out/pmc_$pn.err
     }
-    CMD=("$@" $PMC_EXTRA)   # (PMC_EXTRA: flags for the counter passes only)
+    CMD=("$@" ${PMC_EXTRA:-})   # (PMC_EXTRA: flags for the counter passes only)
     pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES
     pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
     pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS
