@@ -806,6 +806,9 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   long long bt0 = (long long)__builtin_readcyclecounter();
 #endif
   for (;;) {
+#ifdef BA_BSTAMPS
+    const int bphase_at_entry = phase;
+#endif
     if (wave == 0) {
       int cmd = BCMD_NONE;
       while (cmd == BCMD_NONE) {
@@ -1209,6 +1212,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
 #ifdef BA_BSTAMPS
     const long long bt1 = (long long)__builtin_readcyclecounter();
     bph[0] += (double)(bt1 - bt0);
+    if (wave == 0 && lane == 0) atomicAdd(&g_bstamp[8 + (bphase_at_entry & 7)], (unsigned long long)(bt1 - bt0));
 #endif
     __syncthreads();
     const int cmd = (int)ctl[CT_CMD];
@@ -1359,6 +1363,9 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     if (blockIdx.x == 0)
       printf("build stamps (cycles, all chains so far): head/none %llu solve %llu update %llu chol_tile %llu store %llu fence %llu inverses %llu rhs+w %llu\n",
              g_bstamp[0], g_bstamp[1], g_bstamp[2], g_bstamp[3], g_bstamp[4], g_bstamp[5], g_bstamp[6], g_bstamp[7]);
+    if (blockIdx.x == 0)
+      printf("master stamps by phase at entry (cycles, all chains so far): INIT %llu BEGIN %llu SHUFFLED %llu FLIPS %llu SWAP %llu TAIL %llu ADA %llu\n",
+             g_bstamp[8], g_bstamp[9], g_bstamp[10], g_bstamp[11], g_bstamp[12], g_bstamp[13], g_bstamp[14]);
     if (!adaptive)
       for (int i = 0; i < 8; ++i) a[ACC_PHASE0 + i] += bph[i];   // master | EVAL | UNIF | BUILD cycles, then their counts (exit, EVAL, UNIF, BUILD)
 #endif
