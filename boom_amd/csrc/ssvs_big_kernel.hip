@@ -247,6 +247,12 @@ __device__ __forceinline__ void rebuild_g(Chain &ch, int kcap) {
 // A real function (not inlined at its call sites): it is the rare path and its
 // unrolled solves are large.
 #ifdef BA_BSTAMPS
+__device__ unsigned long long g_mstamp[16];
+#define MST(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_mstamp[i], (unsigned long long)(t_ - mst_)); mst_ = t_; } while (0)
+#else
+#define MST(i) do { } while (0)
+#endif
+#ifdef BA_BSTAMPS
 __device__ unsigned long long g_bstamp[16];
 #define BST(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_bstamp[i], (unsigned long long)(t_ - bst_)); bst_ = t_; } while (0)
 #else
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   for (;;) {
 #ifdef BA_BSTAMPS
     const int bphase_at_entry = phase;
+    long long mst_ = (long long)__builtin_readcyclecounter();
 #endif
     if (wave == 0) {
       int cmd = BCMD_NONE;
@@ -880,6 +887,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
             }
             wave_sync();
           } else if (p > 1) parallel_shuffle(ch, sx);
+          MST(0);
           flip_pos = pos + (uint64_t)(P.mode == 2 ? p : (p > 0 ? p - 1 : 0));
           pos = flip_pos + (uint64_t)nflips;
           i0 = 0;
@@ -929,7 +937,9 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
             break;
           }
           DecideResult dr;
+          MST(1);
           decide_walk(ch, key, flip_pos, i0, nflips, dr);
+          MST(2);
           BACC_MIN(dr.margin);
           if (dr.spos < 0) {
             BACC_ADD(ACC_PROPOSALS, nflips - i0);
@@ -1078,6 +1088,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
           break;
         }
         if (phase == PH_SWAP) {
+          MST(3);
           // ---- attempt_swap (BregVsSampler.cpp:277-310)
           phase = PH_TAIL;
           rng.set_pos(pos);
@@ -1095,6 +1106,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
           }
           continue;
         }
+        MST(4);
         // ---- PH_TAIL: draw_sigma (BregVsSampler.cpp:313-324)
         const int k = ch.k;
         rng.set_pos(pos);
@@ -1106,6 +1118,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
           if (bad) { status = CHAIN_RNG_BRANCH; continue; }
         }
         pos = uni(rng.get_pos());
+        MST(5);
         // ---- draw_beta (BregVsSampler.cpp:326-351): beta = L^{-T}(w + sigma z)
         if (P.draw_beta && k > 0) {
           if (!M.pd) { ++failures; status = CHAIN_NOT_PD; continue; }
@@ -1165,6 +1178,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         } else if (P.draw_beta) {
           beta_valid = true;
         }
+        MST(6);
         // ---- summaries, traces, the draw record
         kmax = k > kmax ? k : kmax;
         for (int m = lane; m < k; m += WAVE) {
@@ -1206,7 +1220,9 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         ++iteration;
         rates_saved = false;
         phase = PH_BEGIN;
+        MST(7);
       }
+      MST(8);
       if (lane == 0) ctl[CT_CMD] = (double)cmd;
     }
 #ifdef BA_BSTAMPS
@@ -1363,6 +1379,9 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
     if (blockIdx.x == 0)
       printf("build stamps (cycles, all chains so far): head/none %llu solve %llu update %llu chol_tile %llu store %llu fence %llu inverses %llu rhs+w %llu\n",
              g_bstamp[0], g_bstamp[1], g_bstamp[2], g_bstamp[3], g_bstamp[4], g_bstamp[5], g_bstamp[6], g_bstamp[7]);
+    if (blockIdx.x == 0)
+      printf("master stamps (cycles, all chains so far): shuffle %llu before-walk %llu walk %llu before-swap %llu swap %llu sigma %llu beta %llu summaries %llu other %llu\n",
+             g_mstamp[0], g_mstamp[1], g_mstamp[2], g_mstamp[3], g_mstamp[4], g_mstamp[5], g_mstamp[6], g_mstamp[7], g_mstamp[8]);
     if (blockIdx.x == 0)
       printf("master stamps by phase at entry (cycles, all chains so far): INIT %llu BEGIN %llu SHUFFLED %llu FLIPS %llu SWAP %llu TAIL %llu ADA %llu\n",
              g_bstamp[8], g_bstamp[9], g_bstamp[10], g_bstamp[11], g_bstamp[12], g_bstamp[13], g_bstamp[14]);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: where ssvs_big_kernel's master wavefront spends its cycles, by command
+(and, printed by the kernel itself: the build's phases and the master's own sections)
 (-DBA_BSTAMPS build: make -C boom_amd/csrc ../../tools/build/libboomamd_bstamps.so).
 usage: big_phases.py [signals [chains]]"""
 import os, sys, time
