@@ -166,6 +166,25 @@ def families():
         e.set_state(g0)
         return e
     fam["BregVsSampler sweeps"] = (reg, lambda e, s: e.sweep(40, sync=s), None)
+    # models of 33 .. 128 variables: the table fills on the matrix cores (ssvs_fill_mfma.h) read
+    # the model block another wavefront published -- at capacity 48 / 64 in the LDS kernel,
+    # and in the large-model kernel
+    for nm, nsig in [("BregVsSampler, 40 signals", 40), ("BregVsSampler, 70 signals", 70)]:
+        Xd, yd, _ = regression_data(3000, 200, nsig, seed=40 + nsig)
+
+        def dense(Xd=Xd, yd=yd, nsig=nsig):
+            e = boom_amd.Engine(128, seed=9)
+            e.build_suf_from_xy(Xd, yd)
+            s = e.get_suf()
+            suf = dict(xtx=s["xtx"], xty=s["xty"], yty=s["yty"], n=s["n"], sumy=s["ybar"] * s["n"], xsum=s["xbar"] * s["n"])
+            pr = spike_slab_prior(suf, nsig)
+            e.set_priors(pr["b"], pr["ominv"], pr["pi"], pr["df"], pr["sigma_guess"])
+            g0 = np.zeros(200, np.uint8)
+            g0[0] = 1
+            e.set_state(g0)
+            e.sweep(60)   # (past the growth through the capacities)
+            return e
+        fam[nm] = (dense, lambda e, s: e.sweep(15, sync=s), None)
     fam["adaptive sampler"] = (reg, lambda e, s: e.adaptive_sweep(20, sync=s), None)
     for kind, data in [("probit", probit_data), ("logit", logit_data)]:
         Xl, yl, nt, _ = data(3000, 40, 4, seed=6)

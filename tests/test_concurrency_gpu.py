@@ -46,8 +46,8 @@ def _family(name):
 
 @pytest.mark.parametrize("name", ["bsts local level", "structural template trend+12", "structural template +ar(2)",
                                   "structural general 4x3 + ar", "structural general m=27",
-                                  "BregVsSampler sweeps", "adaptive sampler", "probit spike-and-slab",
-                                  "logit spike-and-slab"])
+                                  "BregVsSampler sweeps", "BregVsSampler, 40 signals", "BregVsSampler, 70 signals",
+                                  "adaptive sampler", "probit spike-and-slab", "logit spike-and-slab"])
 def test_same_draws_alone_and_beside_a_busy_engine(busy_engine, name):
     make, step, extra = _family(name)
     assert alone_vs_loaded(make, step, extra, steps=4, noise=busy_engine) == 0
