@@ -3709,7 +3709,9 @@ int ba_ss_set_local_level(ba_engine *e, double level_df, double level_sigma_gues
 namespace {
 // the scalars of the specification that follow from the block list
 void ssg_finish(SsgSpec &q) {
-  q.ld = q.m | 1;
+  // P's leading dimension: odd (a lane per column and a lane per row both conflict-free), and
+  // one of the four values ssg_simsmooth_kernel is compiled for
+  q.ld = q.m <= 16 ? 17 : (q.m <= 32 ? 33 : (q.m <= 60 ? 61 : 65));
   q.nerr = q.nvar;
   // steps per block of the passes: the most that leaves FOUR workgroups to a CU's 160 KB of
   // LDS (all 1024 chains of a launch resident; at m = 59 sixteen steps left room for three,

@@ -74,7 +74,10 @@ __host__ __device__ inline int ssg_pass_lds_doubles(int m, int ld, int bl, int n
 
 // grid = chains, block = 128, dynamic LDS = max(the normals generator's lists, the
 // sampler's matrices, ssg_pass_lds_doubles).  SMALL: m <= 16.
-template <bool SMALL>
+// LDC: the leading dimension of P as a compile-time constant (17 / 33 / 61 / 65, chosen from
+// the state dimension by ssg_finish): an entry's LDS address is then an immediate offset from
+// the lane's column or row, where a run-time ld cost an address computation per entry.
+template <bool SMALL, int LDC>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void ssg_simsmooth_kernel(SsParams P, int draw_variances) {
   constexpr int SSG_BATCH = SMALL ? 1 : 8;   // entries of a column / row of P asked of the LDS together
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   if (P.only_ran && P.only_ran[chain] == 0) return;
   const SsmParams &M = P.ssm;
   const SsgSpec &Q = *M.spec;
-  const int T = P.T, p = P.p, m = M.m, nb = M.nblocks, ld = M.ld, BL = M.bl, NE = M.nerr;
+  const int T = P.T, p = P.p, m = M.m, nb = M.nblocks, BL = M.bl, NE = M.nerr;
+  constexpr int ld = LDC;   // (== M.ld: launch_ssm_simsmooth picks the instance by it)
   NormalsLds &s_norm = *reinterpret_cast<NormalsLds *>(s_raw);
   ArLds &s_ar = *reinterpret_cast<ArLds *>(s_raw);
   double *s_blk0 = reinterpret_cast<double *>(s_raw);
@@ -374,8 +378,29 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
               // (eight entries of the column in flight at a time: a rolled walk waited for
               // one LDS round trip per entry -- 51 of them a step in bsts's daily model)
               double cs = 0.0;
+              int i0 = 0;
+              if (!SMALL) {
+                // whole batches: no guards, the addresses immediates off the column's start
 #pragma nounroll
-              for (int i0 = 0; i0 < n; i0 += SSG_BATCH) {
+                for (; i0 + SSG_BATCH <= n; i0 += SSG_BATCH) {
+                  double *c0 = col + i0 * ld;
+                  const double *t0 = s_tv + f + i0;
+                  double v[SSG_BATCH], tv[SSG_BATCH];
+#pragma unroll
+                  for (int u = 0; u < SSG_BATCH; ++u) { v[u] = c0[u * ld]; tv[u] = t0[u]; }
+                  if (obs) {
+#pragma unroll
+                    for (int u = 0; u < SSG_BATCH; ++u) {
+                      v[u] -= (tv[u] * PZ) * Finv;
+                      c0[u * ld] = v[u];
+                    }
+                  }
+#pragma unroll
+                  for (int u = 0; u < SSG_BATCH; ++u) cs -= v[u];
+                }
+              }
+#pragma nounroll
+              for (; i0 < n; i0 += SSG_BATCH) {
                 const int nn = n - i0;
                 double v[SSG_BATCH], tv[SSG_BATCH];
 #pragma unroll
@@ -446,8 +471,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           } else if (kd == SSG_SEASONAL) {
             const int w = sprev((int)(B.urc(b) >> 16), n);
             double cs = 0.0;
+            int j0 = 0;
+            if (!SMALL) {
 #pragma nounroll
-            for (int j0 = 0; j0 < n; j0 += SSG_BATCH) {
+              for (; j0 + SSG_BATCH <= n; j0 += SSG_BATCH) {
+                double v[SSG_BATCH];
+#pragma unroll
+                for (int u = 0; u < SSG_BATCH; ++u) v[u] = row[j0 + u];
+#pragma unroll
+                for (int u = 0; u < SSG_BATCH; ++u) cs -= v[u];
+              }
+            }
+#pragma nounroll
+            for (; j0 < n; j0 += SSG_BATCH) {
               const int nn = n - j0;
               double v[SSG_BATCH];
 #pragma unroll
@@ -925,16 +961,24 @@ hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_
     if (P.ssm.tpl_trend > 0) {
       err = launch_ssm_template(stream, P, draw_variances);
       if (err != hipSuccess) return err;
-    } else if (P.ssm.m <= 16) {
-      hipLaunchKernelGGL((ssg_simsmooth_kernel<true>), grid, block, lds, stream, P, draw_variances);
     } else {
       // (more than 64 KB of dynamic LDS has to be asked for -- per device, so every time)
-      if (lds > 65536) {
-        err = hipFuncSetAttribute((const void *)ssg_simsmooth_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return err;
+      auto go = [&](auto kernel) -> hipError_t {
+        if (lds > 65536) {
+          const hipError_t e2 = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e2 != hipSuccess) return e2;
+        }
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, P, draw_variances);
+        return hipSuccess;
+      };
+      switch (P.ssm.ld) {   // ssg_leading_dimension(m)
+        case 17: err = go(ssg_simsmooth_kernel<true, 17>); break;
+        case 33: err = go(ssg_simsmooth_kernel<false, 33>); break;
+        case 61: err = go(ssg_simsmooth_kernel<false, 61>); break;
+        case 65: err = go(ssg_simsmooth_kernel<false, 65>); break;
+        default: return hipErrorInvalidValue;
       }
-      hipLaunchKernelGGL((ssg_simsmooth_kernel<false>), grid, block, lds, stream, P, draw_variances);
+      if (err != hipSuccess) return err;
     }
     err = hipGetLastError();
   }
