@@ -79,7 +79,7 @@ __host__ __device__ inline int ssg_pass_lds_doubles(int m, int ld, int bl, int n
 // the lane's column or row, where a run-time ld cost an address computation per entry.
 template <bool SMALL, int LDC>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void ssg_simsmooth_kernel(SsParams P, int draw_variances) {
-  constexpr int SSG_BATCH = SMALL ? 1 : 8;   // entries of a column / row of P asked of the LDS together
+  constexpr int SSG_BATCH = SMALL ? 4 : 8;   // entries of a column / row of P asked of the LDS together
   extern __shared__ __align__(16) unsigned char s_raw[];
   __shared__ int s_flag;
   __shared__ int s_vprog;            // blocks the variance pass has put out (wave 1 -> wave 0)
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
               // one LDS round trip per entry -- 51 of them a step in bsts's daily model)
               double cs = 0.0;
               int i0 = 0;
-              if (!SMALL) {
+              {
                 // whole batches: no guards, the addresses immediates off the column's start
 #pragma nounroll
                 for (; i0 + SSG_BATCH <= n; i0 += SSG_BATCH) {
@@ -400,25 +400,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
                 }
               }
 #pragma nounroll
-              for (; i0 < n; i0 += SSG_BATCH) {
-                const int nn = n - i0;
-                double v[SSG_BATCH], tv[SSG_BATCH];
-#pragma unroll
-                for (int u = 0; u < SSG_BATCH; ++u) {
-                  const int i = i0 + (u < nn ? u : nn - 1);
-                  v[u] = col[i * ld];
-                  tv[u] = s_tv[f + i];
+              for (; i0 < n; ++i0) {   // (what is left of the block, one by one)
+                double v = col[i0 * ld];
+                if (obs) {
+                  v -= (s_tv[f + i0] * PZ) * Finv;
+                  col[i0 * ld] = v;
                 }
-#pragma unroll
-                for (int u = 0; u < SSG_BATCH; ++u) {
-                  if (u < nn) {
-                    if (obs) {
-                      v[u] -= (tv[u] * PZ) * Finv;
-                      col[(i0 + u) * ld] = v[u];
-                    }
-                    cs -= v[u];
-                  }
-                }
+                cs -= v;
               }
               // the row of the component that drops out becomes that of the new first
               // component, -(sum over the block)
@@ -472,7 +460,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
             const int w = sprev((int)(B.urc(b) >> 16), n);
             double cs = 0.0;
             int j0 = 0;
-            if (!SMALL) {
+            {
 #pragma nounroll
               for (; j0 + SSG_BATCH <= n; j0 += SSG_BATCH) {
                 double v[SSG_BATCH];
@@ -483,15 +471,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
               }
             }
 #pragma nounroll
-            for (; j0 < n; j0 += SSG_BATCH) {
-              const int nn = n - j0;
-              double v[SSG_BATCH];
-#pragma unroll
-              for (int u = 0; u < SSG_BATCH; ++u) v[u] = row[j0 + (u < nn ? u : nn - 1)];
-#pragma unroll
-              for (int u = 0; u < SSG_BATCH; ++u)
-                if (u < nn) cs -= v[u];
-            }
+            for (; j0 < n; ++j0) cs -= row[j0];
             row[w] = cs + (lane == f + w ? sg : 0.0);
           } else {
             const double *ph = s_phi + Blocks::arx_of(d) * AR_MAX;
