@@ -388,6 +388,13 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
         wave_sync();
         BST(3);
         if (!ok) break;
+        // what the table fills on the matrix cores multiply by (ssvs_fill_mfma.h): the
+        // inverses of this tile's 16 x 16 diagonal blocks, from the tile while it is in LDS
+        if (k <= MF_ROWS * MF_MAX_BLOCK_ROWS) {
+          const int nI_all = mf_block_rows(k), nI_here = (nI_all - 4 * I < 4) ? nI_all - 4 * I : 4;
+          if (nI_here > 0)
+            diag_inverses(bx.tile, bx.rdt, dst + (s ? S.ia : S.iv) + (size_t)(4 * I) * (MF_ROWS * MF_ROWS), kk, nI_here, lane);
+        }
         // rows of this tile row go to the factor: parked off-diagonal part, the tile, rd
         if (row < kpad8) {
           for (int m0 = 0; m0 < I * 64; m0 += 8) {   // (eight at a time: a rolled copy waited for every load)
@@ -418,12 +425,6 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
     return;
   }
   BST(5);
-  // what the table fills on the matrix cores multiply by (ssvs_fill_mfma.h)
-  if (!REUSE && k <= MF_ROWS * MF_MAX_BLOCK_ROWS) {
-    diag_inverses(dst + S.Lv, dst + S.rdv, dst + S.iv, k, lane);
-    if (oka) diag_inverses(dst + S.La, dst + S.rda, dst + S.ia, k, lane);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-  }
   BST(6);
   // r = A_g b_g + xty_g, c = b_g' A_g b_g (only non-zero prior means cost)
   double cpart = 0.0;

@@ -509,9 +509,8 @@ __device__ __forceinline__ void publish_model(Chain &ch, const Model &M) {
   if constexpr (NB >= MF_MIN_NB) {
     // what the table fills on the matrix cores multiply by (ssvs_fill_mfma.h); the fence
     // also drops the CU's cached lines of the block's previous contents, for both waves
-    __builtin_amdgcn_s_waitcnt(0);
-    diag_inverses(dst + S.Lv, dst + S.rdv, dst + S.iv, k, lane);
-    diag_inverses(dst + S.La, dst + S.rda, dst + S.ia, k, lane);
+    diag_inverses(ch.Lv, ch.rdv, dst + S.iv, k, mf_block_rows(k), lane);
+    diag_inverses(ch.La, ch.rda, dst + S.ia, k, mf_block_rows(k), lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   }
   unsigned long long u = (unsigned long long)dst;

@@ -45,12 +45,15 @@ __host__ __device__ inline int mf_block_rows(int k) {
 // doubles of a model block's inverse diagonal blocks, per factor
 __host__ __device__ inline int mf_inv_doubles(int kcap) { return (kcap / MF_ROWS) * MF_ROWS * MF_ROWS; }
 
-// inv(L_II) for the block rows mf_block_rows(k) covers, row-major 16 x 16 at inv + 256 I.
-// One wavefront; the factor (block packed, rows < (k + 7) & ~7 written) and its reciprocal
-// diagonal are read from where the build left them.  Rows >= k give zero rows.
-__device__ __noinline__ void diag_inverses(const double *Lst, const double *rdst, double *inv, int k,
-                                           int lane) {
-  const int kpad8 = (k + 7) & ~7, nI = mf_block_rows(k);
+// inv(L_II) for nI block rows of 16, row-major 16 x 16 at inv + 256 I.  One wavefront.  L:
+// the factor, block packed (rows < (krows + 7) & ~7 written), rd its reciprocal diagonal --
+// read from LDS where the factorisation has just left them (the sweep kernel's factors, the
+// large-model kernel's 64 x 64 tile: `L` and `rd` are then tile-local), since reading them
+// back from the model block cost a dozen dependent trips to memory per build.  Rows >= krows
+// give zero rows.
+template <class LP, class RP>
+__device__ __forceinline__ void diag_inverses(LP L, RP rd, double *inv, int krows, int nI, int lane) {
+  const int kpad8 = (krows + 7) & ~7;
   const int b = lane >> 4, c = lane & 15;
   for (int I0 = 0; I0 < nI; I0 += 4) {
     const int I = I0 + b;
@@ -62,12 +65,12 @@ __device__ __noinline__ void diag_inverses(const double *Lst, const double *rdst
         double acc = 0.0;
 #pragma unroll
         for (int s = 0; s < r; ++s) {
-          const double l = Lst[bidx(R, MF_ROWS * I + s)];
+          const double l = L[bidx(R, MF_ROWS * I + s)];
           acc += ((R < kpad8) ? l : 0.0) * x[s];
         }
-        const double rdr = rdst[R];
-        const double rd = (R < k) ? rdr : 0.0;
-        x[r] = (r == c) ? rd : ((r < c) ? 0.0 : -acc * rd);
+        const double rdr = rd[R];
+        const double rdv = (R < krows) ? rdr : 0.0;
+        x[r] = (r == c) ? rdv : ((r < c) ? 0.0 : -acc * rdv);
       }
 #pragma unroll
       for (int r = 0; r < MF_ROWS; ++r) inv[I * (MF_ROWS * MF_ROWS) + r * MF_ROWS + c] = x[r];
