@@ -133,14 +133,16 @@ __device__ __forceinline__ void chol_tile(lds_f64 *T, lds_f64 *rdt, int kk, int 
     const int offj = (jb * (jb + 1) / 2) * 64 + (j & 7) * 8;
     double s = T[bidx(ii, j)];
     for (int nb = 0; nb < jb; ++nb) {
-      double a[8], b[8];
+      // (a block's row is 64 bytes, 16-byte aligned: four 16-byte reads each for the lane's
+      // row and for row j, where eight 8-byte ones were two thirds of the loop's instructions)
+      typedef double d2_t __attribute__((ext_vector_type(2)));
+      const AS_LDS d2_t *pa = (const AS_LDS d2_t *)(T + offi + nb * 64);
+      const AS_LDS d2_t *pb = (const AS_LDS d2_t *)(T + offj + nb * 64);
+      d2_t a[4], b[4];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        a[t] = T[offi + nb * 64 + t];
-        b[t] = T[offj + nb * 64 + t];
-      }
+      for (int t = 0; t < 4; ++t) { a[t] = pa[t]; b[t] = pb[t]; }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) s -= a[t] * b[t];
+      for (int t = 0; t < 4; ++t) { s -= a[t].x * b[t].x; s -= a[t].y * b[t].y; }
     }
     {
       const int rem = j & 7;
