@@ -354,16 +354,18 @@ __device__ __forceinline__ double probit_impute_one(const ProbitParams &P, int c
 
 // grid = (ceil(n / 256), chains), block = 256.
 //
-// Three phases.  A truncated normal on the near side of its mean (the cut at or below it) is
-// a rejection loop over plain normals; on the far side -- an outcome the linear predictor
+// Phases.  A truncated normal on the near side of its mean (the cut at or below it) is a
+// rejection loop over plain normals; on the far side -- an outcome the linear predictor
 // speaks against -- it is the adaptive-rejection sampler: a hull, exponentials, logarithms,
-// several candidates.  With one thread per observation every wavefront held a few of the
-// second kind and ran their whole loop at a fifth of its lanes.  So: (1) every thread takes
-// its observation if all its draws are of the first kind, and queues it otherwise; (2) the
-// workgroup's FIRST wavefront takes the queue, 64 observations at a time, each lane a hull of
-// 16 points in LDS (the other three wavefronts are done); (3) what outgrew 16 points -- rare --
-// is done again, four at a time, with hulls of 64 points.  An observation's draws read its own
-// slot of the chain's stream whichever thread makes them: the same numbers as before.
+// several candidates.  With one thread per observation every wavefront ran both loops to the
+// depth of its unluckiest lane.  So: (1) every thread computes its linear predictor and, for
+// a one-trial observation on the near side, tries the FIRST candidate by Kinderman-Ramage's
+// first branch -- straight-line code, two thirds of all observations end there --; what is
+// left is queued: (1b) near-side observations, done from their first draw by the first three
+// wavefronts, 64 to a chunk; (2) far-side observations by the fourth wavefront, each lane a
+// hull of 16 points in LDS; (3) what outgrew 16 points -- rare -- again, four at a time,
+// with hulls of 64 points.  An observation's draws read its own slot of the chain's stream
+// whichever thread makes them, from its first position: the same numbers as before.
 __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   const int chain = (int)blockIdx.y, i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   // Other workgroups of this chain may write the status word during this launch
@@ -380,13 +382,13 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
   constexpr size_t HULL_BYTES = 3 * sizeof(double) * (TN_LDS_CAP * TN_SLOTS + TN_BIG_CAP * TN_BIG_SLOTS);
   __shared__ __align__(16) unsigned char s_mem[COEF_BYTES > HULL_BYTES ? COEF_BYTES : HULL_BYTES];
   __shared__ double s_eta[256];
-  __shared__ unsigned char s_queue[256], s_again[256];
-  __shared__ int s_nqueue, s_nagain;
+  __shared__ unsigned char s_queue[256], s_near[256], s_again[256];
+  __shared__ int s_nqueue, s_nnear, s_nagain;
   double *s_beta = reinterpret_cast<double *>(s_mem);
   int *s_idx = reinterpret_cast<int *>(s_mem + PROBIT_KMAX * sizeof(double));
   double *s_hull = reinterpret_cast<double *>(s_mem);
   double *s_big = s_hull + 3 * TN_LDS_CAP * TN_SLOTS;
-  if (threadIdx.x == 0) { s_nqueue = 0; s_nagain = 0; }
+  if (threadIdx.x == 0) { s_nqueue = 0; s_nnear = 0; s_nagain = 0; }
   const int k = included_coefficients(P, chain, s_idx, s_beta);
   if (k > PROBIT_KMAX) {
     if (threadIdx.x == 0 && blockIdx.x == 0) P.status[chain] = CHAIN_MODEL_TOO_LARGE;
@@ -402,22 +404,60 @@ __global__ __launch_bounds__(256) void probit_impute_kernel(ProbitParams P) {
     // a success is drawn above 0 around eta (the far side if eta < 0), a failure below
     const bool far = (y > 0 && y <= P.clt_threshold && eta < 0.0) ||
                      (nt - y > 0 && nt - y <= P.clt_threshold && eta > 0.0);
-    if (far) {
+    bool resolved = false;
+    if (!far && nt == 1 && P.clt_threshold >= 1) {
+      // one trial, near side: the first candidate by Kinderman-Ramage's first branch (two
+      // uniforms, 88 % of normals) -- straight-line code for the whole wavefront.  The
+      // other branches' loops and the later candidates are what made every wavefront wait
+      // for its unluckiest lane: an observation that meets one goes to the queue and is done
+      // from its first draw there (the stream is positional: the same numbers)
+      SeqRng rng = SeqRng::slot(PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 8u},
+                                P.sweep * (uint64_t)P.n + (uint64_t)i, PROBIT_STRIDE, slot_serve(P, PROBIT_STRIDE));
+      const bool gt = y == 1;
+      const double cut = gt ? 0.0 - eta : eta - 0.0;   // (rtrun_norm: a - mu / mu - a)
+      // (ONE candidate: a second and third straight-line try settle another tenth of the
+      // observations and measured no gain -- 5.96 vs 5.89 ms per round)
+      for (int c = 0; c < 1 && slot_serve(P, PROBIT_STRIDE) >= 2; ++c) {
+        const double u1 = rng();
+        if (!(u1 < 0.884070402298758)) break;
+        const double u2 = rng();
+        const double x = 2.216035867166471 * (1.131131635444180 * u1 + u2 - 1);   // (d_norm_rand's first return)
+        if (x > cut) {
+          double ans = 0.0;
+          ans += gt ? eta + x : eta - x;
+          P.z[(size_t)chain * P.n + i] = ans;
+          resolved = true;
+          break;
+        }
+      }
+    }
+    if (!resolved) {
       s_eta[threadIdx.x] = eta;
-      s_queue[atomicAdd(&s_nqueue, 1)] = (unsigned char)threadIdx.x;
-    } else {
-      bool overflow = false;
-      P.z[(size_t)chain * P.n + i] = probit_impute_one<false>(P, chain, i, eta, nt, y, none, &overflow, &bad);
+      if (far) s_queue[atomicAdd(&s_nqueue, 1)] = (unsigned char)threadIdx.x;
+      else     s_near[atomicAdd(&s_nnear, 1)] = (unsigned char)threadIdx.x;
     }
   }
   __syncthreads();   // (the coefficients are no longer needed: their memory becomes the hulls)
-  if (threadIdx.x >= 64) {
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  const int first = (int)(blockIdx.x * blockDim.x);
+  // ---- (1b) the near-side observations the first candidate did not settle (and those of
+  // several trials), dense: chunks of 64 over the first three wavefronts
+  if (wave < 3) {
+    const int nnear = s_nnear;
+    for (int base = 64 * wave; base < nnear; base += 192) {
+      const int t = base + lane;
+      if (t < nnear) {
+        const int li = s_near[t], ii = first + li;
+        bool overflow = false;
+        P.z[(size_t)chain * P.n + ii] = probit_impute_one<false>(P, chain, ii, s_eta[li], lround(P.ntrials[ii]),
+                                                                 lround(P.y[ii]), none, &overflow, &bad);
+      }
+    }
     if (bad) P.status[chain] = CHAIN_RNG_BRANCH;
     return;
   }
-  // ---- (2)
-  const int lane = (int)threadIdx.x, nqueue = s_nqueue;
-  const int first = (int)(blockIdx.x * blockDim.x);
+  // ---- (2) the far-side observations, by the last wavefront
+  const int nqueue = s_nqueue;
   for (int base = 0; base < nqueue; base += TN_SLOTS) {
     const int t = base + lane;
     if (t < nqueue) {
