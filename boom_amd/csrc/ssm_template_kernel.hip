@@ -250,7 +250,7 @@ __device__ __forceinline__ bool ar_stationary(double a, int L, int lane) {
 // point i (abscissa, log density, slope, cdf) and knot i; lane n holds the last knot,
 // so up to 63 points.  Every lane of the wave must be active.  Restated as written,
 // update_cdf's increment (exp(y - y0) / d) * expm1(d * knots[k + 1] - knots[k]) included.
-__device__ __noinline__ double ar_tn2_draw(SeqRng &rng, double lo, double hi, int *bad) {
+__device__ __forceinline__ double ar_tn2_draw(SeqRng &rng, double lo, double hi, int *bad) {
   const int lane = (int)(threadIdx.x & 63);
   int n = 2;
   double xs = (lane == 0) ? lo : hi;   // (lanes past n - 1 hold copies of the last point)
