@@ -211,9 +211,9 @@ def other_configs(boom_amd, torch, device, cpu=True):
                         "state_draw_alone": {"kernel": "kalman_lm_kernel as its own launch (separate launches)",
                                              "us": kt_sep.get("kalman_simsmooth_kernel"),
                                              "frac": round(bytes3 / (kt_sep.get("kalman_simsmooth_kernel", 1e9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
-                        "traffic": _profile_traffic("c3", "ss_round_kernel"),
+                        "traffic": (lambda t: None if t is None else round(t / 64.0, 0))(_profile_traffic("c3", "ss_round_kernel")),
                         "traffic_source": "profiles/r*_c3_pmc_traffic.json (rocprofv3 --pmc passes of "
-                                          "tools/ss_bench.py), per launch of 64 rounds",
+                                          "tools/ss_bench.py: launches of 64 rounds), per ROUND like `achieved`",
                         "note": "a round is bound by the two wavefronts' instruction streams (Philox for 2 T normals, "
                                 "the sweep's dependent round trips), not by bandwidth: DESIGN 3.5"}}
     if cpu:

@@ -16,8 +16,8 @@ eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigm
 eng.ss_set_local_level(ss["level_df"], ss["level_sigma_guess"], ss["level_sigma_upper_limit"],
                        ss["initial_state_mean"], ss["initial_state_variance"], ss["initial_level_sigma"])
 eng.set_state(np.zeros(p, np.uint8))
-eng.ss_sweep(50)
-t0 = time.perf_counter(); n = 100
+eng.ss_sweep(64)   # (launches of 64 rounds each: the counters of a profile are per launch)
+t0 = time.perf_counter(); n = 128
 eng.ss_sweep(n)
 dt = time.perf_counter() - t0
 gam, beta, sig = eng.get_states()
