@@ -13,26 +13,33 @@
 // sum) made a round last as long as its SLOWEST chain's sweep + a state draw + a GEMM +
 // three launch gaps: 134 us, of which the mean chain's own work is about half -- the 6 % of
 // the chains that accept a flip in a round take twice as long in the sweep, and every
-// round waited for them.  Here nothing waits for anything but what it needs:
+// round waited for them.  Here nothing waits for anything but what it needs (109 us a round):
 //
 // * sweep -> state draw is program order inside the workgroup; what the state draw needs and
 //   the sweep does not give (the level variance from the previous state draw's statistics,
-//   2 T standard normals: 30-70 us of integer multiplies) is made by wave 1 while wave 0 is
-//   in the X'e step and the next sweep;
+//   2 T standard normals: 78 wave-us of integer multiplies) is made by wave 1 while wave 0 is
+//   in the X'e step and the next sweep -- wave 0 takes what is left of it when its sweep is
+//   done (kalman_prepare_lead / _help, kalman_lm_device.h: the sub-chunks from both ends, no
+//   read-modify-write);
 // * the regression's sufficient statistic X'e needs the design matrix (1.6 MB at T = 2000,
 //   p = 100): read once per chain it would be 1.6 GB of L2 traffic per round, so chains
 //   share it in TILES OF UP TO 16 FORMED IN ARRIVAL ORDER: a chain that has drawn its state
 //   takes the round's next ticket (tile = ticket / 16), writes its name into the tile and
-//   polls the tile's names; with all there -- or when the tile's first member has waited
-//   4 us and closed it, a compare-and-swap that moves the ticket counter to the next tile --
-//   member s multiplies rows s, s + n, ... of the lane-major series (128 time steps each) of
+//   polls the tile's names; with all SIXTEEN there (tiles are exact: the round's first tile
+//   is the short one when the chain count is no multiple of 16; closing a tile early on a
+//   timer made stragglers do sixteen rows alone and launches 2-4 x slower) -- or, as a safety
+//   for launches that share the machine with another engine's, when the tile's first member
+//   has waited SsRoundParams::close_ticks (1 ms) and closed it, a compare-and-swap that moves
+//   the ticket counter to the next tile -- member s multiplies rows s, s + n, ... of the
+//   lane-major series (128 time steps each) of
 //   ALL the tile's residual series with the matching slab of X on the f64 matrix cores
 //   (v_mfma_f64_16x16x4_f64: members x variables) and stores the partial products into the
 //   members' planes; every member adds its own sixteen planes in row order as soon as none
-//   of them holds the "not yet" pattern it left there.  Arrival order costs about the time
-//   16 chains take to arrive (1 us at 14 arrivals per us); the value of X'e does not depend
-//   on who shared the tile (a partial product is one series' row times one slab; the sum is
-//   in row order);
+//   of them holds the "not yet" pattern it left there.  Arrival order costs the time 16
+//   chains take to arrive (measured: 6.7 us of a chain's round waiting for its tile's
+//   members); the value of X'e does not depend on who shared the tile (a partial product is
+//   one series' row times one slab, four consecutive steps per MFMA in the order of the tiled
+//   GEMM of the separate launches: bitwise the same sums);
 // * no workgroup ever waits for one that is not running: a tile is waited for by workgroups
 //   that took its tickets only, so two engines whose launches share the machine cannot lock
 //   each other out; a chain alone in its tile does all sixteen rows.

@@ -114,8 +114,9 @@ def test_round_kernel_capacity_stop_and_catch_up():
 
 
 def test_two_engines_rounds_side_by_side():
-    """Two engines' persistent launches in flight together (neither waits for a workgroup
-    that is not running: tiles close after 4 us without company): each equals its own
+    """Two engines' persistent launches in flight together (each engine's launches go out in
+    groups of chains that are co-resident beside the other's; a tile whose members are not
+    all running is closed by its first member after 1 ms): each equals its own
     separate-launch twin."""
     T, p, chains = 500, 16, 1024
     X, y, _, obs = state_space_data(T, p, 3, seed=8)
