@@ -539,7 +539,11 @@ int ba_ss_set_lookahead(ba_engine *e, int32_t lookahead);
 int ba_ss_lookahead_chains(ba_engine *e, int32_t nchains, const int64_t *chains);
 int ba_ss_draw_next(ba_engine *e);
 /* nsweeps x StateSpacePosteriorSampler::draw()
- * (StateSpacePosteriorSampler.cpp:42-64) on every chain */
+ * (StateSpacePosteriorSampler.cpp:42-64) on every chain.  Local level model, a series of
+ * at most 2048 steps, models of at most 48 variables: the rounds of the call run as ONE
+ * persistent launch per 64 rounds (every chain loops over its rounds by itself; chains
+ * meet in tiles of 16 for X'(y - state)); otherwise three launches per round (regression
+ * sweep, state draw, X'(y - state)).  The same draws either way: ba_ss_set_tuning(e, 4 | 5). */
 int ba_ss_sweep(ba_engine *e, int32_t nsweeps);
 /* one Base::impute_state (StateSpaceModelBase.cpp:278-291) with the current
  * parameters, on every chain */
