@@ -184,8 +184,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
       // (diagnostic: a chain that stopped in the state draw -- what the draw was given)
       const int at = atomicAdd(F.debug + 1, 1);
       if (at < 4) {
-        double *o = reinterpret_cast<double *>(F.debug + 16 + 15 * 16) - 0;   // (rows 15.. of the block are not used by the sums' records)
-        o = reinterpret_cast<double *>(F.debug + 16 * 17) + at * 8;
+        double *o = reinterpret_cast<double *>(F.debug + 16 * 17) + at * 8;   // (behind the sums' fifteen records)
         o[0] = chain; o[1] = r; o[2] = S.status[chain];
         o[3] = __hip_atomic_load(S.sigsq + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         o[4] = __hip_atomic_load(S.level_sigsq + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

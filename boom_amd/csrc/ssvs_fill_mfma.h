@@ -42,8 +42,6 @@ enum : int { MF_ROWS = 16, MF_NT = 2, MF_MAX_BLOCK_ROWS = 8,
 __host__ __device__ inline int mf_block_rows(int k) {
   return k <= 32 ? 2 : (k <= 48 ? 3 : (k <= 64 ? 4 : (k <= 80 ? 5 : (k <= 96 ? 6 : 8))));
 }
-// doubles of a model block's inverse diagonal blocks, per factor
-__host__ __device__ inline int mf_inv_doubles(int kcap) { return (kcap / MF_ROWS) * MF_ROWS * MF_ROWS; }
 
 // inv(L_II) for nI block rows of 16, row-major 16 x 16 at inv + 256 I.  One wavefront.  L:
 // the factor, block packed (rows < (krows + 7) & ~7 written), rd its reciprocal diagonal --
