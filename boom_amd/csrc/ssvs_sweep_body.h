@@ -862,15 +862,25 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
       const double sigma = P.mode ? 1.0 : sqrt(sigsq);
       double y = (lane < k) ? ch.w[lane] + sigma * z : 0.0;
       const double rdm = (lane < k) ? ch.rdv[lane] : 0.0;
-      // column sweep of the back substitution; row i of L is fetched one step
-      // ahead of its use
-      double lrow = (k > 0 && lane < k - 1) ? ch.Lv[bidx(k - 1, lane)] : 0.0;
-      for (int i = k - 1; i >= 0; --i) {
-        const double lcur = lrow;
-        if (i > 0) lrow = (lane < i - 1) ? ch.Lv[bidx(i - 1, lane)] : 0.0;
-        const double xi = bcast_u(y * rdm, i);
-        if (lane == i) y = xi;
-        else if (lane < i) y -= lcur * xi;
+      // column sweep of the back substitution, eight rows of L at a time: a block row's
+      // eight reads go out together (rows of one 8 x 8 block row are 64 bytes apart), then its
+      // eight steps run from registers -- fetched one row ahead of its use, every step had
+      // waited for most of an LDS round trip
+#pragma nounroll
+      for (int ib = (k - 1) >> 3; ib >= 0; --ib) {
+        double lr[8];
+        const int base = bidx(ib * 8, lane < ib * 8 + 8 ? lane : 0);   // (row 8 ib, this lane's column)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lr[t] = ch.Lv[base + t * 8];
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {
+          const int i = ib * 8 + t;
+          if (i < k) {
+            const double xi = bcast_u(y * rdm, i);
+            if (lane == i) y = xi;
+            else if (lane < i) y -= lr[t] * xi;
+          }
+        }
       }
       beta_m = y;
       beta_valid = true;
