@@ -420,10 +420,24 @@ __device__ __forceinline__ void refactor(const SsvsParams &P, Chain &ch, Model &
   // w = L_V^{-1} r, lane m ends up holding w_m
   double x = r;
   const double rdm = (lane < k) ? ch.rdv[lane] : 0.0;
-  for (int j = 0; j < k; ++j) {
-    const double wj = bcast_u(x, j) * bcast_u(rdm, j);
-    if (lane == j) x = wj;
-    else if (lane > j && lane < k) x -= ch.Lv[bidx(lane, j)] * wj;
+  // (eight columns of the lane's row at a time -- 64 contiguous bytes of a block --, then
+  // eight steps from registers: read inside the dependent loop, every step waited for LDS)
+#pragma nounroll
+  for (int jb = 0; jb * 8 < k; ++jb) {
+    double lr[8];
+    const int rowm = (lane >= jb * 8 && lane < k) ? lane : jb * 8;
+    const int base = bidx(rowm, jb * 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) lr[t] = ch.Lv[base + t];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int j = jb * 8 + t;
+      if (j < k) {
+        const double wj = bcast_u(x, j) * bcast_u(rdm, j);
+        if (lane == j) x = wj;
+        else if (lane > j && lane < k) x -= lr[t] * wj;
+      }
+    }
   }
   if (lane < k) ch.w[lane] = x;
   M.Q = wave_sum(lane < k ? x * x : 0.0);
