@@ -319,13 +319,22 @@ __global__ __launch_bounds__(64, 1) void ssvs_adaptive_kernel(SsvsParams P, int 
       const double sigma = sqrt(sigsq);
       double y = (lane < k) ? ch.w[lane] + sigma * z : 0.0;
       const double rdm = (lane < k) ? ch.rdv[lane] : 0.0;
-      double lrow = (k > 0 && lane < k - 1) ? ch.Lv[bidx(k - 1, lane)] : 0.0;
-      for (int r = k - 1; r >= 0; --r) {
-        const double lcur = lrow;
-        if (r > 0) lrow = (lane < r - 1) ? ch.Lv[bidx(r - 1, lane)] : 0.0;
-        const double xi = bcast_u(y * rdm, r);
-        if (lane == r) y = xi;
-        else if (lane < r) y -= lcur * xi;
+      // (eight rows of L at a time, as in ssvs_sweep_body.h)
+#pragma nounroll
+      for (int ib = (k - 1) >> 3; ib >= 0; --ib) {
+        double lr[8];
+        const int base = bidx(ib * 8, lane < ib * 8 + 8 ? lane : 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lr[t] = ch.Lv[base + t * 8];
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {
+          const int r = ib * 8 + t;
+          if (r < k) {
+            const double xi = bcast_u(y * rdm, r);
+            if (lane == r) y = xi;
+            else if (lane < r) y -= lr[t] * xi;
+          }
+        }
       }
       beta_m = y;
       beta_valid = true;
