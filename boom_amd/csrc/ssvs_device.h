@@ -953,9 +953,21 @@ __device__ __forceinline__ double draw_normals(WinRng &rng, int k) {
       const int l = o >> 1;
       const bool odd = o & 1;
       double zm;
-      if (((odd ? mO : mE) >> l) & 1ull) {
-        zm = bcast_u(odd ? zO : zE, l);
-        o += 2;
+      const unsigned long long fastrun = (odd ? mO : mE) >> l;
+      if (fastrun & 1ull) {
+        // a RUN of first-branch draws: each takes two numbers, so they start at o, o + 2, ...
+        // as long as the bits say so -- handed to lanes m, m + 1, ... in one move instead of
+        // one scalar step per draw
+        int run = (~fastrun == 0ull) ? 64 : __ffsll((long long)~fastrun) - 1;
+        const int room = (125 - o) / 2 + 1;
+        run = run < room ? run : room;
+        run = run < k - m ? run : k - m;
+        const int src = l + (lane - m);
+        const double zz = __shfl(odd ? zO : zE, (src >= 0 && src < WAVE) ? src : 0);
+        if (lane >= m && lane < m + run) z = zz;
+        m += run;
+        o += 2 * run;
+        continue;
       } else {
         rng.off = o;
         zm = d_norm_rand(rng);
