@@ -545,9 +545,11 @@ def family_configs(boom_amd, device, O, cores, cpu):
     ea.set_state(ga)
     ea.adaptive_sweep(300)
     ea.reset_summaries()
-    t0 = time.perf_counter()
-    ea.adaptive_sweep(500)
-    dta = time.perf_counter() - t0
+    dta = float("inf")
+    for _ in range(3):   # (22 ms a call: the best of three -- one host hiccup tripled a single shot)
+        t0 = time.perf_counter()
+        ea.adaptive_sweep(500)
+        dta = min(dta, time.perf_counter() - t0)
     sma = ea.get_summaries()
     ka = sma["k_sum"] / sma["sweeps"]
     ea.set_kernel_timing(True)
