@@ -159,6 +159,13 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
                        (int)ctl[CT_EVMODE], wave, ctl, sx_unused);
         HSTAMP(sx_unused, 6);
       } else if (cmd == CMD_DECIDE || cmd == CMD_SHUFFLE_DECIDE) {
+        if (cmd == CMD_SHUFFLE_DECIDE) {
+          // the shuffle's p - 1 uniforms: every wavefront of the workgroup its share, the
+          // master too before it starts on the tail (it has the slack: wave 1's side of a
+          // quiet sweep is the longer one) -- then all meet once more
+          shuffle_targets(key, upos, p, threadIdx.x, WAVE * W, ch.oth);
+          __syncthreads();
+        }
         if (wave == 1) {
           const int sel = (int)ctl[CT_PERMSEL];
           bind_slot(ch, P, chain, (int)ctl[CT_CUR]);
@@ -166,10 +173,8 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
           ch.perm_alt = to_lds<uint16_t>(smem + (sel ? lay.perm0 : lay.perm1));
           uint64_t fpos = upos;
           if (cmd == CMD_SHUFFLE_DECIDE) {
-            // the whole permutation side of a quiet sweep: shuffle(indx) from
-            // stream position upos, then the walk over the new order
-            shuffle_targets(key, upos, p, lane, WAVE, ch.oth);
-            wave_sync();
+            // the permutation side of a quiet sweep: shuffle(indx) from stream position
+            // upos (its targets are in ch.oth: above), then the walk over the new order
             parallel_shuffle(ch, sx_unused);
             fpos = upos + (uint64_t)(p - 1);
           }
@@ -493,6 +498,8 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
             ctl[CT_CUR] = (double)cur;
             ((AS_LDS uint64_t *)(ctl + CT_POS))[0] = pos;
           }
+          __syncthreads();
+          shuffle_targets(key, pos, p, threadIdx.x, WAVE * W, ch.oth);   // (the master's share: see the helpers' loop)
           __syncthreads();
           {  // the shuffled order will be in the other buffer
             lds_u16 *tmp = ch.perm;
