@@ -713,6 +713,7 @@ def run_config3(args, boom_amd, torch, dist, rank, local_rank, world):
     blk = torch.empty(bd.summary_block_size(p), dtype=torch.float64, device="cuda")
     eng.summaries_device(blk.data_ptr())
     allb = bd.gather_blocks(blk, world)
+    coll = _collectives(bd, dist, world)
     elapsed = bd.max_over_ranks(elapsed, world, "cuda")
     if args.dump_blocks:
         dig = torch.tensor([float(rank * C), float(s["xtx"].sum()), float(np.abs(s["xtx"]).sum()), float(s["xty"].sum()),
@@ -744,6 +745,7 @@ def run_config3(args, boom_amd, torch, dist, rank, local_rank, world):
                                  "all-reduce of %d bytes" % (8 * bd.suf_block_size(p))) if world > 1
                                 else "single device MFMA syrk"},
         "suf_build_ms": round(suf_build_s * 1e3, 1),
+        "collectives": coll,
         "decisions": {"min_margin": float(sc[:, 6].min()), "accepted_flips": float(sc[:, 4].sum()),
                       "proposed_flips": float(sc[:, 5].sum())},
         "signal_inclusion_min": round(float(incl[:nsig].min()), 4),
@@ -780,6 +782,7 @@ def run_config4(args, boom_amd, torch, dist, rank, local_rank, world):
     blk = torch.empty(bd.summary_block_size(p), dtype=torch.float64, device="cuda")
     eng.summaries_device(blk.data_ptr())
     allb = bd.gather_blocks(blk, world)
+    coll = _collectives(bd, dist, world)
     elapsed = bd.max_over_ranks(elapsed, world, "cuda")
     gam = eng.get_states()[0]
     if args.dump_blocks and rank == 0:
@@ -802,9 +805,26 @@ def run_config4(args, boom_amd, torch, dist, rank, local_rank, world):
                    "mean_model_size": round(float(gam.sum(1).mean()), 2),
                    "parallelism": "chains sharded, data replicated, %d GPU(s)" % world},
         "sweeps_in_the_summaries": counted,
+        "collectives": coll,
         "signal_inclusion_min": round(float(incl[:8].min()), 4),
         "ms_per_round": round(step_ms / R, 3),
         "cpu_baseline": None}))
+
+
+def _collectives(bd, dist, world):
+    """what the job's collectives were and took on rank 0 (ONE all-reduce of the
+    sufficient-statistics block where the rows are sharded, ONE all-gather of the summary
+    blocks at the end): backend, ranks under RCCL, wall ms (device-synchronised on both sides).
+    Call right after the summary gather."""
+    if world == 1:
+        return {"backend": None, "rccl_ranks": 0}
+    be = dist.get_backend()
+    out = {"backend": be, "rccl_ranks": world if be == "nccl" else 0}
+    for k in ("all_reduce_ms", "all_gather_ms"):
+        if k in bd.timings:
+            out[k] = round(bd.timings[k], 3)
+            out[k.replace("_ms", "_bytes")] = int(bd.timings[k.replace("_ms", "_bytes")])
+    return out
 
 
 def _profile_traffic(tag, kernel_prefix):
@@ -969,6 +989,7 @@ def main():
     block = torch.empty(bd.summary_block_size(P), dtype=torch.float64, device="cuda")
     eng.summaries_device(block.data_ptr())
     allb = bd.gather_blocks(block, world)          # ONE RCCL all-gather
+    coll = _collectives(bd, dist, world)
     elapsed = bd.max_over_ranks(elapsed, world, "cuda")
     if args.dump_blocks:
         # (test hook, outside the timed region: what every rank holds, side by side)
@@ -1225,6 +1246,7 @@ def main():
                                       "time, each as long as its slowest chain (round 3's headline mode)"},
         "other_configs": other,
         "suf_build_ms": round(suf_build_s * 1e3, 2),
+        "collectives": coll,
         "signal_inclusion_min": round(float(incl[:N_SIGNAL].min()), 4),
         "null_inclusion_max": round(float(incl[N_SIGNAL:].max()), 4),
         "roofline": roofline,

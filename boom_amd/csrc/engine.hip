@@ -398,6 +398,8 @@ struct ba_engine {
   bool ss_round_enabled = true;    // (ba_ss_set_tuning 4 / 5: the separate launches of rounds 1-4 / this)
   DevBuf<int32_t> dround_ctl, dround_members, dround_reg;
   int ss_round_resident[4] = {0, 0, 0, 0};
+  bool round_debug = false;        // (ba_ss_set_tuning 6 / 7: the round kernel's notes of a debugging session on / off)
+  DevBuf<int32_t> dround_debug;    // ... on this engine's device
   DevBuf<double> dssm_sigsq, dssm_n, dssm_ss, dssm_work;   // chains x SSG_MAX_VAR (sigsq, n, ss)
   DevBuf<double> dar_phi, dar_suf;                         // chains x SSG_MAX_AR x (AR_MAX | AR_SUF_STRIDE)
   DevBuf<uint64_t> dpos_var;                               // chains x SSG_MAX_VAR
@@ -425,7 +427,8 @@ struct ba_engine {
     bool synced = false;        // the batch being served is complete and its chains sound
     bool busy = false;          // (a settle in progress: entry points it calls do not settle again)
     hipEvent_t done[2] = {nullptr, nullptr};
-    std::vector<int32_t> reg{0};            // chains whose state path is recorded
+    std::vector<int32_t> reg{0};            // chains whose state path is recorded (always the size of dreg / rstate's rows)
+    std::vector<int32_t> want;              // ... and the ones asked for since: ss_la_alloc takes them into reg, as far as the record has room
     DevBuf<int32_t> dreg;
     DevBuf<double> lev_used;                // the level variance every chain's last state draw used
     size_t nvar = 0, nphi = 0, state_doubles = 0;   // per chain and round
@@ -1093,10 +1096,12 @@ hipError_t pinned_reserve(ba_engine *e, size_t bytes) {
   return err;
 }
 
-// (debugging sessions, BA_DEBUG_ROUND: what the round kernel noted, printed when a chain stops)
-DevBuf<int32_t> g_round_debug;
-void dump_round_debug() {
-  if (g_round_debug.count == 0) return;
+// (debugging sessions, ba_ss_set_tuning(e, 6): what THIS engine's round kernel noted, printed
+// when one of its chains stops; the buffer lives on the engine's device)
+int set_device(const ba_engine *e);
+void dump_round_debug(ba_engine *e) {
+  if (!e->round_debug || e->dround_debug.count == 0 || set_device(e)) return;
+  DevBuf<int32_t> &g_round_debug = e->dround_debug;
   int32_t h[16 * 17];
   if (hipMemcpy(h, g_round_debug.ptr, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
   std::fprintf(stderr, "round kernel: %d sums that are not numbers\n", h[0]);
@@ -1156,11 +1161,11 @@ int check_chain_status(ba_engine *e) {
       char buf[64];
       std::snprintf(buf, sizeof buf, " (chain %lld)",
                     (long long)(e->cfg.chain_offset + (int64_t)c));
-      dump_round_debug();
+      dump_round_debug(e);
       {  // (and which chains)
         int bad = 0;
         for (size_t d = 0; d < C; ++d) bad += st[d] != CHAIN_OK;
-        if (g_round_debug.count) {
+        if (e->round_debug && e->dround_debug.count) {
           std::fprintf(stderr, "  %d chains stopped:", bad);
           for (size_t d = 0; d < C; ++d) if (st[d] != CHAIN_OK) std::fprintf(stderr, " %zu(%d)", d, st[d]);
           std::fprintf(stderr, "\n");
@@ -1539,10 +1544,20 @@ hipError_t ss_la_record(ba_engine *e, int slot, int round) {
 // the record's and the snapshots' buffers for the current specification
 int ss_la_alloc(ba_engine *e) {
   ba_engine::SsLa &A = e->ssla;
-  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, L = (size_t)A.len, nreg = A.reg.size();
+  const size_t C = (size_t)e->cfg.chains, p = (size_t)e->p, L = (size_t)A.len;
   A.nvar = e->ssm_set ? (size_t)e->ssg.nvar : 1;
   A.nphi = e->ssm_set ? (size_t)e->ssg.nar * AR_MAX : 0;
   A.state_doubles = e->ssm_set ? (size_t)e->ssg.m * e->T : ss_pitch(*e);
+  {
+    // chains whose state path was read since the last allocation join the record while their
+    // rows fit in 2 GiB (m = 64, T = 2048, 256 rounds: half a gigabyte per chain); the others
+    // keep being read by going back to the draw being served
+    const double per_chain = 2.0 * (double)L * (double)A.state_doubles * 8.0;
+    for (int32_t w : A.want)
+      if (((double)A.reg.size() + 1.0) * per_chain <= 2147483648.0) A.reg.push_back(w);
+    A.want.clear();
+  }
+  const size_t nreg = A.reg.size();
   HIP_TRY(A.rgamma.resize(2 * C * L * p));
   HIP_TRY(A.rbeta.resize(2 * C * L * p));
   HIP_TRY(A.rsig.resize(2 * C * L));
@@ -1653,16 +1668,16 @@ int ss_la_settle(ba_engine *e) {
   // (With the whole batch handed out and the next one running, the next batch's own snapshot
   // IS the chains at the draw served last -- but not the state PATH of that draw, which a
   // forecast or another chain's state read asks for and only the replay brings back: the
-  // batch is replayed here too.)
-  const bool at_boundary = false;
+  // batch is replayed then too.)
   ss_la_reset(e);
-  // (see SsLa::cur: whoever made this necessary may do so after every draw)
+  if (at_end) return check_chain_status(e);   // (nothing dropped, nothing replayed: free)
+  // a rewind and a replay follow (see SsLa::cur: whoever made this necessary may do so after
+  // every draw, so the batches get shorter)
   A.clean = false;
   if (A.cur <= 2 && A.cur > 1) A.probe_wait = std::min(1024, A.probe_wait * 2);
   A.cur = std::max(1, A.cur / 2);
   A.calm = 0;
-  if (at_end) return check_chain_status(e);
-  int rc = ss_la_copy(e, false, at_boundary ? slot ^ 1 : slot);
+  int rc = ss_la_copy(e, false, slot);
   if (rc) return rc;
   {  // (a chain that stopped in the dropped rounds stopped after the point we return to)
     const size_t C = (size_t)e->cfg.chains;
@@ -1671,7 +1686,7 @@ int ss_la_settle(ba_engine *e) {
   }
   e->table_ok = false;
   e->model_ok = false;
-  if (served > 0 && !at_boundary) {
+  if (served > 0) {
     rc = ss_sweep_impl(e, served, -1);
     if (rc) return rc;
   }
@@ -1758,8 +1773,14 @@ bool ss_la_registered(const ba_engine *e, int64_t c) {
 // A chain whose state path was asked for and is not in the record: this read goes back to the
 // draw being served (ss_la_settle), the batches from here on record the chain too -- a caller
 // that reads chain c after every draw pays for it once, not every time.
+// (the list the device buffers are sized by, `reg`, changes in ss_la_alloc only; the state
+// record is bounded there)
 void ss_la_want_state(ba_engine *e, int64_t c) {
-  if (!ss_la_registered(e, c) && e->ssla.reg.size() < 32) e->ssla.reg.push_back((int32_t)c);
+  ba_engine::SsLa &A = e->ssla;
+  if (ss_la_registered(e, c)) return;
+  for (int32_t w : A.want)
+    if (w == c) return;
+  if (A.reg.size() + A.want.size() < 32) A.want.push_back((int32_t)c);
 }
 
 struct ApiScope {
@@ -3862,12 +3883,14 @@ int ba_set_slot_limit(ba_engine *e, int32_t uniforms) {
 // applies (the two are compared by the tests), 1 = the default
 int ba_ss_set_tuning(ba_engine *e, int32_t kernel) {
   if (!e) return fail(BA_E_INVALID, "null engine");
-  if (kernel < 0 || kernel > 5 || kernel == 2)
-    return fail(BA_E_INVALID, "kernel must be 0, 1, 3, 4 or 5 (2, four chains per wavefront, was removed: it never won)");
+  if (kernel < 0 || kernel > 7 || kernel == 2)
+    return fail(BA_E_INVALID, "kernel must be 0, 1, 3, 4, 5, 6 or 7 (2, four chains per wavefront, was removed: it never won)");
   MUTATE(e);
   // 4 / 5: the local-level rounds as the separate launches of rounds 1-4 / as the round
   // kernel (the default where it applies); the structural kernels' choice stays
-  if (kernel >= 4) e->ss_round_enabled = kernel == 5;
+  // 6 / 7: the round kernel's diagnostic notes (printed when a chain stops) on / off
+  if (kernel >= 6) e->round_debug = kernel == 6;
+  else if (kernel >= 4) e->ss_round_enabled = kernel == 5;
   else e->ssg_kernel_choice = kernel;
   return BA_OK;
 }
@@ -4139,7 +4162,7 @@ int ss_round_chains(ba_engine *e) {
       P.p = e->p;
       int n = 0;
       if (launch_ss_round(e->stream, P, S, F, &n) == hipSuccess && n > 0) res = n;
-      if (std::getenv("BA_DEBUG_ROUND")) std::fprintf(stderr, "round kernel: kcap %d lds %zu resident %d\n", e->kcap, ss_round_lds(e->p, e->kcap), n);
+      if (e->round_debug) std::fprintf(stderr, "round kernel: kcap %d lds %zu resident %d\n", e->kcap, ss_round_lds(e->p, e->kcap), n);
     }
   }
   return res > 0 ? std::min<int>(res, e->cfg.chains) : 0;
@@ -4159,12 +4182,12 @@ int ss_round_launches(ba_engine *e, SsvsParams &P, SsParams &S, int rounds, int 
   F.sizes = F.ticket + SS_ROUND_MAX_ROUNDS;
   F.members = e->dround_members.ptr;
   F.planes = e->dxte_planes.ptr;
-  if (std::getenv("BA_DEBUG_ROUND")) {
-    if (g_round_debug.count == 0) {
-      HIP_TRY(g_round_debug.resize(16 * 17 + 64));
-      HIP_TRY(hipMemset(g_round_debug.ptr, 0, (16 * 17 + 64) * 4));
+  if (e->round_debug) {
+    if (e->dround_debug.count == 0) {
+      HIP_TRY(e->dround_debug.resize(16 * 17 + 64));
+      HIP_TRY(hipMemset(e->dround_debug.ptr, 0, (16 * 17 + 64) * 4));
     }
-    F.debug = g_round_debug.ptr;
+    F.debug = e->dround_debug.ptr;
   }
 #ifdef BA_RSTAMPS
   {  // (diagnostic build: printed per call by tools/ss_round_phases.py through BA_RSTAMPS_DUMP)
@@ -4330,6 +4353,7 @@ int ba_ss_lookahead_chains(ba_engine *e, int32_t nchains, const int64_t *chains)
     if (chains[i] < 0 || chains[i] >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   MUTATE(e);
   e->ssla.reg.clear();
+  e->ssla.want.clear();
   for (int i = 0; i < nchains; ++i) e->ssla.reg.push_back((int32_t)chains[i]);
   ss_la_reset(e);
   return BA_OK;

@@ -139,7 +139,7 @@ struct SsRoundParams {
   double *rbeta, *rsig, *rvar, *rstate;
   const int32_t *reg_of_chain;      // chains: index among the chains whose state path is recorded, or -1
   int32_t rec_slot, rec_len, rec_first, nreg;
-  int32_t *debug;           // diagnostic (BA_DEBUG_ROUND in the environment of a debugging session): 16 x 16 words, else nullptr
+  int32_t *debug;           // diagnostic (ba_ss_set_tuning(e, 6) in a debugging session): 16 x 16 words, else nullptr
   int32_t debug_seq;        // diagnostic build: a number per launch
   double *stamps;           // diagnostic build (-DBA_RSTAMPS): chains x 2 waves x 8 phases, 100 MHz ticks; else unused
 };

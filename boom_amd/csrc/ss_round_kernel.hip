@@ -249,8 +249,12 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
     {
       const int fc = lane & 15, fk = lane >> 4;
       const int mem_a = __shfl(mine, lo + (fc < n ? fc : 0));
-      const __amdgpu_buffer_rsrc_t eb = coh_buffer(S.scratch), xb = coh_buffer(S.Xt);
-      const uint32_t eo = (uint32_t)(((size_t)mem_a * S.scratch_stride + S.TP) * 8) + 8u * fk;
+      // (the residual series' resource starts at the launch's FIRST chain: a tile's members are
+      // chains of this launch, at most the resident count of them, so the 32-bit byte offset
+      // stays far below 2^31 whatever the engine's chain count -- from the engine's chain 0 it
+      // passed 2^31 at 14 563 chains and read zeros)
+      const __amdgpu_buffer_rsrc_t eb = coh_buffer(S.scratch + (size_t)P.chain_first * S.scratch_stride), xb = coh_buffer(S.Xt);
+      const uint32_t eo = (uint32_t)(((size_t)(mem_a - P.chain_first) * S.scratch_stride + S.TP) * 8) + 8u * fk;
       for (int rr = slot; rr < RT; rr += n) {
         for (int j0 = 0; j0 < p; j0 += 16 * VG) {
           d4 acc[VG];
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
 #pragma unroll
         for (int z = 1; z < RT; ++z) a += v[z];
         if (F.debug && j < p && !(a == a)) {
-          // (diagnostic, BA_DEBUG_ROUND: a sum that is not a number -- who, when, which row)
+          // (diagnostic, ba_ss_set_tuning 6: a sum that is not a number -- who, when, which row)
           const int at = atomicAdd(F.debug, 1);
           if (at < 15) {
             int zbad = 0;

@@ -7,7 +7,25 @@ CPU tests use gloo).  Nothing here touches the data path.
 """
 import numpy as np
 
+import time
+
 SUMMARY_SCALARS = 16
+# wall milliseconds of the last collectives of this process (device-synchronised on both
+# sides when the tensors are on a GPU): bench.py prints them in the --gpus N line
+timings = {}
+
+
+def _timed(name, tensor, fn):
+    import torch
+    if tensor.is_cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    if tensor.is_cuda:
+        torch.cuda.synchronize()
+    timings[name] = (time.perf_counter() - t0) * 1e3
+    return out
+
 ACC_SWEEPS, ACC_SIGSQ, ACC_SIGSQ2, ACC_K, ACC_ACCEPTS, ACC_PROPOSALS, ACC_MIN_MARGIN = range(7)
 
 
@@ -39,7 +57,8 @@ def gather_blocks(block, world):
         return block.detach().cpu().numpy()[None, :]
     blk, _ = _staged(block)
     out = [torch.empty_like(blk) for _ in range(world)]
-    dist.all_gather(out, blk)
+    _timed("all_gather_ms", blk, lambda: dist.all_gather(out, blk))
+    timings["all_gather_bytes"] = blk.numel() * blk.element_size() * world
     return torch.stack(out).cpu().numpy()
 
 
@@ -72,7 +91,8 @@ def reduce_suf_block(block, world):
     import torch.distributed as dist
     if world > 1:
         blk, staged = _staged(block)
-        dist.all_reduce(blk, op=dist.ReduceOp.SUM)
+        _timed("all_reduce_ms", blk, lambda: dist.all_reduce(blk, op=dist.ReduceOp.SUM))
+        timings["all_reduce_bytes"] = blk.numel() * blk.element_size()
         if staged:
             block.copy_(blk)
     return block

@@ -474,7 +474,9 @@ int ba_ss_add_state_model(ba_engine *e, int32_t kind, const int32_t *iparams,
  * Independently of those: 4 = the local-level model's rounds as separate launches per round
  * (regression sweep, state draw, X'e), 5 = as one persistent launch per call in which every
  * chain loops over the rounds by itself (the default where it applies: a series of at most
- * 2048 steps, models of at most 48 variables) */
+ * 2048 steps, models of at most 48 variables).  And: 6 / 7 = the persistent launch's notes of a
+ * debugging session (printed to stderr when one of this engine's chains stops) on / off (off
+ * by default; the buffer is the engine's own, on its device) */
 int ba_ss_set_tuning(ba_engine *e, int32_t kernel);
 /* the state dimension and the number of state models of the specification */
 int ba_ss_state_dimension(ba_engine *e, int32_t *state_dimension, int32_t *nblocks);

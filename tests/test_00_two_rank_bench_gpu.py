@@ -50,6 +50,12 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rec["n_gpus"] == 2 and rec["steps"] == STEPS and rec["scaling"] == "weak"
     assert rec["config"]["suf_build"].startswith("rows sharded")
     assert rec["decisions"]["min_margin"] > 1e-9
+    # the line names its collectives: here gloo (hence no RCCL ranks), one all-reduce of the
+    # sufficient-statistics block and one all-gather of the summary blocks, with their times
+    coll = rec["collectives"]
+    assert coll["backend"] == "gloo" and coll["rccl_ranks"] == 0
+    assert coll["all_reduce_bytes"] == 8 * (512 * 512 + 2 * 512 + 2) and coll["all_reduce_ms"] > 0
+    assert coll["all_gather_bytes"] == 2 * 8 * (3 * 512 + 16) and coll["all_gather_ms"] > 0
     d = np.load(dump)
     blocks, digests = d["blocks"], d["digests"]
     P, C, SW = 512, 1024, 1000
@@ -272,3 +278,40 @@ def test_bench_config4_two_ranks_logit(tmp_path):
     mine = np.stack(mine)
     assert np.array_equal(blocks[:, :3 * p + 1], mine[:, :3 * p + 1])
     assert not np.array_equal(blocks[0, p:2 * p], blocks[1, p:2 * p])
+
+
+@pytest.mark.parametrize("config", [1, 3, 4])
+def test_bench_two_ranks_over_rccl(tmp_path, config):
+    """VERDICT r5 task 7: bench.py --gpus 2 with the nccl backend (= RCCL), one rank per GPU, as
+    the driver's scaling run launches it -- skipped, with the reason, where fewer than two GPUs
+    are visible, so that the first box with two executes the RCCL all-reduce / all-gather path
+    before any SCALE run does.  The line must say so itself: rccl_ranks == 2 and the
+    collectives' milliseconds."""
+    import torch
+    if torch.cuda.device_count() < 2:     # (counting devices does not initialise the GPU here)
+        pytest.skip("needs two GPUs: %d visible (bench.py --gpus 2 over RCCL, one rank per GPU)"
+                    % torch.cuda.device_count())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "BOOM_AMD_BENCH_BACKEND"):
+        env.pop(k, None)
+    small = {1: [], 3: ["--n-obs", "8192", "--p", "256", "--chains", "64"],
+             4: ["--n-obs", "4000", "--p", "64", "--chains", "32"]}[config]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-curve", "--config", str(config)] + small
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-4000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    coll = rec["collectives"]
+    assert coll["backend"] == "nccl" and coll["rccl_ranks"] == 2
+    assert coll["all_gather_ms"] > 0
+    if config in (1, 3):
+        assert coll["all_reduce_ms"] > 0 and coll["all_reduce_bytes"] > 0
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "two_rank_rccl_c%d.json" % config), "w") as fh:
+            fh.write(lines[0] + "\n")
+    except OSError:
+        pass

@@ -274,3 +274,58 @@ def test_row_sharded_suf_build_matches_single_shot(oracle):
         o = oracle.ssvs_run(suf, prior, ssvs_options(), ("philox", 3, c), g0, 40)
         assert np.array_equal(gam[c], o["gamma"][-1])
         assert relerr(beta[c], o["beta"][-1]) < RTOL
+
+
+def _c2_engine(chains, seed, X, y, nsig):
+    import boom_amd
+    eng = boom_amd.Engine(chains, seed=seed)
+    eng.build_suf_from_xy(X, y)
+    suf = _engine_suf(eng)
+    prior = spike_slab_prior(suf, nsig)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"])
+    return eng, suf, prior
+
+
+def test_c2_every_chain_of_the_headline_against_the_oracle(oracle):
+    """VERDICT r5, weak 1a / task 6a + 6c: ALL 1024 chains of BASELINE configs[1] against the
+    oracle (BregVsSampler::draw, BregVsSampler.cpp:252-261), not four of them -- at 40 and at
+    100 sweeps from the start (the models grow from the intercept to ~16 variables on the way:
+    table fills, forks, both slots), once as ONE launch per checkpoint and once in the
+    HEADLINE's mode: consecutive launches that overlap on two streams and hand the chains
+    over one by one, with nothing between them.  gamma identical, beta / sigma^2 to 1e-8."""
+    import os
+    n, p, nsig, chains, seed = 10000, 512, 16, 1024, 8675309
+    X, y, _ = regression_data(n, p, nsig, seed=8675309)
+    one, suf, prior = _c2_engine(chains, seed, X, y, nsig)
+    lap, _, _ = _c2_engine(chains, seed, X, y, nsig)
+    g0 = np.zeros(p, np.uint8)
+    g0[0] = 1
+    one.set_state(g0)
+    lap.set_state(g0)
+    threads = max(1, len(os.sched_getaffinity(0)))
+    done = 0
+    for upto in (40, 100):
+        one.sweep(upto - done)
+        for _ in range((upto - done) // 10):      # launches of 10 sweeps, nothing in between
+            lap.sweep(10, sync=False)
+        lap.sync()
+        done = upto
+        o = oracle.run_chains(suf, prior, ssvs_options(), seed, chains, upto, threads, g0)
+        assert o["status"] == 0
+        for tag, eng in (("one launch", one), ("overlapped launches", lap)):
+            gam, beta, sig = eng.get_states()
+            bad = np.where((gam != o["gamma"]).any(1))[0]
+            assert len(bad) == 0, (tag, upto, "chains whose inclusion indicators differ", bad[:10])
+            assert relerr(beta, o["beta"]) < RTOL, (tag, upto)
+            assert np.max(np.abs(sig - o["sigsq"]) / o["sigsq"]) < RTOL, (tag, upto)
+    assert 14.0 < o["gamma"].sum(1).mean() < 18.0    # (the chains did get to the benchmark's models)
+    one.close()
+    lap.close()
+
+
+def test_c3_sixty_four_chains_of_the_benchmark_shape(oracle):
+    """task 6b: BASELINE configs[2] (T=2000, p=100, 1024 chains in the persistent round
+    kernel), every sixteenth chain -- 64 of them, one per X'e tile position class -- against
+    the oracle round by round (StateSpacePosteriorSampler::draw, :42-64)."""
+    _ss_compare(oracle, T=2000, p=100, nsig=5, chains=1024, check=list(range(7, 1024, 16)), nsw=6,
+                seed=4, data_seed=8675309)

@@ -69,6 +69,27 @@ def test_round_kernel_equals_the_separate_launches(T, p, chains, missing):
     b.close()
 
 
+def test_round_kernel_beyond_the_32_bit_offsets_of_one_launch():
+    """15 000 chains: a chain's work arrays are 147 KB, so the residual series of chain 14 563 and
+    up lie more than 2^31 bytes behind the engine's first -- the tile product addresses them from
+    the LAUNCH's first chain (from the engine's first it read zeros there, and other
+    chains' series from 29 127 chains on).  The last chains against the separate launches."""
+    T, p, chains = 40, 4, 15000
+    X, y, _, obs = state_space_data(T, p, 2, seed=6)
+    prior, ss, sig_up = bsts_priors(X, y, 2)
+    g0 = np.zeros(p, np.uint8)
+    a = make_engine(chains, 13, y, X, obs, prior, ss, sig_up, g0, True)
+    b = make_engine(chains, 13, y, X, obs, prior, ss, sig_up, g0, False)
+    for n in (1, 5):
+        a.ss_sweep(n)
+        b.ss_sweep(n)
+        same_chains(a, b, [0, 14562, 14563, 14999], "after %d more rounds" % n)
+    for c in (14600, 14999):   # bitwise: the same products in the same order
+        assert np.array_equal(a.ss_get_chain_suf(c)["xty"], b.ss_get_chain_suf(c)["xty"]), c
+    a.close()
+    b.close()
+
+
 def test_round_kernel_every_round_against_the_oracle(oracle):
     """one round per call and ten per call, chains 0 .. 19 draw by draw"""
     T, p, chains, nsw, seed = 300, 12, 20, 30, 41

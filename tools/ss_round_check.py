@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] (T=2000, p=100, 1024 chains): the persistent round kernel against the
 separate launches per round, every chain compared after each call of `step` rounds (argv[1]),
-40 calls.  BA_DEBUG_ROUND=1 in the environment prints what the kernel noted when a chain stops."""
+40 calls.  DEBUG=1 in the environment (-> ba_ss_set_tuning(e, 6)) prints what the kernel noted when a chain stops."""
 import os, sys, time
 ROOT = "/root/repo"
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,6 +19,8 @@ def mk(kernel):
                            ss["initial_state_mean"], ss["initial_state_variance"], ss["initial_level_sigma"])
     eng.set_state(np.zeros(p, np.uint8))
     eng.ss_set_tuning(kernel=kernel)
+    if kernel == 5 and os.environ.get("DEBUG"):
+        eng.ss_set_tuning(kernel=6)
     return eng
 a, b = mk(5), mk(4)
 step = int(sys.argv[1]) if len(sys.argv) > 1 else 10
@@ -40,6 +42,6 @@ for it in range(40):
 else:
     print("no difference in", 40 * step, "rounds")
 try:
-    a.ss_sweep(1)   # (prints the round kernel's diagnostics of the failed call, if BA_DEBUG_ROUND)
+    a.ss_sweep(1)   # (prints the round kernel's diagnostics of the failed call, if DEBUG)
 except Exception as ex:
     pass
