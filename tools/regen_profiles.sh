@@ -14,7 +14,7 @@ set -u
 ROUND=${1:-r03}
 COMMIT=${2:-unknown}
 shift; shift
-ONLY=${@:-c2 c3 c4 dense64 structural structural_ar general logit pg probit xtx_c2 xtx_c4}
+ONLY=${@:-c2 c3 c4 dense64 structural structural_ar general adaptive logit pg probit xtx_c2 xtx_c4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 DEST=$ROOT/gpurun_out/profiles_$ROUND
 mkdir -p $DEST
@@ -50,6 +50,7 @@ for w in $ONLY; do
     c4)         profile c4 yes "ssvs_ xtx_mfma plane_sum col_reduce" $ROOT/bench.py --config 3 --steps 3 --warmup 1 ;;
     dense64)    export NSWEEP=1000; profile dense64 yes "ssvs_" $ROOT/tools/dense_variant.py 64; unset NSWEEP ;;
     general)    profile general yes "ssvs_ ssg_ ssm_ xtwx_" $ROOT/tools/ssg_bench.py ;;
+    adaptive)   profile adaptive yes "ssvs_" $ROOT/tools/adaptive_bench.py ;;
     pg)         profile pg yes "ssvs_ logit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 pg 12 ;;
     logit)      profile logit yes "ssvs_ logit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 logit 12 ;;
     probit)     profile probit yes "ssvs_ probit_ xtwx_ plain_reduce" $ROOT/tools/probit_bench.py 50000 1024 8 512 probit 12 ;;
