@@ -36,6 +36,25 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// One 8-byte LDS read as its own instruction, and the explicit wait that goes with it: see
+// suf_kernel.hip (left to the compiler the fragment reads pair up into ds_read2_b64, which is
+// serviced 16 lanes at a time against 32 banks -- 2-way conflicted on this layout and four
+// times the LDS cycles of the ds_read_b64 pair; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.40
+// in round 5's counters).
+template <int OFF>
+__device__ __forceinline__ double lds_read_b64(uint32_t byte_addr) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(double &a, double &b, double &c, double &d, double &e, double &f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
 constexpr int RT = 64;        // requests per tile
 constexpr int JT = 128;       // variables per tile
 constexpr int KS = 16;        // rows per staging step
@@ -107,18 +126,35 @@ __global__ __launch_bounds__(256, 2) void xtwx_cols_kernel(const double *__restr
   for (int64_t k0 = kbeg; k0 < kend; k0 += KS) {
     const bool more = k0 + KS < kend;
     if (more) fetch(k0 + KS);
-#pragma unroll
-    for (int kk = 0; kk < KS / 4; ++kk) {
-      double a[2], b[4];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) a[t] = sA[cur][(wr * 32 + t * 16 + fc) * LDS_LD + kk * 4 + fr];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) b[t] = sB[cur][(wj * 64 + t * 16 + fc) * LDS_LD + kk * 4 + fr];
-#pragma unroll
-      for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-          acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    {
+      // fragment reads one matrix step ahead of their use, each an instruction of its own
+      const uint32_t pa = lds_addr(&sA[cur][(wr * 32 + fc) * LDS_LD + fr]);
+      const uint32_t pb = lds_addr(&sB[cur][(wj * 64 + fc) * LDS_LD + fr]);
+      constexpr int C16 = 16 * LDS_LD * 8;   // sixteen columns on
+      double a[2][2], b[2][4];
+#define BA_RD(S, K)                                                                                   \
+      a[S][0] = lds_read_b64<(K) * 32>(pa); a[S][1] = lds_read_b64<(K) * 32 + C16>(pa);                 \
+      b[S][0] = lds_read_b64<(K) * 32>(pb); b[S][1] = lds_read_b64<(K) * 32 + C16>(pb);                 \
+      b[S][2] = lds_read_b64<(K) * 32 + 2 * C16>(pb); b[S][3] = lds_read_b64<(K) * 32 + 3 * C16>(pb);
+#define BA_MM(S)                                                                                      \
+      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                                \
+      _Pragma("unroll") for (int tb = 0; tb < 4; ++tb)                                                \
+        acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[S][ta], b[S][tb], acc[ta][tb], 0, 0, 0);
+      static_assert(KS == 16, "four matrix steps per staging step");
+      BA_RD(0, 0)
+      BA_RD(1, 1)
+      lds_wait<6>(a[0][0], a[0][1], b[0][0], b[0][1], b[0][2], b[0][3]);
+      BA_MM(0)
+      BA_RD(0, 2)
+      lds_wait<6>(a[1][0], a[1][1], b[1][0], b[1][1], b[1][2], b[1][3]);
+      BA_MM(1)
+      BA_RD(1, 3)
+      lds_wait<6>(a[0][0], a[0][1], b[0][0], b[0][1], b[0][2], b[0][3]);
+      BA_MM(0)
+      lds_wait<0>(a[1][0], a[1][1], b[1][0], b[1][1], b[1][2], b[1][3]);
+      BA_MM(1)
+#undef BA_RD
+#undef BA_MM
     }
     if (more) stash(cur ^ 1);   // (the other buffer was last read before the previous barrier)
     __syncthreads();

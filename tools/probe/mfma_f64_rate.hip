@@ -39,6 +39,6 @@ void run(int wgs_per_cu) {
   hipFree(out);
 }
 int main() {
-  run<4>(1); run<4>(2); run<8>(1); run<8>(2); run<16>(1);
+  run<4>(1); run<4>(2); run<4>(3); run<4>(4); run<8>(1); run<8>(2); run<16>(1); run<2>(4); run<2>(8);
   return 0;
 }
