@@ -2180,6 +2180,16 @@ int bo_ss_draw(bo_ss *m) {
  *                                               SeasonalStateModel.cpp:89-104, :248-258)
  *   ArStateModel(lags)                         (lags components, phi, 1 variance,
  *                                               ArPosteriorSampler)
+ *   StaticInterceptStateModel                  (1 component, T = 1, no state error, no
+ *                                               parameter and no sampler: the value is its
+ *                                               initial draw, moved by the smoother only;
+ *                                               StaticInterceptStateModel.hpp:35-131, .cpp:29-54)
+ *   TrigStateModel(period, frequencies)        (2 components per frequency, T = the 2 x 2
+ *                                               rotations [[c, s], [-s, c]] of 2 pi f / period,
+ *                                               Z = 1 at each pair's first component, ONE error
+ *                                               variance for all components with its
+ *                                               ZeroMeanGaussianConjSampler;
+ *                                               TrigStateModel.cpp:130-223)
  * SURVEY 8f row f2.  State vector = the blocks one after the other, dimension
  * m <= 64.
  *   Z      ones at the first element of each block
@@ -2208,6 +2218,9 @@ typedef struct {
   /* ArStateModel: coefficients and the NeRegSuf of the block's first element on the
    * block's previous value */
   double phi[BO_AR_MAX], ar_xtx[BO_AR_MAX * BO_AR_MAX], ar_xty[BO_AR_MAX], ar_yty, ar_n;
+  /* TrigStateModel: the rotation of pair q (components first + 2 q, first + 2 q + 1) */
+  int nfreq;
+  double trig_cos[BO_SSM_MAX / 2], trig_sin[BO_SSM_MAX / 2];
 } bo_ssm_block;
 
 struct bo_ssm {
@@ -2217,6 +2230,7 @@ struct bo_ssm {
   uint8_t *observed;
   bo_ssvs *reg;
   double a0[BO_SSM_MAX], P0[BO_SSM_MAX]; /* initial mean, initial variance (diagonal) */
+  int nz, zpos[BO_SSM_MAX];               /* the components Z selects (observation_matrix: ones there) */
   bo_rng state_rng;
   int latent_initialized;
   double *state; /* m x T, column t = state at t */
@@ -2248,7 +2262,8 @@ int bo_ssm_block_stream_id(const bo_ssm *m, int b, int v) {
     const int k = m->blk[i].kind;
     if (((k == BO_BLK_LOCAL_LINEAR_TREND) ? BO_BLK_LOCAL_LEVEL : k) == fam) ++occ;
   }
-  const int base = (kind == BO_BLK_SEASONAL) ? 7 : (kind == BO_BLK_AR) ? 12 : (v == 0 ? 1 : 6);
+  const int base = (kind == BO_BLK_SEASONAL) ? 7 : (kind == BO_BLK_AR) ? 12 : (kind == BO_BLK_TRIG) ? 13
+                   : (v == 0 ? 1 : 6);
   return base + 16 * occ;
 }
 
@@ -2326,10 +2341,24 @@ int bo_ssm_add_block(bo_ssm *m, int kind, const int *iparams, const double *var_
       b->lags = iparams[0];
       b->dim = b->lags;
       break;
+    case BO_BLK_STATIC_INTERCEPT: b->dim = 1; b->nvar = 0; break;   /* (no parameter, no sampler) */
+    case BO_BLK_TRIG:
+      /* iparams = {number of frequencies}; initial_phi = the rotations' (cos, sin) pairs, as
+       * the transition matrix holds them (TrigStateModel.cpp:144-153) */
+      if (!iparams || iparams[0] < 1 || 2 * iparams[0] > BO_SSM_MAX || !initial_phi) return BO_ERR_INVALID;
+      b->nfreq = iparams[0];
+      b->dim = 2 * b->nfreq;
+      for (int q = 0; q < b->nfreq; ++q) {
+        b->trig_cos[q] = initial_phi[2 * q];
+        b->trig_sin[q] = initial_phi[2 * q + 1];
+      }
+      break;
     default: return BO_ERR_INVALID;
   }
   if (m->m + b->dim > BO_SSM_MAX) return BO_ERR_INVALID;
   b->first = m->m;
+  /* observation_matrix: one at the block's first component (every pair's first: trig) */
+  for (int i = 0; i < b->dim; i += (kind == BO_BLK_TRIG ? 2 : b->dim)) m->zpos[m->nz++] = b->first + i;
   for (int v = 0; v < b->nvar; ++v) {
     b->sigsq[v] = var_initial_sigma[v] * var_initial_sigma[v];
     b->prior_df[v] = 2 * (var_df[v] / 2.0);
@@ -2508,6 +2537,14 @@ static void ssm_T(const bo_ssm *m, double *x, int t) {
         first_entry += b->phi[i] * s[i];
         if (i > 0) s[i] = s[i - 1]; else s[i] = first_entry;
       }
+    } else if (b->kind == BO_BLK_TRIG) {
+      /* BlockDiagonalMatrixBlock of DenseMatrix rotations: lhs = rotation * rhs, a row at a time
+       * (Matrix::mult: the row's products summed from the left) */
+      for (int q = 0; q < b->nfreq; ++q) {
+        const double c = b->trig_cos[q], sn = b->trig_sin[q], x0 = s[2 * q], x1 = s[2 * q + 1];
+        s[2 * q] = c * x0 + sn * x1;
+        s[2 * q + 1] = -sn * x0 + c * x1;
+      }
     }
   }
 }
@@ -2530,12 +2567,19 @@ static void ssm_Tt(const bo_ssm *m, double *x, int t) {
       double tmp[BO_AR_MAX];
       for (int i = 0; i < n; ++i) tmp[i] = b->phi[i] * s[0] + (i + 1 < n ? s[i + 1] : 0);
       for (int i = 0; i < n; ++i) s[i] = tmp[i];
+    } else if (b->kind == BO_BLK_TRIG) {
+      /* the rotations' transposes */
+      for (int q = 0; q < b->nfreq; ++q) {
+        const double c = b->trig_cos[q], sn = b->trig_sin[q], x0 = s[2 * q], x1 = s[2 * q + 1];
+        s[2 * q] = c * x0 + -sn * x1;
+        s[2 * q + 1] = sn * x0 + c * x1;
+      }
     }
   }
 }
 static double ssm_Zdot(const bo_ssm *m, const double *x) {
-  double ans = x[m->blk[0].first];
-  for (int b = 1; b < m->nblocks; ++b) ans += x[m->blk[b].first];
+  double ans = x[m->zpos[0]];
+  for (int b = 1; b < m->nz; ++b) ans += x[m->zpos[b]];
   return ans;
 }
 /* the diagonal of RQR_t */
@@ -2544,6 +2588,12 @@ static void ssm_rqr(const bo_ssm *m, double *d, int t) {
   for (int bi = 0; bi < m->nblocks; ++bi) {
     const bo_ssm_block *b = &m->blk[bi];
     if (b->kind == BO_BLK_SEASONAL && !blk_moves(b, t)) continue;   /* RQR1_ = ZeroMatrix */
+    if (b->kind == BO_BLK_STATIC_INTERCEPT) continue;                /* state_variance_matrix: ZeroMatrix(1) */
+    if (b->kind == BO_BLK_TRIG) {
+      /* ConstantMatrixParamView(2 nfreq, sigsq): sigsq on the whole diagonal */
+      for (int i = 0; i < b->dim; ++i) d[b->first + i] = b->sigsq[0];
+      continue;
+    }
     d[b->first] = b->sigsq[0];
     if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) d[b->first + 1] = b->sigsq[1];
   }
@@ -2557,8 +2607,8 @@ static int ssm_update(const bo_ssm *M, int t, double y, int missing, double H,
   const int m = M->m;
   double PZ[BO_SSM_MAX], TPZ[BO_SSM_MAX], rqr[BO_SSM_MAX];
   for (int i = 0; i < m; ++i) {
-    PZ[i] = P[IDX(i, M->blk[0].first, m)];
-    for (int b = 1; b < M->nblocks; ++b) PZ[i] += P[IDX(i, M->blk[b].first, m)];
+    PZ[i] = P[IDX(i, M->zpos[0], m)];
+    for (int b = 1; b < M->nz; ++b) PZ[i] += P[IDX(i, M->zpos[b], m)];
   }
   *F = ssm_Zdot(M, PZ) + H;
   if (*F <= 0) return BO_ERR_FORECAST_VARIANCE;
@@ -2616,7 +2666,7 @@ static void ssm_disturbance_smooth(const bo_ssm *M, const double *v,
     double rt_1[BO_SSM_MAX];
     for (int i = 0; i < m; ++i) rt_1[i] = r[i];
     ssm_Tt(M, rt_1, t);
-    for (int b = 0; b < M->nblocks; ++b) rt_1[M->blk[b].first] += coefficient;
+    for (int b = 0; b < M->nz; ++b) rt_1[M->zpos[b]] += coefficient;
     for (int i = 0; i < m; ++i) rout[IDX(i, t, m)] = r[i];
     for (int i = 0; i < m; ++i) r[i] = rt_1[i];
   }
@@ -2644,6 +2694,12 @@ static void ssm_state_error(const bo_ssm *M, bo_rng *rng, double *eta, int t) {
     } else if (b->kind == BO_BLK_SEASONAL) {
       /* SeasonalStateModel.cpp:124-146: only when the next time point starts a season */
       if (blk_new_season(b, t + 1)) eta[b->first] = bo_rnorm(rng, 0, sqrt(b->sigsq[0]));
+    } else if (b->kind == BO_BLK_STATIC_INTERCEPT) {
+      /* StaticInterceptStateModel.hpp:52-54: eta[0] = 0.0, the generator is not touched */
+    } else if (b->kind == BO_BLK_TRIG) {
+      /* TrigStateModel.cpp:218-223: rnorm_mt(rng, 0, sigma) per component, in order */
+      const double sigma = sqrt(b->sigsq[0]);
+      for (int i = 0; i < b->dim; ++i) eta[b->first + i] = bo_rnorm(rng, 0, sigma);
     } else {
       /* ArStateModel::simulate_state_error, ArStateModel.cpp:85-90: rnorm_mt(rng) * sigma() */
       eta[b->first] = bo_rnorm(rng, 0, 1) * sqrt(b->sigsq[0]);
@@ -2705,8 +2761,9 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
       for (int bi = 0; bi < M->nblocks; ++bi) {
         const bo_ssm_block *b = &M->blk[bi];
         const int f = b->first;
-        if (b->kind == BO_BLK_LOCAL_LEVEL) {
-          /* LocalLevelStateModel::simulate_initial_state, LocalLevelStateModel.cpp:66-69 */
+        if (b->kind == BO_BLK_LOCAL_LEVEL || b->kind == BO_BLK_STATIC_INTERCEPT) {
+          /* LocalLevelStateModel::simulate_initial_state, LocalLevelStateModel.cpp:66-69;
+           * StaticInterceptStateModel.cpp:39-43 */
           st[f] = bo_rnorm(rng, M->a0[f], sqrt(M->P0[f]));
         } else {
           /* StateModelBase::simulate_initial_state: rmvn_mt(mean, variance), diagonal here */
@@ -2773,6 +2830,21 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
             b->mv_sumsq[i] += w * w * (b->mv_n - 1);
             double w2 = err[i] - b->mv_ybar[i];
             b->mv_sumsq[i] += w2 * w2 * 1;
+          }
+        } else if (b->kind == BO_BLK_STATIC_INTERCEPT) {
+          /* observe_state: "There is nothing to do here." (StaticInterceptStateModel.hpp:45-47) */
+        } else if (b->kind == BO_BLK_TRIG) {
+          /* TrigStateModel::observe_state, TrigStateModel.cpp:182-193: every component's
+           * now - (rotation * then) into the error distribution's GaussianSuf */
+          for (int q = 0; q < b->nfreq; ++q) {
+            const double c = b->trig_cos[q], sn = b->trig_sin[q];
+            const double r0 = c * then[f + 2 * q] + sn * then[f + 2 * q + 1];
+            const double r1 = -sn * then[f + 2 * q] + c * then[f + 2 * q + 1];
+            const double e0 = st[f + 2 * q] - r0, e1 = st[f + 2 * q + 1] - r1;
+            b->suf_n[0] += 1;
+            b->suf_ss[0] += e0 * e0;
+            b->suf_n[0] += 1;
+            b->suf_ss[0] += e1 * e1;
           }
         } else if (b->kind == BO_BLK_SEASONAL) {
           /* SeasonalStateModelBase::observe_state, SeasonalStateModel.cpp:74-86 */

@@ -233,7 +233,12 @@ void bo_ss_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX
  * local level; 2: local linear trend; + optional SeasonalStateModel(nseasons, 1);
  * three-element arrays indexed level, slope, seasonal); bo_ssm_create_empty +
  * bo_ssm_add_block build any list. */
-enum { BO_BLK_LOCAL_LEVEL = 1, BO_BLK_LOCAL_LINEAR_TREND = 2, BO_BLK_SEASONAL = 3, BO_BLK_AR = 4 };
+enum { BO_BLK_LOCAL_LEVEL = 1, BO_BLK_LOCAL_LINEAR_TREND = 2, BO_BLK_SEASONAL = 3, BO_BLK_AR = 4,
+       /* round 6 (VERDICT r5 task 8): StaticInterceptStateModel (no parameter: the var_*
+        * arrays are not read), TrigStateModel (iparams = {number of frequencies}; the
+        * rotations' (cos, sin) pairs, two doubles per frequency, go in through
+        * initial_phi; one variance for all its components) */
+       BO_BLK_STATIC_INTERCEPT = 5, BO_BLK_TRIG = 6 };
 typedef struct bo_ssm bo_ssm;
 bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
                       const uint8_t *observed, const double *prior_mean,

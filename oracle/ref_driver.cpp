@@ -46,6 +46,8 @@
 #include "Models/TimeSeries/PosteriorSamplers/ArPosteriorSampler.hpp"
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
+#include "Models/StateSpace/StateModels/StaticInterceptStateModel.hpp"
+#include "Models/StateSpace/StateModels/TrigStateModel.hpp"
 #include "Models/PosteriorSamplers/ZeroMeanMvnIndependenceSampler.hpp"
 #include "Models/StateSpace/StateSpaceRegressionModel.hpp"
 #include "cpputil/shuffle.hpp"
@@ -809,7 +811,11 @@ int ref_ssm_forecast(int T, int p, const double *y, const double *X, const doubl
 // nblocks blocks; kinds[b] = 1 LocalLevelStateModel, 2 LocalLinearTrendStateModel (one
 // ZeroMeanMvnIndependenceSampler per variance), 3 SeasonalStateModel(iparams[3 b],
 // iparams[3 b + 1]) with set_time_of_first_observation(iparams[3 b + 2]), 4
-// ArStateModel(iparams[3 b]) + ArPosteriorSampler.  vpar[8 b + 4 v + {0, 1, 2, 3}] = prior
+// ArStateModel(iparams[3 b]) + ArPosteriorSampler, 5 StaticInterceptStateModel (no
+// parameter, no sampler), 6 TrigStateModel(period = phi0[16 b], the iparams[3 b] <= 15
+// frequencies phi0[16 b + 1 ..]) with a ZeroMeanGaussianConjSampler on its error
+// distribution, as bsts builds it (Interfaces/R/bsts/src/create_state_model.cpp:559-586).
+// vpar[8 b + 4 v + {0, 1, 2, 3}] = prior
 // df, prior sigma guess, sigma upper limit (inf: none), initial sigma of variance v of
 // block b; phi0[16 b ..] the initial autoregression coefficients; a0 / P0: the blocks'
 // initial state means / variances (diagonal) one after the other.
@@ -820,6 +826,8 @@ struct GeneralState {
   std::vector<Ptr<LocalLinearTrendStateModel>> llt;
   std::vector<Ptr<SeasonalStateModel>> seasonal;
   std::vector<Ptr<ArStateModel>> ar;
+  std::vector<Ptr<StaticInterceptStateModel>> intercept;
+  std::vector<Ptr<TrigStateModel>> trig;
   std::vector<int> kind, slot;   // per block: which vector, which element
 };
 
@@ -885,6 +893,34 @@ static void add_general_state(StateSpaceRegressionModel *model, GeneralState &G,
       model->add_state(seasonal);
       G.slot.push_back((int)G.seasonal.size());
       G.seasonal.push_back(seasonal);
+      first += n;
+    } else if (kinds[b] == 5) {
+      Ptr<StaticInterceptStateModel> icpt(new StaticInterceptStateModel);
+      icpt->set_initial_state_mean(a0[first]);
+      icpt->set_initial_state_variance(P0[first]);
+      model->add_state(icpt);
+      G.slot.push_back((int)G.intercept.size());
+      G.intercept.push_back(icpt);
+      first += 1;
+    } else if (kinds[b] == 6) {
+      const int nf = iparams[3 * b];
+      Ptr<TrigStateModel> trig(new TrigStateModel(phi0[16 * b], make_vector(nf, phi0 + 16 * b + 1)));
+      trig->error_distribution()->set_sigsq(vp[3] * vp[3]);
+      if (with_samplers) {
+        NEW(ChisqModel, innovation_precision_prior)(vp[0], vp[1]);
+        NEW(ZeroMeanGaussianConjSampler, s)(trig->error_distribution(), innovation_precision_prior);
+        if (std::isfinite(vp[2])) s->set_sigma_upper_limit(vp[2]);
+        trig->set_method(s);
+      }
+      const int n = 2 * nf;
+      Vector mean(n);
+      SpdMatrix var(n, 0.0);
+      for (int i = 0; i < n; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+      trig->set_initial_state_mean(mean);
+      trig->set_initial_state_variance(var);
+      model->add_state(trig);
+      G.slot.push_back((int)G.trig.size());
+      G.trig.push_back(trig);
       first += n;
     } else {
       const int L = iparams[3 * b];
@@ -959,6 +995,10 @@ int ref_ssg_run(int T, int p, const double *y, const double *X, const uint8_t *o
         v[1] = G.llt[s]->Sigma()(1, 1);
       } else if (G.kind[b] == 3) {
         v[0] = G.seasonal[s]->sigsq();
+      } else if (G.kind[b] == 5) {
+        // (no parameter)
+      } else if (G.kind[b] == 6) {
+        v[0] = G.trig[s]->error_distribution()->sigsq();
       } else {
         v[0] = G.ar[s]->sigsq();
         const int L = iparams[3 * b];
@@ -1001,7 +1041,8 @@ int ref_ssg_forecast(int T, int p, const double *y, const double *X, const doubl
   for (int k = 0; k < nblocks; ++k) {
     vpar[8 * k + 3] = std::sqrt(sigsq[2 * k]);
     vpar[8 * k + 7] = std::sqrt(sigsq[2 * k + 1]);
-    m += kinds[k] == 1 ? 1 : kinds[k] == 2 ? 2 : kinds[k] == 3 ? iparams[3 * k] - 1 : iparams[3 * k];
+    m += (kinds[k] == 1 || kinds[k] == 5) ? 1 : kinds[k] == 2 ? 2 : kinds[k] == 3 ? iparams[3 * k] - 1
+         : kinds[k] == 6 ? 2 * iparams[3 * k] : iparams[3 * k];
   }
   std::vector<double> a0(m, 0.0), P0(m, 1.0);
   GeneralState G;

@@ -142,22 +142,38 @@ def structural_spec(y, trend, nseasons, ar_lags=0):
 
 
 KIND_LOCAL_LEVEL, KIND_LOCAL_LINEAR_TREND, KIND_SEASONAL, KIND_AR = 1, 2, 3, 4
+KIND_STATIC_INTERCEPT, KIND_TRIG = 5, 6
+
+
+def trig_rotations(period, frequencies):
+    """the (cos, sin) pairs of TrigStateModel's rotation blocks as the reference computes them
+    (TrigStateModel.cpp:144-147: freq = 2 * Constants::pi * f / period; C's cos / sin, which
+    math.cos / math.sin call -- numpy's vector forms may differ in the last bit)"""
+    import math
+    out = []
+    for f in frequencies:
+        w = 2 * 3.141592653589793 * float(f) / float(period)
+        out += [math.cos(w), math.sin(w)]
+    return np.array(out)
 
 
 def general_spec(y, blocks):
     """a list of state models in the order they are added (add_state), bsts-style
     defaults as structural_spec.  blocks: tuples ("level",), ("trend",), ("seasonal",
-    nseasons, duration[, time_of_first_observation]), ("ar", lags[, initial_phi]).
+    nseasons, duration[, time_of_first_observation]), ("ar", lags[, initial_phi]),
+    ("intercept",) (StaticInterceptStateModel), ("trig", period, frequencies) (TrigStateModel).
     Returns the list of block dicts the oracle / reference / engine wrappers take."""
     sdy = float(np.std(y, ddof=1))
     out = []
     first = True
-    init_sigma = {"level": [1.0], "trend": [1.0, 0.5], "seasonal": [0.7], "ar": [1.0]}
+    init_sigma = {"level": [1.0], "trend": [1.0, 0.5], "seasonal": [0.7], "ar": [1.0], "intercept": [],
+                  "trig": [0.4]}
     for b in blocks:
         name = b[0]
         kind = {"level": KIND_LOCAL_LEVEL, "trend": KIND_LOCAL_LINEAR_TREND,
-                "seasonal": KIND_SEASONAL, "ar": KIND_AR}[name]
-        nv = 2 if name == "trend" else 1
+                "seasonal": KIND_SEASONAL, "ar": KIND_AR, "intercept": KIND_STATIC_INTERCEPT,
+                "trig": KIND_TRIG}[name]
+        nv = 2 if name == "trend" else (0 if name == "intercept" else 1)
         d = dict(kind=kind, nseasons=0, duration=1, t0=0, lags=0,
                  df=np.full(nv, 0.01), sigma_guess=np.full(nv, 0.01 * sdy),
                  sigma_upper_limit=np.full(nv, sdy),
@@ -171,10 +187,17 @@ def general_spec(y, blocks):
             d["initial_phi"] = (np.asarray(b[2], float) if len(b) > 2
                                 else np.zeros(d["lags"]))
             dim = d["lags"]
+        elif name == "intercept":
+            dim = 1
+        elif name == "trig":
+            d["period"] = float(b[1])
+            d["frequencies"] = np.asarray(b[2], float)
+            d["rotations"] = trig_rotations(d["period"], d["frequencies"])
+            dim = 2 * len(d["frequencies"])
         else:
             dim = nv
         a0 = np.zeros(dim)
-        if first and name in ("level", "trend"):
+        if first and name in ("level", "trend", "intercept"):
             a0[0] = float(y[0])
             first = False
         d["a0"] = a0
@@ -197,6 +220,13 @@ def general_arrays(blocks):
         elif b["kind"] == KIND_AR:
             ip[i, 0] = b["lags"]
             phi0[i, :b["lags"]] = b["initial_phi"]
+        elif b["kind"] == KIND_TRIG:
+            # (ref_ssg_run: the number of frequencies; the period, then the frequencies)
+            nf = len(b["frequencies"])
+            assert nf <= 15
+            ip[i, 0] = nf
+            phi0[i, 0] = b["period"]
+            phi0[i, 1:1 + nf] = b["frequencies"]
         for v in range(len(b["df"])):
             vpar[i, v] = (b["df"][v], b["sigma_guess"][v], b["sigma_upper_limit"][v],
                           b["initial_sigma"][v])
@@ -212,7 +242,7 @@ def blocks_of(g, prefix=""):
     out, first = [], 0
     for i, k in enumerate(kinds):
         k = int(k)
-        nv = 2 if k == KIND_LOCAL_LINEAR_TREND else 1
+        nv = 2 if k == KIND_LOCAL_LINEAR_TREND else (0 if k == KIND_STATIC_INTERCEPT else 1)
         d = dict(kind=k, nseasons=0, duration=1, t0=0, lags=0, df=vpar[i, :nv, 0],
                  sigma_guess=vpar[i, :nv, 1], sigma_upper_limit=vpar[i, :nv, 2],
                  initial_sigma=vpar[i, :nv, 3], initial_phi=np.zeros(0))
@@ -223,6 +253,13 @@ def blocks_of(g, prefix=""):
             d["lags"] = int(ip[i, 0])
             d["initial_phi"] = phi0[i, :d["lags"]]
             dim = d["lags"]
+        elif k == KIND_STATIC_INTERCEPT:
+            dim = 1
+        elif k == KIND_TRIG:
+            nf = int(ip[i, 0])
+            d["period"], d["frequencies"] = float(phi0[i, 0]), np.array(phi0[i, 1:1 + nf])
+            d["rotations"] = trig_rotations(d["period"], d["frequencies"])
+            dim = 2 * nf
         else:
             dim = nv
         d["a0"], d["P0"], d["dim"] = a0[first:first + dim], P0[first:first + dim], dim
@@ -232,7 +269,7 @@ def blocks_of(g, prefix=""):
 
 
 def general_data(T, p, nsig, seasonals, seed, slope=0.02, missing_frac=0.0, ar_coef=None,
-                 level=True):
+                 level=True, trig=None, intercept=0.0):
     """y = [random walk with drift] + seasonal patterns ((nseasons, duration) pairs) +
     X beta + noise [+ a stationary autoregression]"""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -246,6 +283,12 @@ def general_data(T, p, nsig, seasonals, seed, slope=0.02, missing_frac=0.0, ar_c
         pattern = rng.standard_normal(ns)
         pattern -= pattern.mean()
         y = y + pattern[(np.arange(T) // dur) % ns]
+    for period, freqs in (trig or []):
+        for f in freqs:
+            a, b = rng.standard_normal(2)
+            w = 2 * np.pi * f / period * np.arange(T)
+            y = y + a * np.cos(w) + b * np.sin(w)
+    y = y + intercept
     if ar_coef is not None:
         L = len(ar_coef)
         u = np.zeros(T + 50 + L)

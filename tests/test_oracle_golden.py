@@ -429,6 +429,48 @@ def test_general_forecast_known_answers(oracle):
         assert np.max(np.abs(got - g[key + "_forecast"])) < 1e-12, key
 
 
+GLOB_GOLDENS = ["ssq_intercept_ar", "ssq_intercept_seasonal_missing", "ssq_trig_only", "ssq_trend_trig",
+                "ssq_trig_level_seasonal", "ssq_two_trig_intercept"]
+
+
+@pytest.mark.parametrize("name", GLOB_GOLDENS)
+def test_static_intercept_and_trig_state_models_match_reference(oracle, name):
+    """f2 along its glob (VERDICT r5 task 8): StaticInterceptStateModel (one component, T = 1,
+    no state error, no parameter: StaticInterceptStateModel.hpp:35-131) and TrigStateModel (a
+    2 x 2 rotation per frequency, Z = 1 at every pair's first component, ONE variance for all
+    components: TrigStateModel.cpp:130-223), alone, together, and in lists with the round-4
+    models, missing observations included -- the compiled reference's draws (goldens of
+    make_golden_structural_glob.py)."""
+    from cases import blocks_of
+    g = load(name)
+    blocks = blocks_of(g)
+    obs = g["observed"]
+    o = oracle.ssg_run(g["y"], g["X"], None if obs.all() else obs, prior_of(g), opts_of(g),
+                       blocks, ("mt", int(g["seed"])), g["init_gamma"], int(g["nsweeps"]),
+                       int(g["state_every"]))
+    assert o["status"] == 0
+    assert np.array_equal(o["gamma"], g["gamma"])
+    assert relerr(o["beta"], g["beta"]) < RTOL
+    assert relerr(o["sigsq"], g["sigsq"]) < RTOL
+    assert relerr(o["variances"], g["variances"], 1e-300) < RTOL
+    assert o["state"].shape == g["state"].shape
+    assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
+
+
+def test_glob_forecast_known_answers(oracle):
+    """simulate_forecast with a static intercept (no error term, no draw) and trig blocks
+    (2 nfreq error draws a step, rotations)"""
+    from cases import blocks_of
+    g = load("kat_glob_forecast")
+    for key in g["shapes"]:
+        key = str(key)
+        blocks = blocks_of(g, key + "_")
+        got = oracle.ssg_forecast(oracle.rng_mt(int(g["seed"])), int(g[key + "_T"]), g["newX"],
+                                  g["beta"], float(g["sigsq_obs"]), blocks, g[key + "_sigsq"],
+                                  g[key + "_phi"], g[key + "_final_state"])
+        assert np.max(np.abs(got - g[key + "_forecast"])) < 1e-12, key
+
+
 def test_general_form_repeats_the_template(oracle):
     """the block list [trend, seasonal(ns, 1), ar] is the template of rounds 2-3, draw for
     draw (both Philox and MT generators)"""
