@@ -553,9 +553,10 @@ class Engine:
 
     def ss_set_state_models(self, blocks):
         """a general list of state models, in the order they are added: dicts with kind
-        (1 local level, 2 local linear trend, 3 seasonal, 4 autoregression), nseasons,
-        duration, t0, lags, df, sigma_guess, sigma_upper_limit, initial_sigma (one entry
-        per variance parameter), initial_phi, a0, P0 (tests/cases.py: general_spec)"""
+        (1 local level, 2 local linear trend, 3 seasonal, 4 autoregression, 5 static intercept,
+        6 trig), nseasons, duration, t0, lags, df, sigma_guess, sigma_upper_limit, initial_sigma
+        (one entry per variance parameter; none for kind 5), initial_phi, rotations (kind 6: the
+        (cos, sin) pairs of the transition matrix), a0, P0 (tests/cases.py: general_spec)"""
         self._check(self.lib.ba_ss_clear_state_models(self._h))
         self._blocks = []
         for b in blocks:
@@ -565,15 +566,19 @@ class Engine:
                 ip[:] = (b["nseasons"], b["duration"], b.get("t0", 0))
             elif kind == 4:
                 ip[0] = b["lags"]
+            elif kind == 6:
+                ip[0] = len(b["rotations"]) // 2
             arrs = [np.ascontiguousarray(b[k], dtype=np.float64) for k in
                     ("df", "sigma_guess", "sigma_upper_limit", "initial_sigma")]
-            ph = np.ascontiguousarray(b.get("initial_phi", np.zeros(0)), dtype=np.float64)
+            ph = np.ascontiguousarray(b["rotations"] if kind == 6 else b.get("initial_phi", np.zeros(0)),
+                                      dtype=np.float64)
             a0 = np.ascontiguousarray(b["a0"], dtype=np.float64)
             p0 = np.ascontiguousarray(b["P0"], dtype=np.float64)
             self._check(self.lib.ba_ss_add_state_model(
-                self._h, kind, ip.ctypes.data_as(C.POINTER(C.c_int32)), *[_p(a) for a in arrs],
-                _p(ph) if (kind == 4 and ph.size) else None, _p(a0), _p(p0)))
-            self._blocks.append(dict(kind=kind, nvar=2 if kind == 2 else 1,
+                self._h, kind, ip.ctypes.data_as(C.POINTER(C.c_int32)),
+                *[(_p(a) if a.size else None) for a in arrs],
+                _p(ph) if (kind in (4, 6) and ph.size) else None, _p(a0), _p(p0)))
+            self._blocks.append(dict(kind=kind, nvar=2 if kind == 2 else (0 if kind == 5 else 1),
                                      lags=int(ip[0]) if kind == 4 else 0))
         m, nb = C.c_int32(), C.c_int32()
         self._check(self.lib.ba_ss_state_dimension(self._h, C.byref(m), C.byref(nb)))

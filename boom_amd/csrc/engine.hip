@@ -926,7 +926,8 @@ int escalate(ba_engine *e, std::vector<int32_t> &st) {
 // per chain: K (m T) | state (m T) | smoothed disturbances (nvar T) | normals (<= (nvar + 1) T + m + 1)
 int64_t ssm_work_stride(const ba_engine &e) {
   // (the template kernel keeps four disturbance series and up to five normals a step)
-  const int64_t per_step = std::max(2 * e.ssg.m + 2 * e.ssg.nvar + 1, 2 * e.ssg.m + 9);
+  // (general kernel: a smoothed-disturbance series per state-error row, and as many normals a step + 1)
+  const int64_t per_step = std::max(2 * e.ssg.m + 2 * std::max(e.ssg.nvar, e.ssg.nerr) + 1, 2 * e.ssg.m + 9);
   return per_step * e.T + SSG_MAX_STATE + 72;
 }
 
@@ -935,6 +936,8 @@ int64_t ssm_work_stride(const ba_engine &e) {
 void ssg_template_shape(const SsgSpec &q, int32_t *trend, int32_t *nseasons, int32_t *ar_lags) {
   *trend = *nseasons = *ar_lags = 0;
   if (q.nblocks < 1 || q.nblocks > 3 || q.m > 16) return;
+  for (int i = 0; i < q.nblocks; ++i)
+    if (q.blk[i].nvar == 0) return;   // (a static intercept: the general kernel)
   int b = 0, tr = 0, ns = 0, lags = 0;
   if (q.blk[0].kind == SSG_LOCAL_LEVEL) tr = 1;
   else if (q.blk[0].kind == SSG_LOCAL_LINEAR_TREND) tr = 2;
@@ -3733,7 +3736,12 @@ void ssg_finish(SsgSpec &q) {
   // P's leading dimension: odd (a lane per column and a lane per row both conflict-free), and
   // one of the four values ssg_simsmooth_kernel is compiled for
   q.ld = q.m <= 16 ? 17 : (q.m <= 32 ? 33 : (q.m <= 60 ? 61 : 65));
-  q.nerr = q.nvar;
+  // state-error rows: one per variance slot, except that a trig block's every component has one
+  q.nerr = 0;
+  for (int i = 0; i < q.nblocks; ++i) {
+    q.blk[i].err0 = q.nerr;
+    q.nerr += q.blk[i].kind == SSG_TRIG ? q.blk[i].dim : (q.blk[i].kind == SSG_LOCAL_LINEAR_TREND ? 2 : 1);
+  }
   // steps per block of the passes: the most that leaves FOUR workgroups to a CU's 160 KB of
   // LDS (all 1024 chains of a launch resident; at m = 59 sixteen steps left room for three,
   // and the launch ran as two rounds), never below 8; see ssg_pass_lds_doubles
@@ -3764,9 +3772,10 @@ int ssg_stream_id(const SsgSpec &q, int kind, int v) {
   int occ = 0;
   for (int i = 0; i < q.nblocks; ++i) {
     const int k = q.blk[i].kind;
+    if (q.blk[i].nvar == 0) continue;   // (a static intercept has no sampler: it is in no family)
     if ((k == SSG_LOCAL_LINEAR_TREND ? SSG_LOCAL_LEVEL : k) == fam) ++occ;
   }
-  const int base = kind == SSG_SEASONAL ? 7 : (kind == SSG_AR ? 12 : (v == 0 ? 1 : 6));
+  const int base = kind == SSG_SEASONAL ? 7 : (kind == SSG_AR ? 12 : (kind == SSG_TRIG ? 13 : (v == 0 ? 1 : 6)));
   return base + 16 * occ;
 }
 // model->add_state(...) on the engine's copy of the specification
@@ -3775,7 +3784,8 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
             const double *var_initial_sigma, const double *initial_phi,
             const double *initial_state_mean, const double *initial_state_variance) {
   SsgSpec &q = e->ssg;
-  if (!var_df || !var_sigma_guess || !var_sigma_upper_limit || !var_initial_sigma ||
+  const bool is_static = kind == SSG_STATIC_INTERCEPT;   // (no parameter: the var_* arrays are not read)
+  if ((!is_static && (!var_df || !var_sigma_guess || !var_sigma_upper_limit || !var_initial_sigma)) ||
       !initial_state_mean || !initial_state_variance)
     return fail(BA_E_INVALID, "null argument");
   if (q.nblocks >= SSG_MAX_BLOCKS) return fail(BA_E_INVALID, "more than 8 state models");
@@ -3801,6 +3811,22 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
       k.dim = k.nseasons - 1;
       break;
     }
+    case SSG_STATIC_INTERCEPT:
+      // StaticInterceptStateModel: T = 1, RQR = 0, nothing to learn and no sampler -- a local
+      // level whose variance (a slot of its own, never drawn) is 0
+      k.kind = SSG_LOCAL_LEVEL;
+      k.dim = 1;
+      k.nvar = 0;
+      break;
+    case SSG_TRIG:
+      // TrigStateModel: "At least one frequency needed ..."; the rotations as the transition
+      // matrix holds them: (cos, sin) per frequency in initial_phi
+      if (!iparams || !initial_phi) return fail(BA_E_INVALID, "null argument");
+      if (iparams[0] < 1) return fail(BA_E_INVALID, "At least one frequency needed to initialize TrigStateModel.");
+      if (2 * iparams[0] > SSG_MAX_STATE) return fail(BA_E_INVALID, "state dimension exceeds 64");
+      k.nfreq = iparams[0];
+      k.dim = 2 * k.nfreq;
+      break;
     case SSG_AR:
       if (!iparams) return fail(BA_E_INVALID, "null argument");
       if (iparams[0] < 1) return fail(BA_E_INVALID, "lags must be positive");
@@ -3811,10 +3837,11 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
       k.ar_index = q.nar;
       break;
     default:
-      return fail(BA_E_INVALID, "state model kind must be 1 (local level), 2 (local linear trend), 3 (seasonal) or 4 (autoregression)");
+      return fail(BA_E_INVALID, "state model kind must be 1 (local level), 2 (local linear trend), 3 (seasonal), 4 (autoregression), 5 (static intercept) or 6 (trig)");
   }
+  const int nslot = is_static ? 1 : k.nvar;   // variance slots the block takes
   if (q.m + k.dim > SSG_MAX_STATE) return fail(BA_E_INVALID, "state dimension exceeds 64");
-  if (q.nvar + k.nvar > SSG_MAX_VAR) return fail(BA_E_INVALID, "more than 16 variance parameters");
+  if (q.nvar + nslot > SSG_MAX_VAR) return fail(BA_E_INVALID, "more than 16 variance parameters");
   for (int v = 0; v < k.nvar; ++v) {
     if (var_sigma_upper_limit[v] < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
     if (kind == SSG_AR && !(var_initial_sigma[v] > 0)) return fail(BA_E_INVALID, "initial sigma must be positive");
@@ -3823,7 +3850,7 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
     // (a multivariate initial state goes through a Cholesky factor in the reference: it
     // needs a positive variance; the local level model alone does not)
     const bool ok = initial_state_variance[i] > 0.0 ||
-                    (kind == SSG_LOCAL_LEVEL && initial_state_variance[i] == 0.0);
+                    ((kind == SSG_LOCAL_LEVEL || is_static) && initial_state_variance[i] == 0.0);
     if (!ok) return fail(BA_E_INVALID, "initial state variances must be positive");
   }
   if (kind == SSG_AR && initial_phi && !ar_stationary_host(initial_phi, k.lags))
@@ -3839,9 +3866,18 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
     e->ssg_initial_sigsq[vi] = var_initial_sigma[v] * var_initial_sigma[v];
     k.sid[v] = ssg_stream_id(q, kind, v);
   }
+  if (is_static) {
+    // (the slot: variance 0, a sampler that is never run)
+    q.prior_df[k.var0] = 0.0;
+    q.prior_ss[k.var0] = 0.0;
+    q.sigma_max[k.var0] = std::numeric_limits<double>::infinity();
+    e->ssg_initial_sigsq[k.var0] = 0.0;
+  }
   for (int i = 0; i < k.dim; ++i) {
     q.a0[k.first + i] = initial_state_mean[i];
     q.P0[k.first + i] = initial_state_variance[i];
+    q.trig_c[k.first + i] = kind == SSG_TRIG ? initial_phi[2 * (i / 2)] : 0.0;
+    q.trig_s[k.first + i] = kind == SSG_TRIG ? initial_phi[2 * (i / 2) + 1] : 0.0;
   }
   if (kind == SSG_AR) {
     for (int i = 0; i < AR_MAX; ++i)
@@ -3851,7 +3887,7 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
   q.blk[q.nblocks] = k;
   q.nblocks += 1;
   q.m += k.dim;
-  q.nvar += k.nvar;
+  q.nvar += nslot;
   ssg_finish(q);
   e->ssm_set = true;
   e->ss_level_set = false;

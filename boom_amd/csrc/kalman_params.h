@@ -10,13 +10,17 @@ namespace boom_amd {
 
 // Structural state (ssm_kernel.hip): BOOM's block-diagonal state -- any list of state
 // models in the order they were added (StateSpaceModelBase::add_state): local level,
-// local linear trend, seasonal (nseasons, season duration), autoregression.  State
+// local linear trend, seasonal (nseasons, season duration), autoregression, static intercept
+// (StaticInterceptStateModel: on the device a local level whose variance is 0 and has no
+// sampler -- nvar = 0, one variance SLOT that stays 0), trig (TrigStateModel: a 2 x 2 rotation
+// per frequency, one variance for all 2 nfreq components).  State
 // dimension m <= SSG_MAX_STATE (one lane per component), at most SSG_MAX_BLOCKS blocks,
 // SSG_MAX_VAR variance parameters (two for a local linear trend, one otherwise; an
 // autoregression block's error variance is one of them), SSG_MAX_AR autoregression
 // blocks of at most AR_MAX lags.
 enum { SSG_MAX_STATE = 64, SSG_MAX_BLOCKS = 8, SSG_MAX_VAR = 16, SSG_MAX_AR = 4, AR_MAX = 16 };
-enum { SSG_LOCAL_LEVEL = 1, SSG_LOCAL_LINEAR_TREND = 2, SSG_SEASONAL = 3, SSG_AR = 4 };
+enum { SSG_LOCAL_LEVEL = 1, SSG_LOCAL_LINEAR_TREND = 2, SSG_SEASONAL = 3, SSG_AR = 4,
+       SSG_STATIC_INTERCEPT = 5 /* (the C-ABI's number; stored as SSG_LOCAL_LEVEL with nvar = 0) */, SSG_TRIG = 6 };
 // a chain's ArModel sufficient statistics (per autoregression block): xtx (lags x lags at
 // leading dimension AR_MAX) | xty | yty | n
 enum { AR_SUF_XTY = AR_MAX * AR_MAX, AR_SUF_YTY = AR_SUF_XTY + AR_MAX, AR_SUF_N = AR_SUF_YTY + 1,
@@ -27,17 +31,21 @@ struct SsgBlock {
   int32_t nseasons, duration, phase;   // seasonal: a new season starts at the times u with u % duration == phase
   int32_t lags, ar_index;              // autoregression: which of the chain's coefficient / suf slots
   int32_t sid[2];      // Philox sampler ids of the variance samplers (autoregression: its ArPosteriorSampler's)
+  int32_t nfreq;       // trig: frequencies (dim = 2 nfreq)
+  int32_t err0;        // index of the block's first state-error row (a trig block has dim of them, a trend two, the others one)
 };
 // the specification, in device memory (read through the scalar cache)
 struct SsgSpec {
   int32_t m, nblocks, nvar, nar;
   int32_t ld;          // leading dimension of the state variance in LDS (odd)
   int32_t bl;          // steps per block of the passes (64 for m <= 16, ... 16 for m <= 64)
-  int32_t nerr;        // state-error terms per step (one per variance parameter)
+  int32_t nerr;        // rows of the state that carry state error (one per variance slot; a trig block: every component)
   int32_t pad;
   SsgBlock blk[SSG_MAX_BLOCKS];
   double prior_df[SSG_MAX_VAR], prior_ss[SSG_MAX_VAR], sigma_max[SSG_MAX_VAR];
   double a0[SSG_MAX_STATE], P0[SSG_MAX_STATE];   // initial state mean, variance (diagonal)
+  // trig: the rotation [[c, s], [-s, c]] of the pair a component belongs to (by state component)
+  double trig_c[SSG_MAX_STATE], trig_s[SSG_MAX_STATE];
 };
 struct SsmParams {
   const SsgSpec *spec;                  // device copy

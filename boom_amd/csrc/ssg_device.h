@@ -292,6 +292,7 @@ struct Blocks {
   unsigned always;     // bit b: block b's transition is never the identity (trend, autoregression)
   unsigned seasmask;   // bit b: block b is seasonal
   unsigned armask;     // bit b: block b is an autoregression
+  unsigned trigmask;   // bit b: block b is a trig model (pairs of components that rotate)
   static __device__ __forceinline__ int kind_of(unsigned d) { return (int)(d & 7u); }
   static __device__ __forceinline__ int first_of(unsigned d) { return (int)((d >> 3) & 127u); }
   static __device__ __forceinline__ int dim_of(unsigned d) { return (int)((d >> 10) & 127u); }
@@ -310,9 +311,10 @@ struct Blocks {
       dp = (unsigned)K.duration | ((unsigned)K.phase << 16);
     }
     const int kd = kind_of(desc);
-    always = (unsigned)__ballot(kd == SSG_LOCAL_LINEAR_TREND || kd == SSG_AR);
+    always = (unsigned)__ballot(kd == SSG_LOCAL_LINEAR_TREND || kd == SSG_AR || kd == SSG_TRIG);
     seasmask = (unsigned)__ballot(kd == SSG_SEASONAL);
     armask = (unsigned)__ballot(kd == SSG_AR);
+    trigmask = (unsigned)__ballot(kd == SSG_TRIG);
   }
   // the layout of time t; the transitions are walked from index t + shift on (0: the
   // transition OUT of the time, T_t; -1: the one INTO it, T_{t-1})
@@ -354,9 +356,14 @@ struct LaneInfo {
   int blk, kind, first, dim;    // its block (kind 0: the lane holds no component)
   int cur;                      // seasonal: its block's cursor (a per-lane copy)
   double phi;                   // autoregression: the lane's coefficient
+  double tc = 0.0, ts = 0.0;    // trig: cosine and sine of the lane's pair
   __device__ __forceinline__ bool moves(unsigned mv) const { return kind == SSG_SEASONAL && ((mv >> blk) & 1u); }
-  // is this the lane Z selects in its block (the block's first component)?
-  __device__ __forceinline__ bool zsel(int lane) const { return kind != 0 && lane == first + cur; }
+  // trig: is this the second component of its pair?
+  __device__ __forceinline__ bool todd(int lane) const { return ((lane - first) & 1) != 0; }
+  // is this a lane Z selects in its block (the block's first component; trig: every pair's first)?
+  __device__ __forceinline__ bool zsel(int lane) const {
+    return kind != 0 && (kind == SSG_TRIG ? !todd(lane) : lane == first + cur);
+  }
 };
 
 // Z'x
@@ -385,6 +392,12 @@ __device__ __forceinline__ double vecT(const Blocks &B, const LaneInfo &L, doubl
       if (L.blk == b && lane == L.first) y = tot;
     }
   }
+  // trig: every pair rotates, (x0, x1) -> (c x0 + s x1, -s x0 + c x1)  (the DenseMatrix blocks of
+  // TrigStateModel.cpp:144-153)
+  if (B.trigmask) {
+    const double below = from_below(x);
+    if (L.kind == SSG_TRIG) y = L.todd(lane) ? -L.ts * below + L.tc * x : L.tc * x + L.ts * above;
+  }
   // seasonal, a step into a new season: the slot of the component that drops out receives
   // -(sum over the block)
   unsigned sm = mv & B.seasmask;
@@ -411,6 +424,11 @@ __device__ __forceinline__ double vecTt(const Blocks &B, const LaneInfo &L, doub
       const double firstv = rl(x, Blocks::first_of(B.udesc(b)));
       if (L.blk == b) y = L.phi * firstv + ((lane + 1 < L.first + L.dim) ? above : 0.0);
     }
+  }
+  if (B.trigmask) {
+    // the rotations' transposes: (x0, x1) -> (c x0 - s x1, s x0 + c x1)
+    const double above = from_above(x);
+    if (L.kind == SSG_TRIG) y = L.todd(lane) ? L.ts * below + L.tc * x : L.tc * x + -L.ts * above;
   }
   unsigned sm = mv & B.seasmask;
   while (sm) {

@@ -10,6 +10,12 @@
 //                                            identity / zero inside one
 //                                            (SeasonalStateModel.cpp:89-104, :248-258)
 //   ArStateModel(lags)                       lags components, ArPosteriorSampler
+//   StaticInterceptStateModel                1 component, no state error, no sampler: here a
+//                                            local level whose variance slot stays 0
+//                                            (StaticInterceptStateModel.hpp:35-131)
+//   TrigStateModel(period, frequencies)      2 components per frequency that rotate, Z = 1 at
+//                                            every pair's first, ONE variance for all of them
+//                                            (TrigStateModel.cpp:130-223)
 // SURVEY 8f row f2.
 //
 //   state model samplers                 (ZeroMeanGaussianConjSampler.cpp:57-60,
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   B.load(Q, nb, lane);
   LaneInfo LI{-1, 0, 0, 0, 0, 0.0};
   int var_l = 0;          // the variance parameter behind this lane's state error
+  int erow_l = 0;         // which of the state-error rows this lane's is (the smoothed disturbances' series)
   int cbefore_l = 0;      // error terms drawn at EVERY step ahead of this lane's term
   unsigned sbefore_l = 0; // seasonal blocks ahead of it (their terms are drawn on some steps only)
   int ipos_l = 0;         // position of this lane's normal among those of the initial state
@@ -194,20 +201,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   unsigned seas_active = 0;   // seasonal blocks whose error is drawn at all (sigma != 0)
   int nfirst = 0;         // normals of the initial state
   {
-    int cb = 0, ip = 0;
+    int cb = 0, ip = 0, eb = 0;
     unsigned sb = 0;
     for (int b = 0; b < nb; ++b) {
       const unsigned d = B.udesc(b);
       const int f = Blocks::first_of(d), n = Blocks::dim_of(d), kd = Blocks::kind_of(d), v0 = Blocks::var0_of(d);
       const bool mine = lane >= f && lane < f + n;
       const bool second = kd == SSG_LOCAL_LINEAR_TREND && lane == f + 1;
+      const int within = kd == SSG_TRIG ? lane - f : (second ? 1 : 0);   // (a trig block: an error term per component)
       if (mine) {
         LI.blk = b; LI.kind = kd; LI.first = f; LI.dim = n;
         var_l = v0 + (second ? 1 : 0);
-        cbefore_l = cb + (second ? 1 : 0);
+        cbefore_l = cb + within;
+        erow_l = eb + within;
         sbefore_l = sb;
         if (kd == SSG_AR) LI.phi = s_phi[Blocks::arx_of(d) * AR_MAX + (lane - f)];
+        if (kd == SSG_TRIG) { LI.tc = Q.trig_c[lane]; LI.ts = Q.trig_s[lane]; }
       }
+      eb += kd == SSG_TRIG ? n : (kd == SSG_LOCAL_LINEAR_TREND ? 2 : 1);
       // the initial state's normals: a local level draws rnorm(a0, sd0) (nothing when
       // sd0 == 0), every other model rmvn: one per component
       if (kd == SSG_LOCAL_LEVEL) {
@@ -219,11 +230,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         ip += n;
       }
       // the state errors of a step: local level: one if sigma != 0; trend: two, always;
-      // seasonal: one on the steps into a new season if sigma != 0; autoregression: one, always
+      // seasonal: one on the steps into a new season if sigma != 0; autoregression: one, always;
+      // trig: rnorm_mt(0, sigma) per component, i.e. dim of them if sigma != 0
       const bool nz = s_sig2[v0] != 0.0;
       if (kd == SSG_LOCAL_LEVEL) cb += nz ? 1 : 0;
       else if (kd == SSG_LOCAL_LINEAR_TREND) cb += 2;
       else if (kd == SSG_AR) cb += 1;
+      else if (kd == SSG_TRIG) cb += nz ? n : 0;
       else {
         if (nz) seas_active |= 1u << b;
         sb |= 1u << b;
@@ -340,6 +353,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           for (int b = 0; b < SSG_MAX_BLOCKS; ++b)
             if (b < nb) PZ += pz[b];
         }
+        // (a trig block: Z selects every pair's first component, not the block's alone)
+        {
+          unsigned tq = B.trigmask;
+          while (tq) {
+            const int b = __ffs((int)tq) - 1;
+            tq &= tq - 1;
+            const unsigned d = B.udesc(b);
+            const int f = Blocks::first_of(d), n = Blocks::dim_of(d);
+#pragma nounroll
+            for (int i = 2; i < n; i += 2)
+              if (mylane) PZ += s_P[(f + i) * ld + lane];
+          }
+        }
         const double F = zdot<SMALL>(LI, PZ, lane) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
         if (lane == s) F_l = F;
@@ -412,6 +438,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
               // component, -(sum over the block)
               if (moves) col[sprev((int)(B.urc(b) >> 16), n) * ld] = cs;
             }
+          } else if (kd == SSG_TRIG) {
+            // the rotations from the left, a pair of the column's entries at a time
+#pragma nounroll
+            for (int i = 0; i < n; i += 2) {
+              double v0 = col[i * ld], v1 = col[(i + 1) * ld];
+              if (obs) {
+                v0 -= (s_tv[f + i] * PZ) * Finv;
+                v1 -= (s_tv[f + i + 1] * PZ) * Finv;
+              }
+              const double c = Q.trig_c[f + i], sn = Q.trig_s[f + i];
+              col[i * ld] = c * v0 + sn * v1;
+              col[(i + 1) * ld] = -sn * v0 + c * v1;
+            }
           } else {
             // autoregression (logical order): from the last lag down, moving each entry
             // one place on as it is read
@@ -473,6 +512,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma nounroll
             for (; j0 < n; ++j0) cs -= row[j0];
             row[w] = cs + (lane == f + w ? sg : 0.0);
+          } else if (kd == SSG_TRIG) {
+            // the rotations' transposes from the right, + RQR (sigma^2 on the block's whole diagonal)
+#pragma nounroll
+            for (int j = 0; j < n; j += 2) {
+              const double r0 = row[j], r1 = row[j + 1];
+              const double c = Q.trig_c[f + j], sn = Q.trig_s[f + j];
+              row[j] = (c * r0 + sn * r1) + (lane == f + j ? sg : 0.0);
+              row[j + 1] = (-sn * r0 + c * r1) + (lane == f + j + 1 ? sg : 0.0);
+            }
           } else {
             const double *ph = s_phi + Blocks::arx_of(d) * AR_MAX;
             double cs = 0.0;
@@ -499,6 +547,29 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           }
         }
         wave_lds_sync();
+        // -- a trig block's two passes are not the same sums in the same order (T from the left
+        // in one, another block's T' from the right in the other): its rows and columns are made
+        // symmetric the way the reference does after every update (fix_near_symmetry,
+        // SpdMatrix.cpp:350-357) -- lane k averages P(i, k) and P(k, i) for the block's rows i
+        if (B.trigmask) {
+          unsigned tq = B.trigmask;
+          while (tq) {
+            const int b = __ffs((int)tq) - 1;
+            tq &= tq - 1;
+            const unsigned d = B.udesc(b);
+            const int f = Blocks::first_of(d), n = Blocks::dim_of(d);
+#pragma nounroll
+            for (int i = 0; i < n; i += 2) {
+              if (!mylane) continue;
+              double *cu = s_P + (f + i) * ld + lane, *ro = s_P + lane * ld + f + i;
+              const double a0 = cu[0], a1 = cu[ld], b0 = ro[0], b1 = ro[1];
+              const double m0 = .5 * (a0 + b0), m1 = .5 * (a1 + b1);
+              cu[0] = m0; ro[0] = m0;
+              cu[ld] = m1; ro[1] = m1;
+            }
+          }
+          wave_lds_sync();
+        }
         advance(B, LI, mv, lane);
       }
       if (status != CHAIN_OK) break;
@@ -547,6 +618,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           if (LI.kind == SSG_LOCAL_LEVEL) err = sig_l != 0.0;
           else if (LI.kind == SSG_LOCAL_LINEAR_TREND) err = true;
           else if (LI.kind == SSG_AR) err = lane == LI.first;
+          else if (LI.kind == SSG_TRIG) err = sig_l != 0.0;
           else if (LI.kind == SSG_SEASONAL) err = ((act >> LI.blk) & 1u) && lane == LI.first + LI.cur;
           const double z = err ? s_z[zo + cbefore_l + __popc(act & sbefore_l)] : 0.0;
           alpha += sd_l * z;
@@ -626,9 +698,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       if (mylane) {
         bool carrier;
         if (LI.kind == SSG_SEASONAL) carrier = lane == LI.first + LI.cur;
-        else if (LI.kind == SSG_LOCAL_LINEAR_TREND) carrier = true;
+        else if (LI.kind == SSG_LOCAL_LINEAR_TREND || LI.kind == SSG_TRIG) carrier = true;
         else carrier = lane == LI.first;
-        if (carrier) s_z[var_l * BL + s] = r;
+        if (carrier) s_z[erow_l * BL + s] = r;
       }
       const double kr = wsum<SMALL>(K * r);
       const double coef = rl(ef_l, s) - kr;
@@ -679,10 +751,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           bool carrier = false;
           if (mylane) {
             if (LI.kind == SSG_SEASONAL) carrier = LI.moves(mv) && lane == LI.first + LI.cur;
-            else if (LI.kind == SSG_LOCAL_LINEAR_TREND) carrier = true;
+            else if (LI.kind == SSG_LOCAL_LINEAR_TREND || LI.kind == SSG_TRIG) carrier = true;
             else carrier = lane == LI.first;
           }
-          if (carrier) mc += sig_l * s_z[var_l * BL + s];
+          if (carrier) mc += sig_l * s_z[erow_l * BL + s];
         } else {
           advance(B, LI, 0u, lane);
         }
@@ -742,10 +814,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           advance(B, LI, 0u, lane);
         }
         const double then1 = from_above(prev);
+        const double thenb = B.trigmask ? from_below(prev) : 0.0;
         if (tb + s > 0) {
           if (LI.kind == SSG_LOCAL_LEVEL) {
             const double diff = st - prev;
             suf_l += diff * diff;
+          } else if (LI.kind == SSG_TRIG) {
+            // now - rotation * then, every component (TrigStateModel::observe_state, TrigStateModel.cpp:182-193)
+            const double rot = LI.todd(lane) ? -LI.ts * thenb + LI.tc * prev : LI.tc * prev + LI.ts * then1;
+            const double e = st - rot;
+            suf_l += e * e;
           } else if (LI.kind == SSG_LOCAL_LINEAR_TREND) {
             // err = now - T then; MvnSuf::update_raw (MvnBase.cpp:71-86), diagonal only
             const double err = st - ((lane == LI.first) ? prev + then1 : prev);
@@ -816,6 +894,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         M.var_n[at + (lane - f)] = mv_n;
         M.var_ss[at + (lane - f)] = ssv;
       }
+    } else if (kd == SSG_TRIG) {
+      // one GaussianSuf for all the block's components
+      const double tot = wsum<SMALL>(LI.blk == b ? suf_l : 0.0);
+      if (lane == f) {
+        M.var_n[at] = (double)n * (double)(T - 1);
+        M.var_ss[at] = tot;
+      }
     } else if (kd == SSG_SEASONAL) {
       // (the lane that accumulated moved with the cursor: sum over the block)
       const double tot = wsum<SMALL>(LI.blk == b ? suf_l : 0.0);
@@ -882,6 +967,17 @@ __global__ __launch_bounds__(64) void ssg_forecast_kernel(SsParams P, int horizo
         const double x1 = rl(st, f + 1);
         if (lane == f) nx = (st + x1) + (sqrt(sg[0]) * z0 + 0.0);
         if (lane == f + 1) nx = st + (sqrt(sg[1]) * z1 + 0.0);
+      } else if (K.kind == SSG_TRIG) {
+        // rnorm_mt(rng, 0, sigma) per component, in order (TrigStateModel.cpp:218-223), on the rotated state
+        const double sd = sqrt(sg[0]);
+        const double above = from_above(st), below = from_below(st);
+        const double c = mine ? Q.trig_c[lane] : 0.0, sn = mine ? Q.trig_s[lane] : 0.0;
+        double e4 = 0.0;
+        for (int q = 0; q < n; ++q) {
+          const double eq = d_rnorm(rng, 0.0, sd);
+          if (lane == f + q) e4 = eq;
+        }
+        if (mine) nx = (((lane - f) & 1) ? -sn * below + c * st : c * st + sn * above) + e4;
       } else if (K.kind == SSG_SEASONAL) {
         if ((tm + 1) % K.duration == K.phase) {
           const double e2 = d_rnorm(rng, 0.0, sqrt(sg[0]));
@@ -902,8 +998,15 @@ __global__ __launch_bounds__(64) void ssg_forecast_kernel(SsParams P, int horizo
       }
     }
     st = (lane < m) ? nx : 0.0;
-    double zs = rl(st, Q.blk[0].first);
-    for (int b = 1; b < nb; ++b) zs += rl(st, Q.blk[b].first);
+    // Z'state: the blocks' first components (a trig block: every pair's first), in state order
+    double zs = 0.0;
+    for (int b = 0; b < nb; ++b) {
+      const SsgBlock &K = Q.blk[b];
+      for (int i = 0; i < (K.kind == SSG_TRIG ? K.dim : 1); i += 2) {
+        const double zv = rl(st, K.first + i);
+        zs = (b == 0 && i == 0) ? zv : zs + zv;
+      }
+    }
     const double obs = d_rnorm(rng, zs, sd_obs);
     double part = 0.0;
     for (int j = lane; j < p; j += WAVE) part += newX[(size_t)j * horizon + i] * beta[j];

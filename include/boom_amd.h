@@ -446,7 +446,19 @@ int ba_ss_set_local_level(ba_engine *e, double level_df,
  *           proposals for phi, accepted when stationary, else one coefficient at a time
  *           from a truncated normal -- the reference's Tn2Sampler on the device,
  *           distributions/Tn2Sampler.cpp:25-131 --; then sigma)          lags
- * iparams is ignored for kinds 1 and 2 (may be NULL).  The var_* arrays hold one entry
+ *   kind 5  StaticInterceptStateModel (StateModels/StaticInterceptStateModel.hpp:35-131,
+ *           .cpp:29-54): T = 1, no state error, no parameter and no sampler -- the var_*
+ *           arrays are not read (may be NULL); its value is its initial draw
+ *           N(initial_state_mean, initial_state_variance >= 0), moved by the smoother  1
+ *   kind 6  TrigStateModel(period, frequencies) (StateModels/TrigStateModel.cpp:130-223):
+ *           iparams[0] = the number of frequencies (<= 32); initial_phi = the 2 x 2 rotations
+ *           of the transition matrix, (cos, sin) of 2 pi f / period per frequency, as
+ *           state_transition_matrix(0) holds them (the caller computes them -- or reads them
+ *           off the reference's model object -- so that no second cosine routine is involved);
+ *           Z = 1 at every pair's first component; ONE variance for all components with its
+ *           ZeroMeanGaussianConjSampler(ChisqModel(df, sigma_guess)), as bsts builds it
+ *           (Interfaces/R/bsts/src/create_state_model.cpp:559-586)          2 x frequencies
+ * iparams is ignored for kinds 1, 2 and 5 (may be NULL).  The var_* arrays hold one entry
  * per variance parameter of the model (two for kind 2: level, slope; one otherwise):
  * ChisqModel(df, sigma_guess) prior, sigma upper limit (infinity: none), initial sigma.
  * initial_phi: lags entries, NULL = zeros; must be stationary, as ArModel's constructor
@@ -456,7 +468,7 @@ int ba_ss_set_local_level(ba_engine *e, double level_df,
  * variance's diagonal; positive, a local level's may be 0).  Limits: state dimension
  * <= 64, 8 state models, 16 variance parameters, 4 autoregression models.
  * RNG streams: variance parameter v of a model reads the chain's sampler id 1 (level),
- * 6 (slope), 7 (seasonal) or 12 (ArPosteriorSampler: the proposals' normals, then the
+ * 6 (slope), 7 (seasonal), 13 (trig) or 12 (ArPosteriorSampler: the proposals' normals, then the
  * sigma draw -- the reference takes the proposals from GlobalRng::rng and the rest from
  * the sampler's generator) + 16 for every earlier model of the same family (local level
  * and local linear trend are one family); the state draw reads stream 2. */

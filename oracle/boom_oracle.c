@@ -3173,6 +3173,8 @@ void bo_ssm_simulate_forecast_ar(bo_rng *rng, int horizon, int p, const double *
     for (int i = 0; i < ar_lags; ++i) b->phi[i] = phi[i];
     M.m += ar_lags;
   }
+  /* (observation_matrix: one at every block's first component) */
+  for (int k = 0; k < M.nblocks; ++k) M.zpos[M.nz++] = M.blk[k].first;
   bo_ssm_forecast_model(&M, rng, horizon, p, newX, beta, sigsq_obs, final_state, out);
 }
 void bo_ssm_simulate_forecast(bo_rng *rng, int horizon, int p, const double *newX,

@@ -223,10 +223,10 @@ def general_arrays(blocks):
         elif b["kind"] == KIND_TRIG:
             # (ref_ssg_run: the number of frequencies; the period, then the frequencies)
             nf = len(b["frequencies"])
-            assert nf <= 15
             ip[i, 0] = nf
-            phi0[i, 0] = b["period"]
-            phi0[i, 1:1 + nf] = b["frequencies"]
+            if nf <= 15:     # (what fits ref_ssg_run's sixteen slots; the oracle and the engine take b["rotations"])
+                phi0[i, 0] = b["period"]
+                phi0[i, 1:1 + nf] = b["frequencies"]
         for v in range(len(b["df"])):
             vpar[i, v] = (b["df"][v], b["sigma_guess"][v], b["sigma_upper_limit"][v],
                           b["initial_sigma"][v])
