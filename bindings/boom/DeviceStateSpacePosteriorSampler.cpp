@@ -7,6 +7,8 @@
 #include "Models/StateSpace/StateModels/LocalLevelStateModel.hpp"
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
+#include "Models/StateSpace/StateModels/StaticInterceptStateModel.hpp"
+#include "Models/StateSpace/StateModels/TrigStateModel.hpp"
 #include "cpputil/math_utils.hpp"
 #include "cpputil/report_error.hpp"
 #include "distributions/rng.hpp"
@@ -119,9 +121,14 @@ namespace BOOM {
         b.kind = 3; b.dim = seas->nseasons() - 1;
       } else if (const ArStateModel *ar = dynamic_cast<const ArStateModel *>(sm)) {
         b.kind = 4; b.lags = ar->number_of_lags(); b.dim = b.lags;
+      } else if (dynamic_cast<const StaticInterceptStateModel *>(sm)) {
+        b.kind = 5; b.dim = 1; b.nvar = 0;   // (nothing to learn: no entry in state_variance_priors)
+      } else if (dynamic_cast<const TrigStateModel *>(sm)) {
+        b.kind = 6; b.dim = static_cast<int>(sm->state_dimension());   // (one variance for all 2 x frequencies components)
       } else {
         report_error("The device sampler takes LocalLevelStateModel, LocalLinearTrendStateModel, "
-                     "SeasonalStateModel and ArStateModel state models.");
+                     "SeasonalStateModel, ArStateModel, StaticInterceptStateModel and TrigStateModel "
+                     "state models.");
       }
       nvar += b.nvar;
       state_dim_ += b.dim;
@@ -213,15 +220,27 @@ namespace BOOM {
           ip[2] = nseasonal < seasonal_time_of_first_observation.size()
                       ? seasonal_time_of_first_observation[nseasonal] : 0;
           ++nseasonal;
-        } else {
+        } else if (b.kind == 4) {
           const ArStateModel *ar = dynamic_cast<const ArStateModel *>(sm);
           init[0] = ar->sigma();
           ip[0] = b.lags;
           phi = ar->phi();
-        }
+        } else if (b.kind == 6) {
+          // the rotations as the model's own transition matrix holds them (TrigStateModel.cpp:144-153:
+          // [[cos, sin], [-sin, cos]] per frequency): no second cosine routine is involved
+          TrigStateModel *trig = const_cast<TrigStateModel *>(dynamic_cast<const TrigStateModel *>(sm));
+          init[0] = trig->error_distribution()->sigma();
+          ip[0] = b.dim / 2;
+          const Matrix Tm = sm->state_transition_matrix(0)->dense();
+          phi.resize(b.dim);
+          for (int q = 0; q < b.dim / 2; ++q) {
+            phi[2 * q] = Tm(2 * q, 2 * q);
+            phi[2 * q + 1] = Tm(2 * q, 2 * q + 1);
+          }
+        }   // (5, StaticInterceptStateModel: no parameter)
         for (ba_engine *e : engines_)
           check(ba_ss_add_state_model(e, b.kind, ip, df, guess, upper, init,
-                                      b.kind == 4 ? phi.data() : nullptr, a0.data(), v0.data()));
+                                      (b.kind == 4 || b.kind == 6) ? phi.data() : nullptr, a0.data(), v0.data()));
       }
     }
 
@@ -336,10 +355,12 @@ namespace BOOM {
     state_variances = Vector(variance_priors_.size(), 0.0);
     if (structural_) {
       check(ba_ss_get_state_draw(eng, lc, state.data()));
-      for (size_t s = 0; s < blocks_.size(); ++s)
+      for (size_t s = 0; s < blocks_.size(); ++s) {
+        if (blocks_[s].nvar == 0) continue;   // (a StaticInterceptStateModel has no parameter)
         check(ba_ss_get_state_model(eng, lc, static_cast<int32_t>(s),
                                     &state_variances[blocks_[s].var0], nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr));
+      }
     } else {
       check(ba_ss_get_state(eng, lc, state.data(), &state_variances[0], nullptr, nullptr));
     }
@@ -381,6 +402,10 @@ namespace BOOM {
         dynamic_cast<LocalLinearTrendStateModel *>(sm)->set_Sigma(Sigma);
       } else if (b.kind == 3) {
         dynamic_cast<SeasonalStateModel *>(sm)->set_sigsq(variances[b.var0]);
+      } else if (b.kind == 5) {
+        // (StaticInterceptStateModel: nothing but its state, installed below)
+      } else if (b.kind == 6) {
+        dynamic_cast<TrigStateModel *>(sm)->error_distribution()->set_sigsq(variances[b.var0]);
       } else {
         Vector phi(b.lags, 0.0);
         double ar_sigsq = 1.0;

@@ -138,7 +138,7 @@ namespace BOOM {
     unsigned long device_seed_;
     // the state models as the engine knows them
     struct Block {
-      int kind;    // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression
+      int kind;    // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression, 5 static intercept, 6 trig
       int var0;    // index of its first variance parameter (into state_variance_priors)
       int nvar, dim, lags;
     };

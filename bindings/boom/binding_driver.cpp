@@ -15,6 +15,8 @@
 #include "Models/StateSpace/StateModels/LocalLevelStateModel.hpp"
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
+#include "Models/StateSpace/StateModels/StaticInterceptStateModel.hpp"
+#include "Models/StateSpace/StateModels/TrigStateModel.hpp"
 #include "Models/MvnModel.hpp"
 #include "LinAlg/Matrix.hpp"
 #include "LinAlg/SpdMatrix.hpp"
@@ -661,6 +663,26 @@ int ref_binding_ssg_run(int T, int p, const double *y, const double *X, const ui
         seasonal->set_initial_state_variance(var);
         model->add_state(seasonal);
         vprior(0);
+      } else if (kinds[b] == 5) {
+        NEW(StaticInterceptStateModel, icpt)();
+        icpt->set_initial_state_mean(a0[first]);
+        icpt->set_initial_state_variance(P0[first]);
+        model->add_state(icpt);
+        dim = 1;   // (no parameter: no variance prior)
+      } else if (kinds[b] == 6) {
+        const int nf = iparams[3 * b];
+        Vector freqs(nf);
+        for (int i = 0; i < nf; ++i) freqs[i] = phi0[16 * b + 1 + i];
+        NEW(TrigStateModel, trig)(phi0[16 * b], freqs);
+        trig->error_distribution()->set_sigsq(vp[3] * vp[3]);
+        dim = 2 * nf;
+        Vector mean(dim);
+        SpdMatrix var(dim, 0.0);
+        for (int i = 0; i < dim; ++i) { mean[i] = a0[first + i]; var(i, i) = P0[first + i]; }
+        trig->set_initial_state_mean(mean);
+        trig->set_initial_state_variance(var);
+        model->add_state(trig);
+        vprior(0);
       } else {
         dim = iparams[3 * b];
         NEW(ArStateModel, arm)(dim);
@@ -711,6 +733,10 @@ int ref_binding_ssg_run(int T, int p, const double *y, const double *X, const ui
           v[1] = S(1, 1);
         } else if (kinds[b] == 3) {
           v[0] = dynamic_cast<SeasonalStateModel *>(sm)->sigsq();
+        } else if (kinds[b] == 5) {
+          // (no parameter)
+        } else if (kinds[b] == 6) {
+          v[0] = dynamic_cast<TrigStateModel *>(sm)->error_distribution()->sigsq();
         } else {
           ArStateModel *arm = dynamic_cast<ArStateModel *>(sm);
           v[0] = arm->sigsq();

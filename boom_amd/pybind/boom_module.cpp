@@ -350,6 +350,27 @@ PYBIND11_MODULE(_boom, boom) {
            py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
            "ArPosteriorSampler(model, ChisqModel(df, sigma_guess)) + set_sigma_upper_limit");
 
+  py::class_<StaticInterceptStateModel, Ptr<StaticInterceptStateModel>>(boom, "StaticInterceptStateModel")
+      .def(py::init<>())
+      .def_property_readonly("state_dimension", &StaticInterceptStateModel::state_dimension)
+      .def("set_initial_state_mean", &StaticInterceptStateModel::set_initial_state_mean)
+      .def("set_initial_state_variance", &StaticInterceptStateModel::set_initial_state_variance);
+
+  py::class_<TrigStateModel, Ptr<TrigStateModel>>(boom, "TrigStateModel")
+      .def(py::init([](double period, const NpArray &frequencies) {
+             return new TrigStateModel(period, vector_from(frequencies));
+           }),
+           py::arg("period"), py::arg("frequencies"))
+      .def_property_readonly("state_dimension", &TrigStateModel::state_dimension)
+      .def("set_sigsq", &TrigStateModel::set_sigsq)
+      .def("set_initial_state_mean", [](TrigStateModel &m, const NpArray &v) { m.set_initial_state_mean(vector_from(v)); })
+      .def("set_initial_state_variance",
+           [](TrigStateModel &m, const NpArray &v) { m.set_initial_state_variance(vector_from(v)); },
+           "the diagonal of the initial state's variance")
+      .def("set_prior", &TrigStateModel::set_prior, py::arg("df"), py::arg("sigma_guess"),
+           py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
+           "ZeroMeanGaussianConjSampler(error_distribution(), ChisqModel(df, sigma_guess)) + set_sigma_upper_limit");
+
   py::class_<StateSpaceRegressionModel, Ptr<StateSpaceRegressionModel>>(boom, "StateSpaceRegressionModel")
       .def(py::init([](const NpArray &response, const NpArray &predictors, const std::vector<bool> &is_observed,
                        int chains, uint64_t seed, int device) {
@@ -365,6 +386,8 @@ PYBIND11_MODULE(_boom, boom) {
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<LocalLinearTrendStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<SeasonalStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<ArStateModel> &s) { m.add_state(s); })
+      .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<StaticInterceptStateModel> &s) { m.add_state(s); })
+      .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<TrigStateModel> &s) { m.add_state(s); })
       .def_property_readonly("number_of_state_models", &StateSpaceRegressionModel::number_of_state_models)
       .def("ar_phi", [](const StateSpaceRegressionModel &m, int chain, int which) { return to_numpy(m.ar_phi(chain, which)); },
            py::arg("chain") = 0, py::arg("which") = 0,

@@ -421,6 +421,56 @@ class ArStateModel {
   double sigma_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
 };
 
+// StaticInterceptStateModel (StateModels/StaticInterceptStateModel.hpp:35-131): one component,
+// T = 1, no state error, nothing to learn; set_initial_state_mean / _variance are its prior
+class StaticInterceptStateModel {
+ public:
+  StaticInterceptStateModel() {}
+  int state_dimension() const { return 1; }
+  void set_initial_state_mean(double m) { a0_ = m; }
+  void set_initial_state_variance(double v) {
+    if (v < 0) report_error("Initial state variance must be non-negative.");
+    P0_ = v;
+  }
+  double a0_ = 0.0, P0_ = 1.0;
+};
+
+// TrigStateModel(period, frequencies) (StateModels/TrigStateModel.hpp:83, .cpp:130-223): a
+// cosine / sine pair per frequency that rotates by 2 pi f / period a step, one error variance
+// for all components with a ZeroMeanGaussianConjSampler (set_prior), as bsts builds it
+class TrigStateModel {
+ public:
+  TrigStateModel(double period, const Vector &frequencies) : period_(period), frequencies_(frequencies) {
+    if (frequencies.size() == 0) report_error("At least one frequency needed to initialize TrigStateModel.");
+    const int n = 2 * (int)frequencies.size();
+    a0_ = Vector(n, 0.0);
+    P0_ = Vector(n, 1.0);
+    rotations_ = Vector(n, 0.0);
+    for (int i = 0; i < (int)frequencies.size(); ++i) {
+      const double freq = 2 * 3.141592653589793 * frequencies[i] / period;   // (Constants::pi)
+      rotations_[2 * i] = std::cos(freq);
+      rotations_[2 * i + 1] = std::sin(freq);
+    }
+  }
+  int state_dimension() const { return (int)a0_.size(); }
+  void set_sigsq(double s) { sigma_ = std::sqrt(s); }
+  void set_initial_state_mean(const Vector &m) {
+    if ((int)m.size() != state_dimension()) report_error("Argument to TrigStateModel::set_initial_state_mean is of the wrong size.");
+    a0_ = m;
+  }
+  void set_initial_state_variance(const Vector &diagonal) {
+    if ((int)diagonal.size() != state_dimension()) report_error("Argument to TrigStateModel::set_initial_state_variance has the wrong number of rows.");
+    P0_ = diagonal;
+  }
+  // ZeroMeanGaussianConjSampler(error_distribution(), ChisqModel(df, sigma_guess)) + set_sigma_upper_limit
+  void set_prior(double df, double sigma_guess, double sigma_upper_limit = infinity()) {
+    df_ = df; guess_ = sigma_guess; upper_ = sigma_upper_limit;
+  }
+  double period_;
+  Vector frequencies_, rotations_, a0_, P0_;
+  double sigma_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
+};
+
 class StateSpaceRegressionModel : public Model {
  public:
   StateSpaceRegressionModel(const Vector &y, const Matrix &X, const std::vector<bool> &observed,
@@ -433,17 +483,20 @@ class StateSpaceRegressionModel : public Model {
   }
   // add_state, in any order and number (StateSpaceModelBase.hpp:637-638): the list goes to
   // the device when the sampler is attached or at the first draw (finalize_state)
-  void add_state(const Ptr<LocalLevelStateModel> &s) { models_.push_back(Entry{1, s, nullptr, nullptr, nullptr}); finalized_ = false; }
-  void add_state(const Ptr<LocalLinearTrendStateModel> &s) { models_.push_back(Entry{2, nullptr, s, nullptr, nullptr}); finalized_ = false; }
-  void add_state(const Ptr<SeasonalStateModel> &s) { models_.push_back(Entry{3, nullptr, nullptr, s, nullptr}); finalized_ = false; }
-  void add_state(const Ptr<ArStateModel> &s) { models_.push_back(Entry{4, nullptr, nullptr, nullptr, s}); finalized_ = false; }
+  void add_state(const Ptr<LocalLevelStateModel> &s) { Entry e; e.kind = 1; e.level = s; models_.push_back(e); finalized_ = false; }
+  void add_state(const Ptr<LocalLinearTrendStateModel> &s) { Entry e; e.kind = 2; e.trend = s; models_.push_back(e); finalized_ = false; }
+  void add_state(const Ptr<SeasonalStateModel> &s) { Entry e; e.kind = 3; e.seasonal = s; models_.push_back(e); finalized_ = false; }
+  void add_state(const Ptr<ArStateModel> &s) { Entry e; e.kind = 4; e.ar = s; models_.push_back(e); finalized_ = false; }
+  void add_state(const Ptr<StaticInterceptStateModel> &s) { Entry e; e.kind = 5; e.intercept = s; models_.push_back(e); finalized_ = false; }
+  void add_state(const Ptr<TrigStateModel> &s) { Entry e; e.kind = 6; e.trig = s; models_.push_back(e); finalized_ = false; }
   int number_of_state_models() const { return (int)models_.size(); }
   // anything but a lone local level (which runs the local-level kernels)
   bool structural() const { return !(models_.size() == 1 && models_[0].kind == 1); }
   int state_dimension() const {
     int m = 0;
     for (const Entry &e : models_)
-      m += e.kind == 1 ? 1 : e.kind == 2 ? 2 : e.kind == 3 ? e.seasonal->state_dimension() : e.ar->lags_;
+      m += (e.kind == 1 || e.kind == 5) ? 1 : e.kind == 2 ? 2 : e.kind == 3 ? e.seasonal->state_dimension()
+           : e.kind == 6 ? e.trig->state_dimension() : e.ar->lags_;
     return m;
   }
   void finalize_state() {
@@ -466,6 +519,13 @@ class StateSpaceRegressionModel : public Model {
           const SeasonalStateModel &s = *e.seasonal;
           const int32_t ip[3] = {s.nseasons_, s.duration_, s.t0_};
           eng_->check(ba_ss_add_state_model(h, 3, ip, &s.df_, &s.guess_, &s.upper_, &s.sigma_, nullptr, s.a0_.data(), s.P0_.data()));
+        } else if (e.kind == 5) {
+          const StaticInterceptStateModel &s = *e.intercept;
+          eng_->check(ba_ss_add_state_model(h, 5, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &s.a0_, &s.P0_));
+        } else if (e.kind == 6) {
+          const TrigStateModel &s = *e.trig;
+          const int32_t ip[3] = {(int32_t)s.frequencies_.size(), 0, 0};
+          eng_->check(ba_ss_add_state_model(h, 6, ip, &s.df_, &s.guess_, &s.upper_, &s.sigma_, s.rotations_.data(), s.a0_.data(), s.P0_.data()));
         } else {
           const ArStateModel &s = *e.ar;
           const int32_t ip[3] = {s.lags_, 0, 0};
@@ -498,10 +558,11 @@ class StateSpaceRegressionModel : public Model {
     return st;
   }
   // every variance parameter in state-model order (a local linear trend has two: level,
-  // slope; an autoregression's is its error variance)
+  // slope; an autoregression's is its error variance; a static intercept has none)
   Vector state_variances(int chain = 0) const {
     std::vector<double> out;
     for (size_t b = 0; b < models_.size(); ++b) {
+      if (models_[b].kind == 5) continue;
       double v[2] = {0, 0};
       eng_->check(ba_ss_get_state_model(eng_->get(), chain, (int32_t)b, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
       out.push_back(v[0]);
@@ -527,11 +588,13 @@ class StateSpaceRegressionModel : public Model {
   }
  private:
   struct Entry {
-    int kind;   // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression
+    int kind = 0;   // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression, 5 static intercept, 6 trig
     Ptr<LocalLevelStateModel> level;
     Ptr<LocalLinearTrendStateModel> trend;
     Ptr<SeasonalStateModel> seasonal;
     Ptr<ArStateModel> ar;
+    Ptr<StaticInterceptStateModel> intercept;
+    Ptr<TrigStateModel> trig;
   };
   int ar_block(int which) const {
     int seen = 0;

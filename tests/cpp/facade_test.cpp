@@ -392,6 +392,62 @@ static void AutoregressiveState() {
   EXPECT(st.nrow() == 3 && st.ncol() == T);
 }
 
+// ... a static intercept and a harmonic (trig) component -- round 6, SURVEY 8f-2's glob: the
+// shape of Models/StateSpace/StateModels/tests/Trig_test.cc (a sinusoid of known period)
+static void TrigAndStaticInterceptState() {
+  const int T = 480, p = 3, chains = 8;
+  std::mt19937_64 gen(29);
+  std::normal_distribution<double> N(0, 1);
+  Matrix X(T, p);
+  Vector y(T), coef = {1.5, 0.0, -2.0};
+  const double period = 24.0, icpt = 7.5;
+  for (int t = 0; t < T; ++t) {
+    const double w = 2 * 3.141592653589793 * t / period;
+    double mu = icpt + 2.0 * std::cos(w) - 1.2 * std::sin(w) + 0.7 * std::cos(2 * w);
+    for (int j = 0; j < p; ++j) { X(t, j) = N(gen); mu += X(t, j) * coef[j]; }
+    y[t] = mu + 0.2 * N(gen);
+  }
+  StateSpaceRegressionModel model(y, X, std::vector<bool>(), chains, 13);
+  Ptr<StaticInterceptStateModel> intercept(new StaticInterceptStateModel);
+  intercept->set_initial_state_mean(y[0]);
+  intercept->set_initial_state_variance(25.0);
+  model.add_state(intercept);
+  Ptr<TrigStateModel> trig(new TrigStateModel(period, Vector{1.0, 2.0}));
+  trig->set_sigsq(0.01);
+  trig->set_initial_state_variance(Vector(4, 9.0));
+  trig->set_prior(1.0, 0.02, 0.5);
+  model.add_state(trig);
+  EXPECT(model.number_of_state_models() == 2);
+  EXPECT(model.state_dimension() == 5);
+  SpdMatrix om(p, p, 0.0);
+  for (int j = 0; j < p; ++j) om(j, j) = 0.01;
+  Ptr<MvnGivenScalarSigma> slab(new MvnGivenScalarSigma(Vector(p, 0.0), om));
+  Ptr<ChisqModel> siginv(new ChisqModel(1.0, 0.5));
+  Ptr<VariableSelectionPrior> spike(new VariableSelectionPrior(p, 0.5));
+  Ptr<StateSpacePosteriorSampler> sampler(new StateSpacePosteriorSampler(&model, slab, siginv, spike));
+  model.set_method(sampler);
+  for (int i = 0; i < 300; ++i) model.sample_posterior();
+  for (int c : {0, chains - 1}) {
+    Matrix st = model.structural_state(c);
+    EXPECT(st.nrow() == 5 && st.ncol() == T);
+    // the intercept does not move in time (T = 1, no state error) and is the series' level
+    int moved = 0;
+    for (int t = 1; t < T; ++t) moved += std::fabs(st(0, t) - st(0, 0)) > 1e-9 * std::fabs(st(0, 0)) ? 1 : 0;
+    EXPECT(moved == 0);
+    EXPECT(std::fabs(st(0, 0) - icpt) < 0.3);
+    // intercept + the two harmonics' first components track y - X coef
+    double err = 0;
+    for (int t = 0; t < T; ++t) {
+      double target = y[t];
+      for (int j = 0; j < p; ++j) target -= X(t, j) * coef[j];
+      err += std::fabs(st(0, t) + st(1, t) + st(3, t) - target);
+    }
+    EXPECT(err / T < 0.3);
+  }
+  Vector v = model.state_variances(0);   // (the trig model's one variance; the intercept has none)
+  EXPECT(v.size() == 1 && v[0] > 0 && v[0] <= 0.25);
+}
+
 // the logit / probit spike-and-slab samplers in the reference's shape:
 // model.set_method(new BinomialLogitSpikeSlabSampler(&model, slab, spike))
 template <class MODEL, class SAMPLER>
@@ -564,6 +620,7 @@ int main() {
     StateSpace();
     StructuralTimeSeries();
     AutoregressiveState();
+    TrigAndStaticInterceptState();
     AnyStateList();
     BinomialSpikeSlab<BinomialLogitModel, BinomialLogitSpikeSlabSampler>(true);
     BinomialSpikeSlab<BinomialProbitModel, BinomialProbitSpikeSlabSampler>(false);

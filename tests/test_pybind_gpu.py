@@ -268,6 +268,61 @@ def test_any_state_list_on_the_pybind_module():
     assert np.array_equal(model.state(chains - 1), eng.ss_get_state_draw(chains - 1).T)
 
 
+def test_static_intercept_and_trig_on_the_pybind_module():
+    """round 6: boom.StaticInterceptStateModel and boom.TrigStateModel handed to add_state (the
+    module computes the rotations from period and frequencies as the reference does) == the
+    engine through the C-ABI on the block list of tests/cases.py, bit for bit"""
+    import boom_amd
+    import boom_amd._boom as boom
+    from cases import bsts_priors, general_data, general_spec
+    T, p, seed, chains, niter = 96, 4, 21, 4, 9
+    desc = [("intercept",), ("trig", 12.0, [1.0, 2.0, 3.0]), ("level",)]
+    X, y, _, obs = general_data(T, p, 2, [], seed=15, missing_frac=0.03, trig=[(12.0, [1.0, 2.0])], intercept=4.0)
+    prior, _, sig_up = bsts_priors(X, y, 2)
+    blocks = general_spec(y, desc)
+    model = boom.StateSpaceRegressionModel(y, X, [bool(o) for o in obs], chains=chains, seed=seed)
+    b = blocks[0]
+    icpt = boom.StaticInterceptStateModel()
+    icpt.set_initial_state_mean(b["a0"][0])
+    icpt.set_initial_state_variance(b["P0"][0])
+    b = blocks[1]
+    trig = boom.TrigStateModel(12.0, np.array([1.0, 2.0, 3.0]))
+    trig.set_sigsq(b["initial_sigma"][0] ** 2)
+    trig.set_prior(b["df"][0], b["sigma_guess"][0], b["sigma_upper_limit"][0])
+    trig.set_initial_state_mean(b["a0"])
+    trig.set_initial_state_variance(b["P0"])
+    b = blocks[2]
+    level = boom.LocalLevelStateModel(b["initial_sigma"][0])
+    level.set_prior(b["df"][0], b["sigma_guess"][0], b["sigma_upper_limit"][0])
+    level.set_initial_state_mean(b["a0"][0])
+    level.set_initial_state_variance(b["P0"][0])
+    for sm in (icpt, trig, level):
+        model.add_state(sm)
+    assert model.number_of_state_models == 3 and model.state_dimension == 8 and trig.state_dimension == 6
+    sampler = boom.StateSpacePosteriorSampler(model, boom.MvnGivenScalarSigma(prior["b"], prior["ominv"]),
+                                              boom.ChisqModel(prior["df"], prior["sigma_guess"]),
+                                              boom.VariableSelectionPrior(prior["pi"]), sig_up)
+    sampler.set_lookahead(4)
+    model.set_method(sampler)
+    eng = boom_amd.Engine(chains, seed=seed)
+    eng.ss_set_data(y, X, obs)
+    eng.set_priors(prior["b"], prior["ominv"], prior["pi"], prior["df"], prior["sigma_guess"],
+                   sigma_upper_limit=sig_up)
+    eng.ss_set_state_models(blocks)
+    eng.set_state(np.zeros(p, np.uint8))
+    for it in range(niter):
+        model.sample_posterior()
+        eng.ss_sweep(1)
+        G, B, S = model.chain_states()
+        g, bb, s = eng.get_states()
+        assert np.array_equal(G, g) and np.array_equal(B, bb) and np.array_equal(S, s), it
+        assert np.array_equal(model.state(0), eng.ss_get_state_draw(0).T), it
+        want = np.concatenate([eng.ss_get_state_model(0, k)["variances"] for k in range(3)])
+        assert len(want) == 2 and np.array_equal(model.state_variances(0), want), it
+    st = model.state(chains - 1)
+    assert np.all(st[0] == st[0, 0])     # the intercept is one number per draw
+
+
 def test_poisson_spike_slab_on_the_pybind_module():
     """boom.PoissonRegressionModel + PoissonRegressionSpikeSlabSampler: the draws of the
     engine through the C-ABI (ba_poisson_*), the mixture table handed over as data"""

@@ -382,6 +382,9 @@ def test_regression_priors_changed_under_the_state_space_sampler(oracle):
     ([("seasonal", 4, 3, 2), ("level",), ("ar", 2)], 150, 0.0, 1),         # any order, a first-observation offset
     ([("trend",), ("seasonal", 52, 7)], 400, 0.0, 4),                      # m = 53
     ([("level",), ("seasonal", 5, 2)], 90, 0.0, -3),                       # a device list of two (look-ahead 3)
+    # round 6: StaticInterceptStateModel and TrigStateModel objects handed to add_state
+    ([("intercept",), ("trig", 12.0, [1.0, 2.0]), ("ar", 1)], 110, 0.02, 8),
+    ([("trig", 7.0, [1.0, 2.0, 3.0]), ("trend",), ("intercept",)], 130, 0.0, -4),
 ])
 def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler(oracle, desc, T, missing,
                                                                                  lookahead):
@@ -405,7 +408,9 @@ def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler
     seas = [(b[1], b[2]) for b in desc if b[0] == "seasonal"]
     X, y, _, obs = general_data(T, p, 2, seas[:2], seed=31 + T, missing_frac=missing,
                                 ar_coef=[0.5] if any(b[0] == "ar" for b in desc) else None,
-                                level=any(b[0] in ("level", "trend") for b in desc))
+                                level=any(b[0] in ("level", "trend") for b in desc),
+                                trig=[(b[1], b[2][:2]) for b in desc if b[0] == "trig"],
+                                intercept=2.0 if any(b[0] == "intercept" for b in desc) else 0.0)
     prior, _, sig_up = bsts_priors(X, y, 2)
     blocks = general_spec(y, desc)
     kinds, ip, vpar, phi0, a0, P0 = general_arrays(blocks)
