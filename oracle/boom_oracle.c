@@ -2190,6 +2190,14 @@ int bo_ss_draw(bo_ss *m) {
  *                                               variance for all components with its
  *                                               ZeroMeanGaussianConjSampler;
  *                                               TrigStateModel.cpp:130-223)
+ *   SemilocalLinearTrendStateModel             (3 components: level, slope, the slope's
+ *                                               long-run mean; T = [[1, 1, 0], [0, phi, 1 - phi],
+ *                                               [0, 0, 1]]; errors on level and slope; the level's
+ *                                               ZeroMeanGaussianConjSampler and the slope's
+ *                                               NonzeroMeanAr1Sampler (mu, phi, sigma), as bsts
+ *                                               builds it; SemilocalLinearTrend.cpp:29-272,
+ *                                               NonzeroMeanAr1Sampler.cpp:51-155,
+ *                                               NonzeroMeanAr1Model.cpp:31-120)
  * SURVEY 8f row f2.  State vector = the blocks one after the other, dimension
  * m <= 64.
  *   Z      ones at the first element of each block
@@ -2218,6 +2226,11 @@ typedef struct {
   /* ArStateModel: coefficients and the NeRegSuf of the block's first element on the
    * block's previous value */
   double phi[BO_AR_MAX], ar_xtx[BO_AR_MAX * BO_AR_MAX], ar_xty[BO_AR_MAX], ar_yty, ar_n;
+  /* SemilocalLinearTrendStateModel: the slope's NonzeroMeanAr1Model (mu, phi; sigsq[1]), its
+   * Ar1Suf, the sampler's priors (mean: N(m, s^2); phi: N(m, s^2)) and switches */
+  double sl_mu, sl_phi, sl_mean_prior[2], sl_phi_prior[2];
+  int sl_truncate_phi, sl_force_positive;
+  double a1_sumsq, a1_sum, a1_cross, a1_n, a1_first, a1_last;
   /* TrigStateModel: the rotation of pair q (components first + 2 q, first + 2 q + 1) */
   int nfreq;
   double trig_cos[BO_SSM_MAX / 2], trig_sin[BO_SSM_MAX / 2];
@@ -2256,11 +2269,18 @@ static void ssm_alloc_series(bo_ssm *m) {
  * local linear trend are one family), + 16 for every earlier block of the family */
 int bo_ssm_block_stream_id(const bo_ssm *m, int b, int v) {
   const int kind = m->blk[b].kind;
-  const int fam = (kind == BO_BLK_LOCAL_LINEAR_TREND) ? BO_BLK_LOCAL_LEVEL : kind;
+  /* (the semilocal trend's two samplers: its level variance is of the level family -- id 1 --,
+   * the NonzeroMeanAr1Sampler a family of its own, id 14) */
+  if (kind == BO_BLK_SEMILOCAL && v == 1) {
+    int occ = 0;
+    for (int i = 0; i < b; ++i) occ += m->blk[i].kind == BO_BLK_SEMILOCAL;
+    return 14 + 16 * occ;
+  }
+  const int fam = (kind == BO_BLK_LOCAL_LINEAR_TREND || kind == BO_BLK_SEMILOCAL) ? BO_BLK_LOCAL_LEVEL : kind;
   int occ = 0;
   for (int i = 0; i < b; ++i) {
     const int k = m->blk[i].kind;
-    if (((k == BO_BLK_LOCAL_LINEAR_TREND) ? BO_BLK_LOCAL_LEVEL : k) == fam) ++occ;
+    if (((k == BO_BLK_LOCAL_LINEAR_TREND || k == BO_BLK_SEMILOCAL) ? BO_BLK_LOCAL_LEVEL : k) == fam) ++occ;
   }
   const int base = (kind == BO_BLK_SEASONAL) ? 7 : (kind == BO_BLK_AR) ? 12 : (kind == BO_BLK_TRIG) ? 13
                    : (v == 0 ? 1 : 6);
@@ -2353,6 +2373,21 @@ int bo_ssm_add_block(bo_ssm *m, int kind, const int *iparams, const double *var_
         b->trig_sin[q] = initial_phi[2 * q + 1];
       }
       break;
+    case BO_BLK_SEMILOCAL:
+      /* iparams = {force_stationary, force_ar1_positive}; initial_phi = {slope mean prior mu,
+       * sigma; slope AR(1) coefficient prior mu, sigma; initial mu, initial phi}; the var_* arrays:
+       * level, slope; the initial state: level, slope (the third component is mu) */
+      if (!iparams || !initial_phi) return BO_ERR_INVALID;
+      if (iparams[1] && !iparams[0]) return BO_ERR_INVALID;   /* (one-sided truncation: not restated) */
+      b->dim = 3;
+      b->nvar = 2;
+      b->sl_truncate_phi = iparams[0] != 0;
+      b->sl_force_positive = iparams[1] != 0;
+      b->sl_mean_prior[0] = initial_phi[0]; b->sl_mean_prior[1] = initial_phi[1];
+      b->sl_phi_prior[0] = initial_phi[2]; b->sl_phi_prior[1] = initial_phi[3];
+      b->sl_mu = initial_phi[4];
+      b->sl_phi = initial_phi[5];
+      break;
     default: return BO_ERR_INVALID;
   }
   if (m->m + b->dim > BO_SSM_MAX) return BO_ERR_INVALID;
@@ -2368,6 +2403,11 @@ int bo_ssm_add_block(bo_ssm *m, int kind, const int *iparams, const double *var_
   for (int i = 0; i < b->dim; ++i) {
     m->a0[b->first + i] = initial_state_mean[i];
     m->P0[b->first + i] = initial_state_variance[i];
+  }
+  if (kind == BO_BLK_SEMILOCAL) {
+    /* initial_state_mean()[2] = slope_->mu() (kept current by ssm_refresh_semilocal), variance 0 */
+    m->a0[b->first + 2] = b->sl_mu;
+    m->P0[b->first + 2] = 0.0;
   }
   if (kind == BO_BLK_AR)
     for (int i = 0; i < b->lags; ++i) b->phi[i] = initial_phi ? initial_phi[i] : 0.0;
@@ -2436,6 +2476,7 @@ void bo_ssm_block_get(const bo_ssm *m, int b, double *sigsq, double *suf_n, doub
     if (suf_ss) suf_ss[v] = B->suf_ss[v];
   }
   if (phi) for (int i = 0; i < B->lags; ++i) phi[i] = B->phi[i];
+  if (phi && B->kind == BO_BLK_SEMILOCAL) { phi[0] = B->sl_phi; phi[1] = B->sl_mu; }
 }
 void bo_ssm_block_set_sigsq(bo_ssm *m, int b, const double *sigsq) {
   for (int v = 0; v < m->blk[b].nvar; ++v) m->blk[b].sigsq[v] = sigsq[v];
@@ -2537,6 +2578,10 @@ static void ssm_T(const bo_ssm *m, double *x, int t) {
         first_entry += b->phi[i] * s[i];
         if (i > 0) s[i] = s[i - 1]; else s[i] = first_entry;
       }
+    } else if (b->kind == BO_BLK_SEMILOCAL) {
+      /* SemilocalLinearTrendMatrix::multiply_inplace, SemilocalLinearTrend.cpp:78-82 */
+      s[0] += s[1];
+      s[1] = b->sl_phi * s[1] + (1 - b->sl_phi) * s[2];
     } else if (b->kind == BO_BLK_TRIG) {
       /* BlockDiagonalMatrixBlock of DenseMatrix rotations: lhs = rotation * rhs, a row at a time
        * (Matrix::mult: the row's products summed from the left) */
@@ -2567,6 +2612,12 @@ static void ssm_Tt(const bo_ssm *m, double *x, int t) {
       double tmp[BO_AR_MAX];
       for (int i = 0; i < n; ++i) tmp[i] = b->phi[i] * s[0] + (i + 1 < n ? s[i + 1] : 0);
       for (int i = 0; i < n; ++i) s[i] = tmp[i];
+    } else if (b->kind == BO_BLK_SEMILOCAL) {
+      /* SemilocalLinearTrendMatrix::Tmult, SemilocalLinearTrend.cpp:65-76 */
+      const double r0 = s[0], r1 = s[1], r2 = s[2];
+      s[0] = r0;
+      s[1] = r0 + b->sl_phi * r1;
+      s[2] = (1 - b->sl_phi) * r1 + r2;
     } else if (b->kind == BO_BLK_TRIG) {
       /* the rotations' transposes */
       for (int q = 0; q < b->nfreq; ++q) {
@@ -2595,7 +2646,8 @@ static void ssm_rqr(const bo_ssm *m, double *d, int t) {
       continue;
     }
     d[b->first] = b->sigsq[0];
-    if (b->kind == BO_BLK_LOCAL_LINEAR_TREND) d[b->first + 1] = b->sigsq[1];
+    /* (semilocal: UpperLeftDiagonalMatrix(level, slope; 3): the third diagonal element is 0) */
+    if (b->kind == BO_BLK_LOCAL_LINEAR_TREND || b->kind == BO_BLK_SEMILOCAL) d[b->first + 1] = b->sigsq[1];
   }
 }
 
@@ -2673,6 +2725,19 @@ static void ssm_disturbance_smooth(const bo_ssm *M, const double *v,
   for (int i = 0; i < m; ++i) r0[i] = r[i];
 }
 
+/* Ar1Suf::update_raw, NonzeroMeanAr1Model.cpp:39-49 */
+static void ar1_update(bo_ssm_block *b, double y) {
+  if (b->a1_n == 0) {
+    b->a1_first = y;
+  } else {
+    b->a1_cross += y * b->a1_last;
+  }
+  b->a1_n += 1;
+  b->a1_sum += y;
+  b->a1_sumsq += y * y;
+  b->a1_last = y;
+}
+
 static double ssm_observation_variance(const bo_ssm *m, int t) {
   (void)t;
   return m->reg->sigsq; /* one observation per time point, missing or not (StateSpaceRegressionModel.cpp:167-177) */
@@ -2694,6 +2759,11 @@ static void ssm_state_error(const bo_ssm *M, bo_rng *rng, double *eta, int t) {
     } else if (b->kind == BO_BLK_SEASONAL) {
       /* SeasonalStateModel.cpp:124-146: only when the next time point starts a season */
       if (blk_new_season(b, t + 1)) eta[b->first] = bo_rnorm(rng, 0, sqrt(b->sigsq[0]));
+    } else if (b->kind == BO_BLK_SEMILOCAL) {
+      /* SemilocalLinearTrend.cpp:189-194 */
+      eta[b->first] = bo_rnorm(rng, 0, sqrt(b->sigsq[0]));
+      eta[b->first + 1] = bo_rnorm(rng, 0, sqrt(b->sigsq[1]));
+      eta[b->first + 2] = 0;
     } else if (b->kind == BO_BLK_STATIC_INTERCEPT) {
       /* StaticInterceptStateModel.hpp:52-54: eta[0] = 0.0, the generator is not touched */
     } else if (b->kind == BO_BLK_TRIG) {
@@ -2721,6 +2791,7 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
     b->mv_n = 0;
     b->mv_ybar[0] = b->mv_ybar[1] = 0;
     b->mv_sumsq[0] = b->mv_sumsq[1] = 0;
+    b->a1_sumsq = b->a1_sum = b->a1_cross = b->a1_n = b->a1_first = b->a1_last = 0;   /* Ar1Suf::clear */
     if (b->kind == BO_BLK_AR) {
       /* clear_client_data -> ArModel's NeRegSuf::clear */
       for (int i = 0; i < b->lags * b->lags; ++i) b->ar_xtx[i] = 0;
@@ -2730,6 +2801,9 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
     }
   }
 
+  /* a semilocal trend's initial_state_mean()[2] is slope_->mu(), whatever it is now */
+  for (int bi = 0; bi < M->nblocks; ++bi)
+    if (M->blk[bi].kind == BO_BLK_SEMILOCAL) M->a0[M->blk[bi].first + 2] = M->blk[bi].sl_mu;
   double a[BO_SSM_MAX];
   double *P = (double *)xcalloc((size_t)m * m, sizeof(double));
   for (int i = 0; i < m; ++i) { a[i] = M->a0[i]; P[IDX(i, i, m)] = M->P0[i]; }
@@ -2761,7 +2835,12 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
       for (int bi = 0; bi < M->nblocks; ++bi) {
         const bo_ssm_block *b = &M->blk[bi];
         const int f = b->first;
-        if (b->kind == BO_BLK_LOCAL_LEVEL || b->kind == BO_BLK_STATIC_INTERCEPT) {
+        if (b->kind == BO_BLK_SEMILOCAL) {
+          /* SemilocalLinearTrend.cpp:262-270 */
+          st[f] = bo_rnorm(rng, M->a0[f], sqrt(M->P0[f]));
+          st[f + 1] = bo_rnorm(rng, M->a0[f + 1], sqrt(M->P0[f + 1]));
+          st[f + 2] = b->sl_mu;
+        } else if (b->kind == BO_BLK_LOCAL_LEVEL || b->kind == BO_BLK_STATIC_INTERCEPT) {
           /* LocalLevelStateModel::simulate_initial_state, LocalLevelStateModel.cpp:66-69;
            * StaticInterceptStateModel.cpp:39-43 */
           st[f] = bo_rnorm(rng, M->a0[f], sqrt(M->P0[f]));
@@ -2809,6 +2888,14 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
       }
     }
     for (int i = 0; i < m; ++i) st[i] += mean_obs[i] - mean_sim[i];
+    if (t == 0) {
+      /* observe_initial_state (StateSpaceModelBase::observe_state(0)): only the semilocal trend
+       * does anything, SemilocalLinearTrend.cpp:178-180: slope_->suf()->update_raw(state[1]) */
+      for (int bi = 0; bi < M->nblocks; ++bi) {
+        bo_ssm_block *b = &M->blk[bi];
+        if (b->kind == BO_BLK_SEMILOCAL) ar1_update(b, st[b->first + 1]);
+      }
+    }
     if (t > 0) {
       const double *then = M->state + (size_t)(t - 1) * m;
       for (int bi = 0; bi < M->nblocks; ++bi) {
@@ -2831,6 +2918,13 @@ int bo_ssm_impute_state(bo_ssm *M, bo_rng *rng) {
             double w2 = err[i] - b->mv_ybar[i];
             b->mv_sumsq[i] += w2 * w2 * 1;
           }
+        } else if (b->kind == BO_BLK_SEMILOCAL) {
+          /* SemilocalLinearTrend.cpp:168-176: the level's error into its GaussianSuf, the
+           * current slope into the Ar1Suf */
+          double change_in_level = st[f] - then[f] - then[f + 1];
+          b->suf_n[0] += 1;
+          b->suf_ss[0] += change_in_level * change_in_level;
+          ar1_update(b, st[f + 1]);
         } else if (b->kind == BO_BLK_STATIC_INTERCEPT) {
           /* observe_state: "There is nothing to do here." (StaticInterceptStateModel.hpp:45-47) */
         } else if (b->kind == BO_BLK_TRIG) {
@@ -3085,6 +3179,60 @@ static void ar_draw(bo_ssm *M, bo_ssm_block *B, int *status) {
                               status);
 }
 
+/* NonzeroMeanAr1Sampler::draw (NonzeroMeanAr1Sampler.cpp:51-155) on the slope's Ar1Suf
+ * (NonzeroMeanAr1Model.cpp:103-120): draw_mu, draw_phi, draw_sigma, one generator */
+static void semilocal_slope_draw(bo_ssm_block *b, int *status) {
+  bo_rng *rng = &b->rng[1];
+  const double n = b->a1_n;
+  const double lag_sumsq = b->a1_sumsq - pow(b->a1_last, 2);
+  const double lag_sum = b->a1_sum - b->a1_last;
+  const double sum_excluding_first = b->a1_sum - b->a1_first;
+  const double sumsq_excluding_first = b->a1_sumsq - pow(b->a1_first, 2);
+  {  /* draw_mu */
+    const double phi = b->sl_phi, sigsq = b->sigsq[1];
+    const double prior_sigsq = b->sl_mean_prior[1] * b->sl_mean_prior[1];
+    double ivar = (1 + (n - 1) * pow(1 - phi, 2)) / sigsq;
+    ivar += 1.0 / prior_sigsq;
+    double mean = (1 - phi) * (sum_excluding_first - phi * lag_sum) + b->a1_first;
+    mean /= sigsq;
+    mean += b->sl_mean_prior[0] / prior_sigsq;
+    mean /= ivar;
+    const double sd = sqrt(1.0 / ivar);
+    b->sl_mu = bo_rnorm(rng, mean, sd);
+  }
+  {  /* draw_phi */
+    const double mu = b->sl_mu, sigsq = b->sigsq[1];
+    const double prior_sigsq = b->sl_phi_prior[1] * b->sl_phi_prior[1];
+    double ivar = lag_sumsq - 2 * lag_sum * mu + (n - 1) * mu * mu;   /* centered_lag_sumsq(mu) */
+    ivar /= sigsq;
+    ivar += 1.0 / prior_sigsq;
+    /* centered_cross(mu), NonzeroMeanAr1Model.cpp */
+    double mean = b->a1_cross - mu * (sum_excluding_first + lag_sum) + (n - 1) * mu * mu;
+    mean /= sigsq;
+    mean += b->sl_phi_prior[0] / prior_sigsq;
+    mean /= ivar;
+    const double sd = sqrt(1.0 / ivar);
+    double phi;
+    if (b->sl_truncate_phi) {
+      const double lower_limit = b->sl_force_positive ? 0 : -1;
+      phi = bo_rtrun_norm_2(rng, mean, sd, lower_limit, 1, status);
+      if (*status) return;
+    } else {
+      phi = bo_rnorm(rng, mean, sd);
+    }
+    b->sl_phi = phi;
+  }
+  {  /* draw_sigma: sigsq_sampler_.draw(rng, suf->n(), suf->model_sumsq(mu, phi)) */
+    const double mu = b->sl_mu, phi = b->sl_phi;
+    double ss = pow(b->a1_first - mu, 2);
+    ss += sumsq_excluding_first - 2 * phi * b->a1_cross -
+          2 * (1 - phi) * mu * sum_excluding_first + phi * phi * lag_sumsq +
+          2 * phi * (1 - phi) * mu * lag_sum +
+          (n - 1) * pow(mu * (1 - phi), 2);
+    b->sigsq[1] = variance_draw(rng, b->prior_df[1], b->prior_ss[1], b->sigma_max[1], n, ss, status);
+  }
+}
+
 /* StateSpacePosteriorSampler::draw, StateSpacePosteriorSampler.cpp:42-64: the
  * regression, then each state model's samplers in the order the models were added
  * (local level: its variance; local linear trend: level, slope; seasonal: its
@@ -3102,6 +3250,16 @@ int bo_ssm_draw(bo_ssm *m) {
     bo_ssm_block *b = &m->blk[bi];
     if (b->kind == BO_BLK_AR) {
       ar_draw(m, b, &status);
+      if (status) return status;
+      continue;
+    }
+    if (b->kind == BO_BLK_SEMILOCAL) {
+      /* the trend's two samplers in the order bsts attaches them
+       * (create_state_model.cpp:624-672): the level's variance, then the slope model */
+      b->sigsq[0] = variance_draw(&b->rng[0], b->prior_df[0], b->prior_ss[0], b->sigma_max[0],
+                                  b->suf_n[0], b->suf_ss[0], &status);
+      if (status) return status;
+      semilocal_slope_draw(b, &status);
       if (status) return status;
       continue;
     }

@@ -238,7 +238,12 @@ enum { BO_BLK_LOCAL_LEVEL = 1, BO_BLK_LOCAL_LINEAR_TREND = 2, BO_BLK_SEASONAL = 
         * arrays are not read), TrigStateModel (iparams = {number of frequencies}; the
         * rotations' (cos, sin) pairs, two doubles per frequency, go in through
         * initial_phi; one variance for all its components) */
-       BO_BLK_STATIC_INTERCEPT = 5, BO_BLK_TRIG = 6 };
+       BO_BLK_STATIC_INTERCEPT = 5, BO_BLK_TRIG = 6,
+       /* SemilocalLinearTrendStateModel (level, slope, the slope's long-run mean): iparams =
+        * {force_stationary, force_ar1_positive}; var_* = (level, slope); initial_phi = {slope mean
+        * prior mu, sigma, slope AR(1) prior mu, sigma, initial mu, initial phi}; its coefficients
+        * come back through bo_ssm_block_get's phi: (phi, mu) */
+       BO_BLK_SEMILOCAL = 7 };
 typedef struct bo_ssm bo_ssm;
 bo_ssm *bo_ssm_create(int T, int p, const double *y, const double *X,
                       const uint8_t *observed, const double *prior_mean,

@@ -47,6 +47,10 @@
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
 #include "Models/StateSpace/StateModels/StaticInterceptStateModel.hpp"
+#include "Models/StateSpace/StateModels/SemilocalLinearTrend.hpp"
+#include "Models/TimeSeries/NonzeroMeanAr1Model.hpp"
+#include "Models/TimeSeries/PosteriorSamplers/NonzeroMeanAr1Sampler.hpp"
+#include "Models/GaussianModel.hpp"
 #include "Models/StateSpace/StateModels/TrigStateModel.hpp"
 #include "Models/PosteriorSamplers/ZeroMeanMvnIndependenceSampler.hpp"
 #include "Models/StateSpace/StateSpaceRegressionModel.hpp"
@@ -814,7 +818,12 @@ int ref_ssm_forecast(int T, int p, const double *y, const double *X, const doubl
 // ArStateModel(iparams[3 b]) + ArPosteriorSampler, 5 StaticInterceptStateModel (no
 // parameter, no sampler), 6 TrigStateModel(period = phi0[16 b], the iparams[3 b] <= 15
 // frequencies phi0[16 b + 1 ..]) with a ZeroMeanGaussianConjSampler on its error
-// distribution, as bsts builds it (Interfaces/R/bsts/src/create_state_model.cpp:559-586).
+// distribution, as bsts builds it (Interfaces/R/bsts/src/create_state_model.cpp:559-586), 7
+// SemilocalLinearTrendStateModel(ZeroMeanGaussianModel level, NonzeroMeanAr1Model slope) with
+// the level's ZeroMeanGaussianConjSampler and then the slope's NonzeroMeanAr1Sampler attached
+// to the TREND model (create_state_model.cpp:601-672): iparams[3 b + {0, 1}] = force_stationary,
+// force_ar1_positive; phi0[16 b + ..] = slope mean prior mu, sigma, slope AR(1) prior mu, sigma,
+// initial mu, initial phi; variances (level, slope) in vpar; a0 / P0: level, slope, (ignored).
 // vpar[8 b + 4 v + {0, 1, 2, 3}] = prior
 // df, prior sigma guess, sigma upper limit (inf: none), initial sigma of variance v of
 // block b; phi0[16 b ..] the initial autoregression coefficients; a0 / P0: the blocks'
@@ -828,6 +837,9 @@ struct GeneralState {
   std::vector<Ptr<ArStateModel>> ar;
   std::vector<Ptr<StaticInterceptStateModel>> intercept;
   std::vector<Ptr<TrigStateModel>> trig;
+  std::vector<Ptr<SemilocalLinearTrendStateModel>> semilocal;
+  std::vector<Ptr<NonzeroMeanAr1Model>> semilocal_slope;
+  std::vector<Ptr<ZeroMeanGaussianModel>> semilocal_level;
   std::vector<int> kind, slot;   // per block: which vector, which element
 };
 
@@ -902,6 +914,35 @@ static void add_general_state(StateSpaceRegressionModel *model, GeneralState &G,
       G.slot.push_back((int)G.intercept.size());
       G.intercept.push_back(icpt);
       first += 1;
+    } else if (kinds[b] == 7) {
+      const double *pp = phi0 + 16 * b;
+      NEW(ZeroMeanGaussianModel, level)(vp[3]);
+      NEW(NonzeroMeanAr1Model, slope)(pp[4], pp[5], vp[7]);
+      Ptr<SemilocalLinearTrendStateModel> trend(new SemilocalLinearTrendStateModel(level, slope));
+      if (with_samplers) {
+        NEW(ZeroMeanGaussianConjSampler, level_sampler)(level.get(), vp[0], vp[1]);
+        if (std::isfinite(vp[2])) level_sampler->set_sigma_upper_limit(vp[2]);
+        trend->set_method(level_sampler);
+        NEW(GaussianModel, slope_mean_prior)(pp[0], pp[1]);
+        NEW(GaussianModel, slope_ar_prior)(pp[2], pp[3]);
+        NEW(ChisqModel, slope_sigma_prior)(vp[4], vp[5]);
+        NEW(NonzeroMeanAr1Sampler, slope_sampler)(slope.get(), slope_mean_prior, slope_ar_prior,
+                                                  slope_sigma_prior);
+        if (std::isfinite(vp[6])) slope_sampler->set_sigma_upper_limit(vp[6]);
+        if (iparams[3 * b]) slope_sampler->force_stationary();
+        if (iparams[3 * b + 1]) slope_sampler->force_ar1_positive();
+        trend->set_method(slope_sampler);
+      }
+      trend->set_initial_level_mean(a0[first]);
+      trend->set_initial_slope_mean(a0[first + 1]);
+      trend->set_initial_level_sd(std::sqrt(P0[first]));
+      trend->set_initial_slope_sd(std::sqrt(P0[first + 1]));
+      model->add_state(trend);
+      G.slot.push_back((int)G.semilocal.size());
+      G.semilocal.push_back(trend);
+      G.semilocal_slope.push_back(slope);
+      G.semilocal_level.push_back(level);
+      first += 3;
     } else if (kinds[b] == 6) {
       const int nf = iparams[3 * b];
       Ptr<TrigStateModel> trig(new TrigStateModel(phi0[16 * b], make_vector(nf, phi0 + 16 * b + 1)));
@@ -999,6 +1040,11 @@ int ref_ssg_run(int T, int p, const double *y, const double *X, const uint8_t *o
         // (no parameter)
       } else if (G.kind[b] == 6) {
         v[0] = G.trig[s]->error_distribution()->sigsq();
+      } else if (G.kind[b] == 7) {
+        v[0] = G.semilocal_level[s]->sigsq();
+        v[1] = G.semilocal_slope[s]->sigsq();
+        ph[0] = G.semilocal_slope[s]->phi();
+        ph[1] = G.semilocal_slope[s]->mu();
       } else {
         v[0] = G.ar[s]->sigsq();
         const int L = iparams[3 * b];
@@ -1042,7 +1088,7 @@ int ref_ssg_forecast(int T, int p, const double *y, const double *X, const doubl
     vpar[8 * k + 3] = std::sqrt(sigsq[2 * k]);
     vpar[8 * k + 7] = std::sqrt(sigsq[2 * k + 1]);
     m += (kinds[k] == 1 || kinds[k] == 5) ? 1 : kinds[k] == 2 ? 2 : kinds[k] == 3 ? iparams[3 * k] - 1
-         : kinds[k] == 6 ? 2 * iparams[3 * k] : iparams[3 * k];
+         : kinds[k] == 6 ? 2 * iparams[3 * k] : kinds[k] == 7 ? 3 : iparams[3 * k];
   }
   std::vector<double> a0(m, 0.0), P0(m, 1.0);
   GeneralState G;

@@ -142,7 +142,7 @@ def structural_spec(y, trend, nseasons, ar_lags=0):
 
 
 KIND_LOCAL_LEVEL, KIND_LOCAL_LINEAR_TREND, KIND_SEASONAL, KIND_AR = 1, 2, 3, 4
-KIND_STATIC_INTERCEPT, KIND_TRIG = 5, 6
+KIND_STATIC_INTERCEPT, KIND_TRIG, KIND_SEMILOCAL = 5, 6, 7
 
 
 def trig_rotations(period, frequencies):
@@ -161,19 +161,21 @@ def general_spec(y, blocks):
     """a list of state models in the order they are added (add_state), bsts-style
     defaults as structural_spec.  blocks: tuples ("level",), ("trend",), ("seasonal",
     nseasons, duration[, time_of_first_observation]), ("ar", lags[, initial_phi]),
-    ("intercept",) (StaticInterceptStateModel), ("trig", period, frequencies) (TrigStateModel).
+    ("intercept",) (StaticInterceptStateModel), ("trig", period, frequencies) (TrigStateModel),
+    ("semilocal"[, force_stationary[, force_positive]]) (SemilocalLinearTrendStateModel with bsts's
+    AddSemilocalLinearTrend priors: slope mean N(0, sd(y)), AR(1) coefficient N(0, 1)).
     Returns the list of block dicts the oracle / reference / engine wrappers take."""
     sdy = float(np.std(y, ddof=1))
     out = []
     first = True
     init_sigma = {"level": [1.0], "trend": [1.0, 0.5], "seasonal": [0.7], "ar": [1.0], "intercept": [],
-                  "trig": [0.4]}
+                  "trig": [0.4], "semilocal": [0.8, 0.3]}
     for b in blocks:
         name = b[0]
         kind = {"level": KIND_LOCAL_LEVEL, "trend": KIND_LOCAL_LINEAR_TREND,
                 "seasonal": KIND_SEASONAL, "ar": KIND_AR, "intercept": KIND_STATIC_INTERCEPT,
-                "trig": KIND_TRIG}[name]
-        nv = 2 if name == "trend" else (0 if name == "intercept" else 1)
+                "trig": KIND_TRIG, "semilocal": KIND_SEMILOCAL}[name]
+        nv = 2 if name in ("trend", "semilocal") else (0 if name == "intercept" else 1)
         d = dict(kind=kind, nseasons=0, duration=1, t0=0, lags=0,
                  df=np.full(nv, 0.01), sigma_guess=np.full(nv, 0.01 * sdy),
                  sigma_upper_limit=np.full(nv, sdy),
@@ -189,6 +191,12 @@ def general_spec(y, blocks):
             dim = d["lags"]
         elif name == "intercept":
             dim = 1
+        elif name == "semilocal":
+            d["force_stationary"] = int(b[1]) if len(b) > 1 else 1
+            d["force_positive"] = int(b[2]) if len(b) > 2 else 0
+            # slope mean prior (mu, sigma), slope AR(1) prior (mu, sigma), initial mu, initial phi
+            d["slope_priors"] = np.array([0.0, sdy, 0.0, 1.0, 0.0, 0.0])
+            dim = 3
         elif name == "trig":
             d["period"] = float(b[1])
             d["frequencies"] = np.asarray(b[2], float)
@@ -197,11 +205,13 @@ def general_spec(y, blocks):
         else:
             dim = nv
         a0 = np.zeros(dim)
-        if first and name in ("level", "trend", "intercept"):
+        if first and name in ("level", "trend", "intercept", "semilocal"):
             a0[0] = float(y[0])
             first = False
         d["a0"] = a0
         d["P0"] = np.full(dim, sdy * sdy)
+        if name == "semilocal":
+            d["P0"][2] = 0.0      # (the slope's long-run mean is a parameter, not a draw)
         d["dim"] = dim
         out.append(d)
     return out
@@ -220,6 +230,9 @@ def general_arrays(blocks):
         elif b["kind"] == KIND_AR:
             ip[i, 0] = b["lags"]
             phi0[i, :b["lags"]] = b["initial_phi"]
+        elif b["kind"] == KIND_SEMILOCAL:
+            ip[i, 0], ip[i, 1] = b["force_stationary"], b["force_positive"]
+            phi0[i, :6] = b["slope_priors"]
         elif b["kind"] == KIND_TRIG:
             # (ref_ssg_run: the number of frequencies; the period, then the frequencies)
             nf = len(b["frequencies"])
@@ -242,7 +255,7 @@ def blocks_of(g, prefix=""):
     out, first = [], 0
     for i, k in enumerate(kinds):
         k = int(k)
-        nv = 2 if k == KIND_LOCAL_LINEAR_TREND else (0 if k == KIND_STATIC_INTERCEPT else 1)
+        nv = 2 if k in (KIND_LOCAL_LINEAR_TREND, KIND_SEMILOCAL) else (0 if k == KIND_STATIC_INTERCEPT else 1)
         d = dict(kind=k, nseasons=0, duration=1, t0=0, lags=0, df=vpar[i, :nv, 0],
                  sigma_guess=vpar[i, :nv, 1], sigma_upper_limit=vpar[i, :nv, 2],
                  initial_sigma=vpar[i, :nv, 3], initial_phi=np.zeros(0))
@@ -255,6 +268,10 @@ def blocks_of(g, prefix=""):
             dim = d["lags"]
         elif k == KIND_STATIC_INTERCEPT:
             dim = 1
+        elif k == KIND_SEMILOCAL:
+            d["force_stationary"], d["force_positive"] = int(ip[i, 0]), int(ip[i, 1])
+            d["slope_priors"] = np.array(phi0[i, :6])
+            dim = 3
         elif k == KIND_TRIG:
             nf = int(ip[i, 0])
             d["period"], d["frequencies"] = float(phi0[i, 0]), np.array(phi0[i, 1:1 + nf])

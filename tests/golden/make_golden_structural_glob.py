@@ -30,6 +30,13 @@ CASES = [
      [(30.5, [1.0])], 0.0, True, 0.0, None, 65, 40, 4),
     ("ssq_two_trig_intercept", [("intercept",), ("trig", 24.0, [1.0, 3.0]), ("trig", 5.0, [2.0])], 120, [],
      [(24.0, [1.0, 3.0]), (5.0, [2.0])], 1.5, False, 0.0, None, 66, 40, 4),
+    # SemilocalLinearTrendStateModel: stationary slope (phi in [-1, 1]), alone; phi in [0, 1], with a
+    # seasonal block ahead of it and missing observations; no truncation at all, beside a trig block
+    ("ssq_semilocal", [("semilocal",)], 150, [], None, 0.0, True, 0.0, None, 67, 40, 4),
+    ("ssq_seasonal_semilocal_missing", [("seasonal", 7, 1), ("semilocal", 1, 1)], 160, [(7, 1)], None, 0.0, True,
+     0.04, None, 68, 40, 4),
+    ("ssq_semilocal_free_trig", [("semilocal", 0, 0), ("trig", 12.0, [1.0])], 140, [], [(12.0, [1.0])], 0.0, True,
+     0.0, None, 69, 40, 4),
 ]
 
 
@@ -56,6 +63,7 @@ def main():
     shapes = [
         ("a", [("intercept",), ("trig", 12.0, [1.0, 2.0])], 50),
         ("b", [("trig", 7.0, [1.0, 2.0, 3.0]), ("trend",), ("seasonal", 3, 5, 1)], 61),
+        ("c", [("seasonal", 4, 2), ("semilocal",)], 40),
     ]
     g = np.random.Generator(np.random.PCG64(19))
     newX = g.standard_normal((h, p))
@@ -69,7 +77,10 @@ def main():
         for i, b in enumerate(blocks):
             if b["kind"] == 5:
                 sig[i] = 0.0
-        phi = general_arrays(blocks)[3]      # (a trig block's period and frequencies ride there)
+        for b in blocks:
+            if b["kind"] == 7:
+                b["slope_priors"][4:] = (0.07, 0.8)      # (the slope's mu and phi of this forecast)
+        phi = general_arrays(blocks)[3]      # (a trig block's period and frequencies, a semilocal trend's mu and phi ride there)
         fs = g.standard_normal(m)
         out = R.ssg_forecast(T, newX, beta, 0.04, blocks, sig, phi, fs, 78)
         fc[key + "_T"] = T

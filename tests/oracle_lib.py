@@ -939,7 +939,8 @@ class Oracle:
             vp = np.ascontiguousarray(vpar[i].T)   # rows: df, guess, upper limit, initial sigma
             rc = L.bo_ssm_add_block(
                 m, int(kinds[i]), ipi.ctypes.data_as(C.POINTER(C.c_int)), _dp(vp[0]), _dp(vp[1]),
-                _dp(vp[2]), _dp(vp[3]), _dp(f64(b["rotations"] if b["kind"] == 6 else phi0[i])),
+                _dp(vp[2]), _dp(vp[3]),
+                _dp(f64(b["rotations"] if b["kind"] == 6 else (b["slope_priors"] if b["kind"] == 7 else phi0[i]))),
                 _dp(f64(a0[first:first + b["dim"]])),
                 _dp(f64(P0[first:first + b["dim"]])))
             assert rc == 0, rc
@@ -963,7 +964,7 @@ class Oracle:
                               opts["draw_sigma"])
         g0 = np.ascontiguousarray(init_gamma, dtype=np.uint8)
         L.bo_ssvs_set_state(reg, _u8(g0), _dp(np.zeros(p)), 1.0)
-        nvar = [2 if b["kind"] == 2 else (0 if b["kind"] == 5 else 1) for b in blocks]
+        nvar = [2 if b["kind"] in (2, 7) else (0 if b["kind"] == 5 else 1) for b in blocks]
         if rng_setup[0] == "mt":
             glob = self.rng_mt(rng_setup[1])
             # construction order: regression, every state model's samplers, state

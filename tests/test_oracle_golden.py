@@ -430,7 +430,8 @@ def test_general_forecast_known_answers(oracle):
 
 
 GLOB_GOLDENS = ["ssq_intercept_ar", "ssq_intercept_seasonal_missing", "ssq_trig_only", "ssq_trend_trig",
-                "ssq_trig_level_seasonal", "ssq_two_trig_intercept"]
+                "ssq_trig_level_seasonal", "ssq_two_trig_intercept", "ssq_semilocal",
+                "ssq_seasonal_semilocal_missing", "ssq_semilocal_free_trig"]
 
 
 @pytest.mark.parametrize("name", GLOB_GOLDENS)
@@ -439,7 +440,10 @@ def test_static_intercept_and_trig_state_models_match_reference(oracle, name):
     no state error, no parameter: StaticInterceptStateModel.hpp:35-131) and TrigStateModel (a
     2 x 2 rotation per frequency, Z = 1 at every pair's first component, ONE variance for all
     components: TrigStateModel.cpp:130-223), alone, together, and in lists with the round-4
-    models, missing observations included -- the compiled reference's draws (goldens of
+    models, missing observations included; SemilocalLinearTrendStateModel (level, slope, the
+    slope's long-run mean; the level's variance sampler and the slope's NonzeroMeanAr1Sampler:
+    SemilocalLinearTrend.cpp:29-272, NonzeroMeanAr1Sampler.cpp:51-155) with the AR(1) coefficient
+    truncated to [-1, 1], to [0, 1] and not at all -- the compiled reference's draws (goldens of
     make_golden_structural_glob.py)."""
     from cases import blocks_of
     g = load(name)
@@ -453,6 +457,7 @@ def test_static_intercept_and_trig_state_models_match_reference(oracle, name):
     assert relerr(o["beta"], g["beta"]) < RTOL
     assert relerr(o["sigsq"], g["sigsq"]) < RTOL
     assert relerr(o["variances"], g["variances"], 1e-300) < RTOL
+    assert relerr(o["phi"], g["phi"], 1e-6) < RTOL       # (a semilocal trend's phi and mu)
     assert o["state"].shape == g["state"].shape
     assert np.max(np.abs(o["state"] - g["state"])) < 1e-9 * np.abs(g["state"]).max()
 
