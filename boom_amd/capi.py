@@ -568,17 +568,20 @@ class Engine:
                 ip[0] = b["lags"]
             elif kind == 6:
                 ip[0] = len(b["rotations"]) // 2
+            elif kind == 7:
+                ip[0], ip[1] = int(b.get("force_stationary", 1)), int(b.get("force_positive", 0))
             arrs = [np.ascontiguousarray(b[k], dtype=np.float64) for k in
                     ("df", "sigma_guess", "sigma_upper_limit", "initial_sigma")]
-            ph = np.ascontiguousarray(b["rotations"] if kind == 6 else b.get("initial_phi", np.zeros(0)),
+            ph = np.ascontiguousarray(b["rotations"] if kind == 6 else
+                                      (b["slope_priors"] if kind == 7 else b.get("initial_phi", np.zeros(0))),
                                       dtype=np.float64)
             a0 = np.ascontiguousarray(b["a0"], dtype=np.float64)
             p0 = np.ascontiguousarray(b["P0"], dtype=np.float64)
             self._check(self.lib.ba_ss_add_state_model(
                 self._h, kind, ip.ctypes.data_as(C.POINTER(C.c_int32)),
                 *[(_p(a) if a.size else None) for a in arrs],
-                _p(ph) if (kind in (4, 6) and ph.size) else None, _p(a0), _p(p0)))
-            self._blocks.append(dict(kind=kind, nvar=2 if kind == 2 else (0 if kind == 5 else 1),
+                _p(ph) if (kind in (4, 6, 7) and ph.size) else None, _p(a0), _p(p0)))
+            self._blocks.append(dict(kind=kind, nvar=2 if kind in (2, 7) else (0 if kind == 5 else 1),
                                      lags=int(ip[0]) if kind == 4 else 0))
         m, nb = C.c_int32(), C.c_int32()
         self._check(self.lib.ba_ss_state_dimension(self._h, C.byref(m), C.byref(nb)))
@@ -603,6 +606,17 @@ class Engine:
         nv, L = b["nvar"], b["lags"]
         var, n, ss = np.zeros(nv), np.zeros(nv), np.zeros(nv)
         out = dict(variances=var, suf_n=n, suf_ss=ss)
+        if b["kind"] == 7:
+            # a semilocal linear trend: (phi, mu) of the slope model; its Ar1Suf (sumsq, sum, cross,
+            # n, first, last) with suf=True
+            phi, a1 = np.zeros(2), np.zeros(6)
+            self._check(self.lib.ba_ss_get_state_model(self._h, chain, block, _p(var), _p(n) if suf else None,
+                                                       _p(ss) if suf else None, _p(phi), _p(a1) if suf else None,
+                                                       None, None, None))
+            out["phi"] = phi
+            if suf:
+                out["ar1_suf"] = a1
+            return out
         if not suf:
             phi = np.zeros(L) if L else None
             self._check(self.lib.ba_ss_get_state_model(self._h, chain, block, _p(var), None, None,

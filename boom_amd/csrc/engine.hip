@@ -3740,7 +3740,8 @@ void ssg_finish(SsgSpec &q) {
   q.nerr = 0;
   for (int i = 0; i < q.nblocks; ++i) {
     q.blk[i].err0 = q.nerr;
-    q.nerr += q.blk[i].kind == SSG_TRIG ? q.blk[i].dim : (q.blk[i].kind == SSG_LOCAL_LINEAR_TREND ? 2 : 1);
+    q.nerr += q.blk[i].kind == SSG_TRIG ? q.blk[i].dim
+              : ((q.blk[i].kind == SSG_LOCAL_LINEAR_TREND || q.blk[i].kind == SSG_SEMILOCAL) ? 2 : 1);
   }
   // steps per block of the passes: the most that leaves FOUR workgroups to a CU's 160 KB of
   // LDS (all 1024 chains of a launch resident; at m = 59 sixteen steps left room for three,
@@ -3768,12 +3769,20 @@ bool ar_stationary_host(const double *phi, int lags) {
 // slope 6, seasonal 7, autoregression 12 for the first block of its family (local level
 // and local linear trend are one family), + 16 for every earlier block of the family
 int ssg_stream_id(const SsgSpec &q, int kind, int v) {
-  const int fam = kind == SSG_LOCAL_LINEAR_TREND ? SSG_LOCAL_LEVEL : kind;
+  // (a semilocal trend's level variance is of the level family; its NonzeroMeanAr1Sampler a
+  // family of its own, id 14)
+  if (kind == SSG_SEMILOCAL && v == 1) {
+    int occ = 0;
+    for (int i = 0; i < q.nblocks; ++i) occ += q.blk[i].kind == SSG_SEMILOCAL;
+    return 14 + 16 * occ;
+  }
+  auto family = [](int k) { return (k == SSG_LOCAL_LINEAR_TREND || k == SSG_SEMILOCAL) ? (int)SSG_LOCAL_LEVEL : k; };
+  const int fam = family(kind);
   int occ = 0;
   for (int i = 0; i < q.nblocks; ++i) {
     const int k = q.blk[i].kind;
     if (q.blk[i].nvar == 0) continue;   // (a static intercept has no sampler: it is in no family)
-    if ((k == SSG_LOCAL_LINEAR_TREND ? SSG_LOCAL_LEVEL : k) == fam) ++occ;
+    if (family(k) == fam) ++occ;
   }
   const int base = kind == SSG_SEASONAL ? 7 : (kind == SSG_AR ? 12 : (kind == SSG_TRIG ? 13 : (v == 0 ? 1 : 6)));
   return base + 16 * occ;
@@ -3827,6 +3836,22 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
       k.nfreq = iparams[0];
       k.dim = 2 * k.nfreq;
       break;
+    case SSG_SEMILOCAL:
+      // SemilocalLinearTrendStateModel(level, slope): iparams = {force_stationary,
+      // force_ar1_positive}; initial_phi = {slope mean prior mu, sigma, AR(1) coefficient prior mu,
+      // sigma, initial mu, initial phi}
+      if (!iparams || !initial_phi) return fail(BA_E_INVALID, "null argument");
+      if (iparams[1] && !iparams[0])
+        return fail(BA_E_INVALID, "force_ar1_positive without force_stationary (a one-sided truncation of the slope's "
+                                  "AR(1) coefficient) is not built");
+      if (!(initial_phi[1] > 0) || !(initial_phi[3] > 0)) return fail(BA_E_INVALID, "the slope's prior standard deviations must be positive");
+      if (q.nar >= SSG_MAX_AR) return fail(BA_E_INVALID, "more than 4 autoregression / semilocal state models");
+      k.dim = 3;
+      k.nvar = 2;
+      k.ar_index = q.nar;
+      k.sl_truncate = iparams[0] != 0;
+      k.sl_positive = iparams[1] != 0;
+      break;
     case SSG_AR:
       if (!iparams) return fail(BA_E_INVALID, "null argument");
       if (iparams[0] < 1) return fail(BA_E_INVALID, "lags must be positive");
@@ -3837,20 +3862,22 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
       k.ar_index = q.nar;
       break;
     default:
-      return fail(BA_E_INVALID, "state model kind must be 1 (local level), 2 (local linear trend), 3 (seasonal), 4 (autoregression), 5 (static intercept) or 6 (trig)");
+      return fail(BA_E_INVALID, "state model kind must be 1 (local level), 2 (local linear trend), 3 (seasonal), 4 (autoregression), 5 (static intercept), 6 (trig) or 7 (semilocal linear trend)");
   }
   const int nslot = is_static ? 1 : k.nvar;   // variance slots the block takes
   if (q.m + k.dim > SSG_MAX_STATE) return fail(BA_E_INVALID, "state dimension exceeds 64");
   if (q.nvar + nslot > SSG_MAX_VAR) return fail(BA_E_INVALID, "more than 16 variance parameters");
   for (int v = 0; v < k.nvar; ++v) {
     if (var_sigma_upper_limit[v] < 0) return fail(BA_E_INVALID, "sigma_max must be non-negative.");
-    if (kind == SSG_AR && !(var_initial_sigma[v] > 0)) return fail(BA_E_INVALID, "initial sigma must be positive");
+    if ((kind == SSG_AR || kind == SSG_SEMILOCAL) && !(var_initial_sigma[v] > 0))
+      return fail(BA_E_INVALID, "initial sigma must be positive");
   }
   for (int i = 0; i < k.dim; ++i) {
     // (a multivariate initial state goes through a Cholesky factor in the reference: it
     // needs a positive variance; the local level model alone does not)
     const bool ok = initial_state_variance[i] > 0.0 ||
-                    ((kind == SSG_LOCAL_LEVEL || is_static) && initial_state_variance[i] == 0.0);
+                    ((kind == SSG_LOCAL_LEVEL || is_static) && initial_state_variance[i] == 0.0) ||
+                    (kind == SSG_SEMILOCAL && i == 2);   // (the slope's long-run mean: a parameter, variance 0 whatever is passed)
     if (!ok) return fail(BA_E_INVALID, "initial state variances must be positive");
   }
   if (kind == SSG_AR && initial_phi && !ar_stationary_host(initial_phi, k.lags))
@@ -3882,6 +3909,16 @@ int ssg_add(ba_engine *e, int32_t kind, const int32_t *iparams, const double *va
   if (kind == SSG_AR) {
     for (int i = 0; i < AR_MAX; ++i)
       e->ssg_initial_phi[k.ar_index][i] = (initial_phi && i < k.lags) ? initial_phi[i] : 0.0;
+    q.nar += 1;
+  }
+  if (kind == SSG_SEMILOCAL) {
+    for (int i = 0; i < AR_MAX; ++i) e->ssg_initial_phi[k.ar_index][i] = 0.0;
+    e->ssg_initial_phi[k.ar_index][0] = initial_phi[5];   // phi
+    e->ssg_initial_phi[k.ar_index][1] = initial_phi[4];   // mu
+    for (int i = 0; i < 4; ++i) q.sl_prior[k.ar_index][i] = initial_phi[i];
+    // initial_state_mean()[2] = slope->mu() (per chain, per draw: the kernel's), variance 0
+    q.a0[k.first + 2] = initial_phi[4];
+    q.P0[k.first + 2] = 0.0;
     q.nar += 1;
   }
   q.blk[q.nblocks] = k;
@@ -4021,9 +4058,12 @@ int ba_ss_get_state_model(ba_engine *e, int64_t chain, int32_t block, double *va
   if (chain < 0 || chain >= e->cfg.chains) return fail(BA_E_INVALID, "chain index out of range");
   if (block < 0 || block >= e->ssg.nblocks) return fail(BA_E_INVALID, "state model index out of range");
   const SsgBlock &k = e->ssg.blk[block];
-  const bool is_ar = k.kind == SSG_AR;
+  const bool is_sl = k.kind == SSG_SEMILOCAL;
+  const bool is_ar = k.kind == SSG_AR || is_sl;   // (both keep coefficients and statistics in an autoregression slot)
   if (!is_ar && (phi || ar_xtx || ar_xty || ar_yty || ar_n))
     return fail(BA_E_INVALID, "not an autoregression state model");
+  if (is_sl && (ar_xty || ar_yty))
+    return fail(BA_E_INVALID, "a semilocal linear trend's Ar1Suf comes back through ar_xtx (six doubles) and ar_n");
   if (ss_la_serving(e)) {
     if (!suf_n && !suf_ss && !ar_xtx && !ar_xty && !ar_yty && !ar_n) {
       // the draw ba_ss_draw_next is serving, from the record
@@ -4034,7 +4074,7 @@ int ba_ss_get_state_model(ba_engine *e, int64_t chain, int32_t block, double *va
       if (variances)
         for (int v = 0; v < k.nvar; ++v) variances[v] = r->var[row * e->ssla.nvar + k.var0 + v];
       if (phi)
-        for (int i = 0; i < k.lags; ++i) phi[i] = r->phi[row * e->ssla.nphi + (size_t)k.ar_index * AR_MAX + i];
+        for (int i = 0; i < (is_sl ? 2 : k.lags); ++i) phi[i] = r->phi[row * e->ssla.nphi + (size_t)k.ar_index * AR_MAX + i];
       return BA_OK;
     }
     int rcs = ss_la_settle(e);   // (sufficient statistics are not in the record)
@@ -4060,7 +4100,13 @@ int ba_ss_get_state_model(ba_engine *e, int64_t chain, int32_t block, double *va
     if (suf_n) suf_n[v] = hv[2 + v];
     if (suf_ss) suf_ss[v] = hv[4 + v];
   }
-  if (is_ar) {
+  if (k.kind == SSG_SEMILOCAL) {
+    // (phi, mu) of the slope's NonzeroMeanAr1Model; its Ar1Suf -- sumsq, sum, cross, n, first,
+    // last value -- through ar_xtx (six doubles)
+    if (phi) { phi[0] = hphi[0]; phi[1] = hphi[1]; }
+    if (ar_xtx) std::memcpy(ar_xtx, hsuf, 6 * 8);
+    if (ar_n) *ar_n = hsuf[3];
+  } else if (is_ar) {
     const int L = k.lags;
     if (phi) std::memcpy(phi, hphi, (size_t)L * 8);
     if (ar_xtx)

@@ -20,7 +20,11 @@ namespace boom_amd {
 // blocks of at most AR_MAX lags.
 enum { SSG_MAX_STATE = 64, SSG_MAX_BLOCKS = 8, SSG_MAX_VAR = 16, SSG_MAX_AR = 4, AR_MAX = 16 };
 enum { SSG_LOCAL_LEVEL = 1, SSG_LOCAL_LINEAR_TREND = 2, SSG_SEASONAL = 3, SSG_AR = 4,
-       SSG_STATIC_INTERCEPT = 5 /* (the C-ABI's number; stored as SSG_LOCAL_LEVEL with nvar = 0) */, SSG_TRIG = 6 };
+       SSG_STATIC_INTERCEPT = 5 /* (the C-ABI's number; stored as SSG_LOCAL_LEVEL with nvar = 0) */, SSG_TRIG = 6,
+       // SemilocalLinearTrendStateModel: (level, slope, the slope's long-run mean mu); T = [[1, 1, 0],
+       // [0, phi, 1 - phi], [0, 0, 1]]; its (phi, mu) and the slope's Ar1Suf take one of the chain's
+       // autoregression slots (ar_phi[0 .. 1]; ar_suf[0 .. 5] = sumsq, sum, cross, n, first, last)
+       SSG_SEMILOCAL = 7 };
 // a chain's ArModel sufficient statistics (per autoregression block): xtx (lags x lags at
 // leading dimension AR_MAX) | xty | yty | n
 enum { AR_SUF_XTY = AR_MAX * AR_MAX, AR_SUF_YTY = AR_SUF_XTY + AR_MAX, AR_SUF_N = AR_SUF_YTY + 1,
@@ -33,6 +37,7 @@ struct SsgBlock {
   int32_t sid[2];      // Philox sampler ids of the variance samplers (autoregression: its ArPosteriorSampler's)
   int32_t nfreq;       // trig: frequencies (dim = 2 nfreq)
   int32_t err0;        // index of the block's first state-error row (a trig block has dim of them, a trend two, the others one)
+  int32_t sl_truncate, sl_positive;   // semilocal: NonzeroMeanAr1Sampler::force_stationary / force_ar1_positive
 };
 // the specification, in device memory (read through the scalar cache)
 struct SsgSpec {
@@ -46,6 +51,8 @@ struct SsgSpec {
   double a0[SSG_MAX_STATE], P0[SSG_MAX_STATE];   // initial state mean, variance (diagonal)
   // trig: the rotation [[c, s], [-s, c]] of the pair a component belongs to (by state component)
   double trig_c[SSG_MAX_STATE], trig_s[SSG_MAX_STATE];
+  // semilocal (by autoregression slot): the slope's mean prior N(mu, sigma), its AR(1) coefficient's prior N(mu, sigma)
+  double sl_prior[SSG_MAX_AR][4];
 };
 struct SsmParams {
   const SsgSpec *spec;                  // device copy

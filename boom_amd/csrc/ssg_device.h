@@ -279,6 +279,59 @@ __device__ __forceinline__ int ar_draw(ArLds &W, const double *suf, int L, doubl
   return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
 }
 
+// ---- NonzeroMeanAr1Sampler::draw (NonzeroMeanAr1Sampler.cpp:51-155) for a semilocal trend's slope
+// model, on its Ar1Suf (NonzeroMeanAr1Model.cpp:39-128; suf = sumsq, sum, cross, n, first, last):
+// draw_mu, draw_phi (a normal; truncated to [lo, 1] under force_stationary), draw_sigma -- one
+// generator, every lane of the (whole) wave the same numbers.  In / out: mu, phi, sigsq.
+__device__ __forceinline__ int semilocal_slope_draw(const double *suf, const double *prior, bool truncate, bool positive,
+                                                    double prior_df, double prior_ss, double sigma_max, SeqRng &rng,
+                                                    double &mu, double &phi, double &sigsq) {
+  const double a1_sumsq = suf[0], a1_sum = suf[1], a1_cross = suf[2], n = suf[3], a1_first = suf[4], a1_last = suf[5];
+  const double lag_sumsq = a1_sumsq - a1_last * a1_last;
+  const double lag_sum = a1_sum - a1_last;
+  const double sum_excluding_first = a1_sum - a1_first;
+  const double sumsq_excluding_first = a1_sumsq - a1_first * a1_first;
+  {  // draw_mu
+    const double psig = prior[1] * prior[1];
+    const double omp = 1 - phi;
+    double ivar = (1 + (n - 1) * (omp * omp)) / sigsq;
+    ivar += 1.0 / psig;
+    double mean = (1 - phi) * (sum_excluding_first - phi * lag_sum) + a1_first;
+    mean /= sigsq;
+    mean += prior[0] / psig;
+    mean /= ivar;
+    mu = d_rnorm(rng, mean, sqrt(1.0 / ivar));
+  }
+  {  // draw_phi
+    const double psig = prior[3] * prior[3];
+    double ivar = lag_sumsq - 2 * lag_sum * mu + (n - 1) * mu * mu;   // centered_lag_sumsq(mu)
+    ivar /= sigsq;
+    ivar += 1.0 / psig;
+    double mean = a1_cross - mu * (sum_excluding_first + lag_sum) + (n - 1) * mu * mu;   // centered_cross(mu)
+    mean /= sigsq;
+    mean += prior[2] / psig;
+    mean /= ivar;
+    const double sd = sqrt(1.0 / ivar);
+    if (truncate) {
+      int bad = 0;
+      phi = ar_rtrun_norm_2(rng, mean, sd, positive ? 0.0 : -1.0, 1.0, &bad);
+      if (bad) return CHAIN_RNG_BRANCH;
+    } else {
+      phi = d_rnorm(rng, mean, sd);
+    }
+  }
+  {  // draw_sigma: model_sumsq(mu, phi), df = n
+    const double d0 = a1_first - mu, mp = mu * (1 - phi);
+    double ss = d0 * d0;
+    ss += sumsq_excluding_first - 2 * phi * a1_cross - 2 * (1 - phi) * mu * sum_excluding_first +
+          phi * phi * lag_sumsq + 2 * phi * (1 - phi) * mu * lag_sum + (n - 1) * (mp * mp);
+    int bad = 0;
+    sigsq = d_draw_variance(rng, n + prior_df, ss + prior_ss, sigma_max, &bad);
+    if (bad) return CHAIN_RNG_BRANCH;
+  }
+  return CHAIN_OK;
+}
+
 // ---- the block list: lane b of each of three registers holds block b (so that all blocks
 // advance in one vector operation and a loop over blocks is a ROLLED loop that fetches its
 // block with v_readlane -- eight unrolled copies of every per-block code path made a kernel
@@ -293,6 +346,7 @@ struct Blocks {
   unsigned seasmask;   // bit b: block b is seasonal
   unsigned armask;     // bit b: block b is an autoregression
   unsigned trigmask;   // bit b: block b is a trig model (pairs of components that rotate)
+  unsigned slmask;     // bit b: block b is a semilocal linear trend (level, slope, the slope's long-run mean)
   static __device__ __forceinline__ int kind_of(unsigned d) { return (int)(d & 7u); }
   static __device__ __forceinline__ int first_of(unsigned d) { return (int)((d >> 3) & 127u); }
   static __device__ __forceinline__ int dim_of(unsigned d) { return (int)((d >> 10) & 127u); }
@@ -311,7 +365,8 @@ struct Blocks {
       dp = (unsigned)K.duration | ((unsigned)K.phase << 16);
     }
     const int kd = kind_of(desc);
-    always = (unsigned)__ballot(kd == SSG_LOCAL_LINEAR_TREND || kd == SSG_AR || kd == SSG_TRIG);
+    always = (unsigned)__ballot(kd == SSG_LOCAL_LINEAR_TREND || kd == SSG_AR || kd == SSG_TRIG || kd == SSG_SEMILOCAL);
+    slmask = (unsigned)__ballot(kd == SSG_SEMILOCAL);
     seasmask = (unsigned)__ballot(kd == SSG_SEASONAL);
     armask = (unsigned)__ballot(kd == SSG_AR);
     trigmask = (unsigned)__ballot(kd == SSG_TRIG);
@@ -355,7 +410,7 @@ struct Blocks {
 struct LaneInfo {
   int blk, kind, first, dim;    // its block (kind 0: the lane holds no component)
   int cur;                      // seasonal: its block's cursor (a per-lane copy)
-  double phi;                   // autoregression: the lane's coefficient
+  double phi;                   // autoregression: the lane's coefficient; semilocal trend: the slope's AR(1) coefficient (every lane of the block)
   double tc = 0.0, ts = 0.0;    // trig: cosine and sine of the lane's pair
   __device__ __forceinline__ bool moves(unsigned mv) const { return kind == SSG_SEASONAL && ((mv >> blk) & 1u); }
   // trig: is this the second component of its pair?
@@ -392,6 +447,12 @@ __device__ __forceinline__ double vecT(const Blocks &B, const LaneInfo &L, doubl
       if (L.blk == b && lane == L.first) y = tot;
     }
   }
+  // semilocal trend: (level, slope, mean) -> (level + slope, phi slope + (1 - phi) mean, mean)
+  // (SemilocalLinearTrendMatrix::multiply, SemilocalLinearTrend.cpp:36-46)
+  if (L.kind == SSG_SEMILOCAL) {
+    if (lane == L.first) y = x + above;
+    else if (lane == L.first + 1) y = L.phi * x + (1 - L.phi) * above;
+  }
   // trig: every pair rotates, (x0, x1) -> (c x0 + s x1, -s x0 + c x1)  (the DenseMatrix blocks of
   // TrigStateModel.cpp:144-153)
   if (B.trigmask) {
@@ -424,6 +485,11 @@ __device__ __forceinline__ double vecTt(const Blocks &B, const LaneInfo &L, doub
       const double firstv = rl(x, Blocks::first_of(B.udesc(b)));
       if (L.blk == b) y = L.phi * firstv + ((lane + 1 < L.first + L.dim) ? above : 0.0);
     }
+  }
+  // semilocal trend: Tmult (SemilocalLinearTrend.cpp:65-76): (r0, r1, r2) -> (r0, r0 + phi r1, (1 - phi) r1 + r2)
+  if (L.kind == SSG_SEMILOCAL) {
+    if (lane == L.first + 1) y = below + L.phi * x;
+    else if (lane == L.first + 2) y = (1 - L.phi) * below + x;
   }
   if (B.trigmask) {
     // the rotations' transposes: (x0, x1) -> (c x0 - s x1, s x0 + c x1)

@@ -16,6 +16,12 @@
 //   TrigStateModel(period, frequencies)      2 components per frequency that rotate, Z = 1 at
 //                                            every pair's first, ONE variance for all of them
 //                                            (TrigStateModel.cpp:130-223)
+//   SemilocalLinearTrendStateModel           3 components (level, slope, the slope's long-run
+//                                            mean mu): T = [[1, 1, 0], [0, phi, 1 - phi], [0, 0, 1]],
+//                                            errors on level and slope; the level's
+//                                            ZeroMeanGaussianConjSampler and the slope's
+//                                            NonzeroMeanAr1Sampler (SemilocalLinearTrend.cpp:29-272,
+//                                            NonzeroMeanAr1Sampler.cpp:51-155)
 // SURVEY 8f row f2.
 //
 //   state model samplers                 (ZeroMeanGaussianConjSampler.cpp:57-60,
@@ -125,7 +131,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
     for (int b = 0; b < nb; ++b) {
       const SsgBlock &K = Q.blk[b];
       if (K.kind == SSG_AR) continue;
-      for (int v = 0; v < K.nvar; ++v) {
+      // (a semilocal trend: the level's variance here; the slope's NonzeroMeanAr1Sampler below, after it)
+      for (int v = 0; v < (K.kind == SSG_SEMILOCAL ? 1 : K.nvar); ++v) {
         const int vi = K.var0 + v;
         const size_t at = (size_t)chain * SSG_MAX_VAR + vi;
         SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, (uint32_t)K.sid[v]}, M.pos_var[at]};
@@ -153,6 +160,33 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   // ---- the autoregression blocks' samplers, by wave 0 (the sampler's vectors sit at lanes 0 .. L - 1)
   for (int b = 0; b < nb; ++b) {
     const SsgBlock &K = Q.blk[b];
+    if (K.kind == SSG_SEMILOCAL) {
+      // the slope model's sampler (mu, phi, sigma: one stream), by wave 0, every lane alike
+      const int vi = K.var0 + 1;
+      const size_t at = (size_t)chain * SSG_MAX_VAR + vi;
+      double *gphi = M.ar_phi + ((size_t)chain * SSG_MAX_AR + K.ar_index) * AR_MAX;
+      if (wave == 0) {
+        double ph = gphi[0], mu = gphi[1], sig2s = M.var_sigsq[at];
+        if (draw_variances) {
+          SeqRng rng{PhiloxKey{P.seed_lo, P.seed_hi, gchain, (uint32_t)K.sid[1]}, M.pos_var[at]};
+          const double *suf = M.ar_suf + ((size_t)chain * SSG_MAX_AR + K.ar_index) * AR_SUF_STRIDE;
+          const int st = semilocal_slope_draw(suf, Q.sl_prior[K.ar_index], K.sl_truncate != 0, K.sl_positive != 0,
+                                              Q.prior_df[vi], Q.prior_ss[vi], Q.sigma_max[vi], rng, mu, ph, sig2s);
+          if (st != CHAIN_OK) {
+            if (lane == 0) s_flag = st;
+          } else if (lane == 0) {
+            gphi[0] = ph;
+            gphi[1] = mu;
+            M.var_sigsq[at] = sig2s;
+            M.pos_var[at] = rng.pos;
+          }
+        }
+        if (lane < AR_MAX) s_phi[K.ar_index * AR_MAX + lane] = lane == 0 ? ph : (lane == 1 ? mu : 0.0);
+        if (lane == 0) s_sig2[vi] = sig2s;
+      }
+      __syncthreads();
+      continue;
+    }
     if (K.kind != SSG_AR) continue;
     const int L = K.lags, vi = K.var0;
     const size_t at = (size_t)chain * SSG_MAX_VAR + vi;
@@ -192,6 +226,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   LaneInfo LI{-1, 0, 0, 0, 0, 0.0};
   int var_l = 0;          // the variance parameter behind this lane's state error
   int erow_l = 0;         // which of the state-error rows this lane's is (the smoothed disturbances' series)
+  bool sl_mean_lane = false;   // the lane holds a semilocal trend's third component (the slope's long-run mean)
+  double sl_mu_l = 0.0;        // ... and its value
   int cbefore_l = 0;      // error terms drawn at EVERY step ahead of this lane's term
   unsigned sbefore_l = 0; // seasonal blocks ahead of it (their terms are drawn on some steps only)
   int ipos_l = 0;         // position of this lane's normal among those of the initial state
@@ -207,7 +243,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       const unsigned d = B.udesc(b);
       const int f = Blocks::first_of(d), n = Blocks::dim_of(d), kd = Blocks::kind_of(d), v0 = Blocks::var0_of(d);
       const bool mine = lane >= f && lane < f + n;
-      const bool second = kd == SSG_LOCAL_LINEAR_TREND && lane == f + 1;
+      const bool second = (kd == SSG_LOCAL_LINEAR_TREND || kd == SSG_SEMILOCAL) && lane == f + 1;
       const int within = kd == SSG_TRIG ? lane - f : (second ? 1 : 0);   // (a trig block: an error term per component)
       if (mine) {
         LI.blk = b; LI.kind = kd; LI.first = f; LI.dim = n;
@@ -217,14 +253,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         sbefore_l = sb;
         if (kd == SSG_AR) LI.phi = s_phi[Blocks::arx_of(d) * AR_MAX + (lane - f)];
         if (kd == SSG_TRIG) { LI.tc = Q.trig_c[lane]; LI.ts = Q.trig_s[lane]; }
+        if (kd == SSG_SEMILOCAL) {
+          LI.phi = s_phi[Blocks::arx_of(d) * AR_MAX];
+          // (the third component, the slope's long-run mean: no error term -- its variance slot is
+          // the slope's, switched off below -- and its initial mean is mu as it stands)
+          if (lane == f + 2) { var_l = -1; sl_mu_l = s_phi[Blocks::arx_of(d) * AR_MAX + 1]; sl_mean_lane = true; }
+        }
       }
-      eb += kd == SSG_TRIG ? n : (kd == SSG_LOCAL_LINEAR_TREND ? 2 : 1);
+      eb += kd == SSG_TRIG ? n : ((kd == SSG_LOCAL_LINEAR_TREND || kd == SSG_SEMILOCAL) ? 2 : 1);
       // the initial state's normals: a local level draws rnorm(a0, sd0) (nothing when
       // sd0 == 0), every other model rmvn: one per component
       if (kd == SSG_LOCAL_LEVEL) {
         const bool drawn = Q.P0[f] != 0.0;
         if (mine) { ipos_l = ip; init_l = drawn; }
         ip += drawn ? 1 : 0;
+      } else if (kd == SSG_SEMILOCAL) {
+        // rnorm_mt(level mean, sd), rnorm_mt(slope mean, sd), mu (SemilocalLinearTrend.cpp:262-270)
+        if (mine) { ipos_l = ip + (lane - f); init_l = lane < f + 2; }
+        ip += 2;
       } else {
         if (mine) { ipos_l = ip + (lane - f); init_l = true; }
         ip += n;
@@ -235,6 +281,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       const bool nz = s_sig2[v0] != 0.0;
       if (kd == SSG_LOCAL_LEVEL) cb += nz ? 1 : 0;
       else if (kd == SSG_LOCAL_LINEAR_TREND) cb += 2;
+      else if (kd == SSG_SEMILOCAL) cb += 2;   // (rnorm_mt(0, sigma) for level and slope: both sigmas are positive)
       else if (kd == SSG_AR) cb += 1;
       else if (kd == SSG_TRIG) cb += nz ? n : 0;
       else {
@@ -247,8 +294,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
     seas_active = (unsigned)__builtin_amdgcn_readfirstlane((int)seas_active);
   }
   const bool mylane = lane < m;
-  if (mylane) { a0l = Q.a0[lane]; P0l = Q.P0[lane]; }
-  const double sig_l = mylane ? s_sig2[var_l] : 0.0;
+  if (mylane) { a0l = sl_mean_lane ? sl_mu_l : Q.a0[lane]; P0l = Q.P0[lane]; }
+  const double sig_l = (mylane && var_l >= 0) ? s_sig2[var_l] : 0.0;
   const double sd_l = sqrt(sig_l);
 
   const double H = P.sigsq[chain], sqrtH = sqrt(H);
@@ -438,6 +485,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
               // component, -(sum over the block)
               if (moves) col[sprev((int)(B.urc(b) >> 16), n) * ld] = cs;
             }
+          } else if (kd == SSG_SEMILOCAL) {
+            double v0 = col[0], v1 = col[ld], v2 = col[2 * ld];
+            if (obs) {
+              v0 -= (s_tv[f] * PZ) * Finv;
+              v1 -= (s_tv[f + 1] * PZ) * Finv;
+              v2 -= (s_tv[f + 2] * PZ) * Finv;
+              col[2 * ld] = v2;
+            }
+            const double ph = s_phi[Blocks::arx_of(d) * AR_MAX];
+            col[0] = v0 + v1;
+            col[ld] = ph * v1 + (1 - ph) * v2;
           } else if (kd == SSG_TRIG) {
             // the rotations from the left, a pair of the column's entries at a time
 #pragma nounroll
@@ -512,6 +570,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma nounroll
             for (; j0 < n; ++j0) cs -= row[j0];
             row[w] = cs + (lane == f + w ? sg : 0.0);
+          } else if (kd == SSG_SEMILOCAL) {
+            const double r0 = row[0], r1 = row[1], r2 = row[2];
+            const double ph = s_phi[Blocks::arx_of(d) * AR_MAX];
+            row[0] = (r0 + r1) + (lane == f ? sg : 0.0);
+            row[1] = (ph * r1 + (1 - ph) * r2) + (lane == f + 1 ? s_sig2[Blocks::var0_of(d) + 1] : 0.0);
           } else if (kd == SSG_TRIG) {
             // the rotations' transposes from the right, + RQR (sigma^2 on the block's whole diagonal)
 #pragma nounroll
@@ -551,21 +614,26 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         // in one, another block's T' from the right in the other): its rows and columns are made
         // symmetric the way the reference does after every update (fix_near_symmetry,
         // SpdMatrix.cpp:350-357) -- lane k averages P(i, k) and P(k, i) for the block's rows i
-        if (B.trigmask) {
-          unsigned tq = B.trigmask;
+        if (B.trigmask | B.slmask) {
+          unsigned tq = B.trigmask | B.slmask;
           while (tq) {
             const int b = __ffs((int)tq) - 1;
             tq &= tq - 1;
             const unsigned d = B.udesc(b);
             const int f = Blocks::first_of(d), n = Blocks::dim_of(d);
 #pragma nounroll
-            for (int i = 0; i < n; i += 2) {
+            for (int i = 0; i + 1 < n; i += 2) {
               if (!mylane) continue;
               double *cu = s_P + (f + i) * ld + lane, *ro = s_P + lane * ld + f + i;
               const double a0 = cu[0], a1 = cu[ld], b0 = ro[0], b1 = ro[1];
               const double m0 = .5 * (a0 + b0), m1 = .5 * (a1 + b1);
               cu[0] = m0; ro[0] = m0;
               cu[ld] = m1; ro[1] = m1;
+            }
+            if ((n & 1) && mylane) {   // (a semilocal trend's third row)
+              double *cu = s_P + (f + n - 1) * ld + lane, *ro = s_P + lane * ld + f + n - 1;
+              const double m0 = .5 * (cu[0] + ro[0]);
+              cu[0] = m0; ro[0] = m0;
             }
           }
           wave_lds_sync();
@@ -619,6 +687,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           else if (LI.kind == SSG_LOCAL_LINEAR_TREND) err = true;
           else if (LI.kind == SSG_AR) err = lane == LI.first;
           else if (LI.kind == SSG_TRIG) err = sig_l != 0.0;
+          else if (LI.kind == SSG_SEMILOCAL) err = lane < LI.first + 2;
           else if (LI.kind == SSG_SEASONAL) err = ((act >> LI.blk) & 1u) && lane == LI.first + LI.cur;
           const double z = err ? s_z[zo + cbefore_l + __popc(act & sbefore_l)] : 0.0;
           alpha += sd_l * z;
@@ -699,6 +768,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         bool carrier;
         if (LI.kind == SSG_SEASONAL) carrier = lane == LI.first + LI.cur;
         else if (LI.kind == SSG_LOCAL_LINEAR_TREND || LI.kind == SSG_TRIG) carrier = true;
+        else if (LI.kind == SSG_SEMILOCAL) carrier = lane < LI.first + 2;
         else carrier = lane == LI.first;
         if (carrier) s_z[erow_l * BL + s] = r;
       }
@@ -752,6 +822,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           if (mylane) {
             if (LI.kind == SSG_SEASONAL) carrier = LI.moves(mv) && lane == LI.first + LI.cur;
             else if (LI.kind == SSG_LOCAL_LINEAR_TREND || LI.kind == SSG_TRIG) carrier = true;
+            else if (LI.kind == SSG_SEMILOCAL) carrier = lane < LI.first + 2;
             else carrier = lane == LI.first;
           }
           if (carrier) mc += sig_l * s_z[erow_l * BL + s];
@@ -779,6 +850,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   // ArModel's NeRegSuf of now[first] on then[first ..]: lane first + i keeps xty_i and row i
   // of xtx, the row in LDS at s_axx[(block's slot * AR_MAX + i) * (AR_MAX + 1) + q]
   double axy = 0.0, ayy = 0.0;
+  // a semilocal trend's Ar1Suf of the slope draws (its lane first + 1): Ar1Suf::update_raw
+  double a1_sumsq = 0.0, a1_sum = 0.0, a1_cross = 0.0, a1_first = 0.0, a1_last = 0.0;
   for (int e2 = lane; e2 < M.nar * AR_MAX * (AR_MAX + 1); e2 += WAVE) s_axx[e2] = 0.0;
   wave_lds_sync();
   seek(B, LI, 0, -1);
@@ -815,10 +888,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         }
         const double then1 = from_above(prev);
         const double thenb = B.trigmask ? from_below(prev) : 0.0;
+        if (LI.kind == SSG_SEMILOCAL && lane == LI.first + 1) {
+          // observe_initial_state / observe_state: the current slope into the Ar1Suf, every t
+          // (SemilocalLinearTrend.cpp:168-180; NonzeroMeanAr1Model.cpp:39-49)
+          if (tb + s == 0) a1_first = st; else a1_cross += st * a1_last;
+          a1_sum += st;
+          a1_sumsq += st * st;
+          a1_last = st;
+        }
         if (tb + s > 0) {
           if (LI.kind == SSG_LOCAL_LEVEL) {
             const double diff = st - prev;
             suf_l += diff * diff;
+          } else if (LI.kind == SSG_SEMILOCAL) {
+            if (lane == LI.first) {
+              const double change_in_level = st - prev - then1;
+              suf_l += change_in_level * change_in_level;
+            }
           } else if (LI.kind == SSG_TRIG) {
             // now - rotation * then, every component (TrigStateModel::observe_state, TrigStateModel.cpp:182-193)
             const double rot = LI.todd(lane) ? -LI.ts * thenb + LI.tc * prev : LI.tc * prev + LI.ts * then1;
@@ -894,6 +980,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         M.var_n[at + (lane - f)] = mv_n;
         M.var_ss[at + (lane - f)] = ssv;
       }
+    } else if (kd == SSG_SEMILOCAL) {
+      if (lane == f) {
+        M.var_n[at] = (double)(T - 1);
+        M.var_ss[at] = suf_l;
+      }
+      if (lane == f + 1) {
+        double *suf = M.ar_suf + ((size_t)chain * SSG_MAX_AR + Blocks::arx_of(d)) * AR_SUF_STRIDE;
+        suf[0] = a1_sumsq; suf[1] = a1_sum; suf[2] = a1_cross; suf[3] = (double)T; suf[4] = a1_first; suf[5] = a1_last;
+        M.var_n[at + 1] = (double)T;
+        M.var_ss[at + 1] = 0.0;
+      }
     } else if (kd == SSG_TRIG) {
       // one GaussianSuf for all the block's components
       const double tot = wsum<SMALL>(LI.blk == b ? suf_l : 0.0);
@@ -967,6 +1064,12 @@ __global__ __launch_bounds__(64) void ssg_forecast_kernel(SsParams P, int horizo
         const double x1 = rl(st, f + 1);
         if (lane == f) nx = (st + x1) + (sqrt(sg[0]) * z0 + 0.0);
         if (lane == f + 1) nx = st + (sqrt(sg[1]) * z1 + 0.0);
+      } else if (K.kind == SSG_SEMILOCAL) {
+        const double *ph = M.ar_phi + ((size_t)chain * SSG_MAX_AR + K.ar_index) * AR_MAX;
+        const double e0 = d_rnorm(rng, 0.0, sqrt(sg[0])), e1 = d_rnorm(rng, 0.0, sqrt(sg[1]));
+        const double above = from_above(st);
+        if (lane == f) nx = (st + above) + e0;
+        else if (lane == f + 1) nx = (ph[0] * st + (1 - ph[0]) * above) + e1;
       } else if (K.kind == SSG_TRIG) {
         // rnorm_mt(rng, 0, sigma) per component, in order (TrigStateModel.cpp:218-223), on the rotated state
         const double sd = sqrt(sg[0]);

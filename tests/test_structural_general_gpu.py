@@ -57,6 +57,8 @@ def compare(eng, oracle, y, X, obs, prior, opts, blocks, seed, chains, g0, nsw, 
                 assert relerr(sm["variances"], o["variances"][s, b, :nv], 1e-300) < RTOL, tag + (b,)
                 if blk["kind"] == 4:
                     assert relerr(sm["phi"], o["phi"][s, b, :blk["lags"]], 1e-6) < RTOL, tag + (b,)
+                if blk["kind"] == 7:     # (a semilocal trend's phi and mu)
+                    assert relerr(sm["phi"], o["phi"][s, b, :2], 1e-6) < RTOL, tag + (b,)
             st = eng.ss_get_state_draw(c)
             scale = np.abs(o["state"][s]).max()
             assert np.max(np.abs(st - o["state"][s])) < 1e-8 * scale, tag
@@ -72,6 +74,9 @@ def compare(eng, oracle, y, X, obs, prior, opts, blocks, seed, chains, g0, nsw, 
                 assert np.max(np.abs(sm["xtx"] - a["xtx"])) < 1e-8 * sc
                 assert np.max(np.abs(sm["xty"] - a["xty"])) < 1e-8 * sc
                 assert abs(sm["yty"] - a["yty"]) < 1e-8 * sc and sm["n"] == a["n"]
+            elif blk["kind"] == 7:   # (the level's statistics; the slope's Ar1Suf has n = T)
+                assert sm["suf_n"][0] == o["suf_n"][b, 0] and sm["ar1_suf"][3] == len(y), (c, b)
+                assert relerr(sm["suf_ss"][:1], o["suf_ss"][b, :1], 1e-300) < RTOL, (c, b)
             elif nv > 0:
                 assert np.array_equal(sm["suf_n"], o["suf_n"][b, :nv]), (c, b)
                 assert relerr(sm["suf_ss"], o["suf_ss"][b, :nv], 1e-300) < RTOL, (c, b)
@@ -238,7 +243,14 @@ def test_general_argument_errors():
         b.update(kw)
         with pytest.raises(boom_amd.BoomAmdError):
             eng.ss_set_state_models([b])
-    bad(kind=7)
+    bad(kind=8)
+    sl = dict(kind=7, df=np.ones(2), sigma_guess=np.ones(2), sigma_upper_limit=np.full(2, np.inf),
+              initial_sigma=np.ones(2), a0=np.zeros(3), P0=np.array([1.0, 1.0, 0.0]),
+              slope_priors=np.array([0.0, 1.0, 0.0, 1.0, 0.0, 0.0]))
+    bad(**dict(sl, force_stationary=0, force_positive=1))            # the one-sided truncation is not built
+    bad(**dict(sl, slope_priors=np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0])))   # a prior sd of 0
+    bad(**dict(sl, initial_sigma=np.array([1.0, 0.0])))
+    bad(**dict(sl, P0=np.array([1.0, 0.0, 0.0])))
     bad(kind=6, rotations=np.zeros(0), a0=np.zeros(0), P0=np.zeros(0))              # no frequency
     bad(kind=6, rotations=np.tile([1.0, 0.0], 33), a0=np.zeros(66), P0=np.ones(66))  # 66 components
     bad(kind=5, df=np.zeros(0), sigma_guess=np.zeros(0), sigma_upper_limit=np.zeros(0),

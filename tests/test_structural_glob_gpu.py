@@ -46,6 +46,12 @@ def test_static_intercept_and_trig_lists_match_oracle(oracle, name):
     ([("intercept",), ("trig", 4.0, [1.0])], 3, 0.0),
     # a trig block with a frequency of half the period (sin = 1.2e-16: the second component is all but static)
     ([("trig", 6.0, [3.0, 1.0]), ("ar", 2)], 90, 0.0),
+    # semilocal linear trend: with an autoregression block (both take coefficient slots), two of them,
+    # in a list of m = 3 + 11 + 6 + 1 = 21, and on a series of three points
+    ([("semilocal",), ("ar", 2)], 110, 0.02),
+    ([("semilocal", 1, 1), ("seasonal", 4, 2), ("semilocal", 0, 0)], 95, 0.0),
+    ([("seasonal", 12, 1), ("semilocal",), ("trig", 7.0, [1.0, 2.0, 3.0]), ("intercept",)], 130, 0.03),
+    ([("semilocal",)], 3, 0.0),
 ])
 def test_glob_shapes_match_oracle(oracle, desc, T, missing):
     p, chains, seed, nsw = 5, 4, 19, 8
@@ -53,7 +59,7 @@ def test_glob_shapes_match_oracle(oracle, desc, T, missing):
     trig = [(b[1], b[2][:2]) for b in desc if b[0] == "trig"]
     X, y, _, obs = general_data(T, p, 2, seas[:2], seed=7 + T, missing_frac=missing, trig=trig, intercept=1.0,
                                 ar_coef=[0.5] if any(b[0] == "ar" for b in desc) else None,
-                                level=any(b[0] in ("level", "trend") for b in desc))
+                                level=any(b[0] in ("level", "trend", "semilocal") for b in desc))
     prior, _, sig_up = bsts_priors(X, y, 2)
     blocks = general_spec(y, desc)
     opts = ssvs_options(sigma_upper_limit=sig_up)
@@ -77,16 +83,17 @@ def test_static_intercept_is_no_local_level_of_the_stream_families(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("key", ["a", "b"])
+@pytest.mark.parametrize("key", ["a", "b", "c"])
 def test_glob_forecast_matches_oracle(oracle, key):
     """simulate_forecast with a static intercept (no error term drawn) and trig blocks (2 nfreq
     draws a step on the rotated state): every chain's forecast of its current draw against the
     oracle's on the chain's forecast stream"""
     g = load("kat_glob_forecast")
     desc = {"a": [("intercept",), ("trig", 12.0, [1.0, 2.0])],
-            "b": [("trig", 7.0, [1.0, 2.0, 3.0]), ("trend",), ("seasonal", 3, 5, 1)]}[key]
+            "b": [("trig", 7.0, [1.0, 2.0, 3.0]), ("trend",), ("seasonal", 3, 5, 1)],
+            "c": [("seasonal", 4, 2), ("semilocal",)]}[key]
     T, p, chains, seed, h = int(g[key + "_T"]), 6, 4, 33, 20
-    X, y, _, obs = general_data(T, p, 2, [], seed=79, trig=[(desc[-1][1] if key == "a" else 7.0, [1.0])])
+    X, y, _, obs = general_data(T, p, 2, [], seed=79, trig=[(12.0 if key == "a" else 7.0, [1.0])])
     prior, _, sig_up = bsts_priors(X, y, 2)
     blocks = general_spec(y, desc)
     g0 = np.zeros(p, np.uint8)
@@ -98,10 +105,13 @@ def test_glob_forecast_matches_oracle(oracle, key):
     for c in (0, chains - 1):
         st = eng.ss_get_state_draw(c)
         sg = np.zeros((len(blocks), 2))
+        fb = [dict(b) for b in blocks]
         for b in range(len(blocks)):
             sm = eng.ss_get_state_model(c, b)
             sg[b, :len(sm["variances"])] = sm["variances"]
-        want = oracle.ssg_forecast(oracle.rng_philox(seed, c, 5), T, newX, beta[c], sig[c], blocks,
+            if fb[b]["kind"] == 7:     # (the chain's phi and mu go in where the oracle's model is built)
+                fb[b]["slope_priors"] = np.array(list(fb[b]["slope_priors"][:4]) + [sm["phi"][1], sm["phi"][0]])
+        want = oracle.ssg_forecast(oracle.rng_philox(seed, c, 5), T, newX, beta[c], sig[c], fb,
                                    sg, np.zeros((len(blocks), 16)), st[-1])
         assert np.max(np.abs(fc[c] - want)) < 1e-8 * max(1.0, np.abs(want).max()), (key, c)
     eng.close()
@@ -113,7 +123,7 @@ def test_glob_lists_behind_the_look_ahead():
     T, p, chains, seed = 90, 4, 6, 11
     X, y, _, obs = general_data(T, p, 2, [], seed=12, trig=[(12.0, [1.0])], intercept=3.0, missing_frac=0.02)
     prior, _, sig_up = bsts_priors(X, y, 2)
-    blocks = general_spec(y, [("intercept",), ("trig", 12.0, [1.0, 2.0]), ("ar", 1)])
+    blocks = general_spec(y, [("intercept",), ("trig", 12.0, [1.0, 2.0]), ("ar", 1), ("semilocal",)])
     g0 = np.zeros(p, np.uint8)
     a = make_engine(chains, seed, y, X, obs, prior, blocks, sig_up, g0)
     b = make_engine(chains, seed, y, X, obs, prior, blocks, sig_up, g0)
@@ -125,5 +135,7 @@ def test_glob_lists_behind_the_look_ahead():
             assert np.array_equal(x, z), it
         assert np.array_equal(a.ss_get_state_draw(0), b.ss_get_state_draw(0)), it
         assert np.array_equal(a.ss_get_state_model(2, 1)["variances"], b.ss_get_state_model(2, 1)["variances"]), it
+        u, v = a.ss_get_state_model(3, 3, suf=False), b.ss_get_state_model(3, 3, suf=False)
+        assert np.array_equal(u["phi"], v["phi"]) and np.array_equal(u["variances"], v["variances"]), it
     a.close()
     b.close()
