@@ -8,6 +8,7 @@
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
 #include "Models/StateSpace/StateModels/StaticInterceptStateModel.hpp"
+#include "Models/StateSpace/StateModels/SemilocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/TrigStateModel.hpp"
 #include "cpputil/math_utils.hpp"
 #include "cpputil/report_error.hpp"
@@ -125,10 +126,12 @@ namespace BOOM {
         b.kind = 5; b.dim = 1; b.nvar = 0;   // (nothing to learn: no entry in state_variance_priors)
       } else if (dynamic_cast<const TrigStateModel *>(sm)) {
         b.kind = 6; b.dim = static_cast<int>(sm->state_dimension());   // (one variance for all 2 x frequencies components)
+      } else if (dynamic_cast<const SemilocalLinearTrendStateModel *>(sm)) {
+        b.kind = 7; b.dim = 3; b.nvar = 2;   // (level, slope; the slope's entry carries the NonzeroMeanAr1Sampler's other priors)
       } else {
         report_error("The device sampler takes LocalLevelStateModel, LocalLinearTrendStateModel, "
-                     "SeasonalStateModel, ArStateModel, StaticInterceptStateModel and TrigStateModel "
-                     "state models.");
+                     "SeasonalStateModel, ArStateModel, StaticInterceptStateModel, TrigStateModel and "
+                     "SemilocalLinearTrendStateModel state models.");
       }
       nvar += b.nvar;
       state_dim_ += b.dim;
@@ -237,10 +240,28 @@ namespace BOOM {
             phi[2 * q] = Tm(2 * q, 2 * q);
             phi[2 * q + 1] = Tm(2 * q, 2 * q + 1);
           }
+        } else if (b.kind == 7) {
+          const SemilocalLinearTrendStateModel *trend = dynamic_cast<const SemilocalLinearTrendStateModel *>(sm);
+          const DeviceStateVariancePrior &sp(variance_priors_[b.var0 + 1]);
+          if (!sp.slope_mean_prior || !sp.slope_ar1_prior)
+            report_error("The slope entry of a SemilocalLinearTrendStateModel's state_variance_priors needs "
+                         "slope_mean_prior and slope_ar1_prior.");
+          init[0] = trend->level_sd();
+          init[1] = trend->slope_sd();
+          ip[0] = sp.force_stationary ? 1 : 0;
+          ip[1] = sp.force_ar1_positive ? 1 : 0;
+          phi.resize(6);
+          phi[0] = sp.slope_mean_prior->mu();
+          phi[1] = std::sqrt(sp.slope_mean_prior->sigsq());
+          phi[2] = sp.slope_ar1_prior->mu();
+          phi[3] = std::sqrt(sp.slope_ar1_prior->sigsq());
+          phi[4] = trend->slope_mean();
+          phi[5] = trend->slope_ar_coefficient();
         }   // (5, StaticInterceptStateModel: no parameter)
         for (ba_engine *e : engines_)
           check(ba_ss_add_state_model(e, b.kind, ip, df, guess, upper, init,
-                                      (b.kind == 4 || b.kind == 6) ? phi.data() : nullptr, a0.data(), v0.data()));
+                                      (b.kind == 4 || b.kind == 6 || b.kind == 7) ? phi.data() : nullptr, a0.data(),
+                                      v0.data()));
       }
     }
 
@@ -406,6 +427,16 @@ namespace BOOM {
         // (StaticInterceptStateModel: nothing but its state, installed below)
       } else if (b.kind == 6) {
         dynamic_cast<TrigStateModel *>(sm)->error_distribution()->set_sigsq(variances[b.var0]);
+      } else if (b.kind == 7) {
+        // (the model's public setters take standard deviations)
+        double pm[2] = {0.0, 0.0};
+        check(ba_ss_get_state_model(engine_, 0, static_cast<int32_t>(s), nullptr, nullptr, nullptr, pm, nullptr,
+                                    nullptr, nullptr, nullptr));
+        SemilocalLinearTrendStateModel *trend = dynamic_cast<SemilocalLinearTrendStateModel *>(sm);
+        trend->set_level_sd(std::sqrt(variances[b.var0]));
+        trend->set_slope_sd(std::sqrt(variances[b.var0 + 1]));
+        trend->set_slope_ar_coefficient(pm[0]);
+        trend->set_slope_mean(pm[1]);
       } else {
         Vector phi(b.lags, 0.0);
         double ar_sigsq = 1.0;
@@ -444,6 +475,15 @@ namespace BOOM {
         check(ba_ss_get_state_model(engine_, 0, static_cast<int32_t>(s), &sigsq, nullptr, nullptr,
                                     phi.data(), nullptr, nullptr, nullptr, nullptr));
         if (!ArModel::check_stationary(phi)) return negative_infinity();
+      }
+      if (b.kind == 7) {
+        // NonzeroMeanAr1Sampler::logpri (NonzeroMeanAr1Sampler.cpp:57-62): the long-run mean's and the
+        // AR(1) coefficient's priors (the two variance priors below)
+        double pm[2] = {0.0, 0.0};
+        check(ba_ss_get_state_model(engine_, 0, static_cast<int32_t>(s), nullptr, nullptr, nullptr, pm, nullptr,
+                                    nullptr, nullptr, nullptr));
+        const DeviceStateVariancePrior &sp(variance_priors_[b.var0 + 1]);
+        ans += sp.slope_mean_prior->logp(pm[1]) + sp.slope_ar1_prior->logp(pm[0]);
       }
       for (int k = 0; k < b.nvar; ++k) {
         const double sigsq = v[b.var0 + k];

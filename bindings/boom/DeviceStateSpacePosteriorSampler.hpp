@@ -21,6 +21,7 @@
 #include "LinAlg/Selector.hpp"
 #include "LinAlg/Vector.hpp"
 #include "Models/GammaModel.hpp"
+#include "Models/GaussianModelBase.hpp"
 #include "Models/Glm/VariableSelectionPrior.hpp"
 #include "Models/MvnGivenScalarSigma.hpp"
 #include "Models/PosteriorSamplers/PosteriorSampler.hpp"
@@ -40,6 +41,14 @@ namespace BOOM {
   struct DeviceStateVariancePrior {
     Ptr<GammaModelBase> precision_prior;
     double sigma_upper_limit;
+    // For the SLOPE entry of a SemilocalLinearTrendStateModel only (null / ignored elsewhere): what
+    // its NonzeroMeanAr1Sampler takes besides the variance prior (NonzeroMeanAr1Sampler.hpp: the
+    // long-run mean's and the AR(1) coefficient's Gaussian priors, force_stationary(),
+    // force_ar1_positive()), as bsts builds it (Interfaces/R/bsts/src/create_state_model.cpp:601-672).
+    Ptr<GaussianModelBase> slope_mean_prior;
+    Ptr<GaussianModelBase> slope_ar1_prior;
+    bool force_stationary = true;
+    bool force_ar1_positive = false;
   };
 
   // Many-chain drop-in for StateSpacePosteriorSampler on a StateSpaceRegressionModel.
@@ -55,7 +64,9 @@ namespace BOOM {
   //       one entry per variance parameter, in the order the state models were added:
   //       (level) for a LocalLevelStateModel, (level, slope) for a
   //       LocalLinearTrendStateModel, (seasonal) for a SeasonalStateModel, the
-  //       ArPosteriorSampler's prior for an ArStateModel.
+  //       ArPosteriorSampler's prior for an ArStateModel, the error distribution's for a
+  //       TrigStateModel, (level, slope -- with the slope's other priors) for a
+  //       SemilocalLinearTrendStateModel; none for a StaticInterceptStateModel.
   //   seasonal_time_of_first_observation
   //       SeasonalStateModel keeps what set_time_of_first_observation was given to itself:
   //       one entry per SeasonalStateModel, in order (empty: all 0).
@@ -138,7 +149,7 @@ namespace BOOM {
     unsigned long device_seed_;
     // the state models as the engine knows them
     struct Block {
-      int kind;    // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression, 5 static intercept, 6 trig
+      int kind;    // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression, 5 static intercept, 6 trig, 7 semilocal linear trend
       int var0;    // index of its first variance parameter (into state_variance_priors)
       int nvar, dim, lags;
     };

@@ -16,6 +16,9 @@
 #include "Models/StateSpace/StateModels/LocalLinearTrend.hpp"
 #include "Models/StateSpace/StateModels/SeasonalStateModel.hpp"
 #include "Models/StateSpace/StateModels/StaticInterceptStateModel.hpp"
+#include "Models/StateSpace/StateModels/SemilocalLinearTrend.hpp"
+#include "Models/TimeSeries/NonzeroMeanAr1Model.hpp"
+#include "Models/GaussianModel.hpp"
 #include "Models/StateSpace/StateModels/TrigStateModel.hpp"
 #include "Models/MvnModel.hpp"
 #include "LinAlg/Matrix.hpp"
@@ -669,6 +672,23 @@ int ref_binding_ssg_run(int T, int p, const double *y, const double *X, const ui
         icpt->set_initial_state_variance(P0[first]);
         model->add_state(icpt);
         dim = 1;   // (no parameter: no variance prior)
+      } else if (kinds[b] == 7) {
+        const double *pp = phi0 + 16 * b;
+        NEW(ZeroMeanGaussianModel, level)(vp[3]);
+        NEW(NonzeroMeanAr1Model, slope)(pp[4], pp[5], vp[7]);
+        NEW(SemilocalLinearTrendStateModel, trend)(level, slope);
+        trend->set_initial_level_mean(a0[first]);
+        trend->set_initial_slope_mean(a0[first + 1]);
+        trend->set_initial_level_sd(std::sqrt(P0[first]));
+        trend->set_initial_slope_sd(std::sqrt(P0[first + 1]));
+        model->add_state(trend);
+        vprior(0);
+        vprior(1);
+        vpriors.back().slope_mean_prior = new GaussianModel(pp[0], pp[1]);
+        vpriors.back().slope_ar1_prior = new GaussianModel(pp[2], pp[3]);
+        vpriors.back().force_stationary = iparams[3 * b] != 0;
+        vpriors.back().force_ar1_positive = iparams[3 * b + 1] != 0;
+        dim = 3;
       } else if (kinds[b] == 6) {
         const int nf = iparams[3 * b];
         Vector freqs(nf);
@@ -737,6 +757,12 @@ int ref_binding_ssg_run(int T, int p, const double *y, const double *X, const ui
           // (no parameter)
         } else if (kinds[b] == 6) {
           v[0] = dynamic_cast<TrigStateModel *>(sm)->error_distribution()->sigsq();
+        } else if (kinds[b] == 7) {
+          SemilocalLinearTrendStateModel *trend = dynamic_cast<SemilocalLinearTrendStateModel *>(sm);
+          v[0] = trend->level_sd() * trend->level_sd();
+          v[1] = trend->slope_sd() * trend->slope_sd();
+          ph[0] = trend->slope_ar_coefficient();
+          ph[1] = trend->slope_mean();
         } else {
           ArStateModel *arm = dynamic_cast<ArStateModel *>(sm);
           v[0] = arm->sigsq();

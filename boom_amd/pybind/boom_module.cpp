@@ -371,6 +371,31 @@ PYBIND11_MODULE(_boom, boom) {
            py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
            "ZeroMeanGaussianConjSampler(error_distribution(), ChisqModel(df, sigma_guess)) + set_sigma_upper_limit");
 
+  py::class_<ZeroMeanGaussianModel, Ptr<ZeroMeanGaussianModel>>(boom, "ZeroMeanGaussianModel")
+      .def(py::init<double>(), py::arg("sigma") = 1.0)
+      .def_property_readonly("sigma", &ZeroMeanGaussianModel::sigma);
+  py::class_<NonzeroMeanAr1Model, Ptr<NonzeroMeanAr1Model>>(boom, "NonzeroMeanAr1Model")
+      .def(py::init<double, double, double>(), py::arg("mu") = 0.0, py::arg("phi") = 0.0, py::arg("sigma") = 1.0)
+      .def_property_readonly("mu", &NonzeroMeanAr1Model::mu)
+      .def_property_readonly("phi", &NonzeroMeanAr1Model::phi)
+      .def_property_readonly("sigma", &NonzeroMeanAr1Model::sigma);
+  py::class_<SemilocalLinearTrendStateModel, Ptr<SemilocalLinearTrendStateModel>>(boom, "SemilocalLinearTrendStateModel")
+      .def(py::init<const Ptr<ZeroMeanGaussianModel> &, const Ptr<NonzeroMeanAr1Model> &>(), py::arg("level"),
+           py::arg("slope"))
+      .def_property_readonly("state_dimension", &SemilocalLinearTrendStateModel::state_dimension)
+      .def("set_initial_level_mean", &SemilocalLinearTrendStateModel::set_initial_level_mean)
+      .def("set_initial_level_sd", &SemilocalLinearTrendStateModel::set_initial_level_sd)
+      .def("set_initial_slope_mean", &SemilocalLinearTrendStateModel::set_initial_slope_mean)
+      .def("set_initial_slope_sd", &SemilocalLinearTrendStateModel::set_initial_slope_sd)
+      .def("set_level_prior", &SemilocalLinearTrendStateModel::set_level_prior, py::arg("df"), py::arg("sigma_guess"),
+           py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(),
+           "ZeroMeanGaussianConjSampler(level, df, sigma_guess) + set_sigma_upper_limit")
+      .def("set_slope_prior", &SemilocalLinearTrendStateModel::set_slope_prior, py::arg("mean_mu"),
+           py::arg("mean_sigma"), py::arg("ar1_mu"), py::arg("ar1_sigma"), py::arg("df"), py::arg("sigma_guess"),
+           py::arg("sigma_upper_limit") = std::numeric_limits<double>::infinity(), py::arg("force_stationary") = true,
+           py::arg("force_ar1_positive") = false,
+           "NonzeroMeanAr1Sampler(slope, mean prior, AR(1) coefficient prior, ChisqModel(df, sigma_guess)) + its switches");
+
   py::class_<StateSpaceRegressionModel, Ptr<StateSpaceRegressionModel>>(boom, "StateSpaceRegressionModel")
       .def(py::init([](const NpArray &response, const NpArray &predictors, const std::vector<bool> &is_observed,
                        int chains, uint64_t seed, int device) {
@@ -388,6 +413,10 @@ PYBIND11_MODULE(_boom, boom) {
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<ArStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<StaticInterceptStateModel> &s) { m.add_state(s); })
       .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<TrigStateModel> &s) { m.add_state(s); })
+      .def("add_state", [](StateSpaceRegressionModel &m, const Ptr<SemilocalLinearTrendStateModel> &s) { m.add_state(s); })
+      .def("semilocal_slope", [](const StateSpaceRegressionModel &m, int chain, int which) { return to_numpy(m.semilocal_slope(chain, which)); },
+           py::arg("chain") = 0, py::arg("which") = 0,
+           "(AR(1) coefficient, long-run mean) of the which-th SemilocalLinearTrendStateModel's slope in one chain's draw")
       .def_property_readonly("number_of_state_models", &StateSpaceRegressionModel::number_of_state_models)
       .def("ar_phi", [](const StateSpaceRegressionModel &m, int chain, int which) { return to_numpy(m.ar_phi(chain, which)); },
            py::arg("chain") = 0, py::arg("which") = 0,

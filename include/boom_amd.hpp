@@ -471,6 +471,54 @@ class TrigStateModel {
   double sigma_ = 1.0, df_ = 1.0, guess_ = 1.0, upper_ = infinity();
 };
 
+// SemilocalLinearTrendStateModel(level, slope) (StateModels/SemilocalLinearTrend.hpp:75): a level
+// that moves by a slope which is itself a stationary AR(1) around a long-run mean -- state (level,
+// slope, mean).  The two model objects it is built from (Models/ZeroMeanGaussianModel.hpp,
+// Models/TimeSeries/NonzeroMeanAr1Model.hpp:77-84) hold the initial parameter values only.
+class ZeroMeanGaussianModel {
+ public:
+  explicit ZeroMeanGaussianModel(double sigma = 1.0) : sigma_(sigma) {}
+  double sigma() const { return sigma_; }
+  double sigma_;
+};
+class NonzeroMeanAr1Model {
+ public:
+  explicit NonzeroMeanAr1Model(double mu = 0.0, double phi = 0.0, double sigma = 1.0) : mu_(mu), phi_(phi), sigma_(sigma) {}
+  double mu() const { return mu_; }
+  double phi() const { return phi_; }
+  double sigma() const { return sigma_; }
+  double mu_, phi_, sigma_;
+};
+class SemilocalLinearTrendStateModel {
+ public:
+  SemilocalLinearTrendStateModel(const Ptr<ZeroMeanGaussianModel> &level, const Ptr<NonzeroMeanAr1Model> &slope)
+      : level_(level), slope_(slope) {}
+  int state_dimension() const { return 3; }
+  void set_initial_level_mean(double m) { a0_[0] = m; }
+  void set_initial_level_sd(double sd) { P0_[0] = sd * sd; }
+  void set_initial_slope_mean(double m) { a0_[1] = m; }
+  void set_initial_slope_sd(double sd) { P0_[1] = sd * sd; }
+  // ZeroMeanGaussianConjSampler(level, df, sigma_guess) + set_sigma_upper_limit
+  void set_level_prior(double df, double sigma_guess, double sigma_upper_limit = infinity()) {
+    df_[0] = df; guess_[0] = sigma_guess; upper_[0] = sigma_upper_limit;
+  }
+  // NonzeroMeanAr1Sampler(slope, GaussianModel(mean_mu, mean_sigma), GaussianModel(ar1_mu, ar1_sigma),
+  // ChisqModel(df, sigma_guess)) + set_sigma_upper_limit, force_stationary(), force_ar1_positive()
+  void set_slope_prior(double mean_mu, double mean_sigma, double ar1_mu, double ar1_sigma, double df,
+                       double sigma_guess, double sigma_upper_limit = infinity(), bool force_stationary = true,
+                       bool force_ar1_positive = false) {
+    prior_[0] = mean_mu; prior_[1] = mean_sigma; prior_[2] = ar1_mu; prior_[3] = ar1_sigma;
+    df_[1] = df; guess_[1] = sigma_guess; upper_[1] = sigma_upper_limit;
+    force_stationary_ = force_stationary; force_positive_ = force_ar1_positive;
+  }
+  Ptr<ZeroMeanGaussianModel> level_;
+  Ptr<NonzeroMeanAr1Model> slope_;
+  double a0_[3] = {0.0, 0.0, 0.0}, P0_[3] = {1.0, 1.0, 0.0};
+  double df_[2] = {1.0, 1.0}, guess_[2] = {1.0, 1.0}, upper_[2] = {infinity(), infinity()};
+  double prior_[4] = {0.0, 1.0, 0.0, 1.0};
+  bool force_stationary_ = true, force_positive_ = false;
+};
+
 class StateSpaceRegressionModel : public Model {
  public:
   StateSpaceRegressionModel(const Vector &y, const Matrix &X, const std::vector<bool> &observed,
@@ -489,6 +537,7 @@ class StateSpaceRegressionModel : public Model {
   void add_state(const Ptr<ArStateModel> &s) { Entry e; e.kind = 4; e.ar = s; models_.push_back(e); finalized_ = false; }
   void add_state(const Ptr<StaticInterceptStateModel> &s) { Entry e; e.kind = 5; e.intercept = s; models_.push_back(e); finalized_ = false; }
   void add_state(const Ptr<TrigStateModel> &s) { Entry e; e.kind = 6; e.trig = s; models_.push_back(e); finalized_ = false; }
+  void add_state(const Ptr<SemilocalLinearTrendStateModel> &s) { Entry e; e.kind = 7; e.semilocal = s; models_.push_back(e); finalized_ = false; }
   int number_of_state_models() const { return (int)models_.size(); }
   // anything but a lone local level (which runs the local-level kernels)
   bool structural() const { return !(models_.size() == 1 && models_[0].kind == 1); }
@@ -496,7 +545,7 @@ class StateSpaceRegressionModel : public Model {
     int m = 0;
     for (const Entry &e : models_)
       m += (e.kind == 1 || e.kind == 5) ? 1 : e.kind == 2 ? 2 : e.kind == 3 ? e.seasonal->state_dimension()
-           : e.kind == 6 ? e.trig->state_dimension() : e.ar->lags_;
+           : e.kind == 6 ? e.trig->state_dimension() : e.kind == 7 ? 3 : e.ar->lags_;
     return m;
   }
   void finalize_state() {
@@ -522,6 +571,12 @@ class StateSpaceRegressionModel : public Model {
         } else if (e.kind == 5) {
           const StaticInterceptStateModel &s = *e.intercept;
           eng_->check(ba_ss_add_state_model(h, 5, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &s.a0_, &s.P0_));
+        } else if (e.kind == 7) {
+          const SemilocalLinearTrendStateModel &s = *e.semilocal;
+          const int32_t ip[3] = {s.force_stationary_ ? 1 : 0, s.force_positive_ ? 1 : 0, 0};
+          const double sig[2] = {s.level_->sigma_, s.slope_->sigma_};
+          const double pp[6] = {s.prior_[0], s.prior_[1], s.prior_[2], s.prior_[3], s.slope_->mu_, s.slope_->phi_};
+          eng_->check(ba_ss_add_state_model(h, 7, ip, s.df_, s.guess_, s.upper_, sig, pp, s.a0_, s.P0_));
         } else if (e.kind == 6) {
           const TrigStateModel &s = *e.trig;
           const int32_t ip[3] = {(int32_t)s.frequencies_.size(), 0, 0};
@@ -547,6 +602,19 @@ class StateSpaceRegressionModel : public Model {
     eng_->check(ba_ss_get_state_model(eng_->get(), chain, ar_block(which), &s2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
     return s2;
   }
+  // the slope model of the `which`-th SemilocalLinearTrendStateModel in one chain's current draw:
+  // (AR(1) coefficient, long-run mean)
+  Vector semilocal_slope(int chain = 0, int which = 0) const {
+    int seen = 0;
+    for (size_t b = 0; b < models_.size(); ++b) {
+      if (models_[b].kind != 7 || seen++ != which) continue;
+      Vector v(2);
+      eng_->check(ba_ss_get_state_model(eng_->get(), chain, (int32_t)b, nullptr, nullptr, nullptr, v.data(), nullptr, nullptr, nullptr, nullptr));
+      return v;
+    }
+    report_error("The model has no such SemilocalLinearTrendStateModel.");
+    return Vector();
+  }
   // one chain's state draw: state_dimension x time_dimension, the models' components in
   // the order the models were added
   Matrix structural_state(int chain = 0) const {
@@ -566,7 +634,7 @@ class StateSpaceRegressionModel : public Model {
       double v[2] = {0, 0};
       eng_->check(ba_ss_get_state_model(eng_->get(), chain, (int32_t)b, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
       out.push_back(v[0]);
-      if (models_[b].kind == 2) out.push_back(v[1]);
+      if (models_[b].kind == 2 || models_[b].kind == 7) out.push_back(v[1]);
     }
     Vector ans(out.size());
     for (size_t i = 0; i < out.size(); ++i) ans[i] = out[i];
@@ -588,13 +656,14 @@ class StateSpaceRegressionModel : public Model {
   }
  private:
   struct Entry {
-    int kind = 0;   // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression, 5 static intercept, 6 trig
+    int kind = 0;   // 1 local level, 2 local linear trend, 3 seasonal, 4 autoregression, 5 static intercept, 6 trig, 7 semilocal linear trend
     Ptr<LocalLevelStateModel> level;
     Ptr<LocalLinearTrendStateModel> trend;
     Ptr<SeasonalStateModel> seasonal;
     Ptr<ArStateModel> ar;
     Ptr<StaticInterceptStateModel> intercept;
     Ptr<TrigStateModel> trig;
+    Ptr<SemilocalLinearTrendStateModel> semilocal;
   };
   int ar_block(int which) const {
     int seen = 0;

@@ -276,7 +276,7 @@ def test_static_intercept_and_trig_on_the_pybind_module():
     import boom_amd._boom as boom
     from cases import bsts_priors, general_data, general_spec
     T, p, seed, chains, niter = 96, 4, 21, 4, 9
-    desc = [("intercept",), ("trig", 12.0, [1.0, 2.0, 3.0]), ("level",)]
+    desc = [("intercept",), ("trig", 12.0, [1.0, 2.0, 3.0]), ("level",), ("semilocal",)]
     X, y, _, obs = general_data(T, p, 2, [], seed=15, missing_frac=0.03, trig=[(12.0, [1.0, 2.0])], intercept=4.0)
     prior, _, sig_up = bsts_priors(X, y, 2)
     blocks = general_spec(y, desc)
@@ -296,9 +296,21 @@ def test_static_intercept_and_trig_on_the_pybind_module():
     level.set_prior(b["df"][0], b["sigma_guess"][0], b["sigma_upper_limit"][0])
     level.set_initial_state_mean(b["a0"][0])
     level.set_initial_state_variance(b["P0"][0])
-    for sm in (icpt, trig, level):
+    b = blocks[3]
+    sp = b["slope_priors"]
+    semi = boom.SemilocalLinearTrendStateModel(boom.ZeroMeanGaussianModel(b["initial_sigma"][0]),
+                                               boom.NonzeroMeanAr1Model(sp[4], sp[5], b["initial_sigma"][1]))
+    semi.set_level_prior(b["df"][0], b["sigma_guess"][0], b["sigma_upper_limit"][0])
+    semi.set_slope_prior(sp[0], sp[1], sp[2], sp[3], b["df"][1], b["sigma_guess"][1], b["sigma_upper_limit"][1],
+                         bool(b["force_stationary"]), bool(b["force_positive"]))
+    semi.set_initial_level_mean(b["a0"][0])
+    semi.set_initial_slope_mean(b["a0"][1])
+    semi.set_initial_level_sd(float(np.sqrt(b["P0"][0])))
+    semi.set_initial_slope_sd(float(np.sqrt(b["P0"][1])))
+    blocks[3]["P0"] = np.array([np.sqrt(b["P0"][0]) ** 2, np.sqrt(b["P0"][1]) ** 2, 0.0])   # (what the sd setters keep)
+    for sm in (icpt, trig, level, semi):
         model.add_state(sm)
-    assert model.number_of_state_models == 3 and model.state_dimension == 8 and trig.state_dimension == 6
+    assert model.number_of_state_models == 4 and model.state_dimension == 11 and trig.state_dimension == 6
     sampler = boom.StateSpacePosteriorSampler(model, boom.MvnGivenScalarSigma(prior["b"], prior["ominv"]),
                                               boom.ChisqModel(prior["df"], prior["sigma_guess"]),
                                               boom.VariableSelectionPrior(prior["pi"]), sig_up)
@@ -317,8 +329,9 @@ def test_static_intercept_and_trig_on_the_pybind_module():
         g, bb, s = eng.get_states()
         assert np.array_equal(G, g) and np.array_equal(B, bb) and np.array_equal(S, s), it
         assert np.array_equal(model.state(0), eng.ss_get_state_draw(0).T), it
-        want = np.concatenate([eng.ss_get_state_model(0, k)["variances"] for k in range(3)])
-        assert len(want) == 2 and np.array_equal(model.state_variances(0), want), it
+        want = np.concatenate([eng.ss_get_state_model(0, k)["variances"] for k in range(4)])
+        assert len(want) == 4 and np.array_equal(model.state_variances(0), want), it
+        assert np.array_equal(model.semilocal_slope(1), eng.ss_get_state_model(1, 3, suf=False)["phi"]), it
     st = model.state(chains - 1)
     assert np.all(st[0] == st[0, 0])     # the intercept is one number per draw
 

@@ -385,6 +385,8 @@ def test_regression_priors_changed_under_the_state_space_sampler(oracle):
     # round 6: StaticInterceptStateModel and TrigStateModel objects handed to add_state
     ([("intercept",), ("trig", 12.0, [1.0, 2.0]), ("ar", 1)], 110, 0.02, 8),
     ([("trig", 7.0, [1.0, 2.0, 3.0]), ("trend",), ("intercept",)], 130, 0.0, -4),
+    ([("semilocal",), ("seasonal", 7, 1)], 140, 0.02, 8),                  # SemilocalLinearTrendStateModel
+    ([("seasonal", 4, 2), ("semilocal", 1, 1), ("ar", 1)], 120, 0.0, -4),  # ... its AR(1) coefficient in [0, 1]
 ])
 def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler(oracle, desc, T, missing,
                                                                                  lookahead):
@@ -408,7 +410,7 @@ def test_boom_state_space_model_with_any_state_list_driven_by_the_device_sampler
     seas = [(b[1], b[2]) for b in desc if b[0] == "seasonal"]
     X, y, _, obs = general_data(T, p, 2, seas[:2], seed=31 + T, missing_frac=missing,
                                 ar_coef=[0.5] if any(b[0] == "ar" for b in desc) else None,
-                                level=any(b[0] in ("level", "trend") for b in desc),
+                                level=any(b[0] in ("level", "trend", "semilocal") for b in desc),
                                 trig=[(b[1], b[2][:2]) for b in desc if b[0] == "trig"],
                                 intercept=2.0 if any(b[0] == "intercept" for b in desc) else 0.0)
     prior, _, sig_up = bsts_priors(X, y, 2)
