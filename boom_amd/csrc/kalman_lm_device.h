@@ -136,6 +136,15 @@ __device__ __forceinline__ double lane_before(double x, double first) {
 struct LmSlots {   // slot s of the normals array: row s / 128 = 2 j + kind, thread s % 128
   int T, nfirst, nper, dI, dL, dH;
   __device__ __forceinline__ int count() const { return 2 * LM_TP; }
+  // a time step's two normals (state error, observation: rows 2 j and 2 j + 1 of thread q % 128)
+  // are one slot pair -- consecutive draws, i.e. the two halves of one Philox block's Box-Muller
+  // pair whenever the step's first draw has an even global number (stream_normals.h)
+  __device__ __forceinline__ int npairs(int) const { return LM_TP; }
+  __device__ __forceinline__ void pair(int q, int, int *sa, int *sb) const {
+    const int th = q & (LM_THREADS - 1), j = q >> 7;
+    *sa = (2 * j) * LM_THREADS + th;
+    *sb = (2 * j + 1) * LM_THREADS + th;
+  }
   __device__ __forceinline__ int draw(int s) const {
     const int row = s >> 7, kind = row & 1;
     const int t = LM_BS * (s & (LM_THREADS - 1)) + (row >> 1);
@@ -150,7 +159,7 @@ struct LmSlots {   // slot s of the normals array: row s / 128 = 2 j + kind, thr
 // ss_round_kernel.hip): the wave that leads draws the level variance and posts the job; both
 // take sub-chunks of SN_SUB slots from a counter in LDS until none is left (the regression's
 // wave joins when its sweep is done); the leader waits for the last one and finishes the step.
-enum : int { SN_SUB = 512 };
+enum : int { SN_SUB = 128 };   // slot PAIRS per sub-chunk (two per lane: one round of normals_pairs)
 struct NormalsShare {
   int32_t seq;              // the job posted (> 0: its number), or -(number): none this time
   // the leader takes sub-chunks 0, 1, ... and writes `lo` = the next one it will take; the
@@ -160,7 +169,6 @@ struct NormalsShare {
   int32_t lo, hi, hfin, bad;
   uint32_t pos_lo, pos_hi;  // the state stream's position the draws start from
   int32_t N, nfirst, nper, dI, dL, dH;
-  int32_t cnt[2][2];        // the two waves' list counts
 };
 struct KalmanLmLds {
   NormalsLds norm;              // (only a chain whose normals were not prepared uses it)
@@ -629,43 +637,35 @@ __device__ __forceinline__ int lds_ld(const int32_t *p) {
 __device__ __forceinline__ void lds_st(int32_t *p, int32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// The calling wavefront's part of a shared job (w = 0, 1: which half of the lists is its
-// own): phase 1 of a sub-chunk -- its lists go on growing over the sub-chunks it makes --, and
-// at the end phase 2 of everything on them, densely.
+// The calling wavefront's part of a shared job: sub-chunks of SN_SUB slot pairs (a pair = one
+// Philox block, two normals: stream_normals.h; round 6 -- no lists, no second phase).
 struct NormalsShareCtx {
   LmSlots slots;
-  uint64_t bpos0;
+  uint64_t bslot0;
   PhiloxKey key;
   double *szz;
-  int serve;
 };
-__device__ __forceinline__ NormalsShareCtx normals_share_ctx(const SsParams &P, const int chain, KalmanLmLds &lds, const int w) {
+__device__ __forceinline__ NormalsShareCtx normals_share_ctx(const SsParams &P, const int chain, KalmanLmLds &lds) {
   NormalsShare &J = lds.share;
-  NormalsShareCtx c{LmSlots{P.T, J.nfirst, J.nper, J.dI, J.dL, J.dH}, ((uint64_t)J.pos_hi << 32) | J.pos_lo,
-                    PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 2u},
-                    P.scratch + (size_t)chain * P.scratch_stride + (size_t)(5 + 2 * P.zbuf) * P.TP, ss_slot_serve(P)};
-  if (NormalsTeam<true>::tid() == 0) { J.cnt[w][0] = 0; J.cnt[w][1] = 0; }
-  NormalsTeam<true>::sync();
-  return c;
+  return NormalsShareCtx{LmSlots{P.T, J.nfirst, J.nper, J.dI, J.dL, J.dH},
+                         (((uint64_t)J.pos_hi << 32) | J.pos_lo) / STATE_SLOT_STRIDE,
+                         PhiloxKey{P.seed_lo, P.seed_hi, (uint32_t)(P.chain_offset + chain), 2u},
+                         P.scratch + (size_t)chain * P.scratch_stride + (size_t)(5 + 2 * P.zbuf) * P.TP};
 }
-__device__ __forceinline__ void normals_share_chunk(const NormalsShareCtx &X, KalmanLmLds &lds, const int w, const int c) {
-  NormalsShare &J = lds.share;
-  const int S = X.slots.count(), c0 = c * SN_SUB, nc = (S - c0 < SN_SUB) ? S - c0 : SN_SUB;
-  normals_phase1<NormalsTeam<true>>(lds.norm.tail + w * (SN_CHUNK / 2), lds.norm.mid + w * (SN_CHUNK / 2), &J.cnt[w][0],
-                                    &J.cnt[w][1], X.key, X.bpos0, X.szz, X.slots, c0, nc, c0);
-}
-__device__ __forceinline__ void normals_share_finish(const NormalsShareCtx &X, KalmanLmLds &lds, const int w) {
-  typedef NormalsTeam<true> Team;
-  NormalsShare &J = lds.share;
-  Team::sync();
-  const int bad = normals_phase2<Team>(lds.norm.tail + w * (SN_CHUNK / 2), lds.norm.mid + w * (SN_CHUNK / 2), &J.cnt[w][0],
-                                       &J.cnt[w][1], X.key, X.bpos0, X.szz, X.slots, X.serve, 0);
-  if (__ballot(bad != 0) != 0ull && Team::tid() == 0) lds_st(&J.bad, 1);
+__device__ __forceinline__ void normals_share_chunk(const NormalsShareCtx &X, const int c) {
+  const int S = X.slots.npairs(0), c0 = c * SN_SUB, nc = (S - c0 < SN_SUB) ? S - c0 : SN_SUB;
+  normals_pairs<NormalsTeam<true>>(X.key, X.bslot0, X.szz, X.slots, c0, nc);
 }
 // the leading wavefront: what kalman_prepare_body does, the normals through the shared job;
 // seq: the job's number (the other wavefront asks for it by that number)
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// hook: called between the sub-chunks (the round kernel: has the chain's X'e tile formed? then
+// this wavefront's share of the tile product goes first)
+template <class Hook = NoHook>
 __device__ __forceinline__ void kalman_prepare_lead(const SsParams &P, const int chain, const int status_in, const int seq,
-                                                    KalmanLmLds &lds) {
+                                                    KalmanLmLds &lds, Hook hook = Hook()) {
   typedef NormalsTeam<true> Team;
   NormalsShare &J = lds.share;
   const int lane = Team::tid();
@@ -695,7 +695,7 @@ __device__ __forceinline__ void kalman_prepare_lead(const SsParams &P, const int
   const int dI = (sqrt(P.P0) != 0.0), dL = (sqrt(level_sigsq) != 0.0), dH = 1;
   const int N = (dI + dH) + (T - 1) * (dL + dH);
   if (status == CHAIN_OK) {
-    const int nsub = (2 * LM_TP + SN_SUB - 1) / SN_SUB;
+    const int nsub = (LM_TP + SN_SUB - 1) / SN_SUB;
     if (lane == 0) {
       J.lo = 0; J.hi = nsub - 1; J.hfin = nsub; J.bad = 0;
       J.pos_lo = (uint32_t)pos_state0; J.pos_hi = (uint32_t)(pos_state0 >> 32);
@@ -703,14 +703,14 @@ __device__ __forceinline__ void kalman_prepare_lead(const SsParams &P, const int
       lds_st(&J.seq, seq);
     }
     Team::sync();
-    const NormalsShareCtx X = normals_share_ctx(P, chain, lds, 1);
+    const NormalsShareCtx X = normals_share_ctx(P, chain, lds);
     int c = 0;
     for (; c < nsub; ++c) {
       if (c > __builtin_amdgcn_readfirstlane(lds_ld(&J.hi))) break;   // (the helper has the rest)
       if (lane == 0) lds_st(&J.lo, c + 1);
-      normals_share_chunk(X, lds, 1, c);
+      normals_share_chunk(X, c);
+      hook();
     }
-    normals_share_finish(X, lds, 1);
     // (what the helper took is finished: sub-chunks c .. nsub - 1)
     while (__builtin_amdgcn_readfirstlane(lds_ld(&J.hfin)) > c) __builtin_amdgcn_s_sleep(1);
     if (lds_ld(&J.bad)) status = CHAIN_RNG_BRANCH;
@@ -739,12 +739,13 @@ __device__ __forceinline__ void kalman_prepare_help(const SsParams &P, const int
       const int h = __builtin_amdgcn_readfirstlane(lds_ld(&J.hi));
       if (h < __builtin_amdgcn_readfirstlane(lds_ld(&J.lo))) break;   // (the leader has it, or had)
       if (lane == 0) lds_st(&J.hi, h - 1);
-      if (lowest < 0) X = normals_share_ctx(P, chain, lds, 0);
-      normals_share_chunk(X, lds, 0, h);
+      if (lowest < 0) X = normals_share_ctx(P, chain, lds);
+      normals_share_chunk(X, h);
       lowest = h;
     }
     if (lowest >= 0) {
-      normals_share_finish(X, lds, 0);
+      // (this wave's stores are out before the leader is told)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) lds_st(&J.hfin, lowest);
     }
   }

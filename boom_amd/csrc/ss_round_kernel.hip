@@ -109,6 +109,89 @@ __device__ __forceinline__ d2 ld_coh16(__amdgpu_buffer_rsrc_t r, uint32_t byte_o
 #define RSTAMP(i) do { } while (0)
 #endif
 
+// One member's share of a tile's product: out[member, variable] over the 128 steps of rows slot,
+// slot + n, ... of the lane-major series, four steps a matrix instruction in time order (lane l
+// feeds member / variable l & 15 at step l >> 4 of the four) -- the tiled GEMM's products in the
+// tiled GEMM's order (xtwx_cols_kernel<false, 128>: the separate launches' X'e, bit for bit),
+// stored into the members' planes.  mine: lane l < 16 holds the chain of place l.
+// Round 6: a row's 32 residual fragments are ALL asked for before the first product.  They come
+// from other workgroups' stores, past the L1 (sc1), at 1 - 2 us a round trip on the busy chip;
+// fetched a batch ahead of their use (round 5) every one of the eight batches waited most of a
+// trip -- the product took 12.6 us whether a wave multiplied seven variable tiles or four (the
+// attempt to share it between the chain's two wavefronts) -- so the matrix cores were not what
+// it waited for.  X is read-only and comes through the L1: its fragments stay a batch ahead, in
+// two passes of four and three variable tiles over the same residual fragments (registers).
+template <int VGW>
+__device__ __forceinline__ void tile_product_pass(const __amdgpu_buffer_rsrc_t xb, const double (&a)[LM_THREADS / 4],
+                                                  const SsParams &S, const SsRoundParams &F, const int mine, const int lo,
+                                                  const int n, const int rr, const int p, const int fc, const int fk,
+                                                  const int jbase) {
+  d4 acc[VGW];
+#pragma unroll
+  for (int v = 0; v < VGW; ++v) acc[v] = d4{0.0, 0.0, 0.0, 0.0};
+  uint32_t xo[VGW];
+#pragma unroll
+  for (int v = 0; v < VGW; ++v) {
+    int j = jbase + 16 * v + fc;
+    j = j < p ? j : p - 1;
+    xo[v] = (uint32_t)(((size_t)j * LM_TP + (size_t)rr * LM_THREADS) * 8) + 8u * fk;
+  }
+  constexpr int NBAT = LM_THREADS / 16;
+  double b[2][4][VGW];
+  auto fetch = [&](int bi, int m0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < VGW; ++v)
+        b[bi][u][v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)(xo[v] + 32u * (m0 + u)), 0, 0));
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int bt = 0; bt < NBAT; ++bt) {
+    if (bt + 1 < NBAT) fetch((bt + 1) & 1, 4 * (bt + 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < VGW; ++v)
+        acc[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * bt + u], b[bt & 1][u][v], acc[v], 0, 0, 0);
+  }
+  // to the members' planes of this row (register q of lane l: member (l >> 4) + 4 q)
+#pragma unroll
+  for (int v = 0; v < VGW; ++v) {
+    const int j = jbase + 16 * v + fc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mi = fk + 4 * q;
+      const int mc = __shfl(mine, (lo + mi) & (RT - 1));
+      if (mi < n && j < p) st_coh(F.planes + ((size_t)rr * S.chains + mc) * p + j, acc[v][q]);
+    }
+  }
+}
+__device__ __forceinline__ void tile_product(const SsvsParams &P, const SsParams &S, const SsRoundParams &F,
+                                             const int mine, const int lo, const int n, const int slot, const int lane) {
+  const int p = P.p;
+  const int fc = lane & 15, fk = lane >> 4;
+  const int mem_a = __shfl(mine, lo + (fc < n ? fc : 0));
+  // (the residual series' resource starts at the launch's FIRST chain: a tile's members are
+  // chains of this launch, at most the resident count of them, so the 32-bit byte offset
+  // stays far below 2^31 whatever the engine's chain count -- from the engine's chain 0 it
+  // passed 2^31 at 14 563 chains and read zeros)
+  const __amdgpu_buffer_rsrc_t eb = coh_buffer(S.scratch + (size_t)P.chain_first * S.scratch_stride), xb = coh_buffer(S.Xt);
+  const uint32_t eo = (uint32_t)(((size_t)(mem_a - P.chain_first) * S.scratch_stride + S.TP) * 8) + 8u * fk;
+  constexpr int VGA = 4, VGB = VG - VGA;
+  for (int rr = slot; rr < RT; rr += n) {
+    const uint32_t er = eo + (uint32_t)rr * LM_THREADS * 8;
+    double a[LM_THREADS / 4];
+#pragma unroll
+    for (int m = 0; m < LM_THREADS / 4; ++m)
+      a[m] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(eb, (int)(er + 32u * m), 0, 16));
+    for (int j0 = 0; j0 < p; j0 += 16 * VG) {
+      tile_product_pass<VGA>(xb, a, S, F, mine, lo, n, rr, p, fc, fk, j0);
+      if (j0 + 16 * VGA < p) tile_product_pass<VGB>(xb, a, S, F, mine, lo, n, rr, p, fc, fk, j0 + 16 * VGA);
+    }
+  }
+}
+
 }  // namespace
 
 size_t ss_round_lds(int p, int kcap) {
@@ -196,6 +279,9 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
     RSTAMP(2);   // state draw
     if (wave == 1) {
       // ---- 3a. the NEXT round's level variance (from this draw's statistics) and normals
+      // (round 6, tried: this wave taking three of the product's seven variable tiles, between two
+      // sub-chunks of normals or before them -- 4 to 6 us a round SLOWER: the product was waiting
+      // for its loads, not for the matrix cores, and a second wave waits just as long)
       if (r + 1 < F.rounds) kalman_prepare_lead(S, chain, drew ? (int)CHAIN_OK : (int)CHAIN_RNG_BRANCH, r + 2, klds);
       continue;
     }
@@ -242,69 +328,8 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
     }
     const int n = hi - lo, slot = (ticket & (RT - 1)) - lo;   // members, and which of them this chain is
     RSTAMP(3);   // ticket, names
-    // ... multiply this member's rows: out[member, variable] over the row's 128 steps, four
-    // steps a matrix instruction in time order (lane l feeds member / variable l & 15 at step
-    // l >> 4 of the four) -- the tiled GEMM's products in the tiled GEMM's order
-    // (xtwx_cols_kernel<false, 128>: the separate launches' X'e, bit for bit)
-    {
-      const int fc = lane & 15, fk = lane >> 4;
-      const int mem_a = __shfl(mine, lo + (fc < n ? fc : 0));
-      // (the residual series' resource starts at the launch's FIRST chain: a tile's members are
-      // chains of this launch, at most the resident count of them, so the 32-bit byte offset
-      // stays far below 2^31 whatever the engine's chain count -- from the engine's chain 0 it
-      // passed 2^31 at 14 563 chains and read zeros)
-      const __amdgpu_buffer_rsrc_t eb = coh_buffer(S.scratch + (size_t)P.chain_first * S.scratch_stride), xb = coh_buffer(S.Xt);
-      const uint32_t eo = (uint32_t)(((size_t)(mem_a - P.chain_first) * S.scratch_stride + S.TP) * 8) + 8u * fk;
-      for (int rr = slot; rr < RT; rr += n) {
-        for (int j0 = 0; j0 < p; j0 += 16 * VG) {
-          d4 acc[VG];
-#pragma unroll
-          for (int v = 0; v < VG; ++v) acc[v] = d4{0.0, 0.0, 0.0, 0.0};
-          uint32_t xo[VG];
-#pragma unroll
-          for (int v = 0; v < VG; ++v) {
-            int j = j0 + 16 * v + fc;
-            j = j < p ? j : p - 1;
-            xo[v] = (uint32_t)(((size_t)j * LM_TP + (size_t)rr * LM_THREADS) * 8) + 8u * fk;
-          }
-          const uint32_t er = eo + (uint32_t)rr * LM_THREADS * 8;
-          // (eight batches of four steps; a batch's loads go out while the matrix cores are on
-          // the one before)
-          constexpr int NBAT = LM_THREADS / 16;
-          double a[2][4], b[2][4][VG];
-          auto fetch = [&](int bi, int m0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              a[bi][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(eb, (int)(er + 32u * (m0 + u)), 0, 16));
-#pragma unroll
-              for (int v = 0; v < VG; ++v)
-                b[bi][u][v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xb, (int)(xo[v] + 32u * (m0 + u)), 0, 0));
-            }
-          };
-          fetch(0, 0);
-#pragma unroll
-          for (int bt = 0; bt < NBAT; ++bt) {
-            if (bt + 1 < NBAT) fetch((bt + 1) & 1, 4 * (bt + 1));
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int v = 0; v < VG; ++v)
-                acc[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bt & 1][u], b[bt & 1][u][v], acc[v], 0, 0, 0);
-          }
-          // to the members' planes of this row (register q of lane l: member (l >> 4) + 4 q)
-#pragma unroll
-          for (int v = 0; v < VG; ++v) {
-            const int j = j0 + 16 * v + fc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int mi = fk + 4 * q;
-              const int mc = __shfl(mine, (lo + mi) & (RT - 1));
-              if (mi < n && j < p) st_coh(F.planes + ((size_t)rr * S.chains + mc) * p + j, acc[v][q]);
-            }
-          }
-        }
-      }
-    }
+    // ... and multiply this member's rows
+    tile_product(P, S, F, mine, lo, n, slot, lane);
     RSTAMP(4);   // the member's share of the product
     // ... and add the chain's own planes, in row order, once every member's share is there
     if (drew) {

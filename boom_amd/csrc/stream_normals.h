@@ -7,12 +7,23 @@
 // parallel reader of that stream first has to find where every draw starts.  Rounds 1
 // and 2 did exactly that (windows of uniforms in LDS, the draw starting at every
 // offset, jump tables, a binary-lifting walk): parity-exact, and 55 % of the Kalman
-// kernel.  A counter-based generator does not need it: normal i of the chain's state
-// stream reads its uniforms from the FIXED position i * STATE_SLOT_STRIDE (256 i) (the way the
-// probit / logit imputers give every observation its own substream, probit_kernel.hip),
-// so every draw is independent of every other and costs its own uniforms only.  The
-// oracle's Philox mode does the same (bo_rnorm on stream 2); its MT mode -- the one
-// pinned on the compiled reference -- reads in sequence, as the reference does.
+// kernel.  A counter-based generator does not need it: normal number s of the chain's state
+// stream OWNS the positions [s * STATE_SLOT_STRIDE, (s + 1) * STATE_SLOT_STRIDE) (the way the
+// probit / logit imputers give every observation its own substream, probit_kernel.hip), so
+// every draw is independent of every other.  Rounds 2-5 made each draw a Kinderman-Ramage
+// transform of its own slot's uniforms: one Philox block (twenty 32 x 32 -> 64 multiplies at
+// 32 cycles a wave instruction) per normal, plus the rejection branches of 12 % of the draws
+// worked off from lists in LDS -- 79 wave-microseconds of a 109 us bsts round.
+//
+// Round 6 (VERDICT r5 task 2 (i)): TWO draws per Philox block.  Draws 2 j and 2 j + 1 (global
+// draw numbers: the stream position / STATE_SLOT_STRIDE) are the Box-Muller pair of the two
+// uniforms at the start of slot 2 j:
+//     R = sqrt(-2 log(1 - u1)),  z_{2j} = R cos(2 pi u2),  z_{2j+1} = R sin(2 pi u2)
+// -- exact standard normals from full 53-bit uniforms, half the multiplies per normal, no
+// rejection branch, no lists, no second phase.  The oracle's Philox mode draws the same way
+// (bo_rnorm on stream 2); its MT mode -- the one pinned on the compiled reference -- reads in
+// sequence through norm_rand, as the reference does.  The link between the two has been
+// distributional since round 2 and is checked as such (tests/test_substream_bridge.py).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,15 +32,11 @@
 
 namespace boom_amd {
 
-// uniforms reserved per normal of the state stream.  A draw that runs past them goes on in
-// its slot's spill stream (device_rng.h; rounds 1-3 reported CHAIN_RNG_BRANCH and stopped
-// the chain): the rejection loops accept with
-// probability ~0.55 per round of two uniforms, so 64 uniforms (31 rounds) would be
-// exceeded about once per 1e11 slow draws -- every few hundred thousand sweep rounds of
-// 1024 chains -- and 256 (127 rounds) never (1e-44).  The stride costs nothing: counters,
-// not memory.
+// positions reserved per normal of the state stream (counters, not memory).  A slot's first two
+// uniforms are all a Box-Muller pair reads; the imputers' slots (probit_kernel.hip) are the
+// ones that can overrun into their spill streams (device_rng.h).
 enum : int { STATE_SLOT_STRIDE = 256 };
-// (ba_set_slot_limit, for the tests: at least the two uniforms of the first branch, an even number)
+// (ba_set_slot_limit, for the tests of the imputers' spill streams; the state stream ignores it)
 template <class Params>
 __host__ __device__ inline int ss_slot_serve(const Params &P) {
   return (P.slot_limit >= 2 && P.slot_limit < STATE_SLOT_STRIDE) ? (P.slot_limit & ~1) : STATE_SLOT_STRIDE;
@@ -43,28 +50,24 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The draws that leave Kinderman-Ramage's first branch (11.6 %: rejection loops with a
-// log or an exp per round) would make every wavefront wait for its unluckiest lane at
-// every draw; so a chunk of the stream is done in two phases: all threads take the
-// first branch of their draws and put the others on two lists in LDS (tail region /
-// the three middle regions), then the lists are worked off densely -- wavefronts full
-// of draws that all loop, the three middle regions in ONE loop with per-lane constants
-// (the same operations on the same numbers as the reference's three copies of it).
-enum : int { SN_CHUNK = 4096 };
+// (the generator needs no LDS any more; kept so that the kernels' LDS layouts keep their names)
 struct NormalsLds {
-  uint16_t tail[SN_CHUNK], mid[SN_CHUNK];
-  int ntail, nmid;
+  int unused;
 };
 
-// szz[i] = normal i of this sweep, i < N (or the slots' layout); the stream position moves on by N slots.
-// Every thread of the workgroup calls it (it contains barriers); returns the chain
-// status, the same in every thread.
-// Which draw lands in which slot of the output array.  count(): slots; draw(s): the
-// index of the draw that belongs in slot s, or -1 (none).  Threads walk the SLOTS, so
-// the stores are coalesced whatever the layout.
-struct NormalsInOrder {   // szz[i] = draw i
+// Which draw lands in which slot of the output array, a PAIR of slots at a time (the two slots
+// one thread fills from one Philox block where the layout allows).  npairs(par): slot pairs,
+// given the parity of the sweep's first global draw number; pair(q, par, &sa, &sb): the output
+// slots of pair q (-1: none); draw(s): the index of the sweep's draw that belongs in slot s, or
+// -1.  Threads walk the slot pairs, so the stores are coalesced whatever the layout.
+struct NormalsInOrder {   // szz[i] = draw i; pair q = the draws of global pair (first >> 1) + q
   int N;
-  __device__ __forceinline__ int count() const { return N; }
+  __device__ __forceinline__ int npairs(int par) const { return (N + par + 1) >> 1; }
+  __device__ __forceinline__ void pair(int q, int par, int *sa, int *sb) const {
+    const int a = 2 * q - par;
+    *sa = (a >= 0 && a < N) ? a : -1;
+    *sb = (a + 1 < N) ? a + 1 : -1;
+  }
   __device__ __forceinline__ int draw(int s) const { return s; }
 };
 // ONE_WAVE: the calling wavefront alone makes the draws (the round kernel of
@@ -81,150 +84,79 @@ struct NormalsTeam {
   static __device__ __forceinline__ void sync() {
     if (ONE_WAVE) wave_lds_sync(); else __syncthreads();
   }
-  static __device__ __forceinline__ int sync_or(int x) {
-    if (ONE_WAVE) return __ballot(x != 0) != 0ull ? 1 : 0;
-    return __syncthreads_or(x);
-  }
 };
-// The two phases of a stretch of slots, for one team (a workgroup, or ONE wavefront:
-// NormalsTeam).  Phase 1, slots [c0, c0 + nc) of the output array: the draws of the first
-// branch, the others on the team's lists ltail / lmid (entry = slot - c0 + ioff; the counts
-// go on from where they stand).  Phase 2: the lists' draws (slot = origin + entry); returns
-// this thread's "a draw overran its slot and its spill stream" flag.
+
+// the Box-Muller pair of Philox block `block` of the chain's state stream
+__device__ __forceinline__ void normal_pair(const PhiloxKey &key, uint64_t block, double *zc, double *zs) {
+  double u1, u2;
+  philox_pair(key, block, &u1, &u2);
+  const double R = sqrt(-2.0 * log(1.0 - u1));
+  double sn, cs;
+  sincos(6.283185307179586 * u2, &sn, &cs);
+  *zc = R * cs;
+  *zs = R * sn;
+}
+
+// Slot pairs [q0, q0 + nq) of the output array, by one team.  bslot0 = the global number of the
+// sweep's first draw (stream position / STATE_SLOT_STRIDE).  A pair's two slots take their
+// draws from one block when the draws are the two halves of one global pair (the usual case:
+// the layouts put a time step's state-error and observation normals side by side, and a sweep
+// of the local-level model makes an even number of draws); otherwise the second slot costs a
+// block of its own.
 template <class Team, class Slots>
-__device__ __forceinline__ void normals_phase1(uint16_t *ltail, uint16_t *lmid, int *lntail, int *lnmid,
-                                               const PhiloxKey &key, uint64_t bpos0, double *szz, const Slots slots,
-                                               const int c0, const int nc, const int ioff) {
-  const double A = 2.216035867166471;
+__device__ __forceinline__ void normals_pairs(const PhiloxKey &key, uint64_t bslot0, double *szz, const Slots slots,
+                                              const int q0, const int nq) {
   const int tid = Team::tid(), nth = Team::nth();
-    // ---- phase 1: u1 and u2 of every draw (one Philox block: a slot starts at an even
-    // position), the first branch where it applies
-    // (four slots per thread and round: four independent Philox blocks in flight -- one
-    // block is a chain of ten dependent rounds, and the kernel runs two waves to a SIMD)
-    for (int i0 = tid; i0 < nc; i0 += 4 * nth) {
-      int dr[4];
-      double u1[4], u2[4];
+  const int par = (int)(bslot0 & 1ull);
+  // (two pairs per thread and round: two independent Philox blocks in flight -- a block is a
+  // chain of ten dependent rounds)
+  for (int i0 = tid; i0 < nq; i0 += 2 * nth) {
+    int sa[2], sb[2];
+    uint64_t ga[2], gb[2];
+    double zc[2], zs[2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * nth;
-        dr[u] = (i < nc) ? slots.draw(c0 + i) : -1;
-        const uint64_t start = bpos0 + (uint64_t)(dr[u] < 0 ? 0 : dr[u]) * STATE_SLOT_STRIDE;
-        philox_pair(key, start >> 1, &u1[u], &u2[u]);
-      }
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + u * nth;
+      sa[u] = sb[u] = -1;
+      if (i < nq) slots.pair(q0 + i, par, &sa[u], &sb[u]);
+      const int da = sa[u] >= 0 ? slots.draw(sa[u]) : -1, db = sb[u] >= 0 ? slots.draw(sb[u]) : -1;
+      if (da < 0) sa[u] = -1;
+      if (db < 0) sb[u] = -1;
+      ga[u] = bslot0 + (uint64_t)(da < 0 ? 0 : da);
+      gb[u] = bslot0 + (uint64_t)(db < 0 ? 0 : db);
+      // the block of the first slot's draw (of the second's, where the first holds none)
+      const uint64_t g = sa[u] >= 0 ? ga[u] : gb[u];
+      normal_pair(key, ((g & ~1ull) * STATE_SLOT_STRIDE) >> 1, &zc[u], &zs[u]);
+    }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * nth;
-        const bool live = dr[u] >= 0;
-        const bool fast = live && u1[u] < 0.884070402298758;
-        const bool tail = live && u1[u] >= 0.973310954173898;
-        const bool mid = live && !fast && !tail;
-        if (fast) szz[c0 + i] = A * (1.131131635444180 * u1[u] + u2[u] - 1);
-        // one list reservation per wavefront and list (same-address LDS atomics of many
-        // lanes run one after the other: they were most of this function's time)
-        const unsigned long long mt = __ballot(tail), mm = __ballot(mid);
-        const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
-        if (mt) {
-          int base = 0;
-          if ((int)(threadIdx.x & 63) == __ffsll((long long)mt) - 1) base = atomicAdd(lntail, __popcll(mt));
-          base = __builtin_amdgcn_readlane(base, __ffsll((long long)mt) - 1);
-          if (tail) ltail[base + __popcll(mt & below)] = (uint16_t)(i + ioff);
-        }
-        if (mm) {
-          int base = 0;
-          if ((int)(threadIdx.x & 63) == __ffsll((long long)mm) - 1) base = atomicAdd(lnmid, __popcll(mm));
-          base = __builtin_amdgcn_readlane(base, __ffsll((long long)mm) - 1);
-          if (mid) lmid[base + __popcll(mm & below)] = (uint16_t)(i + ioff);
-        }
+    for (int u = 0; u < 2; ++u) {
+      if (sa[u] >= 0) szz[sa[u]] = (ga[u] & 1ull) ? zs[u] : zc[u];
+      const bool same = sa[u] < 0 || (gb[u] >> 1) == (ga[u] >> 1);
+      if (sb[u] >= 0 && same) szz[sb[u]] = (gb[u] & 1ull) ? zs[u] : zc[u];
+      // (a second slot whose draw is half of ANOTHER global pair: rare -- a sweep that starts on
+      // an odd draw number in a layout that pairs by time step)
+      if (__ballot(sb[u] >= 0 && !same) != 0ull) {
+        double c2, s2;
+        normal_pair(key, ((gb[u] & ~1ull) * STATE_SLOT_STRIDE) >> 1, &c2, &s2);
+        if (sb[u] >= 0 && !same) szz[sb[u]] = (gb[u] & 1ull) ? s2 : c2;
       }
     }
-}
-template <class Team, class Slots>
-__device__ __forceinline__ int normals_phase2(const uint16_t *ltail, const uint16_t *lmid, const int *lntail,
-                                              const int *lnmid, const PhiloxKey &key, uint64_t bpos0, double *szz,
-                                              const Slots slots, int serve, const int c0) {
-  const double A = 2.216035867166471;
-  const double C1 = 0.398942280401433, C2 = 0.180025191068563;
-  const int tid = Team::tid(), nth = Team::nth();
-  const uint64_t bslot0 = bpos0 / STATE_SLOT_STRIDE;   // (the stream position is a whole number of slots)
-  int bad = 0;
-    // ---- phase 2a: the tail region
-    const int ntail = *lntail, nmid = *lnmid;
-    for (int q = tid; q < ntail; q += nth) {
-      const int i = ltail[q];
-      PairRng r;
-      r.init_slot(key, bslot0 + (uint64_t)slots.draw(c0 + i), STATE_SLOT_STRIDE, (uint32_t)serve);
-      const double u1 = r();
-      double z;
-      for (;;) {
-        const double u2 = r();
-        const double u3 = r();
-        const double tt = (A * A - 2 * log(u3));
-        if (u2 * u2 < (A * A) / tt) {
-          z = (u1 < 0.986655477086949) ? sqrt(tt) : -sqrt(tt);
-          break;
-        }
-        if (r.overran()) { bad = 1; z = 0.0; break; }
-      }
-      szz[c0 + i] = z;
-    }
-    // ---- phase 2b: the middle regions, one loop:
-    //   tt = t0 + t1 min(u2, u3);  accept when max(u2, u3) <= thr or
-    //   coef |u2 - u3| <= C1 exp(-tt^2 / 2) - C2 (A - tt)
-    for (int q = tid; q < nmid; q += nth) {
-      const int i = lmid[q];
-      PairRng r;
-      r.init_slot(key, bslot0 + (uint64_t)slots.draw(c0 + i), STATE_SLOT_STRIDE, (uint32_t)serve);
-      const double u1 = r();
-      const bool r2 = u1 >= 0.958720824790463, r3 = !r2 && u1 >= 0.911312780288703;
-      const double thr = r2 ? 0.755591531667601 : (r3 ? 0.872834976671790 : 0.805577924423817);
-      const double coef = r2 ? 0.034240503750111 : (r3 ? 0.049264496373128 : 0.053377549506886);
-      double z;
-      for (;;) {
-        const double u2 = r();
-        const double u3 = r();
-        // (written as the reference writes it: A - c min, resp. c0 + c min, c0 - c min)
-        const double tt = r2 ? A - 0.630834801921960 * fmin(u2, u3)
-                             : (r3 ? 0.479727404222441 + 1.105473661022070 * fmin(u2, u3)
-                                   : 0.479727404222441 - 0.595507138015940 * fmin(u2, u3));
-        const bool ok = !(tt < 0.);   // (only the last region can fail this)
-        if (ok && (fmax(u2, u3) <= thr ||
-                   coef * fabs(u2 - u3) <= (C1 * exp(-(tt) * (tt) / 2.0) - C2 * (A - (tt))))) {
-          z = (u2 < u3) ? tt : -tt;
-          break;
-        }
-        if (r.overran()) { bad = 1; z = 0.0; break; }
-      }
-      szz[c0 + i] = z;
-    }
-  return bad;
-}
-// slots [c0, c0 + nc) by one team with lists of its own for the stretch
-template <class Team, class Slots>
-__device__ __forceinline__ int normals_chunk(uint16_t *ltail, uint16_t *lmid, int *lntail, int *lnmid,
-                                             const PhiloxKey &key, uint64_t bpos0, double *szz, const Slots slots,
-                                             int serve, const int c0, const int nc) {
-  if (Team::tid() == 0) { *lntail = 0; *lnmid = 0; }
-  Team::sync();
-  normals_phase1<Team>(ltail, lmid, lntail, lnmid, key, bpos0, szz, slots, c0, nc, 0);
-  Team::sync();
-  const int bad = normals_phase2<Team>(ltail, lmid, lntail, lnmid, key, bpos0, szz, slots, serve, c0);
-  Team::sync();
-  return bad;
-}
-template <bool ONE_WAVE = false, class Slots>
-__device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
-                                              double *szz, uint64_t *pos_out, const Slots slots,
-                                              int serve = STATE_SLOT_STRIDE) {
-  typedef NormalsTeam<ONE_WAVE> Team;
-  const int S = slots.count();
-  int bad = 0;
-  for (int c0 = 0; c0 < S; c0 += SN_CHUNK) {
-    const int nc = (S - c0 < SN_CHUNK) ? S - c0 : SN_CHUNK;
-    bad |= normals_chunk<Team>(L.tail, L.mid, &L.ntail, &L.nmid, key, bpos0, szz, slots, serve, c0, nc);
   }
-  bad = Team::sync_or(bad);
+}
+
+// szz[slot] = the sweep's normals in the slots' layout; the stream position moves on by N slots.
+// Every thread of the team calls it (it contains the team's barrier); returns the chain status
+// (CHAIN_OK: a Box-Muller draw cannot overrun its slot), the same in every thread.
+template <bool ONE_WAVE = false, class Slots>
+__device__ __forceinline__ int stream_normals(NormalsLds &, const PhiloxKey &key, uint64_t bpos0, int N,
+                                              double *szz, uint64_t *pos_out, const Slots slots,
+                                              int = STATE_SLOT_STRIDE) {
+  typedef NormalsTeam<ONE_WAVE> Team;
+  const uint64_t bslot0 = bpos0 / STATE_SLOT_STRIDE;   // (the stream position is a whole number of slots)
+  normals_pairs<Team>(key, bslot0, szz, slots, 0, slots.npairs((int)(bslot0 & 1ull)));
+  Team::sync();
   if (Team::tid() == 0) *pos_out = bpos0 + (uint64_t)N * STATE_SLOT_STRIDE;
-  return bad ? CHAIN_RNG_BRANCH : CHAIN_OK;
+  return CHAIN_OK;
 }
 __device__ __forceinline__ int stream_normals(NormalsLds &L, const PhiloxKey &key, uint64_t bpos0, int N,
                                               double *szz, uint64_t *pos_out, int serve = STATE_SLOT_STRIDE) {

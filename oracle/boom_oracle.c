@@ -102,10 +102,6 @@ void bo_rng_slot(bo_rng *r, uint64_t index, uint64_t stride) {
   r->limit = r->pos + serve;
   r->spill = index << BO_SPILL_SHIFT;
 }
-static void bo_rng_unslot(bo_rng *r) {
-  r->stream &= ~BO_SPILL_STREAM_BIT;
-  r->limit = 0;
-}
 
 /* RNG::operator(), distributions/rng.hpp:45.  For the MT engine this is
  * libstdc++'s uniform_real_distribution<double>(0,1) = generate_canonical<
@@ -235,11 +231,25 @@ double bo_norm_rand(bo_rng *r) {
 double bo_rnorm(bo_rng *r, double mu, double sigma) {
   if (sigma == 0.) return mu;
   if (r->kind == BO_RNG_PHILOX && r->slot_stride) {
-    /* (the state stream's normals have a slot each, see bo_rng) */
-    bo_rng_slot(r, r->slot, r->slot_stride);
+    /* The state stream (id 2) in Philox mode: the normals of simulate_forward have a slot each
+     * (draw number s owns positions [s stride, (s + 1) stride)), and -- round 6 -- TWO draws
+     * share one Philox block: draws 2 j and 2 j + 1 are the Box-Muller pair of the two uniforms
+     * at the start of slot 2 j,
+     *     R = sqrt(-2 log(1 - u1)),  z_{2j} = R cos(2 pi u2),  z_{2j+1} = R sin(2 pi u2)
+     * (G. E. P. Box and M. E. Muller (1958), Ann. Math. Statist. 29, 610-611; 1 - u1 is in
+     * (0, 1]).  Exact standard normals, half the generator's work of a Kinderman-Ramage draw per
+     * block and no rejection branch: the device makes 2 T of them per chain and round
+     * (stream_normals.h).  What ties this stream to the reference is distributional either way
+     * (tests/test_substream_bridge.py): the MT mode -- the one the compiled reference pins --
+     * reads one sequential stream through norm_rand as the reference does. */
+    const uint64_t s = r->slot;
     r->slot += 1;
-    const double z = bo_norm_rand(r);
-    bo_rng_unslot(r);
+    r->stream &= ~BO_SPILL_STREAM_BIT;
+    r->limit = 0;
+    r->pos = (s & ~(uint64_t)1) * r->slot_stride;
+    const double u1 = bo_unif(r), u2 = bo_unif(r);
+    const double R = sqrt(-2.0 * log(1.0 - u1)), th = 6.283185307179586 * u2;
+    const double z = (s & 1) ? R * sin(th) : R * cos(th);
     r->pos = r->slot * r->slot_stride;
     return mu + sigma * z;
   }

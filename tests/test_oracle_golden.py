@@ -114,11 +114,14 @@ def test_philox_stream_layout(oracle):
 
 
 def test_state_stream_gives_every_normal_its_own_position(oracle):
-    """Stream 2 (the normals of simulate_forward) in Philox mode: draw number i reads its
-    uniforms from position 256 i, whatever the draws before it consumed -- the contract the
-    device's stream_normals.h implements (the MT engine, pinned on the reference, reads in
-    sequence; so does every other Philox stream)."""
+    """Stream 2 (the normals of simulate_forward) in Philox mode: draw number s owns the
+    positions [256 s, 256 (s + 1)), whatever the draws before it consumed, and draws 2 j and
+    2 j + 1 are the Box-Muller pair of the two uniforms at position 512 j (round 6; one
+    Kinderman-Ramage draw per slot before) -- the contract the device's stream_normals.h
+    implements (the MT engine, pinned on the reference, reads in sequence through norm_rand; so
+    does every other Philox stream)."""
     import ctypes as C
+    from math import cos, log, sin, sqrt
     L = oracle.lib
     L.bo_rnorm.restype = C.c_double
     L.bo_rnorm.argtypes = [C.c_void_p, C.c_double, C.c_double]
@@ -126,11 +129,18 @@ def test_state_stream_gives_every_normal_its_own_position(oracle):
     seq = [L.bo_rnorm(C.byref(r), 0.0, 1.0) for _ in range(200)]
     assert L.bo_rnorm(C.byref(r), 5.0, 0.0) == 5.0 and r.slot == 200      # sigma = 0: no draw, no slot
     assert r.pos == 200 * 256
-    for i in (0, 1, 57, 199):
-        # the same draw from a plain sequential stream positioned there (stream ids differ
-        # in the key, so compare through the normal transform of that position's uniforms)
+    for i in (0, 1, 57, 198, 199):
+        # the same draw from a stream positioned at its slot: a generator that STARTS on an odd
+        # draw number still takes the second half of that number's pair
         one = oracle.rng_philox(99, chain=3, stream=2, pos=256 * i)
         assert L.bo_rnorm(C.byref(one), 0.0, 1.0) == seq[i]
+        # ... which is the transform of the two uniforms at the pair's first slot (read through
+        # a sequential stream id with the same key: stream 2 | the uniforms do not depend on the mode)
+        u = oracle.uniforms(oracle.rng_philox(99, chain=3, stream=2, pos=256 * (i & ~1)), 2) \
+            if hasattr(oracle, "uniforms") else None
+        if u is not None:
+            R, th = sqrt(-2.0 * log(1.0 - u[0])), 6.283185307179586 * u[1]
+            assert abs(seq[i] - (R * sin(th) if i & 1 else R * cos(th))) < 1e-15 * max(1.0, abs(seq[i]))
     # another stream reads in sequence: the second normal starts where the first stopped
     s0 = oracle.rng_philox(99, chain=3, stream=0)
     a = L.bo_rnorm(C.byref(s0), 0.0, 1.0)

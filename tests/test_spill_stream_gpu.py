@@ -1,7 +1,9 @@
 """A draw that needs more uniforms than its slot of a substream holds goes on in the slot's
-SPILL stream (device_rng.h; the oracle's bo_rng_slot): the state draw's normals (256
-positions a normal), the probit / logit / Polya-Gamma / Poisson imputers (4096 / 256 / 4096 /
-256 an observation).  At those strides that is an event of probability < 1e-40, so the
+SPILL stream (device_rng.h; the oracle's bo_rng_slot): the probit / logit / Polya-Gamma /
+Poisson imputers (4096 / 256 / 4096 / 256 positions an observation; until round 5 the state
+draw's Kinderman-Ramage normals too, 256 a normal -- they are Box-Muller pairs now and read two
+uniforms for two draws, so the state-draw tests below only check that the switch leaves them
+alone).  At those strides that is an event of probability < 1e-40, so the
 path is FORCED here: ba_set_slot_limit / bo_set_slot_limit let a slot serve only a few
 numbers, every slow normal and nearly every imputation then reads its spill stream, and
 the parity tests of each family run once more under that switch -- the device against the
@@ -37,20 +39,35 @@ def small_slots(request, oracle, monkeypatch):
 
 
 def test_the_switch_changes_the_draws(oracle):
-    """(so that the tests below do test something) the same chain with and without it"""
-    from cases import bsts_priors, state_space_data
+    """(so that the tests below do test something) the same probit chain with and without it --
+    and NOT the state draw: since round 6 its normals are Box-Muller pairs (two uniforms for two
+    draws, stream_normals.h), which cannot outrun a slot"""
+    from cases import bsts_priors, probit_data, probit_slab, state_space_data
+    X, y, nt, _ = probit_data(300, 10, 3, seed=4, max_trials=3)
+    slab, pi = probit_slab(X, nt, 3)
+    g0 = np.zeros(10, np.uint8)
+    g0[0] = 1
+    import boom_amd
+    eng = []
+    for limit in (0, 2):
+        e = boom_amd.Engine(2, seed=3)
+        e.probit_set_data(X, y, nt, 3)
+        e.sss_set_slab(slab["mu"], slab["prec"], scales_with_sigsq=False)
+        e.set_spike(pi)
+        e.set_state(g0)
+        e.set_slot_limit(limit)
+        e.probit_sweep(3)
+        eng.append(e)
+    assert not np.array_equal(eng[0].get_states()[1], eng[1].get_states()[1])
     X, y, _, obs = state_space_data(150, 5, 2, seed=2)
     prior, ss, sig_up = bsts_priors(X, y, 2)
     g0 = np.zeros(5, np.uint8)
     a = tss.make_engine(2, 3, y, X, obs, prior, ss, sig_up, g0)
     b = tss.make_engine(2, 3, y, X, obs, prior, ss, sig_up, g0)
     b.set_slot_limit(2)
-    a.ss_sweep(1)
-    b.ss_sweep(1)
-    sa, sb = a.ss_get_state(0)["state"], b.ss_get_state(0)["state"]
-    assert not np.array_equal(sa, sb)
-    # the fast normals (two uniforms) are the same numbers, the slow ones are not: most of the path agrees in its increments
-    assert np.isfinite(sb).all()
+    a.ss_sweep(2)
+    b.ss_sweep(2)
+    assert np.array_equal(a.ss_get_state(0)["state"], b.ss_get_state(0)["state"])
 
 
 def test_state_draw_local_level(oracle, small_slots):

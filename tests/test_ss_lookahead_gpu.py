@@ -158,7 +158,11 @@ def test_a_capacity_stop_inside_a_batch():
             assert np.array_equal(u, v), it
         ua, ub = a.ss_get_state(0, suf=False), b.ss_get_state(0, suf=False)
         assert ua["level_sigsq"] == ub["level_sigsq"] and np.array_equal(ua["state"], ub["state"]), it
-    assert a.get_states()[0].sum(axis=1).min() > 30
+    # (every chain outgrew the first capacity, most of them the second: both stops happened inside
+    # batches.  Round 6 re-rolled the state stream's numbers -- Box-Muller pairs -- and one chain
+    # stands at 26 variables after these 30 rounds where all stood above 30 before.)
+    k = a.get_states()[0].sum(axis=1)
+    assert k.min() > 16 and k.max() > 32
 
 
 @pytest.mark.parametrize("habit", ["statistics", "another chain's state", "a mutator"])
