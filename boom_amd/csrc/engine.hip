@@ -1020,7 +1020,9 @@ void fill_ss_params(ba_engine *e, SsParams &S) {
     S.ssm.nerr = e->ssg.nerr;
     if (e->ssg_kernel_choice == 1 || e->ssg_kernel_choice == 3)
       ssg_template_shape(e->ssg, &S.ssm.tpl_trend, &S.ssm.tpl_nseasons, &S.ssm.tpl_ar_lags);
-    S.ssm.reserved0 = 0;
+    S.ssm.glob = 0;
+    for (int b = 0; b < e->ssg.nblocks; ++b)
+      if (e->ssg.blk[b].kind == SSG_TRIG || e->ssg.blk[b].kind == SSG_SEMILOCAL) S.ssm.glob = 1;
     S.ssm.var_sigsq = e->dssm_sigsq.ptr;
     S.ssm.var_n = e->dssm_n.ptr;
     S.ssm.var_ss = e->dssm_ss.ptr;

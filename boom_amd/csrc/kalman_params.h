@@ -61,7 +61,7 @@ struct SsmParams {
   // autoregression] with m <= 16: the shape-specialised kernel runs (ssm_template_kernel.hip);
   // tpl_trend = 0: the general kernel
   int32_t tpl_trend, tpl_nseasons, tpl_ar_lags;
-  int32_t reserved0;                    // (was: four chains per wavefront, removed in round 5)
+  int32_t glob;                         // the list holds a trig or a semilocal-linear-trend block: the kernel instance that carries their code
   double *var_sigsq, *var_n, *var_ss;   // chains x SSG_MAX_VAR
   uint64_t *pos_var;                    // chains x SSG_MAX_VAR: the variance samplers' stream positions
   double *ar_phi;                       // chains x SSG_MAX_AR x AR_MAX

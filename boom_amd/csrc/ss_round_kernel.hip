@@ -281,7 +281,11 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
       // ---- 3a. the NEXT round's level variance (from this draw's statistics) and normals
       // (round 6, tried: this wave taking three of the product's seven variable tiles, between two
       // sub-chunks of normals or before them -- 4 to 6 us a round SLOWER: the product was waiting
-      // for its loads, not for the matrix cores, and a second wave waits just as long)
+      // for its loads, not for the matrix cores, and a second wave waits just as long; and the
+      // regression sweep by BOTH wavefronts -- ssvs_sweep_body<NB, 2, 2>, this wave leaving the
+      // normals when wave 0 is through with the tile and the two finishing them behind the sweep
+      // --: 118 us a round against 103: a bsts round's sweep refills its table every time, which
+      // the two-wave form does command by command across the workgroup's barrier)
       if (r + 1 < F.rounds) kalman_prepare_lead(S, chain, drew ? (int)CHAIN_OK : (int)CHAIN_RNG_BRANCH, r + 2, klds);
       continue;
     }

@@ -416,20 +416,24 @@ struct LaneInfo {
   // trig: is this the second component of its pair?
   __device__ __forceinline__ bool todd(int lane) const { return ((lane - first) & 1) != 0; }
   // is this a lane Z selects in its block (the block's first component; trig: every pair's first)?
+  template <bool GLOB = true>
   __device__ __forceinline__ bool zsel(int lane) const {
-    return kind != 0 && (kind == SSG_TRIG ? !todd(lane) : lane == first + cur);
+    if (GLOB && kind == SSG_TRIG) return !todd(lane);
+    return kind != 0 && lane == first + cur;
   }
 };
 
 // Z'x
-template <bool SMALL>
+template <bool SMALL, bool GLOB = true>
 __device__ __forceinline__ double zdot(const LaneInfo &L, double x, int lane) {
-  return wsum<SMALL>(L.zsel(lane) ? x : 0.0);
+  return wsum<SMALL>(L.template zsel<GLOB>(lane) ? x : 0.0);
 }
 // y = T x for a vector held one component per lane, in the layout the cursors say; mv:
 // bit b = block b's transition moves at this step (seasonal: the step into a new season);
 // the result is in the next layout (the caller advances the cursors)
-template <bool SMALL>
+// GLOB: the list holds a trig or a semilocal-linear-trend block (round 6); lists without them run
+// the instance that does not carry their code in its per-step loops
+template <bool SMALL, bool GLOB = false>
 __device__ __forceinline__ double vecT(const Blocks &B, const LaneInfo &L, double x, int lane, unsigned mv) {
   double y = x;
   // (cross-lane moves read INACTIVE lanes as nothing: they stay outside the per-lane branches)
@@ -449,13 +453,13 @@ __device__ __forceinline__ double vecT(const Blocks &B, const LaneInfo &L, doubl
   }
   // semilocal trend: (level, slope, mean) -> (level + slope, phi slope + (1 - phi) mean, mean)
   // (SemilocalLinearTrendMatrix::multiply, SemilocalLinearTrend.cpp:36-46)
-  if (L.kind == SSG_SEMILOCAL) {
+  if (GLOB && L.kind == SSG_SEMILOCAL) {
     if (lane == L.first) y = x + above;
     else if (lane == L.first + 1) y = L.phi * x + (1 - L.phi) * above;
   }
   // trig: every pair rotates, (x0, x1) -> (c x0 + s x1, -s x0 + c x1)  (the DenseMatrix blocks of
   // TrigStateModel.cpp:144-153)
-  if (B.trigmask) {
+  if (GLOB && B.trigmask) {
     const double below = from_below(x);
     if (L.kind == SSG_TRIG) y = L.todd(lane) ? -L.ts * below + L.tc * x : L.tc * x + L.ts * above;
   }
@@ -471,6 +475,7 @@ __device__ __forceinline__ double vecT(const Blocks &B, const LaneInfo &L, doubl
   return y;
 }
 // y = T' x; the cursors are those of x's layout (time t + 1); mv as above for the step t -> t + 1
+template <bool GLOB = false>
 __device__ __forceinline__ double vecTt(const Blocks &B, const LaneInfo &L, double x, int lane, unsigned mv) {
   double y = x;
   const double below = from_below(x);
@@ -487,11 +492,11 @@ __device__ __forceinline__ double vecTt(const Blocks &B, const LaneInfo &L, doub
     }
   }
   // semilocal trend: Tmult (SemilocalLinearTrend.cpp:65-76): (r0, r1, r2) -> (r0, r0 + phi r1, (1 - phi) r1 + r2)
-  if (L.kind == SSG_SEMILOCAL) {
+  if (GLOB && L.kind == SSG_SEMILOCAL) {
     if (lane == L.first + 1) y = below + L.phi * x;
     else if (lane == L.first + 2) y = (1 - L.phi) * below + x;
   }
-  if (B.trigmask) {
+  if (GLOB && B.trigmask) {
     // the rotations' transposes: (x0, x1) -> (c x0 - s x1, s x0 + c x1)
     const double above = from_above(x);
     if (L.kind == SSG_TRIG) y = L.todd(lane) ? L.ts * below + L.tc * x : L.tc * x + -L.ts * above;

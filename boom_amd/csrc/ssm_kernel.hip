@@ -89,7 +89,10 @@ __host__ __device__ inline int ssg_pass_lds_doubles(int m, int ld, int bl, int n
 // LDC: the leading dimension of P as a compile-time constant (17 / 33 / 61 / 65, chosen from
 // the state dimension by ssg_finish): an entry's LDS address is then an immediate offset from
 // the lane's column or row, where a run-time ld cost an address computation per entry.
-template <bool SMALL, int LDC>
+// GLOB: the list holds a trig or a semilocal-linear-trend block (round 6): their per-step code
+// (pair rotations, the 3 x 3 trend block, the symmetrisation of their rows of P) is compiled into
+// the GLOB = true instances only -- carried by every list it cost the round-4 lists 6 - 12 %.
+template <bool SMALL, int LDC, bool GLOB>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void ssg_simsmooth_kernel(SsParams P, int draw_variances) {
   constexpr int SSG_BATCH = SMALL ? 4 : 8;   // entries of a column / row of P asked of the LDS together
   extern __shared__ __align__(16) unsigned char s_raw[];
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
             if (b < nb) PZ += pz[b];
         }
         // (a trig block: Z selects every pair's first component, not the block's alone)
-        {
+        if (GLOB) {
           unsigned tq = B.trigmask;
           while (tq) {
             const int b = __ffs((int)tq) - 1;
@@ -413,12 +416,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
               if (mylane) PZ += s_P[(f + i) * ld + lane];
           }
         }
-        const double F = zdot<SMALL>(LI, PZ, lane) + H;
+        const double F = zdot<SMALL, GLOB>(LI, PZ, lane) + H;
         if (!(F > 0.0)) { status = CHAIN_FORECAST_VARIANCE; break; }
         if (lane == s) F_l = F;
         const double Finv = 1.0 / F;
         // K_t = T PZ / F (layout of t + 1)
-        const double TPZ = vecT<SMALL>(B, LI, PZ, lane, mv);
+        const double TPZ = vecT<SMALL, GLOB>(B, LI, PZ, lane, mv);
         if (mylane) {
           blk[s * m + lane] = obs ? TPZ * Finv : 0.0;
           s_tv[lane] = PZ;
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
               // component, -(sum over the block)
               if (moves) col[sprev((int)(B.urc(b) >> 16), n) * ld] = cs;
             }
-          } else if (kd == SSG_SEMILOCAL) {
+          } else if (GLOB && kd == SSG_SEMILOCAL) {
             double v0 = col[0], v1 = col[ld], v2 = col[2 * ld];
             if (obs) {
               v0 -= (s_tv[f] * PZ) * Finv;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
             const double ph = s_phi[Blocks::arx_of(d) * AR_MAX];
             col[0] = v0 + v1;
             col[ld] = ph * v1 + (1 - ph) * v2;
-          } else if (kd == SSG_TRIG) {
+          } else if (GLOB && kd == SSG_TRIG) {
             // the rotations from the left, a pair of the column's entries at a time
 #pragma nounroll
             for (int i = 0; i < n; i += 2) {
@@ -570,12 +573,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma nounroll
             for (; j0 < n; ++j0) cs -= row[j0];
             row[w] = cs + (lane == f + w ? sg : 0.0);
-          } else if (kd == SSG_SEMILOCAL) {
+          } else if (GLOB && kd == SSG_SEMILOCAL) {
             const double r0 = row[0], r1 = row[1], r2 = row[2];
             const double ph = s_phi[Blocks::arx_of(d) * AR_MAX];
             row[0] = (r0 + r1) + (lane == f ? sg : 0.0);
             row[1] = (ph * r1 + (1 - ph) * r2) + (lane == f + 1 ? s_sig2[Blocks::var0_of(d) + 1] : 0.0);
-          } else if (kd == SSG_TRIG) {
+          } else if (GLOB && kd == SSG_TRIG) {
             // the rotations' transposes from the right, + RQR (sigma^2 on the block's whole diagonal)
 #pragma nounroll
             for (int j = 0; j < n; j += 2) {
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         // in one, another block's T' from the right in the other): its rows and columns are made
         // symmetric the way the reference does after every update (fix_near_symmetry,
         // SpdMatrix.cpp:350-357) -- lane k averages P(i, k) and P(k, i) for the block's rows i
-        if (B.trigmask | B.slmask) {
+        if (GLOB && (B.trigmask | B.slmask)) {
           unsigned tq = B.trigmask | B.slmask;
           while (tq) {
             const int b = __ffs((int)tq) - 1;
@@ -680,14 +683,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           // simulate_next_state: T alpha + eta
           const unsigned mv = B.moving();
           const unsigned act = mv & seas_active;
-          alpha = vecT<SMALL>(B, LI, alpha, lane, mv);
+          alpha = vecT<SMALL, GLOB>(B, LI, alpha, lane, mv);
           advance(B, LI, mv, lane);
           bool err = false;
           if (LI.kind == SSG_LOCAL_LEVEL) err = sig_l != 0.0;
           else if (LI.kind == SSG_LOCAL_LINEAR_TREND) err = true;
           else if (LI.kind == SSG_AR) err = lane == LI.first;
-          else if (LI.kind == SSG_TRIG) err = sig_l != 0.0;
-          else if (LI.kind == SSG_SEMILOCAL) err = lane < LI.first + 2;
+          else if (GLOB && LI.kind == SSG_TRIG) err = sig_l != 0.0;
+          else if (GLOB && LI.kind == SSG_SEMILOCAL) err = lane < LI.first + 2;
           else if (LI.kind == SSG_SEASONAL) err = ((act >> LI.blk) & 1u) && lane == LI.first + LI.cur;
           const double z = err ? s_z[zo + cbefore_l + __popc(act & sbefore_l)] : 0.0;
           alpha += sd_l * z;
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         }
         const double zh = dH ? s_z[zo] : 0.0;
         zo += dH;
-        const double yplus = zdot<SMALL>(LI, alpha, lane) + sqrtH * zh;   // simulate_adjusted_observation
+        const double yplus = zdot<SMALL, GLOB>(LI, alpha, lane) + sqrtH * zh;   // simulate_adjusted_observation
         const double w = rl(ys_l, s) - yplus;
         if (lane == s) w_l = w;
         if (mylane) blk[s * m + lane] = alpha;
@@ -735,9 +738,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         const double K = mylane ? blk[s * m + lane] : 0.0;
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
         const unsigned mv = B.moving();
-        const double e = obs ? rl(w_l, s) - zdot<SMALL>(LI, delta, lane) : 0.0;
+        const double e = obs ? rl(w_l, s) - zdot<SMALL, GLOB>(LI, delta, lane) : 0.0;
         if (lane == s) ef_l = obs ? e / F_l : 0.0;
-        delta = vecT<SMALL>(B, LI, delta, lane, mv) + K * e;
+        delta = vecT<SMALL, GLOB>(B, LI, delta, lane, mv) + K * e;
         advance(B, LI, mv, lane);
       }
       __builtin_amdgcn_wave_barrier();
@@ -767,17 +770,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
       if (mylane) {
         bool carrier;
         if (LI.kind == SSG_SEASONAL) carrier = lane == LI.first + LI.cur;
-        else if (LI.kind == SSG_LOCAL_LINEAR_TREND || LI.kind == SSG_TRIG) carrier = true;
-        else if (LI.kind == SSG_SEMILOCAL) carrier = lane < LI.first + 2;
+        else if (LI.kind == SSG_LOCAL_LINEAR_TREND || (GLOB && LI.kind == SSG_TRIG)) carrier = true;
+        else if (GLOB && LI.kind == SSG_SEMILOCAL) carrier = lane < LI.first + 2;
         else carrier = lane == LI.first;
         if (carrier) s_z[erow_l * BL + s] = r;
       }
       const double kr = wsum<SMALL>(K * r);
       const double coef = rl(ef_l, s) - kr;
-      r = vecTt(B, LI, r, lane, mv);
+      r = vecTt<GLOB>(B, LI, r, lane, mv);
       retreat(B, LI, mv, lane);
       // + Z coef (layout of t)
-      if (LI.zsel(lane)) r += coef;
+      if (LI.template zsel<GLOB>(lane)) r += coef;
       if (!mylane) r = 0.0;
     }
     wave_lds_sync();
@@ -815,14 +818,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
         const double ap = mylane ? buf[s * m + lane] : 0.0;
         if (tb + s > 0) {
           const unsigned mv = B.moving();
-          mc = vecT<SMALL>(B, LI, mc, lane, mv);
+          mc = vecT<SMALL, GLOB>(B, LI, mc, lane, mv);
           advance(B, LI, mv, lane);
           // + RQR_{t-1} r_{t-1}
           bool carrier = false;
           if (mylane) {
             if (LI.kind == SSG_SEASONAL) carrier = LI.moves(mv) && lane == LI.first + LI.cur;
-            else if (LI.kind == SSG_LOCAL_LINEAR_TREND || LI.kind == SSG_TRIG) carrier = true;
-            else if (LI.kind == SSG_SEMILOCAL) carrier = lane < LI.first + 2;
+            else if (LI.kind == SSG_LOCAL_LINEAR_TREND || (GLOB && LI.kind == SSG_TRIG)) carrier = true;
+            else if (GLOB && LI.kind == SSG_SEMILOCAL) carrier = lane < LI.first + 2;
             else carrier = lane == LI.first;
           }
           if (carrier) mc += sig_l * s_z[erow_l * BL + s];
@@ -887,8 +890,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           advance(B, LI, 0u, lane);
         }
         const double then1 = from_above(prev);
-        const double thenb = B.trigmask ? from_below(prev) : 0.0;
-        if (LI.kind == SSG_SEMILOCAL && lane == LI.first + 1) {
+        const double thenb = (GLOB && B.trigmask) ? from_below(prev) : 0.0;
+        if (GLOB && LI.kind == SSG_SEMILOCAL && lane == LI.first + 1) {
           // observe_initial_state / observe_state: the current slope into the Ar1Suf, every t
           // (SemilocalLinearTrend.cpp:168-180; NonzeroMeanAr1Model.cpp:39-49)
           if (tb + s == 0) a1_first = st; else a1_cross += st * a1_last;
@@ -900,12 +903,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           if (LI.kind == SSG_LOCAL_LEVEL) {
             const double diff = st - prev;
             suf_l += diff * diff;
-          } else if (LI.kind == SSG_SEMILOCAL) {
+          } else if (GLOB && LI.kind == SSG_SEMILOCAL) {
             if (lane == LI.first) {
               const double change_in_level = st - prev - then1;
               suf_l += change_in_level * change_in_level;
             }
-          } else if (LI.kind == SSG_TRIG) {
+          } else if (GLOB && LI.kind == SSG_TRIG) {
             // now - rotation * then, every component (TrigStateModel::observe_state, TrigStateModel.cpp:182-193)
             const double rot = LI.todd(lane) ? -LI.ts * thenb + LI.tc * prev : LI.tc * prev + LI.ts * then1;
             const double e = st - rot;
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
           buf[s * m + LI.first + (q >= c ? q - c : q - c + LI.dim)] = st;
         }
         const bool obs = __builtin_amdgcn_readlane(ob_l, s) != 0;
-        const double resid = obs ? rl(y_l, s) - zdot<SMALL>(LI, st, lane) : 0.0;
+        const double resid = obs ? rl(y_l, s) - zdot<SMALL, GLOB>(LI, st, lane) : 0.0;
         if (lane == s) res_l = resid;
         if (obs) { yty += resid * resid; nobs += 1.0; }
       }
@@ -1157,11 +1160,12 @@ hipError_t launch_ssm_simsmooth(hipStream_t stream, const SsParams &P, int draw_
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, P, draw_variances);
         return hipSuccess;
       };
+      const bool glob = P.ssm.glob != 0;   // (a trig or semilocal block in the list)
       switch (P.ssm.ld) {   // ssg_leading_dimension(m)
-        case 17: err = go(ssg_simsmooth_kernel<true, 17>); break;
-        case 33: err = go(ssg_simsmooth_kernel<false, 33>); break;
-        case 61: err = go(ssg_simsmooth_kernel<false, 61>); break;
-        case 65: err = go(ssg_simsmooth_kernel<false, 65>); break;
+        case 17: err = glob ? go(ssg_simsmooth_kernel<true, 17, true>) : go(ssg_simsmooth_kernel<true, 17, false>); break;
+        case 33: err = glob ? go(ssg_simsmooth_kernel<false, 33, true>) : go(ssg_simsmooth_kernel<false, 33, false>); break;
+        case 61: err = glob ? go(ssg_simsmooth_kernel<false, 61, true>) : go(ssg_simsmooth_kernel<false, 61, false>); break;
+        case 65: err = glob ? go(ssg_simsmooth_kernel<false, 65, true>) : go(ssg_simsmooth_kernel<false, 65, false>); break;
         default: return hipErrorInvalidValue;
       }
       if (err != hipSuccess) return err;
