@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_rng.h"
+#include "diag.h"
 #include "kalman_params.h"
 #include "stream_normals.h"
 
@@ -12,12 +13,7 @@ namespace boom_amd {
 
 namespace {
 
-// diagnostic build (-DBA_KSTAMPS): chain 0 prints its cycles per phase
-#ifdef BA_KSTAMPS
-#define KSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
-#else
-#define KSTAMP(i) do { } while (0)
-#endif
+// (diagnostic build -DBA_KSTAMPS: chain 0 prints its cycles per phase -- KSTAMP, diag.h)
 
 #ifndef BA_HAVE_WAVE_HELPERS   // (ssvs_device.h, when it comes first, has the same four)
 constexpr int WAVE = 64;

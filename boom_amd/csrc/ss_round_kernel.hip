@@ -103,11 +103,7 @@ __device__ __forceinline__ d2 ld_coh16(__amdgpu_buffer_rsrc_t r, uint32_t byte_o
 
 // diagnostic build (-DBA_RSTAMPS): 100 MHz ticks per phase, summed over the launch's rounds,
 // per chain and wave, into F.stamps (chains x 2 x 8)
-#ifdef BA_RSTAMPS
-#define RSTAMP(i) do { const long long t_ = wall_clock64(); rph[i] += t_ - rlast; rlast = t_; } while (0)
-#else
-#define RSTAMP(i) do { } while (0)
-#endif
+// (RSTAMP: diag.h)
 
 // One member's share of a tile's product: out[member, variable] over the 128 steps of rows slot,
 // slot + n, ... of the lane-major series, four steps a matrix instruction in time order (lane l

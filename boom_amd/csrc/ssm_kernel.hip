@@ -64,6 +64,7 @@
 //     sum in the same order, so P stays exactly symmetric.
 #include <hip/hip_runtime.h>
 
+#include "diag.h"
 #include "ktimer.h"
 
 #include "device_rng.h"
@@ -124,9 +125,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void s
   __syncthreads();
 #ifdef BA_KSTAMPS
   long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
-#define SSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
-#else
-#define SSTAMP(i) do { } while (0)
 #endif
 
   // ---- the state models' samplers, in model order (every sampler reads its own stream)

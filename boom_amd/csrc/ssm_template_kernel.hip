@@ -36,6 +36,7 @@
 // ONE filter runs on w = y* - y+, and one smoother on the difference.
 #include <hip/hip_runtime.h>
 
+#include "diag.h"
 #include "ktimer.h"
 
 #include "device_rng.h"
@@ -546,9 +547,6 @@ __global__ __launch_bounds__(128) void ssm_simsmooth_kernel(SsParams P, int draw
   if (threadIdx.x == 0) { s_flag = CHAIN_OK; s_vprog = 0; s_cprog = 0; s_cdone = 0; }
 #ifdef BA_KSTAMPS
   long long kph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, klast = (long long)__builtin_readcyclecounter();
-#define SSTAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); kph[i] += t_ - klast; klast = t_; } while (0)
-#else
-#define SSTAMP(i) do { } while (0)
 #endif
 
   // ---- the state models' variance draws, in model order: level [, slope], seasonal

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_rng.h"
+#include "diag.h"
 #include "ssvs_params.h"
 
 namespace boom_amd {
@@ -16,39 +17,7 @@ namespace {
 constexpr int WAVE = 64;
 #define BA_INF (__builtin_inf())
 
-// Diagnostic build only (-DBA_STAMPS): cycles per phase, never in the product.
-#ifdef BA_STAMPS
-#define STAMP_DECL long long st_last = (long long)__builtin_readcyclecounter(); double st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define STAMP(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); st_ph[i] += (double)(t_ - st_last); st_last = t_; } while (0)
-#else
-#define STAMP_DECL do { } while (0)
-#define STAMP(i) do { } while (0)
-#endif
-// -DBA_STAMPS -DBA_STAMPS2: the 8 slots time the inside of a proposal batch
-// instead (0 uniform+log, 1 classify, 2 V gather, 3 V solve, 4 A gather,
-// 5 A solve, 6 epilogue, 7 everything outside the batch)
-struct StampCtx { long long last; double ph[8]; };
-#if defined(BA_STAMPS) && defined(BA_STAMPS2)
-#define SUBSTAMP(c, i) do { const long long t_ = (long long)__builtin_readcyclecounter(); (c).ph[i] += (double)(t_ - (c).last); (c).last = t_; } while (0)
-#else
-#define SUBSTAMP(c, i) do { } while (0)
-#endif
-// -DBA_STAMPS -DBA_STAMPS3: the 8 slots time the master's pieces of a forked
-// sweep (0 commit, 1 sweep-start copy, 2 fork, 3 swap proposal, 4 sigma,
-// 5 normals, 6 back substitution, 7 everything else)
-// -DBA_STAMPS -DBA_STAMPS4: the 8 slots time helper wave 1 (0 shuffle uniforms,
-// 1 matching rounds, 2 links, 3 walks, 4 table walk, 5 waiting for commands,
-// 6 its share of proposal rounds, 7 other)
-#if defined(BA_STAMPS) && defined(BA_STAMPS4)
-#define HSTAMP(c, i) do { const long long t_ = (long long)__builtin_readcyclecounter(); (c).ph[i] += (double)(t_ - (c).last); (c).last = t_; } while (0)
-#else
-#define HSTAMP(c, i) do { } while (0)
-#endif
-#if defined(BA_STAMPS) && defined(BA_STAMPS3)
-#define TSTAMP(c, i) do { const long long t_ = (long long)__builtin_readcyclecounter(); (c).ph[i] += (double)(t_ - (c).last); (c).last = t_; } while (0)
-#else
-#define TSTAMP(c, i) do { } while (0)
-#endif
+// (the diagnostic builds' cycle stamps -- STAMP, SUBSTAMP, TSTAMP, HSTAMP -- are diag.h's)
 
 // ---- address spaces ---------------------------------------------------------
 // LDS pointers are typed as such so that every access is a ds_* instruction no

@@ -22,9 +22,6 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
 #ifdef BA_PSTAMPS
   long long pst[8];
   pst[0] = (long long)__builtin_readcyclecounter();
-#define PSTAMP(i) pst[i] = (long long)__builtin_readcyclecounter()
-#else
-#define PSTAMP(i) do { } while (0)
 #endif
   // State-space rounds: the planes of the X'e GEMM that fed this launch are added here
   // (SsvsParams::xty_planes).  Their loads go out FIRST, ahead of everything the prologue

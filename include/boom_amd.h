@@ -458,8 +458,21 @@ int ba_ss_set_local_level(ba_engine *e, double level_df,
  *           Z = 1 at every pair's first component; ONE variance for all components with its
  *           ZeroMeanGaussianConjSampler(ChisqModel(df, sigma_guess)), as bsts builds it
  *           (Interfaces/R/bsts/src/create_state_model.cpp:559-586)          2 x frequencies
+ *   kind 7  SemilocalLinearTrendStateModel(level, slope) (StateModels/SemilocalLinearTrend.cpp:
+ *           37-323): state (level, slope, the slope's long-run mean mu); level' = level + slope +
+ *           e1, slope' = mu + phi (slope - mu) + e2.  The level's variance has a
+ *           ZeroMeanGaussianConjSampler, the slope's NonzeroMeanAr1Model (mu, phi, sigma) a
+ *           NonzeroMeanAr1Sampler (Models/TimeSeries/PosteriorSamplers/NonzeroMeanAr1Sampler.cpp:
+ *           58-137: mu | phi, sigma normal; phi | mu, sigma normal, truncated to (-1, 1) -- or
+ *           (0, 1) -- by rejection when forced stationary (positive); sigma from the residual sum
+ *           of squares), as bsts builds it (create_state_model.cpp:356-446).  iparams =
+ *           {force_stationary, force_positive} (positive without stationary -- a one-sided
+ *           truncation -- is refused); the var_* arrays have two entries (level, slope);
+ *           initial_phi = {mu's prior mean, sd, phi's prior mean, sd, initial mu, initial phi};
+ *           initial_state_mean / _variance have three entries, the third is not read (the
+ *           component IS mu: mean mu, variance 0).  Takes one of the 4 autoregression slots.  3
  * iparams is ignored for kinds 1, 2 and 5 (may be NULL).  The var_* arrays hold one entry
- * per variance parameter of the model (two for kind 2: level, slope; one otherwise):
+ * per variance parameter of the model (two for kinds 2 and 7: level, slope; one otherwise):
  * ChisqModel(df, sigma_guess) prior, sigma upper limit (infinity: none), initial sigma.
  * initial_phi: lags entries, NULL = zeros; must be stationary, as ArModel's constructor
  * demands (ArModel::check_stationary, ArModel.cpp:142-170, decided by the quick bound
@@ -468,7 +481,7 @@ int ba_ss_set_local_level(ba_engine *e, double level_df,
  * variance's diagonal; positive, a local level's may be 0).  Limits: state dimension
  * <= 64, 8 state models, 16 variance parameters, 4 autoregression models.
  * RNG streams: variance parameter v of a model reads the chain's sampler id 1 (level),
- * 6 (slope), 7 (seasonal), 13 (trig) or 12 (ArPosteriorSampler: the proposals' normals, then the
+ * 6 (slope), 7 (seasonal), 13 (trig), 14 (a semilocal slope: NonzeroMeanAr1Sampler) or 12 (ArPosteriorSampler: the proposals' normals, then the
  * sigma draw -- the reference takes the proposals from GlobalRng::rng and the rest from
  * the sampler's generator) + 16 for every earlier model of the same family (local level
  * and local linear trend are one family); the state draw reads stream 2. */
@@ -495,7 +508,11 @@ int ba_ss_state_dimension(ba_engine *e, int32_t *state_dimension, int32_t *nbloc
 /* state model `block` of one chain: its variance parameters (nvar), the model's
  * sufficient statistics of the last sweep (n, sum of squares per variance) and, for an
  * autoregression model, its coefficients (lags) and the ArModel's sufficient
- * statistics (xtx lags x lags column-major, xty, yty, n); any pointer may be NULL */
+ * statistics (xtx lags x lags column-major, xty, yty, n).  A semilocal linear trend (kind 7):
+ * variances = (level, slope), phi[0..1] = (phi, mu) of the slope's NonzeroMeanAr1Model, ar_xtx
+ * [0..5] = its Ar1Suf (sum of squares, sum, cross product of successive values, n, first value,
+ * last value; Models/TimeSeries/NonzeroMeanAr1Model.cpp:33-91), ar_n = n; ar_xty / ar_yty are
+ * refused.  Any pointer may be NULL */
 int ba_ss_get_state_model(ba_engine *e, int64_t chain, int32_t block, double *variances,
                           double *suf_n, double *suf_ss, double *phi, double *ar_xtx,
                           double *ar_xty, double *ar_yty, double *ar_n);
