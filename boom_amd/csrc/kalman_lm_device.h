@@ -273,9 +273,13 @@ __device__ __forceinline__ bool kalman_lm_body(const SsParams &P, const int draw
   // loads in flight together); products accumulate in variable order, as GlmCoefs::predict
   double ys[BS];
   {
+    // (y itself is asked for AFTER the variables' loop: asked for up front -- sixteen more
+    // registers through a loop that holds LM_VB x 16 loads in flight -- the round kernel's
+    // instance waited for each of its loads in turn to park it in scratch memory, ten memory
+    // round trips in a row)
     double pred[BS], yv[BS];
 #pragma unroll
-    for (int j = 0; j < BS; ++j) { pred[j] = 0.0; yv[j] = P.yt[j * NT + tid]; }
+    for (int j = 0; j < BS; ++j) pred[j] = 0.0;
     for (int vb = 0; vb < p; vb += WAVE) {
       const int jv = vb + lane;
       const double bj = (jv < p) ? beta[jv] : 0.0;
@@ -312,8 +316,19 @@ __device__ __forceinline__ bool kalman_lm_body(const SsParams &P, const int draw
         }
       }
     }
+    int yoff = tid;
+    asm volatile("" : "+v"(yoff) : "v"(pred[0]));   // (not before the loop: the compiler would put them back there)
 #pragma unroll
-    for (int j = 0; j < BS; ++j) ys[j] = LM_IN(j) ? yv[j] - pred[j] : 0.0;
+    for (int j = 0; j < BS; ++j) yv[j] = P.yt[j * NT + yoff];
+    // (and the differences taken here and now, in sixteen registers: left to itself the compiler
+    // keeps y and the predictions apart until each step's first use, thirty-two registers more
+    // through the loads of the normals)
+#pragma unroll
+    for (int j = 0; j < BS; ++j) ys[j] = yv[j] - pred[j];
+    asm volatile("" : "+v"(ys[0]), "+v"(ys[1]), "+v"(ys[2]), "+v"(ys[3]), "+v"(ys[4]), "+v"(ys[5]), "+v"(ys[6]), "+v"(ys[7]),
+                      "+v"(ys[8]), "+v"(ys[9]), "+v"(ys[10]), "+v"(ys[11]), "+v"(ys[12]), "+v"(ys[13]), "+v"(ys[14]), "+v"(ys[15]));
+#pragma unroll
+    for (int j = 0; j < BS; ++j) ys[j] = LM_IN(j) ? ys[j] : 0.0;
   }
   KSTAMP(2);
   __builtin_amdgcn_sched_barrier(0);   // (registers: y* is done before the normals come in)

@@ -515,15 +515,27 @@ __device__ __forceinline__ void restore_model(Chain &ch) {
   const int kpad = (k + 7) & ~7;
   const int nblk = (kpad / 8) * (kpad / 8 + 1) / 2;
   const double *src = ch.sc_store;
-  for (int e = lane; e < nblk * 64; e += WAVE) {
-    ch.Lv[e] = src[S.Lv + e];
-    ch.La[e] = src[S.La + e];
+  // (every load goes out before the first LDS write: written load / store / load / store, one
+  // call site's copy came out as six L2 round trips in a row)
+  const bool row = lane < kpad;
+  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+  if (row) {
+    r0 = src[S.rdv + lane];
+    r1 = src[S.rda + lane];
+    r2 = src[S.w + lane];
+    r3 = src[S.bg + lane];
   }
-  if (lane < kpad) {
-    ch.rdv[lane] = src[S.rdv + lane];
-    ch.rda[lane] = src[S.rda + lane];
-    ch.w[lane] = src[S.w + lane];
-    ch.bg[lane] = src[S.bg + lane];
+  for (int e = lane; e < nblk * 64; e += WAVE) {
+    double lv = src[S.Lv + e], la = src[S.La + e];
+    asm volatile("" : "+v"(lv), "+v"(la), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+    ch.Lv[e] = lv;
+    ch.La[e] = la;
+  }
+  if (row) {
+    ch.rdv[lane] = r0;
+    ch.rda[lane] = r1;
+    ch.w[lane] = r2;
+    ch.bg[lane] = r3;
   }
   wave_sync();
 }
@@ -645,13 +657,30 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
       if (I * 8 < k) {
+        // (all sixteen loads of a block go out before any is used, and the compiler is told
+        // so: left to itself it moved each A load under the select that consumes it -- a
+        // conditional block with its own wait -- and a block's gather became eight L2 round
+        // trips in a row, 7.5 k cycles of a fill pass)
+        int gms[8];
+        double rv[8], ra[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int m = I * 8 + r;
-          const int gm = (m < k) ? (int)ch.g[m] : 0;  // LDS broadcast read
-          const size_t o = (size_t)gm * stride_g + lane_off;
-          const double v = P.V[o] * ch.sv, a = P.A[o] * ch.sa;
-          const double e = (gm == j) ? 1.0 : 0.0;
+          gms[r] = (m < k) ? (int)ch.g[m] : 0;  // LDS broadcast read
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const size_t o = (size_t)gms[r] * stride_g + lane_off;
+          rv[r] = P.V[o];
+          ra[r] = P.A[o];
+        }
+        asm volatile("" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),
+                          "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int m = I * 8 + r;
+          const double v = rv[r] * ch.sv, a = ra[r] * ch.sa;
+          const double e = (gms[r] == j) ? 1.0 : 0.0;
           const bool on = fast && m < k;
           xv[m] = on ? (add ? v : e) : 0.0;
           xa[m] = on ? (add ? a : e) : 0.0;
