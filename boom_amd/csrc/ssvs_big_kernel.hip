@@ -329,11 +329,19 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
           c_f64 *rd = (c_f64 *)((unsigned long long)LB + ((unsigned long long)rdst - (unsigned long long)Lst));
           big_solve(LB, rd, I * 64, I, true, bx.xs, lane,
                     [&](int J, double (&a)[64]) {
+                      // (sixteen gathers at a time, all out before the first is used, and the
+                      // compiler told so -- tools/isa_serial_loads.py: it hangs every load whose
+                      // value goes through a per-lane select under a branch of its own, with a
+                      // wait of its own, and a panel's gather was 64 round trips in a row)
 #pragma unroll
-                      for (int r = 0; r < 64; ++r) {
-                        const int gm = (int)ch.g[J * 64 + r];  // (J < I: a full panel of real variables)
-                        const double v = Mrow[gm] * msc;
-                        a[r] = valid ? v : 0.0;
+                      for (int r0 = 0; r0 < 64; r0 += 16) {
+                        double raw[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) raw[r] = Mrow[(int)ch.g[J * 64 + r0 + r]];  // (J < I: a full panel of real variables)
+                        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
+                        "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]), "+v"(raw[15]));
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) a[r0 + r] = valid ? raw[r] * msc : 0.0;
                       }
                     },
                     [&](int, double (&)[64]) {});
@@ -348,12 +356,17 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
           if (cb * 8 < kk) {
+            double raw[8];
 #pragma unroll
-            for (int c = cb * 8; c < cb * 8 + 8; ++c) {
-              const int col = I * 64 + c;
-              const int gc = (col < k) ? (int)ch.g[col] : 0;
-              const double v = Mrow[gc] * msc;
-              acc[c] = (valid && col <= row) ? v : 0.0;
+            for (int c = 0; c < 8; ++c) {
+              const int col = I * 64 + cb * 8 + c;
+              raw[c] = Mrow[(col < k) ? (int)ch.g[col] : 0];
+            }
+            asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int col = I * 64 + cb * 8 + c;
+              acc[cb * 8 + c] = (valid && col <= row) ? raw[c] * msc : 0.0;
             }
           } else {
 #pragma unroll
@@ -571,17 +584,27 @@ __device__ __forceinline__ Proposal big_eval(const BigP &P, Chain &ch, const Mod
     big_solve(LB, rd, k, npan, false, bx.xs, lane,
               [&](int I, double (&a)[64]) {
 #pragma unroll
-                for (int r = 0; r < 64; ++r) {
-                  // (16 gathers in flight at a time: their addresses need registers too)
-                  if ((r & 15) == 0) __builtin_amdgcn_sched_barrier(0);
-                  const int m = I * 64 + r;
-                  const int gm = (m < k) ? (int)ch.g[m] : 0;
-                  const double v = (NAT ? Mat[(size_t)gm * p + j] : Mat[(size_t)j * p + gm]) * msc;
-                  const double e = (gm == j) ? 1.0 : 0.0;
-                  a[r] = (fast && m < k) ? (add ? v : e) : 0.0;
-                  abl += a[r] * sc[S.bg + m];
+                for (int r0 = 0; r0 < 64; r0 += 16) {
+                  // (16 gathers in flight at a time: their addresses need registers too; all of
+                  // them out before the first is used, see the build's panels)
+                  int gms[16];
+                  double raw[16];
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) {
+                    const int m = I * 64 + r0 + r;
+                    gms[r] = (m < k) ? (int)ch.g[m] : 0;
+                    raw[r] = NAT ? Mat[(size_t)gms[r] * p + j] : Mat[(size_t)j * p + gms[r]];
+                  }
+                  asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
+                  "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]), "+v"(raw[15]));
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) {
+                    const int m = I * 64 + r0 + r;
+                    const double e = (gms[r] == j) ? 1.0 : 0.0;
+                    a[r0 + r] = (fast && m < k) ? (add ? raw[r] * msc : e) : 0.0;
+                    abl += a[r0 + r] * sc[S.bg + m];
+                  }
                 }
-                __builtin_amdgcn_sched_barrier(0);
               },
               [&](int I, double (&a)[64]) {
 #pragma unroll

@@ -101,14 +101,13 @@ __device__ __forceinline__ void mf_tri_solve(const double *__restrict__ Lg, cons
       for (int c = 0; c < 4; ++c) a[c] = ip[4 * c];
     } else {
       // element (16 I + r, 16 J + 4 c + g): 8 x 8 block (2 I + (r >> 3), 2 J + (c >> 1))
+      // (as loaded: the sign and the mask of the rows that are not there go on where the group
+      // is used -- applied here, every load was waited for in turn, through one pair of
+      // temporary registers, a chain of four to eleven round trips per group of the prologue)
       const int bi = 2 * I + (r >> 3);
       const double *rowp = Lg + ((bi * (bi + 1)) / 2) * 64 + (r & 7) * 8 + g;
-      const bool rowok = MF_ROWS * I + r < kpad8;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const double l = rowp[(2 * J + (c >> 1)) * 64 + 4 * (c & 1)];
-        a[c] = rowok ? -l : 0.0;
-      }
+      for (int c = 0; c < 4; ++c) a[c] = rowp[(2 * J + (c >> 1)) * 64 + 4 * (c & 1)];
     }
   };
 #pragma unroll
@@ -119,7 +118,14 @@ __device__ __forceinline__ void mf_tri_solve(const double *__restrict__ Lg, cons
     if (n + D < G) fetch(n + D, ring[(n + D) % (D + 1)]);
     __builtin_amdgcn_sched_barrier(0);
     const int I = mf_group_row(n), J = n - I * (I + 1) / 2;
-    const double (&a)[4] = ring[n % (D + 1)];
+    double a[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = ring[n % (D + 1)][c];
+    if (J != I) {
+      const bool rowok = MF_ROWS * I + r < kpad8;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = rowok ? -a[c] : 0.0;
+    }
     if (J == I) {
       v4d out[MF_NT];
 #pragma unroll
@@ -185,13 +191,24 @@ __device__ __forceinline__ void mf_factor(const double *__restrict__ Mat, const 
       for (int t = 0; t < MF_NT; ++t) X[I][t][q] = Mat[(size_t)gm * p + jt[t]];
     }
   }
+  // (the weights of a factor are asked for together, like the gathers: read one at a time where
+  // each is used, every one of up to 32 was a round trip of its own)
+  double wr[NI][4];
+  if (SF) {
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { wr[I][q] = wv[MF_ROWS * I + 4 * q + g]; }
+#pragma unroll
+    for (int I = 0; I < NI; ++I) asm volatile("" : "+v"(wr[I][0]), "+v"(wr[I][1]), "+v"(wr[I][2]), "+v"(wr[I][3]));
+  }
 #pragma unroll
   for (int I = 0; I < NI; ++I) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = MF_ROWS * I + 4 * q + g;
       double wm = 0.0;
-      if (SF) { const double wr = wv[m]; wm = (m < k) ? wr : 0.0; }
+      if (SF) wm = (m < k) ? wr[I][q] : 0.0;
 #pragma unroll
       for (int t = 0; t < MF_NT; ++t) {
         const double e = (gmv[I][q] == jt[t]) ? dropf[t] : 0.0;
@@ -203,13 +220,21 @@ __device__ __forceinline__ void mf_factor(const double *__restrict__ Mat, const 
   }
   __builtin_amdgcn_sched_barrier(0);
   mf_tri_solve<NI>(Lg, Linv, kpad8, lane, X);
+  if (!SF) {
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { wr[I][q] = wv[MF_ROWS * I + 4 * q + g]; }
+#pragma unroll
+    for (int I = 0; I < NI; ++I) asm volatile("" : "+v"(wr[I][0]), "+v"(wr[I][1]), "+v"(wr[I][2]), "+v"(wr[I][3]));
+  }
 #pragma unroll
   for (int I = 0; I < NI; ++I) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = MF_ROWS * I + 4 * q + g;
       double wm = 0.0;
-      if (!SF) { const double wr = wv[m]; wm = (m < k) ? wr : 0.0; }
+      if (!SF) wm = (m < k) ? wr[I][q] : 0.0;
 #pragma unroll
       for (int t = 0; t < MF_NT; ++t) {
         const double x = X[I][t][q];
