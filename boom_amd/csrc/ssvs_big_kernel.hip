@@ -168,6 +168,55 @@ __device__ __forceinline__ void chol_tile(lds_f64 *T, lds_f64 *rdt, int kk, int 
   *logdet_sum = l;
 }
 
+// The same factorisation with the lane's row IN REGISTERS (lane i = row i, acc[c] = its entry
+// in column c), right-looking: column j is scaled, handed round through LDS (64 doubles, every
+// lane reads all of them: broadcast reads) and subtracted from the columns to its right.  Entry
+// (i, c) receives l_i0 l_c0, l_i1 l_c1, ... in that order, each as one fused multiply-subtract
+// -- the subtractions of chol_tile's dot products, in their order, so the factor is bitwise
+// chol_tile's.  What differs is the critical path: chol_tile's column j is a dot product of
+// length j (j dependent fused multiply-adds behind 2 j LDS reads, 3.7 k cycles a column at
+// k = 64: 38 % of a model build); here a column is one multiply-add deep.  col: 2 x 64 doubles
+// of LDS.  Entries above the diagonal hold numbers nobody reads.
+__device__ __forceinline__ void chol_tile_regs(double (&acc)[64], lds_f64 *col, int kk, int lane,
+                                               bool *ok_out, double *logdet_sum, double *rd_out) {
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  bool ok = true;
+  double rdl = 0.0, diag = 1.0;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    if (j < kk && ok) {
+      const double d = bcast_u(acc[j], j);
+      if (!(d > 0.0)) {
+        ok = false;
+      } else {
+        const double sd = sqrt(d);
+        double cj = (lane == j) ? sd : acc[j] / sd;
+        cj = (lane >= j && lane < kk) ? cj : 0.0;
+        acc[j] = cj;
+        if (lane == j) { rdl = 1.0 / sd; diag = sd; }
+        if (j + 1 < 64) {
+          lds_f64 *cb = col + (j & 1) * 64;   // (two buffers: one hand-off a column)
+          cb[lane] = cj;
+          wave_sync();
+          const AS_LDS d2_t *cp = (const AS_LDS d2_t *)cb;
+#pragma unroll
+          for (int c0 = (j + 1) & ~1; c0 < 64; c0 += 2) {
+            const d2_t v = cp[c0 >> 1];
+            if (c0 > j) acc[c0] -= cj * v.x;
+            acc[c0 + 1] -= cj * v.y;
+          }
+        }
+      }
+    }
+  }
+  double l = 0.0;
+  const double lg = (ok && lane < kk) ? log(diag) : 0.0;
+  for (int j = 0; j < kk; ++j) l += bcast_u(lg, j);
+  *ok_out = ok;
+  *logdet_sum = l;
+  *rd_out = rdl;
+}
+
 struct BigCtx {
   int kcap;
   SsvsScalarLayout S;
@@ -360,7 +409,10 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
               const int col = I * 64 + cb * 8 + c;
-              raw[c] = Mrow[(col < k) ? (int)ch.g[col] : 0];
+              // (the list's entries behind k are whatever an earlier model left: any valid index
+              // will do -- a branch on col < k here made the eight loads eight round trips)
+              const int gc = (int)ch.g[col];
+              raw[c] = Mrow[gc < p ? gc : 0];
             }
             asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]));
 #pragma unroll
@@ -392,23 +444,27 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
         }
         BST(2);
         wave_sync();
-#pragma unroll
-        for (int c = 0; c < 64; ++c)
-          if ((c >> 3) <= (lane >> 3)) bx.tile[bidx(lane, c)] = (valid && c <= lane) ? acc[c] : 0.0;
-        bx.rdt[lane] = 0.0;
-        wave_sync();
-        double ldt = 0.0;
-        chol_tile(bx.tile, bx.rdt, kk, lane, &ok, &ldt);
+        double ldt = 0.0, rdl = 0.0;
+        // (the tile's LDS holds the columns on their way round the lanes; the factor itself stays
+        // in acc)
+        chol_tile_regs(acc, bx.tile, kk, lane, &ok, &ldt, &rdl);
         ld += ldt;
         wave_sync();
         BST(3);
         if (!ok) break;
         // what the table fills on the matrix cores multiply by (ssvs_fill_mfma.h): the
-        // inverses of this tile's 16 x 16 diagonal blocks, from the tile while it is in LDS
+        // inverses of this tile's 16 x 16 diagonal blocks, from a copy of the tile in LDS
         if (k <= MF_ROWS * MF_MAX_BLOCK_ROWS) {
           const int nI_all = mf_block_rows(k), nI_here = (nI_all - 4 * I < 4) ? nI_all - 4 * I : 4;
-          if (nI_here > 0)
+          if (nI_here > 0) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c)
+              if ((c >> 3) <= (lane >> 3)) bx.tile[bidx(lane, c)] = (valid && c <= lane) ? acc[c] : 0.0;
+            bx.rdt[lane] = rdl;
+            wave_sync();
             diag_inverses(bx.tile, bx.rdt, dst + (s ? S.ia : S.iv) + (size_t)(4 * I) * (MF_ROWS * MF_ROWS), kk, nI_here, lane);
+            wave_sync();
+          }
         }
         // rows of this tile row go to the factor: parked off-diagonal part, the tile, rd
         if (row < kpad8) {
@@ -422,10 +478,10 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
 #pragma unroll
           for (int c = 0; c < 64; ++c)
             if ((c >> 3) <= (lane >> 3))
-              Lst[bidx(row, I * 64 + c)] = (valid && c <= lane && c < kk) ? bx.tile[bidx(lane, c)] : 0.0;
-          rdst[row] = valid ? bx.rdt[lane] : 0.0;
+              Lst[bidx(row, I * 64 + c)] = (valid && c <= lane && c < kk) ? acc[c] : 0.0;
+          rdst[row] = valid ? rdl : 0.0;
         }
-        if (s == 0 && valid) ch.rdv[row] = bx.rdt[lane];
+        if (s == 0 && valid) ch.rdv[row] = rdl;
         BST(4);
       }
       if (s) { oka = ok; M.lda = 2.0 * ld; }
@@ -484,17 +540,33 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
 #pragma unroll
         for (int u = 0; u < 8; ++u) t -= lv8[u] * ch.w[m0 + u];
       }
-    double lt[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) lt[j] = (valid && j < lane) ? Lv[bidx(row, I * 64 + j)] : 0.0;
     const double rdm = valid ? ch.rdv[row] : 0.0;
     const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
+    // (the lane's row of the tile sixteen columns at a time, every load unconditional -- a lane
+    // reads its own diagonal where the column lies above it -- and out before the first is used:
+    // as 64 loads each under the condition "below the diagonal" they were 64 round trips in a
+    // row, and the array that held them went to scratch memory)
+    const int rowc = valid ? row : I * 64;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      if (j < kk) {
-        const double wj = bcast_u(t, j) * bcast_u(rdm, j);
-        if (lane == j) t = wj;
-        else if (lane > j) t -= lt[j] * wj;
+    for (int j0 = 0; j0 < 64; j0 += 16) {
+      if (j0 < kk) {
+        double raw[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int lr = rowc - I * 64;
+          raw[u] = Lv[bidx(rowc, I * 64 + ((j0 + u < lr) ? j0 + u : lr))];
+        }
+        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
+                          "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]), "+v"(raw[15]));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + u;
+          if (j < kk) {
+            const double wj = bcast_u(t, j) * bcast_u(rdm, j);
+            if (lane == j) t = wj;
+            else if (lane > j && valid) t -= raw[u] * wj;
+          }
+        }
       }
     }
     if (valid) {
@@ -592,7 +664,8 @@ __device__ __forceinline__ Proposal big_eval(const BigP &P, Chain &ch, const Mod
 #pragma unroll
                   for (int r = 0; r < 16; ++r) {
                     const int m = I * 64 + r0 + r;
-                    gms[r] = (m < k) ? (int)ch.g[m] : 0;
+                    const int gr = (int)ch.g[m];   // (behind k: any valid index, see the build)
+                    gms[r] = gr < p ? gr : 0;
                     raw[r] = NAT ? Mat[(size_t)gms[r] * p + j] : Mat[(size_t)j * p + gms[r]];
                   }
                   asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
