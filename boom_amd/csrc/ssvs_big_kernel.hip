@@ -309,8 +309,17 @@ __device__ unsigned long long g_bstamp[16];
 #else
 #define BST(i) do { } while (0)
 #endif
+// part: -1 = this wavefront does all of it; 0 / 1 = the chain's two wavefronts share the
+// factorisations (round 6): wave 1 (part 1) factors A_g and returns, wave 0 (part 0) factors
+// V_g and does everything else; they meet at workgroup barriers -- around the one piece of LDS
+// both need, the tile copy the diagonal blocks' inverses are taken from, and at the end, where
+// wave 1 hands over A_g's verdict and log determinant through xch[BX_OKA], xch[BX_LDA].  Both
+// take every early exit together (same k, same log prior).
+enum : int { BX_K = 32, BX_SLOT = 33, BX_REUSE = 34, BX_OKA = 35, BX_LDA = 36 };
 __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &M, double *dst,
-                                               const BigCtx &bx, const bool REUSE) {
+                                               const BigCtx &bx, const bool REUSE, const int part = -1,
+                                               lds_f64 *xch = nullptr) {
+  const bool two = part >= 0;
   const int lane = ch.lane, p = ch.p, k = ch.k, kcap = bx.kcap;
 #ifdef BA_BSTAMPS
   long long bst_ = (long long)__builtin_readcyclecounter();
@@ -344,6 +353,7 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
   const int npan = (k + 63) >> 6;
   const int kpad8 = (k + 7) & ~7;
   // index list, prior means; zero tails of the k-vectors
+  if (part != 1)
   for (int m = lane; m < kcap; m += WAVE) {
     ((int *)(dst + S.g))[m] = (m < k) ? (int)ch.g[m] : 0;
     dst[S.bg + m] = (m < k) ? P.b[ch.g[m]] : 0.0;
@@ -362,17 +372,25 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
   } else {
 #pragma nounroll
     for (int s = 1; s >= 0; --s) {       // A first, then V (order of chol_blocks2's pair is immaterial)
+      if (two && s != part) continue;
       const double *Mat = s ? P.A : P.V;
       const double msc = s ? ch.sa : ch.sv;
       double *Lst = dst + (s ? S.La : S.Lv);
       double *rdst = dst + (s ? S.rda : S.rdv);
       bool ok = true;
       double ld = 0.0;
-      for (int I = 0; I < npan && ok; ++I) {
+      lds_f64 *colbuf = bx.tile + (part == 1 ? 128 : 0);   // (the columns' way round the lanes, per wave)
+      // (no early exit from the loop: a two-wave build meets at the barriers of every panel)
+      for (int I = 0; I < npan; ++I) {
         const int row = I * 64 + lane;
         const bool valid = row < k;
         const int gi = valid ? (int)ch.g[row] : 0;
         const double *Mrow = Mat + (size_t)gi * p;
+        const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
+        double acc[64];
+        double rdl = 0.0;
+        bool did = false;
+        if (ok) {
         if (I > 0) {
           c_f64 *LB = scalar_view(Lst);
           c_f64 *rd = (c_f64 *)((unsigned long long)LB + ((unsigned long long)rdst - (unsigned long long)Lst));
@@ -400,8 +418,6 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
         // (columns in blocks of eight, only those the tile has: a chain that hovers just
         // above a multiple of 64 variables builds a last tile of one or two rows, and all
         // 64 columns of it cost 4 096 FMAs a tile row for nothing)
-        const int kk = (k - I * 64 < 64) ? (k - I * 64) : 64;
-        double acc[64];
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
           if (cb * 8 < kk) {
@@ -444,19 +460,21 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
         }
         BST(2);
         wave_sync();
-        double ldt = 0.0, rdl = 0.0;
+        double ldt = 0.0;
         // (the tile's LDS holds the columns on their way round the lanes; the factor itself stays
         // in acc)
-        chol_tile_regs(acc, bx.tile, kk, lane, &ok, &ldt, &rdl);
+        chol_tile_regs(acc, colbuf, kk, lane, &ok, &ldt, &rdl);
         ld += ldt;
         wave_sync();
         BST(3);
-        if (!ok) break;
+        did = ok;
+        }
         // what the table fills on the matrix cores multiply by (ssvs_fill_mfma.h): the
         // inverses of this tile's 16 x 16 diagonal blocks, from a copy of the tile in LDS
-        if (k <= MF_ROWS * MF_MAX_BLOCK_ROWS) {
-          const int nI_all = mf_block_rows(k), nI_here = (nI_all - 4 * I < 4) ? nI_all - 4 * I : 4;
-          if (nI_here > 0) {
+        const int nI_all = mf_block_rows(k), nI_here = (nI_all - 4 * I < 4) ? nI_all - 4 * I : 4;
+        const bool need_inv = k <= MF_ROWS * MF_MAX_BLOCK_ROWS && nI_here > 0;
+        auto inverses = [&]() {
+          if (did && need_inv) {
 #pragma unroll
             for (int c = 0; c < 64; ++c)
               if ((c >> 3) <= (lane >> 3)) bx.tile[bidx(lane, c)] = (valid && c <= lane) ? acc[c] : 0.0;
@@ -465,9 +483,10 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
             diag_inverses(bx.tile, bx.rdt, dst + (s ? S.ia : S.iv) + (size_t)(4 * I) * (MF_ROWS * MF_ROWS), kk, nI_here, lane);
             wave_sync();
           }
-        }
+        };
         // rows of this tile row go to the factor: parked off-diagonal part, the tile, rd
-        if (row < kpad8) {
+        auto store = [&]() {
+        if (did && row < kpad8) {
           for (int m0 = 0; m0 < I * 64; m0 += 8) {   // (eight at a time: a rolled copy waited for every load)
             double xv[8];
 #pragma unroll
@@ -481,7 +500,21 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
               Lst[bidx(row, I * 64 + c)] = (valid && c <= lane && c < kk) ? acc[c] : 0.0;
           rdst[row] = valid ? rdl : 0.0;
         }
-        if (s == 0 && valid) ch.rdv[row] = rdl;
+        if (did && s == 0 && valid) ch.rdv[row] = rdl;
+        };
+        if (two && need_inv) {
+          // (the tile copy is the one piece of LDS the two waves share: first V's wave takes its
+          // inverses while A's stores its rows, then the other way round; the third barrier
+          // keeps the next panel's columns out of the tile until both are through with it)
+          __syncthreads();
+          if (part == 0) inverses(); else store();
+          __syncthreads();
+          if (part == 0) store(); else inverses();
+          __syncthreads();
+        } else {
+          inverses();
+          store();
+        }
         BST(4);
       }
       if (s) { oka = ok; M.lda = 2.0 * ld; }
@@ -490,6 +523,13 @@ __device__ __forceinline__ void big_build_body(const BigP &P, Chain &ch, Model &
   }
   // the factor just stored is read back below (and by the tail) with vector loads
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  if (two && !REUSE) {
+    if (part == 1 && lane == 0) { xch[BX_OKA] = oka ? 1.0 : 0.0; xch[BX_LDA] = M.lda; }
+    __syncthreads();
+    if (part == 1) return;
+    oka = xch[BX_OKA] != 0.0;
+    M.lda = xch[BX_LDA];
+  }
   if (!okv) {
     M.pd = false;
     M.logp = -BA_INF;
@@ -1322,7 +1362,10 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         MST(7);
       }
       MST(8);
-      if (lane == 0) ctl[CT_CMD] = (double)cmd;
+      if (lane == 0) {
+        ctl[CT_CMD] = (double)cmd;
+        if (cmd == BCMD_BUILD) { ctl[BX_K] = (double)ch.k; ctl[BX_SLOT] = (double)b_slot; ctl[BX_REUSE] = b_reuse ? 1.0 : 0.0; }
+      }
     }
 #ifdef BA_BSTAMPS
     const long long bt1 = (long long)__builtin_readcyclecounter();
@@ -1356,11 +1399,16 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         ch.tab_lp[idx] = adaptive ? pr.logp : exp(pr.logp - Me.logp);
         ch.tab_kind[idx] = (uint8_t)(pr.bad_ss ? STOP_BAD : (pr.slow ? STOP_SLOW : 0));
       }
-    } else if (wave == 0) {  // BCMD_BUILD
-      double *dst = slot_block(b_slot);
+    } else if (wave == 0 || (int)ctl[BX_REUSE] == 0) {  // BCMD_BUILD
+      // (both wavefronts where factors are to be computed: wave 1 takes A_g's)
+      const bool reuse = wave == 0 ? b_reuse : false;
+      if (wave != 0) ch.k = (int)ctl[BX_K];
+      double *dst = slot_block(wave == 0 ? b_slot : (int)ctl[BX_SLOT]);
       Model Mn = M;
-      big_build_body(BP, ch, Mn, dst, bx, b_reuse);
-      if (Mn.bad) {
+      big_build_body(BP, ch, Mn, dst, bx, reuse, reuse ? -1 : wave, ctl);
+      if (wave != 0) {
+        // (wave 1's part ends with the factor)
+      } else if (Mn.bad) {
         status = Mn.bad;
       } else if (b_reason != BR_TRY) {
         M = Mn;
