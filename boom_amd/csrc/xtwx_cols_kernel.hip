@@ -87,31 +87,52 @@ __global__ __launch_bounds__(256, 2) void xtwx_cols_kernel(const double *__restr
 
   // this thread's share of a panel: row prow of the step, columns pcol0 + 16 it
   const int prow = tid & 15, pcol0 = tid >> 4;
+  // (rows behind R and columns behind p read row / column 0 and are zeroed after the load, steps
+  // behind the plane's end read its last row: every load of a step is unconditional, so all
+  // twelve to sixteen go out together.  As conditional loads -- "in range ? X[...] : 0" -- the
+  // compiler gave each its own branch and its own wait: four memory round trips in a row in
+  // every 16-row step of the main loop; tools/isa_serial_loads.py)
   const double *xa[4], *wa[4];
+  bool rowok[4], colok[8];
+  const double *xb[8];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int r = R0 + pcol0 + 16 * it;
-    if (r < R) {
-      const int2 q = GATHER ? req[r] : make_int2(r, 0);
-      xa[it] = X + (int64_t)q.y * n;
-      wa[it] = w + (int64_t)q.x * (GATHER ? n : ldw);
-    } else {
-      xa[it] = nullptr;
-      wa[it] = nullptr;
-    }
+    rowok[it] = r < R;
+    const int2 q = GATHER ? req[rowok[it] ? r : 0] : make_int2(rowok[it] ? r : 0, 0);
+    xa[it] = X + (int64_t)q.y * n;
+    wa[it] = w + (int64_t)q.x * (GATHER ? n : ldw);
   }
-  double ra[4], rb[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int j = J0 + pcol0 + 16 * it;
+    colok[it] = j < p;
+    xb[it] = X + (int64_t)(colok[it] ? j : 0) * n;
+  }
+  // fetch: the loads of a step go out (before the step's matrix instructions); finish: what they
+  // brought is masked and multiplied (after them), then stashed
+  double ra[4], rb[8], rx[4], rw[4];
+  bool in = false;
   auto fetch = [&](int64_t k0) {
-    const int64_t k = k0 + prow;
-    const bool in = k < kend;
+    const int64_t kr = k0 + prow;
+    in = kr < kend;
+    const int64_t k = in ? kr : kend - 1;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      ra[it] = (in && xa[it]) ? (GATHER ? xa[it][k] * wa[it][k] : wa[it][k]) : 0.0;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int j = J0 + pcol0 + 16 * it;
-      rb[it] = (in && j < p) ? X[(int64_t)j * n + k] : 0.0;
+    for (int it = 0; it < 4; ++it) {
+      rw[it] = wa[it][k];
+      rx[it] = GATHER ? xa[it][k] : 1.0;
     }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rb[it] = xb[it][k];
+  };
+  auto finish = [&]() {
+    asm volatile("" : "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]), "+v"(rw[3]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]),
+                      "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]));
+    if (GATHER) asm volatile("" : "+v"(rx[0]), "+v"(rx[1]), "+v"(rx[2]), "+v"(rx[3]));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) ra[it] = (in && rowok[it]) ? (GATHER ? rx[it] * rw[it] : rw[it]) : 0.0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rb[it] = (in && colok[it]) ? rb[it] : 0.0;
   };
   auto stash = [&](int buf) {
 #pragma unroll
@@ -120,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void xtwx_cols_kernel(const double *__restr
     for (int it = 0; it < 8; ++it) sB[buf][(pcol0 + 16 * it) * LDS_LD + prow] = rb[it];
   };
   fetch(kbeg);
+  finish();
   stash(0);
   __syncthreads();
   int cur = 0;
@@ -156,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void xtwx_cols_kernel(const double *__restr
 #undef BA_RD
 #undef BA_MM
     }
-    if (more) stash(cur ^ 1);   // (the other buffer was last read before the previous barrier)
+    if (more) { finish(); stash(cur ^ 1); }   // (the other buffer was last read before the previous barrier)
     __syncthreads();
     cur ^= 1;
   }
