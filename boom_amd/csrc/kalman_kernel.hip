@@ -247,7 +247,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
       for (int j = 0; j < BS; ++j) {
         const int t = tl + j;
         in[j] = t < T;
-        obs[j] = in[j] && P.observed[in[j] ? t : 0] != 0;
+        obs[j] = (int)in[j] & (int)(P.observed[in[j] ? t : 0] != 0);   // (& not &&: the load unconditional, all eight together)
       }
       // the normals of steps t >= 1 sit nper to a step from nfirst on: state error (if
       // any), then observation error (if any)
@@ -281,10 +281,20 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
               for (int i = 0; i < BS; ++i) pred[i] += xv[i] * b;
             }
           }
+          // (unconditional, all eight together, and the compiler told so: as "in range ? y[t] -
+          // ... : 0" every load had a branch and a wait of its own; tools/isa_serial_loads.py)
+          double yt[BS];
 #pragma unroll
           for (int i = 0; i < BS; ++i) {
             const int t = tw + i * WAVE + lane;
-            yraw[i] = (t < T) ? P.y[t] - pred[i] : 0.0;
+            yt[i] = P.y[t < T ? t : 0];
+          }
+          static_assert(BS == 8, "the list below");
+          asm volatile("" : "+v"(yt[0]), "+v"(yt[1]), "+v"(yt[2]), "+v"(yt[3]), "+v"(yt[4]), "+v"(yt[5]), "+v"(yt[6]), "+v"(yt[7]));
+#pragma unroll
+          for (int i = 0; i < BS; ++i) {
+            const int t = tw + i * WAVE + lane;
+            yraw[i] = (t < T) ? yt[i] - pred[i] : 0.0;
           }
         }
         if (nper == 2) {
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
             for (int j = 0; j < BS; ++j) {
               const int t = tb + j;
               const bool inx = t < T;
-              const bool obx = inx && P.observed[inx ? t : 0] != 0;
+              const bool obx = (int)inx & (int)(P.observed[inx ? t : 0] != 0);
               const double PZ = Pl, Fi = PZ + H;
               const double Ki = obx ? PZ / Fi : 0.0;
               if (hw == wave && lane == l) { Fv[j] = Fi; K[j] = Ki; }
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(128) void kalman_simsmooth_kernel(SsParams P,
       for (int j = 0; j < BS; ++j) {
         const int t = tl + j;
         inr[j] = t < T;
-        ob[j] = inr[j] && P.observed[inr[j] ? t : 0] != 0;
+        ob[j] = (int)inr[j] & (int)(P.observed[inr[j] ? t : 0] != 0);
       }
       {
         double draw[BS], araw[BS], yraw[BS];
