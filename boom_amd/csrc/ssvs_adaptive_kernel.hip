@@ -347,10 +347,12 @@ __global__ __launch_bounds__(64, 1) void ssvs_adaptive_kernel(SsvsParams P, int 
     kmax = k > kmax ? k : kmax;
     if (lane < k) {
       const size_t o = (size_t)chain * p + gprev;
-      P.inc_count[o] += 1u;
+      const unsigned c0 = P.inc_count[o];   // (loads first, then the stores: one round trip, not three)
+      const double b0 = P.beta_sum[o], q0 = P.beta_sumsq[o];
+      P.inc_count[o] = c0 + 1u;
       if (beta_valid) {
-        P.beta_sum[o] += beta_m;
-        P.beta_sumsq[o] += beta_m * beta_m;
+        P.beta_sum[o] = b0 + beta_m;
+        P.beta_sumsq[o] = q0 + beta_m * beta_m;
       }
     }
     AACC_ADD(ACC_SIGSQ, sigsq);

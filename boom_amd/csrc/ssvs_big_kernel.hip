@@ -1321,12 +1321,16 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
         // ---- summaries, traces, the draw record
         kmax = k > kmax ? k : kmax;
         for (int m = lane; m < k; m += WAVE) {
+          // (three loads, then three stores: as three read-modify-writes in a row they were
+          // three memory round trips a sweep)
           const size_t o = (size_t)chain * p + ch.g[m];
-          P.inc_count[o] += 1u;
+          const unsigned c0 = P.inc_count[o];
+          const double b0 = P.beta_sum[o], q0 = P.beta_sumsq[o];
+          const double b = beta_valid ? bx.y[m] : 0.0;
+          P.inc_count[o] = c0 + 1u;
           if (beta_valid) {
-            const double b = bx.y[m];
-            P.beta_sum[o] += b;
-            P.beta_sumsq[o] += b * b;
+            P.beta_sum[o] = b0 + b;
+            P.beta_sumsq[o] = q0 + b * b;
           }
         }
         BACC_ADD(ACC_SIGSQ, sigsq);

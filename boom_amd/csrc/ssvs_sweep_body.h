@@ -793,10 +793,15 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
         if (__any(gnow != gold)) {
           const int n_old = sum_n[lane];
           if (gold >= 0 && n_old) {
+            // (the three read-modify-writes as three loads, then three stores: written one
+            // after the other they were three memory round trips in a row -- the compiler
+            // cannot know that the arrays do not overlap)
             const size_t o = (size_t)chain * p + gold;
-            P.inc_count[o] += (unsigned)n_old;
-            P.beta_sum[o] += sum_b[lane];
-            P.beta_sumsq[o] += sum_b2[lane];
+            const unsigned c0 = P.inc_count[o];
+            const double b0 = P.beta_sum[o], q0 = P.beta_sumsq[o];
+            P.inc_count[o] = c0 + (unsigned)n_old;
+            P.beta_sum[o] = b0 + sum_b[lane];
+            P.beta_sumsq[o] = q0 + sum_b2[lane];
           }
           sum_g[lane] = gnow; sum_n[lane] = 0; sum_b[lane] = 0.0; sum_b2[lane] = 0.0;
         }

@@ -465,7 +465,7 @@ int ba_ss_set_local_level(ba_engine *e, double level_df,
  *           NonzeroMeanAr1Sampler (Models/TimeSeries/PosteriorSamplers/NonzeroMeanAr1Sampler.cpp:
  *           58-137: mu | phi, sigma normal; phi | mu, sigma normal, truncated to (-1, 1) -- or
  *           (0, 1) -- by rejection when forced stationary (positive); sigma from the residual sum
- *           of squares), as bsts builds it (create_state_model.cpp:356-446).  iparams =
+ *           of squares), as bsts builds it (create_state_model.cpp:600-672).  iparams =
  *           {force_stationary, force_positive} (positive without stationary -- a one-sided
  *           truncation -- is refused); the var_* arrays have two entries (level, slope);
  *           initial_phi = {mu's prior mean, sd, phi's prior mean, sd, initial mu, initial phi};
