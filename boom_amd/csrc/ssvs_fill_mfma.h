@@ -191,55 +191,71 @@ __device__ __forceinline__ void mf_factor(const double *__restrict__ Mat, const 
       for (int t = 0; t < MF_NT; ++t) X[I][t][q] = Mat[(size_t)gm * p + jt[t]];
     }
   }
-  // (the weights of a factor are asked for together, like the gathers: read one at a time where
-  // each is used, every one of up to 32 was a round trip of its own)
-  double wr[NI][4];
-  if (SF) {
+  // (the weights of a factor are asked for together, like the gathers -- read one at a time
+  // where each is used, every one of up to 32 was a round trip of its own --, four block rows
+  // (sixteen loads, 32 registers) at a time: all 32 at once cost the capacity-48 / 64 instances of
+  // the sweep kernel 56-72 B/lane more scratch beside X's 96-128 registers)
+  constexpr int WG = 4;
 #pragma unroll
-    for (int I = 0; I < NI; ++I)
+  for (int I0 = 0; I0 < NI; I0 += WG) {
+    double wr[WG][4];
+    if (SF) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { wr[I][q] = wv[MF_ROWS * I + 4 * q + g]; }
+      for (int i = 0; i < WG; ++i)
 #pragma unroll
-    for (int I = 0; I < NI; ++I) asm volatile("" : "+v"(wr[I][0]), "+v"(wr[I][1]), "+v"(wr[I][2]), "+v"(wr[I][3]));
-  }
+        for (int q = 0; q < 4; ++q) wr[i][q] = (I0 + i < NI) ? wv[MF_ROWS * (I0 + i) + 4 * q + g] : 0.0;
 #pragma unroll
-  for (int I = 0; I < NI; ++I) {
+      for (int i = 0; i < WG; ++i) asm volatile("" : "+v"(wr[i][0]), "+v"(wr[i][1]), "+v"(wr[i][2]), "+v"(wr[i][3]));
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = MF_ROWS * I + 4 * q + g;
-      double wm = 0.0;
-      if (SF) wm = (m < k) ? wr[I][q] : 0.0;
+    for (int i = 0; i < WG; ++i) {
+      const int I = I0 + i;
+      if (I < NI) {
 #pragma unroll
-      for (int t = 0; t < MF_NT; ++t) {
-        const double e = (gmv[I][q] == jt[t]) ? dropf[t] : 0.0;
-        const double val = fma(X[I][t][q], addf[t], e);
-        X[I][t][q] = val;
-        if (SF) sum2[t] += val * wm;   // A[j, g] . b_g
+        for (int q = 0; q < 4; ++q) {
+          const int m = MF_ROWS * I + 4 * q + g;
+          double wm = 0.0;
+          if (SF) wm = (m < k) ? wr[i][q] : 0.0;
+#pragma unroll
+          for (int t = 0; t < MF_NT; ++t) {
+            const double e = (gmv[I][q] == jt[t]) ? dropf[t] : 0.0;
+            const double val = fma(X[I][t][q], addf[t], e);
+            X[I][t][q] = val;
+            if (SF) sum2[t] += val * wm;   // A[j, g] . b_g
+          }
+        }
       }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
   mf_tri_solve<NI>(Lg, Linv, kpad8, lane, X);
-  if (!SF) {
 #pragma unroll
-    for (int I = 0; I < NI; ++I)
+  for (int I0 = 0; I0 < NI; I0 += WG) {
+    double wr[WG][4];
+    if (!SF) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { wr[I][q] = wv[MF_ROWS * I + 4 * q + g]; }
+      for (int i = 0; i < WG; ++i)
 #pragma unroll
-    for (int I = 0; I < NI; ++I) asm volatile("" : "+v"(wr[I][0]), "+v"(wr[I][1]), "+v"(wr[I][2]), "+v"(wr[I][3]));
-  }
+        for (int q = 0; q < 4; ++q) wr[i][q] = (I0 + i < NI) ? wv[MF_ROWS * (I0 + i) + 4 * q + g] : 0.0;
 #pragma unroll
-  for (int I = 0; I < NI; ++I) {
+      for (int i = 0; i < WG; ++i) asm volatile("" : "+v"(wr[i][0]), "+v"(wr[i][1]), "+v"(wr[i][2]), "+v"(wr[i][3]));
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = MF_ROWS * I + 4 * q + g;
-      double wm = 0.0;
-      if (!SF) wm = (m < k) ? wr[I][q] : 0.0;
+    for (int i = 0; i < WG; ++i) {
+      const int I = I0 + i;
+      if (I < NI) {
 #pragma unroll
-      for (int t = 0; t < MF_NT; ++t) {
-        const double x = X[I][t][q];
-        n2[t] += x * x;
-        if (!SF) sum2[t] += x * wm;   // x_V . w
+        for (int q = 0; q < 4; ++q) {
+          const int m = MF_ROWS * I + 4 * q + g;
+          double wm = 0.0;
+          if (!SF) wm = (m < k) ? wr[i][q] : 0.0;
+#pragma unroll
+          for (int t = 0; t < MF_NT; ++t) {
+            const double x = X[I][t][q];
+            n2[t] += x * x;
+            if (!SF) sum2[t] += x * wm;   // x_V . w
+          }
+        }
       }
     }
   }
