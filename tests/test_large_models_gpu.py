@@ -211,3 +211,41 @@ def test_state_space_with_a_large_regression_model(oracle):
             st = eng.ss_get_state(c)
             assert np.max(np.abs(st["state"] - o["state"][s])) < 1e-8 * np.abs(o["state"][s]).max()
     assert max(o["gamma"].sum(axis=1).max() for o in ora.values()) > 64
+
+
+@pytest.mark.parametrize("p", [80, 150])
+def test_rank_deficient_large_model_is_the_reference_error(oracle, p):
+    """the same two failures as test_ssvs_gpu's rank-deficient case, on a model of more than 64
+    variables: both of a build's factorisations fail (V_g has a zero column, the prior
+    precision A_g is zero), each on its own wavefront of the large-model kernel since round 6 --
+    the waves have to keep meeting at the build's barriers after either verdict.  p = 80: one
+    panel and the matrix-core fills' inverses (k <= 128); p = 150: three panels, no inverses."""
+    import boom_amd
+    X, y, _ = regression_data(400, p, 3, seed=10)
+    X[:, 70] = 0.0
+    suf = oracle.neregsuf(X, y)
+    prior = spike_slab_prior(suf, 3)
+    prior["ominv"] = np.zeros((p, p))
+    g0 = np.ones(p, np.uint8)
+    for max_flips, want, msg in ((0, 1, "not positive definite"),
+                                 (-1, 3, "did not start with a legal configuration")):
+        opts = ssvs_options(max_flips=max_flips)
+        o = oracle.ssvs_run(suf, prior, opts, ("philox", 3, 0), g0, 2)
+        assert o["status"] == want
+        eng = make_engine(3, 3, suf=suf, prior=prior, opts=opts, g0=g0)
+        with pytest.raises(boom_amd.BoomAmdError) as ei:
+            eng.sweep(2)
+        assert msg in str(ei.value)
+    # ... and a healthy model of the same size next: the engine's large-model state is intact
+    X2, y2, _ = regression_data(400, p, 3, seed=11)
+    suf2 = oracle.neregsuf(X2, y2)
+    prior2 = spike_slab_prior(suf2, 3)
+    g1 = np.ones(p, np.uint8)
+    eng = make_engine(2, 5, suf=suf2, prior=prior2, g0=g1)
+    ora = _oracle_runs(oracle, suf2, prior2, ssvs_options(), 5, g1, 2, [0, 1])
+    eng.sweep(2)
+    gam, beta, sig = eng.get_states()
+    for c in (0, 1):
+        assert ora[c]["status"] == 0
+        assert np.array_equal(gam[c], ora[c]["gamma"][-1]), c
+        assert relerr(beta[c], ora[c]["beta"][-1]) < RTOL, c
