@@ -230,6 +230,12 @@ __global__ __launch_bounds__(LM_THREADS, 2) void ss_round_kernel(SsvsParams P, S
     int chain = (int)blockIdx.x + P.chain_first, tid = threadIdx.x;
     BA_OPAQUE_S(chain);
     BA_OPAQUE_V(tid);
+    // (... and the launch's constants that the state draw turns into vector values -- sqrt(P0),
+    // the level prior's terms, array offsets: computed once before the loop they lived in
+    // scratch memory for the whole launch, six of them)
+    BA_OPAQUE_S(S.P0); BA_OPAQUE_S(S.a0); BA_OPAQUE_S(S.TP); BA_OPAQUE_S(S.T);
+    BA_OPAQUE_S(S.level_prior_df); BA_OPAQUE_S(S.level_prior_ss); BA_OPAQUE_S(S.level_sigma_max);
+    BA_OPAQUE_S(P.sigma_max); BA_OPAQUE_S(P.prior_df); BA_OPAQUE_S(P.prior_ss);
     const int lane = tid & 63, wave = tid >> 6;
     // ---- 1. the regression's draw (wave 0; wave 1 is still making this round's normals)
     if (wave == 0) {
