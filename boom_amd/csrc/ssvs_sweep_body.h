@@ -16,7 +16,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
   }
   int tid_ = threadIdx.x;
   BA_OPAQUE_V(tid_);
-  const int lane = tid_ & (WAVE - 1);
+  int lane = tid_ & (WAVE - 1);
   const int wave = tid_ >> 6;
   const int p = P.p;
 #ifdef BA_PSTAMPS
@@ -334,6 +334,14 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
 
   PSTAMP(4);
   while (status == CHAIN_OK) {
+    if constexpr (W > 1 && !(NB == 4 && W == 2)) {
+      // (every multi-wave instance but the headline's <4, 2, 2>, which needs no scratch as it
+      // is: what the compiler derives from the lane number once before this loop
+      // -- two dozen per-lane addresses -- it then keeps in scratch memory for the whole launch;
+      // made opaque per pass of the state machine, they are recomputed where they are used)
+      asm volatile("" : "+v"(lane));
+      ch.lane = lane;
+    }
     if (pe.kind != EV_NONE && !spec) {
       // ---- the one place where a model is (re)built (a swap proposed by a
       // tail running ahead waits for the join) --------------------------
