@@ -772,7 +772,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W = 2;
   const int chain = (int)blockIdx.x + P.chain_first;
-  const int lane = threadIdx.x & (WAVE - 1);
+  int lane = threadIdx.x & (WAVE - 1);   // (not const: made opaque once per pass of the phase machine, below)
   const int wave = uni((int)(threadIdx.x >> 6));
   const int p = P.p, kcap = P.big_kcap;
   if ((int)blockIdx.x >= P.chain_count) return;
@@ -951,6 +951,11 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
   long long bt0 = (long long)__builtin_readcyclecounter();
 #endif
   for (;;) {
+    // (what the compiler derives from the lane number once before this loop -- dozens of per-lane
+    // addresses -- it keeps in scratch memory for the whole launch; opaque per pass, they are
+    // recomputed where they are used: ssvs_sweep_body.h does the same)
+    asm volatile("" : "+v"(lane));
+    ch.lane = lane;
 #ifdef BA_BSTAMPS
     const int bphase_at_entry = phase;
     long long mst_ = (long long)__builtin_readcyclecounter();
