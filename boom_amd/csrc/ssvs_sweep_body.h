@@ -334,7 +334,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
 
   PSTAMP(4);
   while (status == CHAIN_OK) {
-    if constexpr (W > 1 && !(NB == 4 && W == 2)) {
+    if constexpr ((W > 1 && !(NB == 4 && W == 2)) || (W == 1 && NB >= 4)) {
       // (every multi-wave instance but the headline's <4, 2, 2>, which needs no scratch as it
       // is: what the compiler derives from the lane number once before this loop
       // -- two dozen per-lane addresses -- it then keeps in scratch memory for the whole launch;
