@@ -115,7 +115,7 @@ def _executed(tag, kernel_prefix, units_per_dispatch=None, dependent_trips=None)
     = {"lds": n, "l2": n, "what": str} per unit of one chain's critical wavefront."""
     try:
         import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % tag)))
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_pmc_summary.json" % tag)))
         with open(cand[-1]) as fh:
             pj = json.load(fh)
         ent = [(k, v) for k, v in pj["kernels"].items() if k.startswith(kernel_prefix)]
@@ -956,7 +956,7 @@ def _profile_traffic(tag, kernel_prefix):
     (profiles/r*_<tag>_pmc_traffic.json, tools/regen_profiles.sh), or None"""
     try:
         import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % tag)))
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_pmc_traffic.json" % tag)))
         with open(cand[-1]) as fh:
             tj = json.load(fh)
         ent = [v for k, v in tj["kernels"].items() if k.startswith(kernel_prefix)]
@@ -1193,7 +1193,7 @@ def main():
     traffic, traffic_source = None, None
     try:
         import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_pmc_traffic.json")))
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_c2_pmc_traffic.json")))
         with open(cand[-1]) as fh:
             tj = json.load(fh)
         ent = [v for k, v in tj["kernels"].items() if k.startswith("ssvs_sweep_kernel")]
