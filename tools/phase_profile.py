@@ -15,7 +15,8 @@ import numpy as np
 import boom_amd
 from cases import regression_data, spike_slab_prior
 
-n, p, nsig = 10000, 512, int(sys.argv[1]) if len(sys.argv) > 1 else 16
+n, p = int(os.environ.get("N_ROWS", "10000")), int(os.environ.get("P_VARS", "512"))
+nsig = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 chains = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 X, y, _ = regression_data(n, p, nsig, seed=8675309)
 eng = boom_amd.Engine(chains, seed=1, max_model_size_hint=int(os.environ.get('KCAP_HINT', '0')))
