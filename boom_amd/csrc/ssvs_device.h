@@ -873,16 +873,9 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
     }
   }
   wave_sync();
-  // (a block of NW x 64 steps whose links did not move in a pass is done -- every one of them
-  // points at a chain's end, and ends never move -- and is left out of the passes that the
-  // few long chains elsewhere still need: at p = 4096, eight blocks, the walks were 36 % of
-  // the helper wavefront's sweep)
-  unsigned long long active = ~0ull;   // (bit b: block b still moving; more than 64 blocks share bit 63)
-  while (active) {
-    unsigned long long still = 0ull;
-    for (int tb = 0, b = 0; tb < p; tb += NW * WAVE, ++b) {
-      const unsigned long long bit = 1ull << (b < 63 ? b : 63);
-      if (!(active & bit)) continue;
+  for (bool moved = true; moved;) {
+    moved = false;
+    for (int tb = 0; tb < p; tb += NW * WAVE) {
       int r1[NW], r2[NW];
 #pragma unroll
       for (int u = 0; u < NW; ++u) {
@@ -900,10 +893,9 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
           ch_any = true;
         }
       }
-      if (__any(ch_any) != 0) still |= bit;
+      moved |= (__any(ch_any) != 0);
       wave_sync();
     }
-    active = still;
   }
   for (int ib = 0; ib < p; ib += NW * WAVE) {
     int c0[NW], src[NW];
