@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(128, 2) void ssvs_big_kernel(SsvsParams P, int nswe
               }
             }
             wave_sync();
-          } else if (p > 1) parallel_shuffle(ch, sx);
+          } else if (p > 1) parallel_shuffle<true>(ch, sx);
           MST(0);
           flip_pos = pos + (uint64_t)(P.mode == 2 ? p : (p > 0 ? p - 1 : 0));
           pos = flip_pos + (uint64_t)nflips;

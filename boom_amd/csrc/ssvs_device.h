@@ -814,6 +814,12 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
 // in turn was deposited by the smallest t'' > t' with oth[t''] == t' (nxt),
 // and so on until a slot nobody wrote, which still holds its original value.
 // oth[] must be filled for i = 1..p-1.  Result goes to ch.perm (buffers swap).
+// MASKED: blocks of NW x 64 links that did not move in a pass leave the passes (every link of
+// such a block points at a chain's end, and ends never move): at p = 4096, eight blocks, the
+// walks are a third of the helper wavefront's sweep and the mask takes a quarter off them.  A
+// template flag, not a run-time choice: the bookkeeping costs the single block of p = 512 one
+// per cent and the headline's instance <4, 2, 2> is compiled without it (docs/TRIED.md).
+template <bool MASKED = false>
 __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
   const int p = ch.p, lane = ch.lane;
   constexpr int NONE = 0xFFFF;
@@ -873,6 +879,7 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
     }
   }
   wave_sync();
+  if constexpr (!MASKED) {
   for (bool moved = true; moved;) {
     moved = false;
     for (int tb = 0; tb < p; tb += NW * WAVE) {
@@ -896,6 +903,36 @@ __device__ __forceinline__ void parallel_shuffle(Chain &ch, StampCtx &sx) {
       moved |= (__any(ch_any) != 0);
       wave_sync();
     }
+  }
+  } else {
+  unsigned long long active = ~0ull;   // (bit b: block b still moving; more than 64 blocks share bit 63)
+  while (active) {
+    unsigned long long still = 0ull;
+    for (int tb = 0, b = 0; tb < p; tb += NW * WAVE, ++b) {
+      const unsigned long long bit = 1ull << (b < 63 ? b : 63);
+      if (!(active & bit)) continue;
+      int r1[NW], r2[NW];
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        const int t = tb + u * WAVE + lane;
+        r1[u] = (t >= 1 && t < p) ? (int)ch.last[t] : 1;
+      }
+#pragma unroll
+      for (int u = 0; u < NW; ++u) r2[u] = (int)ch.last[r1[u]];
+      bool ch_any = false;
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        const int t = tb + u * WAVE + lane;
+        if (t >= 1 && t < p && r2[u] != r1[u]) {
+          ch.last[t] = (uint32_t)r2[u];
+          ch_any = true;
+        }
+      }
+      if (__any(ch_any) != 0) still |= bit;
+      wave_sync();
+    }
+    active = still;
+  }
   }
   for (int ib = 0; ib < p; ib += NW * WAVE) {
     int c0[NW], src[NW];

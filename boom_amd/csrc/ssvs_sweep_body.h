@@ -9,6 +9,8 @@ namespace boom_amd {
 template <int NB, int W, int WPE>
 __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const int chain,
                                                 unsigned char *smem) {
+  // (the shuffle's mask of finished blocks: every instance but the headline's, ssvs_device.h)
+  constexpr bool SHUFFLE_MASKED = !(NB == 4 && W == 2);
   P.V += (size_t)chain * (size_t)P.v_chain_stride;   // (a chain's own V: the logit sampler's X'WX moves with its latent data)
   if (P.col_valid) {
     P.col_valid += (size_t)chain * (size_t)P.col_words;
@@ -172,7 +174,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
           if (cmd == CMD_SHUFFLE_DECIDE) {
             // the permutation side of a quiet sweep: shuffle(indx) from stream position
             // upos (its targets are in ch.oth: above), then the walk over the new order
-            parallel_shuffle(ch, sx_unused);
+            parallel_shuffle<SHUFFLE_MASKED>(ch, sx_unused);
             fpos = upos + (uint64_t)(p - 1);
           }
           DecideResult dr;
@@ -554,7 +556,7 @@ __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const
             }
           }
           wave_sync();
-        } else if (p > 1) { parallel_shuffle(ch, sx); perm_sel ^= 1; }
+        } else if (p > 1) { parallel_shuffle<SHUFFLE_MASKED>(ch, sx); perm_sel ^= 1; }
         flip_pos = pos + (uint64_t)(P.mode == 2 ? p : (p > 0 ? p - 1 : 0));
         pos = flip_pos + (uint64_t)nflips;
         STAMP(1);
