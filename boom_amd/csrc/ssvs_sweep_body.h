@@ -9,8 +9,10 @@ namespace boom_amd {
 template <int NB, int W, int WPE>
 __device__ __forceinline__ void ssvs_sweep_body(SsvsParams P, int nsweeps, const int chain,
                                                 unsigned char *smem) {
-  // (the shuffle's mask of finished blocks: every instance but the headline's, ssvs_device.h)
-  constexpr bool SHUFFLE_MASKED = !(NB == 4 && W == 2);
+  // (the shuffle's mask of finished blocks, ssvs_device.h: the multi-wave instances of capacity
+  // 48 / 64 -- large models come with many variables; the headline's <4, 2, 2> and the bsts round's
+  // one-wave instances keep the plain loop their single block is fastest with)
+  constexpr bool SHUFFLE_MASKED = NB >= 6 && W > 1;
   P.V += (size_t)chain * (size_t)P.v_chain_stride;   // (a chain's own V: the logit sampler's X'WX moves with its latent data)
   if (P.col_valid) {
     P.col_valid += (size_t)chain * (size_t)P.col_words;
