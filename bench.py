@@ -968,8 +968,8 @@ def _profile_traffic(tag, kernel_prefix):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-apart", action="store_true",
                     help="(profiling) join the engine's two streams after every launch of the timed region: "
