@@ -573,37 +573,6 @@ __device__ __forceinline__ void solve_blocks(c_f64 *__restrict__ LB,
   }
 }
 
-// The same solve with the factor read from the chain's LDS copy (broadcast reads: every lane the
-// same address) instead of through the scalar cache: for the small capacities' direct
-// evaluations (NB <= 2), where a solve is 36 multiply-adds and the s_loads that feed them were
-// most of its time.
-template <int NB>
-__device__ __forceinline__ void solve_blocks_lds(const lds_f64 *LB, const lds_f64 *rd, int k, double (&x)[NB * 8]) {
-#pragma unroll
-  for (int I = 0; I < NB; ++I) {
-    if (I * 8 < k) {
-      double acc[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] = x[I * 8 + r];
-#pragma unroll
-      for (int J = 0; J < I; ++J) {
-        const lds_f64 *blk = LB + ((I * (I + 1)) / 2 + J) * 64;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-          for (int r = 0; r < 8; ++r) acc[r] -= blk[r * 8 + c] * x[J * 8 + c];
-      }
-      const lds_f64 *blk = LB + ((I * (I + 1)) / 2 + I) * 64;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        x[I * 8 + r] = acc[r] * rd[I * 8 + r];
-#pragma unroll
-        for (int r2 = r + 1; r2 < 8; ++r2) acc[r2] -= blk[r2 * 8 + r] * x[I * 8 + r];
-      }
-    }
-  }
-}
-
 // the logit sampler's V, computed column by column: is vector j of this chain's V
 // (needed by any model that includes j) still to be computed?  (P.col_valid is the
 // chain's own words here.)
@@ -726,19 +695,19 @@ __device__ __forceinline__ Proposal eval_proposal(const SsvsParams &P, Chain &ch
     for (int I = 0; I < NB; ++I)
       if (I * 8 < k) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ab += xa[I * 8 + r] * ch.bg[I * 8 + r];
+        for (int r = 0; r < 8; ++r) ab += xa[I * 8 + r] * sc[S.bg + I * 8 + r];
       }
     SUBSTAMP(sx, 2);
-    solve_blocks_lds<NB>(ch.Lv, ch.rdv, k, xv);
+    solve_blocks<NB>(sc + S.Lv, sc + S.rdv, k, xv);
     SUBSTAMP(sx, 3);
-    solve_blocks_lds<NB>(ch.La, ch.rda, k, xa);
+    solve_blocks<NB>(sc + S.La, sc + S.rda, k, xa);
 #pragma unroll
     for (int I = 0; I < NB; ++I)
       if (I * 8 < k) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           nv += xv[I * 8 + r] * xv[I * 8 + r];
-          dv += xv[I * 8 + r] * ch.w[I * 8 + r];
+          dv += xv[I * 8 + r] * sc[S.w + I * 8 + r];
           na += xa[I * 8 + r] * xa[I * 8 + r];
         }
       }
